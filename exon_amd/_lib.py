@@ -1,0 +1,151 @@
+"""ctypes binding of exon_amd/lib/libexon_hip.so (the C ABI of include/exon_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or fails to load, importing the operators
+raises -- the product path never routes through the oracle or numpy.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libexon_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+
+class ExonHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"exon_hip status {code}: {msg}")
+        self.code = code
+
+
+class ArrowSchema(C.Structure):
+    pass
+
+
+ArrowSchema._fields_ = [
+    ("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_char_p), ("flags", C.c_int64),
+    ("n_children", C.c_int64), ("children", C.POINTER(C.POINTER(ArrowSchema))),
+    ("dictionary", C.POINTER(ArrowSchema)), ("release", C.c_void_p), ("private_data", C.c_void_p),
+]
+
+
+class ArrowArray(C.Structure):
+    pass
+
+
+ArrowArray._fields_ = [
+    ("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64),
+    ("n_children", C.c_int64), ("buffers", C.POINTER(C.c_void_p)),
+    ("children", C.POINTER(C.POINTER(ArrowArray))), ("dictionary", C.POINTER(ArrowArray)),
+    ("release", C.c_void_p), ("private_data", C.c_void_p),
+]
+
+
+class ArrowDeviceArray(C.Structure):
+    _fields_ = [("array", ArrowArray), ("device_id", C.c_int64), ("device_type", C.c_int32),
+                ("sync_event", C.c_void_p), ("reserved", C.c_int64 * 3)]
+
+
+ARROW_DEVICE_CPU = 1
+ARROW_DEVICE_ROCM = 10
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("gcn_arch", C.c_char * 32), ("compute_units", C.c_int32),
+                ("wavefront_size", C.c_int32), ("hbm_bytes", C.c_int64), ("clock_khz", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class Column(C.Structure):
+    _fields_ = [("values", C.c_void_p), ("validity", C.c_void_p), ("offsets", C.c_void_p), ("length", C.c_int64)]
+
+
+class PlanDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("n_groups", C.c_int32),
+        ("region_chrom_id", C.c_int32), ("reserved0", C.c_int32),
+        ("region_start", C.c_int64), ("region_end", C.c_int64),
+        ("flag_mask", C.c_int32), ("flag_value", C.c_int32), ("mapq_min", C.c_int32),
+        ("cmp_op", C.c_int32), ("threshold", C.c_double),
+        ("lmax", C.c_int32), ("reserved1", C.c_int32),
+        ("columns", C.c_int32 * 4),
+    ]
+
+
+PLAN_REGION_COUNT = 2
+PLAN_FLAG_MAPQ_GROUP_COUNT = 3
+PLAN_CMP_AVG_BY_GROUP = 4
+PLAN_QUAL_POS_HIST = 5
+CMP = {">": 0, ">=": 1, "<": 2, "<=": 3, "=": 4, "==": 4, "!=": 5, "<>": 5}
+REGION_OPEN_END = 2**63 - 1
+
+_vp, _i32, _i64, _u64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
+_colp = C.POINTER(Column)
+
+# every symbol include/exon_hip.h declares: (restype, argtypes)
+SIGNATURES = {
+    "exon_hip_abi_version": (C.c_int, []),
+    "exon_hip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "exon_hip_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "exon_hip_ctx_destroy": (C.c_int, [_vp]),
+    "exon_hip_ctx_info": (C.c_int, [_vp, C.POINTER(DeviceInfo)]),
+    "exon_hip_last_error": (C.c_char_p, [_vp]),
+    "exon_hip_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "exon_hip_free": (C.c_int, [_vp, _vp]),
+    "exon_hip_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "exon_hip_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "exon_hip_memset": (C.c_int, [_vp, _vp, C.c_int, C.c_size_t, _vp]),
+    "exon_hip_sync": (C.c_int, [_vp, _vp]),
+    "exon_hip_timer_start": (C.c_int, [_vp, _vp]),
+    "exon_hip_timer_stop_ms": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
+    "exon_hip_region_count": (C.c_int, [_vp, _vp, _colp, _colp, _i64, _i32, _i64, _i64, _vp]),
+    "exon_hip_flag_mapq_group_count": (C.c_int, [_vp, _vp, _colp, _colp, _colp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "exon_hip_cmp_avg_by_group": (C.c_int, [_vp, _vp, _colp, _colp, _colp, _i64, _dbl, _i32, _i32, _vp, _vp]),
+    "exon_hip_qual_pos_hist": (C.c_int, [_vp, _vp, _colp, _i64, _i32, _vp]),
+    "exon_hip_gen_c2": (C.c_int, [_vp, _vp, _u64, _i64, _i64, _i64, _vp, _vp]),
+    "exon_hip_gen_c3": (C.c_int, [_vp, _vp, _u64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "exon_hip_gen_c4": (C.c_int, [_vp, _vp, _u64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "exon_hip_gen_c5": (C.c_int, [_vp, _vp, _u64, _i64, _i64, _i32, _vp, _vp]),
+    "exon_hip_parse_region": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(_i64), C.POINTER(_i64)]),
+    "exon_hip_regroup_files_by_size": (C.c_int, [C.POINTER(_i64), _i32, _i32, C.POINTER(_i32)]),
+    "exon_hip_plan_create": (C.c_int, [_vp, C.POINTER(PlanDesc), C.POINTER(_vp)]),
+    "exon_hip_plan_destroy": (C.c_int, [_vp]),
+    "exon_hip_plan_state_size": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "exon_hip_stream_open": (C.c_int, [_vp, _i32, C.POINTER(_vp)]),
+    "exon_hip_stream_push": (C.c_int, [_vp, C.POINTER(ArrowArray)]),
+    "exon_hip_stream_push_device": (C.c_int, [_vp, C.POINTER(ArrowDeviceArray)]),
+    "exon_hip_stream_state": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "exon_hip_stream_sync": (C.c_int, [_vp]),
+    "exon_hip_stream_finish": (C.c_int, [_vp, _vp, _vp]),
+    "exon_hip_stream_finish_arrow": (C.c_int, [_vp, C.POINTER(ArrowArray), C.POINTER(ArrowSchema)]),
+    "exon_hip_stream_close": (C.c_int, [_vp]),
+}
+
+
+def build(force=False, verbose=False):
+    """Compile libexon_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", CSRC, "-j4"], stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises (no fallback) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(exon_amd has no CPU fallback)")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = ABI drift, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,36 @@
+// internal.h -- shared between capi.cpp (ctx + operator launches) and stream.cpp (plan/stream layer).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+
+#include "../../include/exon_hip.h"
+#include "kernels.h"
+
+struct exon_hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;  // used when the caller passes stream == NULL
+  exon::LaunchCfg cfg;
+  std::mutex mu;
+  std::map<hipStream_t, exon::Workspace> workspaces;
+  std::string error;
+  hipDeviceProp_t props;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+// records the message on the ctx (and the calling thread) and returns `code`
+int fail(exon_hip_ctx* ctx, int code, const char* fmt, ...) __attribute__((format(printf, 3, 4)));
+const std::string& exon_hip_tls_error();
+
+#define HIP_TRY(ctx, expr)                                                                             \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) return fail(ctx, EXON_HIP_EDEVICE, "%s: %s", #expr, hipGetErrorString(e_));  \
+  } while (0)
+
+inline hipStream_t pick_stream(exon_hip_ctx* ctx, void* s) { return s ? (hipStream_t)s : ctx->stream; }
+
+// Workspace of `words` 8-byte partial words for launches on stream `s` (grown on demand).
+int get_workspace(exon_hip_ctx* ctx, hipStream_t s, size_t words, exon::Workspace* out);

@@ -1,0 +1,51 @@
+// kernels.h -- launch interface of the gfx950 kernels (internal; the public surface is include/exon_hip.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace exon {
+
+// Per-(ctx, stream) scratch: per-block partial words written by the main kernels and folded into the
+// caller's state by finalize_partials in a fixed order (deterministic f64 sums, no atomics).
+struct Workspace {
+  unsigned long long* partials = nullptr;  // [blocks][words]
+  size_t partial_capacity = 0;             // in 8-byte words
+  int* status = nullptr;                   // device error word (K5: position >= lmax, bad group id)
+};
+
+struct LaunchCfg {
+  int compute_units = 256;
+  int blocks_per_cu = 8;  // main-kernel grid = compute_units * blocks_per_cu (persistent, grid-stride)
+};
+
+size_t k2_partial_words(const LaunchCfg&);
+size_t k3_partial_words(const LaunchCfg&, int n_refs);
+size_t k4_partial_words(const LaunchCfg&, int n_groups);
+size_t k5_partial_words(const LaunchCfg&, int lmax);
+
+hipError_t launch_region_count(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* chrom,
+                               const uint8_t* chrom_valid, const int64_t* pos, const uint8_t* pos_valid, int64_t n,
+                               int32_t region_chrom, int64_t start, int64_t end, int64_t* d_count);
+
+hipError_t launch_flag_mapq_group_count(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* flag,
+                                        const uint8_t* flag_valid, const uint8_t* mapq, const uint8_t* mapq_valid,
+                                        const int32_t* ref_id, const uint8_t* ref_valid, int64_t n, int32_t flag_mask,
+                                        int32_t flag_value, int32_t mapq_min, int32_t n_refs, int64_t* d_counts);
+
+hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const float* x,
+                                   const uint8_t* x_valid, const float* y, const uint8_t* y_valid, const int32_t* gid,
+                                   int64_t n, double thr, int cmp_op, int n_groups, int64_t* d_counts, double* d_sums);
+
+hipError_t launch_qual_pos_hist(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* offsets,
+                                const uint8_t* bytes, int64_t n_reads, int lmax, int64_t* d_hist);
+
+hipError_t launch_gen_c2(hipStream_t s, uint64_t seed, int64_t n_total, int64_t lo, int64_t hi, int32_t* chrom,
+                         int64_t* pos);
+hipError_t launch_gen_c3(hipStream_t s, uint64_t seed, int64_t lo, int64_t hi, int32_t* flag, uint8_t* mapq,
+                         uint8_t* mapq_valid, int32_t* ref_id, uint8_t* ref_valid);
+hipError_t launch_gen_c4(hipStream_t s, uint64_t seed, int64_t lo, int64_t hi, float* af, uint8_t* af_valid,
+                         float* qual, uint8_t* qual_valid, int32_t* filter_id);
+hipError_t launch_gen_c5(hipStream_t s, uint64_t seed, int64_t lo, int64_t hi, int32_t read_len, int32_t* offsets,
+                         uint8_t* bytes);
+
+}  // namespace exon

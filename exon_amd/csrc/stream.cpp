@@ -1,0 +1,649 @@
+// stream.cpp -- plan / stream layer of the C ABI: the ExecutionPlan-shaped surface.
+//
+// Replaces, for one partition, the reference's operator chain
+//   AggregateExec(Partial) <- CoalesceBatchesExec <- FilterExec <- <Fmt>Scan batches
+// (exon-core/src/datasources/vcf/scanner.rs:142-162 hands 8192-row RecordBatches to DataFusion).
+// Host batches arrive through the Arrow C Data Interface, are appended column-wise into a pinned
+// staging slot (the CoalesceBatches step: 8192-row batches are far too small for a 256-CU launch),
+// copied to HBM asynchronously and consumed by one fused filter+aggregate launch per slot; two slots
+// double-buffer so the host keeps appending while the previous slot is in flight.  HBM-resident
+// batches (Arrow C Device Data Interface, what the device-layout builders emit) skip staging.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "internal.h"
+
+namespace {
+
+struct ColSpec {
+  int elem = 4;        // bytes per value (1 for utf8 payload bytes)
+  bool utf8 = false;   // offsets + bytes
+};
+
+struct ColStage {
+  uint8_t* h_values = nullptr;
+  uint8_t* h_valid = nullptr;
+  int32_t* h_offsets = nullptr;
+  uint8_t* d_values = nullptr;
+  uint8_t* d_valid = nullptr;
+  int32_t* d_offsets = nullptr;
+  bool any_null_bitmap = false;  // at least one appended batch carried a validity bitmap
+};
+
+struct Slot {
+  std::vector<ColStage> cols;
+  int64_t rows = 0;
+  int64_t bytes = 0;  // utf8 payload bytes appended
+  hipEvent_t done = nullptr;
+  bool in_flight = false;
+};
+
+}  // namespace
+
+struct exon_hip_plan {
+  exon_hip_ctx* ctx;
+  exon_hip_plan_desc d;
+  int64_t n_i64, n_f64;
+  int n_cols;
+  ColSpec cols[4];
+};
+
+struct exon_hip_stream {
+  exon_hip_plan* plan;
+  exon_hip_ctx* ctx;
+  hipStream_t stream = nullptr;
+  uint8_t* d_state = nullptr;
+  Slot slots[2];
+  int cur = 0;
+  int64_t cap_rows = 0, cap_bytes = 0;
+  bool closed = false;
+  int64_t rows_pushed = 0;
+};
+
+// ---- bit utilities (Arrow LSB-first bitmaps) -------------------------------------------------------
+static void append_bits(uint8_t* dst, int64_t dst_off, const uint8_t* src, int64_t src_off, int64_t n) {
+  if (n <= 0) return;
+  if (src == nullptr) {  // all valid
+    int64_t i = 0;
+    while (i < n && ((dst_off + i) & 7)) {
+      dst[(dst_off + i) >> 3] |= (uint8_t)(1u << ((dst_off + i) & 7));
+      ++i;
+    }
+    const int64_t full = (n - i) / 8;
+    if (full > 0) memset(dst + ((dst_off + i) >> 3), 0xFF, (size_t)full);
+    i += full * 8;
+    for (; i < n; ++i) dst[(dst_off + i) >> 3] |= (uint8_t)(1u << ((dst_off + i) & 7));
+    return;
+  }
+  if (((dst_off | src_off) & 7) == 0) {
+    const int64_t full = n / 8;
+    memcpy(dst + (dst_off >> 3), src + (src_off >> 3), (size_t)full);
+    for (int64_t i = full * 8; i < n; ++i)
+      if ((src[(src_off + i) >> 3] >> ((src_off + i) & 7)) & 1) dst[(dst_off + i) >> 3] |= (uint8_t)(1u << ((dst_off + i) & 7));
+    return;
+  }
+  for (int64_t i = 0; i < n; ++i)
+    if ((src[(src_off + i) >> 3] >> ((src_off + i) & 7)) & 1) dst[(dst_off + i) >> 3] |= (uint8_t)(1u << ((dst_off + i) & 7));
+}
+
+static void free_slot(Slot& s) {
+  for (auto& c : s.cols) {
+    if (c.h_values) hipHostFree(c.h_values);
+    if (c.h_valid) hipHostFree(c.h_valid);
+    if (c.h_offsets) hipHostFree(c.h_offsets);
+    if (c.d_values) hipFree(c.d_values);
+    if (c.d_valid) hipFree(c.d_valid);
+    if (c.d_offsets) hipFree(c.d_offsets);
+  }
+  s.cols.clear();
+  if (s.done) hipEventDestroy(s.done);
+  s.done = nullptr;
+}
+
+static int alloc_slot(exon_hip_stream* st, Slot& s) {
+  exon_hip_plan* p = st->plan;
+  s.cols.assign((size_t)p->n_cols, ColStage());
+  for (int c = 0; c < p->n_cols; ++c) {
+    ColStage& cs = s.cols[(size_t)c];
+    const size_t vbytes = p->cols[c].utf8 ? (size_t)st->cap_bytes : (size_t)st->cap_rows * (size_t)p->cols[c].elem;
+    const size_t bbytes = (size_t)(st->cap_rows + 7) / 8 + 64;
+    if (hipHostMalloc((void**)&cs.h_values, vbytes + 64) != hipSuccess) return EXON_HIP_ENOMEM;
+    if (hipMalloc((void**)&cs.d_values, vbytes + 64) != hipSuccess) return EXON_HIP_ENOMEM;
+    if (hipHostMalloc((void**)&cs.h_valid, bbytes) != hipSuccess) return EXON_HIP_ENOMEM;
+    if (hipMalloc((void**)&cs.d_valid, bbytes) != hipSuccess) return EXON_HIP_ENOMEM;
+    memset(cs.h_valid, 0, bbytes);
+    if (p->cols[c].utf8) {
+      const size_t ob = ((size_t)st->cap_rows + 1) * 4;
+      if (hipHostMalloc((void**)&cs.h_offsets, ob) != hipSuccess) return EXON_HIP_ENOMEM;
+      if (hipMalloc((void**)&cs.d_offsets, ob) != hipSuccess) return EXON_HIP_ENOMEM;
+      cs.h_offsets[0] = 0;
+    }
+  }
+  if (!s.done && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return EXON_HIP_EDEVICE;
+  s.rows = 0;
+  s.bytes = 0;
+  s.in_flight = false;
+  return EXON_HIP_OK;
+}
+
+// launch the plan's kernel over device columns
+static int launch_plan(exon_hip_stream* st, const exon_hip_column* cols, int64_t n) {
+  const exon_hip_plan_desc& d = st->plan->d;
+  int64_t* counts = reinterpret_cast<int64_t*>(st->d_state);
+  double* sums = reinterpret_cast<double*>(st->d_state + st->plan->n_i64 * 8);
+  switch (d.kind) {
+    case EXON_HIP_PLAN_REGION_COUNT:
+      return exon_hip_region_count(st->ctx, st->stream, &cols[0], &cols[1], n, d.region_chrom_id, d.region_start,
+                                   d.region_end, counts);
+    case EXON_HIP_PLAN_FLAG_MAPQ_GROUP_COUNT:
+      return exon_hip_flag_mapq_group_count(st->ctx, st->stream, &cols[0], &cols[1], &cols[2], n, d.flag_mask,
+                                            d.flag_value, d.mapq_min, d.n_groups, counts);
+    case EXON_HIP_PLAN_CMP_AVG_BY_GROUP:
+      return exon_hip_cmp_avg_by_group(st->ctx, st->stream, &cols[0], &cols[1], &cols[2], n, d.threshold, d.cmp_op,
+                                       d.n_groups, counts, sums);
+    case EXON_HIP_PLAN_QUAL_POS_HIST:
+      return exon_hip_qual_pos_hist(st->ctx, st->stream, &cols[0], n, d.lmax, counts);
+  }
+  return fail(st->ctx, EXON_HIP_EINVAL, "unknown plan kind %d", d.kind);
+}
+
+static int flush_slot(exon_hip_stream* st) {
+  Slot& s = st->slots[st->cur];
+  if (s.rows == 0) return EXON_HIP_OK;
+  exon_hip_plan* p = st->plan;
+  exon_hip_column cols[4];
+  for (int c = 0; c < p->n_cols; ++c) {
+    ColStage& cs = s.cols[(size_t)c];
+    const size_t vbytes = p->cols[c].utf8 ? (size_t)s.bytes : (size_t)s.rows * (size_t)p->cols[c].elem;
+    if (vbytes) HIP_TRY(st->ctx, hipMemcpyAsync(cs.d_values, cs.h_values, vbytes, hipMemcpyHostToDevice, st->stream));
+    cols[c].values = cs.d_values;
+    cols[c].validity = nullptr;
+    cols[c].offsets = nullptr;
+    cols[c].length = s.rows;
+    if (cs.any_null_bitmap) {
+      HIP_TRY(st->ctx, hipMemcpyAsync(cs.d_valid, cs.h_valid, (size_t)(s.rows + 7) / 8, hipMemcpyHostToDevice, st->stream));
+      cols[c].validity = cs.d_valid;
+    }
+    if (p->cols[c].utf8) {
+      HIP_TRY(st->ctx, hipMemcpyAsync(cs.d_offsets, cs.h_offsets, ((size_t)s.rows + 1) * 4, hipMemcpyHostToDevice, st->stream));
+      cols[c].offsets = cs.d_offsets;
+    }
+  }
+  int rc = launch_plan(st, cols, s.rows);
+  if (rc) return rc;
+  HIP_TRY(st->ctx, hipEventRecord(s.done, st->stream));
+  s.in_flight = true;
+  // switch to the other slot; wait until its previous contents have been consumed
+  st->cur ^= 1;
+  Slot& n = st->slots[st->cur];
+  if (n.in_flight) {
+    HIP_TRY(st->ctx, hipEventSynchronize(n.done));
+    n.in_flight = false;
+  }
+  n.rows = 0;
+  n.bytes = 0;
+  for (auto& cs : n.cols) {
+    if (cs.any_null_bitmap) memset(cs.h_valid, 0, (size_t)(st->cap_rows + 7) / 8 + 64);
+    cs.any_null_bitmap = false;
+    if (cs.h_offsets) cs.h_offsets[0] = 0;
+  }
+  return EXON_HIP_OK;
+}
+
+static int ensure_capacity(exon_hip_stream* st, int64_t rows, int64_t bytes) {
+  if (st->cap_rows >= rows && st->cap_bytes >= bytes && !st->slots[0].cols.empty()) return EXON_HIP_OK;
+  // (re)allocate both slots; pending rows must be flushed and consumed first
+  int rc = flush_slot(st);
+  if (rc) return rc;
+  HIP_TRY(st->ctx, hipStreamSynchronize(st->stream));
+  for (auto& s : st->slots) free_slot(s);
+  int64_t def_rows = 4 << 20, def_bytes = 256ll << 20;
+  if (const char* v = getenv("EXON_HIP_COALESCE_ROWS")) {
+    long long x = atoll(v);
+    if (x >= 1) def_rows = x;
+  }
+  st->cap_rows = std::max(st->cap_rows, std::max(rows, def_rows));
+  st->cap_bytes = std::max(st->cap_bytes, std::max(bytes, def_bytes));
+  for (auto& s : st->slots)
+    if ((rc = alloc_slot(st, s))) return fail(st->ctx, rc, "staging allocation failed (%lld rows)", (long long)st->cap_rows);
+  st->cur = 0;
+  return EXON_HIP_OK;
+}
+
+extern "C" {
+
+int exon_hip_plan_create(exon_hip_ctx* ctx, const exon_hip_plan_desc* desc, exon_hip_plan** out) {
+  if (!ctx || !desc || !out) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_plan_create: NULL argument");
+  *out = nullptr;
+  exon_hip_plan* p = new (std::nothrow) exon_hip_plan();
+  if (!p) return fail(ctx, EXON_HIP_ENOMEM, "out of host memory");
+  p->ctx = ctx;
+  p->d = *desc;
+  p->n_i64 = p->n_f64 = 0;
+  switch (desc->kind) {
+    case EXON_HIP_PLAN_REGION_COUNT:
+      p->n_cols = 2;
+      p->cols[0].elem = 4;
+      p->cols[1].elem = 8;
+      p->n_i64 = 1;
+      if (desc->region_start < 1 || desc->region_end < desc->region_start) {
+        delete p;
+        return fail(ctx, EXON_HIP_EINVAL, "region interval must satisfy 1 <= start <= end");
+      }
+      break;
+    case EXON_HIP_PLAN_FLAG_MAPQ_GROUP_COUNT:
+      p->n_cols = 3;
+      p->cols[0].elem = 4;
+      p->cols[1].elem = 1;
+      p->cols[2].elem = 4;
+      if (desc->n_groups < 0 || desc->n_groups + 1 > EXON_HIP_MAX_GROUPS) {
+        delete p;
+        return fail(ctx, EXON_HIP_EUNSUPPORTED, "n_groups %d out of range", desc->n_groups);
+      }
+      p->n_i64 = desc->n_groups + 1;
+      break;
+    case EXON_HIP_PLAN_CMP_AVG_BY_GROUP:
+      p->n_cols = 3;
+      p->cols[0].elem = p->cols[1].elem = p->cols[2].elem = 4;
+      if (desc->n_groups < 1 || desc->n_groups > EXON_HIP_MAX_REG_GROUPS) {
+        delete p;
+        return fail(ctx, EXON_HIP_EUNSUPPORTED, "n_groups %d outside [1, %d]", desc->n_groups, EXON_HIP_MAX_REG_GROUPS);
+      }
+      if (desc->cmp_op < EXON_HIP_GT || desc->cmp_op > EXON_HIP_NE) {
+        delete p;
+        return fail(ctx, EXON_HIP_EINVAL, "bad cmp_op %d", desc->cmp_op);
+      }
+      p->n_i64 = 2 * desc->n_groups;
+      p->n_f64 = desc->n_groups;
+      break;
+    case EXON_HIP_PLAN_QUAL_POS_HIST:
+      p->n_cols = 1;
+      p->cols[0].elem = 1;
+      p->cols[0].utf8 = true;
+      if (desc->lmax < 1 || desc->lmax > 65536) {
+        delete p;
+        return fail(ctx, EXON_HIP_EINVAL, "lmax %d out of range", desc->lmax);
+      }
+      p->n_i64 = (int64_t)desc->lmax * 256;
+      break;
+    default:
+      delete p;
+      return fail(ctx, EXON_HIP_EINVAL, "unknown plan kind %d", desc->kind);
+  }
+  for (int c = 0; c < p->n_cols; ++c)
+    if (desc->columns[c] < 0) {
+      delete p;
+      return fail(ctx, EXON_HIP_EINVAL, "negative column index");
+    }
+  *out = p;
+  return EXON_HIP_OK;
+}
+
+int exon_hip_plan_destroy(exon_hip_plan* plan) {
+  delete plan;
+  return EXON_HIP_OK;
+}
+
+int exon_hip_plan_state_size(const exon_hip_plan* plan, int64_t* n_i64, int64_t* n_f64) {
+  if (!plan || !n_i64 || !n_f64) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_plan_state_size: NULL argument");
+  *n_i64 = plan->n_i64;
+  *n_f64 = plan->n_f64;
+  return EXON_HIP_OK;
+}
+
+int exon_hip_stream_open(exon_hip_plan* plan, int32_t partition, exon_hip_stream** out) {
+  (void)partition;
+  if (!plan || !out) return fail(plan ? plan->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_stream_open: NULL argument");
+  *out = nullptr;
+  exon_hip_ctx* ctx = plan->ctx;
+  exon_hip_stream* st = new (std::nothrow) exon_hip_stream();
+  if (!st) return fail(ctx, EXON_HIP_ENOMEM, "out of host memory");
+  st->plan = plan;
+  st->ctx = ctx;
+  hipSetDevice(ctx->device);
+  hipError_t e;
+  const size_t sbytes = (size_t)(plan->n_i64 + plan->n_f64) * 8;
+  if ((e = hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipMalloc((void**)&st->d_state, sbytes)) != hipSuccess ||
+      (e = hipMemsetAsync(st->d_state, 0, sbytes, st->stream)) != hipSuccess) {
+    if (st->stream) hipStreamDestroy(st->stream);
+    if (st->d_state) hipFree(st->d_state);
+    delete st;
+    return fail(ctx, EXON_HIP_EDEVICE, "stream open: %s", hipGetErrorString(e));
+  }
+  *out = st;
+  return EXON_HIP_OK;
+}
+
+static int column_child(exon_hip_stream* st, const struct ArrowArray* batch, int c, const struct ArrowArray** child,
+                        int64_t* eff_off) {
+  const int idx = st->plan->d.columns[c];
+  if (idx >= batch->n_children) return fail(st->ctx, EXON_HIP_EINVAL, "batch has %lld columns, plan needs index %d", (long long)batch->n_children, idx);
+  const struct ArrowArray* ch = batch->children[idx];
+  if (!ch) return fail(st->ctx, EXON_HIP_EINVAL, "column %d is NULL", idx);
+  const int need = st->plan->cols[c].utf8 ? 3 : 2;
+  if (ch->n_buffers < need) return fail(st->ctx, EXON_HIP_EINVAL, "column %d has %lld buffers, expected %d", idx, (long long)ch->n_buffers, need);
+  *eff_off = batch->offset + ch->offset;
+  if (ch->length + ch->offset < batch->offset + batch->length)
+    return fail(st->ctx, EXON_HIP_EINVAL, "column %d shorter than the batch", idx);
+  *child = ch;
+  return EXON_HIP_OK;
+}
+
+int exon_hip_stream_push(exon_hip_stream* st, struct ArrowArray* batch) {
+  if (!st || !batch) return fail(st ? st->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_stream_push: NULL argument");
+  if (st->closed) return fail(st->ctx, EXON_HIP_ESTATE, "push after finish/close");
+  if (!batch->release) return fail(st->ctx, EXON_HIP_EINVAL, "batch already released");
+  exon_hip_plan* p = st->plan;
+  const int64_t rows = batch->length;
+  int rc = EXON_HIP_OK;
+  const struct ArrowArray* ch[4];
+  int64_t off[4];
+  int64_t need_bytes = 0;
+  for (int c = 0; c < p->n_cols && !rc; ++c) {
+    rc = column_child(st, batch, c, &ch[c], &off[c]);
+    if (!rc && p->cols[c].utf8 && rows > 0) {
+      const int32_t* o = (const int32_t*)ch[c]->buffers[1];
+      need_bytes = std::max<int64_t>(need_bytes, (int64_t)o[off[c] + rows] - o[off[c]]);
+    }
+  }
+  if (!rc && rows > 0) {
+    rc = ensure_capacity(st, rows, need_bytes);
+    if (!rc && (st->slots[st->cur].rows + rows > st->cap_rows || st->slots[st->cur].bytes + need_bytes > st->cap_bytes))
+      rc = flush_slot(st);
+    if (!rc) {
+      Slot& s = st->slots[st->cur];
+      for (int c = 0; c < p->n_cols; ++c) {
+        ColStage& cs = s.cols[(size_t)c];
+        const uint8_t* valid = (const uint8_t*)ch[c]->buffers[0];
+        if (valid && ch[c]->null_count != 0) {
+          if (!cs.any_null_bitmap) {
+            // rows appended so far had no bitmap: mark them valid
+            append_bits(cs.h_valid, 0, nullptr, 0, s.rows);
+            cs.any_null_bitmap = true;
+          }
+          append_bits(cs.h_valid, s.rows, valid, off[c], rows);
+        } else if (cs.any_null_bitmap) {
+          append_bits(cs.h_valid, s.rows, nullptr, 0, rows);
+        }
+        if (p->cols[c].utf8) {
+          const int32_t* o = (const int32_t*)ch[c]->buffers[1] + off[c];
+          const uint8_t* data = (const uint8_t*)ch[c]->buffers[2];
+          const int32_t base = o[0], len = o[rows] - base;
+          if (len) memcpy(cs.h_values + s.bytes, data + base, (size_t)len);
+          const int32_t shift = (int32_t)s.bytes - base;
+          for (int64_t i = 1; i <= rows; ++i) cs.h_offsets[s.rows + i] = o[i] + shift;
+        } else {
+          const int e = p->cols[c].elem;
+          memcpy(cs.h_values + (size_t)s.rows * e, (const uint8_t*)ch[c]->buffers[1] + (size_t)off[c] * e, (size_t)rows * e);
+        }
+      }
+      s.rows += rows;
+      s.bytes += need_bytes;
+      st->rows_pushed += rows;
+    }
+  }
+  batch->release(batch);  // moved: released exactly once, success or not
+  return rc;
+}
+
+int exon_hip_stream_push_device(exon_hip_stream* st, const struct ArrowDeviceArray* dbatch) {
+  if (!st || !dbatch) return fail(st ? st->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_stream_push_device: NULL argument");
+  if (st->closed) return fail(st->ctx, EXON_HIP_ESTATE, "push after finish/close");
+  if (dbatch->device_type != ARROW_DEVICE_ROCM)
+    return fail(st->ctx, EXON_HIP_EINVAL, "device_type %d is not ARROW_DEVICE_ROCM", (int)dbatch->device_type);
+  if (dbatch->device_id != st->ctx->device)
+    return fail(st->ctx, EXON_HIP_EINVAL, "batch lives on device %lld, stream on %d", (long long)dbatch->device_id, st->ctx->device);
+  exon_hip_plan* p = st->plan;
+  const struct ArrowArray* batch = &dbatch->array;
+  const int64_t rows = batch->length;
+  exon_hip_column cols[4];
+  for (int c = 0; c < p->n_cols; ++c) {
+    const struct ArrowArray* ch;
+    int64_t off;
+    int rc = column_child(st, batch, c, &ch, &off);
+    if (rc) return rc;
+    cols[c].length = rows;
+    cols[c].validity = nullptr;
+    cols[c].offsets = nullptr;
+    if (ch->buffers[0] && ch->null_count != 0) {
+      if (off & 7) return fail(st->ctx, EXON_HIP_EINVAL, "device batch: validity bit offset must be a multiple of 8");
+      cols[c].validity = (const uint8_t*)ch->buffers[0] + (off >> 3);
+    }
+    if (p->cols[c].utf8) {
+      cols[c].offsets = (const int32_t*)ch->buffers[1] + off;
+      cols[c].values = ch->buffers[2];
+    } else {
+      cols[c].values = (const uint8_t*)ch->buffers[1] + (size_t)off * p->cols[c].elem;
+    }
+  }
+  if (dbatch->sync_event) HIP_TRY(st->ctx, hipStreamWaitEvent(st->stream, *(hipEvent_t*)dbatch->sync_event, 0));
+  int rc = launch_plan(st, cols, rows);
+  if (!rc) st->rows_pushed += rows;
+  return rc;
+}
+
+int exon_hip_stream_state(exon_hip_stream* st, int64_t** d_i64, double** d_f64, void** hip_stream) {
+  if (!st) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_stream_state: NULL stream");
+  int rc = flush_slot(st);
+  if (rc) return rc;
+  if (d_i64) *d_i64 = reinterpret_cast<int64_t*>(st->d_state);
+  if (d_f64) *d_f64 = reinterpret_cast<double*>(st->d_state + st->plan->n_i64 * 8);
+  if (hip_stream) *hip_stream = (void*)st->stream;
+  return EXON_HIP_OK;
+}
+
+int exon_hip_stream_sync(exon_hip_stream* st) {
+  if (!st) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_stream_sync: NULL stream");
+  int rc = flush_slot(st);
+  if (rc) return rc;
+  return exon_hip_sync(st->ctx, st->stream);
+}
+
+int exon_hip_stream_finish(exon_hip_stream* st, int64_t* counts, double* sums) {
+  if (!st) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_stream_finish: NULL stream");
+  int rc = exon_hip_stream_sync(st);
+  if (rc) return rc;
+  st->closed = true;
+  if (st->plan->n_i64 && !counts) return fail(st->ctx, EXON_HIP_EINVAL, "counts is NULL");
+  if (st->plan->n_f64 && !sums) return fail(st->ctx, EXON_HIP_EINVAL, "sums is NULL");
+  if (st->plan->n_i64) HIP_TRY(st->ctx, hipMemcpy(counts, st->d_state, (size_t)st->plan->n_i64 * 8, hipMemcpyDeviceToHost));
+  if (st->plan->n_f64)
+    HIP_TRY(st->ctx, hipMemcpy(sums, st->d_state + st->plan->n_i64 * 8, (size_t)st->plan->n_f64 * 8, hipMemcpyDeviceToHost));
+  return EXON_HIP_OK;
+}
+
+}  // extern "C"
+
+// ---- Arrow export of the partial-aggregate state ---------------------------------------------------
+namespace {
+struct OwnedArray {
+  std::vector<void*> bufs;            // malloc'ed, owned
+  std::vector<const void*> buf_ptrs;  // what ArrowArray::buffers points at
+  std::vector<struct ArrowArray*> children;
+};
+void release_array(struct ArrowArray* a) {
+  if (!a || !a->release) return;
+  OwnedArray* o = (OwnedArray*)a->private_data;
+  for (auto* c : o->children) {
+    if (c->release) c->release(c);
+    free(c);
+  }
+  for (void* b : o->bufs) free(b);
+  delete o;
+  a->release = nullptr;
+}
+struct OwnedSchema {
+  std::string format, name;
+  std::vector<struct ArrowSchema*> children;
+};
+void release_schema(struct ArrowSchema* s) {
+  if (!s || !s->release) return;
+  OwnedSchema* o = (OwnedSchema*)s->private_data;
+  for (auto* c : o->children) {
+    if (c->release) c->release(c);
+    free(c);
+  }
+  delete o;
+  s->release = nullptr;
+}
+void make_schema(struct ArrowSchema* s, const char* fmt, const char* name, bool nullable, std::vector<struct ArrowSchema*> kids = {}) {
+  OwnedSchema* o = new OwnedSchema{fmt, name, std::move(kids)};
+  memset(s, 0, sizeof *s);
+  s->format = o->format.c_str();
+  s->name = o->name.c_str();
+  s->flags = nullable ? ARROW_FLAG_NULLABLE : 0;
+  s->n_children = (int64_t)o->children.size();
+  s->children = o->children.empty() ? nullptr : o->children.data();
+  s->release = release_schema;
+  s->private_data = o;
+}
+// primitive column of `n` values of `elem` bytes copied from `src`; validity from `valid` (byte per row) or none
+void make_prim(struct ArrowArray* a, const void* src, int64_t n, int elem, const std::vector<uint8_t>* valid) {
+  OwnedArray* o = new OwnedArray();
+  void* vb = nullptr;
+  int64_t nulls = 0;
+  if (valid) {
+    vb = calloc((size_t)(n + 7) / 8 + 8, 1);
+    for (int64_t i = 0; i < n; ++i) {
+      if ((*valid)[(size_t)i]) ((uint8_t*)vb)[i >> 3] |= (uint8_t)(1u << (i & 7));
+      else ++nulls;
+    }
+    o->bufs.push_back(vb);
+  }
+  void* data = malloc((size_t)n * elem + 8);
+  if (n) memcpy(data, src, (size_t)n * elem);
+  o->bufs.push_back(data);
+  o->buf_ptrs = {vb, data};
+  memset(a, 0, sizeof *a);
+  a->length = n;
+  a->null_count = nulls;
+  a->n_buffers = 2;
+  a->buffers = o->buf_ptrs.data();
+  a->release = release_array;
+  a->private_data = o;
+}
+void make_struct(struct ArrowArray* a, int64_t n, std::vector<struct ArrowArray*> kids) {
+  OwnedArray* o = new OwnedArray();
+  o->children = std::move(kids);
+  o->buf_ptrs = {nullptr};
+  memset(a, 0, sizeof *a);
+  a->length = n;
+  a->n_buffers = 1;
+  a->buffers = o->buf_ptrs.data();
+  a->n_children = (int64_t)o->children.size();
+  a->children = o->children.data();
+  a->release = release_array;
+  a->private_data = o;
+}
+template <typename T>
+struct ArrowArray* prim(const std::vector<T>& v, const std::vector<uint8_t>* valid = nullptr) {
+  struct ArrowArray* a = (struct ArrowArray*)malloc(sizeof *a);
+  make_prim(a, v.data(), (int64_t)v.size(), (int)sizeof(T), valid);
+  return a;
+}
+struct ArrowSchema* field(const char* fmt, const char* name, bool nullable) {
+  struct ArrowSchema* s = (struct ArrowSchema*)malloc(sizeof *s);
+  make_schema(s, fmt, name, nullable);
+  return s;
+}
+}  // namespace
+
+extern "C" {
+
+int exon_hip_stream_finish_arrow(exon_hip_stream* st, struct ArrowArray* out, struct ArrowSchema* out_schema) {
+  if (!st || !out || !out_schema) return fail(st ? st->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_stream_finish_arrow: NULL argument");
+  const exon_hip_plan* p = st->plan;
+  std::vector<int64_t> counts((size_t)p->n_i64);
+  std::vector<double> sums((size_t)p->n_f64);
+  int rc = exon_hip_stream_finish(st, counts.data(), sums.data());
+  if (rc) return rc;
+  const exon_hip_plan_desc& d = p->d;
+  switch (d.kind) {
+    case EXON_HIP_PLAN_REGION_COUNT: {
+      make_struct(out, 1, {prim(counts)});
+      make_schema(out_schema, "+s", "", false, {field("l", "count(*)[count]", false)});
+      break;
+    }
+    case EXON_HIP_PLAN_FLAG_MAPQ_GROUP_COUNT: {
+      std::vector<int32_t> key;
+      std::vector<uint8_t> valid;
+      std::vector<int64_t> cnt;
+      for (int g = 0; g <= d.n_groups; ++g)
+        if (counts[(size_t)g]) {
+          key.push_back(g < d.n_groups ? g : 0);
+          valid.push_back(g < d.n_groups);
+          cnt.push_back(counts[(size_t)g]);
+        }
+      make_struct(out, (int64_t)key.size(), {prim(key, &valid), prim(cnt)});
+      make_schema(out_schema, "+s", "", false, {field("i", "reference", true), field("l", "count(*)[count]", false)});
+      break;
+    }
+    case EXON_HIP_PLAN_CMP_AVG_BY_GROUP: {
+      const int G = d.n_groups;
+      std::vector<int32_t> key;
+      std::vector<uint64_t> acnt;
+      std::vector<double> asum;
+      std::vector<int64_t> rows;
+      for (int g = 0; g < G; ++g)
+        if (counts[(size_t)(G + g)]) {
+          key.push_back(g);
+          acnt.push_back((uint64_t)counts[(size_t)g]);
+          asum.push_back(sums[(size_t)g]);
+          rows.push_back(counts[(size_t)(G + g)]);
+        }
+      make_struct(out, (int64_t)key.size(), {prim(key), prim(acnt), prim(asum), prim(rows)});
+      make_schema(out_schema, "+s", "", false,
+                  {field("i", "group", false), field("L", "avg[count]", false), field("g", "avg[sum]", false),
+                   field("l", "count(*)[count]", false)});
+      break;
+    }
+    case EXON_HIP_PLAN_QUAL_POS_HIST: {
+      std::vector<int32_t> pos, score;
+      std::vector<int64_t> cnt;
+      for (int pp = 0; pp < d.lmax; ++pp)
+        for (int b = 0; b < 256; ++b)
+          if (counts[(size_t)pp * 256 + b]) {
+            pos.push_back(pp);
+            score.push_back(b - 33);
+            cnt.push_back(counts[(size_t)pp * 256 + b]);
+          }
+      make_struct(out, (int64_t)pos.size(), {prim(pos), prim(score), prim(cnt)});
+      make_schema(out_schema, "+s", "", false,
+                  {field("i", "position", false), field("i", "quality_score", false), field("l", "count(*)[count]", false)});
+      break;
+    }
+    default:
+      return fail(st->ctx, EXON_HIP_EINVAL, "unknown plan kind");
+  }
+  return EXON_HIP_OK;
+}
+
+int exon_hip_stream_close(exon_hip_stream* st) {
+  if (!st) return EXON_HIP_OK;
+  hipSetDevice(st->ctx->device);
+  if (st->stream) hipStreamSynchronize(st->stream);
+  for (auto& s : st->slots) free_slot(s);
+  {
+    // drop this stream's workspace
+    std::lock_guard<std::mutex> g(st->ctx->mu);
+    auto it = st->ctx->workspaces.find(st->stream);
+    if (it != st->ctx->workspaces.end()) {
+      if (it->second.partials) hipFree(it->second.partials);
+      if (it->second.status) hipFree(it->second.status);
+      st->ctx->workspaces.erase(it);
+    }
+  }
+  if (st->d_state) hipFree(st->d_state);
+  if (st->stream) hipStreamDestroy(st->stream);
+  delete st;
+  return EXON_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,312 @@
+"""Python host side above the C ABI (test harness / bench driver; the product is the HIP library).
+
+`Context` owns a device; `DeviceBuffer` is a typed HBM allocation; `Plan` / `Stream` mirror the
+ExecutionPlan-shaped surface of include/exon_hip.h (plan_create / stream_open / push / finish).
+Every compute call goes through libexon_hip.so -- there is no numpy or oracle fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import CMP, Column, ExonHipError
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceBuffer:
+    """A typed allocation in HBM (hipMalloc through the C ABI)."""
+
+    def __init__(self, ctx, dtype, n):
+        self.ctx = ctx
+        self.dtype = np.dtype(dtype)
+        self.n = int(n)
+        self.nbytes = self.n * self.dtype.itemsize
+        p = C.c_void_p()
+        ctx._check(ctx.lib.exon_hip_malloc(ctx.h, max(self.nbytes, 16), C.byref(p)))
+        self.ptr = p.value
+
+    def copy_from(self, host, stream=None):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        assert host.size <= self.n
+        self.ctx._check(self.ctx.lib.exon_hip_memcpy_h2d(self.ctx.h, self.ptr, _np_ptr(host), host.nbytes, stream))
+        self.ctx.sync(stream)
+        return self
+
+    def to_host(self, n=None, stream=None):
+        n = self.n if n is None else n
+        out = np.empty(n, self.dtype)
+        self.ctx._check(self.ctx.lib.exon_hip_memcpy_d2h(self.ctx.h, _np_ptr(out), self.ptr, out.nbytes, stream))
+        return out
+
+    def zero(self, stream=None):
+        self.ctx._check(self.ctx.lib.exon_hip_memset(self.ctx.h, self.ptr, 0, self.nbytes, stream))
+        return self
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.exon_hip_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _col(values=None, validity=None, offsets=None, length=0):
+    def p(x):
+        if x is None:
+            return None
+        return x.ptr if isinstance(x, DeviceBuffer) else int(x)
+    return Column(p(values), p(validity), p(offsets), int(length))
+
+
+class Context:
+    def __init__(self, device=0):
+        self.lib = L.load()
+        h = C.c_void_p()
+        rc = self.lib.exon_hip_ctx_create(device, C.byref(h))
+        if rc:
+            raise ExonHipError(rc, self.lib.exon_hip_last_error(None).decode())
+        self.h = h
+        self.device = device
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc < 0:
+            raise ExonHipError(rc, self.lib.exon_hip_last_error(self.h).decode())
+        return rc
+
+    def info(self):
+        d = L.DeviceInfo()
+        self._check(self.lib.exon_hip_ctx_info(self.h, C.byref(d)))
+        return {"name": d.name.decode(), "gcn_arch": d.gcn_arch.decode(), "compute_units": d.compute_units,
+                "wavefront_size": d.wavefront_size, "hbm_bytes": d.hbm_bytes, "clock_khz": d.clock_khz}
+
+    def empty(self, dtype, n):
+        return DeviceBuffer(self, dtype, n)
+
+    def zeros(self, dtype, n):
+        return DeviceBuffer(self, dtype, n).zero()
+
+    def to_device(self, host, dtype=None):
+        host = np.ascontiguousarray(host, dtype=dtype)
+        return DeviceBuffer(self, host.dtype, host.size).copy_from(host)
+
+    def sync(self, stream=None):
+        self._check(self.lib.exon_hip_sync(self.h, stream))
+
+    def timer_start(self, stream=None):
+        self._check(self.lib.exon_hip_timer_start(self.h, stream))
+
+    def timer_stop_ms(self, stream=None):
+        ms = C.c_float()
+        self._check(self.lib.exon_hip_timer_stop_ms(self.h, stream, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self.h:
+            self.lib.exon_hip_ctx_destroy(self.h)
+            self.h = None
+
+    # -- operators (asynchronous; accumulate into device state) ---------------------------------
+    def region_count(self, chrom_id, pos, n, region_chrom_id, start, end, d_count, chrom_valid=None,
+                     pos_valid=None, stream=None):
+        end = L.REGION_OPEN_END if end is None else end
+        c0, c1 = _col(chrom_id, chrom_valid, None, n), _col(pos, pos_valid, None, n)
+        self._check(self.lib.exon_hip_region_count(self.h, stream, C.byref(c0), C.byref(c1), n, region_chrom_id,
+                                                   start, end, d_count.ptr))
+
+    def flag_mapq_group_count(self, flag, mapq, mapq_valid, ref_id, ref_valid, n, flag_mask, flag_value, mapq_min,
+                              n_refs, d_counts, flag_valid=None, stream=None):
+        c0, c1, c2 = _col(flag, flag_valid, None, n), _col(mapq, mapq_valid, None, n), _col(ref_id, ref_valid, None, n)
+        self._check(self.lib.exon_hip_flag_mapq_group_count(self.h, stream, C.byref(c0), C.byref(c1), C.byref(c2), n,
+                                                            flag_mask, flag_value, mapq_min, n_refs, d_counts.ptr))
+
+    def cmp_avg_by_group(self, x, x_valid, y, y_valid, group_id, n, threshold, op, n_groups, d_counts, d_sums,
+                         stream=None):
+        c0, c1, c2 = _col(x, x_valid, None, n), _col(y, y_valid, None, n), _col(group_id, None, None, n)
+        self._check(self.lib.exon_hip_cmp_avg_by_group(self.h, stream, C.byref(c0), C.byref(c1), C.byref(c2), n,
+                                                       float(threshold), CMP[op], n_groups, d_counts.ptr, d_sums.ptr))
+
+    def qual_pos_hist(self, offsets, data, n_reads, lmax, d_hist, stream=None):
+        c0 = _col(data, None, offsets, n_reads)
+        self._check(self.lib.exon_hip_qual_pos_hist(self.h, stream, C.byref(c0), n_reads, lmax, d_hist.ptr))
+
+    # -- synthetic inputs in HBM ------------------------------------------------------------------
+    def gen_c2(self, seed, n_total, lo=0, hi=None, stream=None):
+        hi = n_total if hi is None else hi
+        n = hi - lo
+        chrom, pos = self.empty(np.int32, n), self.empty(np.int64, n)
+        self._check(self.lib.exon_hip_gen_c2(self.h, stream, seed, n_total, lo, hi, chrom.ptr, pos.ptr))
+        return chrom, pos
+
+    def gen_c3(self, seed, lo, hi, stream=None):
+        n = hi - lo
+        nb = (n + 7) // 8 + 64
+        flag, mapq, mv = self.empty(np.int32, n), self.empty(np.uint8, n + 64), self.zeros(np.uint8, nb)
+        ref, rv = self.empty(np.int32, n), self.zeros(np.uint8, nb)
+        self._check(self.lib.exon_hip_gen_c3(self.h, stream, seed, lo, hi, flag.ptr, mapq.ptr, mv.ptr, ref.ptr, rv.ptr))
+        return flag, mapq, mv, ref, rv
+
+    def gen_c4(self, seed, lo, hi, stream=None):
+        n = hi - lo
+        nb = (n + 7) // 8 + 64
+        af, av = self.empty(np.float32, n), self.zeros(np.uint8, nb)
+        q, qv = self.empty(np.float32, n), self.zeros(np.uint8, nb)
+        fid = self.empty(np.int32, n)
+        self._check(self.lib.exon_hip_gen_c4(self.h, stream, seed, lo, hi, af.ptr, av.ptr, q.ptr, qv.ptr, fid.ptr))
+        return af, av, q, qv, fid
+
+    def gen_c5(self, seed, lo, hi, read_len, stream=None):
+        n = hi - lo
+        off, data = self.empty(np.int32, n + 1), self.empty(np.uint8, n * read_len + 64)
+        self._check(self.lib.exon_hip_gen_c5(self.h, stream, seed, lo, hi, read_len, off.ptr, data.ptr))
+        return off, data
+
+    # -- plans ------------------------------------------------------------------------------------
+    def plan_region_count(self, region_chrom_id, start=1, end=None, columns=(0, 1)):
+        d = L.PlanDesc(kind=L.PLAN_REGION_COUNT, region_chrom_id=region_chrom_id, region_start=start,
+                       region_end=L.REGION_OPEN_END if end is None else end)
+        return Plan(self, d, columns)
+
+    def plan_flag_mapq_group_count(self, flag_mask, flag_value, mapq_min, n_refs, columns=(0, 1, 2)):
+        d = L.PlanDesc(kind=L.PLAN_FLAG_MAPQ_GROUP_COUNT, n_groups=n_refs, flag_mask=flag_mask,
+                       flag_value=flag_value, mapq_min=mapq_min)
+        return Plan(self, d, columns)
+
+    def plan_cmp_avg_by_group(self, op, threshold, n_groups, columns=(0, 1, 2)):
+        d = L.PlanDesc(kind=L.PLAN_CMP_AVG_BY_GROUP, n_groups=n_groups, cmp_op=CMP[op], threshold=threshold)
+        return Plan(self, d, columns)
+
+    def plan_qual_pos_hist(self, lmax, columns=(0,)):
+        d = L.PlanDesc(kind=L.PLAN_QUAL_POS_HIST, lmax=lmax)
+        return Plan(self, d, columns)
+
+
+def parse_region(region):
+    """`name[:start[-end]]` -> (name, start, end|None)   (host helper of the C ABI)."""
+    lib = L.load()
+    name = C.create_string_buffer(512)
+    a, b = C.c_int64(), C.c_int64()
+    rc = lib.exon_hip_parse_region(region.encode(), name, 512, C.byref(a), C.byref(b))
+    if rc:
+        raise ExonHipError(rc, lib.exon_hip_last_error(None).decode())
+    return name.value.decode(), a.value, (None if b.value == L.REGION_OPEN_END else b.value)
+
+
+def regroup_files_by_size(sizes, target_groups):
+    """Whole-file round-robin repartition; returns a list of groups of ORIGINAL file indexes."""
+    lib = L.load()
+    n = len(sizes)
+    s = (C.c_int64 * max(n, 1))(*sizes)
+    g = (C.c_int32 * max(n, 1))()
+    ng = lib.exon_hip_regroup_files_by_size(s, n, target_groups, g)
+    if ng < 0:
+        raise ExonHipError(ng, lib.exon_hip_last_error(None).decode())
+    groups = [[] for _ in range(ng)]
+    for i in sorted(range(n), key=lambda i: (sizes[i], i)):
+        groups[g[i]].append(i)
+    return groups
+
+
+class Plan:
+    def __init__(self, ctx, desc, columns):
+        self.ctx = ctx
+        for i, c in enumerate(columns):
+            desc.columns[i] = c
+        self.desc = desc
+        h = C.c_void_p()
+        ctx._check(ctx.lib.exon_hip_plan_create(ctx.h, C.byref(desc), C.byref(h)))
+        self.h = h
+        a, b = C.c_int64(), C.c_int64()
+        ctx._check(ctx.lib.exon_hip_plan_state_size(h, C.byref(a), C.byref(b)))
+        self.n_i64, self.n_f64 = a.value, b.value
+
+    def open(self, partition=0):
+        return Stream(self, partition)
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.exon_hip_plan_destroy(self.h)
+            self.h = None
+
+
+class Stream:
+    """One partition's execution (ExecutionPlan::execute analogue)."""
+
+    def __init__(self, plan, partition):
+        self.plan, self.ctx = plan, plan.ctx
+        h = C.c_void_p()
+        self.ctx._check(self.ctx.lib.exon_hip_stream_open(plan.h, partition, C.byref(h)))
+        self.h = h
+
+    def push(self, batch):
+        """Push a pyarrow.RecordBatch (host memory) through the Arrow C Data Interface (moved)."""
+        arr = L.ArrowArray()
+        sch = L.ArrowSchema()
+        batch._export_to_c(C.addressof(arr), C.addressof(sch))
+        try:
+            self.ctx._check(self.ctx.lib.exon_hip_stream_push(self.h, C.byref(arr)))
+        finally:
+            if sch.release:
+                C.CFUNCTYPE(None, C.POINTER(L.ArrowSchema))(sch.release)(C.byref(sch))
+
+    def push_device(self, columns, n_rows):
+        """columns: list of (values DeviceBuffer, validity DeviceBuffer|None, offsets DeviceBuffer|None) already
+        in HBM, in batch-child order; wrapped as an ArrowDeviceArray (ARROW_DEVICE_ROCM)."""
+        keep = []
+        kids = (C.POINTER(L.ArrowArray) * len(columns))()
+        for i, (values, validity, offsets) in enumerate(columns):
+            a = L.ArrowArray()
+            if offsets is not None:
+                bufs = (C.c_void_p * 3)(validity.ptr if validity else None, offsets.ptr, values.ptr)
+                a.n_buffers = 3
+            else:
+                bufs = (C.c_void_p * 2)(validity.ptr if validity else None, values.ptr)
+                a.n_buffers = 2
+            a.length = n_rows
+            a.null_count = -1 if validity else 0
+            a.buffers = C.cast(bufs, C.POINTER(C.c_void_p))
+            keep += [a, bufs]
+            kids[i] = C.pointer(a)
+        top = L.ArrowDeviceArray()
+        tb = (C.c_void_p * 1)(None)
+        top.array.length = n_rows
+        top.array.n_buffers = 1
+        top.array.buffers = C.cast(tb, C.POINTER(C.c_void_p))
+        top.array.n_children = len(columns)
+        top.array.children = C.cast(kids, C.POINTER(C.POINTER(L.ArrowArray)))
+        top.device_id = self.ctx.device
+        top.device_type = L.ARROW_DEVICE_ROCM
+        self.ctx._check(self.ctx.lib.exon_hip_stream_push_device(self.h, C.byref(top)))
+        self._keep = keep + [kids, tb, top]
+
+    def state(self):
+        a, b, s = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self.ctx._check(self.ctx.lib.exon_hip_stream_state(self.h, C.byref(a), C.byref(b), C.byref(s)))
+        return a.value, b.value, s.value
+
+    def sync(self):
+        self.ctx._check(self.ctx.lib.exon_hip_stream_sync(self.h))
+
+    def finish(self):
+        counts = np.zeros(self.plan.n_i64, np.int64)
+        sums = np.zeros(self.plan.n_f64, np.float64)
+        self.ctx._check(self.ctx.lib.exon_hip_stream_finish(self.h, _np_ptr(counts), _np_ptr(sums)))
+        return counts, sums
+
+    def finish_arrow(self):
+        import pyarrow as pa
+        arr, sch = L.ArrowArray(), L.ArrowSchema()
+        self.ctx._check(self.ctx.lib.exon_hip_stream_finish_arrow(self.h, C.byref(arr), C.byref(sch)))
+        return pa.Array._import_from_c(C.addressof(arr), C.addressof(sch))
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.exon_hip_stream_close(self.h)
+            self.h = None

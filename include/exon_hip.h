@@ -1,0 +1,261 @@
+/*
+ * exon_hip.h -- C ABI of the MI355X-native scan -> filter -> aggregate engine (libexon_hip.so).
+ *
+ * This is the drop-in boundary for Exon's hot path.  Every entry point is
+ * extern "C", takes plain pointers / sizes / opaque handles, returns an int status and never
+ * throws.  Data crosses as the Arrow C Data Interface (host batches) or the Arrow C Device Data
+ * Interface (HBM-resident batches, device_type = ARROW_DEVICE_ROCM).  A Rust binding needs only
+ * `extern "C"` declarations of the functions below plus arrow-rs `arrow::ffi` (already enabled in
+ * the reference: exon/exon-core/Cargo.toml:73-77, exon/exon-core/src/ffi/mod.rs:58-73); see
+ * INTEGRATION.md for the shim.
+ *
+ * What each group replaces in the reference (paths relative to /root/reference/exon):
+ *   exon_hip_plan_* / exon_hip_stream_*   ExecutionPlan::execute of the operator chain
+ *        AggregateExec(Partial) <- [CoalesceBatchesExec] <- FilterExec <- {VCF,BAM,FASTQ}Scan
+ *        (exon-core/src/datasources/vcf/scanner.rs:142-162, bam/scanner.rs:138-158; the
+ *        FilterExec/AggregateExec themselves are DataFusion 44, not vendored)
+ *   exon_hip_region_count                 RegionPhysicalExpr::evaluate
+ *        (exon-core/src/physical_plan/region_physical_expr.rs:220-240), region_match UDF
+ *        (exon-core/src/udfs/vcf/mod.rs:65-131), IndexedAsyncBatchStream::filter
+ *        (exon-vcf/src/indexed_async_batch_stream.rs:99-116) + COUNT(*)
+ *   exon_hip_flag_mapq_group_count        sam_flag_function (exon-core/src/udfs/sam/samflags.rs:26-47)
+ *        + CAST(mapping_quality AS INT) >= q + COUNT(*) GROUP BY reference over the columns of
+ *        BAMArrayBuilder::append (exon-bam/src/array_builder.rs:102-218)
+ *   exon_hip_cmp_avg_by_group             info."AF" > lit, AVG(qual), COUNT(*) GROUP BY filter over
+ *        LazyVCFArrayBuilder columns (exon-vcf/src/array_builder/lazy_array_builder.rs:205-216,
+ *        info_builder.rs:152-309)
+ *   exon_hip_qual_pos_hist                QualityScoreStringToList::invoke
+ *        (exon-core/src/udfs/sequence/quality_score_string_to_list.rs:56-117) + unnest + GROUP BY
+ *   exon_hip_regroup_files_by_size        regroup_files_by_size
+ *        (exon-core/src/datasources/exon_file_scan_config.rs:79-110) -- the multi-GPU shard rule
+ */
+#ifndef EXON_HIP_H
+#define EXON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- Arrow C Data Interface (verbatim ABI; https://arrow.apache.org/docs/format/CDataInterface.html) */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+#define ARROW_FLAG_DICTIONARY_ORDERED 1
+#define ARROW_FLAG_NULLABLE 2
+#define ARROW_FLAG_MAP_KEYS_SORTED 4
+struct ArrowSchema {
+  const char* format;
+  const char* name;
+  const char* metadata;
+  int64_t flags;
+  int64_t n_children;
+  struct ArrowSchema** children;
+  struct ArrowSchema* dictionary;
+  void (*release)(struct ArrowSchema*);
+  void* private_data;
+};
+struct ArrowArray {
+  int64_t length;
+  int64_t null_count;
+  int64_t offset;
+  int64_t n_buffers;
+  int64_t n_children;
+  const void** buffers;
+  struct ArrowArray** children;
+  struct ArrowArray* dictionary;
+  void (*release)(struct ArrowArray*);
+  void* private_data;
+};
+#endif
+#ifndef ARROW_C_DEVICE_DATA_INTERFACE
+#define ARROW_C_DEVICE_DATA_INTERFACE
+typedef int32_t ArrowDeviceType;
+#define ARROW_DEVICE_CPU 1
+#define ARROW_DEVICE_ROCM 10
+#define ARROW_DEVICE_ROCM_HOST 11
+struct ArrowDeviceArray {
+  struct ArrowArray array;
+  int64_t device_id;
+  ArrowDeviceType device_type;
+  void* sync_event; /* hipEvent_t* or NULL */
+  int64_t reserved[3];
+};
+#endif
+
+/* ---- status codes ------------------------------------------------------------------------- */
+#define EXON_HIP_OK 0
+#define EXON_HIP_EINVAL (-1)       /* bad argument / schema mismatch / misaligned buffer */
+#define EXON_HIP_ENOMEM (-2)
+#define EXON_HIP_EDEVICE (-3)      /* HIP runtime error (text in exon_hip_last_error) */
+#define EXON_HIP_EUNSUPPORTED (-4) /* valid request this build does not implement */
+#define EXON_HIP_ESTATE (-5)       /* call out of order (e.g. push after finish) */
+
+typedef struct exon_hip_ctx exon_hip_ctx;
+typedef struct exon_hip_plan exon_hip_plan;
+typedef struct exon_hip_stream exon_hip_stream;
+
+/* ---- context ------------------------------------------------------------------------------ */
+typedef struct exon_hip_device_info {
+  char name[64];
+  char gcn_arch[32];
+  int32_t compute_units;
+  int32_t wavefront_size;
+  int64_t hbm_bytes;
+  int32_t clock_khz;
+  int32_t reserved;
+} exon_hip_device_info;
+
+int exon_hip_abi_version(void);
+int exon_hip_device_count(int* out);
+int exon_hip_ctx_create(int device, exon_hip_ctx** out);
+int exon_hip_ctx_destroy(exon_hip_ctx* ctx);
+int exon_hip_ctx_info(exon_hip_ctx* ctx, exon_hip_device_info* out);
+/* Text of the last error on this ctx (or, with ctx == NULL, of the calling thread).  Owned by the
+ * library, valid until the next failing call on the same ctx/thread. */
+const char* exon_hip_last_error(const exon_hip_ctx* ctx);
+
+/* Device-memory helpers so a host without its own HIP binding can stage columns.  `stream` is a
+ * hipStream_t passed as void* (NULL = the ctx's own stream). */
+int exon_hip_malloc(exon_hip_ctx* ctx, size_t bytes, void** dptr);
+int exon_hip_free(exon_hip_ctx* ctx, void* dptr);
+int exon_hip_memcpy_h2d(exon_hip_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream);
+int exon_hip_memcpy_d2h(exon_hip_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream);
+int exon_hip_memset(exon_hip_ctx* ctx, void* dst, int value, size_t bytes, void* stream);
+int exon_hip_sync(exon_hip_ctx* ctx, void* stream);
+/* Wall time of `reps` back-to-back launches measured with hipEvents on `stream` is available to
+ * hosts through these two calls (bench.py uses torch events on the same stream instead). */
+int exon_hip_timer_start(exon_hip_ctx* ctx, void* stream);
+int exon_hip_timer_stop_ms(exon_hip_ctx* ctx, void* stream, float* ms);
+
+/* ---- device column ------------------------------------------------------------------------ */
+/* One Arrow array already resident in HBM.  `values` must be 16-byte aligned, `validity` is the
+ * Arrow LSB-first bitmap (NULL = no nulls) whose bit 0 is row 0 of `values` (no bit offset),
+ * `offsets` is the int32 offsets buffer of a Utf8/Binary column (NULL otherwise). */
+typedef struct exon_hip_column {
+  const void* values;
+  const uint8_t* validity;
+  const int32_t* offsets;
+  int64_t length;
+} exon_hip_column;
+
+/* comparison operators of exon_hip_cmp_avg_by_group */
+#define EXON_HIP_GT 0
+#define EXON_HIP_GE 1
+#define EXON_HIP_LT 2
+#define EXON_HIP_LE 3
+#define EXON_HIP_EQ 4
+#define EXON_HIP_NE 5
+
+#define EXON_HIP_MAX_REG_GROUPS 8   /* group tables kept in registers */
+#define EXON_HIP_MAX_GROUPS 4096    /* group tables kept in LDS */
+#define EXON_HIP_REGION_OPEN_END INT64_MAX
+
+/* ---- operator launches (asynchronous on `stream`; results ACCUMULATE into the state buffers,
+ *      which the caller zeroes once per query: hipMemsetAsync / exon_hip_memset) -------------- */
+
+/* K2.  d_count[0] += |{ i : chrom_id[i] valid && == region_chrom_id && pos[i] valid &&
+ *                           start <= pos[i] <= end }|   (1-based inclusive; Kleene AND, keep TRUE) */
+int exon_hip_region_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* chrom_id /*i32*/,
+                          const exon_hip_column* pos /*i64*/, int64_t n, int32_t region_chrom_id,
+                          int64_t start, int64_t end, int64_t* d_count);
+
+/* K3.  rows with (flag & flag_mask) == flag_value AND mapq valid AND mapq >= mapq_min are counted
+ *      into d_counts[ref_id] or, when ref_id is NULL, d_counts[n_refs].  d_counts has n_refs+1. */
+int exon_hip_flag_mapq_group_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* flag /*i32*/,
+                                   const exon_hip_column* mapq /*u8*/, const exon_hip_column* ref_id /*i32*/,
+                                   int64_t n, int32_t flag_mask, int32_t flag_value, int32_t mapq_min,
+                                   int32_t n_refs, int64_t* d_counts);
+
+/* K4.  For rows with x valid AND (double)x <cmp_op> threshold (f32 widened to f64, as DataFusion
+ *      coerces Float32 vs a Float64 literal), per dictionary id g = group_id[i] in [0, n_groups):
+ *        d_counts[g]            += (y valid)            -- COUNT(y) / AVG denominator
+ *        d_counts[n_groups + g] += 1                    -- COUNT(*)
+ *        d_sums[g]              += (double)y if y valid -- AVG numerator
+ *      Sums are reduced in a fixed order: bit-reproducible run to run for a given launch shape. */
+int exon_hip_cmp_avg_by_group(exon_hip_ctx* ctx, void* stream, const exon_hip_column* x /*f32*/,
+                              const exon_hip_column* y /*f32*/, const exon_hip_column* group_id /*i32*/,
+                              int64_t n, double threshold, int32_t cmp_op, int32_t n_groups,
+                              int64_t* d_counts /*[2*n_groups]*/, double* d_sums /*[n_groups]*/);
+
+/* K5.  d_hist[p*256 + b] += |{ reads r, p < len(r) : bytes[offsets[r] + p] == b }| for p < lmax;
+ *      positions >= lmax are an error (status word, reported by exon_hip_stream_finish / sync). */
+int exon_hip_qual_pos_hist(exon_hip_ctx* ctx, void* stream, const exon_hip_column* quality_scores /*utf8*/,
+                           int64_t n_reads, int32_t lmax, int64_t* d_hist /*[lmax*256]*/);
+
+/* ---- synthetic inputs generated in HBM (DESIGN.md "Synthetic inputs"; bit-identical to the
+ *      oracle's generators, which the parity tests check) ------------------------------------- */
+int exon_hip_gen_c2(exon_hip_ctx* ctx, void* stream, uint64_t seed, int64_t n_total, int64_t lo, int64_t hi,
+                    int32_t* d_chrom_id, int64_t* d_pos);
+int exon_hip_gen_c3(exon_hip_ctx* ctx, void* stream, uint64_t seed, int64_t lo, int64_t hi, int32_t* d_flag,
+                    uint8_t* d_mapq, uint8_t* d_mapq_valid, int32_t* d_ref_id, uint8_t* d_ref_valid);
+int exon_hip_gen_c4(exon_hip_ctx* ctx, void* stream, uint64_t seed, int64_t lo, int64_t hi, float* d_af,
+                    uint8_t* d_af_valid, float* d_qual, uint8_t* d_qual_valid, int32_t* d_filter_id);
+int exon_hip_gen_c5(exon_hip_ctx* ctx, void* stream, uint64_t seed, int64_t lo, int64_t hi, int32_t read_len,
+                    int32_t* d_offsets, uint8_t* d_bytes);
+
+/* ---- host-side planning helpers ------------------------------------------------------------ */
+/* noodles Region grammar `name[:start[-end]]`, 1-based inclusive; end = EXON_HIP_REGION_OPEN_END
+ * when open (exon-core/src/physical_plan/infer_region.rs:25-42). */
+int exon_hip_parse_region(const char* region, char* name_out, size_t name_cap, int64_t* start, int64_t* end);
+/* Whole files, ascending size, dealt round-robin into min(target, n) groups.  group_of[i] = group of
+ * file i; returns the number of groups (or a negative status). */
+int exon_hip_regroup_files_by_size(const int64_t* sizes, int32_t n_files, int32_t target_groups, int32_t* group_of);
+
+/* ---- plan / stream: the ExecutionPlan-shaped surface -------------------------------------- */
+#define EXON_HIP_PLAN_REGION_COUNT 2
+#define EXON_HIP_PLAN_FLAG_MAPQ_GROUP_COUNT 3
+#define EXON_HIP_PLAN_CMP_AVG_BY_GROUP 4
+#define EXON_HIP_PLAN_QUAL_POS_HIST 5
+
+typedef struct exon_hip_plan_desc {
+  int32_t kind;          /* EXON_HIP_PLAN_* */
+  int32_t n_groups;      /* K3: n_refs; K4: dictionary size; else 0 */
+  /* K2 */
+  int32_t region_chrom_id;
+  int32_t reserved0;
+  int64_t region_start, region_end;
+  /* K3 */
+  int32_t flag_mask, flag_value, mapq_min;
+  /* K4 */
+  int32_t cmp_op;
+  double threshold;
+  /* K5 */
+  int32_t lmax;
+  int32_t reserved1;
+  /* input column indexes into the batch's children, in operator argument order
+   * (K2: chrom_id,pos  K3: flag,mapq,ref_id  K4: x,y,group_id  K5: quality_scores) */
+  int32_t columns[4];
+} exon_hip_plan_desc;
+
+int exon_hip_plan_create(exon_hip_ctx* ctx, const exon_hip_plan_desc* desc, exon_hip_plan** out);
+int exon_hip_plan_destroy(exon_hip_plan* plan);
+/* number of int64 / float64 words of the partial-aggregate state of this plan */
+int exon_hip_plan_state_size(const exon_hip_plan* plan, int64_t* n_i64, int64_t* n_f64);
+
+/* One stream per partition (= per file group); single-threaded handle, owns one HIP stream, a
+ * device-resident partial state and pinned staging buffers. */
+int exon_hip_stream_open(exon_hip_plan* plan, int32_t partition, exon_hip_stream** out);
+/* Host Arrow struct batch (children = columns).  The batch is MOVED: the library calls
+ * batch->release exactly once, after its buffers have been copied to HBM.  Dictionary-encoded
+ * int32 indices are accepted for id columns (the dictionary itself stays with the caller). */
+int exon_hip_stream_push(exon_hip_stream* s, struct ArrowArray* batch);
+/* HBM-resident batch (device_type must be ARROW_DEVICE_ROCM on this ctx's device).  Not moved:
+ * buffers must stay alive until the next exon_hip_stream_sync/finish. */
+int exon_hip_stream_push_device(exon_hip_stream* s, const struct ArrowDeviceArray* batch);
+/* Device pointers of the partial state ([n_i64] int64 then [n_f64] float64, one allocation) so the
+ * host can all-reduce them over RCCL, plus the hipStream_t the kernels run on. */
+int exon_hip_stream_state(exon_hip_stream* s, int64_t** d_i64, double** d_f64, void** hip_stream);
+int exon_hip_stream_sync(exon_hip_stream* s);
+/* Copies the (possibly all-reduced) state to host: counts[n_i64], sums[n_f64]. */
+int exon_hip_stream_finish(exon_hip_stream* s, int64_t* counts, double* sums);
+/* Same result as one Arrow struct array in DataFusion's partial-aggregate state layout
+ * (see DESIGN.md "State schema"); caller releases out/out_schema. */
+int exon_hip_stream_finish_arrow(exon_hip_stream* s, struct ArrowArray* out, struct ArrowSchema* out_schema);
+int exon_hip_stream_close(exon_hip_stream* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EXON_HIP_H */

@@ -1,0 +1,185 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bit-exact for counts / interval hits / histograms; <= 1e-6 relative for f64 sums (north_star tolerance;
+in practice ~1e-15: only the association order of the f64 adds differs).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6
+
+
+def bits(bm, n):
+    return np.unpackbits(bm, bitorder="little")[:n].astype(bool)
+
+
+# ---- the device generators are bit-identical to the oracle's ----------------------------------------
+@pytest.mark.parametrize("n", [1, 63, 64, 1000, 100_003])
+def test_generators_match_oracle(ctx, oracle, n):
+    c, p = ctx.gen_c2(2, n)
+    oc, op = oracle.gen_c2(2, n)
+    assert np.array_equal(c.to_host(), oc) and np.array_equal(p.to_host(), op)
+    lo = 4096
+    f, mq, mv, ref, rv = ctx.gen_c3(3, lo, lo + n)
+    of, omq, omv, oref, orv = oracle.gen_c3(3, lo, lo + n)
+    nb = (n + 7) // 8
+    assert np.array_equal(f.to_host(), of) and np.array_equal(mq.to_host(n), omq)
+    assert np.array_equal(mv.to_host(nb), omv) and np.array_equal(ref.to_host(), oref)
+    assert np.array_equal(rv.to_host(nb), orv)
+    af, av, q, qv, fid = ctx.gen_c4(4, lo, lo + n)
+    oaf, oav, oq, oqv, ofid = oracle.gen_c4(4, lo, lo + n)
+    assert np.array_equal(af.to_host().view(np.uint32), oaf.view(np.uint32))
+    assert np.array_equal(q.to_host().view(np.uint32), oq.view(np.uint32))
+    assert np.array_equal(av.to_host(nb), oav) and np.array_equal(qv.to_host(nb), oqv)
+    assert np.array_equal(fid.to_host(), ofid)
+    m = min(n, 5000)
+    off, data = ctx.gen_c5(5, 8, 8 + m, 100)
+    ooff, odata = oracle.gen_c5(5, 8, 8 + m, 100)
+    assert np.array_equal(off.to_host(), ooff) and np.array_equal(data.to_host(m * 100), odata)
+
+
+# ---- K2 -----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [0, 1, 5, 2047, 2048, 2049, 1_000_003, 10_000_000])
+@pytest.mark.parametrize("region", ["7:50000000-100000000", "1", "X:1000000", "22:1-1", "nope"])
+def test_k2_region_count(ctx, oracle, n, region):
+    contigs = oracle.c2_contigs()
+    name, a, b = oracle.parse_region(region)
+    cid = contigs.index(name) if name in contigs else -1
+    if n == 0:
+        d = ctx.zeros(np.int64, 1)
+        ctx.region_count(ctx.empty(np.int32, 4), ctx.empty(np.int64, 4), 0, cid, a, b, d)
+        ctx.sync()
+        assert d.to_host()[0] == 0
+        return
+    c, p = ctx.gen_c2(2, n)
+    d = ctx.zeros(np.int64, 1)
+    ctx.region_count(c, p, n, cid, a, b, d)
+    ctx.sync()
+    hc, hp = oracle.gen_c2(2, n)
+    want, _ = oracle.c2_region_count(hc, hp, contigs, region)
+    assert d.to_host()[0] == want
+
+
+def test_k2_nulls_and_accumulate(ctx, oracle):
+    rng = np.random.default_rng(7)
+    n = 300_001
+    hc, hp = oracle.gen_c2(2, n)
+    cv = rng.integers(0, 256, (n + 7) // 8 + 64, dtype=np.uint8)
+    pv = rng.integers(0, 256, (n + 7) // 8 + 64, dtype=np.uint8)
+    contigs = oracle.c2_contigs()
+    want, _ = oracle.c2_region_count(hc, hp, contigs, "2:1000-200000000", chrom_valid=cv, pos_valid=pv)
+    d = ctx.zeros(np.int64, 1)
+    dc, dp, dcv, dpv = ctx.to_device(hc), ctx.to_device(hp), ctx.to_device(cv), ctx.to_device(pv)
+    for _ in range(3):  # state accumulates across launches
+        ctx.region_count(dc, dp, n, 1, 1000, 200000000, d, chrom_valid=dcv, pos_valid=dpv)
+    ctx.sync()
+    assert d.to_host()[0] == 3 * want
+    assert want == int((bits(cv, n) & bits(pv, n) & (hc == 1) & (hp >= 1000) & (hp <= 200000000)).sum())
+
+
+# ---- K3 -----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 4097, 1_000_001, 20_000_000])
+@pytest.mark.parametrize("mask,value,qmin", [(1284, 0, 30), (4, 4, 0), (0x10, 0x10, 60), (0, 0, -5), (1, 0, 0)])
+def test_k3_flag_mapq_group_count(ctx, oracle, n, mask, value, qmin):
+    if n > 2_000_000 and (mask, value, qmin) != (1284, 0, 30):
+        pytest.skip("large size only for the config-3 predicate")
+    refs = oracle.c3_refs()
+    f, mq, mv, ref, rv = ctx.gen_c3(3, 0, n)
+    d = ctx.zeros(np.int64, len(refs) + 1)
+    ctx.flag_mapq_group_count(f, mq, mv, ref, rv, n, mask, value, qmin, len(refs), d)
+    ctx.sync()
+    hf, hmq, hmv, href, hrv = oracle.gen_c3(3, 0, n)
+    want, _ = oracle.c3_flag_mapq_group_count(hf, hmq, hmv, href, hrv, refs, mask, value, qmin)
+    assert np.array_equal(d.to_host(), want)
+
+
+# ---- K4 -----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2048, 99_999, 5_000_000])
+@pytest.mark.parametrize("op,thr", [(">", 0.01), (">=", 0.01), ("<", 0.5), ("<=", 0.25), ("=", 0.25), ("!=", 0.01),
+                                    (">", float(np.float32(0.01))), (">=", float(np.float32(0.01))), (">", -1.0),
+                                    (">", 2.0)])
+def test_k4_cmp_avg_by_group(ctx, oracle, n, op, thr):
+    filters = oracle.c4_filters()
+    G = len(filters)
+    af, av, q, qv, fid = ctx.gen_c4(4, 0, n)
+    dc, ds = ctx.zeros(np.int64, 2 * G), ctx.zeros(np.float64, G)
+    ctx.cmp_avg_by_group(af, av, q, qv, fid, n, thr, op, G, dc, ds)
+    ctx.sync()
+    haf, hav, hq, hqv, hfid = oracle.gen_c4(4, 0, n)
+    s, cn, cr, _ = oracle.c4_cmp_avg_by_group(haf, hav, hq, hqv, hfid, filters, thr, op)
+    got_c, got_s = dc.to_host(), ds.to_host()
+    assert np.array_equal(got_c[:G], cn) and np.array_equal(got_c[G:], cr)
+    assert np.allclose(got_s, s, rtol=RTOL, atol=0)
+
+
+def test_k4_special_values_total_order(ctx, oracle):
+    """NaN / -0.0 / inf rows: arrow-rs compares floats in IEEE totalOrder (NaN > everything, -0 < +0)."""
+    rng = np.random.default_rng(11)
+    n = 70_000
+    specials = np.array([np.nan, -np.nan, 0.0, -0.0, np.inf, -np.inf, 0.01, 1e-45, -1e-45, 3.4e38], np.float32)
+    af = specials[rng.integers(0, len(specials), n)]
+    q = rng.random(n, dtype=np.float32) * 100
+    fid = rng.integers(0, 3, n).astype(np.int32)
+    av = rng.integers(0, 256, (n + 7) // 8 + 64, dtype=np.uint8)
+    qv = rng.integers(0, 256, (n + 7) // 8 + 64, dtype=np.uint8)
+    names = ["a", "b;c", ""]
+    d = [ctx.to_device(x) for x in (af, av, q, qv, fid)]
+    for op in (">", ">=", "<", "<=", "=", "!="):
+        for thr in (0.0, -0.0, 0.01, float("inf")):
+            dc, ds = ctx.zeros(np.int64, 6), ctx.zeros(np.float64, 3)
+            ctx.cmp_avg_by_group(d[0], d[1], d[2], d[3], d[4], n, thr, op, 3, dc, ds)
+            ctx.sync()
+            s, cn, cr, _ = oracle.c4_cmp_avg_by_group(af, av, q, qv, fid, names, thr, op)
+            got = dc.to_host()
+            assert np.array_equal(got[:3], cn) and np.array_equal(got[3:], cr), (op, thr)
+            assert np.allclose(ds.to_host(), s, rtol=RTOL, atol=0), (op, thr)
+
+
+def test_k4_deterministic(ctx):
+    n = 3_000_000
+    af, av, q, qv, fid = ctx.gen_c4(9, 0, n)
+    outs = []
+    for _ in range(3):
+        dc, ds = ctx.zeros(np.int64, 10), ctx.zeros(np.float64, 5)
+        ctx.cmp_avg_by_group(af, av, q, qv, fid, n, 0.01, ">", 5, dc, ds)
+        ctx.sync()
+        outs.append(ds.to_host().tobytes() + dc.to_host().tobytes())
+    assert outs[0] == outs[1] == outs[2]
+
+
+def test_k4_bad_group_id_is_reported(ctx):
+    import exon_amd
+    n = 5000
+    af, av, q, qv, fid = ctx.gen_c4(4, 0, n)
+    dc, ds = ctx.zeros(np.int64, 4), ctx.zeros(np.float64, 2)
+    ctx.cmp_avg_by_group(af, av, q, qv, fid, n, 0.0, ">", 2, dc, ds)  # ids go up to 4
+    with pytest.raises(exon_amd.ExonHipError):
+        ctx.sync()
+
+
+# ---- K5 -----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_reads,L", [(1, 100), (1000, 100), (200_000, 100), (5000, 151), (3000, 36)])
+def test_k5_qual_pos_hist(ctx, oracle, n_reads, L):
+    off, data = ctx.gen_c5(5, 0, n_reads, L)
+    d = ctx.zeros(np.int64, L * 256)
+    ctx.qual_pos_hist(off, data, n_reads, L, d)
+    ctx.sync()
+    hoff, hdata = oracle.gen_c5(5, 0, n_reads, L)
+    want, _ = oracle.c5_qual_pos_hist(hoff, hdata, L)
+    assert np.array_equal(d.to_host().reshape(L, 256), want)
+
+
+def test_k5_ragged_reads(ctx, oracle):
+    rng = np.random.default_rng(3)
+    lens = rng.integers(0, 180, 20_000)
+    lens[:5] = [0, 1, 179, 0, 64]
+    off = np.zeros(len(lens) + 1, np.int32)
+    off[1:] = np.cumsum(lens)
+    data = rng.integers(33, 75, off[-1], dtype=np.uint8)
+    d = ctx.zeros(np.int64, 180 * 256)
+    ctx.qual_pos_hist(ctx.to_device(off), ctx.to_device(np.concatenate([data, np.zeros(64, np.uint8)])), len(lens), 180, d)
+    ctx.sync()
+    want, _ = oracle.c5_qual_pos_hist(off, data, 180)
+    assert np.array_equal(d.to_host().reshape(180, 256), want)
