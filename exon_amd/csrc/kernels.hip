@@ -1,13 +1,19 @@
 // kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the scan -> filter -> aggregate hot path.
 //
 // All four operators are HBM-read bound (arithmetic intensity < 0.5 op/B), so there is no MFMA here.
-// Shape shared by every main kernel:
-//   * persistent grid (compute_units x blocks_per_cu workgroups of 256 threads = 4 waves), grid-stride
-//     over 2048-row tiles; inside a tile each wave owns 512 rows and every global load instruction is
-//     a fully coalesced 16 B/lane (1 KiB per wave) access;
+// Shape shared by the streaming kernels (K2/K3/K4), settled by A/B runs on MI355X (tools/tune_k4.hip,
+// profiles/r1_tuning.md):
+//   * persistent grid, grid-stride over tiles.  Large inputs use ONE 1024-thread workgroup per CU
+//     (16 waves, each owning 1024 rows of a 16384-row tile: J = 4 sub-tiles of 256 rows, 4 rows per
+//     lane per sub-tile); small inputs use 256-thread workgroups with J = 2 so that every CU still
+//     gets several tiles.  Big workgroups + non-temporal loads are what lift a read-only sweep of the
+//     same columns from 5.7 to 6.7 TB/s on this chip;
+//   * every column load is a fully coalesced, non-temporal 16 B/lane access (1 KiB per wave
+//     instruction; the data is streamed once, so it should not displace L2/MALL lines);
 //   * Arrow validity bitmaps are consumed as one byte per lane-pair (a nibble per lane per 4 rows);
-//   * per-lane register accumulators -> wave shuffle reduction -> LDS across the 4 waves -> one
-//     partial record per workgroup in the workspace (no global atomics);
+//   * per-lane register accumulators (counters packed 8 x 8 bit into one u64 and spilled to u32
+//     registers every <= 255 rows) -> wave shuffle reduction -> LDS across the waves -> one partial
+//     record per workgroup in the workspace: no global atomics anywhere;
 //   * `finalize_partials` folds the per-workgroup records into the caller's running state in a fixed
 //     order, so f64 sums are bit-reproducible for a given launch shape.
 // Reference semantics restated by each kernel are cited at the kernel.
@@ -18,27 +24,40 @@
 
 namespace exon {
 
-constexpr int THREADS = 256;
-constexpr int WAVES = THREADS / 64;
-constexpr int ROWS_PER_LANE = 8;
-constexpr int TILE = THREADS * ROWS_PER_LANE;  // 2048 rows per workgroup iteration
-constexpr int WAVE_TILE = 64 * ROWS_PER_LANE;  // 512 rows per wave iteration
+// launch shapes
+struct ShapeBig {
+  static constexpr int THREADS = 1024, J = 4;
+};
+struct ShapeSmall {
+  static constexpr int THREADS = 256, J = 2;
+};
+template <typename S>
+struct ShapeOf {
+  static constexpr int WAVES = S::THREADS / 64;
+  static constexpr int WAVE_TILE = 256 * S::J;        // rows per wave per iteration
+  static constexpr int TILE = WAVES * WAVE_TILE;      // rows per workgroup per iteration
+};
 
 // ------------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------------
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+// streaming (non-temporal) 16-byte load
 template <typename T>
 __device__ __forceinline__ T ld16(const void* p) {
-  return *reinterpret_cast<const T*>(p);
+  static_assert(sizeof(T) == 16, "16-byte vector expected");
+  const v4i_t v = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(p));
+  T r;
+  __builtin_memcpy(&r, &v, 16);
+  return r;
 }
 
-// validity bits of this lane's 8 rows: rows [wbase + 4*lane, +4) -> bits 0..3, rows [wbase + 256 + 4*lane, +4)
-// -> bits 4..7.  wbase is a multiple of 512, so the wave's 512 validity bits are 64 consecutive bytes.
-__device__ __forceinline__ unsigned valid8(const uint8_t* __restrict__ bm, int64_t wbase, int lane) {
-  if (bm == nullptr) return 0xFFu;
-  const uint8_t* p = bm + (wbase >> 3) + (lane >> 1);
-  const unsigned sh = (lane & 1) * 4;
-  return ((unsigned(p[0]) >> sh) & 0xFu) | (((unsigned(p[32]) >> sh) & 0xFu) << 4);
+// validity nibble of this lane's 4 rows of sub-tile j: rows [wbase + 256 j + 4 lane, +4).
+// wbase is a multiple of 256, so the sub-tile's 256 bits are 32 consecutive bytes.
+__device__ __forceinline__ unsigned valid4(const uint8_t* __restrict__ bm, int64_t wbase, int j, int lane) {
+  if (bm == nullptr) return 0xFu;
+  return (unsigned(bm[(wbase >> 3) + j * 32 + (lane >> 1)]) >> ((lane & 1) * 4)) & 0xFu;
 }
 __device__ __forceinline__ bool valid1(const uint8_t* __restrict__ bm, int64_t r) {
   return bm == nullptr ? true : ((bm[r >> 3] >> (r & 7)) & 1);
@@ -65,7 +84,8 @@ __device__ __forceinline__ int32_t f32_key(float f) {
 // ------------------------------------------------------------------------------------------------
 // finalize: state[v] += sum over workgroups b (fixed order) of partials[b][v]
 // words [0, n_i64) are int64 counters, words [n_i64, V) are float64 sums.
-// grid = ceil(V / 32), block = 256 = 32 values x 8 segments of the workgroup range.
+// grid = ceil(V / 32), block = 256 = 32 values x 8 segments of the workgroup range; every thread keeps
+// 4 independent loads in flight, the 8 segment sums are combined in a fixed order.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void finalize_partials(const unsigned long long* __restrict__ partials, int nblocks,
                                                          int V, int n_i64, int64_t* __restrict__ st_i64,
@@ -78,10 +98,25 @@ __global__ __launch_bounds__(256) void finalize_partials(const unsigned long lon
   unsigned long long acc_i = 0;
   double acc_f = 0.0;
   if (v < V) {
+    const unsigned long long* p = partials + v;
     if (v < n_i64) {
-      for (int b = b0; b < b1; ++b) acc_i += partials[(size_t)b * V + v];
+      int b = b0;
+      for (; b + 4 <= b1; b += 4) {
+        const unsigned long long a0 = p[(size_t)b * V], a1 = p[(size_t)(b + 1) * V], a2 = p[(size_t)(b + 2) * V],
+                                 a3 = p[(size_t)(b + 3) * V];
+        acc_i += a0 + a1 + a2 + a3;
+      }
+      for (; b < b1; ++b) acc_i += p[(size_t)b * V];
     } else {
-      for (int b = b0; b < b1; ++b) acc_f += __longlong_as_double((long long)partials[(size_t)b * V + v]);
+      int b = b0;
+      for (; b + 4 <= b1; b += 4) {
+        const double a0 = __longlong_as_double((long long)p[(size_t)b * V]),
+                     a1 = __longlong_as_double((long long)p[(size_t)(b + 1) * V]),
+                     a2 = __longlong_as_double((long long)p[(size_t)(b + 2) * V]),
+                     a3 = __longlong_as_double((long long)p[(size_t)(b + 3) * V]);
+        acc_f += ((a0 + a1) + (a2 + a3));
+      }
+      for (; b < b1; ++b) acc_f += __longlong_as_double((long long)p[(size_t)b * V]);
     }
   }
   red[seg][vi] = (v < n_i64) ? acc_i : (unsigned long long)__double_as_longlong(acc_f);
@@ -117,13 +152,21 @@ static int resident_blocks(F f, int threads, size_t lds) {
   return nb;
 }
 
+// The big shape pays off once every CU gets at least a few 16384-row tiles.
+static bool use_big_shape(const LaunchCfg& cfg, int64_t n) {
+  return n / ShapeOf<ShapeBig>::TILE >= (int64_t)cfg.compute_units * 4;
+}
+
+template <typename S>
 static int grid_for(const LaunchCfg& cfg, int64_t n, int resident) {
-  int64_t tiles = (n + TILE - 1) / TILE;
-  int64_t g = (int64_t)cfg.compute_units * std::min(cfg.blocks_per_cu, resident);
+  const int64_t tiles = (n + ShapeOf<S>::TILE - 1) / ShapeOf<S>::TILE;
+  const int per_cu = S::THREADS >= 1024 ? 1 : std::min(cfg.blocks_per_cu, resident);
+  int64_t g = (int64_t)cfg.compute_units * per_cu;
   if (g > tiles) g = tiles;
   if (g < 1) g = 1;
   return (int)g;
 }
+static int max_grid(const LaunchCfg& cfg) { return cfg.compute_units * std::max(cfg.blocks_per_cu, 1); }
 
 // ------------------------------------------------------------------------------------------------
 // K2 region_count
@@ -136,30 +179,39 @@ __device__ __forceinline__ unsigned k2_row(int32_t c, int64_t p, unsigned cv, un
   return (cv & pv) & unsigned(c == id) & unsigned(p >= a) & unsigned(p <= b);
 }
 
-__global__ __launch_bounds__(THREADS) void k2_region_count_main(const int32_t* __restrict__ chrom,
-                                                                const uint8_t* __restrict__ cvalid,
-                                                                const int64_t* __restrict__ pos,
-                                                                const uint8_t* __restrict__ pvalid, int64_t n,
-                                                                int32_t id, int64_t a, int64_t b,
-                                                                unsigned long long* __restrict__ partials) {
+template <typename S>
+__global__ __launch_bounds__(S::THREADS) void k2_region_count_main(const int32_t* __restrict__ chrom,
+                                                                   const uint8_t* __restrict__ cvalid,
+                                                                   const int64_t* __restrict__ pos,
+                                                                   const uint8_t* __restrict__ pvalid, int64_t n,
+                                                                   int32_t id, int64_t a, int64_t b,
+                                                                   unsigned long long* __restrict__ partials) {
+  constexpr int J = S::J, THREADS = S::THREADS, WAVES = ShapeOf<S>::WAVES, WT = ShapeOf<S>::WAVE_TILE,
+                TILE = ShapeOf<S>::TILE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned cnt = 0;
   const int64_t ntiles = n / TILE;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t wbase = tile * TILE + (int64_t)wave * WAVE_TILE;
-    const int64_t r0 = wbase + lane * 4, r1 = r0 + 256;
-    const int4 c0 = ld16<int4>(chrom + r0), c1 = ld16<int4>(chrom + r1);
-    const longlong2 p00 = ld16<longlong2>(pos + r0), p01 = ld16<longlong2>(pos + r0 + 2);
-    const longlong2 p10 = ld16<longlong2>(pos + r1), p11 = ld16<longlong2>(pos + r1 + 2);
-    const unsigned cm = valid8(cvalid, wbase, lane), pm = valid8(pvalid, wbase, lane);
-    cnt += k2_row(c0.x, p00.x, cm >> 0 & 1, pm >> 0 & 1, id, a, b);
-    cnt += k2_row(c0.y, p00.y, cm >> 1 & 1, pm >> 1 & 1, id, a, b);
-    cnt += k2_row(c0.z, p01.x, cm >> 2 & 1, pm >> 2 & 1, id, a, b);
-    cnt += k2_row(c0.w, p01.y, cm >> 3 & 1, pm >> 3 & 1, id, a, b);
-    cnt += k2_row(c1.x, p10.x, cm >> 4 & 1, pm >> 4 & 1, id, a, b);
-    cnt += k2_row(c1.y, p10.y, cm >> 5 & 1, pm >> 5 & 1, id, a, b);
-    cnt += k2_row(c1.z, p11.x, cm >> 6 & 1, pm >> 6 & 1, id, a, b);
-    cnt += k2_row(c1.w, p11.y, cm >> 7 & 1, pm >> 7 & 1, id, a, b);
+    const int64_t wbase = tile * TILE + (int64_t)wave * WT;
+    int4 c[J];
+    longlong2 p0[J], p1[J];
+    unsigned cm[J], pm[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int64_t r = wbase + j * 256 + lane * 4;
+      c[j] = ld16<int4>(chrom + r);
+      p0[j] = ld16<longlong2>(pos + r);
+      p1[j] = ld16<longlong2>(pos + r + 2);
+      cm[j] = valid4(cvalid, wbase, j, lane);
+      pm[j] = valid4(pvalid, wbase, j, lane);
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      cnt += k2_row(c[j].x, p0[j].x, cm[j] >> 0 & 1, pm[j] >> 0 & 1, id, a, b);
+      cnt += k2_row(c[j].y, p0[j].y, cm[j] >> 1 & 1, pm[j] >> 1 & 1, id, a, b);
+      cnt += k2_row(c[j].z, p1[j].x, cm[j] >> 2 & 1, pm[j] >> 2 & 1, id, a, b);
+      cnt += k2_row(c[j].w, p1[j].y, cm[j] >> 3 & 1, pm[j] >> 3 & 1, id, a, b);
+    }
   }
   for (int64_t r = ntiles * TILE + (int64_t)blockIdx.x * THREADS + threadIdx.x; r < n;
        r += (int64_t)gridDim.x * THREADS)
@@ -177,17 +229,28 @@ __global__ __launch_bounds__(THREADS) void k2_region_count_main(const int32_t* _
   }
 }
 
-size_t k2_partial_words(const LaunchCfg& cfg) { return (size_t)cfg.compute_units * cfg.blocks_per_cu; }
+size_t k2_partial_words(const LaunchCfg& cfg) { return (size_t)max_grid(cfg); }
+
+template <typename S>
+static hipError_t k2_launch(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* chrom,
+                            const uint8_t* cv, const int64_t* pos, const uint8_t* pv, int64_t n, int32_t id,
+                            int64_t a, int64_t b, int* grid_out) {
+  static const int resident = resident_blocks(k2_region_count_main<S>, S::THREADS, 0);
+  const int grid = grid_for<S>(cfg, n, resident);
+  *grid_out = grid;
+  hipLaunchKernelGGL(k2_region_count_main<S>, dim3(grid), dim3(S::THREADS), 0, s, chrom, cv, pos, pv, n, id, a, b,
+                     ws.partials);
+  return hipGetLastError();
+}
 
 hipError_t launch_region_count(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* chrom,
                                const uint8_t* chrom_valid, const int64_t* pos, const uint8_t* pos_valid, int64_t n,
                                int32_t region_chrom, int64_t start, int64_t end, int64_t* d_count) {
   if (n <= 0) return hipSuccess;
-  static const int resident = resident_blocks(k2_region_count_main, THREADS, 0);
-  const int grid = grid_for(cfg, n, resident);
-  hipLaunchKernelGGL(k2_region_count_main, dim3(grid), dim3(THREADS), 0, s, chrom, chrom_valid, pos, pos_valid, n,
-                     region_chrom, start, end, ws.partials);
-  hipError_t e = hipGetLastError();
+  int grid = 1;
+  hipError_t e = use_big_shape(cfg, n)
+                     ? k2_launch<ShapeBig>(s, cfg, ws, chrom, chrom_valid, pos, pos_valid, n, region_chrom, start, end, &grid)
+                     : k2_launch<ShapeSmall>(s, cfg, ws, chrom, chrom_valid, pos, pos_valid, n, region_chrom, start, end, &grid);
   if (e != hipSuccess) return e;
   return run_finalize(s, ws, grid, 1, 1, d_count, nullptr);
 }
@@ -200,11 +263,14 @@ hipError_t launch_region_count(hipStream_t s, const LaunchCfg& cfg, const Worksp
 //   group (index n_refs).  9.25 B/row: i32 flag + u8 mapq + i32 ref id + 2 validity bits.
 //   Group table: one u32[n_refs+1] table per wave in LDS, LDS atomics, folded per workgroup.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(THREADS) void k3_flag_mapq_group_count_main(
+template <typename S>
+__global__ __launch_bounds__(S::THREADS) void k3_flag_mapq_group_count_main(
     const int32_t* __restrict__ flag, const uint8_t* __restrict__ fvalid, const uint8_t* __restrict__ mapq,
     const uint8_t* __restrict__ mvalid, const int32_t* __restrict__ ref, const uint8_t* __restrict__ rvalid,
     int64_t n, int32_t mask, int32_t value, int32_t qmin, int32_t R, unsigned long long* __restrict__ partials,
     int* __restrict__ status) {
+  constexpr int J = S::J, THREADS = S::THREADS, WAVES = ShapeOf<S>::WAVES, WT = ShapeOf<S>::WAVE_TILE,
+                TILE = ShapeOf<S>::TILE;
   extern __shared__ unsigned k3_tbl[];  // [WAVES][R+1]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int V = R + 1;
@@ -224,22 +290,26 @@ __global__ __launch_bounds__(THREADS) void k3_flag_mapq_group_count_main(
 
   const int64_t ntiles = n / TILE;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t wbase = tile * TILE + (int64_t)wave * WAVE_TILE;
-    const int64_t r0 = wbase + lane * 4, r1 = r0 + 256;
-    const int4 f0 = ld16<int4>(flag + r0), f1 = ld16<int4>(flag + r1);
-    const int4 g0 = ld16<int4>(ref + r0), g1 = ld16<int4>(ref + r1);
-    const unsigned q0 = *reinterpret_cast<const unsigned*>(mapq + r0);
-    const unsigned q1 = *reinterpret_cast<const unsigned*>(mapq + r1);
-    const unsigned fm = valid8(fvalid, wbase, lane), mm = valid8(mvalid, wbase, lane),
-                   rm = valid8(rvalid, wbase, lane);
-    row(f0.x, q0 & 0xFF, g0.x, fm >> 0 & 1, mm >> 0 & 1, rm >> 0 & 1);
-    row(f0.y, q0 >> 8 & 0xFF, g0.y, fm >> 1 & 1, mm >> 1 & 1, rm >> 1 & 1);
-    row(f0.z, q0 >> 16 & 0xFF, g0.z, fm >> 2 & 1, mm >> 2 & 1, rm >> 2 & 1);
-    row(f0.w, q0 >> 24, g0.w, fm >> 3 & 1, mm >> 3 & 1, rm >> 3 & 1);
-    row(f1.x, q1 & 0xFF, g1.x, fm >> 4 & 1, mm >> 4 & 1, rm >> 4 & 1);
-    row(f1.y, q1 >> 8 & 0xFF, g1.y, fm >> 5 & 1, mm >> 5 & 1, rm >> 5 & 1);
-    row(f1.z, q1 >> 16 & 0xFF, g1.z, fm >> 6 & 1, mm >> 6 & 1, rm >> 6 & 1);
-    row(f1.w, q1 >> 24, g1.w, fm >> 7 & 1, mm >> 7 & 1, rm >> 7 & 1);
+    const int64_t wbase = tile * TILE + (int64_t)wave * WT;
+    int4 f[J], g[J];
+    unsigned q[J], fm[J], mm[J], rm[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int64_t r = wbase + j * 256 + lane * 4;
+      f[j] = ld16<int4>(flag + r);
+      g[j] = ld16<int4>(ref + r);
+      q[j] = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(mapq + r));
+      fm[j] = valid4(fvalid, wbase, j, lane);
+      mm[j] = valid4(mvalid, wbase, j, lane);
+      rm[j] = valid4(rvalid, wbase, j, lane);
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      row(f[j].x, q[j] & 0xFF, g[j].x, fm[j] >> 0 & 1, mm[j] >> 0 & 1, rm[j] >> 0 & 1);
+      row(f[j].y, q[j] >> 8 & 0xFF, g[j].y, fm[j] >> 1 & 1, mm[j] >> 1 & 1, rm[j] >> 1 & 1);
+      row(f[j].z, q[j] >> 16 & 0xFF, g[j].z, fm[j] >> 2 & 1, mm[j] >> 2 & 1, rm[j] >> 2 & 1);
+      row(f[j].w, q[j] >> 24, g[j].w, fm[j] >> 3 & 1, mm[j] >> 3 & 1, rm[j] >> 3 & 1);
+    }
   }
   for (int64_t r = ntiles * TILE + (int64_t)blockIdx.x * THREADS + threadIdx.x; r < n;
        r += (int64_t)gridDim.x * THREADS)
@@ -255,8 +325,24 @@ __global__ __launch_bounds__(THREADS) void k3_flag_mapq_group_count_main(
   }
 }
 
-size_t k3_partial_words(const LaunchCfg& cfg, int n_refs) {
-  return (size_t)cfg.compute_units * cfg.blocks_per_cu * (size_t)(n_refs + 1);
+size_t k3_partial_words(const LaunchCfg& cfg, int n_refs) { return (size_t)max_grid(cfg) * (size_t)(n_refs + 1); }
+
+template <typename S>
+static hipError_t k3_launch(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* flag,
+                            const uint8_t* fv, const uint8_t* mapq, const uint8_t* mv, const int32_t* ref,
+                            const uint8_t* rv, int64_t n, int32_t mask, int32_t value, int32_t qmin, int32_t R,
+                            int* grid_out) {
+  const size_t lds = (size_t)ShapeOf<S>::WAVES * (R + 1) * sizeof(unsigned);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k3_flag_mapq_group_count_main<S>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  const int grid = grid_for<S>(cfg, n, resident_blocks(k3_flag_mapq_group_count_main<S>, S::THREADS, lds));
+  *grid_out = grid;
+  hipLaunchKernelGGL(k3_flag_mapq_group_count_main<S>, dim3(grid), dim3(S::THREADS), lds, s, flag, fv, mapq, mv, ref,
+                     rv, n, mask, value, qmin, R, ws.partials, ws.status);
+  return hipGetLastError();
 }
 
 hipError_t launch_flag_mapq_group_count(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* flag,
@@ -264,14 +350,15 @@ hipError_t launch_flag_mapq_group_count(hipStream_t s, const LaunchCfg& cfg, con
                                         const int32_t* ref_id, const uint8_t* ref_valid, int64_t n, int32_t flag_mask,
                                         int32_t flag_value, int32_t mapq_min, int32_t n_refs, int64_t* d_counts) {
   if (n <= 0) return hipSuccess;
-  const int V = n_refs + 1;
-  const size_t lds = (size_t)WAVES * V * sizeof(unsigned);
-  const int grid = grid_for(cfg, n, resident_blocks(k3_flag_mapq_group_count_main, THREADS, lds));
-  hipLaunchKernelGGL(k3_flag_mapq_group_count_main, dim3(grid), dim3(THREADS), lds, s, flag, flag_valid, mapq,
-                     mapq_valid, ref_id, ref_valid, n, flag_mask, flag_value, mapq_min, n_refs, ws.partials,
-                     ws.status);
-  hipError_t e = hipGetLastError();
+  int grid = 1;
+  // the 16-wave shape needs 16 x (n_refs+1) x 4 B of LDS: fine up to ~2.5k references
+  const bool big = use_big_shape(cfg, n) && (size_t)16 * (n_refs + 1) * 4 <= 160 * 1024;
+  hipError_t e = big ? k3_launch<ShapeBig>(s, cfg, ws, flag, flag_valid, mapq, mapq_valid, ref_id, ref_valid, n,
+                                           flag_mask, flag_value, mapq_min, n_refs, &grid)
+                     : k3_launch<ShapeSmall>(s, cfg, ws, flag, flag_valid, mapq, mapq_valid, ref_id, ref_valid, n,
+                                             flag_mask, flag_value, mapq_min, n_refs, &grid);
   if (e != hipSuccess) return e;
+  const int V = n_refs + 1;
   return run_finalize(s, ws, grid, V, V, d_counts, nullptr);
 }
 
@@ -284,13 +371,17 @@ hipError_t launch_flag_mapq_group_count(hipStream_t s, const LaunchCfg& cfg, con
 //   kernel does two 32-bit integer compares per row and is exact (parity-tested against the oracle's
 //   plain f64 comparison, including f32(0.01) which widens to 0.00999999977 < 0.01).
 //   AVG state = f64 sum + count of non-null y (Float32 widened to Float64 before the add).
-//   12.25 B/row: f32 x + f32 y + i32 group id + 2 validity bits.  Group ids < G <= 8 live in registers.
+//   12.25 B/row: f32 x + f32 y + i32 group id + 2 validity bits.  Group ids < G <= 8 live in registers:
+//   COUNT(*) / COUNT(y) in two u64 registers of 8 x 8-bit fields (a row adds 1 << 8g), spilled to
+//   per-group u32 registers before a field can overflow; sums in G f64 registers.
 // ------------------------------------------------------------------------------------------------
-template <int G>
-__global__ __launch_bounds__(THREADS) void k4_cmp_avg_by_group_main(
+template <int G, typename S>
+__global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
     const float* __restrict__ x, const uint8_t* __restrict__ xvalid, const float* __restrict__ y,
     const uint8_t* __restrict__ yvalid, const int32_t* __restrict__ gid, int64_t n, int32_t klo, int32_t khi,
     int32_t negate, unsigned long long* __restrict__ partials, int* __restrict__ status) {
+  constexpr int J = S::J, THREADS = S::THREADS, WAVES = ShapeOf<S>::WAVES, WT = ShapeOf<S>::WAVE_TILE,
+                TILE = ShapeOf<S>::TILE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double sum[G];
   unsigned cnn[G], crow[G];
@@ -300,46 +391,75 @@ __global__ __launch_bounds__(THREADS) void k4_cmp_avg_by_group_main(
     cnn[k] = 0;
     crow[k] = 0;
   }
-  unsigned bad = 0;
+  unsigned long long prow = 0, pnn = 0;  // packed 8-bit counters, field g
+  unsigned gmax = 0;
 
   auto row = [&](float xf, float yf, int32_t g, unsigned xv, unsigned yv) {
     const int32_t kx = f32_key(xf);
     const unsigned inr = unsigned(kx >= klo) & unsigned(kx <= khi);
     const unsigned pass = xv & (inr ^ (unsigned)negate);
     const unsigned yq = pass & yv;
+    gmax = max(gmax, (unsigned)g);  // ids are validated over ALL rows (cheaper than a per-row flag)
+    const unsigned sh = ((unsigned)g & 7u) * 8u;
+    prow += (unsigned long long)pass << sh;
+    pnn += (unsigned long long)yq << sh;
+    const int32_t gq = yq ? g : -1;
     const double yd = (double)yf;
-    bad |= pass & unsigned((unsigned)g >= (unsigned)G);
+#pragma unroll
+    for (int k = 0; k < G; ++k) sum[k] += (gq == k) ? yd : 0.0;
+  };
+  auto spill = [&]() {
 #pragma unroll
     for (int k = 0; k < G; ++k) {
-      const unsigned m = unsigned(g == k);
-      crow[k] += pass & m;
-      cnn[k] += yq & m;
-      sum[k] += (yq & m) ? yd : 0.0;
+      crow[k] += (unsigned)(prow >> (8 * k)) & 0xFFu;
+      cnn[k] += (unsigned)(pnn >> (8 * k)) & 0xFFu;
     }
+    prow = 0;
+    pnn = 0;
   };
 
   const int64_t ntiles = n / TILE;
+  int since = 0;  // rows added to the packed counters since the last spill
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t wbase = tile * TILE + (int64_t)wave * WAVE_TILE;
-    const int64_t r0 = wbase + lane * 4, r1 = r0 + 256;
-    const float4 x0 = ld16<float4>(x + r0), x1 = ld16<float4>(x + r1);
-    const float4 y0 = ld16<float4>(y + r0), y1 = ld16<float4>(y + r1);
-    const int4 g0 = ld16<int4>(gid + r0), g1 = ld16<int4>(gid + r1);
-    const unsigned xm = valid8(xvalid, wbase, lane), ym = valid8(yvalid, wbase, lane);
-    row(x0.x, y0.x, g0.x, xm >> 0 & 1, ym >> 0 & 1);
-    row(x0.y, y0.y, g0.y, xm >> 1 & 1, ym >> 1 & 1);
-    row(x0.z, y0.z, g0.z, xm >> 2 & 1, ym >> 2 & 1);
-    row(x0.w, y0.w, g0.w, xm >> 3 & 1, ym >> 3 & 1);
-    row(x1.x, y1.x, g1.x, xm >> 4 & 1, ym >> 4 & 1);
-    row(x1.y, y1.y, g1.y, xm >> 5 & 1, ym >> 5 & 1);
-    row(x1.z, y1.z, g1.z, xm >> 6 & 1, ym >> 6 & 1);
-    row(x1.w, y1.w, g1.w, xm >> 7 & 1, ym >> 7 & 1);
+    const int64_t wbase = tile * TILE + (int64_t)wave * WT;
+    float4 xs[J], ys[J];
+    int4 gs[J];
+    unsigned xm[J], ym[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int64_t r = wbase + j * 256 + lane * 4;
+      xs[j] = ld16<float4>(x + r);
+      ys[j] = ld16<float4>(y + r);
+      gs[j] = ld16<int4>(gid + r);
+      xm[j] = valid4(xvalid, wbase, j, lane);
+      ym[j] = valid4(yvalid, wbase, j, lane);
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      row(xs[j].x, ys[j].x, gs[j].x, xm[j] >> 0 & 1, ym[j] >> 0 & 1);
+      row(xs[j].y, ys[j].y, gs[j].y, xm[j] >> 1 & 1, ym[j] >> 1 & 1);
+      row(xs[j].z, ys[j].z, gs[j].z, xm[j] >> 2 & 1, ym[j] >> 2 & 1);
+      row(xs[j].w, ys[j].w, gs[j].w, xm[j] >> 3 & 1, ym[j] >> 3 & 1);
+    }
+    since += 4 * J;
+    if (since > 255 - 4 * J) {
+      spill();
+      since = 0;
+    }
   }
+  spill();
+  since = 0;
   for (int64_t r = ntiles * TILE + (int64_t)blockIdx.x * THREADS + threadIdx.x; r < n;
-       r += (int64_t)gridDim.x * THREADS)
+       r += (int64_t)gridDim.x * THREADS) {
     row(x[r], y[r], gid[r], valid1(xvalid, r), valid1(yvalid, r));
+    if (++since == 255) {
+      spill();
+      since = 0;
+    }
+  }
+  spill();
 
-  if (bad) atomicOr(status, 4);
+  if (gmax >= (unsigned)G) atomicOr(status, 4);
 
   // per-workgroup record: [cnn[G]] [crow[G]] [sum[G]]  (fixed-order reductions)
   __shared__ unsigned long long red[WAVES][3 * G];
@@ -372,51 +492,21 @@ __global__ __launch_bounds__(THREADS) void k4_cmp_avg_by_group_main(
   }
 }
 
-// fold per-template-G records (padded to G) into the caller's n_groups-sized state
-__global__ __launch_bounds__(256) void k4_finalize(const unsigned long long* __restrict__ partials, int nblocks, int G,
-                                                   int n_groups, int64_t* __restrict__ counts,
-                                                   double* __restrict__ sums) {
-  // one wave per output word; lanes split the workgroup range, fixed-order shuffle tree
-  const int lane = threadIdx.x & 63, word = blockIdx.x * (256 / 64) + (threadIdx.x >> 6);
-  if (word >= 3 * n_groups) return;
-  const int kind = word / n_groups, g = word % n_groups;  // 0: cnn, 1: crow, 2: sum
-  const int v = kind * G + g;
-  if (kind < 2) {
-    unsigned long long acc = 0;
-    for (int b = lane; b < nblocks; b += 64) acc += partials[(size_t)b * (3 * G) + v];
-    acc = wave_sum(acc);
-    if (lane == 0) counts[kind * n_groups + g] += (int64_t)acc;
-  } else {
-    double acc = 0.0;
-    for (int b = lane; b < nblocks; b += 64) acc += __longlong_as_double((long long)partials[(size_t)b * (3 * G) + v]);
-    acc = wave_sum(acc);
-    if (lane == 0) sums[g] += acc;
-  }
-}
+size_t k4_partial_words(const LaunchCfg& cfg, int n_groups) { return (size_t)max_grid(cfg) * 3 * (size_t)n_groups; }
 
-size_t k4_partial_words(const LaunchCfg& cfg, int n_groups) {
-  (void)n_groups;
-  return (size_t)cfg.compute_units * cfg.blocks_per_cu * 3 * 8;
-}
-
-template <int G>
-static hipError_t k4_launch_g(hipStream_t s, const LaunchCfg& cfg, int* grid_out, const Workspace& ws, const float* x, const uint8_t* xv,
-                              const float* y, const uint8_t* yv, const int32_t* gid, int64_t n, int32_t klo,
-                              int32_t khi, int32_t negate) {
-  static const int resident = resident_blocks(k4_cmp_avg_by_group_main<G>, THREADS, 0);
-  const int grid = grid_for(cfg, n, resident);
+template <int G, typename S>
+static hipError_t k4_launch(hipStream_t s, const LaunchCfg& cfg, int* grid_out, const Workspace& ws, const float* x,
+                            const uint8_t* xv, const float* y, const uint8_t* yv, const int32_t* gid, int64_t n,
+                            int32_t klo, int32_t khi, int32_t negate) {
+  static const int resident = resident_blocks(k4_cmp_avg_by_group_main<G, S>, S::THREADS, 0);
+  const int grid = grid_for<S>(cfg, n, resident);
   *grid_out = grid;
-  hipLaunchKernelGGL(k4_cmp_avg_by_group_main<G>, dim3(grid), dim3(THREADS), 0, s, x, xv, y, yv, gid, n, klo, khi,
-                     negate, ws.partials, ws.status);
+  hipLaunchKernelGGL((k4_cmp_avg_by_group_main<G, S>), dim3(grid), dim3(S::THREADS), 0, s, x, xv, y, yv, gid, n, klo,
+                     khi, negate, ws.partials, ws.status);
   return hipGetLastError();
 }
 
 // ---- host: fold (<op>, thr) into an inclusive f32 totalOrder key range --------------------------
-static inline int32_t h_f32_key(float f) {
-  int32_t b;
-  memcpy(&b, &f, 4);
-  return b ^ ((b >> 31) & 0x7FFFFFFF);
-}
 static inline float h_key_f32(int32_t k) {
   int32_t b = k ^ ((k >> 31) & 0x7FFFFFFF);
   float f;
@@ -428,9 +518,8 @@ static inline int64_t h_f64_key(double d) {
   memcpy(&b, &d, 8);
   return b ^ ((b >> 63) & 0x7FFFFFFFFFFFFFFFLL);
 }
-// number of f32 keys k (as a count from INT32_MIN) with key64((double)f32(k)) < t  -> first key >= t
+// smallest f32 key k in [INT32_MIN, INT32_MAX + 1] whose widening compares >= t (or > t) in totalOrder
 static int64_t first_key_not_less(int64_t t, bool strict_greater) {
-  // smallest key k in [INT32_MIN, INT32_MAX+1] such that key64(widen(k)) >= t (or > t)
   int64_t lo = INT32_MIN, hi = (int64_t)INT32_MAX + 1;
   while (lo < hi) {
     const int64_t mid = lo + (hi - lo) / 2;
@@ -448,12 +537,12 @@ bool cmp_to_key_range(double thr, int cmp_op, int32_t* klo, int32_t* khi, int32_
   int64_t lo, hi;
   *negate = 0;
   switch (cmp_op) {
-    case 0: lo = gt; hi = INT32_MAX; break;                  // >
-    case 1: lo = ge; hi = INT32_MAX; break;                  // >=
-    case 2: lo = INT32_MIN; hi = ge - 1; break;              // <
-    case 3: lo = INT32_MIN; hi = gt - 1; break;              // <=
-    case 4: lo = ge; hi = gt - 1; break;                     // =
-    case 5: lo = ge; hi = gt - 1; *negate = 1; break;        // !=
+    case 0: lo = gt; hi = INT32_MAX; break;            // >
+    case 1: lo = ge; hi = INT32_MAX; break;            // >=
+    case 2: lo = INT32_MIN; hi = ge - 1; break;        // <
+    case 3: lo = INT32_MIN; hi = gt - 1; break;        // <=
+    case 4: lo = ge; hi = gt - 1; break;               // =
+    case 5: lo = ge; hi = gt - 1; *negate = 1; break;  // !=
     default: return false;
   }
   if (lo > hi) {  // empty range: encode as an impossible interval
@@ -474,14 +563,14 @@ hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Wo
   if (n_groups < 1 || n_groups > 8) return hipErrorInvalidValue;
   int32_t klo, khi, negate;
   if (!cmp_to_key_range(thr, cmp_op, &klo, &khi, &negate)) return hipErrorInvalidValue;
+  const bool big = use_big_shape(cfg, n);
   int grid = 1;
   hipError_t e;
-  int G;
   switch (n_groups) {
-#define EXON_K4_CASE(GG)                                                                       \
-  case GG:                                                                                     \
-    G = GG;                                                                                    \
-    e = k4_launch_g<GG>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate);        \
+#define EXON_K4_CASE(GG)                                                                                             \
+  case GG:                                                                                                           \
+    e = big ? k4_launch<GG, ShapeBig>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate)           \
+            : k4_launch<GG, ShapeSmall>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate);        \
     break;
     EXON_K4_CASE(1)
     EXON_K4_CASE(2)
@@ -495,10 +584,8 @@ hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Wo
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
-  const int words = 3 * n_groups;
-  hipLaunchKernelGGL(k4_finalize, dim3((words + 3) / 4), dim3(256), 0, s, ws.partials, grid, G, n_groups, d_counts,
-                     d_sums);
-  return hipGetLastError();
+  // per-workgroup records are [cnn[G]] [crow[G]] [sum[G]] = the state layout [counts[2G]] [sums[G]]
+  return run_finalize(s, ws, grid, 3 * n_groups, 2 * n_groups, d_counts, d_sums);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -117,7 +117,9 @@ void orc_gen_c3(uint64_t seed, int64_t lo, int64_t hi, int32_t* flag, uint8_t* m
   memset(mapq_valid, 0, (size_t)((n + 7) / 8));
   memset(ref_valid, 0, (size_t)((n + 7) / 8));
   const uint32_t m8 = pct_thr(8), m20 = pct_thr(20), m40 = pct_thr(40), m98 = pct_thr(98);
-  for (int64_t i = lo; i < hi; i++) {
+#pragma omp parallel for schedule(static)
+  for (int64_t blk = 0; blk < (n + 4095) / 4096; blk++)
+  for (int64_t i = lo + blk * 4096; i < hi && i < lo + (blk + 1) * 4096; i++) {
     uint64_t r0 = orc_rnd(seed, 0, (uint64_t)i), r1 = orc_rnd(seed, 1, (uint64_t)i),
              r2 = orc_rnd(seed, 2, (uint64_t)i);
     uint32_t u0 = (uint32_t)(r0 >> 32), u1 = (uint32_t)(r1 >> 32), v1 = (uint32_t)r1,
@@ -152,7 +154,9 @@ void orc_gen_c4(uint64_t seed, int64_t lo, int64_t hi, float* af, uint8_t* af_va
   memset(af_valid, 0, (size_t)((n + 7) / 8));
   memset(qual_valid, 0, (size_t)((n + 7) / 8));
   const uint32_t t0 = pct_thr(85), t1 = pct_thr(90), t2 = pct_thr(96), t3 = pct_thr(99);
-  for (int64_t i = lo; i < hi; i++) {
+#pragma omp parallel for schedule(static)
+  for (int64_t blk = 0; blk < (n + 4095) / 4096; blk++)
+  for (int64_t i = lo + blk * 4096; i < hi && i < lo + (blk + 1) * 4096; i++) {
     uint64_t r0 = orc_rnd(seed, 0, (uint64_t)i), r1 = orc_rnd(seed, 1, (uint64_t)i),
              r2 = orc_rnd(seed, 2, (uint64_t)i);
     uint32_t k = (uint32_t)((((r0 >> 23) & 0xFF) * 14) >> 8);
@@ -630,14 +634,23 @@ typedef struct {
 
 typedef struct { group_tbl g; double* sum; uint64_t* cnt; int64_t* rows; int64_t cap; } avg_state;
 
+/* arrow-rs `cmp::{gt,gt_eq,lt,lt_eq,eq,neq}` (arrow-ord 53.3.0, what DataFusion's BinaryExpr calls) compare
+ * floats in IEEE-754 totalOrder: -NaN < -inf < ... < -0 < +0 < ... < +inf < +NaN, so NaN > 0.01 is TRUE and
+ * -0.0 >= 0.0 is FALSE.  Restated with the usual sign-magnitude -> two's-complement key. */
+static inline int64_t f64_total_key(double d) {
+  int64_t b;
+  memcpy(&b, &d, 8);
+  return b ^ (int64_t)(((uint64_t)(b >> 63)) >> 1);
+}
 static inline int cmp_f64(double x, double thr, int op) {
+  const int64_t a = f64_total_key(x), b = f64_total_key(thr);
   switch (op) {
-    case 0: return x > thr;
-    case 1: return x >= thr;
-    case 2: return x < thr;
-    case 3: return x <= thr;
-    case 4: return x == thr;
-    default: return x != thr;
+    case 0: return a > b;
+    case 1: return a >= b;
+    case 2: return a < b;
+    case 3: return a <= b;
+    case 4: return a == b;
+    default: return a != b;
   }
 }
 
