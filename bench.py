@@ -165,12 +165,11 @@ def main():
     n_total = rows * world
     wl = Workload(ctx, a.workload, rows, rank * rows, n_total)
 
+    from exon_amd.distributed import all_reduce_state
+
     def step():
         wl.launch()
-        if world > 1:  # AggregateExec(Final) across GPUs: RCCL all-reduce of the partial state over xGMI
-            dist.all_reduce(wl.counts)
-            if wl.sums is not None:
-                dist.all_reduce(wl.sums)
+        all_reduce_state(wl.counts, wl.sums)  # AggregateExec(Final) across GPUs: RCCL all-reduce over xGMI
 
     for _ in range(a.warmup):
         step()
@@ -185,10 +184,7 @@ def main():
         ev[i][0].record()
         wl.launch()
         ev[i][1].record()
-        if world > 1:
-            dist.all_reduce(wl.counts)
-            if wl.sums is not None:
-                dist.all_reduce(wl.sums)
+        all_reduce_state(wl.counts, wl.sums)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -1,0 +1,51 @@
+//! Raw FFI of include/exon_hip.h (hand-written; bindgen would produce the same).
+#![allow(non_camel_case_types)]
+use arrow::ffi::{FFI_ArrowArray, FFI_ArrowSchema};
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+pub struct exon_hip_ctx { _p: [u8; 0] }
+#[repr(C)]
+pub struct exon_hip_plan { _p: [u8; 0] }
+#[repr(C)]
+pub struct exon_hip_stream { _p: [u8; 0] }
+
+pub const EXON_HIP_PLAN_REGION_COUNT: i32 = 2;
+pub const EXON_HIP_PLAN_FLAG_MAPQ_GROUP_COUNT: i32 = 3;
+pub const EXON_HIP_PLAN_CMP_AVG_BY_GROUP: i32 = 4;
+pub const EXON_HIP_PLAN_QUAL_POS_HIST: i32 = 5;
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct exon_hip_plan_desc {
+    pub kind: i32,
+    pub n_groups: i32,
+    pub region_chrom_id: i32,
+    pub reserved0: i32,
+    pub region_start: i64,
+    pub region_end: i64,
+    pub flag_mask: i32,
+    pub flag_value: i32,
+    pub mapq_min: i32,
+    pub cmp_op: i32,
+    pub threshold: f64,
+    pub lmax: i32,
+    pub reserved1: i32,
+    pub columns: [i32; 4],
+}
+
+extern "C" {
+    pub fn exon_hip_ctx_create(device: c_int, out: *mut *mut exon_hip_ctx) -> c_int;
+    pub fn exon_hip_ctx_destroy(ctx: *mut exon_hip_ctx) -> c_int;
+    pub fn exon_hip_last_error(ctx: *const exon_hip_ctx) -> *const c_char;
+    pub fn exon_hip_plan_create(ctx: *mut exon_hip_ctx, desc: *const exon_hip_plan_desc, out: *mut *mut exon_hip_plan) -> c_int;
+    pub fn exon_hip_plan_destroy(plan: *mut exon_hip_plan) -> c_int;
+    pub fn exon_hip_stream_open(plan: *mut exon_hip_plan, partition: i32, out: *mut *mut exon_hip_stream) -> c_int;
+    /// moves `batch` (the library calls batch.release exactly once)
+    pub fn exon_hip_stream_push(s: *mut exon_hip_stream, batch: *mut FFI_ArrowArray) -> c_int;
+    pub fn exon_hip_stream_state(s: *mut exon_hip_stream, d_i64: *mut *mut i64, d_f64: *mut *mut f64, hip_stream: *mut *mut c_void) -> c_int;
+    pub fn exon_hip_stream_finish_arrow(s: *mut exon_hip_stream, out: *mut FFI_ArrowArray, out_schema: *mut FFI_ArrowSchema) -> c_int;
+    pub fn exon_hip_stream_close(s: *mut exon_hip_stream) -> c_int;
+    pub fn exon_hip_parse_region(region: *const c_char, name_out: *mut c_char, name_cap: usize, start: *mut i64, end: *mut i64) -> c_int;
+    pub fn exon_hip_regroup_files_by_size(sizes: *const i64, n_files: i32, target_groups: i32, group_of: *mut i32) -> c_int;
+}
