@@ -72,6 +72,14 @@ class PlanDesc(C.Structure):
     ]
 
 
+class ScanOptions(C.Structure):
+    _fields_ = [("format", C.c_int32), ("compression", C.c_int32), ("batch_size", C.c_int64),
+                ("info_field", C.c_char_p), ("region", C.c_char_p)]
+
+
+FORMATS = {"vcf": 1, "bam": 2, "fastq": 3, "fasta": 4}
+COMPRESSION = {"auto": 0, None: 0, "none": 1, "gzip": 2}
+
 PLAN_REGION_COUNT = 2
 PLAN_FLAG_MAPQ_GROUP_COUNT = 3
 PLAN_CMP_AVG_BY_GROUP = 4
@@ -119,6 +127,15 @@ SIGNATURES = {
     "exon_hip_stream_finish": (C.c_int, [_vp, _vp, _vp]),
     "exon_hip_stream_finish_arrow": (C.c_int, [_vp, C.POINTER(ArrowArray), C.POINTER(ArrowSchema)]),
     "exon_hip_stream_close": (C.c_int, [_vp]),
+    "exon_hip_scan_open": (C.c_int, [C.c_char_p, C.POINTER(ScanOptions), C.POINTER(_vp)]),
+    "exon_hip_scan_schema": (C.c_int, [_vp, C.POINTER(ArrowSchema)]),
+    "exon_hip_scan_next": (C.c_int, [_vp, C.POINTER(ArrowArray)]),
+    "exon_hip_scan_dictionary_size": (C.c_int, [_vp, _i32, C.POINTER(_i32)]),
+    "exon_hip_scan_dictionary_intern": (C.c_int, [_vp, _i32, C.c_char_p, C.POINTER(_i32)]),
+    "exon_hip_scan_dictionary_value": (C.c_int, [_vp, _i32, _i32, C.POINTER(C.c_char_p)]),
+    "exon_hip_scan_rows": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "exon_hip_scan_close": (C.c_int, [_vp]),
+    "exon_hip_stream_consume_scan": (C.c_int, [_vp, _vp, C.POINTER(_i64)]),
 }
 
 

@@ -1,0 +1,246 @@
+// arrow_build.h -- producing Arrow C Data Interface arrays from C++ (host memory, owned buffers).
+//
+// Mirrors what arrow-rs builders + `RecordBatch::try_new_with_options` do for the reference's
+// ExonArrayBuilder::try_into_record_batch (exon-common/src/array_builder.rs:20-45): typed column builders
+// with validity, and a struct ("record batch") array with an explicit row count so zero-column batches
+// still carry their length (`with_row_count(Some(self.len()))`, :29-33).
+#pragma once
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/exon_hip.h"
+
+namespace exon {
+
+// ---- owned Arrow arrays / schemas --------------------------------------------------------------------
+struct OwnedArray {
+  std::vector<void*> bufs;            // malloc'ed, freed on release
+  std::vector<const void*> buf_ptrs;  // ArrowArray::buffers
+  std::vector<struct ArrowArray*> children;
+  struct ArrowArray* dictionary = nullptr;
+};
+inline void release_array(struct ArrowArray* a) {
+  if (!a || !a->release) return;
+  OwnedArray* o = static_cast<OwnedArray*>(a->private_data);
+  for (auto* c : o->children) {
+    if (c->release) c->release(c);
+    free(c);
+  }
+  if (o->dictionary) {
+    if (o->dictionary->release) o->dictionary->release(o->dictionary);
+    free(o->dictionary);
+  }
+  for (void* b : o->bufs) free(b);
+  delete o;
+  a->release = nullptr;
+}
+struct OwnedSchema {
+  std::string format, name;
+  std::vector<struct ArrowSchema*> children;
+  struct ArrowSchema* dictionary = nullptr;
+};
+inline void release_schema(struct ArrowSchema* s) {
+  if (!s || !s->release) return;
+  OwnedSchema* o = static_cast<OwnedSchema*>(s->private_data);
+  for (auto* c : o->children) {
+    if (c->release) c->release(c);
+    free(c);
+  }
+  if (o->dictionary) {
+    if (o->dictionary->release) o->dictionary->release(o->dictionary);
+    free(o->dictionary);
+  }
+  delete o;
+  s->release = nullptr;
+}
+
+inline void make_schema(struct ArrowSchema* s, const char* fmt, const char* name, bool nullable,
+                        std::vector<struct ArrowSchema*> kids = {}, struct ArrowSchema* dict = nullptr) {
+  OwnedSchema* o = new OwnedSchema{fmt, name, std::move(kids), dict};
+  memset(s, 0, sizeof *s);
+  s->format = o->format.c_str();
+  s->name = o->name.c_str();
+  s->flags = nullable ? ARROW_FLAG_NULLABLE : 0;
+  s->n_children = (int64_t)o->children.size();
+  s->children = o->children.empty() ? nullptr : o->children.data();
+  s->dictionary = dict;
+  s->release = release_schema;
+  s->private_data = o;
+}
+inline struct ArrowSchema* new_field(const char* fmt, const char* name, bool nullable, struct ArrowSchema* dict = nullptr) {
+  struct ArrowSchema* s = static_cast<struct ArrowSchema*>(malloc(sizeof *s));
+  make_schema(s, fmt, name, nullable, {}, dict);
+  return s;
+}
+
+inline void* dup_buf(const void* src, size_t bytes) {
+  void* p = malloc(bytes + 64);  // slack: consumers may read whole 16-byte vectors
+  if (bytes) memcpy(p, src, bytes);
+  memset(static_cast<uint8_t*>(p) + bytes, 0, 64);
+  return p;
+}
+
+// validity: byte-per-row vector -> Arrow bitmap (nullptr when there are no nulls)
+inline void* pack_validity(const std::vector<uint8_t>& valid, int64_t* nulls) {
+  *nulls = 0;
+  for (uint8_t v : valid) *nulls += !v;
+  if (*nulls == 0) return nullptr;
+  const size_t n = valid.size();
+  uint8_t* bm = static_cast<uint8_t*>(calloc((n + 7) / 8 + 64, 1));
+  for (size_t i = 0; i < n; ++i)
+    if (valid[i]) bm[i >> 3] |= (uint8_t)(1u << (i & 7));
+  return bm;
+}
+
+// fixed-width column (values copied); `valid` may be empty (= all valid)
+inline void make_primitive(struct ArrowArray* a, const void* values, int64_t n, int elem, const std::vector<uint8_t>& valid,
+                           struct ArrowArray* dictionary = nullptr) {
+  OwnedArray* o = new OwnedArray();
+  int64_t nulls = 0;
+  void* vb = valid.empty() ? nullptr : pack_validity(valid, &nulls);
+  if (vb) o->bufs.push_back(vb);
+  void* data = dup_buf(values, (size_t)n * elem);
+  o->bufs.push_back(data);
+  o->buf_ptrs = {vb, data};
+  o->dictionary = dictionary;
+  memset(a, 0, sizeof *a);
+  a->length = n;
+  a->null_count = nulls;
+  a->n_buffers = 2;
+  a->buffers = o->buf_ptrs.data();
+  a->dictionary = dictionary;
+  a->release = release_array;
+  a->private_data = o;
+}
+
+// Utf8 column
+inline void make_utf8(struct ArrowArray* a, const std::vector<int32_t>& offsets, const std::string& data,
+                      const std::vector<uint8_t>& valid) {
+  OwnedArray* o = new OwnedArray();
+  const int64_t n = (int64_t)offsets.size() - 1;
+  int64_t nulls = 0;
+  void* vb = valid.empty() ? nullptr : pack_validity(valid, &nulls);
+  if (vb) o->bufs.push_back(vb);
+  void* ob = dup_buf(offsets.data(), offsets.size() * 4);
+  void* db = dup_buf(data.data(), data.size());
+  o->bufs.push_back(ob);
+  o->bufs.push_back(db);
+  o->buf_ptrs = {vb, ob, db};
+  memset(a, 0, sizeof *a);
+  a->length = n < 0 ? 0 : n;
+  a->null_count = nulls;
+  a->n_buffers = 3;
+  a->buffers = o->buf_ptrs.data();
+  a->release = release_array;
+  a->private_data = o;
+}
+
+inline struct ArrowArray* utf8_array(const std::vector<std::string>& strs) {
+  std::vector<int32_t> off(1, 0);
+  std::string data;
+  for (const auto& s : strs) {
+    data += s;
+    off.push_back((int32_t)data.size());
+  }
+  struct ArrowArray* a = static_cast<struct ArrowArray*>(malloc(sizeof *a));
+  make_utf8(a, off, data, {});
+  return a;
+}
+
+inline void make_struct(struct ArrowArray* a, int64_t n, std::vector<struct ArrowArray*> kids) {
+  OwnedArray* o = new OwnedArray();
+  o->children = std::move(kids);
+  o->buf_ptrs = {nullptr};
+  memset(a, 0, sizeof *a);
+  a->length = n;  // explicit row count, as RecordBatchOptions::with_row_count
+  a->n_buffers = 1;
+  a->buffers = o->buf_ptrs.data();
+  a->n_children = (int64_t)o->children.size();
+  a->children = o->children.empty() ? nullptr : o->children.data();
+  a->release = release_array;
+  a->private_data = o;
+}
+
+// ---- typed column builders ---------------------------------------------------------------------------
+template <typename T>
+struct PrimitiveBuilder {
+  std::vector<T> values;
+  std::vector<uint8_t> valid;  // byte per row
+  void append_value(T v) {
+    values.push_back(v);
+    valid.push_back(1);
+  }
+  void append_null(T placeholder = T()) {
+    values.push_back(placeholder);
+    valid.push_back(0);
+  }
+  size_t len() const { return values.size(); }
+  struct ArrowArray* finish(struct ArrowArray* dictionary = nullptr) {
+    struct ArrowArray* a = static_cast<struct ArrowArray*>(malloc(sizeof *a));
+    make_primitive(a, values.data(), (int64_t)values.size(), (int)sizeof(T), valid, dictionary);
+    values.clear();
+    valid.clear();
+    return a;
+  }
+};
+
+struct Utf8Builder {
+  std::vector<int32_t> offsets{0};
+  std::string data;
+  std::vector<uint8_t> valid;
+  void append_value(const char* p, size_t n) {
+    data.append(p, n);
+    offsets.push_back((int32_t)data.size());
+    valid.push_back(1);
+  }
+  void append_value(const std::string& s) { append_value(s.data(), s.size()); }
+  void append_null() {
+    offsets.push_back((int32_t)data.size());
+    valid.push_back(0);
+  }
+  size_t len() const { return offsets.size() - 1; }
+  struct ArrowArray* finish() {
+    struct ArrowArray* a = static_cast<struct ArrowArray*>(malloc(sizeof *a));
+    make_utf8(a, offsets, data, valid);
+    offsets.assign(1, 0);
+    data.clear();
+    valid.clear();
+    return a;
+  }
+};
+
+// append-only string dictionary: ids are stable across batches
+struct Dictionary {
+  std::vector<std::string> names;
+  int32_t lookup_or_insert(const char* p, size_t n) {
+    for (size_t i = 0; i < names.size(); ++i)  // dictionaries on this path are tiny (contigs, FILTER combos)
+      if (names[i].size() == n && memcmp(names[i].data(), p, n) == 0) return (int32_t)i;
+    names.emplace_back(p, n);
+    return (int32_t)names.size() - 1;
+  }
+  int32_t find(const std::string& s) const {
+    for (size_t i = 0; i < names.size(); ++i)
+      if (names[i] == s) return (int32_t)i;
+    return -1;
+  }
+};
+
+// The reference's column-sink contract (exon-common/src/array_builder.rs:20-45)
+class ExonArrayBuilder {
+ public:
+  virtual ~ExonArrayBuilder() = default;
+  // Finishes the internal builders and returns the built arrays (projection order).
+  virtual std::vector<struct ArrowArray*> finish() = 0;
+  virtual size_t len() const = 0;
+  bool is_empty() const { return len() == 0; }
+  // Struct array with an explicit row count (zero-column batches keep their length).
+  void try_into_record_batch(struct ArrowArray* out) {
+    const int64_t n = (int64_t)len();
+    make_struct(out, n, finish());
+  }
+};
+
+}  // namespace exon

@@ -1,0 +1,537 @@
+// formats.h -- native record decoders + device-layout array builders for VCF / BAM / FASTQ / FASTA.
+//
+// C++ counterparts of the reference's per-format crates, emitting the columns the GPU kernels consume
+// (dictionary ids instead of Utf8 keys, raw u8 mapq, Arrow validity bitmaps) instead of the reference's
+// string-heavy Arrow layout:
+//   VCFConfig / VCFArrayBuilder / VCFBatchReader
+//       exon-vcf/src/config.rs:23-64, array_builder/lazy_array_builder.rs:50-495 (append: :153-448),
+//       array_builder/info_builder.rs:152-309 (typed INFO field), async_batch_stream.rs:80-109 (read_batch)
+//   BAMConfig / BAMArrayBuilder / BAMBatchReader
+//       exon-bam/src/config.rs:21-77 (default batch 8096 there; 8192 here as everywhere else),
+//       array_builder.rs:102-218, batch_reader.rs:44-108, indexed_async_batch_stream.rs:35-87 (alignment_end)
+//   FASTQConfig / FASTQArrayBuilder / FASTQBatchReader   exon-fastq/src/{config,array_builder,batch_reader}.rs
+//   FASTAConfig / FASTAArrayBuilder / FASTABatchReader   exon-fasta/src/{config,array_builder,batch_reader}.rs
+// Record syntax itself is noodles' (VCF 4.x text, BAM spec section 4.2, 4-line FASTQ, '>' FASTA).
+#pragma once
+#include <cstdint>
+#include <cstdlib>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "arrow_build.h"
+#include "io.h"
+#include "region.h"
+
+namespace exon {
+
+constexpr int64_t DEFAULT_BATCH_SIZE = 8 * 1024;  // exon-common/src/lib.rs:27
+
+struct RegionFilter {  // pushed-down vcf_region_filter / bam_region_filter (per-record interval hit)
+  bool active = false;
+  Region region;
+};
+
+// ======================================================================================================
+// VCF
+// ======================================================================================================
+struct VCFHeader {
+  std::vector<std::string> contigs;                          // ##contig order = chrom dictionary order
+  std::vector<std::string> filters;                          // ##FILTER ids
+  std::vector<std::pair<std::string, std::string>> infos;    // (ID, "Number|Type")
+  std::vector<std::string> samples;
+};
+
+struct VCFConfig {
+  int64_t batch_size = DEFAULT_BATCH_SIZE;
+  std::string info_field;  // exon.vcf_parse_info=true + SELECT info."<F>": Number=1 Float/Integer field -> f32 column
+  RegionFilter filter;
+};
+
+inline std::string header_attr(const std::string& line, const char* key) {
+  const size_t lt = line.find('<');
+  if (lt == std::string::npos) return "";
+  std::string k = std::string(key) + "=";
+  size_t p = lt + 1;
+  bool inq = false;
+  size_t field_start = p;
+  for (size_t i = p; i <= line.size(); ++i) {
+    const char ch = i < line.size() ? line[i] : '>';
+    if (ch == '"') inq = !inq;
+    if ((ch == ',' || ch == '>') && !inq) {
+      if (line.compare(field_start, k.size(), k) == 0) {
+        std::string v = line.substr(field_start + k.size(), i - field_start - k.size());
+        if (v.size() >= 2 && v.front() == '"' && v.back() == '"') v = v.substr(1, v.size() - 2);
+        return v;
+      }
+      field_start = i + 1;
+      if (ch == '>') break;
+    }
+  }
+  return "";
+}
+
+// Schema of the device-layout VCF batch: chrom (dict), pos, qual, filter (dict of ';'-joined lists,
+// "" = empty list), [info.<F>].  Reference schema: exon-core/src/datasources/vcf/schema_builder.rs:85-129.
+class VCFArrayBuilder : public ExonArrayBuilder {
+ public:
+  VCFArrayBuilder(Dictionary* chrom_dict, Dictionary* filter_dict, const std::string& info_field)
+      : chrom_dict_(chrom_dict), filter_dict_(filter_dict), info_field_(info_field) {}
+
+  // one data line (no terminator).  Field rules: lazy_array_builder.rs:159-216.
+  void append(const std::string& line) {
+    const char* f[9];
+    size_t fl[9];
+    int nf = 0;
+    size_t start = 0;
+    for (size_t i = 0; i <= line.size() && nf < 9; ++i)
+      if (i == line.size() || line[i] == '\t') {
+        f[nf] = line.data() + start;
+        fl[nf] = i - start;
+        ++nf;
+        start = i + 1;
+      }
+    if (nf < 8) throw std::runtime_error("VCF record has fewer than 8 fields");
+    chrom_.append_value(chrom_dict_->lookup_or_insert(f[0], fl[0]));
+    // POS: 0 (telomere) and '.' have no variant_start
+    int64_t pos = 0;
+    bool pos_ok = fl[1] > 0;
+    for (size_t i = 0; i < fl[1] && pos_ok; ++i) {
+      if (f[1][i] < '0' || f[1][i] > '9') pos_ok = false;
+      else pos = pos * 10 + (f[1][i] - '0');
+    }
+    if (pos_ok && pos > 0) pos_.append_value(pos);
+    else pos_.append_null(0);
+    // QUAL: '.' -> NULL, else correctly rounded f32 (Rust str::parse::<f32>)
+    if (fl[5] == 1 && f[5][0] == '.') qual_.append_null(0.f);
+    else qual_.append_value(parse_f32(f[5], fl[5]));
+    // FILTER: '.' -> empty list (never NULL); the list is kept as its ';'-joined text, order preserved
+    if (fl[6] == 1 && f[6][0] == '.') filter_.append_value(filter_dict_->lookup_or_insert("", 0));
+    else filter_.append_value(filter_dict_->lookup_or_insert(f[6], fl[6]));
+    if (!info_field_.empty()) {
+      float v;
+      if (info_lookup(f[7], fl[7], &v)) info_.append_value(v);
+      else info_.append_null(0.f);
+    }
+    ++rows_;
+  }
+
+  // last appended record's (chrom id, pos, has_pos): used by the pushed-down region filter
+  size_t len() const override { return rows_; }
+
+  std::vector<struct ArrowArray*> finish() override {
+    std::vector<struct ArrowArray*> out;
+    out.push_back(chrom_.finish(utf8_array(chrom_dict_->names)));
+    out.push_back(pos_.finish());
+    out.push_back(qual_.finish());
+    out.push_back(filter_.finish(utf8_array(filter_dict_->names)));
+    if (!info_field_.empty()) out.push_back(info_.finish());
+    rows_ = 0;
+    return out;
+  }
+
+  static float parse_f32(const char* p, size_t n) {
+    char tmp[64];
+    if (n >= sizeof tmp) n = sizeof tmp - 1;
+    memcpy(tmp, p, n);
+    tmp[n] = 0;
+    char* end = nullptr;
+    const float v = strtof(tmp, &end);
+    if (end == tmp) throw std::runtime_error(std::string("invalid float '") + tmp + "'");
+    return v;
+  }
+
+ private:
+  // INFO '.' -> NULL struct; key absent or value '.' -> NULL field (info_builder.rs:152-309)
+  bool info_lookup(const char* p, size_t n, float* out) const {
+    if (n == 1 && p[0] == '.') return false;
+    size_t i = 0;
+    while (i < n) {
+      size_t j = i;
+      while (j < n && p[j] != ';') ++j;
+      const size_t kl = info_field_.size();
+      if (j - i > kl && p[i + kl] == '=' && memcmp(p + i, info_field_.data(), kl) == 0) {
+        const char* v = p + i + kl + 1;
+        const size_t vl = j - i - kl - 1;
+        if (vl == 0 || (vl == 1 && v[0] == '.')) return false;
+        *out = parse_f32(v, vl);
+        return true;
+      }
+      i = j + 1;
+    }
+    return false;
+  }
+
+  Dictionary *chrom_dict_, *filter_dict_;
+  std::string info_field_;
+  PrimitiveBuilder<int32_t> chrom_, filter_;
+  PrimitiveBuilder<int64_t> pos_;
+  PrimitiveBuilder<float> qual_, info_;
+  size_t rows_ = 0;
+};
+
+class VCFBatchReader {
+ public:
+  VCFBatchReader(const std::string& path, Compression c, VCFConfig cfg) : r_(path, c), cfg_(std::move(cfg)) {
+    // header (noodles `read_header`): meta lines '##', then '#CHROM ...'
+    std::string line;
+    while (r_.read_line(&line)) {
+      if (line.rfind("##", 0) == 0) {
+        if (line.rfind("##contig=", 0) == 0) header.contigs.push_back(header_attr(line, "ID"));
+        else if (line.rfind("##FILTER=", 0) == 0) header.filters.push_back(header_attr(line, "ID"));
+        else if (line.rfind("##INFO=", 0) == 0)
+          header.infos.emplace_back(header_attr(line, "ID"), header_attr(line, "Number") + "|" + header_attr(line, "Type"));
+        continue;
+      }
+      if (!line.empty() && line[0] == '#') {
+        size_t col = 0, start = 0;
+        for (size_t i = 0; i <= line.size(); ++i)
+          if (i == line.size() || line[i] == '\t') {
+            if (col >= 9) header.samples.push_back(line.substr(start, i - start));
+            ++col;
+            start = i + 1;
+          }
+        break;
+      }
+      pending_ = line;  // headerless input: first data line
+      has_pending_ = true;
+      break;
+    }
+    for (const auto& c2 : header.contigs) chrom_dict.names.push_back(c2);
+    if (!cfg_.info_field.empty()) {
+      bool found = false;
+      for (const auto& kv : header.infos)
+        if (kv.first == cfg_.info_field) {
+          found = true;
+          // INFO typing: schema_builder.rs:197-249 -- Number=0|1 scalar; Float -> Float32, Integer -> Int32
+          if (kv.second.rfind("1|", 0) != 0 || (kv.second != "1|Float" && kv.second != "1|Integer"))
+            throw std::runtime_error("INFO field " + cfg_.info_field + " is not a Number=1 Float/Integer field");
+        }
+      if (!found) throw std::runtime_error("INFO field " + cfg_.info_field + " is not declared in the header");
+    }
+  }
+
+  // AsyncBatchStream::read_batch (exon-vcf/src/async_batch_stream.rs:80-109); with a region filter the
+  // per-record test of IndexedAsyncBatchStream::filter applies to EVERY record
+  // (exon-vcf/src/indexed_async_batch_stream.rs:99-116; see DESIGN.md on the reference's unfiltered tail).
+  bool read_batch(struct ArrowArray* out) {
+    VCFArrayBuilder b(&chrom_dict, &filter_dict, cfg_.info_field);
+    std::string line;
+    while ((int64_t)b.len() < cfg_.batch_size) {
+      if (has_pending_) {
+        line.swap(pending_);
+        has_pending_ = false;
+      } else if (!r_.read_line(&line)) {
+        break;
+      }
+      if (line.empty()) continue;
+      if (cfg_.filter.active && !region_hit(line)) continue;
+      b.append(line);
+    }
+    if (b.is_empty()) return false;
+    b.try_into_record_batch(out);
+    return true;
+  }
+
+  void schema(struct ArrowSchema* out) const {
+    std::vector<struct ArrowSchema*> kids = {new_field("i", "chrom", false, new_field("u", "", false)),
+                                             new_field("l", "pos", true), new_field("f", "qual", true),
+                                             new_field("i", "filter", false, new_field("u", "", false))};
+    if (!cfg_.info_field.empty()) kids.push_back(new_field("f", ("info." + cfg_.info_field).c_str(), true));
+    make_schema(out, "+s", "", false, kids);
+  }
+
+  VCFHeader header;
+  Dictionary chrom_dict, filter_dict;
+
+ private:
+  bool region_hit(const std::string& line) const {
+    const size_t t1 = line.find('\t');
+    if (t1 == std::string::npos) return false;
+    const Region& rg = cfg_.filter.region;
+    if (t1 != rg.name.size() || line.compare(0, t1, rg.name) != 0) return false;
+    const size_t t2 = line.find('\t', t1 + 1);
+    int64_t pos = 0;
+    for (size_t i = t1 + 1; i < (t2 == std::string::npos ? line.size() : t2); ++i) {
+      if (line[i] < '0' || line[i] > '9') return false;
+      pos = pos * 10 + (line[i] - '0');
+    }
+    return pos >= 1 && pos >= rg.start && pos <= rg.end;
+  }
+  BufReader r_;
+  VCFConfig cfg_;
+  std::string pending_;
+  bool has_pending_ = false;
+};
+
+// ======================================================================================================
+// BAM
+// ======================================================================================================
+struct BAMConfig {
+  int64_t batch_size = DEFAULT_BATCH_SIZE;
+  RegionFilter filter;  // bam_region_filter: SemiLazyRecord::intersects
+};
+
+// device-layout BAM batch: flag i32, mapq u8? (255 -> NULL), reference dict? (-1 -> NULL), start i64?, end i64?
+class BAMArrayBuilder : public ExonArrayBuilder {
+ public:
+  explicit BAMArrayBuilder(const std::vector<std::string>* ref_names) : ref_names_(ref_names) {}
+  void append(int32_t flag, int32_t ref_id, int64_t pos0, int mapq, int64_t ref_len) {
+    flag_.append_value(flag);  // array_builder.rs:114-117: raw u16 bits as Int32
+    if (mapq == 255) mapq_.append_null(255);  // :136-143 (reference: decimal string, NULL when missing)
+    else mapq_.append_value((uint8_t)mapq);
+    if (ref_id < 0) ref_.append_null(-1);  // :118-127
+    else ref_.append_value(ref_id);
+    if (pos0 < 0) {
+      start_.append_null(0);
+      end_.append_null(0);
+    } else {
+      start_.append_value(pos0 + 1);            // 1-based
+      end_.append_value(pos0 + 1 + ref_len - 1);  // alignment_end = start + reference length - 1
+    }
+    ++rows_;
+  }
+  size_t len() const override { return rows_; }
+  std::vector<struct ArrowArray*> finish() override {
+    rows_ = 0;
+    return {flag_.finish(), mapq_.finish(), ref_.finish(utf8_array(*ref_names_)), start_.finish(), end_.finish()};
+  }
+
+ private:
+  const std::vector<std::string>* ref_names_;
+  PrimitiveBuilder<int32_t> flag_, ref_;
+  PrimitiveBuilder<uint8_t> mapq_;
+  PrimitiveBuilder<int64_t> start_, end_;
+  size_t rows_ = 0;
+};
+
+class BAMBatchReader {
+ public:
+  BAMBatchReader(const std::string& path, BAMConfig cfg) : r_(path, Compression::Gzip), cfg_(std::move(cfg)) {
+    uint8_t magic[4];
+    if (!r_.read_exact(magic, 4) || memcmp(magic, "BAM\1", 4) != 0) throw std::runtime_error("not a BAM file: " + path);
+    const int32_t l_text = read_i32();
+    header_text.resize((size_t)l_text);
+    if (l_text && !r_.read_exact(reinterpret_cast<uint8_t*>(&header_text[0]), (size_t)l_text)) throw std::runtime_error("truncated BAM header");
+    const int32_t n_ref = read_i32();
+    for (int32_t i = 0; i < n_ref; ++i) {
+      const int32_t l_name = read_i32();
+      std::string name((size_t)l_name, '\0');
+      if (!r_.read_exact(reinterpret_cast<uint8_t*>(&name[0]), (size_t)l_name)) throw std::runtime_error("truncated BAM reference");
+      name.resize(strlen(name.c_str()));
+      ref_names.push_back(name);
+      ref_lengths.push_back(read_i32());
+    }
+    if (cfg_.filter.active) {
+      region_ref_id_ = -2;
+      for (size_t i = 0; i < ref_names.size(); ++i)
+        if (ref_names[i] == cfg_.filter.region.name) region_ref_id_ = (int32_t)i;
+    }
+  }
+
+  bool read_batch(struct ArrowArray* out) {
+    BAMArrayBuilder b(&ref_names);
+    std::vector<uint8_t> rec;
+    while ((int64_t)b.len() < cfg_.batch_size) {
+      uint8_t szb[4];
+      if (!r_.read_exact(szb, 4)) break;
+      int32_t block;
+      memcpy(&block, szb, 4);
+      if (block < 32) throw std::runtime_error("corrupt BAM record");
+      rec.resize((size_t)block);
+      if (!r_.read_exact(rec.data(), rec.size())) throw std::runtime_error("truncated BAM record");
+      int32_t ref_id, pos;
+      uint16_t n_cigar, flag;
+      memcpy(&ref_id, &rec[0], 4);
+      memcpy(&pos, &rec[4], 4);
+      const uint8_t l_read_name = rec[8], mapq = rec[9];
+      memcpy(&n_cigar, &rec[12], 2);
+      memcpy(&flag, &rec[14], 2);
+      // reference length = sum of M/D/N/=/X op lengths (ops 0,2,3,7,8)
+      int64_t ref_len = 0;
+      const size_t co = 32 + l_read_name;
+      if (co + 4u * n_cigar > rec.size()) throw std::runtime_error("corrupt BAM cigar");
+      for (uint16_t k = 0; k < n_cigar; ++k) {
+        uint32_t c;
+        memcpy(&c, &rec[co + 4u * k], 4);
+        const uint32_t op = c & 0xF;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += c >> 4;
+      }
+      if (cfg_.filter.active) {
+        // SemiLazyRecord::intersects (exon-bam/src/indexed_async_batch_stream.rs:66-87)
+        if (ref_id < 0 || pos < 0) continue;
+        const int64_t s = (int64_t)pos + 1, e = s + ref_len - 1;
+        const Region& rg = cfg_.filter.region;
+        if (!(ref_id == region_ref_id_ && s <= rg.end && rg.start <= e)) continue;
+      }
+      b.append((int32_t)flag, ref_id, pos, mapq, ref_len);
+    }
+    if (b.is_empty()) return false;
+    b.try_into_record_batch(out);
+    return true;
+  }
+
+  void schema(struct ArrowSchema* out) const {
+    make_schema(out, "+s", "", false,
+                {new_field("i", "flag", false), new_field("C", "mapping_quality", true),
+                 new_field("i", "reference", true, new_field("u", "", false)), new_field("l", "start", true),
+                 new_field("l", "end", true)});
+  }
+
+  std::string header_text;
+  std::vector<std::string> ref_names;
+  std::vector<int32_t> ref_lengths;
+
+ private:
+  int32_t read_i32() {
+    uint8_t b[4];
+    if (!r_.read_exact(b, 4)) throw std::runtime_error("truncated BAM file");
+    int32_t v;
+    memcpy(&v, b, 4);
+    return v;
+  }
+  BufReader r_;
+  BAMConfig cfg_;
+  int32_t region_ref_id_ = -2;
+};
+
+// ======================================================================================================
+// FASTQ   (name, description?, sequence, quality_scores : exon-fastq/src/config.rs:79-88)
+// ======================================================================================================
+struct FASTQConfig {
+  int64_t batch_size = DEFAULT_BATCH_SIZE;
+};
+
+class FASTQArrayBuilder : public ExonArrayBuilder {
+ public:
+  // array_builder.rs:68-102: name up to the first space, description = rest (NULL if empty)
+  void append(const std::string& head, const std::string& seq, const std::string& qual) {
+    const size_t sp = head.find(' ');
+    if (sp == std::string::npos) {
+      name_.append_value(head);
+      desc_.append_null();
+    } else {
+      name_.append_value(head.data(), sp);
+      if (sp + 1 < head.size()) desc_.append_value(head.data() + sp + 1, head.size() - sp - 1);
+      else desc_.append_null();
+    }
+    seq_.append_value(seq);
+    qual_.append_value(qual);
+  }
+  size_t len() const override { return name_.len(); }
+  std::vector<struct ArrowArray*> finish() override { return {name_.finish(), desc_.finish(), seq_.finish(), qual_.finish()}; }
+
+ private:
+  Utf8Builder name_, desc_, seq_, qual_;
+};
+
+class FASTQBatchReader {
+ public:
+  FASTQBatchReader(const std::string& path, Compression c, FASTQConfig cfg) : r_(path, c), cfg_(cfg) {}
+  bool read_batch(struct ArrowArray* out) {
+    FASTQArrayBuilder b;
+    std::string head, seq, plus, qual;
+    while ((int64_t)b.len() < cfg_.batch_size) {
+      if (!r_.read_line(&head)) break;
+      if (head.empty()) continue;
+      if (head[0] != '@') throw std::runtime_error("FASTQ record does not start with '@'");
+      if (!r_.read_line(&seq) || !r_.read_line(&plus) || !r_.read_line(&qual)) throw std::runtime_error("truncated FASTQ record");
+      if (plus.empty() || plus[0] != '+') throw std::runtime_error("FASTQ separator line missing");
+      b.append(head.substr(1), seq, qual);
+    }
+    if (b.is_empty()) return false;
+    b.try_into_record_batch(out);
+    return true;
+  }
+  void schema(struct ArrowSchema* out) const {
+    make_schema(out, "+s", "", false,
+                {new_field("u", "name", false), new_field("u", "description", true), new_field("u", "sequence", false),
+                 new_field("u", "quality_scores", false)});
+  }
+
+ private:
+  BufReader r_;
+  FASTQConfig cfg_;
+};
+
+// ======================================================================================================
+// FASTA   (id, description?, sequence : exon-fasta/src/config.rs:164-170)
+// ======================================================================================================
+struct FASTAConfig {
+  int64_t batch_size = DEFAULT_BATCH_SIZE;
+};
+
+class FASTAArrayBuilder : public ExonArrayBuilder {
+ public:
+  // array_builder.rs:114-132: id up to the first whitespace, description = rest (NULL if none)
+  void append(const std::string& def, const std::string& seq) {
+    size_t ws = 0;
+    while (ws < def.size() && def[ws] != ' ' && def[ws] != '\t') ++ws;
+    id_.append_value(def.data(), ws);
+    size_t d = ws;
+    while (d < def.size() && (def[d] == ' ' || def[d] == '\t')) ++d;
+    if (d < def.size()) desc_.append_value(def.data() + d, def.size() - d);
+    else desc_.append_null();
+    seq_.append_value(seq);
+  }
+  size_t len() const override { return id_.len(); }
+  std::vector<struct ArrowArray*> finish() override { return {id_.finish(), desc_.finish(), seq_.finish()}; }
+
+ private:
+  Utf8Builder id_, desc_, seq_;
+};
+
+class FASTABatchReader {
+ public:
+  FASTABatchReader(const std::string& path, Compression c, FASTAConfig cfg) : r_(path, c), cfg_(cfg) {}
+  // exon-fasta/src/batch_reader.rs:72-99
+  bool read_batch(struct ArrowArray* out) {
+    FASTAArrayBuilder b;
+    std::string line;
+    while ((int64_t)b.len() < cfg_.batch_size) {
+      if (!have_def_) {
+        bool got = false;
+        while (r_.read_line(&line)) {
+          if (!line.empty() && line[0] == '>') {
+            def_ = line.substr(1);
+            got = true;
+            break;
+          }
+        }
+        if (!got) break;
+        have_def_ = true;
+      }
+      std::string seq;
+      bool next_def = false;
+      while (r_.read_line(&line)) {
+        if (!line.empty() && line[0] == '>') {
+          next_def = true;
+          break;
+        }
+        seq += line;
+      }
+      b.append(def_, seq);
+      if (next_def) {
+        def_ = line.substr(1);
+      } else {
+        have_def_ = false;
+        break;
+      }
+    }
+    if (b.is_empty()) return false;
+    b.try_into_record_batch(out);
+    return true;
+  }
+  void schema(struct ArrowSchema* out) const {
+    make_schema(out, "+s", "", false, {new_field("u", "id", false), new_field("u", "description", true), new_field("u", "sequence", false)});
+  }
+
+ private:
+  BufReader r_;
+  FASTAConfig cfg_;
+  std::string def_;
+  bool have_def_ = false;
+};
+
+}  // namespace exon

@@ -17,6 +17,7 @@
 #include <new>
 #include <vector>
 
+#include "host/arrow_build.h"
 #include "internal.h"
 
 namespace {
@@ -463,96 +464,15 @@ int exon_hip_stream_finish(exon_hip_stream* st, int64_t* counts, double* sums) {
 
 // ---- Arrow export of the partial-aggregate state ---------------------------------------------------
 namespace {
-struct OwnedArray {
-  std::vector<void*> bufs;            // malloc'ed, owned
-  std::vector<const void*> buf_ptrs;  // what ArrowArray::buffers points at
-  std::vector<struct ArrowArray*> children;
-};
-void release_array(struct ArrowArray* a) {
-  if (!a || !a->release) return;
-  OwnedArray* o = (OwnedArray*)a->private_data;
-  for (auto* c : o->children) {
-    if (c->release) c->release(c);
-    free(c);
-  }
-  for (void* b : o->bufs) free(b);
-  delete o;
-  a->release = nullptr;
-}
-struct OwnedSchema {
-  std::string format, name;
-  std::vector<struct ArrowSchema*> children;
-};
-void release_schema(struct ArrowSchema* s) {
-  if (!s || !s->release) return;
-  OwnedSchema* o = (OwnedSchema*)s->private_data;
-  for (auto* c : o->children) {
-    if (c->release) c->release(c);
-    free(c);
-  }
-  delete o;
-  s->release = nullptr;
-}
-void make_schema(struct ArrowSchema* s, const char* fmt, const char* name, bool nullable, std::vector<struct ArrowSchema*> kids = {}) {
-  OwnedSchema* o = new OwnedSchema{fmt, name, std::move(kids)};
-  memset(s, 0, sizeof *s);
-  s->format = o->format.c_str();
-  s->name = o->name.c_str();
-  s->flags = nullable ? ARROW_FLAG_NULLABLE : 0;
-  s->n_children = (int64_t)o->children.size();
-  s->children = o->children.empty() ? nullptr : o->children.data();
-  s->release = release_schema;
-  s->private_data = o;
-}
-// primitive column of `n` values of `elem` bytes copied from `src`; validity from `valid` (byte per row) or none
-void make_prim(struct ArrowArray* a, const void* src, int64_t n, int elem, const std::vector<uint8_t>* valid) {
-  OwnedArray* o = new OwnedArray();
-  void* vb = nullptr;
-  int64_t nulls = 0;
-  if (valid) {
-    vb = calloc((size_t)(n + 7) / 8 + 8, 1);
-    for (int64_t i = 0; i < n; ++i) {
-      if ((*valid)[(size_t)i]) ((uint8_t*)vb)[i >> 3] |= (uint8_t)(1u << (i & 7));
-      else ++nulls;
-    }
-    o->bufs.push_back(vb);
-  }
-  void* data = malloc((size_t)n * elem + 8);
-  if (n) memcpy(data, src, (size_t)n * elem);
-  o->bufs.push_back(data);
-  o->buf_ptrs = {vb, data};
-  memset(a, 0, sizeof *a);
-  a->length = n;
-  a->null_count = nulls;
-  a->n_buffers = 2;
-  a->buffers = o->buf_ptrs.data();
-  a->release = release_array;
-  a->private_data = o;
-}
-void make_struct(struct ArrowArray* a, int64_t n, std::vector<struct ArrowArray*> kids) {
-  OwnedArray* o = new OwnedArray();
-  o->children = std::move(kids);
-  o->buf_ptrs = {nullptr};
-  memset(a, 0, sizeof *a);
-  a->length = n;
-  a->n_buffers = 1;
-  a->buffers = o->buf_ptrs.data();
-  a->n_children = (int64_t)o->children.size();
-  a->children = o->children.data();
-  a->release = release_array;
-  a->private_data = o;
-}
+using exon::make_schema;
+using exon::make_struct;
 template <typename T>
 struct ArrowArray* prim(const std::vector<T>& v, const std::vector<uint8_t>* valid = nullptr) {
   struct ArrowArray* a = (struct ArrowArray*)malloc(sizeof *a);
-  make_prim(a, v.data(), (int64_t)v.size(), (int)sizeof(T), valid);
+  exon::make_primitive(a, v.data(), (int64_t)v.size(), (int)sizeof(T), valid ? *valid : std::vector<uint8_t>());
   return a;
 }
-struct ArrowSchema* field(const char* fmt, const char* name, bool nullable) {
-  struct ArrowSchema* s = (struct ArrowSchema*)malloc(sizeof *s);
-  make_schema(s, fmt, name, nullable);
-  return s;
-}
+struct ArrowSchema* field(const char* fmt, const char* name, bool nullable) { return exon::new_field(fmt, name, nullable); }
 }  // namespace
 
 extern "C" {

@@ -214,6 +214,78 @@ def regroup_files_by_size(sizes, target_groups):
     return groups
 
 
+class Scan:
+    """Native decoder + device-layout array builder over one file (FileOpener::open + read_batch analogue).
+    CPU-only: usable without a GPU."""
+
+    def __init__(self, path, fmt, compression=None, batch_size=0, info_field=None, region=None):
+        self.lib = L.load()
+        self.fmt = fmt
+        opt = L.ScanOptions(L.FORMATS[fmt], L.COMPRESSION[compression], batch_size,
+                            info_field.encode() if info_field else None, region.encode() if region else None)
+        h = C.c_void_p()
+        rc = self.lib.exon_hip_scan_open(str(path).encode(), C.byref(opt), C.byref(h))
+        if rc:
+            raise ExonHipError(rc, self.lib.exon_hip_last_error(None).decode())
+        self.h = h
+
+    def _check(self, rc):
+        if rc < 0:
+            raise ExonHipError(rc, self.lib.exon_hip_last_error(None).decode())
+        return rc
+
+    def schema(self):
+        import pyarrow as pa
+        sch = L.ArrowSchema()
+        self._check(self.lib.exon_hip_scan_schema(self.h, C.byref(sch)))
+        return pa.DataType._import_from_c(C.addressof(sch))
+
+    def next_raw(self):
+        """-> ctypes ArrowArray (caller must release or move it) or None at end of stream."""
+        arr = L.ArrowArray()
+        rc = self._check(self.lib.exon_hip_scan_next(self.h, C.byref(arr)))
+        return None if rc == 1 else arr
+
+    def __iter__(self):
+        """Batches as pyarrow StructArrays (imports = moves each batch)."""
+        import pyarrow as pa
+        while True:
+            arr = self.next_raw()
+            if arr is None:
+                return
+            sch = L.ArrowSchema()
+            self._check(self.lib.exon_hip_scan_schema(self.h, C.byref(sch)))
+            yield pa.Array._import_from_c(C.addressof(arr), C.addressof(sch))
+
+    def dictionary_size(self, column):
+        n = C.c_int32()
+        self._check(self.lib.exon_hip_scan_dictionary_size(self.h, column, C.byref(n)))
+        return n.value
+
+    def dictionary(self, column):
+        out = []
+        for i in range(self.dictionary_size(column)):
+            p = C.c_char_p()
+            self._check(self.lib.exon_hip_scan_dictionary_value(self.h, column, i, C.byref(p)))
+            out.append(p.value.decode())
+        return out
+
+    def intern(self, column, name):
+        i = C.c_int32()
+        self._check(self.lib.exon_hip_scan_dictionary_intern(self.h, column, name.encode(), C.byref(i)))
+        return i.value
+
+    def rows(self):
+        n = C.c_int64()
+        self._check(self.lib.exon_hip_scan_rows(self.h, C.byref(n)))
+        return n.value
+
+    def close(self):
+        if self.h:
+            self.lib.exon_hip_scan_close(self.h)
+            self.h = None
+
+
 class Plan:
     def __init__(self, ctx, desc, columns):
         self.ctx = ctx
@@ -285,6 +357,15 @@ class Stream:
         top.device_type = L.ARROW_DEVICE_ROCM
         self.ctx._check(self.ctx.lib.exon_hip_stream_push_device(self.h, C.byref(top)))
         self._keep = keep + [kids, tb, top]
+
+    def consume(self, scan):
+        """Pull every batch of a Scan through this stream (GpuFilterAggExec::execute in native code)."""
+        n = C.c_int64()
+        rc = self.ctx.lib.exon_hip_stream_consume_scan(self.h, scan.h, C.byref(n))
+        if rc < 0:
+            msg = self.ctx.lib.exon_hip_last_error(self.ctx.h).decode() or self.ctx.lib.exon_hip_last_error(None).decode()
+            raise ExonHipError(rc, msg)
+        return n.value
 
     def state(self):
         a, b, s = C.c_void_p(), C.c_void_p(), C.c_void_p()

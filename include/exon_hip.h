@@ -255,6 +255,46 @@ int exon_hip_stream_finish(exon_hip_stream* s, int64_t* counts, double* sums);
 int exon_hip_stream_finish_arrow(exon_hip_stream* s, struct ArrowArray* out, struct ArrowSchema* out_schema);
 int exon_hip_stream_close(exon_hip_stream* s);
 
+/* ---- scan: native decoders + device-layout array builders (host memory) --------------------------------
+ * FileOpener::open + BatchReader::read_batch of the reference
+ * (exon-core/src/datasources/vcf/file_opener/unindex_file_opener.rs:48-92, exon-vcf/src/async_batch_stream.rs:80-109,
+ *  exon-bam/src/batch_reader.rs:44-108, exon-fastq/src/batch_reader.rs:63-82, exon-fasta/src/batch_reader.rs:72-99).
+ * Batches are Arrow struct arrays in the DEVICE LAYOUT (dictionary<int32,utf8> keys, u8 mapq) ready for
+ * exon_hip_stream_push.  Column order:
+ *   VCF   0 chrom(dict) 1 pos:i64? 2 qual:f32? 3 filter(dict of ';'-joined lists, "" = []) [4 info.<F>:f32?]
+ *   BAM   0 flag:i32 1 mapping_quality:u8? 2 reference(dict)? 3 start:i64? 4 end:i64?
+ *   FASTQ 0 name 1 description? 2 sequence 3 quality_scores      FASTA 0 id 1 description? 2 sequence
+ * CPU-only: no ctx needed; errors are reported through exon_hip_last_error(NULL). */
+#define EXON_HIP_FORMAT_VCF 1
+#define EXON_HIP_FORMAT_BAM 2
+#define EXON_HIP_FORMAT_FASTQ 3
+#define EXON_HIP_FORMAT_FASTA 4
+#define EXON_HIP_COMPRESSION_AUTO 0 /* sniff the gzip/BGZF magic */
+#define EXON_HIP_COMPRESSION_NONE 1
+#define EXON_HIP_COMPRESSION_GZIP 2
+
+typedef struct exon_hip_scan exon_hip_scan;
+typedef struct exon_hip_scan_options {
+  int32_t format;       /* EXON_HIP_FORMAT_* */
+  int32_t compression;  /* EXON_HIP_COMPRESSION_* */
+  int64_t batch_size;   /* 0 = 8192 (exon-common/src/lib.rs:27) */
+  const char* info_field; /* VCF: typed INFO field to extract (exon.vcf_parse_info), NULL = none */
+  const char* region;     /* pushed-down vcf_region_filter / bam_region_filter ("chr1:1-100"), NULL = none */
+} exon_hip_scan_options;
+
+int exon_hip_scan_open(const char* path, const exon_hip_scan_options* options, exon_hip_scan** out);
+int exon_hip_scan_schema(exon_hip_scan* scan, struct ArrowSchema* out);
+/* 0 = a batch was written to *out (caller releases or moves it); 1 = end of stream; <0 = error */
+int exon_hip_scan_next(exon_hip_scan* scan, struct ArrowArray* out);
+/* dictionary of a dict-encoded column (VCF 0/3, BAM 2): current size, and id of `name` (interned if new) */
+int exon_hip_scan_dictionary_size(exon_hip_scan* scan, int32_t column, int32_t* size);
+int exon_hip_scan_dictionary_intern(exon_hip_scan* scan, int32_t column, const char* name, int32_t* id);
+int exon_hip_scan_dictionary_value(exon_hip_scan* scan, int32_t column, int32_t id, const char** name);
+int exon_hip_scan_rows(exon_hip_scan* scan, int64_t* rows_emitted);
+int exon_hip_scan_close(exon_hip_scan* scan);
+/* GpuFilterAggExec::execute in one call: pull every batch of `scan` and push it through `stream`. */
+int exon_hip_stream_consume_scan(exon_hip_stream* s, exon_hip_scan* scan, int64_t* rows);
+
 #ifdef __cplusplus
 }
 #endif

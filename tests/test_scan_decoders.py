@@ -1,0 +1,151 @@
+"""CPU tests of the native decoders / device-layout builders (exon_hip_scan_*) against the oracle's independent
+Python decoders and the reference's pinned fixture values.  No GPU needed: decoding is host code."""
+import os
+
+import numpy as np
+import pytest
+
+import exon_amd
+from oracle import decode
+
+FX = os.path.join(os.path.dirname(__file__), "golden", "ref_fixtures")
+
+
+def fx(*p):
+    return os.path.join(FX, *p)
+
+
+def collect(scan):
+    import pyarrow as pa
+    batches = list(scan)
+    return pa.concat_arrays([b for b in batches]) if len(batches) > 1 else batches[0]
+
+
+@pytest.mark.parametrize("name,comp", [("index.vcf", None), ("index.vcf.gz", None), ("index.vcf.gz", "gzip")])
+def test_vcf_scan_matches_oracle_decoder(name, comp):
+    s = exon_amd.Scan(fx("vcf", name), "vcf", compression=comp, batch_size=100)
+    batches = list(s)
+    assert sum(len(b) for b in batches) == 621 and len(batches) == 7  # slt/vcf-select-tests.slt:47-55
+    v = decode.decode_vcf(fx("vcf", name))
+    chrom = [x for b in batches for x in b.field(0).to_pylist()]
+    pos = [x for b in batches for x in b.field(1).to_pylist()]
+    qual = [x for b in batches for x in b.field(2).to_pylist()]
+    filt = [x for b in batches for x in b.field(3).to_pylist()]
+    assert chrom == v["chrom"] and pos == v["pos"]
+    assert [None if q is None else np.float32(q) for q in qual] == v["qual"]
+    assert [f.split(";") if f else [] for f in filt] == v["filter"]
+    assert s.dictionary(0)[:len(v["contigs"])] == v["contigs"]  # ids follow header contig order
+
+
+def test_vcf_scan_info_field_and_missing():
+    s = exon_amd.Scan(fx("vcf", "index.vcf"), "vcf", info_field="MQ0F")
+    vals = [x for b in s for x in b.field(4).to_pylist()]
+    v = decode.decode_vcf(fx("vcf", "index.vcf"))
+    want = [None if (i is None or "MQ0F" not in i or i["MQ0F"] == ".") else float(np.float32(i["MQ0F"])) for i in v["info"]]
+    assert vals == want
+    with pytest.raises(exon_amd.ExonHipError, match="not declared"):
+        exon_amd.Scan(fx("vcf", "index.vcf"), "vcf", info_field="NOPE")
+    with pytest.raises(exon_amd.ExonHipError, match="Number=1"):
+        exon_amd.Scan(fx("vcf", "index.vcf"), "vcf", info_field="I16")  # Number=16 -> List in the reference
+
+
+@pytest.mark.parametrize("region,want", [("1", 191), ("2", 219), ("10", 211), ("a", 0), ("1:9999921", 189),
+                                         ("1:9999919-9999921", 3)])
+def test_vcf_pushed_down_region_filter(region, want):
+    """IndexedAsyncBatchStream::filter semantics (slt/vcf-indexed-tests.slt:22-43)."""
+    s = exon_amd.Scan(fx("vcf", "index.vcf.gz"), "vcf", region=region)
+    got = sum(len(b) for b in s)
+    v = decode.decode_vcf(fx("vcf", "index.vcf.gz"))
+    name, a, b = exon_amd.parse_region(region)
+    ref = sum(1 for c, p in zip(v["chrom"], v["pos"]) if c == name and p is not None and a <= p <= (b or 2**62))
+    assert got == ref
+    if want is not None and region in ("1", "2", "10", "a"):
+        assert got == want
+
+
+def test_biobear_vcf_region():
+    assert sum(len(b) for b in exon_amd.Scan(fx("biobear-vcf", "vcf_file.vcf.gz"), "vcf", region="1")) == 11
+    assert sum(len(b) for b in exon_amd.Scan(fx("biobear-vcf", "vcf_file.vcf.gz"), "vcf", region="1000")) == 0
+
+
+def test_bam_scan_matches_oracle_decoder():
+    s = exon_amd.Scan(fx("bam", "test.bam"), "bam", batch_size=25)
+    batches = list(s)
+    assert sum(len(b) for b in batches) == 61  # slt/bam-select-tests.slt:56-59
+    refs, recs = decode.decode_bam(fx("bam", "test.bam"))
+    assert s.dictionary(2) == [n for n, _ in refs]
+    flag = [x for b in batches for x in b.field(0).to_pylist()]
+    mapq = [x for b in batches for x in b.field(1).to_pylist()]
+    ref = [x for b in batches for x in b.field(2).to_pylist()]
+    start = [x for b in batches for x in b.field(3).to_pylist()]
+    end = [x for b in batches for x in b.field(4).to_pylist()]
+    assert flag == [r["flag"] for r in recs] and mapq == [r["mapq"] for r in recs]
+    assert ref == [None if r["ref_id"] is None else refs[r["ref_id"]][0] for r in recs]
+    assert start == [r["start"] for r in recs] and end == [r["end"] for r in recs]
+    # first row pinned by slt/bam-select-tests.slt:9-12
+    assert (flag[0], ref[0], start[0], end[0], mapq[0]) == (83, "chr1", 12203704, 12217173, None)
+
+
+def test_bam_pushed_down_region_filter():
+    """SemiLazyRecord::intersects (slt/bam-indexed-select-tests.slt:16-19: 7 hits)."""
+    assert sum(len(b) for b in exon_amd.Scan(fx("bam", "test.bam"), "bam", region="chr1:1-12209145")) == 7
+    assert sum(len(b) for b in exon_amd.Scan(fx("bam", "test.bam"), "bam", region="chr2")) == 0
+    assert sum(len(b) for b in exon_amd.Scan(fx("bam", "test.bam"), "bam", region="nope:1-5")) == 0
+
+
+@pytest.mark.parametrize("name", ["test.fastq", "test.fastq.gz", "test_bgzip.fastq.gz"])
+def test_fastq_scan(name):
+    rows = [r for b in exon_amd.Scan(fx("fastq", name), "fastq") for r in b.to_pylist()]
+    want = decode.decode_fastq(fx("fastq", name))
+    assert rows == want and len(rows) == 2  # slt/fastq-scan-test.slt:51-83
+    assert rows[0]["description"] == "This is a description" and rows[1]["description"] is None
+
+
+@pytest.mark.parametrize("name", ["test.fasta", "test.fasta.gz"])
+def test_fasta_scan(name):
+    rows = [r for b in exon_amd.Scan(fx("fasta", name), "fasta") for r in b.to_pylist()]
+    assert rows == decode.decode_fasta(fx("fasta", name)) and len(rows) == 2  # slt/fasta-scan-tests.slt:31-34
+
+
+def test_fasta_multiline_and_batching(tmp_path):
+    p = tmp_path / "big.fasta"
+    with open(p, "w") as f:
+        for i in range(1000):
+            f.write(f">seq{i} record {i}\n" + ("ACGT" * 15 + "\n") * (1 + i % 3))
+    s = exon_amd.Scan(p, "fasta", batch_size=128)
+    batches = list(s)
+    assert sum(len(b) for b in batches) == 1000 and len(batches) == 8 and s.rows() == 1000
+    rows = [r for b in batches for r in b.to_pylist()]
+    assert rows[999] == {"id": "seq999", "description": "record 999", "sequence": "ACGT" * 15 * (1 + 999 % 3)}
+
+
+def test_vcf_text_round_trip_of_synthetic_columns(tmp_path, oracle):
+    """Ties the synthetic config-4 columns to the decode path: columns -> VCF text -> native decoder -> same columns."""
+    n = 20_000
+    af, av, q, qv, fid = oracle.gen_c4(4, 0, n)
+    avb = np.unpackbits(av, bitorder="little")[:n].astype(bool)
+    qvb = np.unpackbits(qv, bitorder="little")[:n].astype(bool)
+    filters = oracle.c4_filters()
+    p = tmp_path / "syn.vcf"
+    with open(p, "w") as f:
+        f.write("##fileformat=VCFv4.3\n##contig=<ID=1>\n")
+        f.write('##INFO=<ID=AF,Number=1,Type=Float,Description="Allele frequency">\n')
+        f.write('##INFO=<ID=DP,Number=1,Type=Integer,Description="Depth">\n')
+        for x in ("q10", "s50"):
+            f.write(f'##FILTER=<ID={x},Description="{x}">\n')
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+        for i in range(n):
+            info = f"DP=7;AF={np.format_float_scientific(af[i], unique=True)}" if avb[i] else "DP=7"
+            qual = repr(float(q[i])) if qvb[i] else "."
+            f.write(f"1\t{i + 1}\t.\tA\tC\t{qual}\t{filters[fid[i]] or '.'}\t{info}\n")
+    s = exon_amd.Scan(p, "vcf", info_field="AF")
+    batches = list(s)
+    got_af = np.concatenate([np.nan_to_num(b.field(4).to_numpy(zero_copy_only=False).astype(np.float32)) for b in batches])
+    got_av = np.concatenate([b.field(4).is_valid().to_numpy(zero_copy_only=False) for b in batches])
+    got_q = np.concatenate([np.nan_to_num(b.field(2).to_numpy(zero_copy_only=False).astype(np.float32)) for b in batches])
+    got_qv = np.concatenate([b.field(2).is_valid().to_numpy(zero_copy_only=False) for b in batches])
+    got_f = [x for b in batches for x in b.field(3).to_pylist()]
+    assert np.array_equal(got_av, avb) and np.array_equal(got_qv, qvb)
+    assert np.array_equal(got_af[avb].view(np.uint32), af[avb].view(np.uint32))   # correctly rounded f32 parse
+    assert np.array_equal(got_q[qvb].view(np.uint32), q[qvb].view(np.uint32))
+    assert got_f == [filters[i] for i in fid]
