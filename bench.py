@@ -25,7 +25,7 @@ import torch  # noqa: E402  (imported before the HIP library so both share one H
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-BYTES_PER_ROW = {"c4": 12.25, "c2": 12.0, "c3": 9.25}  # algorithmic bytes/row, SURVEY.md section 8(d)
+BYTES_PER_ROW = {"c4": 12.25, "c2": 12.0, "c3": 9.25, "c5": 104.0}  # algorithmic bytes/row, SURVEY.md section 8(d)
 SEED = {"c2": 2, "c3": 3, "c4": 4, "c5": 5}
 
 
@@ -35,7 +35,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=float, default=1e9, help="rows per GPU (weak scaling)")
-    ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3"])
+    ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3", "c5"])
     ap.add_argument("--cpu-sample-rows", type=float, default=128e6)
     ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -80,6 +80,24 @@ class Workload:
             self.R = 25
             self.counts = torch.zeros(self.R + 1, dtype=torch.int64, device=dev)
             self.sums = None
+        elif kind == "c5":
+            # FASTQ quality strings, L = 100.  Arrow Utf8 has int32 offsets, so the shard is a sequence of
+            # batches of <= 16 Mi reads (1.6 GB of quality bytes each); the histogram state accumulates.
+            self.L = 100
+            self.batch = min(rows, 16 << 20)
+            self.bytes = torch.empty(rows * self.L + 64, dtype=torch.uint8, device=dev)
+            self.off = torch.empty(self.batch + 1, dtype=torch.int32, device=dev)
+            for b0 in range(0, rows, self.batch):
+                nb_ = min(self.batch, rows - b0)
+                ctx._check(lib.exon_hip_gen_c5(h, s, SEED["c5"], row0 + b0, row0 + b0 + nb_, self.L, self.off.data_ptr(),
+                                               self.bytes.data_ptr() + b0 * self.L))
+            if rows % self.batch:  # offsets of a full batch (the last generator call wrote a shorter one)
+                ctx._check(lib.exon_hip_gen_c5(h, s, SEED["c5"], 0, self.batch, self.L, self.off.data_ptr(),
+                                               self.bytes.data_ptr()))
+                ctx._check(lib.exon_hip_gen_c5(h, s, SEED["c5"], row0, row0 + self.batch, self.L, self.off.data_ptr(),
+                                               self.bytes.data_ptr()))
+            self.counts = torch.zeros(self.L * 256, dtype=torch.int64, device=dev)
+            self.sums = None
         torch.cuda.synchronize()
 
     def launch(self):
@@ -100,6 +118,11 @@ class Workload:
             c0, c1 = _col(self.chrom.data_ptr(), None, None, n), _col(self.pos.data_ptr(), None, None, n)
             ctx._check(ctx.lib.exon_hip_region_count(ctx.h, s, C.byref(c0), C.byref(c1), n, 6, 50000000, 100000000,
                                                      self.counts.data_ptr()))
+        elif self.kind == "c5":
+            for b0 in range(0, n, self.batch):
+                nb_ = min(self.batch, n - b0)
+                c0 = _col(self.bytes.data_ptr() + b0 * self.L, None, self.off.data_ptr(), nb_)
+                ctx._check(ctx.lib.exon_hip_qual_pos_hist(ctx.h, s, C.byref(c0), nb_, self.L, self.counts.data_ptr()))
         else:
             c0 = _col(self.flag.data_ptr(), None, None, n)
             c1 = _col(self.mapq.data_ptr(), self.mv.data_ptr(), None, n)
@@ -127,6 +150,13 @@ def cpu_baseline(kind, sample_rows, n_total, reps):
             r, t = orc.c2_region_count(c, p, orc.c2_contigs(), "7:50000000-100000000")
             secs.append(t.seconds_exec), mat.append(t.seconds_materialize)
         out = (np.array([r], np.int64), None)
+    elif kind == "c5":
+        n = min(n, 8_000_000)
+        off, data = orc.gen_c5(SEED["c5"], 0, n, 100)
+        for _ in range(reps):
+            hcpu, t = orc.c5_qual_pos_hist(off, data, 100)
+            secs.append(t.seconds_exec), mat.append(t.seconds_materialize)
+        out = (hcpu.reshape(-1), None)
     else:
         f, mq, mv, ref, rv = orc.gen_c3(SEED["c3"], 0, n)
         for _ in range(reps):
@@ -212,7 +242,8 @@ def main():
             "vs_baseline": None, "dtype": "f32 in / f64 sums / i64 counts", "data": "synthetic",
             "config": {"workload": {"c4": "config 4: 1B-row synthetic VCF, WHERE info.AF > 0.01, AVG(qual), COUNT(*) GROUP BY filter",
                                     "c2": "config 2: synthetic VCF, chrom='7' AND pos in [5e7,1e8], COUNT(*)",
-                                    "c3": "config 3: synthetic BAM, flag&1284=0 AND mapq>=30, COUNT(*) GROUP BY reference"}[a.workload],
+                                    "c3": "config 3: synthetic BAM, flag&1284=0 AND mapq>=30, COUNT(*) GROUP BY reference",
+                                    "c5": "config 5: synthetic FASTQ (L=100), per-position 256-bin quality histogram; rows = reads"}[a.workload],
                        "rows_per_gpu": rows, "rows_total": n_total, "sharding": "one contiguous row range (file split) per GPU",
                        "reduce": "RCCL all-reduce of partial state" if world > 1 else "none (1 GPU)",
                        "bytes_per_row": bpr},
@@ -231,6 +262,8 @@ def main():
                 pass
         if not a.no_cpu_baseline and world == 1:
             sample = int(min(a.cpu_sample_rows, rows))
+            if a.workload == "c5":
+                sample = min(sample, 8_000_000)
             base, (oc, os_) = cpu_baseline(a.workload, sample, n_total, a.cpu_reps)
             out["cpu_baseline"] = base
             # parity gate: the GPU path over the same sample rows must reproduce the oracle

@@ -51,8 +51,9 @@ int get_workspace(exon_hip_ctx* ctx, hipStream_t s, size_t words, Workspace* out
   std::lock_guard<std::mutex> g(ctx->mu);
   Workspace& ws = ctx->workspaces[s];
   if (!ws.status) {
-    if (hipMalloc(&ws.status, sizeof(int)) != hipSuccess) return EXON_HIP_ENOMEM;
-    hipMemset(ws.status, 0, sizeof(int));
+    // status[0] = device error word, status[1..7] = scratch flags (K5 path selection)
+    if (hipMalloc(&ws.status, 8 * sizeof(int)) != hipSuccess) return EXON_HIP_ENOMEM;
+    hipMemset(ws.status, 0, 8 * sizeof(int));
   }
   if (ws.partial_capacity < words) {
     if (ws.partials) {

@@ -593,71 +593,237 @@ hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Wo
 //   quality_scores_to_list (char - 33; exon-core/src/udfs/sequence/quality_score_string_to_list.rs:83-86)
 //   + unnest with ordinality + GROUP BY (position, score) COUNT(*), reported on the raw byte
 //   (Phred = bin - 33).  104 B/read at L = 100: i32 offset + L quality bytes.
-//   One 1024-thread workgroup per CU owns a u32[LT][257] LDS histogram (row padded by one bank so that
-//   consecutive positions with similar bytes fall on different banks); positions >= LT fall back to
-//   global atomics.  v1: one wave per read, lanes stride over positions.
+//
+//   The limiter is LDS atomic throughput, i.e. bank conflicts (profiles/r1_tuning.md, tools/tune_k5.hip).
+//   One 1024-thread workgroup per CU owns a u32 LDS histogram of the ASCII half of the byte range (quality
+//   strings are Phred+33 <= 126; a byte >= 128 goes straight to a global atomic).  Three paths, chosen ON THE
+//   DEVICE from `k5_scan_offsets` (no host round trip):
+//     A  uniform read length L, L % 4 == 0, 64 <= L <= 256: every lane loads one dword (4 consecutive positions);
+//        the histogram is byte-major h[byte][perm(p)], perm(p) = (p & 3) * LP/4 + (p >> 2), so for a fixed
+//        byte-in-dword the 64 lanes of a wave hit consecutive banks whatever the data is: conflict-free.
+//     B  any other uniform L <= 310: 16-byte chunk per lane, h[p][129] (+1 pad: bank = p + byte).
+//     G  ragged reads: one wave per read.
+//   Paths A/B never touch the offsets buffer again (they use L), so HBM traffic is 4 + L bytes per read.
 // ------------------------------------------------------------------------------------------------
 constexpr int K5_THREADS = 1024;
-constexpr int K5_LT_MAX = 144;  // 144 * 257 * 4 = 148,032 B of the 160 KiB LDS
-constexpr int K5_STRIDE = 257;
+constexpr int K5_PT_MAX = 310;  // positions kept in LDS by paths B/G: 310 * 129 * 4 B = 159,960 B
+constexpr int K5_JA = 16, K5_JB = 4;
 
-__global__ __launch_bounds__(K5_THREADS) void k5_qual_pos_hist_main(const int32_t* __restrict__ off,
-                                                                    const uint8_t* __restrict__ bytes,
-                                                                    int64_t n_reads, int lmax, int lt,
-                                                                    unsigned long long* __restrict__ partials,
-                                                                    unsigned long long* __restrict__ d_hist,
-                                                                    int* __restrict__ status) {
-  extern __shared__ unsigned k5_h[];  // [lt][257]
-  for (int i = threadIdx.x; i < lt * K5_STRIDE; i += K5_THREADS) k5_h[i] = 0;
+// flags[0] = 1 when read lengths differ (or a read is longer than lmax -> status bit 8)
+__global__ __launch_bounds__(256) void k5_scan_offsets(const int32_t* __restrict__ off, int64_t n, int lmax,
+                                                      int* __restrict__ flags, int* __restrict__ status) {
+  const int L = off[1] - off[0];
+  bool ragged = false, too_long = false;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int len = off[i + 1] - off[i];
+    ragged |= (len != L);
+    too_long |= (len > lmax);
+  }
+  if (__any(ragged) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1);
+  if (__any(too_long) && (threadIdx.x & 63) == 0) atomicOr(status, 8);
+}
+
+enum { K5_PATH_A128 = 0, K5_PATH_A256 = 1, K5_PATH_B = 2, K5_PATH_G = 3 };
+__device__ __forceinline__ int k5_pick_path(const int32_t* off, const uint8_t* bytes, int lmax, const int* flags) {
+  if (flags[0]) return K5_PATH_G;
+  const int L = off[1] - off[0];
+  if (L < 1 || L > lmax) return K5_PATH_G;
+  const uintptr_t base = reinterpret_cast<uintptr_t>(bytes + off[0]);
+  if ((L & 3) == 0 && L >= 64 && L <= 256 && (base & 3) == 0) return L <= 128 ? K5_PATH_A128 : K5_PATH_A256;
+  if (L <= K5_PT_MAX && (base & 15) == 0) return K5_PATH_B;
+  return K5_PATH_G;
+}
+
+// partial record of a workgroup: u64 [pt][128] (position-major, ASCII half); bytes >= 128 never reach it
+template <int LP>
+__global__ __launch_bounds__(K5_THREADS) void k5_path_a(const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes,
+                                                        int64_t n, int lmax, int pt, const int* __restrict__ flags,
+                                                        unsigned long long* __restrict__ partials,
+                                                        unsigned long long* __restrict__ d_hist) {
+  if (k5_pick_path(off, bytes, lmax, flags) != (LP == 128 ? K5_PATH_A128 : K5_PATH_A256)) return;
+  extern __shared__ unsigned k5_h[];  // [128][LP]
+  constexpr int Q = LP / 4, J = K5_JA;
+  for (int i = threadIdx.x; i < 128 * LP; i += K5_THREADS) k5_h[i] = 0;
+  __syncthreads();
+  const int L = off[1] - off[0];
+  const unsigned* src = reinterpret_cast<const unsigned*>(bytes + off[0]);
+  const int64_t nd = n * (int64_t)(L / 4), S = (int64_t)gridDim.x * K5_THREADS;
+  const int64_t c0 = (int64_t)blockIdx.x * K5_THREADS + threadIdx.x;
+  int p0 = (int)((4 * c0) % L);
+  const int pS = (int)((4 * S) % L);
+  auto one = [&](unsigned d, int p) {
+    if (__builtin_expect((d & 0x80808080u) != 0, 0)) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned b = (d >> (8 * k)) & 0xFF;
+        if (b >= 128) atomicAdd(&d_hist[(size_t)(p + k) * 256 + b], 1ull);
+        else atomicAdd(k5_h + b * LP + k * Q + (p >> 2), 1u);
+      }
+      return;
+    }
+    unsigned* base = k5_h + (p >> 2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) atomicAdd(base + ((d >> (8 * k)) & 0xFF) * LP + k * Q, 1u);
+  };
+  int64_t c = c0;
+  for (; c + (J - 1) * S < nd; c += J * S) {
+    unsigned v[J];
+    int pj[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      v[j] = __builtin_nontemporal_load(src + c + j * S);
+      pj[j] = p0;
+      p0 += pS;
+      p0 = p0 >= L ? p0 - L : p0;
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) one(v[j], pj[j]);
+  }
+  for (; c < nd; c += S) {
+    one(src[c], p0);
+    p0 += pS;
+    p0 = p0 >= L ? p0 - L : p0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < pt * 128; i += K5_THREADS) {
+    const int p = i >> 7, b = i & 127;
+    partials[(size_t)blockIdx.x * pt * 128 + i] = p < L ? k5_h[b * LP + (p & 3) * Q + (p >> 2)] : 0u;
+  }
+}
+
+__global__ __launch_bounds__(K5_THREADS) void k5_path_b(const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes,
+                                                        int64_t n, int lmax, int pt, const int* __restrict__ flags,
+                                                        unsigned long long* __restrict__ partials,
+                                                        unsigned long long* __restrict__ d_hist) {
+  if (k5_pick_path(off, bytes, lmax, flags) != K5_PATH_B) return;
+  extern __shared__ unsigned k5_h[];  // [pt][129]
+  constexpr int J = K5_JB;
+  for (int i = threadIdx.x; i < pt * 129; i += K5_THREADS) k5_h[i] = 0;
+  __syncthreads();
+  const int L = off[1] - off[0];
+  const uint8_t* src = bytes + off[0];
+  const int64_t total = n * (int64_t)L, nch = total / 16, S = (int64_t)gridDim.x * K5_THREADS;
+  const int64_t c0 = (int64_t)blockIdx.x * K5_THREADS + threadIdx.x;
+  int p0 = (int)((16 * c0) % L);
+  const int pS = (int)((16 * S) % L);
+  auto add = [&](int p, unsigned b) {
+    if (b >= 128) atomicAdd(&d_hist[(size_t)p * 256 + b], 1ull);
+    else atomicAdd(&k5_h[p * 129 + b], 1u);
+  };
+  auto chunk = [&](v4i_t v, int p) {
+    const unsigned d[4] = {(unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      int pk = p + k;
+      while (pk >= L) pk -= L;  // L may be < 16
+      add(pk, (d[k >> 2] >> (8 * (k & 3))) & 0xFF);
+    }
+  };
+  int64_t c = c0;
+  for (; c + (J - 1) * S < nch; c += J * S) {
+    v4i_t v[J];
+    int pj[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      v[j] = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(src + 16 * (c + j * S)));
+      pj[j] = p0;
+      p0 += pS;
+      p0 = p0 >= L ? p0 - L : p0;
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) chunk(v[j], pj[j]);
+  }
+  for (; c < nch; c += S) {
+    chunk(*reinterpret_cast<const v4i_t*>(src + 16 * c), p0);
+    p0 += pS;
+    p0 = p0 >= L ? p0 - L : p0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)  // < 16 trailing bytes
+    for (int64_t e = nch * 16; e < total; ++e) add((int)(e % L), src[e]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < pt * 128; i += K5_THREADS)
+    partials[(size_t)blockIdx.x * pt * 128 + i] = k5_h[(i >> 7) * 129 + (i & 127)];
+}
+
+__global__ __launch_bounds__(K5_THREADS) void k5_path_g(const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes,
+                                                        int64_t n, int lmax, int pt, const int* __restrict__ flags,
+                                                        unsigned long long* __restrict__ partials,
+                                                        unsigned long long* __restrict__ d_hist) {
+  if (k5_pick_path(off, bytes, lmax, flags) != K5_PATH_G) return;
+  extern __shared__ unsigned k5_h[];  // [pt][129]
+  for (int i = threadIdx.x; i < pt * 129; i += K5_THREADS) k5_h[i] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int64_t gwave = (int64_t)blockIdx.x * (K5_THREADS / 64) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (K5_THREADS / 64);
-  unsigned bad = 0;
-  for (int64_t r = gwave; r < n_reads; r += nwaves) {
-    const int32_t o0 = off[r], o1 = off[r + 1];
-    int len = o1 - o0;
-    if (len > lmax) {
-      bad = 1;
-      len = lmax;
-    }
+  for (int64_t r = gwave; r < n; r += nwaves) {
+    const int32_t o0 = off[r];
+    int len = off[r + 1] - o0;
+    if (len > lmax) len = lmax;  // flagged by k5_scan_offsets
     for (int p = lane; p < len; p += 64) {
       const unsigned b = bytes[(int64_t)o0 + p];
-      if (p < lt) atomicAdd(&k5_h[p * K5_STRIDE + b], 1u);
+      if (p < pt && b < 128) atomicAdd(&k5_h[p * 129 + b], 1u);
       else atomicAdd(&d_hist[(size_t)p * 256 + b], 1ull);
     }
   }
-  if (bad) atomicOr(status, 8);
   __syncthreads();
-  const int W = lt * 256;
-  for (int i = threadIdx.x; i < W; i += K5_THREADS)
-    partials[(size_t)blockIdx.x * W + i] = k5_h[(i >> 8) * K5_STRIDE + (i & 255)];
+  for (int i = threadIdx.x; i < pt * 128; i += K5_THREADS)
+    partials[(size_t)blockIdx.x * pt * 128 + i] = k5_h[(i >> 7) * 129 + (i & 127)];
 }
 
-static int k5_lt(int lmax) { return lmax < K5_LT_MAX ? lmax : K5_LT_MAX; }
-size_t k5_partial_words(const LaunchCfg& cfg, int lmax) { return (size_t)cfg.compute_units * k5_lt(lmax) * 256; }
+// d_hist[p][b] += sum over workgroups of partial[wg][p][b]  (p < pt, b < 128)
+__global__ __launch_bounds__(256) void k5_finalize(const unsigned long long* __restrict__ partials, int nblocks, int pt,
+                                                   unsigned long long* __restrict__ d_hist) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= pt * 128) return;
+  const size_t W = (size_t)pt * 128;
+  unsigned long long acc = 0;
+  int b = 0;
+  for (; b + 4 <= nblocks; b += 4)
+    acc += partials[(size_t)b * W + i] + partials[(size_t)(b + 1) * W + i] + partials[(size_t)(b + 2) * W + i] +
+           partials[(size_t)(b + 3) * W + i];
+  for (; b < nblocks; ++b) acc += partials[(size_t)b * W + i];
+  if (acc) d_hist[(size_t)(i >> 7) * 256 + (i & 127)] += acc;
+}
+
+static int k5_pt(int lmax) { return lmax < K5_PT_MAX ? lmax : K5_PT_MAX; }
+size_t k5_partial_words(const LaunchCfg& cfg, int lmax) { return (size_t)cfg.compute_units * k5_pt(lmax) * 128; }
 
 hipError_t launch_qual_pos_hist(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* offsets,
                                 const uint8_t* bytes, int64_t n_reads, int lmax, int64_t* d_hist) {
   if (n_reads <= 0) return hipSuccess;
   if (lmax < 1) return hipErrorInvalidValue;
-  const int lt = k5_lt(lmax);
-  int64_t g = cfg.compute_units;
-  const int64_t need = (n_reads + (K5_THREADS / 64) - 1) / (K5_THREADS / 64);
-  if (g > need) g = need;
-  const int grid = (int)g;
-  const size_t lds = (size_t)lt * K5_STRIDE * sizeof(unsigned);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_qual_pos_hist_main),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int pt = k5_pt(lmax);
+  const int grid = cfg.compute_units;
+  int* flags = ws.status + 1;
+  unsigned long long* hist = reinterpret_cast<unsigned long long*>(d_hist);
+  hipError_t e = hipMemsetAsync(flags, 0, sizeof(int), s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k5_qual_pos_hist_main, dim3(grid), dim3(K5_THREADS), lds, s, offsets, bytes, n_reads, lmax, lt,
-                     ws.partials, reinterpret_cast<unsigned long long*>(d_hist), ws.status);
+  int sgrid = (int)std::min<int64_t>((n_reads + 255) / 256, (int64_t)cfg.compute_units * 8);
+  hipLaunchKernelGGL(k5_scan_offsets, dim3(sgrid), dim3(256), 0, s, offsets, n_reads, lmax, flags, ws.status);
+  const size_t lds_a128 = 128 * 128 * 4, lds_a256 = 128 * 256 * 4, lds_bg = (size_t)pt * 129 * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_path_a<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a128)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_path_a<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a256)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_path_b), hipFuncAttributeMaxDynamicSharedMemorySize, K5_PT_MAX * 129 * 4)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_path_g), hipFuncAttributeMaxDynamicSharedMemorySize, K5_PT_MAX * 129 * 4)) != hipSuccess) return e;
+    attr_done = true;
+  }
+  // exactly one of the four launches does work (device-side choice); the others return immediately
+  if (lmax >= 64) {
+    hipLaunchKernelGGL(k5_path_a<128>, dim3(grid), dim3(K5_THREADS), lds_a128, s, offsets, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
+    if (lmax > 128) hipLaunchKernelGGL(k5_path_a<256>, dim3(grid), dim3(K5_THREADS), lds_a256, s, offsets, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
+  }
+  hipLaunchKernelGGL(k5_path_b, dim3(grid), dim3(K5_THREADS), lds_bg, s, offsets, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
+  hipLaunchKernelGGL(k5_path_g, dim3(grid), dim3(K5_THREADS), lds_bg, s, offsets, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  const int W = lt * 256;
-  return run_finalize(s, ws, grid, W, W, d_hist, nullptr);
+  hipLaunchKernelGGL(k5_finalize, dim3((pt * 128 + 255) / 256), dim3(256), 0, s, ws.partials, grid, pt, hist);
+  return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------------
 // Synthetic inputs (DESIGN.md "Synthetic inputs"): counter-based, bit-identical to oracle/exon_oracle.c
 // ------------------------------------------------------------------------------------------------

@@ -160,7 +160,9 @@ def test_k4_bad_group_id_is_reported(ctx):
 
 
 # ---- K5 -----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n_reads,L", [(1, 100), (1000, 100), (200_000, 100), (5000, 151), (3000, 36)])
+@pytest.mark.parametrize("n_reads,L", [(1, 100), (1000, 100), (200_000, 100), (5000, 151), (3000, 36), (70_000, 128),
+                                       (40_000, 256), (30_000, 250), (9000, 301), (2000, 400), (50_000, 64), (100_001, 8),
+                                       (77, 3), (1_000_000, 100)])
 def test_k5_qual_pos_hist(ctx, oracle, n_reads, L):
     off, data = ctx.gen_c5(5, 0, n_reads, L)
     d = ctx.zeros(np.int64, L * 256)
@@ -169,6 +171,30 @@ def test_k5_qual_pos_hist(ctx, oracle, n_reads, L):
     hoff, hdata = oracle.gen_c5(5, 0, n_reads, L)
     want, _ = oracle.c5_qual_pos_hist(hoff, hdata, L)
     assert np.array_equal(d.to_host().reshape(L, 256), want)
+
+
+def test_k5_non_ascii_bytes_and_unaligned_base(ctx, oracle):
+    """bytes >= 128 take the global-atomic slow path; a sliced batch (offsets[0] != 0, unaligned) must still be exact."""
+    rng = np.random.default_rng(5)
+    n, L = 20_000, 100
+    data = rng.integers(33, 75, n * L + 7, dtype=np.uint8)
+    data[rng.integers(0, n * L, 500)] = rng.integers(128, 256, 500)
+    for shift in (0, 4, 7):
+        off = (np.arange(n + 1, dtype=np.int32) * L + shift).astype(np.int32)
+        d = ctx.zeros(np.int64, L * 256)
+        ctx.qual_pos_hist(ctx.to_device(off), ctx.to_device(np.concatenate([data, np.zeros(64, np.uint8)])), n, L, d)
+        ctx.sync()
+        want, _ = oracle.c5_qual_pos_hist(off, data, L)
+        assert np.array_equal(d.to_host().reshape(L, 256), want), shift
+
+
+def test_k5_read_longer_than_lmax_is_reported(ctx):
+    import exon_amd
+    off, data = ctx.gen_c5(5, 0, 1000, 100)
+    d = ctx.zeros(np.int64, 50 * 256)
+    ctx.qual_pos_hist(off, data, 1000, 50, d)
+    with pytest.raises(exon_amd.ExonHipError):
+        ctx.sync()
 
 
 def test_k5_ragged_reads(ctx, oracle):
