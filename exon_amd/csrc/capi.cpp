@@ -272,9 +272,8 @@ int exon_hip_cmp_avg_by_group(exon_hip_ctx* ctx, void* stream, const exon_hip_co
   if (n < 0) return fail(ctx, EXON_HIP_EINVAL, "n < 0");
   if (cmp_op < EXON_HIP_GT || cmp_op > EXON_HIP_NE) return fail(ctx, EXON_HIP_EINVAL, "bad cmp_op %d", cmp_op);
   if (n_groups < 1) return fail(ctx, EXON_HIP_EINVAL, "n_groups must be >= 1");
-  if (n_groups > EXON_HIP_MAX_REG_GROUPS)
-    return fail(ctx, EXON_HIP_EUNSUPPORTED, "n_groups %d > %d (LDS group table not built yet)", n_groups,
-                EXON_HIP_MAX_REG_GROUPS);
+  if (n_groups > EXON_HIP_MAX_GROUPS)
+    return fail(ctx, EXON_HIP_EUNSUPPORTED, "n_groups %d > %d", n_groups, EXON_HIP_MAX_GROUPS);
   if (group_id && group_id->validity)
     return fail(ctx, EXON_HIP_EUNSUPPORTED, "nullable group ids: encode NULL as its own dictionary id");
   int rc;

@@ -507,7 +507,7 @@ void exec_select(Session& se, Parser& ps) {
     for (const auto& f : src.files) {
       ScanGuard g; open_scan(src, f, pr.info_field.c_str(), "", &g);
       StreamGuard sg;
-      const int G = EXON_HIP_MAX_REG_GROUPS;
+      const int G = 256;  // distinct FILTER lists supported per file (8 in registers + LDS overflow table)
       exon_hip_plan_desc d; memset(&d, 0, sizeof d);
       d.kind = EXON_HIP_PLAN_CMP_AVG_BY_GROUP; d.n_groups = G; d.cmp_op = pr.cmp_op; d.threshold = pr.literal;
       d.columns[0] = 4; d.columns[1] = 2; d.columns[2] = 3;
@@ -516,7 +516,7 @@ void exec_select(Session& se, Parser& ps) {
       ck(ctx, exon_hip_stream_consume_scan(sg.s, g.s, nullptr));
       int32_t nd = 0;
       ck(nullptr, exon_hip_scan_dictionary_size(g.s, 3, &nd));
-      if (nd > G) throw Err("more than " + std::to_string(G) + " distinct FILTER lists: LDS group table not built yet");
+      if (nd > G) throw Err("more than " + std::to_string(G) + " distinct FILTER lists in one file");
       std::vector<int64_t> c((size_t)2 * G);
       std::vector<double> s((size_t)G);
       ck(ctx, exon_hip_stream_finish(sg.s, c.data(), s.data()));

@@ -31,6 +31,9 @@ struct ShapeBig {
 struct ShapeSmall {
   static constexpr int THREADS = 256, J = 2;
 };
+struct ShapeBigJ2 {  // register-hungry variants (K4 with an LDS overflow table) that would spill at J = 4
+  static constexpr int THREADS = 1024, J = 2;
+};
 template <typename S>
 struct ShapeOf {
   static constexpr int WAVES = S::THREADS / 64;
@@ -375,11 +378,15 @@ hipError_t launch_flag_mapq_group_count(hipStream_t s, const LaunchCfg& cfg, con
 //   COUNT(*) / COUNT(y) in two u64 registers of 8 x 8-bit fields (a row adds 1 << 8g), spilled to
 //   per-group u32 registers before a field can overflow; sums in G f64 registers.
 // ------------------------------------------------------------------------------------------------
-template <int G, typename S>
+//   More than 8 groups (OVF): ids 0..7 stay in registers (dictionary ids are handed out in order of first
+//   appearance, so the frequent keys are the early ones); ids 8..NG-1 go to a per-workgroup LDS table through LDS
+//   atomics (ds_add_f64 / ds_add_u32), taken only by the lanes that need it.  Counts stay exact; the f64 sums of the
+//   overflow groups depend on the LDS atomic order (~1e-16 relative run to run).
+template <int G, typename S, bool OVF>
 __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
     const float* __restrict__ x, const uint8_t* __restrict__ xvalid, const float* __restrict__ y,
     const uint8_t* __restrict__ yvalid, const int32_t* __restrict__ gid, int64_t n, int32_t klo, int32_t khi,
-    int32_t negate, unsigned long long* __restrict__ partials, int* __restrict__ status) {
+    int32_t negate, int32_t NG, unsigned long long* __restrict__ partials, int* __restrict__ status) {
   constexpr int J = S::J, THREADS = S::THREADS, WAVES = ShapeOf<S>::WAVES, WT = ShapeOf<S>::WAVE_TILE,
                 TILE = ShapeOf<S>::TILE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -393,13 +400,39 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
   }
   unsigned long long prow = 0, pnn = 0;  // packed 8-bit counters, field g
   unsigned gmax = 0;
+  // overflow table (OVF only): [sum f64 | cnn u32 | crow u32] x (NG - 8)
+  extern __shared__ double k4_ovf[];
+  const int NO = OVF ? NG - 8 : 0;
+  double* ovf_sum = k4_ovf;
+  unsigned* ovf_cnn = reinterpret_cast<unsigned*>(k4_ovf + NO);
+  unsigned* ovf_crow = ovf_cnn + NO;
+  if (OVF) {
+    for (int i = threadIdx.x; i < NO; i += THREADS) {
+      ovf_sum[i] = 0.0;
+      ovf_cnn[i] = 0;
+      ovf_crow[i] = 0;
+    }
+    __syncthreads();
+  }
 
   auto row = [&](float xf, float yf, int32_t g, unsigned xv, unsigned yv) {
     const int32_t kx = f32_key(xf);
     const unsigned inr = unsigned(kx >= klo) & unsigned(kx <= khi);
-    const unsigned pass = xv & (inr ^ (unsigned)negate);
-    const unsigned yq = pass & yv;
+    unsigned pass = xv & (inr ^ (unsigned)negate);
+    unsigned yq = pass & yv;
     gmax = max(gmax, (unsigned)g);  // ids are validated over ALL rows (cheaper than a per-row flag)
+    if (OVF) {
+      if (pass && (unsigned)g >= 8u && (unsigned)g < (unsigned)NG) {
+        atomicAdd(&ovf_crow[g - 8], 1u);
+        if (yq) {
+          atomicAdd(&ovf_cnn[g - 8], 1u);
+          atomicAdd(&ovf_sum[g - 8], (double)yf);
+        }
+      }
+      const unsigned in_regs = unsigned((unsigned)g < 8u);
+      pass &= in_regs;
+      yq &= in_regs;
+    }
     const unsigned sh = ((unsigned)g & 7u) * 8u;
     prow += (unsigned long long)pass << sh;
     pnn += (unsigned long long)yq << sh;
@@ -459,9 +492,10 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
   }
   spill();
 
-  if (gmax >= (unsigned)G) atomicOr(status, 4);
+  if (gmax >= (unsigned)(OVF ? NG : G)) atomicOr(status, 4);
 
-  // per-workgroup record: [cnn[G]] [crow[G]] [sum[G]]  (fixed-order reductions)
+  // per-workgroup record: [cnn[NG]] [crow[NG]] [sum[NG]]  (fixed-order reductions for the register groups)
+  const int RG = OVF ? NG : G;  // groups per record
   __shared__ unsigned long long red[WAVES][3 * G];
 #pragma unroll
   for (int k = 0; k < G; ++k) {
@@ -488,21 +522,35 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
       for (int w = 0; w < WAVES; ++w) t += __longlong_as_double((long long)red[w][v]);
       out = (unsigned long long)__double_as_longlong(t);
     }
-    partials[(size_t)blockIdx.x * (3 * G) + v] = out;
+    const int kind = v / G, g = v - kind * G;  // 0: cnn, 1: crow, 2: sum
+    partials[(size_t)blockIdx.x * (3 * RG) + kind * RG + g] = out;
+  }
+  if (OVF) {
+    for (int i = threadIdx.x; i < NO; i += THREADS) {
+      unsigned long long* rec = partials + (size_t)blockIdx.x * (3 * RG);
+      rec[8 + i] = ovf_cnn[i];
+      rec[RG + 8 + i] = ovf_crow[i];
+      rec[2 * RG + 8 + i] = (unsigned long long)__double_as_longlong(ovf_sum[i]);
+    }
   }
 }
 
 size_t k4_partial_words(const LaunchCfg& cfg, int n_groups) { return (size_t)max_grid(cfg) * 3 * (size_t)n_groups; }
 
-template <int G, typename S>
+template <int G, typename S, bool OVF>
 static hipError_t k4_launch(hipStream_t s, const LaunchCfg& cfg, int* grid_out, const Workspace& ws, const float* x,
                             const uint8_t* xv, const float* y, const uint8_t* yv, const int32_t* gid, int64_t n,
-                            int32_t klo, int32_t khi, int32_t negate) {
-  static const int resident = resident_blocks(k4_cmp_avg_by_group_main<G, S>, S::THREADS, 0);
-  const int grid = grid_for<S>(cfg, n, resident);
+                            int32_t klo, int32_t khi, int32_t negate, int32_t n_groups) {
+  const size_t lds = OVF ? (size_t)(n_groups - 8) * 16 : 0;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k4_cmp_avg_by_group_main<G, S, OVF>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  const int grid = grid_for<S>(cfg, n, resident_blocks(k4_cmp_avg_by_group_main<G, S, OVF>, S::THREADS, lds));
   *grid_out = grid;
-  hipLaunchKernelGGL((k4_cmp_avg_by_group_main<G, S>), dim3(grid), dim3(S::THREADS), 0, s, x, xv, y, yv, gid, n, klo,
-                     khi, negate, ws.partials, ws.status);
+  hipLaunchKernelGGL((k4_cmp_avg_by_group_main<G, S, OVF>), dim3(grid), dim3(S::THREADS), lds, s, x, xv, y, yv, gid, n,
+                     klo, khi, negate, n_groups, ws.partials, ws.status);
   return hipGetLastError();
 }
 
@@ -560,7 +608,7 @@ hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Wo
                                    int64_t n, double thr, int cmp_op, int n_groups, int64_t* d_counts,
                                    double* d_sums) {
   if (n <= 0) return hipSuccess;
-  if (n_groups < 1 || n_groups > 8) return hipErrorInvalidValue;
+  if (n_groups < 1 || n_groups > 4096) return hipErrorInvalidValue;
   int32_t klo, khi, negate;
   if (!cmp_to_key_range(thr, cmp_op, &klo, &khi, &negate)) return hipErrorInvalidValue;
   const bool big = use_big_shape(cfg, n);
@@ -569,8 +617,8 @@ hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Wo
   switch (n_groups) {
 #define EXON_K4_CASE(GG)                                                                                             \
   case GG:                                                                                                           \
-    e = big ? k4_launch<GG, ShapeBig>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate)           \
-            : k4_launch<GG, ShapeSmall>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate);        \
+    e = big ? k4_launch<GG, ShapeBig, false>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, GG)   \
+            : k4_launch<GG, ShapeSmall, false>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, GG); \
     break;
     EXON_K4_CASE(1)
     EXON_K4_CASE(2)
@@ -581,7 +629,10 @@ hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Wo
     EXON_K4_CASE(7)
     EXON_K4_CASE(8)
 #undef EXON_K4_CASE
-    default: return hipErrorInvalidValue;
+    default:  // > 8 groups: 8 in registers + LDS overflow table
+      e = big ? k4_launch<8, ShapeBigJ2, true>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, n_groups)
+              : k4_launch<8, ShapeSmall, true>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, n_groups);
+      break;
   }
   if (e != hipSuccess) return e;
   // per-workgroup records are [cnn[G]] [crow[G]] [sum[G]] = the state layout [counts[2G]] [sums[G]]
@@ -602,7 +653,7 @@ hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Wo
 //        the histogram is byte-major h[byte][perm(p)], perm(p) = (p & 3) * LP/4 + (p >> 2), so for a fixed
 //        byte-in-dword the 64 lanes of a wave hit consecutive banks whatever the data is: conflict-free.
 //     B  any other uniform L <= 310: 16-byte chunk per lane, h[p][129] (+1 pad: bank = p + byte).
-//     G  ragged reads: one wave per read.
+//     G  ragged reads: one wave per read (same kernel and layout as B).
 //   Paths A/B never touch the offsets buffer again (they use L), so HBM traffic is 4 + L bytes per read.
 // ------------------------------------------------------------------------------------------------
 constexpr int K5_THREADS = 1024;
@@ -691,79 +742,66 @@ __global__ __launch_bounds__(K5_THREADS) void k5_path_a(const int32_t* __restric
   }
 }
 
-__global__ __launch_bounds__(K5_THREADS) void k5_path_b(const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes,
-                                                        int64_t n, int lmax, int pt, const int* __restrict__ flags,
-                                                        unsigned long long* __restrict__ partials,
-                                                        unsigned long long* __restrict__ d_hist) {
-  if (k5_pick_path(off, bytes, lmax, flags) != K5_PATH_B) return;
+__global__ __launch_bounds__(K5_THREADS) void k5_path_bg(const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes,
+                                                         int64_t n, int lmax, int pt, const int* __restrict__ flags,
+                                                         unsigned long long* __restrict__ partials,
+                                                         unsigned long long* __restrict__ d_hist) {
+  const int path = k5_pick_path(off, bytes, lmax, flags);
+  if (path != K5_PATH_B && path != K5_PATH_G) return;
   extern __shared__ unsigned k5_h[];  // [pt][129]
-  constexpr int J = K5_JB;
   for (int i = threadIdx.x; i < pt * 129; i += K5_THREADS) k5_h[i] = 0;
   __syncthreads();
-  const int L = off[1] - off[0];
-  const uint8_t* src = bytes + off[0];
-  const int64_t total = n * (int64_t)L, nch = total / 16, S = (int64_t)gridDim.x * K5_THREADS;
-  const int64_t c0 = (int64_t)blockIdx.x * K5_THREADS + threadIdx.x;
-  int p0 = (int)((16 * c0) % L);
-  const int pS = (int)((16 * S) % L);
   auto add = [&](int p, unsigned b) {
-    if (b >= 128) atomicAdd(&d_hist[(size_t)p * 256 + b], 1ull);
-    else atomicAdd(&k5_h[p * 129 + b], 1u);
+    if (p < pt && b < 128) atomicAdd(&k5_h[p * 129 + b], 1u);
+    else atomicAdd(&d_hist[(size_t)p * 256 + b], 1ull);
   };
-  auto chunk = [&](v4i_t v, int p) {
-    const unsigned d[4] = {(unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w};
+  if (path == K5_PATH_B) {  // uniform read length: 16-byte chunk per lane
+    constexpr int J = K5_JB;
+    const int L = off[1] - off[0];
+    const uint8_t* src = bytes + off[0];
+    const int64_t total = n * (int64_t)L, nch = total / 16, S = (int64_t)gridDim.x * K5_THREADS;
+    const int64_t c0 = (int64_t)blockIdx.x * K5_THREADS + threadIdx.x;
+    int p0 = (int)((16 * c0) % L);
+    const int pS = (int)((16 * S) % L);
+    auto chunk = [&](v4i_t v, int p) {
+      const unsigned d[4] = {(unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w};
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      int pk = p + k;
-      while (pk >= L) pk -= L;  // L may be < 16
-      add(pk, (d[k >> 2] >> (8 * (k & 3))) & 0xFF);
+      for (int k = 0; k < 16; ++k) {
+        int pk = p + k;
+        while (pk >= L) pk -= L;  // L may be < 16
+        add(pk, (d[k >> 2] >> (8 * (k & 3))) & 0xFF);
+      }
+    };
+    int64_t c = c0;
+    for (; c + (J - 1) * S < nch; c += J * S) {
+      v4i_t v[J];
+      int pj[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        v[j] = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(src + 16 * (c + j * S)));
+        pj[j] = p0;
+        p0 += pS;
+        p0 = p0 >= L ? p0 - L : p0;
+      }
+#pragma unroll
+      for (int j = 0; j < J; ++j) chunk(v[j], pj[j]);
     }
-  };
-  int64_t c = c0;
-  for (; c + (J - 1) * S < nch; c += J * S) {
-    v4i_t v[J];
-    int pj[J];
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      v[j] = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(src + 16 * (c + j * S)));
-      pj[j] = p0;
+    for (; c < nch; c += S) {
+      chunk(*reinterpret_cast<const v4i_t*>(src + 16 * c), p0);
       p0 += pS;
       p0 = p0 >= L ? p0 - L : p0;
     }
-#pragma unroll
-    for (int j = 0; j < J; ++j) chunk(v[j], pj[j]);
-  }
-  for (; c < nch; c += S) {
-    chunk(*reinterpret_cast<const v4i_t*>(src + 16 * c), p0);
-    p0 += pS;
-    p0 = p0 >= L ? p0 - L : p0;
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0)  // < 16 trailing bytes
-    for (int64_t e = nch * 16; e < total; ++e) add((int)(e % L), src[e]);
-  __syncthreads();
-  for (int i = threadIdx.x; i < pt * 128; i += K5_THREADS)
-    partials[(size_t)blockIdx.x * pt * 128 + i] = k5_h[(i >> 7) * 129 + (i & 127)];
-}
-
-__global__ __launch_bounds__(K5_THREADS) void k5_path_g(const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes,
-                                                        int64_t n, int lmax, int pt, const int* __restrict__ flags,
-                                                        unsigned long long* __restrict__ partials,
-                                                        unsigned long long* __restrict__ d_hist) {
-  if (k5_pick_path(off, bytes, lmax, flags) != K5_PATH_G) return;
-  extern __shared__ unsigned k5_h[];  // [pt][129]
-  for (int i = threadIdx.x; i < pt * 129; i += K5_THREADS) k5_h[i] = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int64_t gwave = (int64_t)blockIdx.x * (K5_THREADS / 64) + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * (K5_THREADS / 64);
-  for (int64_t r = gwave; r < n; r += nwaves) {
-    const int32_t o0 = off[r];
-    int len = off[r + 1] - o0;
-    if (len > lmax) len = lmax;  // flagged by k5_scan_offsets
-    for (int p = lane; p < len; p += 64) {
-      const unsigned b = bytes[(int64_t)o0 + p];
-      if (p < pt && b < 128) atomicAdd(&k5_h[p * 129 + b], 1u);
-      else atomicAdd(&d_hist[(size_t)p * 256 + b], 1ull);
+    if (blockIdx.x == 0 && threadIdx.x == 0)  // < 16 trailing bytes
+      for (int64_t e = nch * 16; e < total; ++e) add((int)(e % L), src[e]);
+  } else {  // ragged reads: one wave per read, lanes stride over positions
+    const int lane = threadIdx.x & 63;
+    const int64_t gwave = (int64_t)blockIdx.x * (K5_THREADS / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (K5_THREADS / 64);
+    for (int64_t r = gwave; r < n; r += nwaves) {
+      const int32_t o0 = off[r];
+      int len = off[r + 1] - o0;
+      if (len > lmax) len = lmax;  // flagged by k5_scan_offsets
+      for (int p = lane; p < len; p += 64) add(p, bytes[(int64_t)o0 + p]);
     }
   }
   __syncthreads();
@@ -771,19 +809,26 @@ __global__ __launch_bounds__(K5_THREADS) void k5_path_g(const int32_t* __restric
     partials[(size_t)blockIdx.x * pt * 128 + i] = k5_h[(i >> 7) * 129 + (i & 127)];
 }
 
-// d_hist[p][b] += sum over workgroups of partial[wg][p][b]  (p < pt, b < 128)
+// d_hist[p][b] += sum over workgroups of partial[wg][p][b]  (p < pt, b < 128).  blockIdx.y splits the workgroup
+// range 8 ways (integer adds commute, so the segment sums are merged with atomics: still bit-exact).
 __global__ __launch_bounds__(256) void k5_finalize(const unsigned long long* __restrict__ partials, int nblocks, int pt,
                                                    unsigned long long* __restrict__ d_hist) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= pt * 128) return;
   const size_t W = (size_t)pt * 128;
+  const int per = (nblocks + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
   unsigned long long acc = 0;
-  int b = 0;
-  for (; b + 4 <= nblocks; b += 4)
-    acc += partials[(size_t)b * W + i] + partials[(size_t)(b + 1) * W + i] + partials[(size_t)(b + 2) * W + i] +
-           partials[(size_t)(b + 3) * W + i];
-  for (; b < nblocks; ++b) acc += partials[(size_t)b * W + i];
-  if (acc) d_hist[(size_t)(i >> 7) * 256 + (i & 127)] += acc;
+  int b = b0;
+  for (; b + 8 <= b1; b += 8) {
+    unsigned long long t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = partials[(size_t)(b + k) * W + i];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += t[k];
+  }
+  for (; b < b1; ++b) acc += partials[(size_t)b * W + i];
+  if (acc) atomicAdd(&d_hist[(size_t)(i >> 7) * 256 + (i & 127)], acc);
 }
 
 static int k5_pt(int lmax) { return lmax < K5_PT_MAX ? lmax : K5_PT_MAX; }
@@ -806,20 +851,18 @@ hipError_t launch_qual_pos_hist(hipStream_t s, const LaunchCfg& cfg, const Works
   if (!attr_done) {
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_path_a<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a128)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_path_a<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a256)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_path_b), hipFuncAttributeMaxDynamicSharedMemorySize, K5_PT_MAX * 129 * 4)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_path_g), hipFuncAttributeMaxDynamicSharedMemorySize, K5_PT_MAX * 129 * 4)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_path_bg), hipFuncAttributeMaxDynamicSharedMemorySize, K5_PT_MAX * 129 * 4)) != hipSuccess) return e;
     attr_done = true;
   }
-  // exactly one of the four launches does work (device-side choice); the others return immediately
+  // exactly one of the (up to three) launches does work (device-side choice); the others return immediately
   if (lmax >= 64) {
     hipLaunchKernelGGL(k5_path_a<128>, dim3(grid), dim3(K5_THREADS), lds_a128, s, offsets, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
     if (lmax > 128) hipLaunchKernelGGL(k5_path_a<256>, dim3(grid), dim3(K5_THREADS), lds_a256, s, offsets, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
   }
-  hipLaunchKernelGGL(k5_path_b, dim3(grid), dim3(K5_THREADS), lds_bg, s, offsets, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
-  hipLaunchKernelGGL(k5_path_g, dim3(grid), dim3(K5_THREADS), lds_bg, s, offsets, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
+  hipLaunchKernelGGL(k5_path_bg, dim3(grid), dim3(K5_THREADS), lds_bg, s, offsets, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k5_finalize, dim3((pt * 128 + 255) / 256), dim3(256), 0, s, ws.partials, grid, pt, hist);
+  hipLaunchKernelGGL(k5_finalize, dim3((pt * 128 + 255) / 256, 8), dim3(256), 0, s, ws.partials, grid, pt, hist);
   return hipGetLastError();
 }
 

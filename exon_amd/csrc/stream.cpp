@@ -252,9 +252,9 @@ int exon_hip_plan_create(exon_hip_ctx* ctx, const exon_hip_plan_desc* desc, exon
     case EXON_HIP_PLAN_CMP_AVG_BY_GROUP:
       p->n_cols = 3;
       p->cols[0].elem = p->cols[1].elem = p->cols[2].elem = 4;
-      if (desc->n_groups < 1 || desc->n_groups > EXON_HIP_MAX_REG_GROUPS) {
+      if (desc->n_groups < 1 || desc->n_groups > EXON_HIP_MAX_GROUPS) {
         delete p;
-        return fail(ctx, EXON_HIP_EUNSUPPORTED, "n_groups %d outside [1, %d]", desc->n_groups, EXON_HIP_MAX_REG_GROUPS);
+        return fail(ctx, EXON_HIP_EUNSUPPORTED, "n_groups %d outside [1, %d]", desc->n_groups, EXON_HIP_MAX_GROUPS);
       }
       if (desc->cmp_op < EXON_HIP_GT || desc->cmp_op > EXON_HIP_NE) {
         delete p;

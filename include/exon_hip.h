@@ -148,7 +148,7 @@ typedef struct exon_hip_column {
 #define EXON_HIP_EQ 4
 #define EXON_HIP_NE 5
 
-#define EXON_HIP_MAX_REG_GROUPS 8   /* group tables kept in registers */
+#define EXON_HIP_MAX_REG_GROUPS 8   /* group ids kept in registers; ids 8.. use an LDS overflow table */
 #define EXON_HIP_MAX_GROUPS 4096    /* group tables kept in LDS */
 #define EXON_HIP_REGION_OPEN_END INT64_MAX
 

@@ -137,6 +137,24 @@ def test_k4_special_values_total_order(ctx, oracle):
             assert np.allclose(ds.to_host(), s, rtol=RTOL, atol=0), (op, thr)
 
 
+@pytest.mark.parametrize("G,n", [(9, 50_000), (40, 3_000_000), (300, 20_000_000), (4096, 500_000)])
+def test_k4_more_than_8_groups_uses_lds_overflow(ctx, oracle, G, n):
+    """ids 0..7 in registers, ids >= 8 through the LDS overflow table; skewed keys (most rows in the first ids)."""
+    rng = np.random.default_rng(G)
+    af, av, q, qv, _ = oracle.gen_c4(4, 0, n)
+    fid = np.minimum((rng.exponential(3.0, n)).astype(np.int32), G - 1)
+    fid[rng.integers(0, n, 1000)] = rng.integers(0, G, 1000)  # make sure the tail ids occur
+    names = [f"f{i}" for i in range(G)]
+    dc, ds = ctx.zeros(np.int64, 2 * G), ctx.zeros(np.float64, G)
+    ctx.cmp_avg_by_group(ctx.to_device(af), ctx.to_device(av), ctx.to_device(q), ctx.to_device(qv), ctx.to_device(fid),
+                         n, 0.01, ">", G, dc, ds)
+    ctx.sync()
+    s, cn, cr, _ = oracle.c4_cmp_avg_by_group(af, av, q, qv, fid, names, 0.01, ">")
+    got = dc.to_host()
+    assert np.array_equal(got[:G], cn) and np.array_equal(got[G:], cr)
+    assert np.allclose(ds.to_host(), s, rtol=RTOL, atol=0)
+
+
 def test_k4_deterministic(ctx):
     n = 3_000_000
     af, av, q, qv, fid = ctx.gen_c4(9, 0, n)
