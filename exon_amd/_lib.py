@@ -74,7 +74,7 @@ class PlanDesc(C.Structure):
 
 class ScanOptions(C.Structure):
     _fields_ = [("format", C.c_int32), ("compression", C.c_int32), ("batch_size", C.c_int64),
-                ("info_field", C.c_char_p), ("region", C.c_char_p)]
+                ("info_field", C.c_char_p), ("region", C.c_char_p), ("use_index", C.c_int32), ("reserved", C.c_int32)]
 
 
 FORMATS = {"vcf": 1, "bam": 2, "fastq": 3, "fasta": 4}
@@ -135,6 +135,9 @@ SIGNATURES = {
     "exon_hip_scan_dictionary_value": (C.c_int, [_vp, _i32, _i32, C.POINTER(C.c_char_p)]),
     "exon_hip_scan_rows": (C.c_int, [_vp, C.POINTER(_i64)]),
     "exon_hip_scan_close": (C.c_int, [_vp]),
+    "exon_hip_scan_index_chunks": (C.c_int, [_vp, C.POINTER(_i32)]),
+    "exon_hip_index_query": (C.c_int, [C.c_char_p, _i32, C.c_char_p, _i32, _i64, _i64, C.POINTER(_u64), C.POINTER(_u64),
+                                       _i32, C.POINTER(_i32)]),
     "exon_hip_stream_consume_scan": (C.c_int, [_vp, _vp, C.POINTER(_i64)]),
 }
 

@@ -256,6 +256,9 @@ void open_scan(const Source& src, const std::string& file, const char* info_fiel
   o.compression = src.compression;
   o.info_field = info_field;
   o.region = region.empty() ? nullptr : region.c_str();
+  // INDEXED_* tables / *_indexed_scan: plan BGZF chunks from <file>.tbi / <file>.bai
+  // (exon-core/src/datasources/indexed_file/indexed_bgzf_file.rs:129-155)
+  o.use_index = (src.indexed && !region.empty()) ? 1 : 0;
   ck(nullptr, exon_hip_scan_open(file.c_str(), &o, &g->s));
 }
 

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "arrow_build.h"
+#include "bgzf_index.h"
 #include "io.h"
 #include "region.h"
 
@@ -31,6 +32,44 @@ constexpr int64_t DEFAULT_BATCH_SIZE = 8 * 1024;  // exon-common/src/lib.rs:27
 struct RegionFilter {  // pushed-down vcf_region_filter / bam_region_filter (per-record interval hit)
   bool active = false;
   Region region;
+  bool use_index = false;  // plan BGZF chunks from <file>.tbi / <file>.bai instead of scanning the whole file
+};
+
+// Where records come from: the whole (possibly compressed) stream, or the BGZF chunks an index query returned
+// (one PartitionedFile per chunk in the reference: indexed_file/indexed_bgzf_file.rs:129-155).
+struct RecordSource {
+  virtual ~RecordSource() = default;
+  virtual bool next_record() = 0;  // false = no further record may start
+  virtual bool read_line(std::string* line) = 0;
+  virtual bool read_exact(uint8_t* dst, size_t n) = 0;
+};
+struct StreamSource : RecordSource {
+  BufReader r;
+  StreamSource(const std::string& path, Compression c) : r(path, c) {}
+  bool next_record() override { return true; }
+  bool read_line(std::string* line) override { return r.read_line(line); }
+  bool read_exact(uint8_t* dst, size_t n) override { return r.read_exact(dst, n); }
+};
+struct ChunkSource : RecordSource {
+  BgzfReader r;
+  std::vector<Chunk> chunks;
+  size_t ci = 0;
+  bool in_chunk = false;
+  ChunkSource(const std::string& path, std::vector<Chunk> c) : r(path), chunks(std::move(c)) {}
+  bool next_record() override {
+    for (;;) {
+      if (ci >= chunks.size()) return false;
+      if (!in_chunk) {
+        r.seek(chunks[ci].start);
+        in_chunk = true;
+      }
+      if (r.tell() < chunks[ci].end) return true;  // a record may start anywhere before the chunk's end
+      ++ci;
+      in_chunk = false;
+    }
+  }
+  bool read_line(std::string* line) override { return r.read_line(line); }
+  bool read_exact(uint8_t* dst, size_t n) override { return r.read_exact(dst, n); }
 };
 
 // ======================================================================================================
@@ -173,10 +212,11 @@ class VCFArrayBuilder : public ExonArrayBuilder {
 
 class VCFBatchReader {
  public:
-  VCFBatchReader(const std::string& path, Compression c, VCFConfig cfg) : r_(path, c), cfg_(std::move(cfg)) {
+  VCFBatchReader(const std::string& path, Compression c, VCFConfig cfg) : cfg_(std::move(cfg)) {
+    r_.reset(new StreamSource(path, c));
     // header (noodles `read_header`): meta lines '##', then '#CHROM ...'
     std::string line;
-    while (r_.read_line(&line)) {
+    while (r_->read_line(&line)) {
       if (line.rfind("##", 0) == 0) {
         if (line.rfind("##contig=", 0) == 0) header.contigs.push_back(header_attr(line, "ID"));
         else if (line.rfind("##FILTER=", 0) == 0) header.filters.push_back(header_attr(line, "ID"));
@@ -210,6 +250,18 @@ class VCFBatchReader {
         }
       if (!found) throw std::runtime_error("INFO field " + cfg_.info_field + " is not declared in the header");
     }
+    if (cfg_.filter.active && cfg_.filter.use_index) {
+      // get_byte_range_for_file (indexed_bgzf_file.rs:52-112): tabix names -> id -> index.query -> chunks
+      const BinningIndex idx = read_tabix(path + ".tbi");
+      int id = -1;
+      for (size_t i = 0; i < idx.names.size(); ++i)
+        if (idx.names[i] == cfg_.filter.region.name) id = (int)i;
+      std::vector<Chunk> chunks;
+      if (id >= 0) chunks = query_index(idx, id, cfg_.filter.region.start, cfg_.filter.region.end);
+      n_chunks = (int)chunks.size();
+      has_pending_ = false;
+      r_.reset(new ChunkSource(path, std::move(chunks)));
+    }
   }
 
   // AsyncBatchStream::read_batch (exon-vcf/src/async_batch_stream.rs:80-109); with a region filter the
@@ -222,10 +274,10 @@ class VCFBatchReader {
       if (has_pending_) {
         line.swap(pending_);
         has_pending_ = false;
-      } else if (!r_.read_line(&line)) {
+      } else if (!r_->next_record() || !r_->read_line(&line)) {
         break;
       }
-      if (line.empty()) continue;
+      if (line.empty() || line[0] == '#') continue;
       if (cfg_.filter.active && !region_hit(line)) continue;
       b.append(line);
     }
@@ -244,6 +296,7 @@ class VCFBatchReader {
 
   VCFHeader header;
   Dictionary chrom_dict, filter_dict;
+  int n_chunks = -1;  // index chunks planned (-1: not an indexed scan)
 
  private:
   bool region_hit(const std::string& line) const {
@@ -259,7 +312,7 @@ class VCFBatchReader {
     }
     return pos >= 1 && pos >= rg.start && pos <= rg.end;
   }
-  BufReader r_;
+  std::unique_ptr<RecordSource> r_;
   VCFConfig cfg_;
   std::string pending_;
   bool has_pending_ = false;
@@ -308,17 +361,18 @@ class BAMArrayBuilder : public ExonArrayBuilder {
 
 class BAMBatchReader {
  public:
-  BAMBatchReader(const std::string& path, BAMConfig cfg) : r_(path, Compression::Gzip), cfg_(std::move(cfg)) {
+  BAMBatchReader(const std::string& path, BAMConfig cfg) : cfg_(std::move(cfg)) {
+    r_.reset(new StreamSource(path, Compression::Gzip));
     uint8_t magic[4];
-    if (!r_.read_exact(magic, 4) || memcmp(magic, "BAM\1", 4) != 0) throw std::runtime_error("not a BAM file: " + path);
+    if (!r_->read_exact(magic, 4) || memcmp(magic, "BAM\1", 4) != 0) throw std::runtime_error("not a BAM file: " + path);
     const int32_t l_text = read_i32();
     header_text.resize((size_t)l_text);
-    if (l_text && !r_.read_exact(reinterpret_cast<uint8_t*>(&header_text[0]), (size_t)l_text)) throw std::runtime_error("truncated BAM header");
+    if (l_text && !r_->read_exact(reinterpret_cast<uint8_t*>(&header_text[0]), (size_t)l_text)) throw std::runtime_error("truncated BAM header");
     const int32_t n_ref = read_i32();
     for (int32_t i = 0; i < n_ref; ++i) {
       const int32_t l_name = read_i32();
       std::string name((size_t)l_name, '\0');
-      if (!r_.read_exact(reinterpret_cast<uint8_t*>(&name[0]), (size_t)l_name)) throw std::runtime_error("truncated BAM reference");
+      if (!r_->read_exact(reinterpret_cast<uint8_t*>(&name[0]), (size_t)l_name)) throw std::runtime_error("truncated BAM reference");
       name.resize(strlen(name.c_str()));
       ref_names.push_back(name);
       ref_lengths.push_back(read_i32());
@@ -327,6 +381,13 @@ class BAMBatchReader {
       region_ref_id_ = -2;
       for (size_t i = 0; i < ref_names.size(); ++i)
         if (ref_names[i] == cfg_.filter.region.name) region_ref_id_ = (int32_t)i;
+      if (cfg_.filter.use_index) {  // .bai -> chunks (indexed_bgzf_file.rs:87-107)
+        const BinningIndex idx = read_bai(path + ".bai");
+        std::vector<Chunk> chunks;
+        if (region_ref_id_ >= 0) chunks = query_index(idx, region_ref_id_, cfg_.filter.region.start, cfg_.filter.region.end);
+        n_chunks = (int)chunks.size();
+        r_.reset(new ChunkSource(path, std::move(chunks)));
+      }
     }
   }
 
@@ -335,12 +396,12 @@ class BAMBatchReader {
     std::vector<uint8_t> rec;
     while ((int64_t)b.len() < cfg_.batch_size) {
       uint8_t szb[4];
-      if (!r_.read_exact(szb, 4)) break;
+      if (!r_->next_record() || !r_->read_exact(szb, 4)) break;
       int32_t block;
       memcpy(&block, szb, 4);
       if (block < 32) throw std::runtime_error("corrupt BAM record");
       rec.resize((size_t)block);
-      if (!r_.read_exact(rec.data(), rec.size())) throw std::runtime_error("truncated BAM record");
+      if (!r_->read_exact(rec.data(), rec.size())) throw std::runtime_error("truncated BAM record");
       int32_t ref_id, pos;
       uint16_t n_cigar, flag;
       memcpy(&ref_id, &rec[0], 4);
@@ -382,16 +443,17 @@ class BAMBatchReader {
   std::string header_text;
   std::vector<std::string> ref_names;
   std::vector<int32_t> ref_lengths;
+  int n_chunks = -1;
 
  private:
   int32_t read_i32() {
     uint8_t b[4];
-    if (!r_.read_exact(b, 4)) throw std::runtime_error("truncated BAM file");
+    if (!r_->read_exact(b, 4)) throw std::runtime_error("truncated BAM file");
     int32_t v;
     memcpy(&v, b, 4);
     return v;
   }
-  BufReader r_;
+  std::unique_ptr<RecordSource> r_;
   BAMConfig cfg_;
   int32_t region_ref_id_ = -2;
 };

@@ -41,6 +41,7 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
       std::string err;
       if (!exon::parse_region(o->region, &rf.region, &err)) return fail(nullptr, EXON_HIP_EINVAL, "invalid region '%s': %s", o->region, err.c_str());
       rf.active = true;
+      rf.use_index = o->use_index != 0;
     }
     switch (o->format) {
       case EXON_HIP_FORMAT_VCF: {
@@ -143,6 +144,35 @@ int exon_hip_scan_rows(exon_hip_scan* s, int64_t* rows) {
   if (!s || !rows) return fail(nullptr, EXON_HIP_EINVAL, "NULL argument");
   *rows = s->rows;
   return EXON_HIP_OK;
+}
+
+int exon_hip_scan_index_chunks(exon_hip_scan* s, int32_t* n) {
+  if (!s || !n) return fail(nullptr, EXON_HIP_EINVAL, "NULL argument");
+  *n = s->vcf ? s->vcf->n_chunks : s->bam ? s->bam->n_chunks : -1;
+  return EXON_HIP_OK;
+}
+
+int exon_hip_index_query(const char* index_path, int32_t is_bai, const char* ref_name, int32_t ref_id, int64_t start,
+                         int64_t end, uint64_t* starts, uint64_t* ends, int32_t cap, int32_t* n_chunks) {
+  if (!index_path || !n_chunks) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_index_query: NULL argument");
+  try {
+    const exon::BinningIndex idx = is_bai ? exon::read_bai(index_path) : exon::read_tabix(index_path);
+    int id = ref_id;
+    if (!is_bai && ref_name) {
+      id = -1;
+      for (size_t i = 0; i < idx.names.size(); ++i)
+        if (idx.names[i] == ref_name) id = (int)i;
+    }
+    const std::vector<exon::Chunk> chunks = exon::query_index(idx, id, start, end);
+    *n_chunks = (int32_t)chunks.size();
+    for (int32_t i = 0; i < *n_chunks && i < cap; ++i) {
+      if (starts) starts[i] = chunks[(size_t)i].start;
+      if (ends) ends[i] = chunks[(size_t)i].end;
+    }
+    return EXON_HIP_OK;
+  } catch (const std::exception& e) {
+    return fail(nullptr, EXON_HIP_EINVAL, "%s", e.what());
+  }
 }
 
 int exon_hip_scan_close(exon_hip_scan* s) {

@@ -199,6 +199,23 @@ def parse_region(region):
     return name.value.decode(), a.value, (None if b.value == L.REGION_OPEN_END else b.value)
 
 
+def index_query(index_path, region=None, ref_id=None, start=1, end=None, is_bai=False):
+    """Region -> list of (start, end) BGZF virtual-position chunks from a .tbi / .bai index."""
+    lib = L.load()
+    name = None
+    if region is not None:
+        name, start, end = parse_region(region)
+    cap = 4096
+    st, en = (C.c_uint64 * cap)(), (C.c_uint64 * cap)()
+    n = C.c_int32()
+    rc = lib.exon_hip_index_query(str(index_path).encode(), 1 if is_bai else 0, name.encode() if name else None,
+                                  -1 if ref_id is None else ref_id, start, L.REGION_OPEN_END if end is None else end,
+                                  st, en, cap, C.byref(n))
+    if rc:
+        raise ExonHipError(rc, lib.exon_hip_last_error(None).decode())
+    return [(st[i], en[i]) for i in range(min(n.value, cap))]
+
+
 def regroup_files_by_size(sizes, target_groups):
     """Whole-file round-robin repartition; returns a list of groups of ORIGINAL file indexes."""
     lib = L.load()
@@ -218,11 +235,12 @@ class Scan:
     """Native decoder + device-layout array builder over one file (FileOpener::open + read_batch analogue).
     CPU-only: usable without a GPU."""
 
-    def __init__(self, path, fmt, compression=None, batch_size=0, info_field=None, region=None):
+    def __init__(self, path, fmt, compression=None, batch_size=0, info_field=None, region=None, use_index=False):
         self.lib = L.load()
         self.fmt = fmt
         opt = L.ScanOptions(L.FORMATS[fmt], L.COMPRESSION[compression], batch_size,
-                            info_field.encode() if info_field else None, region.encode() if region else None)
+                            info_field.encode() if info_field else None, region.encode() if region else None,
+                            1 if use_index else 0, 0)
         h = C.c_void_p()
         rc = self.lib.exon_hip_scan_open(str(path).encode(), C.byref(opt), C.byref(h))
         if rc:
@@ -278,6 +296,11 @@ class Scan:
     def rows(self):
         n = C.c_int64()
         self._check(self.lib.exon_hip_scan_rows(self.h, C.byref(n)))
+        return n.value
+
+    def index_chunks(self):
+        n = C.c_int32()
+        self._check(self.lib.exon_hip_scan_index_chunks(self.h, C.byref(n)))
         return n.value
 
     def close(self):

@@ -280,6 +280,8 @@ typedef struct exon_hip_scan_options {
   int64_t batch_size;   /* 0 = 8192 (exon-common/src/lib.rs:27) */
   const char* info_field; /* VCF: typed INFO field to extract (exon.vcf_parse_info), NULL = none */
   const char* region;     /* pushed-down vcf_region_filter / bam_region_filter ("chr1:1-100"), NULL = none */
+  int32_t use_index;      /* with `region`: plan BGZF chunks from <path>.tbi / <path>.bai (INDEXED_VCF / INDEXED_BAM) */
+  int32_t reserved;
 } exon_hip_scan_options;
 
 int exon_hip_scan_open(const char* path, const exon_hip_scan_options* options, exon_hip_scan** out);
@@ -291,6 +293,14 @@ int exon_hip_scan_dictionary_size(exon_hip_scan* scan, int32_t column, int32_t* 
 int exon_hip_scan_dictionary_intern(exon_hip_scan* scan, int32_t column, const char* name, int32_t* id);
 int exon_hip_scan_dictionary_value(exon_hip_scan* scan, int32_t column, int32_t id, const char** name);
 int exon_hip_scan_rows(exon_hip_scan* scan, int64_t* rows_emitted);
+/* number of index chunks an indexed scan planned (-1 when the scan is not index-driven) */
+int exon_hip_scan_index_chunks(exon_hip_scan* scan, int32_t* n_chunks);
+/* Region -> BGZF chunks from a tabix (.tbi, is_bai = 0; `ref_name` resolved through the index' names) or BAI
+ * (.bai, is_bai = 1; `ref_id` = BAM header order) index: get_byte_range_for_file
+ * (exon-core/src/datasources/indexed_file/indexed_bgzf_file.rs:52-112).  Virtual positions are written to
+ * starts/ends (up to `cap`); *n_chunks receives the full count. */
+int exon_hip_index_query(const char* index_path, int32_t is_bai, const char* ref_name, int32_t ref_id, int64_t start,
+                         int64_t end, uint64_t* starts, uint64_t* ends, int32_t cap, int32_t* n_chunks);
 int exon_hip_scan_close(exon_hip_scan* scan);
 /* GpuFilterAggExec::execute in one call: pull every batch of `scan` and push it through `stream`. */
 int exon_hip_stream_consume_scan(exon_hip_stream* s, exon_hip_scan* scan, int64_t* rows);

@@ -149,3 +149,40 @@ def test_vcf_text_round_trip_of_synthetic_columns(tmp_path, oracle):
     assert np.array_equal(got_af[avb].view(np.uint32), af[avb].view(np.uint32))   # correctly rounded f32 parse
     assert np.array_equal(got_q[qvb].view(np.uint32), q[qvb].view(np.uint32))
     assert got_f == [filters[i] for i in fid]
+
+
+# ---- index chunk planning -----------------------------------------------------------
+def test_tabix_chunk_kat():
+    """exon-core/src/datasources/indexed_file/indexed_bgzf_file.rs:167-187: region chr1:1-3388930 on
+    bigger-index/test.vcf.gz.tbi -> exactly one chunk, virtual positions 621346816 .. 3014113427456."""
+    chunks = exon_amd.index_query(fx("bigger-index.test.vcf.gz.tbi"), region="chr1:1-3388930")
+    assert chunks == [(621346816, 3014113427456)]
+    assert exon_amd.index_query(fx("bigger-index.test.vcf.gz.tbi"), region="nope") == []
+
+
+@pytest.mark.parametrize("region", ["1", "2", "10", "a", "1:9999921", "1:9999919-9999921", "2:1-5", "10:300000000"])
+def test_indexed_vcf_scan_equals_full_scan(region):
+    """The index only narrows what is read; the per-record filter defines the hits (slt/vcf-indexed-tests.slt)."""
+    full = exon_amd.Scan(fx("vcf", "index.vcf.gz"), "vcf", region=region)
+    idx = exon_amd.Scan(fx("vcf", "index.vcf.gz"), "vcf", region=region, use_index=True)
+    a = [r for b in full for r in b.to_pylist()]
+    b = [r for b in idx for r in b.to_pylist()]
+    assert a == b
+    assert idx.index_chunks() >= 0 and full.index_chunks() == -1
+
+
+def test_indexed_bam_scan_equals_full_scan():
+    for region, want in [("chr1:1-12209145", 7), ("chr1", None), ("chr2", 0), ("chr1:12209146-12209146", None)]:
+        a = [r for b in exon_amd.Scan(fx("bam", "test.bam"), "bam", region=region) for r in b.to_pylist()]
+        s = exon_amd.Scan(fx("bam", "test.bam"), "bam", region=region, use_index=True)
+        b = [r for bb in s for r in bb.to_pylist()]
+        assert a == b
+        if want is not None:
+            assert len(b) == want  # slt/bam-indexed-select-tests.slt:16-19
+
+
+def test_indexed_scan_without_index_file_fails(tmp_path):
+    import shutil
+    shutil.copy(fx("vcf", "index.vcf.gz"), tmp_path / "noidx.vcf.gz")
+    with pytest.raises(exon_amd.ExonHipError, match="cannot open"):
+        exon_amd.Scan(tmp_path / "noidx.vcf.gz", "vcf", region="1", use_index=True)
