@@ -51,9 +51,11 @@ int get_workspace(exon_hip_ctx* ctx, hipStream_t s, size_t words, Workspace* out
   std::lock_guard<std::mutex> g(ctx->mu);
   Workspace& ws = ctx->workspaces[s];
   if (!ws.status) {
-    // status[0] = device error word, status[1..7] = scratch flags (K5 path selection)
-    if (hipMalloc(&ws.status, 8 * sizeof(int)) != hipSuccess) return EXON_HIP_ENOMEM;
+    // status[0] = device error word, status[1..7] = scratch flags (K5 path selection), then 64 bytes of 0xFF
+    // (stand-in for absent validity bitmaps)
+    if (hipMalloc(&ws.status, 8 * sizeof(int) + 64) != hipSuccess) return EXON_HIP_ENOMEM;
     hipMemset(ws.status, 0, 8 * sizeof(int));
+    hipMemset(ws.status + 8, 0xFF, 64);
   }
   if (ws.partial_capacity < words) {
     if (ws.partials) {

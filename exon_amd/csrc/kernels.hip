@@ -58,9 +58,13 @@ __device__ __forceinline__ T ld16(const void* p) {
 
 // validity nibble of this lane's 4 rows of sub-tile j: rows [wbase + 256 j + 4 lane, +4).
 // wbase is a multiple of 256, so the sub-tile's 256 bits are 32 consecutive bytes.
-__device__ __forceinline__ unsigned valid4(const uint8_t* __restrict__ bm, int64_t wbase, int j, int lane) {
-  if (bm == nullptr) return 0xFu;
-  return (unsigned(bm[(wbase >> 3) + j * 32 + (lane >> 1)]) >> ((lane & 1) * 4)) & 0xFu;
+// Branch-free: a NULL bitmap is replaced by a 64-byte all-ones buffer, so the load is unconditional.
+// (With three optional bitmaps the compiler no longer unswitches the tile loop on their nullness and leaves
+// `if (bm) { load; s_waitcnt vmcnt(0) }` inside it, which drains every load in flight -- measured on K3.)
+__device__ __forceinline__ unsigned valid4_ones(const uint8_t* __restrict__ bm, const uint8_t* __restrict__ ones,
+                                                int64_t wbase, int j, int lane) {
+  const uint8_t* p = bm ? bm + (wbase >> 3) + j * 32 + (lane >> 1) : ones + (lane >> 1);
+  return (unsigned(*p) >> ((lane & 1) * 4)) & 0xFu;
 }
 __device__ __forceinline__ bool valid1(const uint8_t* __restrict__ bm, int64_t r) {
   return bm == nullptr ? true : ((bm[r >> 3] >> (r & 7)) & 1);
@@ -188,7 +192,8 @@ __global__ __launch_bounds__(S::THREADS) void k2_region_count_main(const int32_t
                                                                    const int64_t* __restrict__ pos,
                                                                    const uint8_t* __restrict__ pvalid, int64_t n,
                                                                    int32_t id, int64_t a, int64_t b,
-                                                                   unsigned long long* __restrict__ partials) {
+                                                                   unsigned long long* __restrict__ partials,
+                                                                   const uint8_t* __restrict__ ones) {
   constexpr int J = S::J, THREADS = S::THREADS, WAVES = ShapeOf<S>::WAVES, WT = ShapeOf<S>::WAVE_TILE,
                 TILE = ShapeOf<S>::TILE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -205,8 +210,8 @@ __global__ __launch_bounds__(S::THREADS) void k2_region_count_main(const int32_t
       c[j] = ld16<int4>(chrom + r);
       p0[j] = ld16<longlong2>(pos + r);
       p1[j] = ld16<longlong2>(pos + r + 2);
-      cm[j] = valid4(cvalid, wbase, j, lane);
-      pm[j] = valid4(pvalid, wbase, j, lane);
+      cm[j] = valid4_ones(cvalid, ones, wbase, j, lane);
+      pm[j] = valid4_ones(pvalid, ones, wbase, j, lane);
     }
 #pragma unroll
     for (int j = 0; j < J; ++j) {
@@ -242,7 +247,7 @@ static hipError_t k2_launch(hipStream_t s, const LaunchCfg& cfg, const Workspace
   const int grid = grid_for<S>(cfg, n, resident);
   *grid_out = grid;
   hipLaunchKernelGGL(k2_region_count_main<S>, dim3(grid), dim3(S::THREADS), 0, s, chrom, cv, pos, pv, n, id, a, b,
-                     ws.partials);
+                     ws.partials, reinterpret_cast<const uint8_t*>(ws.status + 8));
   return hipGetLastError();
 }
 
@@ -271,24 +276,26 @@ __global__ __launch_bounds__(S::THREADS) void k3_flag_mapq_group_count_main(
     const int32_t* __restrict__ flag, const uint8_t* __restrict__ fvalid, const uint8_t* __restrict__ mapq,
     const uint8_t* __restrict__ mvalid, const int32_t* __restrict__ ref, const uint8_t* __restrict__ rvalid,
     int64_t n, int32_t mask, int32_t value, int32_t qmin, int32_t R, unsigned long long* __restrict__ partials,
-    int* __restrict__ status) {
+    int* __restrict__ status, const uint8_t* __restrict__ ones) {
   constexpr int J = S::J, THREADS = S::THREADS, WAVES = ShapeOf<S>::WAVES, WT = ShapeOf<S>::WAVE_TILE,
                 TILE = ShapeOf<S>::TILE;
-  extern __shared__ unsigned k3_tbl[];  // [WAVES][R+1]
+  // per-wave table: [R+1] group counters + 64 per-lane dummy slots.  Rows that fail the predicate add to their
+  // lane's dummy slot, so the row loop is branch-free straight-line code (an exec-masked `if (pass)` per row costs
+  // 16 tiny basic blocks per iteration and serialises the LDS adds behind the mask updates).
+  extern __shared__ unsigned k3_tbl[];  // [WAVES][R+1+64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int V = R + 1;
-  for (int i = threadIdx.x; i < WAVES * V; i += THREADS) k3_tbl[i] = 0;
+  const int V = R + 1, VS = V + 64;
+  for (int i = threadIdx.x; i < WAVES * VS; i += THREADS) k3_tbl[i] = 0;
   __syncthreads();
-  unsigned* mine = k3_tbl + wave * V;
-  unsigned bad = 0;
+  unsigned* mine = k3_tbl + wave * VS;
+  const unsigned dummy = (unsigned)(V + lane);
+  unsigned kmax = 0;  // largest valid-row key seen (range check once, not per row)
 
   auto row = [&](int32_t f, unsigned q, int32_t r, unsigned fv, unsigned mv, unsigned rv) {
     const bool pass = fv && ((f & mask) == value) && mv && ((int32_t)q >= qmin);
-    if (pass) {
-      const unsigned key = rv ? (unsigned)r : (unsigned)R;
-      if (key <= (unsigned)R) atomicAdd(&mine[key], 1u);
-      else bad = 1;
-    }
+    const unsigned key = rv ? (unsigned)r : (unsigned)R;
+    kmax = max(kmax, pass ? key : 0u);
+    atomicAdd(&mine[(pass && key <= (unsigned)R) ? key : dummy], 1u);
   };
 
   const int64_t ntiles = n / TILE;
@@ -302,9 +309,9 @@ __global__ __launch_bounds__(S::THREADS) void k3_flag_mapq_group_count_main(
       f[j] = ld16<int4>(flag + r);
       g[j] = ld16<int4>(ref + r);
       q[j] = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(mapq + r));
-      fm[j] = valid4(fvalid, wbase, j, lane);
-      mm[j] = valid4(mvalid, wbase, j, lane);
-      rm[j] = valid4(rvalid, wbase, j, lane);
+      fm[j] = valid4_ones(fvalid, ones, wbase, j, lane);
+      mm[j] = valid4_ones(mvalid, ones, wbase, j, lane);
+      rm[j] = valid4_ones(rvalid, ones, wbase, j, lane);
     }
 #pragma unroll
     for (int j = 0; j < J; ++j) {
@@ -318,12 +325,12 @@ __global__ __launch_bounds__(S::THREADS) void k3_flag_mapq_group_count_main(
        r += (int64_t)gridDim.x * THREADS)
     row(flag[r], mapq[r], ref[r], valid1(fvalid, r), valid1(mvalid, r), valid1(rvalid, r));
 
-  if (bad) atomicOr(status, 2);
+  if (kmax > (unsigned)R) atomicOr(status, 2);
   __syncthreads();
   for (int v = threadIdx.x; v < V; v += THREADS) {
     unsigned long long t = 0;
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) t += k3_tbl[w * V + v];
+    for (int w = 0; w < WAVES; ++w) t += k3_tbl[w * VS + v];
     partials[(size_t)blockIdx.x * V + v] = t;
   }
 }
@@ -335,7 +342,7 @@ static hipError_t k3_launch(hipStream_t s, const LaunchCfg& cfg, const Workspace
                             const uint8_t* fv, const uint8_t* mapq, const uint8_t* mv, const int32_t* ref,
                             const uint8_t* rv, int64_t n, int32_t mask, int32_t value, int32_t qmin, int32_t R,
                             int* grid_out) {
-  const size_t lds = (size_t)ShapeOf<S>::WAVES * (R + 1) * sizeof(unsigned);
+  const size_t lds = (size_t)ShapeOf<S>::WAVES * (R + 1 + 64) * sizeof(unsigned);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k3_flag_mapq_group_count_main<S>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -344,7 +351,7 @@ static hipError_t k3_launch(hipStream_t s, const LaunchCfg& cfg, const Workspace
   const int grid = grid_for<S>(cfg, n, resident_blocks(k3_flag_mapq_group_count_main<S>, S::THREADS, lds));
   *grid_out = grid;
   hipLaunchKernelGGL(k3_flag_mapq_group_count_main<S>, dim3(grid), dim3(S::THREADS), lds, s, flag, fv, mapq, mv, ref,
-                     rv, n, mask, value, qmin, R, ws.partials, ws.status);
+                     rv, n, mask, value, qmin, R, ws.partials, ws.status, reinterpret_cast<const uint8_t*>(ws.status + 8));
   return hipGetLastError();
 }
 
@@ -355,7 +362,7 @@ hipError_t launch_flag_mapq_group_count(hipStream_t s, const LaunchCfg& cfg, con
   if (n <= 0) return hipSuccess;
   int grid = 1;
   // the 16-wave shape needs 16 x (n_refs+1) x 4 B of LDS: fine up to ~2.5k references
-  const bool big = use_big_shape(cfg, n) && (size_t)16 * (n_refs + 1) * 4 <= 160 * 1024;
+  const bool big = use_big_shape(cfg, n) && (size_t)16 * (n_refs + 1 + 64) * 4 <= 160 * 1024;
   hipError_t e = big ? k3_launch<ShapeBig>(s, cfg, ws, flag, flag_valid, mapq, mapq_valid, ref_id, ref_valid, n,
                                            flag_mask, flag_value, mapq_min, n_refs, &grid)
                      : k3_launch<ShapeSmall>(s, cfg, ws, flag, flag_valid, mapq, mapq_valid, ref_id, ref_valid, n,
@@ -386,7 +393,8 @@ template <int G, typename S, bool OVF>
 __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
     const float* __restrict__ x, const uint8_t* __restrict__ xvalid, const float* __restrict__ y,
     const uint8_t* __restrict__ yvalid, const int32_t* __restrict__ gid, int64_t n, int32_t klo, int32_t khi,
-    int32_t negate, int32_t NG, unsigned long long* __restrict__ partials, int* __restrict__ status) {
+    int32_t negate, int32_t NG, unsigned long long* __restrict__ partials, int* __restrict__ status,
+    const uint8_t* __restrict__ ones) {
   constexpr int J = S::J, THREADS = S::THREADS, WAVES = ShapeOf<S>::WAVES, WT = ShapeOf<S>::WAVE_TILE,
                 TILE = ShapeOf<S>::TILE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -464,8 +472,8 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
       xs[j] = ld16<float4>(x + r);
       ys[j] = ld16<float4>(y + r);
       gs[j] = ld16<int4>(gid + r);
-      xm[j] = valid4(xvalid, wbase, j, lane);
-      ym[j] = valid4(yvalid, wbase, j, lane);
+      xm[j] = valid4_ones(xvalid, ones, wbase, j, lane);
+      ym[j] = valid4_ones(yvalid, ones, wbase, j, lane);
     }
 #pragma unroll
     for (int j = 0; j < J; ++j) {
@@ -550,7 +558,7 @@ static hipError_t k4_launch(hipStream_t s, const LaunchCfg& cfg, int* grid_out, 
   const int grid = grid_for<S>(cfg, n, resident_blocks(k4_cmp_avg_by_group_main<G, S, OVF>, S::THREADS, lds));
   *grid_out = grid;
   hipLaunchKernelGGL((k4_cmp_avg_by_group_main<G, S, OVF>), dim3(grid), dim3(S::THREADS), lds, s, x, xv, y, yv, gid, n,
-                     klo, khi, negate, n_groups, ws.partials, ws.status);
+                     klo, khi, negate, n_groups, ws.partials, ws.status, reinterpret_cast<const uint8_t*>(ws.status + 8));
   return hipGetLastError();
 }
 
