@@ -23,6 +23,7 @@
 #include "arrow_build.h"
 #include "bgzf_index.h"
 #include "io.h"
+#include "parallel.h"
 #include "region.h"
 
 namespace exon {
@@ -84,6 +85,7 @@ struct VCFHeader {
 
 struct VCFConfig {
   int64_t batch_size = DEFAULT_BATCH_SIZE;
+  int threads = 0;  // decode threads: 0 = all host cores (EXON_HIP_DECODE_THREADS), 1 = sequential reader
   std::string info_field;  // exon.vcf_parse_info=true + SELECT info."<F>": Number=1 Float/Integer field -> f32 column
   RegionFilter filter;
 };
@@ -119,14 +121,15 @@ class VCFArrayBuilder : public ExonArrayBuilder {
       : chrom_dict_(chrom_dict), filter_dict_(filter_dict), info_field_(info_field) {}
 
   // one data line (no terminator).  Field rules: lazy_array_builder.rs:159-216.
-  void append(const std::string& line) {
+  void append(const std::string& line) { append(line.data(), line.size()); }
+  void append(const char* line, size_t len) {
     const char* f[9];
     size_t fl[9];
     int nf = 0;
     size_t start = 0;
-    for (size_t i = 0; i <= line.size() && nf < 9; ++i)
-      if (i == line.size() || line[i] == '\t') {
-        f[nf] = line.data() + start;
+    for (size_t i = 0; i <= len && nf < 9; ++i)
+      if (i == len || line[i] == '\t') {
+        f[nf] = line + start;
         fl[nf] = i - start;
         ++nf;
         start = i + 1;
@@ -170,7 +173,60 @@ class VCFArrayBuilder : public ExonArrayBuilder {
     return out;
   }
 
+  void reserve(size_t rows) {
+    for (auto* v : {&chrom_, &filter_}) { v->values.reserve(rows); v->valid.reserve(rows); }
+    pos_.values.reserve(rows); pos_.valid.reserve(rows);
+    qual_.values.reserve(rows); qual_.valid.reserve(rows);
+    if (!info_field_.empty()) { info_.values.reserve(rows); info_.valid.reserve(rows); }
+  }
+  // raw column vectors (parallel decoder: slabs are parsed with slab-local dictionaries, then re-keyed)
+  PrimitiveBuilder<int32_t>& chrom_ids() { return chrom_; }
+  PrimitiveBuilder<int32_t>& filter_ids() { return filter_; }
+  PrimitiveBuilder<int64_t>& positions() { return pos_; }
+  PrimitiveBuilder<float>& quals() { return qual_; }
+  PrimitiveBuilder<float>& infos() { return info_; }
+
+  // Correctly rounded decimal -> f32 (what Rust's str::parse::<f32> guarantees).  Fast path (Clinger): a
+  // mantissa below 2^24 and a power of ten up to 10^10 are both exact in f32, so ONE IEEE multiply/divide is
+  // correctly rounded; anything else (long mantissas, big exponents, inf/nan spellings) goes to strtof.
   static float parse_f32(const char* p, size_t n) {
+    {
+      static const float P10[11] = {1e0f, 1e1f, 1e2f, 1e3f, 1e4f, 1e5f, 1e6f, 1e7f, 1e8f, 1e9f, 1e10f};
+      size_t i = 0;
+      bool neg = false;
+      if (i < n && (p[i] == '-' || p[i] == '+')) neg = p[i++] == '-';
+      uint32_t mant = 0;
+      int digits = 0, frac = 0;
+      bool ok = true, seen = false;
+      for (; i < n && p[i] >= '0' && p[i] <= '9'; ++i) {
+        seen = true;
+        if (mant || p[i] != '0') { mant = mant * 10 + (uint32_t)(p[i] - '0'); if (++digits > 7) { ok = false; break; } }
+      }
+      if (ok && i < n && p[i] == '.') {
+        for (++i; i < n && p[i] >= '0' && p[i] <= '9'; ++i) {
+          seen = true;
+          ++frac;
+          if (mant || p[i] != '0') { mant = mant * 10 + (uint32_t)(p[i] - '0'); if (++digits > 7) { ok = false; break; } }
+        }
+      }
+      int e10 = 0;
+      if (ok && seen && i < n && (p[i] == 'e' || p[i] == 'E')) {
+        ++i;
+        bool eneg = false;
+        if (i < n && (p[i] == '-' || p[i] == '+')) eneg = p[i++] == '-';
+        int ed = 0;
+        for (; i < n && p[i] >= '0' && p[i] <= '9' && ed < 4; ++i, ++ed) e10 = e10 * 10 + (p[i] - '0');
+        if (ed == 0) ok = false;
+        if (eneg) e10 = -e10;
+      }
+      if (ok && seen && i == n && mant < (1u << 24)) {
+        const int e = e10 - frac;
+        if (mant == 0) return neg ? -0.0f : 0.0f;
+        if (e == 0) return neg ? -(float)mant : (float)mant;
+        if (e < 0 && e >= -10) { const float v = (float)mant / P10[-e]; return neg ? -v : v; }
+        if (e > 0 && e <= 10) { const float v = (float)mant * P10[e]; return neg ? -v : v; }
+      }
+    }
     char tmp[64];
     if (n >= sizeof tmp) n = sizeof tmp - 1;
     memcpy(tmp, p, n);
@@ -209,6 +265,52 @@ class VCFArrayBuilder : public ExonArrayBuilder {
   PrimitiveBuilder<float> qual_, info_;
   size_t rows_ = 0;
 };
+
+// IndexedAsyncBatchStream::filter (exon-vcf/src/indexed_async_batch_stream.rs:99-116) on a raw data line
+inline bool vcf_region_hit(const char* line, size_t len, const Region& rg) {
+  const char* t1 = static_cast<const char*>(memchr(line, '\t', len));
+  if (!t1) return false;
+  const size_t nl = (size_t)(t1 - line);
+  if (nl != rg.name.size() || memcmp(line, rg.name.data(), nl) != 0) return false;
+  int64_t pos = 0;
+  const char* p = t1 + 1;
+  const char* end = line + len;
+  if (p == end || *p == '\t') return false;
+  for (; p < end && *p != '\t'; ++p) {
+    if (*p < '0' || *p > '9') return false;
+    pos = pos * 10 + (*p - '0');
+  }
+  return pos >= 1 && pos >= rg.start && pos <= rg.end;
+}
+
+// one slab of VCF text parsed with slab-local dictionaries (header contigs pre-seeded, so their ids are global)
+struct VCFParseCtx {
+  std::vector<std::string> contigs;
+  std::string info_field;
+  RegionFilter filter;
+};
+struct VCFSlab : TextSlab {
+  Dictionary chrom_dict, filter_dict;
+  std::unique_ptr<VCFArrayBuilder> b;
+  size_t rows = 0;
+};
+inline void parse_vcf_slab(VCFSlab& s, const void* vctx) {
+  const VCFParseCtx& ctx = *static_cast<const VCFParseCtx*>(vctx);
+  s.chrom_dict.names = ctx.contigs;
+  s.b.reset(new VCFArrayBuilder(&s.chrom_dict, &s.filter_dict, ctx.info_field));
+  const char* p = s.data();
+  const char* end = p + s.len;
+  s.b->reserve(s.len / 48 + 16);
+  while (p < end) {
+    const char* nl = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+    size_t len = nl ? (size_t)(nl - p) : (size_t)(end - p);
+    const char* next = nl ? nl + 1 : end;
+    if (len && p[len - 1] == '\r') --len;
+    if (len && p[0] != '#' && (!ctx.filter.active || vcf_region_hit(p, len, ctx.filter.region))) s.b->append(p, len);
+    p = next;
+  }
+  s.rows = s.b->len();
+}
 
 class VCFBatchReader {
  public:
@@ -261,6 +363,27 @@ class VCFBatchReader {
       n_chunks = (int)chunks.size();
       has_pending_ = false;
       r_.reset(new ChunkSource(path, std::move(chunks)));
+    } else {
+      // multi-threaded decode of the rest of the stream (files of at least a couple of slabs)
+      const int threads = cfg_.threads > 0 ? cfg_.threads : decode_threads();
+      FILE* f = fopen(path.c_str(), "rb");
+      long fsize = 0;
+      if (f) {
+        fseek(f, 0, SEEK_END);
+        fsize = ftell(f);
+        fclose(f);
+      }
+      if (threads > 1 && fsize >= (8 << 20)) {
+        StreamSource* ss = static_cast<StreamSource*>(r_.get());
+        std::string carry = has_pending_ ? pending_ + "\n" : std::string();
+        has_pending_ = false;
+        carry += ss->r.take_buffered();
+        pctx_.contigs = header.contigs;
+        pctx_.info_field = cfg_.info_field;
+        pctx_.filter = cfg_.filter;
+        pipe_.reset(new SlabPipeline<VCFSlab>(ss->r.release_source(), std::move(carry), 1, threads,
+                                              [](VCFSlab& s, const void* c) { parse_vcf_slab(s, c); }, &pctx_));
+      }
     }
   }
 
@@ -268,6 +391,7 @@ class VCFBatchReader {
   // per-record test of IndexedAsyncBatchStream::filter applies to EVERY record
   // (exon-vcf/src/indexed_async_batch_stream.rs:99-116; see DESIGN.md on the reference's unfiltered tail).
   bool read_batch(struct ArrowArray* out) {
+    if (pipe_) return read_batch_parallel(out);
     VCFArrayBuilder b(&chrom_dict, &filter_dict, cfg_.info_field);
     std::string line;
     while ((int64_t)b.len() < cfg_.batch_size) {
@@ -278,7 +402,7 @@ class VCFBatchReader {
         break;
       }
       if (line.empty() || line[0] == '#') continue;
-      if (cfg_.filter.active && !region_hit(line)) continue;
+      if (cfg_.filter.active && !vcf_region_hit(line.data(), line.size(), cfg_.filter.region)) continue;
       b.append(line);
     }
     if (b.is_empty()) return false;
@@ -299,23 +423,53 @@ class VCFBatchReader {
   int n_chunks = -1;  // index chunks planned (-1: not an indexed scan)
 
  private:
-  bool region_hit(const std::string& line) const {
-    const size_t t1 = line.find('\t');
-    if (t1 == std::string::npos) return false;
-    const Region& rg = cfg_.filter.region;
-    if (t1 != rg.name.size() || line.compare(0, t1, rg.name) != 0) return false;
-    const size_t t2 = line.find('\t', t1 + 1);
-    int64_t pos = 0;
-    for (size_t i = t1 + 1; i < (t2 == std::string::npos ? line.size() : t2); ++i) {
-      if (line[i] < '0' || line[i] > '9') return false;
-      pos = pos * 10 + (line[i] - '0');
+  // emit up to batch_size rows of the current slab (re-keyed to the reader's dictionaries)
+  bool read_batch_parallel(struct ArrowArray* out) {
+    while (!cur_ || cur_pos_ >= cur_->rows) {
+      cur_ = pipe_->next();
+      if (!cur_) return false;
+      cur_pos_ = 0;
+      // slab-local ids -> global ids (header contigs keep their ids; unseen contigs / FILTER lists are interned
+      // in file order, exactly as the sequential reader would)
+      std::vector<int32_t> cmap(cur_->chrom_dict.names.size()), fmap(cur_->filter_dict.names.size());
+      for (size_t i = 0; i < cmap.size(); ++i)
+        cmap[i] = i < header.contigs.size() ? (int32_t)i : chrom_dict.lookup_or_insert(cur_->chrom_dict.names[i].data(), cur_->chrom_dict.names[i].size());
+      for (int32_t& v : cur_->b->chrom_ids().values) v = cmap[(size_t)v];
+      // FILTER lists must be interned in order of first appearance in the file, not of the slab dictionary
+      std::vector<int32_t>& fv = cur_->b->filter_ids().values;
+      std::fill(fmap.begin(), fmap.end(), -1);
+      for (int32_t& v : fv) {
+        int32_t& g = fmap[(size_t)v];
+        if (g < 0) g = filter_dict.lookup_or_insert(cur_->filter_dict.names[(size_t)v].data(), cur_->filter_dict.names[(size_t)v].size());
+        v = g;
+      }
     }
-    return pos >= 1 && pos >= rg.start && pos <= rg.end;
+    const size_t n = std::min<size_t>((size_t)cfg_.batch_size, cur_->rows - cur_pos_), o = cur_pos_;
+    auto slice = [&](auto& pb, int elem, struct ArrowArray* dict) {
+      struct ArrowArray* a = static_cast<struct ArrowArray*>(malloc(sizeof *a));
+      std::vector<uint8_t> valid(pb.valid.begin() + (long)o, pb.valid.begin() + (long)(o + n));
+      make_primitive(a, reinterpret_cast<const uint8_t*>(pb.values.data()) + o * (size_t)elem, (int64_t)n, elem, valid, dict);
+      return a;
+    };
+    std::vector<struct ArrowArray*> kids;
+    kids.push_back(slice(cur_->b->chrom_ids(), 4, utf8_array(chrom_dict.names)));
+    kids.push_back(slice(cur_->b->positions(), 8, nullptr));
+    kids.push_back(slice(cur_->b->quals(), 4, nullptr));
+    kids.push_back(slice(cur_->b->filter_ids(), 4, utf8_array(filter_dict.names)));
+    if (!cfg_.info_field.empty()) kids.push_back(slice(cur_->b->infos(), 4, nullptr));
+    make_struct(out, (int64_t)n, std::move(kids));
+    cur_pos_ += n;
+    return true;
   }
+
   std::unique_ptr<RecordSource> r_;
   VCFConfig cfg_;
   std::string pending_;
   bool has_pending_ = false;
+  VCFParseCtx pctx_;
+  std::unique_ptr<VCFSlab> cur_;
+  size_t cur_pos_ = 0;
+  std::unique_ptr<SlabPipeline<VCFSlab>> pipe_;  // declared last: destroyed (threads joined) first
 };
 
 // ======================================================================================================
@@ -462,7 +616,8 @@ class BAMBatchReader {
 // FASTQ   (name, description?, sequence, quality_scores : exon-fastq/src/config.rs:79-88)
 // ======================================================================================================
 struct FASTQConfig {
-  int64_t batch_size = DEFAULT_BATCH_SIZE;
+  int64_t batch_size = DEFAULT_BATCH_SIZE;  // sequential reader; the parallel reader emits one batch per ~4 MiB slab
+  int threads = 0;
 };
 
 class FASTQArrayBuilder : public ExonArrayBuilder {
@@ -488,10 +643,67 @@ class FASTQArrayBuilder : public ExonArrayBuilder {
   Utf8Builder name_, desc_, seq_, qual_;
 };
 
+struct FASTQSlab : TextSlab {
+  FASTQArrayBuilder b;
+  std::vector<struct ArrowArray*> cols;  // finished Arrow columns of the slab (name, description, sequence, quality)
+  size_t rows = 0;
+};
+inline void parse_fastq_slab(FASTQSlab& s, const void*) {
+  const char* p = s.data();
+  const char* end = p + s.len;
+  std::string head, seq, qual;
+  auto line = [&](const char** b, size_t* n) {
+    if (p >= end) return false;
+    const char* nl = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+    *b = p;
+    *n = nl ? (size_t)(nl - p) : (size_t)(end - p);
+    if (*n && (*b)[*n - 1] == '\r') --*n;
+    p = nl ? nl + 1 : end;
+    return true;
+  };
+  const char *h, *sq, *pl, *ql;
+  size_t hn, sn, pn, qn;
+  while (line(&h, &hn)) {
+    if (hn == 0) continue;
+    if (h[0] != '@') throw std::runtime_error("FASTQ record does not start with '@'");
+    if (!line(&sq, &sn) || !line(&pl, &pn) || !line(&ql, &qn)) throw std::runtime_error("truncated FASTQ record");
+    if (pn == 0 || pl[0] != '+') throw std::runtime_error("FASTQ separator line missing");
+    head.assign(h + 1, hn - 1);
+    seq.assign(sq, sn);
+    qual.assign(ql, qn);
+    s.b.append(head, seq, qual);
+  }
+  s.rows = s.b.len();
+}
+
 class FASTQBatchReader {
  public:
-  FASTQBatchReader(const std::string& path, Compression c, FASTQConfig cfg) : r_(path, c), cfg_(cfg) {}
+  FASTQBatchReader(const std::string& path, Compression c, FASTQConfig cfg) : r_(path, c), cfg_(cfg) {
+    const int threads = cfg_.threads > 0 ? cfg_.threads : decode_threads();
+    FILE* f = fopen(path.c_str(), "rb");
+    long fsize = 0;
+    if (f) {
+      fseek(f, 0, SEEK_END);
+      fsize = ftell(f);
+      fclose(f);
+    }
+    // whole 4-line records per slab; blank lines between records are not supported in the parallel path, so it is
+    // only taken for inputs that start directly with a record
+    if (threads > 1 && fsize >= (8 << 20))
+      pipe_.reset(new SlabPipeline<FASTQSlab>(r_.release_source(), r_.take_buffered(), 4, threads,
+                                              [](FASTQSlab& s, const void* c2) { parse_fastq_slab(s, c2); }, nullptr));
+  }
   bool read_batch(struct ArrowArray* out) {
+    if (pipe_) {
+      // a slab is emitted as ONE batch (its Utf8 columns are already contiguous); slabs are ~4 MiB of text
+      for (;;) {
+        std::unique_ptr<FASTQSlab> s = pipe_->next();
+        if (!s) return false;
+        if (s->rows == 0) continue;
+        s->b.try_into_record_batch(out);
+        return true;
+      }
+    }
     FASTQArrayBuilder b;
     std::string head, seq, plus, qual;
     while ((int64_t)b.len() < cfg_.batch_size) {
@@ -515,6 +727,7 @@ class FASTQBatchReader {
  private:
   BufReader r_;
   FASTQConfig cfg_;
+  std::unique_ptr<SlabPipeline<FASTQSlab>> pipe_;
 };
 
 // ======================================================================================================

@@ -90,7 +90,15 @@ class ByteReader {
 // buffered line / exact reads over a ByteReader
 class BufReader {
  public:
-  BufReader(const std::string& path, Compression c) : src_(path, c), buf_(1 << 20) {}
+  BufReader(const std::string& path, Compression c) : src_(new ByteReader(path, c)), buf_(1 << 20) {}
+
+  // hand the stream over to a parallel decoder: the bytes already buffered but not consumed, then the source
+  std::string take_buffered() {
+    std::string s(reinterpret_cast<const char*>(buf_.data() + pos_), end_ - pos_);
+    pos_ = end_ = 0;
+    return s;
+  }
+  std::unique_ptr<ByteReader> release_source() { return std::move(src_); }
 
   // reads one line without its terminator ('\n' or "\r\n"); false at end of data
   bool read_line(std::string* line) {
@@ -125,11 +133,11 @@ class BufReader {
 
  private:
   bool fill() {
-    end_ = src_.read(buf_.data(), buf_.size());
+    end_ = src_ ? src_->read(buf_.data(), buf_.size()) : 0;
     pos_ = 0;
     return end_ > 0;
   }
-  ByteReader src_;
+  std::unique_ptr<ByteReader> src_;
   std::vector<uint8_t> buf_;
   size_t pos_ = 0, end_ = 0;
 };

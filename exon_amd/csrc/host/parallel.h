@@ -1,0 +1,222 @@
+// parallel.h -- multi-threaded text decode: one reader thread cuts the (decompressed) byte stream into
+// record-aligned slabs, N workers parse slabs into column vectors, the consumer re-keys slab-local dictionary
+// ids and emits batches in file order.
+//
+// The reference decodes one record at a time on one tokio task per partition
+// (exon-vcf/src/async_batch_stream.rs:59-109, exon-fastq/src/batch_reader.rs:63-82); at ~4 Mrows/s per core that
+// is five orders of magnitude below what the GPU consumes, so the decoders here use every host core of the
+// partition's process.  Results are identical to the sequential readers (tests/test_scan_decoders.py).
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <exception>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "arrow_build.h"
+#include "io.h"
+
+namespace exon {
+
+struct TextSlab {
+  uint64_t id = 0;
+  std::unique_ptr<char[]> buf;  // whole records, '\n'-terminated except possibly the last (uninitialised storage:
+  size_t len = 0;               // no zero-fill pass over every slab)
+  const char* data() const { return buf.get(); }
+  std::exception_ptr error;
+  virtual ~TextSlab() = default;
+};
+
+// Parses slabs on worker threads.  `Result` derives from TextSlab; `parse(Result&)` fills it from `text`.
+template <typename Result>
+class SlabPipeline {
+ public:
+  using ParseFn = void (*)(Result&, const void* ctx);
+
+  SlabPipeline(std::unique_ptr<ByteReader> src, std::string carry, int lines_per_record, int threads, ParseFn parse,
+               const void* ctx, size_t slab_bytes = 4u << 20)
+      : src_(std::move(src)), carry_(std::move(carry)), lpr_(lines_per_record), parse_(parse), ctx_(ctx),
+        slab_bytes_(slab_bytes), max_inflight_((size_t)threads * 2 + 2) {
+    reader_ = std::thread([this] { read_loop(); });
+    for (int i = 0; i < threads; ++i) workers_.emplace_back([this] { work_loop(); });
+  }
+  ~SlabPipeline() {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      stop_ = true;
+    }
+    cv_todo_.notify_all();
+    cv_done_.notify_all();
+    cv_space_.notify_all();
+    if (reader_.joinable()) reader_.join();
+    for (auto& w : workers_) w.join();
+  }
+
+  // next parsed slab in file order; nullptr at end of input.  Rethrows reader / parser errors.
+  std::unique_ptr<Result> next() {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      auto it = done_.find(next_id_);
+      if (it != done_.end()) {
+        std::unique_ptr<Result> r = std::move(it->second);
+        done_.erase(it);
+        ++next_id_;
+        --inflight_;
+        cv_space_.notify_one();
+        lk.unlock();
+        if (r->error) std::rethrow_exception(r->error);
+        return r;
+      }
+      if (read_error_) std::rethrow_exception(read_error_);
+      if (reader_finished_ && next_id_ >= produced_) return nullptr;
+      cv_done_.wait(lk);
+    }
+  }
+
+ private:
+  void read_loop() {
+    try {
+      std::string carry = std::move(carry_);  // bytes after the last whole record of the previous slab
+      uint64_t lines_before = 0;              // complete lines handed out so far (for multi-line records)
+      bool eof = false;
+      while (!eof) {
+        // read straight into the slab's own buffer: [carry | up to slab_bytes_ fresh bytes]
+        std::unique_ptr<Result> slab(new Result());
+        size_t cap = carry.size() + slab_bytes_;
+        slab->buf.reset(new char[cap]);
+        memcpy(slab->buf.get(), carry.data(), carry.size());
+        size_t have = carry.size();
+        carry.clear();
+        size_t cut = 0;
+        for (;;) {
+          while (have < cap) {
+            const size_t k = src_->read(reinterpret_cast<uint8_t*>(slab->buf.get() + have), cap - have);
+            if (k == 0) {
+              eof = true;
+              break;
+            }
+            have += k;
+          }
+          const char* base = slab->buf.get();
+          if (eof) {
+            cut = have;
+          } else if (lpr_ == 1) {
+            cut = have;
+            while (cut > 0 && base[cut - 1] != '\n') --cut;
+          } else {
+            uint64_t lines = lines_before;
+            const char* p = base;
+            const char* end = base + have;
+            cut = 0;
+            while (p < end) {
+              const char* nl = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+              if (!nl) break;
+              ++lines;
+              p = nl + 1;
+              if (lines % (uint64_t)lpr_ == 0) cut = (size_t)(p - base);
+            }
+          }
+          if (cut > 0 || eof) break;
+          // not a single whole record in the buffer: grow it and keep reading
+          std::unique_ptr<char[]> bigger(new char[cap * 2]);
+          memcpy(bigger.get(), slab->buf.get(), have);
+          slab->buf = std::move(bigger);
+          cap *= 2;
+        }
+        carry.assign(slab->buf.get() + cut, have - cut);
+        slab->len = cut;
+        if (lpr_ > 1) {
+          const char* p = slab->buf.get();
+          const char* end = p + cut;
+          while (p < end) {
+            const char* nl = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+            if (!nl) break;
+            ++lines_before;
+            p = nl + 1;
+          }
+        }
+        if (slab->len == 0) continue;
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_space_.wait(lk, [this] { return stop_ || inflight_ < max_inflight_; });
+        if (stop_) return;
+        slab->id = produced_++;
+        ++inflight_;
+        todo_.push_back(std::move(slab));
+        lk.unlock();
+        cv_todo_.notify_one();
+      }
+    } catch (...) {
+      std::lock_guard<std::mutex> g(mu_);
+      read_error_ = std::current_exception();
+    }
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      reader_finished_ = true;
+    }
+    cv_todo_.notify_all();
+    cv_done_.notify_all();
+  }
+
+  void work_loop() {
+    for (;;) {
+      std::unique_ptr<Result> slab;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_todo_.wait(lk, [this] { return stop_ || !todo_.empty() || reader_finished_; });
+        if (stop_) return;
+        if (todo_.empty()) {
+          if (reader_finished_) return;
+          continue;
+        }
+        slab = std::move(todo_.front());
+        todo_.pop_front();
+      }
+      try {
+        parse_(*slab, ctx_);
+      } catch (...) {
+        slab->error = std::current_exception();
+      }
+      slab->buf.reset();  // the text is no longer needed
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        const uint64_t id = slab->id;
+        done_[id] = std::move(slab);
+      }
+      cv_done_.notify_all();
+    }
+  }
+
+  std::unique_ptr<ByteReader> src_;
+  std::string carry_;
+  const int lpr_;
+  ParseFn parse_;
+  const void* ctx_;
+  const size_t slab_bytes_, max_inflight_;
+  std::thread reader_;
+  std::vector<std::thread> workers_;
+  std::mutex mu_;
+  std::condition_variable cv_todo_, cv_done_, cv_space_;
+  std::deque<std::unique_ptr<Result>> todo_;
+  std::map<uint64_t, std::unique_ptr<Result>> done_;
+  uint64_t produced_ = 0, next_id_ = 0;
+  size_t inflight_ = 0;
+  bool stop_ = false, reader_finished_ = false;
+  std::exception_ptr read_error_;
+};
+
+inline int decode_threads() {
+  if (const char* v = getenv("EXON_HIP_DECODE_THREADS")) {
+    const int t = atoi(v);
+    if (t >= 1) return t;
+  }
+  const unsigned hc = std::thread::hardware_concurrency();  // target_partitions = num_cpus in the reference
+  return hc ? (int)hc : 1;
+}
+
+}  // namespace exon

@@ -186,3 +186,136 @@ def test_indexed_scan_without_index_file_fails(tmp_path):
     shutil.copy(fx("vcf", "index.vcf.gz"), tmp_path / "noidx.vcf.gz")
     with pytest.raises(exon_amd.ExonHipError, match="cannot open"):
         exon_amd.Scan(tmp_path / "noidx.vcf.gz", "vcf", region="1", use_index=True)
+
+
+# ---- multi-threaded decode ---------------------------------------------------------------------------------
+def _big_vcf(path, n, seed=7):
+    rng = np.random.default_rng(seed)
+    filters = ["PASS", ".", "q10", "q10;s50", "s50", "lowDP;q10"]
+    with open(path, "w") as f:
+        f.write("##fileformat=VCFv4.3\n##contig=<ID=1>\n##contig=<ID=2>\n")
+        f.write('##INFO=<ID=AF,Number=1,Type=Float,Description="AF">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n')
+        chrom = np.where(np.arange(n) < n // 2, "1", "2")
+        for i in range(n):
+            c = "GL0001.1" if i > n - 5000 and i % 7 == 0 else chrom[i]   # a contig absent from the header, late in the file
+            flt = filters[rng.integers(0, 3)] if i < n // 3 else filters[rng.integers(0, len(filters))]
+            info = f"DP=3;AF={rng.random():.5g};X" if i % 11 else "."
+            qual = f"{rng.random() * 90:.2f}" if i % 13 else "."
+            f.write(f"{c}\t{1 + i % 1000003}\trs{i}\tACGT\tA\t{qual}\t{flt}\t{info}\n")
+
+
+@pytest.mark.parametrize("region", [None, "2:1000-500000", "GL0001.1"])
+def test_parallel_vcf_decode_is_identical_to_sequential(tmp_path, monkeypatch, region):
+    import pyarrow as pa
+    p = tmp_path / "big.vcf"
+    _big_vcf(p, 260_000)  # ~13 MB: several 4 MiB slabs
+    assert p.stat().st_size > (8 << 20)
+
+    def scan(threads):
+        monkeypatch.setenv("EXON_HIP_DECODE_THREADS", str(threads))
+        s = exon_amd.Scan(p, "vcf", info_field="AF", region=region)
+        batches = list(s)
+        out = (pa.concat_arrays(batches) if batches else None, s.dictionary(0), s.dictionary(3))
+        s.close()
+        return out
+
+    a, ac, af = scan(1)
+    b, bc, bf = scan(4)
+    assert ac == bc and af == bf  # dictionaries grow in file order in both modes
+    if a is None:
+        assert b is None
+    else:
+        assert a.equals(b)
+        if region is None:
+            assert len(a) == 260_000 and bc == ["1", "2", "GL0001.1"]
+
+
+def test_parallel_decode_reports_parse_errors(tmp_path, monkeypatch):
+    p = tmp_path / "bad.vcf"
+    _big_vcf(p, 200_000)
+    with open(p, "a") as f:
+        f.write("1\t5\t.\tA\tC\tnot_a_number\tPASS\t.\n")
+    monkeypatch.setenv("EXON_HIP_DECODE_THREADS", "4")
+    s = exon_amd.Scan(p, "vcf")
+    with pytest.raises(exon_amd.ExonHipError, match="invalid float"):
+        for _ in s:
+            pass
+    s.close()
+
+
+def _rn32(s):
+    """Correctly rounded float32 of the decimal string s (exact rational arithmetic; ties to even)."""
+    from fractions import Fraction
+    x = Fraction(s)
+    if x == 0:
+        return np.float32(-0.0 if s.startswith("-") else 0.0)
+    c = np.float32(float(x))
+    if not np.isfinite(c):
+        return c
+    cands = [np.nextafter(c, np.float32(-np.inf)), c, np.nextafter(c, np.float32(np.inf))]
+    best = None
+    for v in cands:
+        if not np.isfinite(v):
+            continue
+        d = abs(Fraction(float(v)) - x)
+        even = (int(np.float32(v).view(np.uint32)) & 1) == 0
+        key = (d, 0 if even else 1)
+        if best is None or key < best[0]:
+            best = (key, v)
+    return best[1]
+
+
+def test_f32_parse_is_correctly_rounded(tmp_path):
+    """QUAL / INFO floats must parse like Rust's str::parse::<f32> (correct rounding), fast path and strtof path alike."""
+    rng = np.random.default_rng(99)
+    strs = ["0", "0.0", "-0.0", "1", "16777216", "16777217", "16777215", "0.1", "0.01", "1e10", "1e-10", "3.4028235e38",
+            "1.17549435e-38", "1e-45", "123456.7", "9999999", "99999999", "0.30000001192092896", "1.00000017881393421514957253748434595763683319091796875",
+            "8.5e-7", "12345678e-3", "1.5E+3", "+2.5", "00012.50", ".5", "5."]
+    for _ in range(20000):
+        nd = int(rng.integers(1, 10))
+        mant = "".join(rng.choice(list("0123456789"), nd))
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            s = mant
+        elif kind == 1:
+            k = int(rng.integers(0, nd + 1))
+            s = (mant[:k] or "0") + "." + (mant[k:] or "0")
+        elif kind == 2:
+            s = mant[0] + "." + (mant[1:] or "0") + "e" + str(int(rng.integers(-14, 15)))
+        else:
+            s = "0." + "0" * int(rng.integers(0, 8)) + mant
+        strs.append(s)
+    p = tmp_path / "floats.vcf"
+    with open(p, "w") as f:
+        f.write("##fileformat=VCFv4.3\n##contig=<ID=1>\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+        for i, s in enumerate(strs):
+            f.write(f"1\t{i + 1}\t.\tA\tC\t{s}\tPASS\t.\n")
+    got = np.concatenate([b.field(2).to_numpy(zero_copy_only=False).astype(np.float32) for b in exon_amd.Scan(p, "vcf")])
+    want = np.array([_rn32(s) for s in strs], np.float32)
+    bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
+    assert len(bad) == 0, [(strs[i], got[i], want[i]) for i in bad[:10]]
+
+
+def test_parallel_fastq_decode_is_identical_to_sequential(tmp_path, monkeypatch):
+    import pyarrow as pa
+    rng = np.random.default_rng(3)
+    p = tmp_path / "big.fastq"
+    n = 60_000
+    with open(p, "wb") as f:
+        for i in range(n):
+            L = int(rng.integers(30, 152))
+            seq = rng.choice(list(b"ACGTN"), L).astype(np.uint8).tobytes()
+            qual = rng.integers(33, 75, L, dtype=np.uint8).tobytes().replace(b"@", b"@")  # '@' may start a quality line
+            desc = b" lane:%d" % (i % 8) if i % 3 else b""
+            f.write(b"@read%d" % i + desc + b"\n" + seq + b"\n+\n" + qual + b"\n")
+    assert p.stat().st_size > (8 << 20)
+
+    def scan(threads):
+        monkeypatch.setenv("EXON_HIP_DECODE_THREADS", str(threads))
+        s = exon_amd.Scan(p, "fastq")
+        out = pa.concat_arrays(list(s))
+        s.close()
+        return out
+
+    a, b = scan(1), scan(4)
+    assert len(a) == n and a.equals(b)
