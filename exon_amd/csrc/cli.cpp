@@ -184,6 +184,7 @@ std::vector<std::string> format_exts(int format, const std::string& custom) {
     case EXON_HIP_FORMAT_FASTA: return {".fasta", ".fa", ".fna", ".faa"};
     case EXON_HIP_FORMAT_FASTQ: return {".fastq", ".fq"};
     case EXON_HIP_FORMAT_VCF: return {".vcf"};
+    case EXON_HIP_FORMAT_SAM: return {".sam"};
     default: return {".bam"};
   }
 }
@@ -196,6 +197,7 @@ int format_of(const std::string& name, bool* indexed) {
   if (f == "fastq") return EXON_HIP_FORMAT_FASTQ;
   if (f == "vcf") return EXON_HIP_FORMAT_VCF;
   if (f == "bam") return EXON_HIP_FORMAT_BAM;
+  if (f == "sam") return EXON_HIP_FORMAT_SAM;
   throw Err("unsupported file type " + name);
 }
 
@@ -469,7 +471,7 @@ void exec_select(Session& se, Parser& ps) {
     print_table({"count(*)"}, {{std::to_string(total)}}, se.quiet);
     return;
   }
-  if (pr.kind == Predicate::FlagMapq && src.format == EXON_HIP_FORMAT_BAM && group_by == "reference") {  // K3
+  if (pr.kind == Predicate::FlagMapq && (src.format == EXON_HIP_FORMAT_BAM || src.format == EXON_HIP_FORMAT_SAM) && group_by == "reference") {  // K3
     exon_hip_ctx* ctx = se.gpu();
     std::map<std::string, int64_t> merged;  // AggregateExec(Final): merge per-file partials by key
     int64_t null_group = 0;

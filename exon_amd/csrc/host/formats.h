@@ -613,6 +613,112 @@ class BAMBatchReader {
 };
 
 // ======================================================================================================
+// SAM (text).  Same schema / device layout as BAM (exon-sam/src/schema_builder.rs:371-402 is shared by
+// SAM, BAM and CRAM; text reader: exon-sam/src/batch_reader.rs, array_builder.rs).
+// ======================================================================================================
+class SAMBatchReader {
+ public:
+  SAMBatchReader(const std::string& path, Compression c, BAMConfig cfg) : r_(path, c), cfg_(std::move(cfg)) {
+    std::string line;
+    while (r_.read_line(&line)) {
+      if (line.empty() || line[0] != '@') {
+        pending_ = line;
+        has_pending_ = !line.empty();
+        break;
+      }
+      if (line.rfind("@SQ", 0) == 0) {  // @SQ SN:<name> LN:<len>
+        std::string name;
+        int32_t len = 0;
+        size_t start = 0;
+        for (size_t i = 0; i <= line.size(); ++i)
+          if (i == line.size() || line[i] == '\t') {
+            if (line.compare(start, 3, "SN:") == 0) name = line.substr(start + 3, i - start - 3);
+            if (line.compare(start, 3, "LN:") == 0) len = atoi(line.c_str() + start + 3);
+            start = i + 1;
+          }
+        ref_names.push_back(name);
+        ref_lengths.push_back(len);
+      }
+      header_text += line + "\n";
+    }
+    if (cfg_.filter.active) {
+      region_ref_id_ = -2;
+      for (size_t i = 0; i < ref_names.size(); ++i)
+        if (ref_names[i] == cfg_.filter.region.name) region_ref_id_ = (int32_t)i;
+    }
+  }
+
+  bool read_batch(struct ArrowArray* out) {
+    BAMArrayBuilder b(&ref_names);
+    std::string line;
+    while ((int64_t)b.len() < cfg_.batch_size) {
+      if (has_pending_) {
+        line.swap(pending_);
+        has_pending_ = false;
+      } else if (!r_.read_line(&line)) {
+        break;
+      }
+      if (line.empty() || line[0] == '@') continue;
+      const char* f[6];
+      size_t fl[6];
+      int nf = 0;
+      size_t start = 0;
+      for (size_t i = 0; i <= line.size() && nf < 6; ++i)
+        if (i == line.size() || line[i] == '\t') {
+          f[nf] = line.data() + start;
+          fl[nf] = i - start;
+          ++nf;
+          start = i + 1;
+        }
+      if (nf < 6) throw std::runtime_error("SAM record has fewer than 6 fields");
+      const int32_t flag = atoi(std::string(f[1], fl[1]).c_str());
+      int32_t ref_id = -1;
+      if (!(fl[2] == 1 && f[2][0] == '*'))
+        for (size_t i = 0; i < ref_names.size(); ++i)
+          if (ref_names[i].size() == fl[2] && memcmp(ref_names[i].data(), f[2], fl[2]) == 0) ref_id = (int32_t)i;
+      const int64_t pos1 = atoll(std::string(f[3], fl[3]).c_str());  // 1-based, 0 = unavailable
+      const int mapq = atoi(std::string(f[4], fl[4]).c_str());
+      int64_t ref_len = 0, num = 0;
+      if (!(fl[5] == 1 && f[5][0] == '*'))
+        for (size_t i = 0; i < fl[5]; ++i) {
+          const char ch = f[5][i];
+          if (ch >= '0' && ch <= '9') num = num * 10 + (ch - '0');
+          else {
+            if (ch == 'M' || ch == 'D' || ch == 'N' || ch == '=' || ch == 'X') ref_len += num;
+            num = 0;
+          }
+        }
+      if (cfg_.filter.active) {
+        if (ref_id < 0 || pos1 < 1) continue;
+        const int64_t e = pos1 + ref_len - 1;
+        const Region& rg = cfg_.filter.region;
+        if (!(ref_id == region_ref_id_ && pos1 <= rg.end && rg.start <= e)) continue;
+      }
+      b.append(flag, ref_id, pos1 - 1, mapq, ref_len);
+    }
+    if (b.is_empty()) return false;
+    b.try_into_record_batch(out);
+    return true;
+  }
+  void schema(struct ArrowSchema* out) const {
+    make_schema(out, "+s", "", false,
+                {new_field("i", "flag", false), new_field("C", "mapping_quality", true),
+                 new_field("i", "reference", true, new_field("u", "", false)), new_field("l", "start", true),
+                 new_field("l", "end", true)});
+  }
+  std::string header_text;
+  std::vector<std::string> ref_names;
+  std::vector<int32_t> ref_lengths;
+
+ private:
+  BufReader r_;
+  BAMConfig cfg_;
+  std::string pending_;
+  bool has_pending_ = false;
+  int32_t region_ref_id_ = -2;
+};
+
+// ======================================================================================================
 // FASTQ   (name, description?, sequence, quality_scores : exon-fastq/src/config.rs:79-88)
 // ======================================================================================================
 struct FASTQConfig {

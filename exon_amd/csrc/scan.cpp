@@ -11,6 +11,7 @@ struct exon_hip_scan {
   int format = 0;
   std::unique_ptr<exon::VCFBatchReader> vcf;
   std::unique_ptr<exon::BAMBatchReader> bam;
+  std::unique_ptr<exon::SAMBatchReader> sam;
   std::unique_ptr<exon::FASTQBatchReader> fastq;
   std::unique_ptr<exon::FASTABatchReader> fasta;
   int64_t rows = 0;
@@ -20,7 +21,7 @@ struct exon_hip_scan {
 static exon::Dictionary* dict_of(exon_hip_scan* s, int col) {
   if (s->format == EXON_HIP_FORMAT_VCF && col == 0) return &s->vcf->chrom_dict;
   if (s->format == EXON_HIP_FORMAT_VCF && col == 3) return &s->vcf->filter_dict;
-  if (s->format == EXON_HIP_FORMAT_BAM && col == 2) return &s->bam_dict_view;
+  if ((s->format == EXON_HIP_FORMAT_BAM || s->format == EXON_HIP_FORMAT_SAM) && col == 2) return &s->bam_dict_view;
   return nullptr;
 }
 
@@ -60,6 +61,15 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         s->bam_dict_view.names = s->bam->ref_names;
         break;
       }
+      case EXON_HIP_FORMAT_SAM: {
+        exon::BAMConfig cfg;
+        cfg.batch_size = bs;
+        cfg.filter = rf;
+        cfg.filter.use_index = false;
+        s->sam.reset(new exon::SAMBatchReader(path, c, cfg));
+        s->bam_dict_view.names = s->sam->ref_names;
+        break;
+      }
       case EXON_HIP_FORMAT_FASTQ: {
         exon::FASTQConfig cfg;
         cfg.batch_size = bs;
@@ -87,6 +97,7 @@ int exon_hip_scan_schema(exon_hip_scan* s, struct ArrowSchema* out) {
   try {
     if (s->vcf) s->vcf->schema(out);
     else if (s->bam) s->bam->schema(out);
+    else if (s->sam) s->sam->schema(out);
     else if (s->fastq) s->fastq->schema(out);
     else s->fasta->schema(out);
     return EXON_HIP_OK;
@@ -102,6 +113,7 @@ int exon_hip_scan_next(exon_hip_scan* s, struct ArrowArray* out) {
     bool got;
     if (s->vcf) got = s->vcf->read_batch(out);
     else if (s->bam) got = s->bam->read_batch(out);
+    else if (s->sam) got = s->sam->read_batch(out);
     else if (s->fastq) got = s->fastq->read_batch(out);
     else got = s->fasta->read_batch(out);
     if (!got) return 1;
@@ -124,7 +136,7 @@ int exon_hip_scan_dictionary_intern(exon_hip_scan* s, int32_t column, const char
   if (!s || !name || !id) return fail(nullptr, EXON_HIP_EINVAL, "NULL argument");
   exon::Dictionary* d = dict_of(s, column);
   if (!d) return fail(nullptr, EXON_HIP_EINVAL, "column %d is not dictionary-encoded", column);
-  if (s->format == EXON_HIP_FORMAT_BAM) {  // BAM reference ids are fixed by the header
+  if (s->format == EXON_HIP_FORMAT_BAM || s->format == EXON_HIP_FORMAT_SAM) {  // reference ids are fixed by the header
     *id = d->find(name);
     return EXON_HIP_OK;
   }

@@ -319,3 +319,15 @@ def test_parallel_fastq_decode_is_identical_to_sequential(tmp_path, monkeypatch)
 
     a, b = scan(1), scan(4)
     assert len(a) == n and a.equals(b)
+
+
+def test_sam_scan_first_row():
+    """slt/sam-select-tests.slt:6-10: ref1_grp1_p001 99 ref1 1 10 0 10M ref1 -- text SAM shares the BAM columns."""
+    s = exon_amd.Scan(fx("sam", "test.sam"), "sam")
+    rows = [r for b in s for r in b.to_pylist()]
+    assert rows[0] == {"flag": 99, "mapping_quality": 0, "reference": "ref1", "start": 1, "end": 10}
+    assert s.dictionary(2) == ["ref1"]
+    n_records = sum(1 for line in open(fx("sam", "test.sam")) if line.strip() and not line.startswith("@"))
+    assert len(rows) == n_records
+    hits = sum(len(b) for b in exon_amd.Scan(fx("sam", "test.sam"), "sam", region="ref1:1-5"))
+    assert hits == sum(1 for r in rows if r["start"] is not None and r["start"] <= 5 and r["end"] >= 1)
