@@ -46,7 +46,7 @@ struct RecordSource {
 };
 struct StreamSource : RecordSource {
   BufReader r;
-  StreamSource(const std::string& path, Compression c) : r(path, c) {}
+  StreamSource(const std::string& path, Compression c, int threads = 0) : r(open_source(path, c, threads)) {}
   bool next_record() override { return true; }
   bool read_line(std::string* line) override { return r.read_line(line); }
   bool read_exact(uint8_t* dst, size_t n) override { return r.read_exact(dst, n); }
@@ -315,7 +315,7 @@ inline void parse_vcf_slab(VCFSlab& s, const void* vctx) {
 class VCFBatchReader {
  public:
   VCFBatchReader(const std::string& path, Compression c, VCFConfig cfg) : cfg_(std::move(cfg)) {
-    r_.reset(new StreamSource(path, c));
+    r_.reset(new StreamSource(path, c, cfg_.threads));
     // header (noodles `read_header`): meta lines '##', then '#CHROM ...'
     std::string line;
     while (r_->read_line(&line)) {
@@ -366,13 +366,7 @@ class VCFBatchReader {
     } else {
       // multi-threaded decode of the rest of the stream (files of at least a couple of slabs)
       const int threads = cfg_.threads > 0 ? cfg_.threads : decode_threads();
-      FILE* f = fopen(path.c_str(), "rb");
-      long fsize = 0;
-      if (f) {
-        fseek(f, 0, SEEK_END);
-        fsize = ftell(f);
-        fclose(f);
-      }
+      const long fsize = file_size(path);
       if (threads > 1 && fsize >= (8 << 20)) {
         StreamSource* ss = static_cast<StreamSource*>(r_.get());
         std::string carry = has_pending_ ? pending_ + "\n" : std::string();
@@ -477,6 +471,7 @@ class VCFBatchReader {
 // ======================================================================================================
 struct BAMConfig {
   int64_t batch_size = DEFAULT_BATCH_SIZE;
+  int threads = 0;  // BGZF inflate threads (0 = all host cores)
   RegionFilter filter;  // bam_region_filter: SemiLazyRecord::intersects
 };
 
@@ -516,7 +511,7 @@ class BAMArrayBuilder : public ExonArrayBuilder {
 class BAMBatchReader {
  public:
   BAMBatchReader(const std::string& path, BAMConfig cfg) : cfg_(std::move(cfg)) {
-    r_.reset(new StreamSource(path, Compression::Gzip));
+    r_.reset(new StreamSource(path, Compression::Gzip, cfg_.threads));
     uint8_t magic[4];
     if (!r_->read_exact(magic, 4) || memcmp(magic, "BAM\1", 4) != 0) throw std::runtime_error("not a BAM file: " + path);
     const int32_t l_text = read_i32();
@@ -784,15 +779,9 @@ inline void parse_fastq_slab(FASTQSlab& s, const void*) {
 
 class FASTQBatchReader {
  public:
-  FASTQBatchReader(const std::string& path, Compression c, FASTQConfig cfg) : r_(path, c), cfg_(cfg) {
+  FASTQBatchReader(const std::string& path, Compression c, FASTQConfig cfg) : r_(open_source(path, c, cfg.threads)), cfg_(cfg) {
     const int threads = cfg_.threads > 0 ? cfg_.threads : decode_threads();
-    FILE* f = fopen(path.c_str(), "rb");
-    long fsize = 0;
-    if (f) {
-      fseek(f, 0, SEEK_END);
-      fsize = ftell(f);
-      fclose(f);
-    }
+    const long fsize = file_size(path);
     // whole 4-line records per slab; blank lines between records are not supported in the parallel path, so it is
     // only taken for inputs that start directly with a record
     if (threads > 1 && fsize >= (8 << 20))

@@ -20,7 +20,14 @@ namespace exon {
 
 enum class Compression { Auto = 0, None = 1, Gzip = 2 };
 
-class ByteReader {
+// a forward-only stream of (decompressed) bytes
+class ByteSource {
+ public:
+  virtual ~ByteSource() = default;
+  virtual size_t read(uint8_t* dst, size_t n) = 0;  // up to n bytes; 0 at end of data
+};
+
+class ByteReader : public ByteSource {
  public:
   ByteReader(const std::string& path, Compression c) : path_(path) {
     f_ = fopen(path.c_str(), "rb");
@@ -45,7 +52,7 @@ class ByteReader {
   ByteReader& operator=(const ByteReader&) = delete;
 
   // up to `n` decompressed bytes; 0 at end of data
-  size_t read(uint8_t* dst, size_t n) {
+  size_t read(uint8_t* dst, size_t n) override {
     if (!gz_) return fread(dst, 1, n, f_);
     size_t produced = 0;
     while (produced < n && !eof_) {
@@ -91,6 +98,7 @@ class ByteReader {
 class BufReader {
  public:
   BufReader(const std::string& path, Compression c) : src_(new ByteReader(path, c)), buf_(1 << 20) {}
+  explicit BufReader(std::unique_ptr<ByteSource> src) : src_(std::move(src)), buf_(1 << 20) {}
 
   // hand the stream over to a parallel decoder: the bytes already buffered but not consumed, then the source
   std::string take_buffered() {
@@ -98,7 +106,7 @@ class BufReader {
     pos_ = end_ = 0;
     return s;
   }
-  std::unique_ptr<ByteReader> release_source() { return std::move(src_); }
+  std::unique_ptr<ByteSource> release_source() { return std::move(src_); }
 
   // reads one line without its terminator ('\n' or "\r\n"); false at end of data
   bool read_line(std::string* line) {
@@ -137,7 +145,7 @@ class BufReader {
     pos_ = 0;
     return end_ > 0;
   }
-  std::unique_ptr<ByteReader> src_;
+  std::unique_ptr<ByteSource> src_;
   std::vector<uint8_t> buf_;
   size_t pos_ = 0, end_ = 0;
 };

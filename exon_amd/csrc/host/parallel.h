@@ -7,6 +7,8 @@
 // is five orders of magnitude below what the GPU consumes, so the decoders here use every host core of the
 // partition's process.  Results are identical to the sequential readers (tests/test_scan_decoders.py).
 #pragma once
+#include <zlib.h>
+
 #include <atomic>
 #include <condition_variable>
 #include <cstring>
@@ -15,6 +17,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -39,7 +42,7 @@ class SlabPipeline {
  public:
   using ParseFn = void (*)(Result&, const void* ctx);
 
-  SlabPipeline(std::unique_ptr<ByteReader> src, std::string carry, int lines_per_record, int threads, ParseFn parse,
+  SlabPipeline(std::unique_ptr<ByteSource> src, std::string carry, int lines_per_record, int threads, ParseFn parse,
                const void* ctx, size_t slab_bytes = 4u << 20)
       : src_(std::move(src)), carry_(std::move(carry)), lpr_(lines_per_record), parse_(parse), ctx_(ctx),
         slab_bytes_(slab_bytes), max_inflight_((size_t)threads * 2 + 2) {
@@ -192,7 +195,7 @@ class SlabPipeline {
     }
   }
 
-  std::unique_ptr<ByteReader> src_;
+  std::unique_ptr<ByteSource> src_;
   std::string carry_;
   const int lpr_;
   ParseFn parse_;
@@ -210,6 +213,198 @@ class SlabPipeline {
   std::exception_ptr read_error_;
 };
 
+// BGZF blocks are independent gzip members of <= 64 KiB: one thread walks the block headers (BSIZE) and hands
+// groups of compressed blocks to N inflate workers; read() returns the inflated bytes in file order.
+// (the reference inflates on the partition's single task via noodles::bgzf::AsyncReader.)
+class BgzfParallelSource : public ByteSource {
+ public:
+  static bool is_bgzf(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    uint8_t h[18];
+    const bool ok = fread(h, 1, 18, f) == 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[12] == 'B' && h[13] == 'C';
+    fclose(f);
+    return ok;
+  }
+  BgzfParallelSource(const std::string& path, int threads) : path_(path), max_inflight_((size_t)threads * 3 + 2) {
+    f_ = fopen(path.c_str(), "rb");
+    if (!f_) throw std::runtime_error("cannot open " + path);
+    reader_ = std::thread([this] { read_loop(); });
+    for (int i = 0; i < threads; ++i) workers_.emplace_back([this] { work_loop(); });
+  }
+  ~BgzfParallelSource() override {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      stop_ = true;
+    }
+    cv_todo_.notify_all();
+    cv_done_.notify_all();
+    cv_space_.notify_all();
+    if (reader_.joinable()) reader_.join();
+    for (auto& w : workers_) w.join();
+    if (f_) fclose(f_);
+  }
+  size_t read(uint8_t* dst, size_t n) override {
+    size_t got = 0;
+    while (got < n) {
+      if (!cur_ || pos_ == cur_->out.size()) {
+        if (!advance()) break;
+        continue;
+      }
+      const size_t k = std::min(n - got, cur_->out.size() - pos_);
+      memcpy(dst + got, cur_->out.data() + pos_, k);
+      pos_ += k;
+      got += k;
+    }
+    return got;
+  }
+
+ private:
+  struct Job {
+    uint64_t id = 0;
+    std::vector<uint8_t> comp;              // whole BGZF blocks, back to back
+    std::vector<std::pair<size_t, size_t>> blocks;  // (offset, size) of each block inside comp
+    std::vector<uint8_t> out;
+    std::exception_ptr error;
+  };
+  bool advance() {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      auto it = done_.find(next_id_);
+      if (it != done_.end()) {
+        cur_ = std::move(it->second);
+        done_.erase(it);
+        ++next_id_;
+        --inflight_;
+        pos_ = 0;
+        cv_space_.notify_one();
+        lk.unlock();
+        if (cur_->error) std::rethrow_exception(cur_->error);
+        return true;
+      }
+      if (read_error_) std::rethrow_exception(read_error_);
+      if (reader_finished_ && next_id_ >= produced_) return false;
+      cv_done_.wait(lk);
+    }
+  }
+  void read_loop() {
+    try {
+      bool eof = false;
+      while (!eof) {
+        std::unique_ptr<Job> job(new Job());
+        while (job->comp.size() < (1u << 20)) {
+          uint8_t h[18];
+          const size_t got = fread(h, 1, 18, f_);
+          if (got == 0) {
+            eof = true;
+            break;
+          }
+          if (got != 18 || h[0] != 0x1f || h[1] != 0x8b || !(h[3] & 4) || h[12] != 'B' || h[13] != 'C')
+            throw std::runtime_error("not a BGZF block: " + path_);
+          uint16_t bsize;
+          memcpy(&bsize, h + 16, 2);
+          const size_t total = (size_t)bsize + 1, off = job->comp.size();
+          job->comp.resize(off + total);
+          memcpy(job->comp.data() + off, h, 18);
+          if (fread(job->comp.data() + off + 18, 1, total - 18, f_) != total - 18) throw std::runtime_error("truncated BGZF block: " + path_);
+          job->blocks.emplace_back(off, total);
+        }
+        if (job->blocks.empty()) continue;
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_space_.wait(lk, [this] { return stop_ || inflight_ < max_inflight_; });
+        if (stop_) return;
+        job->id = produced_++;
+        ++inflight_;
+        todo_.push_back(std::move(job));
+        lk.unlock();
+        cv_todo_.notify_one();
+      }
+    } catch (...) {
+      std::lock_guard<std::mutex> g(mu_);
+      read_error_ = std::current_exception();
+    }
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      reader_finished_ = true;
+    }
+    cv_todo_.notify_all();
+    cv_done_.notify_all();
+  }
+  void work_loop() {
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    const bool zok = inflateInit2(&z, -15) == Z_OK;
+    for (;;) {
+      std::unique_ptr<Job> job;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_todo_.wait(lk, [this] { return stop_ || !todo_.empty() || reader_finished_; });
+        if (stop_) break;
+        if (todo_.empty()) {
+          if (reader_finished_) break;
+          continue;
+        }
+        job = std::move(todo_.front());
+        todo_.pop_front();
+      }
+      try {
+        if (!zok) throw std::runtime_error("inflateInit2 failed");
+        size_t total = 0;
+        for (auto& b : job->blocks) {
+          uint32_t isize;
+          memcpy(&isize, job->comp.data() + b.first + b.second - 4, 4);
+          total += isize;
+        }
+        job->out.resize(total);
+        size_t o = 0;
+        for (auto& b : job->blocks) {
+          const uint8_t* blk = job->comp.data() + b.first;
+          uint16_t xlen;
+          memcpy(&xlen, blk + 10, 2);
+          uint32_t isize;
+          memcpy(&isize, blk + b.second - 4, 4);
+          const size_t hdr = 12 + (size_t)xlen;
+          if (isize) {
+            inflateReset(&z);
+            z.next_in = const_cast<uint8_t*>(blk + hdr);
+            z.avail_in = (uInt)(b.second - hdr - 8);
+            z.next_out = job->out.data() + o;
+            z.avail_out = isize;
+            if (inflate(&z, Z_FINISH) != Z_STREAM_END) throw std::runtime_error("BGZF inflate error: " + path_);
+          }
+          o += isize;
+        }
+        std::vector<uint8_t>().swap(job->comp);
+      } catch (...) {
+        job->error = std::current_exception();
+      }
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        const uint64_t id = job->id;
+        done_[id] = std::move(job);
+      }
+      cv_done_.notify_all();
+    }
+    if (zok) inflateEnd(&z);
+  }
+
+  std::string path_;
+  FILE* f_ = nullptr;
+  const size_t max_inflight_;
+  std::thread reader_;
+  std::vector<std::thread> workers_;
+  std::mutex mu_;
+  std::condition_variable cv_todo_, cv_done_, cv_space_;
+  std::deque<std::unique_ptr<Job>> todo_;
+  std::map<uint64_t, std::unique_ptr<Job>> done_;
+  std::unique_ptr<Job> cur_;
+  size_t pos_ = 0;
+  uint64_t produced_ = 0, next_id_ = 0;
+  size_t inflight_ = 0;
+  bool stop_ = false, reader_finished_ = false;
+  std::exception_ptr read_error_;
+};
+
 inline int decode_threads() {
   if (const char* v = getenv("EXON_HIP_DECODE_THREADS")) {
     const int t = atoi(v);
@@ -217,6 +412,23 @@ inline int decode_threads() {
   }
   const unsigned hc = std::thread::hardware_concurrency();  // target_partitions = num_cpus in the reference
   return hc ? (int)hc : 1;
+}
+
+inline long file_size(const std::string& path) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return -1;
+  fseek(f, 0, SEEK_END);
+  const long n = ftell(f);
+  fclose(f);
+  return n;
+}
+
+// the byte source for a file: parallel BGZF inflate for big BGZF inputs, sequential (gzip / plain) otherwise
+inline std::unique_ptr<ByteSource> open_source(const std::string& path, Compression c, int threads) {
+  if (threads <= 0) threads = decode_threads();
+  if (c != Compression::None && threads > 1 && file_size(path) >= (8 << 20) && BgzfParallelSource::is_bgzf(path))
+    return std::unique_ptr<ByteSource>(new BgzfParallelSource(path, std::min(threads, 32)));
+  return std::unique_ptr<ByteSource>(new ByteReader(path, c));
 }
 
 }  // namespace exon

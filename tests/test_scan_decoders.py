@@ -331,3 +331,74 @@ def test_sam_scan_first_row():
     assert len(rows) == n_records
     hits = sum(len(b) for b in exon_amd.Scan(fx("sam", "test.sam"), "sam", region="ref1:1-5"))
     assert hits == sum(1 for r in rows if r["start"] is not None and r["start"] <= 5 and r["end"] >= 1)
+
+
+# ---- parallel BGZF inflate -----------------------------------------------------------------------------------
+def _bgzf_write(path, data, block=60000, level=1):
+    import struct
+    import zlib
+    with open(path, "wb") as f:
+        for i in list(range(0, len(data), block)) + [None]:
+            chunk = b"" if i is None else data[i:i + block]   # trailing empty block = BGZF EOF marker
+            c = zlib.compressobj(level, zlib.DEFLATED, -15)
+            comp = c.compress(chunk) + c.flush()
+            bsize = len(comp) + 25
+            f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + comp +
+                    struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+
+
+def test_parallel_bgzf_vcf_equals_plain(tmp_path, monkeypatch):
+    import pyarrow as pa
+    p = tmp_path / "big.vcf"
+    _big_vcf(p, 700_000, seed=11)
+    gz = tmp_path / "big.vcf.gz"
+    _bgzf_write(gz, open(p, "rb").read())
+    assert gz.stat().st_size > (8 << 20)
+
+    def scan(path, threads):
+        monkeypatch.setenv("EXON_HIP_DECODE_THREADS", str(threads))
+        s = exon_amd.Scan(path, "vcf", info_field="AF")
+        out = pa.concat_arrays(list(s))
+        s.close()
+        return out
+
+    plain = scan(p, 1)
+    assert plain.equals(scan(gz, 1))   # sequential multi-member inflate
+    assert plain.equals(scan(gz, 4))   # parallel block inflate + parallel parse
+
+
+def test_parallel_bgzf_bam_equals_sequential(tmp_path, monkeypatch):
+    import struct
+    import pyarrow as pa
+    rng = np.random.default_rng(21)
+    refs = [(b"chr1", 248956422), (b"chr2", 242193529), (b"chrM", 16569)]
+    out = bytearray(b"BAM\x01" + struct.pack("<i", 0) + struct.pack("<i", len(refs)))
+    for name, ln in refs:
+        out += struct.pack("<i", len(name) + 1) + name + b"\x00" + struct.pack("<i", ln)
+    n = 400_000
+    flags = rng.choice([99, 147, 83, 163, 77, 1123, 355], n)
+    for i in range(n):
+        unmapped = flags[i] == 77
+        ref_id = -1 if unmapped else int(rng.integers(0, 3))
+        pos = -1 if unmapped else int(rng.integers(0, 10_000_000))
+        mapq = int(rng.choice([0, 17, 30, 60, 255]))
+        cigar = [] if unmapped else [(int(rng.integers(20, 100)) << 4) | 0, (int(rng.integers(1, 2000)) << 4) | 3, (30 << 4) | 0]
+        name = b"r%d\x00" % i
+        l_seq = 8
+        body = struct.pack("<iiBBHHHiiii", ref_id, pos, len(name), mapq, 4680, len(cigar), int(flags[i]), l_seq, -1, -1, 0)
+        body += name + b"".join(struct.pack("<I", c) for c in cigar) + b"\x11" * ((l_seq + 1) // 2) + b"\x1e" * l_seq
+        out += struct.pack("<i", len(body)) + body
+    p = tmp_path / "big.bam"
+    _bgzf_write(p, bytes(out), level=0)  # stored blocks: keeps the file above the parallel threshold
+    assert p.stat().st_size > (8 << 20)
+
+    def scan(threads, **kw):
+        monkeypatch.setenv("EXON_HIP_DECODE_THREADS", str(threads))
+        s = exon_amd.Scan(p, "bam", **kw)
+        out = pa.concat_arrays(list(s))
+        s.close()
+        return out
+
+    a, b = scan(1), scan(4)
+    assert len(a) == n and a.equals(b)
+    assert scan(1, region="chr2:5000-900000").equals(scan(4, region="chr2:5000-900000"))
