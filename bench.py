@@ -164,7 +164,15 @@ def cpu_baseline(kind, sample_rows, n_total, reps):
             secs.append(t.seconds_exec), mat.append(t.seconds_materialize)
         out = (cnt, None)
     best = float(np.median(secs))
+    # single-thread figure on a slice of the same rows (SURVEY section 8d asks for both)
+    one = None
+    if kind == "c4":
+        m = min(n, 8_000_000)
+        _, _, _, t1 = orc.c4_cmp_avg_by_group(af[:m], av[:(m + 7) // 8], q[:m], qv[:(m + 7) // 8], fid[:m], orc.c4_filters(),
+                                              0.01, ">", threads=1)
+        one = round(m / t1.seconds_exec / 1e6, 2)
     res = {"value": round(n / best / 1e6, 2), "unit": "Mrows/s", "cores": t.threads, "kind": "port",
+           "single_thread_value": one,
            "sample": f"rows [0,{n}) of the same synthetic table as 8192-row Arrow-layout batches (Utf8/List<Utf8> keys), "
                      f"{t.threads} partitions = host cores; median of {reps} runs, {best:.3f}s exec each "
                      f"(+{float(np.median(mat)):.2f}s untimed Arrow-layout build); total CPU work "

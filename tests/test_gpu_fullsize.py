@@ -1,0 +1,105 @@
+"""GPU tests at BASELINE.json's full sizes, through size-independent properties (the oracle cannot run 1e9 rows in
+a test): partition identities, shard additivity (the multi-GPU merge rule), determinism."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def k4(ctx, cols, n, thr, op, G=5):
+    af, av, q, qv, fid = cols
+    dc, ds = ctx.zeros(np.int64, 2 * G), ctx.zeros(np.float64, G)
+    ctx.cmp_avg_by_group(af, av, q, qv, fid, n, thr, op, G, dc, ds)
+    ctx.sync()
+    return dc.to_host(), ds.to_host()
+
+
+def test_config4_one_billion_rows_properties(ctx):
+    n = 1_000_000_000
+    cols = ctx.gen_c4(4, 0, n)
+    gt_c, gt_s = k4(ctx, cols, n, 0.01, ">")
+    le_c, le_s = k4(ctx, cols, n, 0.01, "<=")
+    all_c, all_s = k4(ctx, cols, n, float("-inf"), ">=")
+    # {x > t} and {x <= t} partition the rows with a valid x
+    assert np.array_equal(gt_c + le_c, all_c)
+    assert np.allclose(gt_s + le_s, all_s, rtol=1e-12, atol=0)
+    valid_rows = int(all_c[5:].sum())
+    assert 0.9895 * n < valid_rows < 0.9905 * n                      # 1 % NULL AF by construction
+    assert abs(gt_c[5:].sum() / valid_rows - 0.4803) < 0.002         # selectivity of AF > 0.01 for this generator
+    assert np.all(gt_c[:5] <= gt_c[5:])                              # COUNT(qual) <= COUNT(*)
+    shares = gt_c[5:] / gt_c[5:].sum()
+    assert np.allclose(shares, [0.85, 0.05, 0.06, 0.03, 0.01], atol=2e-4)
+    avg = gt_s / gt_c[:5]
+    assert np.all(np.abs(avg - 499.95) < 0.6)                        # qual ~ U{0.0 .. 999.9}
+    # shard additivity: 8 file splits processed separately add up to the whole (what the RCCL merge relies on)
+    tot_c, tot_s = np.zeros(10, np.int64), np.zeros(5)
+    per = n // 8
+    for r in range(8):
+        shard = ctx.gen_c4(4, r * per, (r + 1) * per)
+        c, s = k4(ctx, shard, per, 0.01, ">")
+        tot_c += c
+        tot_s += s
+        del shard
+    assert np.array_equal(tot_c, gt_c) and np.allclose(tot_s, gt_s, rtol=1e-12, atol=0)
+    # run-to-run determinism at full size
+    again_c, again_s = k4(ctx, cols, n, 0.01, ">")
+    assert np.array_equal(again_c, gt_c) and again_s.tobytes() == gt_s.tobytes()
+
+
+def test_config2_region_partition(ctx, oracle):
+    n = 10_000_000  # config 2's stated size
+    c, p = ctx.gen_c2(2, n)
+    starts = np.zeros(25, np.int64)
+    lens = oracle.c2_contig_lens()
+    total = sum(lens)
+    cum = 0
+    for i, ln in enumerate(lens):
+        cum += ln
+        starts[i + 1] = n * cum // total
+    starts[24] = n
+
+    def count(cid, a, b):
+        d = ctx.zeros(np.int64, 1)
+        ctx.region_count(c, p, n, cid, a, b, d)
+        ctx.sync()
+        return int(d.to_host()[0])
+
+    per_contig = [count(cid, 1, None) for cid in range(24)]
+    assert per_contig == [int(starts[i + 1] - starts[i]) for i in range(24)] and sum(per_contig) == n
+    assert count(6, 1, 49_999_999) + count(6, 50_000_000, 100_000_000) + count(6, 100_000_001, None) == per_contig[6]
+    hc, hp = oracle.gen_c2(2, n)
+    assert count(6, 50_000_000, 100_000_000) == oracle.c2_region_count(hc, hp, oracle.c2_contigs(), "7:50000000-100000000")[0]
+
+
+def test_config3_one_hundred_million_rows_properties(ctx):
+    n = 100_000_000
+    f, mq, mv, ref, rv = ctx.gen_c3(3, 0, n)
+
+    def run(mask, value, qmin):
+        d = ctx.zeros(np.int64, 26)
+        ctx.flag_mapq_group_count(f, mq, mv, ref, rv, n, mask, value, qmin, 25, d)
+        ctx.sync()
+        return d.to_host()
+
+    every = run(0, 0, -1)                      # all rows with a non-NULL mapq
+    assert 0.9795 * n < every.sum() < 0.9805 * n   # 2 % NULL mapq
+    mapped, unmapped = run(4, 0, -1), run(4, 4, -1)
+    assert np.array_equal(mapped + unmapped, every)
+    assert unmapped[:25].sum() == 0 and mapped[25] == 0   # reference is NULL exactly when the read is unmapped
+    q30 = run(1284, 0, 30)
+    lo = run(1284, 0, -1) - q30                # same flag predicate, mapq < 30
+    assert np.all(lo >= 0) and abs(q30.sum() / n - 0.89 * 0.78 / 0.98 * 0.98) < 0.01
+
+
+def test_config5_histogram_rows_sum_to_reads(ctx):
+    n, L = 16_000_000, 100
+    off, data = ctx.gen_c5(5, 0, n, L)
+    d = ctx.zeros(np.int64, L * 256)
+    ctx.qual_pos_hist(off, data, n, L, d)
+    ctx.qual_pos_hist(off, data, n, L, d)  # accumulate a second batch
+    ctx.sync()
+    h = d.to_host().reshape(L, 256)
+    assert np.all(h.sum(axis=1) == 2 * n)
+    assert h[:, :33].sum() == 0 and h[:, 75:].sum() == 0   # bytes are 33 + [0, 41]
+    mean_q = (h * np.arange(256)).sum(axis=1) / (2 * n) - 33
+    assert np.all(np.diff(mean_q) < 0.2) and mean_q[0] > mean_q[-1] + 8   # quality declines along the read
