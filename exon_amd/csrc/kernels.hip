@@ -661,8 +661,8 @@ hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Wo
 //
 //   The limiter is LDS atomic throughput, i.e. bank conflicts (profiles/r1_tuning.md, tools/tune_k5.hip).
 //   One 1024-thread workgroup per CU owns a u32 LDS histogram of the ASCII half of the byte range (quality
-//   strings are Phred+33 <= 126; a byte >= 128 goes straight to a global atomic).  Three paths, chosen ON THE
-//   DEVICE from `k5_scan_offsets` (no host round trip):
+//   strings are Phred+33 <= 126; a byte >= 128 goes straight to a global atomic).  Three paths inside ONE kernel,
+//   chosen ON THE DEVICE from `k5_scan_offsets` (no host round trip, no empty launches):
 //     A  uniform read length L, L % 4 == 0, 64 <= L <= 256: every lane loads one dword (4 consecutive positions);
 //        the histogram is byte-major h[byte][perm(p)], perm(p) = (p & 3) * LP/4 + (p >> 2), so for a fixed
 //        byte-in-dword the 64 lanes of a wave hit consecutive banks whatever the data is: conflict-free.
@@ -688,24 +688,34 @@ __global__ __launch_bounds__(256) void k5_scan_offsets(const int32_t* __restrict
   if (__any(too_long) && (threadIdx.x & 63) == 0) atomicOr(status, 8);
 }
 
-enum { K5_PATH_A128 = 0, K5_PATH_A256 = 1, K5_PATH_B = 2, K5_PATH_G = 3 };
-__device__ __forceinline__ int k5_pick_path(const int32_t* off, const uint8_t* bytes, int lmax, const int* flags) {
+enum { K5_PATH_A = 0, K5_PATH_B = 2, K5_PATH_G = 3 };
+__device__ __forceinline__ int k5_pick_path(const int32_t* off, const uint8_t* bytes, int lmax, int lp,
+                                            const int* flags) {
   if (flags[0]) return K5_PATH_G;
   const int L = off[1] - off[0];
   if (L < 1 || L > lmax) return K5_PATH_G;
   const uintptr_t base = reinterpret_cast<uintptr_t>(bytes + off[0]);
-  if ((L & 3) == 0 && L >= 64 && L <= 256 && (base & 3) == 0) return L <= 128 ? K5_PATH_A128 : K5_PATH_A256;
+  if ((L & 3) == 0 && L >= 64 && L <= lp && (base & 3) == 0) return K5_PATH_A;
   if (L <= K5_PT_MAX && (base & 15) == 0) return K5_PATH_B;
   return K5_PATH_G;
 }
 
 // partial record of a workgroup: u64 [pt][128] (position-major, ASCII half); bytes >= 128 never reach it
+__device__ void k5_paths_bg(int path, const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes, int64_t n,
+                            int lmax, int pt, unsigned long long* __restrict__ partials,
+                            unsigned long long* __restrict__ d_hist);
+
+// One launch per batch: path A in place, paths B / G through k5_paths_bg (same workgroup shape, same LDS block).
 template <int LP>
-__global__ __launch_bounds__(K5_THREADS) void k5_path_a(const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes,
-                                                        int64_t n, int lmax, int pt, const int* __restrict__ flags,
-                                                        unsigned long long* __restrict__ partials,
-                                                        unsigned long long* __restrict__ d_hist) {
-  if (k5_pick_path(off, bytes, lmax, flags) != (LP == 128 ? K5_PATH_A128 : K5_PATH_A256)) return;
+__global__ __launch_bounds__(K5_THREADS) void k5_main(const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes,
+                                                      int64_t n, int lmax, int pt, const int* __restrict__ flags,
+                                                      unsigned long long* __restrict__ partials,
+                                                      unsigned long long* __restrict__ d_hist) {
+  const int path = k5_pick_path(off, bytes, lmax, LP, flags);
+  if (path != K5_PATH_A) {
+    k5_paths_bg(path, off, bytes, n, lmax, pt, partials, d_hist);
+    return;
+  }
   extern __shared__ unsigned k5_h[];  // [128][LP]
   constexpr int Q = LP / 4, J = K5_JA;
   for (int i = threadIdx.x; i < 128 * LP; i += K5_THREADS) k5_h[i] = 0;
@@ -756,12 +766,9 @@ __global__ __launch_bounds__(K5_THREADS) void k5_path_a(const int32_t* __restric
   }
 }
 
-__global__ __launch_bounds__(K5_THREADS) void k5_path_bg(const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes,
-                                                         int64_t n, int lmax, int pt, const int* __restrict__ flags,
-                                                         unsigned long long* __restrict__ partials,
-                                                         unsigned long long* __restrict__ d_hist) {
-  const int path = k5_pick_path(off, bytes, lmax, flags);
-  if (path != K5_PATH_B && path != K5_PATH_G) return;
+__device__ void k5_paths_bg(int path, const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes, int64_t n,
+                            int lmax, int pt, unsigned long long* __restrict__ partials,
+                            unsigned long long* __restrict__ d_hist) {
   extern __shared__ unsigned k5_h[];  // [pt][129]
   for (int i = threadIdx.x; i < pt * 129; i += K5_THREADS) k5_h[i] = 0;
   __syncthreads();
@@ -860,22 +867,20 @@ hipError_t launch_qual_pos_hist(hipStream_t s, const LaunchCfg& cfg, const Works
   if (e != hipSuccess) return e;
   int sgrid = (int)std::min<int64_t>((n_reads + 255) / 256, (int64_t)cfg.compute_units * 8);
   hipLaunchKernelGGL(k5_scan_offsets, dim3(sgrid), dim3(256), 0, s, offsets, n_reads, lmax, flags, ws.status);
-  const size_t lds_a128 = 128 * 128 * 4, lds_a256 = 128 * 256 * 4, lds_bg = (size_t)pt * 129 * 4;
+  // LDS block: the larger of path A's [128][LP] and paths B/G's [pt][129]
+  const bool lp256 = lmax > 128;
+  const size_t lds = std::max<size_t>((size_t)128 * (lp256 ? 256 : 128) * 4, (size_t)pt * 129 * 4);
   static std::once_flag attr_once;
   hipError_t attr_err = hipSuccess;
   std::call_once(attr_once, [&] {
-    hipError_t e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_path_a<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a128)) != hipSuccess) attr_err = e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_path_a<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a256)) != hipSuccess) attr_err = e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_path_bg), hipFuncAttributeMaxDynamicSharedMemorySize, K5_PT_MAX * 129 * 4)) != hipSuccess) attr_err = e;
+    hipError_t e2;
+    const int cap = 160 * 1024;
+    if ((e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_main<128>), hipFuncAttributeMaxDynamicSharedMemorySize, cap)) != hipSuccess) attr_err = e2;
+    if ((e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_main<256>), hipFuncAttributeMaxDynamicSharedMemorySize, cap)) != hipSuccess) attr_err = e2;
   });
   if (attr_err != hipSuccess) return attr_err;
-  // exactly one of the (up to three) launches does work (device-side choice); the others return immediately
-  if (lmax >= 64) {
-    hipLaunchKernelGGL(k5_path_a<128>, dim3(grid), dim3(K5_THREADS), lds_a128, s, offsets, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
-    if (lmax > 128) hipLaunchKernelGGL(k5_path_a<256>, dim3(grid), dim3(K5_THREADS), lds_a256, s, offsets, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
-  }
-  hipLaunchKernelGGL(k5_path_bg, dim3(grid), dim3(K5_THREADS), lds_bg, s, offsets, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
+  if (lp256) hipLaunchKernelGGL(k5_main<256>, dim3(grid), dim3(K5_THREADS), lds, s, offsets, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
+  else hipLaunchKernelGGL(k5_main<128>, dim3(grid), dim3(K5_THREADS), lds, s, offsets, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k5_finalize, dim3((pt * 128 + 255) / 256, 8), dim3(256), 0, s, ws.partials, grid, pt, hist);
