@@ -24,6 +24,7 @@
 #include "bgzf_index.h"
 #include "io.h"
 #include "parallel.h"
+#include "raw_batch.h"
 #include "region.h"
 
 namespace exon {
@@ -404,6 +405,28 @@ class VCFBatchReader {
     return true;
   }
 
+  // Parallel mode only: the rest of the current slab as raw columns (no Arrow materialisation); false when the
+  // reader is sequential (use read_batch) or the input is exhausted (*end = true).
+  bool read_raw(RawBatch* out, bool* end) {
+    *end = false;
+    if (!pipe_) return false;
+    if (!next_slab()) {
+      *end = true;
+      return false;
+    }
+    const size_t o = cur_pos_, n = cur_->rows - o;
+    VCFArrayBuilder& b = *cur_->b;
+    out->rows = (int64_t)n;
+    out->cols.clear();
+    out->cols.push_back({b.chrom_ids().values.data() + o, nullptr, 4});
+    out->cols.push_back({b.positions().values.data() + o, b.positions().valid.data() + o, 8});
+    out->cols.push_back({b.quals().values.data() + o, b.quals().valid.data() + o, 4});
+    out->cols.push_back({b.filter_ids().values.data() + o, nullptr, 4});
+    if (!cfg_.info_field.empty()) out->cols.push_back({b.infos().values.data() + o, b.infos().valid.data() + o, 4});
+    cur_pos_ = cur_->rows;
+    return true;
+  }
+
   void schema(struct ArrowSchema* out) const {
     std::vector<struct ArrowSchema*> kids = {new_field("i", "chrom", false, new_field("u", "", false)),
                                              new_field("l", "pos", true), new_field("f", "qual", true),
@@ -418,7 +441,8 @@ class VCFBatchReader {
 
  private:
   // emit up to batch_size rows of the current slab (re-keyed to the reader's dictionaries)
-  bool read_batch_parallel(struct ArrowArray* out) {
+  // advance to the next non-empty slab and re-key it; false at end of input
+  bool next_slab() {
     while (!cur_ || cur_pos_ >= cur_->rows) {
       cur_ = pipe_->next();
       if (!cur_) return false;
@@ -438,6 +462,11 @@ class VCFBatchReader {
         v = g;
       }
     }
+    return true;
+  }
+
+  bool read_batch_parallel(struct ArrowArray* out) {
+    if (!next_slab()) return false;
     const size_t n = std::min<size_t>((size_t)cfg_.batch_size, cur_->rows - cur_pos_), o = cur_pos_;
     auto slice = [&](auto& pb, int elem, struct ArrowArray* dict) {
       struct ArrowArray* a = static_cast<struct ArrowArray*>(malloc(sizeof *a));

@@ -18,6 +18,8 @@ struct exon_hip_scan {
   exon::Dictionary bam_dict_view;  // reference names as a dictionary (ids = header order)
 };
 
+int exon_hip_stream_push_raw(exon_hip_stream* st, const exon::RawBatch& rb);  // stream.cpp
+
 static exon::Dictionary* dict_of(exon_hip_scan* s, int col) {
   if (s->format == EXON_HIP_FORMAT_VCF && col == 0) return &s->vcf->chrom_dict;
   if (s->format == EXON_HIP_FORMAT_VCF && col == 3) return &s->vcf->filter_dict;
@@ -195,6 +197,25 @@ int exon_hip_scan_close(exon_hip_scan* s) {
 int exon_hip_stream_consume_scan(exon_hip_stream* st, exon_hip_scan* scan, int64_t* rows) {
   if (!st || !scan) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_stream_consume_scan: NULL argument");
   int64_t n = 0;
+  // fast path: a multi-threaded VCF scan hands its slabs over as raw vectors (no Arrow batch in between)
+  if (scan->vcf) {
+    try {
+      exon::RawBatch rb;
+      bool end = false;
+      while (scan->vcf->read_raw(&rb, &end)) {
+        const int rc = exon_hip_stream_push_raw(st, rb);
+        if (rc < 0) return rc;
+        n += rb.rows;
+        scan->rows += rb.rows;
+      }
+      if (end) {
+        if (rows) *rows = n;
+        return EXON_HIP_OK;
+      }
+    } catch (const std::exception& e) {
+      return fail(nullptr, EXON_HIP_EINVAL, "%s", e.what());
+    }
+  }
   for (;;) {
     struct ArrowArray batch;
     int rc = exon_hip_scan_next(scan, &batch);

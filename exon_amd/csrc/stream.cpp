@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "host/arrow_build.h"
+#include "host/raw_batch.h"
 #include "internal.h"
 
 namespace {
@@ -393,6 +394,51 @@ int exon_hip_stream_push(exon_hip_stream* st, struct ArrowArray* batch) {
   batch->release(batch);  // moved: released exactly once, success or not
   return rc;
 }
+
+}  // extern "C"
+
+// Internal (C++): append decoder output (raw vectors + validity bytes) to the staging slot.  Fixed-width plans only.
+int exon_hip_stream_push_raw(exon_hip_stream* st, const exon::RawBatch& rb) {
+  exon_hip_plan* p = st->plan;
+  if (st->closed) return fail(st->ctx, EXON_HIP_ESTATE, "push after finish/close");
+  for (int c = 0; c < p->n_cols; ++c) {
+    if (p->cols[c].utf8) return fail(st->ctx, EXON_HIP_EUNSUPPORTED, "raw push of a Utf8 column");
+    const int idx = p->d.columns[c];
+    if (idx >= (int)rb.cols.size()) return fail(st->ctx, EXON_HIP_EINVAL, "scan has %zu columns, plan needs index %d", rb.cols.size(), idx);
+    if (rb.cols[(size_t)idx].elem != p->cols[c].elem) return fail(st->ctx, EXON_HIP_EINVAL, "column %d: element size %d, plan expects %d", idx, rb.cols[(size_t)idx].elem, p->cols[c].elem);
+  }
+  int64_t done = 0;
+  while (done < rb.rows) {
+    int rc = ensure_capacity(st, 1, 0);
+    if (rc) return rc;
+    if (st->slots[st->cur].rows >= st->cap_rows && (rc = flush_slot(st))) return rc;
+    Slot& s = st->slots[st->cur];
+    const int64_t n = std::min<int64_t>(rb.rows - done, st->cap_rows - s.rows);
+    for (int c = 0; c < p->n_cols; ++c) {
+      const exon::RawColumn& rc2 = rb.cols[(size_t)p->d.columns[c]];
+      ColStage& cs = s.cols[(size_t)c];
+      const int e = p->cols[c].elem;
+      memcpy(cs.h_values + (size_t)s.rows * e, static_cast<const uint8_t*>(rc2.values) + (size_t)done * e, (size_t)n * e);
+      if (rc2.valid_bytes) {
+        if (!cs.any_null_bitmap) {
+          append_bits(cs.h_valid, 0, nullptr, 0, s.rows);
+          cs.any_null_bitmap = true;
+        }
+        const uint8_t* v = rc2.valid_bytes + done;
+        for (int64_t i = 0; i < n; ++i)
+          if (v[i]) cs.h_valid[(s.rows + i) >> 3] |= (uint8_t)(1u << ((s.rows + i) & 7));
+      } else if (cs.any_null_bitmap) {
+        append_bits(cs.h_valid, s.rows, nullptr, 0, n);
+      }
+    }
+    s.rows += n;
+    st->rows_pushed += n;
+    done += n;
+  }
+  return EXON_HIP_OK;
+}
+
+extern "C" {
 
 int exon_hip_stream_push_device(exon_hip_stream* st, const struct ArrowDeviceArray* dbatch) {
   if (!st || !dbatch) return fail(st ? st->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_stream_push_device: NULL argument");

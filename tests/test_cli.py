@@ -144,3 +144,31 @@ def test_cli_fastq_histogram(oracle):
     got = {(int(r[0]), int(r[1])): int(r[2]) for r in cells(out)}
     want = {(p + 1, b - 33): int(h[p, b]) for p in range(64) for b in range(256) if h[p, b]}
     assert got == want
+
+
+@pytest.mark.gpu
+def test_cli_big_file_parallel_decode_raw_handoff(tmp_path, oracle):
+    """> 8 MB of text: multi-threaded decode, slabs handed to the stream as raw vectors, several staging flushes."""
+    gen = os.path.join(ROOT, "tools", "bin", "gen_text")
+    if not os.path.exists(gen):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tools", "gen_text.cpp"), "-o", gen])
+    n = 1_500_000
+    p = tmp_path / "syn.vcf"
+    subprocess.check_call([gen, "vcf", str(n), str(p)])
+    assert p.stat().st_size > (8 << 20)
+    env = dict(os.environ, EXON_HIP_COALESCE_ROWS="300000")
+    r = subprocess.run([CLI, "-q", "-c", "SET exon.vcf_parse_info = true;"
+                        f"CREATE EXTERNAL TABLE v STORED AS VCF LOCATION '{p}';"
+                        'SELECT filter, AVG(qual), COUNT(*) FROM v WHERE info."AF" > 0.01 GROUP BY filter'],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr
+    af, av, q, qv, fid = oracle.gen_c4(4, 0, n)
+    filters = oracle.c4_filters()
+    s, cn, cr, _ = oracle.c4_cmp_avg_by_group(af, av, q, qv, fid, filters, 0.01, ">")
+    got = {row[0]: (float(row[1]), int(row[2])) for row in cells(r.stdout)}
+    for g, name in enumerate(filters):
+        key = "[" + ", ".join(name.split(";")) + "]" if name else "[]"
+        assert got[key][1] == cr[g]
+        assert got[key][0] == pytest.approx(s[g] / cn[g], rel=1e-6)
+    out = run(f"SELECT COUNT(*) FROM vcf_scan('{p}') WHERE chrom = '1' AND pos >= 1000 AND pos <= 1200000").stdout
+    assert last_count(out) == 1200000 - 1000 + 1
