@@ -667,11 +667,12 @@ hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Wo
 //        the histogram is byte-major h[byte][perm(p)], perm(p) = (p & 3) * LP/4 + (p >> 2), so for a fixed
 //        byte-in-dword the 64 lanes of a wave hit consecutive banks whatever the data is: conflict-free.
 //     B  any other uniform L <= 310: 16-byte chunk per lane, h[p][129] (+1 pad: bank = p + byte).
-//     G  ragged reads: one wave per read (same kernel and layout as B).
+//     G  ragged reads: a half-wave per read, one (unaligned) dword per lane, 8 reads in flight; byte-major layout
+//        as A when lmax <= LP.
 //   Paths A/B never touch the offsets buffer again (they use L), so HBM traffic is 4 + L bytes per read.
 // ------------------------------------------------------------------------------------------------
 constexpr int K5_THREADS = 1024;
-constexpr int K5_PT_MAX = 310;  // positions kept in LDS by paths B/G: 310 * 129 * 4 B = 159,960 B
+constexpr int K5_PT_MAX = 310;  // positions kept in LDS by the [p][129] layout: 310 * 129 * 4 B = 159,960 B
 constexpr int K5_JA = 16, K5_JB = 4;
 
 // flags[0] = 1 when read lengths differ (or a read is longer than lmax -> status bit 8)
@@ -701,9 +702,12 @@ __device__ __forceinline__ int k5_pick_path(const int32_t* off, const uint8_t* b
 }
 
 // partial record of a workgroup: u64 [pt][128] (position-major, ASCII half); bytes >= 128 never reach it
-__device__ void k5_paths_bg(int path, const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes, int64_t n,
-                            int lmax, int pt, unsigned long long* __restrict__ partials,
-                            unsigned long long* __restrict__ d_hist);
+__device__ void k5_path_b(const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes, int64_t n, int lmax,
+                          int pt, unsigned long long* __restrict__ partials, unsigned long long* __restrict__ d_hist);
+template <int LP>
+__device__ void k5_path_ragged(const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes, int64_t n, int lmax,
+                               int pt, unsigned long long* __restrict__ partials,
+                               unsigned long long* __restrict__ d_hist);
 
 // One launch per batch: path A in place, paths B / G through k5_paths_bg (same workgroup shape, same LDS block).
 template <int LP>
@@ -712,8 +716,12 @@ __global__ __launch_bounds__(K5_THREADS) void k5_main(const int32_t* __restrict_
                                                       unsigned long long* __restrict__ partials,
                                                       unsigned long long* __restrict__ d_hist) {
   const int path = k5_pick_path(off, bytes, lmax, LP, flags);
-  if (path != K5_PATH_A) {
-    k5_paths_bg(path, off, bytes, n, lmax, pt, partials, d_hist);
+  if (path == K5_PATH_B) {
+    k5_path_b(off, bytes, n, lmax, pt, partials, d_hist);
+    return;
+  }
+  if (path == K5_PATH_G) {
+    k5_path_ragged<LP>(off, bytes, n, lmax, pt, partials, d_hist);
     return;
   }
   extern __shared__ unsigned k5_h[];  // [128][LP]
@@ -766,9 +774,8 @@ __global__ __launch_bounds__(K5_THREADS) void k5_main(const int32_t* __restrict_
   }
 }
 
-__device__ void k5_paths_bg(int path, const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes, int64_t n,
-                            int lmax, int pt, unsigned long long* __restrict__ partials,
-                            unsigned long long* __restrict__ d_hist) {
+__device__ void k5_path_b(const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes, int64_t n, int lmax,
+                          int pt, unsigned long long* __restrict__ partials, unsigned long long* __restrict__ d_hist) {
   extern __shared__ unsigned k5_h[];  // [pt][129]
   for (int i = threadIdx.x; i < pt * 129; i += K5_THREADS) k5_h[i] = 0;
   __syncthreads();
@@ -776,7 +783,7 @@ __device__ void k5_paths_bg(int path, const int32_t* __restrict__ off, const uin
     if (p < pt && b < 128) atomicAdd(&k5_h[p * 129 + b], 1u);
     else atomicAdd(&d_hist[(size_t)p * 256 + b], 1ull);
   };
-  if (path == K5_PATH_B) {  // uniform read length: 16-byte chunk per lane
+  {  // uniform read length: 16-byte chunk per lane
     constexpr int J = K5_JB;
     const int L = off[1] - off[0];
     const uint8_t* src = bytes + off[0];
@@ -814,20 +821,110 @@ __device__ void k5_paths_bg(int path, const int32_t* __restrict__ off, const uin
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)  // < 16 trailing bytes
       for (int64_t e = nch * 16; e < total; ++e) add((int)(e % L), src[e]);
-  } else {  // ragged reads: one wave per read, lanes stride over positions
-    const int lane = threadIdx.x & 63;
-    const int64_t gwave = (int64_t)blockIdx.x * (K5_THREADS / 64) + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * (K5_THREADS / 64);
-    for (int64_t r = gwave; r < n; r += nwaves) {
-      const int32_t o0 = off[r];
-      int len = off[r + 1] - o0;
-      if (len > lmax) len = lmax;  // flagged by k5_scan_offsets
-      for (int p = lane; p < len; p += 64) add(p, bytes[(int64_t)o0 + p]);
-    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < pt * 128; i += K5_THREADS)
     partials[(size_t)blockIdx.x * pt * 128 + i] = k5_h[(i >> 7) * 129 + (i & 127)];
+}
+
+// Path G: ragged reads.  A half-wave (32 lanes) owns a read; lane l loads the (possibly unaligned) dword holding
+// positions 4l..4l+3, so positions are known without any search, a wave instruction still covers two ~100-byte
+// reads (like path A's dword loads), and J reads are in flight per half-wave.  With lmax <= LP (BM) the histogram
+// uses path A's conflict-free byte-major layout h[byte][perm(p)] (the two half-waves of a wave are separate LDS
+// lane groups, so their equal positions never conflict) and the inner loop is branch-free: bytes past the end of
+// a read add to a per-lane dummy word, every load is unconditional.  Longer reads fall back to h[p][129].
+template <int LP, bool BM>
+__device__ void k5_path_ragged_impl(const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes, int64_t n,
+                                    int lmax, int pt, unsigned long long* __restrict__ partials,
+                                    unsigned long long* __restrict__ d_hist) {
+  extern __shared__ unsigned k5_h[];
+  constexpr int Q = LP / 4, J = 8;
+  const int nwords = BM ? 128 * LP + 64 : pt * 129;
+  for (int i = threadIdx.x; i < nwords; i += K5_THREADS) k5_h[i] = 0;
+  __syncthreads();
+  unsigned* const dummy = k5_h + 128 * LP + (threadIdx.x & 63);  // BM only
+  auto add_slow = [&](int p, unsigned b) {
+    if (b < 128 && (BM || p < pt)) atomicAdd(&k5_h[BM ? (int)b * LP + (p & 3) * Q + (p >> 2) : p * 129 + (int)b], 1u);
+    else atomicAdd(&d_hist[(size_t)p * 256 + b], 1ull);
+  };
+  auto load_u32 = [&](const uint8_t* p) {
+    unsigned v;
+    __builtin_memcpy(&v, p, 4);  // unaligned dword load
+    return v;
+  };
+  // The dword of positions [q, q+4) of a read of `len` >= 4 bytes at byte offset o0.  A partial last dword is
+  // fetched as the dword that ENDS at the read's end (never touches bytes past the read) and shifted down.  The load
+  // is UNCONDITIONAL (inactive lanes read the first dword of the buffer): a load inside a branch makes the compiler
+  // drain all loads in flight (s_waitcnt vmcnt(0)) at every such branch.  nb = valid bytes (0..4) in the low bytes.
+  auto fetch = [&](int64_t o0, int len, int q, int* nb) -> unsigned {
+    const int rem = len - q;
+    const bool active = rem > 0 && len >= 4;
+    *nb = active ? (rem > 4 ? 4 : rem) : 0;
+    const int64_t a = active ? o0 + (rem >= 4 ? q : len - 4) : 0;
+    const unsigned d = load_u32(bytes + a);
+    return (active && rem < 4) ? d >> (8 * (4 - rem)) : d;
+  };
+  auto emit = [&](unsigned d, int nb, int q) {
+    if (BM) {
+      if (__builtin_expect((d & 0x80808080u) != 0 && nb > 0, 0)) {  // non-ASCII byte somewhere: slow path
+        for (int k = 0; k < nb; ++k) add_slow(q + k, (d >> (8 * k)) & 0xFF);
+        return;
+      }
+      unsigned* base = k5_h + (q >> 2);  // q is a multiple of 4: perm(q + k) = k * Q + (q >> 2)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) atomicAdd(k < nb ? base + ((d >> (8 * k)) & 0x7F) * LP + k * Q : dummy, 1u);
+    } else {
+      for (int k = 0; k < nb; ++k) add_slow(q + k, (d >> (8 * k)) & 0xFF);
+    }
+  };
+  const int hl = threadIdx.x & 31;
+  const int64_t ghw = (int64_t)blockIdx.x * (K5_THREADS / 32) + (threadIdx.x >> 5);
+  const int64_t nhw = (int64_t)gridDim.x * (K5_THREADS / 32);
+  const int q = hl * 4;
+  constexpr bool TWO = LP > 128;  // reads can reach past position 128: fetch a second dword per lane
+  for (int64_t r0 = ghw; r0 < n; r0 += nhw * J) {
+    int64_t o0[J];
+    int len[J], nb0[J], nb1[J];
+    unsigned d0[J], d1[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {  // offsets: unconditional loads (index clamped), length zeroed past the end
+      const int64_t rr = r0 + (int64_t)j * nhw;
+      const int64_t rc = rr < n ? rr : n - 1;
+      const int32_t a = off[rc], b = off[rc + 1];
+      o0[j] = a;
+      len[j] = rr < n ? min(b - a, lmax) : 0;  // reads longer than lmax are flagged by k5_scan_offsets
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {  // all data loads of the iteration are issued before any use
+      d0[j] = fetch(o0[j], len[j], q, &nb0[j]);
+      if (TWO) d1[j] = fetch(o0[j], len[j], q + 128, &nb1[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      emit(d0[j], nb0[j], q);
+      if (TWO) emit(d1[j], nb1[j], q + 128);
+      for (int q2 = q + (TWO ? 256 : 128); q2 < len[j]; q2 += 128) {  // longer reads (only when !BM)
+        int nb;
+        const unsigned d = fetch(o0[j], len[j], q2, &nb);
+        emit(d, nb, q2);
+      }
+      if (len[j] > 0 && len[j] < 4 && hl == 0)  // reads shorter than a dword: bytewise
+        for (int k = 0; k < len[j]; ++k) add_slow(k, bytes[o0[j] + k]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < pt * 128; i += K5_THREADS) {
+    const int p = i >> 7, b = i & 127;
+    partials[(size_t)blockIdx.x * pt * 128 + i] = BM ? k5_h[b * LP + (p & 3) * Q + (p >> 2)] : k5_h[p * 129 + b];
+  }
+}
+
+template <int LP>
+__device__ void k5_path_ragged(const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes, int64_t n, int lmax,
+                               int pt, unsigned long long* __restrict__ partials,
+                               unsigned long long* __restrict__ d_hist) {
+  if (lmax <= LP) k5_path_ragged_impl<LP, true>(off, bytes, n, lmax, pt, partials, d_hist);
+  else k5_path_ragged_impl<LP, false>(off, bytes, n, lmax, pt, partials, d_hist);
 }
 
 // d_hist[p][b] += sum over workgroups of partial[wg][p][b]  (p < pt, b < 128).  blockIdx.y splits the workgroup
@@ -867,9 +964,9 @@ hipError_t launch_qual_pos_hist(hipStream_t s, const LaunchCfg& cfg, const Works
   if (e != hipSuccess) return e;
   int sgrid = (int)std::min<int64_t>((n_reads + 255) / 256, (int64_t)cfg.compute_units * 8);
   hipLaunchKernelGGL(k5_scan_offsets, dim3(sgrid), dim3(256), 0, s, offsets, n_reads, lmax, flags, ws.status);
-  // LDS block: the larger of path A's [128][LP] and paths B/G's [pt][129]
+  // LDS block: the larger of the byte-major [128][LP] layout (paths A and G) and the [pt][129] layout (B, long G)
   const bool lp256 = lmax > 128;
-  const size_t lds = std::max<size_t>((size_t)128 * (lp256 ? 256 : 128) * 4, (size_t)pt * 129 * 4);
+  const size_t lds = std::max<size_t>((size_t)128 * (lp256 ? 256 : 128) * 4 + 256, (size_t)pt * 129 * 4);
   static std::once_flag attr_once;
   hipError_t attr_err = hipSuccess;
   std::call_once(attr_once, [&] {
