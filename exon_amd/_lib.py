@@ -72,6 +72,12 @@ class PlanDesc(C.Structure):
     ]
 
 
+class VCFColumns(C.Structure):
+    _fields_ = [("n_rows", C.c_int64), ("n_undecided", C.c_int64), ("chrom_id", C.c_void_p), ("pos", C.c_void_p),
+                ("pos_valid", C.c_void_p), ("qual", C.c_void_p), ("qual_valid", C.c_void_p), ("filter_id", C.c_void_p),
+                ("info", C.c_void_p), ("info_valid", C.c_void_p)]
+
+
 class ScanOptions(C.Structure):
     _fields_ = [("format", C.c_int32), ("compression", C.c_int32), ("batch_size", C.c_int64),
                 ("info_field", C.c_char_p), ("region", C.c_char_p), ("use_index", C.c_int32), ("reserved", C.c_int32)]
@@ -139,6 +145,10 @@ SIGNATURES = {
     "exon_hip_index_query": (C.c_int, [C.c_char_p, _i32, C.c_char_p, _i32, _i64, _i64, C.POINTER(_u64), C.POINTER(_u64),
                                        _i32, C.POINTER(_i32)]),
     "exon_hip_stream_consume_scan": (C.c_int, [_vp, _vp, C.POINTER(_i64)]),
+    "exon_hip_vcf_parser_create": (C.c_int, [_vp, C.POINTER(C.c_char_p), _i32, C.c_char_p, _i64, C.POINTER(_vp)]),
+    "exon_hip_vcf_parser_parse": (C.c_int, [_vp, _vp, _vp, _i64, C.POINTER(VCFColumns)]),
+    "exon_hip_vcf_parser_filters": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(_i32)]),
+    "exon_hip_vcf_parser_destroy": (C.c_int, [_vp]),
 }
 
 

@@ -1,0 +1,551 @@
+// gpu_parse.hip -- VCF record parsing ON THE GPU: raw text in HBM -> device-layout columns in HBM.
+//
+// The host decoders (host/formats.h, host/parallel.h) top out at ~150 Mrows/s on a 128-core host while the
+// filter+aggregate kernels consume 500 000 Mrows/s; text crossing PCIe as-is and being parsed on the device lifts
+// the decode stage to the PCIe rate ("GPU-side parse later").  Semantics are those of
+// LazyVCFArrayBuilder::append (exon-vcf/src/array_builder/lazy_array_builder.rs:159-216) restricted to the columns
+// of the device layout: chrom -> dictionary id, pos (0 / '.' -> NULL), qual ('.' -> NULL, correctly rounded f32),
+// filter -> dictionary id of the ';'-joined list ('.' -> empty list), one typed INFO field (Number=1 Float/Integer,
+// missing key / '.' -> NULL).
+//
+// Pipeline for one slab of complete lines:
+//   k_count_newlines   every thread counts '\n' in its 16 bytes; per-workgroup totals
+//   k_scan_blocks      exclusive scan of the workgroup totals (single workgroup)
+//   k_fill_newlines    positions of all newlines, in order (line i = (nl[i-1], nl[i]))
+//   k_parse_lines      one thread per line: split on tabs, parse, look names up in hash tables, ballot the validity
+//                      bitmaps; FILTER lists not seen before are inserted with atomicCAS (slot = provisional id)
+//   k_assign_filters   dense ids for newly inserted FILTER lists, their text copied to a persistent pool
+//   k_remap_filters    provisional slot -> dense id
+// Rows the device cannot decide (a float with > 19 significant digits, a contig missing from the header, a malformed
+// line) are counted; the caller then re-decodes that slab on the host, so results never differ from the CPU path.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "host/decimal_f32.h"
+#include "internal.h"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int BYTES_PER_THREAD = 16;
+constexpr int BYTES_PER_BLOCK = TPB * BYTES_PER_THREAD;
+constexpr int FILTER_SLOTS = 8192;  // open addressing; at most EXON_HIP_MAX_GROUPS distinct lists are supported
+constexpr int FILTER_POOL = 1 << 20;
+
+__host__ __device__ inline uint64_t fnv1a(const uint8_t* p, int n) {
+  uint64_t h = 0xCBF29CE484222325ULL;
+  for (int i = 0; i < n; ++i) {
+    h ^= p[i];
+    h *= 0x100000001B3ULL;
+  }
+  return h | 1ULL;  // never 0 (0 = empty slot)
+}
+
+__device__ __forceinline__ int count_nl16(uint4 v) {
+  int c = 0;
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    c += ((w[i] & 0xFF) == 0x0A) + (((w[i] >> 8) & 0xFF) == 0x0A) + (((w[i] >> 16) & 0xFF) == 0x0A) + ((w[i] >> 24) == 0x0A);
+  }
+  return c;
+}
+
+__device__ __forceinline__ uint4 load16(const uint8_t* text, int64_t n, int64_t off) {
+  if (off + 16 <= n) return *reinterpret_cast<const uint4*>(text + off);  // text is 16-byte aligned
+  uint4 v = {0, 0, 0, 0};
+  unsigned* w = &v.x;
+  for (int i = 0; i < 16 && off + i < n; ++i) w[i >> 2] |= (unsigned)text[off + i] << (8 * (i & 3));
+  return v;
+}
+
+__global__ __launch_bounds__(TPB) void k_count_newlines(const uint8_t* __restrict__ text, int64_t n,
+                                                        unsigned* __restrict__ block_counts) {
+  __shared__ unsigned red[TPB / 64];
+  const int64_t off = ((int64_t)blockIdx.x * TPB + threadIdx.x) * BYTES_PER_THREAD;
+  unsigned c = off < n ? (unsigned)count_nl16(load16(text, n, off)) : 0u;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// exclusive scan of `nb` workgroup totals in place; total -> *n_lines
+__global__ __launch_bounds__(1024) void k_scan_blocks(unsigned* __restrict__ counts, int nb, unsigned* __restrict__ n_lines) {
+  __shared__ unsigned part[1024];
+  const int per = (nb + 1023) / 1024;
+  const int b0 = threadIdx.x * per, b1 = min(nb, b0 + per);
+  unsigned s = 0;
+  for (int b = b0; b < b1; ++b) s += counts[b];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {  // inclusive Hillis-Steele scan
+    unsigned v = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  unsigned run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
+  for (int b = b0; b < b1; ++b) {
+    const unsigned c = counts[b];
+    counts[b] = run;
+    run += c;
+  }
+  if (threadIdx.x == 1023) *n_lines = part[1023];
+}
+
+__global__ __launch_bounds__(TPB) void k_fill_newlines(const uint8_t* __restrict__ text, int64_t n,
+                                                       const unsigned* __restrict__ block_offsets,
+                                                       unsigned* __restrict__ nl_pos, unsigned cap) {
+  __shared__ unsigned wave_tot[TPB / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t off = ((int64_t)blockIdx.x * TPB + threadIdx.x) * BYTES_PER_THREAD;
+  uint4 v = {0, 0, 0, 0};
+  unsigned c = 0;
+  if (off < n) {
+    v = load16(text, n, off);
+    c = (unsigned)count_nl16(v);
+  }
+  unsigned incl = c;  // inclusive scan within the wave
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  unsigned base = block_offsets[blockIdx.x];
+  for (int w = 0; w < wave; ++w) base += wave_tot[w];
+  unsigned k = base + incl - c;
+  if (c) {
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (((w[i >> 2] >> (8 * (i & 3))) & 0xFF) == 0x0A) {
+        if (k < cap) nl_pos[k] = (unsigned)(off + i);  // more lines than VCF records can fill: reported by the caller
+        ++k;
+      }
+  }
+}
+
+struct NameTable {  // open-addressing table of strings (contigs): hash -> id, text verified
+  const uint64_t* keys;
+  const int32_t* ids;
+  const uint32_t* text_off;
+  const uint32_t* text_len;
+  const uint8_t* pool;
+  int mask;
+};
+
+struct FilterTable {
+  unsigned long long* keys;  // 0 = empty
+  int32_t* ids;              // -1 until k_assign_filters has run
+  uint32_t* text_off;        // provisional: offset into the CURRENT slab; after assignment: offset into pool
+  uint32_t* text_len;
+  uint8_t* pool;
+  int32_t* counters;  // [0] = number of dense ids, [1] = pool bytes used, [2] = overflow flag
+};
+
+struct ParseOut {
+  int32_t* chrom_id;
+  int64_t* pos;
+  uint8_t* pos_valid;
+  float* qual;
+  uint8_t* qual_valid;
+  int32_t* filter_id;
+  float* info;
+  uint8_t* info_valid;
+  unsigned* exceptions;  // [0] = count of rows the device could not decide
+};
+
+__device__ __forceinline__ void store_valid(uint8_t* bm, int64_t row0_of_wave, int64_t n_rows, bool v, int lane) {
+  const unsigned long long m = __ballot(v);
+  if (lane < 8) {
+    const int64_t r = row0_of_wave + lane * 8;
+    if (r < n_rows) bm[r >> 3] = (uint8_t)(m >> (lane * 8));
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__ text, const unsigned* __restrict__ nl_pos,
+                                                     const unsigned* __restrict__ n_lines_p, NameTable contigs,
+                                                     FilterTable filters, const uint8_t* __restrict__ info_key,
+                                                     int info_key_len, ParseOut out, unsigned cap) {
+  const int64_t n_rows = min(*n_lines_p, cap);
+  const int64_t row = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  bool pos_ok = false, qual_ok = false, info_ok = false, bad = false;
+  if (row < n_rows) {
+    const unsigned begin = row ? nl_pos[row - 1] + 1 : 0u;
+    unsigned end = nl_pos[row];
+    if (end > begin && text[end - 1] == '\r') --end;
+    // split the first 8 fields
+    unsigned fs[9];
+    int nf = 0;
+    fs[0] = begin;
+    for (unsigned i = begin; i < end && nf < 8; ++i)
+      if (text[i] == '\t') fs[++nf] = i + 1;
+    // field f spans [fs[f], fs[f+1] - 1) for f < nf, the last one ends at `end` (INFO may be followed by FORMAT...)
+    auto fbeg = [&](int f) { return fs[f]; };
+    auto fend = [&](int f) { return f < nf ? fs[f + 1] - 1 : end; };
+    if (nf < 7 || begin == end || text[begin] == '#') {
+      bad = true;  // not a data line with 8 fields
+    } else {
+      // CHROM
+      {
+        const uint8_t* p = text + fbeg(0);
+        const int len = (int)(fend(0) - fbeg(0));
+        const uint64_t h = fnv1a(p, len);
+        int slot = (int)(h & (uint64_t)contigs.mask), id = -1;
+        for (int probe = 0; probe <= contigs.mask; ++probe) {
+          const uint64_t k = contigs.keys[slot];
+          if (k == 0) break;
+          if (k == h && (int)contigs.text_len[slot] == len) {
+            bool same = true;
+            for (int i = 0; i < len && same; ++i) same = contigs.pool[contigs.text_off[slot] + i] == p[i];
+            if (same) {
+              id = contigs.ids[slot];
+              break;
+            }
+          }
+          slot = (slot + 1) & contigs.mask;
+        }
+        if (id < 0) bad = true;  // contig not in the header: host decides the id
+        out.chrom_id[row] = id < 0 ? 0 : id;
+      }
+      // POS
+      {
+        int64_t v = 0;
+        bool ok = fend(1) > fbeg(1);
+        for (unsigned i = fbeg(1); i < fend(1) && ok; ++i) {
+          const uint8_t c = text[i];
+          if (c < '0' || c > '9') ok = false;
+          else v = v * 10 + (c - '0');
+        }
+        pos_ok = ok && v > 0;
+        out.pos[row] = pos_ok ? v : 0;
+      }
+      // QUAL
+      {
+        const int len = (int)(fend(5) - fbeg(5));
+        float q = 0.f;
+        if (!(len == 1 && text[fbeg(5)] == '.')) {
+          uint32_t bits;
+          if (exon::dec::parse_f32(reinterpret_cast<const char*>(text + fbeg(5)), len, &bits)) {
+            q = __uint_as_float(bits);
+            qual_ok = true;
+          } else {
+            bad = true;
+          }
+        }
+        out.qual[row] = q;
+      }
+      // FILTER: '.' -> the empty list
+      {
+        const uint8_t* p = text + fbeg(6);
+        int len = (int)(fend(6) - fbeg(6));
+        if (len == 1 && p[0] == '.') len = 0;
+        const unsigned long long h = fnv1a(p, len);
+        int slot = (int)(h & (FILTER_SLOTS - 1));
+        int found = -1;
+        for (int probe = 0; probe < FILTER_SLOTS; ++probe) {
+          unsigned long long k = filters.keys[slot];
+          if (k == 0) {
+            k = atomicCAS(&filters.keys[slot], 0ull, h);
+            if (k == 0) {  // this thread inserted the key: remember where its text lives in this slab
+              filters.text_off[slot] = fbeg(6);
+              filters.text_len[slot] = (uint32_t)len;
+              found = slot;
+              break;
+            }
+          }
+          if (k == h) {
+            found = slot;
+            break;
+          }
+          slot = (slot + 1) & (FILTER_SLOTS - 1);
+        }
+        if (found < 0) {
+          atomicExch(&filters.counters[2], 1);
+          found = 0;
+        }
+        out.filter_id[row] = found;  // provisional: slot index
+      }
+      // INFO: `key=value` among ';'-separated entries
+      if (info_key_len > 0) {
+        float v = 0.f;
+        const unsigned ib = fbeg(7), ie = fend(7);
+        if (!(ie - ib == 1 && text[ib] == '.')) {
+          unsigned i = ib;
+          while (i < ie) {
+            unsigned j = i;
+            while (j < ie && text[j] != ';') ++j;
+            if ((int)(j - i) > info_key_len && text[i + info_key_len] == '=') {
+              bool same = true;
+              for (int k = 0; k < info_key_len && same; ++k) same = text[i + k] == info_key[k];
+              if (same) {
+                const unsigned vb = i + info_key_len + 1;
+                const int vl = (int)(j - vb);
+                if (!(vl == 0 || (vl == 1 && text[vb] == '.'))) {
+                  uint32_t bits;
+                  if (exon::dec::parse_f32(reinterpret_cast<const char*>(text + vb), vl, &bits)) {
+                    v = __uint_as_float(bits);
+                    info_ok = true;
+                  } else {
+                    bad = true;
+                  }
+                }
+                break;
+              }
+            }
+            i = j + 1;
+          }
+        }
+        out.info[row] = v;
+      }
+    }
+  }
+  const int64_t wave_row0 = row - lane;
+  store_valid(out.pos_valid, wave_row0, n_rows, pos_ok, lane);
+  store_valid(out.qual_valid, wave_row0, n_rows, qual_ok, lane);
+  if (info_key_len > 0) store_valid(out.info_valid, wave_row0, n_rows, info_ok, lane);
+  const unsigned long long nb = __ballot(bad);
+  if (lane == 0 && nb) atomicAdd(out.exceptions, (unsigned)__popcll(nb));
+}
+
+// dense ids for FILTER lists inserted during the last parse, text copied into the persistent pool (single workgroup)
+__global__ __launch_bounds__(256) void k_assign_filters(const uint8_t* __restrict__ text, FilterTable f) {
+  __shared__ int next_id, pool_used;
+  if (threadIdx.x == 0) {
+    next_id = f.counters[0];
+    pool_used = f.counters[1];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // deterministic order (by slot); the table is tiny
+    for (int s = 0; s < FILTER_SLOTS; ++s)
+      if (f.keys[s] != 0 && f.ids[s] < 0) {
+        const uint32_t len = f.text_len[s], src = f.text_off[s];
+        if (next_id >= EXON_HIP_MAX_GROUPS || pool_used + (int)len > FILTER_POOL) {
+          f.counters[2] = 1;
+          f.ids[s] = 0;
+          continue;
+        }
+        for (uint32_t i = 0; i < len; ++i) f.pool[pool_used + i] = text[src + i];
+        f.text_off[s] = (uint32_t)pool_used;
+        pool_used += (int)len;
+        f.ids[s] = next_id++;
+      }
+    f.counters[0] = next_id;
+    f.counters[1] = pool_used;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_remap_filters(int32_t* __restrict__ filter_id, const unsigned* __restrict__ n_lines_p,
+                                                       const int32_t* __restrict__ ids, unsigned cap) {
+  const int64_t n = min(*n_lines_p, cap);
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) filter_id[i] = ids[filter_id[i]];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------
+struct exon_hip_vcf_parser {
+  exon_hip_ctx* ctx = nullptr;
+  int64_t max_bytes = 0, max_rows = 0;
+  std::string info_field;
+  // device state
+  uint8_t* d_info_key = nullptr;
+  unsigned *d_block_counts = nullptr, *d_nl = nullptr, *d_scalars = nullptr;  // scalars: [0] n_lines, [1] exceptions
+  NameTable contigs{};
+  void* contig_bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  FilterTable filters{};
+  ParseOut out{};
+  void* out_bufs[8] = {nullptr};
+  unsigned* h_scalars = nullptr;  // pinned mirror of d_scalars
+};
+
+extern "C" {
+
+int exon_hip_vcf_parser_create(exon_hip_ctx* ctx, const char* const* contig_names, int32_t n_contigs,
+                               const char* info_field, int64_t max_bytes, exon_hip_vcf_parser** outp) {
+  if (!ctx || !outp || (n_contigs > 0 && !contig_names) || max_bytes < 16)
+    return fail(ctx, EXON_HIP_EINVAL, "exon_hip_vcf_parser_create: bad argument");
+  if (max_bytes > 0xF0000000LL) return fail(ctx, EXON_HIP_EINVAL, "slab size must stay below 4 GiB (32-bit line offsets)");
+  *outp = nullptr;
+  exon_hip_vcf_parser* p = new (std::nothrow) exon_hip_vcf_parser();
+  if (!p) return fail(ctx, EXON_HIP_ENOMEM, "out of host memory");
+  p->ctx = ctx;
+  p->max_bytes = max_bytes;
+  p->max_rows = max_bytes / 16 + 1;  // a VCF data line has 8 fields: >= 15 bytes + newline
+  p->info_field = info_field ? info_field : "";
+  hipSetDevice(ctx->device);
+  hipError_t e = hipSuccess;
+  auto dalloc = [&](void** ptr, size_t bytes) {
+    if (e == hipSuccess) e = hipMalloc(ptr, bytes ? bytes : 16);
+  };
+  // contig table
+  int cap = 16;
+  while (cap < 2 * n_contigs + 1) cap <<= 1;
+  std::vector<uint64_t> keys((size_t)cap, 0);
+  std::vector<int32_t> ids((size_t)cap, -1);
+  std::vector<uint32_t> toff((size_t)cap, 0), tlen((size_t)cap, 0);
+  std::string pool;
+  for (int i = 0; i < n_contigs; ++i) {
+    const std::string nm = contig_names[i];
+    const uint64_t h = fnv1a(reinterpret_cast<const uint8_t*>(nm.data()), (int)nm.size());
+    int slot = (int)(h & (uint64_t)(cap - 1));
+    while (keys[(size_t)slot] != 0) slot = (slot + 1) & (cap - 1);
+    keys[(size_t)slot] = h;
+    ids[(size_t)slot] = i;
+    toff[(size_t)slot] = (uint32_t)pool.size();
+    tlen[(size_t)slot] = (uint32_t)nm.size();
+    pool += nm;
+  }
+  dalloc(&p->contig_bufs[0], (size_t)cap * 8);
+  dalloc(&p->contig_bufs[1], (size_t)cap * 4);
+  dalloc(&p->contig_bufs[2], (size_t)cap * 4);
+  dalloc(&p->contig_bufs[3], (size_t)cap * 4);
+  dalloc(&p->contig_bufs[4], pool.size() + 16);
+  if (e == hipSuccess) e = hipMemcpy(p->contig_bufs[0], keys.data(), (size_t)cap * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p->contig_bufs[1], ids.data(), (size_t)cap * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p->contig_bufs[2], toff.data(), (size_t)cap * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p->contig_bufs[3], tlen.data(), (size_t)cap * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess && !pool.empty()) e = hipMemcpy(p->contig_bufs[4], pool.data(), pool.size(), hipMemcpyHostToDevice);
+  p->contigs = NameTable{(const uint64_t*)p->contig_bufs[0], (const int32_t*)p->contig_bufs[1], (const uint32_t*)p->contig_bufs[2],
+                         (const uint32_t*)p->contig_bufs[3], (const uint8_t*)p->contig_bufs[4], cap - 1};
+  // filter table
+  dalloc((void**)&p->filters.keys, FILTER_SLOTS * 8);
+  dalloc((void**)&p->filters.ids, FILTER_SLOTS * 4);
+  dalloc((void**)&p->filters.text_off, FILTER_SLOTS * 4);
+  dalloc((void**)&p->filters.text_len, FILTER_SLOTS * 4);
+  dalloc((void**)&p->filters.pool, FILTER_POOL);
+  dalloc((void**)&p->filters.counters, 16);
+  if (e == hipSuccess) e = hipMemset(p->filters.keys, 0, FILTER_SLOTS * 8);
+  if (e == hipSuccess) e = hipMemset(p->filters.ids, 0xFF, FILTER_SLOTS * 4);
+  if (e == hipSuccess) e = hipMemset(p->filters.counters, 0, 16);
+  // scratch + outputs
+  const int64_t nblocks = (max_bytes + BYTES_PER_BLOCK - 1) / BYTES_PER_BLOCK;
+  dalloc((void**)&p->d_block_counts, (size_t)nblocks * 4);
+  dalloc((void**)&p->d_nl, (size_t)p->max_rows * 4);
+  dalloc((void**)&p->d_scalars, 16);
+  dalloc((void**)&p->d_info_key, p->info_field.size() + 16);
+  if (e == hipSuccess && !p->info_field.empty())
+    e = hipMemcpy(p->d_info_key, p->info_field.data(), p->info_field.size(), hipMemcpyHostToDevice);
+  const size_t r = (size_t)p->max_rows, rb = r / 8 + 64;
+  dalloc(&p->out_bufs[0], r * 4);
+  dalloc(&p->out_bufs[1], r * 8);
+  dalloc(&p->out_bufs[2], rb);
+  dalloc(&p->out_bufs[3], r * 4);
+  dalloc(&p->out_bufs[4], rb);
+  dalloc(&p->out_bufs[5], r * 4);
+  dalloc(&p->out_bufs[6], r * 4);
+  dalloc(&p->out_bufs[7], rb);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&p->h_scalars, 16);
+  if (e != hipSuccess) {
+    const std::string msg = hipGetErrorString(e);
+    exon_hip_vcf_parser_destroy(p);
+    return fail(ctx, EXON_HIP_ENOMEM, "vcf parser allocation: %s", msg.c_str());
+  }
+  p->out = ParseOut{(int32_t*)p->out_bufs[0], (int64_t*)p->out_bufs[1], (uint8_t*)p->out_bufs[2], (float*)p->out_bufs[3],
+                    (uint8_t*)p->out_bufs[4], (int32_t*)p->out_bufs[5], (float*)p->out_bufs[6], (uint8_t*)p->out_bufs[7],
+                    p->d_scalars + 1};
+  *outp = p;
+  return EXON_HIP_OK;
+}
+
+int exon_hip_vcf_parser_destroy(exon_hip_vcf_parser* p) {
+  if (!p) return EXON_HIP_OK;
+  for (void* b : p->contig_bufs)
+    if (b) hipFree(b);
+  for (void* b : p->out_bufs)
+    if (b) hipFree(b);
+  if (p->filters.keys) hipFree(p->filters.keys);
+  if (p->filters.ids) hipFree(p->filters.ids);
+  if (p->filters.text_off) hipFree(p->filters.text_off);
+  if (p->filters.text_len) hipFree(p->filters.text_len);
+  if (p->filters.pool) hipFree(p->filters.pool);
+  if (p->filters.counters) hipFree(p->filters.counters);
+  if (p->d_block_counts) hipFree(p->d_block_counts);
+  if (p->d_nl) hipFree(p->d_nl);
+  if (p->d_scalars) hipFree(p->d_scalars);
+  if (p->d_info_key) hipFree(p->d_info_key);
+  if (p->h_scalars) hipHostFree(p->h_scalars);
+  delete p;
+  return EXON_HIP_OK;
+}
+
+int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* p, void* stream, const uint8_t* d_text, int64_t n_bytes,
+                              exon_hip_vcf_columns* cols) {
+  if (!p || !cols || (n_bytes > 0 && !d_text)) return fail(p ? p->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_vcf_parser_parse: NULL argument");
+  exon_hip_ctx* ctx = p->ctx;
+  if (n_bytes > p->max_bytes) return fail(ctx, EXON_HIP_EINVAL, "slab of %lld bytes exceeds the parser's %lld", (long long)n_bytes, (long long)p->max_bytes);
+  if ((reinterpret_cast<uintptr_t>(d_text) & 15) != 0) return fail(ctx, EXON_HIP_EINVAL, "text must be 16-byte aligned");
+  memset(cols, 0, sizeof *cols);
+  if (n_bytes == 0) return EXON_HIP_OK;
+  hipStream_t s = pick_stream(ctx, stream);
+  const int nblocks = (int)((n_bytes + BYTES_PER_BLOCK - 1) / BYTES_PER_BLOCK);
+  HIP_TRY(ctx, hipMemsetAsync(p->d_scalars, 0, 16, s));
+  hipLaunchKernelGGL(k_count_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, p->d_block_counts);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, p->d_block_counts, nblocks, p->d_scalars);
+  hipLaunchKernelGGL(k_fill_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, p->d_block_counts, p->d_nl, (unsigned)p->max_rows);
+  // the number of lines is bounded by n_bytes / 16 + 1 for well-formed data lines; launch for that bound
+  const int64_t row_bound = std::min<int64_t>(p->max_rows, n_bytes / 16 + 1);
+  const int pblocks = (int)((row_bound + TPB - 1) / TPB);
+  hipLaunchKernelGGL(k_parse_lines, dim3(pblocks), dim3(TPB), 0, s, d_text, p->d_nl, p->d_scalars, p->contigs, p->filters,
+                     p->d_info_key, (int)p->info_field.size(), p->out, (unsigned)row_bound);
+  hipLaunchKernelGGL(k_assign_filters, dim3(1), dim3(256), 0, s, d_text, p->filters);
+  hipLaunchKernelGGL(k_remap_filters, dim3(std::min(pblocks, 4096)), dim3(TPB), 0, s, p->out.filter_id, p->d_scalars, p->filters.ids, (unsigned)row_bound);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(p->h_scalars, p->d_scalars, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  const int64_t n_lines = p->h_scalars[0];
+  if (n_lines > row_bound) return fail(ctx, EXON_HIP_EINVAL, "slab has %lld lines, more than its byte size allows for VCF records", (long long)n_lines);
+  cols->n_rows = n_lines;
+  cols->n_undecided = p->h_scalars[1];
+  cols->chrom_id = p->out.chrom_id;
+  cols->pos = p->out.pos;
+  cols->pos_valid = p->out.pos_valid;
+  cols->qual = p->out.qual;
+  cols->qual_valid = p->out.qual_valid;
+  cols->filter_id = p->out.filter_id;
+  cols->info = p->info_field.empty() ? nullptr : p->out.info;
+  cols->info_valid = p->info_field.empty() ? nullptr : p->out.info_valid;
+  return EXON_HIP_OK;
+}
+
+// FILTER dictionary discovered so far: names are written '\0'-separated into `buf` (id order); returns the count
+int exon_hip_vcf_parser_filters(exon_hip_vcf_parser* p, char* buf, size_t cap, int32_t* n_filters) {
+  if (!p || !n_filters) return fail(p ? p->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_vcf_parser_filters: NULL argument");
+  exon_hip_ctx* ctx = p->ctx;
+  int32_t counters[4];
+  HIP_TRY(ctx, hipMemcpy(counters, p->filters.counters, 16, hipMemcpyDeviceToHost));
+  if (counters[2]) return fail(ctx, EXON_HIP_EUNSUPPORTED, "more than %d distinct FILTER lists (or filter pool exhausted)", EXON_HIP_MAX_GROUPS);
+  std::vector<unsigned long long> keys(FILTER_SLOTS);
+  std::vector<int32_t> ids(FILTER_SLOTS);
+  std::vector<uint32_t> toff(FILTER_SLOTS), tlen(FILTER_SLOTS);
+  std::vector<uint8_t> pool((size_t)std::max(counters[1], 1));
+  HIP_TRY(ctx, hipMemcpy(keys.data(), p->filters.keys, FILTER_SLOTS * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(ids.data(), p->filters.ids, FILTER_SLOTS * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(toff.data(), p->filters.text_off, FILTER_SLOTS * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(tlen.data(), p->filters.text_len, FILTER_SLOTS * 4, hipMemcpyDeviceToHost));
+  if (counters[1] > 0) HIP_TRY(ctx, hipMemcpy(pool.data(), p->filters.pool, (size_t)counters[1], hipMemcpyDeviceToHost));
+  std::vector<std::string> names((size_t)counters[0]);
+  for (int s = 0; s < FILTER_SLOTS; ++s)
+    if (keys[(size_t)s] != 0 && ids[(size_t)s] >= 0 && ids[(size_t)s] < counters[0])
+      names[(size_t)ids[(size_t)s]] = std::string(reinterpret_cast<const char*>(pool.data()) + toff[(size_t)s], tlen[(size_t)s]);
+  size_t need = 0;
+  for (const auto& nm : names) need += nm.size() + 1;
+  *n_filters = counters[0];
+  if (buf) {
+    if (need > cap) return fail(ctx, EXON_HIP_EINVAL, "filter name buffer too small (%zu needed)", need);
+    size_t o = 0;
+    for (const auto& nm : names) {
+      memcpy(buf + o, nm.c_str(), nm.size() + 1);
+      o += nm.size() + 1;
+    }
+  }
+  return EXON_HIP_OK;
+}
+
+}  // extern "C"

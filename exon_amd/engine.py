@@ -309,6 +309,65 @@ class Scan:
             self.h = None
 
 
+class VCFParser:
+    """VCF record parsing on the GPU (exon_hip_vcf_parser_*): text slab in HBM -> device-layout columns in HBM."""
+
+    def __init__(self, ctx, contigs, info_field=None, max_slab_bytes=64 << 20):
+        self.ctx = ctx
+        names = (C.c_char_p * max(len(contigs), 1))(*[c.encode() for c in contigs])
+        h = C.c_void_p()
+        ctx._check(ctx.lib.exon_hip_vcf_parser_create(ctx.h, names, len(contigs), info_field.encode() if info_field else None,
+                                                      max_slab_bytes, C.byref(h)))
+        self.h = h
+        self.has_info = bool(info_field)
+
+    def parse_device(self, d_text, n_bytes, stream=None):
+        cols = L.VCFColumns()
+        ptr = d_text.ptr if isinstance(d_text, DeviceBuffer) else int(d_text)
+        self.ctx._check(self.ctx.lib.exon_hip_vcf_parser_parse(self.h, stream, ptr, n_bytes, C.byref(cols)))
+        return cols
+
+    def parse_host(self, text):
+        """Test helper: copy `text` (bytes of complete lines) to HBM, parse, bring the columns back as numpy arrays."""
+        buf = np.frombuffer(text, np.uint8)
+        d = self.ctx.to_device(np.concatenate([buf, np.zeros(64, np.uint8)]))
+        cols = self.parse_device(d, len(buf))
+        n = cols.n_rows
+        nb = (n + 7) // 8
+
+        def get(ptr, dtype, count):
+            out = np.empty(count, dtype)
+            if count:
+                self.ctx._check(self.ctx.lib.exon_hip_memcpy_d2h(self.ctx.h, _np_ptr(out), ptr, out.nbytes, None))
+            return out
+
+        res = {"n_rows": n, "n_undecided": cols.n_undecided,
+               "chrom_id": get(cols.chrom_id, np.int32, n), "pos": get(cols.pos, np.int64, n),
+               "pos_valid": get(cols.pos_valid, np.uint8, nb), "qual": get(cols.qual, np.float32, n),
+               "qual_valid": get(cols.qual_valid, np.uint8, nb), "filter_id": get(cols.filter_id, np.int32, n)}
+        if self.has_info:
+            res["info"] = get(cols.info, np.float32, n)
+            res["info_valid"] = get(cols.info_valid, np.uint8, nb)
+        return res
+
+    def filters(self):
+        n = C.c_int32()
+        buf = C.create_string_buffer(1 << 20)
+        self.ctx._check(self.ctx.lib.exon_hip_vcf_parser_filters(self.h, buf, len(buf), C.byref(n)))
+        names, o = [], 0
+        raw = buf.raw
+        for _ in range(n.value):
+            e = raw.index(b"\0", o)
+            names.append(raw[o:e].decode())
+            o = e + 1
+        return names
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.exon_hip_vcf_parser_destroy(self.h)
+            self.h = None
+
+
 class Plan:
     def __init__(self, ctx, desc, columns):
         self.ctx = ctx

@@ -303,6 +303,33 @@ int exon_hip_scan_index_chunks(exon_hip_scan* scan, int32_t* n_chunks);
 int exon_hip_index_query(const char* index_path, int32_t is_bai, const char* ref_name, int32_t ref_id, int64_t start,
                          int64_t end, uint64_t* starts, uint64_t* ends, int32_t cap, int32_t* n_chunks);
 int exon_hip_scan_close(exon_hip_scan* scan);
+/* ---- VCF record parsing on the GPU (raw text in HBM -> device-layout columns in HBM) ---------------------------
+ * Same field rules as LazyVCFArrayBuilder::append (exon-vcf/src/array_builder/lazy_array_builder.rs:159-216) for the
+ * device-layout columns.  A parser is bound to one header (contig dictionary) and one optional typed INFO field and
+ * keeps the FILTER dictionary it discovers across slabs.  Rows the device cannot decide (float with > 19 significant
+ * digits, contig missing from the header, malformed line) are counted in n_undecided: re-decode that slab on the host. */
+typedef struct exon_hip_vcf_parser exon_hip_vcf_parser;
+typedef struct exon_hip_vcf_columns {
+  int64_t n_rows;
+  int64_t n_undecided;
+  int32_t* chrom_id;   /* device pointers owned by the parser, overwritten by the next parse call */
+  int64_t* pos;
+  uint8_t* pos_valid;
+  float* qual;
+  uint8_t* qual_valid;
+  int32_t* filter_id;
+  float* info;         /* NULL without an INFO field */
+  uint8_t* info_valid;
+} exon_hip_vcf_columns;
+int exon_hip_vcf_parser_create(exon_hip_ctx* ctx, const char* const* contig_names, int32_t n_contigs,
+                               const char* info_field, int64_t max_slab_bytes, exon_hip_vcf_parser** out);
+/* d_text: a slab of complete '\n'-terminated data lines in HBM, 16-byte aligned.  Synchronises `stream`. */
+int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* parser, void* stream, const uint8_t* d_text, int64_t n_bytes,
+                              exon_hip_vcf_columns* cols);
+/* FILTER dictionary discovered so far, '\0'-separated in id order ("" = the empty list) */
+int exon_hip_vcf_parser_filters(exon_hip_vcf_parser* parser, char* buf, size_t cap, int32_t* n_filters);
+int exon_hip_vcf_parser_destroy(exon_hip_vcf_parser* parser);
+
 /* GpuFilterAggExec::execute in one call: pull every batch of `scan` and push it through `stream`. */
 int exon_hip_stream_consume_scan(exon_hip_stream* s, exon_hip_scan* scan, int64_t* rows);
 
