@@ -80,7 +80,7 @@ class VCFColumns(C.Structure):
 
 class ScanOptions(C.Structure):
     _fields_ = [("format", C.c_int32), ("compression", C.c_int32), ("batch_size", C.c_int64),
-                ("info_field", C.c_char_p), ("region", C.c_char_p), ("use_index", C.c_int32), ("reserved", C.c_int32)]
+                ("info_field", C.c_char_p), ("region", C.c_char_p), ("use_index", C.c_int32), ("gpu_parse", C.c_int32)]
 
 
 FORMATS = {"vcf": 1, "bam": 2, "fastq": 3, "fasta": 4, "sam": 5}

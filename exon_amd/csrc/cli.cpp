@@ -251,7 +251,14 @@ struct StreamGuard {
   ~StreamGuard() { if (s) exon_hip_stream_close(s); if (p) exon_hip_plan_destroy(p); }
 };
 
-void open_scan(const Source& src, const std::string& file, const char* info_field, const std::string& region, ScanGuard* g) {
+// VCF queries that end in a fused GPU kernel ship the text to HBM and parse it there (EXON_HIP_GPU_PARSE=0: host decode)
+bool gpu_parse_enabled() {
+  const char* v = getenv("EXON_HIP_GPU_PARSE");
+  return !(v && v[0] == '0');
+}
+
+void open_scan(const Source& src, const std::string& file, const char* info_field, const std::string& region, ScanGuard* g,
+               bool for_gpu_query = false) {
   exon_hip_scan_options o;
   memset(&o, 0, sizeof o);
   o.format = src.format;
@@ -261,6 +268,7 @@ void open_scan(const Source& src, const std::string& file, const char* info_fiel
   // INDEXED_* tables / *_indexed_scan: plan BGZF chunks from <file>.tbi / <file>.bai
   // (exon-core/src/datasources/indexed_file/indexed_bgzf_file.rs:129-155)
   o.use_index = (src.indexed && !region.empty()) ? 1 : 0;
+  o.gpu_parse = (for_gpu_query && src.format == EXON_HIP_FORMAT_VCF && region.empty() && gpu_parse_enabled()) ? 1 : 0;
   ck(nullptr, exon_hip_scan_open(file.c_str(), &o, &g->s));
 }
 
@@ -453,7 +461,7 @@ void exec_select(Session& se, Parser& ps) {
     exon_hip_ctx* ctx = se.gpu();
     int64_t total = 0;
     for (const auto& f : src.files) {
-      ScanGuard g; open_scan(src, f, nullptr, "", &g);
+      ScanGuard g; open_scan(src, f, nullptr, "", &g, true);
       int32_t cid = -1;
       ck(nullptr, exon_hip_scan_dictionary_intern(g.s, 0, pr.chrom.c_str(), &cid));
       StreamGuard sg;
@@ -510,7 +518,7 @@ void exec_select(Session& se, Parser& ps) {
     std::map<std::string, Acc> merged;
     std::vector<std::string> order;
     for (const auto& f : src.files) {
-      ScanGuard g; open_scan(src, f, pr.info_field.c_str(), "", &g);
+      ScanGuard g; open_scan(src, f, pr.info_field.c_str(), "", &g, true);
       StreamGuard sg;
       const int G = 256;  // distinct FILTER lists supported per file (8 in registers + LDS overflow table)
       exon_hip_plan_desc d; memset(&d, 0, sizeof d);

@@ -314,31 +314,24 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
   if (lane == 0 && nb) atomicAdd(out.exceptions, (unsigned)__popcll(nb));
 }
 
-// dense ids for FILTER lists inserted during the last parse, text copied into the persistent pool (single workgroup)
+// dense ids for FILTER lists inserted during the last parse, text copied into the persistent pool.  New lists are
+// rare, so every thread scans its share of the slots and claims ids / pool space with atomics (ids are arbitrary
+// but stable; names are recovered through exon_hip_vcf_parser_filters).
 __global__ __launch_bounds__(256) void k_assign_filters(const uint8_t* __restrict__ text, FilterTable f) {
-  __shared__ int next_id, pool_used;
-  if (threadIdx.x == 0) {
-    next_id = f.counters[0];
-    pool_used = f.counters[1];
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {  // deterministic order (by slot); the table is tiny
-    for (int s = 0; s < FILTER_SLOTS; ++s)
-      if (f.keys[s] != 0 && f.ids[s] < 0) {
-        const uint32_t len = f.text_len[s], src = f.text_off[s];
-        if (next_id >= EXON_HIP_MAX_GROUPS || pool_used + (int)len > FILTER_POOL) {
-          f.counters[2] = 1;
-          f.ids[s] = 0;
-          continue;
-        }
-        for (uint32_t i = 0; i < len; ++i) f.pool[pool_used + i] = text[src + i];
-        f.text_off[s] = (uint32_t)pool_used;
-        pool_used += (int)len;
-        f.ids[s] = next_id++;
+  for (int s = threadIdx.x; s < FILTER_SLOTS; s += 256)
+    if (f.keys[s] != 0 && f.ids[s] < 0) {
+      const uint32_t len = f.text_len[s], src = f.text_off[s];
+      const int id = atomicAdd(&f.counters[0], 1);
+      const int po = atomicAdd(&f.counters[1], (int)len);
+      if (id >= EXON_HIP_MAX_GROUPS || po + (int)len > FILTER_POOL) {
+        f.counters[2] = 1;
+        f.ids[s] = 0;
+        continue;
       }
-    f.counters[0] = next_id;
-    f.counters[1] = pool_used;
-  }
+      for (uint32_t i = 0; i < len; ++i) f.pool[po + i] = text[src + i];
+      f.text_off[s] = (uint32_t)po;
+      f.ids[s] = id;
+    }
 }
 
 __global__ __launch_bounds__(TPB) void k_remap_filters(int32_t* __restrict__ filter_id, const unsigned* __restrict__ n_lines_p,

@@ -87,6 +87,7 @@ struct VCFHeader {
 struct VCFConfig {
   int64_t batch_size = DEFAULT_BATCH_SIZE;
   int threads = 0;  // decode threads: 0 = all host cores (EXON_HIP_DECODE_THREADS), 1 = sequential reader
+  bool defer_decode = false;  // the caller will take the byte stream (GPU-side parsing): start no parse pipeline
   std::string info_field;  // exon.vcf_parse_info=true + SELECT info."<F>": Number=1 Float/Integer field -> f32 column
   RegionFilter filter;
 };
@@ -368,7 +369,7 @@ class VCFBatchReader {
       // multi-threaded decode of the rest of the stream (files of at least a couple of slabs)
       const int threads = cfg_.threads > 0 ? cfg_.threads : decode_threads();
       const long fsize = file_size(path);
-      if (threads > 1 && fsize >= (8 << 20)) {
+      if (threads > 1 && fsize >= (8 << 20) && !cfg_.defer_decode) {
         StreamSource* ss = static_cast<StreamSource*>(r_.get());
         std::string carry = has_pending_ ? pending_ + "\n" : std::string();
         has_pending_ = false;
@@ -404,6 +405,18 @@ class VCFBatchReader {
     b.try_into_record_batch(out);
     return true;
   }
+
+  // Everything after the header as a raw byte stream (for the GPU-side parser); `carry` receives the bytes already
+  // buffered.  Only valid before the first read_batch / read_raw and when no parse pipeline / index source is active.
+  std::unique_ptr<ByteSource> take_stream(std::string* carry) {
+    if (pipe_ || n_chunks >= 0) return nullptr;
+    StreamSource* ss = static_cast<StreamSource*>(r_.get());
+    *carry = has_pending_ ? pending_ + "\n" : std::string();
+    has_pending_ = false;
+    *carry += ss->r.take_buffered();
+    return ss->r.release_source();
+  }
+  const VCFConfig& config() const { return cfg_; }
 
   // Parallel mode only: the rest of the current slab as raw columns (no Arrow materialisation); false when the
   // reader is sequential (use read_batch) or the input is exhausted (*end = true).

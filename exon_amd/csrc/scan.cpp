@@ -1,14 +1,26 @@
 // scan.cpp -- C ABI of the native decoders (host/formats.h): exon_hip_scan_*.
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "host/formats.h"
 #include "internal.h"
 
+struct exon_hip_vcf_parser;  // gpu_parse.hip
+
 struct exon_hip_scan {
   int format = 0;
+  bool gpu_parse = false;
+  std::string path;
+  exon_hip_scan_options opt{};
+  std::string info_field_s, region_s;
+  exon_hip_vcf_parser* parser = nullptr;  // created by the first GPU-parsed consume; owns the FILTER dictionary
+  exon_hip_ctx* parser_ctx = nullptr;
+  exon::Dictionary gpu_filter_dict;       // names fetched from the parser after the consume
   std::unique_ptr<exon::VCFBatchReader> vcf;
   std::unique_ptr<exon::BAMBatchReader> bam;
   std::unique_ptr<exon::SAMBatchReader> sam;
@@ -19,10 +31,15 @@ struct exon_hip_scan {
 };
 
 int exon_hip_stream_push_raw(exon_hip_stream* st, const exon::RawBatch& rb);  // stream.cpp
+int exon_hip_stream_launch_scan_columns(exon_hip_stream* st, const exon_hip_column* scan_cols, int n_scan_cols, int64_t n);
+void* exon_hip_stream_hip_stream(exon_hip_stream* st);
+exon_hip_ctx* exon_hip_stream_ctx(exon_hip_stream* st);
+int exon_hip_stream_state_copy(exon_hip_stream* st, void* d_snapshot, bool restore);
+size_t exon_hip_stream_state_bytes(exon_hip_stream* st);
 
 static exon::Dictionary* dict_of(exon_hip_scan* s, int col) {
   if (s->format == EXON_HIP_FORMAT_VCF && col == 0) return &s->vcf->chrom_dict;
-  if (s->format == EXON_HIP_FORMAT_VCF && col == 3) return &s->vcf->filter_dict;
+  if (s->format == EXON_HIP_FORMAT_VCF && col == 3) return s->parser ? &s->gpu_filter_dict : &s->vcf->filter_dict;
   if ((s->format == EXON_HIP_FORMAT_BAM || s->format == EXON_HIP_FORMAT_SAM) && col == 2) return &s->bam_dict_view;
   return nullptr;
 }
@@ -35,6 +52,10 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
   try {
     std::unique_ptr<exon_hip_scan> s(new exon_hip_scan());
     s->format = o->format;
+    s->path = path;
+    s->opt = *o;
+    s->info_field_s = o->info_field ? o->info_field : "";
+    s->region_s = o->region ? o->region : "";
     const exon::Compression c = o->compression == EXON_HIP_COMPRESSION_GZIP   ? exon::Compression::Gzip
                                 : o->compression == EXON_HIP_COMPRESSION_NONE ? exon::Compression::None
                                                                               : exon::Compression::Auto;
@@ -52,6 +73,8 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         cfg.batch_size = bs;
         cfg.info_field = o->info_field ? o->info_field : "";
         cfg.filter = rf;
+        s->gpu_parse = o->gpu_parse != 0 && !rf.active;  // a pushed-down region filter stays on the host decoder
+        cfg.defer_decode = s->gpu_parse;
         s->vcf.reset(new exon::VCFBatchReader(path, c, cfg));
         break;
       }
@@ -110,6 +133,7 @@ int exon_hip_scan_schema(exon_hip_scan* s, struct ArrowSchema* out) {
 
 int exon_hip_scan_next(exon_hip_scan* s, struct ArrowArray* out) {
   if (!s || !out) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_scan_next: NULL argument");
+  if (s->gpu_parse) return fail(nullptr, EXON_HIP_ESTATE, "this scan was opened with gpu_parse: use exon_hip_stream_consume_scan");
   try {
     memset(out, 0, sizeof *out);
     bool got;
@@ -190,13 +214,182 @@ int exon_hip_index_query(const char* index_path, int32_t is_bai, const char* ref
 }
 
 int exon_hip_scan_close(exon_hip_scan* s) {
+  if (s && s->parser) exon_hip_vcf_parser_destroy(s->parser);
   delete s;
   return EXON_HIP_OK;
 }
 
+}  // extern "C"
+
+// file -> pinned slab -> HBM -> GPU parser -> fused kernel.  A background thread fills the next pinned slab while
+// the current one is copied and parsed.  Returns 1 when a slab held rows the device could not decide: the caller
+// restores the state and re-decodes the file on the host.
+static int consume_vcf_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* rows_out) {
+  exon_hip_ctx* ctx = exon_hip_stream_ctx(st);
+  hipStream_t hs = (hipStream_t)exon_hip_stream_hip_stream(st);
+  std::string carry;
+  std::unique_ptr<exon::ByteSource> src = scan->vcf->take_stream(&carry);
+  if (!src) return fail(ctx, EXON_HIP_ESTATE, "scan already consumed");
+  size_t slab = 64u << 20;
+  if (const char* v = getenv("EXON_HIP_GPU_PARSE_SLAB_MB")) {
+    const long mb = atol(v);
+    if (mb >= 1 && mb <= 2048) slab = (size_t)mb << 20;
+  }
+  if (!scan->parser) {
+    std::vector<const char*> names;
+    for (const auto& c : scan->vcf->header.contigs) names.push_back(c.c_str());
+    int rc = exon_hip_vcf_parser_create(ctx, names.data(), (int32_t)names.size(),
+                                        scan->info_field_s.empty() ? nullptr : scan->info_field_s.c_str(),
+                                        (int64_t)slab + 65536, &scan->parser);
+    if (rc) return rc;
+    scan->parser_ctx = ctx;
+  }
+  uint8_t* h_buf[2] = {nullptr, nullptr};
+  uint8_t* d_buf[2] = {nullptr, nullptr};
+  auto cleanup = [&]() {
+    for (int k = 0; k < 2; ++k) {
+      if (h_buf[k]) hipHostFree(h_buf[k]);
+      if (d_buf[k]) hipFree(d_buf[k]);
+    }
+  };
+  const size_t cap = slab + 65536;
+  for (int k = 0; k < 2; ++k)
+    if (hipHostMalloc((void**)&h_buf[k], cap) != hipSuccess || hipMalloc((void**)&d_buf[k], cap + 64) != hipSuccess) {
+      cleanup();
+      return fail(ctx, EXON_HIP_ENOMEM, "slab buffers (%zu bytes) could not be allocated", cap);
+    }
+  // reader: fills h_buf[k] with [carry | fresh bytes], cuts at the last newline, keeps the tail as the next carry
+  struct Filled { size_t n = 0; bool eof = false; std::exception_ptr err; };
+  auto fill = [&](int k, Filled* f) {
+    try {
+      size_t have = carry.size();
+      if (have > cap) throw std::runtime_error("VCF line longer than the slab size");
+      memcpy(h_buf[k], carry.data(), have);
+      carry.clear();
+      for (;;) {
+        while (have < slab) {
+          const size_t got = src->read(h_buf[k] + have, slab - have);
+          if (got == 0) { f->eof = true; break; }
+          have += got;
+        }
+        size_t cut = have;
+        if (!f->eof) {
+          while (cut > 0 && h_buf[k][cut - 1] != '\n') --cut;
+          if (cut == 0) throw std::runtime_error("VCF line longer than the slab size");
+        } else if (have > 0 && h_buf[k][have - 1] != '\n') {
+          h_buf[k][have++] = '\n';  // last line without a terminator (room: cap > slab)
+          cut = have;
+        }
+        carry.assign(reinterpret_cast<const char*>(h_buf[k]) + cut, have - cut);
+        f->n = cut;
+        return;
+      }
+    } catch (...) {
+      f->err = std::current_exception();
+    }
+  };
+  int64_t total = 0;
+  int rc = EXON_HIP_OK;
+  Filled cur, nxt;
+  fill(0, &cur);
+  int k = 0;
+  while (rc == EXON_HIP_OK) {
+    if (cur.err) {
+      try { std::rethrow_exception(cur.err); } catch (const std::exception& e) { rc = fail(ctx, EXON_HIP_EINVAL, "%s", e.what()); }
+      break;
+    }
+    std::thread reader;
+    const bool more = !cur.eof;
+    if (more) reader = std::thread([&, k] { fill(k ^ 1, &nxt); });  // overlaps with the copy + parse below
+    if (cur.n > 0) {
+      hipError_t e = hipMemcpyAsync(d_buf[k], h_buf[k], cur.n, hipMemcpyHostToDevice, hs);
+      if (e != hipSuccess) rc = fail(ctx, EXON_HIP_EDEVICE, "H2D of a text slab: %s", hipGetErrorString(e));
+      exon_hip_vcf_columns cols;
+      if (!rc) rc = exon_hip_vcf_parser_parse(scan->parser, hs, d_buf[k], (int64_t)cur.n, &cols);
+      if (!rc && cols.n_undecided > 0) rc = 1;  // host fallback
+      if (!rc && cols.n_rows > 0) {
+        exon_hip_column sc[5];
+        memset(sc, 0, sizeof sc);
+        sc[0].values = cols.chrom_id;
+        sc[1].values = cols.pos;
+        sc[1].validity = cols.pos_valid;
+        sc[2].values = cols.qual;
+        sc[2].validity = cols.qual_valid;
+        sc[3].values = cols.filter_id;
+        sc[4].values = cols.info;
+        sc[4].validity = cols.info_valid;
+        for (auto& c : sc) c.length = cols.n_rows;
+        rc = exon_hip_stream_launch_scan_columns(st, sc, 5, cols.n_rows);
+        // the parser's column buffers are reused by the next slab: the fused kernel must be done with them first
+        if (!rc && hipStreamSynchronize(hs) != hipSuccess) rc = fail(ctx, EXON_HIP_EDEVICE, "stream synchronize failed");
+        total += cols.n_rows;
+      }
+    }
+    if (reader.joinable()) reader.join();
+    if (!more) break;
+    cur = nxt;
+    nxt = Filled();
+    k ^= 1;
+  }
+  cleanup();
+  if (rc == EXON_HIP_OK) {
+    // FILTER dictionary -> scan (names in id order)
+    int32_t nf = 0;
+    std::vector<char> buf(1 << 20);
+    rc = exon_hip_vcf_parser_filters(scan->parser, buf.data(), buf.size(), &nf);
+    if (!rc) {
+      scan->gpu_filter_dict.names.clear();
+      size_t o = 0;
+      for (int32_t i = 0; i < nf; ++i) {
+        scan->gpu_filter_dict.names.emplace_back(buf.data() + o);
+        o += scan->gpu_filter_dict.names.back().size() + 1;
+      }
+    }
+    scan->rows += total;
+    if (rows_out) *rows_out = total;
+  }
+  return rc;
+}
+
+extern "C" {
+
 int exon_hip_stream_consume_scan(exon_hip_stream* st, exon_hip_scan* scan, int64_t* rows) {
   if (!st || !scan) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_stream_consume_scan: NULL argument");
   int64_t n = 0;
+  if (scan->gpu_parse && scan->vcf) {
+    // speculative GPU decode; on undecidable rows restore the state and fall back to the host decoder
+    exon_hip_ctx* ctx = exon_hip_stream_ctx(st);
+    void* snap = nullptr;
+    const size_t sb = exon_hip_stream_state_bytes(st);
+    if (hipMalloc(&snap, sb ? sb : 16) != hipSuccess) return fail(ctx, EXON_HIP_ENOMEM, "state snapshot allocation failed");
+    int rc = exon_hip_stream_state_copy(st, snap, false);
+    if (!rc) rc = consume_vcf_gpu(st, scan, rows);
+    if (rc == 1) {
+      rc = exon_hip_stream_state_copy(st, snap, true);
+      hipStreamSynchronize((hipStream_t)exon_hip_stream_hip_stream(st));
+      hipFree(snap);
+      if (rc) return rc;
+      if (scan->parser) {
+        exon_hip_vcf_parser_destroy(scan->parser);
+        scan->parser = nullptr;
+      }
+      scan->gpu_parse = false;
+      try {
+        exon::VCFConfig cfg = scan->vcf->config();
+        cfg.defer_decode = false;
+        const exon::Compression c = scan->opt.compression == EXON_HIP_COMPRESSION_GZIP   ? exon::Compression::Gzip
+                                    : scan->opt.compression == EXON_HIP_COMPRESSION_NONE ? exon::Compression::None
+                                                                                         : exon::Compression::Auto;
+        scan->vcf.reset(new exon::VCFBatchReader(scan->path, c, cfg));
+      } catch (const std::exception& e) {
+        return fail(nullptr, EXON_HIP_EINVAL, "%s", e.what());
+      }
+      // fall through to the host paths below
+    } else {
+      hipFree(snap);
+      return rc;
+    }
+  }
   // fast path: a multi-threaded VCF scan hands its slabs over as raw vectors (no Arrow batch in between)
   if (scan->vcf) {
     try {

@@ -397,6 +397,33 @@ int exon_hip_stream_push(exon_hip_stream* st, struct ArrowArray* batch) {
 
 }  // extern "C"
 
+// Internal (C++) hooks for the GPU decode pipeline (scan.cpp): launch the plan over HBM-resident columns addressed
+// in the SCAN's column order, and snapshot / restore the partial state around a speculative GPU-parsed file.
+int exon_hip_stream_launch_scan_columns(exon_hip_stream* st, const exon_hip_column* scan_cols, int n_scan_cols, int64_t n) {
+  exon_hip_plan* p = st->plan;
+  if (st->closed) return fail(st->ctx, EXON_HIP_ESTATE, "push after finish/close");
+  int rc = flush_slot(st);  // keep stream order with rows staged earlier
+  if (rc) return rc;
+  exon_hip_column cols[4];
+  for (int c = 0; c < p->n_cols; ++c) {
+    const int idx = p->d.columns[c];
+    if (idx >= n_scan_cols || !scan_cols[idx].values) return fail(st->ctx, EXON_HIP_EINVAL, "plan needs scan column %d which this scan does not produce", idx);
+    cols[c] = scan_cols[idx];
+  }
+  rc = launch_plan(st, cols, n);
+  if (!rc) st->rows_pushed += n;
+  return rc;
+}
+void* exon_hip_stream_hip_stream(exon_hip_stream* st) { return (void*)st->stream; }
+exon_hip_ctx* exon_hip_stream_ctx(exon_hip_stream* st) { return st->ctx; }
+int exon_hip_stream_state_copy(exon_hip_stream* st, void* d_snapshot, bool restore) {
+  const size_t bytes = (size_t)(st->plan->n_i64 + st->plan->n_f64) * 8;
+  HIP_TRY(st->ctx, hipMemcpyAsync(restore ? (void*)st->d_state : d_snapshot, restore ? d_snapshot : (void*)st->d_state, bytes,
+                                  hipMemcpyDeviceToDevice, st->stream));
+  return EXON_HIP_OK;
+}
+size_t exon_hip_stream_state_bytes(exon_hip_stream* st) { return (size_t)(st->plan->n_i64 + st->plan->n_f64) * 8; }
+
 // Internal (C++): append decoder output (raw vectors + validity bytes) to the staging slot.  Fixed-width plans only.
 int exon_hip_stream_push_raw(exon_hip_stream* st, const exon::RawBatch& rb) {
   exon_hip_plan* p = st->plan;

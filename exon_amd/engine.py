@@ -235,12 +235,13 @@ class Scan:
     """Native decoder + device-layout array builder over one file (FileOpener::open + read_batch analogue).
     CPU-only: usable without a GPU."""
 
-    def __init__(self, path, fmt, compression=None, batch_size=0, info_field=None, region=None, use_index=False):
+    def __init__(self, path, fmt, compression=None, batch_size=0, info_field=None, region=None, use_index=False,
+                 gpu_parse=False):
         self.lib = L.load()
         self.fmt = fmt
         opt = L.ScanOptions(L.FORMATS[fmt], L.COMPRESSION[compression], batch_size,
                             info_field.encode() if info_field else None, region.encode() if region else None,
-                            1 if use_index else 0, 0)
+                            1 if use_index else 0, 1 if gpu_parse else 0)
         h = C.c_void_p()
         rc = self.lib.exon_hip_scan_open(str(path).encode(), C.byref(opt), C.byref(h))
         if rc:

@@ -282,7 +282,8 @@ typedef struct exon_hip_scan_options {
   const char* info_field; /* VCF: typed INFO field to extract (exon.vcf_parse_info), NULL = none */
   const char* region;     /* pushed-down vcf_region_filter / bam_region_filter ("chr1:1-100"), NULL = none */
   int32_t use_index;      /* with `region`: plan BGZF chunks from <path>.tbi / <path>.bai (INDEXED_VCF / INDEXED_BAM) */
-  int32_t reserved;
+  int32_t gpu_parse;      /* VCF: exon_hip_stream_consume_scan ships the TEXT to HBM and parses it on the GPU
+                             (exon_hip_vcf_parser_*); exon_hip_scan_next is then not available on this scan */
 } exon_hip_scan_options;
 
 int exon_hip_scan_open(const char* path, const exon_hip_scan_options* options, exon_hip_scan** out);

@@ -172,3 +172,20 @@ def test_cli_big_file_parallel_decode_raw_handoff(tmp_path, oracle):
         assert got[key][0] == pytest.approx(s[g] / cn[g], rel=1e-6)
     out = run(f"SELECT COUNT(*) FROM vcf_scan('{p}') WHERE chrom = '1' AND pos >= 1000 AND pos <= 1200000").stdout
     assert last_count(out) == 1200000 - 1000 + 1
+
+
+@pytest.mark.gpu
+def test_cli_gpu_parse_matches_host_decode(tmp_path):
+    gen = os.path.join(ROOT, "tools", "bin", "gen_text")
+    p = tmp_path / "syn.vcf"
+    subprocess.check_call([gen, "vcf", "800000", str(p)])
+    sql = ["SET exon.vcf_parse_info = true;" f"CREATE EXTERNAL TABLE v STORED AS VCF LOCATION '{p}';"
+           'SELECT filter, AVG(qual), COUNT(*) FROM v WHERE info."AF" >= 0.25 GROUP BY filter',
+           f"SELECT COUNT(*) FROM vcf_scan('{p}') WHERE chrom = '1' AND pos >= 5 AND pos <= 700000"]
+    outs = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, EXON_HIP_GPU_PARSE=flag)
+        r = subprocess.run([CLI, "-q", "-c", *sql], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr
+        outs.append(sorted(tuple(row) for row in cells(r.stdout) + [["k2", str(last_count(r.stdout))]]))
+    assert outs[0] == outs[1]

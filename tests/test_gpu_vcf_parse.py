@@ -111,3 +111,47 @@ def test_gpu_parse_undecidable_rows_are_counted(ctx):
     assert bits(res["info_valid"], 5).tolist() == [True, True, True, False, False]
     assert res["qual"][4] == np.float32(0.7) and res["info"][0] == np.float32(0.5)
     p.close()
+
+
+def _k4_through_scan(ctx, path, gpu_parse, info_field="AF"):
+    scan = exon_amd.Scan(path, "vcf", info_field=info_field, gpu_parse=gpu_parse)
+    plan = ctx.plan_cmp_avg_by_group(">", 0.01, 64, columns=(4, 2, 3))
+    st = plan.open()
+    rows = st.consume(scan)
+    counts, sums = st.finish()
+    names = scan.dictionary(3)
+    res = {names[g]: (int(counts[g]), int(counts[64 + g]), float(sums[g])) for g in range(len(names)) if counts[64 + g]}
+    st.close()
+    plan.close()
+    scan.close()
+    return rows, res
+
+
+def test_file_to_gpu_parse_pipeline_equals_host_decode(ctx, tmp_path, monkeypatch):
+    gen = os.path.join(ROOT, "tools", "bin", "gen_text")
+    n = 2_000_000
+    path = tmp_path / "syn.vcf"
+    subprocess.check_call([gen, "vcf", str(n), str(path)])
+    monkeypatch.setenv("EXON_HIP_GPU_PARSE_SLAB_MB", "16")  # several slabs, double-buffered reader
+    rows_g, gpu = _k4_through_scan(ctx, path, True)
+    rows_h, host = _k4_through_scan(ctx, path, False)
+    assert rows_g == rows_h == n
+    assert gpu.keys() == host.keys()
+    for k in host:
+        assert gpu[k][:2] == host[k][:2]                      # counts bit-exact
+        assert gpu[k][2] == pytest.approx(host[k][2], rel=1e-12)
+
+
+def test_gpu_parse_falls_back_to_host_on_undecidable_rows(ctx, tmp_path):
+    """A contig that is not in the header makes the device give up on the slab: the state is restored and the file is
+    re-decoded on the host, so the answer is still the host decoder's."""
+    path = tmp_path / "odd.vcf"
+    with open(path, "w") as f:
+        f.write('##fileformat=VCFv4.3\n##contig=<ID=1>\n##INFO=<ID=AF,Number=1,Type=Float,Description="AF">\n')
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+        for i in range(5000):
+            chrom = "GL99" if i == 4000 else "1"
+            f.write(f"{chrom}\t{i + 1}\t.\tA\tC\t{i % 90}.5\t{'PASS' if i % 3 else 'q10'}\tAF=0.{1 + i % 8}\n")
+    rows_g, gpu = _k4_through_scan(ctx, path, True)
+    rows_h, host = _k4_through_scan(ctx, path, False)
+    assert rows_g == rows_h == 5000 and gpu == host
