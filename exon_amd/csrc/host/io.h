@@ -25,6 +25,9 @@ class ByteSource {
  public:
   virtual ~ByteSource() = default;
   virtual size_t read(uint8_t* dst, size_t n) = 0;  // up to n bytes; 0 at end of data
+  // An uncompressed regular file can also be read with positional reads from several threads: its descriptor and the
+  // offset of the next unread byte.  After the caller starts using them it must not call read() again.
+  virtual bool plain_file(int* fd, int64_t* offset) { (void)fd; (void)offset; return false; }
 };
 
 class ByteReader : public ByteSource {
@@ -47,6 +50,12 @@ class ByteReader : public ByteSource {
   ~ByteReader() {
     if (z_init_) inflateEnd(&z_);
     if (f_) fclose(f_);
+  }
+  bool plain_file(int* fd, int64_t* offset) override {
+    if (gz_) return false;
+    *fd = fileno(f_);
+    *offset = (int64_t)ftell(f_);
+    return true;
   }
   ByteReader(const ByteReader&) = delete;
   ByteReader& operator=(const ByteReader&) = delete;

@@ -1,4 +1,6 @@
 // scan.cpp -- C ABI of the native decoders (host/formats.h): exon_hip_scan_*.
+#include <unistd.h>
+
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -258,6 +260,39 @@ static int consume_vcf_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* ro
       cleanup();
       return fail(ctx, EXON_HIP_ENOMEM, "slab buffers (%zu bytes) could not be allocated", cap);
     }
+  // plain files are read with positional reads from several threads (one fread stream tops out near 6 GB/s)
+  int fd = -1;
+  int64_t foff = 0;
+  const bool plain = src->plain_file(&fd, &foff);
+  auto read_some = [&](uint8_t* dst, size_t n) -> size_t {
+    if (!plain) return src->read(dst, n);
+    const int T = 8;
+    const size_t per = (n + T - 1) / T;
+    size_t got[T] = {0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) {
+      const size_t o = (size_t)t * per;
+      if (o >= n) break;
+      const size_t len = std::min(per, n - o);
+      th.emplace_back([&, t, o, len] {
+        size_t done = 0;
+        while (done < len) {
+          const ssize_t r = pread(fd, dst + o + done, len - done, (off_t)(foff + (int64_t)(o + done)));
+          if (r <= 0) break;
+          done += (size_t)r;
+        }
+        got[t] = done;
+      });
+    }
+    for (auto& x : th) x.join();
+    size_t total = 0;
+    for (int t = 0; t < T; ++t) {
+      total += got[t];
+      if (got[t] < std::min(per, n > (size_t)t * per ? n - (size_t)t * per : 0)) break;  // EOF inside this chunk
+    }
+    foff += (int64_t)total;
+    return total;
+  };
   // reader: fills h_buf[k] with [carry | fresh bytes], cuts at the last newline, keeps the tail as the next carry
   struct Filled { size_t n = 0; bool eof = false; std::exception_ptr err; };
   auto fill = [&](int k, Filled* f) {
@@ -268,7 +303,7 @@ static int consume_vcf_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* ro
       carry.clear();
       for (;;) {
         while (have < slab) {
-          const size_t got = src->read(h_buf[k] + have, slab - have);
+          const size_t got = read_some(h_buf[k] + have, slab - have);
           if (got == 0) { f->eof = true; break; }
           have += got;
         }
