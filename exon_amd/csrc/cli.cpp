@@ -185,6 +185,7 @@ std::vector<std::string> format_exts(int format, const std::string& custom) {
     case EXON_HIP_FORMAT_FASTQ: return {".fastq", ".fq"};
     case EXON_HIP_FORMAT_VCF: return {".vcf"};
     case EXON_HIP_FORMAT_SAM: return {".sam"};
+    case EXON_HIP_FORMAT_BCF: return {".bcf"};
     default: return {".bam"};
   }
 }
@@ -198,6 +199,7 @@ int format_of(const std::string& name, bool* indexed) {
   if (f == "vcf") return EXON_HIP_FORMAT_VCF;
   if (f == "bam") return EXON_HIP_FORMAT_BAM;
   if (f == "sam") return EXON_HIP_FORMAT_SAM;
+  if (f == "bcf") return EXON_HIP_FORMAT_BCF;
   throw Err("unsupported file type " + name);
 }
 
@@ -457,7 +459,7 @@ void exec_select(Session& se, Parser& ps) {
     print_table({"count(*)"}, {{std::to_string(count_rows(src, pr.region))}}, se.quiet);
     return;
   }
-  if (count_only && pr.kind == Predicate::Region && src.format == EXON_HIP_FORMAT_VCF) {  // K2
+  if (count_only && pr.kind == Predicate::Region && (src.format == EXON_HIP_FORMAT_VCF || src.format == EXON_HIP_FORMAT_BCF)) {  // K2
     exon_hip_ctx* ctx = se.gpu();
     int64_t total = 0;
     for (const auto& f : src.files) {
@@ -511,7 +513,7 @@ void exec_select(Session& se, Parser& ps) {
     print_table({"reference", "count(*)"}, rows, se.quiet);
     return;
   }
-  if (pr.kind == Predicate::InfoCmp && src.format == EXON_HIP_FORMAT_VCF && group_by == "filter") {  // K4
+  if (pr.kind == Predicate::InfoCmp && (src.format == EXON_HIP_FORMAT_VCF || src.format == EXON_HIP_FORMAT_BCF) && group_by == "filter") {  // K4
     if (!se.vcf_parse_info) throw Err("info." + pr.info_field + " needs `SET exon.vcf_parse_info = true` (info is a Utf8 column otherwise)");
     exon_hip_ctx* ctx = se.gpu();
     struct Acc { double sum = 0; int64_t cnt = 0, rows = 0; };

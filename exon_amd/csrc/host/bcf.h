@@ -1,0 +1,239 @@
+// bcf.h -- BCF2 (binary VCF) record decoder emitting the VCF device layout.
+//
+// Reference: exon-bcf (config / batch reader / array builder, same Arrow schema as VCF) behind
+// exon-core/src/datasources/bcf/; pinned by exon-core/src/session_context/exon_context_ext.rs:1053-1090
+// (index.bcf: 621 records, 191 on chromosome "1").  Record layout: VCF 4.x specification section 6 (BCF2): BGZF stream,
+// "BCF\2\2", text header, then per record `l_shared, l_indiv`, fixed fields (CHROM id, 0-based POS, rlen, QUAL with the
+// 0x7F800001 missing sentinel, n_info | n_allele << 16, n_fmt << 24 | n_sample), typed ID / alleles / FILTER (dictionary
+// indexes) / INFO (dictionary index -> typed value).
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "formats.h"
+
+namespace exon {
+
+class BCFBatchReader {
+ public:
+  BCFBatchReader(const std::string& path, VCFConfig cfg) : cfg_(std::move(cfg)) {
+    r_.reset(new StreamSource(path, Compression::Gzip, cfg_.threads));
+    uint8_t magic[5];
+    if (!r_->read_exact(magic, 5) || memcmp(magic, "BCF\2\2", 5) != 0) throw std::runtime_error("not a BCF2 file: " + path);
+    uint8_t lb[4];
+    if (!r_->read_exact(lb, 4)) throw std::runtime_error("truncated BCF header");
+    uint32_t l_text;
+    memcpy(&l_text, lb, 4);
+    std::string text((size_t)l_text, '\0');
+    if (l_text && !r_->read_exact(reinterpret_cast<uint8_t*>(&text[0]), l_text)) throw std::runtime_error("truncated BCF header");
+    // dictionaries: contigs by ##contig order (or IDX), strings (FILTER/INFO/FORMAT ids) with PASS = 0
+    std::map<std::string, int> str_idx;
+    auto add_string = [&](const std::string& id, const std::string& idx_attr) {
+      if (str_idx.count(id)) return;
+      const int idx = idx_attr.empty() ? (int)strings_.size() : atoi(idx_attr.c_str());
+      if ((int)strings_.size() <= idx) strings_.resize((size_t)idx + 1);
+      strings_[(size_t)idx] = id;
+      str_idx[id] = idx;
+    };
+    add_string("PASS", "0");
+    size_t start = 0;
+    while (start < text.size()) {
+      size_t nl = text.find('\n', start);
+      if (nl == std::string::npos) nl = text.size();
+      const std::string line = text.substr(start, nl - start);
+      start = nl + 1;
+      if (line.rfind("##contig=", 0) == 0) {
+        const std::string id = header_attr(line, "ID"), idx = header_attr(line, "IDX");
+        const int k = idx.empty() ? (int)header.contigs.size() : atoi(idx.c_str());
+        if ((int)header.contigs.size() <= k) header.contigs.resize((size_t)k + 1);
+        header.contigs[(size_t)k] = id;
+      } else if (line.rfind("##FILTER=", 0) == 0) {
+        header.filters.push_back(header_attr(line, "ID"));
+        add_string(header_attr(line, "ID"), header_attr(line, "IDX"));
+      } else if (line.rfind("##INFO=", 0) == 0) {
+        header.infos.emplace_back(header_attr(line, "ID"), header_attr(line, "Number") + "|" + header_attr(line, "Type"));
+        add_string(header_attr(line, "ID"), header_attr(line, "IDX"));
+      } else if (line.rfind("##FORMAT=", 0) == 0) {
+        add_string(header_attr(line, "ID"), header_attr(line, "IDX"));
+      }
+    }
+    for (const auto& c : header.contigs) chrom_dict.names.push_back(c);
+    info_key_ = -1;
+    if (!cfg_.info_field.empty()) {
+      auto it = str_idx.find(cfg_.info_field);
+      bool ok = false;
+      for (const auto& kv : header.infos)
+        if (kv.first == cfg_.info_field) ok = (kv.second == "1|Float" || kv.second == "1|Integer");
+      if (it == str_idx.end()) throw std::runtime_error("INFO field " + cfg_.info_field + " is not declared in the header");
+      if (!ok) throw std::runtime_error("INFO field " + cfg_.info_field + " is not a Number=1 Float/Integer field");
+      info_key_ = it->second;
+    }
+    if (cfg_.filter.active) {
+      region_chrom_ = -2;
+      for (size_t i = 0; i < header.contigs.size(); ++i)
+        if (header.contigs[i] == cfg_.filter.region.name) region_chrom_ = (int)i;
+    }
+  }
+
+  bool read_batch(struct ArrowArray* out) {
+    PrimitiveBuilder<int32_t> chrom, filter;
+    PrimitiveBuilder<int64_t> pos;
+    PrimitiveBuilder<float> qual, info;
+    std::vector<uint8_t> rec;
+    size_t rows = 0;
+    while ((int64_t)rows < cfg_.batch_size) {
+      uint8_t lens[8];
+      if (!r_->read_exact(lens, 8)) break;
+      uint32_t l_shared, l_indiv;
+      memcpy(&l_shared, lens, 4);
+      memcpy(&l_indiv, lens + 4, 4);
+      if (l_shared < 24) throw std::runtime_error("corrupt BCF record");
+      rec.resize((size_t)l_shared + l_indiv);
+      if (!r_->read_exact(rec.data(), rec.size())) throw std::runtime_error("truncated BCF record");
+      int32_t chrom_id, pos0;
+      uint32_t qbits, nia;
+      memcpy(&chrom_id, &rec[0], 4);
+      memcpy(&pos0, &rec[4], 4);
+      memcpy(&qbits, &rec[12], 4);
+      memcpy(&nia, &rec[16], 4);
+      const int n_info = (int)(nia & 0xFFFF), n_allele = (int)(nia >> 16);
+      if (cfg_.filter.active) {  // same per-record interval hit as the VCF reader
+        const Region& rg = cfg_.filter.region;
+        const int64_t p1 = (int64_t)pos0 + 1;
+        if (chrom_id != region_chrom_ || p1 < rg.start || p1 > rg.end) continue;
+      }
+      size_t o = 24;
+      const size_t end = l_shared;
+      skip_typed(rec, &o, end);                               // ID
+      for (int a = 0; a < n_allele; ++a) skip_typed(rec, &o, end);  // REF + ALTs
+      // FILTER: typed int vector of dictionary indexes; empty = '.'
+      std::string fl;
+      {
+        int type, count;
+        typed_header(rec, &o, end, &type, &count);
+        for (int i = 0; i < count; ++i) {
+          const int64_t v = read_int(rec, &o, end, type);
+          if (v < 0 || v >= (int64_t)strings_.size()) throw std::runtime_error("BCF FILTER index out of range");
+          if (i) fl += ';';
+          fl += strings_[(size_t)v];
+        }
+      }
+      // INFO: (typed key, typed value) pairs
+      bool have = false;
+      float iv = 0.f;
+      for (int k = 0; k < n_info; ++k) {
+        int kt, kc;
+        typed_header(rec, &o, end, &kt, &kc);
+        const int64_t key = kc ? read_int(rec, &o, end, kt) : -1;
+        int vt, vc;
+        typed_header(rec, &o, end, &vt, &vc);
+        if (key == info_key_ && info_key_ >= 0 && vc >= 1) {
+          if (vt == 5) {
+            uint32_t b;
+            if (o + 4 > end) throw std::runtime_error("corrupt BCF INFO");
+            memcpy(&b, &rec[o], 4);
+            if (b != 0x7F800001u && b != 0x7F800002u) {
+              memcpy(&iv, &b, 4);
+              have = true;
+            }
+            o += (size_t)vc * 4;
+          } else if (vt >= 1 && vt <= 3) {
+            size_t oo = o;
+            const int64_t v = read_int(rec, &oo, end, vt);
+            const int64_t missing = vt == 1 ? -128 : vt == 2 ? -32768 : (int64_t)INT32_MIN;
+            if (v != missing) {
+              iv = (float)v;
+              have = true;
+            }
+            o += (size_t)vc * type_size(vt);
+          } else {
+            o += (size_t)vc * type_size(vt);
+          }
+        } else {
+          o += (size_t)vc * type_size(vt);
+        }
+        if (o > end) throw std::runtime_error("corrupt BCF INFO");
+      }
+      if (chrom_id < 0 || chrom_id >= (int)chrom_dict.names.size()) throw std::runtime_error("BCF CHROM index out of range");
+      chrom.append_value(chrom_id);
+      pos.append_value((int64_t)pos0 + 1);
+      if (qbits == 0x7F800001u) qual.append_null(0.f);
+      else {
+        float q;
+        memcpy(&q, &qbits, 4);
+        qual.append_value(q);
+      }
+      filter.append_value(filter_dict.lookup_or_insert(fl.data(), fl.size()));
+      if (info_key_ >= 0) {
+        if (have) info.append_value(iv);
+        else info.append_null(0.f);
+      }
+      ++rows;
+    }
+    if (rows == 0) return false;
+    std::vector<struct ArrowArray*> kids = {chrom.finish(utf8_array(chrom_dict.names)), pos.finish(), qual.finish(),
+                                            filter.finish(utf8_array(filter_dict.names))};
+    if (info_key_ >= 0) kids.push_back(info.finish());
+    make_struct(out, (int64_t)rows, std::move(kids));
+    return true;
+  }
+
+  void schema(struct ArrowSchema* out) const {
+    std::vector<struct ArrowSchema*> kids = {new_field("i", "chrom", false, new_field("u", "", false)), new_field("l", "pos", true),
+                                             new_field("f", "qual", true), new_field("i", "filter", false, new_field("u", "", false))};
+    if (info_key_ >= 0) kids.push_back(new_field("f", ("info." + cfg_.info_field).c_str(), true));
+    make_schema(out, "+s", "", false, kids);
+  }
+
+  VCFHeader header;
+  Dictionary chrom_dict, filter_dict;
+
+ private:
+  static int type_size(int t) { return t == 1 ? 1 : t == 2 ? 2 : t == 3 ? 4 : t == 5 ? 4 : t == 7 ? 1 : 0; }
+  static int64_t read_int(const std::vector<uint8_t>& b, size_t* o, size_t end, int type) {
+    const int sz = type_size(type);
+    if (type < 1 || type > 3 || *o + (size_t)sz > end) throw std::runtime_error("corrupt BCF typed integer");
+    int64_t v;
+    if (type == 1) v = (int8_t)b[*o];
+    else if (type == 2) {
+      int16_t x;
+      memcpy(&x, &b[*o], 2);
+      v = x;
+    } else {
+      int32_t x;
+      memcpy(&x, &b[*o], 4);
+      v = x;
+    }
+    *o += (size_t)sz;
+    return v;
+  }
+  static void typed_header(const std::vector<uint8_t>& b, size_t* o, size_t end, int* type, int* count) {
+    if (*o >= end) throw std::runtime_error("corrupt BCF typed value");
+    const uint8_t d = b[(*o)++];
+    *type = d & 0xF;
+    *count = d >> 4;
+    if (*count == 15) {  // the real count follows as a typed integer
+      int ct, cc;
+      typed_header(b, o, end, &ct, &cc);
+      *count = (int)read_int(b, o, end, ct);
+    }
+  }
+  static void skip_typed(const std::vector<uint8_t>& b, size_t* o, size_t end) {
+    int t, c;
+    typed_header(b, o, end, &t, &c);
+    *o += (size_t)c * type_size(t);
+    if (*o > end) throw std::runtime_error("corrupt BCF typed value");
+  }
+
+  std::unique_ptr<RecordSource> r_;
+  VCFConfig cfg_;
+  std::vector<std::string> strings_;
+  int info_key_ = -1, region_chrom_ = -2;
+};
+
+}  // namespace exon

@@ -9,6 +9,7 @@
 #include <thread>
 #include <vector>
 
+#include "host/bcf.h"
 #include "host/formats.h"
 #include "internal.h"
 
@@ -26,6 +27,7 @@ struct exon_hip_scan {
   std::unique_ptr<exon::VCFBatchReader> vcf;
   std::unique_ptr<exon::BAMBatchReader> bam;
   std::unique_ptr<exon::SAMBatchReader> sam;
+  std::unique_ptr<exon::BCFBatchReader> bcf;
   std::unique_ptr<exon::FASTQBatchReader> fastq;
   std::unique_ptr<exon::FASTABatchReader> fasta;
   int64_t rows = 0;
@@ -40,6 +42,8 @@ int exon_hip_stream_state_copy(exon_hip_stream* st, void* d_snapshot, bool resto
 size_t exon_hip_stream_state_bytes(exon_hip_stream* st);
 
 static exon::Dictionary* dict_of(exon_hip_scan* s, int col) {
+  if (s->format == EXON_HIP_FORMAT_BCF && col == 0) return &s->bcf->chrom_dict;
+  if (s->format == EXON_HIP_FORMAT_BCF && col == 3) return &s->bcf->filter_dict;
   if (s->format == EXON_HIP_FORMAT_VCF && col == 0) return &s->vcf->chrom_dict;
   if (s->format == EXON_HIP_FORMAT_VCF && col == 3) return s->parser ? &s->gpu_filter_dict : &s->vcf->filter_dict;
   if ((s->format == EXON_HIP_FORMAT_BAM || s->format == EXON_HIP_FORMAT_SAM) && col == 2) return &s->bam_dict_view;
@@ -88,6 +92,15 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         s->bam_dict_view.names = s->bam->ref_names;
         break;
       }
+      case EXON_HIP_FORMAT_BCF: {
+        exon::VCFConfig cfg;
+        cfg.batch_size = bs;
+        cfg.info_field = o->info_field ? o->info_field : "";
+        cfg.filter = rf;
+        cfg.filter.use_index = false;
+        s->bcf.reset(new exon::BCFBatchReader(path, cfg));
+        break;
+      }
       case EXON_HIP_FORMAT_SAM: {
         exon::BAMConfig cfg;
         cfg.batch_size = bs;
@@ -125,6 +138,7 @@ int exon_hip_scan_schema(exon_hip_scan* s, struct ArrowSchema* out) {
     if (s->vcf) s->vcf->schema(out);
     else if (s->bam) s->bam->schema(out);
     else if (s->sam) s->sam->schema(out);
+    else if (s->bcf) s->bcf->schema(out);
     else if (s->fastq) s->fastq->schema(out);
     else s->fasta->schema(out);
     return EXON_HIP_OK;
@@ -142,6 +156,7 @@ int exon_hip_scan_next(exon_hip_scan* s, struct ArrowArray* out) {
     if (s->vcf) got = s->vcf->read_batch(out);
     else if (s->bam) got = s->bam->read_batch(out);
     else if (s->sam) got = s->sam->read_batch(out);
+    else if (s->bcf) got = s->bcf->read_batch(out);
     else if (s->fastq) got = s->fastq->read_batch(out);
     else got = s->fasta->read_batch(out);
     if (!got) return 1;

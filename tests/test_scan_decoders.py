@@ -402,3 +402,19 @@ def test_parallel_bgzf_bam_equals_sequential(tmp_path, monkeypatch):
     a, b = scan(1), scan(4)
     assert len(a) == n and a.equals(b)
     assert scan(1, region="chr2:5000-900000").equals(scan(4, region="chr2:5000-900000"))
+
+
+# ---- BCF ----------------------------------------------------------------------------
+def test_bcf_scan_pins_and_equals_vcf_twin():
+    """exon-core/src/session_context/exon_context_ext.rs:1053-1090: index.bcf has 621 records, 191 in region '1'.
+    The BCF is the binary twin of vcf/index.vcf: the device-layout columns must be identical."""
+    bcf = exon_amd.Scan(fx("bcf", "index.bcf"), "bcf", info_field="MQ0F")
+    b = [r for batch in bcf for r in batch.to_pylist()]
+    assert len(b) == 621
+    assert sum(len(x) for x in exon_amd.Scan(fx("bcf", "index.bcf"), "bcf", region="1")) == 191
+    vcf = exon_amd.Scan(fx("vcf", "index.vcf"), "vcf", info_field="MQ0F")
+    v = [r for batch in vcf for r in batch.to_pylist()]
+    assert b == v
+    assert bcf.dictionary(0)[:5] == vcf.dictionary(0)[:5]
+    with pytest.raises(exon_amd.ExonHipError, match="Number=1"):
+        exon_amd.Scan(fx("bcf", "index.bcf"), "bcf", info_field="I16")
