@@ -72,6 +72,11 @@ class PlanDesc(C.Structure):
     ]
 
 
+class FASTQViews(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("n_undecided", C.c_int64), ("consumed_bytes", C.c_int64),
+                ("seq_start", C.c_void_p), ("seq_end", C.c_void_p), ("qual_start", C.c_void_p), ("qual_end", C.c_void_p)]
+
+
 class VCFColumns(C.Structure):
     _fields_ = [("n_rows", C.c_int64), ("n_undecided", C.c_int64), ("chrom_id", C.c_void_p), ("pos", C.c_void_p),
                 ("pos_valid", C.c_void_p), ("qual", C.c_void_p), ("qual_valid", C.c_void_p), ("filter_id", C.c_void_p),
@@ -149,6 +154,10 @@ SIGNATURES = {
     "exon_hip_vcf_parser_parse": (C.c_int, [_vp, _vp, _vp, _i64, C.POINTER(VCFColumns)]),
     "exon_hip_vcf_parser_filters": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(_i32)]),
     "exon_hip_vcf_parser_destroy": (C.c_int, [_vp]),
+    "exon_hip_qual_pos_hist_views": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "exon_hip_fastq_parser_create": (C.c_int, [_vp, _i64, C.POINTER(_vp)]),
+    "exon_hip_fastq_parser_parse": (C.c_int, [_vp, _vp, _vp, _i64, _i32, C.POINTER(FASTQViews)]),
+    "exon_hip_fastq_parser_destroy": (C.c_int, [_vp]),
 }
 
 

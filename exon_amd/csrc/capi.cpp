@@ -310,6 +310,21 @@ int exon_hip_qual_pos_hist(exon_hip_ctx* ctx, void* stream, const exon_hip_colum
   return EXON_HIP_OK;
 }
 
+int exon_hip_qual_pos_hist_views(exon_hip_ctx* ctx, void* stream, const uint8_t* d_bytes, const int32_t* d_starts,
+                                 const int32_t* d_ends, int64_t n_reads, int32_t lmax, int64_t* d_hist) {
+  if (!ctx || !d_hist) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_qual_pos_hist_views: NULL argument");
+  if (n_reads < 0) return fail(ctx, EXON_HIP_EINVAL, "n_reads < 0");
+  if (lmax < 1 || lmax > (1 << 20)) return fail(ctx, EXON_HIP_EINVAL, "lmax %d out of range", lmax);
+  if (n_reads == 0) return EXON_HIP_OK;
+  if (!d_bytes || !d_starts || !d_ends) return fail(ctx, EXON_HIP_EINVAL, "views: bytes/starts/ends NULL");
+  hipStream_t s = pick_stream(ctx, stream);
+  Workspace ws;
+  int rc;
+  if ((rc = get_workspace(ctx, s, exon::k5_partial_words(ctx->cfg, lmax), &ws))) return fail(ctx, rc, "workspace allocation failed");
+  HIP_TRY(ctx, exon::launch_qual_pos_hist_views(s, ctx->cfg, ws, d_starts, d_ends, d_bytes, n_reads, lmax, d_hist));
+  return EXON_HIP_OK;
+}
+
 // ---- synthetic inputs ----------------------------------------------------------------------------
 int exon_hip_gen_c2(exon_hip_ctx* ctx, void* stream, uint64_t seed, int64_t n_total, int64_t lo, int64_t hi,
                     int32_t* d_chrom_id, int64_t* d_pos) {

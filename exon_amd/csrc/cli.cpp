@@ -253,7 +253,7 @@ struct StreamGuard {
   ~StreamGuard() { if (s) exon_hip_stream_close(s); if (p) exon_hip_plan_destroy(p); }
 };
 
-// VCF queries that end in a fused GPU kernel ship the text to HBM and parse it there (EXON_HIP_GPU_PARSE=0: host decode)
+// VCF / FASTQ queries that end in a fused GPU kernel ship the text to HBM and parse it there (EXON_HIP_GPU_PARSE=0: host decode)
 bool gpu_parse_enabled() {
   const char* v = getenv("EXON_HIP_GPU_PARSE");
   return !(v && v[0] == '0');
@@ -270,7 +270,8 @@ void open_scan(const Source& src, const std::string& file, const char* info_fiel
   // INDEXED_* tables / *_indexed_scan: plan BGZF chunks from <file>.tbi / <file>.bai
   // (exon-core/src/datasources/indexed_file/indexed_bgzf_file.rs:129-155)
   o.use_index = (src.indexed && !region.empty()) ? 1 : 0;
-  o.gpu_parse = (for_gpu_query && src.format == EXON_HIP_FORMAT_VCF && region.empty() && gpu_parse_enabled()) ? 1 : 0;
+  o.gpu_parse = (for_gpu_query && (src.format == EXON_HIP_FORMAT_VCF || src.format == EXON_HIP_FORMAT_FASTQ) && region.empty() &&
+                 gpu_parse_enabled()) ? 1 : 0;
   ck(nullptr, exon_hip_scan_open(file.c_str(), &o, &g->s));
 }
 
@@ -434,7 +435,7 @@ void exec_select(Session& se, Parser& ps) {
     const int lmax = 512;
     std::vector<int64_t> total((size_t)lmax * 256, 0);
     for (const auto& f : src.files) {
-      ScanGuard g; open_scan(src, f, nullptr, "", &g);
+      ScanGuard g; open_scan(src, f, nullptr, "", &g, true);
       StreamGuard sg;
       exon_hip_plan_desc d; memset(&d, 0, sizeof d);
       d.kind = EXON_HIP_PLAN_QUAL_POS_HIST; d.lmax = lmax; d.columns[0] = 3;

@@ -542,3 +542,122 @@ int exon_hip_vcf_parser_filters(exon_hip_vcf_parser* p, char* buf, size_t cap, i
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------
+// FASTQ: the newline index above is all the "parsing" a histogram over quality (or sequence) lines needs.  Read r
+// is lines 4r .. 4r+3; its views are byte ranges into the slab itself, consumed in place by K5's ragged / fixed
+// paths (kernels.hip) -- the text is read from HBM once for the index and once for the histogram.
+namespace {
+
+// scalars: [0] n_lines (in), [1] undecided (+=), [2] consumed bytes (out)
+__global__ __launch_bounds__(TPB) void k_fastq_views(const uint8_t* __restrict__ text, const unsigned* __restrict__ nl,
+                                                     unsigned* __restrict__ scalars, unsigned cap_lines, int final_slab,
+                                                     int32_t* __restrict__ seq_s, int32_t* __restrict__ seq_e,
+                                                     int32_t* __restrict__ qual_s, int32_t* __restrict__ qual_e) {
+  const unsigned n_lines = scalars[0];
+  const int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (n_lines > cap_lines) {  // the index was truncated: nothing can be trusted
+    if (r == 0) atomicAdd(&scalars[1], 1u);
+    return;
+  }
+  const unsigned n_reads = n_lines / 4;
+  if (r == 0) {
+    scalars[2] = n_reads ? nl[4 * n_reads - 1] + 1u : 0u;
+    if (final_slab && (n_lines & 3u)) atomicAdd(&scalars[1], 1u);
+  }
+  if (r >= n_reads) return;
+  const unsigned l0 = r ? nl[4 * r - 1] + 1u : 0u;
+  const unsigned e0 = nl[4 * r], e1 = nl[4 * r + 1], e2 = nl[4 * r + 2], e3 = nl[4 * r + 3];
+  const bool bad = text[l0] != '@' || text[e1 + 1] != '+';
+  unsigned se = e1, qe = e3;
+  if (se > e0 + 1 && text[se - 1] == '\r') --se;
+  if (qe > e2 + 1 && text[qe - 1] == '\r') --qe;
+  seq_s[r] = (int32_t)(e0 + 1);
+  seq_e[r] = (int32_t)se;
+  qual_s[r] = (int32_t)(e2 + 1);
+  qual_e[r] = (int32_t)qe;
+  if (bad) atomicAdd(&scalars[1], 1u);
+}
+
+}  // namespace
+
+struct exon_hip_fastq_parser {
+  exon_hip_ctx* ctx = nullptr;
+  int64_t max_bytes = 0, max_lines = 0;
+  unsigned *d_block_counts = nullptr, *d_nl = nullptr, *d_scalars = nullptr;
+  int32_t* d_views = nullptr;  // 4 arrays of max_lines / 4 + 1
+  unsigned* h_scalars = nullptr;
+};
+
+extern "C" {
+
+int exon_hip_fastq_parser_create(exon_hip_ctx* ctx, int64_t max_bytes, exon_hip_fastq_parser** outp) {
+  if (!ctx || !outp || max_bytes < 16) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_fastq_parser_create: bad argument");
+  if (max_bytes > 0x7FFF0000LL) return fail(ctx, EXON_HIP_EINVAL, "slab size must stay below 2 GiB (32-bit views)");
+  *outp = nullptr;
+  exon_hip_fastq_parser* p = new (std::nothrow) exon_hip_fastq_parser();
+  if (!p) return fail(ctx, EXON_HIP_ENOMEM, "out of host memory");
+  p->ctx = ctx;
+  p->max_bytes = max_bytes;
+  p->max_lines = max_bytes / 4 + 8;  // records of >= 16 bytes; denser text is handed back to the host decoder
+  hipSetDevice(ctx->device);
+  const int64_t nblocks = (max_bytes + BYTES_PER_BLOCK - 1) / BYTES_PER_BLOCK;
+  const size_t per = (size_t)(p->max_lines / 4 + 1);
+  hipError_t e = hipMalloc((void**)&p->d_block_counts, (size_t)nblocks * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->d_nl, (size_t)p->max_lines * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->d_scalars, 16);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->d_views, per * 4 * 4);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&p->h_scalars, 16);
+  if (e != hipSuccess) {
+    const std::string msg = hipGetErrorString(e);
+    exon_hip_fastq_parser_destroy(p);
+    return fail(ctx, EXON_HIP_ENOMEM, "fastq parser allocation: %s", msg.c_str());
+  }
+  *outp = p;
+  return EXON_HIP_OK;
+}
+
+int exon_hip_fastq_parser_destroy(exon_hip_fastq_parser* p) {
+  if (!p) return EXON_HIP_OK;
+  if (p->d_block_counts) hipFree(p->d_block_counts);
+  if (p->d_nl) hipFree(p->d_nl);
+  if (p->d_scalars) hipFree(p->d_scalars);
+  if (p->d_views) hipFree(p->d_views);
+  if (p->h_scalars) hipHostFree(p->h_scalars);
+  delete p;
+  return EXON_HIP_OK;
+}
+
+int exon_hip_fastq_parser_parse(exon_hip_fastq_parser* p, void* stream, const uint8_t* d_text, int64_t n_bytes,
+                                int32_t final_slab, exon_hip_fastq_views* views) {
+  if (!p || !views || (n_bytes > 0 && !d_text)) return fail(p ? p->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_fastq_parser_parse: NULL argument");
+  exon_hip_ctx* ctx = p->ctx;
+  if (n_bytes > p->max_bytes) return fail(ctx, EXON_HIP_EINVAL, "slab of %lld bytes exceeds the parser's %lld", (long long)n_bytes, (long long)p->max_bytes);
+  if ((reinterpret_cast<uintptr_t>(d_text) & 15) != 0) return fail(ctx, EXON_HIP_EINVAL, "text must be 16-byte aligned");
+  memset(views, 0, sizeof *views);
+  if (n_bytes == 0) return EXON_HIP_OK;
+  hipStream_t s = pick_stream(ctx, stream);
+  const int nblocks = (int)((n_bytes + BYTES_PER_BLOCK - 1) / BYTES_PER_BLOCK);
+  const size_t per = (size_t)(p->max_lines / 4 + 1);
+  int32_t* v = p->d_views;
+  HIP_TRY(ctx, hipMemsetAsync(p->d_scalars, 0, 16, s));
+  hipLaunchKernelGGL(k_count_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, p->d_block_counts);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, p->d_block_counts, nblocks, p->d_scalars);
+  hipLaunchKernelGGL(k_fill_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, p->d_block_counts, p->d_nl, (unsigned)p->max_lines);
+  const int64_t read_bound = std::min<int64_t>((int64_t)per, n_bytes / 4 + 1);  // a record holds 4 newlines
+  hipLaunchKernelGGL(k_fastq_views, dim3((unsigned)((read_bound + TPB - 1) / TPB)), dim3(TPB), 0, s, d_text, p->d_nl, p->d_scalars,
+                     (unsigned)p->max_lines, (int)final_slab, v, v + per, v + 2 * per, v + 3 * per);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(p->h_scalars, p->d_scalars, 16, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  views->n_undecided = p->h_scalars[1];
+  views->n_reads = p->h_scalars[0] > (unsigned)p->max_lines ? 0 : p->h_scalars[0] / 4;
+  views->consumed_bytes = p->h_scalars[2];
+  views->seq_start = v;
+  views->seq_end = v + per;
+  views->qual_start = v + 2 * per;
+  views->qual_end = v + 3 * per;
+  return EXON_HIP_OK;
+}
+
+}  // extern "C"

@@ -761,6 +761,7 @@ class SAMBatchReader {
 struct FASTQConfig {
   int64_t batch_size = DEFAULT_BATCH_SIZE;  // sequential reader; the parallel reader emits one batch per ~4 MiB slab
   int threads = 0;
+  bool defer_decode = false;  // the text will be taken with take_stream (GPU-side record splitting)
 };
 
 class FASTQArrayBuilder : public ExonArrayBuilder {
@@ -826,7 +827,7 @@ class FASTQBatchReader {
     const long fsize = file_size(path);
     // whole 4-line records per slab; blank lines between records are not supported in the parallel path, so it is
     // only taken for inputs that start directly with a record
-    if (threads > 1 && fsize >= (8 << 20))
+    if (threads > 1 && fsize >= (8 << 20) && !cfg_.defer_decode)
       pipe_.reset(new SlabPipeline<FASTQSlab>(r_.release_source(), r_.take_buffered(), 4, threads,
                                               [](FASTQSlab& s, const void* c2) { parse_fastq_slab(s, c2); }, nullptr));
   }
@@ -855,6 +856,13 @@ class FASTQBatchReader {
     b.try_into_record_batch(out);
     return true;
   }
+  // the whole input as a raw byte stream (GPU-side record splitting); only valid before the first read_batch
+  std::unique_ptr<ByteSource> take_stream(std::string* carry) {
+    if (pipe_) return nullptr;
+    *carry = r_.take_buffered();
+    return r_.release_source();
+  }
+  const FASTQConfig& config() const { return cfg_; }
   void schema(struct ArrowSchema* out) const {
     make_schema(out, "+s", "", false,
                 {new_field("u", "name", false), new_field("u", "description", true), new_field("u", "sequence", false),

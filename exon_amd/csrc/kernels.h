@@ -38,6 +38,10 @@ hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Wo
 
 hipError_t launch_qual_pos_hist(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* offsets,
                                 const uint8_t* bytes, int64_t n_reads, int lmax, int64_t* d_hist);
+// reads given as independent [starts[r], ends[r]) views into `bytes` (e.g. the quality lines of raw FASTQ text)
+hipError_t launch_qual_pos_hist_views(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* starts,
+                                      const int32_t* ends, const uint8_t* bytes, int64_t n_reads, int lmax,
+                                      int64_t* d_hist);
 
 hipError_t launch_gen_c2(hipStream_t s, uint64_t seed, int64_t n_total, int64_t lo, int64_t hi, int32_t* chrom,
                          int64_t* pos);

@@ -676,13 +676,15 @@ constexpr int K5_PT_MAX = 310;  // positions kept in LDS by the [p][129] layout:
 constexpr int K5_JA = 16, K5_JB = 4;
 
 // flags[0] = 1 when read lengths differ (or a read is longer than lmax -> status bit 8)
-__global__ __launch_bounds__(256) void k5_scan_offsets(const int32_t* __restrict__ off, int64_t n, int lmax,
+// `off` / `ends`: start and end byte of every read.  An Arrow Utf8 column passes (offsets, offsets + 1); a view over
+// raw FASTQ text passes two separate arrays (reads are then not contiguous, which forces path G).
+__global__ __launch_bounds__(256) void k5_scan_offsets(const int32_t* __restrict__ off, const int32_t* __restrict__ ends, int64_t n, int lmax,
                                                       int* __restrict__ flags, int* __restrict__ status) {
-  const int L = off[1] - off[0];
+  const int L = ends[0] - off[0];
   bool ragged = false, too_long = false;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int len = off[i + 1] - off[i];
-    ragged |= (len != L);
+    const int len = ends[i] - off[i];
+    ragged |= (len != L) || (i + 1 < n && off[i + 1] != ends[i]);
     too_long |= (len > lmax);
   }
   if (__any(ragged) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1);
@@ -690,10 +692,10 @@ __global__ __launch_bounds__(256) void k5_scan_offsets(const int32_t* __restrict
 }
 
 enum { K5_PATH_A = 0, K5_PATH_B = 2, K5_PATH_G = 3 };
-__device__ __forceinline__ int k5_pick_path(const int32_t* off, const uint8_t* bytes, int lmax, int lp,
-                                            const int* flags) {
+__device__ __forceinline__ int k5_pick_path(const int32_t* off, const int32_t* ends, const uint8_t* bytes, int lmax,
+                                            int lp, const int* flags) {
   if (flags[0]) return K5_PATH_G;
-  const int L = off[1] - off[0];
+  const int L = ends[0] - off[0];
   if (L < 1 || L > lmax) return K5_PATH_G;
   const uintptr_t base = reinterpret_cast<uintptr_t>(bytes + off[0]);
   if ((L & 3) == 0 && L >= 64 && L <= lp && (base & 3) == 0) return K5_PATH_A;
@@ -702,33 +704,35 @@ __device__ __forceinline__ int k5_pick_path(const int32_t* off, const uint8_t* b
 }
 
 // partial record of a workgroup: u64 [pt][128] (position-major, ASCII half); bytes >= 128 never reach it
-__device__ void k5_path_b(const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes, int64_t n, int lmax,
-                          int pt, unsigned long long* __restrict__ partials, unsigned long long* __restrict__ d_hist);
+__device__ void k5_path_b(const int32_t* __restrict__ off, const int32_t* __restrict__ ends,
+                          const uint8_t* __restrict__ bytes, int64_t n, int lmax, int pt,
+                          unsigned long long* __restrict__ partials, unsigned long long* __restrict__ d_hist);
 template <int LP>
-__device__ void k5_path_ragged(const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes, int64_t n, int lmax,
-                               int pt, unsigned long long* __restrict__ partials,
-                               unsigned long long* __restrict__ d_hist);
+__device__ void k5_path_ragged(const int32_t* __restrict__ off, const int32_t* __restrict__ ends,
+                               const uint8_t* __restrict__ bytes, int64_t n, int lmax, int pt,
+                               unsigned long long* __restrict__ partials, unsigned long long* __restrict__ d_hist);
 
 // One launch per batch: path A in place, paths B / G through k5_paths_bg (same workgroup shape, same LDS block).
 template <int LP>
-__global__ __launch_bounds__(K5_THREADS) void k5_main(const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes,
-                                                      int64_t n, int lmax, int pt, const int* __restrict__ flags,
+__global__ __launch_bounds__(K5_THREADS) void k5_main(const int32_t* __restrict__ off, const int32_t* __restrict__ ends,
+                                                      const uint8_t* __restrict__ bytes, int64_t n, int lmax, int pt,
+                                                      const int* __restrict__ flags,
                                                       unsigned long long* __restrict__ partials,
                                                       unsigned long long* __restrict__ d_hist) {
-  const int path = k5_pick_path(off, bytes, lmax, LP, flags);
+  const int path = k5_pick_path(off, ends, bytes, lmax, LP, flags);
   if (path == K5_PATH_B) {
-    k5_path_b(off, bytes, n, lmax, pt, partials, d_hist);
+    k5_path_b(off, ends, bytes, n, lmax, pt, partials, d_hist);
     return;
   }
   if (path == K5_PATH_G) {
-    k5_path_ragged<LP>(off, bytes, n, lmax, pt, partials, d_hist);
+    k5_path_ragged<LP>(off, ends, bytes, n, lmax, pt, partials, d_hist);
     return;
   }
   extern __shared__ unsigned k5_h[];  // [128][LP]
   constexpr int Q = LP / 4, J = K5_JA;
   for (int i = threadIdx.x; i < 128 * LP; i += K5_THREADS) k5_h[i] = 0;
   __syncthreads();
-  const int L = off[1] - off[0];
+  const int L = ends[0] - off[0];
   const unsigned* src = reinterpret_cast<const unsigned*>(bytes + off[0]);
   const int64_t nd = n * (int64_t)(L / 4), S = (int64_t)gridDim.x * K5_THREADS;
   const int64_t c0 = (int64_t)blockIdx.x * K5_THREADS + threadIdx.x;
@@ -774,8 +778,9 @@ __global__ __launch_bounds__(K5_THREADS) void k5_main(const int32_t* __restrict_
   }
 }
 
-__device__ void k5_path_b(const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes, int64_t n, int lmax,
-                          int pt, unsigned long long* __restrict__ partials, unsigned long long* __restrict__ d_hist) {
+__device__ void k5_path_b(const int32_t* __restrict__ off, const int32_t* __restrict__ ends,
+                          const uint8_t* __restrict__ bytes, int64_t n, int lmax, int pt,
+                          unsigned long long* __restrict__ partials, unsigned long long* __restrict__ d_hist) {
   extern __shared__ unsigned k5_h[];  // [pt][129]
   for (int i = threadIdx.x; i < pt * 129; i += K5_THREADS) k5_h[i] = 0;
   __syncthreads();
@@ -785,7 +790,7 @@ __device__ void k5_path_b(const int32_t* __restrict__ off, const uint8_t* __rest
   };
   {  // uniform read length: 16-byte chunk per lane
     constexpr int J = K5_JB;
-    const int L = off[1] - off[0];
+    const int L = ends[0] - off[0];
     const uint8_t* src = bytes + off[0];
     const int64_t total = n * (int64_t)L, nch = total / 16, S = (int64_t)gridDim.x * K5_THREADS;
     const int64_t c0 = (int64_t)blockIdx.x * K5_THREADS + threadIdx.x;
@@ -834,8 +839,9 @@ __device__ void k5_path_b(const int32_t* __restrict__ off, const uint8_t* __rest
 // lane groups, so their equal positions never conflict) and the inner loop is branch-free: bytes past the end of
 // a read add to a per-lane dummy word, every load is unconditional.  Longer reads fall back to h[p][129].
 template <int LP, bool BM>
-__device__ void k5_path_ragged_impl(const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes, int64_t n,
-                                    int lmax, int pt, unsigned long long* __restrict__ partials,
+__device__ void k5_path_ragged_impl(const int32_t* __restrict__ off, const int32_t* __restrict__ ends,
+                                    const uint8_t* __restrict__ bytes, int64_t n, int lmax, int pt,
+                                    unsigned long long* __restrict__ partials,
                                     unsigned long long* __restrict__ d_hist) {
   extern __shared__ unsigned k5_h[];
   constexpr int Q = LP / 4, J = 8;
@@ -890,7 +896,7 @@ __device__ void k5_path_ragged_impl(const int32_t* __restrict__ off, const uint8
     for (int j = 0; j < J; ++j) {  // offsets: unconditional loads (index clamped), length zeroed past the end
       const int64_t rr = r0 + (int64_t)j * nhw;
       const int64_t rc = rr < n ? rr : n - 1;
-      const int32_t a = off[rc], b = off[rc + 1];
+      const int32_t a = off[rc], b = ends[rc];
       o0[j] = a;
       len[j] = rr < n ? min(b - a, lmax) : 0;  // reads longer than lmax are flagged by k5_scan_offsets
     }
@@ -920,11 +926,11 @@ __device__ void k5_path_ragged_impl(const int32_t* __restrict__ off, const uint8
 }
 
 template <int LP>
-__device__ void k5_path_ragged(const int32_t* __restrict__ off, const uint8_t* __restrict__ bytes, int64_t n, int lmax,
-                               int pt, unsigned long long* __restrict__ partials,
-                               unsigned long long* __restrict__ d_hist) {
-  if (lmax <= LP) k5_path_ragged_impl<LP, true>(off, bytes, n, lmax, pt, partials, d_hist);
-  else k5_path_ragged_impl<LP, false>(off, bytes, n, lmax, pt, partials, d_hist);
+__device__ void k5_path_ragged(const int32_t* __restrict__ off, const int32_t* __restrict__ ends,
+                               const uint8_t* __restrict__ bytes, int64_t n, int lmax, int pt,
+                               unsigned long long* __restrict__ partials, unsigned long long* __restrict__ d_hist) {
+  if (lmax <= LP) k5_path_ragged_impl<LP, true>(off, ends, bytes, n, lmax, pt, partials, d_hist);
+  else k5_path_ragged_impl<LP, false>(off, ends, bytes, n, lmax, pt, partials, d_hist);
 }
 
 // d_hist[p][b] += sum over workgroups of partial[wg][p][b]  (p < pt, b < 128).  blockIdx.y splits the workgroup
@@ -954,6 +960,12 @@ size_t k5_partial_words(const LaunchCfg& cfg, int lmax) { return (size_t)cfg.com
 
 hipError_t launch_qual_pos_hist(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* offsets,
                                 const uint8_t* bytes, int64_t n_reads, int lmax, int64_t* d_hist) {
+  return launch_qual_pos_hist_views(s, cfg, ws, offsets, offsets + 1, bytes, n_reads, lmax, d_hist);
+}
+
+hipError_t launch_qual_pos_hist_views(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* offsets,
+                                      const int32_t* ends, const uint8_t* bytes, int64_t n_reads, int lmax,
+                                      int64_t* d_hist) {
   if (n_reads <= 0) return hipSuccess;
   if (lmax < 1) return hipErrorInvalidValue;
   const int pt = k5_pt(lmax);
@@ -963,7 +975,7 @@ hipError_t launch_qual_pos_hist(hipStream_t s, const LaunchCfg& cfg, const Works
   hipError_t e = hipMemsetAsync(flags, 0, sizeof(int), s);
   if (e != hipSuccess) return e;
   int sgrid = (int)std::min<int64_t>((n_reads + 255) / 256, (int64_t)cfg.compute_units * 8);
-  hipLaunchKernelGGL(k5_scan_offsets, dim3(sgrid), dim3(256), 0, s, offsets, n_reads, lmax, flags, ws.status);
+  hipLaunchKernelGGL(k5_scan_offsets, dim3(sgrid), dim3(256), 0, s, offsets, ends, n_reads, lmax, flags, ws.status);
   // LDS block: the larger of the byte-major [128][LP] layout (paths A and G) and the [pt][129] layout (B, long G)
   const bool lp256 = lmax > 128;
   const size_t lds = std::max<size_t>((size_t)128 * (lp256 ? 256 : 128) * 4 + 256, (size_t)pt * 129 * 4);
@@ -976,8 +988,8 @@ hipError_t launch_qual_pos_hist(hipStream_t s, const LaunchCfg& cfg, const Works
     if ((e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_main<256>), hipFuncAttributeMaxDynamicSharedMemorySize, cap)) != hipSuccess) attr_err = e2;
   });
   if (attr_err != hipSuccess) return attr_err;
-  if (lp256) hipLaunchKernelGGL(k5_main<256>, dim3(grid), dim3(K5_THREADS), lds, s, offsets, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
-  else hipLaunchKernelGGL(k5_main<128>, dim3(grid), dim3(K5_THREADS), lds, s, offsets, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
+  if (lp256) hipLaunchKernelGGL(k5_main<256>, dim3(grid), dim3(K5_THREADS), lds, s, offsets, ends, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
+  else hipLaunchKernelGGL(k5_main<128>, dim3(grid), dim3(K5_THREADS), lds, s, offsets, ends, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k5_finalize, dim3((pt * 128 + 255) / 256, 8), dim3(256), 0, s, ws.partials, grid, pt, hist);

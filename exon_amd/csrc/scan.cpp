@@ -23,6 +23,7 @@ struct exon_hip_scan {
   std::string info_field_s, region_s;
   exon_hip_vcf_parser* parser = nullptr;  // created by the first GPU-parsed consume; owns the FILTER dictionary
   exon_hip_ctx* parser_ctx = nullptr;
+  exon_hip_fastq_parser* fq_parser = nullptr;
   exon::Dictionary gpu_filter_dict;       // names fetched from the parser after the consume
   std::unique_ptr<exon::VCFBatchReader> vcf;
   std::unique_ptr<exon::BAMBatchReader> bam;
@@ -36,6 +37,7 @@ struct exon_hip_scan {
 
 int exon_hip_stream_push_raw(exon_hip_stream* st, const exon::RawBatch& rb);  // stream.cpp
 int exon_hip_stream_launch_scan_columns(exon_hip_stream* st, const exon_hip_column* scan_cols, int n_scan_cols, int64_t n);
+int exon_hip_stream_launch_views(exon_hip_stream* st, const uint8_t* d_text, const exon_hip_fastq_views& v);
 void* exon_hip_stream_hip_stream(exon_hip_stream* st);
 exon_hip_ctx* exon_hip_stream_ctx(exon_hip_stream* st);
 int exon_hip_stream_state_copy(exon_hip_stream* st, void* d_snapshot, bool restore);
@@ -113,6 +115,8 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
       case EXON_HIP_FORMAT_FASTQ: {
         exon::FASTQConfig cfg;
         cfg.batch_size = bs;
+        s->gpu_parse = o->gpu_parse != 0;
+        cfg.defer_decode = s->gpu_parse;
         s->fastq.reset(new exon::FASTQBatchReader(path, c, cfg));
         break;
       }
@@ -232,11 +236,68 @@ int exon_hip_index_query(const char* index_path, int32_t is_bai, const char* ref
 
 int exon_hip_scan_close(exon_hip_scan* s) {
   if (s && s->parser) exon_hip_vcf_parser_destroy(s->parser);
+  if (s && s->fq_parser) exon_hip_fastq_parser_destroy(s->fq_parser);
   delete s;
   return EXON_HIP_OK;
 }
 
 }  // extern "C"
+
+// plain files are read with positional reads from several threads (one fread stream tops out near 6 GB/s);
+// compressed inputs go through the (block-parallel) inflating source
+struct SlabReader {
+  explicit SlabReader(exon::ByteSource* s) : src(s) { plain = src->plain_file(&fd, &foff); }
+  size_t read(uint8_t* dst, size_t n) {
+    if (!plain) {
+      size_t have = 0;
+      while (have < n) {
+        const size_t got = src->read(dst + have, n - have);
+        if (got == 0) break;
+        have += got;
+      }
+      return have;
+    }
+    const int T = 8;
+    const size_t per = (n + T - 1) / T;
+    size_t got[T] = {0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) {
+      const size_t o = (size_t)t * per;
+      if (o >= n) break;
+      const size_t len = std::min(per, n - o);
+      th.emplace_back([this, &got, dst, t, o, len] {
+        size_t done = 0;
+        while (done < len) {
+          const ssize_t r = pread(fd, dst + o + done, len - done, (off_t)(foff + (int64_t)(o + done)));
+          if (r <= 0) break;
+          done += (size_t)r;
+        }
+        got[t] = done;
+      });
+    }
+    for (auto& x : th) x.join();
+    size_t total = 0;
+    for (int t = 0; t < T; ++t) {
+      total += got[t];
+      if (got[t] < std::min(per, n > (size_t)t * per ? n - (size_t)t * per : 0)) break;  // EOF inside this chunk
+    }
+    foff += (int64_t)total;
+    return total;
+  }
+  exon::ByteSource* src;
+  bool plain = false;
+  int fd = -1;
+  int64_t foff = 0;
+};
+
+static size_t slab_bytes() {
+  size_t slab = 64u << 20;
+  if (const char* v = getenv("EXON_HIP_GPU_PARSE_SLAB_MB")) {
+    const long mb = atol(v);
+    if (mb >= 1 && mb <= 1024) slab = (size_t)mb << 20;
+  }
+  return slab;
+}
 
 // file -> pinned slab -> HBM -> GPU parser -> fused kernel.  A background thread fills the next pinned slab while
 // the current one is copied and parsed.  Returns 1 when a slab held rows the device could not decide: the caller
@@ -247,11 +308,7 @@ static int consume_vcf_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* ro
   std::string carry;
   std::unique_ptr<exon::ByteSource> src = scan->vcf->take_stream(&carry);
   if (!src) return fail(ctx, EXON_HIP_ESTATE, "scan already consumed");
-  size_t slab = 64u << 20;
-  if (const char* v = getenv("EXON_HIP_GPU_PARSE_SLAB_MB")) {
-    const long mb = atol(v);
-    if (mb >= 1 && mb <= 2048) slab = (size_t)mb << 20;
-  }
+  const size_t slab = slab_bytes();
   if (!scan->parser) {
     std::vector<const char*> names;
     for (const auto& c : scan->vcf->header.contigs) names.push_back(c.c_str());
@@ -275,39 +332,8 @@ static int consume_vcf_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* ro
       cleanup();
       return fail(ctx, EXON_HIP_ENOMEM, "slab buffers (%zu bytes) could not be allocated", cap);
     }
-  // plain files are read with positional reads from several threads (one fread stream tops out near 6 GB/s)
-  int fd = -1;
-  int64_t foff = 0;
-  const bool plain = src->plain_file(&fd, &foff);
-  auto read_some = [&](uint8_t* dst, size_t n) -> size_t {
-    if (!plain) return src->read(dst, n);
-    const int T = 8;
-    const size_t per = (n + T - 1) / T;
-    size_t got[T] = {0};
-    std::vector<std::thread> th;
-    for (int t = 0; t < T; ++t) {
-      const size_t o = (size_t)t * per;
-      if (o >= n) break;
-      const size_t len = std::min(per, n - o);
-      th.emplace_back([&, t, o, len] {
-        size_t done = 0;
-        while (done < len) {
-          const ssize_t r = pread(fd, dst + o + done, len - done, (off_t)(foff + (int64_t)(o + done)));
-          if (r <= 0) break;
-          done += (size_t)r;
-        }
-        got[t] = done;
-      });
-    }
-    for (auto& x : th) x.join();
-    size_t total = 0;
-    for (int t = 0; t < T; ++t) {
-      total += got[t];
-      if (got[t] < std::min(per, n > (size_t)t * per ? n - (size_t)t * per : 0)) break;  // EOF inside this chunk
-    }
-    foff += (int64_t)total;
-    return total;
-  };
+  SlabReader rd(src.get());
+  auto read_some = [&](uint8_t* dst, size_t n) -> size_t { return rd.read(dst, n); };
   // reader: fills h_buf[k] with [carry | fresh bytes], cuts at the last newline, keeps the tail as the next carry
   struct Filled { size_t n = 0; bool eof = false; std::exception_ptr err; };
   auto fill = [&](int k, Filled* f) {
@@ -401,11 +427,129 @@ static int consume_vcf_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* ro
   return rc;
 }
 
+
+// FASTQ: file -> pinned slab -> HBM -> newline index + per-read views -> K5 over the views (no columns are built).
+// The device reports where the last whole record of a slab ends; the tail is carried in front of the next slab, which
+// the reader thread has meanwhile filled behind a reserved gap.  Returns 1 for "decode on the host instead".
+static int consume_fastq_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* rows_out) {
+  exon_hip_ctx* ctx = exon_hip_stream_ctx(st);
+  hipStream_t hs = (hipStream_t)exon_hip_stream_hip_stream(st);
+  std::string carry;
+  std::unique_ptr<exon::ByteSource> src = scan->fastq->take_stream(&carry);
+  if (!src) return fail(ctx, EXON_HIP_ESTATE, "scan already consumed");
+  const size_t slab = slab_bytes();
+  const size_t gap = std::max<size_t>(slab / 4, 1u << 20);  // room for the carried tail (< 1 record + 1 line)
+  const size_t cap = gap + slab + 64;
+  if (!scan->fq_parser) {
+    int rc = exon_hip_fastq_parser_create(ctx, (int64_t)cap, &scan->fq_parser);
+    if (rc) return rc;
+  }
+  uint8_t* h_buf[2] = {nullptr, nullptr};
+  uint8_t* d_buf[2] = {nullptr, nullptr};
+  auto cleanup = [&]() {
+    for (int k = 0; k < 2; ++k) {
+      if (h_buf[k]) hipHostFree(h_buf[k]);
+      if (d_buf[k]) hipFree(d_buf[k]);
+    }
+  };
+  for (int k = 0; k < 2; ++k)
+    if (hipHostMalloc((void**)&h_buf[k], cap) != hipSuccess || hipMalloc((void**)&d_buf[k], cap + 64) != hipSuccess) {
+      cleanup();
+      return fail(ctx, EXON_HIP_ENOMEM, "slab buffers (%zu bytes) could not be allocated", cap);
+    }
+  SlabReader rd(src.get());
+  struct Filled { size_t n = 0; bool eof = false; std::exception_ptr err; };
+  auto fill = [&](int k, Filled* f) {  // fresh bytes behind the gap
+    try {
+      f->n = rd.read(h_buf[k] + gap, slab);
+      f->eof = f->n < slab;
+    } catch (...) {
+      f->err = std::current_exception();
+    }
+  };
+  int64_t total = 0;
+  int rc = EXON_HIP_OK;
+  Filled cur, nxt;
+  fill(0, &cur);
+  int k = 0;
+  while (rc == EXON_HIP_OK) {
+    if (cur.err) {
+      try { std::rethrow_exception(cur.err); } catch (const std::exception& e) { rc = fail(ctx, EXON_HIP_EINVAL, "%s", e.what()); }
+      break;
+    }
+    if (carry.size() > gap) { rc = 1; break; }  // a record larger than the gap: host decoder
+    uint8_t* base = h_buf[k] + gap - carry.size();
+    memcpy(base, carry.data(), carry.size());
+    size_t n = carry.size() + cur.n;
+    carry.clear();
+    if (cur.eof && n > 0 && base[n - 1] != '\n') base[n++] = '\n';  // last line without a terminator
+    std::thread reader;
+    const bool more = !cur.eof;
+    if (more) reader = std::thread([&, k] { fill(k ^ 1, &nxt); });  // overlaps with the copy + index + histogram
+    if (n > 0) {
+      hipError_t e = hipMemcpyAsync(d_buf[k], base, n, hipMemcpyHostToDevice, hs);
+      if (e != hipSuccess) rc = fail(ctx, EXON_HIP_EDEVICE, "H2D of a text slab: %s", hipGetErrorString(e));
+      exon_hip_fastq_views v;
+      if (!rc) rc = exon_hip_fastq_parser_parse(scan->fq_parser, hs, d_buf[k], (int64_t)n, more ? 0 : 1, &v);
+      if (!rc && v.n_undecided > 0) rc = 1;
+      if (!rc && more && v.consumed_bytes == 0) rc = 1;  // not one whole record in a slab
+      if (!rc) {
+        carry.assign(reinterpret_cast<const char*>(base) + v.consumed_bytes, n - (size_t)v.consumed_bytes);
+        if (!more && !carry.empty()) rc = 1;
+      }
+      if (!rc && v.n_reads > 0) {
+        rc = exon_hip_stream_launch_views(st, d_buf[k], v);  // asynchronous: overlaps with preparing the next slab
+        total += v.n_reads;
+      }
+    }
+    if (reader.joinable()) reader.join();
+    if (!more) break;
+    cur = nxt;
+    nxt = Filled();
+    k ^= 1;
+  }
+  if (hipStreamSynchronize(hs) != hipSuccess && rc == EXON_HIP_OK) rc = fail(ctx, EXON_HIP_EDEVICE, "stream synchronize failed");
+  cleanup();
+  if (rc == EXON_HIP_OK) {
+    scan->rows += total;
+    if (rows_out) *rows_out = total;
+  }
+  return rc;
+}
+
 extern "C" {
 
 int exon_hip_stream_consume_scan(exon_hip_stream* st, exon_hip_scan* scan, int64_t* rows) {
   if (!st || !scan) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_stream_consume_scan: NULL argument");
   int64_t n = 0;
+  if (scan->gpu_parse && scan->fastq) {
+    exon_hip_ctx* ctx = exon_hip_stream_ctx(st);
+    void* snap = nullptr;
+    const size_t sb = exon_hip_stream_state_bytes(st);
+    if (hipMalloc(&snap, sb ? sb : 16) != hipSuccess) return fail(ctx, EXON_HIP_ENOMEM, "state snapshot allocation failed");
+    int rc = exon_hip_stream_state_copy(st, snap, false);
+    if (!rc) rc = consume_fastq_gpu(st, scan, rows);
+    if (rc == 1) {  // restore and re-decode on the host
+      rc = exon_hip_stream_state_copy(st, snap, true);
+      hipStreamSynchronize((hipStream_t)exon_hip_stream_hip_stream(st));
+      hipFree(snap);
+      if (rc) return rc;
+      scan->gpu_parse = false;
+      try {
+        exon::FASTQConfig cfg = scan->fastq->config();
+        cfg.defer_decode = false;
+        const exon::Compression c = scan->opt.compression == EXON_HIP_COMPRESSION_GZIP   ? exon::Compression::Gzip
+                                    : scan->opt.compression == EXON_HIP_COMPRESSION_NONE ? exon::Compression::None
+                                                                                         : exon::Compression::Auto;
+        scan->fastq.reset(new exon::FASTQBatchReader(scan->path, c, cfg));
+      } catch (const std::exception& e) {
+        return fail(nullptr, EXON_HIP_EINVAL, "%s", e.what());
+      }
+    } else {
+      hipFree(snap);
+      return rc;
+    }
+  }
   if (scan->gpu_parse && scan->vcf) {
     // speculative GPU decode; on undecidable rows restore the state and fall back to the host decoder
     exon_hip_ctx* ctx = exon_hip_stream_ctx(st);

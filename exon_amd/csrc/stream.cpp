@@ -414,6 +414,21 @@ int exon_hip_stream_launch_scan_columns(exon_hip_stream* st, const exon_hip_colu
   if (!rc) st->rows_pushed += n;
   return rc;
 }
+// K5 over views into text resident in HBM (FASTQ slabs): scan column 2 = sequence lines, 3 = quality lines
+int exon_hip_stream_launch_views(exon_hip_stream* st, const uint8_t* d_text, const exon_hip_fastq_views& v) {
+  exon_hip_plan* p = st->plan;
+  if (st->closed) return fail(st->ctx, EXON_HIP_ESTATE, "push after finish/close");
+  if (p->d.kind != EXON_HIP_PLAN_QUAL_POS_HIST) return fail(st->ctx, EXON_HIP_EUNSUPPORTED, "GPU-side FASTQ splitting serves the per-position histogram plan only");
+  const int idx = p->d.columns[0];
+  if (idx != 2 && idx != 3) return fail(st->ctx, EXON_HIP_EINVAL, "plan needs scan column %d; FASTQ views exist for 2 (sequence) and 3 (quality_scores)", idx);
+  int rc = flush_slot(st);
+  if (rc) return rc;
+  rc = exon_hip_qual_pos_hist_views(st->ctx, st->stream, d_text, idx == 2 ? v.seq_start : v.qual_start,
+                                    idx == 2 ? v.seq_end : v.qual_end, v.n_reads, p->d.lmax,
+                                    reinterpret_cast<int64_t*>(st->d_state));
+  if (!rc) st->rows_pushed += v.n_reads;
+  return rc;
+}
 void* exon_hip_stream_hip_stream(exon_hip_stream* st) { return (void*)st->stream; }
 exon_hip_ctx* exon_hip_stream_ctx(exon_hip_stream* st) { return st->ctx; }
 int exon_hip_stream_state_copy(exon_hip_stream* st, void* d_snapshot, bool restore) {

@@ -137,6 +137,12 @@ class Context:
         c0 = _col(data, None, offsets, n_reads)
         self._check(self.lib.exon_hip_qual_pos_hist(self.h, stream, C.byref(c0), n_reads, lmax, d_hist.ptr))
 
+    def qual_pos_hist_views(self, d_text, starts, ends, n_reads, lmax, d_hist, stream=None):
+        """K5 over [starts[r], ends[r]) views into `d_text` (device pointers / DeviceBuffers)."""
+        ptr = lambda x: x.ptr if isinstance(x, DeviceBuffer) else x  # noqa: E731
+        self._check(self.lib.exon_hip_qual_pos_hist_views(self.h, stream, ptr(d_text), ptr(starts), ptr(ends), n_reads, lmax,
+                                                          d_hist.ptr))
+
     # -- synthetic inputs in HBM ------------------------------------------------------------------
     def gen_c2(self, seed, n_total, lo=0, hi=None, stream=None):
         hi = n_total if hi is None else hi
@@ -366,6 +372,45 @@ class VCFParser:
     def close(self):
         if self.h:
             self.ctx.lib.exon_hip_vcf_parser_destroy(self.h)
+            self.h = None
+
+
+class FASTQParser:
+    """FASTQ record splitting on the GPU (exon_hip_fastq_parser_*): text slab in HBM -> per-read views into it."""
+
+    def __init__(self, ctx, max_slab_bytes=64 << 20):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._check(ctx.lib.exon_hip_fastq_parser_create(ctx.h, max_slab_bytes, C.byref(h)))
+        self.h = h
+
+    def parse_device(self, d_text, n_bytes, final=True, stream=None):
+        v = L.FASTQViews()
+        ptr = d_text.ptr if isinstance(d_text, DeviceBuffer) else int(d_text)
+        self.ctx._check(self.ctx.lib.exon_hip_fastq_parser_parse(self.h, stream, ptr, n_bytes, 1 if final else 0, C.byref(v)))
+        return v
+
+    def parse_host(self, text, final=True):
+        """Test helper: copy `text` to HBM, split it, bring the views back as numpy arrays (the text stays in
+        the returned DeviceBuffer for exon_hip_qual_pos_hist_views)."""
+        buf = np.frombuffer(text, np.uint8)
+        d = self.ctx.to_device(np.concatenate([buf, np.zeros(64, np.uint8)]))
+        v = self.parse_device(d, len(buf), final)
+        n = v.n_reads
+
+        def get(ptr):
+            out = np.empty(n, np.int32)
+            if n:
+                self.ctx._check(self.ctx.lib.exon_hip_memcpy_d2h(self.ctx.h, _np_ptr(out), ptr, out.nbytes, None))
+            return out
+
+        return {"n_reads": n, "n_undecided": v.n_undecided, "consumed_bytes": v.consumed_bytes, "views": v, "d_text": d,
+                "seq_start": get(v.seq_start), "seq_end": get(v.seq_end), "qual_start": get(v.qual_start),
+                "qual_end": get(v.qual_end)}
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.exon_hip_fastq_parser_destroy(self.h)
             self.h = None
 
 

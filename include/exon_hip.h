@@ -184,6 +184,12 @@ int exon_hip_cmp_avg_by_group(exon_hip_ctx* ctx, void* stream, const exon_hip_co
 int exon_hip_qual_pos_hist(exon_hip_ctx* ctx, void* stream, const exon_hip_column* quality_scores /*utf8*/,
                            int64_t n_reads, int32_t lmax, int64_t* d_hist /*[lmax*256]*/);
 
+/* K5 over independent views: read r is bytes[starts[r] .. ends[r]) of `d_bytes` (all device pointers).  Used for
+ * the quality (or sequence) lines of raw FASTQ text resident in HBM (exon_hip_fastq_parser_parse): no Arrow
+ * column is materialised. */
+int exon_hip_qual_pos_hist_views(exon_hip_ctx* ctx, void* stream, const uint8_t* d_bytes, const int32_t* d_starts,
+                                 const int32_t* d_ends, int64_t n_reads, int32_t lmax, int64_t* d_hist /*[lmax*256]*/);
+
 /* ---- synthetic inputs generated in HBM (DESIGN.md "Synthetic inputs"; bit-identical to the
  *      oracle's generators, which the parity tests check) ------------------------------------- */
 int exon_hip_gen_c2(exon_hip_ctx* ctx, void* stream, uint64_t seed, int64_t n_total, int64_t lo, int64_t hi,
@@ -283,8 +289,9 @@ typedef struct exon_hip_scan_options {
   const char* info_field; /* VCF: typed INFO field to extract (exon.vcf_parse_info), NULL = none */
   const char* region;     /* pushed-down vcf_region_filter / bam_region_filter ("chr1:1-100"), NULL = none */
   int32_t use_index;      /* with `region`: plan BGZF chunks from <path>.tbi / <path>.bai (INDEXED_VCF / INDEXED_BAM) */
-  int32_t gpu_parse;      /* VCF: exon_hip_stream_consume_scan ships the TEXT to HBM and parses it on the GPU
-                             (exon_hip_vcf_parser_*); exon_hip_scan_next is then not available on this scan */
+  int32_t gpu_parse;      /* VCF, FASTQ: exon_hip_stream_consume_scan ships the TEXT to HBM and parses it on the GPU
+                             (exon_hip_vcf_parser_* / exon_hip_fastq_parser_*); exon_hip_scan_next is then not
+                             available on this scan */
 } exon_hip_scan_options;
 
 int exon_hip_scan_open(const char* path, const exon_hip_scan_options* options, exon_hip_scan** out);
@@ -331,6 +338,29 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* parser, void* stream, const u
 /* FILTER dictionary discovered so far, '\0'-separated in id order ("" = the empty list) */
 int exon_hip_vcf_parser_filters(exon_hip_vcf_parser* parser, char* buf, size_t cap, int32_t* n_filters);
 int exon_hip_vcf_parser_destroy(exon_hip_vcf_parser* parser);
+
+/* ---- FASTQ record splitting on the GPU (raw text in HBM -> per-read views into that text) ---------------------
+ * Record rules of exon-fastq/src/batch_reader.rs:63-82 (noodles fastq: '@' definition line, sequence line, '+'
+ * line, quality line; "\r\n" accepted).  The slab may end anywhere: consumed_bytes tells how many bytes form
+ * whole records, the rest is carried into the next slab by the caller.  n_undecided != 0 (a record not starting
+ * with '@', a missing '+' line, more lines than the parser was sized for, a partial record in the final slab):
+ * decode that input on the host instead. */
+typedef struct exon_hip_fastq_parser exon_hip_fastq_parser;
+typedef struct exon_hip_fastq_views {
+  int64_t n_reads;
+  int64_t n_undecided;
+  int64_t consumed_bytes;
+  const int32_t* seq_start; /* device pointers owned by the parser, overwritten by the next parse call */
+  const int32_t* seq_end;
+  const int32_t* qual_start;
+  const int32_t* qual_end;
+} exon_hip_fastq_views;
+int exon_hip_fastq_parser_create(exon_hip_ctx* ctx, int64_t max_slab_bytes, exon_hip_fastq_parser** out);
+/* d_text: 16-byte aligned, < 2 GiB.  final_slab != 0: the text ends the input (it must end with '\n').
+ * Synchronises `stream`. */
+int exon_hip_fastq_parser_parse(exon_hip_fastq_parser* parser, void* stream, const uint8_t* d_text, int64_t n_bytes,
+                                int32_t final_slab, exon_hip_fastq_views* views);
+int exon_hip_fastq_parser_destroy(exon_hip_fastq_parser* parser);
 
 /* GpuFilterAggExec::execute in one call: pull every batch of `scan` and push it through `stream`. */
 int exon_hip_stream_consume_scan(exon_hip_stream* s, exon_hip_scan* scan, int64_t* rows);
