@@ -189,13 +189,20 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # one process per GPU.  EXON_BENCH_SHARE_GPU=1 is a test hook for 1-GPU boxes: all ranks share cuda:0 and the
+    # collective runs over gloo (RCCL refuses two ranks on one device); it exercises the launcher path, not xGMI.
+    share = os.environ.get("EXON_BENCH_SHARE_GPU") == "1"
+    device = 0 if share else local_rank
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
 
     import exon_amd
-    ctx = exon_amd.Context(local_rank)
+    ctx = exon_amd.Context(device)
     # kernels, state zeroing, events and collectives all go on ONE explicit (non-default) HIP stream
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
@@ -209,6 +216,8 @@ def main():
         wl.launch()
         all_reduce_state(wl.counts, wl.sums)  # AggregateExec(Final) across GPUs: RCCL all-reduce over xGMI
 
+    if world > 1:  # bring the communicator up outside the timed region even with --warmup 0
+        dist.all_reduce(torch.zeros(1, dtype=torch.int64, device="cuda"))
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
