@@ -72,6 +72,11 @@ class PlanDesc(C.Structure):
     ]
 
 
+class BgzfBlock(C.Structure):
+    _fields_ = [("comp_offset", C.c_uint32), ("comp_size", C.c_uint32), ("out_offset", C.c_uint32), ("out_size", C.c_uint32),
+                ("crc32", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class FASTQViews(C.Structure):
     _fields_ = [("n_reads", C.c_int64), ("n_undecided", C.c_int64), ("consumed_bytes", C.c_int64),
                 ("seq_start", C.c_void_p), ("seq_end", C.c_void_p), ("qual_start", C.c_void_p), ("qual_end", C.c_void_p)]
@@ -80,7 +85,7 @@ class FASTQViews(C.Structure):
 class VCFColumns(C.Structure):
     _fields_ = [("n_rows", C.c_int64), ("n_undecided", C.c_int64), ("chrom_id", C.c_void_p), ("pos", C.c_void_p),
                 ("pos_valid", C.c_void_p), ("qual", C.c_void_p), ("qual_valid", C.c_void_p), ("filter_id", C.c_void_p),
-                ("info", C.c_void_p), ("info_valid", C.c_void_p)]
+                ("info", C.c_void_p), ("info_valid", C.c_void_p), ("consumed_bytes", C.c_int64)]
 
 
 class ScanOptions(C.Structure):
@@ -158,6 +163,9 @@ SIGNATURES = {
     "exon_hip_fastq_parser_create": (C.c_int, [_vp, _i64, C.POINTER(_vp)]),
     "exon_hip_fastq_parser_parse": (C.c_int, [_vp, _vp, _vp, _i64, _i32, C.POINTER(FASTQViews)]),
     "exon_hip_fastq_parser_destroy": (C.c_int, [_vp]),
+    "exon_hip_bgzf_scan": (C.c_int, [_vp, C.c_size_t, C.c_size_t, C.POINTER(BgzfBlock), _i32, C.POINTER(_i32),
+                                     C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "exon_hip_bgzf_inflate": (C.c_int, [_vp, _vp, _vp, C.POINTER(BgzfBlock), _i32, _vp, _i32, C.POINTER(_i32)]),
 }
 
 

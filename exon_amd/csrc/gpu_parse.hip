@@ -130,6 +130,12 @@ __global__ __launch_bounds__(TPB) void k_fill_newlines(const uint8_t* __restrict
   }
 }
 
+// scalars[2] = bytes up to and including the last newline (what a caller may discard after this slab)
+__global__ void k_last_newline(const unsigned* __restrict__ nl_pos, unsigned* __restrict__ scalars, unsigned cap) {
+  const unsigned n = scalars[0];
+  scalars[2] = (n && n <= cap) ? nl_pos[n - 1] + 1u : 0u;
+}
+
 struct NameTable {  // open-addressing table of strings (contigs): hash -> id, text verified
   const uint64_t* keys;
   const int32_t* ids;
@@ -482,6 +488,7 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* p, void* stream, const uint8_
   hipLaunchKernelGGL(k_count_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, p->d_block_counts);
   hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, p->d_block_counts, nblocks, p->d_scalars);
   hipLaunchKernelGGL(k_fill_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, p->d_block_counts, p->d_nl, (unsigned)p->max_rows);
+  hipLaunchKernelGGL(k_last_newline, dim3(1), dim3(1), 0, s, p->d_nl, p->d_scalars, (unsigned)p->max_rows);
   // the number of lines is bounded by n_bytes / 16 + 1 for well-formed data lines; launch for that bound
   const int64_t row_bound = std::min<int64_t>(p->max_rows, n_bytes / 16 + 1);
   const int pblocks = (int)((row_bound + TPB - 1) / TPB);
@@ -490,12 +497,13 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* p, void* stream, const uint8_
   hipLaunchKernelGGL(k_assign_filters, dim3(1), dim3(256), 0, s, d_text, p->filters);
   hipLaunchKernelGGL(k_remap_filters, dim3(std::min(pblocks, 4096)), dim3(TPB), 0, s, p->out.filter_id, p->d_scalars, p->filters.ids, (unsigned)row_bound);
   HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipMemcpyAsync(p->h_scalars, p->d_scalars, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(p->h_scalars, p->d_scalars, 12, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
   const int64_t n_lines = p->h_scalars[0];
   if (n_lines > row_bound) return fail(ctx, EXON_HIP_EINVAL, "slab has %lld lines, more than its byte size allows for VCF records", (long long)n_lines);
   cols->n_rows = n_lines;
   cols->n_undecided = p->h_scalars[1];
+  cols->consumed_bytes = p->h_scalars[2];
   cols->chrom_id = p->out.chrom_id;
   cols->pos = p->out.pos;
   cols->pos_valid = p->out.pos_valid;

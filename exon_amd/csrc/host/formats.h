@@ -417,6 +417,12 @@ class VCFBatchReader {
     return ss->r.release_source();
   }
   const VCFConfig& config() const { return cfg_; }
+  // Uncompressed offset of the first data line (header length), for callers that re-open the file themselves
+  // (GPU-side BGZF inflate).  -1 when it is not known (headerless input, parse pipeline or index source active).
+  int64_t data_offset() const {
+    if (pipe_ || n_chunks >= 0 || has_pending_) return -1;
+    return (int64_t)static_cast<StreamSource*>(r_.get())->r.consumed();
+  }
 
   // Parallel mode only: the rest of the current slab as raw columns (no Arrow materialisation); false when the
   // reader is sequential (use read_batch) or the input is exhausted (*end = true).

@@ -116,6 +116,8 @@ class BufReader {
     return s;
   }
   std::unique_ptr<ByteSource> release_source() { return std::move(src_); }
+  // bytes handed out so far (position of the next unread byte in the uncompressed stream)
+  uint64_t consumed() const { return filled_ - (end_ - pos_); }
 
   // reads one line without its terminator ('\n' or "\r\n"); false at end of data
   bool read_line(std::string* line) {
@@ -152,11 +154,13 @@ class BufReader {
   bool fill() {
     end_ = src_ ? src_->read(buf_.data(), buf_.size()) : 0;
     pos_ = 0;
+    filled_ += end_;
     return end_ > 0;
   }
   std::unique_ptr<ByteSource> src_;
   std::vector<uint8_t> buf_;
   size_t pos_ = 0, end_ = 0;
+  uint64_t filled_ = 0;
 };
 
 }  // namespace exon

@@ -1,0 +1,717 @@
+// inflate.hip -- BGZF block inflate ON THE GPU: compressed blocks in HBM -> text / records in HBM.
+//
+// Reference path replaced: noodles bgzf::AsyncReader wrapped around the object-store byte stream in
+// exon-core/src/datasources/vcf/file_opener/unindex_file_opener.rs:62-70, fastq/file_opener.rs:69-75 and the
+// block-by-block AsyncBGZFReader of exon-core/src/streaming_bgzf.rs:56-64 (third-party arithmetic: RFC 1951 DEFLATE
+// inside RFC 1952 members with the BGZF "BC" extra field, SAM specification section 4.1).  Nearly every VCF / BAM /
+// FASTQ in the wild is BGZF-compressed, and host zlib is what bounds the scan then; BGZF blocks are independent
+// (<= 64 KiB of text each), so a slab of compressed blocks crosses PCIe as it is (3-5x fewer bytes than text) and
+// is inflated by one wavefront per block.
+//
+// One wavefront per block:
+//   * the bit stream is consumed by wave-uniform (scalar) code; the compressed bytes sit in a 256-byte window held
+//     across the lanes of one VGPR (next window prefetched) and are pulled out with v_readlane -- no memory latency on
+//     the symbol-decode chain;
+//   * Huffman tables live in LDS (3.9 KB per wave): a 10-bit (literal/length) and an 8-bit (distance) first-level
+//     table built lane-parallel from the code lengths (ballot ranks give the canonical codes), a bit-serial canonical
+//     decode (count/first arrays) for the rare longer codes;
+//   * literals are collected in one VGPR (lane = output address & 63) and leave as one coalesced 64-byte store;
+//     matches are copied lane-parallel from the already written output in HBM (same-wave store -> load order is
+//     program order on CDNA), overlapping runs (distance < length) by modular addressing.
+// Every block reports a status; any failure makes the caller inflate on the host instead.  The CRC-32 of every
+// inflated block is checked by a second kernel (k_crc32: 64 slices per block, combined in GF(2)[x] mod P).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "internal.h"
+
+namespace {
+
+constexpr int LIT_BITS = 10, DIST_BITS = 10, CL_BITS = 7;
+constexpr int WAVES_PER_WG = 4;     // k_crc32
+constexpr int INFLATE_RING = 2048;  // bytes of recent output kept in LDS per wavefront (k_inflate)
+
+enum : int {
+  INF_OK = 0,
+  INF_BAD_BTYPE = 1,
+  INF_BAD_STORED = 2,
+  INF_BAD_LENGTHS = 3,
+  INF_BAD_CODE = 4,
+  INF_BAD_DISTANCE = 5,
+  INF_OUTPUT_OVERRUN = 6,
+  INF_INPUT_OVERRUN = 7,
+  INF_SIZE_MISMATCH = 8,
+  INF_BAD_CRC = 9,
+};
+
+// Length / distance base values and extra-bit counts of RFC 1951 section 3.2.5 in closed form (table lookups would be
+// vector-memory loads on the serial decode chain):
+//   length symbol s (0..28, = code - 257): s < 8: 3 + s, 0 bits; s = 28: 258; else e = (s - 4) >> 2, 3 + ((4 + (s & 3)) << e)
+//   distance symbol d (0..29): d < 4: 1 + d, 0 bits; else e = (d - 2) >> 1, 1 + ((2 + (d & 1)) << e)
+__device__ __forceinline__ void length_code(int s, uint32_t* base, int* extra) {
+  if (s < 8) {
+    *base = 3u + (uint32_t)s;
+    *extra = 0;
+  } else if (s == 28) {
+    *base = 258u;
+    *extra = 0;
+  } else {
+    const int e = (s - 4) >> 2;
+    *base = 3u + ((4u + (uint32_t)(s & 3)) << e);
+    *extra = e;
+  }
+}
+__device__ __forceinline__ void distance_code(int d, uint32_t* base, int* extra) {
+  if (d < 4) {
+    *base = 1u + (uint32_t)d;
+    *extra = 0;
+  } else {
+    const int e = (d - 2) >> 1;
+    *base = 1u + ((2u + (uint32_t)(d & 1)) << e);
+    *extra = e;
+  }
+}
+// order of the code-length code lengths {16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15}, 5 bits each
+constexpr uint64_t CL_ORDER_LO = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 |
+                                 10ull << 40 | 5ull << 45 | 11ull << 50 | 4ull << 55;
+constexpr uint64_t CL_ORDER_HI = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
+__device__ __forceinline__ int cl_order(int i) {
+  return i < 12 ? (int)((CL_ORDER_LO >> (5 * i)) & 31) : (int)((CL_ORDER_HI >> (5 * (i - 12))) & 31);
+}
+
+// ---- LDS layout: one wavefront per workgroup; [0, RING) recent output, then the tables -----------------------------
+// A file-scope dynamic LDS array keeps the address space visible to the non-inlined helpers (ds_* instructions, not
+// flat_*).
+extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+struct ClTables {  // the code-length code is dead once the two main codes are built: it shares dist_lut's space
+  uint16_t cl_lut[1 << CL_BITS];
+  uint16_t cl_sym[20];
+  uint16_t cl_count[16];
+};
+struct WaveLds {
+  uint16_t lit_lut[1 << LIT_BITS];   // entry = symbol << 4 | code length; 0 = longer than the table (or no code)
+  union {
+    uint16_t dist_lut[1 << DIST_BITS];
+    ClTables cl;
+  };
+  uint16_t lit_sym[288];             // symbols in canonical order (bit-serial decode of long codes)
+  uint16_t dist_sym[32];
+  uint16_t lit_count[16], dist_count[16];  // codes per length
+  uint16_t first[16], offs[16];      // scratch of build_code
+  uint8_t lens[288 + 32];
+};
+static_assert(sizeof(ClTables) <= sizeof(uint16_t) << DIST_BITS, "cl tables must fit under dist_lut");
+enum { CODE_LIT = 0, CODE_DIST = 1, CODE_CL = 2 };
+
+constexpr int INF_WAVES = 4;  // wavefronts (= BGZF blocks) per workgroup
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+template <int RING>
+__device__ __forceinline__ uint8_t* wave_ring();
+template <int RING>
+__device__ __forceinline__ WaveLds* wave_lds() { return reinterpret_cast<WaveLds*>(wave_ring<RING>() + RING); }
+
+template <int RING>
+__device__ __forceinline__ uint8_t* wave_ring() {
+  constexpr uint32_t STRIDE = (RING + (uint32_t)sizeof(WaveLds) + 15u) & ~15u;
+  return smem + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * STRIDE;
+}
+
+struct Code {
+  uint16_t* lut;
+  uint16_t* sym;
+  uint16_t* count;
+  int bits;
+};
+template <int RING>
+__device__ __forceinline__ Code code_of(int which) {
+  WaveLds* L = wave_lds<RING>();
+  if (which == CODE_LIT) return Code{L->lit_lut, L->lit_sym, L->lit_count, LIT_BITS};
+  if (which == CODE_DIST) return Code{L->dist_lut, L->dist_sym, L->dist_count, DIST_BITS};
+  return Code{L->cl.cl_lut, L->cl.cl_sym, L->cl.cl_count, CL_BITS};
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uniu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+template <class T>
+__device__ __forceinline__ T* unip(T* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  return reinterpret_cast<T*>(((uint64_t)uniu((uint32_t)(v >> 32)) << 32) | uniu((uint32_t)v));
+}
+
+// Bit reader over dword-aligned global memory; all fields wave-uniform except the window register (one dword per
+// lane: the aligned 256-byte window that holds dword `widx`).  A window is reloaded synchronously when exhausted: once
+// per 256 input bytes (~250 symbols).  Reading past the block's end is detected by the callers (`overrun()`, checked
+// once per 256 output bytes), so up to ~2 KiB behind a corrupt block may be read: buffers carry 4 KiB of padding.
+struct BitReader {
+  const uint32_t* base;
+  uint32_t widx;   // next dword to take
+  uint32_t cur;    // per lane: base[(widx & ~63) + lane]
+  uint64_t buf;
+  int cnt;
+  uint32_t limit;  // dword index one past the last dword that may hold this block's bits
+
+  __device__ __forceinline__ void init(const uint8_t* data, uint32_t byte_off, uint32_t byte_end) {
+    base = reinterpret_cast<const uint32_t*>(data);
+    widx = byte_off >> 2;
+    limit = (byte_end + 3) >> 2;
+    cur = base[(widx & ~63u) + lane_id()];
+    buf = 0;
+    cnt = 0;
+    refill();
+    refill();
+    const int skip = (int)(byte_off & 3) * 8;
+    buf >>= skip;
+    cnt -= skip;
+  }
+  __device__ __forceinline__ void refill() {
+    if (cnt <= 32) {
+      const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(widx & 63u));
+      buf |= (uint64_t)d << cnt;
+      cnt += 32;
+      ++widx;
+      if ((widx & 63u) == 0) cur = base[widx + lane_id()];
+    }
+  }
+  __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)buf & ((1u << n) - 1u); }
+  __device__ __forceinline__ void drop(int n) {
+    buf >>= n;
+    cnt -= n;
+  }
+  __device__ __forceinline__ uint32_t take(int n) {
+    const uint32_t v = peek(n);
+    drop(n);
+    return v;
+  }
+  // bytes of the input consumed so far (whole bytes; the partial byte counts as consumed)
+  __device__ __forceinline__ uint32_t byte_pos() const { return widx * 4u - (uint32_t)(cnt >> 3); }
+  __device__ __forceinline__ bool overrun() const { return widx > limit + 2u; }  // two dwords of look-ahead are legitimate
+  // values that crossed a function boundary arrive in VGPRs: make them scalar again
+  __device__ __forceinline__ void make_uniform() {
+    base = unip(base);
+    widx = uniu(widx);
+    buf = ((uint64_t)uniu((uint32_t)(buf >> 32)) << 32) | uniu((uint32_t)buf);
+    cnt = uni(cnt);
+    limit = uniu(limit);
+  }
+};
+
+// Build code `which` from lens[0..n): counts, canonical order, first-level table.  Returns 0 for an over-subscribed
+// code, or an incomplete one that is not the single-code case DEFLATE allows.
+template <int RING>
+__device__ __noinline__ int build_code_impl(int which, int lens_off, int n) {
+  which = uni(which);
+  lens_off = uni(lens_off);
+  n = uni(n);
+  WaveLds* L = wave_lds<RING>();
+  const Code c = code_of<RING>(which);
+  const uint8_t* lens = L->lens + lens_off;
+  const int lane = (int)lane_id();
+  const int size = 1 << c.bits;
+  for (int i = lane; i < size; i += 64) c.lut[i] = 0;
+  // totals per length, by ballots
+  int run[16];
+#pragma unroll
+  for (int l = 0; l < 16; ++l) run[l] = 0;
+  for (int s0 = 0; s0 < n; s0 += 64) {
+    const int s = s0 + lane;
+    const int l = s < n ? lens[s] : 0;
+#pragma unroll
+    for (int q = 1; q < 16; ++q) run[q] += __popcll(__ballot(l == q));
+  }
+  int left = 1, total = 0;
+  int first[16], offs[16];
+  first[0] = offs[0] = 0;
+  {
+    int code = 0, off = 0;
+#pragma unroll
+    for (int q = 1; q < 16; ++q) {
+      code <<= 1;
+      first[q] = code;
+      offs[q] = off;
+      code += run[q];
+      off += run[q];
+      left = (left << 1) - run[q];
+      if (left < 0) return 0;  // over-subscribed
+      total += run[q];
+    }
+  }
+  if (left > 0 && total > 1) return 0;  // incomplete (RFC 1951 allows it only for a single distance code)
+  if (lane < 16) {
+    int cq = 0, fq = 0, oq = 0;
+#pragma unroll
+    for (int q = 1; q < 16; ++q)
+      if (lane == q) {
+        cq = run[q];
+        fq = first[q];
+        oq = offs[q];
+      }
+    c.count[lane] = (uint16_t)cq;
+    L->first[lane] = (uint16_t)fq;
+    L->offs[lane] = (uint16_t)oq;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // every symbol gets its canonical code (rank inside its length class, in symbol order); fill the tables
+  int seen[16];
+#pragma unroll
+  for (int l = 0; l < 16; ++l) seen[l] = 0;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int s0 = 0; s0 < n; s0 += 64) {
+    const int s = s0 + lane;
+    const int l = s < n ? lens[s] : 0;
+    int rank = 0;
+#pragma unroll
+    for (int q = 1; q < 16; ++q) {
+      const unsigned long long m = __ballot(l == q);
+      if (l == q) rank = seen[q] + __popcll(m & lt);
+      seen[q] += __popcll(m);
+    }
+    if (l > 0) {
+      const int code = (int)L->first[l] + rank;
+      c.sym[(int)L->offs[l] + rank] = (uint16_t)s;
+      if (l <= c.bits) {
+        const unsigned rev = __brev((unsigned)code) >> (32 - l);
+        const uint16_t e = (uint16_t)((s << 4) | l);
+        for (unsigned k = rev; k < (unsigned)size; k += 1u << l) c.lut[k] = e;
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  return 1;
+}
+template <int RING>
+__device__ __forceinline__ bool build_code(int which, int lens_off, int n) {
+  return uni(build_code_impl<RING>(which, lens_off, n)) != 0;
+}
+
+// Bit-serial canonical decode for codes longer than the first-level table (rare).  Returns symbol << 8 | length,
+// or -1 for a code that does not exist.
+template <int RING>
+__device__ __noinline__ int decode_long(int which, uint32_t bits) {
+  which = uni(which);
+  bits = uniu(bits);
+  const Code c = code_of<RING>(which);
+  int code = 0, first = 0, index = 0;
+  for (int len = 1; len <= 15; ++len) {
+    code |= (int)(bits & 1u);
+    bits >>= 1;
+    const int n = uni((int)c.count[len]);
+    if (code - n < first) return (uni((int)c.sym[index + (code - first)]) << 8) | len;
+    index += n;
+    first += n;
+    first <<= 1;
+    code <<= 1;
+  }
+  return -1;
+}
+
+// Decode one symbol (wave-uniform).  Returns -1 for a code that does not exist.
+template <int RING, int WHICH>
+__device__ __forceinline__ int decode_symbol(BitReader& br) {
+  WaveLds* L = wave_lds<RING>();
+  const uint16_t* lut = WHICH == CODE_LIT ? L->lit_lut : WHICH == CODE_DIST ? L->dist_lut : L->cl.cl_lut;
+  constexpr int BITS = WHICH == CODE_LIT ? LIT_BITS : WHICH == CODE_DIST ? DIST_BITS : CL_BITS;
+  const int e = uni((int)lut[br.peek(BITS)]);
+  if (__builtin_expect(e != 0, 1)) {
+    br.drop(e & 15);
+    return e >> 4;
+  }
+  const int r = uni(decode_long<RING>(WHICH, (uint32_t)br.buf));
+  if (r < 0) return -1;
+  br.drop(r & 255);
+  return r >> 8;
+}
+
+struct Block {  // == exon_hip_bgzf_block
+  uint32_t comp_offset, comp_size, out_offset, out_size, crc32, reserved;
+};
+
+struct Out {  // output cursor of one BGZF block (wave-uniform)
+  uint8_t* out;
+  uint32_t begin, end;  // [begin, end) absolute indexes into `out`
+  uint32_t pos;         // next output byte
+  uint32_t drained;     // output below this index is in HBM; [drained, pos) is only in the ring
+  __device__ __forceinline__ void make_uniform() {
+    out = unip(out);
+    begin = uniu(begin);
+    end = uniu(end);
+    pos = uniu(pos);
+    drained = uniu(drained);
+  }
+};
+
+// ring -> HBM for [drained, limit), in aligned 256-byte rows (one dword per lane) where possible
+template <int RING>
+__device__ __forceinline__ void drain_to(Out& o, uint32_t limit) {
+  constexpr uint32_t M = RING - 1;
+  const uint32_t lane = lane_id();
+  const uint8_t* ring = wave_ring<RING>();
+  while (o.drained < limit) {
+    const uint32_t row_end = min(limit, (o.drained | 255u) + 1u);
+    if (((o.drained | row_end) & 3u) == 0) {
+      const uint32_t p = o.drained + 4u * lane;
+      if (p < row_end) *reinterpret_cast<uint32_t*>(o.out + p) = *reinterpret_cast<const uint32_t*>(ring + (p & M));
+    } else {
+      for (uint32_t p = o.drained + lane; p < row_end; p += 64) o.out[p] = ring[p & M];
+    }
+    o.drained = row_end;
+  }
+}
+
+struct SymResult {
+  BitReader br;
+  Out o;
+  int err;
+};
+
+// The symbols of one DEFLATE block.  RING bytes of the most recent output stay in LDS: matches whose distance fits are
+// LDS -> LDS copies (no memory latency on the decode chain); farther ones read the output already drained to HBM.
+// Output bounds are checked when rows are drained (the ring wraps harmlessly), input bounds when a window is reloaded.
+template <int RING>
+__device__ __noinline__ SymResult decode_symbols(BitReader br, Out o) {
+  constexpr uint32_t M = RING - 1;
+  constexpr uint32_t NEAR = RING - 258;  // largest distance served from the ring (the copy must not overwrite its source)
+  static_assert(RING >= 1024, "far matches rely on NEAR >= 258 + 255");
+  br.make_uniform();
+  o.make_uniform();
+  uint8_t* ring = wave_ring<RING>();
+  const uint32_t lane = lane_id();
+  int err = INF_OK;
+  for (;;) {
+    br.refill();
+    int s = decode_symbol<RING, CODE_LIT>(br);
+    if (s < 256) {
+      if (s < 0) { err = INF_BAD_CODE; break; }
+      ring[o.pos & M] = (uint8_t)s;  // every lane stores the same byte
+      ++o.pos;
+      if ((o.pos & 255u) == 0) {
+        if (o.pos > o.end || br.overrun()) { err = br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN; break; }
+        drain_to<RING>(o, o.pos);
+      }
+      continue;
+    }
+    if (s == 256) break;
+    s -= 257;
+    if (s >= 29) { err = INF_BAD_CODE; break; }
+    uint32_t len;
+    int ext;
+    length_code(s, &len, &ext);
+    len += br.take(ext);
+    br.refill();
+    const int ds = decode_symbol<RING, CODE_DIST>(br);
+    if (ds < 0 || ds >= 30) { err = INF_BAD_CODE; break; }
+    uint32_t d;
+    distance_code(ds, &d, &ext);
+    d += br.take(ext);
+    if (d > o.pos - o.begin) { err = INF_BAD_DISTANCE; break; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (d <= NEAR) {
+      if (d >= len) {
+        for (uint32_t j = lane; j < len; j += 64) ring[(o.pos + j) & M] = ring[(o.pos - d + j) & M];
+      } else {
+        // overlapping run: 64 bytes per step read strictly older bytes (modular source), then write
+        for (uint32_t j0 = 0; j0 < len; j0 += 64) {
+          const uint32_t j = j0 + lane;
+          const uint8_t v = ring[(o.pos - d + j % d) & M];
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          if (j < len) ring[(o.pos + j) & M] = v;
+        }
+      }
+    } else {
+      // far: d > NEAR >= 258 + 255, so the source ends below `drained` (pos - drained < 256): it is in HBM already
+      for (uint32_t j = lane; j < len; j += 64) ring[(o.pos + j) & M] = o.out[o.pos - d + j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const uint32_t npos = o.pos + len;
+    if ((o.pos ^ npos) >> 8) {  // crossed a 256-byte row
+      if (npos > o.end || br.overrun()) { err = br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN; break; }
+      drain_to<RING>(o, npos & ~255u);
+    }
+    o.pos = npos;
+  }
+  return SymResult{br, o, err};
+}
+
+template <int RING>
+__global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks, int n_blocks,
+                                                uint8_t* out, int* __restrict__ status) {
+  constexpr uint32_t M = RING - 1;
+  const int lane = (int)lane_id();
+  const int b = uni((int)(blockIdx.x * INF_WAVES + (threadIdx.x >> 6)));
+  if (b >= n_blocks) return;
+  WaveLds* L = wave_lds<RING>();
+  uint8_t* ring = wave_ring<RING>();
+  const Block blk = blocks[b];
+  const uint32_t comp_end = blk.comp_offset + blk.comp_size;
+
+  BitReader br;
+  br.init(comp, blk.comp_offset, comp_end);
+  Out o{out, blk.out_offset, blk.out_offset + blk.out_size, blk.out_offset, blk.out_offset};
+  int err = INF_OK;
+
+  bool last = false;
+  while (!last && err == INF_OK) {
+    br.refill();
+    last = br.take(1) != 0;
+    const int btype = (int)br.take(2);
+    if (btype == 0) {  // stored: input -> HBM directly, the tail also into the ring for later matches
+      if (o.pos > o.end) { err = INF_OUTPUT_OVERRUN; break; }
+      drain_to<RING>(o, o.pos);
+      br.drop(br.cnt & 7);
+      br.refill();
+      const uint32_t len = br.take(16);
+      br.refill();
+      const uint32_t nlen = br.take(16);
+      if ((len ^ nlen) != 0xFFFFu) { err = INF_BAD_STORED; break; }
+      const uint32_t src = br.byte_pos();
+      if (src + len > comp_end) { err = INF_INPUT_OVERRUN; break; }
+      if (o.pos + len > o.end) { err = INF_OUTPUT_OVERRUN; break; }
+      const uint32_t keep = len > (uint32_t)RING ? len - (uint32_t)RING : 0u;
+      for (uint32_t j = (uint32_t)lane; j < len; j += 64) {
+        const uint8_t v = comp[src + j];
+        out[o.pos + j] = v;
+        if (j >= keep) ring[(o.pos + j) & M] = v;
+      }
+      o.pos += len;
+      o.drained = o.pos;
+      br.init(comp, src + len, comp_end);
+      continue;
+    }
+    if (btype == 3) { err = INF_BAD_BTYPE; break; }
+    if (btype == 1) {  // fixed codes
+      for (int s = lane; s < 288; s += 64) L->lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
+      if (lane < 32) L->lens[288 + lane] = 5;  // 30 and 31 complete the code; using them is an error
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (!build_code<RING>(CODE_LIT, 0, 288) || !build_code<RING>(CODE_DIST, 288, 32)) { err = INF_BAD_LENGTHS; break; }
+    } else {  // dynamic codes
+      br.refill();
+      const int hlit = (int)br.take(5) + 257, hdist = (int)br.take(5) + 1, hclen = (int)br.take(4) + 4;
+      if (hlit > 286 || hdist > 30) { err = INF_BAD_LENGTHS; break; }
+      if (lane < 19) L->lens[lane] = 0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      for (int i = 0; i < hclen; ++i) {
+        br.refill();
+        const uint8_t v = (uint8_t)br.take(3);
+        L->lens[cl_order(i)] = v;  // every lane writes the same byte
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (!build_code<RING>(CODE_CL, 0, 19)) { err = INF_BAD_LENGTHS; break; }
+      // code lengths of the literal/length and distance alphabets, run-length coded
+      int i = 0, prev = 0;
+      const int total = hlit + hdist;
+      while (i < total) {
+        br.refill();
+        const int s = decode_symbol<RING, CODE_CL>(br);
+        if (s < 0) { err = INF_BAD_CODE; break; }
+        if (s < 16) {
+          L->lens[i++] = (uint8_t)s;
+          prev = s;
+        } else {
+          int rep, val = 0;
+          if (s == 16) {
+            if (i == 0) { err = INF_BAD_LENGTHS; break; }
+            val = prev;
+            rep = 3 + (int)br.take(2);
+          } else if (s == 17) {
+            rep = 3 + (int)br.take(3);
+          } else {
+            rep = 11 + (int)br.take(7);
+          }
+          if (i + rep > total) { err = INF_BAD_LENGTHS; break; }
+          for (int k = lane; k < rep; k += 64) L->lens[i + k] = (uint8_t)val;
+          i += rep;
+          prev = val;
+        }
+      }
+      if (err) break;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (uni((int)L->lens[256]) == 0) { err = INF_BAD_LENGTHS; break; }  // no end-of-block code
+      // the distance lengths follow the literal/length lengths directly: move them behind the 288 slots
+      const int dl = lane < hdist ? L->lens[hlit + lane] : 0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (lane < 32) L->lens[288 + lane] = (uint8_t)dl;
+      for (int s = hlit + lane; s < 288; s += 64) L->lens[s] = 0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (!build_code<RING>(CODE_LIT, 0, 288) || !build_code<RING>(CODE_DIST, 288, 30)) { err = INF_BAD_LENGTHS; break; }
+    }
+    const SymResult r = decode_symbols<RING>(br, o);
+    br = r.br;
+    br.make_uniform();
+    o = r.o;
+    o.make_uniform();
+    err = uni(r.err);
+  }
+  if (err == INF_OK && (o.pos > o.end || br.overrun())) err = br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN;
+  if (err != INF_OK) o.pos = min(o.pos, o.end);
+  drain_to<RING>(o, o.pos);
+  if (err == INF_OK && o.pos != o.end) err = INF_SIZE_MISMATCH;
+  if (lane == 0) status[b] = err;
+}
+
+// CRC-32 (IEEE, reflected) of every inflated block: one wavefront per block.  Each lane runs the byte-serial CRC
+// over its own contiguous slice with a zero initial value; slices are then chained with the "append zeros" operator
+// realised as a carry-less exponentiation -- here simply by processing the slices' CRCs through GF(2) matrix-free
+// shifting: crc(A || B) = shift(crc(A), |B|) ^ crc0(B), where shift multiplies by x^(8|B|) mod P.
+__device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b) {  // a * b mod P, reflected representation
+  uint32_t r = 0;
+  for (int i = 0; i < 32; ++i) {
+    if (a & 0x80000000u) r ^= b;
+    a <<= 1;
+    b = (b >> 1) ^ ((b & 1u) ? 0xEDB88320u : 0u);
+  }
+  return r;
+}
+__device__ __forceinline__ uint32_t x_pow_8n(uint32_t n_bytes) {  // x^(8 n) mod P
+  uint32_t result = 0x80000000u;                                  // x^0
+  uint32_t sq = 0x00800000u;                                      // x^8
+  while (n_bytes) {
+    if (n_bytes & 1u) result = gf2_mulmod(result, sq);
+    sq = gf2_mulmod(sq, sq);
+    n_bytes >>= 1;
+  }
+  return result;
+}
+
+__global__ __launch_bounds__(WAVES_PER_WG * 64) void k_crc32(const uint8_t* __restrict__ out, const Block* __restrict__ blocks, int n_blocks,
+                                                             int* __restrict__ status) {
+  __shared__ uint32_t table[4][256];  // slicing-by-4: table[k][b] = CRC of byte b followed by k zero bytes
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+    uint32_t c = (uint32_t)i;
+    for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? 0xEDB88320u : 0u);
+    table[0][i] = c;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+    uint32_t c = table[0][i];
+    for (int k = 1; k < 4; ++k) {
+      c = table[0][c & 0xFFu] ^ (c >> 8);
+      table[k][i] = c;
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * WAVES_PER_WG + wave;
+  if (b >= n_blocks) return;
+  const Block blk = blocks[b];
+  if (status[b] != INF_OK) return;
+  const uint32_t n = blk.out_size;
+  const uint32_t per = (((n + 63u) / 64u) + 3u) & ~3u;  // whole dwords per slice
+  const uint32_t lo = min(n, (uint32_t)lane * per), hi = min(n, lo + per);
+  const uint8_t* p = out + blk.out_offset;
+  uint32_t c = 0;  // raw CRC register over the slice, zero initial value, no final xor
+  uint32_t i = lo;
+  while (i < hi && ((reinterpret_cast<uintptr_t>(p + i)) & 3u)) c = table[0][(c ^ p[i++]) & 0xFFu] ^ (c >> 8);
+  for (; i + 4 <= hi; i += 4) {
+    c ^= *reinterpret_cast<const uint32_t*>(p + i);
+    c = table[3][c & 0xFFu] ^ table[2][(c >> 8) & 0xFFu] ^ table[1][(c >> 16) & 0xFFu] ^ table[0][c >> 24];
+  }
+  for (; i < hi; ++i) c = table[0][(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+  // combine: total = sum over lanes of crc_l * x^(8 * bytes after slice l); the 0xFFFFFFFF initial value is the
+  // CRC of a virtual prefix: init * x^(8 n)
+  uint32_t term = (hi > lo) ? gf2_mulmod(c, x_pow_8n(n - hi)) : 0u;
+  if (lane == 0) term ^= gf2_mulmod(0xFFFFFFFFu, x_pow_8n(n));
+  for (int o = 32; o > 0; o >>= 1) term ^= __shfl_xor(term, o, 64);
+  const uint32_t crc = term ^ 0xFFFFFFFFu;
+  if (lane == 0 && crc != blk.crc32) status[b] = INF_BAD_CRC;
+}
+
+}  // namespace
+
+extern "C" {
+
+int exon_hip_bgzf_scan(const uint8_t* data, size_t n, size_t out_base, exon_hip_bgzf_block* blocks, int32_t cap,
+                       int32_t* n_blocks, size_t* consumed, size_t* out_bytes) {
+  if (!n_blocks || !consumed || !out_bytes || (n && !data)) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_bgzf_scan: NULL argument");
+  size_t o = 0, out = out_base;
+  int32_t k = 0;
+  while (o + 18 <= n) {
+    const uint8_t* h = data + o;
+    if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return fail(nullptr, EXON_HIP_EINVAL, "not a BGZF block at byte %zu", o);
+    const size_t xlen = (size_t)h[10] | ((size_t)h[11] << 8);
+    if (o + 12 + xlen > n) break;
+    size_t bsize = 0;
+    for (size_t x = 12; x + 4 <= 12 + xlen;) {  // extra subfields: SI1 SI2 SLEN data
+      const size_t slen = (size_t)h[x + 2] | ((size_t)h[x + 3] << 8);
+      if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2 && x + 6 <= 12 + xlen) bsize = ((size_t)h[x + 4] | ((size_t)h[x + 5] << 8)) + 1;
+      x += 4 + slen;
+    }
+    if (bsize < 12 + xlen + 8) return fail(nullptr, EXON_HIP_EINVAL, "BGZF block at byte %zu has no valid BC field", o);
+    if (o + bsize > n) break;  // partial block: the caller reads more
+    if (k == cap) break;
+    uint32_t crc, isize;
+    memcpy(&crc, h + bsize - 8, 4);
+    memcpy(&isize, h + bsize - 4, 4);
+    if (isize > 65536u) return fail(nullptr, EXON_HIP_EINVAL, "BGZF block at byte %zu claims %u bytes", o, isize);
+    if (out + isize > 0xFFFFFFFFull || o + bsize > 0xFFFFFFFFull) break;  // 32-bit offsets per call
+    if (blocks) {
+      blocks[k].comp_offset = (uint32_t)(o + 12 + xlen);
+      blocks[k].comp_size = (uint32_t)(bsize - 12 - xlen - 8);
+      blocks[k].out_offset = (uint32_t)out;
+      blocks[k].out_size = isize;
+      blocks[k].crc32 = crc;
+      blocks[k].reserved = 0;
+    }
+    ++k;
+    out += isize;
+    o += bsize;
+  }
+  *n_blocks = k;
+  *consumed = o;
+  *out_bytes = out - out_base;
+  return EXON_HIP_OK;
+}
+
+int exon_hip_bgzf_inflate(exon_hip_ctx* ctx, void* stream, const uint8_t* d_comp, const exon_hip_bgzf_block* blocks,
+                          int32_t n_blocks, uint8_t* d_out, int32_t verify_crc, int32_t* first_bad_block) {
+  if (!ctx || (n_blocks > 0 && (!d_comp || !blocks || !d_out))) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_bgzf_inflate: NULL argument");
+  if (first_bad_block) *first_bad_block = -1;
+  if (n_blocks <= 0) return EXON_HIP_OK;
+  if ((reinterpret_cast<uintptr_t>(d_comp) & 3) != 0 || (reinterpret_cast<uintptr_t>(d_out) & 3) != 0)
+    return fail(ctx, EXON_HIP_EINVAL, "compressed and output buffers must be 4-byte aligned");
+  hipStream_t s = pick_stream(ctx, stream);
+  hipSetDevice(ctx->device);
+  // block table + status words: one scratch allocation per call (freed after the synchronise below)
+  Block* d_blocks = nullptr;
+  const size_t tb = (size_t)n_blocks * sizeof(Block), sb = (size_t)n_blocks * sizeof(int);
+  if (hipMalloc((void**)&d_blocks, tb + sb) != hipSuccess) return fail(ctx, EXON_HIP_ENOMEM, "block table allocation failed");
+  int* d_status = reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(d_blocks) + tb);
+  std::vector<int> h_status((size_t)n_blocks);
+  hipError_t e = hipMemcpyAsync(d_blocks, blocks, tb, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = exon_bgzf_inflate_launch(s, d_comp, reinterpret_cast<const exon_hip_bgzf_block*>(d_blocks), n_blocks, d_out, d_status, verify_crc != 0);
+  if (e == hipSuccess) e = hipMemcpyAsync(h_status.data(), d_status, sb, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  hipFree(d_blocks);
+  if (e != hipSuccess) return fail(ctx, EXON_HIP_EDEVICE, "bgzf inflate: %s", hipGetErrorString(e));
+  for (int32_t b = 0; b < n_blocks; ++b)
+    if (h_status[(size_t)b] != INF_OK) {
+      if (first_bad_block) *first_bad_block = b;
+      return fail(ctx, EXON_HIP_EINVAL, "BGZF block %d: %s", b, exon_bgzf_status_name(h_status[(size_t)b]));
+    }
+  return EXON_HIP_OK;
+}
+
+}  // extern "C"
+
+// Internal (C++): enqueue the inflate (+ CRC) kernels; d_blocks / d_status are device arrays of n_blocks entries.
+hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const exon_hip_bgzf_block* d_blocks, int n_blocks,
+                                    uint8_t* d_out, int* d_status, bool verify_crc) {
+  if (n_blocks <= 0) return hipSuccess;
+  static_assert(sizeof(Block) == sizeof(exon_hip_bgzf_block), "block layouts must agree");
+  const Block* blocks = reinterpret_cast<const Block*>(d_blocks);
+  constexpr size_t lds_per_wave = (INFLATE_RING + sizeof(WaveLds) + 15) & ~size_t(15);
+  hipLaunchKernelGGL(k_inflate<INFLATE_RING>, dim3((n_blocks + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), INF_WAVES * lds_per_wave, s,
+                     d_comp, blocks, n_blocks, d_out, d_status);
+  if (verify_crc)
+    hipLaunchKernelGGL(k_crc32, dim3((n_blocks + WAVES_PER_WG - 1) / WAVES_PER_WG), dim3(WAVES_PER_WG * 64), 0, s, d_out, blocks, n_blocks,
+                       d_status);
+  return hipGetLastError();
+}
+
+const char* exon_bgzf_status_name(int code) {
+  static const char* const names[] = {"ok", "reserved block type", "stored-block length check", "invalid code lengths",
+                                      "invalid Huffman code", "distance before the block start", "more output than ISIZE",
+                                      "compressed data exhausted", "less output than ISIZE", "CRC-32 mismatch"};
+  return code >= 0 && code < 10 ? names[code] : "unknown";
+}

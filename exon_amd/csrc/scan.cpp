@@ -11,6 +11,7 @@
 
 #include "host/bcf.h"
 #include "host/formats.h"
+#include "host/parallel.h"
 #include "internal.h"
 
 struct exon_hip_vcf_parser;  // gpu_parse.hip
@@ -24,6 +25,7 @@ struct exon_hip_scan {
   exon_hip_vcf_parser* parser = nullptr;  // created by the first GPU-parsed consume; owns the FILTER dictionary
   exon_hip_ctx* parser_ctx = nullptr;
   exon_hip_fastq_parser* fq_parser = nullptr;
+  bool gpu_inflated = false;  // the last GPU-parsed consume also inflated BGZF blocks on the device
   exon::Dictionary gpu_filter_dict;       // names fetched from the parser after the consume
   std::unique_ptr<exon::VCFBatchReader> vcf;
   std::unique_ptr<exon::BAMBatchReader> bam;
@@ -42,6 +44,15 @@ void* exon_hip_stream_hip_stream(exon_hip_stream* st);
 exon_hip_ctx* exon_hip_stream_ctx(exon_hip_stream* st);
 int exon_hip_stream_state_copy(exon_hip_stream* st, void* d_snapshot, bool restore);
 size_t exon_hip_stream_state_bytes(exon_hip_stream* st);
+
+// BGZF inputs of GPU-parsed scans are inflated on the GPU too (EXON_HIP_GPU_INFLATE=0: host threads inflate)
+static bool gpu_inflate_enabled() {
+  const char* v = getenv("EXON_HIP_GPU_INFLATE");
+  return !(v && v[0] == '0');
+}
+static bool wants_gpu_inflate(const exon_hip_scan_options* o, const char* path) {
+  return o->gpu_parse != 0 && gpu_inflate_enabled() && o->compression != EXON_HIP_COMPRESSION_NONE && exon::BgzfParallelSource::is_bgzf(path);
+}
 
 static exon::Dictionary* dict_of(exon_hip_scan* s, int col) {
   if (s->format == EXON_HIP_FORMAT_BCF && col == 0) return &s->bcf->chrom_dict;
@@ -83,6 +94,7 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         cfg.filter = rf;
         s->gpu_parse = o->gpu_parse != 0 && !rf.active;  // a pushed-down region filter stays on the host decoder
         cfg.defer_decode = s->gpu_parse;
+        if (s->gpu_parse && wants_gpu_inflate(o, path)) cfg.threads = 1;  // only the header is read on the host
         s->vcf.reset(new exon::VCFBatchReader(path, c, cfg));
         break;
       }
@@ -117,6 +129,7 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         cfg.batch_size = bs;
         s->gpu_parse = o->gpu_parse != 0;
         cfg.defer_decode = s->gpu_parse;
+        if (s->gpu_parse && wants_gpu_inflate(o, path)) cfg.threads = 1;
         s->fastq.reset(new exon::FASTQBatchReader(path, c, cfg));
         break;
       }
@@ -299,91 +312,288 @@ static size_t slab_bytes() {
   return slab;
 }
 
-// file -> pinned slab -> HBM -> GPU parser -> fused kernel.  A background thread fills the next pinned slab while
-// the current one is copied and parsed.  Returns 1 when a slab held rows the device could not decide: the caller
-// restores the state and re-decodes the file on the host.
-static int consume_vcf_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* rows_out) {
-  exon_hip_ctx* ctx = exon_hip_stream_ctx(st);
-  hipStream_t hs = (hipStream_t)exon_hip_stream_hip_stream(st);
-  std::string carry;
-  std::unique_ptr<exon::ByteSource> src = scan->vcf->take_stream(&carry);
-  if (!src) return fail(ctx, EXON_HIP_ESTATE, "scan already consumed");
-  const size_t slab = slab_bytes();
-  if (!scan->parser) {
-    std::vector<const char*> names;
-    for (const auto& c : scan->vcf->header.contigs) names.push_back(c.c_str());
-    int rc = exon_hip_vcf_parser_create(ctx, names.data(), (int32_t)names.size(),
-                                        scan->info_field_s.empty() ? nullptr : scan->info_field_s.c_str(),
-                                        (int64_t)slab + 65536, &scan->parser);
-    if (rc) return rc;
-    scan->parser_ctx = ctx;
+// ---- text slabs in HBM ----------------------------------------------------------------------------------------------
+// Feeds the GPU-side parsers with slabs of text resident in HBM.  The consumer reports how many bytes of a slab form
+// whole records (the device knows, the host never looks at the text); the tail is carried in front of the next slab.
+//   plain text : file -> pinned slab (8-thread pread, filled by a background thread behind a reserved gap) -> HBM
+//   BGZF       : compressed file -> pinned -> HBM as it is -> inflated ON THE GPU (inflate.hip) -> text; the carried tail
+//                moves device-to-device.  3-5x fewer bytes cross PCIe and no host core inflates anything.
+// next() returns 1 for "give up, decode on the host" (a corrupt block, a record larger than the gap).
+class GpuTextSource {
+ public:
+  GpuTextSource(exon_hip_ctx* ctx, hipStream_t hs, std::unique_ptr<exon::ByteSource> src, bool bgzf, uint64_t skip_first,
+                std::string carry)
+      : ctx_(ctx), hs_(hs), src_(std::move(src)), rd_(src_.get()), bgzf_(bgzf), skip_(skip_first), carry_(std::move(carry)) {
+    slab_ = slab_bytes();
+    if (bgzf_) {
+      comp_cap_ = std::max<size_t>(slab_ / 2, 1u << 20) + (1u << 17);  // compressed bytes per slab (+ a carried partial block)
+      text_cap_ = 4 * slab_;                                            // inflated bytes per slab
+    } else {
+      text_cap_ = slab_;
+    }
+    gap_ = std::max<size_t>(text_cap_ / 4, 1u << 20);  // room for the carried tail (< 1 record + 1 line)
   }
-  uint8_t* h_buf[2] = {nullptr, nullptr};
-  uint8_t* d_buf[2] = {nullptr, nullptr};
-  auto cleanup = [&]() {
+  ~GpuTextSource() {
+    if (reader_.joinable()) reader_.join();
     for (int k = 0; k < 2; ++k) {
-      if (h_buf[k]) hipHostFree(h_buf[k]);
-      if (d_buf[k]) hipFree(d_buf[k]);
+      if (h_buf_[k]) hipHostFree(h_buf_[k]);
+      if (d_comp_[k]) hipFree(d_comp_[k]);
+      if (d_text_[k]) hipFree(d_text_[k]);
     }
+    if (h_blocks_) hipHostFree(h_blocks_);
+    if (d_blocks_) hipFree(d_blocks_);
+  }
+  size_t max_text_bytes() const { return gap_ + text_cap_ + 64; }
+
+  int init() {
+    const size_t hcap = bgzf_ ? comp_cap_ + 4096 : gap_ + text_cap_ + 64;
+    for (int k = 0; k < 2; ++k) {
+      if (hipHostMalloc((void**)&h_buf_[k], hcap) != hipSuccess || hipMalloc((void**)&d_text_[k], gap_ + text_cap_ + 256) != hipSuccess ||
+          (bgzf_ && hipMalloc((void**)&d_comp_[k], comp_cap_ + 8192) != hipSuccess))
+        return fail(ctx_, EXON_HIP_ENOMEM, "slab buffers (%zu bytes of text) could not be allocated", text_cap_);
+    }
+    if (bgzf_) {
+      max_blocks_ = (int)(comp_cap_ / 26 + 16);  // an empty BGZF block is 28 bytes
+      if (hipHostMalloc((void**)&h_blocks_, (size_t)max_blocks_ * (sizeof(exon_hip_bgzf_block) + sizeof(int))) != hipSuccess ||
+          hipMalloc((void**)&d_blocks_, (size_t)max_blocks_ * (sizeof(exon_hip_bgzf_block) + sizeof(int))) != hipSuccess)
+        return fail(ctx_, EXON_HIP_ENOMEM, "BGZF block tables could not be allocated");
+    }
+    fill(0, &cur_);
+    k_ = 0;
+    return EXON_HIP_OK;
+  }
+
+  // Next slab: *d_text is 16-byte aligned.  *n == 0 with *final: end of input.
+  int next(const uint8_t** d_text, size_t* n, bool* final) {
+    if (reader_.joinable()) reader_.join();
+    if (started_) {
+      cur_ = nxt_;
+      nxt_ = Filled();
+      k_ ^= 1;
+    }
+    started_ = true;
+    if (cur_.err) {
+      try { std::rethrow_exception(cur_.err); } catch (const std::exception& e) { return fail(ctx_, EXON_HIP_EINVAL, "%s", e.what()); }
+    }
+    const int k = k_;
+    const bool more = !cur_.eof;
+    if (more) reader_ = std::thread([this, k] { fill(k ^ 1, &nxt_); });  // overlaps with everything the GPU does below
+    *final = !more;
+    size_t n_text = 0;
+    size_t front = 0;  // offset of the slab's first byte inside d_text_[k]
+    if (bgzf_) {
+      // [carry (already copied device-to-device by release()) | inflated blocks]; the very first slab instead starts
+      // `skip_` bytes into the inflated text (the header the host reader consumed), shifted so that byte is aligned
+      size_t base = carry_dev_;
+      if (skip_) base = (16 - (size_t)(skip_ & 15)) & 15;
+      if (cur_.n_blocks > 0) {
+        exon_hip_bgzf_block* hb = h_blocks_;
+        const size_t tb = (size_t)cur_.n_blocks * sizeof(exon_hip_bgzf_block);
+        memcpy(hb, block_tables_[k].data(), tb);
+        for (int i = 0; i < cur_.n_blocks; ++i) hb[i].out_offset += (uint32_t)base;
+        exon_hip_bgzf_block* db = d_blocks_;
+        int* dstat = reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(d_blocks_) + (size_t)max_blocks_ * sizeof(exon_hip_bgzf_block));
+        int* hstat = reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(h_blocks_) + (size_t)max_blocks_ * sizeof(exon_hip_bgzf_block));
+        HIP_TRY(ctx_, hipMemcpyAsync(d_comp_[k], h_buf_[k], cur_.n + 4096, hipMemcpyHostToDevice, hs_));
+        HIP_TRY(ctx_, hipMemcpyAsync(db, hb, tb, hipMemcpyHostToDevice, hs_));
+        HIP_TRY(ctx_, exon_bgzf_inflate_launch(hs_, d_comp_[k], db, cur_.n_blocks, d_text_[k], dstat, true));
+        HIP_TRY(ctx_, hipMemcpyAsync(hstat, dstat, (size_t)cur_.n_blocks * sizeof(int), hipMemcpyDeviceToHost, hs_));
+        HIP_TRY(ctx_, hipStreamSynchronize(hs_));
+        for (int i = 0; i < cur_.n_blocks; ++i)
+          if (hstat[i] != 0) {
+            fail(ctx_, EXON_HIP_EINVAL, "BGZF block: %s (decoding on the host instead)", exon_bgzf_status_name(hstat[i]));
+            return 1;
+          }
+      }
+      if (skip_) {
+        if (cur_.out_bytes < skip_) return 1;  // the header spans more than one slab: not worth handling here
+        front = base + (size_t)skip_;
+        n_text = cur_.out_bytes - (size_t)skip_;
+        skip_ = 0;
+      } else {
+        front = 0;
+        n_text = carry_dev_ + cur_.out_bytes;
+      }
+      if (!more && n_text > 0) {  // last line without a terminator
+        uint8_t lastb = 0;
+        HIP_TRY(ctx_, hipMemcpyAsync(&lastb, d_text_[k] + front + n_text - 1, 1, hipMemcpyDeviceToHost, hs_));
+        HIP_TRY(ctx_, hipStreamSynchronize(hs_));
+        if (lastb != '\n') {
+          HIP_TRY(ctx_, hipMemsetAsync(d_text_[k] + front + n_text, '\n', 1, hs_));
+          ++n_text;
+        }
+      }
+    } else {
+      if (carry_.size() > gap_) return 1;  // a record larger than the gap: host decoder
+      uint8_t* base = h_buf_[k] + gap_ - carry_.size();
+      memcpy(base, carry_.data(), carry_.size());
+      n_text = carry_.size() + cur_.n;
+      carry_.clear();
+      if (!more && n_text > 0 && base[n_text - 1] != '\n') base[n_text++] = '\n';  // last line without a terminator
+      if (n_text) HIP_TRY(ctx_, hipMemcpyAsync(d_text_[k], base, n_text, hipMemcpyHostToDevice, hs_));
+      h_base_ = base;
+    }
+    cur_front_ = front;
+    cur_text_ = n_text;
+    *d_text = d_text_[k] + front;
+    *n = n_text;
+    return EXON_HIP_OK;
+  }
+
+  // The consumer used `consumed` bytes of the slab returned last; the rest is carried into the next one.
+  int release(size_t consumed, bool final) {
+    const size_t tail = cur_text_ - consumed;
+    if (final) return tail == 0 ? EXON_HIP_OK : 1;  // a partial record at the end of the input: host decoder decides
+    if (tail > gap_) return 1;
+    if (bgzf_) {
+      // device-to-device, stream-ordered before the next slab's inflate (which appends right behind it)
+      if (tail) HIP_TRY(ctx_, hipMemcpyAsync(d_text_[k_ ^ 1], d_text_[k_] + cur_front_ + consumed, tail, hipMemcpyDeviceToDevice, hs_));
+      carry_dev_ = tail;
+    } else {
+      carry_.assign(reinterpret_cast<const char*>(h_base_) + consumed, tail);
+    }
+    return EXON_HIP_OK;
+  }
+
+ private:
+  struct Filled {
+    size_t n = 0;          // plain: fresh text bytes behind the gap; bgzf: compressed bytes of whole blocks
+    int n_blocks = 0;      // bgzf
+    size_t out_bytes = 0;  // bgzf: inflated size of those blocks
+    bool eof = false;
+    std::exception_ptr err;
   };
-  const size_t cap = slab + 65536;
-  for (int k = 0; k < 2; ++k)
-    if (hipHostMalloc((void**)&h_buf[k], cap) != hipSuccess || hipMalloc((void**)&d_buf[k], cap + 64) != hipSuccess) {
-      cleanup();
-      return fail(ctx, EXON_HIP_ENOMEM, "slab buffers (%zu bytes) could not be allocated", cap);
-    }
-  SlabReader rd(src.get());
-  auto read_some = [&](uint8_t* dst, size_t n) -> size_t { return rd.read(dst, n); };
-  // reader: fills h_buf[k] with [carry | fresh bytes], cuts at the last newline, keeps the tail as the next carry
-  struct Filled { size_t n = 0; bool eof = false; std::exception_ptr err; };
-  auto fill = [&](int k, Filled* f) {
+  // background thread: next chunk of the file into h_buf_[k]
+  void fill(int k, Filled* f) {
     try {
-      size_t have = carry.size();
-      if (have > cap) throw std::runtime_error("VCF line longer than the slab size");
-      memcpy(h_buf[k], carry.data(), have);
-      carry.clear();
-      for (;;) {
-        while (have < slab) {
-          const size_t got = read_some(h_buf[k] + have, slab - have);
-          if (got == 0) { f->eof = true; break; }
-          have += got;
-        }
-        size_t cut = have;
-        if (!f->eof) {
-          while (cut > 0 && h_buf[k][cut - 1] != '\n') --cut;
-          if (cut == 0) throw std::runtime_error("VCF line longer than the slab size");
-        } else if (have > 0 && h_buf[k][have - 1] != '\n') {
-          h_buf[k][have++] = '\n';  // last line without a terminator (room: cap > slab)
-          cut = have;
-        }
-        carry.assign(reinterpret_cast<const char*>(h_buf[k]) + cut, have - cut);
-        f->n = cut;
+      if (!bgzf_) {
+        f->n = rd_.read(h_buf_[k] + gap_, text_cap_);
+        f->eof = f->n < text_cap_;
         return;
       }
+      // [blocks left over from the previous chunk | fresh bytes]; whole blocks only, inflated size <= text_cap_
+      memcpy(h_buf_[k], left_.data(), left_.size());
+      size_t have = left_.size();
+      left_.clear();
+      if (!file_eof_) {
+        const size_t want = comp_cap_ - have;
+        const size_t got = rd_.read(h_buf_[k] + have, want);
+        file_eof_ = got < want;
+        have += got;
+      }
+      int32_t nb = 0;
+      size_t consumed = 0, out_bytes = 0;
+      // leave room for the text cap: scan, then keep the prefix that fits
+      if (exon_hip_bgzf_scan(h_buf_[k], have, 0, h_blocks_tmp(k), max_blocks_, &nb, &consumed, &out_bytes) != EXON_HIP_OK)
+        throw std::runtime_error(exon_hip_last_error(nullptr));
+      exon_hip_bgzf_block* hb = h_blocks_tmp(k);
+      if (out_bytes > text_cap_) {
+        int keep = 0;
+        while (keep < nb && (size_t)hb[keep].out_offset + hb[keep].out_size <= text_cap_) ++keep;
+        nb = keep;
+        out_bytes = nb ? (size_t)hb[nb - 1].out_offset + hb[nb - 1].out_size : 0;
+        consumed = nb ? (size_t)hb[nb - 1].comp_offset + hb[nb - 1].comp_size + 8 : 0;
+      }
+      if (nb == 0 && have > 0 && !(file_eof_ && consumed == have)) {
+        if (file_eof_) throw std::runtime_error("truncated BGZF block at the end of the file");
+        throw std::runtime_error("BGZF block larger than the slab");
+      }
+      left_.assign(reinterpret_cast<const char*>(h_buf_[k]) + consumed, have - consumed);
+      memset(h_buf_[k] + consumed, 0, 4096);  // readable padding behind the last block
+      f->n = consumed;
+      f->n_blocks = nb;
+      f->out_bytes = out_bytes;
+      f->eof = file_eof_ && left_.empty();
+      block_tables_[k].assign(hb, hb + nb);  // copied to the pinned table in next()
     } catch (...) {
       f->err = std::current_exception();
     }
-  };
-  int64_t total = 0;
-  int rc = EXON_HIP_OK;
-  Filled cur, nxt;
-  fill(0, &cur);
-  int k = 0;
-  while (rc == EXON_HIP_OK) {
-    if (cur.err) {
-      try { std::rethrow_exception(cur.err); } catch (const std::exception& e) { rc = fail(ctx, EXON_HIP_EINVAL, "%s", e.what()); }
-      break;
+  }
+  exon_hip_bgzf_block* h_blocks_tmp(int k) {
+    scan_tmp_[k].resize((size_t)max_blocks_);
+    return scan_tmp_[k].data();
+  }
+
+  exon_hip_ctx* ctx_;
+  hipStream_t hs_;
+  std::unique_ptr<exon::ByteSource> src_;
+  SlabReader rd_;
+  bool bgzf_;
+  uint64_t skip_;
+  std::string carry_;      // plain: carried tail (host)
+  size_t carry_dev_ = 0;   // bgzf: carried tail already at the front of the next text buffer
+  size_t slab_ = 0, comp_cap_ = 0, text_cap_ = 0, gap_ = 0;
+  uint8_t* h_buf_[2] = {nullptr, nullptr};
+  uint8_t* d_comp_[2] = {nullptr, nullptr};
+  uint8_t* d_text_[2] = {nullptr, nullptr};
+  exon_hip_bgzf_block* h_blocks_ = nullptr;  // pinned: table + status of the slab in flight
+  exon_hip_bgzf_block* d_blocks_ = nullptr;
+  std::vector<exon_hip_bgzf_block> scan_tmp_[2], block_tables_[2];
+  int max_blocks_ = 0;
+  std::string left_;
+  bool file_eof_ = false;
+  Filled cur_, nxt_;
+  std::thread reader_;
+  int k_ = 0;
+  bool started_ = false;
+  uint8_t* h_base_ = nullptr;
+  size_t cur_front_ = 0, cur_text_ = 0;
+};
+
+
+// VCF / FASTQ file -> text slabs in HBM (GpuTextSource) -> GPU parser -> fused kernel.  Returns 1 when the device could
+// not decide something: the caller restores the state and re-decodes the file on the host.
+static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* rows_out) {
+  exon_hip_ctx* ctx = exon_hip_stream_ctx(st);
+  hipStream_t hs = (hipStream_t)exon_hip_stream_hip_stream(st);
+  const bool is_vcf = scan->vcf != nullptr;
+  std::unique_ptr<GpuTextSource> src;
+  const bool bgzf = gpu_inflate_enabled() && scan->opt.compression != EXON_HIP_COMPRESSION_NONE &&
+                    exon::BgzfParallelSource::is_bgzf(scan->path) && (!is_vcf || scan->vcf->data_offset() >= 0);
+  try {
+    if (bgzf) {
+      const uint64_t skip = is_vcf ? (uint64_t)scan->vcf->data_offset() : 0;
+      std::unique_ptr<exon::ByteSource> raw(new exon::ByteReader(scan->path, exon::Compression::None));
+      src.reset(new GpuTextSource(ctx, hs, std::move(raw), true, skip, std::string()));
+    } else {
+      std::string carry;
+      std::unique_ptr<exon::ByteSource> text = is_vcf ? scan->vcf->take_stream(&carry) : scan->fastq->take_stream(&carry);
+      if (!text) return fail(ctx, EXON_HIP_ESTATE, "scan already consumed");
+      src.reset(new GpuTextSource(ctx, hs, std::move(text), false, 0, std::move(carry)));
     }
-    std::thread reader;
-    const bool more = !cur.eof;
-    if (more) reader = std::thread([&, k] { fill(k ^ 1, &nxt); });  // overlaps with the copy + parse below
-    if (cur.n > 0) {
-      hipError_t e = hipMemcpyAsync(d_buf[k], h_buf[k], cur.n, hipMemcpyHostToDevice, hs);
-      if (e != hipSuccess) rc = fail(ctx, EXON_HIP_EDEVICE, "H2D of a text slab: %s", hipGetErrorString(e));
+  } catch (const std::exception& e) {
+    return fail(ctx, EXON_HIP_EINVAL, "%s", e.what());
+  }
+  scan->gpu_inflated = bgzf;
+  int rc = src->init();
+  if (rc) return rc;
+  if (is_vcf && !scan->parser) {
+    std::vector<const char*> names;
+    for (const auto& c : scan->vcf->header.contigs) names.push_back(c.c_str());
+    rc = exon_hip_vcf_parser_create(ctx, names.data(), (int32_t)names.size(), scan->info_field_s.empty() ? nullptr : scan->info_field_s.c_str(),
+                                    (int64_t)src->max_text_bytes(), &scan->parser);
+    if (rc) return rc;
+    scan->parser_ctx = ctx;
+  }
+  if (!is_vcf && !scan->fq_parser) {
+    rc = exon_hip_fastq_parser_create(ctx, (int64_t)src->max_text_bytes(), &scan->fq_parser);
+    if (rc) return rc;
+  }
+  int64_t total = 0;
+  for (;;) {
+    const uint8_t* d_text = nullptr;
+    size_t n = 0;
+    bool final = false;
+    rc = src->next(&d_text, &n, &final);
+    if (rc) break;
+    size_t consumed = 0;
+    if (n > 0 && is_vcf) {
       exon_hip_vcf_columns cols;
-      if (!rc) rc = exon_hip_vcf_parser_parse(scan->parser, hs, d_buf[k], (int64_t)cur.n, &cols);
-      if (!rc && cols.n_undecided > 0) rc = 1;  // host fallback
-      if (!rc && cols.n_rows > 0) {
+      rc = exon_hip_vcf_parser_parse(scan->parser, hs, d_text, (int64_t)n, &cols);
+      if (!rc && cols.n_undecided > 0) rc = 1;
+      if (rc) break;
+      consumed = (size_t)cols.consumed_bytes;
+      if (cols.n_rows > 0) {
         exon_hip_column sc[5];
         memset(sc, 0, sizeof sc);
         sc[0].values = cols.chrom_id;
@@ -396,19 +606,29 @@ static int consume_vcf_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* ro
         sc[4].validity = cols.info_valid;
         for (auto& c : sc) c.length = cols.n_rows;
         rc = exon_hip_stream_launch_scan_columns(st, sc, 5, cols.n_rows);
-        // the parser's column buffers are reused by the next slab: the fused kernel must be done with them first
-        if (!rc && hipStreamSynchronize(hs) != hipSuccess) rc = fail(ctx, EXON_HIP_EDEVICE, "stream synchronize failed");
+        // the parser's column buffers are reused by the next slab; the kernel is stream-ordered before that parse
         total += cols.n_rows;
       }
+    } else if (n > 0) {
+      exon_hip_fastq_views v;
+      rc = exon_hip_fastq_parser_parse(scan->fq_parser, hs, d_text, (int64_t)n, final ? 1 : 0, &v);
+      if (!rc && v.n_undecided > 0) rc = 1;
+      if (!rc && !final && v.consumed_bytes == 0) rc = 1;  // not one whole record in a slab
+      if (rc) break;
+      consumed = (size_t)v.consumed_bytes;
+      if (v.n_reads > 0) {
+        rc = exon_hip_stream_launch_views(st, d_text, v);  // asynchronous: overlaps with preparing the next slab
+        total += v.n_reads;
+      }
     }
-    if (reader.joinable()) reader.join();
-    if (!more) break;
-    cur = nxt;
-    nxt = Filled();
-    k ^= 1;
+    if (rc) break;
+    if (!final && n > 0 && consumed == 0) { rc = 1; break; }  // a record larger than a slab
+    rc = src->release(consumed, final);
+    if (rc || final) break;
   }
-  cleanup();
-  if (rc == EXON_HIP_OK) {
+  if (hipStreamSynchronize(hs) != hipSuccess && rc == EXON_HIP_OK) rc = fail(ctx, EXON_HIP_EDEVICE, "stream synchronize failed");
+  src.reset();
+  if (rc == EXON_HIP_OK && is_vcf) {
     // FILTER dictionary -> scan (names in id order)
     int32_t nf = 0;
     std::vector<char> buf(1 << 20);
@@ -421,95 +641,7 @@ static int consume_vcf_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* ro
         o += scan->gpu_filter_dict.names.back().size() + 1;
       }
     }
-    scan->rows += total;
-    if (rows_out) *rows_out = total;
   }
-  return rc;
-}
-
-
-// FASTQ: file -> pinned slab -> HBM -> newline index + per-read views -> K5 over the views (no columns are built).
-// The device reports where the last whole record of a slab ends; the tail is carried in front of the next slab, which
-// the reader thread has meanwhile filled behind a reserved gap.  Returns 1 for "decode on the host instead".
-static int consume_fastq_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* rows_out) {
-  exon_hip_ctx* ctx = exon_hip_stream_ctx(st);
-  hipStream_t hs = (hipStream_t)exon_hip_stream_hip_stream(st);
-  std::string carry;
-  std::unique_ptr<exon::ByteSource> src = scan->fastq->take_stream(&carry);
-  if (!src) return fail(ctx, EXON_HIP_ESTATE, "scan already consumed");
-  const size_t slab = slab_bytes();
-  const size_t gap = std::max<size_t>(slab / 4, 1u << 20);  // room for the carried tail (< 1 record + 1 line)
-  const size_t cap = gap + slab + 64;
-  if (!scan->fq_parser) {
-    int rc = exon_hip_fastq_parser_create(ctx, (int64_t)cap, &scan->fq_parser);
-    if (rc) return rc;
-  }
-  uint8_t* h_buf[2] = {nullptr, nullptr};
-  uint8_t* d_buf[2] = {nullptr, nullptr};
-  auto cleanup = [&]() {
-    for (int k = 0; k < 2; ++k) {
-      if (h_buf[k]) hipHostFree(h_buf[k]);
-      if (d_buf[k]) hipFree(d_buf[k]);
-    }
-  };
-  for (int k = 0; k < 2; ++k)
-    if (hipHostMalloc((void**)&h_buf[k], cap) != hipSuccess || hipMalloc((void**)&d_buf[k], cap + 64) != hipSuccess) {
-      cleanup();
-      return fail(ctx, EXON_HIP_ENOMEM, "slab buffers (%zu bytes) could not be allocated", cap);
-    }
-  SlabReader rd(src.get());
-  struct Filled { size_t n = 0; bool eof = false; std::exception_ptr err; };
-  auto fill = [&](int k, Filled* f) {  // fresh bytes behind the gap
-    try {
-      f->n = rd.read(h_buf[k] + gap, slab);
-      f->eof = f->n < slab;
-    } catch (...) {
-      f->err = std::current_exception();
-    }
-  };
-  int64_t total = 0;
-  int rc = EXON_HIP_OK;
-  Filled cur, nxt;
-  fill(0, &cur);
-  int k = 0;
-  while (rc == EXON_HIP_OK) {
-    if (cur.err) {
-      try { std::rethrow_exception(cur.err); } catch (const std::exception& e) { rc = fail(ctx, EXON_HIP_EINVAL, "%s", e.what()); }
-      break;
-    }
-    if (carry.size() > gap) { rc = 1; break; }  // a record larger than the gap: host decoder
-    uint8_t* base = h_buf[k] + gap - carry.size();
-    memcpy(base, carry.data(), carry.size());
-    size_t n = carry.size() + cur.n;
-    carry.clear();
-    if (cur.eof && n > 0 && base[n - 1] != '\n') base[n++] = '\n';  // last line without a terminator
-    std::thread reader;
-    const bool more = !cur.eof;
-    if (more) reader = std::thread([&, k] { fill(k ^ 1, &nxt); });  // overlaps with the copy + index + histogram
-    if (n > 0) {
-      hipError_t e = hipMemcpyAsync(d_buf[k], base, n, hipMemcpyHostToDevice, hs);
-      if (e != hipSuccess) rc = fail(ctx, EXON_HIP_EDEVICE, "H2D of a text slab: %s", hipGetErrorString(e));
-      exon_hip_fastq_views v;
-      if (!rc) rc = exon_hip_fastq_parser_parse(scan->fq_parser, hs, d_buf[k], (int64_t)n, more ? 0 : 1, &v);
-      if (!rc && v.n_undecided > 0) rc = 1;
-      if (!rc && more && v.consumed_bytes == 0) rc = 1;  // not one whole record in a slab
-      if (!rc) {
-        carry.assign(reinterpret_cast<const char*>(base) + v.consumed_bytes, n - (size_t)v.consumed_bytes);
-        if (!more && !carry.empty()) rc = 1;
-      }
-      if (!rc && v.n_reads > 0) {
-        rc = exon_hip_stream_launch_views(st, d_buf[k], v);  // asynchronous: overlaps with preparing the next slab
-        total += v.n_reads;
-      }
-    }
-    if (reader.joinable()) reader.join();
-    if (!more) break;
-    cur = nxt;
-    nxt = Filled();
-    k ^= 1;
-  }
-  if (hipStreamSynchronize(hs) != hipSuccess && rc == EXON_HIP_OK) rc = fail(ctx, EXON_HIP_EDEVICE, "stream synchronize failed");
-  cleanup();
   if (rc == EXON_HIP_OK) {
     scan->rows += total;
     if (rows_out) *rows_out = total;
@@ -528,7 +660,7 @@ int exon_hip_stream_consume_scan(exon_hip_stream* st, exon_hip_scan* scan, int64
     const size_t sb = exon_hip_stream_state_bytes(st);
     if (hipMalloc(&snap, sb ? sb : 16) != hipSuccess) return fail(ctx, EXON_HIP_ENOMEM, "state snapshot allocation failed");
     int rc = exon_hip_stream_state_copy(st, snap, false);
-    if (!rc) rc = consume_fastq_gpu(st, scan, rows);
+    if (!rc) rc = consume_text_gpu(st, scan, rows);
     if (rc == 1) {  // restore and re-decode on the host
       rc = exon_hip_stream_state_copy(st, snap, true);
       hipStreamSynchronize((hipStream_t)exon_hip_stream_hip_stream(st));
@@ -538,6 +670,7 @@ int exon_hip_stream_consume_scan(exon_hip_stream* st, exon_hip_scan* scan, int64
       try {
         exon::FASTQConfig cfg = scan->fastq->config();
         cfg.defer_decode = false;
+        cfg.threads = 0;
         const exon::Compression c = scan->opt.compression == EXON_HIP_COMPRESSION_GZIP   ? exon::Compression::Gzip
                                     : scan->opt.compression == EXON_HIP_COMPRESSION_NONE ? exon::Compression::None
                                                                                          : exon::Compression::Auto;
@@ -557,7 +690,7 @@ int exon_hip_stream_consume_scan(exon_hip_stream* st, exon_hip_scan* scan, int64
     const size_t sb = exon_hip_stream_state_bytes(st);
     if (hipMalloc(&snap, sb ? sb : 16) != hipSuccess) return fail(ctx, EXON_HIP_ENOMEM, "state snapshot allocation failed");
     int rc = exon_hip_stream_state_copy(st, snap, false);
-    if (!rc) rc = consume_vcf_gpu(st, scan, rows);
+    if (!rc) rc = consume_text_gpu(st, scan, rows);
     if (rc == 1) {
       rc = exon_hip_stream_state_copy(st, snap, true);
       hipStreamSynchronize((hipStream_t)exon_hip_stream_hip_stream(st));
@@ -571,6 +704,7 @@ int exon_hip_stream_consume_scan(exon_hip_stream* st, exon_hip_scan* scan, int64
       try {
         exon::VCFConfig cfg = scan->vcf->config();
         cfg.defer_decode = false;
+        cfg.threads = 0;
         const exon::Compression c = scan->opt.compression == EXON_HIP_COMPRESSION_GZIP   ? exon::Compression::Gzip
                                     : scan->opt.compression == EXON_HIP_COMPRESSION_NONE ? exon::Compression::None
                                                                                          : exon::Compression::Auto;

@@ -143,6 +143,21 @@ class Context:
         self._check(self.lib.exon_hip_qual_pos_hist_views(self.h, stream, ptr(d_text), ptr(starts), ptr(ends), n_reads, lmax,
                                                           d_hist.ptr))
 
+    def bgzf_inflate(self, data, verify_crc=True, stream=None):
+        """Test / tool helper: BGZF bytes -> inflated bytes through the GPU (exon_hip_bgzf_inflate).  Returns
+        (inflated uint8 array, seconds spent in the device call)."""
+        import time
+        blocks, n, consumed, out_bytes = bgzf_scan(data)
+        comp = np.frombuffer(data, np.uint8)[:consumed]
+        d_comp = self.to_device(np.concatenate([comp, np.zeros(4096 + (-len(comp)) % 4, np.uint8)]))
+        d_out = self.empty(np.uint8, out_bytes + 64)
+        bad = C.c_int32(-1)
+        t = time.perf_counter()
+        self._check(self.lib.exon_hip_bgzf_inflate(self.h, stream, d_comp.ptr, blocks, n, d_out.ptr, 1 if verify_crc else 0,
+                                                   C.byref(bad)))
+        dt = time.perf_counter() - t
+        return d_out.to_host()[:out_bytes], dt
+
     # -- synthetic inputs in HBM ------------------------------------------------------------------
     def gen_c2(self, seed, n_total, lo=0, hi=None, stream=None):
         hi = n_total if hi is None else hi
@@ -192,6 +207,23 @@ class Context:
     def plan_qual_pos_hist(self, lmax, columns=(0,)):
         d = L.PlanDesc(kind=L.PLAN_QUAL_POS_HIST, lmax=lmax)
         return Plan(self, d, columns)
+
+
+def bgzf_scan(data, out_base=0):
+    """Walk the BGZF block headers of `data` (bytes / uint8 array) -> (ctypes BgzfBlock array, n, consumed, out_bytes).
+    Host-only helper of the C ABI (exon_hip_bgzf_scan)."""
+    lib = L.load()
+    buf = np.frombuffer(data, np.uint8)
+    n, consumed, out_bytes = C.c_int32(), C.c_size_t(), C.c_size_t()
+    ptr = buf.ctypes.data if len(buf) else None
+    rc = lib.exon_hip_bgzf_scan(ptr, len(buf), out_base, None, 1 << 30, C.byref(n), C.byref(consumed), C.byref(out_bytes))
+    if rc:
+        raise ExonHipError(rc, lib.exon_hip_last_error(None).decode())
+    blocks = (L.BgzfBlock * max(n.value, 1))()
+    rc = lib.exon_hip_bgzf_scan(ptr, len(buf), out_base, blocks, n.value, C.byref(n), C.byref(consumed), C.byref(out_bytes))
+    if rc:
+        raise ExonHipError(rc, lib.exon_hip_last_error(None).decode())
+    return blocks, n.value, consumed.value, out_bytes.value
 
 
 def parse_region(region):

@@ -329,15 +329,40 @@ typedef struct exon_hip_vcf_columns {
   int32_t* filter_id;
   float* info;         /* NULL without an INFO field */
   uint8_t* info_valid;
+  int64_t consumed_bytes; /* bytes up to and including the last newline; a trailing partial line is not parsed */
 } exon_hip_vcf_columns;
 int exon_hip_vcf_parser_create(exon_hip_ctx* ctx, const char* const* contig_names, int32_t n_contigs,
                                const char* info_field, int64_t max_slab_bytes, exon_hip_vcf_parser** out);
-/* d_text: a slab of complete '\n'-terminated data lines in HBM, 16-byte aligned.  Synchronises `stream`. */
+/* d_text: a slab of '\n'-terminated data lines in HBM, 16-byte aligned (a trailing partial line is left to the
+ * caller: see consumed_bytes).  Synchronises `stream`. */
 int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* parser, void* stream, const uint8_t* d_text, int64_t n_bytes,
                               exon_hip_vcf_columns* cols);
 /* FILTER dictionary discovered so far, '\0'-separated in id order ("" = the empty list) */
 int exon_hip_vcf_parser_filters(exon_hip_vcf_parser* parser, char* buf, size_t cap, int32_t* n_filters);
 int exon_hip_vcf_parser_destroy(exon_hip_vcf_parser* parser);
+
+/* ---- BGZF inflate on the GPU (compressed blocks in HBM -> inflated bytes in HBM) ------------------------------------
+ * Replaces noodles bgzf::AsyncReader around the byte stream (exon-core/src/datasources/vcf/file_opener/
+ * unindex_file_opener.rs:62-70, fastq/file_opener.rs:69-75, streaming_bgzf.rs:56-64): RFC 1951 DEFLATE in RFC 1952
+ * members carrying the BGZF "BC" extra field (SAM specification 4.1).  Blocks are independent: one wavefront each. */
+typedef struct exon_hip_bgzf_block {
+  uint32_t comp_offset; /* of the raw DEFLATE data inside the compressed buffer */
+  uint32_t comp_size;
+  uint32_t out_offset;  /* where the inflated bytes go inside the output buffer */
+  uint32_t out_size;    /* ISIZE */
+  uint32_t crc32;
+  uint32_t reserved;
+} exon_hip_bgzf_block;
+/* Host: walk the block headers of `data[0..n)`.  Fills up to `cap` entries (blocks may be NULL to count only);
+ * out_offset starts at `out_base` and advances by ISIZE.  *consumed = bytes of whole blocks walked (a trailing
+ * partial block is left for the next call), *out_bytes = sum of ISIZE. */
+int exon_hip_bgzf_scan(const uint8_t* data, size_t n, size_t out_base, exon_hip_bgzf_block* blocks, int32_t cap,
+                       int32_t* n_blocks, size_t* consumed, size_t* out_bytes);
+/* Device: inflate `n_blocks` blocks (table in host memory) from d_comp (4-byte aligned, with >= 4 KiB of readable
+ * padding behind the last block) into d_out (4-byte aligned); verify_crc != 0 also checks every block's CRC-32.  Synchronises
+ * `stream`.  A corrupt block -> EXON_HIP_EINVAL and *first_bad_block (else -1): inflate on the host instead. */
+int exon_hip_bgzf_inflate(exon_hip_ctx* ctx, void* stream, const uint8_t* d_comp, const exon_hip_bgzf_block* blocks,
+                          int32_t n_blocks, uint8_t* d_out, int32_t verify_crc, int32_t* first_bad_block);
 
 /* ---- FASTQ record splitting on the GPU (raw text in HBM -> per-read views into that text) ---------------------
  * Record rules of exon-fastq/src/batch_reader.rs:63-82 (noodles fastq: '@' definition line, sequence line, '+'

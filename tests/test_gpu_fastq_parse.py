@@ -120,6 +120,21 @@ def test_fastq_file_to_gpu_pipeline_equals_host_decode(ctx, tmp_path, monkeypatc
     assert rows_g == rows_h == n and np.array_equal(gpu, host)
 
 
+@pytest.mark.parametrize("ragged", [0, 1])
+def test_fastq_bgzf_is_inflated_on_the_gpu(ctx, tmp_path, monkeypatch, ragged):
+    n = 200_000
+    path = tmp_path / "syn.fastq"
+    subprocess.check_call([GEN, "fastq", str(n), str(path), "150", str(ragged)])
+    gz = tmp_path / "syn.fastq.gz"
+    subprocess.check_call([os.path.join(ROOT, "tools", "bin", "bgzip"), str(path), str(gz), "6"])
+    monkeypatch.setenv("EXON_HIP_GPU_PARSE_SLAB_MB", "4")
+    rows_g, gpu = _hist_through_scan(ctx, gz, True, 256)
+    rows_p, plain = _hist_through_scan(ctx, path, True, 256)
+    rows_h, host = _hist_through_scan(ctx, gz, False, 256)
+    assert rows_g == rows_p == rows_h == n
+    assert np.array_equal(gpu, plain) and np.array_equal(gpu, host)
+
+
 def test_fastq_gpu_pipeline_reference_fixtures(ctx, oracle):
     for name, comp in (("test.fastq", None), ("test_bgzip.fastq.gz", "gzip")):
         path = os.path.join(FX, "fastq", name)

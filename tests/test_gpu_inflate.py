@@ -1,0 +1,136 @@
+"""BGZF inflate on the GPU (exon_hip_bgzf_inflate) against zlib: byte-identical output for every DEFLATE block type,
+CRC-32 verification, and loud failure on corrupt input."""
+import gzip
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import exon_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FX = os.path.join(ROOT, "tests", "golden", "ref_fixtures")
+
+
+def bgzf_block(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, extra=b""):
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    cdata = co.compress(data) + co.flush()
+    xlen = 6 + len(extra)
+    bsize = 12 + xlen + len(cdata) + 8
+    assert bsize <= 65536
+    head = b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", xlen) + extra + b"BC\x02\0" + struct.pack("<H", bsize - 1)
+    return head + cdata + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data))
+
+
+def bgzf_file(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, chunk=65280):
+    out = [bgzf_block(data[i:i + chunk], level, strategy) for i in range(0, len(data), chunk)]
+    out.append(bgzf_block(b""))  # EOF marker
+    return b"".join(out)
+
+
+def vcf_like(n, seed=3):
+    rng = np.random.default_rng(seed)
+    rows = []
+    for i in range(n):
+        rows.append(f"{1 + i % 22}\t{1000 + i * 37}\trs{rng.integers(1, 10**7)}\t{'ACGT'[i % 4]}\t{'TGCA'[i % 4]}\t"
+                    f"{rng.integers(0, 9999) / 10}\t{'PASS' if i % 5 else 'q10;s50'}\tAF={rng.random():.6f};DP={rng.integers(1, 500)}\n")
+    return "".join(rows).encode()
+
+
+def test_bgzf_scan_host():
+    data = vcf_like(3000)
+    f = bgzf_file(data, chunk=30000)
+    blocks, n, consumed, out_bytes = exon_amd.bgzf_scan(f)
+    assert n == (len(data) + 29999) // 30000 + 1 and consumed == len(f) and out_bytes == len(data)
+    assert blocks[0].comp_offset == 18 and blocks[0].out_offset == 0 and blocks[1].out_offset == 30000
+    assert blocks[n - 1].out_size == 0
+    # a trailing partial block is left for the next call; an extra subfield before BC is skipped
+    _, n2, consumed2, _ = exon_amd.bgzf_scan(f[:-5])
+    assert n2 == n - 1 and consumed2 == len(f) - 28
+    g = bgzf_block(b"hello world", extra=b"XY\x03\0abc")
+    blocks, n, consumed, out_bytes = exon_amd.bgzf_scan(g)
+    assert n == 1 and consumed == len(g) and out_bytes == 11 and blocks[0].comp_offset == 12 + 13
+    with pytest.raises(exon_amd.ExonHipError):
+        exon_amd.bgzf_scan(b"\x1f\x8b\x08\x00" + bytes(40))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["vcf/index.vcf.gz", "fastq/test_bgzip.fastq.gz", "bam/test.bam", "bcf/index.bcf"])
+def test_gpu_inflate_reference_fixtures(ctx, name):
+    raw = open(os.path.join(FX, name), "rb").read()
+    want = gzip.decompress(raw)
+    got, _ = ctx.bgzf_inflate(raw)
+    assert got.tobytes() == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["text", "random", "zeros", "runs", "short"])
+@pytest.mark.parametrize("level,strategy", [(6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY),
+                                            (0, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY),
+                                            (6, zlib.Z_RLE)])
+def test_gpu_inflate_equals_zlib(ctx, kind, level, strategy):
+    rng = np.random.default_rng(5)
+    if kind == "text":
+        data = vcf_like(20000)
+    elif kind == "random":
+        data = rng.integers(0, 256, 400_000, dtype=np.uint8).tobytes()
+    elif kind == "zeros":
+        data = bytes(300_000)
+    elif kind == "runs":  # overlapping copies with every small distance, long matches, sparse literals
+        parts = []
+        for d in range(1, 40):
+            unit = rng.integers(65, 91, d, dtype=np.uint8).tobytes()
+            parts.append(unit * (700 // d + 1))
+        data = b"".join(parts) * 8
+    else:
+        data = b"".join(bytes([65 + i % 26]) * (i % 7) for i in range(200))
+    chunk = 65280 if level else 60000
+    if kind == "short":  # blocks of 0..40 bytes, including empty ones in the middle
+        f = b"".join(bgzf_block(data[i:i + (i % 41)], level, strategy) for i in range(0, len(data), 41))
+        want = b"".join(data[i:i + (i % 41)] for i in range(0, len(data), 41))
+    else:
+        f = bgzf_file(data, level, strategy, chunk)
+        want = data
+    got, _ = ctx.bgzf_inflate(f)
+    assert got.tobytes() == want
+
+
+@pytest.mark.gpu
+def test_gpu_inflate_multi_deflate_blocks_per_member(ctx):
+    """Z_FULL_FLUSH / Z_SYNC_FLUSH inside one member: several DEFLATE blocks (stored, empty, dynamic) back to back."""
+    data = vcf_like(600)
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    cdata = b""
+    for i in range(0, len(data), 5000):
+        cdata += co.compress(data[i:i + 5000]) + co.flush(zlib.Z_SYNC_FLUSH if (i // 5000) % 2 else zlib.Z_FULL_FLUSH)
+    cdata += co.flush()
+    bsize = 18 + len(cdata) + 8
+    f = (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", bsize - 1) + cdata +
+         struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+    got, _ = ctx.bgzf_inflate(f)
+    assert got.tobytes() == data
+
+
+@pytest.mark.gpu
+def test_gpu_inflate_reports_corruption(ctx):
+    data = vcf_like(2000)
+    f = bytearray(bgzf_file(data, chunk=20000))
+    blocks, n, _, _ = exon_amd.bgzf_scan(bytes(f))
+    bad_crc = bytearray(f)
+    crc_at = blocks[1].comp_offset + blocks[1].comp_size
+    bad_crc[crc_at] ^= 0x01
+    with pytest.raises(exon_amd.ExonHipError, match="block 1: CRC-32 mismatch"):
+        ctx.bgzf_inflate(bytes(bad_crc))
+    got, _ = ctx.bgzf_inflate(bytes(bad_crc), verify_crc=False)  # the data itself is intact
+    assert got.tobytes() == data
+    flipped = bytearray(f)
+    flipped[blocks[2].comp_offset + blocks[2].comp_size // 2] ^= 0x55
+    with pytest.raises(exon_amd.ExonHipError, match="block 2"):
+        ctx.bgzf_inflate(bytes(flipped))
+    wrong_size = bytearray(f)
+    at = blocks[0].comp_offset + blocks[0].comp_size + 4
+    wrong_size[at:at + 4] = struct.pack("<I", blocks[0].out_size - 1)
+    with pytest.raises(exon_amd.ExonHipError, match="block 0"):
+        ctx.bgzf_inflate(bytes(wrong_size))

@@ -142,6 +142,58 @@ def test_file_to_gpu_parse_pipeline_equals_host_decode(ctx, tmp_path, monkeypatc
         assert gpu[k][2] == pytest.approx(host[k][2], rel=1e-12)
 
 
+@pytest.mark.parametrize("slab_mb", ["4", "64"])
+def test_bgzf_file_is_inflated_and_parsed_on_the_gpu(ctx, tmp_path, monkeypatch, slab_mb):
+    """file.vcf.gz (BGZF): compressed blocks -> HBM -> GPU inflate -> GPU parse -> K4, equal to the host-inflate + host-decode
+    path and to the plain-text twin; lines straddle BGZF blocks and slabs (carried device-to-device)."""
+    gen = os.path.join(ROOT, "tools", "bin", "gen_text")
+    bgzip = os.path.join(ROOT, "tools", "bin", "bgzip")
+    n = 1_500_000
+    path = tmp_path / "syn.vcf"
+    subprocess.check_call([gen, "vcf", str(n), str(path)])
+    gz = tmp_path / "syn.vcf.gz"
+    subprocess.check_call([bgzip, str(path), str(gz), "6"])
+    monkeypatch.setenv("EXON_HIP_GPU_PARSE_SLAB_MB", slab_mb)
+    rows_g, gpu = _k4_through_scan(ctx, gz, True)
+    rows_p, plain = _k4_through_scan(ctx, path, True)
+    monkeypatch.setenv("EXON_HIP_GPU_INFLATE", "0")  # host threads inflate, GPU parses
+    rows_i, hostinf = _k4_through_scan(ctx, gz, True)
+    rows_h, host = _k4_through_scan(ctx, gz, False)
+    assert rows_g == rows_p == rows_i == rows_h == n
+    for other in (plain, hostinf, host):
+        assert gpu.keys() == other.keys()
+        for k in other:
+            assert gpu[k][:2] == other[k][:2]
+            assert gpu[k][2] == pytest.approx(other[k][2], rel=1e-12)
+
+
+def test_bgzf_reference_fixture_through_the_gpu(ctx):
+    """index.vcf.gz of the reference (621 records) through GPU inflate + GPU parse."""
+    path = os.path.join(FX, "vcf", "index.vcf.gz")
+    scan = exon_amd.Scan(path, "vcf", gpu_parse=True)
+    plan = ctx.plan_region_count(scan.dictionary(0).index("1"), 1, None, columns=(0, 1))
+    st = plan.open()
+    rows = st.consume(scan)
+    counts, _ = st.finish()
+    st.close(); plan.close(); scan.close()
+    assert rows == 621 and int(counts[0]) == 191  # exon-core/src/session_context/exon_context_ext.rs / slt pins
+
+
+def test_corrupt_bgzf_block_falls_back_to_the_host_error(ctx, tmp_path):
+    """A flipped byte inside a block: the device reports the block, the host decoder is asked instead and raises."""
+    gen = os.path.join(ROOT, "tools", "bin", "gen_text")
+    bgzip = os.path.join(ROOT, "tools", "bin", "bgzip")
+    path = tmp_path / "c.vcf"
+    subprocess.check_call([gen, "vcf", "300000", str(path)])
+    gz = tmp_path / "c.vcf.gz"
+    subprocess.check_call([bgzip, str(path), str(gz), "6"])
+    raw = bytearray(open(gz, "rb").read())
+    raw[len(raw) // 2] ^= 0x5A
+    open(gz, "wb").write(bytes(raw))
+    with pytest.raises(exon_amd.ExonHipError):
+        _k4_through_scan(ctx, gz, True)
+
+
 def test_gpu_parse_falls_back_to_host_on_undecidable_rows(ctx, tmp_path):
     """A contig that is not in the header makes the device give up on the slab: the state is restored and the file is
     re-decoded on the host, so the answer is still the host decoder's."""
