@@ -122,6 +122,7 @@ int exon_hip_ctx_destroy(exon_hip_ctx* ctx) {
   if (!ctx) return EXON_HIP_OK;
   hipSetDevice(ctx->device);
   hipDeviceSynchronize();
+  exon_hip_release_ctx_caches(ctx);
   for (auto& kv : ctx->workspaces) {
     if (kv.second.partials) hipFree(kv.second.partials);
     if (kv.second.status) hipFree(kv.second.status);

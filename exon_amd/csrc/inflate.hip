@@ -309,8 +309,7 @@ __device__ __noinline__ int decode_long(int which, uint32_t bits) {
 
 // Decode one symbol (wave-uniform).  Returns -1 for a code that does not exist.
 template <int RING, int WHICH>
-__device__ __forceinline__ int decode_symbol(BitReader& br) {
-  WaveLds* L = wave_lds<RING>();
+__device__ __forceinline__ int decode_symbol(BitReader& br, const WaveLds* L) {
   const uint16_t* lut = WHICH == CODE_LIT ? L->lit_lut : WHICH == CODE_DIST ? L->dist_lut : L->cl.cl_lut;
   constexpr int BITS = WHICH == CODE_LIT ? LIT_BITS : WHICH == CODE_DIST ? DIST_BITS : CL_BITS;
   const int e = uni((int)lut[br.peek(BITS)]);
@@ -360,6 +359,41 @@ __device__ __forceinline__ void drain_to(Out& o, uint32_t limit) {
   }
 }
 
+// Rare paths of the symbol loop live in their own functions so that the hot loop stays small for the compiler
+// (fewer live values and exits = fewer scalar copies per iteration).
+template <int RING>
+__device__ __noinline__ uint32_t drain_rows(uint8_t* out, uint32_t drained, uint32_t limit) {
+  Out o{unip(out), 0, 0, 0, uniu(drained)};
+  drain_to<RING>(o, uniu(limit));
+  return o.drained;
+}
+template <int RING>
+__device__ __noinline__ void copy_overlapping(uint32_t pos, uint32_t d, uint32_t len) {
+  constexpr uint32_t M = RING - 1;
+  pos = uniu(pos);
+  d = uniu(d);
+  len = uniu(len);
+  uint8_t* ring = wave_ring<RING>();
+  const uint32_t lane = lane_id();
+  // 64 bytes per step read strictly older bytes (modular source), then write
+  for (uint32_t j0 = 0; j0 < len; j0 += 64) {
+    const uint32_t j = j0 + lane;
+    const uint8_t v = ring[(pos - d + j % d) & M];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (j < len) ring[(pos + j) & M] = v;
+  }
+}
+template <int RING>
+__device__ __noinline__ void copy_far(const uint8_t* out, uint32_t pos, uint32_t d, uint32_t len) {
+  constexpr uint32_t M = RING - 1;
+  out = unip(out);
+  pos = uniu(pos);
+  d = uniu(d);
+  len = uniu(len);
+  uint8_t* ring = wave_ring<RING>();
+  for (uint32_t j = lane_id(); j < len; j += 64) ring[(pos + j) & M] = out[pos - d + j];
+}
+
 struct SymResult {
   BitReader br;
   Out o;
@@ -377,60 +411,54 @@ __device__ __noinline__ SymResult decode_symbols(BitReader br, Out o) {
   br.make_uniform();
   o.make_uniform();
   uint8_t* ring = wave_ring<RING>();
+  const WaveLds* L = wave_lds<RING>();
   const uint32_t lane = lane_id();
   int err = INF_OK;
   for (;;) {
     br.refill();
-    int s = decode_symbol<RING, CODE_LIT>(br);
+    int s = decode_symbol<RING, CODE_LIT>(br, L);
     if (s < 256) {
-      if (s < 0) { err = INF_BAD_CODE; break; }
+      if (__builtin_expect(s < 0, 0)) { err = INF_BAD_CODE; break; }
       ring[o.pos & M] = (uint8_t)s;  // every lane stores the same byte
       ++o.pos;
-      if ((o.pos & 255u) == 0) {
-        if (o.pos > o.end || br.overrun()) { err = br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN; break; }
-        drain_to<RING>(o, o.pos);
+      if (__builtin_expect((o.pos & 255u) == 0, 0)) {
+        if (o.pos > o.end || br.overrun()) { err = INF_OUTPUT_OVERRUN; break; }
+        o.drained = uniu(drain_rows<RING>(o.out, o.drained, o.pos));
       }
       continue;
     }
     if (s == 256) break;
     s -= 257;
-    if (s >= 29) { err = INF_BAD_CODE; break; }
+    if (__builtin_expect(s >= 29, 0)) { err = INF_BAD_CODE; break; }
     uint32_t len;
     int ext;
     length_code(s, &len, &ext);
     len += br.take(ext);
     br.refill();
-    const int ds = decode_symbol<RING, CODE_DIST>(br);
-    if (ds < 0 || ds >= 30) { err = INF_BAD_CODE; break; }
+    const int ds = decode_symbol<RING, CODE_DIST>(br, L);
+    if (__builtin_expect(ds < 0 || ds >= 30, 0)) { err = INF_BAD_CODE; break; }
     uint32_t d;
     distance_code(ds, &d, &ext);
     d += br.take(ext);
-    if (d > o.pos - o.begin) { err = INF_BAD_DISTANCE; break; }
+    if (__builtin_expect(d > o.pos - o.begin, 0)) { err = INF_BAD_DISTANCE; break; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (d <= NEAR) {
-      if (d >= len) {
-        for (uint32_t j = lane; j < len; j += 64) ring[(o.pos + j) & M] = ring[(o.pos - d + j) & M];
-      } else {
-        // overlapping run: 64 bytes per step read strictly older bytes (modular source), then write
-        for (uint32_t j0 = 0; j0 < len; j0 += 64) {
-          const uint32_t j = j0 + lane;
-          const uint8_t v = ring[(o.pos - d + j % d) & M];
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          if (j < len) ring[(o.pos + j) & M] = v;
-        }
-      }
+    if (d <= NEAR && d >= len) {
+      for (uint32_t j = lane; j < len; j += 64) ring[(o.pos + j) & M] = ring[(o.pos - d + j) & M];
+    } else if (d <= NEAR) {
+      copy_overlapping<RING>(o.pos, d, len);
     } else {
       // far: d > NEAR >= 258 + 255, so the source ends below `drained` (pos - drained < 256): it is in HBM already
-      for (uint32_t j = lane; j < len; j += 64) ring[(o.pos + j) & M] = o.out[o.pos - d + j];
+      copy_far<RING>(o.out, o.pos, d, len);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const uint32_t npos = o.pos + len;
-    if ((o.pos ^ npos) >> 8) {  // crossed a 256-byte row
-      if (npos > o.end || br.overrun()) { err = br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN; break; }
-      drain_to<RING>(o, npos & ~255u);
+    if (__builtin_expect(((o.pos ^ npos) >> 8) != 0, 0)) {  // crossed a 256-byte row
+      if (npos > o.end || br.overrun()) { err = INF_OUTPUT_OVERRUN; break; }
+      o.drained = uniu(drain_rows<RING>(o.out, o.drained, npos & ~255u));
     }
     o.pos = npos;
   }
+  if (err == INF_OUTPUT_OVERRUN && br.overrun()) err = INF_INPUT_OVERRUN;
   return SymResult{br, o, err};
 }
 
@@ -503,7 +531,7 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(const uint8_t* __res
       const int total = hlit + hdist;
       while (i < total) {
         br.refill();
-        const int s = decode_symbol<RING, CODE_CL>(br);
+        const int s = decode_symbol<RING, CODE_CL>(br, L);
         if (s < 0) { err = INF_BAD_CODE; break; }
         if (s < 16) {
           L->lens[i++] = (uint8_t)s;

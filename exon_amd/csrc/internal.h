@@ -39,3 +39,6 @@ int get_workspace(exon_hip_ctx* ctx, hipStream_t s, size_t words, exon::Workspac
 hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const exon_hip_bgzf_block* d_blocks, int n_blocks,
                                     uint8_t* d_out, int* d_status, bool verify_crc);
 const char* exon_bgzf_status_name(int code);
+
+// scan.cpp: slab buffers kept per ctx between scans
+void exon_hip_release_ctx_caches(exon_hip_ctx* ctx);

@@ -1,9 +1,12 @@
 // scan.cpp -- C ABI of the native decoders (host/formats.h): exon_hip_scan_*.
+#include <time.h>
 #include <unistd.h>
 
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -319,6 +322,40 @@ static size_t slab_bytes() {
 //   BGZF       : compressed file -> pinned -> HBM as it is -> inflated ON THE GPU (inflate.hip) -> text; the carried tail
 //                moves device-to-device.  3-5x fewer bytes cross PCIe and no host core inflates anything.
 // next() returns 1 for "give up, decode on the host" (a corrupt block, a record larger than the gap).
+// The slab buffers are large (pinned host + HBM); allocating and freeing them costs tens of milliseconds, so one set per
+// ctx is kept between scans (released by exon_hip_ctx_destroy).
+struct SlabBuffers {
+  bool bgzf = false;
+  size_t hcap = 0, tcap = 0, ccap = 0;
+  int max_blocks = 0;
+  uint8_t* h_buf[2] = {nullptr, nullptr};
+  uint8_t* d_comp[2] = {nullptr, nullptr};
+  uint8_t* d_text[2] = {nullptr, nullptr};
+  exon_hip_bgzf_block* h_blocks = nullptr;
+  exon_hip_bgzf_block* d_blocks = nullptr;
+  void free_all() {
+    for (int k = 0; k < 2; ++k) {
+      if (h_buf[k]) hipHostFree(h_buf[k]);
+      if (d_comp[k]) hipFree(d_comp[k]);
+      if (d_text[k]) hipFree(d_text[k]);
+      h_buf[k] = d_comp[k] = d_text[k] = nullptr;
+    }
+    if (h_blocks) hipHostFree(h_blocks);
+    if (d_blocks) hipFree(d_blocks);
+    h_blocks = d_blocks = nullptr;
+  }
+};
+static std::mutex g_slab_mu;
+static std::map<exon_hip_ctx*, SlabBuffers> g_slab_cache;
+
+void exon_hip_release_ctx_caches(exon_hip_ctx* ctx) {
+  std::lock_guard<std::mutex> g(g_slab_mu);
+  auto it = g_slab_cache.find(ctx);
+  if (it == g_slab_cache.end()) return;
+  it->second.free_all();
+  g_slab_cache.erase(it);
+}
+
 class GpuTextSource {
  public:
   GpuTextSource(exon_hip_ctx* ctx, hipStream_t hs, std::unique_ptr<exon::ByteSource> src, bool bgzf, uint64_t skip_first,
@@ -326,8 +363,10 @@ class GpuTextSource {
       : ctx_(ctx), hs_(hs), src_(std::move(src)), rd_(src_.get()), bgzf_(bgzf), skip_(skip_first), carry_(std::move(carry)) {
     slab_ = slab_bytes();
     if (bgzf_) {
-      comp_cap_ = std::max<size_t>(slab_ / 2, 1u << 20) + (1u << 17);  // compressed bytes per slab (+ a carried partial block)
-      text_cap_ = 4 * slab_;                                            // inflated bytes per slab
+      // one wavefront inflates one block and a block takes ~5 ms however many run beside it: a launch wants >= 7000
+      // blocks (28 wavefronts on each of 256 CUs), i.e. ~128 MB of compressed input
+      comp_cap_ = slab_ + (1u << 17);  // compressed bytes per slab (+ a carried partial block)
+      text_cap_ = 8 * slab_;           // inflated bytes per slab
     } else {
       text_cap_ = slab_;
     }
@@ -335,28 +374,65 @@ class GpuTextSource {
   }
   ~GpuTextSource() {
     if (reader_.joinable()) reader_.join();
+    SlabBuffers b;
+    b.bgzf = bgzf_;
+    b.hcap = hcap_;
+    b.tcap = gap_ + text_cap_;
+    b.ccap = comp_cap_;
+    b.max_blocks = max_blocks_;
     for (int k = 0; k < 2; ++k) {
-      if (h_buf_[k]) hipHostFree(h_buf_[k]);
-      if (d_comp_[k]) hipFree(d_comp_[k]);
-      if (d_text_[k]) hipFree(d_text_[k]);
+      b.h_buf[k] = h_buf_[k];
+      b.d_comp[k] = d_comp_[k];
+      b.d_text[k] = d_text_[k];
     }
-    if (h_blocks_) hipHostFree(h_blocks_);
-    if (d_blocks_) hipFree(d_blocks_);
+    b.h_blocks = h_blocks_;
+    b.d_blocks = d_blocks_;
+    if (!complete_) {
+      b.free_all();
+      return;
+    }
+    std::lock_guard<std::mutex> g(g_slab_mu);
+    SlabBuffers& slot = g_slab_cache[ctx_];
+    slot.free_all();
+    slot = b;
   }
   size_t max_text_bytes() const { return gap_ + text_cap_ + 64; }
 
   int init() {
-    const size_t hcap = bgzf_ ? comp_cap_ + 4096 : gap_ + text_cap_ + 64;
-    for (int k = 0; k < 2; ++k) {
-      if (hipHostMalloc((void**)&h_buf_[k], hcap) != hipSuccess || hipMalloc((void**)&d_text_[k], gap_ + text_cap_ + 256) != hipSuccess ||
-          (bgzf_ && hipMalloc((void**)&d_comp_[k], comp_cap_ + 8192) != hipSuccess))
-        return fail(ctx_, EXON_HIP_ENOMEM, "slab buffers (%zu bytes of text) could not be allocated", text_cap_);
+    hcap_ = bgzf_ ? comp_cap_ + 4096 : gap_ + text_cap_ + 64;
+    if (bgzf_) max_blocks_ = (int)(comp_cap_ / 26 + 16);  // an empty BGZF block is 28 bytes
+    {
+      std::lock_guard<std::mutex> g(g_slab_mu);
+      auto it = g_slab_cache.find(ctx_);
+      if (it != g_slab_cache.end()) {
+        SlabBuffers& b = it->second;
+        if (b.bgzf == bgzf_ && b.hcap == hcap_ && b.tcap == gap_ + text_cap_ && b.ccap == comp_cap_ && b.max_blocks == max_blocks_) {
+          for (int k = 0; k < 2; ++k) {
+            h_buf_[k] = b.h_buf[k];
+            d_comp_[k] = b.d_comp[k];
+            d_text_[k] = b.d_text[k];
+          }
+          h_blocks_ = b.h_blocks;
+          d_blocks_ = b.d_blocks;
+          complete_ = true;
+        } else {
+          b.free_all();
+        }
+        g_slab_cache.erase(it);
+      }
     }
-    if (bgzf_) {
-      max_blocks_ = (int)(comp_cap_ / 26 + 16);  // an empty BGZF block is 28 bytes
-      if (hipHostMalloc((void**)&h_blocks_, (size_t)max_blocks_ * (sizeof(exon_hip_bgzf_block) + sizeof(int))) != hipSuccess ||
-          hipMalloc((void**)&d_blocks_, (size_t)max_blocks_ * (sizeof(exon_hip_bgzf_block) + sizeof(int))) != hipSuccess)
-        return fail(ctx_, EXON_HIP_ENOMEM, "BGZF block tables could not be allocated");
+    if (!complete_) {
+      for (int k = 0; k < 2; ++k) {
+        if (hipHostMalloc((void**)&h_buf_[k], hcap_) != hipSuccess || hipMalloc((void**)&d_text_[k], gap_ + text_cap_ + 256) != hipSuccess ||
+            (bgzf_ && hipMalloc((void**)&d_comp_[k], comp_cap_ + 8192) != hipSuccess))
+          return fail(ctx_, EXON_HIP_ENOMEM, "slab buffers (%zu bytes of text) could not be allocated", text_cap_);
+      }
+      if (bgzf_) {
+        if (hipHostMalloc((void**)&h_blocks_, (size_t)max_blocks_ * (sizeof(exon_hip_bgzf_block) + sizeof(int))) != hipSuccess ||
+            hipMalloc((void**)&d_blocks_, (size_t)max_blocks_ * (sizeof(exon_hip_bgzf_block) + sizeof(int))) != hipSuccess)
+          return fail(ctx_, EXON_HIP_ENOMEM, "BGZF block tables could not be allocated");
+      }
+      complete_ = true;
     }
     fill(0, &cur_);
     k_ = 0;
@@ -522,7 +598,8 @@ class GpuTextSource {
   uint64_t skip_;
   std::string carry_;      // plain: carried tail (host)
   size_t carry_dev_ = 0;   // bgzf: carried tail already at the front of the next text buffer
-  size_t slab_ = 0, comp_cap_ = 0, text_cap_ = 0, gap_ = 0;
+  size_t slab_ = 0, comp_cap_ = 0, text_cap_ = 0, gap_ = 0, hcap_ = 0;
+  bool complete_ = false;  // all buffers allocated (only complete sets go back to the cache)
   uint8_t* h_buf_[2] = {nullptr, nullptr};
   uint8_t* d_comp_[2] = {nullptr, nullptr};
   uint8_t* d_text_[2] = {nullptr, nullptr};
@@ -543,7 +620,16 @@ class GpuTextSource {
 
 // VCF / FASTQ file -> text slabs in HBM (GpuTextSource) -> GPU parser -> fused kernel.  Returns 1 when the device could
 // not decide something: the caller restores the state and re-decodes the file on the host.
+static double now_s() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* rows_out) {
+  const bool trace = getenv("EXON_HIP_PIPE_TRACE") != nullptr;  // phase timings on stderr
+  const double t_begin = now_s();
+  double t_next = 0, t_parse = 0, t_launch = 0;
   exon_hip_ctx* ctx = exon_hip_stream_ctx(st);
   hipStream_t hs = (hipStream_t)exon_hip_stream_hip_stream(st);
   const bool is_vcf = scan->vcf != nullptr;
@@ -580,16 +666,21 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
     if (rc) return rc;
   }
   int64_t total = 0;
+  const double t_init = now_s();
   for (;;) {
     const uint8_t* d_text = nullptr;
     size_t n = 0;
     bool final = false;
+    const double t0 = now_s();
     rc = src->next(&d_text, &n, &final);
+    const double t1 = now_s();
+    t_next += t1 - t0;
     if (rc) break;
     size_t consumed = 0;
     if (n > 0 && is_vcf) {
       exon_hip_vcf_columns cols;
       rc = exon_hip_vcf_parser_parse(scan->parser, hs, d_text, (int64_t)n, &cols);
+      t_parse += now_s() - t1;
       if (!rc && cols.n_undecided > 0) rc = 1;
       if (rc) break;
       consumed = (size_t)cols.consumed_bytes;
@@ -627,7 +718,13 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
     if (rc || final) break;
   }
   if (hipStreamSynchronize(hs) != hipSuccess && rc == EXON_HIP_OK) rc = fail(ctx, EXON_HIP_EDEVICE, "stream synchronize failed");
+  const double t_loop = now_s();
   src.reset();
+  if (trace)
+    fprintf(stderr, "[exon-hip pipe] setup %.1f ms, loop %.1f ms (slabs: wait+H2D+inflate %.1f, parse %.1f, other %.1f), teardown %.1f ms\n",
+            (t_init - t_begin) * 1e3, (t_loop - t_init) * 1e3, t_next * 1e3, t_parse * 1e3, (t_loop - t_init - t_next - t_parse) * 1e3,
+            (now_s() - t_loop) * 1e3);
+  (void)t_launch;
   if (rc == EXON_HIP_OK && is_vcf) {
     // FILTER dictionary -> scan (names in id order)
     int32_t nf = 0;
