@@ -5,7 +5,7 @@ this package is the thin host side used by tests, the CLI and bench.py.  Importi
 fails loudly when the library is missing -- there is no CPU fallback.
 """
 from ._lib import ExonHipError, LIB_PATH, build, load  # noqa: F401
-from .engine import (Context, DeviceBuffer, Plan, Scan, Stream, VCFParser, FASTQParser, bgzf_scan, index_query, parse_region,  # noqa: F401
+from .engine import (Context, DeviceBuffer, Plan, Scan, Stream, VCFParser, FASTQParser, BAMParser, bgzf_scan, index_query, parse_region,  # noqa: F401
                      regroup_files_by_size)  # noqa: F401
 
 __all__ = ["Context", "DeviceBuffer", "Plan", "Scan", "Stream", "ExonHipError", "parse_region", "index_query",

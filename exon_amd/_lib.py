@@ -77,6 +77,12 @@ class BgzfBlock(C.Structure):
                 ("crc32", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class BAMColumns(C.Structure):
+    _fields_ = [("n_rows", C.c_int64), ("n_undecided", C.c_int64), ("consumed_bytes", C.c_int64), ("flag", C.c_void_p),
+                ("mapq", C.c_void_p), ("mapq_valid", C.c_void_p), ("ref_id", C.c_void_p), ("ref_valid", C.c_void_p),
+                ("start", C.c_void_p), ("end", C.c_void_p), ("pos_valid", C.c_void_p)]
+
+
 class FASTQViews(C.Structure):
     _fields_ = [("n_reads", C.c_int64), ("n_undecided", C.c_int64), ("consumed_bytes", C.c_int64),
                 ("seq_start", C.c_void_p), ("seq_end", C.c_void_p), ("qual_start", C.c_void_p), ("qual_end", C.c_void_p)]
@@ -163,6 +169,9 @@ SIGNATURES = {
     "exon_hip_fastq_parser_create": (C.c_int, [_vp, _i64, C.POINTER(_vp)]),
     "exon_hip_fastq_parser_parse": (C.c_int, [_vp, _vp, _vp, _i64, _i32, C.POINTER(FASTQViews)]),
     "exon_hip_fastq_parser_destroy": (C.c_int, [_vp]),
+    "exon_hip_bam_parser_create": (C.c_int, [_vp, _i32, _i64, C.POINTER(_vp)]),
+    "exon_hip_bam_parser_parse": (C.c_int, [_vp, _vp, _vp, _i64, C.POINTER(BAMColumns)]),
+    "exon_hip_bam_parser_destroy": (C.c_int, [_vp]),
     "exon_hip_bgzf_scan": (C.c_int, [_vp, C.c_size_t, C.c_size_t, C.POINTER(BgzfBlock), _i32, C.POINTER(_i32),
                                      C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "exon_hip_bgzf_inflate": (C.c_int, [_vp, _vp, _vp, C.POINTER(BgzfBlock), _i32, _vp, _i32, C.POINTER(_i32)]),

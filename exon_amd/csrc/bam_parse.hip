@@ -1,0 +1,304 @@
+// bam_parse.hip -- BAM record splitting + field extraction ON THE GPU: inflated BAM bytes in HBM -> device-layout
+// columns (flag, mapping_quality, reference id, start, end) in HBM.
+//
+// Reference semantics: BAMArrayBuilder::append (exon-bam/src/array_builder.rs:102-218) restricted to the columns of
+// the device layout -- flag = raw u16 bits as Int32 (:114-117), reference = refID (NULL if -1, :118-127), start =
+// pos + 1 (NULL if pos < 0), end = start + (sum of M/D/N/=/X lengths) - 1, mapping_quality NULL when 255 (:136-143);
+// record layout: SAM specification section 4.2.
+//
+// BAM records are a chain (each record starts where the previous one ends), so a slab is cut into 64 KiB segments and
+// the chains are walked by one wavefront per segment in parallel:
+//   k_bam_walk     segment 0 starts at byte 0 (the caller guarantees a record boundary); every other segment GUESSES its
+//                  first record start (smallest offset where three consecutive records look plausible), then walks its
+//                  chain, storing record offsets, until it leaves the segment -> (start, landing, count)
+//   k_bam_check    the guesses are PROVEN by induction: landing(s) must equal start(s+1) for every s.  Any mismatch, a
+//                  segment without a record start (records larger than a segment) or a malformed record -> undecided:
+//                  the caller decodes on the host instead.  Exclusive scan of the counts -> first row of each segment.
+//   k_bam_extract  one thread per record: fixed fields, CIGAR walk for the reference length, columns + validity bits.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "internal.h"
+
+namespace {
+
+constexpr uint32_t SEG = 65536;            // segment size in bytes
+constexpr uint32_t SEG_CAP = SEG / 36 + 2; // most records that can start inside one segment (36 = smallest record)
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);  // unaligned dword load
+  return v;
+}
+__device__ __forceinline__ uint32_t ld16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+
+// Is there a well-formed record header at offset r (fields of SAM spec 4.2)?  Only what is needed to tell record
+// starts from arbitrary bytes; the walk itself trusts block_size alone, as the host decoder does.
+__device__ bool plausible(const uint8_t* d, uint32_t n, uint32_t r, int32_t n_ref) {
+  if ((uint64_t)r + 36 > n) return false;
+  const uint32_t bs = ld32(d + r);
+  if (bs < 32 || bs > (1u << 24)) return false;
+  const int32_t ref = (int32_t)ld32(d + r + 4), pos = (int32_t)ld32(d + r + 8);
+  if (ref < -1 || ref >= n_ref || pos < -1) return false;
+  const uint32_t l_name = d[r + 12], n_cigar = ld16(d + r + 16);
+  const int32_t l_seq = (int32_t)ld32(d + r + 20);
+  const int32_t mref = (int32_t)ld32(d + r + 24), mpos = (int32_t)ld32(d + r + 28);
+  if (l_name == 0 || l_seq < 0 || mref < -1 || mref >= n_ref || mpos < -1) return false;
+  const uint64_t need = 32ull + l_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq;
+  if (need > bs) return false;
+  if ((uint64_t)r + 36 + l_name <= n && d[r + 36 + l_name - 1] != 0) return false;  // read name is NUL-terminated
+  return true;
+}
+
+struct SegInfo {
+  uint32_t start;    // first record start inside the segment (NONE = none found)
+  uint32_t landing;  // where the chain leaves the segment (start of the first record not walked)
+  uint32_t count;    // records walked
+  uint32_t bad;      // 1 = malformed record met (block_size < 32), 2 = stopped at a record that the slab cuts off
+};
+
+__global__ __launch_bounds__(64) void k_bam_walk(const uint8_t* __restrict__ d, uint32_t n, int32_t n_ref, SegInfo* __restrict__ seg,
+                                                 uint32_t* __restrict__ rec_off) {
+  const uint32_t s = blockIdx.x, lane = threadIdx.x;
+  const uint32_t lo = s * SEG, hi = min(n, lo + SEG);
+  uint32_t start = NONE;
+  if (s == 0) {
+    start = 0;
+  } else {
+    for (uint32_t c0 = lo; c0 < hi && start == NONE; c0 += 64) {
+      const uint32_t c = c0 + lane;
+      bool ok = c < hi && plausible(d, n, c, n_ref);
+      if (ok) {  // two more records down the chain (fewer when the slab ends first)
+        uint32_t r = c;
+        for (int k = 0; k < 2 && ok; ++k) {
+          r += 4 + ld32(d + r);
+          if ((uint64_t)r + 36 > n) break;
+          ok = plausible(d, n, r, n_ref);
+        }
+      }
+      const unsigned long long m = __ballot(ok);
+      if (m) start = c0 + (uint32_t)__ffsll((long long)m) - 1;
+    }
+  }
+  uint32_t r = start, k = 0, bad = 0;
+  if (start != NONE) {
+    uint32_t* out = rec_off + (size_t)s * SEG_CAP;
+    while (r < hi) {
+      if ((uint64_t)r + 4 > n) { bad = 2; break; }
+      const uint32_t bs = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld32(d + r));
+      if (bs < 32) { bad = 1; break; }
+      if ((uint64_t)r + 4 + bs > n) { bad = 2; break; }  // record cut off by the end of the slab: carried by the caller
+      if (lane == 0) out[k] = r;
+      ++k;
+      r += 4 + bs;
+    }
+  }
+  if (lane == 0) seg[s] = SegInfo{start, r, k, bad};
+}
+
+// scalars: [0] rows, [1] undecided, [2] consumed bytes.  Segments behind the one whose chain met the cut-off record hold
+// only that record's bytes: they are ignored (their counts are zeroed).
+__global__ __launch_bounds__(1024) void k_bam_check(SegInfo* __restrict__ seg, uint32_t n_seg, uint32_t* __restrict__ base,
+                                                    unsigned* __restrict__ scalars) {
+  __shared__ unsigned part[1024];
+  __shared__ unsigned any_bad, s_cut;
+  if (threadIdx.x == 0) {
+    any_bad = 0;
+    s_cut = n_seg - 1;
+  }
+  __syncthreads();
+  const uint32_t per = (n_seg + 1023) / 1024;
+  const uint32_t s0 = threadIdx.x * per, s1 = min(n_seg, s0 + per);
+  for (uint32_t s = s0; s < s1; ++s)
+    if (seg[s].bad == 2) atomicMin(&s_cut, s);
+  __syncthreads();
+  const uint32_t last = s_cut;
+  unsigned sum = 0, bad = 0;
+  for (uint32_t s = s0; s < s1; ++s) {
+    if (s > last) {
+      seg[s].count = 0;
+      continue;
+    }
+    const SegInfo a = seg[s];
+    sum += a.count;
+    if (a.start == NONE || a.bad == 1) bad = 1;
+    if (s < last && a.landing != seg[s + 1].start) bad = 1;  // also catches chains that skip a whole segment
+  }
+  if (bad) atomicOr(&any_bad, 1u);
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    unsigned v = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  unsigned run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
+  for (uint32_t s = s0; s < s1; ++s) {
+    base[s] = run;
+    run += s > last ? 0u : seg[s].count;
+  }
+  if (threadIdx.x == 1023) {
+    scalars[0] = part[1023];
+    scalars[2] = seg[last].landing;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && any_bad) atomicAdd(&scalars[1], 1u);
+}
+
+struct BamOut {
+  int32_t* flag;
+  uint8_t* mapq;
+  uint32_t* mapq_valid;  // validity bitmaps as 32-bit words
+  int32_t* ref_id;
+  uint32_t* ref_valid;
+  int64_t* start;
+  int64_t* end;
+  uint32_t* pos_valid;
+};
+
+__global__ __launch_bounds__(256) void k_bam_extract(const uint8_t* __restrict__ d, const SegInfo* __restrict__ seg,
+                                                     const uint32_t* __restrict__ base, const uint32_t* __restrict__ rec_off, BamOut o,
+                                                     unsigned* __restrict__ scalars) {
+  const uint32_t s = blockIdx.x;
+  if (scalars[1] != 0) return;  // the segmentation was not proven: nothing here can be trusted
+  const uint32_t cnt = seg[s].count, row0 = base[s];
+  const uint32_t* offs = rec_off + (size_t)s * SEG_CAP;
+  for (uint32_t k = threadIdx.x; k < cnt; k += 256) {
+    const uint32_t r = offs[k], row = row0 + k;
+    const uint32_t bs = ld32(d + r);
+    const int32_t ref = (int32_t)ld32(d + r + 4), pos = (int32_t)ld32(d + r + 8);
+    const uint32_t l_name = d[r + 12], mapq = d[r + 13], n_cigar = ld16(d + r + 16), flag = ld16(d + r + 18);
+    const uint32_t co = 32 + l_name;
+    if (co + 4 * n_cigar > bs) {  // "corrupt BAM cigar" on the host
+      atomicAdd(&scalars[1], 1u);
+      continue;
+    }
+    int64_t ref_len = 0;
+    for (uint32_t c = 0; c < n_cigar; ++c) {
+      const uint32_t op = ld32(d + r + 4 + co + 4 * c);
+      const uint32_t code = op & 0xF;
+      if (code == 0 || code == 2 || code == 3 || code == 7 || code == 8) ref_len += op >> 4;
+    }
+    o.flag[row] = (int32_t)flag;
+    o.mapq[row] = (uint8_t)mapq;
+    o.ref_id[row] = ref < 0 ? -1 : ref;
+    const bool pv = pos >= 0;
+    o.start[row] = pv ? (int64_t)pos + 1 : 0;
+    o.end[row] = pv ? (int64_t)pos + ref_len : 0;
+    const uint32_t bit = 1u << (row & 31);
+    if (mapq != 255) atomicOr(&o.mapq_valid[row >> 5], bit);
+    if (ref >= 0) atomicOr(&o.ref_valid[row >> 5], bit);
+    if (pv) atomicOr(&o.pos_valid[row >> 5], bit);
+  }
+}
+
+}  // namespace
+
+struct exon_hip_bam_parser {
+  exon_hip_ctx* ctx = nullptr;
+  int32_t n_ref = 0;
+  int64_t max_bytes = 0, max_rows = 0;
+  uint32_t max_seg = 0;
+  SegInfo* d_seg = nullptr;
+  uint32_t *d_base = nullptr, *d_rec_off = nullptr, *d_scalars = nullptr;
+  void* bufs[8] = {nullptr};
+  BamOut out{};
+  unsigned* h_scalars = nullptr;
+};
+
+extern "C" {
+
+int exon_hip_bam_parser_create(exon_hip_ctx* ctx, int32_t n_references, int64_t max_bytes, exon_hip_bam_parser** outp) {
+  if (!ctx || !outp || max_bytes < 64 || n_references < 0) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_bam_parser_create: bad argument");
+  if (max_bytes > 0xF0000000LL) return fail(ctx, EXON_HIP_EINVAL, "slab size must stay below 4 GiB (32-bit record offsets)");
+  *outp = nullptr;
+  exon_hip_bam_parser* p = new (std::nothrow) exon_hip_bam_parser();
+  if (!p) return fail(ctx, EXON_HIP_ENOMEM, "out of host memory");
+  p->ctx = ctx;
+  p->n_ref = n_references;
+  p->max_bytes = max_bytes;
+  p->max_seg = (uint32_t)((max_bytes + SEG - 1) / SEG);
+  p->max_rows = max_bytes / 36 + 1;
+  hipSetDevice(ctx->device);
+  hipError_t e = hipSuccess;
+  auto dalloc = [&](void** ptr, size_t bytes) {
+    if (e == hipSuccess) e = hipMalloc(ptr, bytes ? bytes : 16);
+  };
+  const size_t r = (size_t)p->max_rows, w = (r + 31) / 32 * 4 + 64;
+  dalloc((void**)&p->d_seg, (size_t)p->max_seg * sizeof(SegInfo));
+  dalloc((void**)&p->d_base, (size_t)p->max_seg * 4);
+  dalloc((void**)&p->d_rec_off, (size_t)p->max_seg * SEG_CAP * 4);
+  dalloc((void**)&p->d_scalars, 16);
+  dalloc(&p->bufs[0], r * 4);
+  dalloc(&p->bufs[1], r + 64);
+  dalloc(&p->bufs[2], w);
+  dalloc(&p->bufs[3], r * 4);
+  dalloc(&p->bufs[4], w);
+  dalloc(&p->bufs[5], r * 8);
+  dalloc(&p->bufs[6], r * 8);
+  dalloc(&p->bufs[7], w);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&p->h_scalars, 16);
+  if (e != hipSuccess) {
+    const std::string msg = hipGetErrorString(e);
+    exon_hip_bam_parser_destroy(p);
+    return fail(ctx, EXON_HIP_ENOMEM, "bam parser allocation: %s", msg.c_str());
+  }
+  p->out = BamOut{(int32_t*)p->bufs[0], (uint8_t*)p->bufs[1], (uint32_t*)p->bufs[2], (int32_t*)p->bufs[3],
+                  (uint32_t*)p->bufs[4], (int64_t*)p->bufs[5], (int64_t*)p->bufs[6], (uint32_t*)p->bufs[7]};
+  *outp = p;
+  return EXON_HIP_OK;
+}
+
+int exon_hip_bam_parser_destroy(exon_hip_bam_parser* p) {
+  if (!p) return EXON_HIP_OK;
+  for (void* b : p->bufs)
+    if (b) hipFree(b);
+  if (p->d_seg) hipFree(p->d_seg);
+  if (p->d_base) hipFree(p->d_base);
+  if (p->d_rec_off) hipFree(p->d_rec_off);
+  if (p->d_scalars) hipFree(p->d_scalars);
+  if (p->h_scalars) hipHostFree(p->h_scalars);
+  delete p;
+  return EXON_HIP_OK;
+}
+
+int exon_hip_bam_parser_parse(exon_hip_bam_parser* p, void* stream, const uint8_t* d_data, int64_t n_bytes, exon_hip_bam_columns* cols) {
+  if (!p || !cols || (n_bytes > 0 && !d_data)) return fail(p ? p->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_bam_parser_parse: NULL argument");
+  exon_hip_ctx* ctx = p->ctx;
+  if (n_bytes > p->max_bytes) return fail(ctx, EXON_HIP_EINVAL, "slab of %lld bytes exceeds the parser's %lld", (long long)n_bytes, (long long)p->max_bytes);
+  memset(cols, 0, sizeof *cols);
+  if (n_bytes == 0) return EXON_HIP_OK;
+  hipStream_t s = pick_stream(ctx, stream);
+  const uint32_t n = (uint32_t)n_bytes, n_seg = (n + SEG - 1) / SEG;
+  // rows of this slab <= n / 36: clear the validity words they can touch
+  const size_t words = ((size_t)n / 36 + 1 + 31) / 32 * 4 + 4;
+  HIP_TRY(ctx, hipMemsetAsync(p->d_scalars, 0, 16, s));
+  HIP_TRY(ctx, hipMemsetAsync(p->out.mapq_valid, 0, words, s));
+  HIP_TRY(ctx, hipMemsetAsync(p->out.ref_valid, 0, words, s));
+  HIP_TRY(ctx, hipMemsetAsync(p->out.pos_valid, 0, words, s));
+  hipLaunchKernelGGL(k_bam_walk, dim3(n_seg), dim3(64), 0, s, d_data, n, p->n_ref, p->d_seg, p->d_rec_off);
+  hipLaunchKernelGGL(k_bam_check, dim3(1), dim3(1024), 0, s, p->d_seg, n_seg, p->d_base, p->d_scalars);
+  hipLaunchKernelGGL(k_bam_extract, dim3(n_seg), dim3(256), 0, s, d_data, p->d_seg, p->d_base, p->d_rec_off, p->out, p->d_scalars);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(p->h_scalars, p->d_scalars, 12, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  cols->n_rows = p->h_scalars[0];
+  cols->n_undecided = p->h_scalars[1];
+  cols->consumed_bytes = p->h_scalars[2];
+  cols->flag = p->out.flag;
+  cols->mapq = p->out.mapq;
+  cols->mapq_valid = (uint8_t*)p->out.mapq_valid;
+  cols->ref_id = p->out.ref_id;
+  cols->ref_valid = (uint8_t*)p->out.ref_valid;
+  cols->start = p->out.start;
+  cols->end = p->out.end;
+  cols->pos_valid = (uint8_t*)p->out.pos_valid;
+  return EXON_HIP_OK;
+}
+
+}  // extern "C"

@@ -270,8 +270,8 @@ void open_scan(const Source& src, const std::string& file, const char* info_fiel
   // INDEXED_* tables / *_indexed_scan: plan BGZF chunks from <file>.tbi / <file>.bai
   // (exon-core/src/datasources/indexed_file/indexed_bgzf_file.rs:129-155)
   o.use_index = (src.indexed && !region.empty()) ? 1 : 0;
-  o.gpu_parse = (for_gpu_query && (src.format == EXON_HIP_FORMAT_VCF || src.format == EXON_HIP_FORMAT_FASTQ) && region.empty() &&
-                 gpu_parse_enabled()) ? 1 : 0;
+  o.gpu_parse = (for_gpu_query && (src.format == EXON_HIP_FORMAT_VCF || src.format == EXON_HIP_FORMAT_FASTQ || src.format == EXON_HIP_FORMAT_BAM) &&
+                 region.empty() && gpu_parse_enabled()) ? 1 : 0;
   ck(nullptr, exon_hip_scan_open(file.c_str(), &o, &g->s));
 }
 
@@ -488,7 +488,7 @@ void exec_select(Session& se, Parser& ps) {
     int64_t null_group = 0;
     std::vector<std::string> order;
     for (const auto& f : src.files) {
-      ScanGuard g; open_scan(src, f, nullptr, "", &g);
+      ScanGuard g; open_scan(src, f, nullptr, "", &g, true);
       int32_t R = 0;
       ck(nullptr, exon_hip_scan_dictionary_size(g.s, 2, &R));
       StreamGuard sg;

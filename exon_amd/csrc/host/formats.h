@@ -588,6 +588,10 @@ class BAMBatchReader {
     }
   }
 
+  const BAMConfig& config() const { return cfg_; }
+  // uncompressed offset of the first record (header length), for the GPU-side inflate + record splitting
+  int64_t data_offset() const { return n_chunks >= 0 ? -1 : (int64_t)static_cast<StreamSource*>(r_.get())->r.consumed(); }
+
   bool read_batch(struct ArrowArray* out) {
     BAMArrayBuilder b(&ref_names);
     std::vector<uint8_t> rec;

@@ -28,6 +28,7 @@ struct exon_hip_scan {
   exon_hip_vcf_parser* parser = nullptr;  // created by the first GPU-parsed consume; owns the FILTER dictionary
   exon_hip_ctx* parser_ctx = nullptr;
   exon_hip_fastq_parser* fq_parser = nullptr;
+  exon_hip_bam_parser* bam_parser = nullptr;
   bool gpu_inflated = false;  // the last GPU-parsed consume also inflated BGZF blocks on the device
   exon::Dictionary gpu_filter_dict;       // names fetched from the parser after the consume
   std::unique_ptr<exon::VCFBatchReader> vcf;
@@ -105,6 +106,9 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         exon::BAMConfig cfg;
         cfg.batch_size = bs;
         cfg.filter = rf;
+        // BAM is BGZF by definition: the GPU path inflates and splits records on the device or is not taken at all
+        s->gpu_parse = !rf.active && wants_gpu_inflate(o, path);
+        if (s->gpu_parse) cfg.threads = 1;  // only the header is read on the host
         s->bam.reset(new exon::BAMBatchReader(path, cfg));
         s->bam_dict_view.names = s->bam->ref_names;
         break;
@@ -253,6 +257,7 @@ int exon_hip_index_query(const char* index_path, int32_t is_bai, const char* ref
 int exon_hip_scan_close(exon_hip_scan* s) {
   if (s && s->parser) exon_hip_vcf_parser_destroy(s->parser);
   if (s && s->fq_parser) exon_hip_fastq_parser_destroy(s->fq_parser);
+  if (s && s->bam_parser) exon_hip_bam_parser_destroy(s->bam_parser);
   delete s;
   return EXON_HIP_OK;
 }
@@ -359,8 +364,8 @@ void exon_hip_release_ctx_caches(exon_hip_ctx* ctx) {
 class GpuTextSource {
  public:
   GpuTextSource(exon_hip_ctx* ctx, hipStream_t hs, std::unique_ptr<exon::ByteSource> src, bool bgzf, uint64_t skip_first,
-                std::string carry)
-      : ctx_(ctx), hs_(hs), src_(std::move(src)), rd_(src_.get()), bgzf_(bgzf), skip_(skip_first), carry_(std::move(carry)) {
+                std::string carry, bool binary = false)
+      : ctx_(ctx), hs_(hs), src_(std::move(src)), rd_(src_.get()), bgzf_(bgzf), binary_(binary), skip_(skip_first), carry_(std::move(carry)) {
     slab_ = slab_bytes();
     if (bgzf_) {
       // one wavefront inflates one block and a block takes ~5 ms however many run beside it: a launch wants >= 7000
@@ -490,7 +495,7 @@ class GpuTextSource {
         front = 0;
         n_text = carry_dev_ + cur_.out_bytes;
       }
-      if (!more && n_text > 0) {  // last line without a terminator
+      if (!more && n_text > 0 && !binary_) {  // last line without a terminator
         uint8_t lastb = 0;
         HIP_TRY(ctx_, hipMemcpyAsync(&lastb, d_text_[k] + front + n_text - 1, 1, hipMemcpyDeviceToHost, hs_));
         HIP_TRY(ctx_, hipStreamSynchronize(hs_));
@@ -594,7 +599,7 @@ class GpuTextSource {
   hipStream_t hs_;
   std::unique_ptr<exon::ByteSource> src_;
   SlabReader rd_;
-  bool bgzf_;
+  bool bgzf_, binary_;
   uint64_t skip_;
   std::string carry_;      // plain: carried tail (host)
   size_t carry_dev_ = 0;   // bgzf: carried tail already at the front of the next text buffer
@@ -632,15 +637,16 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
   double t_next = 0, t_parse = 0, t_launch = 0;
   exon_hip_ctx* ctx = exon_hip_stream_ctx(st);
   hipStream_t hs = (hipStream_t)exon_hip_stream_hip_stream(st);
-  const bool is_vcf = scan->vcf != nullptr;
+  const bool is_vcf = scan->vcf != nullptr, is_bam = scan->bam != nullptr;
   std::unique_ptr<GpuTextSource> src;
   const bool bgzf = gpu_inflate_enabled() && scan->opt.compression != EXON_HIP_COMPRESSION_NONE &&
                     exon::BgzfParallelSource::is_bgzf(scan->path) && (!is_vcf || scan->vcf->data_offset() >= 0);
+  if (is_bam && !bgzf) return 1;
   try {
     if (bgzf) {
-      const uint64_t skip = is_vcf ? (uint64_t)scan->vcf->data_offset() : 0;
+      const uint64_t skip = is_vcf ? (uint64_t)scan->vcf->data_offset() : is_bam ? (uint64_t)scan->bam->data_offset() : 0;
       std::unique_ptr<exon::ByteSource> raw(new exon::ByteReader(scan->path, exon::Compression::None));
-      src.reset(new GpuTextSource(ctx, hs, std::move(raw), true, skip, std::string()));
+      src.reset(new GpuTextSource(ctx, hs, std::move(raw), true, skip, std::string(), is_bam));
     } else {
       std::string carry;
       std::unique_ptr<exon::ByteSource> text = is_vcf ? scan->vcf->take_stream(&carry) : scan->fastq->take_stream(&carry);
@@ -661,7 +667,11 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
     if (rc) return rc;
     scan->parser_ctx = ctx;
   }
-  if (!is_vcf && !scan->fq_parser) {
+  if (is_bam && !scan->bam_parser) {
+    rc = exon_hip_bam_parser_create(ctx, (int32_t)scan->bam->ref_names.size(), (int64_t)src->max_text_bytes(), &scan->bam_parser);
+    if (rc) return rc;
+  }
+  if (!is_vcf && !is_bam && !scan->fq_parser) {
     rc = exon_hip_fastq_parser_create(ctx, (int64_t)src->max_text_bytes(), &scan->fq_parser);
     if (rc) return rc;
   }
@@ -698,6 +708,29 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
         for (auto& c : sc) c.length = cols.n_rows;
         rc = exon_hip_stream_launch_scan_columns(st, sc, 5, cols.n_rows);
         // the parser's column buffers are reused by the next slab; the kernel is stream-ordered before that parse
+        total += cols.n_rows;
+      }
+    } else if (n > 0 && is_bam) {
+      exon_hip_bam_columns cols;
+      rc = exon_hip_bam_parser_parse(scan->bam_parser, hs, d_text, (int64_t)n, &cols);
+      t_parse += now_s() - t1;
+      if (!rc && cols.n_undecided > 0) rc = 1;
+      if (rc) break;
+      consumed = (size_t)cols.consumed_bytes;
+      if (cols.n_rows > 0) {
+        exon_hip_column sc[5];
+        memset(sc, 0, sizeof sc);
+        sc[0].values = cols.flag;
+        sc[1].values = cols.mapq;
+        sc[1].validity = cols.mapq_valid;
+        sc[2].values = cols.ref_id;
+        sc[2].validity = cols.ref_valid;
+        sc[3].values = cols.start;
+        sc[3].validity = cols.pos_valid;
+        sc[4].values = cols.end;
+        sc[4].validity = cols.pos_valid;
+        for (auto& c : sc) c.length = cols.n_rows;
+        rc = exon_hip_stream_launch_scan_columns(st, sc, 5, cols.n_rows);
         total += cols.n_rows;
       }
     } else if (n > 0) {
@@ -751,69 +784,50 @@ extern "C" {
 int exon_hip_stream_consume_scan(exon_hip_stream* st, exon_hip_scan* scan, int64_t* rows) {
   if (!st || !scan) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_stream_consume_scan: NULL argument");
   int64_t n = 0;
-  if (scan->gpu_parse && scan->fastq) {
+  if (scan->gpu_parse && (scan->vcf || scan->fastq || scan->bam)) {
+    // speculative GPU decode; when the device cannot decide something, restore the state and fall back to the host decoder
     exon_hip_ctx* ctx = exon_hip_stream_ctx(st);
     void* snap = nullptr;
     const size_t sb = exon_hip_stream_state_bytes(st);
     if (hipMalloc(&snap, sb ? sb : 16) != hipSuccess) return fail(ctx, EXON_HIP_ENOMEM, "state snapshot allocation failed");
     int rc = exon_hip_stream_state_copy(st, snap, false);
     if (!rc) rc = consume_text_gpu(st, scan, rows);
-    if (rc == 1) {  // restore and re-decode on the host
-      rc = exon_hip_stream_state_copy(st, snap, true);
-      hipStreamSynchronize((hipStream_t)exon_hip_stream_hip_stream(st));
-      hipFree(snap);
-      if (rc) return rc;
-      scan->gpu_parse = false;
-      try {
-        exon::FASTQConfig cfg = scan->fastq->config();
-        cfg.defer_decode = false;
-        cfg.threads = 0;
-        const exon::Compression c = scan->opt.compression == EXON_HIP_COMPRESSION_GZIP   ? exon::Compression::Gzip
-                                    : scan->opt.compression == EXON_HIP_COMPRESSION_NONE ? exon::Compression::None
-                                                                                         : exon::Compression::Auto;
-        scan->fastq.reset(new exon::FASTQBatchReader(scan->path, c, cfg));
-      } catch (const std::exception& e) {
-        return fail(nullptr, EXON_HIP_EINVAL, "%s", e.what());
-      }
-    } else {
+    if (rc != 1) {
       hipFree(snap);
       return rc;
     }
-  }
-  if (scan->gpu_parse && scan->vcf) {
-    // speculative GPU decode; on undecidable rows restore the state and fall back to the host decoder
-    exon_hip_ctx* ctx = exon_hip_stream_ctx(st);
-    void* snap = nullptr;
-    const size_t sb = exon_hip_stream_state_bytes(st);
-    if (hipMalloc(&snap, sb ? sb : 16) != hipSuccess) return fail(ctx, EXON_HIP_ENOMEM, "state snapshot allocation failed");
-    int rc = exon_hip_stream_state_copy(st, snap, false);
-    if (!rc) rc = consume_text_gpu(st, scan, rows);
-    if (rc == 1) {
-      rc = exon_hip_stream_state_copy(st, snap, true);
-      hipStreamSynchronize((hipStream_t)exon_hip_stream_hip_stream(st));
-      hipFree(snap);
-      if (rc) return rc;
-      if (scan->parser) {
-        exon_hip_vcf_parser_destroy(scan->parser);
-        scan->parser = nullptr;
-      }
-      scan->gpu_parse = false;
-      try {
+    rc = exon_hip_stream_state_copy(st, snap, true);
+    hipStreamSynchronize((hipStream_t)exon_hip_stream_hip_stream(st));
+    hipFree(snap);
+    if (rc) return rc;
+    if (scan->parser) {
+      exon_hip_vcf_parser_destroy(scan->parser);
+      scan->parser = nullptr;
+    }
+    scan->gpu_parse = false;
+    try {
+      const exon::Compression c = scan->opt.compression == EXON_HIP_COMPRESSION_GZIP   ? exon::Compression::Gzip
+                                  : scan->opt.compression == EXON_HIP_COMPRESSION_NONE ? exon::Compression::None
+                                                                                       : exon::Compression::Auto;
+      if (scan->vcf) {
         exon::VCFConfig cfg = scan->vcf->config();
         cfg.defer_decode = false;
         cfg.threads = 0;
-        const exon::Compression c = scan->opt.compression == EXON_HIP_COMPRESSION_GZIP   ? exon::Compression::Gzip
-                                    : scan->opt.compression == EXON_HIP_COMPRESSION_NONE ? exon::Compression::None
-                                                                                         : exon::Compression::Auto;
         scan->vcf.reset(new exon::VCFBatchReader(scan->path, c, cfg));
-      } catch (const std::exception& e) {
-        return fail(nullptr, EXON_HIP_EINVAL, "%s", e.what());
+      } else if (scan->fastq) {
+        exon::FASTQConfig cfg = scan->fastq->config();
+        cfg.defer_decode = false;
+        cfg.threads = 0;
+        scan->fastq.reset(new exon::FASTQBatchReader(scan->path, c, cfg));
+      } else {
+        exon::BAMConfig cfg = scan->bam->config();
+        cfg.threads = 0;
+        scan->bam.reset(new exon::BAMBatchReader(scan->path, cfg));
       }
-      // fall through to the host paths below
-    } else {
-      hipFree(snap);
-      return rc;
+    } catch (const std::exception& e) {
+      return fail(nullptr, EXON_HIP_EINVAL, "%s", e.what());
     }
+    // fall through to the host paths below
   }
   // fast path: a multi-threaded VCF scan hands its slabs over as raw vectors (no Arrow batch in between)
   if (scan->vcf) {

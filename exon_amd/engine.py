@@ -407,6 +407,43 @@ class VCFParser:
             self.h = None
 
 
+class BAMParser:
+    """BAM record splitting + field extraction on the GPU (exon_hip_bam_parser_*): inflated bytes in HBM -> columns."""
+
+    def __init__(self, ctx, n_references, max_slab_bytes=64 << 20):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._check(ctx.lib.exon_hip_bam_parser_create(ctx.h, n_references, max_slab_bytes, C.byref(h)))
+        self.h = h
+
+    def parse_host(self, data):
+        """Test helper: copy `data` (record bytes, starting at a record boundary) to HBM, split + extract, bring the
+        columns back as numpy arrays."""
+        buf = np.frombuffer(data, np.uint8)
+        d = self.ctx.to_device(np.concatenate([buf, np.zeros(64, np.uint8)]))
+        cols = L.BAMColumns()
+        self.ctx._check(self.ctx.lib.exon_hip_bam_parser_parse(self.h, None, d.ptr, len(buf), C.byref(cols)))
+        n = cols.n_rows if cols.n_undecided == 0 else 0
+        nb = (n + 7) // 8
+
+        def get(ptr, dtype, count):
+            out = np.empty(count, dtype)
+            if count:
+                self.ctx._check(self.ctx.lib.exon_hip_memcpy_d2h(self.ctx.h, _np_ptr(out), ptr, out.nbytes, None))
+            return out
+
+        return {"n_rows": cols.n_rows, "n_undecided": cols.n_undecided, "consumed_bytes": cols.consumed_bytes,
+                "flag": get(cols.flag, np.int32, n), "mapq": get(cols.mapq, np.uint8, n),
+                "mapq_valid": get(cols.mapq_valid, np.uint8, nb), "ref_id": get(cols.ref_id, np.int32, n),
+                "ref_valid": get(cols.ref_valid, np.uint8, nb), "start": get(cols.start, np.int64, n),
+                "end": get(cols.end, np.int64, n), "pos_valid": get(cols.pos_valid, np.uint8, nb)}
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.exon_hip_bam_parser_destroy(self.h)
+            self.h = None
+
+
 class FASTQParser:
     """FASTQ record splitting on the GPU (exon_hip_fastq_parser_*): text slab in HBM -> per-read views into it."""
 

@@ -289,9 +289,9 @@ typedef struct exon_hip_scan_options {
   const char* info_field; /* VCF: typed INFO field to extract (exon.vcf_parse_info), NULL = none */
   const char* region;     /* pushed-down vcf_region_filter / bam_region_filter ("chr1:1-100"), NULL = none */
   int32_t use_index;      /* with `region`: plan BGZF chunks from <path>.tbi / <path>.bai (INDEXED_VCF / INDEXED_BAM) */
-  int32_t gpu_parse;      /* VCF, FASTQ: exon_hip_stream_consume_scan ships the TEXT to HBM and parses it on the GPU
-                             (exon_hip_vcf_parser_* / exon_hip_fastq_parser_*); exon_hip_scan_next is then not
-                             available on this scan */
+  int32_t gpu_parse;      /* VCF, FASTQ, BAM: exon_hip_stream_consume_scan ships the file's bytes to HBM and decodes them
+                             on the GPU (exon_hip_bgzf_inflate, exon_hip_vcf_parser_* / exon_hip_fastq_parser_* /
+                             exon_hip_bam_parser_*); exon_hip_scan_next is then not available on this scan */
 } exon_hip_scan_options;
 
 int exon_hip_scan_open(const char* path, const exon_hip_scan_options* options, exon_hip_scan** out);
@@ -386,6 +386,32 @@ int exon_hip_fastq_parser_create(exon_hip_ctx* ctx, int64_t max_slab_bytes, exon
 int exon_hip_fastq_parser_parse(exon_hip_fastq_parser* parser, void* stream, const uint8_t* d_text, int64_t n_bytes,
                                 int32_t final_slab, exon_hip_fastq_views* views);
 int exon_hip_fastq_parser_destroy(exon_hip_fastq_parser* parser);
+
+/* ---- BAM record splitting + field extraction on the GPU (inflated BAM bytes in HBM -> device-layout columns) ----
+ * Column rules of BAMArrayBuilder::append (exon-bam/src/array_builder.rs:102-218) for flag, mapping_quality (NULL when
+ * 255), reference id (NULL when -1), start = pos + 1 and end = start + reference length - 1 (NULL when pos < 0).
+ * d_data must start at a record boundary; the chains of 64 KiB segments are walked in parallel from guessed record
+ * starts and the guesses are proven by matching every chain's end with the next segment's start.  n_undecided != 0
+ * (a proof failed, a record larger than a segment, a malformed record): decode on the host instead. */
+typedef struct exon_hip_bam_parser exon_hip_bam_parser;
+typedef struct exon_hip_bam_columns {
+  int64_t n_rows;
+  int64_t n_undecided;
+  int64_t consumed_bytes; /* whole records; a record cut off by the end of the slab is left to the caller */
+  int32_t* flag;          /* device pointers owned by the parser, overwritten by the next parse call */
+  uint8_t* mapq;
+  uint8_t* mapq_valid;
+  int32_t* ref_id;
+  uint8_t* ref_valid;
+  int64_t* start;
+  int64_t* end;
+  uint8_t* pos_valid;     /* validity of start and end */
+} exon_hip_bam_columns;
+int exon_hip_bam_parser_create(exon_hip_ctx* ctx, int32_t n_references, int64_t max_slab_bytes, exon_hip_bam_parser** out);
+/* Synchronises `stream`. */
+int exon_hip_bam_parser_parse(exon_hip_bam_parser* parser, void* stream, const uint8_t* d_data, int64_t n_bytes,
+                              exon_hip_bam_columns* cols);
+int exon_hip_bam_parser_destroy(exon_hip_bam_parser* parser);
 
 /* GpuFilterAggExec::execute in one call: pull every batch of `scan` and push it through `stream`. */
 int exon_hip_stream_consume_scan(exon_hip_stream* s, exon_hip_scan* scan, int64_t* rows);

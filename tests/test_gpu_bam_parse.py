@@ -1,0 +1,140 @@
+"""GPU-side BAM path: BGZF inflate -> record splitting (parallel chain walk with proven guesses) -> field extraction -> K3,
+against the native host decoder (pinned on the reference's slt values in tests/test_scan_decoders.py)."""
+import gzip
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import exon_amd
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FX = os.path.join(ROOT, "tests", "golden", "ref_fixtures")
+GEN = os.path.join(ROOT, "tools", "bin", "gen_text")
+BGZIP = os.path.join(ROOT, "tools", "bin", "bgzip")
+
+
+def bits(bm, n):
+    return np.unpackbits(bm, bitorder="little")[:n].astype(bool)
+
+
+def host_columns(path):
+    s = exon_amd.Scan(path, "bam")
+    batches = list(s)
+    refs = s.dictionary(2)
+    out = {k: [x for b in batches for x in b.field(i).to_pylist()] for i, k in enumerate(["flag", "mapq", "ref", "start", "end"])}
+    s.close()
+    return out, refs
+
+
+def records_of(path):
+    """(bytes of the record section, n_ref) of a BAM file."""
+    raw = gzip.decompress(open(path, "rb").read())
+    assert raw[:4] == b"BAM\1"
+    l_text = struct.unpack_from("<i", raw, 4)[0]
+    o = 8 + l_text
+    n_ref = struct.unpack_from("<i", raw, o)[0]
+    o += 4
+    for _ in range(n_ref):
+        l_name = struct.unpack_from("<i", raw, o)[0]
+        o += 4 + l_name + 4
+    return raw[o:], n_ref
+
+
+def check(res, host, refs):
+    n = res["n_rows"]
+    assert res["n_undecided"] == 0 and n == len(host["flag"])
+    assert res["flag"].tolist() == host["flag"]
+    mv, rv, pv = bits(res["mapq_valid"], n), bits(res["ref_valid"], n), bits(res["pos_valid"], n)
+    assert [int(m) if v else None for m, v in zip(res["mapq"], mv)] == host["mapq"]
+    assert [refs[r] if v else None for r, v in zip(res["ref_id"], rv)] == host["ref"]
+    assert [int(x) if v else None for x, v in zip(res["start"], pv)] == host["start"]
+    assert [int(x) if v else None for x, v in zip(res["end"], pv)] == host["end"]
+
+
+def test_bam_parser_reference_fixture(ctx):
+    path = os.path.join(FX, "bam", "test.bam")
+    host, refs = host_columns(path)
+    data, n_ref = records_of(path)
+    p = exon_amd.BAMParser(ctx, n_ref, max_slab_bytes=1 << 20)
+    res = p.parse_host(data)
+    assert res["consumed_bytes"] == len(data) and res["n_rows"] == 61
+    check(res, host, refs)
+    # first row of slt/bam-select-tests.slt:9-12: flag 83, chr1, 12203704..12217173, mapq NULL
+    assert res["flag"][0] == 83 and res["start"][0] == 12203704 and res["end"][0] == 12217173 and not bits(res["mapq_valid"], 61)[0]
+    p.close()
+
+
+def test_bam_parser_many_segments_and_cut_off_record(ctx, tmp_path):
+    ub = tmp_path / "syn.ubam"
+    subprocess.check_call([GEN, "bam", "40000", str(ub), "100"])
+    bam = tmp_path / "syn.bam"
+    subprocess.check_call([BGZIP, str(ub), str(bam), "6"])
+    host, refs = host_columns(str(bam))
+    data, n_ref = records_of(str(bam))
+    assert len(data) > 100 * 65536 // 2  # dozens of 64 KiB segments
+    p = exon_amd.BAMParser(ctx, n_ref, max_slab_bytes=len(data) + 64)
+    res = p.parse_host(data)
+    assert res["consumed_bytes"] == len(data) and res["n_rows"] == 40000
+    check(res, host, refs)
+    # a slab that stops in the middle of a record: whole records only, the cut-off one is left to the caller
+    cut = len(data) - 37
+    res = p.parse_host(data[:cut])
+    assert res["n_undecided"] == 0 and res["n_rows"] == 39999 and 0 < res["consumed_bytes"] < cut
+    bs = struct.unpack_from("<i", data, res["consumed_bytes"])[0]
+    assert res["consumed_bytes"] + 4 + bs == len(data)
+    # a slab cut in the middle of the 4-byte length field, and one several segments before the end
+    for cut in (res["consumed_bytes"] + 2, len(data) - 3 * 65536 - 11):
+        r2 = p.parse_host(data[:cut])
+        assert r2["n_undecided"] == 0 and r2["consumed_bytes"] <= cut
+        assert r2["flag"].tolist() == host["flag"][:r2["n_rows"]]
+    p.close()
+
+
+def test_bam_parser_gives_up_on_malformed_input(ctx):
+    path = os.path.join(FX, "bam", "test.bam")
+    data, n_ref = records_of(path)
+    p = exon_amd.BAMParser(ctx, n_ref, max_slab_bytes=1 << 20)
+    bad = bytearray(data)
+    bad[0:4] = struct.pack("<i", 7)  # block_size < 32
+    assert p.parse_host(bytes(bad))["n_undecided"] > 0
+    # a slab that does not start at a record boundary: the chain of segment 0 walks garbage
+    big = bytearray(data * 8)  # ~190 KB: 3 segments
+    res = p.parse_host(bytes(big[5:]))
+    assert res["n_undecided"] > 0 or res["n_rows"] != 61 * 8
+    p.close()
+
+
+def _k3_through_scan(ctx, path, gpu_parse):
+    scan = exon_amd.Scan(str(path), "bam", gpu_parse=gpu_parse)
+    refs = scan.dictionary(2)
+    plan = ctx.plan_flag_mapq_group_count(1284, 0, 30, len(refs), columns=(0, 1, 2))
+    st = plan.open()
+    rows = st.consume(scan)
+    counts, _ = st.finish()
+    st.close(); plan.close(); scan.close()
+    return rows, np.array(counts)
+
+
+@pytest.mark.parametrize("slab_mb", ["1", "64"])
+def test_bam_file_to_gpu_pipeline_equals_host_decode(ctx, tmp_path, monkeypatch, slab_mb):
+    n = 400_000
+    ub = tmp_path / "syn.ubam"
+    subprocess.check_call([GEN, "bam", str(n), str(ub), "100"])
+    bam = tmp_path / "syn.bam"
+    subprocess.check_call([BGZIP, str(ub), str(bam), "6"])
+    monkeypatch.setenv("EXON_HIP_GPU_PARSE_SLAB_MB", slab_mb)  # "1": dozens of slabs, records carried across them
+    rows_g, gpu = _k3_through_scan(ctx, bam, True)
+    rows_h, host = _k3_through_scan(ctx, bam, False)
+    assert rows_g == rows_h == n
+    assert np.array_equal(gpu, host) and gpu.sum() > n // 4
+
+
+def test_bam_reference_fixture_through_the_gpu_pipeline(ctx):
+    path = os.path.join(FX, "bam", "test.bam")
+    rows_g, gpu = _k3_through_scan(ctx, path, True)
+    rows_h, host = _k3_through_scan(ctx, path, False)
+    assert rows_g == rows_h == 61 and np.array_equal(gpu, host)

@@ -1,6 +1,7 @@
 // gen_text.cpp -- developer tool: writes the synthetic config-4 table as VCF text (same counter-based generator as
 // kernels.hip / oracle) so the decode -> HBM -> kernel pipeline can be timed end to end on real files.
-// `gen_text fastq <reads> <out> [read_len=150] [ragged=0]` writes 4-line FASTQ records (config 5 end to end).
+// `gen_text fastq <reads> <out> [read_len=150] [ragged=0]` writes 4-line FASTQ records (config 5 end to end);
+// `gen_text bam <reads> <out> [read_len=100]` an uncompressed BAM stream (bgzip it to get a .bam; config 3 end to end).
 // build: g++ -O2 -std=c++17 tools/gen_text.cpp -o tools/bin/gen_text      run: gen_text vcf <rows> <out.vcf>
 #include <cstdint>
 #include <cstdio>
@@ -17,6 +18,76 @@ int main(int argc, char** argv) {
   if (!f) return 1;
   static char buf[1 << 22];
   setvbuf(f, buf, _IOFBF, sizeof buf);
+  if (!strcmp(argv[1], "bam")) {
+    // uncompressed BAM stream (header + records; tools/bin/bgzip turns it into a .bam): `gen_text bam <reads> <out> [read_len=100]`
+    const int L = argc > 4 ? atoi(argv[4]) : 100;
+    auto w32 = [&](int32_t v) { fwrite(&v, 4, 1, f); };
+    const int NREF = 25;
+    std::string text = "@HD\tVN:1.6\tSO:unsorted\n";
+    for (int r = 0; r < NREF; ++r) text += "@SQ\tSN:chr" + std::to_string(r + 1) + "\tLN:250000000\n";
+    fwrite("BAM\1", 1, 4, f);
+    w32((int32_t)text.size());
+    fwrite(text.data(), 1, text.size(), f);
+    w32(NREF);
+    for (int r = 0; r < NREF; ++r) {
+      const std::string nm = "chr" + std::to_string(r + 1);
+      w32((int32_t)nm.size() + 1);
+      fwrite(nm.c_str(), 1, nm.size() + 1, f);
+      w32(250000000);
+    }
+    static const uint16_t FLAGS[12] = {99, 147, 83, 163, 0, 16, 4, 77, 141, 1024 + 99, 256 + 16, 2048 + 0};
+    std::string rec;
+    for (int64_t i = 0; i < n; ++i) {
+      const uint64_t a = rnd(3, 0, (uint64_t)i), b = rnd(3, 1, (uint64_t)i), c = rnd(3, 2, (uint64_t)i);
+      const uint16_t flag = FLAGS[a % 12];
+      const bool unmapped = (flag & 4) != 0;
+      const int32_t ref = unmapped ? -1 : (int32_t)((a >> 8) % NREF);
+      const int32_t pos = unmapped ? -1 : (int32_t)((a >> 16) % 249000000);
+      const uint32_t mq = (uint32_t)(b % 100);
+      const uint8_t mapq = mq < 2 ? 255 : mq < 10 ? 0 : mq < 22 ? (uint8_t)(1 + b % 29) : mq < 42 ? (uint8_t)(30 + b % 30) : 60;
+      const int len = L - (int)((b >> 32) % (uint64_t)(L / 3 + 1));
+      char name[40];
+      const int ln = snprintf(name, sizeof name, "read%lld:%u", (long long)i, (unsigned)(c & 0xFFF)) + 1;
+      uint32_t cig[3];
+      int ncig = 0;
+      if (!unmapped) {
+        const int kind = (int)((c >> 12) % 4);
+        if (kind == 0) cig[ncig++] = (uint32_t)len << 4 | 0;                                    // lenM
+        else if (kind == 1) { cig[ncig++] = 5u << 4 | 4; cig[ncig++] = (uint32_t)(len - 5) << 4 | 0; }  // 5S..M
+        else if (kind == 2) { cig[ncig++] = (uint32_t)(len / 2) << 4 | 0; cig[ncig++] = (uint32_t)(100 + (c >> 20) % 5000) << 4 | 3; cig[ncig++] = (uint32_t)(len - len / 2) << 4 | 0; }  // M N M
+        else { cig[ncig++] = (uint32_t)(len - 3) << 4 | 0; cig[ncig++] = 2u << 4 | 2; cig[ncig++] = 3u << 4 | 0; }  // M 2D M
+      }
+      const int aux = (int)((c >> 40) % 3) * 7;  // 0, 7 or 14 bytes of aux (NM:i / AS:i as 'C' + padding tags)
+      const int32_t bs = 32 + ln + 4 * ncig + (len + 1) / 2 + len + aux;
+      rec.assign((size_t)bs + 4, '\0');
+      auto p32 = [&](size_t o, int32_t v) { memcpy(&rec[o], &v, 4); };
+      p32(0, bs); p32(4, ref); p32(8, pos);
+      rec[12] = (char)ln; rec[13] = (char)mapq;
+      const uint16_t bin = 4680, nc = (uint16_t)ncig;
+      memcpy(&rec[14], &bin, 2); memcpy(&rec[16], &nc, 2); memcpy(&rec[18], &flag, 2);
+      p32(20, len); p32(24, -1); p32(28, -1); p32(32, 0);
+      memcpy(&rec[36], name, (size_t)ln);
+      size_t o = 36 + (size_t)ln;
+      memcpy(&rec[o], cig, 4u * (size_t)ncig); o += 4u * (size_t)ncig;
+      // bases: 4-bit codes of A/C/G/T; qualities: binned Illumina-like values in runs (what real BAMs look like to DEFLATE)
+      static const uint8_t NIB[4] = {1, 2, 4, 8}, QBIN[4] = {37, 37, 25, 11};
+      for (int k = 0; k < (len + 1) / 2; ++k) {
+        const uint64_t x = rnd(3, 3, (uint64_t)(i * 128 + k));
+        rec[o + (size_t)k] = (char)(NIB[x & 3] << 4 | NIB[(x >> 2) & 3]);
+      }
+      o += (size_t)(len + 1) / 2;
+      for (int k = 0; k < len;) {
+        const uint64_t x = rnd(3, 4, (uint64_t)(i * 256 + k));
+        const int run = 1 + (int)((x >> 8) % 12);
+        for (int j = 0; j < run && k < len; ++j, ++k) rec[o + (size_t)k] = (char)QBIN[x & 3];
+      }
+      o += (size_t)len;
+      for (int k = 0; k < aux; k += 7) memcpy(&rec[o + (size_t)k], "NMC\5ASC", 7);
+      fwrite(rec.data(), 1, rec.size(), f);
+    }
+    fclose(f);
+    return 0;
+  }
   if (!strcmp(argv[1], "fastq")) {
     const int L = argc > 4 ? atoi(argv[4]) : 150;
     const bool ragged = argc > 5 && atoi(argv[5]) != 0;
