@@ -29,7 +29,7 @@
 
 namespace {
 
-constexpr int LIT_BITS = 10, DIST_BITS = 10, CL_BITS = 7;
+constexpr int LIT_BITS = 9, DIST_BITS = 8, CL_BITS = 7;
 constexpr int WAVES_PER_WG = 4;     // k_crc32
 constexpr int INFLATE_RING = 2048;  // bytes of recent output kept in LDS per wavefront (k_inflate)
 
@@ -86,15 +86,21 @@ __device__ __forceinline__ int cl_order(int i) {
 // flat_*).
 extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
+// First-level table entries are complete decode results, so the symbol loop does no arithmetic on symbol numbers:
+//   bits 0-3 code length (0 = longer than the table, or no such code), 4-7 number of extra bits, 8 literal, 9 end of
+//   block, 10 a code that exists but may not be used (286, 287, distance 30, 31); 16-31 literal byte / length base /
+//   distance base / code-length symbol
+constexpr uint32_t E_LIT = 1u << 8, E_EOB = 1u << 9, E_INVALID = 1u << 10;
+
 struct ClTables {  // the code-length code is dead once the two main codes are built: it shares dist_lut's space
-  uint16_t cl_lut[1 << CL_BITS];
+  uint32_t cl_lut[1 << CL_BITS];
   uint16_t cl_sym[20];
   uint16_t cl_count[16];
 };
 struct WaveLds {
-  uint16_t lit_lut[1 << LIT_BITS];   // entry = symbol << 4 | code length; 0 = longer than the table (or no code)
+  uint32_t lit_lut[1 << LIT_BITS];
   union {
-    uint16_t dist_lut[1 << DIST_BITS];
+    uint32_t dist_lut[1 << DIST_BITS];
     ClTables cl;
   };
   uint16_t lit_sym[288];             // symbols in canonical order (bit-serial decode of long codes)
@@ -103,10 +109,10 @@ struct WaveLds {
   uint16_t first[16], offs[16];      // scratch of build_code
   uint8_t lens[288 + 32];
 };
-static_assert(sizeof(ClTables) <= sizeof(uint16_t) << DIST_BITS, "cl tables must fit under dist_lut");
+static_assert(sizeof(ClTables) <= sizeof(uint32_t) << DIST_BITS, "cl tables must fit under dist_lut");
 enum { CODE_LIT = 0, CODE_DIST = 1, CODE_CL = 2 };
 
-constexpr int INF_WAVES = 4;  // wavefronts (= BGZF blocks) per workgroup
+constexpr int INF_WAVES = 1;  // wavefronts (= BGZF blocks) per workgroup (1: LDS addresses need no per-wave base)
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 template <int RING>
 __device__ __forceinline__ uint8_t* wave_ring();
@@ -116,11 +122,12 @@ __device__ __forceinline__ WaveLds* wave_lds() { return reinterpret_cast<WaveLds
 template <int RING>
 __device__ __forceinline__ uint8_t* wave_ring() {
   constexpr uint32_t STRIDE = (RING + (uint32_t)sizeof(WaveLds) + 15u) & ~15u;
+  if (INF_WAVES == 1) return smem;
   return smem + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * STRIDE;
 }
 
 struct Code {
-  uint16_t* lut;
+  uint32_t* lut;
   uint16_t* sym;
   uint16_t* count;
   int bits;
@@ -198,6 +205,23 @@ struct BitReader {
   }
 };
 
+// Table entry (without the code length) of symbol s of code `which`
+__device__ __forceinline__ uint32_t entry_for(int which, int s) {
+  if (which == CODE_CL) return (uint32_t)s << 16;
+  uint32_t base;
+  int extra;
+  if (which == CODE_LIT) {
+    if (s < 256) return E_LIT | ((uint32_t)s << 16);
+    if (s == 256) return E_EOB;
+    if (s > 285) return E_INVALID;
+    length_code(s - 257, &base, &extra);
+  } else {
+    if (s > 29) return E_INVALID;
+    distance_code(s, &base, &extra);
+  }
+  return (base << 16) | ((uint32_t)extra << 4);
+}
+
 // Build code `which` from lens[0..n): counts, canonical order, first-level table.  Returns 0 for an over-subscribed
 // code, or an incomplete one that is not the single-code case DEFLATE allows.
 template <int RING>
@@ -273,7 +297,7 @@ __device__ __noinline__ int build_code_impl(int which, int lens_off, int n) {
       c.sym[(int)L->offs[l] + rank] = (uint16_t)s;
       if (l <= c.bits) {
         const unsigned rev = __brev((unsigned)code) >> (32 - l);
-        const uint16_t e = (uint16_t)((s << 4) | l);
+        const uint32_t e = entry_for(which, s) | (uint32_t)l;
         for (unsigned k = rev; k < (unsigned)size; k += 1u << l) c.lut[k] = e;
       }
     }
@@ -307,20 +331,21 @@ __device__ __noinline__ int decode_long(int which, uint32_t bits) {
   return -1;
 }
 
-// Decode one symbol (wave-uniform).  Returns -1 for a code that does not exist.
+// Decode one symbol (wave-uniform): the table entry with the code's bits consumed (the extra bits are not).
+// E_INVALID for a code that does not exist.
 template <int RING, int WHICH>
-__device__ __forceinline__ int decode_symbol(BitReader& br, const WaveLds* L) {
-  const uint16_t* lut = WHICH == CODE_LIT ? L->lit_lut : WHICH == CODE_DIST ? L->dist_lut : L->cl.cl_lut;
+__device__ __forceinline__ uint32_t decode_symbol(BitReader& br, const WaveLds* L) {
+  const uint32_t* lut = WHICH == CODE_LIT ? L->lit_lut : WHICH == CODE_DIST ? L->dist_lut : L->cl.cl_lut;
   constexpr int BITS = WHICH == CODE_LIT ? LIT_BITS : WHICH == CODE_DIST ? DIST_BITS : CL_BITS;
-  const int e = uni((int)lut[br.peek(BITS)]);
-  if (__builtin_expect(e != 0, 1)) {
-    br.drop(e & 15);
-    return e >> 4;
+  const uint32_t e = uniu(lut[br.peek(BITS)]);
+  if (__builtin_expect((e & 15u) != 0, 1)) {
+    br.drop((int)(e & 15u));
+    return e;
   }
   const int r = uni(decode_long<RING>(WHICH, (uint32_t)br.buf));
-  if (r < 0) return -1;
+  if (r < 0) return E_INVALID;
   br.drop(r & 255);
-  return r >> 8;
+  return entry_for(WHICH, r >> 8) | (uint32_t)(r & 255);
 }
 
 struct Block {  // == exon_hip_bgzf_block
@@ -383,17 +408,6 @@ __device__ __noinline__ void copy_overlapping(uint32_t pos, uint32_t d, uint32_t
     if (j < len) ring[(pos + j) & M] = v;
   }
 }
-template <int RING>
-__device__ __noinline__ void copy_far(const uint8_t* out, uint32_t pos, uint32_t d, uint32_t len) {
-  constexpr uint32_t M = RING - 1;
-  out = unip(out);
-  pos = uniu(pos);
-  d = uniu(d);
-  len = uniu(len);
-  uint8_t* ring = wave_ring<RING>();
-  for (uint32_t j = lane_id(); j < len; j += 64) ring[(pos + j) & M] = out[pos - d + j];
-}
-
 struct SymResult {
   BitReader br;
   Out o;
@@ -413,53 +427,46 @@ __device__ __noinline__ SymResult decode_symbols(BitReader br, Out o) {
   uint8_t* ring = wave_ring<RING>();
   const WaveLds* L = wave_lds<RING>();
   const uint32_t lane = lane_id();
-  int err = INF_OK;
   for (;;) {
     br.refill();
-    int s = decode_symbol<RING, CODE_LIT>(br, L);
-    if (s < 256) {
-      if (__builtin_expect(s < 0, 0)) { err = INF_BAD_CODE; break; }
-      ring[o.pos & M] = (uint8_t)s;  // every lane stores the same byte
+    const uint32_t e = decode_symbol<RING, CODE_LIT>(br, L);
+    if (e & E_LIT) {
+      ring[o.pos & M] = (uint8_t)(e >> 16);  // every lane stores the same byte
       ++o.pos;
       if (__builtin_expect((o.pos & 255u) == 0, 0)) {
-        if (o.pos > o.end || br.overrun()) { err = INF_OUTPUT_OVERRUN; break; }
+        if (o.pos > o.end || br.overrun()) return SymResult{br, o, br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN};
         o.drained = uniu(drain_rows<RING>(o.out, o.drained, o.pos));
       }
       continue;
     }
-    if (s == 256) break;
-    s -= 257;
-    if (__builtin_expect(s >= 29, 0)) { err = INF_BAD_CODE; break; }
-    uint32_t len;
-    int ext;
-    length_code(s, &len, &ext);
-    len += br.take(ext);
+    if (__builtin_expect((e & (E_EOB | E_INVALID)) != 0, 0)) {
+      return SymResult{br, o, (e & E_EOB) ? INF_OK : INF_BAD_CODE};
+    }
+    const uint32_t len = (e >> 16) + br.take((int)((e >> 4) & 15u));
     br.refill();
-    const int ds = decode_symbol<RING, CODE_DIST>(br, L);
-    if (__builtin_expect(ds < 0 || ds >= 30, 0)) { err = INF_BAD_CODE; break; }
-    uint32_t d;
-    distance_code(ds, &d, &ext);
-    d += br.take(ext);
-    if (__builtin_expect(d > o.pos - o.begin, 0)) { err = INF_BAD_DISTANCE; break; }
+    const uint32_t de = decode_symbol<RING, CODE_DIST>(br, L);
+    if (__builtin_expect((de & E_INVALID) != 0, 0)) return SymResult{br, o, INF_BAD_CODE};
+    const uint32_t d = (de >> 16) + br.take((int)((de >> 4) & 15u));
+    if (__builtin_expect(d > o.pos - o.begin, 0)) return SymResult{br, o, INF_BAD_DISTANCE};
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (d <= NEAR && d >= len) {
+    if (d - len <= NEAR - len) {  // len <= d <= NEAR (unsigned wrap-around when d < len)
       for (uint32_t j = lane; j < len; j += 64) ring[(o.pos + j) & M] = ring[(o.pos - d + j) & M];
     } else if (d <= NEAR) {
       copy_overlapping<RING>(o.pos, d, len);
     } else {
       // far: d > NEAR >= 258 + 255, so the source ends below `drained` (pos - drained < 256): it is in HBM already
-      copy_far<RING>(o.out, o.pos, d, len);
+      // (common: DEFLATE windows are 32 KiB, the ring holds 2) -- inline, a call costs ~40 scalar instructions
+      for (uint32_t j = lane; j < len; j += 64) ring[(o.pos + j) & M] = o.out[o.pos - d + j];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const uint32_t npos = o.pos + len;
     if (__builtin_expect(((o.pos ^ npos) >> 8) != 0, 0)) {  // crossed a 256-byte row
-      if (npos > o.end || br.overrun()) { err = INF_OUTPUT_OVERRUN; break; }
+      if (npos > o.end || br.overrun()) return SymResult{br, o, br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN};
       o.drained = uniu(drain_rows<RING>(o.out, o.drained, npos & ~255u));
     }
     o.pos = npos;
   }
-  if (err == INF_OUTPUT_OVERRUN && br.overrun()) err = INF_INPUT_OVERRUN;
-  return SymResult{br, o, err};
+
 }
 
 template <int RING>
@@ -531,8 +538,9 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(const uint8_t* __res
       const int total = hlit + hdist;
       while (i < total) {
         br.refill();
-        const int s = decode_symbol<RING, CODE_CL>(br, L);
-        if (s < 0) { err = INF_BAD_CODE; break; }
+        const uint32_t ce = decode_symbol<RING, CODE_CL>(br, L);
+        if (ce & E_INVALID) { err = INF_BAD_CODE; break; }
+        const int s = (int)(ce >> 16);
         if (s < 16) {
           L->lens[i++] = (uint8_t)s;
           prev = s;

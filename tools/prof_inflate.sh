@@ -1,21 +1,24 @@
-# rocprofv3 kernel stats of the BGZF pipeline (GPU inflate + CRC + VCF parse + K4) on a 50M-row synthetic .vcf.gz
-cd /tmp && export TMPDIR=/tmp
+# inflate kernel time vs number of blocks (resident compressed slab), VCF text level 6
 cd $GRAFT_REPO_ROOT
-tools/bin/gen_text vcf 50000000 /tmp/p.vcf && tools/bin/bgzip /tmp/p.vcf /tmp/p.vcf.gz 6
-cat > /tmp/pipe_one.py <<'PY'
+tools/bin/gen_text vcf 10000000 /tmp/p.vcf && tools/bin/bgzip /tmp/p.vcf /tmp/p.vcf.gz 6
+cat > /tmp/inf_one.py <<'PY'
 import sys, os, time
 sys.path.insert(0, os.getcwd())
+import numpy as np, ctypes as C
 import exon_amd
 ctx = exon_amd.Context(0)
-for rep in range(2):
-    scan = exon_amd.Scan("/tmp/p.vcf.gz", "vcf", info_field="AF", gpu_parse=True)
-    plan = ctx.plan_cmp_avg_by_group(">", 0.01, 64, columns=(4, 2, 3))
-    st = plan.open()
-    t = time.perf_counter()
-    rows = st.consume(scan)
-    counts, sums = st.finish()
-    print(rows, time.perf_counter() - t)
-    st.close(); plan.close(); scan.close()
+raw = open("/tmp/p.vcf.gz","rb").read()
+blocks, n, consumed, out_bytes = exon_amd.bgzf_scan(raw)
+comp = np.frombuffer(raw, np.uint8)[:consumed]
+d_comp = ctx.to_device(np.concatenate([comp, np.zeros(4096 + (-len(comp)) % 4, np.uint8)]))
+d_out = ctx.empty(np.uint8, out_bytes + 64)
+bad = C.c_int32(-1)
+for nb in (1, 2048, 6558):
+    ts = []
+    for rep in range(3):
+        t = time.perf_counter()
+        ctx._check(ctx.lib.exon_hip_bgzf_inflate(ctx.h, None, d_comp.ptr, blocks, nb, d_out.ptr, 0, C.byref(bad)))
+        ts.append(time.perf_counter() - t)
+    print(f"{nb} blocks: {min(ts)*1e3:.3f} ms")
 PY
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bgzf -o run --output-format csv -- python /tmp/pipe_one.py 2>&1 | grep -v "^[EW]2026" | tail -3
-cat gpurun_out/prof_bgzf/run_kernel_stats.csv | cut -c1-200
+python /tmp/inf_one.py
