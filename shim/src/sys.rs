@@ -48,4 +48,29 @@ extern "C" {
     pub fn exon_hip_stream_close(s: *mut exon_hip_stream) -> c_int;
     pub fn exon_hip_parse_region(region: *const c_char, name_out: *mut c_char, name_cap: usize, start: *mut i64, end: *mut i64) -> c_int;
     pub fn exon_hip_regroup_files_by_size(sizes: *const i64, n_files: i32, target_groups: i32, group_of: *mut i32) -> c_int;
+
+    // ---- whole-partition path: the library opens the file itself (native decoders; with gpu_parse = 1 the file's
+    // bytes go to HBM as they are -- BGZF blocks are inflated and VCF / FASTQ / BAM records decoded on the GPU) ----
+    pub fn exon_hip_scan_open(path: *const c_char, options: *const exon_hip_scan_options, out: *mut *mut exon_hip_scan) -> c_int;
+    pub fn exon_hip_scan_dictionary_size(scan: *mut exon_hip_scan, column: i32, size: *mut i32) -> c_int;
+    pub fn exon_hip_scan_dictionary_intern(scan: *mut exon_hip_scan, column: i32, name: *const c_char, id: *mut i32) -> c_int;
+    pub fn exon_hip_scan_dictionary_value(scan: *mut exon_hip_scan, column: i32, id: i32, name: *mut *const c_char) -> c_int;
+    pub fn exon_hip_scan_close(scan: *mut exon_hip_scan) -> c_int;
+    /// GpuFilterAggExec::execute for one file group in one call
+    pub fn exon_hip_stream_consume_scan(s: *mut exon_hip_stream, scan: *mut exon_hip_scan, rows: *mut i64) -> c_int;
+}
+
+#[repr(C)]
+pub struct exon_hip_scan { _p: [u8; 0] }
+
+/// mirrors `exon_hip_scan_options` (include/exon_hip.h)
+#[repr(C)]
+pub struct exon_hip_scan_options {
+    pub format: i32,       // EXON_HIP_FORMAT_* (VCF 1, BAM 2, FASTQ 3, FASTA 4, SAM 5, BCF 6)
+    pub compression: i32,  // 0 auto, 1 none, 2 gzip / BGZF
+    pub batch_size: i64,
+    pub info_field: *const c_char,
+    pub region: *const c_char,
+    pub use_index: i32,
+    pub gpu_parse: i32,
 }

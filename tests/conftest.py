@@ -24,3 +24,11 @@ def ctx():
     c = exon_amd.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _test_tools():
+    """tools/bin/gen_text and tools/bin/bgzip (synthetic inputs of the pipeline tests): built on demand, plain g++."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.call(["make", "-C", os.path.join(root, "tools"), "-s"])
