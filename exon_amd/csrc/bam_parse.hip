@@ -96,6 +96,9 @@ __global__ __launch_bounds__(64) void k_bam_walk(const uint8_t* __restrict__ d, 
       ++k;
       r += 4 + bs;
     }
+    // the next record's header is not fully inside the slab: whatever follows cannot be recognised by the segments
+    // behind this one, and does not need to be -- it is the cut-off tail
+    if (bad == 0 && (uint64_t)r + 36 > n) bad = 2;
   }
   if (lane == 0) seg[s] = SegInfo{start, r, k, bad};
 }

@@ -368,10 +368,12 @@ class GpuTextSource {
       : ctx_(ctx), hs_(hs), src_(std::move(src)), rd_(src_.get()), bgzf_(bgzf), binary_(binary), skip_(skip_first), carry_(std::move(carry)) {
     slab_ = slab_bytes();
     if (bgzf_) {
-      // one wavefront inflates one block and a block takes ~5 ms however many run beside it: a launch wants >= 7000
-      // blocks (28 wavefronts on each of 256 CUs), i.e. ~128 MB of compressed input
-      comp_cap_ = slab_ + (1u << 17);  // compressed bytes per slab (+ a carried partial block)
-      text_cap_ = 8 * slab_;           // inflated bytes per slab
+      // One wavefront inflates one block and a block takes ~3.5 ms however many run beside it, so a launch wants as many
+      // blocks as the chip holds wavefronts of this kernel (25 per CU x 256 CUs) and not one more: slabs are cut by BLOCK
+      // COUNT.  The bytes read per slab follow the running average block size.
+      target_blocks_ = (int)std::max<size_t>(64, 6144 * (slab_ >> 20) / 64);
+      comp_cap_ = 2 * slab_ + (1u << 17);           // compressed bytes per slab (+ a carried partial block)
+      text_cap_ = (size_t)target_blocks_ * 65536;   // inflated bytes per slab
     } else {
       text_cap_ = slab_;
     }
@@ -556,17 +558,18 @@ class GpuTextSource {
       memcpy(h_buf_[k], left_.data(), left_.size());
       size_t have = left_.size();
       left_.clear();
-      if (!file_eof_) {
-        const size_t want = comp_cap_ - have;
+      const size_t goal = std::min(comp_cap_, (size_t)((double)est_block_ * target_blocks_ * 1.03) + (1u << 16));
+      if (!file_eof_ && have < goal) {
+        const size_t want = goal - have;
         const size_t got = rd_.read(h_buf_[k] + have, want);
         file_eof_ = got < want;
         have += got;
       }
       int32_t nb = 0;
       size_t consumed = 0, out_bytes = 0;
-      // leave room for the text cap: scan, then keep the prefix that fits
-      if (exon_hip_bgzf_scan(h_buf_[k], have, 0, h_blocks_tmp(k), max_blocks_, &nb, &consumed, &out_bytes) != EXON_HIP_OK)
+      if (exon_hip_bgzf_scan(h_buf_[k], have, 0, h_blocks_tmp(k), std::min(max_blocks_, target_blocks_), &nb, &consumed, &out_bytes) != EXON_HIP_OK)
         throw std::runtime_error(exon_hip_last_error(nullptr));
+      if (nb > 0) est_block_ = (double)consumed / nb;
       exon_hip_bgzf_block* hb = h_blocks_tmp(k);
       if (out_bytes > text_cap_) {
         int keep = 0;
@@ -611,7 +614,8 @@ class GpuTextSource {
   exon_hip_bgzf_block* h_blocks_ = nullptr;  // pinned: table + status of the slab in flight
   exon_hip_bgzf_block* d_blocks_ = nullptr;
   std::vector<exon_hip_bgzf_block> scan_tmp_[2], block_tables_[2];
-  int max_blocks_ = 0;
+  int max_blocks_ = 0, target_blocks_ = 0;
+  double est_block_ = 20000;  // running average of the compressed block size
   std::string left_;
   bool file_eof_ = false;
   Filled cur_, nxt_;
@@ -714,6 +718,7 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
       exon_hip_bam_columns cols;
       rc = exon_hip_bam_parser_parse(scan->bam_parser, hs, d_text, (int64_t)n, &cols);
       t_parse += now_s() - t1;
+      if (trace) fprintf(stderr, "[exon-hip pipe] bam slab %zu bytes: rc %d rows %lld undecided %lld consumed %lld\n", n, rc, (long long)cols.n_rows, (long long)cols.n_undecided, (long long)cols.consumed_bytes);
       if (!rc && cols.n_undecided > 0) rc = 1;
       if (rc) break;
       consumed = (size_t)cols.consumed_bytes;

@@ -86,8 +86,10 @@ def test_bam_parser_many_segments_and_cut_off_record(ctx, tmp_path):
     assert res["n_undecided"] == 0 and res["n_rows"] == 39999 and 0 < res["consumed_bytes"] < cut
     bs = struct.unpack_from("<i", data, res["consumed_bytes"])[0]
     assert res["consumed_bytes"] + 4 + bs == len(data)
-    # a slab cut in the middle of the 4-byte length field, and one several segments before the end
-    for cut in (res["consumed_bytes"] + 2, len(data) - 3 * 65536 - 11):
+    # a slab cut in the middle of the 4-byte length field, one several segments before the end, and slabs whose last
+    # 64 KiB segment holds only a few bytes of a cut-off record (or nothing at all)
+    seg_edge = (len(data) // 65536) * 65536
+    for cut in (res["consumed_bytes"] + 2, len(data) - 3 * 65536 - 11, seg_edge + 3, seg_edge + 20, seg_edge + 143, seg_edge, seg_edge - 1):
         r2 = p.parse_host(data[:cut])
         assert r2["n_undecided"] == 0 and r2["consumed_bytes"] <= cut
         assert r2["flag"].tolist() == host["flag"][:r2["n_rows"]]
