@@ -54,19 +54,26 @@ __device__ __forceinline__ int count_nl16(uint4 v) {
   return c;
 }
 
-__device__ __forceinline__ uint4 load16(const uint8_t* text, int64_t n, int64_t off) {
-  if (off + 16 <= n) return *reinterpret_cast<const uint4*>(text + off);  // text is 16-byte aligned
+// `text` is 16-byte aligned; the slab proper starts `skip` (< 16) bytes into it: those bytes read as zeros
+__device__ __forceinline__ uint4 load16(const uint8_t* text, int64_t n, int64_t off, unsigned skip) {
   uint4 v = {0, 0, 0, 0};
   unsigned* w = &v.x;
-  for (int i = 0; i < 16 && off + i < n; ++i) w[i >> 2] |= (unsigned)text[off + i] << (8 * (i & 3));
+  if (off + 16 <= n) {
+    v = *reinterpret_cast<const uint4*>(text + off);
+  } else {
+    for (int i = 0; i < 16 && off + i < n; ++i) w[i >> 2] |= (unsigned)text[off + i] << (8 * (i & 3));
+  }
+  if (off == 0 && skip) {
+    for (unsigned i = 0; i < skip; ++i) w[i >> 2] &= ~(0xFFu << (8 * (i & 3)));
+  }
   return v;
 }
 
-__global__ __launch_bounds__(TPB) void k_count_newlines(const uint8_t* __restrict__ text, int64_t n,
+__global__ __launch_bounds__(TPB) void k_count_newlines(const uint8_t* __restrict__ text, int64_t n, unsigned skip,
                                                         unsigned* __restrict__ block_counts) {
   __shared__ unsigned red[TPB / 64];
   const int64_t off = ((int64_t)blockIdx.x * TPB + threadIdx.x) * BYTES_PER_THREAD;
-  unsigned c = off < n ? (unsigned)count_nl16(load16(text, n, off)) : 0u;
+  unsigned c = off < n ? (unsigned)count_nl16(load16(text, n, off, skip)) : 0u;
   for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
   __syncthreads();
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(unsigned* __restrict__ cou
   if (threadIdx.x == 1023) *n_lines = part[1023];
 }
 
-__global__ __launch_bounds__(TPB) void k_fill_newlines(const uint8_t* __restrict__ text, int64_t n,
+__global__ __launch_bounds__(TPB) void k_fill_newlines(const uint8_t* __restrict__ text, int64_t n, unsigned skip,
                                                        const unsigned* __restrict__ block_offsets,
                                                        unsigned* __restrict__ nl_pos, unsigned cap) {
   __shared__ unsigned wave_tot[TPB / 64];
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(TPB) void k_fill_newlines(const uint8_t* __restrict
   uint4 v = {0, 0, 0, 0};
   unsigned c = 0;
   if (off < n) {
-    v = load16(text, n, off);
+    v = load16(text, n, off, skip);
     c = (unsigned)count_nl16(v);
   }
   unsigned incl = c;  // inclusive scan within the wave
@@ -177,13 +184,13 @@ __device__ __forceinline__ void store_valid(uint8_t* bm, int64_t row0_of_wave, i
 __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__ text, const unsigned* __restrict__ nl_pos,
                                                      const unsigned* __restrict__ n_lines_p, NameTable contigs,
                                                      FilterTable filters, const uint8_t* __restrict__ info_key,
-                                                     int info_key_len, ParseOut out, unsigned cap) {
+                                                     int info_key_len, ParseOut out, unsigned cap, unsigned skip) {
   const int64_t n_rows = min(*n_lines_p, cap);
   const int64_t row = (int64_t)blockIdx.x * TPB + threadIdx.x;
   const int lane = threadIdx.x & 63;
   bool pos_ok = false, qual_ok = false, info_ok = false, bad = false;
   if (row < n_rows) {
-    const unsigned begin = row ? nl_pos[row - 1] + 1 : 0u;
+    const unsigned begin = row ? nl_pos[row - 1] + 1 : skip;
     unsigned end = nl_pos[row];
     if (end > begin && text[end - 1] == '\r') --end;
     // split the first 8 fields
@@ -479,21 +486,25 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* p, void* stream, const uint8_
   if (!p || !cols || (n_bytes > 0 && !d_text)) return fail(p ? p->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_vcf_parser_parse: NULL argument");
   exon_hip_ctx* ctx = p->ctx;
   if (n_bytes > p->max_bytes) return fail(ctx, EXON_HIP_EINVAL, "slab of %lld bytes exceeds the parser's %lld", (long long)n_bytes, (long long)p->max_bytes);
-  if ((reinterpret_cast<uintptr_t>(d_text) & 15) != 0) return fail(ctx, EXON_HIP_EINVAL, "text must be 16-byte aligned");
   memset(cols, 0, sizeof *cols);
   if (n_bytes == 0) return EXON_HIP_OK;
+  // the kernels read aligned 16-byte groups: start at the aligned address at or below d_text and ignore the bytes before it
+  const unsigned skip = (unsigned)(reinterpret_cast<uintptr_t>(d_text) & 15);
+  d_text -= skip;
+  n_bytes += skip;
+  if (n_bytes > p->max_bytes) return fail(ctx, EXON_HIP_EINVAL, "slab of %lld bytes exceeds the parser's %lld", (long long)n_bytes, (long long)p->max_bytes);
   hipStream_t s = pick_stream(ctx, stream);
   const int nblocks = (int)((n_bytes + BYTES_PER_BLOCK - 1) / BYTES_PER_BLOCK);
   HIP_TRY(ctx, hipMemsetAsync(p->d_scalars, 0, 16, s));
-  hipLaunchKernelGGL(k_count_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, p->d_block_counts);
+  hipLaunchKernelGGL(k_count_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, skip, p->d_block_counts);
   hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, p->d_block_counts, nblocks, p->d_scalars);
-  hipLaunchKernelGGL(k_fill_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, p->d_block_counts, p->d_nl, (unsigned)p->max_rows);
+  hipLaunchKernelGGL(k_fill_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, skip, p->d_block_counts, p->d_nl, (unsigned)p->max_rows);
   hipLaunchKernelGGL(k_last_newline, dim3(1), dim3(1), 0, s, p->d_nl, p->d_scalars, (unsigned)p->max_rows);
   // the number of lines is bounded by n_bytes / 16 + 1 for well-formed data lines; launch for that bound
   const int64_t row_bound = std::min<int64_t>(p->max_rows, n_bytes / 16 + 1);
   const int pblocks = (int)((row_bound + TPB - 1) / TPB);
   hipLaunchKernelGGL(k_parse_lines, dim3(pblocks), dim3(TPB), 0, s, d_text, p->d_nl, p->d_scalars, p->contigs, p->filters,
-                     p->d_info_key, (int)p->info_field.size(), p->out, (unsigned)row_bound);
+                     p->d_info_key, (int)p->info_field.size(), p->out, (unsigned)row_bound, skip);
   hipLaunchKernelGGL(k_assign_filters, dim3(1), dim3(256), 0, s, d_text, p->filters);
   hipLaunchKernelGGL(k_remap_filters, dim3(std::min(pblocks, 4096)), dim3(TPB), 0, s, p->out.filter_id, p->d_scalars, p->filters.ids, (unsigned)row_bound);
   HIP_TRY(ctx, hipGetLastError());
@@ -503,7 +514,7 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* p, void* stream, const uint8_
   if (n_lines > row_bound) return fail(ctx, EXON_HIP_EINVAL, "slab has %lld lines, more than its byte size allows for VCF records", (long long)n_lines);
   cols->n_rows = n_lines;
   cols->n_undecided = p->h_scalars[1];
-  cols->consumed_bytes = p->h_scalars[2];
+  cols->consumed_bytes = p->h_scalars[2] > skip ? (int64_t)p->h_scalars[2] - skip : 0;
   cols->chrom_id = p->out.chrom_id;
   cols->pos = p->out.pos;
   cols->pos_valid = p->out.pos_valid;
@@ -561,7 +572,7 @@ namespace {
 __global__ __launch_bounds__(TPB) void k_fastq_views(const uint8_t* __restrict__ text, const unsigned* __restrict__ nl,
                                                      unsigned* __restrict__ scalars, unsigned cap_lines, int final_slab,
                                                      int32_t* __restrict__ seq_s, int32_t* __restrict__ seq_e,
-                                                     int32_t* __restrict__ qual_s, int32_t* __restrict__ qual_e) {
+                                                     int32_t* __restrict__ qual_s, int32_t* __restrict__ qual_e, unsigned skip) {
   const unsigned n_lines = scalars[0];
   const int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x;
   if (n_lines > cap_lines) {  // the index was truncated: nothing can be trusted
@@ -574,7 +585,7 @@ __global__ __launch_bounds__(TPB) void k_fastq_views(const uint8_t* __restrict__
     if (final_slab && (n_lines & 3u)) atomicAdd(&scalars[1], 1u);
   }
   if (r >= n_reads) return;
-  const unsigned l0 = r ? nl[4 * r - 1] + 1u : 0u;
+  const unsigned l0 = r ? nl[4 * r - 1] + 1u : skip;
   const unsigned e0 = nl[4 * r], e1 = nl[4 * r + 1], e2 = nl[4 * r + 2], e3 = nl[4 * r + 3];
   const bool bad = text[l0] != '@' || text[e1 + 1] != '+';
   unsigned se = e1, qe = e3;
@@ -641,26 +652,31 @@ int exon_hip_fastq_parser_parse(exon_hip_fastq_parser* p, void* stream, const ui
   if (!p || !views || (n_bytes > 0 && !d_text)) return fail(p ? p->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_fastq_parser_parse: NULL argument");
   exon_hip_ctx* ctx = p->ctx;
   if (n_bytes > p->max_bytes) return fail(ctx, EXON_HIP_EINVAL, "slab of %lld bytes exceeds the parser's %lld", (long long)n_bytes, (long long)p->max_bytes);
-  if ((reinterpret_cast<uintptr_t>(d_text) & 15) != 0) return fail(ctx, EXON_HIP_EINVAL, "text must be 16-byte aligned");
   memset(views, 0, sizeof *views);
   if (n_bytes == 0) return EXON_HIP_OK;
+  // the kernels read aligned 16-byte groups: start at the aligned address at or below d_text and ignore the bytes before it
+  const unsigned skip = (unsigned)(reinterpret_cast<uintptr_t>(d_text) & 15);
+  d_text -= skip;
+  n_bytes += skip;
+  if (n_bytes > p->max_bytes) return fail(ctx, EXON_HIP_EINVAL, "slab of %lld bytes exceeds the parser's %lld", (long long)n_bytes, (long long)p->max_bytes);
   hipStream_t s = pick_stream(ctx, stream);
   const int nblocks = (int)((n_bytes + BYTES_PER_BLOCK - 1) / BYTES_PER_BLOCK);
   const size_t per = (size_t)(p->max_lines / 4 + 1);
   int32_t* v = p->d_views;
   HIP_TRY(ctx, hipMemsetAsync(p->d_scalars, 0, 16, s));
-  hipLaunchKernelGGL(k_count_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, p->d_block_counts);
+  hipLaunchKernelGGL(k_count_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, skip, p->d_block_counts);
   hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, p->d_block_counts, nblocks, p->d_scalars);
-  hipLaunchKernelGGL(k_fill_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, p->d_block_counts, p->d_nl, (unsigned)p->max_lines);
+  hipLaunchKernelGGL(k_fill_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, skip, p->d_block_counts, p->d_nl, (unsigned)p->max_lines);
   const int64_t read_bound = std::min<int64_t>((int64_t)per, n_bytes / 4 + 1);  // a record holds 4 newlines
   hipLaunchKernelGGL(k_fastq_views, dim3((unsigned)((read_bound + TPB - 1) / TPB)), dim3(TPB), 0, s, d_text, p->d_nl, p->d_scalars,
-                     (unsigned)p->max_lines, (int)final_slab, v, v + per, v + 2 * per, v + 3 * per);
+                     (unsigned)p->max_lines, (int)final_slab, v, v + per, v + 2 * per, v + 3 * per, skip);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(p->h_scalars, p->d_scalars, 16, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
   views->n_undecided = p->h_scalars[1];
   views->n_reads = p->h_scalars[0] > (unsigned)p->max_lines ? 0 : p->h_scalars[0] / 4;
-  views->consumed_bytes = p->h_scalars[2];
+  views->consumed_bytes = p->h_scalars[2] > skip ? (int64_t)p->h_scalars[2] - skip : 0;
+  views->text_base = d_text;
   views->seq_start = v;
   views->seq_end = v + per;
   views->qual_start = v + 2 * per;

@@ -320,6 +320,12 @@ static size_t slab_bytes() {
   return slab;
 }
 
+static double now_s() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 // ---- text slabs in HBM ----------------------------------------------------------------------------------------------
 // Feeds the GPU-side parsers with slabs of text resident in HBM.  The consumer reports how many bytes of a slab form
 // whole records (the device knows, the host never looks at the text); the tail is carried in front of the next slab.
@@ -381,6 +387,19 @@ class GpuTextSource {
   }
   ~GpuTextSource() {
     if (reader_.joinable()) reader_.join();
+    if (xs_) {
+      hipStreamSynchronize(xs_);
+      hipStreamDestroy(xs_);
+    }
+    if (cs_) {
+      hipStreamSynchronize(cs_);
+      hipStreamDestroy(cs_);
+    }
+    for (int k = 0; k < 2; ++k) {
+      if (ev_h2d_[k]) hipEventDestroy(ev_h2d_[k]);
+      if (ev_done_[k]) hipEventDestroy(ev_done_[k]);
+      if (ev_free_[k]) hipEventDestroy(ev_free_[k]);
+    }
     SlabBuffers b;
     b.bgzf = bgzf_;
     b.hcap = hcap_;
@@ -404,6 +423,7 @@ class GpuTextSource {
     slot = b;
   }
   size_t max_text_bytes() const { return gap_ + text_cap_ + 64; }
+  double reader_seconds() const { return t_fill_; }
 
   int init() {
     hcap_ = bgzf_ ? comp_cap_ + 4096 : gap_ + text_cap_ + 64;
@@ -435,11 +455,25 @@ class GpuTextSource {
           return fail(ctx_, EXON_HIP_ENOMEM, "slab buffers (%zu bytes of text) could not be allocated", text_cap_);
       }
       if (bgzf_) {
-        if (hipHostMalloc((void**)&h_blocks_, (size_t)max_blocks_ * (sizeof(exon_hip_bgzf_block) + sizeof(int))) != hipSuccess ||
-            hipMalloc((void**)&d_blocks_, (size_t)max_blocks_ * (sizeof(exon_hip_bgzf_block) + sizeof(int))) != hipSuccess)
+        if (hipHostMalloc((void**)&h_blocks_, 2 * table_bytes()) != hipSuccess || hipMalloc((void**)&d_blocks_, 2 * table_bytes()) != hipSuccess)
           return fail(ctx_, EXON_HIP_ENOMEM, "BGZF block tables could not be allocated");
       }
       complete_ = true;
+    }
+    if (bgzf_) {
+      if (hipStreamCreateWithFlags(&cs_, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&xs_, hipStreamNonBlocking) != hipSuccess)
+        return fail(ctx_, EXON_HIP_EDEVICE, "stream creation failed");
+      for (int k = 0; k < 2; ++k)
+        if (hipEventCreateWithFlags(&ev_h2d_[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_done_[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_free_[k], hipEventDisableTiming) != hipSuccess)
+          return fail(ctx_, EXON_HIP_EDEVICE, "event creation failed");
+      fill(0, &f_[0]);
+      if (f_[0].err) return rethrow(f_[0].err);
+      int rc = enqueue_inflate(0);
+      if (rc) return rc;
+      if (!f_[0].eof) reader_ = std::thread([this] { fill(1, &f_[1]); });
+      return EXON_HIP_OK;
     }
     fill(0, &cur_);
     k_ = 0;
@@ -448,6 +482,7 @@ class GpuTextSource {
 
   // Next slab: *d_text is 16-byte aligned.  *n == 0 with *final: end of input.
   int next(const uint8_t** d_text, size_t* n, bool* final) {
+    if (bgzf_) return next_bgzf(d_text, n, final);
     if (reader_.joinable()) reader_.join();
     if (started_) {
       cur_ = nxt_;
@@ -464,49 +499,7 @@ class GpuTextSource {
     *final = !more;
     size_t n_text = 0;
     size_t front = 0;  // offset of the slab's first byte inside d_text_[k]
-    if (bgzf_) {
-      // [carry (already copied device-to-device by release()) | inflated blocks]; the very first slab instead starts
-      // `skip_` bytes into the inflated text (the header the host reader consumed), shifted so that byte is aligned
-      size_t base = carry_dev_;
-      if (skip_) base = (16 - (size_t)(skip_ & 15)) & 15;
-      if (cur_.n_blocks > 0) {
-        exon_hip_bgzf_block* hb = h_blocks_;
-        const size_t tb = (size_t)cur_.n_blocks * sizeof(exon_hip_bgzf_block);
-        memcpy(hb, block_tables_[k].data(), tb);
-        for (int i = 0; i < cur_.n_blocks; ++i) hb[i].out_offset += (uint32_t)base;
-        exon_hip_bgzf_block* db = d_blocks_;
-        int* dstat = reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(d_blocks_) + (size_t)max_blocks_ * sizeof(exon_hip_bgzf_block));
-        int* hstat = reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(h_blocks_) + (size_t)max_blocks_ * sizeof(exon_hip_bgzf_block));
-        HIP_TRY(ctx_, hipMemcpyAsync(d_comp_[k], h_buf_[k], cur_.n + 4096, hipMemcpyHostToDevice, hs_));
-        HIP_TRY(ctx_, hipMemcpyAsync(db, hb, tb, hipMemcpyHostToDevice, hs_));
-        HIP_TRY(ctx_, exon_bgzf_inflate_launch(hs_, d_comp_[k], db, cur_.n_blocks, d_text_[k], dstat, true));
-        HIP_TRY(ctx_, hipMemcpyAsync(hstat, dstat, (size_t)cur_.n_blocks * sizeof(int), hipMemcpyDeviceToHost, hs_));
-        HIP_TRY(ctx_, hipStreamSynchronize(hs_));
-        for (int i = 0; i < cur_.n_blocks; ++i)
-          if (hstat[i] != 0) {
-            fail(ctx_, EXON_HIP_EINVAL, "BGZF block: %s (decoding on the host instead)", exon_bgzf_status_name(hstat[i]));
-            return 1;
-          }
-      }
-      if (skip_) {
-        if (cur_.out_bytes < skip_) return 1;  // the header spans more than one slab: not worth handling here
-        front = base + (size_t)skip_;
-        n_text = cur_.out_bytes - (size_t)skip_;
-        skip_ = 0;
-      } else {
-        front = 0;
-        n_text = carry_dev_ + cur_.out_bytes;
-      }
-      if (!more && n_text > 0 && !binary_) {  // last line without a terminator
-        uint8_t lastb = 0;
-        HIP_TRY(ctx_, hipMemcpyAsync(&lastb, d_text_[k] + front + n_text - 1, 1, hipMemcpyDeviceToHost, hs_));
-        HIP_TRY(ctx_, hipStreamSynchronize(hs_));
-        if (lastb != '\n') {
-          HIP_TRY(ctx_, hipMemsetAsync(d_text_[k] + front + n_text, '\n', 1, hs_));
-          ++n_text;
-        }
-      }
-    } else {
+    {
       if (carry_.size() > gap_) return 1;  // a record larger than the gap: host decoder
       uint8_t* base = h_buf_[k] + gap_ - carry_.size();
       memcpy(base, carry_.data(), carry_.size());
@@ -529,9 +522,11 @@ class GpuTextSource {
     if (final) return tail == 0 ? EXON_HIP_OK : 1;  // a partial record at the end of the input: host decoder decides
     if (tail > gap_) return 1;
     if (bgzf_) {
-      // device-to-device, stream-ordered before the next slab's inflate (which appends right behind it)
-      if (tail) HIP_TRY(ctx_, hipMemcpyAsync(d_text_[k_ ^ 1], d_text_[k_] + cur_front_ + consumed, tail, hipMemcpyDeviceToDevice, hs_));
+      // copied device-to-device in front of the next slab's text when that slab is taken (next_bgzf)
+      carry_k_ = (int)(idx_ & 1);
+      carry_off_ = cur_front_ + consumed;
       carry_dev_ = tail;
+      ++idx_;
     } else {
       carry_.assign(reinterpret_cast<const char*>(h_base_) + consumed, tail);
     }
@@ -539,6 +534,89 @@ class GpuTextSource {
   }
 
  private:
+  size_t table_bytes() const { return (size_t)max_blocks_ * (sizeof(exon_hip_bgzf_block) + sizeof(int)); }
+  exon_hip_bgzf_block* h_table(int k) { return reinterpret_cast<exon_hip_bgzf_block*>(reinterpret_cast<uint8_t*>(h_blocks_) + (size_t)k * table_bytes()); }
+  exon_hip_bgzf_block* d_table(int k) { return reinterpret_cast<exon_hip_bgzf_block*>(reinterpret_cast<uint8_t*>(d_blocks_) + (size_t)k * table_bytes()); }
+  int* h_status(int k) { return reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(h_table(k)) + (size_t)max_blocks_ * sizeof(exon_hip_bgzf_block)); }
+  int* d_status(int k) { return reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(d_table(k)) + (size_t)max_blocks_ * sizeof(exon_hip_bgzf_block)); }
+  int rethrow(std::exception_ptr e) {
+    try { std::rethrow_exception(e); } catch (const std::exception& x) { return fail(ctx_, EXON_HIP_EINVAL, "%s", x.what()); }
+    return EXON_HIP_EINVAL;
+  }
+
+  // BGZF mode is a two-stream pipeline: while the consumer parses slab i on its stream, slab i+1 crosses PCIe and is
+  // inflated on the copy stream `cs_` (the inflated bytes always land at offset gap_ of their text buffer; the tail
+  // carried from the previous slab is copied right in front of them when the slab is taken -- the parsers accept any
+  // alignment).  ev_done_[k]: inflate of buffer k finished; ev_free_[k]: the consumer is done with buffer k.
+  int enqueue_inflate(int k) {
+    const Filled& f = f_[k];
+    enq_[k] = false;
+    if (f.n_blocks == 0) return EXON_HIP_OK;
+    if (free_rec_[k]) HIP_TRY(ctx_, hipStreamWaitEvent(cs_, ev_free_[k], 0));
+    exon_hip_bgzf_block* hb = h_table(k);
+    const size_t tb = (size_t)f.n_blocks * sizeof(exon_hip_bgzf_block);
+    memcpy(hb, block_tables_[k].data(), tb);
+    for (int i = 0; i < f.n_blocks; ++i) hb[i].out_offset += (uint32_t)gap_;
+    HIP_TRY(ctx_, hipStreamWaitEvent(cs_, ev_h2d_[k], 0));  // the compressed bytes (copied by the reader on xs_)
+    HIP_TRY(ctx_, hipMemcpyAsync(d_table(k), hb, tb, hipMemcpyHostToDevice, cs_));
+    HIP_TRY(ctx_, exon_bgzf_inflate_launch(cs_, d_comp_[k], d_table(k), f.n_blocks, d_text_[k], d_status(k), true));
+    HIP_TRY(ctx_, hipMemcpyAsync(h_status(k), d_status(k), (size_t)f.n_blocks * sizeof(int), hipMemcpyDeviceToHost, cs_));
+    HIP_TRY(ctx_, hipEventRecord(ev_done_[k], cs_));
+    enq_[k] = true;
+    return EXON_HIP_OK;
+  }
+
+  int next_bgzf(const uint8_t** d_text, size_t* n, bool* final) {
+    const int k = (int)(idx_ & 1);
+    const Filled f = f_[k];
+    if (enq_[k]) {
+      HIP_TRY(ctx_, hipEventSynchronize(ev_done_[k]));
+      const int* hstat = h_status(k);
+      for (int i = 0; i < f.n_blocks; ++i)
+        if (hstat[i] != 0) {
+          fail(ctx_, EXON_HIP_EINVAL, "BGZF block: %s (decoding on the host instead)", exon_bgzf_status_name(hstat[i]));
+          return 1;
+        }
+    }
+    const bool more = !f.eof;
+    *final = !more;
+    // the tail carried from the previous slab goes right in front of this slab's inflated bytes
+    size_t front = gap_ - carry_dev_, n_text = carry_dev_ + f.out_bytes;
+    if (carry_dev_) HIP_TRY(ctx_, hipMemcpyAsync(d_text_[k] + front, d_text_[carry_k_] + carry_off_, carry_dev_, hipMemcpyDeviceToDevice, hs_));
+    if (idx_ > 0) {  // everything the consumer enqueued on slab i-1 (and this copy out of it) precedes its reuse
+      HIP_TRY(ctx_, hipEventRecord(ev_free_[k ^ 1], hs_));
+      free_rec_[k ^ 1] = true;
+    }
+    carry_dev_ = 0;
+    if (skip_) {  // first slab: the host reader consumed the header
+      if (f.out_bytes < skip_) return 1;  // the header spans more than one slab: not worth handling here
+      front = gap_ + (size_t)skip_;
+      n_text = f.out_bytes - (size_t)skip_;
+      skip_ = 0;
+    }
+    if (more) {  // slab i+1: inflate it while the consumer works on slab i; then let the reader fetch slab i+2
+      if (reader_.joinable()) reader_.join();
+      if (f_[k ^ 1].err) return rethrow(f_[k ^ 1].err);
+      int rc = enqueue_inflate(k ^ 1);
+      if (rc) return rc;
+      if (!f_[k ^ 1].eof) reader_ = std::thread([this, k] { fill(k, &f_[k]); });
+    }
+    if (!more && n_text > 0 && !binary_) {  // last line without a terminator
+      uint8_t lastb = 0;
+      HIP_TRY(ctx_, hipMemcpyAsync(&lastb, d_text_[k] + front + n_text - 1, 1, hipMemcpyDeviceToHost, hs_));
+      HIP_TRY(ctx_, hipStreamSynchronize(hs_));
+      if (lastb != '\n') {
+        HIP_TRY(ctx_, hipMemsetAsync(d_text_[k] + front + n_text, '\n', 1, hs_));
+        ++n_text;
+      }
+    }
+    cur_front_ = front;
+    cur_text_ = n_text;
+    *d_text = d_text_[k] + front;
+    *n = n_text;
+    return EXON_HIP_OK;
+  }
+
   struct Filled {
     size_t n = 0;          // plain: fresh text bytes behind the gap; bgzf: compressed bytes of whole blocks
     int n_blocks = 0;      // bgzf
@@ -548,6 +626,8 @@ class GpuTextSource {
   };
   // background thread: next chunk of the file into h_buf_[k]
   void fill(int k, Filled* f) {
+    const double t_fill0 = now_s();
+    struct Acc { double* a; double t0; ~Acc() { *a += now_s() - t0; } } acc{&t_fill_, t_fill0};
     try {
       if (!bgzf_) {
         f->n = rd_.read(h_buf_[k] + gap_, text_cap_);
@@ -589,6 +669,13 @@ class GpuTextSource {
       f->out_bytes = out_bytes;
       f->eof = file_eof_ && left_.empty();
       block_tables_[k].assign(hb, hb + nb);  // copied to the pinned table in next()
+      if (xs_ && nb > 0) {
+        // the compressed bytes start crossing PCIe right away (their own stream), under the inflate of the previous slab
+        hipSetDevice(ctx_->device);
+        if (hipMemcpyAsync(d_comp_[k], h_buf_[k], consumed + 4096, hipMemcpyHostToDevice, xs_) != hipSuccess ||
+            hipEventRecord(ev_h2d_[k], xs_) != hipSuccess)
+          throw std::runtime_error("H2D of a compressed slab failed");
+      }
     } catch (...) {
       f->err = std::current_exception();
     }
@@ -619,6 +706,14 @@ class GpuTextSource {
   std::string left_;
   bool file_eof_ = false;
   Filled cur_, nxt_;
+  Filled f_[2];            // bgzf: what the reader put into host buffer k
+  double t_fill_ = 0;      // seconds the reader spent filling host buffers
+  uint64_t idx_ = 0;       // bgzf: index of the slab being consumed
+  int carry_k_ = 0;        // bgzf: the carried tail lives in d_text_[carry_k_] at carry_off_
+  size_t carry_off_ = 0;
+  hipStream_t cs_ = nullptr, xs_ = nullptr;  // inflate stream, H2D stream
+  hipEvent_t ev_h2d_[2] = {nullptr, nullptr}, ev_done_[2] = {nullptr, nullptr}, ev_free_[2] = {nullptr, nullptr};
+  bool enq_[2] = {false, false}, free_rec_[2] = {false, false};
   std::thread reader_;
   int k_ = 0;
   bool started_ = false;
@@ -629,12 +724,6 @@ class GpuTextSource {
 
 // VCF / FASTQ file -> text slabs in HBM (GpuTextSource) -> GPU parser -> fused kernel.  Returns 1 when the device could
 // not decide something: the caller restores the state and re-decodes the file on the host.
-static double now_s() {
-  struct timespec ts;
-  clock_gettime(CLOCK_MONOTONIC, &ts);
-  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
-}
-
 static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* rows_out) {
   const bool trace = getenv("EXON_HIP_PIPE_TRACE") != nullptr;  // phase timings on stderr
   const double t_begin = now_s();
@@ -757,10 +846,11 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
   }
   if (hipStreamSynchronize(hs) != hipSuccess && rc == EXON_HIP_OK) rc = fail(ctx, EXON_HIP_EDEVICE, "stream synchronize failed");
   const double t_loop = now_s();
+  const double t_reader = src ? src->reader_seconds() : 0;
   src.reset();
   if (trace)
-    fprintf(stderr, "[exon-hip pipe] setup %.1f ms, loop %.1f ms (slabs: wait+H2D+inflate %.1f, parse %.1f, other %.1f), teardown %.1f ms\n",
-            (t_init - t_begin) * 1e3, (t_loop - t_init) * 1e3, t_next * 1e3, t_parse * 1e3, (t_loop - t_init - t_next - t_parse) * 1e3,
+    fprintf(stderr, "[exon-hip pipe] setup %.1f ms, loop %.1f ms (slabs: wait+H2D+inflate %.1f, parse %.1f, other %.1f; file reader busy %.1f), teardown %.1f ms\n",
+            (t_init - t_begin) * 1e3, (t_loop - t_init) * 1e3, t_next * 1e3, t_parse * 1e3, (t_loop - t_init - t_next - t_parse) * 1e3, t_reader * 1e3,
             (now_s() - t_loop) * 1e3);
   (void)t_launch;
   if (rc == EXON_HIP_OK && is_vcf) {

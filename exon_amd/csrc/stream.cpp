@@ -423,7 +423,8 @@ int exon_hip_stream_launch_views(exon_hip_stream* st, const uint8_t* d_text, con
   if (idx != 2 && idx != 3) return fail(st->ctx, EXON_HIP_EINVAL, "plan needs scan column %d; FASTQ views exist for 2 (sequence) and 3 (quality_scores)", idx);
   int rc = flush_slot(st);
   if (rc) return rc;
-  rc = exon_hip_qual_pos_hist_views(st->ctx, st->stream, d_text, idx == 2 ? v.seq_start : v.qual_start,
+  (void)d_text;  // the views index v.text_base (the aligned address at or below the slab)
+  rc = exon_hip_qual_pos_hist_views(st->ctx, st->stream, v.text_base, idx == 2 ? v.seq_start : v.qual_start,
                                     idx == 2 ? v.seq_end : v.qual_end, v.n_reads, p->d.lmax,
                                     reinterpret_cast<int64_t*>(st->d_state));
   if (!rc) st->rows_pushed += v.n_reads;

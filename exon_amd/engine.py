@@ -366,11 +366,12 @@ class VCFParser:
         self.ctx._check(self.ctx.lib.exon_hip_vcf_parser_parse(self.h, stream, ptr, n_bytes, C.byref(cols)))
         return cols
 
-    def parse_host(self, text):
-        """Test helper: copy `text` (bytes of complete lines) to HBM, parse, bring the columns back as numpy arrays."""
+    def parse_host(self, text, misalign=0):
+        """Test helper: copy `text` (bytes of complete lines) to HBM (`misalign` bytes past a 16-byte boundary), parse,
+        bring the columns back as numpy arrays."""
         buf = np.frombuffer(text, np.uint8)
-        d = self.ctx.to_device(np.concatenate([buf, np.zeros(64, np.uint8)]))
-        cols = self.parse_device(d, len(buf))
+        d = self.ctx.to_device(np.concatenate([np.full(misalign, 10, np.uint8), buf, np.zeros(64, np.uint8)]))
+        cols = self.parse_device(d.ptr + misalign, len(buf))
         n = cols.n_rows
         nb = (n + 7) // 8
 
@@ -459,12 +460,13 @@ class FASTQParser:
         self.ctx._check(self.ctx.lib.exon_hip_fastq_parser_parse(self.h, stream, ptr, n_bytes, 1 if final else 0, C.byref(v)))
         return v
 
-    def parse_host(self, text, final=True):
-        """Test helper: copy `text` to HBM, split it, bring the views back as numpy arrays (the text stays in
-        the returned DeviceBuffer for exon_hip_qual_pos_hist_views)."""
+    def parse_host(self, text, final=True, misalign=0):
+        """Test helper: copy `text` to HBM (`misalign` bytes past a 16-byte boundary), split it, bring the views back as
+        numpy arrays relative to the start of the text (on the device they index views.text_base, which
+        exon_hip_qual_pos_hist_views takes)."""
         buf = np.frombuffer(text, np.uint8)
-        d = self.ctx.to_device(np.concatenate([buf, np.zeros(64, np.uint8)]))
-        v = self.parse_device(d, len(buf), final)
+        d = self.ctx.to_device(np.concatenate([np.full(misalign, 10, np.uint8), buf, np.zeros(64, np.uint8)]))
+        v = self.parse_device(d.ptr + misalign, len(buf), final)
         n = v.n_reads
 
         def get(ptr):
@@ -473,9 +475,10 @@ class FASTQParser:
                 self.ctx._check(self.ctx.lib.exon_hip_memcpy_d2h(self.ctx.h, _np_ptr(out), ptr, out.nbytes, None))
             return out
 
-        return {"n_reads": n, "n_undecided": v.n_undecided, "consumed_bytes": v.consumed_bytes, "views": v, "d_text": d,
-                "seq_start": get(v.seq_start), "seq_end": get(v.seq_end), "qual_start": get(v.qual_start),
-                "qual_end": get(v.qual_end)}
+        shift = (d.ptr + misalign) - (v.text_base or (d.ptr + misalign))
+        return {"n_reads": n, "n_undecided": v.n_undecided, "consumed_bytes": v.consumed_bytes, "views": v, "d_text": v.text_base,
+                "keepalive": d, "seq_start": get(v.seq_start) - shift, "seq_end": get(v.seq_end) - shift,
+                "qual_start": get(v.qual_start) - shift, "qual_end": get(v.qual_end) - shift}
 
     def close(self):
         if self.h:

@@ -333,7 +333,7 @@ typedef struct exon_hip_vcf_columns {
 } exon_hip_vcf_columns;
 int exon_hip_vcf_parser_create(exon_hip_ctx* ctx, const char* const* contig_names, int32_t n_contigs,
                                const char* info_field, int64_t max_slab_bytes, exon_hip_vcf_parser** out);
-/* d_text: a slab of '\n'-terminated data lines in HBM, 16-byte aligned (a trailing partial line is left to the
+/* d_text: a slab of '\n'-terminated data lines in HBM, any alignment (a trailing partial line is left to the
  * caller: see consumed_bytes).  Synchronises `stream`. */
 int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* parser, void* stream, const uint8_t* d_text, int64_t n_bytes,
                               exon_hip_vcf_columns* cols);
@@ -379,9 +379,10 @@ typedef struct exon_hip_fastq_views {
   const int32_t* seq_end;
   const int32_t* qual_start;
   const int32_t* qual_end;
+  const uint8_t* text_base; /* what the views index: the 16-byte aligned address at or below d_text */
 } exon_hip_fastq_views;
 int exon_hip_fastq_parser_create(exon_hip_ctx* ctx, int64_t max_slab_bytes, exon_hip_fastq_parser** out);
-/* d_text: 16-byte aligned, < 2 GiB.  final_slab != 0: the text ends the input (it must end with '\n').
+/* d_text: any alignment, < 2 GiB.  final_slab != 0: the text ends the input (it must end with '\n').
  * Synchronises `stream`. */
 int exon_hip_fastq_parser_parse(exon_hip_fastq_parser* parser, void* stream, const uint8_t* d_text, int64_t n_bytes,
                                 int32_t final_slab, exon_hip_fastq_views* views);

@@ -74,6 +74,22 @@ def test_fastq_views_synthetic_equals_oracle(ctx, oracle, ragged, crlf):
     p.close()
 
 
+@pytest.mark.parametrize("misalign", [1, 5, 15])
+def test_fastq_views_unaligned_text(ctx, oracle, misalign):
+    """The slab may start anywhere (the BGZF pipeline puts the carried tail right in front of the inflated bytes)."""
+    text = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, b"ACGT" * (3 + i % 5), b"IHGF" * (3 + i % 5)) for i in range(3000))
+    p = exon_amd.FASTQParser(ctx, max_slab_bytes=len(text) + 1024)
+    a = p.parse_host(text)
+    hist_a = views_hist(ctx, a, "qual", 64)  # the device views belong to the parser: use them before the next parse
+    b = p.parse_host(text, misalign=misalign)
+    assert b["n_reads"] == a["n_reads"] == 3000 and b["n_undecided"] == 0 and b["consumed_bytes"] == len(text)
+    for k in ("seq_start", "seq_end", "qual_start", "qual_end"):
+        assert np.array_equal(a[k], b[k])
+    assert hist_a.sum() == sum(4 * (3 + i % 5) for i in range(3000))
+    assert np.array_equal(hist_a, views_hist(ctx, b, "qual", 64))
+    p.close()
+
+
 def test_fastq_views_partial_slab_and_malformed(ctx):
     text = b"@a\nACGT\n+\nIIII\n@b\nAC\n+\nII\n@c\nACG"
     p = exon_amd.FASTQParser(ctx, max_slab_bytes=1 << 16)

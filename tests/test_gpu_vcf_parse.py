@@ -94,6 +94,20 @@ def test_gpu_parse_synthetic_slabs_and_filter_dictionary(ctx, tmp_path, oracle):
     p.close()
 
 
+@pytest.mark.parametrize("misalign", [1, 7, 15])
+def test_gpu_parse_unaligned_text(ctx, misalign):
+    path = os.path.join(FX, "vcf", "index.vcf")
+    cpu = cpu_columns(path, "MQ0F")
+    text = data_lines(path)
+    p = exon_amd.VCFParser(ctx, cpu["contigs"], info_field="MQ0F")
+    a = p.parse_host(text)
+    b = p.parse_host(text + b"1\t5\t.", misalign=misalign)  # plus a trailing partial line
+    assert b["n_rows"] == a["n_rows"] == 621 and b["n_undecided"] == 0
+    for k in ("chrom_id", "pos", "qual", "filter_id", "info"):
+        assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), k
+    p.close()
+
+
 def test_gpu_parse_undecidable_rows_are_counted(ctx):
     contigs = ["1", "2"]
     text = (b"1\t5\t.\tA\tC\t30.5\tPASS\tDP=3;AF=0.5\n"
