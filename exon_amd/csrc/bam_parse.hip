@@ -230,7 +230,7 @@ int exon_hip_bam_parser_create(exon_hip_ctx* ctx, int32_t n_references, int64_t 
   hipSetDevice(ctx->device);
   hipError_t e = hipSuccess;
   auto dalloc = [&](void** ptr, size_t bytes) {
-    if (e == hipSuccess) e = hipMalloc(ptr, bytes ? bytes : 16);
+    if (e == hipSuccess && !(*ptr = exon_pool_alloc(ctx, bytes))) e = hipErrorOutOfMemory;
   };
   const size_t r = (size_t)p->max_rows, w = (r + 31) / 32 * 4 + 64;
   dalloc((void**)&p->d_seg, (size_t)p->max_seg * sizeof(SegInfo));
@@ -260,11 +260,11 @@ int exon_hip_bam_parser_create(exon_hip_ctx* ctx, int32_t n_references, int64_t 
 int exon_hip_bam_parser_destroy(exon_hip_bam_parser* p) {
   if (!p) return EXON_HIP_OK;
   for (void* b : p->bufs)
-    if (b) hipFree(b);
-  if (p->d_seg) hipFree(p->d_seg);
-  if (p->d_base) hipFree(p->d_base);
-  if (p->d_rec_off) hipFree(p->d_rec_off);
-  if (p->d_scalars) hipFree(p->d_scalars);
+    if (b) exon_pool_free(p->ctx, b);
+  if (p->d_seg) exon_pool_free(p->ctx, p->d_seg);
+  if (p->d_base) exon_pool_free(p->ctx, p->d_base);
+  if (p->d_rec_off) exon_pool_free(p->ctx, p->d_rec_off);
+  if (p->d_scalars) exon_pool_free(p->ctx, p->d_scalars);
   if (p->h_scalars) hipHostFree(p->h_scalars);
   delete p;
   return EXON_HIP_OK;

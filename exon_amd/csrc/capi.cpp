@@ -118,11 +118,59 @@ int exon_hip_ctx_create(int device, exon_hip_ctx** out) {
   return EXON_HIP_OK;
 }
 
+}  // extern "C"
+
+void* exon_pool_alloc(exon_hip_ctx* ctx, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    auto it = ctx->pool_free.find(bytes);
+    if (it != ctx->pool_free.end()) {
+      void* p = it->second;
+      ctx->pool_free.erase(it);
+      ctx->pool_live[p] = bytes;
+      return p;
+    }
+  }
+  void* p = nullptr;
+  hipSetDevice(ctx->device);
+  if (hipMalloc(&p, bytes) != hipSuccess) {
+    // make room: drop everything that is only cached, then try once more
+    std::lock_guard<std::mutex> g(ctx->mu);
+    for (auto& kv : ctx->pool_free) hipFree(kv.second);
+    ctx->pool_free.clear();
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  }
+  std::lock_guard<std::mutex> g(ctx->mu);
+  ctx->pool_live[p] = bytes;
+  return p;
+}
+
+void exon_pool_free(exon_hip_ctx* ctx, void* p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  auto it = ctx->pool_live.find(p);
+  if (it == ctx->pool_live.end()) {
+    hipFree(p);
+    return;
+  }
+  const size_t bytes = it->second;
+  ctx->pool_live.erase(it);
+  if (ctx->pool_free.size() >= 96) {  // bounded: beyond that, really free
+    hipFree(p);
+    return;
+  }
+  ctx->pool_free.emplace(bytes, p);
+}
+
+extern "C" {
+
 int exon_hip_ctx_destroy(exon_hip_ctx* ctx) {
   if (!ctx) return EXON_HIP_OK;
   hipSetDevice(ctx->device);
   hipDeviceSynchronize();
   exon_hip_release_ctx_caches(ctx);
+  for (auto& kv : ctx->pool_free) hipFree(kv.second);  // buffers still held by live parsers stay theirs
   for (auto& kv : ctx->workspaces) {
     if (kv.second.partials) hipFree(kv.second.partials);
     if (kv.second.status) hipFree(kv.second.status);

@@ -388,7 +388,7 @@ int exon_hip_vcf_parser_create(exon_hip_ctx* ctx, const char* const* contig_name
   hipSetDevice(ctx->device);
   hipError_t e = hipSuccess;
   auto dalloc = [&](void** ptr, size_t bytes) {
-    if (e == hipSuccess) e = hipMalloc(ptr, bytes ? bytes : 16);
+    if (e == hipSuccess && !(*ptr = exon_pool_alloc(ctx, bytes))) e = hipErrorOutOfMemory;
   };
   // contig table
   int cap = 16;
@@ -463,19 +463,19 @@ int exon_hip_vcf_parser_create(exon_hip_ctx* ctx, const char* const* contig_name
 int exon_hip_vcf_parser_destroy(exon_hip_vcf_parser* p) {
   if (!p) return EXON_HIP_OK;
   for (void* b : p->contig_bufs)
-    if (b) hipFree(b);
+    if (b) exon_pool_free(p->ctx, b);
   for (void* b : p->out_bufs)
-    if (b) hipFree(b);
-  if (p->filters.keys) hipFree(p->filters.keys);
-  if (p->filters.ids) hipFree(p->filters.ids);
-  if (p->filters.text_off) hipFree(p->filters.text_off);
-  if (p->filters.text_len) hipFree(p->filters.text_len);
-  if (p->filters.pool) hipFree(p->filters.pool);
-  if (p->filters.counters) hipFree(p->filters.counters);
-  if (p->d_block_counts) hipFree(p->d_block_counts);
-  if (p->d_nl) hipFree(p->d_nl);
-  if (p->d_scalars) hipFree(p->d_scalars);
-  if (p->d_info_key) hipFree(p->d_info_key);
+    if (b) exon_pool_free(p->ctx, b);
+  if (p->filters.keys) exon_pool_free(p->ctx, p->filters.keys);
+  if (p->filters.ids) exon_pool_free(p->ctx, p->filters.ids);
+  if (p->filters.text_off) exon_pool_free(p->ctx, p->filters.text_off);
+  if (p->filters.text_len) exon_pool_free(p->ctx, p->filters.text_len);
+  if (p->filters.pool) exon_pool_free(p->ctx, p->filters.pool);
+  if (p->filters.counters) exon_pool_free(p->ctx, p->filters.counters);
+  if (p->d_block_counts) exon_pool_free(p->ctx, p->d_block_counts);
+  if (p->d_nl) exon_pool_free(p->ctx, p->d_nl);
+  if (p->d_scalars) exon_pool_free(p->ctx, p->d_scalars);
+  if (p->d_info_key) exon_pool_free(p->ctx, p->d_info_key);
   if (p->h_scalars) hipHostFree(p->h_scalars);
   delete p;
   return EXON_HIP_OK;
@@ -622,10 +622,14 @@ int exon_hip_fastq_parser_create(exon_hip_ctx* ctx, int64_t max_bytes, exon_hip_
   hipSetDevice(ctx->device);
   const int64_t nblocks = (max_bytes + BYTES_PER_BLOCK - 1) / BYTES_PER_BLOCK;
   const size_t per = (size_t)(p->max_lines / 4 + 1);
-  hipError_t e = hipMalloc((void**)&p->d_block_counts, (size_t)nblocks * 4);
-  if (e == hipSuccess) e = hipMalloc((void**)&p->d_nl, (size_t)p->max_lines * 4);
-  if (e == hipSuccess) e = hipMalloc((void**)&p->d_scalars, 16);
-  if (e == hipSuccess) e = hipMalloc((void**)&p->d_views, per * 4 * 4);
+  hipError_t e = hipSuccess;
+  auto dalloc = [&](void** ptr, size_t bytes) {
+    if (e == hipSuccess && !(*ptr = exon_pool_alloc(ctx, bytes))) e = hipErrorOutOfMemory;
+  };
+  dalloc((void**)&p->d_block_counts, (size_t)nblocks * 4);
+  dalloc((void**)&p->d_nl, (size_t)p->max_lines * 4);
+  dalloc((void**)&p->d_scalars, 16);
+  dalloc((void**)&p->d_views, per * 4 * 4);
   if (e == hipSuccess) e = hipHostMalloc((void**)&p->h_scalars, 16);
   if (e != hipSuccess) {
     const std::string msg = hipGetErrorString(e);
@@ -638,10 +642,10 @@ int exon_hip_fastq_parser_create(exon_hip_ctx* ctx, int64_t max_bytes, exon_hip_
 
 int exon_hip_fastq_parser_destroy(exon_hip_fastq_parser* p) {
   if (!p) return EXON_HIP_OK;
-  if (p->d_block_counts) hipFree(p->d_block_counts);
-  if (p->d_nl) hipFree(p->d_nl);
-  if (p->d_scalars) hipFree(p->d_scalars);
-  if (p->d_views) hipFree(p->d_views);
+  if (p->d_block_counts) exon_pool_free(p->ctx, p->d_block_counts);
+  if (p->d_nl) exon_pool_free(p->ctx, p->d_nl);
+  if (p->d_scalars) exon_pool_free(p->ctx, p->d_scalars);
+  if (p->d_views) exon_pool_free(p->ctx, p->d_views);
   if (p->h_scalars) hipHostFree(p->h_scalars);
   delete p;
   return EXON_HIP_OK;

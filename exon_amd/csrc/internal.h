@@ -18,6 +18,10 @@ struct exon_hip_ctx {
   std::string error;
   hipDeviceProp_t props;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // device buffers of the GPU-side parsers are recycled between scans (exon_pool_*): their sizes repeat exactly and
+  // hipMalloc / hipFree of gigabytes costs tens of milliseconds per file
+  std::multimap<size_t, void*> pool_free;
+  std::map<void*, size_t> pool_live;
 };
 
 // records the message on the ctx (and the calling thread) and returns `code`
@@ -42,3 +46,7 @@ const char* exon_bgzf_status_name(int code);
 
 // scan.cpp: slab buffers kept per ctx between scans
 void exon_hip_release_ctx_caches(exon_hip_ctx* ctx);
+
+// capi.cpp: size-keyed recycling of device buffers (released by exon_hip_ctx_destroy)
+void* exon_pool_alloc(exon_hip_ctx* ctx, size_t bytes);
+void exon_pool_free(exon_hip_ctx* ctx, void* p);

@@ -344,7 +344,16 @@ struct SlabBuffers {
   uint8_t* d_text[2] = {nullptr, nullptr};
   exon_hip_bgzf_block* h_blocks = nullptr;
   exon_hip_bgzf_block* d_blocks = nullptr;
+  hipStream_t cs = nullptr, xs = nullptr;
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   void free_all() {
+    if (cs) hipStreamDestroy(cs);
+    if (xs) hipStreamDestroy(xs);
+    cs = xs = nullptr;
+    for (auto& e : ev) {
+      if (e) hipEventDestroy(e);
+      e = nullptr;
+    }
     for (int k = 0; k < 2; ++k) {
       if (h_buf[k]) hipHostFree(h_buf[k]);
       if (d_comp[k]) hipFree(d_comp[k]);
@@ -387,20 +396,16 @@ class GpuTextSource {
   }
   ~GpuTextSource() {
     if (reader_.joinable()) reader_.join();
-    if (xs_) {
-      hipStreamSynchronize(xs_);
-      hipStreamDestroy(xs_);
-    }
-    if (cs_) {
-      hipStreamSynchronize(cs_);
-      hipStreamDestroy(cs_);
-    }
-    for (int k = 0; k < 2; ++k) {
-      if (ev_h2d_[k]) hipEventDestroy(ev_h2d_[k]);
-      if (ev_done_[k]) hipEventDestroy(ev_done_[k]);
-      if (ev_free_[k]) hipEventDestroy(ev_free_[k]);
-    }
+    if (xs_) hipStreamSynchronize(xs_);
+    if (cs_) hipStreamSynchronize(cs_);
     SlabBuffers b;
+    b.cs = cs_;
+    b.xs = xs_;
+    for (int k = 0; k < 2; ++k) {
+      b.ev[k] = ev_h2d_[k];
+      b.ev[2 + k] = ev_done_[k];
+      b.ev[4 + k] = ev_free_[k];
+    }
     b.bgzf = bgzf_;
     b.hcap = hcap_;
     b.tcap = gap_ + text_cap_;
@@ -441,6 +446,13 @@ class GpuTextSource {
           }
           h_blocks_ = b.h_blocks;
           d_blocks_ = b.d_blocks;
+          cs_ = b.cs;
+          xs_ = b.xs;
+          for (int k = 0; k < 2; ++k) {
+            ev_h2d_[k] = b.ev[k];
+            ev_done_[k] = b.ev[2 + k];
+            ev_free_[k] = b.ev[4 + k];
+          }
           complete_ = true;
         } else {
           b.free_all();
@@ -461,12 +473,12 @@ class GpuTextSource {
       complete_ = true;
     }
     if (bgzf_) {
-      if (hipStreamCreateWithFlags(&cs_, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&xs_, hipStreamNonBlocking) != hipSuccess)
+      if (!cs_ && (hipStreamCreateWithFlags(&cs_, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&xs_, hipStreamNonBlocking) != hipSuccess))
         return fail(ctx_, EXON_HIP_EDEVICE, "stream creation failed");
       for (int k = 0; k < 2; ++k)
-        if (hipEventCreateWithFlags(&ev_h2d_[k], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_done_[k], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_free_[k], hipEventDisableTiming) != hipSuccess)
+        if (!ev_free_[k] && (hipEventCreateWithFlags(&ev_h2d_[k], hipEventDisableTiming) != hipSuccess ||
+                             hipEventCreateWithFlags(&ev_done_[k], hipEventDisableTiming) != hipSuccess ||
+                             hipEventCreateWithFlags(&ev_free_[k], hipEventDisableTiming) != hipSuccess))
           return fail(ctx_, EXON_HIP_EDEVICE, "event creation failed");
       fill(0, &f_[0]);
       if (f_[0].err) return rethrow(f_[0].err);
@@ -638,7 +650,10 @@ class GpuTextSource {
       memcpy(h_buf_[k], left_.data(), left_.size());
       size_t have = left_.size();
       left_.clear();
-      const size_t goal = std::min(comp_cap_, (size_t)((double)est_block_ * target_blocks_ * 1.03) + (1u << 16));
+      // the first slab is an eighth of the others: the GPU starts early, the pipeline is full from the second slab on
+      const int target = first_fill_ ? std::max(64, target_blocks_ / 8) : target_blocks_;
+      first_fill_ = false;
+      const size_t goal = std::min(comp_cap_, (size_t)((double)est_block_ * target * 1.03) + (1u << 16));
       if (!file_eof_ && have < goal) {
         const size_t want = goal - have;
         const size_t got = rd_.read(h_buf_[k] + have, want);
@@ -647,7 +662,7 @@ class GpuTextSource {
       }
       int32_t nb = 0;
       size_t consumed = 0, out_bytes = 0;
-      if (exon_hip_bgzf_scan(h_buf_[k], have, 0, h_blocks_tmp(k), std::min(max_blocks_, target_blocks_), &nb, &consumed, &out_bytes) != EXON_HIP_OK)
+      if (exon_hip_bgzf_scan(h_buf_[k], have, 0, h_blocks_tmp(k), std::min(max_blocks_, target), &nb, &consumed, &out_bytes) != EXON_HIP_OK)
         throw std::runtime_error(exon_hip_last_error(nullptr));
       if (nb > 0) est_block_ = (double)consumed / nb;
       exon_hip_bgzf_block* hb = h_blocks_tmp(k);
@@ -703,6 +718,7 @@ class GpuTextSource {
   std::vector<exon_hip_bgzf_block> scan_tmp_[2], block_tables_[2];
   int max_blocks_ = 0, target_blocks_ = 0;
   double est_block_ = 20000;  // running average of the compressed block size
+  bool first_fill_ = true;
   std::string left_;
   bool file_eof_ = false;
   Filled cur_, nxt_;
