@@ -256,7 +256,7 @@ def main():
             if a.workload == "c4" else f"Mrows/sec filter+agg ({a.workload})",
             "value": round(value, 1), "unit": "Mrows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"c4": "f64", "c2": "int64", "c3": "int64", "c5": "u8"}[a.workload], "data": "synthetic",
             "config": {"workload": {"c4": "config 4: 1B-row synthetic VCF, WHERE info.AF > 0.01, AVG(qual), COUNT(*) GROUP BY filter",
                                     "c2": "config 2: synthetic VCF, chrom='7' AND pos in [5e7,1e8], COUNT(*)",
                                     "c3": "config 3: synthetic BAM, flag&1284=0 AND mapq>=30, COUNT(*) GROUP BY reference",
@@ -264,7 +264,9 @@ def main():
                        "rows_per_gpu": rows, "rows_total": n_total, "sharding": "one contiguous row range (file split) per GPU",
                        "reduce": "RCCL all-reduce of partial state" if world > 1 else "none (1 GPU)",
                        "bytes_per_row": bpr,
-                       "arithmetic": "f32 columns compared as totalOrder i32 keys, f64 sums, i64 counts"},
+                       "arithmetic": {"c4": "f32 columns compared as totalOrder i32 keys, f64 sums, i64 counts",
+                                      "c2": "i32 / i64 compares, i64 count", "c3": "i32 mask compare, u8 compare, i64 counts",
+                                      "c5": "u8 bytes, u32 LDS counters folded into i64"}[a.workload]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel_ms": round(kern_ms, 4),
