@@ -395,9 +395,12 @@ class GpuTextSource {
     gap_ = std::max<size_t>(text_cap_ / 4, 1u << 20);  // room for the carried tail (< 1 record + 1 line)
   }
   ~GpuTextSource() {
+    const double td0 = now_s();
     if (reader_.joinable()) reader_.join();
+    const double td1 = now_s();
     if (xs_) hipStreamSynchronize(xs_);
     if (cs_) hipStreamSynchronize(cs_);
+    if (getenv("EXON_HIP_PIPE_TRACE")) fprintf(stderr, "[exon-hip pipe] teardown: reader join %.1f ms, stream sync %.1f ms\n", (td1 - td0) * 1e3, (now_s() - td1) * 1e3);
     SlabBuffers b;
     b.cs = cs_;
     b.xs = xs_;
@@ -432,7 +435,7 @@ class GpuTextSource {
 
   int init() {
     hcap_ = bgzf_ ? comp_cap_ + 4096 : gap_ + text_cap_ + 64;
-    if (bgzf_) max_blocks_ = (int)(comp_cap_ / 26 + 16);  // an empty BGZF block is 28 bytes
+    if (bgzf_) max_blocks_ = target_blocks_ + 16;  // a slab never takes more blocks than that (see fill)
     {
       std::lock_guard<std::mutex> g(g_slab_mu);
       auto it = g_slab_cache.find(ctx_);
