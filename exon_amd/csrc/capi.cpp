@@ -293,6 +293,25 @@ int exon_hip_region_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column
   return EXON_HIP_OK;
 }
 
+int exon_hip_overlap_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* ref_id, const exon_hip_column* start,
+                           const exon_hip_column* end, int64_t n, int32_t region_ref_id, int64_t region_start,
+                           int64_t region_end, int64_t* d_count) {
+  if (!ctx || !d_count) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_overlap_count: NULL argument");
+  if (n < 0) return fail(ctx, EXON_HIP_EINVAL, "n < 0");
+  int rc;
+  if ((rc = check_col(ctx, "ref_id", ref_id, n, false)) || (rc = check_col(ctx, "start", start, n, false)) ||
+      (rc = check_col(ctx, "end", end, n, false)))
+    return rc;
+  if (n == 0) return EXON_HIP_OK;
+  hipStream_t s = pick_stream(ctx, stream);
+  Workspace ws;
+  if ((rc = get_workspace(ctx, s, exon::k2_partial_words(ctx->cfg), &ws))) return fail(ctx, rc, "workspace allocation failed");
+  HIP_TRY(ctx, exon::launch_overlap_count(s, ctx->cfg, ws, (const int32_t*)ref_id->values, ref_id->validity,
+                                          (const int64_t*)start->values, start->validity, (const int64_t*)end->values,
+                                          end->validity, n, region_ref_id, region_start, region_end, d_count));
+  return EXON_HIP_OK;
+}
+
 int exon_hip_flag_mapq_group_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* flag,
                                    const exon_hip_column* mapq, const exon_hip_column* ref_id, int64_t n,
                                    int32_t flag_mask, int32_t flag_value, int32_t mapq_min, int32_t n_refs,

@@ -15,6 +15,7 @@
 //   SELECT reference, COUNT(*) FROM b WHERE flag & 1284 = 0 AND CAST(mapping_quality AS INT) >= 30 GROUP BY reference  -- K3
 //   SELECT filter, AVG(qual), COUNT(*) FROM v WHERE info."AF" > 0.01 GROUP BY filter            -- K4
 //   SELECT * FROM fastq_quality_histogram('<p>'[, 'gzip'])                                        -- K5
+//   SELECT COUNT(*) FROM <bam table> WHERE bam_region_filter('<r>', reference, start, end)          -- K6 (plain table; INDEXED_BAM plans chunks on the host)
 //   DROP TABLE t;
 #include <dirent.h>
 #include <sys/stat.h>
@@ -455,6 +456,32 @@ void exec_select(Session& se, Parser& ps) {
   }
 
   const bool count_only = proj.size() == 1 && proj[0] == "count(*)" && group_by.empty() && !star;
+  if (count_only && pr.kind == Predicate::PushedRegion && !src.indexed && gpu_parse_enabled() &&
+      (src.format == EXON_HIP_FORMAT_BAM || src.format == EXON_HIP_FORMAT_SAM)) {  // K6: interval overlap on the GPU
+    exon_hip_ctx* ctx = se.gpu();
+    char name[512];
+    int64_t a = 1, b = INT64_MAX;
+    ck(nullptr, exon_hip_parse_region(pr.region.c_str(), name, sizeof name, &a, &b));
+    int64_t total = 0;
+    for (const auto& f : src.files) {
+      ScanGuard g; open_scan(src, f, nullptr, "", &g, true);
+      int32_t rid = -1;
+      ck(nullptr, exon_hip_scan_dictionary_intern(g.s, 2, name, &rid));
+      if (rid < 0) continue;  // the reference is not in this file's header
+      StreamGuard sg;
+      exon_hip_plan_desc d; memset(&d, 0, sizeof d);
+      d.kind = EXON_HIP_PLAN_OVERLAP_COUNT; d.region_chrom_id = rid; d.region_start = a; d.region_end = b;
+      d.columns[0] = 2; d.columns[1] = 3; d.columns[2] = 4;
+      ck(ctx, exon_hip_plan_create(ctx, &d, &sg.p));
+      ck(ctx, exon_hip_stream_open(sg.p, 0, &sg.s));
+      ck(ctx, exon_hip_stream_consume_scan(sg.s, g.s, nullptr));
+      int64_t c = 0;
+      ck(ctx, exon_hip_stream_finish(sg.s, &c, nullptr));
+      total += c;
+    }
+    print_table({"count(*)"}, {{std::to_string(total)}}, se.quiet);
+    return;
+  }
   if (count_only && (pr.kind == Predicate::None || pr.kind == Predicate::PushedRegion)) {
     // config-1 plumbing / pushed-down region: the decoder's per-record filter is the only filter
     print_table({"count(*)"}, {{std::to_string(count_rows(src, pr.region))}}, se.quiet);

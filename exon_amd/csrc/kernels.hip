@@ -270,6 +270,100 @@ hipError_t launch_region_count(hipStream_t s, const LaunchCfg& cfg, const Worksp
 }
 
 // ------------------------------------------------------------------------------------------------
+// K6 overlap_count  (interval hit, range form)
+//   WHERE bam_region_filter('<ref>:<a>-<b>', reference, start, end)  COUNT(*)
+//   = SemiLazyRecord::intersects (exon-bam/src/indexed_async_batch_stream.rs:66-87): same reference id AND
+//   aln_start <= region_end AND region_start <= aln_end, false when reference / start / end is missing.
+//   20.375 B/row: i32 reference id + i64 start + i64 end + 3 validity bits.  Shape of K2.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned k6_row(int32_t r, int64_t s, int64_t e, unsigned rv, unsigned sv, unsigned ev, int32_t id,
+                                           int64_t a, int64_t b) {
+  return (rv & sv & ev) & unsigned(r == id) & unsigned(s <= b) & unsigned(e >= a);
+}
+
+template <typename S>
+__global__ __launch_bounds__(S::THREADS) void k6_overlap_count_main(const int32_t* __restrict__ ref,
+                                                                    const uint8_t* __restrict__ rvalid,
+                                                                    const int64_t* __restrict__ start,
+                                                                    const uint8_t* __restrict__ svalid,
+                                                                    const int64_t* __restrict__ end,
+                                                                    const uint8_t* __restrict__ evalid, int64_t n,
+                                                                    int32_t id, int64_t a, int64_t b,
+                                                                    unsigned long long* __restrict__ partials,
+                                                                    const uint8_t* __restrict__ ones) {
+  constexpr int J = S::J, THREADS = S::THREADS, WAVES = ShapeOf<S>::WAVES, WT = ShapeOf<S>::WAVE_TILE,
+                TILE = ShapeOf<S>::TILE;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned cnt = 0;
+  const int64_t ntiles = n / TILE;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t wbase = tile * TILE + (int64_t)wave * WT;
+    int4 c[J];
+    longlong2 s0[J], s1[J], e0[J], e1[J];
+    unsigned rm[J], sm[J], em[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int64_t r = wbase + j * 256 + lane * 4;
+      c[j] = ld16<int4>(ref + r);
+      s0[j] = ld16<longlong2>(start + r);
+      s1[j] = ld16<longlong2>(start + r + 2);
+      e0[j] = ld16<longlong2>(end + r);
+      e1[j] = ld16<longlong2>(end + r + 2);
+      rm[j] = valid4_ones(rvalid, ones, wbase, j, lane);
+      sm[j] = valid4_ones(svalid, ones, wbase, j, lane);
+      em[j] = valid4_ones(evalid, ones, wbase, j, lane);
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      cnt += k6_row(c[j].x, s0[j].x, e0[j].x, rm[j] >> 0 & 1, sm[j] >> 0 & 1, em[j] >> 0 & 1, id, a, b);
+      cnt += k6_row(c[j].y, s0[j].y, e0[j].y, rm[j] >> 1 & 1, sm[j] >> 1 & 1, em[j] >> 1 & 1, id, a, b);
+      cnt += k6_row(c[j].z, s1[j].x, e1[j].x, rm[j] >> 2 & 1, sm[j] >> 2 & 1, em[j] >> 2 & 1, id, a, b);
+      cnt += k6_row(c[j].w, s1[j].y, e1[j].y, rm[j] >> 3 & 1, sm[j] >> 3 & 1, em[j] >> 3 & 1, id, a, b);
+    }
+  }
+  for (int64_t r = ntiles * TILE + (int64_t)blockIdx.x * THREADS + threadIdx.x; r < n;
+       r += (int64_t)gridDim.x * THREADS)
+    cnt += k6_row(ref[r], start[r], end[r], valid1(rvalid, r), valid1(svalid, r), valid1(evalid, r), id, a, b);
+
+  __shared__ unsigned long long red[WAVES];
+  const unsigned long long w = wave_sum((unsigned long long)cnt);
+  if (lane == 0) red[wave] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+#pragma unroll
+    for (int i = 0; i < WAVES; ++i) t += red[i];
+    partials[blockIdx.x] = t;
+  }
+}
+
+template <typename S>
+static hipError_t k6_launch(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* ref, const uint8_t* rv,
+                            const int64_t* start, const uint8_t* sv, const int64_t* end, const uint8_t* ev, int64_t n,
+                            int32_t id, int64_t a, int64_t b, int* grid_out) {
+  static const int resident = resident_blocks(k6_overlap_count_main<S>, S::THREADS, 0);
+  const int grid = grid_for<S>(cfg, n, resident);
+  *grid_out = grid;
+  hipLaunchKernelGGL(k6_overlap_count_main<S>, dim3(grid), dim3(S::THREADS), 0, s, ref, rv, start, sv, end, ev, n, id, a, b,
+                     ws.partials, reinterpret_cast<const uint8_t*>(ws.status + 8));
+  return hipGetLastError();
+}
+
+hipError_t launch_overlap_count(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* ref,
+                                const uint8_t* ref_valid, const int64_t* start, const uint8_t* start_valid,
+                                const int64_t* end, const uint8_t* end_valid, int64_t n, int32_t region_ref,
+                                int64_t region_start, int64_t region_end, int64_t* d_count) {
+  if (n <= 0) return hipSuccess;
+  int grid = 1;
+  hipError_t e = use_big_shape(cfg, n) ? k6_launch<ShapeBigJ2>(s, cfg, ws, ref, ref_valid, start, start_valid, end, end_valid, n,
+                                                               region_ref, region_start, region_end, &grid)
+                                       : k6_launch<ShapeSmall>(s, cfg, ws, ref, ref_valid, start, start_valid, end, end_valid, n,
+                                                               region_ref, region_start, region_end, &grid);
+  if (e != hipSuccess) return e;
+  return run_finalize(s, ws, grid, 1, 1, d_count, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
 // K3 flag_mapq_group_count
 //   WHERE (flag & M) = V AND CAST(mapping_quality AS INT) >= Q  GROUP BY reference  COUNT(*)
 //   flag test = sam_flag_function (exon-core/src/udfs/sam/samflags.rs:26-47); mapq NULL when 255

@@ -151,6 +151,9 @@ static int launch_plan(exon_hip_stream* st, const exon_hip_column* cols, int64_t
                                        d.n_groups, counts, sums);
     case EXON_HIP_PLAN_QUAL_POS_HIST:
       return exon_hip_qual_pos_hist(st->ctx, st->stream, &cols[0], n, d.lmax, counts);
+    case EXON_HIP_PLAN_OVERLAP_COUNT:
+      return exon_hip_overlap_count(st->ctx, st->stream, &cols[0], &cols[1], &cols[2], n, d.region_chrom_id, d.region_start,
+                                    d.region_end, counts);
   }
   return fail(st->ctx, EXON_HIP_EINVAL, "unknown plan kind %d", d.kind);
 }
@@ -263,6 +266,16 @@ int exon_hip_plan_create(exon_hip_ctx* ctx, const exon_hip_plan_desc* desc, exon
       }
       p->n_i64 = 2 * desc->n_groups;
       p->n_f64 = desc->n_groups;
+      break;
+    case EXON_HIP_PLAN_OVERLAP_COUNT:
+      p->n_cols = 3;
+      p->cols[0].elem = 4;
+      p->cols[1].elem = p->cols[2].elem = 8;
+      p->n_i64 = 1;
+      if (desc->region_start < 1 || desc->region_end < desc->region_start) {
+        delete p;
+        return fail(ctx, EXON_HIP_EINVAL, "region interval must satisfy 1 <= start <= end");
+      }
       break;
     case EXON_HIP_PLAN_QUAL_POS_HIST:
       p->n_cols = 1;
@@ -575,6 +588,7 @@ int exon_hip_stream_finish_arrow(exon_hip_stream* st, struct ArrowArray* out, st
   if (rc) return rc;
   const exon_hip_plan_desc& d = p->d;
   switch (d.kind) {
+    case EXON_HIP_PLAN_OVERLAP_COUNT:
     case EXON_HIP_PLAN_REGION_COUNT: {
       make_struct(out, 1, {prim(counts)});
       make_schema(out_schema, "+s", "", false, {field("l", "count(*)[count]", false)});

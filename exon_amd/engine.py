@@ -133,6 +133,14 @@ class Context:
         self._check(self.lib.exon_hip_cmp_avg_by_group(self.h, stream, C.byref(c0), C.byref(c1), C.byref(c2), n,
                                                        float(threshold), CMP[op], n_groups, d_counts.ptr, d_sums.ptr))
 
+    def overlap_count(self, ref_id, ref_valid, start, start_valid, end, end_valid, n, region_ref_id, region_start, region_end,
+                      d_count, stream=None):
+        """K6: rows whose [start, end] on reference `region_ref_id` overlaps [region_start, region_end] (all three valid)."""
+        c0, c1, c2 = _col(ref_id, ref_valid, None, n), _col(start, start_valid, None, n), _col(end, end_valid, None, n)
+        end_v = L.REGION_OPEN_END if region_end is None else region_end
+        self._check(self.lib.exon_hip_overlap_count(self.h, stream, C.byref(c0), C.byref(c1), C.byref(c2), n, region_ref_id,
+                                                    region_start, end_v, d_count.ptr))
+
     def qual_pos_hist(self, offsets, data, n_reads, lmax, d_hist, stream=None):
         c0 = _col(data, None, offsets, n_reads)
         self._check(self.lib.exon_hip_qual_pos_hist(self.h, stream, C.byref(c0), n_reads, lmax, d_hist.ptr))
@@ -192,6 +200,12 @@ class Context:
     # -- plans ------------------------------------------------------------------------------------
     def plan_region_count(self, region_chrom_id, start=1, end=None, columns=(0, 1)):
         d = L.PlanDesc(kind=L.PLAN_REGION_COUNT, region_chrom_id=region_chrom_id, region_start=start,
+                       region_end=L.REGION_OPEN_END if end is None else end)
+        return Plan(self, d, columns)
+
+    def plan_overlap_count(self, region_ref_id, start=1, end=None, columns=(2, 3, 4)):
+        """COUNT(*) of BAM-layout rows overlapping a region (scan columns 2 reference, 3 start, 4 end)."""
+        d = L.PlanDesc(kind=L.PLAN_OVERLAP_COUNT, region_chrom_id=region_ref_id, region_start=start,
                        region_end=L.REGION_OPEN_END if end is None else end)
         return Plan(self, d, columns)
 

@@ -168,6 +168,15 @@ int exon_hip_flag_mapq_group_count(exon_hip_ctx* ctx, void* stream, const exon_h
                                    int64_t n, int32_t flag_mask, int32_t flag_value, int32_t mapq_min,
                                    int32_t n_refs, int64_t* d_counts);
 
+/* K6.  *d_count += |{ i : ref_id[i] = region_ref_id AND start[i] <= region_end AND end[i] >= region_start }|, all three
+ *      valid (a missing reference / start / end never matches).  SemiLazyRecord::intersects
+ *      (exon-bam/src/indexed_async_batch_stream.rs:66-87) = bam_region_filter.  1-based inclusive.  (The BED / GFF
+ *      expression of exon-core/src/physical_plan/start_end_interval_physical_expr.rs:93-139 is a different predicate --
+ *      strict `start > a` / `end < b` comparisons -- and is not covered.) */
+int exon_hip_overlap_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* ref_id /*i32*/,
+                           const exon_hip_column* start /*i64*/, const exon_hip_column* end /*i64*/, int64_t n,
+                           int32_t region_ref_id, int64_t region_start, int64_t region_end, int64_t* d_count);
+
 /* K4.  For rows with x valid AND (double)x <cmp_op> threshold (f32 widened to f64, as DataFusion
  *      coerces Float32 vs a Float64 literal), per dictionary id g = group_id[i] in [0, n_groups):
  *        d_counts[g]            += (y valid)            -- COUNT(y) / AVG denominator
@@ -214,6 +223,7 @@ int exon_hip_regroup_files_by_size(const int64_t* sizes, int32_t n_files, int32_
 #define EXON_HIP_PLAN_FLAG_MAPQ_GROUP_COUNT 3
 #define EXON_HIP_PLAN_CMP_AVG_BY_GROUP 4
 #define EXON_HIP_PLAN_QUAL_POS_HIST 5
+#define EXON_HIP_PLAN_OVERLAP_COUNT 6 /* region_chrom_id / region_start / region_end; columns: ref_id, start, end */
 
 typedef struct exon_hip_plan_desc {
   int32_t kind;          /* EXON_HIP_PLAN_* */
@@ -231,7 +241,7 @@ typedef struct exon_hip_plan_desc {
   int32_t lmax;
   int32_t reserved1;
   /* input column indexes into the batch's children, in operator argument order
-   * (K2: chrom_id,pos  K3: flag,mapq,ref_id  K4: x,y,group_id  K5: quality_scores) */
+   * (K2: chrom_id,pos  K3: flag,mapq,ref_id  K4: x,y,group_id  K5: quality_scores  K6: ref_id,start,end) */
   int32_t columns[4];
 } exon_hip_plan_desc;
 

@@ -147,6 +147,25 @@ class Oracle:
             start is not None, C.c_int64(start or 0), end is not None, C.c_int64(end or 0),
             C.c_int32(region_ref_id), C.c_int64(rstart), C.c_int64(rend if rend is not None else 2**63 - 1)))
 
+    def c6_overlap_count(self, ref_id, ref_valid, start, start_valid, end, end_valid, ref_names, region):
+        """Interval hit, range form, over whole columns: numpy restatement of SemiLazyRecord::intersects
+        (exon-bam/src/indexed_async_batch_stream.rs:66-87) on the reference layout -- the `reference` column is compared
+        as a STRING with the region name (the reference materialises it from the header, array_builder.rs:118-127);
+        a missing reference / start / end never matches.  Pinned on the fixture through orc_bam_intersects
+        (tests/test_oracle_pins.py).  Validity arguments are Arrow LSB-first bitmaps or None."""
+        name, a, b = self.parse_region(region)
+        n = len(ref_id)
+
+        def bits(bm):
+            return np.ones(n, bool) if bm is None else np.unpackbits(np.asarray(bm, np.uint8), bitorder="little")[:n].astype(bool)
+
+        rv, sv, ev = bits(ref_valid), bits(start_valid), bits(end_valid)
+        names = np.array(list(ref_names) + [""], dtype=object)
+        ref_str = names[np.where(rv, np.asarray(ref_id), len(ref_names))]
+        hi = np.iinfo(np.int64).max if b is None else b
+        hit = rv & sv & ev & (ref_str == name) & (np.asarray(start) <= hi) & (np.asarray(end) >= a)
+        return int(hit.sum())
+
     def regroup_files_by_size(self, sizes, target):
         s = np.asarray(sizes, np.int64)
         g = np.zeros(len(s), np.int32)

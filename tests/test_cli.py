@@ -58,6 +58,15 @@ def test_external_tables_and_region_pushdown():
     assert last_count(run(bb + "SELECT COUNT(*) FROM v WHERE vcf_region_filter('1000', chrom) = true").stdout) == 0
 
 
+@pytest.mark.gpu
+def test_cli_bam_region_filter_on_a_plain_table_runs_k6():
+    """A plain (not INDEXED_) BAM table: the interval predicate runs on the GPU (K6) over the GPU-decoded columns."""
+    b = f"CREATE EXTERNAL TABLE bam STORED AS BAM LOCATION '{FX}/bam/test.bam';"
+    q = "SELECT COUNT(*) FROM bam WHERE bam_region_filter('chr1:1-12209145', reference, start, end) = true"
+    assert last_count(run(b + q).stdout) == 7
+    assert last_count(run(b + "SELECT COUNT(*) FROM bam WHERE bam_region_filter('chr1', reference, start, end) = true").stdout) == 61
+
+
 def test_indexed_table_without_region_is_an_error():
     """slt/vcf-indexed-tests.slt:6-8 and :48-49 (`statement error`)."""
     r = run(f"CREATE EXTERNAL TABLE v STORED AS INDEXED_VCF LOCATION '{FX}/vcf/index.vcf.gz' OPTIONS (compression gzip); SELECT COUNT(*) FROM v", ok=False)

@@ -140,3 +140,29 @@ def test_bam_reference_fixture_through_the_gpu_pipeline(ctx):
     rows_g, gpu = _k3_through_scan(ctx, path, True)
     rows_h, host = _k3_through_scan(ctx, path, False)
     assert rows_g == rows_h == 61 and np.array_equal(gpu, host)
+
+
+def _k6_through_scan(ctx, path, gpu_parse, region_ref, a, b):
+    scan = exon_amd.Scan(str(path), "bam", gpu_parse=gpu_parse)
+    rid = scan.dictionary(2).index(region_ref)
+    plan = ctx.plan_overlap_count(rid, a, b)
+    st = plan.open()
+    rows = st.consume(scan)
+    counts, _ = st.finish()
+    st.close(); plan.close(); scan.close()
+    return rows, int(counts[0])
+
+
+def test_bam_region_overlap_on_the_gpu(ctx, tmp_path):
+    """bam_region_filter('chr1:1-12209145', reference, start, end) on the reference fixture: 7 (slt/bam-indexed-select-
+    tests.slt:16-19), file -> GPU inflate -> record split -> K6; and a synthetic BAM against the host decoder."""
+    path = os.path.join(FX, "bam", "test.bam")
+    assert _k6_through_scan(ctx, path, True, "chr1", 1, 12209145) == (61, 7)
+    assert _k6_through_scan(ctx, path, False, "chr1", 1, 12209145) == (61, 7)
+    ub = tmp_path / "syn.ubam"
+    subprocess.check_call([GEN, "bam", "300000", str(ub), "100"])
+    bam = tmp_path / "syn.bam"
+    subprocess.check_call([BGZIP, str(ub), str(bam), "6"])
+    g = _k6_through_scan(ctx, bam, True, "chr7", 50_000_000, 100_000_000)
+    h = _k6_through_scan(ctx, bam, False, "chr7", 50_000_000, 100_000_000)
+    assert g == h and g[0] == 300000 and g[1] > 1000

@@ -79,6 +79,46 @@ def test_k2_nulls_and_accumulate(ctx, oracle):
     assert want == int((bits(cv, n) & bits(pv, n) & (hc == 1) & (hp >= 1000) & (hp <= 200000000)).sum())
 
 
+# ---- K6 -----------------------------------------------------------------------------------------------
+def _k6_inputs(n, seed, nulls=True):
+    rng = np.random.default_rng(seed)
+    ref = rng.integers(0, 25, n, dtype=np.int32)
+    start = rng.integers(1, 250_000_000, n, dtype=np.int64)
+    end = start + rng.integers(0, 20_000, n, dtype=np.int64)
+    nb = (n + 7) // 8 + 64
+    mk = (lambda: rng.integers(0, 256, nb, dtype=np.uint8) | rng.integers(0, 256, nb, dtype=np.uint8)) if nulls else (lambda: None)
+    return ref, mk(), start, mk(), end, mk()
+
+
+@pytest.mark.parametrize("n", [1, 5, 2047, 2049, 1_000_003, 12_000_000])
+@pytest.mark.parametrize("region", ["chr7:50000000-100000000", "chr1", "chr25:1000000", "chr3:77-77", "nope:1-5"])
+def test_k6_overlap_count(ctx, oracle, n, region):
+    names = [f"chr{i + 1}" for i in range(25)]
+    ref, rv, start, sv, end, ev = _k6_inputs(n, 60 + n % 7)
+    name, a, b = oracle.parse_region(region)
+    rid = names.index(name) if name in names else -1
+    d = ctx.zeros(np.int64, 1)
+    dev = [ctx.to_device(x) for x in (ref, rv, start, sv, end, ev)]
+    ctx.overlap_count(dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], n, rid, a, b, d)
+    ctx.sync()
+    assert d.to_host()[0] == oracle.c6_overlap_count(ref, rv, start, sv, end, ev, names, region)
+
+
+def test_k6_no_bitmaps_boundaries_and_accumulate(ctx, oracle):
+    names = ["a", "b"]
+    # intervals that touch the region ends exactly (1-based inclusive on both sides)
+    ref = np.array([0, 0, 0, 0, 1, 0], np.int32)
+    start = np.array([1, 100, 201, 50, 100, 200], np.int64)
+    end = np.array([99, 100, 300, 400, 200, 200], np.int64)
+    d = ctx.zeros(np.int64, 1)
+    dev = [ctx.to_device(x) for x in (ref, start, end)]
+    for _ in range(2):
+        ctx.overlap_count(dev[0], None, dev[1], None, dev[2], None, 6, 0, 100, 200, d)
+    ctx.sync()
+    want = oracle.c6_overlap_count(ref, None, start, None, end, None, names, "a:100-200")
+    assert want == 3 and d.to_host()[0] == 2 * want
+
+
 # ---- K3 -----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n", [1, 4097, 1_000_001, 20_000_000])
 @pytest.mark.parametrize("mask,value,qmin", [(1284, 0, 30), (4, 4, 0), (0x10, 0x10, 60), (0, 0, -5), (1, 0, 0)])

@@ -142,6 +142,33 @@ def test_bam_region_hits(oracle):
     assert total == 14    # :26-29 (two files), :47-50
 
 
+def test_c6_overlap_count_matches_per_record_rule(oracle):
+    """The column-wise restatement used against K6 equals the per-record orc_bam_intersects on the fixture (7 hits,
+    slt/bam-indexed-select-tests.slt:16-19) and on random intervals with NULLs."""
+    refs, recs = decode.decode_bam(fx("bam", "test.bam"))
+    names = [n for n, _ in refs]
+
+    def cols(recs):
+        n = len(recs)
+        rid = np.array([r["ref_id"] if r["ref_id"] is not None else -1 for r in recs], np.int32)
+        st = np.array([r["start"] or 0 for r in recs], np.int64)
+        en = np.array([r["end"] or 0 for r in recs], np.int64)
+        pack = lambda v: np.packbits(np.array(v, bool), bitorder="little")  # noqa: E731
+        return (rid, pack([r["ref_id"] is not None for r in recs]), st, pack([r["start"] is not None for r in recs]), en,
+                pack([r["end"] is not None for r in recs]), n)
+
+    rid, rv, st, sv, en, ev, n = cols(recs)
+    assert oracle.c6_overlap_count(rid, rv, st, sv, en, ev, names, "chr1:1-12209145") == 7
+    rng = np.random.default_rng(6)
+    fake = [dict(ref_id=(int(rng.integers(0, 3)) if rng.random() > 0.1 else None),
+                 start=(int(s0) if rng.random() > 0.1 else None), end=(int(s0 + rng.integers(0, 200)) if rng.random() > 0.1 else None))
+            for s0 in rng.integers(1, 5000, 3000)]
+    rid, rv, st, sv, en, ev, n = cols(fake)
+    for region, (k, a, b) in {"chr2:1000-2000": (1, 1000, 2000), "chr1": (0, 1, None), "chr3:4000": (2, 4000, None)}.items():
+        want = sum(oracle.bam_intersects(r["ref_id"], r["start"], r["end"], k, a, b) for r in fake)
+        assert oracle.c6_overlap_count(rid, rv, st, sv, en, ev, ["chr1", "chr2", "chr3"], region) == want
+
+
 def test_bam_group_count_sums_to_file_rows(oracle):
     """No reference test pins GROUP BY reference; the identity sum(groups) == COUNT(*) = 61 must hold."""
     refs, recs = decode.decode_bam(fx("bam", "test.bam"))
