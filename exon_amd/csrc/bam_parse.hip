@@ -6,14 +6,7 @@
 // pos + 1 (NULL if pos < 0), end = start + (sum of M/D/N/=/X lengths) - 1, mapping_quality NULL when 255 (:136-143);
 // record layout: SAM specification section 4.2.
 //
-// BAM records are a chain (each record starts where the previous one ends), so a slab is cut into 64 KiB segments and
-// the chains are walked by one wavefront per segment in parallel:
-//   k_bam_walk     segment 0 starts at byte 0 (the caller guarantees a record boundary); every other segment GUESSES its
-//                  first record start (smallest offset where three consecutive records look plausible), then walks its
-//                  chain, storing record offsets, until it leaves the segment -> (start, landing, count)
-//   k_bam_check    the guesses are PROVEN by induction: landing(s) must equal start(s+1) for every s.  Any mismatch, a
-//                  segment without a record start (records larger than a segment) or a malformed record -> undecided:
-//                  the caller decodes on the host instead.  Exclusive scan of the counts -> first row of each segment.
+// Records are found by the parallel chain walk of chain_walk.h (64 KiB segments, guessed starts proven by induction);
 //   k_bam_extract  one thread per record: fixed fields, CIGAR walk for the reference length, columns + validity bits.
 #include <hip/hip_runtime.h>
 
@@ -21,137 +14,43 @@
 #include <new>
 #include <string>
 
+#include "chain_walk.h"
 #include "internal.h"
 
 namespace {
 
-constexpr uint32_t SEG = 65536;            // segment size in bytes
-constexpr uint32_t SEG_CAP = SEG / 36 + 2; // most records that can start inside one segment (36 = smallest record)
-constexpr uint32_t NONE = 0xFFFFFFFFu;
+using chain::ld16;
+using chain::ld32;
+using chain::SEG;
+using chain::SegInfo;
 
-__device__ __forceinline__ uint32_t ld32(const uint8_t* p) {
-  uint32_t v;
-  __builtin_memcpy(&v, p, 4);  // unaligned dword load
-  return v;
-}
-__device__ __forceinline__ uint32_t ld16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
-
-// Is there a well-formed record header at offset r (fields of SAM spec 4.2)?  Only what is needed to tell record
-// starts from arbitrary bytes; the walk itself trusts block_size alone, as the host decoder does.
-__device__ bool plausible(const uint8_t* d, uint32_t n, uint32_t r, int32_t n_ref) {
-  if ((uint64_t)r + 36 > n) return false;
-  const uint32_t bs = ld32(d + r);
-  if (bs < 32 || bs > (1u << 24)) return false;
-  const int32_t ref = (int32_t)ld32(d + r + 4), pos = (int32_t)ld32(d + r + 8);
-  if (ref < -1 || ref >= n_ref || pos < -1) return false;
-  const uint32_t l_name = d[r + 12], n_cigar = ld16(d + r + 16);
-  const int32_t l_seq = (int32_t)ld32(d + r + 20);
-  const int32_t mref = (int32_t)ld32(d + r + 24), mpos = (int32_t)ld32(d + r + 28);
-  if (l_name == 0 || l_seq < 0 || mref < -1 || mref >= n_ref || mpos < -1) return false;
-  const uint64_t need = 32ull + l_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq;
-  if (need > bs) return false;
-  if ((uint64_t)r + 36 + l_name <= n && d[r + 36 + l_name - 1] != 0) return false;  // read name is NUL-terminated
-  return true;
-}
-
-struct SegInfo {
-  uint32_t start;    // first record start inside the segment (NONE = none found)
-  uint32_t landing;  // where the chain leaves the segment (start of the first record not walked)
-  uint32_t count;    // records walked
-  uint32_t bad;      // 1 = malformed record met (block_size < 32), 2 = stopped at a record that the slab cuts off
+// BAM record: int32 block_size, then block_size bytes (SAM spec 4.2)
+struct BamFormat {
+  static constexpr uint32_t MIN_HEADER = 36, MIN_RECORD = 36, LEN_BYTES = 4;
+  int32_t n_ref;
+  __device__ __forceinline__ uint32_t record_bytes(const uint8_t* d, uint32_t r) const {
+    const uint32_t bs = ld32(d + r);
+    return bs < 32 || bs > (1u << 28) ? 0u : 4u + bs;
+  }
+  // Is there a well-formed record header at offset r?  Only what is needed to tell record starts from arbitrary bytes;
+  // the walk itself trusts block_size alone, as the host decoder does.
+  __device__ bool plausible(const uint8_t* d, uint32_t n, uint32_t r) const {
+    if ((uint64_t)r + 36 > n) return false;
+    const uint32_t bs = ld32(d + r);
+    if (bs < 32 || bs > (1u << 24)) return false;
+    const int32_t ref = (int32_t)ld32(d + r + 4), pos = (int32_t)ld32(d + r + 8);
+    if (ref < -1 || ref >= n_ref || pos < -1) return false;
+    const uint32_t l_name = d[r + 12], n_cigar = ld16(d + r + 16);
+    const int32_t l_seq = (int32_t)ld32(d + r + 20);
+    const int32_t mref = (int32_t)ld32(d + r + 24), mpos = (int32_t)ld32(d + r + 28);
+    if (l_name == 0 || l_seq < 0 || mref < -1 || mref >= n_ref || mpos < -1) return false;
+    const uint64_t need = 32ull + l_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq;
+    if (need > bs) return false;
+    if ((uint64_t)r + 36 + l_name <= n && d[r + 36 + l_name - 1] != 0) return false;  // read name is NUL-terminated
+    return true;
+  }
 };
-
-__global__ __launch_bounds__(64) void k_bam_walk(const uint8_t* __restrict__ d, uint32_t n, int32_t n_ref, SegInfo* __restrict__ seg,
-                                                 uint32_t* __restrict__ rec_off) {
-  const uint32_t s = blockIdx.x, lane = threadIdx.x;
-  const uint32_t lo = s * SEG, hi = min(n, lo + SEG);
-  uint32_t start = NONE;
-  if (s == 0) {
-    start = 0;
-  } else {
-    for (uint32_t c0 = lo; c0 < hi && start == NONE; c0 += 64) {
-      const uint32_t c = c0 + lane;
-      bool ok = c < hi && plausible(d, n, c, n_ref);
-      if (ok) {  // two more records down the chain (fewer when the slab ends first)
-        uint32_t r = c;
-        for (int k = 0; k < 2 && ok; ++k) {
-          r += 4 + ld32(d + r);
-          if ((uint64_t)r + 36 > n) break;
-          ok = plausible(d, n, r, n_ref);
-        }
-      }
-      const unsigned long long m = __ballot(ok);
-      if (m) start = c0 + (uint32_t)__ffsll((long long)m) - 1;
-    }
-  }
-  uint32_t r = start, k = 0, bad = 0;
-  if (start != NONE) {
-    uint32_t* out = rec_off + (size_t)s * SEG_CAP;
-    while (r < hi) {
-      if ((uint64_t)r + 4 > n) { bad = 2; break; }
-      const uint32_t bs = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld32(d + r));
-      if (bs < 32) { bad = 1; break; }
-      if ((uint64_t)r + 4 + bs > n) { bad = 2; break; }  // record cut off by the end of the slab: carried by the caller
-      if (lane == 0) out[k] = r;
-      ++k;
-      r += 4 + bs;
-    }
-    // the next record's header is not fully inside the slab: whatever follows cannot be recognised by the segments
-    // behind this one, and does not need to be -- it is the cut-off tail
-    if (bad == 0 && (uint64_t)r + 36 > n) bad = 2;
-  }
-  if (lane == 0) seg[s] = SegInfo{start, r, k, bad};
-}
-
-// scalars: [0] rows, [1] undecided, [2] consumed bytes.  Segments behind the one whose chain met the cut-off record hold
-// only that record's bytes: they are ignored (their counts are zeroed).
-__global__ __launch_bounds__(1024) void k_bam_check(SegInfo* __restrict__ seg, uint32_t n_seg, uint32_t* __restrict__ base,
-                                                    unsigned* __restrict__ scalars) {
-  __shared__ unsigned part[1024];
-  __shared__ unsigned any_bad, s_cut;
-  if (threadIdx.x == 0) {
-    any_bad = 0;
-    s_cut = n_seg - 1;
-  }
-  __syncthreads();
-  const uint32_t per = (n_seg + 1023) / 1024;
-  const uint32_t s0 = threadIdx.x * per, s1 = min(n_seg, s0 + per);
-  for (uint32_t s = s0; s < s1; ++s)
-    if (seg[s].bad == 2) atomicMin(&s_cut, s);
-  __syncthreads();
-  const uint32_t last = s_cut;
-  unsigned sum = 0, bad = 0;
-  for (uint32_t s = s0; s < s1; ++s) {
-    if (s > last) {
-      seg[s].count = 0;
-      continue;
-    }
-    const SegInfo a = seg[s];
-    sum += a.count;
-    if (a.start == NONE || a.bad == 1) bad = 1;
-    if (s < last && a.landing != seg[s + 1].start) bad = 1;  // also catches chains that skip a whole segment
-  }
-  if (bad) atomicOr(&any_bad, 1u);
-  part[threadIdx.x] = sum;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    unsigned v = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0u;
-    __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
-  }
-  unsigned run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
-  for (uint32_t s = s0; s < s1; ++s) {
-    base[s] = run;
-    run += s > last ? 0u : seg[s].count;
-  }
-  if (threadIdx.x == 1023) {
-    scalars[0] = part[1023];
-    scalars[2] = seg[last].landing;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0 && any_bad) atomicAdd(&scalars[1], 1u);
-}
+constexpr uint32_t SEG_CAP = chain::seg_cap<BamFormat>();
 
 struct BamOut {
   int32_t* flag;
@@ -284,8 +183,8 @@ int exon_hip_bam_parser_parse(exon_hip_bam_parser* p, void* stream, const uint8_
   HIP_TRY(ctx, hipMemsetAsync(p->out.mapq_valid, 0, words, s));
   HIP_TRY(ctx, hipMemsetAsync(p->out.ref_valid, 0, words, s));
   HIP_TRY(ctx, hipMemsetAsync(p->out.pos_valid, 0, words, s));
-  hipLaunchKernelGGL(k_bam_walk, dim3(n_seg), dim3(64), 0, s, d_data, n, p->n_ref, p->d_seg, p->d_rec_off);
-  hipLaunchKernelGGL(k_bam_check, dim3(1), dim3(1024), 0, s, p->d_seg, n_seg, p->d_base, p->d_scalars);
+  hipLaunchKernelGGL(chain::k_chain_walk<BamFormat>, dim3(n_seg), dim3(64), 0, s, d_data, n, BamFormat{p->n_ref}, p->d_seg, p->d_rec_off);
+  hipLaunchKernelGGL(chain::k_chain_check<0>, dim3(1), dim3(1024), 0, s, p->d_seg, n_seg, p->d_base, p->d_scalars);
   hipLaunchKernelGGL(k_bam_extract, dim3(n_seg), dim3(256), 0, s, d_data, p->d_seg, p->d_base, p->d_rec_off, p->out, p->d_scalars);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(p->h_scalars, p->d_scalars, 12, hipMemcpyDeviceToHost, s));

@@ -1,0 +1,133 @@
+// chain_walk.h -- splitting a slab of length-prefixed binary records (BAM, BCF) in HBM, in parallel.
+//
+// The records form a chain (each starts where the previous one ends), so the slab is cut into 64 KiB segments and the
+// chains are walked by one wavefront per segment:
+//   k_chain_walk<F>  segment 0 starts at byte 0 (the caller guarantees a record boundary); every other segment GUESSES its
+//                    first record start (smallest offset where three consecutive record headers look plausible), then walks
+//                    its chain, storing record offsets, until it leaves the segment -> (start, landing, count)
+//   k_chain_check    the guesses are PROVEN by induction: landing(s) must equal start(s+1) for every s.  Any mismatch, a
+//                    segment without a record start (records larger than a segment) or a malformed record -> undecided:
+//                    the caller decodes on the host instead.  Exclusive scan of the counts -> first row of each segment.
+// A format F provides: MIN_HEADER (bytes a plausibility check needs), MIN_RECORD (smallest record), record_bytes(d, r)
+// (total size of the record at r, 0 = malformed) and plausible(d, n, r).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace chain {
+
+constexpr uint32_t SEG = 65536;  // segment size in bytes
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);  // unaligned dword load
+  return v;
+}
+__device__ __forceinline__ uint32_t ld16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+
+struct SegInfo {
+  uint32_t start;    // first record start inside the segment (NONE = none found)
+  uint32_t landing;  // where the chain leaves the segment (start of the first record not walked)
+  uint32_t count;    // records walked
+  uint32_t bad;      // 1 = malformed record met, 2 = stopped at a record that the slab cuts off
+};
+
+template <class F>
+constexpr uint32_t seg_cap() { return SEG / F::MIN_RECORD + 2; }  // most records that can start inside one segment
+
+template <class F>
+__global__ __launch_bounds__(64) void k_chain_walk(const uint8_t* __restrict__ d, uint32_t n, F fmt, SegInfo* __restrict__ seg,
+                                                   uint32_t* __restrict__ rec_off) {
+  const uint32_t s = blockIdx.x, lane = threadIdx.x;
+  const uint32_t lo = s * SEG, hi = min(n, lo + SEG);
+  uint32_t start = NONE;
+  if (s == 0) {
+    start = 0;
+  } else {
+    for (uint32_t c0 = lo; c0 < hi && start == NONE; c0 += 64) {
+      const uint32_t c = c0 + lane;
+      bool ok = c < hi && fmt.plausible(d, n, c);
+      if (ok) {  // two more records down the chain (fewer when the slab ends first)
+        uint32_t r = c;
+        for (int k = 0; k < 2 && ok; ++k) {
+          r += fmt.record_bytes(d, r);
+          if ((uint64_t)r + F::MIN_HEADER > n) break;
+          ok = fmt.plausible(d, n, r);
+        }
+      }
+      const unsigned long long m = __ballot(ok);
+      if (m) start = c0 + (uint32_t)__ffsll((long long)m) - 1;
+    }
+  }
+  uint32_t r = start, k = 0, bad = 0;
+  if (start != NONE) {
+    uint32_t* out = rec_off + (size_t)s * seg_cap<F>();
+    while (r < hi) {
+      if ((uint64_t)r + F::LEN_BYTES > n) { bad = 2; break; }
+      const uint32_t sz = (uint32_t)__builtin_amdgcn_readfirstlane((int)fmt.record_bytes(d, r));
+      if (sz == 0) { bad = 1; break; }
+      if ((uint64_t)r + sz > n) { bad = 2; break; }  // record cut off by the end of the slab: carried by the caller
+      if (lane == 0) out[k] = r;
+      ++k;
+      r += sz;
+    }
+    // the next record's header is not fully inside the slab: whatever follows cannot be recognised by the segments
+    // behind this one, and does not need to be -- it is the cut-off tail
+    if (bad == 0 && (uint64_t)r + F::MIN_HEADER > n) bad = 2;
+  }
+  if (lane == 0) seg[s] = SegInfo{start, r, k, bad};
+}
+
+// scalars: [0] rows, [1] undecided, [2] consumed bytes.  Segments behind the one whose chain met the cut-off record hold
+// only that record's bytes: they are ignored (their counts are zeroed).
+template <int UNUSED = 0>  // a template only so that several translation units may include this header
+__global__ __launch_bounds__(1024) void k_chain_check(SegInfo* __restrict__ seg, uint32_t n_seg, uint32_t* __restrict__ base,
+                                                             unsigned* __restrict__ scalars) {
+  __shared__ unsigned part[1024];
+  __shared__ unsigned any_bad, s_cut;
+  if (threadIdx.x == 0) {
+    any_bad = 0;
+    s_cut = n_seg - 1;
+  }
+  __syncthreads();
+  const uint32_t per = (n_seg + 1023) / 1024;
+  const uint32_t s0 = threadIdx.x * per, s1 = min(n_seg, s0 + per);
+  for (uint32_t s = s0; s < s1; ++s)
+    if (seg[s].bad == 2) atomicMin(&s_cut, s);
+  __syncthreads();
+  const uint32_t last = s_cut;
+  unsigned sum = 0, bad = 0;
+  for (uint32_t s = s0; s < s1; ++s) {
+    if (s > last) {
+      seg[s].count = 0;
+      continue;
+    }
+    const SegInfo a = seg[s];
+    sum += a.count;
+    if (a.start == NONE || a.bad == 1) bad = 1;
+    if (s < last && a.landing != seg[s + 1].start) bad = 1;  // also catches chains that skip a whole segment
+  }
+  if (bad) atomicOr(&any_bad, 1u);
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    unsigned v = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  unsigned run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
+  for (uint32_t s = s0; s < s1; ++s) {
+    base[s] = run;
+    run += s > last ? 0u : seg[s].count;
+  }
+  if (threadIdx.x == 1023) {
+    scalars[0] = part[1023];
+    scalars[2] = seg[last].landing;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && any_bad) atomicAdd(&scalars[1], 1u);
+}
+
+}  // namespace chain
