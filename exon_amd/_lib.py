@@ -159,6 +159,7 @@ SIGNATURES = {
     "exon_hip_scan_dictionary_intern": (C.c_int, [_vp, _i32, C.c_char_p, C.POINTER(_i32)]),
     "exon_hip_scan_dictionary_value": (C.c_int, [_vp, _i32, _i32, C.POINTER(C.c_char_p)]),
     "exon_hip_scan_rows": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "exon_hip_scan_decoded_on_gpu": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "exon_hip_scan_close": (C.c_int, [_vp]),
     "exon_hip_scan_index_chunks": (C.c_int, [_vp, C.POINTER(_i32)]),
     "exon_hip_index_query": (C.c_int, [C.c_char_p, _i32, C.c_char_p, _i32, _i64, _i64, C.POINTER(_u64), C.POINTER(_u64),
@@ -175,6 +176,10 @@ SIGNATURES = {
     "exon_hip_bam_parser_create": (C.c_int, [_vp, _i32, _i64, C.POINTER(_vp)]),
     "exon_hip_bam_parser_parse": (C.c_int, [_vp, _vp, _vp, _i64, C.POINTER(BAMColumns)]),
     "exon_hip_bam_parser_destroy": (C.c_int, [_vp]),
+    "exon_hip_bcf_parser_create": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i64, C.POINTER(_vp)]),
+    "exon_hip_bcf_parser_parse": (C.c_int, [_vp, _vp, _vp, _i64, C.POINTER(VCFColumns)]),
+    "exon_hip_bcf_parser_filters": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), _i32, C.POINTER(_i32)]),
+    "exon_hip_bcf_parser_destroy": (C.c_int, [_vp]),
     "exon_hip_bgzf_scan": (C.c_int, [_vp, C.c_size_t, C.c_size_t, C.POINTER(BgzfBlock), _i32, C.POINTER(_i32),
                                      C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "exon_hip_bgzf_inflate": (C.c_int, [_vp, _vp, _vp, C.POINTER(BgzfBlock), _i32, _vp, _i32, C.POINTER(_i32)]),

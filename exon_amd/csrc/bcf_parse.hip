@@ -1,0 +1,363 @@
+// bcf_parse.hip -- BCF2 record splitting + field extraction ON THE GPU: inflated BCF bytes in HBM -> the VCF device
+// layout (chrom id, pos, qual, filter-list id, one typed INFO field) in HBM.
+//
+// Reference: exon-bcf behind exon-core/src/datasources/bcf/ (same Arrow schema as VCF; pinned by
+// exon-core/src/session_context/exon_context_ext.rs:1053-1090: index.bcf has 621 records, 191 on chromosome "1").
+// Record layout: VCF 4.x specification section 6 (BCF2): `l_shared, l_indiv`, fixed fields (CHROM id, 0-based POS,
+// rlen, QUAL with the 0x7F800001 missing sentinel, n_info | n_allele << 16, n_fmt << 24 | n_sample), typed ID / alleles
+// / FILTER (dictionary indexes) / INFO (dictionary index -> typed value).  Same field rules as host/bcf.h.
+//
+// Records are found by the parallel chain walk of chain_walk.h (64 KiB segments, guessed starts proven by induction);
+//   k_bcf_extract  one thread per record: fixed fields, typed-value walk to FILTER and the wanted INFO key; FILTER index
+//                  lists are interned in a persistent device table (identity = 64-bit hash of the list)
+//   k_bcf_assign / k_bcf_remap   dense ids for lists seen for the first time, provisional slot -> id
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "chain_walk.h"
+#include "internal.h"
+
+namespace {
+
+using chain::ld16;
+using chain::ld32;
+using chain::SEG;
+using chain::SegInfo;
+
+constexpr int FSLOTS = 8192;  // open addressing; at most EXON_HIP_MAX_GROUPS distinct lists are supported
+constexpr int FLIST = 8;      // longest FILTER list kept (longer ones: undecided)
+
+struct BcfFormat {
+  static constexpr uint32_t MIN_HEADER = 32, MIN_RECORD = 32, LEN_BYTES = 8;
+  int32_t n_contigs, n_samples;
+  __device__ __forceinline__ uint32_t record_bytes(const uint8_t* d, uint32_t r) const {
+    const uint32_t ls = ld32(d + r), li = ld32(d + r + 4);
+    return (ls < 24 || ls > (1u << 28) || li > (1u << 28)) ? 0u : 8u + ls + li;
+  }
+  __device__ bool plausible(const uint8_t* d, uint32_t n, uint32_t r) const {
+    if ((uint64_t)r + 32 > n) return false;
+    const uint32_t ls = ld32(d + r), li = ld32(d + r + 4);
+    if (ls < 24 || ls > (1u << 24) || li > (1u << 26)) return false;
+    const int32_t chrom = (int32_t)ld32(d + r + 8), pos = (int32_t)ld32(d + r + 12), rlen = (int32_t)ld32(d + r + 16);
+    if (chrom < 0 || chrom >= n_contigs || pos < -1 || rlen < 0) return false;
+    const uint32_t nia = ld32(d + r + 24), nfs = ld32(d + r + 28);
+    if ((nia >> 16) == 0) return false;                          // at least REF
+    if ((int32_t)(nfs & 0xFFFFFFu) != n_samples) return false;   // every record carries the header's sample count
+    if (n_samples == 0 && li != 0) return false;
+    if (ls > 24 && (uint64_t)r + 33 <= n && (d[r + 32] & 0xF) != 7) return false;  // ID is a typed string
+    return true;
+  }
+};
+constexpr uint32_t SEG_CAP = chain::seg_cap<BcfFormat>();
+
+struct FilterLists {  // persistent across slabs
+  unsigned long long* keys;  // 0 = empty
+  int32_t* ids;              // -1 until assigned
+  int32_t* lists;            // [FSLOTS][FLIST]
+  int32_t* counts;           // [FSLOTS]
+  int32_t* counters;         // [0] ids assigned, [1] table overflow
+};
+
+struct BcfOut {
+  int32_t* chrom_id;
+  int64_t* pos;
+  float* qual;
+  uint32_t* qual_valid;
+  int32_t* filter_id;
+  float* info;
+  uint32_t* info_valid;
+};
+
+__device__ __forceinline__ int type_size(int t) { return t == 1 ? 1 : t == 2 ? 2 : t == 3 ? 4 : t == 5 ? 4 : t == 7 ? 1 : 0; }
+
+struct Cursor {
+  const uint8_t* d;
+  uint32_t o, end;
+  bool bad;
+  __device__ int64_t read_int(int type) {
+    const int sz = type_size(type);
+    if (type < 1 || type > 3 || o + (uint32_t)sz > end) { bad = true; return 0; }
+    int64_t v;
+    if (type == 1) v = (int8_t)d[o];
+    else if (type == 2) v = (int16_t)ld16(d + o);
+    else v = (int32_t)ld32(d + o);
+    o += (uint32_t)sz;
+    return v;
+  }
+  __device__ void typed_header(int* type, int* count) {
+    if (o >= end) { bad = true; *type = 0; *count = 0; return; }
+    const uint8_t b = d[o++];
+    *type = b & 0xF;
+    *count = b >> 4;
+    if (*count == 15) {  // the real count follows as a typed integer
+      if (o >= end) { bad = true; return; }
+      const uint8_t c = d[o++];
+      *count = (int)read_int(c & 0xF);
+      if (*count < 0) bad = true;
+    }
+  }
+  __device__ void skip_typed() {
+    int t, c;
+    typed_header(&t, &c);
+    o += (uint32_t)c * (uint32_t)type_size(t);
+    if (o > end) bad = true;
+  }
+};
+
+__global__ __launch_bounds__(256) void k_bcf_extract(const uint8_t* __restrict__ d, const SegInfo* __restrict__ seg,
+                                                     const uint32_t* __restrict__ base, const uint32_t* __restrict__ rec_off, BcfOut out,
+                                                     FilterLists f, int32_t n_contigs, int32_t n_strings, int32_t info_key,
+                                                     unsigned* __restrict__ scalars) {
+  const uint32_t s = blockIdx.x;
+  if (scalars[1] != 0) return;  // the segmentation was not proven: nothing here can be trusted
+  const uint32_t cnt = seg[s].count, row0 = base[s];
+  const uint32_t* offs = rec_off + (size_t)s * SEG_CAP;
+  for (uint32_t k = threadIdx.x; k < cnt; k += 256) {
+    const uint32_t r = offs[k], row = row0 + k;
+    const uint32_t ls = ld32(d + r);
+    const int32_t chrom = (int32_t)ld32(d + r + 8), pos0 = (int32_t)ld32(d + r + 12);
+    const uint32_t qbits = ld32(d + r + 20), nia = ld32(d + r + 24);
+    const int n_info = (int)(nia & 0xFFFF), n_allele = (int)(nia >> 16);
+    Cursor c{d, r + 32, r + 8 + ls, false};
+    c.skip_typed();                                      // ID
+    for (int a = 0; a < n_allele && !c.bad; ++a) c.skip_typed();  // REF + ALTs
+    // FILTER: typed int vector of dictionary indexes; empty = '.'
+    int ft, fc;
+    c.typed_header(&ft, &fc);
+    int32_t list[FLIST];
+    bool undecided = chrom < 0 || chrom >= n_contigs || fc > FLIST;
+    unsigned long long h = 0xCBF29CE484222325ULL ^ (unsigned long long)(fc < 0 ? 0 : fc);
+    for (int i = 0; i < fc && !c.bad && !undecided; ++i) {
+      const int64_t v = c.read_int(ft);
+      if (v < 0 || v >= n_strings) undecided = true;
+      list[i] = (int32_t)v;
+      h = (h ^ (unsigned long long)(v + 1)) * 0x100000001B3ULL;
+    }
+    // INFO: (typed key, typed value) pairs
+    bool have = false;
+    float iv = 0.f;
+    for (int q = 0; q < n_info && !c.bad && !undecided; ++q) {
+      int kt, kc;
+      c.typed_header(&kt, &kc);
+      const int64_t key = kc ? c.read_int(kt) : -1;
+      int vt, vc;
+      c.typed_header(&vt, &vc);
+      if (c.bad) break;
+      if (key == info_key && info_key >= 0 && vc >= 1) {
+        if (vt == 5) {
+          if (c.o + 4 > c.end) { c.bad = true; break; }
+          const uint32_t b = ld32(d + c.o);
+          if (b != 0x7F800001u && b != 0x7F800002u) {
+            iv = __uint_as_float(b);
+            have = true;
+          }
+        } else if (vt >= 1 && vt <= 3) {
+          Cursor t = c;
+          const int64_t v = t.read_int(vt);
+          if (t.bad) { c.bad = true; break; }
+          const int64_t missing = vt == 1 ? -128 : vt == 2 ? -32768 : (int64_t)INT32_MIN;
+          if (v != missing) {
+            iv = (float)v;
+            have = true;
+          }
+        }
+      }
+      c.o += (uint32_t)vc * (uint32_t)type_size(vt);
+      if (c.o > c.end) c.bad = true;
+    }
+    if (c.bad || undecided) {
+      atomicAdd(&scalars[1], 1u);
+      continue;
+    }
+    // intern the FILTER list
+    h |= 1ull;
+    int slot = (int)(h & (unsigned long long)(FSLOTS - 1)), probes = 0;
+    for (;; slot = (slot + 1) & (FSLOTS - 1)) {
+      const unsigned long long prev = atomicCAS(&f.keys[slot], 0ull, h);
+      if (prev == 0ull) {  // ours: publish the list (read by k_bcf_assign / the host only after this kernel)
+        f.counts[slot] = fc;
+        for (int i = 0; i < fc; ++i) f.lists[slot * FLIST + i] = list[i];
+        break;
+      }
+      if (prev == h) break;
+      if (++probes >= FSLOTS) {
+        f.counters[1] = 1;
+        slot = 0;
+        break;
+      }
+    }
+    out.chrom_id[row] = chrom;
+    out.pos[row] = (int64_t)pos0 + 1;
+    out.qual[row] = qbits == 0x7F800001u ? 0.f : __uint_as_float(qbits);
+    out.filter_id[row] = slot;
+    out.info[row] = have ? iv : 0.f;
+    const uint32_t bit = 1u << (row & 31);
+    if (qbits != 0x7F800001u) atomicOr(&out.qual_valid[row >> 5], bit);
+    if (have) atomicOr(&out.info_valid[row >> 5], bit);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bcf_assign(FilterLists f) {
+  for (int s = threadIdx.x; s < FSLOTS; s += 256)
+    if (f.keys[s] != 0ull && f.ids[s] < 0) f.ids[s] = atomicAdd(&f.counters[0], 1);
+}
+
+__global__ __launch_bounds__(256) void k_bcf_remap(int32_t* __restrict__ filter_id, const unsigned* __restrict__ scalars,
+                                                   const int32_t* __restrict__ ids) {
+  if (scalars[1] != 0) return;
+  const int64_t n = scalars[0];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) filter_id[i] = ids[filter_id[i]];
+}
+
+}  // namespace
+
+struct exon_hip_bcf_parser {
+  exon_hip_ctx* ctx = nullptr;
+  int32_t n_contigs = 0, n_strings = 0, n_samples = 0, info_key = -1;
+  int64_t max_bytes = 0, max_rows = 0;
+  uint32_t max_seg = 0;
+  SegInfo* d_seg = nullptr;
+  uint32_t *d_base = nullptr, *d_rec_off = nullptr, *d_scalars = nullptr;
+  void* bufs[7] = {nullptr};
+  void* fbufs[5] = {nullptr};
+  BcfOut out{};
+  FilterLists filters{};
+  unsigned* h_scalars = nullptr;
+};
+
+extern "C" {
+
+int exon_hip_bcf_parser_create(exon_hip_ctx* ctx, int32_t n_contigs, int32_t n_strings, int32_t n_samples, int32_t info_key,
+                               int64_t max_bytes, exon_hip_bcf_parser** outp) {
+  if (!ctx || !outp || max_bytes < 64 || n_contigs < 0 || n_strings < 0 || n_samples < 0)
+    return fail(ctx, EXON_HIP_EINVAL, "exon_hip_bcf_parser_create: bad argument");
+  if (max_bytes > 0xF0000000LL) return fail(ctx, EXON_HIP_EINVAL, "slab size must stay below 4 GiB (32-bit record offsets)");
+  *outp = nullptr;
+  exon_hip_bcf_parser* p = new (std::nothrow) exon_hip_bcf_parser();
+  if (!p) return fail(ctx, EXON_HIP_ENOMEM, "out of host memory");
+  p->ctx = ctx;
+  p->n_contigs = n_contigs;
+  p->n_strings = n_strings;
+  p->n_samples = n_samples;
+  p->info_key = info_key;
+  p->max_bytes = max_bytes;
+  p->max_seg = (uint32_t)((max_bytes + SEG - 1) / SEG);
+  p->max_rows = max_bytes / 32 + 1;
+  hipSetDevice(ctx->device);
+  hipError_t e = hipSuccess;
+  auto dalloc = [&](void** ptr, size_t bytes) {
+    if (e == hipSuccess && !(*ptr = exon_pool_alloc(ctx, bytes))) e = hipErrorOutOfMemory;
+  };
+  const size_t r = (size_t)p->max_rows, w = (r + 31) / 32 * 4 + 64;
+  dalloc((void**)&p->d_seg, (size_t)p->max_seg * sizeof(SegInfo));
+  dalloc((void**)&p->d_base, (size_t)p->max_seg * 4);
+  dalloc((void**)&p->d_rec_off, (size_t)p->max_seg * SEG_CAP * 4);
+  dalloc((void**)&p->d_scalars, 16);
+  dalloc(&p->bufs[0], r * 4);
+  dalloc(&p->bufs[1], r * 8);
+  dalloc(&p->bufs[2], r * 4);
+  dalloc(&p->bufs[3], w);
+  dalloc(&p->bufs[4], r * 4);
+  dalloc(&p->bufs[5], r * 4);
+  dalloc(&p->bufs[6], w);
+  dalloc(&p->fbufs[0], (size_t)FSLOTS * 8);
+  dalloc(&p->fbufs[1], (size_t)FSLOTS * 4);
+  dalloc(&p->fbufs[2], (size_t)FSLOTS * FLIST * 4);
+  dalloc(&p->fbufs[3], (size_t)FSLOTS * 4);
+  dalloc(&p->fbufs[4], 16);
+  if (e == hipSuccess) e = hipMemset(p->fbufs[0], 0, (size_t)FSLOTS * 8);
+  if (e == hipSuccess) e = hipMemset(p->fbufs[1], 0xFF, (size_t)FSLOTS * 4);
+  if (e == hipSuccess) e = hipMemset(p->fbufs[4], 0, 16);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&p->h_scalars, 16);
+  if (e != hipSuccess) {
+    const std::string msg = hipGetErrorString(e);
+    exon_hip_bcf_parser_destroy(p);
+    return fail(ctx, EXON_HIP_ENOMEM, "bcf parser allocation: %s", msg.c_str());
+  }
+  p->out = BcfOut{(int32_t*)p->bufs[0], (int64_t*)p->bufs[1], (float*)p->bufs[2], (uint32_t*)p->bufs[3],
+                  (int32_t*)p->bufs[4], (float*)p->bufs[5], (uint32_t*)p->bufs[6]};
+  p->filters = FilterLists{(unsigned long long*)p->fbufs[0], (int32_t*)p->fbufs[1], (int32_t*)p->fbufs[2], (int32_t*)p->fbufs[3],
+                           (int32_t*)p->fbufs[4]};
+  *outp = p;
+  return EXON_HIP_OK;
+}
+
+int exon_hip_bcf_parser_destroy(exon_hip_bcf_parser* p) {
+  if (!p) return EXON_HIP_OK;
+  for (void* b : p->bufs) exon_pool_free(p->ctx, b);
+  for (void* b : p->fbufs) exon_pool_free(p->ctx, b);
+  exon_pool_free(p->ctx, p->d_seg);
+  exon_pool_free(p->ctx, p->d_base);
+  exon_pool_free(p->ctx, p->d_rec_off);
+  exon_pool_free(p->ctx, p->d_scalars);
+  if (p->h_scalars) hipHostFree(p->h_scalars);
+  delete p;
+  return EXON_HIP_OK;
+}
+
+int exon_hip_bcf_parser_parse(exon_hip_bcf_parser* p, void* stream, const uint8_t* d_data, int64_t n_bytes, exon_hip_vcf_columns* cols) {
+  if (!p || !cols || (n_bytes > 0 && !d_data)) return fail(p ? p->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_bcf_parser_parse: NULL argument");
+  exon_hip_ctx* ctx = p->ctx;
+  if (n_bytes > p->max_bytes) return fail(ctx, EXON_HIP_EINVAL, "slab of %lld bytes exceeds the parser's %lld", (long long)n_bytes, (long long)p->max_bytes);
+  memset(cols, 0, sizeof *cols);
+  if (n_bytes == 0) return EXON_HIP_OK;
+  hipStream_t s = pick_stream(ctx, stream);
+  const uint32_t n = (uint32_t)n_bytes, n_seg = (n + SEG - 1) / SEG;
+  const size_t words = ((size_t)n / 32 + 1 + 31) / 32 * 4 + 4;
+  HIP_TRY(ctx, hipMemsetAsync(p->d_scalars, 0, 16, s));
+  HIP_TRY(ctx, hipMemsetAsync(p->out.qual_valid, 0, words, s));
+  HIP_TRY(ctx, hipMemsetAsync(p->out.info_valid, 0, words, s));
+  hipLaunchKernelGGL(chain::k_chain_walk<BcfFormat>, dim3(n_seg), dim3(64), 0, s, d_data, n, BcfFormat{p->n_contigs, p->n_samples}, p->d_seg,
+                     p->d_rec_off);
+  hipLaunchKernelGGL(chain::k_chain_check<0>, dim3(1), dim3(1024), 0, s, p->d_seg, n_seg, p->d_base, p->d_scalars);
+  hipLaunchKernelGGL(k_bcf_extract, dim3(n_seg), dim3(256), 0, s, d_data, p->d_seg, p->d_base, p->d_rec_off, p->out, p->filters,
+                     p->n_contigs, p->n_strings, p->info_key, p->d_scalars);
+  hipLaunchKernelGGL(k_bcf_assign, dim3(1), dim3(256), 0, s, p->filters);
+  hipLaunchKernelGGL(k_bcf_remap, dim3(std::min<uint32_t>(n_seg * 4 + 1, 4096)), dim3(256), 0, s, p->out.filter_id, p->d_scalars, p->filters.ids);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(p->h_scalars, p->d_scalars, 12, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  cols->n_rows = p->h_scalars[0];
+  cols->n_undecided = p->h_scalars[1];
+  cols->consumed_bytes = p->h_scalars[2];
+  cols->chrom_id = p->out.chrom_id;
+  cols->pos = p->out.pos;
+  cols->pos_valid = nullptr;  // POS is a fixed field: never NULL
+  cols->qual = p->out.qual;
+  cols->qual_valid = (uint8_t*)p->out.qual_valid;
+  cols->filter_id = p->out.filter_id;
+  cols->info = p->info_key >= 0 ? p->out.info : nullptr;
+  cols->info_valid = p->info_key >= 0 ? (uint8_t*)p->out.info_valid : nullptr;
+  return EXON_HIP_OK;
+}
+
+// FILTER lists discovered so far, in id order: lists[i * 8 .. i * 8 + counts[i]) are dictionary (header string) indexes
+int exon_hip_bcf_parser_filters(exon_hip_bcf_parser* p, int32_t* lists, int32_t* counts, int32_t cap, int32_t* n_filters) {
+  if (!p || !n_filters) return fail(p ? p->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_bcf_parser_filters: NULL argument");
+  exon_hip_ctx* ctx = p->ctx;
+  int32_t counters[4];
+  HIP_TRY(ctx, hipMemcpy(counters, p->filters.counters, 16, hipMemcpyDeviceToHost));
+  if (counters[1] || counters[0] > EXON_HIP_MAX_GROUPS) return fail(ctx, EXON_HIP_EUNSUPPORTED, "more than %d distinct FILTER lists", EXON_HIP_MAX_GROUPS);
+  *n_filters = counters[0];
+  if (!lists || !counts) return EXON_HIP_OK;
+  if (counters[0] > cap) return fail(ctx, EXON_HIP_EINVAL, "filter list buffer too small (%d needed)", counters[0]);
+  std::vector<unsigned long long> keys(FSLOTS);
+  std::vector<int32_t> ids(FSLOTS), l((size_t)FSLOTS * FLIST), c(FSLOTS);
+  HIP_TRY(ctx, hipMemcpy(keys.data(), p->filters.keys, (size_t)FSLOTS * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(ids.data(), p->filters.ids, (size_t)FSLOTS * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(l.data(), p->filters.lists, (size_t)FSLOTS * FLIST * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(c.data(), p->filters.counts, (size_t)FSLOTS * 4, hipMemcpyDeviceToHost));
+  for (int s = 0; s < FSLOTS; ++s)
+    if (keys[(size_t)s] != 0 && ids[(size_t)s] >= 0 && ids[(size_t)s] < counters[0]) {
+      const int id = ids[(size_t)s];
+      counts[id] = c[(size_t)s];
+      for (int i = 0; i < FLIST; ++i) lists[(size_t)id * FLIST + i] = l[(size_t)s * FLIST + i];
+    }
+  return EXON_HIP_OK;
+}
+
+}  // extern "C"

@@ -60,6 +60,14 @@ class BCFBatchReader {
         add_string(header_attr(line, "ID"), header_attr(line, "IDX"));
       } else if (line.rfind("##FORMAT=", 0) == 0) {
         add_string(header_attr(line, "ID"), header_attr(line, "IDX"));
+      } else if (line.rfind("#CHROM", 0) == 0) {
+        size_t col = 0, st = 0;
+        for (size_t i = 0; i <= line.size(); ++i)
+          if (i == line.size() || line[i] == '\t') {
+            if (col >= 9) header.samples.push_back(line.substr(st, i - st));
+            ++col;
+            st = i + 1;
+          }
       }
     }
     for (const auto& c : header.contigs) chrom_dict.names.push_back(c);
@@ -189,6 +197,12 @@ class BCFBatchReader {
     if (info_key_ >= 0) kids.push_back(new_field("f", ("info." + cfg_.info_field).c_str(), true));
     make_schema(out, "+s", "", false, kids);
   }
+
+  // what a GPU-side decoder of the same file needs (bcf_parse.hip)
+  const VCFConfig& config() const { return cfg_; }
+  const std::vector<std::string>& strings() const { return strings_; }
+  int info_key() const { return info_key_; }
+  int64_t data_offset() const { return (int64_t)static_cast<StreamSource*>(r_.get())->r.consumed(); }  // header bytes
 
   VCFHeader header;
   Dictionary chrom_dict, filter_dict;

@@ -29,7 +29,9 @@ struct exon_hip_scan {
   exon_hip_ctx* parser_ctx = nullptr;
   exon_hip_fastq_parser* fq_parser = nullptr;
   exon_hip_bam_parser* bam_parser = nullptr;
+  exon_hip_bcf_parser* bcf_parser = nullptr;
   bool gpu_inflated = false;  // the last GPU-parsed consume also inflated BGZF blocks on the device
+  bool gpu_decoded = false;   // the last consume decoded every record on the device (no host fallback)
   exon::Dictionary gpu_filter_dict;       // names fetched from the parser after the consume
   std::unique_ptr<exon::VCFBatchReader> vcf;
   std::unique_ptr<exon::BAMBatchReader> bam;
@@ -60,7 +62,7 @@ static bool wants_gpu_inflate(const exon_hip_scan_options* o, const char* path) 
 
 static exon::Dictionary* dict_of(exon_hip_scan* s, int col) {
   if (s->format == EXON_HIP_FORMAT_BCF && col == 0) return &s->bcf->chrom_dict;
-  if (s->format == EXON_HIP_FORMAT_BCF && col == 3) return &s->bcf->filter_dict;
+  if (s->format == EXON_HIP_FORMAT_BCF && col == 3) return s->bcf_parser ? &s->gpu_filter_dict : &s->bcf->filter_dict;
   if (s->format == EXON_HIP_FORMAT_VCF && col == 0) return &s->vcf->chrom_dict;
   if (s->format == EXON_HIP_FORMAT_VCF && col == 3) return s->parser ? &s->gpu_filter_dict : &s->vcf->filter_dict;
   if ((s->format == EXON_HIP_FORMAT_BAM || s->format == EXON_HIP_FORMAT_SAM) && col == 2) return &s->bam_dict_view;
@@ -119,6 +121,8 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         cfg.info_field = o->info_field ? o->info_field : "";
         cfg.filter = rf;
         cfg.filter.use_index = false;
+        s->gpu_parse = !rf.active && wants_gpu_inflate(o, path);  // BCF is BGZF by definition
+        if (s->gpu_parse) cfg.threads = 1;  // only the header is read on the host
         s->bcf.reset(new exon::BCFBatchReader(path, cfg));
         break;
       }
@@ -258,6 +262,7 @@ int exon_hip_scan_close(exon_hip_scan* s) {
   if (s && s->parser) exon_hip_vcf_parser_destroy(s->parser);
   if (s && s->fq_parser) exon_hip_fastq_parser_destroy(s->fq_parser);
   if (s && s->bam_parser) exon_hip_bam_parser_destroy(s->bam_parser);
+  if (s && s->bcf_parser) exon_hip_bcf_parser_destroy(s->bcf_parser);
   delete s;
   return EXON_HIP_OK;
 }
@@ -749,16 +754,19 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
   double t_next = 0, t_parse = 0, t_launch = 0;
   exon_hip_ctx* ctx = exon_hip_stream_ctx(st);
   hipStream_t hs = (hipStream_t)exon_hip_stream_hip_stream(st);
-  const bool is_vcf = scan->vcf != nullptr, is_bam = scan->bam != nullptr;
+  const bool is_vcf = scan->vcf != nullptr, is_bam = scan->bam != nullptr, is_bcf = scan->bcf != nullptr;
   std::unique_ptr<GpuTextSource> src;
   const bool bgzf = gpu_inflate_enabled() && scan->opt.compression != EXON_HIP_COMPRESSION_NONE &&
                     exon::BgzfParallelSource::is_bgzf(scan->path) && (!is_vcf || scan->vcf->data_offset() >= 0);
-  if (is_bam && !bgzf) return 1;
+  if ((is_bam || is_bcf) && !bgzf) return 1;
   try {
     if (bgzf) {
-      const uint64_t skip = is_vcf ? (uint64_t)scan->vcf->data_offset() : is_bam ? (uint64_t)scan->bam->data_offset() : 0;
+      const uint64_t skip = is_vcf   ? (uint64_t)scan->vcf->data_offset()
+                            : is_bam ? (uint64_t)scan->bam->data_offset()
+                            : is_bcf ? (uint64_t)scan->bcf->data_offset()
+                                     : 0;
       std::unique_ptr<exon::ByteSource> raw(new exon::ByteReader(scan->path, exon::Compression::None));
-      src.reset(new GpuTextSource(ctx, hs, std::move(raw), true, skip, std::string(), is_bam));
+      src.reset(new GpuTextSource(ctx, hs, std::move(raw), true, skip, std::string(), is_bam || is_bcf));
     } else {
       std::string carry;
       std::unique_ptr<exon::ByteSource> text = is_vcf ? scan->vcf->take_stream(&carry) : scan->fastq->take_stream(&carry);
@@ -769,6 +777,7 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
     return fail(ctx, EXON_HIP_EINVAL, "%s", e.what());
   }
   scan->gpu_inflated = bgzf;
+  scan->gpu_decoded = false;
   int rc = src->init();
   if (rc) return rc;
   if (is_vcf && !scan->parser) {
@@ -783,7 +792,13 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
     rc = exon_hip_bam_parser_create(ctx, (int32_t)scan->bam->ref_names.size(), (int64_t)src->max_text_bytes(), &scan->bam_parser);
     if (rc) return rc;
   }
-  if (!is_vcf && !is_bam && !scan->fq_parser) {
+  if (is_bcf && !scan->bcf_parser) {
+    rc = exon_hip_bcf_parser_create(ctx, (int32_t)scan->bcf->header.contigs.size(), (int32_t)scan->bcf->strings().size(),
+                                    (int32_t)scan->bcf->header.samples.size(), (int32_t)scan->bcf->info_key(), (int64_t)src->max_text_bytes(),
+                                    &scan->bcf_parser);
+    if (rc) return rc;
+  }
+  if (!is_vcf && !is_bam && !is_bcf && !scan->fq_parser) {
     rc = exon_hip_fastq_parser_create(ctx, (int64_t)src->max_text_bytes(), &scan->fq_parser);
     if (rc) return rc;
   }
@@ -799,9 +814,10 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
     t_next += t1 - t0;
     if (rc) break;
     size_t consumed = 0;
-    if (n > 0 && is_vcf) {
+    if (n > 0 && (is_vcf || is_bcf)) {
       exon_hip_vcf_columns cols;
-      rc = exon_hip_vcf_parser_parse(scan->parser, hs, d_text, (int64_t)n, &cols);
+      rc = is_vcf ? exon_hip_vcf_parser_parse(scan->parser, hs, d_text, (int64_t)n, &cols)
+                  : exon_hip_bcf_parser_parse(scan->bcf_parser, hs, d_text, (int64_t)n, &cols);
       t_parse += now_s() - t1;
       if (!rc && cols.n_undecided > 0) rc = 1;
       if (rc) break;
@@ -872,6 +888,25 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
             (t_init - t_begin) * 1e3, (t_loop - t_init) * 1e3, t_next * 1e3, t_parse * 1e3, (t_loop - t_init - t_next - t_parse) * 1e3, t_reader * 1e3,
             (now_s() - t_loop) * 1e3);
   (void)t_launch;
+  if (rc == EXON_HIP_OK && is_bcf) {
+    // FILTER lists (header-string indexes) -> names, in id order
+    int32_t nf = 0;
+    rc = exon_hip_bcf_parser_filters(scan->bcf_parser, nullptr, nullptr, 0, &nf);
+    std::vector<int32_t> lists((size_t)std::max(nf, 1) * 8), counts((size_t)std::max(nf, 1));
+    if (!rc) rc = exon_hip_bcf_parser_filters(scan->bcf_parser, lists.data(), counts.data(), nf, &nf);
+    if (!rc) {
+      scan->gpu_filter_dict.names.clear();
+      const std::vector<std::string>& strs = scan->bcf->strings();
+      for (int32_t i = 0; i < nf; ++i) {
+        std::string name;
+        for (int32_t k = 0; k < counts[(size_t)i]; ++k) {
+          if (k) name += ';';
+          name += strs[(size_t)lists[(size_t)i * 8 + (size_t)k]];
+        }
+        scan->gpu_filter_dict.names.push_back(name);
+      }
+    }
+  }
   if (rc == EXON_HIP_OK && is_vcf) {
     // FILTER dictionary -> scan (names in id order)
     int32_t nf = 0;
@@ -888,6 +923,7 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
   }
   if (rc == EXON_HIP_OK) {
     scan->rows += total;
+    scan->gpu_decoded = true;
     if (rows_out) *rows_out = total;
   }
   return rc;
@@ -895,10 +931,17 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
 
 extern "C" {
 
+int exon_hip_scan_decoded_on_gpu(exon_hip_scan* scan, int32_t* decoded, int32_t* inflated) {
+  if (!scan || !decoded) return fail(nullptr, EXON_HIP_EINVAL, "NULL argument");
+  *decoded = scan->gpu_decoded ? 1 : 0;
+  if (inflated) *inflated = (scan->gpu_decoded && scan->gpu_inflated) ? 1 : 0;
+  return EXON_HIP_OK;
+}
+
 int exon_hip_stream_consume_scan(exon_hip_stream* st, exon_hip_scan* scan, int64_t* rows) {
   if (!st || !scan) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_stream_consume_scan: NULL argument");
   int64_t n = 0;
-  if (scan->gpu_parse && (scan->vcf || scan->fastq || scan->bam)) {
+  if (scan->gpu_parse && (scan->vcf || scan->fastq || scan->bam || scan->bcf)) {
     // speculative GPU decode; when the device cannot decide something, restore the state and fall back to the host decoder
     exon_hip_ctx* ctx = exon_hip_stream_ctx(st);
     void* snap = nullptr;
@@ -918,6 +961,10 @@ int exon_hip_stream_consume_scan(exon_hip_stream* st, exon_hip_scan* scan, int64
       exon_hip_vcf_parser_destroy(scan->parser);
       scan->parser = nullptr;
     }
+    if (scan->bcf_parser) {
+      exon_hip_bcf_parser_destroy(scan->bcf_parser);
+      scan->bcf_parser = nullptr;
+    }
     scan->gpu_parse = false;
     try {
       const exon::Compression c = scan->opt.compression == EXON_HIP_COMPRESSION_GZIP   ? exon::Compression::Gzip
@@ -933,10 +980,14 @@ int exon_hip_stream_consume_scan(exon_hip_stream* st, exon_hip_scan* scan, int64
         cfg.defer_decode = false;
         cfg.threads = 0;
         scan->fastq.reset(new exon::FASTQBatchReader(scan->path, c, cfg));
-      } else {
+      } else if (scan->bam) {
         exon::BAMConfig cfg = scan->bam->config();
         cfg.threads = 0;
         scan->bam.reset(new exon::BAMBatchReader(scan->path, cfg));
+      } else {
+        exon::VCFConfig cfg = scan->bcf->config();
+        cfg.threads = 0;
+        scan->bcf.reset(new exon::BCFBatchReader(scan->path, cfg));
       }
     } catch (const std::exception& e) {
       return fail(nullptr, EXON_HIP_EINVAL, "%s", e.what());

@@ -328,6 +328,12 @@ class Scan:
             self._check(self.lib.exon_hip_scan_schema(self.h, C.byref(sch)))
             yield pa.Array._import_from_c(C.addressof(arr), C.addressof(sch))
 
+    def decoded_on_gpu(self):
+        """(decoded, inflated) of the last Stream.consume: were the records decoded / the BGZF blocks inflated on the GPU?"""
+        d, i = C.c_int32(), C.c_int32()
+        self._check(self.lib.exon_hip_scan_decoded_on_gpu(self.h, C.byref(d), C.byref(i)))
+        return bool(d.value), bool(i.value)
+
     def dictionary_size(self, column):
         n = C.c_int32()
         self._check(self.lib.exon_hip_scan_dictionary_size(self.h, column, C.byref(n)))

@@ -321,6 +321,10 @@ int exon_hip_scan_index_chunks(exon_hip_scan* scan, int32_t* n_chunks);
  * starts/ends (up to `cap`); *n_chunks receives the full count. */
 int exon_hip_index_query(const char* index_path, int32_t is_bai, const char* ref_name, int32_t ref_id, int64_t start,
                          int64_t end, uint64_t* starts, uint64_t* ends, int32_t cap, int32_t* n_chunks);
+/* After exon_hip_stream_consume_scan: *decoded = 1 when every record was decoded on the GPU (0: the host decoder ran,
+ * because gpu_parse was off or the device handed the file back); *inflated (optional) = 1 when the BGZF blocks were
+ * inflated on the GPU as well. */
+int exon_hip_scan_decoded_on_gpu(exon_hip_scan* scan, int32_t* decoded, int32_t* inflated);
 int exon_hip_scan_close(exon_hip_scan* scan);
 /* ---- VCF record parsing on the GPU (raw text in HBM -> device-layout columns in HBM) ---------------------------
  * Same field rules as LazyVCFArrayBuilder::append (exon-vcf/src/array_builder/lazy_array_builder.rs:159-216) for the
@@ -423,6 +427,21 @@ int exon_hip_bam_parser_create(exon_hip_ctx* ctx, int32_t n_references, int64_t 
 int exon_hip_bam_parser_parse(exon_hip_bam_parser* parser, void* stream, const uint8_t* d_data, int64_t n_bytes,
                               exon_hip_bam_columns* cols);
 int exon_hip_bam_parser_destroy(exon_hip_bam_parser* parser);
+
+/* ---- BCF2 record splitting + field extraction on the GPU (inflated BCF bytes in HBM -> the VCF device layout) ----
+ * Same Arrow schema as VCF (exon-core/src/datasources/bcf/, exon-bcf); records are found like BAM's (parallel chain
+ * walk, guessed starts proven by induction) and decoded one thread each: typed-value walk to FILTER (interned as a list
+ * of header-string indexes) and one typed INFO key (dictionary index; Float or Integer value -> f32, missing -> NULL).
+ * `cols` is the VCF column struct (pos_valid is NULL: POS is a fixed field). */
+typedef struct exon_hip_bcf_parser exon_hip_bcf_parser;
+int exon_hip_bcf_parser_create(exon_hip_ctx* ctx, int32_t n_contigs, int32_t n_header_strings, int32_t n_samples,
+                               int32_t info_key /* header-string index of the INFO field, -1 = none */, int64_t max_slab_bytes,
+                               exon_hip_bcf_parser** out);
+int exon_hip_bcf_parser_parse(exon_hip_bcf_parser* parser, void* stream, const uint8_t* d_data, int64_t n_bytes,
+                              exon_hip_vcf_columns* cols);
+/* FILTER lists discovered so far, in id order: lists[8 * i .. 8 * i + counts[i]) are header-string indexes ([] = '.') */
+int exon_hip_bcf_parser_filters(exon_hip_bcf_parser* parser, int32_t* lists, int32_t* counts, int32_t cap, int32_t* n_filters);
+int exon_hip_bcf_parser_destroy(exon_hip_bcf_parser* parser);
 
 /* GpuFilterAggExec::execute in one call: pull every batch of `scan` and push it through `stream`. */
 int exon_hip_stream_consume_scan(exon_hip_stream* s, exon_hip_scan* scan, int64_t* rows);

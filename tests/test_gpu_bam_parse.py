@@ -110,13 +110,14 @@ def test_bam_parser_gives_up_on_malformed_input(ctx):
     p.close()
 
 
-def _k3_through_scan(ctx, path, gpu_parse):
+def _k3_through_scan(ctx, path, gpu_parse, fallback=False):
     scan = exon_amd.Scan(str(path), "bam", gpu_parse=gpu_parse)
     refs = scan.dictionary(2)
     plan = ctx.plan_flag_mapq_group_count(1284, 0, 30, len(refs), columns=(0, 1, 2))
     st = plan.open()
     rows = st.consume(scan)
     counts, _ = st.finish()
+    assert scan.decoded_on_gpu()[0] == (bool(gpu_parse) and not fallback), 'silent host fallback'
     st.close(); plan.close(); scan.close()
     return rows, np.array(counts)
 

@@ -107,7 +107,7 @@ def test_fastq_views_partial_slab_and_malformed(ctx):
     p.close()
 
 
-def _hist_through_scan(ctx, path, gpu_parse, lmax, column=3, compression=None):
+def _hist_through_scan(ctx, path, gpu_parse, lmax, column=3, compression=None, fallback=False):
     scan = exon_amd.Scan(str(path), "fastq", gpu_parse=gpu_parse, compression=compression)
     plan = ctx.plan_qual_pos_hist(lmax, columns=(column,))
     st = plan.open()
@@ -115,6 +115,7 @@ def _hist_through_scan(ctx, path, gpu_parse, lmax, column=3, compression=None):
     counts, _ = st.finish()
     st.close()
     plan.close()
+    assert scan.decoded_on_gpu()[0] == (bool(gpu_parse) and not fallback), 'silent host fallback'
     scan.close()
     return rows, np.array(counts)
 
@@ -168,7 +169,7 @@ def test_fastq_gpu_pipeline_falls_back_to_host(ctx, tmp_path):
             f.write(b"@r%d\nACGTACGT\n+\nIIIIHHHH\n" % i)
             if i == 500:
                 f.write(b"\n")
-    rows_g, gpu = _hist_through_scan(ctx, path, True, 64)
+    rows_g, gpu = _hist_through_scan(ctx, path, True, 64, fallback=True)
     rows_h, host = _hist_through_scan(ctx, path, False, 64)
     assert rows_g == rows_h == 1000 and np.array_equal(gpu, host)
     assert gpu[0 * 256 + ord("I")] == 1000 and gpu[7 * 256 + ord("H")] == 1000

@@ -127,7 +127,7 @@ def test_gpu_parse_undecidable_rows_are_counted(ctx):
     p.close()
 
 
-def _k4_through_scan(ctx, path, gpu_parse, info_field="AF"):
+def _k4_through_scan(ctx, path, gpu_parse, info_field="AF", fallback=False):
     scan = exon_amd.Scan(path, "vcf", info_field=info_field, gpu_parse=gpu_parse)
     plan = ctx.plan_cmp_avg_by_group(">", 0.01, 64, columns=(4, 2, 3))
     st = plan.open()
@@ -137,6 +137,7 @@ def _k4_through_scan(ctx, path, gpu_parse, info_field="AF"):
     res = {names[g]: (int(counts[g]), int(counts[64 + g]), float(sums[g])) for g in range(len(names)) if counts[64 + g]}
     st.close()
     plan.close()
+    assert scan.decoded_on_gpu()[0] == (bool(gpu_parse) and not fallback), 'silent host fallback'
     scan.close()
     return rows, res
 
@@ -218,6 +219,6 @@ def test_gpu_parse_falls_back_to_host_on_undecidable_rows(ctx, tmp_path):
         for i in range(5000):
             chrom = "GL99" if i == 4000 else "1"
             f.write(f"{chrom}\t{i + 1}\t.\tA\tC\t{i % 90}.5\t{'PASS' if i % 3 else 'q10'}\tAF=0.{1 + i % 8}\n")
-    rows_g, gpu = _k4_through_scan(ctx, path, True)
+    rows_g, gpu = _k4_through_scan(ctx, path, True, fallback=True)
     rows_h, host = _k4_through_scan(ctx, path, False)
     assert rows_g == rows_h == 5000 and gpu == host

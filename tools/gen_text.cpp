@@ -12,12 +12,73 @@ static inline uint64_t mix64(uint64_t z) { z = (z ^ (z >> 30)) * 0xBF58476D1CE4E
 static inline uint64_t rnd(uint64_t seed, uint64_t col, uint64_t i) { return mix64(seed + col * 0xD1B54A32D192ED03ULL + (i + 1) * 0x9E3779B97F4A7C15ULL); }
 static inline uint32_t pct_thr(int p) { return (uint32_t)((((uint64_t)p) << 32) / 100); }
 int main(int argc, char** argv) {
-  if (argc < 4) { fprintf(stderr, "usage: gen_text vcf|fastq <rows> <out> [read_len] [ragged]\n"); return 2; }
+  if (argc < 4) { fprintf(stderr, "usage: gen_text vcf|bcf|fastq|bam <rows> <out> [read_len] [ragged]\n"); return 2; }
   const int64_t n = (int64_t)atof(argv[2]);
   FILE* f = fopen(argv[3], "wb");
   if (!f) return 1;
   static char buf[1 << 22];
   setvbuf(f, buf, _IOFBF, sizeof buf);
+  if (!strcmp(argv[1], "bcf")) {
+    // uncompressed BCF2 stream with the SAME rows as `gen_text vcf` (bgzip it to get a .bcf): `gen_text bcf <rows> <out>`
+    std::string text = "##fileformat=VCFv4.3\n##FILTER=<ID=PASS,Description=\"All filters passed\",IDX=0>\n##contig=<ID=1,IDX=0>\n"
+                       "##FILTER=<ID=q10,Description=\"q\",IDX=1>\n##FILTER=<ID=s50,Description=\"s\",IDX=2>\n"
+                       "##INFO=<ID=AF,Number=1,Type=Float,Description=\"AF\",IDX=3>\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n";
+    text.push_back('\0');
+    fwrite("BCF\2\2", 1, 5, f);
+    const uint32_t lt = (uint32_t)text.size();
+    fwrite(&lt, 4, 1, f);
+    fwrite(text.data(), 1, text.size(), f);
+    const uint32_t t0 = pct_thr(85), t1 = pct_thr(90), t2 = pct_thr(96), t3 = pct_thr(99);
+    for (int64_t i = 0; i < n; ++i) {
+      const uint64_t r0 = rnd(4, 0, i), r1 = rnd(4, 1, i), r2 = rnd(4, 2, i);
+      const uint32_t e = (uint32_t)((((r0 >> 23) & 0xFF) * 14) >> 8);
+      uint32_t bits = ((126u - e) << 23) | (uint32_t)(r0 & 0x7FFFFF);
+      float a; memcpy(&a, &bits, 4);
+      if (((r0 >> 31) & 0x3FF) == 0) a = 0.01f;
+      const bool av = (r0 >> 44) >= 10486, qv = (r1 >> 44) >= 31457;
+      const uint32_t kq = (uint32_t)(r1 & 0xFFFFFFFFu) % 10000u;
+      const uint32_t u = (uint32_t)(r2 >> 32);
+      const int fid = (u >= t0) + (u >= t1) + (u >= t2) + (u >= t3);
+      // the text twin prints AF with 9 significant digits and QUAL as k/10: parse them back the same way
+      char tmp[32];
+      snprintf(tmp, sizeof tmp, "%.9g", (double)a);
+      const float af = strtof(tmp, nullptr);
+      snprintf(tmp, sizeof tmp, "%u.%u", kq / 10, kq % 10);
+      const float q = strtof(tmp, nullptr);
+      uint8_t rec[96];
+      size_t o = 8;
+      auto p32 = [&](uint32_t v) { memcpy(rec + o, &v, 4); o += 4; };
+      p32(0);                      // CHROM
+      p32((uint32_t)i);            // POS (0-based) = i  ->  1-based i + 1 as in the text twin
+      p32(1);                      // rlen
+      uint32_t qb = 0x7F800001u;
+      if (qv) memcpy(&qb, &q, 4);
+      p32(qb);
+      p32((uint32_t)(av ? 1 : 0) | (2u << 16));  // n_info | n_allele << 16
+      p32(0);                      // n_fmt << 24 | n_sample
+      rec[o++] = 0x07;             // ID: missing
+      rec[o++] = 0x17; rec[o++] = 'A';
+      rec[o++] = 0x17; rec[o++] = 'C';
+      switch (fid) {               // PASS, ".", q10, q10;s50, s50
+        case 0: rec[o++] = 0x11; rec[o++] = 0; break;
+        case 1: rec[o++] = 0x00; break;
+        case 2: rec[o++] = 0x11; rec[o++] = 1; break;
+        case 3: rec[o++] = 0x21; rec[o++] = 1; rec[o++] = 2; break;
+        default: rec[o++] = 0x11; rec[o++] = 2; break;
+      }
+      if (av) {
+        rec[o++] = 0x11; rec[o++] = 3;  // key AF
+        rec[o++] = 0x15;                // one float
+        memcpy(rec + o, &af, 4); o += 4;
+      }
+      const uint32_t ls = (uint32_t)(o - 8), li = 0;
+      memcpy(rec, &ls, 4);
+      memcpy(rec + 4, &li, 4);
+      fwrite(rec, 1, o, f);
+    }
+    fclose(f);
+    return 0;
+  }
   if (!strcmp(argv[1], "bam")) {
     // uncompressed BAM stream (header + records; tools/bin/bgzip turns it into a .bam): `gen_text bam <reads> <out> [read_len=100]`
     const int L = argc > 4 ? atoi(argv[4]) : 100;

@@ -11,6 +11,8 @@ n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 50_000_000
 plain, gz = f"/tmp/e2e.{kind}", f"/tmp/e2e.{kind}.gz"
 if kind == "bam":
     plain, gz = "/tmp/e2e.ubam", "/tmp/e2e.bam"
+if kind == "bcf":
+    plain, gz = "/tmp/e2e.ubcf", "/tmp/e2e.bcf"
 subprocess.check_call([os.path.join(BIN, "gen_text"), kind, str(n), plain])
 subprocess.check_call([os.path.join(BIN, "bgzip"), plain, gz, "6"])
 open(gz, "rb").read(); open(plain, "rb").read()
@@ -19,8 +21,8 @@ ctx = exon_amd.Context(0)
 
 
 def run(path, gpu_parse):
-    if kind == "vcf":
-        scan = exon_amd.Scan(path, "vcf", info_field="AF", gpu_parse=gpu_parse)
+    if kind in ("vcf", "bcf"):
+        scan = exon_amd.Scan(path, kind, info_field="AF", gpu_parse=gpu_parse)
         plan = ctx.plan_cmp_avg_by_group(">", 0.01, 64, columns=(4, 2, 3))
     elif kind == "bam":
         scan = exon_amd.Scan(path, "bam", gpu_parse=gpu_parse)
@@ -48,7 +50,7 @@ def report(label, path, gpu_parse, reps=3):
 
 print(f"{kind}: {tsize / 1e9:.2f} GB text, {csize / 1e9:.2f} GB BGZF")
 a = report("bgzf: GPU inflate + GPU parse", gz, True)
-if kind == "bam":
+if kind in ("bam", "bcf"):
     c = report("bgzf: host inflate + host decode", gz, False, reps=2)
     print("all equal:", np.array_equal(a, c))
     sys.exit(0)
