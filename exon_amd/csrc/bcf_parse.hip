@@ -177,7 +177,9 @@ __global__ __launch_bounds__(256) void k_bcf_extract(const uint8_t* __restrict__
     h |= 1ull;
     int slot = (int)(h & (unsigned long long)(FSLOTS - 1)), probes = 0;
     for (;; slot = (slot + 1) & (FSLOTS - 1)) {
-      const unsigned long long prev = atomicCAS(&f.keys[slot], 0ull, h);
+      // plain read first: almost every record finds its list already there (device atomics on one address serialise)
+      unsigned long long prev = *reinterpret_cast<volatile unsigned long long*>(&f.keys[slot]);
+      if (prev == 0ull) prev = atomicCAS(&f.keys[slot], 0ull, h);
       if (prev == 0ull) {  // ours: publish the list (read by k_bcf_assign / the host only after this kernel)
         f.counts[slot] = fc;
         for (int i = 0; i < fc; ++i) f.lists[slot * FLIST + i] = list[i];
