@@ -167,3 +167,33 @@ def test_bam_region_overlap_on_the_gpu(ctx, tmp_path):
     g = _k6_through_scan(ctx, bam, True, "chr7", 50_000_000, 100_000_000)
     h = _k6_through_scan(ctx, bam, False, "chr7", 50_000_000, 100_000_000)
     assert g == h and g[0] == 300000 and g[1] > 1000
+
+
+def _raw_bam_records(lengths, rng, n_ref=25):
+    """Minimal well-formed BAM records with the given sequence lengths (1 CIGAR op, no aux)."""
+    out = []
+    for i, ln in enumerate(lengths):
+        name = b"r%d\0" % i
+        ref, pos = int(rng.integers(0, n_ref)), int(rng.integers(0, 1 << 28))
+        body = struct.pack("<iiBBHHHiiii", ref, pos, len(name), int(rng.integers(0, 61)), 4680, 1, 0, ln, -1, -1, 0)
+        body += name + struct.pack("<I", (ln << 4) | 0) + bytes((ln + 1) // 2) + bytes(ln)
+        out.append(struct.pack("<i", len(body)) + body)
+    return out
+
+
+def test_bam_parser_long_reads_and_records_larger_than_a_segment(ctx):
+    """Records of tens of kilobytes (long reads): segments with a single record start are still proven; a record longer
+    than a 64 KiB segment leaves a segment without a start -> the device gives up (host decodes) instead of guessing."""
+    rng = np.random.default_rng(12)
+    recs = _raw_bam_records([int(x) for x in rng.integers(20_000, 40_000, 200)], rng)
+    data = b"".join(recs)
+    p = exon_amd.BAMParser(ctx, 25, max_slab_bytes=len(data) + 200_000)
+    res = p.parse_host(data)
+    assert res["n_undecided"] == 0 and res["n_rows"] == 200 and res["consumed_bytes"] == len(data)
+    lens = [struct.unpack_from("<i", r, 20)[0] for r in recs]
+    pos = [struct.unpack_from("<i", r, 8)[0] for r in recs]
+    assert res["start"].tolist() == [x + 1 for x in pos] and (res["end"] - res["start"] + 1).tolist() == lens
+    big = b"".join(_raw_bam_records([1000, 90_000, 1000, 1000], rng))  # 135 KB record: spans two whole segments
+    res = p.parse_host(big)
+    assert res["n_undecided"] > 0
+    p.close()

@@ -134,3 +134,38 @@ def test_gpu_inflate_reports_corruption(ctx):
     wrong_size[at:at + 4] = struct.pack("<I", blocks[0].out_size - 1)
     with pytest.raises(exon_amd.ExonHipError, match="block 0"):
         ctx.bgzf_inflate(bytes(wrong_size))
+
+
+@pytest.mark.gpu
+def test_gpu_inflate_fuzz_many_blocks_one_launch(ctx):
+    """A few thousand blocks of random size, content class, level and strategy in ONE launch (one wavefront each): every
+    byte equal to zlib's, CRCs verified on the device."""
+    rng = np.random.default_rng(2026)
+    text = vcf_like(4000, seed=9)
+    blocks, want = [], []
+    for i in range(3000):
+        kind = i % 6
+        size = int(rng.integers(0, 65281)) if i % 11 else int(rng.integers(0, 40))
+        if kind == 0:
+            off = int(rng.integers(0, max(1, len(text) - size)))
+            data = text[off:off + size]
+        elif kind == 1:
+            data = rng.integers(0, 256, size, dtype=np.uint8).tobytes()
+        elif kind == 2:
+            data = rng.integers(0, 4, size, dtype=np.uint8).tobytes()          # 2-bit alphabet: very short codes
+        elif kind == 3:
+            data = (bytes(rng.integers(65, 70, 37, dtype=np.uint8)) * (size // 37 + 1))[:size]  # long far/near repeats
+        elif kind == 4:
+            data = bytes([int(rng.integers(0, 256))]) * size                    # one long run (distance 1)
+        else:
+            a = rng.integers(0, 256, size, dtype=np.uint8)
+            a[rng.random(size) < 0.9] = 65                                       # sparse noise in a run
+            data = a.tobytes()
+        level = int(rng.choice([0, 1, 4, 6, 9]))
+        strategy = int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]))
+        if level == 0 and len(data) > 65000:
+            data = data[:65000]
+        blocks.append(bgzf_block(data, level, strategy))
+        want.append(data)
+    got, _ = ctx.bgzf_inflate(b"".join(blocks))
+    assert got.tobytes() == b"".join(want)
