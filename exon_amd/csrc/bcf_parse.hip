@@ -315,7 +315,11 @@ int exon_hip_bcf_parser_parse(exon_hip_bcf_parser* p, void* stream, const uint8_
   HIP_TRY(ctx, hipMemsetAsync(p->out.info_valid, 0, words, s));
   hipLaunchKernelGGL(chain::k_chain_walk<BcfFormat>, dim3(n_seg), dim3(64), 0, s, d_data, n, BcfFormat{p->n_contigs, p->n_samples}, p->d_seg,
                      p->d_rec_off);
-  hipLaunchKernelGGL(chain::k_chain_check<0>, dim3(1), dim3(1024), 0, s, p->d_seg, n_seg, p->d_base, p->d_scalars);
+  if ((size_t)n_seg * 12 > 152 * 1024) return fail(ctx, EXON_HIP_EINVAL, "slab of %u segments is too large for the chain proof", n_seg);
+  static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(chain::k_chain_check<0>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+  (void)lds_ok;
+  hipLaunchKernelGGL(chain::k_chain_check<0>, dim3(1), dim3(1024), (size_t)n_seg * 12, s, p->d_seg, n_seg, p->d_base, p->d_scalars);
   hipLaunchKernelGGL(k_bcf_extract, dim3(n_seg), dim3(256), 0, s, d_data, p->d_seg, p->d_base, p->d_rec_off, p->out, p->filters,
                      p->n_contigs, p->n_strings, p->info_key, p->d_scalars);
   hipLaunchKernelGGL(k_bcf_assign, dim3(1), dim3(256), 0, s, p->filters);

@@ -5,9 +5,10 @@
 //   k_chain_walk<F>  segment 0 starts at byte 0 (the caller guarantees a record boundary); every other segment GUESSES its
 //                    first record start (smallest offset where three consecutive record headers look plausible), then walks
 //                    its chain, storing record offsets, until it leaves the segment -> (start, landing, count)
-//   k_chain_check    the guesses are PROVEN by induction: landing(s) must equal start(s+1) for every s.  Any mismatch, a
-//                    segment without a record start (records larger than a segment) or a malformed record -> undecided:
-//                    the caller decodes on the host instead.  Exclusive scan of the counts -> first row of each segment.
+//   k_chain_check    the guesses are PROVEN by induction: the chain that leaves segment s must land exactly on the guessed
+//                    start of the segment it lands in (segments it jumps over -- records longer than a segment -- are
+//                    ignored).  Any mismatch or a malformed record -> undecided: the caller decodes on the host instead.
+//                    Exclusive scan of the counts -> first row of each segment.
 // A format F provides: MIN_HEADER (bytes a plausibility check needs), MIN_RECORD (smallest record), record_bytes(d, r)
 // (total size of the record at r, 0 = malformed) and plausible(d, n, r).
 #pragma once
@@ -79,36 +80,59 @@ __global__ __launch_bounds__(64) void k_chain_walk(const uint8_t* __restrict__ d
   if (lane == 0) seg[s] = SegInfo{start, r, k, bad};
 }
 
-// scalars: [0] rows, [1] undecided, [2] consumed bytes.  Segments behind the one whose chain met the cut-off record hold
-// only that record's bytes: they are ignored (their counts are zeroed).
+// scalars: [0] rows, [1] undecided, [2] consumed bytes.
+// The proof is a walk over the segments in order (one thread, the per-segment results cached in LDS): the chain that
+// enters segment s at `expected` must find start(s) == expected; a record longer than a segment makes the chain skip
+// whole segments, which are then ignored (whatever their guess was); the segment whose chain met the cut-off record
+// ends the slab.  Dynamic LDS: 3 * n_seg words.
 template <int UNUSED = 0>  // a template only so that several translation units may include this header
 __global__ __launch_bounds__(1024) void k_chain_check(SegInfo* __restrict__ seg, uint32_t n_seg, uint32_t* __restrict__ base,
-                                                             unsigned* __restrict__ scalars) {
+                                                      unsigned* __restrict__ scalars) {
+  extern __shared__ uint32_t chain_lds[];
+  uint32_t* st = chain_lds;              // start(s); NONE marks a segment that turned out inactive
+  uint32_t* ld = chain_lds + n_seg;      // landing(s)
+  uint32_t* bd = chain_lds + 2 * n_seg;  // bad(s)
   __shared__ unsigned part[1024];
-  __shared__ unsigned any_bad, s_cut;
-  if (threadIdx.x == 0) {
-    any_bad = 0;
-    s_cut = n_seg - 1;
+  __shared__ unsigned s_last, s_err;
+  for (uint32_t s = threadIdx.x; s < n_seg; s += 1024) {
+    const SegInfo a = seg[s];
+    st[s] = a.start;
+    ld[s] = a.landing;
+    bd[s] = a.bad;
   }
   __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned err = 0;
+    uint32_t expected = 0, last = n_seg - 1;
+    for (uint32_t s = 0; s < n_seg; ++s) {
+      const uint32_t hi = (s + 1) * SEG;  // the last segment is shorter, but no chain position lies beyond the slab
+      if (expected >= hi) {               // covered by a record that started earlier
+        st[s] = NONE;
+        continue;
+      }
+      if (st[s] != expected || bd[s] == 1) {
+        err = 1;
+        break;
+      }
+      expected = ld[s];
+      if (bd[s] == 2) {  // the cut-off record: everything behind it is its bytes
+        last = s;
+        break;
+      }
+      last = s;
+    }
+    s_last = last;
+    s_err = err;
+  }
+  __syncthreads();
+  const uint32_t last = s_last;
   const uint32_t per = (n_seg + 1023) / 1024;
   const uint32_t s0 = threadIdx.x * per, s1 = min(n_seg, s0 + per);
-  for (uint32_t s = s0; s < s1; ++s)
-    if (seg[s].bad == 2) atomicMin(&s_cut, s);
-  __syncthreads();
-  const uint32_t last = s_cut;
-  unsigned sum = 0, bad = 0;
+  unsigned sum = 0;
   for (uint32_t s = s0; s < s1; ++s) {
-    if (s > last) {
-      seg[s].count = 0;
-      continue;
-    }
-    const SegInfo a = seg[s];
-    sum += a.count;
-    if (a.start == NONE || a.bad == 1) bad = 1;
-    if (s < last && a.landing != seg[s + 1].start) bad = 1;  // also catches chains that skip a whole segment
+    if (s > last || st[s] == NONE) seg[s].count = 0;
+    else sum += seg[s].count;
   }
-  if (bad) atomicOr(&any_bad, 1u);
   part[threadIdx.x] = sum;
   __syncthreads();
   for (int o = 1; o < 1024; o <<= 1) {
@@ -120,14 +144,14 @@ __global__ __launch_bounds__(1024) void k_chain_check(SegInfo* __restrict__ seg,
   unsigned run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
   for (uint32_t s = s0; s < s1; ++s) {
     base[s] = run;
-    run += s > last ? 0u : seg[s].count;
+    run += seg[s].count;
   }
   if (threadIdx.x == 1023) {
     scalars[0] = part[1023];
-    scalars[2] = seg[last].landing;
+    scalars[2] = ld[last];
   }
   __syncthreads();
-  if (threadIdx.x == 0 && any_bad) atomicAdd(&scalars[1], 1u);
+  if (threadIdx.x == 0 && s_err) atomicAdd(&scalars[1], 1u);
 }
 
 }  // namespace chain

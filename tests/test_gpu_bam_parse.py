@@ -183,7 +183,7 @@ def _raw_bam_records(lengths, rng, n_ref=25):
 
 def test_bam_parser_long_reads_and_records_larger_than_a_segment(ctx):
     """Records of tens of kilobytes (long reads): segments with a single record start are still proven; a record longer
-    than a 64 KiB segment leaves a segment without a start -> the device gives up (host decodes) instead of guessing."""
+    than a 64 KiB segment makes the chain jump over whole segments, which the proof then ignores."""
     rng = np.random.default_rng(12)
     recs = _raw_bam_records([int(x) for x in rng.integers(20_000, 40_000, 200)], rng)
     data = b"".join(recs)
@@ -193,7 +193,13 @@ def test_bam_parser_long_reads_and_records_larger_than_a_segment(ctx):
     lens = [struct.unpack_from("<i", r, 20)[0] for r in recs]
     pos = [struct.unpack_from("<i", r, 8)[0] for r in recs]
     assert res["start"].tolist() == [x + 1 for x in pos] and (res["end"] - res["start"] + 1).tolist() == lens
-    big = b"".join(_raw_bam_records([1000, 90_000, 1000, 1000], rng))  # 135 KB record: spans two whole segments
-    res = p.parse_host(big)
-    assert res["n_undecided"] > 0
+    lens = [1000, 90_000, 1000, 300_000, 5, 70_000, 1000]  # 135 KB / 450 KB records: whole segments inside one record
+    big = b"".join(_raw_bam_records(lens, rng))
+    p2 = exon_amd.BAMParser(ctx, 25, max_slab_bytes=len(big) + 200_000)
+    res = p2.parse_host(big)
+    assert res["n_undecided"] == 0 and res["n_rows"] == len(lens) and res["consumed_bytes"] == len(big)
+    assert (res["end"] - res["start"] + 1).tolist() == lens
+    res = p2.parse_host(big[:-100])  # the last (70 KB) record is cut off
+    assert res["n_undecided"] == 0 and res["n_rows"] == len(lens) - 1
     p.close()
+    p2.close()
