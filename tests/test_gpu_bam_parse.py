@@ -203,3 +203,33 @@ def test_bam_parser_long_reads_and_records_larger_than_a_segment(ctx):
     assert res["n_undecided"] == 0 and res["n_rows"] == len(lens) - 1
     p.close()
     p2.close()
+
+
+def test_empty_inputs_through_the_gpu_pipelines(ctx, tmp_path):
+    """Header-only BAM / VCF.gz and an empty FASTQ.gz: zero rows, no error, no fallback needed."""
+    ub = tmp_path / "e.ubam"
+    subprocess.check_call([GEN, "bam", "0", str(ub), "100"])
+    bam = tmp_path / "e.bam"
+    subprocess.check_call([BGZIP, str(ub), str(bam), "6"])
+    rows, counts = _k3_through_scan(ctx, bam, True)
+    assert rows == 0 and counts.sum() == 0
+    vcf = tmp_path / "e.vcf"
+    subprocess.check_call([GEN, "vcf", "0", str(vcf)])
+    gz = tmp_path / "e.vcf.gz"
+    subprocess.check_call([BGZIP, str(vcf), str(gz), "6"])
+    scan = exon_amd.Scan(str(gz), "vcf", info_field="AF", gpu_parse=True)
+    plan = ctx.plan_cmp_avg_by_group(">", 0.01, 8, columns=(4, 2, 3))
+    st = plan.open()
+    assert st.consume(scan) == 0
+    c, s_ = st.finish()
+    assert sum(c) == 0
+    st.close(); plan.close(); scan.close()
+    fq = tmp_path / "e.fastq"
+    fq.write_bytes(b"")
+    fqgz = tmp_path / "e.fastq.gz"
+    subprocess.check_call([BGZIP, str(fq), str(fqgz), "6"])
+    scan = exon_amd.Scan(str(fqgz), "fastq", gpu_parse=True)
+    plan = ctx.plan_qual_pos_hist(64, columns=(3,))
+    st = plan.open()
+    assert st.consume(scan) == 0
+    st.close(); plan.close(); scan.close()
