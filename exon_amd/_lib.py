@@ -176,6 +176,9 @@ SIGNATURES = {
     "exon_hip_bam_parser_create": (C.c_int, [_vp, _i32, _i64, C.POINTER(_vp)]),
     "exon_hip_bam_parser_parse": (C.c_int, [_vp, _vp, _vp, _i64, C.POINTER(BAMColumns)]),
     "exon_hip_bam_parser_destroy": (C.c_int, [_vp]),
+    "exon_hip_sam_parser_create": (C.c_int, [_vp, C.POINTER(C.c_char_p), _i32, _i64, C.POINTER(_vp)]),
+    "exon_hip_sam_parser_parse": (C.c_int, [_vp, _vp, _vp, _i64, C.POINTER(BAMColumns)]),
+    "exon_hip_sam_parser_destroy": (C.c_int, [_vp]),
     "exon_hip_bcf_parser_create": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i64, C.POINTER(_vp)]),
     "exon_hip_bcf_parser_parse": (C.c_int, [_vp, _vp, _vp, _i64, C.POINTER(VCFColumns)]),
     "exon_hip_bcf_parser_filters": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), _i32, C.POINTER(_i32)]),

@@ -271,7 +271,7 @@ void open_scan(const Source& src, const std::string& file, const char* info_fiel
   // INDEXED_* tables / *_indexed_scan: plan BGZF chunks from <file>.tbi / <file>.bai
   // (exon-core/src/datasources/indexed_file/indexed_bgzf_file.rs:129-155)
   o.use_index = (src.indexed && !region.empty()) ? 1 : 0;
-  o.gpu_parse = (for_gpu_query && (src.format == EXON_HIP_FORMAT_VCF || src.format == EXON_HIP_FORMAT_FASTQ || src.format == EXON_HIP_FORMAT_BAM || src.format == EXON_HIP_FORMAT_BCF) &&
+  o.gpu_parse = (for_gpu_query && (src.format == EXON_HIP_FORMAT_VCF || src.format == EXON_HIP_FORMAT_FASTQ || src.format == EXON_HIP_FORMAT_BAM || src.format == EXON_HIP_FORMAT_BCF || src.format == EXON_HIP_FORMAT_SAM) &&
                  region.empty() && gpu_parse_enabled()) ? 1 : 0;
   ck(nullptr, exon_hip_scan_open(file.c_str(), &o, &g->s));
 }

@@ -355,6 +355,44 @@ __global__ __launch_bounds__(TPB) void k_remap_filters(int32_t* __restrict__ fil
 
 }  // namespace
 
+// Upload an open-addressing name table (names[i] -> id i).  bufs[0..5) receive the device allocations.
+static hipError_t build_name_table(exon_hip_ctx* ctx, const char* const* names_in, int32_t n, void** bufs, NameTable* out) {
+  int cap = 16;
+  while (cap < 2 * n + 1) cap <<= 1;
+  std::vector<uint64_t> keys((size_t)cap, 0);
+  std::vector<int32_t> ids((size_t)cap, -1);
+  std::vector<uint32_t> toff((size_t)cap, 0), tlen((size_t)cap, 0);
+  std::string pool;
+  for (int i = 0; i < n; ++i) {
+    const std::string nm = names_in[i];
+    const uint64_t h = fnv1a(reinterpret_cast<const uint8_t*>(nm.data()), (int)nm.size());
+    int slot = (int)(h & (uint64_t)(cap - 1));
+    while (keys[(size_t)slot] != 0) slot = (slot + 1) & (cap - 1);
+    keys[(size_t)slot] = h;
+    ids[(size_t)slot] = i;
+    toff[(size_t)slot] = (uint32_t)pool.size();
+    tlen[(size_t)slot] = (uint32_t)nm.size();
+    pool += nm;
+  }
+  hipError_t e = hipSuccess;
+  auto dalloc = [&](void** ptr, size_t bytes) {
+    if (e == hipSuccess && !(*ptr = exon_pool_alloc(ctx, bytes))) e = hipErrorOutOfMemory;
+  };
+  dalloc(&bufs[0], (size_t)cap * 8);
+  dalloc(&bufs[1], (size_t)cap * 4);
+  dalloc(&bufs[2], (size_t)cap * 4);
+  dalloc(&bufs[3], (size_t)cap * 4);
+  dalloc(&bufs[4], pool.size() + 16);
+  if (e == hipSuccess) e = hipMemcpy(bufs[0], keys.data(), (size_t)cap * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(bufs[1], ids.data(), (size_t)cap * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(bufs[2], toff.data(), (size_t)cap * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(bufs[3], tlen.data(), (size_t)cap * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess && !pool.empty()) e = hipMemcpy(bufs[4], pool.data(), pool.size(), hipMemcpyHostToDevice);
+  *out = NameTable{(const uint64_t*)bufs[0], (const int32_t*)bufs[1], (const uint32_t*)bufs[2], (const uint32_t*)bufs[3],
+                   (const uint8_t*)bufs[4], cap - 1};
+  return e;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 struct exon_hip_vcf_parser {
   exon_hip_ctx* ctx = nullptr;
@@ -391,35 +429,7 @@ int exon_hip_vcf_parser_create(exon_hip_ctx* ctx, const char* const* contig_name
     if (e == hipSuccess && !(*ptr = exon_pool_alloc(ctx, bytes))) e = hipErrorOutOfMemory;
   };
   // contig table
-  int cap = 16;
-  while (cap < 2 * n_contigs + 1) cap <<= 1;
-  std::vector<uint64_t> keys((size_t)cap, 0);
-  std::vector<int32_t> ids((size_t)cap, -1);
-  std::vector<uint32_t> toff((size_t)cap, 0), tlen((size_t)cap, 0);
-  std::string pool;
-  for (int i = 0; i < n_contigs; ++i) {
-    const std::string nm = contig_names[i];
-    const uint64_t h = fnv1a(reinterpret_cast<const uint8_t*>(nm.data()), (int)nm.size());
-    int slot = (int)(h & (uint64_t)(cap - 1));
-    while (keys[(size_t)slot] != 0) slot = (slot + 1) & (cap - 1);
-    keys[(size_t)slot] = h;
-    ids[(size_t)slot] = i;
-    toff[(size_t)slot] = (uint32_t)pool.size();
-    tlen[(size_t)slot] = (uint32_t)nm.size();
-    pool += nm;
-  }
-  dalloc(&p->contig_bufs[0], (size_t)cap * 8);
-  dalloc(&p->contig_bufs[1], (size_t)cap * 4);
-  dalloc(&p->contig_bufs[2], (size_t)cap * 4);
-  dalloc(&p->contig_bufs[3], (size_t)cap * 4);
-  dalloc(&p->contig_bufs[4], pool.size() + 16);
-  if (e == hipSuccess) e = hipMemcpy(p->contig_bufs[0], keys.data(), (size_t)cap * 8, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(p->contig_bufs[1], ids.data(), (size_t)cap * 4, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(p->contig_bufs[2], toff.data(), (size_t)cap * 4, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(p->contig_bufs[3], tlen.data(), (size_t)cap * 4, hipMemcpyHostToDevice);
-  if (e == hipSuccess && !pool.empty()) e = hipMemcpy(p->contig_bufs[4], pool.data(), pool.size(), hipMemcpyHostToDevice);
-  p->contigs = NameTable{(const uint64_t*)p->contig_bufs[0], (const int32_t*)p->contig_bufs[1], (const uint32_t*)p->contig_bufs[2],
-                         (const uint32_t*)p->contig_bufs[3], (const uint8_t*)p->contig_bufs[4], cap - 1};
+  e = build_name_table(ctx, contig_names, n_contigs, p->contig_bufs, &p->contigs);
   // filter table
   dalloc((void**)&p->filters.keys, FILTER_SLOTS * 8);
   dalloc((void**)&p->filters.ids, FILTER_SLOTS * 4);
@@ -685,6 +695,219 @@ int exon_hip_fastq_parser_parse(exon_hip_fastq_parser* p, void* stream, const ui
   views->seq_end = v + per;
   views->qual_start = v + 2 * per;
   views->qual_end = v + 3 * per;
+  return EXON_HIP_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------
+// SAM text: the first six tab-separated fields of every alignment line -> the BAM device layout (flag, mapq, reference
+// id, start, end).  Field rules of host/formats.h's SAM reader (schema of exon-sam/src/schema_builder.rs:371-402, same
+// columns as BAM): RNAME through the header's @SQ order ('*' or unknown -> NULL), POS 0 -> NULL, MAPQ 255 -> NULL,
+// end = POS + (sum of M/D/N/=/X lengths) - 1.  Lines the device cannot decide (fewer than 6 fields, non-digits in a
+// numeric field, header or empty lines in the middle) are counted: the caller decodes on the host instead.
+namespace {
+
+struct SamOut {
+  int32_t* flag;
+  uint8_t* mapq;
+  uint8_t* mapq_valid;
+  int32_t* ref_id;
+  uint8_t* ref_valid;
+  int64_t* start;
+  int64_t* end;
+  uint8_t* pos_valid;
+};
+
+__device__ __forceinline__ bool parse_uint(const uint8_t* text, unsigned b, unsigned e, int64_t* out) {
+  if (e <= b || e - b > 18) return false;
+  int64_t v = 0;
+  for (unsigned i = b; i < e; ++i) {
+    const uint8_t c = text[i];
+    if (c < '0' || c > '9') return false;
+    v = v * 10 + (c - '0');
+  }
+  *out = v;
+  return true;
+}
+
+__global__ __launch_bounds__(TPB) void k_parse_sam_lines(const uint8_t* __restrict__ text, const unsigned* __restrict__ nl_pos,
+                                                         unsigned* __restrict__ scalars, NameTable refs, SamOut out, unsigned cap,
+                                                         unsigned skip) {
+  const int64_t n_rows = min(scalars[0], cap);
+  const int64_t row = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  bool mq_ok = false, ref_ok = false, pos_ok = false, bad = false;
+  if (row < n_rows) {
+    const unsigned begin = row ? nl_pos[row - 1] + 1 : skip;
+    unsigned end = nl_pos[row];
+    if (end > begin && text[end - 1] == '\r') --end;
+    unsigned fs[7];
+    int nf = 0;
+    fs[0] = begin;
+    for (unsigned i = begin; i < end && nf < 6; ++i)
+      if (text[i] == '\t') fs[++nf] = i + 1;
+    auto fbeg = [&](int f) { return fs[f]; };
+    auto fend = [&](int f) { return f < nf ? fs[f + 1] - 1 : end; };
+    int64_t flag = 0, pos1 = 0, mapq = 0;
+    if (begin == end || text[begin] == '@' || nf < 5) {
+      bad = true;
+    } else if (!parse_uint(text, fbeg(1), fend(1), &flag) || !parse_uint(text, fbeg(3), fend(3), &pos1) ||
+               !parse_uint(text, fbeg(4), fend(4), &mapq) || flag > 0xFFFF || mapq > 255 || pos1 > 0x7FFFFFFF) {
+      bad = true;
+    } else {
+      // RNAME
+      int id = -1;
+      const unsigned rb = fbeg(2), re = fend(2);
+      const int len = (int)(re - rb);
+      if (!(len == 1 && text[rb] == '*')) {
+        const uint64_t h = fnv1a(text + rb, len);
+        int slot = (int)(h & (uint64_t)refs.mask);
+        for (int probe = 0; probe <= refs.mask; ++probe) {
+          const uint64_t k = refs.keys[slot];
+          if (k == 0) break;
+          if (k == h && (int)refs.text_len[slot] == len) {
+            bool same = true;
+            for (int i = 0; i < len && same; ++i) same = refs.pool[refs.text_off[slot] + i] == text[rb + i];
+            if (same) {
+              id = refs.ids[slot];
+              break;
+            }
+          }
+          slot = (slot + 1) & refs.mask;
+        }
+      }
+      // CIGAR: reference length
+      int64_t ref_len = 0, num = 0;
+      const unsigned cb = fbeg(5), ce = fend(5);
+      if (!(ce - cb == 1 && text[cb] == '*'))
+        for (unsigned i = cb; i < ce; ++i) {
+          const uint8_t ch = text[i];
+          if (ch >= '0' && ch <= '9') num = num * 10 + (ch - '0');
+          else {
+            if (ch == 'M' || ch == 'D' || ch == 'N' || ch == '=' || ch == 'X') ref_len += num;
+            num = 0;
+          }
+        }
+      out.flag[row] = (int32_t)flag;
+      out.mapq[row] = (uint8_t)mapq;
+      out.ref_id[row] = id;
+      mq_ok = mapq != 255;
+      ref_ok = id >= 0;
+      pos_ok = pos1 >= 1;
+      out.start[row] = pos_ok ? pos1 : 0;
+      out.end[row] = pos_ok ? pos1 + ref_len - 1 : 0;
+    }
+  }
+  const int64_t row0 = ((int64_t)blockIdx.x * TPB + threadIdx.x) - lane;
+  store_valid(out.mapq_valid, row0, n_rows, mq_ok, lane);
+  store_valid(out.ref_valid, row0, n_rows, ref_ok, lane);
+  store_valid(out.pos_valid, row0, n_rows, pos_ok, lane);
+  const unsigned long long bm = __ballot(bad);
+  if (lane == 0 && bm) atomicAdd(&scalars[1], (unsigned)__popcll(bm));
+}
+
+}  // namespace
+
+struct exon_hip_sam_parser {
+  exon_hip_ctx* ctx = nullptr;
+  int64_t max_bytes = 0, max_rows = 0;
+  unsigned *d_block_counts = nullptr, *d_nl = nullptr, *d_scalars = nullptr;
+  NameTable refs{};
+  void* ref_bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  void* bufs[8] = {nullptr};
+  SamOut out{};
+  unsigned* h_scalars = nullptr;
+};
+
+extern "C" {
+
+int exon_hip_sam_parser_create(exon_hip_ctx* ctx, const char* const* ref_names, int32_t n_refs, int64_t max_bytes,
+                               exon_hip_sam_parser** outp) {
+  if (!ctx || !outp || (n_refs > 0 && !ref_names) || max_bytes < 16) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_sam_parser_create: bad argument");
+  if (max_bytes > 0xF0000000LL) return fail(ctx, EXON_HIP_EINVAL, "slab size must stay below 4 GiB (32-bit line offsets)");
+  *outp = nullptr;
+  exon_hip_sam_parser* p = new (std::nothrow) exon_hip_sam_parser();
+  if (!p) return fail(ctx, EXON_HIP_ENOMEM, "out of host memory");
+  p->ctx = ctx;
+  p->max_bytes = max_bytes;
+  p->max_rows = max_bytes / 12 + 1;  // 11 fields: >= 21 bytes + newline; be generous
+  hipSetDevice(ctx->device);
+  hipError_t e = build_name_table(ctx, ref_names, n_refs, p->ref_bufs, &p->refs);
+  auto dalloc = [&](void** ptr, size_t bytes) {
+    if (e == hipSuccess && !(*ptr = exon_pool_alloc(ctx, bytes))) e = hipErrorOutOfMemory;
+  };
+  const int64_t nblocks = (max_bytes + BYTES_PER_BLOCK - 1) / BYTES_PER_BLOCK;
+  const size_t r = (size_t)p->max_rows, rb = r / 8 + 64;
+  dalloc((void**)&p->d_block_counts, (size_t)nblocks * 4);
+  dalloc((void**)&p->d_nl, r * 4);
+  dalloc((void**)&p->d_scalars, 16);
+  dalloc(&p->bufs[0], r * 4);
+  dalloc(&p->bufs[1], r + 64);
+  dalloc(&p->bufs[2], rb);
+  dalloc(&p->bufs[3], r * 4);
+  dalloc(&p->bufs[4], rb);
+  dalloc(&p->bufs[5], r * 8);
+  dalloc(&p->bufs[6], r * 8);
+  dalloc(&p->bufs[7], rb);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&p->h_scalars, 16);
+  if (e != hipSuccess) {
+    const std::string msg = hipGetErrorString(e);
+    exon_hip_sam_parser_destroy(p);
+    return fail(ctx, EXON_HIP_ENOMEM, "sam parser allocation: %s", msg.c_str());
+  }
+  p->out = SamOut{(int32_t*)p->bufs[0], (uint8_t*)p->bufs[1], (uint8_t*)p->bufs[2], (int32_t*)p->bufs[3],
+                  (uint8_t*)p->bufs[4], (int64_t*)p->bufs[5], (int64_t*)p->bufs[6], (uint8_t*)p->bufs[7]};
+  *outp = p;
+  return EXON_HIP_OK;
+}
+
+int exon_hip_sam_parser_destroy(exon_hip_sam_parser* p) {
+  if (!p) return EXON_HIP_OK;
+  for (void* b : p->ref_bufs) exon_pool_free(p->ctx, b);
+  for (void* b : p->bufs) exon_pool_free(p->ctx, b);
+  exon_pool_free(p->ctx, p->d_block_counts);
+  exon_pool_free(p->ctx, p->d_nl);
+  exon_pool_free(p->ctx, p->d_scalars);
+  if (p->h_scalars) hipHostFree(p->h_scalars);
+  delete p;
+  return EXON_HIP_OK;
+}
+
+int exon_hip_sam_parser_parse(exon_hip_sam_parser* p, void* stream, const uint8_t* d_text, int64_t n_bytes, exon_hip_bam_columns* cols) {
+  if (!p || !cols || (n_bytes > 0 && !d_text)) return fail(p ? p->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_sam_parser_parse: NULL argument");
+  exon_hip_ctx* ctx = p->ctx;
+  memset(cols, 0, sizeof *cols);
+  if (n_bytes == 0) return EXON_HIP_OK;
+  const unsigned skip = (unsigned)(reinterpret_cast<uintptr_t>(d_text) & 15);
+  d_text -= skip;
+  n_bytes += skip;
+  if (n_bytes > p->max_bytes) return fail(ctx, EXON_HIP_EINVAL, "slab of %lld bytes exceeds the parser's %lld", (long long)n_bytes, (long long)p->max_bytes);
+  hipStream_t s = pick_stream(ctx, stream);
+  const int nblocks = (int)((n_bytes + BYTES_PER_BLOCK - 1) / BYTES_PER_BLOCK);
+  HIP_TRY(ctx, hipMemsetAsync(p->d_scalars, 0, 16, s));
+  hipLaunchKernelGGL(k_count_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, skip, p->d_block_counts);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, p->d_block_counts, nblocks, p->d_scalars);
+  hipLaunchKernelGGL(k_fill_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, skip, p->d_block_counts, p->d_nl, (unsigned)p->max_rows);
+  hipLaunchKernelGGL(k_last_newline, dim3(1), dim3(1), 0, s, p->d_nl, p->d_scalars, (unsigned)p->max_rows);
+  const int64_t row_bound = std::min<int64_t>(p->max_rows, n_bytes / 12 + 1);
+  const int pblocks = (int)((row_bound + TPB - 1) / TPB);
+  hipLaunchKernelGGL(k_parse_sam_lines, dim3(pblocks), dim3(TPB), 0, s, d_text, p->d_nl, p->d_scalars, p->refs, p->out, (unsigned)row_bound, skip);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(p->h_scalars, p->d_scalars, 12, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  const int64_t n_lines = p->h_scalars[0];
+  cols->n_rows = n_lines;
+  cols->n_undecided = p->h_scalars[1] + (n_lines > row_bound ? 1 : 0);
+  cols->consumed_bytes = p->h_scalars[2] > skip ? (int64_t)p->h_scalars[2] - skip : 0;
+  cols->flag = p->out.flag;
+  cols->mapq = p->out.mapq;
+  cols->mapq_valid = p->out.mapq_valid;
+  cols->ref_id = p->out.ref_id;
+  cols->ref_valid = p->out.ref_valid;
+  cols->start = p->out.start;
+  cols->end = p->out.end;
+  cols->pos_valid = p->out.pos_valid;
   return EXON_HIP_OK;
 }
 

@@ -695,6 +695,15 @@ class SAMBatchReader {
     }
   }
 
+  const BAMConfig& config() const { return cfg_; }
+  // the alignment lines as a raw byte stream (GPU-side parsing); only valid before the first read_batch
+  std::unique_ptr<ByteSource> take_stream(std::string* carry) {
+    *carry = has_pending_ ? pending_ + "\n" : std::string();
+    has_pending_ = false;
+    *carry += r_.take_buffered();
+    return r_.release_source();
+  }
+
   bool read_batch(struct ArrowArray* out) {
     BAMArrayBuilder b(&ref_names);
     std::string line;

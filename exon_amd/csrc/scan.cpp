@@ -30,6 +30,7 @@ struct exon_hip_scan {
   exon_hip_fastq_parser* fq_parser = nullptr;
   exon_hip_bam_parser* bam_parser = nullptr;
   exon_hip_bcf_parser* bcf_parser = nullptr;
+  exon_hip_sam_parser* sam_parser = nullptr;
   bool gpu_inflated = false;  // the last GPU-parsed consume also inflated BGZF blocks on the device
   bool gpu_decoded = false;   // the last consume decoded every record on the device (no host fallback)
   exon::Dictionary gpu_filter_dict;       // names fetched from the parser after the consume
@@ -131,6 +132,7 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         cfg.batch_size = bs;
         cfg.filter = rf;
         cfg.filter.use_index = false;
+        s->gpu_parse = o->gpu_parse != 0 && !rf.active;
         s->sam.reset(new exon::SAMBatchReader(path, c, cfg));
         s->bam_dict_view.names = s->sam->ref_names;
         break;
@@ -263,6 +265,7 @@ int exon_hip_scan_close(exon_hip_scan* s) {
   if (s && s->fq_parser) exon_hip_fastq_parser_destroy(s->fq_parser);
   if (s && s->bam_parser) exon_hip_bam_parser_destroy(s->bam_parser);
   if (s && s->bcf_parser) exon_hip_bcf_parser_destroy(s->bcf_parser);
+  if (s && s->sam_parser) exon_hip_sam_parser_destroy(s->sam_parser);
   delete s;
   return EXON_HIP_OK;
 }
@@ -754,9 +757,10 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
   double t_next = 0, t_parse = 0, t_launch = 0;
   exon_hip_ctx* ctx = exon_hip_stream_ctx(st);
   hipStream_t hs = (hipStream_t)exon_hip_stream_hip_stream(st);
-  const bool is_vcf = scan->vcf != nullptr, is_bam = scan->bam != nullptr, is_bcf = scan->bcf != nullptr;
+  const bool is_vcf = scan->vcf != nullptr, is_bam = scan->bam != nullptr, is_bcf = scan->bcf != nullptr, is_sam = scan->sam != nullptr;
   std::unique_ptr<GpuTextSource> src;
-  const bool bgzf = gpu_inflate_enabled() && scan->opt.compression != EXON_HIP_COMPRESSION_NONE &&
+  // SAM text is taken from its reader's (host-inflated, when compressed) stream: the header length is not tracked there
+  const bool bgzf = !is_sam && gpu_inflate_enabled() && scan->opt.compression != EXON_HIP_COMPRESSION_NONE &&
                     exon::BgzfParallelSource::is_bgzf(scan->path) && (!is_vcf || scan->vcf->data_offset() >= 0);
   if ((is_bam || is_bcf) && !bgzf) return 1;
   try {
@@ -769,7 +773,9 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
       src.reset(new GpuTextSource(ctx, hs, std::move(raw), true, skip, std::string(), is_bam || is_bcf));
     } else {
       std::string carry;
-      std::unique_ptr<exon::ByteSource> text = is_vcf ? scan->vcf->take_stream(&carry) : scan->fastq->take_stream(&carry);
+      std::unique_ptr<exon::ByteSource> text = is_vcf   ? scan->vcf->take_stream(&carry)
+                                               : is_sam ? scan->sam->take_stream(&carry)
+                                                        : scan->fastq->take_stream(&carry);
       if (!text) return fail(ctx, EXON_HIP_ESTATE, "scan already consumed");
       src.reset(new GpuTextSource(ctx, hs, std::move(text), false, 0, std::move(carry)));
     }
@@ -798,7 +804,13 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
                                     &scan->bcf_parser);
     if (rc) return rc;
   }
-  if (!is_vcf && !is_bam && !is_bcf && !scan->fq_parser) {
+  if (is_sam && !scan->sam_parser) {
+    std::vector<const char*> names;
+    for (const auto& c : scan->sam->ref_names) names.push_back(c.c_str());
+    rc = exon_hip_sam_parser_create(ctx, names.data(), (int32_t)names.size(), (int64_t)src->max_text_bytes(), &scan->sam_parser);
+    if (rc) return rc;
+  }
+  if (!is_vcf && !is_bam && !is_bcf && !is_sam && !scan->fq_parser) {
     rc = exon_hip_fastq_parser_create(ctx, (int64_t)src->max_text_bytes(), &scan->fq_parser);
     if (rc) return rc;
   }
@@ -838,9 +850,10 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
         // the parser's column buffers are reused by the next slab; the kernel is stream-ordered before that parse
         total += cols.n_rows;
       }
-    } else if (n > 0 && is_bam) {
+    } else if (n > 0 && (is_bam || is_sam)) {
       exon_hip_bam_columns cols;
-      rc = exon_hip_bam_parser_parse(scan->bam_parser, hs, d_text, (int64_t)n, &cols);
+      rc = is_bam ? exon_hip_bam_parser_parse(scan->bam_parser, hs, d_text, (int64_t)n, &cols)
+                  : exon_hip_sam_parser_parse(scan->sam_parser, hs, d_text, (int64_t)n, &cols);
       t_parse += now_s() - t1;
       if (trace) fprintf(stderr, "[exon-hip pipe] bam slab %zu bytes: rc %d rows %lld undecided %lld consumed %lld\n", n, rc, (long long)cols.n_rows, (long long)cols.n_undecided, (long long)cols.consumed_bytes);
       if (!rc && cols.n_undecided > 0) rc = 1;
@@ -941,7 +954,7 @@ int exon_hip_scan_decoded_on_gpu(exon_hip_scan* scan, int32_t* decoded, int32_t*
 int exon_hip_stream_consume_scan(exon_hip_stream* st, exon_hip_scan* scan, int64_t* rows) {
   if (!st || !scan) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_stream_consume_scan: NULL argument");
   int64_t n = 0;
-  if (scan->gpu_parse && (scan->vcf || scan->fastq || scan->bam || scan->bcf)) {
+  if (scan->gpu_parse && (scan->vcf || scan->fastq || scan->bam || scan->bcf || scan->sam)) {
     // speculative GPU decode; when the device cannot decide something, restore the state and fall back to the host decoder
     exon_hip_ctx* ctx = exon_hip_stream_ctx(st);
     void* snap = nullptr;
@@ -984,10 +997,12 @@ int exon_hip_stream_consume_scan(exon_hip_stream* st, exon_hip_scan* scan, int64
         exon::BAMConfig cfg = scan->bam->config();
         cfg.threads = 0;
         scan->bam.reset(new exon::BAMBatchReader(scan->path, cfg));
-      } else {
+      } else if (scan->bcf) {
         exon::VCFConfig cfg = scan->bcf->config();
         cfg.threads = 0;
         scan->bcf.reset(new exon::BCFBatchReader(scan->path, cfg));
+      } else {
+        scan->sam.reset(new exon::SAMBatchReader(scan->path, c, scan->sam->config()));
       }
     } catch (const std::exception& e) {
       return fail(nullptr, EXON_HIP_EINVAL, "%s", e.what());

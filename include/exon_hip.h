@@ -428,6 +428,17 @@ int exon_hip_bam_parser_parse(exon_hip_bam_parser* parser, void* stream, const u
                               exon_hip_bam_columns* cols);
 int exon_hip_bam_parser_destroy(exon_hip_bam_parser* parser);
 
+/* ---- SAM text parsing on the GPU (alignment lines in HBM -> the BAM device layout; `cols` is the BAM column struct) ----
+ * Columns of exon-sam (schema_builder.rs:371-402, same as BAM): RNAME through the @SQ order ('*' / unknown -> NULL),
+ * POS 0 -> NULL, MAPQ 255 -> NULL, end from the CIGAR.  d_text: '\n'-terminated alignment lines (no header), any
+ * alignment; a trailing partial line is left to the caller (consumed_bytes). */
+typedef struct exon_hip_sam_parser exon_hip_sam_parser;
+int exon_hip_sam_parser_create(exon_hip_ctx* ctx, const char* const* reference_names, int32_t n_references,
+                               int64_t max_slab_bytes, exon_hip_sam_parser** out);
+int exon_hip_sam_parser_parse(exon_hip_sam_parser* parser, void* stream, const uint8_t* d_text, int64_t n_bytes,
+                              exon_hip_bam_columns* cols);
+int exon_hip_sam_parser_destroy(exon_hip_sam_parser* parser);
+
 /* ---- BCF2 record splitting + field extraction on the GPU (inflated BCF bytes in HBM -> the VCF device layout) ----
  * Same Arrow schema as VCF (exon-core/src/datasources/bcf/, exon-bcf); records are found like BAM's (parallel chain
  * walk, guessed starts proven by induction) and decoded one thread each: typed-value walk to FILTER (interned as a list

@@ -1,0 +1,66 @@
+"""GPU-side SAM text parsing (exon_hip_sam_parser_*): alignment lines -> the BAM device layout -> K3 / K6, against the
+native host SAM reader (same columns as BAM, exon-sam/src/schema_builder.rs:371-402)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import exon_amd
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FX = os.path.join(ROOT, "tests", "golden", "ref_fixtures")
+GEN = os.path.join(ROOT, "tools", "bin", "gen_text")
+
+
+def _k3(ctx, path, gpu_parse, fallback=False):
+    scan = exon_amd.Scan(str(path), "sam", gpu_parse=gpu_parse)
+    refs = scan.dictionary(2)
+    plan = ctx.plan_flag_mapq_group_count(1284, 0, 30, len(refs), columns=(0, 1, 2))
+    st = plan.open()
+    rows = st.consume(scan)
+    counts, _ = st.finish()
+    assert scan.decoded_on_gpu()[0] == (bool(gpu_parse) and not fallback), "silent host fallback"
+    st.close(); plan.close(); scan.close()
+    return rows, np.array(counts)
+
+
+def _k6(ctx, path, gpu_parse, ref, a, b):
+    scan = exon_amd.Scan(str(path), "sam", gpu_parse=gpu_parse)
+    plan = ctx.plan_overlap_count(scan.dictionary(2).index(ref), a, b)
+    st = plan.open()
+    rows = st.consume(scan)
+    counts, _ = st.finish()
+    st.close(); plan.close(); scan.close()
+    return rows, int(counts[0])
+
+
+def test_sam_reference_fixture(ctx):
+    path = os.path.join(FX, "sam", "test.sam")
+    g, h = _k3(ctx, path, True), _k3(ctx, path, False)
+    assert g[0] == h[0] > 0 and np.array_equal(g[1], h[1])
+    refs = exon_amd.Scan(path, "sam").dictionary(2)
+    assert _k6(ctx, path, True, refs[0], 1, None) == _k6(ctx, path, False, refs[0], 1, None)
+
+
+@pytest.mark.parametrize("slab_mb", ["1", "64"])
+def test_sam_file_to_gpu_pipeline_equals_host_decode(ctx, tmp_path, monkeypatch, slab_mb):
+    n = 300_000
+    path = tmp_path / "syn.sam"
+    subprocess.check_call([GEN, "sam", str(n), str(path), "100"])
+    monkeypatch.setenv("EXON_HIP_GPU_PARSE_SLAB_MB", slab_mb)
+    g, h = _k3(ctx, path, True), _k3(ctx, path, False)
+    assert g[0] == h[0] == n and np.array_equal(g[1], h[1]) and g[1].sum() > n // 4
+    assert _k6(ctx, path, True, "chr7", 50_000_000, 100_000_000) == _k6(ctx, path, False, "chr7", 50_000_000, 100_000_000)
+
+
+def test_sam_lines_the_device_cannot_decide_fall_back(ctx, tmp_path):
+    path = tmp_path / "odd.sam"
+    with open(path, "w") as f:
+        f.write("@HD\tVN:1.6\n@SQ\tSN:chr1\tLN:1000\n")
+        for i in range(2000):
+            flag = "99x" if i == 1500 else "99"  # atoi("99x") = 99 on the host; the device hands the file back
+            f.write(f"r{i}\t{flag}\tchr1\t{i + 1}\t60\t50M\t*\t0\t0\t*\t*\n")
+    g, h = _k3(ctx, path, True, fallback=True), _k3(ctx, path, False)
+    assert g[0] == h[0] == 2000 and np.array_equal(g[1], h[1])

@@ -12,12 +12,46 @@ static inline uint64_t mix64(uint64_t z) { z = (z ^ (z >> 30)) * 0xBF58476D1CE4E
 static inline uint64_t rnd(uint64_t seed, uint64_t col, uint64_t i) { return mix64(seed + col * 0xD1B54A32D192ED03ULL + (i + 1) * 0x9E3779B97F4A7C15ULL); }
 static inline uint32_t pct_thr(int p) { return (uint32_t)((((uint64_t)p) << 32) / 100); }
 int main(int argc, char** argv) {
-  if (argc < 4) { fprintf(stderr, "usage: gen_text vcf|bcf|fastq|bam <rows> <out> [read_len] [ragged]\n"); return 2; }
+  if (argc < 4) { fprintf(stderr, "usage: gen_text vcf|bcf|fastq|bam|sam <rows> <out> [read_len] [ragged]\n"); return 2; }
   const int64_t n = (int64_t)atof(argv[2]);
   FILE* f = fopen(argv[3], "wb");
   if (!f) return 1;
   static char buf[1 << 22];
   setvbuf(f, buf, _IOFBF, sizeof buf);
+  if (!strcmp(argv[1], "sam")) {
+    // text SAM with the same flag / reference / mapq mix as `gen_text bam`: `gen_text sam <reads> <out> [read_len=100]`
+    const int L = argc > 4 ? atoi(argv[4]) : 100;
+    const int NREF = 25;
+    fputs("@HD\tVN:1.6\tSO:unsorted\n", f);
+    for (int r = 0; r < NREF; ++r) fprintf(f, "@SQ\tSN:chr%d\tLN:250000000\n", r + 1);
+    static const uint16_t FLAGS[12] = {99, 147, 83, 163, 0, 16, 4, 77, 141, 1024 + 99, 256 + 16, 2048 + 0};
+    std::string seq((size_t)L, 'A'), qual((size_t)L, 'I');
+    for (int64_t i = 0; i < n; ++i) {
+      const uint64_t a = rnd(3, 0, (uint64_t)i), b = rnd(3, 1, (uint64_t)i), c = rnd(3, 2, (uint64_t)i);
+      const uint16_t flag = FLAGS[a % 12];
+      const bool unmapped = (flag & 4) != 0;
+      const uint32_t mq = (uint32_t)(b % 100);
+      const int mapq = mq < 2 ? 255 : mq < 10 ? 0 : mq < 22 ? (int)(1 + b % 29) : mq < 42 ? (int)(30 + b % 30) : 60;
+      const int len = L - (int)((b >> 32) % (uint64_t)(L / 3 + 1));
+      char cigar[64] = "*";
+      if (!unmapped) {
+        const int kind = (int)((c >> 12) % 4);
+        if (kind == 0) snprintf(cigar, sizeof cigar, "%dM", len);
+        else if (kind == 1) snprintf(cigar, sizeof cigar, "5S%dM", len - 5);
+        else if (kind == 2) snprintf(cigar, sizeof cigar, "%dM%dN%dM", len / 2, (int)(100 + (c >> 20) % 5000), len - len / 2);
+        else snprintf(cigar, sizeof cigar, "%dM2D3M", len - 3);
+      }
+      if (unmapped) fprintf(f, "read%lld\t%u\t*\t0\t%d\t*\t*\t0\t0\t", (long long)i, (unsigned)flag, mapq);
+      else fprintf(f, "read%lld\t%u\tchr%d\t%d\t%d\t%s\t*\t0\t0\t", (long long)i, (unsigned)flag, (int)((a >> 8) % NREF) + 1,
+                   (int)((a >> 16) % 249000000) + 1, mapq, cigar);
+      fwrite(seq.data(), 1, (size_t)len, f);
+      fputc('\t', f);
+      fwrite(qual.data(), 1, (size_t)len, f);
+      fputs(i % 3 ? "\tNM:i:1\n" : "\n", f);
+    }
+    fclose(f);
+    return 0;
+  }
   if (!strcmp(argv[1], "bcf")) {
     // uncompressed BCF2 stream with the SAME rows as `gen_text vcf` (bgzip it to get a .bcf): `gen_text bcf <rows> <out>`
     std::string text = "##fileformat=VCFv4.3\n##FILTER=<ID=PASS,Description=\"All filters passed\",IDX=0>\n##contig=<ID=1,IDX=0>\n"
