@@ -14,8 +14,8 @@ FX = os.path.join(ROOT, "tests", "golden", "ref_fixtures")
 GEN = os.path.join(ROOT, "tools", "bin", "gen_text")
 
 
-def _k3(ctx, path, gpu_parse, fallback=False):
-    scan = exon_amd.Scan(str(path), "sam", gpu_parse=gpu_parse)
+def _k3(ctx, path, gpu_parse, fallback=False, compression=None):
+    scan = exon_amd.Scan(str(path), "sam", gpu_parse=gpu_parse, compression=compression)
     refs = scan.dictionary(2)
     plan = ctx.plan_flag_mapq_group_count(1284, 0, 30, len(refs), columns=(0, 1, 2))
     st = plan.open()
@@ -53,6 +53,16 @@ def test_sam_file_to_gpu_pipeline_equals_host_decode(ctx, tmp_path, monkeypatch,
     g, h = _k3(ctx, path, True), _k3(ctx, path, False)
     assert g[0] == h[0] == n and np.array_equal(g[1], h[1]) and g[1].sum() > n // 4
     assert _k6(ctx, path, True, "chr7", 50_000_000, 100_000_000) == _k6(ctx, path, False, "chr7", 50_000_000, 100_000_000)
+
+
+def test_sam_gz_host_inflated_stream_parsed_on_the_gpu(ctx, tmp_path):
+    n = 100_000
+    path = tmp_path / "syn.sam"
+    subprocess.check_call([GEN, "sam", str(n), str(path), "100"])
+    gz = tmp_path / "syn.sam.gz"
+    subprocess.check_call([os.path.join(ROOT, "tools", "bin", "bgzip"), str(path), str(gz), "6"])
+    g, h = _k3(ctx, gz, True, compression="gzip"), _k3(ctx, path, False)
+    assert g[0] == h[0] == n and np.array_equal(g[1], h[1])
 
 
 def test_sam_lines_the_device_cannot_decide_fall_back(ctx, tmp_path):
