@@ -25,8 +25,8 @@ import torch  # noqa: E402  (imported before the HIP library so both share one H
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-BYTES_PER_ROW = {"c4": 12.25, "c2": 12.0, "c3": 9.25, "c5": 104.0}  # algorithmic bytes/row, SURVEY.md section 8(d)
-SEED = {"c2": 2, "c3": 3, "c4": 4, "c5": 5}
+BYTES_PER_ROW = {"c4": 12.25, "c2": 12.0, "c3": 9.25, "c5": 104.0, "c6": 20.375}  # algorithmic bytes/row, SURVEY.md section 8(d)
+SEED = {"c2": 2, "c3": 3, "c4": 4, "c5": 5, "c6": 6}
 
 
 def parse_args():
@@ -35,7 +35,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=float, default=1e9, help="rows per GPU (weak scaling)")
-    ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3", "c5"])
+    ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3", "c5", "c6"])
     ap.add_argument("--cpu-sample-rows", type=float, default=128e6)
     ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -67,6 +67,16 @@ class Workload:
             self.pos = torch.empty(rows, dtype=torch.int64, device=dev)
             ctx._check(lib.exon_hip_gen_c2(h, s, SEED["c2"], n_total, row0, row0 + rows, self.chrom.data_ptr(),
                                            self.pos.data_ptr()))
+            self.counts = torch.zeros(1, dtype=torch.int64, device=dev)
+            self.sums = None
+        elif kind == "c6":
+            self.ref = torch.empty(rows, dtype=torch.int32, device=dev)
+            self.start = torch.empty(rows, dtype=torch.int64, device=dev)
+            self.end = torch.empty(rows, dtype=torch.int64, device=dev)
+            self.rv = torch.zeros(nb, dtype=torch.uint8, device=dev)
+            self.pv = torch.zeros(nb, dtype=torch.uint8, device=dev)
+            ctx._check(lib.exon_hip_gen_c6(h, s, SEED["c6"], row0, row0 + rows, self.ref.data_ptr(), self.rv.data_ptr(),
+                                           self.start.data_ptr(), self.end.data_ptr(), self.pv.data_ptr()))
             self.counts = torch.zeros(1, dtype=torch.int64, device=dev)
             self.sums = None
         elif kind == "c3":
@@ -118,6 +128,12 @@ class Workload:
             c0, c1 = _col(self.chrom.data_ptr(), None, None, n), _col(self.pos.data_ptr(), None, None, n)
             ctx._check(ctx.lib.exon_hip_region_count(ctx.h, s, C.byref(c0), C.byref(c1), n, 6, 50000000, 100000000,
                                                      self.counts.data_ptr()))
+        elif self.kind == "c6":
+            c0 = _col(self.ref.data_ptr(), self.rv.data_ptr(), None, n)
+            c1 = _col(self.start.data_ptr(), self.pv.data_ptr(), None, n)
+            c2 = _col(self.end.data_ptr(), self.pv.data_ptr(), None, n)
+            ctx._check(ctx.lib.exon_hip_overlap_count(ctx.h, s, C.byref(c0), C.byref(c1), C.byref(c2), n, 6, 50000000, 100000000,
+                                                      self.counts.data_ptr()))
         elif self.kind == "c5":
             for b0 in range(0, n, self.batch):
                 nb_ = min(self.batch, n - b0)
@@ -149,6 +165,20 @@ def cpu_baseline(kind, sample_rows, n_total, reps):
         for _ in range(reps):
             r, t = orc.c2_region_count(c, p, orc.c2_contigs(), "7:50000000-100000000")
             secs.append(t.seconds_exec), mat.append(t.seconds_materialize)
+        out = (np.array([r], np.int64), None)
+    elif kind == "c6":
+        import time as _t
+
+        class _T:  # the column-wise numpy restatement is single-threaded
+            threads = 1
+        n = min(n, 32_000_000)
+        ref, rv, st, en, pv = orc.gen_c6(SEED["c6"], 0, n)
+        t = _T()
+        names = [orc.c3_refs()[i] for i in range(25)]
+        for _ in range(reps):
+            t0 = _t.perf_counter()
+            r = orc.c6_overlap_count(ref, rv, st, pv, en, pv, names, names[6] + ":50000000-100000000")
+            secs.append(_t.perf_counter() - t0), mat.append(0.0)
         out = (np.array([r], np.int64), None)
     elif kind == "c5":
         n = min(n, 8_000_000)
@@ -256,17 +286,18 @@ def main():
             if a.workload == "c4" else f"Mrows/sec filter+agg ({a.workload})",
             "value": round(value, 1), "unit": "Mrows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"c4": "f64", "c2": "int64", "c3": "int64", "c5": "u8"}[a.workload], "data": "synthetic",
+            "vs_baseline": None, "dtype": {"c4": "f64", "c2": "int64", "c3": "int64", "c5": "u8", "c6": "int64"}[a.workload], "data": "synthetic",
             "config": {"workload": {"c4": "config 4: 1B-row synthetic VCF, WHERE info.AF > 0.01, AVG(qual), COUNT(*) GROUP BY filter",
                                     "c2": "config 2: synthetic VCF, chrom='7' AND pos in [5e7,1e8], COUNT(*)",
                                     "c3": "config 3: synthetic BAM, flag&1284=0 AND mapq>=30, COUNT(*) GROUP BY reference",
-                                    "c5": "config 5: synthetic FASTQ (L=100), per-position 256-bin quality histogram; rows = reads"}[a.workload],
+                                    "c5": "config 5: synthetic FASTQ (L=100), per-position 256-bin quality histogram; rows = reads",
+                                    "c6": "synthetic alignments, bam_region_filter('<ref 7>:50000000-100000000', reference, start, end), COUNT(*)"}[a.workload],
                        "rows_per_gpu": rows, "rows_total": n_total, "sharding": "one contiguous row range (file split) per GPU",
                        "reduce": "RCCL all-reduce of partial state" if world > 1 else "none (1 GPU)",
                        "bytes_per_row": bpr,
                        "arithmetic": {"c4": "f32 columns compared as totalOrder i32 keys, f64 sums, i64 counts",
                                       "c2": "i32 / i64 compares, i64 count", "c3": "i32 mask compare, u8 compare, i64 counts",
-                                      "c5": "u8 bytes, u32 LDS counters folded into i64"}[a.workload]},
+                                      "c5": "u8 bytes, u32 LDS counters folded into i64", "c6": "i32 / i64 compares, i64 count"}[a.workload]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel_ms": round(kern_ms, 4),
@@ -284,6 +315,8 @@ def main():
             sample = int(min(a.cpu_sample_rows, rows))
             if a.workload == "c5":
                 sample = min(sample, 8_000_000)
+            if a.workload == "c6":
+                sample = min(sample, 32_000_000)
             base, (oc, os_) = cpu_baseline(a.workload, sample, n_total, a.cpu_reps)
             out["cpu_baseline"] = base
             # parity gate: the GPU path over the same sample rows must reproduce the oracle

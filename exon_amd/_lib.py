@@ -135,6 +135,7 @@ SIGNATURES = {
     "exon_hip_flag_mapq_group_count": (C.c_int, [_vp, _vp, _colp, _colp, _colp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "exon_hip_cmp_avg_by_group": (C.c_int, [_vp, _vp, _colp, _colp, _colp, _i64, _dbl, _i32, _i32, _vp, _vp]),
     "exon_hip_qual_pos_hist": (C.c_int, [_vp, _vp, _colp, _i64, _i32, _vp]),
+    "exon_hip_gen_c6": (C.c_int, [_vp, _vp, _u64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "exon_hip_gen_c2": (C.c_int, [_vp, _vp, _u64, _i64, _i64, _i64, _vp, _vp]),
     "exon_hip_gen_c3": (C.c_int, [_vp, _vp, _u64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "exon_hip_gen_c4": (C.c_int, [_vp, _vp, _u64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),

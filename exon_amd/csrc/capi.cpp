@@ -417,6 +417,13 @@ int exon_hip_gen_c4(exon_hip_ctx* ctx, void* stream, uint64_t seed, int64_t lo, 
   HIP_TRY(ctx, exon::launch_gen_c4(pick_stream(ctx, stream), seed, lo, hi, d_af, d_af_valid, d_qual, d_qual_valid, d_filter_id));
   return EXON_HIP_OK;
 }
+int exon_hip_gen_c6(exon_hip_ctx* ctx, void* stream, uint64_t seed, int64_t lo, int64_t hi, int32_t* d_ref_id,
+                    uint8_t* d_ref_valid, int64_t* d_start, int64_t* d_end, uint8_t* d_pos_valid) {
+  if (!ctx || !d_ref_id || !d_ref_valid || !d_start || !d_end || !d_pos_valid) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_gen_c6: NULL argument");
+  if (lo < 0 || hi < lo) return fail(ctx, EXON_HIP_EINVAL, "bad row range");
+  HIP_TRY(ctx, exon::launch_gen_c6(pick_stream(ctx, stream), seed, lo, hi, d_ref_id, d_ref_valid, d_start, d_end, d_pos_valid));
+  return EXON_HIP_OK;
+}
 int exon_hip_gen_c5(exon_hip_ctx* ctx, void* stream, uint64_t seed, int64_t lo, int64_t hi, int32_t read_len,
                     int32_t* d_offsets, uint8_t* d_bytes) {
   if (!ctx || !d_offsets || !d_bytes) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_gen_c5: NULL argument");

@@ -55,6 +55,8 @@ hipError_t launch_gen_c3(hipStream_t s, uint64_t seed, int64_t lo, int64_t hi, i
                          uint8_t* mapq_valid, int32_t* ref_id, uint8_t* ref_valid);
 hipError_t launch_gen_c4(hipStream_t s, uint64_t seed, int64_t lo, int64_t hi, float* af, uint8_t* af_valid,
                          float* qual, uint8_t* qual_valid, int32_t* filter_id);
+hipError_t launch_gen_c6(hipStream_t s, uint64_t seed, int64_t lo, int64_t hi, int32_t* ref_id, uint8_t* ref_valid,
+                         int64_t* start, int64_t* end, uint8_t* pos_valid);
 hipError_t launch_gen_c5(hipStream_t s, uint64_t seed, int64_t lo, int64_t hi, int32_t read_len, int32_t* offsets,
                          uint8_t* bytes);
 

@@ -1184,6 +1184,34 @@ __global__ __launch_bounds__(256) void gen_c3_kernel(uint64_t seed, int64_t lo, 
   store_valid64(rvalid, wave_row0, n, rv, lane);
 }
 
+// C6 (seed 6): alignments for the interval-overlap count.  reference id over 25 references ~ length (same thresholds as
+// C3), NULL for 2 % of the rows together with start/end (an unmapped read has neither); start uniform in [1, 249e6],
+// end = start + (rnd % 20000).
+__global__ __launch_bounds__(256) void gen_c6_kernel(uint64_t seed, int64_t lo, int64_t hi, C3Table t, int32_t* __restrict__ ref,
+                                                     uint8_t* __restrict__ rvalid, int64_t* __restrict__ start,
+                                                     int64_t* __restrict__ end, uint8_t* __restrict__ pvalid) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n = hi - lo;
+  const int lane = threadIdx.x & 63;
+  bool mapped = false;
+  if (k < n) {
+    const uint64_t i = (uint64_t)(lo + k);
+    const uint64_t r0 = rnd(seed, 0, i), r1 = rnd(seed, 1, i);
+    const uint32_t u0 = (uint32_t)(r0 >> 32);
+    int rc = 0;
+#pragma unroll
+    for (int c = 0; c < 24; ++c) rc += (u0 >= t.rthr[c]);
+    mapped = ((uint32_t)r0 % 50u) != 0u;
+    ref[k] = mapped ? rc : -1;
+    const int64_t st = 1 + (int64_t)(r1 % 249000000ull);
+    start[k] = mapped ? st : 0;
+    end[k] = mapped ? st + (int64_t)((r1 >> 40) % 20000ull) : 0;
+  }
+  const int64_t wave_row0 = k - lane;
+  store_valid64(rvalid, wave_row0, n, mapped, lane);
+  store_valid64(pvalid, wave_row0, n, mapped, lane);
+}
+
 __global__ __launch_bounds__(256) void gen_c4_kernel(uint64_t seed, int64_t lo, int64_t hi, uint32_t t0, uint32_t t1,
                                                      uint32_t t2, uint32_t t3, float* __restrict__ af,
                                                      uint8_t* __restrict__ avalid, float* __restrict__ qual,
@@ -1248,9 +1276,7 @@ hipError_t launch_gen_c2(hipStream_t s, uint64_t seed, int64_t n_total, int64_t 
   return hipGetLastError();
 }
 
-hipError_t launch_gen_c3(hipStream_t s, uint64_t seed, int64_t lo, int64_t hi, int32_t* flag, uint8_t* mapq,
-                         uint8_t* mapq_valid, int32_t* ref_id, uint8_t* ref_valid) {
-  if (hi <= lo) return hipSuccess;
+static C3Table make_c3_table() {
   static const int32_t FLAGS[12] = {99, 147, 83, 163, 1123, 1171, 1187, 1107, 77, 141, 355, 65};
   static const int PCT[12] = {21, 21, 21, 21, 2, 2, 2, 2, 1, 1, 1, 5};
   C3Table t;
@@ -1270,8 +1296,23 @@ hipError_t launch_gen_c3(hipStream_t s, uint64_t seed, int64_t lo, int64_t hi, i
   t.m20 = pct_thr(20);
   t.m40 = pct_thr(40);
   t.m98 = pct_thr(98);
+  return t;
+}
+
+hipError_t launch_gen_c3(hipStream_t s, uint64_t seed, int64_t lo, int64_t hi, int32_t* flag, uint8_t* mapq,
+                         uint8_t* mapq_valid, int32_t* ref_id, uint8_t* ref_valid) {
+  if (hi <= lo) return hipSuccess;
+  const C3Table t = make_c3_table();
   hipLaunchKernelGGL(gen_c3_kernel, dim3(blocks_for(hi - lo)), dim3(256), 0, s, seed, lo, hi, t, flag, mapq,
                      mapq_valid, ref_id, ref_valid);
+  return hipGetLastError();
+}
+
+hipError_t launch_gen_c6(hipStream_t s, uint64_t seed, int64_t lo, int64_t hi, int32_t* ref_id, uint8_t* ref_valid,
+                         int64_t* start, int64_t* end, uint8_t* pos_valid) {
+  if (hi <= lo) return hipSuccess;
+  hipLaunchKernelGGL(gen_c6_kernel, dim3(blocks_for(hi - lo)), dim3(256), 0, s, seed, lo, hi, make_c3_table(), ref_id, ref_valid,
+                     start, end, pos_valid);
   return hipGetLastError();
 }
 

@@ -174,6 +174,14 @@ class Context:
         self._check(self.lib.exon_hip_gen_c2(self.h, stream, seed, n_total, lo, hi, chrom.ptr, pos.ptr))
         return chrom, pos
 
+    def gen_c6(self, seed, lo, hi, stream=None):
+        n = hi - lo
+        nb = (n + 7) // 8 + 64
+        ref, rv = self.empty(np.int32, n), self.zeros(np.uint8, nb)
+        start, end, pv = self.empty(np.int64, n), self.empty(np.int64, n), self.zeros(np.uint8, nb)
+        self._check(self.lib.exon_hip_gen_c6(self.h, stream, seed, lo, hi, ref.ptr, rv.ptr, start.ptr, end.ptr, pv.ptr))
+        return ref, rv, start, end, pv
+
     def gen_c3(self, seed, lo, hi, stream=None):
         n = hi - lo
         nb = (n + 7) // 8 + 64

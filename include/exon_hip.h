@@ -207,6 +207,9 @@ int exon_hip_gen_c3(exon_hip_ctx* ctx, void* stream, uint64_t seed, int64_t lo, 
                     uint8_t* d_mapq, uint8_t* d_mapq_valid, int32_t* d_ref_id, uint8_t* d_ref_valid);
 int exon_hip_gen_c4(exon_hip_ctx* ctx, void* stream, uint64_t seed, int64_t lo, int64_t hi, float* d_af,
                     uint8_t* d_af_valid, float* d_qual, uint8_t* d_qual_valid, int32_t* d_filter_id);
+/* alignments for K6: reference id (+validity), start / end (+ one shared validity; unmapped rows have neither) */
+int exon_hip_gen_c6(exon_hip_ctx* ctx, void* stream, uint64_t seed, int64_t lo, int64_t hi, int32_t* d_ref_id,
+                    uint8_t* d_ref_valid, int64_t* d_start, int64_t* d_end, uint8_t* d_pos_valid);
 int exon_hip_gen_c5(exon_hip_ctx* ctx, void* stream, uint64_t seed, int64_t lo, int64_t hi, int32_t read_len,
                     int32_t* d_offsets, uint8_t* d_bytes);
 

@@ -95,6 +95,38 @@ void orc_gen_c2(uint64_t seed, int64_t n_total, int64_t lo, int64_t hi, int32_t*
   }
 }
 
+/* C6 (seed 6): alignments for the interval-overlap count; identical to gen_c6_kernel (kernels.hip) */
+void orc_gen_c6(uint64_t seed, int64_t lo, int64_t hi, int32_t* ref_id, uint8_t* ref_valid, int64_t* start, int64_t* end,
+                uint8_t* pos_valid) {
+  uint32_t rthr[24];
+  unsigned __int128 total = 0, c128 = 0;
+  for (int c = 0; c < 25; c++) total += (unsigned __int128)GR_LEN[c];
+  for (int c = 0; c < 24; c++) {
+    c128 += (unsigned __int128)GR_LEN[c];
+    rthr[c] = (uint32_t)((c128 << 32) / total);
+  }
+  int64_t n = hi - lo;
+  memset(ref_valid, 0, (size_t)((n + 7) / 8));
+  memset(pos_valid, 0, (size_t)((n + 7) / 8));
+#pragma omp parallel for schedule(static)
+  for (int64_t blk = 0; blk < (n + 4095) / 4096; blk++)
+  for (int64_t i = lo + blk * 4096; i < hi && i < lo + (blk + 1) * 4096; i++) {
+    uint64_t r0 = orc_rnd(seed, 0, (uint64_t)i), r1 = orc_rnd(seed, 1, (uint64_t)i);
+    uint32_t u0 = (uint32_t)(r0 >> 32);
+    int rc = 0;
+    for (int c = 0; c < 24; c++) rc += (u0 >= rthr[c]);
+    int mapped = ((uint32_t)r0 % 50u) != 0u;
+    int64_t st = 1 + (int64_t)(r1 % 249000000ull);
+    ref_id[i - lo] = mapped ? rc : -1;
+    start[i - lo] = mapped ? st : 0;
+    end[i - lo] = mapped ? st + (int64_t)((r1 >> 40) % 20000ull) : 0;
+    if (mapped) {
+      bit_set(ref_valid, i - lo);
+      bit_set(pos_valid, i - lo);
+    }
+  }
+}
+
 static const int32_t C3_FLAGS[12] = {99, 147, 83, 163, 1123, 1171, 1187, 1107, 77, 141, 355, 65};
 static const int C3_FLAG_PCT[12] = {21, 21, 21, 21, 2, 2, 2, 2, 1, 1, 1, 5};
 static inline uint32_t pct_thr(int cum_pct) { return (uint32_t)((((uint64_t)cum_pct) << 32) / 100); }

@@ -36,6 +36,8 @@ typedef struct {
 /* ---- counter-based synthetic inputs (DESIGN.md "Synthetic inputs") -------------------- */
 uint64_t orc_rnd(uint64_t seed, uint64_t col, uint64_t i);
 void orc_c2_contig_starts(int64_t n_total, int64_t starts[25]);
+void orc_gen_c6(uint64_t seed, int64_t lo, int64_t hi, int32_t* ref_id, uint8_t* ref_valid, int64_t* start, int64_t* end,
+                uint8_t* pos_valid);
 void orc_gen_c2(uint64_t seed, int64_t n_total, int64_t lo, int64_t hi, int32_t* chrom_id, int64_t* pos);
 void orc_gen_c3(uint64_t seed, int64_t lo, int64_t hi, int32_t* flag, uint8_t* mapq,
                 uint8_t* mapq_valid, int32_t* ref_id, uint8_t* ref_valid);

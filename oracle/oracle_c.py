@@ -64,6 +64,15 @@ class Oracle:
     def rnd(self, seed, col, i):
         return self.lib.orc_rnd(seed, col, i)
 
+    def gen_c6(self, seed, lo, hi):
+        n = hi - lo
+        nb = (n + 7) // 8
+        ref, rv = np.empty(n, np.int32), np.empty(max(nb, 1), np.uint8)
+        start, end, pv = np.empty(n, np.int64), np.empty(n, np.int64), np.empty(max(nb, 1), np.uint8)
+        self.lib.orc_gen_c6(C.c_uint64(seed), C.c_int64(lo), C.c_int64(hi), _p(ref, C.c_int32), _p(rv, C.c_uint8),
+                            _p(start, C.c_int64), _p(end, C.c_int64), _p(pv, C.c_uint8))
+        return ref, rv, start, end, pv
+
     def gen_c2(self, seed, n_total, lo=0, hi=None):
         hi = n_total if hi is None else hi
         n = hi - lo

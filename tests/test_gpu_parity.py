@@ -104,6 +104,22 @@ def test_k6_overlap_count(ctx, oracle, n, region):
     assert d.to_host()[0] == oracle.c6_overlap_count(ref, rv, start, sv, end, ev, names, region)
 
 
+def test_k6_generated_alignments_match_the_oracle(ctx, oracle):
+    """exon_hip_gen_c6 is bit-identical to the oracle's generator; K6 over it equals the oracle's count."""
+    n = 3_000_001
+    ref, rv, start, end, pv = ctx.gen_c6(6, 5, 5 + n)
+    href, hrv, hst, hen, hpv = oracle.gen_c6(6, 5, 5 + n)
+    nb = (n + 7) // 8
+    assert np.array_equal(ref.to_host(), href) and np.array_equal(start.to_host(), hst) and np.array_equal(end.to_host(), hen)
+    assert np.array_equal(rv.to_host()[:nb], hrv[:nb]) and np.array_equal(pv.to_host()[:nb], hpv[:nb])
+    names = oracle.c3_refs()
+    d = ctx.zeros(np.int64, 1)
+    ctx.overlap_count(ref, rv, start, pv, end, pv, n, 6, 50_000_000, 100_000_000, d)
+    ctx.sync()
+    want = oracle.c6_overlap_count(href, hrv, hst, hpv, hen, hpv, names, names[6] + ":50000000-100000000")
+    assert d.to_host()[0] == want and want > 1000
+
+
 def test_k6_no_bitmaps_boundaries_and_accumulate(ctx, oracle):
     names = ["a", "b"]
     # intervals that touch the region ends exactly (1-based inclusive on both sides)
