@@ -16,7 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd, wl, rows = sys.argv[1], sys.argv[2], int(float(sys.argv[3]))
 kern = {"c4": "k4_cmp_avg_by_group_main", "c2": "k2_region_count_main", "c3": "k3_flag_mapq_group_count_main",
-        "c5": "k5_qual_pos_hist_main"}[wl]
+        "c5": "k5_main", "c6": "k6_overlap_count_main"}[wl]
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
 src = os.path.join(G, f"prof_{rnd}", f"{wl}_kernel_stats.csv")
