@@ -149,6 +149,7 @@ SIGNATURES = {
     "exon_hip_stream_push": (C.c_int, [_vp, C.POINTER(ArrowArray)]),
     "exon_hip_stream_push_device": (C.c_int, [_vp, C.POINTER(ArrowDeviceArray)]),
     "exon_hip_stream_state": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "exon_hip_stream_all_reduce": (C.c_int, [_vp, _vp]),
     "exon_hip_stream_sync": (C.c_int, [_vp]),
     "exon_hip_stream_finish": (C.c_int, [_vp, _vp, _vp]),
     "exon_hip_stream_finish_arrow": (C.c_int, [_vp, C.POINTER(ArrowArray), C.POINTER(ArrowSchema)]),

@@ -10,6 +10,8 @@
 // batches (Arrow C Device Data Interface, what the device-layout builders emit) skip staging.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -539,6 +541,32 @@ int exon_hip_stream_state(exon_hip_stream* st, int64_t** d_i64, double** d_f64, 
   if (d_i64) *d_i64 = reinterpret_cast<int64_t*>(st->d_state);
   if (d_f64) *d_f64 = reinterpret_cast<double*>(st->d_state + st->plan->n_i64 * 8);
   if (hip_stream) *hip_stream = (void*)st->stream;
+  return EXON_HIP_OK;
+}
+
+// AggregateExec(Final) across GPUs in native code: one in-place all-reduce(sum) of the int64 counters and one of the f64
+// sums over RCCL, enqueued on the stream's hipStream_t.  librccl is resolved at the first call (dlopen), so hosts that
+// never merge across GPUs -- and machines without RCCL -- do not need it.
+int exon_hip_stream_all_reduce(exon_hip_stream* st, void* rccl_comm) {
+  if (!st || !rccl_comm) return fail(st ? st->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_stream_all_reduce: NULL argument");
+  if (st->closed) return fail(st->ctx, EXON_HIP_ESTATE, "all_reduce after finish/close");
+  typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+  static allreduce_fn fn = [] {
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    return h ? (allreduce_fn)dlsym(h, "ncclAllReduce") : (allreduce_fn) nullptr;
+  }();
+  if (!fn) return fail(st->ctx, EXON_HIP_EUNSUPPORTED, "librccl.so (ncclAllReduce) could not be loaded");
+  int rc = flush_slot(st);
+  if (rc) return rc;
+  const exon_hip_plan* p = st->plan;
+  constexpr int NCCL_INT64 = 4, NCCL_FLOAT64 = 8, NCCL_SUM = 0;  // rccl.h: ncclDataType_t / ncclRedOp_t
+  int64_t* counts = reinterpret_cast<int64_t*>(st->d_state);
+  double* sums = reinterpret_cast<double*>(st->d_state + p->n_i64 * 8);
+  int e = 0;
+  if (p->n_i64) e = fn(counts, counts, (size_t)p->n_i64, NCCL_INT64, NCCL_SUM, rccl_comm, st->stream);
+  if (!e && p->n_f64) e = fn(sums, sums, (size_t)p->n_f64, NCCL_FLOAT64, NCCL_SUM, rccl_comm, st->stream);
+  if (e) return fail(st->ctx, EXON_HIP_EDEVICE, "ncclAllReduce failed with ncclResult_t %d", e);
   return EXON_HIP_OK;
 }
 

@@ -600,6 +600,10 @@ class Stream:
         self.ctx._check(self.ctx.lib.exon_hip_stream_state(self.h, C.byref(a), C.byref(b), C.byref(s)))
         return a.value, b.value, s.value
 
+    def all_reduce(self, rccl_comm):
+        """In-place RCCL all-reduce(sum) of the partial state on the stream (`rccl_comm`: an ncclComm_t as an integer)."""
+        self.ctx._check(self.ctx.lib.exon_hip_stream_all_reduce(self.h, C.c_void_p(rccl_comm)))
+
     def sync(self):
         self.ctx._check(self.ctx.lib.exon_hip_stream_sync(self.h))
 

@@ -266,6 +266,9 @@ int exon_hip_stream_push_device(exon_hip_stream* s, const struct ArrowDeviceArra
 /* Device pointers of the partial state ([n_i64] int64 then [n_f64] float64, one allocation) so the
  * host can all-reduce them over RCCL, plus the hipStream_t the kernels run on. */
 int exon_hip_stream_state(exon_hip_stream* s, int64_t** d_i64, double** d_f64, void** hip_stream);
+/* The merge across GPUs in native code: in-place ncclAllReduce(sum) of the int64 counters and of the float64 sums on the
+ * stream's hipStream_t.  `rccl_comm` is an ncclComm_t the host created (one rank per GPU); librccl is loaded on first use. */
+int exon_hip_stream_all_reduce(exon_hip_stream* s, void* rccl_comm);
 int exon_hip_stream_sync(exon_hip_stream* s);
 /* Copies the (possibly all-reduced) state to host: counts[n_i64], sums[n_f64]. */
 int exon_hip_stream_finish(exon_hip_stream* s, int64_t* counts, double* sums);

@@ -44,6 +44,8 @@ extern "C" {
     /// moves `batch` (the library calls batch.release exactly once)
     pub fn exon_hip_stream_push(s: *mut exon_hip_stream, batch: *mut FFI_ArrowArray) -> c_int;
     pub fn exon_hip_stream_state(s: *mut exon_hip_stream, d_i64: *mut *mut i64, d_f64: *mut *mut f64, hip_stream: *mut *mut c_void) -> c_int;
+    /// AggregateExec(Final) across GPUs: in-place ncclAllReduce(sum) of the partial state (comm: ncclComm_t)
+    pub fn exon_hip_stream_all_reduce(s: *mut exon_hip_stream, rccl_comm: *mut c_void) -> c_int;
     pub fn exon_hip_stream_finish_arrow(s: *mut exon_hip_stream, out: *mut FFI_ArrowArray, out_schema: *mut FFI_ArrowSchema) -> c_int;
     pub fn exon_hip_stream_close(s: *mut exon_hip_stream) -> c_int;
     pub fn exon_hip_parse_region(region: *const c_char, name_out: *mut c_char, name_cap: usize, start: *mut i64, end: *mut i64) -> c_int;

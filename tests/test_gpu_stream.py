@@ -136,3 +136,32 @@ def test_push_after_finish_is_an_error(ctx, oracle):
     with pytest.raises(exon_amd.ExonHipError):
         st.push(batches[0])
     st.close()
+
+
+def test_native_rccl_all_reduce_on_a_one_rank_communicator(ctx, oracle):
+    """exon_hip_stream_all_reduce: the AggregateExec(Final) merge through librccl itself (no torch).  One GPU, so the
+    communicator has one rank and the state must come back unchanged; the call path (dlopen, data types, stream) is what
+    the N-GPU merge uses."""
+    import ctypes as C
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        rccl = C.CDLL("/opt/rocm/lib/librccl.so")
+    comm = C.c_void_p()
+    devs = (C.c_int * 1)(0)
+    assert rccl.ncclCommInitAll(C.byref(comm), 1, devs) == 0
+    n = 1_000_000
+    af, av, q, qv, fid = ctx.gen_c4(4, 0, n)
+    plan = ctx.plan_cmp_avg_by_group(">", 0.01, 5, columns=(0, 1, 2))
+    st = plan.open()
+    st.push_device([(af, av, None), (q, qv, None), (fid, None, None)], n)
+    st.all_reduce(comm.value)
+    st.sync()
+    counts, sums = st.finish()
+    haf, hav, hq, hqv, hfid = oracle.gen_c4(4, 0, n)
+    s_, cn, cr, _ = oracle.c4_cmp_avg_by_group(haf, hav, hq, hqv, hfid, oracle.c4_filters(), 0.01, ">")
+    assert np.array_equal(np.array(counts[:5]), cn) and np.array_equal(np.array(counts[5:10]), cr)
+    assert np.allclose(np.array(sums), s_, rtol=1e-9)
+    st.close()
+    plan.close()
+    rccl.ncclCommDestroy(comm)
