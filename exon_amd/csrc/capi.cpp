@@ -318,8 +318,8 @@ int exon_hip_flag_mapq_group_count(exon_hip_ctx* ctx, void* stream, const exon_h
                                    int64_t* d_counts) {
   if (!ctx || !d_counts) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_flag_mapq_group_count: NULL argument");
   if (n < 0) return fail(ctx, EXON_HIP_EINVAL, "n < 0");
-  if (n_refs < 0 || n_refs + 1 > EXON_HIP_MAX_GROUPS)
-    return fail(ctx, EXON_HIP_EUNSUPPORTED, "n_refs %d outside [0, %d)", n_refs, EXON_HIP_MAX_GROUPS);
+  if (n_refs < 0 || n_refs >= EXON_HIP_MAX_REFERENCES)
+    return fail(ctx, EXON_HIP_EUNSUPPORTED, "n_refs %d outside [0, %d)", n_refs, EXON_HIP_MAX_REFERENCES);
   int rc;
   if ((rc = check_col(ctx, "flag", flag, n, false)) || (rc = check_col(ctx, "mapq", mapq, n, false)) ||
       (rc = check_col(ctx, "ref_id", ref_id, n, false)))

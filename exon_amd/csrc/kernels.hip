@@ -435,7 +435,10 @@ __global__ __launch_bounds__(S::THREADS) void k3_flag_mapq_group_count_main(
   }
 }
 
-size_t k3_partial_words(const LaunchCfg& cfg, int n_refs) { return (size_t)max_grid(cfg) * (size_t)(n_refs + 1); }
+size_t k3_partial_words(const LaunchCfg& cfg, int n_refs) {
+  if (n_refs + 1 > 4096) return 16;  // the global-atomic path writes the caller's counters directly
+  return (size_t)max_grid(cfg) * (size_t)(n_refs + 1);
+}
 
 template <typename S>
 static hipError_t k3_launch(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* flag,
@@ -455,11 +458,39 @@ static hipError_t k3_launch(hipStream_t s, const LaunchCfg& cfg, const Workspace
   return hipGetLastError();
 }
 
+// More references than an LDS table holds (assemblies with tens of thousands of scaffolds): one global atomic per passing
+// row straight into the caller's counters.  Keys spread over many addresses, so the atomics do not serialise the way a
+// handful of hot groups would; still several times slower than the LDS path and used only beyond EXON_HIP_MAX_GROUPS.
+__global__ __launch_bounds__(256) void k3_flag_mapq_group_count_global(
+    const int32_t* __restrict__ flag, const uint8_t* __restrict__ fvalid, const uint8_t* __restrict__ mapq,
+    const uint8_t* __restrict__ mvalid, const int32_t* __restrict__ ref, const uint8_t* __restrict__ rvalid, int64_t n,
+    int32_t mask, int32_t value, int32_t qmin, int32_t R, unsigned long long* __restrict__ counts, int* __restrict__ status) {
+  bool bad = false;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
+    const bool pass = valid1(fvalid, r) && ((flag[r] & mask) == value) && valid1(mvalid, r) && ((int32_t)mapq[r] >= qmin);
+    if (!pass) continue;
+    const unsigned key = valid1(rvalid, r) ? (unsigned)ref[r] : (unsigned)R;
+    if (key > (unsigned)R) {
+      bad = true;
+      continue;
+    }
+    atomicAdd(&counts[key], 1ull);
+  }
+  if (bad) atomicOr(&status[0], 2);  // same status bit as the LDS path: reference id out of range
+}
+
 hipError_t launch_flag_mapq_group_count(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* flag,
                                         const uint8_t* flag_valid, const uint8_t* mapq, const uint8_t* mapq_valid,
                                         const int32_t* ref_id, const uint8_t* ref_valid, int64_t n, int32_t flag_mask,
                                         int32_t flag_value, int32_t mapq_min, int32_t n_refs, int64_t* d_counts) {
   if (n <= 0) return hipSuccess;
+  if (n_refs + 1 > 4096) {
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)cfg.compute_units * 32);
+    hipLaunchKernelGGL(k3_flag_mapq_group_count_global, dim3(grid), dim3(256), 0, s, flag, flag_valid, mapq, mapq_valid, ref_id,
+                       ref_valid, n, flag_mask, flag_value, mapq_min, n_refs, reinterpret_cast<unsigned long long*>(d_counts),
+                       ws.status);
+    return hipGetLastError();
+  }
   int grid = 1;
   // the 16-wave shape needs 16 x (n_refs+1) x 4 B of LDS: fine up to ~2.5k references
   const bool big = use_big_shape(cfg, n) && (size_t)16 * (n_refs + 1 + 64) * 4 <= 160 * 1024;

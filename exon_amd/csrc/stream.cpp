@@ -249,7 +249,7 @@ int exon_hip_plan_create(exon_hip_ctx* ctx, const exon_hip_plan_desc* desc, exon
       p->cols[0].elem = 4;
       p->cols[1].elem = 1;
       p->cols[2].elem = 4;
-      if (desc->n_groups < 0 || desc->n_groups + 1 > EXON_HIP_MAX_GROUPS) {
+      if (desc->n_groups < 0 || desc->n_groups >= EXON_HIP_MAX_REFERENCES) {
         delete p;
         return fail(ctx, EXON_HIP_EUNSUPPORTED, "n_groups %d out of range", desc->n_groups);
       }

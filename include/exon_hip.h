@@ -150,6 +150,7 @@ typedef struct exon_hip_column {
 
 #define EXON_HIP_MAX_REG_GROUPS 8   /* group ids kept in registers; ids 8.. use an LDS overflow table */
 #define EXON_HIP_MAX_GROUPS 4096    /* group tables kept in LDS */
+#define EXON_HIP_MAX_REFERENCES (1 << 24) /* K3: beyond EXON_HIP_MAX_GROUPS references the counters are global atomics */
 #define EXON_HIP_REGION_OPEN_END INT64_MAX
 
 /* ---- operator launches (asynchronous on `stream`; results ACCUMULATE into the state buffers,

@@ -151,6 +151,26 @@ def test_k3_flag_mapq_group_count(ctx, oracle, n, mask, value, qmin):
     assert np.array_equal(d.to_host(), want)
 
 
+def test_k3_many_references_global_atomic_path(ctx):
+    """More references than the LDS tables hold (EXON_HIP_MAX_GROUPS): counters are global atomics; bit-exact vs numpy."""
+    rng = np.random.default_rng(33)
+    n, R = 3_000_001, 60_000
+    flag = rng.choice(np.array([99, 147, 83, 163, 4, 1024 + 99, 256], np.int32), n)
+    mapq = rng.integers(0, 61, n).astype(np.uint8)
+    ref = rng.integers(0, R, n, dtype=np.int32)
+    nb = (n + 7) // 8 + 64
+    mv, rv = rng.integers(0, 256, nb, dtype=np.uint8) | 0x0F, rng.integers(0, 256, nb, dtype=np.uint8) | 0xF0
+    d = ctx.zeros(np.int64, R + 1)
+    dev = [ctx.to_device(x) for x in (flag, np.concatenate([mapq, np.zeros(64, np.uint8)]), mv, ref, rv)]
+    for _ in range(2):
+        ctx.flag_mapq_group_count(dev[0], dev[1], dev[2], dev[3], dev[4], n, 1284, 0, 30, R, d)
+    ctx.sync()
+    mvb, rvb = bits(mv, n), bits(rv, n)
+    ok = ((flag & 1284) == 0) & mvb & (mapq >= 30)
+    want = np.bincount(np.where(rvb, ref, R)[ok], minlength=R + 1)
+    assert np.array_equal(d.to_host(), 2 * want) and want[R] > 0
+
+
 # ---- K4 -----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n", [1, 2048, 99_999, 5_000_000])
 @pytest.mark.parametrize("op,thr", [(">", 0.01), (">=", 0.01), ("<", 0.5), ("<=", 0.25), ("=", 0.25), ("!=", 0.01),
