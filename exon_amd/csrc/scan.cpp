@@ -970,6 +970,9 @@ int exon_hip_stream_consume_scan(exon_hip_stream* st, exon_hip_scan* scan, int64
     hipStreamSynchronize((hipStream_t)exon_hip_stream_hip_stream(st));
     hipFree(snap);
     if (rc) return rc;
+    if (const char* strict = getenv("EXON_HIP_GPU_PARSE_STRICT"); strict && strict[0] == '1')
+      return fail(ctx, EXON_HIP_ESTATE, "%s: the GPU decoders could not decide every record and EXON_HIP_GPU_PARSE_STRICT=1 forbids the host decoders",
+                  scan->path.c_str());
     if (scan->parser) {
       exon_hip_vcf_parser_destroy(scan->parser);
       scan->parser = nullptr;

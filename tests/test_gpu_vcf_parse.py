@@ -222,3 +222,22 @@ def test_gpu_parse_falls_back_to_host_on_undecidable_rows(ctx, tmp_path):
     rows_g, gpu = _k4_through_scan(ctx, path, True, fallback=True)
     rows_h, host = _k4_through_scan(ctx, path, False)
     assert rows_g == rows_h == 5000 and gpu == host
+
+
+def test_strict_mode_turns_the_host_fallback_into_an_error(ctx, tmp_path, monkeypatch):
+    """EXON_HIP_GPU_PARSE_STRICT=1: a deployment that must never decode on the host gets an error instead of the fallback."""
+    path = tmp_path / "odd.vcf"
+    with open(path, "w") as f:
+        f.write('##fileformat=VCFv4.3\n##contig=<ID=1>\n##INFO=<ID=AF,Number=1,Type=Float,Description="AF">\n')
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+        for i in range(500):
+            f.write(f"{'GL99' if i == 400 else '1'}\t{i + 1}\t.\tA\tC\t1.5\tPASS\tAF=0.5\n")
+    monkeypatch.setenv("EXON_HIP_GPU_PARSE_STRICT", "1")
+    scan = exon_amd.Scan(path, "vcf", info_field="AF", gpu_parse=True)
+    plan = ctx.plan_cmp_avg_by_group(">", 0.01, 64, columns=(4, 2, 3))
+    st = plan.open()
+    with pytest.raises(exon_amd.ExonHipError, match="EXON_HIP_GPU_PARSE_STRICT"):
+        st.consume(scan)
+    st.close()
+    plan.close()
+    scan.close()

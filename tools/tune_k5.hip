@@ -152,6 +152,46 @@ __global__ __launch_bounds__(1024) void vD(const uint8_t* bytes, int64_t n, int 
     const unsigned v = h[b * LP + (p & 3) * Q + (p >> 2)]; if (v) atomicAdd(&out[p * 256 + b], (unsigned long long)v); }
 }
 
+// ---- E: D for short reads.  With L/4 < 32 two lanes of one 32-lane LDS group can hold the same dword-of-read q
+// (lanes 25 apart at L = 100) and collide on a bank (different byte) or an address (same byte).  Column = position of
+// the lane inside its 32-lane group's run of the stream, u = q(first lane of the group) + (lane & 31) < L/4 + 31: the 32
+// lanes of a group then always hit 32 consecutive banks.  Folded over u mod L/4 at the end.
+template <int J>
+__global__ __launch_bounds__(1024) void vE(const uint8_t* bytes, int64_t n, int L, unsigned long long* out) {
+  extern __shared__ unsigned h[];  // [128][LP], LP = 4 * QP
+  const int QL = L / 4, QP = (QL + 31 + 7) & ~7, LP = 4 * QP;
+  for (int i = threadIdx.x; i < 128 * LP; i += 1024) h[i] = 0;
+  __syncthreads();
+  const int64_t nd = n * QL; const int64_t S = (int64_t)gridDim.x * 1024;
+  const int64_t c0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+  const int l31 = threadIdx.x & 31;
+  int tg = (int)((c0 - l31) % QL); const int tS = (int)(S % QL);
+  const unsigned* src = reinterpret_cast<const unsigned*>(bytes);
+  auto one = [&](unsigned d, int u) {
+    if (__builtin_expect((d & 0x80808080u) != 0, 0)) {
+      int q = u; while (q >= QL) q -= QL;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) atomicAdd(&out[(4 * q + k) * 256 + ((d >> (8 * k)) & 0xFF)], 1ull);
+      return; }
+    unsigned* base = h + u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) atomicAdd(base + ((d >> (8 * k)) & 0xFF) * LP + k * QP, 1u);
+  };
+  int64_t c = c0;
+  for (; c + (J - 1) * S < nd; c += J * S) {
+    unsigned v[J]; int uj[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) { v[j] = __builtin_nontemporal_load(src + c + j * S); uj[j] = tg + l31; tg += tS; tg = tg >= QL ? tg - QL : tg; }
+#pragma unroll
+    for (int j = 0; j < J; ++j) one(v[j], uj[j]);
+  }
+  for (; c < nd; c += S) { one(src[c], tg + l31); tg += tS; tg = tg >= QL ? tg - QL : tg; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < L * 128; i += 1024) { const int p = i % L, b = i / L; unsigned v = 0;
+    for (int u = p >> 2; u < QP; u += QL) v += h[b * LP + (p & 3) * QP + u];
+    if (v) atomicAdd(&out[p * 256 + b], (unsigned long long)v); }
+}
+
 int main(int argc, char** argv) {
   int64_t n = argc > 1 ? (int64_t)atof(argv[1]) : (int64_t)2e8; const int L = argc > 2 ? atoi(argv[2]) : 100;
   n = n / 4096 * 4096;
@@ -183,6 +223,7 @@ int main(int argc, char** argv) {
     if (L % 4 == 0) { run("D cf LP128 J4 A4", vD<128, 4, true>, 128 * 128 * 4, 256); run("D cf LP128 J8 A4", vD<128, 8, true>, 128 * 128 * 4, 256);
       run("D cf LP128 J16 A4", vD<128, 16, true>, 128 * 128 * 4, 256); run("D cf LP128 J8 A4 x2", vD<128, 8, true>, 128 * 128 * 4, 512); }
     run("D cf LP128 J8 gen", vD<128, 8, false>, 128 * 128 * 4, 256); run("D cf LP128 J16 gen", vD<128, 16, false>, 128 * 128 * 4, 256);
+    if (L % 4 == 0) { const int QP = (L / 4 + 31 + 7) & ~7; run("E group-run J8", vE<8>, (size_t)128 * 4 * QP * 4, 256); run("E group-run J16", vE<16>, (size_t)128 * 4 * QP * 4, 256); }
   } else if (L <= 256) {
     if (L % 4 == 0) { run("D cf LP256 J8 A4", vD<256, 8, true>, 128 * 256 * 4, 256); run("D cf LP256 J16 A4", vD<256, 16, true>, 128 * 256 * 4, 256); }
     run("D cf LP256 J8 gen", vD<256, 8, false>, 128 * 256 * 4, 256); run("D cf LP256 J16 gen", vD<256, 16, false>, 128 * 256 * 4, 256);
