@@ -54,8 +54,11 @@ int get_workspace(exon_hip_ctx* ctx, hipStream_t s, size_t words, Workspace* out
     // status[0] = device error word, status[1..7] = scratch flags (K5 path selection), then 64 bytes of 0xFF
     // (stand-in for absent validity bitmaps)
     if (hipMalloc(&ws.status, 8 * sizeof(int) + 64) != hipSuccess) return EXON_HIP_ENOMEM;
-    hipMemset(ws.status, 0, 8 * sizeof(int));
-    hipMemset(ws.status + 8, 0xFF, 64);
+    if (hipMemset(ws.status, 0, 8 * sizeof(int)) != hipSuccess || hipMemset(ws.status + 8, 0xFF, 64) != hipSuccess) {
+      hipFree(ws.status);
+      ws.status = nullptr;
+      return EXON_HIP_EDEVICE;
+    }
   }
   if (ws.partial_capacity < words) {
     if (ws.partials) {
@@ -246,7 +249,7 @@ int exon_hip_sync(exon_hip_ctx* ctx, void* stream) {
     int st = 0;
     HIP_TRY(ctx, hipMemcpy(&st, d_status, sizeof st, hipMemcpyDeviceToHost));
     if (st) {
-      hipMemset(d_status, 0, sizeof st);
+      HIP_TRY(ctx, hipMemset(d_status, 0, sizeof st));
       return fail(ctx, EXON_HIP_EINVAL, "device status 0x%x:%s%s%s", st, (st & 2) ? " reference id out of range" : "",
                   (st & 4) ? " group id out of range" : "", (st & 8) ? " read longer than lmax" : "");
     }

@@ -638,11 +638,26 @@ __global__ __launch_bounds__(WAVES_PER_WG * 64) void k_crc32(const uint8_t* __re
   const uint8_t* p = out + blk.out_offset;
   uint32_t c = 0;  // raw CRC register over the slice, zero initial value, no final xor
   uint32_t i = lo;
-  while (i < hi && ((reinterpret_cast<uintptr_t>(p + i)) & 3u)) c = table[0][(c ^ p[i++]) & 0xFFu] ^ (c >> 8);
-  for (; i + 4 <= hi; i += 4) {
-    c ^= *reinterpret_cast<const uint32_t*>(p + i);
+  auto step4 = [&](uint32_t w) {
+    c ^= w;
     c = table[3][c & 0xFFu] ^ table[2][(c >> 8) & 0xFFu] ^ table[1][(c >> 16) & 0xFFu] ^ table[0][c >> 24];
+  };
+  while (i < hi && ((reinterpret_cast<uintptr_t>(p + i)) & 15u)) c = table[0][(c ^ p[i++]) & 0xFFu] ^ (c >> 8);
+  // the lanes' slices lie ~1 KiB apart, so a load instruction touches 64 different cache lines: take a whole 64-byte
+  // line per lane per iteration (4 x 16 B), or the lines are evicted between the 16 dword loads that share them
+  for (; i + 64 <= hi; i += 64) {
+    uint4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const uint4*>(p + i + 16 * k);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      step4(v[k].x);
+      step4(v[k].y);
+      step4(v[k].z);
+      step4(v[k].w);
+    }
   }
+  for (; i + 4 <= hi; i += 4) step4(*reinterpret_cast<const uint32_t*>(p + i));
   for (; i < hi; ++i) c = table[0][(c ^ p[i]) & 0xFFu] ^ (c >> 8);
   // combine: total = sum over lanes of crc_l * x^(8 * bytes after slice l); the 0xFFFFFFFF initial value is the
   // CRC of a virtual prefix: init * x^(8 n)
