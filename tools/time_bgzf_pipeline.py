@@ -36,7 +36,7 @@ def run(path, gpu_parse):
     counts, sums = st.finish()
     dt = time.perf_counter() - t
     st.close(); plan.close(); scan.close()
-    return rows, np.array(counts), dt
+    return rows, np.sort(np.array(counts)), dt  # FILTER ids are interned in first-seen order, which differs by path
 
 
 def report(label, path, gpu_parse, reps=3):
