@@ -84,7 +84,6 @@ __device__ __forceinline__ int cl_order(int i) {
 // ---- LDS layout: one wavefront per workgroup; [0, RING) recent output, then the tables -----------------------------
 // A file-scope dynamic LDS array keeps the address space visible to the non-inlined helpers (ds_* instructions, not
 // flat_*).
-extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
 // First-level table entries are complete decode results, so the symbol loop does no arithmetic on symbol numbers:
 //   bits 0-3 code length (0 = longer than the table, or no such code), 4-7 number of extra bits, 8 literal, 9 end of
@@ -113,6 +112,8 @@ static_assert(sizeof(ClTables) <= sizeof(uint32_t) << DIST_BITS, "cl tables must
 enum { CODE_LIT = 0, CODE_DIST = 1, CODE_CL = 2 };
 
 constexpr int INF_WAVES = 1;  // wavefronts (= BGZF blocks) per workgroup (1: LDS addresses need no per-wave base)
+// static (not dynamic) LDS: with one kernel using it the addresses are compile-time constants in every function
+__shared__ __attribute__((aligned(16))) uint8_t smem[INF_WAVES * ((INFLATE_RING + sizeof(WaveLds) + 15) & ~size_t(15))];
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 template <int RING>
 __device__ __forceinline__ uint8_t* wave_ring();
@@ -751,8 +752,7 @@ hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const 
   if (n_blocks <= 0) return hipSuccess;
   static_assert(sizeof(Block) == sizeof(exon_hip_bgzf_block), "block layouts must agree");
   const Block* blocks = reinterpret_cast<const Block*>(d_blocks);
-  constexpr size_t lds_per_wave = (INFLATE_RING + sizeof(WaveLds) + 15) & ~size_t(15);
-  hipLaunchKernelGGL(k_inflate<INFLATE_RING>, dim3((n_blocks + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), INF_WAVES * lds_per_wave, s,
+  hipLaunchKernelGGL(k_inflate<INFLATE_RING>, dim3((n_blocks + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), 0, s,
                      d_comp, blocks, n_blocks, d_out, d_status);
   if (verify_crc)
     hipLaunchKernelGGL(k_crc32, dim3((n_blocks + WAVES_PER_WG - 1) / WAVES_PER_WG), dim3(WAVES_PER_WG * 64), 0, s, d_out, blocks, n_blocks,
