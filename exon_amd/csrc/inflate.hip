@@ -29,9 +29,21 @@
 
 namespace {
 
-constexpr int LIT_BITS = 9, DIST_BITS = 8, CL_BITS = 7;
+#ifndef EXON_LIT_BITS
+#define EXON_LIT_BITS 9
+#endif
+#ifndef EXON_DIST_BITS
+#define EXON_DIST_BITS 8
+#endif
+constexpr int LIT_BITS = EXON_LIT_BITS, DIST_BITS = EXON_DIST_BITS, CL_BITS = 7;
 constexpr int WAVES_PER_WG = 4;     // k_crc32
-constexpr int INFLATE_RING = 2048;  // bytes of recent output kept in LDS per wavefront (k_inflate)
+#ifndef EXON_INFLATE_RING
+#define EXON_INFLATE_RING 2048
+#endif
+#ifndef EXON_INFLATE_LIT
+#define EXON_INFLATE_LIT 1  // literal loop: 0 = the compiler's (readable reference), 1 = literal_run (hand-written)
+#endif
+constexpr int INFLATE_RING = EXON_INFLATE_RING;  // bytes of recent output kept in LDS per wavefront (k_inflate)
 
 enum : int {
   INF_OK = 0,
@@ -108,7 +120,7 @@ struct WaveLds {
   uint16_t first[16], offs[16];      // scratch of build_code
   uint8_t lens[288 + 32];
 };
-static_assert(sizeof(ClTables) <= sizeof(uint32_t) << DIST_BITS, "cl tables must fit under dist_lut");
+// (the code-length tables share the bytes of dist_lut: they are dead once the lengths are read)
 enum { CODE_LIT = 0, CODE_DIST = 1, CODE_CL = 2 };
 
 constexpr int INF_WAVES = 1;  // wavefronts (= BGZF blocks) per workgroup (1: LDS addresses need no per-wave base)
@@ -418,6 +430,78 @@ struct SymResult {
 // The symbols of one DEFLATE block.  RING bytes of the most recent output stay in LDS: matches whose distance fits are
 // LDS -> LDS copies (no memory latency on the decode chain); farther ones read the output already drained to HBM.
 // Output bounds are checked when rows are drained (the ring wraps harmlessly), input bounds when a window is reloaded.
+// LDS byte address of a __shared__ object
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+// The literal loop, hand-written: refill -> first-level lookup -> store -> next in 22 instructions per literal (the
+// compiler's version of the same loop, EXON_INFLATE_LIT=0: 26, with two more taken branches).  Table index and ring
+// address are computed on the vector ALU, the row check rides on the SCC of s_and.  Worth +2 % (VCF text), +5 % (BAM),
+// +13 % (FASTQ) on the same box; a batched variant (one lookup for all 64 bit offsets, the chain of literals followed
+// with v_readlane) was no faster on literal-heavy data and slower on match-heavy data (profiles/r1_tuning.md).
+// Leaves with   0: `e` is a first-level entry that is not a literal (its code bits are NOT consumed; 0 = long code)
+//               1: a literal was stored and o.pos entered a new 256-byte row
+// `vpos` is the per-lane copy of `pos` (ring addresses), `lane4` = 4 * lane.  Relies on the ring sitting at LDS
+// address 0 (checked by the kernel).
+template <int RING>
+__device__ __forceinline__ uint32_t literal_run(BitReader& br, uint32_t& pos, uint32_t& vpos, uint32_t lane4, uint32_t& e) {
+  uint32_t why, vt, ve;
+  uint64_t buf = br.buf;
+  int cnt = br.cnt;
+  uint32_t widx = br.widx;
+  asm volatile(
+      "L_lit_loop%=:\n"
+      "  s_cmp_gt_i32 s82, 32\n"
+      "  s_cbranch_scc1 L_lit_have%=\n"
+      "  s_waitcnt vmcnt(0)\n"
+      "  v_readlane_b32 s90, %[cur], s83\n"
+      "  s_mov_b32 s91, 0\n"
+      "  s_lshl_b64 s[90:91], s[90:91], s82\n"
+      "  s_or_b64 s[80:81], s[80:81], s[90:91]\n"
+      "  s_add_i32 s82, s82, 32\n"
+      "  s_add_i32 s83, s83, 1\n"
+      "  s_and_b32 s87, s83, 63\n"
+      "  s_cbranch_scc1 L_lit_have%=\n"
+      "  v_lshl_add_u32 %[vt], s83, 2, %[lane4]\n"
+      "  global_load_dword %[cur], %[vt], s[88:89]\n"
+      "L_lit_have%=:\n"
+      "  v_lshlrev_b32 %[vt], 2, s80\n"
+      "  v_and_b32 %[vt], %[lutmask], %[vt]\n"
+      "  ds_read_b32 %[ve], %[vt] offset:%[lutoff]\n"
+      "  s_waitcnt lgkmcnt(0)\n"
+      "  v_readfirstlane_b32 s85, %[ve]\n"
+      "  s_bitcmp1_b32 s85, 8\n"
+      "  s_cbranch_scc0 L_lit_other%=\n"
+      "  s_and_b32 s87, s85, 15\n"
+      "  s_lshr_b64 s[80:81], s[80:81], s87\n"
+      "  s_sub_i32 s82, s82, s87\n"
+      "  v_and_b32 %[vt], %[ringmask], %[vpos]\n"
+      "  ds_write_b8_d16_hi %[vt], %[ve]\n"
+      "  v_add_u32 %[vpos], 1, %[vpos]\n"
+      "  s_add_i32 s84, s84, 1\n"
+      "  s_and_b32 s87, s84, 0xff\n"
+      "  s_cbranch_scc1 L_lit_loop%=\n"
+      "  s_mov_b32 s86, 1\n"
+      "  s_branch L_lit_out%=\n"
+      "L_lit_other%=:\n"
+      "  s_mov_b32 s86, 0\n"
+      "L_lit_out%=:\n"
+      "  s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+      : [buf] "+{s[80:81]}"(buf), [cnt] "+{s82}"(cnt), [widx] "+{s83}"(widx), [pos] "+{s84}"(pos), [e] "={s85}"(e), [why] "={s86}"(why),
+        [cur] "+v"(br.cur), [vpos] "+v"(vpos), [vt] "=&v"(vt), [ve] "=&v"(ve)
+      : [base] "{s[88:89]}"(br.base), [lane4] "v"(lane4), [lutmask] "i"(((1 << LIT_BITS) - 1) << 2), [ringmask] "i"(RING - 1),
+        [lutoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_lut))
+      : "s87", "s90", "s91", "scc", "memory");
+  // asm results count as divergent for the compiler even in scalar registers: say otherwise (folds to plain copies)
+  br.buf = ((uint64_t)uniu((uint32_t)(buf >> 32)) << 32) | uniu((uint32_t)buf);
+  br.cnt = uni(cnt);
+  br.widx = uniu(widx);
+  pos = uniu(pos);
+  e = uniu(e);
+  return uniu(why);
+}
+
 template <int RING>
 __device__ __noinline__ SymResult decode_symbols(BitReader br, Out o) {
   constexpr uint32_t M = RING - 1;
@@ -428,10 +512,17 @@ __device__ __noinline__ SymResult decode_symbols(BitReader br, Out o) {
   uint8_t* ring = wave_ring<RING>();
   const WaveLds* L = wave_lds<RING>();
   const uint32_t lane = lane_id();
+  uint32_t vpos = o.pos;  // per-lane copy of o.pos: ring addresses of literals come from the vector ALU (literal_run)
+  const uint32_t lane4 = lane * 4u;
+  (void)vpos;
+  (void)lane4;
   for (;;) {
+    uint32_t e;
+#if EXON_INFLATE_LIT == 0
     br.refill();
-    const uint32_t e = decode_symbol<RING, CODE_LIT>(br, L);
-    if (e & E_LIT) {
+    e = uniu(L->lit_lut[br.peek(LIT_BITS)]);
+    if (e & E_LIT) {  // literal with a first-level code (its length field is never 0)
+      br.drop((int)(e & 15u));
       ring[o.pos & M] = (uint8_t)(e >> 16);  // every lane stores the same byte
       ++o.pos;
       if (__builtin_expect((o.pos & 255u) == 0, 0)) {
@@ -439,6 +530,31 @@ __device__ __noinline__ SymResult decode_symbols(BitReader br, Out o) {
         o.drained = uniu(drain_rows<RING>(o.out, o.drained, o.pos));
       }
       continue;
+    }
+#else
+    if (literal_run<RING>(br, o.pos, vpos, lane4, e)) {  // a 256-byte row of the ring is complete
+      if (o.pos > o.end || br.overrun()) return SymResult{br, o, br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN};
+      o.drained = uniu(drain_rows<RING>(o.out, o.drained, o.pos & ~255u));
+      continue;
+    }
+#endif
+    if ((e & 15u) == 0) {  // a code longer than the table, or no such code
+      const int r = uni(decode_long<RING>(CODE_LIT, (uint32_t)br.buf));
+      if (r < 0) return SymResult{br, o, INF_BAD_CODE};
+      br.drop(r & 255);
+      e = entry_for(CODE_LIT, r >> 8) | (uint32_t)(r & 255);
+      if (e & E_LIT) {
+        ring[o.pos & M] = (uint8_t)(e >> 16);  // every lane stores the same byte
+        ++o.pos;
+        vpos = o.pos;
+        if ((o.pos & 255u) == 0) {
+          if (o.pos > o.end || br.overrun()) return SymResult{br, o, br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN};
+          o.drained = uniu(drain_rows<RING>(o.out, o.drained, o.pos));
+        }
+        continue;
+      }
+    } else {
+      br.drop((int)(e & 15u));
     }
     if (__builtin_expect((e & (E_EOB | E_INVALID)) != 0, 0)) {
       return SymResult{br, o, (e & E_EOB) ? INF_OK : INF_BAD_CODE};
@@ -466,8 +582,8 @@ __device__ __noinline__ SymResult decode_symbols(BitReader br, Out o) {
       o.drained = uniu(drain_rows<RING>(o.out, o.drained, npos & ~255u));
     }
     o.pos = npos;
+    vpos = npos;
   }
-
 }
 
 template <int RING>
@@ -479,6 +595,10 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(const uint8_t* __res
   if (b >= n_blocks) return;
   WaveLds* L = wave_lds<RING>();
   uint8_t* ring = wave_ring<RING>();
+  if (lds_addr(smem) != 0) {  // literal_run addresses the ring and the table with immediates (folds away when true)
+    if (lane == 0) status[b] = INF_BAD_BTYPE;
+    return;
+  }
   const Block blk = blocks[b];
   const uint32_t comp_end = blk.comp_offset + blk.comp_size;
 
