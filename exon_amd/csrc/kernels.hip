@@ -1061,7 +1061,8 @@ __device__ void k5_path_ragged(const int32_t* __restrict__ off, const int32_t* _
 // d_hist[p][b] += sum over workgroups of partial[wg][p][b]  (p < pt, b < 128).  blockIdx.y splits the workgroup
 // range 8 ways (integer adds commute, so the segment sums are merged with atomics: still bit-exact).
 __global__ __launch_bounds__(256) void k5_finalize(const unsigned long long* __restrict__ partials, int nblocks, int pt,
-                                                   unsigned long long* __restrict__ d_hist) {
+                                                   unsigned long long* __restrict__ d_hist, int* __restrict__ flags) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) flags[0] = 0;  // ready for the next batch's offsets scan
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= pt * 128) return;
   const size_t W = (size_t)pt * 128;
@@ -1097,8 +1098,10 @@ hipError_t launch_qual_pos_hist_views(hipStream_t s, const LaunchCfg& cfg, const
   const int grid = cfg.compute_units;
   int* flags = ws.status + 1;
   unsigned long long* hist = reinterpret_cast<unsigned long long*>(d_hist);
-  hipError_t e = hipMemsetAsync(flags, 0, sizeof(int), s);
-  if (e != hipSuccess) return e;
+  // flags[0] is zero here: the workspace starts zeroed and k5_finalize, the last kernel of every batch, resets it
+  // (a memset per batch would be a fourth launch; a launch that fails midway can leave it set, which only costs speed:
+  // the ragged path is correct for uniform reads too)
+  hipError_t e;
   int sgrid = (int)std::min<int64_t>((n_reads + 255) / 256, (int64_t)cfg.compute_units * 8);
   hipLaunchKernelGGL(k5_scan_offsets, dim3(sgrid), dim3(256), 0, s, offsets, ends, n_reads, lmax, flags, ws.status);
   // LDS block: the larger of the byte-major [128][LP] layout (paths A and G) and the [pt][129] layout (B, long G)
@@ -1117,7 +1120,7 @@ hipError_t launch_qual_pos_hist_views(hipStream_t s, const LaunchCfg& cfg, const
   else hipLaunchKernelGGL(k5_main<128>, dim3(grid), dim3(K5_THREADS), lds, s, offsets, ends, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k5_finalize, dim3((pt * 128 + 255) / 256, 8), dim3(256), 0, s, ws.partials, grid, pt, hist);
+  hipLaunchKernelGGL(k5_finalize, dim3((pt * 128 + 255) / 256, 8), dim3(256), 0, s, ws.partials, grid, pt, hist, flags);
   return hipGetLastError();
 }
 
