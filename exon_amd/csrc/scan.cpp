@@ -337,7 +337,8 @@ static double now_s() {
 // ---- text slabs in HBM ----------------------------------------------------------------------------------------------
 // Feeds the GPU-side parsers with slabs of text resident in HBM.  The consumer reports how many bytes of a slab form
 // whole records (the device knows, the host never looks at the text); the tail is carried in front of the next slab.
-//   plain text : file -> pinned slab (8-thread pread, filled by a background thread behind a reserved gap) -> HBM
+//   plain text : file -> pinned slab (8-thread pread, filled by a background thread behind a reserved gap) -> HBM on a
+//                copy stream of its own, under the parse of the previous slab; the carried tail moves device-to-device
 //   BGZF       : compressed file -> pinned -> HBM as it is -> inflated ON THE GPU (inflate.hip) -> text; the carried tail
 //                moves device-to-device.  3-5x fewer bytes cross PCIe and no host core inflates anything.
 // next() returns 1 for "give up, decode on the host" (a corrupt block, a record larger than the gap).
@@ -483,14 +484,15 @@ class GpuTextSource {
       }
       complete_ = true;
     }
+    if ((bgzf_ && !cs_ && hipStreamCreateWithFlags(&cs_, hipStreamNonBlocking) != hipSuccess) ||
+        (!xs_ && hipStreamCreateWithFlags(&xs_, hipStreamNonBlocking) != hipSuccess))
+      return fail(ctx_, EXON_HIP_EDEVICE, "stream creation failed");
+    for (int k = 0; k < 2; ++k)
+      if (!ev_free_[k] && (hipEventCreateWithFlags(&ev_h2d_[k], hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&ev_done_[k], hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&ev_free_[k], hipEventDisableTiming) != hipSuccess))
+        return fail(ctx_, EXON_HIP_EDEVICE, "event creation failed");
     if (bgzf_) {
-      if (!cs_ && (hipStreamCreateWithFlags(&cs_, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&xs_, hipStreamNonBlocking) != hipSuccess))
-        return fail(ctx_, EXON_HIP_EDEVICE, "stream creation failed");
-      for (int k = 0; k < 2; ++k)
-        if (!ev_free_[k] && (hipEventCreateWithFlags(&ev_h2d_[k], hipEventDisableTiming) != hipSuccess ||
-                             hipEventCreateWithFlags(&ev_done_[k], hipEventDisableTiming) != hipSuccess ||
-                             hipEventCreateWithFlags(&ev_free_[k], hipEventDisableTiming) != hipSuccess))
-          return fail(ctx_, EXON_HIP_EDEVICE, "event creation failed");
       fill(0, &f_[0]);
       if (f_[0].err) return rethrow(f_[0].err);
       int rc = enqueue_inflate(0);
@@ -498,6 +500,7 @@ class GpuTextSource {
       if (!f_[0].eof) reader_ = std::thread([this] { fill(1, &f_[1]); });
       return EXON_HIP_OK;
     }
+    if (carry_.size() > gap_) return 1;  // the host reader had buffered more than the gap holds: host decoder
     fill(0, &cur_);
     k_ = 0;
     return EXON_HIP_OK;
@@ -518,19 +521,31 @@ class GpuTextSource {
     }
     const int k = k_;
     const bool more = !cur_.eof;
-    if (more) reader_ = std::thread([this, k] { fill(k ^ 1, &nxt_); });  // overlaps with everything the GPU does below
     *final = !more;
-    size_t n_text = 0;
-    size_t front = 0;  // offset of the slab's first byte inside d_text_[k]
-    {
-      if (carry_.size() > gap_) return 1;  // a record larger than the gap: host decoder
-      uint8_t* base = h_buf_[k] + gap_ - carry_.size();
-      memcpy(base, carry_.data(), carry_.size());
-      n_text = carry_.size() + cur_.n;
-      carry_.clear();
-      if (!more && n_text > 0 && base[n_text - 1] != '\n') base[n_text++] = '\n';  // last line without a terminator
-      if (n_text) HIP_TRY(ctx_, hipMemcpyAsync(d_text_[k], base, n_text, hipMemcpyHostToDevice, hs_));
-      h_base_ = base;
+    // The fresh bytes are already on their way to d_text_[k] + gap_ (the reader queued that copy on the copy stream the
+    // moment it had them, under the parse of the previous slab); the tail carried from the previous slab is copied
+    // device-to-device right in front of them.  The first slab carries what the host header reader had buffered.
+    size_t front = gap_ - carry_dev_, n_text = carry_dev_ + cur_.n;
+    if (carry_dev_) HIP_TRY(ctx_, hipMemcpyAsync(d_text_[k] + front, d_text_[carry_k_] + carry_off_, carry_dev_, hipMemcpyDeviceToDevice, hs_));
+    carry_dev_ = 0;
+    if (cur_.front_extra) {
+      front = gap_ - cur_.front_extra;
+      n_text = cur_.front_extra + cur_.n;
+    }
+    HIP_TRY(ctx_, hipStreamWaitEvent(hs_, ev_h2d_[k], 0));
+    if (started_prev_) {  // everything the consumer queued on slab i-1 (and the copy out of it) precedes the reuse of its buffer
+      HIP_TRY(ctx_, hipEventRecord(ev_free_[k ^ 1], hs_));
+      free_rec_[k ^ 1] = true;
+    }
+    started_prev_ = true;
+    if (more) reader_ = std::thread([this, k] { fill(k ^ 1, &nxt_); });  // overlaps with everything the GPU does below
+    if (!more && n_text > 0) {  // last line without a terminator (a carried tail never ends in one)
+      // the slab's last byte is on the host unless the slab is a carried tail only (cur_.n and front_extra both 0)
+      const bool ends_nl = (cur_.n > 0 || cur_.front_extra > 0) && h_buf_[k][gap_ + cur_.n - 1] == '\n';
+      if (!ends_nl) {
+        HIP_TRY(ctx_, hipMemsetAsync(d_text_[k] + front + n_text, '\n', 1, hs_));
+        ++n_text;
+      }
     }
     cur_front_ = front;
     cur_text_ = n_text;
@@ -544,15 +559,11 @@ class GpuTextSource {
     const size_t tail = cur_text_ - consumed;
     if (final) return tail == 0 ? EXON_HIP_OK : 1;  // a partial record at the end of the input: host decoder decides
     if (tail > gap_) return 1;
-    if (bgzf_) {
-      // copied device-to-device in front of the next slab's text when that slab is taken (next_bgzf)
-      carry_k_ = (int)(idx_ & 1);
-      carry_off_ = cur_front_ + consumed;
-      carry_dev_ = tail;
-      ++idx_;
-    } else {
-      carry_.assign(reinterpret_cast<const char*>(h_base_) + consumed, tail);
-    }
+    // copied device-to-device in front of the next slab's text when that slab is taken
+    carry_k_ = bgzf_ ? (int)(idx_ & 1) : k_;
+    carry_off_ = cur_front_ + consumed;
+    carry_dev_ = tail;
+    if (bgzf_) ++idx_;
     return EXON_HIP_OK;
   }
 
@@ -644,6 +655,7 @@ class GpuTextSource {
     size_t n = 0;          // plain: fresh text bytes behind the gap; bgzf: compressed bytes of whole blocks
     int n_blocks = 0;      // bgzf
     size_t out_bytes = 0;  // bgzf: inflated size of those blocks
+    size_t front_extra = 0;  // plain, first slab: bytes of the host reader's buffer placed in front of the fresh ones
     bool eof = false;
     std::exception_ptr err;
   };
@@ -655,6 +667,19 @@ class GpuTextSource {
       if (!bgzf_) {
         f->n = rd_.read(h_buf_[k] + gap_, text_cap_);
         f->eof = f->n < text_cap_;
+        f->front_extra = 0;
+        if (!carry_.empty()) {  // first slab: what the host header reader had already buffered goes in front
+          memcpy(h_buf_[k] + gap_ - carry_.size(), carry_.data(), carry_.size());
+          f->front_extra = carry_.size();
+          carry_.clear();
+        }
+        // the bytes start crossing PCIe right away on the copy stream, under the parse of the previous slab
+        hipSetDevice(ctx_->device);
+        if ((free_rec_[k] && hipStreamWaitEvent(xs_, ev_free_[k], 0) != hipSuccess) ||
+            (f->n + f->front_extra > 0 && hipMemcpyAsync(d_text_[k] + gap_ - f->front_extra, h_buf_[k] + gap_ - f->front_extra, f->n + f->front_extra,
+                                                          hipMemcpyHostToDevice, xs_) != hipSuccess) ||
+            hipEventRecord(ev_h2d_[k], xs_) != hipSuccess)
+          throw std::runtime_error("H2D of a text slab failed");
         return;
       }
       // [blocks left over from the previous chunk | fresh bytes]; whole blocks only, inflated size <= text_cap_
@@ -743,8 +768,7 @@ class GpuTextSource {
   bool enq_[2] = {false, false}, free_rec_[2] = {false, false};
   std::thread reader_;
   int k_ = 0;
-  bool started_ = false;
-  uint8_t* h_base_ = nullptr;
+  bool started_ = false, started_prev_ = false;
   size_t cur_front_ = 0, cur_text_ = 0;
 };
 
