@@ -350,15 +350,13 @@ template <int RING, int WHICH>
 __device__ __forceinline__ uint32_t decode_symbol(BitReader& br, const WaveLds* L) {
   const uint32_t* lut = WHICH == CODE_LIT ? L->lit_lut : WHICH == CODE_DIST ? L->dist_lut : L->cl.cl_lut;
   constexpr int BITS = WHICH == CODE_LIT ? LIT_BITS : WHICH == CODE_DIST ? DIST_BITS : CL_BITS;
-  const uint32_t e = uniu(lut[br.peek(BITS)]);
-  if (__builtin_expect((e & 15u) != 0, 1)) {
-    br.drop((int)(e & 15u));
-    return e;
+  uint32_t e = uniu(lut[br.peek(BITS)]);
+  if (__builtin_expect((e & 15u) == 0, 0)) {
+    const int r = uni(decode_long<RING>(WHICH, (uint32_t)br.buf));
+    e = r < 0 ? (uint32_t)E_INVALID : entry_for(WHICH, r >> 8) | (uint32_t)(r & 255);  // lengths <= 15 fit the length field
   }
-  const int r = uni(decode_long<RING>(WHICH, (uint32_t)br.buf));
-  if (r < 0) return E_INVALID;
-  br.drop(r & 255);
-  return entry_for(WHICH, r >> 8) | (uint32_t)(r & 255);
+  br.drop((int)(e & 15u));  // one merge point for the short and the long code (no flag threaded through the hot path)
+  return e;
 }
 
 struct Block {  // == exon_hip_bgzf_block
@@ -538,26 +536,22 @@ __device__ __noinline__ SymResult decode_symbols(BitReader br, Out o) {
       continue;
     }
 #endif
-    if ((e & 15u) == 0) {  // a code longer than the table, or no such code
+    if (__builtin_expect((e & 15u) == 0, 0)) {  // a code longer than the table, or no such code
       const int r = uni(decode_long<RING>(CODE_LIT, (uint32_t)br.buf));
-      if (r < 0) return SymResult{br, o, INF_BAD_CODE};
-      br.drop(r & 255);
-      e = entry_for(CODE_LIT, r >> 8) | (uint32_t)(r & 255);
-      if (e & E_LIT) {
-        ring[o.pos & M] = (uint8_t)(e >> 16);  // every lane stores the same byte
-        ++o.pos;
-        vpos = o.pos;
-        if ((o.pos & 255u) == 0) {
-          if (o.pos > o.end || br.overrun()) return SymResult{br, o, br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN};
-          o.drained = uniu(drain_rows<RING>(o.out, o.drained, o.pos));
-        }
-        continue;
-      }
-    } else {
-      br.drop((int)(e & 15u));
+      // lengths are <= 15: the entry's length field holds it; no such code -> E_INVALID (caught below, no exit from here)
+      e = r < 0 ? (uint32_t)E_INVALID : entry_for(CODE_LIT, r >> 8) | (uint32_t)(r & 255);
     }
-    if (__builtin_expect((e & (E_EOB | E_INVALID)) != 0, 0)) {
-      return SymResult{br, o, (e & E_EOB) ? INF_OK : INF_BAD_CODE};
+    br.drop((int)(e & 15u));
+    if (__builtin_expect((e & (E_LIT | E_EOB | E_INVALID)) != 0, 0)) {
+      if (!(e & E_LIT)) return SymResult{br, o, (e & E_EOB) ? INF_OK : INF_BAD_CODE};
+      ring[o.pos & M] = (uint8_t)(e >> 16);  // a literal with a long code; every lane stores the same byte
+      ++o.pos;
+      vpos = o.pos;
+      if ((o.pos & 255u) == 0) {
+        if (o.pos > o.end || br.overrun()) return SymResult{br, o, br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN};
+        o.drained = uniu(drain_rows<RING>(o.out, o.drained, o.pos));
+      }
+      continue;
     }
     const uint32_t len = (e >> 16) + br.take((int)((e >> 4) & 15u));
     br.refill();
