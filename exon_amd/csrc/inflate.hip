@@ -514,6 +514,7 @@ __device__ __noinline__ SymResult decode_symbols(BitReader br, Out o) {
   const uint32_t lane4 = lane * 4u;
   (void)vpos;
   (void)lane4;
+  int err;  // every way out of the loop goes through ONE exit (several exit blocks cost a state variable on the back edge)
   for (;;) {
     uint32_t e;
 #if EXON_INFLATE_LIT == 0
@@ -524,14 +525,14 @@ __device__ __noinline__ SymResult decode_symbols(BitReader br, Out o) {
       ring[o.pos & M] = (uint8_t)(e >> 16);  // every lane stores the same byte
       ++o.pos;
       if (__builtin_expect((o.pos & 255u) == 0, 0)) {
-        if (o.pos > o.end || br.overrun()) return SymResult{br, o, br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN};
+        if (o.pos > o.end || br.overrun()) { err = br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN; break; }
         o.drained = uniu(drain_rows<RING>(o.out, o.drained, o.pos));
       }
       continue;
     }
 #else
     if (literal_run<RING>(br, o.pos, vpos, lane4, e)) {  // a 256-byte row of the ring is complete
-      if (o.pos > o.end || br.overrun()) return SymResult{br, o, br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN};
+      if (o.pos > o.end || br.overrun()) { err = br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN; break; }
       o.drained = uniu(drain_rows<RING>(o.out, o.drained, o.pos & ~255u));
       continue;
     }
@@ -543,12 +544,12 @@ __device__ __noinline__ SymResult decode_symbols(BitReader br, Out o) {
     }
     br.drop((int)(e & 15u));
     if (__builtin_expect((e & (E_LIT | E_EOB | E_INVALID)) != 0, 0)) {
-      if (!(e & E_LIT)) return SymResult{br, o, (e & E_EOB) ? INF_OK : INF_BAD_CODE};
+      if (!(e & E_LIT)) { err = (e & E_EOB) ? INF_OK : INF_BAD_CODE; break; }
       ring[o.pos & M] = (uint8_t)(e >> 16);  // a literal with a long code; every lane stores the same byte
       ++o.pos;
       vpos = o.pos;
       if ((o.pos & 255u) == 0) {
-        if (o.pos > o.end || br.overrun()) return SymResult{br, o, br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN};
+        if (o.pos > o.end || br.overrun()) { err = br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN; break; }
         o.drained = uniu(drain_rows<RING>(o.out, o.drained, o.pos));
       }
       continue;
@@ -556,9 +557,9 @@ __device__ __noinline__ SymResult decode_symbols(BitReader br, Out o) {
     const uint32_t len = (e >> 16) + br.take((int)((e >> 4) & 15u));
     br.refill();
     const uint32_t de = decode_symbol<RING, CODE_DIST>(br, L);
-    if (__builtin_expect((de & E_INVALID) != 0, 0)) return SymResult{br, o, INF_BAD_CODE};
+    if (__builtin_expect((de & E_INVALID) != 0, 0)) { err = INF_BAD_CODE; break; }
     const uint32_t d = (de >> 16) + br.take((int)((de >> 4) & 15u));
-    if (__builtin_expect(d > o.pos - o.begin, 0)) return SymResult{br, o, INF_BAD_DISTANCE};
+    if (__builtin_expect(d > o.pos - o.begin, 0)) { err = INF_BAD_DISTANCE; break; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (d - len <= NEAR - len) {  // len <= d <= NEAR (unsigned wrap-around when d < len)
       for (uint32_t j = lane; j < len; j += 64) ring[(o.pos + j) & M] = ring[(o.pos - d + j) & M];
@@ -572,12 +573,13 @@ __device__ __noinline__ SymResult decode_symbols(BitReader br, Out o) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const uint32_t npos = o.pos + len;
     if (__builtin_expect(((o.pos ^ npos) >> 8) != 0, 0)) {  // crossed a 256-byte row
-      if (npos > o.end || br.overrun()) return SymResult{br, o, br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN};
+      if (npos > o.end || br.overrun()) { err = br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN; break; }
       o.drained = uniu(drain_rows<RING>(o.out, o.drained, npos & ~255u));
     }
     o.pos = npos;
     vpos = npos;
   }
+  return SymResult{br, o, err};
 }
 
 template <int RING>
