@@ -562,13 +562,21 @@ __device__ __noinline__ SymResult decode_symbols(BitReader br, Out o) {
     if (__builtin_expect(d > o.pos - o.begin, 0)) { err = INF_BAD_DISTANCE; break; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (d - len <= NEAR - len) {  // len <= d <= NEAR (unsigned wrap-around when d < len)
-      for (uint32_t j = lane; j < len; j += 64) ring[(o.pos + j) & M] = ring[(o.pos - d + j) & M];
+      if (len <= 64) {  // nearly all matches: one masked read + write, no loop bookkeeping
+        if (lane < len) ring[(o.pos + lane) & M] = ring[(o.pos - d + lane) & M];
+      } else {
+        for (uint32_t j = lane; j < len; j += 64) ring[(o.pos + j) & M] = ring[(o.pos - d + j) & M];
+      }
     } else if (d <= NEAR) {
       copy_overlapping<RING>(o.pos, d, len);
     } else {
       // far: d > NEAR >= 258 + 255, so the source ends below `drained` (pos - drained < 256): it is in HBM already
       // (common: DEFLATE windows are 32 KiB, the ring holds 2) -- inline, a call costs ~40 scalar instructions
-      for (uint32_t j = lane; j < len; j += 64) ring[(o.pos + j) & M] = o.out[o.pos - d + j];
+      if (len <= 64) {
+        if (lane < len) ring[(o.pos + lane) & M] = o.out[o.pos - d + lane];
+      } else {
+        for (uint32_t j = lane; j < len; j += 64) ring[(o.pos + j) & M] = o.out[o.pos - d + j];
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const uint32_t npos = o.pos + len;
