@@ -286,9 +286,18 @@ struct SlabReader {
       }
       return have;
     }
-    const int T = 8;
+    // positional reads from the page cache; 8 threads saturate it (16 and 24 measured no faster: the copy out of the
+    // page cache competes with the DMA engine for the same memory).  EXON_HIP_READ_THREADS overrides.
+    static const int T = [] {
+      int t = 8;
+      if (const char* v = getenv("EXON_HIP_READ_THREADS")) {
+        const int x = atoi(v);
+        if (x >= 1 && x <= 32) t = x;
+      }
+      return t;
+    }();
     const size_t per = (n + T - 1) / T;
-    size_t got[T] = {0};
+    size_t got[32] = {0};
     std::vector<std::thread> th;
     for (int t = 0; t < T; ++t) {
       const size_t o = (size_t)t * per;
