@@ -667,12 +667,15 @@ class SAMBatchReader {
  public:
   SAMBatchReader(const std::string& path, Compression c, BAMConfig cfg) : r_(path, c), cfg_(std::move(cfg)) {
     std::string line;
+    uint64_t before = r_.consumed();
     while (r_.read_line(&line)) {
       if (line.empty() || line[0] != '@') {
         pending_ = line;
         has_pending_ = !line.empty();
+        data_offset_ = (int64_t)before;
         break;
       }
+      before = r_.consumed();
       if (line.rfind("@SQ", 0) == 0) {  // @SQ SN:<name> LN:<len>
         std::string name;
         int32_t len = 0;
@@ -696,6 +699,9 @@ class SAMBatchReader {
   }
 
   const BAMConfig& config() const { return cfg_; }
+  // Uncompressed offset of the first alignment line (header length), for callers that re-open the file themselves
+  // (GPU-side BGZF inflate of a bgzip-compressed SAM); the end of the input when there are no alignment lines.
+  int64_t data_offset() const { return data_offset_ >= 0 ? data_offset_ : (int64_t)r_.consumed(); }
   // the alignment lines as a raw byte stream (GPU-side parsing); only valid before the first read_batch
   std::unique_ptr<ByteSource> take_stream(std::string* carry) {
     *carry = has_pending_ ? pending_ + "\n" : std::string();
@@ -771,6 +777,7 @@ class SAMBatchReader {
   BAMConfig cfg_;
   std::string pending_;
   bool has_pending_ = false;
+  int64_t data_offset_ = -1;
   int32_t region_ref_id_ = -2;
 };
 

@@ -792,8 +792,7 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
   hipStream_t hs = (hipStream_t)exon_hip_stream_hip_stream(st);
   const bool is_vcf = scan->vcf != nullptr, is_bam = scan->bam != nullptr, is_bcf = scan->bcf != nullptr, is_sam = scan->sam != nullptr;
   std::unique_ptr<GpuTextSource> src;
-  // SAM text is taken from its reader's (host-inflated, when compressed) stream: the header length is not tracked there
-  const bool bgzf = !is_sam && gpu_inflate_enabled() && scan->opt.compression != EXON_HIP_COMPRESSION_NONE &&
+  const bool bgzf = gpu_inflate_enabled() && scan->opt.compression != EXON_HIP_COMPRESSION_NONE &&
                     exon::BgzfParallelSource::is_bgzf(scan->path) && (!is_vcf || scan->vcf->data_offset() >= 0);
   if ((is_bam || is_bcf) && !bgzf) return 1;
   try {
@@ -801,6 +800,7 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
       const uint64_t skip = is_vcf   ? (uint64_t)scan->vcf->data_offset()
                             : is_bam ? (uint64_t)scan->bam->data_offset()
                             : is_bcf ? (uint64_t)scan->bcf->data_offset()
+                            : is_sam ? (uint64_t)scan->sam->data_offset()
                                      : 0;
       std::unique_ptr<exon::ByteSource> raw(new exon::ByteReader(scan->path, exon::Compression::None));
       src.reset(new GpuTextSource(ctx, hs, std::move(raw), true, skip, std::string(), is_bam || is_bcf));

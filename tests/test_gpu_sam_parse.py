@@ -14,7 +14,7 @@ FX = os.path.join(ROOT, "tests", "golden", "ref_fixtures")
 GEN = os.path.join(ROOT, "tools", "bin", "gen_text")
 
 
-def _k3(ctx, path, gpu_parse, fallback=False, compression=None):
+def _k3(ctx, path, gpu_parse, fallback=False, compression=None, inflated=None):
     scan = exon_amd.Scan(str(path), "sam", gpu_parse=gpu_parse, compression=compression)
     refs = scan.dictionary(2)
     plan = ctx.plan_flag_mapq_group_count(1284, 0, 30, len(refs), columns=(0, 1, 2))
@@ -22,6 +22,8 @@ def _k3(ctx, path, gpu_parse, fallback=False, compression=None):
     rows = st.consume(scan)
     counts, _ = st.finish()
     assert scan.decoded_on_gpu()[0] == (bool(gpu_parse) and not fallback), "silent host fallback"
+    if inflated is not None:
+        assert scan.decoded_on_gpu()[1] == inflated
     st.close(); plan.close(); scan.close()
     return rows, np.array(counts)
 
@@ -55,14 +57,24 @@ def test_sam_file_to_gpu_pipeline_equals_host_decode(ctx, tmp_path, monkeypatch,
     assert _k6(ctx, path, True, "chr7", 50_000_000, 100_000_000) == _k6(ctx, path, False, "chr7", 50_000_000, 100_000_000)
 
 
-def test_sam_gz_host_inflated_stream_parsed_on_the_gpu(ctx, tmp_path):
+def test_sam_bgzf_is_inflated_and_parsed_on_the_gpu(ctx, tmp_path, monkeypatch):
+    """bgzip-compressed SAM: the blocks are inflated by inflate.hip and the text never visits the host; a plain gzip
+    member (not BGZF) is inflated by the host reader and still parsed on the device."""
+    import gzip
     n = 100_000
     path = tmp_path / "syn.sam"
     subprocess.check_call([GEN, "sam", str(n), str(path), "100"])
     gz = tmp_path / "syn.sam.gz"
     subprocess.check_call([os.path.join(ROOT, "tools", "bin", "bgzip"), str(path), str(gz), "6"])
-    g, h = _k3(ctx, gz, True, compression="gzip"), _k3(ctx, path, False)
+    h = _k3(ctx, path, False)
+    monkeypatch.setenv("EXON_HIP_GPU_PARSE_SLAB_MB", "4")  # several slabs: records straddle inflated-slab boundaries
+    g = _k3(ctx, gz, True, compression="gzip", inflated=True)
     assert g[0] == h[0] == n and np.array_equal(g[1], h[1])
+    plain_gz = tmp_path / "member.sam.gz"
+    with gzip.open(plain_gz, "wb", compresslevel=1) as f:
+        f.write(open(path, "rb").read())
+    g2 = _k3(ctx, plain_gz, True, compression="gzip", inflated=False)
+    assert g2[0] == n and np.array_equal(g2[1], h[1])
 
 
 def test_sam_lines_the_device_cannot_decide_fall_back(ctx, tmp_path):
