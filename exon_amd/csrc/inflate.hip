@@ -8,16 +8,19 @@
 // (<= 64 KiB of text each), so a slab of compressed blocks crosses PCIe as it is (3-5x fewer bytes than text) and
 // is inflated by one wavefront per block.
 //
-// One wavefront per block:
+// One wavefront per block (k_inflate, one wavefront per workgroup, 6.2 KB of static LDS -> 24 per CU):
 //   * the bit stream is consumed by wave-uniform (scalar) code; the compressed bytes sit in a 256-byte window held
-//     across the lanes of one VGPR (next window prefetched) and are pulled out with v_readlane -- no memory latency on
-//     the symbol-decode chain;
-//   * Huffman tables live in LDS (3.9 KB per wave): a 10-bit (literal/length) and an 8-bit (distance) first-level
-//     table built lane-parallel from the code lengths (ballot ranks give the canonical codes), a bit-serial canonical
-//     decode (count/first arrays) for the rare longer codes;
-//   * literals are collected in one VGPR (lane = output address & 63) and leave as one coalesced 64-byte store;
-//     matches are copied lane-parallel from the already written output in HBM (same-wave store -> load order is
-//     program order on CDNA), overlapping runs (distance < length) by modular addressing.
+//     across the lanes of one VGPR and are pulled out with v_readlane -- no memory latency on the symbol-decode chain;
+//   * Huffman tables live in LDS: a 9-bit (literal/length) and an 8-bit (distance) first-level table whose entries
+//     are complete decode results (literal byte / length or distance base + extra-bit count + code length), built
+//     lane-parallel from the code lengths (ballot ranks give the canonical codes); a bit-serial canonical decode
+//     (count/first arrays) serves the rare longer codes;
+//   * the last 2 KiB of output stay in an LDS ring: literals and near matches are LDS stores / LDS->LDS copies
+//     (overlapping runs, distance < length, by modular addressing), farther matches read the output already drained
+//     to HBM; the ring is drained in aligned 256-byte rows, one dword per lane;
+//   * the literal loop is hand-written (literal_run); the kernel is bound by instruction issue, so the rest of the
+//     symbol loop is kept free of flags and state variables the compiler would otherwise thread through it
+//     (one merge point for long codes, one exit block, rare paths out of line).  Tuning log: profiles/r1_tuning.md.
 // Every block reports a status; any failure makes the caller inflate on the host instead.  The CRC-32 of every
 // inflated block is checked by a second kernel (k_crc32: 64 slices per block, combined in GF(2)[x] mod P).
 #include <hip/hip_runtime.h>

@@ -402,7 +402,7 @@ class GpuTextSource {
     slab_ = slab_bytes();
     if (bgzf_) {
       // One wavefront inflates one block and a block takes ~3.5 ms however many run beside it, so a launch wants as many
-      // blocks as the chip holds wavefronts of this kernel (25 per CU x 256 CUs) and not one more: slabs are cut by BLOCK
+      // blocks as the chip holds wavefronts of this kernel (24 per CU x 256 CUs) and not one more: slabs are cut by BLOCK
       // COUNT.  The bytes read per slab follow the running average block size.
       target_blocks_ = (int)std::max<size_t>(64, 6144 * (slab_ >> 20) / 64);
       comp_cap_ = 2 * slab_ + (1u << 17);           // compressed bytes per slab (+ a carried partial block)
