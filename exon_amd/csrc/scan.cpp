@@ -751,8 +751,8 @@ class GpuTextSource {
   SlabReader rd_;
   bool bgzf_, binary_;
   uint64_t skip_;
-  std::string carry_;      // plain: carried tail (host)
-  size_t carry_dev_ = 0;   // bgzf: carried tail already at the front of the next text buffer
+  std::string carry_;      // plain: what the host header reader had buffered (goes in front of the first slab)
+  size_t carry_dev_ = 0;   // bytes of the carried tail (lives in d_text_[carry_k_] at carry_off_ until the next slab is taken)
   size_t slab_ = 0, comp_cap_ = 0, text_cap_ = 0, gap_ = 0, hcap_ = 0;
   bool complete_ = false;  // all buffers allocated (only complete sets go back to the cache)
   uint8_t* h_buf_[2] = {nullptr, nullptr};
@@ -770,7 +770,7 @@ class GpuTextSource {
   Filled f_[2];            // bgzf: what the reader put into host buffer k
   double t_fill_ = 0;      // seconds the reader spent filling host buffers
   uint64_t idx_ = 0;       // bgzf: index of the slab being consumed
-  int carry_k_ = 0;        // bgzf: the carried tail lives in d_text_[carry_k_] at carry_off_
+  int carry_k_ = 0;
   size_t carry_off_ = 0;
   hipStream_t cs_ = nullptr, xs_ = nullptr;  // inflate stream, H2D stream
   hipEvent_t ev_h2d_[2] = {nullptr, nullptr}, ev_done_[2] = {nullptr, nullptr}, ev_free_[2] = {nullptr, nullptr};
