@@ -18,9 +18,10 @@
 //   * the last 2 KiB of output stay in an LDS ring: literals and near matches are LDS stores / LDS->LDS copies
 //     (overlapping runs, distance < length, by modular addressing), farther matches read the output already drained
 //     to HBM; the ring is drained in aligned 256-byte rows, one dword per lane;
-//   * the literal loop is hand-written (literal_run); the kernel is bound by instruction issue, so the rest of the
-//     symbol loop is kept free of flags and state variables the compiler would otherwise thread through it
-//     (one merge point for long codes, one exit block, rare paths out of line).  Tuning log: profiles/r1_tuning.md.
+//   * the symbol loop is hand-written (symbol_run: literals and the common matches in one inline-assembly block);
+//     the kernel is bound by instruction issue, so the C++ around it is kept free of flags and state variables the
+//     compiler would otherwise thread through it (one merge point for long codes, one exit block, rare paths out
+//     of line).  Tuning log: profiles/r1_tuning.md.
 // Every block reports a status; any failure makes the caller inflate on the host instead.  The CRC-32 of every
 // inflated block is checked by a second kernel (k_crc32: 64 slices per block, combined in GF(2)[x] mod P).
 #include <hip/hip_runtime.h>
@@ -44,7 +45,7 @@ constexpr int WAVES_PER_WG = 4;     // k_crc32
 #define EXON_INFLATE_RING 2048
 #endif
 #ifndef EXON_INFLATE_LIT
-#define EXON_INFLATE_LIT 1  // literal loop: 0 = the compiler's (readable reference), 1 = literal_run (hand-written)
+#define EXON_INFLATE_LIT 2  // symbol loop: 0 = the compiler's (readable reference), 1 = literal_run, 2 = symbol_run
 #endif
 constexpr int INFLATE_RING = EXON_INFLATE_RING;  // bytes of recent output kept in LDS per wavefront (k_inflate)
 
@@ -503,6 +504,162 @@ __device__ __forceinline__ uint32_t literal_run(BitReader& br, uint32_t& pos, ui
   return uniu(why);
 }
 
+// literal_run plus the common match, in one block: a length code and a distance code that both sit in the first-level
+// tables, at most 64 bytes, source either in the ring without overlap or far enough back to be in HBM already --
+// decoded, copied (one masked read + write) and advanced without leaving the loop.  Anything else leaves with what has
+// been decoded so far:
+//   0: `e` is a first-level entry the loop does not handle (long code, end of block, invalid); nothing consumed
+//   1: o.pos entered a new 256-byte row (after a literal or a match)
+//   2: a match is decoded (len, d; all its bits consumed) but not copied: overlapping, longer than 64, or a bad distance
+//   3: a length is decoded (len) and consumed, the buffer refilled; the distance code needs the slow path
+template <int RING>
+__device__ __forceinline__ uint32_t symbol_run(BitReader& br, uint32_t& pos, uint32_t& vpos, uint32_t lane, uint32_t lane4, uint32_t begin,
+                                               const uint8_t* out, uint32_t& e, uint32_t& len, uint32_t& d) {
+  uint32_t why, vt, ve;
+  uint64_t buf = br.buf;
+  int cnt = br.cnt;
+  uint32_t widx = br.widx;
+#define EXON_REFILL(tag)                                \
+  "  s_cmp_gt_i32 s82, 32\n"                            \
+  "  s_cbranch_scc1 L_have_" tag "%=\n"                 \
+  "  s_waitcnt vmcnt(0)\n"                              \
+  "  v_readlane_b32 s90, %[cur], s83\n"                 \
+  "  s_mov_b32 s91, 0\n"                                \
+  "  s_lshl_b64 s[90:91], s[90:91], s82\n"              \
+  "  s_or_b64 s[80:81], s[80:81], s[90:91]\n"           \
+  "  s_add_i32 s82, s82, 32\n"                          \
+  "  s_add_i32 s83, s83, 1\n"                           \
+  "  s_and_b32 s87, s83, 63\n"                          \
+  "  s_cbranch_scc1 L_have_" tag "%=\n"                 \
+  "  v_lshl_add_u32 %[vt], s83, 2, %[lane4]\n"          \
+  "  global_load_dword %[cur], %[vt], s[88:89]\n"       \
+  "L_have_" tag "%=:\n"
+  asm volatile(
+      "L_sym_loop%=:\n" EXON_REFILL("l")
+      "  v_lshlrev_b32 %[vt], 2, s80\n"
+      "  v_and_b32 %[vt], %[lutmask], %[vt]\n"
+      "  ds_read_b32 %[ve], %[vt] offset:%[lutoff]\n"
+      "  s_waitcnt lgkmcnt(0)\n"
+      "  v_readfirstlane_b32 s85, %[ve]\n"
+      "  s_bitcmp1_b32 s85, 8\n"
+      "  s_cbranch_scc0 L_sym_match%=\n"
+      "  s_and_b32 s87, s85, 15\n"
+      "  s_lshr_b64 s[80:81], s[80:81], s87\n"
+      "  s_sub_i32 s82, s82, s87\n"
+      "  v_and_b32 %[vt], %[ringmask], %[vpos]\n"
+      "  ds_write_b8_d16_hi %[vt], %[ve]\n"
+      "  v_add_u32 %[vpos], 1, %[vpos]\n"
+      "  s_add_i32 s84, s84, 1\n"
+      "  s_and_b32 s87, s84, 0xff\n"
+      "  s_cbranch_scc1 L_sym_loop%=\n"
+      "  s_branch L_sym_row%=\n"
+      // ---- not a literal: a length code?
+      "L_sym_match%=:\n"
+      "  s_and_b32 s87, s85, 15\n"            // code length; SCC = (it is in the table)
+      "  s_cbranch_scc0 L_sym_exit0%=\n"
+      "  s_and_b32 s94, s85, 0x600\n"         // end of block / invalid
+      "  s_cbranch_scc1 L_sym_exit0%=\n"
+      "  s_lshr_b64 s[80:81], s[80:81], s87\n"
+      "  s_sub_i32 s82, s82, s87\n"
+      "  s_lshr_b32 s92, s85, 16\n"           // length base
+      "  s_bfe_u32 s87, s85, 0x40004\n"       // extra bits; SCC = (any)
+      "  s_cbranch_scc0 L_sym_len%=\n"
+      "  s_bfm_b32 s94, s87, 0\n"
+      "  s_and_b32 s94, s80, s94\n"
+      "  s_add_i32 s92, s92, s94\n"
+      "  s_lshr_b64 s[80:81], s[80:81], s87\n"
+      "  s_sub_i32 s82, s82, s87\n"
+      "L_sym_len%=:\n" EXON_REFILL("m")
+      // ---- the distance
+      "  v_lshlrev_b32 %[vt], 2, s80\n"
+      "  v_and_b32 %[vt], %[dmask], %[vt]\n"
+      "  ds_read_b32 %[ve], %[vt] offset:%[dlut]\n"
+      "  s_waitcnt lgkmcnt(0)\n"
+      "  v_readfirstlane_b32 s95, %[ve]\n"
+      "  s_and_b32 s87, s95, 15\n"
+      "  s_cbranch_scc0 L_sym_exit3%=\n"      // long or nonexistent code
+      "  s_bitcmp1_b32 s95, 10\n"
+      "  s_cbranch_scc1 L_sym_exit3%=\n"      // invalid symbol (30, 31)
+      "  s_lshr_b64 s[80:81], s[80:81], s87\n"
+      "  s_sub_i32 s82, s82, s87\n"
+      "  s_lshr_b32 s93, s95, 16\n"           // distance base
+      "  s_bfe_u32 s87, s95, 0x40004\n"       // extra bits; SCC = (any)
+      "  s_cbranch_scc0 L_sym_dist%=\n"
+      "  s_bfm_b32 s94, s87, 0\n"
+      "  s_and_b32 s94, s80, s94\n"
+      "  s_add_i32 s93, s93, s94\n"
+      "  s_lshr_b64 s[80:81], s[80:81], s87\n"
+      "  s_sub_i32 s82, s82, s87\n"
+      "L_sym_dist%=:\n"
+      // ---- the copies the loop does itself: d <= history, len <= 64, and either len <= d <= NEAR (ring -> ring) or
+      //      d > NEAR (the source is below `drained`, i.e. in HBM already)
+      "  s_sub_i32 s87, s84, s96\n"
+      "  s_cmp_gt_u32 s93, s87\n"
+      "  s_cbranch_scc1 L_sym_exit2%=\n"
+      "  s_cmp_gt_u32 s92, 64\n"
+      "  s_cbranch_scc1 L_sym_exit2%=\n"
+      "  v_cmp_gt_u32 vcc, s92, %[lane]\n"     // lanes below len
+      "  s_sub_i32 s87, s84, s93\n"            // first source byte
+      "  s_cmp_gt_u32 s93, %[near]\n"
+      "  s_cbranch_scc1 L_sym_far%=\n"
+      "  s_cmp_gt_u32 s92, s93\n"
+      "  s_cbranch_scc1 L_sym_exit2%=\n"       // overlapping run
+      "  s_and_saveexec_b64 s[90:91], vcc\n"
+      "  v_add_u32 %[vt], s87, %[lane]\n"
+      "  v_and_b32 %[vt], %[ringmask], %[vt]\n"
+      "  ds_read_u8 %[ve], %[vt]\n"
+      "  v_add_u32 %[vt], s84, %[lane]\n"
+      "  v_and_b32 %[vt], %[ringmask], %[vt]\n"
+      "  s_waitcnt lgkmcnt(0)\n"
+      "  ds_write_b8 %[vt], %[ve]\n"
+      "  s_mov_b64 exec, s[90:91]\n"
+      "  s_branch L_sym_adv%=\n"
+      "L_sym_far%=:\n"
+      "  s_and_saveexec_b64 s[90:91], vcc\n"
+      "  v_add_u32 %[vt], s87, %[lane]\n"
+      "  global_load_ubyte %[ve], %[vt], s[98:99]\n"
+      "  v_add_u32 %[vt], s84, %[lane]\n"
+      "  v_and_b32 %[vt], %[ringmask], %[vt]\n"
+      "  s_waitcnt vmcnt(0)\n"
+      "  ds_write_b8 %[vt], %[ve]\n"
+      "  s_mov_b64 exec, s[90:91]\n"
+      "L_sym_adv%=:\n"
+      "  s_add_i32 s87, s84, s92\n"
+      "  s_xor_b32 s94, s87, s84\n"
+      "  s_mov_b32 s84, s87\n"
+      "  v_mov_b32 %[vpos], s87\n"
+      "  s_lshr_b32 s94, s94, 8\n"            // SCC = a 256-byte row boundary was crossed
+      "  s_cbranch_scc0 L_sym_loop%=\n"
+      "L_sym_row%=:\n"
+      "  s_mov_b32 s86, 1\n"
+      "  s_branch L_sym_out%=\n"
+      "L_sym_exit0%=:\n"
+      "  s_mov_b32 s86, 0\n"
+      "  s_branch L_sym_out%=\n"
+      "L_sym_exit2%=:\n"
+      "  s_mov_b32 s86, 2\n"
+      "  s_branch L_sym_out%=\n"
+      "L_sym_exit3%=:\n"
+      "  s_mov_b32 s86, 3\n"
+      "L_sym_out%=:\n"
+      "  s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+      : [buf] "+{s[80:81]}"(buf), [cnt] "+{s82}"(cnt), [widx] "+{s83}"(widx), [pos] "+{s84}"(pos), [e] "={s85}"(e), [why] "={s86}"(why),
+        [len] "={s92}"(len), [d] "={s93}"(d), [cur] "+v"(br.cur), [vpos] "+v"(vpos), [vt] "=&v"(vt), [ve] "=&v"(ve)
+      : [base] "{s[88:89]}"(br.base), [begin] "{s96}"(begin), [out] "{s[98:99]}"(out), [lane] "v"(lane), [lane4] "v"(lane4), [lutmask] "i"(((1 << LIT_BITS) - 1) << 2),
+        [dmask] "i"(((1 << DIST_BITS) - 1) << 2), [ringmask] "i"(RING - 1), [near] "i"(RING - 258),
+        [lutoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_lut)), [dlut] "i"(RING + (int)__builtin_offsetof(WaveLds, dist_lut))
+      : "s87", "s90", "s91", "s94", "s95", "vcc", "scc", "memory");
+#undef EXON_REFILL
+  br.buf = ((uint64_t)uniu((uint32_t)(buf >> 32)) << 32) | uniu((uint32_t)buf);
+  br.cnt = uni(cnt);
+  br.widx = uniu(widx);
+  pos = uniu(pos);
+  e = uniu(e);
+  len = uniu(len);
+  d = uniu(d);
+  return uniu(why);
+}
+
 template <int RING>
 __device__ __noinline__ SymResult decode_symbols(BitReader br, Out o) {
   constexpr uint32_t M = RING - 1;
@@ -533,35 +690,51 @@ __device__ __noinline__ SymResult decode_symbols(BitReader br, Out o) {
       }
       continue;
     }
-#else
+#elif EXON_INFLATE_LIT == 1
     if (literal_run<RING>(br, o.pos, vpos, lane4, e)) {  // a 256-byte row of the ring is complete
       if (o.pos > o.end || br.overrun()) { err = br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN; break; }
       o.drained = uniu(drain_rows<RING>(o.out, o.drained, o.pos & ~255u));
       continue;
     }
 #endif
-    if (__builtin_expect((e & 15u) == 0, 0)) {  // a code longer than the table, or no such code
-      const int r = uni(decode_long<RING>(CODE_LIT, (uint32_t)br.buf));
-      // lengths are <= 15: the entry's length field holds it; no such code -> E_INVALID (caught below, no exit from here)
-      e = r < 0 ? (uint32_t)E_INVALID : entry_for(CODE_LIT, r >> 8) | (uint32_t)(r & 255);
-    }
-    br.drop((int)(e & 15u));
-    if (__builtin_expect((e & (E_LIT | E_EOB | E_INVALID)) != 0, 0)) {
-      if (!(e & E_LIT)) { err = (e & E_EOB) ? INF_OK : INF_BAD_CODE; break; }
-      ring[o.pos & M] = (uint8_t)(e >> 16);  // a literal with a long code; every lane stores the same byte
-      ++o.pos;
-      vpos = o.pos;
-      if ((o.pos & 255u) == 0) {
-        if (o.pos > o.end || br.overrun()) { err = br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN; break; }
-        o.drained = uniu(drain_rows<RING>(o.out, o.drained, o.pos));
-      }
+    uint32_t len, d;
+#if EXON_INFLATE_LIT == 2
+    const uint32_t why = symbol_run<RING>(br, o.pos, vpos, lane, lane4, o.begin, o.out, e, len, d);
+    if (why == 1) {  // a 256-byte row of the ring is complete
+      if (o.pos > o.end || br.overrun()) { err = br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN; break; }
+      o.drained = uniu(drain_rows<RING>(o.out, o.drained, o.pos & ~255u));
       continue;
     }
-    const uint32_t len = (e >> 16) + br.take((int)((e >> 4) & 15u));
-    br.refill();
-    const uint32_t de = decode_symbol<RING, CODE_DIST>(br, L);
-    if (__builtin_expect((de & E_INVALID) != 0, 0)) { err = INF_BAD_CODE; break; }
-    const uint32_t d = (de >> 16) + br.take((int)((de >> 4) & 15u));
+    if (why != 2) {
+      if (why == 0) {
+#else
+    {
+      {
+#endif
+        if (__builtin_expect((e & 15u) == 0, 0)) {  // a code longer than the table, or no such code
+          const int r = uni(decode_long<RING>(CODE_LIT, (uint32_t)br.buf));
+          // lengths are <= 15: the entry's length field holds it; no such code -> E_INVALID (caught below, no exit from here)
+          e = r < 0 ? (uint32_t)E_INVALID : entry_for(CODE_LIT, r >> 8) | (uint32_t)(r & 255);
+        }
+        br.drop((int)(e & 15u));
+        if (__builtin_expect((e & (E_LIT | E_EOB | E_INVALID)) != 0, 0)) {
+          if (!(e & E_LIT)) { err = (e & E_EOB) ? INF_OK : INF_BAD_CODE; break; }
+          ring[o.pos & M] = (uint8_t)(e >> 16);  // a literal with a long code; every lane stores the same byte
+          ++o.pos;
+          vpos = o.pos;
+          if ((o.pos & 255u) == 0) {
+            if (o.pos > o.end || br.overrun()) { err = br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN; break; }
+            o.drained = uniu(drain_rows<RING>(o.out, o.drained, o.pos));
+          }
+          continue;
+        }
+        len = (e >> 16) + br.take((int)((e >> 4) & 15u));
+        br.refill();
+      }
+      const uint32_t de = decode_symbol<RING, CODE_DIST>(br, L);
+      if (__builtin_expect((de & E_INVALID) != 0, 0)) { err = INF_BAD_CODE; break; }
+      d = (de >> 16) + br.take((int)((de >> 4) & 15u));
+    }
     if (__builtin_expect(d > o.pos - o.begin, 0)) { err = INF_BAD_DISTANCE; break; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (d - len <= NEAR - len) {  // len <= d <= NEAR (unsigned wrap-around when d < len)
