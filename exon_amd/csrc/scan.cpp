@@ -397,8 +397,9 @@ void exon_hip_release_ctx_caches(exon_hip_ctx* ctx) {
 class GpuTextSource {
  public:
   GpuTextSource(exon_hip_ctx* ctx, hipStream_t hs, std::unique_ptr<exon::ByteSource> src, bool bgzf, uint64_t skip_first,
-                std::string carry, bool binary = false)
-      : ctx_(ctx), hs_(hs), src_(std::move(src)), rd_(src_.get()), bgzf_(bgzf), binary_(binary), skip_(skip_first), carry_(std::move(carry)) {
+                std::string carry, bool binary = false, bool text_async = false)
+      : ctx_(ctx), hs_(hs), src_(std::move(src)), rd_(src_.get()), bgzf_(bgzf), binary_(binary), text_async_(text_async), skip_(skip_first),
+        carry_(std::move(carry)) {
     slab_ = slab_bytes();
     if (bgzf_) {
       // One wavefront inflates one block and a block takes ~3.5 ms however many run beside it, so a launch wants as many
@@ -418,7 +419,10 @@ class GpuTextSource {
     const double td1 = now_s();
     if (xs_) hipStreamSynchronize(xs_);
     if (cs_) hipStreamSynchronize(cs_);
-    if (getenv("EXON_HIP_PIPE_TRACE")) fprintf(stderr, "[exon-hip pipe] teardown: reader join %.1f ms, stream sync %.1f ms\n", (td1 - td0) * 1e3, (now_s() - td1) * 1e3);
+    if (ev_carry_) hipEventDestroy(ev_carry_);
+    if (getenv("EXON_HIP_PIPE_TRACE"))
+      fprintf(stderr, "[exon-hip pipe] teardown: reader join %.1f ms, stream sync %.1f ms; reader: file reads %.1f ms, header walk %.1f ms; consumer waited %.1f ms for inflates, %.1f ms for the reader\n",
+              (td1 - td0) * 1e3, (now_s() - td1) * 1e3, t_read_ * 1e3, t_scan_ * 1e3, t_wait_inflate_ * 1e3, t_wait_reader_ * 1e3);
     SlabBuffers b;
     b.cs = cs_;
     b.xs = xs_;
@@ -502,6 +506,7 @@ class GpuTextSource {
                            hipEventCreateWithFlags(&ev_free_[k], hipEventDisableTiming) != hipSuccess))
         return fail(ctx_, EXON_HIP_EDEVICE, "event creation failed");
     if (bgzf_) {
+      if (!ev_carry_ && hipEventCreateWithFlags(&ev_carry_, hipEventDisableTiming) != hipSuccess) return fail(ctx_, EXON_HIP_EDEVICE, "event creation failed");
       fill(0, &f_[0]);
       if (f_[0].err) return rethrow(f_[0].err);
       int rc = enqueue_inflate(0);
@@ -612,8 +617,10 @@ class GpuTextSource {
   int next_bgzf(const uint8_t** d_text, size_t* n, bool* final) {
     const int k = (int)(idx_ & 1);
     const Filled f = f_[k];
+    const double tw0 = now_s();
     if (enq_[k]) {
       HIP_TRY(ctx_, hipEventSynchronize(ev_done_[k]));
+      t_wait_inflate_ += now_s() - tw0;
       const int* hstat = h_status(k);
       for (int i = 0; i < f.n_blocks; ++i)
         if (hstat[i] != 0) {
@@ -625,10 +632,21 @@ class GpuTextSource {
     *final = !more;
     // the tail carried from the previous slab goes right in front of this slab's inflated bytes
     size_t front = gap_ - carry_dev_, n_text = carry_dev_ + f.out_bytes;
-    if (carry_dev_) HIP_TRY(ctx_, hipMemcpyAsync(d_text_[k] + front, d_text_[carry_k_] + carry_off_, carry_dev_, hipMemcpyDeviceToDevice, hs_));
-    if (idx_ > 0) {  // everything the consumer enqueued on slab i-1 (and this copy out of it) precedes its reuse
-      HIP_TRY(ctx_, hipEventRecord(ev_free_[k ^ 1], hs_));
-      free_rec_[k ^ 1] = true;
+    if (text_async_) {
+      // the plan's kernel reads the text of slab i-1 in place: its buffer is free when the plan's stream gets here
+      if (carry_dev_) HIP_TRY(ctx_, hipMemcpyAsync(d_text_[k] + front, d_text_[carry_k_] + carry_off_, carry_dev_, hipMemcpyDeviceToDevice, hs_));
+      if (idx_ > 0) {
+        HIP_TRY(ctx_, hipEventRecord(ev_free_[k ^ 1], hs_));
+        free_rec_[k ^ 1] = true;
+      }
+    } else if (carry_dev_) {
+      // The parsers return (synchronously) with everything they need copied out of the text, so the buffer of slab i-1
+      // is free but for the carried tail.  Copy it on the INFLATE stream: stream order puts it ahead of the inflate that
+      // overwrites its source, and it does not queue behind the plan's kernel of slab i-1, which the inflate that is
+      // running may starve for milliseconds (the next inflate used to wait for that kernel: a 2.8 ms hole per slab).
+      HIP_TRY(ctx_, hipMemcpyAsync(d_text_[k] + front, d_text_[carry_k_] + carry_off_, carry_dev_, hipMemcpyDeviceToDevice, cs_));
+      HIP_TRY(ctx_, hipEventRecord(ev_carry_, cs_));
+      HIP_TRY(ctx_, hipStreamWaitEvent(hs_, ev_carry_, 0));
     }
     carry_dev_ = 0;
     if (skip_) {  // first slab: the host reader consumed the header
@@ -638,7 +656,9 @@ class GpuTextSource {
       skip_ = 0;
     }
     if (more) {  // slab i+1: inflate it while the consumer works on slab i; then let the reader fetch slab i+2
+      const double tj0 = now_s();
       if (reader_.joinable()) reader_.join();
+      t_wait_reader_ += now_s() - tj0;
       if (f_[k ^ 1].err) return rethrow(f_[k ^ 1].err);
       int rc = enqueue_inflate(k ^ 1);
       if (rc) return rc;
@@ -699,16 +719,28 @@ class GpuTextSource {
       const int target = first_fill_ ? std::max(64, target_blocks_ / 8) : target_blocks_;
       first_fill_ = false;
       const size_t goal = std::min(comp_cap_, (size_t)((double)est_block_ * target * 1.03) + (1u << 16));
+      const double tf0 = now_s();
       if (!file_eof_ && have < goal) {
         const size_t want = goal - have;
         const size_t got = rd_.read(h_buf_[k] + have, want);
         file_eof_ = got < want;
         have += got;
       }
+      const double tf1 = now_s();
+      if (xs_ && have > 0) {
+        // Everything read starts crossing PCIe at once (its own stream, under the inflate of the previous slab) and the
+        // header walk below runs under that copy: the slab must be in HBM one inflate period after this thread
+        // started, and read + walk + copy in a row did not fit.  (A trailing partial block goes along; it is unused.)
+        hipSetDevice(ctx_->device);
+        if (hipMemcpyAsync(d_comp_[k], h_buf_[k], have + 4096, hipMemcpyHostToDevice, xs_) != hipSuccess || hipEventRecord(ev_h2d_[k], xs_) != hipSuccess)
+          throw std::runtime_error("H2D of a compressed slab failed");
+      }
       int32_t nb = 0;
       size_t consumed = 0, out_bytes = 0;
       if (exon_hip_bgzf_scan(h_buf_[k], have, 0, h_blocks_tmp(k), std::min(max_blocks_, target), &nb, &consumed, &out_bytes) != EXON_HIP_OK)
         throw std::runtime_error(exon_hip_last_error(nullptr));
+      t_read_ += tf1 - tf0;
+      t_scan_ += now_s() - tf1;
       if (nb > 0) est_block_ = (double)consumed / nb;
       exon_hip_bgzf_block* hb = h_blocks_tmp(k);
       if (out_bytes > text_cap_) {
@@ -729,13 +761,6 @@ class GpuTextSource {
       f->out_bytes = out_bytes;
       f->eof = file_eof_ && left_.empty();
       block_tables_[k].assign(hb, hb + nb);  // copied to the pinned table in next()
-      if (xs_ && nb > 0) {
-        // the compressed bytes start crossing PCIe right away (their own stream), under the inflate of the previous slab
-        hipSetDevice(ctx_->device);
-        if (hipMemcpyAsync(d_comp_[k], h_buf_[k], consumed + 4096, hipMemcpyHostToDevice, xs_) != hipSuccess ||
-            hipEventRecord(ev_h2d_[k], xs_) != hipSuccess)
-          throw std::runtime_error("H2D of a compressed slab failed");
-      }
     } catch (...) {
       f->err = std::current_exception();
     }
@@ -750,6 +775,8 @@ class GpuTextSource {
   std::unique_ptr<exon::ByteSource> src_;
   SlabReader rd_;
   bool bgzf_, binary_;
+  bool text_async_;  // the consumer's kernels read the slab text after the parser has returned (FASTQ views)
+  hipEvent_t ev_carry_ = nullptr;
   uint64_t skip_;
   std::string carry_;      // plain: what the host header reader had buffered (goes in front of the first slab)
   size_t carry_dev_ = 0;   // bytes of the carried tail (lives in d_text_[carry_k_] at carry_off_ until the next slab is taken)
@@ -769,6 +796,8 @@ class GpuTextSource {
   Filled cur_, nxt_;
   Filled f_[2];            // bgzf: what the reader put into host buffer k
   double t_fill_ = 0;      // seconds the reader spent filling host buffers
+  double t_read_ = 0, t_scan_ = 0;  // of which: file reads, BGZF header walk
+  double t_wait_inflate_ = 0, t_wait_reader_ = 0;  // consumer: blocked on the inflate of the slab it wants / on the reader
   uint64_t idx_ = 0;       // bgzf: index of the slab being consumed
   int carry_k_ = 0;
   size_t carry_off_ = 0;
@@ -803,7 +832,7 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
                             : is_sam ? (uint64_t)scan->sam->data_offset()
                                      : 0;
       std::unique_ptr<exon::ByteSource> raw(new exon::ByteReader(scan->path, exon::Compression::None));
-      src.reset(new GpuTextSource(ctx, hs, std::move(raw), true, skip, std::string(), is_bam || is_bcf));
+      src.reset(new GpuTextSource(ctx, hs, std::move(raw), true, skip, std::string(), is_bam || is_bcf, /*text_async=*/!is_vcf && !is_bam && !is_bcf && !is_sam));
     } else {
       std::string carry;
       std::unique_ptr<exon::ByteSource> text = is_vcf   ? scan->vcf->take_stream(&carry)
