@@ -121,7 +121,9 @@ struct WaveLds {
   uint16_t lit_sym[288];             // symbols in canonical order (bit-serial decode of long codes)
   uint16_t dist_sym[32];
   uint16_t lit_count[16], dist_count[16];  // codes per length
-  uint16_t first[16], offs[16];      // scratch of build_code
+  // per length: first canonical code / symbols of shorter lengths.  Scratch of every build_code; the literal/length
+  // code is built LAST, so between table builds these hold ITS values, which decode_long uses.
+  uint16_t first[16], offs[16];
   uint8_t lens[288 + 32];
 };
 // (the code-length tables share the bytes of dist_lut: they are dead once the lengths are read)
@@ -147,14 +149,16 @@ struct Code {
   uint32_t* lut;
   uint16_t* sym;
   uint16_t* count;
+  uint16_t* first;  // per length: first canonical code
+  uint16_t* offs;   // per length: symbols of shorter lengths
   int bits;
 };
 template <int RING>
 __device__ __forceinline__ Code code_of(int which) {
   WaveLds* L = wave_lds<RING>();
-  if (which == CODE_LIT) return Code{L->lit_lut, L->lit_sym, L->lit_count, LIT_BITS};
-  if (which == CODE_DIST) return Code{L->dist_lut, L->dist_sym, L->dist_count, DIST_BITS};
-  return Code{L->cl.cl_lut, L->cl.cl_sym, L->cl.cl_count, CL_BITS};
+  if (which == CODE_LIT) return Code{L->lit_lut, L->lit_sym, L->lit_count, L->first, L->offs, LIT_BITS};
+  if (which == CODE_DIST) return Code{L->dist_lut, L->dist_sym, L->dist_count, L->first, L->offs, DIST_BITS};
+  return Code{L->cl.cl_lut, L->cl.cl_sym, L->cl.cl_count, L->first, L->offs, CL_BITS};
 }
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -290,8 +294,8 @@ __device__ __noinline__ int build_code_impl(int which, int lens_off, int n) {
         oq = offs[q];
       }
     c.count[lane] = (uint16_t)cq;
-    L->first[lane] = (uint16_t)fq;
-    L->offs[lane] = (uint16_t)oq;
+    c.first[lane] = (uint16_t)fq;
+    c.offs[lane] = (uint16_t)oq;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   // every symbol gets its canonical code (rank inside its length class, in symbol order); fill the tables
@@ -310,8 +314,8 @@ __device__ __noinline__ int build_code_impl(int which, int lens_off, int n) {
       seen[q] += __popcll(m);
     }
     if (l > 0) {
-      const int code = (int)L->first[l] + rank;
-      c.sym[(int)L->offs[l] + rank] = (uint16_t)s;
+      const int code = (int)c.first[l] + rank;
+      c.sym[(int)c.offs[l] + rank] = (uint16_t)s;
       if (l <= c.bits) {
         const unsigned rev = __brev((unsigned)code) >> (32 - l);
         const uint32_t e = entry_for(which, s) | (uint32_t)l;
@@ -327,13 +331,28 @@ __device__ __forceinline__ bool build_code(int which, int lens_off, int n) {
   return uni(build_code_impl<RING>(which, lens_off, n)) != 0;
 }
 
-// Bit-serial canonical decode for codes longer than the first-level table (rare).  Returns symbol << 8 | length,
-// or -1 for a code that does not exist.
+// Canonical decode of a code longer than the first-level table.  Returns symbol << 8 | length, or -1 for a code that
+// does not exist.  Literal/length codes: all candidate lengths at once -- lane L (1..15) takes the first L bits as a
+// code of that length and tests it against the codes of its length (first[L] <= code < first[L] + count[L]); codes
+// are prefix-free, so at most one length matches.  (High-entropy payloads -- BAM -- come here for ~2 % of their bytes;
+// the bit-serial loop cost ~150 instructions a time: +21 % on BAM.)  Distance and code-length codes, which hardly
+// ever get here, keep the bit-serial loop (their first[] / offs[] do not outlive their table build).
 template <int RING>
 __device__ __noinline__ int decode_long(int which, uint32_t bits) {
   which = uni(which);
   bits = uniu(bits);
   const Code c = code_of<RING>(which);
+  if (which == CODE_LIT) {
+    const int len = (int)lane_id() & 15;  // lanes 16.. repeat 0..15: only the ballot's low 16 bits are used
+    const uint32_t code = len ? __brev(bits) >> (32 - len) : 0u;  // DEFLATE packs Huffman codes starting from their MSB
+    const uint32_t rel = code - (uint32_t)c.first[len];
+    const bool hit = len != 0 && rel < (uint32_t)c.count[len];
+    const uint32_t m = (uint32_t)__ballot(hit) & 0xFFFEu;
+    if (m == 0) return -1;
+    const int l = __ffs((int)m) - 1;
+    const int idx = __builtin_amdgcn_readlane((int)((uint32_t)c.offs[len] + rel), l);
+    return ((int)c.sym[idx] << 8) | l;
+  }
   int code = 0, first = 0, index = 0;
   for (int len = 1; len <= 15; ++len) {
     code |= (int)(bits & 1u);
@@ -820,7 +839,8 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(const uint8_t* __res
       for (int s = lane; s < 288; s += 64) L->lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
       if (lane < 32) L->lens[288 + lane] = 5;  // 30 and 31 complete the code; using them is an error
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      if (!build_code<RING>(CODE_LIT, 0, 288) || !build_code<RING>(CODE_DIST, 288, 32)) { err = INF_BAD_LENGTHS; break; }
+      // the literal/length code LAST: its first[] / offs[] must survive the build (decode_long)
+      if (!build_code<RING>(CODE_DIST, 288, 32) || !build_code<RING>(CODE_LIT, 0, 288)) { err = INF_BAD_LENGTHS; break; }
     } else {  // dynamic codes
       br.refill();
       const int hlit = (int)br.take(5) + 257, hdist = (int)br.take(5) + 1, hclen = (int)br.take(4) + 4;
@@ -871,7 +891,8 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(const uint8_t* __res
       if (lane < 32) L->lens[288 + lane] = (uint8_t)dl;
       for (int s = hlit + lane; s < 288; s += 64) L->lens[s] = 0;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      if (!build_code<RING>(CODE_LIT, 0, 288) || !build_code<RING>(CODE_DIST, 288, 30)) { err = INF_BAD_LENGTHS; break; }
+      // the literal/length code LAST: its first[] / offs[] must survive the build (decode_long)
+      if (!build_code<RING>(CODE_DIST, 288, 30) || !build_code<RING>(CODE_LIT, 0, 288)) { err = INF_BAD_LENGTHS; break; }
     }
     const SymResult r = decode_symbols<RING>(br, o);
     br = r.br;
