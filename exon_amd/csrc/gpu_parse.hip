@@ -30,7 +30,7 @@
 namespace {
 
 constexpr int TPB = 256;
-constexpr int BYTES_PER_THREAD = 16;
+constexpr int BYTES_PER_THREAD = 64;  // four 16-byte loads per thread (one cache line): 4 KiB workgroups were launch-bound
 constexpr int BYTES_PER_BLOCK = TPB * BYTES_PER_THREAD;
 constexpr int FILTER_SLOTS = 8192;  // open addressing; at most EXON_HIP_MAX_GROUPS distinct lists are supported
 constexpr int FILTER_POOL = 1 << 20;
@@ -73,7 +73,10 @@ __global__ __launch_bounds__(TPB) void k_count_newlines(const uint8_t* __restric
                                                         unsigned* __restrict__ block_counts) {
   __shared__ unsigned red[TPB / 64];
   const int64_t off = ((int64_t)blockIdx.x * TPB + threadIdx.x) * BYTES_PER_THREAD;
-  unsigned c = off < n ? (unsigned)count_nl16(load16(text, n, off, skip)) : 0u;
+  unsigned c = 0;
+#pragma unroll
+  for (int j = 0; j < BYTES_PER_THREAD / 16; ++j)
+    if (off + 16 * j < n) c += (unsigned)count_nl16(load16(text, n, off + 16 * j, skip));
   for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
   __syncthreads();
@@ -110,11 +113,16 @@ __global__ __launch_bounds__(TPB) void k_fill_newlines(const uint8_t* __restrict
   __shared__ unsigned wave_tot[TPB / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t off = ((int64_t)blockIdx.x * TPB + threadIdx.x) * BYTES_PER_THREAD;
-  uint4 v = {0, 0, 0, 0};
+  constexpr int Q = BYTES_PER_THREAD / 16;
+  uint4 v[Q];
   unsigned c = 0;
-  if (off < n) {
-    v = load16(text, n, off, skip);
-    c = (unsigned)count_nl16(v);
+#pragma unroll
+  for (int j = 0; j < Q; ++j) {
+    v[j] = uint4{0, 0, 0, 0};
+    if (off + 16 * j < n) {
+      v[j] = load16(text, n, off + 16 * j, skip);
+      c += (unsigned)count_nl16(v[j]);
+    }
   }
   unsigned incl = c;  // inclusive scan within the wave
   for (int o = 1; o < 64; o <<= 1) {
@@ -127,13 +135,17 @@ __global__ __launch_bounds__(TPB) void k_fill_newlines(const uint8_t* __restrict
   for (int w = 0; w < wave; ++w) base += wave_tot[w];
   unsigned k = base + incl - c;
   if (c) {
-    const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-      if (((w[i >> 2] >> (8 * (i & 3))) & 0xFF) == 0x0A) {
-        if (k < cap) nl_pos[k] = (unsigned)(off + i);  // more lines than VCF records can fill: reported by the caller
-        ++k;
-      }
+    for (int j = 0; j < Q; ++j) {
+      const unsigned w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+      if ((w[0] | w[1] | w[2] | w[3]) == 0) continue;
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (((w[i >> 2] >> (8 * (i & 3))) & 0xFF) == 0x0A) {
+          if (k < cap) nl_pos[k] = (unsigned)(off + 16 * j + i);  // more lines than VCF records can fill: reported by the caller
+          ++k;
+        }
+    }
   }
 }
 
@@ -244,11 +256,22 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
       // POS
       {
         int64_t v = 0;
-        bool ok = fend(1) > fbeg(1);
-        for (unsigned i = fbeg(1); i < fend(1) && ok; ++i) {
-          const uint8_t c = text[i];
-          if (c < '0' || c > '9') ok = false;
-          else v = v * 10 + (c - '0');
+        const unsigned pb = fbeg(1), pn = fend(1) - fbeg(1);
+        bool ok = pn > 0;
+        if (pn <= 16) {  // the digits from two (unaligned) 8-byte loads instead of a chain of byte loads
+          uint64_t w[2];
+          __builtin_memcpy(w, text + pb, 16);
+          for (unsigned k = 0; k < pn && ok; ++k) {
+            const unsigned c = (unsigned)(w[k >> 3] >> (8 * (k & 7))) & 0xFFu;
+            if (c < '0' || c > '9') ok = false;
+            else v = v * 10 + (c - '0');
+          }
+        } else {
+          for (unsigned i = pb; i < pb + pn && ok; ++i) {
+            const uint8_t c = text[i];
+            if (c < '0' || c > '9') ok = false;
+            else v = v * 10 + (c - '0');
+          }
         }
         pos_ok = ok && v > 0;
         out.pos[row] = pos_ok ? v : 0;
@@ -304,10 +327,10 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
         float v = 0.f;
         const unsigned ib = fbeg(7), ie = fend(7);
         if (!(ie - ib == 1 && text[ib] == '.')) {
-          unsigned i = ib;
-          while (i < ie) {
-            unsigned j = i;
-            while (j < ie && text[j] != ';') ++j;
+          // entries are separated by ';': find the separators 16 bytes per load, test the key at every entry start
+          unsigned i = ib;  // start of the current entry
+          bool done = false;
+          auto entry = [&](unsigned j) {  // the entry [i, j): is it `key=value`?
             if ((int)(j - i) > info_key_len && text[i + info_key_len] == '=') {
               bool same = true;
               for (int k = 0; k < info_key_len && same; ++k) same = text[i + k] == info_key[k];
@@ -323,11 +346,26 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
                     bad = true;
                   }
                 }
-                break;
+                done = true;
               }
             }
             i = j + 1;
+          };
+          for (unsigned a = ib & ~15u; a < ie && !done; a += 16) {
+            const uint4 q = *reinterpret_cast<const uint4*>(text + a);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const uint32_t x = w[k] ^ 0x3B3B3B3Bu;  // bytes equal to ';' become 0
+              uint32_t m = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+              while (m && !done) {
+                const unsigned idx = a + 4u * (unsigned)k + ((unsigned)__ffs((int)m) - 1u) / 8u;
+                if (idx >= ib && idx < ie) entry(idx);
+                m &= m - 1;
+              }
+            }
           }
+          if (!done && i < ie) entry(ie);  // the last entry has no ';' behind it
         }
         out.info[row] = v;
       }
