@@ -196,8 +196,19 @@ __device__ __forceinline__ void store_valid(uint8_t* bm, int64_t row0_of_wave, i
 __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__ text, const unsigned* __restrict__ nl_pos,
                                                      const unsigned* __restrict__ n_lines_p, NameTable contigs,
                                                      FilterTable filters, const uint8_t* __restrict__ info_key,
-                                                     int info_key_len, ParseOut out, unsigned cap, unsigned skip) {
+                                                     int info_key_len, ParseOut out, unsigned cap, unsigned skip, unsigned n_total) {
   const int64_t n_rows = min(*n_lines_p, cap);
+  // an aligned 16-byte group of the slab; the last one is read byte by byte (nothing behind n_total is touched)
+  auto group16 = [&](unsigned a) {
+    uint4 v = {0, 0, 0, 0};
+    if (a + 16u <= n_total) {
+      v = *reinterpret_cast<const uint4*>(text + a);
+    } else {
+      unsigned* w = &v.x;
+      for (unsigned i = 0; a + i < n_total; ++i) w[i >> 2] |= (unsigned)text[a + i] << (8 * (i & 3));
+    }
+    return v;
+  };
   const int64_t row = (int64_t)blockIdx.x * TPB + threadIdx.x;
   const int lane = threadIdx.x & 63;
   bool pos_ok = false, qual_ok = false, info_ok = false, bad = false;
@@ -212,7 +223,7 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
     // tabs, 16 bytes per load (aligned groups; `text` is 16-byte aligned and padded): the byte-at-a-time version of this
     // loop was a chain of ~35 dependent loads per line, a quarter of the kernel's memory waits
     for (unsigned a = begin & ~15u; a < end && nf < 8; a += 16) {
-      const uint4 v = *reinterpret_cast<const uint4*>(text + a);
+      const uint4 v = group16(a);
       const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -258,7 +269,7 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
         int64_t v = 0;
         const unsigned pb = fbeg(1), pn = fend(1) - fbeg(1);
         bool ok = pn > 0;
-        if (pn <= 16) {  // the digits from two (unaligned) 8-byte loads instead of a chain of byte loads
+        if (pn <= 16 && pb + 16u <= n_total) {  // the digits from two (unaligned) 8-byte loads instead of a chain of byte loads
           uint64_t w[2];
           __builtin_memcpy(w, text + pb, 16);
           for (unsigned k = 0; k < pn && ok; ++k) {
@@ -352,7 +363,7 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
             i = j + 1;
           };
           for (unsigned a = ib & ~15u; a < ie && !done; a += 16) {
-            const uint4 q = *reinterpret_cast<const uint4*>(text + a);
+            const uint4 q = group16(a);
             const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -566,7 +577,7 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* p, void* stream, const uint8_
   const int64_t row_bound = std::min<int64_t>(p->max_rows, n_bytes / 16 + 1);
   const int pblocks = (int)((row_bound + TPB - 1) / TPB);
   hipLaunchKernelGGL(k_parse_lines, dim3(pblocks), dim3(TPB), 0, s, d_text, p->d_nl, p->d_scalars, p->contigs, p->filters,
-                     p->d_info_key, (int)p->info_field.size(), p->out, (unsigned)row_bound, skip);
+                     p->d_info_key, (int)p->info_field.size(), p->out, (unsigned)row_bound, skip, (unsigned)n_bytes);
   hipLaunchKernelGGL(k_assign_filters, dim3(1), dim3(256), 0, s, d_text, p->filters);
   hipLaunchKernelGGL(k_remap_filters, dim3(std::min(pblocks, 4096)), dim3(TPB), 0, s, p->out.filter_id, p->d_scalars, p->filters.ids, (unsigned)row_bound);
   HIP_TRY(ctx, hipGetLastError());
