@@ -4,14 +4,19 @@
     SET exon.vcf_parse_info = true;
     SELECT filter, AVG(qual), COUNT(*) FROM v WHERE info."AF" > 0.01 GROUP BY filter
 
-One "step" = one full pass of the fused filter+aggregate kernel over this rank's HBM-resident shard
-(default 1e9 rows per GPU: weak scaling, one file split per GPU), state zeroing included, followed -- when
-N > 1 -- by the RCCL all-reduce of the partial aggregate state (5 x {f64 sum, 2 x i64 count} = 120 B).
+One "step" = one full pass of the fused filter+aggregate kernel over this rank's HBM-resident shard followed -- when
+N > 1 -- by the merge of the packed partial states (5 x {2 x i64 count, f64 sum} = 120 B): ONE RCCL all-gather and a
+fold in rank order.  The kernel's finalize WRITES the state (EXON_HIP_LAUNCH_OVERWRITE): no zeroing pass in the step.
+
+Scaling ("1 B rows, 8 equal shards"):
+  --scaling strong (default)  --rows is the TOTAL (default 1e9); rank k owns rows [k N/W, (k+1) N/W)
+  --scaling weak              --rows is per GPU; the table grows with the number of GPUs
 Launch: `python bench.py --gpus 1` or
 `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N --steps K --warmup W`.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -27,6 +32,19 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 BYTES_PER_ROW = {"c4": 12.25, "c2": 12.0, "c3": 9.25, "c5": 104.0, "c6": 20.375}  # algorithmic bytes/row, SURVEY.md section 8(d)
 SEED = {"c2": 2, "c3": 3, "c4": 4, "c5": 5, "c6": 6}
+DTYPE = {"c4": "f64", "c2": "int64", "c3": "int64", "c5": "u8", "c6": "int64"}
+WORKLOAD = {"c4": "config 4: 1B-row synthetic VCF, WHERE info.AF > 0.01, AVG(qual), COUNT(*) GROUP BY filter",
+            "c2": "config 2: synthetic VCF, chrom='7' AND pos in [5e7,1e8], COUNT(*)",
+            "c3": "config 3: synthetic BAM, flag&1284=0 AND mapq>=30, COUNT(*) GROUP BY reference",
+            "c5": "config 5: synthetic FASTQ (L=100), per-position 256-bin quality histogram; rows = reads",
+            "c6": "synthetic alignments, bam_region_filter('<ref 7>:50000000-100000000', reference, start, end), COUNT(*)"}
+ARITH = {"c4": "f32 columns compared as totalOrder i32 keys, f64 sums, i64 counts",
+         "c2": "i32 / i64 compares, i64 count", "c3": "i32 mask compare, u8 compare, i64 counts",
+         "c5": "u8 bytes, u32 LDS counters folded into i64", "c6": "i32 / i64 compares, i64 count"}
+GENERATOR_NOTE = {
+    "c4": "counter-based generator (DESIGN.md section 5); deviates from SURVEY 8(d): AF is log-uniform BY OCTAVE over "
+          "[2^-14, 1) with 0.01f planted at p=1/1024 instead of 10^U[-4,0] (bit-identical on CPU and GPU without libm); "
+          "47.5 % of the rows pass AF > 0.01 instead of 50 %; NULL rates and FILTER mix as in SURVEY"}
 
 
 def parse_args():
@@ -34,16 +52,24 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=float, default=1e9, help="rows per GPU (weak scaling)")
+    ap.add_argument("--rows", type=float, default=1e9, help="total rows (strong scaling) / rows per GPU (weak scaling)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--merge", default="auto", choices=["auto", "native", "torch"],
+                    help="N > 1: native = ncclAllGather on the kernels' stream through the C ABI; torch = torch.distributed; "
+                         "auto = native when it initialises and reproduces torch's result during warm-up, else torch")
     ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3", "c5", "c6"])
     ap.add_argument("--cpu-sample-rows", type=float, default=128e6)
     ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (stated-size configs, H2D-inclusive rate)")
     return ap.parse_args()
 
 
 class Workload:
-    """Device-resident synthetic shard + one launch of the hot path on torch's current stream."""
+    """Device-resident synthetic shard + one launch of the hot path on torch's current stream.
+
+    The partial state is ONE packed int64-typed tensor `[n_i64 counters][n_f64 sums bit-cast]` (exon_hip_plan_state_size)
+    written by exon_hip_plan_launch; `counts` / `sums` are views of it."""
 
     def __init__(self, ctx, kind, rows, row0, n_total):
         self.ctx, self.kind, self.n = ctx, kind, rows
@@ -51,50 +77,54 @@ class Workload:
         s = torch.cuda.current_stream().cuda_stream
         lib, h = ctx.lib, ctx.h
         nb = (rows + 7) // 8 + 64
+        alloc = max(rows, 16)
         if kind == "c4":
-            self.af = torch.empty(rows, dtype=torch.float32, device=dev)
-            self.qual = torch.empty(rows, dtype=torch.float32, device=dev)
-            self.fid = torch.empty(rows, dtype=torch.int32, device=dev)
+            self.af = torch.empty(alloc, dtype=torch.float32, device=dev)
+            self.qual = torch.empty(alloc, dtype=torch.float32, device=dev)
+            self.fid = torch.empty(alloc, dtype=torch.int32, device=dev)
             self.av = torch.zeros(nb, dtype=torch.uint8, device=dev)
             self.qv = torch.zeros(nb, dtype=torch.uint8, device=dev)
             ctx._check(lib.exon_hip_gen_c4(h, s, SEED["c4"], row0, row0 + rows, self.af.data_ptr(), self.av.data_ptr(),
                                            self.qual.data_ptr(), self.qv.data_ptr(), self.fid.data_ptr()))
             self.G = 5
-            self.counts = torch.zeros(2 * self.G, dtype=torch.int64, device=dev)
-            self.sums = torch.zeros(self.G, dtype=torch.float64, device=dev)
+            self.plan = ctx.plan_cmp_avg_by_group(">", 0.01, self.G)
+            self.cols = [(self.af.data_ptr(), self.av.data_ptr(), None), (self.qual.data_ptr(), self.qv.data_ptr(), None),
+                         (self.fid.data_ptr(), None, None)]
         elif kind == "c2":
-            self.chrom = torch.empty(rows, dtype=torch.int32, device=dev)
-            self.pos = torch.empty(rows, dtype=torch.int64, device=dev)
+            self.chrom = torch.empty(alloc, dtype=torch.int32, device=dev)
+            self.pos = torch.empty(alloc, dtype=torch.int64, device=dev)
             ctx._check(lib.exon_hip_gen_c2(h, s, SEED["c2"], n_total, row0, row0 + rows, self.chrom.data_ptr(),
                                            self.pos.data_ptr()))
-            self.counts = torch.zeros(1, dtype=torch.int64, device=dev)
-            self.sums = None
+            self.plan = ctx.plan_region_count(6, 50000000, 100000000)
+            self.cols = [(self.chrom.data_ptr(), None, None), (self.pos.data_ptr(), None, None)]
         elif kind == "c6":
-            self.ref = torch.empty(rows, dtype=torch.int32, device=dev)
-            self.start = torch.empty(rows, dtype=torch.int64, device=dev)
-            self.end = torch.empty(rows, dtype=torch.int64, device=dev)
+            self.ref = torch.empty(alloc, dtype=torch.int32, device=dev)
+            self.start = torch.empty(alloc, dtype=torch.int64, device=dev)
+            self.end = torch.empty(alloc, dtype=torch.int64, device=dev)
             self.rv = torch.zeros(nb, dtype=torch.uint8, device=dev)
             self.pv = torch.zeros(nb, dtype=torch.uint8, device=dev)
             ctx._check(lib.exon_hip_gen_c6(h, s, SEED["c6"], row0, row0 + rows, self.ref.data_ptr(), self.rv.data_ptr(),
                                            self.start.data_ptr(), self.end.data_ptr(), self.pv.data_ptr()))
-            self.counts = torch.zeros(1, dtype=torch.int64, device=dev)
-            self.sums = None
+            self.plan = ctx.plan_overlap_count(6, 50000000, 100000000, columns=(0, 1, 2))
+            self.cols = [(self.ref.data_ptr(), self.rv.data_ptr(), None), (self.start.data_ptr(), self.pv.data_ptr(), None),
+                         (self.end.data_ptr(), self.pv.data_ptr(), None)]
         elif kind == "c3":
-            self.flag = torch.empty(rows, dtype=torch.int32, device=dev)
-            self.mapq = torch.empty(rows + 64, dtype=torch.uint8, device=dev)
-            self.ref = torch.empty(rows, dtype=torch.int32, device=dev)
+            self.flag = torch.empty(alloc, dtype=torch.int32, device=dev)
+            self.mapq = torch.empty(alloc + 64, dtype=torch.uint8, device=dev)
+            self.ref = torch.empty(alloc, dtype=torch.int32, device=dev)
             self.mv = torch.zeros(nb, dtype=torch.uint8, device=dev)
             self.rv = torch.zeros(nb, dtype=torch.uint8, device=dev)
             ctx._check(lib.exon_hip_gen_c3(h, s, SEED["c3"], row0, row0 + rows, self.flag.data_ptr(), self.mapq.data_ptr(),
                                            self.mv.data_ptr(), self.ref.data_ptr(), self.rv.data_ptr()))
             self.R = 25
-            self.counts = torch.zeros(self.R + 1, dtype=torch.int64, device=dev)
-            self.sums = None
+            self.plan = ctx.plan_flag_mapq_group_count(1284, 0, 30, self.R)
+            self.cols = [(self.flag.data_ptr(), None, None), (self.mapq.data_ptr(), self.mv.data_ptr(), None),
+                         (self.ref.data_ptr(), self.rv.data_ptr(), None)]
         elif kind == "c5":
             # FASTQ quality strings, L = 100.  Arrow Utf8 has int32 offsets, so the shard is a sequence of
             # batches of <= 16 Mi reads (1.6 GB of quality bytes each); the histogram state accumulates.
             self.L = 100
-            self.batch = min(rows, 16 << 20)
+            self.batch = max(1, min(rows, 16 << 20))
             self.bytes = torch.empty(rows * self.L + 64, dtype=torch.uint8, device=dev)
             self.off = torch.empty(self.batch + 1, dtype=torch.int32, device=dev)
             for b0 in range(0, rows, self.batch):
@@ -106,52 +136,25 @@ class Workload:
                                                self.bytes.data_ptr()))
                 ctx._check(lib.exon_hip_gen_c5(h, s, SEED["c5"], row0, row0 + self.batch, self.L, self.off.data_ptr(),
                                                self.bytes.data_ptr()))
-            self.counts = torch.zeros(self.L * 256, dtype=torch.int64, device=dev)
-            self.sums = None
+            self.plan = ctx.plan_qual_pos_hist(self.L)
+        self.n_i64, self.n_f64 = self.plan.n_i64, self.plan.n_f64
+        self.state = torch.zeros(self.n_i64 + self.n_f64, dtype=torch.int64, device=dev)
+        self.counts = self.state[:self.n_i64]
+        self.sums = self.state[self.n_i64:].view(torch.float64) if self.n_f64 else None
         torch.cuda.synchronize()
 
-    def launch(self):
-        self.zero()
-        self.run()
-
-    def zero(self):
-        """Aggregation state of one step (part of the step, not of the kernel: outside the HIP-event bracket)."""
-        self.counts.zero_()
-        if self.sums is not None:
-            self.sums.zero_()
-
     def run(self):
-        from exon_amd.engine import _col
-        import ctypes as C
-        ctx, n = self.ctx, self.n
+        """The hot path over the shard: main + finalize kernels; the state is DEFINED by the launch (overwrite mode),
+        so there is no zeroing pass.  c5: one launch per <= 16 Mi-read batch, the first one overwrites."""
         s = torch.cuda.current_stream().cuda_stream
-        if self.kind == "c4":
-            c0 = _col(self.af.data_ptr(), self.av.data_ptr(), None, n)
-            c1 = _col(self.qual.data_ptr(), self.qv.data_ptr(), None, n)
-            c2 = _col(self.fid.data_ptr(), None, None, n)
-            ctx._check(ctx.lib.exon_hip_cmp_avg_by_group(ctx.h, s, C.byref(c0), C.byref(c1), C.byref(c2), n, 0.01, 0,
-                                                         self.G, self.counts.data_ptr(), self.sums.data_ptr()))
-        elif self.kind == "c2":
-            c0, c1 = _col(self.chrom.data_ptr(), None, None, n), _col(self.pos.data_ptr(), None, None, n)
-            ctx._check(ctx.lib.exon_hip_region_count(ctx.h, s, C.byref(c0), C.byref(c1), n, 6, 50000000, 100000000,
-                                                     self.counts.data_ptr()))
-        elif self.kind == "c6":
-            c0 = _col(self.ref.data_ptr(), self.rv.data_ptr(), None, n)
-            c1 = _col(self.start.data_ptr(), self.pv.data_ptr(), None, n)
-            c2 = _col(self.end.data_ptr(), self.pv.data_ptr(), None, n)
-            ctx._check(ctx.lib.exon_hip_overlap_count(ctx.h, s, C.byref(c0), C.byref(c1), C.byref(c2), n, 6, 50000000, 100000000,
-                                                      self.counts.data_ptr()))
-        elif self.kind == "c5":
-            for b0 in range(0, n, self.batch):
+        if self.kind == "c5":
+            n = self.n
+            for b0 in range(0, max(n, 1), self.batch):
                 nb_ = min(self.batch, n - b0)
-                c0 = _col(self.bytes.data_ptr() + b0 * self.L, None, self.off.data_ptr(), nb_)
-                ctx._check(ctx.lib.exon_hip_qual_pos_hist(ctx.h, s, C.byref(c0), nb_, self.L, self.counts.data_ptr()))
+                self.plan.launch([(self.bytes.data_ptr() + b0 * self.L, None, self.off.data_ptr())], nb_, self.state.data_ptr(),
+                                 overwrite=(b0 == 0), stream=s)
         else:
-            c0 = _col(self.flag.data_ptr(), None, None, n)
-            c1 = _col(self.mapq.data_ptr(), self.mv.data_ptr(), None, n)
-            c2 = _col(self.ref.data_ptr(), self.rv.data_ptr(), None, n)
-            ctx._check(ctx.lib.exon_hip_flag_mapq_group_count(ctx.h, s, C.byref(c0), C.byref(c1), C.byref(c2), n, 1284,
-                                                              0, 30, self.R, self.counts.data_ptr()))
+            self.plan.launch(self.cols, self.n, self.state.data_ptr(), overwrite=True, stream=s)
 
 
 def cpu_baseline(kind, sample_rows, n_total, reps):
@@ -217,6 +220,57 @@ def cpu_baseline(kind, sample_rows, n_total, reps):
     return res, out
 
 
+def time_config(ctx, kind, rows, steps=20, warmup=3):
+    """A config at the size BASELINE.json states it (c2 @ 1e7, c3 @ 1e8): (ms per step, kernel ms, roofline fraction)."""
+    wl = Workload(ctx, kind, rows, 0, rows)
+    for _ in range(warmup):
+        wl.run()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ev[i][0].record()
+        wl.run()
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    kms = sum(a.elapsed_time(b) for a, b in ev) / steps
+    gbs = rows * BYTES_PER_ROW[kind] / (kms * 1e-3) / 1e9
+    return {"rows": rows, "ms_per_step": round(ms, 4), "kernel_ms": round(kms, 4), "Mrows_per_s": round(rows / ms / 1e3, 1),
+            "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+
+def h2d_inclusive(ctx, n=32_000_000):
+    """PCIe-inclusive rate of the config-4 path (never `value`): host Arrow batches -> exon_hip_stream_push (pinned
+    staging, async H2D, double-buffered) -> fused kernel, for 4 Mi-row batches and the reference's 8192-row batches."""
+    import pyarrow as pa
+    rng = np.random.default_rng(4)
+    af = rng.random(n, dtype=np.float32)
+    q = (rng.integers(0, 10000, n) / 10).astype(np.float32)
+    fid = rng.integers(0, 5, n).astype(np.int32)
+    rb = pa.record_batch({"af": pa.array(af), "qual": pa.array(q),
+                          "filter": pa.DictionaryArray.from_arrays(pa.array(fid), pa.array(["PASS", "", "q10", "q10;s50", "s50"]))})
+    out = {}
+    for name, batch in (("batch_4Mi_rows", 4 << 20), ("batch_8192_rows", 8192)):
+        m = n if batch > 8192 else n // 4
+        batches = [rb.slice(i, batch) for i in range(0, m, batch)]
+        plan = ctx.plan_cmp_avg_by_group(">", 0.01, 5)
+        best = None
+        for _ in range(3):
+            st = plan.open()
+            t0 = time.perf_counter()
+            for b in batches:
+                st.push(b)
+            st.finish()
+            dt = time.perf_counter() - t0
+            st.close()
+            best = dt if best is None else min(best, dt)
+        plan.close()
+        out[name] = {"Mrows_per_s": round(m / best / 1e6, 1), "GBps_device_layout": round(m * 12.25 / best / 1e9, 2), "rows": m}
+    out["note"] = "host Arrow batches through exon_hip_stream_push (staging memcpy + H2D + kernel); reported, never `value`"
+    return out
+
+
 def main():
     a = parse_args()
     rank = int(os.environ.get("RANK", 0))
@@ -239,24 +293,61 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
 
     import exon_amd
+    from exon_amd.distributed import NativeComm, merge_state, shard_rows
     ctx = exon_amd.Context(device)
-    # kernels, state zeroing, events and collectives all go on ONE explicit (non-default) HIP stream
+    # kernels, events and collectives all go on ONE explicit (non-default) HIP stream
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
-    rows = int(a.rows)
-    n_total = rows * world
-    wl = Workload(ctx, a.workload, rows, rank * rows, n_total)
+    if a.scaling == "strong":
+        n_total = int(a.rows)
+        lo, hi = shard_rows(n_total, rank, world)
+    else:
+        n_total = int(a.rows) * world
+        lo, hi = rank * int(a.rows), (rank + 1) * int(a.rows)
+    rows = hi - lo
+    wl = Workload(ctx, a.workload, rows, lo, n_total)
+    V = wl.state.numel()
+    merged = torch.zeros_like(wl.state) if world > 1 else wl.state
+    gathered = torch.zeros(world * V, dtype=torch.int64, device=wl.state.device) if world > 1 else None
 
-    from exon_amd.distributed import all_reduce_state
+    # ---- the merge across GPUs: pick the path outside the timed region --------------------------------------------
+    merge_path = "none (1 GPU)"
+    native = None
+    if world > 1:
+        wl.run()
+        ref = merge_state(wl.state, wl.n_i64, gathered, merged, ctx=ctx).clone()  # also brings torch's communicator up
+        merge_path = "torch.distributed all_gather_into_tensor + exon_hip_fold_states"
+        if a.merge in ("auto", "native") and not share:
+            ok = 1
+            try:
+                native = NativeComm(ctx)
+                merged.zero_()
+                native.merge(wl.state, wl.n_i64, gathered, merged)
+                torch.cuda.synchronize()
+                ok = int(torch.equal(merged, ref))
+            except Exception as e:  # noqa: BLE001 -- any failure means: use torch's collective
+                ok = 0
+                if a.merge == "native":
+                    raise
+                print(f"[rank {rank}] native RCCL merge unavailable ({e}); using torch.distributed", file=sys.stderr)
+            flag = torch.tensor([ok], dtype=torch.int64, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # every rank takes the same path
+            if int(flag.item()) == 1:
+                merge_path = "exon_hip_merge_states: ncclAllGather on the kernels' stream + exon_hip_fold_states"
+            else:
+                native = None
 
-    def step():
-        wl.launch()
-        all_reduce_state(wl.counts, wl.sums)  # AggregateExec(Final) across GPUs: RCCL all-reduce over xGMI
+    def merge():
+        if world == 1:
+            return
+        if native is not None:
+            native.merge(wl.state, wl.n_i64, gathered, merged)
+        else:
+            merge_state(wl.state, wl.n_i64, gathered, merged, ctx=ctx)
 
-    if world > 1:  # bring the communicator up outside the timed region even with --warmup 0
-        dist.all_reduce(torch.zeros(1, dtype=torch.int64, device="cuda"))
     for _ in range(a.warmup):
-        step()
+        wl.run()
+        merge()
     torch.cuda.synchronize()
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
@@ -265,11 +356,10 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        wl.zero()
         ev[i][0].record()
         wl.run()  # the hot path's kernels only: main + finalize (c5: per batch, offsets scan + main + finalize)
         ev[i][1].record()
-        all_reduce_state(wl.counts, wl.sums)
+        merge()   # AggregateExec(Final) across GPUs: one all-gather over RCCL/xGMI + fixed-order fold
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -281,8 +371,9 @@ def main():
         dist.all_reduce(kern_ms, op=dist.ReduceOp.MAX)
     elapsed, kern_ms = float(elapsed.item()), float(kern_ms.item())
 
-    counts = wl.counts.cpu().numpy()
-    sums = wl.sums.cpu().numpy() if wl.sums is not None else None
+    final = merged.cpu()
+    counts = final[:wl.n_i64].numpy()
+    sums = final[wl.n_i64:].view(torch.float64).numpy() if wl.n_f64 else None
 
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
@@ -293,23 +384,19 @@ def main():
             "metric": "Mrows/sec filter+agg on 1B-row synthetic VCF; achieved HBM GB/s vs peak"
             if a.workload == "c4" else f"Mrows/sec filter+agg ({a.workload})",
             "value": round(value, 1), "unit": "Mrows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"c4": "f64", "c2": "int64", "c3": "int64", "c5": "u8", "c6": "int64"}[a.workload], "data": "synthetic",
-            "config": {"workload": {"c4": "config 4: 1B-row synthetic VCF, WHERE info.AF > 0.01, AVG(qual), COUNT(*) GROUP BY filter",
-                                    "c2": "config 2: synthetic VCF, chrom='7' AND pos in [5e7,1e8], COUNT(*)",
-                                    "c3": "config 3: synthetic BAM, flag&1284=0 AND mapq>=30, COUNT(*) GROUP BY reference",
-                                    "c5": "config 5: synthetic FASTQ (L=100), per-position 256-bin quality histogram; rows = reads",
-                                    "c6": "synthetic alignments, bam_region_filter('<ref 7>:50000000-100000000', reference, start, end), COUNT(*)"}[a.workload],
-                       "rows_per_gpu": rows, "rows_total": n_total, "sharding": "one contiguous row range (file split) per GPU",
-                       "reduce": "RCCL all-reduce of partial state" if world > 1 else "none (1 GPU)",
-                       "bytes_per_row": bpr,
-                       "arithmetic": {"c4": "f32 columns compared as totalOrder i32 keys, f64 sums, i64 counts",
-                                      "c2": "i32 / i64 compares, i64 count", "c3": "i32 mask compare, u8 compare, i64 counts",
-                                      "c5": "u8 bytes, u32 LDS counters folded into i64", "c6": "i32 / i64 compares, i64 count"}[a.workload]},
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": a.scaling,
+            "vs_baseline": None, "dtype": DTYPE[a.workload], "data": "synthetic",
+            "config": {"workload": WORKLOAD[a.workload],
+                       "rows_total": n_total, "rows_per_gpu": rows,
+                       "sharding": f"rank k owns the contiguous row range (file split) [k N/{world}, (k+1) N/{world})",
+                       "reduce": merge_path, "state_bytes": V * 8,
+                       "bytes_per_row": bpr, "arithmetic": ARITH[a.workload],
+                       "generator": GENERATOR_NOTE.get(a.workload, "counter-based generator of DESIGN.md section 5")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel_ms": round(kern_ms, 4),
-                         "note": "achieved = rows_per_gpu x bytes_per_row / mean HIP-event time of one launch (main + finalize kernels; the state zeroing of the step is outside the bracket)"},
+                         "note": "achieved = rows_per_gpu x bytes_per_row / mean HIP-event time of one launch (main + finalize "
+                                 "kernels, max over ranks); the finalize writes the state, there is no zeroing pass"},
         }
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(traffic_file):
@@ -317,6 +404,8 @@ def main():
                 t = json.load(open(traffic_file)).get(a.workload)
                 if t and int(t.get("rows", 0)) == rows:
                     out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = (f"profiles/traffic.json (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                         f"passes of round {t.get('round', '?')}, NOT measured in this run)")
             except Exception:
                 pass
         if not a.no_cpu_baseline and world == 1:
@@ -329,7 +418,7 @@ def main():
             out["cpu_baseline"] = base
             # parity gate: the GPU path over the same sample rows must reproduce the oracle
             chk = Workload(ctx, a.workload, sample, 0, n_total)
-            chk.launch()
+            chk.run()
             torch.cuda.synchronize()
             gc = chk.counts.cpu().numpy()
             if not np.array_equal(gc, oc):
@@ -337,6 +426,17 @@ def main():
             if os_ is not None and not np.allclose(chk.sums.cpu().numpy(), os_, rtol=1e-6, atol=0):
                 raise SystemExit("PARITY FAILURE: sums")
             out["parity"] = f"bit-exact counts, sums within 1e-6 rel. vs oracle on rows [0,{sample})"
+            del chk
+        if world == 1 and not a.no_extras and a.workload == "c4":
+            extras = {}
+            try:
+                extras["configs_at_stated_size"] = {"c2_1e7_rows": time_config(ctx, "c2", 10_000_000),
+                                                    "c3_1e8_rows": time_config(ctx, "c3", 100_000_000),
+                                                    "c4_shard_of_8_125e6_rows": time_config(ctx, "c4", 125_000_000)}
+                extras["h2d_inclusive"] = h2d_inclusive(ctx)
+            except Exception as e:  # noqa: BLE001 -- side measurements never cost the headline line
+                extras["error"] = repr(e)
+            out["extras"] = extras
         if a.workload == "c4":
             G = 5
             out["result"] = {"filter_rows": counts[G:].tolist(),
@@ -345,6 +445,8 @@ def main():
             out["result"] = {"counts": counts.tolist()}
         print(json.dumps(out))
     ctx.sync()
+    if native is not None:
+        native.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -108,6 +108,8 @@ PLAN_FLAG_MAPQ_GROUP_COUNT = 3
 PLAN_CMP_AVG_BY_GROUP = 4
 PLAN_QUAL_POS_HIST = 5
 PLAN_OVERLAP_COUNT = 6
+LAUNCH_ACCUMULATE = 0
+LAUNCH_OVERWRITE = 1
 CMP = {">": 0, ">=": 1, "<": 2, "<=": 3, "=": 4, "==": 4, "!=": 5, "<>": 5}
 REGION_OPEN_END = 2**63 - 1
 
@@ -145,6 +147,13 @@ SIGNATURES = {
     "exon_hip_plan_create": (C.c_int, [_vp, C.POINTER(PlanDesc), C.POINTER(_vp)]),
     "exon_hip_plan_destroy": (C.c_int, [_vp]),
     "exon_hip_plan_state_size": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "exon_hip_plan_launch": (C.c_int, [_vp, _vp, _colp, _i32, _i64, _i32, _vp]),
+    "exon_hip_fold_states": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _vp]),
+    "exon_hip_merge_states": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "exon_hip_rccl_unique_id": (C.c_int, [_vp]),
+    "exon_hip_rccl_comm_init": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_vp)]),
+    "exon_hip_rccl_comm_destroy": (C.c_int, [_vp]),
+    "exon_hip_stream_reset": (C.c_int, [_vp]),
     "exon_hip_stream_open": (C.c_int, [_vp, _i32, C.POINTER(_vp)]),
     "exon_hip_stream_push": (C.c_int, [_vp, C.POINTER(ArrowArray)]),
     "exon_hip_stream_push_device": (C.c_int, [_vp, C.POINTER(ArrowDeviceArray)]),

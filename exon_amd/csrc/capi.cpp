@@ -79,7 +79,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 extern "C" {
 
-int exon_hip_abi_version(void) { return 1; }
+int exon_hip_abi_version(void) { return 2; }
 
 int exon_hip_device_count(int* out) {
   if (!out) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_device_count: out is NULL");
@@ -271,6 +271,18 @@ int exon_hip_timer_stop_ms(exon_hip_ctx* ctx, void* stream, float* ms) {
 }
 
 // ---- operator launches ---------------------------------------------------------------------------
+// `flags`: EXON_HIP_LAUNCH_*.  OVERWRITE makes the launch DEFINE the state (finalize writes instead of adding), so a
+// query needs no zeroing pass; an empty input then still has to leave zeros behind.
+static LaunchCfg cfg_for(const exon_hip_ctx* ctx, int flags) {
+  LaunchCfg c = ctx->cfg;
+  c.overwrite = (flags & EXON_HIP_LAUNCH_OVERWRITE) != 0;
+  return c;
+}
+static int empty_input(exon_hip_ctx* ctx, hipStream_t s, int flags, void* state, size_t bytes) {
+  if ((flags & EXON_HIP_LAUNCH_OVERWRITE) && bytes) HIP_TRY(ctx, hipMemsetAsync(state, 0, bytes, s));
+  return EXON_HIP_OK;
+}
+
 static int check_col(exon_hip_ctx* ctx, const char* what, const exon_hip_column* c, int64_t n, bool need_offsets) {
   if (!c) return fail(ctx, EXON_HIP_EINVAL, "%s: column is NULL", what);
   if (n > 0 && !c->values) return fail(ctx, EXON_HIP_EINVAL, "%s: values is NULL", what);
@@ -280,45 +292,47 @@ static int check_col(exon_hip_ctx* ctx, const char* what, const exon_hip_column*
   return EXON_HIP_OK;
 }
 
-int exon_hip_region_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* chrom_id, const exon_hip_column* pos,
-                          int64_t n, int32_t region_chrom_id, int64_t start, int64_t end, int64_t* d_count) {
+}  // extern "C"
+
+int exon_op_region_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* chrom_id, const exon_hip_column* pos,
+                         int64_t n, int32_t region_chrom_id, int64_t start, int64_t end, int64_t* d_count, int flags) {
   if (!ctx || !d_count) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_region_count: NULL argument");
   if (n < 0) return fail(ctx, EXON_HIP_EINVAL, "n < 0");
   int rc;
   if ((rc = check_col(ctx, "chrom_id", chrom_id, n, false)) || (rc = check_col(ctx, "pos", pos, n, false))) return rc;
-  if (n == 0) return EXON_HIP_OK;
   hipStream_t s = pick_stream(ctx, stream);
+  if (n == 0) return empty_input(ctx, s, flags, d_count, 8);
   Workspace ws;
   if ((rc = get_workspace(ctx, s, exon::k2_partial_words(ctx->cfg), &ws))) return fail(ctx, rc, "workspace allocation failed");
-  HIP_TRY(ctx, exon::launch_region_count(s, ctx->cfg, ws, (const int32_t*)chrom_id->values, chrom_id->validity,
+  HIP_TRY(ctx, exon::launch_region_count(s, cfg_for(ctx, flags), ws, (const int32_t*)chrom_id->values, chrom_id->validity,
                                          (const int64_t*)pos->values, pos->validity, n, region_chrom_id, start, end,
                                          d_count));
   return EXON_HIP_OK;
 }
 
-int exon_hip_overlap_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* ref_id, const exon_hip_column* start,
-                           const exon_hip_column* end, int64_t n, int32_t region_ref_id, int64_t region_start,
-                           int64_t region_end, int64_t* d_count) {
+int exon_op_overlap_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* ref_id, const exon_hip_column* start,
+                          const exon_hip_column* end, int64_t n, int32_t region_ref_id, int64_t region_start,
+                          int64_t region_end, int64_t* d_count, int flags) {
   if (!ctx || !d_count) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_overlap_count: NULL argument");
   if (n < 0) return fail(ctx, EXON_HIP_EINVAL, "n < 0");
   int rc;
   if ((rc = check_col(ctx, "ref_id", ref_id, n, false)) || (rc = check_col(ctx, "start", start, n, false)) ||
       (rc = check_col(ctx, "end", end, n, false)))
     return rc;
-  if (n == 0) return EXON_HIP_OK;
   hipStream_t s = pick_stream(ctx, stream);
+  if (n == 0) return empty_input(ctx, s, flags, d_count, 8);
   Workspace ws;
   if ((rc = get_workspace(ctx, s, exon::k2_partial_words(ctx->cfg), &ws))) return fail(ctx, rc, "workspace allocation failed");
-  HIP_TRY(ctx, exon::launch_overlap_count(s, ctx->cfg, ws, (const int32_t*)ref_id->values, ref_id->validity,
+  HIP_TRY(ctx, exon::launch_overlap_count(s, cfg_for(ctx, flags), ws, (const int32_t*)ref_id->values, ref_id->validity,
                                           (const int64_t*)start->values, start->validity, (const int64_t*)end->values,
                                           end->validity, n, region_ref_id, region_start, region_end, d_count));
   return EXON_HIP_OK;
 }
 
-int exon_hip_flag_mapq_group_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* flag,
-                                   const exon_hip_column* mapq, const exon_hip_column* ref_id, int64_t n,
-                                   int32_t flag_mask, int32_t flag_value, int32_t mapq_min, int32_t n_refs,
-                                   int64_t* d_counts) {
+int exon_op_flag_mapq_group_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* flag,
+                                  const exon_hip_column* mapq, const exon_hip_column* ref_id, int64_t n,
+                                  int32_t flag_mask, int32_t flag_value, int32_t mapq_min, int32_t n_refs,
+                                  int64_t* d_counts, int flags) {
   if (!ctx || !d_counts) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_flag_mapq_group_count: NULL argument");
   if (n < 0) return fail(ctx, EXON_HIP_EINVAL, "n < 0");
   if (n_refs < 0 || n_refs >= EXON_HIP_MAX_REFERENCES)
@@ -327,20 +341,20 @@ int exon_hip_flag_mapq_group_count(exon_hip_ctx* ctx, void* stream, const exon_h
   if ((rc = check_col(ctx, "flag", flag, n, false)) || (rc = check_col(ctx, "mapq", mapq, n, false)) ||
       (rc = check_col(ctx, "ref_id", ref_id, n, false)))
     return rc;
-  if (n == 0) return EXON_HIP_OK;
   hipStream_t s = pick_stream(ctx, stream);
+  if (n == 0) return empty_input(ctx, s, flags, d_counts, (size_t)(n_refs + 1) * 8);
   Workspace ws;
   if ((rc = get_workspace(ctx, s, exon::k3_partial_words(ctx->cfg, n_refs), &ws))) return fail(ctx, rc, "workspace allocation failed");
-  HIP_TRY(ctx, exon::launch_flag_mapq_group_count(s, ctx->cfg, ws, (const int32_t*)flag->values, flag->validity,
+  HIP_TRY(ctx, exon::launch_flag_mapq_group_count(s, cfg_for(ctx, flags), ws, (const int32_t*)flag->values, flag->validity,
                                                   (const uint8_t*)mapq->values, mapq->validity,
                                                   (const int32_t*)ref_id->values, ref_id->validity, n, flag_mask,
                                                   flag_value, mapq_min, n_refs, d_counts));
   return EXON_HIP_OK;
 }
 
-int exon_hip_cmp_avg_by_group(exon_hip_ctx* ctx, void* stream, const exon_hip_column* x, const exon_hip_column* y,
-                              const exon_hip_column* group_id, int64_t n, double threshold, int32_t cmp_op,
-                              int32_t n_groups, int64_t* d_counts, double* d_sums) {
+int exon_op_cmp_avg_by_group(exon_hip_ctx* ctx, void* stream, const exon_hip_column* x, const exon_hip_column* y,
+                             const exon_hip_column* group_id, int64_t n, double threshold, int32_t cmp_op,
+                             int32_t n_groups, int64_t* d_counts, double* d_sums, int flags) {
   if (!ctx || !d_counts || !d_sums) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_cmp_avg_by_group: NULL argument");
   if (n < 0) return fail(ctx, EXON_HIP_EINVAL, "n < 0");
   if (cmp_op < EXON_HIP_GT || cmp_op > EXON_HIP_NE) return fail(ctx, EXON_HIP_EINVAL, "bad cmp_op %d", cmp_op);
@@ -353,31 +367,74 @@ int exon_hip_cmp_avg_by_group(exon_hip_ctx* ctx, void* stream, const exon_hip_co
   if ((rc = check_col(ctx, "x", x, n, false)) || (rc = check_col(ctx, "y", y, n, false)) ||
       (rc = check_col(ctx, "group_id", group_id, n, false)))
     return rc;
-  if (n == 0) return EXON_HIP_OK;
   hipStream_t s = pick_stream(ctx, stream);
+  if (n == 0) {
+    if ((rc = empty_input(ctx, s, flags, d_counts, (size_t)n_groups * 16))) return rc;
+    return empty_input(ctx, s, flags, d_sums, (size_t)n_groups * 8);
+  }
   Workspace ws;
   if ((rc = get_workspace(ctx, s, exon::k4_partial_words(ctx->cfg, n_groups), &ws))) return fail(ctx, rc, "workspace allocation failed");
-  HIP_TRY(ctx, exon::launch_cmp_avg_by_group(s, ctx->cfg, ws, (const float*)x->values, x->validity,
+  HIP_TRY(ctx, exon::launch_cmp_avg_by_group(s, cfg_for(ctx, flags), ws, (const float*)x->values, x->validity,
                                              (const float*)y->values, y->validity, (const int32_t*)group_id->values,
                                              n, threshold, cmp_op, n_groups, d_counts, d_sums));
   return EXON_HIP_OK;
 }
 
-int exon_hip_qual_pos_hist(exon_hip_ctx* ctx, void* stream, const exon_hip_column* q, int64_t n_reads, int32_t lmax,
-                           int64_t* d_hist) {
+int exon_op_qual_pos_hist(exon_hip_ctx* ctx, void* stream, const exon_hip_column* q, int64_t n_reads, int32_t lmax,
+                          int64_t* d_hist, int flags) {
   if (!ctx || !d_hist) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_qual_pos_hist: NULL argument");
   if (n_reads < 0) return fail(ctx, EXON_HIP_EINVAL, "n_reads < 0");
   if (lmax < 1 || lmax > (1 << 20)) return fail(ctx, EXON_HIP_EINVAL, "lmax %d out of range", lmax);
   if (!q) return fail(ctx, EXON_HIP_EINVAL, "quality_scores column is NULL");
   if (q->validity) return fail(ctx, EXON_HIP_EUNSUPPORTED, "nullable quality_scores (the reference column is non-null)");
-  if (n_reads == 0) return EXON_HIP_OK;
+  if (n_reads == 0) return empty_input(ctx, pick_stream(ctx, stream), flags, d_hist, (size_t)lmax * 256 * 8);
   if (!q->offsets || !q->values) return fail(ctx, EXON_HIP_EINVAL, "quality_scores: offsets/values NULL");
   if (q->length < n_reads) return fail(ctx, EXON_HIP_EINVAL, "quality_scores: length < n_reads");
   hipStream_t s = pick_stream(ctx, stream);
   Workspace ws;
   int rc;
   if ((rc = get_workspace(ctx, s, exon::k5_partial_words(ctx->cfg, lmax), &ws))) return fail(ctx, rc, "workspace allocation failed");
-  HIP_TRY(ctx, exon::launch_qual_pos_hist(s, ctx->cfg, ws, q->offsets, (const uint8_t*)q->values, n_reads, lmax, d_hist));
+  HIP_TRY(ctx, exon::launch_qual_pos_hist(s, cfg_for(ctx, flags), ws, q->offsets, (const uint8_t*)q->values, n_reads, lmax, d_hist));
+  return EXON_HIP_OK;
+}
+
+extern "C" {
+
+int exon_hip_region_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* chrom_id, const exon_hip_column* pos,
+                          int64_t n, int32_t region_chrom_id, int64_t start, int64_t end, int64_t* d_count) {
+  return exon_op_region_count(ctx, stream, chrom_id, pos, n, region_chrom_id, start, end, d_count, EXON_HIP_LAUNCH_ACCUMULATE);
+}
+int exon_hip_overlap_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* ref_id, const exon_hip_column* start,
+                           const exon_hip_column* end, int64_t n, int32_t region_ref_id, int64_t region_start,
+                           int64_t region_end, int64_t* d_count) {
+  return exon_op_overlap_count(ctx, stream, ref_id, start, end, n, region_ref_id, region_start, region_end, d_count,
+                               EXON_HIP_LAUNCH_ACCUMULATE);
+}
+int exon_hip_flag_mapq_group_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* flag,
+                                   const exon_hip_column* mapq, const exon_hip_column* ref_id, int64_t n,
+                                   int32_t flag_mask, int32_t flag_value, int32_t mapq_min, int32_t n_refs,
+                                   int64_t* d_counts) {
+  return exon_op_flag_mapq_group_count(ctx, stream, flag, mapq, ref_id, n, flag_mask, flag_value, mapq_min, n_refs, d_counts,
+                                       EXON_HIP_LAUNCH_ACCUMULATE);
+}
+int exon_hip_cmp_avg_by_group(exon_hip_ctx* ctx, void* stream, const exon_hip_column* x, const exon_hip_column* y,
+                              const exon_hip_column* group_id, int64_t n, double threshold, int32_t cmp_op,
+                              int32_t n_groups, int64_t* d_counts, double* d_sums) {
+  return exon_op_cmp_avg_by_group(ctx, stream, x, y, group_id, n, threshold, cmp_op, n_groups, d_counts, d_sums,
+                                  EXON_HIP_LAUNCH_ACCUMULATE);
+}
+int exon_hip_qual_pos_hist(exon_hip_ctx* ctx, void* stream, const exon_hip_column* q, int64_t n_reads, int32_t lmax,
+                           int64_t* d_hist) {
+  return exon_op_qual_pos_hist(ctx, stream, q, n_reads, lmax, d_hist, EXON_HIP_LAUNCH_ACCUMULATE);
+}
+
+// Fixed-order fold of `world` gathered packed states (AggregateExec(Final) across GPUs after one all-gather).
+int exon_hip_fold_states(exon_hip_ctx* ctx, void* stream, const void* d_gathered, int32_t world, int64_t n_i64,
+                         int64_t n_f64, void* d_out) {
+  if (!ctx || !d_gathered || !d_out) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_fold_states: NULL argument");
+  if (world < 1 || n_i64 < 0 || n_f64 < 0 || n_i64 + n_f64 < 1 || n_i64 + n_f64 > INT32_MAX)
+    return fail(ctx, EXON_HIP_EINVAL, "exon_hip_fold_states: bad sizes (world %d, %lld + %lld words)", world, (long long)n_i64, (long long)n_f64);
+  HIP_TRY(ctx, exon::launch_fold_states(pick_stream(ctx, stream), d_gathered, world, n_i64, n_f64, d_out));
   return EXON_HIP_OK;
 }
 

@@ -50,3 +50,19 @@ void exon_hip_release_ctx_caches(exon_hip_ctx* ctx);
 // capi.cpp: size-keyed recycling of device buffers (released by exon_hip_ctx_destroy)
 void* exon_pool_alloc(exon_hip_ctx* ctx, size_t bytes);
 void exon_pool_free(exon_hip_ctx* ctx, void* p);
+
+// capi.cpp: the operator launches with EXON_HIP_LAUNCH_* flags (the extern "C" operators are the ACCUMULATE forms)
+int exon_op_region_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* chrom_id, const exon_hip_column* pos,
+                         int64_t n, int32_t region_chrom_id, int64_t start, int64_t end, int64_t* d_count, int flags);
+int exon_op_overlap_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* ref_id, const exon_hip_column* start,
+                          const exon_hip_column* end, int64_t n, int32_t region_ref_id, int64_t region_start,
+                          int64_t region_end, int64_t* d_count, int flags);
+int exon_op_flag_mapq_group_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* flag,
+                                  const exon_hip_column* mapq, const exon_hip_column* ref_id, int64_t n,
+                                  int32_t flag_mask, int32_t flag_value, int32_t mapq_min, int32_t n_refs,
+                                  int64_t* d_counts, int flags);
+int exon_op_cmp_avg_by_group(exon_hip_ctx* ctx, void* stream, const exon_hip_column* x, const exon_hip_column* y,
+                             const exon_hip_column* group_id, int64_t n, double threshold, int32_t cmp_op,
+                             int32_t n_groups, int64_t* d_counts, double* d_sums, int flags);
+int exon_op_qual_pos_hist(exon_hip_ctx* ctx, void* stream, const exon_hip_column* q, int64_t n_reads, int32_t lmax,
+                          int64_t* d_hist, int flags);

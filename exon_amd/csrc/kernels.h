@@ -16,6 +16,7 @@ struct Workspace {
 struct LaunchCfg {
   int compute_units = 256;
   int blocks_per_cu = 8;  // main-kernel grid = compute_units * blocks_per_cu (persistent, grid-stride)
+  bool overwrite = false; // state := result of this launch (EXON_HIP_LAUNCH_OVERWRITE) instead of state += result
 };
 
 size_t k2_partial_words(const LaunchCfg&);
@@ -48,6 +49,9 @@ hipError_t launch_qual_pos_hist(hipStream_t s, const LaunchCfg& cfg, const Works
 hipError_t launch_qual_pos_hist_views(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* starts,
                                       const int32_t* ends, const uint8_t* bytes, int64_t n_reads, int lmax,
                                       int64_t* d_hist);
+
+// out[v] = sum over ranks (rank order) of gathered[rank][v]; words [0, n_i64) int64, then n_f64 float64
+hipError_t launch_fold_states(hipStream_t s, const void* gathered, int world, int64_t n_i64, int64_t n_f64, void* out);
 
 hipError_t launch_gen_c2(hipStream_t s, uint64_t seed, int64_t n_total, int64_t lo, int64_t hi, int32_t* chrom,
                          int64_t* pos);

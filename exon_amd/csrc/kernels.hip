@@ -96,9 +96,13 @@ __device__ __forceinline__ int32_t f32_key(float f) {
 // grid = ceil(V / 32), block = 256 = 32 values x 8 segments of the workgroup range; every thread keeps
 // 4 independent loads in flight, the 8 segment sums are combined in a fixed order.
 // ------------------------------------------------------------------------------------------------
+// overwrite != 0: state[v] = sum (the state needs no zeroing pass before the launch that produces it).
+// (Folding inside the main kernel by the last workgroup to finish -- the ticket pattern -- was tried and dropped: the
+// agent-scope release/acquire fences it needs are L2 writeback / invalidate scans on this chip and cost more than this
+// second launch, 37 vs 28 us on config 2's 10 M rows; profiles/r2_tuning.md.)
 __global__ __launch_bounds__(256) void finalize_partials(const unsigned long long* __restrict__ partials, int nblocks,
                                                          int V, int n_i64, int64_t* __restrict__ st_i64,
-                                                         double* __restrict__ st_f64) {
+                                                         double* __restrict__ st_f64, int overwrite) {
   __shared__ unsigned long long red[8][32];
   const int vi = threadIdx.x & 31, seg = threadIdx.x >> 5;
   const int v = blockIdx.x * 32 + vi;
@@ -135,20 +139,50 @@ __global__ __launch_bounds__(256) void finalize_partials(const unsigned long lon
       unsigned long long t = 0;
 #pragma unroll
       for (int s = 0; s < 8; ++s) t += red[s][vi];
-      st_i64[v] += (int64_t)t;
+      st_i64[v] = (overwrite ? 0 : st_i64[v]) + (int64_t)t;
     } else {
       double t = 0.0;
 #pragma unroll
       for (int s = 0; s < 8; ++s) t += __longlong_as_double((long long)red[s][vi]);
-      st_f64[v - n_i64] += t;
+      st_f64[v - n_i64] = (overwrite ? 0.0 : st_f64[v - n_i64]) + t;
     }
   }
 }
 
-static hipError_t run_finalize(hipStream_t s, const Workspace& ws, int nblocks, int V, int n_i64, int64_t* st_i64,
-                               double* st_f64) {
+static hipError_t run_finalize(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, int nblocks, int V, int n_i64,
+                               int64_t* st_i64, double* st_f64) {
   const int grid = (V + 31) / 32;
-  hipLaunchKernelGGL(finalize_partials, dim3(grid), dim3(256), 0, s, ws.partials, nblocks, V, n_i64, st_i64, st_f64);
+  hipLaunchKernelGGL(finalize_partials, dim3(grid), dim3(256), 0, s, ws.partials, nblocks, V, n_i64, st_i64, st_f64,
+                     cfg.overwrite ? 1 : 0);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// fold_states: AggregateExec(Final) across GPUs after ONE all-gather of the packed partial states.
+// gathered = [world][V] words (rank-major; words [0, n_i64) int64, the rest float64); out[v] = sum over ranks in
+// rank order 0, 1, ..., world-1: every rank computes the same bits whatever algorithm the collective used.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fold_states(const unsigned long long* __restrict__ gathered, int world, int V,
+                                                   int n_i64, unsigned long long* __restrict__ out) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= V) return;
+  if (v < n_i64) {
+    unsigned long long t = 0;
+    for (int r = 0; r < world; ++r) t += gathered[(size_t)r * V + v];
+    out[v] = t;
+  } else {
+    double t = 0.0;
+    for (int r = 0; r < world; ++r) t += __longlong_as_double((long long)gathered[(size_t)r * V + v]);
+    out[v] = (unsigned long long)__double_as_longlong(t);
+  }
+}
+
+hipError_t launch_fold_states(hipStream_t s, const void* gathered, int world, int64_t n_i64, int64_t n_f64, void* out) {
+  const int64_t V = n_i64 + n_f64;
+  if (V <= 0 || world < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fold_states, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, s,
+                     static_cast<const unsigned long long*>(gathered), world, (int)V, (int)n_i64,
+                     static_cast<unsigned long long*>(out));
   return hipGetLastError();
 }
 
@@ -266,7 +300,7 @@ hipError_t launch_region_count(hipStream_t s, const LaunchCfg& cfg, const Worksp
                      ? k2_launch<ShapeBig>(s, cfg, ws, chrom, chrom_valid, pos, pos_valid, n, region_chrom, start, end, &grid)
                      : k2_launch<ShapeSmall>(s, cfg, ws, chrom, chrom_valid, pos, pos_valid, n, region_chrom, start, end, &grid);
   if (e != hipSuccess) return e;
-  return run_finalize(s, ws, grid, 1, 1, d_count, nullptr);
+  return run_finalize(s, cfg, ws, grid, 1, 1, d_count, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -360,7 +394,7 @@ hipError_t launch_overlap_count(hipStream_t s, const LaunchCfg& cfg, const Works
                                        : k6_launch<ShapeSmall>(s, cfg, ws, ref, ref_valid, start, start_valid, end, end_valid, n,
                                                                region_ref, region_start, region_end, &grid);
   if (e != hipSuccess) return e;
-  return run_finalize(s, ws, grid, 1, 1, d_count, nullptr);
+  return run_finalize(s, cfg, ws, grid, 1, 1, d_count, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -485,6 +519,10 @@ hipError_t launch_flag_mapq_group_count(hipStream_t s, const LaunchCfg& cfg, con
                                         int32_t flag_value, int32_t mapq_min, int32_t n_refs, int64_t* d_counts) {
   if (n <= 0) return hipSuccess;
   if (n_refs + 1 > 4096) {
+    if (cfg.overwrite) {  // the global-atomic path adds straight into the caller's counters
+      hipError_t e0 = hipMemsetAsync(d_counts, 0, (size_t)(n_refs + 1) * 8, s);
+      if (e0 != hipSuccess) return e0;
+    }
     const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)cfg.compute_units * 32);
     hipLaunchKernelGGL(k3_flag_mapq_group_count_global, dim3(grid), dim3(256), 0, s, flag, flag_valid, mapq, mapq_valid, ref_id,
                        ref_valid, n, flag_mask, flag_value, mapq_min, n_refs, reinterpret_cast<unsigned long long*>(d_counts),
@@ -500,7 +538,7 @@ hipError_t launch_flag_mapq_group_count(hipStream_t s, const LaunchCfg& cfg, con
                                              flag_mask, flag_value, mapq_min, n_refs, &grid);
   if (e != hipSuccess) return e;
   const int V = n_refs + 1;
-  return run_finalize(s, ws, grid, V, V, d_counts, nullptr);
+  return run_finalize(s, cfg, ws, grid, V, V, d_counts, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -775,7 +813,7 @@ hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Wo
   }
   if (e != hipSuccess) return e;
   // per-workgroup records are [cnn[G]] [crow[G]] [sum[G]] = the state layout [counts[2G]] [sums[G]]
-  return run_finalize(s, ws, grid, 3 * n_groups, 2 * n_groups, d_counts, d_sums);
+  return run_finalize(s, cfg, ws, grid, 3 * n_groups, 2 * n_groups, d_counts, d_sums);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1102,6 +1140,7 @@ hipError_t launch_qual_pos_hist_views(hipStream_t s, const LaunchCfg& cfg, const
   // (a memset per batch would be a fourth launch; a launch that fails midway can leave it set, which only costs speed:
   // the ragged path is correct for uniform reads too)
   hipError_t e;
+  if (cfg.overwrite && (e = hipMemsetAsync(d_hist, 0, (size_t)lmax * 256 * 8, s)) != hipSuccess) return e;  // k5_finalize adds
   int sgrid = (int)std::min<int64_t>((n_reads + 255) / 256, (int64_t)cfg.compute_units * 8);
   hipLaunchKernelGGL(k5_scan_offsets, dim3(sgrid), dim3(256), 0, s, offsets, ends, n_reads, lmax, flags, ws.status);
   // LDS block: the larger of the byte-major [128][LP] layout (paths A and G) and the [pt][129] layout (B, long G)

@@ -68,6 +68,9 @@ struct exon_hip_stream {
   int64_t cap_rows = 0, cap_bytes = 0;
   bool closed = false;
   int64_t rows_pushed = 0;
+  bool overwrite_next = false;  // exon_hip_stream_reset: the next launch DEFINES the state (no zeroing kernel)
+  uint8_t* d_gather = nullptr;  // [world][state words] receive buffer of the all-gather merge
+  size_t gather_bytes = 0;
 };
 
 // ---- bit utilities (Arrow LSB-first bitmaps) -------------------------------------------------------
@@ -136,28 +139,42 @@ static int alloc_slot(exon_hip_stream* st, Slot& s) {
   return EXON_HIP_OK;
 }
 
-// launch the plan's kernel over device columns
-static int launch_plan(exon_hip_stream* st, const exon_hip_column* cols, int64_t n) {
-  const exon_hip_plan_desc& d = st->plan->d;
-  int64_t* counts = reinterpret_cast<int64_t*>(st->d_state);
-  double* sums = reinterpret_cast<double*>(st->d_state + st->plan->n_i64 * 8);
+// launch the plan's kernel over device columns (operator argument order) into the packed state [n_i64][n_f64]
+static int run_plan(const exon_hip_plan* p, void* stream, const exon_hip_column* cols, int64_t n, int flags, void* d_state) {
+  const exon_hip_plan_desc& d = p->d;
+  exon_hip_ctx* ctx = p->ctx;
+  int64_t* counts = reinterpret_cast<int64_t*>(d_state);
+  double* sums = reinterpret_cast<double*>(static_cast<uint8_t*>(d_state) + p->n_i64 * 8);
   switch (d.kind) {
     case EXON_HIP_PLAN_REGION_COUNT:
-      return exon_hip_region_count(st->ctx, st->stream, &cols[0], &cols[1], n, d.region_chrom_id, d.region_start,
-                                   d.region_end, counts);
+      return exon_op_region_count(ctx, stream, &cols[0], &cols[1], n, d.region_chrom_id, d.region_start, d.region_end, counts,
+                                  flags);
     case EXON_HIP_PLAN_FLAG_MAPQ_GROUP_COUNT:
-      return exon_hip_flag_mapq_group_count(st->ctx, st->stream, &cols[0], &cols[1], &cols[2], n, d.flag_mask,
-                                            d.flag_value, d.mapq_min, d.n_groups, counts);
+      return exon_op_flag_mapq_group_count(ctx, stream, &cols[0], &cols[1], &cols[2], n, d.flag_mask, d.flag_value, d.mapq_min,
+                                           d.n_groups, counts, flags);
     case EXON_HIP_PLAN_CMP_AVG_BY_GROUP:
-      return exon_hip_cmp_avg_by_group(st->ctx, st->stream, &cols[0], &cols[1], &cols[2], n, d.threshold, d.cmp_op,
-                                       d.n_groups, counts, sums);
+      return exon_op_cmp_avg_by_group(ctx, stream, &cols[0], &cols[1], &cols[2], n, d.threshold, d.cmp_op, d.n_groups, counts,
+                                      sums, flags);
     case EXON_HIP_PLAN_QUAL_POS_HIST:
-      return exon_hip_qual_pos_hist(st->ctx, st->stream, &cols[0], n, d.lmax, counts);
+      return exon_op_qual_pos_hist(ctx, stream, &cols[0], n, d.lmax, counts, flags);
     case EXON_HIP_PLAN_OVERLAP_COUNT:
-      return exon_hip_overlap_count(st->ctx, st->stream, &cols[0], &cols[1], &cols[2], n, d.region_chrom_id, d.region_start,
-                                    d.region_end, counts);
+      return exon_op_overlap_count(ctx, stream, &cols[0], &cols[1], &cols[2], n, d.region_chrom_id, d.region_start,
+                                   d.region_end, counts, flags);
   }
-  return fail(st->ctx, EXON_HIP_EINVAL, "unknown plan kind %d", d.kind);
+  return fail(ctx, EXON_HIP_EINVAL, "unknown plan kind %d", d.kind);
+}
+static int launch_plan(exon_hip_stream* st, const exon_hip_column* cols, int64_t n) {
+  const int flags = st->overwrite_next ? EXON_HIP_LAUNCH_OVERWRITE : EXON_HIP_LAUNCH_ACCUMULATE;
+  int rc = run_plan(st->plan, st->stream, cols, n, flags, st->d_state);
+  if (!rc) st->overwrite_next = false;
+  return rc;
+}
+// a reset that no launch has followed yet: the state is all zeros
+static int settle_reset(exon_hip_stream* st) {
+  if (!st->overwrite_next) return EXON_HIP_OK;
+  HIP_TRY(st->ctx, hipMemsetAsync(st->d_state, 0, (size_t)(st->plan->n_i64 + st->plan->n_f64) * 8, st->stream));
+  st->overwrite_next = false;
+  return EXON_HIP_OK;
 }
 
 static int flush_slot(exon_hip_stream* st) {
@@ -437,6 +454,7 @@ int exon_hip_stream_launch_views(exon_hip_stream* st, const uint8_t* d_text, con
   const int idx = p->d.columns[0];
   if (idx != 2 && idx != 3) return fail(st->ctx, EXON_HIP_EINVAL, "plan needs scan column %d; FASTQ views exist for 2 (sequence) and 3 (quality_scores)", idx);
   int rc = flush_slot(st);
+  if (!rc) rc = settle_reset(st);
   if (rc) return rc;
   (void)d_text;  // the views index v.text_base (the aligned address at or below the slab)
   rc = exon_hip_qual_pos_hist_views(st->ctx, st->stream, v.text_base, idx == 2 ? v.seq_start : v.qual_start,
@@ -448,6 +466,12 @@ int exon_hip_stream_launch_views(exon_hip_stream* st, const uint8_t* d_text, con
 void* exon_hip_stream_hip_stream(exon_hip_stream* st) { return (void*)st->stream; }
 exon_hip_ctx* exon_hip_stream_ctx(exon_hip_stream* st) { return st->ctx; }
 int exon_hip_stream_state_copy(exon_hip_stream* st, void* d_snapshot, bool restore) {
+  if (!restore) {
+    int rc = settle_reset(st);
+    if (rc) return rc;
+  } else {
+    st->overwrite_next = false;
+  }
   const size_t bytes = (size_t)(st->plan->n_i64 + st->plan->n_f64) * 8;
   HIP_TRY(st->ctx, hipMemcpyAsync(restore ? (void*)st->d_state : d_snapshot, restore ? d_snapshot : (void*)st->d_state, bytes,
                                   hipMemcpyDeviceToDevice, st->stream));
@@ -537,6 +561,7 @@ int exon_hip_stream_push_device(exon_hip_stream* st, const struct ArrowDeviceArr
 int exon_hip_stream_state(exon_hip_stream* st, int64_t** d_i64, double** d_f64, void** hip_stream) {
   if (!st) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_stream_state: NULL stream");
   int rc = flush_slot(st);
+  if (!rc) rc = settle_reset(st);
   if (rc) return rc;
   if (d_i64) *d_i64 = reinterpret_cast<int64_t*>(st->d_state);
   if (d_f64) *d_f64 = reinterpret_cast<double*>(st->d_state + st->plan->n_i64 * 8);
@@ -544,35 +569,173 @@ int exon_hip_stream_state(exon_hip_stream* st, int64_t** d_i64, double** d_f64, 
   return EXON_HIP_OK;
 }
 
-// AggregateExec(Final) across GPUs in native code: one in-place all-reduce(sum) of the int64 counters and one of the f64
-// sums over RCCL, enqueued on the stream's hipStream_t.  librccl is resolved at the first call (dlopen), so hosts that
-// never merge across GPUs -- and machines without RCCL -- do not need it.
+}  // extern "C"
+
+// ---- RCCL (loaded on first use: hosts that never merge across GPUs -- and machines without RCCL -- do not need it) ----
+namespace {
+struct Rccl {
+  typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+  typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+  typedef int (*count_fn)(void*, int*);
+  typedef int (*uid_fn)(void*);
+  typedef int (*destroy_fn)(void*);
+  void* lib = nullptr;
+  allreduce_fn all_reduce = nullptr;
+  allgather_fn all_gather = nullptr;
+  count_fn comm_count = nullptr, comm_rank = nullptr;
+  uid_fn get_unique_id = nullptr;
+  void* init_rank = nullptr;  // ncclCommInitRank(ncclComm_t*, int, ncclUniqueId /* 128 bytes BY VALUE */, int)
+  destroy_fn comm_destroy = nullptr;
+  Rccl() {
+    lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return;
+    all_reduce = (allreduce_fn)dlsym(lib, "ncclAllReduce");
+    all_gather = (allgather_fn)dlsym(lib, "ncclAllGather");
+    comm_count = (count_fn)dlsym(lib, "ncclCommCount");
+    comm_rank = (count_fn)dlsym(lib, "ncclCommUserRank");
+    get_unique_id = (uid_fn)dlsym(lib, "ncclGetUniqueId");
+    init_rank = dlsym(lib, "ncclCommInitRank");
+    comm_destroy = (destroy_fn)dlsym(lib, "ncclCommDestroy");
+  }
+  bool ok() const { return all_reduce && all_gather && comm_count && comm_rank && get_unique_id && init_rank && comm_destroy; }
+};
+const Rccl& rccl() {
+  static Rccl r;
+  return r;
+}
+struct UniqueId {
+  char internal[128];  // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+};
+constexpr int NCCL_INT64 = 4, NCCL_SUM = 0;  // rccl.h: ncclDataType_t / ncclRedOp_t
+constexpr size_t GATHER_MERGE_MAX_STATE = 1 << 20;  // larger states (K3 with millions of references) are all-reduced
+}  // namespace
+
+extern "C" {
+
+// ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy for hosts without an RCCL binding of their own: rank 0 creates the id,
+// ships its 128 bytes to the other ranks by any means, every rank (one process per GPU) calls comm_init on its ctx.
+int exon_hip_rccl_unique_id(uint8_t* id128) {
+  if (!id128) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_rccl_unique_id: NULL argument");
+  if (!rccl().ok()) return fail(nullptr, EXON_HIP_EUNSUPPORTED, "librccl.so could not be loaded");
+  UniqueId id;
+  const int e = rccl().get_unique_id(&id);
+  if (e) return fail(nullptr, EXON_HIP_EDEVICE, "ncclGetUniqueId failed with ncclResult_t %d", e);
+  memcpy(id128, id.internal, 128);
+  return EXON_HIP_OK;
+}
+int exon_hip_rccl_comm_init(exon_hip_ctx* ctx, const uint8_t* id128, int32_t world, int32_t rank, void** comm) {
+  if (!ctx || !id128 || !comm) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_rccl_comm_init: NULL argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(ctx, EXON_HIP_EINVAL, "rank %d outside a world of %d", rank, world);
+  if (!rccl().ok()) return fail(ctx, EXON_HIP_EUNSUPPORTED, "librccl.so could not be loaded");
+  UniqueId id;
+  memcpy(id.internal, id128, 128);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  typedef int (*init_fn)(void**, int, UniqueId, int);
+  *comm = nullptr;
+  const int e = ((init_fn)rccl().init_rank)(comm, world, id, rank);
+  if (e) return fail(ctx, EXON_HIP_EDEVICE, "ncclCommInitRank(world %d, rank %d) failed with ncclResult_t %d", world, rank, e);
+  return EXON_HIP_OK;
+}
+int exon_hip_rccl_comm_destroy(void* comm) {
+  if (!comm) return EXON_HIP_OK;
+  if (!rccl().ok()) return fail(nullptr, EXON_HIP_EUNSUPPORTED, "librccl.so could not be loaded");
+  const int e = rccl().comm_destroy(comm);
+  return e ? fail(nullptr, EXON_HIP_EDEVICE, "ncclCommDestroy failed with ncclResult_t %d", e) : EXON_HIP_OK;
+}
+
+// Merge of packed partial states across the ranks of `rccl_comm`, enqueued on `stream`: ONE ncclAllGather of the state
+// (d_state -> d_gather[world][words]) + the fixed-order fold into d_out (may be d_state itself).  The f64 sums come out
+// bit-identical on every rank and for every collective algorithm RCCL may pick.  States above 1 MiB are integer counters
+// only (K3 with millions of references) or too large to gather 8x: those are all-reduced in place (integer sums are exact).
+int exon_hip_merge_states(exon_hip_ctx* ctx, void* stream, void* rccl_comm, void* d_state, int64_t n_i64, int64_t n_f64,
+                          void* d_gather, void* d_out) {
+  if (!ctx || !rccl_comm || !d_state || !d_out) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_merge_states: NULL argument");
+  if (!rccl().ok()) return fail(ctx, EXON_HIP_EUNSUPPORTED, "librccl.so could not be loaded");
+  if (n_i64 < 0 || n_f64 < 0 || n_i64 + n_f64 < 1) return fail(ctx, EXON_HIP_EINVAL, "empty state");
+  hipStream_t s = pick_stream(ctx, stream);
+  const size_t words = (size_t)(n_i64 + n_f64);
+  if (d_gather == nullptr) {  // in-place all-reduce form (large integer states)
+    if (n_f64) return fail(ctx, EXON_HIP_EINVAL, "a state with float64 sums is merged by gather + fold: pass d_gather");
+    if (d_out != d_state) return fail(ctx, EXON_HIP_EINVAL, "the all-reduce form is in place");
+    const int e = rccl().all_reduce(d_state, d_state, words, NCCL_INT64, NCCL_SUM, rccl_comm, s);
+    return e ? fail(ctx, EXON_HIP_EDEVICE, "ncclAllReduce failed with ncclResult_t %d", e) : EXON_HIP_OK;
+  }
+  int world = 0;
+  int e = rccl().comm_count(rccl_comm, &world);
+  if (e || world < 1) return fail(ctx, EXON_HIP_EDEVICE, "ncclCommCount failed with ncclResult_t %d", e);
+  e = rccl().all_gather(d_state, d_gather, words, NCCL_INT64, rccl_comm, s);  // 8-byte words; no arithmetic in flight
+  if (e) return fail(ctx, EXON_HIP_EDEVICE, "ncclAllGather failed with ncclResult_t %d", e);
+  HIP_TRY(ctx, exon::launch_fold_states(s, d_gather, world, n_i64, n_f64, d_out));
+  return EXON_HIP_OK;
+}
+
+// AggregateExec(Final) across GPUs in native code, on the stream's hipStream_t: afterwards every rank's state holds the
+// sum over all ranks (the name is kept from ABI 1; since ABI 2 it is one all-gather + a fixed-order fold, see above).
 int exon_hip_stream_all_reduce(exon_hip_stream* st, void* rccl_comm) {
   if (!st || !rccl_comm) return fail(st ? st->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_stream_all_reduce: NULL argument");
   if (st->closed) return fail(st->ctx, EXON_HIP_ESTATE, "all_reduce after finish/close");
-  typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
-  static allreduce_fn fn = [] {
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    return h ? (allreduce_fn)dlsym(h, "ncclAllReduce") : (allreduce_fn) nullptr;
-  }();
-  if (!fn) return fail(st->ctx, EXON_HIP_EUNSUPPORTED, "librccl.so (ncclAllReduce) could not be loaded");
+  if (!rccl().ok()) return fail(st->ctx, EXON_HIP_EUNSUPPORTED, "librccl.so could not be loaded");
   int rc = flush_slot(st);
+  if (!rc) rc = settle_reset(st);
   if (rc) return rc;
   const exon_hip_plan* p = st->plan;
-  constexpr int NCCL_INT64 = 4, NCCL_FLOAT64 = 8, NCCL_SUM = 0;  // rccl.h: ncclDataType_t / ncclRedOp_t
-  int64_t* counts = reinterpret_cast<int64_t*>(st->d_state);
-  double* sums = reinterpret_cast<double*>(st->d_state + p->n_i64 * 8);
-  int e = 0;
-  if (p->n_i64) e = fn(counts, counts, (size_t)p->n_i64, NCCL_INT64, NCCL_SUM, rccl_comm, st->stream);
-  if (!e && p->n_f64) e = fn(sums, sums, (size_t)p->n_f64, NCCL_FLOAT64, NCCL_SUM, rccl_comm, st->stream);
-  if (e) return fail(st->ctx, EXON_HIP_EDEVICE, "ncclAllReduce failed with ncclResult_t %d", e);
+  const size_t sbytes = (size_t)(p->n_i64 + p->n_f64) * 8;
+  if (sbytes > GATHER_MERGE_MAX_STATE && p->n_f64 == 0)
+    return exon_hip_merge_states(st->ctx, st->stream, rccl_comm, st->d_state, p->n_i64, 0, nullptr, st->d_state);
+  int world = 0;
+  const int e = rccl().comm_count(rccl_comm, &world);
+  if (e || world < 1) return fail(st->ctx, EXON_HIP_EDEVICE, "ncclCommCount failed with ncclResult_t %d", e);
+  if (st->gather_bytes < sbytes * (size_t)world) {
+    if (st->d_gather) {
+      HIP_TRY(st->ctx, hipStreamSynchronize(st->stream));
+      hipFree(st->d_gather);
+      st->d_gather = nullptr;
+      st->gather_bytes = 0;
+    }
+    if (hipMalloc((void**)&st->d_gather, sbytes * (size_t)world) != hipSuccess)
+      return fail(st->ctx, EXON_HIP_ENOMEM, "gather buffer of %zu bytes", sbytes * (size_t)world);
+    st->gather_bytes = sbytes * (size_t)world;
+  }
+  return exon_hip_merge_states(st->ctx, st->stream, rccl_comm, st->d_state, p->n_i64, p->n_f64, st->d_gather, st->d_state);
+}
+
+// The next launch on this stream defines the state instead of adding to it: a new query on the same stream without a
+// zeroing kernel (finalize writes in overwrite mode).  Rows staged but not yet launched belong to the old query and are
+// dropped with it.
+int exon_hip_stream_reset(exon_hip_stream* st) {
+  if (!st) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_stream_reset: NULL stream");
+  Slot& s = st->slots[st->cur];
+  if (!s.cols.empty()) {
+    s.rows = 0;
+    s.bytes = 0;
+    for (auto& cs : s.cols) {
+      if (cs.any_null_bitmap) memset(cs.h_valid, 0, (size_t)(st->cap_rows + 7) / 8 + 64);
+      cs.any_null_bitmap = false;
+      if (cs.h_offsets) cs.h_offsets[0] = 0;
+    }
+  }
+  st->overwrite_next = true;
+  st->closed = false;
+  st->rows_pushed = 0;
   return EXON_HIP_OK;
+}
+
+// Stateless form of a push: run the plan's fused kernel over HBM-resident columns (operator argument order, see
+// exon_hip_plan_desc.columns) on the caller's hipStream_t into a caller-owned packed state [n_i64 x int64][n_f64 x float64].
+int exon_hip_plan_launch(exon_hip_plan* plan, void* stream, const exon_hip_column* columns, int32_t n_columns, int64_t n,
+                         int32_t flags, void* d_state) {
+  if (!plan || !columns || !d_state) return fail(plan ? plan->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_plan_launch: NULL argument");
+  if (n_columns != plan->n_cols) return fail(plan->ctx, EXON_HIP_EINVAL, "plan takes %d columns, %d given", plan->n_cols, n_columns);
+  if (flags & ~EXON_HIP_LAUNCH_OVERWRITE) return fail(plan->ctx, EXON_HIP_EINVAL, "unknown launch flags 0x%x", flags);
+  if (reinterpret_cast<uintptr_t>(d_state) & 7) return fail(plan->ctx, EXON_HIP_EINVAL, "d_state must be 8-byte aligned");
+  return run_plan(plan, stream, columns, n, flags, d_state);
 }
 
 int exon_hip_stream_sync(exon_hip_stream* st) {
   if (!st) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_stream_sync: NULL stream");
   int rc = flush_slot(st);
+  if (!rc) rc = settle_reset(st);
   if (rc) return rc;
   return exon_hip_sync(st->ctx, st->stream);
 }
@@ -692,6 +855,7 @@ int exon_hip_stream_close(exon_hip_stream* st) {
     }
   }
   if (st->d_state) hipFree(st->d_state);
+  if (st->d_gather) hipFree(st->d_gather);
   if (st->stream) hipStreamDestroy(st->stream);
   delete st;
   return EXON_HIP_OK;

@@ -1,12 +1,18 @@
 """Multi-GPU merge of partial aggregates: the AggregateExec(Final) step across ranks.
 
 One process per GPU; every rank scans its own file splits (the reference deals whole files round-robin by
-ascending size: exon-core/src/datasources/exon_file_scan_config.rs:79-110) and owns a partial state of
-int64 counters (+ float64 sums).  The only exchange on the path is one all-reduce(sum) of that state --
-RCCL over xGMI when the backend is "nccl", gloo in the CPU tests.  The payload is tiny (config 4: 120 B,
-config 5: 204.8 KB), so it is latency-bound: counts and sums travel as two collectives, counts stay
-integers (bit-exact), sums are float64.
+ascending size: exon-core/src/datasources/exon_file_scan_config.rs:79-110) and owns ONE packed partial state
+`[n_i64 x int64][n_f64 x float64]` (config 4: 15 words = 120 B, config 5: 204.8 KB).  The only exchange on the
+path is ONE all-gather of that state followed by a fold in rank order 0..world-1 on every rank: counts stay
+integers (bit-exact), the float64 sums come out bit-identical on all ranks and for every algorithm the collective
+library may pick (an all-reduce's association order is the library's business).  Latency-bound, so it is issued
+
+* natively -- `exon_hip_merge_states`: ncclAllGather on the kernels' own hipStream_t through a communicator made with
+  `exon_hip_rccl_comm_init` (no cross-stream hops; what a Rust host would call), or
+* through torch.distributed (`all_gather_into_tensor`; backend "nccl" = RCCL on the GPU box, "gloo" in the CPU tests)
+  followed by the same fold kernel (`exon_hip_fold_states`; a torch loop for CPU tensors, which only tests hold).
 """
+import ctypes as C
 import os
 
 
@@ -31,10 +37,98 @@ def shard_files(sizes, rank, world):
     return groups[rank] if rank < len(groups) else []
 
 
-def all_reduce_state(counts, sums=None, group=None):
-    """In-place sum of the partial state over all ranks (no-op without an initialised process group)."""
+def _initialised(group=None):
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def fold_states(gathered, world, n_i64, out, ctx=None, stream=None):
+    """out[v] = sum over ranks r = 0..world-1 (in that order) of gathered[r][v]; words [0, n_i64) are int64 counters,
+    the rest float64 sums bit-cast into the int64 tensor.  Device tensors go through the HIP kernel of the C ABI."""
+    import torch
+    V = out.numel()
+    if gathered.is_cuda:
+        if ctx is None:
+            raise RuntimeError("fold_states on device tensors needs the exon_amd Context (no torch fallback on the GPU)")
+        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        ctx._check(ctx.lib.exon_hip_fold_states(ctx.h, s, gathered.data_ptr(), world, n_i64, V - n_i64, out.data_ptr()))
+        return out
+    g = gathered.view(world, V)
+    out[:n_i64] = g[:, :n_i64].sum(0)
+    if V > n_i64:
+        acc = torch.zeros(V - n_i64, dtype=torch.float64)
+        for r in range(world):  # fixed order, like the kernel
+            acc = acc + g[r, n_i64:].view(torch.float64)
+        out[n_i64:] = acc.view(torch.int64)
+    return out
+
+
+def merge_state(state, n_i64, gathered=None, out=None, group=None, ctx=None):
+    """ONE all-gather of the packed int64-typed `state` (float64 sums bit-cast) + the fixed-order fold.  Returns the
+    merged state (`out`, or a new tensor); without an initialised process group of more than one rank: `state`."""
+    import torch
+    import torch.distributed as dist
+    if not _initialised(group):
+        if out is not None and out.data_ptr() != state.data_ptr():
+            out.copy_(state)
+            return out
+        return state
+    world = dist.get_world_size(group)
+    V = state.numel()
+    if gathered is None:
+        gathered = torch.empty(world * V, dtype=state.dtype, device=state.device)
+    if out is None:
+        out = torch.empty_like(state)
+    # gloo knows CPU tensors only for this collective: a device-resident state (the one-GPU launcher test) is staged
+    if state.is_cuda and dist.get_backend(group) == "gloo":
+        h = torch.empty(world * V, dtype=state.dtype)
+        dist.all_gather_into_tensor(h, state.cpu(), group=group)
+        gathered.copy_(h)
+    else:
+        dist.all_gather_into_tensor(gathered, state, group=group)
+    return fold_states(gathered, world, n_i64, out, ctx=ctx)
+
+
+class NativeComm:
+    """An ncclComm_t created through the C ABI (exon_hip_rccl_unique_id / _comm_init): rank 0 makes the unique id, the
+    128 bytes travel through the already initialised torch.distributed group, every rank joins on its own GPU."""
+
+    def __init__(self, ctx, group=None):
+        import torch
+        import torch.distributed as dist
+        self.ctx = ctx
+        self.h = None
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        uid = (C.c_uint8 * 128)()
+        if rank == 0:
+            ctx._check(ctx.lib.exon_hip_rccl_unique_id(uid))
+        dev = torch.device("cuda", ctx.device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        t = torch.tensor(list(uid), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, 0, group=group)
+        uid = (C.c_uint8 * 128)(*t.cpu().tolist())
+        h = C.c_void_p()
+        ctx._check(ctx.lib.exon_hip_rccl_comm_init(ctx.h, uid, world, rank, C.byref(h)))
+        self.h, self.world, self.rank = h, world, rank
+
+    def merge(self, state, n_i64, gathered, out, stream=None):
+        """exon_hip_merge_states on `stream` (default: torch's current stream): ncclAllGather + fold, no stream hops."""
+        import torch
+        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        self.ctx._check(self.ctx.lib.exon_hip_merge_states(self.ctx.h, s, self.h, state.data_ptr(), n_i64,
+                                                           state.numel() - n_i64, gathered.data_ptr(), out.data_ptr()))
+        return out
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.exon_hip_rccl_comm_destroy(self.h)
+            self.h = None
+
+
+def all_reduce_state(counts, sums=None, group=None):
+    """In-place sum of separately held counters / sums over all ranks (two all-reduces; kept for hosts that hold the
+    state as two tensors -- the packed form above needs one collective)."""
+    import torch.distributed as dist
+    if not _initialised(group):
         return counts, sums
     dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
     if sums is not None:

@@ -530,6 +530,15 @@ class Plan:
     def open(self, partition=0):
         return Stream(self, partition)
 
+    def launch(self, columns, n, d_state, overwrite=False, stream=None):
+        """exon_hip_plan_launch: the plan's fused kernel over HBM-resident columns (operator argument order; each a
+        (values, validity, offsets) triple of DeviceBuffers / raw device pointers) into the packed state `d_state`
+        ([n_i64 int64][n_f64 float64], DeviceBuffer or raw pointer).  overwrite: state := this batch (no zeroing)."""
+        cols = (Column * len(columns))(*[_col(v, b, o, n) for (v, b, o) in columns])
+        ptr = d_state.ptr if isinstance(d_state, DeviceBuffer) else int(d_state)
+        self.ctx._check(self.ctx.lib.exon_hip_plan_launch(self.h, stream, cols, len(columns), n,
+                                                          L.LAUNCH_OVERWRITE if overwrite else L.LAUNCH_ACCUMULATE, ptr))
+
     def close(self):
         if self.h:
             self.ctx.lib.exon_hip_plan_destroy(self.h)
@@ -601,8 +610,13 @@ class Stream:
         return a.value, b.value, s.value
 
     def all_reduce(self, rccl_comm):
-        """In-place RCCL all-reduce(sum) of the partial state on the stream (`rccl_comm`: an ncclComm_t as an integer)."""
+        """Merge of the partial state over the ranks of `rccl_comm` (an ncclComm_t as an integer) on the stream: one
+        ncclAllGather + fixed-order fold; afterwards every rank's state is the sum over all ranks."""
         self.ctx._check(self.ctx.lib.exon_hip_stream_all_reduce(self.h, C.c_void_p(rccl_comm)))
+
+    def reset(self):
+        """New query on this stream: the next launch defines the state (overwrite mode, no zeroing kernel)."""
+        self.ctx._check(self.ctx.lib.exon_hip_stream_reset(self.h))
 
     def sync(self):
         self.ctx._check(self.ctx.lib.exon_hip_stream_sync(self.h))

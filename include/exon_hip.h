@@ -154,7 +154,8 @@ typedef struct exon_hip_column {
 #define EXON_HIP_REGION_OPEN_END INT64_MAX
 
 /* ---- operator launches (asynchronous on `stream`; results ACCUMULATE into the state buffers,
- *      which the caller zeroes once per query: hipMemsetAsync / exon_hip_memset) -------------- */
+ *      which the caller zeroes once per query: hipMemsetAsync / exon_hip_memset -- or see
+ *      exon_hip_plan_launch with EXON_HIP_LAUNCH_OVERWRITE, which needs no zeroing pass) ------ */
 
 /* K2.  d_count[0] += |{ i : chrom_id[i] valid && == region_chrom_id && pos[i] valid &&
  *                           start <= pos[i] <= end }|   (1-based inclusive; Kleene AND, keep TRUE) */
@@ -254,6 +255,35 @@ int exon_hip_plan_destroy(exon_hip_plan* plan);
 /* number of int64 / float64 words of the partial-aggregate state of this plan */
 int exon_hip_plan_state_size(const exon_hip_plan* plan, int64_t* n_i64, int64_t* n_f64);
 
+/* Stateless form of a push: run the plan's fused kernel over HBM-resident columns (`columns[i]` = operator argument i, see
+ * exon_hip_plan_desc.columns for the order; n_columns must match the plan) on the caller's hipStream_t into a caller-owned
+ * packed partial state [n_i64 x int64][n_f64 x float64] (exon_hip_plan_state_size; 8-byte aligned device memory).
+ * EXON_HIP_LAUNCH_ACCUMULATE: state += this batch.  EXON_HIP_LAUNCH_OVERWRITE: state := this batch -- the first batch of a
+ * query then needs no zeroing kernel in front of it (AggregateExec(Partial) starting from empty accumulators). */
+#define EXON_HIP_LAUNCH_ACCUMULATE 0
+#define EXON_HIP_LAUNCH_OVERWRITE 1
+int exon_hip_plan_launch(exon_hip_plan* plan, void* stream, const exon_hip_column* columns, int32_t n_columns, int64_t n,
+                         int32_t flags, void* d_state);
+
+/* ---- merge of partial states across GPUs (AggregateExec(Final) over RCCL / xGMI; one process per GPU) -------------------
+ * The reference merges partitions in AggregateExec(Final) behind a RepartitionExec / CoalescePartitionsExec (DataFusion 44,
+ * reached from exon-core/src/session_context/exon_context_ext.rs:297-311); file groups come from regroup_files_by_size
+ * (exon-core/src/datasources/exon_file_scan_config.rs:79-110).  Here every rank holds one packed state; the merge is ONE
+ * ncclAllGather of it plus a fold in rank order 0..world-1, so all ranks end with bit-identical float64 sums whatever
+ * algorithm RCCL picks.  librccl.so is dlopen'ed at the first call. */
+/* out[v] = sum over r < world of gathered[r][v]  (gathered = `world` packed states, rank-major; d_out may not alias it) */
+int exon_hip_fold_states(exon_hip_ctx* ctx, void* stream, const void* d_gathered, int32_t world, int64_t n_i64,
+                         int64_t n_f64, void* d_out);
+/* all-gather d_state into d_gather (world x state bytes) on `stream`, fold into d_out (may be d_state).  d_gather == NULL:
+ * in-place ncclAllReduce of an integer-only state (n_f64 == 0, d_out == d_state) -- for states too large to gather. */
+int exon_hip_merge_states(exon_hip_ctx* ctx, void* stream, void* rccl_comm, void* d_state, int64_t n_i64, int64_t n_f64,
+                          void* d_gather, void* d_out);
+/* ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy for hosts without an RCCL binding: rank 0 makes the 128-byte id and
+ * ships it to the other ranks by any means; every rank then calls comm_init (collective) on its own ctx / GPU. */
+int exon_hip_rccl_unique_id(uint8_t* id128);
+int exon_hip_rccl_comm_init(exon_hip_ctx* ctx, const uint8_t* id128, int32_t world, int32_t rank, void** rccl_comm);
+int exon_hip_rccl_comm_destroy(void* rccl_comm);
+
 /* One stream per partition (= per file group); single-threaded handle, owns one HIP stream, a
  * device-resident partial state and pinned staging buffers. */
 int exon_hip_stream_open(exon_hip_plan* plan, int32_t partition, exon_hip_stream** out);
@@ -267,9 +297,13 @@ int exon_hip_stream_push_device(exon_hip_stream* s, const struct ArrowDeviceArra
 /* Device pointers of the partial state ([n_i64] int64 then [n_f64] float64, one allocation) so the
  * host can all-reduce them over RCCL, plus the hipStream_t the kernels run on. */
 int exon_hip_stream_state(exon_hip_stream* s, int64_t** d_i64, double** d_f64, void** hip_stream);
-/* The merge across GPUs in native code: in-place ncclAllReduce(sum) of the int64 counters and of the float64 sums on the
- * stream's hipStream_t.  `rccl_comm` is an ncclComm_t the host created (one rank per GPU); librccl is loaded on first use. */
+/* The merge across GPUs in native code on the stream's hipStream_t: afterwards the state of every rank is the sum over all
+ * ranks.  One ncclAllGather + fixed-order fold (exon_hip_merge_states); `rccl_comm` is an ncclComm_t the host created (one
+ * rank per GPU, e.g. exon_hip_rccl_comm_init). */
 int exon_hip_stream_all_reduce(exon_hip_stream* s, void* rccl_comm);
+/* Start a new query on this stream: the next launch DEFINES the state (overwrite mode, no zeroing kernel); rows staged but
+ * not yet launched are dropped; a finished stream can be pushed to again. */
+int exon_hip_stream_reset(exon_hip_stream* s);
 int exon_hip_stream_sync(exon_hip_stream* s);
 /* Copies the (possibly all-reduced) state to host: counts[n_i64], sums[n_f64]. */
 int exon_hip_stream_finish(exon_hip_stream* s, int64_t* counts, double* sums);

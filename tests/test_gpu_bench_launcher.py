@@ -20,17 +20,41 @@ def _bench(args, env=None, launcher=None):
     return json.loads(line)
 
 
-def test_two_ranks_on_one_gpu_add_up_to_the_single_rank_answer():
-    rows = 20_000_000
+LAUNCH = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
+
+
+def test_two_ranks_strong_scaling_split_the_table(tmp_path):
+    """Default mode: --rows is the TOTAL, rank k owns [k N/2, (k+1) N/2); the merged state equals one rank over all rows."""
+    rows = 40_000_000
     two = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--rows", str(rows), "--no-cpu-baseline"],
-                 env={"EXON_BENCH_SHARE_GPU": "1"},
-                 launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                           "--master-port", "29533"])
-    one = _bench(["--steps", "3", "--warmup", "1", "--rows", str(2 * rows), "--no-cpu-baseline"])
+                 env={"EXON_BENCH_SHARE_GPU": "1"}, launcher=LAUNCH + ["--master-port", "29533"])
+    one = _bench(["--steps", "3", "--warmup", "1", "--rows", str(rows), "--no-cpu-baseline", "--no-extras"])
     for d, n in ((two, 2), (one, 1)):
-        assert d["n_gpus"] == n and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
-        assert d["unit"] == "Mrows/s" and d["value"] > 0 and d["roofline"]["bound"] == "hbm" and d["config"]["rows_total"] == 2 * rows
-    # rank 0 holds rows [0, rows), rank 1 rows [rows, 2 rows): the reduced state equals one rank over [0, 2 rows)
+        assert d["n_gpus"] == n and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "strong" and d["higher_is_better"] is True
+        assert d["unit"] == "Mrows/s" and d["value"] > 0 and d["roofline"]["bound"] == "hbm"
+        assert d["config"]["rows_total"] == rows and d["config"]["rows_per_gpu"] == rows // n
+    assert "all_gather" in two["config"]["reduce"]
     assert two["result"]["filter_rows"] == one["result"]["filter_rows"]
     for a, b in zip(two["result"]["avg_qual"], one["result"]["avg_qual"]):
         assert a == pytest.approx(b, rel=1e-12)
+
+
+def test_two_ranks_weak_scaling_grow_the_table():
+    rows = 20_000_000
+    two = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--rows", str(rows), "--scaling", "weak", "--no-cpu-baseline"],
+                 env={"EXON_BENCH_SHARE_GPU": "1"}, launcher=LAUNCH + ["--master-port", "29534"])
+    one = _bench(["--steps", "3", "--warmup", "1", "--rows", str(2 * rows), "--no-cpu-baseline", "--no-extras"])
+    assert two["scaling"] == "weak" and two["config"]["rows_total"] == 2 * rows and two["config"]["rows_per_gpu"] == rows
+    # rank 0 holds rows [0, rows), rank 1 rows [rows, 2 rows): the merged state equals one rank over [0, 2 rows)
+    assert two["result"]["filter_rows"] == one["result"]["filter_rows"]
+    for a, b in zip(two["result"]["avg_qual"], one["result"]["avg_qual"]):
+        assert a == pytest.approx(b, rel=1e-12)
+
+
+def test_histogram_workload_merges_a_large_state_across_ranks():
+    """config 5 under the launcher: 204.8 KB of state per rank through the gather + fold merge."""
+    reads = 2_000_000
+    two = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", str(reads), "--workload", "c5", "--no-cpu-baseline"],
+                 env={"EXON_BENCH_SHARE_GPU": "1"}, launcher=LAUNCH + ["--master-port", "29535"])
+    one = _bench(["--steps", "2", "--warmup", "1", "--rows", str(reads), "--workload", "c5", "--no-cpu-baseline"])
+    assert two["result"]["counts"] == one["result"]["counts"] and sum(one["result"]["counts"]) == reads * 100

@@ -165,3 +165,157 @@ def test_native_rccl_all_reduce_on_a_one_rank_communicator(ctx, oracle):
     st.close()
     plan.close()
     rccl.ncclCommDestroy(comm)
+
+
+# ---- ABI 2: overwrite launches, stream reset, gather + fold merge --------------------------------------------------
+def _c4_device(ctx, n, seed=4, lo=0):
+    af, av, q, qv, fid = ctx.gen_c4(seed, lo, lo + n)
+    return [(af, av, None), (q, qv, None), (fid, None, None)]
+
+
+@pytest.mark.parametrize("n", [0, 1, 2049, 1_000_003, 20_000_000])
+def test_plan_launch_overwrite_equals_zero_then_accumulate(ctx, oracle, n):
+    """EXON_HIP_LAUNCH_OVERWRITE defines the state whatever it held before; ACCUMULATE adds to it."""
+    cols = _c4_device(ctx, max(n, 16))
+    plan = ctx.plan_cmp_avg_by_group(">", 0.01, 5)
+    V = plan.n_i64 + plan.n_f64
+    garbage = np.full(V, 0x7B7B7B7B7B7B7B7B, np.int64)
+    st = ctx.to_device(garbage)
+    plan.launch(cols, n, st, overwrite=True)
+    ctx.sync()
+    got = st.to_host()
+    if n:
+        haf, hav, hq, hqv, hfid = oracle.gen_c4(4, 0, max(n, 16))
+        s, cn, cr, _ = oracle.c4_cmp_avg_by_group(haf[:n], hav, hq[:n], hqv, hfid[:n], oracle.c4_filters(), 0.01, ">")
+    else:
+        s, cn, cr = np.zeros(5), np.zeros(5, np.int64), np.zeros(5, np.int64)
+    assert np.array_equal(got[:5], cn) and np.array_equal(got[5:10], cr)
+    assert np.allclose(got[10:].view(np.float64), s, rtol=1e-6, atol=0)
+    plan.launch(cols, n, st, overwrite=False)  # accumulate on top: exactly twice the counts
+    ctx.sync()
+    got2 = st.to_host()
+    assert np.array_equal(got2[:10], 2 * got[:10])
+    assert np.allclose(got2[10:].view(np.float64), 2 * got[10:].view(np.float64), rtol=1e-12, atol=0)
+    plan.close()
+
+
+def test_plan_launch_overwrite_every_kind(ctx, oracle):
+    n = 300_001
+    # K2
+    c, p = ctx.gen_c2(2, n)
+    plan = ctx.plan_region_count(6, 50_000_000, 100_000_000)
+    st = ctx.to_device(np.full(1, -5, np.int64))
+    plan.launch([(c, None, None), (p, None, None)], n, st, overwrite=True)
+    hc, hp = oracle.gen_c2(2, n)
+    assert st.to_host()[0] == oracle.c2_region_count(hc, hp, oracle.c2_contigs(), "7:50000000-100000000")[0]
+    plan.close()
+    # K3
+    f, mq, mv, ref, rv = ctx.gen_c3(3, 0, n)
+    plan = ctx.plan_flag_mapq_group_count(1284, 0, 30, 25)
+    st = ctx.to_device(np.full(26, 77, np.int64))
+    plan.launch([(f, None, None), (mq, mv, None), (ref, rv, None)], n, st, overwrite=True)
+    hf, hmq, hmv, href, hrv = oracle.gen_c3(3, 0, n)
+    want, _ = oracle.c3_flag_mapq_group_count(hf, hmq, hmv, href, hrv, oracle.c3_refs(), 1284, 0, 30)
+    assert np.array_equal(st.to_host(), want)
+    plan.close()
+    # K5: two batches, the first overwrites, the second accumulates
+    L, m = 100, 40_000
+    off, data = ctx.gen_c5(5, 0, m, L)
+    plan = ctx.plan_qual_pos_hist(L)
+    st = ctx.to_device(np.full(L * 256, 9, np.int64))
+    plan.launch([(data, None, off)], m, st, overwrite=True)
+    plan.launch([(data, None, off)], m, st, overwrite=False)
+    hoff, hdata = oracle.gen_c5(5, 0, m, L)
+    want, _ = oracle.c5_qual_pos_hist(hoff, hdata, L)
+    assert np.array_equal(st.to_host().reshape(L, 256), 2 * want)
+    plan.close()
+    # K6
+    ref, rv, s_, e_, pv = ctx.gen_c6(6, 0, n)
+    plan = ctx.plan_overlap_count(6, 50_000_000, 100_000_000, columns=(0, 1, 2))
+    st = ctx.to_device(np.full(1, 123456, np.int64))
+    plan.launch([(ref, rv, None), (s_, pv, None), (e_, pv, None)], n, st, overwrite=True)
+    href, hrv, hs, he, hpv = oracle.gen_c6(6, 0, n)
+    names = [oracle.c3_refs()[i] for i in range(25)]
+    assert st.to_host()[0] == oracle.c6_overlap_count(href, hrv, hs, hpv, he, hpv, names, names[6] + ":50000000-100000000")
+    plan.close()
+
+
+def test_stream_reset_starts_a_new_query_without_a_zeroing_pass(ctx, oracle):
+    n = 500_000
+    cols = _c4_device(ctx, n)
+    plan = ctx.plan_cmp_avg_by_group(">", 0.01, 5)
+    st = plan.open()
+    st.push_device(cols, n)
+    st.push_device(cols, n)
+    first, _ = st.finish()
+    st.reset()                 # finished stream, new query
+    st.push_device(cols, n)
+    second, sums = st.finish()
+    assert np.array_equal(2 * second, first)
+    st.reset()                 # a reset that nothing follows leaves zeros
+    third, sums3 = st.finish()
+    assert not third.any() and not sums3.any()
+    st.close()
+    plan.close()
+
+
+def test_fold_states_is_the_rank_ordered_sum(ctx):
+    import ctypes as C
+    rng = np.random.default_rng(7)
+    world, n_i64, n_f64 = 8, 10, 5
+    V = n_i64 + n_f64
+    g = np.empty((world, V), np.int64)
+    g[:, :n_i64] = rng.integers(0, 1 << 40, (world, n_i64))
+    f = rng.standard_normal((world, n_f64)) * 10.0 ** rng.integers(-8, 8, (world, n_f64))
+    g[:, n_i64:] = f.view(np.int64)
+    d_g, d_o = ctx.to_device(g.reshape(-1)), ctx.empty(np.int64, V)
+    ctx._check(ctx.lib.exon_hip_fold_states(ctx.h, None, d_g.ptr, world, n_i64, n_f64, d_o.ptr))
+    ctx.sync()
+    out = d_o.to_host()
+    assert np.array_equal(out[:n_i64], g[:, :n_i64].sum(0))
+    acc = np.zeros(n_f64)
+    for r in range(world):
+        acc = acc + f[r]
+    assert np.array_equal(out[n_i64:].view(np.float64), acc)  # same association order: same bits
+
+
+def test_native_merge_through_the_abi_made_communicator(ctx, oracle):
+    """exon_hip_rccl_unique_id / _comm_init / exon_hip_merge_states / _comm_destroy: a one-rank world (one GPU here), the
+    call path of the N-GPU merge (ncclAllGather of the packed state on the caller's stream + fold)."""
+    import ctypes as C
+    uid = (C.c_uint8 * 128)()
+    ctx._check(ctx.lib.exon_hip_rccl_unique_id(uid))
+    comm = C.c_void_p()
+    ctx._check(ctx.lib.exon_hip_rccl_comm_init(ctx.h, uid, 1, 0, C.byref(comm)))
+    n = 1_000_000
+    cols = _c4_device(ctx, n)
+    plan = ctx.plan_cmp_avg_by_group(">", 0.01, 5)
+    V = plan.n_i64 + plan.n_f64
+    st, gat, out = ctx.empty(np.int64, V), ctx.empty(np.int64, V), ctx.empty(np.int64, V)
+    plan.launch(cols, n, st, overwrite=True)
+    ctx._check(ctx.lib.exon_hip_merge_states(ctx.h, None, comm, st.ptr, plan.n_i64, plan.n_f64, gat.ptr, out.ptr))
+    ctx.sync()
+    assert np.array_equal(out.to_host(), st.to_host())
+    ctx._check(ctx.lib.exon_hip_rccl_comm_destroy(comm))
+    plan.close()
+
+
+def test_back_to_back_overwrite_launches_are_bit_identical(ctx):
+    """400 launches of the big and the small shape queued without a host sync in between (the finalize of launch i reads
+    the workspace that launch i+1 rewrites): all bit-identical -- f64 sums included (fixed fold order)."""
+    plan = ctx.plan_cmp_avg_by_group(">", 0.01, 5)
+    V = plan.n_i64 + plan.n_f64
+    for n in (6_000_000, 700_001):
+        cols = _c4_device(ctx, n)
+        st = ctx.empty(np.int64, V)
+        plan.launch(cols, n, st, overwrite=True)
+        ctx.sync()
+        want = st.to_host()
+        assert want[5:10].sum() > 0
+        outs = [ctx.empty(np.int64, V) for _ in range(400)]
+        for o in outs:  # back to back, no host sync in between
+            plan.launch(cols, n, o, overwrite=True)
+        ctx.sync()
+        for o in outs:
+            assert np.array_equal(o.to_host(), want)
+    plan.close()
