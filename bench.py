@@ -122,9 +122,9 @@ class Workload:
                          (self.ref.data_ptr(), self.rv.data_ptr(), None)]
         elif kind == "c5":
             # FASTQ quality strings, L = 100.  Arrow Utf8 has int32 offsets, so the shard is a sequence of
-            # batches of <= 16 Mi reads (1.6 GB of quality bytes each); the histogram state accumulates.
+            # batches as large as int32 offsets allow (21 474 836 reads = 2^31 - 48 quality bytes); the histogram accumulates.
             self.L = 100
-            self.batch = max(1, min(rows, 16 << 20))
+            self.batch = max(1, min(rows, (2**31 - 1) // self.L))
             self.bytes = torch.empty(rows * self.L + 64, dtype=torch.uint8, device=dev)
             self.off = torch.empty(self.batch + 1, dtype=torch.int32, device=dev)
             for b0 in range(0, rows, self.batch):
@@ -145,7 +145,7 @@ class Workload:
 
     def run(self):
         """The hot path over the shard: main + finalize kernels; the state is DEFINED by the launch (overwrite mode),
-        so there is no zeroing pass.  c5: one launch per <= 16 Mi-read batch, the first one overwrites."""
+        so there is no zeroing pass.  c5: one launch per Arrow batch (<= 2^31 bytes), the first one overwrites."""
         s = torch.cuda.current_stream().cuda_stream
         if self.kind == "c5":
             n = self.n

@@ -822,21 +822,29 @@ hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Wo
 //   + unnest with ordinality + GROUP BY (position, score) COUNT(*), reported on the raw byte
 //   (Phred = bin - 33).  104 B/read at L = 100: i32 offset + L quality bytes.
 //
-//   The limiter is LDS atomic throughput, i.e. bank conflicts (profiles/r1_tuning.md, tools/tune_k5.hip).
-//   One 1024-thread workgroup per CU owns a u32 LDS histogram of the ASCII half of the byte range (quality
-//   strings are Phred+33 <= 126; a byte >= 128 goes straight to a global atomic).  Three paths inside ONE kernel,
-//   chosen ON THE DEVICE from `k5_scan_offsets` (no host round trip, no empty launches):
-//     A  uniform read length L, L % 4 == 0, 64 <= L <= 256: every lane loads one dword (4 consecutive positions);
-//        the histogram is byte-major h[byte][perm(p)], perm(p) = (p & 3) * LP/4 + (p >> 2), so for a fixed
-//        byte-in-dword the 64 lanes of a wave hit consecutive banks whatever the data is: conflict-free.
+//   What limits it (profiles/r2_tuning.md, tools/lds_atomic_rate.hip, tools/tune_k5.hip): one ds_add_u32 per byte is
+//   unavoidable, and a wave instruction of them costs 4.2 LDS clocks when the 64 addresses differ (15 bytes/clock/CU =
+//   9.3 TB/s on the chip, above what HBM delivers) -- but (a) two lanes of one 32-lane half on the SAME address serialise
+//   (6-7 clocks with many such pairs; equal addresses in different halves are free), (b) data-dependent banks cost 6
+//   clocks, and (c) the vector ALU competes: round 1's path A spent 22 VALU instructions per dword (position bookkeeping,
+//   shift/mask/multiply-add per byte) and ran at 5.5 TB/s.  One 1024-thread workgroup per CU owns a u32 LDS histogram of
+//   the ASCII half of the byte range (quality strings are Phred+33 <= 126; a byte >= 128 goes straight to a global
+//   atomic).  Three paths inside ONE kernel, chosen ON THE DEVICE from `k5_scan_offsets` (no host round trip):
+//     A  uniform read length L, L % 4 == 0, 32 <= L <= 256: a wave owns the 64-dword rows of the byte stream whose row
+//        index is == r (mod L/4), so every lane keeps ONE dword-of-read d (4 fixed positions) and one wrap count w for the
+//        whole launch: no per-iteration position arithmetic.  Table [k = byte-in-dword][byte < 128][64 columns] u32
+//        (128 KiB); column = d + 32 (w & 1) for L <= 128, d otherwise: two lanes of a half with equal d always differ by
+//        one in w, so a half never holds two equal addresses; the bank is d.  A bin's address is b << 8 | column << 2
+//        (+ k planes): ONE v_perm_b32 per byte.  8 VALU instructions per dword, all 64 lanes busy: 6.5 TB/s at L = 100.
 //     B  any other uniform L <= 310: 16-byte chunk per lane, h[p][129] (+1 pad: bank = p + byte).
 //     G  ragged reads: a half-wave per read, one (unaligned) dword per lane, 8 reads in flight; byte-major layout
-//        as A when lmax <= LP.
+//        h[byte][perm(p)], perm(p) = (p & 3) * LP/4 + (p >> 2), when lmax <= LP.
 //   Paths A/B never touch the offsets buffer again (they use L), so HBM traffic is 4 + L bytes per read.
 // ------------------------------------------------------------------------------------------------
 constexpr int K5_THREADS = 1024;
 constexpr int K5_PT_MAX = 310;  // positions kept in LDS by the [p][129] layout: 310 * 129 * 4 B = 159,960 B
-constexpr int K5_JA = 16, K5_JB = 4;
+constexpr int K5_JA = 24, K5_JB = 4;
+constexpr int K5_A_WORDS = 4 * 128 * 64;  // path A table: [k][byte][column]
 
 // flags[0] = 1 when read lengths differ (or a read is longer than lmax -> status bit 8)
 // `off` / `ends`: start and end byte of every read.  An Arrow Utf8 column passes (offsets, offsets + 1); a view over
@@ -845,7 +853,23 @@ __global__ __launch_bounds__(256) void k5_scan_offsets(const int32_t* __restrict
                                                       int* __restrict__ flags, int* __restrict__ status) {
   const int L = ends[0] - off[0];
   bool ragged = false, too_long = false;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+  // four reads per thread per step: two 16-byte loads (4-byte aligned: the hardware takes unaligned dwordx4)
+  const int64_t n4 = n >> 2, S = (int64_t)gridDim.x * 256;
+  auto ld4 = [](const int32_t* p) {
+    int4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+  };
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n4; c += S) {
+    const int64_t i = c << 2;
+    const int4 a = ld4(off + i), b = ld4(ends + i);
+    const int l0 = b.x - a.x, l1 = b.y - a.y, l2 = b.z - a.z, l3 = b.w - a.w;
+    ragged |= (l0 != L) | (l1 != L) | (l2 != L) | (l3 != L) | (a.y != b.x) | (a.z != b.y) | (a.w != b.z);
+    if (i + 4 < n) ragged |= (off[i + 4] != b.w);
+    too_long |= (l0 > lmax) | (l1 > lmax) | (l2 > lmax) | (l3 > lmax);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // the last n % 4 reads
+    const int64_t i = (n4 << 2) + threadIdx.x;
     const int len = ends[i] - off[i];
     ragged |= (len != L) || (i + 1 < n && off[i + 1] != ends[i]);
     too_long |= (len > lmax);
@@ -861,12 +885,12 @@ __device__ __forceinline__ int k5_pick_path(const int32_t* off, const int32_t* e
   const int L = ends[0] - off[0];
   if (L < 1 || L > lmax) return K5_PATH_G;
   const uintptr_t base = reinterpret_cast<uintptr_t>(bytes + off[0]);
-  if ((L & 3) == 0 && L >= 64 && L <= lp && (base & 3) == 0) return K5_PATH_A;
+  if ((L & 3) == 0 && L >= 32 && L <= 256 && (base & 3) == 0) return K5_PATH_A;
   if (L <= K5_PT_MAX && (base & 15) == 0) return K5_PATH_B;
   return K5_PATH_G;
 }
 
-// partial record of a workgroup: u64 [pt][128] (position-major, ASCII half); bytes >= 128 never reach it
+// partial record of a workgroup: u32 [pt][128] (position-major, ASCII half; a batch holds < 2^31 reads); bytes >= 128 never reach it
 __device__ void k5_path_b(const int32_t* __restrict__ off, const int32_t* __restrict__ ends,
                           const uint8_t* __restrict__ bytes, int64_t n, int lmax, int pt,
                           unsigned long long* __restrict__ partials, unsigned long long* __restrict__ d_hist);
@@ -891,53 +915,86 @@ __global__ __launch_bounds__(K5_THREADS) void k5_main(const int32_t* __restrict_
     k5_path_ragged<LP>(off, ends, bytes, n, lmax, pt, partials, d_hist);
     return;
   }
-  extern __shared__ unsigned k5_h[];  // [128][LP]
-  constexpr int Q = LP / 4, J = K5_JA;
-  for (int i = threadIdx.x; i < 128 * LP; i += K5_THREADS) k5_h[i] = 0;
+  // ---- path A ----
+  extern __shared__ unsigned k5_h[];  // [4 k][128 bytes][64 columns]
+  constexpr int J = K5_JA;
+  for (int i = threadIdx.x; i < K5_A_WORDS; i += K5_THREADS) k5_h[i] = 0;
   __syncthreads();
-  const int L = ends[0] - off[0];
+  const int L = ends[0] - off[0], Ld = L >> 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int NW = (int)gridDim.x * (K5_THREADS / 64), g = (int)blockIdx.x * (K5_THREADS / 64) + wave;
+  const int r = g % Ld, slot = g / Ld, nslots = NW / Ld;  // the wave's rows: index == r (mod Ld), every nslots-th of them
+  const int64_t nd = n * (int64_t)Ld, nrows = nd >> 6;
+  const int t = (64 * r) % Ld + lane, w = t / Ld, d = t - w * Ld;
+  const unsigned col = (unsigned)(Ld <= 32 ? d + 32 * (w & 1) : d);
   const unsigned* src = reinterpret_cast<const unsigned*>(bytes + off[0]);
-  const int64_t nd = n * (int64_t)(L / 4), S = (int64_t)gridDim.x * K5_THREADS;
-  const int64_t c0 = (int64_t)blockIdx.x * K5_THREADS + threadIdx.x;
-  int p0 = (int)((4 * c0) % L);
-  const int pS = (int)((4 * S) % L);
-  auto one = [&](unsigned d, int p) {
-    if (__builtin_expect((d & 0x80808080u) != 0, 0)) {
+  // bin address (bytes) = k-plane | byte << 8 | col << 2; planes: k = 0 at 0, 1 at 32 KiB (instruction offset), 2 / 3 at +64 KiB
+  const unsigned c01 = col * 4u, c23 = c01 | 0x10000u;
+  char* hb = reinterpret_cast<char*>(k5_h);
+  auto slow = [&](unsigned dw, int q, unsigned cc) {  // a byte >= 128 somewhere, or the ragged tail row
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const unsigned b = (d >> (8 * k)) & 0xFF;
-        if (b >= 128) atomicAdd(&d_hist[(size_t)(p + k) * 256 + b], 1ull);
-        else atomicAdd(k5_h + b * LP + k * Q + (p >> 2), 1u);
-      }
+    for (int k = 0; k < 4; ++k) {
+      const unsigned b = (dw >> (8 * k)) & 0xFF;
+      if (b < 128) atomicAdd(reinterpret_cast<unsigned*>(hb + (k >> 1) * 65536 + (k & 1) * 32768 + b * 256 + cc), 1u);
+      else atomicAdd(&d_hist[(size_t)(4 * q + k) * 256 + b], 1ull);
+    }
+  };
+  auto one = [&](unsigned dw) {
+    if (__builtin_expect((dw & 0x80808080u) != 0, 0)) {
+      slow(dw, d, c01);
       return;
     }
-    unsigned* base = k5_h + (p >> 2);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) atomicAdd(base + ((d >> (8 * k)) & 0xFF) * LP + k * Q, 1u);
+    // v_perm_b32: result byte 1 <- data byte k, bytes 0 / 2 / 3 <- the lane's constant
+    const unsigned a0 = __builtin_amdgcn_perm(dw, c01, 0x03020400u);
+    const unsigned a1 = __builtin_amdgcn_perm(dw, c01, 0x03020500u);
+    const unsigned a2 = __builtin_amdgcn_perm(dw, c23, 0x03020600u);
+    const unsigned a3 = __builtin_amdgcn_perm(dw, c23, 0x03020700u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a0), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a1 + 32768), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a2), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a3 + 32768), 1u);
   };
-  int64_t c = c0;
-  for (; c + (J - 1) * S < nd; c += J * S) {
-    unsigned v[J];
-    int pj[J];
+  if (slot < nslots) {
+    const int64_t qstep = nslots;
+    int64_t q = slot;
+    for (; (q + (J - 1) * qstep) * Ld + r < nrows; q += J * qstep) {
+      unsigned v[J];
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-      v[j] = __builtin_nontemporal_load(src + c + j * S);
-      pj[j] = p0;
-      p0 += pS;
-      p0 = p0 >= L ? p0 - L : p0;
+      for (int j = 0; j < J; ++j) v[j] = __builtin_nontemporal_load(src + ((q + j * qstep) * Ld + r) * 64 + lane);
+#pragma unroll
+      for (int j = 0; j < J; ++j) one(v[j]);
     }
+    if (q * Ld + r < nrows) {
+      // the last < J rows of this wave, all loads in flight at once (one at a time they cost a memory round trip each:
+      // 40 us of a 345 us launch at 20 M reads).  A row's validity is wave-uniform; invalid slots re-read the first row.
+      unsigned v[J];
 #pragma unroll
-    for (int j = 0; j < J; ++j) one(v[j], pj[j]);
+      for (int j = 0; j < J; ++j) {
+        const int64_t row = (q + j * qstep) * Ld + r;
+        v[j] = __builtin_nontemporal_load(src + (row < nrows ? row : q * Ld + r) * 64 + lane);
+      }
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+        if ((q + j * qstep) * Ld + r < nrows) one(v[j]);
+    }
   }
-  for (; c < nd; c += S) {
-    one(src[c], p0);
-    p0 += pS;
-    p0 = p0 >= L ? p0 - L : p0;
+  if (g == NW - 1) {  // the last, partial row (< 64 dwords): column = dword-of-read, first copy
+    const int64_t c = nrows * 64 + lane;
+    if (c < nd) {
+      const int q = (int)(c % Ld);
+      slow(src[c], q, (unsigned)q * 4u);
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < pt * 128; i += K5_THREADS) {
-    const int p = i >> 7, b = i & 127;
-    partials[(size_t)blockIdx.x * pt * 128 + i] = p < L ? k5_h[b * LP + (p & 3) * Q + (p >> 2)] : 0u;
+    const int p = i >> 7, b = i & 127, k = p & 3;
+    unsigned v = 0;
+    if (p < L) {
+      const unsigned* row = k5_h + (k >> 1) * 16384 + (k & 1) * 8192 + b * 64 + (p >> 2);
+      v = row[0];
+      if (Ld <= 32) v += row[32];
+    }
+    reinterpret_cast<unsigned*>(partials)[(size_t)blockIdx.x * pt * 128 + i] = v;
   }
 }
 
@@ -992,7 +1049,7 @@ __device__ void k5_path_b(const int32_t* __restrict__ off, const int32_t* __rest
   }
   __syncthreads();
   for (int i = threadIdx.x; i < pt * 128; i += K5_THREADS)
-    partials[(size_t)blockIdx.x * pt * 128 + i] = k5_h[(i >> 7) * 129 + (i & 127)];
+    reinterpret_cast<unsigned*>(partials)[(size_t)blockIdx.x * pt * 128 + i] = k5_h[(i >> 7) * 129 + (i & 127)];
 }
 
 // Path G: ragged reads.  A half-wave (32 lanes) owns a read; lane l loads the (possibly unaligned) dword holding
@@ -1084,7 +1141,7 @@ __device__ void k5_path_ragged_impl(const int32_t* __restrict__ off, const int32
   __syncthreads();
   for (int i = threadIdx.x; i < pt * 128; i += K5_THREADS) {
     const int p = i >> 7, b = i & 127;
-    partials[(size_t)blockIdx.x * pt * 128 + i] = BM ? k5_h[b * LP + (p & 3) * Q + (p >> 2)] : k5_h[p * 129 + b];
+    reinterpret_cast<unsigned*>(partials)[(size_t)blockIdx.x * pt * 128 + i] = BM ? k5_h[b * LP + (p & 3) * Q + (p >> 2)] : k5_h[p * 129 + b];
   }
 }
 
@@ -1098,7 +1155,7 @@ __device__ void k5_path_ragged(const int32_t* __restrict__ off, const int32_t* _
 
 // d_hist[p][b] += sum over workgroups of partial[wg][p][b]  (p < pt, b < 128).  blockIdx.y splits the workgroup
 // range 8 ways (integer adds commute, so the segment sums are merged with atomics: still bit-exact).
-__global__ __launch_bounds__(256) void k5_finalize(const unsigned long long* __restrict__ partials, int nblocks, int pt,
+__global__ __launch_bounds__(256) void k5_finalize(const unsigned* __restrict__ partials, int nblocks, int pt,
                                                    unsigned long long* __restrict__ d_hist, int* __restrict__ flags) {
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) flags[0] = 0;  // ready for the next batch's offsets scan
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1109,7 +1166,7 @@ __global__ __launch_bounds__(256) void k5_finalize(const unsigned long long* __r
   unsigned long long acc = 0;
   int b = b0;
   for (; b + 8 <= b1; b += 8) {
-    unsigned long long t[8];
+    unsigned t[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) t[k] = partials[(size_t)(b + k) * W + i];
 #pragma unroll
@@ -1120,7 +1177,7 @@ __global__ __launch_bounds__(256) void k5_finalize(const unsigned long long* __r
 }
 
 static int k5_pt(int lmax) { return lmax < K5_PT_MAX ? lmax : K5_PT_MAX; }
-size_t k5_partial_words(const LaunchCfg& cfg, int lmax) { return (size_t)cfg.compute_units * k5_pt(lmax) * 128; }
+size_t k5_partial_words(const LaunchCfg& cfg, int lmax) { return ((size_t)cfg.compute_units * k5_pt(lmax) * 128 + 1) / 2; }  // u32 records
 
 hipError_t launch_qual_pos_hist(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* offsets,
                                 const uint8_t* bytes, int64_t n_reads, int lmax, int64_t* d_hist) {
@@ -1141,11 +1198,12 @@ hipError_t launch_qual_pos_hist_views(hipStream_t s, const LaunchCfg& cfg, const
   // the ragged path is correct for uniform reads too)
   hipError_t e;
   if (cfg.overwrite && (e = hipMemsetAsync(d_hist, 0, (size_t)lmax * 256 * 8, s)) != hipSuccess) return e;  // k5_finalize adds
-  int sgrid = (int)std::min<int64_t>((n_reads + 255) / 256, (int64_t)cfg.compute_units * 8);
+  int sgrid = (int)std::min<int64_t>((n_reads / 4 + 255) / 256 + 1, (int64_t)cfg.compute_units * 8);
   hipLaunchKernelGGL(k5_scan_offsets, dim3(sgrid), dim3(256), 0, s, offsets, ends, n_reads, lmax, flags, ws.status);
   // LDS block: the larger of the byte-major [128][LP] layout (paths A and G) and the [pt][129] layout (B, long G)
   const bool lp256 = lmax > 128;
-  const size_t lds = std::max<size_t>((size_t)128 * (lp256 ? 256 : 128) * 4 + 256, (size_t)pt * 129 * 4);
+  const size_t lds = std::max<size_t>(std::max<size_t>((size_t)128 * (lp256 ? 256 : 128) * 4 + 256, (size_t)pt * 129 * 4),
+                                      (size_t)K5_A_WORDS * 4);
   static std::once_flag attr_once;
   hipError_t attr_err = hipSuccess;
   std::call_once(attr_once, [&] {
@@ -1159,7 +1217,7 @@ hipError_t launch_qual_pos_hist_views(hipStream_t s, const LaunchCfg& cfg, const
   else hipLaunchKernelGGL(k5_main<128>, dim3(grid), dim3(K5_THREADS), lds, s, offsets, ends, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k5_finalize, dim3((pt * 128 + 255) / 256, 8), dim3(256), 0, s, ws.partials, grid, pt, hist, flags);
+  hipLaunchKernelGGL(k5_finalize, dim3((pt * 128 + 255) / 256, 8), dim3(256), 0, s, reinterpret_cast<const unsigned*>(ws.partials), grid, pt, hist, flags);
   return hipGetLastError();
 }
 

@@ -256,7 +256,13 @@ def test_k4_bad_group_id_is_reported(ctx):
 # ---- K5 -----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n_reads,L", [(1, 100), (1000, 100), (200_000, 100), (5000, 151), (3000, 36), (70_000, 128),
                                        (40_000, 256), (30_000, 250), (9000, 301), (2000, 400), (50_000, 64), (100_001, 8),
-                                       (77, 3), (1_000_000, 100)])
+                                       (77, 3), (1_000_000, 100),
+                                       # path A (rows == r mod L/4, one column per lane): every kind of L/4 -- odd, even, prime,
+                                       # < 16 (three lanes of a half share a dword-of-read), 32 < L/4 <= 64 (single copy), and
+                                       # read counts that leave partial rows / idle waves
+                                       (1, 32), (3, 36), (65_537, 32), (250_001, 44), (123_457, 76), (99_999, 92), (64, 100),
+                                       (4_200_000, 100), (333_333, 124), (80_001, 132), (60_001, 148), (50_001, 200),
+                                       (40_001, 252), (4096 * 16 + 1, 256)])
 def test_k5_qual_pos_hist(ctx, oracle, n_reads, L):
     off, data = ctx.gen_c5(5, 0, n_reads, L)
     d = ctx.zeros(np.int64, L * 256)
@@ -280,6 +286,25 @@ def test_k5_non_ascii_bytes_and_unaligned_base(ctx, oracle):
         ctx.sync()
         want, _ = oracle.c5_qual_pos_hist(off, data, L)
         assert np.array_equal(d.to_host().reshape(L, 256), want), shift
+
+
+def test_k5_path_a_with_non_ascii_bytes_lmax_above_read_length_and_accumulation(ctx, oracle):
+    """Uniform reads (path A) holding bytes >= 128 (global-atomic side path) and control bytes < 32 (ordinary rows), with
+    lmax larger than the read length and two launches accumulating into one state."""
+    rng = np.random.default_rng(5)
+    n, L, lmax = 70_001, 100, 180
+    data = rng.integers(33, 75, n * L).astype(np.uint8)
+    idx = rng.integers(0, n * L, 5000)
+    data[idx] = rng.integers(0, 256, 5000).astype(np.uint8)
+    off = (np.arange(n + 1, dtype=np.int64) * L).astype(np.int32)
+    d = ctx.zeros(np.int64, lmax * 256)
+    d_off, d_data = ctx.to_device(off), ctx.to_device(np.concatenate([data, np.zeros(64, np.uint8)]))
+    ctx.qual_pos_hist(d_off, d_data, n, lmax, d)
+    ctx.qual_pos_hist(d_off, d_data, n, lmax, d)
+    ctx.sync()
+    want, _ = oracle.c5_qual_pos_hist(off, data, lmax)
+    assert np.array_equal(d.to_host().reshape(lmax, 256), 2 * want)
+    assert want[:, 128:].sum() > 0 and want[:, :32].sum() > 0 and want[L:].sum() == 0
 
 
 def test_k5_read_longer_than_lmax_is_reported(ctx):

@@ -192,6 +192,202 @@ __global__ __launch_bounds__(1024) void vE(const uint8_t* bytes, int64_t n, int 
     if (v) atomicAdd(&out[p * 256 + b], (unsigned long long)v); }
 }
 
+
+// ---- F: collision-free for EVERY lane of a wave instruction.  ds_add_u32 costs 4.2 LDS clocks per wave instruction when all
+// 64 addresses differ, 7+ when two lanes hit the SAME address (tools/lds_atomic_rate.hip) -- and with D's layout lanes 25
+// apart (L = 100) share a column, so nearly every instruction holds such a pair.  Here a wave always works on whole "rows"
+// of 64 consecutive dwords whose row index is == r (mod Ld), Ld = L/4: lane l then sits at dword-of-read (64 r + l) % Ld in
+// EVERY iteration; lanes that wrap around the read length (w = (d0 + l) / Ld = 0..3) use separate table copies, so no two
+// lanes of an instruction ever share an address, whatever the data.  Table: [w][byte - 32 (96 printable rows)][k][Ld].
+template <int J>
+__global__ __launch_bounds__(1024) void vF(const uint8_t* bytes, int64_t n, int L, unsigned long long* out) {
+  extern __shared__ unsigned h[];
+  const int Ld = L / 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = (Ld - 1 + 63) / Ld + 1;
+  const int nwords = C * 96 * 4 * Ld;
+  for (int i = threadIdx.x; i < nwords; i += 1024) h[i] = 0;
+  __syncthreads();
+  const int NW = gridDim.x * 16, g = blockIdx.x * 16 + wave;
+  const int r = g % Ld, slot = g / Ld, nslots = NW / Ld;
+  const int64_t nd = n * Ld, nrows = nd / 64;
+  const int t = (64 * r) % Ld + lane, w = t / Ld, d = t - w * Ld;
+  const unsigned* src = reinterpret_cast<const unsigned*>(bytes);
+  // byte address of bin (byte, k) for this lane: byte * 16 Ld + base[k]
+  const unsigned rowb = 16u * Ld;
+  unsigned base[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) base[k] = 4u * (unsigned)(((w * 96 - 32) * 4 + k) * Ld + d);
+  auto slow = [&](unsigned dw, int q) {  // q = dword-of-read
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned b = (dw >> (8 * k)) & 0xFF;
+      if (b >= 32 && b < 128) atomicAdd(reinterpret_cast<unsigned*>(reinterpret_cast<char*>(h) + b * rowb + base[k]), 1u);
+      else atomicAdd(&out[(size_t)(4 * q + k) * 256 + b], 1ull);
+    }
+  };
+  auto one = [&](unsigned dw) {
+    const unsigned u = (dw & 0x7F7F7F7Fu) + 0x60606060u;          // bit 7 of each byte: (b & 127) >= 32
+    if (__builtin_expect(((u & ~dw) & 0x80808080u) != 0x80808080u, 0)) { slow(dw, d); return; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned b = (dw >> (8 * k)) & 0xFF;
+      atomicAdd(reinterpret_cast<unsigned*>(reinterpret_cast<char*>(h) + b * rowb + base[k]), 1u);
+    }
+  };
+  if (slot < nslots) {
+    const int64_t qstep = nslots;
+    int64_t q = slot;
+    for (; (q + (J - 1) * qstep) * Ld + r < nrows; q += J * qstep) {
+      unsigned v[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) v[j] = __builtin_nontemporal_load(src + ((q + j * qstep) * Ld + r) * 64 + lane);
+#pragma unroll
+      for (int j = 0; j < J; ++j) one(v[j]);
+    }
+    for (; q * Ld + r < nrows; q += qstep) one(src[(q * Ld + r) * 64 + lane]);
+  }
+  if (g == NW - 1) {  // the last partial row (< 64 dwords)
+    const int64_t c = nrows * 64 + lane;
+    if (c < nd) {
+      const int q = (int)(c % Ld);
+      const unsigned dw = src[c];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned b = (dw >> (8 * k)) & 0xFF;
+        if (b >= 32 && b < 128) atomicAdd(&h[((0 * 96 + (int)b - 32) * 4 + k) * Ld + q], 1u);
+        else atomicAdd(&out[(size_t)(4 * q + k) * 256 + b], 1ull);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < L * 96; i += 1024) {
+    const int p = i % L, b = i / L;  // b = byte - 32
+    unsigned v = 0;
+    for (int ww = 0; ww < C; ++ww) v += h[((ww * 96 + b) * 4 + (p & 3)) * Ld + (p >> 2)];
+    if (v) atomicAdd(&out[p * 256 + b + 32], (unsigned long long)v);
+  }
+}
+
+// ---- H: a lane GROUP (G = 16 / 32 / 64 lanes) per read, lane-in-group = dword-of-read, one table copy per group of the
+// wave: [k][byte < 128][copy][G] x u32 -- every lane of a wave instruction owns its own word whatever the data is (no bank
+// conflict, no same-address serialisation), the address is ONE v_perm_b32 (byte 1 of the address = the data byte; byte 0
+// = per-lane constant; k in the instruction offset / byte 2).  L/4 of the G lanes are active.
+template <int G, int J>
+__global__ __launch_bounds__(1024) void vH(const uint8_t* bytes, int64_t n, int L, unsigned long long* out) {
+  extern __shared__ unsigned h[];  // [4][128][64] words = 128 KB
+  const int Ld = L / 4;
+  for (int i = threadIdx.x; i < 4 * 128 * 64; i += 1024) h[i] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int d = lane & (G - 1);
+  const bool active = d < Ld;
+  constexpr int RPW = 64 / G;                       // reads per wave instruction
+  const int64_t gw = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 16;
+  const unsigned* src = reinterpret_cast<const unsigned*>(bytes);
+  // address bytes: [0] = lane * 4 (copy * G * 4 + d * 4 = lane * 4 since copy = lane / G), [1] = data byte, [2] = k >> 1; k & 1 -> +32 KiB
+  const unsigned c01 = (unsigned)lane * 4u, c23 = c01 | 0x10000u;
+  char* hb = reinterpret_cast<char*>(h);
+  auto one = [&](unsigned dw, int q) {
+    if (__builtin_expect((dw & 0x80808080u) != 0, 0)) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const unsigned b = (dw >> (8 * k)) & 0xFF;
+        if (b < 128) atomicAdd(reinterpret_cast<unsigned*>(hb + (k >> 1) * 65536 + (k & 1) * 32768 + b * 256 + c01), 1u);
+        else atomicAdd(&out[(size_t)(4 * q + k) * 256 + b], 1ull); }
+      return; }
+    // v_perm_b32 D = {S0, S1} bytes: selector byte i picks: 0-3 = S1 bytes, 4-7 = S0 bytes
+    const unsigned a0 = __builtin_amdgcn_perm(dw, c01, 0x03020400u);  // byte1 <- dw.byte0
+    const unsigned a1 = __builtin_amdgcn_perm(dw, c01, 0x03020500u);  // byte1 <- dw.byte1
+    const unsigned a2 = __builtin_amdgcn_perm(dw, c23, 0x03020600u);  // byte1 <- dw.byte2, byte2 = 1
+    const unsigned a3 = __builtin_amdgcn_perm(dw, c23, 0x03020700u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a0), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a1 + 32768), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a2), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a3 + 32768), 1u);
+  };
+  const int64_t nrw = n / RPW;  // whole wave-rows of RPW reads
+  int64_t rw = gw;
+  const int sub = lane / G;
+  for (; rw + (J - 1) * nw < nrw; rw += J * nw) {
+    unsigned v[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int64_t idx = ((rw + j * nw) * RPW + sub) * Ld + (active ? d : 0);
+      v[j] = __builtin_nontemporal_load(src + idx);
+    }
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) one(v[j], d);
+    }
+  }
+  for (; rw < nrw; rw += nw) { if (active) one(src[(rw * RPW + sub) * Ld + d], d); }
+  if (gw == 0) for (int64_t r = nrw * RPW + sub; r < n; r += RPW) if (active) one(src[r * Ld + d], d);
+  __syncthreads();
+  for (int i = threadIdx.x; i < L * 128; i += 1024) { const int p = i % L, b = i / L; unsigned v = 0;
+    for (int c = 0; c < RPW; ++c) v += h[((p & 3) >> 1) * 16384 + ((p & 3) & 1) * 8192 + b * 64 + c * G + (p >> 2)];
+    if (v) atomicAdd(&out[p * 256 + b], (unsigned long long)v); }
+}
+
+// ---- I: F's work distribution (a wave owns the 64-dword rows whose index is == r mod Ld, so every lane keeps ONE
+// dword-of-read d and wrap count w for the whole launch; all 64 lanes busy) + H's table and addressing ([k][byte][64 cols],
+// one v_perm_b32 per byte).  Column = d + 32 (w & 1) for Ld <= 32, d otherwise: two lanes of a 32-lane half with the same d
+// always differ by one in w, so a half never holds two equal addresses (equal addresses ACROSS halves cost nothing:
+// tools/lds_atomic_rate.hip); bank = d, at worst a few 2-way conflicts (4.3 instead of 4.2 clocks).
+template <int J>
+__global__ __launch_bounds__(1024) void vI(const uint8_t* bytes, int64_t n, int L, unsigned long long* out) {
+  extern __shared__ unsigned h[];  // [4][128][64] words = 128 KB
+  const int Ld = L / 4;
+  for (int i = threadIdx.x; i < 4 * 128 * 64; i += 1024) h[i] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int NW = gridDim.x * 16, g = blockIdx.x * 16 + wave;
+  const int r = g % Ld, slot = g / Ld, nslots = NW / Ld;
+  const int64_t nd = n * Ld, nrows = nd / 64;
+  const int t = (64 * r) % Ld + lane, w = t / Ld, d = t - w * Ld;
+  const int col = Ld <= 32 ? d + 32 * (w & 1) : d;
+  const unsigned* src = reinterpret_cast<const unsigned*>(bytes);
+  const unsigned c01 = (unsigned)col * 4u, c23 = c01 | 0x10000u;
+  char* hb = reinterpret_cast<char*>(h);
+  auto slow = [&](unsigned dw, int q, unsigned cc) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const unsigned b = (dw >> (8 * k)) & 0xFF;
+      if (b < 128) atomicAdd(reinterpret_cast<unsigned*>(hb + (k >> 1) * 65536 + (k & 1) * 32768 + b * 256 + cc), 1u);
+      else atomicAdd(&out[(size_t)(4 * q + k) * 256 + b], 1ull); }
+  };
+  auto one = [&](unsigned dw) {
+    if (__builtin_expect((dw & 0x80808080u) != 0, 0)) { slow(dw, d, c01); return; }
+    const unsigned a0 = __builtin_amdgcn_perm(dw, c01, 0x03020400u);
+    const unsigned a1 = __builtin_amdgcn_perm(dw, c01, 0x03020500u);
+    const unsigned a2 = __builtin_amdgcn_perm(dw, c23, 0x03020600u);
+    const unsigned a3 = __builtin_amdgcn_perm(dw, c23, 0x03020700u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a0), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a1 + 32768), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a2), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a3 + 32768), 1u);
+  };
+  if (slot < nslots) {
+    const int64_t qstep = nslots;
+    int64_t q = slot;
+    for (; (q + (J - 1) * qstep) * Ld + r < nrows; q += J * qstep) {
+      unsigned v[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) v[j] = __builtin_nontemporal_load(src + ((q + j * qstep) * Ld + r) * 64 + lane);
+#pragma unroll
+      for (int j = 0; j < J; ++j) one(v[j]);
+    }
+    for (; q * Ld + r < nrows; q += qstep) one(src[(q * Ld + r) * 64 + lane]);
+  }
+  if (g == NW - 1) {  // the last partial row (< 64 dwords)
+    const int64_t c = nrows * 64 + lane;
+    if (c < nd) { const int q = (int)(c % Ld); slow(src[c], q, (unsigned)q * 4u); }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < L * 128; i += 1024) { const int p = i % L, b = i / L, k = p & 3;
+    unsigned v = h[(k >> 1) * 16384 + (k & 1) * 8192 + b * 64 + (p >> 2)];
+    if (Ld <= 32) v += h[(k >> 1) * 16384 + (k & 1) * 8192 + b * 64 + (p >> 2) + 32];
+    if (v) atomicAdd(&out[p * 256 + b], (unsigned long long)v); }
+}
+
 int main(int argc, char** argv) {
   int64_t n = argc > 1 ? (int64_t)atof(argv[1]) : (int64_t)2e8; const int L = argc > 2 ? atoi(argv[2]) : 100;
   n = n / 4096 * 4096;
@@ -217,14 +413,21 @@ int main(int argc, char** argv) {
   run("R read-only J1", vR<1>, 0, 256);
   run("R read-only J4", vR<4>, 0, 256);
   run("R read-only J4 x2", vR<4>, 0, 512);
+  if (L % 4 == 0 && L >= 64 && L <= 256) { const size_t il = 4 * 128 * 64 * 4; run("I rows+perm J8", vI<8>, il, 256); run("I rows+perm J16", vI<16>, il, 256); run("I rows+perm J24", vI<24>, il, 256); }
   run("B reg-direct J1 s257", vB<1, 0>, (size_t)L * 257 * 4, 256);
   run("B reg-direct J4 s257", vB<4, 0>, (size_t)L * 257 * 4, 256);
   if (L <= 128) {
     if (L % 4 == 0) { run("D cf LP128 J4 A4", vD<128, 4, true>, 128 * 128 * 4, 256); run("D cf LP128 J8 A4", vD<128, 8, true>, 128 * 128 * 4, 256);
       run("D cf LP128 J16 A4", vD<128, 16, true>, 128 * 128 * 4, 256); run("D cf LP128 J8 A4 x2", vD<128, 8, true>, 128 * 128 * 4, 512); }
     run("D cf LP128 J8 gen", vD<128, 8, false>, 128 * 128 * 4, 256); run("D cf LP128 J16 gen", vD<128, 16, false>, 128 * 128 * 4, 256);
+    if (L % 4 == 0) { const int Ld = L / 4, C = (Ld - 1 + 63) / Ld + 1; const size_t fl = (size_t)C * 96 * 4 * Ld * 4;
+      if (fl <= 160 * 1024) { run("F collision-free J8", vF<8>, fl, 256); run("F collision-free J16", vF<16>, fl, 256); run("F collision-free J24", vF<24>, fl, 256); } }
+    if (L % 4 == 0) { const size_t hl = 4 * 128 * 64 * 4;
+      if (L <= 64) { run("H group16 J8", vH<16, 8>, hl, 256); run("H group16 J16", vH<16, 16>, hl, 256); }
+      if (L <= 128) { run("H group32 J8", vH<32, 8>, hl, 256); run("H group32 J16", vH<32, 16>, hl, 256); run("H group32 J24", vH<32, 24>, hl, 256); } }
     if (L % 4 == 0) { const int QP = (L / 4 + 31 + 7) & ~7; run("E group-run J8", vE<8>, (size_t)128 * 4 * QP * 4, 256); run("E group-run J16", vE<16>, (size_t)128 * 4 * QP * 4, 256); }
   } else if (L <= 256) {
+    if (L % 4 == 0) { const size_t hl = 4 * 128 * 64 * 4; run("H group64 J8", vH<64, 8>, hl, 256); run("H group64 J16", vH<64, 16>, hl, 256); }
     if (L % 4 == 0) { run("D cf LP256 J8 A4", vD<256, 8, true>, 128 * 256 * 4, 256); run("D cf LP256 J16 A4", vD<256, 16, true>, 128 * 256 * 4, 256); }
     run("D cf LP256 J8 gen", vD<256, 8, false>, 128 * 256 * 4, 256); run("D cf LP256 J16 gen", vD<256, 16, false>, 128 * 256 * 4, 256);
   }
