@@ -21,6 +21,7 @@
 #include <string>
 #include <vector>
 
+#include "bgzf_block.h"
 #include "io.h"
 
 namespace exon {
@@ -171,6 +172,7 @@ class BgzfReader {
     if (!f_) throw std::runtime_error("cannot open " + path);
   }
   ~BgzfReader() {
+    if (z_init_) inflateEnd(&z_);
     if (f_) fclose(f_);
   }
   BgzfReader(const BgzfReader&) = delete;
@@ -227,9 +229,8 @@ class BgzfReader {
   }
   bool load_block(int64_t coff) {
     if (fseek(f_, (long)coff, SEEK_SET) != 0) throw std::runtime_error("seek failed: " + path_);
-    uint8_t h[18];
-    const size_t got = fread(h, 1, 18, f_);
-    if (got == 0) {
+    BgzfBlockInfo info;
+    if (!read_bgzf_block(f_, &comp_, &info, path_)) {
       eof_ = true;
       block_.clear();
       pos_ = 0;
@@ -237,40 +238,23 @@ class BgzfReader {
       block_csize_ = 0;
       return false;
     }
-    if (got != 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) throw std::runtime_error("not a BGZF block: " + path_);
-    uint16_t xlen;
-    memcpy(&xlen, h + 10, 2);
-    // the BC subfield is the first (and in practice only) extra subfield
-    if (xlen < 6 || h[12] != 'B' || h[13] != 'C') throw std::runtime_error("BGZF extra field missing: " + path_);
-    uint16_t bsize;
-    memcpy(&bsize, h + 16, 2);
-    const size_t total = (size_t)bsize + 1, hdr = 12 + (size_t)xlen;
-    std::vector<uint8_t> comp(total - 18);
-    if (fread(comp.data(), 1, comp.size(), f_) != comp.size()) throw std::runtime_error("truncated BGZF block: " + path_);
-    const size_t cdata_off = hdr - 18, cdata_len = total - hdr - 8;
-    uint32_t isize;
-    memcpy(&isize, comp.data() + comp.size() - 4, 4);
-    block_.resize(isize);
-    if (isize) {
-      z_stream z;
-      memset(&z, 0, sizeof z);
-      if (inflateInit2(&z, -15) != Z_OK) throw std::runtime_error("inflateInit2 failed");
-      z.next_in = comp.data() + cdata_off;
-      z.avail_in = (uInt)cdata_len;
-      z.next_out = block_.data();
-      z.avail_out = isize;
-      const int rc = inflate(&z, Z_FINISH);
-      inflateEnd(&z);
-      if (rc != Z_STREAM_END) throw std::runtime_error("BGZF inflate error: " + path_);
+    if (!z_init_) {
+      memset(&z_, 0, sizeof z_);
+      if (inflateInit2(&z_, -15) != Z_OK) throw std::runtime_error("inflateInit2 failed");
+      z_init_ = true;
     }
+    block_.resize(info.isize);
+    inflate_bgzf_block(&z_, comp_.data(), info, block_.data(), path_);
     block_off_ = coff;
-    block_csize_ = (int64_t)total;
+    block_csize_ = (int64_t)info.total;
     eof_ = false;
     return true;
   }
   std::string path_;
   FILE* f_ = nullptr;
-  std::vector<uint8_t> block_;
+  std::vector<uint8_t> block_, comp_;
+  z_stream z_;
+  bool z_init_ = false;
   size_t pos_ = 0;
   int64_t block_off_ = 0, block_csize_ = 0;
   bool eof_ = false;

@@ -363,6 +363,7 @@ class VCFBatchReader {
       std::vector<Chunk> chunks;
       if (id >= 0) chunks = query_index(idx, id, cfg_.filter.region.start, cfg_.filter.region.end);
       n_chunks = (int)chunks.size();
+      planned_chunks = chunks;
       has_pending_ = false;
       r_.reset(new ChunkSource(path, std::move(chunks)));
     } else {
@@ -457,6 +458,7 @@ class VCFBatchReader {
   VCFHeader header;
   Dictionary chrom_dict, filter_dict;
   int n_chunks = -1;  // index chunks planned (-1: not an indexed scan)
+  std::vector<Chunk> planned_chunks;  // ... and the chunks themselves (the GPU decode path ships exactly these blocks)
 
  private:
   // emit up to batch_size rows of the current slab (re-keyed to the reader's dictionaries)
@@ -583,6 +585,7 @@ class BAMBatchReader {
         std::vector<Chunk> chunks;
         if (region_ref_id_ >= 0) chunks = query_index(idx, region_ref_id_, cfg_.filter.region.start, cfg_.filter.region.end);
         n_chunks = (int)chunks.size();
+        planned_chunks = chunks;
         r_.reset(new ChunkSource(path, std::move(chunks)));
       }
     }
@@ -645,6 +648,8 @@ class BAMBatchReader {
   std::vector<std::string> ref_names;
   std::vector<int32_t> ref_lengths;
   int n_chunks = -1;
+  std::vector<Chunk> planned_chunks;  // the chunks of an indexed scan (the GPU decode path ships exactly these blocks)
+  int32_t region_ref_id() const { return region_ref_id_; }  // header index of the pushed-down region's reference (-2: unknown)
 
  private:
   int32_t read_i32() {

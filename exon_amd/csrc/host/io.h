@@ -69,15 +69,19 @@ class ByteReader : public ByteSource {
         z_.avail_in = (uInt)fread(in_.data(), 1, in_.size(), f_);
         z_.next_in = in_.data();
         if (z_.avail_in == 0) {
+          // the file ends inside a gzip member (e.g. a header whose XLEN runs past the end): an error, not an empty tail
+          if (in_member_) throw std::runtime_error("truncated gzip stream: " + path_);
           eof_ = true;
           break;
         }
       }
+      in_member_ = true;
       z_.next_out = dst + produced;
       z_.avail_out = (uInt)(n - produced);
       const int rc = inflate(&z_, Z_NO_FLUSH);
       produced = n - z_.avail_out;
       if (rc == Z_STREAM_END) {
+        in_member_ = false;
         // next gzip member (BGZF block) if any bytes remain
         if (z_.avail_in == 0) {
           z_.avail_in = (uInt)fread(in_.data(), 1, in_.size(), f_);
@@ -98,7 +102,7 @@ class ByteReader : public ByteSource {
  private:
   std::string path_;
   FILE* f_ = nullptr;
-  bool gz_ = false, z_init_ = false, eof_ = false;
+  bool gz_ = false, z_init_ = false, eof_ = false, in_member_ = false;
   z_stream z_;
   std::vector<uint8_t> in_;
 };

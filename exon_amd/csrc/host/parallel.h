@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "arrow_build.h"
+#include "bgzf_block.h"
 #include "io.h"
 
 namespace exon {
@@ -293,21 +294,14 @@ class BgzfParallelSource : public ByteSource {
       while (!eof) {
         std::unique_ptr<Job> job(new Job());
         while (job->comp.size() < (1u << 20)) {
-          uint8_t h[18];
-          const size_t got = fread(h, 1, 18, f_);
-          if (got == 0) {
+          BgzfBlockInfo info;  // every length checked before use (host/bgzf_block.h)
+          if (!read_bgzf_block(f_, &blk_, &info, path_)) {
             eof = true;
             break;
           }
-          if (got != 18 || h[0] != 0x1f || h[1] != 0x8b || !(h[3] & 4) || h[12] != 'B' || h[13] != 'C')
-            throw std::runtime_error("not a BGZF block: " + path_);
-          uint16_t bsize;
-          memcpy(&bsize, h + 16, 2);
-          const size_t total = (size_t)bsize + 1, off = job->comp.size();
-          job->comp.resize(off + total);
-          memcpy(job->comp.data() + off, h, 18);
-          if (fread(job->comp.data() + off + 18, 1, total - 18, f_) != total - 18) throw std::runtime_error("truncated BGZF block: " + path_);
-          job->blocks.emplace_back(off, total);
+          const size_t off = job->comp.size();
+          job->comp.insert(job->comp.end(), blk_.begin(), blk_.end());
+          job->blocks.emplace_back(off, info.total);
         }
         if (job->blocks.empty()) continue;
         std::unique_lock<std::mutex> lk(mu_);
@@ -350,29 +344,16 @@ class BgzfParallelSource : public ByteSource {
       try {
         if (!zok) throw std::runtime_error("inflateInit2 failed");
         size_t total = 0;
-        for (auto& b : job->blocks) {
-          uint32_t isize;
-          memcpy(&isize, job->comp.data() + b.first + b.second - 4, 4);
-          total += isize;
+        std::vector<BgzfBlockInfo> infos(job->blocks.size());
+        for (size_t i = 0; i < job->blocks.size(); ++i) {
+          bgzf_block_info(job->comp.data() + job->blocks[i].first, job->blocks[i].second, &infos[i], path_);
+          total += infos[i].isize;
         }
         job->out.resize(total);
         size_t o = 0;
-        for (auto& b : job->blocks) {
-          const uint8_t* blk = job->comp.data() + b.first;
-          uint16_t xlen;
-          memcpy(&xlen, blk + 10, 2);
-          uint32_t isize;
-          memcpy(&isize, blk + b.second - 4, 4);
-          const size_t hdr = 12 + (size_t)xlen;
-          if (isize) {
-            inflateReset(&z);
-            z.next_in = const_cast<uint8_t*>(blk + hdr);
-            z.avail_in = (uInt)(b.second - hdr - 8);
-            z.next_out = job->out.data() + o;
-            z.avail_out = isize;
-            if (inflate(&z, Z_FINISH) != Z_STREAM_END) throw std::runtime_error("BGZF inflate error: " + path_);
-          }
-          o += isize;
+        for (size_t i = 0; i < job->blocks.size(); ++i) {  // inflate + CRC-32 check
+          inflate_bgzf_block(&z, job->comp.data() + job->blocks[i].first, infos[i], job->out.data() + o, path_);
+          o += infos[i].isize;
         }
         std::vector<uint8_t>().swap(job->comp);
       } catch (...) {
@@ -390,6 +371,7 @@ class BgzfParallelSource : public ByteSource {
 
   std::string path_;
   FILE* f_ = nullptr;
+  std::vector<uint8_t> blk_;  // reader thread: the block being read
   const size_t max_inflight_;
   std::thread reader_;
   std::vector<std::thread> workers_;

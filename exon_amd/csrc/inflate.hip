@@ -808,6 +808,9 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(const uint8_t* __res
 
   bool last = false;
   while (!last && err == INF_OK) {
+    // a corrupt member made of empty non-final blocks must not keep reading: stop at the end of the compressed data
+    // instead of relying on what lies behind it
+    if (br.overrun()) { err = INF_INPUT_OVERRUN; break; }
     br.refill();
     last = br.take(1) != 0;
     const int btype = (int)br.take(2);

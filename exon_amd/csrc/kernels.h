@@ -50,6 +50,12 @@ hipError_t launch_qual_pos_hist_views(hipStream_t s, const LaunchCfg& cfg, const
                                       const int32_t* ends, const uint8_t* bytes, int64_t n_reads, int lmax,
                                       int64_t* d_hist);
 
+// pushed-down region filter as a row mask: out_valid = in_valid AND (row hits the region); *n_pass += rows kept.
+// point form (VCF): id_col = chrom id, start = pos; range form (BAM): id_col = reference id, [start, end].
+hipError_t launch_region_mask(hipStream_t s, bool range_form, const int32_t* id_col, const uint8_t* id_valid, const int64_t* start,
+                              const int64_t* end, const uint8_t* pos_valid, const uint8_t* in_valid, int64_t n, int32_t id,
+                              int64_t a, int64_t b, uint8_t* out_valid, unsigned long long* n_pass);
+
 // out[v] = sum over ranks (rank order) of gathered[rank][v]; words [0, n_i64) int64, then n_f64 float64
 hipError_t launch_fold_states(hipStream_t s, const void* gathered, int world, int64_t n_i64, int64_t n_f64, void* out);
 

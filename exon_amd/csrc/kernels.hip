@@ -398,6 +398,65 @@ hipError_t launch_overlap_count(hipStream_t s, const LaunchCfg& cfg, const Works
 }
 
 // ------------------------------------------------------------------------------------------------
+// Pushed-down region filter as a row mask (vcf_region_filter / bam_region_filter evaluated by the scan itself):
+//   point form  IndexedAsyncBatchStream::filter (exon-vcf/src/indexed_async_batch_stream.rs:99-116):
+//               chrom == region.name AND start <= pos <= end; a record without pos never matches
+//   range form  SemiLazyRecord::intersects (exon-bam/src/indexed_async_batch_stream.rs:66-87):
+//               same reference AND aln_start <= region_end AND region_start <= aln_end; any of them missing: no match
+// The GPU decode path keeps every parsed row in place and hands the plan's kernel a validity bitmap for its FIRST
+// operand = (that operand's own validity) AND (row passes): all fused kernels drop rows whose first operand is NULL, so
+// the filter costs one pass over 12-20 B/row of freshly parsed columns and no compaction.  *n_pass counts the rows kept
+// (the scan reports rows it emitted, like the reference's filtered stream).
+// ------------------------------------------------------------------------------------------------
+template <bool RANGE>
+__global__ __launch_bounds__(256) void k_region_mask(const int32_t* __restrict__ id_col, const uint8_t* __restrict__ id_valid,
+                                                     const int64_t* __restrict__ start, const int64_t* __restrict__ end,
+                                                     const uint8_t* __restrict__ pos_valid, const uint8_t* __restrict__ in_valid,
+                                                     int64_t n, int32_t id, int64_t a, int64_t b, uint8_t* __restrict__ out_valid,
+                                                     unsigned long long* __restrict__ n_pass) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long kept = 0;
+  const int64_t n64 = (n + 63) & ~(int64_t)63;  // whole waves: the ballot needs every lane
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n64; r += (int64_t)gridDim.x * 256) {
+    bool pass = false;
+    if (r < n) {
+      const bool ok = valid1(id_valid, r) && valid1(pos_valid, r) && id_col[r] == id;
+      if (RANGE) pass = ok && start[r] <= b && end[r] >= a;
+      else pass = ok && start[r] >= a && start[r] <= b;
+    }
+    const unsigned long long hits = __ballot(pass);                           // rows the scan emits
+    const unsigned long long m = __ballot(pass && valid1(in_valid, r < n ? r : 0));  // ... of which the plan's operand is valid
+    if (lane < 8) {
+      const int64_t r0 = r - lane + lane * 8;
+      if (r0 < n) out_valid[r0 >> 3] = (uint8_t)(m >> (lane * 8));
+    }
+    if (lane == 0) kept += (unsigned long long)__popcll(hits);
+  }
+  // one atomic per workgroup
+  __shared__ unsigned long long red[4];
+  if (lane == 0) red[threadIdx.x >> 6] = kept;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = red[0] + red[1] + red[2] + red[3];
+    if (t) atomicAdd(n_pass, t);
+  }
+}
+
+hipError_t launch_region_mask(hipStream_t s, bool range_form, const int32_t* id_col, const uint8_t* id_valid, const int64_t* start,
+                              const int64_t* end, const uint8_t* pos_valid, const uint8_t* in_valid, int64_t n, int32_t id,
+                              int64_t a, int64_t b, uint8_t* out_valid, unsigned long long* n_pass) {
+  if (n <= 0) return hipSuccess;
+  const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+  if (range_form)
+    hipLaunchKernelGGL(k_region_mask<true>, dim3(grid), dim3(256), 0, s, id_col, id_valid, start, end, pos_valid, in_valid, n, id, a, b,
+                       out_valid, n_pass);
+  else
+    hipLaunchKernelGGL(k_region_mask<false>, dim3(grid), dim3(256), 0, s, id_col, id_valid, start, end, pos_valid, in_valid, n, id, a, b,
+                       out_valid, n_pass);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // K3 flag_mapq_group_count
 //   WHERE (flag & M) = V AND CAST(mapping_quality AS INT) >= Q  GROUP BY reference  COUNT(*)
 //   flag test = sam_flag_function (exon-core/src/udfs/sam/samflags.rs:26-47); mapq NULL when 255

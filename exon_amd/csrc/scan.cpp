@@ -42,14 +42,22 @@ struct exon_hip_scan {
   std::unique_ptr<exon::FASTABatchReader> fasta;
   int64_t rows = 0;
   exon::Dictionary bam_dict_view;  // reference names as a dictionary (ids = header order)
+  // pushed-down region filter (vcf_region_filter / bam_region_filter) on the GPU decode path
+  exon::RegionFilter region;
+  uint8_t* d_region_mask = nullptr;         // row mask of the slab being consumed (grown on demand)
+  size_t region_mask_cap = 0;
+  unsigned long long* d_region_pass = nullptr;  // rows kept so far in this consume
+  exon_hip_ctx* region_ctx = nullptr;
 };
 
 int exon_hip_stream_push_raw(exon_hip_stream* st, const exon::RawBatch& rb);  // stream.cpp
-int exon_hip_stream_launch_scan_columns(exon_hip_stream* st, const exon_hip_column* scan_cols, int n_scan_cols, int64_t n);
+int exon_hip_stream_launch_scan_columns(exon_hip_stream* st, const exon_hip_column* scan_cols, int n_scan_cols, int64_t n,
+                                        const uint8_t* row_mask);
+int exon_hip_stream_plan_first_column(exon_hip_stream* st);
 int exon_hip_stream_launch_views(exon_hip_stream* st, const uint8_t* d_text, const exon_hip_fastq_views& v);
 void* exon_hip_stream_hip_stream(exon_hip_stream* st);
 exon_hip_ctx* exon_hip_stream_ctx(exon_hip_stream* st);
-int exon_hip_stream_state_copy(exon_hip_stream* st, void* d_snapshot, bool restore);
+int exon_hip_stream_state_copy(exon_hip_stream* st, void* d_snapshot, bool restore, int64_t* rows_pushed);
 size_t exon_hip_stream_state_bytes(exon_hip_stream* st);
 
 // BGZF inputs of GPU-parsed scans are inflated on the GPU too (EXON_HIP_GPU_INFLATE=0: host threads inflate)
@@ -93,13 +101,16 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
       rf.active = true;
       rf.use_index = o->use_index != 0;
     }
+    s->region = rf;
     switch (o->format) {
       case EXON_HIP_FORMAT_VCF: {
         exon::VCFConfig cfg;
         cfg.batch_size = bs;
         cfg.info_field = o->info_field ? o->info_field : "";
         cfg.filter = rf;
-        s->gpu_parse = o->gpu_parse != 0 && !rf.active;  // a pushed-down region filter stays on the host decoder
+        // a pushed-down region filter rides along as a row mask (k_region_mask); with use_index the host plans the
+        // tabix chunks and only their BGZF blocks are shipped (indexed scans are BGZF by definition)
+        s->gpu_parse = o->gpu_parse != 0 && (!rf.use_index || (rf.active && wants_gpu_inflate(o, path)));
         cfg.defer_decode = s->gpu_parse;
         if (s->gpu_parse && wants_gpu_inflate(o, path)) cfg.threads = 1;  // only the header is read on the host
         s->vcf.reset(new exon::VCFBatchReader(path, c, cfg));
@@ -110,7 +121,7 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         cfg.batch_size = bs;
         cfg.filter = rf;
         // BAM is BGZF by definition: the GPU path inflates and splits records on the device or is not taken at all
-        s->gpu_parse = !rf.active && wants_gpu_inflate(o, path);
+        s->gpu_parse = wants_gpu_inflate(o, path);  // with a region: row mask on the device, BAI chunks planned on the host
         if (s->gpu_parse) cfg.threads = 1;  // only the header is read on the host
         s->bam.reset(new exon::BAMBatchReader(path, cfg));
         s->bam_dict_view.names = s->bam->ref_names;
@@ -122,7 +133,7 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         cfg.info_field = o->info_field ? o->info_field : "";
         cfg.filter = rf;
         cfg.filter.use_index = false;
-        s->gpu_parse = !rf.active && wants_gpu_inflate(o, path);  // BCF is BGZF by definition
+        s->gpu_parse = wants_gpu_inflate(o, path);  // BCF is BGZF by definition; a region becomes a row mask
         if (s->gpu_parse) cfg.threads = 1;  // only the header is read on the host
         s->bcf.reset(new exon::BCFBatchReader(path, cfg));
         break;
@@ -132,7 +143,7 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         cfg.batch_size = bs;
         cfg.filter = rf;
         cfg.filter.use_index = false;
-        s->gpu_parse = o->gpu_parse != 0 && !rf.active;
+        s->gpu_parse = o->gpu_parse != 0;
         s->sam.reset(new exon::SAMBatchReader(path, c, cfg));
         s->bam_dict_view.names = s->sam->ref_names;
         break;
@@ -266,6 +277,8 @@ int exon_hip_scan_close(exon_hip_scan* s) {
   if (s && s->bam_parser) exon_hip_bam_parser_destroy(s->bam_parser);
   if (s && s->bcf_parser) exon_hip_bcf_parser_destroy(s->bcf_parser);
   if (s && s->sam_parser) exon_hip_sam_parser_destroy(s->sam_parser);
+  if (s && s->d_region_mask) hipFree(s->d_region_mask);
+  if (s && s->d_region_pass) hipFree(s->d_region_pass);
   delete s;
   return EXON_HIP_OK;
 }
@@ -396,10 +409,11 @@ void exon_hip_release_ctx_caches(exon_hip_ctx* ctx) {
 
 class GpuTextSource {
  public:
+  // trim_last (BGZF only): inflated bytes to drop behind the last block -- an index chunk ends inside its last block
   GpuTextSource(exon_hip_ctx* ctx, hipStream_t hs, std::unique_ptr<exon::ByteSource> src, bool bgzf, uint64_t skip_first,
-                std::string carry, bool binary = false, bool text_async = false)
+                std::string carry, bool binary = false, bool text_async = false, size_t trim_last = 0)
       : ctx_(ctx), hs_(hs), src_(std::move(src)), rd_(src_.get()), bgzf_(bgzf), binary_(binary), text_async_(text_async), skip_(skip_first),
-        carry_(std::move(carry)) {
+        trim_last_(trim_last), carry_(std::move(carry)) {
     slab_ = slab_bytes();
     if (bgzf_) {
       // One wavefront inflates one block and a block takes ~3.5 ms however many run beside it, so a launch wants as many
@@ -655,6 +669,10 @@ class GpuTextSource {
       n_text = f.out_bytes - (size_t)skip_;
       skip_ = 0;
     }
+    if (!more && trim_last_) {  // an index chunk ends inside its last block: the rest of that block is not part of it
+      if (trim_last_ > n_text) return 1;
+      n_text -= trim_last_;
+    }
     if (more) {  // slab i+1: inflate it while the consumer works on slab i; then let the reader fetch slab i+2
       const double tj0 = now_s();
       if (reader_.joinable()) reader_.join();
@@ -727,6 +745,7 @@ class GpuTextSource {
         have += got;
       }
       const double tf1 = now_s();
+      memset(h_buf_[k] + have, 0, 4096);  // readable zero padding behind the last byte, written BEFORE the copy is queued
       if (xs_ && have > 0) {
         // Everything read starts crossing PCIe at once (its own stream, under the inflate of the previous slab) and the
         // header walk below runs under that copy: the slab must be in HBM one inflate period after this thread
@@ -755,7 +774,6 @@ class GpuTextSource {
         throw std::runtime_error("BGZF block larger than the slab");
       }
       left_.assign(reinterpret_cast<const char*>(h_buf_[k]) + consumed, have - consumed);
-      memset(h_buf_[k] + consumed, 0, 4096);  // readable padding behind the last block
       f->n = consumed;
       f->n_blocks = nb;
       f->out_bytes = out_bytes;
@@ -778,6 +796,7 @@ class GpuTextSource {
   bool text_async_;  // the consumer's kernels read the slab text after the parser has returned (FASTQ views)
   hipEvent_t ev_carry_ = nullptr;
   uint64_t skip_;
+  size_t trim_last_ = 0;
   std::string carry_;      // plain: what the host header reader had buffered (goes in front of the first slab)
   size_t carry_dev_ = 0;   // bytes of the carried tail (lives in d_text_[carry_k_] at carry_off_ until the next slab is taken)
   size_t slab_ = 0, comp_cap_ = 0, text_cap_ = 0, gap_ = 0, hcap_ = 0;
@@ -811,158 +830,303 @@ class GpuTextSource {
 };
 
 
+// raw bytes [lo, hi) of a file (the BGZF blocks of one index chunk)
+class FileRangeSource : public exon::ByteSource {
+ public:
+  FileRangeSource(const std::string& path, int64_t lo, int64_t hi) : left_((size_t)(hi - lo)) {
+    f_ = fopen(path.c_str(), "rb");
+    if (!f_ || fseek(f_, (long)lo, SEEK_SET) != 0) {
+      if (f_) fclose(f_);
+      throw std::runtime_error("cannot open " + path);
+    }
+  }
+  ~FileRangeSource() override {
+    if (f_) fclose(f_);
+  }
+  size_t read(uint8_t* dst, size_t n) override {
+    const size_t got = fread(dst, 1, std::min(n, left_), f_);
+    left_ -= got;
+    return got;
+  }
+
+ private:
+  FILE* f_ = nullptr;
+  size_t left_;
+};
+
+// One index chunk [start, end) of BGZF virtual positions as a byte range of whole blocks + what to cut off at both ends
+// of the inflated bytes (IndexedBGZFFile -> BGZFIndexedOffsets in the reference: indexed_bgzf_file.rs:129-155; the opener
+// seeks to the block and skips to the intra-block offset: indexed_file_opener.rs:114-162).
+struct ChunkRange {
+  int64_t lo = 0, hi = 0;  // compressed bytes
+  uint64_t skip = 0;       // inflated bytes in front of the chunk's first record
+  size_t trim = 0;         // inflated bytes behind its last record
+};
+static std::vector<ChunkRange> plan_chunk_ranges(const std::string& path, const std::vector<exon::Chunk>& chunks) {
+  std::vector<ChunkRange> out;
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) throw std::runtime_error("cannot open " + path);
+  try {
+    std::vector<uint8_t> blk;
+    for (const exon::Chunk& c : chunks) {
+      if (c.end <= c.start) continue;
+      ChunkRange r;
+      r.lo = (int64_t)(c.start >> 16);
+      r.skip = c.start & 0xFFFF;
+      r.hi = (int64_t)(c.end >> 16);
+      const size_t ue = (size_t)(c.end & 0xFFFF);
+      if (ue) {  // the chunk ends inside the block at r.hi: that block is needed, its tail is not
+        if (fseek(f, (long)r.hi, SEEK_SET) != 0) throw std::runtime_error("seek failed: " + path);
+        exon::BgzfBlockInfo info;
+        if (!exon::read_bgzf_block(f, &blk, &info, path)) throw std::runtime_error("index chunk ends beyond the file: " + path);
+        if (ue > info.isize) throw std::runtime_error("index chunk ends beyond its block: " + path);
+        r.hi += (int64_t)info.total;
+        r.trim = info.isize - ue;
+      }
+      if (r.hi > r.lo) out.push_back(r);
+    }
+  } catch (...) {
+    fclose(f);
+    throw;
+  }
+  fclose(f);
+  return out;
+}
+
+// the pushed-down region as (dictionary id, [a, b]) for the device row mask; id < 0: no row can match
+static void region_target(const exon_hip_scan* scan, int32_t* id, int64_t* a, int64_t* b, bool* range_form) {
+  const exon::Region& rg = scan->region.region;
+  const std::vector<std::string>* names = scan->vcf   ? &scan->vcf->header.contigs
+                                          : scan->bcf ? &scan->bcf->header.contigs
+                                          : scan->bam ? &scan->bam->ref_names
+                                                      : &scan->sam->ref_names;
+  *id = -1;
+  for (size_t i = 0; i < names->size(); ++i)
+    if ((*names)[i] == rg.name) *id = (int32_t)i;
+  *a = rg.start;
+  *b = rg.end;
+  *range_form = scan->bam != nullptr || scan->sam != nullptr;
+}
+
 // VCF / FASTQ file -> text slabs in HBM (GpuTextSource) -> GPU parser -> fused kernel.  Returns 1 when the device could
 // not decide something: the caller restores the state and re-decodes the file on the host.
 static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* rows_out) {
   const bool trace = getenv("EXON_HIP_PIPE_TRACE") != nullptr;  // phase timings on stderr
   const double t_begin = now_s();
-  double t_next = 0, t_parse = 0, t_launch = 0;
+  double t_next = 0, t_parse = 0;
   exon_hip_ctx* ctx = exon_hip_stream_ctx(st);
   hipStream_t hs = (hipStream_t)exon_hip_stream_hip_stream(st);
   const bool is_vcf = scan->vcf != nullptr, is_bam = scan->bam != nullptr, is_bcf = scan->bcf != nullptr, is_sam = scan->sam != nullptr;
-  std::unique_ptr<GpuTextSource> src;
+  const bool filtered = scan->region.active && (is_vcf || is_bam || is_bcf || is_sam);
+  const bool indexed = filtered && scan->region.use_index && (is_vcf || is_bam);
   const bool bgzf = gpu_inflate_enabled() && scan->opt.compression != EXON_HIP_COMPRESSION_NONE &&
-                    exon::BgzfParallelSource::is_bgzf(scan->path) && (!is_vcf || scan->vcf->data_offset() >= 0);
-  if ((is_bam || is_bcf) && !bgzf) return 1;
-  try {
-    if (bgzf) {
-      const uint64_t skip = is_vcf   ? (uint64_t)scan->vcf->data_offset()
-                            : is_bam ? (uint64_t)scan->bam->data_offset()
-                            : is_bcf ? (uint64_t)scan->bcf->data_offset()
-                            : is_sam ? (uint64_t)scan->sam->data_offset()
-                                     : 0;
-      std::unique_ptr<exon::ByteSource> raw(new exon::ByteReader(scan->path, exon::Compression::None));
-      src.reset(new GpuTextSource(ctx, hs, std::move(raw), true, skip, std::string(), is_bam || is_bcf, /*text_async=*/!is_vcf && !is_bam && !is_bcf && !is_sam));
-    } else {
-      std::string carry;
-      std::unique_ptr<exon::ByteSource> text = is_vcf   ? scan->vcf->take_stream(&carry)
-                                               : is_sam ? scan->sam->take_stream(&carry)
-                                                        : scan->fastq->take_stream(&carry);
-      if (!text) return fail(ctx, EXON_HIP_ESTATE, "scan already consumed");
-      src.reset(new GpuTextSource(ctx, hs, std::move(text), false, 0, std::move(carry)));
-    }
-  } catch (const std::exception& e) {
-    return fail(ctx, EXON_HIP_EINVAL, "%s", e.what());
-  }
+                    exon::BgzfParallelSource::is_bgzf(scan->path) && (!is_vcf || indexed || scan->vcf->data_offset() >= 0);
+  if ((is_bam || is_bcf || indexed) && !bgzf) return 1;
   scan->gpu_inflated = bgzf;
   scan->gpu_decoded = false;
-  int rc = src->init();
-  if (rc) return rc;
-  if (is_vcf && !scan->parser) {
-    std::vector<const char*> names;
-    for (const auto& c : scan->vcf->header.contigs) names.push_back(c.c_str());
-    rc = exon_hip_vcf_parser_create(ctx, names.data(), (int32_t)names.size(), scan->info_field_s.empty() ? nullptr : scan->info_field_s.c_str(),
-                                    (int64_t)src->max_text_bytes(), &scan->parser);
-    if (rc) return rc;
-    scan->parser_ctx = ctx;
-  }
-  if (is_bam && !scan->bam_parser) {
-    rc = exon_hip_bam_parser_create(ctx, (int32_t)scan->bam->ref_names.size(), (int64_t)src->max_text_bytes(), &scan->bam_parser);
-    if (rc) return rc;
-  }
-  if (is_bcf && !scan->bcf_parser) {
-    rc = exon_hip_bcf_parser_create(ctx, (int32_t)scan->bcf->header.contigs.size(), (int32_t)scan->bcf->strings().size(),
-                                    (int32_t)scan->bcf->header.samples.size(), (int32_t)scan->bcf->info_key(), (int64_t)src->max_text_bytes(),
-                                    &scan->bcf_parser);
-    if (rc) return rc;
-  }
-  if (is_sam && !scan->sam_parser) {
-    std::vector<const char*> names;
-    for (const auto& c : scan->sam->ref_names) names.push_back(c.c_str());
-    rc = exon_hip_sam_parser_create(ctx, names.data(), (int32_t)names.size(), (int64_t)src->max_text_bytes(), &scan->sam_parser);
-    if (rc) return rc;
-  }
-  if (!is_vcf && !is_bam && !is_bcf && !is_sam && !scan->fq_parser) {
-    rc = exon_hip_fastq_parser_create(ctx, (int64_t)src->max_text_bytes(), &scan->fq_parser);
-    if (rc) return rc;
-  }
-  int64_t total = 0;
-  const double t_init = now_s();
-  for (;;) {
-    const uint8_t* d_text = nullptr;
-    size_t n = 0;
-    bool final = false;
-    const double t0 = now_s();
-    rc = src->next(&d_text, &n, &final);
-    const double t1 = now_s();
-    t_next += t1 - t0;
-    if (rc) break;
-    size_t consumed = 0;
-    if (n > 0 && (is_vcf || is_bcf)) {
-      exon_hip_vcf_columns cols;
-      rc = is_vcf ? exon_hip_vcf_parser_parse(scan->parser, hs, d_text, (int64_t)n, &cols)
-                  : exon_hip_bcf_parser_parse(scan->bcf_parser, hs, d_text, (int64_t)n, &cols);
-      t_parse += now_s() - t1;
-      if (!rc && cols.n_undecided > 0) rc = 1;
-      if (rc) break;
-      consumed = (size_t)cols.consumed_bytes;
-      if (cols.n_rows > 0) {
-        exon_hip_column sc[5];
-        memset(sc, 0, sizeof sc);
-        sc[0].values = cols.chrom_id;
-        sc[1].values = cols.pos;
-        sc[1].validity = cols.pos_valid;
-        sc[2].values = cols.qual;
-        sc[2].validity = cols.qual_valid;
-        sc[3].values = cols.filter_id;
-        sc[4].values = cols.info;
-        sc[4].validity = cols.info_valid;
-        for (auto& c : sc) c.length = cols.n_rows;
-        rc = exon_hip_stream_launch_scan_columns(st, sc, 5, cols.n_rows);
-        // the parser's column buffers are reused by the next slab; the kernel is stream-ordered before that parse
-        total += cols.n_rows;
-      }
-    } else if (n > 0 && (is_bam || is_sam)) {
-      exon_hip_bam_columns cols;
-      rc = is_bam ? exon_hip_bam_parser_parse(scan->bam_parser, hs, d_text, (int64_t)n, &cols)
-                  : exon_hip_sam_parser_parse(scan->sam_parser, hs, d_text, (int64_t)n, &cols);
-      t_parse += now_s() - t1;
-      if (trace) fprintf(stderr, "[exon-hip pipe] bam slab %zu bytes: rc %d rows %lld undecided %lld consumed %lld\n", n, rc, (long long)cols.n_rows, (long long)cols.n_undecided, (long long)cols.consumed_bytes);
-      if (!rc && cols.n_undecided > 0) rc = 1;
-      if (rc) break;
-      consumed = (size_t)cols.consumed_bytes;
-      if (cols.n_rows > 0) {
-        exon_hip_column sc[5];
-        memset(sc, 0, sizeof sc);
-        sc[0].values = cols.flag;
-        sc[1].values = cols.mapq;
-        sc[1].validity = cols.mapq_valid;
-        sc[2].values = cols.ref_id;
-        sc[2].validity = cols.ref_valid;
-        sc[3].values = cols.start;
-        sc[3].validity = cols.pos_valid;
-        sc[4].values = cols.end;
-        sc[4].validity = cols.pos_valid;
-        for (auto& c : sc) c.length = cols.n_rows;
-        rc = exon_hip_stream_launch_scan_columns(st, sc, 5, cols.n_rows);
-        total += cols.n_rows;
-      }
-    } else if (n > 0) {
-      exon_hip_fastq_views v;
-      rc = exon_hip_fastq_parser_parse(scan->fq_parser, hs, d_text, (int64_t)n, final ? 1 : 0, &v);
-      if (!rc && v.n_undecided > 0) rc = 1;
-      if (!rc && !final && v.consumed_bytes == 0) rc = 1;  // not one whole record in a slab
-      if (rc) break;
-      consumed = (size_t)v.consumed_bytes;
-      if (v.n_reads > 0) {
-        rc = exon_hip_stream_launch_views(st, d_text, v);  // asynchronous: overlaps with preparing the next slab
-        total += v.n_reads;
-      }
+
+  // ---- the pushed-down region filter: (id, [a, b]) + a row-mask buffer + the count of rows kept -----------------
+  int32_t rg_id = -1;
+  int64_t rg_a = 0, rg_b = 0;
+  bool rg_range = false;
+  if (filtered) {
+    region_target(scan, &rg_id, &rg_a, &rg_b, &rg_range);
+    if (!scan->d_region_pass) {
+      HIP_TRY(ctx, hipMalloc((void**)&scan->d_region_pass, 8));
+      scan->region_ctx = ctx;
     }
-    if (rc) break;
-    if (!final && n > 0 && consumed == 0) { rc = 1; break; }  // a record larger than a slab
-    rc = src->release(consumed, final);
-    if (rc || final) break;
+    HIP_TRY(ctx, hipMemsetAsync(scan->d_region_pass, 0, 8, hs));
   }
-  if (hipStreamSynchronize(hs) != hipSuccess && rc == EXON_HIP_OK) rc = fail(ctx, EXON_HIP_EDEVICE, "stream synchronize failed");
+
+  // ---- the byte sources: the whole stream, or one per index chunk ------------------------------------------------
+  std::vector<ChunkRange> ranges;
+  if (indexed) {
+    try {
+      ranges = plan_chunk_ranges(scan->path, is_vcf ? scan->vcf->planned_chunks : scan->bam->planned_chunks);
+    } catch (const std::exception& e) {
+      return fail(ctx, EXON_HIP_EINVAL, "%s", e.what());
+    }
+  }
+  const size_t n_sources = indexed ? ranges.size() : 1;
+
+  int64_t total = 0;
+  int rc = EXON_HIP_OK;
+  double t_init = t_begin, t_reader = 0;
+  for (size_t si = 0; si < n_sources && rc == EXON_HIP_OK; ++si) {
+    std::unique_ptr<GpuTextSource> src;
+    try {
+      if (indexed) {
+        const ChunkRange& r = ranges[si];
+        std::unique_ptr<exon::ByteSource> raw(new FileRangeSource(scan->path, r.lo, r.hi));
+        src.reset(new GpuTextSource(ctx, hs, std::move(raw), true, r.skip, std::string(), is_bam, false, r.trim));
+      } else if (bgzf) {
+        const uint64_t skip = is_vcf   ? (uint64_t)scan->vcf->data_offset()
+                              : is_bam ? (uint64_t)scan->bam->data_offset()
+                              : is_bcf ? (uint64_t)scan->bcf->data_offset()
+                              : is_sam ? (uint64_t)scan->sam->data_offset()
+                                       : 0;
+        std::unique_ptr<exon::ByteSource> raw(new exon::ByteReader(scan->path, exon::Compression::None));
+        src.reset(new GpuTextSource(ctx, hs, std::move(raw), true, skip, std::string(), is_bam || is_bcf, /*text_async=*/!is_vcf && !is_bam && !is_bcf && !is_sam));
+      } else {
+        std::string carry;
+        std::unique_ptr<exon::ByteSource> text = is_vcf   ? scan->vcf->take_stream(&carry)
+                                                 : is_sam ? scan->sam->take_stream(&carry)
+                                                          : scan->fastq->take_stream(&carry);
+        if (!text) return fail(ctx, EXON_HIP_ESTATE, "scan already consumed");
+        src.reset(new GpuTextSource(ctx, hs, std::move(text), false, 0, std::move(carry)));
+      }
+    } catch (const std::exception& e) {
+      return fail(ctx, EXON_HIP_EINVAL, "%s", e.what());
+    }
+    rc = src->init();
+    if (rc) break;
+    if (is_vcf && !scan->parser) {
+      std::vector<const char*> names;
+      for (const auto& c : scan->vcf->header.contigs) names.push_back(c.c_str());
+      rc = exon_hip_vcf_parser_create(ctx, names.data(), (int32_t)names.size(), scan->info_field_s.empty() ? nullptr : scan->info_field_s.c_str(),
+                                      (int64_t)src->max_text_bytes(), &scan->parser);
+      if (rc) break;
+      scan->parser_ctx = ctx;
+    }
+    if (is_bam && !scan->bam_parser) {
+      rc = exon_hip_bam_parser_create(ctx, (int32_t)scan->bam->ref_names.size(), (int64_t)src->max_text_bytes(), &scan->bam_parser);
+      if (rc) break;
+    }
+    if (is_bcf && !scan->bcf_parser) {
+      rc = exon_hip_bcf_parser_create(ctx, (int32_t)scan->bcf->header.contigs.size(), (int32_t)scan->bcf->strings().size(),
+                                      (int32_t)scan->bcf->header.samples.size(), (int32_t)scan->bcf->info_key(), (int64_t)src->max_text_bytes(),
+                                      &scan->bcf_parser);
+      if (rc) break;
+    }
+    if (is_sam && !scan->sam_parser) {
+      std::vector<const char*> names;
+      for (const auto& c : scan->sam->ref_names) names.push_back(c.c_str());
+      rc = exon_hip_sam_parser_create(ctx, names.data(), (int32_t)names.size(), (int64_t)src->max_text_bytes(), &scan->sam_parser);
+      if (rc) break;
+    }
+    if (!is_vcf && !is_bam && !is_bcf && !is_sam && !scan->fq_parser) {
+      rc = exon_hip_fastq_parser_create(ctx, (int64_t)src->max_text_bytes(), &scan->fq_parser);
+      if (rc) break;
+    }
+    if (si == 0) t_init = now_s();
+    for (;;) {
+      const uint8_t* d_text = nullptr;
+      size_t n = 0;
+      bool final = false;
+      const double t0 = now_s();
+      rc = src->next(&d_text, &n, &final);
+      const double t1 = now_s();
+      t_next += t1 - t0;
+      if (rc) break;
+      size_t consumed = 0;
+      if (n > 0 && (is_vcf || is_bcf || is_bam || is_sam)) {
+        // parsed columns in the scan's column order: VCF / BCF 0 chrom 1 pos 2 qual 3 filter 4 info; BAM / SAM 0 flag 1 mapq 2 ref 3 start 4 end
+        exon_hip_column sc[5];
+        memset(sc, 0, sizeof sc);
+        int64_t n_rows = 0;
+        const int32_t* id_col = nullptr;
+        const uint8_t *id_valid = nullptr, *pos_valid = nullptr;
+        const int64_t *c_start = nullptr, *c_end = nullptr;
+        if (is_vcf || is_bcf) {
+          exon_hip_vcf_columns cols;
+          rc = is_vcf ? exon_hip_vcf_parser_parse(scan->parser, hs, d_text, (int64_t)n, &cols)
+                      : exon_hip_bcf_parser_parse(scan->bcf_parser, hs, d_text, (int64_t)n, &cols);
+          t_parse += now_s() - t1;
+          if (!rc && cols.n_undecided > 0) rc = 1;
+          if (rc) break;
+          consumed = (size_t)cols.consumed_bytes;
+          n_rows = cols.n_rows;
+          sc[0].values = cols.chrom_id;
+          sc[1].values = cols.pos;
+          sc[1].validity = cols.pos_valid;
+          sc[2].values = cols.qual;
+          sc[2].validity = cols.qual_valid;
+          sc[3].values = cols.filter_id;
+          sc[4].values = cols.info;
+          sc[4].validity = cols.info_valid;
+          id_col = cols.chrom_id;
+          c_start = c_end = cols.pos;
+          pos_valid = cols.pos_valid;
+        } else {
+          exon_hip_bam_columns cols;
+          rc = is_bam ? exon_hip_bam_parser_parse(scan->bam_parser, hs, d_text, (int64_t)n, &cols)
+                      : exon_hip_sam_parser_parse(scan->sam_parser, hs, d_text, (int64_t)n, &cols);
+          t_parse += now_s() - t1;
+          if (trace) fprintf(stderr, "[exon-hip pipe] bam slab %zu bytes: rc %d rows %lld undecided %lld consumed %lld\n", n, rc, (long long)cols.n_rows, (long long)cols.n_undecided, (long long)cols.consumed_bytes);
+          if (!rc && cols.n_undecided > 0) rc = 1;
+          if (rc) break;
+          consumed = (size_t)cols.consumed_bytes;
+          n_rows = cols.n_rows;
+          sc[0].values = cols.flag;
+          sc[1].values = cols.mapq;
+          sc[1].validity = cols.mapq_valid;
+          sc[2].values = cols.ref_id;
+          sc[2].validity = cols.ref_valid;
+          sc[3].values = cols.start;
+          sc[3].validity = cols.pos_valid;
+          sc[4].values = cols.end;
+          sc[4].validity = cols.pos_valid;
+          id_col = cols.ref_id;
+          id_valid = cols.ref_valid;
+          c_start = cols.start;
+          c_end = cols.end;
+          pos_valid = cols.pos_valid;
+        }
+        if (n_rows > 0) {
+          for (auto& c : sc) c.length = n_rows;
+          const uint8_t* row_mask = nullptr;
+          if (filtered) {
+            // the per-record interval hit, on the device: mask = (first operand's validity) AND hit
+            const size_t need = (size_t)(n_rows + 7) / 8 + 64;
+            if (scan->region_mask_cap < need) {
+              HIP_TRY(ctx, hipStreamSynchronize(hs));  // the previous slab's kernel may still read the old buffer
+              if (scan->d_region_mask) hipFree(scan->d_region_mask);
+              scan->d_region_mask = nullptr;
+              scan->region_mask_cap = 0;
+              const size_t cap = need + need / 2;
+              if (hipMalloc((void**)&scan->d_region_mask, cap) != hipSuccess) return fail(ctx, EXON_HIP_ENOMEM, "row mask of %zu bytes", cap);
+              scan->region_mask_cap = cap;
+            }
+            const int first = exon_hip_stream_plan_first_column(st);
+            const uint8_t* in_valid = first >= 0 && first < 5 ? sc[first].validity : nullptr;
+            HIP_TRY(ctx, exon::launch_region_mask(hs, rg_range, id_col, id_valid, c_start, c_end, pos_valid, in_valid, n_rows, rg_id, rg_a, rg_b,
+                                                  scan->d_region_mask, scan->d_region_pass));
+            row_mask = scan->d_region_mask;
+          }
+          rc = exon_hip_stream_launch_scan_columns(st, sc, 5, n_rows, row_mask);
+          // the parser's column buffers (and the row mask) are reused by the next slab; the kernel is stream-ordered before that
+          total += n_rows;
+        }
+      } else if (n > 0) {
+        exon_hip_fastq_views v;
+        rc = exon_hip_fastq_parser_parse(scan->fq_parser, hs, d_text, (int64_t)n, final ? 1 : 0, &v);
+        if (!rc && v.n_undecided > 0) rc = 1;
+        if (!rc && !final && v.consumed_bytes == 0) rc = 1;  // not one whole record in a slab
+        if (rc) break;
+        consumed = (size_t)v.consumed_bytes;
+        if (v.n_reads > 0) {
+          rc = exon_hip_stream_launch_views(st, d_text, v);  // asynchronous: overlaps with preparing the next slab
+          total += v.n_reads;
+        }
+      }
+      if (rc) break;
+      if (!final && n > 0 && consumed == 0) { rc = 1; break; }  // a record larger than a slab
+      rc = src->release(consumed, final);
+      if (rc || final) break;
+    }
+    if (hipStreamSynchronize(hs) != hipSuccess && rc == EXON_HIP_OK) rc = fail(ctx, EXON_HIP_EDEVICE, "stream synchronize failed");
+    t_reader += src->reader_seconds();
+    src.reset();
+  }
   const double t_loop = now_s();
-  const double t_reader = src ? src->reader_seconds() : 0;
-  src.reset();
   if (trace)
-    fprintf(stderr, "[exon-hip pipe] setup %.1f ms, loop %.1f ms (slabs: wait+H2D+inflate %.1f, parse %.1f, other %.1f; file reader busy %.1f), teardown %.1f ms\n",
-            (t_init - t_begin) * 1e3, (t_loop - t_init) * 1e3, t_next * 1e3, t_parse * 1e3, (t_loop - t_init - t_next - t_parse) * 1e3, t_reader * 1e3,
-            (now_s() - t_loop) * 1e3);
-  (void)t_launch;
+    fprintf(stderr, "[exon-hip pipe] setup %.1f ms, loop %.1f ms (%zu source(s); slabs: wait+H2D+inflate %.1f, parse %.1f, other %.1f; file reader busy %.1f)\n",
+            (t_init - t_begin) * 1e3, (t_loop - t_init) * 1e3, n_sources, t_next * 1e3, t_parse * 1e3, (t_loop - t_init - t_next - t_parse) * 1e3, t_reader * 1e3);
+  if (rc == EXON_HIP_OK && filtered) {  // the scan emitted the rows that hit the region
+    unsigned long long kept = 0;
+    HIP_TRY(ctx, hipMemcpy(&kept, scan->d_region_pass, 8, hipMemcpyDeviceToHost));
+    total = (int64_t)kept;
+  }
   if (rc == EXON_HIP_OK && is_bcf) {
     // FILTER lists (header-string indexes) -> names, in id order
     int32_t nf = 0;
@@ -982,7 +1146,7 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
       }
     }
   }
-  if (rc == EXON_HIP_OK && is_vcf) {
+  if (rc == EXON_HIP_OK && is_vcf && scan->parser) {
     // FILTER dictionary -> scan (names in id order)
     int32_t nf = 0;
     std::vector<char> buf(1 << 20);
@@ -1022,13 +1186,14 @@ int exon_hip_stream_consume_scan(exon_hip_stream* st, exon_hip_scan* scan, int64
     void* snap = nullptr;
     const size_t sb = exon_hip_stream_state_bytes(st);
     if (hipMalloc(&snap, sb ? sb : 16) != hipSuccess) return fail(ctx, EXON_HIP_ENOMEM, "state snapshot allocation failed");
-    int rc = exon_hip_stream_state_copy(st, snap, false);
+    int64_t rows_before = 0;
+    int rc = exon_hip_stream_state_copy(st, snap, false, &rows_before);  // flushes rows staged by earlier pushes first
     if (!rc) rc = consume_text_gpu(st, scan, rows);
     if (rc != 1) {
       hipFree(snap);
       return rc;
     }
-    rc = exon_hip_stream_state_copy(st, snap, true);
+    rc = exon_hip_stream_state_copy(st, snap, true, &rows_before);
     hipStreamSynchronize((hipStream_t)exon_hip_stream_hip_stream(st));
     hipFree(snap);
     if (rc) return rc;

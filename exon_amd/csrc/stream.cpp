@@ -431,7 +431,10 @@ int exon_hip_stream_push(exon_hip_stream* st, struct ArrowArray* batch) {
 
 // Internal (C++) hooks for the GPU decode pipeline (scan.cpp): launch the plan over HBM-resident columns addressed
 // in the SCAN's column order, and snapshot / restore the partial state around a speculative GPU-parsed file.
-int exon_hip_stream_launch_scan_columns(exon_hip_stream* st, const exon_hip_column* scan_cols, int n_scan_cols, int64_t n) {
+// `row_mask` (optional): validity bitmap that REPLACES the one of the plan's first operand (the pushed-down region filter:
+// the caller has already ANDed that operand's own validity into it; every fused kernel drops rows whose first operand is NULL).
+int exon_hip_stream_launch_scan_columns(exon_hip_stream* st, const exon_hip_column* scan_cols, int n_scan_cols, int64_t n,
+                                        const uint8_t* row_mask) {
   exon_hip_plan* p = st->plan;
   if (st->closed) return fail(st->ctx, EXON_HIP_ESTATE, "push after finish/close");
   int rc = flush_slot(st);  // keep stream order with rows staged earlier
@@ -442,10 +445,12 @@ int exon_hip_stream_launch_scan_columns(exon_hip_stream* st, const exon_hip_colu
     if (idx >= n_scan_cols || !scan_cols[idx].values) return fail(st->ctx, EXON_HIP_EINVAL, "plan needs scan column %d which this scan does not produce", idx);
     cols[c] = scan_cols[idx];
   }
+  if (row_mask) cols[0].validity = row_mask;
   rc = launch_plan(st, cols, n);
   if (!rc) st->rows_pushed += n;
   return rc;
 }
+int exon_hip_stream_plan_first_column(exon_hip_stream* st) { return st->plan->d.columns[0]; }
 // K5 over views into text resident in HBM (FASTQ slabs): scan column 2 = sequence lines, 3 = quality lines
 int exon_hip_stream_launch_views(exon_hip_stream* st, const uint8_t* d_text, const exon_hip_fastq_views& v) {
   exon_hip_plan* p = st->plan;
@@ -465,12 +470,17 @@ int exon_hip_stream_launch_views(exon_hip_stream* st, const uint8_t* d_text, con
 }
 void* exon_hip_stream_hip_stream(exon_hip_stream* st) { return (void*)st->stream; }
 exon_hip_ctx* exon_hip_stream_ctx(exon_hip_stream* st) { return st->ctx; }
-int exon_hip_stream_state_copy(exon_hip_stream* st, void* d_snapshot, bool restore) {
+// snapshot (restore = false) / roll back (restore = true) the partial state around a speculative GPU decode.  Rows staged
+// by earlier pushes are launched BEFORE the snapshot is taken (they belong to it), and the row counter travels with it.
+int exon_hip_stream_state_copy(exon_hip_stream* st, void* d_snapshot, bool restore, int64_t* rows_pushed) {
   if (!restore) {
-    int rc = settle_reset(st);
+    int rc = flush_slot(st);
+    if (!rc) rc = settle_reset(st);
     if (rc) return rc;
+    if (rows_pushed) *rows_pushed = st->rows_pushed;
   } else {
     st->overwrite_next = false;
+    if (rows_pushed) st->rows_pushed = *rows_pushed;
   }
   const size_t bytes = (size_t)(st->plan->n_i64 + st->plan->n_f64) * 8;
   HIP_TRY(st->ctx, hipMemcpyAsync(restore ? (void*)st->d_state : d_snapshot, restore ? d_snapshot : (void*)st->d_state, bytes,
