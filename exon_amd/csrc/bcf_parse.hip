@@ -70,6 +70,7 @@ struct BcfOut {
   int32_t* filter_id;
   float* info;
   uint32_t* info_valid;
+  uint32_t* pos_valid;  // POS 0 (BCF pos0 = -1, the telomere) is NULL like in the VCF path
 };
 
 __device__ __forceinline__ int type_size(int t) { return t == 1 ? 1 : t == 2 ? 2 : t == 3 ? 4 : t == 5 ? 4 : t == 7 ? 1 : 0; }
@@ -193,12 +194,13 @@ __global__ __launch_bounds__(256) void k_bcf_extract(const uint8_t* __restrict__
       }
     }
     out.chrom_id[row] = chrom;
-    out.pos[row] = (int64_t)pos0 + 1;
+    out.pos[row] = pos0 >= 0 ? (int64_t)pos0 + 1 : 0;
     out.qual[row] = qbits == 0x7F800001u ? 0.f : __uint_as_float(qbits);
     out.filter_id[row] = slot;
     out.info[row] = have ? iv : 0.f;
     const uint32_t bit = 1u << (row & 31);
     if (qbits != 0x7F800001u) atomicOr(&out.qual_valid[row >> 5], bit);
+    if (pos0 >= 0) atomicOr(&out.pos_valid[row >> 5], bit);
     if (have) atomicOr(&out.info_valid[row >> 5], bit);
   }
 }
@@ -224,7 +226,7 @@ struct exon_hip_bcf_parser {
   uint32_t max_seg = 0;
   SegInfo* d_seg = nullptr;
   uint32_t *d_base = nullptr, *d_rec_off = nullptr, *d_scalars = nullptr;
-  void* bufs[7] = {nullptr};
+  void* bufs[8] = {nullptr};
   void* fbufs[5] = {nullptr};
   BcfOut out{};
   FilterLists filters{};
@@ -266,6 +268,7 @@ int exon_hip_bcf_parser_create(exon_hip_ctx* ctx, int32_t n_contigs, int32_t n_s
   dalloc(&p->bufs[4], r * 4);
   dalloc(&p->bufs[5], r * 4);
   dalloc(&p->bufs[6], w);
+  dalloc(&p->bufs[7], w);
   dalloc(&p->fbufs[0], (size_t)FSLOTS * 8);
   dalloc(&p->fbufs[1], (size_t)FSLOTS * 4);
   dalloc(&p->fbufs[2], (size_t)FSLOTS * FLIST * 4);
@@ -281,7 +284,7 @@ int exon_hip_bcf_parser_create(exon_hip_ctx* ctx, int32_t n_contigs, int32_t n_s
     return fail(ctx, EXON_HIP_ENOMEM, "bcf parser allocation: %s", msg.c_str());
   }
   p->out = BcfOut{(int32_t*)p->bufs[0], (int64_t*)p->bufs[1], (float*)p->bufs[2], (uint32_t*)p->bufs[3],
-                  (int32_t*)p->bufs[4], (float*)p->bufs[5], (uint32_t*)p->bufs[6]};
+                  (int32_t*)p->bufs[4], (float*)p->bufs[5], (uint32_t*)p->bufs[6], (uint32_t*)p->bufs[7]};
   p->filters = FilterLists{(unsigned long long*)p->fbufs[0], (int32_t*)p->fbufs[1], (int32_t*)p->fbufs[2], (int32_t*)p->fbufs[3],
                            (int32_t*)p->fbufs[4]};
   *outp = p;
@@ -313,6 +316,7 @@ int exon_hip_bcf_parser_parse(exon_hip_bcf_parser* p, void* stream, const uint8_
   HIP_TRY(ctx, hipMemsetAsync(p->d_scalars, 0, 16, s));
   HIP_TRY(ctx, hipMemsetAsync(p->out.qual_valid, 0, words, s));
   HIP_TRY(ctx, hipMemsetAsync(p->out.info_valid, 0, words, s));
+  HIP_TRY(ctx, hipMemsetAsync(p->out.pos_valid, 0, words, s));
   hipLaunchKernelGGL(chain::k_chain_walk<BcfFormat>, dim3(n_seg), dim3(64), 0, s, d_data, n, BcfFormat{p->n_contigs, p->n_samples}, p->d_seg,
                      p->d_rec_off);
   if ((size_t)n_seg * 12 > 152 * 1024) return fail(ctx, EXON_HIP_EINVAL, "slab of %u segments is too large for the chain proof", n_seg);
@@ -332,7 +336,7 @@ int exon_hip_bcf_parser_parse(exon_hip_bcf_parser* p, void* stream, const uint8_
   cols->consumed_bytes = p->h_scalars[2];
   cols->chrom_id = p->out.chrom_id;
   cols->pos = p->out.pos;
-  cols->pos_valid = nullptr;  // POS is a fixed field: never NULL
+  cols->pos_valid = (uint8_t*)p->out.pos_valid;  // pos0 = -1 (POS 0) -> NULL
   cols->qual = p->out.qual;
   cols->qual_valid = (uint8_t*)p->out.qual_valid;
   cols->filter_id = p->out.filter_id;

@@ -285,6 +285,7 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
           }
         }
         pos_ok = ok && v > 0;
+        if (!ok) bad = true;  // not a number: `variant_start().transpose()?` is an error in the reference -- the host reports it
         out.pos[row] = pos_ok ? v : 0;
       }
       // QUAL

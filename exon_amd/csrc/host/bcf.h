@@ -169,7 +169,8 @@ class BCFBatchReader {
       }
       if (chrom_id < 0 || chrom_id >= (int)chrom_dict.names.size()) throw std::runtime_error("BCF CHROM index out of range");
       chrom.append_value(chrom_id);
-      pos.append_value((int64_t)pos0 + 1);
+      if (pos0 >= 0) pos.append_value((int64_t)pos0 + 1);
+      else pos.append_null(0);  // POS 0 (the telomere) has no variant_start: NULL, as in the VCF path
       if (qbits == 0x7F800001u) qual.append_null(0.f);
       else {
         float q;

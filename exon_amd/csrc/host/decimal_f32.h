@@ -10,7 +10,8 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define EXON_HD __host__ __device__ __forceinline__
 #else
 #define EXON_HD inline

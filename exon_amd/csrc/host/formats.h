@@ -22,6 +22,7 @@
 
 #include "arrow_build.h"
 #include "bgzf_index.h"
+#include "decimal_f32.h"
 #include "io.h"
 #include "parallel.h"
 #include "raw_batch.h"
@@ -138,14 +139,11 @@ class VCFArrayBuilder : public ExonArrayBuilder {
       }
     if (nf < 8) throw std::runtime_error("VCF record has fewer than 8 fields");
     chrom_.append_value(chrom_dict_->lookup_or_insert(f[0], fl[0]));
-    // POS: 0 (telomere) and '.' have no variant_start
+    // POS: "0" (telomere) has no variant_start -> NULL; anything that is not a number is the reference's parse error
+    // (`record.variant_start().transpose()?`, lazy_array_builder.rs:163-168)
     int64_t pos = 0;
-    bool pos_ok = fl[1] > 0;
-    for (size_t i = 0; i < fl[1] && pos_ok; ++i) {
-      if (f[1][i] < '0' || f[1][i] > '9') pos_ok = false;
-      else pos = pos * 10 + (f[1][i] - '0');
-    }
-    if (pos_ok && pos > 0) pos_.append_value(pos);
+    if (!parse_pos(f[1], fl[1], &pos)) throw std::runtime_error("invalid POS '" + std::string(f[1], fl[1]) + "'");
+    if (pos > 0) pos_.append_value(pos);
     else pos_.append_null(0);
     // QUAL: '.' -> NULL, else correctly rounded f32 (Rust str::parse::<f32>)
     if (fl[5] == 1 && f[5][0] == '.') qual_.append_null(0.f);
@@ -188,6 +186,17 @@ class VCFArrayBuilder : public ExonArrayBuilder {
   PrimitiveBuilder<float>& quals() { return qual_; }
   PrimitiveBuilder<float>& infos() { return info_; }
 
+  static bool parse_pos(const char* p, size_t n, int64_t* out) {
+    if (n == 0 || n > 18) return false;
+    int64_t v = 0;
+    for (size_t i = 0; i < n; ++i) {
+      if (p[i] < '0' || p[i] > '9') return false;
+      v = v * 10 + (p[i] - '0');
+    }
+    *out = v;
+    return true;
+  }
+
   // Correctly rounded decimal -> f32 (what Rust's str::parse::<f32> guarantees).  Fast path (Clinger): a
   // mantissa below 2^24 and a power of ten up to 10^10 are both exact in f32, so ONE IEEE multiply/divide is
   // correctly rounded; anything else (long mantissas, big exponents, inf/nan spellings) goes to strtof.
@@ -229,13 +238,33 @@ class VCFArrayBuilder : public ExonArrayBuilder {
         if (e > 0 && e <= 10) { const float v = (float)mant * P10[e]; return neg ? -v : v; }
       }
     }
-    char tmp[64];
-    if (n >= sizeof tmp) n = sizeof tmp - 1;
-    memcpy(tmp, p, n);
-    tmp[n] = 0;
+    // Everything else: the Eisel-Lemire path the GPU parser uses (<= 19 significant digits), then strtof for what is left
+    // -- but only for text Rust's grammar accepts: [sign] (inf | infinity | nan | digits [. digits] [e [sign] digits]), the
+    // whole field, no hex floats, no leading blanks, any length, independent of the process locale's decimal point.
+    uint32_t bits;
+    if (n <= (size_t)INT32_MAX && dec::parse_f32(p, (int)n, &bits)) {
+      float v;
+      memcpy(&v, &bits, 4);
+      return v;
+    }
+    const std::string tmp(p, n);
+    size_t i = 0;
+    if (i < n && (p[i] == '+' || p[i] == '-')) ++i;
+    auto ieq = [&](const char* w) {
+      const size_t wl = strlen(w);
+      if (n - i != wl) return false;
+      for (size_t k = 0; k < wl; ++k)
+        if ((p[i + k] | 0x20) != w[k]) return false;
+      return true;
+    };
+    bool ok = ieq("inf") || ieq("infinity") || ieq("nan");
+    if (!ok) {
+      ok = i < n;
+      for (size_t k = i; k < n && ok; ++k) ok = (p[k] >= '0' && p[k] <= '9') || p[k] == '.' || p[k] == 'e' || p[k] == 'E' || p[k] == '+' || p[k] == '-';
+    }
     char* end = nullptr;
-    const float v = strtof(tmp, &end);
-    if (end == tmp) throw std::runtime_error(std::string("invalid float '") + tmp + "'");
+    const float v = ok ? strtof(tmp.c_str(), &end) : 0.f;
+    if (!ok || end != tmp.c_str() + n) throw std::runtime_error("invalid float '" + tmp + "'");
     return v;
   }
 
@@ -274,14 +303,12 @@ inline bool vcf_region_hit(const char* line, size_t len, const Region& rg) {
   if (!t1) return false;
   const size_t nl = (size_t)(t1 - line);
   if (nl != rg.name.size() || memcmp(line, rg.name.data(), nl) != 0) return false;
-  int64_t pos = 0;
+  // the contig matches: now the position is parsed, and a malformed one is an error (`position?`), "0" is no position
   const char* p = t1 + 1;
-  const char* end = line + len;
-  if (p == end || *p == '\t') return false;
-  for (; p < end && *p != '\t'; ++p) {
-    if (*p < '0' || *p > '9') return false;
-    pos = pos * 10 + (*p - '0');
-  }
+  const char* end = static_cast<const char*>(memchr(p, '\t', (size_t)(line + len - p)));
+  if (!end) end = line + len;
+  int64_t pos = 0;
+  if (!VCFArrayBuilder::parse_pos(p, (size_t)(end - p), &pos)) throw std::runtime_error("invalid POS '" + std::string(p, (size_t)(end - p)) + "'");
   return pos >= 1 && pos >= rg.start && pos <= rg.end;
 }
 

@@ -46,7 +46,11 @@ def decode_vcf(path):
             continue
         c = line.split("\t")
         rows["chrom"].append(c[0])
-        rows["pos"].append(int(c[1]) if c[1] != "." else None)
+        # noodles-vcf lazy record: POS "0" (telomere) has no variant_start -> None; anything else must parse as an
+        # unsigned integer or `record.variant_start().transpose()?` fails (lazy_array_builder.rs:163-168)
+        if not c[1].isascii() or not c[1].isdigit():
+            raise ValueError(f"invalid POS {c[1]!r}")
+        rows["pos"].append(int(c[1]) or None)
         rows["qual"].append(None if c[5] == "." else np.float32(c[5]))
         rows["filter"].append([] if c[6] == "." else c[6].split(";"))
         if c[7] == ".":
@@ -144,6 +148,118 @@ def bam_device_columns(recs):
     ref = np.array([r["ref_id"] if r["ref_id"] is not None else -1 for r in recs], np.int32)
     rv = np.packbits(np.array([r["ref_id"] is not None for r in recs], bool), bitorder="little")
     return n, flag, mapq, mv, ref, rv
+
+
+# ---- SAM (text) --------------------------------------------------------------------------------------
+def decode_sam(path):
+    """Same columns as BAM (exon-sam/src/schema_builder.rs:371-402): RNAME through the @SQ order ('*' -> None), POS 0 ->
+    None, MAPQ 255 -> None, end from the CIGAR."""
+    refs, recs = [], []
+    for line in read_bytes(path).decode().split("\n"):
+        if not line:
+            continue
+        if line.startswith("@"):
+            if line.startswith("@SQ"):
+                f = dict(x.split(":", 1) for x in line.split("\t")[1:] if ":" in x)
+                refs.append((f["SN"], int(f.get("LN", 0))))
+            continue
+        c = line.split("\t")
+        names = [r[0] for r in refs]
+        pos, mapq = int(c[3]), int(c[4])
+        ref_len, num = 0, ""
+        if c[5] != "*":
+            for ch in c[5]:
+                if ch.isdigit():
+                    num += ch
+                else:
+                    if CIGAR_OPS.index(ch) in REF_CONSUMING:
+                        ref_len += int(num)
+                    num = ""
+        start = pos if pos >= 1 else None
+        recs.append(dict(name=c[0], flag=int(c[1]), ref_id=names.index(c[2]) if c[2] in names else None, start=start,
+                         end=(start + ref_len - 1) if start is not None else None, mapq=None if mapq == 255 else mapq,
+                         cigar=c[5]))
+    return refs, recs
+
+
+# ---- BCF2 ----------------------------------------------------------------------------------------------
+def decode_bcf(path):
+    """BCF 2.2 (VCF specification section 6) -> the same dict as decode_vcf: CHROM through the header contigs, POS = pos0 + 1
+    (pos0 = -1 -> None), QUAL 0x7F800001 -> None, FILTER / INFO keys through the header string dictionary (PASS = 0, then
+    FILTER / INFO / FORMAT IDs in order of first appearance unless IDX= says otherwise)."""
+    b = read_bytes(path)
+    assert b[:5] == b"BCF\x02\x02"
+    l_text, = struct.unpack_from("<I", b, 5)
+    text = b[9:9 + l_text].rstrip(b"\0").decode()
+    contigs, strings, filt_hdr, info_hdr = [], {"PASS": 0}, [], {}
+    order = ["PASS"]
+    for line in text.split("\n"):
+        if line.startswith("##contig=<"):
+            contigs.append(_hdr_fields(line)["ID"])
+        elif line.startswith(("##FILTER=<", "##INFO=<", "##FORMAT=<")):
+            f = _hdr_fields(line)
+            if line.startswith("##FILTER=<"):
+                filt_hdr.append(f["ID"])
+            if line.startswith("##INFO=<"):
+                info_hdr[f["ID"]] = (f.get("Number"), f.get("Type"))
+            if f["ID"] not in strings:
+                strings[f["ID"]] = int(f["IDX"]) if "IDX" in f else len(order)
+                order.append(f["ID"])
+    by_idx = {v: k for k, v in strings.items()}
+    rows = dict(chrom=[], pos=[], qual=[], filter=[], info=[])
+    size = {1: 1, 2: 2, 3: 4, 5: 4, 7: 1}
+    fmt = {1: "b", 2: "h", 3: "i", 5: "f"}
+    missing = {1: -128, 2: -32768, 3: -2147483648}
+
+    def typed(o):
+        d = b[o]
+        o += 1
+        n, t = d >> 4, d & 15
+        if n == 15:
+            (cnt, o2) = typed(o)
+            n, o = cnt[0], o2
+        if t == 0:
+            return [], o
+        if t == 7:
+            return b[o:o + n], o + n
+        vals = list(struct.unpack_from(f"<{n}{fmt[t]}", b, o))
+        if t == 5:
+            raw = struct.unpack_from(f"<{n}I", b, o)
+            vals = [None if r == 0x7F800001 else v for v, r in zip(vals, raw) if r != 0x7F800002]
+        else:
+            vals = [None if v == missing[t] else v for v in vals if v != missing[t] + 1]
+        return vals, o + n * size[t]
+
+    o = 9 + l_text
+    while o < len(b):
+        l_shared, l_indiv = struct.unpack_from("<II", b, o)
+        r = o + 8
+        chrom, pos0, _rlen, qbits, nia, _nfs = struct.unpack_from("<iiiIII", b, r)
+        n_info, n_allele = nia & 0xFFFF, nia >> 16
+        p = r + 24
+        _id, p = typed(p)
+        for _ in range(n_allele):
+            _a, p = typed(p)
+        filt, p = typed(p)
+        info = {}
+        for _ in range(n_info):
+            key, p = typed(p)
+            val, p = typed(p)
+            name = by_idx[key[0]]
+            if isinstance(val, (bytes, bytearray)):
+                info[name] = val.decode()
+            elif len(val) == 0:
+                info[name] = True
+            else:
+                info[name] = val[0] if len(val) == 1 else val
+        rows["chrom"].append(contigs[chrom])
+        rows["pos"].append(pos0 + 1 if pos0 >= 0 else None)
+        rows["qual"].append(None if qbits == 0x7F800001 else np.frombuffer(struct.pack("<I", qbits), np.float32)[0])
+        rows["filter"].append([by_idx[i] for i in filt])
+        rows["info"].append(info if n_info else None)
+        o += 8 + l_shared + l_indiv
+    rows.update(contigs=contigs, filters_header=filt_hdr, info_header=info_hdr)
+    return rows
 
 
 # ---- FASTQ / FASTA -----------------------------------------------------------------------------------

@@ -1,5 +1,6 @@
 """GPU-side BAM path: BGZF inflate -> record splitting (parallel chain walk with proven guesses) -> field extraction -> K3,
-against the native host decoder (pinned on the reference's slt values in tests/test_scan_decoders.py)."""
+against the ORACLE's decoder (oracle/decode.py: decode_bam restates the reference's builder) and, as a second opinion, the
+product's native host decoder."""
 import gzip
 import os
 import struct
@@ -9,6 +10,7 @@ import numpy as np
 import pytest
 
 import exon_amd
+from oracle_expect import bam_columns, k3_expected, k6_expected
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -58,10 +60,12 @@ def check(res, host, refs):
 def test_bam_parser_reference_fixture(ctx):
     path = os.path.join(FX, "bam", "test.bam")
     host, refs = host_columns(path)
+    orefs, orc = bam_columns(path)                           # the oracle's decoder: the parity reference
     data, n_ref = records_of(path)
     p = exon_amd.BAMParser(ctx, n_ref, max_slab_bytes=1 << 20)
     res = p.parse_host(data)
     assert res["consumed_bytes"] == len(data) and res["n_rows"] == 61
+    check(res, orc, orefs)
     check(res, host, refs)
     # first row of slt/bam-select-tests.slt:9-12: flag 83, chr1, 12203704..12217173, mapq NULL
     assert res["flag"][0] == 83 and res["start"][0] == 12203704 and res["end"][0] == 12217173 and not bits(res["mapq_valid"], 61)[0]
@@ -74,11 +78,13 @@ def test_bam_parser_many_segments_and_cut_off_record(ctx, tmp_path):
     bam = tmp_path / "syn.bam"
     subprocess.check_call([BGZIP, str(ub), str(bam), "6"])
     host, refs = host_columns(str(bam))
+    orefs, orc = bam_columns(str(bam))
     data, n_ref = records_of(str(bam))
     assert len(data) > 100 * 65536 // 2  # dozens of 64 KiB segments
     p = exon_amd.BAMParser(ctx, n_ref, max_slab_bytes=len(data) + 64)
     res = p.parse_host(data)
     assert res["consumed_bytes"] == len(data) and res["n_rows"] == 40000
+    check(res, orc, orefs)
     check(res, host, refs)
     # a slab that stops in the middle of a record: whole records only, the cut-off one is left to the caller
     cut = len(data) - 37
@@ -136,11 +142,25 @@ def test_bam_file_to_gpu_pipeline_equals_host_decode(ctx, tmp_path, monkeypatch,
     assert np.array_equal(gpu, host) and gpu.sum() > n // 4
 
 
-def test_bam_reference_fixture_through_the_gpu_pipeline(ctx):
+def test_bam_reference_fixture_through_the_gpu_pipeline(ctx, oracle):
     path = os.path.join(FX, "bam", "test.bam")
     rows_g, gpu = _k3_through_scan(ctx, path, True)
+    rows_o, want = k3_expected(oracle, path)                 # oracle decoder + oracle aggregate
     rows_h, host = _k3_through_scan(ctx, path, False)
-    assert rows_g == rows_h == 61 and np.array_equal(gpu, host)
+    assert rows_g == rows_o == rows_h == 61 and np.array_equal(gpu, want) and np.array_equal(gpu, host)
+
+
+def test_bam_file_to_gpu_pipeline_equals_the_oracle(ctx, oracle, tmp_path, monkeypatch):
+    n = 120_000
+    ub = tmp_path / "syn.ubam"
+    subprocess.check_call([GEN, "bam", str(n), str(ub), "100"])
+    bam = tmp_path / "syn.bam"
+    subprocess.check_call([BGZIP, str(ub), str(bam), "6"])
+    monkeypatch.setenv("EXON_HIP_GPU_PARSE_SLAB_MB", "1")
+    rows_g, gpu = _k3_through_scan(ctx, bam, True)
+    rows_o, want = k3_expected(oracle, bam)
+    assert rows_g == rows_o == n and np.array_equal(gpu, want) and gpu.sum() > n // 4
+    assert _k6_through_scan(ctx, bam, True, "chr7", 50_000_000, 100_000_000) == k6_expected(bam, "bam", "chr7", 50_000_000, 100_000_000)
 
 
 def _k6_through_scan(ctx, path, gpu_parse, region_ref, a, b):

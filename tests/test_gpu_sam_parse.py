@@ -1,5 +1,6 @@
 """GPU-side SAM text parsing (exon_hip_sam_parser_*): alignment lines -> the BAM device layout -> K3 / K6, against the
-native host SAM reader (same columns as BAM, exon-sam/src/schema_builder.rs:371-402)."""
+ORACLE (oracle/decode.py decode_sam + the oracle's aggregates) and, as a second opinion, the native host SAM reader (same
+columns as BAM, exon-sam/src/schema_builder.rs:371-402)."""
 import os
 import subprocess
 
@@ -7,6 +8,7 @@ import numpy as np
 import pytest
 
 import exon_amd
+from oracle_expect import k3_expected, k6_expected
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,10 +16,10 @@ FX = os.path.join(ROOT, "tests", "golden", "ref_fixtures")
 GEN = os.path.join(ROOT, "tools", "bin", "gen_text")
 
 
-def _k3(ctx, path, gpu_parse, fallback=False, compression=None, inflated=None):
+def _k3(ctx, path, gpu_parse, fallback=False, compression=None, inflated=None, qmin=30):
     scan = exon_amd.Scan(str(path), "sam", gpu_parse=gpu_parse, compression=compression)
     refs = scan.dictionary(2)
-    plan = ctx.plan_flag_mapq_group_count(1284, 0, 30, len(refs), columns=(0, 1, 2))
+    plan = ctx.plan_flag_mapq_group_count(1284, 0, qmin, len(refs), columns=(0, 1, 2))
     st = plan.open()
     rows = st.consume(scan)
     counts, _ = st.finish()
@@ -38,12 +40,24 @@ def _k6(ctx, path, gpu_parse, ref, a, b):
     return rows, int(counts[0])
 
 
-def test_sam_reference_fixture(ctx):
+def test_sam_reference_fixture(ctx, oracle):
     path = os.path.join(FX, "sam", "test.sam")
-    g, h = _k3(ctx, path, True), _k3(ctx, path, False)
-    assert g[0] == h[0] > 0 and np.array_equal(g[1], h[1])
+    g, h = _k3(ctx, path, True, qmin=0), _k3(ctx, path, False, qmin=0)
+    rows_o, want = k3_expected(oracle, path, "sam", qmin=0)
+    assert g[0] == rows_o == h[0] == 1 and np.array_equal(g[1], want) and np.array_equal(g[1], h[1]) and want.sum() == 1
     refs = exon_amd.Scan(path, "sam").dictionary(2)
-    assert _k6(ctx, path, True, refs[0], 1, None) == _k6(ctx, path, False, refs[0], 1, None)
+    assert _k6(ctx, path, True, refs[0], 1, None) == k6_expected(path, "sam", refs[0], 1, None) == _k6(ctx, path, False, refs[0], 1, None)
+
+
+def test_sam_file_to_gpu_pipeline_equals_the_oracle(ctx, oracle, tmp_path, monkeypatch):
+    n = 120_000
+    path = tmp_path / "syn.sam"
+    subprocess.check_call([GEN, "sam", str(n), str(path), "100"])
+    monkeypatch.setenv("EXON_HIP_GPU_PARSE_SLAB_MB", "1")
+    g = _k3(ctx, path, True)
+    rows_o, want = k3_expected(oracle, path, "sam")
+    assert g[0] == rows_o == n and np.array_equal(g[1], want) and want.sum() > n // 4
+    assert _k6(ctx, path, True, "chr7", 50_000_000, 100_000_000) == k6_expected(path, "sam", "chr7", 50_000_000, 100_000_000)
 
 
 @pytest.mark.parametrize("slab_mb", ["1", "64"])

@@ -1,5 +1,6 @@
-"""GPU-side VCF record parsing (exon_hip_vcf_parser_*) against the native CPU decoder and the oracle's decoder:
-bit-identical columns, same dictionaries (up to id permutation for FILTER, resolved through the names)."""
+"""GPU-side VCF record parsing (exon_hip_vcf_parser_*) against the ORACLE's decoder (oracle/decode.py, which restates the
+reference's builders) and, as a second opinion, the product's native CPU decoder: bit-identical columns, same dictionaries
+(up to id permutation for FILTER, resolved through the names)."""
 import os
 import subprocess
 
@@ -7,6 +8,7 @@ import numpy as np
 import pytest
 
 import exon_amd
+from oracle_expect import k4_expected, vcf_columns
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -56,9 +58,11 @@ def check(res, cpu, contigs, filters, info=False):
 
 def test_gpu_parse_reference_fixture(ctx):
     path = os.path.join(FX, "vcf", "index.vcf")
-    cpu = cpu_columns(path, "MQ0F")
-    p = exon_amd.VCFParser(ctx, cpu["contigs"], info_field="MQ0F")
+    orc = vcf_columns(path, "vcf", "MQ0F")                     # the oracle's decoder: the parity reference
+    cpu = cpu_columns(path, "MQ0F")                            # the product's host decoder: second opinion
+    p = exon_amd.VCFParser(ctx, orc["contigs"], info_field="MQ0F")
     res = p.parse_host(data_lines(path))
+    check(res, orc, orc["contigs"], p.filters(), info=True)
     check(res, cpu, cpu["contigs"], p.filters(), info=True)
     assert res["n_rows"] == 621  # slt/vcf-select-tests.slt:47-50
     p.close()
@@ -72,8 +76,9 @@ def test_gpu_parse_synthetic_slabs_and_filter_dictionary(ctx, tmp_path, oracle):
     path = tmp_path / "syn.vcf"
     subprocess.check_call([gen, "vcf", str(n), str(path)])
     cpu = cpu_columns(path, "AF")
+    orc = vcf_columns(path, "vcf", "AF")
     text = data_lines(path)
-    p = exon_amd.VCFParser(ctx, cpu["contigs"], info_field="AF", max_slab_bytes=8 << 20)
+    p = exon_amd.VCFParser(ctx, orc["contigs"], info_field="AF", max_slab_bytes=8 << 20)
     # two slabs cut at a line boundary: the FILTER dictionary persists across slabs
     cut = text.rfind(b"\n", 0, len(text) // 2) + 1
     r1, r2 = p.parse_host(text[:cut]), p.parse_host(text[cut:])
@@ -85,6 +90,7 @@ def test_gpu_parse_synthetic_slabs_and_filter_dictionary(ctx, tmp_path, oracle):
     for k in ("pos_valid", "qual_valid", "info_valid"):
         res[k] = np.packbits(np.concatenate([bits(r1[k], n1), bits(r2[k], r2["n_rows"])]), bitorder="little")
     res["n_rows"], res["n_undecided"] = n1 + r2["n_rows"], r1["n_undecided"] + r2["n_undecided"]
+    check(res, orc, orc["contigs"], filters, info=True)
     check(res, cpu, cpu["contigs"], filters, info=True)
     # and the parsed AF column equals the generator's (text round trip through the GPU parser)
     af, av, q, qv, fid = oracle.gen_c4(4, 0, n)
@@ -127,9 +133,9 @@ def test_gpu_parse_undecidable_rows_are_counted(ctx):
     p.close()
 
 
-def _k4_through_scan(ctx, path, gpu_parse, info_field="AF", fallback=False):
+def _k4_through_scan(ctx, path, gpu_parse, info_field="AF", fallback=False, thr=0.01):
     scan = exon_amd.Scan(path, "vcf", info_field=info_field, gpu_parse=gpu_parse)
-    plan = ctx.plan_cmp_avg_by_group(">", 0.01, 64, columns=(4, 2, 3))
+    plan = ctx.plan_cmp_avg_by_group(">", thr, 64, columns=(4, 2, 3))
     st = plan.open()
     rows = st.consume(scan)
     counts, sums = st.finish()
@@ -140,6 +146,37 @@ def _k4_through_scan(ctx, path, gpu_parse, info_field="AF", fallback=False):
     assert scan.decoded_on_gpu()[0] == (bool(gpu_parse) and not fallback), 'silent host fallback'
     scan.close()
     return rows, res
+
+
+def _same(a, b, rel=1e-9):
+    assert a.keys() == b.keys()
+    for k in b:
+        assert a[k][:2] == b[k][:2], k                     # counts bit-exact
+        assert a[k][2] == pytest.approx(b[k][2], rel=rel), k
+
+
+@pytest.mark.parametrize("kind", ["text", "bgzf"])
+def test_file_to_gpu_pipeline_equals_the_oracle(ctx, oracle, tmp_path, monkeypatch, kind):
+    """file -> (GPU inflate) -> GPU parse -> K4 against oracle/decode.py + oracle/exon_oracle.c over the same file."""
+    gen = os.path.join(ROOT, "tools", "bin", "gen_text")
+    n = 250_000
+    path = tmp_path / "syn.vcf"
+    subprocess.check_call([gen, "vcf", str(n), str(path)])
+    rows_o, want = k4_expected(oracle, path, "vcf", "AF")
+    if kind == "bgzf":
+        gz = tmp_path / "syn.vcf.gz"
+        subprocess.check_call([os.path.join(ROOT, "tools", "bin", "bgzip"), str(path), str(gz), "6"])
+        path = gz
+    monkeypatch.setenv("EXON_HIP_GPU_PARSE_SLAB_MB", "4")
+    rows_g, gpu = _k4_through_scan(ctx, path, True)
+    assert rows_g == rows_o == n
+    _same(gpu, want)
+    # the reference fixture too (typed INFO field MQ0F, all FILTER lists empty)
+    fx = os.path.join(FX, "vcf", "index.vcf.gz" if kind == "bgzf" else "index.vcf")
+    rows_o, want = k4_expected(oracle, fx, "vcf", "MQ0F", thr=-1.0)
+    rows_g, gpu = _k4_through_scan(ctx, fx, True, info_field="MQ0F", thr=-1.0)
+    assert rows_g == rows_o == 621
+    _same(gpu, want)
 
 
 def test_file_to_gpu_parse_pipeline_equals_host_decode(ctx, tmp_path, monkeypatch):

@@ -230,6 +230,40 @@ def test_c4_against_pyarrow(oracle):
     assert not pc.greater(pc.cast(pa.array([np.float32(0.01)]), pa.float64()), pa.scalar(0.01)).to_pylist()[0]
 
 
+def _total_order_key_f64(x):
+    """IEEE 754 totalOrder as an integer sort key, computed with integer bit tricks only (no float compare): flip all bits
+    of negatives, only the sign bit of positives.  -NaN < -inf < ... < -0 < +0 < ... < +inf < +NaN."""
+    b = np.asarray(x, np.float64).view(np.uint64)
+    neg = (b >> np.uint64(63)).astype(bool)
+    return np.where(neg, ~b, b | np.uint64(1 << 63))
+
+
+@pytest.mark.parametrize("op", [">", ">=", "<", "<=", "=", "!="])
+@pytest.mark.parametrize("thr", [0.0, -0.0, 0.01, float("inf"), float("nan")])
+def test_c4_float_compare_is_total_order_checked_without_the_oracle(oracle, op, thr):
+    """arrow-rs' `cmp` kernels (what DataFusion 44's BinaryExpr runs for `CAST(af AS DOUBLE) <op> lit`) order floats by IEEE
+    totalOrder: NaN above +inf, -0 below +0, NaN = NaN.  pyarrow's compare is plain IEEE (NaN unordered), so it cannot check
+    this; the expectation here comes from integer sort keys built with numpy bit operations -- an implementation that shares
+    nothing with oracle/exon_oracle.c's f64 total_cmp."""
+    rng = np.random.default_rng(17)
+    n = 60_000
+    specials = np.array([np.nan, -np.nan, 0.0, -0.0, np.inf, -np.inf, 0.01, 1e-45, -1e-45, 3.4e38, 0.25, -7.5], np.float32)
+    af = specials[rng.integers(0, len(specials), n)]
+    q = (rng.integers(0, 1000, n) / 8).astype(np.float32)       # eighths: every partial sum is exact in f64
+    fid = rng.integers(0, 3, n).astype(np.int32)
+    avb, qvb = rng.random(n) < 0.9, rng.random(n) < 0.8
+    av = np.concatenate([np.packbits(avb, bitorder="little"), np.zeros(64, np.uint8)])
+    qv = np.concatenate([np.packbits(qvb, bitorder="little"), np.zeros(64, np.uint8)])
+    names = ["a", "b;c", ""]
+    s, cn, cr, _ = oracle.c4_cmp_avg_by_group(af, av, q, qv, fid, names, thr, op)
+    kx, kt = _total_order_key_f64(af.astype(np.float64)), _total_order_key_f64(np.float64(thr))
+    keep = {">": kx > kt, ">=": kx >= kt, "<": kx < kt, "<=": kx <= kt, "=": kx == kt, "!=": kx != kt}[op] & avb
+    for g in range(3):
+        m = keep & (fid == g)
+        assert cr[g] == int(m.sum()) and cn[g] == int((m & qvb).sum())
+        assert s[g] == float(q[m & qvb].astype(np.float64).sum())  # exact: eighths below 2^53
+
+
 def test_c3_against_numpy(oracle):
     n = 300_000
     f, mq, mv, ref, rv = oracle.gen_c3(3, 0, n)
