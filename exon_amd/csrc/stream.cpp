@@ -11,12 +11,18 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <time.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "host/arrow_build.h"
@@ -68,10 +74,99 @@ struct exon_hip_stream {
   int64_t cap_rows = 0, cap_bytes = 0;
   bool closed = false;
   int64_t rows_pushed = 0;
+  double t_copy = 0, t_wait = 0, t_enqueue = 0;  // EXON_HIP_STAGE_TRACE: staging copies / waits for a free slot / H2D + launch calls
   bool overwrite_next = false;  // exon_hip_stream_reset: the next launch DEFINES the state (no zeroing kernel)
   uint8_t* d_gather = nullptr;  // [world][state words] receive buffer of the all-gather merge
   size_t gather_bytes = 0;
 };
+
+// ---- staging copies on several cores -----------------------------------------------------------------------------------
+// One thread copies into pinned memory at ~10-12 GB/s, a fifth of what PCIe Gen5 takes; the staging copy of a large batch is
+// therefore cut into 1 MiB pieces for a small pool of helper threads (lazily started, shared by all streams of the process;
+// EXON_HIP_STAGE_THREADS overrides the count, 1 = the caller copies alone).  Small batches (the reference's 8192 rows =
+// ~100 KB) stay on the calling thread: handing them over would cost more than the copy.
+namespace {
+class CopyPool {
+ public:
+  static CopyPool& get() {
+    static CopyPool p;
+    return p;
+  }
+  void copy(void* dst, const void* src, size_t n) {
+    constexpr size_t PIECE = 1u << 20;
+    if (threads_.empty() || n < 4 * PIECE) {
+      memcpy(dst, src, n);
+      return;
+    }
+    std::atomic<size_t> left{0};
+    size_t pieces = 0;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      for (size_t o = 0; o < n; o += PIECE) {
+        jobs_.push_back(Job{static_cast<uint8_t*>(dst) + o, static_cast<const uint8_t*>(src) + o, std::min(PIECE, n - o), &left});
+        ++pieces;
+      }
+      left.store(pieces, std::memory_order_relaxed);
+    }
+    cv_.notify_all();
+    // the caller works too, then waits for the pieces the helpers took
+    for (;;) {
+      Job j;
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        if (jobs_.empty()) break;
+        j = jobs_.front();
+        jobs_.pop_front();
+      }
+      memcpy(j.dst, j.src, j.n);
+      j.left->fetch_sub(1, std::memory_order_acq_rel);
+    }
+    while (left.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+  }
+
+ private:
+  struct Job {
+    uint8_t* dst;
+    const uint8_t* src;
+    size_t n;
+    std::atomic<size_t>* left;
+  };
+  CopyPool() {
+    int t = 8;
+    if (const char* v = getenv("EXON_HIP_STAGE_THREADS")) t = atoi(v);
+    const int hc = (int)std::thread::hardware_concurrency();
+    if (hc > 0) t = std::min(t, std::max(1, hc / 2));
+    for (int i = 1; i < t; ++i) threads_.emplace_back([this] { run(); });
+  }
+  ~CopyPool() {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& th : threads_) th.join();
+  }
+  void run() {
+    for (;;) {
+      Job j;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return stop_ || !jobs_.empty(); });
+        if (stop_) return;
+        j = jobs_.front();
+        jobs_.pop_front();
+      }
+      memcpy(j.dst, j.src, j.n);
+      j.left->fetch_sub(1, std::memory_order_acq_rel);
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<Job> jobs_;
+  std::vector<std::thread> threads_;
+  bool stop_ = false;
+};
+}  // namespace
 
 // ---- bit utilities (Arrow LSB-first bitmaps) -------------------------------------------------------
 static void append_bits(uint8_t* dst, int64_t dst_off, const uint8_t* src, int64_t src_off, int64_t n) {
@@ -97,6 +192,12 @@ static void append_bits(uint8_t* dst, int64_t dst_off, const uint8_t* src, int64
   }
   for (int64_t i = 0; i < n; ++i)
     if ((src[(src_off + i) >> 3] >> ((src_off + i) & 7)) & 1) dst[(dst_off + i) >> 3] |= (uint8_t)(1u << ((dst_off + i) & 7));
+}
+
+static double now_s() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
 static void free_slot(Slot& s) {
@@ -181,6 +282,7 @@ static int flush_slot(exon_hip_stream* st) {
   Slot& s = st->slots[st->cur];
   if (s.rows == 0) return EXON_HIP_OK;
   exon_hip_plan* p = st->plan;
+  const double t_f0 = now_s();
   exon_hip_column cols[4];
   for (int c = 0; c < p->n_cols; ++c) {
     ColStage& cs = s.cols[(size_t)c];
@@ -203,6 +305,8 @@ static int flush_slot(exon_hip_stream* st) {
   if (rc) return rc;
   HIP_TRY(st->ctx, hipEventRecord(s.done, st->stream));
   s.in_flight = true;
+  const double t_f1 = now_s();
+  st->t_enqueue += t_f1 - t_f0;
   // switch to the other slot; wait until its previous contents have been consumed
   st->cur ^= 1;
   Slot& n = st->slots[st->cur];
@@ -210,6 +314,7 @@ static int flush_slot(exon_hip_stream* st) {
     HIP_TRY(st->ctx, hipEventSynchronize(n.done));
     n.in_flight = false;
   }
+  st->t_wait += now_s() - t_f1;
   n.rows = 0;
   n.bytes = 0;
   for (auto& cs : n.cols) {
@@ -393,6 +498,7 @@ int exon_hip_stream_push(exon_hip_stream* st, struct ArrowArray* batch) {
       rc = flush_slot(st);
     if (!rc) {
       Slot& s = st->slots[st->cur];
+      const double t_c0 = now_s();
       for (int c = 0; c < p->n_cols; ++c) {
         ColStage& cs = s.cols[(size_t)c];
         const uint8_t* valid = (const uint8_t*)ch[c]->buffers[0];
@@ -410,17 +516,18 @@ int exon_hip_stream_push(exon_hip_stream* st, struct ArrowArray* batch) {
           const int32_t* o = (const int32_t*)ch[c]->buffers[1] + off[c];
           const uint8_t* data = (const uint8_t*)ch[c]->buffers[2];
           const int32_t base = o[0], len = o[rows] - base;
-          if (len) memcpy(cs.h_values + s.bytes, data + base, (size_t)len);
+          if (len) CopyPool::get().copy(cs.h_values + s.bytes, data + base, (size_t)len);
           const int32_t shift = (int32_t)s.bytes - base;
           for (int64_t i = 1; i <= rows; ++i) cs.h_offsets[s.rows + i] = o[i] + shift;
         } else {
           const int e = p->cols[c].elem;
-          memcpy(cs.h_values + (size_t)s.rows * e, (const uint8_t*)ch[c]->buffers[1] + (size_t)off[c] * e, (size_t)rows * e);
+          CopyPool::get().copy(cs.h_values + (size_t)s.rows * e, (const uint8_t*)ch[c]->buffers[1] + (size_t)off[c] * e, (size_t)rows * e);
         }
       }
       s.rows += rows;
       s.bytes += need_bytes;
       st->rows_pushed += rows;
+      st->t_copy += now_s() - t_c0;
     }
   }
   batch->release(batch);  // moved: released exactly once, success or not
@@ -510,7 +617,7 @@ int exon_hip_stream_push_raw(exon_hip_stream* st, const exon::RawBatch& rb) {
       const exon::RawColumn& rc2 = rb.cols[(size_t)p->d.columns[c]];
       ColStage& cs = s.cols[(size_t)c];
       const int e = p->cols[c].elem;
-      memcpy(cs.h_values + (size_t)s.rows * e, static_cast<const uint8_t*>(rc2.values) + (size_t)done * e, (size_t)n * e);
+      CopyPool::get().copy(cs.h_values + (size_t)s.rows * e, static_cast<const uint8_t*>(rc2.values) + (size_t)done * e, (size_t)n * e);
       if (rc2.valid_bytes) {
         if (!cs.any_null_bitmap) {
           append_bits(cs.h_valid, 0, nullptr, 0, s.rows);
@@ -851,6 +958,9 @@ int exon_hip_stream_finish_arrow(exon_hip_stream* st, struct ArrowArray* out, st
 
 int exon_hip_stream_close(exon_hip_stream* st) {
   if (!st) return EXON_HIP_OK;
+  if (getenv("EXON_HIP_STAGE_TRACE"))
+    fprintf(stderr, "[exon-hip stage] %lld rows: staging copies %.1f ms, H2D + launch calls %.1f ms, waiting for a free slot %.1f ms\n",
+            (long long)st->rows_pushed, st->t_copy * 1e3, st->t_enqueue * 1e3, st->t_wait * 1e3);
   hipSetDevice(st->ctx->device);
   if (st->stream) hipStreamSynchronize(st->stream);
   for (auto& s : st->slots) free_slot(s);
