@@ -108,6 +108,7 @@ PLAN_FLAG_MAPQ_GROUP_COUNT = 3
 PLAN_CMP_AVG_BY_GROUP = 4
 PLAN_QUAL_POS_HIST = 5
 PLAN_OVERLAP_COUNT = 6
+PLAN_WITHIN_COUNT = 7
 LAUNCH_ACCUMULATE = 0
 LAUNCH_OVERWRITE = 1
 CMP = {">": 0, ">=": 1, "<": 2, "<=": 3, "=": 4, "==": 4, "!=": 5, "<>": 5}
@@ -134,6 +135,7 @@ SIGNATURES = {
     "exon_hip_timer_stop_ms": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "exon_hip_region_count": (C.c_int, [_vp, _vp, _colp, _colp, _i64, _i32, _i64, _i64, _vp]),
     "exon_hip_overlap_count": (C.c_int, [_vp, _vp, _colp, _colp, _colp, _i64, _i32, _i64, _i64, _vp]),
+    "exon_hip_within_count": (C.c_int, [_vp, _vp, _colp, _colp, _colp, _i64, _i32, _i64, _i64, _vp]),
     "exon_hip_flag_mapq_group_count": (C.c_int, [_vp, _vp, _colp, _colp, _colp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "exon_hip_cmp_avg_by_group": (C.c_int, [_vp, _vp, _colp, _colp, _colp, _i64, _dbl, _i32, _i32, _vp, _vp]),
     "exon_hip_qual_pos_hist": (C.c_int, [_vp, _vp, _colp, _i64, _i32, _vp]),

@@ -312,7 +312,7 @@ int exon_op_region_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column*
 
 int exon_op_overlap_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* ref_id, const exon_hip_column* start,
                           const exon_hip_column* end, int64_t n, int32_t region_ref_id, int64_t region_start,
-                          int64_t region_end, int64_t* d_count, int flags) {
+                          int64_t region_end, int64_t* d_count, int flags, bool strict) {
   if (!ctx || !d_count) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_overlap_count: NULL argument");
   if (n < 0) return fail(ctx, EXON_HIP_EINVAL, "n < 0");
   int rc;
@@ -325,7 +325,7 @@ int exon_op_overlap_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column
   if ((rc = get_workspace(ctx, s, exon::k2_partial_words(ctx->cfg), &ws))) return fail(ctx, rc, "workspace allocation failed");
   HIP_TRY(ctx, exon::launch_overlap_count(s, cfg_for(ctx, flags), ws, (const int32_t*)ref_id->values, ref_id->validity,
                                           (const int64_t*)start->values, start->validity, (const int64_t*)end->values,
-                                          end->validity, n, region_ref_id, region_start, region_end, d_count));
+                                          end->validity, n, region_ref_id, region_start, region_end, d_count, strict));
   return EXON_HIP_OK;
 }
 
@@ -359,8 +359,8 @@ int exon_op_cmp_avg_by_group(exon_hip_ctx* ctx, void* stream, const exon_hip_col
   if (n < 0) return fail(ctx, EXON_HIP_EINVAL, "n < 0");
   if (cmp_op < EXON_HIP_GT || cmp_op > EXON_HIP_NE) return fail(ctx, EXON_HIP_EINVAL, "bad cmp_op %d", cmp_op);
   if (n_groups < 1) return fail(ctx, EXON_HIP_EINVAL, "n_groups must be >= 1");
-  if (n_groups > EXON_HIP_MAX_GROUPS)
-    return fail(ctx, EXON_HIP_EUNSUPPORTED, "n_groups %d > %d", n_groups, EXON_HIP_MAX_GROUPS);
+  if (n_groups > EXON_HIP_MAX_GROUPS_GLOBAL)
+    return fail(ctx, EXON_HIP_EUNSUPPORTED, "n_groups %d > %d", n_groups, EXON_HIP_MAX_GROUPS_GLOBAL);
   if (group_id && group_id->validity)
     return fail(ctx, EXON_HIP_EUNSUPPORTED, "nullable group ids: encode NULL as its own dictionary id");
   int rc;
@@ -408,7 +408,13 @@ int exon_hip_overlap_count(exon_hip_ctx* ctx, void* stream, const exon_hip_colum
                            const exon_hip_column* end, int64_t n, int32_t region_ref_id, int64_t region_start,
                            int64_t region_end, int64_t* d_count) {
   return exon_op_overlap_count(ctx, stream, ref_id, start, end, n, region_ref_id, region_start, region_end, d_count,
-                               EXON_HIP_LAUNCH_ACCUMULATE);
+                               EXON_HIP_LAUNCH_ACCUMULATE, false);
+}
+int exon_hip_within_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* ref_id, const exon_hip_column* start,
+                          const exon_hip_column* end, int64_t n, int32_t region_ref_id, int64_t after, int64_t before,
+                          int64_t* d_count) {
+  return exon_op_overlap_count(ctx, stream, ref_id, start, end, n, region_ref_id, after, before, d_count, EXON_HIP_LAUNCH_ACCUMULATE,
+                               true);
 }
 int exon_hip_flag_mapq_group_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* flag,
                                    const exon_hip_column* mapq, const exon_hip_column* ref_id, int64_t n,

@@ -56,7 +56,7 @@ int exon_op_region_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column*
                          int64_t n, int32_t region_chrom_id, int64_t start, int64_t end, int64_t* d_count, int flags);
 int exon_op_overlap_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* ref_id, const exon_hip_column* start,
                           const exon_hip_column* end, int64_t n, int32_t region_ref_id, int64_t region_start,
-                          int64_t region_end, int64_t* d_count, int flags);
+                          int64_t region_end, int64_t* d_count, int flags, bool strict);
 int exon_op_flag_mapq_group_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* flag,
                                   const exon_hip_column* mapq, const exon_hip_column* ref_id, int64_t n,
                                   int32_t flag_mask, int32_t flag_value, int32_t mapq_min, int32_t n_refs,

@@ -28,11 +28,12 @@ hipError_t launch_region_count(hipStream_t s, const LaunchCfg& cfg, const Worksp
                                const uint8_t* chrom_valid, const int64_t* pos, const uint8_t* pos_valid, int64_t n,
                                int32_t region_chrom, int64_t start, int64_t end, int64_t* d_count);
 
-// K6: COUNT(*) of rows whose [start, end] interval on reference `region_ref` overlaps [region_start, region_end]
+// K6: COUNT(*) of rows whose [start, end] interval on reference `region_ref` overlaps [region_start, region_end];
+// strict: ... lies strictly inside (region_start, region_end) (start > a AND end < b: the BED / GFF form)
 hipError_t launch_overlap_count(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* ref,
                                 const uint8_t* ref_valid, const int64_t* start, const uint8_t* start_valid,
                                 const int64_t* end, const uint8_t* end_valid, int64_t n, int32_t region_ref,
-                                int64_t region_start, int64_t region_end, int64_t* d_count);
+                                int64_t region_start, int64_t region_end, int64_t* d_count, bool strict = false);
 
 hipError_t launch_flag_mapq_group_count(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* flag,
                                         const uint8_t* flag_valid, const uint8_t* mapq, const uint8_t* mapq_valid,

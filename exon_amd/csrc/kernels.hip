@@ -310,12 +310,17 @@ hipError_t launch_region_count(hipStream_t s, const LaunchCfg& cfg, const Worksp
 //   aln_start <= region_end AND region_start <= aln_end, false when reference / start / end is missing.
 //   20.375 B/row: i32 reference id + i64 start + i64 end + 3 validity bits.  Shape of K2.
 // ------------------------------------------------------------------------------------------------
+//   STRICT: the BED / GFF form `reference = lit AND start > a AND "end" < b` (StartEndIntervalPhysicalExpr evaluates its
+//   inner BinaryExprs: exon-core/src/physical_plan/start_end_interval_physical_expr.rs:93-139, 186-191): the row's interval
+//   lies strictly inside (a, b).  Same columns, same traffic.
+template <bool STRICT>
 __device__ __forceinline__ unsigned k6_row(int32_t r, int64_t s, int64_t e, unsigned rv, unsigned sv, unsigned ev, int32_t id,
                                            int64_t a, int64_t b) {
+  if (STRICT) return (rv & sv & ev) & unsigned(r == id) & unsigned(s > a) & unsigned(e < b);
   return (rv & sv & ev) & unsigned(r == id) & unsigned(s <= b) & unsigned(e >= a);
 }
 
-template <typename S>
+template <typename S, bool STRICT>
 __global__ __launch_bounds__(S::THREADS) void k6_overlap_count_main(const int32_t* __restrict__ ref,
                                                                     const uint8_t* __restrict__ rvalid,
                                                                     const int64_t* __restrict__ start,
@@ -349,15 +354,15 @@ __global__ __launch_bounds__(S::THREADS) void k6_overlap_count_main(const int32_
     }
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      cnt += k6_row(c[j].x, s0[j].x, e0[j].x, rm[j] >> 0 & 1, sm[j] >> 0 & 1, em[j] >> 0 & 1, id, a, b);
-      cnt += k6_row(c[j].y, s0[j].y, e0[j].y, rm[j] >> 1 & 1, sm[j] >> 1 & 1, em[j] >> 1 & 1, id, a, b);
-      cnt += k6_row(c[j].z, s1[j].x, e1[j].x, rm[j] >> 2 & 1, sm[j] >> 2 & 1, em[j] >> 2 & 1, id, a, b);
-      cnt += k6_row(c[j].w, s1[j].y, e1[j].y, rm[j] >> 3 & 1, sm[j] >> 3 & 1, em[j] >> 3 & 1, id, a, b);
+      cnt += k6_row<STRICT>(c[j].x, s0[j].x, e0[j].x, rm[j] >> 0 & 1, sm[j] >> 0 & 1, em[j] >> 0 & 1, id, a, b);
+      cnt += k6_row<STRICT>(c[j].y, s0[j].y, e0[j].y, rm[j] >> 1 & 1, sm[j] >> 1 & 1, em[j] >> 1 & 1, id, a, b);
+      cnt += k6_row<STRICT>(c[j].z, s1[j].x, e1[j].x, rm[j] >> 2 & 1, sm[j] >> 2 & 1, em[j] >> 2 & 1, id, a, b);
+      cnt += k6_row<STRICT>(c[j].w, s1[j].y, e1[j].y, rm[j] >> 3 & 1, sm[j] >> 3 & 1, em[j] >> 3 & 1, id, a, b);
     }
   }
   for (int64_t r = ntiles * TILE + (int64_t)blockIdx.x * THREADS + threadIdx.x; r < n;
        r += (int64_t)gridDim.x * THREADS)
-    cnt += k6_row(ref[r], start[r], end[r], valid1(rvalid, r), valid1(svalid, r), valid1(evalid, r), id, a, b);
+    cnt += k6_row<STRICT>(ref[r], start[r], end[r], valid1(rvalid, r), valid1(svalid, r), valid1(evalid, r), id, a, b);
 
   __shared__ unsigned long long red[WAVES];
   const unsigned long long w = wave_sum((unsigned long long)cnt);
@@ -371,14 +376,14 @@ __global__ __launch_bounds__(S::THREADS) void k6_overlap_count_main(const int32_
   }
 }
 
-template <typename S>
+template <typename S, bool STRICT>
 static hipError_t k6_launch(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* ref, const uint8_t* rv,
                             const int64_t* start, const uint8_t* sv, const int64_t* end, const uint8_t* ev, int64_t n,
                             int32_t id, int64_t a, int64_t b, int* grid_out) {
-  static const int resident = resident_blocks(k6_overlap_count_main<S>, S::THREADS, 0);
+  static const int resident = resident_blocks(k6_overlap_count_main<S, STRICT>, S::THREADS, 0);
   const int grid = grid_for<S>(cfg, n, resident);
   *grid_out = grid;
-  hipLaunchKernelGGL(k6_overlap_count_main<S>, dim3(grid), dim3(S::THREADS), 0, s, ref, rv, start, sv, end, ev, n, id, a, b,
+  hipLaunchKernelGGL((k6_overlap_count_main<S, STRICT>), dim3(grid), dim3(S::THREADS), 0, s, ref, rv, start, sv, end, ev, n, id, a, b,
                      ws.partials, reinterpret_cast<const uint8_t*>(ws.status + 8));
   return hipGetLastError();
 }
@@ -386,13 +391,16 @@ static hipError_t k6_launch(hipStream_t s, const LaunchCfg& cfg, const Workspace
 hipError_t launch_overlap_count(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* ref,
                                 const uint8_t* ref_valid, const int64_t* start, const uint8_t* start_valid,
                                 const int64_t* end, const uint8_t* end_valid, int64_t n, int32_t region_ref,
-                                int64_t region_start, int64_t region_end, int64_t* d_count) {
+                                int64_t region_start, int64_t region_end, int64_t* d_count, bool strict) {
   if (n <= 0) return hipSuccess;
   int grid = 1;
-  hipError_t e = use_big_shape(cfg, n) ? k6_launch<ShapeBigJ2>(s, cfg, ws, ref, ref_valid, start, start_valid, end, end_valid, n,
-                                                               region_ref, region_start, region_end, &grid)
-                                       : k6_launch<ShapeSmall>(s, cfg, ws, ref, ref_valid, start, start_valid, end, end_valid, n,
-                                                               region_ref, region_start, region_end, &grid);
+  const bool big = use_big_shape(cfg, n);
+  hipError_t e;
+#define EXON_K6(SHAPE, STRICT) \
+  k6_launch<SHAPE, STRICT>(s, cfg, ws, ref, ref_valid, start, start_valid, end, end_valid, n, region_ref, region_start, region_end, &grid)
+  if (strict) e = big ? EXON_K6(ShapeBigJ2, true) : EXON_K6(ShapeSmall, true);
+  else e = big ? EXON_K6(ShapeBigJ2, false) : EXON_K6(ShapeSmall, false);
+#undef EXON_K6
   if (e != hipSuccess) return e;
   return run_finalize(s, cfg, ws, grid, 1, 1, d_count, nullptr);
 }
@@ -771,7 +779,10 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
   }
 }
 
-size_t k4_partial_words(const LaunchCfg& cfg, int n_groups) { return (size_t)max_grid(cfg) * 3 * (size_t)n_groups; }
+size_t k4_partial_words(const LaunchCfg& cfg, int n_groups) {
+  if (n_groups > 4096) return 16;  // the global-atomic path writes the caller's state directly
+  return (size_t)max_grid(cfg) * 3 * (size_t)n_groups;
+}
 
 template <int G, typename S, bool OVF>
 static hipError_t k4_launch(hipStream_t s, const LaunchCfg& cfg, int* grid_out, const Workspace& ws, const float* x,
@@ -839,12 +850,55 @@ bool cmp_to_key_range(double thr, int cmp_op, int32_t* klo, int32_t* khi, int32_
   return true;
 }
 
+// More groups than the LDS overflow table holds (EXON_HIP_MAX_GROUPS < G <= EXON_HIP_MAX_GROUPS_GLOBAL: a GROUP BY over a
+// high-cardinality dictionary, e.g. a string INFO field): the caller's state arrays ARE the table -- dictionary ids are dense,
+// so there is nothing to hash -- and every passing row adds to them with global atomics (u64 counters, global_atomic_add_f64
+// sums).  Keys spread over many addresses, so the atomics do not serialise the way a handful of hot groups would; counts
+// stay exact, the f64 sums depend on the atomic order (~1e-16 relative run to run, inside the 1e-6 budget).  Several times
+// slower than the register / LDS paths and taken only above 4096 groups.
+__global__ __launch_bounds__(256) void k4_cmp_avg_by_group_global(const float* __restrict__ x, const uint8_t* __restrict__ xvalid,
+                                                                  const float* __restrict__ y, const uint8_t* __restrict__ yvalid,
+                                                                  const int32_t* __restrict__ gid, int64_t n, int32_t klo, int32_t khi,
+                                                                  int32_t negate, int32_t NG, unsigned long long* __restrict__ counts,
+                                                                  double* __restrict__ sums, int* __restrict__ status) {
+  bool bad = false;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
+    const unsigned g = (unsigned)gid[r];
+    if (g >= (unsigned)NG) {  // ids are validated over ALL rows, like the LDS paths do
+      bad = true;
+      continue;
+    }
+    const int32_t kx = f32_key(x[r]);
+    const unsigned inr = unsigned(kx >= klo) & unsigned(kx <= khi);
+    if (!(valid1(xvalid, r) && (inr ^ (unsigned)negate))) continue;
+    atomicAdd(&counts[NG + g], 1ull);
+    if (valid1(yvalid, r)) {
+      atomicAdd(&counts[g], 1ull);
+      atomicAdd(&sums[g], (double)y[r]);
+    }
+  }
+  if (bad) atomicOr(&status[0], 4);
+}
+
 hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const float* x,
                                    const uint8_t* x_valid, const float* y, const uint8_t* y_valid, const int32_t* gid,
                                    int64_t n, double thr, int cmp_op, int n_groups, int64_t* d_counts,
                                    double* d_sums) {
   if (n <= 0) return hipSuccess;
-  if (n_groups < 1 || n_groups > 4096) return hipErrorInvalidValue;
+  if (n_groups < 1) return hipErrorInvalidValue;
+  if (n_groups > 4096) {
+    int32_t klo, khi, negate;
+    if (!cmp_to_key_range(thr, cmp_op, &klo, &khi, &negate)) return hipErrorInvalidValue;
+    if (cfg.overwrite) {  // this path adds straight into the caller's arrays
+      hipError_t e0 = hipMemsetAsync(d_counts, 0, (size_t)n_groups * 16, s);
+      if (e0 == hipSuccess) e0 = hipMemsetAsync(d_sums, 0, (size_t)n_groups * 8, s);
+      if (e0 != hipSuccess) return e0;
+    }
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)cfg.compute_units * 32);
+    hipLaunchKernelGGL(k4_cmp_avg_by_group_global, dim3(grid), dim3(256), 0, s, x, x_valid, y, y_valid, gid, n, klo, khi, negate, n_groups,
+                       reinterpret_cast<unsigned long long*>(d_counts), d_sums, ws.status);
+    return hipGetLastError();
+  }
   int32_t klo, khi, negate;
   if (!cmp_to_key_range(thr, cmp_op, &klo, &khi, &negate)) return hipErrorInvalidValue;
   const bool big = use_big_shape(cfg, n);

@@ -259,8 +259,9 @@ static int run_plan(const exon_hip_plan* p, void* stream, const exon_hip_column*
     case EXON_HIP_PLAN_QUAL_POS_HIST:
       return exon_op_qual_pos_hist(ctx, stream, &cols[0], n, d.lmax, counts, flags);
     case EXON_HIP_PLAN_OVERLAP_COUNT:
+    case EXON_HIP_PLAN_WITHIN_COUNT:
       return exon_op_overlap_count(ctx, stream, &cols[0], &cols[1], &cols[2], n, d.region_chrom_id, d.region_start,
-                                   d.region_end, counts, flags);
+                                   d.region_end, counts, flags, d.kind == EXON_HIP_PLAN_WITHIN_COUNT);
   }
   return fail(ctx, EXON_HIP_EINVAL, "unknown plan kind %d", d.kind);
 }
@@ -380,9 +381,9 @@ int exon_hip_plan_create(exon_hip_ctx* ctx, const exon_hip_plan_desc* desc, exon
     case EXON_HIP_PLAN_CMP_AVG_BY_GROUP:
       p->n_cols = 3;
       p->cols[0].elem = p->cols[1].elem = p->cols[2].elem = 4;
-      if (desc->n_groups < 1 || desc->n_groups > EXON_HIP_MAX_GROUPS) {
+      if (desc->n_groups < 1 || desc->n_groups > EXON_HIP_MAX_GROUPS_GLOBAL) {
         delete p;
-        return fail(ctx, EXON_HIP_EUNSUPPORTED, "n_groups %d outside [1, %d]", desc->n_groups, EXON_HIP_MAX_GROUPS);
+        return fail(ctx, EXON_HIP_EUNSUPPORTED, "n_groups %d outside [1, %d]", desc->n_groups, EXON_HIP_MAX_GROUPS_GLOBAL);
       }
       if (desc->cmp_op < EXON_HIP_GT || desc->cmp_op > EXON_HIP_NE) {
         delete p;
@@ -400,6 +401,12 @@ int exon_hip_plan_create(exon_hip_ctx* ctx, const exon_hip_plan_desc* desc, exon
         delete p;
         return fail(ctx, EXON_HIP_EINVAL, "region interval must satisfy 1 <= start <= end");
       }
+      break;
+    case EXON_HIP_PLAN_WITHIN_COUNT:  // start > region_start AND end < region_end: any pair of bounds is a valid predicate
+      p->n_cols = 3;
+      p->cols[0].elem = 4;
+      p->cols[1].elem = p->cols[2].elem = 8;
+      p->n_i64 = 1;
       break;
     case EXON_HIP_PLAN_QUAL_POS_HIST:
       p->n_cols = 1;
@@ -897,6 +904,7 @@ int exon_hip_stream_finish_arrow(exon_hip_stream* st, struct ArrowArray* out, st
   const exon_hip_plan_desc& d = p->d;
   switch (d.kind) {
     case EXON_HIP_PLAN_OVERLAP_COUNT:
+    case EXON_HIP_PLAN_WITHIN_COUNT:
     case EXON_HIP_PLAN_REGION_COUNT: {
       make_struct(out, 1, {prim(counts)});
       make_schema(out_schema, "+s", "", false, {field("l", "count(*)[count]", false)});

@@ -141,6 +141,13 @@ class Context:
         self._check(self.lib.exon_hip_overlap_count(self.h, stream, C.byref(c0), C.byref(c1), C.byref(c2), n, region_ref_id,
                                                     region_start, end_v, d_count.ptr))
 
+    def within_count(self, ref_id, ref_valid, start, start_valid, end, end_valid, n, region_ref_id, after, before, d_count,
+                     stream=None):
+        """K6 strict form: rows with start > after AND end < before on reference `region_ref_id` (BED / GFF predicate)."""
+        c0, c1, c2 = _col(ref_id, ref_valid, None, n), _col(start, start_valid, None, n), _col(end, end_valid, None, n)
+        self._check(self.lib.exon_hip_within_count(self.h, stream, C.byref(c0), C.byref(c1), C.byref(c2), n, region_ref_id,
+                                                   after, L.REGION_OPEN_END if before is None else before, d_count.ptr))
+
     def qual_pos_hist(self, offsets, data, n_reads, lmax, d_hist, stream=None):
         c0 = _col(data, None, offsets, n_reads)
         self._check(self.lib.exon_hip_qual_pos_hist(self.h, stream, C.byref(c0), n_reads, lmax, d_hist.ptr))
@@ -215,6 +222,12 @@ class Context:
         """COUNT(*) of BAM-layout rows overlapping a region (scan columns 2 reference, 3 start, 4 end)."""
         d = L.PlanDesc(kind=L.PLAN_OVERLAP_COUNT, region_chrom_id=region_ref_id, region_start=start,
                        region_end=L.REGION_OPEN_END if end is None else end)
+        return Plan(self, d, columns)
+
+    def plan_within_count(self, region_ref_id, after=0, before=None, columns=(2, 3, 4)):
+        """COUNT(*) of rows with reference = id AND start > after AND end < before (StartEndIntervalPhysicalExpr)."""
+        d = L.PlanDesc(kind=L.PLAN_WITHIN_COUNT, region_chrom_id=region_ref_id, region_start=after,
+                       region_end=L.REGION_OPEN_END if before is None else before)
         return Plan(self, d, columns)
 
     def plan_flag_mapq_group_count(self, flag_mask, flag_value, mapq_min, n_refs, columns=(0, 1, 2)):

@@ -150,6 +150,7 @@ typedef struct exon_hip_column {
 
 #define EXON_HIP_MAX_REG_GROUPS 8   /* group ids kept in registers; ids 8.. use an LDS overflow table */
 #define EXON_HIP_MAX_GROUPS 4096    /* group tables kept in LDS */
+#define EXON_HIP_MAX_GROUPS_GLOBAL (1 << 24) /* K4: beyond EXON_HIP_MAX_GROUPS the state arrays are updated with global atomics */
 #define EXON_HIP_MAX_REFERENCES (1 << 24) /* K3: beyond EXON_HIP_MAX_GROUPS references the counters are global atomics */
 #define EXON_HIP_REGION_OPEN_END INT64_MAX
 
@@ -172,19 +173,25 @@ int exon_hip_flag_mapq_group_count(exon_hip_ctx* ctx, void* stream, const exon_h
 
 /* K6.  *d_count += |{ i : ref_id[i] = region_ref_id AND start[i] <= region_end AND end[i] >= region_start }|, all three
  *      valid (a missing reference / start / end never matches).  SemiLazyRecord::intersects
- *      (exon-bam/src/indexed_async_batch_stream.rs:66-87) = bam_region_filter.  1-based inclusive.  (The BED / GFF
- *      expression of exon-core/src/physical_plan/start_end_interval_physical_expr.rs:93-139 is a different predicate --
- *      strict `start > a` / `end < b` comparisons -- and is not covered.) */
+ *      (exon-bam/src/indexed_async_batch_stream.rs:66-87) = bam_region_filter.  1-based inclusive. */
 int exon_hip_overlap_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* ref_id /*i32*/,
                            const exon_hip_column* start /*i64*/, const exon_hip_column* end /*i64*/, int64_t n,
                            int32_t region_ref_id, int64_t region_start, int64_t region_end, int64_t* d_count);
+/* K6, strict form: *d_count += |{ i : ref_id[i] = region_ref_id AND start[i] > after AND end[i] < before }|, all three valid.
+ *      The BED / GFF interval predicate: StartEndIntervalPhysicalExpr keeps `start > a` / `end < b` BinaryExprs and evaluates
+ *      them as written (exon-core/src/physical_plan/start_end_interval_physical_expr.rs:93-139, 186-191): strictly inside
+ *      (after, before).  `start > a` alone: before = INT64_MAX; `end < b` alone: after = 0 (its constructor's default). */
+int exon_hip_within_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* ref_id /*i32*/,
+                          const exon_hip_column* start /*i64*/, const exon_hip_column* end /*i64*/, int64_t n,
+                          int32_t region_ref_id, int64_t after, int64_t before, int64_t* d_count);
 
 /* K4.  For rows with x valid AND (double)x <cmp_op> threshold (f32 widened to f64, as DataFusion
  *      coerces Float32 vs a Float64 literal), per dictionary id g = group_id[i] in [0, n_groups):
  *        d_counts[g]            += (y valid)            -- COUNT(y) / AVG denominator
  *        d_counts[n_groups + g] += 1                    -- COUNT(*)
  *        d_sums[g]              += (double)y if y valid -- AVG numerator
- *      Sums are reduced in a fixed order: bit-reproducible run to run for a given launch shape. */
+ *      Sums are reduced in a fixed order: bit-reproducible run to run for a given launch shape (up to EXON_HIP_MAX_GROUPS
+ *      groups; beyond that, up to EXON_HIP_MAX_GROUPS_GLOBAL, global atomics: exact counts, sums in atomic order). */
 int exon_hip_cmp_avg_by_group(exon_hip_ctx* ctx, void* stream, const exon_hip_column* x /*f32*/,
                               const exon_hip_column* y /*f32*/, const exon_hip_column* group_id /*i32*/,
                               int64_t n, double threshold, int32_t cmp_op, int32_t n_groups,
@@ -229,6 +236,7 @@ int exon_hip_regroup_files_by_size(const int64_t* sizes, int32_t n_files, int32_
 #define EXON_HIP_PLAN_CMP_AVG_BY_GROUP 4
 #define EXON_HIP_PLAN_QUAL_POS_HIST 5
 #define EXON_HIP_PLAN_OVERLAP_COUNT 6 /* region_chrom_id / region_start / region_end; columns: ref_id, start, end */
+#define EXON_HIP_PLAN_WITHIN_COUNT 7  /* same fields, strict form: start > region_start AND end < region_end */
 
 typedef struct exon_hip_plan_desc {
   int32_t kind;          /* EXON_HIP_PLAN_* */

@@ -175,6 +175,35 @@ class Oracle:
         hit = rv & sv & ev & (ref_str == name) & (np.asarray(start) <= hi) & (np.asarray(end) >= a)
         return int(hit.sum())
 
+    @staticmethod
+    def start_end_interval_from_expr(column, op, value):
+        """StartEndIntervalPhysicalExpr::try_from(BinaryExpr) (exon-core/src/physical_plan/start_end_interval_physical_expr.rs:
+        93-139): `start > v` -> (v, None); `end < v` -> (0, Some(v)); anything else is an error."""
+        if op == ">":
+            if column != "start":
+                raise ValueError("Failed to parse interval: left name is not start")
+            return int(value), None
+        if op == "<":
+            if column != "end":
+                raise ValueError("Failed to parse interval: left name is not end")
+            return 0, int(value)
+        raise ValueError("Failed to parse interval: operator is not > or <")
+
+    def c7_within_count(self, ref_id, ref_valid, start, start_valid, end, end_valid, ref_names, name, after=0, before=None):
+        """COUNT(*) WHERE reference = name AND start > after AND "end" < before: the BED / GFF predicate, evaluated as its
+        inner BinaryExprs are (same file :186-191), Kleene AND, keep TRUE.  Column-wise numpy (single-threaded)."""
+        n = len(ref_id)
+
+        def bits(bm):
+            return np.ones(n, bool) if bm is None else np.unpackbits(np.asarray(bm, np.uint8), bitorder="little")[:n].astype(bool)
+        if name not in ref_names:
+            return 0
+        keep = bits(ref_valid) & bits(start_valid) & bits(end_valid) & (np.asarray(ref_id) == list(ref_names).index(name))
+        keep &= np.asarray(start, np.int64) > after
+        if before is not None:
+            keep &= np.asarray(end, np.int64) < before
+        return int(keep.sum())
+
     def regroup_files_by_size(self, sizes, target):
         s = np.asarray(sizes, np.int64)
         g = np.zeros(len(s), np.int32)

@@ -20,6 +20,7 @@ pub const EXON_HIP_PLAN_FLAG_MAPQ_GROUP_COUNT: i32 = 3;
 pub const EXON_HIP_PLAN_CMP_AVG_BY_GROUP: i32 = 4;
 pub const EXON_HIP_PLAN_QUAL_POS_HIST: i32 = 5;
 pub const EXON_HIP_PLAN_OVERLAP_COUNT: i32 = 6;
+pub const EXON_HIP_PLAN_WITHIN_COUNT: i32 = 7;
 pub const EXON_HIP_GT: i32 = 0;
 pub const EXON_HIP_GE: i32 = 1;
 pub const EXON_HIP_LT: i32 = 2;

@@ -120,6 +120,41 @@ def test_k6_generated_alignments_match_the_oracle(ctx, oracle):
     assert d.to_host()[0] == want and want > 1000
 
 
+@pytest.mark.parametrize("n", [1, 2047, 300_000, 6_000_000])
+@pytest.mark.parametrize("after,before", [(50_000_000, 100_000_000), (0, 5_000_000), (240_000_000, None), (7, 7)])
+def test_k6_strict_within_count(ctx, oracle, n, after, before):
+    """BED / GFF form: reference = r AND start > a AND end < b (StartEndIntervalPhysicalExpr), strict comparisons, NULLs drop."""
+    ref, rv, st, en, pv = ctx.gen_c6(6, 0, n)
+    d = ctx.zeros(np.int64, 1)
+    ctx.within_count(ref, rv, st, pv, en, pv, n, 6, after, before, d)
+    ctx.sync()
+    href, hrv, hs, he, hpv = oracle.gen_c6(6, 0, n)
+    names = [oracle.c3_refs()[i] for i in range(25)]
+    assert d.to_host()[0] == oracle.c7_within_count(href, hrv, hs, hpv, he, hpv, names, names[6], after, before)
+
+
+def test_k6_strict_boundaries_and_plan(ctx, oracle):
+    """start == a and end == b are OUT in the strict form and IN in the overlap form; the plan layer runs the same kernel."""
+    ref = np.zeros(6, np.int32)
+    st = np.array([10, 11, 10, 11, 5, 30], np.int64)
+    en = np.array([20, 19, 19, 20, 9, 40], np.int64)
+    d_ref, d_st, d_en = ctx.to_device(ref), ctx.to_device(st), ctx.to_device(en)
+    d = ctx.zeros(np.int64, 1)
+    ctx.within_count(d_ref, None, d_st, None, d_en, None, 6, 0, 10, 20, d)
+    ctx.sync()
+    assert d.to_host()[0] == 1 == oracle.c7_within_count(ref, None, st, None, en, None, ["r"], "r", 10, 20)   # only (11, 19)
+    d2 = ctx.zeros(np.int64, 1)
+    ctx.overlap_count(d_ref, None, d_st, None, d_en, None, 6, 0, 10, 20, d2)
+    ctx.sync()
+    assert d2.to_host()[0] == 4
+    plan = ctx.plan_within_count(0, 10, 20, columns=(0, 1, 2))
+    state = ctx.to_device(np.full(1, 99, np.int64))
+    plan.launch([(d_ref, None, None), (d_st, None, None), (d_en, None, None)], 6, state, overwrite=True)
+    ctx.sync()
+    assert state.to_host()[0] == 1
+    plan.close()
+
+
 def test_k6_no_bitmaps_boundaries_and_accumulate(ctx, oracle):
     names = ["a", "b"]
     # intervals that touch the region ends exactly (1-based inclusive on both sides)
@@ -229,6 +264,41 @@ def test_k4_more_than_8_groups_uses_lds_overflow(ctx, oracle, G, n):
     got = dc.to_host()
     assert np.array_equal(got[:G], cn) and np.array_equal(got[G:], cr)
     assert np.allclose(ds.to_host(), s, rtol=RTOL, atol=0)
+
+
+@pytest.mark.parametrize("G,n", [(4097, 400_000), (100_000, 3_000_000), (1 << 20, 2_000_000)])
+def test_k4_beyond_4096_groups_uses_the_global_table(ctx, oracle, G, n):
+    """GROUP BY over a high-cardinality dictionary: the state arrays are the table, rows add with global atomics; counts
+    bit-exact, sums within the budget; overwrite mode must clear the arrays first."""
+    rng = np.random.default_rng(G)
+    af, av, q, qv, _ = oracle.gen_c4(4, 0, n)
+    fid = rng.integers(0, G, n).astype(np.int32)
+    fid[:5] = [0, G - 1, G // 2, 1, G - 2]
+    names = [f"f{i}" for i in range(G)] if G <= 8192 else None
+    d = [ctx.to_device(x) for x in (af, av, q, qv, fid)]
+    dc, ds = ctx.zeros(np.int64, 2 * G), ctx.zeros(np.float64, G)
+    ctx.cmp_avg_by_group(d[0], d[1], d[2], d[3], d[4], n, 0.01, ">", G, dc, ds)
+    ctx.sync()
+    if G <= 8192:
+        s, cn, cr, _ = oracle.c4_cmp_avg_by_group(af, av, q, qv, fid, names, 0.01, ">")
+    else:
+        # the oracle interns variable-width keys the way DataFusion does and is not built for 10^5+ groups of test data:
+        # the same arithmetic column-wise (no NaN in the generated AF, so the plain f64 compare is the totalOrder one)
+        avb, qvb = bits(av, n), bits(qv, n)
+        keep = avb & (af.astype(np.float64) > 0.01)
+        cr = np.bincount(fid[keep], minlength=G)
+        cn = np.bincount(fid[keep & qvb], minlength=G)
+        s = np.bincount(fid[keep & qvb], weights=q[keep & qvb].astype(np.float64), minlength=G)
+    got = dc.to_host()
+    assert np.array_equal(got[:G], cn) and np.array_equal(got[G:], cr)
+    assert np.allclose(ds.to_host(), s, rtol=RTOL, atol=0)
+    plan = ctx.plan_cmp_avg_by_group(">", 0.01, G)
+    state = ctx.to_device(np.full(3 * G, 0x0101010101010101, np.int64))
+    plan.launch([(d[0], d[1], None), (d[2], d[3], None), (d[4], None, None)], n, state, overwrite=True)
+    ctx.sync()
+    st = state.to_host()
+    assert np.array_equal(st[:G], cn) and np.array_equal(st[G:2 * G], cr) and np.allclose(st[2 * G:].view(np.float64), s, rtol=RTOL, atol=0)
+    plan.close()
 
 
 def test_k4_deterministic(ctx):

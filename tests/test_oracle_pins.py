@@ -54,6 +54,15 @@ def test_pos_interval_physical_expr_evaluate(oracle):
     assert [oracle.interval_match(p, "1-1") for p in (1, 2, 3)] == [True, False, False]
 
 
+def test_start_end_interval_expr_construction(oracle):
+    """src/physical_plan/start_end_interval_physical_expr.rs:222-268 (test_from_start_expr / test_from_end_expr)."""
+    assert oracle.start_end_interval_from_expr("start", ">", 4) == (4, None)
+    assert oracle.start_end_interval_from_expr("end", "<", 4) == (0, 4)
+    for col, op in (("start", "<"), ("end", ">"), ("pos", ">"), ("start", ">=")):
+        with pytest.raises(ValueError):
+            oracle.start_end_interval_from_expr(col, op, 4)
+
+
 def test_region_grammar(oracle):
     """datasources/vcf/table_provider.rs:583-587 region strings; region_physical_expr.rs:91-104 defaults."""
     assert oracle.parse_region("1") == ("1", 1, None)
