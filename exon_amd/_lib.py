@@ -92,7 +92,8 @@ class FASTQViews(C.Structure):
 class VCFColumns(C.Structure):
     _fields_ = [("n_rows", C.c_int64), ("n_undecided", C.c_int64), ("chrom_id", C.c_void_p), ("pos", C.c_void_p),
                 ("pos_valid", C.c_void_p), ("qual", C.c_void_p), ("qual_valid", C.c_void_p), ("filter_id", C.c_void_p),
-                ("info", C.c_void_p), ("info_valid", C.c_void_p), ("consumed_bytes", C.c_int64)]
+                ("info", C.c_void_p), ("info_valid", C.c_void_p), ("consumed_bytes", C.c_int64),
+                ("n_info", C.c_int32), ("reserved", C.c_int32), ("infos", C.c_void_p * 4), ("infos_valid", C.c_void_p * 4)]
 
 
 class ScanOptions(C.Structure):
@@ -193,6 +194,7 @@ SIGNATURES = {
     "exon_hip_sam_parser_parse": (C.c_int, [_vp, _vp, _vp, _i64, C.POINTER(BAMColumns)]),
     "exon_hip_sam_parser_destroy": (C.c_int, [_vp]),
     "exon_hip_bcf_parser_create": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i64, C.POINTER(_vp)]),
+    "exon_hip_bcf_parser_set_info_keys": (C.c_int, [_vp, C.POINTER(_i32), C.c_char_p, _i32]),
     "exon_hip_bcf_parser_parse": (C.c_int, [_vp, _vp, _vp, _i64, C.POINTER(VCFColumns)]),
     "exon_hip_bcf_parser_filters": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), _i32, C.POINTER(_i32)]),
     "exon_hip_bcf_parser_destroy": (C.c_int, [_vp]),

@@ -68,9 +68,14 @@ struct BcfOut {
   float* qual;
   uint32_t* qual_valid;
   int32_t* filter_id;
-  float* info;
-  uint32_t* info_valid;
+  float* info[4];          // typed INFO fields, in the order of exon_hip_bcf_parser_set_info_keys
+  uint32_t* info_valid[4];
   uint32_t* pos_valid;  // POS 0 (BCF pos0 = -1, the telomere) is NULL like in the VCF path
+};
+struct BcfInfoKeys {  // header-string indexes of the INFO fields to extract; kind 'f' numeric -> f32, 'b' Flag -> presence
+  int n;
+  int32_t key[4];
+  char kind[4];
 };
 
 __device__ __forceinline__ int type_size(int t) { return t == 1 ? 1 : t == 2 ? 2 : t == 3 ? 4 : t == 5 ? 4 : t == 7 ? 1 : 0; }
@@ -111,7 +116,7 @@ struct Cursor {
 
 __global__ __launch_bounds__(256) void k_bcf_extract(const uint8_t* __restrict__ d, const SegInfo* __restrict__ seg,
                                                      const uint32_t* __restrict__ base, const uint32_t* __restrict__ rec_off, BcfOut out,
-                                                     FilterLists f, int32_t n_contigs, int32_t n_strings, int32_t info_key,
+                                                     FilterLists f, int32_t n_contigs, int32_t n_strings, BcfInfoKeys ik,
                                                      unsigned* __restrict__ scalars) {
   const uint32_t s = blockIdx.x;
   if (scalars[1] != 0) return;  // the segmentation was not proven: nothing here can be trusted
@@ -138,9 +143,9 @@ __global__ __launch_bounds__(256) void k_bcf_extract(const uint8_t* __restrict__
       list[i] = (int32_t)v;
       h = (h ^ (unsigned long long)(v + 1)) * 0x100000001B3ULL;
     }
-    // INFO: (typed key, typed value) pairs
-    bool have = false;
-    float iv = 0.f;
+    // INFO: (typed key, typed value) pairs; the first occurrence of a key wins
+    bool have[4] = {false, false, false, false};
+    float iv[4] = {0.f, 0.f, 0.f, 0.f};
     for (int q = 0; q < n_info && !c.bad && !undecided; ++q) {
       int kt, kc;
       c.typed_header(&kt, &kc);
@@ -148,25 +153,32 @@ __global__ __launch_bounds__(256) void k_bcf_extract(const uint8_t* __restrict__
       int vt, vc;
       c.typed_header(&vt, &vc);
       if (c.bad) break;
-      if (key == info_key && info_key >= 0 && vc >= 1) {
-        if (vt == 5) {
-          if (c.o + 4 > c.end) { c.bad = true; break; }
-          const uint32_t b = ld32(d + c.o);
-          if (b != 0x7F800001u && b != 0x7F800002u) {
-            iv = __uint_as_float(b);
-            have = true;
-          }
-        } else if (vt >= 1 && vt <= 3) {
-          Cursor t = c;
-          const int64_t v = t.read_int(vt);
-          if (t.bad) { c.bad = true; break; }
-          const int64_t missing = vt == 1 ? -128 : vt == 2 ? -32768 : (int64_t)INT32_MIN;
-          if (v != missing) {
-            iv = (float)v;
-            have = true;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        if (w >= ik.n || key != ik.key[w] || have[w]) continue;
+        if (ik.kind[w] == 'b') {
+          have[w] = true;  // a Flag is true by being there
+        } else if (vc >= 1) {
+          if (vt == 5) {
+            if (c.o + 4 > c.end) { c.bad = true; break; }
+            const uint32_t bb = ld32(d + c.o);
+            if (bb != 0x7F800001u && bb != 0x7F800002u) {
+              iv[w] = __uint_as_float(bb);
+              have[w] = true;
+            }
+          } else if (vt >= 1 && vt <= 3) {
+            Cursor t = c;
+            const int64_t v = t.read_int(vt);
+            if (t.bad) { c.bad = true; break; }
+            const int64_t missing = vt == 1 ? -128 : vt == 2 ? -32768 : (int64_t)INT32_MIN;
+            if (v != missing) {
+              iv[w] = (float)v;
+              have[w] = true;
+            }
           }
         }
       }
+      if (c.bad) break;
       c.o += (uint32_t)vc * (uint32_t)type_size(vt);
       if (c.o > c.end) c.bad = true;
     }
@@ -197,11 +209,15 @@ __global__ __launch_bounds__(256) void k_bcf_extract(const uint8_t* __restrict__
     out.pos[row] = pos0 >= 0 ? (int64_t)pos0 + 1 : 0;
     out.qual[row] = qbits == 0x7F800001u ? 0.f : __uint_as_float(qbits);
     out.filter_id[row] = slot;
-    out.info[row] = have ? iv : 0.f;
     const uint32_t bit = 1u << (row & 31);
     if (qbits != 0x7F800001u) atomicOr(&out.qual_valid[row >> 5], bit);
     if (pos0 >= 0) atomicOr(&out.pos_valid[row >> 5], bit);
-    if (have) atomicOr(&out.info_valid[row >> 5], bit);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w >= ik.n) continue;
+      if (ik.kind[w] == 'f') out.info[w][row] = have[w] ? iv[w] : 0.f;
+      if (have[w]) atomicOr(&out.info_valid[w][row >> 5], bit);
+    }
   }
 }
 
@@ -222,6 +238,9 @@ __global__ __launch_bounds__(256) void k_bcf_remap(int32_t* __restrict__ filter_
 struct exon_hip_bcf_parser {
   exon_hip_ctx* ctx = nullptr;
   int32_t n_contigs = 0, n_strings = 0, n_samples = 0, info_key = -1;
+  BcfInfoKeys ik{};
+  void* ibufs[6] = {nullptr};  // value / validity buffers of INFO fields 1 .. 3 (field 0 lives in bufs[5] / bufs[6])
+  size_t words = 0;
   int64_t max_bytes = 0, max_rows = 0;
   uint32_t max_seg = 0;
   SegInfo* d_seg = nullptr;
@@ -283,16 +302,52 @@ int exon_hip_bcf_parser_create(exon_hip_ctx* ctx, int32_t n_contigs, int32_t n_s
     exon_hip_bcf_parser_destroy(p);
     return fail(ctx, EXON_HIP_ENOMEM, "bcf parser allocation: %s", msg.c_str());
   }
-  p->out = BcfOut{(int32_t*)p->bufs[0], (int64_t*)p->bufs[1], (float*)p->bufs[2], (uint32_t*)p->bufs[3],
-                  (int32_t*)p->bufs[4], (float*)p->bufs[5], (uint32_t*)p->bufs[6], (uint32_t*)p->bufs[7]};
+  p->out = BcfOut{};
+  p->out.chrom_id = (int32_t*)p->bufs[0];
+  p->out.pos = (int64_t*)p->bufs[1];
+  p->out.qual = (float*)p->bufs[2];
+  p->out.qual_valid = (uint32_t*)p->bufs[3];
+  p->out.filter_id = (int32_t*)p->bufs[4];
+  p->out.info[0] = (float*)p->bufs[5];
+  p->out.info_valid[0] = (uint32_t*)p->bufs[6];
+  p->out.pos_valid = (uint32_t*)p->bufs[7];
+  p->words = w;
+  if (info_key >= 0) {
+    p->ik.n = 1;
+    p->ik.key[0] = info_key;
+    p->ik.kind[0] = 'f';
+  }
   p->filters = FilterLists{(unsigned long long*)p->fbufs[0], (int32_t*)p->fbufs[1], (int32_t*)p->fbufs[2], (int32_t*)p->fbufs[3],
                            (int32_t*)p->fbufs[4]};
   *outp = p;
   return EXON_HIP_OK;
 }
 
+// Several typed INFO fields (InfosBuilder children): header-string indexes + kinds ('f' numeric -> f32, 'b' Flag).  Replaces
+// the single key given to _create; call before the first parse.
+int exon_hip_bcf_parser_set_info_keys(exon_hip_bcf_parser* p, const int32_t* keys, const char* kinds, int32_t n) {
+  if (!p || n < 0 || n > 4 || (n > 0 && (!keys || !kinds))) return fail(p ? p->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_bcf_parser_set_info_keys: bad argument");
+  p->ik = BcfInfoKeys{};
+  p->ik.n = n;
+  hipSetDevice(p->ctx->device);
+  for (int q = 0; q < n; ++q) {
+    if (kinds[q] != 'f' && kinds[q] != 'b') return fail(p->ctx, EXON_HIP_EUNSUPPORTED, "INFO kind '%c' is not decoded on the device", kinds[q]);
+    p->ik.key[q] = keys[q];
+    p->ik.kind[q] = kinds[q];
+    if (q == 0) continue;
+    if (!p->ibufs[2 * (q - 1)]) p->ibufs[2 * (q - 1)] = exon_pool_alloc(p->ctx, (size_t)p->max_rows * 4);
+    if (!p->ibufs[2 * (q - 1) + 1]) p->ibufs[2 * (q - 1) + 1] = exon_pool_alloc(p->ctx, p->words);
+    if (!p->ibufs[2 * (q - 1)] || !p->ibufs[2 * (q - 1) + 1]) return fail(p->ctx, EXON_HIP_ENOMEM, "INFO column buffers");
+    p->out.info[q] = (float*)p->ibufs[2 * (q - 1)];
+    p->out.info_valid[q] = (uint32_t*)p->ibufs[2 * (q - 1) + 1];
+  }
+  p->info_key = n ? keys[0] : -1;
+  return EXON_HIP_OK;
+}
+
 int exon_hip_bcf_parser_destroy(exon_hip_bcf_parser* p) {
   if (!p) return EXON_HIP_OK;
+  for (void* b : p->ibufs) exon_pool_free(p->ctx, b);
   for (void* b : p->bufs) exon_pool_free(p->ctx, b);
   for (void* b : p->fbufs) exon_pool_free(p->ctx, b);
   exon_pool_free(p->ctx, p->d_seg);
@@ -315,7 +370,7 @@ int exon_hip_bcf_parser_parse(exon_hip_bcf_parser* p, void* stream, const uint8_
   const size_t words = ((size_t)n / 32 + 1 + 31) / 32 * 4 + 4;
   HIP_TRY(ctx, hipMemsetAsync(p->d_scalars, 0, 16, s));
   HIP_TRY(ctx, hipMemsetAsync(p->out.qual_valid, 0, words, s));
-  HIP_TRY(ctx, hipMemsetAsync(p->out.info_valid, 0, words, s));
+  for (int q = 0; q < (p->ik.n ? p->ik.n : 1); ++q) HIP_TRY(ctx, hipMemsetAsync(p->out.info_valid[q], 0, words, s));
   HIP_TRY(ctx, hipMemsetAsync(p->out.pos_valid, 0, words, s));
   hipLaunchKernelGGL(chain::k_chain_walk<BcfFormat>, dim3(n_seg), dim3(64), 0, s, d_data, n, BcfFormat{p->n_contigs, p->n_samples}, p->d_seg,
                      p->d_rec_off);
@@ -325,7 +380,7 @@ int exon_hip_bcf_parser_parse(exon_hip_bcf_parser* p, void* stream, const uint8_
   (void)lds_ok;
   hipLaunchKernelGGL(chain::k_chain_check<0>, dim3(1), dim3(1024), (size_t)n_seg * 12, s, p->d_seg, n_seg, p->d_base, p->d_scalars);
   hipLaunchKernelGGL(k_bcf_extract, dim3(n_seg), dim3(256), 0, s, d_data, p->d_seg, p->d_base, p->d_rec_off, p->out, p->filters,
-                     p->n_contigs, p->n_strings, p->info_key, p->d_scalars);
+                     p->n_contigs, p->n_strings, p->ik, p->d_scalars);
   hipLaunchKernelGGL(k_bcf_assign, dim3(1), dim3(256), 0, s, p->filters);
   hipLaunchKernelGGL(k_bcf_remap, dim3(std::min<uint32_t>(n_seg * 4 + 1, 4096)), dim3(256), 0, s, p->out.filter_id, p->d_scalars, p->filters.ids);
   HIP_TRY(ctx, hipGetLastError());
@@ -340,8 +395,13 @@ int exon_hip_bcf_parser_parse(exon_hip_bcf_parser* p, void* stream, const uint8_
   cols->qual = p->out.qual;
   cols->qual_valid = (uint8_t*)p->out.qual_valid;
   cols->filter_id = p->out.filter_id;
-  cols->info = p->info_key >= 0 ? p->out.info : nullptr;
-  cols->info_valid = p->info_key >= 0 ? (uint8_t*)p->out.info_valid : nullptr;
+  cols->info = p->ik.n ? p->out.info[0] : nullptr;
+  cols->info_valid = p->ik.n ? (uint8_t*)p->out.info_valid[0] : nullptr;
+  cols->n_info = p->ik.n;
+  for (int q = 0; q < p->ik.n; ++q) {
+    cols->infos[q] = p->ik.kind[q] == 'f' ? p->out.info[q] : nullptr;
+    cols->infos_valid[q] = (uint8_t*)p->out.info_valid[q];
+  }
   return EXON_HIP_OK;
 }
 

@@ -173,6 +173,16 @@ struct FilterTable {
   int32_t* counters;  // [0] = number of dense ids, [1] = pool bytes used, [2] = overflow flag
 };
 
+constexpr int MAX_INFO = 4;
+// the typed INFO fields a parser extracts (InfosBuilder children: exon-vcf/src/array_builder/info_builder.rs:152-309):
+// kind 'f' = Number=1 Float / Integer -> f32 + validity; 'b' = Flag -> presence bitmap (value true where valid)
+struct InfoKeys {
+  int n;
+  int len[MAX_INFO];
+  int off[MAX_INFO];  // into `text`
+  char kind[MAX_INFO];
+  const uint8_t* text;
+};
 struct ParseOut {
   int32_t* chrom_id;
   int64_t* pos;
@@ -180,8 +190,8 @@ struct ParseOut {
   float* qual;
   uint8_t* qual_valid;
   int32_t* filter_id;
-  float* info;
-  uint8_t* info_valid;
+  float* info[MAX_INFO];
+  uint8_t* info_valid[MAX_INFO];
   unsigned* exceptions;  // [0] = count of rows the device could not decide
 };
 
@@ -195,8 +205,8 @@ __device__ __forceinline__ void store_valid(uint8_t* bm, int64_t row0_of_wave, i
 
 __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__ text, const unsigned* __restrict__ nl_pos,
                                                      const unsigned* __restrict__ n_lines_p, NameTable contigs,
-                                                     FilterTable filters, const uint8_t* __restrict__ info_key,
-                                                     int info_key_len, ParseOut out, unsigned cap, unsigned skip, unsigned n_total) {
+                                                     FilterTable filters, InfoKeys ik, ParseOut out, unsigned cap, unsigned skip,
+                                                     unsigned n_total) {
   const int64_t n_rows = min(*n_lines_p, cap);
   // an aligned 16-byte group of the slab; the last one is read byte by byte (nothing behind n_total is touched)
   auto group16 = [&](unsigned a) {
@@ -211,7 +221,8 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
   };
   const int64_t row = (int64_t)blockIdx.x * TPB + threadIdx.x;
   const int lane = threadIdx.x & 63;
-  bool pos_ok = false, qual_ok = false, info_ok = false, bad = false;
+  bool pos_ok = false, qual_ok = false, bad = false;
+  bool info_ok[MAX_INFO] = {false, false, false, false};
   if (row < n_rows) {
     const unsigned begin = row ? nl_pos[row - 1] + 1 : skip;
     unsigned end = nl_pos[row];
@@ -334,59 +345,69 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
         }
         out.filter_id[row] = found;  // provisional: slot index
       }
-      // INFO: `key=value` among ';'-separated entries
-      if (info_key_len > 0) {
-        float v = 0.f;
+      // INFO: `key=value` (or a bare Flag key) among ';'-separated entries; the first occurrence of a key wins
+      if (ik.n > 0) {
+        float v[MAX_INFO] = {0.f, 0.f, 0.f, 0.f};
+        bool seen[MAX_INFO] = {false, false, false, false};
+        int left = ik.n;
         const unsigned ib = fbeg(7), ie = fend(7);
-        if (!(ie - ib == 1 && text[ib] == '.')) {
-          // entries are separated by ';': find the separators 16 bytes per load, test the key at every entry start
+        if (!(ie - ib == 1 && text[ib] == '.')) {  // INFO '.': the whole struct is NULL
+          // entries are separated by ';': find the separators 16 bytes per load, test the keys at every entry start
           unsigned i = ib;  // start of the current entry
-          bool done = false;
-          auto entry = [&](unsigned j) {  // the entry [i, j): is it `key=value`?
-            if ((int)(j - i) > info_key_len && text[i + info_key_len] == '=') {
+          auto entry = [&](unsigned j) {  // the entry [i, j)
+            for (int q = 0; q < ik.n; ++q) {
+              const int kl = ik.len[q];
+              if (seen[q] || (int)(j - i) < kl) continue;
+              const bool valued = (int)(j - i) > kl && text[i + kl] == '=';
+              if (!valued && (int)(j - i) != kl) continue;
               bool same = true;
-              for (int k = 0; k < info_key_len && same; ++k) same = text[i + k] == info_key[k];
-              if (same) {
-                const unsigned vb = i + info_key_len + 1;
+              for (int k = 0; k < kl && same; ++k) same = text[i + k] == ik.text[ik.off[q] + k];
+              if (!same) continue;
+              seen[q] = true;
+              --left;
+              if (ik.kind[q] == 'b') {
+                info_ok[q] = true;  // a Flag is true by being there
+              } else if (valued) {
+                const unsigned vb = i + kl + 1;
                 const int vl = (int)(j - vb);
                 if (!(vl == 0 || (vl == 1 && text[vb] == '.'))) {
                   uint32_t bits;
                   if (exon::dec::parse_f32(reinterpret_cast<const char*>(text + vb), vl, &bits)) {
-                    v = __uint_as_float(bits);
-                    info_ok = true;
+                    v[q] = __uint_as_float(bits);
+                    info_ok[q] = true;
                   } else {
                     bad = true;
                   }
                 }
-                done = true;
               }
             }
             i = j + 1;
           };
-          for (unsigned a = ib & ~15u; a < ie && !done; a += 16) {
+          for (unsigned a = ib & ~15u; a < ie && left > 0; a += 16) {
             const uint4 q = group16(a);
             const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               const uint32_t x = w[k] ^ 0x3B3B3B3Bu;  // bytes equal to ';' become 0
               uint32_t m = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
-              while (m && !done) {
+              while (m && left > 0) {
                 const unsigned idx = a + 4u * (unsigned)k + ((unsigned)__ffs((int)m) - 1u) / 8u;
                 if (idx >= ib && idx < ie) entry(idx);
                 m &= m - 1;
               }
             }
           }
-          if (!done && i < ie) entry(ie);  // the last entry has no ';' behind it
+          if (left > 0 && i < ie) entry(ie);  // the last entry has no ';' behind it
         }
-        out.info[row] = v;
+        for (int q = 0; q < ik.n; ++q)
+          if (ik.kind[q] == 'f') out.info[q][row] = v[q];
       }
     }
   }
   const int64_t wave_row0 = row - lane;
   store_valid(out.pos_valid, wave_row0, n_rows, pos_ok, lane);
   store_valid(out.qual_valid, wave_row0, n_rows, qual_ok, lane);
-  if (info_key_len > 0) store_valid(out.info_valid, wave_row0, n_rows, info_ok, lane);
+  for (int q = 0; q < ik.n; ++q) store_valid(out.info_valid[q], wave_row0, n_rows, info_ok[q], lane);
   const unsigned long long nb = __ballot(bad);
   if (lane == 0 && nb) atomicAdd(out.exceptions, (unsigned)__popcll(nb));
 }
@@ -461,7 +482,8 @@ static hipError_t build_name_table(exon_hip_ctx* ctx, const char* const* names_i
 struct exon_hip_vcf_parser {
   exon_hip_ctx* ctx = nullptr;
   int64_t max_bytes = 0, max_rows = 0;
-  std::string info_field;
+  std::string info_field;  // "name[:kind],..." as given; kinds f (default) / b
+  InfoKeys ik{};
   // device state
   uint8_t* d_info_key = nullptr;
   unsigned *d_block_counts = nullptr, *d_nl = nullptr, *d_scalars = nullptr;  // scalars: [0] n_lines, [1] exceptions
@@ -469,7 +491,7 @@ struct exon_hip_vcf_parser {
   void* contig_bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   FilterTable filters{};
   ParseOut out{};
-  void* out_bufs[8] = {nullptr};
+  void* out_bufs[6 + 2 * MAX_INFO] = {nullptr};
   unsigned* h_scalars = nullptr;  // pinned mirror of d_scalars
 };
 
@@ -509,9 +531,38 @@ int exon_hip_vcf_parser_create(exon_hip_ctx* ctx, const char* const* contig_name
   dalloc((void**)&p->d_block_counts, (size_t)nblocks * 4);
   dalloc((void**)&p->d_nl, (size_t)p->max_rows * 4);
   dalloc((void**)&p->d_scalars, 16);
-  dalloc((void**)&p->d_info_key, p->info_field.size() + 16);
-  if (e == hipSuccess && !p->info_field.empty())
-    e = hipMemcpy(p->d_info_key, p->info_field.data(), p->info_field.size(), hipMemcpyHostToDevice);
+  // INFO keys: "AF,DP:f,DB:b" -> names back to back + (offset, length, kind) per key
+  std::string key_text;
+  {
+    size_t i = 0;
+    const std::string& f = p->info_field;
+    while (i < f.size()) {
+      size_t j = f.find(',', i);
+      if (j == std::string::npos) j = f.size();
+      std::string item = f.substr(i, j - i);
+      char kind = 'f';
+      const size_t c = item.rfind(':');
+      if (c != std::string::npos && c + 2 == item.size() && (item[c + 1] == 'f' || item[c + 1] == 'b')) {
+        kind = item[c + 1];
+        item.resize(c);
+      }
+      if (!item.empty()) {
+        if (p->ik.n == MAX_INFO) {
+          exon_hip_vcf_parser_destroy(p);
+          return fail(ctx, EXON_HIP_EUNSUPPORTED, "at most %d INFO fields per parser", MAX_INFO);
+        }
+        p->ik.off[p->ik.n] = (int)key_text.size();
+        p->ik.len[p->ik.n] = (int)item.size();
+        p->ik.kind[p->ik.n] = kind;
+        key_text += item;
+        ++p->ik.n;
+      }
+      i = j + 1;
+    }
+  }
+  dalloc((void**)&p->d_info_key, key_text.size() + 16);
+  if (e == hipSuccess && !key_text.empty()) e = hipMemcpy(p->d_info_key, key_text.data(), key_text.size(), hipMemcpyHostToDevice);
+  p->ik.text = p->d_info_key;
   const size_t r = (size_t)p->max_rows, rb = r / 8 + 64;
   dalloc(&p->out_bufs[0], r * 4);
   dalloc(&p->out_bufs[1], r * 8);
@@ -519,17 +570,28 @@ int exon_hip_vcf_parser_create(exon_hip_ctx* ctx, const char* const* contig_name
   dalloc(&p->out_bufs[3], r * 4);
   dalloc(&p->out_bufs[4], rb);
   dalloc(&p->out_bufs[5], r * 4);
-  dalloc(&p->out_bufs[6], r * 4);
-  dalloc(&p->out_bufs[7], rb);
+  for (int q = 0; q < p->ik.n; ++q) {
+    if (p->ik.kind[q] == 'f') dalloc(&p->out_bufs[6 + 2 * q], r * 4);
+    dalloc(&p->out_bufs[7 + 2 * q], rb);
+  }
   if (e == hipSuccess) e = hipHostMalloc((void**)&p->h_scalars, 16);
   if (e != hipSuccess) {
     const std::string msg = hipGetErrorString(e);
     exon_hip_vcf_parser_destroy(p);
     return fail(ctx, EXON_HIP_ENOMEM, "vcf parser allocation: %s", msg.c_str());
   }
-  p->out = ParseOut{(int32_t*)p->out_bufs[0], (int64_t*)p->out_bufs[1], (uint8_t*)p->out_bufs[2], (float*)p->out_bufs[3],
-                    (uint8_t*)p->out_bufs[4], (int32_t*)p->out_bufs[5], (float*)p->out_bufs[6], (uint8_t*)p->out_bufs[7],
-                    p->d_scalars + 1};
+  p->out = ParseOut{};
+  p->out.chrom_id = (int32_t*)p->out_bufs[0];
+  p->out.pos = (int64_t*)p->out_bufs[1];
+  p->out.pos_valid = (uint8_t*)p->out_bufs[2];
+  p->out.qual = (float*)p->out_bufs[3];
+  p->out.qual_valid = (uint8_t*)p->out_bufs[4];
+  p->out.filter_id = (int32_t*)p->out_bufs[5];
+  for (int q = 0; q < p->ik.n; ++q) {
+    p->out.info[q] = (float*)p->out_bufs[6 + 2 * q];
+    p->out.info_valid[q] = (uint8_t*)p->out_bufs[7 + 2 * q];
+  }
+  p->out.exceptions = p->d_scalars + 1;
   *outp = p;
   return EXON_HIP_OK;
 }
@@ -578,7 +640,7 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* p, void* stream, const uint8_
   const int64_t row_bound = std::min<int64_t>(p->max_rows, n_bytes / 16 + 1);
   const int pblocks = (int)((row_bound + TPB - 1) / TPB);
   hipLaunchKernelGGL(k_parse_lines, dim3(pblocks), dim3(TPB), 0, s, d_text, p->d_nl, p->d_scalars, p->contigs, p->filters,
-                     p->d_info_key, (int)p->info_field.size(), p->out, (unsigned)row_bound, skip, (unsigned)n_bytes);
+                     p->ik, p->out, (unsigned)row_bound, skip, (unsigned)n_bytes);
   hipLaunchKernelGGL(k_assign_filters, dim3(1), dim3(256), 0, s, d_text, p->filters);
   hipLaunchKernelGGL(k_remap_filters, dim3(std::min(pblocks, 4096)), dim3(TPB), 0, s, p->out.filter_id, p->d_scalars, p->filters.ids, (unsigned)row_bound);
   HIP_TRY(ctx, hipGetLastError());
@@ -595,8 +657,13 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* p, void* stream, const uint8_
   cols->qual = p->out.qual;
   cols->qual_valid = p->out.qual_valid;
   cols->filter_id = p->out.filter_id;
-  cols->info = p->info_field.empty() ? nullptr : p->out.info;
-  cols->info_valid = p->info_field.empty() ? nullptr : p->out.info_valid;
+  cols->info = p->ik.n ? p->out.info[0] : nullptr;
+  cols->info_valid = p->ik.n ? p->out.info_valid[0] : nullptr;
+  cols->n_info = p->ik.n;
+  for (int q = 0; q < p->ik.n; ++q) {
+    cols->infos[q] = p->out.info[q];  // NULL for a Flag: its column IS the presence bitmap
+    cols->infos_valid[q] = p->out.info_valid[q];
+  }
   return EXON_HIP_OK;
 }
 

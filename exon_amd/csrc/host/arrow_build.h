@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../../include/exon_hip.h"
@@ -116,6 +117,26 @@ inline void make_primitive(struct ArrowArray* a, const void* values, int64_t n, 
   a->private_data = o;
 }
 
+// Boolean column: values and validity are Arrow bitmaps (byte-per-row inputs)
+inline void make_boolean(struct ArrowArray* a, const std::vector<uint8_t>& values, const std::vector<uint8_t>& valid) {
+  OwnedArray* o = new OwnedArray();
+  const int64_t n = (int64_t)values.size();
+  int64_t nulls = 0;
+  void* vbits = pack_validity(valid, &nulls);
+  uint8_t* bits = static_cast<uint8_t*>(calloc((size_t)(n + 7) / 8 + 64, 1));
+  for (int64_t i = 0; i < n; ++i)
+    if (values[(size_t)i]) bits[i >> 3] |= (uint8_t)(1u << (i & 7));
+  o->bufs = {vbits, bits};
+  o->buf_ptrs = {vbits, bits};
+  memset(a, 0, sizeof *a);
+  a->length = n;
+  a->null_count = nulls;
+  a->n_buffers = 2;
+  a->buffers = o->buf_ptrs.data();
+  a->release = release_array;
+  a->private_data = o;
+}
+
 // Utf8 column
 inline void make_utf8(struct ArrowArray* a, const std::vector<int32_t>& offsets, const std::string& data,
                       const std::vector<uint8_t>& valid) {
@@ -216,11 +237,22 @@ struct Utf8Builder {
 struct Dictionary {
   std::vector<std::string> names;
   int32_t lookup_or_insert(const char* p, size_t n) {
-    for (size_t i = 0; i < names.size(); ++i)  // dictionaries on this path are tiny (contigs, FILTER combos)
-      if (names[i].size() == n && memcmp(names[i].data(), p, n) == 0) return (int32_t)i;
+    if (names.size() <= 32) {  // contigs, FILTER combos: a handful of short names, a scan beats hashing
+      for (size_t i = 0; i < names.size(); ++i)
+        if (names[i].size() == n && memcmp(names[i].data(), p, n) == 0) return (int32_t)i;
+    } else {  // string INFO values can be many: hash index over everything appended so far
+      if (index_.size() != names.size()) {
+        index_.clear();
+        for (size_t i = 0; i < names.size(); ++i) index_.emplace(names[i], (int32_t)i);
+      }
+      auto it = index_.find(std::string(p, n));
+      if (it != index_.end()) return it->second;
+      index_.emplace(std::string(p, n), (int32_t)names.size());
+    }
     names.emplace_back(p, n);
     return (int32_t)names.size() - 1;
   }
+  std::unordered_map<std::string, int32_t> index_;
   int32_t find(const std::string& s) const {
     for (size_t i = 0; i < names.size(); ++i)
       if (names[i] == s) return (int32_t)i;

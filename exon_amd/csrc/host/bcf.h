@@ -71,16 +71,16 @@ class BCFBatchReader {
       }
     }
     for (const auto& c : header.contigs) chrom_dict.names.push_back(c);
-    info_key_ = -1;
-    if (!cfg_.info_field.empty()) {
-      auto it = str_idx.find(cfg_.info_field);
-      bool ok = false;
-      for (const auto& kv : header.infos)
-        if (kv.first == cfg_.info_field) ok = (kv.second == "1|Float" || kv.second == "1|Integer");
-      if (it == str_idx.end()) throw std::runtime_error("INFO field " + cfg_.info_field + " is not declared in the header");
-      if (!ok) throw std::runtime_error("INFO field " + cfg_.info_field + " is not a Number=1 Float/Integer field");
-      info_key_ = it->second;
+    // typed INFO fields of the scan (same rules as the VCF reader: formats.h InfoSpec); keys are header-string indexes here
+    info_specs = resolve_info_specs(cfg_.info_field, header.infos);
+    info_dicts.assign(info_specs.size(), Dictionary());
+    info_keys_.clear();
+    for (const auto& sp : info_specs) {
+      auto it = str_idx.find(sp.name);
+      if (it == str_idx.end()) throw std::runtime_error("INFO field " + sp.name + " is not declared in the header");
+      info_keys_.push_back(it->second);
     }
+    info_key_ = info_keys_.empty() ? -1 : info_keys_[0];
     if (cfg_.filter.active) {
       region_chrom_ = -2;
       for (size_t i = 0; i < header.contigs.size(); ++i)
@@ -91,7 +91,10 @@ class BCFBatchReader {
   bool read_batch(struct ArrowArray* out) {
     PrimitiveBuilder<int32_t> chrom, filter;
     PrimitiveBuilder<int64_t> pos;
-    PrimitiveBuilder<float> qual, info;
+    PrimitiveBuilder<float> qual;
+    const size_t K = info_specs.size();
+    std::vector<PrimitiveBuilder<float>> info_f(K);
+    std::vector<PrimitiveBuilder<int32_t>> info_i(K);
     std::vector<uint8_t> rec;
     size_t rows = 0;
     while ((int64_t)rows < cfg_.batch_size) {
@@ -132,40 +135,49 @@ class BCFBatchReader {
         }
       }
       // INFO: (typed key, typed value) pairs
-      bool have = false;
-      float iv = 0.f;
+      bool have[MAX_INFO_FIELDS] = {false, false, false, false};
+      float fv[MAX_INFO_FIELDS] = {0.f, 0.f, 0.f, 0.f};
+      int32_t sv[MAX_INFO_FIELDS] = {0, 0, 0, 0};
       for (int k = 0; k < n_info; ++k) {
         int kt, kc;
         typed_header(rec, &o, end, &kt, &kc);
         const int64_t key = kc ? read_int(rec, &o, end, kt) : -1;
         int vt, vc;
         typed_header(rec, &o, end, &vt, &vc);
-        if (key == info_key_ && info_key_ >= 0 && vc >= 1) {
-          if (vt == 5) {
-            uint32_t b;
-            if (o + 4 > end) throw std::runtime_error("corrupt BCF INFO");
-            memcpy(&b, &rec[o], 4);
-            if (b != 0x7F800001u && b != 0x7F800002u) {
-              memcpy(&iv, &b, 4);
-              have = true;
+        const size_t vbytes = (size_t)vc * type_size(vt);
+        if (o + vbytes > end) throw std::runtime_error("corrupt BCF INFO");
+        for (size_t q = 0; q < K; ++q) {
+          if (key != info_keys_[q] || have[q]) continue;
+          const char kind = info_specs[q].kind;
+          if (kind == 'b') {
+            have[q] = true;  // a Flag is true by being there (typed value: missing type, or an int8 1)
+          } else if (kind == 'f' && vc >= 1) {
+            if (vt == 5) {
+              uint32_t b;
+              memcpy(&b, &rec[o], 4);
+              if (b != 0x7F800001u && b != 0x7F800002u) {
+                memcpy(&fv[q], &b, 4);
+                have[q] = true;
+              }
+            } else if (vt >= 1 && vt <= 3) {
+              size_t oo = o;
+              const int64_t v = read_int(rec, &oo, end, vt);
+              const int64_t missing = vt == 1 ? -128 : vt == 2 ? -32768 : (int64_t)INT32_MIN;
+              if (v != missing) {
+                fv[q] = (float)v;
+                have[q] = true;
+              }
             }
-            o += (size_t)vc * 4;
-          } else if (vt >= 1 && vt <= 3) {
-            size_t oo = o;
-            const int64_t v = read_int(rec, &oo, end, vt);
-            const int64_t missing = vt == 1 ? -128 : vt == 2 ? -32768 : (int64_t)INT32_MIN;
-            if (v != missing) {
-              iv = (float)v;
-              have = true;
+          } else if (kind == 's' && vt == 7 && vc >= 1) {
+            size_t len = (size_t)vc;
+            while (len > 0 && rec[o + len - 1] == 0) --len;  // strings may be NUL-padded
+            if (!(len == 1 && rec[o] == '.') && len > 0) {
+              sv[q] = info_dicts[q].lookup_or_insert(reinterpret_cast<const char*>(&rec[o]), len);
+              have[q] = true;
             }
-            o += (size_t)vc * type_size(vt);
-          } else {
-            o += (size_t)vc * type_size(vt);
           }
-        } else {
-          o += (size_t)vc * type_size(vt);
         }
-        if (o > end) throw std::runtime_error("corrupt BCF INFO");
+        o += vbytes;
       }
       if (chrom_id < 0 || chrom_id >= (int)chrom_dict.names.size()) throw std::runtime_error("BCF CHROM index out of range");
       chrom.append_value(chrom_id);
@@ -178,16 +190,29 @@ class BCFBatchReader {
         qual.append_value(q);
       }
       filter.append_value(filter_dict.lookup_or_insert(fl.data(), fl.size()));
-      if (info_key_ >= 0) {
-        if (have) info.append_value(iv);
-        else info.append_null(0.f);
+      for (size_t q = 0; q < K; ++q) {
+        if (info_specs[q].kind == 'f') {
+          if (have[q]) info_f[q].append_value(fv[q]);
+          else info_f[q].append_null(0.f);
+        } else {
+          if (have[q]) info_i[q].append_value(info_specs[q].kind == 'b' ? 1 : sv[q]);
+          else info_i[q].append_null(0);
+        }
       }
       ++rows;
     }
     if (rows == 0) return false;
     std::vector<struct ArrowArray*> kids = {chrom.finish(utf8_array(chrom_dict.names)), pos.finish(), qual.finish(),
                                             filter.finish(utf8_array(filter_dict.names))};
-    if (info_key_ >= 0) kids.push_back(info.finish());
+    for (size_t q = 0; q < K; ++q) {
+      if (info_specs[q].kind == 'f') kids.push_back(info_f[q].finish());
+      else if (info_specs[q].kind == 's') kids.push_back(info_i[q].finish(utf8_array(info_dicts[q].names)));
+      else {
+        struct ArrowArray* a = static_cast<struct ArrowArray*>(malloc(sizeof *a));
+        make_boolean(a, info_i[q].valid, info_i[q].valid);
+        kids.push_back(a);
+      }
+    }
     make_struct(out, (int64_t)rows, std::move(kids));
     return true;
   }
@@ -195,7 +220,12 @@ class BCFBatchReader {
   void schema(struct ArrowSchema* out) const {
     std::vector<struct ArrowSchema*> kids = {new_field("i", "chrom", false, new_field("u", "", false)), new_field("l", "pos", true),
                                              new_field("f", "qual", true), new_field("i", "filter", false, new_field("u", "", false))};
-    if (info_key_ >= 0) kids.push_back(new_field("f", ("info." + cfg_.info_field).c_str(), true));
+    for (const auto& sp : info_specs) {
+      const std::string name = "info." + sp.name;
+      if (sp.kind == 'f') kids.push_back(new_field("f", name.c_str(), true));
+      else if (sp.kind == 'b') kids.push_back(new_field("b", name.c_str(), true));
+      else kids.push_back(new_field("i", name.c_str(), true, new_field("u", "", false)));
+    }
     make_schema(out, "+s", "", false, kids);
   }
 
@@ -203,12 +233,16 @@ class BCFBatchReader {
   const VCFConfig& config() const { return cfg_; }
   const std::vector<std::string>& strings() const { return strings_; }
   int info_key() const { return info_key_; }
+  const std::vector<int>& info_keys() const { return info_keys_; }
   int64_t data_offset() const { return (int64_t)static_cast<StreamSource*>(r_.get())->r.consumed(); }  // header bytes
 
   VCFHeader header;
   Dictionary chrom_dict, filter_dict;
+  std::vector<InfoSpec> info_specs;
+  std::vector<Dictionary> info_dicts;
 
  private:
+  std::vector<int> info_keys_;
   static int type_size(int t) { return t == 1 ? 1 : t == 2 ? 2 : t == 3 ? 4 : t == 5 ? 4 : t == 7 ? 1 : 0; }
   static int64_t read_int(const std::vector<uint8_t>& b, size_t* o, size_t end, int type) {
     const int sz = type_size(type);

@@ -118,10 +118,56 @@ inline std::string header_attr(const std::string& line, const char* key) {
 
 // Schema of the device-layout VCF batch: chrom (dict), pos, qual, filter (dict of ';'-joined lists,
 // "" = empty list), [info.<F>].  Reference schema: exon-core/src/datasources/vcf/schema_builder.rs:85-129.
+// One typed INFO field of the scan (exon.vcf_parse_info = true; `info."<F>"`): InfosBuilder builds a child per header INFO
+// (exon-vcf/src/array_builder/info_builder.rs:152-309, typing in exon-core/src/datasources/vcf/schema_builder.rs:197-249); a
+// scan here builds the ones the query names (up to MAX_INFO_FIELDS, comma-separated in the options), in the device layout:
+//   'f'  Number=1 Float / Integer -> f32 + validity      'b'  Number=0 Flag -> Boolean, true when present, NULL when absent
+//   's'  Number=1 String / Character -> dictionary<int32, utf8> + validity
+// Key absent, value '.', or INFO itself '.' (the whole struct is NULL then): NULL in every kind.
+struct InfoSpec {
+  std::string name;
+  char kind = 'f';
+};
+constexpr int MAX_INFO_FIELDS = 4;
+
+inline std::vector<std::string> split_list(const std::string& s, char sep = ',') {
+  std::vector<std::string> out;
+  size_t i = 0;
+  while (i <= s.size() && !s.empty()) {
+    size_t j = s.find(sep, i);
+    if (j == std::string::npos) j = s.size();
+    if (j > i) out.push_back(s.substr(i, j - i));
+    i = j + 1;
+  }
+  return out;
+}
+
+// "AF,DP,DB" + the header's (ID, "Number|Type") list -> typed specs; throws on unknown / list-valued fields
+inline std::vector<InfoSpec> resolve_info_specs(const std::string& fields, const std::vector<std::pair<std::string, std::string>>& header_infos) {
+  std::vector<InfoSpec> specs;
+  for (const std::string& name : split_list(fields)) {
+    const std::string* ty = nullptr;
+    for (const auto& kv : header_infos)
+      if (kv.first == name) ty = &kv.second;
+    if (!ty) throw std::runtime_error("INFO field " + name + " is not declared in the header");
+    InfoSpec sp;
+    sp.name = name;
+    if (*ty == "1|Float" || *ty == "1|Integer") sp.kind = 'f';
+    else if (*ty == "0|Flag") sp.kind = 'b';
+    else if (*ty == "1|String" || *ty == "1|Character") sp.kind = 's';
+    else throw std::runtime_error("INFO field " + name + " is not a Number=1 Float/Integer/String/Character or a Flag field (" + *ty + ")");
+    specs.push_back(sp);
+  }
+  if ((int)specs.size() > MAX_INFO_FIELDS) throw std::runtime_error("at most 4 INFO fields per scan");
+  return specs;
+}
+
 class VCFArrayBuilder : public ExonArrayBuilder {
  public:
-  VCFArrayBuilder(Dictionary* chrom_dict, Dictionary* filter_dict, const std::string& info_field)
-      : chrom_dict_(chrom_dict), filter_dict_(filter_dict), info_field_(info_field) {}
+  // info_dicts: one dictionary per spec (used by the 's' kind only), owned by the caller like the other dictionaries
+  VCFArrayBuilder(Dictionary* chrom_dict, Dictionary* filter_dict, const std::vector<InfoSpec>& specs, std::vector<Dictionary>* info_dicts)
+      : chrom_dict_(chrom_dict), filter_dict_(filter_dict), specs_(specs), info_dicts_(info_dicts), info_f_(specs.size()),
+        info_i_(specs.size()) {}
 
   // one data line (no terminator).  Field rules: lazy_array_builder.rs:159-216.
   void append(const std::string& line) { append(line.data(), line.size()); }
@@ -151,11 +197,7 @@ class VCFArrayBuilder : public ExonArrayBuilder {
     // FILTER: '.' -> empty list (never NULL); the list is kept as its ';'-joined text, order preserved
     if (fl[6] == 1 && f[6][0] == '.') filter_.append_value(filter_dict_->lookup_or_insert("", 0));
     else filter_.append_value(filter_dict_->lookup_or_insert(f[6], fl[6]));
-    if (!info_field_.empty()) {
-      float v;
-      if (info_lookup(f[7], fl[7], &v)) info_.append_value(v);
-      else info_.append_null(0.f);
-    }
+    if (!specs_.empty()) append_info(f[7], fl[7]);
     ++rows_;
   }
 
@@ -168,7 +210,17 @@ class VCFArrayBuilder : public ExonArrayBuilder {
     out.push_back(pos_.finish());
     out.push_back(qual_.finish());
     out.push_back(filter_.finish(utf8_array(filter_dict_->names)));
-    if (!info_field_.empty()) out.push_back(info_.finish());
+    for (size_t k = 0; k < specs_.size(); ++k) {
+      if (specs_[k].kind == 'f') out.push_back(info_f_[k].finish());
+      else if (specs_[k].kind == 's') out.push_back(info_i_[k].finish(utf8_array((*info_dicts_)[k].names)));
+      else {  // Flag -> Boolean: value true where present
+        struct ArrowArray* a = static_cast<struct ArrowArray*>(malloc(sizeof *a));
+        make_boolean(a, info_i_[k].valid, info_i_[k].valid);
+        info_i_[k].values.clear();
+        info_i_[k].valid.clear();
+        out.push_back(a);
+      }
+    }
     rows_ = 0;
     return out;
   }
@@ -177,14 +229,19 @@ class VCFArrayBuilder : public ExonArrayBuilder {
     for (auto* v : {&chrom_, &filter_}) { v->values.reserve(rows); v->valid.reserve(rows); }
     pos_.values.reserve(rows); pos_.valid.reserve(rows);
     qual_.values.reserve(rows); qual_.valid.reserve(rows);
-    if (!info_field_.empty()) { info_.values.reserve(rows); info_.valid.reserve(rows); }
+    for (size_t k = 0; k < specs_.size(); ++k) {
+      if (specs_[k].kind == 'f') { info_f_[k].values.reserve(rows); info_f_[k].valid.reserve(rows); }
+      else { info_i_[k].values.reserve(rows); info_i_[k].valid.reserve(rows); }
+    }
   }
   // raw column vectors (parallel decoder: slabs are parsed with slab-local dictionaries, then re-keyed)
   PrimitiveBuilder<int32_t>& chrom_ids() { return chrom_; }
   PrimitiveBuilder<int32_t>& filter_ids() { return filter_; }
   PrimitiveBuilder<int64_t>& positions() { return pos_; }
   PrimitiveBuilder<float>& quals() { return qual_; }
-  PrimitiveBuilder<float>& infos() { return info_; }
+  const std::vector<InfoSpec>& info_specs() const { return specs_; }
+  PrimitiveBuilder<float>& info_f32(size_t k) { return info_f_[k]; }      // 'f'
+  PrimitiveBuilder<int32_t>& info_i32(size_t k) { return info_i_[k]; }    // 's': dictionary ids; 'b': 1 where present
 
   static bool parse_pos(const char* p, size_t n, int64_t* out) {
     if (n == 0 || n > 18) return false;
@@ -269,31 +326,55 @@ class VCFArrayBuilder : public ExonArrayBuilder {
   }
 
  private:
-  // INFO '.' -> NULL struct; key absent or value '.' -> NULL field (info_builder.rs:152-309)
-  bool info_lookup(const char* p, size_t n, float* out) const {
-    if (n == 1 && p[0] == '.') return false;
-    size_t i = 0;
-    while (i < n) {
-      size_t j = i;
-      while (j < n && p[j] != ';') ++j;
-      const size_t kl = info_field_.size();
-      if (j - i > kl && p[i + kl] == '=' && memcmp(p + i, info_field_.data(), kl) == 0) {
-        const char* v = p + i + kl + 1;
-        const size_t vl = j - i - kl - 1;
-        if (vl == 0 || (vl == 1 && v[0] == '.')) return false;
-        *out = parse_f32(v, vl);
-        return true;
+  // INFO '.' -> NULL struct (every field NULL); key absent or value '.' -> NULL field (info_builder.rs:152-309).  One pass over
+  // the ';'-separated entries; the FIRST occurrence of a key wins.
+  void append_info(const char* p, size_t n) {
+    const size_t K = specs_.size();
+    bool seen[MAX_INFO_FIELDS] = {false, false, false, false};
+    if (!(n == 1 && p[0] == '.')) {
+      size_t i = 0;
+      while (i < n) {
+        size_t j = i;
+        while (j < n && p[j] != ';') ++j;
+        size_t eq = i;
+        while (eq < j && p[eq] != '=') ++eq;
+        for (size_t k = 0; k < K; ++k) {
+          const std::string& name = specs_[k].name;
+          if (seen[k] || eq - i != name.size() || memcmp(p + i, name.data(), name.size()) != 0) continue;
+          const char* v = eq < j ? p + eq + 1 : p + j;
+          const size_t vl = eq < j ? j - eq - 1 : 0;
+          const bool missing = eq < j && (vl == 0 || (vl == 1 && v[0] == '.'));
+          if (specs_[k].kind == 'b') {
+            info_i_[k].append_value(1);  // a Flag is true by being there
+            seen[k] = true;
+          } else if (eq < j && !missing) {
+            if (specs_[k].kind == 'f') info_f_[k].append_value(parse_f32(v, vl));
+            else info_i_[k].append_value((*info_dicts_)[k].lookup_or_insert(v, vl));
+            seen[k] = true;
+          } else {
+            seen[k] = true;  // `key=.` / bare key of a valued field: present but missing -> NULL
+            if (specs_[k].kind == 'f') info_f_[k].append_null(0.f);
+            else info_i_[k].append_null(0);
+          }
+        }
+        i = j + 1;
       }
-      i = j + 1;
     }
-    return false;
+    for (size_t k = 0; k < K; ++k)
+      if (!seen[k]) {
+        if (specs_[k].kind == 'f') info_f_[k].append_null(0.f);
+        else info_i_[k].append_null(0);
+      }
   }
 
   Dictionary *chrom_dict_, *filter_dict_;
-  std::string info_field_;
+  std::vector<InfoSpec> specs_;
+  std::vector<Dictionary>* info_dicts_;
   PrimitiveBuilder<int32_t> chrom_, filter_;
   PrimitiveBuilder<int64_t> pos_;
-  PrimitiveBuilder<float> qual_, info_;
+  PrimitiveBuilder<float> qual_;
+  std::vector<PrimitiveBuilder<float>> info_f_;
+  std::vector<PrimitiveBuilder<int32_t>> info_i_;
   size_t rows_ = 0;
 };
 
@@ -315,18 +396,20 @@ inline bool vcf_region_hit(const char* line, size_t len, const Region& rg) {
 // one slab of VCF text parsed with slab-local dictionaries (header contigs pre-seeded, so their ids are global)
 struct VCFParseCtx {
   std::vector<std::string> contigs;
-  std::string info_field;
+  std::vector<InfoSpec> info_specs;  // numeric / Flag kinds only: string INFO fields keep the reader sequential
   RegionFilter filter;
 };
 struct VCFSlab : TextSlab {
   Dictionary chrom_dict, filter_dict;
+  std::vector<Dictionary> info_dicts;
   std::unique_ptr<VCFArrayBuilder> b;
   size_t rows = 0;
 };
 inline void parse_vcf_slab(VCFSlab& s, const void* vctx) {
   const VCFParseCtx& ctx = *static_cast<const VCFParseCtx*>(vctx);
   s.chrom_dict.names = ctx.contigs;
-  s.b.reset(new VCFArrayBuilder(&s.chrom_dict, &s.filter_dict, ctx.info_field));
+  s.info_dicts.assign(ctx.info_specs.size(), Dictionary());
+  s.b.reset(new VCFArrayBuilder(&s.chrom_dict, &s.filter_dict, ctx.info_specs, &s.info_dicts));
   const char* p = s.data();
   const char* end = p + s.len;
   s.b->reserve(s.len / 48 + 16);
@@ -370,17 +453,10 @@ class VCFBatchReader {
       break;
     }
     for (const auto& c2 : header.contigs) chrom_dict.names.push_back(c2);
-    if (!cfg_.info_field.empty()) {
-      bool found = false;
-      for (const auto& kv : header.infos)
-        if (kv.first == cfg_.info_field) {
-          found = true;
-          // INFO typing: schema_builder.rs:197-249 -- Number=0|1 scalar; Float -> Float32, Integer -> Int32
-          if (kv.second.rfind("1|", 0) != 0 || (kv.second != "1|Float" && kv.second != "1|Integer"))
-            throw std::runtime_error("INFO field " + cfg_.info_field + " is not a Number=1 Float/Integer field");
-        }
-      if (!found) throw std::runtime_error("INFO field " + cfg_.info_field + " is not declared in the header");
-    }
+    info_specs = resolve_info_specs(cfg_.info_field, header.infos);  // INFO typing: schema_builder.rs:197-249
+    info_dicts.assign(info_specs.size(), Dictionary());
+    bool string_info = false;
+    for (const auto& sp : info_specs) string_info |= sp.kind == 's';
     if (cfg_.filter.active && cfg_.filter.use_index) {
       // get_byte_range_for_file (indexed_bgzf_file.rs:52-112): tabix names -> id -> index.query -> chunks
       const BinningIndex idx = read_tabix(path + ".tbi");
@@ -397,13 +473,13 @@ class VCFBatchReader {
       // multi-threaded decode of the rest of the stream (files of at least a couple of slabs)
       const int threads = cfg_.threads > 0 ? cfg_.threads : decode_threads();
       const long fsize = file_size(path);
-      if (threads > 1 && fsize >= (8 << 20) && !cfg_.defer_decode) {
+      if (threads > 1 && fsize >= (8 << 20) && !cfg_.defer_decode && !string_info) {
         StreamSource* ss = static_cast<StreamSource*>(r_.get());
         std::string carry = has_pending_ ? pending_ + "\n" : std::string();
         has_pending_ = false;
         carry += ss->r.take_buffered();
         pctx_.contigs = header.contigs;
-        pctx_.info_field = cfg_.info_field;
+        pctx_.info_specs = info_specs;
         pctx_.filter = cfg_.filter;
         pipe_.reset(new SlabPipeline<VCFSlab>(ss->r.release_source(), std::move(carry), 1, threads,
                                               [](VCFSlab& s, const void* c) { parse_vcf_slab(s, c); }, &pctx_));
@@ -416,7 +492,7 @@ class VCFBatchReader {
   // (exon-vcf/src/indexed_async_batch_stream.rs:99-116; see DESIGN.md on the reference's unfiltered tail).
   bool read_batch(struct ArrowArray* out) {
     if (pipe_) return read_batch_parallel(out);
-    VCFArrayBuilder b(&chrom_dict, &filter_dict, cfg_.info_field);
+    VCFArrayBuilder b(&chrom_dict, &filter_dict, info_specs, &info_dicts);
     std::string line;
     while ((int64_t)b.len() < cfg_.batch_size) {
       if (has_pending_) {
@@ -469,7 +545,10 @@ class VCFBatchReader {
     out->cols.push_back({b.positions().values.data() + o, b.positions().valid.data() + o, 8});
     out->cols.push_back({b.quals().values.data() + o, b.quals().valid.data() + o, 4});
     out->cols.push_back({b.filter_ids().values.data() + o, nullptr, 4});
-    if (!cfg_.info_field.empty()) out->cols.push_back({b.infos().values.data() + o, b.infos().valid.data() + o, 4});
+    for (size_t k = 0; k < info_specs.size(); ++k) {  // 'f': f32 values; 'b': the 0 / 1 words of the presence column
+      if (info_specs[k].kind == 'f') out->cols.push_back({b.info_f32(k).values.data() + o, b.info_f32(k).valid.data() + o, 4});
+      else out->cols.push_back({b.info_i32(k).values.data() + o, b.info_i32(k).valid.data() + o, 4});
+    }
     cur_pos_ = cur_->rows;
     return true;
   }
@@ -478,12 +557,19 @@ class VCFBatchReader {
     std::vector<struct ArrowSchema*> kids = {new_field("i", "chrom", false, new_field("u", "", false)),
                                              new_field("l", "pos", true), new_field("f", "qual", true),
                                              new_field("i", "filter", false, new_field("u", "", false))};
-    if (!cfg_.info_field.empty()) kids.push_back(new_field("f", ("info." + cfg_.info_field).c_str(), true));
+    for (const auto& sp : info_specs) {
+      const std::string name = "info." + sp.name;
+      if (sp.kind == 'f') kids.push_back(new_field("f", name.c_str(), true));
+      else if (sp.kind == 'b') kids.push_back(new_field("b", name.c_str(), true));
+      else kids.push_back(new_field("i", name.c_str(), true, new_field("u", "", false)));
+    }
     make_schema(out, "+s", "", false, kids);
   }
 
   VCFHeader header;
   Dictionary chrom_dict, filter_dict;
+  std::vector<InfoSpec> info_specs;    // the typed INFO fields of this scan (scan columns 4 ..)
+  std::vector<Dictionary> info_dicts;  // dictionaries of the 's' kind (same index as info_specs)
   int n_chunks = -1;  // index chunks planned (-1: not an indexed scan)
   std::vector<Chunk> planned_chunks;  // ... and the chunks themselves (the GPU decode path ships exactly these blocks)
 
@@ -527,7 +613,17 @@ class VCFBatchReader {
     kids.push_back(slice(cur_->b->positions(), 8, nullptr));
     kids.push_back(slice(cur_->b->quals(), 4, nullptr));
     kids.push_back(slice(cur_->b->filter_ids(), 4, utf8_array(filter_dict.names)));
-    if (!cfg_.info_field.empty()) kids.push_back(slice(cur_->b->infos(), 4, nullptr));
+    for (size_t k = 0; k < info_specs.size(); ++k) {
+      if (info_specs[k].kind == 'f') {
+        kids.push_back(slice(cur_->b->info_f32(k), 4, nullptr));
+      } else {  // Flag (string kinds never reach the parallel reader)
+        struct ArrowArray* a = static_cast<struct ArrowArray*>(malloc(sizeof *a));
+        const auto& pb = cur_->b->info_i32(k);
+        std::vector<uint8_t> valid(pb.valid.begin() + (long)o, pb.valid.begin() + (long)(o + n));
+        make_boolean(a, valid, valid);
+        kids.push_back(a);
+      }
+    }
     make_struct(out, (int64_t)n, std::move(kids));
     cur_pos_ += n;
     return true;

@@ -75,6 +75,11 @@ static exon::Dictionary* dict_of(exon_hip_scan* s, int col) {
   if (s->format == EXON_HIP_FORMAT_VCF && col == 0) return &s->vcf->chrom_dict;
   if (s->format == EXON_HIP_FORMAT_VCF && col == 3) return s->parser ? &s->gpu_filter_dict : &s->vcf->filter_dict;
   if ((s->format == EXON_HIP_FORMAT_BAM || s->format == EXON_HIP_FORMAT_SAM) && col == 2) return &s->bam_dict_view;
+  // string INFO fields (scan columns 4 ..) are dictionary-encoded by the host readers
+  if (s->format == EXON_HIP_FORMAT_VCF && col >= 4 && (size_t)(col - 4) < s->vcf->info_specs.size() && s->vcf->info_specs[(size_t)(col - 4)].kind == 's')
+    return &s->vcf->info_dicts[(size_t)(col - 4)];
+  if (s->format == EXON_HIP_FORMAT_BCF && col >= 4 && (size_t)(col - 4) < s->bcf->info_specs.size() && s->bcf->info_specs[(size_t)(col - 4)].kind == 's')
+    return &s->bcf->info_dicts[(size_t)(col - 4)];
   return nullptr;
 }
 
@@ -114,6 +119,16 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         cfg.defer_decode = s->gpu_parse;
         if (s->gpu_parse && wants_gpu_inflate(o, path)) cfg.threads = 1;  // only the header is read on the host
         s->vcf.reset(new exon::VCFBatchReader(path, c, cfg));
+        if (s->gpu_parse) {
+          bool string_info = false;
+          for (const auto& sp : s->vcf->info_specs) string_info |= sp.kind == 's';
+          if (string_info) {  // string INFO fields are dictionary-encoded by the host reader only: decode there
+            s->gpu_parse = false;
+            cfg.defer_decode = false;
+            cfg.threads = 0;
+            s->vcf.reset(new exon::VCFBatchReader(path, c, cfg));
+          }
+        }
         break;
       }
       case EXON_HIP_FORMAT_BAM: {
@@ -136,6 +151,15 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         s->gpu_parse = wants_gpu_inflate(o, path);  // BCF is BGZF by definition; a region becomes a row mask
         if (s->gpu_parse) cfg.threads = 1;  // only the header is read on the host
         s->bcf.reset(new exon::BCFBatchReader(path, cfg));
+        if (s->gpu_parse) {
+          bool string_info = false;
+          for (const auto& sp : s->bcf->info_specs) string_info |= sp.kind == 's';
+          if (string_info) {
+            s->gpu_parse = false;
+            cfg.threads = 0;
+            s->bcf.reset(new exon::BCFBatchReader(path, cfg));
+          }
+        }
         break;
       }
       case EXON_HIP_FORMAT_SAM: {
@@ -983,7 +1007,9 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
     if (is_vcf && !scan->parser) {
       std::vector<const char*> names;
       for (const auto& c : scan->vcf->header.contigs) names.push_back(c.c_str());
-      rc = exon_hip_vcf_parser_create(ctx, names.data(), (int32_t)names.size(), scan->info_field_s.empty() ? nullptr : scan->info_field_s.c_str(),
+      std::string keys;  // "name:kind,..." from the header-typed specs of the host reader
+      for (const auto& sp : scan->vcf->info_specs) keys += (keys.empty() ? "" : ",") + sp.name + ":" + std::string(1, sp.kind);
+      rc = exon_hip_vcf_parser_create(ctx, names.data(), (int32_t)names.size(), keys.empty() ? nullptr : keys.c_str(),
                                       (int64_t)src->max_text_bytes(), &scan->parser);
       if (rc) break;
       scan->parser_ctx = ctx;
@@ -997,6 +1023,13 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
                                       (int32_t)scan->bcf->header.samples.size(), (int32_t)scan->bcf->info_key(), (int64_t)src->max_text_bytes(),
                                       &scan->bcf_parser);
       if (rc) break;
+      if (scan->bcf->info_specs.size() > 0) {
+        std::vector<int32_t> keys(scan->bcf->info_keys().begin(), scan->bcf->info_keys().end());
+        std::string kinds;
+        for (const auto& sp : scan->bcf->info_specs) kinds += sp.kind;
+        rc = exon_hip_bcf_parser_set_info_keys(scan->bcf_parser, keys.data(), kinds.c_str(), (int32_t)keys.size());
+        if (rc) break;
+      }
     }
     if (is_sam && !scan->sam_parser) {
       std::vector<const char*> names;
@@ -1020,8 +1053,8 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
       if (rc) break;
       size_t consumed = 0;
       if (n > 0 && (is_vcf || is_bcf || is_bam || is_sam)) {
-        // parsed columns in the scan's column order: VCF / BCF 0 chrom 1 pos 2 qual 3 filter 4 info; BAM / SAM 0 flag 1 mapq 2 ref 3 start 4 end
-        exon_hip_column sc[5];
+        // parsed columns in the scan's column order: VCF / BCF 0 chrom 1 pos 2 qual 3 filter 4.. info fields; BAM / SAM 0 flag 1 mapq 2 ref 3 start 4 end
+        exon_hip_column sc[8];
         memset(sc, 0, sizeof sc);
         int64_t n_rows = 0;
         const int32_t* id_col = nullptr;
@@ -1042,8 +1075,10 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
           sc[2].values = cols.qual;
           sc[2].validity = cols.qual_valid;
           sc[3].values = cols.filter_id;
-          sc[4].values = cols.info;
-          sc[4].validity = cols.info_valid;
+          for (int q = 0; q < cols.n_info && q < 4; ++q) {
+            sc[4 + q].values = cols.infos[q] ? (const void*)cols.infos[q] : (const void*)cols.infos_valid[q];  // a Flag's values ARE its bitmap
+            sc[4 + q].validity = cols.infos_valid[q];
+          }
           id_col = cols.chrom_id;
           c_start = c_end = cols.pos;
           pos_valid = cols.pos_valid;
@@ -1088,12 +1123,12 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
               scan->region_mask_cap = cap;
             }
             const int first = exon_hip_stream_plan_first_column(st);
-            const uint8_t* in_valid = first >= 0 && first < 5 ? sc[first].validity : nullptr;
+            const uint8_t* in_valid = first >= 0 && first < 8 ? sc[first].validity : nullptr;
             HIP_TRY(ctx, exon::launch_region_mask(hs, rg_range, id_col, id_valid, c_start, c_end, pos_valid, in_valid, n_rows, rg_id, rg_a, rg_b,
                                                   scan->d_region_mask, scan->d_region_pass));
             row_mask = scan->d_region_mask;
           }
-          rc = exon_hip_stream_launch_scan_columns(st, sc, 5, n_rows, row_mask);
+          rc = exon_hip_stream_launch_scan_columns(st, sc, 8, n_rows, row_mask);
           // the parser's column buffers (and the row mask) are reused by the next slab; the kernel is stream-ordered before that
           total += n_rows;
         }

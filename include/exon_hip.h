@@ -326,7 +326,7 @@ int exon_hip_stream_close(exon_hip_stream* s);
  *  exon-bam/src/batch_reader.rs:44-108, exon-fastq/src/batch_reader.rs:63-82, exon-fasta/src/batch_reader.rs:72-99).
  * Batches are Arrow struct arrays in the DEVICE LAYOUT (dictionary<int32,utf8> keys, u8 mapq) ready for
  * exon_hip_stream_push.  Column order:
- *   VCF   0 chrom(dict) 1 pos:i64? 2 qual:f32? 3 filter(dict of ';'-joined lists, "" = []) [4 info.<F>:f32?]
+ *   VCF   0 chrom(dict) 1 pos:i64? 2 qual:f32? 3 filter(dict of ';'-joined lists, "" = []) [4.. info.<F>: f32? | bool? | dict?]
  *   BAM   0 flag:i32 1 mapping_quality:u8? 2 reference(dict)? 3 start:i64? 4 end:i64?
  *   FASTQ 0 name 1 description? 2 sequence 3 quality_scores      FASTA 0 id 1 description? 2 sequence
  * CPU-only: no ctx needed; errors are reported through exon_hip_last_error(NULL). */
@@ -345,7 +345,10 @@ typedef struct exon_hip_scan_options {
   int32_t format;       /* EXON_HIP_FORMAT_* */
   int32_t compression;  /* EXON_HIP_COMPRESSION_* */
   int64_t batch_size;   /* 0 = 8192 (exon-common/src/lib.rs:27) */
-  const char* info_field; /* VCF: typed INFO field to extract (exon.vcf_parse_info), NULL = none */
+  const char* info_field; /* VCF / BCF: typed INFO fields to extract (exon.vcf_parse_info), up to 4 comma-separated header
+                             IDs ("AF,DP,DB"), NULL = none.  They become scan columns 4, 5, ...: Number=1 Float / Integer ->
+                             f32?, Flag -> bool? (true when present, NULL when absent), Number=1 String / Character ->
+                             dictionary?; INFO '.' makes all of them NULL (the struct itself is NULL in the reference) */
   const char* region;     /* pushed-down vcf_region_filter / bam_region_filter ("chr1:1-100"), NULL = none */
   int32_t use_index;      /* with `region`: plan BGZF chunks from <path>.tbi / <path>.bai (INDEXED_VCF / INDEXED_BAM) */
   int32_t gpu_parse;      /* VCF, FASTQ, BAM: exon_hip_stream_consume_scan ships the file's bytes to HBM and decodes them
@@ -390,10 +393,18 @@ typedef struct exon_hip_vcf_columns {
   float* qual;
   uint8_t* qual_valid;
   int32_t* filter_id;
-  float* info;         /* NULL without an INFO field */
+  float* info;         /* NULL without an INFO field; = infos[0] */
   uint8_t* info_valid;
   int64_t consumed_bytes; /* bytes up to and including the last newline; a trailing partial line is not parsed */
+  /* all typed INFO fields of the parser, in the order given to *_parser_create (scan columns 4 ..): Float / Integer fields
+   * are f32 + validity; a Flag has infos[k] == NULL, its column is the presence bitmap infos_valid[k] (true where set) */
+  int32_t n_info;
+  int32_t reserved;
+  float* infos[4];
+  uint8_t* infos_valid[4];
 } exon_hip_vcf_columns;
+/* info_field: NULL, or up to 4 comma-separated INFO keys "name[:kind]" -- kind f (default): Number=1 Float / Integer -> f32;
+ * kind b: Flag -> presence bitmap.  (String INFO fields are decoded by the host reader only.) */
 int exon_hip_vcf_parser_create(exon_hip_ctx* ctx, const char* const* contig_names, int32_t n_contigs,
                                const char* info_field, int64_t max_slab_bytes, exon_hip_vcf_parser** out);
 /* d_text: a slab of '\n'-terminated data lines in HBM, any alignment (a trailing partial line is left to the
@@ -497,6 +508,9 @@ typedef struct exon_hip_bcf_parser exon_hip_bcf_parser;
 int exon_hip_bcf_parser_create(exon_hip_ctx* ctx, int32_t n_contigs, int32_t n_header_strings, int32_t n_samples,
                                int32_t info_key /* header-string index of the INFO field, -1 = none */, int64_t max_slab_bytes,
                                exon_hip_bcf_parser** out);
+/* several typed INFO fields instead of the single key of _create: header-string indexes + kinds ('f' Float / Integer -> f32,
+ * 'b' Flag -> presence bitmap), up to 4; call before the first parse */
+int exon_hip_bcf_parser_set_info_keys(exon_hip_bcf_parser* parser, const int32_t* keys, const char* kinds, int32_t n);
 int exon_hip_bcf_parser_parse(exon_hip_bcf_parser* parser, void* stream, const uint8_t* d_data, int64_t n_bytes,
                               exon_hip_vcf_columns* cols);
 /* FILTER lists discovered so far, in id order: lists[8 * i .. 8 * i + counts[i]) are header-string indexes ([] = '.') */

@@ -59,7 +59,8 @@ def decode_vcf(path):
             d = {}
             for kv in c[7].split(";"):
                 k, _, v = kv.partition("=")
-                d[k] = v if _ else True
+                if k not in d:  # `Info::get` returns the first field whose key matches (a repeated key is malformed VCF anyway)
+                    d[k] = v if _ else True
             rows["info"].append(d)
     rows.update(contigs=contigs, filters_header=filt_hdr, info_header=info_hdr)
     return rows
