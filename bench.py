@@ -122,9 +122,10 @@ class Workload:
                          (self.ref.data_ptr(), self.rv.data_ptr(), None)]
         elif kind == "c5":
             # FASTQ quality strings, L = 100.  Arrow Utf8 has int32 offsets, so the shard is a sequence of
-            # batches as large as int32 offsets allow (21 474 836 reads = 2^31 - 48 quality bytes); the histogram accumulates.
+            # batches of 20 M reads (2.0e9 quality bytes, under the 2^31 limit; a batch of exactly 2^31 - 48 bytes measured 25 %
+            # slower per byte, EXON_BENCH_C5_BATCH overrides); the histogram accumulates.
             self.L = 100
-            self.batch = max(1, min(rows, (2**31 - 1) // self.L))
+            self.batch = max(1, min(rows, int(os.environ.get("EXON_BENCH_C5_BATCH", 20_000_000))))
             self.bytes = torch.empty(rows * self.L + 64, dtype=torch.uint8, device=dev)
             self.off = torch.empty(self.batch + 1, dtype=torch.int32, device=dev)
             for b0 in range(0, rows, self.batch):
@@ -145,7 +146,7 @@ class Workload:
 
     def run(self):
         """The hot path over the shard: main + finalize kernels; the state is DEFINED by the launch (overwrite mode),
-        so there is no zeroing pass.  c5: one launch per Arrow batch (<= 2^31 bytes), the first one overwrites."""
+        so there is no zeroing pass.  c5: one launch per 20 M-read Arrow batch, the first one overwrites."""
         s = torch.cuda.current_stream().cuda_stream
         if self.kind == "c5":
             n = self.n

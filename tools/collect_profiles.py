@@ -22,6 +22,17 @@ os.makedirs(P, exist_ok=True)
 src = os.path.join(G, f"prof_{rnd}", f"{wl}_kernel_stats.csv")
 if os.path.exists(src):
     shutil.copy(src, os.path.join(P, f"{rnd}_{wl}_kernel_stats.csv"))
+bj = os.path.join(G, f"prof_{rnd}", f"bench_{wl}.json")
+if os.path.exists(bj) and os.path.getsize(bj):
+    line = open(bj).read().strip().splitlines()[-1]
+    d = json.loads(line)
+    if wl != "c4":
+        d.pop("result", None)
+    json.dump(d, open(os.path.join(P, f"{rnd}_bench_{wl}_1gpu.json"), "w"), indent=1)
+for extra in ("bgzf_pipeline_kernel_stats.csv", "bam_pipeline_kernel_stats.csv", "vcfgz_end_to_end.log", "bam_end_to_end.log"):
+    e = os.path.join(G, f"prof_{rnd}", extra)
+    if os.path.exists(e):
+        shutil.copy(e, os.path.join(P, f"{rnd}_{extra}"))
 vals = {}
 out_rows = []
 for name in ("fetch", "write"):

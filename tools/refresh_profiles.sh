@@ -1,23 +1,69 @@
+#!/bin/bash
+# Regenerates every rocprofv3 summary the docs quote, at HEAD, on the GPU box:  tools/refresh_profiles.sh r2
+#   (note: `bench.py` under --kernel-trace pays tens of microseconds per launch: its JSON is not a throughput figure for c5's 30
+#   launches per step; the quoted bench lines come from unprofiled runs, profiles/<round>_bench_<wl>_1gpu.json)
+#   gpurun_out/prof_<round>/<wl>_kernel_stats.csv     rocprofv3 --kernel-trace --stats of `bench.py --workload <wl>`
+#   gpurun_out/pmc_fetch|pmc_write/<wl>_counter_collection.csv   separate --pmc FETCH_SIZE / WRITE_SIZE passes (kernel trace only)
+#   gpurun_out/prof_<round>/{bgzf,bam}_pipeline_kernel_stats.csv  file -> answer pipelines
+# then tools/collect_profiles.py copies the summaries into profiles/<round>_* and rewrites profiles/traffic.json.
+R=${1:-r2}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/prof_r1
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r1/c4 -o c4 --output-format csv -- python bench.py --steps 20 --warmup 3 > gpurun_out/prof_r1/bench_c4.json 2>/dev/null
-cp gpurun_out/prof_r1/c4/c4_kernel_stats.csv gpurun_out/prof_r1/c4_kernel_stats.csv
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r1/k6 -o k6 --output-format csv -- python tools/time_k6.py 1e9 > gpurun_out/prof_r1/k6.log 2>/dev/null
-cp gpurun_out/prof_r1/k6/k6_kernel_stats.csv gpurun_out/prof_r1/k6_kernel_stats.csv
-tools/bin/gen_text bam 20000000 /tmp/e2e.ubam 100 && tools/bin/bgzip /tmp/e2e.ubam /tmp/e2e.bam 6
-cat > /tmp/bam_one.py <<PY
-import sys, os
+P=gpurun_out/prof_$R
+mkdir -p $P gpurun_out/pmc_fetch gpurun_out/pmc_write
+run_wl() {  # workload rows steps
+  rocprofv3 --kernel-trace --stats -d $P/tmp_$1 -o $1 --output-format csv -- python bench.py --workload $1 --rows $2 --steps $3 --warmup 3 --no-extras > $P/bench_$1.json 2> $P/bench_$1.err
+  cp $P/tmp_$1/$1_kernel_stats.csv $P/$1_kernel_stats.csv; rm -rf $P/tmp_$1
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    d=gpurun_out/pmc_$( [ $ctr = FETCH_SIZE ] && echo fetch || echo write )
+    rm -rf $d/tmp_$1
+    rocprofv3 --pmc $ctr --kernel-trace -d $d/tmp_$1 -o $1 --output-format csv -- python bench.py --workload $1 --rows $2 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
+    f=$(find $d/tmp_$1 -name "*counter_collection.csv" | head -1)
+    [ -n "$f" ] && cp "$f" $d/$1_counter_collection.csv
+    rm -rf $d/tmp_$1
+  done
+  python tools/collect_profiles.py $R $1 $2 | tail -1
+  tail -1 $P/bench_$1.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac'])"
+}
+WHAT=${2:-"c4 c2 c3 c6 c5 pipelines"}   # second argument: a subset, e.g. "c5"
+for w in $WHAT; do
+  case $w in
+    c5) run_wl c5 2e8 10 ;;
+    c2|c3|c4|c6) run_wl $w 1e9 20 ;;
+  esac
+done
+case " $WHAT " in *" pipelines "*) ;; *) exit 0 ;; esac
+# file -> answer pipelines
+tools/bin/gen_text vcf 100000000 /tmp/e2e.vcf && tools/bin/bgzip /tmp/e2e.vcf /tmp/e2e.vcf.gz 6
+cat > /tmp/vcfgz_one.py <<PY
+import sys, os, time
 sys.path.insert(0, os.getcwd())
 import exon_amd
 ctx = exon_amd.Context(0)
-for rep in range(2):
+for rep in range(3):
+    t0 = time.perf_counter()
+    scan = exon_amd.Scan("/tmp/e2e.vcf.gz", "vcf", info_field="AF", gpu_parse=True)
+    plan = ctx.plan_cmp_avg_by_group(">", 0.01, 64, columns=(4, 2, 3))
+    st = plan.open(); rows = st.consume(scan); st.finish(); st.close(); plan.close(); scan.close()
+    print("vcf.gz end to end", rows, "rows", round(time.perf_counter() - t0, 4), "s", flush=True)
+PY
+python /tmp/vcfgz_one.py > $P/vcfgz_end_to_end.log 2>&1
+rocprofv3 --kernel-trace --stats -d $P/tmp_bgzf -o bgzf --output-format csv -- python /tmp/vcfgz_one.py > /dev/null 2>&1
+cp $P/tmp_bgzf/bgzf_kernel_stats.csv $P/bgzf_pipeline_kernel_stats.csv; rm -rf $P/tmp_bgzf
+tools/bin/gen_text bam 20000000 /tmp/e2e.ubam 100 && tools/bin/bgzip /tmp/e2e.ubam /tmp/e2e.bam 6
+cat > /tmp/bam_one.py <<PY
+import sys, os, time
+sys.path.insert(0, os.getcwd())
+import exon_amd
+ctx = exon_amd.Context(0)
+for rep in range(3):
+    t0 = time.perf_counter()
     scan = exon_amd.Scan("/tmp/e2e.bam", "bam", gpu_parse=True)
     plan = ctx.plan_flag_mapq_group_count(1284, 0, 30, 25, columns=(0, 1, 2))
     st = plan.open(); rows = st.consume(scan); st.finish(); st.close(); plan.close(); scan.close()
+    print("bam end to end", rows, "rows", round(time.perf_counter() - t0, 4), "s", flush=True)
 PY
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r1/bam -o bam --output-format csv -- python /tmp/bam_one.py > /dev/null 2>&1
-cp gpurun_out/prof_r1/bam/bam_kernel_stats.csv gpurun_out/prof_r1/bam_pipeline_kernel_stats.csv
-tail -1 gpurun_out/prof_r1/bench_c4.json | cut -c1-400
-head -3 gpurun_out/prof_r1/k6_kernel_stats.csv | cut -c1-200
-head -5 gpurun_out/prof_r1/bam_pipeline_kernel_stats.csv | cut -c1-160
+python /tmp/bam_one.py > $P/bam_end_to_end.log 2>&1
+rocprofv3 --kernel-trace --stats -d $P/tmp_bam -o bam --output-format csv -- python /tmp/bam_one.py > /dev/null 2>&1
+cp $P/tmp_bam/bam_kernel_stats.csv $P/bam_pipeline_kernel_stats.csv; rm -rf $P/tmp_bam
+cat $P/vcfgz_end_to_end.log $P/bam_end_to_end.log
