@@ -127,16 +127,16 @@ class Workload:
             self.L = 100
             self.batch = max(1, min(rows, int(os.environ.get("EXON_BENCH_C5_BATCH", 20_000_000))))
             self.bytes = torch.empty(rows * self.L + 64, dtype=torch.uint8, device=dev)
-            self.off = torch.empty(self.batch + 1, dtype=torch.int32, device=dev)
-            for b0 in range(0, rows, self.batch):
+            nb = (rows + self.batch - 1) // self.batch
+            self.off = torch.empty(rows + nb + 4, dtype=torch.int32, device=dev)  # every batch has its own offsets buffer
+            self.chunks = []
+            for k, b0 in enumerate(range(0, rows, self.batch)):
                 nb_ = min(self.batch, rows - b0)
-                ctx._check(lib.exon_hip_gen_c5(h, s, SEED["c5"], row0 + b0, row0 + b0 + nb_, self.L, self.off.data_ptr(),
-                                               self.bytes.data_ptr() + b0 * self.L))
-            if rows % self.batch:  # offsets of a full batch (the last generator call wrote a shorter one)
-                ctx._check(lib.exon_hip_gen_c5(h, s, SEED["c5"], 0, self.batch, self.L, self.off.data_ptr(),
-                                               self.bytes.data_ptr()))
-                ctx._check(lib.exon_hip_gen_c5(h, s, SEED["c5"], row0, row0 + self.batch, self.L, self.off.data_ptr(),
-                                               self.bytes.data_ptr()))
+                d_off = self.off.data_ptr() + 4 * (b0 + k)
+                d_bytes = self.bytes.data_ptr() + b0 * self.L
+                ctx._check(lib.exon_hip_gen_c5(h, s, SEED["c5"], row0 + b0, row0 + b0 + nb_, self.L, d_off, d_bytes))
+                self.chunks.append(([(d_bytes, None, d_off)], nb_))
+            self.fused = os.environ.get("EXON_BENCH_C5_FUSED", "1") != "0"
             self.plan = ctx.plan_qual_pos_hist(self.L)
         self.n_i64, self.n_f64 = self.plan.n_i64, self.plan.n_f64
         self.state = torch.zeros(self.n_i64 + self.n_f64, dtype=torch.int64, device=dev)
@@ -146,14 +146,14 @@ class Workload:
 
     def run(self):
         """The hot path over the shard: main + finalize kernels; the state is DEFINED by the launch (overwrite mode),
-        so there is no zeroing pass.  c5: one launch per 20 M-read Arrow batch, the first one overwrites."""
+        so there is no zeroing pass.  c5: the shard is a list of 20 M-read Arrow batches handed over in one call."""
         s = torch.cuda.current_stream().cuda_stream
         if self.kind == "c5":
-            n = self.n
-            for b0 in range(0, max(n, 1), self.batch):
-                nb_ = min(self.batch, n - b0)
-                self.plan.launch([(self.bytes.data_ptr() + b0 * self.L, None, self.off.data_ptr())], nb_, self.state.data_ptr(),
-                                 overwrite=(b0 == 0), stream=s)
+            if self.fused:  # exon_hip_plan_launch_chunks: one offsets scan + one main kernel + one fold per 64 batches
+                self.plan.launch_chunks(self.chunks, self.state.data_ptr(), overwrite=True, stream=s)
+            else:           # one launch (scan + main + fold) per batch
+                for k, (cols, nb_) in enumerate(self.chunks):
+                    self.plan.launch(cols, nb_, self.state.data_ptr(), overwrite=(k == 0), stream=s)
         else:
             self.plan.launch(self.cols, self.n, self.state.data_ptr(), overwrite=True, stream=s)
 

@@ -151,6 +151,7 @@ SIGNATURES = {
     "exon_hip_plan_destroy": (C.c_int, [_vp]),
     "exon_hip_plan_state_size": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "exon_hip_plan_launch": (C.c_int, [_vp, _vp, _colp, _i32, _i64, _i32, _vp]),
+    "exon_hip_plan_launch_chunks": (C.c_int, [_vp, _vp, _colp, _i32, _i32, _vp, _i32, _vp]),
     "exon_hip_fold_states": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _vp]),
     "exon_hip_merge_states": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "exon_hip_rccl_unique_id": (C.c_int, [_vp]),
@@ -183,6 +184,7 @@ SIGNATURES = {
     "exon_hip_vcf_parser_parse": (C.c_int, [_vp, _vp, _vp, _i64, C.POINTER(VCFColumns)]),
     "exon_hip_vcf_parser_filters": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(_i32)]),
     "exon_hip_vcf_parser_destroy": (C.c_int, [_vp]),
+    "exon_hip_qual_pos_hist_chunks": (C.c_int, [_vp, _vp, _colp, _i32, _vp, _i32, _vp]),
     "exon_hip_qual_pos_hist_views": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "exon_hip_fastq_parser_create": (C.c_int, [_vp, _i64, C.POINTER(_vp)]),
     "exon_hip_fastq_parser_parse": (C.c_int, [_vp, _vp, _vp, _i64, _i32, C.POINTER(FASTQViews)]),

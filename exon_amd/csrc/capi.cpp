@@ -382,19 +382,56 @@ int exon_op_cmp_avg_by_group(exon_hip_ctx* ctx, void* stream, const exon_hip_col
 
 int exon_op_qual_pos_hist(exon_hip_ctx* ctx, void* stream, const exon_hip_column* q, int64_t n_reads, int32_t lmax,
                           int64_t* d_hist, int flags) {
-  if (!ctx || !d_hist) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_qual_pos_hist: NULL argument");
-  if (n_reads < 0) return fail(ctx, EXON_HIP_EINVAL, "n_reads < 0");
-  if (lmax < 1 || lmax > (1 << 20)) return fail(ctx, EXON_HIP_EINVAL, "lmax %d out of range", lmax);
   if (!q) return fail(ctx, EXON_HIP_EINVAL, "quality_scores column is NULL");
-  if (q->validity) return fail(ctx, EXON_HIP_EUNSUPPORTED, "nullable quality_scores (the reference column is non-null)");
-  if (n_reads == 0) return empty_input(ctx, pick_stream(ctx, stream), flags, d_hist, (size_t)lmax * 256 * 8);
-  if (!q->offsets || !q->values) return fail(ctx, EXON_HIP_EINVAL, "quality_scores: offsets/values NULL");
-  if (q->length < n_reads) return fail(ctx, EXON_HIP_EINVAL, "quality_scores: length < n_reads");
+  return exon_op_qual_pos_hist_chunks(ctx, stream, q, 1, 1, &n_reads, lmax, d_hist, flags);
+}
+
+int exon_op_qual_pos_hist_chunks(exon_hip_ctx* ctx, void* stream, const exon_hip_column* q, int stride, int32_t n_chunks,
+                                 const int64_t* n_reads, int32_t lmax, int64_t* d_hist, int flags) {
+  if (!ctx || !d_hist) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_qual_pos_hist: NULL argument");
+  if (lmax < 1 || lmax > (1 << 20)) return fail(ctx, EXON_HIP_EINVAL, "lmax %d out of range", lmax);
+  if (n_chunks < 0) return fail(ctx, EXON_HIP_EINVAL, "n_chunks < 0");
+  if (n_chunks && (!q || !n_reads)) return fail(ctx, EXON_HIP_EINVAL, "quality_scores column is NULL");
+  for (int c = 0; c < n_chunks; ++c) {
+    const exon_hip_column& col = q[(size_t)c * stride];
+    if (n_reads[c] < 0) return fail(ctx, EXON_HIP_EINVAL, "n_reads < 0");
+    if (col.validity) return fail(ctx, EXON_HIP_EUNSUPPORTED, "nullable quality_scores (the reference column is non-null)");
+    if (n_reads[c] == 0) continue;
+    if (!col.offsets || !col.values) return fail(ctx, EXON_HIP_EINVAL, "quality_scores: offsets/values NULL");
+    if (col.length < n_reads[c]) return fail(ctx, EXON_HIP_EINVAL, "quality_scores: length < n_reads");
+  }
   hipStream_t s = pick_stream(ctx, stream);
   Workspace ws;
   int rc;
-  if ((rc = get_workspace(ctx, s, exon::k5_partial_words(ctx->cfg, lmax), &ws))) return fail(ctx, rc, "workspace allocation failed");
-  HIP_TRY(ctx, exon::launch_qual_pos_hist(s, cfg_for(ctx, flags), ws, q->offsets, (const uint8_t*)q->values, n_reads, lmax, d_hist));
+  bool launched = false;
+  exon::K5Chunks ch;
+  ch.count = 0;
+  int64_t reads = 0;
+  auto flush = [&]() -> int {
+    if (!ch.count) return EXON_HIP_OK;
+    if (!launched && (rc = get_workspace(ctx, s, exon::k5_partial_words(ctx->cfg, lmax), &ws))) return fail(ctx, rc, "workspace allocation failed");
+    HIP_TRY(ctx, exon::launch_qual_pos_hist_chunks(s, cfg_for(ctx, launched ? EXON_HIP_LAUNCH_ACCUMULATE : flags), ws, ch, lmax, d_hist));
+    launched = true;
+    ch.count = 0;
+    reads = 0;
+    return EXON_HIP_OK;
+  };
+  // a workgroup's u32 counters see at most (reads of a launch) / (workgroups) + a wave's share increments per bin
+  const int64_t reads_cap = (int64_t)ctx->cfg.compute_units << 30;
+  for (int c = 0; c < n_chunks; ++c) {
+    if (n_reads[c] == 0) continue;
+    if (ch.count == exon::K5_MAX_CHUNKS || (ch.count && reads + n_reads[c] > reads_cap))
+      if ((rc = flush())) return rc;
+    const exon_hip_column& col = q[(size_t)c * stride];
+    ch.off[ch.count] = col.offsets;
+    ch.ends[ch.count] = col.offsets + 1;
+    ch.bytes[ch.count] = (const uint8_t*)col.values;
+    ch.n[ch.count] = n_reads[c];
+    ++ch.count;
+    reads += n_reads[c];
+  }
+  if ((rc = flush())) return rc;
+  if (!launched) return empty_input(ctx, s, flags, d_hist, (size_t)lmax * 256 * 8);
   return EXON_HIP_OK;
 }
 
@@ -442,6 +479,11 @@ int exon_hip_fold_states(exon_hip_ctx* ctx, void* stream, const void* d_gathered
     return fail(ctx, EXON_HIP_EINVAL, "exon_hip_fold_states: bad sizes (world %d, %lld + %lld words)", world, (long long)n_i64, (long long)n_f64);
   HIP_TRY(ctx, exon::launch_fold_states(pick_stream(ctx, stream), d_gathered, world, n_i64, n_f64, d_out));
   return EXON_HIP_OK;
+}
+
+int exon_hip_qual_pos_hist_chunks(exon_hip_ctx* ctx, void* stream, const exon_hip_column* chunks, int32_t n_chunks,
+                                  const int64_t* n_reads, int32_t lmax, int64_t* d_hist) {
+  return exon_op_qual_pos_hist_chunks(ctx, stream, chunks, 1, n_chunks, n_reads, lmax, d_hist, EXON_HIP_LAUNCH_ACCUMULATE);
 }
 
 int exon_hip_qual_pos_hist_views(exon_hip_ctx* ctx, void* stream, const uint8_t* d_bytes, const int32_t* d_starts,

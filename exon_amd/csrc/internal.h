@@ -66,3 +66,6 @@ int exon_op_cmp_avg_by_group(exon_hip_ctx* ctx, void* stream, const exon_hip_col
                              int32_t n_groups, int64_t* d_counts, double* d_sums, int flags);
 int exon_op_qual_pos_hist(exon_hip_ctx* ctx, void* stream, const exon_hip_column* q, int64_t n_reads, int32_t lmax,
                           int64_t* d_hist, int flags);
+// chunk c is q[c * stride]
+int exon_op_qual_pos_hist_chunks(exon_hip_ctx* ctx, void* stream, const exon_hip_column* q, int stride, int32_t n_chunks,
+                                 const int64_t* n_reads, int32_t lmax, int64_t* d_hist, int flags);

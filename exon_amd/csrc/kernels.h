@@ -51,6 +51,20 @@ hipError_t launch_qual_pos_hist_views(hipStream_t s, const LaunchCfg& cfg, const
                                       const int32_t* ends, const uint8_t* bytes, int64_t n_reads, int lmax,
                                       int64_t* d_hist);
 
+// a quality column held as several Arrow batches (chunks): ONE offsets scan, ONE main kernel (the workgroups' LDS
+// histograms live across chunks), ONE finalize for up to K5_MAX_CHUNKS chunks.  Passed to the kernels by value.
+constexpr int K5_MAX_CHUNKS = 64;
+struct K5Chunks {
+  const int32_t* off[K5_MAX_CHUNKS];
+  const int32_t* ends[K5_MAX_CHUNKS];
+  const uint8_t* bytes[K5_MAX_CHUNKS];
+  int64_t n[K5_MAX_CHUNKS];
+  int count;
+};
+// every chunk must have n > 0; 1 <= count <= K5_MAX_CHUNKS
+hipError_t launch_qual_pos_hist_chunks(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const K5Chunks& ch, int lmax,
+                                       int64_t* d_hist);
+
 // pushed-down region filter as a row mask: out_valid = in_valid AND (row hits the region); *n_pass += rows kept.
 // point form (VCF): id_col = chrom id, start = pos; range form (BAM): id_col = reference id, [start, end].
 hipError_t launch_region_mask(hipStream_t s, bool range_form, const int32_t* id_col, const uint8_t* id_valid, const int64_t* start,

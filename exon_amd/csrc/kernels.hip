@@ -958,28 +958,74 @@ constexpr int K5_THREADS = 1024;
 constexpr int K5_PT_MAX = 310;  // positions kept in LDS by the [p][129] layout: 310 * 129 * 4 B = 159,960 B
 constexpr int K5_JA = 24, K5_JB = 4;
 constexpr int K5_A_WORDS = 4 * 128 * 64;  // path A table: [k][byte][column]
+// The workgroup's histogram block, STATIC so that its LDS address is the constant 0: with `extern __shared__` the compiler
+// keeps one `v_add_u32 v, <lds base>, v` per atomic after the v_perm (4 of path A's 10 vector instructions per dword;
+// tools/tune_k5.hip variant K: +3 %).  Sized for the largest layout: [K5_PT_MAX][129] words.
+constexpr int K5_LDS_WORDS = 40000;
+static_assert(K5_LDS_WORDS >= K5_PT_MAX * 129 && K5_LDS_WORDS >= K5_A_WORDS && K5_LDS_WORDS >= 128 * 256 + 64, "K5 LDS block");
+__shared__ __attribute__((aligned(16))) unsigned k5_h[K5_LDS_WORDS];
 
-// flags[0] = 1 when read lengths differ (or a read is longer than lmax -> status bit 8)
+// flags[0]: bit 0 = read lengths differ inside a chunk or between chunks, or reads are not back to back (-> path G);
+// bit 1 / bit 2 = some chunk's first byte is not 4- / 16-byte aligned (path A / B need it); a read longer than lmax -> status bit 8.
 // `off` / `ends`: start and end byte of every read.  An Arrow Utf8 column passes (offsets, offsets + 1); a view over
 // raw FASTQ text passes two separate arrays (reads are then not contiguous, which forces path G).
-__global__ __launch_bounds__(256) void k5_scan_offsets(const int32_t* __restrict__ off, const int32_t* __restrict__ ends, int64_t n, int lmax,
-                                                      int* __restrict__ flags, int* __restrict__ status) {
-  const int L = ends[0] - off[0];
+// blockIdx.y = chunk.
+// CONTIG: every chunk is an Arrow column (ends == off + 1), so read r's length is off[r+1] - off[r] and "back to back" holds
+// by construction: ONE 16-byte load per four reads (the fifth offset comes from the next lane), two in flight per thread.
+template <bool CONTIG>
+__global__ __launch_bounds__(256) void k5_scan_offsets(const K5Chunks ch, int lmax, int* __restrict__ flags, int* __restrict__ status) {
+  const int32_t* __restrict__ off = ch.off[blockIdx.y];
+  const int32_t* __restrict__ ends = ch.ends[blockIdx.y];
+  const int64_t n = ch.n[blockIdx.y];
+  const int L = ch.ends[0][0] - ch.off[0][0];  // every chunk is held to the first chunk's read length
   bool ragged = false, too_long = false;
-  // four reads per thread per step: two 16-byte loads (4-byte aligned: the hardware takes unaligned dwordx4)
+  // four reads per thread per step: 16-byte loads (4-byte aligned: the hardware takes unaligned dwordx4)
   const int64_t n4 = n >> 2, S = (int64_t)gridDim.x * 256;
   auto ld4 = [](const int32_t* p) {
     int4 v;
     __builtin_memcpy(&v, p, 16);
     return v;
   };
-  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n4; c += S) {
-    const int64_t i = c << 2;
-    const int4 a = ld4(off + i), b = ld4(ends + i);
-    const int l0 = b.x - a.x, l1 = b.y - a.y, l2 = b.z - a.z, l3 = b.w - a.w;
-    ragged |= (l0 != L) | (l1 != L) | (l2 != L) | (l3 != L) | (a.y != b.x) | (a.z != b.y) | (a.w != b.z);
-    if (i + 4 < n) ragged |= (off[i + 4] != b.w);
-    too_long |= (l0 > lmax) | (l1 > lmax) | (l2 > lmax) | (l3 > lmax);
+  if (CONTIG) {
+    const int lane = threadIdx.x & 63;
+    // whole waves stay in the loop together (the shuffle needs the neighbour): c is clamped, `live` masks the result
+    const int64_t c0 = (int64_t)blockIdx.x * 256 + threadIdx.x, w0 = c0 - lane;
+    for (int64_t w = w0; w < n4; w += 2 * S) {
+      const int64_t ca = w + lane, cb = ca + S;
+      const bool la = ca < n4, lb = cb < n4;
+      const int4 a = la ? ld4(off + (ca << 2)) : int4{0, 0, 0, 0};
+      const int4 b = lb ? ld4(off + (cb << 2)) : int4{0, 0, 0, 0};
+      // the last live lane of a wave cannot trust the shuffle (its neighbour is dead): give it the direct load
+      {
+        int nx = __shfl_down(a.x, 1);
+        const bool direct = la && (lane == 63 || ca + 1 >= n4);
+        if (direct) nx = off[(ca << 2) + 4];
+        const int l0 = a.y - a.x, l1 = a.z - a.y, l2 = a.w - a.z, l3 = nx - a.w;
+        if (la) {
+          ragged |= (l0 != L) | (l1 != L) | (l2 != L) | (l3 != L);
+          too_long |= (l0 > lmax) | (l1 > lmax) | (l2 > lmax) | (l3 > lmax);
+        }
+      }
+      {
+        int nx = __shfl_down(b.x, 1);
+        const bool direct = lb && (lane == 63 || cb + 1 >= n4);
+        if (direct) nx = off[(cb << 2) + 4];
+        const int l0 = b.y - b.x, l1 = b.z - b.y, l2 = b.w - b.z, l3 = nx - b.w;
+        if (lb) {
+          ragged |= (l0 != L) | (l1 != L) | (l2 != L) | (l3 != L);
+          too_long |= (l0 > lmax) | (l1 > lmax) | (l2 > lmax) | (l3 > lmax);
+        }
+      }
+    }
+  } else {
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n4; c += S) {
+      const int64_t i = c << 2;
+      const int4 a = ld4(off + i), b = ld4(ends + i);
+      const int l0 = b.x - a.x, l1 = b.y - a.y, l2 = b.z - a.z, l3 = b.w - a.w;
+      ragged |= (l0 != L) | (l1 != L) | (l2 != L) | (l3 != L) | (a.y != b.x) | (a.z != b.y) | (a.w != b.z);
+      if (i + 4 < n) ragged |= (off[i + 4] != b.w);
+      too_long |= (l0 > lmax) | (l1 > lmax) | (l2 > lmax) | (l3 > lmax);
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // the last n % 4 reads
     const int64_t i = (n4 << 2) + threadIdx.x;
@@ -989,58 +1035,57 @@ __global__ __launch_bounds__(256) void k5_scan_offsets(const int32_t* __restrict
   }
   if (__any(ragged) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1);
   if (__any(too_long) && (threadIdx.x & 63) == 0) atomicOr(status, 8);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const uintptr_t base = reinterpret_cast<uintptr_t>(ch.bytes[blockIdx.y] + off[0]);
+    const int f = ((base & 3) ? 2 : 0) | ((base & 15) ? 4 : 0);
+    if (f) atomicOr(&flags[0], f);
+  }
 }
 
 enum { K5_PATH_A = 0, K5_PATH_B = 2, K5_PATH_G = 3 };
-__device__ __forceinline__ int k5_pick_path(const int32_t* off, const int32_t* ends, const uint8_t* bytes, int lmax,
-                                            int lp, const int* flags) {
-  if (flags[0]) return K5_PATH_G;
-  const int L = ends[0] - off[0];
+__device__ __forceinline__ int k5_pick_path(const K5Chunks& ch, int lmax, const int* flags) {
+  const int f = flags[0];
+  if (f & 1) return K5_PATH_G;
+  const int L = ch.ends[0][0] - ch.off[0][0];
   if (L < 1 || L > lmax) return K5_PATH_G;
-  const uintptr_t base = reinterpret_cast<uintptr_t>(bytes + off[0]);
-  if ((L & 3) == 0 && L >= 32 && L <= 256 && (base & 3) == 0) return K5_PATH_A;
-  if (L <= K5_PT_MAX && (base & 15) == 0) return K5_PATH_B;
+  if ((L & 3) == 0 && L >= 32 && L <= 256 && !(f & 2)) return K5_PATH_A;
+  if (L <= K5_PT_MAX && !(f & 4)) return K5_PATH_B;
   return K5_PATH_G;
 }
 
-// partial record of a workgroup: u32 [pt][128] (position-major, ASCII half; a batch holds < 2^31 reads); bytes >= 128 never reach it
-__device__ void k5_path_b(const int32_t* __restrict__ off, const int32_t* __restrict__ ends,
-                          const uint8_t* __restrict__ bytes, int64_t n, int lmax, int pt,
-                          unsigned long long* __restrict__ partials, unsigned long long* __restrict__ d_hist);
+// partial record of a workgroup: u32 [pt][128] (position-major, ASCII half; a launch gives a workgroup < 2^32 reads); bytes >= 128 never reach it
+__device__ void k5_path_b(const K5Chunks& ch, int lmax, int pt, unsigned long long* __restrict__ partials,
+                          unsigned long long* __restrict__ d_hist);
 template <int LP>
-__device__ void k5_path_ragged(const int32_t* __restrict__ off, const int32_t* __restrict__ ends,
-                               const uint8_t* __restrict__ bytes, int64_t n, int lmax, int pt,
-                               unsigned long long* __restrict__ partials, unsigned long long* __restrict__ d_hist);
+__device__ void k5_path_ragged(const K5Chunks& ch, int lmax, int pt, unsigned long long* __restrict__ partials,
+                               unsigned long long* __restrict__ d_hist);
 
-// One launch per batch: path A in place, paths B / G through k5_paths_bg (same workgroup shape, same LDS block).
+// One launch for all chunks: path A in place, paths B / G through their functions (same workgroup shape, same LDS block).
+// The LDS histogram is zeroed once, fed by every chunk, and flushed once into the workgroup's partial record.
 template <int LP>
-__global__ __launch_bounds__(K5_THREADS) void k5_main(const int32_t* __restrict__ off, const int32_t* __restrict__ ends,
-                                                      const uint8_t* __restrict__ bytes, int64_t n, int lmax, int pt,
-                                                      const int* __restrict__ flags,
+__global__ __launch_bounds__(K5_THREADS) void k5_main(const K5Chunks ch, int lmax, int pt, const int* __restrict__ flags,
                                                       unsigned long long* __restrict__ partials,
                                                       unsigned long long* __restrict__ d_hist) {
-  const int path = k5_pick_path(off, ends, bytes, lmax, LP, flags);
+  const int path = k5_pick_path(ch, lmax, flags);
   if (path == K5_PATH_B) {
-    k5_path_b(off, ends, bytes, n, lmax, pt, partials, d_hist);
+    k5_path_b(ch, lmax, pt, partials, d_hist);
     return;
   }
   if (path == K5_PATH_G) {
-    k5_path_ragged<LP>(off, ends, bytes, n, lmax, pt, partials, d_hist);
+    k5_path_ragged<LP>(ch, lmax, pt, partials, d_hist);
     return;
   }
   // ---- path A ----
-  extern __shared__ unsigned k5_h[];  // [4 k][128 bytes][64 columns]
+  // k5_h as [4 k][128 bytes][64 columns]
   constexpr int J = K5_JA;
   for (int i = threadIdx.x; i < K5_A_WORDS; i += K5_THREADS) k5_h[i] = 0;
   __syncthreads();
-  const int L = ends[0] - off[0], Ld = L >> 2;
+  const int L = ch.ends[0][0] - ch.off[0][0], Ld = L >> 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int NW = (int)gridDim.x * (K5_THREADS / 64), g = (int)blockIdx.x * (K5_THREADS / 64) + wave;
   const int r = g % Ld, slot = g / Ld, nslots = NW / Ld;  // the wave's rows: index == r (mod Ld), every nslots-th of them
-  const int64_t nd = n * (int64_t)Ld, nrows = nd >> 6;
   const int t = (64 * r) % Ld + lane, w = t / Ld, d = t - w * Ld;
   const unsigned col = (unsigned)(Ld <= 32 ? d + 32 * (w & 1) : d);
-  const unsigned* src = reinterpret_cast<const unsigned*>(bytes + off[0]);
   // bin address (bytes) = k-plane | byte << 8 | col << 2; planes: k = 0 at 0, 1 at 32 KiB (instruction offset), 2 / 3 at +64 KiB
   const unsigned c01 = col * 4u, c23 = c01 | 0x10000u;
   char* hb = reinterpret_cast<char*>(k5_h);
@@ -1067,35 +1112,39 @@ __global__ __launch_bounds__(K5_THREADS) void k5_main(const int32_t* __restrict_
     atomicAdd(reinterpret_cast<unsigned*>(hb + a2), 1u);
     atomicAdd(reinterpret_cast<unsigned*>(hb + a3 + 32768), 1u);
   };
-  if (slot < nslots) {
-    const int64_t qstep = nslots;
-    int64_t q = slot;
-    for (; (q + (J - 1) * qstep) * Ld + r < nrows; q += J * qstep) {
-      unsigned v[J];
+  for (int ci = 0; ci < ch.count; ++ci) {  // every chunk starts at a read boundary: the wave keeps its rows, d and w
+    const int64_t nd = ch.n[ci] * (int64_t)Ld, nrows = nd >> 6;
+    const unsigned* src = reinterpret_cast<const unsigned*>(ch.bytes[ci] + ch.off[ci][0]);
+    if (slot < nslots) {
+      const int64_t qstep = nslots;
+      int64_t q = slot;
+      for (; (q + (J - 1) * qstep) * Ld + r < nrows; q += J * qstep) {
+        unsigned v[J];
 #pragma unroll
-      for (int j = 0; j < J; ++j) v[j] = __builtin_nontemporal_load(src + ((q + j * qstep) * Ld + r) * 64 + lane);
+        for (int j = 0; j < J; ++j) v[j] = __builtin_nontemporal_load(src + ((q + j * qstep) * Ld + r) * 64 + lane);
 #pragma unroll
-      for (int j = 0; j < J; ++j) one(v[j]);
-    }
-    if (q * Ld + r < nrows) {
-      // the last < J rows of this wave, all loads in flight at once (one at a time they cost a memory round trip each:
-      // 40 us of a 345 us launch at 20 M reads).  A row's validity is wave-uniform; invalid slots re-read the first row.
-      unsigned v[J];
-#pragma unroll
-      for (int j = 0; j < J; ++j) {
-        const int64_t row = (q + j * qstep) * Ld + r;
-        v[j] = __builtin_nontemporal_load(src + (row < nrows ? row : q * Ld + r) * 64 + lane);
+        for (int j = 0; j < J; ++j) one(v[j]);
       }
+      if (q * Ld + r < nrows) {
+        // the last < J rows of this wave, all loads in flight at once (one at a time they cost a memory round trip each:
+        // 40 us of a 345 us launch at 20 M reads).  A row's validity is wave-uniform; invalid slots re-read the first row.
+        unsigned v[J];
 #pragma unroll
-      for (int j = 0; j < J; ++j)
-        if ((q + j * qstep) * Ld + r < nrows) one(v[j]);
+        for (int j = 0; j < J; ++j) {
+          const int64_t row = (q + j * qstep) * Ld + r;
+          v[j] = __builtin_nontemporal_load(src + (row < nrows ? row : q * Ld + r) * 64 + lane);
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+          if ((q + j * qstep) * Ld + r < nrows) one(v[j]);
+      }
     }
-  }
-  if (g == NW - 1) {  // the last, partial row (< 64 dwords): column = dword-of-read, first copy
-    const int64_t c = nrows * 64 + lane;
-    if (c < nd) {
-      const int q = (int)(c % Ld);
-      slow(src[c], q, (unsigned)q * 4u);
+    if (g == NW - 1) {  // the last, partial row (< 64 dwords): column = dword-of-read, first copy
+      const int64_t c = nrows * 64 + lane;
+      if (c < nd) {
+        const int q = (int)(c % Ld);
+        slow(src[c], q, (unsigned)q * 4u);
+      }
     }
   }
   __syncthreads();
@@ -1111,21 +1160,20 @@ __global__ __launch_bounds__(K5_THREADS) void k5_main(const int32_t* __restrict_
   }
 }
 
-__device__ void k5_path_b(const int32_t* __restrict__ off, const int32_t* __restrict__ ends,
-                          const uint8_t* __restrict__ bytes, int64_t n, int lmax, int pt,
-                          unsigned long long* __restrict__ partials, unsigned long long* __restrict__ d_hist) {
-  extern __shared__ unsigned k5_h[];  // [pt][129]
+__device__ void k5_path_b(const K5Chunks& ch, int lmax, int pt, unsigned long long* __restrict__ partials,
+                          unsigned long long* __restrict__ d_hist) {
+  // k5_h as [pt][129]
   for (int i = threadIdx.x; i < pt * 129; i += K5_THREADS) k5_h[i] = 0;
   __syncthreads();
   auto add = [&](int p, unsigned b) {
     if (p < pt && b < 128) atomicAdd(&k5_h[p * 129 + b], 1u);
     else atomicAdd(&d_hist[(size_t)p * 256 + b], 1ull);
   };
-  {  // uniform read length: 16-byte chunk per lane
+  const int L = ch.ends[0][0] - ch.off[0][0];
+  for (int ci = 0; ci < ch.count; ++ci) {  // uniform read length: 16-byte chunk per lane
     constexpr int J = K5_JB;
-    const int L = ends[0] - off[0];
-    const uint8_t* src = bytes + off[0];
-    const int64_t total = n * (int64_t)L, nch = total / 16, S = (int64_t)gridDim.x * K5_THREADS;
+    const uint8_t* src = ch.bytes[ci] + ch.off[ci][0];
+    const int64_t total = ch.n[ci] * (int64_t)L, nch = total / 16, S = (int64_t)gridDim.x * K5_THREADS;
     const int64_t c0 = (int64_t)blockIdx.x * K5_THREADS + threadIdx.x;
     int p0 = (int)((16 * c0) % L);
     const int pS = (int)((16 * S) % L);
@@ -1172,11 +1220,8 @@ __device__ void k5_path_b(const int32_t* __restrict__ off, const int32_t* __rest
 // lane groups, so their equal positions never conflict) and the inner loop is branch-free: bytes past the end of
 // a read add to a per-lane dummy word, every load is unconditional.  Longer reads fall back to h[p][129].
 template <int LP, bool BM>
-__device__ void k5_path_ragged_impl(const int32_t* __restrict__ off, const int32_t* __restrict__ ends,
-                                    const uint8_t* __restrict__ bytes, int64_t n, int lmax, int pt,
-                                    unsigned long long* __restrict__ partials,
+__device__ void k5_path_ragged_impl(const K5Chunks& ch, int lmax, int pt, unsigned long long* __restrict__ partials,
                                     unsigned long long* __restrict__ d_hist) {
-  extern __shared__ unsigned k5_h[];
   constexpr int Q = LP / 4, J = 8;
   const int nwords = BM ? 128 * LP + 64 : pt * 129;
   for (int i = threadIdx.x; i < nwords; i += K5_THREADS) k5_h[i] = 0;
@@ -1191,6 +1236,16 @@ __device__ void k5_path_ragged_impl(const int32_t* __restrict__ off, const int32
     __builtin_memcpy(&v, p, 4);  // unaligned dword load
     return v;
   };
+  const int hl = threadIdx.x & 31;
+  const int64_t ghw = (int64_t)blockIdx.x * (K5_THREADS / 32) + (threadIdx.x >> 5);
+  const int64_t nhw = (int64_t)gridDim.x * (K5_THREADS / 32);
+  const int q = hl * 4;
+  constexpr bool TWO = LP > 128;  // reads can reach past position 128: fetch a second dword per lane
+  for (int ci = 0; ci < ch.count; ++ci) {
+  const int32_t* __restrict__ off = ch.off[ci];
+  const int32_t* __restrict__ ends = ch.ends[ci];
+  const uint8_t* __restrict__ bytes = ch.bytes[ci];
+  const int64_t n = ch.n[ci];
   // The dword of positions [q, q+4) of a read of `len` >= 4 bytes at byte offset o0.  A partial last dword is
   // fetched as the dword that ENDS at the read's end (never touches bytes past the read) and shifted down.  The load
   // is UNCONDITIONAL (inactive lanes read the first dword of the buffer): a load inside a branch makes the compiler
@@ -1216,11 +1271,6 @@ __device__ void k5_path_ragged_impl(const int32_t* __restrict__ off, const int32
       for (int k = 0; k < nb; ++k) add_slow(q + k, (d >> (8 * k)) & 0xFF);
     }
   };
-  const int hl = threadIdx.x & 31;
-  const int64_t ghw = (int64_t)blockIdx.x * (K5_THREADS / 32) + (threadIdx.x >> 5);
-  const int64_t nhw = (int64_t)gridDim.x * (K5_THREADS / 32);
-  const int q = hl * 4;
-  constexpr bool TWO = LP > 128;  // reads can reach past position 128: fetch a second dword per lane
   for (int64_t r0 = ghw; r0 < n; r0 += nhw * J) {
     int64_t o0[J];
     int len[J], nb0[J], nb1[J];
@@ -1251,6 +1301,7 @@ __device__ void k5_path_ragged_impl(const int32_t* __restrict__ off, const int32
         for (int k = 0; k < len[j]; ++k) add_slow(k, bytes[o0[j] + k]);
     }
   }
+  }  // chunks
   __syncthreads();
   for (int i = threadIdx.x; i < pt * 128; i += K5_THREADS) {
     const int p = i >> 7, b = i & 127;
@@ -1259,11 +1310,10 @@ __device__ void k5_path_ragged_impl(const int32_t* __restrict__ off, const int32
 }
 
 template <int LP>
-__device__ void k5_path_ragged(const int32_t* __restrict__ off, const int32_t* __restrict__ ends,
-                               const uint8_t* __restrict__ bytes, int64_t n, int lmax, int pt,
-                               unsigned long long* __restrict__ partials, unsigned long long* __restrict__ d_hist) {
-  if (lmax <= LP) k5_path_ragged_impl<LP, true>(off, ends, bytes, n, lmax, pt, partials, d_hist);
-  else k5_path_ragged_impl<LP, false>(off, ends, bytes, n, lmax, pt, partials, d_hist);
+__device__ void k5_path_ragged(const K5Chunks& ch, int lmax, int pt, unsigned long long* __restrict__ partials,
+                               unsigned long long* __restrict__ d_hist) {
+  if (lmax <= LP) k5_path_ragged_impl<LP, true>(ch, lmax, pt, partials, d_hist);
+  else k5_path_ragged_impl<LP, false>(ch, lmax, pt, partials, d_hist);
 }
 
 // d_hist[p][b] += sum over workgroups of partial[wg][p][b]  (p < pt, b < 128).  blockIdx.y splits the workgroup
@@ -1301,33 +1351,41 @@ hipError_t launch_qual_pos_hist_views(hipStream_t s, const LaunchCfg& cfg, const
                                       const int32_t* ends, const uint8_t* bytes, int64_t n_reads, int lmax,
                                       int64_t* d_hist) {
   if (n_reads <= 0) return hipSuccess;
-  if (lmax < 1) return hipErrorInvalidValue;
+  K5Chunks ch;
+  ch.off[0] = offsets;
+  ch.ends[0] = ends;
+  ch.bytes[0] = bytes;
+  ch.n[0] = n_reads;
+  ch.count = 1;
+  return launch_qual_pos_hist_chunks(s, cfg, ws, ch, lmax, d_hist);
+}
+
+hipError_t launch_qual_pos_hist_chunks(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const K5Chunks& ch, int lmax,
+                                       int64_t* d_hist) {
+  if (ch.count < 1 || ch.count > K5_MAX_CHUNKS || lmax < 1) return hipErrorInvalidValue;
+  int64_t n_max = 0;
+  for (int c = 0; c < ch.count; ++c) {
+    if (ch.n[c] <= 0) return hipErrorInvalidValue;
+    n_max = std::max(n_max, ch.n[c]);
+  }
   const int pt = k5_pt(lmax);
   const int grid = cfg.compute_units;
   int* flags = ws.status + 1;
   unsigned long long* hist = reinterpret_cast<unsigned long long*>(d_hist);
-  // flags[0] is zero here: the workspace starts zeroed and k5_finalize, the last kernel of every batch, resets it
-  // (a memset per batch would be a fourth launch; a launch that fails midway can leave it set, which only costs speed:
+  // flags[0] is zero here: the workspace starts zeroed and k5_finalize, the last kernel of every launch, resets it
+  // (a memset per launch would be a fourth kernel; a launch that fails midway can leave it set, which only costs speed:
   // the ragged path is correct for uniform reads too)
   hipError_t e;
   if (cfg.overwrite && (e = hipMemsetAsync(d_hist, 0, (size_t)lmax * 256 * 8, s)) != hipSuccess) return e;  // k5_finalize adds
-  int sgrid = (int)std::min<int64_t>((n_reads / 4 + 255) / 256 + 1, (int64_t)cfg.compute_units * 8);
-  hipLaunchKernelGGL(k5_scan_offsets, dim3(sgrid), dim3(256), 0, s, offsets, ends, n_reads, lmax, flags, ws.status);
-  // LDS block: the larger of the byte-major [128][LP] layout (paths A and G) and the [pt][129] layout (B, long G)
-  const bool lp256 = lmax > 128;
-  const size_t lds = std::max<size_t>(std::max<size_t>((size_t)128 * (lp256 ? 256 : 128) * 4 + 256, (size_t)pt * 129 * 4),
-                                      (size_t)K5_A_WORDS * 4);
-  static std::once_flag attr_once;
-  hipError_t attr_err = hipSuccess;
-  std::call_once(attr_once, [&] {
-    hipError_t e2;
-    const int cap = 160 * 1024;
-    if ((e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_main<128>), hipFuncAttributeMaxDynamicSharedMemorySize, cap)) != hipSuccess) attr_err = e2;
-    if ((e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k5_main<256>), hipFuncAttributeMaxDynamicSharedMemorySize, cap)) != hipSuccess) attr_err = e2;
-  });
-  if (attr_err != hipSuccess) return attr_err;
-  if (lp256) hipLaunchKernelGGL(k5_main<256>, dim3(grid), dim3(K5_THREADS), lds, s, offsets, ends, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
-  else hipLaunchKernelGGL(k5_main<128>, dim3(grid), dim3(K5_THREADS), lds, s, offsets, ends, bytes, n_reads, lmax, pt, flags, ws.partials, hist);
+  int sgrid = (int)std::min<int64_t>((n_max / 4 + 255) / 256 + 1, (int64_t)cfg.compute_units * 8);
+  if (ch.count > 1) sgrid = std::max(1, std::min(sgrid, cfg.compute_units * 16 / ch.count));
+  bool contig = true;
+  for (int c = 0; c < ch.count; ++c) contig &= (ch.ends[c] == ch.off[c] + 1);
+  if (contig) hipLaunchKernelGGL(k5_scan_offsets<true>, dim3(sgrid, ch.count), dim3(256), 0, s, ch, lmax, flags, ws.status);
+  else hipLaunchKernelGGL(k5_scan_offsets<false>, dim3(sgrid, ch.count), dim3(256), 0, s, ch, lmax, flags, ws.status);
+  const bool lp256 = lmax > 128;  // LDS: the static k5_h block holds every layout ([128][LP] + dummies, [pt][129], path A's table)
+  if (lp256) hipLaunchKernelGGL(k5_main<256>, dim3(grid), dim3(K5_THREADS), 0, s, ch, lmax, pt, flags, ws.partials, hist);
+  else hipLaunchKernelGGL(k5_main<128>, dim3(grid), dim3(K5_THREADS), 0, s, ch, lmax, pt, flags, ws.partials, hist);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k5_finalize, dim3((pt * 128 + 255) / 256, 8), dim3(256), 0, s, reinterpret_cast<const unsigned*>(ws.partials), grid, pt, hist, flags);

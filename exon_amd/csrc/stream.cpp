@@ -856,6 +856,29 @@ int exon_hip_plan_launch(exon_hip_plan* plan, void* stream, const exon_hip_colum
   return run_plan(plan, stream, columns, n, flags, d_state);
 }
 
+int exon_hip_plan_launch_chunks(exon_hip_plan* plan, void* stream, const exon_hip_column* columns, int32_t n_columns,
+                                int32_t n_chunks, const int64_t* n, int32_t flags, void* d_state) {
+  if (!plan || !d_state) return fail(plan ? plan->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_plan_launch_chunks: NULL argument");
+  if (n_chunks < 0 || (n_chunks && (!columns || !n))) return fail(plan->ctx, EXON_HIP_EINVAL, "exon_hip_plan_launch_chunks: bad chunk list");
+  if (n_columns != plan->n_cols) return fail(plan->ctx, EXON_HIP_EINVAL, "plan takes %d columns, %d given", plan->n_cols, n_columns);
+  if (flags & ~EXON_HIP_LAUNCH_OVERWRITE) return fail(plan->ctx, EXON_HIP_EINVAL, "unknown launch flags 0x%x", flags);
+  if (reinterpret_cast<uintptr_t>(d_state) & 7) return fail(plan->ctx, EXON_HIP_EINVAL, "d_state must be 8-byte aligned");
+  if (plan->d.kind == EXON_HIP_PLAN_QUAL_POS_HIST)
+    return exon_op_qual_pos_hist_chunks(plan->ctx, stream, columns, n_columns, n_chunks, n, plan->d.lmax,
+                                        reinterpret_cast<int64_t*>(d_state), flags);
+  bool first = true;
+  for (int c = 0; c < n_chunks; ++c) {
+    if (n[c] < 0) return fail(plan->ctx, EXON_HIP_EINVAL, "n < 0");
+    if (n[c] == 0) continue;
+    int rc = run_plan(plan, stream, columns + (size_t)c * n_columns, n[c], first ? flags : EXON_HIP_LAUNCH_ACCUMULATE, d_state);
+    if (rc) return rc;
+    first = false;
+  }
+  if (first && (flags & EXON_HIP_LAUNCH_OVERWRITE))  // nothing launched: an overwrite of nothing is the empty state
+    HIP_TRY(plan->ctx, hipMemsetAsync(d_state, 0, (size_t)(plan->n_i64 + plan->n_f64) * 8, pick_stream(plan->ctx, stream)));
+  return EXON_HIP_OK;
+}
+
 int exon_hip_stream_sync(exon_hip_stream* st) {
   if (!st) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_stream_sync: NULL stream");
   int rc = flush_slot(st);

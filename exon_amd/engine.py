@@ -152,6 +152,12 @@ class Context:
         c0 = _col(data, None, offsets, n_reads)
         self._check(self.lib.exon_hip_qual_pos_hist(self.h, stream, C.byref(c0), n_reads, lmax, d_hist.ptr))
 
+    def qual_pos_hist_chunks(self, chunks, lmax, d_hist, stream=None):
+        """chunks = [(offsets, data, n_reads)]: one Utf8 batch each; fused launches of up to 64 chunks."""
+        arr = (Column * max(1, len(chunks)))(*[_col(d, None, o, n) for (o, d, n) in chunks])
+        ns = (C.c_int64 * max(1, len(chunks)))(*[n for _, _, n in chunks])
+        self._check(self.lib.exon_hip_qual_pos_hist_chunks(self.h, stream, arr, len(chunks), ns, lmax, d_hist.ptr))
+
     def qual_pos_hist_views(self, d_text, starts, ends, n_reads, lmax, d_hist, stream=None):
         """K5 over [starts[r], ends[r]) views into `d_text` (device pointers / DeviceBuffers)."""
         ptr = lambda x: x.ptr if isinstance(x, DeviceBuffer) else x  # noqa: E731
@@ -533,6 +539,7 @@ class Plan:
         for i, c in enumerate(columns):
             desc.columns[i] = c
         self.desc = desc
+        self.n_cols = len(columns)
         h = C.c_void_p()
         ctx._check(ctx.lib.exon_hip_plan_create(ctx.h, C.byref(desc), C.byref(h)))
         self.h = h
@@ -551,6 +558,17 @@ class Plan:
         ptr = d_state.ptr if isinstance(d_state, DeviceBuffer) else int(d_state)
         self.ctx._check(self.ctx.lib.exon_hip_plan_launch(self.h, stream, cols, len(columns), n,
                                                           L.LAUNCH_OVERWRITE if overwrite else L.LAUNCH_ACCUMULATE, ptr))
+
+    def launch_chunks(self, chunks, d_state, overwrite=False, stream=None):
+        """exon_hip_plan_launch_chunks: `chunks` = [(columns, n)], columns as in launch().  A quality-histogram plan
+        runs up to 64 chunks per kernel launch; the other kinds launch per chunk."""
+        ncol = len(chunks[0][0]) if chunks else self.n_cols
+        flat = [_col(v, b, o, n) for (cols, n) in chunks for (v, b, o) in cols]
+        arr = (Column * max(1, len(flat)))(*flat)
+        ns = (C.c_int64 * max(1, len(chunks)))(*[n for _, n in chunks])
+        ptr = d_state.ptr if isinstance(d_state, DeviceBuffer) else int(d_state)
+        self.ctx._check(self.ctx.lib.exon_hip_plan_launch_chunks(self.h, stream, arr, ncol, len(chunks), ns,
+                                                                 L.LAUNCH_OVERWRITE if overwrite else L.LAUNCH_ACCUMULATE, ptr))
 
     def close(self):
         if self.h:

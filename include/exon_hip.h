@@ -202,6 +202,14 @@ int exon_hip_cmp_avg_by_group(exon_hip_ctx* ctx, void* stream, const exon_hip_co
 int exon_hip_qual_pos_hist(exon_hip_ctx* ctx, void* stream, const exon_hip_column* quality_scores /*utf8*/,
                            int64_t n_reads, int32_t lmax, int64_t* d_hist /*[lmax*256]*/);
 
+/* K5 over a column held as several Arrow batches ("chunks": a Utf8 column has int32 offsets, so a quality column beyond
+ * 2^31 bytes IS several batches -- the reference streams 8192-row batches into one accumulator).  chunks[c] is a utf8
+ * column of n_reads[c] reads; chunks with n_reads[c] == 0 are skipped.  Equivalent to calling exon_hip_qual_pos_hist per
+ * chunk, but up to 64 chunks share ONE offsets scan, ONE main kernel (the per-workgroup LDS histograms live across
+ * chunks) and ONE fold instead of three launches each. */
+int exon_hip_qual_pos_hist_chunks(exon_hip_ctx* ctx, void* stream, const exon_hip_column* chunks /*utf8 each*/,
+                                  int32_t n_chunks, const int64_t* n_reads, int32_t lmax, int64_t* d_hist /*[lmax*256]*/);
+
 /* K5 over independent views: read r is bytes[starts[r] .. ends[r]) of `d_bytes` (all device pointers).  Used for
  * the quality (or sequence) lines of raw FASTQ text resident in HBM (exon_hip_fastq_parser_parse): no Arrow
  * column is materialised. */
@@ -272,6 +280,11 @@ int exon_hip_plan_state_size(const exon_hip_plan* plan, int64_t* n_i64, int64_t*
 #define EXON_HIP_LAUNCH_OVERWRITE 1
 int exon_hip_plan_launch(exon_hip_plan* plan, void* stream, const exon_hip_column* columns, int32_t n_columns, int64_t n,
                          int32_t flags, void* d_state);
+/* The same over a table held as n_chunks batches: columns[c * n_columns + i] = operator argument i of chunk c, n[c] its rows.
+ * `flags` applies to the whole call (OVERWRITE: state := all chunks).  Plans of kind QUAL_POS_HIST fuse up to 64 chunks per
+ * kernel launch (exon_hip_qual_pos_hist_chunks); the other kinds launch once per chunk. */
+int exon_hip_plan_launch_chunks(exon_hip_plan* plan, void* stream, const exon_hip_column* columns, int32_t n_columns,
+                                int32_t n_chunks, const int64_t* n, int32_t flags, void* d_state);
 
 /* ---- merge of partial states across GPUs (AggregateExec(Final) over RCCL / xGMI; one process per GPU) -------------------
  * The reference merges partitions in AggregateExec(Final) behind a RepartitionExec / CoalescePartitionsExec (DataFusion 44,

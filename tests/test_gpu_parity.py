@@ -377,6 +377,86 @@ def test_k5_path_a_with_non_ascii_bytes_lmax_above_read_length_and_accumulation(
     assert want[:, 128:].sum() > 0 and want[:, :32].sum() > 0 and want[L:].sum() == 0
 
 
+def _k5_chunk(rng, n, L, shift=0, ragged=False, lmax=None):
+    """(offsets, bytes) of one Utf8 batch: uniform length L, or ragged lengths in [0, lmax]"""
+    lens = rng.integers(0, lmax + 1, n) if ragged else np.full(n, L)
+    off = np.zeros(n + 1, np.int64)
+    off[1:] = np.cumsum(lens)
+    data = rng.integers(33, 75, int(off[-1]) + shift, dtype=np.uint8)
+    if off[-1]:
+        k = max(1, int(off[-1]) // 997)
+        data[shift + rng.integers(0, int(off[-1]), k)] = rng.integers(128, 256, k)  # a few bytes on the global-atomic side path
+    return (off + shift).astype(np.int32), data
+
+
+@pytest.mark.parametrize("case", ["path_a", "path_a_one_chunk_misaligned", "path_b", "mixed_lengths", "ragged", "more_than_64"])
+def test_k5_chunked_column_equals_per_chunk_launches(ctx, oracle, case):
+    """exon_hip_qual_pos_hist_chunks (one scan + one main kernel + one fold for up to 64 Arrow batches) against the oracle
+    applied chunk by chunk, for every device-side path decision: all chunks uniform and aligned (A), one chunk starting at
+    an odd byte (the whole launch must leave path A), L % 4 != 0 (B), chunks of different uniform lengths and ragged
+    chunks (G), more chunks than one launch holds, empty chunks in between; accumulate semantics."""
+    rng = np.random.default_rng(77)
+    lmax = 120
+    if case == "path_a":
+        specs = [(30_001, 100, 0, False), (1, 100, 0, False), (64, 100, 4, False), (70_000, 100, 0, False), (0, 100, 0, False), (12_345, 100, 8, False)]
+    elif case == "path_a_one_chunk_misaligned":
+        specs = [(20_000, 100, 0, False), (20_000, 100, 3, False), (5_000, 100, 0, False)]
+    elif case == "path_b":
+        specs = [(20_000, 99, 0, False), (33_333, 99, 16, False), (7, 99, 0, False)]
+    elif case == "mixed_lengths":
+        specs = [(20_000, 100, 0, False), (20_000, 96, 0, False), (100, 120, 0, False)]
+    elif case == "ragged":
+        specs = [(20_000, 100, 0, False), (15_000, 0, 5, True), (0, 0, 0, True), (9_999, 0, 0, True)]
+    else:
+        specs = [(500 + 13 * i, 100, 0, False) for i in range(150)]
+    chunks, want = [], np.zeros((lmax, 256), np.int64)
+    for n, L, shift, ragged in specs:
+        off, data = _k5_chunk(rng, n, L, shift, ragged, lmax)
+        chunks.append((ctx.to_device(off), ctx.to_device(np.concatenate([data, np.zeros(64, np.uint8)])), n))
+        if n:
+            want += oracle.c5_qual_pos_hist(off, data, lmax)[0]
+    d = ctx.zeros(np.int64, lmax * 256)
+    ctx.qual_pos_hist_chunks(chunks, lmax, d)
+    ctx.sync()
+    assert np.array_equal(d.to_host().reshape(lmax, 256), want), case
+    ctx.qual_pos_hist_chunks(chunks, lmax, d)  # accumulates
+    ctx.sync()
+    assert np.array_equal(d.to_host().reshape(lmax, 256), 2 * want), case
+    # the plan form: OVERWRITE defines the state whatever was in it, then ACCUMULATE adds
+    plan = ctx.plan_qual_pos_hist(lmax)
+    plan.launch_chunks([([(dd, None, o)], n) for (o, dd, n) in chunks], d, overwrite=True)
+    ctx.sync()
+    assert np.array_equal(d.to_host().reshape(lmax, 256), want), case
+    plan.launch_chunks([([(dd, None, o)], n) for (o, dd, n) in chunks[:2]], d, overwrite=False)
+    plan.launch_chunks([], d, overwrite=False)
+    ctx.sync()
+    plan.launch_chunks([([(dd, None, o)], 0) for (o, dd, n) in chunks[:1]], d, overwrite=True)  # only empty chunks: state := 0
+    ctx.sync()
+    assert not d.to_host().any()
+    plan.close()
+
+
+def test_plan_launch_chunks_on_a_row_plan(ctx, oracle):
+    """kinds other than the histogram launch per chunk: K2 over three chunks == K2 over the concatenation"""
+    n = 300_000
+    chrom, pos = ctx.gen_c2(2, n, 0, n)
+    plan = ctx.plan_region_count(6, 50_000_000, 100_000_000)
+    st = ctx.zeros(np.int64, 1)
+    plan.launch([(chrom, None, None), (pos, None, None)], n, st, overwrite=True)
+    ctx.sync()
+    whole = int(st.to_host()[0])
+    cuts = [0, 100_000, 100_000, 250_004, n]  # chunk starts stay 16-byte aligned (i32: 4 rows)
+    chunks = [([(chrom.ptr + 4 * a, None, None), (pos.ptr + 8 * a, None, None)], b - a) for a, b in zip(cuts, cuts[1:])]
+    st2 = ctx.to_device(np.array([12345], np.int64))
+    plan.launch_chunks(chunks, st2, overwrite=True)
+    ctx.sync()
+    assert int(st2.to_host()[0]) == whole and whole > 0
+    plan.launch_chunks(chunks, st2)
+    ctx.sync()
+    assert int(st2.to_host()[0]) == 2 * whole
+    plan.close()
+
+
 def test_k5_read_longer_than_lmax_is_reported(ctx):
     import exon_amd
     off, data = ctx.gen_c5(5, 0, 1000, 100)

@@ -388,6 +388,83 @@ __global__ __launch_bounds__(1024) void vI(const uint8_t* bytes, int64_t n, int 
     if (v) atomicAdd(&out[p * 256 + b], (unsigned long long)v); }
 }
 
+// ---- J: I with (1) a STATIC LDS table -- its address is the constant 0, so the bin address needs no add after the v_perm
+// (with extern __shared__ the compiler keeps a `v_add_u32 v, <lds base>, v` per atomic: 4 of I's 10 VALU per dword) and
+// (2) the non-ASCII test hoisted: the J dwords of an iteration are ORed together (v_or3) and tested once.
+template <int J, int G>
+__global__ __launch_bounds__(1024) void vJ(const uint8_t* bytes, int64_t n, int L, unsigned long long* out) {
+  __shared__ unsigned h[4 * 128 * 64];  // [4][128][64] words = 128 KB
+  const int Ld = L / 4;
+  for (int i = threadIdx.x; i < 4 * 128 * 64; i += 1024) h[i] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int NW = gridDim.x * 16, g = blockIdx.x * 16 + wave;
+  const int r = g % Ld, slot = g / Ld, nslots = NW / Ld;
+  const int64_t nd = n * Ld, nrows = nd / 64;
+  const int t = (64 * r) % Ld + lane, w = t / Ld, d = t - w * Ld;
+  const int col = Ld <= 32 ? d + 32 * (w & 1) : d;
+  const unsigned* src = reinterpret_cast<const unsigned*>(bytes);
+  const unsigned c01 = (unsigned)col * 4u, c23 = c01 | 0x10000u;
+  char* hb = reinterpret_cast<char*>(h);
+  auto slow = [&](unsigned dw, int q, unsigned cc) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const unsigned b = (dw >> (8 * k)) & 0xFF;
+      if (b < 128) atomicAdd(reinterpret_cast<unsigned*>(hb + (k >> 1) * 65536 + (k & 1) * 32768 + b * 256 + cc), 1u);
+      else atomicAdd(&out[(size_t)(4 * q + k) * 256 + b], 1ull); }
+  };
+  auto fast = [&](unsigned dw) {
+    const unsigned a0 = __builtin_amdgcn_perm(dw, c01, 0x03020400u);
+    const unsigned a1 = __builtin_amdgcn_perm(dw, c01, 0x03020500u);
+    const unsigned a2 = __builtin_amdgcn_perm(dw, c23, 0x03020600u);
+    const unsigned a3 = __builtin_amdgcn_perm(dw, c23, 0x03020700u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a0), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a1 + 32768), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a2), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a3 + 32768), 1u);
+  };
+  auto one = [&](unsigned dw) {
+    if (__builtin_expect((dw & 0x80808080u) != 0, 0)) { slow(dw, d, c01); return; }
+    fast(dw);
+  };
+  if (slot < nslots) {
+    const int64_t qstep = nslots;
+    int64_t q = slot;
+    for (; (q + (J - 1) * qstep) * Ld + r < nrows; q += J * qstep) {
+      unsigned v[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) v[j] = __builtin_nontemporal_load(src + ((q + j * qstep) * Ld + r) * 64 + lane);
+      if (G == 1) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) one(v[j]);
+      } else {
+#pragma unroll
+        for (int j0 = 0; j0 < J; j0 += G) {
+          unsigned any = 0;
+#pragma unroll
+          for (int j = j0; j < j0 + G; ++j) any |= v[j];
+          if (__builtin_expect(__any((any & 0x80808080u) != 0), 0)) {
+#pragma unroll 1
+            for (int j = j0; j < j0 + G; ++j) one(v[j]);
+          } else {
+#pragma unroll
+            for (int j = j0; j < j0 + G; ++j) fast(v[j]);
+          }
+        }
+      }
+    }
+    for (; q * Ld + r < nrows; q += qstep) one(src[(q * Ld + r) * 64 + lane]);
+  }
+  if (g == NW - 1) {  // the last partial row (< 64 dwords)
+    const int64_t c = nrows * 64 + lane;
+    if (c < nd) { const int q = (int)(c % Ld); slow(src[c], q, (unsigned)q * 4u); }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < L * 128; i += 1024) { const int p = i % L, b = i / L, k = p & 3;
+    unsigned v = h[(k >> 1) * 16384 + (k & 1) * 8192 + b * 64 + (p >> 2)];
+    if (Ld <= 32) v += h[(k >> 1) * 16384 + (k & 1) * 8192 + b * 64 + (p >> 2) + 32];
+    if (v) atomicAdd(&out[p * 256 + b], (unsigned long long)v); }
+}
+
 int main(int argc, char** argv) {
   int64_t n = argc > 1 ? (int64_t)atof(argv[1]) : (int64_t)2e8; const int L = argc > 2 ? atoi(argv[2]) : 100;
   n = n / 4096 * 4096;
@@ -409,6 +486,20 @@ int main(int argc, char** argv) {
     printf("%-26s grid=%4d  avg %.3f ms best %.3f ms  %.0f GB/s (%.1f%% of 8TB/s) %s\n", name, grid, tot / reps, best, gbs, gbs / 80.0, ok);
   };
   printf("n_reads=%lld L=%d bytes=%.2f GB\n", (long long)n, L, (double)n * L / 1e9);
+  if (getenv("TUNE_K5_ONLY_IJ")) {  // the shipped variant against its successors, on one box; the list runs three times
+    const size_t il = 4 * 128 * 64 * 4;  // (the clocks of an idle GPU take ~100 ms of load to settle: early entries read low)
+    for (int pass = 0; pass < 3; ++pass) {
+      printf("pass %d\n", pass);
+      run("R read-only J4", vR<4>, 0, 256);
+      run("I rows+perm J24", vI<24>, il, 256);
+      run("K I+static J24", vJ<24, 1>, 4, 256);
+      run("J hoist24 J24", vJ<24, 24>, 4, 256);
+      run("J hoist8 J24", vJ<24, 8>, 4, 256);
+      run("J hoist4 J24", vJ<24, 4>, 4, 256);
+      run("J hoist8 J32", vJ<32, 8>, 4, 256);
+    }
+    return 0;
+  }
   run("A v1 wave/read", vA, (size_t)L * 257 * 4, 256);
   run("R read-only J1", vR<1>, 0, 256);
   run("R read-only J4", vR<4>, 0, 256);
