@@ -20,6 +20,7 @@ import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -301,6 +302,7 @@ def main():
     # ---- the merge across GPUs: pick the path outside the timed region --------------------------------------------
     merge_path = "none (1 GPU)"
     native = None
+    hung_native_init = False
     if world > 1:
         wl.run()
         ref = merge_state(wl.state, wl.n_i64, gathered, merged, ctx=ctx).clone()  # also brings torch's communicator up
@@ -308,7 +310,25 @@ def main():
         if a.merge in ("auto", "native") and not share:
             ok = 1
             try:
-                native = NativeComm(ctx)
+                # ncclCommInitRank bootstraps over sockets: bound it, so that a rank that cannot join costs a minute and the
+                # torch path, not the run (a thread stuck in native code cannot be cancelled; the process then leaves via os._exit)
+                box = {}
+
+                def _init():
+                    try:
+                        torch.cuda.set_device(device)
+                        box["comm"] = NativeComm(ctx)
+                    except Exception as e:  # noqa: BLE001
+                        box["err"] = e
+                th = threading.Thread(target=_init, daemon=True)
+                th.start()
+                th.join(float(os.environ.get("EXON_BENCH_NATIVE_INIT_TIMEOUT", 120)))
+                if th.is_alive():
+                    hung_native_init = True
+                    raise TimeoutError("exon_hip_rccl_comm_init did not return in time")
+                if "err" in box:
+                    raise box["err"]
+                native = box["comm"]
                 merged.zero_()
                 native.merge(wl.state, wl.n_i64, gathered, merged)
                 torch.cuda.synchronize()
@@ -437,6 +457,10 @@ def main():
         native.close()
     if world > 1:
         dist.destroy_process_group()
+    if hung_native_init:  # a thread is still inside ncclCommInitRank: leave without waiting for it
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -25,6 +25,10 @@
 // Every block reports a status; any failure makes the caller inflate on the host instead.  The CRC-32 of every
 // inflated block is checked by a second kernel (k_crc32: 64 slices per block, combined in GF(2)[x] mod P).
 #include <hip/hip_runtime.h>
+#include <map>
+#include <mutex>
+#include <algorithm>
+#include <utility>
 
 #include <cstring>
 #include <vector>
@@ -785,13 +789,451 @@ __device__ __noinline__ SymResult decode_symbols(BitReader br, Out o) {
   return SymResult{br, o, err};
 }
 
+
+// ================================================================================================================
+// Lane-parallel decode of one DEFLATE block (speculative decoding, round 2).  The symbol chain of a block is serial, but
+// Huffman streams SELF-SYNCHRONISE: a decoder started at a wrong bit offset falls into step with the true symbol boundaries
+// after a few symbols (measured on VCF text: median 110 bits, 95 % within 512, 99.6 % within 1024).  So the payload bits
+// [P0, P1) are cut into 64 dword-aligned ranges, one per lane:
+//   phase 1  every lane decodes from its range start to its range end (lane 0 from the true start), one symbol per step in
+//            lockstep: token records go to scratch ([step][lane]: coalesced), a bitmap marks each symbol start;
+//   phase 2  every lane keeps decoding past its range end until it lands on a marked bit (= it merged into the chain of a
+//            later lane) or meets the end-of-block code;
+//   phase 3  the true chain is followed lane to lane from lane 0: lane -> its continuation -> the lane it merged into (from
+//            the merge index on) -> ...; lanes that were stepped over are dropped;
+//   phase 4  output offsets by prefix sums over the surviving token ranges; literals are stored by their lanes, matches
+//            are listed in output order;
+//   phase 5  matches are copied 64 at a time, one per lane, in rounds: a match runs once its source lies below the first
+//            unfinished match of its batch (far matches -- most of them in text -- all run in the first round).
+// Anything unusual (caps exceeded, a dead end on the true chain, an invalid code) returns nonzero WITHOUT committing:
+// the caller then decodes the block with the serial symbol loop, which also owns all error reporting.
+// ================================================================================================================
+constexpr int PAR_T1 = 512, PAR_T2 = 256;            // token steps per lane: own range / continuation
+constexpr int PAR_BM_WORDS = 16384 + 64;             // one bit per payload bit of a member (<= 64 KiB of DEFLATE data)
+constexpr int PAR_ML = 21888;                        // matches of one member (<= 65536 / 3)
+constexpr size_t PAR_SLOT_BYTES = (size_t)(PAR_T1 + PAR_T2) * 64 * 8 + (size_t)PAR_BM_WORDS * 4 + (size_t)PAR_ML * 8;
+constexpr uint32_t PAR_MIN_BITS = 64 * 96;           // smaller payloads are not worth the set-up
+struct ParSlot {
+  uint64_t* t1;   // [PAR_T1][64]
+  uint64_t* t2;   // [PAR_T2][64]
+  uint32_t* bm;   // [PAR_BM_WORDS]
+  uint64_t* ml;   // [PAR_ML]  dst (32) | len (9) | dist (16) << 9
+};
+__device__ __forceinline__ ParSlot par_slot(uint8_t* base, uint32_t slot) {
+  uint8_t* p = base + (size_t)slot * PAR_SLOT_BYTES;
+  ParSlot s;
+  s.t1 = reinterpret_cast<uint64_t*>(p);
+  s.t2 = s.t1 + (size_t)PAR_T1 * 64;
+  s.ml = s.t2 + (size_t)PAR_T2 * 64;
+  s.bm = reinterpret_cast<uint32_t*>(s.ml + PAR_ML);
+  return s;
+}
+// token: lo = literal byte | T_MATCH | (len - 3) | (dist - 1) << 8 | T_EOB ; hi = cum (18 bits) | relpos << 18
+constexpr uint32_t T_MATCH = 1u << 31, T_EOB = 1u << 30;
+enum { PE_RUN = 0, PE_EXIT = 1, PE_EOB = 2, PE_DEAD = 3, PE_MERGED = 4 };
+
+// per-lane canonical decode of a code longer than the first-level table, resumed after its first `kbits` lengths
+// (first_k / index_k = the bit-serial loop's state after kbits lengths, wave-uniform).  Returns entry | length, or E_INVALID.
+__device__ __forceinline__ uint32_t par_long(int which, const uint16_t* count, const uint16_t* sym, uint64_t w, int kbits, int first_k,
+                                             int index_k) {
+  int code = (int)(__brev((uint32_t)w) >> (32 - kbits));
+  int first = first_k, index = index_k;
+  uint32_t bits = (uint32_t)(w >> kbits);
+  for (int len = kbits + 1; len <= 15; ++len) {
+    code = (code << 1) | (int)(bits & 1u);
+    bits >>= 1;
+    const int n = (int)count[len];
+    if (code - n < first) return entry_for(which, (int)sym[index + (code - first)]) | (uint32_t)len;
+    index += n;
+    first += n;
+    first <<= 1;
+  }
+  return E_INVALID;
+}
+
+struct ParSym {
+  uint32_t tok;   // token low word
+  uint32_t olen;  // output bytes
+  uint32_t bits;  // bits consumed
+  int kind;       // PE_RUN (ordinary) / PE_EOB / PE_DEAD
+};
+struct ParCodes {
+  int lit_first, lit_index, dist_first, dist_index;  // par_long resume state (wave-uniform)
+};
+// A lane's window on the compressed bits: three aligned 8-byte words, the third one always in flight -- a symbol takes at
+// most 48 bits, so the word loaded when the window moves is first needed two moves later and the memory latency stays off
+// the symbol chain (with one unaligned load per symbol every step waited a full L2 round trip).
+struct ParBits {
+  const uint64_t* base;  // member start rounded down to 8 bytes
+  uint32_t skew;         // bits between `base` and bit 0 of the member
+  uint32_t wbit;         // bit index (from base) of w0, a multiple of 64
+  uint64_t w0, w1, w2;
+  __device__ __forceinline__ void init(const uint8_t* comp, uint32_t p) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(comp);
+    base = reinterpret_cast<const uint64_t*>(a & ~uintptr_t(7));
+    skew = (uint32_t)(a & 7u) * 8u;
+    wbit = (p + skew) & ~63u;
+    const uint64_t* q = base + (wbit >> 6);
+    w0 = q[0];
+    w1 = q[1];
+    w2 = q[2];
+  }
+  // >= 57 valid bits starting at member bit p; p never moves backwards and by at most 48 bits between calls
+  __device__ __forceinline__ uint64_t at(uint32_t p) {
+    uint32_t off = p + skew - wbit;
+    if (off >= 64u) {
+      w0 = w1;
+      w1 = w2;
+      wbit += 64u;
+      w2 = base[(wbit >> 6) + 2];
+      off -= 64u;
+    }
+    return off ? (w0 >> off) | (w1 << (64u - off)) : w0;
+  }
+};
+// one symbol (literal, or length + distance) at bit position p of the member (per lane)
 template <int RING>
-__global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks, int n_blocks,
-                                                uint8_t* out, int* __restrict__ status) {
+__device__ __forceinline__ ParSym par_symbol(ParBits& pb, uint32_t p, const WaveLds* L, const ParCodes& pc) {
+  uint64_t w = pb.at(p);  // code 15 + extra 5 + code 15 + extra 13 = 48 bits at most
+  ParSym r;
+  uint32_t e = L->lit_lut[(uint32_t)w & ((1u << LIT_BITS) - 1u)];
+  if (__builtin_expect((e & 15u) == 0, 0)) e = par_long(CODE_LIT, L->lit_count, L->lit_sym, w, LIT_BITS, pc.lit_first, pc.lit_index);
+  uint32_t used = e & 15u;
+  r.kind = PE_RUN;
+  if (e & E_LIT) {
+    r.tok = e >> 16;
+    r.olen = 1;
+    r.bits = used;
+    return r;
+  }
+  if (__builtin_expect((e & (E_EOB | E_INVALID)) != 0, 0)) {
+    r.kind = (e & E_INVALID) ? PE_DEAD : PE_EOB;
+    r.tok = T_EOB;
+    r.olen = 0;
+    r.bits = used;
+    return r;
+  }
+  w >>= used;
+  const uint32_t xb = (e >> 4) & 15u;
+  const uint32_t len = (e >> 16) + ((uint32_t)w & ((1u << xb) - 1u));
+  w >>= xb;
+  used += xb;
+  uint32_t de = L->dist_lut[(uint32_t)w & ((1u << DIST_BITS) - 1u)];
+  if (__builtin_expect((de & 15u) == 0, 0)) de = par_long(CODE_DIST, L->dist_count, L->dist_sym, w, DIST_BITS, pc.dist_first, pc.dist_index);
+  if (__builtin_expect((de & E_INVALID) != 0, 0)) r.kind = PE_DEAD;
+  const uint32_t dl = de & 15u;
+  w >>= dl;
+  const uint32_t dxb = (de >> 4) & 15u;
+  const uint32_t dist = (de >> 16) + ((uint32_t)w & ((1u << dxb) - 1u));
+  r.tok = T_MATCH | (len - 3u) | ((dist - 1u) << 8);
+  r.olen = len;
+  r.bits = used + dl + dxb;
+  return r;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
+  return uniu(v);
+}
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t* total) {
+  const int lane = (int)lane_id();
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = (uint32_t)__shfl_up((int)x, d);
+    if (lane >= d) x += y;
+  }
+  *total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+  return x - v;
+}
+
+// Decodes the DEFLATE block whose symbols start at bit P0 of the member (tables are built) straight into out[o.pos ..].
+// On success returns 0, advances o.pos / o.drained and sets *end_bit to the bit after the end-of-block code.
+template <int RING>
+__device__ __noinline__ int par_decode_block(const uint8_t* __restrict__ comp /* member base */, uint32_t P0, uint32_t P1, Out& o,
+                                             const ParSlot sl, uint32_t* end_bit, unsigned* __restrict__ stats) {
+  const WaveLds* L = wave_lds<RING>();
+  const int lane = (int)lane_id();
+  uint64_t tq = __builtin_amdgcn_s_memtime();
+  auto lap = [&](int idx) {  // EXON_INFLATE_PROFILE: kilo-clocks per phase into stats[8 + idx]
+#ifdef EXON_INFLATE_PROFILE
+    const uint64_t now = __builtin_amdgcn_s_memtime();
+    if (lane == 0) atomicAdd(&stats[8 + idx], (unsigned)((now - tq) >> 10));
+    tq = now;
+#endif
+  };
+  (void)tq;
+  P0 = uniu(P0);
+  P1 = uniu(P1);
+  if (P1 <= P0 || P1 - P0 < PAR_MIN_BITS || (P1 >> 5) + 2 >= (uint32_t)PAR_BM_WORDS) return 1;
+  // resume state of the long-code decoders
+  ParCodes pc;
+  {
+    int first = 0, index = 0;
+    for (int q = 1; q <= LIT_BITS; ++q) {
+      const int n = uni((int)L->lit_count[q]);
+      index += n;
+      first += n;
+      first <<= 1;
+    }
+    pc.lit_first = first;
+    pc.lit_index = index;
+    first = index = 0;
+    for (int q = 1; q <= DIST_BITS; ++q) {
+      const int n = uni((int)L->dist_count[q]);
+      index += n;
+      first += n;
+      first <<= 1;
+    }
+    pc.dist_first = first;
+    pc.dist_index = index;
+  }
+  // ---- ranges: A = P0 rounded down to a dword; lane l owns bits [A + l S, A + (l + 1) S), S a multiple of 32
+  const uint32_t A = P0 & ~31u;
+  const uint32_t S = (((P1 - A + 63u) / 64u) + 31u) & ~31u;
+  if (S + 64u >= (1u << 14)) return 1;  // relpos field
+  const uint32_t rs = lane == 0 ? P0 : A + (uint32_t)lane * S;
+  const uint32_t re = min(P1, A + (uint32_t)(lane + 1) * S);
+  const int nlanes = (int)((P1 - A + S - 1u) / S);
+  // zero the bitmap over the payload
+  for (uint32_t wi = (A >> 5) + (uint32_t)lane; wi <= (P1 >> 5) + 1u; wi += 64) sl.bm[wi] = 0;
+
+  lap(0);
+  // ---- phase 1 ---------------------------------------------------------------------------------------------------
+  uint32_t p = rs, cum = 0, n1 = 0;
+  int kind = lane < nlanes && rs < P1 ? PE_RUN : PE_DEAD;
+  ParBits pb;
+  pb.init(comp, kind == PE_RUN ? rs : P0);
+  uint32_t bm_wi = rs >> 5, bm_acc = 0;
+  for (int step = 0; step < PAR_T1; ++step) {
+    const bool act = kind == PE_RUN;
+    if (!__any(act)) break;
+    if (act) {
+      const ParSym sy = par_symbol<RING>(pb, p, L, pc);
+      const uint32_t wi = p >> 5;
+      if (wi != bm_wi) {
+        sl.bm[bm_wi] = bm_acc;
+        bm_acc = 0;
+        bm_wi = wi;
+      }
+      bm_acc |= 1u << (p & 31u);
+      sl.t1[(size_t)step * 64 + lane] = (uint64_t)sy.tok | ((uint64_t)(cum | ((p - rs) << 18)) << 32);
+      ++n1;
+      cum += sy.olen;
+      p += sy.bits;
+      if (sy.kind != PE_RUN) kind = sy.kind;
+      else if (cum >= (1u << 18)) kind = PE_DEAD;
+      else if (p >= re) kind = p > P1 ? PE_DEAD : PE_EXIT;
+    }
+  }
+  if (kind == PE_RUN) kind = PE_DEAD;  // out of token space
+#ifdef EXON_INFLATE_PROFILE
+  { const uint32_t mx = wave_max_u32(n1); if (lane == 0) atomicAdd(&stats[14], mx); }
+#endif
+  if (lane < nlanes && rs < P1) sl.bm[bm_wi] = bm_acc;
+  const uint32_t cum1 = cum;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+  lap(1);
+  // ---- phase 2: continue until the chain lands on a symbol start of a later lane --------------------------------
+  int ckind = kind == PE_EXIT ? PE_RUN : PE_DEAD;
+  uint32_t cn = 0, mpos = 0;
+  for (int step = 0; step < PAR_T2; ++step) {
+    bool act = ckind == PE_RUN;
+    if (!__any(act)) break;
+    if (act) {
+      if (p >= P1) {
+        ckind = PE_DEAD;
+      } else if ((sl.bm[p >> 5] >> (p & 31u)) & 1u) {
+        ckind = PE_MERGED;
+        mpos = p;
+      } else {
+        const ParSym sy = par_symbol<RING>(pb, p, L, pc);
+        sl.t2[(size_t)step * 64 + lane] = (uint64_t)sy.tok | ((uint64_t)cum << 32);
+        ++cn;
+        cum += sy.olen;
+        p += sy.bits;
+        if (sy.kind != PE_RUN) ckind = sy.kind;
+        else if (cum >= (1u << 18) || p > P1) ckind = PE_DEAD;
+      }
+    }
+  }
+  if (ckind == PE_RUN) ckind = PE_DEAD;
+#ifdef EXON_INFLATE_PROFILE
+  { const uint32_t mx = wave_max_u32(cn); if (lane == 0) atomicAdd(&stats[15], mx); }
+#endif
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+  lap(2);
+  // ---- phase 3: follow the true chain ---------------------------------------------------------------------------
+  unsigned long long valid = 0;
+  uint32_t k0 = 0;  // per lane: first valid token of its own list
+  int last = -1;
+  bool end_in_cont = false;
+  {
+    int cur = 0;
+    uint32_t kcur = 0;
+    for (int it = 0; it < 64; ++it) {
+      valid |= 1ull << cur;
+      if (lane == cur) k0 = kcur;
+      const int ek = __builtin_amdgcn_readlane(kind, cur);
+      if (ek == PE_EOB) {
+        last = cur;
+        break;
+      }
+      if (ek != PE_EXIT) return 2;
+      const int ck = __builtin_amdgcn_readlane(ckind, cur);
+      if (ck == PE_EOB) {
+        last = cur;
+        end_in_cont = true;
+        break;
+      }
+      if (ck != PE_MERGED) return 3;
+      const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)mpos, cur);
+      const int nxt = (int)((m - A) / S);
+      if (nxt <= cur || nxt >= nlanes) return 4;
+      const uint32_t n1n = (uint32_t)__builtin_amdgcn_readlane((int)n1, nxt);
+      const uint32_t target = m - (A + (uint32_t)nxt * S);
+      int found = -1;
+      for (uint32_t kb = 0; kb < n1n; kb += 64) {
+        const uint32_t k = kb + (uint32_t)lane;
+        const bool hit = k < n1n && (uint32_t)(sl.t1[(size_t)k * 64 + nxt] >> 50) == target;
+        const unsigned long long bal = __ballot(hit);
+        if (bal) {
+          found = (int)kb + __ffsll((long long)bal) - 1;
+          break;
+        }
+      }
+      if (found < 0) return 5;
+      cur = nxt;
+      kcur = (uint32_t)found;
+    }
+    if (last < 0) return 6;
+  }
+  const bool mine = (valid >> lane) & 1ull;
+  // the end-of-block token is the last one of lane `last` (own list, or continuation)
+  *end_bit = (uint32_t)__builtin_amdgcn_readlane((int)p, last);
+
+  lap(3);
+  // ---- phase 4: output offsets, literals, the ordered match list -------------------------------------------------
+  const uint32_t cum_k0 = mine ? (uint32_t)(sl.t1[(size_t)k0 * 64 + lane] >> 32) & 0x3FFFFu : 0u;
+  // a lane that ended with EOB inside its own range has no continuation (cn = 0); every other valid lane's continuation counts
+  const uint32_t obytes = mine ? cum - cum_k0 : 0u;
+  uint32_t total;
+  const uint32_t obase = wave_excl_scan(obytes, &total);
+  if (o.pos + total > o.end) return 7;
+  (void)cum1;
+  (void)end_in_cont;
+  uint8_t* const dst0 = o.out + o.pos + obase - cum_k0;  // + cum of a token = its output address
+  uint32_t mcount = 0;
+  const uint32_t n1max = wave_max_u32(mine ? n1 : 0u), cnmax = wave_max_u32(mine ? cn : 0u);
+  // visit(lo, cum) for every valid token of this lane, own list then continuation; 8 coalesced loads in flight per lane
+  auto walk = [&](auto&& visit) {
+    for (uint32_t kb = 0; kb < n1max; kb += 8) {
+      uint64_t t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = sl.t1[(size_t)min(kb + j, (uint32_t)PAR_T1 - 1u) * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t k = kb + j;
+        if (mine && k >= k0 && k < n1) visit((uint32_t)t[j], (uint32_t)(t[j] >> 32) & 0x3FFFFu);
+      }
+    }
+    for (uint32_t kb = 0; kb < cnmax; kb += 8) {
+      uint64_t t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = sl.t2[(size_t)min(kb + j, (uint32_t)PAR_T2 - 1u) * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t k = kb + j;
+        if (mine && k < cn) visit((uint32_t)t[j], (uint32_t)(t[j] >> 32));
+      }
+    }
+  };
+  walk([&](uint32_t lo, uint32_t c) {
+    if (lo & T_MATCH) ++mcount;
+    else if (!(lo & T_EOB)) dst0[c] = (uint8_t)lo;
+  });
+  uint32_t M;
+  const uint32_t mbase = wave_excl_scan(mcount, &M);
+  if (M > (uint32_t)PAR_ML) return 8;
+  {
+    uint32_t mi = mbase;
+    const uint32_t dpos0 = o.pos + obase - cum_k0;
+    walk([&](uint32_t lo, uint32_t c) {
+      if (lo & T_MATCH) sl.ml[mi++] = (uint64_t)(dpos0 + c) | ((uint64_t)(((lo & 255u) + 3u) | ((((lo >> 8) & 0x7FFFu) + 1u) << 9)) << 32);
+    });
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+  lap(4);
+  // ---- phase 5: matches, 64 at a time, one per lane, in dependency rounds -----------------------------------------
+  uint8_t* const out = o.out;
+  int bad = 0;
+  for (uint32_t i0 = 0; i0 < M; i0 += 64) {
+    const bool have = i0 + (uint32_t)lane < M;
+    const uint64_t rec = have ? sl.ml[i0 + lane] : 0ull;
+    const uint32_t dst = (uint32_t)rec, len = (uint32_t)(rec >> 32) & 511u, dist = (uint32_t)(rec >> 41);
+    if (have && dist > dst - o.begin) bad = 1;  // reaches before the start of the member's output
+    if (__any(bad)) return 9;
+    const uint32_t src = dst - dist;
+    bool done = !have;
+    for (;;) {
+      const unsigned long long pend = __ballot(!done);
+      if (!pend) break;
+      const int f = __ffsll((long long)pend) - 1;
+      const uint32_t dst_f = (uint32_t)__builtin_amdgcn_readlane((int)dst, f);
+      const bool go = !done && (lane == f || src + min(len, dist) <= dst_f);
+      if (go) {
+        if (dist >= len) {  // source and destination do not overlap: 32 bytes per trip, all loads before the stores
+          for (uint32_t q = 0; q < len; q += 32) {
+            const uint32_t nb = min(32u, len - q);
+            uint32_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+              if ((uint32_t)(4 * i) < nb) __builtin_memcpy(&v[i], out + src + q + 4 * i, 4);  // reads < 4 bytes past the source: unused
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              if ((uint32_t)(4 * i + 4) <= nb) {
+                __builtin_memcpy(out + dst + q + 4 * i, &v[i], 4);
+              } else if ((uint32_t)(4 * i) < nb) {
+                for (uint32_t b = 0; b < nb - 4 * i; ++b) out[dst + q + 4 * i + b] = (uint8_t)(v[i] >> (8 * b));
+              }
+            }
+          }
+        } else {  // overlapping run: every byte comes from the `dist` bytes before the match; 8 loads in flight
+          for (uint32_t q = 0; q < len; q += 8) {
+            uint8_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = out[src + (q + i) % dist];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+              if (q + i < len) out[dst + q + i] = v[i];
+          }
+        }
+        done = true;
+      }
+      // the next round reads what this one wrote: memory operations of ONE wavefront reach the cache hierarchy in program
+      // order (the same guarantee plain C code relies on for a store followed by a load), so no wait is needed here
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#ifdef EXON_INFLATE_PAR_WAIT
+      __builtin_amdgcn_s_waitcnt(0);
+#endif
+    }
+  }
+  lap(5);
+  o.pos += total;
+  o.drained = o.pos;
+  return 0;
+}
+
+// One BGZF member.  PAR: dynamic / fixed DEFLATE blocks first try par_decode_block (scratch slot `sl`, fallback counters `stats`).
+template <int RING, bool PAR>
+__device__ __forceinline__ void inflate_member(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks, int b, uint8_t* out,
+                                               int* __restrict__ status, const ParSlot sl, unsigned* __restrict__ stats) {
   constexpr uint32_t M = RING - 1;
   const int lane = (int)lane_id();
-  const int b = uni((int)(blockIdx.x * INF_WAVES + (threadIdx.x >> 6)));
-  if (b >= n_blocks) return;
   WaveLds* L = wave_lds<RING>();
   uint8_t* ring = wave_ring<RING>();
   if (lds_addr(smem) != 0) {  // literal_run addresses the ring and the table with immediates (folds away when true)
@@ -897,6 +1339,27 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(const uint8_t* __res
       // the literal/length code LAST: its first[] / offs[] must survive the build (decode_long)
       if (!build_code<RING>(CODE_DIST, 288, 30) || !build_code<RING>(CODE_LIT, 0, 288)) { err = INF_BAD_LENGTHS; break; }
     }
+    if (PAR) {
+      // everything decoded so far must be in HBM: matches of the parallel path read the output buffer
+      drain_to<RING>(o, o.pos);
+      const uint32_t P0 = br.widx * 32u - (uint32_t)br.cnt - blk.comp_offset * 8u;  // bit position inside the member
+      uint32_t end_bit = 0;
+      const int why = uni(par_decode_block<RING>(comp + blk.comp_offset, P0, blk.comp_size * 8u, o, sl, &end_bit, stats));
+      if (lane == 0) atomicAdd(&stats[why & 15], 1u);
+      if (why == 0) {
+        o.make_uniform();
+        end_bit = uniu(end_bit);
+        br.init(comp, blk.comp_offset + (end_bit >> 3), comp_end);
+        br.drop((int)(end_bit & 7u));
+        if (!last) {  // a serial block may follow: it finds the last RING bytes of output in the ring
+          __builtin_amdgcn_s_waitcnt(0);
+          const uint32_t lo = o.pos - o.begin > (uint32_t)RING ? o.pos - (uint32_t)RING : o.begin;
+          for (uint32_t j = lo + (uint32_t)lane; j < o.pos; j += 64) ring[j & M] = out[j];
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        continue;
+      }
+    }
     const SymResult r = decode_symbols<RING>(br, o);
     br = r.br;
     br.make_uniform();
@@ -909,6 +1372,30 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(const uint8_t* __res
   drain_to<RING>(o, o.pos);
   if (err == INF_OK && o.pos != o.end) err = INF_SIZE_MISMATCH;
   if (lane == 0) status[b] = err;
+}
+
+template <int RING>
+__global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks, int n_blocks,
+                                                uint8_t* out, int* __restrict__ status) {
+  const int b = uni((int)(blockIdx.x * INF_WAVES + (threadIdx.x >> 6)));
+  if (b >= n_blocks) return;
+  inflate_member<RING, false>(comp, blocks, b, out, status, ParSlot{}, nullptr);
+}
+
+// The lane-parallel variant: a fixed set of workgroups (one scratch slot each) takes members off a shared counter.
+template <int RING>
+__global__ __launch_bounds__(64) void k_inflate_par(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks, int n_blocks, uint8_t* out,
+                                                    int* __restrict__ status, uint8_t* __restrict__ scratch, unsigned* __restrict__ counter,
+                                                    unsigned* __restrict__ stats) {
+  const ParSlot sl = par_slot(scratch, blockIdx.x);
+  for (;;) {
+    unsigned b = 0;
+    if (lane_id() == 0) b = atomicAdd(counter, 1u);
+    b = uniu(b);
+    if (b >= (unsigned)n_blocks) return;
+    inflate_member<RING, true>(comp, blocks, (int)b, out, status, sl, stats);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
 }
 
 // CRC-32 (IEEE, reflected) of every inflated block: one wavefront per block.  Each lane runs the byte-serial CRC
@@ -1071,13 +1558,85 @@ int exon_hip_bgzf_inflate(exon_hip_ctx* ctx, void* stream, const uint8_t* d_comp
 }  // extern "C"
 
 // Internal (C++): enqueue the inflate (+ CRC) kernels; d_blocks / d_status are device arrays of n_blocks entries.
+namespace {
+// Scratch of the lane-parallel kernel: one slot per resident workgroup, one pool per HIP stream (two scans inflating at the
+// same time must not share slots).  Allocated on first use, kept for the life of the process.
+struct ParPool {
+  uint8_t* scratch = nullptr;
+  unsigned* counter = nullptr;  // [0] next member, [16..32) outcome counters of par_decode_block (0 = decoded in parallel)
+  int slots = 0;
+};
+std::mutex g_par_mu;
+std::map<std::pair<int, hipStream_t>, ParPool> g_par_pools;
+int par_mode() {  // EXON_HIP_INFLATE_PAR: 0 = wavefront-per-member serial symbol loop, 1 = speculative lane-parallel blocks
+  static const int m = [] {
+    const char* e = getenv("EXON_HIP_INFLATE_PAR");
+    return e ? atoi(e) : 0;
+  }();
+  return m;
+}
+int par_slots() {
+  static const int n = [] {
+    const char* e = getenv("EXON_HIP_INFLATE_PAR_SLOTS");
+    const int v = e ? atoi(e) : 4096;
+    return v < 64 ? 64 : v > 16384 ? 16384 : v;
+  }();
+  return n;
+}
+hipError_t par_pool(hipStream_t s, ParPool* out) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> g(g_par_mu);
+  ParPool& p = g_par_pools[std::make_pair(dev, s)];
+  if (!p.scratch) {
+    const int n = par_slots();
+    if ((e = hipMalloc((void**)&p.scratch, (size_t)n * PAR_SLOT_BYTES)) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&p.counter, 64 * sizeof(unsigned))) != hipSuccess) {
+      hipFree(p.scratch);
+      p.scratch = nullptr;
+      return e;
+    }
+    if ((e = hipMemset(p.counter, 0, 64 * sizeof(unsigned))) != hipSuccess) return e;
+    p.slots = n;
+  }
+  *out = p;
+  return hipSuccess;
+}
+}  // namespace
+
+// fallback / success counters of the lane-parallel path on `stream` since the process started (index = reason, 0 = parallel)
+extern "C" int exon_hip_bgzf_inflate_par_stats(void* stream, uint32_t* out16) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || !out16) return -1;
+  std::lock_guard<std::mutex> g(g_par_mu);
+  memset(out16, 0, 16 * sizeof(uint32_t));
+  for (auto& kv : g_par_pools) {  // stream == NULL: all streams of the device
+    if (kv.first.first != dev || !kv.second.counter || (stream && kv.first.second != (hipStream_t)stream)) continue;
+    uint32_t t[16];
+    if (hipMemcpy(t, kv.second.counter + 16, sizeof t, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    for (int i = 0; i < 16; ++i) out16[i] += t[i];
+  }
+  return 0;
+}
+
+// Internal (C++): enqueue the inflate (+ CRC) kernels; d_blocks / d_status are device arrays of n_blocks entries.
 hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const exon_hip_bgzf_block* d_blocks, int n_blocks,
                                     uint8_t* d_out, int* d_status, bool verify_crc) {
   if (n_blocks <= 0) return hipSuccess;
   static_assert(sizeof(Block) == sizeof(exon_hip_bgzf_block), "block layouts must agree");
   const Block* blocks = reinterpret_cast<const Block*>(d_blocks);
-  hipLaunchKernelGGL(k_inflate<INFLATE_RING>, dim3((n_blocks + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), 0, s,
-                     d_comp, blocks, n_blocks, d_out, d_status);
+  if (par_mode() == 1) {
+    ParPool pool;
+    hipError_t e = par_pool(s, &pool);
+    if (e != hipSuccess) return e;
+    if ((e = hipMemsetAsync(pool.counter, 0, sizeof(unsigned), s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_inflate_par<INFLATE_RING>, dim3(std::min(n_blocks, pool.slots)), dim3(64), 0, s, d_comp, blocks, n_blocks, d_out,
+                       d_status, pool.scratch, pool.counter, pool.counter + 16);
+  } else {
+    hipLaunchKernelGGL(k_inflate<INFLATE_RING>, dim3((n_blocks + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), 0, s,
+                       d_comp, blocks, n_blocks, d_out, d_status);
+  }
   if (verify_crc)
     hipLaunchKernelGGL(k_crc32, dim3((n_blocks + WAVES_PER_WG - 1) / WAVES_PER_WG), dim3(WAVES_PER_WG * 64), 0, s, d_out, blocks, n_blocks,
                        d_status);
