@@ -810,22 +810,24 @@ __device__ __noinline__ SymResult decode_symbols(BitReader br, Out o) {
 // ================================================================================================================
 constexpr int PAR_T1 = 512, PAR_T2 = 256;            // token steps per lane: own range / continuation
 constexpr int PAR_BM_WORDS = 16384 + 64;             // one bit per payload bit of a member (<= 64 KiB of DEFLATE data)
-constexpr int PAR_ML = 21888;                        // matches of one member (<= 65536 / 3)
-constexpr size_t PAR_SLOT_BYTES = (size_t)(PAR_T1 + PAR_T2) * 64 * 8 + (size_t)PAR_BM_WORDS * 4 + (size_t)PAR_ML * 8;
+constexpr int PAR_OL = 65536 + 64;                   // ordered output tokens of one member (each yields >= 1 byte)
+constexpr size_t PAR_SLOT_BYTES = (size_t)(PAR_T1 + PAR_T2) * 64 * 8 + (size_t)PAR_BM_WORDS * 4 + (size_t)PAR_OL * 8;
 constexpr uint32_t PAR_MIN_BITS = 64 * 96;           // smaller payloads are not worth the set-up
+constexpr uint32_t PAR_MAX_LANE_BITS = 3072;         // = 24 KiB of DEFLATE data per member
+constexpr uint32_t PAR_WIN = EXON_INFLATE_RING, PAR_SPAN = 1024;  // the window IS the serial path's ring (idle while a block is decoded in parallel)  // phase 5: LDS window of recent output / output bytes per batch of tokens
 struct ParSlot {
   uint64_t* t1;   // [PAR_T1][64]
   uint64_t* t2;   // [PAR_T2][64]
   uint32_t* bm;   // [PAR_BM_WORDS]
-  uint64_t* ml;   // [PAR_ML]  dst (32) | len (9) | dist (16) << 9
+  uint64_t* ol;   // [PAR_OL]  dst (32) | literal byte, or T_MATCH | (len - 1) (len <= 16) | dist << 8
 };
 __device__ __forceinline__ ParSlot par_slot(uint8_t* base, uint32_t slot) {
   uint8_t* p = base + (size_t)slot * PAR_SLOT_BYTES;
   ParSlot s;
   s.t1 = reinterpret_cast<uint64_t*>(p);
   s.t2 = s.t1 + (size_t)PAR_T1 * 64;
-  s.ml = s.t2 + (size_t)PAR_T2 * 64;
-  s.bm = reinterpret_cast<uint32_t*>(s.ml + PAR_ML);
+  s.ol = s.t2 + (size_t)PAR_T2 * 64;
+  s.bm = reinterpret_cast<uint32_t*>(s.ol + PAR_OL);
   return s;
 }
 // token: lo = literal byte | T_MATCH | (len - 3) | (dist - 1) << 8 | T_EOB ; hi = cum (18 bits) | relpos << 18
@@ -849,6 +851,31 @@ __device__ __forceinline__ uint32_t par_long(int which, const uint16_t* count, c
     first <<= 1;
   }
   return E_INVALID;
+}
+
+
+// A match (len, dist) as pieces of <= 16 bytes that never overlap their own source (piece dist >= piece len), so that phase 5
+// copies every piece with one aligned read and one write.  dist >= 16 (or dist >= len): consecutive 16-byte cuts with the
+// match's distance.  A run (dist < len, dist < 16) repeats its `dist` bytes: the first piece copies one period, and every
+// later piece copies from a whole number of periods back, as many bytes as are already there (d, 2d, 4d ... up to 16).
+template <class F>
+__device__ __forceinline__ uint32_t par_pieces(uint32_t len, uint32_t dist, F&& emit) {
+  uint32_t n = 0;
+  if (dist >= 16u || dist >= len) {
+    for (uint32_t q = 0; q < len; q += 16u, ++n) emit(q, min(16u, len - q), dist);
+    return n;
+  }
+  uint32_t w = 0, avail = dist;  // avail = the largest multiple of dist <= w + dist
+  while (w < len) {
+    const uint32_t pl = min(min(16u, len - w), avail);
+    uint32_t pd = dist;
+    while (pd < pl) pd += dist;
+    emit(w, pl, pd);
+    ++n;
+    w += pl;
+    while (avail + dist <= w + dist) avail += dist;
+  }
+  return n;
 }
 
 struct ParSym {
@@ -993,6 +1020,7 @@ __device__ __noinline__ int par_decode_block(const uint8_t* __restrict__ comp /*
   const uint32_t A = P0 & ~31u;
   const uint32_t S = (((P1 - A + 63u) / 64u) + 31u) & ~31u;
   if (S + 64u >= (1u << 14)) return 1;  // relpos field
+  if (S > PAR_MAX_LANE_BITS) return 1;   // literal-heavy members (FASTQ) would run out of token steps: the serial loop is faster there
   const uint32_t rs = lane == 0 ? P0 : A + (uint32_t)lane * S;
   const uint32_t re = min(P1, A + (uint32_t)(lane + 1) * S);
   const int nlanes = (int)((P1 - A + S - 1u) / S);
@@ -1001,7 +1029,7 @@ __device__ __noinline__ int par_decode_block(const uint8_t* __restrict__ comp /*
 
   lap(0);
   // ---- phase 1 ---------------------------------------------------------------------------------------------------
-  uint32_t p = rs, cum = 0, n1 = 0;
+  uint32_t p = rs, cum = 0, n1 = 0, tc = 0;  // tc: output tokens so far (a match counts once per 16 bytes)
   int kind = lane < nlanes && rs < P1 ? PE_RUN : PE_DEAD;
   ParBits pb;
   pb.init(comp, kind == PE_RUN ? rs : P0);
@@ -1021,6 +1049,7 @@ __device__ __noinline__ int par_decode_block(const uint8_t* __restrict__ comp /*
       sl.t1[(size_t)step * 64 + lane] = (uint64_t)sy.tok | ((uint64_t)(cum | ((p - rs) << 18)) << 32);
       ++n1;
       cum += sy.olen;
+      tc += (sy.tok & T_MATCH) ? par_pieces(sy.olen, ((sy.tok >> 8) & 0x7FFFu) + 1u, [](uint32_t, uint32_t, uint32_t) {}) : sy.olen;
       p += sy.bits;
       if (sy.kind != PE_RUN) kind = sy.kind;
       else if (cum >= (1u << 18)) kind = PE_DEAD;
@@ -1053,6 +1082,7 @@ __device__ __noinline__ int par_decode_block(const uint8_t* __restrict__ comp /*
         sl.t2[(size_t)step * 64 + lane] = (uint64_t)sy.tok | ((uint64_t)cum << 32);
         ++cn;
         cum += sy.olen;
+        tc += (sy.tok & T_MATCH) ? par_pieces(sy.olen, ((sy.tok >> 8) & 0x7FFFu) + 1u, [](uint32_t, uint32_t, uint32_t) {}) : sy.olen;
         p += sy.bits;
         if (sy.kind != PE_RUN) ckind = sy.kind;
         else if (cum >= (1u << 18) || p > P1) ckind = PE_DEAD;
@@ -1125,8 +1155,9 @@ __device__ __noinline__ int par_decode_block(const uint8_t* __restrict__ comp /*
   if (o.pos + total > o.end) return 7;
   (void)cum1;
   (void)end_in_cont;
-  uint8_t* const dst0 = o.out + o.pos + obase - cum_k0;  // + cum of a token = its output address
-  uint32_t mcount = 0;
+  // ---- phase 4: the tokens in output order.  Matches are cut into pieces of <= 16 bytes (a copy is byte-sequential, so the
+  // pieces are ordinary matches with the same distance): phase 5 then never runs a long per-lane loop.
+  uint32_t tcount = 0;
   const uint32_t n1max = wave_max_u32(mine ? n1 : 0u), cnmax = wave_max_u32(mine ? cn : 0u);
   // visit(lo, cum) for every valid token of this lane, own list then continuation; 8 coalesced loads in flight per lane
   auto walk = [&](auto&& visit) {
@@ -1151,76 +1182,177 @@ __device__ __noinline__ int par_decode_block(const uint8_t* __restrict__ comp /*
       }
     }
   };
-  walk([&](uint32_t lo, uint32_t c) {
-    if (lo & T_MATCH) ++mcount;
-    else if (!(lo & T_EOB)) dst0[c] = (uint8_t)lo;
-  });
-  uint32_t M;
-  const uint32_t mbase = wave_excl_scan(mcount, &M);
-  if (M > (uint32_t)PAR_ML) return 8;
+  {  // tokens of this lane's list before k0 are not on the true chain: count them out (k0 is small: chains merge early)
+    uint32_t before = 0;
+    const uint32_t k0max = wave_max_u32(mine ? k0 : 0u);
+    for (uint32_t kb = 0; kb < k0max; kb += 8) {
+      uint64_t t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = sl.t1[(size_t)min(kb + j, (uint32_t)PAR_T1 - 1u) * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t lo = (uint32_t)t[j];
+        if (mine && kb + j < k0)
+          before += (lo & T_MATCH) ? par_pieces((lo & 255u) + 3u, ((lo >> 8) & 0x7FFFu) + 1u, [](uint32_t, uint32_t, uint32_t) {}) : ((lo & T_EOB) ? 0u : 1u);
+      }
+    }
+    tcount = mine ? tc - before : 0u;
+  }
+  uint32_t T;
+  const uint32_t tbase = wave_excl_scan(tcount, &T);
+  if (T > (uint32_t)PAR_OL - 64u) return 8;
   {
-    uint32_t mi = mbase;
+    uint32_t ti = tbase;
     const uint32_t dpos0 = o.pos + obase - cum_k0;
     walk([&](uint32_t lo, uint32_t c) {
-      if (lo & T_MATCH) sl.ml[mi++] = (uint64_t)(dpos0 + c) | ((uint64_t)(((lo & 255u) + 3u) | ((((lo >> 8) & 0x7FFFu) + 1u) << 9)) << 32);
+      if (lo & T_MATCH) {
+        par_pieces((lo & 255u) + 3u, ((lo >> 8) & 0x7FFFu) + 1u, [&](uint32_t q, uint32_t pl, uint32_t pd) {
+          sl.ol[ti++] = (uint64_t)(dpos0 + c + q) | ((uint64_t)(T_MATCH | (pl - 1u) | (pd << 8)) << 32);
+        });
+      } else if (!(lo & T_EOB)) {
+        sl.ol[ti++] = (uint64_t)(dpos0 + c) | ((uint64_t)(lo & 255u) << 32);
+      }
     });
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
   lap(4);
-  // ---- phase 5: matches, 64 at a time, one per lane, in dependency rounds -----------------------------------------
-  uint8_t* const out = o.out;
-  int bad = 0;
-  for (uint32_t i0 = 0; i0 < M; i0 += 64) {
-    const bool have = i0 + (uint32_t)lane < M;
-    const uint64_t rec = have ? sl.ml[i0 + lane] : 0ull;
-    const uint32_t dst = (uint32_t)rec, len = (uint32_t)(rec >> 32) & 511u, dist = (uint32_t)(rec >> 41);
-    if (have && dist > dst - o.begin) bad = 1;  // reaches before the start of the member's output
-    if (__any(bad)) return 9;
-    const uint32_t src = dst - dist;
-    bool done = !have;
-    for (;;) {
-      const unsigned long long pend = __ballot(!done);
-      if (!pend) break;
-      const int f = __ffsll((long long)pend) - 1;
-      const uint32_t dst_f = (uint32_t)__builtin_amdgcn_readlane((int)dst, f);
-      const bool go = !done && (lane == f || src + min(len, dist) <= dst_f);
-      if (go) {
-        if (dist >= len) {  // source and destination do not overlap: 32 bytes per trip, all loads before the stores
-          for (uint32_t q = 0; q < len; q += 32) {
-            const uint32_t nb = min(32u, len - q);
-            uint32_t v[8];
+  // ---- phase 5: replay through an LDS window, 64 tokens at a time -------------------------------------------------
+  // The window holds output bytes [batch end - PW, batch end) (slot = position mod PW); rows of 256 complete bytes are
+  // flushed to HBM as the serial kernel's ring does.  Literals store their byte; a match whose source starts below the
+  // window ("far") copies from HBM -- such a source always lies below `drained` (PW - PSPAN > 258 + 255) -- the others copy
+  // inside the window in dependency rounds: a piece runs once its source ends below the first unfinished piece.
+  {
+    constexpr uint32_t PM = PAR_WIN - 1u;
+    uint8_t* const out = o.out;
+    uint8_t* const win = wave_ring<RING>();
+    static_assert(PAR_WIN - PAR_SPAN > 258 + 255 + 16, "far sources must end below the drained rows");
+    uint32_t pos = o.pos, drained = o.pos;
+    // bytes of earlier DEFLATE blocks of this member that a near match may reach (they are in HBM: the caller drained)
+    const uint32_t hist = min(o.pos - o.begin, PAR_WIN - PAR_SPAN - 530u);
+    const uint32_t wvalid = o.pos - hist;
+    for (uint32_t x = wvalid + (uint32_t)lane; x < o.pos; x += 64) win[x & PM] = out[x];
+    auto flush_to = [&](uint32_t limit) {  // window -> HBM for [drained, limit)
+      while (drained < limit) {
+        const uint32_t row_end = min(limit, (drained | 255u) + 1u);
+        if (((drained | row_end) & 3u) == 0) {
+          const uint32_t x = drained + 4u * (uint32_t)lane;
+          if (x < row_end) *reinterpret_cast<uint32_t*>(out + x) = *reinterpret_cast<const uint32_t*>(win + (x & PM));
+        } else {
+          for (uint32_t x = drained + (uint32_t)lane; x < row_end; x += 64) out[x] = win[x & PM];
+        }
+        drained = row_end;
+      }
+    };
+    int bad = 0;
+#ifdef EXON_INFLATE_PROFILE
+    uint64_t t_wait = 0, t_rounds = 0;
+    uint32_t n_batches = 0, n_rounds = 0;
+#endif
+    uint64_t rec = (uint32_t)lane < T ? sl.ol[lane] : ~0ull;
+    for (uint32_t i0 = 0; i0 < T;) {
+      const uint32_t dst = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
+      const bool is_match = (hi & T_MATCH) != 0;
+      const uint32_t len = is_match ? (hi & 15u) + 1u : 1u, dist = (hi >> 8) & 0xFFFFu;
+      const bool fits = i0 + (uint32_t)lane < T && dst + len - pos <= PAR_SPAN;
+      const uint32_t nb = (uint32_t)__popcll(__ballot(fits));  // dst increases with the lane: the fitting tokens are a prefix; >= 1
+      const bool have = (uint32_t)lane < nb;
+      const uint32_t bend = (uint32_t)__builtin_amdgcn_readlane((int)(dst + len), (int)nb - 1);
+      const uint32_t lo_valid = max(wvalid, bend > PAR_WIN ? bend - PAR_WIN : 0u);
+      if (have && is_match && dist > dst - o.begin) bad = 1;  // reaches before the start of the member's output
+      if (__any(bad)) return 9;
+      const uint32_t src = dst - dist;
+      const bool far = have && is_match && src < lo_valid;
+      bool pending = have && is_match && !far;
+      // vector memory, in this order: rows completed by the previous batch -> HBM (stores); the next batch's records and
+      // this batch's far sources (loads).  ONE wait then covers all of it (the counter is in-order: a load waits for
+      // every older store anyway).
+      if ((pos & ~255u) > drained) flush_to(pos & ~255u);
+      const uint32_t inext = i0 + nb;
+      const uint64_t rec_next = inext + (uint32_t)lane < T ? sl.ol[inext + lane] : ~0ull;
+      uint32_t v[4] = {0, 0, 0, 0};
+      if (far) {  // the source ends below `drained`
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-              if ((uint32_t)(4 * i) < nb) __builtin_memcpy(&v[i], out + src + q + 4 * i, 4);  // reads < 4 bytes past the source: unused
+        for (int i = 0; i < 4; ++i)
+          if ((uint32_t)(4 * i) < len) __builtin_memcpy(&v[i], out + src + 4 * i, 4);
+      }
+#ifdef EXON_INFLATE_PROFILE
+      const uint64_t tw0 = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_waitcnt(0);
+      const uint64_t tw1 = __builtin_amdgcn_s_memtime();
+      t_wait += tw1 - tw0;
+      ++n_batches;
+#endif
+      // `len` (<= 16) bytes held in v[0..3] -> window at dst: bytes up to the first dword boundary, whole dwords, tail bytes
+      // (10 LDS stores at most instead of 16; a read-modify-write of the edge dwords would race with the neighbour piece)
+      auto put = [&](const uint32_t* v, uint32_t dst, uint32_t len) {
+        const uint32_t head = min(len, (0u - dst) & 3u);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              if ((uint32_t)(4 * i + 4) <= nb) {
-                __builtin_memcpy(out + dst + q + 4 * i, &v[i], 4);
-              } else if ((uint32_t)(4 * i) < nb) {
-                for (uint32_t b = 0; b < nb - 4 * i; ++b) out[dst + q + 4 * i + b] = (uint8_t)(v[i] >> (8 * b));
-              }
-            }
-          }
-        } else {  // overlapping run: every byte comes from the `dist` bytes before the match; 8 loads in flight
-          for (uint32_t q = 0; q < len; q += 8) {
-            uint8_t v[8];
+        for (int i = 0; i < 3; ++i)
+          if ((uint32_t)i < head) win[(dst + i) & PM] = (uint8_t)(v[0] >> (8 * i));
+        // the stream re-aligned to the first dword boundary: w[j] = bytes head + 4 j .. of v
+        const uint32_t body = (len - head) >> 2;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = out[src + (q + i) % dist];
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-              if (q + i < len) out[dst + q + i] = v[i];
+        for (int j = 0; j < 4; ++j) {
+          if ((uint32_t)j < body) {
+            const uint32_t lo_w = v[j], hi_w = j + 1 < 4 ? v[j + 1] : 0u;
+            const uint32_t w = head == 0 ? lo_w : (lo_w >> (8 * head)) | (hi_w << (32 - 8 * head));
+            *reinterpret_cast<uint32_t*>(win + ((dst + head + 4 * j) & PM)) = w;
           }
         }
-        done = true;
-      }
-      // the next round reads what this one wrote: memory operations of ONE wavefront reach the cache hierarchy in program
-      // order (the same guarantee plain C code relies on for a store followed by a load), so no wait is needed here
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#ifdef EXON_INFLATE_PAR_WAIT
-      __builtin_amdgcn_s_waitcnt(0);
+        const uint32_t tail0 = head + 4 * body;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const uint32_t q = tail0 + i;
+          if (q < len) win[(dst + q) & PM] = (uint8_t)(v[q >> 2 & 3] >> (8 * (q & 3)));
+        }
+      };
+      // `len` (<= 16) bytes of the window starting at src -> v[0..3]: five aligned dwords, byte-aligned in registers
+      auto get = [&](uint32_t src, uint32_t* v) {
+        const uint32_t a = src & ~3u, sh = src & 3u;
+        uint32_t d[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) d[i] = *reinterpret_cast<const uint32_t*>(win + ((a + 4 * i) & PM));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
+      };
+      if (have && !is_match) win[dst & PM] = (uint8_t)hi;
+      if (far) put(v, dst, len);
+#ifdef EXON_INFLATE_PROFILE
+      const uint64_t tr0 = __builtin_amdgcn_s_memtime();
 #endif
+      while (__any(pending)) {
+#ifdef EXON_INFLATE_PROFILE
+        ++n_rounds;
+#endif
+        const int f = __ffsll((long long)__ballot(pending)) - 1;
+        const uint32_t dst_f = (uint32_t)__builtin_amdgcn_readlane((int)dst, f);
+        if (pending && (lane == f || src + len <= dst_f)) {
+          uint32_t w[4];
+          get(src, w);  // pieces never overlap their source (par_pieces)
+          put(w, dst, len);
+          pending = false;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
+#ifdef EXON_INFLATE_PROFILE
+      __builtin_amdgcn_s_waitcnt(0);
+      t_rounds += __builtin_amdgcn_s_memtime() - tr0;
+#endif
+      pos = bend;
+      i0 = inext;
+      rec = rec_next;
     }
+#ifdef EXON_INFLATE_PROFILE
+    if (lane == 0) {
+      atomicAdd(&stats[16], (unsigned)(t_wait >> 10));
+      atomicAdd(&stats[17], (unsigned)(t_rounds >> 10));
+      atomicAdd(&stats[18], n_batches);
+      atomicAdd(&stats[19], n_rounds);
+    }
+#endif
+    flush_to(pos);
+    if (pos != o.pos + total) return 10;
   }
   lap(5);
   o.pos += total;
@@ -1384,7 +1516,7 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(const uint8_t* __res
 
 // The lane-parallel variant: a fixed set of workgroups (one scratch slot each) takes members off a shared counter.
 template <int RING>
-__global__ __launch_bounds__(64) void k_inflate_par(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks, int n_blocks, uint8_t* out,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_inflate_par(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks, int n_blocks, uint8_t* out,
                                                     int* __restrict__ status, uint8_t* __restrict__ scratch, unsigned* __restrict__ counter,
                                                     unsigned* __restrict__ stats) {
   const ParSlot sl = par_slot(scratch, blockIdx.x);
@@ -1588,16 +1720,28 @@ hipError_t par_pool(hipStream_t s, ParPool* out) {
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
   std::lock_guard<std::mutex> g(g_par_mu);
-  ParPool& p = g_par_pools[std::make_pair(dev, s)];
+  auto key = std::make_pair(dev, s);
+  if (!g_par_pools.count(key) && g_par_pools.size() >= 4) {  // pools are never freed: more streams than this inflate serially
+    *out = ParPool();
+    return hipSuccess;
+  }
+  ParPool& p = g_par_pools[key];
   if (!p.scratch) {
     const int n = par_slots();
-    if ((e = hipMalloc((void**)&p.scratch, (size_t)n * PAR_SLOT_BYTES)) != hipSuccess) return e;
-    if ((e = hipMalloc((void**)&p.counter, 64 * sizeof(unsigned))) != hipSuccess) {
+    // no memory for the scratch (or the counters): this stream inflates serially; nothing is an error
+    if (hipMalloc((void**)&p.scratch, (size_t)n * PAR_SLOT_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      p.scratch = nullptr;
+      *out = ParPool();
+      return hipSuccess;
+    }
+    if (hipMalloc((void**)&p.counter, 64 * sizeof(unsigned)) != hipSuccess || hipMemset(p.counter, 0, 64 * sizeof(unsigned)) != hipSuccess) {
+      (void)hipGetLastError();
       hipFree(p.scratch);
       p.scratch = nullptr;
-      return e;
+      *out = ParPool();
+      return hipSuccess;
     }
-    if ((e = hipMemset(p.counter, 0, 64 * sizeof(unsigned))) != hipSuccess) return e;
     p.slots = n;
   }
   *out = p;
@@ -1606,16 +1750,16 @@ hipError_t par_pool(hipStream_t s, ParPool* out) {
 }  // namespace
 
 // fallback / success counters of the lane-parallel path on `stream` since the process started (index = reason, 0 = parallel)
-extern "C" int exon_hip_bgzf_inflate_par_stats(void* stream, uint32_t* out16) {
+extern "C" int exon_hip_bgzf_inflate_par_stats(void* stream, uint32_t* out16 /* 32 entries */) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || !out16) return -1;
   std::lock_guard<std::mutex> g(g_par_mu);
-  memset(out16, 0, 16 * sizeof(uint32_t));
+  memset(out16, 0, 32 * sizeof(uint32_t));
   for (auto& kv : g_par_pools) {  // stream == NULL: all streams of the device
     if (kv.first.first != dev || !kv.second.counter || (stream && kv.first.second != (hipStream_t)stream)) continue;
-    uint32_t t[16];
+    uint32_t t[32];
     if (hipMemcpy(t, kv.second.counter + 16, sizeof t, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    for (int i = 0; i < 16; ++i) out16[i] += t[i];
+    for (int i = 0; i < 32; ++i) out16[i] += t[i];
   }
   return 0;
 }
@@ -1630,9 +1774,14 @@ hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const 
     ParPool pool;
     hipError_t e = par_pool(s, &pool);
     if (e != hipSuccess) return e;
+    if (pool.scratch) {
     if ((e = hipMemsetAsync(pool.counter, 0, sizeof(unsigned), s)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_inflate_par<INFLATE_RING>, dim3(std::min(n_blocks, pool.slots)), dim3(64), 0, s, d_comp, blocks, n_blocks, d_out,
                        d_status, pool.scratch, pool.counter, pool.counter + 16);
+    } else {
+      hipLaunchKernelGGL(k_inflate<INFLATE_RING>, dim3((n_blocks + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), 0, s, d_comp, blocks, n_blocks,
+                         d_out, d_status);
+    }
   } else {
     hipLaunchKernelGGL(k_inflate<INFLATE_RING>, dim3((n_blocks + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), 0, s,
                        d_comp, blocks, n_blocks, d_out, d_status);

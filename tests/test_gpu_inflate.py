@@ -172,3 +172,26 @@ def test_gpu_inflate_fuzz_many_blocks_one_launch(ctx):
         want.append(data)
     got, _ = ctx.bgzf_inflate(b"".join(blocks))
     assert got.tobytes() == b"".join(want)
+
+
+@pytest.mark.gpu
+def test_lane_parallel_block_decoder_in_a_fresh_process():
+    """EXON_HIP_INFLATE_PAR=1 (speculative lane-parallel DEFLATE blocks, default off) is read once per process: this module's
+    cases, the indexed region scans and the BAM pipeline rerun under it in a subprocess -- byte equality with zlib, CRC
+    verification and corruption reports must not depend on which decoder ran."""
+    import subprocess
+    import sys
+    env = dict(os.environ, EXON_HIP_INFLATE_PAR="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "--timeout", "300", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_gpu_inflate.py"), os.path.join(ROOT, "tests", "test_gpu_region_pushdown.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_bam_parse.py"),
+                        "-k", "not fresh_process"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    # and the parallel path did decode members (a silent fall-back to the serial loop would prove nothing)
+    code = ("import exon_amd, ctypes, numpy as np, sys; sys.path.insert(0, %r); import test_gpu_inflate as t;"
+            "ctx = exon_amd.Context(0); raw = t.bgzf_file(t.vcf_like(40000)); got, _ = ctx.bgzf_inflate(raw);"
+            "st = (ctypes.c_uint32 * 32)(); ctx.lib.exon_hip_bgzf_inflate_par_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p];"
+            "assert ctx.lib.exon_hip_bgzf_inflate_par_stats(None, st) == 0; print(st[0])") % os.path.join(ROOT, "tests")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert int(r.stdout.strip().splitlines()[-1]) > 10

@@ -36,7 +36,7 @@ tz = time.perf_counter() - t
 print(f"host: block scan {consumed / ts / 1e9:.1f} GB/s; zlib 1 thread {o / tz / 1e6:.0f} MB/s out")
 try:  # outcome counters of the lane-parallel path (EXON_HIP_INFLATE_PAR=1): index 0 = blocks decoded in parallel
     import ctypes
-    st = (ctypes.c_uint32 * 16)()
+    st = (ctypes.c_uint32 * 32)()
     ctx.lib.exon_hip_bgzf_inflate_par_stats.restype = ctypes.c_int
     ctx.lib.exon_hip_bgzf_inflate_par_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     import exon_amd._lib as _L
