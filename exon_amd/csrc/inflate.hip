@@ -1695,8 +1695,10 @@ namespace {
 // same time must not share slots).  Allocated on first use, kept for the life of the process.
 struct ParPool {
   uint8_t* scratch = nullptr;
-  unsigned* counter = nullptr;  // [0] next member, [16..32) outcome counters of par_decode_block (0 = decoded in parallel)
+  unsigned* counter = nullptr;  // [0] next member, [16..48) outcome counters of par_decode_block (0 = decoded in parallel)
   int slots = 0;
+  hipStream_t side = nullptr;   // hybrid mode: the serial kernel's share of a launch runs here, beside the parallel one
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 std::mutex g_par_mu;
 std::map<std::pair<int, hipStream_t>, ParPool> g_par_pools;
@@ -1706,6 +1708,14 @@ int par_mode() {  // EXON_HIP_INFLATE_PAR: 0 = wavefront-per-member serial symbo
     return e ? atoi(e) : 0;
   }();
   return m;
+}
+double par_serial_share() {  // hybrid mode: fraction of a launch's members given to the serial kernel
+  static const double r = [] {
+    const char* e = getenv("EXON_HIP_INFLATE_PAR_SERIAL_SHARE");
+    const double v = e ? atof(e) : 0.4;
+    return v < 0 ? 0.0 : v > 0.95 ? 0.95 : v;
+  }();
+  return r;
 }
 int par_slots() {
   static const int n = [] {
@@ -1743,6 +1753,11 @@ hipError_t par_pool(hipStream_t s, ParPool* out) {
       return hipSuccess;
     }
     p.slots = n;
+    if (hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p.ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p.ev_join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      p.side = nullptr;  // no hybrid mode on this stream
+    }
   }
   *out = p;
   return hipSuccess;
@@ -1770,14 +1785,26 @@ hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const 
   if (n_blocks <= 0) return hipSuccess;
   static_assert(sizeof(Block) == sizeof(exon_hip_bgzf_block), "block layouts must agree");
   const Block* blocks = reinterpret_cast<const Block*>(d_blocks);
-  if (par_mode() == 1) {
+  if (par_mode() >= 1) {
     ParPool pool;
     hipError_t e = par_pool(s, &pool);
     if (e != hipSuccess) return e;
     if (pool.scratch) {
-    if ((e = hipMemsetAsync(pool.counter, 0, sizeof(unsigned), s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_inflate_par<INFLATE_RING>, dim3(std::min(n_blocks, pool.slots)), dim3(64), 0, s, d_comp, blocks, n_blocks, d_out,
-                       d_status, pool.scratch, pool.counter, pool.counter + 16);
+      // mode 2 (hybrid): the serial kernel is bound by the CU's one scalar unit, the parallel one by vector issue and memory
+      // latency -- a share of the members goes to each, on two streams, so that they run side by side on every CU
+      int n_ser = 0;
+      if (par_mode() == 2 && pool.side && n_blocks >= 256) n_ser = (int)((double)n_blocks * par_serial_share());
+      if (n_ser > 0) {
+        if ((e = hipEventRecord(pool.ev_fork, s)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(pool.side, pool.ev_fork, 0)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_inflate<INFLATE_RING>, dim3(n_ser), dim3(64), 0, pool.side, d_comp, blocks, n_ser, d_out, d_status);
+        if ((e = hipEventRecord(pool.ev_join, pool.side)) != hipSuccess) return e;
+      }
+      const int n_par = n_blocks - n_ser;
+      if ((e = hipMemsetAsync(pool.counter, 0, sizeof(unsigned), s)) != hipSuccess) return e;
+      hipLaunchKernelGGL(k_inflate_par<INFLATE_RING>, dim3(std::min(n_par, pool.slots)), dim3(64), 0, s, d_comp, blocks + n_ser, n_par, d_out,
+                         d_status + n_ser, pool.scratch, pool.counter, pool.counter + 16);
+      if (n_ser > 0 && (e = hipStreamWaitEvent(s, pool.ev_join, 0)) != hipSuccess) return e;
     } else {
       hipLaunchKernelGGL(k_inflate<INFLATE_RING>, dim3((n_blocks + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), 0, s, d_comp, blocks, n_blocks,
                          d_out, d_status);
