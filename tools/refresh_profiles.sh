@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates every rocprofv3 summary the docs quote, at HEAD, on the GPU box:  tools/refresh_profiles.sh r2
-#   (note: `bench.py` under --kernel-trace pays tens of microseconds per launch: its JSON is not a throughput figure for c5's 30
+#   (note: `bench.py` under --kernel-trace pays tens of microseconds per launch: its JSON is not a throughput figure for the per-batch c5 path's many
 #   launches per step; the quoted bench lines come from unprofiled runs, profiles/<round>_bench_<wl>_1gpu.json)
 #   gpurun_out/prof_<round>/<wl>_kernel_stats.csv     rocprofv3 --kernel-trace --stats of `bench.py --workload <wl>`
 #   gpurun_out/pmc_fetch|pmc_write/<wl>_counter_collection.csv   separate --pmc FETCH_SIZE / WRITE_SIZE passes (kernel trace only)
@@ -28,7 +28,7 @@ run_wl() {  # workload rows steps
 WHAT=${2:-"c4 c2 c3 c6 c5 pipelines"}   # second argument: a subset, e.g. "c5"
 for w in $WHAT; do
   case $w in
-    c5) run_wl c5 2e8 10 ;;
+    c5) run_wl c5 1e9 6 ;;
     c2|c3|c4|c6) run_wl $w 1e9 20 ;;
   esac
 done
