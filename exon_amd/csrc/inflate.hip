@@ -1691,21 +1691,17 @@ int exon_hip_bgzf_inflate(exon_hip_ctx* ctx, void* stream, const uint8_t* d_comp
 
 // Internal (C++): enqueue the inflate (+ CRC) kernels; d_blocks / d_status are device arrays of n_blocks entries.
 namespace {
-// Scratch of the lane-parallel kernel: one slot per resident workgroup, one pool per HIP stream (two scans inflating at the
-// same time must not share slots).  Allocated on first use, kept for the life of the process.
-struct ParPool {
-  uint8_t* scratch = nullptr;
-  unsigned* counter = nullptr;  // [0] next member, [16..48) outcome counters of par_decode_block (0 = decoded in parallel)
-  int slots = 0;
-  hipStream_t side = nullptr;   // hybrid mode: the serial kernel's share of a launch runs here, beside the parallel one
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-};
-std::mutex g_par_mu;
-std::map<std::pair<int, hipStream_t>, ParPool> g_par_pools;
-int par_mode() {  // EXON_HIP_INFLATE_PAR: 0 = wavefront-per-member serial symbol loop, 1 = speculative lane-parallel blocks
+// Which decoder a launch uses (EXON_HIP_INFLATE_PAR):
+//   unset  auto: the lane-parallel decoder for launches of at most PAR_AUTO_MAX members, the serial one above that.  A
+//          member alone takes ~2.5 ms through the serial symbol loop and ~0.5 ms through the parallel one, so small files,
+//          index chunks and first slabs finish 3x sooner; a machine-full of members (a pipeline slab) is the serial
+//          kernel's best case, and far above that the parallel one wins again by 1.26x (profiles/r2_tuning.md)
+//   0      serial always      1  lane-parallel always      2  both side by side (a share of the members each)
+constexpr int PAR_AUTO_MAX = 1536;
+int par_mode() {
   static const int m = [] {
     const char* e = getenv("EXON_HIP_INFLATE_PAR");
-    return e ? atoi(e) : 0;
+    return e && *e ? atoi(e) : -1;
   }();
   return m;
 }
@@ -1717,7 +1713,7 @@ double par_serial_share() {  // hybrid mode: fraction of a launch's members give
   }();
   return r;
 }
-int par_slots() {
+int par_slots() {  // resident workgroups of the parallel kernel = scratch slots (16 per CU on 256 CUs)
   static const int n = [] {
     const char* e = getenv("EXON_HIP_INFLATE_PAR_SLOTS");
     const int v = e ? atoi(e) : 4096;
@@ -1725,94 +1721,132 @@ int par_slots() {
   }();
   return n;
 }
-hipError_t par_pool(hipStream_t s, ParPool* out) {
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return e;
+// per device: outcome counters of par_decode_block (64 words, never freed) and, for the hybrid mode, a side stream per
+// caller stream with its fork / join events
+struct ParDev {
+  unsigned* stats = nullptr;
+};
+struct ParSide {
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+};
+// scratch of the parallel kernel: 256 bytes (work counter) + one slot per workgroup, per caller stream (two scans inflating
+// at the same time must not share slots).  Grows to the largest launch seen on the stream, is never freed otherwise.
+// (hipMallocAsync / hipFreeAsync per launch would be the natural fit; on ROCm 7.0 the file pipeline then stalls with an idle
+// GPU after its second slab -- the inflate stream never runs again -- so the pools are managed here.)
+struct ParPool {
+  uint8_t* mem = nullptr;
+  int slots = 0;
+};
+std::map<std::pair<int, hipStream_t>, ParPool> g_par_pools;
+std::mutex g_par_mu;
+std::map<int, ParDev> g_par_dev;
+std::map<std::pair<int, hipStream_t>, ParSide> g_par_side;
+unsigned* par_stats_buffer(int dev) {
+  std::lock_guard<std::mutex> g(g_par_mu);
+  ParDev& d = g_par_dev[dev];
+  if (!d.stats) {
+    if (hipMalloc((void**)&d.stats, 64 * sizeof(unsigned)) != hipSuccess || hipMemset(d.stats, 0, 64 * sizeof(unsigned)) != hipSuccess) {
+      (void)hipGetLastError();
+      d.stats = nullptr;
+    }
+  }
+  return d.stats;
+}
+uint8_t* par_pool(int dev, hipStream_t s, int want) {
   std::lock_guard<std::mutex> g(g_par_mu);
   auto key = std::make_pair(dev, s);
-  if (!g_par_pools.count(key) && g_par_pools.size() >= 4) {  // pools are never freed: more streams than this inflate serially
-    *out = ParPool();
-    return hipSuccess;
-  }
+  if (!g_par_pools.count(key) && g_par_pools.size() >= 8) return nullptr;  // more streams than this inflate serially
   ParPool& p = g_par_pools[key];
-  if (!p.scratch) {
-    const int n = par_slots();
-    // no memory for the scratch (or the counters): this stream inflates serially; nothing is an error
-    if (hipMalloc((void**)&p.scratch, (size_t)n * PAR_SLOT_BYTES) != hipSuccess) {
-      (void)hipGetLastError();
-      p.scratch = nullptr;
-      *out = ParPool();
-      return hipSuccess;
+  if (p.slots < want) {
+    int n = 64;
+    while (n < want) n *= 2;
+    if (p.mem) {  // kernels queued on `s` may still use the old block
+      if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
+      hipFree(p.mem);
+      p.mem = nullptr;
+      p.slots = 0;
     }
-    if (hipMalloc((void**)&p.counter, 64 * sizeof(unsigned)) != hipSuccess || hipMemset(p.counter, 0, 64 * sizeof(unsigned)) != hipSuccess) {
+    if (hipMalloc((void**)&p.mem, 256 + (size_t)n * PAR_SLOT_BYTES) != hipSuccess) {
       (void)hipGetLastError();
-      hipFree(p.scratch);
-      p.scratch = nullptr;
-      *out = ParPool();
-      return hipSuccess;
+      p.mem = nullptr;
+      return nullptr;
     }
     p.slots = n;
+  }
+  return p.mem;
+}
+bool par_side(int dev, hipStream_t s, ParSide* out) {
+  std::lock_guard<std::mutex> g(g_par_mu);
+  auto key = std::make_pair(dev, s);
+  if (!g_par_side.count(key) && g_par_side.size() >= 8) return false;
+  ParSide& p = g_par_side[key];
+  if (!p.side) {
     if (hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p.ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p.ev_join, hipEventDisableTiming) != hipSuccess) {
       (void)hipGetLastError();
-      p.side = nullptr;  // no hybrid mode on this stream
+      g_par_side.erase(key);
+      return false;
     }
   }
   *out = p;
-  return hipSuccess;
+  return true;
 }
 }  // namespace
 
-// fallback / success counters of the lane-parallel path on `stream` since the process started (index = reason, 0 = parallel)
-extern "C" int exon_hip_bgzf_inflate_par_stats(void* stream, uint32_t* out16 /* 32 entries */) {
+// outcome counters of the lane-parallel path on the current device since the process started (index 0 = blocks decoded in
+// parallel, 1..15 = blocks handed back to the serial loop, by reason); `stream` is ignored (kept for the ABI)
+extern "C" int exon_hip_bgzf_inflate_par_stats(void* stream, uint32_t* out32) {
+  (void)stream;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || !out16) return -1;
-  std::lock_guard<std::mutex> g(g_par_mu);
-  memset(out16, 0, 32 * sizeof(uint32_t));
-  for (auto& kv : g_par_pools) {  // stream == NULL: all streams of the device
-    if (kv.first.first != dev || !kv.second.counter || (stream && kv.first.second != (hipStream_t)stream)) continue;
-    uint32_t t[32];
-    if (hipMemcpy(t, kv.second.counter + 16, sizeof t, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    for (int i = 0; i < 32; ++i) out16[i] += t[i];
+  if (hipGetDevice(&dev) != hipSuccess || !out32) return -1;
+  memset(out32, 0, 32 * sizeof(uint32_t));
+  unsigned* st = nullptr;
+  {
+    std::lock_guard<std::mutex> g(g_par_mu);
+    auto it = g_par_dev.find(dev);
+    if (it != g_par_dev.end()) st = it->second.stats;
   }
-  return 0;
+  if (!st) return 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return hipMemcpy(out32, st, 32 * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 
-// Internal (C++): enqueue the inflate (+ CRC) kernels; d_blocks / d_status are device arrays of n_blocks entries.
 hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const exon_hip_bgzf_block* d_blocks, int n_blocks,
                                     uint8_t* d_out, int* d_status, bool verify_crc) {
   if (n_blocks <= 0) return hipSuccess;
   static_assert(sizeof(Block) == sizeof(exon_hip_bgzf_block), "block layouts must agree");
   const Block* blocks = reinterpret_cast<const Block*>(d_blocks);
-  if (par_mode() >= 1) {
-    ParPool pool;
-    hipError_t e = par_pool(s, &pool);
-    if (e != hipSuccess) return e;
-    if (pool.scratch) {
-      // mode 2 (hybrid): the serial kernel is bound by the CU's one scalar unit, the parallel one by vector issue and memory
-      // latency -- a share of the members goes to each, on two streams, so that they run side by side on every CU
-      int n_ser = 0;
-      if (par_mode() == 2 && pool.side && n_blocks >= 256) n_ser = (int)((double)n_blocks * par_serial_share());
+  const int mode = par_mode();
+  bool parallel = mode >= 1 || (mode < 0 && n_blocks <= PAR_AUTO_MAX);
+  int dev = 0;
+  unsigned* stats = nullptr;
+  uint8_t* scratch = nullptr;
+  int n_ser = 0, n_wg = 0;
+  if (parallel) {
+    // scratch: one slot per workgroup + the work counter; anything that fails here just means "decode serially"
+    parallel = hipGetDevice(&dev) == hipSuccess && (stats = par_stats_buffer(dev)) != nullptr;
+    ParSide side;
+    if (parallel && mode == 2 && n_blocks >= 256 && par_side(dev, s, &side)) n_ser = (int)((double)n_blocks * par_serial_share());
+    n_wg = std::min(n_blocks - n_ser, par_slots());
+    if (parallel && !(scratch = par_pool(dev, s, n_wg))) parallel = false;
+    if (parallel) {
+      hipError_t e;
+      if ((e = hipMemsetAsync(scratch, 0, 256, s)) != hipSuccess) return e;
       if (n_ser > 0) {
-        if ((e = hipEventRecord(pool.ev_fork, s)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(pool.side, pool.ev_fork, 0)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_inflate<INFLATE_RING>, dim3(n_ser), dim3(64), 0, pool.side, d_comp, blocks, n_ser, d_out, d_status);
-        if ((e = hipEventRecord(pool.ev_join, pool.side)) != hipSuccess) return e;
+        if ((e = hipEventRecord(side.ev_fork, s)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(side.side, side.ev_fork, 0)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_inflate<INFLATE_RING>, dim3(n_ser), dim3(64), 0, side.side, d_comp, blocks, n_ser, d_out, d_status);
+        if ((e = hipEventRecord(side.ev_join, side.side)) != hipSuccess) return e;
       }
-      const int n_par = n_blocks - n_ser;
-      if ((e = hipMemsetAsync(pool.counter, 0, sizeof(unsigned), s)) != hipSuccess) return e;
-      hipLaunchKernelGGL(k_inflate_par<INFLATE_RING>, dim3(std::min(n_par, pool.slots)), dim3(64), 0, s, d_comp, blocks + n_ser, n_par, d_out,
-                         d_status + n_ser, pool.scratch, pool.counter, pool.counter + 16);
-      if (n_ser > 0 && (e = hipStreamWaitEvent(s, pool.ev_join, 0)) != hipSuccess) return e;
-    } else {
-      hipLaunchKernelGGL(k_inflate<INFLATE_RING>, dim3((n_blocks + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), 0, s, d_comp, blocks, n_blocks,
-                         d_out, d_status);
+      hipLaunchKernelGGL(k_inflate_par<INFLATE_RING>, dim3(n_wg), dim3(64), 0, s, d_comp, blocks + n_ser, n_blocks - n_ser, d_out, d_status + n_ser,
+                         scratch + 256, reinterpret_cast<unsigned*>(scratch), stats);
+      if (n_ser > 0 && (e = hipStreamWaitEvent(s, side.ev_join, 0)) != hipSuccess) return e;
     }
-  } else {
-    hipLaunchKernelGGL(k_inflate<INFLATE_RING>, dim3((n_blocks + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), 0, s,
-                       d_comp, blocks, n_blocks, d_out, d_status);
   }
+  if (!parallel)
+    hipLaunchKernelGGL(k_inflate<INFLATE_RING>, dim3((n_blocks + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), 0, s, d_comp, blocks, n_blocks,
+                       d_out, d_status);
   if (verify_crc)
     hipLaunchKernelGGL(k_crc32, dim3((n_blocks + WAVES_PER_WG - 1) / WAVES_PER_WG), dim3(WAVES_PER_WG * 64), 0, s, d_out, blocks, n_blocks,
                        d_status);

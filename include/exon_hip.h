@@ -450,9 +450,10 @@ int exon_hip_bgzf_scan(const uint8_t* data, size_t n, size_t out_base, exon_hip_
  * `stream`.  A corrupt block -> EXON_HIP_EINVAL and *first_bad_block (else -1): inflate on the host instead. */
 int exon_hip_bgzf_inflate(exon_hip_ctx* ctx, void* stream, const uint8_t* d_comp, const exon_hip_bgzf_block* blocks,
                           int32_t n_blocks, uint8_t* d_out, int32_t verify_crc, int32_t* first_bad_block);
-/* Diagnostics of the optional lane-parallel block decoder (environment EXON_HIP_INFLATE_PAR=1, off by default; see DESIGN.md
- * section 7e): out32[0] = DEFLATE blocks decoded by it since the process started on `stream` (NULL: all streams of the
- * current device), out32[1..15] = blocks it handed back to the serial symbol loop, by reason.  Always 0 when the switch is off. */
+/* Diagnostics of the lane-parallel block decoder (used for launches of up to 1536 members unless
+ * EXON_HIP_INFLATE_PAR says otherwise: 0 = never, 1 = always, 2 = side by side with the serial kernel): out32[0] = DEFLATE blocks
+ * it decoded on the current device since the process started, out32[1..15] = blocks it handed back to the serial symbol loop, by
+ * reason.  `stream` is ignored.  Synchronises the device. */
 int exon_hip_bgzf_inflate_par_stats(void* stream, uint32_t* out32);
 
 /* ---- FASTQ record splitting on the GPU (raw text in HBM -> per-read views into that text) ---------------------
