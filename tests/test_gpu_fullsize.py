@@ -103,3 +103,34 @@ def test_config5_histogram_rows_sum_to_reads(ctx):
     assert h[:, :33].sum() == 0 and h[:, 75:].sum() == 0   # bytes are 33 + [0, 41]
     mean_q = (h * np.arange(256)).sum(axis=1) / (2 * n) - 33
     assert np.all(np.diff(mean_q) < 0.2) and mean_q[0] > mean_q[-1] + 8   # quality declines along the read
+
+
+def test_config5_one_billion_reads_in_one_chunked_launch(ctx):
+    """BASELINE config 5 at its full size (1e9 reads of 100 bytes = 50 Arrow batches, 104 GB resident) through
+    exon_hip_plan_launch_chunks: every position's row sums to the number of reads, the byte range is the generator's, and the
+    fused launch equals the per-batch launches bit for bit (checked on all 50 batches)."""
+    import ctypes as C
+    n, L, batch = 1_000_000_000, 100, 20_000_000
+    if ctx.info()["hbm_bytes"] < 200 * 2**30:
+        pytest.skip("needs a 288 GB part: 104 GB of resident input")
+    data = ctx.empty(np.uint8, n * L + 64)
+    nb = n // batch
+    off = ctx.empty(np.int32, n + nb + 4)
+    chunks = []
+    for k in range(nb):
+        d_off, d_bytes = off.ptr + 4 * (k * batch + k), data.ptr + k * batch * L
+        ctx._check(ctx.lib.exon_hip_gen_c5(ctx.h, None, 5, k * batch, (k + 1) * batch, L, C.c_void_p(d_off), C.c_void_p(d_bytes)))
+        chunks.append(([(d_bytes, None, d_off)], batch))
+    plan = ctx.plan_qual_pos_hist(L)
+    fused = ctx.to_device(np.full(L * 256, 7, np.int64))          # OVERWRITE must not care what was there
+    plan.launch_chunks(chunks, fused, overwrite=True)
+    each = ctx.zeros(np.int64, L * 256)
+    for cols, m in chunks:
+        plan.launch(cols, m, each, overwrite=False)
+    ctx.sync()
+    h = fused.to_host().reshape(L, 256)
+    assert np.array_equal(h, each.to_host().reshape(L, 256))
+    assert np.all(h.sum(axis=1) == n)
+    assert h[:, :33].sum() == 0 and h[:, 75:].sum() == 0
+    plan.close()
+    data.free(); off.free()
