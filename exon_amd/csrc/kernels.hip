@@ -57,6 +57,17 @@ __device__ __forceinline__ T ld16(const void* p) {
   __builtin_memcpy(&r, &v, 16);
   return r;
 }
+// The same without the streaming hint.  An i64 column gives every lane 32 consecutive bytes = two 16-byte loads that touch
+// the SAME cache lines (lane stride 32 B): when both carry the streaming hint, some lines are fetched from HBM twice (PMC:
+// 1.047 x the algorithmic bytes in K2, 1.049 x in K6); with a plain second load the line is still there: K2 1.877 -> 1.827 ms.
+template <class T>
+__device__ __forceinline__ T ld16_plain(const void* p) {
+  static_assert(sizeof(T) == 16, "16-byte vector expected");
+  const v4i_t v = *reinterpret_cast<const v4i_t*>(p);
+  T r;
+  __builtin_memcpy(&r, &v, 16);
+  return r;
+}
 
 // validity nibble of this lane's 4 rows of sub-tile j: rows [wbase + 256 j + 4 lane, +4).
 // wbase is a multiple of 256, so the sub-tile's 256 bits are 32 consecutive bytes.
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(S::THREADS) void k2_region_count_main(const int32_t
       const int64_t r = wbase + j * 256 + lane * 4;
       c[j] = ld16<int4>(chrom + r);
       p0[j] = ld16<longlong2>(pos + r);
-      p1[j] = ld16<longlong2>(pos + r + 2);
+      p1[j] = ld16_plain<longlong2>(pos + r + 2);
       cm[j] = valid4_ones(cvalid, ones, wbase, j, lane);
       pm[j] = valid4_ones(pvalid, ones, wbase, j, lane);
     }
@@ -345,9 +356,9 @@ __global__ __launch_bounds__(S::THREADS) void k6_overlap_count_main(const int32_
       const int64_t r = wbase + j * 256 + lane * 4;
       c[j] = ld16<int4>(ref + r);
       s0[j] = ld16<longlong2>(start + r);
-      s1[j] = ld16<longlong2>(start + r + 2);
+      s1[j] = ld16_plain<longlong2>(start + r + 2);
       e0[j] = ld16<longlong2>(end + r);
-      e1[j] = ld16<longlong2>(end + r + 2);
+      e1[j] = ld16_plain<longlong2>(end + r + 2);
       rm[j] = valid4_ones(rvalid, ones, wbase, j, lane);
       sm[j] = valid4_ones(svalid, ones, wbase, j, lane);
       em[j] = valid4_ones(evalid, ones, wbase, j, lane);
