@@ -187,6 +187,12 @@ def test_lane_parallel_block_decoder_in_a_fresh_process():
                         os.path.join(ROOT, "tests", "test_gpu_bam_parse.py"),
                         "-k", "not fresh_process"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    # mode 2: a share of every launch on the serial kernel, the rest on the parallel one, two streams joined by events
+    env2 = dict(os.environ, EXON_HIP_INFLATE_PAR="2", EXON_HIP_INFLATE_PAR_SERIAL_SHARE="0.5")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "--timeout", "300", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_gpu_inflate.py"), "-k", "not fresh_process"], env=env2, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     # and the parallel path did decode members (a silent fall-back to the serial loop would prove nothing)
     code = ("import exon_amd, ctypes, numpy as np, sys; sys.path.insert(0, %r); import test_gpu_inflate as t;"
             "ctx = exon_amd.Context(0); raw = t.bgzf_file(t.vcf_like(40000)); got, _ = ctx.bgzf_inflate(raw);"
