@@ -101,7 +101,7 @@ class ScanOptions(C.Structure):
                 ("info_field", C.c_char_p), ("region", C.c_char_p), ("use_index", C.c_int32), ("gpu_parse", C.c_int32)]
 
 
-FORMATS = {"vcf": 1, "bam": 2, "fastq": 3, "fasta": 4, "sam": 5, "bcf": 6}
+FORMATS = {"vcf": 1, "bam": 2, "fastq": 3, "fasta": 4, "sam": 5, "bcf": 6, "cram": 7}
 COMPRESSION = {"auto": 0, None: 0, "none": 1, "gzip": 2}
 
 PLAN_REGION_COUNT = 2

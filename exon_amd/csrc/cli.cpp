@@ -187,6 +187,7 @@ std::vector<std::string> format_exts(int format, const std::string& custom) {
     case EXON_HIP_FORMAT_VCF: return {".vcf"};
     case EXON_HIP_FORMAT_SAM: return {".sam"};
     case EXON_HIP_FORMAT_BCF: return {".bcf"};
+    case EXON_HIP_FORMAT_CRAM: return {".cram"};
     default: return {".bam"};
   }
 }
@@ -201,6 +202,7 @@ int format_of(const std::string& name, bool* indexed) {
   if (f == "bam") return EXON_HIP_FORMAT_BAM;
   if (f == "sam") return EXON_HIP_FORMAT_SAM;
   if (f == "bcf") return EXON_HIP_FORMAT_BCF;
+  if (f == "cram") return EXON_HIP_FORMAT_CRAM;
   throw Err("unsupported file type " + name);
 }
 
@@ -457,7 +459,7 @@ void exec_select(Session& se, Parser& ps) {
 
   const bool count_only = proj.size() == 1 && proj[0] == "count(*)" && group_by.empty() && !star;
   if (count_only && pr.kind == Predicate::PushedRegion && !src.indexed && gpu_parse_enabled() &&
-      (src.format == EXON_HIP_FORMAT_BAM || src.format == EXON_HIP_FORMAT_SAM)) {  // K6: interval overlap on the GPU
+      (src.format == EXON_HIP_FORMAT_BAM || src.format == EXON_HIP_FORMAT_SAM || src.format == EXON_HIP_FORMAT_CRAM)) {  // K6: interval overlap on the GPU
     exon_hip_ctx* ctx = se.gpu();
     char name[512];
     int64_t a = 1, b = INT64_MAX;
@@ -509,7 +511,7 @@ void exec_select(Session& se, Parser& ps) {
     print_table({"count(*)"}, {{std::to_string(total)}}, se.quiet);
     return;
   }
-  if (pr.kind == Predicate::FlagMapq && (src.format == EXON_HIP_FORMAT_BAM || src.format == EXON_HIP_FORMAT_SAM) && group_by == "reference") {  // K3
+  if (pr.kind == Predicate::FlagMapq && (src.format == EXON_HIP_FORMAT_BAM || src.format == EXON_HIP_FORMAT_SAM || src.format == EXON_HIP_FORMAT_CRAM) && group_by == "reference") {  // K3
     exon_hip_ctx* ctx = se.gpu();
     std::map<std::string, int64_t> merged;  // AggregateExec(Final): merge per-file partials by key
     int64_t null_group = 0;

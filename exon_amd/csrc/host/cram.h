@@ -1,0 +1,669 @@
+// cram.h -- CRAM 3.0 front end (host): containers -> slices -> records -> the BAM device layout (flag, mapq, reference id,
+// start, end), so that the fused kernels K3 / K6 run on CRAM input as they do on BAM / SAM.
+//
+// Replaces exon-cram/src/{async_batch_stream,array_builder}.rs (columns of the schema shared by SAM, BAM and CRAM:
+// exon-sam/src/schema_builder.rs:371-402) and the noodles-cram reader underneath (absent from /root/reference; restated from
+// the published CRAM 3.0 specification).  What the path needs is decoded -- BF, CF, RI, RL, AP, RG, RN, the mate fields, the tag
+// line, the read features (for the reference span), MQ -- everything else is consumed to keep the streams in step.  The
+// reference sequence is NOT needed for these columns (the reference opens it to rebuild the bases; a missing FASTA is an error
+// there and irrelevant here).
+//   block codecs   raw, gzip, rANS 4x8 orders 0 and 1 (what htslib writes by default and the reference's fixtures use);
+//                  bzip2 / lzma / CRAM 3.1 codecs -> error
+//   encodings      EXTERNAL, HUFFMAN, BETA, BYTE_ARRAY_LEN, BYTE_ARRAY_STOP (GOLOMB / SUBEXP / GAMMA are CRAM 2 leftovers -> error)
+// Every length is checked against the bytes in hand; a malformed file is an error, never a read past a buffer.
+#pragma once
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "formats.h"
+
+namespace exon {
+namespace cram {
+
+struct Cursor {  // bounds-checked reads from a byte buffer
+  const uint8_t* p;
+  size_t n, o = 0;
+  Cursor(const uint8_t* p_, size_t n_) : p(p_), n(n_) {}
+  uint8_t u8() {
+    if (o >= n) throw std::runtime_error("CRAM: truncated data");
+    return p[o++];
+  }
+  void need(size_t k) const {
+    if (k > n - o) throw std::runtime_error("CRAM: truncated data");
+  }
+  int32_t i32le() {
+    need(4);
+    int32_t v;
+    memcpy(&v, p + o, 4);
+    o += 4;
+    return v;
+  }
+  uint32_t itf8() {
+    const uint32_t v = u8();
+    if (v < 0x80) return v;
+    if (v < 0xC0) return ((v & 0x3F) << 8) | u8();
+    if (v < 0xE0) {
+      const uint32_t a = u8(), b = u8();
+      return ((v & 0x1F) << 16) | (a << 8) | b;
+    }
+    if (v < 0xF0) {
+      const uint32_t a = u8(), b = u8(), c = u8();
+      return ((v & 0x0F) << 24) | (a << 16) | (b << 8) | c;
+    }
+    const uint32_t a = u8(), b = u8(), c = u8(), d = u8();
+    return ((v & 0x0F) << 28) | (a << 20) | (b << 12) | (c << 4) | (d & 0x0F);
+  }
+  int32_t itf8s() { return (int32_t)itf8(); }
+  uint64_t ltf8() {
+    const uint32_t v = u8();
+    int k = 0;
+    while (k < 8 && ((v << k) & 0x80)) ++k;
+    uint64_t val = k < 7 ? (v & (0xFFu >> (k + 1))) : 0;
+    for (int i = 0; i < k; ++i) val = (val << 8) | u8();
+    return val;
+  }
+  void skip(size_t k) {
+    need(k);
+    o += k;
+  }
+};
+
+// ---- rANS 4x8 (CRAM 3.0 section 13): four interleaved states, 12-bit frequencies, byte renormalisation ------------------
+struct RansTable {
+  uint16_t F[256], C[257];
+  uint8_t lut[4096];
+};
+inline void rans_read_freqs(Cursor& c, RansTable* t) {
+  memset(t->F, 0, sizeof t->F);
+  int sym = c.u8(), last = sym, rle = 0;
+  for (;;) {
+    uint32_t f = c.u8();
+    if (f >= 128) f = ((f & 127) << 8) | c.u8();
+    t->F[sym] = (uint16_t)f;
+    if (rle) {
+      --rle;
+      ++sym;
+      if (sym > 255) throw std::runtime_error("CRAM: rANS symbol run past 255");
+    } else {
+      sym = c.u8();
+      if (sym == last + 1) rle = c.u8();
+    }
+    last = sym;
+    if (sym == 0) break;
+  }
+  uint32_t acc = 0;
+  for (int i = 0; i < 256; ++i) {
+    t->C[i] = (uint16_t)acc;
+    if (acc + t->F[i] > 4096) throw std::runtime_error("CRAM: rANS frequencies exceed 4096");
+    memset(t->lut + acc, i, t->F[i]);
+    acc += t->F[i];
+  }
+  t->C[256] = (uint16_t)acc;
+  memset(t->lut + acc, 0, 4096 - acc);
+}
+inline void rans_step(uint32_t& R, const RansTable& t, uint8_t* out, Cursor& c) {
+  const uint32_t f = R & 0xFFF;
+  const uint8_t s = t.lut[f];
+  *out = s;
+  R = (uint32_t)t.F[s] * (R >> 12) + f - t.C[s];
+  while (R < (1u << 23)) R = (R << 8) | c.u8();
+}
+inline std::vector<uint8_t> rans_4x8(const uint8_t* data, size_t size) {
+  Cursor c(data, size);
+  const int order = c.u8();
+  (void)c.i32le();
+  const uint32_t n = (uint32_t)c.i32le();
+  if (n > (1u << 30)) throw std::runtime_error("CRAM: rANS block too large");
+  std::vector<uint8_t> out(n);
+  if (order == 0) {
+    std::unique_ptr<RansTable> t(new RansTable);
+    rans_read_freqs(c, t.get());
+    uint32_t R[4];
+    for (int j = 0; j < 4; ++j) R[j] = (uint32_t)c.i32le();
+    for (uint32_t i = 0; i < n; ++i) rans_step(R[i & 3], *t, &out[i], c);
+    return out;
+  }
+  if (order != 1) throw std::runtime_error("CRAM: rANS order " + std::to_string(order));
+  std::vector<std::unique_ptr<RansTable>> tabs(256);
+  int ctx = c.u8(), last = ctx, rle = 0;
+  for (;;) {
+    tabs[(size_t)ctx].reset(new RansTable);
+    rans_read_freqs(c, tabs[(size_t)ctx].get());
+    if (rle) {
+      --rle;
+      ++ctx;
+      if (ctx > 255) throw std::runtime_error("CRAM: rANS context run past 255");
+    } else {
+      ctx = c.u8();
+      if (ctx == last + 1) rle = c.u8();
+    }
+    last = ctx;
+    if (ctx == 0) break;
+  }
+  uint32_t R[4];
+  for (int j = 0; j < 4; ++j) R[j] = (uint32_t)c.i32le();
+  const uint32_t q = n >> 2;
+  const uint32_t idx[4] = {0, q, 2 * q, 3 * q};
+  uint8_t prev[4] = {0, 0, 0, 0};
+  auto tab = [&](uint8_t ctx_) -> const RansTable& {
+    if (!tabs[ctx_]) throw std::runtime_error("CRAM: rANS context without a table");
+    return *tabs[ctx_];
+  };
+  for (uint32_t k = 0; k < q; ++k)
+    for (int j = 0; j < 4; ++j) {
+      rans_step(R[j], tab(prev[j]), &out[idx[j] + k], c);
+      prev[j] = out[idx[j] + k];
+    }
+  for (uint32_t i = 4 * q; i < n; ++i) {  // the remainder belongs to the last state
+    rans_step(R[3], tab(prev[3]), &out[i], c);
+    prev[3] = out[i];
+  }
+  return out;
+}
+
+struct Block {
+  int type = 0;
+  uint32_t id = 0;
+  std::vector<uint8_t> data;
+};
+inline Block read_block(Cursor& c) {
+  Block b;
+  const int method = c.u8();
+  b.type = c.u8();
+  b.id = c.itf8();
+  const uint32_t csz = c.itf8(), rsz = c.itf8();
+  c.need((size_t)csz + 4);
+  const uint8_t* src = c.p + c.o;
+  if (rsz > (1u << 30)) throw std::runtime_error("CRAM: block too large");
+  if (method == 0) {
+    b.data.assign(src, src + csz);
+  } else if (method == 1) {
+    b.data.resize(rsz);
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (inflateInit2(&z, 15 + 32) != Z_OK) throw std::runtime_error("inflateInit2 failed");
+    z.next_in = const_cast<uint8_t*>(src);
+    z.avail_in = csz;
+    z.next_out = b.data.data();
+    z.avail_out = rsz;
+    const int rc = rsz ? inflate(&z, Z_FINISH) : Z_STREAM_END;
+    inflateEnd(&z);
+    if (rc != Z_STREAM_END || z.avail_out != 0) throw std::runtime_error("CRAM: corrupt gzip block");
+  } else if (method == 4) {
+    b.data = rans_4x8(src, csz);
+  } else {
+    throw std::runtime_error("CRAM: block compression method " + std::to_string(method) + " is not supported (raw, gzip, rANS 4x8 are)");
+  }
+  if (b.data.size() != rsz) throw std::runtime_error("CRAM: block size mismatch");
+  c.o += (size_t)csz + 4;  // CRC-32 of the block (not verified: the codecs above check their own sizes)
+  return b;
+}
+
+struct Encoding {
+  enum Kind { NONE, EXTERNAL, HUFFMAN, BYTE_ARRAY_LEN, BYTE_ARRAY_STOP, BETA } kind = NONE;
+  uint32_t id = 0;                  // EXTERNAL / BYTE_ARRAY_STOP: block content id
+  uint8_t stop = 0;                 // BYTE_ARRAY_STOP
+  int32_t offset = 0, nbits = 0;    // BETA
+  std::vector<int32_t> syms;        // HUFFMAN
+  std::vector<uint32_t> lens, codes;
+  std::shared_ptr<Encoding> len_enc, val_enc;  // BYTE_ARRAY_LEN
+};
+inline Encoding read_encoding(Cursor& c) {
+  Encoding e;
+  const uint32_t codec = c.itf8(), ln = c.itf8();
+  c.need(ln);
+  Cursor p(c.p + c.o, ln);
+  switch (codec) {
+    case 0: break;
+    case 1:
+      e.kind = Encoding::EXTERNAL;
+      e.id = p.itf8();
+      break;
+    case 3: {
+      e.kind = Encoding::HUFFMAN;
+      const uint32_t n = p.itf8();
+      for (uint32_t i = 0; i < n; ++i) e.syms.push_back(p.itf8s());
+      const uint32_t n2 = p.itf8();
+      for (uint32_t i = 0; i < n2; ++i) e.lens.push_back(p.itf8());
+      if (n != n2 || n == 0) throw std::runtime_error("CRAM: malformed Huffman encoding");
+      // canonical codes: by (length, symbol)
+      std::vector<size_t> order(n);
+      for (size_t i = 0; i < n; ++i) order[i] = i;
+      std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return e.lens[a] != e.lens[b] ? e.lens[a] < e.lens[b] : e.syms[a] < e.syms[b]; });
+      e.codes.assign(n, 0);
+      uint32_t code = 0, prev = 0;
+      for (size_t k = 0; k < n; ++k) {
+        const size_t i = order[k];
+        if (e.lens[i] > 31) throw std::runtime_error("CRAM: Huffman code too long");
+        code <<= (e.lens[i] - prev);
+        e.codes[i] = code++;
+        prev = e.lens[i];
+      }
+      break;
+    }
+    case 4:
+      e.kind = Encoding::BYTE_ARRAY_LEN;
+      e.len_enc = std::make_shared<Encoding>(read_encoding(p));
+      e.val_enc = std::make_shared<Encoding>(read_encoding(p));
+      break;
+    case 5:
+      e.kind = Encoding::BYTE_ARRAY_STOP;
+      e.stop = p.u8();
+      e.id = p.itf8();
+      break;
+    case 6:
+      e.kind = Encoding::BETA;
+      e.offset = p.itf8s();
+      e.nbits = (int32_t)p.itf8();
+      if (e.nbits > 32) throw std::runtime_error("CRAM: BETA width");
+      break;
+    default:
+      throw std::runtime_error("CRAM: encoding " + std::to_string(codec) + " is not supported");
+  }
+  c.o += ln;
+  return e;
+}
+
+// the blocks of one slice + read positions
+struct SliceData {
+  std::vector<uint8_t> core;
+  size_t core_bit = 0;
+  std::map<uint32_t, Block> ext;
+  std::map<uint32_t, size_t> pos;
+
+  uint32_t bits(int n) {
+    uint32_t v = 0;
+    for (int i = 0; i < n; ++i) {
+      if ((core_bit >> 3) >= core.size()) throw std::runtime_error("CRAM: core block exhausted");
+      v = (v << 1) | ((core[core_bit >> 3] >> (7 - (core_bit & 7))) & 1u);
+      ++core_bit;
+    }
+    return v;
+  }
+  Cursor ext_cursor(uint32_t id) {
+    auto it = ext.find(id);
+    if (it == ext.end()) throw std::runtime_error("CRAM: external block " + std::to_string(id) + " is missing");
+    Cursor c(it->second.data.data(), it->second.data.size());
+    c.o = pos[id];
+    return c;
+  }
+  int32_t get_int(const Encoding& e) {
+    switch (e.kind) {
+      case Encoding::EXTERNAL: {
+        Cursor c = ext_cursor(e.id);
+        const int32_t v = c.itf8s();
+        pos[e.id] = c.o;
+        return v;
+      }
+      case Encoding::HUFFMAN: {
+        if (e.syms.size() == 1 && e.lens[0] == 0) return e.syms[0];
+        uint32_t code = 0, len = 0;
+        for (;;) {
+          code = (code << 1) | bits(1);
+          ++len;
+          for (size_t i = 0; i < e.syms.size(); ++i)
+            if (e.lens[i] == len && e.codes[i] == code) return e.syms[i];
+          if (len > 31) throw std::runtime_error("CRAM: bad Huffman code");
+        }
+      }
+      case Encoding::BETA:
+        return (int32_t)bits(e.nbits) - e.offset;
+      default:
+        throw std::runtime_error("CRAM: integer data series with a byte-array encoding");
+    }
+  }
+  uint8_t get_byte(const Encoding& e) {
+    if (e.kind == Encoding::EXTERNAL) {
+      Cursor c = ext_cursor(e.id);
+      const uint8_t v = c.u8();
+      pos[e.id] = c.o;
+      return v;
+    }
+    return (uint8_t)get_int(e);
+  }
+  // length of the byte array; the bytes themselves are skipped (only lengths matter to the columns of this path)
+  size_t skip_bytes(const Encoding& e, std::string* keep = nullptr) {
+    if (e.kind == Encoding::BYTE_ARRAY_STOP) {
+      Cursor c = ext_cursor(e.id);
+      const size_t start = c.o;
+      while (c.u8() != e.stop) {
+      }
+      pos[e.id] = c.o;
+      if (keep) keep->assign(reinterpret_cast<const char*>(c.p + start), c.o - 1 - start);
+      return c.o - 1 - start;
+    }
+    if (e.kind == Encoding::BYTE_ARRAY_LEN) {
+      const int32_t n = get_int(*e.len_enc);
+      if (n < 0) throw std::runtime_error("CRAM: negative byte-array length");
+      if (e.val_enc->kind == Encoding::EXTERNAL) {
+        Cursor c = ext_cursor(e.val_enc->id);
+        c.need((size_t)n);
+        if (keep) keep->assign(reinterpret_cast<const char*>(c.p + c.o), (size_t)n);
+        pos[e.val_enc->id] = c.o + (size_t)n;
+      } else {
+        if (keep) keep->clear();
+        for (int32_t i = 0; i < n; ++i) {
+          const uint8_t b = get_byte(*e.val_enc);
+          if (keep) keep->push_back((char)b);
+        }
+      }
+      return (size_t)n;
+    }
+    throw std::runtime_error("CRAM: byte-array data series with an integer encoding");
+  }
+};
+
+}  // namespace cram
+
+class CRAMBatchReader {
+ public:
+  CRAMBatchReader(const std::string& path, BAMConfig cfg) : cfg_(std::move(cfg)) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + path);
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (sz < 26) {
+      fclose(f);
+      throw std::runtime_error("not a CRAM file: " + path);
+    }
+    file_.resize((size_t)sz);
+    const size_t got = fread(file_.data(), 1, (size_t)sz, f);
+    fclose(f);
+    if (got != (size_t)sz) throw std::runtime_error("short read: " + path);
+    if (memcmp(file_.data(), "CRAM", 4) != 0) throw std::runtime_error("not a CRAM file: " + path);
+    if (file_[4] != 3 || file_[5] != 0) throw std::runtime_error("CRAM " + std::to_string(file_[4]) + "." + std::to_string(file_[5]) + " is not supported (3.0 is)");
+    off_ = 26;
+    // the first container holds the SAM header
+    ContainerHeader h = read_container_header();
+    cram::Cursor c(file_.data() + off_, h.length);
+    cram::Block b = cram::read_block(c);
+    cram::Cursor t(b.data.data(), b.data.size());
+    const int32_t l_text = t.i32le();
+    if (l_text < 0) throw std::runtime_error("CRAM: bad header length");
+    t.need((size_t)l_text);
+    header_text.assign(reinterpret_cast<const char*>(t.p + t.o), (size_t)l_text);
+    off_ += h.length;
+    size_t ls = 0;
+    while (ls < header_text.size()) {
+      size_t le = header_text.find('\n', ls);
+      if (le == std::string::npos) le = header_text.size();
+      if (header_text.compare(ls, 3, "@SQ") == 0) {
+        std::string name;
+        int32_t len = 0;
+        size_t start = ls;
+        for (size_t i = ls; i <= le; ++i)
+          if (i == le || header_text[i] == '\t') {
+            if (header_text.compare(start, 3, "SN:") == 0) name = header_text.substr(start + 3, i - start - 3);
+            if (header_text.compare(start, 3, "LN:") == 0) len = atoi(header_text.c_str() + start + 3);
+            start = i + 1;
+          }
+        ref_names.push_back(name);
+        ref_lengths.push_back(len);
+      }
+      ls = le + 1;
+    }
+    if (cfg_.filter.active) {
+      region_ref_id_ = -2;
+      for (size_t i = 0; i < ref_names.size(); ++i)
+        if (ref_names[i] == cfg_.filter.region.name) region_ref_id_ = (int32_t)i;
+    }
+  }
+
+  const BAMConfig& config() const { return cfg_; }
+
+  bool read_batch(struct ArrowArray* out) {
+    BAMArrayBuilder b(&ref_names);
+    while ((int64_t)b.len() < cfg_.batch_size) {
+      if (pending_pos_ >= pending_.size()) {
+        pending_.clear();
+        pending_pos_ = 0;
+        if (!next_container()) break;
+        continue;
+      }
+      const Rec& r = pending_[pending_pos_++];
+      if (cfg_.filter.active) {  // the range hit of the indexed BAM stream (cram_region_filter has the same meaning)
+        if (r.ref_id < 0 || r.pos0 < 0) continue;
+        const int64_t s = r.pos0 + 1, e = s + r.ref_len - 1;
+        const Region& rg = cfg_.filter.region;
+        if (!(r.ref_id == region_ref_id_ && s <= rg.end && rg.start <= e)) continue;
+      }
+      b.append(r.flag, r.ref_id, r.pos0, r.mapq, r.ref_len);
+    }
+    if (b.is_empty()) return false;
+    b.try_into_record_batch(out);
+    return true;
+  }
+  void schema(struct ArrowSchema* out) const {
+    make_schema(out, "+s", "", false,
+                {new_field("i", "flag", false), new_field("C", "mapping_quality", true),
+                 new_field("i", "reference", true, new_field("u", "", false)), new_field("l", "start", true),
+                 new_field("l", "end", true)});
+  }
+  // read names of the records decoded so far (tests: the reference pins the first row's name)
+  std::vector<std::string> names;
+  bool keep_names = false;
+  std::string header_text;
+  std::vector<std::string> ref_names;
+  std::vector<int32_t> ref_lengths;
+
+ private:
+  struct Rec {
+    int32_t flag, ref_id;
+    int64_t pos0, ref_len;
+    int mapq;
+  };
+  struct ContainerHeader {
+    size_t length = 0;
+    int32_t ref_id = 0;
+    uint32_t n_records = 0, n_blocks = 0;
+  };
+  ContainerHeader read_container_header() {
+    cram::Cursor c(file_.data() + off_, file_.size() - off_);
+    ContainerHeader h;
+    const int32_t len = c.i32le();
+    if (len < 0) throw std::runtime_error("CRAM: negative container length");
+    h.length = (size_t)len;
+    h.ref_id = c.itf8s();
+    (void)c.itf8();
+    (void)c.itf8();
+    h.n_records = c.itf8();
+    (void)c.ltf8();
+    (void)c.ltf8();
+    h.n_blocks = c.itf8();
+    const uint32_t nl = c.itf8();
+    for (uint32_t i = 0; i < nl; ++i) (void)c.itf8();
+    c.skip(4);
+    off_ += c.o;
+    if (h.length > file_.size() - off_) throw std::runtime_error("CRAM: container runs past the end of the file");
+    return h;
+  }
+
+  bool next_container() {
+    for (;;) {
+      if (off_ >= file_.size()) return false;
+      const ContainerHeader h = read_container_header();
+      const size_t end = off_ + h.length;
+      if (h.n_records == 0) {  // EOF container (or an empty one)
+        off_ = end;
+        continue;
+      }
+      cram::Cursor c(file_.data() + off_, h.length);
+      decode_container(c);
+      off_ = end;
+      return true;
+    }
+  }
+
+  void decode_container(cram::Cursor& c) {
+    using namespace cram;
+    Block ch = read_block(c);
+    if (ch.type != 1) throw std::runtime_error("CRAM: compression header expected");
+    Cursor h(ch.data.data(), ch.data.size());
+    bool rn_preserved = true, ap_delta = true;
+    std::vector<std::vector<uint32_t>> tag_lines;
+    {
+      (void)h.itf8();
+      const uint32_t n = h.itf8();
+      for (uint32_t i = 0; i < n; ++i) {
+        const char k0 = (char)h.u8(), k1 = (char)h.u8();
+        if (k0 == 'R' && k1 == 'N') rn_preserved = h.u8() != 0;
+        else if (k0 == 'A' && k1 == 'P') ap_delta = h.u8() != 0;
+        else if (k0 == 'R' && k1 == 'R') (void)h.u8();
+        else if (k0 == 'S' && k1 == 'M') h.skip(5);
+        else if (k0 == 'T' && k1 == 'D') {
+          const uint32_t ln = h.itf8();
+          h.need(ln);
+          std::vector<uint32_t> line;
+          for (uint32_t q = 0; q < ln;) {
+            if (h.p[h.o + q] == 0) {
+              tag_lines.push_back(line);
+              line.clear();
+              ++q;
+              continue;
+            }
+            if (q + 3 > ln) throw std::runtime_error("CRAM: malformed tag dictionary");
+            line.push_back(((uint32_t)h.p[h.o + q] << 16) | ((uint32_t)h.p[h.o + q + 1] << 8) | h.p[h.o + q + 2]);
+            q += 3;
+          }
+          h.skip(ln);
+        } else {
+          throw std::runtime_error(std::string("CRAM: preservation key ") + k0 + k1);
+        }
+      }
+    }
+    std::map<std::string, Encoding> ds;
+    {
+      (void)h.itf8();
+      const uint32_t n = h.itf8();
+      for (uint32_t i = 0; i < n; ++i) {
+        std::string key(2, ' ');
+        key[0] = (char)h.u8();
+        key[1] = (char)h.u8();
+        ds[key] = read_encoding(h);
+      }
+    }
+    std::map<uint32_t, Encoding> tags;
+    {
+      (void)h.itf8();
+      const uint32_t n = h.itf8();
+      for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t key = h.itf8();
+        tags[key] = read_encoding(h);
+      }
+    }
+    auto enc = [&](const char* k) -> const Encoding& {
+      auto it = ds.find(k);
+      if (it == ds.end() || it->second.kind == Encoding::NONE) throw std::runtime_error(std::string("CRAM: data series ") + k + " has no encoding");
+      return it->second;
+    };
+    while (c.o < c.n) {
+      Block sh = read_block(c);
+      if (sh.type != 2) throw std::runtime_error("CRAM: slice header expected");
+      Cursor s(sh.data.data(), sh.data.size());
+      const int32_t s_ref = s.itf8s();
+      const int32_t s_start = s.itf8s();
+      (void)s.itf8();
+      const uint32_t s_nrec = s.itf8();
+      (void)s.ltf8();
+      const uint32_t s_nblocks = s.itf8();
+      SliceData sl;
+      for (uint32_t i = 0; i < s_nblocks; ++i) {
+        Block b = read_block(c);
+        if (b.type == 5) sl.core.swap(b.data);
+        else if (b.type == 4) {
+          const uint32_t id = b.id;
+          sl.pos[id] = 0;
+          sl.ext[id] = std::move(b);
+        }
+      }
+      int64_t prev = s_start;
+      for (uint32_t r = 0; r < s_nrec; ++r) {
+        Rec rec;
+        rec.flag = sl.get_int(enc("BF"));
+        const int32_t cf = sl.get_int(enc("CF"));
+        rec.ref_id = s_ref == -2 ? sl.get_int(enc("RI")) : s_ref;
+        const int32_t rl = sl.get_int(enc("RL"));
+        int64_t ap = sl.get_int(enc("AP"));
+        if (ap_delta) {
+          ap += prev;
+          prev = ap;
+        }
+        (void)sl.get_int(enc("RG"));
+        std::string name;
+        if (rn_preserved) sl.skip_bytes(enc("RN"), keep_names ? &name : nullptr);
+        if (cf & 2) {
+          (void)sl.get_int(enc("MF"));
+          if (!rn_preserved) sl.skip_bytes(enc("RN"), keep_names ? &name : nullptr);
+          (void)sl.get_int(enc("NS"));
+          (void)sl.get_int(enc("NP"));
+          (void)sl.get_int(enc("TS"));
+        } else if (cf & 4) {
+          (void)sl.get_int(enc("NF"));
+        }
+        const int32_t tl = sl.get_int(enc("TL"));
+        if (tl < 0 || (size_t)tl >= tag_lines.size()) throw std::runtime_error("CRAM: tag line out of range");
+        for (uint32_t key : tag_lines[(size_t)tl]) {
+          auto it = tags.find(key);
+          if (it == tags.end()) throw std::runtime_error("CRAM: tag without an encoding");
+          sl.skip_bytes(it->second);
+        }
+        int64_t span = rl;
+        rec.mapq = 255;
+        if (!(rec.flag & 4)) {
+          const int32_t fn = sl.get_int(enc("FN"));
+          for (int32_t i = 0; i < fn; ++i) {
+            const char code = (char)sl.get_byte(enc("FC"));
+            (void)sl.get_int(enc("FP"));
+            switch (code) {
+              case 'B': (void)sl.get_byte(enc("BA")); (void)sl.get_byte(enc("QS")); break;
+              case 'X': (void)sl.get_byte(enc("BS")); break;
+              case 'I': span -= (int64_t)sl.skip_bytes(enc("IN")); break;
+              case 'i': (void)sl.get_byte(enc("BA")); span -= 1; break;
+              case 'D': span += sl.get_int(enc("DL")); break;
+              case 'S': span -= (int64_t)sl.skip_bytes(enc("SC")); break;
+              case 'N': span += sl.get_int(enc("RS")); break;
+              case 'P': (void)sl.get_int(enc("PD")); break;
+              case 'H': (void)sl.get_int(enc("HC")); break;
+              case 'Q': (void)sl.get_byte(enc("QS")); break;
+              case 'b': sl.skip_bytes(enc("BB")); break;
+              case 'q': sl.skip_bytes(enc("QQ")); break;
+              default: throw std::runtime_error(std::string("CRAM: read feature '") + code + "'");
+            }
+          }
+          rec.mapq = sl.get_int(enc("MQ"));
+          if (cf & 1)
+            for (int32_t i = 0; i < rl; ++i) (void)sl.get_byte(enc("QS"));
+        } else {
+          for (int32_t i = 0; i < rl; ++i) (void)sl.get_byte(enc("BA"));
+          if (cf & 1)
+            for (int32_t i = 0; i < rl; ++i) (void)sl.get_byte(enc("QS"));
+          span = 0;  // no CIGAR: as in the BAM path, end = start - 1
+        }
+        rec.pos0 = ap - 1;       // 0 -> "no position" (-1)
+        rec.ref_len = span;
+        if (rec.mapq < 0 || rec.mapq > 255) rec.mapq = 255;
+        pending_.push_back(rec);
+        if (keep_names) names.push_back(name);
+      }
+    }
+  }
+
+  BAMConfig cfg_;
+  std::vector<uint8_t> file_;
+  size_t off_ = 0;
+  std::vector<Rec> pending_;
+  size_t pending_pos_ = 0;
+  int32_t region_ref_id_ = -2;
+};
+
+}  // namespace exon

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "host/bcf.h"
+#include "host/cram.h"
 #include "host/formats.h"
 #include "host/parallel.h"
 #include "internal.h"
@@ -37,6 +38,7 @@ struct exon_hip_scan {
   std::unique_ptr<exon::VCFBatchReader> vcf;
   std::unique_ptr<exon::BAMBatchReader> bam;
   std::unique_ptr<exon::SAMBatchReader> sam;
+  std::unique_ptr<exon::CRAMBatchReader> cram;
   std::unique_ptr<exon::BCFBatchReader> bcf;
   std::unique_ptr<exon::FASTQBatchReader> fastq;
   std::unique_ptr<exon::FASTABatchReader> fasta;
@@ -74,7 +76,7 @@ static exon::Dictionary* dict_of(exon_hip_scan* s, int col) {
   if (s->format == EXON_HIP_FORMAT_BCF && col == 3) return s->bcf_parser ? &s->gpu_filter_dict : &s->bcf->filter_dict;
   if (s->format == EXON_HIP_FORMAT_VCF && col == 0) return &s->vcf->chrom_dict;
   if (s->format == EXON_HIP_FORMAT_VCF && col == 3) return s->parser ? &s->gpu_filter_dict : &s->vcf->filter_dict;
-  if ((s->format == EXON_HIP_FORMAT_BAM || s->format == EXON_HIP_FORMAT_SAM) && col == 2) return &s->bam_dict_view;
+  if ((s->format == EXON_HIP_FORMAT_BAM || s->format == EXON_HIP_FORMAT_SAM || s->format == EXON_HIP_FORMAT_CRAM) && col == 2) return &s->bam_dict_view;
   // string INFO fields (scan columns 4 ..) are dictionary-encoded by the host readers
   if (s->format == EXON_HIP_FORMAT_VCF && col >= 4 && (size_t)(col - 4) < s->vcf->info_specs.size() && s->vcf->info_specs[(size_t)(col - 4)].kind == 's')
     return &s->vcf->info_dicts[(size_t)(col - 4)];
@@ -172,6 +174,16 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         s->bam_dict_view.names = s->sam->ref_names;
         break;
       }
+      case EXON_HIP_FORMAT_CRAM: {  // host decoder only: the columns go to HBM through the staging path
+        exon::BAMConfig cfg;
+        cfg.batch_size = bs;
+        cfg.filter = rf;
+        cfg.filter.use_index = false;
+        s->gpu_parse = false;
+        s->cram.reset(new exon::CRAMBatchReader(path, cfg));
+        s->bam_dict_view.names = s->cram->ref_names;
+        break;
+      }
       case EXON_HIP_FORMAT_FASTQ: {
         exon::FASTQConfig cfg;
         cfg.batch_size = bs;
@@ -203,6 +215,7 @@ int exon_hip_scan_schema(exon_hip_scan* s, struct ArrowSchema* out) {
     if (s->vcf) s->vcf->schema(out);
     else if (s->bam) s->bam->schema(out);
     else if (s->sam) s->sam->schema(out);
+    else if (s->cram) s->cram->schema(out);
     else if (s->bcf) s->bcf->schema(out);
     else if (s->fastq) s->fastq->schema(out);
     else s->fasta->schema(out);
@@ -221,6 +234,7 @@ int exon_hip_scan_next(exon_hip_scan* s, struct ArrowArray* out) {
     if (s->vcf) got = s->vcf->read_batch(out);
     else if (s->bam) got = s->bam->read_batch(out);
     else if (s->sam) got = s->sam->read_batch(out);
+    else if (s->cram) got = s->cram->read_batch(out);
     else if (s->bcf) got = s->bcf->read_batch(out);
     else if (s->fastq) got = s->fastq->read_batch(out);
     else got = s->fasta->read_batch(out);
@@ -244,7 +258,7 @@ int exon_hip_scan_dictionary_intern(exon_hip_scan* s, int32_t column, const char
   if (!s || !name || !id) return fail(nullptr, EXON_HIP_EINVAL, "NULL argument");
   exon::Dictionary* d = dict_of(s, column);
   if (!d) return fail(nullptr, EXON_HIP_EINVAL, "column %d is not dictionary-encoded", column);
-  if (s->format == EXON_HIP_FORMAT_BAM || s->format == EXON_HIP_FORMAT_SAM) {  // reference ids are fixed by the header
+  if (s->format == EXON_HIP_FORMAT_BAM || s->format == EXON_HIP_FORMAT_SAM || s->format == EXON_HIP_FORMAT_CRAM) {  // reference ids are fixed by the header
     *id = d->find(name);
     return EXON_HIP_OK;
   }

@@ -295,3 +295,439 @@ def decode_fasta(path):
         elif line and recs:
             recs[-1]["sequence"] += line.strip()
     return recs
+
+
+# ---- CRAM 3.0 ------------------------------------------------------------------------------------------
+# Reference: exon-cram/src/array_builder.rs (columns of the shared SAM/BAM/CRAM schema, exon-sam/src/schema_builder.rs:371-402)
+# over noodles-cram 0.x (Cargo.lock), which is absent from /root/reference: restated from the published CRAM 3.0
+# specification (file definition, containers, compression header, slices, blocks, data-series encodings, record layout).
+# Block codecs: raw, gzip and rANS 4x8 (what the reference's fixtures use); bzip2 / lzma are reported as unsupported.
+def _itf8(b, o):
+    v = b[o]
+    if v < 0x80:
+        return v, o + 1
+    if v < 0xC0:
+        return ((v & 0x3F) << 8) | b[o + 1], o + 2
+    if v < 0xE0:
+        return ((v & 0x1F) << 16) | (b[o + 1] << 8) | b[o + 2], o + 3
+    if v < 0xF0:
+        return ((v & 0x0F) << 24) | (b[o + 1] << 16) | (b[o + 2] << 8) | b[o + 3], o + 4
+    return ((v & 0x0F) << 28) | (b[o + 1] << 20) | (b[o + 2] << 12) | (b[o + 3] << 4) | (b[o + 4] & 0x0F), o + 5
+
+
+def _itf8s(b, o):
+    v, o = _itf8(b, o)
+    return (v - (1 << 32) if v >= (1 << 31) else v), o
+
+
+def _ltf8(b, o):
+    v = b[o]
+    n = 0
+    while n < 8 and (v << n) & 0x80:
+        n += 1
+    val = v & (0xFF >> (n + 1)) if n < 7 else 0
+    for i in range(n):
+        val = (val << 8) | b[o + 1 + i]
+    return val, o + 1 + n
+
+
+def _rans_freqs(b, o):
+    """one frequency table of rANS 4x8: symbols run-length coded, frequencies 1 or 2 bytes, total 4096"""
+    F = [0] * 256
+    sym, rle = b[o], 0
+    o += 1
+    last = sym
+    while True:
+        f = b[o]
+        o += 1
+        if f >= 128:
+            f = ((f & 127) << 8) | b[o]
+            o += 1
+        F[sym] = f
+        if rle:
+            rle -= 1
+            sym += 1
+        else:
+            sym = b[o]
+            o += 1
+            if sym == last + 1:
+                rle = b[o]
+                o += 1
+        last = sym
+        if sym == 0:
+            break
+    C = [0] * 257
+    for i in range(256):
+        C[i + 1] = C[i] + F[i]
+    lut = []
+    for i in range(256):
+        lut += [i] * F[i]
+    lut += [0] * (4096 - len(lut))
+    return F, C, lut, o
+
+
+def _rans_4x8(b):
+    """CRAM 3.0 rANS codec (4 interleaved states, 12-bit frequencies, byte renormalisation), orders 0 and 1"""
+    order = b[0]
+    _csz, n = struct.unpack_from("<II", b, 1)
+    o = 9
+    out = bytearray(n)
+    if order == 0:
+        F, C, lut, o = _rans_freqs(b, o)
+        R = list(struct.unpack_from("<4I", b, o))
+        o += 16
+        for i in range(n):
+            j = i & 3
+            f = R[j] & 0xFFF
+            sy = lut[f]
+            out[i] = sy
+            R[j] = F[sy] * (R[j] >> 12) + f - C[sy]
+            while R[j] < (1 << 23):
+                R[j] = (R[j] << 8) | b[o]
+                o += 1
+        return bytes(out)
+    tabs = {}
+    ctx, rle = b[o], 0
+    o += 1
+    last = ctx
+    while True:
+        F, C, lut, o = _rans_freqs(b, o)
+        tabs[ctx] = (F, C, lut)
+        if rle:
+            rle -= 1
+            ctx += 1
+        else:
+            ctx = b[o]
+            o += 1
+            if ctx == last + 1:
+                rle = b[o]
+                o += 1
+        last = ctx
+        if ctx == 0:
+            break
+    R = list(struct.unpack_from("<4I", b, o))
+    o += 16
+    q = n >> 2
+    idx = [0, q, 2 * q, 3 * q]
+    prev = [0, 0, 0, 0]
+    for k in range(q):
+        for j in range(4):
+            F, C, lut = tabs[prev[j]]
+            f = R[j] & 0xFFF
+            sy = lut[f]
+            out[idx[j] + k] = sy
+            R[j] = F[sy] * (R[j] >> 12) + f - C[sy]
+            while R[j] < (1 << 23):
+                R[j] = (R[j] << 8) | b[o]
+                o += 1
+            prev[j] = sy
+    for i in range(4 * q, n):  # the remainder belongs to the last state
+        F, C, lut = tabs[prev[3]]
+        f = R[3] & 0xFFF
+        sy = lut[f]
+        out[i] = sy
+        R[3] = F[sy] * (R[3] >> 12) + f - C[sy]
+        while R[3] < (1 << 23):
+            R[3] = (R[3] << 8) | b[o]
+            o += 1
+        prev[3] = sy
+    return bytes(out)
+
+
+def _cram_block(b, o):
+    method, ctype = b[o], b[o + 1]
+    o += 2
+    cid, o = _itf8(b, o)
+    csz, o = _itf8(b, o)
+    rsz, o = _itf8(b, o)
+    raw = bytes(b[o:o + csz])
+    if method == 1:
+        raw = gzip.decompress(raw)
+    elif method == 4:
+        raw = _rans_4x8(raw)
+    elif method != 0:
+        raise ValueError(f"CRAM block compression method {method} is not supported")
+    assert len(raw) == rsz
+    return dict(type=ctype, id=cid, data=raw), o + csz + 4
+
+
+class _Bits:
+    def __init__(self, data):
+        self.d, self.p = data, 0
+
+    def get(self, n):
+        v = 0
+        for _ in range(n):
+            v = (v << 1) | ((self.d[self.p >> 3] >> (7 - (self.p & 7))) & 1)
+            self.p += 1
+        return v
+
+
+def _cram_encoding(b, o):
+    codec, o = _itf8(b, o)
+    ln, o = _itf8(b, o)
+    p, e = o, o + ln
+    if codec == 0:
+        enc = ("null",)
+    elif codec == 1:
+        cid, p = _itf8(b, p)
+        enc = ("external", cid)
+    elif codec == 3:
+        n, p = _itf8(b, p)
+        syms = []
+        for _ in range(n):
+            s, p = _itf8s(b, p)
+            syms.append(s)
+        n2, p = _itf8(b, p)
+        lens = []
+        for _ in range(n2):
+            l, p = _itf8(b, p)
+            lens.append(l)
+        enc = ("huffman", syms, lens)
+    elif codec == 4:
+        le, p = _cram_encoding(b, p)
+        ve, p = _cram_encoding(b, p)
+        enc = ("byte_array_len", le, ve)
+    elif codec == 5:
+        stop = b[p]
+        cid, p = _itf8(b, p + 1)
+        enc = ("byte_array_stop", stop, cid)
+    elif codec == 6:
+        off, p = _itf8s(b, p)
+        nbits, p = _itf8(b, p)
+        enc = ("beta", off, nbits)
+    else:
+        raise ValueError(f"CRAM encoding {codec} is not supported")
+    return enc, e
+
+
+class _Slice:
+    def __init__(self, core, ext):
+        self.core, self.ext, self.pos = _Bits(core), ext, {k: 0 for k in ext}
+
+    def int(self, enc):
+        k = enc[0]
+        if k == "external":
+            v, self.pos[enc[1]] = _itf8s(self.ext[enc[1]], self.pos[enc[1]])
+            return v
+        if k == "huffman":
+            syms, lens = enc[1], enc[2]
+            if len(syms) == 1 and lens[0] == 0:
+                return syms[0]
+            order = sorted(range(len(syms)), key=lambda i: (lens[i], syms[i]))  # canonical codes
+            code, prev_len, codes = 0, 0, {}
+            for i in order:
+                code <<= lens[i] - prev_len
+                codes[(lens[i], code)] = syms[i]
+                prev_len = lens[i]
+                code += 1
+            v, n = 0, 0
+            while True:
+                v = (v << 1) | self.core.get(1)
+                n += 1
+                if (n, v) in codes:
+                    return codes[(n, v)]
+        if k == "beta":
+            return self.core.get(enc[2]) - enc[1]
+        raise ValueError(f"integer through {k}")
+
+    def byte(self, enc):
+        if enc[0] == "external":
+            v = self.ext[enc[1]][self.pos[enc[1]]]
+            self.pos[enc[1]] += 1
+            return v
+        return self.int(enc) & 0xFF
+
+    def bytes(self, enc):
+        if enc[0] == "byte_array_stop":
+            d, p = self.ext[enc[2]], self.pos[enc[2]]
+            e = d.index(bytes([enc[1]]), p)
+            self.pos[enc[2]] = e + 1
+            return d[p:e]
+        if enc[0] == "byte_array_len":
+            n = self.int(enc[1])
+            if enc[2][0] == "external":
+                p = self.pos[enc[2][1]]
+                self.pos[enc[2][1]] = p + n
+                return self.ext[enc[2][1]][p:p + n]
+            return bytes(self.byte(enc[2]) for _ in range(n))
+        raise ValueError(f"byte array through {enc[0]}")
+
+
+def decode_cram(path):
+    """-> (references [(name, length)], records [dict(name, flag, ref_id, start, end, mapq, cigar)]).  Columns as
+    exon-cram/src/array_builder.rs: reference id -1 -> None, start = alignment position (0 -> None), end = start + reference
+    span - 1 with the span from the read length and the read features, mapping quality 255 -> None."""
+    b = read_bytes(path)
+    assert b[:4] == b"CRAM" and b[4] == 3, "CRAM 3.x expected"
+    o, refs, recs, first = 26, [], [], True
+    while o < len(b):
+        length, = struct.unpack_from("<i", b, o)
+        o += 4
+        ref_id, o = _itf8s(b, o)
+        _start, o = _itf8(b, o)
+        _span, o = _itf8(b, o)
+        n_rec, o = _itf8(b, o)
+        _rc, o = _ltf8(b, o)
+        _bases, o = _ltf8(b, o)
+        n_blocks, o = _itf8(b, o)
+        n_land, o = _itf8(b, o)
+        for _ in range(n_land):
+            _, o = _itf8(b, o)
+        o += 4
+        end = o + length
+        if first:  # the SAM header container
+            blk, _ = _cram_block(b, o)
+            l_text, = struct.unpack_from("<i", blk["data"], 0)
+            for line in blk["data"][4:4 + l_text].decode().split("\n"):
+                if line.startswith("@SQ"):
+                    f = dict(x.split(":", 1) for x in line.split("\t")[1:] if ":" in x)
+                    refs.append((f["SN"], int(f.get("LN", 0))))
+            first, o = False, end
+            continue
+        if n_rec == 0 and ref_id == -1 and n_blocks <= 1:  # EOF container
+            o = end
+            continue
+        blk, p = _cram_block(b, o)
+        assert blk["type"] == 1
+        h, q = blk["data"], 0
+        # preservation map
+        _sz, q = _itf8(h, q)
+        n, q = _itf8(h, q)
+        pres = dict(RN=True, AP=True, RR=True)
+        tag_lines = []
+        for _ in range(n):
+            key = h[q:q + 2].decode()
+            q += 2
+            if key in ("RN", "AP", "RR"):
+                pres[key] = h[q] != 0
+                q += 1
+            elif key == "SM":
+                q += 5
+            elif key == "TD":
+                ln, q = _itf8(h, q)
+                for line in h[q:q + ln].split(b"\0")[:-1]:
+                    tag_lines.append([line[i:i + 3] for i in range(0, len(line), 3)])
+                q += ln
+            else:
+                raise ValueError(f"preservation key {key}")
+        # data series encodings
+        _sz, q = _itf8(h, q)
+        n, q = _itf8(h, q)
+        ds = {}
+        for _ in range(n):
+            key = h[q:q + 2].decode()
+            ds[key], q = _cram_encoding(h, q + 2)
+        # tag encodings
+        _sz, q = _itf8(h, q)
+        n, q = _itf8(h, q)
+        tags = {}
+        for _ in range(n):
+            key, q = _itf8(h, q)
+            tags[key], q = _cram_encoding(h, q)
+        # slices
+        while p < end:
+            sh, p = _cram_block(b, p)
+            assert sh["type"] == 2
+            d, q = sh["data"], 0
+            s_ref, q = _itf8s(d, q)
+            s_start, q = _itf8(d, q)
+            _s_span, q = _itf8(d, q)
+            s_nrec, q = _itf8(d, q)
+            _ctr, q = _ltf8(d, q)
+            s_nblocks, q = _itf8(d, q)
+            core, ext = b"", {}
+            for _ in range(s_nblocks):
+                blk, p = _cram_block(b, p)
+                if blk["type"] == 5:
+                    core = blk["data"]
+                elif blk["type"] == 4:
+                    ext[blk["id"]] = blk["data"]
+            sl = _Slice(core, ext)
+            prev = s_start
+            for _ in range(s_nrec):
+                bf, cf = sl.int(ds["BF"]), sl.int(ds["CF"])
+                ri = sl.int(ds["RI"]) if s_ref == -2 else s_ref
+                rl = sl.int(ds["RL"])
+                ap = sl.int(ds["AP"])
+                if pres["AP"]:
+                    ap += prev
+                    prev = ap
+                sl.int(ds["RG"])
+                name = sl.bytes(ds["RN"]) if pres["RN"] else b""
+                if cf & 2:
+                    sl.int(ds["MF"])
+                    if not pres["RN"]:
+                        name = sl.bytes(ds["RN"])
+                    sl.int(ds["NS"]); sl.int(ds["NP"]); sl.int(ds["TS"])
+                elif cf & 4:
+                    sl.int(ds["NF"])
+                tl = sl.int(ds["TL"])
+                for t in tag_lines[tl]:
+                    sl.bytes(tags[(t[0] << 16) | (t[1] << 8) | t[2]])
+                mapq, span, cigar = 255, rl, None
+                if not bf & 4:
+                    fn = sl.int(ds["FN"])
+                    feats, at = [], 0
+                    for _ in range(fn):
+                        code = chr(sl.byte(ds["FC"]))
+                        at += sl.int(ds["FP"])
+                        if code == "B":
+                            sl.byte(ds["BA"]); sl.byte(ds["QS"])
+                        elif code == "X":
+                            sl.byte(ds["BS"])
+                        elif code == "I":
+                            n_ins = len(sl.bytes(ds["IN"])); span -= n_ins; feats.append((at, "I", n_ins))
+                        elif code == "i":
+                            sl.byte(ds["BA"]); span -= 1; feats.append((at, "I", 1))
+                        elif code == "D":
+                            n_del = sl.int(ds["DL"]); span += n_del; feats.append((at, "D", n_del))
+                        elif code == "S":
+                            n_sc = len(sl.bytes(ds["SC"])); span -= n_sc; feats.append((at, "S", n_sc))
+                        elif code == "N":
+                            n_sk = sl.int(ds["RS"]); span += n_sk; feats.append((at, "N", n_sk))
+                        elif code == "P":
+                            feats.append((at, "P", sl.int(ds["PD"])))
+                        elif code == "H":
+                            feats.append((at, "H", sl.int(ds["HC"])))
+                        elif code == "Q":
+                            sl.byte(ds["QS"])
+                        elif code == "b":
+                            sl.bytes(ds["BB"])
+                        elif code == "q":
+                            sl.bytes(ds["QQ"])
+                        else:
+                            raise ValueError(f"read feature {code!r}")
+                    mapq = sl.int(ds["MQ"])
+                    if cf & 1:
+                        for _ in range(rl):
+                            sl.byte(ds["QS"])
+                    # CIGAR from the features: matches fill the gaps between the features that consume read bases
+                    ops, rp = [], 1
+                    for at, op, n_op in feats:
+                        if at > rp:
+                            ops.append((at - rp, "M")); rp = at
+                        ops.append((n_op, op))
+                        if op in "IS":
+                            rp += n_op
+                    if rp <= rl:
+                        ops.append((rl - rp + 1, "M"))
+                    merged = []
+                    for n_op, op in ops:
+                        if merged and merged[-1][1] == op:
+                            merged[-1] = (merged[-1][0] + n_op, op)
+                        else:
+                            merged.append((n_op, op))
+                    cigar = "".join(f"{n_op}{op}" for n_op, op in merged)
+                else:
+                    for _ in range(rl):
+                        sl.byte(ds["BA"])
+                    if cf & 1:
+                        for _ in range(rl):
+                            sl.byte(ds["QS"])
+                start = ap if ap >= 1 else None
+                recs.append(dict(name=name.decode(), flag=bf, ref_id=ri if ri >= 0 else None, start=start,
+                                 end=(start + (0 if bf & 4 else span) - 1) if start is not None else None,
+                                 mapq=None if mapq == 255 else mapq, cigar=cigar))
+        o = end
+    return refs, recs

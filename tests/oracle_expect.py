@@ -45,7 +45,7 @@ def region_count_expected(path, fmt, chrom, start=1, end=None):
 
 
 def bam_columns(path, fmt="bam"):
-    refs, recs = decode.decode_sam(path) if fmt == "sam" else decode.decode_bam(path)
+    refs, recs = decode.decode_sam(path) if fmt == "sam" else decode.decode_cram(path) if fmt == "cram" else decode.decode_bam(path)
     names = [r[0] for r in refs]
     return names, {"flag": [r["flag"] for r in recs], "mapq": [r["mapq"] for r in recs],
                    "ref": [None if r["ref_id"] is None else names[r["ref_id"]] for r in recs],

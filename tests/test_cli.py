@@ -58,6 +58,14 @@ def test_external_tables_and_region_pushdown():
     assert last_count(run(bb + "SELECT COUNT(*) FROM v WHERE vcf_region_filter('1000', chrom) = true").stdout) == 0
 
 
+def test_cram_external_table_counts_its_records():
+    """STORED AS CRAM (exon-core/src/datasources/cram/table_provider.rs): the host CRAM 3.0 decoder behind the CLI; 15 / 910 are
+    the sums of the container headers' record counts, and the rows the oracle's decoder returns (tests/test_cram.py)"""
+    for name, want in (("test_input_1_a.cram", 15), ("1404_index_multislice.cram", 910)):
+        out = run(f"CREATE EXTERNAL TABLE c STORED AS CRAM LOCATION '{FX}/cram/{name}'; SELECT COUNT(*) FROM c;").stdout
+        assert last_count(out) == want
+
+
 @pytest.mark.gpu
 def test_cli_bam_region_filter_on_a_plain_table_runs_k6():
     """A plain (not INDEXED_) BAM table: the interval predicate runs on the GPU (K6) over the GPU-decoded columns."""

@@ -1,0 +1,140 @@
+"""CRAM 3.0 front end (host decoder -> the BAM device layout -> K3 / K6): SURVEY section 8(f-4).
+
+Pins: the reference's first rows (exon-core/tests/sqllogictests/slt/cram-select-tests.slt:9-12, 33-36, 53-56: r000 / match /
+read1-1), the record counts of the container headers, and -- for everything else -- the oracle's independent CRAM decoder
+(oracle/decode.py decode_cram: containers, compression header, raw / gzip / rANS 4x8 blocks, data-series encodings, read
+features), which the product decoder must equal column for column on every record of the four fixtures."""
+import os
+import struct
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+import exon_amd
+from oracle import decode
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FX = os.path.join(ROOT, "tests", "golden", "ref_fixtures", "cram")
+FILES = ["test_input_1_a.cram", "0500_mapped.cram", "twolib.sorted.cram", "1404_index_multislice.cram"]
+
+
+def product_columns(path, region=None):
+    scan = exon_amd.Scan(path, "cram", region=region)
+    names = scan.dictionary(2)
+    batches = [pa.RecordBatch.from_struct_array(b) if isinstance(b, pa.StructArray) else b for b in scan]
+    scan.close()
+    if not batches:
+        return names, [], [], [], [], []
+    t = pa.Table.from_batches(batches)
+    return (names,) + tuple(t.column(i).to_pylist() for i in range(5))
+
+
+def test_oracle_reproduces_the_reference_pins():
+    refs, recs = decode.decode_cram(os.path.join(FX, "test_input_1_a.cram"))
+    r = recs[0]  # cram-select-tests.slt:9-12: r000 99 insert 50 59 30 10M
+    assert (r["name"], r["flag"], refs[r["ref_id"]][0], r["start"], r["end"], r["mapq"], r["cigar"]) == ("r000", 99, "insert", 50, 59, 30, "10M")
+    assert len(recs) == 15 and recs[-1]["flag"] == 4 and recs[-1]["ref_id"] is None and recs[-1]["start"] is None
+    # the SAM-specification example alignments this file is built from
+    by_name = {(x["name"], x["flag"]): x for x in recs}
+    assert by_name[("r004", 0)]["cigar"] == "6M14N1I5M" and by_name[("r004", 0)]["end"] == 40
+    assert by_name[("r003", 0)]["cigar"] == "5H6M" and by_name[("r001", 83)]["cigar"] == "9M"
+    refs, recs = decode.decode_cram(os.path.join(FX, "0500_mapped.cram"))
+    r = recs[0]  # :33-36: match 99 CHROMOSOME_I 1000 1099
+    assert (r["name"], r["flag"], refs[r["ref_id"]][0], r["start"], r["end"]) == ("match", 99, "CHROMOSOME_I", 1000, 1099)
+    refs, recs = decode.decode_cram(os.path.join(FX, "twolib.sorted.cram"))
+    r = recs[0]  # :53-56: read1-1 0 rand1k 1 60 60 60M
+    assert (r["name"], r["flag"], refs[r["ref_id"]][0], r["start"], r["end"], r["mapq"], r["cigar"]) == ("read1-1", 0, "rand1k", 1, 60, 60, "60M")
+
+
+def container_record_counts(path):
+    b = open(path, "rb").read()
+    o, counts, first = 26, [], True
+    while o < len(b):
+        length, = struct.unpack_from("<i", b, o)
+        o += 4
+        vals = []
+        for _ in range(4):
+            v, o = decode._itf8(b, o)
+            vals.append(v)
+        _, o = decode._ltf8(b, o)
+        _, o = decode._ltf8(b, o)
+        _, o = decode._itf8(b, o)
+        nl, o = decode._itf8(b, o)
+        for _ in range(nl):
+            _, o = decode._itf8(b, o)
+        o += 4 + length
+        if not first:
+            counts.append(vals[3])
+        first = False
+    return counts
+
+
+@pytest.mark.parametrize("name", FILES)
+def test_host_decoder_equals_the_oracle_on_every_record(name):
+    path = os.path.join(FX, name)
+    refs, recs = decode.decode_cram(path)
+    names, flag, mapq, ref, start, end = product_columns(path)
+    assert names == [r[0] for r in refs]
+    assert len(flag) == len(recs) == sum(container_record_counts(path))
+    assert flag == [r["flag"] for r in recs]
+    assert mapq == [r["mapq"] for r in recs]
+    assert ref == [None if r["ref_id"] is None else names[r["ref_id"]] for r in recs]
+    assert start == [r["start"] for r in recs]
+    assert end == [r["end"] for r in recs]
+
+
+@pytest.mark.parametrize("region", ["CHROMOSOME_I:100-150", "CHROMOSOME_II", "CHROMOSOME_III:1-5", "CHROMOSOME_I:1000000-1000100", "nope:1-2"])
+def test_region_filter_is_the_range_hit_of_the_bam_stream(region):
+    """cram_region_filter / the indexed CRAM stream keep a record when it overlaps the region on the same reference
+    (exon-cram/src/indexed_async_batch_stream.rs, same predicate as exon-bam/src/indexed_async_batch_stream.rs:66-87)."""
+    path = os.path.join(FX, "1404_index_multislice.cram")
+    refs, recs = decode.decode_cram(path)
+    name, _, span = region.partition(":")
+    a, b = (1, 2**62) if not span else (int(span.split("-")[0]), int(span.split("-")[1]))
+    want = [r for r in recs if r["ref_id"] is not None and refs[r["ref_id"]][0] == name and r["start"] is not None and r["start"] <= b and r["end"] >= a]
+    _, flag, _, ref, start, end = product_columns(path, region=region)
+    assert len(flag) == len(want) and start == [r["start"] for r in want] and end == [r["end"] for r in want]
+
+
+def test_malformed_inputs_are_errors(tmp_path):
+    good = open(os.path.join(FX, "test_input_1_a.cram"), "rb").read()
+    cases = {"magic": b"CRAX" + good[4:], "version": good[:4] + b"\x02\x01" + good[6:], "truncated": good[:1500],
+             "short": good[:20], "container_length": good[:26] + struct.pack("<i", 10**9) + good[30:]}
+    # an rANS block whose frequency table is cut short / corrupt bytes in the middle of the data containers
+    bad = bytearray(good)
+    for i in range(1960, 2000):
+        bad[i] ^= 0x5A
+    cases["corrupt_block"] = bytes(bad)
+    for name, data in cases.items():
+        p = tmp_path / f"{name}.cram"
+        p.write_bytes(data)
+        with pytest.raises(exon_amd.ExonHipError):
+            scan = exon_amd.Scan(str(p), "cram")
+            list(scan)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", FILES)
+def test_cram_file_to_gpu_aggregates_equal_the_oracle(ctx, oracle, name):
+    """file -> host CRAM decoder -> staging -> HBM -> K3 (flag / MAPQ predicate, COUNT(*) GROUP BY reference) and K6 (range hit)"""
+    from oracle_expect import k3_expected, k6_expected
+    path = os.path.join(FX, name)
+    for qmin in (0, 30):
+        scan = exon_amd.Scan(path, "cram")
+        refs = scan.dictionary(2)
+        plan = ctx.plan_flag_mapq_group_count(1284, 0, qmin, len(refs), columns=(0, 1, 2))
+        st = plan.open()
+        rows = st.consume(scan)
+        counts, _ = st.finish()
+        st.close(); plan.close(); scan.close()
+        rows_o, want = k3_expected(oracle, path, "cram", qmin=qmin)
+        assert rows == rows_o and np.array_equal(np.array(counts), want)
+    for a, b in ((1, None), (5, 60), (1000, 1100)):
+        scan = exon_amd.Scan(path, "cram")
+        plan = ctx.plan_overlap_count(0, a, b)
+        st = plan.open()
+        rows = st.consume(scan)
+        counts, _ = st.finish()
+        st.close(); plan.close(); scan.close()
+        assert (rows, int(counts[0])) == k6_expected(path, "cram", refs[0], a, b)
