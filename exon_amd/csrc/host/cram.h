@@ -452,6 +452,7 @@ class CRAMBatchReader {
   // read names of the records decoded so far (tests: the reference pins the first row's name)
   std::vector<std::string> names;
   bool keep_names = false;
+  int64_t containers_skipped = 0;
   std::string header_text;
   std::vector<std::string> ref_names;
   std::vector<int32_t> ref_lengths;
@@ -465,6 +466,7 @@ class CRAMBatchReader {
   struct ContainerHeader {
     size_t length = 0;
     int32_t ref_id = 0;
+    int64_t start = 0, span = 0;
     uint32_t n_records = 0, n_blocks = 0;
   };
   ContainerHeader read_container_header() {
@@ -474,8 +476,8 @@ class CRAMBatchReader {
     if (len < 0) throw std::runtime_error("CRAM: negative container length");
     h.length = (size_t)len;
     h.ref_id = c.itf8s();
-    (void)c.itf8();
-    (void)c.itf8();
+    h.start = c.itf8s();
+    h.span = c.itf8s();
     h.n_records = c.itf8();
     (void)c.ltf8();
     (void)c.ltf8();
@@ -496,6 +498,17 @@ class CRAMBatchReader {
       if (h.n_records == 0) {  // EOF container (or an empty one)
         off_ = end;
         continue;
+      }
+      // a pushed-down region: the container header says which reference and span its records cover (what a .crai entry
+      // repeats), so containers that cannot hold a hit are skipped undecoded; multi-reference (-2) ones are always decoded
+      if (cfg_.filter.active && h.ref_id != -2) {
+        const Region& rg = cfg_.filter.region;
+        const bool may_hit = h.ref_id == region_ref_id_ && h.ref_id >= 0 && (h.span <= 0 || (h.start <= rg.end && rg.start <= h.start + h.span - 1));
+        if (!may_hit) {
+          off_ = end;
+          ++containers_skipped;
+          continue;
+        }
       }
       cram::Cursor c(file_.data() + off_, h.length);
       decode_container(c);
