@@ -22,6 +22,8 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "formats.h"
@@ -216,6 +218,7 @@ struct Encoding {
   std::vector<int32_t> syms;        // HUFFMAN
   std::vector<uint32_t> lens, codes;
   std::shared_ptr<Encoding> len_enc, val_enc;  // BYTE_ARRAY_LEN
+  int slot = -1;  // EXTERNAL / BYTE_ARRAY_STOP: index of the block with content id `id` in the current slice (SliceData::bind)
 };
 inline Encoding read_encoding(Cursor& c) {
   Encoding e;
@@ -273,13 +276,41 @@ inline Encoding read_encoding(Cursor& c) {
   return e;
 }
 
-// the blocks of one slice + read positions
+// the blocks of one slice + read positions.  External blocks are flat streams addressed by slot; an encoding is bound to its
+// slot once per slice (a map lookup per VALUE made the decoder 10x slower).
 struct SliceData {
   std::vector<uint8_t> core;
   size_t core_bit = 0;
-  std::map<uint32_t, Block> ext;
-  std::map<uint32_t, size_t> pos;
+  std::vector<Block> blocks;            // external blocks in file order
+  std::vector<const uint8_t*> ptr;
+  std::vector<size_t> len, pos;
 
+  void add(Block&& b) {
+    blocks.push_back(std::move(b));
+  }
+  void finish_blocks() {
+    ptr.resize(blocks.size());
+    len.resize(blocks.size());
+    pos.assign(blocks.size(), 0);
+    for (size_t i = 0; i < blocks.size(); ++i) {
+      ptr[i] = blocks[i].data.data();
+      len[i] = blocks[i].data.size();
+    }
+  }
+  void bind(Encoding& e) const {
+    e.slot = -1;
+    if (e.kind == Encoding::EXTERNAL || e.kind == Encoding::BYTE_ARRAY_STOP) {
+      for (size_t i = 0; i < blocks.size(); ++i)
+        if (blocks[i].id == e.id) e.slot = (int)i;
+    } else if (e.kind == Encoding::BYTE_ARRAY_LEN) {
+      bind(*e.len_enc);
+      bind(*e.val_enc);
+    }
+  }
+  int slot_of(const Encoding& e) const {
+    if (e.slot < 0) throw std::runtime_error("CRAM: external block " + std::to_string(e.id) + " is missing");
+    return e.slot;
+  }
   uint32_t bits(int n) {
     uint32_t v = 0;
     for (int i = 0; i < n; ++i) {
@@ -289,30 +320,25 @@ struct SliceData {
     }
     return v;
   }
-  Cursor ext_cursor(uint32_t id) {
-    auto it = ext.find(id);
-    if (it == ext.end()) throw std::runtime_error("CRAM: external block " + std::to_string(id) + " is missing");
-    Cursor c(it->second.data.data(), it->second.data.size());
-    c.o = pos[id];
-    return c;
-  }
   int32_t get_int(const Encoding& e) {
     switch (e.kind) {
       case Encoding::EXTERNAL: {
-        Cursor c = ext_cursor(e.id);
+        const int k = slot_of(e);
+        Cursor c(ptr[k], len[k]);
+        c.o = pos[k];
         const int32_t v = c.itf8s();
-        pos[e.id] = c.o;
+        pos[k] = c.o;
         return v;
       }
       case Encoding::HUFFMAN: {
         if (e.syms.size() == 1 && e.lens[0] == 0) return e.syms[0];
-        uint32_t code = 0, len = 0;
+        uint32_t code = 0, l = 0;
         for (;;) {
           code = (code << 1) | bits(1);
-          ++len;
+          ++l;
           for (size_t i = 0; i < e.syms.size(); ++i)
-            if (e.lens[i] == len && e.codes[i] == code) return e.syms[i];
-          if (len > 31) throw std::runtime_error("CRAM: bad Huffman code");
+            if (e.lens[i] == l && e.codes[i] == code) return e.syms[i];
+          if (l > 31) throw std::runtime_error("CRAM: bad Huffman code");
         }
       }
       case Encoding::BETA:
@@ -323,37 +349,46 @@ struct SliceData {
   }
   uint8_t get_byte(const Encoding& e) {
     if (e.kind == Encoding::EXTERNAL) {
-      Cursor c = ext_cursor(e.id);
-      const uint8_t v = c.u8();
-      pos[e.id] = c.o;
-      return v;
+      const int k = slot_of(e);
+      if (pos[k] >= len[k]) throw std::runtime_error("CRAM: truncated data");
+      return ptr[k][pos[k]++];
     }
     return (uint8_t)get_int(e);
+  }
+  void skip_n(const Encoding& e, size_t n) {  // n single-byte values of one series
+    if (e.kind == Encoding::EXTERNAL) {
+      const int k = slot_of(e);
+      if (n > len[k] - pos[k]) throw std::runtime_error("CRAM: truncated data");
+      pos[k] += n;
+      return;
+    }
+    for (size_t i = 0; i < n; ++i) (void)get_int(e);
   }
   // length of the byte array; the bytes themselves are skipped (only lengths matter to the columns of this path)
   size_t skip_bytes(const Encoding& e, std::string* keep = nullptr) {
     if (e.kind == Encoding::BYTE_ARRAY_STOP) {
-      Cursor c = ext_cursor(e.id);
-      const size_t start = c.o;
-      while (c.u8() != e.stop) {
-      }
-      pos[e.id] = c.o;
-      if (keep) keep->assign(reinterpret_cast<const char*>(c.p + start), c.o - 1 - start);
-      return c.o - 1 - start;
+      const int k = slot_of(e);
+      const uint8_t* b = ptr[k] + pos[k];
+      const void* hit = memchr(b, e.stop, len[k] - pos[k]);
+      if (!hit) throw std::runtime_error("CRAM: truncated data");
+      const size_t n = (size_t)(static_cast<const uint8_t*>(hit) - b);
+      if (keep) keep->assign(reinterpret_cast<const char*>(b), n);
+      pos[k] += n + 1;
+      return n;
     }
     if (e.kind == Encoding::BYTE_ARRAY_LEN) {
       const int32_t n = get_int(*e.len_enc);
       if (n < 0) throw std::runtime_error("CRAM: negative byte-array length");
       if (e.val_enc->kind == Encoding::EXTERNAL) {
-        Cursor c = ext_cursor(e.val_enc->id);
-        c.need((size_t)n);
-        if (keep) keep->assign(reinterpret_cast<const char*>(c.p + c.o), (size_t)n);
-        pos[e.val_enc->id] = c.o + (size_t)n;
+        const int k = slot_of(*e.val_enc);
+        if ((size_t)n > len[k] - pos[k]) throw std::runtime_error("CRAM: truncated data");
+        if (keep) keep->assign(reinterpret_cast<const char*>(ptr[k] + pos[k]), (size_t)n);
+        pos[k] += (size_t)n;
       } else {
         if (keep) keep->clear();
         for (int32_t i = 0; i < n; ++i) {
-          const uint8_t b = get_byte(*e.val_enc);
-          if (keep) keep->push_back((char)b);
+          const uint8_t v = get_byte(*e.val_enc);
+          if (keep) keep->push_back((char)v);
         }
       }
       return (size_t)n;
@@ -417,6 +452,9 @@ class CRAMBatchReader {
       for (size_t i = 0; i < ref_names.size(); ++i)
         if (ref_names[i] == cfg_.filter.region.name) region_ref_id_ = (int32_t)i;
     }
+    // containers are independent: cfg.threads of them are decoded at a time (0 = the host's cores, at most 32)
+    const unsigned hc = std::thread::hardware_concurrency();
+    threads_ = cfg_.threads > 0 ? cfg_.threads : (int)std::min(32u, hc ? hc : 1u);
   }
 
   const BAMConfig& config() const { return cfg_; }
@@ -490,34 +528,66 @@ class CRAMBatchReader {
     return h;
   }
 
+  // The next group of containers (those that can hold a hit), decoded on `threads` threads, appended in file order.
   bool next_container() {
-    for (;;) {
-      if (off_ >= file_.size()) return false;
+    struct Job {
+      size_t off, length;
+      std::vector<Rec> recs;
+      std::vector<std::string> names;
+      std::string error;
+    };
+    std::vector<Job> jobs;
+    const size_t want = (size_t)std::max(1, threads_);
+    while (jobs.size() < want && off_ < file_.size()) {
       const ContainerHeader h = read_container_header();
       const size_t end = off_ + h.length;
-      if (h.n_records == 0) {  // EOF container (or an empty one)
-        off_ = end;
-        continue;
-      }
+      bool take = h.n_records != 0;  // 0: the EOF container (or an empty one)
       // a pushed-down region: the container header says which reference and span its records cover (what a .crai entry
       // repeats), so containers that cannot hold a hit are skipped undecoded; multi-reference (-2) ones are always decoded
-      if (cfg_.filter.active && h.ref_id != -2) {
+      if (take && cfg_.filter.active && h.ref_id != -2) {
         const Region& rg = cfg_.filter.region;
-        const bool may_hit = h.ref_id == region_ref_id_ && h.ref_id >= 0 && (h.span <= 0 || (h.start <= rg.end && rg.start <= h.start + h.span - 1));
-        if (!may_hit) {
-          off_ = end;
-          ++containers_skipped;
-          continue;
-        }
+        take = h.ref_id == region_ref_id_ && h.ref_id >= 0 && (h.span <= 0 || (h.start <= rg.end && rg.start <= h.start + h.span - 1));
+        if (!take) ++containers_skipped;
       }
-      cram::Cursor c(file_.data() + off_, h.length);
-      decode_container(c);
+      if (take) {
+        Job j;
+        j.off = off_;
+        j.length = h.length;
+        jobs.push_back(std::move(j));
+      }
       off_ = end;
-      return true;
     }
+    if (jobs.empty()) return false;
+    auto run = [&](Job& j) {
+      try {
+        cram::Cursor c(file_.data() + j.off, j.length);
+        decode_container(c, &j.recs, keep_names ? &j.names : nullptr);
+      } catch (const std::exception& e) {
+        j.error = e.what();
+        if (j.error.empty()) j.error = "CRAM: decode error";
+      }
+    };
+    if (jobs.size() == 1) {
+      run(jobs[0]);
+    } else {
+      std::vector<std::thread> pool;
+      for (size_t i = 1; i < jobs.size(); ++i) pool.emplace_back(run, std::ref(jobs[i]));
+      run(jobs[0]);
+      for (auto& t : pool) t.join();
+    }
+    for (auto& j : jobs) {
+      if (!j.error.empty()) throw std::runtime_error(j.error);
+      pending_.insert(pending_.end(), j.recs.begin(), j.recs.end());
+      if (keep_names) names.insert(names.end(), j.names.begin(), j.names.end());
+    }
+    return true;
   }
 
-  void decode_container(cram::Cursor& c) {
+  struct Series {  // the data series this decoder reads, resolved once per container
+    cram::Encoding BF, CF, RI, RL, AP, RG, RN, MF, NS, NP, TS, NF, TL, FN, FC, FP, DL, BA, QS, BS, IN, SC, RS, PD, HC, MQ, BB, QQ;
+  };
+
+  void decode_container(cram::Cursor& c, std::vector<Rec>* out, std::vector<std::string>* out_names) const {
     using namespace cram;
     Block ch = read_block(c);
     if (ch.type != 1) throw std::runtime_error("CRAM: compression header expected");
@@ -554,31 +624,46 @@ class CRAMBatchReader {
         }
       }
     }
-    std::map<std::string, Encoding> ds;
+    Series S;
     {
       (void)h.itf8();
       const uint32_t n = h.itf8();
       for (uint32_t i = 0; i < n; ++i) {
-        std::string key(2, ' ');
-        key[0] = (char)h.u8();
-        key[1] = (char)h.u8();
-        ds[key] = read_encoding(h);
+        const char k0 = (char)h.u8(), k1 = (char)h.u8();
+        Encoding e = read_encoding(h);
+#define EXON_CRAM_DS(K) if (k0 == #K[0] && k1 == #K[1]) S.K = std::move(e); else
+        EXON_CRAM_DS(BF) EXON_CRAM_DS(CF) EXON_CRAM_DS(RI) EXON_CRAM_DS(RL) EXON_CRAM_DS(AP) EXON_CRAM_DS(RG) EXON_CRAM_DS(RN)
+        EXON_CRAM_DS(MF) EXON_CRAM_DS(NS) EXON_CRAM_DS(NP) EXON_CRAM_DS(TS) EXON_CRAM_DS(NF) EXON_CRAM_DS(TL) EXON_CRAM_DS(FN)
+        EXON_CRAM_DS(FC) EXON_CRAM_DS(FP) EXON_CRAM_DS(DL) EXON_CRAM_DS(BA) EXON_CRAM_DS(QS) EXON_CRAM_DS(BS) EXON_CRAM_DS(IN)
+        EXON_CRAM_DS(SC) EXON_CRAM_DS(RS) EXON_CRAM_DS(PD) EXON_CRAM_DS(HC) EXON_CRAM_DS(MQ) EXON_CRAM_DS(BB) EXON_CRAM_DS(QQ)
+        {}  // a data series this path never reads (TC, TN, TM, TV ...)
+#undef EXON_CRAM_DS
       }
     }
-    std::map<uint32_t, Encoding> tags;
+    std::vector<std::pair<uint32_t, Encoding>> tags;
     {
       (void)h.itf8();
       const uint32_t n = h.itf8();
       for (uint32_t i = 0; i < n; ++i) {
         const uint32_t key = h.itf8();
-        tags[key] = read_encoding(h);
+        tags.emplace_back(key, read_encoding(h));
       }
     }
-    auto enc = [&](const char* k) -> const Encoding& {
-      auto it = ds.find(k);
-      if (it == ds.end() || it->second.kind == Encoding::NONE) throw std::runtime_error(std::string("CRAM: data series ") + k + " has no encoding");
-      return it->second;
+    // tag lines as indexes into `tags`
+    std::vector<std::vector<int>> tag_idx(tag_lines.size());
+    for (size_t l = 0; l < tag_lines.size(); ++l)
+      for (uint32_t key : tag_lines[l]) {
+        int at = -1;
+        for (size_t t = 0; t < tags.size(); ++t)
+          if (tags[t].first == key) at = (int)t;
+        if (at < 0) throw std::runtime_error("CRAM: tag without an encoding");
+        tag_idx[l].push_back(at);
+      }
+    auto need = [](const Encoding& e, const char* k) -> const Encoding& {
+      if (e.kind == Encoding::NONE) throw std::runtime_error(std::string("CRAM: data series ") + k + " has no encoding");
+      return e;
     };
+#define DS(K) need(S.K, #K)
     while (c.o < c.n) {
       Block sh = read_block(c);
       if (sh.type != 2) throw std::runtime_error("CRAM: slice header expected");
@@ -593,85 +678,84 @@ class CRAMBatchReader {
       for (uint32_t i = 0; i < s_nblocks; ++i) {
         Block b = read_block(c);
         if (b.type == 5) sl.core.swap(b.data);
-        else if (b.type == 4) {
-          const uint32_t id = b.id;
-          sl.pos[id] = 0;
-          sl.ext[id] = std::move(b);
-        }
+        else if (b.type == 4) sl.add(std::move(b));
       }
+      sl.finish_blocks();
+      for (Encoding* e : {&S.BF, &S.CF, &S.RI, &S.RL, &S.AP, &S.RG, &S.RN, &S.MF, &S.NS, &S.NP, &S.TS, &S.NF, &S.TL, &S.FN, &S.FC, &S.FP,
+                          &S.DL, &S.BA, &S.QS, &S.BS, &S.IN, &S.SC, &S.RS, &S.PD, &S.HC, &S.MQ, &S.BB, &S.QQ})
+        sl.bind(*e);
+      for (auto& t : tags) sl.bind(t.second);
+      out->reserve(out->size() + s_nrec);
       int64_t prev = s_start;
       for (uint32_t r = 0; r < s_nrec; ++r) {
         Rec rec;
-        rec.flag = sl.get_int(enc("BF"));
-        const int32_t cf = sl.get_int(enc("CF"));
-        rec.ref_id = s_ref == -2 ? sl.get_int(enc("RI")) : s_ref;
-        const int32_t rl = sl.get_int(enc("RL"));
-        int64_t ap = sl.get_int(enc("AP"));
+        rec.flag = sl.get_int(DS(BF));
+        const int32_t cf = sl.get_int(DS(CF));
+        rec.ref_id = s_ref == -2 ? sl.get_int(DS(RI)) : s_ref;
+        const int32_t rl = sl.get_int(DS(RL));
+        if (rl < 0) throw std::runtime_error("CRAM: negative read length");
+        int64_t ap = sl.get_int(DS(AP));
         if (ap_delta) {
           ap += prev;
           prev = ap;
         }
-        (void)sl.get_int(enc("RG"));
+        (void)sl.get_int(DS(RG));
         std::string name;
-        if (rn_preserved) sl.skip_bytes(enc("RN"), keep_names ? &name : nullptr);
+        if (rn_preserved) sl.skip_bytes(DS(RN), out_names ? &name : nullptr);
         if (cf & 2) {
-          (void)sl.get_int(enc("MF"));
-          if (!rn_preserved) sl.skip_bytes(enc("RN"), keep_names ? &name : nullptr);
-          (void)sl.get_int(enc("NS"));
-          (void)sl.get_int(enc("NP"));
-          (void)sl.get_int(enc("TS"));
+          (void)sl.get_int(DS(MF));
+          if (!rn_preserved) sl.skip_bytes(DS(RN), out_names ? &name : nullptr);
+          (void)sl.get_int(DS(NS));
+          (void)sl.get_int(DS(NP));
+          (void)sl.get_int(DS(TS));
         } else if (cf & 4) {
-          (void)sl.get_int(enc("NF"));
+          (void)sl.get_int(DS(NF));
         }
-        const int32_t tl = sl.get_int(enc("TL"));
-        if (tl < 0 || (size_t)tl >= tag_lines.size()) throw std::runtime_error("CRAM: tag line out of range");
-        for (uint32_t key : tag_lines[(size_t)tl]) {
-          auto it = tags.find(key);
-          if (it == tags.end()) throw std::runtime_error("CRAM: tag without an encoding");
-          sl.skip_bytes(it->second);
-        }
+        const int32_t tl = sl.get_int(DS(TL));
+        if (tl < 0 || (size_t)tl >= tag_idx.size()) throw std::runtime_error("CRAM: tag line out of range");
+        for (int t : tag_idx[(size_t)tl]) sl.skip_bytes(tags[(size_t)t].second);
         int64_t span = rl;
         rec.mapq = 255;
         if (!(rec.flag & 4)) {
-          const int32_t fn = sl.get_int(enc("FN"));
+          const int32_t fn = sl.get_int(DS(FN));
           for (int32_t i = 0; i < fn; ++i) {
-            const char code = (char)sl.get_byte(enc("FC"));
-            (void)sl.get_int(enc("FP"));
+            const char code = (char)sl.get_byte(DS(FC));
+            (void)sl.get_int(DS(FP));
             switch (code) {
-              case 'B': (void)sl.get_byte(enc("BA")); (void)sl.get_byte(enc("QS")); break;
-              case 'X': (void)sl.get_byte(enc("BS")); break;
-              case 'I': span -= (int64_t)sl.skip_bytes(enc("IN")); break;
-              case 'i': (void)sl.get_byte(enc("BA")); span -= 1; break;
-              case 'D': span += sl.get_int(enc("DL")); break;
-              case 'S': span -= (int64_t)sl.skip_bytes(enc("SC")); break;
-              case 'N': span += sl.get_int(enc("RS")); break;
-              case 'P': (void)sl.get_int(enc("PD")); break;
-              case 'H': (void)sl.get_int(enc("HC")); break;
-              case 'Q': (void)sl.get_byte(enc("QS")); break;
-              case 'b': sl.skip_bytes(enc("BB")); break;
-              case 'q': sl.skip_bytes(enc("QQ")); break;
+              case 'B': (void)sl.get_byte(DS(BA)); (void)sl.get_byte(DS(QS)); break;
+              case 'X': (void)sl.get_byte(DS(BS)); break;
+              case 'I': span -= (int64_t)sl.skip_bytes(DS(IN)); break;
+              case 'i': (void)sl.get_byte(DS(BA)); span -= 1; break;
+              case 'D': span += sl.get_int(DS(DL)); break;
+              case 'S': span -= (int64_t)sl.skip_bytes(DS(SC)); break;
+              case 'N': span += sl.get_int(DS(RS)); break;
+              case 'P': (void)sl.get_int(DS(PD)); break;
+              case 'H': (void)sl.get_int(DS(HC)); break;
+              case 'Q': (void)sl.get_byte(DS(QS)); break;
+              case 'b': sl.skip_bytes(DS(BB)); break;
+              case 'q': sl.skip_bytes(DS(QQ)); break;
               default: throw std::runtime_error(std::string("CRAM: read feature '") + code + "'");
             }
           }
-          rec.mapq = sl.get_int(enc("MQ"));
-          if (cf & 1)
-            for (int32_t i = 0; i < rl; ++i) (void)sl.get_byte(enc("QS"));
+          rec.mapq = sl.get_int(DS(MQ));
+          if (cf & 1) sl.skip_n(DS(QS), (size_t)rl);
         } else {
-          for (int32_t i = 0; i < rl; ++i) (void)sl.get_byte(enc("BA"));
-          if (cf & 1)
-            for (int32_t i = 0; i < rl; ++i) (void)sl.get_byte(enc("QS"));
+          sl.skip_n(DS(BA), (size_t)rl);
+          if (cf & 1) sl.skip_n(DS(QS), (size_t)rl);
           span = 0;  // no CIGAR: as in the BAM path, end = start - 1
         }
-        rec.pos0 = ap - 1;       // 0 -> "no position" (-1)
+        rec.pos0 = ap - 1;  // 0 -> "no position" (-1)
         rec.ref_len = span;
         if (rec.mapq < 0 || rec.mapq > 255) rec.mapq = 255;
-        pending_.push_back(rec);
-        if (keep_names) names.push_back(name);
+        out->push_back(rec);
+        if (out_names) out_names->push_back(name);
       }
     }
+#undef DS
   }
 
   BAMConfig cfg_;
+  int threads_ = 1;
   std::vector<uint8_t> file_;
   size_t off_ = 0;
   std::vector<Rec> pending_;

@@ -138,3 +138,35 @@ def test_cram_file_to_gpu_aggregates_equal_the_oracle(ctx, oracle, name):
         counts, _ = st.finish()
         st.close(); plan.close(); scan.close()
         assert (rows, int(counts[0])) == k6_expected(path, "cram", refs[0], a, b)
+
+
+def test_synthetic_cram_with_every_span_changing_feature(tmp_path):
+    """Files from tests/cram_writer.py: many containers, two slices each, single- and multi-reference slices, absolute and
+    delta positions, detached mates, BETA / multi-symbol HUFFMAN series in the core bit stream, gzip and raw blocks,
+    insertions / deletions / soft clips / reference skips / padding / hard clips.  Oracle == truth on 20 k records;
+    product == truth on 200 k; pushed-down regions == brute force (and skip whole containers)."""
+    from cram_writer import synthetic_records, write_cram
+    refs = [("chrA", 3_000_000), ("chrB", 1_500_000), ("chrC", 400_000)]
+    for n, per_slice, check_oracle in ((20_000, 300, True), (200_000, 1500, False)):
+        recs = synthetic_records(n, refs, seed=n)
+        path = str(tmp_path / f"syn{n}.cram")
+        write_cram(path, refs, recs, per_slice=per_slice, slices_per_container=2, seed=n)
+        want_flag = [r["flag"] for r in recs]
+        want_ref = [None if r["ref_id"] < 0 else refs[r["ref_id"]][0] for r in recs]
+        want_start = [r["pos"] if r["pos"] > 0 else None for r in recs]
+        want_end = [r["pos"] + r["span"] - 1 if r["pos"] > 0 else None for r in recs]
+        want_mapq = [None if r["flag"] & 4 or r["mapq"] == 255 else r["mapq"] for r in recs]
+        if check_oracle:
+            orefs, orecs = decode.decode_cram(path)
+            assert orefs == refs and len(orecs) == n
+            assert [r["flag"] for r in orecs] == want_flag and [r["start"] for r in orecs] == want_start
+            assert [r["end"] for r in orecs] == want_end and [r["mapq"] for r in orecs] == want_mapq
+            assert [r["name"] for r in orecs] == [r["name"] for r in recs]
+        names, flag, mapq, ref, start, end = product_columns(path)
+        assert names == [r[0] for r in refs]
+        assert flag == want_flag and ref == want_ref and start == want_start and end == want_end and mapq == want_mapq
+        for region, (rname, a, b) in (("chrB:500000-600000", ("chrB", 500_000, 600_000)), ("chrC", ("chrC", 1, 2**62)),
+                                      ("chrA:2999000-3000000", ("chrA", 2_999_000, 3_000_000))):
+            hit = [i for i in range(n) if want_ref[i] == rname and want_start[i] is not None and want_start[i] <= b and want_end[i] >= a]
+            _, f2, _, _, s2, e2 = product_columns(path, region=region)
+            assert s2 == [want_start[i] for i in hit] and e2 == [want_end[i] for i in hit] and f2 == [want_flag[i] for i in hit]
