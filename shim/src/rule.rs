@@ -1,5 +1,5 @@
 //! `GpuFilterAggRule`: substitutes [`GpuFilterAggExec`] for
-//! `AggregateExec(Partial) <- [CoalesceBatchesExec] <- FilterExec <- {VCFScan | BAMScan | FASTQScan}`.
+//! `AggregateExec(Partial) <- [CoalesceBatchesExec] <- FilterExec <- {VCFScan | BAMScan | SAMScan | CRAMScan | FASTQScan}`.
 //! NOT COMPILED HERE (see lib.rs).  Mirrors the recursion of the reference's own rule
 //! (exon-core/src/physical_optimizer/chrom_optimizer_rule.rs:26-64) and the plan shape its tests assert
 //! (exon-core/src/datasources/vcf/table_provider.rs:571-611).
@@ -24,6 +24,8 @@ use datafusion::physical_plan::coalesce_batches::CoalesceBatchesExec;
 use datafusion::physical_plan::filter::FilterExec;
 use datafusion::physical_plan::{with_new_children_if_necessary, ExecutionPlan};
 use exon::datasources::bam::BAMScan;
+use exon::datasources::cram::CRAMScan;
+use exon::datasources::sam::SAMScan;
 use exon::datasources::vcf::VCFScan;
 
 use crate::{sys, GpuFilterAggExec, Shape, Source};
@@ -265,7 +267,12 @@ impl GpuFilterAggRule {
         let scan_plan = filter.input().clone();
         let matched = if let Some(scan) = scan_plan.as_any().downcast_ref::<VCFScan>() {
             match_vcf(agg, filter.predicate(), &scan_plan, scan)
-        } else if scan_plan.as_any().downcast_ref::<BAMScan>().is_some() {
+        } else if scan_plan.as_any().downcast_ref::<BAMScan>().is_some()
+            || scan_plan.as_any().downcast_ref::<SAMScan>().is_some()
+            || scan_plan.as_any().downcast_ref::<CRAMScan>().is_some()
+        {
+            // SAM, BAM and CRAM share one schema (exon-sam/src/schema_builder.rs:371-402): the same two shapes apply; the
+            // child scan's batches are pushed (their FileScanConfig is private)
             match_bam(agg, filter.predicate(), &scan_plan)
         } else {
             None

@@ -30,6 +30,9 @@ pub const EXON_HIP_NE: i32 = 5;
 pub const EXON_HIP_FORMAT_VCF: i32 = 1;
 pub const EXON_HIP_FORMAT_BAM: i32 = 2;
 pub const EXON_HIP_FORMAT_FASTQ: i32 = 3;
+pub const EXON_HIP_FORMAT_SAM: i32 = 5;
+pub const EXON_HIP_FORMAT_BCF: i32 = 6;
+pub const EXON_HIP_FORMAT_CRAM: i32 = 7;
 pub const EXON_HIP_COMPRESSION_AUTO: i32 = 0;
 pub const EXON_HIP_MAX_GROUPS: i32 = 4096;
 pub const EXON_HIP_REGION_OPEN_END: i64 = i64::MAX;
