@@ -12,6 +12,9 @@
 //   encodings      EXTERNAL, HUFFMAN, BETA, BYTE_ARRAY_LEN, BYTE_ARRAY_STOP (GOLOMB / SUBEXP / GAMMA are CRAM 2 leftovers -> error)
 // Every length is checked against the bytes in hand; a malformed file is an error, never a read past a buffer.
 #pragma once
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -402,25 +405,19 @@ struct SliceData {
 class CRAMBatchReader {
  public:
   CRAMBatchReader(const std::string& path, BAMConfig cfg) : cfg_(std::move(cfg)) {
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) throw std::runtime_error("cannot open " + path);
-    fseek(f, 0, SEEK_END);
-    const long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    if (sz < 26) {
-      fclose(f);
-      throw std::runtime_error("not a CRAM file: " + path);
-    }
-    file_.resize((size_t)sz);
-    const size_t got = fread(file_.data(), 1, (size_t)sz, f);
-    fclose(f);
-    if (got != (size_t)sz) throw std::runtime_error("short read: " + path);
-    if (memcmp(file_.data(), "CRAM", 4) != 0) throw std::runtime_error("not a CRAM file: " + path);
-    if (file_[4] != 3 || file_[5] != 0) throw std::runtime_error("CRAM " + std::to_string(file_[4]) + "." + std::to_string(file_[5]) + " is not supported (3.0 is)");
+    fd_ = fdh_.v = ::open(path.c_str(), O_RDONLY);
+    if (fd_ < 0) throw std::runtime_error("cannot open " + path);
+    struct stat st;
+    if (fstat(fd_, &st) != 0 || st.st_size < 26) throw std::runtime_error("not a CRAM file: " + path);
+    size_ = (size_t)st.st_size;
+    const std::vector<uint8_t> def = read_at(0, 26);
+    if (memcmp(def.data(), "CRAM", 4) != 0) throw std::runtime_error("not a CRAM file: " + path);
+    if (def[4] != 3 || def[5] != 0) throw std::runtime_error("CRAM " + std::to_string(def[4]) + "." + std::to_string(def[5]) + " is not supported (3.0 is)");
     off_ = 26;
     // the first container holds the SAM header
     ContainerHeader h = read_container_header();
-    cram::Cursor c(file_.data() + off_, h.length);
+    const std::vector<uint8_t> first = read_at(off_, h.length);
+    cram::Cursor c(first.data(), first.size());
     cram::Block b = cram::read_block(c);
     cram::Cursor t(b.data.data(), b.data.size());
     const int32_t l_text = t.i32le();
@@ -457,6 +454,8 @@ class CRAMBatchReader {
     threads_ = cfg_.threads > 0 ? cfg_.threads : (int)std::min(32u, hc ? hc : 1u);
   }
 
+  CRAMBatchReader(const CRAMBatchReader&) = delete;
+  CRAMBatchReader& operator=(const CRAMBatchReader&) = delete;
   const BAMConfig& config() const { return cfg_; }
 
   bool read_batch(struct ArrowArray* out) {
@@ -507,25 +506,45 @@ class CRAMBatchReader {
     int64_t start = 0, span = 0;
     uint32_t n_records = 0, n_blocks = 0;
   };
+  // The file is read container by container (positional reads: the workers fetch their own payloads); it is never held whole.
+  std::vector<uint8_t> read_at(size_t off, size_t n) const {
+    if (off > size_ || n > size_ - off) throw std::runtime_error("CRAM: read past the end of the file");
+    std::vector<uint8_t> buf(n);
+    size_t got = 0;
+    while (got < n) {
+      const ssize_t r = pread(fd_, buf.data() + got, n - got, (off_t)(off + got));
+      if (r <= 0) throw std::runtime_error("CRAM: read error");
+      got += (size_t)r;
+    }
+    return buf;
+  }
   ContainerHeader read_container_header() {
-    cram::Cursor c(file_.data() + off_, file_.size() - off_);
-    ContainerHeader h;
-    const int32_t len = c.i32le();
-    if (len < 0) throw std::runtime_error("CRAM: negative container length");
-    h.length = (size_t)len;
-    h.ref_id = c.itf8s();
-    h.start = c.itf8s();
-    h.span = c.itf8s();
-    h.n_records = c.itf8();
-    (void)c.ltf8();
-    (void)c.ltf8();
-    h.n_blocks = c.itf8();
-    const uint32_t nl = c.itf8();
-    for (uint32_t i = 0; i < nl; ++i) (void)c.itf8();
-    c.skip(4);
-    off_ += c.o;
-    if (h.length > file_.size() - off_) throw std::runtime_error("CRAM: container runs past the end of the file");
-    return h;
+    for (size_t window = 4096;; window *= 16) {  // the header is tens of bytes plus one ITF8 per slice landmark
+      const size_t n = std::min(window, size_ - off_);
+      const std::vector<uint8_t> buf = read_at(off_, n);
+      try {
+        cram::Cursor c(buf.data(), buf.size());
+        ContainerHeader h;
+        const int32_t len = c.i32le();
+        if (len < 0) throw std::runtime_error("CRAM: negative container length");
+        h.length = (size_t)len;
+        h.ref_id = c.itf8s();
+        h.start = c.itf8s();
+        h.span = c.itf8s();
+        h.n_records = c.itf8();
+        (void)c.ltf8();
+        (void)c.ltf8();
+        h.n_blocks = c.itf8();
+        const uint32_t nl = c.itf8();
+        for (uint32_t i = 0; i < nl; ++i) (void)c.itf8();
+        c.skip(4);
+        off_ += c.o;
+        if (h.length > size_ - off_) throw std::runtime_error("CRAM: container runs past the end of the file");
+        return h;
+      } catch (const std::runtime_error& e) {
+        if (n == size_ - off_ || window >= (size_t(1) << 28) || std::string(e.what()) != "CRAM: truncated data") throw;
+      }
+    }
   }
 
   // The next group of containers (those that can hold a hit), decoded on `threads` threads, appended in file order.
@@ -538,7 +557,7 @@ class CRAMBatchReader {
     };
     std::vector<Job> jobs;
     const size_t want = (size_t)std::max(1, threads_);
-    while (jobs.size() < want && off_ < file_.size()) {
+    while (jobs.size() < want && off_ < size_) {
       const ContainerHeader h = read_container_header();
       const size_t end = off_ + h.length;
       bool take = h.n_records != 0;  // 0: the EOF container (or an empty one)
@@ -560,7 +579,8 @@ class CRAMBatchReader {
     if (jobs.empty()) return false;
     auto run = [&](Job& j) {
       try {
-        cram::Cursor c(file_.data() + j.off, j.length);
+        const std::vector<uint8_t> buf = read_at(j.off, j.length);
+        cram::Cursor c(buf.data(), buf.size());
         decode_container(c, &j.recs, keep_names ? &j.names : nullptr);
       } catch (const std::exception& e) {
         j.error = e.what();
@@ -756,8 +776,14 @@ class CRAMBatchReader {
 
   BAMConfig cfg_;
   int threads_ = 1;
-  std::vector<uint8_t> file_;
-  size_t off_ = 0;
+  struct Fd {  // closes on destruction, also when the constructor throws
+    int v = -1;
+    ~Fd() {
+      if (v >= 0) ::close(v);
+    }
+  } fdh_;
+  int fd_ = -1;
+  size_t size_ = 0, off_ = 0;
   std::vector<Rec> pending_;
   size_t pending_pos_ = 0;
   int32_t region_ref_id_ = -2;
