@@ -1244,6 +1244,14 @@ __device__ __noinline__ int par_decode_block(const uint8_t* __restrict__ comp /*
         drained = row_end;
       }
     };
+    // the window is the serial path's ring: a late hand-back (only corrupt data gets here) must leave it as it was found,
+    // i.e. holding the last bytes in front of this block, all of which the caller has drained to HBM
+    auto restore_ring = [&]() {
+      __builtin_amdgcn_s_waitcnt(0);
+      const uint32_t lo = o.pos - o.begin > PAR_WIN ? o.pos - PAR_WIN : o.begin;
+      for (uint32_t x = lo + (uint32_t)lane; x < o.pos; x += 64) win[x & PM] = out[x];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
     int bad = 0;
 #ifdef EXON_INFLATE_PROFILE
     uint64_t t_wait = 0, t_rounds = 0;
@@ -1260,7 +1268,10 @@ __device__ __noinline__ int par_decode_block(const uint8_t* __restrict__ comp /*
       const uint32_t bend = (uint32_t)__builtin_amdgcn_readlane((int)(dst + len), (int)nb - 1);
       const uint32_t lo_valid = max(wvalid, bend > PAR_WIN ? bend - PAR_WIN : 0u);
       if (have && is_match && dist > dst - o.begin) bad = 1;  // reaches before the start of the member's output
-      if (__any(bad)) return 9;
+      if (__any(bad)) {
+        restore_ring();
+        return 9;
+      }
       const uint32_t src = dst - dist;
       const bool far = have && is_match && src < lo_valid;
       bool pending = have && is_match && !far;
@@ -1352,7 +1363,10 @@ __device__ __noinline__ int par_decode_block(const uint8_t* __restrict__ comp /*
     }
 #endif
     flush_to(pos);
-    if (pos != o.pos + total) return 10;
+    if (pos != o.pos + total) {
+      restore_ring();
+      return 10;
+    }
   }
   lap(5);
   o.pos += total;
