@@ -34,6 +34,15 @@
 namespace exon {
 namespace cram {
 
+// a byte of the file inside an error message: itself when printable ASCII, \\xHH otherwise
+inline std::string printable(char ch) {
+  const unsigned char u = (unsigned char)ch;
+  if (u >= 0x20 && u < 0x7F) return std::string(1, ch);
+  char buf[8];
+  snprintf(buf, sizeof buf, "\\x%02X", u);
+  return buf;
+}
+
 struct Cursor {  // bounds-checked reads from a byte buffer
   const uint8_t* p;
   size_t n, o = 0;
@@ -127,7 +136,7 @@ inline std::vector<uint8_t> rans_4x8(const uint8_t* data, size_t size) {
   const int order = c.u8();
   (void)c.i32le();
   const uint32_t n = (uint32_t)c.i32le();
-  if (n > (1u << 30)) throw std::runtime_error("CRAM: rANS block too large");
+  if (n > (1u << 28)) throw std::runtime_error("CRAM: rANS block too large");
   std::vector<uint8_t> out(n);
   if (order == 0) {
     std::unique_ptr<RansTable> t(new RansTable);
@@ -188,7 +197,8 @@ inline Block read_block(Cursor& c) {
   const uint32_t csz = c.itf8(), rsz = c.itf8();
   c.need((size_t)csz + 4);
   const uint8_t* src = c.p + c.o;
-  if (rsz > (1u << 30)) throw std::runtime_error("CRAM: block too large");
+  // a corrupt size must not turn into a huge allocation: DEFLATE expands at most ~1032x, rANS blocks are capped outright
+  if (rsz > (1u << 28) || (method == 1 && (uint64_t)rsz > (uint64_t)csz * 1032u + 1024u)) throw std::runtime_error("CRAM: block too large");
   if (method == 0) {
     b.data.assign(src, src + csz);
   } else if (method == 1) {
@@ -640,7 +650,7 @@ class CRAMBatchReader {
           }
           h.skip(ln);
         } else {
-          throw std::runtime_error(std::string("CRAM: preservation key ") + k0 + k1);
+          throw std::runtime_error("CRAM: preservation key " + cram::printable(k0) + cram::printable(k1));
         }
       }
     }
@@ -754,7 +764,7 @@ class CRAMBatchReader {
               case 'Q': (void)sl.get_byte(DS(QS)); break;
               case 'b': sl.skip_bytes(DS(BB)); break;
               case 'q': sl.skip_bytes(DS(QQ)); break;
-              default: throw std::runtime_error(std::string("CRAM: read feature '") + code + "'");
+              default: throw std::runtime_error("CRAM: read feature " + printable(code));
             }
           }
           rec.mapq = sl.get_int(DS(MQ));

@@ -71,14 +71,14 @@ class Context:
         h = C.c_void_p()
         rc = self.lib.exon_hip_ctx_create(device, C.byref(h))
         if rc:
-            raise ExonHipError(rc, self.lib.exon_hip_last_error(None).decode())
+            raise ExonHipError(rc, self.lib.exon_hip_last_error(None).decode(errors="replace"))
         self.h = h
         self.device = device
 
     # -- plumbing ---------------------------------------------------------------------------
     def _check(self, rc):
         if rc < 0:
-            raise ExonHipError(rc, self.lib.exon_hip_last_error(self.h).decode())
+            raise ExonHipError(rc, self.lib.exon_hip_last_error(self.h).decode(errors="replace"))
         return rc
 
     def info(self):
@@ -259,11 +259,11 @@ def bgzf_scan(data, out_base=0):
     ptr = buf.ctypes.data if len(buf) else None
     rc = lib.exon_hip_bgzf_scan(ptr, len(buf), out_base, None, 1 << 30, C.byref(n), C.byref(consumed), C.byref(out_bytes))
     if rc:
-        raise ExonHipError(rc, lib.exon_hip_last_error(None).decode())
+        raise ExonHipError(rc, lib.exon_hip_last_error(None).decode(errors="replace"))
     blocks = (L.BgzfBlock * max(n.value, 1))()
     rc = lib.exon_hip_bgzf_scan(ptr, len(buf), out_base, blocks, n.value, C.byref(n), C.byref(consumed), C.byref(out_bytes))
     if rc:
-        raise ExonHipError(rc, lib.exon_hip_last_error(None).decode())
+        raise ExonHipError(rc, lib.exon_hip_last_error(None).decode(errors="replace"))
     return blocks, n.value, consumed.value, out_bytes.value
 
 
@@ -274,7 +274,7 @@ def parse_region(region):
     a, b = C.c_int64(), C.c_int64()
     rc = lib.exon_hip_parse_region(region.encode(), name, 512, C.byref(a), C.byref(b))
     if rc:
-        raise ExonHipError(rc, lib.exon_hip_last_error(None).decode())
+        raise ExonHipError(rc, lib.exon_hip_last_error(None).decode(errors="replace"))
     return name.value.decode(), a.value, (None if b.value == L.REGION_OPEN_END else b.value)
 
 
@@ -291,7 +291,7 @@ def index_query(index_path, region=None, ref_id=None, start=1, end=None, is_bai=
                                   -1 if ref_id is None else ref_id, start, L.REGION_OPEN_END if end is None else end,
                                   st, en, cap, C.byref(n))
     if rc:
-        raise ExonHipError(rc, lib.exon_hip_last_error(None).decode())
+        raise ExonHipError(rc, lib.exon_hip_last_error(None).decode(errors="replace"))
     return [(st[i], en[i]) for i in range(min(n.value, cap))]
 
 
@@ -303,7 +303,7 @@ def regroup_files_by_size(sizes, target_groups):
     g = (C.c_int32 * max(n, 1))()
     ng = lib.exon_hip_regroup_files_by_size(s, n, target_groups, g)
     if ng < 0:
-        raise ExonHipError(ng, lib.exon_hip_last_error(None).decode())
+        raise ExonHipError(ng, lib.exon_hip_last_error(None).decode(errors="replace"))
     groups = [[] for _ in range(ng)]
     for i in sorted(range(n), key=lambda i: (sizes[i], i)):
         groups[g[i]].append(i)
@@ -324,12 +324,12 @@ class Scan:
         h = C.c_void_p()
         rc = self.lib.exon_hip_scan_open(str(path).encode(), C.byref(opt), C.byref(h))
         if rc:
-            raise ExonHipError(rc, self.lib.exon_hip_last_error(None).decode())
+            raise ExonHipError(rc, self.lib.exon_hip_last_error(None).decode(errors="replace"))
         self.h = h
 
     def _check(self, rc):
         if rc < 0:
-            raise ExonHipError(rc, self.lib.exon_hip_last_error(None).decode())
+            raise ExonHipError(rc, self.lib.exon_hip_last_error(None).decode(errors="replace"))
         return rc
 
     def schema(self):

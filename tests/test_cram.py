@@ -170,3 +170,29 @@ def test_synthetic_cram_with_every_span_changing_feature(tmp_path):
             hit = [i for i in range(n) if want_ref[i] == rname and want_start[i] is not None and want_start[i] <= b and want_end[i] >= a]
             _, f2, _, _, s2, e2 = product_columns(path, region=region)
             assert s2 == [want_start[i] for i in hit] and e2 == [want_end[i] for i in hit] and f2 == [want_flag[i] for i in hit]
+
+
+def test_corrupted_files_never_crash_the_reader(tmp_path):
+    """800 random corruptions of the four fixtures (1-16 bytes overwritten, some files cut short): every one is either decoded
+    or reported as an error -- no crash, no hang, no out-of-bounds read (sizes are checked against the bytes in hand)."""
+    import random
+    rnd = random.Random(7)
+    ok = err = 0
+    for name in FILES:
+        good = open(os.path.join(FX, name), "rb").read()
+        for _ in range(200):
+            b = bytearray(good)
+            for _ in range(rnd.choice([1, 1, 2, 4, 16])):
+                b[rnd.randrange(len(b))] = rnd.randrange(256)
+            if rnd.random() < 0.1:
+                b = b[:rnd.randrange(len(b))]
+            p = tmp_path / "fz.cram"
+            p.write_bytes(bytes(b))
+            try:
+                scan = exon_amd.Scan(str(p), "cram")
+                sum(len(x) for x in scan)
+                scan.close()
+                ok += 1
+            except exon_amd.ExonHipError:
+                err += 1
+    assert ok + err == 800 and err > 400
