@@ -230,7 +230,10 @@ __global__ __launch_bounds__(256) void k_bcf_remap(int32_t* __restrict__ filter_
                                                    const int32_t* __restrict__ ids) {
   if (scalars[1] != 0) return;
   const int64_t n = scalars[0];
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) filter_id[i] = ids[filter_id[i]];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const unsigned slot = (unsigned)filter_id[i];
+    filter_id[i] = slot < (unsigned)FSLOTS ? ids[slot] : 0;
+  }
 }
 
 }  // namespace

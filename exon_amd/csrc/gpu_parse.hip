@@ -252,6 +252,12 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
     auto fend = [&](int f) { return f < nf ? fs[f + 1] - 1 : end; };
     if (nf < 7 || begin == end || text[begin] == '#') {
       bad = true;  // not a data line with 8 fields
+      // the row's slots still get defined values: k_remap_filters indexes a table with filter_id, and the buffers are
+      // recycled between scans (a corrupted file after other scans faulted there: found by tools/fuzz_gpu_decode.py)
+      out.chrom_id[row] = 0;
+      out.pos[row] = 0;
+      out.qual[row] = 0.f;
+      out.filter_id[row] = 0;
     } else {
       // CHROM
       {
@@ -435,7 +441,10 @@ __global__ __launch_bounds__(256) void k_assign_filters(const uint8_t* __restric
 __global__ __launch_bounds__(TPB) void k_remap_filters(int32_t* __restrict__ filter_id, const unsigned* __restrict__ n_lines_p,
                                                        const int32_t* __restrict__ ids, unsigned cap) {
   const int64_t n = min(*n_lines_p, cap);
-  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) filter_id[i] = ids[filter_id[i]];
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    const unsigned slot = (unsigned)filter_id[i];
+    filter_id[i] = slot < (unsigned)FILTER_SLOTS ? ids[slot] : 0;
+  }
 }
 
 }  // namespace

@@ -371,7 +371,7 @@ class Scan:
         for i in range(self.dictionary_size(column)):
             p = C.c_char_p()
             self._check(self.lib.exon_hip_scan_dictionary_value(self.h, column, i, C.byref(p)))
-            out.append(p.value.decode())
+            out.append(p.value.decode(errors="replace"))
         return out
 
     def intern(self, column, name):
@@ -445,7 +445,7 @@ class VCFParser:
         raw = buf.raw
         for _ in range(n.value):
             e = raw.index(b"\0", o)
-            names.append(raw[o:e].decode())
+            names.append(raw[o:e].decode(errors="replace"))
             o = e + 1
         return names
 
@@ -631,7 +631,7 @@ class Stream:
         n = C.c_int64()
         rc = self.ctx.lib.exon_hip_stream_consume_scan(self.h, scan.h, C.byref(n))
         if rc < 0:
-            msg = self.ctx.lib.exon_hip_last_error(self.ctx.h).decode() or self.ctx.lib.exon_hip_last_error(None).decode()
+            msg = self.ctx.lib.exon_hip_last_error(self.ctx.h).decode(errors="replace") or self.ctx.lib.exon_hip_last_error(None).decode(errors="replace")
             raise ExonHipError(rc, msg)
         return n.value
 

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Corrupted files through the GPU decode pipelines (inflate + record splitting + parse on the device): every input must
+either give the host decoder's answer or raise -- never hang, never a different answer.  usage: fuzz_gpu_decode.py [n_per_format]"""
+import os, random, struct, sys, zlib
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import exon_amd
+from bgzf_index_writer import bgzf_blocks
+FX = os.path.join(ROOT, "tests", "golden", "ref_fixtures")
+
+
+def bgzf_file(data, chunk=65280):
+    out = []
+    for i in list(range(0, len(data), chunk)) + [None]:
+        d = b"" if i is None else data[i:i + chunk]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        c = co.compress(d) + co.flush()
+        bs = 12 + 6 + len(c) + 8
+        out.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 6) + b"BC\x02\0" + struct.pack("<H", bs - 1) + c +
+                   struct.pack("<II", zlib.crc32(d) & 0xFFFFFFFF, len(d)))
+    return b"".join(out)
+
+
+def answer(ctx, path, fmt, gpu):
+    scan = exon_amd.Scan(path, fmt, gpu_parse=gpu)
+    if fmt in ("bam", "sam"):
+        plan = ctx.plan_flag_mapq_group_count(0, 0, 0, max(1, scan.dictionary_size(2)), columns=(0, 1, 2))
+    else:
+        plan = ctx.plan_region_count(0, 1, None, columns=(0, 1))
+    st = plan.open()
+    try:
+        rows = st.consume(scan)
+        counts, _ = st.finish()
+        return rows, tuple(int(x) for x in counts)
+    finally:
+        st.close(); plan.close(); scan.close()
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    rnd = random.Random(9)
+    ctx = exon_amd.Context(0)
+    only = os.environ.get("FUZZ_ONLY")
+    srcs = {"bam": ("bam/test.bam", True), "bcf": ("bcf/index.bcf", True), "vcf": ("vcf/index.vcf.gz", True), "sam": ("sam/test.sam", False)}
+    for fmt, (rel, framed) in srcs.items():
+        good = open(os.path.join(FX, rel), "rb").read()
+        raw = b"".join(d for _, _, d in bgzf_blocks(good)) if framed else good
+        same = both_err = gpu_only_err = 0
+        for it in range(n):
+            b = bytearray(raw)
+            lo = 0 if rnd.random() < 0.2 else min(len(b) - 1, 1500)
+            for _ in range(rnd.choice([1, 1, 2, 4, 16])):
+                b[rnd.randrange(lo, len(b))] = rnd.randrange(256)
+            if rnd.random() < 0.1:
+                b = b[:rnd.randrange(1, len(b))]
+            if only and fmt != only:  # same random stream, nothing run
+                continue
+            path = f"/tmp/fz_gpu.{fmt}" + (".gz" if fmt == "vcf" else "")
+            open(path, "wb").write(bgzf_file(bytes(b)) if framed else bytes(b))
+            if os.environ.get("FUZZ_KEEP"):  # the input that is running when the process dies
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                open(os.path.join(ROOT, "gpurun_out", "fuzz_last." + fmt), "wb").write(bytes(b))
+                print(fmt, it, flush=True)
+            if os.environ.get("FUZZ_SAVE_DIR"):
+                open(os.path.join(os.environ["FUZZ_SAVE_DIR"], f"{fmt}_{it:03d}"), "wb").write(bytes(b))
+            try:
+                h = answer(ctx, path, fmt, False)
+            except exon_amd.ExonHipError:
+                h = None
+            try:
+                g = answer(ctx, path, fmt, True)
+            except exon_amd.ExonHipError:
+                g = None
+            if h is None and g is None:
+                both_err += 1
+            elif g is None:
+                gpu_only_err += 1
+            else:
+                assert g == h, (fmt, it, g, h)
+                same += 1
+        print(fmt, "same answer", same, "both rejected", both_err, "only the GPU path rejected", gpu_only_err, flush=True)
+
+
+if __name__ == "__main__":
+    main()
