@@ -24,7 +24,9 @@ def bgzf_file(data, chunk=65280):
 
 def answer(ctx, path, fmt, gpu):
     scan = exon_amd.Scan(path, fmt, gpu_parse=gpu)
-    if fmt in ("bam", "sam"):
+    if fmt == "fastq":
+        plan = ctx.plan_qual_pos_hist(256, columns=(3,))
+    elif fmt in ("bam", "sam"):
         plan = ctx.plan_flag_mapq_group_count(0, 0, 0, max(1, scan.dictionary_size(2)), columns=(0, 1, 2))
     else:
         plan = ctx.plan_region_count(0, 1, None, columns=(0, 1))
@@ -82,5 +84,47 @@ def main():
         print(fmt, "same answer", same, "both rejected", both_err, "only the GPU path rejected", gpu_only_err, flush=True)
 
 
+def big():
+    """multi-slab inputs: synthetic files of 150 k records, 1 MB slabs, corrupted before framing"""
+    import subprocess
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+    os.environ["EXON_HIP_GPU_PARSE_SLAB_MB"] = "1"
+    rnd = random.Random(21)
+    ctx = exon_amd.Context(0)
+    gen = os.path.join(ROOT, "tools", "bin", "gen_text")
+    for fmt, kind, framed in (("vcf", "vcf", True), ("bam", "bam", True), ("sam", "sam", False), ("fastq", "fastq", False), ("fastq", "fastq", True), ("bcf", "bcf", True)):
+        subprocess.check_call([gen, kind, "150000", "/tmp/fz_big.raw"] + (["100"] if kind in ("bam", "sam") else []))
+        raw = open("/tmp/fz_big.raw", "rb").read()
+        same = both_err = gpu_only_err = 0
+        for it in range(n):
+            b = bytearray(raw)
+            for _ in range(rnd.choice([0, 1, 2, 8, 64])):
+                b[rnd.randrange(min(len(b) - 1, 3000), len(b))] = rnd.randrange(256)
+            if rnd.random() < 0.15:
+                b = b[:rnd.randrange(len(b) // 2, len(b))]
+            ext = {"vcf": ".vcf.gz", "bam": ".bam", "bcf": ".bcf", "sam": ".sam", "fastq": ".fastq.gz" if framed else ".fastq"}[fmt]
+            path = "/tmp/fz_big" + ext
+            open(path, "wb").write(bgzf_file(bytes(b)) if framed else bytes(b))
+            try:
+                h = answer(ctx, path, fmt, False)
+            except exon_amd.ExonHipError:
+                h = None
+            try:
+                g = answer(ctx, path, fmt, True)
+            except exon_amd.ExonHipError:
+                g = None
+            if h is None and g is None:
+                both_err += 1
+            elif g is None:
+                gpu_only_err += 1
+            else:
+                assert g == h, (fmt, it, g and g[0], h and h[0])
+                same += 1
+        print("big", fmt, "framed" if framed else "plain", "same answer", same, "both rejected", both_err, "only the GPU path rejected", gpu_only_err, flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "big":
+        big()
+    else:
+        main()
