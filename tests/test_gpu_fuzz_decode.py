@@ -17,7 +17,7 @@ def test_corrupted_files_give_the_host_answer_or_an_error():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu_decode.py"), "60"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if "same answer" in l]
-    assert len(lines) == 4
+    assert len(lines) == 8
     for l in lines:
         w = l.split()
         same, both, gpu_only = int(w[3]), int(w[6]), int(w[-1])

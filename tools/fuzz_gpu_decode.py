@@ -23,7 +23,23 @@ def bgzf_file(data, chunk=65280):
 
 
 def answer(ctx, path, fmt, gpu):
-    scan = exon_amd.Scan(path, fmt, gpu_parse=gpu)
+    if fmt in ("vcfinfo", "bcfinfo"):  # typed INFO keys + the config-4 shape: WHERE info.DP > 1, AVG(qual), COUNT(*) GROUP BY filter
+        scan = exon_amd.Scan(path, fmt[:3], info_field="DP,MQ0F,MQSB", gpu_parse=gpu)
+        plan = ctx.plan_cmp_avg_by_group(">", 1.0, 64, columns=(4, 2, 3))
+        st = plan.open()
+        try:
+            rows = st.consume(scan)
+            counts, sums = st.finish()
+            # FILTER ids are interned in first-seen order, which may differ between the paths: compare the multiset
+            groups = sorted((int(counts[g]), int(counts[64 + g]), round(float(sums[g]), 3)) for g in range(64) if counts[64 + g])
+            return rows, tuple(groups)
+        finally:
+            st.close(); plan.close(); scan.close()
+    if fmt in ("vcfreg", "bamreg"):  # a pushed-down region without an index: the whole file is decoded, rows are masked
+        scan = exon_amd.Scan(path, fmt[:3], region="1:10000000-10000100" if fmt == "vcfreg" else "chr1:1-12209145", use_index=False, gpu_parse=gpu)
+        fmt = fmt[:3]
+    else:
+        scan = exon_amd.Scan(path, fmt, gpu_parse=gpu)
     if fmt == "fastq":
         plan = ctx.plan_qual_pos_hist(256, columns=(3,))
     elif fmt in ("bam", "sam"):
@@ -44,7 +60,7 @@ def main():
     rnd = random.Random(9)
     ctx = exon_amd.Context(0)
     only = os.environ.get("FUZZ_ONLY")
-    srcs = {"bam": ("bam/test.bam", True), "bcf": ("bcf/index.bcf", True), "vcf": ("vcf/index.vcf.gz", True), "sam": ("sam/test.sam", False)}
+    srcs = {"vcfreg": ("vcf/index.vcf.gz", True), "bamreg": ("bam/test.bam", True), "vcfinfo": ("vcf/index.vcf.gz", True), "bcfinfo": ("bcf/index.bcf", True), "bam": ("bam/test.bam", True), "bcf": ("bcf/index.bcf", True), "vcf": ("vcf/index.vcf.gz", True), "sam": ("sam/test.sam", False)}
     for fmt, (rel, framed) in srcs.items():
         good = open(os.path.join(FX, rel), "rb").read()
         raw = b"".join(d for _, _, d in bgzf_blocks(good)) if framed else good
@@ -58,7 +74,7 @@ def main():
                 b = b[:rnd.randrange(1, len(b))]
             if only and fmt != only:  # same random stream, nothing run
                 continue
-            path = f"/tmp/fz_gpu.{fmt}" + (".gz" if fmt == "vcf" else "")
+            path = f"/tmp/fz_gpu.{fmt[:3]}" + (".gz" if fmt.startswith("vcf") else "")
             open(path, "wb").write(bgzf_file(bytes(b)) if framed else bytes(b))
             if os.environ.get("FUZZ_KEEP"):  # the input that is running when the process dies
                 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
