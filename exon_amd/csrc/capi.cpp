@@ -180,7 +180,10 @@ int exon_hip_ctx_destroy(exon_hip_ctx* ctx) {
   }
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
-  if (ctx->stream) hipStreamDestroy(ctx->stream);
+  if (ctx->stream) {
+    exon_bgzf_forget_stream(ctx->stream);
+    hipStreamDestroy(ctx->stream);
+  }
   delete ctx;
   return EXON_HIP_OK;
 }

@@ -1826,6 +1826,25 @@ extern "C" int exon_hip_bgzf_inflate_par_stats(void* stream, uint32_t* out32) {
   return hipMemcpy(out32, st, 32 * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 
+void exon_bgzf_forget_stream(hipStream_t s) {
+  int dev = 0;
+  if (!s || hipGetDevice(&dev) != hipSuccess) return;
+  std::lock_guard<std::mutex> g(g_par_mu);
+  auto key = std::make_pair(dev, s);
+  auto it = g_par_pools.find(key);
+  if (it != g_par_pools.end()) {
+    if (it->second.mem) hipFree(it->second.mem);
+    g_par_pools.erase(it);
+  }
+  auto sd = g_par_side.find(key);
+  if (sd != g_par_side.end()) {
+    if (sd->second.side) hipStreamDestroy(sd->second.side);
+    if (sd->second.ev_fork) hipEventDestroy(sd->second.ev_fork);
+    if (sd->second.ev_join) hipEventDestroy(sd->second.ev_join);
+    g_par_side.erase(sd);
+  }
+}
+
 hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const exon_hip_bgzf_block* d_blocks, int n_blocks,
                                     uint8_t* d_out, int* d_status, bool verify_crc) {
   if (n_blocks <= 0) return hipSuccess;

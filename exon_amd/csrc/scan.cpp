@@ -416,7 +416,10 @@ struct SlabBuffers {
   hipStream_t cs = nullptr, xs = nullptr;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   void free_all() {
-    if (cs) hipStreamDestroy(cs);
+    if (cs) {
+      exon_bgzf_forget_stream(cs);
+      hipStreamDestroy(cs);
+    }
     if (xs) hipStreamDestroy(xs);
     cs = xs = nullptr;
     for (auto& e : ev) {
