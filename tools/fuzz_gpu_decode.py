@@ -57,7 +57,7 @@ def answer(ctx, path, fmt, gpu):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-    rnd = random.Random(9)
+    rnd = random.Random(int(os.environ.get("FUZZ_SEED", 9)))
     ctx = exon_amd.Context(0)
     only = os.environ.get("FUZZ_ONLY")
     srcs = {"vcfreg": ("vcf/index.vcf.gz", True), "bamreg": ("bam/test.bam", True), "vcfinfo": ("vcf/index.vcf.gz", True), "bcfinfo": ("bcf/index.bcf", True), "bam": ("bam/test.bam", True), "bcf": ("bcf/index.bcf", True), "vcf": ("vcf/index.vcf.gz", True), "sam": ("sam/test.sam", False)}
@@ -105,7 +105,7 @@ def big():
     import subprocess
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 12
     os.environ["EXON_HIP_GPU_PARSE_SLAB_MB"] = "1"
-    rnd = random.Random(21)
+    rnd = random.Random(int(os.environ.get("FUZZ_SEED", 21)))
     ctx = exon_amd.Context(0)
     gen = os.path.join(ROOT, "tools", "bin", "gen_text")
     for fmt, kind, framed in (("vcf", "vcf", True), ("bam", "bam", True), ("sam", "sam", False), ("fastq", "fastq", False), ("fastq", "fastq", True), ("bcf", "bcf", True)):
