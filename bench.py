@@ -140,6 +140,7 @@ class Workload:
             self.fused = os.environ.get("EXON_BENCH_C5_FUSED", "1") != "0"
             self.plan = ctx.plan_qual_pos_hist(self.L)
         self.n_i64, self.n_f64 = self.plan.n_i64, self.plan.n_f64
+        self._go = None
         self.state = torch.zeros(self.n_i64 + self.n_f64, dtype=torch.int64, device=dev)
         self.counts = self.state[:self.n_i64]
         self.sums = self.state[self.n_i64:].view(torch.float64) if self.n_f64 else None
@@ -156,7 +157,10 @@ class Workload:
                 for k, (cols, nb_) in enumerate(self.chunks):
                     self.plan.launch(cols, nb_, self.state.data_ptr(), overwrite=(k == 0), stream=s)
         else:
-            self.plan.launch(self.cols, self.n, self.state.data_ptr(), overwrite=True, stream=s)
+            if self._go is None or self._go_stream != s:  # arguments marshalled once per (table, stream)
+                self._go = self.plan.prepared(self.cols, self.n, self.state.data_ptr(), overwrite=True, stream=s)
+                self._go_stream = s
+            self._go()
 
 
 def cpu_baseline(kind, sample_rows, n_total, reps):
@@ -222,21 +226,23 @@ def cpu_baseline(kind, sample_rows, n_total, reps):
     return res, out
 
 
-def time_config(ctx, kind, rows, steps=20, warmup=3):
+def time_config(ctx, kind, rows, steps=50, warmup=5):
     """A config at the size BASELINE.json states it (c2 @ 1e7, c3 @ 1e8): (ms per step, kernel ms, roofline fraction)."""
     wl = Workload(ctx, kind, rows, 0, rows)
     for _ in range(warmup):
         wl.run()
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    # ONE event pair around the K back-to-back steps: at these sizes a step is 20-250 us of GPU time and per-step event
+    # records would be a visible share of it; kernel_ms = GPU time between the two events / K (gaps between steps included)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    e0.record()
     for i in range(steps):
-        ev[i][0].record()
         wl.run()
-        ev[i][1].record()
+    e1.record()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    kms = sum(a.elapsed_time(b) for a, b in ev) / steps
+    kms = e0.elapsed_time(e1) / steps
     gbs = rows * BYTES_PER_ROW[kind] / (kms * 1e-3) / 1e9
     return {"rows": rows, "ms_per_step": round(ms, 4), "kernel_ms": round(kms, 4), "Mrows_per_s": round(rows / ms / 1e3, 1),
             "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
@@ -260,13 +266,41 @@ def h2d_inclusive(ctx, n=64_000_000):
     return out
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start the N ranks ourselves with the driver's own command line
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...) and pass its output and exit code through.  The
+    line printed then says n_gpus = N, or the run fails: `--gpus 8` can never come back as a 1-GPU number."""
+    import socket
+    import subprocess
+    share = os.environ.get("EXON_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < 1:
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    if have < a.gpus and not share:
+        raise SystemExit(f"--gpus {a.gpus} but this node exposes {have} GPU(s) (EXON_BENCH_SHARE_GPU=1 lets all ranks share cuda:0 "
+                         f"for launcher tests; it measures nothing)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     a = parse_args()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if a.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus} ...)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
     # one process per GPU.  EXON_BENCH_SHARE_GPU=1 is a test hook for 1-GPU boxes: all ranks share cuda:0 and the
@@ -345,6 +379,8 @@ def main():
             else:
                 native = None
 
+    rccl_ranks = native.count()[0] if native is not None else (world if (world > 1 and not share) else None)
+
     def merge():
         if world == 1:
             return
@@ -398,6 +434,9 @@ def main():
                        "rows_total": n_total, "rows_per_gpu": rows,
                        "sharding": f"rank k owns the contiguous row range (file split) [k N/{world}, (k+1) N/{world})",
                        "reduce": merge_path, "state_bytes": V * 8,
+                       "rccl_ranks": rccl_ranks,  # ncclCommCount of the communicator the merge ran on (None: 1 GPU / gloo test hook)
+                       "rccl_ranks_source": ("ncclCommCount" if native is not None else
+                                             "torch.distributed world size (RCCL backend)" if rccl_ranks else None),
                        "bytes_per_row": bpr, "arithmetic": ARITH[a.workload],
                        "generator": GENERATOR_NOTE.get(a.workload, "counter-based generator of DESIGN.md section 5")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -157,6 +157,7 @@ SIGNATURES = {
     "exon_hip_rccl_unique_id": (C.c_int, [_vp]),
     "exon_hip_rccl_comm_init": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_vp)]),
     "exon_hip_rccl_comm_destroy": (C.c_int, [_vp]),
+    "exon_hip_rccl_comm_count": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "exon_hip_stream_reset": (C.c_int, [_vp]),
     "exon_hip_stream_open": (C.c_int, [_vp, _i32, C.POINTER(_vp)]),
     "exon_hip_stream_push": (C.c_int, [_vp, C.POINTER(ArrowArray)]),

@@ -160,8 +160,120 @@ __global__ __launch_bounds__(256) void finalize_partials(const unsigned long lon
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Single-launch step (round 3): the LAST workgroup to finish folds the per-workgroup records, in the same fixed
+// order as finalize_partials, so a step is ONE kernel -- no dependent launch (~3 us on this chip) and half the host
+// launch cost, which is what configs 2 / 3 and the 125e6-row shard of an 8-GPU run are made of.
+// Round 2's ticket pattern used agent-scope release / acquire FENCES, which on gfx950 are L2 writeback / invalidate
+// scans (the 8 XCDs do not share an L2) and cost more than the second launch.  This one needs no fence:
+//   * a workgroup's record words are written with agent-scope relaxed ATOMIC stores (global_store ... sc1: written
+//     through to the memory side, never left dirty in this XCD's L2);
+//   * s_waitcnt vmcnt(0) in the writing waves + the workgroup barrier: those stores are acknowledged before
+//   * thread 0 takes a ticket (agent-scope relaxed fetch-add on ws.status[2]);
+//   * the workgroup that draws the last ticket reads every record with agent-scope relaxed ATOMIC loads (sc1: served
+//     from the memory side, not from a stale L2 line), folds them block 0, 1, ... (bit-reproducible f64 sums for a
+//     given launch shape), writes the state and resets the ticket for the next launch on this stream.
+// Only records of <= FUSE_MAX_V words take this route: bigger ones (LDS group tables) are a multi-workgroup job and
+// keep the finalize_partials launch.  EXON_HIP_FUSE_FOLD=0 turns it off (A/B runs).
+// ------------------------------------------------------------------------------------------------
+constexpr int FUSE_MAX_V = 256;
+struct FoldArgs {
+  unsigned* ticket;  // nullptr: no fused fold (finalize_partials follows)
+  int64_t* st_i64;
+  double* st_f64;
+  int V, n_i64, overwrite;
+};
+__device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Call with ALL threads of the workgroup after the record `partials[blockIdx.x * V ...]` was written with st_agent().
+template <int THREADS>
+__device__ __forceinline__ void fold_if_last(const FoldArgs& fa, const unsigned long long* __restrict__ partials) {
+  __shared__ unsigned long long fold_red[THREADS];
+  __shared__ int fold_last;
+  __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): this wave's record stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(fa.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fold_last = (prev == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!fold_last) return;
+  // thread = (segment of the workgroup range) x (value): VP values side by side, THREADS / VP segments; a segment adds
+  // its blocks in order (8 independent loads in flight), the segments are combined by a fixed binary tree.
+  const int nblocks = (int)gridDim.x, V = fa.V, n_i64 = fa.n_i64;
+  const int lg = V > 16 ? 5 : V > 8 ? 4 : V > 4 ? 3 : V > 2 ? 2 : V > 1 ? 1 : 0;
+  const int VP = 1 << lg, SEGS = THREADS >> lg;
+  const int vi = threadIdx.x & (VP - 1), seg = threadIdx.x >> lg;
+  const int per = (nblocks + SEGS - 1) / SEGS;
+  const int b0 = seg * per, b1 = min(nblocks, b0 + per);
+  for (int v0 = 0; v0 < V; v0 += VP) {
+    const int v = v0 + vi;
+    const bool is_int = v < n_i64;
+    unsigned long long acc_i = 0;
+    double acc_f = 0.0;
+    if (v < V) {
+      const unsigned long long* p = partials + v;
+      for (int b = b0; b < b1; b += 8) {
+        unsigned long long a[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = (b + i < b1) ? ld_agent(p + (size_t)(b + i) * V) : 0ull;  // 0 bits = +0.0
+        if (is_int) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc_i += a[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc_f += __longlong_as_double((long long)a[i]);
+        }
+      }
+    }
+    fold_red[threadIdx.x] = is_int ? acc_i : (unsigned long long)__double_as_longlong(acc_f);
+    __syncthreads();
+    for (int st = SEGS >> 1; st > 0; st >>= 1) {
+      if (seg < st) {
+        const unsigned long long x = fold_red[threadIdx.x], y = fold_red[threadIdx.x + (st << lg)];
+        fold_red[threadIdx.x] =
+            is_int ? x + y
+                   : (unsigned long long)__double_as_longlong(__longlong_as_double((long long)x) + __longlong_as_double((long long)y));
+      }
+      __syncthreads();
+    }
+    if (seg == 0 && v < V) {
+      if (is_int) {
+        fa.st_i64[v] = (fa.overwrite ? 0 : fa.st_i64[v]) + (int64_t)fold_red[threadIdx.x];
+      } else {
+        fa.st_f64[v - n_i64] = (fa.overwrite ? 0.0 : fa.st_f64[v - n_i64]) + __longlong_as_double((long long)fold_red[threadIdx.x]);
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(fa.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+static bool fuse_fold_enabled() {
+  static const bool on = [] {
+    const char* v = getenv("EXON_HIP_FUSE_FOLD");
+    return !(v && v[0] == '0');
+  }();
+  return on;
+}
+static FoldArgs fold_args(const LaunchCfg& cfg, const Workspace& ws, int V, int n_i64, int64_t* st_i64, double* st_f64) {
+  FoldArgs fa;
+  fa.ticket = (fuse_fold_enabled() && V <= FUSE_MAX_V) ? reinterpret_cast<unsigned*>(ws.status + 2) : nullptr;
+  fa.st_i64 = st_i64;
+  fa.st_f64 = st_f64;
+  fa.V = V;
+  fa.n_i64 = n_i64;
+  fa.overwrite = cfg.overwrite ? 1 : 0;
+  return fa;
+}
+
 static hipError_t run_finalize(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, int nblocks, int V, int n_i64,
                                int64_t* st_i64, double* st_f64) {
+  if (fuse_fold_enabled() && V <= FUSE_MAX_V) return hipSuccess;  // folded by the main kernel's last workgroup
   const int grid = (V + 31) / 32;
   hipLaunchKernelGGL(finalize_partials, dim3(grid), dim3(256), 0, s, ws.partials, nblocks, V, n_i64, st_i64, st_f64,
                      cfg.overwrite ? 1 : 0);
@@ -206,14 +318,26 @@ static int resident_blocks(F f, int threads, size_t lds) {
   return nb;
 }
 
-// The big shape pays off as soon as every CU gets a 16384-row tile (>= 4.2 M rows on 256 CUs).
-static bool use_big_shape(const LaunchCfg& cfg, int64_t n) {
-  static const int min_tiles = [] {
-    const char* v = getenv("EXON_HIP_BIG_MIN_TILES");
-    return v && atoi(v) > 0 ? atoi(v) : 1;  // measured: even ~2 tiles per CU beat the 256-thread shape (10 M rows: 41 -> 31 us)
+// The big shapes pay off as soon as every CU gets a tile (>= 2.1 M rows on 256 CUs: even ~2 tiles per CU beat the
+// 256-thread shape, 10 M rows: 41 -> 31 us).  Between J = 4 (16384-row tiles) and J = 2 (8192-row tiles) the static
+// tile -> workgroup deal decides: the critical path is ceil(tiles / CUs) tiles, which at 10 M rows (config 2's stated
+// size) is 3 x 16384 rows with J = 4 but 5 x 8192 with J = 2 (610 tiles over 256 CUs leave a third round that only a
+// third of the chip works on).  Ties go to the bigger tile (more loads in flight per lane).
+enum { SHAPE_SMALL = 0, SHAPE_BIG_J2 = 1, SHAPE_BIG_J4 = 2 };
+static int pick_shape(const LaunchCfg& cfg, int64_t n) {
+  static const int forced = [] {
+    const char* v = getenv("EXON_HIP_SHAPE");  // A/B runs: 0 small, 1 big J=2, 2 big J=4
+    return v && v[0] >= '0' && v[0] <= '2' ? v[0] - '0' : -1;
   }();
-  return n / ShapeOf<ShapeBig>::TILE >= (int64_t)cfg.compute_units * min_tiles;
+  if (forced >= 0) return forced;
+  const int64_t cus = std::max(cfg.compute_units, 1);
+  const int64_t t2 = n / ShapeOf<ShapeBigJ2>::TILE, t4 = n / ShapeOf<ShapeBig>::TILE;
+  if (t2 < cus) return SHAPE_SMALL;
+  if (t4 < cus) return SHAPE_BIG_J2;
+  const int64_t c4 = ((t4 + cus - 1) / cus) * ShapeOf<ShapeBig>::TILE, c2 = ((t2 + cus - 1) / cus) * ShapeOf<ShapeBigJ2>::TILE;
+  return c2 < c4 ? SHAPE_BIG_J2 : SHAPE_BIG_J4;
 }
+static bool use_big_shape(const LaunchCfg& cfg, int64_t n) { return pick_shape(cfg, n) != SHAPE_SMALL; }
 
 template <typename S>
 static int grid_for(const LaunchCfg& cfg, int64_t n, int resident) {
@@ -244,7 +368,7 @@ __global__ __launch_bounds__(S::THREADS) void k2_region_count_main(const int32_t
                                                                    const uint8_t* __restrict__ pvalid, int64_t n,
                                                                    int32_t id, int64_t a, int64_t b,
                                                                    unsigned long long* __restrict__ partials,
-                                                                   const uint8_t* __restrict__ ones) {
+                                                                   const uint8_t* __restrict__ ones, const FoldArgs fa) {
   constexpr int J = S::J, THREADS = S::THREADS, WAVES = ShapeOf<S>::WAVES, WT = ShapeOf<S>::WAVE_TILE,
                 TILE = ShapeOf<S>::TILE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -284,8 +408,9 @@ __global__ __launch_bounds__(S::THREADS) void k2_region_count_main(const int32_t
     unsigned long long t = 0;
 #pragma unroll
     for (int i = 0; i < WAVES; ++i) t += red[i];
-    partials[blockIdx.x] = t;
+    st_agent(&partials[blockIdx.x], t);
   }
+  if (fa.ticket) fold_if_last<THREADS>(fa, partials);
 }
 
 size_t k2_partial_words(const LaunchCfg& cfg) { return (size_t)max_grid(cfg); }
@@ -293,12 +418,12 @@ size_t k2_partial_words(const LaunchCfg& cfg) { return (size_t)max_grid(cfg); }
 template <typename S>
 static hipError_t k2_launch(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* chrom,
                             const uint8_t* cv, const int64_t* pos, const uint8_t* pv, int64_t n, int32_t id,
-                            int64_t a, int64_t b, int* grid_out) {
+                            int64_t a, int64_t b, int* grid_out, const FoldArgs& fa) {
   static const int resident = resident_blocks(k2_region_count_main<S>, S::THREADS, 0);
   const int grid = grid_for<S>(cfg, n, resident);
   *grid_out = grid;
   hipLaunchKernelGGL(k2_region_count_main<S>, dim3(grid), dim3(S::THREADS), 0, s, chrom, cv, pos, pv, n, id, a, b,
-                     ws.partials, reinterpret_cast<const uint8_t*>(ws.status + 8));
+                     ws.partials, reinterpret_cast<const uint8_t*>(ws.status + 8), fa);
   return hipGetLastError();
 }
 
@@ -307,9 +432,13 @@ hipError_t launch_region_count(hipStream_t s, const LaunchCfg& cfg, const Worksp
                                int32_t region_chrom, int64_t start, int64_t end, int64_t* d_count) {
   if (n <= 0) return hipSuccess;
   int grid = 1;
-  hipError_t e = use_big_shape(cfg, n)
-                     ? k2_launch<ShapeBig>(s, cfg, ws, chrom, chrom_valid, pos, pos_valid, n, region_chrom, start, end, &grid)
-                     : k2_launch<ShapeSmall>(s, cfg, ws, chrom, chrom_valid, pos, pos_valid, n, region_chrom, start, end, &grid);
+  const FoldArgs fa = fold_args(cfg, ws, 1, 1, d_count, nullptr);
+  const int shape = pick_shape(cfg, n);
+  hipError_t e = shape == SHAPE_BIG_J4
+                     ? k2_launch<ShapeBig>(s, cfg, ws, chrom, chrom_valid, pos, pos_valid, n, region_chrom, start, end, &grid, fa)
+                 : shape == SHAPE_BIG_J2
+                     ? k2_launch<ShapeBigJ2>(s, cfg, ws, chrom, chrom_valid, pos, pos_valid, n, region_chrom, start, end, &grid, fa)
+                     : k2_launch<ShapeSmall>(s, cfg, ws, chrom, chrom_valid, pos, pos_valid, n, region_chrom, start, end, &grid, fa);
   if (e != hipSuccess) return e;
   return run_finalize(s, cfg, ws, grid, 1, 1, d_count, nullptr);
 }
@@ -340,7 +469,7 @@ __global__ __launch_bounds__(S::THREADS) void k6_overlap_count_main(const int32_
                                                                     const uint8_t* __restrict__ evalid, int64_t n,
                                                                     int32_t id, int64_t a, int64_t b,
                                                                     unsigned long long* __restrict__ partials,
-                                                                    const uint8_t* __restrict__ ones) {
+                                                                    const uint8_t* __restrict__ ones, const FoldArgs fa) {
   constexpr int J = S::J, THREADS = S::THREADS, WAVES = ShapeOf<S>::WAVES, WT = ShapeOf<S>::WAVE_TILE,
                 TILE = ShapeOf<S>::TILE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -383,19 +512,20 @@ __global__ __launch_bounds__(S::THREADS) void k6_overlap_count_main(const int32_
     unsigned long long t = 0;
 #pragma unroll
     for (int i = 0; i < WAVES; ++i) t += red[i];
-    partials[blockIdx.x] = t;
+    st_agent(&partials[blockIdx.x], t);
   }
+  if (fa.ticket) fold_if_last<THREADS>(fa, partials);
 }
 
 template <typename S, bool STRICT>
 static hipError_t k6_launch(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* ref, const uint8_t* rv,
                             const int64_t* start, const uint8_t* sv, const int64_t* end, const uint8_t* ev, int64_t n,
-                            int32_t id, int64_t a, int64_t b, int* grid_out) {
+                            int32_t id, int64_t a, int64_t b, int* grid_out, const FoldArgs& fa) {
   static const int resident = resident_blocks(k6_overlap_count_main<S, STRICT>, S::THREADS, 0);
   const int grid = grid_for<S>(cfg, n, resident);
   *grid_out = grid;
   hipLaunchKernelGGL((k6_overlap_count_main<S, STRICT>), dim3(grid), dim3(S::THREADS), 0, s, ref, rv, start, sv, end, ev, n, id, a, b,
-                     ws.partials, reinterpret_cast<const uint8_t*>(ws.status + 8));
+                     ws.partials, reinterpret_cast<const uint8_t*>(ws.status + 8), fa);
   return hipGetLastError();
 }
 
@@ -408,7 +538,8 @@ hipError_t launch_overlap_count(hipStream_t s, const LaunchCfg& cfg, const Works
   const bool big = use_big_shape(cfg, n);
   hipError_t e;
 #define EXON_K6(SHAPE, STRICT) \
-  k6_launch<SHAPE, STRICT>(s, cfg, ws, ref, ref_valid, start, start_valid, end, end_valid, n, region_ref, region_start, region_end, &grid)
+  k6_launch<SHAPE, STRICT>(s, cfg, ws, ref, ref_valid, start, start_valid, end, end_valid, n, region_ref, region_start, region_end, &grid, fa)
+  const FoldArgs fa = fold_args(cfg, ws, 1, 1, d_count, nullptr);
   if (strict) e = big ? EXON_K6(ShapeBigJ2, true) : EXON_K6(ShapeSmall, true);
   else e = big ? EXON_K6(ShapeBigJ2, false) : EXON_K6(ShapeSmall, false);
 #undef EXON_K6
@@ -488,7 +619,7 @@ __global__ __launch_bounds__(S::THREADS) void k3_flag_mapq_group_count_main(
     const int32_t* __restrict__ flag, const uint8_t* __restrict__ fvalid, const uint8_t* __restrict__ mapq,
     const uint8_t* __restrict__ mvalid, const int32_t* __restrict__ ref, const uint8_t* __restrict__ rvalid,
     int64_t n, int32_t mask, int32_t value, int32_t qmin, int32_t R, unsigned long long* __restrict__ partials,
-    int* __restrict__ status, const uint8_t* __restrict__ ones) {
+    int* __restrict__ status, const uint8_t* __restrict__ ones, const FoldArgs fa) {
   constexpr int J = S::J, THREADS = S::THREADS, WAVES = ShapeOf<S>::WAVES, WT = ShapeOf<S>::WAVE_TILE,
                 TILE = ShapeOf<S>::TILE;
   // per-wave table: [R+1] group counters + 64 per-lane dummy slots.  Rows that fail the predicate add to their
@@ -543,8 +674,9 @@ __global__ __launch_bounds__(S::THREADS) void k3_flag_mapq_group_count_main(
     unsigned long long t = 0;
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) t += k3_tbl[w * VS + v];
-    partials[(size_t)blockIdx.x * V + v] = t;
+    st_agent(&partials[(size_t)blockIdx.x * V + v], t);
   }
+  if (fa.ticket) fold_if_last<THREADS>(fa, partials);
 }
 
 size_t k3_partial_words(const LaunchCfg& cfg, int n_refs) {
@@ -556,7 +688,7 @@ template <typename S>
 static hipError_t k3_launch(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* flag,
                             const uint8_t* fv, const uint8_t* mapq, const uint8_t* mv, const int32_t* ref,
                             const uint8_t* rv, int64_t n, int32_t mask, int32_t value, int32_t qmin, int32_t R,
-                            int* grid_out) {
+                            int* grid_out, const FoldArgs& fa) {
   const size_t lds = (size_t)ShapeOf<S>::WAVES * (R + 1 + 64) * sizeof(unsigned);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k3_flag_mapq_group_count_main<S>),
@@ -566,7 +698,7 @@ static hipError_t k3_launch(hipStream_t s, const LaunchCfg& cfg, const Workspace
   const int grid = grid_for<S>(cfg, n, resident_blocks(k3_flag_mapq_group_count_main<S>, S::THREADS, lds));
   *grid_out = grid;
   hipLaunchKernelGGL(k3_flag_mapq_group_count_main<S>, dim3(grid), dim3(S::THREADS), lds, s, flag, fv, mapq, mv, ref,
-                     rv, n, mask, value, qmin, R, ws.partials, ws.status, reinterpret_cast<const uint8_t*>(ws.status + 8));
+                     rv, n, mask, value, qmin, R, ws.partials, ws.status, reinterpret_cast<const uint8_t*>(ws.status + 8), fa);
   return hipGetLastError();
 }
 
@@ -610,12 +742,16 @@ hipError_t launch_flag_mapq_group_count(hipStream_t s, const LaunchCfg& cfg, con
   int grid = 1;
   // the 16-wave shape needs 16 x (n_refs+1) x 4 B of LDS: fine up to ~2.5k references
   const bool big = use_big_shape(cfg, n) && (size_t)16 * (n_refs + 1 + 64) * 4 <= 160 * 1024;
-  hipError_t e = big ? k3_launch<ShapeBig>(s, cfg, ws, flag, flag_valid, mapq, mapq_valid, ref_id, ref_valid, n,
-                                           flag_mask, flag_value, mapq_min, n_refs, &grid)
-                     : k3_launch<ShapeSmall>(s, cfg, ws, flag, flag_valid, mapq, mapq_valid, ref_id, ref_valid, n,
-                                             flag_mask, flag_value, mapq_min, n_refs, &grid);
-  if (e != hipSuccess) return e;
   const int V = n_refs + 1;
+  const FoldArgs fa = fold_args(cfg, ws, V, V, d_counts, nullptr);
+  hipError_t e = big ? (pick_shape(cfg, n) == SHAPE_BIG_J2
+                            ? k3_launch<ShapeBigJ2>(s, cfg, ws, flag, flag_valid, mapq, mapq_valid, ref_id, ref_valid, n, flag_mask,
+                                                    flag_value, mapq_min, n_refs, &grid, fa)
+                            : k3_launch<ShapeBig>(s, cfg, ws, flag, flag_valid, mapq, mapq_valid, ref_id, ref_valid, n,
+                                                  flag_mask, flag_value, mapq_min, n_refs, &grid, fa))
+                     : k3_launch<ShapeSmall>(s, cfg, ws, flag, flag_valid, mapq, mapq_valid, ref_id, ref_valid, n,
+                                             flag_mask, flag_value, mapq_min, n_refs, &grid, fa);
+  if (e != hipSuccess) return e;
   return run_finalize(s, cfg, ws, grid, V, V, d_counts, nullptr);
 }
 
@@ -641,7 +777,7 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
     const float* __restrict__ x, const uint8_t* __restrict__ xvalid, const float* __restrict__ y,
     const uint8_t* __restrict__ yvalid, const int32_t* __restrict__ gid, int64_t n, int32_t klo, int32_t khi,
     int32_t negate, int32_t NG, unsigned long long* __restrict__ partials, int* __restrict__ status,
-    const uint8_t* __restrict__ ones) {
+    const uint8_t* __restrict__ ones, const FoldArgs fa) {
   constexpr int J = S::J, THREADS = S::THREADS, WAVES = ShapeOf<S>::WAVES, WT = ShapeOf<S>::WAVE_TILE,
                 TILE = ShapeOf<S>::TILE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -778,16 +914,17 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
       out = (unsigned long long)__double_as_longlong(t);
     }
     const int kind = v / G, g = v - kind * G;  // 0: cnn, 1: crow, 2: sum
-    partials[(size_t)blockIdx.x * (3 * RG) + kind * RG + g] = out;
+    st_agent(&partials[(size_t)blockIdx.x * (3 * RG) + kind * RG + g], out);
   }
   if (OVF) {
     for (int i = threadIdx.x; i < NO; i += THREADS) {
       unsigned long long* rec = partials + (size_t)blockIdx.x * (3 * RG);
-      rec[8 + i] = ovf_cnn[i];
-      rec[RG + 8 + i] = ovf_crow[i];
-      rec[2 * RG + 8 + i] = (unsigned long long)__double_as_longlong(ovf_sum[i]);
+      st_agent(&rec[8 + i], ovf_cnn[i]);
+      st_agent(&rec[RG + 8 + i], ovf_crow[i]);
+      st_agent(&rec[2 * RG + 8 + i], (unsigned long long)__double_as_longlong(ovf_sum[i]));
     }
   }
+  if (fa.ticket) fold_if_last<THREADS>(fa, partials);
 }
 
 size_t k4_partial_words(const LaunchCfg& cfg, int n_groups) {
@@ -798,7 +935,7 @@ size_t k4_partial_words(const LaunchCfg& cfg, int n_groups) {
 template <int G, typename S, bool OVF>
 static hipError_t k4_launch(hipStream_t s, const LaunchCfg& cfg, int* grid_out, const Workspace& ws, const float* x,
                             const uint8_t* xv, const float* y, const uint8_t* yv, const int32_t* gid, int64_t n,
-                            int32_t klo, int32_t khi, int32_t negate, int32_t n_groups) {
+                            int32_t klo, int32_t khi, int32_t negate, int32_t n_groups, const FoldArgs& fa) {
   const size_t lds = OVF ? (size_t)(n_groups - 8) * 16 : 0;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k4_cmp_avg_by_group_main<G, S, OVF>),
@@ -808,7 +945,7 @@ static hipError_t k4_launch(hipStream_t s, const LaunchCfg& cfg, int* grid_out, 
   const int grid = grid_for<S>(cfg, n, resident_blocks(k4_cmp_avg_by_group_main<G, S, OVF>, S::THREADS, lds));
   *grid_out = grid;
   hipLaunchKernelGGL((k4_cmp_avg_by_group_main<G, S, OVF>), dim3(grid), dim3(S::THREADS), lds, s, x, xv, y, yv, gid, n,
-                     klo, khi, negate, n_groups, ws.partials, ws.status, reinterpret_cast<const uint8_t*>(ws.status + 8));
+                     klo, khi, negate, n_groups, ws.partials, ws.status, reinterpret_cast<const uint8_t*>(ws.status + 8), fa);
   return hipGetLastError();
 }
 
@@ -912,14 +1049,21 @@ hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Wo
   }
   int32_t klo, khi, negate;
   if (!cmp_to_key_range(thr, cmp_op, &klo, &khi, &negate)) return hipErrorInvalidValue;
-  const bool big = use_big_shape(cfg, n);
+  // K4 keeps the 16384-row tile whenever every CU gets one: measured on MI355X at 1e7 rows J = 4 27.8 us, J = 2 31.5 us
+  // (its per-tile bookkeeping -- counter spills, 15-value reductions -- outweighs the better tile balance that pays for K2)
+  int shape = pick_shape(cfg, n);
+  if (shape == SHAPE_BIG_J2 && getenv("EXON_HIP_SHAPE") == nullptr)
+    shape = n / ShapeOf<ShapeBig>::TILE >= (int64_t)cfg.compute_units ? SHAPE_BIG_J4 : SHAPE_SMALL;
+  const bool big = shape != SHAPE_SMALL;
   int grid = 1;
   hipError_t e;
+  const FoldArgs fa = fold_args(cfg, ws, 3 * n_groups, 2 * n_groups, d_counts, d_sums);
   switch (n_groups) {
 #define EXON_K4_CASE(GG)                                                                                             \
   case GG:                                                                                                           \
-    e = big ? k4_launch<GG, ShapeBig, false>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, GG)   \
-            : k4_launch<GG, ShapeSmall, false>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, GG); \
+    e = shape == SHAPE_BIG_J4 ? k4_launch<GG, ShapeBig, false>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, GG, fa)   \
+        : shape == SHAPE_BIG_J2 ? k4_launch<GG, ShapeBigJ2, false>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, GG, fa) \
+            : k4_launch<GG, ShapeSmall, false>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, GG, fa); \
     break;
     EXON_K4_CASE(1)
     EXON_K4_CASE(2)
@@ -931,8 +1075,8 @@ hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Wo
     EXON_K4_CASE(8)
 #undef EXON_K4_CASE
     default:  // > 8 groups: 8 in registers + LDS overflow table
-      e = big ? k4_launch<8, ShapeBigJ2, true>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, n_groups)
-              : k4_launch<8, ShapeSmall, true>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, n_groups);
+      e = big ? k4_launch<8, ShapeBigJ2, true>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, n_groups, fa)
+              : k4_launch<8, ShapeSmall, true>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, n_groups, fa);
       break;
   }
   if (e != hipSuccess) return e;

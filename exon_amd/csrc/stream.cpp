@@ -768,6 +768,18 @@ int exon_hip_rccl_comm_destroy(void* comm) {
   return e ? fail(nullptr, EXON_HIP_EDEVICE, "ncclCommDestroy failed with ncclResult_t %d", e) : EXON_HIP_OK;
 }
 
+int exon_hip_rccl_comm_count(void* comm, int32_t* world, int32_t* rank) {
+  if (!comm || !world) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_rccl_comm_count: NULL argument");
+  if (!rccl().ok()) return fail(nullptr, EXON_HIP_EUNSUPPORTED, "librccl.so could not be loaded");
+  int w = 0, r = 0;
+  int e = rccl().comm_count(comm, &w);
+  if (!e && rank) e = rccl().comm_rank(comm, &r);
+  if (e) return fail(nullptr, EXON_HIP_EDEVICE, "ncclCommCount / ncclCommUserRank failed with ncclResult_t %d", e);
+  *world = w;
+  if (rank) *rank = r;
+  return EXON_HIP_OK;
+}
+
 // Merge of packed partial states across the ranks of `rccl_comm`, enqueued on `stream`: ONE ncclAllGather of the state
 // (d_state -> d_gather[world][words]) + the fixed-order fold into d_out (may be d_state itself).  The f64 sums come out
 // bit-identical on every rank and for every collective algorithm RCCL may pick.  States above 1 MiB are integer counters
@@ -779,6 +791,8 @@ int exon_hip_merge_states(exon_hip_ctx* ctx, void* stream, void* rccl_comm, void
   if (n_i64 < 0 || n_f64 < 0 || n_i64 + n_f64 < 1) return fail(ctx, EXON_HIP_EINVAL, "empty state");
   hipStream_t s = pick_stream(ctx, stream);
   const size_t words = (size_t)(n_i64 + n_f64);
+  if (d_gather != nullptr && n_i64 + n_f64 > INT32_MAX)  // the fold kernel indexes words with an int (same limit as exon_hip_fold_states)
+    return fail(ctx, EXON_HIP_EINVAL, "state of %lld words is too large for the gather + fold form", (long long)(n_i64 + n_f64));
   if (d_gather == nullptr) {  // in-place all-reduce form (large integer states)
     if (n_f64) return fail(ctx, EXON_HIP_EINVAL, "a state with float64 sums is merged by gather + fold: pass d_gather");
     if (d_out != d_state) return fail(ctx, EXON_HIP_EINVAL, "the all-reduce form is in place");
@@ -788,6 +802,10 @@ int exon_hip_merge_states(exon_hip_ctx* ctx, void* stream, void* rccl_comm, void
   int world = 0;
   int e = rccl().comm_count(rccl_comm, &world);
   if (e || world < 1) return fail(ctx, EXON_HIP_EDEVICE, "ncclCommCount failed with ncclResult_t %d", e);
+  {  // the fold reads every rank's copy while it writes d_out: d_out inside the gather buffer would race
+    const uintptr_t g0 = reinterpret_cast<uintptr_t>(d_gather), g1 = g0 + (size_t)world * words * 8, o0 = reinterpret_cast<uintptr_t>(d_out);
+    if (o0 + words * 8 > g0 && o0 < g1) return fail(ctx, EXON_HIP_EINVAL, "d_out must not lie inside d_gather");
+  }
   e = rccl().all_gather(d_state, d_gather, words, NCCL_INT64, rccl_comm, s);  // 8-byte words; no arithmetic in flight
   if (e) return fail(ctx, EXON_HIP_EDEVICE, "ncclAllGather failed with ncclResult_t %d", e);
   HIP_TRY(ctx, exon::launch_fold_states(s, d_gather, world, n_i64, n_f64, d_out));

@@ -110,6 +110,12 @@ class NativeComm:
         ctx._check(ctx.lib.exon_hip_rccl_comm_init(ctx.h, uid, world, rank, C.byref(h)))
         self.h, self.world, self.rank = h, world, rank
 
+    def count(self):
+        """(ncclCommCount, ncclCommUserRank) of the communicator itself -- not what the launcher believes."""
+        w, r = C.c_int32(), C.c_int32()
+        self.ctx._check(self.ctx.lib.exon_hip_rccl_comm_count(self.h, C.byref(w), C.byref(r)))
+        return w.value, r.value
+
     def merge(self, state, n_i64, gathered, out, stream=None):
         """exon_hip_merge_states on `stream` (default: torch's current stream): ncclAllGather + fold, no stream hops."""
         import torch

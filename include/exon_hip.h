@@ -304,6 +304,8 @@ int exon_hip_merge_states(exon_hip_ctx* ctx, void* stream, void* rccl_comm, void
 int exon_hip_rccl_unique_id(uint8_t* id128);
 int exon_hip_rccl_comm_init(exon_hip_ctx* ctx, const uint8_t* id128, int32_t world, int32_t rank, void** rccl_comm);
 int exon_hip_rccl_comm_destroy(void* rccl_comm);
+/* ncclCommCount / ncclCommUserRank of a communicator (rank may be NULL): what a launcher prints to prove how many GPUs merged */
+int exon_hip_rccl_comm_count(void* rccl_comm, int32_t* world, int32_t* rank);
 
 /* One stream per partition (= per file group); single-threaded handle, owns one HIP stream, a
  * device-resident partial state and pinned staging buffers. */

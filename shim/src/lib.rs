@@ -1,21 +1,31 @@
 //! exon-hip: DataFusion glue for the MI355X filter+aggregate path.  NOT COMPILED HERE (no Rust toolchain in the build
 //! image); written against datafusion 44 / arrow 53 as pinned by the reference's Cargo.lock.  What CAN be checked without
-//! cargo is checked: `tests/test_shim_layout.py` pins `sys.rs` on `include/exon_hip.h`, and `tests/abi_harness.c` drives the
-//! same call sequence (`open -> push (hand-built ArrowArray) -> finish_arrow -> release`) from plain C.
+//! cargo is checked by `tests/test_shim_layout.py`: `sys.rs` is pinned on `include/exon_hip.h` (struct layouts AND every
+//! extern signature, type by type), every `use exon::...` path of this crate is checked against the `pub` items of
+//! `/root/reference/exon/exon-core/src` (a `pub(crate)` module cannot be imported), every plan shape the rule claims has
+//! a matcher, and `tests/abi_harness.c` drives the same call sequence (`open -> push -> finish_arrow -> release`) from C.
 //!
-//! * [`rule::GpuFilterAggRule`] is the `PhysicalOptimizerRule` that recognises
-//!   `AggregateExec(Partial) <- [CoalesceBatchesExec] <- FilterExec <- {VCFScan | BAMScan | FASTQScan}` (the plan shape
-//!   of exon-core/src/datasources/vcf/table_provider.rs:571-611) for the four fused query shapes and substitutes
-//! * [`GpuFilterAggExec`], an `ExecutionPlan` with the SAME output schema as the `AggregateExec(Partial)` it replaces (group
-//!   columns, then each aggregate's state fields), so `AggregateExec(Final)` above it is untouched.  Per partition it either
-//!   - hands the partition's files to `exon_hip_scan_open` + `exon_hip_stream_consume_scan` (local files of a `VCFScan`,
-//!     whose `base_config()` is public: bytes go to HBM as they are, inflate + parse + filter + aggregate on the GPU), or
-//!   - consumes the child scan's RecordBatches and pushes them through `exon_hip_stream_push` (any object store, BAM /
-//!     FASTQ scans whose file list is private), interning group keys into dictionary ids on the way.
-//! * Registration does not touch exon-core: `ExonSession::new(ctx)` accepts any SessionContext
-//!   (exon-core/src/session_context/exon_context_ext.rs:103-112); see INTEGRATION.md section 3.
+//! * [`rule::GpuFilterAggRule`] is the `PhysicalOptimizerRule` that recognises the plans the reference really produces:
+//!   `AggregateExec(Partial) <- [CoalesceBatchesExec] <- FilterExec <- {VCFScan | BAMScan | SAMScan | CRAMScan | ...}` for
+//!   table scans (exon-core/src/datasources/vcf/scanner.rs:86-162) and `AggregateExec(Partial) <- IndexedVCFScanner` /
+//!   `... <- FilterExec <- IndexedVCFScanner | IndexedBAMScan` for pushed-down region filters, which leave NO FilterExec
+//!   for the region itself (exon-core/src/datasources/vcf/table_provider.rs:299-320, 571-611) -- and substitutes
+//! * [`GpuFilterAggExec`], an `ExecutionPlan` with the SAME output schema as the `AggregateExec(Partial)` it replaces
+//!   (group columns, then each aggregate's state fields), so `AggregateExec(Final)` above it is untouched.  Per partition
+//!   it either
+//!   - hands the partition's files to `exon_hip_scan_open` + `exon_hip_stream_consume_scan` (local files of a `VCFScan` /
+//!     `IndexedVCFScanner`, whose `base_config()` is public: bytes go to HBM as they are; inflate, parse, region mask,
+//!     filter and aggregate run on the GPU), or
+//!   - consumes the child scan's RecordBatches and pushes them through `exon_hip_stream_push` (any object store; BAM / SAM /
+//!     CRAM / FASTQ scans, whose file list is private), interning group keys into dictionary ids on the way.
+//! * [`udtf::FastqQualityHistogram`] is the table function `fastq_quality_histogram('<path>')` for config 5: DataFusion has
+//!   no single operator whose plan could be pattern-matched for a per-position histogram, so the shape gets its own entry
+//!   point, registered like the reference's `fastq_scan` (exon-core/src/session_context/exon_context_ext.rs:216-223).
+//! * Registration does not touch exon-core: `ExonSession::new(ctx)` accepts any SessionContext and returns `Self`
+//!   (exon-core/src/session_context/exon_context_ext.rs:108-112); see INTEGRATION.md section 3.
 pub mod rule;
 pub mod sys;
+pub mod udtf;
 
 use std::any::Any;
 use std::collections::HashMap;
@@ -23,13 +33,14 @@ use std::ffi::{CStr, CString};
 use std::sync::Arc;
 
 use arrow::array::{
-    Array, ArrayRef, AsArray, Float64Array, Int32Array, Int64Array, ListBuilder, RecordBatch, StringArray, StringBuilder,
-    StructArray, UInt64Array,
+    Array, ArrayRef, AsArray, Int32Array, ListBuilder, RecordBatch, StringArray, StringBuilder, StructArray, UInt8Array,
 };
 use arrow::datatypes::{DataType, Field, Schema, SchemaRef};
 use arrow::ffi::{from_ffi, to_ffi, FFI_ArrowArray, FFI_ArrowSchema};
 use datafusion::common::{DataFusionError, Result};
 use datafusion::execution::{SendableRecordBatchStream, TaskContext};
+use datafusion::physical_expr::EquivalenceProperties;
+use datafusion::physical_plan::execution_plan::{Boundedness, EmissionType};
 use datafusion::physical_plan::stream::RecordBatchStreamAdapter;
 use datafusion::physical_plan::{DisplayAs, DisplayFormatType, ExecutionPlan, PlanProperties};
 use futures::StreamExt;
@@ -42,7 +53,8 @@ pub(crate) fn check(ctx: *const sys::exon_hip_ctx, rc: i32) -> Result<()> {
     Err(DataFusionError::External(format!("exon_hip status {rc}: {msg}").into()))
 }
 
-/// Owns the device context + the immutable fused plan; Send + Sync (the C side locks internally).
+/// Owns the device context + one immutable fused plan; Send + Sync (the C side locks internally: include/exon_hip.h,
+/// "ctx / plan are thread-safe").
 #[derive(Debug)]
 pub struct GpuPlan {
     ctx: *mut sys::exon_hip_ctx,
@@ -74,29 +86,99 @@ impl Drop for GpuPlan {
     }
 }
 
+/// One partition's `exon_hip_stream`.  A stream handle is single-threaded but may MIGRATE between threads between calls
+/// (include/exon_hip.h, threading contract) -- exactly what a tokio task does across `.await` -- so the handle is `Send`.
+/// Without this newtype the raw pointer held across `input.next().await` makes the future `!Send`, and
+/// `SendableRecordBatchStream` (= `Pin<Box<dyn RecordBatchStream + Send>>`) rejects it.
+struct StreamHandle(*mut sys::exon_hip_stream);
+unsafe impl Send for StreamHandle {}
+impl StreamHandle {
+    fn open(gpu: &GpuPlan, partition: usize) -> Result<Self> {
+        let mut s = std::ptr::null_mut();
+        check(gpu.ctx, unsafe { sys::exon_hip_stream_open(gpu.plan, partition as i32, &mut s) })?;
+        Ok(Self(s))
+    }
+    /// moves `batch` into the library (it calls `release` exactly once, success or not)
+    fn push(&self, gpu: &GpuPlan, batch: &RecordBatch) -> Result<()> {
+        let (mut arr, _sch) = to_ffi(&StructArray::from(batch.clone()).to_data())?; // zero-copy export
+        let rc = unsafe { sys::exon_hip_stream_push(self.0, &mut arr as *mut FFI_ArrowArray) };
+        std::mem::forget(arr); // released by the library; `_sch` stays ours and is released by its Drop
+        check(gpu.ctx, rc)
+    }
+    /// the packed partial state as an Arrow struct array (one row per observed group)
+    fn finish(&self, gpu: &GpuPlan) -> Result<StructArray> {
+        let mut out = FFI_ArrowArray::empty();
+        let mut out_s = FFI_ArrowSchema::empty();
+        check(gpu.ctx, unsafe { sys::exon_hip_stream_finish_arrow(self.0, &mut out, &mut out_s) })?;
+        let data = unsafe { from_ffi(out, &out_s) }?; // takes ownership of `out`; `out_s` is released by its Drop
+        Ok(StructArray::from(data))
+    }
+}
+impl Drop for StreamHandle {
+    fn drop(&mut self) {
+        unsafe { sys::exon_hip_stream_close(self.0) };
+    }
+}
+
+/// An open `exon_hip_scan`; only ever used between two `.await`s, closed on drop.
+struct ScanHandle(*mut sys::exon_hip_scan);
+unsafe impl Send for ScanHandle {}
+impl Drop for ScanHandle {
+    fn drop(&mut self) {
+        unsafe { sys::exon_hip_scan_close(self.0) };
+    }
+}
+impl ScanHandle {
+    /// names of a dictionary-encoded scan column, in id order
+    fn dictionary(&self, column: i32) -> Vec<Option<String>> {
+        let mut n = 0i32;
+        let mut out = Vec::new();
+        if unsafe { sys::exon_hip_scan_dictionary_size(self.0, column, &mut n) } != 0 {
+            return out;
+        }
+        for id in 0..n {
+            let mut p = std::ptr::null();
+            if unsafe { sys::exon_hip_scan_dictionary_value(self.0, column, id, &mut p) } != 0 || p.is_null() {
+                out.push(None);
+            } else {
+                out.push(Some(unsafe { CStr::from_ptr(p) }.to_string_lossy().into_owned()));
+            }
+        }
+        out
+    }
+    fn id_of(&self, column: i32, name: &str) -> Result<i32> {
+        let c = CString::new(name).map_err(|e| DataFusionError::Plan(e.to_string()))?;
+        let mut id = 0i32;
+        check(std::ptr::null(), unsafe { sys::exon_hip_scan_dictionary_intern(self.0, column, c.as_ptr(), &mut id) })?;
+        Ok(id)
+    }
+}
+
 /// Which of the fused shapes (BASELINE.json configs 2-5 + the range form) a `GpuFilterAggExec` runs, with what the state
 /// batch needs to become the replaced node's output.
 #[derive(Debug, Clone)]
 pub enum Shape {
-    /// `chrom = lit AND pos BETWEEN a AND b`, COUNT(*): no group column
+    /// `chrom = lit AND pos BETWEEN a AND b` / `vcf_region_filter(...)`, COUNT(*): no group column
     RegionCount,
-    /// `bam_region_filter(...)`, COUNT(*)
+    /// `reference = lit AND start <= b AND "end" >= a` / `bam_region_filter(...)`, COUNT(*)
     OverlapCount,
     /// `flag & M = V AND CAST(mapping_quality AS INT) >= q`, COUNT(*) GROUP BY reference (Utf8, nullable)
     FlagMapqGroupCount,
     /// `info.F <op> lit`, AVG(qual), COUNT(*) GROUP BY filter (List<Utf8>); `info_field` = F
     CmpAvgByGroup { info_field: String },
-    /// per-position histogram of quality_scores
+    /// per-position histogram of quality_scores (`fastq_quality_histogram`)
     QualPosHist,
 }
 
 /// Where the rows of a partition come from.
 #[derive(Debug, Clone)]
 pub enum Source {
-    /// the library opens these local files itself (`exon_hip_scan_open`, gpu_parse = 1); one Vec per partition
+    /// the library opens these local files itself (`exon_hip_scan_open`, gpu_parse = 1); one Vec per partition.
+    /// `region`: a pushed-down `vcf_region_filter` / the region a `chrom = .. AND pos ..` conjunction spells, as text.
     Files { format: i32, groups: Vec<Vec<String>>, region: Option<String>, use_index: bool },
-    /// the child scan's batches are pushed (`exon_hip_stream_push`); key columns are interned into ids on the way
-    ChildBatches,
+    /// the child scan's batches are pushed (`exon_hip_stream_push`); key columns are interned into ids on the way.
+    /// `seed_key`: a key that must get id 0 (the literal of `chrom = 'c'` / `reference = 'r'`: the plan compares with id 0).
+    ChildBatches { seed_key: Option<String> },
 }
 
 #[derive(Debug)]
@@ -107,7 +189,23 @@ pub struct GpuFilterAggExec {
     source: Source,
     partial_schema: SchemaRef, // schema of the replaced AggregateExec(Partial): group columns, then state fields
     props: PlanProperties,
-    gpu: Arc<GpuPlan>,
+    device: i32,
+    gpu: Option<Arc<GpuPlan>>, // None: the plan depends on a file's header (region shapes over files) and is made per file
+}
+
+/// Arrow types of the partial-aggregate state of a shape, in DataFusion's order (group columns first).
+fn state_types(shape: &Shape) -> Vec<DataType> {
+    match shape {
+        Shape::RegionCount | Shape::OverlapCount => vec![DataType::Int64],
+        Shape::FlagMapqGroupCount => vec![DataType::Utf8, DataType::Int64],
+        Shape::CmpAvgByGroup { .. } => vec![
+            DataType::List(Arc::new(Field::new("item", DataType::Utf8, true))),
+            DataType::UInt64,
+            DataType::Float64,
+            DataType::Int64,
+        ],
+        Shape::QualPosHist => vec![DataType::Int32, DataType::Int32, DataType::Int64],
+    }
 }
 
 impl GpuFilterAggExec {
@@ -122,45 +220,47 @@ impl GpuFilterAggExec {
         partial_schema: SchemaRef,
         device: i32,
     ) -> Result<Self> {
-        let want: Vec<DataType> = match &shape {
-            Shape::RegionCount | Shape::OverlapCount => vec![DataType::Int64],
-            Shape::FlagMapqGroupCount => vec![DataType::Utf8, DataType::Int64],
-            Shape::CmpAvgByGroup { .. } => vec![
-                DataType::List(Arc::new(Field::new("item", DataType::Utf8, true))),
-                DataType::UInt64,
-                DataType::Float64,
-                DataType::Int64,
-            ],
-            Shape::QualPosHist => vec![DataType::Int32, DataType::Int32, DataType::Int64],
-        };
+        let want = state_types(&shape);
         let got: Vec<&DataType> = partial_schema.fields().iter().map(|f| f.data_type()).collect();
         if got.len() != want.len() || got.iter().zip(&want).any(|(g, w)| !g.equals_datatype(w)) {
             return Err(DataFusionError::Plan(format!(
                 "GpuFilterAggExec: the partial aggregate's schema {got:?} is not the state layout {want:?} of {shape:?}"
             )));
         }
+        let n_parts = input.properties().output_partitioning().partition_count();
         if let Source::Files { groups, .. } = &source {
-            if groups.len() != input.properties().output_partitioning().partition_count() {
+            if groups.len() != n_parts {
                 return Err(DataFusionError::Plan("GpuFilterAggExec: one file group per input partition expected".into()));
             }
         }
-        let gpu = Arc::new(GpuPlan::try_new(device, &desc)?);
-        // same partitioning as the scan; one state batch per partition, emitted once
+        // region shapes over files need the contig's id in EACH file's header: their plan is created per file
+        let per_file_plan = matches!((&shape, &source), (Shape::RegionCount | Shape::OverlapCount, Source::Files { .. }));
+        let gpu = if per_file_plan {
+            // fail at plan time when there is no GPU or the library is missing: the rule then keeps DataFusion's plan
+            let mut probe = desc;
+            probe.region_chrom_id = 0;
+            drop(GpuPlan::try_new(device, &probe)?);
+            None
+        } else {
+            Some(Arc::new(GpuPlan::try_new(device, &desc)?))
+        };
+        // same partitioning as the scan; one state batch per file (or per partition), emitted at the end
         let props = PlanProperties::new(
-            datafusion::physical_expr::EquivalenceProperties::new(partial_schema.clone()),
+            EquivalenceProperties::new(partial_schema.clone()),
             input.properties().output_partitioning().clone(),
-            datafusion::physical_plan::execution_plan::EmissionType::Final,
-            datafusion::physical_plan::execution_plan::Boundedness::Bounded,
+            EmissionType::Final,
+            Boundedness::Bounded,
         );
-        Ok(Self { input, desc, shape, source, partial_schema, props, gpu })
+        Ok(Self { input, desc, shape, source, partial_schema, props, device, gpu })
     }
 }
 
 impl DisplayAs for GpuFilterAggExec {
     fn fmt_as(&self, _t: DisplayFormatType, f: &mut std::fmt::Formatter) -> std::fmt::Result {
         let src = match &self.source {
-            Source::Files { .. } => "files->HBM",
-            Source::ChildBatches => "child batches",
+            Source::Files { region: Some(r), use_index, .. } => format!("files->HBM, region={r}, indexed={use_index}"),
+            Source::Files { .. } => "files->HBM".to_string(),
+            Source::ChildBatches { .. } => "child batches".to_string(),
         };
         write!(f, "GpuFilterAggExec: kind={}, shape={:?}, source={}", self.desc.kind, self.shape, src)
     }
@@ -203,6 +303,7 @@ fn state_to_partial(shape: &Shape, state: &StructArray, keys: &Keys, schema: &Sc
 fn intern_keys(batch: &RecordBatch, key_col: usize, ids: &mut HashMap<Option<String>, i32>, keys: &mut Keys) -> Result<RecordBatch> {
     let col = batch.column(key_col);
     let mut out = Vec::with_capacity(col.len());
+    let mut valid = Vec::with_capacity(col.len());
     for row in 0..col.len() {
         let k: Option<String> = match col.data_type() {
             DataType::Utf8 => {
@@ -216,6 +317,7 @@ fn intern_keys(batch: &RecordBatch, key_col: usize, ids: &mut HashMap<Option<Str
             }
             other => return Err(DataFusionError::Plan(format!("cannot intern a key column of type {other}"))),
         };
+        valid.push(k.is_some());
         let next = ids.len() as i32;
         let id = *ids.entry(k.clone()).or_insert_with(|| {
             keys.0.push(k);
@@ -223,11 +325,38 @@ fn intern_keys(batch: &RecordBatch, key_col: usize, ids: &mut HashMap<Option<Str
         });
         out.push(id);
     }
+    // a NULL key (unmapped read's reference) stays NULL in the id column: K3 gives NULL its own group, K2 / K6 drop the row
+    let id_col = Int32Array::from(out.into_iter().zip(valid).map(|(v, ok)| ok.then_some(v)).collect::<Vec<Option<i32>>>());
     let mut cols = batch.columns().to_vec();
-    cols[key_col] = Arc::new(Int32Array::from(out));
+    cols[key_col] = Arc::new(id_col);
     let mut fields: Vec<Field> = batch.schema().fields().iter().map(|f| f.as_ref().clone()).collect();
-    fields[key_col] = Field::new(fields[key_col].name(), DataType::Int32, false);
+    fields[key_col] = Field::new(fields[key_col].name(), DataType::Int32, true);
     RecordBatch::try_new(Arc::new(Schema::new(fields)), cols).map_err(DataFusionError::from)
+}
+
+/// `mapping_quality` is Utf8 in the reference's SAM/BAM schema (exon-sam/src/schema_builder.rs:392: decimal text, NULL for
+/// 255, exon-bam/src/array_builder.rs:136-143); the device layout is u8 + validity.  `CAST(mapping_quality AS INT)` of a
+/// non-numeric string is an error in DataFusion; here such a value becomes NULL (the row is dropped either way).
+fn mapq_to_u8(batch: &RecordBatch, col: usize) -> Result<RecordBatch> {
+    let c = batch.column(col);
+    let a = match c.data_type() {
+        DataType::Utf8 => c.as_string::<i32>(),
+        DataType::UInt8 => return Ok(batch.clone()),
+        other => return Err(DataFusionError::Plan(format!("mapping_quality: expected Utf8, found {other}"))),
+    };
+    let out: UInt8Array = (0..a.len())
+        .map(|i| if a.is_null(i) { None } else { a.value(i).trim().parse::<u8>().ok() })
+        .collect();
+    let mut cols = batch.columns().to_vec();
+    cols[col] = Arc::new(out);
+    let mut fields: Vec<Field> = batch.schema().fields().iter().map(|f| f.as_ref().clone()).collect();
+    fields[col] = Field::new(fields[col].name(), DataType::UInt8, true);
+    RecordBatch::try_new(Arc::new(Schema::new(fields)), cols).map_err(DataFusionError::from)
+}
+
+/// name part of a region string ("chr1:1-100" -> "chr1")
+fn region_name(region: &str) -> &str {
+    region.split(':').next().unwrap_or(region)
 }
 
 impl ExecutionPlan for GpuFilterAggExec {
@@ -254,6 +383,7 @@ impl ExecutionPlan for GpuFilterAggExec {
             source: self.source.clone(),
             partial_schema: self.partial_schema.clone(),
             props: self.props.clone(),
+            device: self.device,
             gpu: self.gpu.clone(),
         }))
     }
@@ -261,19 +391,26 @@ impl ExecutionPlan for GpuFilterAggExec {
     /// One HIP stream per partition; partitions = file groups (regroup_files_by_size), one GPU each in a multi-GPU job.
     fn execute(&self, partition: usize, ctx: Arc<TaskContext>) -> Result<SendableRecordBatchStream> {
         let gpu = self.gpu.clone();
+        let device = self.device;
+        let desc = self.desc;
         let shape = self.shape.clone();
         let schema = self.partial_schema.clone();
         let out_schema = schema.clone();
         let source = self.source.clone();
-        let key_col = self.desc.columns[2] as usize; // K3 / K4: the group key is the third operator argument
+        // operator argument order (include/exon_hip.h, exon_hip_plan_desc.columns): K2 / K6 key = argument 0,
+        // K3 / K4 group key = argument 2, K3 mapq = argument 1
+        let key_arg = match shape {
+            Shape::RegionCount | Shape::OverlapCount => 0,
+            _ => 2,
+        };
+        let key_col = self.desc.columns[key_arg] as usize;
+        let mapq_col = self.desc.columns[1] as usize;
         let mut input = match &source {
-            Source::ChildBatches => Some(self.input.execute(partition, ctx)?),
+            Source::ChildBatches { .. } => Some(self.input.execute(partition, ctx)?),
             Source::Files { .. } => None,
         };
         let fut = async move {
-            let mut s: *mut sys::exon_hip_stream = std::ptr::null_mut();
-            check(gpu.ctx, unsafe { sys::exon_hip_stream_open(gpu.plan, partition as i32, &mut s) })?;
-            let mut keys = Keys(Vec::new());
+            let mut out: Vec<RecordBatch> = Vec::new();
             match &source {
                 Source::Files { format, groups, region, use_index } => {
                     let info = match &shape {
@@ -281,6 +418,7 @@ impl ExecutionPlan for GpuFilterAggExec {
                         _ => None,
                     };
                     let region_c = region.as_ref().map(|r| CString::new(r.as_str()).unwrap());
+                    // no `.await` inside this loop: the raw handles never cross a suspension point
                     for path in &groups[partition] {
                         let opt = sys::exon_hip_scan_options {
                             format: *format,
@@ -292,58 +430,68 @@ impl ExecutionPlan for GpuFilterAggExec {
                             gpu_parse: 1,
                         };
                         let cpath = CString::new(path.as_str()).unwrap();
-                        let mut scan = std::ptr::null_mut();
-                        check(std::ptr::null(), unsafe { sys::exon_hip_scan_open(cpath.as_ptr(), &opt, &mut scan) })?;
-                        let mut rows = 0i64;
-                        let rc = unsafe { sys::exon_hip_stream_consume_scan(s, scan, &mut rows) };
-                        // dictionary of the key column (VCF: scan column 3 = filter; BAM: 2 = reference), in id order;
-                        // every file of the partition interns into the same scan-side order because ids are handed out
-                        // in order of first appearance per FILE: one file per partition keeps this exact, several files
-                        // need `exon_hip_scan_dictionary_intern` of the first file's names before consuming the next.
-                        let dict_col = match shape {
-                            Shape::CmpAvgByGroup { .. } => 3,
-                            _ => 2,
-                        };
-                        let mut n = 0i32;
-                        if rc >= 0 && unsafe { sys::exon_hip_scan_dictionary_size(scan, dict_col, &mut n) } == 0 {
-                            for id in keys.0.len() as i32..n {
-                                let mut p = std::ptr::null();
-                                unsafe { sys::exon_hip_scan_dictionary_value(scan, dict_col, id, &mut p) };
-                                keys.0.push(Some(unsafe { CStr::from_ptr(p) }.to_string_lossy().into_owned()));
+                        let mut raw = std::ptr::null_mut();
+                        check(std::ptr::null(), unsafe { sys::exon_hip_scan_open(cpath.as_ptr(), &opt, &mut raw) })?;
+                        let scan = ScanHandle(raw);
+                        // region shapes: the plan's `chrom = <id>` is this file's dictionary id of the region's contig, and
+                        // the scan's row mask (k_region_mask) has already applied the interval: pos >= 1, open end
+                        let file_plan;
+                        let plan: &GpuPlan = match (&gpu, &shape) {
+                            (Some(p), _) => p.as_ref(),
+                            (None, _) => {
+                                let mut d = desc;
+                                let dict_col = if matches!(shape, Shape::OverlapCount) { 2 } else { 0 };
+                                d.region_chrom_id = scan.id_of(dict_col, region_name(region.as_deref().unwrap_or("")))?;
+                                d.region_start = 1;
+                                d.region_end = sys::EXON_HIP_REGION_OPEN_END;
+                                file_plan = GpuPlan::try_new(device, &d)?;
+                                &file_plan
                             }
-                        }
-                        unsafe { sys::exon_hip_scan_close(scan) };
-                        check(gpu.ctx, rc)?;
+                        };
+                        let stream = StreamHandle::open(plan, partition)?;
+                        let mut rows = 0i64;
+                        check(plan.ctx, unsafe { sys::exon_hip_stream_consume_scan(stream.0, scan.0, &mut rows) })?;
+                        // dictionary of the key column (VCF: scan column 3 = filter; BAM: 2 = reference), in id order; one
+                        // state batch per FILE, so ids never have to agree between files (Final merges by key VALUE)
+                        let keys = Keys(match shape {
+                            Shape::CmpAvgByGroup { .. } => scan.dictionary(3),
+                            Shape::FlagMapqGroupCount => scan.dictionary(2),
+                            _ => Vec::new(),
+                        });
+                        let state = stream.finish(plan)?;
+                        out.push(state_to_partial(&shape, &state, &keys, &schema)?);
                     }
                 }
-                Source::ChildBatches => {
-                    let mut ids = HashMap::new();
+                Source::ChildBatches { seed_key } => {
+                    let plan = gpu.as_ref().expect("ChildBatches always has a shared plan").clone();
+                    let stream = StreamHandle::open(&plan, partition)?; // Send: may be held across the awaits below
+                    let mut keys = Keys(Vec::new());
+                    let mut ids: HashMap<Option<String>, i32> = HashMap::new();
+                    if let Some(k) = seed_key {
+                        ids.insert(Some(k.clone()), 0); // the plan compares the key column with id 0
+                        keys.0.push(Some(k.clone()));
+                    }
                     let input = input.as_mut().unwrap();
                     while let Some(batch) = input.next().await {
                         let mut batch: RecordBatch = batch?;
-                        if matches!(shape, Shape::FlagMapqGroupCount | Shape::CmpAvgByGroup { .. }) {
+                        if !matches!(shape, Shape::QualPosHist) {
                             batch = intern_keys(&batch, key_col, &mut ids, &mut keys)?;
                         }
-                        let (mut arr, _sch) = to_ffi(&StructArray::from(batch).to_data())?; // zero-copy export
-                        // the batch is MOVED: the library calls arr.release exactly once; `_sch` stays ours and is
-                        // released by its Drop at the end of this iteration
-                        check(gpu.ctx, unsafe { sys::exon_hip_stream_push(s, &mut arr as *mut FFI_ArrowArray) })?;
-                        std::mem::forget(arr);
+                        if matches!(shape, Shape::FlagMapqGroupCount) {
+                            batch = mapq_to_u8(&batch, mapq_col)?;
+                        }
+                        stream.push(&plan, &batch)?;
                     }
+                    let state = stream.finish(&plan)?;
+                    out.push(state_to_partial(&shape, &state, &keys, &schema)?);
                 }
             }
-            let mut out = FFI_ArrowArray::empty();
-            let mut out_s = FFI_ArrowSchema::empty();
-            let rc = unsafe { sys::exon_hip_stream_finish_arrow(s, &mut out, &mut out_s) };
-            unsafe { sys::exon_hip_stream_close(s) };
-            check(gpu.ctx, rc)?;
-            let data = unsafe { from_ffi(out, &out_s) }?; // takes ownership of `out`; `out_s` is released by its Drop
-            state_to_partial(&shape, &StructArray::from(data), &keys, &schema)
+            Ok::<_, DataFusionError>(futures::stream::iter(out.into_iter().map(Ok::<RecordBatch, DataFusionError>)))
         };
-        Ok(Box::pin(RecordBatchStreamAdapter::new(out_schema, futures::stream::once(fut))))
+        let batches = futures::stream::once(fut).map(|r| match r {
+            Ok(s) => s.boxed(),
+            Err(e) => futures::stream::once(async move { Err(e) }).boxed(),
+        });
+        Ok(Box::pin(RecordBatchStreamAdapter::new(out_schema, batches.flatten())))
     }
 }
-
-// keep the unused-import lint quiet for the state column types named in the docs above
-#[allow(dead_code)]
-fn _state_types(_: &UInt64Array, _: &Float64Array, _: &Int64Array) {}

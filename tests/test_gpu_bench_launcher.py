@@ -58,3 +58,37 @@ def test_histogram_workload_merges_a_large_state_across_ranks():
                  env={"EXON_BENCH_SHARE_GPU": "1"}, launcher=LAUNCH + ["--master-port", "29535"])
     one = _bench(["--steps", "2", "--warmup", "1", "--rows", str(reads), "--workload", "c5", "--no-cpu-baseline"])
     assert two["result"]["counts"] == one["result"]["counts"] and sum(one["result"]["counts"]) == reads * 100
+
+
+def test_gpus_flag_without_a_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must come back with n_gpus == 2 (it starts the
+    ranks itself) -- never with a 1-GPU line."""
+    rows = 20_000_000
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", str(rows),
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env={**env, "EXON_BENCH_SHARE_GPU": "1"}, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    two = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["config"]["rows_per_gpu"] == rows // 2
+    one = _bench(["--steps", "2", "--warmup", "1", "--rows", str(rows), "--no-cpu-baseline", "--no-extras"])
+    assert two["result"]["filter_rows"] == one["result"]["filter_rows"]
+
+
+def test_gpus_flag_beyond_the_node_fails_loudly():
+    """Without the share-GPU test hook a one-GPU box must refuse --gpus 2 (exit code != 0, no JSON line)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has the GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "EXON_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_world_size_must_match_gpus_flag():
+    """--gpus 1 under a 2-rank launcher is a mistake, not a 1-GPU run."""
+    r = subprocess.run([sys.executable] + LAUNCH + ["--master-port", "29536", os.path.join(ROOT, "bench.py"), "--gpus", "1",
+                                                    "--steps", "1", "--warmup", "0", "--rows", "1000000", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env={**os.environ, "EXON_BENCH_SHARE_GPU": "1"}, cwd=ROOT, timeout=300)
+    assert r.returncode != 0
