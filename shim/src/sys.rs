@@ -110,6 +110,7 @@ extern "C" {
     pub fn exon_hip_rccl_unique_id(id128: *mut u8) -> c_int;
     pub fn exon_hip_rccl_comm_init(ctx: *mut exon_hip_ctx, id128: *const u8, world: i32, rank: i32, comm: *mut *mut c_void) -> c_int;
     pub fn exon_hip_rccl_comm_destroy(comm: *mut c_void) -> c_int;
+    pub fn exon_hip_rccl_comm_count(comm: *mut c_void, world: *mut i32, rank: *mut i32) -> c_int;
     pub fn exon_hip_parse_region(region: *const c_char, name_out: *mut c_char, name_cap: usize, start: *mut i64, end: *mut i64) -> c_int;
     pub fn exon_hip_regroup_files_by_size(sizes: *const i64, n_files: i32, target_groups: i32, group_of: *mut i32) -> c_int;
 
@@ -120,6 +121,7 @@ extern "C" {
     pub fn exon_hip_scan_dictionary_intern(scan: *mut exon_hip_scan, column: i32, name: *const c_char, id: *mut i32) -> c_int;
     pub fn exon_hip_scan_dictionary_value(scan: *mut exon_hip_scan, column: i32, id: i32, name: *mut *const c_char) -> c_int;
     pub fn exon_hip_scan_decoded_on_gpu(scan: *mut exon_hip_scan, decoded: *mut i32, inflated: *mut i32) -> c_int;
+    pub fn exon_hip_scan_rows(scan: *mut exon_hip_scan, rows_emitted: *mut i64) -> c_int;
     pub fn exon_hip_scan_close(scan: *mut exon_hip_scan) -> c_int;
     /// GpuFilterAggExec::execute for one file in one call
     pub fn exon_hip_stream_consume_scan(s: *mut exon_hip_stream, scan: *mut exon_hip_scan, rows: *mut i64) -> c_int;

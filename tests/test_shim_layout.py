@@ -7,6 +7,8 @@ import os
 import re
 import subprocess
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SYS_RS = open(os.path.join(ROOT, "shim", "src", "sys.rs")).read()
 HEADER = os.path.join(ROOT, "include", "exon_hip.h")
@@ -72,20 +74,64 @@ def test_repr_c_structs_match_the_header(tmp_path):
         assert c_fields == [f for f, _, _ in lay], name
 
 
-def _params(sig):
+C_BASE = {"int": "i32", "int32_t": "i32", "int64_t": "i64", "uint64_t": "u64", "uint32_t": "u32", "uint8_t": "u8", "char": "c_char",
+          "void": "c_void", "size_t": "usize", "double": "f64", "float": "f32", "struct ArrowArray": "FFI_ArrowArray",
+          "struct ArrowSchema": "FFI_ArrowSchema"}
+RUST_BASE = {"c_int": "i32", "c_uint": "u32"}
+
+
+def c_type(decl, is_param):
+    """canonical form of a C parameter / return type: '<ptr levels, outermost first> base', e.g. 'mut const c_char'"""
+    d = " ".join(decl.replace("*", " * ").split())
+    const = d.startswith("const ")
+    if const:
+        d = d[6:]
+    toks = d.split()
+    n_ptr = toks.count("*")
+    toks = [t for t in toks if t != "*"]
+    if is_param and len(toks) > (2 if toks[0] == "struct" else 1):
+        toks = toks[:-1]  # the parameter's name
+    base = " ".join(toks)
+    base = C_BASE.get(base, base)
+    levels = ["mut"] * n_ptr
+    if const and n_ptr:
+        levels[-1] = "const"
+    return " ".join(levels + [base])
+
+
+def rust_type(t):
+    t = t.strip()
+    levels = []
+    while t.startswith("*"):
+        kind, t = t[1:].split(None, 1)
+        levels.append(kind)
+        t = t.strip()
+    return " ".join(levels + [RUST_BASE.get(t, t)])
+
+
+def split_params(sig):
     sig = sig.strip()
-    return 0 if sig in ("", "void") else sig.count(",") + 1
+    return [] if sig in ("", "void") else [p.strip() for p in sig.split(",")]
 
 
 def test_extern_functions_and_constants_match_the_header():
+    """Every `extern "C"` function of sys.rs: same return type and the same parameter TYPES, position by position, as the
+    prototype in include/exon_hip.h (pointer depth, const-ness of the pointee, integer width) -- not just the count."""
     h = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
-    protos = {m.group(1): _params(m.group(2)) for m in re.finditer(r"\b(exon_hip_\w+)\s*\(([^;{]*?)\)\s*;", h, re.S)}
+    protos = {m.group(2): (m.group(1), split_params(m.group(3)))
+              for m in re.finditer(r"(?m)^\s*([\w\s\*]+?)\s*\b(exon_hip_\w+)\s*\(([^;{]*?)\)\s*;", h, re.S)}
     block = SYS_RS[SYS_RS.index('extern "C" {'):]
-    rust = {m.group(1): _params(m.group(2)) for m in re.finditer(r"pub fn (exon_hip_\w+)\(([^)]*)\)", block)}
-    assert len(rust) >= 25
-    for name, n in rust.items():
+    rust = {m.group(1): (m.group(3) or "", split_params(m.group(2)))
+            for m in re.finditer(r"pub fn (exon_hip_\w+)\(([^)]*)\)(?:\s*->\s*([^;]+))?;", block)}
+    assert len(rust) >= 27
+    for name, (ret, params) in rust.items():
         assert name in protos, f"{name} is bound in sys.rs but not declared in include/exon_hip.h"
-        assert protos[name] == n, f"{name}: {n} parameters in sys.rs, {protos[name]} in the header"
+        c_ret, c_params = protos[name]
+        assert len(c_params) == len(params), f"{name}: {len(params)} parameters in sys.rs, {len(c_params)} in the header"
+        assert rust_type(ret) == c_type(c_ret, False), f"{name}: returns {ret!r} in sys.rs, {c_ret!r} in the header"
+        for i, (rp, cp) in enumerate(zip(params, c_params)):
+            rt = rust_type(rp.split(":", 1)[1])
+            assert rt == c_type(cp, True), f"{name} parameter {i}: {rp!r} in sys.rs vs {cp!r} in the header"
     defines = dict(re.findall(r"#define (EXON_HIP_\w+)\s+\(?(-?\d+)\)?\s*$", h, re.M))
     consts = dict(re.findall(r"pub const (EXON_HIP_\w+): i32 = (-?\d+);", SYS_RS))
     consts.pop("EXON_HIP_ABI_VERSION")
@@ -96,11 +142,148 @@ def test_extern_functions_and_constants_match_the_header():
     assert int(re.search(r"pub const EXON_HIP_ABI_VERSION: i32 = (\d+);", SYS_RS).group(1)) == exon_amd.load().exon_hip_abi_version()
 
 
+def test_type_canonicalisation_catches_a_wrong_binding():
+    assert c_type("const char** name", True) == "mut const c_char" == rust_type("*mut *const c_char")
+    assert c_type("struct ArrowArray* batch", True) == "mut FFI_ArrowArray" == rust_type("*mut FFI_ArrowArray")
+    assert c_type("const exon_hip_plan_desc* desc", True) == rust_type("*const exon_hip_plan_desc")
+    assert c_type("int64_t** d_i64", True) == rust_type("*mut *mut i64")
+    assert c_type("int32_t partition", True) == rust_type("i32") == rust_type("c_int")
+    assert c_type("const uint8_t* id128", True) != rust_type("*mut u8")
+    assert c_type("int64_t n", True) != rust_type("i32")
+
+
+# ---- `use exon::...` paths of the shim against the reference's module visibility ------------------------------------
+REF_SRC = "/root/reference/exon/exon-core/src"
+SHIM_FILES = ["lib.rs", "rule.rs", "udtf.rs"]
+
+
+def _shim(name):
+    return open(os.path.join(ROOT, "shim", "src", name)).read()
+
+
+def _strip_comments(src):
+    return re.sub(r"//[^\n]*", "", src)
+
+
+def exon_use_paths():
+    """[(file, ['datasources', 'vcf', 'VCFScan']), ...] for every `use exon::...;` (brace groups expanded)"""
+    out = []
+    for f in SHIM_FILES:
+        for m in re.finditer(r"\buse exon::([^;]+);", _strip_comments(_shim(f))):
+            path = "".join(m.group(1).split())
+            g = re.fullmatch(r"(.*)::\{(.*)\}", path)
+            leaves = [f"{g.group(1)}::{x}" for x in g.group(2).split(",") if x] if g else [path]
+            out += [(f, leaf.split("::")) for leaf in leaves]
+    return out
+
+
+def _module_file(dirpath, name):
+    for cand in (os.path.join(dirpath, name + ".rs"), os.path.join(dirpath, name, "mod.rs")):
+        if os.path.exists(cand):
+            return cand
+    return None
+
+
+def resolve_public(path):
+    """None when `exon::<path>` is importable from another crate, else the reason it is not."""
+    cur_file, cur_dir = os.path.join(REF_SRC, "lib.rs"), REF_SRC
+    for i, seg in enumerate(path):
+        src = _strip_comments(open(cur_file).read())
+        last = i == len(path) - 1
+        if re.search(r"(?m)^\s*pub mod " + seg + r"\s*;", src):
+            nxt = _module_file(cur_dir, seg)
+            if nxt is None:
+                return f"module file of {seg} not found"
+            cur_file, cur_dir = nxt, (os.path.join(cur_dir, seg) if nxt.endswith("mod.rs") else cur_dir)
+            if last:
+                return None
+            continue
+        if re.search(r"(?m)^\s*(pub\(\w+\)\s+)?mod " + seg + r"\s*;", src):
+            return f"`{seg}` is not a `pub mod` in {os.path.relpath(cur_file, REF_SRC)}"
+        if not last:
+            return f"`{seg}` is not a module of {os.path.relpath(cur_file, REF_SRC)}"
+        if re.search(r"(?m)^\s*pub use [^;]*\b" + seg + r"\b[^;]*;", src) or \
+                re.search(r"(?m)^\s*pub (struct|enum|trait|fn|type|const|static) " + seg + r"\b", src):
+            return None
+        return f"`{seg}` is not a `pub` item or re-export of {os.path.relpath(cur_file, REF_SRC)}"
+    return None
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="the reference tree is only present in the build container")
+def test_every_exon_import_of_the_shim_is_public_in_the_reference():
+    paths = exon_use_paths()
+    assert len(paths) >= 4
+    for f, path in paths:
+        why = resolve_public(path)
+        assert why is None, f"shim/src/{f}: use exon::{'::'.join(path)} -- {why}"
+    # the resolver itself: CRAMScan sits in a pub(crate) module (exon-core/src/datasources/cram/mod.rs:15-20)
+    assert resolve_public(["datasources", "cram", "scanner", "CRAMScan"]) is not None
+    assert resolve_public(["datasources", "cram", "CRAMScan"]) is not None
+    assert resolve_public(["datasources", "vcf", "VCFScan"]) is None
+    assert resolve_public(["ExonSession"]) is None
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="the reference tree is only present in the build container")
+def test_accessors_and_scan_names_the_rule_relies_on_exist_in_the_reference():
+    ds = os.path.join(REF_SRC, "datasources")
+    rule = _shim("rule.rs")
+    # public accessors used through a downcast
+    assert "pub fn base_config(&self)" in open(os.path.join(ds, "vcf", "scanner.rs")).read()
+    assert "pub fn base_config(&self)" in open(os.path.join(ds, "vcf", "indexed_scanner.rs")).read()
+    # the region has NO accessor upstream (hence region_from_debug / the feature) but both scanners derive Debug
+    for f in ("vcf/indexed_scanner.rs", "bam/indexed_scanner.rs"):
+        src = open(os.path.join(ds, f)).read()
+        assert "pub fn region(" not in src and re.search(r"#\[derive\(Debug, Clone\)\]", src) and "region: Arc<Region>" in src
+    # scans matched by ExecutionPlan::name(): the strings must be what the reference returns
+    names = re.search(r"const ALIGNMENT_SCANS: \[&str; \d+\] = \[([^\]]*)\]", rule).group(1)
+    returned = set()
+    for root, _, files in os.walk(ds):
+        for fn in files:
+            if fn.endswith(".rs"):
+                returned |= set(re.findall(r'fn name\(&self\) -> &str \{\s*"(\w+)"', open(os.path.join(root, fn)).read()))
+    for n in re.findall(r'"(\w+)"', names):
+        assert n in returned, f"no ExecutionPlan in the reference is named {n}"
+    # mapping_quality really is Utf8 upstream, which is why the Exec converts it
+    assert re.search(r'Field::new\("mapping_quality", DataType::Utf8', open("/root/reference/exon/exon-sam/src/schema_builder.rs").read())
+    # ExonSession::new returns Self (no `?` on it anywhere in the shim or INTEGRATION.md)
+    ext = open(os.path.join(REF_SRC, "session_context", "exon_context_ext.rs")).read()
+    assert re.search(r"pub fn new\(session: SessionContext\) -> Self", ext)
+    for text in [_shim(f) for f in SHIM_FILES] + [open(os.path.join(ROOT, "INTEGRATION.md")).read()]:
+        assert not re.search(r"ExonSession::new\([^;\n]*\)\s*\?", text), "ExonSession::new returns Self, not a Result"
+
+
+def test_plan_shapes_have_matchers_and_the_known_defects_stay_fixed():
+    rule, lib = _strip_comments(_shim("rule.rs")), _strip_comments(_shim("lib.rs"))
+    doc = _shim("rule.rs")
+    # every matcher the shape table names is defined AND called from rewrite()
+    table = re.findall(r"\| `(match_\w+)` \|", doc)
+    assert set(table) == {"match_vcf_filter", "match_indexed_vcf", "match_alignment_filter", "match_indexed_bam"}
+    body = rule[rule.index("fn rewrite("):]
+    for fn in set(table):
+        assert re.search(r"\bfn " + fn + r"\(", rule) and re.search(r"\b" + fn + r"\(", body), fn
+    # pushed-down region scans are matched WITHOUT a FilterExec above them
+    assert "downcast_ref::<IndexedVCFScanner>()" in body and "downcast_ref::<IndexedBAMScan>()" in body
+    # get_field is matched structurally, never through Display text
+    assert 'downcast_ref::<ScalarFunctionExpr>()' in rule and 'f.name() != "get_field"' in rule
+    assert ".to_string()" not in rule[rule.index("fn info_field_of"):rule.index("fn aggregates_are")]
+    # no import of the pub(crate) CRAM scanner
+    assert "cram::CRAMScan" not in rule and "cram::CRAMScan" not in lib
+    # the stream handle crosses `.await` inside a Send newtype; no bare stream pointer lives in execute()
+    assert "unsafe impl Send for StreamHandle {}" in lib
+    exe = lib[lib.index("fn execute("):]
+    assert "*mut sys::exon_hip_stream" not in exe and "input.next().await" in exe
+    # Utf8 mapping_quality is converted before the push
+    assert "fn mapq_to_u8(" in lib and "mapq_to_u8(&batch, mapq_col)" in exe
+    # the table function of config 5 is registered under its SQL name
+    udtf = _shim("udtf.rs")
+    assert 'register_udtf("fastq_quality_histogram"' in udtf and "impl TableFunctionImpl for FastqQualityHistogram" in udtf
+
+
 def test_rule_and_exec_are_written():
     """the planner-side half must exist, not just be named."""
     lib = open(os.path.join(ROOT, "shim", "src", "lib.rs")).read()
     rule = open(os.path.join(ROOT, "shim", "src", "rule.rs")).read()
     assert "impl PhysicalOptimizerRule for GpuFilterAggRule" in rule and "pub fn try_new(" in lib
     assert "impl ExecutionPlan for GpuFilterAggExec" in lib and "AggregateMode::Partial" in rule
-    for sym in re.findall(r"sys::(exon_hip_\w+)\(", lib + rule):
+    for sym in re.findall(r"sys::(exon_hip_\w+)\(", lib + rule + _shim("udtf.rs")):
         assert f"pub fn {sym}(" in SYS_RS, f"{sym} used by the shim but not bound in sys.rs"
