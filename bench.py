@@ -59,6 +59,12 @@ def parse_args():
                     help="N > 1: native = ncclAllGather on the kernels' stream through the C ABI; torch = torch.distributed; "
                          "auto = native when it initialises and reproduces torch's result during warm-up, else torch")
     ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3", "c5", "c6"])
+    ap.add_argument("--groups", type=int, default=5,
+                    help="c4 only: number of GROUP BY keys.  5 = config 4's FILTER mix (ids in registers); > 8 adds the LDS table "
+                         "(ids 8..4103) and, beyond 4104 ids, global atomics -- the paths files and high-cardinality keys take")
+    ap.add_argument("--group-dist", default="zipf", choices=["zipf", "uniform"],
+                    help="--groups != 5: key frequencies.  zipf = log-uniform ids (P(id < k) = ln(k+1)/ln(G+1): dictionary ids "
+                         "are handed out in order of first appearance, so frequent keys are early); uniform = the worst case")
     ap.add_argument("--cpu-sample-rows", type=float, default=128e6)
     ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -72,7 +78,7 @@ class Workload:
     The partial state is ONE packed int64-typed tensor `[n_i64 counters][n_f64 sums bit-cast]` (exon_hip_plan_state_size)
     written by exon_hip_plan_launch; `counts` / `sums` are views of it."""
 
-    def __init__(self, ctx, kind, rows, row0, n_total):
+    def __init__(self, ctx, kind, rows, row0, n_total, groups=5, group_dist="zipf"):
         self.ctx, self.kind, self.n = ctx, kind, rows
         dev = torch.device("cuda", torch.cuda.current_device())
         s = torch.cuda.current_stream().cuda_stream
@@ -87,7 +93,9 @@ class Workload:
             self.qv = torch.zeros(nb, dtype=torch.uint8, device=dev)
             ctx._check(lib.exon_hip_gen_c4(h, s, SEED["c4"], row0, row0 + rows, self.af.data_ptr(), self.av.data_ptr(),
                                            self.qual.data_ptr(), self.qv.data_ptr(), self.fid.data_ptr()))
-            self.G = 5
+            self.G = groups
+            if groups != 5:
+                synth_group_ids(self.fid, rows, row0, groups, group_dist)
             self.plan = ctx.plan_cmp_avg_by_group(">", 0.01, self.G)
             self.cols = [(self.af.data_ptr(), self.av.data_ptr(), None), (self.qual.data_ptr(), self.qv.data_ptr(), None),
                          (self.fid.data_ptr(), None, None)]
@@ -161,6 +169,39 @@ class Workload:
                 self._go = self.plan.prepared(self.cols, self.n, self.state.data_ptr(), overwrite=True, stream=s)
                 self._go_stream = s
             self._go()
+
+
+def synth_group_ids(fid, rows, row0, groups, dist):
+    """--groups G: overwrite the FILTER ids with G synthetic keys (seeded per 16 Mi-row chunk by its global start row, so a
+    shard of a multi-GPU run holds the same ids as the same rows of a 1-GPU run when shards start on chunk boundaries)."""
+    import math
+    step = 1 << 24
+    for c0 in range(0, rows, step):
+        m = min(step, rows - c0)
+        g = torch.Generator(device=fid.device)
+        g.manual_seed(0x5EED0000 + (row0 + c0) // step)
+        u = torch.rand(m, generator=g, device=fid.device, dtype=torch.float32)
+        if dist == "uniform":
+            ids = (u * groups).to(torch.int32)
+        else:
+            ids = (torch.exp(u.double() * math.log(groups + 1.0)) - 1.0).to(torch.int32)
+        fid[c0:c0 + m] = ids.clamp_(0, groups - 1)
+
+
+def torch_reference_c4(wl, thr=0.01):
+    """Plain torch fp64 statement of config 4's query over a Workload's device columns (used when --groups != 5, where the
+    C oracle has no generator): (count(y)[G], count(*)[G], sum(y)[G])."""
+    n, G = wl.n, wl.G
+    idx = torch.arange(n, device=wl.af.device)
+    av = ((wl.av[idx >> 3] >> (idx & 7).to(torch.uint8)) & 1).bool()
+    qv = ((wl.qv[idx >> 3] >> (idx & 7).to(torch.uint8)) & 1).bool()
+    keep = av & (wl.af[:n].double() > thr)
+    gid = wl.fid[:n].long()
+    crow = torch.bincount(gid[keep], minlength=G)
+    kq = keep & qv
+    cnn = torch.bincount(gid[kq], minlength=G)
+    sums = torch.zeros(G, dtype=torch.float64, device=gid.device).index_add_(0, gid[kq], wl.qual[:n][kq].double())
+    return cnn, crow, sums
 
 
 def cpu_baseline(kind, sample_rows, n_total, reps):
@@ -328,7 +369,11 @@ def main():
         n_total = int(a.rows) * world
         lo, hi = rank * int(a.rows), (rank + 1) * int(a.rows)
     rows = hi - lo
-    wl = Workload(ctx, a.workload, rows, lo, n_total)
+    if a.groups != 5 and a.workload != "c4":
+        raise SystemExit("--groups applies to --workload c4")
+    if a.groups < 1:
+        raise SystemExit("--groups must be >= 1")
+    wl = Workload(ctx, a.workload, rows, lo, n_total, groups=a.groups, group_dist=a.group_dist)
     V = wl.state.numel()
     merged = torch.zeros_like(wl.state) if world > 1 else wl.state
     gathered = torch.zeros(world * V, dtype=torch.int64, device=wl.state.device) if world > 1 else None
@@ -430,7 +475,7 @@ def main():
             "value": round(value, 1), "unit": "Mrows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": DTYPE[a.workload], "data": "synthetic",
-            "config": {"workload": WORKLOAD[a.workload],
+            "config": {"workload": WORKLOAD[a.workload] + (f" -- with {a.groups} synthetic GROUP BY keys ({a.group_dist})" if a.groups != 5 else ""),
                        "rows_total": n_total, "rows_per_gpu": rows,
                        "sharding": f"rank k owns the contiguous row range (file split) [k N/{world}, (k+1) N/{world})",
                        "reduce": merge_path, "state_bytes": V * 8,
@@ -449,13 +494,31 @@ def main():
         if os.path.exists(traffic_file):
             try:
                 t = json.load(open(traffic_file)).get(a.workload)
-                if t and int(t.get("rows", 0)) == rows:
+                if t and int(t.get("rows", 0)) == rows and a.groups == 5:
                     out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = (f"profiles/traffic.json (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                                          f"passes of round {t.get('round', '?')}, NOT measured in this run)")
             except Exception:
                 pass
-        if not a.no_cpu_baseline and world == 1:
+        if a.groups != 5:
+            # no C-oracle generator for synthetic keys: the checker is a plain torch fp64 statement of the query on the
+            # first rows of the same resident table
+            m = int(min(rows, 64_000_000))
+            chk = Workload(ctx, "c4", m, lo, n_total, groups=a.groups, group_dist=a.group_dist)
+            chk.run()
+            torch.cuda.synchronize()
+            cnn, crow, sm = torch_reference_c4(chk)
+            G = a.groups
+            if not (torch.equal(chk.counts[:G], cnn) and torch.equal(chk.counts[G:], crow)):
+                raise SystemExit("PARITY FAILURE: counts vs torch reference")
+            if not torch.allclose(chk.sums, sm, rtol=1e-9, atol=0):
+                raise SystemExit("PARITY FAILURE: sums vs torch reference")
+            out["parity"] = f"bit-exact counts, sums within 1e-9 rel. vs a torch fp64 reference on rows [{lo},{lo + m})"
+            out["config"]["groups"] = {"n": G, "dist": a.group_dist, "rows_in_registers_ids_lt_8": int(crow[:8].sum()),
+                                       "rows_in_lds_ids_8_to_4103": int(crow[8:4104].sum()), "rows_by_global_atomics": int(crow[4104:].sum()),
+                                       "of_rows_passing": int(crow.sum()), "sample_rows": m}
+            del chk
+        elif not a.no_cpu_baseline and world == 1:
             sample = int(min(a.cpu_sample_rows, rows))
             if a.workload == "c5":
                 sample = min(sample, 8_000_000)
@@ -474,7 +537,7 @@ def main():
                 raise SystemExit("PARITY FAILURE: sums")
             out["parity"] = f"bit-exact counts, sums within 1e-6 rel. vs oracle on rows [0,{sample})"
             del chk
-        if world == 1 and not a.no_extras and a.workload == "c4":
+        if world == 1 and not a.no_extras and a.workload == "c4" and a.groups == 5:
             extras = {}
             try:
                 extras["configs_at_stated_size"] = {"c2_1e7_rows": time_config(ctx, "c2", 10_000_000),
@@ -484,8 +547,10 @@ def main():
             except Exception as e:  # noqa: BLE001 -- side measurements never cost the headline line
                 extras["error"] = repr(e)
             out["extras"] = extras
-        if a.workload == "c4":
-            G = 5
+        if a.workload == "c4" and a.groups > 64:
+            out["result"] = {"groups_observed": int((counts[a.groups:] > 0).sum()), "rows_passing": int(counts[a.groups:].sum())}
+        elif a.workload == "c4":
+            G = a.groups
             out["result"] = {"filter_rows": counts[G:].tolist(),
                              "avg_qual": [float(sums[g] / counts[g]) if counts[g] else None for g in range(G)]}
         else:

@@ -63,11 +63,11 @@ class Column(C.Structure):
 class PlanDesc(C.Structure):
     _fields_ = [
         ("kind", C.c_int32), ("n_groups", C.c_int32),
-        ("region_chrom_id", C.c_int32), ("reserved0", C.c_int32),
+        ("region_chrom_id", C.c_int32), ("x_type", C.c_int32),
         ("region_start", C.c_int64), ("region_end", C.c_int64),
         ("flag_mask", C.c_int32), ("flag_value", C.c_int32), ("mapq_min", C.c_int32),
         ("cmp_op", C.c_int32), ("threshold", C.c_double),
-        ("lmax", C.c_int32), ("reserved1", C.c_int32),
+        ("lmax", C.c_int32), ("y_type", C.c_int32),
         ("columns", C.c_int32 * 4),
     ]
 

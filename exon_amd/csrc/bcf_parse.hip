@@ -158,6 +158,18 @@ __global__ __launch_bounds__(256) void k_bcf_extract(const uint8_t* __restrict__
         if (w >= ik.n || key != ik.key[w] || have[w]) continue;
         if (ik.kind[w] == 'b') {
           have[w] = true;  // a Flag is true by being there
+        } else if (ik.kind[w] == 'i') {
+          // Type=Integer: int8 / int16 / int32 widened to Int32 exactly (bit pattern in the 4-byte column)
+          if (vc >= 1 && vt >= 1 && vt <= 3) {
+            Cursor t = c;
+            const int64_t v = t.read_int(vt);
+            if (t.bad) { c.bad = true; break; }
+            const int64_t missing = vt == 1 ? -128 : vt == 2 ? -32768 : (int64_t)INT32_MIN;
+            if (v != missing) {
+              iv[w] = __int_as_float((int32_t)v);
+              have[w] = true;
+            }
+          }
         } else if (vc >= 1) {
           if (vt == 5) {
             if (c.o + 4 > c.end) { c.bad = true; break; }
@@ -215,7 +227,7 @@ __global__ __launch_bounds__(256) void k_bcf_extract(const uint8_t* __restrict__
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       if (w >= ik.n) continue;
-      if (ik.kind[w] == 'f') out.info[w][row] = have[w] ? iv[w] : 0.f;
+      if (ik.kind[w] != 'b') out.info[w][row] = have[w] ? iv[w] : 0.f;
       if (have[w]) atomicOr(&out.info_valid[w][row >> 5], bit);
     }
   }
@@ -334,7 +346,7 @@ int exon_hip_bcf_parser_set_info_keys(exon_hip_bcf_parser* p, const int32_t* key
   p->ik.n = n;
   hipSetDevice(p->ctx->device);
   for (int q = 0; q < n; ++q) {
-    if (kinds[q] != 'f' && kinds[q] != 'b') return fail(p->ctx, EXON_HIP_EUNSUPPORTED, "INFO kind '%c' is not decoded on the device", kinds[q]);
+    if (kinds[q] != 'f' && kinds[q] != 'b' && kinds[q] != 'i') return fail(p->ctx, EXON_HIP_EUNSUPPORTED, "INFO kind '%c' is not decoded on the device", kinds[q]);
     p->ik.key[q] = keys[q];
     p->ik.kind[q] = kinds[q];
     if (q == 0) continue;
@@ -402,7 +414,7 @@ int exon_hip_bcf_parser_parse(exon_hip_bcf_parser* p, void* stream, const uint8_
   cols->info_valid = p->ik.n ? (uint8_t*)p->out.info_valid[0] : nullptr;
   cols->n_info = p->ik.n;
   for (int q = 0; q < p->ik.n; ++q) {
-    cols->infos[q] = p->ik.kind[q] == 'f' ? p->out.info[q] : nullptr;
+    cols->infos[q] = p->ik.kind[q] != 'b' ? p->out.info[q] : nullptr;
     cols->infos_valid[q] = (uint8_t*)p->out.info_valid[q];
   }
   return EXON_HIP_OK;

@@ -279,6 +279,8 @@ int exon_hip_timer_stop_ms(exon_hip_ctx* ctx, void* stream, float* ms) {
 static LaunchCfg cfg_for(const exon_hip_ctx* ctx, int flags) {
   LaunchCfg c = ctx->cfg;
   c.overwrite = (flags & EXON_HIP_LAUNCH_OVERWRITE) != 0;
+  c.x_is_int = (flags & EXON_LAUNCH_X_INT32) != 0;
+  c.y_is_int = (flags & EXON_LAUNCH_Y_INT32) != 0;
   return c;
 }
 static int empty_input(exon_hip_ctx* ctx, hipStream_t s, int flags, void* state, size_t bytes) {

@@ -175,7 +175,8 @@ struct FilterTable {
 
 constexpr int MAX_INFO = 4;
 // the typed INFO fields a parser extracts (InfosBuilder children: exon-vcf/src/array_builder/info_builder.rs:152-309):
-// kind 'f' = Number=1 Float / Integer -> f32 + validity; 'b' = Flag -> presence bitmap (value true where valid)
+// kind 'f' = Number=1 Float -> f32 + validity; 'i' = Number=1 Integer -> i32 + validity (the 4-byte column holds the bit
+// pattern); 'b' = Flag -> presence bitmap (value true where valid)
 struct InfoKeys {
   int n;
   int len[MAX_INFO];
@@ -378,7 +379,27 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
                 const int vl = (int)(j - vb);
                 if (!(vl == 0 || (vl == 1 && text[vb] == '.'))) {
                   uint32_t bits;
-                  if (exon::dec::parse_f32(reinterpret_cast<const char*>(text + vb), vl, &bits)) {
+                  if (ik.kind[q] == 'i') {
+                    // Type=Integer: exact int32 ([+-] digits); the value travels as its bit pattern in the 4-byte column.
+                    // Anything else (including out of range) is the reference's parse error: the row is left to the host
+                    int k = 0;
+                    const bool neg = text[vb] == '-';
+                    if (neg || text[vb] == '+') k = 1;
+                    int64_t iv = 0;
+                    bool ok = k < vl && vl - k <= 10;
+                    for (; k < vl && ok; ++k) {
+                      const unsigned d = (unsigned)text[vb + k] - '0';
+                      ok = d <= 9u;
+                      iv = iv * 10 + d;
+                    }
+                    if (neg) iv = -iv;
+                    if (ok && iv >= INT32_MIN && iv <= INT32_MAX) {
+                      v[q] = __int_as_float((int32_t)iv);
+                      info_ok[q] = true;
+                    } else {
+                      bad = true;
+                    }
+                  } else if (exon::dec::parse_f32(reinterpret_cast<const char*>(text + vb), vl, &bits)) {
                     v[q] = __uint_as_float(bits);
                     info_ok[q] = true;
                   } else {
@@ -406,7 +427,7 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
           if (left > 0 && i < ie) entry(ie);  // the last entry has no ';' behind it
         }
         for (int q = 0; q < ik.n; ++q)
-          if (ik.kind[q] == 'f') out.info[q][row] = v[q];
+          if (ik.kind[q] != 'b') out.info[q][row] = v[q];
       }
     }
   }
@@ -551,7 +572,7 @@ int exon_hip_vcf_parser_create(exon_hip_ctx* ctx, const char* const* contig_name
       std::string item = f.substr(i, j - i);
       char kind = 'f';
       const size_t c = item.rfind(':');
-      if (c != std::string::npos && c + 2 == item.size() && (item[c + 1] == 'f' || item[c + 1] == 'b')) {
+      if (c != std::string::npos && c + 2 == item.size() && (item[c + 1] == 'f' || item[c + 1] == 'b' || item[c + 1] == 'i')) {
         kind = item[c + 1];
         item.resize(c);
       }
@@ -580,7 +601,7 @@ int exon_hip_vcf_parser_create(exon_hip_ctx* ctx, const char* const* contig_name
   dalloc(&p->out_bufs[4], rb);
   dalloc(&p->out_bufs[5], r * 4);
   for (int q = 0; q < p->ik.n; ++q) {
-    if (p->ik.kind[q] == 'f') dalloc(&p->out_bufs[6 + 2 * q], r * 4);
+    if (p->ik.kind[q] == 'f' || p->ik.kind[q] == 'i') dalloc(&p->out_bufs[6 + 2 * q], r * 4);
     dalloc(&p->out_bufs[7 + 2 * q], rb);
   }
   if (e == hipSuccess) e = hipHostMalloc((void**)&p->h_scalars, 16);

@@ -241,24 +241,81 @@ struct Dictionary {
       for (size_t i = 0; i < names.size(); ++i)
         if (names[i].size() == n && memcmp(names[i].data(), p, n) == 0) return (int32_t)i;
     } else {  // string INFO values can be many: hash index over everything appended so far
-      if (index_.size() != names.size()) {
+      // `indexed_` = how many of `names` the index covers.  (Comparing index_.size() with names.size() instead rebuilt the
+      // whole map on EVERY lookup once `names` held a duplicate -- e.g. a header repeating a ##contig line.)
+      if (indexed_ > names.size()) {  // `names` was replaced from outside: start over
         index_.clear();
-        for (size_t i = 0; i < names.size(); ++i) index_.emplace(names[i], (int32_t)i);
+        indexed_ = 0;
       }
+      for (; indexed_ < names.size(); ++indexed_) index_.emplace(names[indexed_], (int32_t)indexed_);  // first occurrence wins
       auto it = index_.find(std::string(p, n));
       if (it != index_.end()) return it->second;
       index_.emplace(std::string(p, n), (int32_t)names.size());
+      ++indexed_;
     }
     names.emplace_back(p, n);
     return (int32_t)names.size() - 1;
   }
   std::unordered_map<std::string, int32_t> index_;
+  size_t indexed_ = 0;
   int32_t find(const std::string& s) const {
     for (size_t i = 0; i < names.size(); ++i)
       if (names[i] == s) return (int32_t)i;
     return -1;
   }
 };
+
+// List<item> column (INFO fields with Number other than 0 / 1: exon-vcf/src/array_builder/info_builder.rs:258-305): Arrow
+// layout = validity bitmap + int32 offsets, one child holding the items (themselves nullable: a '.' element is a NULL item)
+inline void make_list(struct ArrowArray* a, const std::vector<int32_t>& offsets, const std::vector<uint8_t>& valid,
+                      struct ArrowArray* child) {
+  OwnedArray* o = new OwnedArray();
+  const int64_t n = (int64_t)offsets.size() - 1;
+  int64_t nulls = 0;
+  void* vb = valid.empty() ? nullptr : pack_validity(valid, &nulls);
+  if (vb) o->bufs.push_back(vb);
+  void* ob = dup_buf(offsets.data(), offsets.size() * 4);
+  o->bufs.push_back(ob);
+  o->buf_ptrs = {vb, ob};
+  o->children = {child};
+  memset(a, 0, sizeof *a);
+  a->length = n < 0 ? 0 : n;
+  a->null_count = nulls;
+  a->n_buffers = 2;
+  a->buffers = o->buf_ptrs.data();
+  a->n_children = 1;
+  a->children = o->children.data();
+  a->release = release_array;
+  a->private_data = o;
+}
+template <typename T>
+struct ListBuilder {
+  std::vector<int32_t> offsets{0};
+  std::vector<uint8_t> valid;  // byte per row
+  PrimitiveBuilder<T> items;
+  void append_null() {
+    offsets.push_back((int32_t)items.len());
+    valid.push_back(0);
+  }
+  void close_row() {  // after items.append_value / append_null calls for this row
+    offsets.push_back((int32_t)items.len());
+    valid.push_back(1);
+  }
+  size_t len() const { return offsets.size() - 1; }
+  struct ArrowArray* finish(struct ArrowArray* item_dictionary = nullptr) {
+    struct ArrowArray* a = static_cast<struct ArrowArray*>(malloc(sizeof *a));
+    make_list(a, offsets, valid, items.finish(item_dictionary));
+    offsets.assign(1, 0);
+    valid.clear();
+    return a;
+  }
+};
+// schema field "+l" with its "item" child (item_fmt "f" / "i"; a dictionary-encoded item passes its value type in `dict`)
+inline struct ArrowSchema* new_list_field(const char* item_fmt, const char* name, struct ArrowSchema* item_dict = nullptr) {
+  struct ArrowSchema* s = static_cast<struct ArrowSchema*>(malloc(sizeof *s));
+  make_schema(s, "+l", name, true, {new_field(item_fmt, "item", true, item_dict)});
+  return s;
+}
 
 // The reference's column-sink contract (exon-common/src/array_builder.rs:20-45)
 class ExonArrayBuilder {

@@ -95,6 +95,8 @@ class BCFBatchReader {
     const size_t K = info_specs.size();
     std::vector<PrimitiveBuilder<float>> info_f(K);
     std::vector<PrimitiveBuilder<int32_t>> info_i(K);
+    std::vector<ListBuilder<float>> info_lf(K);    // 'F'
+    std::vector<ListBuilder<int32_t>> info_li(K);  // 'I' values, 'S' dictionary ids
     std::vector<uint8_t> rec;
     size_t rows = 0;
     while ((int64_t)rows < cfg_.batch_size) {
@@ -135,9 +137,9 @@ class BCFBatchReader {
         }
       }
       // INFO: (typed key, typed value) pairs
-      bool have[MAX_INFO_FIELDS] = {false, false, false, false};
-      float fv[MAX_INFO_FIELDS] = {0.f, 0.f, 0.f, 0.f};
-      int32_t sv[MAX_INFO_FIELDS] = {0, 0, 0, 0};
+      bool have[MAX_INFO_FIELDS] = {};
+      float fv[MAX_INFO_FIELDS] = {};
+      int32_t sv[MAX_INFO_FIELDS] = {};
       for (int k = 0; k < n_info; ++k) {
         int kt, kc;
         typed_header(rec, &o, end, &kt, &kc);
@@ -151,6 +153,17 @@ class BCFBatchReader {
           const char kind = info_specs[q].kind;
           if (kind == 'b') {
             have[q] = true;  // a Flag is true by being there (typed value: missing type, or an int8 1)
+          } else if (kind == 'i' && vc >= 1) {
+            // Type=Integer: int8 / int16 / int32 typed value, widened to Int32 exactly; the type's minimum is 'missing'
+            if (vt >= 1 && vt <= 3) {
+              size_t oo = o;
+              const int64_t v = read_int(rec, &oo, end, vt);
+              const int64_t missing = vt == 1 ? -128 : vt == 2 ? -32768 : (int64_t)INT32_MIN;
+              if (v != missing) {
+                sv[q] = (int32_t)v;
+                have[q] = true;
+              }
+            }
           } else if (kind == 'f' && vc >= 1) {
             if (vt == 5) {
               uint32_t b;
@@ -165,6 +178,71 @@ class BCFBatchReader {
               const int64_t missing = vt == 1 ? -128 : vt == 2 ? -32768 : (int64_t)INT32_MIN;
               if (v != missing) {
                 fv[q] = (float)v;
+                have[q] = true;
+              }
+            }
+          } else if (info_kind_is_list(kind) && vc >= 1) {
+            // typed vector -> List<item>: the type's 'missing' value is a NULL item, its 'end of vector' value ends the list
+            // (VCF specification 6.3.3); a character vector holds the ','-joined text of a String list
+            if (kind == 'S' && vt == 7) {
+              size_t len = (size_t)vc;
+              while (len > 0 && rec[o + len - 1] == 0) --len;
+              if (!(len == 1 && rec[o] == '.') && len > 0) {
+                size_t a = 0;
+                while (a <= len) {
+                  size_t e = a;
+                  while (e < len && rec[o + e] != ',') ++e;
+                  if (e == a || (e - a == 1 && rec[o + a] == '.')) info_li[q].items.append_null(0);
+                  else info_li[q].items.append_value(info_dicts[q].lookup_or_insert(reinterpret_cast<const char*>(&rec[o + a]), e - a));
+                  a = e + 1;
+                }
+                info_li[q].close_row();
+                have[q] = true;
+              }
+            } else if (kind == 'F' && vt == 5) {
+              int items = 0;
+              if (vc == 1) {  // a single 'missing' item is `key=.`: the whole value is missing
+                uint32_t b0;
+                memcpy(&b0, &rec[o], 4);
+                if (b0 == 0x7F800001u) continue;
+              }
+              for (int e = 0; e < vc; ++e) {
+                uint32_t b;
+                memcpy(&b, &rec[o + 4 * (size_t)e], 4);
+                if (b == 0x7F800002u) break;
+                float f;
+                memcpy(&f, &b, 4);
+                if (b == 0x7F800001u) info_lf[q].items.append_null(0.f);
+                else info_lf[q].items.append_value(f);
+                ++items;
+              }
+              if (items > 0) {
+                info_lf[q].close_row();
+                have[q] = true;
+              }
+            } else if ((kind == 'I' || kind == 'F') && vt >= 1 && vt <= 3) {
+              size_t oo = o;
+              const int64_t missing = vt == 1 ? -128 : vt == 2 ? -32768 : (int64_t)INT32_MIN;
+              int items = 0;
+              if (vc == 1) {  // a single 'missing' item is `key=.`: the whole value is missing
+                size_t o1 = o;
+                if (read_int(rec, &o1, end, vt) == missing) continue;
+              }
+              for (int e = 0; e < vc; ++e) {
+                const int64_t v = read_int(rec, &oo, end, vt);
+                if (v == missing + 1) break;  // end of vector
+                if (kind == 'I') {
+                  if (v == missing) info_li[q].items.append_null(0);
+                  else info_li[q].items.append_value((int32_t)v);
+                } else {
+                  if (v == missing) info_lf[q].items.append_null(0.f);
+                  else info_lf[q].items.append_value((float)v);
+                }
+                ++items;
+              }
+              if (items > 0) {
+                if (kind == 'I') info_li[q].close_row();
+                else info_lf[q].close_row();
                 have[q] = true;
               }
             }
@@ -191,7 +269,11 @@ class BCFBatchReader {
       }
       filter.append_value(filter_dict.lookup_or_insert(fl.data(), fl.size()));
       for (size_t q = 0; q < K; ++q) {
-        if (info_specs[q].kind == 'f') {
+        if (info_specs[q].kind == 'F') {
+          if (!have[q]) info_lf[q].append_null();  // (a present list closed its row when it was decoded)
+        } else if (info_specs[q].kind == 'I' || info_specs[q].kind == 'S') {
+          if (!have[q]) info_li[q].append_null();
+        } else if (info_specs[q].kind == 'f') {
           if (have[q]) info_f[q].append_value(fv[q]);
           else info_f[q].append_null(0.f);
         } else {
@@ -206,6 +288,10 @@ class BCFBatchReader {
                                             filter.finish(utf8_array(filter_dict.names))};
     for (size_t q = 0; q < K; ++q) {
       if (info_specs[q].kind == 'f') kids.push_back(info_f[q].finish());
+      else if (info_specs[q].kind == 'i') kids.push_back(info_i[q].finish());
+      else if (info_specs[q].kind == 'F') kids.push_back(info_lf[q].finish());
+      else if (info_specs[q].kind == 'I') kids.push_back(info_li[q].finish());
+      else if (info_specs[q].kind == 'S') kids.push_back(info_li[q].finish(utf8_array(info_dicts[q].names)));
       else if (info_specs[q].kind == 's') kids.push_back(info_i[q].finish(utf8_array(info_dicts[q].names)));
       else {
         struct ArrowArray* a = static_cast<struct ArrowArray*>(malloc(sizeof *a));
@@ -223,6 +309,10 @@ class BCFBatchReader {
     for (const auto& sp : info_specs) {
       const std::string name = "info." + sp.name;
       if (sp.kind == 'f') kids.push_back(new_field("f", name.c_str(), true));
+      else if (sp.kind == 'i') kids.push_back(new_field("i", name.c_str(), true));
+      else if (sp.kind == 'F') kids.push_back(new_list_field("f", name.c_str()));
+      else if (sp.kind == 'I') kids.push_back(new_list_field("i", name.c_str()));
+      else if (sp.kind == 'S') kids.push_back(new_list_field("i", name.c_str(), new_field("u", "", false)));
       else if (sp.kind == 'b') kids.push_back(new_field("b", name.c_str(), true));
       else kids.push_back(new_field("i", name.c_str(), true, new_field("u", "", false)));
     }

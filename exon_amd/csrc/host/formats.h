@@ -121,14 +121,21 @@ inline std::string header_attr(const std::string& line, const char* key) {
 // One typed INFO field of the scan (exon.vcf_parse_info = true; `info."<F>"`): InfosBuilder builds a child per header INFO
 // (exon-vcf/src/array_builder/info_builder.rs:152-309, typing in exon-core/src/datasources/vcf/schema_builder.rs:197-249); a
 // scan here builds the ones the query names (up to MAX_INFO_FIELDS, comma-separated in the options), in the device layout:
-//   'f'  Number=1 Float / Integer -> f32 + validity      'b'  Number=0 Flag -> Boolean, true when present, NULL when absent
+//   'f'  Number=1 Float -> f32 + validity                'i'  Number=1 Integer -> i32 + validity (exact: never through f32)
+//   'b'  Number=0 Flag -> Boolean, true when present, NULL when absent
 //   's'  Number=1 String / Character -> dictionary<int32, utf8> + validity
+//   'F' / 'I' / 'S'  any other Number (A, R, G, '.', 2, ...) of Float / Integer / String|Character -> List<f32 / i32 /
+//        dictionary<int32, utf8>>: items split on ',', an item '.' is a NULL item (info_builder.rs:258-305)
 // Key absent, value '.', or INFO itself '.' (the whole struct is NULL then): NULL in every kind.
 struct InfoSpec {
   std::string name;
   char kind = 'f';
 };
-constexpr int MAX_INFO_FIELDS = 4;
+// Fields per scan: the reference builds a child for EVERY header INFO line; a scan here builds the ones the query names
+// (projection pushdown).  16 is what the device parsers' by-value key table holds (exon_hip_vcf_columns.infos[16]).
+constexpr int MAX_INFO_FIELDS = 16;
+inline bool info_kind_is_list(char k) { return k == 'F' || k == 'I' || k == 'S'; }
+inline bool info_kind_on_device(char k) { return k == 'f' || k == 'i' || k == 'b'; }  // the others keep the scan on the host
 
 inline std::vector<std::string> split_list(const std::string& s, char sep = ',') {
   std::vector<std::string> out;
@@ -152,13 +159,23 @@ inline std::vector<InfoSpec> resolve_info_specs(const std::string& fields, const
     if (!ty) throw std::runtime_error("INFO field " + name + " is not declared in the header");
     InfoSpec sp;
     sp.name = name;
-    if (*ty == "1|Float" || *ty == "1|Integer") sp.kind = 'f';
+    if (*ty == "1|Float") sp.kind = 'f';
+    else if (*ty == "1|Integer") sp.kind = 'i';  // Int32 in the reference's schema (schema_builder.rs:197-205)
     else if (*ty == "0|Flag") sp.kind = 'b';
     else if (*ty == "1|String" || *ty == "1|Character") sp.kind = 's';
-    else throw std::runtime_error("INFO field " + name + " is not a Number=1 Float/Integer/String/Character or a Flag field (" + *ty + ")");
+    else {
+      // Number other than 0 / 1 -> List<item> (schema_builder.rs:235-249)
+      const size_t bar = ty->find('|');
+      const std::string number = ty->substr(0, bar), type = bar == std::string::npos ? "" : ty->substr(bar + 1);
+      if (number.empty() || number == "0" || number == "1") throw std::runtime_error("INFO field " + name + " has an unsupported Number / Type (" + *ty + ")");
+      if (type == "Float") sp.kind = 'F';
+      else if (type == "Integer") sp.kind = 'I';
+      else if (type == "String" || type == "Character") sp.kind = 'S';
+      else throw std::runtime_error("INFO field " + name + " has an unsupported Number / Type (" + *ty + ")");
+    }
     specs.push_back(sp);
   }
-  if ((int)specs.size() > MAX_INFO_FIELDS) throw std::runtime_error("at most 4 INFO fields per scan");
+  if ((int)specs.size() > MAX_INFO_FIELDS) throw std::runtime_error("at most " + std::to_string(MAX_INFO_FIELDS) + " INFO fields per scan");
   return specs;
 }
 
@@ -167,7 +184,7 @@ class VCFArrayBuilder : public ExonArrayBuilder {
   // info_dicts: one dictionary per spec (used by the 's' kind only), owned by the caller like the other dictionaries
   VCFArrayBuilder(Dictionary* chrom_dict, Dictionary* filter_dict, const std::vector<InfoSpec>& specs, std::vector<Dictionary>* info_dicts)
       : chrom_dict_(chrom_dict), filter_dict_(filter_dict), specs_(specs), info_dicts_(info_dicts), info_f_(specs.size()),
-        info_i_(specs.size()) {}
+        info_i_(specs.size()), info_lf_(specs.size()), info_li_(specs.size()) {}
 
   // one data line (no terminator).  Field rules: lazy_array_builder.rs:159-216.
   void append(const std::string& line) { append(line.data(), line.size()); }
@@ -212,7 +229,11 @@ class VCFArrayBuilder : public ExonArrayBuilder {
     out.push_back(filter_.finish(utf8_array(filter_dict_->names)));
     for (size_t k = 0; k < specs_.size(); ++k) {
       if (specs_[k].kind == 'f') out.push_back(info_f_[k].finish());
+      else if (specs_[k].kind == 'i') out.push_back(info_i_[k].finish());
       else if (specs_[k].kind == 's') out.push_back(info_i_[k].finish(utf8_array((*info_dicts_)[k].names)));
+      else if (specs_[k].kind == 'F') out.push_back(info_lf_[k].finish());
+      else if (specs_[k].kind == 'I') out.push_back(info_li_[k].finish());
+      else if (specs_[k].kind == 'S') out.push_back(info_li_[k].finish(utf8_array((*info_dicts_)[k].names)));
       else {  // Flag -> Boolean: value true where present
         struct ArrowArray* a = static_cast<struct ArrowArray*>(malloc(sizeof *a));
         make_boolean(a, info_i_[k].valid, info_i_[k].valid);
@@ -231,7 +252,7 @@ class VCFArrayBuilder : public ExonArrayBuilder {
     qual_.values.reserve(rows); qual_.valid.reserve(rows);
     for (size_t k = 0; k < specs_.size(); ++k) {
       if (specs_[k].kind == 'f') { info_f_[k].values.reserve(rows); info_f_[k].valid.reserve(rows); }
-      else { info_i_[k].values.reserve(rows); info_i_[k].valid.reserve(rows); }
+      else if (!info_kind_is_list(specs_[k].kind)) { info_i_[k].values.reserve(rows); info_i_[k].valid.reserve(rows); }
     }
   }
   // raw column vectors (parallel decoder: slabs are parsed with slab-local dictionaries, then re-keyed)
@@ -241,7 +262,25 @@ class VCFArrayBuilder : public ExonArrayBuilder {
   PrimitiveBuilder<float>& quals() { return qual_; }
   const std::vector<InfoSpec>& info_specs() const { return specs_; }
   PrimitiveBuilder<float>& info_f32(size_t k) { return info_f_[k]; }      // 'f'
-  PrimitiveBuilder<int32_t>& info_i32(size_t k) { return info_i_[k]; }    // 's': dictionary ids; 'b': 1 where present
+  PrimitiveBuilder<int32_t>& info_i32(size_t k) { return info_i_[k]; }    // 'i': values; 's': dictionary ids; 'b': 1 where present
+
+  // INFO Type=Integer value: Rust's `str::parse::<i32>` ([+-] digits, the whole field, no blanks); anything else -- and a
+  // value outside int32 -- is the reference's parse error for the record (noodles `Info::get(...).transpose()?`)
+  static int32_t parse_i32(const char* p, size_t n) {
+    size_t i = 0;
+    bool neg = false;
+    if (i < n && (p[i] == '-' || p[i] == '+')) neg = p[i++] == '-';
+    if (i == n) throw std::runtime_error("invalid INFO integer '" + std::string(p, n) + "'");
+    int64_t v = 0;
+    for (; i < n; ++i) {
+      if (p[i] < '0' || p[i] > '9') throw std::runtime_error("invalid INFO integer '" + std::string(p, n) + "'");
+      v = v * 10 + (p[i] - '0');
+      if (v > (int64_t)INT32_MAX + 1) throw std::runtime_error("INFO integer out of the int32 range '" + std::string(p, n) + "'");
+    }
+    if (neg) v = -v;
+    if (v > INT32_MAX || v < INT32_MIN) throw std::runtime_error("INFO integer out of the int32 range '" + std::string(p, n) + "'");
+    return (int32_t)v;
+  }
 
   static bool parse_pos(const char* p, size_t n, int64_t* out) {
     if (n == 0 || n > 18) return false;
@@ -330,7 +369,14 @@ class VCFArrayBuilder : public ExonArrayBuilder {
   // the ';'-separated entries; the FIRST occurrence of a key wins.
   void append_info(const char* p, size_t n) {
     const size_t K = specs_.size();
-    bool seen[MAX_INFO_FIELDS] = {false, false, false, false};
+    bool seen[MAX_INFO_FIELDS] = {};
+    auto null_of = [&](size_t k) {
+      const char kind = specs_[k].kind;
+      if (kind == 'f') info_f_[k].append_null(0.f);
+      else if (kind == 'F') info_lf_[k].append_null();
+      else if (kind == 'I' || kind == 'S') info_li_[k].append_null();
+      else info_i_[k].append_null(0);
+    };
     if (!(n == 1 && p[0] == '.')) {
       size_t i = 0;
       while (i < n) {
@@ -344,27 +390,44 @@ class VCFArrayBuilder : public ExonArrayBuilder {
           const char* v = eq < j ? p + eq + 1 : p + j;
           const size_t vl = eq < j ? j - eq - 1 : 0;
           const bool missing = eq < j && (vl == 0 || (vl == 1 && v[0] == '.'));
-          if (specs_[k].kind == 'b') {
+          const char kind = specs_[k].kind;
+          seen[k] = true;
+          if (kind == 'b') {
             info_i_[k].append_value(1);  // a Flag is true by being there
-            seen[k] = true;
           } else if (eq < j && !missing) {
-            if (specs_[k].kind == 'f') info_f_[k].append_value(parse_f32(v, vl));
-            else info_i_[k].append_value((*info_dicts_)[k].lookup_or_insert(v, vl));
-            seen[k] = true;
+            if (kind == 'f') info_f_[k].append_value(parse_f32(v, vl));
+            else if (kind == 'i') info_i_[k].append_value(parse_i32(v, vl));
+            else if (kind == 's') info_i_[k].append_value((*info_dicts_)[k].lookup_or_insert(v, vl));
+            else {  // list: items split on ','; '.' (or an empty item) is a NULL item
+              size_t a = 0;
+              while (a <= vl) {
+                size_t e = a;
+                while (e < vl && v[e] != ',') ++e;
+                const bool dot = e == a || (e - a == 1 && v[a] == '.');
+                if (kind == 'F') {
+                  if (dot) info_lf_[k].items.append_null(0.f);
+                  else info_lf_[k].items.append_value(parse_f32(v + a, e - a));
+                } else if (kind == 'I') {
+                  if (dot) info_li_[k].items.append_null(0);
+                  else info_li_[k].items.append_value(parse_i32(v + a, e - a));
+                } else {
+                  if (dot) info_li_[k].items.append_null(0);
+                  else info_li_[k].items.append_value((*info_dicts_)[k].lookup_or_insert(v + a, e - a));
+                }
+                a = e + 1;
+              }
+              if (kind == 'F') info_lf_[k].close_row();
+              else info_li_[k].close_row();
+            }
           } else {
-            seen[k] = true;  // `key=.` / bare key of a valued field: present but missing -> NULL
-            if (specs_[k].kind == 'f') info_f_[k].append_null(0.f);
-            else info_i_[k].append_null(0);
+            null_of(k);  // `key=.` / bare key of a valued field: present but missing -> NULL
           }
         }
         i = j + 1;
       }
     }
     for (size_t k = 0; k < K; ++k)
-      if (!seen[k]) {
-        if (specs_[k].kind == 'f') info_f_[k].append_null(0.f);
-        else info_i_[k].append_null(0);
-      }
+      if (!seen[k]) null_of(k);
   }
 
   Dictionary *chrom_dict_, *filter_dict_;
@@ -375,6 +438,8 @@ class VCFArrayBuilder : public ExonArrayBuilder {
   PrimitiveBuilder<float> qual_;
   std::vector<PrimitiveBuilder<float>> info_f_;
   std::vector<PrimitiveBuilder<int32_t>> info_i_;
+  std::vector<ListBuilder<float>> info_lf_;    // 'F'
+  std::vector<ListBuilder<int32_t>> info_li_;  // 'I' values, 'S' dictionary ids
   size_t rows_ = 0;
 };
 
@@ -456,7 +521,7 @@ class VCFBatchReader {
     info_specs = resolve_info_specs(cfg_.info_field, header.infos);  // INFO typing: schema_builder.rs:197-249
     info_dicts.assign(info_specs.size(), Dictionary());
     bool string_info = false;
-    for (const auto& sp : info_specs) string_info |= sp.kind == 's';
+    for (const auto& sp : info_specs) string_info |= !info_kind_on_device(sp.kind);  // dictionary / list kinds: sequential reader
     if (cfg_.filter.active && cfg_.filter.use_index) {
       // get_byte_range_for_file (indexed_bgzf_file.rs:52-112): tabix names -> id -> index.query -> chunks
       const BinningIndex idx = read_tabix(path + ".tbi");
@@ -560,7 +625,11 @@ class VCFBatchReader {
     for (const auto& sp : info_specs) {
       const std::string name = "info." + sp.name;
       if (sp.kind == 'f') kids.push_back(new_field("f", name.c_str(), true));
+      else if (sp.kind == 'i') kids.push_back(new_field("i", name.c_str(), true));
       else if (sp.kind == 'b') kids.push_back(new_field("b", name.c_str(), true));
+      else if (sp.kind == 'F') kids.push_back(new_list_field("f", name.c_str()));
+      else if (sp.kind == 'I') kids.push_back(new_list_field("i", name.c_str()));
+      else if (sp.kind == 'S') kids.push_back(new_list_field("i", name.c_str(), new_field("u", "", false)));
       else kids.push_back(new_field("i", name.c_str(), true, new_field("u", "", false)));
     }
     make_schema(out, "+s", "", false, kids);
@@ -616,6 +685,8 @@ class VCFBatchReader {
     for (size_t k = 0; k < info_specs.size(); ++k) {
       if (info_specs[k].kind == 'f') {
         kids.push_back(slice(cur_->b->info_f32(k), 4, nullptr));
+      } else if (info_specs[k].kind == 'i') {
+        kids.push_back(slice(cur_->b->info_i32(k), 4, nullptr));
       } else {  // Flag (string kinds never reach the parallel reader)
         struct ArrowArray* a = static_cast<struct ArrowArray*>(malloc(sizeof *a));
         const auto& pb = cur_->b->info_i32(k);

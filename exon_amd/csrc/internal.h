@@ -53,6 +53,11 @@ void exon_hip_release_ctx_caches(exon_hip_ctx* ctx);
 void* exon_pool_alloc(exon_hip_ctx* ctx, size_t bytes);
 void exon_pool_free(exon_hip_ctx* ctx, void* p);
 
+// internal launch flags next to the public EXON_HIP_LAUNCH_* bits: K4's compared column / AVG argument is Int32
+// (exon_hip_plan_desc.x_type / y_type)
+#define EXON_LAUNCH_X_INT32 0x100
+#define EXON_LAUNCH_Y_INT32 0x200
+
 // capi.cpp: the operator launches with EXON_HIP_LAUNCH_* flags (the extern "C" operators are the ACCUMULATE forms)
 int exon_op_region_count(exon_hip_ctx* ctx, void* stream, const exon_hip_column* chrom_id, const exon_hip_column* pos,
                          int64_t n, int32_t region_chrom_id, int64_t start, int64_t end, int64_t* d_count, int flags);

@@ -17,6 +17,8 @@ struct LaunchCfg {
   int compute_units = 256;
   int blocks_per_cu = 8;  // main-kernel grid = compute_units * blocks_per_cu (persistent, grid-stride)
   bool overwrite = false; // state := result of this launch (EXON_HIP_LAUNCH_OVERWRITE) instead of state += result
+  bool x_is_int = false;  // K4: the compared column holds Int32 values (exon_hip_plan_desc.x_type), not Float32
+  bool y_is_int = false;  // K4: AVG's argument holds Int32 values (exon_hip_plan_desc.y_type)
 };
 
 size_t k2_partial_words(const LaunchCfg&);

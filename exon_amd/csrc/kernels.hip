@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 
 namespace exon {
 
@@ -768,18 +769,42 @@ hipError_t launch_flag_mapq_group_count(hipStream_t s, const LaunchCfg& cfg, con
 //   COUNT(*) / COUNT(y) in two u64 registers of 8 x 8-bit fields (a row adds 1 << 8g), spilled to
 //   per-group u32 registers before a field can overflow; sums in G f64 registers.
 // ------------------------------------------------------------------------------------------------
-//   More than 8 groups (OVF): ids 0..7 stay in registers (dictionary ids are handed out in order of first
-//   appearance, so the frequent keys are the early ones); ids 8..NG-1 go to a per-workgroup LDS table through LDS
-//   atomics (ds_add_f64 / ds_add_u32), taken only by the lanes that need it.  Counts stay exact; the f64 sums of the
-//   overflow groups depend on the LDS atomic order (~1e-16 relative run to run).
+//   More than 8 groups (OVF), three tiers by dictionary id -- ids are handed out in order of first appearance, so the
+//   frequent keys of a skewed column are the early ones:
+//     ids 0..G-1          registers, as above (G = 4 in this variant);
+//     ids G..NL-1         a per-workgroup LDS table (NL <= G + 4096) of 16-byte entries {f64 sum, u32 count(y), u32 count(*)}:
+//                         ds_add_f64 + 2 x ds_add_u32 on ONE address register.  The block is entered only when some lane
+//                         of the wave needs it (one scalar branch per 4 rows per lane) and is branch-free inside: a row
+//                         that does not belong there adds to its lane's dummy entry (K3's finding: an exec-masked `if`
+//                         per row costs a basic block each and serialises the adds behind the masks), a passing row
+//                         whose y is NULL adds 0 / +0.0 to its group's count(y) / sum;
+//     ids NL..NG-1        global atomics straight into the caller's state (only when NG > NL: high-cardinality keys), again
+//                         behind a wave-uniform test, so a column whose hot keys are early hardly ever gets there.
+//   Counts stay exact; the f64 sums of tiers 2 / 3 depend on the atomic order (~1e-16 relative run to run).
+//   The variant is bound by vector-instruction issue, not by LDS conflicts or HBM (profiles/r3_groupby.md: the same time
+//   for 64 and 4096 keys, uniform and skewed): a CU issues one wave64 vector instruction per clock, so every instruction
+//   per row is 0.025 ms per 1e9 rows.  Hence 4 register groups instead of 8 (4 instead of 8 conditional f64 adds, 32-bit
+//   packed counters), the predicate evaluated once per row for all tiers, one LDS address per row.
+struct K4Tail {                 // tier 3 (nullptr / unused when NG == NL)
+  unsigned long long* counts;   // the caller's [cnn[NG]] [crow[NG]]
+  double* sums;                 // the caller's [sum[NG]]
+};
+struct K4Entry {  // tier-2 table entry
+  double sum;
+  unsigned cnn, crow;
+};
 template <int G, typename S, bool OVF>
 __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
     const float* __restrict__ x, const uint8_t* __restrict__ xvalid, const float* __restrict__ y,
     const uint8_t* __restrict__ yvalid, const int32_t* __restrict__ gid, int64_t n, int32_t klo, int32_t khi,
-    int32_t negate, int32_t NG, unsigned long long* __restrict__ partials, int* __restrict__ status,
-    const uint8_t* __restrict__ ones, const FoldArgs fa) {
+    int32_t negate, int32_t keymask, int32_t yint, int32_t NG, int32_t NL, unsigned long long* __restrict__ partials,
+    int* __restrict__ status, const uint8_t* __restrict__ ones, const FoldArgs fa, const K4Tail tail) {
   constexpr int J = S::J, THREADS = S::THREADS, WAVES = ShapeOf<S>::WAVES, WT = ShapeOf<S>::WAVE_TILE,
                 TILE = ShapeOf<S>::TILE;
+  // packed 8-bit row counters: 4 fields in a u32 when G <= 4, 8 fields in a u64 otherwise
+  constexpr bool NARROW = G <= 4;
+  using Packed = typename std::conditional<NARROW, unsigned, unsigned long long>::type;
+  constexpr unsigned FMASK = NARROW ? 3u : 7u;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double sum[G];
   unsigned cnn[G], crow[G];
@@ -789,48 +814,66 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
     cnn[k] = 0;
     crow[k] = 0;
   }
-  unsigned long long prow = 0, pnn = 0;  // packed 8-bit counters, field g
+  Packed prow = 0, pnn = 0;  // field g
   unsigned gmax = 0;
-  // overflow table (OVF only): [sum f64 | cnn u32 | crow u32] x (NG - 8)
-  extern __shared__ double k4_ovf[];
-  const int NO = OVF ? NG - 8 : 0;
-  double* ovf_sum = k4_ovf;
-  unsigned* ovf_cnn = reinterpret_cast<unsigned*>(k4_ovf + NO);
-  unsigned* ovf_crow = ovf_cnn + NO;
+  // tier-2 table (OVF only): NO entries + 64 per-lane dummy entries
+  extern __shared__ K4Entry k4_ovf[];
+  const int NO = OVF ? NL - G : 0, NOD = NO + 64;
   if (OVF) {
-    for (int i = threadIdx.x; i < NO; i += THREADS) {
-      ovf_sum[i] = 0.0;
-      ovf_cnn[i] = 0;
-      ovf_crow[i] = 0;
+    for (int i = threadIdx.x; i < NOD; i += THREADS) {
+      k4_ovf[i].sum = 0.0;
+      k4_ovf[i].cnn = 0;
+      k4_ovf[i].crow = 0;
     }
     __syncthreads();
   }
+  const unsigned dummy = (unsigned)(NO + lane);
 
-  auto row = [&](float xf, float yf, int32_t g, unsigned xv, unsigned yv) {
-    const int32_t kx = f32_key(xf);
+  // keymask = 0x7FFFFFFF: x is Float32, compared through its totalOrder key; keymask = 0: x is Int32 (INFO Type=Integer,
+  // schema_builder.rs:197-205), the bit pattern IS the key -- integer predicates never pass through f32
+  auto passes = [&](float xf, unsigned xv) -> unsigned {
+    const int32_t bx = __float_as_int(xf);
+    const int32_t kx = bx ^ ((bx >> 31) & keymask);
     const unsigned inr = unsigned(kx >= klo) & unsigned(kx <= khi);
-    unsigned pass = xv & (inr ^ (unsigned)negate);
+    return xv & (inr ^ (unsigned)negate);
+  };
+  // AVG's argument widened to f64 (DataFusion casts Float32 AND Int32 arguments of avg to Float64): yint != 0 when the
+  // column holds Int32 values (an INFO field of Type=Integer)
+  auto ydbl = [&](float yf) -> double { return yint ? (double)__float_as_int(yf) : (double)yf; };
+  // tier 1: register groups (every row); `pass` = the row's predicate
+  auto row = [&](unsigned pass, float yf, int32_t g, unsigned yv) {
     unsigned yq = pass & yv;
     gmax = max(gmax, (unsigned)g);  // ids are validated over ALL rows (cheaper than a per-row flag)
     if (OVF) {
-      if (pass && (unsigned)g >= 8u && (unsigned)g < (unsigned)NG) {
-        atomicAdd(&ovf_crow[g - 8], 1u);
-        if (yq) {
-          atomicAdd(&ovf_cnn[g - 8], 1u);
-          atomicAdd(&ovf_sum[g - 8], (double)yf);
-        }
-      }
-      const unsigned in_regs = unsigned((unsigned)g < 8u);
+      const unsigned in_regs = unsigned((unsigned)g < (unsigned)G);
       pass &= in_regs;
       yq &= in_regs;
     }
-    const unsigned sh = ((unsigned)g & 7u) * 8u;
-    prow += (unsigned long long)pass << sh;
-    pnn += (unsigned long long)yq << sh;
+    const unsigned sh = ((unsigned)g & FMASK) * 8u;
+    prow += (Packed)pass << sh;
+    pnn += (Packed)yq << sh;
     const int32_t gq = yq ? g : -1;
-    const double yd = (double)yf;
+    const double yd = ydbl(yf);
 #pragma unroll
     for (int k = 0; k < G; ++k) sum[k] += (gq == k) ? yd : 0.0;
+  };
+  // tier 2: branch-free LDS adds (called for all 64 lanes once any lane of the wave has a row with id >= G)
+  auto row_lds = [&](unsigned pass, float yf, int32_t g, unsigned yv) {
+    const unsigned in2 = pass & unsigned((unsigned)g - (unsigned)G < (unsigned)NO);
+    K4Entry* e = &k4_ovf[in2 ? (unsigned)g - (unsigned)G : dummy];
+    atomicAdd(&e->crow, 1u);
+    atomicAdd(&e->cnn, yv);
+    atomicAdd(&e->sum, yv ? ydbl(yf) : 0.0);
+  };
+  // tier 3: global atomics (rare by construction; divergent on purpose)
+  auto row_tail = [&](unsigned pass, float yf, int32_t g, unsigned yv) {
+    if (pass && (unsigned)g >= (unsigned)NL && (unsigned)g < (unsigned)NG) {
+      atomicAdd(&tail.counts[NG + g], 1ull);
+      if (yv) {
+        atomicAdd(&tail.counts[g], 1ull);
+        atomicAdd(&tail.sums[g], ydbl(yf));
+      }
+    }
   };
   auto spill = [&]() {
 #pragma unroll
@@ -860,10 +903,28 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
     }
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      row(xs[j].x, ys[j].x, gs[j].x, xm[j] >> 0 & 1, ym[j] >> 0 & 1);
-      row(xs[j].y, ys[j].y, gs[j].y, xm[j] >> 1 & 1, ym[j] >> 1 & 1);
-      row(xs[j].z, ys[j].z, gs[j].z, xm[j] >> 2 & 1, ym[j] >> 2 & 1);
-      row(xs[j].w, ys[j].w, gs[j].w, xm[j] >> 3 & 1, ym[j] >> 3 & 1);
+      const unsigned p0 = passes(xs[j].x, xm[j] >> 0 & 1), p1 = passes(xs[j].y, xm[j] >> 1 & 1),
+                     p2 = passes(xs[j].z, xm[j] >> 2 & 1), p3 = passes(xs[j].w, xm[j] >> 3 & 1);
+      row(p0, ys[j].x, gs[j].x, ym[j] >> 0 & 1);
+      row(p1, ys[j].y, gs[j].y, ym[j] >> 1 & 1);
+      row(p2, ys[j].z, gs[j].z, ym[j] >> 2 & 1);
+      row(p3, ys[j].w, gs[j].w, ym[j] >> 3 & 1);
+      if (OVF) {
+        // largest id among this lane's 4 rows (unsigned: a negative id is "huge" and is reported through gmax)
+        const unsigned gm = max(max((unsigned)gs[j].x, (unsigned)gs[j].y), max((unsigned)gs[j].z, (unsigned)gs[j].w));
+        if (__any(gm >= (unsigned)G)) {
+          row_lds(p0, ys[j].x, gs[j].x, ym[j] >> 0 & 1);
+          row_lds(p1, ys[j].y, gs[j].y, ym[j] >> 1 & 1);
+          row_lds(p2, ys[j].z, gs[j].z, ym[j] >> 2 & 1);
+          row_lds(p3, ys[j].w, gs[j].w, ym[j] >> 3 & 1);
+          if (NG > NL && __any(gm >= (unsigned)NL)) {
+            row_tail(p0, ys[j].x, gs[j].x, ym[j] >> 0 & 1);
+            row_tail(p1, ys[j].y, gs[j].y, ym[j] >> 1 & 1);
+            row_tail(p2, ys[j].z, gs[j].z, ym[j] >> 2 & 1);
+            row_tail(p3, ys[j].w, gs[j].w, ym[j] >> 3 & 1);
+          }
+        }
+      }
     }
     since += 4 * J;
     if (since > 255 - 4 * J) {
@@ -875,7 +936,24 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
   since = 0;
   for (int64_t r = ntiles * TILE + (int64_t)blockIdx.x * THREADS + threadIdx.x; r < n;
        r += (int64_t)gridDim.x * THREADS) {
-    row(x[r], y[r], gid[r], valid1(xvalid, r), valid1(yvalid, r));
+    const float yf = y[r];
+    const int32_t g = gid[r];
+    const unsigned yv = valid1(yvalid, r), pass = passes(x[r], valid1(xvalid, r));
+    row(pass, yf, g, yv);
+    if (OVF && (unsigned)g >= (unsigned)G) {  // the tail loop is short: plain divergent code
+      if ((unsigned)g < (unsigned)NL) {
+        if (pass) {
+          K4Entry* e = &k4_ovf[g - G];
+          atomicAdd(&e->crow, 1u);
+          if (yv) {
+            atomicAdd(&e->cnn, 1u);
+            atomicAdd(&e->sum, ydbl(yf));
+          }
+        }
+      } else if (NG > NL) {
+        row_tail(pass, yf, g, yv);
+      }
+    }
     if (++since == 255) {
       spill();
       since = 0;
@@ -885,8 +963,8 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
 
   if (gmax >= (unsigned)(OVF ? NG : G)) atomicOr(status, 4);
 
-  // per-workgroup record: [cnn[NG]] [crow[NG]] [sum[NG]]  (fixed-order reductions for the register groups)
-  const int RG = OVF ? NG : G;  // groups per record
+  // per-workgroup record: [cnn[RG]] [crow[RG]] [sum[RG]]  (fixed-order reductions for the register groups)
+  const int RG = OVF ? NL : G;  // groups per record
   __shared__ unsigned long long red[WAVES][3 * G];
 #pragma unroll
   for (int k = 0; k < G; ++k) {
@@ -919,24 +997,27 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
   if (OVF) {
     for (int i = threadIdx.x; i < NO; i += THREADS) {
       unsigned long long* rec = partials + (size_t)blockIdx.x * (3 * RG);
-      st_agent(&rec[8 + i], ovf_cnn[i]);
-      st_agent(&rec[RG + 8 + i], ovf_crow[i]);
-      st_agent(&rec[2 * RG + 8 + i], (unsigned long long)__double_as_longlong(ovf_sum[i]));
+      st_agent(&rec[G + i], k4_ovf[i].cnn);
+      st_agent(&rec[RG + G + i], k4_ovf[i].crow);
+      st_agent(&rec[2 * RG + G + i], (unsigned long long)__double_as_longlong(k4_ovf[i].sum));
     }
   }
   if (fa.ticket) fold_if_last<THREADS>(fa, partials);
 }
 
-size_t k4_partial_words(const LaunchCfg& cfg, int n_groups) {
-  if (n_groups > 4096) return 16;  // the global-atomic path writes the caller's state directly
-  return (size_t)max_grid(cfg) * 3 * (size_t)n_groups;
-}
+constexpr int K4_OVF_REGS = 4;                   // register groups of the > 8-group variant
+constexpr int K4_LDS_GROUPS = K4_OVF_REGS + 4096;  // ids handled by registers + the LDS table
+static int k4_nl(int n_groups) { return n_groups < K4_LDS_GROUPS ? n_groups : K4_LDS_GROUPS; }
+
+size_t k4_partial_words(const LaunchCfg& cfg, int n_groups) { return (size_t)max_grid(cfg) * 3 * (size_t)k4_nl(n_groups); }
 
 template <int G, typename S, bool OVF>
 static hipError_t k4_launch(hipStream_t s, const LaunchCfg& cfg, int* grid_out, const Workspace& ws, const float* x,
                             const uint8_t* xv, const float* y, const uint8_t* yv, const int32_t* gid, int64_t n,
-                            int32_t klo, int32_t khi, int32_t negate, int32_t n_groups, const FoldArgs& fa) {
-  const size_t lds = OVF ? (size_t)(n_groups - 8) * 16 : 0;
+                            int32_t klo, int32_t khi, int32_t negate, int32_t keymask, int32_t yint, int32_t n_groups,
+                            const FoldArgs& fa, const K4Tail& tail) {
+  const int nl = k4_nl(n_groups);
+  const size_t lds = OVF ? (size_t)(nl - G + 64) * sizeof(K4Entry) : 0;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k4_cmp_avg_by_group_main<G, S, OVF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -945,7 +1026,8 @@ static hipError_t k4_launch(hipStream_t s, const LaunchCfg& cfg, int* grid_out, 
   const int grid = grid_for<S>(cfg, n, resident_blocks(k4_cmp_avg_by_group_main<G, S, OVF>, S::THREADS, lds));
   *grid_out = grid;
   hipLaunchKernelGGL((k4_cmp_avg_by_group_main<G, S, OVF>), dim3(grid), dim3(S::THREADS), lds, s, x, xv, y, yv, gid, n,
-                     klo, khi, negate, n_groups, ws.partials, ws.status, reinterpret_cast<const uint8_t*>(ws.status + 8), fa);
+                     klo, khi, negate, keymask, yint, n_groups, nl, ws.partials, ws.status, reinterpret_cast<const uint8_t*>(ws.status + 8), fa,
+                     tail);
   return hipGetLastError();
 }
 
@@ -961,22 +1043,27 @@ static inline int64_t h_f64_key(double d) {
   memcpy(&b, &d, 8);
   return b ^ ((b >> 63) & 0x7FFFFFFFFFFFFFFFLL);
 }
-// smallest f32 key k in [INT32_MIN, INT32_MAX + 1] whose widening compares >= t (or > t) in totalOrder
-static int64_t first_key_not_less(int64_t t, bool strict_greater) {
+// smallest key k in [INT32_MIN, INT32_MAX + 1] whose column value compares >= t (or > t) with the literal.
+//   Float32 column: the value of key k is the f32 with that totalOrder key, widened to f64, compared in totalOrder;
+//   Int32 column (x_is_int): the value IS k.  DataFusion compares Int32 with an Int64 literal as integers and with a
+//   Float64 literal after casting the column to Float64; every int32 is exact in f64, so one f64 comparison covers both
+//   (an integer literal beyond 2^53 is beyond int32 anyway: the range saturates the same way).  A NaN or -0.0 literal
+//   behaves as in arrow-rs' totalOrder float compare: NaN above every number, (f64)0 = +0.0 above -0.0.
+static int64_t first_key_not_less(int64_t t, bool strict_greater, bool x_is_int) {
   int64_t lo = INT32_MIN, hi = (int64_t)INT32_MAX + 1;
   while (lo < hi) {
     const int64_t mid = lo + (hi - lo) / 2;
-    const int64_t km = h_f64_key((double)h_key_f32((int32_t)mid));
+    const int64_t km = h_f64_key(x_is_int ? (double)(int32_t)mid : (double)h_key_f32((int32_t)mid));
     const bool ok = strict_greater ? (km > t) : (km >= t);
     if (ok) hi = mid;
     else lo = mid + 1;
   }
   return lo;
 }
-bool cmp_to_key_range(double thr, int cmp_op, int32_t* klo, int32_t* khi, int32_t* negate) {
+bool cmp_to_key_range(double thr, int cmp_op, bool x_is_int, int32_t* klo, int32_t* khi, int32_t* negate) {
   const int64_t t = h_f64_key(thr);
-  const int64_t ge = first_key_not_less(t, false);  // first key with widen >= thr
-  const int64_t gt = first_key_not_less(t, true);   // first key with widen >  thr
+  const int64_t ge = first_key_not_less(t, false, x_is_int);  // first key with value >= thr
+  const int64_t gt = first_key_not_less(t, true, x_is_int);   // first key with value >  thr
   int64_t lo, hi;
   *negate = 0;
   switch (cmp_op) {
@@ -998,17 +1085,14 @@ bool cmp_to_key_range(double thr, int cmp_op, int32_t* klo, int32_t* khi, int32_
   return true;
 }
 
-// More groups than the LDS overflow table holds (EXON_HIP_MAX_GROUPS < G <= EXON_HIP_MAX_GROUPS_GLOBAL: a GROUP BY over a
-// high-cardinality dictionary, e.g. a string INFO field): the caller's state arrays ARE the table -- dictionary ids are dense,
-// so there is nothing to hash -- and every passing row adds to them with global atomics (u64 counters, global_atomic_add_f64
-// sums).  Keys spread over many addresses, so the atomics do not serialise the way a handful of hot groups would; counts
-// stay exact, the f64 sums depend on the atomic order (~1e-16 relative run to run, inside the 1e-6 budget).  Several times
-// slower than the register / LDS paths and taken only above 4096 groups.
+// Round 2's path for more groups than the LDS table holds: ONE global atomic triple per passing row, whatever its id.
+// Kept behind EXON_HIP_K4_GLOBAL_ONLY=1 as the A/B baseline of the tiered kernel above (profiles/r3_groupby.md).
 __global__ __launch_bounds__(256) void k4_cmp_avg_by_group_global(const float* __restrict__ x, const uint8_t* __restrict__ xvalid,
                                                                   const float* __restrict__ y, const uint8_t* __restrict__ yvalid,
                                                                   const int32_t* __restrict__ gid, int64_t n, int32_t klo, int32_t khi,
-                                                                  int32_t negate, int32_t NG, unsigned long long* __restrict__ counts,
-                                                                  double* __restrict__ sums, int* __restrict__ status) {
+                                                                  int32_t negate, int32_t keymask, int32_t yint, int32_t NG,
+                                                                  unsigned long long* __restrict__ counts, double* __restrict__ sums,
+                                                                  int* __restrict__ status) {
   bool bad = false;
   for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
     const unsigned g = (unsigned)gid[r];
@@ -1016,16 +1100,38 @@ __global__ __launch_bounds__(256) void k4_cmp_avg_by_group_global(const float* _
       bad = true;
       continue;
     }
-    const int32_t kx = f32_key(x[r]);
+    const int32_t bx = __float_as_int(x[r]);
+    const int32_t kx = bx ^ ((bx >> 31) & keymask);
     const unsigned inr = unsigned(kx >= klo) & unsigned(kx <= khi);
     if (!(valid1(xvalid, r) && (inr ^ (unsigned)negate))) continue;
     atomicAdd(&counts[NG + g], 1ull);
     if (valid1(yvalid, r)) {
       atomicAdd(&counts[g], 1ull);
-      atomicAdd(&sums[g], (double)y[r]);
+      atomicAdd(&sums[g], yint ? (double)__float_as_int(y[r]) : (double)y[r]);
     }
   }
   if (bad) atomicOr(&status[0], 4);
+}
+
+// records [blocks][3 x RG] (kinds cnn, crow, sum over the first RG ids) ADDED into a state of NG > RG groups
+// ([cnn[NG]] [crow[NG]] | [sum[NG]]): the fold of the tiered kernel when tier 3 exists.  One thread per (kind, id),
+// blocks summed in order.  The state was zeroed (overwrite) or holds earlier launches; tier 3 has added to it already.
+__global__ __launch_bounds__(256) void k4_finalize_head(const unsigned long long* __restrict__ partials, int nblocks, int RG, int NG,
+                                                        unsigned long long* __restrict__ counts, double* __restrict__ sums) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= 3 * RG) return;
+  const int kind = v / RG, g = v - kind * RG;
+  const unsigned long long* p = partials + v;
+  const size_t stride = (size_t)3 * RG;
+  if (kind < 2) {
+    unsigned long long t = 0;
+    for (int b = 0; b < nblocks; ++b) t += p[(size_t)b * stride];
+    if (t) counts[(size_t)kind * NG + g] += t;
+  } else {
+    double t = 0.0;
+    for (int b = 0; b < nblocks; ++b) t += __longlong_as_double((long long)p[(size_t)b * stride]);
+    sums[g] += t;
+  }
 }
 
 hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const float* x,
@@ -1034,36 +1140,39 @@ hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Wo
                                    double* d_sums) {
   if (n <= 0) return hipSuccess;
   if (n_groups < 1) return hipErrorInvalidValue;
-  if (n_groups > 4096) {
-    int32_t klo, khi, negate;
-    if (!cmp_to_key_range(thr, cmp_op, &klo, &khi, &negate)) return hipErrorInvalidValue;
-    if (cfg.overwrite) {  // this path adds straight into the caller's arrays
-      hipError_t e0 = hipMemsetAsync(d_counts, 0, (size_t)n_groups * 16, s);
-      if (e0 == hipSuccess) e0 = hipMemsetAsync(d_sums, 0, (size_t)n_groups * 8, s);
-      if (e0 != hipSuccess) return e0;
-    }
+  int32_t klo, khi, negate;
+  if (!cmp_to_key_range(thr, cmp_op, cfg.x_is_int, &klo, &khi, &negate)) return hipErrorInvalidValue;
+  const int32_t keymask = cfg.x_is_int ? 0 : 0x7FFFFFFF, yint = cfg.y_is_int ? 1 : 0;
+  const int nl = k4_nl(n_groups);
+  const bool has_tail = n_groups > nl;
+  static const bool global_only = [] {
+    const char* v = getenv("EXON_HIP_K4_GLOBAL_ONLY");
+    return v && v[0] == '1';
+  }();
+  if (has_tail && cfg.overwrite) {  // tier 3 (and k4_finalize_head) ADD to the caller's arrays
+    hipError_t e0 = hipMemsetAsync(d_counts, 0, (size_t)n_groups * 16, s);
+    if (e0 == hipSuccess) e0 = hipMemsetAsync(d_sums, 0, (size_t)n_groups * 8, s);
+    if (e0 != hipSuccess) return e0;
+  }
+  if (has_tail && global_only) {
     const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)cfg.compute_units * 32);
-    hipLaunchKernelGGL(k4_cmp_avg_by_group_global, dim3(grid), dim3(256), 0, s, x, x_valid, y, y_valid, gid, n, klo, khi, negate, n_groups,
+    hipLaunchKernelGGL(k4_cmp_avg_by_group_global, dim3(grid), dim3(256), 0, s, x, x_valid, y, y_valid, gid, n, klo, khi, negate, keymask, yint, n_groups,
                        reinterpret_cast<unsigned long long*>(d_counts), d_sums, ws.status);
     return hipGetLastError();
   }
-  int32_t klo, khi, negate;
-  if (!cmp_to_key_range(thr, cmp_op, &klo, &khi, &negate)) return hipErrorInvalidValue;
   // K4 keeps the 16384-row tile whenever every CU gets one: measured on MI355X at 1e7 rows J = 4 27.8 us, J = 2 31.5 us
   // (its per-tile bookkeeping -- counter spills, 15-value reductions -- outweighs the better tile balance that pays for K2)
-  int shape = pick_shape(cfg, n);
-  if (shape == SHAPE_BIG_J2 && getenv("EXON_HIP_SHAPE") == nullptr)
-    shape = n / ShapeOf<ShapeBig>::TILE >= (int64_t)cfg.compute_units ? SHAPE_BIG_J4 : SHAPE_SMALL;
-  const bool big = shape != SHAPE_SMALL;
+  const bool big = n / ShapeOf<ShapeBig>::TILE >= (int64_t)cfg.compute_units && pick_shape(cfg, n) != SHAPE_SMALL;
   int grid = 1;
   hipError_t e;
-  const FoldArgs fa = fold_args(cfg, ws, 3 * n_groups, 2 * n_groups, d_counts, d_sums);
+  const FoldArgs fa = has_tail ? FoldArgs{nullptr, nullptr, nullptr, 0, 0, 0}
+                               : fold_args(cfg, ws, 3 * n_groups, 2 * n_groups, d_counts, d_sums);
+  const K4Tail tail{reinterpret_cast<unsigned long long*>(d_counts), d_sums};
   switch (n_groups) {
-#define EXON_K4_CASE(GG)                                                                                             \
-  case GG:                                                                                                           \
-    e = shape == SHAPE_BIG_J4 ? k4_launch<GG, ShapeBig, false>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, GG, fa)   \
-        : shape == SHAPE_BIG_J2 ? k4_launch<GG, ShapeBigJ2, false>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, GG, fa) \
-            : k4_launch<GG, ShapeSmall, false>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, GG, fa); \
+#define EXON_K4_CASE(GG)                                                                                                        \
+  case GG:                                                                                                                      \
+    e = big ? k4_launch<GG, ShapeBig, false>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, keymask, yint, GG, fa, tail)   \
+            : k4_launch<GG, ShapeSmall, false>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, keymask, yint, GG, fa, tail); \
     break;
     EXON_K4_CASE(1)
     EXON_K4_CASE(2)
@@ -1074,12 +1183,18 @@ hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Wo
     EXON_K4_CASE(7)
     EXON_K4_CASE(8)
 #undef EXON_K4_CASE
-    default:  // > 8 groups: 8 in registers + LDS overflow table
-      e = big ? k4_launch<8, ShapeBigJ2, true>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, n_groups, fa)
-              : k4_launch<8, ShapeSmall, true>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, n_groups, fa);
+    default:  // > 8 groups: 4 in registers + LDS table (+ global atomics beyond K4_LDS_GROUPS ids)
+      // (16384-row tiles fit too -- 124 VGPRs -- and measured the same: profiles/r3_groupby.md)
+      e = big ? k4_launch<K4_OVF_REGS, ShapeBigJ2, true>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, keymask, yint, n_groups, fa, tail)
+              : k4_launch<K4_OVF_REGS, ShapeSmall, true>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, keymask, yint, n_groups, fa, tail);
       break;
   }
   if (e != hipSuccess) return e;
+  if (has_tail) {
+    hipLaunchKernelGGL(k4_finalize_head, dim3((3 * nl + 255) / 256), dim3(256), 0, s, ws.partials, grid, nl, n_groups,
+                       reinterpret_cast<unsigned long long*>(d_counts), d_sums);
+    return hipGetLastError();
+  }
   // per-workgroup records are [cnn[G]] [crow[G]] [sum[G]] = the state layout [counts[2G]] [sums[G]]
   return run_finalize(s, cfg, ws, grid, 3 * n_groups, 2 * n_groups, d_counts, d_sums);
 }

@@ -56,6 +56,9 @@ int exon_hip_stream_push_raw(exon_hip_stream* st, const exon::RawBatch& rb);  //
 int exon_hip_stream_launch_scan_columns(exon_hip_stream* st, const exon_hip_column* scan_cols, int n_scan_cols, int64_t n,
                                         const uint8_t* row_mask);
 int exon_hip_stream_plan_first_column(exon_hip_stream* st);
+int exon_hip_stream_plan_kind(exon_hip_stream* st);
+int exon_hip_stream_plan_column(exon_hip_stream* st, int arg);
+void exon_hip_stream_set_value_types(exon_hip_stream* st, int x_type, int y_type);
 int exon_hip_stream_launch_views(exon_hip_stream* st, const uint8_t* d_text, const exon_hip_fastq_views& v);
 void* exon_hip_stream_hip_stream(exon_hip_stream* st);
 exon_hip_ctx* exon_hip_stream_ctx(exon_hip_stream* st);
@@ -78,9 +81,9 @@ static exon::Dictionary* dict_of(exon_hip_scan* s, int col) {
   if (s->format == EXON_HIP_FORMAT_VCF && col == 3) return s->parser ? &s->gpu_filter_dict : &s->vcf->filter_dict;
   if ((s->format == EXON_HIP_FORMAT_BAM || s->format == EXON_HIP_FORMAT_SAM || s->format == EXON_HIP_FORMAT_CRAM) && col == 2) return &s->bam_dict_view;
   // string INFO fields (scan columns 4 ..) are dictionary-encoded by the host readers
-  if (s->format == EXON_HIP_FORMAT_VCF && col >= 4 && (size_t)(col - 4) < s->vcf->info_specs.size() && s->vcf->info_specs[(size_t)(col - 4)].kind == 's')
+  if (s->format == EXON_HIP_FORMAT_VCF && col >= 4 && (size_t)(col - 4) < s->vcf->info_specs.size() && (s->vcf->info_specs[(size_t)(col - 4)].kind == 's' || s->vcf->info_specs[(size_t)(col - 4)].kind == 'S'))
     return &s->vcf->info_dicts[(size_t)(col - 4)];
-  if (s->format == EXON_HIP_FORMAT_BCF && col >= 4 && (size_t)(col - 4) < s->bcf->info_specs.size() && s->bcf->info_specs[(size_t)(col - 4)].kind == 's')
+  if (s->format == EXON_HIP_FORMAT_BCF && col >= 4 && (size_t)(col - 4) < s->bcf->info_specs.size() && (s->bcf->info_specs[(size_t)(col - 4)].kind == 's' || s->bcf->info_specs[(size_t)(col - 4)].kind == 'S'))
     return &s->bcf->info_dicts[(size_t)(col - 4)];
   return nullptr;
 }
@@ -123,7 +126,7 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         s->vcf.reset(new exon::VCFBatchReader(path, c, cfg));
         if (s->gpu_parse) {
           bool string_info = false;
-          for (const auto& sp : s->vcf->info_specs) string_info |= sp.kind == 's';
+          for (const auto& sp : s->vcf->info_specs) string_info |= !exon::info_kind_on_device(sp.kind);
           if (string_info) {  // string INFO fields are dictionary-encoded by the host reader only: decode there
             s->gpu_parse = false;
             cfg.defer_decode = false;
@@ -155,7 +158,7 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         s->bcf.reset(new exon::BCFBatchReader(path, cfg));
         if (s->gpu_parse) {
           bool string_info = false;
-          for (const auto& sp : s->bcf->info_specs) string_info |= sp.kind == 's';
+          for (const auto& sp : s->bcf->info_specs) string_info |= !exon::info_kind_on_device(sp.kind);
           if (string_info) {
             s->gpu_parse = false;
             cfg.threads = 0;
@@ -1232,6 +1235,15 @@ int exon_hip_scan_decoded_on_gpu(exon_hip_scan* scan, int32_t* decoded, int32_t*
 int exon_hip_stream_consume_scan(exon_hip_stream* st, exon_hip_scan* scan, int64_t* rows) {
   if (!st || !scan) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_stream_consume_scan: NULL argument");
   int64_t n = 0;
+  // K4 over a VCF / BCF scan: the compared column and AVG's argument may be typed INFO fields (scan columns 4 ..), whose
+  // type the FILE's header decides: Type=Integer -> Int32 values, compared / averaged as integers (schema_builder.rs:197-205)
+  if (exon_hip_stream_plan_kind(st) == EXON_HIP_PLAN_CMP_AVG_BY_GROUP && (scan->vcf || scan->bcf)) {
+    const std::vector<exon::InfoSpec>& specs = scan->vcf ? scan->vcf->info_specs : scan->bcf->info_specs;
+    auto type_of = [&](int col) {
+      return col >= 4 && (size_t)(col - 4) < specs.size() && specs[(size_t)(col - 4)].kind == 'i' ? EXON_HIP_X_INT32 : EXON_HIP_X_FLOAT32;
+    };
+    exon_hip_stream_set_value_types(st, type_of(exon_hip_stream_plan_column(st, 0)), type_of(exon_hip_stream_plan_column(st, 1)));
+  }
   if (scan->gpu_parse && (scan->vcf || scan->fastq || scan->bam || scan->bcf || scan->sam)) {
     // speculative GPU decode; when the device cannot decide something, restore the state and fall back to the host decoder
     exon_hip_ctx* ctx = exon_hip_stream_ctx(st);

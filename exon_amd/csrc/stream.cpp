@@ -76,6 +76,7 @@ struct exon_hip_stream {
   int64_t rows_pushed = 0;
   double t_copy = 0, t_wait = 0, t_enqueue = 0;  // EXON_HIP_STAGE_TRACE: staging copies / waits for a free slot / H2D + launch calls
   bool overwrite_next = false;  // exon_hip_stream_reset: the next launch DEFINES the state (no zeroing kernel)
+  int x_type = -1, y_type = -1; // K4 fed by a scan: the INFO fields' types from the file's header (-1: the plan's)
   uint8_t* d_gather = nullptr;  // [world][state words] receive buffer of the all-gather merge
   size_t gather_bytes = 0;
 };
@@ -241,8 +242,14 @@ static int alloc_slot(exon_hip_stream* st, Slot& s) {
 }
 
 // launch the plan's kernel over device columns (operator argument order) into the packed state [n_i64][n_f64]
-static int run_plan(const exon_hip_plan* p, void* stream, const exon_hip_column* cols, int64_t n, int flags, void* d_state) {
+// x_type / y_type: EXON_HIP_X_* of K4's compared column / AVG argument, or -1 = what the plan says
+static int run_plan(const exon_hip_plan* p, void* stream, const exon_hip_column* cols, int64_t n, int flags, void* d_state, int x_type = -1,
+                    int y_type = -1) {
   const exon_hip_plan_desc& d = p->d;
+  if (x_type < 0) x_type = d.x_type;
+  if (y_type < 0) y_type = d.y_type;
+  if (x_type == EXON_HIP_X_INT32) flags |= EXON_LAUNCH_X_INT32;
+  if (y_type == EXON_HIP_X_INT32) flags |= EXON_LAUNCH_Y_INT32;
   exon_hip_ctx* ctx = p->ctx;
   int64_t* counts = reinterpret_cast<int64_t*>(d_state);
   double* sums = reinterpret_cast<double*>(static_cast<uint8_t*>(d_state) + p->n_i64 * 8);
@@ -267,7 +274,7 @@ static int run_plan(const exon_hip_plan* p, void* stream, const exon_hip_column*
 }
 static int launch_plan(exon_hip_stream* st, const exon_hip_column* cols, int64_t n) {
   const int flags = st->overwrite_next ? EXON_HIP_LAUNCH_OVERWRITE : EXON_HIP_LAUNCH_ACCUMULATE;
-  int rc = run_plan(st->plan, st->stream, cols, n, flags, st->d_state);
+  int rc = run_plan(st->plan, st->stream, cols, n, flags, st->d_state, st->x_type, st->y_type);
   if (!rc) st->overwrite_next = false;
   return rc;
 }
@@ -473,6 +480,8 @@ static int column_child(exon_hip_stream* st, const struct ArrowArray* batch, int
   if (idx >= batch->n_children) return fail(st->ctx, EXON_HIP_EINVAL, "batch has %lld columns, plan needs index %d", (long long)batch->n_children, idx);
   const struct ArrowArray* ch = batch->children[idx];
   if (!ch) return fail(st->ctx, EXON_HIP_EINVAL, "column %d is NULL", idx);
+  if (ch->n_children != 0)  // a List<item> column (a list-valued INFO field): no fused kernel takes one as an operand
+    return fail(st->ctx, EXON_HIP_EUNSUPPORTED, "column %d is a nested (list) column; the plan's operands are scalar columns", idx);
   const int need = st->plan->cols[c].utf8 ? 3 : 2;
   if (ch->n_buffers < need) return fail(st->ctx, EXON_HIP_EINVAL, "column %d has %lld buffers, expected %d", idx, (long long)ch->n_buffers, need);
   *eff_off = batch->offset + ch->offset;
@@ -565,6 +574,12 @@ int exon_hip_stream_launch_scan_columns(exon_hip_stream* st, const exon_hip_colu
   return rc;
 }
 int exon_hip_stream_plan_first_column(exon_hip_stream* st) { return st->plan->d.columns[0]; }
+int exon_hip_stream_plan_kind(exon_hip_stream* st) { return st->plan->d.kind; }
+int exon_hip_stream_plan_column(exon_hip_stream* st, int arg) { return arg >= 0 && arg < 4 ? st->plan->d.columns[arg] : -1; }
+void exon_hip_stream_set_value_types(exon_hip_stream* st, int x_type, int y_type) {
+  st->x_type = x_type;
+  st->y_type = y_type;
+}
 // K5 over views into text resident in HBM (FASTQ slabs): scan column 2 = sequence lines, 3 = quality lines
 int exon_hip_stream_launch_views(exon_hip_stream* st, const uint8_t* d_text, const exon_hip_fastq_views& v) {
   exon_hip_plan* p = st->plan;

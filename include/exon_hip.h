@@ -246,12 +246,18 @@ int exon_hip_regroup_files_by_size(const int64_t* sizes, int32_t n_files, int32_
 #define EXON_HIP_PLAN_OVERLAP_COUNT 6 /* region_chrom_id / region_start / region_end; columns: ref_id, start, end */
 #define EXON_HIP_PLAN_WITHIN_COUNT 7  /* same fields, strict form: start > region_start AND end < region_end */
 
+#define EXON_HIP_X_FLOAT32 0
+#define EXON_HIP_X_INT32 1
 typedef struct exon_hip_plan_desc {
   int32_t kind;          /* EXON_HIP_PLAN_* */
   int32_t n_groups;      /* K3: n_refs; K4: dictionary size; else 0 */
   /* K2 */
   int32_t region_chrom_id;
-  int32_t reserved0;
+  /* K4: type of the compared column x.  EXON_HIP_X_FLOAT32 (0): Float32, widened to Float64 and compared in IEEE totalOrder.
+   * EXON_HIP_X_INT32 (1): Int32 -- an INFO field of Type=Integer (exon-core/src/datasources/vcf/schema_builder.rs:197-205);
+   * compared exactly (DataFusion: as Int64 against an integer literal, as Float64 against a float literal -- every int32
+   * is exact in both), never through f32.  exon_hip_stream_consume_scan takes the type from the file's header instead. */
+  int32_t x_type;
   int64_t region_start, region_end;
   /* K3 */
   int32_t flag_mask, flag_value, mapq_min;
@@ -260,7 +266,8 @@ typedef struct exon_hip_plan_desc {
   double threshold;
   /* K5 */
   int32_t lmax;
-  int32_t reserved1;
+  /* K4: type of AVG's argument y, EXON_HIP_X_FLOAT32 / EXON_HIP_X_INT32 (DataFusion's avg casts either to Float64) */
+  int32_t y_type;
   /* input column indexes into the batch's children, in operator argument order
    * (K2: chrom_id,pos  K3: flag,mapq,ref_id  K4: x,y,group_id  K5: quality_scores  K6: ref_id,start,end) */
   int32_t columns[4];

@@ -66,6 +66,47 @@ def decode_vcf(path):
     return rows
 
 
+def typed_info(v, key):
+    """info.<key> of a decoded VCF / BCF (`decode_vcf` / `decode_bcf`) the way the reference types and builds it:
+    schema (exon-core/src/datasources/vcf/schema_builder.rs:197-249): Integer -> Int32, Float -> Float32, Flag -> Boolean,
+    String / Character -> Utf8; Number = 0 | 1 -> the scalar, any other Number -> List<item>.
+    values (exon-vcf/src/array_builder/info_builder.rs:152-309): INFO '.' (NULL struct), key absent or value '.' -> NULL;
+    a Flag is true by being there; list elements '.' -> NULL items; an unparsable value is the record's parse error.
+    -> (arrow type as text, python list of None | int | float (f32-rounded) | True | str | list)"""
+    number, typ = v["info_header"][key]
+    scalar = number in ("0", "1")
+    item = {"Integer": "int32", "Float": "float", "Flag": "bool", "String": "string", "Character": "string"}[typ]
+
+    def conv(x):
+        if x is None or x == ".":
+            return None
+        if typ == "Integer":
+            if isinstance(x, str):
+                if not (x.lstrip("+-").isdigit() and x.isascii() and len(x) - len(x.lstrip("+-")) <= 1):
+                    raise ValueError(f"invalid INFO integer {x!r}")
+                x = int(x)
+            if isinstance(x, float) or not -2**31 <= x < 2**31:
+                raise ValueError(f"INFO integer out of the int32 range: {x!r}")
+            return int(x)
+        if typ == "Float":
+            return float(np.float32(x))
+        return str(x)
+
+    col = []
+    for i in v["info"]:
+        x = None if i is None else i.get(key)
+        if typ == "Flag":
+            col.append(True if x is not None else None)
+        elif x is None or x is True or x == "." or x == "":
+            col.append(None)
+        elif scalar:
+            col.append(conv(x))
+        else:
+            items = x.split(",") if isinstance(x, str) else (list(x) if isinstance(x, (list, tuple)) else [x])
+            col.append([conv(e) for e in items])
+    return (item if scalar else f"list<item: {item}>"), col
+
+
 def _hdr_fields(line):
     body = line[line.index("<") + 1:line.rindex(">")]
     out, cur, inq, key = {}, "", False, None

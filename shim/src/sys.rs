@@ -43,7 +43,7 @@ pub struct exon_hip_plan_desc {
     pub kind: i32,
     pub n_groups: i32,
     pub region_chrom_id: i32,
-    pub reserved0: i32,
+    pub x_type: i32,
     pub region_start: i64,
     pub region_end: i64,
     pub flag_mask: i32,
@@ -52,7 +52,7 @@ pub struct exon_hip_plan_desc {
     pub cmp_op: i32,
     pub threshold: f64,
     pub lmax: i32,
-    pub reserved1: i32,
+    pub y_type: i32,
     pub columns: [i32; 4],
 }
 

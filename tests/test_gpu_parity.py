@@ -301,6 +301,41 @@ def test_k4_beyond_4096_groups_uses_the_global_table(ctx, oracle, G, n):
     plan.close()
 
 
+@pytest.mark.parametrize("G,n,dist", [(4104, 300_000, "uniform"), (4105, 300_000, "uniform"), (20_000, 6_000_000, "zipf"),
+                                      (20_000, 6_000_000, "uniform"), (64, 6_000_000, "uniform")])
+def test_k4_three_tiers_registers_lds_global(ctx, oracle, G, n, dist):
+    """Round 3: ids 0..7 in registers, 8..4103 in the LDS table, 4104.. by global atomics -- one kernel.  Checked against
+    a column-wise numpy statement (no oracle involved), in overwrite mode and accumulating over two launches, small and
+    big launch shapes, keys early-heavy (zipf) and uniform, the tier boundaries 4103 / 4104 present."""
+    rng = np.random.default_rng(G + n)
+    af, av, q, qv, _ = oracle.gen_c4(4, 0, n)
+    if dist == "uniform":
+        fid = rng.integers(0, G, n).astype(np.int32)
+    else:
+        fid = np.minimum(np.exp(rng.random(n) * np.log(G + 1.0)) - 1.0, G - 1).astype(np.int32)
+    fid[:6] = [0, 7, 8, min(G - 1, 4103), min(G - 1, 4104), G - 1]
+    avb, qvb = bits(av, n), bits(qv, n)
+    keep = avb & (af.astype(np.float64) > 0.01)
+    cr = np.bincount(fid[keep], minlength=G)
+    cn = np.bincount(fid[keep & qvb], minlength=G)
+    s = np.bincount(fid[keep & qvb], weights=q[keep & qvb].astype(np.float64), minlength=G)
+    d = [ctx.to_device(x) for x in (af, av, q, qv, fid)]
+    cols = [(d[0], d[1], None), (d[2], d[3], None), (d[4], None, None)]
+    plan = ctx.plan_cmp_avg_by_group(">", 0.01, G)
+    state = ctx.to_device(np.full(3 * G, 0x0101010101010101, np.int64))
+    plan.launch(cols, n, state, overwrite=True)
+    ctx.sync()
+    st = state.to_host()
+    assert np.array_equal(st[:G], cn) and np.array_equal(st[G:2 * G], cr)
+    assert np.allclose(st[2 * G:].view(np.float64), s, rtol=RTOL, atol=0)
+    plan.launch(cols, n, state, overwrite=False)  # accumulate: twice the table
+    ctx.sync()
+    st = state.to_host()
+    assert np.array_equal(st[:G], 2 * cn) and np.array_equal(st[G:2 * G], 2 * cr)
+    assert np.allclose(st[2 * G:].view(np.float64), 2 * s, rtol=RTOL, atol=0)
+    plan.close()
+
+
 def test_k4_deterministic(ctx):
     n = 3_000_000
     af, av, q, qv, fid = ctx.gen_c4(9, 0, n)

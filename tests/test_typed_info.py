@@ -1,6 +1,6 @@
 """Typed INFO fields (InfosBuilder, exon-vcf/src/array_builder/info_builder.rs:152-309 + typing in
-exon-core/src/datasources/vcf/schema_builder.rs:197-249): several keys per scan, Float / Integer -> f32, Flag -> Boolean (true
-when present, NULL when absent), String / Character -> dictionary, whole struct NULL when INFO is '.'.  CPU tests compare
+exon-core/src/datasources/vcf/schema_builder.rs:197-249): several keys per scan, Float -> f32, Integer -> i32 (exact), Flag ->
+Boolean (true when present, NULL when absent), String / Character -> dictionary, whole struct NULL when INFO is '.'.  CPU tests compare
 the host decoders with the oracle's decoder; the gpu-marked ones run the same expectations through the device parsers."""
 import os
 import subprocess
@@ -26,23 +26,9 @@ ROWS = ["AF=0.5;DP=10;DB;CSQ=missense;AA=T", "DP=7;AF=.;CSQ=.", ".", "DB;DBX=1;X
 
 
 def oracle_typed(v, fields):
-    """per field: python values (float / True / str / None) from the oracle's decoded INFO dicts + header types"""
-    out = []
-    for f in fields:
-        number, typ = v["info_header"][f]
-        col = []
-        for i in v["info"]:
-            x = None if i is None else i.get(f)
-            if typ == "Flag":
-                col.append(True if x is not None else None)
-            elif x is None or x is True or x == ".":
-                col.append(None)
-            elif typ in ("Float", "Integer"):
-                col.append(float(np.float32(x)))
-            else:
-                col.append(x)
-        out.append(col)
-    return out
+    """per field: python values (int / float / True / str / list / None) typed by the oracle from the header
+    (decode.typed_info: schema_builder.rs:197-249 + info_builder.rs:152-309)"""
+    return [decode.typed_info(v, f)[1] for f in fields]
 
 
 def host_typed(path, fmt, fields):
@@ -59,19 +45,52 @@ def test_host_decoder_typed_info_kinds_and_null_rules(tmp_path):
     p.write_text(HEAD + "".join(f"1\t{i + 1}\t.\tA\tC\t1\tPASS\t{r}\n" for i, r in enumerate(ROWS)))
     fields = ["AF", "DP", "DB", "CSQ"]
     got, types = host_typed(p, "vcf", fields)
-    assert types == ["float", "float", "bool", "dictionary<values=string, indices=int32, ordered=0>"]
+    assert types == ["float", "int32", "bool", "dictionary<values=string, indices=int32, ordered=0>"]
+    assert got[1] == [10, 7, None, None, 3, None, None] and all(isinstance(x, int) for x in got[1] if x is not None)
     want = oracle_typed(decode.decode_vcf(str(p)), fields)
     assert got == want
     assert got[0] == [0.5, None, None, 0.25, pytest.approx(1e-3), None, None]        # first occurrence wins; '.' -> NULL
     assert got[2] == [True, None, None, True, None, True, None]                        # Flag: true when present, NULL when absent
     assert got[3] == ["missense", None, None, None, "stop", None, "missense"]
     assert host_typed(p, "vcf", ["AA"])[0] == [["T", None, None, None, None, None, None]]
-    with pytest.raises(exon_amd.ExonHipError, match="AC"):                              # list-valued fields are not scalars
-        host_typed(p, "vcf", ["AC"])
+    ac, ac_type = host_typed(p, "vcf", ["AC"])                                          # Number=A -> List<Int32>
+    assert ac_type == ["list<item: int32>"] and ac[0] == [None, None, None, None, None, None, [1, 2]]
+    assert ac == oracle_typed(decode.decode_vcf(str(p)), ["AC"])
     with pytest.raises(exon_amd.ExonHipError, match="NOPE"):
         host_typed(p, "vcf", ["NOPE"])
-    with pytest.raises(exon_amd.ExonHipError, match="at most 4"):
-        host_typed(p, "vcf", ["AF", "DP", "DB", "CSQ", "AA"])
+    assert len(host_typed(p, "vcf", ["AF", "DP", "DB", "CSQ", "AA", "AC"])[0]) == 6     # more than round 2's four keys
+    with pytest.raises(exon_amd.ExonHipError, match="at most 16"):
+        host_typed(p, "vcf", ["AF"] * 17)
+    bad = tmp_path / "bad.vcf"
+    for val in ("1.5", "2147483648", "x", "1,2"):                                       # not an int32: the record's parse error
+        bad.write_text(HEAD + f"1\t1\t.\tA\tC\t1\tPASS\tDP={val}\n")
+        with pytest.raises(exon_amd.ExonHipError, match="integer"):
+            host_typed(bad, "vcf", ["DP"])
+        with pytest.raises(ValueError):
+            decode.typed_info(decode.decode_vcf(str(bad)), "DP")
+
+
+def test_every_info_kind_vcf_and_bcf_twin(tmp_path):
+    """Float / Integer / Flag / String scalars and Integer / Float / String lists, written by tests/vcf_bcf_writer.py as a VCF
+    and its BCF twin: host decoders == the rows they were written from == the oracle's typing of its own decode."""
+    import vcf_bcf_writer as W
+    rows = W.make_rows(3000)
+    vcf, bcf = tmp_path / "k.vcf", tmp_path / "k.bcf"
+    W.write_vcf(vcf, rows)
+    W.write_bcf(bcf, rows, BGZIP)
+    fields = [n for n, _, _ in W.INFO_HEADER]
+    want = [W.expected_column(rows, f) for f in fields]
+    want_types = ["float", "int32", "bool", "dictionary<values=string, indices=int32, ordered=0>", "list<item: int32>",
+                  "list<item: float>", "list<item: dictionary<values=string, indices=int32, ordered=0>>"]
+    assert sum(x is not None for x in want[4]) > 1000 and any(None in x for x in want[4] if x)
+    for path, fmt, dec in ((vcf, "vcf", decode.decode_vcf), (bcf, "bcf", decode.decode_bcf)):
+        got, types = host_typed(path, fmt, fields)
+        assert types == want_types, fmt
+        for k, f in enumerate(fields):
+            assert got[k] == want[k], (fmt, f)
+        o = dec(str(path))
+        for k, f in enumerate(fields):
+            assert decode.typed_info(o, f)[1] == want[k], (fmt, f, "oracle")
 
 
 def test_reference_fixture_typed_info_vcf_and_bcf_twin():
@@ -79,7 +98,7 @@ def test_reference_fixture_typed_info_vcf_and_bcf_twin():
     v = decode.decode_vcf(os.path.join(FX, "vcf", "index.vcf"))
     want = oracle_typed(v, fields)
     got, types = host_typed(os.path.join(FX, "vcf", "index.vcf"), "vcf", fields)
-    assert types == ["float", "float", "bool", "float"] and got == want
+    assert types == ["int32", "float", "bool", "int32"] and got == want
     assert sum(x is not None for x in want[0]) == 621 and all(x is None for x in want[2])
     gotb, typesb = host_typed(os.path.join(FX, "bcf", "index.bcf"), "bcf", fields)
     assert typesb == types and gotb == want
@@ -109,7 +128,7 @@ def test_gpu_vcf_parser_typed_info(ctx, tmp_path):
     p.write_text(HEAD + "".join(f"1\t{i + 1}\t.\tA\tC\t1\tPASS\t{r}\n" for i, r in enumerate(rows)))
     want = oracle_typed(decode.decode_vcf(str(p)), ["AF", "DP", "DB"])
     text = "".join(f"1\t{i + 1}\t.\tA\tC\t1\tPASS\t{r}\n" for i, r in enumerate(rows)).encode()
-    par = exon_amd.VCFParser(ctx, ["1"], info_field="AF,DP:f,DB:b")
+    par = exon_amd.VCFParser(ctx, ["1"], info_field="AF,DP:i,DB:b")
     d = ctx.to_device(np.frombuffer(text + bytes(64), np.uint8))
     cols = par.parse_device(d.ptr, len(text))
     n = cols.n_rows
@@ -124,9 +143,9 @@ def test_gpu_vcf_parser_typed_info(ctx, tmp_path):
         if want[k] and isinstance(next((x for x in want[k] if x is not None), None), bool):
             assert not cols.infos[k] and valid.tolist() == [x is True for x in want[k]]
         else:
-            vals = dev(cols.infos[k], np.float32, n)
+            vals = dev(cols.infos[k], np.int32 if k == 1 else np.float32, n)  # DP is Type=Integer: an Int32 column
             assert valid.tolist() == [x is not None for x in want[k]]
-            assert [float(v) for v, ok in zip(vals, valid) if ok] == [x for x in want[k] if x is not None]
+            assert [v.item() for v, ok in zip(vals, valid) if ok] == [x for x in want[k] if x is not None]
     par.close()
 
 
@@ -166,6 +185,66 @@ def test_two_info_fields_through_the_gpu_pipeline(ctx, oracle, fmt):
         for k in want:
             assert got[k][:2] == want[k][:2] and got[k][2] == pytest.approx(want[k][2], rel=1e-9)
         assert sum(v[0] for v in got.values()) == 621 and sum(v[2] for v in got.values()) > 621
+
+
+def _int_k4_expected(rows, xkey, op, thr, ykey=None):
+    """{filter text: (COUNT(y), COUNT(*), SUM(y))} in exact python arithmetic: WHERE info.<xkey> <op> thr GROUP BY filter;
+    y = qual, or info.<ykey>"""
+    import operator
+    cmp = {">": operator.gt, ">=": operator.ge, "<": operator.lt, "<=": operator.le, "=": operator.eq, "!=": operator.ne}[op]
+    out = {}
+    for r in rows:
+        x = None if r["info"] is None else r["info"].get(xkey)
+        if x is None or x is True or not cmp(x, thr):
+            continue
+        y = r["qual"] if ykey is None else (None if r["info"] is None else r["info"].get(ykey))
+        k = ";".join(r["filter"])
+        cn, cr, sm = out.get(k, (0, 0, 0.0))
+        out[k] = (cn + (y is not None), cr + 1, sm + (0.0 if y is None else float(y)))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["vcf", "bcf"])
+def test_integer_info_predicate_is_exact_beyond_2_pow_24(ctx, tmp_path, fmt):
+    """`WHERE info.DP > 16777217` (missing #3): as f32 the literal and the values 16777216..16777219 collapse;
+    typed Int32 (schema_builder.rs:197-205) the comparison is exact -- on the GPU decoders and the host decoders, VCF and
+    BCF, for every operator, with integer and fractional literals; and AVG(info.DP) sums the integers exactly."""
+    import vcf_bcf_writer as W
+    rows = W.make_rows(40_000, seed=11)
+    path = tmp_path / ("k." + fmt)
+    (W.write_vcf(path, rows) if fmt == "vcf" else W.write_bcf(path, rows, BGZIP))
+    o = (decode.decode_vcf if fmt == "vcf" else decode.decode_bcf)(str(path))
+    assert decode.typed_info(o, "DP")[1] == W.expected_column(rows, "DP")  # the oracle sees the same integers
+    cases = [(">", 16777217), (">=", 16777217), ("<", 16777217), ("=", 16777217), ("!=", 16777216), (">", 16777216.5), ("<=", -5),
+             (">", 2**31 - 2), (">", 2.0**40), ("<", -2.0**40)]
+    for gpu in (True, False):
+        for op, thr in cases:
+            rows_n, got, on_gpu = _k4_op(ctx, path, fmt, "DP", (4, 2, 3), gpu, op, float(thr))
+            want = _int_k4_expected(rows, "DP", op, thr)
+            assert rows_n == len(rows) and on_gpu == gpu
+            assert {k: v[:2] for k, v in got.items()} == {k: v[:2] for k, v in want.items()}, (fmt, gpu, op, thr)
+            for k in want:
+                assert got[k][2] == pytest.approx(want[k][2], rel=1e-9)
+        # y = info.DP (Int32) under AVG: x = AF (column 4), y = DP (column 5)
+        rows_n, got, on_gpu = _k4_op(ctx, path, fmt, "AF,DP", (4, 5, 3), gpu, ">", 0.01)
+        want = _int_k4_expected(rows, "AF", ">", float(np.float32(0.01)) if False else 0.01, ykey="DP")
+        assert {k: v[:2] for k, v in got.items()} == {k: v[:2] for k, v in want.items()}, (fmt, gpu, "avg(DP)")
+        for k in want:
+            assert got[k][2] == want[k][2], (fmt, gpu, k)  # integer sums below 2^53: exact in f64
+
+
+def _k4_op(ctx, path, fmt, fields, columns, gpu_parse, op, thr):
+    scan = exon_amd.Scan(str(path), fmt, info_field=fields, gpu_parse=gpu_parse)
+    plan = ctx.plan_cmp_avg_by_group(op, thr, 64, columns=columns)
+    st = plan.open()
+    rows = st.consume(scan)
+    counts, sums = st.finish()
+    names = scan.dictionary(3)
+    res = {names[g]: (int(counts[g]), int(counts[64 + g]), float(sums[g])) for g in range(len(names)) if counts[64 + g]}
+    on_gpu = scan.decoded_on_gpu()[0]
+    st.close(); plan.close(); scan.close()
+    return rows, res, on_gpu
 
 
 @pytest.mark.gpu
