@@ -93,7 +93,8 @@ class VCFColumns(C.Structure):
     _fields_ = [("n_rows", C.c_int64), ("n_undecided", C.c_int64), ("chrom_id", C.c_void_p), ("pos", C.c_void_p),
                 ("pos_valid", C.c_void_p), ("qual", C.c_void_p), ("qual_valid", C.c_void_p), ("filter_id", C.c_void_p),
                 ("info", C.c_void_p), ("info_valid", C.c_void_p), ("consumed_bytes", C.c_int64),
-                ("n_info", C.c_int32), ("reserved", C.c_int32), ("infos", C.c_void_p * 4), ("infos_valid", C.c_void_p * 4)]
+                ("n_info", C.c_int32), ("reserved", C.c_int32), ("infos", C.c_void_p * 16), ("infos_valid", C.c_void_p * 16),
+                ("info_kinds", C.c_char * 16)]
 
 
 class ScanOptions(C.Structure):

@@ -68,14 +68,14 @@ struct BcfOut {
   float* qual;
   uint32_t* qual_valid;
   int32_t* filter_id;
-  float* info[4];          // typed INFO fields, in the order of exon_hip_bcf_parser_set_info_keys
-  uint32_t* info_valid[4];
+  float* info[EXON_HIP_MAX_INFO_FIELDS];  // typed INFO fields (4-byte values), in the order of exon_hip_bcf_parser_set_info_keys
+  uint32_t* info_valid[EXON_HIP_MAX_INFO_FIELDS];
   uint32_t* pos_valid;  // POS 0 (BCF pos0 = -1, the telomere) is NULL like in the VCF path
 };
-struct BcfInfoKeys {  // header-string indexes of the INFO fields to extract; kind 'f' numeric -> f32, 'b' Flag -> presence
+struct BcfInfoKeys {  // header-string indexes of the INFO fields to extract; kind 'f' -> f32, 'i' -> i32, 'b' Flag -> presence
   int n;
-  int32_t key[4];
-  char kind[4];
+  int32_t key[EXON_HIP_MAX_INFO_FIELDS];
+  char kind[EXON_HIP_MAX_INFO_FIELDS];
 };
 
 __device__ __forceinline__ int type_size(int t) { return t == 1 ? 1 : t == 2 ? 2 : t == 3 ? 4 : t == 5 ? 4 : t == 7 ? 1 : 0; }
@@ -144,8 +144,7 @@ __global__ __launch_bounds__(256) void k_bcf_extract(const uint8_t* __restrict__
       h = (h ^ (unsigned long long)(v + 1)) * 0x100000001B3ULL;
     }
     // INFO: (typed key, typed value) pairs; the first occurrence of a key wins
-    bool have[4] = {false, false, false, false};
-    float iv[4] = {0.f, 0.f, 0.f, 0.f};
+    unsigned have = 0;  // bit w: INFO field w has a value (bit mask + direct stores: up to 16 keys without per-thread arrays)
     for (int q = 0; q < n_info && !c.bad && !undecided; ++q) {
       int kt, kc;
       c.typed_header(&kt, &kc);
@@ -153,11 +152,10 @@ __global__ __launch_bounds__(256) void k_bcf_extract(const uint8_t* __restrict__
       int vt, vc;
       c.typed_header(&vt, &vc);
       if (c.bad) break;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        if (w >= ik.n || key != ik.key[w] || have[w]) continue;
+      for (int w = 0; w < ik.n; ++w) {
+        if (key != ik.key[w] || (have >> w & 1u)) continue;
         if (ik.kind[w] == 'b') {
-          have[w] = true;  // a Flag is true by being there
+          have |= 1u << w;  // a Flag is true by being there
         } else if (ik.kind[w] == 'i') {
           // Type=Integer: int8 / int16 / int32 widened to Int32 exactly (bit pattern in the 4-byte column)
           if (vc >= 1 && vt >= 1 && vt <= 3) {
@@ -166,8 +164,8 @@ __global__ __launch_bounds__(256) void k_bcf_extract(const uint8_t* __restrict__
             if (t.bad) { c.bad = true; break; }
             const int64_t missing = vt == 1 ? -128 : vt == 2 ? -32768 : (int64_t)INT32_MIN;
             if (v != missing) {
-              iv[w] = __int_as_float((int32_t)v);
-              have[w] = true;
+              out.info[w][row] = __int_as_float((int32_t)v);
+              have |= 1u << w;
             }
           }
         } else if (vc >= 1) {
@@ -175,8 +173,8 @@ __global__ __launch_bounds__(256) void k_bcf_extract(const uint8_t* __restrict__
             if (c.o + 4 > c.end) { c.bad = true; break; }
             const uint32_t bb = ld32(d + c.o);
             if (bb != 0x7F800001u && bb != 0x7F800002u) {
-              iv[w] = __uint_as_float(bb);
-              have[w] = true;
+              out.info[w][row] = __uint_as_float(bb);
+              have |= 1u << w;
             }
           } else if (vt >= 1 && vt <= 3) {
             Cursor t = c;
@@ -184,8 +182,8 @@ __global__ __launch_bounds__(256) void k_bcf_extract(const uint8_t* __restrict__
             if (t.bad) { c.bad = true; break; }
             const int64_t missing = vt == 1 ? -128 : vt == 2 ? -32768 : (int64_t)INT32_MIN;
             if (v != missing) {
-              iv[w] = (float)v;
-              have[w] = true;
+              out.info[w][row] = (float)v;
+              have |= 1u << w;
             }
           }
         }
@@ -224,11 +222,9 @@ __global__ __launch_bounds__(256) void k_bcf_extract(const uint8_t* __restrict__
     const uint32_t bit = 1u << (row & 31);
     if (qbits != 0x7F800001u) atomicOr(&out.qual_valid[row >> 5], bit);
     if (pos0 >= 0) atomicOr(&out.pos_valid[row >> 5], bit);
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      if (w >= ik.n) continue;
-      if (ik.kind[w] != 'b') out.info[w][row] = have[w] ? iv[w] : 0.f;
-      if (have[w]) atomicOr(&out.info_valid[w][row >> 5], bit);
+    for (int w = 0; w < ik.n; ++w) {
+      if (have >> w & 1u) atomicOr(&out.info_valid[w][row >> 5], bit);
+      else if (ik.kind[w] != 'b') out.info[w][row] = 0.f;  // NULL slots hold a defined value
     }
   }
 }
@@ -254,7 +250,7 @@ struct exon_hip_bcf_parser {
   exon_hip_ctx* ctx = nullptr;
   int32_t n_contigs = 0, n_strings = 0, n_samples = 0, info_key = -1;
   BcfInfoKeys ik{};
-  void* ibufs[6] = {nullptr};  // value / validity buffers of INFO fields 1 .. 3 (field 0 lives in bufs[5] / bufs[6])
+  void* ibufs[2 * (EXON_HIP_MAX_INFO_FIELDS - 1)] = {nullptr};  // value / validity buffers of INFO fields 1 .. 15 (field 0 lives in bufs[5] / bufs[6])
   size_t words = 0;
   int64_t max_bytes = 0, max_rows = 0;
   uint32_t max_seg = 0;
@@ -341,7 +337,7 @@ int exon_hip_bcf_parser_create(exon_hip_ctx* ctx, int32_t n_contigs, int32_t n_s
 // Several typed INFO fields (InfosBuilder children): header-string indexes + kinds ('f' numeric -> f32, 'b' Flag).  Replaces
 // the single key given to _create; call before the first parse.
 int exon_hip_bcf_parser_set_info_keys(exon_hip_bcf_parser* p, const int32_t* keys, const char* kinds, int32_t n) {
-  if (!p || n < 0 || n > 4 || (n > 0 && (!keys || !kinds))) return fail(p ? p->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_bcf_parser_set_info_keys: bad argument");
+  if (!p || n < 0 || n > EXON_HIP_MAX_INFO_FIELDS || (n > 0 && (!keys || !kinds))) return fail(p ? p->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_bcf_parser_set_info_keys: bad argument");
   p->ik = BcfInfoKeys{};
   p->ik.n = n;
   hipSetDevice(p->ctx->device);
@@ -416,6 +412,7 @@ int exon_hip_bcf_parser_parse(exon_hip_bcf_parser* p, void* stream, const uint8_
   for (int q = 0; q < p->ik.n; ++q) {
     cols->infos[q] = p->ik.kind[q] != 'b' ? p->out.info[q] : nullptr;
     cols->infos_valid[q] = (uint8_t*)p->out.info_valid[q];
+    cols->info_kinds[q] = p->ik.kind[q];
   }
   return EXON_HIP_OK;
 }

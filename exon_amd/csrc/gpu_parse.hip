@@ -173,7 +173,7 @@ struct FilterTable {
   int32_t* counters;  // [0] = number of dense ids, [1] = pool bytes used, [2] = overflow flag
 };
 
-constexpr int MAX_INFO = 4;
+constexpr int MAX_INFO = EXON_HIP_MAX_INFO_FIELDS;  // 16: the by-value key table below is 16 x 9 bytes of kernel arguments
 // the typed INFO fields a parser extracts (InfosBuilder children: exon-vcf/src/array_builder/info_builder.rs:152-309):
 // kind 'f' = Number=1 Float -> f32 + validity; 'i' = Number=1 Integer -> i32 + validity (the 4-byte column holds the bit
 // pattern); 'b' = Flag -> presence bitmap (value true where valid)
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
   const int64_t row = (int64_t)blockIdx.x * TPB + threadIdx.x;
   const int lane = threadIdx.x & 63;
   bool pos_ok = false, qual_ok = false, bad = false;
-  bool info_ok[MAX_INFO] = {false, false, false, false};
+  unsigned info_ok = 0;  // bit q: INFO field q has a value in this row (bit masks, not arrays: up to 16 keys stay in registers)
   if (row < n_rows) {
     const unsigned begin = row ? nl_pos[row - 1] + 1 : skip;
     unsigned end = nl_pos[row];
@@ -354,8 +354,7 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
       }
       // INFO: `key=value` (or a bare Flag key) among ';'-separated entries; the first occurrence of a key wins
       if (ik.n > 0) {
-        float v[MAX_INFO] = {0.f, 0.f, 0.f, 0.f};
-        bool seen[MAX_INFO] = {false, false, false, false};
+        unsigned seen = 0;  // bit q: key q was met (the first occurrence wins); values are stored as they are parsed
         int left = ik.n;
         const unsigned ib = fbeg(7), ie = fend(7);
         if (!(ie - ib == 1 && text[ib] == '.')) {  // INFO '.': the whole struct is NULL
@@ -364,16 +363,16 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
           auto entry = [&](unsigned j) {  // the entry [i, j)
             for (int q = 0; q < ik.n; ++q) {
               const int kl = ik.len[q];
-              if (seen[q] || (int)(j - i) < kl) continue;
+              if ((seen >> q & 1u) || (int)(j - i) < kl) continue;
               const bool valued = (int)(j - i) > kl && text[i + kl] == '=';
               if (!valued && (int)(j - i) != kl) continue;
               bool same = true;
               for (int k = 0; k < kl && same; ++k) same = text[i + k] == ik.text[ik.off[q] + k];
               if (!same) continue;
-              seen[q] = true;
+              seen |= 1u << q;
               --left;
               if (ik.kind[q] == 'b') {
-                info_ok[q] = true;  // a Flag is true by being there
+                info_ok |= 1u << q;  // a Flag is true by being there
               } else if (valued) {
                 const unsigned vb = i + kl + 1;
                 const int vl = (int)(j - vb);
@@ -394,14 +393,14 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
                     }
                     if (neg) iv = -iv;
                     if (ok && iv >= INT32_MIN && iv <= INT32_MAX) {
-                      v[q] = __int_as_float((int32_t)iv);
-                      info_ok[q] = true;
+                      out.info[q][row] = __int_as_float((int32_t)iv);
+                      info_ok |= 1u << q;
                     } else {
                       bad = true;
                     }
                   } else if (exon::dec::parse_f32(reinterpret_cast<const char*>(text + vb), vl, &bits)) {
-                    v[q] = __uint_as_float(bits);
-                    info_ok[q] = true;
+                    out.info[q][row] = __uint_as_float(bits);
+                    info_ok |= 1u << q;
                   } else {
                     bad = true;
                   }
@@ -427,14 +426,14 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
           if (left > 0 && i < ie) entry(ie);  // the last entry has no ';' behind it
         }
         for (int q = 0; q < ik.n; ++q)
-          if (ik.kind[q] != 'b') out.info[q][row] = v[q];
+          if (ik.kind[q] != 'b' && !(info_ok >> q & 1u)) out.info[q][row] = 0.f;  // NULL slots hold a defined value
       }
     }
   }
   const int64_t wave_row0 = row - lane;
   store_valid(out.pos_valid, wave_row0, n_rows, pos_ok, lane);
   store_valid(out.qual_valid, wave_row0, n_rows, qual_ok, lane);
-  for (int q = 0; q < ik.n; ++q) store_valid(out.info_valid[q], wave_row0, n_rows, info_ok[q], lane);
+  for (int q = 0; q < ik.n; ++q) store_valid(out.info_valid[q], wave_row0, n_rows, (info_ok >> q & 1u) != 0, lane);
   const unsigned long long nb = __ballot(bad);
   if (lane == 0 && nb) atomicAdd(out.exceptions, (unsigned)__popcll(nb));
 }
@@ -693,6 +692,7 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* p, void* stream, const uint8_
   for (int q = 0; q < p->ik.n; ++q) {
     cols->infos[q] = p->out.info[q];  // NULL for a Flag: its column IS the presence bitmap
     cols->infos_valid[q] = p->out.info_valid[q];
+    cols->info_kinds[q] = p->ik.kind[q];
   }
   return EXON_HIP_OK;
 }

@@ -191,6 +191,7 @@ struct Block {
 };
 inline Block read_block(Cursor& c) {
   Block b;
+  const size_t block_start = c.o;
   const int method = c.u8();
   b.type = c.u8();
   b.id = c.itf8();
@@ -219,12 +220,19 @@ inline Block read_block(Cursor& c) {
     throw std::runtime_error("CRAM: block compression method " + std::to_string(method) + " is not supported (raw, gzip, rANS 4x8 are)");
   }
   if (b.data.size() != rsz) throw std::runtime_error("CRAM: block size mismatch");
-  c.o += (size_t)csz + 4;  // CRC-32 of the block (not verified: the codecs above check their own sizes)
+  // CRC-32 over the block's header and payload (CRAM 3.0 section 8): a raw or rANS block has no other integrity check, and
+  // a flipped byte in an external block would otherwise become silently wrong flag / position columns (noodles-cram
+  // reports a checksum mismatch)
+  c.o += (size_t)csz;
+  const uint32_t want = (uint32_t)c.i32le();
+  const uint32_t got = (uint32_t)crc32(crc32(0L, Z_NULL, 0), c.p + block_start, (uInt)(c.o - 4 - block_start));
+  if (got != want) throw std::runtime_error("CRAM: block CRC-32 mismatch");
   return b;
 }
 
 struct Encoding {
-  enum Kind { NONE, EXTERNAL, HUFFMAN, BYTE_ARRAY_LEN, BYTE_ARRAY_STOP, BETA } kind = NONE;
+  enum Kind { NONE, EXTERNAL, HUFFMAN, BYTE_ARRAY_LEN, BYTE_ARRAY_STOP, BETA, UNSUPPORTED } kind = NONE;
+  uint32_t codec = 0;               // UNSUPPORTED: the codec id, reported when (and only when) the series is read
   uint32_t id = 0;                  // EXTERNAL / BYTE_ARRAY_STOP: block content id
   uint8_t stop = 0;                 // BYTE_ARRAY_STOP
   int32_t offset = 0, nbits = 0;    // BETA
@@ -233,7 +241,10 @@ struct Encoding {
   std::shared_ptr<Encoding> len_enc, val_enc;  // BYTE_ARRAY_LEN
   int slot = -1;  // EXTERNAL / BYTE_ARRAY_STOP: index of the block with content id `id` in the current slice (SliceData::bind)
 };
-inline Encoding read_encoding(Cursor& c) {
+// depth: BYTE_ARRAY_LEN (codec 4) nests two encodings.  The specification only ever puts scalar encodings there (the length
+// is an integer series, the values a byte series), so a BYTE_ARRAY_LEN inside a BYTE_ARRAY_LEN is rejected -- a crafted header
+// nesting them ~100 k deep would otherwise overflow the decoding thread's stack (read_encoding and SliceData::bind recurse).
+inline Encoding read_encoding(Cursor& c, int depth = 0) {
   Encoding e;
   const uint32_t codec = c.itf8(), ln = c.itf8();
   c.need(ln);
@@ -267,9 +278,10 @@ inline Encoding read_encoding(Cursor& c) {
       break;
     }
     case 4:
+      if (depth >= 1) throw std::runtime_error("CRAM: BYTE_ARRAY_LEN nested inside BYTE_ARRAY_LEN");
       e.kind = Encoding::BYTE_ARRAY_LEN;
-      e.len_enc = std::make_shared<Encoding>(read_encoding(p));
-      e.val_enc = std::make_shared<Encoding>(read_encoding(p));
+      e.len_enc = std::make_shared<Encoding>(read_encoding(p, depth + 1));
+      e.val_enc = std::make_shared<Encoding>(read_encoding(p, depth + 1));
       break;
     case 5:
       e.kind = Encoding::BYTE_ARRAY_STOP;
@@ -283,7 +295,11 @@ inline Encoding read_encoding(Cursor& c) {
       if (e.nbits > 32) throw std::runtime_error("CRAM: BETA width");
       break;
     default:
-      throw std::runtime_error("CRAM: encoding " + std::to_string(codec) + " is not supported");
+      // GOLOMB / SUBEXP / GAMMA ...: recorded, and an error only if a value of this series is ever decoded -- a file that
+      // uses one on a series this reader never touches (TC, TN) still decodes
+      e.kind = Encoding::UNSUPPORTED;
+      e.codec = codec;
+      break;
   }
   c.o += ln;
   return e;
@@ -356,6 +372,8 @@ struct SliceData {
       }
       case Encoding::BETA:
         return (int32_t)bits(e.nbits) - e.offset;
+      case Encoding::UNSUPPORTED:
+        throw std::runtime_error("CRAM: encoding " + std::to_string(e.codec) + " is not supported");
       default:
         throw std::runtime_error("CRAM: integer data series with a byte-array encoding");
     }
@@ -547,7 +565,11 @@ class CRAMBatchReader {
         h.n_blocks = c.itf8();
         const uint32_t nl = c.itf8();
         for (uint32_t i = 0; i < nl; ++i) (void)c.itf8();
-        c.skip(4);
+        {  // CRC-32 of the container header bytes before it (CRAM 3.0 section 7)
+          const size_t hdr = c.o;
+          const uint32_t want = (uint32_t)c.i32le();
+          if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), buf.data(), (uInt)hdr) != want) throw std::runtime_error("CRAM: container header CRC-32 mismatch");
+        }
         off_ += c.o;
         if (h.length > size_ - off_) throw std::runtime_error("CRAM: container runs past the end of the file");
         return h;

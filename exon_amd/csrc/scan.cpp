@@ -1074,7 +1074,7 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
       size_t consumed = 0;
       if (n > 0 && (is_vcf || is_bcf || is_bam || is_sam)) {
         // parsed columns in the scan's column order: VCF / BCF 0 chrom 1 pos 2 qual 3 filter 4.. info fields; BAM / SAM 0 flag 1 mapq 2 ref 3 start 4 end
-        exon_hip_column sc[8];
+        exon_hip_column sc[4 + EXON_HIP_MAX_INFO_FIELDS];
         memset(sc, 0, sizeof sc);
         int64_t n_rows = 0;
         const int32_t* id_col = nullptr;
@@ -1095,7 +1095,7 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
           sc[2].values = cols.qual;
           sc[2].validity = cols.qual_valid;
           sc[3].values = cols.filter_id;
-          for (int q = 0; q < cols.n_info && q < 4; ++q) {
+          for (int q = 0; q < cols.n_info && q < EXON_HIP_MAX_INFO_FIELDS; ++q) {
             sc[4 + q].values = cols.infos[q] ? (const void*)cols.infos[q] : (const void*)cols.infos_valid[q];  // a Flag's values ARE its bitmap
             sc[4 + q].validity = cols.infos_valid[q];
           }
@@ -1143,12 +1143,12 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
               scan->region_mask_cap = cap;
             }
             const int first = exon_hip_stream_plan_first_column(st);
-            const uint8_t* in_valid = first >= 0 && first < 8 ? sc[first].validity : nullptr;
+            const uint8_t* in_valid = first >= 0 && first < 4 + EXON_HIP_MAX_INFO_FIELDS ? sc[first].validity : nullptr;
             HIP_TRY(ctx, exon::launch_region_mask(hs, rg_range, id_col, id_valid, c_start, c_end, pos_valid, in_valid, n_rows, rg_id, rg_a, rg_b,
                                                   scan->d_region_mask, scan->d_region_pass));
             row_mask = scan->d_region_mask;
           }
-          rc = exon_hip_stream_launch_scan_columns(st, sc, 8, n_rows, row_mask);
+          rc = exon_hip_stream_launch_scan_columns(st, sc, 4 + EXON_HIP_MAX_INFO_FIELDS, n_rows, row_mask);
           // the parser's column buffers (and the row mask) are reused by the next slab; the kernel is stream-ordered before that
           total += n_rows;
         }

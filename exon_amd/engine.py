@@ -241,8 +241,11 @@ class Context:
                        flag_value=flag_value, mapq_min=mapq_min)
         return Plan(self, d, columns)
 
-    def plan_cmp_avg_by_group(self, op, threshold, n_groups, columns=(0, 1, 2)):
-        d = L.PlanDesc(kind=L.PLAN_CMP_AVG_BY_GROUP, n_groups=n_groups, cmp_op=CMP[op], threshold=threshold)
+    def plan_cmp_avg_by_group(self, op, threshold, n_groups, columns=(0, 1, 2), x_type="f32", y_type="f32"):
+        """x_type / y_type "i32": the compared column / AVG's argument holds Int32 values (an INFO field of Type=Integer);
+        a plan fed by Stream.consume(scan) takes both from the file's header instead."""
+        d = L.PlanDesc(kind=L.PLAN_CMP_AVG_BY_GROUP, n_groups=n_groups, cmp_op=CMP[op], threshold=threshold,
+                       x_type=1 if x_type == "i32" else 0, y_type=1 if y_type == "i32" else 0)
         return Plan(self, d, columns)
 
     def plan_qual_pos_hist(self, lmax, columns=(0,)):

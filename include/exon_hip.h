@@ -107,7 +107,7 @@ typedef struct exon_hip_device_info {
   int32_t reserved;
 } exon_hip_device_info;
 
-int exon_hip_abi_version(void);
+int exon_hip_abi_version(void); /* 3 (round 3: plan_desc.x_type / y_type, 16 typed INFO fields with kinds, rccl_comm_count) */
 int exon_hip_device_count(int* out);
 int exon_hip_ctx_create(int device, exon_hip_ctx** out);
 int exon_hip_ctx_destroy(exon_hip_ctx* ctx);
@@ -368,10 +368,12 @@ typedef struct exon_hip_scan_options {
   int32_t format;       /* EXON_HIP_FORMAT_* */
   int32_t compression;  /* EXON_HIP_COMPRESSION_* */
   int64_t batch_size;   /* 0 = 8192 (exon-common/src/lib.rs:27) */
-  const char* info_field; /* VCF / BCF: typed INFO fields to extract (exon.vcf_parse_info), up to 4 comma-separated header
-                             IDs ("AF,DP,DB"), NULL = none.  They become scan columns 4, 5, ...: Number=1 Float / Integer ->
-                             f32?, Flag -> bool? (true when present, NULL when absent), Number=1 String / Character ->
-                             dictionary?; INFO '.' makes all of them NULL (the struct itself is NULL in the reference) */
+  const char* info_field; /* VCF / BCF: typed INFO fields to extract (exon.vcf_parse_info), up to 16 comma-separated header
+                             IDs ("AF,DP,DB"), NULL = none.  They become scan columns 4, 5, ..., typed from the header as the
+                             reference does (schema_builder.rs:197-249): Number=1 Float -> f32?, Number=1 Integer -> i32?,
+                             Flag -> bool? (true when present, NULL when absent), Number=1 String / Character -> dictionary?,
+                             any other Number -> List<f32 | i32 | dictionary>? (items '.' are NULL items; host decoders);
+                             INFO '.' makes all of them NULL (the struct itself is NULL in the reference) */
   const char* region;     /* pushed-down vcf_region_filter / bam_region_filter ("chr1:1-100"), NULL = none */
   int32_t use_index;      /* with `region`: plan BGZF chunks from <path>.tbi / <path>.bai (INDEXED_VCF / INDEXED_BAM) */
   int32_t gpu_parse;      /* VCF, FASTQ, BAM: exon_hip_stream_consume_scan ships the file's bytes to HBM and decodes them
@@ -406,6 +408,7 @@ int exon_hip_scan_close(exon_hip_scan* scan);
  * device-layout columns.  A parser is bound to one header (contig dictionary) and one optional typed INFO field and
  * keeps the FILTER dictionary it discovers across slabs.  Rows the device cannot decide (float with > 19 significant
  * digits, contig missing from the header, malformed line) are counted in n_undecided: re-decode that slab on the host. */
+#define EXON_HIP_MAX_INFO_FIELDS 16 /* typed INFO fields per scan / parser */
 typedef struct exon_hip_vcf_parser exon_hip_vcf_parser;
 typedef struct exon_hip_vcf_columns {
   int64_t n_rows;
@@ -419,15 +422,18 @@ typedef struct exon_hip_vcf_columns {
   float* info;         /* NULL without an INFO field; = infos[0] */
   uint8_t* info_valid;
   int64_t consumed_bytes; /* bytes up to and including the last newline; a trailing partial line is not parsed */
-  /* all typed INFO fields of the parser, in the order given to *_parser_create (scan columns 4 ..): Float / Integer fields
-   * are f32 + validity; a Flag has infos[k] == NULL, its column is the presence bitmap infos_valid[k] (true where set) */
+  /* all typed INFO fields of the parser, in the order given to *_parser_create (scan columns 4 ..), 4-byte values + validity:
+   * info_kinds[k] = 'f' Float -> float values; 'i' Integer -> int32_t values (exact; schema_builder.rs:197-205); 'b' Flag ->
+   * infos[k] == NULL, the column is the presence bitmap infos_valid[k] (true where set) */
   int32_t n_info;
   int32_t reserved;
-  float* infos[4];
-  uint8_t* infos_valid[4];
+  void* infos[EXON_HIP_MAX_INFO_FIELDS];
+  uint8_t* infos_valid[EXON_HIP_MAX_INFO_FIELDS];
+  char info_kinds[EXON_HIP_MAX_INFO_FIELDS];
 } exon_hip_vcf_columns;
-/* info_field: NULL, or up to 4 comma-separated INFO keys "name[:kind]" -- kind f (default): Number=1 Float / Integer -> f32;
- * kind b: Flag -> presence bitmap.  (String INFO fields are decoded by the host reader only.) */
+/* info_field: NULL, or up to EXON_HIP_MAX_INFO_FIELDS comma-separated INFO keys "name[:kind]" -- kind f (default): Number=1
+ * Float -> f32; kind i: Number=1 Integer -> i32; kind b: Flag -> presence bitmap.  (String and list-valued INFO fields are
+ * decoded by the host reader only.) */
 int exon_hip_vcf_parser_create(exon_hip_ctx* ctx, const char* const* contig_names, int32_t n_contigs,
                                const char* info_field, int64_t max_slab_bytes, exon_hip_vcf_parser** out);
 /* d_text: a slab of '\n'-terminated data lines in HBM, any alignment (a trailing partial line is left to the
@@ -536,8 +542,8 @@ typedef struct exon_hip_bcf_parser exon_hip_bcf_parser;
 int exon_hip_bcf_parser_create(exon_hip_ctx* ctx, int32_t n_contigs, int32_t n_header_strings, int32_t n_samples,
                                int32_t info_key /* header-string index of the INFO field, -1 = none */, int64_t max_slab_bytes,
                                exon_hip_bcf_parser** out);
-/* several typed INFO fields instead of the single key of _create: header-string indexes + kinds ('f' Float / Integer -> f32,
- * 'b' Flag -> presence bitmap), up to 4; call before the first parse */
+/* several typed INFO fields instead of the single key of _create: header-string indexes + kinds ('f' Float -> f32, 'i' Integer
+ * -> i32, 'b' Flag -> presence bitmap), up to EXON_HIP_MAX_INFO_FIELDS; call before the first parse */
 int exon_hip_bcf_parser_set_info_keys(exon_hip_bcf_parser* parser, const int32_t* keys, const char* kinds, int32_t n);
 int exon_hip_bcf_parser_parse(exon_hip_bcf_parser* parser, void* stream, const uint8_t* d_data, int64_t n_bytes,
                               exon_hip_vcf_columns* cols);

@@ -1,4 +1,4 @@
-//! Raw FFI of include/exon_hip.h (hand-written; bindgen would produce the same).  ABI version 2.
+//! Raw FFI of include/exon_hip.h (hand-written; bindgen would produce the same).  ABI version 3.
 //! `tests/test_shim_layout.py` parses the `#[repr(C)]` structs below and checks field order, offsets and sizes against
 //! `include/exon_hip.h` through a gcc-compiled `offsetof` dump, so this file cannot drift from the header unnoticed.
 #![allow(non_camel_case_types)]
@@ -14,7 +14,7 @@ pub struct exon_hip_stream { _p: [u8; 0] }
 #[repr(C)]
 pub struct exon_hip_scan { _p: [u8; 0] }
 
-pub const EXON_HIP_ABI_VERSION: i32 = 2;
+pub const EXON_HIP_ABI_VERSION: i32 = 3;
 pub const EXON_HIP_PLAN_REGION_COUNT: i32 = 2;
 pub const EXON_HIP_PLAN_FLAG_MAPQ_GROUP_COUNT: i32 = 3;
 pub const EXON_HIP_PLAN_CMP_AVG_BY_GROUP: i32 = 4;

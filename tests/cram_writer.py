@@ -99,7 +99,7 @@ IDS = dict(BF=1, CF=2, RI=3, RL=4, AP=5, RG=6, RN=7, MF=8, NS=9, NP=10, TS=11, N
            QS=19, BS=20, IN=21, SC=22, RS=23, PD=24, HC=25, LEN=26)
 
 
-def write_cram(path, refs, records, per_slice=700, slices_per_container=2, seed=0):
+def write_cram(path, refs, records, per_slice=700, slices_per_container=2, seed=0, ds_patch=None):
     """refs: [(name, length)]; records: dicts(flag, ref_id (-1 unmapped), pos (1-based, 0 none), mapq, name, rl, feats) with
     feats = [(read position, code, value)], code in I i D S N P H X.  Records are written in the given order; a run of records
     on one reference makes single-reference slices, mixed runs make multi-reference (-2) slices."""
@@ -125,6 +125,7 @@ def write_cram(path, refs, records, per_slice=700, slices_per_container=2, seed=
         ds["RN"] = enc_stop(0, IDS["RN"])
         ds["IN"] = enc_stop(9, IDS["IN"])
         ds["SC"] = enc_len(enc_external(IDS["LEN"]), enc_external(IDS["SC"]))
+        ds.update(ds_patch or {})  # tests: replace / add data-series encodings (raw bytes: codec id, length, parameters)
         dmap = itf8(len(ds)) + b"".join(k.encode() + v for k, v in ds.items())
         tmap = itf8(0)
         ch = block(1, 0, itf8(len(pmap)) + pmap + itf8(len(dmap)) + dmap + itf8(len(tmap)) + tmap)

@@ -172,6 +172,54 @@ def test_synthetic_cram_with_every_span_changing_feature(tmp_path):
             assert s2 == [want_start[i] for i in hit] and e2 == [want_end[i] for i in hit] and f2 == [want_flag[i] for i in hit]
 
 
+def test_hostile_compression_headers_and_flipped_bytes(tmp_path):
+    """ADVICE r2: (1) BYTE_ARRAY_LEN encodings nested tens of thousands deep must be an error, not a stack overflow;
+    (2) an encoding this reader does not implement (GOLOMB) is an error only when its series is actually read; (3) every
+    block carries a CRC-32 that is verified, so a flipped byte in a RAW external block cannot become wrong columns."""
+    from cram_writer import IDS, enc_external, enc_len, itf8, synthetic_records, write_cram
+    refs = [("chrA", 3_000_000)]
+    recs = synthetic_records(3000, refs, seed=3)
+
+    def rows(path):
+        scan = exon_amd.Scan(str(path), "cram")
+        n = sum(len(b) for b in scan)
+        scan.close()
+        return n
+    good = tmp_path / "good.cram"
+    write_cram(str(good), refs, recs, per_slice=500)
+    assert rows(good) == 3000
+    # (1) nesting: two levels is already outside the specification; 30 000 levels would need ~10 MB of stack
+    nested = enc_external(IDS["SC"])
+    for _ in range(30_000):
+        nested = enc_len(enc_external(IDS["LEN"]), nested)
+    for name, enc in (("two", enc_len(enc_len(enc_external(IDS["LEN"]), enc_external(IDS["SC"])), enc_external(IDS["SC"]))), ("deep", nested)):
+        p = tmp_path / f"nested_{name}.cram"
+        write_cram(str(p), refs, recs[:600], per_slice=500, ds_patch={"SC": enc})
+        with pytest.raises(exon_amd.ExonHipError, match="nested"):
+            rows(p)
+    # (2) GOLOMB (codec 2) on a series nobody reads (TC) is fine; on MQ it is the error
+    golomb = itf8(2) + itf8(2) + itf8(0) + itf8(3)
+    p = tmp_path / "unused_series.cram"
+    write_cram(str(p), refs, recs, per_slice=500, ds_patch={"TC": golomb})
+    assert rows(p) == 3000
+    p = tmp_path / "used_series.cram"
+    write_cram(str(p), refs, recs, per_slice=500, ds_patch={"MQ": golomb})
+    with pytest.raises(exon_amd.ExonHipError, match="encoding 2 is not supported"):
+        rows(p)
+    # (3) flip one payload byte of every kilobyte in turn until a RAW block is hit: always an error, never other columns
+    data = bytearray(good.read_bytes())
+    flipped = 0
+    for at in range(600, len(data) - 64, 997):
+        b = bytearray(data)
+        b[at] ^= 0x01
+        q = tmp_path / "flip.cram"
+        q.write_bytes(bytes(b))
+        with pytest.raises(exon_amd.ExonHipError):
+            rows(q)
+        flipped += 1
+    assert flipped > 20
+
+
 def test_corrupted_files_never_crash_the_reader(tmp_path):
     """800 random corruptions of the four fixtures (1-16 bytes overwritten, some files cut short): every one is either decoded
     or reported as an error -- no crash, no hang, no out-of-bounds read (sizes are checked against the bytes in hand)."""
