@@ -94,7 +94,7 @@ class VCFColumns(C.Structure):
                 ("pos_valid", C.c_void_p), ("qual", C.c_void_p), ("qual_valid", C.c_void_p), ("filter_id", C.c_void_p),
                 ("info", C.c_void_p), ("info_valid", C.c_void_p), ("consumed_bytes", C.c_int64),
                 ("n_info", C.c_int32), ("reserved", C.c_int32), ("infos", C.c_void_p * 16), ("infos_valid", C.c_void_p * 16),
-                ("info_kinds", C.c_char * 16)]
+                ("info_kinds", C.c_char * 16), ("list_offsets", C.c_void_p * 16), ("list_item_valid", C.c_void_p * 16)]
 
 
 class ScanOptions(C.Structure):

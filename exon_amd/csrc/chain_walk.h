@@ -39,8 +39,10 @@ constexpr uint32_t seg_cap() { return SEG / F::MIN_RECORD + 2; }  // most record
 
 template <class F>
 __global__ __launch_bounds__(64) void k_chain_walk(const uint8_t* __restrict__ d, uint32_t n, F fmt, SegInfo* __restrict__ seg,
-                                                   uint32_t* __restrict__ rec_off) {
+                                                   uint32_t* __restrict__ rec_off, unsigned* __restrict__ scalars) {
   const uint32_t s = blockIdx.x, lane = threadIdx.x;
+  // the slab's scalars start at zero: nothing in this kernel touches them, the kernels behind it (stream order) add
+  if (s == 0 && lane < 4) scalars[lane] = 0;
   const uint32_t lo = s * SEG, hi = min(n, lo + SEG);
   uint32_t start = NONE;
   if (s == 0) {
@@ -80,46 +82,52 @@ __global__ __launch_bounds__(64) void k_chain_walk(const uint8_t* __restrict__ d
   if (lane == 0) seg[s] = SegInfo{start, r, k, bad};
 }
 
+// buffers k_chain_check clears before the extract kernel ORs validity bits into them (round 3: these were three to five
+// hipMemsetAsync calls per slab, each a tiny kernel queued behind whatever else runs on the chip)
+struct ZeroList {
+  uint32_t* p[2 + 16];
+  int n;
+  uint32_t words;  // 32-bit words to clear in each
+};
+
 // scalars: [0] rows, [1] undecided, [2] consumed bytes.
-// The proof is a walk over the segments in order (one thread, the per-segment results cached in LDS): the chain that
-// enters segment s at `expected` must find start(s) == expected; a record longer than a segment makes the chain skip
-// whole segments, which are then ignored (whatever their guess was); the segment whose chain met the cut-off record
-// ends the slab.  Dynamic LDS: 3 * n_seg words.
+// The proof is a walk over the segments in order (one thread, the per-segment results cached in LDS as 16-byte entries:
+// one ds_read_b128 per step, the next segment's entry already in flight -- the chain nearly always advances by one
+// segment): the chain that enters segment s at `expected` must find start(s) == expected; a record longer than a
+// segment makes the chain skip whole segments, which are then ignored (whatever their guess was); the segment whose chain
+// met the cut-off record ends the slab.  Dynamic LDS: 4 * n_seg words.
 template <int UNUSED = 0>  // a template only so that several translation units may include this header
 __global__ __launch_bounds__(1024) void k_chain_check(SegInfo* __restrict__ seg, uint32_t n_seg, uint32_t* __restrict__ base,
-                                                      unsigned* __restrict__ scalars) {
-  extern __shared__ uint32_t chain_lds[];
-  uint32_t* st = chain_lds;              // start(s); NONE marks a segment that turned out inactive
-  uint32_t* ld = chain_lds + n_seg;      // landing(s)
-  uint32_t* bd = chain_lds + 2 * n_seg;  // bad(s)
+                                                      unsigned* __restrict__ scalars, const ZeroList zl) {
+  extern __shared__ uint4 chain_lds[];  // {start, landing, bad, count}; start = NONE marks a segment that turned out inactive
   __shared__ unsigned part[1024];
   __shared__ unsigned s_last, s_err;
   for (uint32_t s = threadIdx.x; s < n_seg; s += 1024) {
     const SegInfo a = seg[s];
-    st[s] = a.start;
-    ld[s] = a.landing;
-    bd[s] = a.bad;
+    chain_lds[s] = uint4{a.start, a.landing, a.bad, a.count};
   }
+  for (int b = 0; b < zl.n; ++b)
+    for (uint32_t i = threadIdx.x; i < zl.words; i += 1024) zl.p[b][i] = 0;
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned err = 0;
     uint32_t expected = 0, last = n_seg - 1;
+    uint4 nxt = chain_lds[0];
     for (uint32_t s = 0; s < n_seg; ++s) {
+      const uint4 cur = nxt;
+      if (s + 1 < n_seg) nxt = chain_lds[s + 1];
       const uint32_t hi = (s + 1) * SEG;  // the last segment is shorter, but no chain position lies beyond the slab
       if (expected >= hi) {               // covered by a record that started earlier
-        st[s] = NONE;
+        chain_lds[s].x = NONE;
         continue;
       }
-      if (st[s] != expected || bd[s] == 1) {
+      if (cur.x != expected || cur.z == 1) {
         err = 1;
         break;
       }
-      expected = ld[s];
-      if (bd[s] == 2) {  // the cut-off record: everything behind it is its bytes
-        last = s;
-        break;
-      }
+      expected = cur.y;
       last = s;
+      if (cur.z == 2) break;  // the cut-off record: everything behind it is its bytes
     }
     s_last = last;
     s_err = err;
@@ -130,8 +138,12 @@ __global__ __launch_bounds__(1024) void k_chain_check(SegInfo* __restrict__ seg,
   const uint32_t s0 = threadIdx.x * per, s1 = min(n_seg, s0 + per);
   unsigned sum = 0;
   for (uint32_t s = s0; s < s1; ++s) {
-    if (s > last || st[s] == NONE) seg[s].count = 0;
-    else sum += seg[s].count;
+    if (s > last || chain_lds[s].x == NONE) {
+      seg[s].count = 0;
+      chain_lds[s].w = 0;
+    } else {
+      sum += chain_lds[s].w;
+    }
   }
   part[threadIdx.x] = sum;
   __syncthreads();
@@ -144,11 +156,11 @@ __global__ __launch_bounds__(1024) void k_chain_check(SegInfo* __restrict__ seg,
   unsigned run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
   for (uint32_t s = s0; s < s1; ++s) {
     base[s] = run;
-    run += seg[s].count;
+    run += chain_lds[s].w;
   }
   if (threadIdx.x == 1023) {
     scalars[0] = part[1023];
-    scalars[2] = ld[last];
+    scalars[2] = chain_lds[last].y;
   }
   __syncthreads();
   if (threadIdx.x == 0 && s_err) atomicAdd(&scalars[1], 1u);

@@ -176,7 +176,10 @@ struct FilterTable {
 constexpr int MAX_INFO = EXON_HIP_MAX_INFO_FIELDS;  // 16: the by-value key table below is 16 x 9 bytes of kernel arguments
 // the typed INFO fields a parser extracts (InfosBuilder children: exon-vcf/src/array_builder/info_builder.rs:152-309):
 // kind 'f' = Number=1 Float -> f32 + validity; 'i' = Number=1 Integer -> i32 + validity (the 4-byte column holds the bit
-// pattern); 'b' = Flag -> presence bitmap (value true where valid)
+// pattern); 'b' = Flag -> presence bitmap (value true where valid); 'F' / 'I' = any other Number of Float / Integer ->
+// List<f32> / List<i32> (info_builder.rs:258-305): k_parse_lines records where the value text is and how many items it has,
+// k_list_fill parses the items behind an exclusive scan of the counts (offsets), k_pack_bits turns the per-item flags
+// into the child validity bitmap.  info_valid[q] is the LIST validity (NULL list: key absent, `key=.`, INFO '.')
 struct InfoKeys {
   int n;
   int len[MAX_INFO];
@@ -193,6 +196,8 @@ struct ParseOut {
   int32_t* filter_id;
   float* info[MAX_INFO];
   uint8_t* info_valid[MAX_INFO];
+  uint32_t* lv_off[MAX_INFO];  // list kinds: offset of the value text in the slab / number of items, per row
+  uint32_t* lv_cnt[MAX_INFO];
   unsigned* exceptions;  // [0] = count of rows the device could not decide
 };
 
@@ -259,6 +264,8 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
       out.pos[row] = 0;
       out.qual[row] = 0.f;
       out.filter_id[row] = 0;
+      for (int q = 0; q < ik.n; ++q)
+        if (ik.kind[q] == 'F' || ik.kind[q] == 'I') out.lv_cnt[q][row] = 0;  // summed by the offsets scan
     } else {
       // CHROM
       {
@@ -378,7 +385,13 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
                 const int vl = (int)(j - vb);
                 if (!(vl == 0 || (vl == 1 && text[vb] == '.'))) {
                   uint32_t bits;
-                  if (ik.kind[q] == 'i') {
+                  if (ik.kind[q] == 'F' || ik.kind[q] == 'I') {
+                    unsigned items = 1;  // items are separated by ','; they are parsed by k_list_fill
+                    for (int k = 0; k < vl; ++k) items += text[vb + k] == ',';
+                    out.lv_off[q][row] = vb;
+                    out.lv_cnt[q][row] = items;
+                    info_ok |= 1u << q;
+                  } else if (ik.kind[q] == 'i') {
                     // Type=Integer: exact int32 ([+-] digits); the value travels as its bit pattern in the 4-byte column.
                     // Anything else (including out of range) is the reference's parse error: the row is left to the host
                     int k = 0;
@@ -425,8 +438,11 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
           }
           if (left > 0 && i < ie) entry(ie);  // the last entry has no ';' behind it
         }
-        for (int q = 0; q < ik.n; ++q)
-          if (ik.kind[q] != 'b' && !(info_ok >> q & 1u)) out.info[q][row] = 0.f;  // NULL slots hold a defined value
+        for (int q = 0; q < ik.n; ++q) {
+          if (info_ok >> q & 1u) continue;
+          if (ik.kind[q] == 'F' || ik.kind[q] == 'I') out.lv_cnt[q][row] = 0;  // NULL list: no items
+          else if (ik.kind[q] != 'b') out.info[q][row] = 0.f;                   // NULL slots hold a defined value
+        }
       }
     }
   }
@@ -508,6 +524,95 @@ static hipError_t build_name_table(exon_hip_ctx* ctx, const char* const* names_i
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// ---- list-valued INFO fields ('F' / 'I'): offsets by a scan of the per-row item counts, then the items ------------------
+constexpr int LIST_TPB = 256;
+// per-workgroup sums of cnt[0 .. n_rows) (n_rows read from the device: the line count of this slab)
+__global__ __launch_bounds__(LIST_TPB) void k_list_block_sums(const uint32_t* __restrict__ cnt, const unsigned* __restrict__ n_rows_p,
+                                                              unsigned cap, unsigned* __restrict__ block_sums) {
+  __shared__ unsigned red[LIST_TPB / 64];
+  const unsigned n_rows = min(*n_rows_p, cap);
+  const unsigned row = blockIdx.x * LIST_TPB + threadIdx.x;
+  unsigned c = row < n_rows ? cnt[row] : 0u;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// offsets[row] = exclusive prefix of cnt (block_offsets = scanned block sums), offsets[n_rows] = total; every row parses its
+// items into values[offsets[row] ..]: '.' or an empty item -> NULL item (flag 0), anything unparsable -> undecided (host)
+__global__ __launch_bounds__(LIST_TPB) void k_list_fill(const uint8_t* __restrict__ text, unsigned n_total, const uint32_t* __restrict__ lv_off,
+                                                        const uint32_t* __restrict__ cnt, const unsigned* __restrict__ block_offsets,
+                                                        const unsigned* __restrict__ n_rows_p, unsigned cap, unsigned cap_items, char kind,
+                                                        int32_t* __restrict__ offsets, float* __restrict__ values,
+                                                        uint8_t* __restrict__ item_flags, unsigned* __restrict__ exceptions) {
+  __shared__ unsigned wave_tot[LIST_TPB / 64];
+  const unsigned n_rows = min(*n_rows_p, cap);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned row = blockIdx.x * LIST_TPB + threadIdx.x;
+  const unsigned c = row < n_rows ? cnt[row] : 0u;
+  unsigned incl = c;
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  unsigned base = block_offsets[blockIdx.x];
+  for (int w = 0; w < wave; ++w) base += wave_tot[w];
+  const unsigned first = base + incl - c;
+  if (row < n_rows) offsets[row] = (int32_t)first;
+  if (row + 1 == n_rows) offsets[n_rows] = (int32_t)(first + c);
+  if (row == 0 && n_rows == 0) offsets[0] = 0;
+  if (row >= n_rows || c == 0) return;
+  if ((uint64_t)first + c > cap_items) {  // cannot happen for cap_items = slab bytes / 2 + 1 (an item and its comma take 2 bytes)
+    atomicAdd(exceptions, 1u);
+    return;
+  }
+  unsigned a = lv_off[row];
+  bool bad = false;
+  for (unsigned i = 0; i < c; ++i) {
+    unsigned e = a;
+    while (e < n_total && text[e] != ',' && text[e] != ';' && text[e] != '\t' && text[e] != '\n' && text[e] != '\r') ++e;
+    const int len = (int)(e - a);
+    uint32_t bits = 0;
+    bool ok = false;
+    if (!(len == 0 || (len == 1 && text[a] == '.'))) {
+      if (kind == 'I') {
+        int k = 0;
+        const bool neg = text[a] == '-';
+        if (neg || text[a] == '+') k = 1;
+        int64_t iv = 0;
+        ok = k < len && len - k <= 10;
+        for (; k < len && ok; ++k) {
+          const unsigned d = (unsigned)text[a + k] - '0';
+          ok = d <= 9u;
+          iv = iv * 10 + d;
+        }
+        if (neg) iv = -iv;
+        ok = ok && iv >= INT32_MIN && iv <= INT32_MAX;
+        bits = (uint32_t)(int32_t)iv;
+      } else {
+        ok = exon::dec::parse_f32(reinterpret_cast<const char*>(text + a), len, &bits);
+      }
+      if (!ok) bad = true;
+    }
+    values[first + i] = __uint_as_float(ok ? bits : 0u);
+    item_flags[first + i] = ok ? 1 : 0;
+    a = e + 1;
+  }
+  if (bad) atomicAdd(exceptions, 1u);
+}
+// byte-per-item flags -> Arrow validity bitmap (8 items per thread); n = offsets[n_rows]
+__global__ __launch_bounds__(256) void k_pack_bits(const uint8_t* __restrict__ flags, const int32_t* __restrict__ offsets,
+                                                   const unsigned* __restrict__ n_rows_p, unsigned cap, uint8_t* __restrict__ bitmap) {
+  const unsigned n = (unsigned)offsets[min(*n_rows_p, cap)];
+  for (unsigned b = blockIdx.x * 256 + threadIdx.x; b * 8 < n; b += gridDim.x * 256) {
+    unsigned v = 0;
+    for (unsigned k = 0; k < 8 && b * 8 + k < n; ++k) v |= (unsigned)(flags[b * 8 + k] & 1) << k;
+    bitmap[b] = (uint8_t)v;
+  }
+}
+
 struct exon_hip_vcf_parser {
   exon_hip_ctx* ctx = nullptr;
   int64_t max_bytes = 0, max_rows = 0;
@@ -521,6 +626,10 @@ struct exon_hip_vcf_parser {
   FilterTable filters{};
   ParseOut out{};
   void* out_bufs[6 + 2 * MAX_INFO] = {nullptr};
+  // list kinds: per key { value offsets per row, item counts per row, Arrow offsets [rows + 1], item flags, item validity bitmap }
+  void* list_bufs[5 * MAX_INFO] = {nullptr};
+  unsigned* d_list_blocks = nullptr;  // per-workgroup sums of the item counts (scanned in place)
+  int64_t cap_items = 0;
   unsigned* h_scalars = nullptr;  // pinned mirror of d_scalars
 };
 
@@ -571,7 +680,7 @@ int exon_hip_vcf_parser_create(exon_hip_ctx* ctx, const char* const* contig_name
       std::string item = f.substr(i, j - i);
       char kind = 'f';
       const size_t c = item.rfind(':');
-      if (c != std::string::npos && c + 2 == item.size() && (item[c + 1] == 'f' || item[c + 1] == 'b' || item[c + 1] == 'i')) {
+      if (c != std::string::npos && c + 2 == item.size() && (item[c + 1] == 'f' || item[c + 1] == 'b' || item[c + 1] == 'i' || item[c + 1] == 'F' || item[c + 1] == 'I')) {
         kind = item[c + 1];
         item.resize(c);
       }
@@ -599,9 +708,20 @@ int exon_hip_vcf_parser_create(exon_hip_ctx* ctx, const char* const* contig_name
   dalloc(&p->out_bufs[3], r * 4);
   dalloc(&p->out_bufs[4], rb);
   dalloc(&p->out_bufs[5], r * 4);
+  p->cap_items = max_bytes / 2 + 1;  // an item and its separator take at least two bytes of the slab
   for (int q = 0; q < p->ik.n; ++q) {
-    if (p->ik.kind[q] == 'f' || p->ik.kind[q] == 'i') dalloc(&p->out_bufs[6 + 2 * q], r * 4);
+    const char kind = p->ik.kind[q];
+    if (kind == 'f' || kind == 'i') dalloc(&p->out_bufs[6 + 2 * q], r * 4);
     dalloc(&p->out_bufs[7 + 2 * q], rb);
+    if (kind == 'F' || kind == 'I') {
+      dalloc(&p->out_bufs[6 + 2 * q], (size_t)p->cap_items * 4);  // the items
+      dalloc(&p->list_bufs[5 * q + 0], r * 4);
+      dalloc(&p->list_bufs[5 * q + 1], r * 4);
+      dalloc(&p->list_bufs[5 * q + 2], (r + 1) * 4);
+      dalloc(&p->list_bufs[5 * q + 3], (size_t)p->cap_items);
+      dalloc(&p->list_bufs[5 * q + 4], (size_t)p->cap_items / 8 + 64);
+      if (!p->d_list_blocks) dalloc((void**)&p->d_list_blocks, (r / LIST_TPB + 2) * 4);
+    }
   }
   if (e == hipSuccess) e = hipHostMalloc((void**)&p->h_scalars, 16);
   if (e != hipSuccess) {
@@ -619,6 +739,8 @@ int exon_hip_vcf_parser_create(exon_hip_ctx* ctx, const char* const* contig_name
   for (int q = 0; q < p->ik.n; ++q) {
     p->out.info[q] = (float*)p->out_bufs[6 + 2 * q];
     p->out.info_valid[q] = (uint8_t*)p->out_bufs[7 + 2 * q];
+    p->out.lv_off[q] = (uint32_t*)p->list_bufs[5 * q + 0];
+    p->out.lv_cnt[q] = (uint32_t*)p->list_bufs[5 * q + 1];
   }
   p->out.exceptions = p->d_scalars + 1;
   *outp = p;
@@ -641,6 +763,9 @@ int exon_hip_vcf_parser_destroy(exon_hip_vcf_parser* p) {
   if (p->d_nl) exon_pool_free(p->ctx, p->d_nl);
   if (p->d_scalars) exon_pool_free(p->ctx, p->d_scalars);
   if (p->d_info_key) exon_pool_free(p->ctx, p->d_info_key);
+  for (void* b : p->list_bufs)
+    if (b) exon_pool_free(p->ctx, b);
+  if (p->d_list_blocks) exon_pool_free(p->ctx, p->d_list_blocks);
   if (p->h_scalars) hipHostFree(p->h_scalars);
   delete p;
   return EXON_HIP_OK;
@@ -672,6 +797,19 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* p, void* stream, const uint8_
                      p->ik, p->out, (unsigned)row_bound, skip, (unsigned)n_bytes);
   hipLaunchKernelGGL(k_assign_filters, dim3(1), dim3(256), 0, s, d_text, p->filters);
   hipLaunchKernelGGL(k_remap_filters, dim3(std::min(pblocks, 4096)), dim3(TPB), 0, s, p->out.filter_id, p->d_scalars, p->filters.ids, (unsigned)row_bound);
+  for (int q = 0; q < p->ik.n; ++q) {  // list-valued fields: counts -> offsets -> items -> child validity
+    const char kind = p->ik.kind[q];
+    if (kind != 'F' && kind != 'I') continue;
+    const int lblocks = (int)((row_bound + LIST_TPB - 1) / LIST_TPB);
+    int32_t* offsets = (int32_t*)p->list_bufs[5 * q + 2];
+    hipLaunchKernelGGL(k_list_block_sums, dim3(lblocks), dim3(LIST_TPB), 0, s, p->out.lv_cnt[q], p->d_scalars, (unsigned)row_bound, p->d_list_blocks);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, p->d_list_blocks, lblocks, p->d_scalars + 3);
+    hipLaunchKernelGGL(k_list_fill, dim3(lblocks), dim3(LIST_TPB), 0, s, d_text, (unsigned)n_bytes, p->out.lv_off[q], p->out.lv_cnt[q], p->d_list_blocks,
+                       p->d_scalars, (unsigned)row_bound, (unsigned)std::min<int64_t>(p->cap_items, 0xFFFFFFFFLL), kind, offsets, p->out.info[q],
+                       (uint8_t*)p->list_bufs[5 * q + 3], p->out.exceptions);
+    hipLaunchKernelGGL(k_pack_bits, dim3(1024), dim3(256), 0, s, (const uint8_t*)p->list_bufs[5 * q + 3], offsets, p->d_scalars, (unsigned)row_bound,
+                       (uint8_t*)p->list_bufs[5 * q + 4]);
+  }
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(p->h_scalars, p->d_scalars, 12, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -693,6 +831,10 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* p, void* stream, const uint8_
     cols->infos[q] = p->out.info[q];  // NULL for a Flag: its column IS the presence bitmap
     cols->infos_valid[q] = p->out.info_valid[q];
     cols->info_kinds[q] = p->ik.kind[q];
+    if (p->ik.kind[q] == 'F' || p->ik.kind[q] == 'I') {
+      cols->list_offsets[q] = (int32_t*)p->list_bufs[5 * q + 2];
+      cols->list_item_valid[q] = (uint8_t*)p->list_bufs[5 * q + 4];
+    }
   }
   return EXON_HIP_OK;
 }

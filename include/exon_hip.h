@@ -430,10 +430,16 @@ typedef struct exon_hip_vcf_columns {
   void* infos[EXON_HIP_MAX_INFO_FIELDS];
   uint8_t* infos_valid[EXON_HIP_MAX_INFO_FIELDS];
   char info_kinds[EXON_HIP_MAX_INFO_FIELDS];
+  /* list-valued fields, info_kinds[k] = 'F' (List<f32>) / 'I' (List<i32>) -- any Number other than 0 / 1
+   * (schema_builder.rs:235-249): Arrow List layout.  infos_valid[k] = validity of the LIST per row (NULL list: key absent,
+   * `key=.`, INFO '.'), list_offsets[k] = int32 offsets [n_rows + 1] into the items, infos[k] = the items,
+   * list_item_valid[k] = validity of the items (a '.' item is a NULL item: info_builder.rs:258-305).  NULL for scalar kinds. */
+  int32_t* list_offsets[EXON_HIP_MAX_INFO_FIELDS];
+  uint8_t* list_item_valid[EXON_HIP_MAX_INFO_FIELDS];
 } exon_hip_vcf_columns;
 /* info_field: NULL, or up to EXON_HIP_MAX_INFO_FIELDS comma-separated INFO keys "name[:kind]" -- kind f (default): Number=1
- * Float -> f32; kind i: Number=1 Integer -> i32; kind b: Flag -> presence bitmap.  (String and list-valued INFO fields are
- * decoded by the host reader only.) */
+ * Float -> f32; kind i: Number=1 Integer -> i32; kind b: Flag -> presence bitmap; kinds F / I: list-valued Float / Integer
+ * fields -> List<f32> / List<i32>.  (String INFO fields, scalar or list, are decoded by the host reader only.) */
 int exon_hip_vcf_parser_create(exon_hip_ctx* ctx, const char* const* contig_names, int32_t n_contigs,
                                const char* info_field, int64_t max_slab_bytes, exon_hip_vcf_parser** out);
 /* d_text: a slab of '\n'-terminated data lines in HBM, any alignment (a trailing partial line is left to the

@@ -149,6 +149,45 @@ def test_gpu_vcf_parser_typed_info(ctx, tmp_path):
     par.close()
 
 
+@pytest.mark.gpu
+def test_gpu_vcf_parser_list_valued_info(ctx, tmp_path):
+    """List<Int32> / List<Float32> INFO fields decoded on the device (Arrow List layout: list validity, int32 offsets, items,
+    item validity) == the rows the file was written from; Number=1 Integer next to them stays an exact Int32 column."""
+    import vcf_bcf_writer as W
+    rows = W.make_rows(20_000, seed=5)
+    path = tmp_path / "l.vcf"
+    W.write_vcf(path, rows)
+    raw = open(path, "rb").read()
+    body = raw[raw.index(b"#CHROM"):]
+    text = body[body.index(b"\n") + 1:]
+    par = exon_amd.VCFParser(ctx, ["1", "2"], info_field="AC:I,MQS:F,DP:i", max_slab_bytes=len(text) + 4096)
+    d = ctx.to_device(np.frombuffer(text + bytes(64), np.uint8))
+    cols = par.parse_device(d.ptr, len(text))
+    n = cols.n_rows
+    assert n == len(rows) and cols.n_undecided == 0 and cols.n_info == 3 and cols.info_kinds[:3] == b"IFi"
+
+    def dev(ptr, dtype, count):
+        out = np.empty(count, dtype)
+        if count:
+            ctx._check(ctx.lib.exon_hip_memcpy_d2h(ctx.h, out.ctypes.data, ptr, out.nbytes, None))
+        return out
+    for k, (key, dtype) in enumerate((("AC", np.int32), ("MQS", np.float32))):
+        want = W.expected_column(rows, key)
+        valid = _bits(dev(cols.infos_valid[k], np.uint8, (n + 7) // 8), n)
+        off = dev(cols.list_offsets[k], np.int32, n + 1)
+        total = int(off[-1])
+        items = dev(cols.infos[k], dtype, total)
+        ivalid = _bits(dev(cols.list_item_valid[k], np.uint8, (total + 7) // 8), total) if total else np.zeros(0, bool)
+        assert off[0] == 0 and np.all(np.diff(off) >= 0) and total == sum(len(x) for x in want if x is not None)
+        got = [None if not valid[r] else [items[i].item() if ivalid[i] else None for i in range(off[r], off[r + 1])] for r in range(n)]
+        assert got == want, key
+    dp = W.expected_column(rows, "DP")
+    v = _bits(dev(cols.infos_valid[2], np.uint8, (n + 7) // 8), n)
+    vals = dev(cols.infos[2], np.int32, n)
+    assert [vals[r].item() if v[r] else None for r in range(n)] == dp
+    par.close()
+
+
 def _k4(ctx, path, fmt, fields, columns, gpu_parse, thr):
     scan = exon_amd.Scan(str(path), fmt, info_field=fields, gpu_parse=gpu_parse)
     plan = ctx.plan_cmp_avg_by_group(">", thr, 64, columns=columns)
