@@ -205,6 +205,7 @@ SIGNATURES = {
     "exon_hip_bgzf_scan": (C.c_int, [_vp, C.c_size_t, C.c_size_t, C.POINTER(BgzfBlock), _i32, C.POINTER(_i32),
                                      C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "exon_hip_bgzf_inflate": (C.c_int, [_vp, _vp, _vp, C.POINTER(BgzfBlock), _i32, _vp, _i32, C.POINTER(_i32)]),
+    "exon_hip_bgzf_forget_stream": (C.c_int, [_vp]),
     "exon_hip_bgzf_inflate_par_stats": (C.c_int, [_vp, _vp]),
 }
 

@@ -1770,11 +1770,17 @@ unsigned* par_stats_buffer(int dev) {
 uint8_t* par_pool(int dev, hipStream_t s, int want) {
   std::lock_guard<std::mutex> g(g_par_mu);
   auto key = std::make_pair(dev, s);
-  if (!g_par_pools.count(key) && g_par_pools.size() >= 8) return nullptr;  // more streams than this inflate serially
+  if (!g_par_pools.count(key)) {  // at most 8 pools PER DEVICE (a 9th stream on a device inflates serially)
+    int on_dev = 0;
+    for (const auto& kv : g_par_pools) on_dev += kv.first.first == dev;
+    if (on_dev >= 8) return nullptr;
+  }
   ParPool& p = g_par_pools[key];
   if (p.slots < want) {
-    int n = 64;
-    while (n < want) n *= 2;
+    // sized to the launch (rounded to 64 slots), not to the next power of two: a slot is ~0.94 MiB, so the AUTO mode's
+    // largest launch (1536 members) keeps ~1.4 GB per inflating stream instead of 2 GB, EXON_HIP_INFLATE_PAR=1's 4096
+    // slots 3.8 GB.  The pool stays with the stream until exon_hip_bgzf_forget_stream / the owner's destructor.
+    const int n = (want + 63) / 64 * 64;
     if (p.mem) {  // kernels queued on `s` may still use the old block
       if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
       hipFree(p.mem);
@@ -1793,7 +1799,11 @@ uint8_t* par_pool(int dev, hipStream_t s, int want) {
 bool par_side(int dev, hipStream_t s, ParSide* out) {
   std::lock_guard<std::mutex> g(g_par_mu);
   auto key = std::make_pair(dev, s);
-  if (!g_par_side.count(key) && g_par_side.size() >= 8) return false;
+  if (!g_par_side.count(key)) {
+    int on_dev = 0;
+    for (const auto& kv : g_par_side) on_dev += kv.first.first == dev;
+    if (on_dev >= 8) return false;
+  }
   ParSide& p = g_par_side[key];
   if (!p.side) {
     if (hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p.ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -1827,22 +1837,33 @@ extern "C" int exon_hip_bgzf_inflate_par_stats(void* stream, uint32_t* out32) {
 }
 
 void exon_bgzf_forget_stream(hipStream_t s) {
-  int dev = 0;
-  if (!s || hipGetDevice(&dev) != hipSuccess) return;
+  if (!s) return;
   std::lock_guard<std::mutex> g(g_par_mu);
-  auto key = std::make_pair(dev, s);
-  auto it = g_par_pools.find(key);
-  if (it != g_par_pools.end()) {
-    if (it->second.mem) hipFree(it->second.mem);
-    g_par_pools.erase(it);
+  // keyed on the STREAM, whatever device is current here: a stream belongs to exactly one device
+  for (auto it = g_par_pools.begin(); it != g_par_pools.end();) {
+    if (it->first.second == s) {
+      if (it->second.mem) hipFree(it->second.mem);
+      it = g_par_pools.erase(it);
+    } else {
+      ++it;
+    }
   }
-  auto sd = g_par_side.find(key);
-  if (sd != g_par_side.end()) {
-    if (sd->second.side) hipStreamDestroy(sd->second.side);
-    if (sd->second.ev_fork) hipEventDestroy(sd->second.ev_fork);
-    if (sd->second.ev_join) hipEventDestroy(sd->second.ev_join);
-    g_par_side.erase(sd);
+  for (auto sd = g_par_side.begin(); sd != g_par_side.end();) {
+    if (sd->first.second == s) {
+      if (sd->second.side) hipStreamDestroy(sd->second.side);
+      if (sd->second.ev_fork) hipEventDestroy(sd->second.ev_fork);
+      if (sd->second.ev_join) hipEventDestroy(sd->second.ev_join);
+      sd = g_par_side.erase(sd);
+    } else {
+      ++sd;
+    }
   }
+}
+
+// public form for caller-owned streams handed to exon_hip_bgzf_inflate: releases the scratch kept for `stream` (idle stream)
+extern "C" int exon_hip_bgzf_forget_stream(void* stream) {
+  exon_bgzf_forget_stream((hipStream_t)stream);
+  return EXON_HIP_OK;
 }
 
 hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const exon_hip_bgzf_block* d_blocks, int n_blocks,

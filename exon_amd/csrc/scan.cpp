@@ -555,7 +555,12 @@ class GpuTextSource {
       }
       complete_ = true;
     }
-    if ((bgzf_ && !cs_ && hipStreamCreateWithFlags(&cs_, hipStreamNonBlocking) != hipSuccess) ||
+    // the inflate stream runs at the LOWEST priority: its kernels fill every workgroup slot for milliseconds, and the parse
+    // kernels of the previous slab (the consumer's stream, highest priority: stream.cpp) are short and on the critical path
+    int prio_least = 0, prio_greatest = 0;
+    const char* pv = getenv("EXON_HIP_STREAM_PRIORITY");
+    const bool use_prio = !(pv && pv[0] == '0') && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess && prio_least != prio_greatest;
+    if ((bgzf_ && !cs_ && (use_prio ? hipStreamCreateWithPriority(&cs_, hipStreamNonBlocking, prio_least) : hipStreamCreateWithFlags(&cs_, hipStreamNonBlocking)) != hipSuccess) ||
         (!xs_ && hipStreamCreateWithFlags(&xs_, hipStreamNonBlocking) != hipSuccess))
       return fail(ctx_, EXON_HIP_EDEVICE, "stream creation failed");
     for (int k = 0; k < 2; ++k)

@@ -462,7 +462,15 @@ int exon_hip_stream_open(exon_hip_plan* plan, int32_t partition, exon_hip_stream
   hipSetDevice(ctx->device);
   hipError_t e;
   const size_t sbytes = (size_t)(plan->n_i64 + plan->n_f64) * 8;
-  if ((e = hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking)) != hipSuccess ||
+  // The partition's stream carries the parse + filter/aggregate kernels of the file pipelines: many short kernels that
+  // must not queue behind the thousands of workgroups of the NEXT slab's inflate (its own, lower-priority stream in
+  // scan.cpp) -- rocprofv3 showed 16-byte fills and single-workgroup scans "taking" milliseconds there.
+  // EXON_HIP_STREAM_PRIORITY=0: plain streams (A/B runs).
+  int prio_least = 0, prio_greatest = 0;
+  const char* pv = getenv("EXON_HIP_STREAM_PRIORITY");
+  const bool use_prio = !(pv && pv[0] == '0') && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess && prio_least != prio_greatest;
+  if ((e = use_prio ? hipStreamCreateWithPriority(&st->stream, hipStreamNonBlocking, prio_greatest)
+                    : hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipMalloc((void**)&st->d_state, sbytes)) != hipSuccess ||
       (e = hipMemsetAsync(st->d_state, 0, sbytes, st->stream)) != hipSuccess) {
     if (st->stream) hipStreamDestroy(st->stream);

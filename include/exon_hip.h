@@ -472,6 +472,10 @@ int exon_hip_bgzf_scan(const uint8_t* data, size_t n, size_t out_base, exon_hip_
  * `stream`.  A corrupt block -> EXON_HIP_EINVAL and *first_bad_block (else -1): inflate on the host instead. */
 int exon_hip_bgzf_inflate(exon_hip_ctx* ctx, void* stream, const uint8_t* d_comp, const exon_hip_bgzf_block* blocks,
                           int32_t n_blocks, uint8_t* d_out, int32_t verify_crc, int32_t* first_bad_block);
+/* The lane-parallel decoder keeps ~0.94 MiB of scratch per resident workgroup in a pool per (device, stream) -- up to ~1.4 GB
+ * for a stream that inflated a 1536-member launch -- until the stream's owner lets go: streams the library owns do that
+ * themselves; for a caller-owned `stream` passed to exon_hip_bgzf_inflate call this once the stream is idle. */
+int exon_hip_bgzf_forget_stream(void* stream);
 /* Diagnostics of the lane-parallel block decoder (used for launches of up to 1536 members unless
  * EXON_HIP_INFLATE_PAR says otherwise: 0 = never, 1 = always, 2 = side by side with the serial kernel): out32[0] = DEFLATE blocks
  * it decoded on the current device since the process started, out32[1..15] = blocks it handed back to the serial symbol loop, by
