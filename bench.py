@@ -4,14 +4,15 @@
     SET exon.vcf_parse_info = true;
     SELECT filter, AVG(qual), COUNT(*) FROM v WHERE info."AF" > 0.01 GROUP BY filter
 
-One "step" = one full pass of the fused filter+aggregate kernel over this rank's HBM-resident shard followed -- when
-N > 1 -- by the merge of the packed partial states (5 x {2 x i64 count, f64 sum} = 120 B): ONE RCCL all-gather and a
-fold in rank order.  The kernel's finalize WRITES the state (EXON_HIP_LAUNCH_OVERWRITE): no zeroing pass in the step.
+One "step" = one full pass of the fused filter+aggregate kernel over this rank's HBM-resident shard (ONE launch: the last
+workgroup folds the per-workgroup records and WRITES the state -- EXON_HIP_LAUNCH_OVERWRITE, no zeroing pass) followed --
+when N > 1 -- by the merge of the packed partial states (5 x {2 x i64 count, f64 sum} = 120 B): ONE RCCL all-gather and a
+fold in rank order.
 
 Scaling ("1 B rows, 8 equal shards"):
   --scaling strong (default)  --rows is the TOTAL (default 1e9); rank k owns rows [k N/W, (k+1) N/W)
   --scaling weak              --rows is per GPU; the table grows with the number of GPUs
-Launch: `python bench.py --gpus 1` or
+Launch: `python bench.py --gpus N` (N > 1 without a launcher: the script starts its own N ranks) or
 `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N --steps K --warmup W`.
 Prints ONE JSON line on rank 0.
 """
@@ -446,7 +447,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         ev[i][0].record()
-        wl.run()  # the hot path's kernels only: main + finalize (c5: per batch, offsets scan + main + finalize)
+        wl.run()  # the hot path's kernel only (one launch; c5: offsets scan + main + fold)
         ev[i][1].record()
         merge()   # AggregateExec(Final) across GPUs: one all-gather over RCCL/xGMI + fixed-order fold
     torch.cuda.synchronize()
@@ -487,8 +488,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel_ms": round(kern_ms, 4),
-                         "note": "achieved = rows_per_gpu x bytes_per_row / mean HIP-event time of one launch (main + finalize "
-                                 "kernels, max over ranks); the finalize writes the state, there is no zeroing pass"},
+                         "note": "achieved = rows_per_gpu x bytes_per_row / mean HIP-event time of one launch (max over ranks).  A launch is "
+                                 "ONE kernel: the last workgroup to finish folds the per-workgroup records and writes the state "
+                                 "(no finalize launch, no zeroing pass); c5: offsets scan + main + fold"},
         }
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(traffic_file):

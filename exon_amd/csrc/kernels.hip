@@ -785,9 +785,17 @@ hipError_t launch_flag_mapq_group_count(hipStream_t s, const LaunchCfg& cfg, con
 //   for 64 and 4096 keys, uniform and skewed): a CU issues one wave64 vector instruction per clock, so every instruction
 //   per row is 0.025 ms per 1e9 rows.  Hence 4 register groups instead of 8 (4 instead of 8 conditional f64 adds, 32-bit
 //   packed counters), the predicate evaluated once per row for all tiers, one LDS address per row.
-struct K4Tail {                 // tier 3 (nullptr / unused when NG == NL)
+constexpr int K4_TAIL_RANGE = 8192;  // ids per range of the partitioned tier 3 = entries of k4_tail_aggregate's LDS table (128 KiB)
+struct K4Tail {                 // tier 3 (unused when NG == NL)
   unsigned long long* counts;   // the caller's [cnn[NG]] [crow[NG]]
   double* sums;                 // the caller's [sum[NG]]
+  // partitioned form (round 3, default): instead of three global atomics per row the main kernel COMPACTS the tier-3 rows
+  // into a private region per workgroup -- records {id | y-valid << 31, y bits} -- and counts them per id range of
+  // K4_TAIL_RANGE ids; k4_tail_scatter then groups the records by range and k4_tail_aggregate runs the LDS table over
+  // each range.  rec == nullptr: the atomic form (EXON_HIP_K4_TAIL_ATOMICS=1, and the short tail loop of a launch).
+  uint2* rec;                   // [grid][cap_wg]
+  unsigned* wg_count;           // [grid] records each workgroup wrote
+  unsigned* hist;               // [n_ranges] records per id range (all workgroups)
 };
 struct K4Entry {  // tier-2 table entry
   double sum;
@@ -865,7 +873,33 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
     atomicAdd(&e->cnn, yv);
     atomicAdd(&e->sum, yv ? ydbl(yf) : 0.0);
   };
-  // tier 3: global atomics (rare by construction; divergent on purpose)
+  // tier 3, partitioned form: append the row to this workgroup's region (one LDS atomic per wave instruction reserves the
+  // slots of all its tier-3 lanes; the id ranges are counted in an LDS histogram, flushed once per workgroup)
+  __shared__ unsigned tail_cursor;
+  unsigned* tail_hist = reinterpret_cast<unsigned*>(k4_ovf + NOD);  // behind the tier-2 table (dynamic LDS)
+  const int n_ranges = (OVF && tail.rec) ? (NG - NL + K4_TAIL_RANGE - 1) / K4_TAIL_RANGE : 0;
+  // rows a workgroup can meet in the tile loop = the size of its region (the host computes the same number)
+  const unsigned cap_wg = (unsigned)(((n / TILE + gridDim.x - 1) / gridDim.x) * TILE);
+  if (OVF && tail.rec) {
+    if (threadIdx.x == 0) tail_cursor = 0;
+    for (int i = threadIdx.x; i < n_ranges; i += THREADS) tail_hist[i] = 0;
+    __syncthreads();
+  }
+  auto row_tail_append = [&](unsigned pass, float yf, int32_t g, unsigned yv) {
+    const bool t3 = pass && (unsigned)g >= (unsigned)NL && (unsigned)g < (unsigned)NG;
+    const unsigned long long m = __ballot(t3);
+    if (m == 0) return;
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(&tail_cursor, (unsigned)__popcll(m));
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    if (t3) {
+      const unsigned at = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+      if (at < cap_wg)  // cannot overflow: cap_wg covers every row this workgroup reads in the tile loop
+        tail.rec[(size_t)blockIdx.x * cap_wg + at] = uint2{(unsigned)g | (yv << 31), (unsigned)__float_as_int(yf)};
+      atomicAdd(&tail_hist[((unsigned)g - (unsigned)NL) / K4_TAIL_RANGE], 1u);
+    }
+  };
+  // tier 3, atomic form: global atomics straight into the state (divergent on purpose)
   auto row_tail = [&](unsigned pass, float yf, int32_t g, unsigned yv) {
     if (pass && (unsigned)g >= (unsigned)NL && (unsigned)g < (unsigned)NG) {
       atomicAdd(&tail.counts[NG + g], 1ull);
@@ -918,10 +952,17 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
           row_lds(p2, ys[j].z, gs[j].z, ym[j] >> 2 & 1);
           row_lds(p3, ys[j].w, gs[j].w, ym[j] >> 3 & 1);
           if (NG > NL && __any(gm >= (unsigned)NL)) {
-            row_tail(p0, ys[j].x, gs[j].x, ym[j] >> 0 & 1);
-            row_tail(p1, ys[j].y, gs[j].y, ym[j] >> 1 & 1);
-            row_tail(p2, ys[j].z, gs[j].z, ym[j] >> 2 & 1);
-            row_tail(p3, ys[j].w, gs[j].w, ym[j] >> 3 & 1);
+            if (tail.rec) {
+              row_tail_append(p0, ys[j].x, gs[j].x, ym[j] >> 0 & 1);
+              row_tail_append(p1, ys[j].y, gs[j].y, ym[j] >> 1 & 1);
+              row_tail_append(p2, ys[j].z, gs[j].z, ym[j] >> 2 & 1);
+              row_tail_append(p3, ys[j].w, gs[j].w, ym[j] >> 3 & 1);
+            } else {
+              row_tail(p0, ys[j].x, gs[j].x, ym[j] >> 0 & 1);
+              row_tail(p1, ys[j].y, gs[j].y, ym[j] >> 1 & 1);
+              row_tail(p2, ys[j].z, gs[j].z, ym[j] >> 2 & 1);
+              row_tail(p3, ys[j].w, gs[j].w, ym[j] >> 3 & 1);
+            }
           }
         }
       }
@@ -962,6 +1003,12 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
   spill();
 
   if (gmax >= (unsigned)(OVF ? NG : G)) atomicOr(status, 4);
+  if (OVF && tail.rec) {  // what this workgroup compacted: its record count, and its share of the per-range histogram
+    __syncthreads();
+    if (threadIdx.x == 0) tail.wg_count[blockIdx.x] = min(tail_cursor, cap_wg);
+    for (int i = threadIdx.x; i < n_ranges; i += THREADS)
+      if (tail_hist[i]) atomicAdd(&tail.hist[i], tail_hist[i]);
+  }
 
   // per-workgroup record: [cnn[RG]] [crow[RG]] [sum[RG]]  (fixed-order reductions for the register groups)
   const int RG = OVF ? NL : G;  // groups per record
@@ -1017,7 +1064,8 @@ static hipError_t k4_launch(hipStream_t s, const LaunchCfg& cfg, int* grid_out, 
                             int32_t klo, int32_t khi, int32_t negate, int32_t keymask, int32_t yint, int32_t n_groups,
                             const FoldArgs& fa, const K4Tail& tail) {
   const int nl = k4_nl(n_groups);
-  const size_t lds = OVF ? (size_t)(nl - G + 64) * sizeof(K4Entry) : 0;
+  const size_t n_ranges = (OVF && tail.rec) ? (size_t)(n_groups - nl + K4_TAIL_RANGE - 1) / K4_TAIL_RANGE : 0;
+  const size_t lds = OVF ? (size_t)(nl - G + 64) * sizeof(K4Entry) + n_ranges * sizeof(unsigned) : 0;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k4_cmp_avg_by_group_main<G, S, OVF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1131,6 +1179,103 @@ __global__ __launch_bounds__(256) void k4_finalize_head(const unsigned long long
     double t = 0.0;
     for (int b = 0; b < nblocks; ++b) t += __longlong_as_double((long long)p[(size_t)b * stride]);
     sums[g] += t;
+  }
+}
+
+// ---- partitioned tier 3 (ids >= K4_LDS_GROUPS): scatter by id range, then the LDS table over each range ---------------------
+// offsets[r] = exclusive prefix of hist[0 .. n_ranges); cursor[r] = 0.  One workgroup; n_ranges <= 2048.
+__global__ __launch_bounds__(1024) void k4_tail_offsets(const unsigned* __restrict__ hist, int n_ranges, unsigned* __restrict__ offsets,
+                                                        unsigned* __restrict__ cursor) {
+  __shared__ unsigned part[1024];
+  const int per = (n_ranges + 1023) / 1024;
+  const int r0 = threadIdx.x * per, r1 = min(n_ranges, r0 + per);
+  unsigned sum = 0;
+  for (int r = r0; r < r1; ++r) sum += hist[r];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const unsigned v = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  unsigned run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
+  for (int r = r0; r < r1; ++r) {
+    offsets[r] = run;
+    cursor[r] = 0;
+    run += hist[r];
+  }
+  if (threadIdx.x == 1023) offsets[n_ranges] = part[1023];
+}
+// One workgroup per source region (= per workgroup of the main kernel), chunks of 8 records per thread: an LDS histogram
+// gives every record its rank inside (chunk, range), ONE global atomic per (chunk, non-empty range) reserves the run in the
+// output, the records are written there.  8 B read + 8 B written per record.
+constexpr int K4_SCATTER_PER = 8;
+__global__ __launch_bounds__(1024) void k4_tail_scatter(const uint2* __restrict__ rec, const unsigned* __restrict__ wg_count, unsigned cap_wg,
+                                                        int NL, int n_ranges, const unsigned* __restrict__ offsets,
+                                                        unsigned* __restrict__ cursor, uint2* __restrict__ out) {
+  extern __shared__ unsigned sc_lds[];  // [n_ranges] counts of the chunk, then [n_ranges] global bases
+  unsigned* cnt = sc_lds;
+  unsigned* gbase = sc_lds + n_ranges;
+  const uint2* src = rec + (size_t)blockIdx.x * cap_wg;
+  const unsigned total = wg_count[blockIdx.x];
+  constexpr unsigned CH = 1024 * K4_SCATTER_PER;
+  for (unsigned c0 = 0; c0 < total; c0 += CH) {
+    for (int i = threadIdx.x; i < n_ranges; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    uint2 v[K4_SCATTER_PER];
+    unsigned rank[K4_SCATTER_PER];
+#pragma unroll
+    for (int k = 0; k < K4_SCATTER_PER; ++k) {
+      const unsigned i = c0 + (unsigned)k * 1024u + threadIdx.x;
+      rank[k] = 0xFFFFFFFFu;
+      if (i < total) {
+        v[k] = src[i];
+        rank[k] = atomicAdd(&cnt[((v[k].x & 0x7FFFFFFFu) - (unsigned)NL) / K4_TAIL_RANGE], 1u);
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_ranges; i += 1024) gbase[i] = cnt[i] ? offsets[i] + atomicAdd(&cursor[i], cnt[i]) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K4_SCATTER_PER; ++k)
+      if (rank[k] != 0xFFFFFFFFu) out[gbase[((v[k].x & 0x7FFFFFFFu) - (unsigned)NL) / K4_TAIL_RANGE] + rank[k]] = v[k];
+    __syncthreads();
+  }
+}
+// blockIdx.x = range, blockIdx.y = slice of the range's records: the tier-2 LDS table over K4_TAIL_RANGE ids, flushed into
+// the caller's state with one global atomic triple per id the slice touched.
+__global__ __launch_bounds__(1024) void k4_tail_aggregate(const uint2* __restrict__ recs, const unsigned* __restrict__ offsets, int NL, int NG,
+                                                          int yint, unsigned long long* __restrict__ counts, double* __restrict__ sums) {
+  __shared__ K4Entry tab[K4_TAIL_RANGE];
+  const unsigned lo = offsets[blockIdx.x], hi = offsets[blockIdx.x + 1];
+  const unsigned len = hi - lo, per = (len + gridDim.y - 1) / gridDim.y;
+  const unsigned a = lo + blockIdx.y * per, b = min(hi, a + per);
+  if (a >= b) return;
+  for (int i = threadIdx.x; i < K4_TAIL_RANGE; i += 1024) {
+    tab[i].sum = 0.0;
+    tab[i].cnn = 0;
+    tab[i].crow = 0;
+  }
+  __syncthreads();
+  const unsigned id0 = (unsigned)NL + blockIdx.x * (unsigned)K4_TAIL_RANGE;
+  for (unsigned i = a + threadIdx.x; i < b; i += 1024) {
+    const uint2 v = recs[i];
+    K4Entry* e = &tab[(v.x & 0x7FFFFFFFu) - id0];
+    const unsigned yv = v.x >> 31;
+    atomicAdd(&e->crow, 1u);
+    atomicAdd(&e->cnn, yv);
+    atomicAdd(&e->sum, yv ? (yint ? (double)(int32_t)v.y : (double)__uint_as_float(v.y)) : 0.0);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < K4_TAIL_RANGE; i += 1024) {
+    const unsigned g = id0 + (unsigned)i;
+    if (g >= (unsigned)NG || tab[i].crow == 0) continue;
+    atomicAdd(&counts[NG + g], (unsigned long long)tab[i].crow);
+    if (tab[i].cnn) {
+      atomicAdd(&counts[g], (unsigned long long)tab[i].cnn);
+      atomicAdd(&sums[g], tab[i].sum);
+    }
   }
 }
 

@@ -336,6 +336,41 @@ def test_k4_three_tiers_registers_lds_global(ctx, oracle, G, n, dist):
     plan.close()
 
 
+@pytest.mark.parametrize("n", [100_000, 3_000_000, 10_000_000, 20_000_003])
+def test_single_launch_fold_never_reads_a_stale_record(ctx, oracle, n):
+    """Round 3: the last workgroup folds the per-workgroup records inside the main kernel (agent-scope atomics, no
+    fences).  500 accumulating launches back to back on one stream -- small and big shapes, K2 / K3 / K4 interleaved so the
+    workspace is reused with different record sizes -- must add up to exactly 500 x one launch: a fold that ever read a
+    record of an earlier launch (or missed one) shows up in the integer counters."""
+    reps = 500
+    c, p = oracle.gen_c2(2, n, 0, n)
+    f, mq, mv, ref, rv = oracle.gen_c3(3, 0, n)
+    af, av, q, qv, fid = oracle.gen_c4(4, 0, n)
+    d2 = [ctx.to_device(x) for x in (c, p)]
+    d3 = [ctx.to_device(x) for x in (f, np.concatenate([mq, np.zeros(64, np.uint8)]), mv, ref, rv)]
+    d4 = [ctx.to_device(x) for x in (af, av, q, qv, fid)]
+    one2, one3 = ctx.zeros(np.int64, 1), ctx.zeros(np.int64, 26)
+    one4c, one4s = ctx.zeros(np.int64, 10), ctx.zeros(np.float64, 5)
+    acc2, acc3 = ctx.zeros(np.int64, 1), ctx.zeros(np.int64, 26)
+    acc4c, acc4s = ctx.zeros(np.int64, 10), ctx.zeros(np.float64, 5)
+
+    def launch(o2, o3, o4c, o4s):
+        ctx.region_count(d2[0], d2[1], n, 6, 50_000_000, 100_000_000, o2)
+        ctx.flag_mapq_group_count(d3[0], d3[1], d3[2], d3[3], d3[4], n, 1284, 0, 30, 25, o3)
+        ctx.cmp_avg_by_group(d4[0], d4[1], d4[2], d4[3], d4[4], n, 0.01, ">", 5, o4c, o4s)
+    launch(one2, one3, one4c, one4s)
+    for _ in range(reps):
+        launch(acc2, acc3, acc4c, acc4s)
+    ctx.sync()
+    assert acc2.to_host()[0] == reps * one2.to_host()[0] and one2.to_host()[0] > 0
+    assert np.array_equal(acc3.to_host(), reps * one3.to_host()) and one3.to_host().sum() > 0
+    assert np.array_equal(acc4c.to_host(), reps * one4c.to_host())
+    assert np.allclose(acc4s.to_host(), reps * one4s.to_host(), rtol=1e-9, atol=0)
+    # and against the oracle once
+    r2, _ = oracle.c2_region_count(c, p, oracle.c2_contigs(), "7:50000000-100000000")
+    assert one2.to_host()[0] == r2
+
+
 def test_k4_deterministic(ctx):
     n = 3_000_000
     af, av, q, qv, fid = ctx.gen_c4(9, 0, n)
