@@ -75,6 +75,35 @@ int get_workspace(exon_hip_ctx* ctx, hipStream_t s, size_t words, Workspace* out
   return EXON_HIP_OK;
 }
 
+// K4's tier-3 scratch (plans with more group ids than registers + the LDS table hold): grown on demand, kept with the
+// stream's workspace.  Failure to allocate is not an error: the kernel then keeps the atomic form of tier 3.
+static void ensure_tail_scratch(exon_hip_ctx* ctx, hipStream_t s, size_t records, Workspace* out) {
+  if (records == 0) return;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  Workspace& ws = ctx->workspaces[s];
+  if (ws.tail_capacity < records) {
+    if (ws.tail_rec_a || ws.tail_rec_b) {
+      hipStreamSynchronize(s);
+      if (ws.tail_rec_a) hipFree(ws.tail_rec_a);
+      if (ws.tail_rec_b) hipFree(ws.tail_rec_b);
+      ws.tail_rec_a = ws.tail_rec_b = nullptr;
+      ws.tail_capacity = 0;
+    }
+    if (hipMalloc((void**)&ws.tail_rec_a, records * 8) != hipSuccess || hipMalloc((void**)&ws.tail_rec_b, records * 8) != hipSuccess) {
+      (void)hipGetLastError();
+      if (ws.tail_rec_a) hipFree(ws.tail_rec_a);
+      ws.tail_rec_a = ws.tail_rec_b = nullptr;
+    } else {
+      ws.tail_capacity = records;
+    }
+  }
+  if (!ws.tail_u32 && hipMalloc((void**)&ws.tail_u32, exon::K4_TAIL_U32_WORDS * 4) != hipSuccess) {
+    (void)hipGetLastError();
+    ws.tail_u32 = nullptr;
+  }
+  *out = ws;
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" {
@@ -177,6 +206,9 @@ int exon_hip_ctx_destroy(exon_hip_ctx* ctx) {
   for (auto& kv : ctx->workspaces) {
     if (kv.second.partials) hipFree(kv.second.partials);
     if (kv.second.status) hipFree(kv.second.status);
+    if (kv.second.tail_rec_a) hipFree(kv.second.tail_rec_a);
+    if (kv.second.tail_rec_b) hipFree(kv.second.tail_rec_b);
+    if (kv.second.tail_u32) hipFree(kv.second.tail_u32);
   }
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -379,6 +411,7 @@ int exon_op_cmp_avg_by_group(exon_hip_ctx* ctx, void* stream, const exon_hip_col
   }
   Workspace ws;
   if ((rc = get_workspace(ctx, s, exon::k4_partial_words(ctx->cfg, n_groups), &ws))) return fail(ctx, rc, "workspace allocation failed");
+  ensure_tail_scratch(ctx, s, exon::k4_tail_records(n, n_groups), &ws);
   HIP_TRY(ctx, exon::launch_cmp_avg_by_group(s, cfg_for(ctx, flags), ws, (const float*)x->values, x->validity,
                                              (const float*)y->values, y->validity, (const int32_t*)group_id->values,
                                              n, threshold, cmp_op, n_groups, d_counts, d_sums));

@@ -11,6 +11,12 @@ struct Workspace {
   unsigned long long* partials = nullptr;  // [blocks][words]
   size_t partial_capacity = 0;             // in 8-byte words
   int* status = nullptr;                   // device error word (K5: position >= lmax, bad group id)
+  // K4 with more ids than registers + the LDS table hold (tier 3): two record buffers of `tail_capacity` 8-byte records
+  // (compacted rows, then the same rows grouped by id range) and a block of counters; absent until such a plan runs
+  uint2* tail_rec_a = nullptr;
+  uint2* tail_rec_b = nullptr;
+  size_t tail_capacity = 0;
+  unsigned* tail_u32 = nullptr;
 };
 
 struct LaunchCfg {
@@ -24,6 +30,9 @@ struct LaunchCfg {
 size_t k2_partial_words(const LaunchCfg&);
 size_t k3_partial_words(const LaunchCfg&, int n_refs);
 size_t k4_partial_words(const LaunchCfg&, int n_groups);
+// 8-byte records of tier-3 scratch a K4 launch over n rows wants (0: no tier 3); per buffer
+size_t k4_tail_records(int64_t n, int n_groups);
+constexpr size_t K4_TAIL_U32_WORDS = 2048 + 3 * 2048 + 1;  // workgroup counts, range histogram, offsets, cursors
 size_t k5_partial_words(const LaunchCfg&, int lmax);
 
 hipError_t launch_region_count(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* chrom,

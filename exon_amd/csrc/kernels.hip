@@ -336,7 +336,7 @@ static int pick_shape(const LaunchCfg& cfg, int64_t n) {
   if (t2 < cus) return SHAPE_SMALL;
   if (t4 < cus) return SHAPE_BIG_J2;
   const int64_t c4 = ((t4 + cus - 1) / cus) * ShapeOf<ShapeBig>::TILE, c2 = ((t2 + cus - 1) / cus) * ShapeOf<ShapeBigJ2>::TILE;
-  return c2 < c4 ? SHAPE_BIG_J2 : SHAPE_BIG_J4;
+  return c2 + c2 / 32 < c4 ? SHAPE_BIG_J2 : SHAPE_BIG_J4;  // J = 2 only when it shortens the critical path by > 3 %: the big tile keeps more loads in flight
 }
 static bool use_big_shape(const LaunchCfg& cfg, int64_t n) { return pick_shape(cfg, n) != SHAPE_SMALL; }
 
@@ -785,6 +785,7 @@ hipError_t launch_flag_mapq_group_count(hipStream_t s, const LaunchCfg& cfg, con
 //   for 64 and 4096 keys, uniform and skewed): a CU issues one wave64 vector instruction per clock, so every instruction
 //   per row is 0.025 ms per 1e9 rows.  Hence 4 register groups instead of 8 (4 instead of 8 conditional f64 adds, 32-bit
 //   packed counters), the predicate evaluated once per row for all tiers, one LDS address per row.
+constexpr int K4_TAIL_MAX_RANGES = 2048;  // (2^24 - 4100) / 8192 ids
 constexpr int K4_TAIL_RANGE = 8192;  // ids per range of the partitioned tier 3 = entries of k4_tail_aggregate's LDS table (128 KiB)
 struct K4Tail {                 // tier 3 (unused when NG == NL)
   unsigned long long* counts;   // the caller's [cnn[NG]] [crow[NG]]
@@ -1279,32 +1280,27 @@ __global__ __launch_bounds__(1024) void k4_tail_aggregate(const uint2* __restric
   }
 }
 
-hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const float* x,
-                                   const uint8_t* x_valid, const float* y, const uint8_t* y_valid, const int32_t* gid,
-                                   int64_t n, double thr, int cmp_op, int n_groups, int64_t* d_counts,
-                                   double* d_sums) {
-  if (n <= 0) return hipSuccess;
-  if (n_groups < 1) return hipErrorInvalidValue;
-  int32_t klo, khi, negate;
-  if (!cmp_to_key_range(thr, cmp_op, cfg.x_is_int, &klo, &khi, &negate)) return hipErrorInvalidValue;
-  const int32_t keymask = cfg.x_is_int ? 0 : 0x7FFFFFFF, yint = cfg.y_is_int ? 1 : 0;
-  const int nl = k4_nl(n_groups);
-  const bool has_tail = n_groups > nl;
-  static const bool global_only = [] {
-    const char* v = getenv("EXON_HIP_K4_GLOBAL_ONLY");
+// rows per launch of the partitioned tier 3: its scratch is 2 x 8 bytes per row of a launch, so a longer table is cut
+// into launches of this many rows (a multiple of every tile size and of 8: column and bitmap pointers stay aligned)
+constexpr int64_t K4_TAIL_CHUNK_ROWS = int64_t(1) << 28;
+constexpr int64_t K4_TAIL_SLACK = 2048 * 2048;  // grid x tile of the largest launch shape: rounding of the per-workgroup regions
+size_t k4_tail_records(int64_t n, int n_groups) {
+  if (n_groups <= K4_LDS_GROUPS) return 0;
+  return (size_t)(std::min<int64_t>(n, K4_TAIL_CHUNK_ROWS) + K4_TAIL_SLACK);
+}
+static bool k4_tail_atomics_forced() {
+  static const bool on = [] {
+    const char* v = getenv("EXON_HIP_K4_TAIL_ATOMICS");  // A/B: tier 3 as global atomics (round 3's first version)
     return v && v[0] == '1';
   }();
-  if (has_tail && cfg.overwrite) {  // tier 3 (and k4_finalize_head) ADD to the caller's arrays
-    hipError_t e0 = hipMemsetAsync(d_counts, 0, (size_t)n_groups * 16, s);
-    if (e0 == hipSuccess) e0 = hipMemsetAsync(d_sums, 0, (size_t)n_groups * 8, s);
-    if (e0 != hipSuccess) return e0;
-  }
-  if (has_tail && global_only) {
-    const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)cfg.compute_units * 32);
-    hipLaunchKernelGGL(k4_cmp_avg_by_group_global, dim3(grid), dim3(256), 0, s, x, x_valid, y, y_valid, gid, n, klo, khi, negate, keymask, yint, n_groups,
-                       reinterpret_cast<unsigned long long*>(d_counts), d_sums, ws.status);
-    return hipGetLastError();
-  }
+  return on;
+}
+
+static hipError_t k4_one_launch(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const float* x, const uint8_t* x_valid,
+                                const float* y, const uint8_t* y_valid, const int32_t* gid, int64_t n, int32_t klo, int32_t khi,
+                                int32_t negate, int32_t keymask, int32_t yint, int n_groups, int64_t* d_counts, double* d_sums) {
+  const int nl = k4_nl(n_groups);
+  const bool has_tail = n_groups > nl;
   // K4 keeps the 16384-row tile whenever every CU gets one: measured on MI355X at 1e7 rows J = 4 27.8 us, J = 2 31.5 us
   // (its per-tile bookkeeping -- counter spills, 15-value reductions -- outweighs the better tile balance that pays for K2)
   const bool big = n / ShapeOf<ShapeBig>::TILE >= (int64_t)cfg.compute_units && pick_shape(cfg, n) != SHAPE_SMALL;
@@ -1312,7 +1308,22 @@ hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Wo
   hipError_t e;
   const FoldArgs fa = has_tail ? FoldArgs{nullptr, nullptr, nullptr, 0, 0, 0}
                                : fold_args(cfg, ws, 3 * n_groups, 2 * n_groups, d_counts, d_sums);
-  const K4Tail tail{reinterpret_cast<unsigned long long*>(d_counts), d_sums};
+  K4Tail tail{reinterpret_cast<unsigned long long*>(d_counts), d_sums, nullptr, nullptr, nullptr};
+  const int n_ranges = has_tail ? (n_groups - nl + K4_TAIL_RANGE - 1) / K4_TAIL_RANGE : 0;
+  // partitioned tier 3 when its scratch is there (capi.cpp sizes it with k4_tail_records) and the launch has whole tiles
+  const bool partition = has_tail && !k4_tail_atomics_forced() && ws.tail_rec_a && ws.tail_rec_b && ws.tail_u32 &&
+                         ws.tail_capacity >= (size_t)(n + K4_TAIL_SLACK) && n_ranges <= K4_TAIL_MAX_RANGES;
+  unsigned *wg_count = nullptr, *hist = nullptr, *offsets = nullptr, *cursor = nullptr;
+  if (partition) {
+    wg_count = ws.tail_u32;                       // [2048]
+    hist = ws.tail_u32 + 2048;                    // [K4_TAIL_MAX_RANGES]
+    offsets = hist + K4_TAIL_MAX_RANGES;          // [K4_TAIL_MAX_RANGES + 1]
+    cursor = offsets + K4_TAIL_MAX_RANGES + 1;    // [K4_TAIL_MAX_RANGES]
+    if ((e = hipMemsetAsync(ws.tail_u32, 0, (size_t)(2048 + K4_TAIL_MAX_RANGES) * 4, s)) != hipSuccess) return e;
+    tail.rec = ws.tail_rec_a;
+    tail.wg_count = wg_count;
+    tail.hist = hist;
+  }
   switch (n_groups) {
 #define EXON_K4_CASE(GG)                                                                                                        \
   case GG:                                                                                                                      \
@@ -1328,7 +1339,7 @@ hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Wo
     EXON_K4_CASE(7)
     EXON_K4_CASE(8)
 #undef EXON_K4_CASE
-    default:  // > 8 groups: 4 in registers + LDS table (+ global atomics beyond K4_LDS_GROUPS ids)
+    default:  // > 8 groups: 4 in registers + LDS table (+ tier 3 beyond K4_LDS_GROUPS ids)
       // (16384-row tiles fit too -- 124 VGPRs -- and measured the same: profiles/r3_groupby.md)
       e = big ? k4_launch<K4_OVF_REGS, ShapeBigJ2, true>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, keymask, yint, n_groups, fa, tail)
               : k4_launch<K4_OVF_REGS, ShapeSmall, true>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, keymask, yint, n_groups, fa, tail);
@@ -1338,10 +1349,62 @@ hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Wo
   if (has_tail) {
     hipLaunchKernelGGL(k4_finalize_head, dim3((3 * nl + 255) / 256), dim3(256), 0, s, ws.partials, grid, nl, n_groups,
                        reinterpret_cast<unsigned long long*>(d_counts), d_sums);
+    if (partition) {
+      const int64_t tile = big ? ShapeOf<ShapeBigJ2>::TILE : ShapeOf<ShapeSmall>::TILE;
+      const unsigned cap_wg = (unsigned)(((n / tile + grid - 1) / grid) * tile);  // the main kernel's formula
+      hipLaunchKernelGGL(k4_tail_offsets, dim3(1), dim3(1024), 0, s, hist, n_ranges, offsets, cursor);
+      hipLaunchKernelGGL(k4_tail_scatter, dim3(grid), dim3(1024), (size_t)n_ranges * 8, s, ws.tail_rec_a, wg_count, cap_wg, nl, n_ranges, offsets,
+                         cursor, ws.tail_rec_b);
+      // slices per range: enough workgroups to fill the chip (one 128 KiB LDS table each), few enough that the flushes
+      // (one atomic triple per id and slice) stay small next to the records
+      const int slices = std::max(1, std::min(64, (4 * cfg.compute_units + n_ranges - 1) / n_ranges));
+      hipLaunchKernelGGL(k4_tail_aggregate, dim3(n_ranges, slices), dim3(1024), 0, s, ws.tail_rec_b, offsets, nl, n_groups, yint,
+                         reinterpret_cast<unsigned long long*>(d_counts), d_sums);
+    }
     return hipGetLastError();
   }
   // per-workgroup records are [cnn[G]] [crow[G]] [sum[G]] = the state layout [counts[2G]] [sums[G]]
   return run_finalize(s, cfg, ws, grid, 3 * n_groups, 2 * n_groups, d_counts, d_sums);
+}
+
+hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const float* x,
+                                   const uint8_t* x_valid, const float* y, const uint8_t* y_valid, const int32_t* gid,
+                                   int64_t n, double thr, int cmp_op, int n_groups, int64_t* d_counts,
+                                   double* d_sums) {
+  if (n <= 0) return hipSuccess;
+  if (n_groups < 1) return hipErrorInvalidValue;
+  int32_t klo, khi, negate;
+  if (!cmp_to_key_range(thr, cmp_op, cfg.x_is_int, &klo, &khi, &negate)) return hipErrorInvalidValue;
+  const int32_t keymask = cfg.x_is_int ? 0 : 0x7FFFFFFF, yint = cfg.y_is_int ? 1 : 0;
+  const bool has_tail = n_groups > k4_nl(n_groups);
+  static const bool global_only = [] {
+    const char* v = getenv("EXON_HIP_K4_GLOBAL_ONLY");
+    return v && v[0] == '1';
+  }();
+  if (has_tail && cfg.overwrite) {  // tier 3 (and k4_finalize_head) ADD to the caller's arrays
+    hipError_t e0 = hipMemsetAsync(d_counts, 0, (size_t)n_groups * 16, s);
+    if (e0 == hipSuccess) e0 = hipMemsetAsync(d_sums, 0, (size_t)n_groups * 8, s);
+    if (e0 != hipSuccess) return e0;
+  }
+  if (has_tail && global_only) {
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)cfg.compute_units * 32);
+    hipLaunchKernelGGL(k4_cmp_avg_by_group_global, dim3(grid), dim3(256), 0, s, x, x_valid, y, y_valid, gid, n, klo, khi, negate, keymask, yint, n_groups,
+                       reinterpret_cast<unsigned long long*>(d_counts), d_sums, ws.status);
+    return hipGetLastError();
+  }
+  if (!has_tail || n <= K4_TAIL_CHUNK_ROWS)
+    return k4_one_launch(s, cfg, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, keymask, yint, n_groups, d_counts, d_sums);
+  // a table longer than the tier-3 scratch covers: launches of K4_TAIL_CHUNK_ROWS rows, all accumulating (the state was
+  // cleared above when the caller asked for overwrite)
+  LaunchCfg acc = cfg;
+  acc.overwrite = false;
+  for (int64_t r0 = 0; r0 < n; r0 += K4_TAIL_CHUNK_ROWS) {
+    const int64_t m = std::min<int64_t>(K4_TAIL_CHUNK_ROWS, n - r0);
+    hipError_t e = k4_one_launch(s, acc, ws, x + r0, x_valid ? x_valid + (r0 >> 3) : nullptr, y + r0, y_valid ? y_valid + (r0 >> 3) : nullptr, gid + r0, m,
+                                 klo, khi, negate, keymask, yint, n_groups, d_counts, d_sums);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 // ------------------------------------------------------------------------------------------------
