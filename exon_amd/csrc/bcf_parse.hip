@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "chain_walk.h"
+#include "list_kernels.h"
 #include "internal.h"
 
 namespace {
@@ -70,9 +71,12 @@ struct BcfOut {
   int32_t* filter_id;
   float* info[EXON_HIP_MAX_INFO_FIELDS];  // typed INFO fields (4-byte values), in the order of exon_hip_bcf_parser_set_info_keys
   uint32_t* info_valid[EXON_HIP_MAX_INFO_FIELDS];
+  uint32_t* lv_off[EXON_HIP_MAX_INFO_FIELDS];  // list kinds ('F' / 'I'): where the row's typed vector starts (| value type << 29)
+  uint32_t* lv_cnt[EXON_HIP_MAX_INFO_FIELDS];  // ... and how many items it holds (0: NULL list)
   uint32_t* pos_valid;  // POS 0 (BCF pos0 = -1, the telomere) is NULL like in the VCF path
 };
-struct BcfInfoKeys {  // header-string indexes of the INFO fields to extract; kind 'f' -> f32, 'i' -> i32, 'b' Flag -> presence
+struct BcfInfoKeys {  // header-string indexes of the INFO fields to extract; kind 'f' -> f32, 'i' -> i32, 'b' Flag -> presence,
+                      // 'F' / 'I' -> List<f32> / List<i32> (typed vectors: list_kernels.h + k_bcf_list_fill)
   int n;
   int32_t key[EXON_HIP_MAX_INFO_FIELDS];
   char kind[EXON_HIP_MAX_INFO_FIELDS];
@@ -156,6 +160,36 @@ __global__ __launch_bounds__(256) void k_bcf_extract(const uint8_t* __restrict__
         if (key != ik.key[w] || (have >> w & 1u)) continue;
         if (ik.kind[w] == 'b') {
           have |= 1u << w;  // a Flag is true by being there
+        } else if (ik.kind[w] == 'F' || ik.kind[w] == 'I') {
+          // a typed vector -> List<item>: count the items up to the type's end-of-vector value; ONE item that is the type's
+          // 'missing' value is `key=.` (NULL list).  The items are parsed by k_bcf_list_fill behind the offsets scan.
+          const bool ints = vt >= 1 && vt <= 3, flts = vt == 5 && ik.kind[w] == 'F';
+          if (vc >= 1 && (ints || flts)) {
+            const uint32_t sz = (uint32_t)type_size(vt);
+            if ((uint64_t)c.o + (uint64_t)vc * sz > c.end) { c.bad = true; break; }
+            const int64_t missing = vt == 1 ? -128 : vt == 2 ? -32768 : (int64_t)INT32_MIN;
+            unsigned items = 0;
+            bool first_missing = false;
+            for (int e = 0; e < vc; ++e) {
+              Cursor t = c;
+              t.o = c.o + (uint32_t)e * sz;
+              if (flts) {
+                const uint32_t bb = ld32(d + t.o);
+                if (bb == 0x7F800002u) break;
+                if (e == 0) first_missing = bb == 0x7F800001u;
+              } else {
+                const int64_t v = t.read_int(vt);
+                if (v == missing + 1) break;
+                if (e == 0) first_missing = v == missing;
+              }
+              ++items;
+            }
+            if (items > 0 && !(vc == 1 && first_missing)) {
+              out.lv_off[w][row] = c.o | ((uint32_t)vt << 29);
+              out.lv_cnt[w][row] = items;
+              have |= 1u << w;
+            }
+          }
         } else if (ik.kind[w] == 'i') {
           // Type=Integer: int8 / int16 / int32 widened to Int32 exactly (bit pattern in the 4-byte column)
           if (vc >= 1 && vt >= 1 && vt <= 3) {
@@ -224,8 +258,51 @@ __global__ __launch_bounds__(256) void k_bcf_extract(const uint8_t* __restrict__
     if (pos0 >= 0) atomicOr(&out.pos_valid[row >> 5], bit);
     for (int w = 0; w < ik.n; ++w) {
       if (have >> w & 1u) atomicOr(&out.info_valid[w][row >> 5], bit);
+      else if (ik.kind[w] == 'F' || ik.kind[w] == 'I') out.lv_cnt[w][row] = 0;  // NULL list: no items (summed by the offsets scan)
       else if (ik.kind[w] != 'b') out.info[w][row] = 0.f;  // NULL slots hold a defined value
     }
+  }
+}
+
+// list-valued INFO fields: offsets[row] = exclusive prefix of the item counts, every row copies its typed vector into
+// values[offsets[row] ..] ('I': int8 / int16 / int32 -> int32 exactly; 'F': float bits, or integers converted); the type's
+// 'missing' value is a NULL item (flag 0).  rows = scalars[0] (written by k_chain_check).
+__global__ __launch_bounds__(LIST_TPB) void k_bcf_list_fill(const uint8_t* __restrict__ d, const uint32_t* __restrict__ lv_off,
+                                                            const uint32_t* __restrict__ cnt, const unsigned* __restrict__ block_offsets,
+                                                            const unsigned* __restrict__ n_rows_p, unsigned cap, unsigned cap_items, char kind,
+                                                            int32_t* __restrict__ offsets, float* __restrict__ values,
+                                                            uint8_t* __restrict__ item_flags, unsigned* __restrict__ exceptions) {
+  const unsigned n_rows = min(*n_rows_p, cap);
+  const unsigned row = blockIdx.x * LIST_TPB + threadIdx.x;
+  const unsigned c = row < n_rows ? cnt[row] : 0u;
+  const unsigned first = list_first_item(c, block_offsets);
+  if (row < n_rows) offsets[row] = (int32_t)first;
+  if (row + 1 == n_rows) offsets[n_rows] = (int32_t)(first + c);
+  if (row == 0 && n_rows == 0) offsets[0] = 0;
+  if (row >= n_rows || c == 0) return;
+  if ((uint64_t)first + c > cap_items) {
+    atomicAdd(exceptions, 1u);
+    return;
+  }
+  const uint32_t o = lv_off[row] & 0x1FFFFFFFu;
+  const int vt = (int)(lv_off[row] >> 29);
+  const int64_t missing = vt == 1 ? -128 : vt == 2 ? -32768 : (int64_t)INT32_MIN;
+  for (unsigned i = 0; i < c; ++i) {
+    uint32_t bits = 0;
+    bool ok;
+    if (vt == 5) {
+      bits = ld32(d + o + 4 * i);
+      ok = bits != 0x7F800001u;
+    } else {
+      int64_t v;
+      if (vt == 1) v = (int8_t)d[o + i];
+      else if (vt == 2) v = (int16_t)ld16(d + o + 2 * i);
+      else v = (int32_t)ld32(d + o + 4 * i);
+      ok = v != missing;
+      bits = kind == 'I' ? (uint32_t)(int32_t)v : __float_as_uint((float)v);
+    }
+    values[first + i] = __uint_as_float(ok ? bits : 0u);
+    item_flags[first + i] = ok ? 1 : 0;
   }
 }
 
@@ -251,6 +328,9 @@ struct exon_hip_bcf_parser {
   int32_t n_contigs = 0, n_strings = 0, n_samples = 0, info_key = -1;
   BcfInfoKeys ik{};
   void* ibufs[2 * (EXON_HIP_MAX_INFO_FIELDS - 1)] = {nullptr};  // value / validity buffers of INFO fields 1 .. 15 (field 0 lives in bufs[5] / bufs[6])
+  // list kinds: per key { vector offsets per row, item counts per row, Arrow offsets [rows + 1], item flags, item bitmap, items }
+  void* lbufs[6 * EXON_HIP_MAX_INFO_FIELDS] = {nullptr};
+  unsigned* d_list_blocks = nullptr;
   size_t words = 0;
   int64_t max_bytes = 0, max_rows = 0;
   uint32_t max_seg = 0;
@@ -342,14 +422,27 @@ int exon_hip_bcf_parser_set_info_keys(exon_hip_bcf_parser* p, const int32_t* key
   p->ik.n = n;
   hipSetDevice(p->ctx->device);
   for (int q = 0; q < n; ++q) {
-    if (kinds[q] != 'f' && kinds[q] != 'b' && kinds[q] != 'i') return fail(p->ctx, EXON_HIP_EUNSUPPORTED, "INFO kind '%c' is not decoded on the device", kinds[q]);
+    if (kinds[q] != 'f' && kinds[q] != 'b' && kinds[q] != 'i' && kinds[q] != 'F' && kinds[q] != 'I')
+      return fail(p->ctx, EXON_HIP_EUNSUPPORTED, "INFO kind '%c' is not decoded on the device", kinds[q]);
     p->ik.key[q] = keys[q];
     p->ik.kind[q] = kinds[q];
-    if (q == 0) continue;
+    if (kinds[q] == 'F' || kinds[q] == 'I') {  // an item takes at least one byte of the slab
+      const size_t r = (size_t)p->max_rows, items = (size_t)p->max_bytes + 1;
+      const size_t sizes[6] = {r * 4, r * 4, (r + 1) * 4, items, items / 8 + 64, items * 4};
+      for (int k = 0; k < 6; ++k)
+        if (!p->lbufs[6 * q + k] && !(p->lbufs[6 * q + k] = exon_pool_alloc(p->ctx, sizes[k]))) return fail(p->ctx, EXON_HIP_ENOMEM, "INFO list buffers");
+      if (!p->d_list_blocks && !(p->d_list_blocks = (unsigned*)exon_pool_alloc(p->ctx, (r / LIST_TPB + 2) * 4))) return fail(p->ctx, EXON_HIP_ENOMEM, "INFO list buffers");
+      p->out.lv_off[q] = (uint32_t*)p->lbufs[6 * q + 0];
+      p->out.lv_cnt[q] = (uint32_t*)p->lbufs[6 * q + 1];
+    }
+    if (q == 0) {
+      if (kinds[q] == 'F' || kinds[q] == 'I') p->out.info[0] = (float*)p->lbufs[5];
+      continue;
+    }
     if (!p->ibufs[2 * (q - 1)]) p->ibufs[2 * (q - 1)] = exon_pool_alloc(p->ctx, (size_t)p->max_rows * 4);
     if (!p->ibufs[2 * (q - 1) + 1]) p->ibufs[2 * (q - 1) + 1] = exon_pool_alloc(p->ctx, p->words);
     if (!p->ibufs[2 * (q - 1)] || !p->ibufs[2 * (q - 1) + 1]) return fail(p->ctx, EXON_HIP_ENOMEM, "INFO column buffers");
-    p->out.info[q] = (float*)p->ibufs[2 * (q - 1)];
+    p->out.info[q] = (kinds[q] == 'F' || kinds[q] == 'I') ? (float*)p->lbufs[6 * q + 5] : (float*)p->ibufs[2 * (q - 1)];
     p->out.info_valid[q] = (uint32_t*)p->ibufs[2 * (q - 1) + 1];
   }
   p->info_key = n ? keys[0] : -1;
@@ -359,6 +452,9 @@ int exon_hip_bcf_parser_set_info_keys(exon_hip_bcf_parser* p, const int32_t* key
 int exon_hip_bcf_parser_destroy(exon_hip_bcf_parser* p) {
   if (!p) return EXON_HIP_OK;
   for (void* b : p->ibufs) exon_pool_free(p->ctx, b);
+  for (void* b : p->lbufs)
+    if (b) exon_pool_free(p->ctx, b);
+  if (p->d_list_blocks) exon_pool_free(p->ctx, p->d_list_blocks);
   for (void* b : p->bufs) exon_pool_free(p->ctx, b);
   for (void* b : p->fbufs) exon_pool_free(p->ctx, b);
   exon_pool_free(p->ctx, p->d_seg);
@@ -396,6 +492,20 @@ int exon_hip_bcf_parser_parse(exon_hip_bcf_parser* p, void* stream, const uint8_
                      p->n_contigs, p->n_strings, p->ik, p->d_scalars);
   hipLaunchKernelGGL(k_bcf_assign, dim3(1), dim3(256), 0, s, p->filters);
   hipLaunchKernelGGL(k_bcf_remap, dim3(std::min<uint32_t>(n_seg * 4 + 1, 4096)), dim3(256), 0, s, p->out.filter_id, p->d_scalars, p->filters.ids);
+  for (int q = 0; q < p->ik.n; ++q) {  // list-valued fields: counts -> offsets -> items -> child validity
+    const char kind = p->ik.kind[q];
+    if (kind != 'F' && kind != 'I') continue;
+    const unsigned row_bound = (unsigned)p->max_rows;
+    const int lblocks = (int)((std::min<int64_t>(p->max_rows, n_bytes / 32 + 1) + LIST_TPB - 1) / LIST_TPB);  // a BCF record is >= 32 bytes
+    int32_t* offsets = (int32_t*)p->lbufs[6 * q + 2];
+    hipLaunchKernelGGL(k_list_block_sums, dim3(lblocks), dim3(LIST_TPB), 0, s, p->out.lv_cnt[q], p->d_scalars, row_bound, p->d_list_blocks);
+    hipLaunchKernelGGL(k_list_scan_blocks, dim3(1), dim3(1024), 0, s, p->d_list_blocks, lblocks, p->d_scalars + 3);
+    hipLaunchKernelGGL(k_bcf_list_fill, dim3(lblocks), dim3(LIST_TPB), 0, s, d_data, p->out.lv_off[q], p->out.lv_cnt[q], p->d_list_blocks, p->d_scalars,
+                       row_bound, (unsigned)std::min<int64_t>(p->max_bytes + 1, 0xFFFFFFFFLL), kind, offsets, p->out.info[q],
+                       (uint8_t*)p->lbufs[6 * q + 3], p->d_scalars + 1);
+    hipLaunchKernelGGL(k_pack_bits, dim3(1024), dim3(256), 0, s, (const uint8_t*)p->lbufs[6 * q + 3], offsets, p->d_scalars, row_bound,
+                       (uint8_t*)p->lbufs[6 * q + 4]);
+  }
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(p->h_scalars, p->d_scalars, 12, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -415,6 +525,10 @@ int exon_hip_bcf_parser_parse(exon_hip_bcf_parser* p, void* stream, const uint8_
     cols->infos[q] = p->ik.kind[q] != 'b' ? p->out.info[q] : nullptr;
     cols->infos_valid[q] = (uint8_t*)p->out.info_valid[q];
     cols->info_kinds[q] = p->ik.kind[q];
+    if (p->ik.kind[q] == 'F' || p->ik.kind[q] == 'I') {
+      cols->list_offsets[q] = (int32_t*)p->lbufs[6 * q + 2];
+      cols->list_item_valid[q] = (uint8_t*)p->lbufs[6 * q + 4];
+    }
   }
   return EXON_HIP_OK;
 }

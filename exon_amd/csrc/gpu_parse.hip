@@ -26,6 +26,7 @@
 
 #include "host/decimal_f32.h"
 #include "internal.h"
+#include "list_kernels.h"
 
 namespace {
 
@@ -527,20 +528,7 @@ static hipError_t build_name_table(exon_hip_ctx* ctx, const char* const* names_i
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// ---- list-valued INFO fields ('F' / 'I'): offsets by a scan of the per-row item counts, then the items ------------------
-constexpr int LIST_TPB = 256;
-// per-workgroup sums of cnt[0 .. n_rows) (n_rows read from the device: the line count of this slab)
-__global__ __launch_bounds__(LIST_TPB) void k_list_block_sums(const uint32_t* __restrict__ cnt, const unsigned* __restrict__ n_rows_p,
-                                                              unsigned cap, unsigned* __restrict__ block_sums) {
-  __shared__ unsigned red[LIST_TPB / 64];
-  const unsigned n_rows = min(*n_rows_p, cap);
-  const unsigned row = blockIdx.x * LIST_TPB + threadIdx.x;
-  unsigned c = row < n_rows ? cnt[row] : 0u;
-  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-}
+// ---- list-valued INFO fields ('F' / 'I'): offsets by a scan of the per-row item counts (list_kernels.h), then the items ------
 // offsets[row] = exclusive prefix of cnt (block_offsets = scanned block sums), offsets[n_rows] = total; every row parses its
 // items into values[offsets[row] ..]: '.' or an empty item -> NULL item (flag 0), anything unparsable -> undecided (host)
 __global__ __launch_bounds__(LIST_TPB) void k_list_fill(const uint8_t* __restrict__ text, unsigned n_total, const uint32_t* __restrict__ lv_off,
@@ -548,21 +536,10 @@ __global__ __launch_bounds__(LIST_TPB) void k_list_fill(const uint8_t* __restric
                                                         const unsigned* __restrict__ n_rows_p, unsigned cap, unsigned cap_items, char kind,
                                                         int32_t* __restrict__ offsets, float* __restrict__ values,
                                                         uint8_t* __restrict__ item_flags, unsigned* __restrict__ exceptions) {
-  __shared__ unsigned wave_tot[LIST_TPB / 64];
   const unsigned n_rows = min(*n_rows_p, cap);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned row = blockIdx.x * LIST_TPB + threadIdx.x;
   const unsigned c = row < n_rows ? cnt[row] : 0u;
-  unsigned incl = c;
-  for (int o = 1; o < 64; o <<= 1) {
-    const unsigned t = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += t;
-  }
-  if (lane == 63) wave_tot[wave] = incl;
-  __syncthreads();
-  unsigned base = block_offsets[blockIdx.x];
-  for (int w = 0; w < wave; ++w) base += wave_tot[w];
-  const unsigned first = base + incl - c;
+  const unsigned first = list_first_item(c, block_offsets);
   if (row < n_rows) offsets[row] = (int32_t)first;
   if (row + 1 == n_rows) offsets[n_rows] = (int32_t)(first + c);
   if (row == 0 && n_rows == 0) offsets[0] = 0;
@@ -605,17 +582,6 @@ __global__ __launch_bounds__(LIST_TPB) void k_list_fill(const uint8_t* __restric
   }
   if (bad) atomicAdd(exceptions, 1u);
 }
-// byte-per-item flags -> Arrow validity bitmap (8 items per thread); n = offsets[n_rows]
-__global__ __launch_bounds__(256) void k_pack_bits(const uint8_t* __restrict__ flags, const int32_t* __restrict__ offsets,
-                                                   const unsigned* __restrict__ n_rows_p, unsigned cap, uint8_t* __restrict__ bitmap) {
-  const unsigned n = (unsigned)offsets[min(*n_rows_p, cap)];
-  for (unsigned b = blockIdx.x * 256 + threadIdx.x; b * 8 < n; b += gridDim.x * 256) {
-    unsigned v = 0;
-    for (unsigned k = 0; k < 8 && b * 8 + k < n; ++k) v |= (unsigned)(flags[b * 8 + k] & 1) << k;
-    bitmap[b] = (uint8_t)v;
-  }
-}
-
 struct exon_hip_vcf_parser {
   exon_hip_ctx* ctx = nullptr;
   int64_t max_bytes = 0, max_rows = 0;
@@ -805,7 +771,7 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* p, void* stream, const uint8_
     const int lblocks = (int)((row_bound + LIST_TPB - 1) / LIST_TPB);
     int32_t* offsets = (int32_t*)p->list_bufs[5 * q + 2];
     hipLaunchKernelGGL(k_list_block_sums, dim3(lblocks), dim3(LIST_TPB), 0, s, p->out.lv_cnt[q], p->d_scalars, (unsigned)row_bound, p->d_list_blocks);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, p->d_list_blocks, lblocks, p->d_scalars + 3, 0);
+    hipLaunchKernelGGL(k_list_scan_blocks, dim3(1), dim3(1024), 0, s, p->d_list_blocks, lblocks, p->d_scalars + 3);
     hipLaunchKernelGGL(k_list_fill, dim3(lblocks), dim3(LIST_TPB), 0, s, d_text, (unsigned)n_bytes, p->out.lv_off[q], p->out.lv_cnt[q], p->d_list_blocks,
                        p->d_scalars, (unsigned)row_bound, (unsigned)std::min<int64_t>(p->cap_items, 0xFFFFFFFFLL), kind, offsets, p->out.info[q],
                        (uint8_t*)p->list_bufs[5 * q + 3], p->out.exceptions);

@@ -642,6 +642,34 @@ __global__ __launch_bounds__(S::THREADS) void k3_flag_mapq_group_count_main(
     atomicAdd(&mine[(pass && key <= (unsigned)R) ? key : dummy], 1u);
   };
 
+  // The 4 rows of a lane x 64 lanes = 256 consecutive rows.  In a coordinate-sorted BAM (the normal case) they all carry
+  // ONE reference: 64 lanes adding to the same LDS counter serialise (measured: 1.6 x the step time of the synthetic mix,
+  // tools/time_skew.py), so when every passing row of the group has the same key one lane adds the group's count --
+  // three wave-uniform tests per 256 rows.  Mixed keys take the branch-free per-row adds.
+  auto rows4 = [&](int4 f4, unsigned q4, int4 r4, unsigned fv, unsigned mv, unsigned rv) {
+    const bool p0 = (fv >> 0 & 1) && ((f4.x & mask) == value) && (mv >> 0 & 1) && ((int32_t)(q4 & 0xFF) >= qmin);
+    const bool p1 = (fv >> 1 & 1) && ((f4.y & mask) == value) && (mv >> 1 & 1) && ((int32_t)(q4 >> 8 & 0xFF) >= qmin);
+    const bool p2 = (fv >> 2 & 1) && ((f4.z & mask) == value) && (mv >> 2 & 1) && ((int32_t)(q4 >> 16 & 0xFF) >= qmin);
+    const bool p3 = (fv >> 3 & 1) && ((f4.w & mask) == value) && (mv >> 3 & 1) && ((int32_t)(q4 >> 24) >= qmin);
+    const unsigned k0 = (rv >> 0 & 1) ? (unsigned)r4.x : (unsigned)R, k1 = (rv >> 1 & 1) ? (unsigned)r4.y : (unsigned)R;
+    const unsigned k2 = (rv >> 2 & 1) ? (unsigned)r4.z : (unsigned)R, k3 = (rv >> 3 & 1) ? (unsigned)r4.w : (unsigned)R;
+    kmax = max(max(kmax, p0 ? k0 : 0u), max(max(p1 ? k1 : 0u, p2 ? k2 : 0u), p3 ? k3 : 0u));
+    const unsigned long long has = __ballot(p0 | p1 | p2 | p3);
+    if (has == 0) return;  // no passing row among the 256
+    const unsigned mine_key = p0 ? k0 : p1 ? k1 : p2 ? k2 : k3;
+    const unsigned kw = (unsigned)__builtin_amdgcn_readlane((int)mine_key, (int)__ffsll((long long)has) - 1);
+    const bool mixed = (p0 && k0 != kw) | (p1 && k1 != kw) | (p2 && k2 != kw) | (p3 && k3 != kw);
+    if (!__any(mixed) && kw <= (unsigned)R) {
+      const unsigned total = (unsigned)(__popcll(__ballot(p0)) + __popcll(__ballot(p1)) + __popcll(__ballot(p2)) + __popcll(__ballot(p3)));
+      if (lane == 0) atomicAdd(&mine[kw], total);
+      return;
+    }
+    atomicAdd(&mine[(p0 && k0 <= (unsigned)R) ? k0 : dummy], 1u);
+    atomicAdd(&mine[(p1 && k1 <= (unsigned)R) ? k1 : dummy], 1u);
+    atomicAdd(&mine[(p2 && k2 <= (unsigned)R) ? k2 : dummy], 1u);
+    atomicAdd(&mine[(p3 && k3 <= (unsigned)R) ? k3 : dummy], 1u);
+  };
+
   const int64_t ntiles = n / TILE;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t wbase = tile * TILE + (int64_t)wave * WT;
@@ -658,12 +686,8 @@ __global__ __launch_bounds__(S::THREADS) void k3_flag_mapq_group_count_main(
       rm[j] = valid4_ones(rvalid, ones, wbase, j, lane);
     }
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-      row(f[j].x, q[j] & 0xFF, g[j].x, fm[j] >> 0 & 1, mm[j] >> 0 & 1, rm[j] >> 0 & 1);
-      row(f[j].y, q[j] >> 8 & 0xFF, g[j].y, fm[j] >> 1 & 1, mm[j] >> 1 & 1, rm[j] >> 1 & 1);
-      row(f[j].z, q[j] >> 16 & 0xFF, g[j].z, fm[j] >> 2 & 1, mm[j] >> 2 & 1, rm[j] >> 2 & 1);
-      row(f[j].w, q[j] >> 24, g[j].w, fm[j] >> 3 & 1, mm[j] >> 3 & 1, rm[j] >> 3 & 1);
-    }
+    for (int j = 0; j < J; ++j)
+      rows4(f[j], q[j], g[j], fm[j], mm[j], rm[j]);
   }
   for (int64_t r = ntiles * TILE + (int64_t)blockIdx.x * THREADS + threadIdx.x; r < n;
        r += (int64_t)gridDim.x * THREADS)
@@ -711,15 +735,29 @@ __global__ __launch_bounds__(256) void k3_flag_mapq_group_count_global(
     const uint8_t* __restrict__ mvalid, const int32_t* __restrict__ ref, const uint8_t* __restrict__ rvalid, int64_t n,
     int32_t mask, int32_t value, int32_t qmin, int32_t R, unsigned long long* __restrict__ counts, int* __restrict__ status) {
   bool bad = false;
-  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
-    const bool pass = valid1(fvalid, r) && ((flag[r] & mask) == value) && valid1(mvalid, r) && ((int32_t)mapq[r] >= qmin);
-    if (!pass) continue;
-    const unsigned key = valid1(rvalid, r) ? (unsigned)ref[r] : (unsigned)R;
-    if (key > (unsigned)R) {
-      bad = true;
-      continue;
+  const int lane = threadIdx.x & 63;
+  const int64_t n64 = (n + 63) & ~(int64_t)63;  // whole waves stay in the loop together: the ballots need every lane
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n64; r += (int64_t)gridDim.x * 256) {
+    bool pass = false;
+    unsigned key = 0;
+    if (r < n) {
+      pass = valid1(fvalid, r) && ((flag[r] & mask) == value) && valid1(mvalid, r) && ((int32_t)mapq[r] >= qmin);
+      key = valid1(rvalid, r) ? (unsigned)ref[r] : (unsigned)R;
+      if (pass && key > (unsigned)R) {
+        bad = true;
+        pass = false;
+      }
     }
-    atomicAdd(&counts[key], 1ull);
+    // a coordinate-sorted file gives a wave 64 reads of ONE reference: one atomic for the wave instead of 64 on one address
+    const unsigned long long pm = __ballot(pass);
+    if (pm == 0) continue;  // wave-uniform
+    const int leader = (int)__ffsll((long long)pm) - 1;
+    const unsigned kw = (unsigned)__builtin_amdgcn_readlane((int)key, leader);
+    if (__ballot(pass && key != kw) == 0) {
+      if (lane == leader) atomicAdd(&counts[kw], (unsigned long long)__popcll(pm));
+    } else if (pass) {
+      atomicAdd(&counts[key], 1ull);
+    }
   }
   if (bad) atomicOr(&status[0], 2);  // same status bit as the LDS path: reference id out of range
 }
@@ -874,6 +912,37 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
     atomicAdd(&e->cnn, yv);
     atomicAdd(&e->sum, yv ? ydbl(yf) : 0.0);
   };
+  // The 4 rows of a lane x 64 lanes = 256 consecutive rows.  When every tier-2 row among them has the SAME key -- a file whose
+  // dominant FILTER list got a dictionary id >= G, or rows sorted by key -- 64 lanes adding to one LDS entry serialise
+  // (measured: 2.6 x the step time of the mixed-key case, tools/time_skew.py); then ONE lane adds the group's totals
+  // (counts from ballots, the sum from a wave reduction).  Mixed keys take the branch-free per-row adds.
+  auto rows4_lds = [&](unsigned p0, unsigned p1, unsigned p2, unsigned p3, float4 y4, int4 g4, unsigned yv) {
+    const unsigned i0 = p0 & unsigned((unsigned)g4.x - (unsigned)G < (unsigned)NO), i1 = p1 & unsigned((unsigned)g4.y - (unsigned)G < (unsigned)NO);
+    const unsigned i2 = p2 & unsigned((unsigned)g4.z - (unsigned)G < (unsigned)NO), i3 = p3 & unsigned((unsigned)g4.w - (unsigned)G < (unsigned)NO);
+    const unsigned long long has = __ballot((i0 | i1 | i2 | i3) != 0);
+    if (has == 0) return;
+    const int mine_key = i0 ? g4.x : i1 ? g4.y : i2 ? g4.z : g4.w;
+    const int kw = __builtin_amdgcn_readlane(mine_key, (int)__ffsll((long long)has) - 1);
+    const bool mixed = (i0 && g4.x != kw) | (i1 && g4.y != kw) | (i2 && g4.z != kw) | (i3 && g4.w != kw);
+    if (!__any(mixed)) {
+      const unsigned y0 = i0 & (yv >> 0 & 1), y1 = i1 & (yv >> 1 & 1), y2 = i2 & (yv >> 2 & 1), y3 = i3 & (yv >> 3 & 1);
+      const unsigned rows = (unsigned)(__popcll(__ballot(i0 != 0)) + __popcll(__ballot(i1 != 0)) + __popcll(__ballot(i2 != 0)) + __popcll(__ballot(i3 != 0)));
+      const unsigned nn = (unsigned)(__popcll(__ballot(y0 != 0)) + __popcll(__ballot(y1 != 0)) + __popcll(__ballot(y2 != 0)) + __popcll(__ballot(y3 != 0)));
+      const double part = ((y0 ? ydbl(y4.x) : 0.0) + (y1 ? ydbl(y4.y) : 0.0)) + ((y2 ? ydbl(y4.z) : 0.0) + (y3 ? ydbl(y4.w) : 0.0));
+      const double tot = wave_sum(part);
+      if (lane == 0) {
+        K4Entry* e = &k4_ovf[(unsigned)kw - (unsigned)G];
+        atomicAdd(&e->crow, rows);
+        atomicAdd(&e->cnn, nn);
+        atomicAdd(&e->sum, tot);
+      }
+      return;
+    }
+    row_lds(p0, y4.x, g4.x, yv >> 0 & 1);
+    row_lds(p1, y4.y, g4.y, yv >> 1 & 1);
+    row_lds(p2, y4.z, g4.z, yv >> 2 & 1);
+    row_lds(p3, y4.w, g4.w, yv >> 3 & 1);
+  };
   // tier 3, partitioned form: append the row to this workgroup's region (one LDS atomic per wave instruction reserves the
   // slots of all its tier-3 lanes; the id ranges are counted in an LDS histogram, flushed once per workgroup)
   __shared__ unsigned tail_cursor;
@@ -948,10 +1017,7 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
         // largest id among this lane's 4 rows (unsigned: a negative id is "huge" and is reported through gmax)
         const unsigned gm = max(max((unsigned)gs[j].x, (unsigned)gs[j].y), max((unsigned)gs[j].z, (unsigned)gs[j].w));
         if (__any(gm >= (unsigned)G)) {
-          row_lds(p0, ys[j].x, gs[j].x, ym[j] >> 0 & 1);
-          row_lds(p1, ys[j].y, gs[j].y, ym[j] >> 1 & 1);
-          row_lds(p2, ys[j].z, gs[j].z, ym[j] >> 2 & 1);
-          row_lds(p3, ys[j].w, gs[j].w, ym[j] >> 3 & 1);
+          rows4_lds(p0, p1, p2, p3, ys[j], gs[j], ym[j]);
           if (NG > NL && __any(gm >= (unsigned)NL)) {
             if (tail.rec) {
               row_tail_append(p0, ys[j].x, gs[j].x, ym[j] >> 0 & 1);
@@ -1167,19 +1233,44 @@ __global__ __launch_bounds__(256) void k4_cmp_avg_by_group_global(const float* _
 // blocks summed in order.  The state was zeroed (overwrite) or holds earlier launches; tier 3 has added to it already.
 __global__ __launch_bounds__(256) void k4_finalize_head(const unsigned long long* __restrict__ partials, int nblocks, int RG, int NG,
                                                         unsigned long long* __restrict__ counts, double* __restrict__ sums) {
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  if (v >= 3 * RG) return;
-  const int kind = v / RG, g = v - kind * RG;
-  const unsigned long long* p = partials + v;
-  const size_t stride = (size_t)3 * RG;
-  if (kind < 2) {
-    unsigned long long t = 0;
-    for (int b = 0; b < nblocks; ++b) t += p[(size_t)b * stride];
-    if (t) counts[(size_t)kind * NG + g] += t;
-  } else {
-    double t = 0.0;
-    for (int b = 0; b < nblocks; ++b) t += __longlong_as_double((long long)p[(size_t)b * stride]);
-    sums[g] += t;
+  // the shape of finalize_partials: 32 values x 8 segments of the workgroup range per block, 4 loads in flight per thread
+  __shared__ unsigned long long red[8][32];
+  const int vi = threadIdx.x & 31, seg = threadIdx.x >> 5;
+  const int v = blockIdx.x * 32 + vi, V = 3 * RG;
+  const int kind = v < V ? v / RG : 0, g = v - kind * RG;
+  const int per = (nblocks + 7) / 8;
+  const int b0 = seg * per, b1 = min(nblocks, b0 + per);
+  unsigned long long acc_i = 0;
+  double acc_f = 0.0;
+  if (v < V) {
+    const unsigned long long* p = partials + v;
+    int b = b0;
+    if (kind < 2) {
+      for (; b + 4 <= b1; b += 4) acc_i += p[(size_t)b * V] + p[(size_t)(b + 1) * V] + p[(size_t)(b + 2) * V] + p[(size_t)(b + 3) * V];
+      for (; b < b1; ++b) acc_i += p[(size_t)b * V];
+    } else {
+      for (; b + 4 <= b1; b += 4) {
+        const double a0 = __longlong_as_double((long long)p[(size_t)b * V]), a1 = __longlong_as_double((long long)p[(size_t)(b + 1) * V]),
+                     a2 = __longlong_as_double((long long)p[(size_t)(b + 2) * V]), a3 = __longlong_as_double((long long)p[(size_t)(b + 3) * V]);
+        acc_f += ((a0 + a1) + (a2 + a3));
+      }
+      for (; b < b1; ++b) acc_f += __longlong_as_double((long long)p[(size_t)b * V]);
+    }
+  }
+  red[seg][vi] = kind < 2 ? acc_i : (unsigned long long)__double_as_longlong(acc_f);
+  __syncthreads();
+  if (seg == 0 && v < V) {
+    if (kind < 2) {
+      unsigned long long t = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += red[k][vi];
+      if (t) counts[(size_t)kind * NG + g] += t;
+    } else {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += __longlong_as_double((long long)red[k][vi]);
+      sums[g] += t;
+    }
   }
 }
 
@@ -1347,7 +1438,7 @@ static hipError_t k4_one_launch(hipStream_t s, const LaunchCfg& cfg, const Works
   }
   if (e != hipSuccess) return e;
   if (has_tail) {
-    hipLaunchKernelGGL(k4_finalize_head, dim3((3 * nl + 255) / 256), dim3(256), 0, s, ws.partials, grid, nl, n_groups,
+    hipLaunchKernelGGL(k4_finalize_head, dim3((3 * nl + 31) / 32), dim3(256), 0, s, ws.partials, grid, nl, n_groups,
                        reinterpret_cast<unsigned long long*>(d_counts), d_sums);
     if (partition) {
       const int64_t tile = big ? ShapeOf<ShapeBigJ2>::TILE : ShapeOf<ShapeSmall>::TILE;

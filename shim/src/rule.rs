@@ -248,9 +248,15 @@ fn match_c4(
         return None;
     }
     let (l, op, r) = cmp(&parts[0])?;
+    // Float32 field vs Float64 literal (DataFusion widens the column); Int32 field (INFO Type=Integer,
+    // exon-core/src/datasources/vcf/schema_builder.rs:197-205) vs an integer literal: the library compares integers exactly
+    // (exon_hip_plan_desc.x_type comes from the file's header in exon_hip_stream_consume_scan); an i64 beyond 2^53 loses
+    // bits in `as f64`, but it is beyond int32 too, so the comparison saturates the same way
     let thr = match lit(&r)? {
         ScalarValue::Float64(Some(v)) => v,
         ScalarValue::Float32(Some(v)) => v as f64,
+        ScalarValue::Int64(Some(v)) => v as f64,
+        ScalarValue::Int32(Some(v)) => v as f64,
         _ => return None,
     };
     let field = info_field_of(&l)?;

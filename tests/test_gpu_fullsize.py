@@ -134,3 +134,24 @@ def test_config5_one_billion_reads_in_one_chunked_launch(ctx):
     assert h[:, :33].sum() == 0 and h[:, 75:].sum() == 0
     plan.close()
     data.free(); off.free()
+
+
+def test_high_cardinality_group_by_beyond_one_tier3_launch_properties(ctx):
+    """K4 with 50 000 keys over 3e8 rows: more rows than one launch of the partitioned tier 3 covers (2^28), so the table runs
+    as two launches.  Property: folding the 50 000 keys onto the 5 FILTER ids they were derived from reproduces the 5-key
+    kernel's counts exactly (and its sums to 1e-12) -- registers, LDS tier and the compacted / partitioned tier all feed it --
+    and every key is seen."""
+    n, G = 300_000_000, 50_000
+    af, av, q, qv, fid = ctx.gen_c4(4, 0, n)
+    base_c, base_s = k4(ctx, (af, av, q, qv, fid), n, 0.01, ">")
+    keys = fid.to_host().astype(np.int32)
+    keys += (5 * (np.arange(n, dtype=np.int64) % 10_000)).astype(np.int32)  # key = filter id + 5 * (row mod 10 000)
+    d_keys = ctx.to_device(keys)
+    del keys
+    c, s = k4(ctx, (af, av, q, qv, d_keys), n, 0.01, ">", G=G)
+
+    def fold(v):
+        return v.reshape(10_000, 5).sum(axis=0)
+    assert np.array_equal(fold(c[:G]), base_c[:5]) and np.array_equal(fold(c[G:]), base_c[5:])
+    assert np.allclose(fold(s), base_s, rtol=1e-12, atol=0)
+    assert (c[G:] > 0).all()

@@ -188,6 +188,53 @@ def test_gpu_vcf_parser_list_valued_info(ctx, tmp_path):
     par.close()
 
 
+@pytest.mark.gpu
+def test_gpu_bcf_parser_list_valued_info(ctx, tmp_path):
+    """The BCF twin of the test above: typed int8 / int16 / int32 / float vectors -> List<Int32> / List<Float32> on the device
+    (missing value -> NULL item, one missing item -> NULL list), next to an exact Int32 scalar."""
+    import ctypes as C
+    import gzip
+    import struct
+    import vcf_bcf_writer as W
+    from exon_amd import _lib as L
+    rows = W.make_rows(20_000, seed=6)
+    path = tmp_path / "l.bcf"
+    W.write_bcf(path, rows, BGZIP)
+    raw = gzip.decompress(open(path, "rb").read())
+    l_text, = struct.unpack_from("<I", raw, 5)
+    body = raw[9 + l_text:]
+    sidx = W.string_index()
+    h = C.c_void_p()
+    ctx._check(ctx.lib.exon_hip_bcf_parser_create(ctx.h, 2, len(sidx), 0, -1, len(body) + 4096, C.byref(h)))
+    keys = (C.c_int32 * 3)(sidx["AC"], sidx["MQS"], sidx["DP"])
+    ctx._check(ctx.lib.exon_hip_bcf_parser_set_info_keys(h, keys, b"IFi", 3))
+    d = ctx.to_device(np.frombuffer(body + bytes(64), np.uint8))
+    cols = L.VCFColumns()
+    ctx._check(ctx.lib.exon_hip_bcf_parser_parse(h, None, d.ptr, len(body), C.byref(cols)))
+    n = cols.n_rows
+    assert n == len(rows) and cols.n_undecided == 0 and cols.n_info == 3 and cols.info_kinds[:3] == b"IFi"
+
+    def dev(ptr, dtype, count):
+        out = np.empty(count, dtype)
+        if count:
+            ctx._check(ctx.lib.exon_hip_memcpy_d2h(ctx.h, out.ctypes.data, ptr, out.nbytes, None))
+        return out
+    for k, (key, dtype) in enumerate((("AC", np.int32), ("MQS", np.float32))):
+        want = W.expected_column(rows, key)
+        valid = _bits(dev(cols.infos_valid[k], np.uint8, (n + 7) // 8), n)
+        off = dev(cols.list_offsets[k], np.int32, n + 1)
+        total = int(off[-1])
+        items = dev(cols.infos[k], dtype, total)
+        ivalid = _bits(dev(cols.list_item_valid[k], np.uint8, (total + 7) // 8), total) if total else np.zeros(0, bool)
+        assert off[0] == 0 and np.all(np.diff(off) >= 0) and total == sum(len(x) for x in want if x is not None)
+        got = [None if not valid[r] else [items[i].item() if ivalid[i] else None for i in range(off[r], off[r + 1])] for r in range(n)]
+        assert got == want, key
+    v = _bits(dev(cols.infos_valid[2], np.uint8, (n + 7) // 8), n)
+    vals = dev(cols.infos[2], np.int32, n)
+    assert [vals[r].item() if v[r] else None for r in range(n)] == W.expected_column(rows, "DP")
+    ctx._check(ctx.lib.exon_hip_bcf_parser_destroy(h))
+
+
 def _k4(ctx, path, fmt, fields, columns, gpu_parse, thr):
     scan = exon_amd.Scan(str(path), fmt, info_field=fields, gpu_parse=gpu_parse)
     plan = ctx.plan_cmp_avg_by_group(">", thr, 64, columns=columns)
