@@ -646,6 +646,7 @@ __global__ __launch_bounds__(S::THREADS) void k3_flag_mapq_group_count_main(
   // ONE reference: 64 lanes adding to the same LDS counter serialise (measured: 1.6 x the step time of the synthetic mix,
   // tools/time_skew.py), so when every passing row of the group has the same key one lane adds the group's count --
   // three wave-uniform tests per 256 rows.  Mixed keys take the branch-free per-row adds.
+  int uni_skip = 0;  // wave-uniform
   auto rows4 = [&](int4 f4, unsigned q4, int4 r4, unsigned fv, unsigned mv, unsigned rv) {
     const bool p0 = (fv >> 0 & 1) && ((f4.x & mask) == value) && (mv >> 0 & 1) && ((int32_t)(q4 & 0xFF) >= qmin);
     const bool p1 = (fv >> 1 & 1) && ((f4.y & mask) == value) && (mv >> 1 & 1) && ((int32_t)(q4 >> 8 & 0xFF) >= qmin);
@@ -654,20 +655,29 @@ __global__ __launch_bounds__(S::THREADS) void k3_flag_mapq_group_count_main(
     const unsigned k0 = (rv >> 0 & 1) ? (unsigned)r4.x : (unsigned)R, k1 = (rv >> 1 & 1) ? (unsigned)r4.y : (unsigned)R;
     const unsigned k2 = (rv >> 2 & 1) ? (unsigned)r4.z : (unsigned)R, k3 = (rv >> 3 & 1) ? (unsigned)r4.w : (unsigned)R;
     kmax = max(max(kmax, p0 ? k0 : 0u), max(max(p1 ? k1 : 0u, p2 ? k2 : 0u), p3 ? k3 : 0u));
-    const unsigned long long has = __ballot(p0 | p1 | p2 | p3);
-    if (has == 0) return;  // no passing row among the 256
-    const unsigned mine_key = p0 ? k0 : p1 ? k1 : p2 ? k2 : k3;
-    const unsigned kw = (unsigned)__builtin_amdgcn_readlane((int)mine_key, (int)__ffsll((long long)has) - 1);
-    const bool mixed = (p0 && k0 != kw) | (p1 && k1 != kw) | (p2 && k2 != kw) | (p3 && k3 != kw);
-    if (!__any(mixed) && kw <= (unsigned)R) {
-      const unsigned total = (unsigned)(__popcll(__ballot(p0)) + __popcll(__ballot(p1)) + __popcll(__ballot(p2)) + __popcll(__ballot(p3)));
-      if (lane == 0) atomicAdd(&mine[kw], total);
-      return;
+    // operands of the four adds; ONE code path issues them -- the uniform-key case only rewrites the operands
+    unsigned s0 = (p0 && k0 <= (unsigned)R) ? k0 : dummy, s1 = (p1 && k1 <= (unsigned)R) ? k1 : dummy;
+    unsigned s2 = (p2 && k2 <= (unsigned)R) ? k2 : dummy, s3 = (p3 && k3 <= (unsigned)R) ? k3 : dummy;
+    unsigned a0 = 1u;
+    if (uni_skip > 0) {  // the last test found mixed keys: no test for the next 15 groups
+      --uni_skip;
+    } else {
+      const unsigned kw = (unsigned)__builtin_amdgcn_readfirstlane((int)k0);
+      const bool same = (k0 == kw) & (k1 == kw) & (k2 == kw) & (k3 == kw);
+      if (__all(same) && kw <= (unsigned)R) {
+        // all 256 rows carry ONE reference: lane 0 adds the group's count once, every other add goes to a dummy slot
+        const unsigned total = (unsigned)(__popcll(__ballot(p0)) + __popcll(__ballot(p1)) + __popcll(__ballot(p2)) + __popcll(__ballot(p3)));
+        s0 = lane == 0 ? kw : dummy;
+        a0 = lane == 0 ? total : 0u;
+        s1 = s2 = s3 = dummy;
+      } else {
+        uni_skip = 15;
+      }
     }
-    atomicAdd(&mine[(p0 && k0 <= (unsigned)R) ? k0 : dummy], 1u);
-    atomicAdd(&mine[(p1 && k1 <= (unsigned)R) ? k1 : dummy], 1u);
-    atomicAdd(&mine[(p2 && k2 <= (unsigned)R) ? k2 : dummy], 1u);
-    atomicAdd(&mine[(p3 && k3 <= (unsigned)R) ? k3 : dummy], 1u);
+    atomicAdd(&mine[s0], a0);
+    atomicAdd(&mine[s1], 1u);
+    atomicAdd(&mine[s2], 1u);
+    atomicAdd(&mine[s3], 1u);
   };
 
   const int64_t ntiles = n / TILE;
@@ -835,12 +845,13 @@ struct K4Tail {                 // tier 3 (unused when NG == NL)
   uint2* rec;                   // [grid][cap_wg]
   unsigned* wg_count;           // [grid] records each workgroup wrote
   unsigned* hist;               // [n_ranges] records per id range (all workgroups)
+  int no_uniform_test;          // EXON_HIP_K4_UNIFORM=0 (A/B): tier 2 never tests for a uniform key
 };
 struct K4Entry {  // tier-2 table entry
   double sum;
   unsigned cnn, crow;
 };
-template <int G, typename S, bool OVF>
+template <int G, typename S, bool OVF, bool YI = false>
 __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
     const float* __restrict__ x, const uint8_t* __restrict__ xvalid, const float* __restrict__ y,
     const uint8_t* __restrict__ yvalid, const int32_t* __restrict__ gid, int64_t n, int32_t klo, int32_t khi,
@@ -886,7 +897,12 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
   };
   // AVG's argument widened to f64 (DataFusion casts Float32 AND Int32 arguments of avg to Float64): yint != 0 when the
   // column holds Int32 values (an INFO field of Type=Integer)
-  auto ydbl = [&](float yf) -> double { return yint ? (double)__float_as_int(yf) : (double)yf; };
+  // (the instruction-bound > 8-group variant gets the choice at compile time -- YI -- instead of two conversions and a
+  // 64-bit select per row: 3 of its ~50 vector instructions)
+  auto ydbl = [&](float yf) -> double {
+    if (OVF) return YI ? (double)__float_as_int(yf) : (double)yf;
+    return yint ? (double)__float_as_int(yf) : (double)yf;
+  };
   // tier 1: register groups (every row); `pass` = the row's predicate
   auto row = [&](unsigned pass, float yf, int32_t g, unsigned yv) {
     unsigned yq = pass & yv;
@@ -909,39 +925,27 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
     const unsigned in2 = pass & unsigned((unsigned)g - (unsigned)G < (unsigned)NO);
     K4Entry* e = &k4_ovf[in2 ? (unsigned)g - (unsigned)G : dummy];
     atomicAdd(&e->crow, 1u);
-    atomicAdd(&e->cnn, yv);
-    atomicAdd(&e->sum, yv ? ydbl(yf) : 0.0);
+    atomicAdd(&e->cnn, in2 & yv);
+    atomicAdd(&e->sum, (in2 & yv) ? ydbl(yf) : 0.0);
   };
-  // The 4 rows of a lane x 64 lanes = 256 consecutive rows.  When every tier-2 row among them has the SAME key -- a file whose
-  // dominant FILTER list got a dictionary id >= G, or rows sorted by key -- 64 lanes adding to one LDS entry serialise
-  // (measured: 2.6 x the step time of the mixed-key case, tools/time_skew.py); then ONE lane adds the group's totals
-  // (counts from ballots, the sum from a wave reduction).  Mixed keys take the branch-free per-row adds.
-  auto rows4_lds = [&](unsigned p0, unsigned p1, unsigned p2, unsigned p3, float4 y4, int4 g4, unsigned yv) {
-    const unsigned i0 = p0 & unsigned((unsigned)g4.x - (unsigned)G < (unsigned)NO), i1 = p1 & unsigned((unsigned)g4.y - (unsigned)G < (unsigned)NO);
-    const unsigned i2 = p2 & unsigned((unsigned)g4.z - (unsigned)G < (unsigned)NO), i3 = p3 & unsigned((unsigned)g4.w - (unsigned)G < (unsigned)NO);
-    const unsigned long long has = __ballot((i0 | i1 | i2 | i3) != 0);
-    if (has == 0) return;
-    const int mine_key = i0 ? g4.x : i1 ? g4.y : i2 ? g4.z : g4.w;
-    const int kw = __builtin_amdgcn_readlane(mine_key, (int)__ffsll((long long)has) - 1);
-    const bool mixed = (i0 && g4.x != kw) | (i1 && g4.y != kw) | (i2 && g4.z != kw) | (i3 && g4.w != kw);
-    if (!__any(mixed)) {
-      const unsigned y0 = i0 & (yv >> 0 & 1), y1 = i1 & (yv >> 1 & 1), y2 = i2 & (yv >> 2 & 1), y3 = i3 & (yv >> 3 & 1);
-      const unsigned rows = (unsigned)(__popcll(__ballot(i0 != 0)) + __popcll(__ballot(i1 != 0)) + __popcll(__ballot(i2 != 0)) + __popcll(__ballot(i3 != 0)));
-      const unsigned nn = (unsigned)(__popcll(__ballot(y0 != 0)) + __popcll(__ballot(y1 != 0)) + __popcll(__ballot(y2 != 0)) + __popcll(__ballot(y3 != 0)));
-      const double part = ((y0 ? ydbl(y4.x) : 0.0) + (y1 ? ydbl(y4.y) : 0.0)) + ((y2 ? ydbl(y4.z) : 0.0) + (y3 ? ydbl(y4.w) : 0.0));
-      const double tot = wave_sum(part);
-      if (lane == 0) {
-        K4Entry* e = &k4_ovf[(unsigned)kw - (unsigned)G];
-        atomicAdd(&e->crow, rows);
-        atomicAdd(&e->cnn, nn);
-        atomicAdd(&e->sum, tot);
-      }
-      return;
+  // The 4 rows of a lane x 64 lanes = 256 consecutive rows.  When ALL of them carry the same key -- a file whose dominant
+  // FILTER list got a dictionary id >= G, or rows sorted by key -- 64 lanes adding to one LDS entry serialise (measured:
+  // 2.6 x the step time of the mixed-key case, tools/time_skew.py); then lane 0 adds the group's totals (counts from
+  // ballots, the sum from a wave reduction).  The test (4 compares + a vote) is skipped for 15 groups after it found mixed
+  // keys, and the mixed-key code is the plain per-row path above: this variant is instruction-bound.
+  int uni_skip = tail.no_uniform_test ? 0x7FFFFFFF : 0;  // wave-uniform
+  auto rows4_uniform = [&](int kw, unsigned p0, unsigned p1, unsigned p2, unsigned p3, float4 y4, unsigned yv) {
+    if ((unsigned)kw - (unsigned)G >= (unsigned)NO) return;  // the one key lives in another tier
+    const unsigned n0 = p0 & (yv >> 0 & 1), n1 = p1 & (yv >> 1 & 1), n2 = p2 & (yv >> 2 & 1), n3 = p3 & (yv >> 3 & 1);
+    const unsigned rows = (unsigned)(__popcll(__ballot(p0 != 0)) + __popcll(__ballot(p1 != 0)) + __popcll(__ballot(p2 != 0)) + __popcll(__ballot(p3 != 0)));
+    const unsigned nn = (unsigned)(__popcll(__ballot(n0 != 0)) + __popcll(__ballot(n1 != 0)) + __popcll(__ballot(n2 != 0)) + __popcll(__ballot(n3 != 0)));
+    const double tot = wave_sum(((n0 ? ydbl(y4.x) : 0.0) + (n1 ? ydbl(y4.y) : 0.0)) + ((n2 ? ydbl(y4.z) : 0.0) + (n3 ? ydbl(y4.w) : 0.0)));
+    if (lane == 0 && rows != 0) {
+      K4Entry* e = &k4_ovf[(unsigned)kw - (unsigned)G];
+      atomicAdd(&e->crow, rows);
+      atomicAdd(&e->cnn, nn);
+      atomicAdd(&e->sum, tot);
     }
-    row_lds(p0, y4.x, g4.x, yv >> 0 & 1);
-    row_lds(p1, y4.y, g4.y, yv >> 1 & 1);
-    row_lds(p2, y4.z, g4.z, yv >> 2 & 1);
-    row_lds(p3, y4.w, g4.w, yv >> 3 & 1);
   };
   // tier 3, partitioned form: append the row to this workgroup's region (one LDS atomic per wave instruction reserves the
   // slots of all its tier-3 lanes; the id ranges are counted in an LDS histogram, flushed once per workgroup)
@@ -1017,7 +1021,22 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
         // largest id among this lane's 4 rows (unsigned: a negative id is "huge" and is reported through gmax)
         const unsigned gm = max(max((unsigned)gs[j].x, (unsigned)gs[j].y), max((unsigned)gs[j].z, (unsigned)gs[j].w));
         if (__any(gm >= (unsigned)G)) {
-          rows4_lds(p0, p1, p2, p3, ys[j], gs[j], ym[j]);
+          bool uni = false;
+          const int kw = __builtin_amdgcn_readfirstlane(gs[j].x);
+          if (uni_skip > 0) {
+            --uni_skip;
+          } else {
+            uni = __all((gs[j].x == kw) & (gs[j].y == kw) & (gs[j].z == kw) & (gs[j].w == kw));
+            uni_skip = uni ? 0 : 15;
+          }
+          if (uni) {
+            rows4_uniform(kw, p0, p1, p2, p3, ys[j], ym[j]);
+          } else {
+            row_lds(p0, ys[j].x, gs[j].x, ym[j] >> 0 & 1);
+            row_lds(p1, ys[j].y, gs[j].y, ym[j] >> 1 & 1);
+            row_lds(p2, ys[j].z, gs[j].z, ym[j] >> 2 & 1);
+            row_lds(p3, ys[j].w, gs[j].w, ym[j] >> 3 & 1);
+          }
           if (NG > NL && __any(gm >= (unsigned)NL)) {
             if (tail.rec) {
               row_tail_append(p0, ys[j].x, gs[j].x, ym[j] >> 0 & 1);
@@ -1125,7 +1144,7 @@ static int k4_nl(int n_groups) { return n_groups < K4_LDS_GROUPS ? n_groups : K4
 
 size_t k4_partial_words(const LaunchCfg& cfg, int n_groups) { return (size_t)max_grid(cfg) * 3 * (size_t)k4_nl(n_groups); }
 
-template <int G, typename S, bool OVF>
+template <int G, typename S, bool OVF, bool YI = false>
 static hipError_t k4_launch(hipStream_t s, const LaunchCfg& cfg, int* grid_out, const Workspace& ws, const float* x,
                             const uint8_t* xv, const float* y, const uint8_t* yv, const int32_t* gid, int64_t n,
                             int32_t klo, int32_t khi, int32_t negate, int32_t keymask, int32_t yint, int32_t n_groups,
@@ -1134,13 +1153,13 @@ static hipError_t k4_launch(hipStream_t s, const LaunchCfg& cfg, int* grid_out, 
   const size_t n_ranges = (OVF && tail.rec) ? (size_t)(n_groups - nl + K4_TAIL_RANGE - 1) / K4_TAIL_RANGE : 0;
   const size_t lds = OVF ? (size_t)(nl - G + 64) * sizeof(K4Entry) + n_ranges * sizeof(unsigned) : 0;
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k4_cmp_avg_by_group_main<G, S, OVF>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k4_cmp_avg_by_group_main<G, S, OVF, YI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  const int grid = grid_for<S>(cfg, n, resident_blocks(k4_cmp_avg_by_group_main<G, S, OVF>, S::THREADS, lds));
+  const int grid = grid_for<S>(cfg, n, resident_blocks(k4_cmp_avg_by_group_main<G, S, OVF, YI>, S::THREADS, lds));
   *grid_out = grid;
-  hipLaunchKernelGGL((k4_cmp_avg_by_group_main<G, S, OVF>), dim3(grid), dim3(S::THREADS), lds, s, x, xv, y, yv, gid, n,
+  hipLaunchKernelGGL((k4_cmp_avg_by_group_main<G, S, OVF, YI>), dim3(grid), dim3(S::THREADS), lds, s, x, xv, y, yv, gid, n,
                      klo, khi, negate, keymask, yint, n_groups, nl, ws.partials, ws.status, reinterpret_cast<const uint8_t*>(ws.status + 8), fa,
                      tail);
   return hipGetLastError();
@@ -1399,7 +1418,11 @@ static hipError_t k4_one_launch(hipStream_t s, const LaunchCfg& cfg, const Works
   hipError_t e;
   const FoldArgs fa = has_tail ? FoldArgs{nullptr, nullptr, nullptr, 0, 0, 0}
                                : fold_args(cfg, ws, 3 * n_groups, 2 * n_groups, d_counts, d_sums);
-  K4Tail tail{reinterpret_cast<unsigned long long*>(d_counts), d_sums, nullptr, nullptr, nullptr};
+  static const int no_uni = [] {
+    const char* v = getenv("EXON_HIP_K4_UNIFORM");
+    return v && v[0] == '0' ? 1 : 0;
+  }();
+  K4Tail tail{reinterpret_cast<unsigned long long*>(d_counts), d_sums, nullptr, nullptr, nullptr, no_uni};
   const int n_ranges = has_tail ? (n_groups - nl + K4_TAIL_RANGE - 1) / K4_TAIL_RANGE : 0;
   // partitioned tier 3 when its scratch is there (capi.cpp sizes it with k4_tail_records) and the launch has whole tiles
   const bool partition = has_tail && !k4_tail_atomics_forced() && ws.tail_rec_a && ws.tail_rec_b && ws.tail_u32 &&
@@ -1432,8 +1455,9 @@ static hipError_t k4_one_launch(hipStream_t s, const LaunchCfg& cfg, const Works
 #undef EXON_K4_CASE
     default:  // > 8 groups: 4 in registers + LDS table (+ tier 3 beyond K4_LDS_GROUPS ids)
       // (16384-row tiles fit too -- 124 VGPRs -- and measured the same: profiles/r3_groupby.md)
-      e = big ? k4_launch<K4_OVF_REGS, ShapeBigJ2, true>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, keymask, yint, n_groups, fa, tail)
-              : k4_launch<K4_OVF_REGS, ShapeSmall, true>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, keymask, yint, n_groups, fa, tail);
+#define EXON_K4_OVF(SHAPE, YI) k4_launch<K4_OVF_REGS, SHAPE, true, YI>(s, cfg, &grid, ws, x, x_valid, y, y_valid, gid, n, klo, khi, negate, keymask, yint, n_groups, fa, tail)
+      e = big ? (yint ? EXON_K4_OVF(ShapeBigJ2, true) : EXON_K4_OVF(ShapeBigJ2, false)) : (yint ? EXON_K4_OVF(ShapeSmall, true) : EXON_K4_OVF(ShapeSmall, false));
+#undef EXON_K4_OVF
       break;
   }
   if (e != hipSuccess) return e;

@@ -206,6 +206,51 @@ def test_k3_many_references_global_atomic_path(ctx):
     assert np.array_equal(d.to_host(), 2 * want) and want[R] > 0
 
 
+@pytest.mark.parametrize("R,n", [(25, 6_000_007), (3000, 5_000_000), (60_000, 3_000_001)])
+def test_k3_sorted_runs_and_one_hot_reference(ctx, R, n):
+    """Coordinate-sorted input: long runs of ONE reference (what a real BAM looks like), runs that change inside a wave's 256
+    rows, and a single reference for the whole column.  The uniform-key path (one lane adds the group's count) and the
+    per-row path must agree with numpy bit for bit -- per-wave LDS tables (R = 25), the 4-wave shape (R = 3000), and the
+    global-atomic path beyond 4096 references (R = 60 000)."""
+    rng = np.random.default_rng(R)
+    flag = rng.choice(np.array([99, 147, 83, 163, 4, 1024 + 99, 256], np.int32), n)
+    mapq = rng.integers(0, 61, n).astype(np.uint8)
+    nb = (n + 7) // 8 + 64
+    mv, rv = rng.integers(0, 256, nb, dtype=np.uint8) | 0x0F, np.full(nb, 0xFF, np.uint8)
+    runs = np.sort(rng.integers(0, R, n // 100_000 + 2).astype(np.int32))     # sorted runs of ~100 k rows
+    cuts = np.sort(rng.integers(0, n, len(runs) - 1))
+    sorted_ref = np.repeat(runs, np.diff(np.concatenate([[0], cuts, [n]]))).astype(np.int32)
+    short = (np.arange(n) // 37 % R).astype(np.int32)                        # runs of 37: every wave group is mixed
+    for name, ref in (("sorted", sorted_ref), ("one", np.full(n, R - 1, np.int32)), ("short runs", short)):
+        d = ctx.zeros(np.int64, R + 1)
+        dev = [ctx.to_device(x) for x in (flag, np.concatenate([mapq, np.zeros(64, np.uint8)]), mv, ref, rv)]
+        ctx.flag_mapq_group_count(dev[0], dev[1], dev[2], dev[3], dev[4], n, 1284, 0, 30, R, d)
+        ctx.sync()
+        ok = ((flag & 1284) == 0) & bits(mv, n) & (mapq >= 30)
+        want = np.bincount(ref[ok], minlength=R + 1)
+        assert np.array_equal(d.to_host(), want), name
+
+
+def test_k4_one_hot_key_in_the_lds_tier_and_sorted_keys(ctx, oracle):
+    """Every row carries dictionary id 10 (a hot key that lives in the LDS tier), then keys in sorted runs: the uniform-key
+    path of K4's LDS tier (counts from ballots, the sum from a wave reduction) against numpy."""
+    n, G = 6_000_000, 64
+    af, av, q, qv, _ = oracle.gen_c4(4, 0, n)
+    avb, qvb = bits(av, n), bits(qv, n)
+    keep = avb & (af.astype(np.float64) > 0.01)
+    d = [ctx.to_device(x) for x in (af, av, q, qv)]
+    for name, fid in (("one hot key", np.full(n, 10, np.int32)), ("sorted runs", (np.arange(n) // 50_000 % G).astype(np.int32)),
+                      ("runs of 100", (np.arange(n) // 100 % G).astype(np.int32))):
+        dc, ds = ctx.zeros(np.int64, 2 * G), ctx.zeros(np.float64, G)
+        ctx.cmp_avg_by_group(d[0], d[1], d[2], d[3], ctx.to_device(fid), n, 0.01, ">", G, dc, ds)
+        ctx.sync()
+        got = dc.to_host()
+        assert np.array_equal(got[G:], np.bincount(fid[keep], minlength=G)), name
+        assert np.array_equal(got[:G], np.bincount(fid[keep & qvb], minlength=G)), name
+        want_s = np.bincount(fid[keep & qvb], weights=q[keep & qvb].astype(np.float64), minlength=G)
+        assert np.allclose(ds.to_host(), want_s, rtol=RTOL, atol=0), name
+
+
 # ---- K4 -----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n", [1, 2048, 99_999, 5_000_000])
 @pytest.mark.parametrize("op,thr", [(">", 0.01), (">=", 0.01), ("<", 0.5), ("<=", 0.25), ("=", 0.25), ("!=", 0.01),
