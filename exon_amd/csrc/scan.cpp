@@ -543,11 +543,20 @@ class GpuTextSource {
         g_slab_cache.erase(it);
       }
     }
+    const bool trace = getenv("EXON_HIP_PIPE_TRACE") != nullptr;
+    const double ti0 = now_s();
+    double t_host = 0, t_dev = 0;
     if (!complete_) {
+      // (a fresh context pays ~0.23 ms per MB of pinned memory -- 58 ms for the two 128 MB BGZF staging buffers -- and the
+      // runtime serialises allocations: handing the second set to a helper thread moved the wait, it did not shorten it)
       for (int k = 0; k < 2; ++k) {
-        if (hipHostMalloc((void**)&h_buf_[k], hcap_) != hipSuccess || hipMalloc((void**)&d_text_[k], gap_ + text_cap_ + 256) != hipSuccess ||
-            (bgzf_ && hipMalloc((void**)&d_comp_[k], comp_cap_ + 8192) != hipSuccess))
+        const double a0 = now_s();
+        if (hipHostMalloc((void**)&h_buf_[k], hcap_) != hipSuccess) return fail(ctx_, EXON_HIP_ENOMEM, "pinned slab buffer of %zu bytes could not be allocated", hcap_);
+        const double a1 = now_s();
+        if (hipMalloc((void**)&d_text_[k], gap_ + text_cap_ + 256) != hipSuccess || (bgzf_ && hipMalloc((void**)&d_comp_[k], comp_cap_ + 8192) != hipSuccess))
           return fail(ctx_, EXON_HIP_ENOMEM, "slab buffers (%zu bytes of text) could not be allocated", text_cap_);
+        t_host += a1 - a0;
+        t_dev += now_s() - a1;
       }
       if (bgzf_) {
         if (hipHostMalloc((void**)&h_blocks_, 2 * table_bytes()) != hipSuccess || hipMalloc((void**)&d_blocks_, 2 * table_bytes()) != hipSuccess)
@@ -555,6 +564,7 @@ class GpuTextSource {
       }
       complete_ = true;
     }
+    const double ti1 = now_s();
     // the inflate stream runs at the LOWEST priority: its kernels fill every workgroup slot for milliseconds, and the parse
     // kernels of the previous slab (the consumer's stream, highest priority: stream.cpp) are short and on the critical path
     int prio_least = 0, prio_greatest = 0;
@@ -570,10 +580,15 @@ class GpuTextSource {
         return fail(ctx_, EXON_HIP_EDEVICE, "event creation failed");
     if (bgzf_) {
       if (!ev_carry_ && hipEventCreateWithFlags(&ev_carry_, hipEventDisableTiming) != hipSuccess) return fail(ctx_, EXON_HIP_EDEVICE, "event creation failed");
+      const double ti2 = now_s();
       fill(0, &f_[0]);
       if (f_[0].err) return rethrow(f_[0].err);
+      const double ti3 = now_s();
       int rc = enqueue_inflate(0);
       if (rc) return rc;
+      if (trace)
+        fprintf(stderr, "[exon-hip pipe] init: pinned allocations %.1f ms (%zu MB), device allocations %.1f ms, tables %.1f ms, streams+events %.1f ms, first fill %.1f ms, first inflate enqueue %.1f ms\n",
+                t_host * 1e3, (2 * hcap_) >> 20, t_dev * 1e3, (ti1 - ti0 - t_host - t_dev) * 1e3, (ti2 - ti1) * 1e3, (ti3 - ti2) * 1e3, (now_s() - ti3) * 1e3);
       if (!f_[0].eof) reader_ = std::thread([this] { fill(1, &f_[1]); });
       return EXON_HIP_OK;
     }
@@ -1029,6 +1044,7 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
     }
     rc = src->init();
     if (rc) break;
+    const double t_src = now_s();
     if (is_vcf && !scan->parser) {
       std::vector<const char*> names;
       for (const auto& c : scan->vcf->header.contigs) names.push_back(c.c_str());
@@ -1066,7 +1082,10 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
       rc = exon_hip_fastq_parser_create(ctx, (int64_t)src->max_text_bytes(), &scan->fq_parser);
       if (rc) break;
     }
-    if (si == 0) t_init = now_s();
+    if (si == 0) {
+      t_init = now_s();
+      if (trace) fprintf(stderr, "[exon-hip pipe] source init %.1f ms, parser create %.1f ms\n", (t_src - t_begin) * 1e3, (t_init - t_src) * 1e3);
+    }
     for (;;) {
       const uint8_t* d_text = nullptr;
       size_t n = 0;
