@@ -32,7 +32,7 @@ size_t k3_partial_words(const LaunchCfg&, int n_refs);
 size_t k4_partial_words(const LaunchCfg&, int n_groups);
 // 8-byte records of tier-3 scratch a K4 launch over n rows wants (0: no tier 3); per buffer
 size_t k4_tail_records(int64_t n, int n_groups);
-constexpr size_t K4_TAIL_U32_WORDS = 2048 + 3 * 2048 + 1;  // workgroup counts, range histogram, offsets, cursors
+constexpr size_t K4_TAIL_U32_WORDS = 2048 + 3 * 2048 + 2 + (size_t)2048 * 2048;  // workgroup counts, range totals, offsets, slice starts, [workgroup][range] histogram
 size_t k5_partial_words(const LaunchCfg&, int lmax);
 
 hipError_t launch_region_count(hipStream_t s, const LaunchCfg& cfg, const Workspace& ws, const int32_t* chrom,

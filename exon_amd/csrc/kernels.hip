@@ -58,6 +58,12 @@ __device__ __forceinline__ T ld16(const void* p) {
   __builtin_memcpy(&r, &v, 16);
   return r;
 }
+// streaming 8-byte load (tier-3 records: written once, read once)
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 ldnt8(const uint2* p) {
+  const v2u_t v = __builtin_nontemporal_load(reinterpret_cast<const v2u_t*>(p));
+  return uint2{v.x, v.y};
+}
 // The same without the streaming hint.  An i64 column gives every lane 32 consecutive bytes = two 16-byte loads that touch
 // the SAME cache lines (lane stride 32 B): when both carry the streaming hint, some lines are fetched from HBM twice (PMC:
 // 1.047 x the algorithmic bytes in K2, 1.049 x in K6); with a plain second load the line is still there: K2 1.877 -> 1.827 ms.
@@ -834,7 +840,15 @@ hipError_t launch_flag_mapq_group_count(hipStream_t s, const LaunchCfg& cfg, con
 //   per row is 0.025 ms per 1e9 rows.  Hence 4 register groups instead of 8 (4 instead of 8 conditional f64 adds, 32-bit
 //   packed counters), the predicate evaluated once per row for all tiers, one LDS address per row.
 constexpr int K4_TAIL_MAX_RANGES = 2048;  // (2^24 - 4100) / 8192 ids
+constexpr int K4_TAIL_MAX_GRID = 2048;    // workgroups of the main kernel the partitioned tier 3 has histogram rows for
 constexpr int K4_TAIL_RANGE = 8192;  // ids per range of the partitioned tier 3 = entries of k4_tail_aggregate's LDS table (128 KiB)
+// The main kernel counts its tier-3 records per id range in LDS.  With few ranges the 64 lanes of a wave instruction land on
+// a handful of counters and same-address LDS atomics serialise, so every range gets 2^k counters picked by lane (summed when
+// the workgroup stores its row of the histogram); k shrinks as the ranges grow: at most 3072 counters = 12 KiB behind the
+// tier-2 table, which keeps two workgroups on a CU.
+__host__ __device__ static inline int k4_hist_copies_log2(int n_ranges) {
+  return n_ranges <= 192 ? 4 : n_ranges <= 384 ? 3 : n_ranges <= 768 ? 2 : n_ranges <= 1536 ? 1 : 0;
+}
 struct K4Tail {                 // tier 3 (unused when NG == NL)
   unsigned long long* counts;   // the caller's [cnn[NG]] [crow[NG]]
   double* sums;                 // the caller's [sum[NG]]
@@ -844,7 +858,7 @@ struct K4Tail {                 // tier 3 (unused when NG == NL)
   // each range.  rec == nullptr: the atomic form (EXON_HIP_K4_TAIL_ATOMICS=1, and the short tail loop of a launch).
   uint2* rec;                   // [grid][cap_wg]
   unsigned* wg_count;           // [grid] records each workgroup wrote
-  unsigned* hist;               // [n_ranges] records per id range (all workgroups)
+  unsigned* wg_hist;            // [grid][n_ranges] records per workgroup and id range
   int no_uniform_test;          // EXON_HIP_K4_UNIFORM=0 (A/B): tier 2 never tests for a uniform key
 };
 struct K4Entry {  // tier-2 table entry
@@ -952,26 +966,40 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
   __shared__ unsigned tail_cursor;
   unsigned* tail_hist = reinterpret_cast<unsigned*>(k4_ovf + NOD);  // behind the tier-2 table (dynamic LDS)
   const int n_ranges = (OVF && tail.rec) ? (NG - NL + K4_TAIL_RANGE - 1) / K4_TAIL_RANGE : 0;
+  const int hcl = k4_hist_copies_log2(n_ranges);
+  const unsigned hcopy = (unsigned)lane & ((1u << hcl) - 1u);
   // rows a workgroup can meet in the tile loop = the size of its region (the host computes the same number)
   const unsigned cap_wg = (unsigned)(((n / TILE + gridDim.x - 1) / gridDim.x) * TILE);
   if (OVF && tail.rec) {
     if (threadIdx.x == 0) tail_cursor = 0;
-    for (int i = threadIdx.x; i < n_ranges; i += THREADS) tail_hist[i] = 0;
+    for (int i = threadIdx.x; i < (n_ranges << hcl); i += THREADS) tail_hist[i] = 0;
     __syncthreads();
   }
-  auto row_tail_append = [&](unsigned pass, float yf, int32_t g, unsigned yv) {
-    const bool t3 = pass && (unsigned)g >= (unsigned)NL && (unsigned)g < (unsigned)NG;
-    const unsigned long long m = __ballot(t3);
-    if (m == 0) return;
+  // (one reservation for the 4 rows of every lane: the returning LDS atomic and the readfirstlane behind it are a round trip
+  //  the wave waits for)
+  auto rows4_tail_append = [&](unsigned p0, unsigned p1, unsigned p2, unsigned p3, float4 y4, int4 g4, unsigned yv) {
+    const unsigned span = (unsigned)(NG - NL);
+    const unsigned d0 = (unsigned)g4.x - (unsigned)NL, d1 = (unsigned)g4.y - (unsigned)NL, d2 = (unsigned)g4.z - (unsigned)NL,
+                   d3 = (unsigned)g4.w - (unsigned)NL;
+    const bool t0 = p0 && d0 < span, t1 = p1 && d1 < span, t2 = p2 && d2 < span, t3 = p3 && d3 < span;
+    const unsigned long long m0 = __ballot(t0), m1 = __ballot(t1), m2 = __ballot(t2), m3 = __ballot(t3);
+    const unsigned c0 = (unsigned)__popcll(m0), c1 = (unsigned)__popcll(m1), c2 = (unsigned)__popcll(m2), c3 = (unsigned)__popcll(m3);
+    if (c0 + c1 + c2 + c3 == 0) return;
     unsigned base = 0;
-    if (lane == 0) base = atomicAdd(&tail_cursor, (unsigned)__popcll(m));
+    if (lane == 0) base = atomicAdd(&tail_cursor, c0 + c1 + c2 + c3);
     base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-    if (t3) {
-      const unsigned at = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint2* dst = tail.rec + (size_t)blockIdx.x * cap_wg;
+    auto put = [&](bool t, unsigned at, unsigned d, int32_t g, float yf, unsigned y1) {
+      if (!t) return;
       if (at < cap_wg)  // cannot overflow: cap_wg covers every row this workgroup reads in the tile loop
-        tail.rec[(size_t)blockIdx.x * cap_wg + at] = uint2{(unsigned)g | (yv << 31), (unsigned)__float_as_int(yf)};
-      atomicAdd(&tail_hist[((unsigned)g - (unsigned)NL) / K4_TAIL_RANGE], 1u);
-    }
+        dst[at] = uint2{(unsigned)g | (y1 << 31), (unsigned)__float_as_int(yf)};
+      atomicAdd(&tail_hist[((d / K4_TAIL_RANGE) << hcl) + hcopy], 1u);
+    };
+    put(t0, base + (unsigned)__popcll(m0 & below), d0, g4.x, y4.x, yv >> 0 & 1);
+    put(t1, base + c0 + (unsigned)__popcll(m1 & below), d1, g4.y, y4.y, yv >> 1 & 1);
+    put(t2, base + c0 + c1 + (unsigned)__popcll(m2 & below), d2, g4.z, y4.z, yv >> 2 & 1);
+    put(t3, base + c0 + c1 + c2 + (unsigned)__popcll(m3 & below), d3, g4.w, y4.w, yv >> 3 & 1);
   };
   // tier 3, atomic form: global atomics straight into the state (divergent on purpose)
   auto row_tail = [&](unsigned pass, float yf, int32_t g, unsigned yv) {
@@ -1039,10 +1067,7 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
           }
           if (NG > NL && __any(gm >= (unsigned)NL)) {
             if (tail.rec) {
-              row_tail_append(p0, ys[j].x, gs[j].x, ym[j] >> 0 & 1);
-              row_tail_append(p1, ys[j].y, gs[j].y, ym[j] >> 1 & 1);
-              row_tail_append(p2, ys[j].z, gs[j].z, ym[j] >> 2 & 1);
-              row_tail_append(p3, ys[j].w, gs[j].w, ym[j] >> 3 & 1);
+              rows4_tail_append(p0, p1, p2, p3, ys[j], gs[j], ym[j]);
             } else {
               row_tail(p0, ys[j].x, gs[j].x, ym[j] >> 0 & 1);
               row_tail(p1, ys[j].y, gs[j].y, ym[j] >> 1 & 1);
@@ -1092,8 +1117,11 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
   if (OVF && tail.rec) {  // what this workgroup compacted: its record count, and its share of the per-range histogram
     __syncthreads();
     if (threadIdx.x == 0) tail.wg_count[blockIdx.x] = min(tail_cursor, cap_wg);
-    for (int i = threadIdx.x; i < n_ranges; i += THREADS)
-      if (tail_hist[i]) atomicAdd(&tail.hist[i], tail_hist[i]);
+    for (int i = threadIdx.x; i < n_ranges; i += THREADS) {
+      unsigned t = 0;
+      for (int c = 0; c < (1 << hcl); ++c) t += tail_hist[(i << hcl) + c];
+      tail.wg_hist[(size_t)blockIdx.x * n_ranges + i] = t;
+    }
   }
 
   // per-workgroup record: [cnn[RG]] [crow[RG]] [sum[RG]]  (fixed-order reductions for the register groups)
@@ -1151,7 +1179,7 @@ static hipError_t k4_launch(hipStream_t s, const LaunchCfg& cfg, int* grid_out, 
                             const FoldArgs& fa, const K4Tail& tail) {
   const int nl = k4_nl(n_groups);
   const size_t n_ranges = (OVF && tail.rec) ? (size_t)(n_groups - nl + K4_TAIL_RANGE - 1) / K4_TAIL_RANGE : 0;
-  const size_t lds = OVF ? (size_t)(nl - G + 64) * sizeof(K4Entry) + n_ranges * sizeof(unsigned) : 0;
+  const size_t lds = OVF ? (size_t)(nl - G + 64) * sizeof(K4Entry) + (n_ranges << k4_hist_copies_log2((int)n_ranges)) * sizeof(unsigned) : 0;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k4_cmp_avg_by_group_main<G, S, OVF, YI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1250,14 +1278,16 @@ __global__ __launch_bounds__(256) void k4_cmp_avg_by_group_global(const float* _
 // records [blocks][3 x RG] (kinds cnn, crow, sum over the first RG ids) ADDED into a state of NG > RG groups
 // ([cnn[NG]] [crow[NG]] | [sum[NG]]): the fold of the tiered kernel when tier 3 exists.  One thread per (kind, id),
 // blocks summed in order.  The state was zeroed (overwrite) or holds earlier launches; tier 3 has added to it already.
-__global__ __launch_bounds__(256) void k4_finalize_head(const unsigned long long* __restrict__ partials, int nblocks, int RG, int NG,
-                                                        unsigned long long* __restrict__ counts, double* __restrict__ sums) {
-  // the shape of finalize_partials: 32 values x 8 segments of the workgroup range per block, 4 loads in flight per thread
-  __shared__ unsigned long long red[8][32];
+__global__ __launch_bounds__(1024) void k4_finalize_head(const unsigned long long* __restrict__ partials, int nblocks, int RG, int NG,
+                                                         unsigned long long* __restrict__ counts, double* __restrict__ sums) {
+  // 32 values x 32 segments of the workgroup range per block, 8 loads in flight per thread: the records are 3 x RG x 8 bytes
+  // apart (98 KB at RG = 4100), every load of a thread is a new page, and the fold is latency-bound (8 segments x 4 loads
+  // took 0.10 ms for 512 records, a seventh of a 2^28-row launch's main kernel)
+  __shared__ unsigned long long red[32][32];
   const int vi = threadIdx.x & 31, seg = threadIdx.x >> 5;
   const int v = blockIdx.x * 32 + vi, V = 3 * RG;
   const int kind = v < V ? v / RG : 0, g = v - kind * RG;
-  const int per = (nblocks + 7) / 8;
+  const int per = (nblocks + 31) / 32;
   const int b0 = seg * per, b1 = min(nblocks, b0 + per);
   unsigned long long acc_i = 0;
   double acc_f = 0.0;
@@ -1265,13 +1295,21 @@ __global__ __launch_bounds__(256) void k4_finalize_head(const unsigned long long
     const unsigned long long* p = partials + v;
     int b = b0;
     if (kind < 2) {
-      for (; b + 4 <= b1; b += 4) acc_i += p[(size_t)b * V] + p[(size_t)(b + 1) * V] + p[(size_t)(b + 2) * V] + p[(size_t)(b + 3) * V];
+      for (; b + 8 <= b1; b += 8) {
+        unsigned long long t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = p[(size_t)(b + k) * V];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc_i += t[k];
+      }
       for (; b < b1; ++b) acc_i += p[(size_t)b * V];
     } else {
-      for (; b + 4 <= b1; b += 4) {
-        const double a0 = __longlong_as_double((long long)p[(size_t)b * V]), a1 = __longlong_as_double((long long)p[(size_t)(b + 1) * V]),
-                     a2 = __longlong_as_double((long long)p[(size_t)(b + 2) * V]), a3 = __longlong_as_double((long long)p[(size_t)(b + 3) * V]);
-        acc_f += ((a0 + a1) + (a2 + a3));
+      for (; b + 8 <= b1; b += 8) {
+        unsigned long long t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = p[(size_t)(b + k) * V];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc_f += __longlong_as_double((long long)t[k]);
       }
       for (; b < b1; ++b) acc_f += __longlong_as_double((long long)p[(size_t)b * V]);
     }
@@ -1282,26 +1320,27 @@ __global__ __launch_bounds__(256) void k4_finalize_head(const unsigned long long
     if (kind < 2) {
       unsigned long long t = 0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) t += red[k][vi];
+      for (int k = 0; k < 32; ++k) t += red[k][vi];
       if (t) counts[(size_t)kind * NG + g] += t;
     } else {
       double t = 0.0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) t += __longlong_as_double((long long)red[k][vi]);
+      for (int k = 0; k < 32; ++k) t += __longlong_as_double((long long)red[k][vi]);
       sums[g] += t;
     }
   }
 }
 
 // ---- partitioned tier 3 (ids >= K4_LDS_GROUPS): scatter by id range, then the LDS table over each range ---------------------
-// offsets[r] = exclusive prefix of hist[0 .. n_ranges); cursor[r] = 0.  One workgroup; n_ranges <= 2048.
-__global__ __launch_bounds__(1024) void k4_tail_offsets(const unsigned* __restrict__ hist, int n_ranges, unsigned* __restrict__ offsets,
-                                                        unsigned* __restrict__ cursor) {
+// wg_hist[w][r] (records of workgroup w in range r) -> in place, the exclusive prefix over w; totals[r] = the range's records.
+// One workgroup per range; grid_main <= 2048 (two rows per thread at most).
+__global__ __launch_bounds__(1024) void k4_tail_wg_scan(unsigned* __restrict__ wg_hist, int grid_main, int n_ranges, unsigned* __restrict__ totals) {
   __shared__ unsigned part[1024];
-  const int per = (n_ranges + 1023) / 1024;
-  const int r0 = threadIdx.x * per, r1 = min(n_ranges, r0 + per);
+  const int r = blockIdx.x;
+  const int per = (grid_main + 1023) / 1024;
+  const int w0 = threadIdx.x * per, w1 = min(grid_main, w0 + per);
   unsigned sum = 0;
-  for (int r = r0; r < r1; ++r) sum += hist[r];
+  for (int w = w0; w < w1; ++w) sum += wg_hist[(size_t)w * n_ranges + r];
   part[threadIdx.x] = sum;
   __syncthreads();
   for (int o = 1; o < 1024; o <<= 1) {
@@ -1311,57 +1350,117 @@ __global__ __launch_bounds__(1024) void k4_tail_offsets(const unsigned* __restri
     __syncthreads();
   }
   unsigned run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
+  for (int w = w0; w < w1; ++w) {
+    const unsigned c = wg_hist[(size_t)w * n_ranges + r];
+    wg_hist[(size_t)w * n_ranges + r] = run;
+    run += c;
+  }
+  if (threadIdx.x == 1023) totals[r] = part[1023];
+}
+// offsets[r] = exclusive prefix of totals[0 .. n_ranges), offsets[n_ranges] = all records; slice_start[r] = exclusive prefix
+// of the workgroups k4_tail_aggregate gives range r: its share of `target` by records (at least one; none for an empty
+// range), so that a skewed key distribution does not leave the chip to the few heavy ranges.  One workgroup; n_ranges <= 2048.
+__global__ __launch_bounds__(1024) void k4_tail_offsets(const unsigned* __restrict__ totals, int n_ranges, unsigned* __restrict__ offsets,
+                                                        int target, unsigned* __restrict__ slice_start) {
+  __shared__ unsigned part[1024];
+  const int per = (n_ranges + 1023) / 1024;
+  const int r0 = threadIdx.x * per, r1 = min(n_ranges, r0 + per);
+  unsigned sum = 0;
+  for (int r = r0; r < r1; ++r) sum += totals[r];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const unsigned v = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  const unsigned all = part[1023];
+  unsigned run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
   for (int r = r0; r < r1; ++r) {
     offsets[r] = run;
-    cursor[r] = 0;
-    run += hist[r];
+    run += totals[r];
   }
-  if (threadIdx.x == 1023) offsets[n_ranges] = part[1023];
+  if (threadIdx.x == 1023) offsets[n_ranges] = all;
+  __syncthreads();
+  auto slices_of = [&](unsigned len) -> unsigned {
+    if (len == 0) return 0u;
+    const unsigned long long q = ((unsigned long long)len * (unsigned)target + all - 1) / all;
+    return (unsigned)(q < 1 ? 1 : q);
+  };
+  sum = 0;
+  for (int r = r0; r < r1; ++r) sum += slices_of(totals[r]);
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const unsigned v = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
+  for (int r = r0; r < r1; ++r) {
+    slice_start[r] = run;
+    run += slices_of(totals[r]);
+  }
+  if (threadIdx.x == 1023) slice_start[n_ranges] = part[1023];
 }
-// One workgroup per source region (= per workgroup of the main kernel), chunks of 8 records per thread: an LDS histogram
-// gives every record its rank inside (chunk, range), ONE global atomic per (chunk, non-empty range) reserves the run in the
-// output, the records are written there.  8 B read + 8 B written per record.
+// One workgroup per source region (= per workgroup of the main kernel).  Where this workgroup's records of range r go is
+// known before it starts -- offsets[r] + the records the workgroups before it hold of r (k4_tail_wg_scan) -- so an LDS
+// cursor per range hands out the output slots: no global atomics (512 workgroups drawing from a dozen global cursors
+// serialised: 12 ns per draw on one address), no barriers inside the loop, and the next 8 records of a thread are in flight
+// while the current ones are placed.  8 B read + 8 B written per record.
 constexpr int K4_SCATTER_PER = 8;
 __global__ __launch_bounds__(1024) void k4_tail_scatter(const uint2* __restrict__ rec, const unsigned* __restrict__ wg_count, unsigned cap_wg,
                                                         int NL, int n_ranges, const unsigned* __restrict__ offsets,
-                                                        unsigned* __restrict__ cursor, uint2* __restrict__ out) {
-  extern __shared__ unsigned sc_lds[];  // [n_ranges] counts of the chunk, then [n_ranges] global bases
-  unsigned* cnt = sc_lds;
-  unsigned* gbase = sc_lds + n_ranges;
+                                                        const unsigned* __restrict__ wg_excl, uint2* __restrict__ out) {
+  extern __shared__ unsigned sc_pos[];  // [n_ranges] next output slot of this workgroup in each range
+  for (int i = threadIdx.x; i < n_ranges; i += 1024) sc_pos[i] = offsets[i] + wg_excl[(size_t)blockIdx.x * n_ranges + i];
+  __syncthreads();
   const uint2* src = rec + (size_t)blockIdx.x * cap_wg;
   const unsigned total = wg_count[blockIdx.x];
   constexpr unsigned CH = 1024 * K4_SCATTER_PER;
+  uint2 v[K4_SCATTER_PER], nx[K4_SCATTER_PER];
+#pragma unroll
+  for (int k = 0; k < K4_SCATTER_PER; ++k) {
+    const unsigned i = (unsigned)k * 1024u + threadIdx.x;
+    v[k] = i < total ? ldnt8(src + i) : uint2{0, 0};
+  }
   for (unsigned c0 = 0; c0 < total; c0 += CH) {
-    for (int i = threadIdx.x; i < n_ranges; i += 1024) cnt[i] = 0;
-    __syncthreads();
-    uint2 v[K4_SCATTER_PER];
-    unsigned rank[K4_SCATTER_PER];
+#pragma unroll
+    for (int k = 0; k < K4_SCATTER_PER; ++k) {
+      const unsigned i = c0 + CH + (unsigned)k * 1024u + threadIdx.x;
+      nx[k] = i < total ? ldnt8(src + i) : uint2{0, 0};
+    }
 #pragma unroll
     for (int k = 0; k < K4_SCATTER_PER; ++k) {
       const unsigned i = c0 + (unsigned)k * 1024u + threadIdx.x;
-      rank[k] = 0xFFFFFFFFu;
-      if (i < total) {
-        v[k] = src[i];
-        rank[k] = atomicAdd(&cnt[((v[k].x & 0x7FFFFFFFu) - (unsigned)NL) / K4_TAIL_RANGE], 1u);
-      }
+      if (i < total) out[atomicAdd(&sc_pos[((v[k].x & 0x7FFFFFFFu) - (unsigned)NL) / K4_TAIL_RANGE], 1u)] = v[k];
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n_ranges; i += 1024) gbase[i] = cnt[i] ? offsets[i] + atomicAdd(&cursor[i], cnt[i]) : 0u;
-    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < K4_SCATTER_PER; ++k)
-      if (rank[k] != 0xFFFFFFFFu) out[gbase[((v[k].x & 0x7FFFFFFFu) - (unsigned)NL) / K4_TAIL_RANGE] + rank[k]] = v[k];
-    __syncthreads();
+    for (int k = 0; k < K4_SCATTER_PER; ++k) v[k] = nx[k];
   }
 }
-// blockIdx.x = range, blockIdx.y = slice of the range's records: the tier-2 LDS table over K4_TAIL_RANGE ids, flushed into
-// the caller's state with one global atomic triple per id the slice touched.
-__global__ __launch_bounds__(1024) void k4_tail_aggregate(const uint2* __restrict__ recs, const unsigned* __restrict__ offsets, int NL, int NG,
+// A workgroup = one slice of one range's records (slice_start, k4_tail_offsets): the tier-2 LDS table over K4_TAIL_RANGE ids,
+// flushed into the caller's state with one global atomic triple per id the slice touched.  One 128 KiB table = one workgroup
+// per CU, so the loads have to come from inside the thread: 8 records in flight each.  count(*) and count(y) of an entry are
+// one 64-bit LDS add (count(y) in the low word: a slice holds < 2^28 records, it cannot carry).
+__global__ __launch_bounds__(1024) void k4_tail_aggregate(const uint2* __restrict__ recs, const unsigned* __restrict__ offsets,
+                                                          const unsigned* __restrict__ slice_start, int n_ranges, int NL, int NG,
                                                           int yint, unsigned long long* __restrict__ counts, double* __restrict__ sums) {
   __shared__ K4Entry tab[K4_TAIL_RANGE];
-  const unsigned lo = offsets[blockIdx.x], hi = offsets[blockIdx.x + 1];
-  const unsigned len = hi - lo, per = (len + gridDim.y - 1) / gridDim.y;
-  const unsigned a = lo + blockIdx.y * per, b = min(hi, a + per);
+  if (blockIdx.x >= slice_start[n_ranges]) return;
+  int rlo = 0, rhi = n_ranges - 1;  // the last range whose first slice is <= blockIdx.x (empty ranges have no slices)
+  while (rlo < rhi) {
+    const int mid = (rlo + rhi + 1) >> 1;
+    if (slice_start[mid] <= blockIdx.x) rlo = mid;
+    else rhi = mid - 1;
+  }
+  const int range = rlo;
+  const unsigned n_slices = slice_start[range + 1] - slice_start[range], slice = blockIdx.x - slice_start[range];
+  const unsigned lo = offsets[range], hi = offsets[range + 1];
+  const unsigned len = hi - lo, per = (len + n_slices - 1) / n_slices;
+  const unsigned a = lo + slice * per, b = min(hi, a + per);
   if (a >= b) return;
   for (int i = threadIdx.x; i < K4_TAIL_RANGE; i += 1024) {
     tab[i].sum = 0.0;
@@ -1369,14 +1468,24 @@ __global__ __launch_bounds__(1024) void k4_tail_aggregate(const uint2* __restric
     tab[i].crow = 0;
   }
   __syncthreads();
-  const unsigned id0 = (unsigned)NL + blockIdx.x * (unsigned)K4_TAIL_RANGE;
-  for (unsigned i = a + threadIdx.x; i < b; i += 1024) {
-    const uint2 v = recs[i];
-    K4Entry* e = &tab[(v.x & 0x7FFFFFFFu) - id0];
-    const unsigned yv = v.x >> 31;
-    atomicAdd(&e->crow, 1u);
-    atomicAdd(&e->cnn, yv);
-    atomicAdd(&e->sum, yv ? (yint ? (double)(int32_t)v.y : (double)__uint_as_float(v.y)) : 0.0);
+  const unsigned id0 = (unsigned)NL + (unsigned)range * (unsigned)K4_TAIL_RANGE;
+  constexpr int PER = 8;
+  for (unsigned i0 = a; i0 < b; i0 += PER * 1024u) {
+    uint2 v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const unsigned i = i0 + (unsigned)k * 1024u + threadIdx.x;
+      v[k] = i < b ? ldnt8(recs + i) : uint2{0xFFFFFFFFu, 0};
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const unsigned i = i0 + (unsigned)k * 1024u + threadIdx.x;
+      if (i >= b) continue;
+      K4Entry* e = &tab[(v[k].x & 0x7FFFFFFFu) - id0];
+      const unsigned yv = v[k].x >> 31;
+      atomicAdd(reinterpret_cast<unsigned long long*>(&e->cnn), (1ull << 32) | yv);  // {cnn, crow} are adjacent, cnn first
+      atomicAdd(&e->sum, yv ? (yint ? (double)(int32_t)v[k].y : (double)__uint_as_float(v[k].y)) : 0.0);
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < K4_TAIL_RANGE; i += 1024) {
@@ -1426,17 +1535,18 @@ static hipError_t k4_one_launch(hipStream_t s, const LaunchCfg& cfg, const Works
   const int n_ranges = has_tail ? (n_groups - nl + K4_TAIL_RANGE - 1) / K4_TAIL_RANGE : 0;
   // partitioned tier 3 when its scratch is there (capi.cpp sizes it with k4_tail_records) and the launch has whole tiles
   const bool partition = has_tail && !k4_tail_atomics_forced() && ws.tail_rec_a && ws.tail_rec_b && ws.tail_u32 &&
-                         ws.tail_capacity >= (size_t)(n + K4_TAIL_SLACK) && n_ranges <= K4_TAIL_MAX_RANGES;
-  unsigned *wg_count = nullptr, *hist = nullptr, *offsets = nullptr, *cursor = nullptr;
-  if (partition) {
-    wg_count = ws.tail_u32;                       // [2048]
-    hist = ws.tail_u32 + 2048;                    // [K4_TAIL_MAX_RANGES]
-    offsets = hist + K4_TAIL_MAX_RANGES;          // [K4_TAIL_MAX_RANGES + 1]
-    cursor = offsets + K4_TAIL_MAX_RANGES + 1;    // [K4_TAIL_MAX_RANGES]
-    if ((e = hipMemsetAsync(ws.tail_u32, 0, (size_t)(2048 + K4_TAIL_MAX_RANGES) * 4, s)) != hipSuccess) return e;
+                         ws.tail_capacity >= (size_t)(n + K4_TAIL_SLACK) && n_ranges <= K4_TAIL_MAX_RANGES &&
+                         max_grid(cfg) <= K4_TAIL_MAX_GRID;
+  unsigned *wg_count = nullptr, *totals = nullptr, *offsets = nullptr, *slice_start = nullptr, *wg_hist = nullptr;
+  if (partition) {  // every word the kernels below read is written by the launch before it: nothing to clear
+    wg_count = ws.tail_u32;                       // [K4_TAIL_MAX_GRID]
+    totals = wg_count + K4_TAIL_MAX_GRID;         // [K4_TAIL_MAX_RANGES]
+    offsets = totals + K4_TAIL_MAX_RANGES;        // [K4_TAIL_MAX_RANGES + 1]
+    slice_start = offsets + K4_TAIL_MAX_RANGES + 1;      // [K4_TAIL_MAX_RANGES + 1]
+    wg_hist = slice_start + K4_TAIL_MAX_RANGES + 1;      // [grid][n_ranges]
     tail.rec = ws.tail_rec_a;
     tail.wg_count = wg_count;
-    tail.hist = hist;
+    tail.wg_hist = wg_hist;
   }
   switch (n_groups) {
 #define EXON_K4_CASE(GG)                                                                                                        \
@@ -1462,18 +1572,26 @@ static hipError_t k4_one_launch(hipStream_t s, const LaunchCfg& cfg, const Works
   }
   if (e != hipSuccess) return e;
   if (has_tail) {
-    hipLaunchKernelGGL(k4_finalize_head, dim3((3 * nl + 31) / 32), dim3(256), 0, s, ws.partials, grid, nl, n_groups,
+    hipLaunchKernelGGL(k4_finalize_head, dim3((3 * nl + 31) / 32), dim3(1024), 0, s, ws.partials, grid, nl, n_groups,
                        reinterpret_cast<unsigned long long*>(d_counts), d_sums);
     if (partition) {
       const int64_t tile = big ? ShapeOf<ShapeBigJ2>::TILE : ShapeOf<ShapeSmall>::TILE;
       const unsigned cap_wg = (unsigned)(((n / tile + grid - 1) / grid) * tile);  // the main kernel's formula
-      hipLaunchKernelGGL(k4_tail_offsets, dim3(1), dim3(1024), 0, s, hist, n_ranges, offsets, cursor);
-      hipLaunchKernelGGL(k4_tail_scatter, dim3(grid), dim3(1024), (size_t)n_ranges * 8, s, ws.tail_rec_a, wg_count, cap_wg, nl, n_ranges, offsets,
-                         cursor, ws.tail_rec_b);
-      // slices per range: enough workgroups to fill the chip (one 128 KiB LDS table each), few enough that the flushes
-      // (one atomic triple per id and slice) stay small next to the records
-      const int slices = std::max(1, std::min(64, (4 * cfg.compute_units + n_ranges - 1) / n_ranges));
-      hipLaunchKernelGGL(k4_tail_aggregate, dim3(n_ranges, slices), dim3(1024), 0, s, ws.tail_rec_b, offsets, nl, n_groups, yint,
+      hipLaunchKernelGGL(k4_tail_wg_scan, dim3(n_ranges), dim3(1024), 0, s, wg_hist, grid, n_ranges, totals);
+      // k4_tail_aggregate holds one workgroup per CU (128 KiB table): `rounds` workgroups per CU in all, shared out over the
+      // ranges by their records -- whole rounds, because a workgroup more than a multiple of the CUs is a round more.
+      // One round measured best (1e5 zipf keys: 3.90 / 4.07 / 4.32 / 4.54 ms per 1e9 rows for 1 / 2 / 3 / 4: every
+      // workgroup zeroes and flushes a whole table)
+      static const int rounds = [] {
+        const char* v = getenv("EXON_HIP_K4_TAIL_ROUNDS");  // A/B
+        const int k = v ? atoi(v) : 0;
+        return k >= 1 && k <= 16 ? k : 1;
+      }();
+      const int target = std::max(1, rounds * cfg.compute_units - n_ranges);  // + at most one per range from rounding up
+      hipLaunchKernelGGL(k4_tail_offsets, dim3(1), dim3(1024), 0, s, totals, n_ranges, offsets, target, slice_start);
+      hipLaunchKernelGGL(k4_tail_scatter, dim3(grid), dim3(1024), (size_t)n_ranges * 4, s, ws.tail_rec_a, wg_count, cap_wg, nl, n_ranges, offsets,
+                         wg_hist, ws.tail_rec_b);
+      hipLaunchKernelGGL(k4_tail_aggregate, dim3(target + n_ranges), dim3(1024), 0, s, ws.tail_rec_b, offsets, slice_start, n_ranges, nl, n_groups, yint,
                          reinterpret_cast<unsigned long long*>(d_counts), d_sums);
     }
     return hipGetLastError();
