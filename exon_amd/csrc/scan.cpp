@@ -679,14 +679,11 @@ class GpuTextSource {
     enq_[k] = false;
     if (f.n_blocks == 0) return EXON_HIP_OK;
     if (free_rec_[k]) HIP_TRY(ctx_, hipStreamWaitEvent(cs_, ev_free_[k], 0));
-    exon_hip_bgzf_block* hb = h_table(k);
-    const size_t tb = (size_t)f.n_blocks * sizeof(exon_hip_bgzf_block);
-    memcpy(hb, block_tables_[k].data(), tb);
-    for (int i = 0; i < f.n_blocks; ++i) hb[i].out_offset += (uint32_t)gap_;
-    HIP_TRY(ctx_, hipStreamWaitEvent(cs_, ev_h2d_[k], 0));  // the compressed bytes (copied by the reader on xs_)
-    HIP_TRY(ctx_, hipMemcpyAsync(d_table(k), hb, tb, hipMemcpyHostToDevice, cs_));
-    HIP_TRY(ctx_, exon_bgzf_inflate_launch(cs_, d_comp_[k], d_table(k), f.n_blocks, d_text_[k], d_status(k), true));
-    HIP_TRY(ctx_, hipMemcpyAsync(h_status(k), d_status(k), (size_t)f.n_blocks * sizeof(int), hipMemcpyDeviceToHost, cs_));
+    HIP_TRY(ctx_, hipStreamWaitEvent(cs_, ev_h2d_[k], 0));  // the compressed bytes + the block table (copied by the reader on xs_)
+    // the kernels write the per-block status straight into the pinned (device-visible) host words: 4 bytes per block
+    int* status_dev = nullptr;
+    HIP_TRY(ctx_, hipHostGetDevicePointer((void**)&status_dev, h_status(k), 0));
+    HIP_TRY(ctx_, exon_bgzf_inflate_launch(cs_, d_comp_[k], d_table(k), f.n_blocks, d_text_[k], status_dev, true));
     HIP_TRY(ctx_, hipEventRecord(ev_done_[k], cs_));
     enq_[k] = true;
     return EXON_HIP_OK;
@@ -815,7 +812,7 @@ class GpuTextSource {
         // header walk below runs under that copy: the slab must be in HBM one inflate period after this thread
         // started, and read + walk + copy in a row did not fit.  (A trailing partial block goes along; it is unused.)
         hipSetDevice(ctx_->device);
-        if (hipMemcpyAsync(d_comp_[k], h_buf_[k], have + 4096, hipMemcpyHostToDevice, xs_) != hipSuccess || hipEventRecord(ev_h2d_[k], xs_) != hipSuccess)
+        if (hipMemcpyAsync(d_comp_[k], h_buf_[k], have + 4096, hipMemcpyHostToDevice, xs_) != hipSuccess)
           throw std::runtime_error("H2D of a compressed slab failed");
       }
       int32_t nb = 0;
@@ -842,7 +839,21 @@ class GpuTextSource {
       f->n_blocks = nb;
       f->out_bytes = out_bytes;
       f->eof = file_eof_ && left_.empty();
-      block_tables_[k].assign(hb, hb + nb);  // copied to the pinned table in next()
+      // The block table follows the compressed bytes on the SAME copy stream and the event behind it covers both: the inflate
+      // stream then holds kernels only.  (The table used to cross on the inflate stream, and the status words came back on it
+      // behind the kernels: copies that wait for kernels sit at the head of a DMA queue, and the next slab's 112 MB copy,
+      // queued behind them by the runtime, did not start until the inflate had finished -- the timeline showed the inflate
+      // stream idle for 2 ms per slab.)  The pinned table of buffer k is free: the inflate of the slab two back has finished.
+      if (xs_) {
+        exon_hip_bgzf_block* pt = h_table(k);
+        for (int i = 0; i < nb; ++i) {
+          pt[i] = hb[i];
+          pt[i].out_offset += (uint32_t)gap_;
+        }
+        if ((nb > 0 && hipMemcpyAsync(d_table(k), pt, (size_t)nb * sizeof(exon_hip_bgzf_block), hipMemcpyHostToDevice, xs_) != hipSuccess) ||
+            (have > 0 && hipEventRecord(ev_h2d_[k], xs_) != hipSuccess))
+          throw std::runtime_error("H2D of a block table failed");
+      }
     } catch (...) {
       f->err = std::current_exception();
     }
@@ -870,7 +881,7 @@ class GpuTextSource {
   uint8_t* d_text_[2] = {nullptr, nullptr};
   exon_hip_bgzf_block* h_blocks_ = nullptr;  // pinned: table + status of the slab in flight
   exon_hip_bgzf_block* d_blocks_ = nullptr;
-  std::vector<exon_hip_bgzf_block> scan_tmp_[2], block_tables_[2];
+  std::vector<exon_hip_bgzf_block> scan_tmp_[2];
   int max_blocks_ = 0, target_blocks_ = 0;
   double est_block_ = 20000;  // running average of the compressed block size
   bool first_fill_ = true;
