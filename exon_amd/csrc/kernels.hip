@@ -1792,7 +1792,7 @@ __global__ __launch_bounds__(K5_THREADS) void k5_main(const K5Chunks ch, int lma
   for (int i = threadIdx.x; i < K5_A_WORDS; i += K5_THREADS) k5_h[i] = 0;
   __syncthreads();
   const int L = ch.ends[0][0] - ch.off[0][0], Ld = L >> 2;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: the row bases below are wave-uniform
   const int NW = (int)gridDim.x * (K5_THREADS / 64), g = (int)blockIdx.x * (K5_THREADS / 64) + wave;
   const int r = g % Ld, slot = g / Ld, nslots = NW / Ld;  // the wave's rows: index == r (mod Ld), every nslots-th of them
   const int t = (64 * r) % Ld + lane, w = t / Ld, d = t - w * Ld;
@@ -1823,31 +1823,95 @@ __global__ __launch_bounds__(K5_THREADS) void k5_main(const K5Chunks ch, int lma
     atomicAdd(reinterpret_cast<unsigned*>(hb + a2), 1u);
     atomicAdd(reinterpret_cast<unsigned*>(hb + a3 + 32768), 1u);
   };
+  // The steady state has no branch per dword (round 3; tools/tune_k5.hip variant M: 6.52 -> 6.77 TB/s at L = 100, 6.44 -> 6.76 at
+  // L = 148, 6.00 -> 6.42 at L = 64).  A dword is masked to 7 bits per byte before the v_perm, so a byte >= 128 lands in the bin
+  // of byte & 127 for the moment; the unmasked dwords of J rows are ORed together and ONE wave-uniform test per J rows sends an
+  // iteration that saw a high bit through `fix`: its rows are read again and every byte >= 128 is taken out of the bin it went
+  // to (ds_sub) and added to the global histogram.  Quality strings never take it.  With the test per dword (v_and, v_cmp, six
+  // scalar instructions and two branches between the load and its atomics) a wave's dependent chain per dword was longer than
+  // the LDS pipe needs for it, and four waves per SIMD did not cover that.
+  auto fast = [&](unsigned dw) {
+    const unsigned m = dw & 0x7F7F7F7Fu;
+    // v_perm_b32: result byte 1 <- data byte k, bytes 0 / 2 / 3 <- the lane's constant
+    const unsigned a0 = __builtin_amdgcn_perm(m, c01, 0x03020400u);
+    const unsigned a1 = __builtin_amdgcn_perm(m, c01, 0x03020500u);
+    const unsigned a2 = __builtin_amdgcn_perm(m, c23, 0x03020600u);
+    const unsigned a3 = __builtin_amdgcn_perm(m, c23, 0x03020700u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a0), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a1 + 32768), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a2), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a3 + 32768), 1u);
+  };
+  auto fix = [&](unsigned dw) {  // dw went through fast(): move its bytes >= 128 to where they belong
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned b = (dw >> (8 * k)) & 0xFF;
+      if (b >= 128) {
+        atomicSub(reinterpret_cast<unsigned*>(hb + (k >> 1) * 65536 + (k & 1) * 32768 + (b & 127) * 256 + c01), 1u);
+        atomicAdd(&d_hist[(size_t)(4 * d + k) * 256 + b], 1ull);
+      }
+    }
+  };
+  const int64_t stride = (int64_t)nslots * Ld, first = (int64_t)slot * Ld + r;  // this wave's rows: first + i * stride
   for (int ci = 0; ci < ch.count; ++ci) {  // every chunk starts at a read boundary: the wave keeps its rows, d and w
     const int64_t nd = ch.n[ci] * (int64_t)Ld, nrows = nd >> 6;
     const unsigned* src = reinterpret_cast<const unsigned*>(ch.bytes[ci] + ch.off[ci][0]);
     if (slot < nslots) {
-      const int64_t qstep = nslots;
-      int64_t q = slot;
-      for (; (q + (J - 1) * qstep) * Ld + r < nrows; q += J * qstep) {
+      const int64_t nmine = first < nrows ? (nrows - first + stride - 1) / stride : 0;
+      const unsigned* p = src + first * 64;  // wave-uniform
+      const int64_t pstep = stride * 64;
+      int64_t i = 0;
+      auto fixup = [&](unsigned acc) {
+        if (__builtin_expect(__any((acc & 0x80808080u) != 0), 0)) {
+#pragma unroll 1
+          for (int j = 0; j < J; ++j) fix(p[j * pstep + lane]);
+        }
+      };
+      if (nmine >= J) {
+        // A ROLLING window of J loads: a register is refilled with the row J ahead as soon as its dword is consumed
+        // (s_waitcnt vmcnt(J - 1) throughout).  The scheduling barriers keep the compiler from gathering the J masked copies
+        // first (= a wait for every load) and issuing the loads in one burst.
         unsigned v[J];
+        const unsigned* ld = p + lane;  // the next row to load: loads go out in row order, so ONE running pointer serves them
+#pragma unroll                          // (J scalar row offsets would not fit the scalar registers next to the chunk table)
+        for (int j = 0; j < J; ++j) {
+          v[j] = __builtin_nontemporal_load(ld);
+          ld += pstep;
+          __builtin_amdgcn_sched_barrier(0);  // in row order, as the loop issues them: the loop's wait counts hold from the first pass
+        }
+        for (i = J; i + J <= nmine; i += J) {
+          unsigned acc = 0;
 #pragma unroll
-        for (int j = 0; j < J; ++j) v[j] = __builtin_nontemporal_load(src + ((q + j * qstep) * Ld + r) * 64 + lane);
+          for (int j = 0; j < J; ++j) {
+            // as asm: the compiler would merge two rows' ORs into a v_or3 placed after the first row's reload, which costs
+            // a new register per load and a rotation of register copies at the loop head (and the wait that goes with it)
+            asm volatile("v_or_b32 %0, %0, %1" : "+v"(acc) : "v"(v[j]));
+            fast(v[j]);
+            v[j] = __builtin_nontemporal_load(ld);
+            ld += pstep;
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          fixup(acc);
+          p += J * pstep;
+        }
+        unsigned acc = 0;
 #pragma unroll
-        for (int j = 0; j < J; ++j) one(v[j]);
+        for (int j = 0; j < J; ++j) {
+          acc |= v[j];
+          fast(v[j]);
+        }
+        fixup(acc);
+        p += J * pstep;
       }
-      if (q * Ld + r < nrows) {
+      if (i < nmine) {
         // the last < J rows of this wave, all loads in flight at once (one at a time they cost a memory round trip each:
         // 40 us of a 345 us launch at 20 M reads).  A row's validity is wave-uniform; invalid slots re-read the first row.
         unsigned v[J];
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
-          const int64_t row = (q + j * qstep) * Ld + r;
-          v[j] = __builtin_nontemporal_load(src + (row < nrows ? row : q * Ld + r) * 64 + lane);
-        }
+        for (int j = 0; j < J; ++j) v[j] = __builtin_nontemporal_load(p + (i + j < nmine ? j : 0) * pstep + lane);
 #pragma unroll
         for (int j = 0; j < J; ++j)
-          if ((q + j * qstep) * Ld + r < nrows) one(v[j]);
+          if (i + j < nmine) one(v[j]);
       }
     }
     if (g == NW - 1) {  // the last, partial row (< 64 dwords): column = dword-of-read, first copy

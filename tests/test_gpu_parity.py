@@ -492,6 +492,29 @@ def test_k5_path_a_with_non_ascii_bytes_lmax_above_read_length_and_accumulation(
     assert want[:, 128:].sum() > 0 and want[:, :32].sum() > 0 and want[L:].sum() == 0
 
 
+@pytest.mark.parametrize("n,L,n_bad", [(1_300_003, 100, 20_000), (900_001, 148, 3), (2_000_000, 64, 50_000), (700_000, 100, 1)])
+def test_k5_path_a_steady_state_moves_non_ascii_bytes(ctx, oracle, n, L, n_bad):
+    """Round 3's path A masks a dword to 7 bits per byte in its steady state (no branch per dword) and repairs, once per 24
+    rows, the rows in which a byte >= 128 went to the bin of byte & 127.  The steady state needs >= 48 rows per wavefront
+    (> 5e5 reads at L = 100), which the small cases above do not reach: here every wavefront runs it, with many, few and
+    exactly one high byte, in two accumulating launches (the repair must not leak into the next launch)."""
+    rng = np.random.default_rng(n_bad)
+    data = rng.integers(33, 75, n * L).astype(np.uint8)
+    idx = rng.integers(0, n * L, n_bad)
+    data[idx] = rng.integers(128, 256, n_bad).astype(np.uint8)
+    data[idx[: n_bad // 2] ^ 1] = 255  # neighbours in one dword
+    off = (np.arange(n + 1, dtype=np.int64) * L).astype(np.int32)
+    d = ctx.zeros(np.int64, L * 256)
+    d_off, d_data = ctx.to_device(off), ctx.to_device(np.concatenate([data, np.zeros(64, np.uint8)]))
+    ctx.qual_pos_hist(d_off, d_data, n, L, d)
+    ctx.qual_pos_hist(d_off, d_data, n, L, d)
+    ctx.sync()
+    want, _ = oracle.c5_qual_pos_hist(off, data, L)
+    got = d.to_host().reshape(L, 256)
+    assert want[:, 128:].sum() >= 1
+    assert np.array_equal(got, 2 * want)
+
+
 def _k5_chunk(rng, n, L, shift=0, ragged=False, lmax=None):
     """(offsets, bytes) of one Utf8 batch: uniform length L, or ragged lengths in [0, lmax]"""
     lens = rng.integers(0, lmax + 1, n) if ragged else np.full(n, L)

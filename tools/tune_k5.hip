@@ -465,6 +465,183 @@ __global__ __launch_bounds__(1024) void vJ(const uint8_t* bytes, int64_t n, int 
     if (v) atomicAdd(&out[p * 256 + b], (unsigned long long)v); }
 }
 
+// ---- L: K (static LDS table) with (1) a ROLLING load window: after a dword is consumed its register is refilled with the row J
+// ahead, so a wave keeps J - 1 loads in flight all the time (K issues J, then drains them to zero while it works through the
+// atomics: 12 in flight on average) and (2) wave-uniform row addressing: the wave index goes through readfirstlane, so the row
+// base is scalar and the load is `global_load_dword v, v_lane_off, s[base]` -- no 64-bit vector add per load.
+template <int J>
+__global__ __launch_bounds__(1024) void vL(const uint8_t* bytes, int64_t n, int L, unsigned long long* out) {
+  __shared__ unsigned h[4 * 128 * 64];
+  const int Ld = L / 4;
+  for (int i = threadIdx.x; i < 4 * 128 * 64; i += 1024) h[i] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int NW = gridDim.x * 16, g = blockIdx.x * 16 + wave;
+  const int r = g % Ld, slot = g / Ld, nslots = NW / Ld;
+  const int64_t nd = n * Ld, nrows = nd / 64;
+  const int t = (64 * r) % Ld + lane, w = t / Ld, d = t - w * Ld;
+  const int col = Ld <= 32 ? d + 32 * (w & 1) : d;
+  const unsigned* src = reinterpret_cast<const unsigned*>(bytes);
+  const unsigned c01 = (unsigned)col * 4u, c23 = c01 | 0x10000u;
+  char* hb = reinterpret_cast<char*>(h);
+  auto slow = [&](unsigned dw, int q, unsigned cc) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const unsigned b = (dw >> (8 * k)) & 0xFF;
+      if (b < 128) atomicAdd(reinterpret_cast<unsigned*>(hb + (k >> 1) * 65536 + (k & 1) * 32768 + b * 256 + cc), 1u);
+      else atomicAdd(&out[(size_t)(4 * q + k) * 256 + b], 1ull); }
+  };
+  auto one = [&](unsigned dw) {
+    if (__builtin_expect((dw & 0x80808080u) != 0, 0)) { slow(dw, d, c01); return; }
+    const unsigned a0 = __builtin_amdgcn_perm(dw, c01, 0x03020400u);
+    const unsigned a1 = __builtin_amdgcn_perm(dw, c01, 0x03020500u);
+    const unsigned a2 = __builtin_amdgcn_perm(dw, c23, 0x03020600u);
+    const unsigned a3 = __builtin_amdgcn_perm(dw, c23, 0x03020700u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a0), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a1 + 32768), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a2), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a3 + 32768), 1u);
+  };
+  if (slot < nslots) {
+    const int64_t stride = (int64_t)nslots * Ld, first = (int64_t)slot * Ld + r;  // this wave's rows: first + i * stride
+    const int64_t nmine = first < nrows ? (nrows - first + stride - 1) / stride : 0;
+    const unsigned* p = src + first * 64;  // wave-uniform
+    const int64_t pstep = stride * 64;
+    int64_t i = 0;
+    if (nmine >= J) {
+      unsigned v[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) v[j] = __builtin_nontemporal_load(p + j * pstep + lane);
+      p += J * pstep;
+      for (i = J; i + J <= nmine; i += J) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          one(v[j]);
+          v[j] = __builtin_nontemporal_load(p + j * pstep + lane);
+        }
+        p += J * pstep;
+      }
+#pragma unroll
+      for (int j = 0; j < J; ++j) one(v[j]);
+    }
+    if (i < nmine) {  // the last < J rows, all loads at once
+      unsigned v[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) v[j] = __builtin_nontemporal_load(p + (i + j < nmine ? j : 0) * pstep + lane);
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+        if (i + j < nmine) one(v[j]);
+    }
+  }
+  if (g == NW - 1) {  // the last partial row (< 64 dwords)
+    const int64_t c = nrows * 64 + lane;
+    if (c < nd) { const int q = (int)(c % Ld); slow(src[c], q, (unsigned)q * 4u); }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < L * 128; i += 1024) { const int p = i % L, b = i / L, k = p & 3;
+    unsigned v = h[(k >> 1) * 16384 + (k & 1) * 8192 + b * 64 + (p >> 2)];
+    if (Ld <= 32) v += h[(k >> 1) * 16384 + (k & 1) * 8192 + b * 64 + (p >> 2) + 32];
+    if (v) atomicAdd(&out[p * 256 + b], (unsigned long long)v); }
+}
+
+// ---- M: L without a branch per dword.  The dword is masked to 7 bits per byte before the v_perm (a byte >= 128 lands in the bin
+// of byte & 127 for the moment), the unmasked dwords of an iteration are ORed together, and ONE wave-uniform test per J rows
+// sends an iteration that saw a high bit through a fix-up: its rows are read again, and every byte >= 128 is taken out of the bin
+// it went to (ds_sub) and added to the global histogram.  Real quality strings never take it.  Per dword: v_and, v_or, 4 v_perm,
+// 4 ds_add, 1 load with a scalar base -- no exec-mask juggling (L: v_and, v_cmp, 6 scalar instructions and 2 branches).
+template <int J>
+__global__ __launch_bounds__(1024) void vM(const uint8_t* bytes, int64_t n, int L, unsigned long long* out) {
+  __shared__ unsigned h[4 * 128 * 64];
+  const int Ld = L / 4;
+  for (int i = threadIdx.x; i < 4 * 128 * 64; i += 1024) h[i] = 0;
+  __syncthreads();
+  const unsigned lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int NW = gridDim.x * 16, g = blockIdx.x * 16 + wave;
+  const int r = g % Ld, slot = g / Ld, nslots = NW / Ld;
+  const int64_t nd = n * Ld, nrows = nd / 64;
+  const int t = (64 * r) % Ld + (int)lane, w = t / Ld, d = t - w * Ld;
+  const int col = Ld <= 32 ? d + 32 * (w & 1) : d;
+  const unsigned* src = reinterpret_cast<const unsigned*>(bytes);
+  const unsigned c01 = (unsigned)col * 4u, c23 = c01 | 0x10000u;
+  char* hb = reinterpret_cast<char*>(h);
+  auto bin = [&](int k, unsigned b, unsigned cc) { return reinterpret_cast<unsigned*>(hb + (k >> 1) * 65536 + (k & 1) * 32768 + b * 256 + cc); };
+  auto slow = [&](unsigned dw, int q, unsigned cc) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const unsigned b = (dw >> (8 * k)) & 0xFF;
+      if (b < 128) atomicAdd(bin(k, b, cc), 1u);
+      else atomicAdd(&out[(size_t)(4 * q + k) * 256 + b], 1ull); }
+  };
+  auto fix = [&](unsigned dw) {  // dw went through fast(): move its bytes >= 128 to where they belong
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const unsigned b = (dw >> (8 * k)) & 0xFF;
+      if (b >= 128) { atomicSub(bin(k, b & 127, c01), 1u); atomicAdd(&out[(size_t)(4 * d + k) * 256 + b], 1ull); } }
+  };
+  auto fast = [&](unsigned dw) {
+    const unsigned m = dw & 0x7F7F7F7Fu;
+    const unsigned a0 = __builtin_amdgcn_perm(m, c01, 0x03020400u);
+    const unsigned a1 = __builtin_amdgcn_perm(m, c01, 0x03020500u);
+    const unsigned a2 = __builtin_amdgcn_perm(m, c23, 0x03020600u);
+    const unsigned a3 = __builtin_amdgcn_perm(m, c23, 0x03020700u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a0), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a1 + 32768), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a2), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a3 + 32768), 1u);
+  };
+  if (slot < nslots) {
+    const int64_t stride = (int64_t)nslots * Ld, first = (int64_t)slot * Ld + r;  // this wave's rows: first + i * stride
+    const int64_t nmine = first < nrows ? (nrows - first + stride - 1) / stride : 0;
+    const unsigned* p = src + first * 64;  // wave-uniform
+    const int64_t pstep = stride * 64;
+    int64_t i = 0;
+    auto fixup = [&](unsigned acc) {
+      if (__builtin_expect(__any((acc & 0x80808080u) != 0), 0)) {
+#pragma unroll 1
+        for (int j = 0; j < J; ++j) fix(p[j * pstep + lane]);
+      }
+    };
+    if (nmine >= J) {
+      unsigned v[J];
+      const unsigned* ld = p + lane;  // running pointer: loads go out in row order
+#pragma unroll
+      for (int j = 0; j < J; ++j) { v[j] = __builtin_nontemporal_load(ld); ld += pstep; __builtin_amdgcn_sched_barrier(0); }  // in row order, as the loop issues them
+      for (i = J; i + J <= nmine; i += J) {
+        unsigned acc = 0;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          asm volatile("v_or_b32 %0, %0, %1" : "+v"(acc) : "v"(v[j]));  // as asm: a v_or3 of two rows would be placed after the
+          fast(v[j]);                                                     // first one's reload and cost a register rotation
+          v[j] = __builtin_nontemporal_load(ld); ld += pstep;
+          __builtin_amdgcn_sched_barrier(0);  // keep the window rolling: without it the scheduler copies all J masked dwords
+        }                                     // first (a wait for every load) and issues the J loads in one burst
+        fixup(acc);
+        p += J * pstep;
+      }
+      unsigned acc = 0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) { acc |= v[j]; fast(v[j]); }
+      fixup(acc);
+      p += J * pstep;
+    }
+    if (i < nmine) {  // the last < J rows, all loads at once
+      unsigned v[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) v[j] = __builtin_nontemporal_load(p + (i + j < nmine ? j : 0) * pstep + lane);
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+        if (i + j < nmine) slow(v[j], d, c01);
+    }
+  }
+  if (g == NW - 1) {  // the last partial row (< 64 dwords)
+    const int64_t c = nrows * 64 + lane;
+    if (c < nd) { const int q = (int)(c % Ld); slow(src[c], q, (unsigned)q * 4u); }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < L * 128; i += 1024) { const int p = i % L, b = i / L, k = p & 3;
+    unsigned v = h[(k >> 1) * 16384 + (k & 1) * 8192 + b * 64 + (p >> 2)];
+    if (Ld <= 32) v += h[(k >> 1) * 16384 + (k & 1) * 8192 + b * 64 + (p >> 2) + 32];
+    if (v) atomicAdd(&out[p * 256 + b], (unsigned long long)v); }
+}
+
 int main(int argc, char** argv) {
   int64_t n = argc > 1 ? (int64_t)atof(argv[1]) : (int64_t)2e8; const int L = argc > 2 ? atoi(argv[2]) : 100;
   n = n / 4096 * 4096;
@@ -493,10 +670,13 @@ int main(int argc, char** argv) {
       run("R read-only J4", vR<4>, 0, 256);
       run("I rows+perm J24", vI<24>, il, 256);
       run("K I+static J24", vJ<24, 1>, 4, 256);
-      run("J hoist24 J24", vJ<24, 24>, 4, 256);
-      run("J hoist8 J24", vJ<24, 8>, 4, 256);
-      run("J hoist4 J24", vJ<24, 4>, 4, 256);
-      run("J hoist8 J32", vJ<32, 8>, 4, 256);
+      run("L rolling J16", vL<16>, 4, 256);
+      run("L rolling J24", vL<24>, 4, 256);
+      run("L rolling J32", vL<32>, 4, 256);
+      run("L rolling J48", vL<48>, 4, 256);
+      run("M branch-free J16", vM<16>, 4, 256);
+      run("M branch-free J24", vM<24>, 4, 256);
+      run("M branch-free J32", vM<32>, 4, 256);
     }
     return 0;
   }
