@@ -1668,11 +1668,11 @@ hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Wo
 constexpr int K5_THREADS = 1024;
 constexpr int K5_PT_MAX = 310;  // positions kept in LDS by the [p][129] layout: 310 * 129 * 4 B = 159,960 B
 constexpr int K5_JA = 24, K5_JB = 4;
-constexpr int K5_A_WORDS = 4 * 128 * 64;  // path A table: [k][byte][column]
+constexpr int K5_A_WORDS = 5 * 128 * 64;  // path A table: [plane][byte][column], 320 slots
 // The workgroup's histogram block, STATIC so that its LDS address is the constant 0: with `extern __shared__` the compiler
 // keeps one `v_add_u32 v, <lds base>, v` per atomic after the v_perm (4 of path A's 10 vector instructions per dword;
 // tools/tune_k5.hip variant K: +3 %).  Sized for the largest layout: [K5_PT_MAX][129] words.
-constexpr int K5_LDS_WORDS = 40000;
+constexpr int K5_LDS_WORDS = 40960;  // all 160 KiB of the CU
 static_assert(K5_LDS_WORDS >= K5_PT_MAX * 129 && K5_LDS_WORDS >= K5_A_WORDS && K5_LDS_WORDS >= 128 * 256 + 64, "K5 LDS block");
 __shared__ __attribute__((aligned(16))) unsigned k5_h[K5_LDS_WORDS];
 
@@ -1754,12 +1754,16 @@ __global__ __launch_bounds__(256) void k5_scan_offsets(const K5Chunks ch, int lm
 }
 
 enum { K5_PATH_A = 0, K5_PATH_B = 2, K5_PATH_G = 3 };
+// path A: period of the (dword -> positions) map in dwords, and the number of table copies that keep two lanes of one 32-lane
+// half off the same address (see k5_main)
+__host__ __device__ __forceinline__ int k5_period(int L) { return (L & 3) == 0 ? L >> 2 : (L & 1) == 0 ? L >> 1 : L; }
+__host__ __device__ __forceinline__ int k5_copies(int P) { return P >= 32 ? 1 : P >= 16 ? 2 : 4; }
 __device__ __forceinline__ int k5_pick_path(const K5Chunks& ch, int lmax, const int* flags) {
   const int f = flags[0];
   if (f & 1) return K5_PATH_G;
   const int L = ch.ends[0][0] - ch.off[0][0];
   if (L < 1 || L > lmax) return K5_PATH_G;
-  if ((L & 3) == 0 && L >= 32 && L <= 256 && !(f & 2)) return K5_PATH_A;
+  if (k5_period(L) >= 8 && L <= K5_PT_MAX && !(f & 2)) return K5_PATH_A;  // slots: copies x 4 ceil(L / 4) <= 320
   if (L <= K5_PT_MAX && !(f & 4)) return K5_PATH_B;
   return K5_PATH_G;
 }
@@ -1786,44 +1790,57 @@ __global__ __launch_bounds__(K5_THREADS) void k5_main(const K5Chunks ch, int lma
     k5_path_ragged<LP>(ch, lmax, pt, partials, d_hist);
     return;
   }
-  // ---- path A ----
-  // k5_h as [4 k][128 bytes][64 columns]
+  // ---- path A: any uniform read length (round 3; was L % 4 == 0 only, and 101 / 150 / 151 / 250-byte reads ran path B at 2.2 TB/s) ----
+  // The byte stream is read as dwords.  Dword D of a chunk holds the bytes of positions (4 D + k) mod L; that repeats with the
+  // period P = L / gcd(L, 4) dwords.  A wave owns the 64-dword rows whose index is == r (mod P), so a lane keeps ONE
+  // dword-of-period d -- four fixed positions p_k -- for the whole launch.  Position p lives in slot s(p) = (p & 3) C + (p >> 2),
+  // C = ceil(L / 4): the lanes of a row step p by 4, i.e. s by 1, so their banks differ (s mod 64 = the column = the bank).  Lanes
+  // that share d (P < 64) sit P lanes apart; when that is inside one 32-lane half (P < 32) they use `copies` = 2 (P >= 16) or 4
+  // (P >= 8) copies of the table, chosen by the wrap count w, so a half never holds two equal addresses.  Table: 5 planes of
+  // [128 bytes][64 columns] u32 = 160 KiB = 320 slots.  Bin address = plane << 15 | byte << 8 | column << 2: bits 16-17 and the
+  // column come from the lane's constant c_k, bit 15 (the plane's low bit) is ORed into the masked data byte's bit 7 by the same
+  // v_and_or_b32 that masks the dword, and ONE v_perm_b32 per byte drops the data byte into bits 8-15.
   constexpr int J = K5_JA;
   for (int i = threadIdx.x; i < K5_A_WORDS; i += K5_THREADS) k5_h[i] = 0;
   __syncthreads();
-  const int L = ch.ends[0][0] - ch.off[0][0], Ld = L >> 2;
+  const int L = ch.ends[0][0] - ch.off[0][0];
+  const int P = k5_period(L), C = (L + 3) >> 2, copies = k5_copies(P);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: the row bases below are wave-uniform
   const int NW = (int)gridDim.x * (K5_THREADS / 64), g = (int)blockIdx.x * (K5_THREADS / 64) + wave;
-  const int r = g % Ld, slot = g / Ld, nslots = NW / Ld;  // the wave's rows: index == r (mod Ld), every nslots-th of them
-  const int t = (64 * r) % Ld + lane, w = t / Ld, d = t - w * Ld;
-  const unsigned col = (unsigned)(Ld <= 32 ? d + 32 * (w & 1) : d);
-  // bin address (bytes) = k-plane | byte << 8 | col << 2; planes: k = 0 at 0, 1 at 32 KiB (instruction offset), 2 / 3 at +64 KiB
-  const unsigned c01 = col * 4u, c23 = c01 | 0x10000u;
+  // The wave's rows: index == r (mod Pr), every nslots-th of them.  Pr = P, except when P divides 64: a lane's dword-of-period
+  // is then lane % P in EVERY row and the rows can be dealt one by one.  A wave's consecutive rows must NOT sit a multiple of
+  // 4 KiB apart (16 rows: its 24 loads in flight then queue on the same HBM channel; L = 125 / 249 / 251, where 4096 / P waves
+  // per residue is a power of two, ran at 4.5-5.1 TB/s instead of 6.1, L = 64 at 5.7): a slot is given up until the stride is odd
+  // enough (at most 6 % of the waves; L = 192, P = 48, cannot avoid it).
+  const int Pr = 64 % P == 0 ? 1 : P;
+  int nslots = NW / Pr;
+  if ((Pr & 15) != 0)  // (a period of 48 rows cannot be helped)
+    while (nslots > 1 && ((nslots * Pr) & 15) == 0) --nslots;
+  const int r = g % Pr, slot = g / Pr;
+  const int t = (64 * r) % P + lane, w = t / P, d = t - w * P;
   char* hb = reinterpret_cast<char*>(k5_h);
-  auto slow = [&](unsigned dw, int q, unsigned cc) {  // a byte >= 128 somewhere, or the ragged tail row
+  // byte address of the bin of (dword-of-period dd, wrap count ww, byte-in-dword k) without the byte value, and its position
+  auto pos_of = [&](int dd, int k) { return (4 * dd + k) % L; };
+  auto bin_base = [&](int dd, int ww, int k) {
+    const int p = pos_of(dd, k), sl = (p & 3) * C + (p >> 2) + (ww & (copies - 1)) * 4 * C;
+    return (unsigned)((sl >> 6) << 15 | (sl & 63) << 2);
+  };
+  unsigned ck[4], pb = 0;  // the lane's constants: address bits 16-17 + column per k; the planes' low bits at bit 7 of byte k
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned a = bin_base(d, w, k);
+    ck[k] = a & ~0x8000u;
+    pb |= ((a >> 15) & 1u) << (8 * k + 7);
+  }
+  auto slow = [&](unsigned dw, int dd, int ww) {  // a byte >= 128 somewhere, or the last, partial row (dd is not the lane's d)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const unsigned b = (dw >> (8 * k)) & 0xFF;
-      if (b < 128) atomicAdd(reinterpret_cast<unsigned*>(hb + (k >> 1) * 65536 + (k & 1) * 32768 + b * 256 + cc), 1u);
-      else atomicAdd(&d_hist[(size_t)(4 * q + k) * 256 + b], 1ull);
+      if (b < 128) atomicAdd(reinterpret_cast<unsigned*>(hb + bin_base(dd, ww, k) + b * 256), 1u);
+      else atomicAdd(&d_hist[(size_t)pos_of(dd, k) * 256 + b], 1ull);
     }
   };
-  auto one = [&](unsigned dw) {
-    if (__builtin_expect((dw & 0x80808080u) != 0, 0)) {
-      slow(dw, d, c01);
-      return;
-    }
-    // v_perm_b32: result byte 1 <- data byte k, bytes 0 / 2 / 3 <- the lane's constant
-    const unsigned a0 = __builtin_amdgcn_perm(dw, c01, 0x03020400u);
-    const unsigned a1 = __builtin_amdgcn_perm(dw, c01, 0x03020500u);
-    const unsigned a2 = __builtin_amdgcn_perm(dw, c23, 0x03020600u);
-    const unsigned a3 = __builtin_amdgcn_perm(dw, c23, 0x03020700u);
-    atomicAdd(reinterpret_cast<unsigned*>(hb + a0), 1u);
-    atomicAdd(reinterpret_cast<unsigned*>(hb + a1 + 32768), 1u);
-    atomicAdd(reinterpret_cast<unsigned*>(hb + a2), 1u);
-    atomicAdd(reinterpret_cast<unsigned*>(hb + a3 + 32768), 1u);
-  };
-  // The steady state has no branch per dword (round 3; tools/tune_k5.hip variant M: 6.52 -> 6.77 TB/s at L = 100, 6.44 -> 6.76 at
+  // The steady state has no branch per dword (tools/tune_k5.hip variant M: 6.52 -> 6.77 TB/s at L = 100, 6.44 -> 6.76 at
   // L = 148, 6.00 -> 6.42 at L = 64).  A dword is masked to 7 bits per byte before the v_perm, so a byte >= 128 lands in the bin
   // of byte & 127 for the moment; the unmasked dwords of J rows are ORed together and ONE wave-uniform test per J rows sends an
   // iteration that saw a high bit through `fix`: its rows are read again and every byte >= 128 is taken out of the bin it went
@@ -1831,30 +1848,34 @@ __global__ __launch_bounds__(K5_THREADS) void k5_main(const K5Chunks ch, int lma
   // scalar instructions and two branches between the load and its atomics) a wave's dependent chain per dword was longer than
   // the LDS pipe needs for it, and four waves per SIMD did not cover that.
   auto fast = [&](unsigned dw) {
-    const unsigned m = dw & 0x7F7F7F7Fu;
-    // v_perm_b32: result byte 1 <- data byte k, bytes 0 / 2 / 3 <- the lane's constant
-    const unsigned a0 = __builtin_amdgcn_perm(m, c01, 0x03020400u);
-    const unsigned a1 = __builtin_amdgcn_perm(m, c01, 0x03020500u);
-    const unsigned a2 = __builtin_amdgcn_perm(m, c23, 0x03020600u);
-    const unsigned a3 = __builtin_amdgcn_perm(m, c23, 0x03020700u);
+    const unsigned m = (dw & 0x7F7F7F7Fu) | pb;  // v_and_or_b32
+    // v_perm_b32: result byte 1 <- data byte k (bit 7 = the plane's low bit), bytes 0 / 2 / 3 <- the lane's constant
+    const unsigned a0 = __builtin_amdgcn_perm(m, ck[0], 0x03020400u);
+    const unsigned a1 = __builtin_amdgcn_perm(m, ck[1], 0x03020500u);
+    const unsigned a2 = __builtin_amdgcn_perm(m, ck[2], 0x03020600u);
+    const unsigned a3 = __builtin_amdgcn_perm(m, ck[3], 0x03020700u);
     atomicAdd(reinterpret_cast<unsigned*>(hb + a0), 1u);
-    atomicAdd(reinterpret_cast<unsigned*>(hb + a1 + 32768), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a1), 1u);
     atomicAdd(reinterpret_cast<unsigned*>(hb + a2), 1u);
-    atomicAdd(reinterpret_cast<unsigned*>(hb + a3 + 32768), 1u);
+    atomicAdd(reinterpret_cast<unsigned*>(hb + a3), 1u);
+  };
+  auto one = [&](unsigned dw) {  // the rows outside the steady state
+    if (__builtin_expect((dw & 0x80808080u) != 0, 0)) slow(dw, d, w);
+    else fast(dw);
   };
   auto fix = [&](unsigned dw) {  // dw went through fast(): move its bytes >= 128 to where they belong
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const unsigned b = (dw >> (8 * k)) & 0xFF;
       if (b >= 128) {
-        atomicSub(reinterpret_cast<unsigned*>(hb + (k >> 1) * 65536 + (k & 1) * 32768 + (b & 127) * 256 + c01), 1u);
-        atomicAdd(&d_hist[(size_t)(4 * d + k) * 256 + b], 1ull);
+        atomicSub(reinterpret_cast<unsigned*>(hb + bin_base(d, w, k) + (b & 127) * 256), 1u);
+        atomicAdd(&d_hist[(size_t)pos_of(d, k) * 256 + b], 1ull);
       }
     }
   };
-  const int64_t stride = (int64_t)nslots * Ld, first = (int64_t)slot * Ld + r;  // this wave's rows: first + i * stride
+  const int64_t stride = (int64_t)nslots * Pr, first = (int64_t)slot * Pr + r;  // this wave's rows: first + i * stride
   for (int ci = 0; ci < ch.count; ++ci) {  // every chunk starts at a read boundary: the wave keeps its rows, d and w
-    const int64_t nd = ch.n[ci] * (int64_t)Ld, nrows = nd >> 6;
+    const int64_t nbytes = ch.n[ci] * (int64_t)L, nd = nbytes >> 2, nrows = nd >> 6;
     const unsigned* src = reinterpret_cast<const unsigned*>(ch.bytes[ci] + ch.off[ci][0]);
     if (slot < nslots) {
       const int64_t nmine = first < nrows ? (nrows - first + stride - 1) / stride : 0;
@@ -1914,22 +1935,28 @@ __global__ __launch_bounds__(K5_THREADS) void k5_main(const K5Chunks ch, int lma
           if (i + j < nmine) one(v[j]);
       }
     }
-    if (g == NW - 1) {  // the last, partial row (< 64 dwords): column = dword-of-read, first copy
+    if (g == NW - 1) {  // the last, partial row (< 64 dwords) and the chunk's last n L mod 4 bytes
       const int64_t c = nrows * 64 + lane;
-      if (c < nd) {
-        const int q = (int)(c % Ld);
-        slow(src[c], q, (unsigned)q * 4u);
+      if (c < nd) slow(src[c], (int)(c % P), 0);
+      if (lane < (int)(nbytes & 3)) {
+        const int64_t e = (nd << 2) + lane;
+        const unsigned b = reinterpret_cast<const uint8_t*>(src)[e];
+        const int pe = (int)(e % L);
+        if (b < 128) atomicAdd(reinterpret_cast<unsigned*>(hb + (unsigned)((((pe & 3) * C + (pe >> 2)) >> 6) << 15 | (((pe & 3) * C + (pe >> 2)) & 63) << 2) + b * 256), 1u);
+        else atomicAdd(&d_hist[(size_t)pe * 256 + b], 1ull);
       }
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < pt * 128; i += K5_THREADS) {
-    const int p = i >> 7, b = i & 127, k = p & 3;
+    const int p = i >> 7, b = i & 127;
     unsigned v = 0;
     if (p < L) {
-      const unsigned* row = k5_h + (k >> 1) * 16384 + (k & 1) * 8192 + b * 64 + (p >> 2);
-      v = row[0];
-      if (Ld <= 32) v += row[32];
+      const int sl = (p & 3) * C + (p >> 2);
+      for (int c = 0; c < copies; ++c) {
+        const int sc = sl + c * 4 * C;
+        v += k5_h[(sc >> 6) * 8192 + b * 64 + (sc & 63)];
+      }
     }
     reinterpret_cast<unsigned*>(partials)[(size_t)blockIdx.x * pt * 128 + i] = v;
   }

@@ -447,7 +447,14 @@ def test_k4_bad_group_id_is_reported(ctx):
                                        # read counts that leave partial rows / idle waves
                                        (1, 32), (3, 36), (65_537, 32), (250_001, 44), (123_457, 76), (99_999, 92), (64, 100),
                                        (4_200_000, 100), (333_333, 124), (80_001, 132), (60_001, 148), (50_001, 200),
-                                       (40_001, 252), (4096 * 16 + 1, 256)])
+                                       (40_001, 252), (4096 * 16 + 1, 256),
+                                       # path A for ANY uniform length (round 3): odd L (period L dwords), L = 2 mod 4 (period
+                                       # L / 2), periods < 32 (two table copies) and < 16 (four), the 5-plane table (L > 256),
+                                       # lengths that leave 1-3 trailing bytes, and enough reads for the steady state
+                                       (800_003, 101), (530_001, 151), (540_001, 150), (1_600_001, 51), (1_600_003, 50),
+                                       (4_500_001, 18), (9_000_001, 9), (2_400_001, 33), (260_001, 310), (270_003, 309),
+                                       (280_001, 302), (320_001, 250), (1_000_001, 75), (3_000_001, 26), (5, 151), (63, 101),
+                                       (1_000_003, 10), (6_000_001, 13)])
 def test_k5_qual_pos_hist(ctx, oracle, n_reads, L):
     off, data = ctx.gen_c5(5, 0, n_reads, L)
     d = ctx.zeros(np.int64, L * 256)
@@ -492,7 +499,8 @@ def test_k5_path_a_with_non_ascii_bytes_lmax_above_read_length_and_accumulation(
     assert want[:, 128:].sum() > 0 and want[:, :32].sum() > 0 and want[L:].sum() == 0
 
 
-@pytest.mark.parametrize("n,L,n_bad", [(1_300_003, 100, 20_000), (900_001, 148, 3), (2_000_000, 64, 50_000), (700_000, 100, 1)])
+@pytest.mark.parametrize("n,L,n_bad", [(1_300_003, 100, 20_000), (900_001, 148, 3), (2_000_000, 64, 50_000), (700_000, 100, 1),
+                                          (600_001, 151, 5000), (1_700_001, 50, 5000), (5_000_001, 13, 3000), (300_001, 301, 2000)])
 def test_k5_path_a_steady_state_moves_non_ascii_bytes(ctx, oracle, n, L, n_bad):
     """Round 3's path A masks a dword to 7 bits per byte in its steady state (no branch per dword) and repairs, once per 24
     rows, the rows in which a byte >= 128 went to the bin of byte & 127.  The steady state needs >= 48 rows per wavefront
