@@ -32,13 +32,14 @@ import torch  # noqa: E402  (imported before the HIP library so both share one H
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-BYTES_PER_ROW = {"c4": 12.25, "c2": 12.0, "c3": 9.25, "c5": 104.0, "c6": 20.375}  # algorithmic bytes/row, SURVEY.md section 8(d)
+C5_L = int(os.environ.get("EXON_BENCH_C5_L", 100))  # config 5's read length (BASELINE.json: 100)
+BYTES_PER_ROW = {"c4": 12.25, "c2": 12.0, "c3": 9.25, "c5": 4.0 + C5_L, "c6": 20.375}  # algorithmic bytes/row, SURVEY.md section 8(d)
 SEED = {"c2": 2, "c3": 3, "c4": 4, "c5": 5, "c6": 6}
 DTYPE = {"c4": "f64", "c2": "int64", "c3": "int64", "c5": "u8", "c6": "int64"}
 WORKLOAD = {"c4": "config 4: 1B-row synthetic VCF, WHERE info.AF > 0.01, AVG(qual), COUNT(*) GROUP BY filter",
             "c2": "config 2: synthetic VCF, chrom='7' AND pos in [5e7,1e8], COUNT(*)",
             "c3": "config 3: synthetic BAM, flag&1284=0 AND mapq>=30, COUNT(*) GROUP BY reference",
-            "c5": "config 5: synthetic FASTQ (L=100), per-position 256-bin quality histogram; rows = reads",
+            "c5": f"config 5: synthetic FASTQ (L={C5_L}), per-position 256-bin quality histogram; rows = reads",
             "c6": "synthetic alignments, bam_region_filter('<ref 7>:50000000-100000000', reference, start, end), COUNT(*)"}
 ARITH = {"c4": "f32 columns compared as totalOrder i32 keys, f64 sums, i64 counts",
          "c2": "i32 / i64 compares, i64 count", "c3": "i32 mask compare, u8 compare, i64 counts",
@@ -131,11 +132,13 @@ class Workload:
             self.cols = [(self.flag.data_ptr(), None, None), (self.mapq.data_ptr(), self.mv.data_ptr(), None),
                          (self.ref.data_ptr(), self.rv.data_ptr(), None)]
         elif kind == "c5":
-            # FASTQ quality strings, L = 100.  Arrow Utf8 has int32 offsets, so the shard is a sequence of
-            # batches of 20 M reads (2.0e9 quality bytes, under the 2^31 limit; a batch of exactly 2^31 - 48 bytes measured 25 %
-            # slower per byte, EXON_BENCH_C5_BATCH overrides); the histogram accumulates.
-            self.L = 100
-            self.batch = max(1, min(rows, int(os.environ.get("EXON_BENCH_C5_BATCH", 20_000_000))))
+            # FASTQ quality strings, L = 100.  Arrow Utf8 has int32 offsets, so the shard is a sequence of batches, each as
+            # large as such a column gets (21,474,835 reads at L = 100; EXON_BENCH_C5_BATCH overrides), packed back to back in
+            # one allocation -- so most batches start at an odd address.  (Round 2 used 20 M-read batches because full ones ran
+            # 25 % slower; the cause was that their first bytes were not 256-byte aligned and the kernel's 256-byte rows then
+            # straddled cache lines.  Round 3's kernel reads memory-aligned rows whatever the base.)  The histogram accumulates.
+            self.L = C5_L  # 100 = BASELINE.json's config; EXON_BENCH_C5_L times other uniform read lengths (151, 250 ...)
+            self.batch = max(1, min(rows, int(os.environ.get("EXON_BENCH_C5_BATCH", (2**31 - 64) // self.L))))
             self.bytes = torch.empty(rows * self.L + 64, dtype=torch.uint8, device=dev)
             nb = (rows + self.batch - 1) // self.batch
             self.off = torch.empty(rows + nb + 4, dtype=torch.int32, device=dev)  # every batch has its own offsets buffer
@@ -157,7 +160,7 @@ class Workload:
 
     def run(self):
         """The hot path over the shard: main + finalize kernels; the state is DEFINED by the launch (overwrite mode),
-        so there is no zeroing pass.  c5: the shard is a list of 20 M-read Arrow batches handed over in one call."""
+        so there is no zeroing pass.  c5: the shard is a list of full Arrow batches handed over in one call."""
         s = torch.cuda.current_stream().cuda_stream
         if self.kind == "c5":
             if self.fused:  # exon_hip_plan_launch_chunks: one offsets scan + one main kernel + one fold per 64 batches
@@ -240,9 +243,9 @@ def cpu_baseline(kind, sample_rows, n_total, reps):
         out = (np.array([r], np.int64), None)
     elif kind == "c5":
         n = min(n, 8_000_000)
-        off, data = orc.gen_c5(SEED["c5"], 0, n, 100)
+        off, data = orc.gen_c5(SEED["c5"], 0, n, C5_L)
         for _ in range(reps):
-            hcpu, t = orc.c5_qual_pos_hist(off, data, 100)
+            hcpu, t = orc.c5_qual_pos_hist(off, data, C5_L)
             secs.append(t.seconds_exec), mat.append(t.seconds_materialize)
         out = (hcpu.reshape(-1), None)
     else:

@@ -1763,7 +1763,7 @@ __device__ __forceinline__ int k5_pick_path(const K5Chunks& ch, int lmax, const 
   if (f & 1) return K5_PATH_G;
   const int L = ch.ends[0][0] - ch.off[0][0];
   if (L < 1 || L > lmax) return K5_PATH_G;
-  if (k5_period(L) >= 8 && L <= K5_PT_MAX && !(f & 2)) return K5_PATH_A;  // slots: copies x 4 ceil(L / 4) <= 320
+  if (k5_period(L) >= 8 && L <= K5_PT_MAX) return K5_PATH_A;  // any base alignment; slots: copies x 4 ceil(L / 4) <= 320
   if (L <= K5_PT_MAX && !(f & 4)) return K5_PATH_B;
   return K5_PATH_G;
 }
@@ -1820,18 +1820,24 @@ __global__ __launch_bounds__(K5_THREADS) void k5_main(const K5Chunks ch, int lma
   const int t = (64 * r) % P + lane, w = t / P, d = t - w * P;
   char* hb = reinterpret_cast<char*>(k5_h);
   // byte address of the bin of (dword-of-period dd, wrap count ww, byte-in-dword k) without the byte value, and its position
-  auto pos_of = [&](int dd, int k) { return (4 * dd + k) % L; };
+  // Rows are 256-byte pieces of MEMORY (aligned loads whatever the chunk's first byte is): a chunk whose bytes start `sh` bytes
+  // into its first row has dword D = 64 R + lane of row R holding the positions (4 D + k - sh) mod L.  shl = (-sh) mod L, per chunk.
+  int shl = 0;
+  auto pos_of = [&](int dd, int k) { return (4 * dd + k + shl) % L; };
   auto bin_base = [&](int dd, int ww, int k) {
     const int p = pos_of(dd, k), sl = (p & 3) * C + (p >> 2) + (ww & (copies - 1)) * 4 * C;
     return (unsigned)((sl >> 6) << 15 | (sl & 63) << 2);
   };
-  unsigned ck[4], pb = 0;  // the lane's constants: address bits 16-17 + column per k; the planes' low bits at bit 7 of byte k
+  unsigned ck[4], pb = 0;  // the lane's constants (per chunk: they follow shl): address bits 16-17 + column per k; the planes' low bits at bit 7 of byte k
+  auto lane_constants = [&]() {
+    pb = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const unsigned a = bin_base(d, w, k);
-    ck[k] = a & ~0x8000u;
-    pb |= ((a >> 15) & 1u) << (8 * k + 7);
-  }
+    for (int k = 0; k < 4; ++k) {
+      const unsigned a = bin_base(d, w, k);
+      ck[k] = a & ~0x8000u;
+      pb |= ((a >> 15) & 1u) << (8 * k + 7);
+    }
+  };
   auto slow = [&](unsigned dw, int dd, int ww) {  // a byte >= 128 somewhere, or the last, partial row (dd is not the lane's d)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1874,12 +1880,18 @@ __global__ __launch_bounds__(K5_THREADS) void k5_main(const K5Chunks ch, int lma
     }
   };
   const int64_t stride = (int64_t)nslots * Pr, first = (int64_t)slot * Pr + r;  // this wave's rows: first + i * stride
-  for (int ci = 0; ci < ch.count; ++ci) {  // every chunk starts at a read boundary: the wave keeps its rows, d and w
-    const int64_t nbytes = ch.n[ci] * (int64_t)L, nd = nbytes >> 2, nrows = nd >> 6;
-    const unsigned* src = reinterpret_cast<const unsigned*>(ch.bytes[ci] + ch.off[ci][0]);
+  for (int ci = 0; ci < ch.count; ++ci) {  // the wave keeps its rows, d and w; the positions behind them shift with the chunk's base
+    const uint8_t* base = ch.bytes[ci] + ch.off[ci][0];
+    const int sh = (int)(reinterpret_cast<uintptr_t>(base) & 255);
+    const unsigned* src = reinterpret_cast<const unsigned*>(base - sh);  // 256-byte aligned
+    const int64_t nbytes = ch.n[ci] * (int64_t)L, span = sh + nbytes;    // the chunk's bytes are [sh, span) of the row grid
+    const int64_t R0 = sh ? 1 : 0, R1 = span >> 8;                       // rows [R0, R1) lie entirely inside the chunk
+    shl = (L - sh % L) % L;
+    lane_constants();
     if (slot < nslots) {
-      const int64_t nmine = first < nrows ? (nrows - first + stride - 1) / stride : 0;
-      const unsigned* p = src + first * 64;  // wave-uniform
+      const int64_t firstc = first < R0 ? first + stride : first;
+      const int64_t nmine = firstc < R1 ? (R1 - firstc + stride - 1) / stride : 0;
+      const unsigned* p = src + firstc * 64;  // wave-uniform
       const int64_t pstep = stride * 64;
       int64_t i = 0;
       auto fixup = [&](unsigned acc) {
@@ -1935,16 +1947,23 @@ __global__ __launch_bounds__(K5_THREADS) void k5_main(const K5Chunks ch, int lma
           if (i + j < nmine) one(v[j]);
       }
     }
-    if (g == NW - 1) {  // the last, partial row (< 64 dwords) and the chunk's last n L mod 4 bytes
-      const int64_t c = nrows * 64 + lane;
-      if (c < nd) slow(src[c], (int)(c % P), 0);
-      if (lane < (int)(nbytes & 3)) {
-        const int64_t e = (nd << 2) + lane;
-        const unsigned b = reinterpret_cast<const uint8_t*>(src)[e];
-        const int pe = (int)(e % L);
-        if (b < 128) atomicAdd(reinterpret_cast<unsigned*>(hb + (unsigned)((((pe & 3) * C + (pe >> 2)) >> 6) << 15 | (((pe & 3) * C + (pe >> 2)) & 63) << 2) + b * 256), 1u);
-        else atomicAdd(&d_hist[(size_t)pe * 256 + b], 1ull);
-      }
+    if (g == NW - 1 && nbytes > 0) {  // the rows the chunk covers only in part: its first (sh > 0) and its last, byte by byte
+      auto edge_row = [&](int64_t R) {
+        const int64_t e0 = (R * 64 + lane) * 4;  // byte offset of this lane's dword in the row grid
+        if (e0 + 4 <= sh || e0 >= span) return;
+        const unsigned dw = src[R * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int64_t e = e0 + k;
+          if (e < sh || e >= span) continue;
+          const unsigned b = (dw >> (8 * k)) & 0xFF;
+          const int pe = (int)((e - sh) % L), sl = (pe & 3) * C + (pe >> 2);
+          if (b < 128) atomicAdd(reinterpret_cast<unsigned*>(hb + (unsigned)((sl >> 6) << 15 | (sl & 63) << 2) + b * 256), 1u);
+          else atomicAdd(&d_hist[(size_t)pe * 256 + b], 1ull);
+        }
+      };
+      if (R0) edge_row(0);
+      if ((span & 255) != 0 && !(R0 && R1 == 0)) edge_row(R1);
     }
   }
   __syncthreads();

@@ -523,6 +523,28 @@ def test_k5_path_a_steady_state_moves_non_ascii_bytes(ctx, oracle, n, L, n_bad):
     assert np.array_equal(got, 2 * want)
 
 
+@pytest.mark.parametrize("n,L,shift", [(900_001, 100, 7), (700_001, 151, 3), (1_200_001, 76, 130), (800_001, 101, 255), (600_001, 64, 1),
+                                       (3, 100, 250), (2, 151, 255), (1, 36, 254), (700, 100, 253), (1_000_003, 50, 2)])
+def test_k5_path_a_on_any_base_alignment(ctx, oracle, n, L, shift):
+    """Path A reads 256-byte rows of MEMORY and shifts the positions by where the column's first byte sits in its row, so a
+    sliced batch (offsets[0] != 0), a byte-unaligned base and batches packed back to back all keep the fast path; the rows a
+    chunk covers only in part (first and last) are added byte by byte.  Large cases reach the steady state; the tiny ones put
+    the whole column inside one or two rows.  A few bytes >= 128 ride along."""
+    rng = np.random.default_rng(shift)
+    data = rng.integers(33, 75, n * L + shift, dtype=np.uint8)
+    bad = rng.integers(shift, n * L + shift, max(1, n * L // 50_000))
+    data[bad] = rng.integers(128, 256, len(bad)).astype(np.uint8)
+    data[:shift] = 200  # bytes in front of the column must not be counted
+    off = (np.arange(n + 1, dtype=np.int64) * L + shift).astype(np.int32)
+    d = ctx.zeros(np.int64, L * 256)
+    ctx.qual_pos_hist(ctx.to_device(off), ctx.to_device(np.concatenate([data, np.full(300, 201, np.uint8)])), n, L, d)
+    ctx.sync()
+    want, _ = oracle.c5_qual_pos_hist(off, data, L)
+    got = d.to_host().reshape(L, 256)
+    assert got.sum() == n * L
+    assert np.array_equal(got, want)
+
+
 def _k5_chunk(rng, n, L, shift=0, ragged=False, lmax=None):
     """(offsets, bytes) of one Utf8 batch: uniform length L, or ragged lengths in [0, lmax]"""
     lens = rng.integers(0, lmax + 1, n) if ragged else np.full(n, L)
