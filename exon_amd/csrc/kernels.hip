@@ -1807,14 +1807,14 @@ __global__ __launch_bounds__(K5_THREADS) void k5_main(const K5Chunks ch, int lma
   const int P = k5_period(L), C = (L + 3) >> 2, copies = k5_copies(P);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: the row bases below are wave-uniform
   const int NW = (int)gridDim.x * (K5_THREADS / 64), g = (int)blockIdx.x * (K5_THREADS / 64) + wave;
-  // The wave's rows: index == r (mod Pr), every nslots-th of them.  Pr = P, except when P divides 64: a lane's dword-of-period
-  // is then lane % P in EVERY row and the rows can be dealt one by one.  A wave's consecutive rows must NOT sit a multiple of
-  // 4 KiB apart (16 rows: its 24 loads in flight then queue on the same HBM channel; L = 125 / 249 / 251, where 4096 / P waves
-  // per residue is a power of two, ran at 4.5-5.1 TB/s instead of 6.1, L = 64 at 5.7): a slot is given up until the stride is odd
-  // enough (at most 6 % of the waves; L = 192, P = 48, cannot avoid it).
-  const int Pr = 64 % P == 0 ? 1 : P;
+  // The wave's rows: index == r (mod Pr), every nslots-th of them.  A lane's dword-of-period in row R is (64 R + lane) mod P, which
+  // depends on R mod Pr only, Pr = P / gcd(P, 64) (Pr = 1 when P divides 64: rows are then dealt one by one).  A wave's consecutive
+  // rows must NOT sit a multiple of 4 KiB apart (16 rows: its 24 loads in flight then queue on the same HBM channel; L = 125 /
+  // 249 / 251, where 4096 / P waves per residue is a power of two, ran at 4.5-5.1 TB/s instead of 6.1, L = 64 at 5.7): a slot is
+  // given up until the stride is not (at most 6 % of the waves).
+  const int Pr = P / min(P & -P, 64);
   int nslots = NW / Pr;
-  if ((Pr & 15) != 0)  // (a period of 48 rows cannot be helped)
+  if ((Pr & 15) != 0)
     while (nslots > 1 && ((nslots * Pr) & 15) == 0) --nslots;
   const int r = g % Pr, slot = g / Pr;
   const int t = (64 * r) % P + lane, w = t / P, d = t - w * P;
