@@ -1654,13 +1654,15 @@ hipError_t launch_cmp_avg_by_group(hipStream_t s, const LaunchCfg& cfg, const Wo
 //   shift/mask/multiply-add per byte) and ran at 5.5 TB/s.  One 1024-thread workgroup per CU owns a u32 LDS histogram of
 //   the ASCII half of the byte range (quality strings are Phred+33 <= 126; a byte >= 128 goes straight to a global
 //   atomic).  Three paths inside ONE kernel, chosen ON THE DEVICE from `k5_scan_offsets` (no host round trip):
-//     A  uniform read length L, L % 4 == 0, 32 <= L <= 256: a wave owns the 64-dword rows of the byte stream whose row
-//        index is == r (mod L/4), so every lane keeps ONE dword-of-read d (4 fixed positions) and one wrap count w for the
-//        whole launch: no per-iteration position arithmetic.  Table [k = byte-in-dword][byte < 128][64 columns] u32
-//        (128 KiB); column = d + 32 (w & 1) for L <= 128, d otherwise: two lanes of a half with equal d always differ by
-//        one in w, so a half never holds two equal addresses; the bank is d.  A bin's address is b << 8 | column << 2
-//        (+ k planes): ONE v_perm_b32 per byte.  8 VALU instructions per dword, all 64 lanes busy: 6.5 TB/s at L = 100.
-//     B  any other uniform L <= 310: 16-byte chunk per lane, h[p][129] (+1 pad: bank = p + byte).
+//     A  ANY uniform read length 9 <= L <= 310 whose position pattern repeats after P = L / gcd(L, 4) >= 8 dwords, any base
+//        alignment (round 3; round 2: L % 4 == 0, 32 <= L <= 256, 4-byte aligned).  The bytes are read as 256-byte rows of
+//        MEMORY; a wave owns the rows of one residue class, so every lane keeps ONE dword-of-period d (4 fixed positions) and
+//        one wrap count w for the whole launch: no per-iteration position arithmetic.  Table [5 planes][byte < 128][64 columns]
+//        u32 (160 KiB), position p in slot (p & 3) ceil(L / 4) + (p >> 2) (+ a copy chosen by w when P < 32: a 32-lane half
+//        never holds two equal addresses); a bin's address is plane << 15 | byte << 8 | column << 2: ONE v_perm_b32 per byte.
+//        No branch per dword, a rolling window of 24 loads: 7 VALU instructions per dword, all 64 lanes busy: 6.4-6.5 TB/s.
+//        Details at the head of the path in k5_main.
+//     B  what is left of the uniform lengths (P < 8): 16-byte chunk per lane, h[p][129] (+1 pad: bank = p + byte).
 //     G  ragged reads: a half-wave per read, one (unaligned) dword per lane, 8 reads in flight; byte-major layout
 //        h[byte][perm(p)], perm(p) = (p & 3) * LP/4 + (p >> 2), when lmax <= LP.
 //   Paths A/B never touch the offsets buffer again (they use L), so HBM traffic is 4 + L bytes per read.
@@ -1677,7 +1679,7 @@ static_assert(K5_LDS_WORDS >= K5_PT_MAX * 129 && K5_LDS_WORDS >= K5_A_WORDS && K
 __shared__ __attribute__((aligned(16))) unsigned k5_h[K5_LDS_WORDS];
 
 // flags[0]: bit 0 = read lengths differ inside a chunk or between chunks, or reads are not back to back (-> path G);
-// bit 1 / bit 2 = some chunk's first byte is not 4- / 16-byte aligned (path A / B need it); a read longer than lmax -> status bit 8.
+// bit 1 / bit 2 = some chunk's first byte is not 4- / 16-byte aligned (path B needs the latter; path A takes any base); a read longer than lmax -> status bit 8.
 // `off` / `ends`: start and end byte of every read.  An Arrow Utf8 column passes (offsets, offsets + 1); a view over
 // raw FASTQ text passes two separate arrays (reads are then not contiguous, which forces path G).
 // blockIdx.y = chunk.
