@@ -7,14 +7,18 @@
 // line, the read features (for the reference span), MQ -- everything else is consumed to keep the streams in step.  The
 // reference sequence is NOT needed for these columns (the reference opens it to rebuild the bases; a missing FASTA is an error
 // there and irrelevant here).
-//   block codecs   raw, gzip, rANS 4x8 orders 0 and 1 (what htslib writes by default and the reference's fixtures use);
-//                  bzip2 / lzma / CRAM 3.1 codecs -> error
+//   block codecs   raw, gzip, rANS 4x8 orders 0 and 1 (what htslib writes by default and the reference's fixtures use), and
+//                  bzip2 / lzma (methods 2 / 3: htslib's use_bzip2 / use_lzma and its archive profile) through the system's
+//                  libbz2.so.1.0 / liblzma.so.5, bound at first use with dlopen (this image ships the runtime libraries but not
+//                  their headers; without them such a block is an error).  CRAM 3.1 codecs (rANS Nx16, adaptive arithmetic,
+//                  fqzcomp, name tokeniser: methods 5-8) -> error, never a mis-decode
 //   encodings      EXTERNAL, HUFFMAN, BETA, BYTE_ARRAY_LEN, BYTE_ARRAY_STOP (GOLOMB / SUBEXP / GAMMA are CRAM 2 leftovers -> error)
 // Every length is checked against the bytes in hand; a malformed file is an error, never a read past a buffer.
 #pragma once
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -184,6 +188,26 @@ inline std::vector<uint8_t> rans_4x8(const uint8_t* data, size_t size) {
   return out;
 }
 
+// bzip2 / xz block payloads: one-shot decoders of the system libraries, bound by name (their C ABIs: bzlib.h 1.0, lzma.h 5.x)
+using bz2_decompress_fn = int (*)(char* dest, unsigned* dest_len, char* source, unsigned source_len, int small, int verbosity);
+using lzma_buffer_decode_fn = int (*)(uint64_t* memlimit, uint32_t flags, const void* allocator, const uint8_t* in, size_t* in_pos,
+                                      size_t in_size, uint8_t* out, size_t* out_pos, size_t out_size);
+inline bz2_decompress_fn bz2_decompress() {
+  static const bz2_decompress_fn fn = [] {
+    void* h = dlopen("libbz2.so.1.0", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("libbz2.so.1", RTLD_NOW | RTLD_LOCAL);
+    return h ? reinterpret_cast<bz2_decompress_fn>(dlsym(h, "BZ2_bzBuffToBuffDecompress")) : nullptr;
+  }();
+  return fn;
+}
+inline lzma_buffer_decode_fn lzma_buffer_decode() {
+  static const lzma_buffer_decode_fn fn = [] {
+    void* h = dlopen("liblzma.so.5", RTLD_NOW | RTLD_LOCAL);
+    return h ? reinterpret_cast<lzma_buffer_decode_fn>(dlsym(h, "lzma_stream_buffer_decode")) : nullptr;
+  }();
+  return fn;
+}
+
 struct Block {
   int type = 0;
   uint32_t id = 0;
@@ -214,10 +238,27 @@ inline Block read_block(Cursor& c) {
     const int rc = rsz ? inflate(&z, Z_FINISH) : Z_STREAM_END;
     inflateEnd(&z);
     if (rc != Z_STREAM_END || z.avail_out != 0) throw std::runtime_error("CRAM: corrupt gzip block");
+  } else if (method == 2) {  // bzip2 (CRAM 3.0 section 8.1)
+    const bz2_decompress_fn f = bz2_decompress();
+    if (!f) throw std::runtime_error("CRAM: bzip2 block, but libbz2.so.1.0 is not on this machine");
+    b.data.resize(rsz ? rsz : 1);
+    unsigned got = (unsigned)b.data.size();
+    const int rc = f(reinterpret_cast<char*>(b.data.data()), &got, reinterpret_cast<char*>(const_cast<uint8_t*>(src)), csz, 0, 0);
+    if (rc != 0 /* BZ_OK */ || got != rsz) throw std::runtime_error("CRAM: corrupt bzip2 block");
+    b.data.resize(rsz);
+  } else if (method == 3) {  // lzma: an .xz stream
+    const lzma_buffer_decode_fn f = lzma_buffer_decode();
+    if (!f) throw std::runtime_error("CRAM: lzma block, but liblzma.so.5 is not on this machine");
+    b.data.resize(rsz);
+    uint64_t memlimit = 1ull << 30;
+    size_t in_pos = 0, out_pos = 0;
+    const int rc = f(&memlimit, 0, nullptr, src, &in_pos, csz, b.data.data(), &out_pos, rsz);
+    if (rc != 0 /* LZMA_OK */ || out_pos != rsz) throw std::runtime_error("CRAM: corrupt lzma block");
   } else if (method == 4) {
     b.data = rans_4x8(src, csz);
   } else {
-    throw std::runtime_error("CRAM: block compression method " + std::to_string(method) + " is not supported (raw, gzip, rANS 4x8 are)");
+    throw std::runtime_error("CRAM: block compression method " + std::to_string(method) +
+                             " is not supported (raw, gzip, bzip2, lzma, rANS 4x8 are; 5-8 are the CRAM 3.1 codecs)");
   }
   if (b.data.size() != rsz) throw std::runtime_error("CRAM: block size mismatch");
   // CRC-32 over the block's header and payload (CRAM 3.0 section 8): a raw or rANS block has no other integrity check, and

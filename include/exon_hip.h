@@ -358,7 +358,7 @@ int exon_hip_stream_close(exon_hip_stream* s);
 #define EXON_HIP_FORMAT_FASTA 4
 #define EXON_HIP_FORMAT_SAM 5 /* text SAM: same columns as BAM */
 #define EXON_HIP_FORMAT_BCF 6 /* BCF2: same columns as VCF */
-#define EXON_HIP_FORMAT_CRAM 7 /* CRAM 3.0 (raw / gzip / rANS 4x8 blocks), host decoder: same columns as BAM */
+#define EXON_HIP_FORMAT_CRAM 7 /* CRAM 3.0 (raw / gzip / bzip2 / lzma / rANS 4x8 blocks), host decoder: same columns as BAM */
 #define EXON_HIP_COMPRESSION_AUTO 0 /* sniff the gzip/BGZF magic */
 #define EXON_HIP_COMPRESSION_NONE 1
 #define EXON_HIP_COMPRESSION_GZIP 2

@@ -342,7 +342,7 @@ def decode_fasta(path):
 # Reference: exon-cram/src/array_builder.rs (columns of the shared SAM/BAM/CRAM schema, exon-sam/src/schema_builder.rs:371-402)
 # over noodles-cram 0.x (Cargo.lock), which is absent from /root/reference: restated from the published CRAM 3.0
 # specification (file definition, containers, compression header, slices, blocks, data-series encodings, record layout).
-# Block codecs: raw, gzip and rANS 4x8 (what the reference's fixtures use); bzip2 / lzma are reported as unsupported.
+# Block codecs: raw, gzip, bzip2, lzma (python's own modules) and rANS 4x8 (what the reference's fixtures use); the CRAM 3.1 codecs are reported as unsupported.
 def _itf8(b, o):
     v = b[o]
     if v < 0x80:
@@ -484,6 +484,12 @@ def _cram_block(b, o):
     raw = bytes(b[o:o + csz])
     if method == 1:
         raw = gzip.decompress(raw)
+    elif method == 2:
+        import bz2
+        raw = bz2.decompress(raw)
+    elif method == 3:
+        import lzma
+        raw = lzma.decompress(raw)
     elif method == 4:
         raw = _rans_4x8(raw)
     elif method != 0:

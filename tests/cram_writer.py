@@ -6,6 +6,8 @@ core bit stream; names BYTE_ARRAY_STOP, insertions / soft clips BYTE_ARRAY_LEN. 
 import gzip
 import struct
 import zlib
+import bz2
+import lzma
 
 import numpy as np
 
@@ -35,7 +37,8 @@ def ltf8(v):
 
 
 def block(ctype, cid, data, method=0):
-    comp = gzip.compress(data, mtime=0) if method == 1 else data
+    """method: 0 raw, 1 gzip, 2 bzip2, 3 lzma (an .xz stream) -- CRAM 3.0 section 8.1"""
+    comp = {0: lambda d: d, 1: lambda d: gzip.compress(d, mtime=0), 2: bz2.compress, 3: lzma.compress}[method](data)
     body = bytes([method, ctype]) + itf8(cid) + itf8(len(comp)) + itf8(len(data)) + comp
     return body + struct.pack("<I", zlib.crc32(body) & 0xFFFFFFFF)
 
@@ -99,10 +102,11 @@ IDS = dict(BF=1, CF=2, RI=3, RL=4, AP=5, RG=6, RN=7, MF=8, NS=9, NP=10, TS=11, N
            QS=19, BS=20, IN=21, SC=22, RS=23, PD=24, HC=25, LEN=26)
 
 
-def write_cram(path, refs, records, per_slice=700, slices_per_container=2, seed=0, ds_patch=None):
+def write_cram(path, refs, records, per_slice=700, slices_per_container=2, seed=0, ds_patch=None, methods=(0, 1)):
     """refs: [(name, length)]; records: dicts(flag, ref_id (-1 unmapped), pos (1-based, 0 none), mapq, name, rl, feats) with
     feats = [(read position, code, value)], code in I i D S N P H X.  Records are written in the given order; a run of records
-    on one reference makes single-reference slices, mixed runs make multi-reference (-2) slices."""
+    on one reference makes single-reference slices, mixed runs make multi-reference (-2) slices.  `methods`: the block
+    compression methods the external blocks draw from (0 raw, 1 gzip, 2 bzip2, 3 lzma)."""
     rng = np.random.default_rng(seed)
     text = "@HD\tVN:1.6\tSO:unsorted\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in refs)
     hdr = struct.pack("<i", len(text)) + text.encode()
@@ -188,7 +192,7 @@ def write_cram(path, refs, records, per_slice=700, slices_per_container=2, seed=
                 itf8(1 + len(used)) + itf8(1 + len(used)) + itf8(0) + b"".join(itf8(k) for k in used) + itf8(-1) + bytes(16)
             sh = block(2, 0, body)
             landmarks.append(off)
-            sblocks = [sh, block(5, 0, core.bytes())] + [block(4, k, bytes(ext[k]), int(rng.integers(0, 2))) for k in used]
+            sblocks = [sh, block(5, 0, core.bytes())] + [block(4, k, bytes(ext[k]), methods[int(rng.integers(0, len(methods)))]) for k in used]
             blocks += sblocks
             off += sum(len(x) for x in sblocks)
             counter += len(sl)

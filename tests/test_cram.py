@@ -172,6 +172,43 @@ def test_synthetic_cram_with_every_span_changing_feature(tmp_path):
             assert s2 == [want_start[i] for i in hit] and e2 == [want_end[i] for i in hit] and f2 == [want_flag[i] for i in hit]
 
 
+def test_bzip2_and_lzma_blocks(tmp_path):
+    """Block compression methods 2 (bzip2) and 3 (lzma / xz) -- what htslib writes with use_bzip2 / use_lzma and in its archive
+    profile; the reference reads them through noodles-cram's bzip2 / xz dependencies.  The product binds the system's
+    libbz2.so.1.0 / liblzma.so.5 at first use; the writer and the oracle use Python's bz2 / lzma modules (independent code).
+    Product = oracle = the records written; a damaged payload is an error."""
+    from cram_writer import synthetic_records, write_cram
+    refs = [("chrA", 3_000_000), ("chrB", 1_500_000), ("chrC", 400_000)]
+    n = 20_000
+    recs = synthetic_records(n, refs, seed=9)
+    want_flag = [r["flag"] for r in recs]
+    want_start = [r["pos"] if r["pos"] > 0 else None for r in recs]
+    want_end = [r["pos"] + r["span"] - 1 if r["pos"] > 0 else None for r in recs]
+    want_mapq = [None if r["flag"] & 4 or r["mapq"] == 255 else r["mapq"] for r in recs]
+    raw = None
+    for methods in ((2,), (3,), (0, 1, 2, 3)):
+        path = str(tmp_path / f"m{'_'.join(map(str, methods))}.cram")
+        write_cram(path, refs, recs, per_slice=900, slices_per_container=2, seed=5, methods=methods)
+        raw = open(path, "rb").read()
+        orefs, orecs = decode.decode_cram(path)
+        assert orefs == refs and [r["flag"] for r in orecs] == want_flag and [r["end"] for r in orecs] == want_end
+        names, flag, mapq, ref, start, end = product_columns(path)
+        assert flag == want_flag and start == want_start and end == want_end and mapq == want_mapq, methods
+    # flipped bytes inside bzip2 / lzma payloads: the block CRC (or the codec) must refuse the file, never mis-decode it
+    refused = 0
+    for at in range(len(raw) // 3, len(raw) - 64, len(raw) // 23):
+        bad = bytearray(raw)
+        bad[at] ^= 0x55
+        p = tmp_path / "bad.cram"
+        p.write_bytes(bytes(bad))
+        try:
+            _, flag, mapq, _, start, end = product_columns(str(p))
+            assert flag == want_flag and start == want_start and end == want_end  # the flip fell outside what is read
+        except Exception:
+            refused += 1
+    assert refused >= 10
+
+
 def test_hostile_compression_headers_and_flipped_bytes(tmp_path):
     """ADVICE r2: (1) BYTE_ARRAY_LEN encodings nested tens of thousands deep must be an error, not a stack overflow;
     (2) an encoding this reader does not implement (GOLOMB) is an error only when its series is actually read; (3) every
