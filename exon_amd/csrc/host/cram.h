@@ -24,11 +24,13 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <future>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -212,18 +214,18 @@ struct Block {
   int type = 0;
   uint32_t id = 0;
   std::vector<uint8_t> data;
+  // a block read lazily (read_block(c, true)) keeps its compressed payload -- which lives in the container's buffer -- until
+  // expand() is called: the external blocks of data series this path never looks at (quality scores, bases, names, tag
+  // values: most of a file) are then never decompressed (what htslib's `required_fields` does; the reference decodes all)
+  int method = 0;
+  uint32_t csz = 0, rsz = 0;
+  const uint8_t* src = nullptr;
+  bool ready = true;
+  void expand();
 };
-inline Block read_block(Cursor& c) {
-  Block b;
-  const size_t block_start = c.o;
-  const int method = c.u8();
-  b.type = c.u8();
-  b.id = c.itf8();
-  const uint32_t csz = c.itf8(), rsz = c.itf8();
-  c.need((size_t)csz + 4);
-  const uint8_t* src = c.p + c.o;
-  // a corrupt size must not turn into a huge allocation: DEFLATE expands at most ~1032x, rANS blocks are capped outright
-  if (rsz > (1u << 28) || (method == 1 && (uint64_t)rsz > (uint64_t)csz * 1032u + 1024u)) throw std::runtime_error("CRAM: block too large");
+inline void Block::expand() {
+  if (ready) return;
+  Block& b = *this;
   if (method == 0) {
     b.data.assign(src, src + csz);
   } else if (method == 1) {
@@ -257,17 +259,36 @@ inline Block read_block(Cursor& c) {
   } else if (method == 4) {
     b.data = rans_4x8(src, csz);
   } else {
-    throw std::runtime_error("CRAM: block compression method " + std::to_string(method) +
-                             " is not supported (raw, gzip, bzip2, lzma, rANS 4x8 are; 5-8 are the CRAM 3.1 codecs)");
+    throw std::runtime_error("CRAM: block compression method " + std::to_string(method) + " is not supported");
   }
   if (b.data.size() != rsz) throw std::runtime_error("CRAM: block size mismatch");
+  ready = true;
+}
+inline Block read_block(Cursor& c, bool lazy = false) {
+  Block b;
+  const size_t block_start = c.o;
+  b.method = c.u8();
+  b.type = c.u8();
+  b.id = c.itf8();
+  const uint32_t csz = c.itf8(), rsz = c.itf8();
+  c.need((size_t)csz + 4);
+  b.csz = csz;
+  b.rsz = rsz;
+  b.src = c.p + c.o;
+  b.ready = false;
+  // a corrupt size must not turn into a huge allocation: DEFLATE expands at most ~1032x, rANS blocks are capped outright
+  if (rsz > (1u << 28) || (b.method == 1 && (uint64_t)rsz > (uint64_t)csz * 1032u + 1024u)) throw std::runtime_error("CRAM: block too large");
+  if (b.method < 0 || b.method > 4)
+    throw std::runtime_error("CRAM: block compression method " + std::to_string(b.method) +
+                             " is not supported (raw, gzip, bzip2, lzma, rANS 4x8 are; 5-8 are the CRAM 3.1 codecs)");
   // CRC-32 over the block's header and payload (CRAM 3.0 section 8): a raw or rANS block has no other integrity check, and
   // a flipped byte in an external block would otherwise become silently wrong flag / position columns (noodles-cram
-  // reports a checksum mismatch)
+  // reports a checksum mismatch).  Checked for every block, expanded or not.
   c.o += (size_t)csz;
   const uint32_t want = (uint32_t)c.i32le();
   const uint32_t got = (uint32_t)crc32(crc32(0L, Z_NULL, 0), c.p + block_start, (uInt)(c.o - 4 - block_start));
   if (got != want) throw std::runtime_error("CRAM: block CRC-32 mismatch");
+  if (!lazy) b.expand();
   return b;
 }
 
@@ -358,14 +379,37 @@ struct SliceData {
   void add(Block&& b) {
     blocks.push_back(std::move(b));
   }
+  // needed[k]: some data series whose VALUES the columns depend on lives in external block k.  A block that only holds series
+  // this path discards (quality scores, bases, names, tag values, mate fields ...) is never expanded and the skip_* calls on
+  // it are no-ops: every external block is its own stream, so nothing else falls out of step.  (A block that mixes both kinds
+  // is `needed` and consumed value by value as before.)
+  std::vector<char> needed;
   void finish_blocks() {
-    ptr.resize(blocks.size());
-    len.resize(blocks.size());
+    ptr.assign(blocks.size(), nullptr);
+    len.assign(blocks.size(), 0);
     pos.assign(blocks.size(), 0);
-    for (size_t i = 0; i < blocks.size(); ++i) {
-      ptr[i] = blocks[i].data.data();
-      len[i] = blocks[i].data.size();
+    needed.assign(blocks.size(), 0);
+    for (size_t i = 0; i < blocks.size(); ++i)
+      if (blocks[i].ready) {
+        ptr[i] = blocks[i].data.data();
+        len[i] = blocks[i].data.size();
+      }
+  }
+  void ensure(int k) {  // expand block k on first use
+    if (blocks[(size_t)k].ready) return;
+    blocks[(size_t)k].expand();
+    ptr[(size_t)k] = blocks[(size_t)k].data.data();
+    len[(size_t)k] = blocks[(size_t)k].data.size();
+  }
+  void need_values(const Encoding& e) {  // call after bind()
+    if ((e.kind == Encoding::EXTERNAL || e.kind == Encoding::BYTE_ARRAY_STOP) && e.slot >= 0) needed[(size_t)e.slot] = 1;
+    else if (e.kind == Encoding::BYTE_ARRAY_LEN) {
+      need_values(*e.len_enc);
+      need_values(*e.val_enc);
     }
+  }
+  bool discardable(const Encoding& e) const {  // an external series alone (with other discarded ones) in its block
+    return (e.kind == Encoding::EXTERNAL || e.kind == Encoding::BYTE_ARRAY_STOP) && e.slot >= 0 && !needed[(size_t)e.slot];
   }
   void bind(Encoding& e) const {
     e.slot = -1;
@@ -394,6 +438,7 @@ struct SliceData {
     switch (e.kind) {
       case Encoding::EXTERNAL: {
         const int k = slot_of(e);
+        ensure(k);
         Cursor c(ptr[k], len[k]);
         c.o = pos[k];
         const int32_t v = c.itf8s();
@@ -419,9 +464,17 @@ struct SliceData {
         throw std::runtime_error("CRAM: integer data series with a byte-array encoding");
     }
   }
+  // a value this path discards: nothing to do when its block holds nothing else of interest
+  void skip_int(const Encoding& e) {
+    if (!discardable(e)) (void)get_int(e);
+  }
+  void skip_byte(const Encoding& e) {
+    if (!discardable(e)) (void)get_byte(e);
+  }
   uint8_t get_byte(const Encoding& e) {
     if (e.kind == Encoding::EXTERNAL) {
       const int k = slot_of(e);
+      ensure(k);
       if (pos[k] >= len[k]) throw std::runtime_error("CRAM: truncated data");
       return ptr[k][pos[k]++];
     }
@@ -430,6 +483,8 @@ struct SliceData {
   void skip_n(const Encoding& e, size_t n) {  // n single-byte values of one series
     if (e.kind == Encoding::EXTERNAL) {
       const int k = slot_of(e);
+      if (!needed[(size_t)k]) return;
+      ensure(k);
       if (n > len[k] - pos[k]) throw std::runtime_error("CRAM: truncated data");
       pos[k] += n;
       return;
@@ -437,9 +492,12 @@ struct SliceData {
     for (size_t i = 0; i < n; ++i) (void)get_int(e);
   }
   // length of the byte array; the bytes themselves are skipped (only lengths matter to the columns of this path)
-  size_t skip_bytes(const Encoding& e, std::string* keep = nullptr) {
+  // `want_len` false: the caller uses neither the bytes nor their count
+  size_t skip_bytes(const Encoding& e, std::string* keep = nullptr, bool want_len = true) {
     if (e.kind == Encoding::BYTE_ARRAY_STOP) {
       const int k = slot_of(e);
+      if (!want_len && !keep && !needed[(size_t)k]) return 0;
+      ensure(k);
       const uint8_t* b = ptr[k] + pos[k];
       const void* hit = memchr(b, e.stop, len[k] - pos[k]);
       if (!hit) throw std::runtime_error("CRAM: truncated data");
@@ -449,10 +507,13 @@ struct SliceData {
       return n;
     }
     if (e.kind == Encoding::BYTE_ARRAY_LEN) {
+      if (!want_len && !keep && discardable(*e.len_enc) && discardable(*e.val_enc)) return 0;
       const int32_t n = get_int(*e.len_enc);
       if (n < 0) throw std::runtime_error("CRAM: negative byte-array length");
       if (e.val_enc->kind == Encoding::EXTERNAL) {
         const int k = slot_of(*e.val_enc);
+        if (!keep && !needed[(size_t)k]) return (size_t)n;  // the bytes live alone in a block nobody reads
+        ensure(k);
         if ((size_t)n > len[k] - pos[k]) throw std::runtime_error("CRAM: truncated data");
         if (keep) keep->assign(reinterpret_cast<const char*>(ptr[k] + pos[k]), (size_t)n);
         pos[k] += (size_t)n;
@@ -620,14 +681,16 @@ class CRAMBatchReader {
     }
   }
 
-  // The next group of containers (those that can hold a hit), decoded on `threads` threads, appended in file order.
-  bool next_container() {
-    struct Job {
-      size_t off, length;
-      std::vector<Rec> recs;
-      std::vector<std::string> names;
-      std::string error;
-    };
+  // The next group of containers (those that can hold a hit), decoded on `threads` threads, appended in file order.  The group
+  // after it is decoded in the background while the caller turns this one into batches (round 3: building the Arrow batches is
+  // single-threaded and had the decoder threads idle for half of the time).
+  struct Job {
+    size_t off, length;
+    std::vector<Rec> recs;
+    std::vector<std::string> names;
+    std::string error;
+  };
+  std::vector<Job> plan_group() {  // walks container headers (caller's thread)
     std::vector<Job> jobs;
     const size_t want = (size_t)std::max(1, threads_);
     while (jobs.size() < want && off_ < size_) {
@@ -649,12 +712,15 @@ class CRAMBatchReader {
       }
       off_ = end;
     }
-    if (jobs.empty()) return false;
-    auto run = [&](Job& j) {
+    return jobs;
+  }
+  std::vector<Job> decode_group(std::vector<Job> jobs) const {  // any thread: positional reads, no shared state
+    const bool want_names = keep_names;
+    auto run = [this, want_names](Job& j) {
       try {
         const std::vector<uint8_t> buf = read_at(j.off, j.length);
         cram::Cursor c(buf.data(), buf.size());
-        decode_container(c, &j.recs, keep_names ? &j.names : nullptr);
+        decode_container(c, &j.recs, want_names ? &j.names : nullptr);
       } catch (const std::exception& e) {
         j.error = e.what();
         if (j.error.empty()) j.error = "CRAM: decode error";
@@ -668,6 +734,27 @@ class CRAMBatchReader {
       run(jobs[0]);
       for (auto& t : pool) t.join();
     }
+    return jobs;
+  }
+  void start_ahead() {  // header errors (a malformed container header) surface here, in file order, as before
+    std::vector<Job> jobs = plan_group();
+    if (jobs.empty()) return;
+    if (threads_ <= 1) {  // sequential reader: no helper thread either
+      std::promise<std::vector<Job>> p;
+      ahead_ = p.get_future();
+      p.set_value(std::move(jobs));
+      ahead_deferred_ = true;
+      return;
+    }
+    ahead_deferred_ = false;
+    ahead_ = std::async(std::launch::async, [this](std::vector<Job> j) { return decode_group(std::move(j)); }, std::move(jobs));
+  }
+  bool next_container() {
+    if (!ahead_.valid()) start_ahead();
+    if (!ahead_.valid()) return false;
+    std::vector<Job> jobs = ahead_.get();
+    if (ahead_deferred_) jobs = decode_group(std::move(jobs));
+    start_ahead();  // the next group decodes while this one is consumed
     for (auto& j : jobs) {
       if (!j.error.empty()) throw std::runtime_error(j.error);
       pending_.insert(pending_.end(), j.recs.begin(), j.recs.end());
@@ -769,15 +856,26 @@ class CRAMBatchReader {
       const uint32_t s_nblocks = s.itf8();
       SliceData sl;
       for (uint32_t i = 0; i < s_nblocks; ++i) {
-        Block b = read_block(c);
-        if (b.type == 5) sl.core.swap(b.data);
-        else if (b.type == 4) sl.add(std::move(b));
+        static const bool eager = getenv("EXON_HIP_CRAM_EAGER") != nullptr;  // A/B: expand every block, as round 2 did
+        Block b = read_block(c, /*lazy=*/!eager);  // external blocks are expanded when a series first reads them
+        if (b.type == 5) {
+          b.expand();
+          sl.core.swap(b.data);
+        } else if (b.type == 4) {
+          sl.add(std::move(b));
+        }
       }
       sl.finish_blocks();
       for (Encoding* e : {&S.BF, &S.CF, &S.RI, &S.RL, &S.AP, &S.RG, &S.RN, &S.MF, &S.NS, &S.NP, &S.TS, &S.NF, &S.TL, &S.FN, &S.FC, &S.FP,
                           &S.DL, &S.BA, &S.QS, &S.BS, &S.IN, &S.SC, &S.RS, &S.PD, &S.HC, &S.MQ, &S.BB, &S.QQ})
         sl.bind(*e);
       for (auto& t : tags) sl.bind(t.second);
+      // the series whose values reach the columns (or steer the decode): everything else is discarded unread
+      for (const Encoding* e : {&S.BF, &S.CF, &S.RI, &S.RL, &S.AP, &S.TL, &S.FN, &S.FC, &S.DL, &S.RS, &S.MQ}) sl.need_values(*e);
+      for (const Encoding* e : {&S.IN, &S.SC})  // byte arrays of which only the LENGTH counts (reference span)
+        if (e->kind == Encoding::BYTE_ARRAY_LEN) sl.need_values(*e->len_enc);
+        else sl.need_values(*e);  // BYTE_ARRAY_STOP: the length is found by scanning the bytes
+      if (out_names) sl.need_values(S.RN);
       out->reserve(out->size() + s_nrec);
       int64_t prev = s_start;
       for (uint32_t r = 0; r < s_nrec; ++r) {
@@ -792,41 +890,41 @@ class CRAMBatchReader {
           ap += prev;
           prev = ap;
         }
-        (void)sl.get_int(DS(RG));
+        sl.skip_int(DS(RG));
         std::string name;
-        if (rn_preserved) sl.skip_bytes(DS(RN), out_names ? &name : nullptr);
+        if (rn_preserved) sl.skip_bytes(DS(RN), out_names ? &name : nullptr, false);
         if (cf & 2) {
-          (void)sl.get_int(DS(MF));
-          if (!rn_preserved) sl.skip_bytes(DS(RN), out_names ? &name : nullptr);
-          (void)sl.get_int(DS(NS));
-          (void)sl.get_int(DS(NP));
-          (void)sl.get_int(DS(TS));
+          sl.skip_int(DS(MF));
+          if (!rn_preserved) sl.skip_bytes(DS(RN), out_names ? &name : nullptr, false);
+          sl.skip_int(DS(NS));
+          sl.skip_int(DS(NP));
+          sl.skip_int(DS(TS));
         } else if (cf & 4) {
-          (void)sl.get_int(DS(NF));
+          sl.skip_int(DS(NF));
         }
         const int32_t tl = sl.get_int(DS(TL));
         if (tl < 0 || (size_t)tl >= tag_idx.size()) throw std::runtime_error("CRAM: tag line out of range");
-        for (int t : tag_idx[(size_t)tl]) sl.skip_bytes(tags[(size_t)t].second);
+        for (int t : tag_idx[(size_t)tl]) sl.skip_bytes(tags[(size_t)t].second, nullptr, false);
         int64_t span = rl;
         rec.mapq = 255;
         if (!(rec.flag & 4)) {
           const int32_t fn = sl.get_int(DS(FN));
           for (int32_t i = 0; i < fn; ++i) {
             const char code = (char)sl.get_byte(DS(FC));
-            (void)sl.get_int(DS(FP));
+            sl.skip_int(DS(FP));
             switch (code) {
-              case 'B': (void)sl.get_byte(DS(BA)); (void)sl.get_byte(DS(QS)); break;
-              case 'X': (void)sl.get_byte(DS(BS)); break;
+              case 'B': sl.skip_byte(DS(BA)); sl.skip_byte(DS(QS)); break;
+              case 'X': sl.skip_byte(DS(BS)); break;
               case 'I': span -= (int64_t)sl.skip_bytes(DS(IN)); break;
-              case 'i': (void)sl.get_byte(DS(BA)); span -= 1; break;
+              case 'i': sl.skip_byte(DS(BA)); span -= 1; break;
               case 'D': span += sl.get_int(DS(DL)); break;
               case 'S': span -= (int64_t)sl.skip_bytes(DS(SC)); break;
               case 'N': span += sl.get_int(DS(RS)); break;
-              case 'P': (void)sl.get_int(DS(PD)); break;
-              case 'H': (void)sl.get_int(DS(HC)); break;
-              case 'Q': (void)sl.get_byte(DS(QS)); break;
-              case 'b': sl.skip_bytes(DS(BB)); break;
-              case 'q': sl.skip_bytes(DS(QQ)); break;
+              case 'P': sl.skip_int(DS(PD)); break;
+              case 'H': sl.skip_int(DS(HC)); break;
+              case 'Q': sl.skip_byte(DS(QS)); break;
+              case 'b': sl.skip_bytes(DS(BB), nullptr, false); break;
+              case 'q': sl.skip_bytes(DS(QQ), nullptr, false); break;
               default: throw std::runtime_error("CRAM: read feature " + printable(code));
             }
           }
@@ -860,6 +958,8 @@ class CRAMBatchReader {
   std::vector<Rec> pending_;
   size_t pending_pos_ = 0;
   int32_t region_ref_id_ = -2;
+  bool ahead_deferred_ = false;
+  std::future<std::vector<Job>> ahead_;  // declared last: its destructor waits for the helper thread before the file closes
 };
 
 }  // namespace exon

@@ -102,11 +102,12 @@ IDS = dict(BF=1, CF=2, RI=3, RL=4, AP=5, RG=6, RN=7, MF=8, NS=9, NP=10, TS=11, N
            QS=19, BS=20, IN=21, SC=22, RS=23, PD=24, HC=25, LEN=26)
 
 
-def write_cram(path, refs, records, per_slice=700, slices_per_container=2, seed=0, ds_patch=None, methods=(0, 1)):
+def write_cram(path, refs, records, per_slice=700, slices_per_container=2, seed=0, ds_patch=None, methods=(0, 1), qualities=False):
     """refs: [(name, length)]; records: dicts(flag, ref_id (-1 unmapped), pos (1-based, 0 none), mapq, name, rl, feats) with
     feats = [(read position, code, value)], code in I i D S N P H X.  Records are written in the given order; a run of records
     on one reference makes single-reference slices, mixed runs make multi-reference (-2) slices.  `methods`: the block
-    compression methods the external blocks draw from (0 raw, 1 gzip, 2 bzip2, 3 lzma)."""
+    compression methods the external blocks draw from (0 raw, 1 gzip, 2 bzip2, 3 lzma).  `qualities`: records carry their
+    quality scores (CF bit 0, `rl` bytes in the QS series) -- most of a real file's bytes."""
     rng = np.random.default_rng(seed)
     text = "@HD\tVN:1.6\tSO:unsorted\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in refs)
     hdr = struct.pack("<i", len(text)) + text.encode()
@@ -145,7 +146,7 @@ def write_cram(path, refs, records, per_slice=700, slices_per_container=2, seed=
             s_end = max((r["pos"] + r["span"] - 1 for r in mapped), default=0) if s_ref >= 0 else 0
             prev = s_start
             for r in sl:
-                cf = 2 if r.get("detached") else 0
+                cf = (2 if r.get("detached") else 0) | (1 if qualities else 0)
                 ext[IDS["BF"]] += itf8(r["flag"])
                 ext[IDS["CF"]] += itf8(cf)
                 if s_ref == -2:
@@ -186,6 +187,8 @@ def write_cram(path, refs, records, per_slice=700, slices_per_container=2, seed=
                     core.put(code, nb)
                 else:
                     ext[IDS["BA"]] += b"N" * r["rl"]
+                if qualities:
+                    ext[IDS["QS"]] += rng.integers(2, 42, r["rl"], dtype=np.uint8).tobytes()
                 c_bases += r["rl"]
             used = [k for k, v in ext.items() if v]
             body = itf8(s_ref) + itf8(s_start) + itf8(max(0, s_end - s_start + 1) if s_ref >= 0 else 0) + itf8(len(sl)) + ltf8(counter) + \

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Host CRAM decoder throughput on a synthetic file from tests/cram_writer.py, and the file -> K3 pipeline."""
+"""Host CRAM decoder throughput on a synthetic file from tests/cram_writer.py (gzip blocks, quality scores kept: CRAM_QUALITIES=0
+leaves them out), and the file -> K3 pipeline.  EXON_HIP_CRAM_EAGER=1 expands every block as round 2 did."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -8,7 +9,7 @@ import exon_amd
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000
 refs = [("chrA", 30_000_000), ("chrB", 15_000_000), ("chrC", 4_000_000)]
 path = "/tmp/time.cram"
-t = time.time(); recs = synthetic_records(n, refs, seed=5); write_cram(path, refs, recs, per_slice=5000, slices_per_container=2, seed=1)
+t = time.time(); recs = synthetic_records(n, refs, seed=5); write_cram(path, refs, recs, per_slice=5000, slices_per_container=2, seed=1, methods=(1,), qualities=os.environ.get("CRAM_QUALITIES", "1") != "0")
 print(f"wrote {n} records, {os.path.getsize(path) / 1e6:.1f} MB in {time.time() - t:.1f} s (python writer)")
 for rep in range(3):
     t = time.time(); scan = exon_amd.Scan(path, "cram"); rows = sum(len(b) for b in scan); dt = time.time() - t; scan.close()
