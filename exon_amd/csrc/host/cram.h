@@ -584,8 +584,10 @@ class CRAMBatchReader {
         if (ref_names[i] == cfg_.filter.region.name) region_ref_id_ = (int32_t)i;
     }
     // containers are independent: cfg.threads of them are decoded at a time (0 = the host's cores, at most 32)
+    // containers in flight: EXON_HIP_CRAM_THREADS, else the host's cores, at most 32 (more buys nothing: one thread turns the records into batches)
     const unsigned hc = std::thread::hardware_concurrency();
-    threads_ = cfg_.threads > 0 ? cfg_.threads : (int)std::min(32u, hc ? hc : 1u);
+    const char* ev = getenv("EXON_HIP_CRAM_THREADS");
+    threads_ = cfg_.threads > 0 ? cfg_.threads : ev && atoi(ev) > 0 ? atoi(ev) : (int)std::min(32u, hc ? hc : 1u);
   }
 
   CRAMBatchReader(const CRAMBatchReader&) = delete;
