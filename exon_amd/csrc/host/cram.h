@@ -1,4 +1,4 @@
-// cram.h -- CRAM 3.0 front end (host): containers -> slices -> records -> the BAM device layout (flag, mapq, reference id,
+// cram.h -- CRAM 3.0 / 3.1 front end (host): containers -> slices -> records -> the BAM device layout (flag, mapq, reference id,
 // start, end), so that the fused kernels K3 / K6 run on CRAM input as they do on BAM / SAM.
 //
 // Replaces exon-cram/src/{async_batch_stream,array_builder}.rs (columns of the schema shared by SAM, BAM and CRAM:
@@ -10,8 +10,10 @@
 //   block codecs   raw, gzip, rANS 4x8 orders 0 and 1 (what htslib writes by default and the reference's fixtures use), and
 //                  bzip2 / lzma (methods 2 / 3: htslib's use_bzip2 / use_lzma and its archive profile) through the system's
 //                  libbz2.so.1.0 / liblzma.so.5, bound at first use with dlopen (this image ships the runtime libraries but not
-//                  their headers; without them such a block is an error).  CRAM 3.1 codecs (rANS Nx16, adaptive arithmetic,
-//                  fqzcomp, name tokeniser: methods 5-8) -> error, never a mis-decode
+//                  their headers; without them such a block is an error); CRAM 3.1's rANS Nx16 (method 5: htslib's default
+//                  entropy coder since 1.22) with all of its transforms.  The other 3.1 codecs -- adaptive arithmetic coder 6,
+//                  fqzcomp 7, name tokeniser 8 -- are an error naming the codec, and only when a series this path READS sits in
+//                  such a block: htslib uses 7 and 8 for quality scores and read names, which stay closed (lazy blocks)
 //   encodings      EXTERNAL, HUFFMAN, BETA, BYTE_ARRAY_LEN, BYTE_ARRAY_STOP (GOLOMB / SUBEXP / GAMMA are CRAM 2 leftovers -> error)
 // Every length is checked against the bytes in hand; a malformed file is an error, never a read past a buffer.
 #pragma once
@@ -137,6 +139,14 @@ inline void rans_step(uint32_t& R, const RansTable& t, uint8_t* out, Cursor& c) 
   R = (uint32_t)t.F[s] * (R >> 12) + f - t.C[s];
   while (R < (1u << 23)) R = (R << 8) | c.u8();
 }
+// An rANS encoder starts every state at the lower bound of the renormalisation interval and the decoder retraces it backwards, so
+// a stream decoded to its end leaves each state AT that bound.  Checked (round 3): raw and rANS blocks carry no checksum of the
+// DECODED bytes, and this is what pins the rANS Nx16 decoder below, for which no htslib-written stream is at hand -- every rANS
+// 4x8 stream of the reference's four htslib-written fixtures passes it.
+inline void rans_4x8_done(const uint32_t* R) {
+  for (int j = 0; j < 4; ++j)
+    if (R[j] != (1u << 23)) throw std::runtime_error("CRAM: rANS 4x8 stream does not end in its initial state (corrupt block)");
+}
 inline std::vector<uint8_t> rans_4x8(const uint8_t* data, size_t size) {
   Cursor c(data, size);
   const int order = c.u8();
@@ -150,6 +160,7 @@ inline std::vector<uint8_t> rans_4x8(const uint8_t* data, size_t size) {
     uint32_t R[4];
     for (int j = 0; j < 4; ++j) R[j] = (uint32_t)c.i32le();
     for (uint32_t i = 0; i < n; ++i) rans_step(R[i & 3], *t, &out[i], c);
+    rans_4x8_done(R);
     return out;
   }
   if (order != 1) throw std::runtime_error("CRAM: rANS order " + std::to_string(order));
@@ -186,6 +197,266 @@ inline std::vector<uint8_t> rans_4x8(const uint8_t* data, size_t size) {
   for (uint32_t i = 4 * q; i < n; ++i) {  // the remainder belongs to the last state
     rans_step(R[3], tab(prev[3]), &out[i], c);
     prev[3] = out[i];
+  }
+  rans_4x8_done(R);
+  return out;
+}
+
+// ---- rANS Nx16 (CRAM 3.1, block method 5) ---------------------------------------------------------------------------------
+// The entropy coder htslib >= 1.22 writes by default ("CRAM codecs" specification section 3; noodles-cram, which the reference
+// reads CRAM through, decodes it): N = 4 or 32 interleaved states, 16-bit renormalisation above a lower bound of 2^15,
+// frequencies summing to 2^12 (order 0) or 2^shift (order 1, shift from the stream), and, in front of the entropy coder, up to
+// three byte transforms the flags byte announces: bit-packing of <= 16 distinct symbols, run-length coding with the run lengths in
+// a side stream, and N-way striping into separately coded sub-streams.  No htslib-written 3.1 file exists in this image or in the
+// reference's fixtures, so every stream is also CHECKED rather than trusted: an encoder starts each state at the lower bound,
+// so a decoder that has undone the encoding exactly ends with every state equal to it -- a stream decoded under a wrong reading
+// of the format fails that test (and the size tests) instead of yielding wrong columns.  The same test on the rANS 4x8
+// streams of the reference's own fixtures (written by htslib) holds, which pins the premise on the encoder family.
+enum : int { RANS16_ORDER = 0x01, RANS16_X32 = 0x04, RANS16_STRIPE = 0x08, RANS16_NOSZ = 0x10, RANS16_CAT = 0x20, RANS16_RLE = 0x40, RANS16_PACK = 0x80 };
+constexpr uint32_t RANS16_LOW = 1u << 15;
+constexpr uint32_t RANS16_MAX_OUT = 1u << 28;
+inline uint32_t uint7(Cursor& c) {  // big-endian base-128, high bit = "more"
+  uint32_t v = 0;
+  for (int i = 0; i < 5; ++i) {
+    const uint8_t b = c.u8();
+    v = (v << 7) | (b & 0x7Fu);
+    if (!(b & 0x80)) return v;
+  }
+  throw std::runtime_error("CRAM: rANS Nx16 length longer than 5 bytes");
+}
+inline void rans16_alphabet(Cursor& c, bool* A) {  // the run-length coded symbol list rANS 4x8 uses too
+  std::fill(A, A + 256, false);
+  int sym = c.u8(), last = sym, rle = 0;
+  do {
+    A[sym] = true;
+    if (rle) {
+      --rle;
+      if (++sym > 255) throw std::runtime_error("CRAM: rANS symbol run past 255");
+    } else {
+      sym = c.u8();
+      if (sym == last + 1) rle = c.u8();
+    }
+    last = sym;
+  } while (sym != 0);
+}
+struct Rans16Table {
+  uint16_t F[256], C[256];
+  uint8_t lut[4096];
+  bool live = false;  // false: every frequency is zero (an order-1 context the data never enters)
+  // frequencies as read -> scaled up by a power of two to 2^bits, cumulative sums, slot -> symbol table
+  void finish(int bits) {
+    uint32_t tot = 0;
+    for (int i = 0; i < 256; ++i) tot += F[i];
+    live = tot != 0;
+    if (!live) return;
+    const uint32_t full = 1u << bits;
+    int up = 0;
+    while ((tot << up) < full) ++up;
+    if ((tot << up) != full) throw std::runtime_error("CRAM: rANS Nx16 frequencies do not sum to a power of two <= 2^" + std::to_string(bits));
+    uint32_t acc = 0;
+    for (int i = 0; i < 256; ++i) {
+      const uint32_t f = (uint32_t)F[i] << up;
+      F[i] = (uint16_t)f;
+      C[i] = (uint16_t)acc;
+      memset(lut + acc, i, f);
+      acc += f;
+    }
+  }
+};
+struct Rans16States {
+  uint32_t R[32];
+  const uint8_t *p, *end;
+  int N;
+  Rans16States(Cursor& c, int n_states) : N(n_states) {
+    for (int j = 0; j < N; ++j) R[j] = (uint32_t)c.i32le();
+    p = c.p + c.o;
+    end = c.p + c.n;
+  }
+  inline uint8_t step(int j, const Rans16Table& t, int bits) {
+    uint32_t r = R[j];
+    const uint32_t f = r & ((1u << bits) - 1);
+    const uint8_t s = t.lut[f];
+    r = (uint32_t)t.F[s] * (r >> bits) + f - t.C[s];
+    if (r < RANS16_LOW) {
+      if (end - p < 2) throw std::runtime_error("CRAM: truncated data");
+      r = (r << 16) | (uint32_t)p[0] | ((uint32_t)p[1] << 8);
+      p += 2;
+    }
+    R[j] = r;
+    return s;
+  }
+  void done(Cursor& c) {  // see the note above: every state is back at the encoder's initial value
+    for (int j = 0; j < N; ++j)
+      if (R[j] != RANS16_LOW) throw std::runtime_error("CRAM: rANS Nx16 stream does not end in its initial state (corrupt, or not this codec)");
+    c.o = (size_t)(p - c.p);
+  }
+};
+inline void rans16_order0(Cursor& c, uint8_t* out, size_t n, int N) {
+  if (n == 0) return;
+  bool A[256];
+  rans16_alphabet(c, A);
+  std::unique_ptr<Rans16Table> t(new Rans16Table);
+  for (int i = 0; i < 256; ++i) {
+    const uint32_t f = A[i] ? uint7(c) : 0;
+    if (f > 4096) throw std::runtime_error("CRAM: rANS Nx16 frequency above 4096");
+    t->F[i] = (uint16_t)f;
+  }
+  t->finish(12);
+  if (!t->live) throw std::runtime_error("CRAM: rANS Nx16 table without a symbol");
+  Rans16States st(c, N);
+  for (size_t i = 0; i < n; ++i) out[i] = st.step((int)(i & (size_t)(N - 1)), *t, 12);
+  st.done(c);
+}
+inline void rans16_order1(Cursor& c, uint8_t* out, size_t n, int N) {
+  if (n == 0) return;
+  const int comp = c.u8(), bits = comp >> 4;
+  if (bits < 1 || bits > 12) throw std::runtime_error("CRAM: rANS Nx16 order-1 frequency width " + std::to_string(bits));
+  std::vector<uint8_t> plain;
+  Cursor own(nullptr, 0);
+  Cursor* tc = &c;
+  if (comp & 1) {  // the table itself went through the order-0 coder (always four states)
+    const uint32_t usz = uint7(c), csz = uint7(c);
+    if (usz > (1u << 20)) throw std::runtime_error("CRAM: rANS Nx16 order-1 table too large");
+    c.need(csz);
+    plain.resize(usz);
+    Cursor sub(c.p + c.o, csz);
+    rans16_order0(sub, plain.data(), usz, 4);
+    c.o += csz;
+    own = Cursor(plain.data(), plain.size());
+    tc = &own;
+  }
+  bool A[256];
+  rans16_alphabet(*tc, A);
+  std::vector<std::unique_ptr<Rans16Table>> tabs(256);
+  for (int i = 0; i < 256; ++i) {
+    if (!A[i]) continue;
+    tabs[(size_t)i].reset(new Rans16Table);
+    Rans16Table& t = *tabs[(size_t)i];
+    int run = 0;
+    for (int j = 0; j < 256; ++j) {
+      t.F[j] = 0;
+      if (!A[j]) continue;
+      if (run) {
+        --run;
+        continue;
+      }
+      const uint32_t f = uint7(*tc);
+      if (f > (1u << bits)) throw std::runtime_error("CRAM: rANS Nx16 frequency above its total");
+      t.F[j] = (uint16_t)f;
+      if (f == 0) run = tc->u8();
+    }
+    t.finish(bits);
+  }
+  Rans16States st(c, N);
+  auto tab = [&](uint8_t ctx) -> const Rans16Table& {
+    if (!tabs[ctx] || !tabs[ctx]->live) throw std::runtime_error("CRAM: rANS context without a table");
+    return *tabs[ctx];
+  };
+  const size_t seg = n / (size_t)N;  // state j codes out[j * seg ...), the last one also the remainder
+  uint8_t last[32] = {0};
+  for (size_t k = 0; k < seg; ++k)
+    for (int j = 0; j < N; ++j) last[j] = out[(size_t)j * seg + k] = st.step(j, tab(last[j]), bits);
+  for (size_t i = seg * (size_t)N; i < n; ++i) last[N - 1] = out[i] = st.step(N - 1, tab(last[N - 1]), bits);
+  st.done(c);
+}
+// `expect`: the decoded size the caller knows (the block's raw size; a stripe's share); read from the stream unless NOSZ is set
+inline std::vector<uint8_t> rans_nx16(const uint8_t* data, size_t size, uint32_t expect, int depth = 0) {
+  Cursor c(data, size);
+  const int flags = c.u8();
+  uint32_t n = (flags & RANS16_NOSZ) ? expect : uint7(c);
+  if (n > RANS16_MAX_OUT) throw std::runtime_error("CRAM: rANS block too large");
+  const int N = (flags & RANS16_X32) ? 32 : 4;
+  if (flags & RANS16_STRIPE) {  // byte i of the data went to sub-stream i mod X; each sub-stream is a stream of its own
+    if (depth) throw std::runtime_error("CRAM: rANS Nx16 stripes inside stripes");
+    const uint32_t X = c.u8();
+    if (X == 0) throw std::runtime_error("CRAM: rANS Nx16 with zero stripes");
+    std::vector<uint32_t> clen(X);
+    for (uint32_t j = 0; j < X; ++j) clen[j] = uint7(c);
+    std::vector<uint8_t> out(n);
+    for (uint32_t j = 0; j < X; ++j) {
+      const uint32_t share = n / X + ((n % X) > j ? 1u : 0u);
+      c.need(clen[j]);
+      const std::vector<uint8_t> sub = rans_nx16(c.p + c.o, clen[j], share, depth + 1);
+      if (sub.size() != share) throw std::runtime_error("CRAM: rANS Nx16 stripe of the wrong length");
+      c.o += clen[j];
+      for (uint32_t i = 0; i < share; ++i) out[(size_t)i * X + j] = sub[i];
+    }
+    return out;
+  }
+  uint8_t pack_map[16] = {0};
+  uint32_t pack_nsym = 0, pack_out = 0;
+  if (flags & RANS16_PACK) {
+    pack_nsym = c.u8();
+    if (pack_nsym > 16) throw std::runtime_error("CRAM: rANS Nx16 packs more than 16 symbols");
+    for (uint32_t i = 0; i < pack_nsym; ++i) pack_map[i] = c.u8();
+    pack_out = n;
+    n = uint7(c);
+    const uint32_t per = pack_nsym <= 1 ? 0 : pack_nsym <= 2 ? 8 : pack_nsym <= 4 ? 4 : 2;  // symbols per packed byte
+    if (pack_out && (pack_nsym == 0 || (per && (uint64_t)n * per < pack_out))) throw std::runtime_error("CRAM: rANS Nx16 packed data too short");
+    if (n > RANS16_MAX_OUT) throw std::runtime_error("CRAM: rANS block too large");
+  }
+  std::vector<uint8_t> rle_meta;
+  uint32_t rle_out = 0;
+  if (flags & RANS16_RLE) {
+    const uint32_t m2 = uint7(c);
+    rle_out = n;
+    n = uint7(c);
+    if (n > RANS16_MAX_OUT || m2 / 2 > RANS16_MAX_OUT) throw std::runtime_error("CRAM: rANS block too large");
+    if (m2 & 1) {  // run lengths stored as they are
+      c.need(m2 / 2);
+      rle_meta.assign(c.p + c.o, c.p + c.o + m2 / 2);
+      c.o += m2 / 2;
+    } else {
+      const uint32_t csz = uint7(c);
+      c.need(csz);
+      rle_meta.resize(m2 / 2);
+      Cursor sub(c.p + c.o, csz);
+      rans16_order0(sub, rle_meta.data(), rle_meta.size(), N);
+      c.o += csz;
+    }
+  }
+  std::vector<uint8_t> out(n);
+  if (flags & RANS16_CAT) {
+    c.need(n);
+    if (n) memcpy(out.data(), c.p + c.o, n);
+    c.o += n;
+  } else if (flags & RANS16_ORDER) {
+    rans16_order1(c, out.data(), n, N);
+  } else {
+    rans16_order0(c, out.data(), n, N);
+  }
+  if (flags & RANS16_RLE) {  // literals -> runs: a symbol on the list is followed (in the side stream) by how often it repeats
+    Cursor m(rle_meta.data(), rle_meta.size());
+    bool runs[256] = {false};
+    uint32_t nsym = rle_out ? m.u8() : 0;
+    if (rle_out && nsym == 0) nsym = 256;
+    for (uint32_t i = 0; i < nsym; ++i) runs[m.u8()] = true;
+    std::vector<uint8_t> wide(rle_out);
+    size_t w = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint8_t b = out[i];
+      const size_t reps = runs[b] ? (size_t)uint7(m) + 1 : 1;
+      if (reps > wide.size() - w) throw std::runtime_error("CRAM: rANS Nx16 runs exceed the block");
+      memset(wide.data() + w, b, reps);
+      w += reps;
+    }
+    if (w != wide.size()) throw std::runtime_error("CRAM: rANS Nx16 runs fall short of the block");
+    out.swap(wide);
+  }
+  if (flags & RANS16_PACK) {
+    std::vector<uint8_t> wide(pack_out);
+    if (pack_nsym <= 1) {
+      std::fill(wide.begin(), wide.end(), pack_map[0]);
+    } else {
+      const int width = pack_nsym <= 2 ? 1 : pack_nsym <= 4 ? 2 : 4, per = 8 / width;
+      const uint32_t mask = (1u << width) - 1;
+      for (size_t i = 0; i < wide.size(); ++i) {  // low bits first
+        const uint32_t v = (out[i / (size_t)per] >> ((i % (size_t)per) * (size_t)width)) & mask;
+        if (v >= pack_nsym) throw std::runtime_error("CRAM: rANS Nx16 packed value without a symbol");
+        wide[i] = pack_map[v];
+      }
+    }
+    out.swap(wide);
   }
   return out;
 }
@@ -258,8 +529,16 @@ inline void Block::expand() {
     if (rc != 0 /* LZMA_OK */ || out_pos != rsz) throw std::runtime_error("CRAM: corrupt lzma block");
   } else if (method == 4) {
     b.data = rans_4x8(src, csz);
+  } else if (method == 5) {
+    b.data = rans_nx16(src, csz, rsz);
   } else {
-    throw std::runtime_error("CRAM: block compression method " + std::to_string(method) + " is not supported");
+    // 6 adaptive arithmetic coder, 7 fqzcomp (quality scores), 8 name tokeniser: reached only when a data series this path
+    // READS lives in such a block -- the blocks of discarded series (names, quality scores: where htslib's 3.1 profiles put
+    // 7 and 8) are never expanded
+    static const char* const names[] = {"adaptive arithmetic coder", "fqzcomp", "name tokeniser"};
+    throw std::runtime_error("CRAM: block compression method " + std::to_string(method) +
+                             (method >= 6 && method <= 8 ? std::string(" (") + names[method - 6] + ")" : std::string()) +
+                             " is not supported (raw, gzip, bzip2, lzma, rANS 4x8 and rANS Nx16 are)");
   }
   if (b.data.size() != rsz) throw std::runtime_error("CRAM: block size mismatch");
   ready = true;
@@ -278,9 +557,7 @@ inline Block read_block(Cursor& c, bool lazy = false) {
   b.ready = false;
   // a corrupt size must not turn into a huge allocation: DEFLATE expands at most ~1032x, rANS blocks are capped outright
   if (rsz > (1u << 28) || (b.method == 1 && (uint64_t)rsz > (uint64_t)csz * 1032u + 1024u)) throw std::runtime_error("CRAM: block too large");
-  if (b.method < 0 || b.method > 4)
-    throw std::runtime_error("CRAM: block compression method " + std::to_string(b.method) +
-                             " is not supported (raw, gzip, bzip2, lzma, rANS 4x8 are; 5-8 are the CRAM 3.1 codecs)");
+  if (b.method < 0 || b.method > 8) throw std::runtime_error("CRAM: block compression method " + std::to_string(b.method) + " does not exist");
   // CRC-32 over the block's header and payload (CRAM 3.0 section 8): a raw or rANS block has no other integrity check, and
   // a flipped byte in an external block would otherwise become silently wrong flag / position columns (noodles-cram
   // reports a checksum mismatch).  Checked for every block, expanded or not.
@@ -546,7 +823,8 @@ class CRAMBatchReader {
     size_ = (size_t)st.st_size;
     const std::vector<uint8_t> def = read_at(0, 26);
     if (memcmp(def.data(), "CRAM", 4) != 0) throw std::runtime_error("not a CRAM file: " + path);
-    if (def[4] != 3 || def[5] != 0) throw std::runtime_error("CRAM " + std::to_string(def[4]) + "." + std::to_string(def[5]) + " is not supported (3.0 is)");
+    // 3.1 = 3.0 + four more block compression methods (no change to containers, slices, encodings or ITF8 integers)
+    if (def[4] != 3 || def[5] > 1) throw std::runtime_error("CRAM " + std::to_string(def[4]) + "." + std::to_string(def[5]) + " is not supported (3.0 and 3.1 are)");
     off_ = 26;
     // the first container holds the SAM header
     ContainerHeader h = read_container_header();

@@ -475,6 +475,201 @@ def _rans_4x8(b):
     return bytes(out)
 
 
+# ---- rANS Nx16 (CRAM 3.1 block method 5; "CRAM codecs" specification, section 3) ------------------------------------------
+# Restated from the published format (noodles-cram, through which exon-cram/src/async_batch_stream.rs reads CRAM, is not in
+# the tree): flags byte -- 0x01 order-1, 0x04 32 states instead of 4, 0x08 striped, 0x10 size not stored, 0x20 stored as is,
+# 0x40 run-length coded, 0x80 bit-packed -- then sizes as big-endian base-128 integers.  PARITY UNPINNED against htslib: no CRAM 3.1
+# file exists here; the decoder is pinned on streams of the test-side encoder (tests/cram_writer.py), and both it and the
+# product insist that every rANS state ends at the encoder's initial value 2^15, which a misread format does not survive.
+class _Bytes:
+    def __init__(self, b, o=0):
+        self.b, self.o = b, o
+
+    def u8(self):
+        v = self.b[self.o]
+        self.o += 1
+        return v
+
+    def uint7(self):
+        v = 0
+        while True:
+            c = self.u8()
+            v = (v << 7) | (c & 0x7F)
+            if not c & 0x80:
+                return v
+
+    def take(self, n):
+        if n > len(self.b) - self.o:
+            raise ValueError("rANS Nx16: truncated")
+        v = self.b[self.o:self.o + n]
+        self.o += n
+        return v
+
+    def alphabet(self):
+        syms, sym, run = [], self.u8(), 0
+        last = sym
+        while True:
+            syms.append(sym)
+            if run:
+                run -= 1
+                sym += 1
+            else:
+                sym = self.u8()
+                if sym == last + 1:
+                    run = self.u8()
+            last = sym
+            if sym == 0:
+                return syms
+
+
+def _nx16_table(freqs, bits):
+    """{symbol: f} -> (F, C, slot -> symbol) with the frequencies scaled up to 2^bits; None for an all-zero row"""
+    tot = sum(freqs.values())
+    if tot == 0:
+        return None
+    up = 0
+    while (tot << up) < (1 << bits):
+        up += 1
+    if (tot << up) != (1 << bits):
+        raise ValueError("rANS Nx16: frequencies do not sum to a power of two")
+    F, C, lut, acc = {}, {}, [], 0
+    for sy in sorted(freqs):
+        F[sy], C[sy] = freqs[sy] << up, acc
+        lut += [sy] * F[sy]
+        acc += F[sy]
+    return F, C, lut
+
+
+class _Nx16States:
+    def __init__(self, src, n_states):
+        self.src = src
+        self.R = list(struct.unpack_from(f"<{n_states}I", src.b, src.o))
+        src.o += 4 * n_states
+
+    def symbol(self, j, table, bits):
+        F, C, lut = table
+        r = self.R[j]
+        slot = r & ((1 << bits) - 1)
+        sy = lut[slot]
+        r = F[sy] * (r >> bits) + slot - C[sy]
+        if r < (1 << 15):
+            lo, hi = self.src.take(2)
+            r = (r << 16) | lo | (hi << 8)
+        self.R[j] = r
+        return sy
+
+    def finish(self):
+        if any(r != (1 << 15) for r in self.R):
+            raise ValueError("rANS Nx16: a state does not end at 2^15")
+
+
+def _nx16_order0(src, n, n_states):
+    if n == 0:
+        return b""
+    syms = src.alphabet()
+    table = _nx16_table({sy: src.uint7() for sy in sorted(set(syms))}, 12)
+    st = _Nx16States(src, n_states)
+    out = bytes(st.symbol(i % n_states, table, 12) for i in range(n))
+    st.finish()
+    return out
+
+
+def _nx16_order1(src, n, n_states):
+    if n == 0:
+        return b""
+    comp = src.u8()
+    bits, tsrc = comp >> 4, src
+    if comp & 1:  # the table itself is order-0 coded, always with four states
+        usz, csz = src.uint7(), src.uint7()
+        tsrc = _Bytes(_nx16_order0(_Bytes(src.take(csz)), usz, 4))
+    syms = sorted(set(tsrc.alphabet()))
+    tables = {}
+    for ctx in syms:
+        row, run = {}, 0
+        for sy in syms:
+            if run:
+                run -= 1
+                row[sy] = 0
+                continue
+            row[sy] = tsrc.uint7()
+            if row[sy] == 0:
+                run = tsrc.u8()
+        tables[ctx] = _nx16_table(row, bits)
+    st = _Nx16States(src, n_states)
+    seg = n // n_states
+    out = bytearray(n)
+    for j in range(n_states):  # a state never reads another one's symbols; only the 16-bit words interleave
+        pass
+    prev = [0] * n_states
+    for k in range(seg):
+        for j in range(n_states):
+            prev[j] = out[j * seg + k] = st.symbol(j, tables[prev[j]], bits)
+    for i in range(seg * n_states, n):
+        prev[-1] = out[i] = st.symbol(n_states - 1, tables[prev[-1]], bits)
+    st.finish()
+    return bytes(out)
+
+
+def _rans_nx16(b, expect, nested=False):
+    src = _Bytes(bytes(b))
+    flags = src.u8()
+    n = expect if flags & 0x10 else src.uint7()
+    n_states = 32 if flags & 0x04 else 4
+    if flags & 0x08:
+        assert not nested, "stripes inside stripes"
+        x = src.u8()
+        clen = [src.uint7() for _ in range(x)]
+        out = bytearray(n)
+        for j in range(x):
+            share = n // x + (1 if n % x > j else 0)
+            part = _rans_nx16(src.take(clen[j]), share, nested=True)
+            assert len(part) == share
+            out[j::x] = part
+        return bytes(out)
+    pack = None
+    if flags & 0x80:
+        nsym = src.u8()
+        pack = (bytes(src.u8() for _ in range(nsym)), n)
+        n = src.uint7()
+    rle = None
+    if flags & 0x40:
+        m2, wide = src.uint7(), n
+        n = src.uint7()
+        if m2 & 1:
+            meta = src.take(m2 // 2)
+        else:
+            csz = src.uint7()
+            meta = _nx16_order0(_Bytes(src.take(csz)), m2 // 2, n_states)
+        rle = (meta, wide)
+    if flags & 0x20:
+        data = src.take(n)
+    elif flags & 0x01:
+        data = _nx16_order1(src, n, n_states)
+    else:
+        data = _nx16_order0(src, n, n_states)
+    if rle:
+        meta, wide = rle
+        m = _Bytes(meta)
+        out = bytearray()
+        if wide:
+            k = m.u8() or 256
+            runs = set(m.u8() for _ in range(k))
+            for c in data:
+                out += bytes([c]) * ((m.uint7() + 1) if c in runs else 1)
+        if len(out) != wide:
+            raise ValueError("rANS Nx16: runs do not fill the block")
+        data = bytes(out)
+    if pack:
+        pmap, wide = pack
+        if len(pmap) <= 1:
+            data = bytes(pmap[:1]) * wide if wide else b""
+        else:
+            width = 1 if len(pmap) <= 2 else 2 if len(pmap) <= 4 else 4
+            per, mask = 8 // width, (1 << width) - 1
+            data = bytes(pmap[(data[i // per] >> ((i % per) * width)) & mask] for i in range(wide))
+    return data
+
+
 def _cram_block(b, o):
     method, ctype = b[o], b[o + 1]
     o += 2
@@ -492,6 +687,10 @@ def _cram_block(b, o):
         raw = lzma.decompress(raw)
     elif method == 4:
         raw = _rans_4x8(raw)
+    elif method == 5:
+        raw = _rans_nx16(raw, rsz)
+    elif method in (6, 7, 8):  # arithmetic coder / fqzcomp / name tokeniser: an error only if a series of the block is read
+        return dict(type=ctype, id=cid, data=None, method=method), o + csz + 4
     elif method != 0:
         raise ValueError(f"CRAM block compression method {method} is not supported")
     assert len(raw) == rsz
@@ -555,6 +754,8 @@ class _Slice:
     def int(self, enc):
         k = enc[0]
         if k == "external":
+            if self.ext[enc[1]] is None:
+                raise ValueError("an integer data series lives in a block whose compression method is not supported")
             v, self.pos[enc[1]] = _itf8s(self.ext[enc[1]], self.pos[enc[1]])
             return v
         if k == "huffman":
@@ -578,8 +779,12 @@ class _Slice:
             return self.core.get(enc[2]) - enc[1]
         raise ValueError(f"integer through {k}")
 
+    # a block coded with fqzcomp / the name tokeniser / the arithmetic coder has data None (_cram_block): the byte series in it
+    # (quality scores, names -- where CRAM 3.1 writers use those codecs) read as None / 0; an integer series in one is an error
     def byte(self, enc):
         if enc[0] == "external":
+            if self.ext[enc[1]] is None:
+                return 0
             v = self.ext[enc[1]][self.pos[enc[1]]]
             self.pos[enc[1]] += 1
             return v
@@ -588,6 +793,8 @@ class _Slice:
     def bytes(self, enc):
         if enc[0] == "byte_array_stop":
             d, p = self.ext[enc[2]], self.pos[enc[2]]
+            if d is None:
+                return None
             e = d.index(bytes([enc[1]]), p)
             self.pos[enc[2]] = e + 1
             return d[p:e]
@@ -596,6 +803,8 @@ class _Slice:
             if enc[2][0] == "external":
                 p = self.pos[enc[2][1]]
                 self.pos[enc[2][1]] = p + n
+                if self.ext[enc[2][1]] is None:
+                    return None
                 return self.ext[enc[2][1]][p:p + n]
             return bytes(self.byte(enc[2]) for _ in range(n))
         raise ValueError(f"byte array through {enc[0]}")
@@ -773,7 +982,7 @@ def decode_cram(path):
                         for _ in range(rl):
                             sl.byte(ds["QS"])
                 start = ap if ap >= 1 else None
-                recs.append(dict(name=name.decode(), flag=bf, ref_id=ri if ri >= 0 else None, start=start,
+                recs.append(dict(name=None if name is None else name.decode(), flag=bf, ref_id=ri if ri >= 0 else None, start=start,
                                  end=(start + (0 if bf & 4 else span) - 1) if start is not None else None,
                                  mapq=None if mapq == 255 else mapq, cigar=cigar))
         o = end

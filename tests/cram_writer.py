@@ -36,9 +36,17 @@ def ltf8(v):
     raise ValueError(v)
 
 
-def block(ctype, cid, data, method=0):
-    """method: 0 raw, 1 gzip, 2 bzip2, 3 lzma (an .xz stream) -- CRAM 3.0 section 8.1"""
-    comp = {0: lambda d: d, 1: lambda d: gzip.compress(d, mtime=0), 2: bz2.compress, 3: lzma.compress}[method](data)
+def block(ctype, cid, data, method=0, nx16=None, payload=None):
+    """method: 0 raw, 1 gzip, 2 bzip2, 3 lzma (an .xz stream) -- CRAM 3.0 section 8.1; 5 rANS Nx16 (CRAM 3.1; `nx16` = keyword
+    arguments of rans_nx16_writer.encode: flags ...).  `payload`: bytes to store as they are under `method` (a block coded with
+    a method nobody here can produce -- fqzcomp, name tokeniser: a reader that needs no series of it must never open it)"""
+    if payload is not None:
+        comp = payload
+    elif method == 5:
+        import rans_nx16_writer
+        comp = rans_nx16_writer.encode(data, **(nx16 or {}))
+    else:
+        comp = {0: lambda d: d, 1: lambda d: gzip.compress(d, mtime=0), 2: bz2.compress, 3: lzma.compress}[method](data)
     body = bytes([method, ctype]) + itf8(cid) + itf8(len(comp)) + itf8(len(data)) + comp
     return body + struct.pack("<I", zlib.crc32(body) & 0xFFFFFFFF)
 
@@ -102,16 +110,34 @@ IDS = dict(BF=1, CF=2, RI=3, RL=4, AP=5, RG=6, RN=7, MF=8, NS=9, NP=10, TS=11, N
            QS=19, BS=20, IN=21, SC=22, RS=23, PD=24, HC=25, LEN=26)
 
 
-def write_cram(path, refs, records, per_slice=700, slices_per_container=2, seed=0, ds_patch=None, methods=(0, 1), qualities=False):
+NX16_FLAGS = (0x00, 0x01, 0x04, 0x05, 0x40, 0x41, 0x80, 0x81, 0xC0, 0xC1, 0xC5, 0x08, 0x09, 0x0C, 0x20)  # what a 3.1 writer may pick per block
+
+
+def write_cram(path, refs, records, per_slice=700, slices_per_container=2, seed=0, ds_patch=None, methods=(0, 1), qualities=False,
+               opaque=None):
     """refs: [(name, length)]; records: dicts(flag, ref_id (-1 unmapped), pos (1-based, 0 none), mapq, name, rl, feats) with
     feats = [(read position, code, value)], code in I i D S N P H X.  Records are written in the given order; a run of records
     on one reference makes single-reference slices, mixed runs make multi-reference (-2) slices.  `methods`: the block
     compression methods the external blocks draw from (0 raw, 1 gzip, 2 bzip2, 3 lzma).  `qualities`: records carry their
-    quality scores (CF bit 0, `rl` bytes in the QS series) -- most of a real file's bytes."""
+    quality scores (CF bit 0, `rl` bytes in the QS series) -- most of a real file's bytes.  Method 5 (rANS Nx16) makes the file
+    CRAM 3.1, each such block with flags drawn from NX16_FLAGS.  `opaque`: {data series: method} -- the series' block is
+    written under that method number with a payload no decoder understands (stands for fqzcomp / name-tokeniser blocks)."""
+    opaque = {IDS[k]: m for k, m in (opaque or {}).items()}
+    v31 = any(m >= 5 for m in methods) or bool(opaque)
+
+    def ext_block(k, data):
+        if k in opaque:
+            return block(4, k, data, opaque[k], payload=bytes(reversed(data)) + b"?")
+        m = methods[int(rng.integers(0, len(methods)))]
+        if m == 5:
+            nx16 = dict(flags=NX16_FLAGS[int(rng.integers(0, len(NX16_FLAGS)))], o1_bits=(10, 12)[int(rng.integers(0, 2))],
+                        code_table=bool(rng.integers(0, 2)), code_rle_meta=bool(rng.integers(0, 2)))
+            return block(4, k, data, 5, nx16=nx16)
+        return block(4, k, data, m)
     rng = np.random.default_rng(seed)
     text = "@HD\tVN:1.6\tSO:unsorted\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in refs)
     hdr = struct.pack("<i", len(text)) + text.encode()
-    out = [b"CRAM\x03\x00" + b"exon-hip-test-file\0\0", container(0, 0, 0, 0, 0, 0, [block(0, 0, hdr, 1)], [0])]
+    out = [(b"CRAM\x03\x01" if v31 else b"CRAM\x03\x00") + b"exon-hip-test-file\0\0", container(0, 0, 0, 0, 0, 0, [block(0, 0, hdr, 1)], [0])]
     mq = canonical(MQ_SYMS, MQ_LENS)
     counter = 0
     groups = [records[i:i + per_slice] for i in range(0, len(records), per_slice)]
@@ -195,7 +221,7 @@ def write_cram(path, refs, records, per_slice=700, slices_per_container=2, seed=
                 itf8(1 + len(used)) + itf8(1 + len(used)) + itf8(0) + b"".join(itf8(k) for k in used) + itf8(-1) + bytes(16)
             sh = block(2, 0, body)
             landmarks.append(off)
-            sblocks = [sh, block(5, 0, core.bytes())] + [block(4, k, bytes(ext[k]), methods[int(rng.integers(0, len(methods)))]) for k in used]
+            sblocks = [sh, block(5, 0, core.bytes(), 5, nx16=dict(flags=int(rng.integers(0, 2)))) if 5 in methods else block(5, 0, core.bytes())] + [ext_block(k, bytes(ext[k])) for k in used]
             blocks += sblocks
             off += sum(len(x) for x in sblocks)
             counter += len(sl)
