@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -874,21 +875,24 @@ class CRAMBatchReader {
 
   bool read_batch(struct ArrowArray* out) {
     BAMArrayBuilder b(&ref_names);
+    b.reserve((size_t)std::max<int64_t>(0, std::min<int64_t>(cfg_.batch_size, 1 << 20)));
     while ((int64_t)b.len() < cfg_.batch_size) {
-      if (pending_pos_ >= pending_.size()) {
-        pending_.clear();
-        pending_pos_ = 0;
+      if (pending_.empty()) {
         if (!next_container()) break;
         continue;
       }
-      const Rec& r = pending_[pending_pos_++];
-      if (cfg_.filter.active) {  // the range hit of the indexed BAM stream (cram_region_filter has the same meaning)
-        if (r.ref_id < 0 || r.pos0 < 0) continue;
-        const int64_t s = r.pos0 + 1, e = s + r.ref_len - 1;
-        const Region& rg = cfg_.filter.region;
-        if (!(r.ref_id == region_ref_id_ && s <= rg.end && rg.start <= e)) continue;
+      const Cols& k = pending_.front();
+      // the decode threads have already turned the records into columns (and applied a pushed-down region): this thread,
+      // the only serial one, moves blocks of them
+      const size_t n = std::min(k.size() - pending_pos_, (size_t)(cfg_.batch_size - (int64_t)b.len()));
+      const size_t o = pending_pos_;
+      b.append_columns(k.flag.data() + o, k.mapq.data() + o, k.mapq_ok.data() + o, k.ref.data() + o, k.ref_ok.data() + o, k.start.data() + o,
+                       k.end.data() + o, k.pos_ok.data() + o, n);
+      pending_pos_ += n;
+      if (pending_pos_ >= k.size()) {
+        pending_.pop_front();
+        pending_pos_ = 0;
       }
-      b.append(r.flag, r.ref_id, r.pos0, r.mapq, r.ref_len);
     }
     if (b.is_empty()) return false;
     b.try_into_record_batch(out);
@@ -913,6 +917,28 @@ class CRAMBatchReader {
     int32_t flag, ref_id;
     int64_t pos0, ref_len;
     int mapq;
+  };
+  // the records of one container as the columns BAMArrayBuilder keeps (values + one validity byte per row; NULL placeholders as
+  // BAMArrayBuilder::append writes them), built by the thread that decoded the container
+  struct Cols {
+    std::vector<int32_t> flag, ref;
+    std::vector<uint8_t> mapq, mapq_ok, ref_ok, pos_ok;
+    std::vector<int64_t> start, end;
+    size_t size() const { return flag.size(); }
+    void reserve(size_t n) {
+      flag.reserve(n), ref.reserve(n), mapq.reserve(n), mapq_ok.reserve(n), ref_ok.reserve(n), pos_ok.reserve(n), start.reserve(n), end.reserve(n);
+    }
+    void push(const Rec& r) {
+      flag.push_back(r.flag);
+      mapq.push_back((uint8_t)r.mapq);  // 255 = missing (its own placeholder)
+      mapq_ok.push_back(r.mapq != 255);
+      ref.push_back(r.ref_id < 0 ? -1 : r.ref_id);
+      ref_ok.push_back(r.ref_id >= 0);
+      const bool has = r.pos0 >= 0;
+      start.push_back(has ? r.pos0 + 1 : 0);                // 1-based
+      end.push_back(has ? r.pos0 + 1 + r.ref_len - 1 : 0);  // alignment end = start + reference span - 1
+      pos_ok.push_back(has);
+    }
   };
   struct ContainerHeader {
     size_t length = 0;
@@ -976,7 +1002,7 @@ class CRAMBatchReader {
   // single-threaded and had the decoder threads idle for half of the time).
   struct Job {
     size_t off, length;
-    std::vector<Rec> recs;
+    Cols cols;
     std::vector<std::string> names;
     std::string error;
   };
@@ -1010,7 +1036,19 @@ class CRAMBatchReader {
       try {
         const std::vector<uint8_t> buf = read_at(j.off, j.length);
         cram::Cursor c(buf.data(), buf.size());
-        decode_container(c, &j.recs, want_names ? &j.names : nullptr);
+        std::vector<Rec> recs;
+        decode_container(c, &recs, want_names ? &j.names : nullptr);
+        j.cols.reserve(recs.size());
+        const bool filter = cfg_.filter.active;
+        const Region& rg = cfg_.filter.region;
+        for (const Rec& r : recs) {
+          if (filter) {  // the range hit of the indexed BAM stream (cram_region_filter has the same meaning)
+            if (r.ref_id < 0 || r.pos0 < 0) continue;
+            const int64_t s = r.pos0 + 1, e = s + r.ref_len - 1;
+            if (!(r.ref_id == region_ref_id_ && s <= rg.end && rg.start <= e)) continue;
+          }
+          j.cols.push(r);
+        }
       } catch (const std::exception& e) {
         j.error = e.what();
         if (j.error.empty()) j.error = "CRAM: decode error";
@@ -1047,7 +1085,7 @@ class CRAMBatchReader {
     start_ahead();  // the next group decodes while this one is consumed
     for (auto& j : jobs) {
       if (!j.error.empty()) throw std::runtime_error(j.error);
-      pending_.insert(pending_.end(), j.recs.begin(), j.recs.end());
+      if (j.cols.size()) pending_.push_back(std::move(j.cols));
       if (keep_names) names.insert(names.end(), j.names.begin(), j.names.end());
     }
     return true;
@@ -1245,7 +1283,7 @@ class CRAMBatchReader {
   } fdh_;
   int fd_ = -1;
   size_t size_ = 0, off_ = 0;
-  std::vector<Rec> pending_;
+  std::deque<Cols> pending_;  // decoded containers, in file order; pending_pos_ = rows of the front one already handed out
   size_t pending_pos_ = 0;
   int32_t region_ref_id_ = -2;
   bool ahead_deferred_ = false;

@@ -9,7 +9,13 @@ import exon_amd
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000
 refs = [("chrA", 30_000_000), ("chrB", 15_000_000), ("chrC", 4_000_000)]
 path = "/tmp/time.cram"
-t = time.time(); recs = synthetic_records(n, refs, seed=5); write_cram(path, refs, recs, per_slice=5000, slices_per_container=2, seed=1, methods=(1,), qualities=os.environ.get("CRAM_QUALITIES", "1") != "0")
+reuse = os.environ.get("CRAM_REUSE") == "1" and os.path.exists(path)  # A/B runs over one file: skip the (slow) python writer
+rep = int(os.environ.get("CRAM_REPEAT", "1"))
+if reuse:
+    n *= rep
+    rep = 1
+    os.environ["CRAM_REPEAT"] = "1"
+t = time.time(); recs = [] if reuse else synthetic_records(n, refs, seed=5); reuse or write_cram(path, refs, recs, per_slice=5000, slices_per_container=2, seed=1, methods=(1,), qualities=os.environ.get("CRAM_QUALITIES", "1") != "0")
 print(f"wrote {n} records, {os.path.getsize(path) / 1e6:.1f} MB in {time.time() - t:.1f} s (python writer)")
 rep = int(os.environ.get("CRAM_REPEAT", "1"))
 if rep > 1:  # the python writer is slow: repeat the data containers (each is self-contained) to get a file worth timing
