@@ -365,6 +365,9 @@ inline std::vector<uint8_t> rans_nx16(const uint8_t* data, size_t size, uint32_t
   Cursor c(data, size);
   const int flags = c.u8();
   uint32_t n = (flags & RANS16_NOSZ) ? expect : uint7(c);
+  // the stream's own size must be the one the block header (or the stripe's share) announced: checked BEFORE anything is
+  // allocated for it (run lengths and packing expand without bound, so no ratio to the compressed size can be asked for)
+  if (n != expect) throw std::runtime_error("CRAM: rANS Nx16 stream of " + std::to_string(n) + " bytes in a block of " + std::to_string(expect));
   if (n > RANS16_MAX_OUT) throw std::runtime_error("CRAM: rANS block too large");
   const int N = (flags & RANS16_X32) ? 32 : 4;
   if (flags & RANS16_STRIPE) {  // byte i of the data went to sub-stream i mod X; each sub-stream is a stream of its own
