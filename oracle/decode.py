@@ -8,6 +8,10 @@ oracle can be pinned on the reference's own fixture files:
   BAM   exon-bam/src/array_builder.rs:102-218 over noodles-bam 0.72 records (BAM spec 4.2);
         alignment_end = start + sum(len of M/D/N/=/X ops) - 1 (exon-bam/src/indexed_async_batch_stream.rs:45-64)
   FASTQ exon-fastq/src/array_builder.rs:68-102    FASTA exon-fasta/src/array_builder.rs:114-132
+  CRAM  exon-cram/src/{async_batch_stream,array_builder}.rs over noodles-cram (not in tree): CRAM 3.0 restated from the
+        specification and pinned on the reference's slt first rows + container record counts (tests/test_cram.py); the
+        CRAM 3.1 rANS Nx16 block codec (`_rans_nx16`) is PARITY UNPINNED -- no 3.1 stream exists in the reference's
+        fixtures or in this image; see the note above it and DESIGN.md section 7j
 The product has its own C++ decoders (exon_amd/csrc/host); nothing here is shipped.
 """
 import gzip
