@@ -1188,7 +1188,8 @@ class CRAMBatchReader {
       SliceData sl;
       for (uint32_t i = 0; i < s_nblocks; ++i) {
         static const bool eager = getenv("EXON_HIP_CRAM_EAGER") != nullptr;  // A/B: expand every block, as round 2 did
-        Block b = read_block(c, /*lazy=*/!eager);  // external blocks are expanded when a series first reads them
+        Block b = read_block(c, /*lazy=*/true);  // external blocks are expanded when a series first reads them
+        if (eager && b.method <= 5) b.expand();  // (a block in a codec this reader lacks stays closed either way)
         if (b.type == 5) {
           b.expand();
           sl.core.swap(b.data);
