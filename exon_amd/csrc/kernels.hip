@@ -2383,6 +2383,11 @@ __global__ __launch_bounds__(256) void gen_c5_kernel(uint64_t seed, int64_t lo, 
 }
 
 static unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+// One dispatch holds fewer than 2^32 work-items (a larger grid is cut off without an error: 4.6e9 rows came back as the
+// 3e8 rows of the remainder, found by tests/test_gpu_fullsize.py's > 2^32-row case).  The one-thread-per-row generators
+// therefore write tables in pieces of 2^30 rows; a piece starts on a multiple of 64 rows, so its validity bits start on a
+// byte and the kernels' wave-wide validity stores stay aligned.
+constexpr int64_t GEN_PIECE = int64_t(1) << 30;
 
 hipError_t launch_gen_c2(hipStream_t s, uint64_t seed, int64_t n_total, int64_t lo, int64_t hi, int32_t* chrom,
                          int64_t* pos) {
@@ -2397,7 +2402,10 @@ hipError_t launch_gen_c2(hipStream_t s, uint64_t seed, int64_t n_total, int64_t 
     t.len[c] = GRCH37_LEN[c];
   }
   t.starts[24] = n_total;
-  hipLaunchKernelGGL(gen_c2_kernel, dim3(blocks_for(hi - lo)), dim3(256), 0, s, seed, lo, hi, t, chrom, pos);
+  for (int64_t o = 0; o < hi - lo; o += GEN_PIECE) {
+    const int64_t m = std::min(GEN_PIECE, hi - lo - o);
+    hipLaunchKernelGGL(gen_c2_kernel, dim3(blocks_for(m)), dim3(256), 0, s, seed, lo + o, lo + o + m, t, chrom + o, pos + o);
+  }
   return hipGetLastError();
 }
 
@@ -2428,24 +2436,33 @@ hipError_t launch_gen_c3(hipStream_t s, uint64_t seed, int64_t lo, int64_t hi, i
                          uint8_t* mapq_valid, int32_t* ref_id, uint8_t* ref_valid) {
   if (hi <= lo) return hipSuccess;
   const C3Table t = make_c3_table();
-  hipLaunchKernelGGL(gen_c3_kernel, dim3(blocks_for(hi - lo)), dim3(256), 0, s, seed, lo, hi, t, flag, mapq,
-                     mapq_valid, ref_id, ref_valid);
+  for (int64_t o = 0; o < hi - lo; o += GEN_PIECE) {
+    const int64_t m = std::min(GEN_PIECE, hi - lo - o);
+    hipLaunchKernelGGL(gen_c3_kernel, dim3(blocks_for(m)), dim3(256), 0, s, seed, lo + o, lo + o + m, t, flag + o, mapq + o,
+                       mapq_valid + o / 8, ref_id + o, ref_valid + o / 8);
+  }
   return hipGetLastError();
 }
 
 hipError_t launch_gen_c6(hipStream_t s, uint64_t seed, int64_t lo, int64_t hi, int32_t* ref_id, uint8_t* ref_valid,
                          int64_t* start, int64_t* end, uint8_t* pos_valid) {
   if (hi <= lo) return hipSuccess;
-  hipLaunchKernelGGL(gen_c6_kernel, dim3(blocks_for(hi - lo)), dim3(256), 0, s, seed, lo, hi, make_c3_table(), ref_id, ref_valid,
-                     start, end, pos_valid);
+  for (int64_t o = 0; o < hi - lo; o += GEN_PIECE) {
+    const int64_t m = std::min(GEN_PIECE, hi - lo - o);
+    hipLaunchKernelGGL(gen_c6_kernel, dim3(blocks_for(m)), dim3(256), 0, s, seed, lo + o, lo + o + m, make_c3_table(), ref_id + o,
+                       ref_valid + o / 8, start + o, end + o, pos_valid + o / 8);
+  }
   return hipGetLastError();
 }
 
 hipError_t launch_gen_c4(hipStream_t s, uint64_t seed, int64_t lo, int64_t hi, float* af, uint8_t* af_valid,
                          float* qual, uint8_t* qual_valid, int32_t* filter_id) {
   if (hi <= lo) return hipSuccess;
-  hipLaunchKernelGGL(gen_c4_kernel, dim3(blocks_for(hi - lo)), dim3(256), 0, s, seed, lo, hi, pct_thr(85),
-                     pct_thr(90), pct_thr(96), pct_thr(99), af, af_valid, qual, qual_valid, filter_id);
+  for (int64_t o = 0; o < hi - lo; o += GEN_PIECE) {
+    const int64_t m = std::min(GEN_PIECE, hi - lo - o);
+    hipLaunchKernelGGL(gen_c4_kernel, dim3(blocks_for(m)), dim3(256), 0, s, seed, lo + o, lo + o + m, pct_thr(85), pct_thr(90),
+                       pct_thr(96), pct_thr(99), af + o, af_valid + o / 8, qual + o, qual_valid + o / 8, filter_id + o);
+  }
   return hipGetLastError();
 }
 

@@ -155,3 +155,50 @@ def test_high_cardinality_group_by_beyond_one_tier3_launch_properties(ctx):
     assert np.array_equal(fold(c[:G]), base_c[:5]) and np.array_equal(fold(c[G:]), base_c[5:])
     assert np.allclose(fold(s), base_s, rtol=1e-12, atol=0)
     assert (c[G:] > 0).all()
+
+
+def test_more_than_two_to_the_32_rows_in_one_launch(ctx):
+    """Maximum sizes: a single launch over more rows than a 32-bit index can count (4.6e9 rows: 43 GB of config-3 columns, then
+    56 GB of config-4 columns -- a fraction of the 288 GB of HBM these kernels are laid out for).  Tile, row and bitmap indices
+    must be 64-bit end to end, in the kernels and in the counter-based generators: the whole-table launch has to equal the sum
+    over eight file splits generated and counted separately (each well below 2^32 rows), and the per-group totals must add up
+    to the row count."""
+    import gc
+    n = (1 << 32) + 300_000_007
+    cuts = [n * k // 8 for k in range(9)]
+    # K3: flag / mapq / reference
+    f, mq, mv, ref, rv = ctx.gen_c3(3, 0, n)
+
+    def k3(cols, rows, mask, value, qmin):
+        d = ctx.zeros(np.int64, 26)
+        ctx.flag_mapq_group_count(*cols, rows, mask, value, qmin, 25, d)
+        ctx.sync()
+        return d.to_host()
+
+    whole = k3((f, mq, mv, ref, rv), n, 1284, 0, 30)
+    every = k3((f, mq, mv, ref, rv), n, 0, 0, -1)
+    assert 0.9795 * n < every.sum() < 0.9805 * n            # 2 % NULL mapq, over ALL 4.6e9 rows
+    del f, mq, mv, ref, rv
+    gc.collect()
+    parts = np.zeros(26, np.int64)
+    for k in range(8):
+        cols = ctx.gen_c3(3, cuts[k], cuts[k + 1])
+        parts += k3(cols, cuts[k + 1] - cuts[k], 1284, 0, 30)
+        del cols
+    assert np.array_equal(parts, whole)
+    gc.collect()
+    # K4: AF / qual / FILTER id
+    cols = ctx.gen_c4(4, 0, n)
+    gt_c, gt_s = k4(ctx, cols, n, 0.01, ">")
+    all_c, _ = k4(ctx, cols, n, float("-inf"), ">=")
+    assert 0.9895 * n < int(all_c[5:].sum()) < 0.9905 * n    # 1 % NULL AF
+    del cols
+    gc.collect()
+    tot_c, tot_s = np.zeros(10, np.int64), np.zeros(5)
+    for k in range(8):
+        shard = ctx.gen_c4(4, cuts[k], cuts[k + 1])
+        c, s = k4(ctx, shard, cuts[k + 1] - cuts[k], 0.01, ">")
+        tot_c += c
+        tot_s += s
+        del shard
+    assert np.array_equal(tot_c, gt_c) and np.allclose(tot_s, gt_s, rtol=1e-12, atol=0)
