@@ -202,3 +202,42 @@ def test_more_than_two_to_the_32_rows_in_one_launch(ctx):
         tot_s += s
         del shard
     assert np.array_equal(tot_c, gt_c) and np.allclose(tot_s, gt_s, rtol=1e-12, atol=0)
+
+
+def test_more_than_two_to_the_32_rows_point_and_range_hits(ctx):
+    """K2 and K6 over 2^32 + 3e8 rows in one launch (55 GB / 93 GB of columns): per-contig counts add up to the row count and
+    equal the generator's contig boundaries; the range-hit count of the whole table equals the sum over eight splits."""
+    import gc
+    n = (1 << 32) + 300_000_007
+    c, p = ctx.gen_c2(2, n)
+
+    def k2(cid, a, b):
+        d = ctx.zeros(np.int64, 1)
+        ctx.region_count(c, p, n, cid, a, b, d)
+        ctx.sync()
+        return int(d.to_host()[0])
+
+    per_contig = [k2(cid, 1, None) for cid in range(24)]
+    assert sum(per_contig) == n and min(per_contig) > 0
+    assert k2(6, 1, 49_999_999) + k2(6, 50_000_000, 100_000_000) + k2(6, 100_000_001, None) == per_contig[6]
+    del c, p
+    gc.collect()
+    cuts = [n * k // 8 for k in range(9)]
+
+    def k6(cols, rows):
+        ref, rv, st, en, pv = cols
+        d = ctx.zeros(np.int64, 1)
+        ctx.overlap_count(ref, rv, st, pv, en, pv, rows, 3, 50_000_000, 60_000_000, d)
+        ctx.sync()
+        return int(d.to_host()[0])
+
+    cols = ctx.gen_c6(6, 0, n)
+    whole = k6(cols, n)
+    del cols
+    gc.collect()
+    parts = 0
+    for k in range(8):
+        cols = ctx.gen_c6(6, cuts[k], cuts[k + 1])
+        parts += k6(cols, cuts[k + 1] - cuts[k])
+        del cols
+    assert whole == parts and whole > 1_000_000
