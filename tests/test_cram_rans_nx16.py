@@ -210,3 +210,33 @@ def test_blocks_of_discarded_series_in_unsupported_codecs_are_never_opened(tmp_p
     bad.write_bytes(bytes(raw))
     with pytest.raises(exon_amd.ExonHipError, match="3.2"):
         product_columns(str(bad))
+
+
+@pytest.mark.gpu
+def test_cram_31_file_to_gpu_aggregates(ctx, oracle, tmp_path):
+    """a CRAM 3.1 file (rANS Nx16 blocks, names / qualities in codecs nobody here can open) -> host decoder -> staging -> HBM -> K3 /
+    K6: the aggregates equal the oracle's over its own decode of the same file"""
+    import exon_amd
+    from cram_writer import synthetic_records, write_cram
+    from oracle_expect import k3_expected, k6_expected
+    refs = [("chrA", 3_000_000), ("chrB", 1_500_000), ("chrC", 400_000)]
+    recs = synthetic_records(8_000, refs, seed=33)
+    path = str(tmp_path / "v31_gpu.cram")
+    write_cram(path, refs, recs, per_slice=700, seed=6, methods=(5,), qualities=True, opaque={"RN": 8, "QS": 7})
+    for qmin in (0, 30):
+        scan = exon_amd.Scan(path, "cram")
+        names = scan.dictionary(2)
+        plan = ctx.plan_flag_mapq_group_count(1284, 0, qmin, len(names), columns=(0, 1, 2))
+        st = plan.open()
+        rows = st.consume(scan)
+        counts, _ = st.finish()
+        st.close(); plan.close(); scan.close()
+        rows_o, want = k3_expected(oracle, path, "cram", qmin=qmin)
+        assert rows == rows_o == len(recs) and np.array_equal(np.array(counts), want)
+    scan = exon_amd.Scan(path, "cram")
+    plan = ctx.plan_overlap_count(0, 200_000, 900_000)
+    st = plan.open()
+    rows = st.consume(scan)
+    counts, _ = st.finish()
+    st.close(); plan.close(); scan.close()
+    assert (rows, int(counts[0])) == k6_expected(path, "cram", "chrA", 200_000, 900_000)
