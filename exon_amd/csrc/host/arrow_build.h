@@ -22,6 +22,11 @@ struct OwnedArray {
   std::vector<const void*> buf_ptrs;  // ArrowArray::buffers
   std::vector<struct ArrowArray*> children;
   struct ArrowArray* dictionary = nullptr;
+  // a block the buffers of this array (and of its children) live in, handed back through `block_put` on release instead of
+  // being freed buffer by buffer (host/cram.h: batches built on decoder threads and released on the consumer's)
+  void* block = nullptr;
+  size_t block_bytes = 0;
+  void (*block_put)(void*, size_t) = nullptr;
 };
 inline void release_array(struct ArrowArray* a) {
   if (!a || !a->release) return;
@@ -35,8 +40,25 @@ inline void release_array(struct ArrowArray* a) {
     free(o->dictionary);
   }
   for (void* b : o->bufs) free(b);
+  if (o->block && o->block_put) o->block_put(o->block, o->block_bytes);
   delete o;
   a->release = nullptr;
+}
+// an array whose buffers belong to somebody else (a block owned by the parent struct array)
+inline struct ArrowArray* new_view_array(const void* validity, const void* values, int64_t n, int64_t nulls, struct ArrowArray* dictionary = nullptr) {
+  struct ArrowArray* a = static_cast<struct ArrowArray*>(malloc(sizeof *a));
+  OwnedArray* o = new OwnedArray();
+  o->buf_ptrs = {validity, values};
+  o->dictionary = dictionary;
+  memset(a, 0, sizeof *a);
+  a->length = n;
+  a->null_count = nulls;
+  a->n_buffers = 2;
+  a->buffers = o->buf_ptrs.data();
+  a->dictionary = dictionary;
+  a->release = release_array;
+  a->private_data = o;
+  return a;
 }
 struct OwnedSchema {
   std::string format, name;

@@ -24,13 +24,17 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
 #include <deque>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <future>
@@ -485,6 +489,32 @@ inline lzma_buffer_decode_fn lzma_buffer_decode() {
   return fn;
 }
 
+// What a decode thread keeps from one slice to the next: the byte vectors expanded blocks live in and the inflate state.  Without it
+// every slice allocates and frees a few hundred KiB in 5-50 KiB pieces (and zlib 40 KiB per gzip block); with dozens of threads doing
+// that, glibc grows and trims their heaps continuously, and those calls and the page faults behind them queue on the process-wide
+// memory-map lock (the per-container decode time doubled from 8 to 64 threads).
+struct ByteCache {
+  std::vector<std::vector<uint8_t>> spare;
+  z_stream z;
+  bool z_ready = false;
+  ByteCache() { memset(&z, 0, sizeof z); }
+  ByteCache(const ByteCache&) = delete;
+  ByteCache& operator=(const ByteCache&) = delete;
+  ~ByteCache() {
+    if (z_ready) inflateEnd(&z);
+  }
+  std::vector<uint8_t> take() {
+    if (spare.empty()) return {};
+    std::vector<uint8_t> v = std::move(spare.back());
+    spare.pop_back();
+    v.clear();
+    return v;
+  }
+  void give(std::vector<uint8_t>&& v) {
+    if (v.capacity() && spare.size() < 256) spare.push_back(std::move(v));
+  }
+};
+
 struct Block {
   int type = 0;
   uint32_t id = 0;
@@ -496,25 +526,35 @@ struct Block {
   uint32_t csz = 0, rsz = 0;
   const uint8_t* src = nullptr;
   bool ready = true;
+  ByteCache* cache = nullptr;  // where `data` comes from and goes back to (may be null)
   void expand();
 };
 inline void Block::expand() {
   if (ready) return;
   Block& b = *this;
+  if (cache) b.data = cache->take();
   if (method == 0) {
     b.data.assign(src, src + csz);
   } else if (method == 1) {
     b.data.resize(rsz);
-    z_stream z;
-    memset(&z, 0, sizeof z);
-    if (inflateInit2(&z, 15 + 32) != Z_OK) throw std::runtime_error("inflateInit2 failed");
-    z.next_in = const_cast<uint8_t*>(src);
-    z.avail_in = csz;
-    z.next_out = b.data.data();
-    z.avail_out = rsz;
-    const int rc = rsz ? inflate(&z, Z_FINISH) : Z_STREAM_END;
-    inflateEnd(&z);
-    if (rc != Z_STREAM_END || z.avail_out != 0) throw std::runtime_error("CRAM: corrupt gzip block");
+    z_stream own;
+    z_stream* z = &own;
+    if (cache) {  // one inflate state per decode thread, reset per block
+      z = &cache->z;
+      if (cache->z_ready ? inflateReset2(z, 15 + 32) != Z_OK : inflateInit2(z, 15 + 32) != Z_OK) throw std::runtime_error("inflateInit2 failed");
+      cache->z_ready = true;
+    } else {
+      memset(&own, 0, sizeof own);
+      if (inflateInit2(z, 15 + 32) != Z_OK) throw std::runtime_error("inflateInit2 failed");
+    }
+    z->next_in = const_cast<uint8_t*>(src);
+    z->avail_in = csz;
+    z->next_out = b.data.data();
+    z->avail_out = rsz;
+    const int rc = rsz ? inflate(z, Z_FINISH) : Z_STREAM_END;
+    const bool whole = z->avail_out == 0;
+    if (!cache) inflateEnd(z);
+    if (rc != Z_STREAM_END || !whole) throw std::runtime_error("CRAM: corrupt gzip block");
   } else if (method == 2) {  // bzip2 (CRAM 3.0 section 8.1)
     const bz2_decompress_fn f = bz2_decompress();
     if (!f) throw std::runtime_error("CRAM: bzip2 block, but libbz2.so.1.0 is not on this machine");
@@ -547,8 +587,9 @@ inline void Block::expand() {
   if (b.data.size() != rsz) throw std::runtime_error("CRAM: block size mismatch");
   ready = true;
 }
-inline Block read_block(Cursor& c, bool lazy = false) {
+inline Block read_block(Cursor& c, bool lazy = false, ByteCache* cache = nullptr) {
   Block b;
+  b.cache = cache;
   const size_t block_start = c.o;
   b.method = c.u8();
   b.type = c.u8();
@@ -655,6 +696,15 @@ inline Encoding read_encoding(Cursor& c, int depth = 0) {
 // the blocks of one slice + read positions.  External blocks are flat streams addressed by slot; an encoding is bound to its
 // slot once per slice (a map lookup per VALUE made the decoder 10x slower).
 struct SliceData {
+  ByteCache* cache = nullptr;
+  SliceData() = default;
+  SliceData(const SliceData&) = delete;
+  SliceData& operator=(const SliceData&) = delete;
+  ~SliceData() {
+    if (!cache) return;
+    cache->give(std::move(core));
+    for (Block& b : blocks) cache->give(std::move(b.data));
+  }
   std::vector<uint8_t> core;
   size_t core_bit = 0;
   std::vector<Block> blocks;            // external blocks in file order
@@ -817,6 +867,54 @@ struct SliceData {
 
 }  // namespace cram
 
+// Blocks that hold the buffers of one batch.  Batches are built on the decoder threads and released on the consumer's; with
+// malloc / free that pattern makes glibc grow and trim the decoder threads' heaps for every batch (32-64 KiB buffers: page
+// faults under the process-wide mmap lock -- 8 threads decoded 3.8 M records/s instead of 19), so the blocks cycle through a
+// small pool instead: no system call in the steady state.  At most 128 MiB are kept; the rest is freed.
+class BlockPool {
+ public:
+  void* get(size_t bytes) {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      auto it = free_.find(bytes);
+      if (it != free_.end() && !it->second.empty()) {
+        void* p = it->second.back();
+        it->second.pop_back();
+        held_ -= bytes;
+        return p;
+      }
+    }
+    void* p = malloc(bytes);
+    if (!p) throw std::bad_alloc();
+    return p;
+  }
+  static void put(void* p, size_t bytes) { instance().put_(p, bytes); }
+  static BlockPool& instance() {
+    static BlockPool pool;
+    return pool;
+  }
+  ~BlockPool() {
+    for (auto& kv : free_)
+      for (void* p : kv.second) free(p);
+  }
+
+ private:
+  void put_(void* p, size_t bytes) {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      if (held_ + bytes <= (size_t(128) << 20)) {
+        free_[bytes].push_back(p);
+        held_ += bytes;
+        return;
+      }
+    }
+    free(p);
+  }
+  std::mutex mu_;
+  std::map<size_t, std::vector<void*>> free_;
+  size_t held_ = 0;
+};
+
 class CRAMBatchReader {
  public:
   CRAMBatchReader(const std::string& path, BAMConfig cfg) : cfg_(std::move(cfg)) {
@@ -865,8 +963,10 @@ class CRAMBatchReader {
       for (size_t i = 0; i < ref_names.size(); ++i)
         if (ref_names[i] == cfg_.filter.region.name) region_ref_id_ = (int32_t)i;
     }
-    // containers are independent: cfg.threads of them are decoded at a time (0 = the host's cores, at most 32)
-    // containers in flight: EXON_HIP_CRAM_THREADS, else the host's cores, at most 32 (more buys nothing: one thread turns the records into batches)
+    // decode threads: cfg.threads, else EXON_HIP_CRAM_THREADS, else the host's cores, at most 32.  Containers are independent
+    // and the threads also build the batches, so the caller's thread only hands them out.  (On the GPU box -- 256 hardware
+    // threads that deliver about 16 cores' worth of work -- throughput is flat from 16 threads up: 80-100 M records/s, the
+    // per-container thread time growing in step with the thread count; EXON_HIP_CRAM_TRACE=1 prints the split.)
     const unsigned hc = std::thread::hardware_concurrency();
     const char* ev = getenv("EXON_HIP_CRAM_THREADS");
     threads_ = cfg_.threads > 0 ? cfg_.threads : ev && atoi(ev) > 0 ? atoi(ev) : (int)std::min(32u, hc ? hc : 1u);
@@ -876,29 +976,16 @@ class CRAMBatchReader {
   CRAMBatchReader& operator=(const CRAMBatchReader&) = delete;
   const BAMConfig& config() const { return cfg_; }
 
+  // Batches are built by the threads that decode the containers (round 3, last): a container's records become its own
+  // batches of at most batch_size rows -- a batch never spans two containers -- so this call, the only serial step of the
+  // reader, hands out finished arrays.  (The reference's reader fills every batch to batch_size across container borders;
+  // batch boundaries carry no meaning for the operators above a scan.)
   bool read_batch(struct ArrowArray* out) {
-    BAMArrayBuilder b(&ref_names);
-    b.reserve((size_t)std::max<int64_t>(0, std::min<int64_t>(cfg_.batch_size, 1 << 20)));
-    while ((int64_t)b.len() < cfg_.batch_size) {
-      if (pending_.empty()) {
-        if (!next_container()) break;
-        continue;
-      }
-      const Cols& k = pending_.front();
-      // the decode threads have already turned the records into columns (and applied a pushed-down region): this thread,
-      // the only serial one, moves blocks of them
-      const size_t n = std::min(k.size() - pending_pos_, (size_t)(cfg_.batch_size - (int64_t)b.len()));
-      const size_t o = pending_pos_;
-      b.append_columns(k.flag.data() + o, k.mapq.data() + o, k.mapq_ok.data() + o, k.ref.data() + o, k.ref_ok.data() + o, k.start.data() + o,
-                       k.end.data() + o, k.pos_ok.data() + o, n);
-      pending_pos_ += n;
-      if (pending_pos_ >= k.size()) {
-        pending_.pop_front();
-        pending_pos_ = 0;
-      }
-    }
-    if (b.is_empty()) return false;
-    b.try_into_record_batch(out);
+    while (pending_.empty())
+      if (!next_container()) return false;
+    *out = pending_.front().a;
+    pending_.front().a.release = nullptr;  // moved out
+    pending_.pop_front();
     return true;
   }
   void schema(struct ArrowSchema* out) const {
@@ -921,6 +1008,24 @@ class CRAMBatchReader {
     int64_t pos0, ref_len;
     int mapq;
   };
+  struct OwnedBatch {  // an Arrow struct array that is released unless it is handed out
+    struct ArrowArray a;
+    OwnedBatch() { memset(&a, 0, sizeof a); }
+    OwnedBatch(OwnedBatch&& o) noexcept : a(o.a) { o.a.release = nullptr; }
+    OwnedBatch& operator=(OwnedBatch&& o) noexcept {
+      if (this != &o) {
+        if (a.release) a.release(&a);
+        a = o.a;
+        o.a.release = nullptr;
+      }
+      return *this;
+    }
+    OwnedBatch(const OwnedBatch&) = delete;
+    OwnedBatch& operator=(const OwnedBatch&) = delete;
+    ~OwnedBatch() {
+      if (a.release) a.release(&a);
+    }
+  };
   // the records of one container as the columns BAMArrayBuilder keeps (values + one validity byte per row; NULL placeholders as
   // BAMArrayBuilder::append writes them), built by the thread that decoded the container
   struct Cols {
@@ -928,6 +1033,7 @@ class CRAMBatchReader {
     std::vector<uint8_t> mapq, mapq_ok, ref_ok, pos_ok;
     std::vector<int64_t> start, end;
     size_t size() const { return flag.size(); }
+    void clear() { flag.clear(), ref.clear(), mapq.clear(), mapq_ok.clear(), ref_ok.clear(), pos_ok.clear(), start.clear(), end.clear(); }
     void reserve(size_t n) {
       flag.reserve(n), ref.reserve(n), mapq.reserve(n), mapq_ok.reserve(n), ref_ok.reserve(n), pos_ok.reserve(n), start.reserve(n), end.reserve(n);
     }
@@ -951,15 +1057,20 @@ class CRAMBatchReader {
   };
   // The file is read container by container (positional reads: the workers fetch their own payloads); it is never held whole.
   std::vector<uint8_t> read_at(size_t off, size_t n) const {
+    std::vector<uint8_t> buf;
+    read_into(off, n, &buf);
+    return buf;
+  }
+  void read_into(size_t off, size_t n, std::vector<uint8_t>* out) const {
     if (off > size_ || n > size_ - off) throw std::runtime_error("CRAM: read past the end of the file");
-    std::vector<uint8_t> buf(n);
+    std::vector<uint8_t>& buf = *out;
+    buf.resize(n);
     size_t got = 0;
     while (got < n) {
       const ssize_t r = pread(fd_, buf.data() + got, n - got, (off_t)(off + got));
       if (r <= 0) throw std::runtime_error("CRAM: read error");
       got += (size_t)r;
     }
-    return buf;
   }
   ContainerHeader read_container_header() {
     for (size_t window = 4096;; window *= 16) {  // the header is tens of bytes plus one ITF8 per slice landmark
@@ -1003,16 +1114,76 @@ class CRAMBatchReader {
   // The next group of containers (those that can hold a hit), decoded on `threads` threads, appended in file order.  The group
   // after it is decoded in the background while the caller turns this one into batches (round 3: building the Arrow batches is
   // single-threaded and had the decoder threads idle for half of the time).
+  // rows [o, o + n) of `k` as one struct array (the BAM device layout) whose nine buffers share one pooled block of the size a
+  // full batch of `per` rows needs
+  void make_batch(const Cols& k, size_t o, size_t n, size_t per, struct ArrowArray* out) const {
+    auto pad = [](size_t b) { return (b + 63) & ~size_t(63); };
+    const size_t bm = pad(per / 8 + 16);
+    const size_t bytes = 2 * pad(per * 8 + 64) + 2 * pad(per * 4 + 64) + pad(per + 64) + 4 * bm;
+    uint8_t* base = static_cast<uint8_t*>(BlockPool::instance().get(bytes));
+    uint8_t* p = base;
+    auto take = [&](size_t b) {
+      uint8_t* q = p;
+      p += b;
+      return q;
+    };
+    int64_t* start = reinterpret_cast<int64_t*>(take(pad(per * 8 + 64)));
+    int64_t* end = reinterpret_cast<int64_t*>(take(pad(per * 8 + 64)));
+    int32_t* flag = reinterpret_cast<int32_t*>(take(pad(per * 4 + 64)));
+    int32_t* ref = reinterpret_cast<int32_t*>(take(pad(per * 4 + 64)));
+    uint8_t* mapq = take(pad(per + 64));
+    uint8_t* v_mapq = take(bm);
+    uint8_t* v_ref = take(bm);
+    uint8_t* v_pos = take(bm);
+    uint8_t* v_pos2 = take(bm);  // start and end are separate arrays: separate bitmaps, same bits
+    memcpy(start, k.start.data() + o, n * 8);
+    memcpy(end, k.end.data() + o, n * 8);
+    memcpy(flag, k.flag.data() + o, n * 4);
+    memcpy(ref, k.ref.data() + o, n * 4);
+    memcpy(mapq, k.mapq.data() + o, n);
+    memset(reinterpret_cast<uint8_t*>(start) + n * 8, 0, 64);  // slack: consumers may read whole 16-byte vectors
+    memset(reinterpret_cast<uint8_t*>(end) + n * 8, 0, 64);
+    memset(reinterpret_cast<uint8_t*>(flag) + n * 4, 0, 64);
+    memset(reinterpret_cast<uint8_t*>(ref) + n * 4, 0, 64);
+    memset(mapq + n, 0, 64);
+    auto pack = [&](const uint8_t* ok, uint8_t* bits) -> int64_t {  // byte per row -> Arrow bitmap; returns the NULL count
+      memset(bits, 0, bm);
+      int64_t nulls = 0;
+      for (size_t i = 0; i < n; ++i) {
+        bits[i >> 3] |= (uint8_t)((ok[i] & 1u) << (i & 7));
+        nulls += !ok[i];
+      }
+      return nulls;
+    };
+    const int64_t n_mapq = pack(k.mapq_ok.data() + o, v_mapq), n_ref = pack(k.ref_ok.data() + o, v_ref), n_pos = pack(k.pos_ok.data() + o, v_pos);
+    if (n_pos) memcpy(v_pos2, v_pos, bm);
+    std::vector<struct ArrowArray*> kids = {
+        new_view_array(nullptr, flag, (int64_t)n, 0),
+        new_view_array(n_mapq ? v_mapq : nullptr, mapq, (int64_t)n, n_mapq),
+        new_view_array(n_ref ? v_ref : nullptr, ref, (int64_t)n, n_ref, utf8_array(ref_names)),
+        new_view_array(n_pos ? v_pos : nullptr, start, (int64_t)n, n_pos),
+        new_view_array(n_pos ? v_pos2 : nullptr, end, (int64_t)n, n_pos)};
+    make_struct(out, (int64_t)n, std::move(kids));
+    OwnedArray* own = static_cast<OwnedArray*>(out->private_data);
+    own->block = base;
+    own->block_bytes = bytes;
+    own->block_put = &BlockPool::put;
+  }
+
   struct Job {
     size_t off, length;
-    Cols cols;
+    std::vector<OwnedBatch> batches;
     std::vector<std::string> names;
     std::string error;
   };
   std::vector<Job> plan_group() {  // walks container headers (caller's thread)
     std::vector<Job> jobs;
-    const size_t want = (size_t)std::max(1, threads_);
-    while (jobs.size() < want && off_ < size_) {
+    // a group = up to four containers per decode thread (the threads of a group are started once and pick containers from a
+    // shared counter: one container per thread and group spent a third of the time starting threads and waiting for the
+    // slowest one), at most 256 MiB of compressed containers; the sequential reader keeps one container at a time
+    const size_t want = threads_ <= 1 ? 1 : (size_t)threads_ * 4;
+    size_t bytes = 0;
+    while (jobs.size() < want && bytes < (size_t(256) << 20) && off_ < size_) {
       const ContainerHeader h = read_container_header();
       const size_t end = off_ + h.length;
       bool take = h.n_records != 0;  // 0: the EOF container (or an empty one)
@@ -1027,6 +1198,7 @@ class CRAMBatchReader {
         Job j;
         j.off = off_;
         j.length = h.length;
+        bytes += h.length;
         jobs.push_back(std::move(j));
       }
       off_ = end;
@@ -1034,14 +1206,31 @@ class CRAMBatchReader {
     return jobs;
   }
   std::vector<Job> decode_group(std::vector<Job> jobs) const {  // any thread: positional reads, no shared state
-    const bool want_names = keep_names;
-    auto run = [this, want_names](Job& j) {
+    const long tg0 = now_us();
+    // A decode thread keeps its large buffers (compressed container, records, columns) from one container to the next: freeing
+    // and re-allocating them per container made glibc grow and trim the threads' heaps under the process-wide mmap lock (8
+    // threads: 3.4 instead of 20+ M records/s).
+    struct Scratch {
+      std::vector<uint8_t> buf;
+      std::vector<Rec> recs;
+      Cols cols;
+      cram::ByteCache bytes;
+    };
+    auto run = [this](Job& j, Scratch& sc) {
       try {
-        const std::vector<uint8_t> buf = read_at(j.off, j.length);
+        const bool want_names = keep_names;
+        const long t0 = now_us();
+        read_into(j.off, j.length, &sc.buf);
+        const long t1 = now_us();
+        const std::vector<uint8_t>& buf = sc.buf;
         cram::Cursor c(buf.data(), buf.size());
-        std::vector<Rec> recs;
-        decode_container(c, &recs, want_names ? &j.names : nullptr);
-        j.cols.reserve(recs.size());
+        std::vector<Rec>& recs = sc.recs;
+        recs.clear();
+        decode_container(c, &recs, want_names ? &j.names : nullptr, &sc.bytes);
+        const long t2 = now_us();
+        Cols& cols = sc.cols;
+        cols.clear();
+        cols.reserve(recs.size());
         const bool filter = cfg_.filter.active;
         const Region& rg = cfg_.filter.region;
         for (const Rec& r : recs) {
@@ -1050,25 +1239,63 @@ class CRAMBatchReader {
             const int64_t s = r.pos0 + 1, e = s + r.ref_len - 1;
             if (!(r.ref_id == region_ref_id_ && s <= rg.end && rg.start <= e)) continue;
           }
-          j.cols.push(r);
+          cols.push(r);
+        }
+        const long t3 = now_us();
+        const size_t per = (size_t)std::max<int64_t>(1, cfg_.batch_size);
+        for (size_t o = 0; o < cols.size(); o += per) {
+          const size_t n = std::min(per, cols.size() - o);
+          OwnedBatch ob;
+          make_batch(cols, o, n, per, &ob.a);
+          j.batches.push_back(std::move(ob));
+        }
+        if (tracing()) {
+          const long t4 = now_us();
+          trace_.read += t1 - t0, trace_.decode += t2 - t1, trace_.columns += t3 - t2, trace_.batches += t4 - t3, ++trace_.containers;
         }
       } catch (const std::exception& e) {
         j.error = e.what();
         if (j.error.empty()) j.error = "CRAM: decode error";
       }
     };
-    if (jobs.size() == 1) {
-      run(jobs[0]);
+    if (jobs.size() == 1 || threads_ <= 1) {
+      Scratch sc;
+      for (Job& j : jobs) run(j, sc);
     } else {
-      std::vector<std::thread> pool;
-      for (size_t i = 1; i < jobs.size(); ++i) pool.emplace_back(run, std::ref(jobs[i]));
-      run(jobs[0]);
-      for (auto& t : pool) t.join();
+      // the reader's decode threads live as long as the reader (started with the first group): starting `threads_` threads per
+      // group cost their stacks' mmap / munmap under the process-wide lock every few milliseconds
+      Workers& w = *workers_;
+      std::unique_lock<std::mutex> lk(w.mu);
+      if (w.threads.empty()) {
+        const size_t n = (size_t)std::max(1, threads_);
+        for (size_t i = 0; i < n; ++i)
+          w.threads.emplace_back([&w, run] {
+            Scratch sc;
+            std::unique_lock<std::mutex> l(w.mu);
+            for (;;) {
+              w.cv_work.wait(l, [&w] { return w.stop || (w.jobs && w.next < w.jobs->size()); });
+              if (w.stop) return;
+              Job& j = (*w.jobs)[w.next++];
+              l.unlock();
+              run(j, sc);  // never throws: errors are kept in the job
+              l.lock();
+              if (++w.done == w.jobs->size()) w.cv_done.notify_all();
+            }
+          });
+      }
+      w.jobs = &jobs;
+      w.next = w.done = 0;
+      w.cv_work.notify_all();
+      w.cv_done.wait(lk, [&w, &jobs] { return w.done == jobs.size(); });
+      w.jobs = nullptr;
     }
+    if (tracing()) trace_.group += now_us() - tg0, ++trace_.groups;
     return jobs;
   }
   void start_ahead() {  // header errors (a malformed container header) surface here, in file order, as before
+    const long tp0 = now_us();
     std::vector<Job> jobs = plan_group();
+    trace_.plan += now_us() - tp0;
     if (jobs.empty()) return;
     if (threads_ <= 1) {  // sequential reader: no helper thread either
       std::promise<std::vector<Job>> p;
@@ -1083,12 +1310,14 @@ class CRAMBatchReader {
   bool next_container() {
     if (!ahead_.valid()) start_ahead();
     if (!ahead_.valid()) return false;
+    const long tw0 = now_us();
     std::vector<Job> jobs = ahead_.get();
+    trace_.wait += now_us() - tw0;
     if (ahead_deferred_) jobs = decode_group(std::move(jobs));
     start_ahead();  // the next group decodes while this one is consumed
     for (auto& j : jobs) {
       if (!j.error.empty()) throw std::runtime_error(j.error);
-      if (j.cols.size()) pending_.push_back(std::move(j.cols));
+      for (auto& ob : j.batches) pending_.push_back(std::move(ob));
       if (keep_names) names.insert(names.end(), j.names.begin(), j.names.end());
     }
     return true;
@@ -1098,7 +1327,7 @@ class CRAMBatchReader {
     cram::Encoding BF, CF, RI, RL, AP, RG, RN, MF, NS, NP, TS, NF, TL, FN, FC, FP, DL, BA, QS, BS, IN, SC, RS, PD, HC, MQ, BB, QQ;
   };
 
-  void decode_container(cram::Cursor& c, std::vector<Rec>* out, std::vector<std::string>* out_names) const {
+  void decode_container(cram::Cursor& c, std::vector<Rec>* out, std::vector<std::string>* out_names, cram::ByteCache* cache = nullptr) const {
     using namespace cram;
     Block ch = read_block(c);
     if (ch.type != 1) throw std::runtime_error("CRAM: compression header expected");
@@ -1186,9 +1415,10 @@ class CRAMBatchReader {
       (void)s.ltf8();
       const uint32_t s_nblocks = s.itf8();
       SliceData sl;
+      sl.cache = cache;
       for (uint32_t i = 0; i < s_nblocks; ++i) {
         static const bool eager = getenv("EXON_HIP_CRAM_EAGER") != nullptr;  // A/B: expand every block, as round 2 did
-        Block b = read_block(c, /*lazy=*/true);  // external blocks are expanded when a series first reads them
+        Block b = read_block(c, /*lazy=*/true, cache);  // external blocks are expanded when a series first reads them
         if (eager && b.method <= 5) b.expand();  // (a block in a codec this reader lacks stays closed either way)
         if (b.type == 5) {
           b.expand();
@@ -1287,11 +1517,47 @@ class CRAMBatchReader {
   } fdh_;
   int fd_ = -1;
   size_t size_ = 0, off_ = 0;
-  std::deque<Cols> pending_;  // decoded containers, in file order; pending_pos_ = rows of the front one already handed out
-  size_t pending_pos_ = 0;
+  std::deque<OwnedBatch> pending_;  // finished batches of the decoded containers, in file order
   int32_t region_ref_id_ = -2;
+  // EXON_HIP_CRAM_TRACE=1: where a scan's wall time went, printed when the reader closes (microseconds; the per-container
+  // parts are sums over all decode threads)
+  struct Trace {
+    std::atomic<long> plan{0}, wait{0}, group{0}, read{0}, decode{0}, columns{0}, batches{0}, groups{0}, containers{0};
+  };
+  mutable Trace trace_;
+  static bool tracing() {
+    static const bool on = getenv("EXON_HIP_CRAM_TRACE") != nullptr;
+    return on;
+  }
+  static long now_us() { return (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  struct Workers {  // decode threads + the group they are working on (decode_group)
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::vector<std::thread> threads;
+    std::vector<Job>* jobs = nullptr;
+    size_t next = 0, done = 0;
+    bool stop = false;
+  };
+  std::unique_ptr<Workers> workers_{new Workers};
   bool ahead_deferred_ = false;
-  std::future<std::vector<Job>> ahead_;  // declared last: its destructor waits for the helper thread before the file closes
+  std::future<std::vector<Job>> ahead_;  // a group being decoded in the background
+
+ public:
+  ~CRAMBatchReader() {  // the background group first (it uses the decode threads and the file), then the threads
+    if (ahead_.valid()) ahead_.wait();
+    {
+      std::lock_guard<std::mutex> g(workers_->mu);
+      workers_->stop = true;
+    }
+    workers_->cv_work.notify_all();
+    for (auto& t : workers_->threads) t.join();
+    if (tracing())
+      fprintf(stderr, "[exon-hip cram] %ld containers in %ld groups on %d threads: caller planned %.1f ms, waited %.1f ms for groups; groups took %.1f ms; "
+              "per container (thread time) read %.0f us, decode %.0f us, columns %.0f us, batches %.0f us\n",
+              trace_.containers.load(), trace_.groups.load(), threads_, trace_.plan / 1e3, trace_.wait / 1e3, trace_.group / 1e3,
+              (double)trace_.read / std::max(1L, trace_.containers.load()), (double)trace_.decode / std::max(1L, trace_.containers.load()),
+              (double)trace_.columns / std::max(1L, trace_.containers.load()), (double)trace_.batches / std::max(1L, trace_.containers.load()));
+  }
 };
 
 }  // namespace exon
