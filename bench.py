@@ -264,6 +264,9 @@ def cpu_baseline(kind, sample_rows, n_total, reps):
         one = round(m / t1.seconds_exec / 1e6, 2)
     res = {"value": round(n / best / 1e6, 2), "unit": "Mrows/s", "cores": t.threads, "kind": "port",
            "single_thread_value": one,
+           # value / single_thread_value: how many cores' worth of work the host's threads delivered in this run (GPU boxes of
+           # this pool show ~13 for 128 threads, which is why `value` moves from box to box while the per-thread figure does not)
+           "parallel_speedup": round(n / best / 1e6 / one, 1) if one else None,
            "sample": f"rows [0,{n}) of the same synthetic table as 8192-row Arrow-layout batches (Utf8/List<Utf8> keys), "
                      f"{t.threads} partitions = host cores; median of {reps} runs, {best:.3f}s exec each "
                      f"(+{float(np.median(mat)):.2f}s untimed Arrow-layout build); total CPU work "
