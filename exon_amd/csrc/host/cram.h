@@ -1118,6 +1118,11 @@ class CRAMBatchReader {
   // full batch of `per` rows needs
   void make_batch(const Cols& k, size_t o, size_t n, size_t per, struct ArrowArray* out) const {
     auto pad = [](size_t b) { return (b + 63) & ~size_t(63); };
+    // the block is sized for the rows it holds, rounded up to a power of two (size classes the pool can reuse) -- not for
+    // batch_size, which a caller may set to millions of rows while a container holds ten thousand
+    size_t cls = 1024;
+    while (cls < n) cls <<= 1;
+    per = std::min(per, cls);
     const size_t bm = pad(per / 8 + 16);
     const size_t bytes = 2 * pad(per * 8 + 64) + 2 * pad(per * 4 + 64) + pad(per + 64) + 4 * bm;
     uint8_t* base = static_cast<uint8_t*>(BlockPool::instance().get(bytes));
