@@ -738,29 +738,6 @@ class BAMArrayBuilder : public ExonArrayBuilder {
     }
     ++rows_;
   }
-  // n rows that are already column-shaped (the CRAM reader's decode threads produce them: values with the same NULL
-  // placeholders append() writes, one validity byte per row) -- five block copies instead of n x 10 push_backs
-  void append_columns(const int32_t* flag, const uint8_t* mapq, const uint8_t* mapq_ok, const int32_t* ref, const uint8_t* ref_ok,
-                      const int64_t* start, const int64_t* end, const uint8_t* pos_ok, size_t n) {
-    flag_.values.insert(flag_.values.end(), flag, flag + n);
-    flag_.valid.insert(flag_.valid.end(), n, (uint8_t)1);
-    mapq_.values.insert(mapq_.values.end(), mapq, mapq + n);
-    mapq_.valid.insert(mapq_.valid.end(), mapq_ok, mapq_ok + n);
-    ref_.values.insert(ref_.values.end(), ref, ref + n);
-    ref_.valid.insert(ref_.valid.end(), ref_ok, ref_ok + n);
-    start_.values.insert(start_.values.end(), start, start + n);
-    start_.valid.insert(start_.valid.end(), pos_ok, pos_ok + n);
-    end_.values.insert(end_.values.end(), end, end + n);
-    end_.valid.insert(end_.valid.end(), pos_ok, pos_ok + n);
-    rows_ += n;
-  }
-  void reserve(size_t n) {
-    for (auto* v : {&flag_.valid, &mapq_.valid, &ref_.valid, &start_.valid, &end_.valid, &mapq_.values}) v->reserve(n);
-    flag_.values.reserve(n);
-    ref_.values.reserve(n);
-    start_.values.reserve(n);
-    end_.values.reserve(n);
-  }
   size_t len() const override { return rows_; }
   std::vector<struct ArrowArray*> finish() override {
     rows_ = 0;
