@@ -822,6 +822,7 @@ def decode_cram(path):
     assert b[:4] == b"CRAM" and b[4] == 3, "CRAM 3.x expected"
     o, refs, recs, first = 26, [], [], True
     while o < len(b):
+        c_off = o  # where this container's header starts (what a .crai entry's fourth field holds)
         length, = struct.unpack_from("<i", b, o)
         o += 4
         ref_id, o = _itf8s(b, o)
@@ -887,6 +888,7 @@ def decode_cram(path):
             tags[key], q = _cram_encoding(h, q)
         # slices
         while p < end:
+            s_off = p - (end - length)  # the slice header's offset from the end of the container header (.crai field five)
             sh, p = _cram_block(b, p)
             assert sh["type"] == 2
             d, q = sh["data"], 0
@@ -986,7 +988,7 @@ def decode_cram(path):
                         for _ in range(rl):
                             sl.byte(ds["QS"])
                 start = ap if ap >= 1 else None
-                recs.append(dict(name=None if name is None else name.decode(), flag=bf, ref_id=ri if ri >= 0 else None, start=start,
+                recs.append(dict(name=None if name is None else name.decode(), container=c_off, slice=s_off, flag=bf, ref_id=ri if ri >= 0 else None, start=start,
                                  end=(start + (0 if bf & 4 else span) - 1) if start is not None else None,
                                  mapq=None if mapq == 255 else mapq, cigar=cigar))
         o = end

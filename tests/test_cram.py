@@ -281,3 +281,34 @@ def test_corrupted_files_never_crash_the_reader(tmp_path):
             except exon_amd.ExonHipError:
                 err += 1
     assert ok + err == 800 and err > 400
+
+
+@pytest.mark.parametrize("name", ["1404_index_multislice.cram", "twolib.sorted.cram"])
+def test_slice_spans_equal_the_htslib_written_index(name):
+    """The reference's fixtures come with the .crai files htslib wrote beside them (exon-core/test-data/datasources/cram/
+    1404_index_multislice.cram.crai, two-cram/twolib.sorted.cram.crai; read by exon-core/src/datasources/cram/index.rs:29-41):
+    one line per slice and reference -- reference id, alignment start, alignment SPAN, byte offset of the container header,
+    offset of the slice header behind it.  Seventeen values of a third party for what this path computes from the read features
+    (end = start + reference span - 1): per slice, min(start) and max(end) - min(start) + 1 of the oracle's records AND of the
+    product's columns must reproduce every line, as must the container and slice offsets the oracle walked."""
+    import gzip
+    path = os.path.join(FX, name)
+    crai = [tuple(int(x) for x in line.split("\t")) for line in gzip.open(path + ".crai", "rt").read().split("\n") if line]
+    refs, recs = decode.decode_cram(path)
+    _, flag, mapq, ref, start, end = product_columns(path)
+    assert len(flag) == len(recs)
+    names = [r[0] for r in refs]
+    for source in ("oracle", "product"):
+        groups = {}
+        for i, r in enumerate(recs):
+            if source == "oracle":
+                rid, s, e = r["ref_id"], r["start"], r["end"]
+            else:
+                rid, s, e = (None if ref[i] is None else names.index(ref[i])), start[i], end[i]
+            key = (r["container"], r["slice"], -1 if rid is None else rid)
+            g = groups.setdefault(key, [None, None])
+            if s is not None:
+                g[0] = s if g[0] is None else min(g[0], s)
+                g[1] = e if g[1] is None else max(g[1], e)
+        mine = [(k[2], v[0] or 0, v[1] - v[0] + 1 if v[0] else 1, k[0], k[1]) for k, v in groups.items()]
+        assert mine == [c[:5] for c in crai], source
