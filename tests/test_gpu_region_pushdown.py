@@ -163,3 +163,18 @@ def test_region_mask_on_sam_and_bcf_full_scans(ctx):
             st.close(); plan.close(); scan.close()
             got.append((rows, int(counts[0])))
         assert got[0] == got[1] == (want, want), region
+
+
+@pytest.mark.parametrize("rel", ["vcf/index.vcf.gz", "biobear-vcf/vcf_file.vcf.gz"])
+def test_every_contig_count_equals_the_htslib_written_index(ctx, rel):
+    """The tabix indexes beside the reference's fixtures carry htslib's own per-contig record counts (pseudo-bin 37450): 191 / 219 /
+    211 and 11 / 1 / 1 / 2.  The slt files pin one contig of each; through the GPU indexed path and through the unindexed GPU
+    parse + row mask EVERY contig must come out with htslib's count."""
+    from index_meta import tabix_counts
+    p = os.path.join(FX, rel)
+    want = tabix_counts(p + ".tbi")
+    assert len(want) >= 3
+    for contig, n in want.items():
+        rows, cnt, on_gpu, chunks = vcf_region_rows(ctx, p, contig, use_index=True, gpu_parse=True)
+        assert (rows, cnt, on_gpu) == (n, n, True) and chunks >= 1, contig
+        assert vcf_region_rows(ctx, p, contig, use_index=False, gpu_parse=True)[0] == n, contig

@@ -426,3 +426,37 @@ def test_bcf_scan_pins_and_equals_vcf_twin():
     lv = [x for batch in exon_amd.Scan(fx("vcf", "index.vcf"), "vcf", info_field="I16,QS") for x in batch.to_pylist()]
     assert lb == lv and all(len(r["info.I16"]) == 16 for r in lb)
     assert [r["info.QS"] for r in lb] == decode.typed_info(decode.decode_bcf(fx("bcf", "index.bcf")), "QS")[1]
+
+
+def test_per_contig_counts_equal_the_htslib_written_indexes():
+    """Third-party pins beyond the slt values: htslib stores per-reference record counts in its indexes (pseudo-bin 37450; what
+    `bcftools index --stats` / `samtools idxstats` print).  For the reference's fixtures: index.vcf.gz 191 / 219 / 211 on contigs
+    1 / 2 / 10 (the slt pins only the 191), biobear's 11 / 1 / 1 / 2, and test.bam's 61 mapped + 0 unmapped reads on chr1.  The host decoders' per-contig counts must equal every one of them."""
+    import collections
+    import pyarrow as pa
+    from index_meta import bai_counts, tabix_counts
+
+    def per_key(path, fmt, col):
+        scan = exon_amd.Scan(path, fmt)
+        c = collections.Counter()
+        for b in scan:
+            b = pa.RecordBatch.from_struct_array(b) if isinstance(b, pa.StructArray) else b
+            c.update(b.column(col).to_pylist())
+        scan.close()
+        return dict(c)
+
+    for rel in ("vcf/index.vcf.gz", "biobear-vcf/vcf_file.vcf.gz", "vcf-partition/sample=1/index1.vcf.gz", "vcf-partition/sample=2/index2.vcf.gz"):
+        want = tabix_counts(fx(rel + ".tbi"))
+        assert sum(want.values()) > 0 and per_key(fx(rel), "vcf", 0) == want, rel
+    assert tabix_counts(fx("vcf/index.vcf.gz.tbi")) == {"1": 191, "2": 219, "10": 211}
+    meta, n_no_coor = bai_counts(fx("bam/test.bam.bai"))
+    assert meta[0] == (61, 0) and n_no_coor == 0 and all(m is None for m in meta[1:])
+    scan = exon_amd.Scan(fx("bam/test.bam"), "bam")
+    refs = scan.dictionary(2)
+    mapped = collections.Counter()
+    for b in scan:
+        b = pa.RecordBatch.from_struct_array(b) if isinstance(b, pa.StructArray) else b
+        for f, r in zip(b.column(0).to_pylist(), b.column(2).to_pylist()):
+            mapped[(r, bool(f & 4))] += 1
+    scan.close()
+    assert dict(mapped) == {(refs[0], False): 61}
