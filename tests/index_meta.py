@@ -44,3 +44,27 @@ def bai_counts(path):
     meta, o = _walk(b, 8, n_ref)
     n_no_coor = struct.unpack_from("<Q", b, o)[0] if o + 8 <= len(b) else None
     return meta, n_no_coor
+
+
+def csi_counts(path):
+    """[records or None per contig, in header order] of a .csi (CSI v1: bcftools / htslib's index for BCF)"""
+    b = gzip.open(path, "rb").read()
+    assert b[:4] == b"CSI\x01"
+    _min_shift, depth, l_aux = struct.unpack_from("<3i", b, 4)
+    o = 16 + l_aux
+    n_ref, = struct.unpack_from("<i", b, o)
+    o += 4
+    meta_bin = ((1 << ((depth + 1) * 3)) - 1) // 7 + 1
+    out = []
+    for _ in range(n_ref):
+        n_bin, = struct.unpack_from("<i", b, o)
+        o += 4
+        meta = None
+        for _ in range(n_bin):
+            bin_, _loffset, n_chunk = struct.unpack_from("<IQi", b, o)
+            o += 16
+            if bin_ == meta_bin:
+                meta = struct.unpack_from("<QQQQ", b, o)[2]
+            o += 16 * n_chunk
+        out.append(meta)
+    return out

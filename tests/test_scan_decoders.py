@@ -434,7 +434,7 @@ def test_per_contig_counts_equal_the_htslib_written_indexes():
     1 / 2 / 10 (the slt pins only the 191), biobear's 11 / 1 / 1 / 2, and test.bam's 61 mapped + 0 unmapped reads on chr1.  The host decoders' per-contig counts must equal every one of them."""
     import collections
     import pyarrow as pa
-    from index_meta import bai_counts, tabix_counts
+    from index_meta import bai_counts, csi_counts, tabix_counts
 
     def per_key(path, fmt, col):
         scan = exon_amd.Scan(path, fmt)
@@ -449,6 +449,12 @@ def test_per_contig_counts_equal_the_htslib_written_indexes():
         want = tabix_counts(fx(rel + ".tbi"))
         assert sum(want.values()) > 0 and per_key(fx(rel), "vcf", 0) == want, rel
     assert tabix_counts(fx("vcf/index.vcf.gz.tbi")) == {"1": 191, "2": 219, "10": 211}
+    per_contig = csi_counts(fx("bcf/index.bcf.csi"))  # BCF: counts by contig index of the header (86 contigs, three with records)
+    scan = exon_amd.Scan(fx("bcf/index.bcf"), "bcf")
+    contigs = scan.dictionary(0)
+    scan.close()
+    got = per_key(fx("bcf/index.bcf"), "bcf", 0)
+    assert {contigs[i]: n for i, n in enumerate(per_contig) if n} == got == {"1": 191, "2": 219, "10": 211}
     meta, n_no_coor = bai_counts(fx("bam/test.bam.bai"))
     assert meta[0] == (61, 0) and n_no_coor == 0 and all(m is None for m in meta[1:])
     scan = exon_amd.Scan(fx("bam/test.bam"), "bam")
