@@ -278,3 +278,39 @@ def test_strict_mode_turns_the_host_fallback_into_an_error(ctx, tmp_path, monkey
     st.close()
     plan.close()
     scan.close()
+
+
+@pytest.mark.parametrize("fixture", ["index.vcf", "index.vcf.gz"])
+@pytest.mark.parametrize("field,thr", [("DP", 0), ("DP", 1), ("DP", 4), ("MQ0F", -1.0), ("MQSB", 0.5), ("SGB", -0.5)])
+def test_fixture_aggregates_against_a_regex_statement_of_the_query(ctx, fixture, field, thr):
+    """A second opinion that shares no code with the oracle or the decoders: `SELECT filter, COUNT(qual), COUNT(*), SUM(qual)
+    WHERE info.<field> > thr GROUP BY filter` over the reference's 621-row fixture, stated with `str.split` and one regular
+    expression on the text (an Integer field compared as integers, a Float field through float32, as the reference types
+    them: exon-core/src/datasources/vcf/schema_builder.rs:197-205), against file -> (GPU inflate) -> GPU parse -> K4."""
+    import gzip
+    import re
+    path = os.path.join(FX, "vcf", fixture)
+    text = (gzip.open(path, "rt") if fixture.endswith(".gz") else open(path)).read()
+    want = {}
+    pat = re.compile(r"(?:^|;)" + field + r"=([^;]+)")
+    n = 0
+    for line in text.split("\n"):
+        if not line or line.startswith("#"):
+            continue
+        n += 1
+        c = line.split("\t")
+        m = pat.search(c[7])
+        if not m:
+            continue  # NULL never passes a comparison
+        x = int(m.group(1)) if field in ("DP", "IDV") else float(np.float32(float(m.group(1))))
+        if not x > thr:
+            continue
+        key = "" if c[6] == "." else c[6]
+        cnt_q, cnt, sm = want.get(key, (0, 0, 0.0))
+        if c[5] != ".":
+            cnt_q, sm = cnt_q + 1, sm + float(np.float32(float(c[5])))
+        want[key] = (cnt_q, cnt + 1, sm)
+    assert n == 621 and want, "the fixture and the field must give the query something to do"
+    rows, got = _k4_through_scan(ctx, path, True, info_field=field, thr=thr)
+    assert rows == 621
+    _same(got, want)
