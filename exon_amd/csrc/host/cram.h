@@ -224,6 +224,7 @@ inline uint32_t uint7(Cursor& c) {  // big-endian base-128, high bit = "more"
   uint32_t v = 0;
   for (int i = 0; i < 5; ++i) {
     const uint8_t b = c.u8();
+    if (v >> 25) throw std::runtime_error("CRAM: rANS Nx16 length does not fit 32 bits");
     v = (v << 7) | (b & 0x7Fu);
     if (!(b & 0x80)) return v;
   }
