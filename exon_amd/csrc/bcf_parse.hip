@@ -504,7 +504,7 @@ int exon_hip_bcf_parser_parse(exon_hip_bcf_parser* p, void* stream, const uint8_
                        row_bound, (unsigned)std::min<int64_t>(p->max_bytes + 1, 0xFFFFFFFFLL), kind, offsets, p->out.info[q],
                        (uint8_t*)p->lbufs[6 * q + 3], p->d_scalars + 1);
     hipLaunchKernelGGL(k_pack_bits, dim3(1024), dim3(256), 0, s, (const uint8_t*)p->lbufs[6 * q + 3], offsets, p->d_scalars, row_bound,
-                       (uint8_t*)p->lbufs[6 * q + 4]);
+                       (unsigned)std::min<int64_t>(p->max_bytes + 1, 0xFFFFFFFFLL), (uint8_t*)p->lbufs[6 * q + 4]);
   }
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(p->h_scalars, p->d_scalars, 12, hipMemcpyDeviceToHost, s));

@@ -544,7 +544,7 @@ __global__ __launch_bounds__(LIST_TPB) void k_list_fill(const uint8_t* __restric
   if (row + 1 == n_rows) offsets[n_rows] = (int32_t)(first + c);
   if (row == 0 && n_rows == 0) offsets[0] = 0;
   if (row >= n_rows || c == 0) return;
-  if ((uint64_t)first + c > cap_items) {  // cannot happen for cap_items = slab bytes / 2 + 1 (an item and its comma take 2 bytes)
+  if ((uint64_t)first + c > cap_items) {  // comma-dense values ("AF=,,,,": one EMPTY item per byte) can exceed slab bytes / 2 + 1: host decoder
     atomicAdd(exceptions, 1u);
     return;
   }
@@ -677,7 +677,8 @@ int exon_hip_vcf_parser_create(exon_hip_ctx* ctx, const char* const* contig_name
   dalloc(&p->out_bufs[3], r * 4);
   dalloc(&p->out_bufs[4], rb);
   dalloc(&p->out_bufs[5], r * 4);
-  p->cap_items = max_bytes / 2 + 1;  // an item and its separator take at least two bytes of the slab
+  p->cap_items = max_bytes / 2 + 1;  // a non-empty item and its separator take at least two bytes of the slab; a slab of mostly EMPTY
+                                     // items (legal: "AF=,,,,") overflows this and is decoded by the host reader (k_list_fill / k_pack_bits clamp)
   for (int q = 0; q < p->ik.n; ++q) {
     const char kind = p->ik.kind[q];
     if (kind == 'f' || kind == 'i') dalloc(&p->out_bufs[6 + 2 * q], r * 4);
@@ -776,7 +777,7 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* p, void* stream, const uint8_
                        p->d_scalars, (unsigned)row_bound, (unsigned)std::min<int64_t>(p->cap_items, 0xFFFFFFFFLL), kind, offsets, p->out.info[q],
                        (uint8_t*)p->list_bufs[5 * q + 3], p->out.exceptions);
     hipLaunchKernelGGL(k_pack_bits, dim3(1024), dim3(256), 0, s, (const uint8_t*)p->list_bufs[5 * q + 3], offsets, p->d_scalars, (unsigned)row_bound,
-                       (uint8_t*)p->list_bufs[5 * q + 4]);
+                       (unsigned)std::min<int64_t>(p->cap_items, 0xFFFFFFFFLL), (uint8_t*)p->list_bufs[5 * q + 4]);
   }
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(p->h_scalars, p->d_scalars, 12, hipMemcpyDeviceToHost, s));

@@ -59,10 +59,13 @@ __device__ __forceinline__ unsigned list_first_item(unsigned c, const unsigned* 
   for (int w = 0; w < wave; ++w) base += wave_tot[w];
   return base + incl - c;
 }
-// byte-per-item flags -> Arrow validity bitmap (8 items per thread); n = offsets[n_rows]
+// byte-per-item flags -> Arrow validity bitmap (8 items per thread); n = offsets[n_rows], never more than the `cap_items`
+// the flag / bitmap buffers were sized for (a slab whose items do not fit is handed back to the host decoder by the fill
+// kernel's exception count: nothing past the buffers may be touched on the way there)
 __global__ __launch_bounds__(256) void k_pack_bits(const uint8_t* __restrict__ flags, const int32_t* __restrict__ offsets,
-                                                   const unsigned* __restrict__ n_rows_p, unsigned cap, uint8_t* __restrict__ bitmap) {
-  const unsigned n = (unsigned)offsets[min(*n_rows_p, cap)];
+                                                   const unsigned* __restrict__ n_rows_p, unsigned cap, unsigned cap_items,
+                                                   uint8_t* __restrict__ bitmap) {
+  const unsigned n = min((unsigned)offsets[min(*n_rows_p, cap)], cap_items);
   for (unsigned b = blockIdx.x * 256 + threadIdx.x; b * 8 < n; b += gridDim.x * 256) {
     unsigned v = 0;
     for (unsigned k = 0; k < 8 && b * 8 + k < n; ++k) v |= (unsigned)(flags[b * 8 + k] & 1) << k;

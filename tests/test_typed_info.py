@@ -189,6 +189,34 @@ def test_gpu_vcf_parser_list_valued_info(ctx, tmp_path):
 
 
 @pytest.mark.gpu
+def test_gpu_vcf_parser_comma_dense_list_is_handed_back_not_overrun(ctx):
+    """`AF=,,,,` is legal (every item is an EMPTY = NULL item) and holds one item per byte: more items than the device buffers,
+    sized for slab bytes / 2 + 1, can take.  The parser must report the slab as undecided (host decoder) WITHOUT writing past
+    its item-flag / bitmap buffers: a guard allocation made right after the parser's keeps its pattern, and a normal slab
+    parsed next on the same parser still decodes."""
+    lines = [b"1\t%d\t.\tA\tC\t1\tPASS\tAF=" % (i + 1) + b"," * 4000 + b"\n" for i in range(64)]
+    text = b"".join(lines)
+    cap = len(text) + 4096
+    par = exon_amd.VCFParser(ctx, ["1"], info_field="AF:F", max_slab_bytes=cap)
+    guard = ctx.to_device(np.full(1 << 20, 0xA5, np.uint8))
+    d = ctx.to_device(np.frombuffer(text + bytes(64), np.uint8))
+    cols = par.parse_device(d.ptr, len(text))
+    assert cols.n_rows == 64 and cols.n_undecided > 0                    # 64 x 4001 items > cap / 2 + 1
+    assert np.all(guard.to_host() == 0xA5)
+    few = b"".join(b"1\t%d\t.\tA\tC\t1\tPASS\tAF=,0.5,,\n" % (i + 1) for i in range(10))
+    d2 = ctx.to_device(np.frombuffer(few + bytes(64), np.uint8))
+    cols = par.parse_device(d2.ptr, len(few))
+    assert cols.n_rows == 10 and cols.n_undecided == 0
+    off = np.empty(11, np.int32)
+    ctx._check(ctx.lib.exon_hip_memcpy_d2h(ctx.h, off.ctypes.data, cols.list_offsets[0], off.nbytes, None))
+    assert off.tolist() == list(range(0, 44, 4))
+    bits = np.empty(5, np.uint8)
+    ctx._check(ctx.lib.exon_hip_memcpy_d2h(ctx.h, bits.ctypes.data, cols.list_item_valid[0], 5, None))
+    assert _bits(bits, 40).tolist() == [False, True, False, False] * 10
+    par.close()
+
+
+@pytest.mark.gpu
 def test_gpu_bcf_parser_list_valued_info(ctx, tmp_path):
     """The BCF twin of the test above: typed int8 / int16 / int32 / float vectors -> List<Int32> / List<Float32> on the device
     (missing value -> NULL item, one missing item -> NULL list), next to an exact Int32 scalar."""
