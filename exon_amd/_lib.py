@@ -165,6 +165,12 @@ SIGNATURES = {
     "exon_hip_stream_push_device": (C.c_int, [_vp, C.POINTER(ArrowDeviceArray)]),
     "exon_hip_stream_state": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "exon_hip_stream_all_reduce": (C.c_int, [_vp, _vp]),
+    "exon_hip_stream_keys": (C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(_i32), C.POINTER(C.c_size_t), C.POINTER(_i32)]),
+    "exon_hip_stream_set_keys": (C.c_int, [_vp, C.c_char_p, C.c_size_t, _i32]),
+    "exon_hip_keys_union": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(_i32), _i32, _vp, C.c_size_t, C.POINTER(_i32),
+                                      C.POINTER(C.c_size_t), C.POINTER(_i32)]),
+    "exon_hip_stream_reconcile_keys": (C.c_int, [_vp, _vp]),
+    "exon_hip_stream_set_region_contig": (C.c_int, [_vp, C.c_char_p]),
     "exon_hip_stream_sync": (C.c_int, [_vp]),
     "exon_hip_stream_finish": (C.c_int, [_vp, _vp, _vp]),
     "exon_hip_stream_finish_arrow": (C.c_int, [_vp, C.POINTER(ArrowArray), C.POINTER(ArrowSchema)]),

@@ -85,6 +85,13 @@ hipError_t launch_region_mask(hipStream_t s, bool range_form, const int32_t* id_
 // out[v] = sum over ranks (rank order) of gathered[rank][v]; words [0, n_i64) int64, then n_f64 float64
 hipError_t launch_fold_states(hipStream_t s, const void* gathered, int world, int64_t n_i64, int64_t n_f64, void* out);
 
+// Re-keying of a packed partial state: dst[plane][map[g]] += src[plane][g] for every keyed plane (`planes_i64` int64 planes of G
+// words, then `tail_i64` unkeyed int64 words that are added in place -- K3's NULL-reference group --, then `planes_f64` float64
+// planes of G words); map[g] < 0: key g carries nothing and is skipped.  Used when the dictionary ids of one scan / one rank
+// are brought into the order of a shared key dictionary (merge by key VALUE, not by id).
+hipError_t launch_permute_add_state(hipStream_t s, const void* src, void* dst, const int32_t* map, int n_map, int G, int planes_i64,
+                                    int tail_i64, int planes_f64);
+
 hipError_t launch_gen_c2(hipStream_t s, uint64_t seed, int64_t n_total, int64_t lo, int64_t hi, int32_t* chrom,
                          int64_t* pos);
 hipError_t launch_gen_c3(hipStream_t s, uint64_t seed, int64_t lo, int64_t hi, int32_t* flag, uint8_t* mapq,

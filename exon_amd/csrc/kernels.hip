@@ -316,6 +316,43 @@ hipError_t launch_fold_states(hipStream_t s, const void* gathered, int world, in
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// permute_add_state: bring a packed partial state keyed by one dictionary's ids into the id order of another.
+// One thread per source key; targets are distinct unless a dictionary repeats a name (then the adds to the shared target
+// are atomic: counts stay exact).  Layout: [planes_i64 x G int64][tail_i64 int64][planes_f64 x G float64].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void permute_add_state(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst,
+                                                         const int32_t* __restrict__ map, int n_map, int G, int planes_i64, int tail_i64,
+                                                         int planes_f64) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g < tail_i64) {
+    const size_t w = (size_t)planes_i64 * G + g;
+    if (src[w]) atomicAdd(&dst[w], src[w]);
+  }
+  if (g >= n_map || g >= G) return;
+  const int t = map[g];
+  if (t < 0 || t >= G) return;
+  for (int p = 0; p < planes_i64; ++p) {
+    const unsigned long long v = src[(size_t)p * G + g];
+    if (v) atomicAdd(&dst[(size_t)p * G + t], v);
+  }
+  const size_t fbase = (size_t)planes_i64 * G + tail_i64;
+  for (int p = 0; p < planes_f64; ++p) {
+    const double v = __longlong_as_double((long long)src[fbase + (size_t)p * G + g]);
+    if (v != 0.0) atomicAdd(reinterpret_cast<double*>(dst) + fbase + (size_t)p * G + t, v);
+  }
+}
+
+hipError_t launch_permute_add_state(hipStream_t s, const void* src, void* dst, const int32_t* map, int n_map, int G, int planes_i64,
+                                    int tail_i64, int planes_f64) {
+  if (G < 0 || n_map < 0 || planes_i64 < 0 || planes_f64 < 0 || tail_i64 < 0) return hipErrorInvalidValue;
+  const int threads = std::max(std::min(n_map, G), tail_i64);
+  if (threads == 0) return hipSuccess;
+  hipLaunchKernelGGL(permute_add_state, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, static_cast<const unsigned long long*>(src),
+                     static_cast<unsigned long long*>(dst), map, n_map, G, planes_i64, tail_i64, planes_f64);
+  return hipGetLastError();
+}
+
 // resident workgroups per CU of kernel `f` (the persistent grid must not exceed what is co-resident,
 // otherwise the surplus workgroups run as a second, badly balanced round)
 template <typename F>

@@ -64,6 +64,11 @@ void* exon_hip_stream_hip_stream(exon_hip_stream* st);
 exon_hip_ctx* exon_hip_stream_ctx(exon_hip_stream* st);
 int exon_hip_stream_state_copy(exon_hip_stream* st, void* d_snapshot, bool restore, int64_t* rows_pushed);
 size_t exon_hip_stream_state_bytes(exon_hip_stream* st);
+bool exon_hip_stream_is_keyed(exon_hip_stream* st);
+int exon_hip_stream_begin_scan(exon_hip_stream* st, bool* tracked, bool* redirected);
+int exon_hip_stream_end_scan(exon_hip_stream* st, const std::vector<std::string>* scan_keys, bool tracked, bool redirected, bool ok);
+bool exon_hip_stream_region_contig(exon_hip_stream* st, std::string* name);
+void exon_hip_stream_set_region_id(exon_hip_stream* st, int32_t id);
 
 // BGZF inputs of GPU-parsed scans are inflated on the GPU too (EXON_HIP_GPU_INFLATE=0: host threads inflate)
 static bool gpu_inflate_enabled() {
@@ -1267,8 +1272,41 @@ int exon_hip_scan_decoded_on_gpu(exon_hip_scan* scan, int32_t* decoded, int32_t*
   return EXON_HIP_OK;
 }
 
+static int consume_scan_impl(exon_hip_stream* st, exon_hip_scan* scan, int64_t* rows);
+
+// column of the scan that holds the contig / reference dictionary a region is named in
+static int region_dict_column(const exon_hip_scan* s) {
+  return (s->format == EXON_HIP_FORMAT_VCF || s->format == EXON_HIP_FORMAT_BCF) ? 0 : 2;
+}
+
 int exon_hip_stream_consume_scan(exon_hip_stream* st, exon_hip_scan* scan, int64_t* rows) {
   if (!st || !scan) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_stream_consume_scan: NULL argument");
+  // a region plan fed by files names its contig; every file numbers its contigs in its own header order
+  std::string contig;
+  if (exon_hip_stream_region_contig(st, &contig)) {
+    exon::Dictionary* d = dict_of(scan, region_dict_column(scan));
+    if (!d) return fail(exon_hip_stream_ctx(st), EXON_HIP_EINVAL, "this scan has no contig / reference dictionary to resolve '%s' in", contig.c_str());
+    const bool fixed = scan->format == EXON_HIP_FORMAT_BAM || scan->format == EXON_HIP_FORMAT_SAM || scan->format == EXON_HIP_FORMAT_CRAM;
+    int32_t id = d->find(contig);
+    if (id < 0 && !fixed) id = d->lookup_or_insert(contig.data(), contig.size());  // VCF text may name contigs its header lacks
+    exon_hip_stream_set_region_id(st, id < 0 ? -1 : id);  // -1: no reference of that name, no row matches
+  }
+  // group keys travel by VALUE: the scan's dictionary ids are re-keyed into the stream's (stream.cpp)
+  bool tracked = false, redirected = false;
+  int rc = exon_hip_stream_begin_scan(st, &tracked, &redirected);
+  if (rc) return rc;
+  rc = consume_scan_impl(st, scan, rows);
+  const std::vector<std::string>* keys = nullptr;
+  if (tracked) {
+    if (exon::Dictionary* d = dict_of(scan, exon_hip_stream_plan_column(st, 2))) keys = &d->names;
+  }
+  const int rc2 = exon_hip_stream_end_scan(st, keys, tracked, redirected, rc == EXON_HIP_OK);
+  return rc ? rc : rc2;
+}
+
+}  // extern "C"
+
+static int consume_scan_impl(exon_hip_stream* st, exon_hip_scan* scan, int64_t* rows) {
   int64_t n = 0;
   // K4 over a VCF / BCF scan: the compared column and AVG's argument may be typed INFO fields (scan columns 4 ..), whose
   // type the FILE's header decides: Type=Integer -> Int32 values, compared / averaged as integers (schema_builder.rs:197-205)
@@ -1369,5 +1407,3 @@ int exon_hip_stream_consume_scan(exon_hip_stream* st, exon_hip_scan* scan, int64
   if (rows) *rows = n;
   return EXON_HIP_OK;
 }
-
-}  // extern "C"

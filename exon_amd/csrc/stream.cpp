@@ -22,7 +22,9 @@
 #include <deque>
 #include <mutex>
 #include <new>
+#include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "host/arrow_build.h"
@@ -79,7 +81,37 @@ struct exon_hip_stream {
   int x_type = -1, y_type = -1; // K4 fed by a scan: the INFO fields' types from the file's header (-1: the plan's)
   uint8_t* d_gather = nullptr;  // [world][state words] receive buffer of the all-gather merge
   size_t gather_bytes = 0;
+  // ---- group keys by VALUE (ABI 4).  A plan that groups by a dictionary-encoded key (K3 reference, K4 filter) indexes its
+  // state by dictionary id; ids are per file (FILTER lists are numbered in order of first appearance, @SQ order differs between
+  // BAMs), so a stream that consumes scans remembers which key VALUE each state index stands for, re-keys every further scan
+  // into that order, and refuses a cross-rank merge until the ranks have agreed on one dictionary (AggregateExec(Final) merges
+  // by key value: SURVEY section 8e "dictionaries identical across shards, else union").
+  std::vector<std::string> keys;  // keys[g] = value of state index g
+  int keys_state = 0;             // KEYS_NONE: ids are the caller's business; KEYS_LOCAL: from scans, this rank only; KEYS_AGREED
+  uint8_t* d_rekey_state = nullptr;  // scratch state of the scan being consumed / of a reorder
+  int32_t* d_map = nullptr;
+  size_t map_cap = 0;
+  uint8_t* saved_state = nullptr;  // the real state while a scan writes into d_rekey_state
+  bool saved_overwrite = false;
+  // region plans (K2 / K6 / K7) over files: the contig is resolved by NAME in every scan's own dictionary
+  std::string region_contig;
+  bool has_region_contig = false;
+  int32_t region_id_override = INT32_MIN;
 };
+enum { KEYS_NONE = 0, KEYS_LOCAL = 1, KEYS_AGREED = 2 };
+
+// keyed layout of a plan's packed state: [planes_i x G int64][tail int64][planes_f x G float64]
+static bool key_layout(const exon_hip_plan* p, int* G, int* planes_i, int* tail, int* planes_f) {
+  switch (p->d.kind) {
+    case EXON_HIP_PLAN_FLAG_MAPQ_GROUP_COUNT:  // count[R] + the NULL-reference group
+      *G = p->d.n_groups, *planes_i = 1, *tail = 1, *planes_f = 0;
+      return true;
+    case EXON_HIP_PLAN_CMP_AVG_BY_GROUP:  // count(y)[G], count(*)[G], sum(y)[G]
+      *G = p->d.n_groups, *planes_i = 2, *tail = 0, *planes_f = 1;
+      return true;
+  }
+  return false;
+}
 
 // ---- staging copies on several cores -----------------------------------------------------------------------------------
 // One thread copies into pinned memory at ~10-12 GB/s, a fifth of what PCIe Gen5 takes; the staging copy of a large batch is
@@ -244,8 +276,9 @@ static int alloc_slot(exon_hip_stream* st, Slot& s) {
 // launch the plan's kernel over device columns (operator argument order) into the packed state [n_i64][n_f64]
 // x_type / y_type: EXON_HIP_X_* of K4's compared column / AVG argument, or -1 = what the plan says
 static int run_plan(const exon_hip_plan* p, void* stream, const exon_hip_column* cols, int64_t n, int flags, void* d_state, int x_type = -1,
-                    int y_type = -1) {
-  const exon_hip_plan_desc& d = p->d;
+                    int y_type = -1, int32_t region_id = INT32_MIN) {
+  exon_hip_plan_desc d = p->d;
+  if (region_id != INT32_MIN) d.region_chrom_id = region_id;
   if (x_type < 0) x_type = d.x_type;
   if (y_type < 0) y_type = d.y_type;
   if (x_type == EXON_HIP_X_INT32) flags |= EXON_LAUNCH_X_INT32;
@@ -274,7 +307,7 @@ static int run_plan(const exon_hip_plan* p, void* stream, const exon_hip_column*
 }
 static int launch_plan(exon_hip_stream* st, const exon_hip_column* cols, int64_t n) {
   const int flags = st->overwrite_next ? EXON_HIP_LAUNCH_OVERWRITE : EXON_HIP_LAUNCH_ACCUMULATE;
-  int rc = run_plan(st->plan, st->stream, cols, n, flags, st->d_state, st->x_type, st->y_type);
+  int rc = run_plan(st->plan, st->stream, cols, n, flags, st->d_state, st->x_type, st->y_type, st->region_id_override);
   if (!rc) st->overwrite_next = false;
   return rc;
 }
@@ -718,6 +751,111 @@ int exon_hip_stream_state(exon_hip_stream* st, int64_t** d_i64, double** d_f64, 
 
 }  // extern "C"
 
+
+// ---- group keys by value: internal machinery ------------------------------------------------------------------------------
+static size_t state_bytes_of(const exon_hip_stream* st) { return (size_t)(st->plan->n_i64 + st->plan->n_f64) * 8; }
+
+static int ensure_rekey_buffers(exon_hip_stream* st, size_t map_entries) {
+  if (!st->d_rekey_state && hipMalloc((void**)&st->d_rekey_state, std::max<size_t>(state_bytes_of(st), 16)) != hipSuccess)
+    return fail(st->ctx, EXON_HIP_ENOMEM, "re-keying scratch state of %zu bytes", state_bytes_of(st));
+  if (st->map_cap < map_entries) {
+    if (st->d_map) hipFree(st->d_map);
+    st->d_map = nullptr;
+    st->map_cap = 0;
+    if (hipMalloc((void**)&st->d_map, std::max<size_t>(map_entries, 64) * 4) != hipSuccess)
+      return fail(st->ctx, EXON_HIP_ENOMEM, "re-keying map of %zu entries", map_entries);
+    st->map_cap = std::max<size_t>(map_entries, 64);
+  }
+  return EXON_HIP_OK;
+}
+
+// dst += src with src's index g landing on map[g]; synchronises the stream (the map is staged from pageable memory)
+static int permute_add(exon_hip_stream* st, const uint8_t* src, uint8_t* dst, const std::vector<int32_t>& map) {
+  int G = 0, pi = 0, tail = 0, pf = 0;
+  if (!key_layout(st->plan, &G, &pi, &tail, &pf)) return fail(st->ctx, EXON_HIP_EINVAL, "this plan has no group keys");
+  int rc = ensure_rekey_buffers(st, map.size());
+  if (rc) return rc;
+  if (!map.empty()) HIP_TRY(st->ctx, hipMemcpyAsync(st->d_map, map.data(), map.size() * 4, hipMemcpyHostToDevice, st->stream));
+  HIP_TRY(st->ctx, exon::launch_permute_add_state(st->stream, src, dst, st->d_map, (int)map.size(), G, pi, tail, pf));
+  HIP_TRY(st->ctx, hipStreamSynchronize(st->stream));
+  return EXON_HIP_OK;
+}
+
+// Internal (scan.cpp): bracket one consumed scan.  begin: when the stream's state is already keyed by earlier scans (or by an
+// agreed dictionary), the scan's kernels write into a scratch state under the SCAN's ids; end: the scan's dictionary is
+// interned into the stream's, and the scratch state is added into the real one under the stream's ids.
+bool exon_hip_stream_is_keyed(exon_hip_stream* st) {
+  int G, a, b, c;
+  return key_layout(st->plan, &G, &a, &b, &c);
+}
+int exon_hip_stream_begin_scan(exon_hip_stream* st, bool* tracked, bool* redirected) {
+  *tracked = *redirected = false;
+  if (!exon_hip_stream_is_keyed(st)) return EXON_HIP_OK;
+  int rc = flush_slot(st);
+  if (rc) return rc;
+  if (st->keys_state == KEYS_NONE) {
+    // rows pushed earlier came with the caller's own ids: the stream cannot know their values and keeps out of it
+    *tracked = st->rows_pushed == 0;
+    return EXON_HIP_OK;
+  }
+  *tracked = true;
+  rc = settle_reset(st);
+  if (!rc) rc = ensure_rekey_buffers(st, 0);
+  if (rc) return rc;
+  st->saved_state = st->d_state;
+  st->saved_overwrite = st->overwrite_next;
+  st->d_state = st->d_rekey_state;
+  st->overwrite_next = true;  // the first launch of the scan defines the scratch state
+  *redirected = true;
+  return EXON_HIP_OK;
+}
+int exon_hip_stream_end_scan(exon_hip_stream* st, const std::vector<std::string>* scan_keys, bool tracked, bool redirected, bool ok) {
+  int rc = EXON_HIP_OK;
+  if (redirected) {
+    rc = flush_slot(st);
+    if (!rc) rc = settle_reset(st);  // a scan that launched nothing leaves an all-zero scratch state
+    st->d_state = st->saved_state;
+    st->overwrite_next = st->saved_overwrite;
+    st->saved_state = nullptr;
+  }
+  if (rc || !ok || !tracked) return rc;
+  int G = 0, pi, tail, pf;
+  key_layout(st->plan, &G, &pi, &tail, &pf);
+  if (!scan_keys) {  // the key column of this scan is not dictionary-encoded: nothing to re-key by
+    if (redirected) return fail(st->ctx, EXON_HIP_EUNSUPPORTED, "the stream is keyed by value but this scan's group column has no dictionary");
+    return EXON_HIP_OK;
+  }
+  if ((int64_t)scan_keys->size() > G)
+    return fail(st->ctx, EXON_HIP_EINVAL, "the scan's group-key dictionary has %zu entries, the plan was created for n_groups = %d", scan_keys->size(), G);
+  if (!redirected) {  // first scan of the stream: its ids ARE the stream's
+    st->keys = *scan_keys;
+    st->keys_state = KEYS_LOCAL;
+    return EXON_HIP_OK;
+  }
+  std::vector<int32_t> map(scan_keys->size());
+  std::unordered_map<std::string, int32_t> index;
+  for (size_t i = 0; i < st->keys.size(); ++i) index.emplace(st->keys[i], (int32_t)i);  // first occurrence wins
+  for (size_t i = 0; i < scan_keys->size(); ++i) {
+    auto it = index.find((*scan_keys)[i]);
+    if (it == index.end()) {
+      if ((int64_t)st->keys.size() >= G)
+        return fail(st->ctx, EXON_HIP_EINVAL, "the scans' group keys hold more than the %d distinct values the plan was created for (n_groups)", G);
+      it = index.emplace((*scan_keys)[i], (int32_t)st->keys.size()).first;
+      st->keys.push_back((*scan_keys)[i]);
+    }
+    map[i] = it->second;
+  }
+  st->keys_state = KEYS_LOCAL;
+  return permute_add(st, st->d_rekey_state, st->d_state, map);
+}
+// region plans over files: the stream's contig NAME (exon_hip_stream_set_region_contig) -> this scan's dictionary id
+bool exon_hip_stream_region_contig(exon_hip_stream* st, std::string* name) {
+  if (!st->has_region_contig) return false;
+  *name = st->region_contig;
+  return true;
+}
+void exon_hip_stream_set_region_id(exon_hip_stream* st, int32_t id) { st->region_id_override = id; }
+
 // ---- RCCL (loaded on first use: hosts that never merge across GPUs -- and machines without RCCL -- do not need it) ----
 namespace {
 struct Rccl {
@@ -840,6 +978,10 @@ int exon_hip_merge_states(exon_hip_ctx* ctx, void* stream, void* rccl_comm, void
 int exon_hip_stream_all_reduce(exon_hip_stream* st, void* rccl_comm) {
   if (!st || !rccl_comm) return fail(st ? st->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_stream_all_reduce: NULL argument");
   if (st->closed) return fail(st->ctx, EXON_HIP_ESTATE, "all_reduce after finish/close");
+  if (st->keys_state == KEYS_LOCAL)  // ids of file-derived keys are per rank: adding states by id would merge different groups
+    return fail(st->ctx, EXON_HIP_ESTATE,
+                "the state is keyed by this rank's own dictionary (%zu keys from its scans): call exon_hip_stream_reconcile_keys "
+                "(or exon_hip_stream_set_keys with the agreed dictionary) on every rank before the merge", st->keys.size());
   if (!rccl().ok()) return fail(st->ctx, EXON_HIP_EUNSUPPORTED, "librccl.so could not be loaded");
   int rc = flush_slot(st);
   if (!rc) rc = settle_reset(st);
@@ -865,6 +1007,192 @@ int exon_hip_stream_all_reduce(exon_hip_stream* st, void* rccl_comm) {
   return exon_hip_merge_states(st->ctx, st->stream, rccl_comm, st->d_state, p->n_i64, p->n_f64, st->d_gather, st->d_state);
 }
 
+// ---- group keys by value: the C ABI (include/exon_hip.h "group keys") ---------------------------------------------------------
+// '\0'-terminated names back to back -> vector; false when the buffer ends before n names do
+static bool unpack_names(const char* packed, size_t bytes, int32_t n, std::vector<std::string>* out) {
+  size_t o = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    const void* z = o < bytes ? memchr(packed + o, 0, bytes - o) : nullptr;
+    if (!z) return false;
+    const size_t len = (size_t)(static_cast<const char*>(z) - (packed + o));
+    out->emplace_back(packed + o, len);
+    o += len + 1;
+  }
+  return true;
+}
+static size_t packed_size(const std::vector<std::string>& names) {
+  size_t b = 0;
+  for (const auto& k : names) b += k.size() + 1;
+  return b;
+}
+static void pack_names(const std::vector<std::string>& names, char* out) {
+  for (const auto& k : names) {
+    memcpy(out, k.data(), k.size());
+    out[k.size()] = 0;
+    out += k.size() + 1;
+  }
+}
+// union of `world` dictionaries in rank order, first appearance first (rank 0's keys keep their ids: its frequent keys stay
+// early, where the kernels keep them in registers); maps (optional): union id of every input key, rank-major
+static void union_in_rank_order(const std::vector<std::vector<std::string>>& dicts, std::vector<std::string>* uni, std::vector<int32_t>* maps) {
+  std::unordered_map<std::string, int32_t> index;
+  for (const auto& d : dicts)
+    for (const auto& k : d) {
+      auto it = index.find(k);
+      if (it == index.end()) {
+        it = index.emplace(k, (int32_t)uni->size()).first;
+        uni->push_back(k);
+      }
+      if (maps) maps->push_back(it->second);
+    }
+}
+
+int exon_hip_keys_union(const char* packed, size_t packed_bytes, const int32_t* n_keys, int32_t world, char* out, size_t cap,
+                        int32_t* n_out, size_t* out_bytes, int32_t* maps) {
+  if ((!packed && packed_bytes) || !n_keys || world < 1 || !n_out || !out_bytes) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_keys_union: bad argument");
+  std::vector<std::vector<std::string>> dicts((size_t)world);
+  size_t o = 0;
+  for (int32_t r = 0; r < world; ++r) {
+    if (n_keys[r] < 0) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_keys_union: n_keys[%d] < 0", r);
+    if (!unpack_names(packed + o, packed_bytes - o, n_keys[r], &dicts[(size_t)r]))
+      return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_keys_union: the packed names end before rank %d's %d keys do", r, n_keys[r]);
+    o += packed_size(dicts[(size_t)r]);
+  }
+  std::vector<std::string> uni;
+  std::vector<int32_t> m;
+  union_in_rank_order(dicts, &uni, maps ? &m : nullptr);
+  *n_out = (int32_t)uni.size();
+  *out_bytes = packed_size(uni);
+  if (maps) memcpy(maps, m.data(), m.size() * 4);
+  if (out) {
+    if (cap < *out_bytes) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_keys_union: output needs %zu bytes, %zu given", *out_bytes, cap);
+    pack_names(uni, out);
+  }
+  return EXON_HIP_OK;
+}
+
+int exon_hip_stream_keys(exon_hip_stream* st, char* buf, size_t cap, int32_t* n_keys, size_t* bytes, int32_t* agreed) {
+  if (!st || !n_keys || !bytes) return fail(st ? st->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_stream_keys: NULL argument");
+  *n_keys = (int32_t)st->keys.size();
+  *bytes = packed_size(st->keys);
+  if (agreed) *agreed = st->keys_state == KEYS_AGREED ? 1 : 0;
+  if (buf) {
+    if (cap < *bytes) return fail(st->ctx, EXON_HIP_EINVAL, "exon_hip_stream_keys: the names need %zu bytes, %zu given", *bytes, cap);
+    pack_names(st->keys, buf);
+  }
+  return EXON_HIP_OK;
+}
+
+// adopt `names` as the stream's dictionary: state index g stands for names[g] afterwards.  A stream without keys takes the
+// names as a declaration of what its ids mean; a keyed stream must find every key it holds in `names` and has its state
+// permuted into the new order.
+static int adopt_keys(exon_hip_stream* st, const std::vector<std::string>& names) {
+  int G = 0, pi, tail, pf;
+  if (!key_layout(st->plan, &G, &pi, &tail, &pf)) return fail(st->ctx, EXON_HIP_EINVAL, "this plan does not group by a key");
+  if ((int64_t)names.size() > G)
+    return fail(st->ctx, EXON_HIP_EINVAL, "%zu group keys do not fit the plan's n_groups = %d (create the plan for the union's size)", names.size(), G);
+  {
+    std::unordered_map<std::string, int> seen;
+    for (const auto& k : names)
+      if (!seen.emplace(k, 0).second) return fail(st->ctx, EXON_HIP_EINVAL, "group key '%s' appears twice in the dictionary", k.c_str());
+  }
+  if (st->keys_state != KEYS_NONE && !st->keys.empty()) {
+    std::unordered_map<std::string, int32_t> index;
+    for (size_t i = 0; i < names.size(); ++i) index.emplace(names[i], (int32_t)i);
+    std::vector<int32_t> map(st->keys.size());
+    bool identity = true;
+    for (size_t i = 0; i < st->keys.size(); ++i) {
+      auto it = index.find(st->keys[i]);
+      if (it == index.end()) return fail(st->ctx, EXON_HIP_EINVAL, "the new dictionary lacks the key '%s' this stream holds rows for", st->keys[i].c_str());
+      map[i] = it->second;
+      identity = identity && map[i] == (int32_t)i;
+    }
+    if (!identity) {
+      int rc = flush_slot(st);
+      if (!rc) rc = settle_reset(st);
+      if (!rc) rc = ensure_rekey_buffers(st, map.size());
+      if (rc) return rc;
+      const size_t sb = state_bytes_of(st);
+      HIP_TRY(st->ctx, hipMemsetAsync(st->d_rekey_state, 0, sb, st->stream));
+      rc = permute_add(st, st->d_state, st->d_rekey_state, map);
+      if (rc) return rc;
+      HIP_TRY(st->ctx, hipMemcpyAsync(st->d_state, st->d_rekey_state, sb, hipMemcpyDeviceToDevice, st->stream));
+    }
+  }
+  st->keys = names;
+  st->keys_state = KEYS_AGREED;
+  return EXON_HIP_OK;
+}
+
+int exon_hip_stream_set_keys(exon_hip_stream* st, const char* packed, size_t packed_bytes, int32_t n_keys) {
+  if (!st || (!packed && n_keys) || n_keys < 0) return fail(st ? st->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_stream_set_keys: bad argument");
+  if (st->closed) return fail(st->ctx, EXON_HIP_ESTATE, "set_keys after finish/close");
+  std::vector<std::string> names;
+  if (!unpack_names(packed, packed_bytes, n_keys, &names)) return fail(st->ctx, EXON_HIP_EINVAL, "exon_hip_stream_set_keys: the packed names end before %d keys do", n_keys);
+  return adopt_keys(st, names);
+}
+
+int exon_hip_stream_set_region_contig(exon_hip_stream* st, const char* name) {
+  if (!st || !name) return fail(st ? st->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_stream_set_region_contig: NULL argument");
+  const int k = st->plan->d.kind;
+  if (k != EXON_HIP_PLAN_REGION_COUNT && k != EXON_HIP_PLAN_OVERLAP_COUNT && k != EXON_HIP_PLAN_WITHIN_COUNT)
+    return fail(st->ctx, EXON_HIP_EINVAL, "plan kind %d has no region", k);
+  st->region_contig = name;
+  st->has_region_contig = true;
+  return EXON_HIP_OK;
+}
+
+// The ranks of `rccl_comm` agree on ONE dictionary: two small all-gathers (sizes, then the packed names padded to the longest),
+// the union in rank order on every rank, each state permuted into it.  Collective: every rank must call it.
+int exon_hip_stream_reconcile_keys(exon_hip_stream* st, void* rccl_comm) {
+  if (!st || !rccl_comm) return fail(st ? st->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_stream_reconcile_keys: NULL argument");
+  if (st->closed) return fail(st->ctx, EXON_HIP_ESTATE, "reconcile_keys after finish/close");
+  if (!exon_hip_stream_is_keyed(st)) return EXON_HIP_OK;  // plans without group keys have nothing to agree on
+  if (st->keys_state == KEYS_NONE && st->rows_pushed > 0)
+    return fail(st->ctx, EXON_HIP_ESTATE, "this stream's rows were pushed with the caller's own dictionary ids: declare their values with exon_hip_stream_set_keys");
+  if (!rccl().ok()) return fail(st->ctx, EXON_HIP_EUNSUPPORTED, "librccl.so could not be loaded");
+  int world = 0, rank = 0;
+  int e = rccl().comm_count(rccl_comm, &world);
+  if (!e) e = rccl().comm_rank(rccl_comm, &rank);
+  if (e || world < 1) return fail(st->ctx, EXON_HIP_EDEVICE, "ncclCommCount / ncclCommUserRank failed with ncclResult_t %d", e);
+  hipSetDevice(st->ctx->device);
+  // (1) sizes
+  int64_t mine[2] = {(int64_t)st->keys.size(), (int64_t)packed_size(st->keys)};
+  int64_t* d_sz = nullptr;
+  HIP_TRY(st->ctx, hipMalloc((void**)&d_sz, (size_t)(world + 1) * 16));
+  std::vector<int64_t> sizes((size_t)world * 2);
+  hipError_t he = hipMemcpyAsync(d_sz + 2 * world, mine, 16, hipMemcpyHostToDevice, st->stream);
+  if (he == hipSuccess) e = rccl().all_gather(d_sz + 2 * world, d_sz, 2, NCCL_INT64, rccl_comm, st->stream);
+  if (he == hipSuccess && !e) he = hipMemcpyAsync(sizes.data(), d_sz, (size_t)world * 16, hipMemcpyDeviceToHost, st->stream);
+  if (he == hipSuccess && !e) he = hipStreamSynchronize(st->stream);
+  hipFree(d_sz);
+  if (e) return fail(st->ctx, EXON_HIP_EDEVICE, "ncclAllGather (key dictionary sizes) failed with ncclResult_t %d", e);
+  if (he != hipSuccess) return fail(st->ctx, EXON_HIP_EDEVICE, "key dictionary sizes: %s", hipGetErrorString(he));
+  size_t slot = 8;
+  for (int r = 0; r < world; ++r) slot = std::max(slot, (size_t)sizes[(size_t)r * 2 + 1]);
+  slot = (slot + 7) / 8 * 8;
+  // (2) the packed names, one padded slot per rank
+  std::vector<char> all(slot * (size_t)world), own(slot, 0);
+  pack_names(st->keys, own.data());
+  char* d_txt = nullptr;
+  HIP_TRY(st->ctx, hipMalloc((void**)&d_txt, slot * (size_t)(world + 1)));
+  he = hipMemcpyAsync(d_txt + slot * (size_t)world, own.data(), slot, hipMemcpyHostToDevice, st->stream);
+  if (he == hipSuccess) e = rccl().all_gather(d_txt + slot * (size_t)world, d_txt, slot / 8, NCCL_INT64, rccl_comm, st->stream);
+  if (he == hipSuccess && !e) he = hipMemcpyAsync(all.data(), d_txt, all.size(), hipMemcpyDeviceToHost, st->stream);
+  if (he == hipSuccess && !e) he = hipStreamSynchronize(st->stream);
+  hipFree(d_txt);
+  if (e) return fail(st->ctx, EXON_HIP_EDEVICE, "ncclAllGather (key dictionaries) failed with ncclResult_t %d", e);
+  if (he != hipSuccess) return fail(st->ctx, EXON_HIP_EDEVICE, "key dictionaries: %s", hipGetErrorString(he));
+  std::vector<std::vector<std::string>> dicts((size_t)world);
+  for (int r = 0; r < world; ++r)
+    if (!unpack_names(all.data() + slot * (size_t)r, (size_t)sizes[(size_t)r * 2 + 1], (int32_t)sizes[(size_t)r * 2], &dicts[(size_t)r]))
+      return fail(st->ctx, EXON_HIP_EINVAL, "rank %d sent a malformed key dictionary", r);
+  std::vector<std::string> uni;
+  union_in_rank_order(dicts, &uni, nullptr);
+  if (st->keys_state == KEYS_NONE) st->keys_state = KEYS_LOCAL;  // a rank that scanned nothing holds an empty dictionary
+  return adopt_keys(st, uni);
+}
+
 // The next launch on this stream defines the state instead of adding to it: a new query on the same stream without a
 // zeroing kernel (finalize writes in overwrite mode).  Rows staged but not yet launched belong to the old query and are
 // dropped with it.
@@ -883,6 +1211,8 @@ int exon_hip_stream_reset(exon_hip_stream* st) {
   st->overwrite_next = true;
   st->closed = false;
   st->rows_pushed = 0;
+  st->keys.clear();  // a new query: its scans define the key dictionary afresh
+  st->keys_state = KEYS_NONE;
   return EXON_HIP_OK;
 }
 
@@ -1051,6 +1381,8 @@ int exon_hip_stream_close(exon_hip_stream* st) {
   }
   if (st->d_state) hipFree(st->d_state);
   if (st->d_gather) hipFree(st->d_gather);
+  if (st->d_rekey_state) hipFree(st->d_rekey_state);
+  if (st->d_map) hipFree(st->d_map);
   if (st->stream) hipStreamDestroy(st->stream);
   delete st;
   return EXON_HIP_OK;

@@ -15,6 +15,8 @@ library may pick (an all-reduce's association order is the library's business). 
 import ctypes as C
 import os
 
+from ._lib import PLAN_CMP_AVG_BY_GROUP as L_PLAN_K4, PLAN_FLAG_MAPQ_GROUP_COUNT as L_PLAN_K3
+
 
 def env_world():
     """(rank, local_rank, world_size) from the torch.distributed.run environment."""
@@ -87,6 +89,125 @@ def merge_state(state, n_i64, gathered=None, out=None, group=None, ctx=None):
     else:
         dist.all_gather_into_tensor(gathered, state, group=group)
     return fold_states(gathered, world, n_i64, out, ctx=ctx)
+
+
+# ---- group keys by VALUE across ranks ("dictionaries identical across shards, else union") -----------------
+# A K3 / K4 state is indexed by dictionary id and ids are per file (FILTER lists: order of first appearance; references: each
+# BAM's @SQ order).  Before the states of different ranks may be added index by index, the ranks agree on ONE dictionary -- the
+# union in rank order -- and every rank permutes its state into it.  The reference gets the same result from
+# AggregateExec(Final), which merges the partitions' partial states by key value.
+
+def state_layout(kind, n_groups):
+    """(G, planes_i64, tail_i64, planes_f64) of a plan's packed state, as exon_hip_stream_set_keys lays it out:
+    [planes_i64 x G int64][tail_i64 int64 (K3: the NULL-reference group)][planes_f64 x G float64]."""
+    from ._lib import PLAN_CMP_AVG_BY_GROUP, PLAN_FLAG_MAPQ_GROUP_COUNT
+    if kind == PLAN_FLAG_MAPQ_GROUP_COUNT:
+        return n_groups, 1, 1, 0
+    if kind == PLAN_CMP_AVG_BY_GROUP:
+        return n_groups, 2, 0, 1
+    raise ValueError(f"plan kind {kind} has no group keys")
+
+
+def permute_state(state, layout, mapping):
+    """CPU statement of the device re-keying (launch_permute_add_state): a packed int64-typed host tensor keyed by local
+    ids -> the same state under the ids `mapping[local]`.  Host tensors only -- tests and gloo launchers hold those; a
+    device-resident state is permuted by exon_hip_stream_set_keys."""
+    import torch
+    if state.is_cuda:
+        raise RuntimeError("permute_state is the host form; a device state is re-keyed by Stream.set_keys (no torch fallback on the GPU)")
+    G, pi, tail, pf = layout
+    out = torch.zeros_like(state)
+    idx = torch.as_tensor(list(mapping), dtype=torch.int64)
+    src = torch.arange(len(idx))
+    for p in range(pi):
+        out[p * G:(p + 1) * G].index_add_(0, idx, state[p * G + src])
+    out[pi * G:pi * G + tail] = state[pi * G:pi * G + tail]
+    fb = pi * G + tail
+    for p in range(pf):
+        o = torch.zeros(G, dtype=torch.float64)
+        o.index_add_(0, idx, state[fb + p * G + src].view(torch.float64))
+        out[fb + p * G:fb + (p + 1) * G] = o.view(torch.int64)
+    return out
+
+
+def reconcile_keys(keys=None, state=None, layout=None, stream=None, group=None):
+    """Every rank of `group` ends up with the same dictionary (the union in rank order, first appearance first) and a state
+    keyed by it.  Stream form (`stream=`): the names travel through torch.distributed, the device state is permuted by
+    exon_hip_stream_set_keys.  Host form (`keys=, state=, layout=`): returns (union, permuted host tensor).  Collective."""
+    import torch.distributed as dist
+    from .engine import keys_union
+    if stream is not None:
+        keys, _ = stream.keys()
+    keys = list(keys)
+    if _initialised(group):
+        world = dist.get_world_size(group)
+        dicts = [None] * world
+        dist.all_gather_object(dicts, keys, group=group)
+        rank = dist.get_rank(group)
+    else:
+        dicts, rank = [keys], 0
+    union, maps = keys_union(dicts)
+    if stream is not None:
+        stream.set_keys(union)
+        return union
+    return union, permute_state(state, layout, maps[rank])
+
+
+def scan_files(ctx, paths, fmt, make_plan, rank=None, world=None, group=None, comm=None, region_contig=None, **scan_kw):
+    """A sharded file scan end to end, one process per GPU: the files are dealt by `regroup_files_by_size`
+    (exon-core/src/datasources/exon_file_scan_config.rs:79-110), this rank's files are consumed on the GPU into ONE stream
+    (keys by value: every file is re-keyed into the stream's dictionary), the ranks agree on the union dictionary, and the
+    states are merged -- natively over RCCL when `comm` (a NativeComm) is given, else through torch.distributed.
+    `make_plan(ctx)` builds the same plan on every rank (its n_groups = the capacity for distinct keys).
+    Returns {"keys", "counts", "sums", "rows", "files"} with counts / sums as host arrays, equal on every rank."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from .engine import Scan
+    if rank is None or world is None:
+        if _initialised(group):
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+        else:
+            rank, world = 0, 1
+    sizes = [os.path.getsize(p) for p in paths]
+    mine = shard_files(sizes, rank, world)
+    plan = make_plan(ctx)
+    stream = plan.open(rank)
+    rows = 0
+    try:
+        if region_contig is not None:
+            stream.set_region_contig(region_contig)
+        for i in mine:
+            scan = Scan(paths[i], fmt, gpu_parse=True, **scan_kw)
+            try:
+                rows += stream.consume(scan)
+            finally:
+                scan.close()
+        keyed = plan.desc.kind in (L_PLAN_K3, L_PLAN_K4)
+        if world > 1 and comm is not None:
+            if keyed:
+                stream.reconcile_keys(comm.h.value)
+            stream.all_reduce(comm.h.value)
+            counts, sums = stream.snapshot()
+        else:
+            if keyed and world > 1:
+                reconcile_keys(stream=stream, group=group)
+            counts, sums = stream.snapshot()
+            if world > 1:
+                state = torch.from_numpy(np.concatenate([counts, sums.view(np.int64)]))
+                merged = merge_state(state, len(counts), group=group).numpy()
+                counts, sums = merged[:len(counts)].copy(), merged[len(counts):].view(np.float64).copy()
+        keys = stream.keys()[0] if keyed else []
+        total_rows = rows
+        if world > 1 and _initialised(group):
+            dev = torch.device("cpu") if dist.get_backend(group) == "gloo" else torch.device("cuda", ctx.device)
+            t = torch.tensor([rows], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, group=group)
+            total_rows = int(t[0])
+        return {"keys": keys, "counts": counts, "sums": sums, "rows": total_rows, "files": [paths[i] for i in mine]}
+    finally:
+        stream.close()
+        plan.close()
 
 
 class NativeComm:

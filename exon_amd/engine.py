@@ -298,6 +298,38 @@ def index_query(index_path, region=None, ref_id=None, start=1, end=None, is_bai=
     return [(st[i], en[i]) for i in range(min(n.value, cap))]
 
 
+def pack_names(names):
+    """'\\0'-terminated names back to back (the wire form of a key dictionary in the C ABI)."""
+    return b"".join((n if isinstance(n, bytes) else n.encode()) + b"\0" for n in names)
+
+
+def unpack_names(packed, n):
+    parts = packed.split(b"\0")[:n]
+    return [p.decode(errors="replace") for p in parts]
+
+
+def keys_union(dicts):
+    """exon_hip_keys_union (host-only C): the union of the ranks' dictionaries in rank order, first appearance first.
+    Returns (union names, [per-rank list: union id of every local id])."""
+    lib = L.load()
+    packed = b"".join(pack_names(d) for d in dicts)
+    n_keys = (C.c_int32 * len(dicts))(*[len(d) for d in dicts])
+    n_out, nb = C.c_int32(), C.c_size_t()
+    maps = (C.c_int32 * max(1, sum(len(d) for d in dicts)))()
+    rc = lib.exon_hip_keys_union(packed, len(packed), n_keys, len(dicts), None, 0, C.byref(n_out), C.byref(nb), maps)
+    if rc:
+        raise ExonHipError(rc, lib.exon_hip_last_error(None).decode(errors="replace"))
+    buf = C.create_string_buffer(max(nb.value, 1))
+    rc = lib.exon_hip_keys_union(packed, len(packed), n_keys, len(dicts), buf, nb.value, C.byref(n_out), C.byref(nb), maps)
+    if rc:
+        raise ExonHipError(rc, lib.exon_hip_last_error(None).decode(errors="replace"))
+    out, o = [], 0
+    for d in dicts:
+        out.append(list(maps[o:o + len(d)]))
+        o += len(d)
+    return unpack_names(buf.raw[:nb.value], n_out.value), out
+
+
 def regroup_files_by_size(sizes, target_groups):
     """Whole-file round-robin repartition; returns a list of groups of ORIGINAL file indexes."""
     lib = L.load()
@@ -665,6 +697,42 @@ class Stream:
         """Merge of the partial state over the ranks of `rccl_comm` (an ncclComm_t as an integer) on the stream: one
         ncclAllGather + fixed-order fold; afterwards every rank's state is the sum over all ranks."""
         self.ctx._check(self.ctx.lib.exon_hip_stream_all_reduce(self.h, C.c_void_p(rccl_comm)))
+
+    # ---- group keys by value (ABI 4): what the state's indexes stand for when the rows came from files
+    def keys(self):
+        """(names in state-index order, agreed) -- the dictionary exon_hip_stream_consume_scan built up; `agreed` is True once
+        set_keys / reconcile_keys ran and no scan was consumed since."""
+        n, b, a = C.c_int32(), C.c_size_t(), C.c_int32()
+        self.ctx._check(self.ctx.lib.exon_hip_stream_keys(self.h, None, 0, C.byref(n), C.byref(b), C.byref(a)))
+        buf = C.create_string_buffer(max(b.value, 1))
+        self.ctx._check(self.ctx.lib.exon_hip_stream_keys(self.h, buf, b.value, C.byref(n), C.byref(b), C.byref(a)))
+        return unpack_names(buf.raw[:b.value], n.value), bool(a.value)
+
+    def set_keys(self, names):
+        """Adopt `names` as the dictionary (every key held must be among them): the device state is permuted into that order."""
+        packed = pack_names(names)
+        self.ctx._check(self.ctx.lib.exon_hip_stream_set_keys(self.h, packed, len(packed), len(names)))
+
+    def reconcile_keys(self, rccl_comm):
+        """Collective: the ranks of `rccl_comm` (an ncclComm_t as an integer) agree on the union dictionary, natively."""
+        self.ctx._check(self.ctx.lib.exon_hip_stream_reconcile_keys(self.h, C.c_void_p(rccl_comm)))
+
+    def set_region_contig(self, name):
+        """Region plans over files: the contig by name; every consumed file resolves it in its own header order."""
+        self.ctx._check(self.ctx.lib.exon_hip_stream_set_region_contig(self.h, name.encode()))
+
+    def snapshot(self):
+        """(counts, sums) of the state as it stands, without finishing the stream."""
+        a, b, s = self.state()
+        self.ctx._check(self.ctx.lib.exon_hip_sync(self.ctx.h, C.c_void_p(s)))
+        counts = np.zeros(self.plan.n_i64, np.int64)
+        sums = np.zeros(self.plan.n_f64, np.float64)
+        if counts.size:
+            self.ctx._check(self.ctx.lib.exon_hip_memcpy_d2h(self.ctx.h, _np_ptr(counts), C.c_void_p(a), counts.nbytes, None))
+        if sums.size:
+            self.ctx._check(self.ctx.lib.exon_hip_memcpy_d2h(self.ctx.h, _np_ptr(sums), C.c_void_p(b), sums.nbytes, None))
+        self.ctx.sync()
+        return counts, sums
 
     def reset(self):
         """New query on this stream: the next launch defines the state (overwrite mode, no zeroing kernel)."""

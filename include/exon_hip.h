@@ -107,7 +107,8 @@ typedef struct exon_hip_device_info {
   int32_t reserved;
 } exon_hip_device_info;
 
-int exon_hip_abi_version(void); /* 3 (round 3: plan_desc.x_type / y_type, 16 typed INFO fields with kinds, rccl_comm_count) */
+int exon_hip_abi_version(void); /* 4 (round 4: group keys by value -- exon_hip_stream_keys / _set_keys / _reconcile_keys, exon_hip_keys_union,
+                                      exon_hip_stream_set_region_contig; round 3: plan_desc.x_type / y_type, 16 typed INFO fields, rccl_comm_count) */
 int exon_hip_device_count(int* out);
 int exon_hip_ctx_create(int device, exon_hip_ctx** out);
 int exon_hip_ctx_destroy(exon_hip_ctx* ctx);
@@ -331,6 +332,36 @@ int exon_hip_stream_state(exon_hip_stream* s, int64_t** d_i64, double** d_f64, v
  * ranks.  One ncclAllGather + fixed-order fold (exon_hip_merge_states); `rccl_comm` is an ncclComm_t the host created (one
  * rank per GPU, e.g. exon_hip_rccl_comm_init). */
 int exon_hip_stream_all_reduce(exon_hip_stream* s, void* rccl_comm);
+/* ---- group keys by VALUE (ABI 4) --------------------------------------------------------------------------------------------
+ * K3 / K4 states are indexed by dictionary id, and ids are per FILE: FILTER lists are numbered in order of first appearance in
+ * a scan, reference ids follow each BAM's own @SQ order.  The reference merges partitions by key VALUE (AggregateExec(Final)
+ * over the file groups of exon-core/src/datasources/exon_file_scan_config.rs:79-110).  So a stream fed by
+ * exon_hip_stream_consume_scan remembers the value behind every state index: the first scan's dictionary becomes the stream's,
+ * every further scan is aggregated under its own ids and added in under the stream's (new values are appended; more distinct
+ * values than the plan's n_groups is EXON_HIP_EINVAL).  Across ranks, exon_hip_stream_all_reduce REFUSES (EXON_HIP_ESTATE) a
+ * state keyed by a rank-local dictionary until the ranks have agreed on one -- exon_hip_stream_reconcile_keys, or
+ * exon_hip_stream_keys on every rank + exon_hip_keys_union + exon_hip_stream_set_keys when the host moves the names itself.
+ * Names are packed as '\0'-terminated strings back to back ("" is a legal key: the empty FILTER list); K3's NULL-reference
+ * group is not a key (it stays the last word of the state).  Streams that are only ever pushed to (caller-owned dictionary
+ * ids) are not tracked; exon_hip_stream_set_keys lets such a caller declare what its ids mean. */
+/* the stream's dictionary in state-index order: *n_keys names, *bytes in all (buf may be NULL to size it);
+ * *agreed (optional) = 1 once set_keys / reconcile_keys has run and no scan was consumed since */
+int exon_hip_stream_keys(exon_hip_stream* s, char* buf, size_t cap, int32_t* n_keys, size_t* bytes, int32_t* agreed);
+/* adopt `names` (n_keys packed strings, no duplicates, at most the plan's n_groups): every key the stream holds must be among
+ * them; the state is permuted into the new order on the device.  On a stream without keys: a declaration / a seed. */
+int exon_hip_stream_set_keys(exon_hip_stream* s, const char* packed_names, size_t packed_bytes, int32_t n_keys);
+/* host-only: union of `world` dictionaries (packed back to back, n_keys[r] names each) in rank order, first appearance first --
+ * deterministic, so every rank computes the same.  out (may be NULL to size it) receives the packed union, maps (optional,
+ * sum of n_keys entries, rank-major) the union id of every input key. */
+int exon_hip_keys_union(const char* packed, size_t packed_bytes, const int32_t* n_keys, int32_t world, char* out, size_t cap,
+                        int32_t* n_out, size_t* out_bytes, int32_t* maps);
+/* collective over `rccl_comm` (every rank calls it, between its last consume_scan and exon_hip_stream_all_reduce): two small
+ * ncclAllGathers move the dictionaries, every rank forms the same union and permutes its state into it. */
+int exon_hip_stream_reconcile_keys(exon_hip_stream* s, void* rccl_comm);
+/* Region plans (K2 / K6 / K7) fed by files: name the contig instead of fixing exon_hip_plan_desc.region_chrom_id -- every
+ * exon_hip_stream_consume_scan then resolves the name in that file's own contig / reference dictionary (a BAM without such
+ * a reference contributes no rows). */
+int exon_hip_stream_set_region_contig(exon_hip_stream* s, const char* name);
 /* Start a new query on this stream: the next launch DEFINES the state (overwrite mode, no zeroing kernel); rows staged but
  * not yet launched are dropped; a finished stream can be pushed to again. */
 int exon_hip_stream_reset(exon_hip_stream* s);

@@ -1,4 +1,4 @@
-//! Raw FFI of include/exon_hip.h (hand-written; bindgen would produce the same).  ABI version 3.
+//! Raw FFI of include/exon_hip.h (hand-written; bindgen would produce the same).  ABI version 4.
 //! `tests/test_shim_layout.py` parses the `#[repr(C)]` structs below and checks field order, offsets and sizes against
 //! `include/exon_hip.h` through a gcc-compiled `offsetof` dump, so this file cannot drift from the header unnoticed.
 #![allow(non_camel_case_types)]
@@ -14,7 +14,7 @@ pub struct exon_hip_stream { _p: [u8; 0] }
 #[repr(C)]
 pub struct exon_hip_scan { _p: [u8; 0] }
 
-pub const EXON_HIP_ABI_VERSION: i32 = 3;
+pub const EXON_HIP_ABI_VERSION: i32 = 4;
 pub const EXON_HIP_PLAN_REGION_COUNT: i32 = 2;
 pub const EXON_HIP_PLAN_FLAG_MAPQ_GROUP_COUNT: i32 = 3;
 pub const EXON_HIP_PLAN_CMP_AVG_BY_GROUP: i32 = 4;
@@ -105,6 +105,15 @@ extern "C" {
     pub fn exon_hip_stream_state(s: *mut exon_hip_stream, d_i64: *mut *mut i64, d_f64: *mut *mut f64, hip_stream: *mut *mut c_void) -> c_int;
     /// AggregateExec(Final) across GPUs: one ncclAllGather of the packed state + a fold in rank order (comm: ncclComm_t)
     pub fn exon_hip_stream_all_reduce(s: *mut exon_hip_stream, rccl_comm: *mut c_void) -> c_int;
+    // ---- group keys by VALUE (ABI 4): FILTER-list / reference ids are per file; the stream remembers the value behind every
+    // state index, re-keys each further scan into its own order, and the ranks agree on one dictionary before the merge
+    pub fn exon_hip_stream_keys(s: *mut exon_hip_stream, buf: *mut c_char, cap: usize, n_keys: *mut i32, bytes: *mut usize, agreed: *mut i32) -> c_int;
+    pub fn exon_hip_stream_set_keys(s: *mut exon_hip_stream, packed_names: *const c_char, packed_bytes: usize, n_keys: i32) -> c_int;
+    pub fn exon_hip_keys_union(packed: *const c_char, packed_bytes: usize, n_keys: *const i32, world: i32, out: *mut c_char, cap: usize, n_out: *mut i32, out_bytes: *mut usize, maps: *mut i32) -> c_int;
+    /// collective over the communicator: two small ncclAllGathers move the dictionaries, every rank permutes its state into the union
+    pub fn exon_hip_stream_reconcile_keys(s: *mut exon_hip_stream, rccl_comm: *mut c_void) -> c_int;
+    /// region plans over files: the contig travels by name, each file resolves it in its own header order
+    pub fn exon_hip_stream_set_region_contig(s: *mut exon_hip_stream, name: *const c_char) -> c_int;
     pub fn exon_hip_stream_finish_arrow(s: *mut exon_hip_stream, out: *mut FFI_ArrowArray, out_schema: *mut FFI_ArrowSchema) -> c_int;
     pub fn exon_hip_stream_close(s: *mut exon_hip_stream) -> c_int;
     pub fn exon_hip_rccl_unique_id(id128: *mut u8) -> c_int;
