@@ -68,7 +68,7 @@ bool exon_hip_stream_is_keyed(exon_hip_stream* st);
 int exon_hip_stream_begin_scan(exon_hip_stream* st, bool* tracked, bool* redirected);
 int exon_hip_stream_end_scan(exon_hip_stream* st, const std::vector<std::string>* scan_keys, bool tracked, bool redirected, bool ok);
 bool exon_hip_stream_region_contig(exon_hip_stream* st, std::string* name);
-void exon_hip_stream_set_region_id(exon_hip_stream* st, int32_t id);
+int exon_hip_stream_set_region_id(exon_hip_stream* st, int32_t id);
 
 // BGZF inputs of GPU-parsed scans are inflated on the GPU too (EXON_HIP_GPU_INFLATE=0: host threads inflate)
 static bool gpu_inflate_enabled() {
@@ -1289,7 +1289,8 @@ int exon_hip_stream_consume_scan(exon_hip_stream* st, exon_hip_scan* scan, int64
     const bool fixed = scan->format == EXON_HIP_FORMAT_BAM || scan->format == EXON_HIP_FORMAT_SAM || scan->format == EXON_HIP_FORMAT_CRAM;
     int32_t id = d->find(contig);
     if (id < 0 && !fixed) id = d->lookup_or_insert(contig.data(), contig.size());  // VCF text may name contigs its header lacks
-    exon_hip_stream_set_region_id(st, id < 0 ? -1 : id);  // -1: no reference of that name, no row matches
+    const int rc0 = exon_hip_stream_set_region_id(st, id < 0 ? -1 : id);  // -1: no reference of that name, no row matches
+    if (rc0) return rc0;
   }
   // group keys travel by VALUE: the scan's dictionary ids are re-keyed into the stream's (stream.cpp)
   bool tracked = false, redirected = false;

@@ -854,7 +854,15 @@ bool exon_hip_stream_region_contig(exon_hip_stream* st, std::string* name) {
   *name = st->region_contig;
   return true;
 }
-void exon_hip_stream_set_region_id(exon_hip_stream* st, int32_t id) { st->region_id_override = id; }
+// rows staged by the previous file were decoded under ITS header's ids: they are launched before the id changes
+int exon_hip_stream_set_region_id(exon_hip_stream* st, int32_t id) {
+  if (st->region_id_override != id) {
+    const int rc = flush_slot(st);
+    if (rc) return rc;
+  }
+  st->region_id_override = id;
+  return EXON_HIP_OK;
+}
 
 // ---- RCCL (loaded on first use: hosts that never merge across GPUs -- and machines without RCCL -- do not need it) ----
 namespace {

@@ -105,6 +105,17 @@ impl StreamHandle {
         std::mem::forget(arr); // released by the library; `_sch` stays ours and is released by its Drop
         check(gpu.ctx, rc)
     }
+    /// the stream's group-key dictionary (exon_hip_stream_keys): the value behind every state index, in index order
+    fn keys(&self, gpu: &GpuPlan) -> Result<Vec<String>> {
+        let (mut n, mut bytes) = (0i32, 0usize);
+        check(gpu.ctx, unsafe { sys::exon_hip_stream_keys(self.0, std::ptr::null_mut(), 0, &mut n, &mut bytes, std::ptr::null_mut()) })?;
+        let mut buf = vec![0u8; bytes.max(1)];
+        check(gpu.ctx, unsafe {
+            sys::exon_hip_stream_keys(self.0, buf.as_mut_ptr() as *mut std::os::raw::c_char, bytes, &mut n, &mut bytes, std::ptr::null_mut())
+        })?;
+        // n '\0'-terminated names back to back ("" = the empty FILTER list is a legal key)
+        Ok(buf[..bytes].split(|b| *b == 0).take(n as usize).map(|k| String::from_utf8_lossy(k).into_owned()).collect())
+    }
     /// the packed partial state as an Arrow struct array (one row per observed group)
     fn finish(&self, gpu: &GpuPlan) -> Result<StructArray> {
         let mut out = FFI_ArrowArray::empty();
@@ -128,32 +139,6 @@ impl Drop for ScanHandle {
         unsafe { sys::exon_hip_scan_close(self.0) };
     }
 }
-impl ScanHandle {
-    /// names of a dictionary-encoded scan column, in id order
-    fn dictionary(&self, column: i32) -> Vec<Option<String>> {
-        let mut n = 0i32;
-        let mut out = Vec::new();
-        if unsafe { sys::exon_hip_scan_dictionary_size(self.0, column, &mut n) } != 0 {
-            return out;
-        }
-        for id in 0..n {
-            let mut p = std::ptr::null();
-            if unsafe { sys::exon_hip_scan_dictionary_value(self.0, column, id, &mut p) } != 0 || p.is_null() {
-                out.push(None);
-            } else {
-                out.push(Some(unsafe { CStr::from_ptr(p) }.to_string_lossy().into_owned()));
-            }
-        }
-        out
-    }
-    fn id_of(&self, column: i32, name: &str) -> Result<i32> {
-        let c = CString::new(name).map_err(|e| DataFusionError::Plan(e.to_string()))?;
-        let mut id = 0i32;
-        check(std::ptr::null(), unsafe { sys::exon_hip_scan_dictionary_intern(self.0, column, c.as_ptr(), &mut id) })?;
-        Ok(id)
-    }
-}
-
 /// Which of the fused shapes (BASELINE.json configs 2-5 + the range form) a `GpuFilterAggExec` runs, with what the state
 /// batch needs to become the replaced node's output.
 #[derive(Debug, Clone)]
@@ -190,7 +175,7 @@ pub struct GpuFilterAggExec {
     partial_schema: SchemaRef, // schema of the replaced AggregateExec(Partial): group columns, then state fields
     props: PlanProperties,
     device: i32,
-    gpu: Option<Arc<GpuPlan>>, // None: the plan depends on a file's header (region shapes over files) and is made per file
+    gpu: Option<Arc<GpuPlan>>, // always Some since ABI 4 (region shapes name their contig per stream); kept Option for with_new_children
 }
 
 /// Arrow types of the partial-aggregate state of a shape, in DataFusion's order (group columns first).
@@ -233,18 +218,19 @@ impl GpuFilterAggExec {
                 return Err(DataFusionError::Plan("GpuFilterAggExec: one file group per input partition expected".into()));
             }
         }
-        // region shapes over files need the contig's id in EACH file's header: their plan is created per file
-        let per_file_plan = matches!((&shape, &source), (Shape::RegionCount | Shape::OverlapCount, Source::Files { .. }));
-        let gpu = if per_file_plan {
-            // fail at plan time when there is no GPU or the library is missing: the rule then keeps DataFusion's plan
-            let mut probe = desc;
-            probe.region_chrom_id = 0;
-            drop(GpuPlan::try_new(device, &probe)?);
-            None
-        } else {
-            Some(Arc::new(GpuPlan::try_new(device, &desc)?))
-        };
-        // same partitioning as the scan; one state batch per file (or per partition), emitted at the end
+        // ONE device plan for all partitions.  Region shapes over files name their contig per stream
+        // (exon_hip_stream_set_region_contig: every file resolves it in its own header order), so the id in the description
+        // is a placeholder; the scan's row mask applies the interval, the plan counts the rows the scan emits.
+        let mut desc = desc;
+        if matches!((&shape, &source), (Shape::RegionCount | Shape::OverlapCount, Source::Files { .. })) {
+            desc.region_chrom_id = 0;
+            desc.region_start = 1;
+            desc.region_end = sys::EXON_HIP_REGION_OPEN_END;
+        }
+        // fails at plan time when there is no GPU or the library is missing: the rule then keeps DataFusion's plan
+        let gpu = Some(Arc::new(GpuPlan::try_new(device, &desc)?));
+        // same partitioning as the scan (a RepartitionExec(RoundRobinBatch) the rule peeled off is gone with the nodes it
+        // fed); one state batch per partition, emitted at the end
         let props = PlanProperties::new(
             EquivalenceProperties::new(partial_schema.clone()),
             input.properties().output_partitioning().clone(),
@@ -413,54 +399,56 @@ impl ExecutionPlan for GpuFilterAggExec {
             let mut out: Vec<RecordBatch> = Vec::new();
             match &source {
                 Source::Files { format, groups, region, use_index } => {
-                    let info = match &shape {
-                        Shape::CmpAvgByGroup { info_field } => Some(CString::new(info_field.as_str()).unwrap()),
-                        _ => None,
-                    };
-                    let region_c = region.as_ref().map(|r| CString::new(r.as_str()).unwrap());
-                    // no `.await` inside this loop: the raw handles never cross a suspension point
-                    for path in &groups[partition] {
-                        let opt = sys::exon_hip_scan_options {
-                            format: *format,
-                            compression: sys::EXON_HIP_COMPRESSION_AUTO,
-                            batch_size: 0,
-                            info_field: info.as_ref().map_or(std::ptr::null(), |c| c.as_ptr()),
-                            region: region_c.as_ref().map_or(std::ptr::null(), |c| c.as_ptr()),
-                            use_index: *use_index as i32,
-                            gpu_parse: 1,
+                    // Whole files are decoded and aggregated inside ONE blocking call per file (tens of milliseconds to
+                    // seconds): that must not run on a tokio worker, where it would stall every other task of the runtime
+                    // (the reference's scans are async all the way down: exon-core/src/datasources/vcf/scanner.rs:142-162).
+                    // The handles are Send (see StreamHandle / ScanHandle), the closure owns clones of everything it needs.
+                    let (format, use_index) = (*format, *use_index);
+                    let files = groups[partition].clone();
+                    let region = region.clone();
+                    let (shape_b, schema_b) = (shape.clone(), schema.clone());
+                    let plan = gpu.clone().expect("GpuFilterAggExec::try_new always creates the plan");
+                    let batch = tokio::task::spawn_blocking(move || -> Result<RecordBatch> {
+                        let info = match &shape_b {
+                            Shape::CmpAvgByGroup { info_field } => Some(CString::new(info_field.as_str()).unwrap()),
+                            _ => None,
                         };
-                        let cpath = CString::new(path.as_str()).unwrap();
-                        let mut raw = std::ptr::null_mut();
-                        check(std::ptr::null(), unsafe { sys::exon_hip_scan_open(cpath.as_ptr(), &opt, &mut raw) })?;
-                        let scan = ScanHandle(raw);
-                        // region shapes: the plan's `chrom = <id>` is this file's dictionary id of the region's contig, and
-                        // the scan's row mask (k_region_mask) has already applied the interval: pos >= 1, open end
-                        let file_plan;
-                        let plan: &GpuPlan = match (&gpu, &shape) {
-                            (Some(p), _) => p.as_ref(),
-                            (None, _) => {
-                                let mut d = desc;
-                                let dict_col = if matches!(shape, Shape::OverlapCount) { 2 } else { 0 };
-                                d.region_chrom_id = scan.id_of(dict_col, region_name(region.as_deref().unwrap_or("")))?;
-                                d.region_start = 1;
-                                d.region_end = sys::EXON_HIP_REGION_OPEN_END;
-                                file_plan = GpuPlan::try_new(device, &d)?;
-                                &file_plan
-                            }
-                        };
-                        let stream = StreamHandle::open(plan, partition)?;
-                        let mut rows = 0i64;
-                        check(plan.ctx, unsafe { sys::exon_hip_stream_consume_scan(stream.0, scan.0, &mut rows) })?;
-                        // dictionary of the key column (VCF: scan column 3 = filter; BAM: 2 = reference), in id order; one
-                        // state batch per FILE, so ids never have to agree between files (Final merges by key VALUE)
-                        let keys = Keys(match shape {
-                            Shape::CmpAvgByGroup { .. } => scan.dictionary(3),
-                            Shape::FlagMapqGroupCount => scan.dictionary(2),
-                            _ => Vec::new(),
-                        });
-                        let state = stream.finish(plan)?;
-                        out.push(state_to_partial(&shape, &state, &keys, &schema)?);
-                    }
+                        let region_c = region.as_ref().map(|r| CString::new(r.as_str()).unwrap());
+                        // ONE stream per partition: group keys travel by VALUE (ABI 4) -- the first file's dictionary
+                        // becomes the stream's, every further file is aggregated under its own ids and added in under
+                        // the stream's -- so a partition emits one state batch however many files it holds
+                        let stream = StreamHandle::open(&plan, partition)?;
+                        if matches!(shape_b, Shape::RegionCount | Shape::OverlapCount) {
+                            // `chrom = <id>` is resolved by NAME in every file's own header order; the scan's row mask
+                            // (k_region_mask) has already applied the interval, so the plan counts what the scan emits
+                            let name = CString::new(region_name(region.as_deref().unwrap_or(""))).unwrap();
+                            check(plan.ctx, unsafe { sys::exon_hip_stream_set_region_contig(stream.0, name.as_ptr()) })?;
+                        }
+                        for path in &files {
+                            let opt = sys::exon_hip_scan_options {
+                                format,
+                                compression: sys::EXON_HIP_COMPRESSION_AUTO,
+                                batch_size: 0,
+                                info_field: info.as_ref().map_or(std::ptr::null(), |c| c.as_ptr()),
+                                region: region_c.as_ref().map_or(std::ptr::null(), |c| c.as_ptr()),
+                                use_index: use_index as i32,
+                                gpu_parse: 1,
+                            };
+                            let cpath = CString::new(path.as_str()).unwrap();
+                            let mut raw = std::ptr::null_mut();
+                            check(std::ptr::null(), unsafe { sys::exon_hip_scan_open(cpath.as_ptr(), &opt, &mut raw) })?;
+                            let scan = ScanHandle(raw);
+                            let mut rows = 0i64;
+                            check(plan.ctx, unsafe { sys::exon_hip_stream_consume_scan(stream.0, scan.0, &mut rows) })?;
+                        }
+                        // key VALUES of the state's indexes (VCF: FILTER lists as ';'-joined text; BAM: reference names)
+                        let keys = Keys(stream.keys(&plan)?.into_iter().map(Some).collect());
+                        let state = stream.finish(&plan)?;
+                        state_to_partial(&shape_b, &state, &keys, &schema_b)
+                    })
+                    .await
+                    .map_err(|e| DataFusionError::External(Box::new(e)))??;
+                    out.push(batch);
                 }
                 Source::ChildBatches { seed_key } => {
                     let plan = gpu.as_ref().expect("ChildBatches always has a shared plan").clone();

@@ -3,7 +3,13 @@
 //! (exon-core/src/physical_optimizer/chrom_optimizer_rule.rs:26-64) and the plan shapes its tests assert
 //! (exon-core/src/datasources/vcf/table_provider.rs:571-611).
 //!
-//! Plan shapes (`A` = `AggregateExec(mode=Partial)`, `[C]` = optional `CoalesceBatchesExec`, `F` = `FilterExec`):
+//! Plan shapes (`A` = `AggregateExec(mode=Partial)`, `F` = `FilterExec` -- with or without an embedded `projection=[..]`;
+//! `[C]` = any run of the nodes DataFusion's own rules put in between and that change neither rows nor values:
+//! `CoalesceBatchesExec`, `RepartitionExec(RoundRobinBatch)` and a `ProjectionExec` of plain columns.  `new_exon_config` sets
+//! `target_partitions = num_cpus` and leaves round-robin repartitioning on (exon-core/src/config/mod.rs:27-45), so with
+//! fewer files than cores `EnforceDistribution` puts `RepartitionExec(RoundRobinBatch(n))` between `F` and a one-partition
+//! scan, and between `A` and an indexed scan; this rule runs AFTER the default rules and must see
+//! through those nodes -- `[C]` is peeled both above and below `F`):
 //!
 //! | id  | SQL                                                                  | physical plan below `A`                         | matcher |
 //! |-----|----------------------------------------------------------------------|--------------------------------------------------|---------|
@@ -33,7 +39,9 @@ use datafusion::physical_optimizer::PhysicalOptimizerRule;
 use datafusion::physical_plan::aggregates::{AggregateExec, AggregateMode};
 use datafusion::physical_plan::coalesce_batches::CoalesceBatchesExec;
 use datafusion::physical_plan::filter::FilterExec;
-use datafusion::physical_plan::{with_new_children_if_necessary, ExecutionPlan};
+use datafusion::physical_plan::projection::ProjectionExec;
+use datafusion::physical_plan::repartition::RepartitionExec;
+use datafusion::physical_plan::{with_new_children_if_necessary, ExecutionPlan, Partitioning};
 use exon::datasources::bam::IndexedBAMScan;
 use exon::datasources::vcf::{IndexedVCFScanner, VCFScan};
 
@@ -303,7 +311,10 @@ fn point_region(parts: &[Arc<dyn PhysicalExpr>]) -> Option<(String, i64, i64)> {
             _ => return None,
         }
     }
-    Some((chrom?, a, b))
+    if a > b || b < 1 {
+        return None; // an empty interval (`pos <= 0`, `pos >= 10 AND pos <= 5`): DataFusion answers 0 by itself
+    }
+    Some((chrom?, a.max(1), b))
 }
 fn region_text(name: &str, a: i64, b: i64) -> String {
     if b == sys::EXON_HIP_REGION_OPEN_END {
@@ -458,6 +469,37 @@ fn match_alignment_filter(agg: &AggregateExec, pred: &Arc<dyn PhysicalExpr>, sca
     Some(Matched { desc, shape: Shape::FlagMapqGroupCount, source: Source::ChildBatches { seed_key: None }, scan: scan_plan.clone() })
 }
 
+/// Skips the nodes DataFusion's default rules insert between the partial aggregate, the filter and the scan and that
+/// change neither the set of rows nor their values: `CoalesceBatchesExec` (the `CoalesceBatches` rule wraps every
+/// FilterExec), `RepartitionExec` with `Partitioning::RoundRobinBatch` (`EnforceDistribution` adds one on top of a scan with
+/// fewer partitions than `target_partitions`; a Hash repartition is NOT skipped -- it sits above the partial aggregate,
+/// never below) and, when `projections` is set, a `ProjectionExec` whose expressions are all plain columns kept under
+/// their own names (DataFusion < 43 dropped the predicate's columns with one between the aggregate and the filter; from
+/// 43 on the same thing is the FilterExec's embedded projection).  The substituted node executes the SCAN directly and
+/// reports the scan's partitioning, so the peeled RepartitionExec disappears with the nodes it fed.
+fn peel(plan: &Arc<dyn ExecutionPlan>, projections: bool) -> Arc<dyn ExecutionPlan> {
+    let mut cur = plan.clone();
+    loop {
+        let next = if let Some(c) = cur.as_any().downcast_ref::<CoalesceBatchesExec>() {
+            c.input().clone()
+        } else if let Some(r) = cur.as_any().downcast_ref::<RepartitionExec>() {
+            match r.partitioning() {
+                Partitioning::RoundRobinBatch(_) => r.input().clone(),
+                _ => return cur,
+            }
+        } else if let Some(p) = cur.as_any().downcast_ref::<ProjectionExec>() {
+            let plain = projections && p.expr().iter().all(|(e, alias)| col_name(e).map_or(false, |(n, _)| &n == alias));
+            if !plain {
+                return cur;
+            }
+            p.input().clone()
+        } else {
+            return cur;
+        };
+        cur = next;
+    }
+}
+
 impl GpuFilterAggRule {
     fn rewrite(&self, plan: Arc<dyn ExecutionPlan>) -> Result<Transformed<Arc<dyn ExecutionPlan>>> {
         // children first (same recursion as ExonChromOptimizer)
@@ -475,17 +517,13 @@ impl GpuFilterAggRule {
         if *agg.mode() != AggregateMode::Partial {
             return Ok(Transformed::no(plan));
         }
-        // below the aggregate: [CoalesceBatchesExec] <- FilterExec <- scan, or the scan itself when the only predicate
-        // was pushed down into it
-        let mut below = agg.input().clone();
-        if let Some(c) = below.as_any().downcast_ref::<CoalesceBatchesExec>() {
-            below = c.input().clone();
-        }
+        // below the aggregate: [C] <- FilterExec <- [C] <- scan, or [C] <- scan when the only predicate was pushed down
+        // into the scan ([C]: see `peel`)
+        let below = peel(agg.input(), true);
         let matched = if let Some(filter) = below.as_any().downcast_ref::<FilterExec>() {
-            if filter.projection().is_some() {
-                return Ok(Transformed::no(plan));
-            }
-            let scan_plan = filter.input().clone();
+            // a FilterExec with an embedded projection only drops columns above it; the predicate is written against the
+            // filter's INPUT (the scan's schema) and every matcher goes by column NAME, so it is accepted as it is
+            let scan_plan = peel(filter.input(), false);
             if let Some(scan) = scan_plan.as_any().downcast_ref::<VCFScan>() {
                 match_vcf_filter(agg, filter.predicate(), &scan_plan, scan.base_config(), None)
             } else if let Some(scan) = scan_plan.as_any().downcast_ref::<IndexedVCFScanner>() {
@@ -614,6 +652,39 @@ mod tests {
         let c6 = "SELECT COUNT(*) FROM b WHERE reference = 'chr1' AND start <= 12209145 AND \"end\" >= 1";
         assert!(plan_text(&ctx, c6).await?.contains("GpuFilterAggExec"));
         assert_eq!(one_i64(&ctx, c6).await?, 7);
+        Ok(())
+    }
+
+    /// The headline one-file C4 plan as DataFusion 44 emits it under `new_exon_config` (target_partitions = num_cpus,
+    /// round-robin repartitioning on): `RepartitionExec(RoundRobinBatch)` between the FilterExec and the one-partition
+    /// VCFScan (INTEGRATION.md section 3 has the expected EXPLAIN).  The rule must substitute anyway, and the
+    /// substituted node must not keep the repartition below it.
+    #[tokio::test]
+    async fn plan_shape_c4_behind_round_robin_repartition() -> std::result::Result<(), Box<dyn std::error::Error>> {
+        let ctx = session()?;
+        ctx.session.sql("SET datafusion.execution.target_partitions = 8").await?;
+        ctx.session.sql("SET exon.vcf_parse_info = true").await?;
+        ctx.session.sql("CREATE EXTERNAL TABLE v STORED AS VCF LOCATION 'test-data/datasources/vcf/index.vcf'").await?;
+        let sql = "SELECT filter, AVG(qual), COUNT(*) FROM v WHERE info.\"MQ0F\" > -1 GROUP BY filter";
+        let shown = plan_text(&ctx, sql).await?;
+        assert!(shown.contains("GpuFilterAggExec"), "{shown}");
+        let below = &shown[shown.find("GpuFilterAggExec").unwrap()..];
+        assert!(!below.contains("RoundRobinBatch") && !below.contains("FilterExec") && below.contains("VCFScan"), "{shown}");
+        let sql = "SELECT COUNT(*) FROM v WHERE chrom = '1' AND pos >= 1";
+        assert!(plan_text(&ctx, sql).await?.contains("GpuFilterAggExec"));
+        assert_eq!(one_i64(&ctx, sql).await?, 191);
+        Ok(())
+    }
+
+    /// empty / non-positive intervals are left to DataFusion (`pos <= 0` used to become the region text `1:1-0`)
+    #[tokio::test]
+    async fn empty_intervals_are_not_substituted() -> std::result::Result<(), Box<dyn std::error::Error>> {
+        let ctx = session()?;
+        ctx.session.sql("CREATE EXTERNAL TABLE v STORED AS VCF LOCATION 'test-data/datasources/vcf/index.vcf'").await?;
+        for sql in ["SELECT COUNT(*) FROM v WHERE chrom = '1' AND pos <= 0", "SELECT COUNT(*) FROM v WHERE chrom = '1' AND pos >= 10 AND pos <= 5"] {
+            assert!(!plan_text(&ctx, sql).await?.contains("GpuFilterAggExec"), "{sql}");
+            assert_eq!(one_i64(&ctx, sql).await?, 0);
+        }
         Ok(())
     }
 

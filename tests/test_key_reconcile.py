@@ -67,6 +67,8 @@ def write_sam(path, n, seed, sq_order):
             unm = rng.random() < 0.05
             flag = 4 if unm else int(rng.choice([99, 147, 83, 163, 1123, 355]))
             ref = "*" if unm else sq_order[int(rng.integers(0, len(sq_order)))]
+            if not unm and rng.random() < 0.03:   # no RNAME although the flag does not say unmapped: a row of the NULL-reference group
+                ref, unm = "*", True
             pos = 0 if unm else int(rng.integers(1, 900000))
             mapq = int(rng.choice([0, 20, 30, 40, 60, 255]))
             cigar = "*" if unm else "50M"
@@ -162,7 +164,8 @@ def _host_k3_partial(path, G):
 def _gloo_worker(rank, world, port, vcfs, sams, out):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ["EXON_HIP_DECODE_THREADS"] = "1"   # sequential host decode: ids in order of first appearance, so the two files
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # provably number their FILTER lists in opposite orders
     from exon_amd.distributed import merge_state, reconcile_keys, shard_files
     G = 8
     mine = shard_files([os.path.getsize(p) for p in vcfs], rank, world)
@@ -208,8 +211,10 @@ def test_two_ranks_whose_dictionaries_disagree_merge_by_value(tmp_path, oracle):
     got = k4_by_value(union, r["k4"][:2 * G], r["k4"][2 * G:].view(np.float64), G)
     assert got == want                                                      # counts exact; QUAL in eighths: sums exact too
     # adding the two partials index by index -- what the merge did before -- is NOT the answer on these files
+    os.environ["EXON_HIP_DECODE_THREADS"] = "1"
     ka, sa_ = _host_k4_partial(a, G)
     kb, sb_ = _host_k4_partial(b, G)
+    del os.environ["EXON_HIP_DECODE_THREADS"]
     naive = k4_by_value(ka, (sa_ + sb_).numpy()[:2 * G], (sa_[2 * G:].view(torch.float64) + sb_[2 * G:].view(torch.float64)).numpy(), G)
     assert naive != want
     want3 = k3_expected_by_name(oracle, [sa, sb], "sam")
@@ -249,7 +254,9 @@ def test_one_stream_consuming_files_with_opposite_filter_orders_is_keyed_by_valu
                 assert s.decoded_on_gpu()[0]
             s.close()
         keys, agreed = st.keys()
-        assert rows == n and not agreed and keys[:3] == ["PASS", "", "q10"] and sorted(keys) == sorted(["PASS", "", "q10", "q10;s50", "s50"])
+        # (which id a value gets inside one scan is the decoder's business -- several decode threads / wavefronts intern
+        # concurrently --; what is checked is that every file's ids were translated to the stream's by VALUE)
+        assert rows == n and not agreed and sorted(keys) == sorted(["PASS", "", "q10", "q10;s50", "s50"])
         c, s_ = st.finish()
         assert k4_by_value(keys, c, s_, 64) == want
         st.close()
@@ -363,7 +370,7 @@ def test_merge_of_a_rank_local_dictionary_is_refused_until_reconciled(ctx, tmp_p
         comm = NativeComm(ctx)
         st.reconcile_keys(comm.h.value)
         keys, agreed = st.keys()
-        assert agreed and keys[:2] == ["s50", "PASS"]
+        assert agreed and {"PASS", "s50"} <= set(keys)
         st.all_reduce(comm.h.value)
         c, s_ = st.finish()
         assert k4_by_value(keys, c, s_, 64) == want

@@ -274,6 +274,25 @@ def test_plan_shapes_have_matchers_and_the_known_defects_stay_fixed():
     assert "*mut sys::exon_hip_stream" not in exe and "input.next().await" in exe
     # Utf8 mapping_quality is converted before the push
     assert "fn mapq_to_u8(" in lib and "mapq_to_u8(&batch, mapq_col)" in exe
+    #  the plans DataFusion really emits: a round-robin RepartitionExec / CoalesceBatchesExec / column-only
+    # ProjectionExec between the partial aggregate, the filter and the scan is peeled off -- above AND below the filter --
+    # and a FilterExec with an embedded projection is no longer a reason to give up
+    assert "fn peel(" in rule and "downcast_ref::<RepartitionExec>()" in rule and "Partitioning::RoundRobinBatch(_)" in rule
+    assert "peel(agg.input(), true)" in body and "peel(filter.input(), false)" in body
+    assert "filter.projection().is_some()" not in body
+    peel = rule[rule.index("fn peel("):rule.index("impl GpuFilterAggRule", rule.index("fn peel("))]
+    assert "CoalesceBatchesExec" in peel and "ProjectionExec" in peel and "_ => return cur" in peel   # a Hash repartition is NOT skipped
+    #  whole-file decode + kernels run inside spawn_blocking, never on a tokio worker; one stream per partition,
+    # its keys by value, the region's contig by name
+    files = exe[exe.index("Source::Files {"):exe.index("Source::ChildBatches { seed_key } =>")]
+    assert "tokio::task::spawn_blocking(move ||" in files and files.index("spawn_blocking") < files.index("exon_hip_stream_consume_scan")
+    assert "stream.keys(&plan)" in files and "exon_hip_stream_set_region_contig" in files and "GpuPlan::try_new" not in files
+    assert re.search(r'^tokio = ', open(os.path.join(ROOT, "shim", "Cargo.toml")).read().split("[dev-dependencies]")[0], re.M)
+    #  an empty / non-positive point interval is not turned into a region string
+    pr = rule[rule.index("fn point_region("):rule.index("fn region_text(")]
+    assert "a > b || b < 1" in pr
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "RepartitionExec: partitioning=RoundRobinBatch(n), input_partitions=1" in integ and "GpuFilterAggExec: kind=4" in integ
     # the table function of config 5 is registered under its SQL name
     udtf = _shim("udtf.rs")
     assert 'register_udtf("fastq_quality_histogram"' in udtf and "impl TableFunctionImpl for FastqQualityHistogram" in udtf
