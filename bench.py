@@ -208,6 +208,28 @@ def torch_reference_c4(wl, thr=0.01):
     return cnn, crow, sums
 
 
+def host_cpus():
+    """(usable, logical, quota): CPUs this process can keep busy = logical CPUs of its affinity mask capped by the container's
+    CFS quota (cgroup v2 cpu.max / v1 cfs_quota_us).  The GPU boxes of this pool show 256 logical CPUs under a quota of 16:
+    128 threads there ran 12.6 cores' worth of work, 16 threads run 15.6 (tools/host_scaling.py, profiles/r4_host_scaling.log)."""
+    logical = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and period > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    usable = logical if quota is None else max(1, min(logical, int(quota + 0.999)))
+    return usable, logical, quota
+
+
 def cpu_baseline(kind, sample_rows, n_total, reps):
     """The CPU restatement of the Exon/DataFusion plan (oracle/exon_oracle.c) on a bounded sample of the
     SAME synthetic rows [0, sample_rows), all host cores; returns (result dict, oracle outputs)."""
@@ -215,16 +237,17 @@ def cpu_baseline(kind, sample_rows, n_total, reps):
     orc = Oracle()
     n = int(sample_rows)
     secs, mat = [], []
+    T, logical, quota = host_cpus()   # partitions = the CPUs the container may really use (target_partitions = num_cpus)
     if kind == "c4":
         af, av, q, qv, fid = orc.gen_c4(SEED["c4"], 0, n)
         for _ in range(reps):
-            s, cn, cr, t = orc.c4_cmp_avg_by_group(af, av, q, qv, fid, orc.c4_filters(), 0.01, ">")
+            s, cn, cr, t = orc.c4_cmp_avg_by_group(af, av, q, qv, fid, orc.c4_filters(), 0.01, ">", threads=T)
             secs.append(t.seconds_exec), mat.append(t.seconds_materialize)
         out = (np.concatenate([cn, cr]), s)
     elif kind == "c2":
         c, p = orc.gen_c2(SEED["c2"], n_total, 0, n)
         for _ in range(reps):
-            r, t = orc.c2_region_count(c, p, orc.c2_contigs(), "7:50000000-100000000")
+            r, t = orc.c2_region_count(c, p, orc.c2_contigs(), "7:50000000-100000000", threads=T)
             secs.append(t.seconds_exec), mat.append(t.seconds_materialize)
         out = (np.array([r], np.int64), None)
     elif kind == "c6":
@@ -245,13 +268,13 @@ def cpu_baseline(kind, sample_rows, n_total, reps):
         n = min(n, 8_000_000)
         off, data = orc.gen_c5(SEED["c5"], 0, n, C5_L)
         for _ in range(reps):
-            hcpu, t = orc.c5_qual_pos_hist(off, data, C5_L)
+            hcpu, t = orc.c5_qual_pos_hist(off, data, C5_L, threads=T)
             secs.append(t.seconds_exec), mat.append(t.seconds_materialize)
         out = (hcpu.reshape(-1), None)
     else:
         f, mq, mv, ref, rv = orc.gen_c3(SEED["c3"], 0, n)
         for _ in range(reps):
-            cnt, t = orc.c3_flag_mapq_group_count(f, mq, mv, ref, rv, orc.c3_refs(), 1284, 0, 30)
+            cnt, t = orc.c3_flag_mapq_group_count(f, mq, mv, ref, rv, orc.c3_refs(), 1284, 0, 30, threads=T)
             secs.append(t.seconds_exec), mat.append(t.seconds_materialize)
         out = (cnt, None)
     best = float(np.median(secs))
@@ -263,14 +286,18 @@ def cpu_baseline(kind, sample_rows, n_total, reps):
                                               0.01, ">", threads=1)
         one = round(m / t1.seconds_exec / 1e6, 2)
     res = {"value": round(n / best / 1e6, 2), "unit": "Mrows/s", "cores": t.threads, "kind": "port",
+           # the stable figure of this leg: one partition on one core (box to box within a few percent); `value` = that x the
+           # cores the container may use x the parallel efficiency below
            "single_thread_value": one,
-           # value / single_thread_value: how many cores' worth of work the host's threads delivered in this run (GPU boxes of
-           # this pool show ~13 for 128 threads, which is why `value` moves from box to box while the per-thread figure does not)
            "parallel_speedup": round(n / best / 1e6 / one, 1) if one else None,
+           "core_seconds": round(best * t.threads, 3),
+           "host": {"logical_cpus": logical, "cfs_quota_cpus": quota, "partitions": t.threads},
            "sample": f"rows [0,{n}) of the same synthetic table as 8192-row Arrow-layout batches (Utf8/List<Utf8> keys), "
-                     f"{t.threads} partitions = host cores; median of {reps} runs, {best:.3f}s exec each "
-                     f"(+{float(np.median(mat)):.2f}s untimed Arrow-layout build); total CPU work "
-                     f"~{sum(secs) * t.threads:.0f} core-seconds"}
+                     f"{t.threads} partitions = the CPUs this container may use ({logical} logical CPUs"
+                     + (f", CFS quota {quota:g}: threads beyond the quota are throttled every 100 ms period -- 128 threads "
+                        f"delivered 12.6 cores' worth in round 3" if quota else ", no CFS quota")
+                     + f"); median of {reps} runs, {best:.3f}s exec each "
+                     f"(+{float(np.median(mat)):.2f}s untimed Arrow-layout build); {best * t.threads:.2f} core-seconds per run"}
     return res, out
 
 

@@ -968,7 +968,8 @@ class CRAMBatchReader {
     // and the threads also build the batches, so the caller's thread only hands them out.  (On the GPU box -- 256 hardware
     // threads that deliver about 16 cores' worth of work -- throughput is flat from 16 threads up: 80-100 M records/s, the
     // per-container thread time growing in step with the thread count; EXON_HIP_CRAM_TRACE=1 prints the split.)
-    const unsigned hc = std::thread::hardware_concurrency();
+    // (round 4: the "16 cores' worth" is the container's CFS quota -- usable_cpus() in parallel.h reads it)
+    const unsigned hc = (unsigned)usable_cpus();
     const char* ev = getenv("EXON_HIP_CRAM_THREADS");
     threads_ = cfg_.threads > 0 ? cfg_.threads : ev && atoi(ev) > 0 ? atoi(ev) : (int)std::min(32u, hc ? hc : 1u);
   }

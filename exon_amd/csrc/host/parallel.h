@@ -7,6 +7,7 @@
 // is five orders of magnitude below what the GPU consumes, so the decoders here use every host core of the
 // partition's process.  Results are identical to the sequential readers (tests/test_scan_decoders.py).
 #pragma once
+#include <sched.h>
 #include <zlib.h>
 
 #include <atomic>
@@ -387,13 +388,47 @@ class BgzfParallelSource : public ByteSource {
   std::exception_ptr read_error_;
 };
 
+// CPUs this process can really keep busy: the logical CPUs it may run on (affinity mask), capped by the container's CFS
+// quota (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us).  The GPU boxes of this pool show 256 logical CPUs
+// and a quota of 16: 128 decode threads there ran 12.6 cores' worth of work (throttled every 100 ms period), 16 threads run
+// 15.6 (tools/host_scaling.py, profiles/r4_host_scaling.log).
+inline int usable_cpus() {
+  static const int n = [] {
+    int hc = (int)std::thread::hardware_concurrency();
+    if (hc < 1) hc = 1;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) hc = std::min(hc, (int)CPU_COUNT(&set));
+    double quota = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[64] = {0};
+      double period = 0;
+      if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) quota = atof(q) / period;
+      fclose(f);
+    } else {
+      double q = -1, period = 0;
+      if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (fscanf(g, "%lf", &q) != 1) q = -1;
+        fclose(g);
+      }
+      if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+        if (fscanf(g, "%lf", &period) != 1) period = 0;
+        fclose(g);
+      }
+      if (q > 0 && period > 0) quota = q / period;
+    }
+    if (quota > 0) hc = std::min(hc, std::max(1, (int)(quota + 0.999)));
+    return hc;
+  }();
+  return n;
+}
+
 inline int decode_threads() {
   if (const char* v = getenv("EXON_HIP_DECODE_THREADS")) {
     const int t = atoi(v);
     if (t >= 1) return t;
   }
-  const unsigned hc = std::thread::hardware_concurrency();  // target_partitions = num_cpus in the reference
-  return hc ? (int)hc : 1;
+  return usable_cpus();  // target_partitions = num_cpus in the reference (exon-core/src/config/mod.rs:44)
 }
 
 inline long file_size(const std::string& path) {
