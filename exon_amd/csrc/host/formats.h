@@ -45,6 +45,7 @@ struct RecordSource {
   virtual bool next_record() = 0;  // false = no further record may start
   virtual bool read_line(std::string* line) = 0;
   virtual bool read_exact(uint8_t* dst, size_t n) = 0;
+  virtual size_t chunk_index() const { return 0; }  // which index chunk the next record comes from (ChunkSource)
 };
 struct StreamSource : RecordSource {
   BufReader r;
@@ -73,6 +74,7 @@ struct ChunkSource : RecordSource {
   }
   bool read_line(std::string* line) override { return r.read_line(line); }
   bool read_exact(uint8_t* dst, size_t n) override { return r.read_exact(dst, n); }
+  size_t chunk_index() const override { return ci; }
 };
 
 // ======================================================================================================
@@ -91,6 +93,11 @@ struct VCFConfig {
   bool defer_decode = false;  // the caller will take the byte stream (GPU-side parsing): start no parse pipeline
   std::string info_field;  // exon.vcf_parse_info=true + SELECT info."<F>": Number=1 Float/Integer field -> f32 column
   RegionFilter filter;
+  // EXON_HIP_REFERENCE_QUIRKS=1: reproduce IndexedAsyncBatchStream::read_batch as written
+  // (exon-vcf/src/indexed_async_batch_stream.rs:118-166) on indexed scans: one stream per index chunk; a batch takes records
+  // until `batch_size` of them hit the region, then appends up to `batch_size` FURTHER records of the chunk UNFILTERED
+  // (:143-154).  Off (default): every record is tested -- the documented semantics of vcf_region_filter.
+  bool reference_tail_quirk = false;
 };
 
 inline std::string header_attr(const std::string& line, const char* key) {
@@ -557,6 +564,7 @@ class VCFBatchReader {
   // (exon-vcf/src/indexed_async_batch_stream.rs:99-116; see DESIGN.md on the reference's unfiltered tail).
   bool read_batch(struct ArrowArray* out) {
     if (pipe_) return read_batch_parallel(out);
+    if (cfg_.reference_tail_quirk && n_chunks >= 0 && cfg_.filter.active) return read_batch_reference_quirk(out);
     VCFArrayBuilder b(&chrom_dict, &filter_dict, info_specs, &info_dicts);
     std::string line;
     while ((int64_t)b.len() < cfg_.batch_size) {
@@ -571,6 +579,44 @@ class VCFBatchReader {
       b.append(line);
     }
     if (b.is_empty()) return false;
+    b.try_into_record_batch(out);
+    return true;
+  }
+
+  // IndexedAsyncBatchStream::read_batch exactly as the reference has it (exon-vcf/src/indexed_async_batch_stream.rs:118-166),
+  // one stream per index chunk (indexed_bgzf_file.rs:145-152: one PartitionedFile per chunk): the first loop takes records
+  // until batch_size of them passed `filter` or the chunk ends; the second loop then reads up to batch_size MORE records and
+  // appends them WITHOUT the test (it reads nothing when the first loop stopped at the chunk's end).  Opt-in only.
+  bool read_batch_reference_quirk(struct ArrowArray* out) {
+    VCFArrayBuilder b(&chrom_dict, &filter_dict, info_specs, &info_dicts);
+    std::string line;
+    for (;;) {  // skip chunks that yield nothing (the reference's stream of such a chunk ends without a batch)
+      if (!r_->next_record()) return false;
+      const size_t chunk = r_->chunk_index();
+      auto next_of_chunk = [&](std::string* l) {  // read_record(): None at the end of THIS chunk
+        for (;;) {
+          if (!r_->next_record() || r_->chunk_index() != chunk || !r_->read_line(l)) return false;
+          if (!l->empty() && (*l)[0] != '#') return true;
+        }
+      };
+      int64_t hits = 0;
+      bool ended = false;
+      while (hits < cfg_.batch_size) {
+        if (!next_of_chunk(&line)) {
+          ended = true;
+          break;
+        }
+        if (vcf_region_hit(line.data(), line.size(), cfg_.filter.region)) {
+          b.append(line);
+          ++hits;
+        }
+      }
+      for (int64_t i = 0; i < cfg_.batch_size && !ended; ++i) {
+        if (!next_of_chunk(&line)) break;
+        b.append(line);  // unfiltered: indexed_async_batch_stream.rs:143-154
+      }
+      if (!b.is_empty()) break;
+    }
     b.try_into_record_batch(out);
     return true;
   }

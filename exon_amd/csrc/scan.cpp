@@ -126,6 +126,13 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         // a pushed-down region filter rides along as a row mask (k_region_mask); with use_index the host plans the
         // tabix chunks and only their BGZF blocks are shipped (indexed scans are BGZF by definition)
         s->gpu_parse = o->gpu_parse != 0 && (!rf.use_index || (rf.active && wants_gpu_inflate(o, path)));
+        // EXON_HIP_REFERENCE_QUIRKS=1: an indexed VCF scan reproduces the reference's unfiltered tail after a full batch of
+        // hits (exon-vcf/src/indexed_async_batch_stream.rs:143-154) -- a property of its per-chunk record loop, so the host
+        // reader runs it; default: every record is tested (what vcf_region_filter documents)
+        if (const char* qv = getenv("EXON_HIP_REFERENCE_QUIRKS"); qv && qv[0] == '1' && rf.active && rf.use_index) {
+          cfg.reference_tail_quirk = true;
+          s->gpu_parse = false;
+        }
         cfg.defer_decode = s->gpu_parse;
         if (s->gpu_parse && wants_gpu_inflate(o, path)) cfg.threads = 1;  // only the header is read on the host
         s->vcf.reset(new exon::VCFBatchReader(path, c, cfg));

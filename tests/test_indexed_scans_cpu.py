@@ -141,3 +141,67 @@ def test_block_parallel_reader_validates_every_length(tmp_path, what):
     else:
         with pytest.raises(exon_amd.ExonHipError):
             count_rows(p, "vcf")
+
+
+def _reference_indexed_stream_rows(gz, region_name, a, b, batch=8192):
+    """What IndexedAsyncBatchStream::read_batch returns, restated from exon-vcf/src/indexed_async_batch_stream.rs:118-166 over
+    the records of every index chunk (one stream per chunk, indexed_bgzf_file.rs:145-152): per batch, records until `batch` of
+    them hit the region, then up to `batch` further records UNFILTERED.  Independent of the product: the chunks come from
+    exon_hip_index_query, the record -> virtual-offset map from this test's own BGZF walk."""
+    from bgzf_index_writer import VirtualOffsets
+    blocks = bgzf_blocks(open(gz, "rb").read())
+    vo = VirtualOffsets(blocks)
+    text = b"".join(d for _, _, d in blocks)
+    recs, u = [], 0
+    while u < len(text):
+        e = text.find(b"\n", u) + 1
+        if text[u:u + 1] != b"#":
+            f = text[u:e].split(b"\t", 3)
+            recs.append((vo.at(u), f[0].decode(), int(f[1])))
+        u = e
+    total = 0
+    for c0, c1 in exon_amd.index_query(str(gz) + ".tbi", region=f"{region_name}:{a}-{b}"):
+        stream = [r for r in recs if c0 <= r[0] < c1]
+        i = 0
+        while i < len(stream):
+            hits = 0
+            while hits < batch and i < len(stream):            # first loop: filtered
+                _, ch, pos = stream[i]
+                i += 1
+                if ch == region_name and a <= pos <= b:
+                    hits += 1
+                    total += 1
+            if hits == batch:                                    # second loop: unfiltered (it reads nothing at a chunk's end)
+                n = min(batch, len(stream) - i)
+                total += n
+                i += n
+    return total
+
+
+def test_indexed_vcf_unfiltered_tail_of_the_reference_is_a_switch(tmp_path, monkeypatch):
+    """More than 8192 hits in one index chunk.  Default: every record is tested (what vcf_region_filter documents) -> the hits.
+    EXON_HIP_REFERENCE_QUIRKS=1: the reference's stream as written appends up to batch_size UNFILTERED records after a full
+    batch of hits (exon-vcf/src/indexed_async_batch_stream.rs:143-154) -> more rows than hits.  Both are stated here, so
+    "identical results on the same inputs" is a switch, not a footnote."""
+    n = 60_000
+    path = tmp_path / "s.vcf"
+    subprocess.check_call([GEN, "vcf", str(n), str(path)])          # contig 1, POS = 1 .. n
+    gz = tmp_path / "s.vcf.gz"
+    subprocess.check_call([BGZIP, str(path), str(gz), "6"])
+    assert write_tabix(gz) == n
+    a, b = 1, 10_000
+    monkeypatch.delenv("EXON_HIP_REFERENCE_QUIRKS", raising=False)
+    assert count_rows(gz, "vcf", region=f"1:{a}-{b}", use_index=True)[0] == 10_000
+    want_quirk = _reference_indexed_stream_rows(gz, "1", a, b)
+    assert want_quirk > 10_000                                       # the chunk runs past the region: unfiltered records follow
+    monkeypatch.setenv("EXON_HIP_REFERENCE_QUIRKS", "1")
+    got, chunks = count_rows(gz, "vcf", region=f"1:{a}-{b}", use_index=True)
+    assert got == want_quirk and chunks >= 1
+    s = exon_amd.Scan(gz, "vcf", region=f"1:{a}-{b}", use_index=True)
+    pos = np.concatenate([bt.field(1).to_numpy(zero_copy_only=False) for bt in s])
+    s.close()
+    assert int((pos <= b).sum()) == 10_000 and int((pos > b).sum()) == want_quirk - 10_000 and pos.max() <= 8192 * 2 + 8192
+    # fewer than batch_size hits per chunk: the two behaviours coincide (every reference test of this path sits here)
+    assert count_rows(gz, "vcf", region="1:50000-55000", use_index=True)[0] == 5001 == _reference_indexed_stream_rows(gz, "1", 50_000, 55_000)
+    # a scan without the index is the plain filtered stream in both modes
+    assert count_rows(gz, "vcf", region=f"1:{a}-{b}")[0] == 10_000
