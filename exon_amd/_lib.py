@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libexon_hip.so")
+# EXON_HIP_LIB: another build of the same library (A/B runs of kernel variants: tools/build_variant.sh)
+LIB_PATH = os.environ.get("EXON_HIP_LIB") or os.path.join(_HERE, "lib", "libexon_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 

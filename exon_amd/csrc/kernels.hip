@@ -53,7 +53,11 @@ typedef int v4i_t __attribute__((ext_vector_type(4)));
 template <typename T>
 __device__ __forceinline__ T ld16(const void* p) {
   static_assert(sizeof(T) == 16, "16-byte vector expected");
+#ifdef EXON_LD16_PLAIN  // A/B builds only (tools/build_variant.sh): every column load without the streaming hint
+  const v4i_t v = *reinterpret_cast<const v4i_t*>(p);
+#else
   const v4i_t v = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(p));
+#endif
   T r;
   __builtin_memcpy(&r, &v, 16);
   return r;

@@ -2,6 +2,7 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -342,18 +343,24 @@ int exon_hip_scan_close(exon_hip_scan* s) {
 // compressed inputs go through the (block-parallel) inflating source
 struct SlabReader {
   explicit SlabReader(exon::ByteSource* s) : src(s) { plain = src->plain_file(&fd, &foff); }
-  size_t read(uint8_t* dst, size_t n) {
-    if (!plain) {
-      size_t have = 0;
-      while (have < n) {
-        const size_t got = src->read(dst + have, n - have);
-        if (got == 0) break;
-        have += got;
-      }
-      return have;
+  ~SlabReader() {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      stop_ = true;
     }
-    // positional reads from the page cache; 8 threads saturate it (16 and 24 measured no faster: the copy out of the
-    // page cache competes with the DMA engine for the same memory).  EXON_HIP_READ_THREADS overrides.
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  // Asynchronous form: begin() starts reading the next `n` bytes of the input into `dst` and returns; finish() waits and
+  // returns how many arrived (fewer = end of input).  One read may be outstanding.  Positional files: a pool of threads that
+  // lives as long as the reader (spawning eight threads per 8 MB piece cost more than the reads themselves) copies slices
+  // out of the page cache; 8 threads saturate it (16 and 24 measured no faster: the copy out of the page cache competes with
+  // the DMA engine for the same memory).  EXON_HIP_READ_THREADS overrides.  Other sources are read at finish().
+  void begin(uint8_t* dst, size_t n) {
+    pend_dst_ = dst;
+    pend_n_ = n;
+    begun_ = true;
+    if (!plain || n == 0) return;
     static const int T = [] {
       int t = 8;
       if (const char* v = getenv("EXON_HIP_READ_THREADS")) {
@@ -362,36 +369,86 @@ struct SlabReader {
       }
       return t;
     }();
-    const size_t per = (n + T - 1) / T;
-    size_t got[32] = {0};
-    std::vector<std::thread> th;
-    for (int t = 0; t < T; ++t) {
-      const size_t o = (size_t)t * per;
-      if (o >= n) break;
-      const size_t len = std::min(per, n - o);
-      th.emplace_back([this, &got, dst, t, o, len] {
-        size_t done = 0;
-        while (done < len) {
-          const ssize_t r = pread(fd, dst + o + done, len - done, (off_t)(foff + (int64_t)(o + done)));
-          if (r <= 0) break;
-          done += (size_t)r;
-        }
-        got[t] = done;
-      });
+    if (th_.empty())
+      for (int t = 0; t < T; ++t) th_.emplace_back([this, t] { run(t); });
+    const size_t per = std::max<size_t>((n + T - 1) / T, 256u << 10);
+    std::lock_guard<std::mutex> g(mu_);
+    njobs_ = 0;
+    for (size_t o = 0; o < n; o += per) jobs_[njobs_++] = Job{dst + o, foff + (int64_t)o, std::min(per, n - o), 0};
+    pending_ = njobs_;
+    ++gen_;
+    cv_.notify_all();
+  }
+  size_t finish() {
+    if (!begun_) return 0;
+    begun_ = false;
+    if (!plain) {
+      size_t have = 0;
+      while (have < pend_n_) {
+        const size_t got = src->read(pend_dst_ + have, pend_n_ - have);
+        if (got == 0) break;
+        have += got;
+      }
+      return have;
     }
-    for (auto& x : th) x.join();
+    if (pend_n_ == 0) return 0;
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [this] { return pending_ == 0; });
     size_t total = 0;
-    for (int t = 0; t < T; ++t) {
-      total += got[t];
-      if (got[t] < std::min(per, n > (size_t)t * per ? n - (size_t)t * per : 0)) break;  // EOF inside this chunk
+    for (int j = 0; j < njobs_; ++j) {
+      total += jobs_[j].got;
+      if (jobs_[j].got < jobs_[j].len) break;  // EOF inside this slice
     }
     foff += (int64_t)total;
     return total;
+  }
+  size_t read(uint8_t* dst, size_t n) {
+    begin(dst, n);
+    return finish();
   }
   exon::ByteSource* src;
   bool plain = false;
   int fd = -1;
   int64_t foff = 0;
+
+ private:
+  struct Job {
+    uint8_t* dst;
+    int64_t off;
+    size_t len, got;
+  };
+  void run(int t) {
+    uint64_t seen = 0;
+    for (;;) {
+      Job j;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+        if (t >= njobs_) continue;
+        j = jobs_[t];
+      }
+      size_t done = 0;
+      while (done < j.len) {
+        const ssize_t r = pread(fd, j.dst + done, j.len - done, (off_t)(j.off + (int64_t)done));
+        if (r <= 0) break;
+        done += (size_t)r;
+      }
+      std::lock_guard<std::mutex> g(mu_);
+      jobs_[t].got = done;
+      if (--pending_ == 0) cv_done_.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_, cv_done_;
+  std::vector<std::thread> th_;
+  Job jobs_[32];
+  int njobs_ = 0, pending_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false, begun_ = false;
+  uint8_t* pend_dst_ = nullptr;
+  size_t pend_n_ = 0;
 };
 
 static size_t slab_bytes() {
@@ -424,6 +481,9 @@ struct SlabBuffers {
   size_t hcap = 0, tcap = 0, ccap = 0;
   int max_blocks = 0;
   uint8_t* h_buf[2] = {nullptr, nullptr};
+  uint8_t* h_ring = nullptr;  // the pinned staging ring (a few pieces) instead of two slab-sized pinned buffers
+  size_t ring_bytes = 0;
+  hipEvent_t ev_piece[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   uint8_t* d_comp[2] = {nullptr, nullptr};
   uint8_t* d_text[2] = {nullptr, nullptr};
   exon_hip_bgzf_block* h_blocks = nullptr;
@@ -431,6 +491,12 @@ struct SlabBuffers {
   hipStream_t cs = nullptr, xs = nullptr;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   void free_all() {
+    if (h_ring) hipHostFree(h_ring);
+    h_ring = nullptr;
+    for (auto& e : ev_piece) {
+      if (e) hipEventDestroy(e);
+      e = nullptr;
+    }
     if (cs) {
       exon_bgzf_forget_stream(cs);
       hipStreamDestroy(cs);
@@ -471,6 +537,7 @@ class GpuTextSource {
       : ctx_(ctx), hs_(hs), src_(std::move(src)), rd_(src_.get()), bgzf_(bgzf), binary_(binary), text_async_(text_async), skip_(skip_first),
         trim_last_(trim_last), carry_(std::move(carry)) {
     slab_ = slab_bytes();
+    ring_geometry();
     if (bgzf_) {
       // One wavefront inflates one block and a block takes ~3.5 ms however many run beside it, so a launch wants as many
       // blocks as the chip holds wavefronts of this kernel (24 per CU x 256 CUs) and not one more: slabs are cut by BLOCK
@@ -513,6 +580,9 @@ class GpuTextSource {
     }
     b.h_blocks = h_blocks_;
     b.d_blocks = d_blocks_;
+    b.h_ring = h_ring_;
+    b.ring_bytes = (size_t)RING_N * (RING_HEAD + RING_PIECE);
+    for (int q = 0; q < RING_MAX; ++q) b.ev_piece[q] = ev_piece_[q];
     if (!complete_) {
       b.free_all();
       return;
@@ -526,14 +596,18 @@ class GpuTextSource {
   double reader_seconds() const { return t_fill_; }
 
   int init() {
-    hcap_ = bgzf_ ? comp_cap_ + 4096 : gap_ + text_cap_ + 64;
+    // BGZF: compressed bytes are staged through a small pinned RING, piece by piece (read -> H2D -> header walk), so the pinned
+    // memory a scan needs no longer grows with the slab: 4 x 8 MB instead of 2 x 128 MB, i.e. ~8 ms of page pinning on a
+    // fresh context instead of 58 (0.23 ms per MB), and reads, copies and the header walk of one slab overlap piecewise.
+    hcap_ = 0;  // (plain text goes through the same ring: no slab-sized pinned buffers in either mode)
     if (bgzf_) max_blocks_ = target_blocks_ + 16;  // a slab never takes more blocks than that (see fill)
     {
       std::lock_guard<std::mutex> g(g_slab_mu);
       auto it = g_slab_cache.find(ctx_);
       if (it != g_slab_cache.end()) {
         SlabBuffers& b = it->second;
-        if (b.bgzf == bgzf_ && b.hcap == hcap_ && b.tcap == gap_ + text_cap_ && b.ccap == comp_cap_ && b.max_blocks == max_blocks_) {
+        if (b.bgzf == bgzf_ && b.hcap == hcap_ && b.tcap == gap_ + text_cap_ && b.ccap == comp_cap_ && b.max_blocks == max_blocks_ &&
+            b.ring_bytes == (size_t)RING_N * (RING_HEAD + RING_PIECE)) {
           for (int k = 0; k < 2; ++k) {
             h_buf_[k] = b.h_buf[k];
             d_comp_[k] = b.d_comp[k];
@@ -541,6 +615,12 @@ class GpuTextSource {
           }
           h_blocks_ = b.h_blocks;
           d_blocks_ = b.d_blocks;
+          h_ring_ = b.h_ring;
+          b.h_ring = nullptr;
+          for (int q = 0; q < RING_MAX; ++q) {
+            ev_piece_[q] = b.ev_piece[q];
+            b.ev_piece[q] = nullptr;
+          }
           cs_ = b.cs;
           xs_ = b.xs;
           for (int k = 0; k < 2; ++k) {
@@ -563,7 +643,9 @@ class GpuTextSource {
       // runtime serialises allocations: handing the second set to a helper thread moved the wait, it did not shorten it)
       for (int k = 0; k < 2; ++k) {
         const double a0 = now_s();
-        if (hipHostMalloc((void**)&h_buf_[k], hcap_) != hipSuccess) return fail(ctx_, EXON_HIP_ENOMEM, "pinned slab buffer of %zu bytes could not be allocated", hcap_);
+        if (hcap_ && hipHostMalloc((void**)&h_buf_[k], hcap_) != hipSuccess) return fail(ctx_, EXON_HIP_ENOMEM, "pinned slab buffer of %zu bytes could not be allocated", hcap_);
+        if (k == 0 && !h_ring_ && hipHostMalloc((void**)&h_ring_, (size_t)RING_N * (RING_HEAD + RING_PIECE)) != hipSuccess)
+          return fail(ctx_, EXON_HIP_ENOMEM, "pinned staging ring could not be allocated");
         const double a1 = now_s();
         if (hipMalloc((void**)&d_text_[k], gap_ + text_cap_ + 256) != hipSuccess || (bgzf_ && hipMalloc((void**)&d_comp_[k], comp_cap_ + 8192) != hipSuccess))
           return fail(ctx_, EXON_HIP_ENOMEM, "slab buffers (%zu bytes of text) could not be allocated", text_cap_);
@@ -578,7 +660,10 @@ class GpuTextSource {
     }
     const double ti1 = now_s();
     // the inflate stream runs at the LOWEST priority: its kernels fill every workgroup slot for milliseconds, and the parse
-    // kernels of the previous slab (the consumer's stream, highest priority: stream.cpp) are short and on the critical path
+    // kernels of the previous slab (the consumer's stream, highest priority: stream.cpp) are short and on the critical path.
+    // (Round 4 tried making the streams -- ~17 ms on a fresh context: the first use of two more hardware queues -- and the first
+    // inflate's scratch + code objects on a helper thread while this one pins the ring and reads the first piece: the runtime
+    // serialises them with the allocations, the setup stayed at 41-42 ms, and the thread was dropped.)
     int prio_least = 0, prio_greatest = 0;
     const char* pv = getenv("EXON_HIP_STREAM_PRIORITY");
     const bool use_prio = !(pv && pv[0] == '0') && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess && prio_least != prio_greatest;
@@ -590,6 +675,8 @@ class GpuTextSource {
                            hipEventCreateWithFlags(&ev_done_[k], hipEventDisableTiming) != hipSuccess ||
                            hipEventCreateWithFlags(&ev_free_[k], hipEventDisableTiming) != hipSuccess))
         return fail(ctx_, EXON_HIP_EDEVICE, "event creation failed");
+    for (int q = 0; q < RING_N; ++q)
+      if (!ev_piece_[q] && hipEventCreateWithFlags(&ev_piece_[q], hipEventDisableTiming) != hipSuccess) return fail(ctx_, EXON_HIP_EDEVICE, "event creation failed");
     if (bgzf_) {
       if (!ev_carry_ && hipEventCreateWithFlags(&ev_carry_, hipEventDisableTiming) != hipSuccess) return fail(ctx_, EXON_HIP_EDEVICE, "event creation failed");
       const double ti2 = now_s();
@@ -600,7 +687,7 @@ class GpuTextSource {
       if (rc) return rc;
       if (trace)
         fprintf(stderr, "[exon-hip pipe] init: pinned allocations %.1f ms (%zu MB), device allocations %.1f ms, tables %.1f ms, streams+events %.1f ms, first fill %.1f ms, first inflate enqueue %.1f ms\n",
-                t_host * 1e3, (2 * hcap_) >> 20, t_dev * 1e3, (ti1 - ti0 - t_host - t_dev) * 1e3, (ti2 - ti1) * 1e3, (ti3 - ti2) * 1e3, (now_s() - ti3) * 1e3);
+                t_host * 1e3, (2 * hcap_ + (size_t)RING_N * (RING_HEAD + RING_PIECE)) >> 20, t_dev * 1e3, (ti1 - ti0 - t_host - t_dev) * 1e3, (ti2 - ti1) * 1e3, (ti3 - ti2) * 1e3, (now_s() - ti3) * 1e3);
       if (!f_[0].eof) reader_ = std::thread([this] { fill(1, &f_[1]); });
       return EXON_HIP_OK;
     }
@@ -645,7 +732,7 @@ class GpuTextSource {
     if (more) reader_ = std::thread([this, k] { fill(k ^ 1, &nxt_); });  // overlaps with everything the GPU does below
     if (!more && n_text > 0) {  // last line without a terminator (a carried tail never ends in one)
       // the slab's last byte is on the host unless the slab is a carried tail only (cur_.n and front_extra both 0)
-      const bool ends_nl = (cur_.n > 0 || cur_.front_extra > 0) && h_buf_[k][gap_ + cur_.n - 1] == '\n';
+      const bool ends_nl = (cur_.n > 0 || cur_.front_extra > 0) && cur_.last_byte == '\n';
       if (!ends_nl) {
         HIP_TRY(ctx_, hipMemsetAsync(d_text_[k] + front + n_text, '\n', 1, hs_));
         ++n_text;
@@ -776,6 +863,7 @@ class GpuTextSource {
     int n_blocks = 0;      // bgzf
     size_t out_bytes = 0;  // bgzf: inflated size of those blocks
     size_t front_extra = 0;  // plain, first slab: bytes of the host reader's buffer placed in front of the fresh ones
+    uint8_t last_byte = 0;   // plain: the slab's last byte (does the input end with a newline?)
     bool eof = false;
     std::exception_ptr err;
   };
@@ -785,69 +873,182 @@ class GpuTextSource {
     struct Acc { double* a; double t0; ~Acc() { *a += now_s() - t0; } } acc{&t_fill_, t_fill0};
     try {
       if (!bgzf_) {
-        f->n = rd_.read(h_buf_[k] + gap_, text_cap_);
-        f->eof = f->n < text_cap_;
+        // plain text: file -> pinned ring piece -> d_text_[k] behind the gap, piece by piece on the copy stream (under the parse
+        // of the previous slab); what the host header reader had buffered goes in front of the first slab
+        hipSetDevice(ctx_->device);
+        if (free_rec_[k] && hipStreamWaitEvent(xs_, ev_free_[k], 0) != hipSuccess) throw std::runtime_error("H2D of a text slab failed");
         f->front_extra = 0;
-        if (!carry_.empty()) {  // first slab: what the host header reader had already buffered goes in front
-          memcpy(h_buf_[k] + gap_ - carry_.size(), carry_.data(), carry_.size());
+        if (!carry_.empty()) {
+          if (hipMemcpyAsync(d_text_[k] + gap_ - carry_.size(), carry_.data(), carry_.size(), hipMemcpyHostToDevice, xs_) != hipSuccess ||
+              hipStreamSynchronize(xs_) != hipSuccess)  // pageable source: it must stay alive until the copy has been staged
+            throw std::runtime_error("H2D of a text slab failed");
           f->front_extra = carry_.size();
+          f->last_byte = (uint8_t)carry_.back();
           carry_.clear();
         }
-        // the bytes start crossing PCIe right away on the copy stream, under the parse of the previous slab
-        hipSetDevice(ctx_->device);
-        if ((free_rec_[k] && hipStreamWaitEvent(xs_, ev_free_[k], 0) != hipSuccess) ||
-            (f->n + f->front_extra > 0 && hipMemcpyAsync(d_text_[k] + gap_ - f->front_extra, h_buf_[k] + gap_ - f->front_extra, f->n + f->front_extra,
-                                                          hipMemcpyHostToDevice, xs_) != hipSuccess) ||
-            hipEventRecord(ev_h2d_[k], xs_) != hipSuccess)
-          throw std::runtime_error("H2D of a text slab failed");
+        size_t off = 0;
+        bool eof = false;
+        struct Piece {
+          bool active = false;
+          int p = 0;
+          uint8_t* base = nullptr;
+          size_t want = 0;
+        };
+        auto start_piece = [&](size_t at_off) {
+          Piece pc;
+          if (at_off >= text_cap_) return pc;
+          pc.p = ring_next_;
+          ring_next_ = (pc.p + 1) % RING_N;
+          if (piece_used_[pc.p] && hipEventSynchronize(ev_piece_[pc.p]) != hipSuccess) throw std::runtime_error("staging ring: event wait failed");
+          pc.base = h_ring_ + (size_t)pc.p * (RING_HEAD + RING_PIECE) + RING_HEAD;
+          pc.want = std::min(RING_PIECE, text_cap_ - at_off);
+          rd_.begin(pc.base, pc.want);
+          pc.active = true;
+          return pc;
+        };
+        Piece cur = start_piece(0);
+        while (cur.active) {
+          const double tf0 = now_s();
+          const size_t got = rd_.finish();
+          t_read_ += now_s() - tf0;
+          eof = got < cur.want;
+          Piece nxt;
+          if (!eof) nxt = start_piece(off + got);  // read under this piece's copy
+          if (got == 0) break;
+          if (hipMemcpyAsync(d_text_[k] + gap_ + off, cur.base, got, hipMemcpyHostToDevice, xs_) != hipSuccess || hipEventRecord(ev_piece_[cur.p], xs_) != hipSuccess)
+            throw std::runtime_error("H2D of a text slab failed");
+          piece_used_[cur.p] = true;
+          f->last_byte = cur.base[got - 1];
+          off += got;
+          cur = nxt;
+        }
+        f->n = off;
+        f->eof = eof;
+        if (hipEventRecord(ev_h2d_[k], xs_) != hipSuccess) throw std::runtime_error("H2D of a text slab failed");
         return;
       }
-      // [blocks left over from the previous chunk | fresh bytes]; whole blocks only, inflated size <= text_cap_
-      memcpy(h_buf_[k], left_.data(), left_.size());
-      size_t have = left_.size();
-      left_.clear();
-      // the first slab is an eighth of the others: the GPU starts early, the pipeline is full from the second slab on
+      // [bytes left over from the previous slab | fresh bytes] -> d_comp_[k], through the pinned ring one piece at a time:
+      // the piece's H2D is queued the moment it is read (its own stream, under the inflate of the previous slab) and the
+      // header walk of the piece runs under that copy.  Whole blocks only, at most `target` of them, inflated size <= text_cap_.
+      // The first slab is an eighth of the others: the GPU starts early, the pipeline is full from the second slab on.
       const int target = first_fill_ ? std::max(64, target_blocks_ / 8) : target_blocks_;
       first_fill_ = false;
+      const int cap_blocks = std::min(max_blocks_, target);
       const size_t goal = std::min(comp_cap_, (size_t)((double)est_block_ * target * 1.03) + (1u << 16));
-      const double tf0 = now_s();
-      if (!file_eof_ && have < goal) {
-        const size_t want = goal - have;
-        const size_t got = rd_.read(h_buf_[k] + have, want);
-        file_eof_ = got < want;
-        have += got;
-      }
-      const double tf1 = now_s();
-      memset(h_buf_[k] + have, 0, 4096);  // readable zero padding behind the last byte, written BEFORE the copy is queued
-      if (xs_ && have > 0) {
-        // Everything read starts crossing PCIe at once (its own stream, under the inflate of the previous slab) and the
-        // header walk below runs under that copy: the slab must be in HBM one inflate period after this thread
-        // started, and read + walk + copy in a row did not fit.  (A trailing partial block goes along; it is unused.)
-        hipSetDevice(ctx_->device);
-        if (hipMemcpyAsync(d_comp_[k], h_buf_[k], have + 4096, hipMemcpyHostToDevice, xs_) != hipSuccess)
-          throw std::runtime_error("H2D of a compressed slab failed");
-      }
-      int32_t nb = 0;
-      size_t consumed = 0, out_bytes = 0;
-      if (exon_hip_bgzf_scan(h_buf_[k], have, 0, h_blocks_tmp(k), std::min(max_blocks_, target), &nb, &consumed, &out_bytes) != EXON_HIP_OK)
-        throw std::runtime_error(exon_hip_last_error(nullptr));
-      t_read_ += tf1 - tf0;
-      t_scan_ += now_s() - tf1;
-      if (nb > 0) est_block_ = (double)consumed / nb;
       exon_hip_bgzf_block* hb = h_blocks_tmp(k);
-      if (out_bytes > text_cap_) {
+      std::string pend;
+      pend.swap(left_);
+      size_t pend_pos = 0, off = 0, consumed_total = 0, out_bytes = 0, view_carry = 0;
+      int nb = 0;
+      bool stop = false;
+      std::string rest;  // what follows the last accepted block in the bytes already taken
+      hipSetDevice(ctx_->device);
+      // piece i+1 is being read (SlabReader's pool) while piece i crosses PCIe and its headers are walked
+      struct Piece {
+        bool active = false, reading = false;
+        int p = 0;
+        uint8_t* base = nullptr;
+        size_t n_pend = 0, want = 0;
+      };
+      auto start_piece = [&](size_t at_off) {
+        Piece pc;
+        if (at_off >= goal) return pc;
+        pc.p = ring_next_;
+        ring_next_ = (pc.p + 1) % RING_N;
+        if (piece_used_[pc.p] && hipEventSynchronize(ev_piece_[pc.p]) != hipSuccess) throw std::runtime_error("staging ring: event wait failed");
+        pc.base = h_ring_ + (size_t)pc.p * (RING_HEAD + RING_PIECE) + RING_HEAD;
+        pc.want = std::min(RING_PIECE, goal - at_off);
+        if (pend_pos < pend.size()) {
+          pc.n_pend = std::min(pc.want, pend.size() - pend_pos);
+          memcpy(pc.base, pend.data() + pend_pos, pc.n_pend);
+          pend_pos += pc.n_pend;
+        }
+        if (pc.n_pend < pc.want && !file_eof_) {
+          rd_.begin(pc.base + pc.n_pend, pc.want - pc.n_pend);
+          pc.reading = true;
+        }
+        pc.active = pc.reading || pc.n_pend > 0;
+        return pc;
+      };
+      Piece cur = start_piece(0);
+      while (cur.active) {
+        const double tf0 = now_s();
+        size_t n = cur.n_pend;
+        if (cur.reading) {
+          const size_t got = rd_.finish();
+          file_eof_ = got < cur.want - cur.n_pend;
+          n += got;
+        }
+        const double tf1 = now_s();
+        t_read_ += tf1 - tf0;
+        Piece nxt;
+        if (n == cur.want) nxt = start_piece(off + n);  // its read runs under everything below
+        if (n == 0) break;
+        uint8_t* base = cur.base;
+        const int p = cur.p;
+        if (hipMemcpyAsync(d_comp_[k] + off, base, n, hipMemcpyHostToDevice, xs_) != hipSuccess || hipEventRecord(ev_piece_[p], xs_) != hipSuccess)
+          throw std::runtime_error("H2D of a compressed piece failed");
+        piece_used_[p] = true;
+        // the block that straddles the piece boundary: its head (kept in piece_carry_) goes right in front of this piece's bytes
+        uint8_t* view = base - view_carry;
+        if (view_carry) memcpy(view, piece_carry_.data(), view_carry);
+        const size_t vn = view_carry + n;
+        int32_t got_nb = 0;
+        size_t consumed = 0, ob = 0;
+        if (exon_hip_bgzf_scan(view, vn, out_bytes, hb + nb, cap_blocks - nb, &got_nb, &consumed, &ob) != EXON_HIP_OK)
+          throw std::runtime_error(exon_hip_last_error(nullptr));
+        // text capacity: keep the blocks that fit
         int keep = 0;
-        while (keep < nb && (size_t)hb[keep].out_offset + hb[keep].out_size <= text_cap_) ++keep;
-        nb = keep;
-        out_bytes = nb ? (size_t)hb[nb - 1].out_offset + hb[nb - 1].out_size : 0;
-        consumed = nb ? (size_t)hb[nb - 1].comp_offset + hb[nb - 1].comp_size + 8 : 0;
+        size_t kept_out = 0, kept_consumed = 0;
+        while (keep < got_nb && (size_t)hb[nb + keep].out_offset + hb[nb + keep].out_size <= text_cap_) {
+          kept_out += hb[nb + keep].out_size;
+          ++keep;
+        }
+        const uint32_t view_global = (uint32_t)(off - view_carry);  // where `view` starts inside d_comp_[k]
+        if (keep < got_nb) {  // the slab's text is full: everything from the first rejected block on belongs to the next slab
+          kept_consumed = keep ? (size_t)hb[nb + keep - 1].comp_offset + hb[nb + keep - 1].comp_size + 8 : 0;
+          stop = true;
+        } else {
+          kept_consumed = consumed;
+          if (nb + keep >= cap_blocks) stop = true;
+        }
+        for (int i = 0; i < keep; ++i) hb[nb + i].comp_offset += view_global;
+        nb += keep;
+        out_bytes += kept_out;
+        consumed_total = (size_t)view_global + kept_consumed;
+        off += n;
+        t_scan_ += now_s() - tf1;
+        const size_t tail = vn - kept_consumed;
+        if (stop) {
+          rest.assign(reinterpret_cast<const char*>(view) + kept_consumed, tail);
+          if (nxt.active) {  // the slab filled up while the next piece was being read: those bytes open the next slab
+            size_t m = nxt.n_pend;
+            if (nxt.reading) {
+              const size_t got = rd_.finish();
+              file_eof_ = got < nxt.want - nxt.n_pend;
+              m += got;
+            }
+            rest.append(reinterpret_cast<const char*>(nxt.base), m);
+          }
+          break;
+        }
+        if (tail > RING_HEAD) throw std::runtime_error("BGZF block larger than the staging headroom");
+        piece_carry_.assign(view + kept_consumed, view + vn);
+        view_carry = tail;
+        cur = nxt;
       }
-      if (nb == 0 && have > 0 && !(file_eof_ && consumed == have)) {
+      if (!stop && view_carry) rest.assign(reinterpret_cast<const char*>(piece_carry_.data()), view_carry);
+      // readable zero padding behind the last byte (the bit reader looks ahead)
+      if (off > 0 && hipMemsetAsync(d_comp_[k] + off, 0, 4096, xs_) != hipSuccess) throw std::runtime_error("padding of a compressed slab failed");
+      if (nb > 0) est_block_ = (double)consumed_total / nb;
+      left_ = rest;
+      if (pend_pos < pend.size()) left_.append(pend, pend_pos, std::string::npos);
+      if (nb == 0 && off > 0 && !(file_eof_ && left_.empty())) {
         if (file_eof_) throw std::runtime_error("truncated BGZF block at the end of the file");
         throw std::runtime_error("BGZF block larger than the slab");
       }
-      left_.assign(reinterpret_cast<const char*>(h_buf_[k]) + consumed, have - consumed);
-      f->n = consumed;
+      const size_t have = off;
+      f->n = consumed_total;
       f->n_blocks = nb;
       f->out_bytes = out_bytes;
       f->eof = file_eof_ && left_.empty();
@@ -889,6 +1090,32 @@ class GpuTextSource {
   size_t slab_ = 0, comp_cap_ = 0, text_cap_ = 0, gap_ = 0, hcap_ = 0;
   bool complete_ = false;  // all buffers allocated (only complete sets go back to the cache)
   uint8_t* h_buf_[2] = {nullptr, nullptr};
+  static constexpr size_t RING_HEAD = 1u << 17;  // headroom in front of a piece for a block that straddles the piece boundary
+  static constexpr int RING_MAX = 8;
+  // piece size / count of the pinned staging ring.  Same-box sweep (profiles/r4_ring_sweep.log, warm, against round 3's two
+  // slab-sized pinned buffers): BGZF inputs run the same with 8, 16 or 32 MB pieces (65-67 ms for the 100 M-row .vcf.gz, the loop
+  // is inflate-bound), plain text gets FASTER with pieces of 16 MB and more (plain VCF 108-113 -> 86-90 ms, plain FASTQ 161 ->
+  // 126-128 ms: read, copy and parse now overlap piece by piece instead of slab by slab).  BGZF takes the smallest ring (pinning
+  // costs 0.23 ms per MB on a fresh context), plain text 4 x 16 MB.  EXON_HIP_RING_PIECE_MB / EXON_HIP_RING_PIECES override.
+  size_t RING_PIECE = 8u << 20;
+  int RING_N = 4;
+  void ring_geometry() {
+    RING_PIECE = (size_t)(bgzf_ ? 8 : 16) << 20;
+    RING_N = 4;
+    if (const char* v = getenv("EXON_HIP_RING_PIECE_MB")) {
+      const long mb = atol(v);
+      if (mb >= 1 && mb <= 64) RING_PIECE = (size_t)mb << 20;
+    }
+    if (const char* v = getenv("EXON_HIP_RING_PIECES")) {
+      const int n = atoi(v);
+      if (n >= 2 && n <= RING_MAX) RING_N = n;
+    }
+  }
+  uint8_t* h_ring_ = nullptr;
+  hipEvent_t ev_piece_[RING_MAX] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool piece_used_[RING_MAX] = {false, false, false, false, false, false, false, false};
+  int ring_next_ = 0;
+  std::vector<uint8_t> piece_carry_;
   uint8_t* d_comp_[2] = {nullptr, nullptr};
   uint8_t* d_text_[2] = {nullptr, nullptr};
   exon_hip_bgzf_block* h_blocks_ = nullptr;  // pinned: table + status of the slab in flight
