@@ -367,10 +367,13 @@ static int resident_blocks(F f, int threads, size_t lds) {
 }
 
 // The big shapes pay off as soon as every CU gets a tile (>= 2.1 M rows on 256 CUs: even ~2 tiles per CU beat the
-// 256-thread shape, 10 M rows: 41 -> 31 us).  Between J = 4 (16384-row tiles) and J = 2 (8192-row tiles) the static
-// tile -> workgroup deal decides: the critical path is ceil(tiles / CUs) tiles, which at 10 M rows (config 2's stated
-// size) is 3 x 16384 rows with J = 4 but 5 x 8192 with J = 2 (610 tiles over 256 CUs leave a third round that only a
-// third of the chip works on).  Ties go to the bigger tile (more loads in flight per lane).
+// 256-thread shape, 10 M rows: 41 -> 31 us).  Between J = 4 (16384-row tiles) and J = 2 (8192-row tiles): round 3 took J = 2 only
+// where the static tile -> workgroup deal made its critical path (ceil(tiles / CUs) tiles) more than 3 % shorter, ties going to
+// the bigger tile.  Round 4 swept both shapes over 1e7 .. 1e9 rows on one box (profiles/r4_shape_sweep.log): for K2 and K3
+// J = 2 is never slower and up to 9 % faster below 1e8 rows (K2 at 2e7 rows: 38.5 vs 42.0 us = 0.78 vs 0.72 of peak, at 5e7:
+// 92.0 vs 96.8 us; K3 at 2e7: 31.7 vs 33.4 us), equal within the box-to-box noise from 2.5e8 rows up -- a tie on the critical
+// path is not a tie: the smaller tile also ramps up and drains faster.  K2 / K3 / K6 take J = 2 whenever they take a big
+// shape; K4 keeps J = 4 (its own rule below).
 enum { SHAPE_SMALL = 0, SHAPE_BIG_J2 = 1, SHAPE_BIG_J4 = 2 };
 static int pick_shape(const LaunchCfg& cfg, int64_t n) {
   static const int forced = [] {
@@ -379,11 +382,7 @@ static int pick_shape(const LaunchCfg& cfg, int64_t n) {
   }();
   if (forced >= 0) return forced;
   const int64_t cus = std::max(cfg.compute_units, 1);
-  const int64_t t2 = n / ShapeOf<ShapeBigJ2>::TILE, t4 = n / ShapeOf<ShapeBig>::TILE;
-  if (t2 < cus) return SHAPE_SMALL;
-  if (t4 < cus) return SHAPE_BIG_J2;
-  const int64_t c4 = ((t4 + cus - 1) / cus) * ShapeOf<ShapeBig>::TILE, c2 = ((t2 + cus - 1) / cus) * ShapeOf<ShapeBigJ2>::TILE;
-  return c2 + c2 / 32 < c4 ? SHAPE_BIG_J2 : SHAPE_BIG_J4;  // J = 2 only when it shortens the critical path by > 3 %: the big tile keeps more loads in flight
+  return n / ShapeOf<ShapeBigJ2>::TILE < cus ? SHAPE_SMALL : SHAPE_BIG_J2;
 }
 static bool use_big_shape(const LaunchCfg& cfg, int64_t n) { return pick_shape(cfg, n) != SHAPE_SMALL; }
 
