@@ -62,8 +62,9 @@ def parse_args():
                          "auto = native when it initialises and reproduces torch's result during warm-up, else torch")
     ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3", "c5", "c6"])
     ap.add_argument("--groups", type=int, default=5,
-                    help="c4 only: number of GROUP BY keys.  5 = config 4's FILTER mix (ids in registers); > 8 adds the LDS table "
-                         "(ids 8..4103) and, beyond 4104 ids, global atomics -- the paths files and high-cardinality keys take")
+                    help="c4 only: number of GROUP BY keys.  5 = config 4's FILTER mix (ids in registers); > 8 keeps ids 0..3 in "
+                         "registers, ids 4..4099 in the LDS table and partitions ids >= 4100 by id range -- the paths files and "
+                         "high-cardinality keys take")
     ap.add_argument("--group-dist", default="zipf", choices=["zipf", "uniform"],
                     help="--groups != 5: key frequencies.  zipf = log-uniform ids (P(id < k) = ln(k+1)/ln(G+1): dictionary ids "
                          "are handed out in order of first appearance, so frequent keys are early); uniform = the worst case")
@@ -549,8 +550,12 @@ def main():
             if not torch.allclose(chk.sums, sm, rtol=1e-9, atol=0):
                 raise SystemExit("PARITY FAILURE: sums vs torch reference")
             out["parity"] = f"bit-exact counts, sums within 1e-9 rel. vs a torch fp64 reference on rows [{lo},{lo + m})"
-            out["config"]["groups"] = {"n": G, "dist": a.group_dist, "rows_in_registers_ids_lt_8": int(crow[:8].sum()),
-                                       "rows_in_lds_ids_8_to_4103": int(crow[8:4104].sum()), "rows_by_global_atomics": int(crow[4104:].sum()),
+            # tiers of the > 8-key kernel (kernels.hip: K4_OVF_REGS = 4 register ids, K4_LDS_GROUPS = 4100 ids up to the LDS
+            # table's end, the rest partitioned by id range and aggregated range by range); <= 8 keys: all in registers
+            reg = G if G <= 8 else 4
+            out["config"]["groups"] = {"n": G, "dist": a.group_dist, f"rows_in_registers_ids_lt_{reg}": int(crow[:reg].sum()),
+                                       "rows_in_lds_table_ids_4_to_4099": int(crow[reg:4100].sum()) if G > 8 else 0,
+                                       "rows_partitioned_ids_ge_4100": int(crow[4100:].sum()) if G > 8 else 0,
                                        "of_rows_passing": int(crow.sum()), "sample_rows": m}
             del chk
         elif not a.no_cpu_baseline and world == 1:

@@ -5,6 +5,7 @@
 // with validity, and a struct ("record batch") array with an explicit row count so zero-column batches
 // still carry their length (`with_row_count(Some(self.len()))`, :29-33).
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -17,16 +18,28 @@
 namespace exon {
 
 // ---- owned Arrow arrays / schemas --------------------------------------------------------------------
+// A pooled block that the buffers of several arrays live in (host/cram.h: batches built on decoder threads and released on
+// the consumer's).  Reference-counted: the struct array AND each of its view children hold a reference, because the Arrow C
+// data interface lets a consumer move a child out of its parent and release the parent first -- the block goes back to its
+// pool (`put`) when the last holder is released, never while a moved-out child still points into it.
+struct SharedBlock {
+  std::atomic<int> refs{1};
+  void* block = nullptr;
+  size_t bytes = 0;
+  void (*put)(void*, size_t) = nullptr;
+};
+inline void block_unref(SharedBlock* b) {
+  if (b && b->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+    if (b->block && b->put) b->put(b->block, b->bytes);
+    delete b;
+  }
+}
 struct OwnedArray {
   std::vector<void*> bufs;            // malloc'ed, freed on release
   std::vector<const void*> buf_ptrs;  // ArrowArray::buffers
   std::vector<struct ArrowArray*> children;
   struct ArrowArray* dictionary = nullptr;
-  // a block the buffers of this array (and of its children) live in, handed back through `block_put` on release instead of
-  // being freed buffer by buffer (host/cram.h: batches built on decoder threads and released on the consumer's)
-  void* block = nullptr;
-  size_t block_bytes = 0;
-  void (*block_put)(void*, size_t) = nullptr;
+  SharedBlock* block = nullptr;       // one reference to the block the buffers live in (nullptr: bufs own them)
 };
 inline void release_array(struct ArrowArray* a) {
   if (!a || !a->release) return;
@@ -40,16 +53,21 @@ inline void release_array(struct ArrowArray* a) {
     free(o->dictionary);
   }
   for (void* b : o->bufs) free(b);
-  if (o->block && o->block_put) o->block_put(o->block, o->block_bytes);
+  block_unref(o->block);
   delete o;
   a->release = nullptr;
 }
-// an array whose buffers belong to somebody else (a block owned by the parent struct array)
-inline struct ArrowArray* new_view_array(const void* validity, const void* values, int64_t n, int64_t nulls, struct ArrowArray* dictionary = nullptr) {
+// an array whose buffers live in a shared pooled block: it takes its own reference to the block
+inline struct ArrowArray* new_view_array(SharedBlock* block, const void* validity, const void* values, int64_t n, int64_t nulls,
+                                         struct ArrowArray* dictionary = nullptr) {
   struct ArrowArray* a = static_cast<struct ArrowArray*>(malloc(sizeof *a));
   OwnedArray* o = new OwnedArray();
   o->buf_ptrs = {validity, values};
   o->dictionary = dictionary;
+  if (block) {
+    block->refs.fetch_add(1, std::memory_order_relaxed);
+    o->block = block;
+  }
   memset(a, 0, sizeof *a);
   a->length = n;
   a->null_count = nulls;

@@ -1164,17 +1164,19 @@ class CRAMBatchReader {
     };
     const int64_t n_mapq = pack(k.mapq_ok.data() + o, v_mapq), n_ref = pack(k.ref_ok.data() + o, v_ref), n_pos = pack(k.pos_ok.data() + o, v_pos);
     if (n_pos) memcpy(v_pos2, v_pos, bm);
+    // the parent and every child hold a reference to the block: a consumer may move children out and release the parent first
+    SharedBlock* blk = new SharedBlock();
+    blk->block = base;
+    blk->bytes = bytes;
+    blk->put = &BlockPool::put;
     std::vector<struct ArrowArray*> kids = {
-        new_view_array(nullptr, flag, (int64_t)n, 0),
-        new_view_array(n_mapq ? v_mapq : nullptr, mapq, (int64_t)n, n_mapq),
-        new_view_array(n_ref ? v_ref : nullptr, ref, (int64_t)n, n_ref, utf8_array(ref_names)),
-        new_view_array(n_pos ? v_pos : nullptr, start, (int64_t)n, n_pos),
-        new_view_array(n_pos ? v_pos2 : nullptr, end, (int64_t)n, n_pos)};
+        new_view_array(blk, nullptr, flag, (int64_t)n, 0),
+        new_view_array(blk, n_mapq ? v_mapq : nullptr, mapq, (int64_t)n, n_mapq),
+        new_view_array(blk, n_ref ? v_ref : nullptr, ref, (int64_t)n, n_ref, utf8_array(ref_names)),
+        new_view_array(blk, n_pos ? v_pos : nullptr, start, (int64_t)n, n_pos),
+        new_view_array(blk, n_pos ? v_pos2 : nullptr, end, (int64_t)n, n_pos)};
     make_struct(out, (int64_t)n, std::move(kids));
-    OwnedArray* own = static_cast<OwnedArray*>(out->private_data);
-    own->block = base;
-    own->block_bytes = bytes;
-    own->block_put = &BlockPool::put;
+    static_cast<OwnedArray*>(out->private_data)->block = blk;  // the creator's reference passes to the parent
   }
 
   struct Job {

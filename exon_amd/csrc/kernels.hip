@@ -94,6 +94,18 @@ __device__ __forceinline__ bool valid1(const uint8_t* __restrict__ bm, int64_t r
   return bm == nullptr ? true : ((bm[r >> 3] >> (r & 7)) & 1);
 }
 
+// Which workgroup takes the rows behind the last whole tile.  Tiles are dealt b, b + grid, ...: the LAST workgroups are the
+// ones with a tile less when the tiles do not divide evenly, so the remainder -- a dependent load behind the tile loop, one
+// HBM latency -- goes to them and stays off the critical path (the first workgroups carried it until round 4; A/B build:
+// -DEXON_REM_FRONT, profiles/r4_small_configs.log).
+__device__ __forceinline__ unsigned rem_block() {
+#ifdef EXON_REM_FRONT
+  return blockIdx.x;
+#else
+  return gridDim.x - 1u - blockIdx.x;
+#endif
+}
+
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -443,7 +455,7 @@ __global__ __launch_bounds__(S::THREADS) void k2_region_count_main(const int32_t
       cnt += k2_row(c[j].w, p1[j].y, cm[j] >> 3 & 1, pm[j] >> 3 & 1, id, a, b);
     }
   }
-  for (int64_t r = ntiles * TILE + (int64_t)blockIdx.x * THREADS + threadIdx.x; r < n;
+  for (int64_t r = ntiles * TILE + (int64_t)rem_block() * THREADS + threadIdx.x; r < n;
        r += (int64_t)gridDim.x * THREADS)
     cnt += k2_row(chrom[r], pos[r], valid1(cvalid, r), valid1(pvalid, r), id, a, b);
 
@@ -547,7 +559,7 @@ __global__ __launch_bounds__(S::THREADS) void k6_overlap_count_main(const int32_
       cnt += k6_row<STRICT>(c[j].w, s1[j].y, e1[j].y, rm[j] >> 3 & 1, sm[j] >> 3 & 1, em[j] >> 3 & 1, id, a, b);
     }
   }
-  for (int64_t r = ntiles * TILE + (int64_t)blockIdx.x * THREADS + threadIdx.x; r < n;
+  for (int64_t r = ntiles * TILE + (int64_t)rem_block() * THREADS + threadIdx.x; r < n;
        r += (int64_t)gridDim.x * THREADS)
     cnt += k6_row<STRICT>(ref[r], start[r], end[r], valid1(rvalid, r), valid1(svalid, r), valid1(evalid, r), id, a, b);
 
@@ -745,7 +757,7 @@ __global__ __launch_bounds__(S::THREADS) void k3_flag_mapq_group_count_main(
     for (int j = 0; j < J; ++j)
       rows4(f[j], q[j], g[j], fm[j], mm[j], rm[j]);
   }
-  for (int64_t r = ntiles * TILE + (int64_t)blockIdx.x * THREADS + threadIdx.x; r < n;
+  for (int64_t r = ntiles * TILE + (int64_t)rem_block() * THREADS + threadIdx.x; r < n;
        r += (int64_t)gridDim.x * THREADS)
     row(flag[r], mapq[r], ref[r], valid1(fvalid, r), valid1(mvalid, r), valid1(rvalid, r));
 
@@ -1126,7 +1138,7 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
   }
   spill();
   since = 0;
-  for (int64_t r = ntiles * TILE + (int64_t)blockIdx.x * THREADS + threadIdx.x; r < n;
+  for (int64_t r = ntiles * TILE + (int64_t)rem_block() * THREADS + threadIdx.x; r < n;
        r += (int64_t)gridDim.x * THREADS) {
     const float yf = y[r];
     const int32_t g = gid[r];

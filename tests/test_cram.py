@@ -312,3 +312,37 @@ def test_slice_spans_equal_the_htslib_written_index(name):
                 g[1] = e if g[1] is None else max(g[1], e)
         mine = [(k[2], v[0] or 0, v[1] - v[0] + 1 if v[0] else 1, k[0], k[1]) for k, v in groups.items()]
         assert mine == [c[:5] for c in crai], source
+
+
+def test_a_child_moved_out_of_a_batch_outlives_its_parent():
+    """Arrow C data interface: a consumer may MOVE a child out of a struct array and release the parent first.  CRAM batches
+    keep all their buffers in one pooled block; the parent and every child hold a reference to it, so the block returns to
+    the pool only when the last of them is released (not when the parent is: a decode thread would reuse it under the child)."""
+    import ctypes as C
+    from exon_amd import _lib as L
+    path = os.path.join(FX, "1404_index_multislice.cram")
+    _, recs = decode.decode_cram(path)
+    scan = exon_amd.Scan(path, "cram", batch_size=64)  # several small batches: released blocks are taken again at once
+    first = scan.next_raw()
+    n = first.length
+    assert first.n_children == 5 and 0 < n <= 64
+    src = first.children[0].contents           # `flag`
+    moved = L.ArrowArray()
+    C.memmove(C.byref(moved), C.byref(src), C.sizeof(L.ArrowArray))
+    src.release = None                         # the move: the source is marked released, the parent will skip it
+    release_t = C.CFUNCTYPE(None, C.POINTER(L.ArrowArray))
+    C.cast(first.release, release_t)(C.byref(first))
+    assert not first.release
+    later = []
+    while True:                                # the rest of the file: the pool hands out blocks of the same size class
+        a = scan.next_raw()
+        if a is None:
+            break
+        later.append(a)
+    flags = np.ctypeslib.as_array(C.cast(moved.buffers[1], C.POINTER(C.c_int32)), shape=(n,)).copy()
+    assert flags.tolist() == [r["flag"] for r in recs[:n]]
+    C.cast(moved.release, release_t)(C.byref(moved))
+    assert not moved.release
+    for a in later:
+        C.cast(a.release, release_t)(C.byref(a))
+    scan.close()
