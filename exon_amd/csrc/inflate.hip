@@ -683,13 +683,195 @@ __device__ __forceinline__ uint32_t symbol_run(BitReader& br, uint32_t& pos, uin
   return uniu(why);
 }
 
+// symbol_run on the VECTOR unit (round 4).  The loop above keeps the bit buffer in scalar registers, so nearly every
+// instruction of a symbol goes through the CU's ONE scalar ALU: it issues one instruction per clock for the whole CU
+// (tools/issue_rate.hip: 1.02 per clock and CU from 16 waves up), and with 24 waves decoding there the loop is bound by
+// exactly that -- ~10 scalar instructions per literal, ~65 per match.  The four SIMD-32 units of a gfx950 CU issue a wave64
+// vector instruction every two clocks EACH (measured: 1.8-1.95 per clock and CU on the same dependent chains, and a
+// v_cmp + s_cbranch_vccnz pair costs what s_cmp + s_cbranch_scc costs), and a wave-uniform value can just as well live in a
+// vector register with all 64 lanes computing the same thing.  So here the bit buffer, the bit count, the table entries,
+// length and distance are VGPRs; what stays scalar is what is cheap there and would cost a transfer: the output position
+// (ring address, row test), the window index of the refill, the exec mask of the copy.  A literal is 8 vector + 3 scalar
+// instructions (was 5 + 10), the common match ~36 + 7 (was ~8 + 65).  Same contract as symbol_run: same `why` codes, same
+// registers in and out, so the slow paths around it do not know which loop ran.
+// Hazards the assembler does not see inside an asm block (gfx940 family): a VALU-written SGPR needs 2 wait states before a
+// VALU reads it (v_readlane -> v_lshlrev_b64 below: two scalar instructions in between), a VALU-written VGPR 1 before
+// v_readfirstlane reads it (the exits start with a scalar instruction).  VALU-written VCC / SGPRs read by the scalar unit
+// or by s_cbranch_vcc* are interlocked.
 template <int RING>
-__device__ __noinline__ SymResult decode_symbols(BitReader br, Out o) {
+__device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, uint32_t& vpos, uint32_t lane, uint32_t lane4, uint32_t begin,
+                                                 const uint8_t* out, uint32_t& e, uint32_t& len, uint32_t& d) {
+  uint32_t why, vt, ve;
+  uint64_t buf = br.buf;
+  int cnt = br.cnt;
+  uint32_t widx = br.widx;
+  // v[48:49] bit buffer, v50 bit count, v51 literal/length entry, v52 distance entry, v53 length, v54 distance, v55 code
+  // length, v[64:65] / v66 / v67 scratch, v68 = 1
+#define EXON_REFILL_V(tag)                              \
+  "  v_cmp_lt_i32 vcc, 32, v50\n"                       \
+  "  s_cbranch_vccnz L_vhave_" tag "%=\n"               \
+  "  s_waitcnt vmcnt(0)\n"                              \
+  "  v_readlane_b32 s90, %[cur], s83\n"                 \
+  "  s_mov_b32 s91, 0\n"                                \
+  "  s_add_i32 s83, s83, 1\n"                           \
+  "  v_lshlrev_b64 v[64:65], v50, s[90:91]\n"           \
+  "  v_or_b32 v48, v48, v64\n"                          \
+  "  v_or_b32 v49, v49, v65\n"                          \
+  "  v_add_u32 v50, 32, v50\n"                          \
+  "  s_and_b32 s87, s83, 63\n"                          \
+  "  s_cbranch_scc1 L_vhave_" tag "%=\n"                \
+  "  v_lshl_add_u32 %[vt], s83, 2, %[lane4]\n"          \
+  "  global_load_dword %[cur], %[vt], s[88:89]\n"       \
+  "L_vhave_" tag "%=:\n"
+  asm volatile(
+      "  v_mov_b32 v48, s80\n"
+      "  v_mov_b32 v49, s81\n"
+      "  v_mov_b32 v50, s82\n"
+      "  v_mov_b32 v68, 1\n"
+      "L_vsym_loop%=:\n" EXON_REFILL_V("l")
+      "  v_lshlrev_b32 %[vt], 2, v48\n"
+      "  v_and_b32 %[vt], %[lutmask], %[vt]\n"
+      "  ds_read_b32 v51, %[vt] offset:%[lutoff]\n"
+      "  s_waitcnt lgkmcnt(0)\n"
+      "  v_cmp_eq_u32_sdwa vcc, v51, v68 src0_sel:BYTE_1 src1_sel:DWORD\n"  // bits 8-15 == 1: a literal (E_LIT alone)
+      "  s_cbranch_vccz L_vsym_match%=\n"
+      "  v_and_b32 v55, 15, v51\n"
+      "  v_lshrrev_b64 v[48:49], v55, v[48:49]\n"
+      "  v_sub_u32 v50, v50, v55\n"
+      "  s_and_b32 s87, s84, %[ringmask]\n"
+      "  v_mov_b32 %[vt], s87\n"
+      "  ds_write_b8_d16_hi %[vt], v51\n"
+      "  s_add_i32 s84, s84, 1\n"
+      "  s_and_b32 s87, s84, 0xff\n"
+      "  s_cbranch_scc1 L_vsym_loop%=\n"
+      "  s_branch L_vsym_row%=\n"
+      // ---- not a literal: a length code in the table (length field 1..15, neither end of block nor invalid)?
+      "L_vsym_match%=:\n"
+      "  v_and_b32 v67, 0x60f, v51\n"
+      "  v_add_u32 v67, -1, v67\n"
+      "  v_cmp_lt_u32 vcc, 14, v67\n"
+      "  s_cbranch_vccnz L_vsym_exit0%=\n"
+      "  v_and_b32 v55, 15, v51\n"
+      "  v_lshrrev_b64 v[48:49], v55, v[48:49]\n"
+      "  v_sub_u32 v50, v50, v55\n"
+      "  v_lshrrev_b32 v53, 16, v51\n"         // length base
+      "  v_bfe_u32 v66, v51, 4, 4\n"           // extra bits
+      "  v_cmp_ne_u32 vcc, 0, v66\n"
+      "  s_cbranch_vccz L_vsym_len%=\n"
+      "  v_bfm_b32 v67, v66, 0\n"
+      "  v_and_b32 v67, v48, v67\n"
+      "  v_add_u32 v53, v53, v67\n"
+      "  v_lshrrev_b64 v[48:49], v66, v[48:49]\n"
+      "  v_sub_u32 v50, v50, v66\n"
+      "L_vsym_len%=:\n" EXON_REFILL_V("m")
+      // ---- the distance
+      "  v_lshlrev_b32 %[vt], 2, v48\n"
+      "  v_and_b32 %[vt], %[dmask], %[vt]\n"
+      "  ds_read_b32 v52, %[vt] offset:%[dlut]\n"
+      "  s_waitcnt lgkmcnt(0)\n"
+      "  v_and_b32 v67, 0x40f, v52\n"          // length field 1..15 and not E_INVALID (symbols 30, 31)
+      "  v_add_u32 v67, -1, v67\n"
+      "  v_cmp_lt_u32 vcc, 14, v67\n"
+      "  s_cbranch_vccnz L_vsym_exit3%=\n"
+      "  v_and_b32 v55, 15, v52\n"
+      "  v_lshrrev_b64 v[48:49], v55, v[48:49]\n"
+      "  v_sub_u32 v50, v50, v55\n"
+      "  v_lshrrev_b32 v54, 16, v52\n"         // distance base
+      "  v_bfe_u32 v66, v52, 4, 4\n"           // extra bits: nearly always some, so no branch (0 bits: an empty mask)
+      "  v_bfm_b32 v67, v66, 0\n"
+      "  v_and_b32 v67, v48, v67\n"
+      "  v_add_u32 v54, v54, v67\n"
+      "  v_lshrrev_b64 v[48:49], v66, v[48:49]\n"
+      "  v_sub_u32 v50, v50, v66\n"
+      // ---- the copies the loop does itself (as in symbol_run): d <= history, len <= 64, and either len <= d <= NEAR or d > NEAR
+      "  s_sub_i32 s87, s84, s96\n"
+      "  v_cmp_lt_u32 vcc, s87, v54\n"
+      "  s_cbranch_vccnz L_vsym_exit2%=\n"
+      "  v_cmp_lt_u32 vcc, 64, v53\n"
+      "  s_cbranch_vccnz L_vsym_exit2%=\n"
+      "  v_cmp_gt_u32_e64 s[90:91], v53, %[lane]\n"  // lanes below len
+      "  v_sub_u32 v67, s84, v54\n"                  // first source byte
+      "  v_cmp_lt_u32 vcc, %[near], v54\n"
+      "  s_cbranch_vccnz L_vsym_far%=\n"
+      "  v_cmp_gt_u32 vcc, v53, v54\n"
+      "  s_cbranch_vccnz L_vsym_exit2%=\n"           // overlapping run
+      "  s_and_saveexec_b64 s[94:95], s[90:91]\n"
+      "  v_add_u32 %[vt], v67, %[lane]\n"
+      "  v_and_b32 %[vt], %[ringmask], %[vt]\n"
+      "  ds_read_u8 %[ve], %[vt]\n"
+      "  v_add_u32 %[vt], s84, %[lane]\n"
+      "  v_and_b32 %[vt], %[ringmask], %[vt]\n"
+      "  s_waitcnt lgkmcnt(0)\n"
+      "  ds_write_b8 %[vt], %[ve]\n"
+      "  s_mov_b64 exec, s[94:95]\n"
+      "  s_branch L_vsym_adv%=\n"
+      "L_vsym_far%=:\n"
+      "  s_and_saveexec_b64 s[94:95], s[90:91]\n"
+      "  v_add_u32 %[vt], v67, %[lane]\n"
+      "  global_load_ubyte %[ve], %[vt], s[98:99]\n"
+      "  v_add_u32 %[vt], s84, %[lane]\n"
+      "  v_and_b32 %[vt], %[ringmask], %[vt]\n"
+#ifndef EXON_INFLATE_FAR_NOWAIT  // timing experiment only (wrong bytes): what the loop would cost if far copies were free
+      "  s_waitcnt vmcnt(0)\n"
+      "  ds_write_b8 %[vt], %[ve]\n"
+#endif
+      "  s_mov_b64 exec, s[94:95]\n"
+      "L_vsym_adv%=:\n"
+      "  v_readfirstlane_b32 s92, v53\n"
+      "  s_add_i32 s87, s84, s92\n"
+      "  s_xor_b32 s94, s87, s84\n"
+      "  s_mov_b32 s84, s87\n"
+      "  s_lshr_b32 s94, s94, 8\n"             // SCC = a 256-byte row boundary was crossed
+      "  s_cbranch_scc0 L_vsym_loop%=\n"
+      "L_vsym_row%=:\n"
+      "  s_mov_b32 s86, 1\n"
+      "  s_branch L_vsym_out%=\n"
+      "L_vsym_exit0%=:\n"
+      "  s_mov_b32 s86, 0\n"
+      "  s_branch L_vsym_out%=\n"
+      "L_vsym_exit2%=:\n"
+      "  s_mov_b32 s86, 2\n"
+      "  s_branch L_vsym_out%=\n"
+      "L_vsym_exit3%=:\n"
+      "  s_mov_b32 s86, 3\n"
+      "L_vsym_out%=:\n"
+      "  s_nop 0\n"
+      "  v_readfirstlane_b32 s80, v48\n"
+      "  v_readfirstlane_b32 s81, v49\n"
+      "  v_readfirstlane_b32 s82, v50\n"
+      "  v_readfirstlane_b32 s85, v51\n"
+      "  v_readfirstlane_b32 s92, v53\n"
+      "  v_readfirstlane_b32 s93, v54\n"
+      "  v_mov_b32 %[vpos], s84\n"
+      "  s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+      "  s_nop 1\n"  // the compiler does not know a VALU instruction wrote s80-s93: keep its next VALU read two states away
+      : [buf] "+{s[80:81]}"(buf), [cnt] "+{s82}"(cnt), [widx] "+{s83}"(widx), [pos] "+{s84}"(pos), [e] "={s85}"(e), [why] "={s86}"(why),
+        [len] "={s92}"(len), [d] "={s93}"(d), [cur] "+v"(br.cur), [vpos] "+v"(vpos), [vt] "=&v"(vt), [ve] "=&v"(ve)
+      : [base] "{s[88:89]}"(br.base), [begin] "{s96}"(begin), [out] "{s[98:99]}"(out), [lane] "v"(lane), [lane4] "v"(lane4), [lutmask] "i"(((1 << LIT_BITS) - 1) << 2),
+        [dmask] "i"(((1 << DIST_BITS) - 1) << 2), [ringmask] "i"(RING - 1), [near] "i"(RING - 258),
+        [lutoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_lut)), [dlut] "i"(RING + (int)__builtin_offsetof(WaveLds, dist_lut))
+      : "s87", "s90", "s91", "s94", "s95", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v64", "v65", "v66", "v67", "v68", "vcc", "scc",
+        "memory");
+#undef EXON_REFILL_V
+  br.buf = ((uint64_t)uniu((uint32_t)(buf >> 32)) << 32) | uniu((uint32_t)buf);
+  br.cnt = uni(cnt);
+  br.widx = uniu(widx);
+  pos = uniu(pos);
+  e = uniu(e);
+  len = uniu(len);
+  d = uniu(d);
+  return uniu(why);
+}
+
+// `vflav` (wave-uniform): the hand-written symbol loop runs on the vector unit (symbol_run_v) instead of the scalar one
+template <int RING>
+__device__ __noinline__ SymResult decode_symbols(BitReader br, Out o, int vflav) {
   constexpr uint32_t M = RING - 1;
   constexpr uint32_t NEAR = RING - 258;  // largest distance served from the ring (the copy must not overwrite its source)
   static_assert(RING >= 1024, "far matches rely on NEAR >= 258 + 255");
   br.make_uniform();
   o.make_uniform();
+  vflav = uni(vflav);
   uint8_t* ring = wave_ring<RING>();
   const WaveLds* L = wave_lds<RING>();
   const uint32_t lane = lane_id();
@@ -722,7 +904,8 @@ __device__ __noinline__ SymResult decode_symbols(BitReader br, Out o) {
 #endif
     uint32_t len, d;
 #if EXON_INFLATE_LIT == 2
-    const uint32_t why = symbol_run<RING>(br, o.pos, vpos, lane, lane4, o.begin, o.out, e, len, d);
+    const uint32_t why = vflav ? symbol_run_v<RING>(br, o.pos, vpos, lane, lane4, o.begin, o.out, e, len, d)
+                               : symbol_run<RING>(br, o.pos, vpos, lane, lane4, o.begin, o.out, e, len, d);
     if (why == 1) {  // a 256-byte row of the ring is complete
       if (o.pos > o.end || br.overrun()) { err = br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN; break; }
       o.drained = uniu(drain_rows<RING>(o.out, o.drained, o.pos & ~255u));
@@ -1377,7 +1560,7 @@ __device__ __noinline__ int par_decode_block(const uint8_t* __restrict__ comp /*
 // One BGZF member.  PAR: dynamic / fixed DEFLATE blocks first try par_decode_block (scratch slot `sl`, fallback counters `stats`).
 template <int RING, bool PAR>
 __device__ __forceinline__ void inflate_member(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks, int b, uint8_t* out,
-                                               int* __restrict__ status, const ParSlot sl, unsigned* __restrict__ stats) {
+                                               int* __restrict__ status, const ParSlot sl, unsigned* __restrict__ stats, int vflav) {
   constexpr uint32_t M = RING - 1;
   const int lane = (int)lane_id();
   WaveLds* L = wave_lds<RING>();
@@ -1506,7 +1689,7 @@ __device__ __forceinline__ void inflate_member(const uint8_t* __restrict__ comp,
         continue;
       }
     }
-    const SymResult r = decode_symbols<RING>(br, o);
+    const SymResult r = decode_symbols<RING>(br, o, vflav);
     br = r.br;
     br.make_uniform();
     o = r.o;
@@ -1520,26 +1703,31 @@ __device__ __forceinline__ void inflate_member(const uint8_t* __restrict__ comp,
   if (lane == 0) status[b] = err;
 }
 
+// Which symbol loop a wave runs: 0 scalar (symbol_run), 1 vector (symbol_run_v), 2 both on every CU -- workgroup b lands on
+// XCD b % 8 and the XCD deals its workgroups over its 32 CUs, so bit 8 of b splits the waves of a CU, not the CUs
+__device__ __forceinline__ int flavor_of(int flavor) { return flavor == 2 ? (int)((blockIdx.x >> 8) & 1u) : flavor; }
+
 template <int RING>
 __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks, int n_blocks,
-                                                uint8_t* out, int* __restrict__ status) {
+                                                uint8_t* out, int* __restrict__ status, int flavor) {
   const int b = uni((int)(blockIdx.x * INF_WAVES + (threadIdx.x >> 6)));
   if (b >= n_blocks) return;
-  inflate_member<RING, false>(comp, blocks, b, out, status, ParSlot{}, nullptr);
+  inflate_member<RING, false>(comp, blocks, b, out, status, ParSlot{}, nullptr, flavor_of(flavor));
 }
 
 // The lane-parallel variant: a fixed set of workgroups (one scratch slot each) takes members off a shared counter.
 template <int RING>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_inflate_par(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks, int n_blocks, uint8_t* out,
                                                     int* __restrict__ status, uint8_t* __restrict__ scratch, unsigned* __restrict__ counter,
-                                                    unsigned* __restrict__ stats) {
+                                                    unsigned* __restrict__ stats, int flavor) {
   const ParSlot sl = par_slot(scratch, blockIdx.x);
+  const int vflav = flavor_of(flavor);
   for (;;) {
     unsigned b = 0;
     if (lane_id() == 0) b = atomicAdd(counter, 1u);
     b = uniu(b);
     if (b >= (unsigned)n_blocks) return;
-    inflate_member<RING, true>(comp, blocks, (int)b, out, status, sl, stats);
+    inflate_member<RING, true>(comp, blocks, (int)b, out, status, sl, stats, vflav);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
 }
@@ -1866,9 +2054,19 @@ extern "C" int exon_hip_bgzf_forget_stream(void* stream) {
   return EXON_HIP_OK;
 }
 
+// EXON_HIP_INFLATE_FLAVOR: which unit the hand-written symbol loop runs on (0 scalar, 1 vector, 2 both side by side)
+static int inflate_flavor() {
+  static const int f = [] {
+    const char* e = getenv("EXON_HIP_INFLATE_FLAVOR");
+    return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 0;
+  }();
+  return f;
+}
+
 hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const exon_hip_bgzf_block* d_blocks, int n_blocks,
                                     uint8_t* d_out, int* d_status, bool verify_crc) {
   if (n_blocks <= 0) return hipSuccess;
+  const int flavor = inflate_flavor();
   static_assert(sizeof(Block) == sizeof(exon_hip_bgzf_block), "block layouts must agree");
   const Block* blocks = reinterpret_cast<const Block*>(d_blocks);
   const int mode = par_mode();
@@ -1890,17 +2088,17 @@ hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const 
       if (n_ser > 0) {
         if ((e = hipEventRecord(side.ev_fork, s)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(side.side, side.ev_fork, 0)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_inflate<INFLATE_RING>, dim3(n_ser), dim3(64), 0, side.side, d_comp, blocks, n_ser, d_out, d_status);
+        hipLaunchKernelGGL(k_inflate<INFLATE_RING>, dim3(n_ser), dim3(64), 0, side.side, d_comp, blocks, n_ser, d_out, d_status, flavor);
         if ((e = hipEventRecord(side.ev_join, side.side)) != hipSuccess) return e;
       }
       hipLaunchKernelGGL(k_inflate_par<INFLATE_RING>, dim3(n_wg), dim3(64), 0, s, d_comp, blocks + n_ser, n_blocks - n_ser, d_out, d_status + n_ser,
-                         scratch + 256, reinterpret_cast<unsigned*>(scratch), stats);
+                         scratch + 256, reinterpret_cast<unsigned*>(scratch), stats, flavor);
       if (n_ser > 0 && (e = hipStreamWaitEvent(s, side.ev_join, 0)) != hipSuccess) return e;
     }
   }
   if (!parallel)
     hipLaunchKernelGGL(k_inflate<INFLATE_RING>, dim3((n_blocks + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), 0, s, d_comp, blocks, n_blocks,
-                       d_out, d_status);
+                       d_out, d_status, flavor);
   if (verify_crc)
     hipLaunchKernelGGL(k_crc32, dim3((n_blocks + WAVES_PER_WG - 1) / WAVES_PER_WG), dim3(WAVES_PER_WG * 64), 0, s, d_out, blocks, n_blocks,
                        d_status);
