@@ -683,34 +683,44 @@ __device__ __forceinline__ uint32_t symbol_run(BitReader& br, uint32_t& pos, uin
   return uniu(why);
 }
 
-// symbol_run on the VECTOR unit (round 4).  The loop above keeps the bit buffer in scalar registers, so nearly every
-// instruction of a symbol goes through the CU's ONE scalar ALU: it issues one instruction per clock for the whole CU
-// (tools/issue_rate.hip: 1.02 per clock and CU from 16 waves up), and with 24 waves decoding there the loop is bound by
-// exactly that -- ~10 scalar instructions per literal, ~65 per match.  The four SIMD-32 units of a gfx950 CU issue a wave64
-// vector instruction every two clocks EACH (measured: 1.8-1.95 per clock and CU on the same dependent chains, and a
-// v_cmp + s_cbranch_vccnz pair costs what s_cmp + s_cbranch_scc costs), and a wave-uniform value can just as well live in a
-// vector register with all 64 lanes computing the same thing.  So here the bit buffer, the bit count, the table entries,
-// length and distance are VGPRs; what stays scalar is what is cheap there and would cost a transfer: the output position
-// (ring address, row test), the window index of the refill, the exec mask of the copy.  A literal is 8 vector + 3 scalar
-// instructions (was 5 + 10), the common match ~36 + 7 (was ~8 + 65).  Same contract as symbol_run: same `why` codes, same
-// registers in and out, so the slow paths around it do not know which loop ran.
+// symbol_run on the VECTOR unit, software-pipelined (round 4).
+// (1) Where the instructions issue.  The loop above keeps the bit buffer in scalar registers, so nearly every instruction of a
+// symbol goes through the CU's ONE scalar ALU, which issues one instruction per clock for the whole CU (tools/issue_rate.hip:
+// 1.02 per clock and CU from 16 waves up).  The four SIMD-32 units of a gfx950 CU issue a wave64 vector instruction every two
+// clocks EACH (measured 1.8-1.95 per clock and CU on the same dependent chains; a v_cmp + s_cbranch_vccnz pair costs what
+// s_cmp + s_cbranch_scc costs), and a wave-uniform value can just as well live in a vector register with all 64 lanes
+// computing the same thing.  So here the bit buffer, the bit count, the table entries, length and distance are VGPRs; what
+// stays scalar is what is cheap there: the output position (ring address, row test), the window index of the refill, the
+// exec mask of the copy.  A plain translation of symbol_run (8 vector + 3 scalar instructions per literal instead of 5 + 10)
+// measured the SAME throughput as the scalar loop on every format (profiles/r4_inflate_flavor_v1.log), and so did making the
+// far copies free (r4_inflate_far_nowait.log: +6..12 %): 24 waves per CU are bound by each wave's own dependency chain
+// buffer -> table index -> LDS lookup (~100 clocks) -> code length -> shift, not by an issue port.
+// (2) So the chain is what this version shortens.  A first-level lookup needs 9 valid bits and the buffer never holds fewer
+// than 12 where one is issued, so the NEXT symbol's lookup goes out as soon as the current code's bits are shifted away --
+// before the literal is stored, the counters move, the buffer is refilled or the match is copied; all of that now runs under
+// the lookup's latency.  Length + extra bits (and distance + extra bits) leave the buffer with ONE 64-bit shift, the extra
+// value comes from a v_bfe with register operands.  The refill is out of line (the common no-refill case falls through).
+// Same contract as symbol_run: same `why` codes, same registers in and out; a lookup in flight at an exit is dropped.
 // Hazards the assembler does not see inside an asm block (gfx940 family): a VALU-written SGPR needs 2 wait states before a
-// VALU reads it (v_readlane -> v_lshlrev_b64 below: two scalar instructions in between), a VALU-written VGPR 1 before
-// v_readfirstlane reads it (the exits start with a scalar instruction).  VALU-written VCC / SGPRs read by the scalar unit
-// or by s_cbranch_vcc* are interlocked.
+// VALU reads it (v_readlane -> v_lshlrev_b64 in the refill: two scalar instructions in between), a VALU-written VGPR 1 before
+// v_readfirstlane reads it (the exits start with scalar instructions).  VALU-written VCC / SGPRs read by the scalar unit or by
+// s_cbranch_vcc* are interlocked.
 template <int RING>
 __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, uint32_t& vpos, uint32_t lane, uint32_t lane4, uint32_t begin,
                                                  const uint8_t* out, uint32_t& e, uint32_t& len, uint32_t& d) {
-  uint32_t why, vt, ve;
+  uint32_t why, vt, ve, vfa, vfb;
   uint64_t buf = br.buf;
   int cnt = br.cnt;
   uint32_t widx = br.widx;
   // v[48:49] bit buffer, v50 bit count, v51 literal/length entry, v52 distance entry, v53 length, v54 distance, v55 code
-  // length, v[64:65] / v66 / v67 scratch, v68 = 1
-#define EXON_REFILL_V(tag)                              \
-  "  v_cmp_lt_i32 vcc, 32, v50\n"                       \
-  "  s_cbranch_vccnz L_vhave_" tag "%=\n"               \
+  // length, v[64:65] / v66 / v67 / v70 scratch, v68 = 1, v69 ring address of `pos`, v71 first source byte -- all caller-saved
+  // in the AMDGPU calling convention (v40-v47, v56-v63, v72-v79 are callee-saved: clobbering those would make the non-inlined
+  // decode_symbols spill them to scratch)
+#define EXON_REFILL_BODY(tag)                           \
+  "  s_and_b32 s87, s83, 63\n"                          \
+  "  s_cbranch_scc1 L_vwin_" tag "%=\n"                 \
   "  s_waitcnt vmcnt(0)\n"                              \
+  "L_vwin_" tag "%=:\n"                                 \
   "  v_readlane_b32 s90, %[cur], s83\n"                 \
   "  s_mov_b32 s91, 0\n"                                \
   "  s_add_i32 s83, s83, 1\n"                           \
@@ -718,30 +728,70 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
   "  v_or_b32 v48, v48, v64\n"                          \
   "  v_or_b32 v49, v49, v65\n"                          \
   "  v_add_u32 v50, 32, v50\n"                          \
-  "  s_and_b32 s87, s83, 63\n"                          \
+  "  s_and_b32 s87, s83, 63\n"
+#define EXON_REFILL_V(tag)                              \
+  "  v_cmp_lt_i32 vcc, 32, v50\n"                       \
+  "  s_cbranch_vccnz L_vhave_" tag "%=\n"               \
+  EXON_REFILL_BODY(tag)                                 \
   "  s_cbranch_scc1 L_vhave_" tag "%=\n"                \
   "  v_lshl_add_u32 %[vt], s83, 2, %[lane4]\n"          \
   "  global_load_dword %[cur], %[vt], s[88:89]\n"       \
   "L_vhave_" tag "%=:\n"
+#define EXON_REFILL_OUT(tag)                            \
+  "L_vrefill_" tag "%=:\n"                              \
+  EXON_REFILL_BODY(tag)                                 \
+  "  s_cbranch_scc1 L_vback_" tag "%=\n"                \
+  "  v_lshl_add_u32 %[vt], s83, 2, %[lane4]\n"          \
+  "  global_load_dword %[cur], %[vt], s[88:89]\n"       \
+  "  s_branch L_vback_" tag "%=\n"
+// a deferred far copy lands in the ring: the lanes below its length (s101) write their byte at s100 + lane
+#define EXON_FAR_COMPLETE(vx)                           \
+  "  v_cmp_gt_u32_e64 s[90:91], s101, %[lane]\n"        \
+  "  s_and_saveexec_b64 s[94:95], s[90:91]\n"           \
+  "  v_add_u32 %[vt], s100, %[lane]\n"                  \
+  "  v_and_b32 %[vt], %[ringmask], %[vt]\n"             \
+  "  ds_write_b8 %[vt], " vx "\n"                       \
+  "  s_mov_b64 exec, s[94:95]\n"
+#define EXON_FAR_COMPLETE_PENDING(tag)                  \
+  "  s_waitcnt vmcnt(0)\n"                              \
+  "  s_cmp_eq_u32 s97, 1\n"                             \
+  "  s_cbranch_scc0 L_vcpb_" tag "%=\n"                 \
+  EXON_FAR_COMPLETE("%[vfa]")                           \
+  "  s_branch L_vcpd_" tag "%=\n"                       \
+  "L_vcpb_" tag "%=:\n"                                 \
+  EXON_FAR_COMPLETE("%[vfb]")                           \
+  "L_vcpd_" tag "%=:\n"                                 \
+  "  s_mov_b32 s97, 0\n"
+#define EXON_LOOKUP_LIT                                 \
+  "  v_lshlrev_b32 %[vt], 2, v48\n"                     \
+  "  v_and_b32 %[vt], %[lutmask], %[vt]\n"              \
+  "  ds_read_b32 v51, %[vt] offset:%[lutoff]\n"
   asm volatile(
       "  v_mov_b32 v48, s80\n"
       "  v_mov_b32 v49, s81\n"
       "  v_mov_b32 v50, s82\n"
       "  v_mov_b32 v68, 1\n"
-      "L_vsym_loop%=:\n" EXON_REFILL_V("l")
-      "  v_lshlrev_b32 %[vt], 2, v48\n"
-      "  v_and_b32 %[vt], %[lutmask], %[vt]\n"
-      "  ds_read_b32 v51, %[vt] offset:%[lutoff]\n"
+      "  s_mov_b32 s97, 0\n"                    // far copies in flight: 0 none, 1 one in vfa, 2 one in vfb
+      EXON_REFILL_V("e")
+      EXON_LOOKUP_LIT
+      "  s_and_b32 s87, s84, %[ringmask]\n"
+      "  v_mov_b32 v69, s87\n"
+      // ---- invariant at the loop head: the lookup of the current symbol is in flight into v51, v69 = pos & (RING - 1)
+      "L_vsym_loop%=:\n"
       "  s_waitcnt lgkmcnt(0)\n"
       "  v_cmp_eq_u32_sdwa vcc, v51, v68 src0_sel:BYTE_1 src1_sel:DWORD\n"  // bits 8-15 == 1: a literal (E_LIT alone)
       "  s_cbranch_vccz L_vsym_match%=\n"
       "  v_and_b32 v55, 15, v51\n"
       "  v_lshrrev_b64 v[48:49], v55, v[48:49]\n"
+      "  ds_write_b8_d16_hi v69, v51\n"
+      EXON_LOOKUP_LIT                          // the next symbol; everything below runs under its latency
       "  v_sub_u32 v50, v50, v55\n"
-      "  s_and_b32 s87, s84, %[ringmask]\n"
-      "  v_mov_b32 %[vt], s87\n"
-      "  ds_write_b8_d16_hi %[vt], v51\n"
       "  s_add_i32 s84, s84, 1\n"
+      "  s_and_b32 s87, s84, %[ringmask]\n"
+      "  v_mov_b32 v69, s87\n"
+      "  v_cmp_lt_i32 vcc, 32, v50\n"
+      "  s_cbranch_vccz L_vrefill_l%=\n"
+      "L_vback_l%=:\n"
       "  s_and_b32 s87, s84, 0xff\n"
       "  s_cbranch_scc1 L_vsym_loop%=\n"
       "  s_branch L_vsym_row%=\n"
@@ -751,52 +801,56 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       "  v_add_u32 v67, -1, v67\n"
       "  v_cmp_lt_u32 vcc, 14, v67\n"
       "  s_cbranch_vccnz L_vsym_exit0%=\n"
-      "  v_and_b32 v55, 15, v51\n"
-      "  v_lshrrev_b64 v[48:49], v55, v[48:49]\n"
-      "  v_sub_u32 v50, v50, v55\n"
-      "  v_lshrrev_b32 v53, 16, v51\n"         // length base
+      "  v_and_b32 v55, 15, v51\n"             // code length
       "  v_bfe_u32 v66, v51, 4, 4\n"           // extra bits
-      "  v_cmp_ne_u32 vcc, 0, v66\n"
-      "  s_cbranch_vccz L_vsym_len%=\n"
-      "  v_bfm_b32 v67, v66, 0\n"
-      "  v_and_b32 v67, v48, v67\n"
-      "  v_add_u32 v53, v53, v67\n"
-      "  v_lshrrev_b64 v[48:49], v66, v[48:49]\n"
-      "  v_sub_u32 v50, v50, v66\n"
-      "L_vsym_len%=:\n" EXON_REFILL_V("m")
-      // ---- the distance
-      "  v_lshlrev_b32 %[vt], 2, v48\n"
+      "  v_add_u32 v70, v55, v66\n"
+      "  v_bfe_u32 v67, v48, v55, v66\n"       // their value (0 bits: 0)
+      "  v_lshrrev_b64 v[48:49], v70, v[48:49]\n"
+      "  v_lshlrev_b32 %[vt], 2, v48\n"        // the distance lookup (8 valid bits are there; the refill comes under it)
       "  v_and_b32 %[vt], %[dmask], %[vt]\n"
       "  ds_read_b32 v52, %[vt] offset:%[dlut]\n"
+      "  v_lshrrev_b32 v53, 16, v51\n"
+      "  v_add_u32 v53, v53, v67\n"            // length
+      "  v_sub_u32 v50, v50, v70\n"
+      EXON_REFILL_V("m")
       "  s_waitcnt lgkmcnt(0)\n"
       "  v_and_b32 v67, 0x40f, v52\n"          // length field 1..15 and not E_INVALID (symbols 30, 31)
       "  v_add_u32 v67, -1, v67\n"
       "  v_cmp_lt_u32 vcc, 14, v67\n"
       "  s_cbranch_vccnz L_vsym_exit3%=\n"
       "  v_and_b32 v55, 15, v52\n"
-      "  v_lshrrev_b64 v[48:49], v55, v[48:49]\n"
-      "  v_sub_u32 v50, v50, v55\n"
-      "  v_lshrrev_b32 v54, 16, v52\n"         // distance base
-      "  v_bfe_u32 v66, v52, 4, 4\n"           // extra bits: nearly always some, so no branch (0 bits: an empty mask)
-      "  v_bfm_b32 v67, v66, 0\n"
-      "  v_and_b32 v67, v48, v67\n"
-      "  v_add_u32 v54, v54, v67\n"
-      "  v_lshrrev_b64 v[48:49], v66, v[48:49]\n"
-      "  v_sub_u32 v50, v50, v66\n"
+      "  v_bfe_u32 v66, v52, 4, 4\n"
+      "  v_add_u32 v70, v55, v66\n"
+      "  v_bfe_u32 v67, v48, v55, v66\n"
+      "  v_lshrrev_b64 v[48:49], v70, v[48:49]\n"
+      EXON_LOOKUP_LIT                          // the symbol behind the match, under the copy
+      "  v_lshrrev_b32 v54, 16, v52\n"
+      "  v_add_u32 v54, v54, v67\n"            // distance
+      "  v_sub_u32 v50, v50, v70\n"
       // ---- the copies the loop does itself (as in symbol_run): d <= history, len <= 64, and either len <= d <= NEAR or d > NEAR
       "  s_sub_i32 s87, s84, s96\n"
       "  v_cmp_lt_u32 vcc, s87, v54\n"
       "  s_cbranch_vccnz L_vsym_exit2%=\n"
       "  v_cmp_lt_u32 vcc, 64, v53\n"
       "  s_cbranch_vccnz L_vsym_exit2%=\n"
-      "  v_cmp_gt_u32_e64 s[90:91], v53, %[lane]\n"  // lanes below len
-      "  v_sub_u32 v67, s84, v54\n"                  // first source byte
+      "  v_readfirstlane_b32 s92, v53\n"
+      "  v_sub_u32 v71, s84, v54\n"                  // first source byte
       "  v_cmp_lt_u32 vcc, %[near], v54\n"
       "  s_cbranch_vccnz L_vsym_far%=\n"
       "  v_cmp_gt_u32 vcc, v53, v54\n"
       "  s_cbranch_vccnz L_vsym_exit2%=\n"           // overlapping run
+      // near: ring -> ring.  A far copy still in flight must land first if this source reaches into its bytes
+      // (source end > its first byte; it ends at or below pos, where every source starts below)
+      "  s_cmp_eq_u32 s97, 0\n"
+      "  s_cbranch_scc1 L_vsym_near%=\n"
+      "  v_add_u32 v67, v71, v53\n"
+      "  v_cmp_lt_u32 vcc, s100, v67\n"
+      "  s_cbranch_vccz L_vsym_near%=\n"
+      EXON_FAR_COMPLETE_PENDING("n")
+      "L_vsym_near%=:\n"
+      "  v_cmp_gt_u32_e64 s[90:91], v53, %[lane]\n"  // lanes below len
       "  s_and_saveexec_b64 s[94:95], s[90:91]\n"
-      "  v_add_u32 %[vt], v67, %[lane]\n"
+      "  v_add_u32 %[vt], v71, %[lane]\n"
       "  v_and_b32 %[vt], %[ringmask], %[vt]\n"
       "  ds_read_u8 %[ve], %[vt]\n"
       "  v_add_u32 %[vt], s84, %[lane]\n"
@@ -805,27 +859,50 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       "  ds_write_b8 %[vt], %[ve]\n"
       "  s_mov_b64 exec, s[94:95]\n"
       "  s_branch L_vsym_adv%=\n"
+      // far: the source is in HBM already (d > NEAR: below `drained`).  The load is ISSUED here and its bytes are put into
+      // the ring later -- when the next far copy has issued its own load (two data registers take turns), when a near copy
+      // reads them, when the block is left (row drains, slow paths) -- so the round trip to L2 / HBM runs under the decoding
+      // of the symbols behind it.  Nothing reads those ring bytes earlier: literals and copies only write at `pos` and above.
       "L_vsym_far%=:\n"
+      "  v_cmp_gt_u32_e64 s[90:91], v53, %[lane]\n"
       "  s_and_saveexec_b64 s[94:95], s[90:91]\n"
-      "  v_add_u32 %[vt], v67, %[lane]\n"
-      "  global_load_ubyte %[ve], %[vt], s[98:99]\n"
-      "  v_add_u32 %[vt], s84, %[lane]\n"
-      "  v_and_b32 %[vt], %[ringmask], %[vt]\n"
-#ifndef EXON_INFLATE_FAR_NOWAIT  // timing experiment only (wrong bytes): what the loop would cost if far copies were free
-      "  s_waitcnt vmcnt(0)\n"
-      "  ds_write_b8 %[vt], %[ve]\n"
-#endif
+      "  v_add_u32 %[vt], v71, %[lane]\n"
+      "  s_cmp_eq_u32 s97, 1\n"
+      "  s_cbranch_scc1 L_vsym_far_b%=\n"
+      "  global_load_ubyte %[vfa], %[vt], s[98:99]\n"
       "  s_mov_b64 exec, s[94:95]\n"
+      "  s_cmp_eq_u32 s97, 0\n"
+      "  s_cbranch_scc1 L_vsym_far_a1%=\n"
+      "  s_waitcnt vmcnt(1)\n"                       // the older one (in vfb) has landed; loads return in order
+      EXON_FAR_COMPLETE("%[vfb]")
+      "L_vsym_far_a1%=:\n"
+      "  s_mov_b32 s97, 1\n"
+      "  s_branch L_vsym_far_rec%=\n"
+      "L_vsym_far_b%=:\n"
+      "  global_load_ubyte %[vfb], %[vt], s[98:99]\n"
+      "  s_mov_b64 exec, s[94:95]\n"
+      "  s_waitcnt vmcnt(1)\n"
+      EXON_FAR_COMPLETE("%[vfa]")
+      "  s_mov_b32 s97, 2\n"
+      "L_vsym_far_rec%=:\n"
+      "  s_mov_b32 s100, s84\n"
+      "  s_mov_b32 s101, s92\n"
       "L_vsym_adv%=:\n"
-      "  v_readfirstlane_b32 s92, v53\n"
       "  s_add_i32 s87, s84, s92\n"
       "  s_xor_b32 s94, s87, s84\n"
       "  s_mov_b32 s84, s87\n"
+      "  s_and_b32 s87, s87, %[ringmask]\n"
+      "  v_mov_b32 v69, s87\n"
+      "  v_cmp_lt_i32 vcc, 32, v50\n"
+      "  s_cbranch_vccz L_vrefill_a%=\n"
+      "L_vback_a%=:\n"
       "  s_lshr_b32 s94, s94, 8\n"             // SCC = a 256-byte row boundary was crossed
       "  s_cbranch_scc0 L_vsym_loop%=\n"
       "L_vsym_row%=:\n"
       "  s_mov_b32 s86, 1\n"
       "  s_branch L_vsym_out%=\n"
+      EXON_REFILL_OUT("l")
+      EXON_REFILL_OUT("a")
       "L_vsym_exit0%=:\n"
       "  s_mov_b32 s86, 0\n"
       "  s_branch L_vsym_out%=\n"
@@ -835,6 +912,10 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       "L_vsym_exit3%=:\n"
       "  s_mov_b32 s86, 3\n"
       "L_vsym_out%=:\n"
+      "  s_cmp_eq_u32 s97, 0\n"
+      "  s_cbranch_scc1 L_vsym_fin%=\n"
+      EXON_FAR_COMPLETE_PENDING("x")
+      "L_vsym_fin%=:\n"
       "  s_nop 0\n"
       "  v_readfirstlane_b32 s80, v48\n"
       "  v_readfirstlane_b32 s81, v49\n"
@@ -846,13 +927,18 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       "  s_waitcnt vmcnt(0) lgkmcnt(0)\n"
       "  s_nop 1\n"  // the compiler does not know a VALU instruction wrote s80-s93: keep its next VALU read two states away
       : [buf] "+{s[80:81]}"(buf), [cnt] "+{s82}"(cnt), [widx] "+{s83}"(widx), [pos] "+{s84}"(pos), [e] "={s85}"(e), [why] "={s86}"(why),
-        [len] "={s92}"(len), [d] "={s93}"(d), [cur] "+v"(br.cur), [vpos] "+v"(vpos), [vt] "=&v"(vt), [ve] "=&v"(ve)
+        [len] "={s92}"(len), [d] "={s93}"(d), [cur] "+v"(br.cur), [vpos] "+v"(vpos), [vt] "=&v"(vt), [ve] "=&v"(ve), [vfa] "=&v"(vfa), [vfb] "=&v"(vfb)
       : [base] "{s[88:89]}"(br.base), [begin] "{s96}"(begin), [out] "{s[98:99]}"(out), [lane] "v"(lane), [lane4] "v"(lane4), [lutmask] "i"(((1 << LIT_BITS) - 1) << 2),
         [dmask] "i"(((1 << DIST_BITS) - 1) << 2), [ringmask] "i"(RING - 1), [near] "i"(RING - 258),
         [lutoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_lut)), [dlut] "i"(RING + (int)__builtin_offsetof(WaveLds, dist_lut))
-      : "s87", "s90", "s91", "s94", "s95", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v64", "v65", "v66", "v67", "v68", "vcc", "scc",
-        "memory");
+      : "s87", "s90", "s91", "s94", "s95", "s97", "s100", "s101", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71",
+        "vcc", "scc", "memory");
 #undef EXON_REFILL_V
+#undef EXON_REFILL_OUT
+#undef EXON_REFILL_BODY
+#undef EXON_LOOKUP_LIT
+#undef EXON_FAR_COMPLETE
+#undef EXON_FAR_COMPLETE_PENDING
   br.buf = ((uint64_t)uniu((uint32_t)(buf >> 32)) << 32) | uniu((uint32_t)buf);
   br.cnt = uni(cnt);
   br.widx = uniu(widx);
