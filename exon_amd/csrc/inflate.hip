@@ -713,9 +713,9 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
   int cnt = br.cnt;
   uint32_t widx = br.widx;
   // v[48:49] bit buffer, v50 bit count, v51 literal/length entry, v52 distance entry, v53 length, v54 distance, v55 code
-  // length, v[64:65] / v66 / v67 / v70 scratch, v68 = 1, v69 ring address of `pos`, v71 first source byte -- all caller-saved
-  // in the AMDGPU calling convention (v40-v47, v56-v63, v72-v79 are callee-saved: clobbering those would make the non-inlined
-  // decode_symbols spill them to scratch)
+  // length, v[56:57] / v58 / v59 / v62 scratch, v60 = 1, v61 ring address of `pos`, v63 first source byte -- below v64, so that the kernel
+  // fits the 64 registers that let 8 waves share a SIMD (v56-v63 are callee-saved in the AMDGPU calling convention: the
+  // non-inlined decode_symbols saves them once per DEFLATE block)
 #define EXON_REFILL_BODY(tag)                           \
   "  s_and_b32 s87, s83, 63\n"                          \
   "  s_cbranch_scc1 L_vwin_" tag "%=\n"                 \
@@ -724,9 +724,9 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
   "  v_readlane_b32 s90, %[cur], s83\n"                 \
   "  s_mov_b32 s91, 0\n"                                \
   "  s_add_i32 s83, s83, 1\n"                           \
-  "  v_lshlrev_b64 v[64:65], v50, s[90:91]\n"           \
-  "  v_or_b32 v48, v48, v64\n"                          \
-  "  v_or_b32 v49, v49, v65\n"                          \
+  "  v_lshlrev_b64 v[56:57], v50, s[90:91]\n"           \
+  "  v_or_b32 v48, v48, v56\n"                          \
+  "  v_or_b32 v49, v49, v57\n"                          \
   "  v_add_u32 v50, 32, v50\n"                          \
   "  s_and_b32 s87, s83, 63\n"
 #define EXON_REFILL_V(tag)                              \
@@ -770,25 +770,25 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       "  v_mov_b32 v48, s80\n"
       "  v_mov_b32 v49, s81\n"
       "  v_mov_b32 v50, s82\n"
-      "  v_mov_b32 v68, 1\n"
+      "  v_mov_b32 v60, 1\n"
       "  s_mov_b32 s97, 0\n"                    // far copies in flight: 0 none, 1 one in vfa, 2 one in vfb
       EXON_REFILL_V("e")
       EXON_LOOKUP_LIT
       "  s_and_b32 s87, s84, %[ringmask]\n"
-      "  v_mov_b32 v69, s87\n"
-      // ---- invariant at the loop head: the lookup of the current symbol is in flight into v51, v69 = pos & (RING - 1)
+      "  v_mov_b32 v61, s87\n"
+      // ---- invariant at the loop head: the lookup of the current symbol is in flight into v51, v61 = pos & (RING - 1)
       "L_vsym_loop%=:\n"
       "  s_waitcnt lgkmcnt(0)\n"
-      "  v_cmp_eq_u32_sdwa vcc, v51, v68 src0_sel:BYTE_1 src1_sel:DWORD\n"  // bits 8-15 == 1: a literal (E_LIT alone)
+      "  v_cmp_eq_u32_sdwa vcc, v51, v60 src0_sel:BYTE_1 src1_sel:DWORD\n"  // bits 8-15 == 1: a literal (E_LIT alone)
       "  s_cbranch_vccz L_vsym_match%=\n"
       "  v_and_b32 v55, 15, v51\n"
       "  v_lshrrev_b64 v[48:49], v55, v[48:49]\n"
-      "  ds_write_b8_d16_hi v69, v51\n"
+      "  ds_write_b8_d16_hi v61, v51\n"
       EXON_LOOKUP_LIT                          // the next symbol; everything below runs under its latency
       "  v_sub_u32 v50, v50, v55\n"
       "  s_add_i32 s84, s84, 1\n"
       "  s_and_b32 s87, s84, %[ringmask]\n"
-      "  v_mov_b32 v69, s87\n"
+      "  v_mov_b32 v61, s87\n"
       "  v_cmp_lt_i32 vcc, 32, v50\n"
       "  s_cbranch_vccz L_vrefill_l%=\n"
       "L_vback_l%=:\n"
@@ -797,36 +797,36 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       "  s_branch L_vsym_row%=\n"
       // ---- not a literal: a length code in the table (length field 1..15, neither end of block nor invalid)?
       "L_vsym_match%=:\n"
-      "  v_and_b32 v67, 0x60f, v51\n"
-      "  v_add_u32 v67, -1, v67\n"
-      "  v_cmp_lt_u32 vcc, 14, v67\n"
+      "  v_and_b32 v59, 0x60f, v51\n"
+      "  v_add_u32 v59, -1, v59\n"
+      "  v_cmp_lt_u32 vcc, 14, v59\n"
       "  s_cbranch_vccnz L_vsym_exit0%=\n"
       "  v_and_b32 v55, 15, v51\n"             // code length
-      "  v_bfe_u32 v66, v51, 4, 4\n"           // extra bits
-      "  v_add_u32 v70, v55, v66\n"
-      "  v_bfe_u32 v67, v48, v55, v66\n"       // their value (0 bits: 0)
-      "  v_lshrrev_b64 v[48:49], v70, v[48:49]\n"
+      "  v_bfe_u32 v58, v51, 4, 4\n"           // extra bits
+      "  v_add_u32 v62, v55, v58\n"
+      "  v_bfe_u32 v59, v48, v55, v58\n"       // their value (0 bits: 0)
+      "  v_lshrrev_b64 v[48:49], v62, v[48:49]\n"
       "  v_lshlrev_b32 %[vt], 2, v48\n"        // the distance lookup (8 valid bits are there; the refill comes under it)
       "  v_and_b32 %[vt], %[dmask], %[vt]\n"
       "  ds_read_b32 v52, %[vt] offset:%[dlut]\n"
       "  v_lshrrev_b32 v53, 16, v51\n"
-      "  v_add_u32 v53, v53, v67\n"            // length
-      "  v_sub_u32 v50, v50, v70\n"
+      "  v_add_u32 v53, v53, v59\n"            // length
+      "  v_sub_u32 v50, v50, v62\n"
       EXON_REFILL_V("m")
       "  s_waitcnt lgkmcnt(0)\n"
-      "  v_and_b32 v67, 0x40f, v52\n"          // length field 1..15 and not E_INVALID (symbols 30, 31)
-      "  v_add_u32 v67, -1, v67\n"
-      "  v_cmp_lt_u32 vcc, 14, v67\n"
+      "  v_and_b32 v59, 0x40f, v52\n"          // length field 1..15 and not E_INVALID (symbols 30, 31)
+      "  v_add_u32 v59, -1, v59\n"
+      "  v_cmp_lt_u32 vcc, 14, v59\n"
       "  s_cbranch_vccnz L_vsym_exit3%=\n"
       "  v_and_b32 v55, 15, v52\n"
-      "  v_bfe_u32 v66, v52, 4, 4\n"
-      "  v_add_u32 v70, v55, v66\n"
-      "  v_bfe_u32 v67, v48, v55, v66\n"
-      "  v_lshrrev_b64 v[48:49], v70, v[48:49]\n"
+      "  v_bfe_u32 v58, v52, 4, 4\n"
+      "  v_add_u32 v62, v55, v58\n"
+      "  v_bfe_u32 v59, v48, v55, v58\n"
+      "  v_lshrrev_b64 v[48:49], v62, v[48:49]\n"
       EXON_LOOKUP_LIT                          // the symbol behind the match, under the copy
       "  v_lshrrev_b32 v54, 16, v52\n"
-      "  v_add_u32 v54, v54, v67\n"            // distance
-      "  v_sub_u32 v50, v50, v70\n"
+      "  v_add_u32 v54, v54, v59\n"            // distance
+      "  v_sub_u32 v50, v50, v62\n"
       // ---- the copies the loop does itself (as in symbol_run): d <= history, len <= 64, and either len <= d <= NEAR or d > NEAR
       "  s_sub_i32 s87, s84, s96\n"
       "  v_cmp_lt_u32 vcc, s87, v54\n"
@@ -834,7 +834,7 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       "  v_cmp_lt_u32 vcc, 64, v53\n"
       "  s_cbranch_vccnz L_vsym_exit2%=\n"
       "  v_readfirstlane_b32 s92, v53\n"
-      "  v_sub_u32 v71, s84, v54\n"                  // first source byte
+      "  v_sub_u32 v63, s84, v54\n"                  // first source byte
       "  v_cmp_lt_u32 vcc, %[near], v54\n"
       "  s_cbranch_vccnz L_vsym_far%=\n"
       "  v_cmp_gt_u32 vcc, v53, v54\n"
@@ -843,14 +843,14 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       // (source end > its first byte; it ends at or below pos, where every source starts below)
       "  s_cmp_eq_u32 s97, 0\n"
       "  s_cbranch_scc1 L_vsym_near%=\n"
-      "  v_add_u32 v67, v71, v53\n"
-      "  v_cmp_lt_u32 vcc, s100, v67\n"
+      "  v_add_u32 v59, v63, v53\n"
+      "  v_cmp_lt_u32 vcc, s100, v59\n"
       "  s_cbranch_vccz L_vsym_near%=\n"
       EXON_FAR_COMPLETE_PENDING("n")
       "L_vsym_near%=:\n"
       "  v_cmp_gt_u32_e64 s[90:91], v53, %[lane]\n"  // lanes below len
       "  s_and_saveexec_b64 s[94:95], s[90:91]\n"
-      "  v_add_u32 %[vt], v71, %[lane]\n"
+      "  v_add_u32 %[vt], v63, %[lane]\n"
       "  v_and_b32 %[vt], %[ringmask], %[vt]\n"
       "  ds_read_u8 %[ve], %[vt]\n"
       "  v_add_u32 %[vt], s84, %[lane]\n"
@@ -866,7 +866,7 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       "L_vsym_far%=:\n"
       "  v_cmp_gt_u32_e64 s[90:91], v53, %[lane]\n"
       "  s_and_saveexec_b64 s[94:95], s[90:91]\n"
-      "  v_add_u32 %[vt], v71, %[lane]\n"
+      "  v_add_u32 %[vt], v63, %[lane]\n"
       "  s_cmp_eq_u32 s97, 1\n"
       "  s_cbranch_scc1 L_vsym_far_b%=\n"
       "  global_load_ubyte %[vfa], %[vt], s[98:99]\n"
@@ -892,7 +892,7 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       "  s_xor_b32 s94, s87, s84\n"
       "  s_mov_b32 s84, s87\n"
       "  s_and_b32 s87, s87, %[ringmask]\n"
-      "  v_mov_b32 v69, s87\n"
+      "  v_mov_b32 v61, s87\n"
       "  v_cmp_lt_i32 vcc, 32, v50\n"
       "  s_cbranch_vccz L_vrefill_a%=\n"
       "L_vback_a%=:\n"
@@ -931,7 +931,7 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       : [base] "{s[88:89]}"(br.base), [begin] "{s96}"(begin), [out] "{s[98:99]}"(out), [lane] "v"(lane), [lane4] "v"(lane4), [lutmask] "i"(((1 << LIT_BITS) - 1) << 2),
         [dmask] "i"(((1 << DIST_BITS) - 1) << 2), [ringmask] "i"(RING - 1), [near] "i"(RING - 258),
         [lutoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_lut)), [dlut] "i"(RING + (int)__builtin_offsetof(WaveLds, dist_lut))
-      : "s87", "s90", "s91", "s94", "s95", "s97", "s100", "s101", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71",
+      : "s87", "s90", "s91", "s94", "s95", "s97", "s100", "s101", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
         "vcc", "scc", "memory");
 #undef EXON_REFILL_V
 #undef EXON_REFILL_OUT
@@ -1793,8 +1793,13 @@ __device__ __forceinline__ void inflate_member(const uint8_t* __restrict__ comp,
 // XCD b % 8 and the XCD deals its workgroups over its 32 CUs, so bit 8 of b splits the waves of a CU, not the CUs
 __device__ __forceinline__ int flavor_of(int flavor) { return flavor == 2 ? (int)((blockIdx.x >> 8) & 1u) : flavor; }
 
+#ifdef EXON_INFLATE_WPE  // A/B builds: waves per SIMD the register allocation aims for (8 = 64 VGPRs)
+#define EXON_INFLATE_WPE_ATTR __attribute__((amdgpu_waves_per_eu(EXON_INFLATE_WPE, EXON_INFLATE_WPE)))
+#else
+#define EXON_INFLATE_WPE_ATTR
+#endif
 template <int RING>
-__global__ __launch_bounds__(64 * INF_WAVES) void k_inflate(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks, int n_blocks,
+__global__ __launch_bounds__(64 * INF_WAVES) EXON_INFLATE_WPE_ATTR void k_inflate(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks, int n_blocks,
                                                 uint8_t* out, int* __restrict__ status, int flavor) {
   const int b = uni((int)(blockIdx.x * INF_WAVES + (threadIdx.x >> 6)));
   if (b >= n_blocks) return;
@@ -2140,19 +2145,24 @@ extern "C" int exon_hip_bgzf_forget_stream(void* stream) {
   return EXON_HIP_OK;
 }
 
-// EXON_HIP_INFLATE_FLAVOR: which unit the hand-written symbol loop runs on (0 scalar, 1 vector, 2 both side by side)
-static int inflate_flavor() {
-  static const int f = [] {
+// Which hand-written symbol loop a launch runs: 1 the software-pipelined vector-unit loop with deferred far copies
+// (symbol_run_v), 0 round 1's scalar loop (symbol_run), 2 both side by side.  EXON_HIP_INFLATE_FLAVOR forces one; otherwise
+// the caller's hint, otherwise 1.  Resident launches: VCF text +10 %, BAM +9 %, FASTQ +15 % for the vector loop
+// (profiles/r4_inflate_flavor_v3.log).  In the file pipelines the inflate of slab i+1 runs beside the parse kernels of slab i:
+// .vcf.gz 70.6 -> 63 ms and .fastq.gz 175 -> 155 ms with the vector loop, but BAM 69.6 -> 71 ms -- its parse kernels (record
+// chain walk) are vector-bound themselves -- so the BAM / BCF pipelines hint 0 (profiles/r4_pipes_by_flavor.log).
+static int inflate_flavor(int hint) {
+  static const int forced = [] {
     const char* e = getenv("EXON_HIP_INFLATE_FLAVOR");
-    return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 0;
+    return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : -1;
   }();
-  return f;
+  return forced >= 0 ? forced : hint >= 0 && hint <= 2 ? hint : 1;
 }
 
 hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const exon_hip_bgzf_block* d_blocks, int n_blocks,
-                                    uint8_t* d_out, int* d_status, bool verify_crc) {
+                                    uint8_t* d_out, int* d_status, bool verify_crc, int flavor_hint) {
   if (n_blocks <= 0) return hipSuccess;
-  const int flavor = inflate_flavor();
+  const int flavor = inflate_flavor(flavor_hint);
   static_assert(sizeof(Block) == sizeof(exon_hip_bgzf_block), "block layouts must agree");
   const Block* blocks = reinterpret_cast<const Block*>(d_blocks);
   const int mode = par_mode();

@@ -201,3 +201,19 @@ def test_lane_parallel_block_decoder_in_a_fresh_process():
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert int(r.stdout.strip().splitlines()[-1]) > 10
+
+
+@pytest.mark.gpu
+def test_every_symbol_loop_in_a_fresh_process():
+    """EXON_HIP_INFLATE_FLAVOR picks the hand-written symbol loop of the serial kernel (read once per process): 1 = the
+    software-pipelined vector-unit loop with deferred far copies (default), 0 = the scalar loop, 2 = both side by side.  Small
+    launches take the lane-parallel decoder by default, so the serial kernel is forced (EXON_HIP_INFLATE_PAR=0) and this module's
+    cases -- byte equality with zlib, CRC verification, corruption reports -- rerun under each loop."""
+    import subprocess
+    import sys
+    for flavor in ("0", "1", "2"):
+        env = dict(os.environ, EXON_HIP_INFLATE_PAR="0", EXON_HIP_INFLATE_FLAVOR=flavor)
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "--timeout", "300", "-p", "no:cacheprovider",
+                            os.path.join(ROOT, "tests", "test_gpu_inflate.py"), os.path.join(ROOT, "tests", "test_gpu_region_pushdown.py"),
+                            "-k", "not fresh_process"], env=env, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, f"flavor {flavor}\n" + r.stdout[-3000:] + r.stderr[-2000:]
