@@ -51,7 +51,11 @@ constexpr int WAVES_PER_WG = 4;     // k_crc32
 #ifndef EXON_INFLATE_LIT
 #define EXON_INFLATE_LIT 2  // symbol loop: 0 = the compiler's (readable reference), 1 = literal_run, 2 = symbol_run
 #endif
-constexpr int INFLATE_RING = EXON_INFLATE_RING;  // bytes of recent output kept in LDS per wavefront (k_inflate)
+constexpr int INFLATE_RING = EXON_INFLATE_RING;  // bytes of recent output kept in LDS per wavefront (k_inflate_par: also its window)
+#ifndef EXON_INFLATE_RING_SERIAL
+#define EXON_INFLATE_RING_SERIAL EXON_INFLATE_RING
+#endif
+constexpr int INFLATE_RING_SERIAL = EXON_INFLATE_RING_SERIAL;  // the same for k_inflate (A/B builds: a smaller ring = more waves per CU)
 
 enum : int {
   INF_OK = 0,
@@ -136,6 +140,11 @@ enum { CODE_LIT = 0, CODE_DIST = 1, CODE_CL = 2 };
 constexpr int INF_WAVES = 1;  // wavefronts (= BGZF blocks) per workgroup (1: LDS addresses need no per-wave base)
 // static (not dynamic) LDS: with one kernel using it the addresses are compile-time constants in every function
 __shared__ __attribute__((aligned(16))) uint8_t smem[INF_WAVES * ((INFLATE_RING + sizeof(WaveLds) + 15) & ~size_t(15))];
+#if EXON_INFLATE_RING_SERIAL != EXON_INFLATE_RING  // a kernel is charged for the arrays it references: each kernel its own
+__shared__ __attribute__((aligned(16))) uint8_t smem_serial[INF_WAVES * ((INFLATE_RING_SERIAL + sizeof(WaveLds) + 15) & ~size_t(15))];
+#else
+#define smem_serial smem
+#endif
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 template <int RING>
 __device__ __forceinline__ uint8_t* wave_ring();
@@ -145,8 +154,9 @@ __device__ __forceinline__ WaveLds* wave_lds() { return reinterpret_cast<WaveLds
 template <int RING>
 __device__ __forceinline__ uint8_t* wave_ring() {
   constexpr uint32_t STRIDE = (RING + (uint32_t)sizeof(WaveLds) + 15u) & ~15u;
-  if (INF_WAVES == 1) return smem;
-  return smem + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * STRIDE;
+  uint8_t* base = RING == INFLATE_RING ? smem : smem_serial;
+  if (INF_WAVES == 1) return base;
+  return base + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * STRIDE;
 }
 
 struct Code {
@@ -713,8 +723,8 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
   int cnt = br.cnt;
   uint32_t widx = br.widx;
   // v[48:49] bit buffer, v50 bit count, v51 literal/length entry, v52 distance entry, v53 length, v54 distance, v55 code
-  // length, v[56:57] / v58 / v59 / v62 scratch, v60 = 1, v61 ring address of `pos`, v63 first source byte -- below v64, so that the kernel
-  // fits the 64 registers that let 8 waves share a SIMD (v56-v63 are callee-saved in the AMDGPU calling convention: the
+  // length, v[32:33] / v34 / v35 / v38 scratch, v36 = 1, v37 ring address of `pos`, v39 first source byte -- below v64, so that the kernel
+  // fits the 64 registers that let 8 waves share a SIMD (v32-v39 are callee-saved in the AMDGPU calling convention: the
   // non-inlined decode_symbols saves them once per DEFLATE block)
 #define EXON_REFILL_BODY(tag)                           \
   "  s_and_b32 s87, s83, 63\n"                          \
@@ -724,9 +734,9 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
   "  v_readlane_b32 s90, %[cur], s83\n"                 \
   "  s_mov_b32 s91, 0\n"                                \
   "  s_add_i32 s83, s83, 1\n"                           \
-  "  v_lshlrev_b64 v[56:57], v50, s[90:91]\n"           \
-  "  v_or_b32 v48, v48, v56\n"                          \
-  "  v_or_b32 v49, v49, v57\n"                          \
+  "  v_lshlrev_b64 v[32:33], v50, s[90:91]\n"           \
+  "  v_or_b32 v48, v48, v32\n"                          \
+  "  v_or_b32 v49, v49, v33\n"                          \
   "  v_add_u32 v50, 32, v50\n"                          \
   "  s_and_b32 s87, s83, 63\n"
 #define EXON_REFILL_V(tag)                              \
@@ -770,25 +780,25 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       "  v_mov_b32 v48, s80\n"
       "  v_mov_b32 v49, s81\n"
       "  v_mov_b32 v50, s82\n"
-      "  v_mov_b32 v60, 1\n"
+      "  v_mov_b32 v36, 1\n"
       "  s_mov_b32 s97, 0\n"                    // far copies in flight: 0 none, 1 one in vfa, 2 one in vfb
       EXON_REFILL_V("e")
       EXON_LOOKUP_LIT
       "  s_and_b32 s87, s84, %[ringmask]\n"
-      "  v_mov_b32 v61, s87\n"
-      // ---- invariant at the loop head: the lookup of the current symbol is in flight into v51, v61 = pos & (RING - 1)
+      "  v_mov_b32 v37, s87\n"
+      // ---- invariant at the loop head: the lookup of the current symbol is in flight into v51, v37 = pos & (RING - 1)
       "L_vsym_loop%=:\n"
       "  s_waitcnt lgkmcnt(0)\n"
-      "  v_cmp_eq_u32_sdwa vcc, v51, v60 src0_sel:BYTE_1 src1_sel:DWORD\n"  // bits 8-15 == 1: a literal (E_LIT alone)
+      "  v_cmp_eq_u32_sdwa vcc, v51, v36 src0_sel:BYTE_1 src1_sel:DWORD\n"  // bits 8-15 == 1: a literal (E_LIT alone)
       "  s_cbranch_vccz L_vsym_match%=\n"
       "  v_and_b32 v55, 15, v51\n"
       "  v_lshrrev_b64 v[48:49], v55, v[48:49]\n"
-      "  ds_write_b8_d16_hi v61, v51\n"
+      "  ds_write_b8_d16_hi v37, v51\n"
       EXON_LOOKUP_LIT                          // the next symbol; everything below runs under its latency
       "  v_sub_u32 v50, v50, v55\n"
       "  s_add_i32 s84, s84, 1\n"
       "  s_and_b32 s87, s84, %[ringmask]\n"
-      "  v_mov_b32 v61, s87\n"
+      "  v_mov_b32 v37, s87\n"
       "  v_cmp_lt_i32 vcc, 32, v50\n"
       "  s_cbranch_vccz L_vrefill_l%=\n"
       "L_vback_l%=:\n"
@@ -797,36 +807,36 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       "  s_branch L_vsym_row%=\n"
       // ---- not a literal: a length code in the table (length field 1..15, neither end of block nor invalid)?
       "L_vsym_match%=:\n"
-      "  v_and_b32 v59, 0x60f, v51\n"
-      "  v_add_u32 v59, -1, v59\n"
-      "  v_cmp_lt_u32 vcc, 14, v59\n"
+      "  v_and_b32 v35, 0x60f, v51\n"
+      "  v_add_u32 v35, -1, v35\n"
+      "  v_cmp_lt_u32 vcc, 14, v35\n"
       "  s_cbranch_vccnz L_vsym_exit0%=\n"
       "  v_and_b32 v55, 15, v51\n"             // code length
-      "  v_bfe_u32 v58, v51, 4, 4\n"           // extra bits
-      "  v_add_u32 v62, v55, v58\n"
-      "  v_bfe_u32 v59, v48, v55, v58\n"       // their value (0 bits: 0)
-      "  v_lshrrev_b64 v[48:49], v62, v[48:49]\n"
+      "  v_bfe_u32 v34, v51, 4, 4\n"           // extra bits
+      "  v_add_u32 v38, v55, v34\n"
+      "  v_bfe_u32 v35, v48, v55, v34\n"       // their value (0 bits: 0)
+      "  v_lshrrev_b64 v[48:49], v38, v[48:49]\n"
       "  v_lshlrev_b32 %[vt], 2, v48\n"        // the distance lookup (8 valid bits are there; the refill comes under it)
       "  v_and_b32 %[vt], %[dmask], %[vt]\n"
       "  ds_read_b32 v52, %[vt] offset:%[dlut]\n"
       "  v_lshrrev_b32 v53, 16, v51\n"
-      "  v_add_u32 v53, v53, v59\n"            // length
-      "  v_sub_u32 v50, v50, v62\n"
+      "  v_add_u32 v53, v53, v35\n"            // length
+      "  v_sub_u32 v50, v50, v38\n"
       EXON_REFILL_V("m")
       "  s_waitcnt lgkmcnt(0)\n"
-      "  v_and_b32 v59, 0x40f, v52\n"          // length field 1..15 and not E_INVALID (symbols 30, 31)
-      "  v_add_u32 v59, -1, v59\n"
-      "  v_cmp_lt_u32 vcc, 14, v59\n"
+      "  v_and_b32 v35, 0x40f, v52\n"          // length field 1..15 and not E_INVALID (symbols 30, 31)
+      "  v_add_u32 v35, -1, v35\n"
+      "  v_cmp_lt_u32 vcc, 14, v35\n"
       "  s_cbranch_vccnz L_vsym_exit3%=\n"
       "  v_and_b32 v55, 15, v52\n"
-      "  v_bfe_u32 v58, v52, 4, 4\n"
-      "  v_add_u32 v62, v55, v58\n"
-      "  v_bfe_u32 v59, v48, v55, v58\n"
-      "  v_lshrrev_b64 v[48:49], v62, v[48:49]\n"
+      "  v_bfe_u32 v34, v52, 4, 4\n"
+      "  v_add_u32 v38, v55, v34\n"
+      "  v_bfe_u32 v35, v48, v55, v34\n"
+      "  v_lshrrev_b64 v[48:49], v38, v[48:49]\n"
       EXON_LOOKUP_LIT                          // the symbol behind the match, under the copy
       "  v_lshrrev_b32 v54, 16, v52\n"
-      "  v_add_u32 v54, v54, v59\n"            // distance
-      "  v_sub_u32 v50, v50, v62\n"
+      "  v_add_u32 v54, v54, v35\n"            // distance
+      "  v_sub_u32 v50, v50, v38\n"
       // ---- the copies the loop does itself (as in symbol_run): d <= history, len <= 64, and either len <= d <= NEAR or d > NEAR
       "  s_sub_i32 s87, s84, s96\n"
       "  v_cmp_lt_u32 vcc, s87, v54\n"
@@ -834,7 +844,7 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       "  v_cmp_lt_u32 vcc, 64, v53\n"
       "  s_cbranch_vccnz L_vsym_exit2%=\n"
       "  v_readfirstlane_b32 s92, v53\n"
-      "  v_sub_u32 v63, s84, v54\n"                  // first source byte
+      "  v_sub_u32 v39, s84, v54\n"                  // first source byte
       "  v_cmp_lt_u32 vcc, %[near], v54\n"
       "  s_cbranch_vccnz L_vsym_far%=\n"
       "  v_cmp_gt_u32 vcc, v53, v54\n"
@@ -843,14 +853,14 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       // (source end > its first byte; it ends at or below pos, where every source starts below)
       "  s_cmp_eq_u32 s97, 0\n"
       "  s_cbranch_scc1 L_vsym_near%=\n"
-      "  v_add_u32 v59, v63, v53\n"
-      "  v_cmp_lt_u32 vcc, s100, v59\n"
+      "  v_add_u32 v35, v39, v53\n"
+      "  v_cmp_lt_u32 vcc, s100, v35\n"
       "  s_cbranch_vccz L_vsym_near%=\n"
       EXON_FAR_COMPLETE_PENDING("n")
       "L_vsym_near%=:\n"
       "  v_cmp_gt_u32_e64 s[90:91], v53, %[lane]\n"  // lanes below len
       "  s_and_saveexec_b64 s[94:95], s[90:91]\n"
-      "  v_add_u32 %[vt], v63, %[lane]\n"
+      "  v_add_u32 %[vt], v39, %[lane]\n"
       "  v_and_b32 %[vt], %[ringmask], %[vt]\n"
       "  ds_read_u8 %[ve], %[vt]\n"
       "  v_add_u32 %[vt], s84, %[lane]\n"
@@ -866,7 +876,7 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       "L_vsym_far%=:\n"
       "  v_cmp_gt_u32_e64 s[90:91], v53, %[lane]\n"
       "  s_and_saveexec_b64 s[94:95], s[90:91]\n"
-      "  v_add_u32 %[vt], v63, %[lane]\n"
+      "  v_add_u32 %[vt], v39, %[lane]\n"
       "  s_cmp_eq_u32 s97, 1\n"
       "  s_cbranch_scc1 L_vsym_far_b%=\n"
       "  global_load_ubyte %[vfa], %[vt], s[98:99]\n"
@@ -892,7 +902,7 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       "  s_xor_b32 s94, s87, s84\n"
       "  s_mov_b32 s84, s87\n"
       "  s_and_b32 s87, s87, %[ringmask]\n"
-      "  v_mov_b32 v61, s87\n"
+      "  v_mov_b32 v37, s87\n"
       "  v_cmp_lt_i32 vcc, 32, v50\n"
       "  s_cbranch_vccz L_vrefill_a%=\n"
       "L_vback_a%=:\n"
@@ -931,7 +941,7 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       : [base] "{s[88:89]}"(br.base), [begin] "{s96}"(begin), [out] "{s[98:99]}"(out), [lane] "v"(lane), [lane4] "v"(lane4), [lutmask] "i"(((1 << LIT_BITS) - 1) << 2),
         [dmask] "i"(((1 << DIST_BITS) - 1) << 2), [ringmask] "i"(RING - 1), [near] "i"(RING - 258),
         [lutoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_lut)), [dlut] "i"(RING + (int)__builtin_offsetof(WaveLds, dist_lut))
-      : "s87", "s90", "s91", "s94", "s95", "s97", "s100", "s101", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
+      : "s87", "s90", "s91", "s94", "s95", "s97", "s100", "s101", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",
         "vcc", "scc", "memory");
 #undef EXON_REFILL_V
 #undef EXON_REFILL_OUT
@@ -1651,7 +1661,7 @@ __device__ __forceinline__ void inflate_member(const uint8_t* __restrict__ comp,
   const int lane = (int)lane_id();
   WaveLds* L = wave_lds<RING>();
   uint8_t* ring = wave_ring<RING>();
-  if (lds_addr(smem) != 0) {  // literal_run addresses the ring and the table with immediates (folds away when true)
+  if (lds_addr(wave_ring<RING>()) != 0) {  // literal_run addresses the ring and the table with immediates (folds away when true)
     if (lane == 0) status[b] = INF_BAD_BTYPE;
     return;
   }
@@ -2184,7 +2194,7 @@ hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const 
       if (n_ser > 0) {
         if ((e = hipEventRecord(side.ev_fork, s)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(side.side, side.ev_fork, 0)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_inflate<INFLATE_RING>, dim3(n_ser), dim3(64), 0, side.side, d_comp, blocks, n_ser, d_out, d_status, flavor);
+        hipLaunchKernelGGL(k_inflate<INFLATE_RING_SERIAL>, dim3(n_ser), dim3(64), 0, side.side, d_comp, blocks, n_ser, d_out, d_status, flavor);
         if ((e = hipEventRecord(side.ev_join, side.side)) != hipSuccess) return e;
       }
       hipLaunchKernelGGL(k_inflate_par<INFLATE_RING>, dim3(n_wg), dim3(64), 0, s, d_comp, blocks + n_ser, n_blocks - n_ser, d_out, d_status + n_ser,
@@ -2193,7 +2203,7 @@ hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const 
     }
   }
   if (!parallel)
-    hipLaunchKernelGGL(k_inflate<INFLATE_RING>, dim3((n_blocks + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), 0, s, d_comp, blocks, n_blocks,
+    hipLaunchKernelGGL(k_inflate<INFLATE_RING_SERIAL>, dim3((n_blocks + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), 0, s, d_comp, blocks, n_blocks,
                        d_out, d_status, flavor);
   if (verify_crc)
     hipLaunchKernelGGL(k_crc32, dim3((n_blocks + WAVES_PER_WG - 1) / WAVES_PER_WG), dim3(WAVES_PER_WG * 64), 0, s, d_out, blocks, n_blocks,
