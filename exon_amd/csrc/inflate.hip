@@ -874,6 +874,9 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       // reads them, when the block is left (row drains, slow paths) -- so the round trip to L2 / HBM runs under the decoding
       // of the symbols behind it.  Nothing reads those ring bytes earlier: literals and copies only write at `pos` and above.
       "L_vsym_far%=:\n"
+#ifdef EXON_INFLATE_FAR_NOWAIT  // timing experiment only (wrong bytes): what the loop would cost if far copies were free
+      "  s_branch L_vsym_adv%=\n"
+#endif
       "  v_cmp_gt_u32_e64 s[90:91], v53, %[lane]\n"
       "  s_and_saveexec_b64 s[94:95], s[90:91]\n"
       "  v_add_u32 %[vt], v39, %[lane]\n"
