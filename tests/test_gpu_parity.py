@@ -3,6 +3,7 @@
 Bit-exact for counts / interval hits / histograms; <= 1e-6 relative for f64 sums (north_star tolerance;
 in practice ~1e-15: only the association order of the f64 adds differs).
 """
+import os
 import numpy as np
 import pytest
 
@@ -646,3 +647,53 @@ def test_k5_ragged_reads(ctx, oracle):
     ctx.sync()
     want, _ = oracle.c5_qual_pos_hist(off, data, 180)
     assert np.array_equal(d.to_host().reshape(180, 256), want)
+
+
+@pytest.mark.parametrize("G,dist", [(4105, "uniform"), (20_000, "uniform"), (100_000, "uniform"), (100_000, "early"), (4100 + 64 * 8192, "uniform"),
+                                    (4100 + 64 * 8192 + 1, "uniform")])
+def test_k4_tier3_grouped_by_range_inside_the_main_kernel(ctx, G, dist):
+    """Launches big enough for the 1024-thread shape (>= 16384 rows per CU) with id ranges beyond the LDS table.  By default they
+    take compact -> scatter -> aggregate; under EXON_HIP_K4_TAIL_BINNED=1 (read once per process: the test below reruns this one
+    in a subprocess) and with up to 64 ranges the main kernel writes its tier-3 records grouped by range, tile by tile
+    (k4_main_binned), and k4_tail_aggregate_runs reads the runs; one range more falls back.  Counts bit-exact vs numpy, sums
+    within the budget; a second launch accumulates; the row count is not a multiple of the tile (remainder rows: atomic form)."""
+    from oracle import Oracle
+    orc = Oracle()
+    n = 6_000_000 + 4321
+    rng = np.random.default_rng(G + len(dist))
+    af, av, q, qv, _ = orc.gen_c4(4, 0, n)
+    if dist == "uniform":
+        fid = rng.integers(0, G, n).astype(np.int32)
+    else:  # most rows on early ids, a long thin tail
+        fid = np.minimum((rng.exponential(G / 30.0, n)).astype(np.int64), G - 1).astype(np.int32)
+    fid[:5] = [0, G - 1, G // 2, 1, G - 2]
+    avb, qvb = bits(av, n), bits(qv, n)
+    keep = avb & (af.astype(np.float64) > 0.01)
+    cr = np.bincount(fid[keep], minlength=G)
+    cn = np.bincount(fid[keep & qvb], minlength=G)
+    s = np.bincount(fid[keep & qvb], weights=q[keep & qvb].astype(np.float64), minlength=G)
+    d = [ctx.to_device(x) for x in (af, av, q, qv, fid)]
+    plan = ctx.plan_cmp_avg_by_group(">", 0.01, G)
+    state = ctx.to_device(np.full(3 * G, 0x0101010101010101, np.int64))
+    cols = [(d[0], d[1], None), (d[2], d[3], None), (d[4], None, None)]
+    plan.launch(cols, n, state, overwrite=True)
+    ctx.sync()
+    st = state.to_host()
+    assert np.array_equal(st[:G], cn) and np.array_equal(st[G:2 * G], cr)
+    assert np.allclose(st[2 * G:].view(np.float64), s, rtol=RTOL, atol=0)
+    plan.launch(cols, n, state, overwrite=False)
+    ctx.sync()
+    st = state.to_host()
+    assert np.array_equal(st[:G], 2 * cn) and np.array_equal(st[G:2 * G], 2 * cr)
+    assert np.allclose(st[2 * G:].view(np.float64), 2 * s, rtol=RTOL, atol=0)
+
+
+@pytest.mark.gpu
+def test_k4_tier3_grouped_inside_the_main_kernel_in_a_fresh_process():
+    """The opt-in in-kernel partition of tier 3 (EXON_HIP_K4_TAIL_BINNED=1, profiles/r4_groupby_binned.md) stays correct."""
+    import subprocess
+    import sys
+    env = dict(os.environ, EXON_HIP_K4_TAIL_BINNED="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "--timeout", "600", "-p", "no:cacheprovider", os.path.abspath(__file__),
+                        "-k", "tier3_grouped_by_range or beyond_4096"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
