@@ -146,6 +146,7 @@ int exon_hip_ctx_create(int device, exon_hip_ctx** out) {
     int b = atoi(v);
     if (b >= 1 && b <= 32) ctx->cfg.blocks_per_cu = b;
   }
+  exon_hip_prewarm_ctx(ctx);
   *out = ctx;
   return EXON_HIP_OK;
 }

@@ -48,6 +48,7 @@ const char* exon_bgzf_status_name(int code);
 
 // scan.cpp: slab buffers kept per ctx between scans
 void exon_hip_release_ctx_caches(exon_hip_ctx* ctx);
+void exon_hip_prewarm_ctx(exon_hip_ctx* ctx);  // scan.cpp: the file pipelines' side streams and events, made with the context
 
 // capi.cpp: size-keyed recycling of device buffers (released by exon_hip_ctx_destroy)
 void* exon_pool_alloc(exon_hip_ctx* ctx, size_t bytes);

@@ -490,6 +490,23 @@ struct SlabBuffers {
   exon_hip_bgzf_block* d_blocks = nullptr;
   hipStream_t cs = nullptr, xs = nullptr;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // everything but the streams and events (those fit any scan)
+  void free_buffers() {
+    if (h_ring) hipHostFree(h_ring);
+    h_ring = nullptr;
+    ring_bytes = 0;
+    for (int k = 0; k < 2; ++k) {
+      if (h_buf[k]) hipHostFree(h_buf[k]);
+      if (d_comp[k]) hipFree(d_comp[k]);
+      if (d_text[k]) hipFree(d_text[k]);
+      h_buf[k] = d_comp[k] = d_text[k] = nullptr;
+    }
+    if (h_blocks) hipHostFree(h_blocks);
+    if (d_blocks) hipFree(d_blocks);
+    h_blocks = d_blocks = nullptr;
+    hcap = tcap = ccap = 0;
+    max_blocks = 0;
+  }
   void free_all() {
     if (h_ring) hipHostFree(h_ring);
     h_ring = nullptr;
@@ -520,6 +537,27 @@ struct SlabBuffers {
 };
 static std::mutex g_slab_mu;
 static std::map<exon_hip_ctx*, SlabBuffers> g_slab_cache;
+
+// Called by exon_hip_ctx_create (EXON_HIP_CTX_PREWARM=0 skips it): the two side streams and the events of the file pipelines
+// are made with the context instead of inside its first scan (~17 ms of a first scan's 125: profiles/r4_first_scan.log).
+void exon_hip_prewarm_ctx(exon_hip_ctx* ctx) {
+  if (const char* v = getenv("EXON_HIP_CTX_PREWARM"))
+    if (v[0] == '0') return;
+  SlabBuffers b;
+  int prio_least = 0, prio_greatest = 0;
+  const char* pv = getenv("EXON_HIP_STREAM_PRIORITY");
+  const bool use_prio = !(pv && pv[0] == '0') && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess && prio_least != prio_greatest;
+  bool ok = (use_prio ? hipStreamCreateWithPriority(&b.cs, hipStreamNonBlocking, prio_least) : hipStreamCreateWithFlags(&b.cs, hipStreamNonBlocking)) == hipSuccess &&
+            hipStreamCreateWithFlags(&b.xs, hipStreamNonBlocking) == hipSuccess;
+  for (int k = 0; ok && k < 6; ++k) ok = hipEventCreateWithFlags(&b.ev[k], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {  // not an error: the first scan makes what is missing
+    (void)hipGetLastError();
+    b.free_all();
+    return;
+  }
+  std::lock_guard<std::mutex> g(g_slab_mu);
+  g_slab_cache[ctx] = b;
+}
 
 void exon_hip_release_ctx_caches(exon_hip_ctx* ctx) {
   std::lock_guard<std::mutex> g(g_slab_mu);
@@ -583,10 +621,7 @@ class GpuTextSource {
     b.h_ring = h_ring_;
     b.ring_bytes = (size_t)RING_N * (RING_HEAD + RING_PIECE);
     for (int q = 0; q < RING_MAX; ++q) b.ev_piece[q] = ev_piece_[q];
-    if (!complete_) {
-      b.free_all();
-      return;
-    }
+    if (!complete_) b.free_buffers();  // a failed init: the streams and events still go back
     std::lock_guard<std::mutex> g(g_slab_mu);
     SlabBuffers& slot = g_slab_cache[ctx_];
     slot.free_all();
@@ -606,8 +641,21 @@ class GpuTextSource {
       auto it = g_slab_cache.find(ctx_);
       if (it != g_slab_cache.end()) {
         SlabBuffers& b = it->second;
+        // the streams and events fit any scan (exon_hip_ctx_create makes them up front: the first use of two more hardware
+        // queues costs ~17 ms on a fresh context); the buffers only one of the same shape
+        for (int q = 0; q < RING_MAX; ++q) {
+          ev_piece_[q] = b.ev_piece[q];
+          b.ev_piece[q] = nullptr;
+        }
+        cs_ = b.cs;
+        xs_ = b.xs;
+        for (int k = 0; k < 2; ++k) {
+          ev_h2d_[k] = b.ev[k];
+          ev_done_[k] = b.ev[2 + k];
+          ev_free_[k] = b.ev[4 + k];
+        }
         if (b.bgzf == bgzf_ && b.hcap == hcap_ && b.tcap == gap_ + text_cap_ && b.ccap == comp_cap_ && b.max_blocks == max_blocks_ &&
-            b.ring_bytes == (size_t)RING_N * (RING_HEAD + RING_PIECE)) {
+            b.ring_bytes == (size_t)RING_N * (RING_HEAD + RING_PIECE) && b.d_text[0]) {
           for (int k = 0; k < 2; ++k) {
             h_buf_[k] = b.h_buf[k];
             d_comp_[k] = b.d_comp[k];
@@ -617,20 +665,9 @@ class GpuTextSource {
           d_blocks_ = b.d_blocks;
           h_ring_ = b.h_ring;
           b.h_ring = nullptr;
-          for (int q = 0; q < RING_MAX; ++q) {
-            ev_piece_[q] = b.ev_piece[q];
-            b.ev_piece[q] = nullptr;
-          }
-          cs_ = b.cs;
-          xs_ = b.xs;
-          for (int k = 0; k < 2; ++k) {
-            ev_h2d_[k] = b.ev[k];
-            ev_done_[k] = b.ev[2 + k];
-            ev_free_[k] = b.ev[4 + k];
-          }
           complete_ = true;
         } else {
-          b.free_all();
+          b.free_buffers();
         }
         g_slab_cache.erase(it);
       }
