@@ -2205,8 +2205,14 @@ hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const 
       if (n_ser > 0 && (e = hipStreamWaitEvent(s, side.ev_join, 0)) != hipSuccess) return e;
     }
   }
+  // (experiment knob: EXON_HIP_INFLATE_PAD_LDS=<bytes> of unused dynamic LDS per workgroup = fewer resident waves per CU)
+  static const size_t pad_lds = [] {
+    const char* e = getenv("EXON_HIP_INFLATE_PAD_LDS");
+    const long v = e ? atol(e) : 0;
+    return (size_t)(v > 0 && v <= 32768 ? v : 0);
+  }();
   if (!parallel)
-    hipLaunchKernelGGL(k_inflate<INFLATE_RING_SERIAL>, dim3((n_blocks + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), 0, s, d_comp, blocks, n_blocks,
+    hipLaunchKernelGGL(k_inflate<INFLATE_RING_SERIAL>, dim3((n_blocks + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), pad_lds, s, d_comp, blocks, n_blocks,
                        d_out, d_status, flavor);
   if (verify_crc)
     hipLaunchKernelGGL(k_crc32, dim3((n_blocks + WAVES_PER_WG - 1) / WAVES_PER_WG), dim3(WAVES_PER_WG * 64), 0, s, d_out, blocks, n_blocks,
