@@ -71,6 +71,8 @@ def parse_args():
     ap.add_argument("--cpu-sample-rows", type=float, default=128e6)
     ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not measure roofline.traffic in this run (two rocprofv3 --pmc passes of a short child run); use profiles/traffic.json")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (stated-size configs, H2D-inclusive rate)")
     return ap.parse_args()
 
@@ -302,6 +304,53 @@ def cpu_baseline(kind, sample_rows, n_total, reps):
     return res, out
 
 
+PMC_KERNEL = {"c4": "k4_cmp_avg_by_group_main", "c2": "k2_region_count_main", "c3": "k3_flag_mapq_group_count_main",
+              "c5": "k5_main", "c6": "k6_overlap_count_main"}
+
+
+def measure_traffic(a, rows):
+    """roofline.traffic measured in THIS run: HBM bytes per launch of the dominant kernel from rocprofv3 PMC counters, collected
+    the way /opt/skills/guides/MI355X_MICROARCH.md prescribes -- FETCH_SIZE and WRITE_SIZE in SEPARATE passes, each with
+    --kernel-trace only, values in KiB, and on gfx950 FETCH_SIZE counts half of the bytes of a wide (16 B per lane) coalesced
+    stream: read bytes = 2 x FETCH_SIZE x 1024.  Each pass is a short child run of this script on the same workload (3 steps);
+    launches of the full table are the ones whose counter is within 2x of the largest (the parity gate's launch is smaller).
+    Returns (bytes, note) or None (no rocprofv3, a failed pass: the caller falls back to profiles/traffic.json)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):  # no profiler, or this run is already a traced one
+        return None
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="exon_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable,
+                   os.path.abspath(__file__), "--workload", a.workload, "--rows", str(int(rows)), "--steps", "3", "--warmup", "1",
+                   "--no-cpu-baseline", "--no-extras", "--no-pmc"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=300)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            v = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                 if PMC_KERNEL[a.workload] in row["Kernel_Name"] and row["Counter_Name"] == ctr]
+            if not v:
+                return None
+            full = [x for x in v if x >= 0.5 * max(v)] if max(v) > 0 else v
+            vals[ctr] = (sum(full) / len(full), len(full))
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    b = int(2 * vals["FETCH_SIZE"][0] * 1024 + vals["WRITE_SIZE"][0] * 1024)
+    note = (f"measured in this run: two rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE, each with --kernel-trace only) of a 3-step child "
+            f"run, {vals['FETCH_SIZE'][1]} full launches averaged; read bytes = 2 x FETCH_SIZE KiB x 1024 (gfx950 wide-stream "
+            f"undercount, MI355X_MICROARCH.md), write bytes = WRITE_SIZE KiB x 1024")
+    return b, note
+
+
 def time_config(ctx, kind, rows, steps=50, warmup=5):
     """A config at the size BASELINE.json states it (c2 @ 1e7, c3 @ 1e8): (ms per step, kernel ms, roofline fraction)."""
     wl = Workload(ctx, kind, rows, 0, rows)
@@ -527,7 +576,10 @@ def main():
                                  "(no finalize launch, no zeroing pass); c5: offsets scan + main + fold"},
         }
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(traffic_file):
+        live = measure_traffic(a, rows) if (world == 1 and not a.no_pmc and a.groups == 5) else None
+        if live is not None:
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = live
+        elif os.path.exists(traffic_file):
             try:
                 t = json.load(open(traffic_file)).get(a.workload)
                 if t and int(t.get("rows", 0)) == rows and a.groups == 5:

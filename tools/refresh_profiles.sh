@@ -12,12 +12,12 @@ cd $GRAFT_REPO_ROOT
 P=gpurun_out/prof_$R
 mkdir -p $P gpurun_out/pmc_fetch gpurun_out/pmc_write
 run_wl() {  # workload rows steps
-  rocprofv3 --kernel-trace --stats -d $P/tmp_$1 -o $1 --output-format csv -- python bench.py --workload $1 --rows $2 --steps $3 --warmup 3 --no-extras > $P/bench_$1.json 2> $P/bench_$1.err
+  rocprofv3 --kernel-trace --stats -d $P/tmp_$1 -o $1 --output-format csv -- python bench.py --workload $1 --rows $2 --steps $3 --warmup 3 --no-extras --no-pmc > $P/bench_$1.json 2> $P/bench_$1.err
   cp $P/tmp_$1/$1_kernel_stats.csv $P/$1_kernel_stats.csv; rm -rf $P/tmp_$1
   for ctr in FETCH_SIZE WRITE_SIZE; do
     d=gpurun_out/pmc_$( [ $ctr = FETCH_SIZE ] && echo fetch || echo write )
     rm -rf $d/tmp_$1
-    rocprofv3 --pmc $ctr --kernel-trace -d $d/tmp_$1 -o $1 --output-format csv -- python bench.py --workload $1 --rows $2 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
+    rocprofv3 --pmc $ctr --kernel-trace -d $d/tmp_$1 -o $1 --output-format csv -- python bench.py --workload $1 --rows $2 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-pmc > /dev/null 2>&1
     f=$(find $d/tmp_$1 -name "*counter_collection.csv" | head -1)
     [ -n "$f" ] && cp "$f" $d/$1_counter_collection.csv
     rm -rf $d/tmp_$1
