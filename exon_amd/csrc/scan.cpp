@@ -581,7 +581,15 @@ class GpuTextSource {
       // blocks as the chip holds wavefronts of this kernel (24 per CU x 256 CUs) and not one more: slabs are cut by BLOCK
       // COUNT.  The bytes read per slab follow the running average block size.
       target_blocks_ = (int)std::max<size_t>(64, 6144 * (slab_ >> 20) / 64);
-      comp_cap_ = 2 * slab_ + (1u << 17);           // compressed bytes per slab (+ a carried partial block)
+      // compressed bytes per slab (+ a carried partial block): room for `target_blocks_` members whatever their ratio.  (Until
+      // round 4 the cap was 2 x slab_ = 128 MB: enough for the 6144 members of VCF text (112 MB) or BAM (131 MB), but a
+      // .fastq.gz member is ~35 KB, its slabs stopped at 3700 members = 14 waves per CU, and the inflate -- whose throughput
+      // grows with the resident waves, profiles/r4_inflate_waves_per_cu.log -- ran at 60 % occupancy.  EXON_HIP_COMP_CAP_MB: A/B.)
+      comp_cap_ = (size_t)target_blocks_ * 65536 + (1u << 17);
+      if (const char* v = getenv("EXON_HIP_COMP_CAP_MB")) {
+        const long mb = atol(v);
+        if (mb >= 16 && mb <= 2048) comp_cap_ = ((size_t)mb << 20) + (1u << 17);
+      }
       text_cap_ = (size_t)target_blocks_ * 65536;   // inflated bytes per slab
     } else {
       text_cap_ = slab_;
