@@ -330,7 +330,7 @@ def measure_traffic(a, rows):
             cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable,
                    os.path.abspath(__file__), "--workload", a.workload, "--rows", str(int(rows)), "--steps", "3", "--warmup", "1",
                    "--no-cpu-baseline", "--no-extras", "--no-pmc"]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=300)
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=120)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None
