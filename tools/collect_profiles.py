@@ -29,7 +29,8 @@ if os.path.exists(bj) and os.path.getsize(bj):
     if wl != "c4":
         d.pop("result", None)
     json.dump(d, open(os.path.join(P, f"{rnd}_bench_{wl}_1gpu.json"), "w"), indent=1)
-for extra in ("bgzf_pipeline_kernel_stats.csv", "bam_pipeline_kernel_stats.csv", "vcfgz_end_to_end.log", "bam_end_to_end.log"):
+for extra in ("bgzf_pipeline_kernel_stats.csv", "bam_pipeline_kernel_stats.csv", "fastq_pipeline_kernel_stats.csv", "vcfgz_end_to_end.log",
+              "bam_end_to_end.log", "fastqgz_end_to_end.log"):
     e = os.path.join(G, f"prof_{rnd}", extra)
     if os.path.exists(e):
         shutil.copy(e, os.path.join(P, f"{rnd}_{extra}"))

@@ -66,4 +66,9 @@ PY
 python /tmp/bam_one.py > $P/bam_end_to_end.log 2>&1
 rocprofv3 --kernel-trace --stats -d $P/tmp_bam -o bam --output-format csv -- python /tmp/bam_one.py > /dev/null 2>&1
 cp $P/tmp_bam/bam_kernel_stats.csv $P/bam_pipeline_kernel_stats.csv; rm -rf $P/tmp_bam
-cat $P/vcfgz_end_to_end.log $P/bam_end_to_end.log
+tools/bin/gen_text fastq 20000000 /tmp/e2e.fastq && tools/bin/bgzip /tmp/e2e.fastq /tmp/e2e.fastq.gz 6
+cat /tmp/e2e.fastq.gz > /dev/null
+python tools/time_pipeline_file.py /tmp/e2e.fastq.gz fastq 4 > $P/fastqgz_end_to_end.log 2>&1
+rocprofv3 --kernel-trace --stats -d $P/tmp_fq -o fq --output-format csv -- python tools/time_pipeline_file.py /tmp/e2e.fastq.gz fastq 4 > /dev/null 2>&1
+cp $P/tmp_fq/fq_kernel_stats.csv $P/fastq_pipeline_kernel_stats.csv; rm -rf $P/tmp_fq
+cat $P/vcfgz_end_to_end.log $P/bam_end_to_end.log $P/fastqgz_end_to_end.log
