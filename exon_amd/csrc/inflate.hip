@@ -121,7 +121,14 @@ struct ClTables {  // the code-length code is dead once the two main codes are b
   uint16_t cl_count[16];
 };
 struct WaveLds {
-  uint32_t lit_lut[1 << LIT_BITS];
+  // The code lengths read from a block header are only needed until the tables are built, and the literal/length table -- built
+  // LAST, from lengths its builder has taken into registers before it writes the first entry -- is dead from the header on:
+  // they share its bytes (round 4: 320 bytes less per member = 26 instead of 24 resident waves per CU; the inflate's
+  // throughput grows with them, profiles/r4_inflate_waves_per_cu.log)
+  union {
+    uint32_t lit_lut[1 << LIT_BITS];
+    uint8_t lens[288 + 32];
+  };
   union {
     uint32_t dist_lut[1 << DIST_BITS];
     ClTables cl;
@@ -132,7 +139,6 @@ struct WaveLds {
   // per length: first canonical code / symbols of shorter lengths.  Scratch of every build_code; the literal/length
   // code is built LAST, so between table builds these hold ITS values, which decode_long uses.
   uint16_t first[16], offs[16];
-  uint8_t lens[288 + 32];
 };
 // (the code-length tables share the bytes of dist_lut: they are dead once the lengths are read)
 enum { CODE_LIT = 0, CODE_DIST = 1, CODE_CL = 2 };
@@ -269,14 +275,24 @@ __device__ __noinline__ int build_code_impl(int which, int lens_off, int n) {
   const uint8_t* lens = L->lens + lens_off;
   const int lane = (int)lane_id();
   const int size = 1 << c.bits;
+  // this lane's lengths (symbols lane, lane + 64, ...: n <= 288) BEFORE the table is touched: the literal/length table
+  // overlays the lengths
+  int myl[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int s = k * 64 + lane;
+    myl[k] = s < n ? (int)lens[s] : 0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   for (int i = lane; i < size; i += 64) c.lut[i] = 0;
   // totals per length, by ballots
   int run[16];
 #pragma unroll
   for (int l = 0; l < 16; ++l) run[l] = 0;
-  for (int s0 = 0; s0 < n; s0 += 64) {
-    const int s = s0 + lane;
-    const int l = s < n ? lens[s] : 0;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    if (k * 64 >= n) break;
+    const int l = myl[k];
 #pragma unroll
     for (int q = 1; q < 16; ++q) run[q] += __popcll(__ballot(l == q));
   }
@@ -317,9 +333,11 @@ __device__ __noinline__ int build_code_impl(int which, int lens_off, int n) {
 #pragma unroll
   for (int l = 0; l < 16; ++l) seen[l] = 0;
   const unsigned long long lt = (1ull << lane) - 1ull;
-  for (int s0 = 0; s0 < n; s0 += 64) {
-    const int s = s0 + lane;
-    const int l = s < n ? lens[s] : 0;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    if (k * 64 >= n) break;
+    const int s = k * 64 + lane;
+    const int l = myl[k];
     int rank = 0;
 #pragma unroll
     for (int q = 1; q < 16; ++q) {
