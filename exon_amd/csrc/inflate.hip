@@ -2238,6 +2238,13 @@ hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const 
   return hipGetLastError();
 }
 
+// resident workgroups per CU of the serial kernel, as the runtime computes it (tools / DESIGN only)
+extern "C" int exon_hip_debug_inflate_occupancy(int dynamic_lds_bytes) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_inflate<INFLATE_RING_SERIAL>, 64, (size_t)dynamic_lds_bytes) != hipSuccess) return -1;
+  return nb;
+}
+
 const char* exon_bgzf_status_name(int code) {
   static const char* const names[] = {"ok", "reserved block type", "stored-block length check", "invalid code lengths",
                                       "invalid Huffman code", "distance before the block start", "more output than ISIZE",
