@@ -2180,8 +2180,10 @@ extern "C" int exon_hip_bgzf_forget_stream(void* stream) {
 // (symbol_run_v), 0 round 1's scalar loop (symbol_run), 2 both side by side.  EXON_HIP_INFLATE_FLAVOR forces one; otherwise
 // the caller's hint, otherwise 1.  Resident launches: VCF text +10 %, BAM +9 %, FASTQ +15 % for the vector loop
 // (profiles/r4_inflate_flavor_v3.log).  In the file pipelines the inflate of slab i+1 runs beside the parse kernels of slab i:
-// .vcf.gz 70.6 -> 63 ms and .fastq.gz 175 -> 155 ms with the vector loop, but BAM 69.6 -> 71 ms -- its parse kernels (record
-// chain walk) are vector-bound themselves -- so the BAM / BCF pipelines hint 0 (profiles/r4_pipes_by_flavor.log).
+// .vcf.gz 70.6 -> 63 ms, .fastq.gz 175 -> 155 ms with the vector loop.  The BAM pipeline first measured 69.6 -> 71 ms and kept
+// the scalar loop (profiles/r4_pipes_by_flavor.log); with 27 instead of 26 resident members per CU (the code lengths overlaid
+// on the literal table) and the record chain's proof done in parallel the vector loop wins there too (BAM 73.5 -> 67.3-68.9
+// ms, BCF 43.6 -> 40.8-41.8 on one box: profiles/r4_bam_chain_check_ab.log), so nothing hints the scalar loop any more.
 static int inflate_flavor(int hint) {
   static const int forced = [] {
     const char* e = getenv("EXON_HIP_INFLATE_FLAVOR");
