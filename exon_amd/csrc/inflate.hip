@@ -265,6 +265,10 @@ __device__ __forceinline__ uint32_t entry_for(int which, int s) {
 
 // Build code `which` from lens[0..n): counts, canonical order, first-level table.  Returns 0 for an over-subscribed
 // code, or an incomplete one that is not the single-code case DEFLATE allows.
+// (96 SGPRs in all -- 90 + VCC, flat scratch, XNACK -- is what lets a SIMD hold 7 waves of a kernel, 80 what lets it hold 8:
+//  tools/occupancy_probe.hip.  The per-length totals of this function are wave-uniform; as four 16-entry arrays they took 102
+//  scalar registers and capped the whole kernel at 6 waves per SIMD.  They live in the LANES of vector registers now: lane q
+//  holds the value for code length q.)
 template <int RING>
 __device__ __noinline__ int build_code_impl(int which, int lens_off, int n) {
   which = uni(which);
@@ -285,53 +289,46 @@ __device__ __noinline__ int build_code_impl(int which, int lens_off, int n) {
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   for (int i = lane; i < size; i += 64) c.lut[i] = 0;
-  // totals per length, by ballots
-  int run[16];
-#pragma unroll
-  for (int l = 0; l < 16; ++l) run[l] = 0;
+  // totals per length, by ballots: lane q accumulates the symbols of length q
+  int run_l = 0;
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     if (k * 64 >= n) break;
     const int l = myl[k];
-#pragma unroll
-    for (int q = 1; q < 16; ++q) run[q] += __popcll(__ballot(l == q));
+#pragma unroll 1  // (rolled: unrolled, the 5 x 15 ballots kept ~90 scalar registers live)
+    for (int q = 1; q < 16; ++q) {
+      const int cq = __popcll(__ballot(l == q));
+      if (lane == q) run_l += cq;
+    }
   }
   int left = 1, total = 0;
-  int first[16], offs[16];
-  first[0] = offs[0] = 0;
+  int first_l = 0, offs_l = 0;  // lane q: first canonical code of length q / symbols of shorter lengths
   {
     int code = 0, off = 0;
-#pragma unroll
+#pragma unroll 1
     for (int q = 1; q < 16; ++q) {
+      const int rq = __builtin_amdgcn_readlane(run_l, q);
       code <<= 1;
-      first[q] = code;
-      offs[q] = off;
-      code += run[q];
-      off += run[q];
-      left = (left << 1) - run[q];
+      if (lane == q) {
+        first_l = code;
+        offs_l = off;
+      }
+      code += rq;
+      off += rq;
+      left = (left << 1) - rq;
       if (left < 0) return 0;  // over-subscribed
-      total += run[q];
+      total += rq;
     }
   }
   if (left > 0 && total > 1) return 0;  // incomplete (RFC 1951 allows it only for a single distance code)
   if (lane < 16) {
-    int cq = 0, fq = 0, oq = 0;
-#pragma unroll
-    for (int q = 1; q < 16; ++q)
-      if (lane == q) {
-        cq = run[q];
-        fq = first[q];
-        oq = offs[q];
-      }
-    c.count[lane] = (uint16_t)cq;
-    c.first[lane] = (uint16_t)fq;
-    c.offs[lane] = (uint16_t)oq;
+    c.count[lane] = (uint16_t)run_l;
+    c.first[lane] = (uint16_t)first_l;
+    c.offs[lane] = (uint16_t)offs_l;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   // every symbol gets its canonical code (rank inside its length class, in symbol order); fill the tables
-  int seen[16];
-#pragma unroll
-  for (int l = 0; l < 16; ++l) seen[l] = 0;
+  int seen_l = 0;  // lane q: symbols of length q placed so far
   const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
@@ -339,11 +336,12 @@ __device__ __noinline__ int build_code_impl(int which, int lens_off, int n) {
     const int s = k * 64 + lane;
     const int l = myl[k];
     int rank = 0;
-#pragma unroll
+#pragma unroll 1
     for (int q = 1; q < 16; ++q) {
       const unsigned long long m = __ballot(l == q);
-      if (l == q) rank = seen[q] + __popcll(m & lt);
-      seen[q] += __popcll(m);
+      const int sq = __builtin_amdgcn_readlane(seen_l, q);
+      if (l == q) rank = sq + __popcll(m & lt);
+      if (lane == q) seen_l += __popcll(m);
     }
     if (l > 0) {
       const int code = (int)c.first[l] + rank;
@@ -351,7 +349,7 @@ __device__ __noinline__ int build_code_impl(int which, int lens_off, int n) {
       if (l <= c.bits) {
         const unsigned rev = __brev((unsigned)code) >> (32 - l);
         const uint32_t e = entry_for(which, s) | (uint32_t)l;
-        for (unsigned k = rev; k < (unsigned)size; k += 1u << l) c.lut[k] = e;
+        for (unsigned k2 = rev; k2 < (unsigned)size; k2 += 1u << l) c.lut[k2] = e;
       }
     }
   }
@@ -505,47 +503,47 @@ __device__ __forceinline__ uint32_t literal_run(BitReader& br, uint32_t& pos, ui
   uint32_t widx = br.widx;
   asm volatile(
       "L_lit_loop%=:\n"
-      "  s_cmp_gt_i32 s82, 32\n"
+      "  s_cmp_gt_i32 s68, 32\n"
       "  s_cbranch_scc1 L_lit_have%=\n"
       "  s_waitcnt vmcnt(0)\n"
-      "  v_readlane_b32 s90, %[cur], s83\n"
-      "  s_mov_b32 s91, 0\n"
-      "  s_lshl_b64 s[90:91], s[90:91], s82\n"
-      "  s_or_b64 s[80:81], s[80:81], s[90:91]\n"
-      "  s_add_i32 s82, s82, 32\n"
-      "  s_add_i32 s83, s83, 1\n"
-      "  s_and_b32 s87, s83, 63\n"
+      "  v_readlane_b32 s76, %[cur], s69\n"
+      "  s_mov_b32 s77, 0\n"
+      "  s_lshl_b64 s[76:77], s[76:77], s68\n"
+      "  s_or_b64 s[66:67], s[66:67], s[76:77]\n"
+      "  s_add_i32 s68, s68, 32\n"
+      "  s_add_i32 s69, s69, 1\n"
+      "  s_and_b32 s73, s69, 63\n"
       "  s_cbranch_scc1 L_lit_have%=\n"
-      "  v_lshl_add_u32 %[vt], s83, 2, %[lane4]\n"
-      "  global_load_dword %[cur], %[vt], s[88:89]\n"
+      "  v_lshl_add_u32 %[vt], s69, 2, %[lane4]\n"
+      "  global_load_dword %[cur], %[vt], s[74:75]\n"
       "L_lit_have%=:\n"
-      "  v_lshlrev_b32 %[vt], 2, s80\n"
+      "  v_lshlrev_b32 %[vt], 2, s66\n"
       "  v_and_b32 %[vt], %[lutmask], %[vt]\n"
       "  ds_read_b32 %[ve], %[vt] offset:%[lutoff]\n"
       "  s_waitcnt lgkmcnt(0)\n"
-      "  v_readfirstlane_b32 s85, %[ve]\n"
-      "  s_bitcmp1_b32 s85, 8\n"
+      "  v_readfirstlane_b32 s71, %[ve]\n"
+      "  s_bitcmp1_b32 s71, 8\n"
       "  s_cbranch_scc0 L_lit_other%=\n"
-      "  s_and_b32 s87, s85, 15\n"
-      "  s_lshr_b64 s[80:81], s[80:81], s87\n"
-      "  s_sub_i32 s82, s82, s87\n"
+      "  s_and_b32 s73, s71, 15\n"
+      "  s_lshr_b64 s[66:67], s[66:67], s73\n"
+      "  s_sub_i32 s68, s68, s73\n"
       "  v_and_b32 %[vt], %[ringmask], %[vpos]\n"
       "  ds_write_b8_d16_hi %[vt], %[ve]\n"
       "  v_add_u32 %[vpos], 1, %[vpos]\n"
-      "  s_add_i32 s84, s84, 1\n"
-      "  s_and_b32 s87, s84, 0xff\n"
+      "  s_add_i32 s70, s70, 1\n"
+      "  s_and_b32 s73, s70, 0xff\n"
       "  s_cbranch_scc1 L_lit_loop%=\n"
-      "  s_mov_b32 s86, 1\n"
+      "  s_mov_b32 s72, 1\n"
       "  s_branch L_lit_out%=\n"
       "L_lit_other%=:\n"
-      "  s_mov_b32 s86, 0\n"
+      "  s_mov_b32 s72, 0\n"
       "L_lit_out%=:\n"
       "  s_waitcnt vmcnt(0) lgkmcnt(0)\n"
-      : [buf] "+{s[80:81]}"(buf), [cnt] "+{s82}"(cnt), [widx] "+{s83}"(widx), [pos] "+{s84}"(pos), [e] "={s85}"(e), [why] "={s86}"(why),
+      : [buf] "+{s[66:67]}"(buf), [cnt] "+{s68}"(cnt), [widx] "+{s69}"(widx), [pos] "+{s70}"(pos), [e] "={s71}"(e), [why] "={s72}"(why),
         [cur] "+v"(br.cur), [vpos] "+v"(vpos), [vt] "=&v"(vt), [ve] "=&v"(ve)
-      : [base] "{s[88:89]}"(br.base), [lane4] "v"(lane4), [lutmask] "i"(((1 << LIT_BITS) - 1) << 2), [ringmask] "i"(RING - 1),
+      : [base] "{s[74:75]}"(br.base), [lane4] "v"(lane4), [lutmask] "i"(((1 << LIT_BITS) - 1) << 2), [ringmask] "i"(RING - 1),
         [lutoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_lut))
-      : "s87", "s90", "s91", "scc", "memory");
+      : "s73", "s76", "s77", "scc", "memory");
   // asm results count as divergent for the compiler even in scalar registers: say otherwise (folds to plain copies)
   br.buf = ((uint64_t)uniu((uint32_t)(buf >> 32)) << 32) | uniu((uint32_t)buf);
   br.cnt = uni(cnt);
@@ -571,135 +569,135 @@ __device__ __forceinline__ uint32_t symbol_run(BitReader& br, uint32_t& pos, uin
   int cnt = br.cnt;
   uint32_t widx = br.widx;
 #define EXON_REFILL(tag)                                \
-  "  s_cmp_gt_i32 s82, 32\n"                            \
+  "  s_cmp_gt_i32 s68, 32\n"                            \
   "  s_cbranch_scc1 L_have_" tag "%=\n"                 \
   "  s_waitcnt vmcnt(0)\n"                              \
-  "  v_readlane_b32 s90, %[cur], s83\n"                 \
-  "  s_mov_b32 s91, 0\n"                                \
-  "  s_lshl_b64 s[90:91], s[90:91], s82\n"              \
-  "  s_or_b64 s[80:81], s[80:81], s[90:91]\n"           \
-  "  s_add_i32 s82, s82, 32\n"                          \
-  "  s_add_i32 s83, s83, 1\n"                           \
-  "  s_and_b32 s87, s83, 63\n"                          \
+  "  v_readlane_b32 s76, %[cur], s69\n"                 \
+  "  s_mov_b32 s77, 0\n"                                \
+  "  s_lshl_b64 s[76:77], s[76:77], s68\n"              \
+  "  s_or_b64 s[66:67], s[66:67], s[76:77]\n"           \
+  "  s_add_i32 s68, s68, 32\n"                          \
+  "  s_add_i32 s69, s69, 1\n"                           \
+  "  s_and_b32 s73, s69, 63\n"                          \
   "  s_cbranch_scc1 L_have_" tag "%=\n"                 \
-  "  v_lshl_add_u32 %[vt], s83, 2, %[lane4]\n"          \
-  "  global_load_dword %[cur], %[vt], s[88:89]\n"       \
+  "  v_lshl_add_u32 %[vt], s69, 2, %[lane4]\n"          \
+  "  global_load_dword %[cur], %[vt], s[74:75]\n"       \
   "L_have_" tag "%=:\n"
   asm volatile(
       "L_sym_loop%=:\n" EXON_REFILL("l")
-      "  v_lshlrev_b32 %[vt], 2, s80\n"
+      "  v_lshlrev_b32 %[vt], 2, s66\n"
       "  v_and_b32 %[vt], %[lutmask], %[vt]\n"
       "  ds_read_b32 %[ve], %[vt] offset:%[lutoff]\n"
       "  s_waitcnt lgkmcnt(0)\n"
-      "  v_readfirstlane_b32 s85, %[ve]\n"
-      "  s_bitcmp1_b32 s85, 8\n"
+      "  v_readfirstlane_b32 s71, %[ve]\n"
+      "  s_bitcmp1_b32 s71, 8\n"
       "  s_cbranch_scc0 L_sym_match%=\n"
-      "  s_and_b32 s87, s85, 15\n"
-      "  s_lshr_b64 s[80:81], s[80:81], s87\n"
-      "  s_sub_i32 s82, s82, s87\n"
+      "  s_and_b32 s73, s71, 15\n"
+      "  s_lshr_b64 s[66:67], s[66:67], s73\n"
+      "  s_sub_i32 s68, s68, s73\n"
       "  v_and_b32 %[vt], %[ringmask], %[vpos]\n"
       "  ds_write_b8_d16_hi %[vt], %[ve]\n"
       "  v_add_u32 %[vpos], 1, %[vpos]\n"
-      "  s_add_i32 s84, s84, 1\n"
-      "  s_and_b32 s87, s84, 0xff\n"
+      "  s_add_i32 s70, s70, 1\n"
+      "  s_and_b32 s73, s70, 0xff\n"
       "  s_cbranch_scc1 L_sym_loop%=\n"
       "  s_branch L_sym_row%=\n"
       // ---- not a literal: a length code?
       "L_sym_match%=:\n"
-      "  s_and_b32 s87, s85, 15\n"            // code length; SCC = (it is in the table)
+      "  s_and_b32 s73, s71, 15\n"            // code length; SCC = (it is in the table)
       "  s_cbranch_scc0 L_sym_exit0%=\n"
-      "  s_and_b32 s94, s85, 0x600\n"         // end of block / invalid
+      "  s_and_b32 s80, s71, 0x600\n"         // end of block / invalid
       "  s_cbranch_scc1 L_sym_exit0%=\n"
-      "  s_lshr_b64 s[80:81], s[80:81], s87\n"
-      "  s_sub_i32 s82, s82, s87\n"
-      "  s_lshr_b32 s92, s85, 16\n"           // length base
-      "  s_bfe_u32 s87, s85, 0x40004\n"       // extra bits; SCC = (any)
+      "  s_lshr_b64 s[66:67], s[66:67], s73\n"
+      "  s_sub_i32 s68, s68, s73\n"
+      "  s_lshr_b32 s78, s71, 16\n"           // length base
+      "  s_bfe_u32 s73, s71, 0x40004\n"       // extra bits; SCC = (any)
       "  s_cbranch_scc0 L_sym_len%=\n"
-      "  s_bfm_b32 s94, s87, 0\n"
-      "  s_and_b32 s94, s80, s94\n"
-      "  s_add_i32 s92, s92, s94\n"
-      "  s_lshr_b64 s[80:81], s[80:81], s87\n"
-      "  s_sub_i32 s82, s82, s87\n"
+      "  s_bfm_b32 s80, s73, 0\n"
+      "  s_and_b32 s80, s66, s80\n"
+      "  s_add_i32 s78, s78, s80\n"
+      "  s_lshr_b64 s[66:67], s[66:67], s73\n"
+      "  s_sub_i32 s68, s68, s73\n"
       "L_sym_len%=:\n" EXON_REFILL("m")
       // ---- the distance
-      "  v_lshlrev_b32 %[vt], 2, s80\n"
+      "  v_lshlrev_b32 %[vt], 2, s66\n"
       "  v_and_b32 %[vt], %[dmask], %[vt]\n"
       "  ds_read_b32 %[ve], %[vt] offset:%[dlut]\n"
       "  s_waitcnt lgkmcnt(0)\n"
-      "  v_readfirstlane_b32 s95, %[ve]\n"
-      "  s_and_b32 s87, s95, 15\n"
+      "  v_readfirstlane_b32 s81, %[ve]\n"
+      "  s_and_b32 s73, s81, 15\n"
       "  s_cbranch_scc0 L_sym_exit3%=\n"      // long or nonexistent code
-      "  s_bitcmp1_b32 s95, 10\n"
+      "  s_bitcmp1_b32 s81, 10\n"
       "  s_cbranch_scc1 L_sym_exit3%=\n"      // invalid symbol (30, 31)
-      "  s_lshr_b64 s[80:81], s[80:81], s87\n"
-      "  s_sub_i32 s82, s82, s87\n"
-      "  s_lshr_b32 s93, s95, 16\n"           // distance base
-      "  s_bfe_u32 s87, s95, 0x40004\n"       // extra bits; SCC = (any)
+      "  s_lshr_b64 s[66:67], s[66:67], s73\n"
+      "  s_sub_i32 s68, s68, s73\n"
+      "  s_lshr_b32 s79, s81, 16\n"           // distance base
+      "  s_bfe_u32 s73, s81, 0x40004\n"       // extra bits; SCC = (any)
       "  s_cbranch_scc0 L_sym_dist%=\n"
-      "  s_bfm_b32 s94, s87, 0\n"
-      "  s_and_b32 s94, s80, s94\n"
-      "  s_add_i32 s93, s93, s94\n"
-      "  s_lshr_b64 s[80:81], s[80:81], s87\n"
-      "  s_sub_i32 s82, s82, s87\n"
+      "  s_bfm_b32 s80, s73, 0\n"
+      "  s_and_b32 s80, s66, s80\n"
+      "  s_add_i32 s79, s79, s80\n"
+      "  s_lshr_b64 s[66:67], s[66:67], s73\n"
+      "  s_sub_i32 s68, s68, s73\n"
       "L_sym_dist%=:\n"
       // ---- the copies the loop does itself: d <= history, len <= 64, and either len <= d <= NEAR (ring -> ring) or
       //      d > NEAR (the source is below `drained`, i.e. in HBM already)
-      "  s_sub_i32 s87, s84, s96\n"
-      "  s_cmp_gt_u32 s93, s87\n"
+      "  s_sub_i32 s73, s70, s82\n"
+      "  s_cmp_gt_u32 s79, s73\n"
       "  s_cbranch_scc1 L_sym_exit2%=\n"
-      "  s_cmp_gt_u32 s92, 64\n"
+      "  s_cmp_gt_u32 s78, 64\n"
       "  s_cbranch_scc1 L_sym_exit2%=\n"
-      "  v_cmp_gt_u32 vcc, s92, %[lane]\n"     // lanes below len
-      "  s_sub_i32 s87, s84, s93\n"            // first source byte
-      "  s_cmp_gt_u32 s93, %[near]\n"
+      "  v_cmp_gt_u32 vcc, s78, %[lane]\n"     // lanes below len
+      "  s_sub_i32 s73, s70, s79\n"            // first source byte
+      "  s_cmp_gt_u32 s79, %[near]\n"
       "  s_cbranch_scc1 L_sym_far%=\n"
-      "  s_cmp_gt_u32 s92, s93\n"
+      "  s_cmp_gt_u32 s78, s79\n"
       "  s_cbranch_scc1 L_sym_exit2%=\n"       // overlapping run
-      "  s_and_saveexec_b64 s[90:91], vcc\n"
-      "  v_add_u32 %[vt], s87, %[lane]\n"
+      "  s_and_saveexec_b64 s[76:77], vcc\n"
+      "  v_add_u32 %[vt], s73, %[lane]\n"
       "  v_and_b32 %[vt], %[ringmask], %[vt]\n"
       "  ds_read_u8 %[ve], %[vt]\n"
-      "  v_add_u32 %[vt], s84, %[lane]\n"
+      "  v_add_u32 %[vt], s70, %[lane]\n"
       "  v_and_b32 %[vt], %[ringmask], %[vt]\n"
       "  s_waitcnt lgkmcnt(0)\n"
       "  ds_write_b8 %[vt], %[ve]\n"
-      "  s_mov_b64 exec, s[90:91]\n"
+      "  s_mov_b64 exec, s[76:77]\n"
       "  s_branch L_sym_adv%=\n"
       "L_sym_far%=:\n"
-      "  s_and_saveexec_b64 s[90:91], vcc\n"
-      "  v_add_u32 %[vt], s87, %[lane]\n"
-      "  global_load_ubyte %[ve], %[vt], s[98:99]\n"
-      "  v_add_u32 %[vt], s84, %[lane]\n"
+      "  s_and_saveexec_b64 s[76:77], vcc\n"
+      "  v_add_u32 %[vt], s73, %[lane]\n"
+      "  global_load_ubyte %[ve], %[vt], s[84:85]\n"
+      "  v_add_u32 %[vt], s70, %[lane]\n"
       "  v_and_b32 %[vt], %[ringmask], %[vt]\n"
       "  s_waitcnt vmcnt(0)\n"
       "  ds_write_b8 %[vt], %[ve]\n"
-      "  s_mov_b64 exec, s[90:91]\n"
+      "  s_mov_b64 exec, s[76:77]\n"
       "L_sym_adv%=:\n"
-      "  s_add_i32 s87, s84, s92\n"
-      "  s_xor_b32 s94, s87, s84\n"
-      "  s_mov_b32 s84, s87\n"
-      "  v_mov_b32 %[vpos], s87\n"
-      "  s_lshr_b32 s94, s94, 8\n"            // SCC = a 256-byte row boundary was crossed
+      "  s_add_i32 s73, s70, s78\n"
+      "  s_xor_b32 s80, s73, s70\n"
+      "  s_mov_b32 s70, s73\n"
+      "  v_mov_b32 %[vpos], s73\n"
+      "  s_lshr_b32 s80, s80, 8\n"            // SCC = a 256-byte row boundary was crossed
       "  s_cbranch_scc0 L_sym_loop%=\n"
       "L_sym_row%=:\n"
-      "  s_mov_b32 s86, 1\n"
+      "  s_mov_b32 s72, 1\n"
       "  s_branch L_sym_out%=\n"
       "L_sym_exit0%=:\n"
-      "  s_mov_b32 s86, 0\n"
+      "  s_mov_b32 s72, 0\n"
       "  s_branch L_sym_out%=\n"
       "L_sym_exit2%=:\n"
-      "  s_mov_b32 s86, 2\n"
+      "  s_mov_b32 s72, 2\n"
       "  s_branch L_sym_out%=\n"
       "L_sym_exit3%=:\n"
-      "  s_mov_b32 s86, 3\n"
+      "  s_mov_b32 s72, 3\n"
       "L_sym_out%=:\n"
       "  s_waitcnt vmcnt(0) lgkmcnt(0)\n"
-      : [buf] "+{s[80:81]}"(buf), [cnt] "+{s82}"(cnt), [widx] "+{s83}"(widx), [pos] "+{s84}"(pos), [e] "={s85}"(e), [why] "={s86}"(why),
-        [len] "={s92}"(len), [d] "={s93}"(d), [cur] "+v"(br.cur), [vpos] "+v"(vpos), [vt] "=&v"(vt), [ve] "=&v"(ve)
-      : [base] "{s[88:89]}"(br.base), [begin] "{s96}"(begin), [out] "{s[98:99]}"(out), [lane] "v"(lane), [lane4] "v"(lane4), [lutmask] "i"(((1 << LIT_BITS) - 1) << 2),
+      : [buf] "+{s[66:67]}"(buf), [cnt] "+{s68}"(cnt), [widx] "+{s69}"(widx), [pos] "+{s70}"(pos), [e] "={s71}"(e), [why] "={s72}"(why),
+        [len] "={s78}"(len), [d] "={s79}"(d), [cur] "+v"(br.cur), [vpos] "+v"(vpos), [vt] "=&v"(vt), [ve] "=&v"(ve)
+      : [base] "{s[74:75]}"(br.base), [begin] "{s82}"(begin), [out] "{s[84:85]}"(out), [lane] "v"(lane), [lane4] "v"(lane4), [lutmask] "i"(((1 << LIT_BITS) - 1) << 2),
         [dmask] "i"(((1 << DIST_BITS) - 1) << 2), [ringmask] "i"(RING - 1), [near] "i"(RING - 258),
         [lutoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_lut)), [dlut] "i"(RING + (int)__builtin_offsetof(WaveLds, dist_lut))
-      : "s87", "s90", "s91", "s94", "s95", "vcc", "scc", "memory");
+      : "s73", "s76", "s77", "s80", "s81", "vcc", "scc", "memory");
 #undef EXON_REFILL
   br.buf = ((uint64_t)uniu((uint32_t)(buf >> 32)) << 32) | uniu((uint32_t)buf);
   br.cnt = uni(cnt);
@@ -745,65 +743,65 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
   // fits the 64 registers that let 8 waves share a SIMD (v32-v39 are callee-saved in the AMDGPU calling convention: the
   // non-inlined decode_symbols saves them once per DEFLATE block)
 #define EXON_REFILL_BODY(tag)                           \
-  "  s_and_b32 s87, s83, 63\n"                          \
+  "  s_and_b32 s73, s69, 63\n"                          \
   "  s_cbranch_scc1 L_vwin_" tag "%=\n"                 \
   "  s_waitcnt vmcnt(0)\n"                              \
   "L_vwin_" tag "%=:\n"                                 \
-  "  v_readlane_b32 s90, %[cur], s83\n"                 \
-  "  s_mov_b32 s91, 0\n"                                \
-  "  s_add_i32 s83, s83, 1\n"                           \
-  "  v_lshlrev_b64 v[32:33], v50, s[90:91]\n"           \
+  "  v_readlane_b32 s76, %[cur], s69\n"                 \
+  "  s_mov_b32 s77, 0\n"                                \
+  "  s_add_i32 s69, s69, 1\n"                           \
+  "  v_lshlrev_b64 v[32:33], v50, s[76:77]\n"           \
   "  v_or_b32 v48, v48, v32\n"                          \
   "  v_or_b32 v49, v49, v33\n"                          \
   "  v_add_u32 v50, 32, v50\n"                          \
-  "  s_and_b32 s87, s83, 63\n"
+  "  s_and_b32 s73, s69, 63\n"
 #define EXON_REFILL_V(tag)                              \
   "  v_cmp_lt_i32 vcc, 32, v50\n"                       \
   "  s_cbranch_vccnz L_vhave_" tag "%=\n"               \
   EXON_REFILL_BODY(tag)                                 \
   "  s_cbranch_scc1 L_vhave_" tag "%=\n"                \
-  "  v_lshl_add_u32 %[vt], s83, 2, %[lane4]\n"          \
-  "  global_load_dword %[cur], %[vt], s[88:89]\n"       \
+  "  v_lshl_add_u32 %[vt], s69, 2, %[lane4]\n"          \
+  "  global_load_dword %[cur], %[vt], s[74:75]\n"       \
   "L_vhave_" tag "%=:\n"
 #define EXON_REFILL_OUT(tag)                            \
   "L_vrefill_" tag "%=:\n"                              \
   EXON_REFILL_BODY(tag)                                 \
   "  s_cbranch_scc1 L_vback_" tag "%=\n"                \
-  "  v_lshl_add_u32 %[vt], s83, 2, %[lane4]\n"          \
-  "  global_load_dword %[cur], %[vt], s[88:89]\n"       \
+  "  v_lshl_add_u32 %[vt], s69, 2, %[lane4]\n"          \
+  "  global_load_dword %[cur], %[vt], s[74:75]\n"       \
   "  s_branch L_vback_" tag "%=\n"
-// a deferred far copy lands in the ring: the lanes below its length (s101) write their byte at s100 + lane
+// a deferred far copy lands in the ring: the lanes below its length (s87) write their byte at s86 + lane
 #define EXON_FAR_COMPLETE(vx)                           \
-  "  v_cmp_gt_u32_e64 s[90:91], s101, %[lane]\n"        \
-  "  s_and_saveexec_b64 s[94:95], s[90:91]\n"           \
-  "  v_add_u32 %[vt], s100, %[lane]\n"                  \
+  "  v_cmp_gt_u32_e64 s[76:77], s87, %[lane]\n"        \
+  "  s_and_saveexec_b64 s[80:81], s[76:77]\n"           \
+  "  v_add_u32 %[vt], s86, %[lane]\n"                  \
   "  v_and_b32 %[vt], %[ringmask], %[vt]\n"             \
   "  ds_write_b8 %[vt], " vx "\n"                       \
-  "  s_mov_b64 exec, s[94:95]\n"
+  "  s_mov_b64 exec, s[80:81]\n"
 #define EXON_FAR_COMPLETE_PENDING(tag)                  \
   "  s_waitcnt vmcnt(0)\n"                              \
-  "  s_cmp_eq_u32 s97, 1\n"                             \
+  "  s_cmp_eq_u32 s83, 1\n"                             \
   "  s_cbranch_scc0 L_vcpb_" tag "%=\n"                 \
   EXON_FAR_COMPLETE("%[vfa]")                           \
   "  s_branch L_vcpd_" tag "%=\n"                       \
   "L_vcpb_" tag "%=:\n"                                 \
   EXON_FAR_COMPLETE("%[vfb]")                           \
   "L_vcpd_" tag "%=:\n"                                 \
-  "  s_mov_b32 s97, 0\n"
+  "  s_mov_b32 s83, 0\n"
 #define EXON_LOOKUP_LIT                                 \
   "  v_lshlrev_b32 %[vt], 2, v48\n"                     \
   "  v_and_b32 %[vt], %[lutmask], %[vt]\n"              \
   "  ds_read_b32 v51, %[vt] offset:%[lutoff]\n"
   asm volatile(
-      "  v_mov_b32 v48, s80\n"
-      "  v_mov_b32 v49, s81\n"
-      "  v_mov_b32 v50, s82\n"
+      "  v_mov_b32 v48, s66\n"
+      "  v_mov_b32 v49, s67\n"
+      "  v_mov_b32 v50, s68\n"
       "  v_mov_b32 v36, 1\n"
-      "  s_mov_b32 s97, 0\n"                    // far copies in flight: 0 none, 1 one in vfa, 2 one in vfb
+      "  s_mov_b32 s83, 0\n"                    // far copies in flight: 0 none, 1 one in vfa, 2 one in vfb
       EXON_REFILL_V("e")
       EXON_LOOKUP_LIT
-      "  s_and_b32 s87, s84, %[ringmask]\n"
-      "  v_mov_b32 v37, s87\n"
+      "  s_and_b32 s73, s70, %[ringmask]\n"
+      "  v_mov_b32 v37, s73\n"
       // ---- invariant at the loop head: the lookup of the current symbol is in flight into v51, v37 = pos & (RING - 1)
       "L_vsym_loop%=:\n"
       "  s_waitcnt lgkmcnt(0)\n"
@@ -814,13 +812,13 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       "  ds_write_b8_d16_hi v37, v51\n"
       EXON_LOOKUP_LIT                          // the next symbol; everything below runs under its latency
       "  v_sub_u32 v50, v50, v55\n"
-      "  s_add_i32 s84, s84, 1\n"
-      "  s_and_b32 s87, s84, %[ringmask]\n"
-      "  v_mov_b32 v37, s87\n"
+      "  s_add_i32 s70, s70, 1\n"
+      "  s_and_b32 s73, s70, %[ringmask]\n"
+      "  v_mov_b32 v37, s73\n"
       "  v_cmp_lt_i32 vcc, 32, v50\n"
       "  s_cbranch_vccz L_vrefill_l%=\n"
       "L_vback_l%=:\n"
-      "  s_and_b32 s87, s84, 0xff\n"
+      "  s_and_b32 s73, s70, 0xff\n"
       "  s_cbranch_scc1 L_vsym_loop%=\n"
       "  s_branch L_vsym_row%=\n"
       // ---- not a literal: a length code in the table (length field 1..15, neither end of block nor invalid)?
@@ -856,36 +854,36 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       "  v_add_u32 v54, v54, v35\n"            // distance
       "  v_sub_u32 v50, v50, v38\n"
       // ---- the copies the loop does itself (as in symbol_run): d <= history, len <= 64, and either len <= d <= NEAR or d > NEAR
-      "  s_sub_i32 s87, s84, s96\n"
-      "  v_cmp_lt_u32 vcc, s87, v54\n"
+      "  s_sub_i32 s73, s70, s82\n"
+      "  v_cmp_lt_u32 vcc, s73, v54\n"
       "  s_cbranch_vccnz L_vsym_exit2%=\n"
       "  v_cmp_lt_u32 vcc, 64, v53\n"
       "  s_cbranch_vccnz L_vsym_exit2%=\n"
-      "  v_readfirstlane_b32 s92, v53\n"
-      "  v_sub_u32 v39, s84, v54\n"                  // first source byte
+      "  v_readfirstlane_b32 s78, v53\n"
+      "  v_sub_u32 v39, s70, v54\n"                  // first source byte
       "  v_cmp_lt_u32 vcc, %[near], v54\n"
       "  s_cbranch_vccnz L_vsym_far%=\n"
       "  v_cmp_gt_u32 vcc, v53, v54\n"
       "  s_cbranch_vccnz L_vsym_exit2%=\n"           // overlapping run
       // near: ring -> ring.  A far copy still in flight must land first if this source reaches into its bytes
       // (source end > its first byte; it ends at or below pos, where every source starts below)
-      "  s_cmp_eq_u32 s97, 0\n"
+      "  s_cmp_eq_u32 s83, 0\n"
       "  s_cbranch_scc1 L_vsym_near%=\n"
       "  v_add_u32 v35, v39, v53\n"
-      "  v_cmp_lt_u32 vcc, s100, v35\n"
+      "  v_cmp_lt_u32 vcc, s86, v35\n"
       "  s_cbranch_vccz L_vsym_near%=\n"
       EXON_FAR_COMPLETE_PENDING("n")
       "L_vsym_near%=:\n"
-      "  v_cmp_gt_u32_e64 s[90:91], v53, %[lane]\n"  // lanes below len
-      "  s_and_saveexec_b64 s[94:95], s[90:91]\n"
+      "  v_cmp_gt_u32_e64 s[76:77], v53, %[lane]\n"  // lanes below len
+      "  s_and_saveexec_b64 s[80:81], s[76:77]\n"
       "  v_add_u32 %[vt], v39, %[lane]\n"
       "  v_and_b32 %[vt], %[ringmask], %[vt]\n"
       "  ds_read_u8 %[ve], %[vt]\n"
-      "  v_add_u32 %[vt], s84, %[lane]\n"
+      "  v_add_u32 %[vt], s70, %[lane]\n"
       "  v_and_b32 %[vt], %[ringmask], %[vt]\n"
       "  s_waitcnt lgkmcnt(0)\n"
       "  ds_write_b8 %[vt], %[ve]\n"
-      "  s_mov_b64 exec, s[94:95]\n"
+      "  s_mov_b64 exec, s[80:81]\n"
       "  s_branch L_vsym_adv%=\n"
       // far: the source is in HBM already (d > NEAR: below `drained`).  The load is ISSUED here and its bytes are put into
       // the ring later -- when the next far copy has issued its own load (two data registers take turns), when a near copy
@@ -895,74 +893,74 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
 #ifdef EXON_INFLATE_FAR_NOWAIT  // timing experiment only (wrong bytes): what the loop would cost if far copies were free
       "  s_branch L_vsym_adv%=\n"
 #endif
-      "  v_cmp_gt_u32_e64 s[90:91], v53, %[lane]\n"
-      "  s_and_saveexec_b64 s[94:95], s[90:91]\n"
+      "  v_cmp_gt_u32_e64 s[76:77], v53, %[lane]\n"
+      "  s_and_saveexec_b64 s[80:81], s[76:77]\n"
       "  v_add_u32 %[vt], v39, %[lane]\n"
-      "  s_cmp_eq_u32 s97, 1\n"
+      "  s_cmp_eq_u32 s83, 1\n"
       "  s_cbranch_scc1 L_vsym_far_b%=\n"
-      "  global_load_ubyte %[vfa], %[vt], s[98:99]\n"
-      "  s_mov_b64 exec, s[94:95]\n"
-      "  s_cmp_eq_u32 s97, 0\n"
+      "  global_load_ubyte %[vfa], %[vt], s[84:85]\n"
+      "  s_mov_b64 exec, s[80:81]\n"
+      "  s_cmp_eq_u32 s83, 0\n"
       "  s_cbranch_scc1 L_vsym_far_a1%=\n"
       "  s_waitcnt vmcnt(1)\n"                       // the older one (in vfb) has landed; loads return in order
       EXON_FAR_COMPLETE("%[vfb]")
       "L_vsym_far_a1%=:\n"
-      "  s_mov_b32 s97, 1\n"
+      "  s_mov_b32 s83, 1\n"
       "  s_branch L_vsym_far_rec%=\n"
       "L_vsym_far_b%=:\n"
-      "  global_load_ubyte %[vfb], %[vt], s[98:99]\n"
-      "  s_mov_b64 exec, s[94:95]\n"
+      "  global_load_ubyte %[vfb], %[vt], s[84:85]\n"
+      "  s_mov_b64 exec, s[80:81]\n"
       "  s_waitcnt vmcnt(1)\n"
       EXON_FAR_COMPLETE("%[vfa]")
-      "  s_mov_b32 s97, 2\n"
+      "  s_mov_b32 s83, 2\n"
       "L_vsym_far_rec%=:\n"
-      "  s_mov_b32 s100, s84\n"
-      "  s_mov_b32 s101, s92\n"
+      "  s_mov_b32 s86, s70\n"
+      "  s_mov_b32 s87, s78\n"
       "L_vsym_adv%=:\n"
-      "  s_add_i32 s87, s84, s92\n"
-      "  s_xor_b32 s94, s87, s84\n"
-      "  s_mov_b32 s84, s87\n"
-      "  s_and_b32 s87, s87, %[ringmask]\n"
-      "  v_mov_b32 v37, s87\n"
+      "  s_add_i32 s73, s70, s78\n"
+      "  s_xor_b32 s80, s73, s70\n"
+      "  s_mov_b32 s70, s73\n"
+      "  s_and_b32 s73, s73, %[ringmask]\n"
+      "  v_mov_b32 v37, s73\n"
       "  v_cmp_lt_i32 vcc, 32, v50\n"
       "  s_cbranch_vccz L_vrefill_a%=\n"
       "L_vback_a%=:\n"
-      "  s_lshr_b32 s94, s94, 8\n"             // SCC = a 256-byte row boundary was crossed
+      "  s_lshr_b32 s80, s80, 8\n"             // SCC = a 256-byte row boundary was crossed
       "  s_cbranch_scc0 L_vsym_loop%=\n"
       "L_vsym_row%=:\n"
-      "  s_mov_b32 s86, 1\n"
+      "  s_mov_b32 s72, 1\n"
       "  s_branch L_vsym_out%=\n"
       EXON_REFILL_OUT("l")
       EXON_REFILL_OUT("a")
       "L_vsym_exit0%=:\n"
-      "  s_mov_b32 s86, 0\n"
+      "  s_mov_b32 s72, 0\n"
       "  s_branch L_vsym_out%=\n"
       "L_vsym_exit2%=:\n"
-      "  s_mov_b32 s86, 2\n"
+      "  s_mov_b32 s72, 2\n"
       "  s_branch L_vsym_out%=\n"
       "L_vsym_exit3%=:\n"
-      "  s_mov_b32 s86, 3\n"
+      "  s_mov_b32 s72, 3\n"
       "L_vsym_out%=:\n"
-      "  s_cmp_eq_u32 s97, 0\n"
+      "  s_cmp_eq_u32 s83, 0\n"
       "  s_cbranch_scc1 L_vsym_fin%=\n"
       EXON_FAR_COMPLETE_PENDING("x")
       "L_vsym_fin%=:\n"
       "  s_nop 0\n"
-      "  v_readfirstlane_b32 s80, v48\n"
-      "  v_readfirstlane_b32 s81, v49\n"
-      "  v_readfirstlane_b32 s82, v50\n"
-      "  v_readfirstlane_b32 s85, v51\n"
-      "  v_readfirstlane_b32 s92, v53\n"
-      "  v_readfirstlane_b32 s93, v54\n"
-      "  v_mov_b32 %[vpos], s84\n"
+      "  v_readfirstlane_b32 s66, v48\n"
+      "  v_readfirstlane_b32 s67, v49\n"
+      "  v_readfirstlane_b32 s68, v50\n"
+      "  v_readfirstlane_b32 s71, v51\n"
+      "  v_readfirstlane_b32 s78, v53\n"
+      "  v_readfirstlane_b32 s79, v54\n"
+      "  v_mov_b32 %[vpos], s70\n"
       "  s_waitcnt vmcnt(0) lgkmcnt(0)\n"
-      "  s_nop 1\n"  // the compiler does not know a VALU instruction wrote s80-s93: keep its next VALU read two states away
-      : [buf] "+{s[80:81]}"(buf), [cnt] "+{s82}"(cnt), [widx] "+{s83}"(widx), [pos] "+{s84}"(pos), [e] "={s85}"(e), [why] "={s86}"(why),
-        [len] "={s92}"(len), [d] "={s93}"(d), [cur] "+v"(br.cur), [vpos] "+v"(vpos), [vt] "=&v"(vt), [ve] "=&v"(ve), [vfa] "=&v"(vfa), [vfb] "=&v"(vfb)
-      : [base] "{s[88:89]}"(br.base), [begin] "{s96}"(begin), [out] "{s[98:99]}"(out), [lane] "v"(lane), [lane4] "v"(lane4), [lutmask] "i"(((1 << LIT_BITS) - 1) << 2),
+      "  s_nop 1\n"  // the compiler does not know a VALU instruction wrote s66-s79: keep its next VALU read two states away
+      : [buf] "+{s[66:67]}"(buf), [cnt] "+{s68}"(cnt), [widx] "+{s69}"(widx), [pos] "+{s70}"(pos), [e] "={s71}"(e), [why] "={s72}"(why),
+        [len] "={s78}"(len), [d] "={s79}"(d), [cur] "+v"(br.cur), [vpos] "+v"(vpos), [vt] "=&v"(vt), [ve] "=&v"(ve), [vfa] "=&v"(vfa), [vfb] "=&v"(vfb)
+      : [base] "{s[74:75]}"(br.base), [begin] "{s82}"(begin), [out] "{s[84:85]}"(out), [lane] "v"(lane), [lane4] "v"(lane4), [lutmask] "i"(((1 << LIT_BITS) - 1) << 2),
         [dmask] "i"(((1 << DIST_BITS) - 1) << 2), [ringmask] "i"(RING - 1), [near] "i"(RING - 258),
         [lutoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_lut)), [dlut] "i"(RING + (int)__builtin_offsetof(WaveLds, dist_lut))
-      : "s87", "s90", "s91", "s94", "s95", "s97", "s100", "s101", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",
+      : "s73", "s76", "s77", "s80", "s81", "s83", "s86", "s87", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",
         "vcc", "scc", "memory");
 #undef EXON_REFILL_V
 #undef EXON_REFILL_OUT
@@ -1830,7 +1828,7 @@ __device__ __forceinline__ int flavor_of(int flavor) { return flavor == 2 ? (int
 #define EXON_INFLATE_WPE_ATTR
 #endif
 template <int RING>
-__global__ __launch_bounds__(64 * INF_WAVES) EXON_INFLATE_WPE_ATTR void k_inflate(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks, int n_blocks,
+__global__ __launch_bounds__(64 * INF_WAVES) EXON_INFLATE_WPE_ATTR __attribute__((amdgpu_num_sgpr(88))) void k_inflate(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks, int n_blocks,
                                                 uint8_t* out, int* __restrict__ status, int flavor) {
   const int b = uni((int)(blockIdx.x * INF_WAVES + (threadIdx.x >> 6)));
   if (b >= n_blocks) return;
