@@ -52,10 +52,15 @@ constexpr int WAVES_PER_WG = 4;     // k_crc32
 #define EXON_INFLATE_LIT 2  // symbol loop: 0 = the compiler's (readable reference), 1 = literal_run, 2 = symbol_run
 #endif
 constexpr int INFLATE_RING = EXON_INFLATE_RING;  // bytes of recent output kept in LDS per wavefront (k_inflate_par: also its window)
+// The serial kernel's ring is 1 KiB since round 4: 1024 + 3840 bytes of LDS per member are under the 5120-byte tier that lets a
+// CU hold 32 workgroups (tools/occupancy_probe.hip), so the kernel's 94 SGPRs / 70 VGPRs decide: 28 members per CU instead of 25.
+// A launch of 7168 members takes 4.75 ms where 6144 took 4.28 (+5 % throughput); the far copies the smaller ring adds are
+// deferred ones.  With 6720-member slabs: .vcf.gz 58.6 -> 56.3 ms, BAM 63.9 -> 61.6, .fastq.gz 128 -> 121 on one box
+// (profiles/r4_pipes_ring1k_slab.log).  -DEXON_INFLATE_RING_SERIAL=2048 restores the old ring.
 #ifndef EXON_INFLATE_RING_SERIAL
-#define EXON_INFLATE_RING_SERIAL EXON_INFLATE_RING
+#define EXON_INFLATE_RING_SERIAL 1024
 #endif
-constexpr int INFLATE_RING_SERIAL = EXON_INFLATE_RING_SERIAL;  // the same for k_inflate (A/B builds: a smaller ring = more waves per CU)
+constexpr int INFLATE_RING_SERIAL = EXON_INFLATE_RING_SERIAL;
 
 enum : int {
   INF_OK = 0,

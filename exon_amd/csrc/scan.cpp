@@ -452,7 +452,9 @@ struct SlabReader {
 };
 
 static size_t slab_bytes() {
-  size_t slab = 64u << 20;
+  // 70 MB = 6720 BGZF members per slab: 26 of the 28 members a CU holds of the inflate kernel, the rest of the wave slots left to
+  // the parse kernels of the previous slab (72 MB: the same or worse, 74 MB: worse on every format; profiles/r4_pipes_ring1k_slab.log)
+  size_t slab = 70u << 20;
   if (const char* v = getenv("EXON_HIP_GPU_PARSE_SLAB_MB")) {
     const long mb = atol(v);
     if (mb >= 1 && mb <= 1024) slab = (size_t)mb << 20;
