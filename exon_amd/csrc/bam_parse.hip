@@ -177,11 +177,6 @@ int exon_hip_bam_parser_parse(exon_hip_bam_parser* p, void* stream, const uint8_
   if (n_bytes == 0) return EXON_HIP_OK;
   hipStream_t s = pick_stream(ctx, stream);
   const uint32_t n = (uint32_t)n_bytes, n_seg = (n + SEG - 1) / SEG;
-  // the proof kernel keeps 16 bytes per segment in LDS: checked BEFORE anything is launched
-  if ((size_t)n_seg * 16 > 152 * 1024) return fail(ctx, EXON_HIP_EINVAL, "slab of %u segments is too large for the chain proof", n_seg);
-  static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(chain::k_chain_check<0>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-  if (lds_ok != hipSuccess) return fail(ctx, EXON_HIP_EDEVICE, "hipFuncSetAttribute(k_chain_check): %s", hipGetErrorString(lds_ok));
   // rows of this slab <= n / 36: the validity words they can touch are cleared by k_chain_check, the scalars by k_chain_walk
   chain::ZeroList zl{};
   zl.p[0] = p->out.mapq_valid;
@@ -191,7 +186,7 @@ int exon_hip_bam_parser_parse(exon_hip_bam_parser* p, void* stream, const uint8_
   zl.words = (uint32_t)(((size_t)n / 36 + 1 + 31) / 32 + 1);
   hipLaunchKernelGGL(chain::k_chain_walk<BamFormat>, dim3(n_seg), dim3(64), 0, s, d_data, n, BamFormat{p->n_ref}, p->d_seg, p->d_rec_off,
                      p->d_scalars);
-  hipLaunchKernelGGL(chain::k_chain_check<0>, dim3(1), dim3(1024), (size_t)n_seg * 16, s, p->d_seg, n_seg, p->d_base, p->d_scalars, zl);
+  hipLaunchKernelGGL(chain::k_chain_check<0>, dim3(1), dim3(1024), 0, s, p->d_seg, n_seg, p->d_base, p->d_scalars, zl);
   hipLaunchKernelGGL(k_bam_extract, dim3(n_seg), dim3(256), 0, s, d_data, p->d_seg, p->d_base, p->d_rec_off, p->out, p->d_scalars);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(p->h_scalars, p->d_scalars, 12, hipMemcpyDeviceToHost, s));

@@ -474,11 +474,6 @@ int exon_hip_bcf_parser_parse(exon_hip_bcf_parser* p, void* stream, const uint8_
   if (n_bytes == 0) return EXON_HIP_OK;
   hipStream_t s = pick_stream(ctx, stream);
   const uint32_t n = (uint32_t)n_bytes, n_seg = (n + SEG - 1) / SEG;
-  // the proof kernel keeps 16 bytes per segment in LDS: checked BEFORE anything is launched
-  if ((size_t)n_seg * 16 > 152 * 1024) return fail(ctx, EXON_HIP_EINVAL, "slab of %u segments is too large for the chain proof", n_seg);
-  static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(chain::k_chain_check<0>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-  if (lds_ok != hipSuccess) return fail(ctx, EXON_HIP_EDEVICE, "hipFuncSetAttribute(k_chain_check): %s", hipGetErrorString(lds_ok));
   // rows of this slab <= n / 32: the validity words they can touch are cleared by k_chain_check, the scalars by k_chain_walk
   chain::ZeroList zl{};
   zl.p[zl.n++] = p->out.qual_valid;
@@ -487,7 +482,7 @@ int exon_hip_bcf_parser_parse(exon_hip_bcf_parser* p, void* stream, const uint8_
   zl.words = (uint32_t)(((size_t)n / 32 + 1 + 31) / 32 + 1);
   hipLaunchKernelGGL(chain::k_chain_walk<BcfFormat>, dim3(n_seg), dim3(64), 0, s, d_data, n, BcfFormat{p->n_contigs, p->n_samples}, p->d_seg,
                      p->d_rec_off, p->d_scalars);
-  hipLaunchKernelGGL(chain::k_chain_check<0>, dim3(1), dim3(1024), (size_t)n_seg * 16, s, p->d_seg, n_seg, p->d_base, p->d_scalars, zl);
+  hipLaunchKernelGGL(chain::k_chain_check<0>, dim3(1), dim3(1024), 0, s, p->d_seg, n_seg, p->d_base, p->d_scalars, zl);
   hipLaunchKernelGGL(k_bcf_extract, dim3(n_seg), dim3(256), 0, s, d_data, p->d_seg, p->d_base, p->d_rec_off, p->out, p->filters,
                      p->n_contigs, p->n_strings, p->ik, p->d_scalars);
   hipLaunchKernelGGL(k_bcf_assign, dim3(1), dim3(256), 0, s, p->filters);

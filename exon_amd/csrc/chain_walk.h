@@ -91,39 +91,35 @@ struct ZeroList {
 };
 
 // scalars: [0] rows, [1] undecided, [2] consumed bytes.
-// The proof is a walk over the segments in order (one thread, the per-segment results cached in LDS as 16-byte entries:
-// one ds_read_b128 per step, the next segment's entry already in flight -- the chain nearly always advances by one
-// segment): the chain that enters segment s at `expected` must find start(s) == expected; a record longer than a
-// segment makes the chain skip whole segments, which are then ignored (whatever their guess was); the segment whose chain
-// met the cut-off record ends the slab.  Dynamic LDS: 4 * n_seg words.
+// The proof: the chain that enters segment s at `expected` must find start(s) == expected; a record longer than a segment makes
+// the chain skip whole segments, which are then ignored (whatever their guess was); the segment whose chain met the cut-off
+// record ends the slab.
+//   * The common slab needs no walk: every segment's chain lands on the guessed start of the NEXT segment (no record spans a
+//     whole segment, nothing malformed, only the last segment may meet the cut-off record) -- one comparison per segment, all at
+//     once, straight from the segment records in HBM.
+//   * Otherwise one thread walks the segments in order, eight records in flight (the chain nearly always advances by one segment,
+//     so the loads do not depend on the walk) and marks the segments it jumped over.
+// No dynamic LDS (round 4): until then the kernel staged 16 bytes per segment in LDS -- 107 KB for a 6720-segment slab -- and its
+// one workgroup could not start on any CU before enough inflate waves of the next slab had drained there: the "1.3-1.9 ms" rocprofv3
+// showed for it in the BAM pipeline were that wait, a quarter of the parse stream.
 template <int UNUSED = 0>  // a template only so that several translation units may include this header
 __global__ __launch_bounds__(1024) void k_chain_check(SegInfo* __restrict__ seg, uint32_t n_seg, uint32_t* __restrict__ base,
                                                       unsigned* __restrict__ scalars, const ZeroList zl) {
-  extern __shared__ uint4 chain_lds[];  // {start, landing, bad, count}; start = NONE marks a segment that turned out inactive
   __shared__ unsigned part[1024];
-  __shared__ unsigned s_last, s_err;
-  for (uint32_t s = threadIdx.x; s < n_seg; s += 1024) {
-    const SegInfo a = seg[s];
-    chain_lds[s] = uint4{a.start, a.landing, a.bad, a.count};
-  }
+  __shared__ unsigned s_last, s_err, s_plain;
+  if (threadIdx.x == 0) s_plain = 1;
   for (int b = 0; b < zl.n; ++b)
     for (uint32_t i = threadIdx.x; i < zl.words; i += 1024) zl.p[b][i] = 0;
   __syncthreads();
-  // The common slab needs no walk: every segment's chain lands on the guessed start of the NEXT segment (no record spans a
-  // whole segment, nothing malformed, only the last segment may meet the cut-off record).  That is one comparison per segment,
-  // all at once; the serial proof below (6144 dependent steps of one thread: 1.3 ms per 400 MB slab, a quarter of the BAM
-  // pipeline's parse stream) only runs when it fails.
-  __shared__ unsigned s_plain;
-  if (threadIdx.x == 0) s_plain = 1;
-  __syncthreads();
+  const uint4* seg4 = reinterpret_cast<const uint4*>(seg);  // {start, landing, count, bad}
   {
     bool ok = true;
     for (uint32_t s = threadIdx.x; s < n_seg; s += 1024) {
-      const uint4 cur = chain_lds[s];
+      const uint4 cur = seg4[s];
       if (s == 0 && cur.x != 0) ok = false;
       if (s + 1 < n_seg) {
-        if (cur.z != 0 || cur.x == NONE || chain_lds[s + 1].x != cur.y) ok = false;
-      } else if (cur.z == 1 || cur.x == NONE) {
+        if (cur.w != 0 || cur.x == NONE || seg[s + 1].start != cur.y) ok = false;
+      } else if (cur.w == 1 || cur.x == NONE) {
         ok = false;
       }
     }
@@ -140,22 +136,29 @@ __global__ __launch_bounds__(1024) void k_chain_check(SegInfo* __restrict__ seg,
   if (threadIdx.x == 0 && !s_plain) {
     unsigned err = 0;
     uint32_t expected = 0, last = n_seg - 1;
-    uint4 nxt = chain_lds[0];
-    for (uint32_t s = 0; s < n_seg; ++s) {
-      const uint4 cur = nxt;
-      if (s + 1 < n_seg) nxt = chain_lds[s + 1];
-      const uint32_t hi = (s + 1) * SEG;  // the last segment is shorter, but no chain position lies beyond the slab
-      if (expected >= hi) {               // covered by a record that started earlier
-        chain_lds[s].x = NONE;
-        continue;
+    bool done = false;
+    for (uint32_t s0 = 0; s0 < n_seg && !done; s0 += 8) {
+      uint4 e[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) e[k] = s0 + k < n_seg ? seg4[s0 + k] : uint4{0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t s = s0 + k;
+        if (done || s >= n_seg) break;
+        const uint32_t hi = (s + 1) * SEG;  // the last segment is shorter, but no chain position lies beyond the slab
+        if (expected >= hi) {               // covered by a record that started earlier: not part of the chain
+          seg[s].count = 0;
+          continue;
+        }
+        if (e[k].x != expected || e[k].w == 1) {
+          err = 1;
+          done = true;
+          break;
+        }
+        expected = e[k].y;
+        last = s;
+        if (e[k].w == 2) done = true;  // the cut-off record: everything behind it is its bytes
       }
-      if (cur.x != expected || cur.z == 1) {
-        err = 1;
-        break;
-      }
-      expected = cur.y;
-      last = s;
-      if (cur.z == 2) break;  // the cut-off record: everything behind it is its bytes
     }
     s_last = last;
     s_err = err;
@@ -166,12 +169,8 @@ __global__ __launch_bounds__(1024) void k_chain_check(SegInfo* __restrict__ seg,
   const uint32_t s0 = threadIdx.x * per, s1 = min(n_seg, s0 + per);
   unsigned sum = 0;
   for (uint32_t s = s0; s < s1; ++s) {
-    if (s > last || chain_lds[s].x == NONE) {
-      seg[s].count = 0;
-      chain_lds[s].w = 0;
-    } else {
-      sum += chain_lds[s].w;
-    }
+    if (s > last) seg[s].count = 0;
+    else sum += seg[s].count;
   }
   part[threadIdx.x] = sum;
   __syncthreads();
@@ -184,12 +183,10 @@ __global__ __launch_bounds__(1024) void k_chain_check(SegInfo* __restrict__ seg,
   unsigned run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
   for (uint32_t s = s0; s < s1; ++s) {
     base[s] = run;
-    run += chain_lds[s].w;
+    run += seg[s].count;
   }
-  if (threadIdx.x == 1023) {
-    scalars[0] = part[1023];
-    scalars[2] = chain_lds[last].y;
-  }
+  if (threadIdx.x == 1023) scalars[0] = part[1023];
+  if (threadIdx.x == 0) scalars[2] = seg[last].landing;
   __syncthreads();
   if (threadIdx.x == 0 && s_err) atomicAdd(&scalars[1], 1u);
 }
