@@ -53,10 +53,10 @@ constexpr int WAVES_PER_WG = 4;     // k_crc32
 #endif
 constexpr int INFLATE_RING = EXON_INFLATE_RING;  // bytes of recent output kept in LDS per wavefront (k_inflate_par: also its window)
 // The serial kernel's ring is 1 KiB since round 4: 1024 + 3840 bytes of LDS per member are under the 5120-byte tier that lets a
-// CU hold 32 workgroups (tools/occupancy_probe.hip), so the kernel's 94 SGPRs / 70 VGPRs decide: 28 members per CU instead of 25.
-// A launch of 7168 members takes 4.75 ms where 6144 took 4.28 (+5 % throughput); the far copies the smaller ring adds are
-// deferred ones.  With 6720-member slabs: .vcf.gz 58.6 -> 56.3 ms, BAM 63.9 -> 61.6, .fastq.gz 128 -> 121 on one box
-// (profiles/r4_pipes_ring1k_slab.log).  -DEXON_INFLATE_RING_SERIAL=2048 restores the old ring.
+// CU hold 32 workgroups (tools/occupancy_probe.hip); with the kernel at 64 VGPRs (__launch_bounds__(64, 8)) and 78 SGPRs (pinned
+// registers s50-s71, amdgpu_num_sgpr(72)) a CU holds 32 members instead of 24.  One launch: 6144 members 4.3 ms, 7168 4.77,
+// 8192 5.26 (+9.5 % throughput); the far copies the smaller ring adds are deferred ones.  With 7680-member slabs: .vcf.gz
+// 58.6 -> 56 ms, BAM 63.9 -> 61, .fastq.gz 128 -> 119 on one box.  -DEXON_INFLATE_RING_SERIAL=2048 restores the old ring.
 #ifndef EXON_INFLATE_RING_SERIAL
 #define EXON_INFLATE_RING_SERIAL 1024
 #endif
@@ -508,47 +508,47 @@ __device__ __forceinline__ uint32_t literal_run(BitReader& br, uint32_t& pos, ui
   uint32_t widx = br.widx;
   asm volatile(
       "L_lit_loop%=:\n"
-      "  s_cmp_gt_i32 s68, 32\n"
+      "  s_cmp_gt_i32 s52, 32\n"
       "  s_cbranch_scc1 L_lit_have%=\n"
       "  s_waitcnt vmcnt(0)\n"
-      "  v_readlane_b32 s76, %[cur], s69\n"
-      "  s_mov_b32 s77, 0\n"
-      "  s_lshl_b64 s[76:77], s[76:77], s68\n"
-      "  s_or_b64 s[66:67], s[66:67], s[76:77]\n"
-      "  s_add_i32 s68, s68, 32\n"
-      "  s_add_i32 s69, s69, 1\n"
-      "  s_and_b32 s73, s69, 63\n"
+      "  v_readlane_b32 s60, %[cur], s53\n"
+      "  s_mov_b32 s61, 0\n"
+      "  s_lshl_b64 s[60:61], s[60:61], s52\n"
+      "  s_or_b64 s[50:51], s[50:51], s[60:61]\n"
+      "  s_add_i32 s52, s52, 32\n"
+      "  s_add_i32 s53, s53, 1\n"
+      "  s_and_b32 s57, s53, 63\n"
       "  s_cbranch_scc1 L_lit_have%=\n"
-      "  v_lshl_add_u32 %[vt], s69, 2, %[lane4]\n"
-      "  global_load_dword %[cur], %[vt], s[74:75]\n"
+      "  v_lshl_add_u32 %[vt], s53, 2, %[lane4]\n"
+      "  global_load_dword %[cur], %[vt], s[58:59]\n"
       "L_lit_have%=:\n"
-      "  v_lshlrev_b32 %[vt], 2, s66\n"
+      "  v_lshlrev_b32 %[vt], 2, s50\n"
       "  v_and_b32 %[vt], %[lutmask], %[vt]\n"
       "  ds_read_b32 %[ve], %[vt] offset:%[lutoff]\n"
       "  s_waitcnt lgkmcnt(0)\n"
-      "  v_readfirstlane_b32 s71, %[ve]\n"
-      "  s_bitcmp1_b32 s71, 8\n"
+      "  v_readfirstlane_b32 s55, %[ve]\n"
+      "  s_bitcmp1_b32 s55, 8\n"
       "  s_cbranch_scc0 L_lit_other%=\n"
-      "  s_and_b32 s73, s71, 15\n"
-      "  s_lshr_b64 s[66:67], s[66:67], s73\n"
-      "  s_sub_i32 s68, s68, s73\n"
+      "  s_and_b32 s57, s55, 15\n"
+      "  s_lshr_b64 s[50:51], s[50:51], s57\n"
+      "  s_sub_i32 s52, s52, s57\n"
       "  v_and_b32 %[vt], %[ringmask], %[vpos]\n"
       "  ds_write_b8_d16_hi %[vt], %[ve]\n"
       "  v_add_u32 %[vpos], 1, %[vpos]\n"
-      "  s_add_i32 s70, s70, 1\n"
-      "  s_and_b32 s73, s70, 0xff\n"
+      "  s_add_i32 s54, s54, 1\n"
+      "  s_and_b32 s57, s54, 0xff\n"
       "  s_cbranch_scc1 L_lit_loop%=\n"
-      "  s_mov_b32 s72, 1\n"
+      "  s_mov_b32 s56, 1\n"
       "  s_branch L_lit_out%=\n"
       "L_lit_other%=:\n"
-      "  s_mov_b32 s72, 0\n"
+      "  s_mov_b32 s56, 0\n"
       "L_lit_out%=:\n"
       "  s_waitcnt vmcnt(0) lgkmcnt(0)\n"
-      : [buf] "+{s[66:67]}"(buf), [cnt] "+{s68}"(cnt), [widx] "+{s69}"(widx), [pos] "+{s70}"(pos), [e] "={s71}"(e), [why] "={s72}"(why),
+      : [buf] "+{s[50:51]}"(buf), [cnt] "+{s52}"(cnt), [widx] "+{s53}"(widx), [pos] "+{s54}"(pos), [e] "={s55}"(e), [why] "={s56}"(why),
         [cur] "+v"(br.cur), [vpos] "+v"(vpos), [vt] "=&v"(vt), [ve] "=&v"(ve)
-      : [base] "{s[74:75]}"(br.base), [lane4] "v"(lane4), [lutmask] "i"(((1 << LIT_BITS) - 1) << 2), [ringmask] "i"(RING - 1),
+      : [base] "{s[58:59]}"(br.base), [lane4] "v"(lane4), [lutmask] "i"(((1 << LIT_BITS) - 1) << 2), [ringmask] "i"(RING - 1),
         [lutoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_lut))
-      : "s73", "s76", "s77", "scc", "memory");
+      : "s57", "s60", "s61", "scc", "memory");
   // asm results count as divergent for the compiler even in scalar registers: say otherwise (folds to plain copies)
   br.buf = ((uint64_t)uniu((uint32_t)(buf >> 32)) << 32) | uniu((uint32_t)buf);
   br.cnt = uni(cnt);
@@ -574,135 +574,135 @@ __device__ __forceinline__ uint32_t symbol_run(BitReader& br, uint32_t& pos, uin
   int cnt = br.cnt;
   uint32_t widx = br.widx;
 #define EXON_REFILL(tag)                                \
-  "  s_cmp_gt_i32 s68, 32\n"                            \
+  "  s_cmp_gt_i32 s52, 32\n"                            \
   "  s_cbranch_scc1 L_have_" tag "%=\n"                 \
   "  s_waitcnt vmcnt(0)\n"                              \
-  "  v_readlane_b32 s76, %[cur], s69\n"                 \
-  "  s_mov_b32 s77, 0\n"                                \
-  "  s_lshl_b64 s[76:77], s[76:77], s68\n"              \
-  "  s_or_b64 s[66:67], s[66:67], s[76:77]\n"           \
-  "  s_add_i32 s68, s68, 32\n"                          \
-  "  s_add_i32 s69, s69, 1\n"                           \
-  "  s_and_b32 s73, s69, 63\n"                          \
+  "  v_readlane_b32 s60, %[cur], s53\n"                 \
+  "  s_mov_b32 s61, 0\n"                                \
+  "  s_lshl_b64 s[60:61], s[60:61], s52\n"              \
+  "  s_or_b64 s[50:51], s[50:51], s[60:61]\n"           \
+  "  s_add_i32 s52, s52, 32\n"                          \
+  "  s_add_i32 s53, s53, 1\n"                           \
+  "  s_and_b32 s57, s53, 63\n"                          \
   "  s_cbranch_scc1 L_have_" tag "%=\n"                 \
-  "  v_lshl_add_u32 %[vt], s69, 2, %[lane4]\n"          \
-  "  global_load_dword %[cur], %[vt], s[74:75]\n"       \
+  "  v_lshl_add_u32 %[vt], s53, 2, %[lane4]\n"          \
+  "  global_load_dword %[cur], %[vt], s[58:59]\n"       \
   "L_have_" tag "%=:\n"
   asm volatile(
       "L_sym_loop%=:\n" EXON_REFILL("l")
-      "  v_lshlrev_b32 %[vt], 2, s66\n"
+      "  v_lshlrev_b32 %[vt], 2, s50\n"
       "  v_and_b32 %[vt], %[lutmask], %[vt]\n"
       "  ds_read_b32 %[ve], %[vt] offset:%[lutoff]\n"
       "  s_waitcnt lgkmcnt(0)\n"
-      "  v_readfirstlane_b32 s71, %[ve]\n"
-      "  s_bitcmp1_b32 s71, 8\n"
+      "  v_readfirstlane_b32 s55, %[ve]\n"
+      "  s_bitcmp1_b32 s55, 8\n"
       "  s_cbranch_scc0 L_sym_match%=\n"
-      "  s_and_b32 s73, s71, 15\n"
-      "  s_lshr_b64 s[66:67], s[66:67], s73\n"
-      "  s_sub_i32 s68, s68, s73\n"
+      "  s_and_b32 s57, s55, 15\n"
+      "  s_lshr_b64 s[50:51], s[50:51], s57\n"
+      "  s_sub_i32 s52, s52, s57\n"
       "  v_and_b32 %[vt], %[ringmask], %[vpos]\n"
       "  ds_write_b8_d16_hi %[vt], %[ve]\n"
       "  v_add_u32 %[vpos], 1, %[vpos]\n"
-      "  s_add_i32 s70, s70, 1\n"
-      "  s_and_b32 s73, s70, 0xff\n"
+      "  s_add_i32 s54, s54, 1\n"
+      "  s_and_b32 s57, s54, 0xff\n"
       "  s_cbranch_scc1 L_sym_loop%=\n"
       "  s_branch L_sym_row%=\n"
       // ---- not a literal: a length code?
       "L_sym_match%=:\n"
-      "  s_and_b32 s73, s71, 15\n"            // code length; SCC = (it is in the table)
+      "  s_and_b32 s57, s55, 15\n"            // code length; SCC = (it is in the table)
       "  s_cbranch_scc0 L_sym_exit0%=\n"
-      "  s_and_b32 s80, s71, 0x600\n"         // end of block / invalid
+      "  s_and_b32 s64, s55, 0x600\n"         // end of block / invalid
       "  s_cbranch_scc1 L_sym_exit0%=\n"
-      "  s_lshr_b64 s[66:67], s[66:67], s73\n"
-      "  s_sub_i32 s68, s68, s73\n"
-      "  s_lshr_b32 s78, s71, 16\n"           // length base
-      "  s_bfe_u32 s73, s71, 0x40004\n"       // extra bits; SCC = (any)
+      "  s_lshr_b64 s[50:51], s[50:51], s57\n"
+      "  s_sub_i32 s52, s52, s57\n"
+      "  s_lshr_b32 s62, s55, 16\n"           // length base
+      "  s_bfe_u32 s57, s55, 0x40004\n"       // extra bits; SCC = (any)
       "  s_cbranch_scc0 L_sym_len%=\n"
-      "  s_bfm_b32 s80, s73, 0\n"
-      "  s_and_b32 s80, s66, s80\n"
-      "  s_add_i32 s78, s78, s80\n"
-      "  s_lshr_b64 s[66:67], s[66:67], s73\n"
-      "  s_sub_i32 s68, s68, s73\n"
+      "  s_bfm_b32 s64, s57, 0\n"
+      "  s_and_b32 s64, s50, s64\n"
+      "  s_add_i32 s62, s62, s64\n"
+      "  s_lshr_b64 s[50:51], s[50:51], s57\n"
+      "  s_sub_i32 s52, s52, s57\n"
       "L_sym_len%=:\n" EXON_REFILL("m")
       // ---- the distance
-      "  v_lshlrev_b32 %[vt], 2, s66\n"
+      "  v_lshlrev_b32 %[vt], 2, s50\n"
       "  v_and_b32 %[vt], %[dmask], %[vt]\n"
       "  ds_read_b32 %[ve], %[vt] offset:%[dlut]\n"
       "  s_waitcnt lgkmcnt(0)\n"
-      "  v_readfirstlane_b32 s81, %[ve]\n"
-      "  s_and_b32 s73, s81, 15\n"
+      "  v_readfirstlane_b32 s65, %[ve]\n"
+      "  s_and_b32 s57, s65, 15\n"
       "  s_cbranch_scc0 L_sym_exit3%=\n"      // long or nonexistent code
-      "  s_bitcmp1_b32 s81, 10\n"
+      "  s_bitcmp1_b32 s65, 10\n"
       "  s_cbranch_scc1 L_sym_exit3%=\n"      // invalid symbol (30, 31)
-      "  s_lshr_b64 s[66:67], s[66:67], s73\n"
-      "  s_sub_i32 s68, s68, s73\n"
-      "  s_lshr_b32 s79, s81, 16\n"           // distance base
-      "  s_bfe_u32 s73, s81, 0x40004\n"       // extra bits; SCC = (any)
+      "  s_lshr_b64 s[50:51], s[50:51], s57\n"
+      "  s_sub_i32 s52, s52, s57\n"
+      "  s_lshr_b32 s63, s65, 16\n"           // distance base
+      "  s_bfe_u32 s57, s65, 0x40004\n"       // extra bits; SCC = (any)
       "  s_cbranch_scc0 L_sym_dist%=\n"
-      "  s_bfm_b32 s80, s73, 0\n"
-      "  s_and_b32 s80, s66, s80\n"
-      "  s_add_i32 s79, s79, s80\n"
-      "  s_lshr_b64 s[66:67], s[66:67], s73\n"
-      "  s_sub_i32 s68, s68, s73\n"
+      "  s_bfm_b32 s64, s57, 0\n"
+      "  s_and_b32 s64, s50, s64\n"
+      "  s_add_i32 s63, s63, s64\n"
+      "  s_lshr_b64 s[50:51], s[50:51], s57\n"
+      "  s_sub_i32 s52, s52, s57\n"
       "L_sym_dist%=:\n"
       // ---- the copies the loop does itself: d <= history, len <= 64, and either len <= d <= NEAR (ring -> ring) or
       //      d > NEAR (the source is below `drained`, i.e. in HBM already)
-      "  s_sub_i32 s73, s70, s82\n"
-      "  s_cmp_gt_u32 s79, s73\n"
+      "  s_sub_i32 s57, s54, s66\n"
+      "  s_cmp_gt_u32 s63, s57\n"
       "  s_cbranch_scc1 L_sym_exit2%=\n"
-      "  s_cmp_gt_u32 s78, 64\n"
+      "  s_cmp_gt_u32 s62, 64\n"
       "  s_cbranch_scc1 L_sym_exit2%=\n"
-      "  v_cmp_gt_u32 vcc, s78, %[lane]\n"     // lanes below len
-      "  s_sub_i32 s73, s70, s79\n"            // first source byte
-      "  s_cmp_gt_u32 s79, %[near]\n"
+      "  v_cmp_gt_u32 vcc, s62, %[lane]\n"     // lanes below len
+      "  s_sub_i32 s57, s54, s63\n"            // first source byte
+      "  s_cmp_gt_u32 s63, %[near]\n"
       "  s_cbranch_scc1 L_sym_far%=\n"
-      "  s_cmp_gt_u32 s78, s79\n"
+      "  s_cmp_gt_u32 s62, s63\n"
       "  s_cbranch_scc1 L_sym_exit2%=\n"       // overlapping run
-      "  s_and_saveexec_b64 s[76:77], vcc\n"
-      "  v_add_u32 %[vt], s73, %[lane]\n"
+      "  s_and_saveexec_b64 s[60:61], vcc\n"
+      "  v_add_u32 %[vt], s57, %[lane]\n"
       "  v_and_b32 %[vt], %[ringmask], %[vt]\n"
       "  ds_read_u8 %[ve], %[vt]\n"
-      "  v_add_u32 %[vt], s70, %[lane]\n"
+      "  v_add_u32 %[vt], s54, %[lane]\n"
       "  v_and_b32 %[vt], %[ringmask], %[vt]\n"
       "  s_waitcnt lgkmcnt(0)\n"
       "  ds_write_b8 %[vt], %[ve]\n"
-      "  s_mov_b64 exec, s[76:77]\n"
+      "  s_mov_b64 exec, s[60:61]\n"
       "  s_branch L_sym_adv%=\n"
       "L_sym_far%=:\n"
-      "  s_and_saveexec_b64 s[76:77], vcc\n"
-      "  v_add_u32 %[vt], s73, %[lane]\n"
-      "  global_load_ubyte %[ve], %[vt], s[84:85]\n"
-      "  v_add_u32 %[vt], s70, %[lane]\n"
+      "  s_and_saveexec_b64 s[60:61], vcc\n"
+      "  v_add_u32 %[vt], s57, %[lane]\n"
+      "  global_load_ubyte %[ve], %[vt], s[68:69]\n"
+      "  v_add_u32 %[vt], s54, %[lane]\n"
       "  v_and_b32 %[vt], %[ringmask], %[vt]\n"
       "  s_waitcnt vmcnt(0)\n"
       "  ds_write_b8 %[vt], %[ve]\n"
-      "  s_mov_b64 exec, s[76:77]\n"
+      "  s_mov_b64 exec, s[60:61]\n"
       "L_sym_adv%=:\n"
-      "  s_add_i32 s73, s70, s78\n"
-      "  s_xor_b32 s80, s73, s70\n"
-      "  s_mov_b32 s70, s73\n"
-      "  v_mov_b32 %[vpos], s73\n"
-      "  s_lshr_b32 s80, s80, 8\n"            // SCC = a 256-byte row boundary was crossed
+      "  s_add_i32 s57, s54, s62\n"
+      "  s_xor_b32 s64, s57, s54\n"
+      "  s_mov_b32 s54, s57\n"
+      "  v_mov_b32 %[vpos], s57\n"
+      "  s_lshr_b32 s64, s64, 8\n"            // SCC = a 256-byte row boundary was crossed
       "  s_cbranch_scc0 L_sym_loop%=\n"
       "L_sym_row%=:\n"
-      "  s_mov_b32 s72, 1\n"
+      "  s_mov_b32 s56, 1\n"
       "  s_branch L_sym_out%=\n"
       "L_sym_exit0%=:\n"
-      "  s_mov_b32 s72, 0\n"
+      "  s_mov_b32 s56, 0\n"
       "  s_branch L_sym_out%=\n"
       "L_sym_exit2%=:\n"
-      "  s_mov_b32 s72, 2\n"
+      "  s_mov_b32 s56, 2\n"
       "  s_branch L_sym_out%=\n"
       "L_sym_exit3%=:\n"
-      "  s_mov_b32 s72, 3\n"
+      "  s_mov_b32 s56, 3\n"
       "L_sym_out%=:\n"
       "  s_waitcnt vmcnt(0) lgkmcnt(0)\n"
-      : [buf] "+{s[66:67]}"(buf), [cnt] "+{s68}"(cnt), [widx] "+{s69}"(widx), [pos] "+{s70}"(pos), [e] "={s71}"(e), [why] "={s72}"(why),
-        [len] "={s78}"(len), [d] "={s79}"(d), [cur] "+v"(br.cur), [vpos] "+v"(vpos), [vt] "=&v"(vt), [ve] "=&v"(ve)
-      : [base] "{s[74:75]}"(br.base), [begin] "{s82}"(begin), [out] "{s[84:85]}"(out), [lane] "v"(lane), [lane4] "v"(lane4), [lutmask] "i"(((1 << LIT_BITS) - 1) << 2),
+      : [buf] "+{s[50:51]}"(buf), [cnt] "+{s52}"(cnt), [widx] "+{s53}"(widx), [pos] "+{s54}"(pos), [e] "={s55}"(e), [why] "={s56}"(why),
+        [len] "={s62}"(len), [d] "={s63}"(d), [cur] "+v"(br.cur), [vpos] "+v"(vpos), [vt] "=&v"(vt), [ve] "=&v"(ve)
+      : [base] "{s[58:59]}"(br.base), [begin] "{s66}"(begin), [out] "{s[68:69]}"(out), [lane] "v"(lane), [lane4] "v"(lane4), [lutmask] "i"(((1 << LIT_BITS) - 1) << 2),
         [dmask] "i"(((1 << DIST_BITS) - 1) << 2), [ringmask] "i"(RING - 1), [near] "i"(RING - 258),
         [lutoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_lut)), [dlut] "i"(RING + (int)__builtin_offsetof(WaveLds, dist_lut))
-      : "s73", "s76", "s77", "s80", "s81", "vcc", "scc", "memory");
+      : "s57", "s60", "s61", "s64", "s65", "vcc", "scc", "memory");
 #undef EXON_REFILL
   br.buf = ((uint64_t)uniu((uint32_t)(buf >> 32)) << 32) | uniu((uint32_t)buf);
   br.cnt = uni(cnt);
@@ -748,65 +748,65 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
   // fits the 64 registers that let 8 waves share a SIMD (v32-v39 are callee-saved in the AMDGPU calling convention: the
   // non-inlined decode_symbols saves them once per DEFLATE block)
 #define EXON_REFILL_BODY(tag)                           \
-  "  s_and_b32 s73, s69, 63\n"                          \
+  "  s_and_b32 s57, s53, 63\n"                          \
   "  s_cbranch_scc1 L_vwin_" tag "%=\n"                 \
   "  s_waitcnt vmcnt(0)\n"                              \
   "L_vwin_" tag "%=:\n"                                 \
-  "  v_readlane_b32 s76, %[cur], s69\n"                 \
-  "  s_mov_b32 s77, 0\n"                                \
-  "  s_add_i32 s69, s69, 1\n"                           \
-  "  v_lshlrev_b64 v[32:33], v50, s[76:77]\n"           \
+  "  v_readlane_b32 s60, %[cur], s53\n"                 \
+  "  s_mov_b32 s61, 0\n"                                \
+  "  s_add_i32 s53, s53, 1\n"                           \
+  "  v_lshlrev_b64 v[32:33], v50, s[60:61]\n"           \
   "  v_or_b32 v48, v48, v32\n"                          \
   "  v_or_b32 v49, v49, v33\n"                          \
   "  v_add_u32 v50, 32, v50\n"                          \
-  "  s_and_b32 s73, s69, 63\n"
+  "  s_and_b32 s57, s53, 63\n"
 #define EXON_REFILL_V(tag)                              \
   "  v_cmp_lt_i32 vcc, 32, v50\n"                       \
   "  s_cbranch_vccnz L_vhave_" tag "%=\n"               \
   EXON_REFILL_BODY(tag)                                 \
   "  s_cbranch_scc1 L_vhave_" tag "%=\n"                \
-  "  v_lshl_add_u32 %[vt], s69, 2, %[lane4]\n"          \
-  "  global_load_dword %[cur], %[vt], s[74:75]\n"       \
+  "  v_lshl_add_u32 %[vt], s53, 2, %[lane4]\n"          \
+  "  global_load_dword %[cur], %[vt], s[58:59]\n"       \
   "L_vhave_" tag "%=:\n"
 #define EXON_REFILL_OUT(tag)                            \
   "L_vrefill_" tag "%=:\n"                              \
   EXON_REFILL_BODY(tag)                                 \
   "  s_cbranch_scc1 L_vback_" tag "%=\n"                \
-  "  v_lshl_add_u32 %[vt], s69, 2, %[lane4]\n"          \
-  "  global_load_dword %[cur], %[vt], s[74:75]\n"       \
+  "  v_lshl_add_u32 %[vt], s53, 2, %[lane4]\n"          \
+  "  global_load_dword %[cur], %[vt], s[58:59]\n"       \
   "  s_branch L_vback_" tag "%=\n"
-// a deferred far copy lands in the ring: the lanes below its length (s87) write their byte at s86 + lane
+// a deferred far copy lands in the ring: the lanes below its length (s71) write their byte at s70 + lane
 #define EXON_FAR_COMPLETE(vx)                           \
-  "  v_cmp_gt_u32_e64 s[76:77], s87, %[lane]\n"        \
-  "  s_and_saveexec_b64 s[80:81], s[76:77]\n"           \
-  "  v_add_u32 %[vt], s86, %[lane]\n"                  \
+  "  v_cmp_gt_u32_e64 s[60:61], s71, %[lane]\n"        \
+  "  s_and_saveexec_b64 s[64:65], s[60:61]\n"           \
+  "  v_add_u32 %[vt], s70, %[lane]\n"                  \
   "  v_and_b32 %[vt], %[ringmask], %[vt]\n"             \
   "  ds_write_b8 %[vt], " vx "\n"                       \
-  "  s_mov_b64 exec, s[80:81]\n"
+  "  s_mov_b64 exec, s[64:65]\n"
 #define EXON_FAR_COMPLETE_PENDING(tag)                  \
   "  s_waitcnt vmcnt(0)\n"                              \
-  "  s_cmp_eq_u32 s83, 1\n"                             \
+  "  s_cmp_eq_u32 s67, 1\n"                             \
   "  s_cbranch_scc0 L_vcpb_" tag "%=\n"                 \
   EXON_FAR_COMPLETE("%[vfa]")                           \
   "  s_branch L_vcpd_" tag "%=\n"                       \
   "L_vcpb_" tag "%=:\n"                                 \
   EXON_FAR_COMPLETE("%[vfb]")                           \
   "L_vcpd_" tag "%=:\n"                                 \
-  "  s_mov_b32 s83, 0\n"
+  "  s_mov_b32 s67, 0\n"
 #define EXON_LOOKUP_LIT                                 \
   "  v_lshlrev_b32 %[vt], 2, v48\n"                     \
   "  v_and_b32 %[vt], %[lutmask], %[vt]\n"              \
   "  ds_read_b32 v51, %[vt] offset:%[lutoff]\n"
   asm volatile(
-      "  v_mov_b32 v48, s66\n"
-      "  v_mov_b32 v49, s67\n"
-      "  v_mov_b32 v50, s68\n"
+      "  v_mov_b32 v48, s50\n"
+      "  v_mov_b32 v49, s51\n"
+      "  v_mov_b32 v50, s52\n"
       "  v_mov_b32 v36, 1\n"
-      "  s_mov_b32 s83, 0\n"                    // far copies in flight: 0 none, 1 one in vfa, 2 one in vfb
+      "  s_mov_b32 s67, 0\n"                    // far copies in flight: 0 none, 1 one in vfa, 2 one in vfb
       EXON_REFILL_V("e")
       EXON_LOOKUP_LIT
-      "  s_and_b32 s73, s70, %[ringmask]\n"
-      "  v_mov_b32 v37, s73\n"
+      "  s_and_b32 s57, s54, %[ringmask]\n"
+      "  v_mov_b32 v37, s57\n"
       // ---- invariant at the loop head: the lookup of the current symbol is in flight into v51, v37 = pos & (RING - 1)
       "L_vsym_loop%=:\n"
       "  s_waitcnt lgkmcnt(0)\n"
@@ -817,13 +817,13 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       "  ds_write_b8_d16_hi v37, v51\n"
       EXON_LOOKUP_LIT                          // the next symbol; everything below runs under its latency
       "  v_sub_u32 v50, v50, v55\n"
-      "  s_add_i32 s70, s70, 1\n"
-      "  s_and_b32 s73, s70, %[ringmask]\n"
-      "  v_mov_b32 v37, s73\n"
+      "  s_add_i32 s54, s54, 1\n"
+      "  s_and_b32 s57, s54, %[ringmask]\n"
+      "  v_mov_b32 v37, s57\n"
       "  v_cmp_lt_i32 vcc, 32, v50\n"
       "  s_cbranch_vccz L_vrefill_l%=\n"
       "L_vback_l%=:\n"
-      "  s_and_b32 s73, s70, 0xff\n"
+      "  s_and_b32 s57, s54, 0xff\n"
       "  s_cbranch_scc1 L_vsym_loop%=\n"
       "  s_branch L_vsym_row%=\n"
       // ---- not a literal: a length code in the table (length field 1..15, neither end of block nor invalid)?
@@ -859,36 +859,36 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       "  v_add_u32 v54, v54, v35\n"            // distance
       "  v_sub_u32 v50, v50, v38\n"
       // ---- the copies the loop does itself (as in symbol_run): d <= history, len <= 64, and either len <= d <= NEAR or d > NEAR
-      "  s_sub_i32 s73, s70, s82\n"
-      "  v_cmp_lt_u32 vcc, s73, v54\n"
+      "  s_sub_i32 s57, s54, s66\n"
+      "  v_cmp_lt_u32 vcc, s57, v54\n"
       "  s_cbranch_vccnz L_vsym_exit2%=\n"
       "  v_cmp_lt_u32 vcc, 64, v53\n"
       "  s_cbranch_vccnz L_vsym_exit2%=\n"
-      "  v_readfirstlane_b32 s78, v53\n"
-      "  v_sub_u32 v39, s70, v54\n"                  // first source byte
+      "  v_readfirstlane_b32 s62, v53\n"
+      "  v_sub_u32 v39, s54, v54\n"                  // first source byte
       "  v_cmp_lt_u32 vcc, %[near], v54\n"
       "  s_cbranch_vccnz L_vsym_far%=\n"
       "  v_cmp_gt_u32 vcc, v53, v54\n"
       "  s_cbranch_vccnz L_vsym_exit2%=\n"           // overlapping run
       // near: ring -> ring.  A far copy still in flight must land first if this source reaches into its bytes
       // (source end > its first byte; it ends at or below pos, where every source starts below)
-      "  s_cmp_eq_u32 s83, 0\n"
+      "  s_cmp_eq_u32 s67, 0\n"
       "  s_cbranch_scc1 L_vsym_near%=\n"
       "  v_add_u32 v35, v39, v53\n"
-      "  v_cmp_lt_u32 vcc, s86, v35\n"
+      "  v_cmp_lt_u32 vcc, s70, v35\n"
       "  s_cbranch_vccz L_vsym_near%=\n"
       EXON_FAR_COMPLETE_PENDING("n")
       "L_vsym_near%=:\n"
-      "  v_cmp_gt_u32_e64 s[76:77], v53, %[lane]\n"  // lanes below len
-      "  s_and_saveexec_b64 s[80:81], s[76:77]\n"
+      "  v_cmp_gt_u32_e64 s[60:61], v53, %[lane]\n"  // lanes below len
+      "  s_and_saveexec_b64 s[64:65], s[60:61]\n"
       "  v_add_u32 %[vt], v39, %[lane]\n"
       "  v_and_b32 %[vt], %[ringmask], %[vt]\n"
       "  ds_read_u8 %[ve], %[vt]\n"
-      "  v_add_u32 %[vt], s70, %[lane]\n"
+      "  v_add_u32 %[vt], s54, %[lane]\n"
       "  v_and_b32 %[vt], %[ringmask], %[vt]\n"
       "  s_waitcnt lgkmcnt(0)\n"
       "  ds_write_b8 %[vt], %[ve]\n"
-      "  s_mov_b64 exec, s[80:81]\n"
+      "  s_mov_b64 exec, s[64:65]\n"
       "  s_branch L_vsym_adv%=\n"
       // far: the source is in HBM already (d > NEAR: below `drained`).  The load is ISSUED here and its bytes are put into
       // the ring later -- when the next far copy has issued its own load (two data registers take turns), when a near copy
@@ -898,74 +898,74 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
 #ifdef EXON_INFLATE_FAR_NOWAIT  // timing experiment only (wrong bytes): what the loop would cost if far copies were free
       "  s_branch L_vsym_adv%=\n"
 #endif
-      "  v_cmp_gt_u32_e64 s[76:77], v53, %[lane]\n"
-      "  s_and_saveexec_b64 s[80:81], s[76:77]\n"
+      "  v_cmp_gt_u32_e64 s[60:61], v53, %[lane]\n"
+      "  s_and_saveexec_b64 s[64:65], s[60:61]\n"
       "  v_add_u32 %[vt], v39, %[lane]\n"
-      "  s_cmp_eq_u32 s83, 1\n"
+      "  s_cmp_eq_u32 s67, 1\n"
       "  s_cbranch_scc1 L_vsym_far_b%=\n"
-      "  global_load_ubyte %[vfa], %[vt], s[84:85]\n"
-      "  s_mov_b64 exec, s[80:81]\n"
-      "  s_cmp_eq_u32 s83, 0\n"
+      "  global_load_ubyte %[vfa], %[vt], s[68:69]\n"
+      "  s_mov_b64 exec, s[64:65]\n"
+      "  s_cmp_eq_u32 s67, 0\n"
       "  s_cbranch_scc1 L_vsym_far_a1%=\n"
       "  s_waitcnt vmcnt(1)\n"                       // the older one (in vfb) has landed; loads return in order
       EXON_FAR_COMPLETE("%[vfb]")
       "L_vsym_far_a1%=:\n"
-      "  s_mov_b32 s83, 1\n"
+      "  s_mov_b32 s67, 1\n"
       "  s_branch L_vsym_far_rec%=\n"
       "L_vsym_far_b%=:\n"
-      "  global_load_ubyte %[vfb], %[vt], s[84:85]\n"
-      "  s_mov_b64 exec, s[80:81]\n"
+      "  global_load_ubyte %[vfb], %[vt], s[68:69]\n"
+      "  s_mov_b64 exec, s[64:65]\n"
       "  s_waitcnt vmcnt(1)\n"
       EXON_FAR_COMPLETE("%[vfa]")
-      "  s_mov_b32 s83, 2\n"
+      "  s_mov_b32 s67, 2\n"
       "L_vsym_far_rec%=:\n"
-      "  s_mov_b32 s86, s70\n"
-      "  s_mov_b32 s87, s78\n"
+      "  s_mov_b32 s70, s54\n"
+      "  s_mov_b32 s71, s62\n"
       "L_vsym_adv%=:\n"
-      "  s_add_i32 s73, s70, s78\n"
-      "  s_xor_b32 s80, s73, s70\n"
-      "  s_mov_b32 s70, s73\n"
-      "  s_and_b32 s73, s73, %[ringmask]\n"
-      "  v_mov_b32 v37, s73\n"
+      "  s_add_i32 s57, s54, s62\n"
+      "  s_xor_b32 s64, s57, s54\n"
+      "  s_mov_b32 s54, s57\n"
+      "  s_and_b32 s57, s57, %[ringmask]\n"
+      "  v_mov_b32 v37, s57\n"
       "  v_cmp_lt_i32 vcc, 32, v50\n"
       "  s_cbranch_vccz L_vrefill_a%=\n"
       "L_vback_a%=:\n"
-      "  s_lshr_b32 s80, s80, 8\n"             // SCC = a 256-byte row boundary was crossed
+      "  s_lshr_b32 s64, s64, 8\n"             // SCC = a 256-byte row boundary was crossed
       "  s_cbranch_scc0 L_vsym_loop%=\n"
       "L_vsym_row%=:\n"
-      "  s_mov_b32 s72, 1\n"
+      "  s_mov_b32 s56, 1\n"
       "  s_branch L_vsym_out%=\n"
       EXON_REFILL_OUT("l")
       EXON_REFILL_OUT("a")
       "L_vsym_exit0%=:\n"
-      "  s_mov_b32 s72, 0\n"
+      "  s_mov_b32 s56, 0\n"
       "  s_branch L_vsym_out%=\n"
       "L_vsym_exit2%=:\n"
-      "  s_mov_b32 s72, 2\n"
+      "  s_mov_b32 s56, 2\n"
       "  s_branch L_vsym_out%=\n"
       "L_vsym_exit3%=:\n"
-      "  s_mov_b32 s72, 3\n"
+      "  s_mov_b32 s56, 3\n"
       "L_vsym_out%=:\n"
-      "  s_cmp_eq_u32 s83, 0\n"
+      "  s_cmp_eq_u32 s67, 0\n"
       "  s_cbranch_scc1 L_vsym_fin%=\n"
       EXON_FAR_COMPLETE_PENDING("x")
       "L_vsym_fin%=:\n"
       "  s_nop 0\n"
-      "  v_readfirstlane_b32 s66, v48\n"
-      "  v_readfirstlane_b32 s67, v49\n"
-      "  v_readfirstlane_b32 s68, v50\n"
-      "  v_readfirstlane_b32 s71, v51\n"
-      "  v_readfirstlane_b32 s78, v53\n"
-      "  v_readfirstlane_b32 s79, v54\n"
-      "  v_mov_b32 %[vpos], s70\n"
+      "  v_readfirstlane_b32 s50, v48\n"
+      "  v_readfirstlane_b32 s51, v49\n"
+      "  v_readfirstlane_b32 s52, v50\n"
+      "  v_readfirstlane_b32 s55, v51\n"
+      "  v_readfirstlane_b32 s62, v53\n"
+      "  v_readfirstlane_b32 s63, v54\n"
+      "  v_mov_b32 %[vpos], s54\n"
       "  s_waitcnt vmcnt(0) lgkmcnt(0)\n"
-      "  s_nop 1\n"  // the compiler does not know a VALU instruction wrote s66-s79: keep its next VALU read two states away
-      : [buf] "+{s[66:67]}"(buf), [cnt] "+{s68}"(cnt), [widx] "+{s69}"(widx), [pos] "+{s70}"(pos), [e] "={s71}"(e), [why] "={s72}"(why),
-        [len] "={s78}"(len), [d] "={s79}"(d), [cur] "+v"(br.cur), [vpos] "+v"(vpos), [vt] "=&v"(vt), [ve] "=&v"(ve), [vfa] "=&v"(vfa), [vfb] "=&v"(vfb)
-      : [base] "{s[74:75]}"(br.base), [begin] "{s82}"(begin), [out] "{s[84:85]}"(out), [lane] "v"(lane), [lane4] "v"(lane4), [lutmask] "i"(((1 << LIT_BITS) - 1) << 2),
+      "  s_nop 1\n"  // the compiler does not know a VALU instruction wrote s50-s63: keep its next VALU read two states away
+      : [buf] "+{s[50:51]}"(buf), [cnt] "+{s52}"(cnt), [widx] "+{s53}"(widx), [pos] "+{s54}"(pos), [e] "={s55}"(e), [why] "={s56}"(why),
+        [len] "={s62}"(len), [d] "={s63}"(d), [cur] "+v"(br.cur), [vpos] "+v"(vpos), [vt] "=&v"(vt), [ve] "=&v"(ve), [vfa] "=&v"(vfa), [vfb] "=&v"(vfb)
+      : [base] "{s[58:59]}"(br.base), [begin] "{s66}"(begin), [out] "{s[68:69]}"(out), [lane] "v"(lane), [lane4] "v"(lane4), [lutmask] "i"(((1 << LIT_BITS) - 1) << 2),
         [dmask] "i"(((1 << DIST_BITS) - 1) << 2), [ringmask] "i"(RING - 1), [near] "i"(RING - 258),
         [lutoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_lut)), [dlut] "i"(RING + (int)__builtin_offsetof(WaveLds, dist_lut))
-      : "s73", "s76", "s77", "s80", "s81", "s83", "s86", "s87", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",
+      : "s57", "s60", "s61", "s64", "s65", "s67", "s70", "s71", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",
         "vcc", "scc", "memory");
 #undef EXON_REFILL_V
 #undef EXON_REFILL_OUT
@@ -1718,6 +1718,7 @@ __device__ __forceinline__ void inflate_member(const uint8_t* __restrict__ comp,
       if (src + len > comp_end) { err = INF_INPUT_OVERRUN; break; }
       if (o.pos + len > o.end) { err = INF_OUTPUT_OVERRUN; break; }
       const uint32_t keep = len > (uint32_t)RING ? len - (uint32_t)RING : 0u;
+#pragma unroll 2  // (unrolled by 8 this loop alone took the kernel from 64 to 70 VGPRs = from 8 to 7 waves per SIMD)
       for (uint32_t j = (uint32_t)lane; j < len; j += 64) {
         const uint8_t v = comp[src + j];
         out[o.pos + j] = v;
@@ -1833,7 +1834,7 @@ __device__ __forceinline__ int flavor_of(int flavor) { return flavor == 2 ? (int
 #define EXON_INFLATE_WPE_ATTR
 #endif
 template <int RING>
-__global__ __launch_bounds__(64 * INF_WAVES) EXON_INFLATE_WPE_ATTR __attribute__((amdgpu_num_sgpr(88))) void k_inflate(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks, int n_blocks,
+__global__ __launch_bounds__(64 * INF_WAVES, 8) EXON_INFLATE_WPE_ATTR __attribute__((amdgpu_num_sgpr(72))) void k_inflate(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks, int n_blocks,
                                                 uint8_t* out, int* __restrict__ status, int flavor) {
   const int b = uni((int)(blockIdx.x * INF_WAVES + (threadIdx.x >> 6)));
   if (b >= n_blocks) return;

@@ -452,9 +452,9 @@ struct SlabReader {
 };
 
 static size_t slab_bytes() {
-  // 70 MB = 6720 BGZF members per slab: 26 of the 28 members a CU holds of the inflate kernel, the rest of the wave slots left to
-  // the parse kernels of the previous slab (72 MB: the same or worse, 74 MB: worse on every format; profiles/r4_pipes_ring1k_slab.log)
-  size_t slab = 70u << 20;
+  // 80 MB = 7680 BGZF members per slab: 30 of the 32 members a CU holds of the inflate kernel (64 VGPRs, 78 SGPRs, 4864 B of LDS),
+  // the rest of the wave slots left to the parse kernels of the previous slab (profiles/r4_pipes_ring1k_slab.log, r4_pipes_32_waves.log)
+  size_t slab = 80u << 20;
   if (const char* v = getenv("EXON_HIP_GPU_PARSE_SLAB_MB")) {
     const long mb = atol(v);
     if (mb >= 1 && mb <= 1024) slab = (size_t)mb << 20;
