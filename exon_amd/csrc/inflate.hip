@@ -119,6 +119,9 @@ __device__ __forceinline__ int cl_order(int i) {
 //   block, 10 a code that exists but may not be used (286, 287, distance 30, 31); 16-31 literal byte / length base /
 //   distance base / code-length symbol
 constexpr uint32_t E_LIT = 1u << 8, E_EOB = 1u << 9, E_INVALID = 1u << 10;
+// bit 11: a length / distance symbol the hand-written vector loop may take as it is (in the table, neither end of block nor
+// invalid): with the three flags above in the same byte, "byte 1 == 8" is ONE sdwa compare instead of mask, add, compare
+constexpr uint32_t E_FAST = 1u << 11;
 
 struct ClTables {  // the code-length code is dead once the two main codes are built: it shares dist_lut's space
   uint32_t cl_lut[1 << CL_BITS];
@@ -265,7 +268,7 @@ __device__ __forceinline__ uint32_t entry_for(int which, int s) {
     if (s > 29) return E_INVALID;
     distance_code(s, &base, &extra);
   }
-  return (base << 16) | ((uint32_t)extra << 4);
+  return (base << 16) | ((uint32_t)extra << 4) | E_FAST;
 }
 
 // Build code `which` from lens[0..n): counts, canonical order, first-level table.  Returns 0 for an over-subscribed
@@ -744,7 +747,7 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
   int cnt = br.cnt;
   uint32_t widx = br.widx;
   // v[48:49] bit buffer, v50 bit count, v51 literal/length entry, v52 distance entry, v53 length, v54 distance, v55 code
-  // length, v[32:33] / v34 / v35 / v38 scratch, v36 = 1, v37 ring address of `pos`, v39 first source byte -- below v64, so that the kernel
+  // length, v[32:33] / v34 / v35 / v38 scratch, v37 ring address of `pos`, v39 first source byte -- below v64, so that the kernel
   // fits the 64 registers that let 8 waves share a SIMD (v32-v39 are callee-saved in the AMDGPU calling convention: the
   // non-inlined decode_symbols saves them once per DEFLATE block)
 #define EXON_REFILL_BODY(tag)                           \
@@ -801,7 +804,6 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       "  v_mov_b32 v48, s50\n"
       "  v_mov_b32 v49, s51\n"
       "  v_mov_b32 v50, s52\n"
-      "  v_mov_b32 v36, 1\n"
       "  s_mov_b32 s67, 0\n"                    // far copies in flight: 0 none, 1 one in vfa, 2 one in vfb
       EXON_REFILL_V("e")
       EXON_LOOKUP_LIT
@@ -810,7 +812,7 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       // ---- invariant at the loop head: the lookup of the current symbol is in flight into v51, v37 = pos & (RING - 1)
       "L_vsym_loop%=:\n"
       "  s_waitcnt lgkmcnt(0)\n"
-      "  v_cmp_eq_u32_sdwa vcc, v51, v36 src0_sel:BYTE_1 src1_sel:DWORD\n"  // bits 8-15 == 1: a literal (E_LIT alone)
+      "  v_cmp_eq_u32_sdwa vcc, v51, 1 src0_sel:BYTE_1 src1_sel:DWORD\n"  // bits 8-15 == 1: a literal (E_LIT alone)
       "  s_cbranch_vccz L_vsym_match%=\n"
       "  v_and_b32 v55, 15, v51\n"
       "  v_lshrrev_b64 v[48:49], v55, v[48:49]\n"
@@ -828,10 +830,8 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       "  s_branch L_vsym_row%=\n"
       // ---- not a literal: a length code in the table (length field 1..15, neither end of block nor invalid)?
       "L_vsym_match%=:\n"
-      "  v_and_b32 v35, 0x60f, v51\n"
-      "  v_add_u32 v35, -1, v35\n"
-      "  v_cmp_lt_u32 vcc, 14, v35\n"
-      "  s_cbranch_vccnz L_vsym_exit0%=\n"
+      "  v_cmp_eq_u32_sdwa vcc, v51, 8 src0_sel:BYTE_1 src1_sel:DWORD\n"  // E_FAST alone (long codes are 0 entries)
+      "  s_cbranch_vccz L_vsym_exit0%=\n"
       "  v_and_b32 v55, 15, v51\n"             // code length
       "  v_bfe_u32 v34, v51, 4, 4\n"           // extra bits
       "  v_add_u32 v38, v55, v34\n"
@@ -845,10 +845,8 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       "  v_sub_u32 v50, v50, v38\n"
       EXON_REFILL_V("m")
       "  s_waitcnt lgkmcnt(0)\n"
-      "  v_and_b32 v35, 0x40f, v52\n"          // length field 1..15 and not E_INVALID (symbols 30, 31)
-      "  v_add_u32 v35, -1, v35\n"
-      "  v_cmp_lt_u32 vcc, 14, v35\n"
-      "  s_cbranch_vccnz L_vsym_exit3%=\n"
+      "  v_cmp_eq_u32_sdwa vcc, v52, 8 src0_sel:BYTE_1 src1_sel:DWORD\n"  // a usable distance code (not long, not 30 / 31)
+      "  s_cbranch_vccz L_vsym_exit3%=\n"
       "  v_and_b32 v55, 15, v52\n"
       "  v_bfe_u32 v34, v52, 4, 4\n"
       "  v_add_u32 v38, v55, v34\n"
