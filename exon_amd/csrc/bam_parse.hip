@@ -186,11 +186,12 @@ int exon_hip_bam_parser_parse(exon_hip_bam_parser* p, void* stream, const uint8_
   zl.words = (uint32_t)(((size_t)n / 36 + 1 + 31) / 32 + 1);
   hipLaunchKernelGGL(chain::k_chain_walk<BamFormat>, dim3(n_seg), dim3(64), 0, s, d_data, n, BamFormat{p->n_ref}, p->d_seg, p->d_rec_off,
                      p->d_scalars);
-  hipLaunchKernelGGL(chain::k_chain_check<0>, dim3(1), dim3(1024), 0, s, p->d_seg, n_seg, p->d_base, p->d_scalars, zl);
+  hipLaunchKernelGGL(chain::k_chain_check<0>, dim3(1), dim3(256), 0, s, p->d_seg, n_seg, p->d_base, p->d_scalars, zl);
   hipLaunchKernelGGL(k_bam_extract, dim3(n_seg), dim3(256), 0, s, d_data, p->d_seg, p->d_base, p->d_rec_off, p->out, p->d_scalars);
   HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipMemcpyAsync(p->h_scalars, p->d_scalars, 12, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(p->h_scalars, p->d_scalars, 16, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
+  if (getenv("EXON_HIP_CHAIN_TRACE")) fprintf(stderr, "[exon-hip chain] %u segments, %u rows, plain proof %u\n", n_seg, p->h_scalars[0], p->h_scalars[3]);
   cols->n_rows = p->h_scalars[0];
   cols->n_undecided = p->h_scalars[1];
   cols->consumed_bytes = p->h_scalars[2];

@@ -482,7 +482,7 @@ int exon_hip_bcf_parser_parse(exon_hip_bcf_parser* p, void* stream, const uint8_
   zl.words = (uint32_t)(((size_t)n / 32 + 1 + 31) / 32 + 1);
   hipLaunchKernelGGL(chain::k_chain_walk<BcfFormat>, dim3(n_seg), dim3(64), 0, s, d_data, n, BcfFormat{p->n_contigs, p->n_samples}, p->d_seg,
                      p->d_rec_off, p->d_scalars);
-  hipLaunchKernelGGL(chain::k_chain_check<0>, dim3(1), dim3(1024), 0, s, p->d_seg, n_seg, p->d_base, p->d_scalars, zl);
+  hipLaunchKernelGGL(chain::k_chain_check<0>, dim3(1), dim3(256), 0, s, p->d_seg, n_seg, p->d_base, p->d_scalars, zl);
   hipLaunchKernelGGL(k_bcf_extract, dim3(n_seg), dim3(256), 0, s, d_data, p->d_seg, p->d_base, p->d_rec_off, p->out, p->filters,
                      p->n_contigs, p->n_strings, p->ik, p->d_scalars);
   hipLaunchKernelGGL(k_bcf_assign, dim3(1), dim3(256), 0, s, p->filters);
@@ -494,7 +494,7 @@ int exon_hip_bcf_parser_parse(exon_hip_bcf_parser* p, void* stream, const uint8_
     const int lblocks = (int)((std::min<int64_t>(p->max_rows, n_bytes / 32 + 1) + LIST_TPB - 1) / LIST_TPB);  // a BCF record is >= 32 bytes
     int32_t* offsets = (int32_t*)p->lbufs[6 * q + 2];
     hipLaunchKernelGGL(k_list_block_sums, dim3(lblocks), dim3(LIST_TPB), 0, s, p->out.lv_cnt[q], p->d_scalars, row_bound, p->d_list_blocks);
-    hipLaunchKernelGGL(k_list_scan_blocks, dim3(1), dim3(1024), 0, s, p->d_list_blocks, lblocks, p->d_scalars + 3);
+    hipLaunchKernelGGL(k_list_scan_blocks, dim3(1), dim3(256), 0, s, p->d_list_blocks, lblocks, p->d_scalars + 3);
     hipLaunchKernelGGL(k_bcf_list_fill, dim3(lblocks), dim3(LIST_TPB), 0, s, d_data, p->out.lv_off[q], p->out.lv_cnt[q], p->d_list_blocks, p->d_scalars,
                        row_bound, (unsigned)std::min<int64_t>(p->max_bytes + 1, 0xFFFFFFFFLL), kind, offsets, p->out.info[q],
                        (uint8_t*)p->lbufs[6 * q + 3], p->d_scalars + 1);

@@ -99,27 +99,37 @@ struct ZeroList {
 //     once, straight from the segment records in HBM.
 //   * Otherwise one thread walks the segments in order, eight records in flight (the chain nearly always advances by one segment,
 //     so the loads do not depend on the walk) and marks the segments it jumped over.
-// No dynamic LDS (round 4): until then the kernel staged 16 bytes per segment in LDS -- 107 KB for a 6720-segment slab -- and its
+// One workgroup of 256 threads and no dynamic LDS (round 4: a 1024-thread workgroup needs sixteen free wave slots on ONE CU): until then the kernel staged 16 bytes per segment in LDS -- 107 KB for a 6720-segment slab -- and its
 // one workgroup could not start on any CU before enough inflate waves of the next slab had drained there: the "1.3-1.9 ms" rocprofv3
 // showed for it in the BAM pipeline were that wait, a quarter of the parse stream.
 template <int UNUSED = 0>  // a template only so that several translation units may include this header
-__global__ __launch_bounds__(1024) void k_chain_check(SegInfo* __restrict__ seg, uint32_t n_seg, uint32_t* __restrict__ base,
+__global__ __launch_bounds__(256) void k_chain_check(SegInfo* __restrict__ seg, uint32_t n_seg, uint32_t* __restrict__ base,
                                                       unsigned* __restrict__ scalars, const ZeroList zl) {
-  __shared__ unsigned part[1024];
+  __shared__ unsigned part[256];
   __shared__ unsigned s_last, s_err, s_plain;
   if (threadIdx.x == 0) s_plain = 1;
   for (int b = 0; b < zl.n; ++b)
-    for (uint32_t i = threadIdx.x; i < zl.words; i += 1024) zl.p[b][i] = 0;
+    for (uint32_t i = threadIdx.x; i < zl.words; i += 256) zl.p[b][i] = 0;
   __syncthreads();
   const uint4* seg4 = reinterpret_cast<const uint4*>(seg);  // {start, landing, count, bad}
+  // the segment whose chain met the cut-off record ends the slab (usually the last one, sometimes the one before: the record
+  // that the slab cuts off may start there): L = the first such segment, the proof covers segments 0 .. L
+  __shared__ unsigned s_cut;
+  if (threadIdx.x == 0) s_cut = n_seg - 1;
+  __syncthreads();
+  for (uint32_t s = threadIdx.x; s < n_seg; s += 256)
+    if (seg[s].bad == 2) atomicMin(&s_cut, s);
+  __syncthreads();
   {
+    const uint32_t L = s_cut;
     bool ok = true;
-    for (uint32_t s = threadIdx.x; s < n_seg; s += 1024) {
+    for (uint32_t s = threadIdx.x; s <= L; s += 256) {
       const uint4 cur = seg4[s];
       if (s == 0 && cur.x != 0) ok = false;
-      if (s + 1 < n_seg) {
-        if (cur.w != 0 || cur.x == NONE || seg[s + 1].start != cur.y) ok = false;
-      } else if (cur.w == 1 || cur.x == NONE) {
+      if (cur.x == NONE) ok = false;
+      if (s < L) {
+        if (cur.w != 0 || seg[s + 1].start != cur.y) ok = false;
+      } else if (cur.w == 1) {
         ok = false;
       }
     }
@@ -130,7 +140,7 @@ __global__ __launch_bounds__(1024) void k_chain_check(SegInfo* __restrict__ seg,
   }
   __syncthreads();
   if (threadIdx.x == 0 && s_plain) {
-    s_last = n_seg - 1;
+    s_last = s_cut;
     s_err = 0;
   }
   if (threadIdx.x == 0 && !s_plain) {
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(1024) void k_chain_check(SegInfo* __restrict__ seg,
   }
   __syncthreads();
   const uint32_t last = s_last;
-  const uint32_t per = (n_seg + 1023) / 1024;
+  const uint32_t per = (n_seg + 255) / 256;
   const uint32_t s0 = threadIdx.x * per, s1 = min(n_seg, s0 + per);
   unsigned sum = 0;
   for (uint32_t s = s0; s < s1; ++s) {
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(1024) void k_chain_check(SegInfo* __restrict__ seg,
   }
   part[threadIdx.x] = sum;
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
+  for (int o = 1; o < 256; o <<= 1) {
     unsigned v = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0u;
     __syncthreads();
     part[threadIdx.x] += v;
@@ -185,8 +195,11 @@ __global__ __launch_bounds__(1024) void k_chain_check(SegInfo* __restrict__ seg,
     base[s] = run;
     run += seg[s].count;
   }
-  if (threadIdx.x == 1023) scalars[0] = part[1023];
-  if (threadIdx.x == 0) scalars[2] = seg[last].landing;
+  if (threadIdx.x == 255) scalars[0] = part[255];
+  if (threadIdx.x == 0) {
+    scalars[2] = seg[last].landing;
+    scalars[3] = s_plain;  // diagnostics: 1 = the parallel proof sufficed
+  }
   __syncthreads();
   if (threadIdx.x == 0 && s_err) atomicAdd(&scalars[1], 1u);
 }

@@ -87,16 +87,18 @@ __global__ __launch_bounds__(TPB) void k_count_newlines(const uint8_t* __restric
 // exclusive scan of `nb` workgroup totals in place; total -> *n_lines.  zero_rest: n_lines is the slab's scalar block
 // {lines, exceptions, consumed, -}: words 1..3 are cleared here (the kernels behind this one add to them), which replaces
 // the 16-byte hipMemsetAsync every slab used to start with -- a tiny kernel of its own, queued behind the inflate
-__global__ __launch_bounds__(1024) void k_scan_blocks(unsigned* __restrict__ counts, int nb, unsigned* __restrict__ n_lines, int zero_rest) {
+// (One workgroup of 256 threads, not 1024: a workgroup starts only when ONE CU has wave slots for all of it, and beside the
+//  inflate of the next slab -- 30 of a CU's 32 slots -- sixteen free slots took 0.5-1.3 ms to appear: round 4.)
+__global__ __launch_bounds__(256) void k_scan_blocks(unsigned* __restrict__ counts, int nb, unsigned* __restrict__ n_lines, int zero_rest) {
   if (zero_rest && threadIdx.x >= 1 && threadIdx.x <= 3) n_lines[threadIdx.x] = 0;
-  __shared__ unsigned part[1024];
-  const int per = (nb + 1023) / 1024;
+  __shared__ unsigned part[256];
+  const int per = (nb + 255) / 256;
   const int b0 = threadIdx.x * per, b1 = min(nb, b0 + per);
   unsigned s = 0;
   for (int b = b0; b < b1; ++b) s += counts[b];
   part[threadIdx.x] = s;
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {  // inclusive Hillis-Steele scan
+  for (int o = 1; o < 256; o <<= 1) {  // inclusive Hillis-Steele scan
     unsigned v = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
     __syncthreads();
     part[threadIdx.x] += v;
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(unsigned* __restrict__ cou
     counts[b] = run;
     run += c;
   }
-  if (threadIdx.x == 1023) *n_lines = part[1023];
+  if (threadIdx.x == 255) *n_lines = part[255];
 }
 
 __global__ __launch_bounds__(TPB) void k_fill_newlines(const uint8_t* __restrict__ text, int64_t n, unsigned skip,
@@ -756,7 +758,7 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* p, void* stream, const uint8_
   hipStream_t s = pick_stream(ctx, stream);
   const int nblocks = (int)((n_bytes + BYTES_PER_BLOCK - 1) / BYTES_PER_BLOCK);
   hipLaunchKernelGGL(k_count_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, skip, p->d_block_counts);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, p->d_block_counts, nblocks, p->d_scalars, 1);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, s, p->d_block_counts, nblocks, p->d_scalars, 1);
   hipLaunchKernelGGL(k_fill_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, skip, p->d_block_counts, p->d_nl, (unsigned)p->max_rows);
   hipLaunchKernelGGL(k_last_newline, dim3(1), dim3(1), 0, s, p->d_nl, p->d_scalars, (unsigned)p->max_rows);
   // the number of lines is bounded by n_bytes / 16 + 1 for well-formed data lines; launch for that bound
@@ -772,7 +774,7 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* p, void* stream, const uint8_
     const int lblocks = (int)((row_bound + LIST_TPB - 1) / LIST_TPB);
     int32_t* offsets = (int32_t*)p->list_bufs[5 * q + 2];
     hipLaunchKernelGGL(k_list_block_sums, dim3(lblocks), dim3(LIST_TPB), 0, s, p->out.lv_cnt[q], p->d_scalars, (unsigned)row_bound, p->d_list_blocks);
-    hipLaunchKernelGGL(k_list_scan_blocks, dim3(1), dim3(1024), 0, s, p->d_list_blocks, lblocks, p->d_scalars + 3);
+    hipLaunchKernelGGL(k_list_scan_blocks, dim3(1), dim3(256), 0, s, p->d_list_blocks, lblocks, p->d_scalars + 3);
     hipLaunchKernelGGL(k_list_fill, dim3(lblocks), dim3(LIST_TPB), 0, s, d_text, (unsigned)n_bytes, p->out.lv_off[q], p->out.lv_cnt[q], p->d_list_blocks,
                        p->d_scalars, (unsigned)row_bound, (unsigned)std::min<int64_t>(p->cap_items, 0xFFFFFFFFLL), kind, offsets, p->out.info[q],
                        (uint8_t*)p->list_bufs[5 * q + 3], p->out.exceptions);
@@ -950,7 +952,7 @@ int exon_hip_fastq_parser_parse(exon_hip_fastq_parser* p, void* stream, const ui
   const size_t per = (size_t)(p->max_lines / 4 + 1);
   int32_t* v = p->d_views;
   hipLaunchKernelGGL(k_count_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, skip, p->d_block_counts);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, p->d_block_counts, nblocks, p->d_scalars, 1);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, s, p->d_block_counts, nblocks, p->d_scalars, 1);
   hipLaunchKernelGGL(k_fill_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, skip, p->d_block_counts, p->d_nl, (unsigned)p->max_lines);
   const int64_t read_bound = std::min<int64_t>((int64_t)per, n_bytes / 4 + 1);  // a record holds 4 newlines
   hipLaunchKernelGGL(k_fastq_views, dim3((unsigned)((read_bound + TPB - 1) / TPB)), dim3(TPB), 0, s, d_text, p->d_nl, p->d_scalars,
@@ -1157,7 +1159,7 @@ int exon_hip_sam_parser_parse(exon_hip_sam_parser* p, void* stream, const uint8_
   hipStream_t s = pick_stream(ctx, stream);
   const int nblocks = (int)((n_bytes + BYTES_PER_BLOCK - 1) / BYTES_PER_BLOCK);
   hipLaunchKernelGGL(k_count_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, skip, p->d_block_counts);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, p->d_block_counts, nblocks, p->d_scalars, 1);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, s, p->d_block_counts, nblocks, p->d_scalars, 1);
   hipLaunchKernelGGL(k_fill_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, skip, p->d_block_counts, p->d_nl, (unsigned)p->max_rows);
   hipLaunchKernelGGL(k_last_newline, dim3(1), dim3(1), 0, s, p->d_nl, p->d_scalars, (unsigned)p->max_rows);
   const int64_t row_bound = std::min<int64_t>(p->max_rows, n_bytes / 12 + 1);

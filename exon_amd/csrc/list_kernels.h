@@ -22,15 +22,17 @@ __global__ __launch_bounds__(LIST_TPB) void k_list_block_sums(const uint32_t* __
   if (threadIdx.x == 0) block_sums[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 // exclusive scan of `nb` workgroup totals in place; total -> *total_out
-__global__ __launch_bounds__(1024) void k_list_scan_blocks(unsigned* __restrict__ counts, int nb, unsigned* __restrict__ total_out) {
-  __shared__ unsigned part[1024];
-  const int per = (nb + 1023) / 1024;
+// (One workgroup of 256 threads, not 1024: a workgroup starts only when ONE CU has wave slots for all of it, and beside the
+//  inflate of the next slab -- 30 of a CU's 32 slots -- sixteen free slots took 0.5-1.3 ms to appear: round 4.)
+__global__ __launch_bounds__(256) void k_list_scan_blocks(unsigned* __restrict__ counts, int nb, unsigned* __restrict__ total_out) {
+  __shared__ unsigned part[256];
+  const int per = (nb + 255) / 256;
   const int b0 = threadIdx.x * per, b1 = min(nb, b0 + per);
   unsigned s = 0;
   for (int b = b0; b < b1; ++b) s += counts[b];
   part[threadIdx.x] = s;
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
+  for (int o = 1; o < 256; o <<= 1) {
     const unsigned v = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0u;
     __syncthreads();
     part[threadIdx.x] += v;
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(1024) void k_list_scan_blocks(unsigned* __restrict_
     counts[b] = run;
     run += c;
   }
-  if (threadIdx.x == 1023) *total_out = part[1023];
+  if (threadIdx.x == 255) *total_out = part[255];
 }
 // row -> first item index: block_offsets[block] + the prefix of the counts inside the block (call with all LIST_TPB threads)
 __device__ __forceinline__ unsigned list_first_item(unsigned c, const unsigned* __restrict__ block_offsets) {
