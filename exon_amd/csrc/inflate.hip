@@ -2022,8 +2022,11 @@ namespace {
 //          member alone takes ~2.5 ms through the serial symbol loop and ~0.5 ms through the parallel one, so small files,
 //          index chunks and first slabs finish 3x sooner; a machine-full of members (a pipeline slab) is the serial
 //          kernel's best case, and far above that the parallel one wins again by 1.26x (profiles/r2_tuning.md)
+//          Round 4 (profiles/r4_inflate_par_crossover.log, one launch of K members through either decoder): VCF text 0.9 ms
+//          against 2.9 ms up to 256 members (one per CU) and 2.97-3.2 against 2.9-3.0 ms from 512 on; BAM and FASTQ members
+//          (mostly handed back to the serial loop inside the parallel kernel) 10 % slower at every size.  The limit was 1536.
 //   0      serial always      1  lane-parallel always      2  both side by side (a share of the members each)
-constexpr int PAR_AUTO_MAX = 1536;
+constexpr int PAR_AUTO_MAX = 256;
 int par_mode() {
   static const int m = [] {
     const char* e = getenv("EXON_HIP_INFLATE_PAR");

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """How many members of the serial inflate kernel are resident at once: time of ONE launch over the first K members of a VCF-text
-slab, K around the machine-full.  The time steps up where a second round of workgroups begins.  usage: inflate_knee.py [kind]"""
+slab, K around the machine-full.  The time steps up where a second round of workgroups begins.  usage: inflate_knee.py [kind] [n1,n2,...]
+(small counts + EXON_HIP_INFLATE_PAR=0 / 1: where the lane-parallel decoder stops paying)"""
 import ctypes as C
 import os
 import subprocess
@@ -25,7 +26,8 @@ d_comp = ctx.to_device(np.concatenate([buf, np.zeros(4096 + (-len(buf)) % 4, np.
 d_out = ctx.empty(np.uint8, out_bytes + 64)
 bad = C.c_int32(-1)
 print(f"{kind}: {n} members available")
-for nb in (4096, 5632, 5888, 6016, 6144, 6272, 6400, 6656, 6912, 7168, 7680, 8192):
+sizes = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else (4096, 5632, 5888, 6016, 6144, 6272, 6400, 6656, 6912, 7168, 7680, 8192)
+for nb in sizes:
     if nb > n:
         break
     ts = []
