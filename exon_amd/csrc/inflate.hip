@@ -822,6 +822,21 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
       "  s_add_i32 s54, s54, 1\n"
       "  s_and_b32 s57, s54, %[ringmask]\n"
       "  v_mov_b32 v37, s57\n"
+      "  s_and_b32 s57, s54, 0xff\n"
+      "  s_cbranch_scc0 L_vsym_row%=\n"
+      // a second symbol without a look at the bit count: the loop head had more than 32 bits, a literal took at most 9, and 24 are
+      // enough for another literal or for a length code with its extra bits (the match path refills behind the length itself)
+      "  s_waitcnt lgkmcnt(0)\n"
+      "  v_cmp_eq_u32_sdwa vcc, v51, 1 src0_sel:BYTE_1 src1_sel:DWORD\n"
+      "  s_cbranch_vccz L_vsym_match%=\n"
+      "  v_and_b32 v55, 15, v51\n"
+      "  v_lshrrev_b64 v[48:49], v55, v[48:49]\n"
+      "  ds_write_b8_d16_hi v37, v51\n"
+      EXON_LOOKUP_LIT
+      "  v_sub_u32 v50, v50, v55\n"
+      "  s_add_i32 s54, s54, 1\n"
+      "  s_and_b32 s57, s54, %[ringmask]\n"
+      "  v_mov_b32 v37, s57\n"
       "  v_cmp_lt_i32 vcc, 32, v50\n"
       "  s_cbranch_vccz L_vrefill_l%=\n"
       "L_vback_l%=:\n"
