@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of two library builds on the warm file pipelines: tools/r4_ab_pipes.sh <out> <libA> <libB>
+# same-box A/B of two library builds on the warm file pipelines: tools/ab_pipes_libs.sh <out> <libA> <libB>
 out=$1; a=$2; b=$3
 mkdir -p $out
 tools/bin/gen_text vcf 100000000 /tmp/e2e.vcf && tools/bin/bgzip /tmp/e2e.vcf /tmp/e2e.vcf.gz 6
