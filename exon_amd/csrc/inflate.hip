@@ -996,8 +996,189 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
   return uniu(why);
 }
 
-// `vflav` (wave-uniform): the hand-written symbol loop runs on the vector unit (symbol_run_v) instead of the scalar one
+
+// ================================================================================================================
+// The WIDE symbol loop (round 5): 64 lanes = 64 consecutive BIT OFFSETS of the stream.
+// The loops above decode one symbol per step with one useful lane: every step pays an LDS round trip (table lookup) on the
+// wave's own dependency chain, ~300 clocks per symbol with 8 waves sharing a SIMD.  Here a ROUND takes 64 bits of the stream
+// at once: lane l decodes the complete symbol that WOULD start at bit l (literal, or length + extra bits + distance + extra
+// bits: two table lookups for all 64 offsets together), so after two LDS round trips every possible symbol start of the
+// round is decoded.  The true chain 0 -> next(0) -> next(next(0)) ... is then followed with one v_readlane per symbol (no
+// memory on the chain), and while it is walked every OUTPUT BYTE of the round finds its owner: byte lane b keeps the record of
+// the last symbol that starts at or before output byte b.  The round's output (<= 64 bytes) is then produced in ONE step for
+// all its symbols -- literal lanes store their byte, near-match lanes copy ring -> ring, far-match lanes load from the output
+// already in HBM (the load is deferred by one round) -- instead of one masked copy per match.
+//   * a match that does not fit the round's 64 output bytes is carried into the next round as (rest, distance): rounds split
+//     matches freely, a copy is byte-sequential;
+//   * a byte whose source lies in its own round (distance <= lane: overlapping runs, very near matches) takes the slow path
+//     of the round: the bytes are produced in dependency order, as many per step as are ready;
+//   * a symbol the tables do not resolve (long code, end of block, invalid code) ends the chain in front of it: the round
+//     consumes what precedes it and the caller's slow path takes the symbol, as for the loops above.
+// Same contract as symbol_run: why 0 / 1 / 2 as there (e / len / d), 4 = a distance reaches before the member's output.
+// Window: `cur` = dwords [wb, wb + 64) of the compressed data, one per lane, wb a multiple of 32; a round needs the dwords
+// k .. k + 4 with k = bp >> 5 < 32 + 4; when bp passes 1024 the window moves by 32 dwords (upper half of cur + lower half of
+// nxt, nxt = dwords [wb + 64, wb + 128) loaded long before).
+// tools/deflate_stats.cpp has what a round sees: VCF text 5.4 symbols (3.4 matches) and 31 output bytes per round, BAM 6.7
+// (2.3) and 27, FASTQ 8.7 (1.4) and 16; 0.5 % / 8 % / 0.7 % of the rounds take the slow path.
+// ================================================================================================================
 template <int RING>
+__device__ __forceinline__ uint32_t wide_run(BitReader& br, Out& o, uint32_t& e_out, uint32_t& len_out, uint32_t& d_out) {
+  constexpr uint32_t RM = RING - 1, NEARW = RING - 258;
+  static_assert(NEARW >= 64 + 255 + 64, "a far source must lie below the drained rows");
+  const uint32_t lane = lane_id();
+  uint8_t* ring = wave_ring<RING>();
+  const WaveLds* L = wave_lds<RING>();
+  const uint32_t* base = br.base;
+  auto bperm = [](uint32_t byte_addr, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)byte_addr, (int)v); };
+  auto rdl = [](uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); };
+  const uint32_t P0 = br.widx * 32u - (uint32_t)br.cnt;  // bit index of the next symbol, from `base`
+  uint32_t wb = (P0 >> 5) & ~31u;
+  uint32_t bp = P0 - wb * 32u;
+  uint32_t cur = base[wb + lane];
+  uint32_t nxt = base[wb + 64u + lane];
+  uint32_t pos = o.pos;
+  uint32_t carry_len = 0, carry_rec = 0;
+  uint32_t fdata = 0, faddr = ~0u;  // the deferred far copy: bytes in flight and their ring addresses (~0: none for this lane)
+  uint32_t pend_lo = ~0u;           // its first output index (~0: nothing pending)
+  uint32_t why;
+  auto complete_far = [&]() {
+    if (faddr != ~0u) ring[faddr] = (uint8_t)fdata;
+    faddr = ~0u;
+    pend_lo = ~0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  };
+  for (;;) {
+    if (bp >= 1024u) {  // move the window by 32 dwords
+      const uint32_t c1 = bperm((lane ^ 32u) << 2, cur), c2 = bperm((lane ^ 32u) << 2, nxt);
+      cur = lane < 32u ? c1 : c2;
+      wb += 32u;
+      bp -= 1024u;
+      nxt = base[wb + 64u + lane];
+    }
+    // ---- every lane's 64 bits of the stream, from bit bp + lane
+    const uint32_t t = bp + lane;
+    const uint32_t a = (t >> 5) << 2;
+    const uint32_t d0 = bperm(a, cur), d1 = bperm(a + 4u, cur), d2 = bperm(a + 8u, cur);
+    const uint32_t wlo = __builtin_amdgcn_alignbit(d1, d0, t & 31u), whi = __builtin_amdgcn_alignbit(d2, d1, t & 31u);
+    // ---- the symbol that would start there
+    const uint32_t ev = L->lit_lut[wlo & ((1u << LIT_BITS) - 1u)];
+    const uint32_t l1 = ev & 15u, xb = (ev >> 4) & 15u, lx = l1 + xb;
+    const uint32_t exv = __builtin_amdgcn_ubfe(wlo, l1, xb);
+    const uint32_t w2lo = (uint32_t)((((uint64_t)whi << 32) | wlo) >> lx);
+    const uint32_t dv = L->dist_lut[w2lo & ((1u << DIST_BITS) - 1u)];
+    const bool is_lit = ((ev >> 8) & 0xFFu) == 1u;                                  // E_LIT alone
+    const bool mok = ((ev >> 8) & 0xFFu) == 8u && ((dv >> 8) & 0xFFu) == 8u;        // E_FAST alone, twice
+    const uint32_t dl = dv & 15u, dxb = (dv >> 4) & 15u;
+    const uint32_t dm1 = (dv >> 16) + __builtin_amdgcn_ubfe(w2lo, dl, dxb) - 1u;
+    const uint32_t tot = is_lit ? l1 : lx + dl + dxb;
+    // record: bits 0-8 output bytes; literal: bit 31 + the byte in bits 16-23; match: distance - 1 in bits 16-30
+    uint32_t rec = is_lit ? (0x80000001u | (ev & 0x00FF0000u)) : (((ev >> 16) + exv) | (dm1 << 16));
+    const bool ok = is_lit || mok;
+    if (!ok) rec = 0;
+    const uint32_t nextp = ok ? lane + tot : 128u + lane;
+    // ---- the chain; byte lane b keeps the record of the last symbol that starts at or before output byte b
+    uint32_t p = 0, vo = carry_len, lastrec = carry_rec, rb = carry_rec;
+    while (p < 64u && vo < 64u) {
+      const uint32_t r = rdl(rec, p), pn = rdl(nextp, p);
+      rb = lane >= vo ? r : rb;
+      vo += r & 0x1FFu;
+      lastrec = r;
+      p = pn;
+    }
+    const bool special = p >= 128u;
+    const uint32_t consumed = special ? p - 128u : p;
+    // ---- the round's output bytes
+    const uint32_t nb = min(vo, 64u);
+    const bool valid = lane < nb;
+    const int32_t dm1b = (int32_t)rb >> 16;
+    const bool blit = (int32_t)rb < 0;
+    const bool bmatch = valid && !blit;
+    const uint32_t dst = pos + lane, ra = dst & RM;
+    const uint32_t src1 = dst - (uint32_t)dm1b;  // source index + 1
+    if (__any(bmatch && (uint32_t)dm1b >= dst - o.begin)) {
+      why = 4;
+      break;
+    }
+    const bool bfar = bmatch && dm1b >= (int32_t)NEARW;
+    const bool bnear = bmatch && !bfar;
+    if (__builtin_expect(__any(bnear && (uint32_t)dm1b < lane), 0)) {
+      // a source inside this round's own output: produce the bytes in dependency order
+      complete_far();
+      if (valid && blit) ring[ra] = (uint8_t)(rb >> 16);
+      if (bfar) ring[ra] = o.out[src1 - 1u];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const uint32_t need = bnear && (uint32_t)dm1b < lane ? lane - (uint32_t)dm1b : 0u;  // bytes of the round this one waits for
+      for (uint32_t D = 0; D < nb;) {
+        const unsigned long long blocked = __ballot(valid && need > D);
+        const uint32_t Dn = blocked ? (uint32_t)__ffsll((long long)blocked) - 1u : nb;
+        if (bnear && lane >= D && lane < Dn) {
+          const uint8_t v = ring[(src1 - 1u) & RM];
+          ring[ra] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        D = Dn;
+      }
+    } else {
+      if (pend_lo != ~0u && __any(bnear && src1 > pend_lo)) complete_far();  // a near source inside the bytes still in flight
+      if (valid && blit) ring[ra] = (uint8_t)(rb >> 16);
+      uint8_t nv = 0;
+      if (bnear) nv = ring[(src1 - 1u) & RM];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (bnear) ring[ra] = nv;
+      if (__any(bfar)) {
+        uint32_t fnew = 0;
+        if (bfar) fnew = o.out[src1 - 1u];  // below `drained`: in HBM already
+        complete_far();                      // the previous round's, under this load
+        fdata = fnew;
+        faddr = bfar ? ra : ~0u;
+        pend_lo = pos;
+#ifdef EXON_WIDE_SYNC_FAR  // debugging: no deferral
+        complete_far();
+#endif
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    const uint32_t npos = pos + nb;
+    const bool crossed = ((pos ^ npos) >> 8) != 0;
+    pos = npos;
+    carry_len = vo - nb;
+    carry_rec = lastrec;
+    bp += consumed;
+    if (crossed) {
+      why = 1;
+      break;
+    }
+    if (special) {
+      why = 0;
+      e_out = rdl(ev, p - 128u);
+      break;
+    }
+  }
+  complete_far();
+  if (why != 4 && carry_len != 0) {  // the rest of a match: the caller copies it (any length, any distance)
+    why = 2;
+    len_out = carry_len;
+    d_out = ((carry_rec >> 16) & 0x7FFFu) + 1u;
+  }
+  // ---- back to the caller's bit reader: two whole dwords from bit bp on
+  o.pos = pos;
+  const uint32_t k = bp >> 5;  // < 36
+  const uint32_t w0 = rdl(cur, k), w1 = rdl(cur, k + 1u);
+  br.buf = (((uint64_t)w1 << 32) | w0) >> (bp & 31u);
+  br.cnt = 64 - (int)(bp & 31u);
+  br.widx = wb + k + 2u;
+  const uint32_t w64 = br.widx & ~63u;
+  if (w64 == wb) {
+    br.cur = cur;
+  } else {  // wb is an odd multiple of 32: the reader's window is [wb - 32, wb + 32) (its lower half is behind the reader) or [wb + 32, wb + 96)
+    const uint32_t c1 = bperm((lane ^ 32u) << 2, cur), c2 = bperm((lane ^ 32u) << 2, nxt);
+    br.cur = (w64 > wb && lane >= 32u) ? c2 : c1;
+  }
+  return why;
+}
+
+// `vflav` (wave-uniform): the hand-written symbol loop runs on the vector unit (symbol_run_v) instead of the scalar one
+template <int RING, bool WIDE>
 __device__ __noinline__ SymResult decode_symbols(BitReader br, Out o, int vflav) {
   constexpr uint32_t M = RING - 1;
   constexpr uint32_t NEAR = RING - 258;  // largest distance served from the ring (the copy must not overwrite its source)
@@ -1037,8 +1218,27 @@ __device__ __noinline__ SymResult decode_symbols(BitReader br, Out o, int vflav)
 #endif
     uint32_t len, d;
 #if EXON_INFLATE_LIT == 2
-    const uint32_t why = vflav ? symbol_run_v<RING>(br, o.pos, vpos, lane, lane4, o.begin, o.out, e, len, d)
-                               : symbol_run<RING>(br, o.pos, vpos, lane, lane4, o.begin, o.out, e, len, d);
+    uint32_t why;
+    if (WIDE) {
+      why = uniu(wide_run<RING>(br, o, e, len, d));
+      br.make_uniform();
+      o.pos = uniu(o.pos);
+      e = uniu(e);
+      len = uniu(len);
+      d = uniu(d);
+      vpos = o.pos;
+      if (__builtin_expect(why == 4, 0)) { err = INF_BAD_DISTANCE; break; }
+      // rows completed inside the rounds are drained here, whatever else the loop left with (a carried match would otherwise
+      // hide the crossing: the next drain would come a row late, behind far sources and, after two, behind the ring)
+      if ((o.pos & ~255u) > o.drained) {
+        if (o.pos > o.end || br.overrun()) { err = br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN; break; }
+        o.drained = uniu(drain_rows<RING>(o.out, o.drained, o.pos & ~255u));
+      }
+      if (why == 1) continue;
+    } else {
+      why = vflav ? symbol_run_v<RING>(br, o.pos, vpos, lane, lane4, o.begin, o.out, e, len, d)
+                  : symbol_run<RING>(br, o.pos, vpos, lane, lane4, o.begin, o.out, e, len, d);
+    }
     if (why == 1) {  // a 256-byte row of the ring is complete
       if (o.pos > o.end || br.overrun()) { err = br.overrun() ? INF_INPUT_OVERRUN : INF_OUTPUT_OVERRUN; break; }
       o.drained = uniu(drain_rows<RING>(o.out, o.drained, o.pos & ~255u));
@@ -1691,7 +1891,7 @@ __device__ __noinline__ int par_decode_block(const uint8_t* __restrict__ comp /*
 }
 
 // One BGZF member.  PAR: dynamic / fixed DEFLATE blocks first try par_decode_block (scratch slot `sl`, fallback counters `stats`).
-template <int RING, bool PAR>
+template <int RING, bool PAR, bool WIDE = false>
 __device__ __forceinline__ void inflate_member(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks, int b, uint8_t* out,
                                                int* __restrict__ status, const ParSlot sl, unsigned* __restrict__ stats, int vflav) {
   constexpr uint32_t M = RING - 1;
@@ -1823,7 +2023,7 @@ __device__ __forceinline__ void inflate_member(const uint8_t* __restrict__ comp,
         continue;
       }
     }
-    const SymResult r = decode_symbols<RING>(br, o, vflav);
+    const SymResult r = decode_symbols<RING, WIDE>(br, o, vflav);
     br = r.br;
     br.make_uniform();
     o = r.o;
@@ -1852,6 +2052,16 @@ __global__ __launch_bounds__(64 * INF_WAVES, 8) EXON_INFLATE_WPE_ATTR __attribut
   const int b = uni((int)(blockIdx.x * INF_WAVES + (threadIdx.x >> 6)));
   if (b >= n_blocks) return;
   inflate_member<RING, false>(comp, blocks, b, out, status, ParSlot{}, nullptr, flavor_of(flavor));
+}
+
+
+// The wide symbol loop (wide_run) as its own kernel: its register budget is not the serial loops'
+template <int RING>
+__global__ __launch_bounds__(64 * INF_WAVES) void k_inflate_w(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks, int n_blocks, uint8_t* out,
+                                                              int* __restrict__ status) {
+  const int b = uni((int)(blockIdx.x * INF_WAVES + (threadIdx.x >> 6)));
+  if (b >= n_blocks) return;
+  inflate_member<RING, false, true>(comp, blocks, b, out, status, ParSlot{}, nullptr, 1);
 }
 
 // The lane-parallel variant: a fixed set of workgroups (one scratch slot each) takes members off a shared counter.
@@ -2207,9 +2417,9 @@ extern "C" int exon_hip_bgzf_forget_stream(void* stream) {
 static int inflate_flavor(int hint) {
   static const int forced = [] {
     const char* e = getenv("EXON_HIP_INFLATE_FLAVOR");
-    return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : -1;
+    return e && e[0] >= '0' && e[0] <= '3' ? e[0] - '0' : -1;
   }();
-  return forced >= 0 ? forced : hint >= 0 && hint <= 2 ? hint : 1;
+  return forced >= 0 ? forced : hint >= 0 && hint <= 3 ? hint : 1;
 }
 
 hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const exon_hip_bgzf_block* d_blocks, int n_blocks,
@@ -2251,7 +2461,10 @@ hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const 
     const long v = e ? atol(e) : 0;
     return (size_t)(v > 0 && v <= 32768 ? v : 0);
   }();
-  if (!parallel)
+  if (!parallel && flavor == 3)
+    hipLaunchKernelGGL(k_inflate_w<INFLATE_RING_SERIAL>, dim3((n_blocks + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), pad_lds, s, d_comp, blocks,
+                       n_blocks, d_out, d_status);
+  else if (!parallel)
     hipLaunchKernelGGL(k_inflate<INFLATE_RING_SERIAL>, dim3((n_blocks + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), pad_lds, s, d_comp, blocks, n_blocks,
                        d_out, d_status, flavor);
   if (verify_crc)
