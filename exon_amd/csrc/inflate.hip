@@ -1021,6 +1021,255 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
 // tools/deflate_stats.cpp has what a round sees: VCF text 5.4 symbols (3.4 matches) and 31 output bytes per round, BAM 6.7
 // (2.3) and 27, FASTQ 8.7 (1.4) and 16; 0.5 % / 8 % / 0.7 % of the rounds take the slow path.
 // ================================================================================================================
+
+#ifndef EXON_WIDE_ASM
+#define EXON_WIDE_ASM 1
+#endif
+// The rounds of wide_run that need nothing special, hand-written.  Why by hand: the compiler's version of the round spends 78
+// scalar + 83 vector instructions (VCF text; rocprofv3 PMC, profiles/r5_inflate_wide_pmc.md), and a CU has ONE scalar ALU for its
+// 32 waves (tools/issue_rate.hip: 1.0 instruction per clock and CU) against 4 x 0.5 vector instructions.  So everything
+// wave-uniform that is not a branch condition or a lane select lives in vector registers here (all 64 lanes computing the same
+// value), masks are taken by v_cmpx straight into EXEC, and the chain walk is two v_readlane + four vector instructions + one
+// compare-and-branch per symbol.
+// Wait states the assembler does not insert inside an asm block (gfx940 family, LLVM's GCNHazardRecognizer): a VALU-written SGPR
+// or VCC needs 2 states before a VALU reads it as an operand or a v_cndmask mask, 4 before v_readlane uses it as the lane select; a
+// VALU-written VGPR 1 before v_readlane / v_readfirstlane reads it; a VALU-written EXEC 4 before v_readlane.  SALU reads of
+// VALU-written SGPRs and s_cbranch_vcc* are interlocked.
+// Registers: s40-s71 and v30-v61 are this block's; the interface values travel in the operands.
+template <int RING>
+__device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address_space(1))) uint32_t* base, const __attribute__((address_space(1))) uint8_t* out,
+                                                    uint32_t& bp, uint32_t& wb, uint32_t& pos, uint32_t& drained, uint32_t& carry_len, uint32_t& carry_rec,
+                                                    uint32_t begin, uint32_t end, uint32_t limit, uint32_t lane, uint32_t& cur, uint32_t& nxt, uint32_t& fdata,
+                                                    uint32_t& faddr, uint32_t& pend_lo, uint32_t& rec, uint32_t& nextp, uint32_t& ev, uint32_t& p_out, uint32_t& e_out) {
+  uint32_t code;
+  uint32_t vpend = pend_lo;
+  asm volatile(
+      "  v_add_u32 v60, 0x80, %[lane]\n"                 // 128 + lane: where the chain goes from a symbol the tables do not resolve
+      "L_wr_round%=:\n"
+      "  s_cmpk_lt_u32 s44, 0x400\n"
+      "  s_cbranch_scc0 L_wr_switch%=\n"
+      "L_wr_win%=:\n"
+      // ---- every lane's 64 bits of the stream from bit bp + lane
+      "  v_add_u32 v33, s44, %[lane]\n"
+      "  v_lshrrev_b32 v34, 3, v33\n"
+      "  v_and_b32 v34, 0xfc, v34\n"
+      "  ds_bpermute_b32 v35, v34, %[cur]\n"
+      "  ds_bpermute_b32 v36, v34, %[cur] offset:4\n"
+      "  ds_bpermute_b32 v37, v34, %[cur] offset:8\n"
+      "  s_waitcnt lgkmcnt(1)\n"
+      "  v_alignbit_b32 v38, v36, v35, v33\n"
+      "  v_and_b32 v34, 0x1ff, v38\n"
+      "  v_lshlrev_b32 v34, 2, v34\n"
+      "  ds_read_b32 %[ev], v34 offset:%[lutoff]\n"
+      "  s_waitcnt lgkmcnt(1)\n"
+      "  v_alignbit_b32 v39, v37, v36, v33\n"
+      "  s_waitcnt lgkmcnt(0)\n"
+      // ---- the symbol that would start there: literal, or length + extra bits + distance + extra bits
+      "  v_and_b32 v42, 15, %[ev]\n"                      // code length
+      "  v_bfe_u32 v43, %[ev], 4, 4\n"                    // extra bits
+      "  v_add_u32 v44, v42, v43\n"
+      "  v_lshrrev_b64 v[46:47], v44, v[38:39]\n"
+      "  v_lshlrev_b32 v34, 2, v46\n"
+      "  v_and_b32 v34, 0x3fc, v34\n"
+      "  ds_read_b32 v41, v34 offset:%[dlut]\n"
+      "  v_bfe_u32 v45, v38, v42, v43\n"                  // value of the extra bits
+      "  v_cmp_eq_u32_sdwa s[58:59], %[ev], 1 src0_sel:BYTE_1 src1_sel:DWORD\n"  // E_LIT alone: a literal
+      "  v_cmp_eq_u32_sdwa s[60:61], %[ev], 8 src0_sel:BYTE_1 src1_sel:DWORD\n"  // E_FAST alone: a length the tables resolve
+      "  v_add_u32_sdwa v48, v45, %[ev] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"  // length
+      "  v_and_b32 v49, 0xff0000, %[ev]\n"
+      "  v_or_b32 v49, 0x80000001, v49\n"                 // a literal's record
+      "  s_waitcnt lgkmcnt(0)\n"
+      "  v_cmp_eq_u32_sdwa vcc, v41, 8 src0_sel:BYTE_1 src1_sel:DWORD\n"         // ... and a distance they resolve
+      "  s_and_b64 s[60:61], s[60:61], vcc\n"
+      "  v_and_b32 v35, 15, v41\n"
+      "  v_bfe_u32 v36, v41, 4, 4\n"
+      "  v_bfe_u32 v37, v46, v35, v36\n"
+      "  v_add_u32_sdwa v37, v37, v41 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"    // distance
+      "  v_add_u32 v37, -1, v37\n"
+      "  v_lshl_or_b32 %[rec], v37, 16, v48\n"           // a match's record
+      "  v_add3_u32 %[nextp], v44, v35, v36\n"           // its bits
+      "  s_or_b64 s[60:61], s[60:61], s[58:59]\n"        // resolved at all
+      "  v_cndmask_b32 %[nextp], %[nextp], v42, s[58:59]\n"
+      "  v_cndmask_b32 %[rec], %[rec], v49, s[58:59]\n"
+      "  v_add_u32 %[nextp], %[nextp], %[lane]\n"
+      "  v_cndmask_b32 %[nextp], v60, %[nextp], s[60:61]\n"
+      "  v_cndmask_b32 %[rec], 0, %[rec], s[60:61]\n"
+      // ---- the chain.  v52 = output bytes so far, v53 = per byte lane the record of the last symbol that starts at or before it
+      "  v_mov_b32 v52, s51\n"
+      "  v_mov_b32 v53, s52\n"
+      "  s_mov_b32 s53, 0\n"
+      "  s_mov_b32 s54, s52\n"
+      "  s_cmp_ge_u32 s51, 64\n"
+      "  s_cbranch_scc1 L_wr_walked2%=\n"
+      "L_wr_walk%=:\n"
+      "  v_readlane_b32 s54, %[rec], s53\n"
+      "  v_readlane_b32 s53, %[nextp], s53\n"
+      "  v_cmp_le_u32 vcc, v52, %[lane]\n"
+      "  v_mov_b32 v54, s54\n"
+      "  v_add_u32_sdwa v52, v52, v54 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n"
+      "  v_cndmask_b32 v53, v53, v54, vcc\n"
+      "  s_cmp_lt_u32 s53, 64\n"
+      "  s_cbranch_scc1 L_wr_walk%=\n"
+      // a symbol that STARTS beyond the 64 output bytes of the round was walked over: the careful walk of the C++ round
+      "  v_readfirstlane_b32 s65, v52\n"
+      "  s_and_b32 s57, s54, 0x1ff\n"
+      "  s_sub_u32 s57, s65, s57\n"
+      "  s_cmp_ge_u32 s57, 64\n"
+      "  s_cbranch_scc1 L_wr_slow%=\n"
+      "  s_branch L_wr_walked%=\n"
+      "L_wr_walked2%=:\n"
+      "  s_nop 0\n"
+      "  v_readfirstlane_b32 s65, v52\n"
+      "L_wr_walked%=:\n"
+      "  s_and_b32 s70, s53, 0x7f\n"                      // bits consumed (a symbol not resolved sits at 128 + its lane)
+      "  s_min_u32 s64, s65, 64\n"                        // bytes of the round
+      // ---- the output bytes
+      "  v_ashrrev_i32 v55, 16, v53\n"                    // distance - 1 (a literal: negative)
+      "  v_add_u32 v56, s46, %[lane]\n"                   // where the byte goes
+      "  v_sub_u32 v58, v56, v55\n"                       // its source + 1
+      "  v_and_b32 v57, %[ringmask], v56\n"
+      "  v_cmpx_gt_u32 vcc, s64, %[lane]\n"               // EXEC = the round's byte lanes
+      "  v_subrev_u32 v48, s47, v56\n"
+      "  v_cmp_ge_i32 vcc, v55, v48\n"                    // a distance that reaches before the member's output
+      "  s_cbranch_vccnz L_wr_bad%=\n"
+      "  v_cmp_lt_u32 vcc, v55, %[lane]\n"                // a source inside the round's own output
+      "  s_cbranch_vccnz L_wr_slow%=\n"
+      "  s_mov_b64 s[62:63], exec\n"
+      "  v_cmpx_gt_i32 vcc, 0, v53\n"                     // literals
+      "  ds_write_b8_d16_hi v57, v53\n"
+      "  s_andn2_b64 exec, s[62:63], exec\n"              // matches
+      "  s_cbranch_execz L_wr_nomatch%=\n"
+      "  s_mov_b64 s[62:63], exec\n"
+      "  v_cmpx_gt_u32 vcc, %[nearw], v55\n"              // near: ring -> ring
+      "  s_cbranch_execz L_wr_nonear%=\n"
+      "  v_cmp_gt_u32 vcc, v58, %[vpend]\n"               // a source inside the bytes of the deferred far copy?
+      "  s_cbranch_vccz L_wr_near%=\n"
+      "  s_mov_b64 s[68:69], exec\n"
+      "  s_mov_b64 exec, -1\n"
+      "  s_waitcnt vmcnt(0)\n"
+      "  v_cmpx_ne_u32 vcc, -1, %[faddr]\n"
+      "  ds_write_b8 %[faddr], %[fdata]\n"
+      "  s_mov_b64 exec, -1\n"
+      "  v_mov_b32 %[faddr], -1\n"
+      "  v_mov_b32 %[vpend], -1\n"
+      "  s_mov_b64 exec, s[68:69]\n"
+      "L_wr_near%=:\n"
+      "  v_add_u32 v48, -1, v58\n"
+      "  v_and_b32 v48, %[ringmask], v48\n"
+      "  ds_read_u8 v59, v48\n"
+      "  s_waitcnt lgkmcnt(0)\n"
+      "  ds_write_b8 v57, v59\n"
+      "L_wr_nonear%=:\n"
+      "  s_andn2_b64 exec, s[62:63], exec\n"              // far: the source is in HBM already
+      "  s_cbranch_execz L_wr_nomatch%=\n"
+      "  s_mov_b64 s[62:63], exec\n"
+      "  s_mov_b64 exec, -1\n"
+      "  s_waitcnt vmcnt(0)\n"                            // the previous deferred copy lands (its load is a round old) ...
+      "  v_cmpx_ne_u32 vcc, -1, %[faddr]\n"
+      "  ds_write_b8 %[faddr], %[fdata]\n"
+      "  s_mov_b64 exec, -1\n"
+      "  v_mov_b32 %[faddr], -1\n"
+      "  v_mov_b32 %[vpend], s46\n"
+      "  s_mov_b64 exec, s[62:63]\n"
+      "  global_load_ubyte %[fdata], v58, s[42:43] offset:-1\n"   // ... and this round's is issued: it lands a round later
+      "  v_mov_b32 %[faddr], v57\n"
+      "L_wr_nomatch%=:\n"
+      "  s_mov_b64 exec, -1\n"
+      // ---- advance
+      "  s_sub_u32 s51, s65, s64\n"                       // the rest of a match that did not fit
+      "  s_mov_b32 s52, s54\n"
+      "  s_add_u32 s67, s46, s64\n"
+      "  s_xor_b32 s57, s67, s46\n"
+      "  s_mov_b32 s46, s67\n"
+      "  s_add_u32 s44, s44, s70\n"
+      "  s_lshr_b32 s57, s57, 8\n"                        // SCC = a 256-byte row of the ring is complete
+      "  s_cbranch_scc1 L_wr_cross%=\n"
+      "L_wr_crossed%=:\n"
+      "  s_bitcmp1_b32 s53, 7\n"
+      "  s_cbranch_scc0 L_wr_round%=\n"
+      "  s_and_b32 s57, s53, 63\n"                        // a symbol the tables do not resolve: its first-level entry for the caller
+      "  s_nop 0\n"
+      "  v_readlane_b32 s56, %[ev], s57\n"
+      "  s_mov_b32 s55, 0\n"
+      "  s_branch L_wr_out%=\n"
+      // ---- a row is complete: drained here when it is exactly one aligned row and there is nothing to report
+      "L_wr_cross%=:\n"
+      "  s_cmp_gt_u32 s46, s48\n"
+      "  s_cbranch_scc1 L_wr_exit1%=\n"
+      "  s_lshr_b32 s57, s44, 5\n"
+      "  s_add_u32 s57, s57, s45\n"
+      "  s_cmp_gt_u32 s57, s49\n"
+      "  s_cbranch_scc1 L_wr_exit1%=\n"
+      "  s_and_b32 s57, s50, 0xff\n"
+      "  s_cbranch_scc1 L_wr_exit1%=\n"
+      "  s_and_b32 s66, s46, 0xffffff00\n"
+      "  s_sub_u32 s57, s66, s50\n"
+      "  s_cmp_eq_u32 s57, 0x100\n"
+      "  s_cbranch_scc0 L_wr_exit1%=\n"
+      "  s_waitcnt vmcnt(0)\n"
+      "  v_cmpx_ne_u32 vcc, -1, %[faddr]\n"
+      "  ds_write_b8 %[faddr], %[fdata]\n"
+      "  s_mov_b64 exec, -1\n"
+      "  v_mov_b32 %[faddr], -1\n"
+      "  v_mov_b32 %[vpend], -1\n"
+      "  s_and_b32 s57, s50, %[ringmask]\n"
+      "  v_lshl_add_u32 v48, %[lane], 2, s57\n"
+      "  ds_read_b32 v49, v48\n"
+      "  v_lshl_add_u32 v48, %[lane], 2, s50\n"
+      "  s_waitcnt lgkmcnt(0)\n"
+      "  global_store_dword v48, v49, s[42:43]\n"
+      "  s_mov_b32 s50, s66\n"
+      "  s_branch L_wr_crossed%=\n"
+      "L_wr_exit1%=:\n"
+      "  s_mov_b32 s55, 1\n"
+      "  s_branch L_wr_out%=\n"
+      // ---- the window moves by 32 dwords: upper half of cur + lower half of nxt
+      "L_wr_switch%=:\n"
+      "  v_xor_b32 v34, 32, %[lane]\n"
+      "  v_lshlrev_b32 v34, 2, v34\n"
+      "  s_waitcnt vmcnt(0)\n"
+      "  ds_bpermute_b32 v35, v34, %[cur]\n"
+      "  ds_bpermute_b32 v36, v34, %[nxt]\n"
+      "  v_cmp_gt_u32 vcc, 32, %[lane]\n"
+      "  s_add_u32 s45, s45, 32\n"
+      "  s_sub_u32 s44, s44, 0x400\n"
+      "  s_waitcnt lgkmcnt(0)\n"
+      "  v_cndmask_b32 %[cur], v36, v35, vcc\n"
+      "  v_add_u32 v34, s45, %[lane]\n"
+      "  v_lshlrev_b32 v34, 2, v34\n"
+      "  global_load_dword %[nxt], v34, s[40:41] offset:256\n"
+      "  s_branch L_wr_win%=\n"
+      "L_wr_bad%=:\n"
+      "  s_mov_b64 exec, -1\n"
+      "  s_mov_b32 s55, 4\n"
+      "  s_branch L_wr_out%=\n"
+      "L_wr_slow%=:\n"
+      "  s_mov_b64 exec, -1\n"
+      "  s_mov_b32 s55, 5\n"
+      "L_wr_out%=:\n"
+      "  s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+      "  s_nop 1\n"
+      : [code] "={s55}"(code), [e] "={s56}"(e_out), [p] "={s53}"(p_out), [bp] "+{s44}"(bp), [wb] "+{s45}"(wb), [pos] "+{s46}"(pos), [drained] "+{s50}"(drained),
+        [cl] "+{s51}"(carry_len), [cr] "+{s52}"(carry_rec), [cur] "+v"(cur), [nxt] "+v"(nxt), [fdata] "+v"(fdata), [faddr] "+v"(faddr), [vpend] "+v"(vpend),
+        [rec] "=&v"(rec), [nextp] "=&v"(nextp), [ev] "=&v"(ev)
+      : [base] "{s[40:41]}"(base), [out] "{s[42:43]}"(out), [begin] "{s47}"(begin), [end] "{s48}"(end), [limit] "{s49}"(limit), [lane] "v"(lane),
+        [ringmask] "i"(RING - 1), [nearw] "i"(RING - 258), [lutoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_lut)),
+        [dlut] "i"(RING + (int)__builtin_offsetof(WaveLds, dist_lut))
+      : "s54", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "v33", "v34", "v35", "v36", "v37", "v38",
+        "v39", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "vcc", "scc",
+        "memory");
+  bp = uniu(bp);
+  wb = uniu(wb);
+  pos = uniu(pos);
+  drained = uniu(drained);
+  carry_len = uniu(carry_len);
+  carry_rec = uniu(carry_rec);
+  p_out = uniu(p_out);
+  e_out = uniu(e_out);
+  pend_lo = uniu(vpend);
+  return uniu(code);
+}
+
 template <int RING>
 __device__ __forceinline__ uint32_t wide_run(BitReader& br, Out& o, uint32_t& e_out, uint32_t& len_out, uint32_t& d_out) {
   constexpr uint32_t RM = RING - 1, NEARW = RING - 258;
@@ -1028,7 +1277,11 @@ __device__ __forceinline__ uint32_t wide_run(BitReader& br, Out& o, uint32_t& e_
   const uint32_t lane = lane_id();
   uint8_t* ring = wave_ring<RING>();
   const WaveLds* L = wave_lds<RING>();
-  const uint32_t* base = br.base;
+  typedef const __attribute__((address_space(1))) uint32_t* gptr32;  // global_load, not flat_load (a flat load also counts as an LDS operation)
+  typedef const __attribute__((address_space(1))) uint8_t* gptr8;
+  gptr32 base = (gptr32)br.base;
+  gptr8 gout = (gptr8)o.out;
+  uint32_t drained = o.drained;
   auto bperm = [](uint32_t byte_addr, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)byte_addr, (int)v); };
   auto rdl = [](uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); };
   const uint32_t P0 = br.widx * 32u - (uint32_t)br.cnt;  // bit index of the next symbol, from `base`
@@ -1048,6 +1301,43 @@ __device__ __forceinline__ uint32_t wide_run(BitReader& br, Out& o, uint32_t& e_
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   };
   for (;;) {
+    uint32_t rec, nextp, ev;
+#if EXON_WIDE_ASM
+    // ---- the rounds that need nothing special, hand-written (wide_rounds_asm): comes back with
+    //   0 / 1 / 4: as `why` (1: `p` still holds the special flag of the round that crossed the row)
+    //   5: a round this C++ code has to finish from the chain walk on (a source inside the round's own output, or a symbol
+    //      that starts beyond the round's 64 output bytes): rec / nextp / ev are that round's, nothing of it is consumed
+    {
+      uint32_t p_asm = 0, e_asm = 0;
+      const uint32_t code = wide_rounds_asm<RING>(base, gout, bp, wb, pos, drained, carry_len, carry_rec, o.begin, o.end, br.limit, lane, cur, nxt,
+                                                  fdata, faddr, pend_lo, rec, nextp, ev, p_asm, e_asm);
+      if (code == 0) {
+        why = 0;
+        e_out = e_asm;
+        break;
+      }
+      if (code == 4) {
+        why = 4;
+        break;
+      }
+      if (code == 1) {
+        if (pos > o.end || wb + (bp >> 5) > br.limit) {
+          why = 1;
+          break;
+        }
+        complete_far();
+        Out od{o.out, 0, 0, 0, drained};
+        drain_to<RING>(od, pos & ~255u);
+        drained = od.drained;
+        if (p_asm >= 128u) {
+          why = 0;
+          e_out = rdl(ev, p_asm - 128u);
+          break;
+        }
+        continue;
+      }
+    }
+#else
     if (bp >= 1024u) {  // move the window by 32 dwords
       const uint32_t c1 = bperm((lane ^ 32u) << 2, cur), c2 = bperm((lane ^ 32u) << 2, nxt);
       cur = lane < 32u ? c1 : c2;
@@ -1061,7 +1351,7 @@ __device__ __forceinline__ uint32_t wide_run(BitReader& br, Out& o, uint32_t& e_
     const uint32_t d0 = bperm(a, cur), d1 = bperm(a + 4u, cur), d2 = bperm(a + 8u, cur);
     const uint32_t wlo = __builtin_amdgcn_alignbit(d1, d0, t & 31u), whi = __builtin_amdgcn_alignbit(d2, d1, t & 31u);
     // ---- the symbol that would start there
-    const uint32_t ev = L->lit_lut[wlo & ((1u << LIT_BITS) - 1u)];
+    ev = L->lit_lut[wlo & ((1u << LIT_BITS) - 1u)];
     const uint32_t l1 = ev & 15u, xb = (ev >> 4) & 15u, lx = l1 + xb;
     const uint32_t exv = __builtin_amdgcn_ubfe(wlo, l1, xb);
     const uint32_t w2lo = (uint32_t)((((uint64_t)whi << 32) | wlo) >> lx);
@@ -1072,10 +1362,11 @@ __device__ __forceinline__ uint32_t wide_run(BitReader& br, Out& o, uint32_t& e_
     const uint32_t dm1 = (dv >> 16) + __builtin_amdgcn_ubfe(w2lo, dl, dxb) - 1u;
     const uint32_t tot = is_lit ? l1 : lx + dl + dxb;
     // record: bits 0-8 output bytes; literal: bit 31 + the byte in bits 16-23; match: distance - 1 in bits 16-30
-    uint32_t rec = is_lit ? (0x80000001u | (ev & 0x00FF0000u)) : (((ev >> 16) + exv) | (dm1 << 16));
+    rec = is_lit ? (0x80000001u | (ev & 0x00FF0000u)) : (((ev >> 16) + exv) | (dm1 << 16));
     const bool ok = is_lit || mok;
     if (!ok) rec = 0;
-    const uint32_t nextp = ok ? lane + tot : 128u + lane;
+    nextp = ok ? lane + tot : 128u + lane;
+#endif
     // ---- the chain; byte lane b keeps the record of the last symbol that starts at or before output byte b
     uint32_t p = 0, vo = carry_len, lastrec = carry_rec, rb = carry_rec;
     while (p < 64u && vo < 64u) {
@@ -1105,7 +1396,7 @@ __device__ __forceinline__ uint32_t wide_run(BitReader& br, Out& o, uint32_t& e_
       // a source inside this round's own output: produce the bytes in dependency order
       complete_far();
       if (valid && blit) ring[ra] = (uint8_t)(rb >> 16);
-      if (bfar) ring[ra] = o.out[src1 - 1u];
+      if (bfar) ring[ra] = gout[src1 - 1u];
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       const uint32_t need = bnear && (uint32_t)dm1b < lane ? lane - (uint32_t)dm1b : 0u;  // bytes of the round this one waits for
       for (uint32_t D = 0; D < nb;) {
@@ -1127,7 +1418,7 @@ __device__ __forceinline__ uint32_t wide_run(BitReader& br, Out& o, uint32_t& e_
       if (bnear) ring[ra] = nv;
       if (__any(bfar)) {
         uint32_t fnew = 0;
-        if (bfar) fnew = o.out[src1 - 1u];  // below `drained`: in HBM already
+        if (bfar) fnew = gout[src1 - 1u];  // below `drained`: in HBM already
         complete_far();                      // the previous round's, under this load
         fdata = fnew;
         faddr = bfar ? ra : ~0u;
@@ -1144,9 +1435,15 @@ __device__ __forceinline__ uint32_t wide_run(BitReader& br, Out& o, uint32_t& e_
     carry_len = vo - nb;
     carry_rec = lastrec;
     bp += consumed;
-    if (crossed) {
-      why = 1;
-      break;
+    if (crossed) {  // rows of the ring are complete: drain them here unless there is something to report (the caller's business)
+      if (pos > o.end || wb + (bp >> 5) > br.limit) {
+        why = 1;
+        break;
+      }
+      if (pend_lo < (pos & ~255u)) complete_far();
+      Out od{o.out, 0, 0, 0, drained};
+      drain_to<RING>(od, pos & ~255u);
+      drained = od.drained;
     }
     if (special) {
       why = 0;
@@ -1155,6 +1452,7 @@ __device__ __forceinline__ uint32_t wide_run(BitReader& br, Out& o, uint32_t& e_
     }
   }
   complete_far();
+  o.drained = drained;
   if (why != 4 && carry_len != 0) {  // the rest of a match: the caller copies it (any length, any distance)
     why = 2;
     len_out = carry_len;
@@ -1223,6 +1521,7 @@ __device__ __noinline__ SymResult decode_symbols(BitReader br, Out o, int vflav)
       why = uniu(wide_run<RING>(br, o, e, len, d));
       br.make_uniform();
       o.pos = uniu(o.pos);
+      o.drained = uniu(o.drained);
       e = uniu(e);
       len = uniu(len);
       d = uniu(d);

@@ -7,7 +7,7 @@ if [ -z "$3" ]; then
   echo "== tests, flavor 3" >> $out/wide.log
   EXON_HIP_INFLATE_PAR=0 EXON_HIP_INFLATE_FLAVOR=3 timeout 900 python -m pytest tests/test_gpu_inflate.py -x -q -m gpu -k "not fresh_process" -p no:cacheprovider 2>&1 | tail -15 >> $out/wide.log
 fi
-for spec in "vcf $rows" "bam 5000000" "fastq 5000000"; do
+for spec in "vcf $rows" "bam 5000000" "fastq 2500000"; do
   for f in 1 3; do
     echo "== $spec flavor $f" >> $out/wide.log
     EXON_HIP_INFLATE_PAR=0 EXON_HIP_INFLATE_FLAVOR=$f timeout 300 python tools/time_inflate.py $spec 2>&1 | grep -E "crc=0" >> $out/wide.log

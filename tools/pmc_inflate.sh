@@ -1,14 +1,14 @@
 #!/bin/bash
-# rocprofv3 PMC passes over the serial inflate kernel (one resident launch of VCF text): tools/pmc_inflate.sh <out> [flavor]
+# rocprofv3 PMC passes over the serial inflate kernel (one resident launch): tools/pmc_inflate.sh <out> [flavor] [kind rows]
 # (separate --pmc passes with --kernel-trace only, as the MI355X guide prescribes)
-out=$1; flavor=${2:-0}
+out=$1; flavor=${2:-0}; kind=${3:-vcf}; rows=${4:-2e7}
 export TMPDIR=/tmp EXON_HIP_INFLATE_PAR=0 EXON_HIP_INFLATE_FLAVOR=$flavor
 mkdir -p $out
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU" "SQ_INSTS_BRANCH SQ_IFETCH SQ_WAIT_INST_LDS SQ_WAVES" "GRBM_GUI_ACTIVE SQ_CYCLES SQ_INSTS_SENDMSG SQ_IFETCH_LEVEL"; do
   n=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  timeout 300 rocprofv3 --pmc $grp --kernel-trace -d $out/tmp_$n -o p --output-format csv -- python tools/time_inflate.py vcf 2e7 > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $grp --kernel-trace -d $out/tmp_$n -o p --output-format csv -- python tools/time_inflate.py $kind $rows > /dev/null 2>&1
   f=$(find $out/tmp_$n -name "*counter_collection.csv" | head -1)
-  python3 - "$f" >> $out/pmc_flavor$flavor.txt <<'PY'
+  python3 - "$f" >> $out/pmc_${kind}_flavor$flavor.txt <<'PY'
 import csv,sys,collections
 acc=collections.defaultdict(float); n=collections.Counter()
 try:
@@ -22,4 +22,4 @@ for k in sorted(acc): print(k[1], "launches", n[k], "per launch", acc[k]/n[k])
 PY
   rm -rf $out/tmp_$n
 done
-cat $out/pmc_flavor$flavor.txt
+cat $out/pmc_${kind}_flavor$flavor.txt
