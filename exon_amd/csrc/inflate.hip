@@ -1045,6 +1045,15 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
   uint32_t vpend = pend_lo;
   asm volatile(
       "  v_add_u32 v60, 0x80, %[lane]\n"                 // 128 + lane: where the chain goes from a symbol the tables do not resolve
+      // lane q (1..15): first canonical code / number of codes / symbols of shorter lengths, of literal/length codes q bits long
+      "  v_and_b32 v48, 15, %[lane]\n"
+      "  v_lshlrev_b32 v48, 1, v48\n"
+      "  ds_read_u16 v61, v48 offset:%[firstoff]\n"
+      "  ds_read_u16 v62, v48 offset:%[countoff]\n"
+      "  ds_read_u16 v63, v48 offset:%[offsoff]\n"
+      "  v_cmp_gt_u32 vcc, 16, %[lane]\n"
+      "  s_waitcnt lgkmcnt(0)\n"
+      "  v_cndmask_b32 v62, 0, v62, vcc\n"
       "L_wr_round%=:\n"
       "  s_cmpk_lt_u32 s44, 0x400\n"
       "  s_cbranch_scc0 L_wr_switch%=\n"
@@ -1110,6 +1119,9 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  v_cndmask_b32 v53, v53, v54, vcc\n"
       "  s_cmp_lt_u32 s53, 64\n"
       "  s_cbranch_scc1 L_wr_walk%=\n"
+      "  s_bitcmp1_b32 s53, 7\n"
+      "  s_cbranch_scc1 L_wr_long%=\n"
+      "L_wr_postwalk%=:\n"
       // a symbol that STARTS beyond the 64 output bytes of the round was walked over: the careful walk of the C++ round
       "  v_readfirstlane_b32 s65, v52\n"
       "  s_and_b32 s57, s54, 0x1ff\n"
@@ -1239,6 +1251,45 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  v_lshlrev_b32 v34, 2, v34\n"
       "  global_load_dword %[nxt], v34, s[40:41] offset:256\n"
       "  s_branch L_wr_win%=\n"
+      // ---- the chain stopped at a symbol the first-level table does not resolve.  A literal with a code longer than the table
+      // (7 % of the symbols of BAM payloads) is decoded here and the walk goes on: all candidate lengths at once -- lane q takes the
+      // first q bits as a code of that length and tests it against the codes of its length; codes are prefix-free, so at most one
+      // length matches (decode_long's method).  Anything else (end of block, a long length code, no such code) stays the caller's.
+      "L_wr_long%=:\n"
+      "  s_and_b32 s57, s53, 63\n"
+      "  v_and_b32 v49, 15, %[lane]\n"
+      "  v_readlane_b32 s66, %[ev], s57\n"
+      "  v_sub_u32 v49, 32, v49\n"
+      "  s_cmp_eq_u32 s66, 0\n"
+      "  s_cbranch_scc0 L_wr_postwalk%=\n"
+      "  v_readlane_b32 s66, v38, s57\n"
+      "  s_nop 1\n"
+      "  v_bfrev_b32 v48, s66\n"
+      "  v_lshrrev_b32 v48, v49, v48\n"
+      "  v_sub_u32 v48, v48, v61\n"
+      "  v_cmp_lt_u32 vcc, v48, v62\n"
+      "  v_add_u32 v48, v48, v63\n"
+      "  s_ff1_i32_b64 s66, vcc\n"
+      "  s_cmp_lt_i32 s66, 0\n"
+      "  s_cbranch_scc1 L_wr_postwalk%=\n"
+      "  v_readlane_b32 s68, v48, s66\n"
+      "  s_lshl_b32 s68, s68, 1\n"
+      "  v_mov_b32 v49, s68\n"
+      "  ds_read_u16 v49, v49 offset:%[symoff]\n"
+      "  s_waitcnt lgkmcnt(0)\n"
+      "  v_readfirstlane_b32 s68, v49\n"
+      "  s_cmp_lt_u32 s68, 0x100\n"
+      "  s_cbranch_scc0 L_wr_postwalk%=\n"
+      "  s_lshl_b32 s68, s68, 16\n"
+      "  s_or_b32 s54, s68, 0x80000001\n"                // the literal's record, and the walk's step for it
+      "  v_cmp_le_u32 vcc, v52, %[lane]\n"
+      "  v_mov_b32 v54, s54\n"
+      "  v_add_u32 v52, 1, v52\n"
+      "  s_add_u32 s53, s57, s66\n"
+      "  v_cndmask_b32 v53, v53, v54, vcc\n"
+      "  s_cmp_lt_u32 s53, 64\n"
+      "  s_cbranch_scc1 L_wr_walk%=\n"
+      "  s_branch L_wr_postwalk%=\n"
       "L_wr_bad%=:\n"
       "  s_mov_b64 exec, -1\n"
       "  s_mov_b32 s55, 4\n"
@@ -1254,9 +1305,11 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
         [rec] "=&v"(rec), [nextp] "=&v"(nextp), [ev] "=&v"(ev)
       : [base] "{s[40:41]}"(base), [out] "{s[42:43]}"(out), [begin] "{s47}"(begin), [end] "{s48}"(end), [limit] "{s49}"(limit), [lane] "v"(lane),
         [ringmask] "i"(RING - 1), [nearw] "i"(RING - 258), [lutoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_lut)),
-        [dlut] "i"(RING + (int)__builtin_offsetof(WaveLds, dist_lut))
+        [dlut] "i"(RING + (int)__builtin_offsetof(WaveLds, dist_lut)), [firstoff] "i"(RING + (int)__builtin_offsetof(WaveLds, first)),
+        [countoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_count)), [offsoff] "i"(RING + (int)__builtin_offsetof(WaveLds, offs)),
+        [symoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_sym))
       : "s54", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "v33", "v34", "v35", "v36", "v37", "v38",
-        "v39", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "vcc", "scc",
+        "v39", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "vcc", "scc",
         "memory");
   bp = uniu(bp);
   wb = uniu(wb);
