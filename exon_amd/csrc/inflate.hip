@@ -1337,9 +1337,10 @@ __device__ __forceinline__ uint32_t wide_run(BitReader& br, Out& o, uint32_t& e_
   uint32_t drained = o.drained;
   auto bperm = [](uint32_t byte_addr, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)byte_addr, (int)v); };
   auto rdl = [](uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); };
-  const uint32_t P0 = br.widx * 32u - (uint32_t)br.cnt;  // bit index of the next symbol, from `base`
-  uint32_t wb = (P0 >> 5) & ~31u;
-  uint32_t bp = P0 - wb * 32u;
+  // the next symbol's bit: `back` dwords behind the reader's next dword (no absolute bit index: it would pass 2^32 at 512 MB)
+  const uint32_t back = ((uint32_t)br.cnt + 31u) >> 5, dw0 = br.widx - back;
+  uint32_t wb = dw0 & ~31u;
+  uint32_t bp = (dw0 - wb) * 32u + (back * 32u - (uint32_t)br.cnt);
   uint32_t cur = base[wb + lane];
   uint32_t nxt = base[wb + 64u + lane];
   uint32_t pos = o.pos;
@@ -2409,7 +2410,7 @@ __global__ __launch_bounds__(64 * INF_WAVES, 8) EXON_INFLATE_WPE_ATTR __attribut
 
 // The wide symbol loop (wide_run) as its own kernel: its register budget is not the serial loops'
 template <int RING>
-__global__ __launch_bounds__(64 * INF_WAVES) void k_inflate_w(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks, int n_blocks, uint8_t* out,
+__global__ __launch_bounds__(64 * INF_WAVES, 8) __attribute__((amdgpu_num_sgpr(72))) void k_inflate_w(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks, int n_blocks, uint8_t* out,
                                                               int* __restrict__ status) {
   const int b = uni((int)(blockIdx.x * INF_WAVES + (threadIdx.x >> 6)));
   if (b >= n_blocks) return;
@@ -2758,20 +2759,17 @@ extern "C" int exon_hip_bgzf_forget_stream(void* stream) {
   return EXON_HIP_OK;
 }
 
-// Which hand-written symbol loop a launch runs: 1 the software-pipelined vector-unit loop with deferred far copies
-// (symbol_run_v), 0 round 1's scalar loop (symbol_run), 2 both side by side.  EXON_HIP_INFLATE_FLAVOR forces one; otherwise
-// the caller's hint, otherwise 1.  Resident launches: VCF text +10 %, BAM +9 %, FASTQ +15 % for the vector loop
-// (profiles/r4_inflate_flavor_v3.log).  In the file pipelines the inflate of slab i+1 runs beside the parse kernels of slab i:
-// .vcf.gz 70.6 -> 63 ms, .fastq.gz 175 -> 155 ms with the vector loop.  The BAM pipeline first measured 69.6 -> 71 ms and kept
-// the scalar loop (profiles/r4_pipes_by_flavor.log); with 27 instead of 26 resident members per CU (the code lengths overlaid
-// on the literal table) and the record chain's proof done in parallel the vector loop wins there too (BAM 73.5 -> 67.3-68.9
-// ms, BCF 43.6 -> 40.8-41.8 on one box: profiles/r4_bam_chain_check_ab.log), so nothing hints the scalar loop any more.
+// Which symbol loop a launch runs: 3 the wide loop (wide_run: 64 bit offsets per round, round 5), 1 the software-pipelined
+// vector-unit loop with deferred far copies (symbol_run_v, round 4), 0 round 1's scalar loop (symbol_run), 2 loops 0 and 1 side by
+// side.  EXON_HIP_INFLATE_FLAVOR forces one; otherwise the caller's hint, otherwise 3.  One resident launch, same box
+// (profiles/r5_inflate_wide_v3_32waves.log): VCF text 113 -> 178 GB/s, BAM payloads 102 -> 127, FASTQ 81 -> 82; the file pipelines
+// .vcf.gz 59 -> 41 ms, BAM 59 -> 48-51 ms, .fastq.gz 119 -> 115-120 ms.  (Round 4's history of loops 0 / 1 / 2: DESIGN.md section 7e.)
 static int inflate_flavor(int hint) {
   static const int forced = [] {
     const char* e = getenv("EXON_HIP_INFLATE_FLAVOR");
     return e && e[0] >= '0' && e[0] <= '3' ? e[0] - '0' : -1;
   }();
-  return forced >= 0 ? forced : hint >= 0 && hint <= 3 ? hint : 1;
+  return forced >= 0 ? forced : hint >= 0 && hint <= 3 ? hint : 3;
 }
 
 hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const exon_hip_bgzf_block* d_blocks, int n_blocks,

@@ -205,15 +205,34 @@ def test_lane_parallel_block_decoder_in_a_fresh_process():
 
 @pytest.mark.gpu
 def test_every_symbol_loop_in_a_fresh_process():
-    """EXON_HIP_INFLATE_FLAVOR picks the hand-written symbol loop of the serial kernel (read once per process): 1 = the
-    software-pipelined vector-unit loop with deferred far copies (default), 0 = the scalar loop, 2 = both side by side.  Small
+    """EXON_HIP_INFLATE_FLAVOR picks the symbol loop of the serial kernels (read once per process): 3 = the wide loop (64 bit
+    offsets per round; default since round 5), 1 = the software-pipelined vector-unit loop with deferred far copies, 0 = the scalar
+    loop, 2 = loops 0 and 1 side by side.  Small
     launches take the lane-parallel decoder by default, so the serial kernel is forced (EXON_HIP_INFLATE_PAR=0) and this module's
     cases -- byte equality with zlib, CRC verification, corruption reports -- rerun under each loop."""
     import subprocess
     import sys
-    for flavor in ("0", "1", "2"):
+    for flavor in ("0", "1", "2", "3"):
         env = dict(os.environ, EXON_HIP_INFLATE_PAR="0", EXON_HIP_INFLATE_FLAVOR=flavor)
         r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "--timeout", "300", "-p", "no:cacheprovider",
                             os.path.join(ROOT, "tests", "test_gpu_inflate.py"), "-k", "not fresh_process"], env=env, capture_output=True, text=True,
                            timeout=1500)
         assert r.returncode == 0, f"flavor {flavor}\n" + r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_gpu_inflate_compressed_slab_beyond_512_mib(ctx):
+    """Members whose compressed bytes lie beyond 2^32 BITS of the slab (512 MiB): a symbol loop that keeps an absolute 32-bit bit
+    index goes wrong there (round 5's wide loop did, on a 634 MB BAM slab).  One noisy text member repeated 12 000 times (~560 MB
+    compressed); the device verifies every member's CRC-32, the host compares the first, one past the boundary, and the last."""
+    rng = np.random.default_rng(11)
+    a = np.frombuffer(vcf_like(1500, seed=4)[:65000], np.uint8).copy()
+    noise = rng.random(a.size) < 0.55
+    a[noise] = rng.integers(0, 256, int(noise.sum()), dtype=np.uint8)  # ~47 KB per member at level 6: matches AND long literal codes
+    data = a.tobytes()
+    blk = bgzf_block(data, 6)
+    n = (560 << 20) // len(blk) + 1
+    got, _ = ctx.bgzf_inflate(blk * n, verify_crc=True)
+    assert got.size == n * len(data)
+    for k in (0, (512 << 20) // len(blk) + 1, n - 1):
+        assert got[k * len(data):(k + 1) * len(data)].tobytes() == data, k
