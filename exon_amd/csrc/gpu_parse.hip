@@ -298,7 +298,8 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
       // POS
       {
         int64_t v = 0;
-        const unsigned pb = fbeg(1), pn = fend(1) - fbeg(1);
+        unsigned pb = fbeg(1), pn = fend(1) - fbeg(1);
+        if (pn && text[pb] == '+') ++pb, --pn;  // usize::from_str takes one leading '+' (host/formats.h parse_pos)
         bool ok = pn > 0;
         if (pn <= 16 && pb + 16u <= n_total) {  // the digits from two (unaligned) 8-byte loads instead of a chain of byte loads
           uint64_t w[2];

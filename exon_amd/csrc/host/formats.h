@@ -289,7 +289,11 @@ class VCFArrayBuilder : public ExonArrayBuilder {
     return (int32_t)v;
   }
 
+  // Rust's usize::from_str -- what noodles-vcf 0.70 parses POS with: the crate has no number parser of its own among its
+  // dependencies (the reference's Cargo.lock:3915-3930), and core's FromStr for unsigned integers takes an optional '+' and then
+  // digits only -- so "+5" is 5, while "-5", "", "+", " 7", "1e3" are errors
   static bool parse_pos(const char* p, size_t n, int64_t* out) {
+    if (n && p[0] == '+') ++p, --n;
     if (n == 0 || n > 18) return false;
     int64_t v = 0;
     for (size_t i = 0; i < n; ++i) {

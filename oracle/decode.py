@@ -35,6 +35,7 @@ def decode_vcf(path):
     contigs, filt_hdr, info_hdr = [], [], {}
     rows = dict(chrom=[], pos=[], qual=[], filter=[], info=[])
     for line in text.split("\n"):
+        line = line[:-1] if line.endswith("\r") else line  # the line reader drops a CR in front of the LF (noodles' read_line)
         if not line:
             continue
         if line.startswith("##"):
@@ -52,9 +53,12 @@ def decode_vcf(path):
         rows["chrom"].append(c[0])
         # noodles-vcf lazy record: POS "0" (telomere) has no variant_start -> None; anything else must parse as an
         # unsigned integer or `record.variant_start().transpose()?` fails (lazy_array_builder.rs:163-168)
-        if not c[1].isascii() or not c[1].isdigit():
+        # (usize::from_str: one optional '+', then digits -- noodles-vcf 0.70 has no number parser among its dependencies,
+        # Cargo.lock:3915-3930, so POS goes through core's FromStr)
+        digits = c[1][1:] if c[1].startswith("+") else c[1]
+        if not digits.isascii() or not digits.isdigit():
             raise ValueError(f"invalid POS {c[1]!r}")
-        rows["pos"].append(int(c[1]) or None)
+        rows["pos"].append(int(digits) or None)
         rows["qual"].append(None if c[5] == "." else np.float32(c[5]))
         rows["filter"].append([] if c[6] == "." else c[6].split(";"))
         if c[7] == ".":

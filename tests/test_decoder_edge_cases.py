@@ -31,7 +31,7 @@ def write(tmp_path, body, name="t.vcf"):
     return p
 
 
-@pytest.mark.parametrize("pos", [".", "12x", "", "-5", "1e3", " 7"])
+@pytest.mark.parametrize("pos", [".", "12x", "", "-5", "1e3", " 7", "+", "++5", "+-5", "5+"])
 def test_malformed_pos_is_an_error_like_in_the_reference(tmp_path, pos):
     p = write(tmp_path, f"1\t5\t.\tA\tC\t1\tPASS\tAF=0.5\n1\t{pos}\t.\tA\tC\t1\tPASS\tAF=0.5\n")
     with pytest.raises(exon_amd.ExonHipError, match="POS"):
@@ -42,6 +42,29 @@ def test_malformed_pos_is_an_error_like_in_the_reference(tmp_path, pos):
     assert sum(len(b) for b in rows_of(p, region="2:1-100")) == 0
     with pytest.raises(exon_amd.ExonHipError, match="POS"):
         rows_of(p, region="1:1-100")
+
+
+def test_pos_with_a_leading_plus_is_a_number_as_for_rusts_from_str(tmp_path):
+    """`record.variant_start()` (lazy_array_builder.rs:163-168) parses POS with Rust's usize::from_str: noodles-vcf 0.70.0 -- the
+    version the reference's Cargo.lock pins (lines 3915-3930) -- depends on no number parser (futures, indexmap, memchr, noodles-*,
+    percent-encoding, pin-project-lite, tokio), and core's FromStr for unsigned integers accepts ONE leading '+' ("+5" -> 5, "+0" ->
+    0, i.e. NULL here) and nothing else in front of the digits.  Host decoder, device decoder (tests/test_gpu_vcf_parse.py has the
+    device twin) and oracle agree."""
+    p = write(tmp_path, "1\t+5\t.\tA\tC\t1\tPASS\tAF=0.5\n1\t+0\t.\tA\tC\t1\tPASS\tAF=0.5\n1\t+0012\t.\tA\tC\t1\tPASS\tAF=0.5\n")
+    assert rows_of(p)[0].field(1).to_pylist() == [5, None, 12]
+    assert decode.decode_vcf(str(p))["pos"] == [5, None, 12]
+    assert sum(len(b) for b in rows_of(p, region="1:5-5")) == 1
+
+
+def test_crlf_lines_lose_their_cr_in_product_and_oracle(tmp_path):
+    """A CRLF-terminated VCF: the CR is the line terminator's, not the last INFO value's (product and oracle alike; round 4's
+    oracle kept it inside the value)."""
+    p = tmp_path / "crlf.vcf"
+    p.write_bytes((HEAD + "1\t5\t.\tA\tC\t1.5\tPASS\tAF=0.25\n2\t9\t.\tA\tC\t.\tq10\tAF=0.5\n").replace("\n", "\r\n").encode())
+    b = rows_of(p, info_field="AF")[0]
+    assert b.field(1).to_pylist() == [5, 9] and [np.float32(x) for x in b.field(4).to_pylist()] == [np.float32(0.25), np.float32(0.5)]
+    v = decode.decode_vcf(str(p))
+    assert v["pos"] == [5, 9] and [i["AF"] for i in v["info"]] == ["0.25", "0.5"] and v["filter"] == [["PASS"], ["q10"]]
 
 
 def test_pos_zero_is_null_in_vcf_and_oracle(tmp_path):

@@ -133,6 +133,19 @@ def test_gpu_parse_undecidable_rows_are_counted(ctx):
     p.close()
 
 
+def test_gpu_parse_pos_takes_one_leading_plus(ctx):
+    """POS through Rust's usize::from_str (tests/test_decoder_edge_cases.py has the evidence): "+5" is 5 and "+0" NULL ON THE
+    DEVICE, no undecided row; "++5", "+" and "-5" are not numbers: undecided, the host reports them."""
+    text = (b"1\t+5\t.\tA\tC\t1\tPASS\tAF=0.5\n1\t+0\t.\tA\tC\t1\tPASS\tAF=0.5\n1\t+0012\t.\tA\tC\t1\tPASS\tAF=0.5\n")
+    p = exon_amd.VCFParser(ctx, ["1"], info_field="AF")
+    res = p.parse_host(text)
+    assert res["n_rows"] == 3 and res["n_undecided"] == 0
+    assert res["pos"].tolist()[0] == 5 and res["pos"].tolist()[2] == 12 and bits(res["pos_valid"], 3).tolist() == [True, False, True]
+    res = p.parse_host(b"1\t++5\t.\tA\tC\t1\tPASS\tAF=0.5\n1\t+\t.\tA\tC\t1\tPASS\tAF=0.5\n1\t-5\t.\tA\tC\t1\tPASS\tAF=0.5\n")
+    assert res["n_rows"] == 3 and res["n_undecided"] == 3
+    p.close()
+
+
 def _k4_through_scan(ctx, path, gpu_parse, info_field="AF", fallback=False, thr=0.01):
     scan = exon_amd.Scan(path, "vcf", info_field=info_field, gpu_parse=gpu_parse)
     plan = ctx.plan_cmp_avg_by_group(">", thr, 64, columns=(4, 2, 3))
