@@ -1551,400 +1551,6 @@ __global__ __launch_bounds__(1024) void k4_tail_aggregate(const uint2* __restric
   }
 }
 
-// ---- tier 3 partitioned INSIDE the main kernel (round 4; up to K4_BIN_MAX_RANGES id ranges = 528 k ids) ---------------------
-// The pipeline above moves a tier-3 row four times (compact 8 B out, scatter 8 B in + 8 B out, aggregate 8 B in), each pass at
-// 4-5.5 TB/s: only dropping a pass helps.  Here the main kernel writes a tile's tier-3 records ALREADY GROUPED BY ID RANGE into
-// its workgroup's region, one segment per 8192-row tile, and k4_tail_aggregate_runs reads every range's run of every tile
-// straight from there: 16 B per tier-3 row instead of 32, no scatter launch.  Per tile: every tier-3 row draws its rank within
-// (range, counter copy) from a returning LDS atomic on a shared histogram; ONE workgroup barrier; every wave scans the histogram
-// for itself (256 counters, four per lane) into its own table of exclusive offsets and stores its rows at segment base +
-// offset + rank.  The histogram is triple-buffered by tile (the one used two tiles ago is cleared behind the barrier, when
-// nobody can still be scanning it), the next tile's columns are requested before the barrier, and wave 0 writes the tile's
-// descriptor: where each range's run starts in the region.
-constexpr int K4_BIN_MAX_RANGES = 64;  // 64 x 8192 ids: one lane of wave 0 per range
-constexpr int K4_BIN_COUNTERS = 256;  // ranges x counter copies per histogram (copies: 64 lanes on a dozen counters serialise)
-__host__ __device__ static inline int k4_bin_copies_log2(int n_ranges) { return n_ranges <= 16 ? 4 : n_ranges <= 32 ? 3 : 2; }
-
-template <bool YI>
-__global__ __launch_bounds__(1024) void k4_main_binned(
-    const float* __restrict__ x, const uint8_t* __restrict__ xvalid, const float* __restrict__ y, const uint8_t* __restrict__ yvalid,
-    const int32_t* __restrict__ gid, int64_t n, int32_t klo, int32_t khi, int32_t negate, int32_t keymask, int32_t NG, int32_t NL,
-    unsigned long long* __restrict__ partials, int* __restrict__ status, const uint8_t* __restrict__ ones, const K4Tail tail,
-    unsigned* __restrict__ tile_desc) {
-  using S = ShapeBigJ2;
-  constexpr int G = K4_OVF_REGS, J = S::J, THREADS = S::THREADS, WAVES = ShapeOf<S>::WAVES, WT = ShapeOf<S>::WAVE_TILE, TILE = ShapeOf<S>::TILE;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double sum[G];
-  unsigned cnn[G], crow[G];
-#pragma unroll
-  for (int k = 0; k < G; ++k) {
-    sum[k] = 0.0;
-    cnn[k] = 0;
-    crow[k] = 0;
-  }
-  unsigned prow = 0, pnn = 0;  // 4 x 8-bit row counters
-  unsigned gmax = 0;
-  extern __shared__ K4Entry k4_ovf[];  // tier-2 table: NO entries + 64 per-lane dummies, then the binning tables
-  const int NO = NL - G, NOD = NO + 64;
-  unsigned* bin_hist = reinterpret_cast<unsigned*>(k4_ovf + NOD);     // [3][K4_BIN_COUNTERS]
-  unsigned* bin_excl = bin_hist + 3 * K4_BIN_COUNTERS + wave * K4_BIN_COUNTERS;  // this wave's exclusive offsets
-  for (int i = threadIdx.x; i < NOD; i += THREADS) {
-    k4_ovf[i].sum = 0.0;
-    k4_ovf[i].cnn = 0;
-    k4_ovf[i].crow = 0;
-  }
-  for (int i = threadIdx.x; i < 3 * K4_BIN_COUNTERS; i += THREADS) bin_hist[i] = 0;
-  __syncthreads();
-  const unsigned dummy = (unsigned)(NO + lane);
-  const int n_ranges = (NG - NL + K4_TAIL_RANGE - 1) / K4_TAIL_RANGE;
-  const int cl = k4_bin_copies_log2(n_ranges);
-  const unsigned copy = (unsigned)lane & ((1u << cl) - 1u);
-  const unsigned span = (unsigned)(NG - NL);
-  const unsigned cap_wg = (unsigned)(((n / TILE + gridDim.x - 1) / gridDim.x) * TILE);
-  uint2* const region = tail.rec + (size_t)blockIdx.x * cap_wg;
-
-  auto passes = [&](float xf, unsigned xv) -> unsigned {
-    const int32_t bx = __float_as_int(xf);
-    const int32_t kx = bx ^ ((bx >> 31) & keymask);
-    const unsigned inr = unsigned(kx >= klo) & unsigned(kx <= khi);
-    return xv & (inr ^ (unsigned)negate);
-  };
-  auto ydbl = [&](float yf) -> double { return YI ? (double)__float_as_int(yf) : (double)yf; };
-  auto row = [&](unsigned pass, float yf, int32_t g, unsigned yv) {
-    unsigned yq = pass & yv;
-    gmax = max(gmax, (unsigned)g);
-    const unsigned in_regs = unsigned((unsigned)g < (unsigned)G);
-    pass &= in_regs;
-    yq &= in_regs;
-    const unsigned sh = ((unsigned)g & 3u) * 8u;
-    prow += pass << sh;
-    pnn += yq << sh;
-    const int32_t gq = yq ? g : -1;
-    const double yd = ydbl(yf);
-#pragma unroll
-    for (int k = 0; k < G; ++k) sum[k] += (gq == k) ? yd : 0.0;
-  };
-  auto row_lds = [&](unsigned pass, float yf, int32_t g, unsigned yv) {
-    const unsigned in2 = pass & unsigned((unsigned)g - (unsigned)G < (unsigned)NO);
-    K4Entry* e = &k4_ovf[in2 ? (unsigned)g - (unsigned)G : dummy];
-    atomicAdd(&e->crow, 1u);
-    atomicAdd(&e->cnn, in2 & yv);
-    atomicAdd(&e->sum, (in2 & yv) ? ydbl(yf) : 0.0);
-  };
-  int uni_skip = tail.no_uniform_test ? 0x7FFFFFFF : 0;
-  auto rows4_uniform = [&](int kw, unsigned p0, unsigned p1, unsigned p2, unsigned p3, float4 y4, unsigned yv) {
-    if ((unsigned)kw - (unsigned)G >= (unsigned)NO) return;
-    const unsigned n0 = p0 & (yv >> 0 & 1), n1 = p1 & (yv >> 1 & 1), n2 = p2 & (yv >> 2 & 1), n3 = p3 & (yv >> 3 & 1);
-    const unsigned rows = (unsigned)(__popcll(__ballot(p0 != 0)) + __popcll(__ballot(p1 != 0)) + __popcll(__ballot(p2 != 0)) + __popcll(__ballot(p3 != 0)));
-    const unsigned nn = (unsigned)(__popcll(__ballot(n0 != 0)) + __popcll(__ballot(n1 != 0)) + __popcll(__ballot(n2 != 0)) + __popcll(__ballot(n3 != 0)));
-    const double tot = wave_sum(((n0 ? ydbl(y4.x) : 0.0) + (n1 ? ydbl(y4.y) : 0.0)) + ((n2 ? ydbl(y4.z) : 0.0) + (n3 ? ydbl(y4.w) : 0.0)));
-    if (lane == 0 && rows != 0) {
-      K4Entry* e = &k4_ovf[(unsigned)kw - (unsigned)G];
-      atomicAdd(&e->crow, rows);
-      atomicAdd(&e->cnn, nn);
-      atomicAdd(&e->sum, tot);
-    }
-  };
-  auto row_tail = [&](unsigned pass, float yf, int32_t g, unsigned yv) {  // remainder rows only: global atomics
-    if (pass && (unsigned)g >= (unsigned)NL && (unsigned)g < (unsigned)NG) {
-      atomicAdd(&tail.counts[NG + g], 1ull);
-      if (yv) {
-        atomicAdd(&tail.counts[g], 1ull);
-        atomicAdd(&tail.sums[g], ydbl(yf));
-      }
-    }
-  };
-  auto spill = [&]() {
-#pragma unroll
-    for (int k = 0; k < G; ++k) {
-      crow[k] += (prow >> (8 * k)) & 0xFFu;
-      cnn[k] += (pnn >> (8 * k)) & 0xFFu;
-    }
-    prow = 0;
-    pnn = 0;
-  };
-
-  const int64_t ntiles = n / TILE;
-  float4 xs[J], ys[J];
-  int4 gs[J];
-  unsigned xm[J], ym[J];
-  auto load_tile = [&](int64_t tile, float4* lx, float4* ly, int4* lg, unsigned* lxm, unsigned* lym) {
-    const int64_t wbase = tile * TILE + (int64_t)wave * WT;
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      const int64_t r = wbase + j * 256 + lane * 4;
-      lx[j] = ld16<float4>(x + r);
-      ly[j] = ld16<float4>(y + r);
-      lg[j] = ld16<int4>(gid + r);
-      lxm[j] = valid4_ones(xvalid, ones, wbase, j, lane);
-      lym[j] = valid4_ones(yvalid, ones, wbase, j, lane);
-    }
-  };
-  int64_t tile = blockIdx.x;
-  if (tile < ntiles) load_tile(tile, xs, ys, gs, xm, ym);
-  unsigned seg_base = 0;   // records this workgroup has written (the same number in every wave)
-  unsigned range_cnt = 0;  // wave 0, lane r: records of range r so far
-  int since = 0, par = 0;
-  for (; tile < ntiles; tile += gridDim.x) {
-    float4 nxs[J], nys[J];
-    int4 ngs[J];
-    unsigned nxm[J], nym[J];
-    const bool more = tile + gridDim.x < ntiles;
-#ifndef EXON_K4_BIN_NOPF
-    if (more) load_tile(tile + gridDim.x, nxs, nys, ngs, nxm, nym);  // in flight across the barrier below
-#endif
-    unsigned* hist = bin_hist + par * K4_BIN_COUNTERS;
-    unsigned slot[J][4];  // tier-3 rows: counter << 16 | rank inside the counter; others ~0
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      const unsigned p0 = passes(xs[j].x, xm[j] >> 0 & 1), p1 = passes(xs[j].y, xm[j] >> 1 & 1),
-                     p2 = passes(xs[j].z, xm[j] >> 2 & 1), p3 = passes(xs[j].w, xm[j] >> 3 & 1);
-      row(p0, ys[j].x, gs[j].x, ym[j] >> 0 & 1);
-      row(p1, ys[j].y, gs[j].y, ym[j] >> 1 & 1);
-      row(p2, ys[j].z, gs[j].z, ym[j] >> 2 & 1);
-      row(p3, ys[j].w, gs[j].w, ym[j] >> 3 & 1);
-      slot[j][0] = slot[j][1] = slot[j][2] = slot[j][3] = 0xFFFFFFFFu;
-      const unsigned gm = max(max((unsigned)gs[j].x, (unsigned)gs[j].y), max((unsigned)gs[j].z, (unsigned)gs[j].w));
-      if (__any(gm >= (unsigned)G)) {
-        bool uni = false;
-        const int kw = __builtin_amdgcn_readfirstlane(gs[j].x);
-        if (uni_skip > 0) {
-          --uni_skip;
-        } else {
-          uni = __all((gs[j].x == kw) & (gs[j].y == kw) & (gs[j].z == kw) & (gs[j].w == kw));
-          uni_skip = uni ? 0 : 15;
-        }
-        if (uni) {
-          rows4_uniform(kw, p0, p1, p2, p3, ys[j], ym[j]);
-        } else {
-          row_lds(p0, ys[j].x, gs[j].x, ym[j] >> 0 & 1);
-          row_lds(p1, ys[j].y, gs[j].y, ym[j] >> 1 & 1);
-          row_lds(p2, ys[j].z, gs[j].z, ym[j] >> 2 & 1);
-          row_lds(p3, ys[j].w, gs[j].w, ym[j] >> 3 & 1);
-        }
-        if (__any(gm >= (unsigned)NL)) {
-          auto draw = [&](unsigned p, int32_t g) -> unsigned {
-            const unsigned dd = (unsigned)g - (unsigned)NL;
-            if (!(p && dd < span)) return 0xFFFFFFFFu;
-            const unsigned c = ((dd / K4_TAIL_RANGE) << cl) + copy;
-            return (c << 16) | atomicAdd(&hist[c], 1u);  // at most 8192 rows per tile: the rank fits 16 bits
-          };
-          slot[j][0] = draw(p0, gs[j].x);
-          slot[j][1] = draw(p1, gs[j].y);
-          slot[j][2] = draw(p2, gs[j].z);
-          slot[j][3] = draw(p3, gs[j].w);
-        }
-      }
-    }
-    since += 4 * J;
-    if (since > 255 - 4 * J) {
-      spill();
-      since = 0;
-    }
-    __syncthreads();  // this tile's histogram is complete; nobody scans the one of two tiles ago any more
-    {
-      // the histogram of the PREVIOUS tile (everybody finished scanning it before arriving at this barrier) is cleared for the
-      // tile after next, whose rows are only drawn behind the next barrier; the next tile's was cleared one tile ago
-      unsigned* old = bin_hist + ((par + 2) % 3) * K4_BIN_COUNTERS;
-      if (threadIdx.x < K4_BIN_COUNTERS) old[threadIdx.x] = 0;
-    }
-    // every wave scans for itself: lane l owns counters 4l .. 4l+3
-    const uint4 c4 = *reinterpret_cast<const uint4*>(hist + 4 * lane);
-    const unsigned s4 = c4.x + c4.y + c4.z + c4.w;
-    unsigned inc = s4;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const unsigned v = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += v;
-    }
-    const unsigned ex = inc - s4;
-    *reinterpret_cast<uint4*>(bin_excl + 4 * lane) = uint4{ex, ex + c4.x, ex + c4.x + c4.y, ex + c4.x + c4.y + c4.z};
-    const unsigned tile_total = (unsigned)__builtin_amdgcn_readlane((int)inc, 63);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      auto put = [&](unsigned sl, int32_t g, float yf, unsigned y1) {
-        if (sl == 0xFFFFFFFFu) return;
-        const unsigned at = seg_base + bin_excl[sl >> 16] + (sl & 0xFFFFu);
-        if (at < cap_wg) region[at] = uint2{(unsigned)g | (y1 << 31), (unsigned)__float_as_int(yf)};
-      };
-      put(slot[j][0], gs[j].x, ys[j].x, ym[j] >> 0 & 1);
-      put(slot[j][1], gs[j].y, ys[j].y, ym[j] >> 1 & 1);
-      put(slot[j][2], gs[j].z, ys[j].z, ym[j] >> 2 & 1);
-      put(slot[j][3], gs[j].w, ys[j].w, ym[j] >> 3 & 1);
-    }
-    if (wave == 0) {  // the tile's descriptor: start of every range's run in the region (+ the end of the last)
-      unsigned* d = tile_desc + (size_t)tile * (n_ranges + 1);
-      if (lane < n_ranges) {
-        const unsigned st = bin_excl[lane << cl];
-        const unsigned en = lane + 1 < n_ranges ? bin_excl[(lane + 1) << cl] : tile_total;
-        d[lane] = seg_base + st;
-        range_cnt += en - st;
-      }
-      if (lane == 0) d[n_ranges] = seg_base + tile_total;
-    }
-    seg_base += tile_total;
-    par = (par + 1) % 3;
-#ifdef EXON_K4_BIN_NOPF  // A/B: the next tile's columns requested behind the barrier (fewer registers, no spills)
-    if (more) load_tile(tile + gridDim.x, nxs, nys, ngs, nxm, nym);
-#endif
-    if (more) {
-#pragma unroll
-      for (int j = 0; j < J; ++j) {
-        xs[j] = nxs[j];
-        ys[j] = nys[j];
-        gs[j] = ngs[j];
-        xm[j] = nxm[j];
-        ym[j] = nym[j];
-      }
-    }
-  }
-  spill();
-  since = 0;
-  for (int64_t r = ntiles * TILE + (int64_t)rem_block() * THREADS + threadIdx.x; r < n; r += (int64_t)gridDim.x * THREADS) {
-    const float yf = y[r];
-    const int32_t g = gid[r];
-    const unsigned yv = valid1(yvalid, r), pass = passes(x[r], valid1(xvalid, r));
-    row(pass, yf, g, yv);
-    if ((unsigned)g >= (unsigned)G) {
-      if ((unsigned)g < (unsigned)NL) {
-        if (pass) {
-          K4Entry* e = &k4_ovf[g - G];
-          atomicAdd(&e->crow, 1u);
-          if (yv) {
-            atomicAdd(&e->cnn, 1u);
-            atomicAdd(&e->sum, ydbl(yf));
-          }
-        }
-      } else {
-        row_tail(pass, yf, g, yv);
-      }
-    }
-    if (++since == 255) {
-      spill();
-      since = 0;
-    }
-  }
-  spill();
-  if (gmax >= (unsigned)NG) atomicOr(status, 4);
-  if (threadIdx.x == 0) tail.wg_count[blockIdx.x] = min(seg_base, cap_wg);
-  if (wave == 0 && lane < n_ranges) tail.wg_hist[(size_t)blockIdx.x * n_ranges + lane] = range_cnt;
-  __syncthreads();
-
-  // per-workgroup record of the first NL ids: [cnn[NL]] [crow[NL]] [sum[NL]] (folded by k4_finalize_head)
-  const int RG = NL;
-  __shared__ unsigned long long red[WAVES][3 * G];
-#pragma unroll
-  for (int k = 0; k < G; ++k) {
-    const unsigned long long a = wave_sum((unsigned long long)cnn[k]);
-    const unsigned long long b = wave_sum((unsigned long long)crow[k]);
-    const double c = wave_sum(sum[k]);
-    if (lane == 0) {
-      red[wave][k] = a;
-      red[wave][G + k] = b;
-      red[wave][2 * G + k] = (unsigned long long)__double_as_longlong(c);
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < 3 * G) {
-    const int v = threadIdx.x;
-    unsigned long long out;
-    if (v < 2 * G) {
-      out = 0;
-#pragma unroll
-      for (int w = 0; w < WAVES; ++w) out += red[w][v];
-    } else {
-      double t = 0.0;
-#pragma unroll
-      for (int w = 0; w < WAVES; ++w) t += __longlong_as_double((long long)red[w][v]);
-      out = (unsigned long long)__double_as_longlong(t);
-    }
-    const int kind = v / G, g = v - kind * G;
-    st_agent(&partials[(size_t)blockIdx.x * (3 * RG) + kind * RG + g], out);
-  }
-  for (int i = threadIdx.x; i < NO; i += THREADS) {
-    unsigned long long* rec = partials + (size_t)blockIdx.x * (3 * RG);
-    st_agent(&rec[G + i], k4_ovf[i].cnn);
-    st_agent(&rec[RG + G + i], k4_ovf[i].crow);
-    st_agent(&rec[2 * RG + G + i], (unsigned long long)__double_as_longlong(k4_ovf[i].sum));
-  }
-}
-
-// A workgroup = one slice (of tiles) of one id range: it walks the tiles' descriptors, reads the range's run of every tile
-// from the main kernel's regions (tile t was written by workgroup t % grid_main) and adds it into the 128 KiB LDS table, which
-// is flushed with one global atomic triple per id the slice touched.  A wave takes 64 tiles at a time (one descriptor pair per
-// lane), then run after run with all 64 lanes: up to 8 records in flight per lane.
-__global__ __launch_bounds__(1024) void k4_tail_aggregate_runs(const uint2* __restrict__ recs, const unsigned* __restrict__ tile_desc,
-                                                               const unsigned* __restrict__ slice_start, int n_ranges, int64_t ntiles,
-                                                               int grid_main, unsigned cap_wg, int NL, int NG, int yint,
-                                                               unsigned long long* __restrict__ counts, double* __restrict__ sums) {
-  __shared__ K4Entry tab[K4_TAIL_RANGE];
-  if (blockIdx.x >= slice_start[n_ranges]) return;
-  int rlo = 0, rhi = n_ranges - 1;
-  while (rlo < rhi) {
-    const int mid = (rlo + rhi + 1) >> 1;
-    if (slice_start[mid] <= blockIdx.x) rlo = mid;
-    else rhi = mid - 1;
-  }
-  const int range = rlo;
-  const unsigned n_slices = slice_start[range + 1] - slice_start[range], slice = blockIdx.x - slice_start[range];
-  const int64_t t_lo = ntiles * slice / n_slices, t_hi = ntiles * (slice + 1) / n_slices;
-  if (t_lo >= t_hi) return;
-  for (int i = threadIdx.x; i < K4_TAIL_RANGE; i += 1024) {
-    tab[i].sum = 0.0;
-    tab[i].cnn = 0;
-    tab[i].crow = 0;
-  }
-  __syncthreads();
-  const unsigned id0 = (unsigned)NL + (unsigned)range * (unsigned)K4_TAIL_RANGE;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int PER = 8;
-  for (int64_t t0 = t_lo + (int64_t)wave * 64; t0 < t_hi; t0 += 16 * 64) {
-    const int64_t t = t0 + lane;
-    unsigned long long a = 0, b = 0;  // this lane's tile: its run [a, b) in `recs`
-    if (t < t_hi) {
-      const unsigned* d = tile_desc + (size_t)t * (n_ranges + 1) + range;
-      const unsigned long long base = (unsigned long long)(t % grid_main) * cap_wg;
-      a = base + d[0];
-      b = base + d[1];
-    }
-    const int cnt = (int)min((int64_t)64, t_hi - t0);
-    for (int k = 0; k < cnt; ++k) {
-      const unsigned long long ra = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(a >> 32), k) << 32) | (unsigned)__builtin_amdgcn_readlane((int)a, k);
-      const unsigned len = (unsigned)__builtin_amdgcn_readlane((int)(b - a), k);
-      for (unsigned i0 = 0; i0 < len; i0 += PER * 64u) {
-        uint2 v[PER];
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-          const unsigned i = i0 + (unsigned)q * 64u + (unsigned)lane;
-          v[q] = i < len ? ldnt8(recs + ra + i) : uint2{0xFFFFFFFFu, 0};
-        }
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-          const unsigned i = i0 + (unsigned)q * 64u + (unsigned)lane;
-          if (i >= len) continue;
-          K4Entry* e = &tab[(v[q].x & 0x7FFFFFFFu) - id0];
-          const unsigned yv = v[q].x >> 31;
-          atomicAdd(reinterpret_cast<unsigned long long*>(&e->cnn), (1ull << 32) | yv);
-          atomicAdd(&e->sum, yv ? (yint ? (double)(int32_t)v[q].y : (double)__uint_as_float(v[q].y)) : 0.0);
-        }
-      }
-    }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < K4_TAIL_RANGE; i += 1024) {
-    const unsigned g = id0 + (unsigned)i;
-    if (g >= (unsigned)NG || tab[i].crow == 0) continue;
-    atomicAdd(&counts[NG + g], (unsigned long long)tab[i].crow);
-    if (tab[i].cnn) {
-      atomicAdd(&counts[g], (unsigned long long)tab[i].cnn);
-      atomicAdd(&sums[g], tab[i].sum);
-    }
-  }
-}
-
 // rows per launch of the partitioned tier 3: its scratch is 2 x 8 bytes per row of a launch, so a longer table is cut
 // into launches of this many rows (a multiple of every tile size and of 8: column and bitmap pointers stay aligned)
 constexpr int64_t K4_TAIL_CHUNK_ROWS = int64_t(1) << 28;
@@ -1994,29 +1600,9 @@ static hipError_t k4_one_launch(hipStream_t s, const LaunchCfg& cfg, const Works
     tail.wg_count = wg_count;
     tail.wg_hist = wg_hist;
   }
-  // round 4, opt-in (EXON_HIP_K4_TAIL_BINNED=1): up to K4_BIN_MAX_RANGES id ranges the main kernel groups the tier-3 records by
-  // range itself and the scatter pass disappears.  Measured per 2^28-row launch at 1e5 keys (profiles/r4_groupby_binned.md):
-  // uniform keys main 741 -> 1134 us, scatter 418 -> 0, aggregate 231 -> 248: 5.84 -> 5.82 ms per 1e9 rows, nothing; zipf keys
-  // (28 % of the rows in tier 3) main 699 -> 946, scatter 113 -> 0, aggregate 99 -> 286: 3.84 -> 5.19 ms, a loss.  The barrier
-  // per 8192-row tile costs the 16-wave workgroup ~2-3 us whatever is behind it (requesting the next tile before the barrier
-  // or behind it: the same), more than the scatter pass it saves; short runs make the run-by-run aggregate latency-bound.
-  static const bool bin_on = [] {
-    const char* v = getenv("EXON_HIP_K4_TAIL_BINNED");
-    return v && v[0] == '1';
-  }();
-  const bool binned = partition && big && bin_on && n_ranges <= K4_BIN_MAX_RANGES;
-  if (binned) {
-    const size_t lds = (size_t)(nl - K4_OVF_REGS + 64) * sizeof(K4Entry) + (size_t)(3 + 16) * K4_BIN_COUNTERS * sizeof(unsigned);
-    auto go = [&](auto kern) -> hipError_t {
-      hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e1 != hipSuccess) return e1;
-      grid = grid_for<ShapeBigJ2>(cfg, n, 1);
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, s, x, x_valid, y, y_valid, gid, n, klo, khi, negate, keymask, n_groups, nl, ws.partials, ws.status,
-                         reinterpret_cast<const uint8_t*>(ws.status + 8), tail, reinterpret_cast<unsigned*>(ws.tail_rec_b));
-      return hipGetLastError();
-    };
-    e = yint ? go(k4_main_binned<true>) : go(k4_main_binned<false>);
-  } else
+  // (Round 4 also built the partition INSIDE the main kernel -- records grouped by id range per tile, no scatter pass -- bit-identical
+  // and not faster: 5.84 -> 5.82 ms per 1e9 rows at 1e5 uniform keys, 3.84 -> 5.19 ms at zipf keys; the barrier per 8192-row tile
+  // costs more than the scatter pass saves.  Removed in round 5; the measurements are in profiles/r4_groupby_binned.md.)
   switch (n_groups) {
 #define EXON_K4_CASE(GG)                                                                                                        \
   case GG:                                                                                                                      \
@@ -2043,15 +1629,7 @@ static hipError_t k4_one_launch(hipStream_t s, const LaunchCfg& cfg, const Works
   if (has_tail) {
     hipLaunchKernelGGL(k4_finalize_head, dim3((3 * nl + 31) / 32), dim3(1024), 0, s, ws.partials, grid, nl, n_groups,
                        reinterpret_cast<unsigned long long*>(d_counts), d_sums);
-    if (binned) {  // the records lie grouped by range in the workgroups' regions: totals -> slices -> aggregate, no scatter
-      const int64_t tile = ShapeOf<ShapeBigJ2>::TILE;
-      const unsigned cap_wg = (unsigned)(((n / tile + grid - 1) / grid) * tile);
-      hipLaunchKernelGGL(k4_tail_wg_scan, dim3(n_ranges), dim3(1024), 0, s, wg_hist, grid, n_ranges, totals);
-      const int target = std::max(1, cfg.compute_units - n_ranges);
-      hipLaunchKernelGGL(k4_tail_offsets, dim3(1), dim3(1024), 0, s, totals, n_ranges, offsets, target, slice_start);
-      hipLaunchKernelGGL(k4_tail_aggregate_runs, dim3(target + n_ranges), dim3(1024), 0, s, ws.tail_rec_a, reinterpret_cast<const unsigned*>(ws.tail_rec_b),
-                         slice_start, n_ranges, n / tile, grid, cap_wg, nl, n_groups, yint, reinterpret_cast<unsigned long long*>(d_counts), d_sums);
-    } else if (partition) {
+    if (partition) {
       const int64_t tile = big ? ShapeOf<ShapeBigJ2>::TILE : ShapeOf<ShapeSmall>::TILE;
       const unsigned cap_wg = (unsigned)(((n / tile + grid - 1) / grid) * tile);  // the main kernel's formula
       hipLaunchKernelGGL(k4_tail_wg_scan, dim3(n_ranges), dim3(1024), 0, s, wg_hist, grid, n_ranges, totals);

@@ -1156,8 +1156,9 @@ int exon_hip_stream_reconcile_keys(exon_hip_stream* st, void* rccl_comm) {
   if (!st || !rccl_comm) return fail(st ? st->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_stream_reconcile_keys: NULL argument");
   if (st->closed) return fail(st->ctx, EXON_HIP_ESTATE, "reconcile_keys after finish/close");
   if (!exon_hip_stream_is_keyed(st)) return EXON_HIP_OK;  // plans without group keys have nothing to agree on
-  if (st->keys_state == KEYS_NONE && st->rows_pushed > 0)
-    return fail(st->ctx, EXON_HIP_ESTATE, "this stream's rows were pushed with the caller's own dictionary ids: declare their values with exon_hip_stream_set_keys");
+  // A rank that may not take part (rows pushed under the caller's own ids, never declared) still ENTERS the collective and says so
+  // in the size exchange: every rank then fails together.  Returning here would leave the other ranks blocked in ncclAllGather.
+  const bool unkeyed = st->keys_state == KEYS_NONE && st->rows_pushed > 0;
   if (!rccl().ok()) return fail(st->ctx, EXON_HIP_EUNSUPPORTED, "librccl.so could not be loaded");
   int world = 0, rank = 0;
   int e = rccl().comm_count(rccl_comm, &world);
@@ -1165,17 +1166,26 @@ int exon_hip_stream_reconcile_keys(exon_hip_stream* st, void* rccl_comm) {
   if (e || world < 1) return fail(st->ctx, EXON_HIP_EDEVICE, "ncclCommCount / ncclCommUserRank failed with ncclResult_t %d", e);
   hipSetDevice(st->ctx->device);
   // (1) sizes
-  int64_t mine[2] = {(int64_t)st->keys.size(), (int64_t)packed_size(st->keys)};
+  // (per rank: number of keys, packed bytes, "I cannot take part")
+  int64_t mine[4] = {unkeyed ? 0 : (int64_t)st->keys.size(), unkeyed ? 0 : (int64_t)packed_size(st->keys), unkeyed ? 1 : 0, 0};
   int64_t* d_sz = nullptr;
-  HIP_TRY(st->ctx, hipMalloc((void**)&d_sz, (size_t)(world + 1) * 16));
-  std::vector<int64_t> sizes((size_t)world * 2);
-  hipError_t he = hipMemcpyAsync(d_sz + 2 * world, mine, 16, hipMemcpyHostToDevice, st->stream);
-  if (he == hipSuccess) e = rccl().all_gather(d_sz + 2 * world, d_sz, 2, NCCL_INT64, rccl_comm, st->stream);
-  if (he == hipSuccess && !e) he = hipMemcpyAsync(sizes.data(), d_sz, (size_t)world * 16, hipMemcpyDeviceToHost, st->stream);
+  HIP_TRY(st->ctx, hipMalloc((void**)&d_sz, (size_t)(world + 1) * 32));
+  std::vector<int64_t> sizes4((size_t)world * 4), sizes((size_t)world * 2);
+  hipError_t he = hipMemcpyAsync(d_sz + 4 * world, mine, 32, hipMemcpyHostToDevice, st->stream);
+  if (he == hipSuccess) e = rccl().all_gather(d_sz + 4 * world, d_sz, 4, NCCL_INT64, rccl_comm, st->stream);
+  if (he == hipSuccess && !e) he = hipMemcpyAsync(sizes4.data(), d_sz, (size_t)world * 32, hipMemcpyDeviceToHost, st->stream);
   if (he == hipSuccess && !e) he = hipStreamSynchronize(st->stream);
   hipFree(d_sz);
   if (e) return fail(st->ctx, EXON_HIP_EDEVICE, "ncclAllGather (key dictionary sizes) failed with ncclResult_t %d", e);
   if (he != hipSuccess) return fail(st->ctx, EXON_HIP_EDEVICE, "key dictionary sizes: %s", hipGetErrorString(he));
+  for (int r = 0; r < world; ++r) {
+    sizes[(size_t)r * 2] = sizes4[(size_t)r * 4];
+    sizes[(size_t)r * 2 + 1] = sizes4[(size_t)r * 4 + 1];
+    if (sizes4[(size_t)r * 4 + 2])  // decided by all ranks on the same data: all of them leave here
+      return fail(st->ctx, EXON_HIP_ESTATE,
+                  "rank %d pushed rows under the caller's own dictionary ids and never declared their values (exon_hip_stream_set_keys): "
+                  "no rank's state was touched", r);
+  }
   size_t slot = 8;
   for (int r = 0; r < world; ++r) slot = std::max(slot, (size_t)sizes[(size_t)r * 2 + 1]);
   slot = (slot + 7) / 8 * 8;

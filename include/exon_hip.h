@@ -330,7 +330,12 @@ int exon_hip_stream_push_device(exon_hip_stream* s, const struct ArrowDeviceArra
 int exon_hip_stream_state(exon_hip_stream* s, int64_t** d_i64, double** d_f64, void** hip_stream);
 /* The merge across GPUs in native code on the stream's hipStream_t: afterwards the state of every rank is the sum over all
  * ranks.  One ncclAllGather + fixed-order fold (exon_hip_merge_states); `rccl_comm` is an ncclComm_t the host created (one
- * rank per GPU, e.g. exon_hip_rccl_comm_init). */
+ * rank per GPU, e.g. exon_hip_rccl_comm_init).
+ * The argument and state checks of this call are RANK-LOCAL (the step budget has no room for a second collective): a rank
+ * that fails them -- EXON_HIP_ESTATE for a state keyed by its own dictionary, above all -- returns WITHOUT entering the
+ * collective, and the ranks that did enter wait for it.  Treat a nonzero return on any rank as fatal for the communicator
+ * (abort the job, or ncclCommAbort), and call exon_hip_stream_reconcile_keys first wherever keys come from files: that call
+ * decides collectively and fails on every rank together. */
 int exon_hip_stream_all_reduce(exon_hip_stream* s, void* rccl_comm);
 /* ---- group keys by VALUE (ABI 4) --------------------------------------------------------------------------------------------
  * K3 / K4 states are indexed by dictionary id, and ids are per FILE: FILTER lists are numbered in order of first appearance in
@@ -356,7 +361,9 @@ int exon_hip_stream_set_keys(exon_hip_stream* s, const char* packed_names, size_
 int exon_hip_keys_union(const char* packed, size_t packed_bytes, const int32_t* n_keys, int32_t world, char* out, size_t cap,
                         int32_t* n_out, size_t* out_bytes, int32_t* maps);
 /* collective over `rccl_comm` (every rank calls it, between its last consume_scan and exon_hip_stream_all_reduce): two small
- * ncclAllGathers move the dictionaries, every rank forms the same union and permutes its state into it. */
+ * ncclAllGathers move the dictionaries, every rank forms the same union and permutes its state into it.  A rank that cannot take
+ * part (rows pushed under undeclared ids) says so INSIDE the first exchange: every rank then returns EXON_HIP_ESTATE, none hangs.
+ * A union larger than the plan's n_groups is EXON_HIP_EINVAL on every rank (all ranks compute the same union). */
 int exon_hip_stream_reconcile_keys(exon_hip_stream* s, void* rccl_comm);
 /* Region plans (K2 / K6 / K7) fed by files: name the contig instead of fixing exon_hip_plan_desc.region_chrom_id -- every
  * exon_hip_stream_consume_scan then resolves the name in that file's own contig / reference dictionary (a BAM without such

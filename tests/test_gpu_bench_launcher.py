@@ -51,6 +51,34 @@ def test_two_ranks_weak_scaling_grow_the_table():
         assert a == pytest.approx(b, rel=1e-12)
 
 
+LAUNCH8 = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1"]
+
+
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_eight_ranks_under_the_drivers_launch_line(scaling):
+    """The SCALE run's 8-rank line rehearsed on one GPU (EXON_BENCH_SHARE_GPU=1: eight ranks on cuda:0, gloo carries the merge):
+    rank k owns rows [k N/8, (k+1) N/8); the merged answer equals one rank over the whole table, strong and weak."""
+    rows = 64_000_000 if scaling == "strong" else 8_000_000
+    total = rows if scaling == "strong" else 8 * rows
+    eight = _bench(["--gpus", "8", "--steps", "2", "--warmup", "1", "--rows", str(rows), "--scaling", scaling, "--no-cpu-baseline"],
+                   env={"EXON_BENCH_SHARE_GPU": "1"}, launcher=LAUNCH8 + ["--master-port", "29537" if scaling == "strong" else "29538"])
+    one = _bench(["--steps", "2", "--warmup", "1", "--rows", str(total), "--no-cpu-baseline", "--no-extras"])
+    assert eight["n_gpus"] == 8 and eight["scaling"] == scaling and eight["config"]["rows_total"] == total
+    assert eight["config"]["rows_per_gpu"] == total // 8 and "all_gather" in eight["config"]["reduce"]
+    assert eight["result"]["filter_rows"] == one["result"]["filter_rows"]
+    for a, b in zip(eight["result"]["avg_qual"], one["result"]["avg_qual"]):
+        assert a == pytest.approx(b, rel=1e-12)
+
+
+def test_eight_ranks_histogram_workload():
+    """config 5 at 8 ranks: 204.8 KB of state per rank, 8 x that through the gather + fold merge."""
+    reads = 4_000_000
+    eight = _bench(["--gpus", "8", "--steps", "2", "--warmup", "1", "--rows", str(reads), "--workload", "c5", "--no-cpu-baseline"],
+                   env={"EXON_BENCH_SHARE_GPU": "1"}, launcher=LAUNCH8 + ["--master-port", "29539"])
+    one = _bench(["--steps", "2", "--warmup", "1", "--rows", str(reads), "--workload", "c5", "--no-cpu-baseline"])
+    assert eight["n_gpus"] == 8 and eight["result"]["counts"] == one["result"]["counts"] and sum(one["result"]["counts"]) == reads * 100
+
+
 def test_histogram_workload_merges_a_large_state_across_ranks():
     """config 5 under the launcher: 204.8 KB of state per rank through the gather + fold merge."""
     reads = 2_000_000

@@ -350,9 +350,10 @@ def test_k4_beyond_4096_groups_uses_the_global_table(ctx, oracle, G, n):
 @pytest.mark.parametrize("G,n,dist", [(4104, 300_000, "uniform"), (4105, 300_000, "uniform"), (20_000, 6_000_000, "zipf"),
                                       (20_000, 6_000_000, "uniform"), (64, 6_000_000, "uniform")])
 def test_k4_three_tiers_registers_lds_global(ctx, oracle, G, n, dist):
-    """Round 3: ids 0..7 in registers, 8..4103 in the LDS table, 4104.. by global atomics -- one kernel.  Checked against
-    a column-wise numpy statement (no oracle involved), in overwrite mode and accumulating over two launches, small and
-    big launch shapes, keys early-heavy (zipf) and uniform, the tier boundaries 4103 / 4104 present."""
+    """The three tiers of the GROUP BY kernel as shipped since round 3: ids 0..3 in registers, 4..4099 in the LDS table, 4100.. in
+    tier 3 (compact -> scatter -> aggregate; global atomics for launches without whole tiles) -- G = 4104 / 4105 put ids on both
+    sides of the 4099 | 4100 boundary.  Checked against a column-wise numpy statement (no oracle involved), in overwrite mode and
+    accumulating over two launches, small and big launch shapes, keys early-heavy (zipf) and uniform."""
     rng = np.random.default_rng(G + n)
     af, av, q, qv, _ = oracle.gen_c4(4, 0, n)
     if dist == "uniform":
@@ -651,12 +652,11 @@ def test_k5_ragged_reads(ctx, oracle):
 
 @pytest.mark.parametrize("G,dist", [(4105, "uniform"), (20_000, "uniform"), (100_000, "uniform"), (100_000, "early"), (4100 + 64 * 8192, "uniform"),
                                     (4100 + 64 * 8192 + 1, "uniform")])
-def test_k4_tier3_grouped_by_range_inside_the_main_kernel(ctx, G, dist):
-    """Launches big enough for the 1024-thread shape (>= 16384 rows per CU) with id ranges beyond the LDS table.  By default they
-    take compact -> scatter -> aggregate; under EXON_HIP_K4_TAIL_BINNED=1 (read once per process: the test below reruns this one
-    in a subprocess) and with up to 64 ranges the main kernel writes its tier-3 records grouped by range, tile by tile
-    (k4_main_binned), and k4_tail_aggregate_runs reads the runs; one range more falls back.  Counts bit-exact vs numpy, sums
-    within the budget; a second launch accumulates; the row count is not a multiple of the tile (remainder rows: atomic form)."""
+def test_k4_tier3_big_launches_with_many_id_ranges(ctx, G, dist):
+    """Launches big enough for the 1024-thread shape (>= 16384 rows per CU) with id ranges beyond the LDS table: tier 3 =
+    compact -> scatter -> aggregate, with 1, 2, 12, 64 and 65 id ranges of 8192 ids.  Counts bit-exact vs numpy, sums within the
+    budget; a second launch accumulates; the row count is not a multiple of the tile (remainder rows: atomic form).  (Round 4's
+    opt-in partition inside the main kernel, which this test was written for, was removed in round 5: bit-identical, not faster.)"""
     from oracle import Oracle
     orc = Oracle()
     n = 6_000_000 + 4321
@@ -686,14 +686,3 @@ def test_k4_tier3_grouped_by_range_inside_the_main_kernel(ctx, G, dist):
     st = state.to_host()
     assert np.array_equal(st[:G], 2 * cn) and np.array_equal(st[G:2 * G], 2 * cr)
     assert np.allclose(st[2 * G:].view(np.float64), 2 * s, rtol=RTOL, atol=0)
-
-
-@pytest.mark.gpu
-def test_k4_tier3_grouped_inside_the_main_kernel_in_a_fresh_process():
-    """The opt-in in-kernel partition of tier 3 (EXON_HIP_K4_TAIL_BINNED=1, profiles/r4_groupby_binned.md) stays correct."""
-    import subprocess
-    import sys
-    env = dict(os.environ, EXON_HIP_K4_TAIL_BINNED="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "--timeout", "600", "-p", "no:cacheprovider", os.path.abspath(__file__),
-                        "-k", "tier3_grouped_by_range or beyond_4096"], env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -393,11 +393,13 @@ paths = json.loads(sys.argv[2])
 kind = sys.argv[3]
 if kind == "k4":
     r = scan_files(ctx, paths, "vcf", lambda c: c.plan_cmp_avg_by_group(">", 0.01, 64, columns=(4, 2, 3)), info_field="AF")
+elif kind == "k4small":  # capacity for 4 distinct FILTER lists only
+    r = scan_files(ctx, paths, "vcf", lambda c: c.plan_cmp_avg_by_group(">", 0.01, 4, columns=(4, 2, 3)), info_field="AF")
 else:
     r = scan_files(ctx, paths, "sam", lambda c: c.plan_flag_mapq_group_count(1284, 0, 30, 8))
 both = [None] * dist.get_world_size()
 dist.all_gather_object(both, (r["keys"], r["counts"].tolist(), r["sums"].tolist(), r["files"]))
-assert both[0][:3] == both[1][:3], "ranks disagree after the merge"
+assert all(b[:3] == both[0][:3] for b in both), "ranks disagree after the merge"
 if dist.get_rank() == 0:
     print("RESULT " + json.dumps({"keys": r["keys"], "counts": r["counts"].tolist(), "sums": r["sums"].tolist(), "rows": r["rows"],
                                   "files": [b[3] for b in both]}))
@@ -407,15 +409,21 @@ dist.destroy_process_group()
 '''
 
 
-def _two_ranks(tmp_path, paths, kind, port):
+def _ranks(tmp_path, paths, kind, port, world=2, expect_fail=False):
     import json
     script = tmp_path / "rank.py"
     script.write_text(_RANK_SCRIPT)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script), ROOT, json.dumps(paths), kind]
-    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900)
+    if expect_fail:
+        return r
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+
+
+def _two_ranks(tmp_path, paths, kind, port):
+    return _ranks(tmp_path, paths, kind, port, 2)
 
 
 @pytest.mark.gpu
@@ -446,3 +454,46 @@ def test_two_ranks_scan_files_with_disagreeing_dictionaries(tmp_path, oracle):
     if r["counts"][8]:
         got3[None] = int(r["counts"][8])
     assert got3 == want3 and r["rows"] == 44000
+
+
+@pytest.mark.gpu
+def test_eight_ranks_three_files_five_ranks_with_empty_dictionaries(tmp_path, oracle):
+    """The driver's 8-GPU launch line rehearsed on the one GPU (eight ranks share cuda:0, gloo carries names and states): three files
+    over eight ranks = five ranks that scan nothing and bring an EMPTY dictionary and an all-zero state into the reconcile and the
+    merge (regroup_files_by_size leaves their groups empty, exon_file_scan_config.rs:79-110).  Every rank ends with the oracle's
+    answer over the concatenated table; same for two SAMs over eight ranks."""
+    paths = [str(tmp_path / f"{c}.vcf") for c in "abc"]
+    write_vcf(paths[0], 9000, 1, ["PASS", ".", "q10"])
+    write_vcf(paths[1], 12000, 2, ["s50", "q10;s50", "q10", ".", "PASS"])
+    write_vcf(paths[2], 10000, 3, ["q10;s50", "PASS"])
+    one = str(tmp_path / "all.vcf")
+    cat_vcf(one, paths)
+    n, want = OX.k4_expected(oracle, one, "vcf", "AF")
+    gz = []
+    for p in paths:
+        subprocess.check_call([BGZIP, p, p + ".gz"])
+        gz.append(p + ".gz")
+    r = _ranks(tmp_path, gz, "k4", 29551, world=8)
+    assert r["rows"] == n and sorted(len(f) for f in r["files"]) == [0, 0, 0, 0, 0, 1, 1, 1]
+    assert k4_by_value(r["keys"], np.array(r["counts"]), np.array(r["sums"]), 64) == want
+    sams = [str(tmp_path / f"{c}.sam") for c in "ab"]
+    write_sam(sams[0], 9000, 3, ["chr1", "chr2", "chr3"])
+    write_sam(sams[1], 11000, 4, ["chrX", "chr3", "chr1", "chr2"])
+    want3 = k3_expected_by_name(oracle, sams, "sam")
+    r = _ranks(tmp_path, sams, "k3", 29552, world=8)
+    got3 = {r["keys"][g]: int(c) for g, c in enumerate(r["counts"][:len(r["keys"])]) if c}
+    if r["counts"][8]:
+        got3[None] = int(r["counts"][8])
+    assert got3 == want3 and r["rows"] == 20000
+
+
+@pytest.mark.gpu
+def test_a_union_beyond_the_plans_capacity_fails_on_every_rank(tmp_path):
+    """Each rank's own dictionary fits the plan (3 and 3 distinct FILTER lists, capacity 4), the UNION (5) does not: the
+    reconcile must fail loudly on every rank -- not merge a truncated dictionary -- and the launcher comes back non-zero."""
+    paths = [str(tmp_path / f"{c}.vcf") for c in "ab"]
+    write_vcf(paths[0], 6000, 1, ["PASS", ".", "q10"])
+    write_vcf(paths[1], 6000, 2, ["s50", "q10;s50", "PASS"])
+    r = _ranks(tmp_path, paths, "k4small", 29553, world=2, expect_fail=True)
+    assert r.returncode != 0 and "RESULT " not in r.stdout
+    assert "n_groups" in (r.stdout + r.stderr) or "distinct" in (r.stdout + r.stderr), (r.stdout + r.stderr)[-2000:]
