@@ -1026,25 +1026,31 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
 #define EXON_WIDE_ASM 1
 #endif
 // The rounds of wide_run that need nothing special, hand-written.  Why by hand: the compiler's version of the round spends 78
-// scalar + 83 vector instructions (VCF text; rocprofv3 PMC, profiles/r5_inflate_wide_pmc.md), and a CU has ONE scalar ALU for its
-// 32 waves (tools/issue_rate.hip: 1.0 instruction per clock and CU) against 4 x 0.5 vector instructions.  So everything
+// scalar + 83 vector instructions (VCF text; rocprofv3 PMC, profiles/r5_inflate_wide_v0_pmc.txt), and a CU has ONE scalar ALU for
+// its 32 waves (tools/issue_rate.hip: 1.0 instruction per clock and CU) against 4 x 0.5 vector instructions.  So everything
 // wave-uniform that is not a branch condition or a lane select lives in vector registers here (all 64 lanes computing the same
 // value), masks are taken by v_cmpx straight into EXEC, and the chain walk is two v_readlane + four vector instructions + one
 // compare-and-branch per symbol.
+// Order of a round: window (its three ds_bpermute were issued in the previous round, under that round's output) -> two table
+// lookups -> the chain -> the next round's window is requested -> the far copy deferred in the previous round lands (its load had
+// this round's decode and walk to come back) -> a row of the ring completed by the PREVIOUS round is drained (one round late, so
+// that nothing waits for a load just issued) -> literals, near copies, this round's far loads -> advance.
 // Wait states the assembler does not insert inside an asm block (gfx940 family, LLVM's GCNHazardRecognizer): a VALU-written SGPR
 // or VCC needs 2 states before a VALU reads it as an operand or a v_cndmask mask, 4 before v_readlane uses it as the lane select; a
 // VALU-written VGPR 1 before v_readlane / v_readfirstlane reads it; a VALU-written EXEC 4 before v_readlane.  SALU reads of
 // VALU-written SGPRs and s_cbranch_vcc* are interlocked.
-// Registers: s40-s71 and v30-v61 are this block's; the interface values travel in the operands.
+// Registers: s40-s71 and v33-v63 are this block's; the interface values travel in the operands.
+// Comes back with 0 / 4 as wide_run's `why`; 1: a completed row needs the caller (something to report, or not one whole aligned
+// row) BEFORE the next round; 5: a round the caller finishes from the chain walk on (rec / nextp / ev are that round's, nothing
+// of it is consumed).
 template <int RING>
 __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address_space(1))) uint32_t* base, const __attribute__((address_space(1))) uint8_t* out,
                                                     uint32_t& bp, uint32_t& wb, uint32_t& pos, uint32_t& drained, uint32_t& carry_len, uint32_t& carry_rec,
                                                     uint32_t begin, uint32_t end, uint32_t limit, uint32_t lane, uint32_t& cur, uint32_t& nxt, uint32_t& fdata,
-                                                    uint32_t& faddr, uint32_t& pend_lo, uint32_t& rec, uint32_t& nextp, uint32_t& ev, uint32_t& p_out, uint32_t& e_out) {
+                                                    uint32_t& faddr, uint32_t& rec, uint32_t& nextp, uint32_t& ev, uint32_t& e_out) {
   uint32_t code;
-  uint32_t vpend = pend_lo;
   asm volatile(
-      "  v_add_u32 v60, 0x80, %[lane]\n"                 // 128 + lane: where the chain goes from a symbol the tables do not resolve
+      "  v_add_u32 v60, 64, %[lane]\n"                   // 64 + lane: where the chain goes from a symbol the tables do not resolve
       // lane q (1..15): first canonical code / number of codes / symbols of shorter lengths, of literal/length codes q bits long
       "  v_and_b32 v48, 15, %[lane]\n"
       "  v_lshlrev_b32 v48, 1, v48\n"
@@ -1054,30 +1060,31 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  v_cmp_gt_u32 vcc, 16, %[lane]\n"
       "  s_waitcnt lgkmcnt(0)\n"
       "  v_cndmask_b32 v62, 0, v62, vcc\n"
-      "L_wr_round%=:\n"
       "  s_cmpk_lt_u32 s44, 0x400\n"
-      "  s_cbranch_scc0 L_wr_switch%=\n"
-      "L_wr_win%=:\n"
-      // ---- every lane's 64 bits of the stream from bit bp + lane
+      "  s_cbranch_scc1 L_wr_first%=\n"
+      "  s_mov_b32 s71, 0\n"                              // (return address of the window switch: 0 = the first window)
+      "  s_branch L_wr_switch%=\n"
+      "L_wr_first%=:\n"
       "  v_add_u32 v33, s44, %[lane]\n"
       "  v_lshrrev_b32 v34, 3, v33\n"
       "  v_and_b32 v34, 0xfc, v34\n"
       "  ds_bpermute_b32 v35, v34, %[cur]\n"
       "  ds_bpermute_b32 v36, v34, %[cur] offset:4\n"
       "  ds_bpermute_b32 v37, v34, %[cur] offset:8\n"
-      "  s_waitcnt lgkmcnt(1)\n"
+      // ---- a round: every lane's 64 bits of the stream from bit bp + lane (v33) are on their way
+      "L_wr_round%=:\n"
+      "  s_waitcnt lgkmcnt(0)\n"
       "  v_alignbit_b32 v38, v36, v35, v33\n"
+      "  v_alignbit_b32 v39, v37, v36, v33\n"
       "  v_and_b32 v34, 0x1ff, v38\n"
       "  v_lshlrev_b32 v34, 2, v34\n"
       "  ds_read_b32 %[ev], v34 offset:%[lutoff]\n"
-      "  s_waitcnt lgkmcnt(1)\n"
-      "  v_alignbit_b32 v39, v37, v36, v33\n"
       "  s_waitcnt lgkmcnt(0)\n"
       // ---- the symbol that would start there: literal, or length + extra bits + distance + extra bits
       "  v_and_b32 v42, 15, %[ev]\n"                      // code length
       "  v_bfe_u32 v43, %[ev], 4, 4\n"                    // extra bits
       "  v_add_u32 v44, v42, v43\n"
-      "  v_lshrrev_b64 v[46:47], v44, v[38:39]\n"
+      "  v_alignbit_b32 v46, v39, v38, v44\n"            // the 32 bits behind the length code and its extra bits (at most 20)
       "  v_lshlrev_b32 v34, 2, v46\n"
       "  v_and_b32 v34, 0x3fc, v34\n"
       "  ds_read_b32 v41, v34 offset:%[dlut]\n"
@@ -1101,51 +1108,80 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  v_cndmask_b32 %[nextp], %[nextp], v42, s[58:59]\n"
       "  v_cndmask_b32 %[rec], %[rec], v49, s[58:59]\n"
       "  v_add_u32 %[nextp], %[nextp], %[lane]\n"
-      "  v_cndmask_b32 %[nextp], v60, %[nextp], s[60:61]\n"
-      "  v_cndmask_b32 %[rec], 0, %[rec], s[60:61]\n"
-      // ---- the chain.  v52 = output bytes so far, v53 = per byte lane the record of the last symbol that starts at or before it
-      "  v_mov_b32 v52, s51\n"
+      "  v_cndmask_b32 %[nextp], v60, %[nextp], s[60:61]\n"   // not resolved: the chain goes to 64 + lane ...
+      "  v_cndmask_b32 %[rec], 0, %[rec], s[60:61]\n"         // ... with a record of no output bytes
+      "  v_lshl_or_b32 v51, %[nextp], 9, %[rec]\n"            // the walk's word: record + next position in bits 9-15
+      // ---- the chain.  s65 = output bytes so far; v53 = per byte lane the record of the last symbol that starts at or before it:
+      // EXEC shrinks to the byte lanes at or beyond the current symbol's first byte (it only ever shrinks: the bytes below keep
+      // their records), so a symbol's record is ONE masked v_mov.  The scalar unit has the headroom (PMC: the vector unit is 95 %
+      // busy, the scalar one 45 %): position, byte count and loop test are scalar, 3 vector + 5 scalar instructions per symbol.
       "  v_mov_b32 v53, s52\n"
+      "  s_mov_b32 s65, s51\n"
       "  s_mov_b32 s53, 0\n"
       "  s_mov_b32 s54, s52\n"
+      "  s_mov_b32 s57, 1\n"                             // (last symbol's bytes: not 0 = no unresolved symbol met)
       "  s_cmp_ge_u32 s51, 64\n"
-      "  s_cbranch_scc1 L_wr_walked2%=\n"
+      "  s_cbranch_scc1 L_wr_walked%=\n"
       "L_wr_walk%=:\n"
-      "  v_readlane_b32 s54, %[rec], s53\n"
-      "  v_readlane_b32 s53, %[nextp], s53\n"
-      "  v_cmp_le_u32 vcc, v52, %[lane]\n"
-      "  v_mov_b32 v54, s54\n"
-      "  v_add_u32_sdwa v52, v52, v54 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n"
-      "  v_cndmask_b32 v53, v53, v54, vcc\n"
+      "  v_readlane_b32 s54, v51, s53\n"
+      "  v_cmpx_le_u32 vcc, s65, %[lane]\n"
+      "  s_bfe_u32 s53, s54, 0x70009\n"                  // where the next symbol starts
+      "  s_and_b32 s57, s54, 0x1ff\n"                    // this symbol's bytes
+      "  v_mov_b32 v53, s54\n"
+      "  s_add_u32 s65, s65, s57\n"
       "  s_cmp_lt_u32 s53, 64\n"
       "  s_cbranch_scc1 L_wr_walk%=\n"
-      "  s_bitcmp1_b32 s53, 7\n"
+      "  s_cmp_eq_u32 s57, 0\n"                          // the last symbol gave no bytes: one the tables do not resolve
       "  s_cbranch_scc1 L_wr_long%=\n"
       "L_wr_postwalk%=:\n"
+      "  s_mov_b64 exec, -1\n"
       // a symbol that STARTS beyond the 64 output bytes of the round was walked over: the careful walk of the C++ round
-      "  v_readfirstlane_b32 s65, v52\n"
-      "  s_and_b32 s57, s54, 0x1ff\n"
-      "  s_sub_u32 s57, s65, s57\n"
-      "  s_cmp_ge_u32 s57, 64\n"
+      "  s_sub_u32 s66, s65, s57\n"
+      "  s_cmp_ge_u32 s66, 64\n"
       "  s_cbranch_scc1 L_wr_slow%=\n"
-      "  s_branch L_wr_walked%=\n"
-      "L_wr_walked2%=:\n"
-      "  s_nop 0\n"
-      "  v_readfirstlane_b32 s65, v52\n"
       "L_wr_walked%=:\n"
-      "  s_and_b32 s70, s53, 0x7f\n"                      // bits consumed (a symbol not resolved sits at 128 + its lane)
-      "  s_min_u32 s64, s65, 64\n"                        // bytes of the round
+      "  s_mov_b32 s70, s53\n"                           // bits consumed ...
+      "  s_mov_b32 s67, s57\n"                           // (0: the round ends in front of an unresolved symbol; kept until the advance)
+      "  s_cmp_eq_u32 s57, 0\n"
+      "  s_cbranch_scc0 L_wr_consumed%=\n"
+      "  s_sub_u32 s70, s53, 64\n"                       // ... up to the unresolved symbol (it sits at 64 + its lane)
+      "L_wr_consumed%=:\n"
+      "  s_min_u32 s64, s65, 64\n"                       // bytes of the round
+      // ---- the far copy deferred in the previous round lands (lanes without one write a byte nobody reads)
+      "  s_waitcnt vmcnt(0)\n"
+      "  ds_write_b8 %[faddr], %[fdata]\n"
+      "  v_mov_b32 %[faddr], %[dummy]\n"
+      // ---- the next round's window is requested now: it arrives under this round's output
+      "  s_add_u32 s44, s44, s70\n"
+      "  s_cmpk_lt_u32 s44, 0x400\n"
+      "  s_cbranch_scc0 L_wr_switch1%=\n"
+      "L_wr_win%=:\n"
+      "  v_add_u32 v33, s44, %[lane]\n"
+      "  v_lshrrev_b32 v34, 3, v33\n"
+      "  v_and_b32 v34, 0xfc, v34\n"
+      "  ds_bpermute_b32 v35, v34, %[cur]\n"
+      "  ds_bpermute_b32 v36, v34, %[cur] offset:4\n"
+      "  ds_bpermute_b32 v37, v34, %[cur] offset:8\n"
+      // ---- a row of the ring completed before this round goes to HBM
+      "  s_and_b32 s66, s46, 0xffffff00\n"
+      "  s_cmp_gt_u32 s66, s50\n"
+      "  s_cbranch_scc1 L_wr_drain%=\n"
+      "L_wr_drained%=:\n"
       // ---- the output bytes
       "  v_ashrrev_i32 v55, 16, v53\n"                    // distance - 1 (a literal: negative)
       "  v_add_u32 v56, s46, %[lane]\n"                   // where the byte goes
       "  v_sub_u32 v58, v56, v55\n"                       // its source + 1
       "  v_and_b32 v57, %[ringmask], v56\n"
       "  v_cmpx_gt_u32 vcc, s64, %[lane]\n"               // EXEC = the round's byte lanes
+      "  s_sub_u32 s66, s46, s47\n"                      // (no distance reaches back 32 KiB: nothing to check from there on)
+      "  s_cmpk_ge_u32 s66, 0x8000\n"
+      "  s_cbranch_scc1 L_wr_nobad%=\n"
       "  v_subrev_u32 v48, s47, v56\n"
       "  v_cmp_ge_i32 vcc, v55, v48\n"                    // a distance that reaches before the member's output
       "  s_cbranch_vccnz L_wr_bad%=\n"
+      "L_wr_nobad%=:\n"
       "  v_cmp_lt_u32 vcc, v55, %[lane]\n"                // a source inside the round's own output
-      "  s_cbranch_vccnz L_wr_slow%=\n"
+      "  s_cbranch_vccnz L_wr_slow_unwind%=\n"
       "  s_mov_b64 s[62:63], exec\n"
       "  v_cmpx_gt_i32 vcc, 0, v53\n"                     // literals
       "  ds_write_b8_d16_hi v57, v53\n"
@@ -1154,58 +1190,30 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  s_mov_b64 s[62:63], exec\n"
       "  v_cmpx_gt_u32 vcc, %[nearw], v55\n"              // near: ring -> ring
       "  s_cbranch_execz L_wr_nonear%=\n"
-      "  v_cmp_gt_u32 vcc, v58, %[vpend]\n"               // a source inside the bytes of the deferred far copy?
-      "  s_cbranch_vccz L_wr_near%=\n"
-      "  s_mov_b64 s[68:69], exec\n"
-      "  s_mov_b64 exec, -1\n"
-      "  s_waitcnt vmcnt(0)\n"
-      "  v_cmpx_ne_u32 vcc, -1, %[faddr]\n"
-      "  ds_write_b8 %[faddr], %[fdata]\n"
-      "  s_mov_b64 exec, -1\n"
-      "  v_mov_b32 %[faddr], -1\n"
-      "  v_mov_b32 %[vpend], -1\n"
-      "  s_mov_b64 exec, s[68:69]\n"
-      "L_wr_near%=:\n"
       "  v_add_u32 v48, -1, v58\n"
       "  v_and_b32 v48, %[ringmask], v48\n"
       "  ds_read_u8 v59, v48\n"
       "  s_waitcnt lgkmcnt(0)\n"
       "  ds_write_b8 v57, v59\n"
       "L_wr_nonear%=:\n"
-      "  s_andn2_b64 exec, s[62:63], exec\n"              // far: the source is in HBM already
+      "  s_andn2_b64 exec, s[62:63], exec\n"              // far: the source is in HBM already; the load lands in the next round
       "  s_cbranch_execz L_wr_nomatch%=\n"
-      "  s_mov_b64 s[62:63], exec\n"
-      "  s_mov_b64 exec, -1\n"
-      "  s_waitcnt vmcnt(0)\n"                            // the previous deferred copy lands (its load is a round old) ...
-      "  v_cmpx_ne_u32 vcc, -1, %[faddr]\n"
-      "  ds_write_b8 %[faddr], %[fdata]\n"
-      "  s_mov_b64 exec, -1\n"
-      "  v_mov_b32 %[faddr], -1\n"
-      "  v_mov_b32 %[vpend], s46\n"
-      "  s_mov_b64 exec, s[62:63]\n"
-      "  global_load_ubyte %[fdata], v58, s[42:43] offset:-1\n"   // ... and this round's is issued: it lands a round later
+      "  global_load_ubyte %[fdata], v58, s[42:43] offset:-1\n"
       "  v_mov_b32 %[faddr], v57\n"
       "L_wr_nomatch%=:\n"
       "  s_mov_b64 exec, -1\n"
       // ---- advance
       "  s_sub_u32 s51, s65, s64\n"                       // the rest of a match that did not fit
       "  s_mov_b32 s52, s54\n"
-      "  s_add_u32 s67, s46, s64\n"
-      "  s_xor_b32 s57, s67, s46\n"
-      "  s_mov_b32 s46, s67\n"
-      "  s_add_u32 s44, s44, s70\n"
-      "  s_lshr_b32 s57, s57, 8\n"                        // SCC = a 256-byte row of the ring is complete
-      "  s_cbranch_scc1 L_wr_cross%=\n"
-      "L_wr_crossed%=:\n"
-      "  s_bitcmp1_b32 s53, 7\n"
+      "  s_add_u32 s46, s46, s64\n"
+      "  s_cmp_eq_u32 s67, 0\n"
       "  s_cbranch_scc0 L_wr_round%=\n"
-      "  s_and_b32 s57, s53, 63\n"                        // a symbol the tables do not resolve: its first-level entry for the caller
-      "  s_nop 0\n"
-      "  v_readlane_b32 s56, %[ev], s57\n"
+      "  s_nop 0\n"                                       // a symbol the tables do not resolve: its first-level entry for the caller
+      "  v_readlane_b32 s56, %[ev], s70\n"               // (s70 = bits consumed = its lane)
       "  s_mov_b32 s55, 0\n"
       "  s_branch L_wr_out%=\n"
-      // ---- a row is complete: drained here when it is exactly one aligned row and there is nothing to report
-      "L_wr_cross%=:\n"
+      // ---- rows completed by earlier rounds: drained here when it is exactly one aligned row and there is nothing to report
+      "L_wr_drain%=:\n"
       "  s_cmp_gt_u32 s46, s48\n"
       "  s_cbranch_scc1 L_wr_exit1%=\n"
       "  s_lshr_b32 s57, s44, 5\n"
@@ -1214,16 +1222,9 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  s_cbranch_scc1 L_wr_exit1%=\n"
       "  s_and_b32 s57, s50, 0xff\n"
       "  s_cbranch_scc1 L_wr_exit1%=\n"
-      "  s_and_b32 s66, s46, 0xffffff00\n"
       "  s_sub_u32 s57, s66, s50\n"
       "  s_cmp_eq_u32 s57, 0x100\n"
       "  s_cbranch_scc0 L_wr_exit1%=\n"
-      "  s_waitcnt vmcnt(0)\n"
-      "  v_cmpx_ne_u32 vcc, -1, %[faddr]\n"
-      "  ds_write_b8 %[faddr], %[fdata]\n"
-      "  s_mov_b64 exec, -1\n"
-      "  v_mov_b32 %[faddr], -1\n"
-      "  v_mov_b32 %[vpend], -1\n"
       "  s_and_b32 s57, s50, %[ringmask]\n"
       "  v_lshl_add_u32 v48, %[lane], 2, s57\n"
       "  ds_read_b32 v49, v48\n"
@@ -1231,11 +1232,14 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  s_waitcnt lgkmcnt(0)\n"
       "  global_store_dword v48, v49, s[42:43]\n"
       "  s_mov_b32 s50, s66\n"
-      "  s_branch L_wr_crossed%=\n"
-      "L_wr_exit1%=:\n"
+      "  s_branch L_wr_drained%=\n"
+      "L_wr_exit1%=:\n"                                   // (nothing of this round is consumed: the position goes back)
+      "  s_sub_u32 s44, s44, s70\n"
       "  s_mov_b32 s55, 1\n"
       "  s_branch L_wr_out%=\n"
       // ---- the window moves by 32 dwords: upper half of cur + lower half of nxt
+      "L_wr_switch1%=:\n"
+      "  s_mov_b32 s71, 1\n"
       "L_wr_switch%=:\n"
       "  v_xor_b32 v34, 32, %[lane]\n"
       "  v_lshlrev_b32 v34, 2, v34\n"
@@ -1249,20 +1253,25 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  v_cndmask_b32 %[cur], v36, v35, vcc\n"
       "  v_add_u32 v34, s45, %[lane]\n"
       "  v_lshlrev_b32 v34, 2, v34\n"
+      // (no far copy is in flight here: inside the loop it has just landed, at the entry the caller's loads are waited for)
       "  global_load_dword %[nxt], v34, s[40:41] offset:256\n"
+      "  s_cmp_eq_u32 s71, 0\n"
+      "  s_cbranch_scc1 L_wr_first%=\n"
       "  s_branch L_wr_win%=\n"
       // ---- the chain stopped at a symbol the first-level table does not resolve.  A literal with a code longer than the table
       // (7 % of the symbols of BAM payloads) is decoded here and the walk goes on: all candidate lengths at once -- lane q takes the
       // first q bits as a code of that length and tests it against the codes of its length; codes are prefix-free, so at most one
       // length matches (decode_long's method).  Anything else (end of block, a long length code, no such code) stays the caller's.
       "L_wr_long%=:\n"
-      "  s_and_b32 s57, s53, 63\n"
+      "  s_sub_u32 s67, s53, 64\n"                       // its lane
+      "  s_mov_b64 s[68:69], exec\n"
+      "  s_mov_b64 exec, -1\n"
       "  v_and_b32 v49, 15, %[lane]\n"
-      "  v_readlane_b32 s66, %[ev], s57\n"
+      "  v_readlane_b32 s66, %[ev], s67\n"
       "  v_sub_u32 v49, 32, v49\n"
       "  s_cmp_eq_u32 s66, 0\n"
       "  s_cbranch_scc0 L_wr_postwalk%=\n"
-      "  v_readlane_b32 s66, v38, s57\n"
+      "  v_readlane_b32 s66, v38, s67\n"
       "  s_nop 1\n"
       "  v_bfrev_b32 v48, s66\n"
       "  v_lshrrev_b32 v48, v49, v48\n"
@@ -1272,54 +1281,56 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  s_ff1_i32_b64 s66, vcc\n"
       "  s_cmp_lt_i32 s66, 0\n"
       "  s_cbranch_scc1 L_wr_postwalk%=\n"
-      "  v_readlane_b32 s68, v48, s66\n"
-      "  s_lshl_b32 s68, s68, 1\n"
-      "  v_mov_b32 v49, s68\n"
+      "  v_readlane_b32 s71, v48, s66\n"
+      "  s_lshl_b32 s71, s71, 1\n"
+      "  v_mov_b32 v49, s71\n"
       "  ds_read_u16 v49, v49 offset:%[symoff]\n"
       "  s_waitcnt lgkmcnt(0)\n"
-      "  v_readfirstlane_b32 s68, v49\n"
-      "  s_cmp_lt_u32 s68, 0x100\n"
+      "  v_readfirstlane_b32 s71, v49\n"
+      "  s_cmp_lt_u32 s71, 0x100\n"
       "  s_cbranch_scc0 L_wr_postwalk%=\n"
-      "  s_lshl_b32 s68, s68, 16\n"
-      "  s_or_b32 s54, s68, 0x80000001\n"                // the literal's record, and the walk's step for it
-      "  v_cmp_le_u32 vcc, v52, %[lane]\n"
-      "  v_mov_b32 v54, s54\n"
-      "  v_add_u32 v52, 1, v52\n"
-      "  s_add_u32 s53, s57, s66\n"
-      "  v_cndmask_b32 v53, v53, v54, vcc\n"
+      "  s_lshl_b32 s71, s71, 16\n"
+      "  s_or_b32 s54, s71, 0x80000001\n"                // the literal's record, and the walk's step for it
+      "  s_mov_b64 exec, s[68:69]\n"
+      "  v_cmpx_le_u32 vcc, s65, %[lane]\n"
+      "  s_add_u32 s53, s67, s66\n"
+      "  s_mov_b32 s57, 1\n"
+      "  v_mov_b32 v53, s54\n"
+      "  s_add_u32 s65, s65, 1\n"
       "  s_cmp_lt_u32 s53, 64\n"
       "  s_cbranch_scc1 L_wr_walk%=\n"
       "  s_branch L_wr_postwalk%=\n"
       "L_wr_bad%=:\n"
       "  s_mov_b64 exec, -1\n"
+      "  s_sub_u32 s44, s44, s70\n"
       "  s_mov_b32 s55, 4\n"
       "  s_branch L_wr_out%=\n"
-      "L_wr_slow%=:\n"
+      "L_wr_slow_unwind%=:\n"                             // (the position was moved for the next window: it goes back)
       "  s_mov_b64 exec, -1\n"
+      "  s_sub_u32 s44, s44, s70\n"
+      "L_wr_slow%=:\n"
       "  s_mov_b32 s55, 5\n"
       "L_wr_out%=:\n"
       "  s_waitcnt vmcnt(0) lgkmcnt(0)\n"
       "  s_nop 1\n"
-      : [code] "={s55}"(code), [e] "={s56}"(e_out), [p] "={s53}"(p_out), [bp] "+{s44}"(bp), [wb] "+{s45}"(wb), [pos] "+{s46}"(pos), [drained] "+{s50}"(drained),
-        [cl] "+{s51}"(carry_len), [cr] "+{s52}"(carry_rec), [cur] "+v"(cur), [nxt] "+v"(nxt), [fdata] "+v"(fdata), [faddr] "+v"(faddr), [vpend] "+v"(vpend),
+      : [code] "={s55}"(code), [e] "={s56}"(e_out), [bp] "+{s44}"(bp), [wb] "+{s45}"(wb), [pos] "+{s46}"(pos), [drained] "+{s50}"(drained),
+        [cl] "+{s51}"(carry_len), [cr] "+{s52}"(carry_rec), [cur] "+v"(cur), [nxt] "+v"(nxt), [fdata] "+v"(fdata), [faddr] "+v"(faddr),
         [rec] "=&v"(rec), [nextp] "=&v"(nextp), [ev] "=&v"(ev)
       : [base] "{s[40:41]}"(base), [out] "{s[42:43]}"(out), [begin] "{s47}"(begin), [end] "{s48}"(end), [limit] "{s49}"(limit), [lane] "v"(lane),
         [ringmask] "i"(RING - 1), [nearw] "i"(RING - 258), [lutoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_lut)),
         [dlut] "i"(RING + (int)__builtin_offsetof(WaveLds, dist_lut)), [firstoff] "i"(RING + (int)__builtin_offsetof(WaveLds, first)),
         [countoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_count)), [offsoff] "i"(RING + (int)__builtin_offsetof(WaveLds, offs)),
-        [symoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_sym))
-      : "s54", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "v33", "v34", "v35", "v36", "v37", "v38",
-        "v39", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "vcc", "scc",
-        "memory");
+        [symoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_sym)), [dummy] "i"(RING + (int)__builtin_offsetof(WaveLds, dist_count))
+      : "s53", "s54", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "v33", "v34", "v35", "v36", "v37",
+        "v38", "v39", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61",
+        "v62", "v63", "vcc", "scc", "memory");
   bp = uniu(bp);
   wb = uniu(wb);
   pos = uniu(pos);
   drained = uniu(drained);
   carry_len = uniu(carry_len);
   carry_rec = uniu(carry_rec);
-  p_out = uniu(p_out);
   e_out = uniu(e_out);
-  pend_lo = uniu(vpend);
   return uniu(code);
 }
 
@@ -1345,13 +1356,14 @@ __device__ __forceinline__ uint32_t wide_run(BitReader& br, Out& o, uint32_t& e_
   uint32_t nxt = base[wb + 64u + lane];
   uint32_t pos = o.pos;
   uint32_t carry_len = 0, carry_rec = 0;
-  uint32_t fdata = 0, faddr = ~0u;  // the deferred far copy: bytes in flight and their ring addresses (~0: none for this lane)
-  uint32_t pend_lo = ~0u;           // its first output index (~0: nothing pending)
+  // the deferred far copy: bytes in flight and their LDS addresses -- a lane without one writes a byte nobody reads (the
+  // never-used "codes of length 0" slot of the distance code's per-length counts)
+  constexpr uint32_t FAR_NONE = RING + (uint32_t)__builtin_offsetof(WaveLds, dist_count);
+  uint32_t fdata = 0, faddr = FAR_NONE;
   uint32_t why;
   auto complete_far = [&]() {
-    if (faddr != ~0u) ring[faddr] = (uint8_t)fdata;
-    faddr = ~0u;
-    pend_lo = ~0u;
+    ring[faddr] = (uint8_t)fdata;  // (the ring sits at LDS address 0: `faddr` is an LDS address)
+    faddr = FAR_NONE;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   };
   for (;;) {
@@ -1362,19 +1374,25 @@ __device__ __forceinline__ uint32_t wide_run(BitReader& br, Out& o, uint32_t& e_
     //   5: a round this C++ code has to finish from the chain walk on (a source inside the round's own output, or a symbol
     //      that starts beyond the round's 64 output bytes): rec / nextp / ev are that round's, nothing of it is consumed
     {
-      uint32_t p_asm = 0, e_asm = 0;
+      uint32_t e_asm = 0;
       const uint32_t code = wide_rounds_asm<RING>(base, gout, bp, wb, pos, drained, carry_len, carry_rec, o.begin, o.end, br.limit, lane, cur, nxt,
-                                                  fdata, faddr, pend_lo, rec, nextp, ev, p_asm, e_asm);
+                                                  fdata, faddr, rec, nextp, ev, e_asm);
       if (code == 0) {
         why = 0;
         e_out = e_asm;
         break;
       }
+      if ((int32_t)bp < 0) {  // the window moved for a round that then was not consumed: it moves back
+        wb -= 32u;
+        bp += 1024u;
+        cur = base[wb + lane];
+        nxt = base[wb + 64u + lane];
+      }
       if (code == 4) {
         why = 4;
         break;
       }
-      if (code == 1) {
+      if (code == 1) {  // rows are complete and the drain is not the plain one
         if (pos > o.end || wb + (bp >> 5) > br.limit) {
           why = 1;
           break;
@@ -1383,11 +1401,6 @@ __device__ __forceinline__ uint32_t wide_run(BitReader& br, Out& o, uint32_t& e_
         Out od{o.out, 0, 0, 0, drained};
         drain_to<RING>(od, pos & ~255u);
         drained = od.drained;
-        if (p_asm >= 128u) {
-          why = 0;
-          e_out = rdl(ev, p_asm - 128u);
-          break;
-        }
         continue;
       }
     }
@@ -1419,19 +1432,23 @@ __device__ __forceinline__ uint32_t wide_run(BitReader& br, Out& o, uint32_t& e_
     rec = is_lit ? (0x80000001u | (ev & 0x00FF0000u)) : (((ev >> 16) + exv) | (dm1 << 16));
     const bool ok = is_lit || mok;
     if (!ok) rec = 0;
-    nextp = ok ? lane + tot : 128u + lane;
+    nextp = ok ? lane + tot : 64u + lane;
 #endif
     // ---- the chain; byte lane b keeps the record of the last symbol that starts at or before output byte b
     uint32_t p = 0, vo = carry_len, lastrec = carry_rec, rb = carry_rec;
+    bool special = false;
     while (p < 64u && vo < 64u) {
       const uint32_t r = rdl(rec, p), pn = rdl(nextp, p);
+      if (r == 0) {  // a symbol the tables do not resolve: the round ends in front of it
+        special = true;
+        break;
+      }
       rb = lane >= vo ? r : rb;
       vo += r & 0x1FFu;
       lastrec = r;
       p = pn;
     }
-    const bool special = p >= 128u;
-    const uint32_t consumed = special ? p - 128u : p;
+    const uint32_t consumed = p;
     // ---- the round's output bytes
     const uint32_t nb = min(vo, 64u);
     const bool valid = lane < nb;
@@ -1464,7 +1481,7 @@ __device__ __forceinline__ uint32_t wide_run(BitReader& br, Out& o, uint32_t& e_
         D = Dn;
       }
     } else {
-      if (pend_lo != ~0u && __any(bnear && src1 > pend_lo)) complete_far();  // a near source inside the bytes still in flight
+      complete_far();  // (a near source may lie inside the bytes still in flight)
       if (valid && blit) ring[ra] = (uint8_t)(rb >> 16);
       uint8_t nv = 0;
       if (bnear) nv = ring[(src1 - 1u) & RM];
@@ -1473,10 +1490,8 @@ __device__ __forceinline__ uint32_t wide_run(BitReader& br, Out& o, uint32_t& e_
       if (__any(bfar)) {
         uint32_t fnew = 0;
         if (bfar) fnew = gout[src1 - 1u];  // below `drained`: in HBM already
-        complete_far();                      // the previous round's, under this load
         fdata = fnew;
-        faddr = bfar ? ra : ~0u;
-        pend_lo = pos;
+        faddr = bfar ? ra : FAR_NONE;
 #ifdef EXON_WIDE_SYNC_FAR  // debugging: no deferral
         complete_far();
 #endif
@@ -1494,14 +1509,14 @@ __device__ __forceinline__ uint32_t wide_run(BitReader& br, Out& o, uint32_t& e_
         why = 1;
         break;
       }
-      if (pend_lo < (pos & ~255u)) complete_far();
+      complete_far();
       Out od{o.out, 0, 0, 0, drained};
       drain_to<RING>(od, pos & ~255u);
       drained = od.drained;
     }
     if (special) {
       why = 0;
-      e_out = rdl(ev, p - 128u);
+      e_out = rdl(ev, p);
       break;
     }
   }
