@@ -1051,6 +1051,8 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
   uint32_t code;
   asm volatile(
       "  v_add_u32 v60, 64, %[lane]\n"                   // 64 + lane: where the chain goes from a symbol the tables do not resolve
+      "  v_mov_b32 v50, 0xff0000\n"                      // (constants of the literal's record: one v_and_or instead of two instructions)
+      "  v_mov_b32 v54, 0x80000001\n"
       // lane q (1..15): first canonical code / number of codes / symbols of shorter lengths, of literal/length codes q bits long
       "  v_and_b32 v48, 15, %[lane]\n"
       "  v_lshlrev_b32 v48, 1, v48\n"
@@ -1067,7 +1069,6 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "L_wr_first%=:\n"
       "  v_add_u32 v33, s44, %[lane]\n"
       "  v_lshrrev_b32 v34, 3, v33\n"
-      "  v_and_b32 v34, 0xfc, v34\n"
       "  ds_bpermute_b32 v35, v34, %[cur]\n"
       "  ds_bpermute_b32 v36, v34, %[cur] offset:4\n"
       "  ds_bpermute_b32 v37, v34, %[cur] offset:8\n"
@@ -1092,8 +1093,7 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  v_cmp_eq_u32_sdwa s[58:59], %[ev], 1 src0_sel:BYTE_1 src1_sel:DWORD\n"  // E_LIT alone: a literal
       "  v_cmp_eq_u32_sdwa s[60:61], %[ev], 8 src0_sel:BYTE_1 src1_sel:DWORD\n"  // E_FAST alone: a length the tables resolve
       "  v_add_u32_sdwa v48, v45, %[ev] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"  // length
-      "  v_and_b32 v49, 0xff0000, %[ev]\n"
-      "  v_or_b32 v49, 0x80000001, v49\n"                 // a literal's record
+      "  v_and_or_b32 v49, %[ev], v50, v54\n"            // a literal's record
       "  s_waitcnt lgkmcnt(0)\n"
       "  v_cmp_eq_u32_sdwa vcc, v41, 8 src0_sel:BYTE_1 src1_sel:DWORD\n"         // ... and a distance they resolve
       "  s_and_b64 s[60:61], s[60:61], vcc\n"
@@ -1158,7 +1158,6 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "L_wr_win%=:\n"
       "  v_add_u32 v33, s44, %[lane]\n"
       "  v_lshrrev_b32 v34, 3, v33\n"
-      "  v_and_b32 v34, 0xfc, v34\n"
       "  ds_bpermute_b32 v35, v34, %[cur]\n"
       "  ds_bpermute_b32 v36, v34, %[cur] offset:4\n"
       "  ds_bpermute_b32 v37, v34, %[cur] offset:8\n"
@@ -1170,7 +1169,7 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       // ---- the output bytes
       "  v_ashrrev_i32 v55, 16, v53\n"                    // distance - 1 (a literal: negative)
       "  v_add_u32 v56, s46, %[lane]\n"                   // where the byte goes
-      "  v_sub_u32 v58, v56, v55\n"                       // its source + 1
+      "  v_xad_u32 v58, v55, -1, v56\n"                  // its source: where it goes - distance = ~(distance - 1) + where it goes
       "  v_and_b32 v57, %[ringmask], v56\n"
       "  v_cmpx_gt_u32 vcc, s64, %[lane]\n"               // EXEC = the round's byte lanes
       "  s_sub_u32 s66, s46, s47\n"                      // (no distance reaches back 32 KiB: nothing to check from there on)
@@ -1190,15 +1189,14 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  s_mov_b64 s[62:63], exec\n"
       "  v_cmpx_gt_u32 vcc, %[nearw], v55\n"              // near: ring -> ring
       "  s_cbranch_execz L_wr_nonear%=\n"
-      "  v_add_u32 v48, -1, v58\n"
-      "  v_and_b32 v48, %[ringmask], v48\n"
+      "  v_and_b32 v48, %[ringmask], v58\n"
       "  ds_read_u8 v59, v48\n"
       "  s_waitcnt lgkmcnt(0)\n"
       "  ds_write_b8 v57, v59\n"
       "L_wr_nonear%=:\n"
       "  s_andn2_b64 exec, s[62:63], exec\n"              // far: the source is in HBM already; the load lands in the next round
       "  s_cbranch_execz L_wr_nomatch%=\n"
-      "  global_load_ubyte %[fdata], v58, s[42:43] offset:-1\n"
+      "  global_load_ubyte %[fdata], v58, s[42:43]\n"
       "  v_mov_b32 %[faddr], v57\n"
       "L_wr_nomatch%=:\n"
       "  s_mov_b64 exec, -1\n"
@@ -1264,7 +1262,7 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       // length matches (decode_long's method).  Anything else (end of block, a long length code, no such code) stays the caller's.
       "L_wr_long%=:\n"
       "  s_sub_u32 s67, s53, 64\n"                       // its lane
-      "  s_mov_b64 s[68:69], exec\n"
+      "  s_mov_b64 s[62:63], exec\n"
       "  s_mov_b64 exec, -1\n"
       "  v_and_b32 v49, 15, %[lane]\n"
       "  v_readlane_b32 s66, %[ev], s67\n"
@@ -1291,7 +1289,7 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  s_cbranch_scc0 L_wr_postwalk%=\n"
       "  s_lshl_b32 s71, s71, 16\n"
       "  s_or_b32 s54, s71, 0x80000001\n"                // the literal's record, and the walk's step for it
-      "  s_mov_b64 exec, s[68:69]\n"
+      "  s_mov_b64 exec, s[62:63]\n"
       "  v_cmpx_le_u32 vcc, s65, %[lane]\n"
       "  s_add_u32 s53, s67, s66\n"
       "  s_mov_b32 s57, 1\n"
@@ -1322,7 +1320,7 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
         [countoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_count)), [offsoff] "i"(RING + (int)__builtin_offsetof(WaveLds, offs)),
         [symoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_sym)), [dummy] "i"(RING + (int)__builtin_offsetof(WaveLds, dist_count))
       : "s53", "s54", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "v33", "v34", "v35", "v36", "v37",
-        "v38", "v39", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61",
+        "v38", "v39", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61",
         "v62", "v63", "vcc", "scc", "memory");
   bp = uniu(bp);
   wb = uniu(wb);
@@ -1357,7 +1355,8 @@ __device__ __forceinline__ uint32_t wide_run(BitReader& br, Out& o, uint32_t& e_
   uint32_t pos = o.pos;
   uint32_t carry_len = 0, carry_rec = 0;
   // the deferred far copy: bytes in flight and their LDS addresses -- a lane without one writes a byte nobody reads (the
-  // never-used "codes of length 0" slot of the distance code's per-length counts)
+  // never-used "codes of length 0" slot of the distance code's per-length counts).  (Keeping the lanes as a scalar mask instead
+  // -- one vector instruction less, three scalar ones more per round -- measured 3 % slower: both units are equally loaded.)
   constexpr uint32_t FAR_NONE = RING + (uint32_t)__builtin_offsetof(WaveLds, dist_count);
   uint32_t fdata = 0, faddr = FAR_NONE;
   uint32_t why;
