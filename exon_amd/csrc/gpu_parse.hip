@@ -1,6 +1,6 @@
 // gpu_parse.hip -- VCF record parsing ON THE GPU: raw text in HBM -> device-layout columns in HBM.
 //
-// The host decoders (host/formats.h, host/parallel.h) top out at ~150 Mrows/s on a 128-core host while the
+// The host decoders (host/formats.h, host/parallel.h) top out at ~150 Mrows/s on the GPU boxes' 16-CPU quota while the
 // filter+aggregate kernels consume 500 000 Mrows/s; text crossing PCIe as-is and being parsed on the device lifts
 // the decode stage to the PCIe rate ("GPU-side parse later").  Semantics are those of
 // LazyVCFArrayBuilder::append (exon-vcf/src/array_builder/lazy_array_builder.rs:159-216) restricted to the columns

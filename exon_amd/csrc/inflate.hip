@@ -8,20 +8,18 @@
 // (<= 64 KiB of text each), so a slab of compressed blocks crosses PCIe as it is (3-5x fewer bytes than text) and
 // is inflated by one wavefront per block.
 //
-// One wavefront per block (k_inflate, one wavefront per workgroup, 6.2 KB of static LDS -> 24 per CU):
-//   * the bit stream is consumed by wave-uniform (scalar) code; the compressed bytes sit in a 256-byte window held
-//     across the lanes of one VGPR and are pulled out with v_readlane -- no memory latency on the symbol-decode chain;
-//   * Huffman tables live in LDS: a 9-bit (literal/length) and an 8-bit (distance) first-level table whose entries
-//     are complete decode results (literal byte / length or distance base + extra-bit count + code length), built
-//     lane-parallel from the code lengths (ballot ranks give the canonical codes); a bit-serial canonical decode
-//     (count/first arrays) serves the rare longer codes;
-//   * the last 2 KiB of output stay in an LDS ring: literals and near matches are LDS stores / LDS->LDS copies
-//     (overlapping runs, distance < length, by modular addressing), farther matches read the output already drained
-//     to HBM; the ring is drained in aligned 256-byte rows, one dword per lane;
-//   * the symbol loop is hand-written (symbol_run: literals and the common matches in one inline-assembly block);
-//     the kernel is bound by instruction issue, so the C++ around it is kept free of flags and state variables the
-//     compiler would otherwise thread through it (one merge point for long codes, one exit block, rare paths out
-//     of line).  Tuning log: profiles/r1_tuning.md.
+// One wavefront per block (k_inflate_w / k_inflate, one wavefront per workgroup, 4864 B of static LDS, 64 VGPRs, <= 79 SGPRs -> 32
+// members per CU):
+//   * Huffman tables live in LDS: a 9-bit (literal/length) and an 8-bit (distance) first-level table whose entries are complete
+//     decode results (literal byte / length or distance base + extra-bit count + code length), built lane-parallel from the code
+//     lengths (ballot ranks give the canonical codes); per-length first-code / count / offset arrays serve the longer codes;
+//   * the last 1 KiB of output stays in an LDS ring: literals and near matches are LDS stores / LDS->LDS copies, farther matches
+//     read the output already drained to HBM; the ring is drained in aligned 256-byte rows, one dword per lane;
+//   * the symbol loop (round 5, default): wide_run -- 64 lanes decode the symbols that would start at 64 consecutive BIT offsets,
+//     the true chain is followed with one v_readlane per symbol and the round's output (<= 64 bytes) is produced in one step;
+//     its ordinary rounds are hand-written (wide_rounds_asm).  Rounds 1-4's loops -- one symbol per step on the scalar unit
+//     (symbol_run), on the vector unit with software pipelining (symbol_run_v) -- stay selectable (EXON_HIP_INFLATE_FLAVOR=0|1|2)
+//     and serve the lane-parallel kernel's hand-backs.  Tuning logs: profiles/r1_tuning.md ... DESIGN.md section 7e.
 // Every block reports a status; any failure makes the caller inflate on the host instead.  The CRC-32 of every
 // inflated block is checked by a second kernel (k_crc32: 64 slices per block, combined in GF(2)[x] mod P).
 #include <hip/hip_runtime.h>
@@ -1012,8 +1010,10 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
 //     matches freely, a copy is byte-sequential;
 //   * a byte whose source lies in its own round (distance <= lane: overlapping runs, very near matches) takes the slow path
 //     of the round: the bytes are produced in dependency order, as many per step as are ready;
-//   * a symbol the tables do not resolve (long code, end of block, invalid code) ends the chain in front of it: the round
-//     consumes what precedes it and the caller's slow path takes the symbol, as for the loops above.
+//   * a symbol the tables do not resolve ends the chain in front of it (its lane's record is 0, the chain goes to 64 + lane).  A
+//     LITERAL with a code longer than the table is decoded right there (all candidate lengths at once, one per lane) and the walk
+//     goes on; end of block, a long length / distance code or an invalid code leave the loop: the round consumes what precedes
+//     it and the caller's slow path takes the symbol, as for the loops above.
 // Same contract as symbol_run: why 0 / 1 / 2 as there (e / len / d), 4 = a distance reaches before the member's output.
 // Window: `cur` = dwords [wb, wb + 64) of the compressed data, one per lane, wb a multiple of 32; a round needs the dwords
 // k .. k + 4 with k = bp >> 5 < 32 + 4; when bp passes 1024 the window moves by 32 dwords (upper half of cur + lower half of
@@ -1026,11 +1026,13 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
 #define EXON_WIDE_ASM 1
 #endif
 // The rounds of wide_run that need nothing special, hand-written.  Why by hand: the compiler's version of the round spends 78
-// scalar + 83 vector instructions (VCF text; rocprofv3 PMC, profiles/r5_inflate_wide_v0_pmc.txt), and a CU has ONE scalar ALU for
-// its 32 waves (tools/issue_rate.hip: 1.0 instruction per clock and CU) against 4 x 0.5 vector instructions.  So everything
-// wave-uniform that is not a branch condition or a lane select lives in vector registers here (all 64 lanes computing the same
-// value), masks are taken by v_cmpx straight into EXEC, and the chain walk is two v_readlane + four vector instructions + one
-// compare-and-branch per symbol.
+// scalar + 83 vector instructions (VCF text; rocprofv3 PMC, profiles/r5_inflate_wide_v0_pmc.txt) around divergent branches; the first
+// hand-written version moved everything wave-uniform onto the vector unit (44 scalar + 86 vector per round) -- and PMC then showed the
+// VECTOR unit 95 % busy and the scalar one 45 % (profiles/r5_inflate_wide_v3_pmc.txt: a wave64 integer instruction holds its SIMD for 4
+// clocks, so 8 waves x 86 instructions x 4 clocks were the round).  Now the two units carry about the same load: the chain walk is
+// scalar (position, byte count, loop test) with ONE v_readlane and one masked v_mov per symbol -- EXEC shrinks to the byte lanes at
+// or beyond the current symbol, so no compare-and-select per symbol -- masks are taken by v_cmpx straight into EXEC, and per-lane
+// arithmetic uses the fused forms (v_and_or, v_xad, v_lshl_or, v_add3, v_alignbit instead of a 64-bit shift, SDWA byte / word selects).
 // Order of a round: window (its three ds_bpermute were issued in the previous round, under that round's output) -> two table
 // lookups -> the chain -> the next round's window is requested -> the far copy deferred in the previous round lands (its load had
 // this round's decode and walk to come back) -> a row of the ring completed by the PREVIOUS round is drained (one round late, so
