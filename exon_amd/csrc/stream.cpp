@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -48,12 +49,34 @@ struct ColStage {
   bool any_null_bitmap = false;  // at least one appended batch carried a validity bitmap
 };
 
+// A small pushed batch (the reference's 8192 rows = ~100 KB) is not copied when it arrives: it is HELD -- the stream owns it,
+// its rows have their place in the slot -- and all held batches of a slot are copied together, by the whole pool, when the
+// slot is flushed; then they are released.  One thread copies 32 KB pieces at ~10 GB/s; the pool takes them at the rate of one
+// large batch (bench.py extras.h2d_inclusive: 8192-row batches 29 -> the 4 Mi-row rate).
+struct CopySpan {
+  uint8_t* dst;
+  const uint8_t* src;
+  size_t n;
+};
+struct HeldBatch {
+  struct ArrowArray array;           // moved in (the caller's copy is marked released); released after the copy
+  const struct ArrowArray* ch[4];
+  int64_t off[4];
+  int64_t rows, row0;                // its rows and where they go in the slot
+};
 struct Slot {
   std::vector<ColStage> cols;
   int64_t rows = 0;
   int64_t bytes = 0;  // utf8 payload bytes appended
   hipEvent_t done = nullptr;
   bool in_flight = false;
+  std::vector<HeldBatch> held;
+  // held batches are handed to the copy pool in runs of a few MB WHILE further batches arrive (the pushing thread only keeps
+  // books); the slot's flush waits for the last run
+  size_t submitted = 0;                                        // held[0 .. submitted) are with the pool
+  int64_t unsubmitted_bytes = 0;
+  std::vector<std::unique_ptr<std::vector<CopySpan>>> span_runs;  // the pool reads these until `pending` is 0
+  std::atomic<size_t> pending{0};
 };
 
 }  // namespace
@@ -99,6 +122,7 @@ struct exon_hip_stream {
   int32_t region_id_override = INT32_MIN;
 };
 enum { KEYS_NONE = 0, KEYS_LOCAL = 1, KEYS_AGREED = 2 };
+constexpr int64_t HOLD_MAX_ROWS = 1 << 17;  // batches up to this many rows are held until their slot is flushed
 
 // keyed layout of a plan's packed state: [planes_i x G int64][tail int64][planes_f x G float64]
 static bool key_layout(const exon_hip_plan* p, int* G, int* planes_i, int* tail, int* planes_f) {
@@ -124,6 +148,44 @@ class CopyPool {
   static CopyPool& get() {
     static CopyPool p;
     return p;
+  }
+  typedef CopySpan Span;
+  // many small copies, asynchronously: the list (which must stay alive until *left is 0) is cut into runs of ~1 MiB for the
+  // helper threads; the caller goes on and later calls help_until(left).  Without helpers the copies are done here.
+  void submit(const Span* v, size_t count, std::atomic<size_t>* left) {
+    if (threads_.empty()) {
+      for (size_t i = 0; i < count; ++i) memcpy(v[i].dst, v[i].src, v[i].n);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      size_t i = 0;
+      while (i < count) {
+        size_t j = i, bytes = 0;
+        while (j < count && bytes < (1u << 20)) bytes += v[j++].n;
+        left->fetch_add(1, std::memory_order_relaxed);
+        jobs_.push_back(Job{nullptr, reinterpret_cast<const uint8_t*>(v + i), j - i, left});  // dst == nullptr: a run of spans
+        i = j;
+      }
+    }
+    cv_.notify_all();
+  }
+  // the caller takes jobs too (anybody's), then waits for the runs the helpers hold
+  void help_until(std::atomic<size_t>* left) {
+    while (left->load(std::memory_order_acquire) != 0) {
+      Job j;
+      bool have = false;
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        if (!jobs_.empty()) {
+          j = jobs_.front();
+          jobs_.pop_front();
+          have = true;
+        }
+      }
+      if (have) do_job(j);
+      else std::this_thread::yield();
+    }
   }
   void copy(void* dst, const void* src, size_t n) {
     constexpr size_t PIECE = 1u << 20;
@@ -151,19 +213,27 @@ class CopyPool {
         j = jobs_.front();
         jobs_.pop_front();
       }
-      memcpy(j.dst, j.src, j.n);
-      j.left->fetch_sub(1, std::memory_order_acq_rel);
+      do_job(j);
     }
     while (left.load(std::memory_order_acquire) != 0) std::this_thread::yield();
   }
 
  private:
   struct Job {
-    uint8_t* dst;
+    uint8_t* dst;        // nullptr: `src` points at a run of `n` Spans
     const uint8_t* src;
     size_t n;
     std::atomic<size_t>* left;
   };
+  static void do_job(const Job& j) {
+    if (j.dst) {
+      memcpy(j.dst, j.src, j.n);
+    } else {
+      const Span* v = reinterpret_cast<const Span*>(j.src);
+      for (size_t i = 0; i < j.n; ++i) memcpy(v[i].dst, v[i].src, v[i].n);
+    }
+    j.left->fetch_sub(1, std::memory_order_acq_rel);
+  }
   CopyPool() {
     int t = 8;
     if (const char* v = getenv("EXON_HIP_STAGE_THREADS")) t = atoi(v);
@@ -189,8 +259,7 @@ class CopyPool {
         j = jobs_.front();
         jobs_.pop_front();
       }
-      memcpy(j.dst, j.src, j.n);
-      j.left->fetch_sub(1, std::memory_order_acq_rel);
+      do_job(j);
     }
   }
   std::mutex mu_;
@@ -234,6 +303,13 @@ static double now_s() {
 }
 
 static void free_slot(Slot& s) {
+  CopyPool::get().help_until(&s.pending);
+  for (auto& h : s.held)
+    if (h.array.release) h.array.release(&h.array);
+  s.held.clear();
+  s.span_runs.clear();
+  s.submitted = 0;
+  s.unsubmitted_bytes = 0;
   for (auto& c : s.cols) {
     if (c.h_values) hipHostFree(c.h_values);
     if (c.h_valid) hipHostFree(c.h_valid);
@@ -319,9 +395,57 @@ static int settle_reset(exon_hip_stream* st) {
   return EXON_HIP_OK;
 }
 
+static void release_held(Slot& s) {
+  CopyPool::get().help_until(&s.pending);  // (nobody may still be reading a batch that is released)
+  for (auto& h : s.held)
+    if (h.array.release) h.array.release(&h.array);
+  s.held.clear();
+  s.span_runs.clear();
+  s.submitted = 0;
+  s.unsubmitted_bytes = 0;
+}
+// held[submitted ..) go to the copy pool (values) and into the bitmaps (in arrival order, on this thread)
+static void submit_held(exon_hip_stream* st, Slot& s) {
+  if (s.submitted == s.held.size()) return;
+  exon_hip_plan* p = st->plan;
+  auto run = std::make_unique<std::vector<CopySpan>>();
+  run->reserve((s.held.size() - s.submitted) * (size_t)p->n_cols);
+  for (size_t k = s.submitted; k < s.held.size(); ++k) {
+    const HeldBatch& h = s.held[k];
+    for (int c = 0; c < p->n_cols; ++c) {
+      ColStage& cs = s.cols[(size_t)c];
+      const int e = p->cols[c].elem;
+      run->push_back(CopySpan{cs.h_values + (size_t)h.row0 * e, (const uint8_t*)h.ch[c]->buffers[1] + (size_t)h.off[c] * e, (size_t)h.rows * e});
+      const uint8_t* valid = (const uint8_t*)h.ch[c]->buffers[0];
+      if (valid && h.ch[c]->null_count != 0) {
+        if (!cs.any_null_bitmap) {
+          append_bits(cs.h_valid, 0, nullptr, 0, h.row0);  // the rows in front of it had no bitmap: mark them valid
+          cs.any_null_bitmap = true;
+        }
+        append_bits(cs.h_valid, h.row0, valid, h.off[c], h.rows);
+      } else if (cs.any_null_bitmap) {
+        append_bits(cs.h_valid, h.row0, nullptr, 0, h.rows);
+      }
+    }
+  }
+  CopyPool::get().submit(run->data(), run->size(), &s.pending);
+  s.span_runs.push_back(std::move(run));
+  s.submitted = s.held.size();
+  s.unsubmitted_bytes = 0;
+}
+// every held batch of the slot is in its staging buffers; then they are released
+static void materialise_held(exon_hip_stream* st, Slot& s) {
+  if (s.held.empty()) return;
+  const double t_c0 = now_s();
+  submit_held(st, s);
+  release_held(s);
+  st->t_copy += now_s() - t_c0;
+}
+
 static int flush_slot(exon_hip_stream* st) {
   Slot& s = st->slots[st->cur];
   if (s.rows == 0) return EXON_HIP_OK;
+  materialise_held(st, s);
   exon_hip_plan* p = st->plan;
   const double t_f0 = now_s();
   exon_hip_column cols[4];
@@ -553,8 +677,34 @@ int exon_hip_stream_push(exon_hip_stream* st, struct ArrowArray* batch) {
     rc = ensure_capacity(st, rows, need_bytes);
     if (!rc && (st->slots[st->cur].rows + rows > st->cap_rows || st->slots[st->cur].bytes + need_bytes > st->cap_bytes))
       rc = flush_slot(st);
+    bool fixed = true;
+    for (int c = 0; c < p->n_cols; ++c) fixed = fixed && !p->cols[c].utf8;
+    static const bool hold_on = [] {
+      const char* v = getenv("EXON_HIP_HOLD_SMALL_BATCHES");
+      return !(v && v[0] == '0');
+    }();
+    if (!rc && fixed && hold_on && rows <= HOLD_MAX_ROWS) {  // a small batch: held, copied with the slot's others when the slot is flushed
+      Slot& s = st->slots[st->cur];
+      HeldBatch h;
+      h.array = *batch;
+      batch->release = nullptr;  // moved: the stream releases it after the copy
+      for (int c = 0; c < p->n_cols; ++c) {
+        // (the children pointers stay valid: they belong to the moved array's private data, not to the caller's struct)
+        h.ch[c] = ch[c];
+        h.off[c] = off[c];
+      }
+      h.rows = rows;
+      h.row0 = s.rows;
+      s.held.push_back(h);
+      s.rows += rows;
+      st->rows_pushed += rows;
+      for (int c = 0; c < p->n_cols; ++c) s.unsubmitted_bytes += rows * p->cols[c].elem;
+      if (s.unsubmitted_bytes >= (4 << 20)) submit_held(st, s);  // the pool copies them while the next batches arrive
+      return EXON_HIP_OK;
+    }
     if (!rc) {
       Slot& s = st->slots[st->cur];
+      materialise_held(st, s);  // (keeps the bitmap bookkeeping in arrival order)
       const double t_c0 = now_s();
       for (int c = 0; c < p->n_cols; ++c) {
         ColStage& cs = s.cols[(size_t)c];
@@ -1217,6 +1367,7 @@ int exon_hip_stream_reconcile_keys(exon_hip_stream* st, void* rccl_comm) {
 int exon_hip_stream_reset(exon_hip_stream* st) {
   if (!st) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_stream_reset: NULL stream");
   Slot& s = st->slots[st->cur];
+  release_held(s);  // (batches held for the old query: dropped with it, released uncopied)
   if (!s.cols.empty()) {
     s.rows = 0;
     s.bytes = 0;

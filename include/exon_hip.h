@@ -318,9 +318,14 @@ int exon_hip_rccl_comm_count(void* rccl_comm, int32_t* world, int32_t* rank);
 /* One stream per partition (= per file group); single-threaded handle, owns one HIP stream, a
  * device-resident partial state and pinned staging buffers. */
 int exon_hip_stream_open(exon_hip_plan* plan, int32_t partition, exon_hip_stream** out);
-/* Host Arrow struct batch (children = columns).  The batch is MOVED: the library calls
- * batch->release exactly once, after its buffers have been copied to HBM.  Dictionary-encoded
- * int32 indices are accepted for id columns (the dictionary itself stays with the caller). */
+/* Host Arrow struct batch (children = columns).  The batch is MOVED (Arrow C Data Interface: on return `batch->release` is
+ * NULL and the stream owns the array): the library calls the array's release callback exactly once, after its buffers have
+ * been copied -- for a batch of up to 131072 rows of fixed-width columns that may be AFTER this call returns: such batches are
+ * held and copied together, by a pool of threads, when their staging slot is flushed (the next push that fills it, sync,
+ * state, finish, reset or close).  Everything the array points to must therefore stay valid until the callback runs, as the
+ * interface requires of any exported array (an array whose children or buffer tables live on the caller's stack is not one).
+ * EXON_HIP_HOLD_SMALL_BATCHES=0: copy and release inside the call.  Dictionary-encoded int32 indices are accepted for id
+ * columns (the dictionary itself stays with the caller). */
 int exon_hip_stream_push(exon_hip_stream* s, struct ArrowArray* batch);
 /* HBM-resident batch (device_type must be ARROW_DEVICE_ROCM on this ctx's device).  Not moved:
  * buffers must stay alive until the next exon_hip_stream_sync/finish. */

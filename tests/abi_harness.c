@@ -115,10 +115,11 @@ int main(int argc, char** argv) {
     CHECK(exon_hip_stream_push(st, &batch));
     if (batch.release != NULL) { fprintf(stderr, "batch %d was not released (moved) by the library\n", b); return 1; }
   }
-  if (releases != BATCHES) { fprintf(stderr, "%d releases for %d batches\n", releases, BATCHES); return 1; }
   struct ArrowArray out;
   struct ArrowSchema out_schema;
   CHECK(exon_hip_stream_finish_arrow(st, &out, &out_schema));
+  /* a small batch may be HELD by the stream and released when its staging slot is flushed: by now every one is released, once */
+  if (releases != BATCHES) { fprintf(stderr, "%d releases for %d batches\n", releases, BATCHES); return 1; }
   /* {group: i32, avg[count]: u64, avg[sum]: f64, count(*)[count]: i64}, observed groups only */
   if (strcmp(out_schema.format, "+s") != 0 || out_schema.n_children != 4 || out.n_children != 4) { fprintf(stderr, "state batch shape\n"); return 1; }
   static const char* want_fmt[4] = {"i", "L", "g", "l"};

@@ -319,3 +319,42 @@ def test_back_to_back_overwrite_launches_are_bit_identical(ctx):
         for o in outs:
             assert np.array_equal(o.to_host(), want)
     plan.close()
+
+
+def test_small_batches_are_held_and_copied_by_the_pool(ctx, oracle, monkeypatch):
+    """Batches of up to 131072 rows are HELD by the stream (released after their slot's pooled copy, not inside the push): many
+    8192-row pushes with runs handed to the pool while more arrive, a first stretch without validity bitmaps and a later one with
+    (the bitmap starts mid-slot), a big batch in between (copied at once, in order), a reset that drops held batches uncopied, a
+    slot boundary inside the held rows -- same state as one big launch over all rows, and as with holding switched off."""
+    import pyarrow as pa
+    import subprocess, sys
+    n = 1_200_000
+    af, av, q, qv, fid = oracle.gen_c4(9, 0, n)
+    avb, qvb = bits(av, n), bits(qv, n)
+    avb[:300_000] = True  # no NULL in the first stretch: those batches carry no bitmap at all
+    qvb[:300_000] = True
+    av2, qv2 = np.packbits(avb, bitorder="little"), np.packbits(qvb, bitorder="little")
+    filters = oracle.c4_filters()
+
+    def rb(lo, hi):
+        a = pa.array(af[lo:hi], mask=~avb[lo:hi]) if not avb[lo:hi].all() else pa.array(af[lo:hi])
+        b = pa.array(q[lo:hi], mask=~qvb[lo:hi]) if not qvb[lo:hi].all() else pa.array(q[lo:hi])
+        return pa.record_batch({"af": a, "qual": b, "filter": pa.DictionaryArray.from_arrays(pa.array(fid[lo:hi]), pa.array(filters))})
+
+    monkeypatch.setenv("EXON_HIP_COALESCE_ROWS", "500000")
+    plan = ctx.plan_cmp_avg_by_group(">", 0.01, 5)
+    st = plan.open()
+    for lo in range(0, 90_000, 8192):      # a query that is abandoned: its held batches are released uncopied
+        st.push(rb(lo, min(lo + 8192, 90_000)))
+    st.reset()
+    lo = 0
+    while lo < n:
+        hi = min(n, lo + (200_000 if lo == 40 * 8192 else 8192))  # one batch above the holding limit in between
+        st.push(rb(lo, hi))
+        lo = hi
+    counts, sums = st.finish()
+    s, cn, cr, _ = oracle.c4_cmp_avg_by_group(af, av2, q, qv2, fid, filters, 0.01, ">")
+    assert np.array_equal(counts[:5], cn) and np.array_equal(counts[5:], cr)
+    assert np.allclose(sums, s, rtol=1e-6, atol=0)
+    st.close()
+    plan.close()

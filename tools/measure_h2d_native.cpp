@@ -48,21 +48,31 @@ int main(int argc, char** argv) {
     const auto t0 = std::chrono::steady_clock::now();
     for (int64_t o = 0; o < total; o += batch) {
       const int64_t n = std::min(batch, total - o);
-      const void* b0[2] = {nullptr, af.data() + o};
-      const void* b1[2] = {nullptr, qual.data() + o};
-      const void* b2[2] = {nullptr, fid.data() + o};
-      const void* bt[1] = {nullptr};
-      struct ArrowArray kids[3];
-      const void** bufs[3] = {b0, b1, b2};
-      struct ArrowArray* kp[3];
+      // an exported batch owns what it points to until its release callback runs -- which may be AFTER the push returns (a
+      // small batch is held until its staging slot is flushed): everything lives in one heap block freed by the callback
+      struct Mem {
+        const void* b[3][2];
+        const void* bt[1];
+        struct ArrowArray kids[3];
+        struct ArrowArray* kp[3];
+      };
+      Mem* m = new Mem();
+      m->b[0][0] = nullptr; m->b[0][1] = af.data() + o;
+      m->b[1][0] = nullptr; m->b[1][1] = qual.data() + o;
+      m->b[2][0] = nullptr; m->b[2][1] = fid.data() + o;
+      m->bt[0] = nullptr;
       for (int c = 0; c < 3; ++c) {
-        memset(&kids[c], 0, sizeof kids[c]);
-        kids[c].length = n; kids[c].n_buffers = 2; kids[c].buffers = bufs[c]; kids[c].release = release_noop;
-        kp[c] = &kids[c];
+        memset(&m->kids[c], 0, sizeof m->kids[c]);
+        m->kids[c].length = n; m->kids[c].n_buffers = 2; m->kids[c].buffers = m->b[c]; m->kids[c].release = release_noop;
+        m->kp[c] = &m->kids[c];
       }
       struct ArrowArray top;
       memset(&top, 0, sizeof top);
-      top.length = n; top.n_buffers = 1; top.buffers = bt; top.n_children = 3; top.children = kp; top.release = release_noop;
+      top.length = n; top.n_buffers = 1; top.buffers = m->bt; top.n_children = 3; top.children = m->kp; top.private_data = m;
+      top.release = [](struct ArrowArray* a) {
+        delete static_cast<Mem*>(a->private_data);
+        a->release = nullptr;
+      };
       if (exon_hip_stream_push(st, &top) != EXON_HIP_OK) { fprintf(stderr, "%s\n", exon_hip_last_error(ctx)); return 1; }
     }
     int64_t counts[10];
