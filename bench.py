@@ -74,6 +74,8 @@ def parse_args():
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not measure roofline.traffic in this run (two rocprofv3 --pmc passes of a short child run); use profiles/traffic.json")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (stated-size configs, H2D-inclusive rate)")
+    ap.add_argument("--calib-copy", action="store_true",
+                    help="(child runs of measure_traffic) one 1 GiB device-to-device copy first: the counter pass calibrates its bytes-per-count on it")
     return ap.parse_args()
 
 
@@ -311,10 +313,15 @@ PMC_KERNEL = {"c4": "k4_cmp_avg_by_group_main", "c2": "k2_region_count_main", "c
 def measure_traffic(a, rows):
     """roofline.traffic measured in THIS run: HBM bytes per launch of the dominant kernel from rocprofv3 PMC counters, collected
     the way /opt/skills/guides/MI355X_MICROARCH.md prescribes -- FETCH_SIZE and WRITE_SIZE in SEPARATE passes, each with
-    --kernel-trace only, values in KiB, and on gfx950 FETCH_SIZE counts half of the bytes of a wide (16 B per lane) coalesced
-    stream: read bytes = 2 x FETCH_SIZE x 1024.  Each pass is a short child run of this script on the same workload (3 steps);
-    launches of the full table are the ones whose counter is within 2x of the largest (the parity gate's launch is smaller).
-    Returns (bytes, note) or None (no rocprofv3, a failed pass: the caller falls back to profiles/traffic.json)."""
+    --kernel-trace only, values in KiB.  On gfx950 FETCH_SIZE counts about half of the bytes of a wide (16 B per lane) coalesced
+    stream; instead of assuming the factor 2, every pass CALIBRATES it: the child run first copies 1 GiB device to device (a
+    transfer of known size through wide coalesced accesses, the kernel `copyBuffer` of the runtime), and bytes per count =
+    2^30 / that kernel's counter.  The kernels of this path read their columns with 16 B per lane non-temporal loads (K2-K6;
+    K5's chunk path too), i.e. the access pattern the calibration copy has.  A calibration outside [0.8, 2.5] for reads or
+    [0.8, 1.3] for writes (or no copy kernel in the trace) falls back to the guide's 2 / 1 and says so.
+    Each pass is a short child run of this script on the same workload (3 steps); launches of the full table are the ones whose
+    counter is within 2x of the largest (the parity gate's launch is smaller).
+    Returns (bytes, note, raw) or None (no rocprofv3, a failed pass: the caller falls back to profiles/traffic.json)."""
     import csv
     import glob
     import shutil
@@ -323,32 +330,42 @@ def measure_traffic(a, rows):
     exe = shutil.which("rocprofv3")
     if exe is None or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):  # no profiler, or this run is already a traced one
         return None
-    vals = {}
+    vals, factor, how = {}, {}, {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="exon_pmc_", dir="/tmp")
         try:
             cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable,
                    os.path.abspath(__file__), "--workload", a.workload, "--rows", str(int(rows)), "--steps", "3", "--warmup", "1",
-                   "--no-cpu-baseline", "--no-extras", "--no-pmc"]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=120)
+                   "--no-cpu-baseline", "--no-extras", "--no-pmc", "--calib-copy"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=180)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None
-            v = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
-                 if PMC_KERNEL[a.workload] in row["Kernel_Name"] and row["Counter_Name"] == ctr]
+            rows_csv = list(csv.DictReader(open(files[0])))
+            v = [float(row["Counter_Value"]) for row in rows_csv if PMC_KERNEL[a.workload] in row["Kernel_Name"] and row["Counter_Name"] == ctr]
             if not v:
                 return None
             full = [x for x in v if x >= 0.5 * max(v)] if max(v) > 0 else v
             vals[ctr] = (sum(full) / len(full), len(full))
+            cal = [float(row["Counter_Value"]) for row in rows_csv if "copyBuffer" in row["Kernel_Name"] and row["Counter_Name"] == ctr]
+            cal = [x for x in cal if x > 0.25 * (1 << 20)]  # the 1 GiB copy (KiB counts of half a GiB and more), not the small ones
+            default, lo, hi = (2.0, 0.8, 2.5) if ctr == "FETCH_SIZE" else (1.0, 0.8, 1.3)
+            f = (1 << 20) / (sum(cal) / len(cal)) if cal else None
+            if f is not None and lo <= f <= hi:
+                factor[ctr], how[ctr] = f, f"calibrated on a 1 GiB device-to-device copy in the same pass ({f:.4f} bytes per counted byte)"
+            else:
+                factor[ctr], how[ctr] = default, (f"the guide's {default:g} (calibration copy " + ("not found in the trace" if f is None else f"gave {f:.3f}: out of range") + ")")
         except Exception:
             return None
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    b = int(2 * vals["FETCH_SIZE"][0] * 1024 + vals["WRITE_SIZE"][0] * 1024)
+    b = int(factor["FETCH_SIZE"] * vals["FETCH_SIZE"][0] * 1024 + factor["WRITE_SIZE"] * vals["WRITE_SIZE"][0] * 1024)
+    raw = {"FETCH_SIZE_KiB": round(vals["FETCH_SIZE"][0], 1), "WRITE_SIZE_KiB": round(vals["WRITE_SIZE"][0], 1),
+           "fetch_bytes_per_count": round(factor["FETCH_SIZE"], 4), "write_bytes_per_count": round(factor["WRITE_SIZE"], 4)}
     note = (f"measured in this run: two rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE, each with --kernel-trace only) of a 3-step child "
-            f"run, {vals['FETCH_SIZE'][1]} full launches averaged; read bytes = 2 x FETCH_SIZE KiB x 1024 (gfx950 wide-stream "
-            f"undercount, MI355X_MICROARCH.md), write bytes = WRITE_SIZE KiB x 1024")
-    return b, note
+            f"run, {vals['FETCH_SIZE'][1]} full launches averaged; read bytes = FETCH_SIZE KiB x 1024 x {factor['FETCH_SIZE']:.4f} ({how['FETCH_SIZE']}), "
+            f"write bytes = WRITE_SIZE KiB x 1024 x {factor['WRITE_SIZE']:.4f} ({how['WRITE_SIZE']}); raw counters in roofline.traffic_raw")
+    return b, note, raw
 
 
 def time_config(ctx, kind, rows, steps=50, warmup=5):
@@ -443,6 +460,13 @@ def main():
     import exon_amd
     from exon_amd.distributed import NativeComm, merge_state, shard_rows
     ctx = exon_amd.Context(device)
+    if a.calib_copy:  # a transfer of KNOWN size for the PMC pass around this run: 1 GiB read, 1 GiB written, wide coalesced accesses
+        cs_, cd_ = torch.empty(1 << 30, dtype=torch.uint8, device=f"cuda:{device}"), torch.empty(1 << 30, dtype=torch.uint8, device=f"cuda:{device}")
+        cs_.fill_(1)
+        torch.cuda.synchronize()
+        cd_.copy_(cs_)
+        torch.cuda.synchronize()
+        del cs_, cd_
     # kernels, events and collectives all go on ONE explicit (non-default) HIP stream
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
@@ -578,7 +602,7 @@ def main():
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
         live = measure_traffic(a, rows) if (world == 1 and not a.no_pmc and a.groups == 5) else None
         if live is not None:
-            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = live
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"], out["roofline"]["traffic_raw"] = live
         elif os.path.exists(traffic_file):
             try:
                 t = json.load(open(traffic_file)).get(a.workload)

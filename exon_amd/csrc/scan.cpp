@@ -601,6 +601,9 @@ class GpuTextSource {
   ~GpuTextSource() {
     const double td0 = now_s();
     if (reader_.joinable()) reader_.join();
+    // fill() starts the next piece's read before the H2D copy and the header walk, either of which may throw: a read may still
+    // be in flight into the pinned ring that is handed back to the cache (or freed) below -- wait for it first
+    (void)rd_.finish();
     const double td1 = now_s();
     if (xs_) hipStreamSynchronize(xs_);
     if (cs_) hipStreamSynchronize(cs_);

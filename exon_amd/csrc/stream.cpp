@@ -976,27 +976,36 @@ int exon_hip_stream_end_scan(exon_hip_stream* st, const std::vector<std::string>
     return EXON_HIP_OK;
   }
   if ((int64_t)scan_keys->size() > G)
-    return fail(st->ctx, EXON_HIP_EINVAL, "the scan's group-key dictionary has %zu entries, the plan was created for n_groups = %d", scan_keys->size(), G);
+    return fail(st->ctx, EXON_HIP_ECAPACITY, "the scan's group-key dictionary has %zu entries, the plan was created for n_groups = %d", scan_keys->size(), G);
   if (!redirected) {  // first scan of the stream: its ids ARE the stream's
     st->keys = *scan_keys;
     st->keys_state = KEYS_LOCAL;
     return EXON_HIP_OK;
   }
+  // The map and the enlarged dictionary are worked out on the side and adopted only when the scan's state has been added in: a
+  // scan that does not fit (or whose add fails) leaves the stream's dictionary and state exactly as they were -- the scan's rows
+  // are lost (the call fails), but nothing half-done stays behind.
   std::vector<int32_t> map(scan_keys->size());
+  std::vector<std::string> grown = st->keys;
   std::unordered_map<std::string, int32_t> index;
-  for (size_t i = 0; i < st->keys.size(); ++i) index.emplace(st->keys[i], (int32_t)i);  // first occurrence wins
+  for (size_t i = 0; i < grown.size(); ++i) index.emplace(grown[i], (int32_t)i);  // first occurrence wins
   for (size_t i = 0; i < scan_keys->size(); ++i) {
     auto it = index.find((*scan_keys)[i]);
     if (it == index.end()) {
-      if ((int64_t)st->keys.size() >= G)
-        return fail(st->ctx, EXON_HIP_EINVAL, "the scans' group keys hold more than the %d distinct values the plan was created for (n_groups)", G);
-      it = index.emplace((*scan_keys)[i], (int32_t)st->keys.size()).first;
-      st->keys.push_back((*scan_keys)[i]);
+      if ((int64_t)grown.size() >= G)
+        return fail(st->ctx, EXON_HIP_ECAPACITY,
+                    "the scans' group keys hold more than the %d distinct values the plan was created for (n_groups); this scan's "
+                    "rows were not added, the stream's state and dictionary are unchanged", G);
+      it = index.emplace((*scan_keys)[i], (int32_t)grown.size()).first;
+      grown.push_back((*scan_keys)[i]);
     }
     map[i] = it->second;
   }
+  rc = permute_add(st, st->d_rekey_state, st->d_state, map);
+  if (rc) return rc;
+  st->keys.swap(grown);
   st->keys_state = KEYS_LOCAL;
-  return permute_add(st, st->d_rekey_state, st->d_state, map);
+  return EXON_HIP_OK;
 }
 // region plans over files: the stream's contig NAME (exon_hip_stream_set_region_contig) -> this scan's dictionary id
 bool exon_hip_stream_region_contig(exon_hip_stream* st, std::string* name) {
@@ -1248,7 +1257,7 @@ static int adopt_keys(exon_hip_stream* st, const std::vector<std::string>& names
   int G = 0, pi, tail, pf;
   if (!key_layout(st->plan, &G, &pi, &tail, &pf)) return fail(st->ctx, EXON_HIP_EINVAL, "this plan does not group by a key");
   if ((int64_t)names.size() > G)
-    return fail(st->ctx, EXON_HIP_EINVAL, "%zu group keys do not fit the plan's n_groups = %d (create the plan for the union's size)", names.size(), G);
+    return fail(st->ctx, EXON_HIP_ECAPACITY, "%zu group keys do not fit the plan's n_groups = %d (create the plan for the union's size)", names.size(), G);
   {
     std::unordered_map<std::string, int> seen;
     for (const auto& k : names)

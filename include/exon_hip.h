@@ -91,6 +91,9 @@ struct ArrowDeviceArray {
 #define EXON_HIP_EDEVICE (-3)      /* HIP runtime error (text in exon_hip_last_error) */
 #define EXON_HIP_EUNSUPPORTED (-4) /* valid request this build does not implement */
 #define EXON_HIP_ESTATE (-5)       /* call out of order (e.g. push after finish) */
+#define EXON_HIP_ECAPACITY (-6)    /* more distinct group keys than the plan's n_groups: the stream's state and dictionary are
+                                      unchanged (the offending scan's rows were not added) -- finish the stream, emit its state,
+                                      and continue on a fresh one, or create the plan for more groups (round 5; EINVAL before) */
 
 typedef struct exon_hip_ctx exon_hip_ctx;
 typedef struct exon_hip_plan exon_hip_plan;
@@ -348,7 +351,7 @@ int exon_hip_stream_all_reduce(exon_hip_stream* s, void* rccl_comm);
  * over the file groups of exon-core/src/datasources/exon_file_scan_config.rs:79-110).  So a stream fed by
  * exon_hip_stream_consume_scan remembers the value behind every state index: the first scan's dictionary becomes the stream's,
  * every further scan is aggregated under its own ids and added in under the stream's (new values are appended; more distinct
- * values than the plan's n_groups is EXON_HIP_EINVAL).  Across ranks, exon_hip_stream_all_reduce REFUSES (EXON_HIP_ESTATE) a
+ * values than the plan's n_groups is EXON_HIP_ECAPACITY and leaves the stream as it was).  Across ranks, exon_hip_stream_all_reduce REFUSES (EXON_HIP_ESTATE) a
  * state keyed by a rank-local dictionary until the ranks have agreed on one -- exon_hip_stream_reconcile_keys, or
  * exon_hip_stream_keys on every rank + exon_hip_keys_union + exon_hip_stream_set_keys when the host moves the names itself.
  * Names are packed as '\0'-terminated strings back to back ("" is a legal key: the empty FILTER list); K3's NULL-reference
@@ -368,7 +371,7 @@ int exon_hip_keys_union(const char* packed, size_t packed_bytes, const int32_t* 
 /* collective over `rccl_comm` (every rank calls it, between its last consume_scan and exon_hip_stream_all_reduce): two small
  * ncclAllGathers move the dictionaries, every rank forms the same union and permutes its state into it.  A rank that cannot take
  * part (rows pushed under undeclared ids) says so INSIDE the first exchange: every rank then returns EXON_HIP_ESTATE, none hangs.
- * A union larger than the plan's n_groups is EXON_HIP_EINVAL on every rank (all ranks compute the same union). */
+ * A union larger than the plan's n_groups is EXON_HIP_ECAPACITY on every rank (all ranks compute the same union). */
 int exon_hip_stream_reconcile_keys(exon_hip_stream* s, void* rccl_comm);
 /* Region plans (K2 / K6 / K7) fed by files: name the contig instead of fixing exon_hip_plan_desc.region_chrom_id -- every
  * exon_hip_stream_consume_scan then resolves the name in that file's own contig / reference dictionary (a BAM without such

@@ -98,7 +98,8 @@ impl StreamHandle {
         check(gpu.ctx, unsafe { sys::exon_hip_stream_open(gpu.plan, partition as i32, &mut s) })?;
         Ok(Self(s))
     }
-    /// moves `batch` into the library (it calls `release` exactly once, success or not)
+    /// moves `batch` into the library: it calls `release` exactly once, success or not -- for a small batch possibly AFTER this
+    /// call returns (held until its staging slot is flushed).  `to_ffi` exports heap-owned arrays, as the interface requires.
     fn push(&self, gpu: &GpuPlan, batch: &RecordBatch) -> Result<()> {
         let (mut arr, _sch) = to_ffi(&StructArray::from(batch.clone()).to_data())?; // zero-copy export
         let rc = unsafe { sys::exon_hip_stream_push(self.0, &mut arr as *mut FFI_ArrowArray) };
@@ -408,7 +409,7 @@ impl ExecutionPlan for GpuFilterAggExec {
                     let region = region.clone();
                     let (shape_b, schema_b) = (shape.clone(), schema.clone());
                     let plan = gpu.clone().expect("GpuFilterAggExec::try_new always creates the plan");
-                    let batch = tokio::task::spawn_blocking(move || -> Result<RecordBatch> {
+                    let batches = tokio::task::spawn_blocking(move || -> Result<Vec<RecordBatch>> {
                         let info = match &shape_b {
                             Shape::CmpAvgByGroup { info_field } => Some(CString::new(info_field.as_str()).unwrap()),
                             _ => None,
@@ -417,13 +418,25 @@ impl ExecutionPlan for GpuFilterAggExec {
                         // ONE stream per partition: group keys travel by VALUE (ABI 4) -- the first file's dictionary
                         // becomes the stream's, every further file is aggregated under its own ids and added in under
                         // the stream's -- so a partition emits one state batch however many files it holds
-                        let stream = StreamHandle::open(&plan, partition)?;
-                        if matches!(shape_b, Shape::RegionCount | Shape::OverlapCount) {
-                            // `chrom = <id>` is resolved by NAME in every file's own header order; the scan's row mask
-                            // (k_region_mask) has already applied the interval, so the plan counts what the scan emits
-                            let name = CString::new(region_name(region.as_deref().unwrap_or(""))).unwrap();
-                            check(plan.ctx, unsafe { sys::exon_hip_stream_set_region_contig(stream.0, name.as_ptr()) })?;
-                        }
+                        let open_stream = || -> Result<StreamHandle> {
+                            let stream = StreamHandle::open(&plan, partition)?;
+                            if matches!(shape_b, Shape::RegionCount | Shape::OverlapCount) {
+                                // `chrom = <id>` is resolved by NAME in every file's own header order; the scan's row mask
+                                // (k_region_mask) has already applied the interval, so the plan counts what the scan emits
+                                let name = CString::new(region_name(region.as_deref().unwrap_or(""))).unwrap();
+                                check(plan.ctx, unsafe { sys::exon_hip_stream_set_region_contig(stream.0, name.as_ptr()) })?;
+                            }
+                            Ok(stream)
+                        };
+                        // the state of one stream as the partial-aggregate batch AggregateExec(Final) consumes
+                        let emit = |stream: &StreamHandle| -> Result<RecordBatch> {
+                            // key VALUES of the state's indexes (VCF: FILTER lists as ';'-joined text; BAM: reference names)
+                            let keys = Keys(stream.keys(&plan)?.into_iter().map(Some).collect());
+                            let state = stream.finish(&plan)?;
+                            state_to_partial(&shape_b, &state, &keys, &schema_b)
+                        };
+                        let mut done: Vec<RecordBatch> = Vec::new();
+                        let mut stream = open_stream()?;
                         for path in &files {
                             let opt = sys::exon_hip_scan_options {
                                 format,
@@ -439,16 +452,29 @@ impl ExecutionPlan for GpuFilterAggExec {
                             check(std::ptr::null(), unsafe { sys::exon_hip_scan_open(cpath.as_ptr(), &opt, &mut raw) })?;
                             let scan = ScanHandle(raw);
                             let mut rows = 0i64;
-                            check(plan.ctx, unsafe { sys::exon_hip_stream_consume_scan(stream.0, scan.0, &mut rows) })?;
+                            let mut rc = unsafe { sys::exon_hip_stream_consume_scan(stream.0, scan.0, &mut rows) };
+                            if rc == sys::EXON_HIP_ECAPACITY {
+                                // The UNION of the dictionaries of this partition's files no longer fits the plan's n_groups
+                                // (each file's own does, or the retry below fails too).  The library left the stream as it
+                                // was before this file: emit its state as one partial batch -- AggregateExec(Final) merges
+                                // partial batches by key VALUE, any number of them per partition -- and give the file a
+                                // fresh stream (what every file had before the partition shared one).
+                                done.push(emit(&stream)?);
+                                stream = open_stream()?;
+                                drop(scan);
+                                let mut raw2 = std::ptr::null_mut();
+                                check(std::ptr::null(), unsafe { sys::exon_hip_scan_open(cpath.as_ptr(), &opt, &mut raw2) })?;
+                                let scan2 = ScanHandle(raw2);
+                                rc = unsafe { sys::exon_hip_stream_consume_scan(stream.0, scan2.0, &mut rows) };
+                            }
+                            check(plan.ctx, rc)?;
                         }
-                        // key VALUES of the state's indexes (VCF: FILTER lists as ';'-joined text; BAM: reference names)
-                        let keys = Keys(stream.keys(&plan)?.into_iter().map(Some).collect());
-                        let state = stream.finish(&plan)?;
-                        state_to_partial(&shape_b, &state, &keys, &schema_b)
+                        done.push(emit(&stream)?);
+                        Ok(done)
                     })
                     .await
                     .map_err(|e| DataFusionError::External(Box::new(e)))??;
-                    out.push(batch);
+                    out.extend(batches);
                 }
                 Source::ChildBatches { seed_key } => {
                     let plan = gpu.as_ref().expect("ChildBatches always has a shared plan").clone();

@@ -25,6 +25,7 @@ pub const EXON_HIP_GT: i32 = 0;
 pub const EXON_HIP_GE: i32 = 1;
 pub const EXON_HIP_LT: i32 = 2;
 pub const EXON_HIP_LE: i32 = 3;
+pub const EXON_HIP_ECAPACITY: i32 = -6; // more distinct group keys than the plan's n_groups; the stream is unchanged
 pub const EXON_HIP_EQ: i32 = 4;
 pub const EXON_HIP_NE: i32 = 5;
 pub const EXON_HIP_FORMAT_VCF: i32 = 1;

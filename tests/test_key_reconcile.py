@@ -492,8 +492,61 @@ def test_a_union_beyond_the_plans_capacity_fails_on_every_rank(tmp_path):
     """Each rank's own dictionary fits the plan (3 and 3 distinct FILTER lists, capacity 4), the UNION (5) does not: the
     reconcile must fail loudly on every rank -- not merge a truncated dictionary -- and the launcher comes back non-zero."""
     paths = [str(tmp_path / f"{c}.vcf") for c in "ab"]
-    write_vcf(paths[0], 6000, 1, ["PASS", ".", "q10"])
-    write_vcf(paths[1], 6000, 2, ["s50", "q10;s50", "PASS"])
+    for path, seed, filters in ((paths[0], 1, ["PASS", ".", "q10"]), (paths[1], 2, ["s50", "q10;s50", "PASS"])):
+        rng = np.random.default_rng(seed)
+        rows = [f"1\t{i + 1}\t.\tA\tC\t{int(rng.integers(0, 8000)) / 8}\t{filters[i] if i < 3 else filters[int(rng.integers(0, 3))]}\tAF={10 ** rng.uniform(-4, 0):.4g}\n"
+                for i in range(6000)]
+        with open(path, "w") as fh:
+            fh.write(VCF_HEAD + "".join(rows))
     r = _ranks(tmp_path, paths, "k4small", 29553, world=2, expect_fail=True)
     assert r.returncode != 0 and "RESULT " not in r.stdout
     assert "n_groups" in (r.stdout + r.stderr) or "distinct" in (r.stdout + r.stderr), (r.stdout + r.stderr)[-2000:]
+
+
+@pytest.mark.gpu
+def test_a_scan_that_does_not_fit_leaves_the_stream_as_it_was(ctx, tmp_path, oracle):
+    """exon_hip_stream_consume_scan of a file whose FILTER lists do not fit the plan's n_groups any more: EXON_HIP_ECAPACITY (-6),
+    and the stream's dictionary and state are EXACTLY what they were before that file (the keys used to be appended
+    before the failure) -- finishing the stream gives the first file's answer; the file then goes through a fresh stream (what the
+    shim does: one more partial batch for AggregateExec(Final))."""
+    a, b = str(tmp_path / "a.vcf"), str(tmp_path / "b.vcf")
+
+    def write(path, seed, filters):  # every row draws from `filters` only: the file's dictionary is exactly that set
+        rng = np.random.default_rng(seed)
+        rows = []
+        for i in range(5000):
+            f = filters[i] if i < len(filters) else filters[int(rng.integers(0, len(filters)))]
+            af = "." if rng.random() < 0.05 else ("%.4g" % (10 ** rng.uniform(-4, 0)))
+            q = "." if rng.random() < 0.05 else str(int(rng.integers(0, 8000)) / 8)
+            rows.append(f"1\t{i + 1}\t.\tA\tC\t{q}\t{f}\tAF={af}\n")
+        with open(path, "w") as fh:
+            fh.write(VCF_HEAD + "".join(rows))
+
+    write(a, 1, ["PASS", ".", "q10"])                 # 3 keys
+    write(b, 2, ["s50", "q10;s50", "PASS"])           # 3 keys, two of them new: the union (5) exceeds n_groups = 4
+    na, want_a = OX.k4_expected(oracle, a, "vcf", "AF")
+    nb, want_b = OX.k4_expected(oracle, b, "vcf", "AF")
+    plan = ctx.plan_cmp_avg_by_group(">", 0.01, 4, columns=(4, 2, 3))
+    st = plan.open()
+    s = exon_amd.Scan(a, "vcf", info_field="AF", gpu_parse=True)
+    assert st.consume(s) == na
+    s.close()
+    keys_before = st.keys()[0]
+    s = exon_amd.Scan(b, "vcf", info_field="AF", gpu_parse=True)
+    with pytest.raises(exon_amd.ExonHipError) as e:
+        st.consume(s)
+    s.close()
+    assert e.value.code == -6 and "n_groups" in str(e.value)
+    assert st.keys()[0] == keys_before
+    c, sm = st.finish()
+    assert k4_by_value(keys_before, c, sm, 4) == want_a
+    st.close()
+    st = plan.open()                                   # the file that did not fit, on a stream of its own
+    s = exon_amd.Scan(b, "vcf", info_field="AF", gpu_parse=True)
+    assert st.consume(s) == nb
+    s.close()
+    keys_b = st.keys()[0]
+    c, sm = st.finish()
+    assert k4_by_value(keys_b, c, sm, 4) == want_b
+    st.close()
+    plan.close()
