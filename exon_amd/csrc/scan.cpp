@@ -33,6 +33,10 @@ struct exon_hip_scan {
   exon_hip_bam_parser* bam_parser = nullptr;
   exon_hip_bcf_parser* bcf_parser = nullptr;
   exon_hip_sam_parser* sam_parser = nullptr;
+  // opened with gpu_parse but with INFO keys only the host reader builds (String / Character values, list-valued keys): batches
+  // (exon_hip_scan_next) come from the host reader, but a consume_scan whose plan reads none of those columns still takes the
+  // GPU pipeline -- the device parser decodes and validates the list keys and does not look at the string keys at all
+  bool gpu_candidate = false;
   bool gpu_inflated = false;  // the last GPU-parsed consume also inflated BGZF blocks on the device
   bool gpu_decoded = false;   // the last consume decoded every record on the device (no host fallback)
   exon::Dictionary gpu_filter_dict;       // names fetched from the parser after the consume
@@ -140,8 +144,9 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         if (s->gpu_parse) {
           bool string_info = false;
           for (const auto& sp : s->vcf->info_specs) string_info |= !exon::info_kind_on_device(sp.kind);
-          if (string_info) {  // string INFO fields are dictionary-encoded by the host reader only: decode there
+          if (string_info) {  // string / list INFO columns are built by the host reader only: batches come from there
             s->gpu_parse = false;
+            s->gpu_candidate = true;
             cfg.defer_decode = false;
             cfg.threads = 0;
             s->vcf.reset(new exon::VCFBatchReader(path, c, cfg));
@@ -174,6 +179,7 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
           for (const auto& sp : s->bcf->info_specs) string_info |= !exon::info_kind_on_device(sp.kind);
           if (string_info) {
             s->gpu_parse = false;
+            s->gpu_candidate = true;
             cfg.threads = 0;
             s->bcf.reset(new exon::BCFBatchReader(path, cfg));
           }
@@ -1348,8 +1354,9 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
     if (is_vcf && !scan->parser) {
       std::vector<const char*> names;
       for (const auto& c : scan->vcf->header.contigs) names.push_back(c.c_str());
-      std::string keys;  // "name:kind,..." from the header-typed specs of the host reader
-      for (const auto& sp : scan->vcf->info_specs) keys += (keys.empty() ? "" : ",") + sp.name + ":" + std::string(1, sp.kind);
+      std::string keys;  // "name:kind,..." from the header-typed specs of the host reader; String / Character keys are not decoded
+      for (const auto& sp : scan->vcf->info_specs)
+        if (sp.kind != 's' && sp.kind != 'S') keys += (keys.empty() ? "" : ",") + sp.name + ":" + std::string(1, sp.kind);
       rc = exon_hip_vcf_parser_create(ctx, names.data(), (int32_t)names.size(), keys.empty() ? nullptr : keys.c_str(),
                                       (int64_t)src->max_text_bytes(), &scan->parser);
       if (rc) break;
@@ -1365,10 +1372,15 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
                                       &scan->bcf_parser);
       if (rc) break;
       if (scan->bcf->info_specs.size() > 0) {
-        std::vector<int32_t> keys(scan->bcf->info_keys().begin(), scan->bcf->info_keys().end());
+        std::vector<int32_t> keys;
         std::string kinds;
-        for (const auto& sp : scan->bcf->info_specs) kinds += sp.kind;
-        rc = exon_hip_bcf_parser_set_info_keys(scan->bcf_parser, keys.data(), kinds.c_str(), (int32_t)keys.size());
+        for (size_t k = 0; k < scan->bcf->info_specs.size(); ++k) {
+          const char kind = scan->bcf->info_specs[k].kind;
+          if (kind == 's' || kind == 'S') continue;  // String / Character keys are not decoded on the device
+          keys.push_back(scan->bcf->info_keys()[k]);
+          kinds += kind;
+        }
+        if (!keys.empty()) rc = exon_hip_bcf_parser_set_info_keys(scan->bcf_parser, keys.data(), kinds.c_str(), (int32_t)keys.size());
         if (rc) break;
       }
     }
@@ -1419,9 +1431,18 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
           sc[2].values = cols.qual;
           sc[2].validity = cols.qual_valid;
           sc[3].values = cols.filter_id;
-          for (int q = 0; q < cols.n_info && q < EXON_HIP_MAX_INFO_FIELDS; ++q) {
-            sc[4 + q].values = cols.infos[q] ? (const void*)cols.infos[q] : (const void*)cols.infos_valid[q];  // a Flag's values ARE its bitmap
-            sc[4 + q].validity = cols.infos_valid[q];
+          {  // device key q -> scan column 4 + k: String / Character keys were left out, list keys are no plan operands
+            const std::vector<exon::InfoSpec>& specs = is_vcf ? scan->vcf->info_specs : scan->bcf->info_specs;
+            int q = 0;
+            for (size_t k = 0; k < specs.size() && k < (size_t)EXON_HIP_MAX_INFO_FIELDS; ++k) {
+              const char kind = specs[k].kind;
+              if (kind == 's' || kind == 'S') continue;
+              if (q < cols.n_info && !exon::info_kind_is_list(kind)) {
+                sc[4 + k].values = cols.infos[q] ? (const void*)cols.infos[q] : (const void*)cols.infos_valid[q];  // a Flag's values ARE its bitmap
+                sc[4 + k].validity = cols.infos_valid[q];
+              }
+              ++q;
+            }
           }
           id_col = cols.chrom_id;
           c_start = c_end = cols.pos;
@@ -1601,6 +1622,35 @@ static int consume_scan_impl(exon_hip_stream* st, exon_hip_scan* scan, int64_t* 
       return col >= 4 && (size_t)(col - 4) < specs.size() && specs[(size_t)(col - 4)].kind == 'i' ? EXON_HIP_X_INT32 : EXON_HIP_X_FLOAT32;
     };
     exon_hip_stream_set_value_types(st, type_of(exon_hip_stream_plan_column(st, 0)), type_of(exon_hip_stream_plan_column(st, 1)));
+  }
+  if (!scan->gpu_parse && scan->gpu_candidate && scan->rows == 0 && (scan->vcf || scan->bcf)) {
+    const std::vector<exon::InfoSpec>& specs = scan->vcf ? scan->vcf->info_specs : scan->bcf->info_specs;
+    bool reads_host_only = false;
+    for (int a = 0; a < 4; ++a) {
+      const int col = exon_hip_stream_plan_column(st, a);
+      if (col >= 4 && (size_t)(col - 4) < specs.size() && !exon::info_kind_on_device(specs[(size_t)(col - 4)].kind)) reads_host_only = true;
+    }
+    if (!reads_host_only) {
+      try {  // the host reader goes back to "header only": the bytes are the device's
+        if (scan->vcf) {
+          const exon::Compression c = scan->opt.compression == EXON_HIP_COMPRESSION_GZIP   ? exon::Compression::Gzip
+                                      : scan->opt.compression == EXON_HIP_COMPRESSION_NONE ? exon::Compression::None
+                                                                                           : exon::Compression::Auto;
+          exon::VCFConfig cfg = scan->vcf->config();
+          cfg.defer_decode = true;
+          if (wants_gpu_inflate(&scan->opt, scan->path.c_str())) cfg.threads = 1;
+          scan->vcf.reset(new exon::VCFBatchReader(scan->path, c, cfg));
+        } else {
+          exon::VCFConfig cfg = scan->bcf->config();
+          cfg.threads = 1;
+          scan->bcf.reset(new exon::BCFBatchReader(scan->path, cfg));
+        }
+        scan->gpu_parse = true;
+        scan->gpu_candidate = false;
+      } catch (const std::exception& e) {
+        return fail(nullptr, EXON_HIP_EINVAL, "%s", e.what());
+      }
+    }
   }
   if (scan->gpu_parse && (scan->vcf || scan->fastq || scan->bam || scan->bcf || scan->sam)) {
     // speculative GPU decode; when the device cannot decide something, restore the state and fall back to the host decoder

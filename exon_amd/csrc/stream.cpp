@@ -766,7 +766,7 @@ int exon_hip_stream_launch_scan_columns(exon_hip_stream* st, const exon_hip_colu
 }
 int exon_hip_stream_plan_first_column(exon_hip_stream* st) { return st->plan->d.columns[0]; }
 int exon_hip_stream_plan_kind(exon_hip_stream* st) { return st->plan->d.kind; }
-int exon_hip_stream_plan_column(exon_hip_stream* st, int arg) { return arg >= 0 && arg < 4 ? st->plan->d.columns[arg] : -1; }
+int exon_hip_stream_plan_column(exon_hip_stream* st, int arg) { return arg >= 0 && arg < st->plan->n_cols ? st->plan->d.columns[arg] : -1; }
 void exon_hip_stream_set_value_types(exon_hip_stream* st, int x_type, int y_type) {
   st->x_type = x_type;
   st->y_type = y_type;

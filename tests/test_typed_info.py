@@ -362,11 +362,74 @@ def _k4_op(ctx, path, fmt, fields, columns, gpu_parse, op, thr):
 
 
 @pytest.mark.gpu
-def test_string_info_field_keeps_the_scan_on_the_host(ctx, tmp_path):
+@pytest.mark.parametrize("fmt", ["vcf", "vcf.gz", "bcf"])
+def test_string_and_list_info_keys_the_plan_does_not_read_stay_on_the_gpu(ctx, tmp_path, fmt):
+    """A scan that NAMES a String key, a String list and Integer / Float lists (info_field = "AF,CSQ,AC,MQS,TAGS,DP") consumed by a
+    plan that reads AF and DP only: the file goes through the GPU pipeline (round 4: any such key sent the whole scan to the host
+    decoder) -- the device parser decodes and validates the numeric lists, does not look at the string keys, and the plan's columns
+    keep their SCAN positions (DP is scan column 9, behind keys the device skipped).  Expected values straight from the writer's
+    rows (tests/vcf_bcf_writer.py: independent of decoders and oracle).  Batches of the same file still come from the host reader
+    with every column built."""
+    import vcf_bcf_writer as W
+    rows = W.make_rows(20000, seed=11)
+    path = str(tmp_path / "t.vcf")
+    W.write_vcf(path, rows)
+    if fmt == "vcf.gz":
+        subprocess.check_call([BGZIP, path, path + ".gz"])
+        path += ".gz"
+    elif fmt == "bcf":
+        path = str(tmp_path / "t.bcf")
+        W.write_bcf(path, rows, BGZIP)
+    kind = "bcf" if fmt == "bcf" else "vcf"
+    want = {}
+    for r in rows:
+        info = r["info"] or {}
+        af, dp = info.get("AF"), info.get("DP")
+        if af is not None and float(np.float32(af)) > 0.01:
+            c = want.setdefault(";".join(r["filter"]), [0, 0, 0.0])
+            c[1] += 1
+            if dp is not None:
+                c[0] += 1
+                c[2] += dp
+    fields = "AF,CSQ,AC,MQS,TAGS,DP"
+    scan = exon_amd.Scan(path, kind, info_field=fields, gpu_parse=True)
+    plan = ctx.plan_cmp_avg_by_group(">", 0.01, 8, columns=(4, 9, 3))   # info.AF > 0.01, AVG(info.DP) GROUP BY filter
+    st = plan.open()
+    n = st.consume(scan)
+    counts, sums = st.finish()
+    names = scan.dictionary(3)
+    got = {names[g]: [int(counts[g]), int(counts[8 + g]), float(sums[g])] for g in range(len(names)) if counts[8 + g]}
+    assert scan.decoded_on_gpu()[0], "the scan fell back to the host decoder"
+    assert n == len(rows) and got.keys() == want.keys()
+    for k in want:
+        assert got[k][:2] == want[k][:2] and got[k][2] == pytest.approx(want[k][2], rel=1e-12), k
+    st.close()
+    plan.close()
+    scan.close()
+    s = exon_amd.Scan(path, kind, info_field=fields, gpu_parse=True)   # batches: the host reader, every column built
+    b = list(s)
+    assert sum(len(x) for x in b) == len(rows) and sorted(s.dictionary(5)) == ["missense", "stop", "syn"]
+    col_ac = [x for bb in b for x in bb.field(6).to_pylist()]
+    assert col_ac == W.expected_column(rows, "AC")
+    s.close()
+
+
+@pytest.mark.gpu
+def test_a_plan_that_reads_a_string_info_key_keeps_the_scan_on_the_host(ctx, tmp_path):
+    """GROUP BY info.CSQ (a String key: the host reader's dictionary ids are the group ids): the device does not build that column,
+    so this consume stays with the host decoder -- and says so."""
     p = tmp_path / "t.vcf"
     p.write_text(HEAD + "".join(f"1\t{i + 1}\t.\tA\tC\t{i}\tPASS\tAF=0.{1 + i % 9};CSQ=c{i % 3}\n" for i in range(5000)))
-    rows, got, on_gpu = _k4(ctx, p, "vcf", "AF,CSQ", (4, 2, 3), True, 0.01)
-    assert rows == 5000 and not on_gpu and got["PASS"][1] == 5000
+    scan = exon_amd.Scan(str(p), "vcf", info_field="AF,CSQ", gpu_parse=True)
+    plan = ctx.plan_cmp_avg_by_group(">", 0.01, 8, columns=(4, 2, 5))
+    st = plan.open()
+    assert st.consume(scan) == 5000 and not scan.decoded_on_gpu()[0]
+    counts, sums = st.finish()
+    names = scan.dictionary(5)
+    assert sorted(names) == ["c0", "c1", "c2"] and sorted(int(counts[8 + g]) for g in range(3)) == [1666, 1667, 1667]
+    st.close()
+    plan.close()
+    scan.close()
     s = exon_amd.Scan(str(p), "vcf", info_field="AF,CSQ")
     assert s.dictionary(5) == [] and len(list(s)) == 1 and s.dictionary(5) == ["c0", "c1", "c2"]
     s.close()
