@@ -1154,6 +1154,7 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  ds_write_b8 %[faddr], %[fdata]\n"
       "  v_mov_b32 %[faddr], %[dummy]\n"
       // ---- the next round's window is requested now: it arrives under this round's output
+      "L_wr_rewin%=:\n"
       "  s_add_u32 s44, s44, s70\n"
       "  s_cmpk_lt_u32 s44, 0x400\n"
       "  s_cbranch_scc0 L_wr_switch1%=\n"
@@ -1182,7 +1183,7 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  s_cbranch_vccnz L_wr_bad%=\n"
       "L_wr_nobad%=:\n"
       "  v_cmp_lt_u32 vcc, v55, %[lane]\n"                // a source inside the round's own output
-      "  s_cbranch_vccnz L_wr_slow_unwind%=\n"
+      "  s_cbranch_vccnz L_wr_dep%=\n"
       "  s_mov_b64 s[62:63], exec\n"
       "  v_cmpx_gt_i32 vcc, 0, v53\n"                     // literals
       "  ds_write_b8_d16_hi v57, v53\n"
@@ -1300,6 +1301,43 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  s_cmp_lt_u32 s53, 64\n"
       "  s_cbranch_scc1 L_wr_walk%=\n"
       "  s_branch L_wr_postwalk%=\n"
+      // ---- a byte of the round has its source inside the round (8 % of the rounds of BAM payloads: a match right behind the
+      // literals it repeats, runs).  The round is cut in front of the symbol that owns the first such byte: what precedes it has
+      // all its sources in earlier rounds, and that symbol, first of the next round, has too -- unless it overlaps ITSELF
+      // (distance < length), which only the caller's byte-ordered slow path resolves.
+      "L_wr_dep%=:\n"
+      "  s_ff1_i32_b64 s66, vcc\n"                       // the first byte whose source lies inside the round
+      "  s_mov_b64 exec, -1\n"
+      "  s_sub_u32 s44, s44, s70\n"                      // back to the round's first bit (a borrow: the window has moved, the caller rewinds)
+      "  s_cbranch_scc1 L_wr_slow%=\n"
+      "  s_cmp_gt_u32 s51, s66\n"                        // the byte belongs to the match carried in: an overlapping one
+      "  s_cbranch_scc1 L_wr_slow%=\n"
+      "  v_mov_b32 v53, s52\n"
+      "  s_mov_b32 s65, s51\n"
+      "  s_mov_b32 s53, 0\n"
+      "  s_mov_b32 s54, s52\n"
+      "L_wr_walk2%=:\n"
+      "  v_readlane_b32 s71, v51, s53\n"
+      "  s_and_b32 s62, s71, 0x1ff\n"                    // its bytes; none: an unresolved symbol, the round ends in front of it too
+      "  s_cbranch_scc0 L_wr_walk2_done%=\n"
+      "  s_add_u32 s57, s65, s62\n"
+      "  s_cmp_gt_u32 s57, s66\n"                        // it owns the byte
+      "  s_cbranch_scc1 L_wr_walk2_done%=\n"
+      "  v_cmpx_le_u32 vcc, s65, %[lane]\n"
+      "  s_mov_b32 s54, s71\n"
+      "  s_bfe_u32 s53, s71, 0x70009\n"
+      "  v_mov_b32 v53, s71\n"
+      "  s_mov_b32 s65, s57\n"
+      "  s_branch L_wr_walk2%=\n"
+      "L_wr_walk2_done%=:\n"
+      "  s_mov_b64 exec, -1\n"
+      "  s_or_b32 s57, s53, s51\n"                       // no symbol taken and nothing carried in: no progress this way
+      "  s_cbranch_scc0 L_wr_slow%=\n"
+      "  s_mov_b32 s57, 1\n"
+      "  s_mov_b32 s67, 1\n"
+      "  s_mov_b32 s70, s53\n"
+      "  s_mov_b32 s64, s65\n"
+      "  s_branch L_wr_rewin%=\n"
       "L_wr_bad%=:\n"
       "  s_mov_b64 exec, -1\n"
       "  s_sub_u32 s44, s44, s70\n"
