@@ -183,6 +183,7 @@ SIGNATURES = {
     "exon_hip_scan_dictionary_intern": (C.c_int, [_vp, _i32, C.c_char_p, C.POINTER(_i32)]),
     "exon_hip_scan_dictionary_value": (C.c_int, [_vp, _i32, _i32, C.POINTER(C.c_char_p)]),
     "exon_hip_scan_rows": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "exon_hip_scan_bind_ctx": (C.c_int, [_vp, _vp]),
     "exon_hip_scan_decoded_on_gpu": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "exon_hip_scan_close": (C.c_int, [_vp]),
     "exon_hip_scan_index_chunks": (C.c_int, [_vp, C.POINTER(_i32)]),

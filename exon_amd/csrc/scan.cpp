@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -33,6 +34,7 @@ struct exon_hip_scan {
   exon_hip_bam_parser* bam_parser = nullptr;
   exon_hip_bcf_parser* bcf_parser = nullptr;
   exon_hip_sam_parser* sam_parser = nullptr;
+  struct GpuExporter* exporter = nullptr;  // exon_hip_scan_bind_ctx: batches (exon_hip_scan_next) come out of the GPU pipeline
   // opened with gpu_parse but with INFO keys only the host reader builds (String / Character values, list-valued keys): batches
   // (exon_hip_scan_next) come from the host reader, but a consume_scan whose plan reads none of those columns still takes the
   // GPU pipeline -- the device parser decodes and validates the list keys and does not look at the string keys at all
@@ -57,6 +59,33 @@ struct exon_hip_scan {
   exon_hip_ctx* region_ctx = nullptr;
 };
 
+// Batches from the GPU decode pipeline (exon_hip_scan_bind_ctx + exon_hip_scan_next on a scan opened with gpu_parse): a producer
+// thread drives the same slab pipeline exon_hip_stream_consume_scan drives -- file bytes to HBM, BGZF inflate, record parse,
+// region mask, all on the device -- but instead of a fused filter + aggregate kernel every slab's columns come back over PCIe
+// and are cut into batch_size-row Arrow batches, built by the SAME column builders the host readers use (so the layout is
+// theirs: dictionary-encoded chrom / filter / reference, NULL rules included).  The consumer takes them off a bounded queue
+// (the producer waits when it is full).  If the device cannot decide a record, the producer goes on with the host reader
+// from the first row it has not emitted.  For queries whose plan the optimizer rule does not match: the reference's
+// <Fmt>Scan::execute (exon-core/src/datasources/vcf/scanner.rs:142-162, bam/scanner.rs:138-158) is exactly this surface.
+struct GpuExporter {
+  exon_hip_ctx* ctx = nullptr;
+  exon_hip_plan* plan = nullptr;
+  exon_hip_stream* st = nullptr;
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv_put, cv_get;
+  std::deque<struct ArrowArray*> q;
+  size_t cap = 64;
+  bool started = false, done = false, stop = false;
+  int rc = 0;
+  std::string err;
+  int64_t emitted = 0;                       // rows handed to the queue so far
+  std::vector<std::string> final_filters;    // the FILTER dictionary when the producer has finished
+  bool decoded_on_gpu = false, inflated_on_gpu = false;
+};
+
+static int gpu_next(exon_hip_scan* s, struct ArrowArray* out);
+static void gpu_export_shutdown(exon_hip_scan* s);
 int exon_hip_stream_push_raw(exon_hip_stream* st, const exon::RawBatch& rb);  // stream.cpp
 int exon_hip_stream_launch_scan_columns(exon_hip_stream* st, const exon_hip_column* scan_cols, int n_scan_cols, int64_t n,
                                         const uint8_t* row_mask);
@@ -249,7 +278,9 @@ int exon_hip_scan_schema(exon_hip_scan* s, struct ArrowSchema* out) {
 
 int exon_hip_scan_next(exon_hip_scan* s, struct ArrowArray* out) {
   if (!s || !out) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_scan_next: NULL argument");
-  if (s->gpu_parse) return fail(nullptr, EXON_HIP_ESTATE, "this scan was opened with gpu_parse: use exon_hip_stream_consume_scan");
+  if (s->gpu_parse && s->exporter) return gpu_next(s, out);
+  if (s->gpu_parse)
+    return fail(nullptr, EXON_HIP_ESTATE, "this scan was opened with gpu_parse: use exon_hip_stream_consume_scan, or exon_hip_scan_bind_ctx for batches from the GPU pipeline");
   try {
     memset(out, 0, sizeof *out);
     bool got;
@@ -331,7 +362,21 @@ int exon_hip_index_query(const char* index_path, int32_t is_bai, const char* ref
   }
 }
 
+int exon_hip_scan_bind_ctx(exon_hip_scan* s, exon_hip_ctx* ctx) {
+  if (!s || !ctx) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_scan_bind_ctx: NULL argument");
+  if (s->exporter) return fail(ctx, EXON_HIP_ESTATE, "the scan is bound to a context already");
+  if (!(s->vcf || s->bcf || s->bam || s->sam))
+    return fail(ctx, EXON_HIP_EUNSUPPORTED, "batches from the GPU pipeline: VCF, BCF, BAM and SAM scans (FASTQ / FASTA / CRAM batches come from the host readers)");
+  if (!s->gpu_parse)  // not opened with gpu_parse, or String / list-valued INFO keys were named: the host reader builds those columns
+    return fail(ctx, EXON_HIP_EUNSUPPORTED, "this scan's batches come from the host reader (opened without gpu_parse, or it names INFO keys only the host reader builds)");
+  if (s->rows != 0) return fail(ctx, EXON_HIP_ESTATE, "the scan has been read from already");
+  s->exporter = new GpuExporter();
+  s->exporter->ctx = ctx;
+  return EXON_HIP_OK;
+}
+
 int exon_hip_scan_close(exon_hip_scan* s) {
+  if (s && s->exporter) gpu_export_shutdown(s);
   if (s && s->parser) exon_hip_vcf_parser_destroy(s->parser);
   if (s && s->fq_parser) exon_hip_fastq_parser_destroy(s->fq_parser);
   if (s && s->bam_parser) exon_hip_bam_parser_destroy(s->bam_parser);
@@ -1280,6 +1325,210 @@ static void region_target(const exon_hip_scan* scan, int32_t* id, int64_t* a, in
 
 // VCF / FASTQ file -> text slabs in HBM (GpuTextSource) -> GPU parser -> fused kernel.  Returns 1 when the device could
 // not decide something: the caller restores the state and re-decodes the file on the host.
+// FILTER dictionary of the device parser, names in id order
+static int gpu_filter_names(exon_hip_scan* scan, std::vector<std::string>* names) {
+  names->clear();
+  int rc = EXON_HIP_OK;
+  if (scan->bcf && scan->bcf_parser) {
+    int32_t nf = 0;
+    rc = exon_hip_bcf_parser_filters(scan->bcf_parser, nullptr, nullptr, 0, &nf);
+    std::vector<int32_t> lists((size_t)std::max(nf, 1) * 8), counts((size_t)std::max(nf, 1));
+    if (!rc) rc = exon_hip_bcf_parser_filters(scan->bcf_parser, lists.data(), counts.data(), nf, &nf);
+    if (rc) return rc;
+    const std::vector<std::string>& strs = scan->bcf->strings();
+    for (int32_t i = 0; i < nf; ++i) {
+      std::string name;
+      for (int32_t k = 0; k < counts[(size_t)i]; ++k) {
+        if (k) name += ';';
+        name += strs[(size_t)lists[(size_t)i * 8 + (size_t)k]];
+      }
+      names->push_back(name);
+    }
+  } else if (scan->vcf && scan->parser) {
+    int32_t nf = 0;
+    std::vector<char> buf(1 << 20);
+    rc = exon_hip_vcf_parser_filters(scan->parser, buf.data(), buf.size(), &nf);
+    if (rc) return rc;
+    size_t o = 0;
+    for (int32_t i = 0; i < nf; ++i) {
+      names->emplace_back(buf.data() + o);
+      o += names->back().size() + 1;
+    }
+  }
+  return rc;
+}
+
+// pinned host blocks that carry a slab's columns: a few are kept for reuse (pinning costs ~0.2 ms per MB); a block goes back
+// when the last batch that views it has been released -- which may be long after its scan was closed, hence process-wide
+namespace {
+std::mutex g_export_pool_mu;
+std::vector<std::pair<void*, size_t>> g_export_pool;
+void* export_block_get(size_t bytes) {
+  {
+    std::lock_guard<std::mutex> g(g_export_pool_mu);
+    for (size_t i = 0; i < g_export_pool.size(); ++i)
+      if (g_export_pool[i].second >= bytes && g_export_pool[i].second <= 2 * bytes + (1u << 20)) {
+        void* p = g_export_pool[i].first;
+        g_export_pool.erase(g_export_pool.begin() + (long)i);
+        return p;
+      }
+  }
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+void export_block_put(void* p, size_t bytes) {
+  {
+    std::lock_guard<std::mutex> g(g_export_pool_mu);
+    if (g_export_pool.size() < 4) {
+      g_export_pool.emplace_back(p, bytes);
+      return;
+    }
+  }
+  hipHostFree(p);
+}
+}  // namespace
+
+// One slab's device columns -> one pinned host block -> batch_size-row Arrow batches on the exporter's queue.  Without a region
+// mask the batches are VIEWS into the block (children with an offset; validity bitmaps shared, null counts left to the
+// consumer); with one the kept rows are gathered.  Returns 2 when the consumer has gone away (scan closed with batches left).
+static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n_rows, const uint8_t* row_mask, hipStream_t hs) {
+  GpuExporter* ex = scan->exporter;
+  exon_hip_ctx* ctx = ex->ctx;
+  const bool vcf_like = scan->vcf || scan->bcf;
+  const std::vector<exon::InfoSpec>* specs = scan->vcf ? &scan->vcf->info_specs : scan->bcf ? &scan->bcf->info_specs : nullptr;
+  const int n_cols = vcf_like ? 4 + (int)specs->size() : 5;
+  // element widths in the scan's column order (0 = no values: a Flag, whose bitmap is its value)
+  std::vector<int> elem((size_t)n_cols, 4);
+  if (vcf_like) {
+    elem[1] = 8;
+    for (size_t k = 0; k < specs->size(); ++k) elem[4 + k] = (*specs)[k].kind == 'b' ? 0 : 4;
+  } else {
+    elem[1] = 1;
+    elem[3] = elem[4] = 8;
+  }
+  const size_t nb = ((size_t)(n_rows + 7) / 8 + 63) & ~size_t(63);
+  std::vector<size_t> voff((size_t)n_cols, 0), boff((size_t)n_cols, 0);
+  size_t bytes = 0;
+  for (int c = 0; c < n_cols; ++c) {
+    voff[(size_t)c] = bytes;
+    bytes += (((size_t)n_rows * (size_t)elem[(size_t)c]) + 63) & ~size_t(63);
+    boff[(size_t)c] = bytes;
+    bytes += nb;
+  }
+  const size_t moff = bytes;
+  bytes += nb;
+  uint8_t* blk = static_cast<uint8_t*>(export_block_get(bytes));
+  if (!blk) return fail(ctx, EXON_HIP_ENOMEM, "no pinned block of %zu bytes for a slab's columns", bytes);
+  exon::SharedBlock* sb = new exon::SharedBlock();
+  sb->block = blk;
+  sb->bytes = bytes;
+  sb->put = export_block_put;
+  struct Unref {
+    exon::SharedBlock* b;
+    ~Unref() { exon::block_unref(b); }
+  } unref{sb};  // this function's own reference
+  std::vector<bool> has_bits((size_t)n_cols, false);
+  hipError_t e = hipSuccess;
+  for (int c = 0; c < n_cols && e == hipSuccess; ++c) {
+    if (elem[(size_t)c] && sc[c].values) e = hipMemcpyAsync(blk + voff[(size_t)c], sc[c].values, (size_t)n_rows * (size_t)elem[(size_t)c], hipMemcpyDeviceToHost, hs);
+    if (e == hipSuccess && sc[c].validity) {
+      e = hipMemcpyAsync(blk + boff[(size_t)c], sc[c].validity, (size_t)(n_rows + 7) / 8, hipMemcpyDeviceToHost, hs);
+      has_bits[(size_t)c] = true;
+    }
+  }
+  if (e == hipSuccess && row_mask) e = hipMemcpyAsync(blk + moff, row_mask, (size_t)(n_rows + 7) / 8, hipMemcpyDeviceToHost, hs);
+  if (e == hipSuccess) e = hipStreamSynchronize(hs);
+  if (e != hipSuccess) return fail(ctx, EXON_HIP_EDEVICE, "columns of a slab back to the host: %s", hipGetErrorString(e));
+  std::vector<std::string> filters;
+  if (vcf_like) {
+    const int rc = gpu_filter_names(scan, &filters);
+    if (rc) return rc;
+  }
+  const int64_t bs = scan->opt.batch_size > 0 ? scan->opt.batch_size : 8192;
+  auto dict_of_col = [&](int c) -> struct ArrowArray* {
+    if (vcf_like && c == 0) return exon::utf8_array(scan->vcf ? scan->vcf->chrom_dict.names : scan->bcf->chrom_dict.names);
+    if (vcf_like && c == 3) return exon::utf8_array(filters);
+    if (!vcf_like && c == 2) return exon::utf8_array(scan->bam_dict_view.names);
+    return nullptr;
+  };
+  auto enqueue = [&](std::vector<struct ArrowArray*> kids, int64_t n) -> int {
+    struct ArrowArray* out = static_cast<struct ArrowArray*>(malloc(sizeof *out));
+    exon::make_struct(out, n, std::move(kids));
+    std::unique_lock<std::mutex> lk(ex->mu);
+    ex->cv_put.wait(lk, [&] { return ex->stop || ex->q.size() < ex->cap; });
+    if (ex->stop) {
+      lk.unlock();
+      out->release(out);
+      free(out);
+      return 2;
+    }
+    ex->q.push_back(out);
+    ex->emitted += n;
+    lk.unlock();
+    ex->cv_get.notify_one();
+    return EXON_HIP_OK;
+  };
+  if (!row_mask) {
+    for (int64_t b0 = 0; b0 < n_rows; b0 += bs) {
+      const int64_t n = std::min(n_rows, b0 + bs) - b0;
+      std::vector<struct ArrowArray*> kids;
+      for (int c = 0; c < n_cols; ++c) {
+        const void* bits = has_bits[(size_t)c] ? blk + boff[(size_t)c] : nullptr;
+        const void* vals = elem[(size_t)c] ? (const void*)(blk + voff[(size_t)c]) : bits;  // a Flag: true where present
+        struct ArrowArray* a = exon::new_view_array(sb, bits, vals, n, bits ? -1 : 0, dict_of_col(c));
+        a->offset = b0;
+        kids.push_back(a);
+      }
+      const int rc = enqueue(std::move(kids), n);
+      if (rc) return rc;
+    }
+    return EXON_HIP_OK;
+  }
+  // rows kept by the pushed-down region filter, gathered
+  std::vector<int64_t> keep;
+  const uint8_t* mask = blk + moff;
+  for (int64_t r = 0; r < n_rows; ++r)
+    if ((mask[(size_t)(r >> 3)] >> (r & 7)) & 1) keep.push_back(r);
+  auto bit = [&](int c, int64_t r) { return !has_bits[(size_t)c] ? (uint8_t)1 : (uint8_t)((blk[boff[(size_t)c] + (size_t)(r >> 3)] >> (r & 7)) & 1); };
+  for (int64_t b0 = 0; b0 < (int64_t)keep.size(); b0 += bs) {
+    const int64_t n = std::min((int64_t)keep.size(), b0 + bs) - b0;
+    std::vector<struct ArrowArray*> kids;
+    auto prim = [&](int c, auto tag) {
+      typedef decltype(tag) T;
+      exon::PrimitiveBuilder<T> pb;
+      pb.values.resize((size_t)n);
+      pb.valid.resize((size_t)n);
+      const T* src = reinterpret_cast<const T*>(blk + voff[(size_t)c]);
+      for (int64_t i = 0; i < n; ++i) {
+        const int64_t r = keep[(size_t)(b0 + i)];
+        pb.values[(size_t)i] = src[r];
+        pb.valid[(size_t)i] = bit(c, r);
+      }
+      kids.push_back(pb.finish(dict_of_col(c)));
+    };
+    for (int c = 0; c < n_cols; ++c) {
+      if (elem[(size_t)c] == 8) prim(c, int64_t());
+      else if (elem[(size_t)c] == 1) prim(c, uint8_t());
+      else if (elem[(size_t)c] == 4 && vcf_like && (c == 2 || (c >= 4 && (*specs)[(size_t)(c - 4)].kind == 'f'))) prim(c, float());
+      else if (elem[(size_t)c] == 4) prim(c, int32_t());
+      else {  // Flag -> Boolean: true where present, NULL elsewhere
+        std::vector<uint8_t> v((size_t)n);
+        for (int64_t i = 0; i < n; ++i) v[(size_t)i] = bit(c, keep[(size_t)(b0 + i)]);
+        struct ArrowArray* a = static_cast<struct ArrowArray*>(malloc(sizeof *a));
+        exon::make_boolean(a, v, v);
+        kids.push_back(a);
+      }
+    }
+    const int rc = enqueue(std::move(kids), n);
+    if (rc) return rc;
+  }
+  return EXON_HIP_OK;
+}
+
 static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* rows_out) {
   const bool trace = getenv("EXON_HIP_PIPE_TRACE") != nullptr;  // phase timings on stderr
   const double t_begin = now_s();
@@ -1292,8 +1541,10 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
   const bool bgzf = gpu_inflate_enabled() && scan->opt.compression != EXON_HIP_COMPRESSION_NONE &&
                     exon::BgzfParallelSource::is_bgzf(scan->path) && (!is_vcf || indexed || scan->vcf->data_offset() >= 0);
   if ((is_bam || is_bcf || indexed) && !bgzf) return 1;
-  scan->gpu_inflated = bgzf;
-  scan->gpu_decoded = false;
+  if (!scan->exporter) {
+    scan->gpu_inflated = bgzf;
+    scan->gpu_decoded = false;
+  }
 
   // ---- the pushed-down region filter: (id, [a, b]) + a row-mask buffer + the count of rows kept -----------------
   int32_t rg_id = -1;
@@ -1493,7 +1744,8 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
                                                   scan->d_region_mask, scan->d_region_pass));
             row_mask = scan->d_region_mask;
           }
-          rc = exon_hip_stream_launch_scan_columns(st, sc, 4 + EXON_HIP_MAX_INFO_FIELDS, n_rows, row_mask);
+          rc = scan->exporter ? export_slab(scan, sc, n_rows, row_mask, hs)
+                              : exon_hip_stream_launch_scan_columns(st, sc, 4 + EXON_HIP_MAX_INFO_FIELDS, n_rows, row_mask);
           // the parser's column buffers (and the row mask) are reused by the next slab; the kernel is stream-ordered before that
           total += n_rows;
         }
@@ -1527,42 +1779,22 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
     HIP_TRY(ctx, hipMemcpy(&kept, scan->d_region_pass, 8, hipMemcpyDeviceToHost));
     total = (int64_t)kept;
   }
-  if (rc == EXON_HIP_OK && is_bcf) {
-    // FILTER lists (header-string indexes) -> names, in id order
-    int32_t nf = 0;
-    rc = exon_hip_bcf_parser_filters(scan->bcf_parser, nullptr, nullptr, 0, &nf);
-    std::vector<int32_t> lists((size_t)std::max(nf, 1) * 8), counts((size_t)std::max(nf, 1));
-    if (!rc) rc = exon_hip_bcf_parser_filters(scan->bcf_parser, lists.data(), counts.data(), nf, &nf);
+  if (rc == EXON_HIP_OK && (is_bcf || (is_vcf && scan->parser))) {  // FILTER dictionary -> scan (names in id order)
+    std::vector<std::string> names;
+    rc = gpu_filter_names(scan, &names);
     if (!rc) {
-      scan->gpu_filter_dict.names.clear();
-      const std::vector<std::string>& strs = scan->bcf->strings();
-      for (int32_t i = 0; i < nf; ++i) {
-        std::string name;
-        for (int32_t k = 0; k < counts[(size_t)i]; ++k) {
-          if (k) name += ';';
-          name += strs[(size_t)lists[(size_t)i * 8 + (size_t)k]];
-        }
-        scan->gpu_filter_dict.names.push_back(name);
-      }
-    }
-  }
-  if (rc == EXON_HIP_OK && is_vcf && scan->parser) {
-    // FILTER dictionary -> scan (names in id order)
-    int32_t nf = 0;
-    std::vector<char> buf(1 << 20);
-    rc = exon_hip_vcf_parser_filters(scan->parser, buf.data(), buf.size(), &nf);
-    if (!rc) {
-      scan->gpu_filter_dict.names.clear();
-      size_t o = 0;
-      for (int32_t i = 0; i < nf; ++i) {
-        scan->gpu_filter_dict.names.emplace_back(buf.data() + o);
-        o += scan->gpu_filter_dict.names.back().size() + 1;
-      }
+      if (scan->exporter) scan->exporter->final_filters.swap(names);  // (adopted by the consumer's thread at the end of the batches)
+      else scan->gpu_filter_dict.names.swap(names);
     }
   }
   if (rc == EXON_HIP_OK) {
-    scan->rows += total;
-    scan->gpu_decoded = true;
+    if (scan->exporter) {
+      scan->exporter->decoded_on_gpu = true;
+      scan->exporter->inflated_on_gpu = bgzf;
+    } else {
+      scan->rows += total;
+      scan->gpu_decoded = true;
+    }
     if (rows_out) *rows_out = total;
   }
   return rc;
@@ -1583,6 +1815,161 @@ static int consume_scan_impl(exon_hip_stream* st, exon_hip_scan* scan, int64_t* 
 static int region_dict_column(const exon_hip_scan* s) {
   return (s->format == EXON_HIP_FORMAT_VCF || s->format == EXON_HIP_FORMAT_BCF) ? 0 : 2;
 }
+
+}  // extern "C"
+
+// the host reader from the start (a scan opened for the GPU pipeline has read the header only)
+static void reopen_host_reader(exon_hip_scan* scan) {
+  const exon::Compression c = scan->opt.compression == EXON_HIP_COMPRESSION_GZIP   ? exon::Compression::Gzip
+                              : scan->opt.compression == EXON_HIP_COMPRESSION_NONE ? exon::Compression::None
+                                                                                   : exon::Compression::Auto;
+  if (scan->vcf) {
+    exon::VCFConfig cfg = scan->vcf->config();
+    cfg.defer_decode = false;
+    cfg.threads = 0;
+    scan->vcf.reset(new exon::VCFBatchReader(scan->path, c, cfg));
+  } else if (scan->bam) {
+    exon::BAMConfig cfg = scan->bam->config();
+    cfg.threads = 0;
+    scan->bam.reset(new exon::BAMBatchReader(scan->path, cfg));
+  } else if (scan->bcf) {
+    exon::VCFConfig cfg = scan->bcf->config();
+    cfg.threads = 0;
+    scan->bcf.reset(new exon::BCFBatchReader(scan->path, cfg));
+  } else if (scan->sam) {
+    scan->sam.reset(new exon::SAMBatchReader(scan->path, c, scan->sam->config()));
+  }
+}
+
+static void gpu_export_producer(exon_hip_scan* scan) {
+  GpuExporter* ex = scan->exporter;
+  int rc = EXON_HIP_OK;
+  std::string err;
+  exon_hip_plan_desc d;
+  memset(&d, 0, sizeof d);
+  d.kind = EXON_HIP_PLAN_REGION_COUNT;  // (a carrier for context and stream: its kernel is never launched, export_slab takes the slabs)
+  d.region_start = d.region_end = 1;
+  d.columns[0] = 0;
+  d.columns[1] = 1;
+  rc = exon_hip_plan_create(ex->ctx, &d, &ex->plan);
+  if (!rc) rc = exon_hip_stream_open(ex->plan, 0, &ex->st);
+  int64_t rows = 0;
+  if (!rc) rc = consume_text_gpu(ex->st, scan, &rows);
+  if (rc == 1) {
+    // the device could not decide something: the host reader goes over the file again and takes over behind the rows emitted
+    try {
+      reopen_host_reader(scan);
+      int64_t skip = 0;
+      {
+        std::lock_guard<std::mutex> g(ex->mu);
+        skip = ex->emitted;
+        ex->decoded_on_gpu = false;
+      }
+      rc = EXON_HIP_OK;
+      for (;;) {
+        struct ArrowArray* out = static_cast<struct ArrowArray*>(malloc(sizeof *out));
+        memset(out, 0, sizeof *out);
+        const bool got = scan->vcf ? scan->vcf->read_batch(out) : scan->bam ? scan->bam->read_batch(out) : scan->bcf ? scan->bcf->read_batch(out) : scan->sam->read_batch(out);
+        if (!got) {
+          free(out);
+          break;
+        }
+        if (skip >= out->length) {  // emitted by the GPU pipeline already
+          skip -= out->length;
+          out->release(out);
+          free(out);
+          continue;
+        }
+        if (skip > 0) {  // the batch that straddles the hand-over: its tail, as a slice (children share the offset)
+          for (int64_t c = 0; c < out->n_children; ++c) {
+            out->children[c]->offset += skip;
+            out->children[c]->length -= skip;
+            out->children[c]->null_count = -1;
+          }
+          out->length -= skip;
+          skip = 0;
+        }
+        std::unique_lock<std::mutex> lk(ex->mu);
+        ex->cv_put.wait(lk, [&] { return ex->stop || ex->q.size() < ex->cap; });
+        if (ex->stop) {
+          lk.unlock();
+          out->release(out);
+          free(out);
+          break;
+        }
+        ex->q.push_back(out);
+        ex->emitted += out->length;
+        lk.unlock();
+        ex->cv_get.notify_one();
+      }
+    } catch (const std::exception& e) {
+      rc = EXON_HIP_EINVAL;
+      err = e.what();
+    }
+  } else if (rc == 2) {
+    rc = EXON_HIP_OK;  // the consumer closed the scan
+  } else if (rc) {
+    err = exon_hip_last_error(ex->ctx);
+  }
+  {
+    std::lock_guard<std::mutex> g(ex->mu);
+    ex->rc = rc;
+    ex->err = err;
+    ex->done = true;
+  }
+  ex->cv_get.notify_all();
+}
+
+static int gpu_next(exon_hip_scan* s, struct ArrowArray* out) {
+  GpuExporter* ex = s->exporter;
+  if (!ex->started) {
+    ex->started = true;
+    ex->th = std::thread(gpu_export_producer, s);
+  }
+  struct ArrowArray* a = nullptr;
+  {
+    std::unique_lock<std::mutex> lk(ex->mu);
+    ex->cv_get.wait(lk, [&] { return ex->done || !ex->q.empty(); });
+    if (!ex->q.empty()) {
+      a = ex->q.front();
+      ex->q.pop_front();
+    }
+  }
+  if (a) {
+    ex->cv_put.notify_one();
+    *out = *a;  // moved
+    free(a);
+    s->rows += out->length;
+    return EXON_HIP_OK;
+  }
+  // the producer has finished: its verdict, the FILTER dictionary and the "decoded on the GPU" flags become the scan's
+  if (ex->th.joinable()) ex->th.join();
+  if (ex->rc) return fail(ex->ctx, ex->rc, "%s", ex->err.c_str());
+  if (!ex->final_filters.empty()) s->gpu_filter_dict.names.swap(ex->final_filters);
+  s->gpu_decoded = ex->decoded_on_gpu;
+  s->gpu_inflated = ex->inflated_on_gpu;
+  return 1;
+}
+
+static void gpu_export_shutdown(exon_hip_scan* s) {
+  GpuExporter* ex = s->exporter;
+  {
+    std::lock_guard<std::mutex> g(ex->mu);
+    ex->stop = true;
+  }
+  ex->cv_put.notify_all();
+  if (ex->th.joinable()) ex->th.join();
+  for (struct ArrowArray* a : ex->q) {
+    if (a->release) a->release(a);
+    free(a);
+  }
+  if (ex->st) exon_hip_stream_close(ex->st);
+  if (ex->plan) exon_hip_plan_destroy(ex->plan);
+  delete ex;
+  s->exporter = nullptr;
+}
+
+extern "C" {
 
 int exon_hip_stream_consume_scan(exon_hip_stream* st, exon_hip_scan* scan, int64_t* rows) {
   if (!st || !scan) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_stream_consume_scan: NULL argument");

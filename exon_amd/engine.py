@@ -390,6 +390,12 @@ class Scan:
             self._check(self.lib.exon_hip_scan_schema(self.h, C.byref(sch)))
             yield pa.Array._import_from_c(C.addressof(arr), C.addressof(sch))
 
+    def bind_ctx(self, ctx):
+        """Batches of a scan opened with gpu_parse=True come out of the GPU decode pipeline on `ctx` (exon_hip_scan_bind_ctx): iterate
+        the scan as usual afterwards."""
+        self._check(self.lib.exon_hip_scan_bind_ctx(self.h, ctx.h))
+        return self
+
     def decoded_on_gpu(self):
         """(decoded, inflated) of the last Stream.consume: were the records decoded / the BGZF blocks inflated on the GPU?"""
         d, i = C.c_int32(), C.c_int32()

@@ -436,6 +436,16 @@ int exon_hip_scan_dictionary_size(exon_hip_scan* scan, int32_t column, int32_t* 
 int exon_hip_scan_dictionary_intern(exon_hip_scan* scan, int32_t column, const char* name, int32_t* id);
 int exon_hip_scan_dictionary_value(exon_hip_scan* scan, int32_t column, int32_t id, const char** name);
 int exon_hip_scan_rows(exon_hip_scan* scan, int64_t* rows_emitted);
+/* (round 5, additive) Batches of a scan opened with gpu_parse = 1 come out of the GPU decode pipeline on `ctx`: after this
+ * call exon_hip_scan_next drives the same slab pipeline exon_hip_stream_consume_scan drives (file bytes to HBM, BGZF inflate,
+ * record parse, pushed-down region mask on the device), copies every slab's columns back and returns them as batch_size-row
+ * batches in the host readers' layout and file order -- for queries that do NOT end in one of the fused kernels (the surface
+ * of <Fmt>Scan::execute, exon/exon-core/src/datasources/vcf/scanner.rs:142-162, bam/scanner.rs:138-158).  A producer thread
+ * fills a bounded queue; if the device cannot decide a record the host reader takes over behind the last row emitted.
+ * VCF / BCF (chrom, pos, qual, filter, Float / Integer / Flag INFO keys), BAM, SAM; EXON_HIP_EUNSUPPORTED for other formats and
+ * for scans whose batches the host reader must build (String / list-valued INFO keys).  Call before the first
+ * exon_hip_scan_next; `ctx` must outlive the scan. */
+int exon_hip_scan_bind_ctx(exon_hip_scan* scan, exon_hip_ctx* ctx);
 /* number of index chunks an indexed scan planned (-1 when the scan is not index-driven) */
 int exon_hip_scan_index_chunks(exon_hip_scan* scan, int32_t* n_chunks);
 /* Region -> BGZF chunks from a tabix (.tbi, is_bai = 0; `ref_name` resolved through the index' names) or BAI

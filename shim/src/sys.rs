@@ -132,6 +132,7 @@ extern "C" {
     pub fn exon_hip_scan_dictionary_value(scan: *mut exon_hip_scan, column: i32, id: i32, name: *mut *const c_char) -> c_int;
     pub fn exon_hip_scan_decoded_on_gpu(scan: *mut exon_hip_scan, decoded: *mut i32, inflated: *mut i32) -> c_int;
     pub fn exon_hip_scan_rows(scan: *mut exon_hip_scan, rows_emitted: *mut i64) -> c_int;
+    pub fn exon_hip_scan_bind_ctx(scan: *mut exon_hip_scan, ctx: *mut exon_hip_ctx) -> c_int;
     pub fn exon_hip_scan_close(scan: *mut exon_hip_scan) -> c_int;
     /// GpuFilterAggExec::execute for one file in one call
     pub fn exon_hip_stream_consume_scan(s: *mut exon_hip_stream, scan: *mut exon_hip_scan, rows: *mut i64) -> c_int;

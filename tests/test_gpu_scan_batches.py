@@ -1,0 +1,119 @@
+"""Batches from the GPU decode pipeline (exon_hip_scan_bind_ctx + exon_hip_scan_next): the surface of <Fmt>Scan::execute
+(exon-core/src/datasources/vcf/scanner.rs:142-162, bam/scanner.rs:138-158) for queries that do not end in a fused kernel.  Every
+batch column must equal what the host reader builds from the same file (which tests/test_scan_decoders.py pins on the oracle),
+batch boundaries included."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import exon_amd
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FX = os.path.join(ROOT, "tests", "golden", "ref_fixtures")
+GEN = os.path.join(ROOT, "tools", "bin", "gen_text")
+BGZIP = os.path.join(ROOT, "tools", "bin", "bgzip")
+
+
+def columns(batches):
+    n = batches[0].type.num_fields if batches else 0
+    return [[x for b in batches for x in b.field(c).to_pylist()] for c in range(n)], [len(b) for b in batches]
+
+
+def host_and_gpu(ctx, path, fmt, **kw):
+    h = exon_amd.Scan(path, fmt, **kw)
+    want, want_sizes = columns(list(h))
+    h.close()
+    g = exon_amd.Scan(path, fmt, gpu_parse=True, **kw).bind_ctx(ctx)
+    got, got_sizes = columns(list(g))
+    flags = g.decoded_on_gpu()
+    rows = g.rows()
+    g.close()
+    return want, want_sizes, got, got_sizes, flags, rows
+
+
+def same(want, got):
+    assert len(want) == len(got)
+    for c, (a, b) in enumerate(zip(want, got)):
+        if a and isinstance(next((x for x in a if x is not None), None), float):
+            a2 = np.array([np.nan if x is None else x for x in a], np.float32)
+            b2 = np.array([np.nan if x is None else x for x in b], np.float32)
+            assert np.array_equal(a2.view(np.uint32), b2.view(np.uint32)), c
+            assert [x is None for x in a] == [x is None for x in b], c
+        else:
+            assert a == b, c
+
+
+@pytest.mark.parametrize("kind", ["vcf", "vcf.gz", "bcf", "bam", "sam"])
+def test_batches_from_the_gpu_pipeline_equal_the_host_readers(ctx, tmp_path, kind):
+    n = 60_000
+    if kind in ("vcf", "vcf.gz"):
+        path = str(tmp_path / "t.vcf")
+        subprocess.check_call([GEN, "vcf", str(n), path], stdout=subprocess.DEVNULL)
+        if kind == "vcf.gz":
+            subprocess.check_call([BGZIP, path, path + ".gz", "6"], stdout=subprocess.DEVNULL)
+            path += ".gz"
+        fmt, kw = "vcf", {"info_field": "AF"}
+    elif kind == "bcf":
+        ub, path = str(tmp_path / "t.ubcf"), str(tmp_path / "t.bcf")
+        subprocess.check_call([GEN, "bcf", str(n), ub], stdout=subprocess.DEVNULL)
+        subprocess.check_call([BGZIP, ub, path, "6"], stdout=subprocess.DEVNULL)
+        fmt, kw = "bcf", {"info_field": "AF"}
+    elif kind == "bam":
+        ub, path = str(tmp_path / "t.ubam"), str(tmp_path / "t.bam")
+        subprocess.check_call([GEN, "bam", str(n), ub], stdout=subprocess.DEVNULL)
+        subprocess.check_call([BGZIP, ub, path, "6"], stdout=subprocess.DEVNULL)
+        fmt, kw = "bam", {}
+    else:
+        path = str(tmp_path / "t.sam")
+        subprocess.check_call([GEN, "sam", str(n), path], stdout=subprocess.DEVNULL)
+        fmt, kw = "sam", {}
+    want, want_sizes, got, got_sizes, flags, rows = host_and_gpu(ctx, path, fmt, batch_size=5000, **kw)
+    assert rows == n and sum(got_sizes) == n and flags[0], "the batches did not come from the GPU pipeline"
+    assert flags[1] == (kind in ("vcf.gz", "bcf", "bam"))
+    same(want, got)
+    assert all(k <= 5000 for k in got_sizes)
+
+
+def test_reference_fixture_batches_and_region_filter(ctx):
+    """index.vcf.gz of the reference: 621 rows, 191 on chromosome '1' (exon_context_ext.rs:1053-1090) -- whole file and with the
+    pushed-down region, typed INFO keys of three kinds, through the GPU pipeline = the host reader."""
+    path = os.path.join(FX, "vcf", "index.vcf.gz")
+    for kw in ({}, {"region": "1"}, {"region": "1:10000-100000"}):
+        want, want_sizes, got, sizes, flags, rows = host_and_gpu(ctx, path, "vcf", info_field="DP,MQ0F,INDEL", **kw)
+        assert flags[0] and rows == sum(want_sizes) == sum(sizes)
+        if rows:
+            same(want, got)
+    assert host_and_gpu(ctx, path, "vcf", region="1")[5] == 191
+    path = os.path.join(FX, "bam", "test.bam")
+    want, _, got, sizes, flags, rows = host_and_gpu(ctx, path, "bam")
+    assert flags[0] and rows == sum(sizes)
+    same(want, got)
+
+
+def test_rows_the_device_cannot_decide_come_from_the_host_reader_in_order(ctx, tmp_path):
+    """A contig the header does not declare, deep inside the file: the GPU pipeline hands over, the host reader continues behind the
+    rows already emitted -- same batches' content as the host reader alone, nothing twice, nothing lost."""
+    path = str(tmp_path / "t.vcf")
+    subprocess.check_call([GEN, "vcf", "40000", path], stdout=subprocess.DEVNULL)
+    lines = open(path).read().split("\n")
+    body = [i for i, ln in enumerate(lines) if ln and not ln.startswith("#")]
+    k = body[31_000]
+    lines[k] = "chrUn_x" + lines[k][lines[k].index("\t"):]
+    open(path, "w").write("\n".join(lines))
+    want, _, got, sizes, flags, rows = host_and_gpu(ctx, path, "vcf", info_field="AF", batch_size=3000)
+    assert rows == 40000 and not flags[0]
+    same(want, got)
+
+
+def test_scan_closed_with_batches_outstanding(ctx, tmp_path):
+    path = str(tmp_path / "t.vcf")
+    subprocess.check_call([GEN, "vcf", "300000", path], stdout=subprocess.DEVNULL)
+    g = exon_amd.Scan(path, "vcf", gpu_parse=True, batch_size=1000).bind_ctx(ctx)
+    it = iter(g)
+    assert len(next(it)) == 1000
+    g.close()                      # the producer is blocked on a full queue: close() must wake and join it
+    with pytest.raises(exon_amd.ExonHipError):
+        exon_amd.Scan(path, "fasta", gpu_parse=True).bind_ctx(ctx)
