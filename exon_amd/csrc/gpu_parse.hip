@@ -9,9 +9,9 @@
 // missing key / '.' -> NULL).
 //
 // Pipeline for one slab of complete lines:
-//   k_count_newlines   every thread counts '\n' in its 16 bytes; per-workgroup totals
-//   k_scan_blocks      exclusive scan of the workgroup totals (single workgroup)
-//   k_fill_newlines    positions of all newlines, in order (line i = (nl[i-1], nl[i]))
+//   k_index_lines      positions of all newlines, in order (line i = (nl[i-1], nl[i])), in ONE pass: decoupled look-back over
+//                      the tiles' counts (round 5; k_count_newlines / k_scan_blocks / k_fill_newlines, the three-launch form of
+//                      rounds 1-4, stay behind EXON_HIP_LINE_INDEX_PASSES=2)
 //   k_parse_lines      one thread per line: split on tabs, parse, look names up in hash tables, ballot the validity
 //                      bitmaps; FILTER lists not seen before are inserted with atomicCAS (slot = provisional id)
 //   k_assign_filters   dense ids for newly inserted FILTER lists, their text copied to a persistent pool
@@ -153,6 +153,140 @@ __global__ __launch_bounds__(TPB) void k_fill_newlines(const uint8_t* __restrict
         }
     }
   }
+}
+
+// ---- the line index in ONE pass over the text (round 5) -------------------------------------------------------------------------
+// k_count_newlines + k_scan_blocks + k_fill_newlines read the slab twice and are three launches (each of which queues behind the
+// next slab's inflate).  Here a workgroup takes its tile off a counter (so tile t runs only after tiles 0 .. t-1 have started),
+// counts its newlines, publishes the count, finds the number of newlines in front of its tile by looking BACK over its
+// predecessors' published words -- a word is (generation, value, flag): flag 1 = the tile's own count, flag 2 = the count of
+// everything up to and including the tile; a wave reads 64 predecessors at a time and stops at the first "inclusive" word -- and
+// writes the positions of its newlines.  Decoupled look-back; the words are written and read with agent-scope atomics (the 8
+// XCDs do not share an L2), the generation makes last slab's words read as "not there yet" (no clearing pass), and the counter
+// wraps to 0 by itself (atomicInc).  A look-back that does not see its predecessor within LOOKBACK_SPINS reads gives up, poisons its
+// own word (the tiles behind it give up at once) and marks the slab "one undecided record": the host decoder takes it -- a hang is
+// not possible.
+constexpr unsigned LOOKBACK_SPINS = 1u << 22;
+__device__ __forceinline__ void st_agent_u64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_agent_u64(const unsigned long long* p) {
+  return __hip_atomic_load(const_cast<unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(TPB) void k_index_lines(const uint8_t* __restrict__ text, int64_t n, unsigned skip, unsigned long long* __restrict__ words,
+                                                     unsigned* __restrict__ tile_ctr, unsigned nblocks, unsigned gen, unsigned* __restrict__ nl_pos,
+                                                     unsigned cap, unsigned* __restrict__ scalars) {
+  __shared__ unsigned wave_tot[TPB / 64];
+  __shared__ unsigned s_tile, s_prefix, s_bad;
+  if (threadIdx.x == 0) {
+    s_tile = atomicInc(tile_ctr, nblocks - 1u);
+    s_bad = 0;
+  }
+  __syncthreads();
+  const unsigned tile = s_tile;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t off = ((int64_t)tile * TPB + threadIdx.x) * BYTES_PER_THREAD;
+  constexpr int Q = BYTES_PER_THREAD / 16;
+  uint4 v[Q];
+  unsigned c = 0;
+#pragma unroll
+  for (int j = 0; j < Q; ++j) {
+    v[j] = uint4{0, 0, 0, 0};
+    if (off + 16 * j < n) {
+      v[j] = load16(text, n, off + 16 * j, skip);
+      c += (unsigned)count_nl16(v[j]);
+    }
+  }
+  unsigned incl = c;  // inclusive scan within the wave
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  const unsigned T = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+  const unsigned long long g = (unsigned long long)(gen & 0x3FFFFFFFu) << 34;
+  if (wave == 0) {
+    if (lane == 0) st_agent_u64(&words[tile], g | ((unsigned long long)T << 2) | (tile == 0 ? 2ull : 1ull));
+    unsigned prefix = 0;
+    bool bad = false;
+    if (tile != 0) {
+      for (int64_t j0 = (int64_t)tile - 1;; j0 -= 64) {
+        const int64_t j = j0 - lane;
+        unsigned long long w = 0;
+        if (j >= 0) {
+          unsigned spins = 0;
+          do {
+            w = ld_agent_u64(&words[j]);
+          } while (((w >> 34) != (g >> 34) || (w & 3ull) == 0) && ++spins < LOOKBACK_SPINS);
+          if ((w >> 34) != (g >> 34) || (w & 3ull) == 0 || (w & 3ull) == 3ull) bad = true;  // (3: a predecessor gave up)
+        }
+        if (__any(bad)) {
+          bad = true;
+          break;
+        }
+        const unsigned long long incl_lanes = __ballot(j >= 0 && (w & 3ull) == 2ull);
+        const int first = incl_lanes ? __ffsll((long long)incl_lanes) - 1 : 64;
+        unsigned add = (j >= 0 && lane <= first) ? (unsigned)(w >> 2) : 0u;
+        for (int o = 32; o > 0; o >>= 1) add += __shfl_xor(add, o, 64);
+        prefix += add;
+        if (incl_lanes || j0 < 64) break;
+      }
+    }
+    if (lane == 0) {
+      s_prefix = prefix;
+      s_bad = bad ? 1u : 0u;
+      if (bad) st_agent_u64(&words[tile], g | 3ull);  // the tiles behind this one give up at once
+      else if (tile != 0) st_agent_u64(&words[tile], g | ((unsigned long long)(prefix + T) << 2) | 2ull);
+    }
+  }
+  __syncthreads();
+  if (s_bad) {
+    if (threadIdx.x == 0) {  // no lines, one undecided record: the kernels behind do nothing, the caller hands the slab to the host decoder
+      scalars[0] = 0;
+      scalars[1] = 1;
+    }
+    return;
+  }
+  unsigned base = s_prefix;
+  for (int w = 0; w < wave; ++w) base += wave_tot[w];
+  unsigned k = base + incl - c;
+  if (c) {
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+      const unsigned w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+      if ((w[0] | w[1] | w[2] | w[3]) == 0) continue;
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (((w[i >> 2] >> (8 * (i & 3))) & 0xFF) == 0x0A) {
+          if (k < cap) nl_pos[k] = (unsigned)(off + 16 * j + i);
+          ++k;
+        }
+    }
+  }
+  // the last tile in tile order holds the total; it also clears words 1..3 of the slab's scalar block {lines, exceptions,
+  // consumed, -}, which only the kernels BEHIND this one add to (what k_scan_blocks did; no 16-byte memset per slab)
+  if (tile == nblocks - 1u && threadIdx.x < 4) {
+    if (threadIdx.x == 0) scalars[0] = s_prefix + T;
+    else scalars[threadIdx.x] = 0;
+  }
+}
+// one launch instead of count / scan / fill; EXON_HIP_LINE_INDEX_PASSES=2 keeps the three kernels (A/B)
+static void launch_line_index(hipStream_t s, const uint8_t* d_text, int64_t n_bytes, unsigned skip, unsigned* d_block_counts, int64_t max_blocks, int nblocks, unsigned* gen,
+                              unsigned* d_nl, unsigned cap, unsigned* d_scalars) {
+  static const bool two_pass = [] {
+    const char* v = getenv("EXON_HIP_LINE_INDEX_PASSES");
+    return v && v[0] == '2';
+  }();
+  if (two_pass) {
+    hipLaunchKernelGGL(k_count_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, skip, d_block_counts);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, s, d_block_counts, nblocks, d_scalars, 1);
+    hipLaunchKernelGGL(k_fill_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, skip, d_block_counts, d_nl, cap);
+    return;
+  }
+  unsigned long long* words = reinterpret_cast<unsigned long long*>(d_block_counts);  // [max blocks] words, then the tile counter
+  *gen = (*gen + 1u) & 0x3FFFFFFFu;
+  if (*gen == 0) *gen = 1;
+  hipLaunchKernelGGL(k_index_lines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, skip, words, reinterpret_cast<unsigned*>(words + max_blocks), (unsigned)nblocks,
+                     *gen, d_nl, cap, d_scalars);
 }
 
 // scalars[2] = bytes up to and including the last newline (what a caller may discard after this slab)
@@ -593,6 +727,8 @@ struct exon_hip_vcf_parser {
   // device state
   uint8_t* d_info_key = nullptr;
   unsigned *d_block_counts = nullptr, *d_nl = nullptr, *d_scalars = nullptr;  // scalars: [0] n_lines, [1] exceptions
+  int64_t index_blocks = 0;
+  unsigned index_gen = 0;
   NameTable contigs{};
   void* contig_bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   FilterTable filters{};
@@ -638,7 +774,9 @@ int exon_hip_vcf_parser_create(exon_hip_ctx* ctx, const char* const* contig_name
   if (e == hipSuccess) e = hipMemset(p->filters.counters, 0, 16);
   // scratch + outputs
   const int64_t nblocks = (max_bytes + BYTES_PER_BLOCK - 1) / BYTES_PER_BLOCK;
-  dalloc((void**)&p->d_block_counts, (size_t)nblocks * 4);
+  dalloc((void**)&p->d_block_counts, ((size_t)nblocks + 1) * 8);  // the line index's words + its tile counter (zeroed below)
+  p->index_blocks = nblocks;
+  if (e == hipSuccess && p->d_block_counts) e = hipMemset(p->d_block_counts, 0, ((size_t)nblocks + 1) * 8);
   dalloc((void**)&p->d_nl, (size_t)p->max_rows * 4);
   dalloc((void**)&p->d_scalars, 16);
   // INFO keys: "AF,DP:f,DB:b" -> names back to back + (offset, length, kind) per key
@@ -758,9 +896,7 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* p, void* stream, const uint8_
   if (n_bytes > p->max_bytes) return fail(ctx, EXON_HIP_EINVAL, "slab of %lld bytes exceeds the parser's %lld", (long long)n_bytes, (long long)p->max_bytes);
   hipStream_t s = pick_stream(ctx, stream);
   const int nblocks = (int)((n_bytes + BYTES_PER_BLOCK - 1) / BYTES_PER_BLOCK);
-  hipLaunchKernelGGL(k_count_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, skip, p->d_block_counts);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, s, p->d_block_counts, nblocks, p->d_scalars, 1);
-  hipLaunchKernelGGL(k_fill_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, skip, p->d_block_counts, p->d_nl, (unsigned)p->max_rows);
+  launch_line_index(s, d_text, n_bytes, skip, p->d_block_counts, p->index_blocks, nblocks, &p->index_gen, p->d_nl, (unsigned)p->max_rows, p->d_scalars);
   hipLaunchKernelGGL(k_last_newline, dim3(1), dim3(1), 0, s, p->d_nl, p->d_scalars, (unsigned)p->max_rows);
   // the number of lines is bounded by n_bytes / 16 + 1 for well-formed data lines; launch for that bound
   const int64_t row_bound = std::min<int64_t>(p->max_rows, n_bytes / 16 + 1);
@@ -889,6 +1025,8 @@ struct exon_hip_fastq_parser {
   exon_hip_ctx* ctx = nullptr;
   int64_t max_bytes = 0, max_lines = 0;
   unsigned *d_block_counts = nullptr, *d_nl = nullptr, *d_scalars = nullptr;
+  int64_t index_blocks = 0;
+  unsigned index_gen = 0;
   int32_t* d_views = nullptr;  // 4 arrays of max_lines / 4 + 1
   unsigned* h_scalars = nullptr;
 };
@@ -911,7 +1049,9 @@ int exon_hip_fastq_parser_create(exon_hip_ctx* ctx, int64_t max_bytes, exon_hip_
   auto dalloc = [&](void** ptr, size_t bytes) {
     if (e == hipSuccess && !(*ptr = exon_pool_alloc(ctx, bytes))) e = hipErrorOutOfMemory;
   };
-  dalloc((void**)&p->d_block_counts, (size_t)nblocks * 4);
+  dalloc((void**)&p->d_block_counts, ((size_t)nblocks + 1) * 8);  // the line index's words + its tile counter (zeroed below)
+  p->index_blocks = nblocks;
+  if (e == hipSuccess && p->d_block_counts) e = hipMemset(p->d_block_counts, 0, ((size_t)nblocks + 1) * 8);
   dalloc((void**)&p->d_nl, (size_t)p->max_lines * 4);
   dalloc((void**)&p->d_scalars, 16);
   dalloc((void**)&p->d_views, per * 4 * 4);
@@ -952,9 +1092,7 @@ int exon_hip_fastq_parser_parse(exon_hip_fastq_parser* p, void* stream, const ui
   const int nblocks = (int)((n_bytes + BYTES_PER_BLOCK - 1) / BYTES_PER_BLOCK);
   const size_t per = (size_t)(p->max_lines / 4 + 1);
   int32_t* v = p->d_views;
-  hipLaunchKernelGGL(k_count_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, skip, p->d_block_counts);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, s, p->d_block_counts, nblocks, p->d_scalars, 1);
-  hipLaunchKernelGGL(k_fill_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, skip, p->d_block_counts, p->d_nl, (unsigned)p->max_lines);
+  launch_line_index(s, d_text, n_bytes, skip, p->d_block_counts, p->index_blocks, nblocks, &p->index_gen, p->d_nl, (unsigned)p->max_lines, p->d_scalars);
   const int64_t read_bound = std::min<int64_t>((int64_t)per, n_bytes / 4 + 1);  // a record holds 4 newlines
   hipLaunchKernelGGL(k_fastq_views, dim3((unsigned)((read_bound + TPB - 1) / TPB)), dim3(TPB), 0, s, d_text, p->d_nl, p->d_scalars,
                      (unsigned)p->max_lines, (int)final_slab, v, v + per, v + 2 * per, v + 3 * per, skip);
@@ -1087,6 +1225,8 @@ struct exon_hip_sam_parser {
   exon_hip_ctx* ctx = nullptr;
   int64_t max_bytes = 0, max_rows = 0;
   unsigned *d_block_counts = nullptr, *d_nl = nullptr, *d_scalars = nullptr;
+  int64_t index_blocks = 0;
+  unsigned index_gen = 0;
   NameTable refs{};
   void* ref_bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   void* bufs[8] = {nullptr};
@@ -1113,7 +1253,9 @@ int exon_hip_sam_parser_create(exon_hip_ctx* ctx, const char* const* ref_names, 
   };
   const int64_t nblocks = (max_bytes + BYTES_PER_BLOCK - 1) / BYTES_PER_BLOCK;
   const size_t r = (size_t)p->max_rows, rb = r / 8 + 64;
-  dalloc((void**)&p->d_block_counts, (size_t)nblocks * 4);
+  dalloc((void**)&p->d_block_counts, ((size_t)nblocks + 1) * 8);  // the line index's words + its tile counter (zeroed below)
+  p->index_blocks = nblocks;
+  if (e == hipSuccess && p->d_block_counts) e = hipMemset(p->d_block_counts, 0, ((size_t)nblocks + 1) * 8);
   dalloc((void**)&p->d_nl, r * 4);
   dalloc((void**)&p->d_scalars, 16);
   dalloc(&p->bufs[0], r * 4);
@@ -1159,9 +1301,7 @@ int exon_hip_sam_parser_parse(exon_hip_sam_parser* p, void* stream, const uint8_
   if (n_bytes > p->max_bytes) return fail(ctx, EXON_HIP_EINVAL, "slab of %lld bytes exceeds the parser's %lld", (long long)n_bytes, (long long)p->max_bytes);
   hipStream_t s = pick_stream(ctx, stream);
   const int nblocks = (int)((n_bytes + BYTES_PER_BLOCK - 1) / BYTES_PER_BLOCK);
-  hipLaunchKernelGGL(k_count_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, skip, p->d_block_counts);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, s, p->d_block_counts, nblocks, p->d_scalars, 1);
-  hipLaunchKernelGGL(k_fill_newlines, dim3(nblocks), dim3(TPB), 0, s, d_text, n_bytes, skip, p->d_block_counts, p->d_nl, (unsigned)p->max_rows);
+  launch_line_index(s, d_text, n_bytes, skip, p->d_block_counts, p->index_blocks, nblocks, &p->index_gen, p->d_nl, (unsigned)p->max_rows, p->d_scalars);
   hipLaunchKernelGGL(k_last_newline, dim3(1), dim3(1), 0, s, p->d_nl, p->d_scalars, (unsigned)p->max_rows);
   const int64_t row_bound = std::min<int64_t>(p->max_rows, n_bytes / 12 + 1);
   const int pblocks = (int)((row_bound + TPB - 1) / TPB);
