@@ -2535,7 +2535,9 @@ __global__ __launch_bounds__(WAVES_PER_WG * 64) void k_crc32(const uint8_t* __re
   const Block blk = blocks[b];
   if (status[b] != INF_OK) return;
   const uint32_t n = blk.out_size;
-  const uint32_t per = (((n + 63u) / 64u) + 3u) & ~3u;  // whole dwords per slice
+  // whole 128-byte lines per slice (65280 bytes: 1024 per lane): a lane reads full cache lines -- with 64-byte steps half of every
+  // 128-byte line fetched belonged to nobody's current step and was fetched again later
+  const uint32_t per = (((n + 63u) / 64u) + 127u) & ~127u;
   const uint32_t lo = min(n, (uint32_t)lane * per), hi = min(n, lo + per);
   const uint8_t* p = out + blk.out_offset;
   uint32_t c = 0;  // raw CRC register over the slice, zero initial value, no final xor
@@ -2547,6 +2549,18 @@ __global__ __launch_bounds__(WAVES_PER_WG * 64) void k_crc32(const uint8_t* __re
   while (i < hi && ((reinterpret_cast<uintptr_t>(p + i)) & 15u)) c = table[0][(c ^ p[i++]) & 0xFFu] ^ (c >> 8);
   // the lanes' slices lie ~1 KiB apart, so a load instruction touches 64 different cache lines: take a whole 64-byte
   // line per lane per iteration (4 x 16 B), or the lines are evicted between the 16 dword loads that share them
+  for (; i + 128 <= hi; i += 128) {
+    uint4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const uint4*>(p + i + 16 * k);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      step4(v[k].x);
+      step4(v[k].y);
+      step4(v[k].z);
+      step4(v[k].w);
+    }
+  }
   for (; i + 64 <= hi; i += 64) {
     uint4 v[4];
 #pragma unroll
