@@ -53,8 +53,10 @@ GENERATOR_NOTE = {
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: the chip reaches its steady clocks some tens of milliseconds into a run (same box, alternating: 3 warm-up steps +
+    # 20 timed 1.888-1.891 ms per step, 20 + 20 1.864-1.871, 50 + 100 1.841-1.873: profiles/r5_bench_warmup_sensitivity.log)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--rows", type=float, default=1e9, help="total rows (strong scaling) / rows per GPU (weak scaling)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--merge", default="auto", choices=["auto", "native", "torch"],
