@@ -2841,13 +2841,16 @@ static int inflate_flavor(int hint) {
 }
 
 hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const exon_hip_bgzf_block* d_blocks, int n_blocks,
-                                    uint8_t* d_out, int* d_status, bool verify_crc, int flavor_hint) {
+                                    uint8_t* d_out, int* d_status, bool verify_crc, int flavor_hint, bool text_like) {
   if (n_blocks <= 0) return hipSuccess;
   const int flavor = inflate_flavor(flavor_hint);
   static_assert(sizeof(Block) == sizeof(exon_hip_bgzf_block), "block layouts must agree");
   const Block* blocks = reinterpret_cast<const Block*>(d_blocks);
   const int mode = par_mode();
-  bool parallel = mode >= 1 || (mode < 0 && n_blocks <= PAR_AUTO_MAX);
+  // (auto: small launches of TEXT only -- members of BAM / BCF records and FASTQ reads are literal-heavy, the lane-parallel decoder
+  //  hands most of them back to a serial loop: 50 k BAM records 3.9 ms through it against 2.1 ms through the wide loop alone,
+  //  where 100 k rows of VCF text take 0.93 against 1.32 ms: profiles/r5_inflate_small_launches.log)
+  bool parallel = mode >= 1 || (mode < 0 && n_blocks <= PAR_AUTO_MAX && text_like);
   int dev = 0;
   unsigned* stats = nullptr;
   uint8_t* scratch = nullptr;

@@ -43,7 +43,7 @@ int get_workspace(exon_hip_ctx* ctx, hipStream_t s, size_t words, exon::Workspac
 // a stream that is about to be destroyed: release the inflate scratch kept for it (the stream must be idle)
 void exon_bgzf_forget_stream(hipStream_t s);
 hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const exon_hip_bgzf_block* d_blocks, int n_blocks,
-                                    uint8_t* d_out, int* d_status, bool verify_crc, int flavor_hint = -1);
+                                    uint8_t* d_out, int* d_status, bool verify_crc, int flavor_hint = -1, bool text_like = true);
 const char* exon_bgzf_status_name(int code);
 
 // scan.cpp: slab buffers kept per ctx between scans

@@ -883,7 +883,7 @@ class GpuTextSource {
     // the kernels write the per-block status straight into the pinned (device-visible) host words: 4 bytes per block
     int* status_dev = nullptr;
     HIP_TRY(ctx_, hipHostGetDevicePointer((void**)&status_dev, h_status(k), 0));
-    HIP_TRY(ctx_, exon_bgzf_inflate_launch(cs_, d_comp_[k], d_table(k), f.n_blocks, d_text_[k], status_dev, true));
+    HIP_TRY(ctx_, exon_bgzf_inflate_launch(cs_, d_comp_[k], d_table(k), f.n_blocks, d_text_[k], status_dev, true, -1, /*text_like=*/!binary_ && !text_async_));
     HIP_TRY(ctx_, hipEventRecord(ev_done_[k], cs_));
     enq_[k] = true;
     return EXON_HIP_OK;
