@@ -236,3 +236,36 @@ def test_gpu_inflate_compressed_slab_beyond_512_mib(ctx):
     assert got.size == n * len(data)
     for k in (0, (512 << 20) // len(blk) + 1, n - 1):
         assert got[k * len(data):(k + 1) * len(data)].tobytes() == data, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wbits,mem", [(15, 1), (9, 1), (9, 9), (12, 4)])
+def test_gpu_inflate_many_small_deflate_blocks_and_small_windows(ctx, wbits, mem):
+    """zlib's memLevel 1 cuts a member into DEFLATE blocks of 128 symbols (hundreds of table builds, end-of-block codes and
+    symbol-loop entries per member); a 512-byte window (wbits 9) makes every match a near one.  Text, runs, sparse noise and
+    literal-heavy bytes, every symbol loop's default path."""
+    rng = np.random.default_rng(31)
+    text = vcf_like(9000, seed=5)
+    noisy = np.frombuffer(text, np.uint8).copy()
+    m = rng.random(noisy.size) < 0.3
+    noisy[m] = rng.integers(0, 256, int(m.sum()), dtype=np.uint8)
+    runs = b"".join(bytes([65 + i % 26]) * int(k) for i, k in enumerate(rng.integers(1, 400, 3000)))
+    quals = rng.integers(33, 74, 600_000, dtype=np.uint8).tobytes()
+    for data in (text, noisy.tobytes(), runs, quals):
+        blocks = []
+        for i in range(0, len(data), 65280):
+            chunk = data[i:i + 65280]
+            co = zlib.compressobj(6, zlib.DEFLATED, -wbits, mem)
+            c = co.compress(chunk) + co.flush()
+            if 18 + len(c) + 8 > 65536:   # incompressible under these settings: smaller members
+                half = len(chunk) // 2
+                for part in (chunk[:half], chunk[half:]):
+                    co = zlib.compressobj(6, zlib.DEFLATED, -wbits, mem)
+                    cc = co.compress(part) + co.flush()
+                    blocks.append((part, cc))
+            else:
+                blocks.append((chunk, c))
+        f = b"".join(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", 18 + len(c) + 8 - 1) + c +
+                     struct.pack("<II", zlib.crc32(d) & 0xFFFFFFFF, len(d)) for d, c in blocks)
+        got, _ = ctx.bgzf_inflate(f)
+        assert got.tobytes() == b"".join(d for d, _ in blocks)
