@@ -1008,8 +1008,10 @@ __device__ __forceinline__ uint32_t symbol_run_v(BitReader& br, uint32_t& pos, u
 // already in HBM (the load is deferred by one round) -- instead of one masked copy per match.
 //   * a match that does not fit the round's 64 output bytes is carried into the next round as (rest, distance): rounds split
 //     matches freely, a copy is byte-sequential;
-//   * a byte whose source lies in its own round (distance <= lane: overlapping runs, very near matches) takes the slow path
-//     of the round: the bytes are produced in dependency order, as many per step as are ready;
+//   * a byte whose source lies in its own round (distance <= lane: a match right behind the literals it repeats, runs): the round
+//     is cut in front of the symbol that owns the first such byte (what precedes it has its sources in earlier rounds, and so has
+//     that symbol as the first of the next round); only a match that overlaps ITSELF (distance < length) takes the slow path of
+//     the round, where the bytes are produced in dependency order, as many per step as are ready;
 //   * a symbol the tables do not resolve ends the chain in front of it (its lane's record is 0, the chain goes to 64 + lane).  A
 //     LITERAL with a code longer than the table is decoded right there (all candidate lengths at once, one per lane) and the walk
 //     goes on; end of block, a long length / distance code or an invalid code leave the loop: the round consumes what precedes

@@ -825,6 +825,7 @@ int exon_hip_stream_push_raw(exon_hip_stream* st, const exon::RawBatch& rb) {
     if (rc) return rc;
     if (st->slots[st->cur].rows >= st->cap_rows && (rc = flush_slot(st))) return rc;
     Slot& s = st->slots[st->cur];
+    materialise_held(st, s);  // (batches held by exon_hip_stream_push land first: the bitmap bookkeeping below is in arrival order)
     const int64_t n = std::min<int64_t>(rb.rows - done, st->cap_rows - s.rows);
     for (int c = 0; c < p->n_cols; ++c) {
       const exon::RawColumn& rc2 = rb.cols[(size_t)p->d.columns[c]];
