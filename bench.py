@@ -400,6 +400,7 @@ def h2d_inclusive(ctx, n=64_000_000):
     import subprocess
     exe = os.path.join(ROOT, "tools", "bin", "measure_h2d_native")
     out = {}
+    time.sleep(0.3)  # (the CPU baseline has just used the container's whole CFS quota: let the 100 ms period roll over)
     for name, batch in (("batch_4Mi_rows", 4 << 20), ("batch_8192_rows", 8192)):
         r = subprocess.run([exe, str(n), str(batch)], capture_output=True, text=True, timeout=300)
         if r.returncode != 0:

@@ -43,7 +43,7 @@ int main(int argc, char** argv) {
   // pinned staging slots are allocated by the first push of the first repetition (tens of milliseconds, once per partition)
   exon_hip_stream* st = nullptr;
   if (exon_hip_stream_open(plan, 0, &st) != EXON_HIP_OK) { fprintf(stderr, "%s\n", exon_hip_last_error(ctx)); return 1; }
-  for (int rep = 0; rep < 5; ++rep) {
+  for (int rep = 0; rep < 9; ++rep) {  // best of 8 warm repetitions (host scheduling makes single ones vary by 20 %)
     if (exon_hip_stream_reset(st) != EXON_HIP_OK) { fprintf(stderr, "%s\n", exon_hip_last_error(ctx)); return 1; }
     const auto t0 = std::chrono::steady_clock::now();
     for (int64_t o = 0; o < total; o += batch) {
