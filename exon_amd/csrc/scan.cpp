@@ -660,8 +660,10 @@ class GpuTextSource {
     if (cs_) hipStreamSynchronize(cs_);
     if (ev_carry_) hipEventDestroy(ev_carry_);
     if (getenv("EXON_HIP_PIPE_TRACE"))
-      fprintf(stderr, "[exon-hip pipe] teardown: reader join %.1f ms, stream sync %.1f ms; reader: file reads %.1f ms, header walk %.1f ms; consumer waited %.1f ms for inflates, %.1f ms for the reader\n",
-              (td1 - td0) * 1e3, (now_s() - td1) * 1e3, t_read_ * 1e3, t_scan_ * 1e3, t_wait_inflate_ * 1e3, t_wait_reader_ * 1e3);
+      fprintf(stderr, "[exon-hip pipe] teardown: reader join %.1f ms, stream sync %.1f ms; reader: busy %.1f ms = file reads %.1f ms + pieces %.1f ms (next piece's start %.1f, copy calls %.1f, header walk %.1f) + "
+              "leftovers %.1f ms + the rest; thread start lag %.1f ms; consumer waited %.1f ms for inflates, %.1f ms for the reader\n",
+              (td1 - td0) * 1e3, (now_s() - td1) * 1e3, t_fill_ * 1e3, t_read_ * 1e3, t_scan_ * 1e3, t_piece_start_ * 1e3, t_h2d_calls_ * 1e3, t_walk_ * 1e3,
+              t_rest_ * 1e3, t_spawn_ * 1e3, t_wait_inflate_ * 1e3, t_wait_reader_ * 1e3);
     SlabBuffers b;
     b.cs = cs_;
     b.xs = xs_;
@@ -941,7 +943,10 @@ class GpuTextSource {
       if (f_[k ^ 1].err) return rethrow(f_[k ^ 1].err);
       int rc = enqueue_inflate(k ^ 1);
       if (rc) return rc;
-      if (!f_[k ^ 1].eof) reader_ = std::thread([this, k] { fill(k, &f_[k]); });
+      if (!f_[k ^ 1].eof) {
+        t_spawn_at_ = now_s();
+        reader_ = std::thread([this, k] { fill(k, &f_[k]); });
+      }
     }
     if (!more && n_text > 0 && !binary_) {  // last line without a terminator
       uint8_t lastb = 0;
@@ -971,6 +976,7 @@ class GpuTextSource {
   // background thread: next chunk of the file into h_buf_[k]
   void fill(int k, Filled* f) {
     const double t_fill0 = now_s();
+    if (t_spawn_at_ > 0) t_spawn_ += t_fill0 - t_spawn_at_;
     struct Acc { double* a; double t0; ~Acc() { *a += now_s() - t0; } } acc{&t_fill_, t_fill0};
     try {
       if (!bgzf_) {
@@ -1085,11 +1091,15 @@ class GpuTextSource {
         Piece nxt;
         if (n == cur.want) nxt = start_piece(off + n);  // its read runs under everything below
         if (n == 0) break;
+        const double tf2 = now_s();
+        t_piece_start_ += tf2 - tf1;
         uint8_t* base = cur.base;
         const int p = cur.p;
         if (hipMemcpyAsync(d_comp_[k] + off, base, n, hipMemcpyHostToDevice, xs_) != hipSuccess || hipEventRecord(ev_piece_[p], xs_) != hipSuccess)
           throw std::runtime_error("H2D of a compressed piece failed");
         piece_used_[p] = true;
+        const double tf3 = now_s();
+        t_h2d_calls_ += tf3 - tf2;
         // the block that straddles the piece boundary: its head (kept in piece_carry_) goes right in front of this piece's bytes
         uint8_t* view = base - view_carry;
         if (view_carry) memcpy(view, piece_carry_.data(), view_carry);
@@ -1098,6 +1108,7 @@ class GpuTextSource {
         size_t consumed = 0, ob = 0;
         if (exon_hip_bgzf_scan(view, vn, out_bytes, hb + nb, cap_blocks - nb, &got_nb, &consumed, &ob) != EXON_HIP_OK)
           throw std::runtime_error(exon_hip_last_error(nullptr));
+        t_walk_ += now_s() - tf3;
         // text capacity: keep the blocks that fit
         int keep = 0;
         size_t kept_out = 0, kept_consumed = 0;
@@ -1118,7 +1129,9 @@ class GpuTextSource {
         out_bytes += kept_out;
         consumed_total = (size_t)view_global + kept_consumed;
         off += n;
-        t_scan_ += now_s() - tf1;
+        const double tf4 = now_s();
+        t_scan_ += tf4 - tf1;
+        struct AccRest { double* a; double t0; ~AccRest() { *a += now_s() - t0; } } acc_rest{&t_rest_, tf4};
         const size_t tail = vn - kept_consumed;
         if (stop) {
           rest.assign(reinterpret_cast<const char*>(view) + kept_consumed, tail);
@@ -1230,7 +1243,8 @@ class GpuTextSource {
   Filled cur_, nxt_;
   Filled f_[2];            // bgzf: what the reader put into host buffer k
   double t_fill_ = 0;      // seconds the reader spent filling host buffers
-  double t_read_ = 0, t_scan_ = 0;  // of which: file reads, BGZF header walk
+  double t_read_ = 0, t_scan_ = 0;  // of which: file reads, BGZF header walk (with the copy calls and the next piece's start)
+  double t_walk_ = 0, t_h2d_calls_ = 0, t_piece_start_ = 0, t_rest_ = 0, t_spawn_ = 0, t_spawn_at_ = 0;  // finer (EXON_HIP_PIPE_TRACE)
   double t_wait_inflate_ = 0, t_wait_reader_ = 0;  // consumer: blocked on the inflate of the slab it wants / on the reader
   uint64_t idx_ = 0;       // bgzf: index of the slab being consumed
   int carry_k_ = 0;
