@@ -1186,6 +1186,7 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "L_wr_nobad%=:\n"
       "  v_cmp_lt_u32 vcc, v55, %[lane]\n"                // a source inside the round's own output
       "  s_cbranch_vccnz L_wr_dep%=\n"
+      "L_wr_copy%=:\n"
       "  s_mov_b64 s[62:63], exec\n"
       "  v_cmpx_gt_i32 vcc, 0, v53\n"                     // literals
       "  ds_write_b8_d16_hi v57, v53\n"
@@ -1307,7 +1308,47 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       // literals it repeats, runs).  The round is cut in front of the symbol that owns the first such byte: what precedes it has
       // all its sources in earlier rounds, and that symbol, first of the next round, has too -- unless it overlaps ITSELF
       // (distance < length), which only the caller's byte-ordered slow path resolves.
+      // First the round's FIRST symbol, carried in or not: a match that overlaps its own output (distance < length: runs, 1.5 % of the
+      // matches of BAM payloads) repeats with period `distance`, so its bytes take their sources floor(lane / distance) periods
+      // further back -- in front of the round -- and depend on nothing.  (They used to go to the caller's byte-ordered loop: an
+      // iteration per byte of a run, ~20 rounds' worth of instructions for one round, 3.4 % of the rounds of BAM payloads.)
       "L_wr_dep%=:\n"
+      "  s_mov_b64 s[58:59], vcc\n"                      // the dependent byte lanes
+      "  s_mov_b32 s57, s52\n"
+      "  s_min_u32 s62, s51, 64\n"                       // bytes of the first symbol in this round: of a match carried in ...
+      "  s_cmp_eq_u32 s51, 0\n"
+      "  s_cbranch_scc0 L_wr_fold_first%=\n"
+      "  s_nop 3\n"
+      "  v_readlane_b32 s57, v51, 0\n"                   // ... or of the symbol at the round's first bit
+      "  s_and_b32 s62, s57, 0x1ff\n"
+      "L_wr_fold_first%=:\n"
+      "  s_ashr_i32 s66, s57, 16\n"                      // its distance - 1 (a literal: negative)
+      "  s_cmp_lt_i32 s66, 0\n"
+      "  s_cbranch_scc1 L_wr_dep_others%=\n"
+      "  s_mov_b64 s[60:61], -1\n"
+      "  s_cmp_ge_u32 s62, 64\n"
+      "  s_cbranch_scc1 L_wr_fold_mask%=\n"
+      "  s_bfm_b64 s[60:61], s62, 0\n"                   // the byte lanes of that symbol
+      "L_wr_fold_mask%=:\n"
+      "  s_and_b64 vcc, s[60:61], s[58:59]\n"
+      "  s_cbranch_scc0 L_wr_dep_others%=\n"             // none of them dependent
+      "  s_add_u32 s66, s66, 1\n"                        // the distance
+      "  v_cvt_f32_u32 v48, %[lane]\n"
+      "  v_cvt_f32_u32 v49, s66\n"
+      "  v_rcp_f32 v49, v49\n"
+      "  v_add_f32 v48, 0.5, v48\n"                      // (lane + 1/2) / distance is never within rounding of a whole number
+      "  s_nop 0\n"
+      "  v_mul_f32 v48, v48, v49\n"
+      "  v_cvt_u32_f32 v48, v48\n"                       // whole periods between the byte and the symbol's start in this round
+      "  v_mul_u32_u24 v48, s66, v48\n"
+      "  v_cndmask_b32 v48, 0, v48, s[60:61]\n"
+      "  v_sub_u32 v58, v58, v48\n"
+      "  s_andn2_b64 vcc, s[58:59], s[60:61]\n"          // dependent bytes of the symbols behind it
+      "  s_cbranch_scc0 L_wr_copy%=\n"
+      "  s_branch L_wr_dep_cut%=\n"
+      "L_wr_dep_others%=:\n"
+      "  s_mov_b64 vcc, s[58:59]\n"
+      "L_wr_dep_cut%=:\n"
       "  s_ff1_i32_b64 s66, vcc\n"                       // the first byte whose source lies inside the round
       "  s_mov_b64 exec, -1\n"
       "  s_sub_u32 s44, s44, s70\n"                      // back to the round's first bit (a borrow: the window has moved, the caller rewinds)
@@ -1497,20 +1538,31 @@ __device__ __forceinline__ uint32_t wide_run(BitReader& br, Out& o, uint32_t& e_
     const bool blit = (int32_t)rb < 0;
     const bool bmatch = valid && !blit;
     const uint32_t dst = pos + lane, ra = dst & RM;
-    const uint32_t src1 = dst - (uint32_t)dm1b;  // source index + 1
+    uint32_t src1 = dst - (uint32_t)dm1b;  // source index + 1
     if (__any(bmatch && (uint32_t)dm1b >= dst - o.begin)) {
       why = 4;
       break;
     }
     const bool bfar = bmatch && dm1b >= (int32_t)NEARW;
     const bool bnear = bmatch && !bfar;
-    if (__builtin_expect(__any(bnear && (uint32_t)dm1b < lane), 0)) {
+    // A match that overlaps its own output (distance < length: runs; 1.5 % of the matches of BAM payloads) repeats with period
+    // `distance`: the bytes of the round's FIRST symbol -- carried in or not -- take their sources that many whole periods further
+    // back, in front of the round, and wait for nothing.  (Left to the dependency loop below, a run of one byte costs an iteration
+    // per byte: ~20 rounds' worth of instructions for one round.)
+    {
+      const uint32_t first_rec = carry_len ? carry_rec : rdl(rec, 0);
+      const uint32_t F = carry_len ? min(carry_len, 64u) : (first_rec & 0x1FFu);
+      const int32_t fd1 = (int32_t)first_rec >> 16;
+      if (fd1 >= 0 && (uint32_t)fd1 + 1u < 64u && lane < F && bnear) src1 -= (lane / ((uint32_t)fd1 + 1u)) * ((uint32_t)fd1 + 1u);
+    }
+    const bool bdep = bnear && src1 > dst - lane;  // the source (index src1 - 1) lies inside the round's own output
+    if (__builtin_expect(__any(bdep), 0)) {
       // a source inside this round's own output: produce the bytes in dependency order
       complete_far();
       if (valid && blit) ring[ra] = (uint8_t)(rb >> 16);
       if (bfar) ring[ra] = gout[src1 - 1u];
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      const uint32_t need = bnear && (uint32_t)dm1b < lane ? lane - (uint32_t)dm1b : 0u;  // bytes of the round this one waits for
+      const uint32_t need = bdep ? src1 - (dst - lane) : 0u;  // bytes of the round this one waits for
       for (uint32_t D = 0; D < nb;) {
         const unsigned long long blocked = __ballot(valid && need > D);
         const uint32_t Dn = blocked ? (uint32_t)__ffsll((long long)blocked) - 1u : nb;

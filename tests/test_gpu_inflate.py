@@ -66,7 +66,7 @@ def test_gpu_inflate_reference_fixtures(ctx, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["text", "random", "zeros", "runs", "short", "farlong"])
+@pytest.mark.parametrize("kind", ["text", "random", "zeros", "runs", "periods", "short", "farlong"])
 @pytest.mark.parametrize("level,strategy", [(6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY),
                                             (0, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY),
                                             (6, zlib.Z_RLE)])
@@ -84,6 +84,13 @@ def test_gpu_inflate_equals_zlib(ctx, kind, level, strategy):
             unit = rng.integers(65, 91, d, dtype=np.uint8).tobytes()
             parts.append(unit * (700 // d + 1))
         data = b"".join(parts) * 8
+    elif kind == "periods":  # self-overlapping matches of every period 1..70 and length 3..600 behind 0..70 fresh literals: the
+        parts = []           # wide loop folds a first symbol's bytes by whole periods; runs carried across rounds, periods at 63-65
+        for i in range(3000):
+            d, total = int(rng.integers(1, 71)), int(rng.integers(3, 601))
+            unit = rng.integers(0, 256, d, dtype=np.uint8).tobytes()
+            parts.append(rng.integers(0, 256, int(rng.integers(0, 71)), dtype=np.uint8).tobytes() + (unit * (total // d + 1))[:total])
+        data = b"".join(parts)
     elif kind == "farlong":  # 258-byte matches from 3-5 KB back (beyond the 2 KiB ring): the far path with len > 64,
         unit = rng.integers(0, 256, 3000, dtype=np.uint8).tobytes()  # and short far ones at its seams
         data = b"".join(unit + rng.integers(0, 256, int(k), dtype=np.uint8).tobytes() for k in rng.integers(0, 2000, 60))

@@ -58,7 +58,7 @@ static const uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2,
 static const uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
 static const uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 
-struct Tok { uint32_t bitpos, bits, len, dist; bool longcode; };
+struct Tok { uint32_t bitpos, bits, len, dist; bool longcode, longlen, longdist; };
 
 int main(int argc, char** argv) {
   if (argc < 2) return 1;
@@ -74,7 +74,7 @@ int main(int argc, char** argv) {
   uint64_t dist_le[5] = {0, 0, 0, 0, 0};
   const uint32_t dist_cut[5] = {1024 - 258, 2048 - 258, 4096 - 258, 8192 - 258, 32768};
   uint64_t rounds = 0, round_syms = 0, round_matches = 0, round_dep = 0, round_hist[20] = {0}, rm_hist[12] = {0}, round_out = 0, round_out_gt64 = 0;
-  uint64_t matchbytes = 0, lit_run_hist[10] = {0};
+  uint64_t matchbytes = 0, lit_run_hist[10] = {0}, long_len = 0, r_longlen = 0, r_longdist = 0, r_overlap = 0, r_any_slow = 0, r_longlit = 0;
   static uint64_t cl_hist[16] = {0};
   while (o + 18 <= raw.size() && members < want) {
     const uint8_t* h = raw.data() + o;
@@ -141,10 +141,11 @@ int main(int argc, char** argv) {
           t.longcode = l > 9;
         } else {
           t.longcode = l > 9;
+          t.longlen = l > 9;
           t.len = LBASE[s - 257] + b.take(LEXT[s - 257]);
           int dl;
           const int d = dist.decode(b, &dl);
-          if (dl > 8) t.longcode = true, ++long_dist;
+          if (dl > 8) t.longcode = true, t.longdist = true, ++long_dist;
           t.dist = DBASE[d] + b.take(DEXT[d]);
         }
         if (t.longcode && !t.dist) ++long_lit;
@@ -164,6 +165,7 @@ int main(int argc, char** argv) {
       ++nmatch;
       matchbytes += t.len;
       if (t.len > 64) ++len_gt64;
+      if (t.longlen) ++long_len;
       if (t.dist < t.len) ++overlap;
       for (int k = 0; k < 5; ++k)
         if (t.dist <= dist_cut[k]) dist_le[k]++;
@@ -172,10 +174,14 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < toks.size();) {
       const uint32_t p0 = toks[i].bitpos;
       uint32_t ns = 0, nm = 0, outb = 0;
-      bool dep = false;
+      bool dep = false, s_ll = false, s_ld = false, s_ov = false;
       while (i < toks.size() && toks[i].bitpos - p0 < 64) {
+        if (toks[i].longcode && !toks[i].dist) ++r_longlit;
         if (toks[i].dist) {
           ++nm;
+          if (toks[i].longlen) s_ll = true;
+          if (toks[i].longdist) s_ld = true;
+          if (toks[i].dist < toks[i].len) s_ov = true;
           if (toks[i].dist < outb + toks[i].len) dep = true;  // reads bytes this round wrote (or its own)
         }
         outb += toks[i].len;
@@ -186,6 +192,7 @@ int main(int argc, char** argv) {
       round_syms += ns;
       round_matches += nm;
       round_dep += dep;
+      r_longlen += s_ll; r_longdist += s_ld; r_overlap += s_ov; r_any_slow += (s_ll || s_ld || s_ov);
       round_out += outb;
       round_out_gt64 += outb > 64;
       round_hist[ns > 19 ? 19 : ns]++;
@@ -205,6 +212,8 @@ int main(int argc, char** argv) {
   printf("wide rounds (64 bit offsets): %.0f / member, %.2f symbols, %.2f matches, %.1f out bytes per round; rounds with a match that reads its own round's output %.2f %%, rounds with > 64 out bytes %.2f %%\n",
          (double)rounds / members, (double)round_syms / rounds, (double)round_matches / rounds, (double)round_out / rounds, 100.0 * round_dep / rounds,
          100.0 * round_out_gt64 / rounds);
+  printf("rounds holding a match with a long LENGTH code %.2f %%, a long distance code %.2f %%, an overlapping match %.2f %%, any of the three %.2f %%; long-code literals %.3f per round; long length codes %.2f %% of matches\n",
+         100.0 * r_longlen / rounds, 100.0 * r_longdist / rounds, 100.0 * r_overlap / rounds, 100.0 * r_any_slow / rounds, (double)r_longlit / rounds, 100.0 * long_len / (nmatch ? nmatch : 1));
   printf("symbols per round:");
   for (int k = 0; k < 20; ++k) printf(" %d:%.1f%%", k, 100.0 * round_hist[k] / rounds);
   printf("\nmatches per round:");
