@@ -1076,7 +1076,13 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  ds_bpermute_b32 v35, v34, %[cur]\n"
       "  ds_bpermute_b32 v36, v34, %[cur] offset:4\n"
       "  ds_bpermute_b32 v37, v34, %[cur] offset:8\n"
-      // ---- a round: every lane's 64 bits of the stream from bit bp + lane (v33) are on their way
+      // ---- a round: every lane's 64 bits of the stream from bit bp + lane (v33) are on their way.  (The round's first instruction
+      // sits on a 64-byte line: the chain walk's loop, 268 bytes further on, then lies inside one line -- the kernel is 1.2 % faster on
+      // FASTQ and VCF members than with the loop 4 bytes further along, profiles/r5_inflate_code_alignment.log.  The padding is only
+      // run through when the rounds are entered.)
+#ifndef EXON_WIDE_NO_ALIGN
+      "  .p2align 6\n"
+#endif
       "L_wr_round%=:\n"
       "  s_waitcnt lgkmcnt(0)\n"
       "  v_alignbit_b32 v38, v36, v35, v33\n"
@@ -1139,10 +1145,12 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  s_cbranch_scc1 L_wr_long%=\n"
       "L_wr_postwalk%=:\n"
       "  s_mov_b64 exec, -1\n"
-      // a symbol that STARTS beyond the 64 output bytes of the round was walked over: the careful walk of the C++ round
+      // a symbol that STARTS beyond the 64 output bytes of the round was walked over (a long match with more symbols behind it in
+      // the same 64 bits: 2 % of the rounds of BAM payloads): the byte lanes are right -- such a symbol found EXEC empty -- but
+      // the round must end in front of the first of them.  A second, scalar-only walk finds it.
       "  s_sub_u32 s66, s65, s57\n"
       "  s_cmp_ge_u32 s66, 64\n"
-      "  s_cbranch_scc1 L_wr_slow%=\n"
+      "  s_cbranch_scc1 L_wr_walk64_start%=\n"
       "L_wr_walked%=:\n"
       "  s_mov_b32 s70, s53\n"                           // bits consumed ...
       "  s_mov_b32 s67, s57\n"                           // (0: the round ends in front of an unresolved symbol; kept until the advance)
@@ -1381,6 +1389,24 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  s_mov_b32 s70, s53\n"
       "  s_mov_b32 s64, s65\n"
       "  s_branch L_wr_rewin%=\n"
+      "L_wr_walk64_start%=:\n"
+      "  s_mov_b32 s65, s51\n"
+      "  s_mov_b32 s53, 0\n"
+      "  s_mov_b32 s54, s52\n"
+      "  s_nop 3\n"
+      "L_wr_walk64%=:\n"
+      "  v_readlane_b32 s71, v51, s53\n"
+      "  s_cmp_ge_u32 s65, 64\n"                         // this one starts beyond the round's bytes
+      "  s_cbranch_scc1 L_wr_walk64_done%=\n"
+      "  s_and_b32 s57, s71, 0x1ff\n"
+      "  s_cbranch_scc0 L_wr_slow%=\n"                   // (no bytes: a long literal the first walk decoded on the way -- the caller's)
+      "  s_mov_b32 s54, s71\n"
+      "  s_bfe_u32 s53, s71, 0x70009\n"
+      "  s_add_u32 s65, s65, s57\n"
+      "  s_branch L_wr_walk64%=\n"
+      "L_wr_walk64_done%=:\n"
+      "  s_mov_b32 s57, 1\n"                             // (the round does not end in front of an unresolved symbol)
+      "  s_branch L_wr_walked%=\n"
       "L_wr_bad%=:\n"
       "  s_mov_b64 exec, -1\n"
       "  s_sub_u32 s44, s44, s70\n"
@@ -1415,6 +1441,10 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
   return uniu(code);
 }
 
+#ifdef EXON_WIDE_STATS  // developer build (tools/build_variant.sh stats -DEXON_WIDE_STATS): where a member's clocks go
+// [0] clocks inside wide_rounds_asm, [1] clocks of whole members, [2..7] returns of wide_rounds_asm by code 0..5, [8] members
+__device__ unsigned long long g_wide_stats[16];
+#endif
 template <int RING>
 __device__ __forceinline__ uint32_t wide_run(BitReader& br, Out& o, uint32_t& e_out, uint32_t& len_out, uint32_t& d_out) {
   constexpr uint32_t RM = RING - 1, NEARW = RING - 258;
@@ -1457,8 +1487,17 @@ __device__ __forceinline__ uint32_t wide_run(BitReader& br, Out& o, uint32_t& e_
     //      that starts beyond the round's 64 output bytes): rec / nextp / ev are that round's, nothing of it is consumed
     {
       uint32_t e_asm = 0;
+#ifdef EXON_WIDE_STATS
+      const unsigned long long ws0 = __builtin_readcyclecounter();
+#endif
       const uint32_t code = wide_rounds_asm<RING>(base, gout, bp, wb, pos, drained, carry_len, carry_rec, o.begin, o.end, br.limit, lane, cur, nxt,
                                                   fdata, faddr, rec, nextp, ev, e_asm);
+#ifdef EXON_WIDE_STATS
+      if (lane == 0) {
+        atomicAdd(&g_wide_stats[0], __builtin_readcyclecounter() - ws0);
+        atomicAdd(&g_wide_stats[2 + (code < 6 ? code : 5)], 1ull);
+      }
+#endif
       if (code == 0) {
         why = 0;
         e_out = e_asm;
@@ -2522,7 +2561,16 @@ __global__ __launch_bounds__(64 * INF_WAVES, 8) __attribute__((amdgpu_num_sgpr(7
                                                               int* __restrict__ status) {
   const int b = uni((int)(blockIdx.x * INF_WAVES + (threadIdx.x >> 6)));
   if (b >= n_blocks) return;
+#ifdef EXON_WIDE_STATS
+  const unsigned long long ws0 = __builtin_readcyclecounter();
+#endif
   inflate_member<RING, false, true>(comp, blocks, b, out, status, ParSlot{}, nullptr, 1);
+#ifdef EXON_WIDE_STATS
+  if (lane_id() == 0) {
+    atomicAdd(&g_wide_stats[1], __builtin_readcyclecounter() - ws0);
+    atomicAdd(&g_wide_stats[8], 1ull);
+  }
+#endif
 }
 
 // The lane-parallel variant: a fixed set of workgroups (one scratch slot each) takes members off a shared counter.
@@ -2912,6 +2960,15 @@ extern "C" int exon_hip_bgzf_inflate_par_stats(void* stream, uint32_t* out32) {
     auto it = g_par_dev.find(dev);
     if (it != g_par_dev.end()) st = it->second.stats;
   }
+#ifdef EXON_WIDE_STATS  // the wide loop's clock split instead: 16 x u64 in the 32 words, then zeroed
+  {
+    unsigned long long w[16] = {0}, z[16] = {0};
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(w, HIP_SYMBOL(g_wide_stats), sizeof w) != hipSuccess) return -1;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wide_stats), z, sizeof z);
+    memcpy(out32, w, sizeof w);
+    return 0;
+  }
+#endif
   if (!st) return 0;
   if (hipDeviceSynchronize() != hipSuccess) return -1;
   return hipMemcpy(out32, st, 32 * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
