@@ -145,7 +145,15 @@ struct WaveLds {
   // per length: first canonical code / symbols of shorter lengths.  Scratch of every build_code; the literal/length
   // code is built LAST, so between table builds these hold ITS values, which decode_long uses.
   uint16_t first[16], offs[16];
+  // the same two of the DISTANCE code, kept when its table is built: the wide loop decodes distance codes longer than the table
+  // itself (they are the largest group of symbols that used to leave its rounds: 0.8-1.6 % of the rounds), and decode_long takes
+  // all candidate lengths at once for them too.  (first / offs / dfirst / doffs and lit_count / dist_count are read as two arrays
+  // of 32 by the wide loop: keep them adjacent.)
+  uint16_t dfirst[16], doffs[16];
 };
+static_assert(__builtin_offsetof(WaveLds, offs) == __builtin_offsetof(WaveLds, first) + 32 && __builtin_offsetof(WaveLds, dfirst) == __builtin_offsetof(WaveLds, first) + 64 &&
+                  __builtin_offsetof(WaveLds, doffs) == __builtin_offsetof(WaveLds, first) + 96 && __builtin_offsetof(WaveLds, dist_count) == __builtin_offsetof(WaveLds, lit_count) + 32,
+              "the wide loop's prologue reads these as arrays of 32");
 // (the code-length tables share the bytes of dist_lut: they are dead once the lengths are read)
 enum { CODE_LIT = 0, CODE_DIST = 1, CODE_CL = 2 };
 
@@ -331,6 +339,10 @@ __device__ __noinline__ int build_code_impl(int which, int lens_off, int n) {
     c.count[lane] = (uint16_t)run_l;
     c.first[lane] = (uint16_t)first_l;
     c.offs[lane] = (uint16_t)offs_l;
+    if (which == CODE_DIST) {
+      L->dfirst[lane] = (uint16_t)first_l;
+      L->doffs[lane] = (uint16_t)offs_l;
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   // every symbol gets its canonical code (rank inside its length class, in symbol order); fill the tables
@@ -372,21 +384,24 @@ __device__ __forceinline__ bool build_code(int which, int lens_off, int n) {
 // code of that length and tests it against the codes of its length (first[L] <= code < first[L] + count[L]); codes
 // are prefix-free, so at most one length matches.  (High-entropy payloads -- BAM -- come here for ~2 % of their bytes;
 // the bit-serial loop cost ~150 instructions a time: +21 % on BAM.)  Distance and code-length codes, which hardly
-// ever get here, keep the bit-serial loop (their first[] / offs[] do not outlive their table build).
+// ever get here, kept the bit-serial loop until round 5 (the distance code's first[] / offs[] now outlive its build: dfirst / doffs).
 template <int RING>
 __device__ __noinline__ int decode_long(int which, uint32_t bits) {
   which = uni(which);
   bits = uniu(bits);
   const Code c = code_of<RING>(which);
-  if (which == CODE_LIT) {
+  if (which == CODE_LIT || which == CODE_DIST) {
+    const WaveLds* L = wave_lds<RING>();
+    const uint16_t* first = which == CODE_LIT ? c.first : L->dfirst;  // (c.first / c.offs are the literal/length code's between builds)
+    const uint16_t* offs = which == CODE_LIT ? c.offs : L->doffs;
     const int len = (int)lane_id() & 15;  // lanes 16.. repeat 0..15: only the ballot's low 16 bits are used
     const uint32_t code = len ? __brev(bits) >> (32 - len) : 0u;  // DEFLATE packs Huffman codes starting from their MSB
-    const uint32_t rel = code - (uint32_t)c.first[len];
+    const uint32_t rel = code - (uint32_t)first[len];
     const bool hit = len != 0 && rel < (uint32_t)c.count[len];
     const uint32_t m = (uint32_t)__ballot(hit) & 0xFFFEu;
     if (m == 0) return -1;
     const int l = __ffs((int)m) - 1;
-    const int idx = __builtin_amdgcn_readlane((int)((uint32_t)c.offs[len] + rel), l);
+    const int idx = __builtin_amdgcn_readlane((int)((uint32_t)offs[len] + rel), l);
     return ((int)c.sym[idx] << 8) | l;
   }
   int code = 0, first = 0, index = 0;
@@ -1057,13 +1072,19 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  v_add_u32 v60, 64, %[lane]\n"                   // 64 + lane: where the chain goes from a symbol the tables do not resolve
       "  v_mov_b32 v50, 0xff0000\n"                      // (constants of the literal's record: one v_and_or instead of two instructions)
       "  v_mov_b32 v54, 0x80000001\n"
-      // lane q (1..15): first canonical code / number of codes / symbols of shorter lengths, of literal/length codes q bits long
-      "  v_and_b32 v48, 15, %[lane]\n"
-      "  v_lshlrev_b32 v48, 1, v48\n"
+      // lane q (1..15): first canonical code / number of codes / symbols of shorter lengths, of literal/length codes q bits long;
+      // lane 16 + q: the same of distance codes q bits long (first | offs | dfirst | doffs and lit_count | dist_count are adjacent)
+      "  v_and_b32 v48, 31, %[lane]\n"
+      "  v_lshlrev_b32 v49, 1, v48\n"                    // counts: 2 bytes x (lane & 31)
+      "  v_and_b32 v47, 16, %[lane]\n"
+      "  v_lshl_add_u32 v48, v47, 1, v49\n"              // first / offs: the distance code's sit 64 bytes further on (32 + 2 x 16)
       "  ds_read_u16 v61, v48 offset:%[firstoff]\n"
-      "  ds_read_u16 v62, v48 offset:%[countoff]\n"
+      "  ds_read_u16 v62, v49 offset:%[countoff]\n"
       "  ds_read_u16 v63, v48 offset:%[offsoff]\n"
-      "  v_cmp_gt_u32 vcc, 16, %[lane]\n"
+      "  v_and_b32 v47, 15, %[lane]\n"
+      "  v_cmp_gt_u32 vcc, 32, %[lane]\n"
+      "  v_cmp_ne_u32 s[58:59], 0, v47\n"                // (no code of length 0; the distance code's slot for it is the far copy's dummy byte)
+      "  s_and_b64 vcc, vcc, s[58:59]\n"
       "  s_waitcnt lgkmcnt(0)\n"
       "  v_cndmask_b32 v62, 0, v62, vcc\n"
       "  s_cmpk_lt_u32 s44, 0x400\n"
@@ -1282,7 +1303,7 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  v_readlane_b32 s66, %[ev], s67\n"
       "  v_sub_u32 v49, 32, v49\n"
       "  s_cmp_eq_u32 s66, 0\n"
-      "  s_cbranch_scc0 L_wr_postwalk%=\n"
+      "  s_cbranch_scc0 L_wr_longdist%=\n"
       "  v_readlane_b32 s66, v38, s67\n"
       "  s_nop 1\n"
       "  v_bfrev_b32 v48, s66\n"
@@ -1290,7 +1311,8 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  v_sub_u32 v48, v48, v61\n"
       "  v_cmp_lt_u32 vcc, v48, v62\n"
       "  v_add_u32 v48, v48, v63\n"
-      "  s_ff1_i32_b64 s66, vcc\n"
+      "  s_and_b32 s66, vcc_lo, 0xfffe\n"               // (lanes 16-31 test the distance code's lengths)
+      "  s_ff1_i32_b32 s66, s66\n"
       "  s_cmp_lt_i32 s66, 0\n"
       "  s_cbranch_scc1 L_wr_postwalk%=\n"
       "  v_readlane_b32 s71, v48, s66\n"
@@ -1309,6 +1331,65 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  s_mov_b32 s57, 1\n"
       "  v_mov_b32 v53, s54\n"
       "  s_add_u32 s65, s65, 1\n"
+      "  s_cmp_lt_u32 s53, 64\n"
+      "  s_cbranch_scc1 L_wr_walk%=\n"
+      "  s_branch L_wr_postwalk%=\n"
+      // ---- ... or at a length the tables resolve whose DISTANCE code is longer than its table (1 % of the matches of FASTQ members,
+      // the largest group of symbols that left the rounds): the same test of all candidate lengths in lanes 17-31, the symbol's
+      // base and extra bits from its number, and the walk goes on with the match's record.
+      "L_wr_longdist%=:\n"
+      "  s_bfe_u32 s71, s66, 0x80008\n"
+      "  s_cmp_eq_u32 s71, 8\n"                          // E_FAST alone
+      "  s_cbranch_scc0 L_wr_postwalk%=\n"
+      "  v_readlane_b32 s71, v41, s67\n"
+      "  s_cmp_eq_u32 s71, 0\n"                          // (long codes are 0 entries)
+      "  s_cbranch_scc0 L_wr_postwalk%=\n"
+      "  v_readlane_b32 s71, v46, s67\n"                // the bits behind the length code and its extra bits
+      "  s_nop 1\n"
+      "  v_bfrev_b32 v48, s71\n"
+      "  v_lshrrev_b32 v48, v49, v48\n"
+      "  v_sub_u32 v48, v48, v61\n"
+      "  v_cmp_lt_u32 vcc, v48, v62\n"
+      "  v_add_u32 v48, v48, v63\n"
+      "  s_lshr_b32 s58, vcc_lo, 16\n"
+      "  s_ff1_i32_b32 s58, s58\n"                       // the code's length
+      "  s_cmp_lt_i32 s58, 0\n"
+      "  s_cbranch_scc1 L_wr_postwalk%=\n"
+      "  s_add_u32 s59, s58, 16\n"
+      "  v_readlane_b32 s60, v48, s59\n"
+      "  s_lshl_b32 s60, s60, 1\n"
+      "  v_mov_b32 v48, s60\n"
+      "  ds_read_u16 v48, v48 offset:%[dsymoff]\n"
+      "  v_readlane_b32 s69, v45, s67\n"                // value of the length's extra bits
+      "  v_readlane_b32 s59, v44, s67\n"                // bits of the length code and its extra bits
+      "  s_waitcnt lgkmcnt(0)\n"
+      "  v_readfirstlane_b32 s60, v48\n"                // the distance symbol
+      "  s_cmp_gt_u32 s60, 29\n"
+      "  s_cbranch_scc1 L_wr_postwalk%=\n"
+      "  s_lshr_b32 s61, s60, 1\n"
+      "  s_sub_u32 s61, s61, 1\n"
+      "  s_max_i32 s61, s61, 0\n"                        // its extra bits
+      "  s_and_b32 s68, s60, 1\n"
+      "  s_or_b32 s68, s68, 2\n"
+      "  s_lshl_b32 s68, s68, s61\n"                     // distance - 1 of the symbol's first distance (symbols 2 ..)
+      "  s_cmp_lt_u32 s60, 2\n"
+      "  s_cselect_b32 s68, s60, s68\n"                  // (symbols 0 and 1: distances 1 and 2)
+      "  s_lshr_b32 s71, s71, s58\n"
+      "  s_bfm_b32 s60, s61, 0\n"
+      "  s_and_b32 s71, s71, s60\n"                      // value of the distance's extra bits
+      "  s_add_u32 s68, s68, s71\n"                      // distance - 1
+      "  s_lshr_b32 s66, s66, 16\n"
+      "  s_add_u32 s57, s66, s69\n"                      // length
+      "  s_add_u32 s59, s59, s58\n"
+      "  s_add_u32 s59, s59, s61\n"
+      "  s_add_u32 s53, s59, s67\n"                      // where the next symbol starts
+      "  s_lshl_b32 s68, s68, 16\n"
+      "  s_or_b32 s54, s68, s57\n"                       // the match's record
+      "  s_mov_b64 exec, s[62:63]\n"
+      "  v_cmpx_le_u32 vcc, s65, %[lane]\n"
+      "  s_add_u32 s65, s65, s57\n"
+      "  s_nop 0\n"
+      "  v_mov_b32 v53, s54\n"
       "  s_cmp_lt_u32 s53, 64\n"
       "  s_cbranch_scc1 L_wr_walk%=\n"
       "  s_branch L_wr_postwalk%=\n"
@@ -1427,7 +1508,7 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
         [ringmask] "i"(RING - 1), [nearw] "i"(RING - 258), [lutoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_lut)),
         [dlut] "i"(RING + (int)__builtin_offsetof(WaveLds, dist_lut)), [firstoff] "i"(RING + (int)__builtin_offsetof(WaveLds, first)),
         [countoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_count)), [offsoff] "i"(RING + (int)__builtin_offsetof(WaveLds, offs)),
-        [symoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_sym)), [dummy] "i"(RING + (int)__builtin_offsetof(WaveLds, dist_count))
+        [symoff] "i"(RING + (int)__builtin_offsetof(WaveLds, lit_sym)), [dsymoff] "i"(RING + (int)__builtin_offsetof(WaveLds, dist_sym)), [dummy] "i"(RING + (int)__builtin_offsetof(WaveLds, dist_count))
       : "s53", "s54", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "v33", "v34", "v35", "v36", "v37",
         "v38", "v39", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61",
         "v62", "v63", "vcc", "scc", "memory");
