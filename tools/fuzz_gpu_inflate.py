@@ -11,7 +11,18 @@ import test_gpu_inflate as T
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rnd = random.Random(13)
 ctx = exon_amd.Context(0)
-text = T.vcf_like(60000)
+kind = sys.argv[2] if len(sys.argv) > 2 else "text"
+if kind == "text":
+    text = T.vcf_like(60000)
+else:  # "mixed": runs of every period, high-entropy bytes with long codes, text -- the wide loop's rare paths (overlap fold, long
+    rng = np.random.default_rng(17)  # literal / distance codes decoded in the walk, symbols beyond a round's 64 bytes)
+    parts = []
+    for i in range(1500):
+        d, total = int(rng.integers(1, 71)), int(rng.integers(3, 601))
+        unit = rng.integers(0, 256, d, dtype=np.uint8).tobytes()
+        parts.append(rng.integers(0, 256, int(rng.integers(0, 71)), dtype=np.uint8).tobytes() + (unit * (total // d + 1))[:total])
+    skew = (rng.standard_normal(400_000) * 30 + 128).clip(0, 255).astype(np.uint8).tobytes()  # ~200 distinct bytes: codes of 4-14 bits
+    text = b"".join(parts) + skew + T.vcf_like(8000)
 good = T.bgzf_file(text)
 want = np.frombuffer(text, np.uint8)
 ok = rejected = 0
