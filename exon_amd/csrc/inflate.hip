@@ -2695,8 +2695,18 @@ __device__ __forceinline__ uint32_t x_pow_8n(uint32_t n_bytes) {  // x^(8 n) mod
   return result;
 }
 
+// Powers of x mod P the combine needs, made once on the host (crc_powers): slices are `per` = 128 m bytes (m = 1..8) long, so the
+// multiplier of lane l's CRC is x^(8 per k) x^(8 t) with k = whole slices behind it and t = the bytes of the last, partial one.
+// (Computing it per lane by square-and-multiply -- ~40 multiplications of 32 steps, divergent, and lane 0's x^(8 n) on top -- was
+// three times the table phase's vector instructions.)
+struct CrcPowers {
+  uint32_t xp[8][64];   // [m - 1][k]  = x^(8 * 128 m * k)
+  uint32_t ixp[8][64];  // 0xFFFFFFFF times that: the initial value's term
+  uint32_t xt[1025];    // [t] = x^(8 t)
+};
+
 __global__ __launch_bounds__(WAVES_PER_WG * 64) void k_crc32(const uint8_t* __restrict__ out, const Block* __restrict__ blocks, int n_blocks,
-                                                             int* __restrict__ status) {
+                                                             int* __restrict__ status, const CrcPowers* __restrict__ pw) {
   __shared__ uint32_t table[4][256];  // slicing-by-4: table[k][b] = CRC of byte b followed by k zero bytes
   for (int i = threadIdx.x; i < 256; i += blockDim.x) {
     uint32_t c = (uint32_t)i;
@@ -2760,10 +2770,20 @@ __global__ __launch_bounds__(WAVES_PER_WG * 64) void k_crc32(const uint8_t* __re
   for (; i < hi; ++i) c = table[0][(c ^ p[i]) & 0xFFu] ^ (c >> 8);
   // combine: total = sum over lanes of crc_l * x^(8 * bytes after slice l); the 0xFFFFFFFF initial value is the
   // CRC of a virtual prefix: init * x^(8 n)
-  uint32_t term = (hi > lo) ? gf2_mulmod(c, x_pow_8n(n - hi)) : 0u;
-  if (lane == 0) term ^= gf2_mulmod(0xFFFFFFFFu, x_pow_8n(n));
-  for (int o = 32; o > 0; o >>= 1) term ^= __shfl_xor(term, o, 64);
-  const uint32_t crc = term ^ 0xFFFFFFFFu;
+  uint32_t crc;
+  if (pw && per >= 128u && per <= 1024u && n > 0) {
+    // n = last * per + t: the lanes in front of the last non-empty one share the factor x^(8 t)
+    const uint32_t m1 = (per >> 7) - 1u, last = (n - 1u) / per, t = n - last * per;
+    uint32_t term = (uint32_t)lane < last ? gf2_mulmod(c, pw->xp[m1][last - 1u - (uint32_t)lane]) : 0u;
+    if (lane == 0) term ^= pw->ixp[m1][last];
+    for (int o = 32; o > 0; o >>= 1) term ^= __shfl_xor(term, o, 64);
+    crc = gf2_mulmod(term, pw->xt[t]) ^ (uint32_t)__shfl((int)c, (int)last, 64) ^ 0xFFFFFFFFu;
+  } else {
+    uint32_t term = (hi > lo) ? gf2_mulmod(c, x_pow_8n(n - hi)) : 0u;
+    if (lane == 0) term ^= gf2_mulmod(0xFFFFFFFFu, x_pow_8n(n));
+    for (int o = 32; o > 0; o >>= 1) term ^= __shfl_xor(term, o, 64);
+    crc = term ^ 0xFFFFFFFFu;
+  }
   if (lane == 0 && crc != blk.crc32) status[b] = INF_BAD_CRC;
 }
 
@@ -3098,6 +3118,46 @@ static int inflate_flavor(int hint) {
   return forced >= 0 ? forced : hint >= 0 && hint <= 3 ? hint : 3;
 }
 
+// The CRC combine's powers of x: computed once per process, one copy per device (never freed).
+namespace {
+uint32_t gf2_mulmod_host(uint32_t a, uint32_t b) {
+  uint32_t r = 0;
+  for (int i = 0; i < 32; ++i) {
+    if (a & 0x80000000u) r ^= b;
+    a <<= 1;
+    b = (b >> 1) ^ ((b & 1u) ? 0xEDB88320u : 0u);
+  }
+  return r;
+}
+const CrcPowers* crc_powers(int dev) {
+  static const CrcPowers* host = [] {
+    CrcPowers* t = new CrcPowers;
+    t->xt[0] = 0x80000000u;
+    for (int i = 1; i <= 1024; ++i) t->xt[i] = gf2_mulmod_host(t->xt[i - 1], 0x00800000u);
+    for (int m = 1; m <= 8; ++m) {
+      const uint32_t X = t->xt[128 * m];
+      t->xp[m - 1][0] = 0x80000000u;
+      for (int k = 1; k < 64; ++k) t->xp[m - 1][k] = gf2_mulmod_host(t->xp[m - 1][k - 1], X);
+      for (int k = 0; k < 64; ++k) t->ixp[m - 1][k] = gf2_mulmod_host(0xFFFFFFFFu, t->xp[m - 1][k]);
+    }
+    return t;
+  }();
+  static std::mutex mu;
+  static std::map<int, const CrcPowers*> per_dev;
+  std::lock_guard<std::mutex> g(mu);
+  auto it = per_dev.find(dev);
+  if (it != per_dev.end()) return it->second;
+  CrcPowers* d = nullptr;
+  if (hipMalloc((void**)&d, sizeof(CrcPowers)) != hipSuccess || hipMemcpy(d, host, sizeof(CrcPowers), hipMemcpyHostToDevice) != hipSuccess) {
+    if (d) hipFree(d);
+    (void)hipGetLastError();
+    d = nullptr;
+  }
+  per_dev[dev] = d;
+  return d;
+}
+}  // namespace
+
 hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const exon_hip_bgzf_block* d_blocks, int n_blocks,
                                     uint8_t* d_out, int* d_status, bool verify_crc, int flavor_hint, bool text_like) {
   if (n_blocks <= 0) return hipSuccess;
@@ -3146,9 +3206,12 @@ hipError_t exon_bgzf_inflate_launch(hipStream_t s, const uint8_t* d_comp, const 
   else if (!parallel)
     hipLaunchKernelGGL(k_inflate<INFLATE_RING_SERIAL>, dim3((n_blocks + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), pad_lds, s, d_comp, blocks, n_blocks,
                        d_out, d_status, flavor);
-  if (verify_crc)
+  if (verify_crc) {
+    int cdev = 0;
+    const CrcPowers* pw = hipGetDevice(&cdev) == hipSuccess ? crc_powers(cdev) : nullptr;  // (nullptr: the kernel computes the powers itself)
     hipLaunchKernelGGL(k_crc32, dim3((n_blocks + WAVES_PER_WG - 1) / WAVES_PER_WG), dim3(WAVES_PER_WG * 64), 0, s, d_out, blocks, n_blocks,
-                       d_status);
+                       d_status, pw);
+  }
   return hipGetLastError();
 }
 
