@@ -421,8 +421,11 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
       for (int q = 0; q < ik.n; ++q)
         if (ik.kind[q] == 'F' || ik.kind[q] == 'I') out.lv_cnt[q][row] = 0;  // summed by the offsets scan
     } else {
+#ifndef EXON_PARSE_SKIP  // (profiling builds: bit 0 CHROM, 1 POS, 2 QUAL, 3 FILTER, 4 INFO left out)
+#define EXON_PARSE_SKIP 0
+#endif
       // CHROM
-      {
+      if (!(EXON_PARSE_SKIP & 1)) {
         const uint8_t* p = text + fbeg(0);
         const int len = (int)(fend(0) - fbeg(0));
         const uint64_t h = fnv1a(p, len);
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
         out.chrom_id[row] = id < 0 ? 0 : id;
       }
       // POS
-      {
+      if (!(EXON_PARSE_SKIP & 2)) {
         int64_t v = 0;
         unsigned pb = fbeg(1), pn = fend(1) - fbeg(1);
         if (pn && text[pb] == '+') ++pb, --pn;  // usize::from_str takes one leading '+' (host/formats.h parse_pos)
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
         out.pos[row] = pos_ok ? v : 0;
       }
       // QUAL
-      {
+      if (!(EXON_PARSE_SKIP & 4)) {
         const int len = (int)(fend(5) - fbeg(5));
         float q = 0.f;
         if (!(len == 1 && text[fbeg(5)] == '.')) {
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
         out.qual[row] = q;
       }
       // FILTER: '.' -> the empty list
-      {
+      if (!(EXON_PARSE_SKIP & 8)) {
         const uint8_t* p = text + fbeg(6);
         int len = (int)(fend(6) - fbeg(6));
         if (len == 1 && p[0] == '.') len = 0;
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
         out.filter_id[row] = found;  // provisional: slot index
       }
       // INFO: `key=value` (or a bare Flag key) among ';'-separated entries; the first occurrence of a key wins
-      if (ik.n > 0) {
+      if (ik.n > 0 && !(EXON_PARSE_SKIP & 16)) {
         unsigned seen = 0;  // bit q: key q was met (the first occurrence wins); values are stored as they are parsed
         int left = ik.n;
         const unsigned ib = fbeg(7), ie = fend(7);
