@@ -1437,7 +1437,18 @@ __device__ __forceinline__ uint32_t wide_rounds_asm(const __attribute__((address
       "  s_branch L_wr_dep_cut%=\n"
       "L_wr_dep_others%=:\n"
       "  s_mov_b64 vcc, s[58:59]\n"
+      // A source that is a LITERAL of this round is no dependence at all: the copy below stores the round's literals before it reads
+      // the near sources (the usual shape in BAM payloads: fresh literals, then a match that repeats them).  Only a source that is
+      // itself a match byte of the round has to wait for it.
       "L_wr_dep_cut%=:\n"
+      "  v_cmp_gt_i32 s[60:61], 0, v53\n"                // the round's literal lanes ...
+      "  s_andn2_b64 s[60:61], exec, s[60:61]\n"         // ... and its match lanes
+      "  v_subrev_u32 v48, s46, v58\n"                   // the lane a dependent byte's source was written by
+      "  v_lshrrev_b64 v[48:49], v48, s[60:61]\n"
+      "  v_and_b32 v48, 1, v48\n"
+      "  v_cmp_ne_u32 s[60:61], 0, v48\n"
+      "  s_and_b64 vcc, vcc, s[60:61]\n"                 // dependent bytes whose source is a match byte of the round
+      "  s_cbranch_scc0 L_wr_copy%=\n"
       "  s_ff1_i32_b64 s66, vcc\n"                       // the first byte whose source lies inside the round
       "  s_mov_b64 exec, -1\n"
       "  s_sub_u32 s44, s44, s70\n"                      // back to the round's first bit (a borrow: the window has moved, the caller rewinds)
