@@ -363,6 +363,27 @@ __device__ __forceinline__ void store_valid(uint8_t* bm, int64_t row0_of_wave, i
   }
 }
 
+// bit b = byte b of the 16-byte group equals `c` (splat as c * 0x01010101).  ONE mask per group and one loop over its bits: an inner
+// loop per dword -- four divergent regions per group -- is exec-mask bookkeeping on the CU's scalar unit, which bounds k_parse_lines.
+__device__ __forceinline__ unsigned eq_mask16(const uint4& v, uint32_t splat) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  unsigned mask = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t x = w[k] ^ splat;  // equal bytes become 0
+    const uint32_t m = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);  // 0x80 exactly in the zero bytes
+    const uint32_t t = m >> 7;                                                 // bits 0, 8, 16, 24
+    mask |= ((t | (t >> 7) | (t >> 14) | (t >> 21)) & 0xFu) << (4 * k);
+  }
+  return mask;
+}
+// ... restricted to the bytes [begin, end) of the slab, the group starting at byte a
+__device__ __forceinline__ unsigned clip_mask16(unsigned mask, unsigned a, unsigned begin, unsigned end) {
+  if (begin > a) mask &= 0xFFFFu << (begin - a);
+  if (end - a < 16u) mask &= (1u << (end - a)) - 1u;
+  return mask;
+}
+
 __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__ text, const unsigned* __restrict__ nl_pos,
                                                      const unsigned* __restrict__ n_lines_p, NameTable contigs,
                                                      FilterTable filters, InfoKeys ik, ParseOut out, unsigned cap, unsigned skip,
@@ -394,17 +415,10 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
     // tabs, 16 bytes per load (aligned groups; `text` is 16-byte aligned and padded): the byte-at-a-time version of this
     // loop was a chain of ~35 dependent loads per line, a quarter of the kernel's memory waits
     for (unsigned a = begin & ~15u; a < end && nf < 8; a += 16) {
-      const uint4 v = group16(a);
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t x = w[k] ^ 0x09090909u;  // bytes equal to '\t' become 0
-        uint32_t m = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);  // 0x80 exactly in the zero bytes
-        while (m && nf < 8) {
-          const unsigned idx = a + 4u * (unsigned)k + ((unsigned)__ffs((int)m) - 1u) / 8u;
-          if (idx >= begin && idx < end) fs[++nf] = idx + 1;
-          m &= m - 1;
-        }
+      unsigned m = clip_mask16(eq_mask16(group16(a), 0x09090909u), a, begin, end);  // the group's tabs
+      while (m && nf < 8) {
+        fs[++nf] = a + (unsigned)__ffs((int)m);  // the field starts behind the tab
+        m &= m - 1;
       }
     }
     // field f spans [fs[f], fs[f+1] - 1) for f < nf, the last one ends at `end` (INFO may be followed by FORMAT...)
@@ -455,10 +469,10 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
         if (pn <= 16 && pb + 16u <= n_total) {  // the digits from two (unaligned) 8-byte loads instead of a chain of byte loads
           uint64_t w[2];
           __builtin_memcpy(w, text + pb, 16);
-          for (unsigned k = 0; k < pn && ok; ++k) {
-            const unsigned c = (unsigned)(w[k >> 3] >> (8 * (k & 7))) & 0xFFu;
-            if (c < '0' || c > '9') ok = false;
-            else v = v * 10 + (c - '0');
+          for (unsigned k = 0; k < pn; ++k) {  // (no branch inside: a non-digit spoils v, which is then not used)
+            const unsigned d = ((unsigned)(w[k >> 3] >> (8 * (k & 7))) & 0xFFu) - (unsigned)'0';
+            ok &= d <= 9u;
+            v = v * 10 + d;
           }
         } else {
           for (unsigned i = pb; i < pb + pn && ok; ++i) {
@@ -581,17 +595,10 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
             i = j + 1;
           };
           for (unsigned a = ib & ~15u; a < ie && left > 0; a += 16) {
-            const uint4 q = group16(a);
-            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const uint32_t x = w[k] ^ 0x3B3B3B3Bu;  // bytes equal to ';' become 0
-              uint32_t m = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
-              while (m && left > 0) {
-                const unsigned idx = a + 4u * (unsigned)k + ((unsigned)__ffs((int)m) - 1u) / 8u;
-                if (idx >= ib && idx < ie) entry(idx);
-                m &= m - 1;
-              }
+            unsigned m = clip_mask16(eq_mask16(group16(a), 0x3B3B3B3Bu), a, ib, ie);  // the group's ';'
+            while (m && left > 0) {
+              entry(a + (unsigned)__ffs((int)m) - 1u);
+              m &= m - 1;
             }
           }
           if (left > 0 && i < ie) entry(ie);  // the last entry has no ';' behind it

@@ -200,27 +200,35 @@ EXON_HD int parse_f32(const char* p, int n, uint32_t* bits) {
   int i = 0;
   uint32_t sign = 0;
   if (i < n && (p[i] == '-' || p[i] == '+')) sign = (p[i++] == '-') ? 0x80000000u : 0u;
+  // (one exit per digit and nothing else to branch on: leading zeros leave w at 0 by themselves, a digit is significant from the
+  //  first one that is not '0' on, and "more than 19" is asked once at the end -- on the GPU every `if` inside a loop that lanes leave at different
+  //  times is exec-mask bookkeeping on the CU's one scalar unit, which is what bounds k_parse_lines)
   uint64_t w = 0;
+  unsigned nz = 0;  // not 0 from the first digit that is not '0' on
   int digits = 0, q = 0;
-  bool seen = false;
-  for (; i < n && p[i] >= '0' && p[i] <= '9'; ++i) {
-    seen = true;
-    if (w || p[i] != '0') {
-      if (++digits > 19) return 0;
-      w = w * 10 + (uint64_t)(p[i] - '0');
-    }
+  const int i0 = i;
+  for (; i < n; ++i) {
+    const unsigned d = (unsigned)(unsigned char)p[i] - (unsigned)'0';
+    if (d > 9u) break;
+    w = w * 10 + d;
+    nz |= d;
+    digits += nz != 0;
   }
+  int nd = i - i0;  // digits met, significant or not
   if (i < n && p[i] == '.') {
-    for (++i; i < n && p[i] >= '0' && p[i] <= '9'; ++i) {
-      seen = true;
-      --q;
-      if (w || p[i] != '0') {
-        if (++digits > 19) return 0;
-        w = w * 10 + (uint64_t)(p[i] - '0');
-      }
+    const int f0 = ++i;
+    for (; i < n; ++i) {
+      const unsigned d = (unsigned)(unsigned char)p[i] - (unsigned)'0';
+      if (d > 9u) break;
+      w = w * 10 + d;
+      nz |= d;
+      digits += nz != 0;
     }
+    q = f0 - i;
+    nd += i - f0;
   }
-  if (!seen) return 0;
+  if (nd == 0) return 0;
+  if (digits > 19) return 0;  // (w has wrapped by then: not used)
   if (i < n && (p[i] == 'e' || p[i] == 'E')) {
     ++i;
     bool eneg = false;
