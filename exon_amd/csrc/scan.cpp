@@ -1,4 +1,6 @@
 // scan.cpp -- C ABI of the native decoders (host/formats.h): exon_hip_scan_*.
+#include <pthread.h>
+#include <sched.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -390,10 +392,64 @@ int exon_hip_scan_close(exon_hip_scan* s) {
 
 }  // extern "C"
 
+// The file pipelines' host threads (the reader and its read pool) run on the CPUs of the GPU's NUMA node: they copy the file out of
+// the page cache into the pinned staging ring the DMA engine reads a moment later, and on a two-socket host the same scan takes
+// 90 ms with them on the GPU's socket and 115-126 ms on the other one -- left to the scheduler it was one or the other from run to
+// run (profiles/r5_reader_numa.log).  The caller's own thread is not touched.  EXON_HIP_READER_AFFINITY=0 turns it off.
+static const cpu_set_t* gpu_local_cpus(int device) {
+  static std::mutex mu;
+  static std::map<int, cpu_set_t*> cache;  // nullptr: unknown / not applicable
+  std::lock_guard<std::mutex> g(mu);
+  auto it = cache.find(device);
+  if (it != cache.end()) return it->second;
+  cpu_set_t* set = nullptr;
+  const char* sw = getenv("EXON_HIP_READER_AFFINITY");
+  char bdf[64] = {0};
+  if (!(sw && sw[0] == '0') && hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) == hipSuccess) {
+    for (char* c = bdf; *c; ++c)
+      if (*c >= 'A' && *c <= 'Z') *c = (char)(*c - 'A' + 'a');
+    int node = -1;
+    if (FILE* f = fopen((std::string("/sys/bus/pci/devices/") + bdf + "/numa_node").c_str(), "r")) {
+      if (fscanf(f, "%d", &node) != 1) node = -1;
+      fclose(f);
+    }
+    char list[4096] = {0};
+    if (node >= 0)
+      if (FILE* f = fopen(("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r")) {
+        if (!fgets(list, (int)sizeof list, f)) list[0] = 0;
+        fclose(f);
+      }
+    cpu_set_t allowed, local;
+    CPU_ZERO(&local);
+    for (const char* q = list; *q && *q != '\n';) {  // "0-63,128-191"
+      char* e = nullptr;
+      const long a = strtol(q, &e, 10);
+      if (e == q) break;
+      long b = a;
+      if (*e == '-') b = strtol(e + 1, &e, 10);
+      for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+        if (c >= 0) CPU_SET((int)c, &local);
+      if (*e != ',') break;
+      q = e + 1;
+    }
+    if (sched_getaffinity(0, sizeof allowed, &allowed) == 0) {
+      cpu_set_t both;
+      CPU_AND(&both, &allowed, &local);
+      if (CPU_COUNT(&both) >= 4 && CPU_COUNT(&both) < CPU_COUNT(&allowed)) set = new cpu_set_t(both);  // (a one-node host: nothing to choose)
+    }
+  }
+  cache[device] = set;
+  return set;
+}
+static void run_on(const cpu_set_t* cpus) {
+  if (cpus) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), cpus);
+}
+
 // plain files are read with positional reads from several threads (one fread stream tops out near 6 GB/s);
 // compressed inputs go through the (block-parallel) inflating source
 struct SlabReader {
   explicit SlabReader(exon::ByteSource* s) : src(s) { plain = src->plain_file(&fd, &foff); }
+  const cpu_set_t* cpus = nullptr;  // where the pool's threads run (set before the first read)
   ~SlabReader() {
     {
       std::lock_guard<std::mutex> g(mu_);
@@ -469,6 +525,7 @@ struct SlabReader {
     size_t len, got;
   };
   void run(int t) {
+    run_on(cpus);
     uint64_t seen = 0;
     for (;;) {
       Job j;
@@ -629,6 +686,8 @@ class GpuTextSource {
         trim_last_(trim_last), carry_(std::move(carry)) {
     slab_ = slab_bytes();
     ring_geometry();
+    local_cpus_ = gpu_local_cpus(ctx_->device);
+    rd_.cpus = local_cpus_;
     if (bgzf_) {
       // One wavefront inflates one block and a block takes ~3.5 ms however many run beside it, so a launch wants as many
       // blocks as the chip holds wavefronts of this kernel (24 per CU x 256 CUs) and not one more: slabs are cut by BLOCK
@@ -791,7 +850,7 @@ class GpuTextSource {
       if (trace)
         fprintf(stderr, "[exon-hip pipe] init: pinned allocations %.1f ms (%zu MB), device allocations %.1f ms, tables %.1f ms, streams+events %.1f ms, first fill %.1f ms, first inflate enqueue %.1f ms\n",
                 t_host * 1e3, (2 * hcap_ + (size_t)RING_N * (RING_HEAD + RING_PIECE)) >> 20, t_dev * 1e3, (ti1 - ti0 - t_host - t_dev) * 1e3, (ti2 - ti1) * 1e3, (ti3 - ti2) * 1e3, (now_s() - ti3) * 1e3);
-      if (!f_[0].eof) reader_ = std::thread([this] { fill(1, &f_[1]); });
+      if (!f_[0].eof) reader_ = std::thread([this] { run_on(local_cpus_); fill(1, &f_[1]); });
       return EXON_HIP_OK;
     }
     if (carry_.size() > gap_) return 1;  // the host reader had buffered more than the gap holds: host decoder
@@ -832,7 +891,7 @@ class GpuTextSource {
       free_rec_[k ^ 1] = true;
     }
     started_prev_ = true;
-    if (more) reader_ = std::thread([this, k] { fill(k ^ 1, &nxt_); });  // overlaps with everything the GPU does below
+    if (more) reader_ = std::thread([this, k] { run_on(local_cpus_); fill(k ^ 1, &nxt_); });  // overlaps with everything the GPU does below
     if (!more && n_text > 0) {  // last line without a terminator (a carried tail never ends in one)
       // the slab's last byte is on the host unless the slab is a carried tail only (cur_.n and front_extra both 0)
       const bool ends_nl = (cur_.n > 0 || cur_.front_extra > 0) && cur_.last_byte == '\n';
@@ -945,7 +1004,7 @@ class GpuTextSource {
       if (rc) return rc;
       if (!f_[k ^ 1].eof) {
         t_spawn_at_ = now_s();
-        reader_ = std::thread([this, k] { fill(k, &f_[k]); });
+        reader_ = std::thread([this, k] { run_on(local_cpus_); fill(k, &f_[k]); });
       }
     }
     if (!more && n_text > 0 && !binary_) {  // last line without a terminator
@@ -1253,6 +1312,7 @@ class GpuTextSource {
   hipEvent_t ev_h2d_[2] = {nullptr, nullptr}, ev_done_[2] = {nullptr, nullptr}, ev_free_[2] = {nullptr, nullptr};
   bool enq_[2] = {false, false}, free_rec_[2] = {false, false};
   std::thread reader_;
+  const cpu_set_t* local_cpus_ = nullptr;
   int k_ = 0;
   bool started_ = false, started_prev_ = false;
   size_t cur_front_ = 0, cur_text_ = 0;

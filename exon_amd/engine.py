@@ -682,6 +682,10 @@ class Stream:
         top.array.children = C.cast(kids, C.POINTER(C.POINTER(L.ArrowArray)))
         top.device_id = self.ctx.device
         top.device_type = L.ARROW_DEVICE_ROCM
+        # no sync_event travels with the batch, which by the Arrow C Device interface means "the data is ready": whatever this
+        # harness queued on the context's stream to produce the columns (gen_c4 ...) has to be finished first (the plan runs on
+        # its own stream; found by a test that only failed beside three other workers on the same GPU)
+        self.ctx.sync()
         self.ctx._check(self.ctx.lib.exon_hip_stream_push_device(self.h, C.byref(top)))
         self._keep = keep + [kids, tb, top]
 
