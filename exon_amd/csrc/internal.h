@@ -48,6 +48,8 @@ const char* exon_bgzf_status_name(int code);
 
 // scan.cpp: slab buffers kept per ctx between scans
 void exon_hip_release_ctx_caches(exon_hip_ctx* ctx);
+const void* exon_hip_gpu_local_cpus(int device);  // scan.cpp: a cpu_set_t of the GPU's NUMA node (nullptr: nothing to choose), and ...
+void exon_hip_run_on(const void* cpus);            // ... the calling thread's affinity set to it (host threads that feed the DMA engine)
 void exon_hip_prewarm_ctx(exon_hip_ctx* ctx);  // scan.cpp: the file pipelines' side streams and events, made with the context
 
 // capi.cpp: size-keyed recycling of device buffers (released by exon_hip_ctx_destroy)

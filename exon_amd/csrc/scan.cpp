@@ -396,6 +396,11 @@ int exon_hip_scan_close(exon_hip_scan* s) {
 // the page cache into the pinned staging ring the DMA engine reads a moment later, and on a two-socket host the same scan takes
 // 90 ms with them on the GPU's socket and 115-126 ms on the other one -- left to the scheduler it was one or the other from run to
 // run (profiles/r5_reader_numa.log).  The caller's own thread is not touched.  EXON_HIP_READER_AFFINITY=0 turns it off.
+static const cpu_set_t* gpu_local_cpus(int device);
+const void* exon_hip_gpu_local_cpus(int device) { return gpu_local_cpus(device); }
+void exon_hip_run_on(const void* cpus) {
+  if (cpus) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), static_cast<const cpu_set_t*>(cpus));
+}
 static const cpu_set_t* gpu_local_cpus(int device) {
   static std::mutex mu;
   static std::map<int, cpu_set_t*> cache;  // nullptr: unknown / not applicable

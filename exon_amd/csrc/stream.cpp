@@ -239,7 +239,15 @@ class CopyPool {
     if (const char* v = getenv("EXON_HIP_STAGE_THREADS")) t = atoi(v);
     const int hc = (int)std::thread::hardware_concurrency();
     if (hc > 0) t = std::min(t, std::max(1, hc / 2));
-    for (int i = 1; i < t; ++i) threads_.emplace_back([this] { run(); });
+    // (the pool's threads copy host batches into the pinned staging blocks the DMA engine reads next: they run on the GPU's NUMA
+    //  node like the file pipelines' reader, scan.cpp; one process drives one GPU, so the device current at first use decides)
+    int dev = 0;
+    const void* cpus = hipGetDevice(&dev) == hipSuccess ? exon_hip_gpu_local_cpus(dev) : nullptr;
+    for (int i = 1; i < t; ++i)
+      threads_.emplace_back([this, cpus] {
+        exon_hip_run_on(cpus);
+        run();
+      });
   }
   ~CopyPool() {
     {
