@@ -8,7 +8,7 @@
 // (<= 64 KiB of text each), so a slab of compressed blocks crosses PCIe as it is (3-5x fewer bytes than text) and
 // is inflated by one wavefront per block.
 //
-// One wavefront per block (k_inflate_w / k_inflate, one wavefront per workgroup, 4864 B of static LDS, 64 VGPRs, <= 79 SGPRs -> 32
+// One wavefront per block (k_inflate_w / k_inflate, one wavefront per workgroup, 4928 B of static LDS, 64 VGPRs, <= 79 SGPRs -> 32
 // members per CU):
 //   * Huffman tables live in LDS: a 9-bit (literal/length) and an 8-bit (distance) first-level table whose entries are complete
 //     decode results (literal byte / length or distance base + extra-bit count + code length), built lane-parallel from the code
@@ -17,11 +17,13 @@
 //     read the output already drained to HBM; the ring is drained in aligned 256-byte rows, one dword per lane;
 //   * the symbol loop (round 5, default): wide_run -- 64 lanes decode the symbols that would start at 64 consecutive BIT offsets,
 //     the true chain is followed with one v_readlane per symbol and the round's output (<= 64 bytes) is produced in one step;
-//     its ordinary rounds are hand-written (wide_rounds_asm).  Rounds 1-4's loops -- one symbol per step on the scalar unit
+//     its ordinary rounds are hand-written (wide_rounds_asm), and so are the common rare ones: literal and distance codes longer than
+//     the tables are decoded inside the walk, a match that overlaps its own output takes its sources whole periods back, a round
+//     ends in front of a symbol that starts beyond its 64 bytes.  Rounds 1-4's loops -- one symbol per step on the scalar unit
 //     (symbol_run), on the vector unit with software pipelining (symbol_run_v) -- stay selectable (EXON_HIP_INFLATE_FLAVOR=0|1|2)
 //     and serve the lane-parallel kernel's hand-backs.  Tuning logs: profiles/r1_tuning.md ... DESIGN.md section 7e.
 // Every block reports a status; any failure makes the caller inflate on the host instead.  The CRC-32 of every
-// inflated block is checked by a second kernel (k_crc32: 64 slices per block, combined in GF(2)[x] mod P).
+// inflated block is checked by a second kernel (k_crc32: 64 slices per block, combined in GF(2)[x] mod P with powers of x from a table).
 #include <hip/hip_runtime.h>
 #include <map>
 #include <mutex>
