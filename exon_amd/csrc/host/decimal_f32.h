@@ -244,6 +244,17 @@ EXON_HD int parse_f32(const char* p, int n, uint32_t* bits) {
     *bits = sign;
     return 1;
   }
+  // Clinger's exact case first: a significand below 2^24 and a power of ten up to 10^10 are both binary32 values, so ONE correctly
+  // rounded division (IEEE; hipcc's default for fp32 too) is the correctly rounded result -- what QUAL and most INFO numbers are
+  // (381.1, 0.0123), at a tenth of the instructions of the general path below.
+  if (w < (1ull << 24) && q <= 0 && q >= -10) {
+    const float p10[11] = {1.f, 10.f, 100.f, 1e3f, 1e4f, 1e5f, 1e6f, 1e7f, 1e8f, 1e9f, 1e10f};
+    const float r = (float)(uint32_t)w / p10[-q];
+    uint32_t rb;
+    __builtin_memcpy(&rb, &r, 4);
+    *bits = sign | rb;
+    return 1;
+  }
   *bits = sign | eisel_lemire_f32(w, q < -100000 ? -100000 : (q > 100000 ? 100000 : q));
   return 1;
 }

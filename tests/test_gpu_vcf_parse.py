@@ -146,6 +146,37 @@ def test_gpu_parse_pos_takes_one_leading_plus(ctx):
     p.close()
 
 
+def test_gpu_decimal_to_f32_is_the_nearest_value_bit_for_bit(ctx):
+    """QUAL and a Float INFO value over every shape of plain decimal: short significands with up to ten fraction digits (one exact
+    IEEE division on the device: Clinger's case), long ones (Eisel-Lemire), leading zeros, integers, values around 2^24.  The bits
+    must be those of the correctly rounded binary32 -- glibc's strtof -- which is what Rust's f32::from_str (noodles' QUAL and INFO
+    Float) gives."""
+    rng = np.random.default_rng(11)
+    vals = ["0", "0.0", "1", "16777215", "16777216", "16777217", "0.1", "0.0000000001", "123.4567", "9999999", "0.9999999", "381.1",
+            "0.000684898929", "33554433", "1.0000001", "0.30000001192092896", "8388607.5", "0.0000001234567", "7.000000", "000012.50"]
+    for _ in range(20000):
+        nd = int(rng.integers(1, 13))
+        digits = "".join(str(int(d)) for d in rng.integers(0, 10, nd))
+        k = int(rng.integers(0, nd + 1))
+        vals.append((digits[:k] or "0") + "." + (digits[k:] or "0") if rng.random() < 0.8 else digits)
+        if rng.random() < 0.2:
+            vals[-1] = "0." + "0" * int(rng.integers(0, 9)) + digits
+    text = "".join(f"1\t{i + 1}\t.\tA\tC\t{v}\tPASS\tAF={vals[-1 - i]}\n" for i, v in enumerate(vals)).encode()
+    p = exon_amd.VCFParser(ctx, ["1"], info_field="AF", max_slab_bytes=len(text) + 4096)
+    res = p.parse_host(text)
+    n = len(vals)
+    assert res["n_rows"] == n and res["n_undecided"] == 0
+    import ctypes
+    libc = ctypes.CDLL(None)  # glibc's strtof rounds the decimal to binary32 directly (numpy's float32(str) goes through a double)
+    libc.strtof.restype = ctypes.c_float
+    libc.strtof.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+    want_q = np.array([libc.strtof(v.encode(), None) for v in vals], np.float32)
+    want_i = want_q[::-1]
+    assert np.array_equal(res["qual"].view(np.uint32), want_q.view(np.uint32))
+    assert np.array_equal(res["info"].view(np.uint32), want_i.view(np.uint32))
+    p.close()
+
+
 def _k4_through_scan(ctx, path, gpu_parse, info_field="AF", fallback=False, thr=0.01):
     scan = exon_amd.Scan(path, "vcf", info_field=info_field, gpu_parse=gpu_parse)
     plan = ctx.plan_cmp_avg_by_group(">", thr, 64, columns=(4, 2, 3))
