@@ -70,32 +70,44 @@ __global__ __launch_bounds__(256) void k_bam_extract(const uint8_t* __restrict__
   if (scalars[1] != 0) return;  // the segmentation was not proven: nothing here can be trusted
   const uint32_t cnt = seg[s].count, row0 = base[s];
   const uint32_t* offs = rec_off + (size_t)s * SEG_CAP;
+  // validity bits: ONE atomicOr per 32-row word and wave (a wave's 64 consecutive rows touch at most three words; words at segment
+  // seams are shared with the neighbouring workgroup) instead of one per row and column -- three global atomics per record were
+  // most of this kernel's time
+  const uint32_t lane = threadIdx.x & 63u;
+  auto publish = [&](uint32_t* bitmap, bool bit, uint32_t wave_row) {
+    const unsigned long long b = __ballot(bit);
+    if (b == 0) return;
+    const uint32_t sh = wave_row & 31u;
+    const unsigned long long x = b << sh;
+    const uint32_t part = lane == 0 ? (uint32_t)x : lane == 1 ? (uint32_t)(x >> 32) : (sh ? (uint32_t)(b >> (64u - sh)) : 0u);
+    if (lane < 3 && part) atomicOr(&bitmap[(wave_row >> 5) + lane], part);
+  };
   for (uint32_t k = threadIdx.x; k < cnt; k += 256) {
     const uint32_t r = offs[k], row = row0 + k;
     const uint32_t bs = ld32(d + r);
     const int32_t ref = (int32_t)ld32(d + r + 4), pos = (int32_t)ld32(d + r + 8);
     const uint32_t l_name = d[r + 12], mapq = d[r + 13], n_cigar = ld16(d + r + 16), flag = ld16(d + r + 18);
     const uint32_t co = 32 + l_name;
-    if (co + 4 * n_cigar > bs) {  // "corrupt BAM cigar" on the host
-      atomicAdd(&scalars[1], 1u);
-      continue;
-    }
+    const bool ok = co + 4 * n_cigar <= bs;  // else "corrupt BAM cigar" on the host
+    if (!ok) atomicAdd(&scalars[1], 1u);
     int64_t ref_len = 0;
-    for (uint32_t c = 0; c < n_cigar; ++c) {
+    for (uint32_t c = 0; ok && c < n_cigar; ++c) {
       const uint32_t op = ld32(d + r + 4 + co + 4 * c);
       const uint32_t code = op & 0xF;
       if (code == 0 || code == 2 || code == 3 || code == 7 || code == 8) ref_len += op >> 4;
     }
-    o.flag[row] = (int32_t)flag;
-    o.mapq[row] = (uint8_t)mapq;
-    o.ref_id[row] = ref < 0 ? -1 : ref;
     const bool pv = pos >= 0;
-    o.start[row] = pv ? (int64_t)pos + 1 : 0;
-    o.end[row] = pv ? (int64_t)pos + ref_len : 0;
-    const uint32_t bit = 1u << (row & 31);
-    if (mapq != 255) atomicOr(&o.mapq_valid[row >> 5], bit);
-    if (ref >= 0) atomicOr(&o.ref_valid[row >> 5], bit);
-    if (pv) atomicOr(&o.pos_valid[row >> 5], bit);
+    if (ok) {
+      o.flag[row] = (int32_t)flag;
+      o.mapq[row] = (uint8_t)mapq;
+      o.ref_id[row] = ref < 0 ? -1 : ref;
+      o.start[row] = pv ? (int64_t)pos + 1 : 0;
+      o.end[row] = pv ? (int64_t)pos + ref_len : 0;
+    }
+    const uint32_t wave_row = row - lane;  // the row of the wave's lane 0 (rows are consecutive across a wave's lanes)
+    publish(o.mapq_valid, ok && mapq != 255, wave_row);
+    publish(o.ref_valid, ok && ref >= 0, wave_row);
+    publish(o.pos_valid, ok && pv, wave_row);
   }
 }
 
