@@ -126,8 +126,21 @@ __global__ __launch_bounds__(256) void k_bcf_extract(const uint8_t* __restrict__
   if (scalars[1] != 0) return;  // the segmentation was not proven: nothing here can be trusted
   const uint32_t cnt = seg[s].count, row0 = base[s];
   const uint32_t* offs = rec_off + (size_t)s * SEG_CAP;
+  // validity bits: one atomicOr per 32-row word and wave (a wave's 64 consecutive rows touch at most three words, words at segment
+  // seams are shared with the neighbouring workgroup) instead of one per row and column (bam_parse.hip: 3.3 x on that kernel)
+  const uint32_t lane = threadIdx.x & 63u;
+  auto publish = [&](uint32_t* bitmap, bool bit, uint32_t wave_row) {
+    const unsigned long long b = __ballot(bit);
+    if (b == 0) return;
+    const uint32_t sh = wave_row & 31u;
+    const unsigned long long x = b << sh;
+    const uint32_t part = lane == 0 ? (uint32_t)x : lane == 1 ? (uint32_t)(x >> 32) : (sh ? (uint32_t)(b >> (64u - sh)) : 0u);
+    if (lane < 3 && part) atomicOr(&bitmap[(wave_row >> 5) + lane], part);
+  };
   for (uint32_t k = threadIdx.x; k < cnt; k += 256) {
     const uint32_t r = offs[k], row = row0 + k;
+    const uint32_t wave_row = row - lane;  // the row of the wave's lane 0 (rows are consecutive across a wave's lanes)
+    bool row_ok = false;                   // the record was decided: its validity bits count
     const uint32_t ls = ld32(d + r);
     const int32_t chrom = (int32_t)ld32(d + r + 8), pos0 = (int32_t)ld32(d + r + 12);
     const uint32_t qbits = ld32(d + r + 20), nia = ld32(d + r + 24);
@@ -228,8 +241,8 @@ __global__ __launch_bounds__(256) void k_bcf_extract(const uint8_t* __restrict__
     }
     if (c.bad || undecided) {
       atomicAdd(&scalars[1], 1u);
-      continue;
-    }
+    } else {
+    row_ok = true;
     // intern the FILTER list
     h |= 1ull;
     int slot = (int)(h & (unsigned long long)(FSLOTS - 1)), probes = 0;
@@ -253,14 +266,15 @@ __global__ __launch_bounds__(256) void k_bcf_extract(const uint8_t* __restrict__
     out.pos[row] = pos0 >= 0 ? (int64_t)pos0 + 1 : 0;
     out.qual[row] = qbits == 0x7F800001u ? 0.f : __uint_as_float(qbits);
     out.filter_id[row] = slot;
-    const uint32_t bit = 1u << (row & 31);
-    if (qbits != 0x7F800001u) atomicOr(&out.qual_valid[row >> 5], bit);
-    if (pos0 >= 0) atomicOr(&out.pos_valid[row >> 5], bit);
     for (int w = 0; w < ik.n; ++w) {
-      if (have >> w & 1u) atomicOr(&out.info_valid[w][row >> 5], bit);
-      else if (ik.kind[w] == 'F' || ik.kind[w] == 'I') out.lv_cnt[w][row] = 0;  // NULL list: no items (summed by the offsets scan)
+      if (have >> w & 1u) continue;
+      if (ik.kind[w] == 'F' || ik.kind[w] == 'I') out.lv_cnt[w][row] = 0;  // NULL list: no items (summed by the offsets scan)
       else if (ik.kind[w] != 'b') out.info[w][row] = 0.f;  // NULL slots hold a defined value
     }
+    }  // decided record
+    publish(out.qual_valid, row_ok && qbits != 0x7F800001u, wave_row);
+    publish(out.pos_valid, row_ok && pos0 >= 0, wave_row);
+    for (int w = 0; w < ik.n; ++w) publish(out.info_valid[w], row_ok && (have >> w & 1u) != 0, wave_row);
   }
 }
 
