@@ -564,10 +564,14 @@ struct SlabReader {
   size_t pend_n_ = 0;
 };
 
-static size_t slab_bytes() {
-  // 80 MB = 7680 BGZF members per slab: 30 of the 32 members a CU holds of the inflate kernel (64 VGPRs, 78 SGPRs, 4864 B of LDS),
-  // the rest of the wave slots left to the parse kernels of the previous slab (profiles/r4_pipes_ring1k_slab.log, r4_pipes_32_waves.log)
-  size_t slab = 80u << 20;
+static size_t slab_bytes(bool bgzf_parsed_apart) {
+  // BGZF slabs are cut by member count, 96 per MB: 80 MB = 7680 members = 30 of the 32 a CU holds of the inflate kernel (64 VGPRs,
+  // 78 SGPRs, 4928 B of LDS); 64 MB = 6144 = 24 per CU, which leaves a quarter of the wave slots to the parse kernels of the
+  // previous slab.  Inputs whose records are split and parsed by kernels of their own (VCF, BAM, BCF, SAM) take 64 since the end of
+  // round 5 -- with the inflate twice as fast as in round 4 those kernels are a quarter of a slab's work, and waiting for slots they
+  // set the period: .vcf.gz 36.4 -> 34.5 ms, BAM 39.2 -> 36.7, same box, three passes each -- FASTQ, whose histogram reads the text in
+  // place and whose scans are as much reader- as kernel-bound, keeps 80 (90.4 against 91.3-100.9 ms): profiles/r5_slab_size.log.
+  size_t slab = (size_t)(bgzf_parsed_apart ? 64 : 80) << 20;
   if (const char* v = getenv("EXON_HIP_GPU_PARSE_SLAB_MB")) {
     const long mb = atol(v);
     if (mb >= 1 && mb <= 1024) slab = (size_t)mb << 20;
@@ -689,7 +693,7 @@ class GpuTextSource {
                 std::string carry, bool binary = false, bool text_async = false, size_t trim_last = 0)
       : ctx_(ctx), hs_(hs), src_(std::move(src)), rd_(src_.get()), bgzf_(bgzf), binary_(binary), text_async_(text_async), skip_(skip_first),
         trim_last_(trim_last), carry_(std::move(carry)) {
-    slab_ = slab_bytes();
+    slab_ = slab_bytes(bgzf_ && !text_async_);
     ring_geometry();
     local_cpus_ = gpu_local_cpus(ctx_->device);
     rd_.cpus = local_cpus_;
