@@ -115,6 +115,21 @@ static bool wants_gpu_inflate(const exon_hip_scan_options* o, const char* path) 
   return o->gpu_parse != 0 && gpu_inflate_enabled() && o->compression != EXON_HIP_COMPRESSION_NONE && exon::BgzfParallelSource::is_bgzf(path);
 }
 
+// File-level codecs the reference's openers accept through `file_compression_type.convert_stream`
+// (exon-core/src/datasources/fastq/file_opener.rs:93-105) that this library does not read: zstd, bzip2, xz.  Told apart
+// by their magic numbers (none of the formats' own first bytes -- '#', '@', '>', "CRAM", the gzip magic -- collide).
+static const char* unsupported_codec(const char* path) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return nullptr;  // the reader reports the missing file
+  unsigned char m[6] = {0, 0, 0, 0, 0, 0};
+  const size_t got = fread(m, 1, 6, f);
+  fclose(f);
+  if (got >= 4 && m[0] == 0x28 && m[1] == 0xB5 && m[2] == 0x2F && m[3] == 0xFD) return "zstd";
+  if (got >= 4 && m[0] == 'B' && m[1] == 'Z' && m[2] == 'h' && m[3] >= '1' && m[3] <= '9') return "bzip2";
+  if (got >= 6 && m[0] == 0xFD && m[1] == '7' && m[2] == 'z' && m[3] == 'X' && m[4] == 'Z' && m[5] == 0) return "xz";
+  return nullptr;
+}
+
 static exon::Dictionary* dict_of(exon_hip_scan* s, int col) {
   if (s->format == EXON_HIP_FORMAT_BCF && col == 0) return &s->bcf->chrom_dict;
   if (s->format == EXON_HIP_FORMAT_BCF && col == 3) return s->bcf_parser ? &s->gpu_filter_dict : &s->bcf->filter_dict;
@@ -134,6 +149,9 @@ extern "C" {
 int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hip_scan** out) {
   if (!path || !o || !out) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_scan_open: NULL argument");
   *out = nullptr;
+  if (o->compression != EXON_HIP_COMPRESSION_NONE)
+    if (const char* codec = unsupported_codec(path))
+      return fail(nullptr, EXON_HIP_EUNSUPPORTED, "%s: %s-compressed input (only uncompressed, gzip and BGZF files are read; decompress or re-compress with bgzip)", path, codec);
   try {
     std::unique_ptr<exon_hip_scan> s(new exon_hip_scan());
     s->format = o->format;

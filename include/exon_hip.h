@@ -408,6 +408,8 @@ int exon_hip_stream_close(exon_hip_stream* s);
 #define EXON_HIP_COMPRESSION_AUTO 0 /* sniff the gzip/BGZF magic */
 #define EXON_HIP_COMPRESSION_NONE 1
 #define EXON_HIP_COMPRESSION_GZIP 2
+/* zstd / bzip2 / xz inputs (file_compression_type.convert_stream of the reference's openers) are recognised by their magic
+ * numbers and refused by exon_hip_scan_open with EXON_HIP_EUNSUPPORTED and a text naming the codec. */
 
 typedef struct exon_hip_scan exon_hip_scan;
 typedef struct exon_hip_scan_options {
@@ -422,9 +424,10 @@ typedef struct exon_hip_scan_options {
                              INFO '.' makes all of them NULL (the struct itself is NULL in the reference) */
   const char* region;     /* pushed-down vcf_region_filter / bam_region_filter ("chr1:1-100"), NULL = none */
   int32_t use_index;      /* with `region`: plan BGZF chunks from <path>.tbi / <path>.bai (INDEXED_VCF / INDEXED_BAM) */
-  int32_t gpu_parse;      /* VCF, FASTQ, BAM: exon_hip_stream_consume_scan ships the file's bytes to HBM and decodes them
-                             on the GPU (exon_hip_bgzf_inflate, exon_hip_vcf_parser_* / exon_hip_fastq_parser_* /
-                             exon_hip_bam_parser_*); exon_hip_scan_next is then not available on this scan */
+  int32_t gpu_parse;      /* VCF, BCF, FASTQ, BAM, SAM: exon_hip_stream_consume_scan ships the file's bytes to HBM and decodes
+                             them on the GPU (exon_hip_bgzf_inflate, exon_hip_vcf_parser_* / exon_hip_fastq_parser_* /
+                             exon_hip_bam_parser_* ...).  exon_hip_scan_next on such a scan needs exon_hip_scan_bind_ctx first
+                             (batches then come out of the same GPU pipeline); without a bound ctx it returns ESTATE */
 } exon_hip_scan_options;
 
 int exon_hip_scan_open(const char* path, const exon_hip_scan_options* options, exon_hip_scan** out);

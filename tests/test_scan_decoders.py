@@ -466,3 +466,21 @@ def test_per_contig_counts_equal_the_htslib_written_indexes():
             mapped[(r, bool(f & 4))] += 1
     scan.close()
     assert dict(mapped) == {(refs[0], False): 61}
+
+
+@pytest.mark.parametrize("codec,magic", [("zstd", b"\x28\xb5\x2f\xfd\x04\x58"), ("bzip2", b"BZh91AY&SY"),
+                                         ("xz", b"\xfd7zXZ\x00\x00\x04")])
+def test_zstd_bzip2_xz_inputs_are_refused_by_name(tmp_path, codec, magic):
+    """file_compression_type.convert_stream (exon-core/src/datasources/fastq/file_opener.rs:93-105) also reads zstd / bzip2 /
+    xz; this library does not: the open fails with EXON_HIP_EUNSUPPORTED and says which codec it saw (not a parse error
+    twenty lines into the garbage)."""
+    p = tmp_path / f"reads.fastq.{codec}"
+    p.write_bytes(magic + bytes(64))
+    for fmt in ("fastq", "vcf"):
+        with pytest.raises(exon_amd.ExonHipError) as e:
+            exon_amd.Scan(str(p), fmt)
+        assert e.value.code == -4 and codec in str(e.value)  # EXON_HIP_EUNSUPPORTED
+    # compression = none: the caller says the bytes are the format's own -- no sniffing, the format reader decides
+    with pytest.raises(exon_amd.ExonHipError) as e:
+        list(exon_amd.Scan(str(p), "fastq", compression="none"))
+    assert codec not in str(e.value)
