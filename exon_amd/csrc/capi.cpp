@@ -108,7 +108,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 extern "C" {
 
-int exon_hip_abi_version(void) { return 4; }
+int exon_hip_abi_version(void) { return 5; }
 
 int exon_hip_device_count(int* out) {
   if (!out) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_device_count: out is NULL");

@@ -252,7 +252,12 @@ __global__ __launch_bounds__(IDX_TPB) void k_index_lines(const uint8_t* __restri
   }
   __syncthreads();
   if (s_bad) {
-    if (threadIdx.x == 0) {  // no lines, one undecided record: the kernels behind do nothing, the caller hands the slab to the host decoder
+    // no lines, one undecided record: the kernels behind do nothing, the caller hands the slab to the host decoder.  The verdict
+    // is STICKY in tile_ctr[1] (= this launch's generation; no tile ever clears it): a tile further on may have read this tile's
+    // aggregate before it gave up, finish its look-back, and -- as the last tile -- publish a total and zero scalars[1..3] AFTER
+    // the two stores below.  k_index_verdict, ordered behind this kernel, re-applies the verdict from the sticky word.
+    if (threadIdx.x == 0) {
+      atomicExch(&tile_ctr[1], gen);
       scalars[0] = 0;
       scalars[1] = 1;
     }
@@ -281,6 +286,13 @@ __global__ __launch_bounds__(IDX_TPB) void k_index_lines(const uint8_t* __restri
     else scalars[threadIdx.x] = 0;
   }
 }
+// behind k_index_lines on the same stream: a tile that gave up wins over whatever the last tile published
+__global__ void k_index_verdict(const unsigned* __restrict__ tile_ctr, unsigned gen, unsigned* __restrict__ scalars) {
+  if (tile_ctr[1] == gen) {
+    scalars[0] = 0;
+    scalars[1] = 1;
+  }
+}
 // one launch instead of count / scan / fill; EXON_HIP_LINE_INDEX_PASSES=2 keeps the three kernels (A/B)
 static void launch_line_index(hipStream_t s, const uint8_t* d_text, int64_t n_bytes, unsigned skip, unsigned* d_block_counts, int64_t max_blocks, int nblocks, unsigned* gen,
                               unsigned* d_nl, unsigned cap, unsigned* d_scalars) {
@@ -301,6 +313,7 @@ static void launch_line_index(hipStream_t s, const uint8_t* d_text, int64_t n_by
   const unsigned ntiles = (unsigned)std::max<int64_t>(1, (n_bytes + tile_bytes - 1) / tile_bytes);  // (<= nblocks <= max_blocks: the words fit)
   hipLaunchKernelGGL(k_index_lines, dim3(ntiles), dim3(IDX_TPB), 0, s, d_text, n_bytes, skip, words, reinterpret_cast<unsigned*>(words + max_blocks), ntiles, *gen, d_nl,
                      cap, d_scalars);
+  hipLaunchKernelGGL(k_index_verdict, dim3(1), dim3(1), 0, s, reinterpret_cast<const unsigned*>(words + max_blocks), *gen, d_scalars);
 }
 
 // scalars[2] = bytes up to and including the last newline (what a caller may discard after this slab)
@@ -462,7 +475,7 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
       }
       // POS
       if (!(EXON_PARSE_SKIP & 2)) {
-        int64_t v = 0;
+        uint64_t v = 0;  // (unsigned: a spoiled or over-long value wraps, it never overflows a signed integer)
         unsigned pb = fbeg(1), pn = fend(1) - fbeg(1);
         if (pn && text[pb] == '+') ++pb, --pn;  // usize::from_str takes one leading '+' (host/formats.h parse_pos)
         bool ok = pn > 0;
@@ -481,9 +494,10 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
             else v = v * 10 + (c - '0');
           }
         }
+        if (pn > 18) ok = false;  // beyond 18 digits the host decides (usize overflow is an error there)
         pos_ok = ok && v > 0;
         if (!ok) bad = true;  // not a number: `variant_start().transpose()?` is an error in the reference -- the host reports it
-        out.pos[row] = pos_ok ? v : 0;
+        out.pos[row] = pos_ok ? (int64_t)v : 0;
       }
       // QUAL
       if (!(EXON_PARSE_SKIP & 4)) {

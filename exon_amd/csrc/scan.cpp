@@ -84,6 +84,14 @@ struct GpuExporter {
   int64_t emitted = 0;                       // rows handed to the queue so far
   std::vector<std::string> final_filters;    // the FILTER dictionary when the producer has finished
   bool decoded_on_gpu = false, inflated_on_gpu = false;
+  // the host reader that takes over when the device hands the file back.  It lives HERE while the producer thread runs: the
+  // scan's own reader (which exon_hip_scan_schema / _dictionary_* read from the consumer's thread) is never touched by the
+  // producer; gpu_next moves the fallback into the scan after the thread has been joined.
+  std::unique_ptr<exon::VCFBatchReader> fb_vcf;
+  std::unique_ptr<exon::BAMBatchReader> fb_bam;
+  std::unique_ptr<exon::SAMBatchReader> fb_sam;
+  std::unique_ptr<exon::BCFBatchReader> fb_bcf;
+  bool handed_over = false;
 };
 
 static int gpu_next(exon_hip_scan* s, struct ArrowArray* out);
@@ -1920,7 +1928,9 @@ static int region_dict_column(const exon_hip_scan* s) {
 }  // extern "C"
 
 // the host reader from the start (a scan opened for the GPU pipeline has read the header only)
-static void reopen_host_reader(exon_hip_scan* scan) {
+// (built into the exporter, NOT into the scan: the consumer thread may be inside exon_hip_scan_schema / _dictionary_* on the
+// scan's own reader at this very moment)
+static void open_fallback_reader(exon_hip_scan* scan, GpuExporter* ex) {
   const exon::Compression c = scan->opt.compression == EXON_HIP_COMPRESSION_GZIP   ? exon::Compression::Gzip
                               : scan->opt.compression == EXON_HIP_COMPRESSION_NONE ? exon::Compression::None
                                                                                    : exon::Compression::Auto;
@@ -1928,17 +1938,17 @@ static void reopen_host_reader(exon_hip_scan* scan) {
     exon::VCFConfig cfg = scan->vcf->config();
     cfg.defer_decode = false;
     cfg.threads = 0;
-    scan->vcf.reset(new exon::VCFBatchReader(scan->path, c, cfg));
+    ex->fb_vcf.reset(new exon::VCFBatchReader(scan->path, c, cfg));
   } else if (scan->bam) {
     exon::BAMConfig cfg = scan->bam->config();
     cfg.threads = 0;
-    scan->bam.reset(new exon::BAMBatchReader(scan->path, cfg));
+    ex->fb_bam.reset(new exon::BAMBatchReader(scan->path, cfg));
   } else if (scan->bcf) {
     exon::VCFConfig cfg = scan->bcf->config();
     cfg.threads = 0;
-    scan->bcf.reset(new exon::BCFBatchReader(scan->path, cfg));
+    ex->fb_bcf.reset(new exon::BCFBatchReader(scan->path, cfg));
   } else if (scan->sam) {
-    scan->sam.reset(new exon::SAMBatchReader(scan->path, c, scan->sam->config()));
+    ex->fb_sam.reset(new exon::SAMBatchReader(scan->path, c, scan->sam->config()));
   }
 }
 
@@ -1959,18 +1969,19 @@ static void gpu_export_producer(exon_hip_scan* scan) {
   if (rc == 1) {
     // the device could not decide something: the host reader goes over the file again and takes over behind the rows emitted
     try {
-      reopen_host_reader(scan);
+      open_fallback_reader(scan, ex);
       int64_t skip = 0;
       {
         std::lock_guard<std::mutex> g(ex->mu);
         skip = ex->emitted;
         ex->decoded_on_gpu = false;
+        ex->handed_over = true;
       }
       rc = EXON_HIP_OK;
       for (;;) {
         struct ArrowArray* out = static_cast<struct ArrowArray*>(malloc(sizeof *out));
         memset(out, 0, sizeof *out);
-        const bool got = scan->vcf ? scan->vcf->read_batch(out) : scan->bam ? scan->bam->read_batch(out) : scan->bcf ? scan->bcf->read_batch(out) : scan->sam->read_batch(out);
+        const bool got = ex->fb_vcf ? ex->fb_vcf->read_batch(out) : ex->fb_bam ? ex->fb_bam->read_batch(out) : ex->fb_bcf ? ex->fb_bcf->read_batch(out) : ex->fb_sam->read_batch(out);
         if (!got) {
           free(out);
           break;
@@ -2045,6 +2056,23 @@ static int gpu_next(exon_hip_scan* s, struct ArrowArray* out) {
   }
   // the producer has finished: its verdict, the FILTER dictionary and the "decoded on the GPU" flags become the scan's
   if (ex->th.joinable()) ex->th.join();
+  if (ex->handed_over) {
+    // the producer thread is gone: the reader that finished the file becomes the scan's (its dictionaries are the ones the
+    // last batches were built with; every batch carries its dictionary values itself, so nothing emitted earlier depends on it)
+    if (ex->fb_vcf) {
+      s->gpu_filter_dict.names = ex->fb_vcf->filter_dict.names;
+      s->vcf = std::move(ex->fb_vcf);
+    } else if (ex->fb_bcf) {
+      s->gpu_filter_dict.names = ex->fb_bcf->filter_dict.names;
+      s->bcf = std::move(ex->fb_bcf);
+    } else if (ex->fb_bam) {
+      s->bam = std::move(ex->fb_bam);
+    } else if (ex->fb_sam) {
+      s->sam = std::move(ex->fb_sam);
+    }
+    ex->handed_over = false;
+    ex->final_filters.clear();
+  }
   if (ex->rc) return fail(ex->ctx, ex->rc, "%s", ex->err.c_str());
   if (!ex->final_filters.empty()) s->gpu_filter_dict.names.swap(ex->final_filters);
   s->gpu_decoded = ex->decoded_on_gpu;

@@ -984,8 +984,18 @@ int exon_hip_stream_end_scan(exon_hip_stream* st, const std::vector<std::string>
     if (redirected) return fail(st->ctx, EXON_HIP_EUNSUPPORTED, "the stream is keyed by value but this scan's group column has no dictionary");
     return EXON_HIP_OK;
   }
-  if ((int64_t)scan_keys->size() > G)
-    return fail(st->ctx, EXON_HIP_ECAPACITY, "the scan's group-key dictionary has %zu entries, the plan was created for n_groups = %d", scan_keys->size(), G);
+  if ((int64_t)scan_keys->size() > G) {
+    if (!redirected) {
+      // first scan of the stream: its rows went straight into the state (there was nothing to protect and no scratch to pay
+      // for) -- under ids beyond n_groups that the kernels dropped or folded.  "Unchanged" means EMPTY here: the stream had no
+      // rows and no keys before this scan (tracked && !redirected <=> rows_pushed was 0, KEYS_NONE), so it gets that back.
+      const int rc2 = flush_slot(st);
+      st->overwrite_next = true;  // the next launch defines the state; exon_hip_stream_state / finish zero it (settle_reset)
+      st->rows_pushed = 0;
+      if (rc2) return rc2;
+    }
+    return fail(st->ctx, EXON_HIP_ECAPACITY, "the scan's group-key dictionary has %zu entries, the plan was created for n_groups = %d; this scan's rows were not added, the stream's state and dictionary are unchanged", scan_keys->size(), G);
+  }
   if (!redirected) {  // first scan of the stream: its ids ARE the stream's
     st->keys = *scan_keys;
     st->keys_state = KEYS_LOCAL;

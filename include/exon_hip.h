@@ -110,7 +110,11 @@ typedef struct exon_hip_device_info {
   int32_t reserved;
 } exon_hip_device_info;
 
-int exon_hip_abi_version(void); /* 4 (round 4: group keys by value -- exon_hip_stream_keys / _set_keys / _reconcile_keys, exon_hip_keys_union,
+int exon_hip_abi_version(void); /* 5 (round 6: the CONTRACT of exon_hip_stream_push changed in round 5 -- batches of up to 131072 rows are held and
+                                      their release callback runs at the slot flush, not before push returns; key overflow is ECAPACITY,
+                                      not EINVAL -- so a caller built against 4 must not load this library unchanged; also new: scan
+                                      projection, plain-gzip inputs on the device, exon_hip_read_probe, collective fault votes;
+                                      round 4: group keys by value -- exon_hip_stream_keys / _set_keys / _reconcile_keys, exon_hip_keys_union,
                                       exon_hip_stream_set_region_contig; round 3: plan_desc.x_type / y_type, 16 typed INFO fields, rccl_comm_count) */
 int exon_hip_device_count(int* out);
 int exon_hip_ctx_create(int device, exon_hip_ctx** out);

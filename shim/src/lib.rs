@@ -459,7 +459,11 @@ impl ExecutionPlan for GpuFilterAggExec {
                                 // was before this file: emit its state as one partial batch -- AggregateExec(Final) merges
                                 // partial batches by key VALUE, any number of them per partition -- and give the file a
                                 // fresh stream (what every file had before the partition shared one).
-                                done.push(emit(&stream)?);
+                                // (a stream that has consumed nothing yet -- the failing file was its first -- is
+                                // empty after ECAPACITY: no keys, no rows, nothing to emit)
+                                if !stream.keys(&plan)?.is_empty() {
+                                    done.push(emit(&stream)?);
+                                }
                                 stream = open_stream()?;
                                 drop(scan);
                                 let mut raw2 = std::ptr::null_mut();

@@ -14,7 +14,7 @@ pub struct exon_hip_stream { _p: [u8; 0] }
 #[repr(C)]
 pub struct exon_hip_scan { _p: [u8; 0] }
 
-pub const EXON_HIP_ABI_VERSION: i32 = 4;
+pub const EXON_HIP_ABI_VERSION: i32 = 5;
 pub const EXON_HIP_PLAN_REGION_COUNT: i32 = 2;
 pub const EXON_HIP_PLAN_FLAG_MAPQ_GROUP_COUNT: i32 = 3;
 pub const EXON_HIP_PLAN_CMP_AVG_BY_GROUP: i32 = 4;

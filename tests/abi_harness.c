@@ -88,7 +88,7 @@ static void make_batch(struct ArrowArray* top, int64_t* cnn, int64_t* crow, doub
 int main(int argc, char** argv) {
   const int allow_no_device = argc > 1 && strcmp(argv[1], "--allow-no-device") == 0;
   exon_hip_ctx* ctx = NULL;
-  if (exon_hip_abi_version() != 4) { fprintf(stderr, "ABI version %d\n", exon_hip_abi_version()); return 1; }
+  if (exon_hip_abi_version() != 5) { fprintf(stderr, "ABI version %d\n", exon_hip_abi_version()); return 1; }
   int rc = exon_hip_ctx_create(0, &ctx);
   if (rc != EXON_HIP_OK) {
     const char* msg = exon_hip_last_error(NULL);

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_abi_version():
-    assert exon_amd.load().exon_hip_abi_version() == 4
+    assert exon_amd.load().exon_hip_abi_version() == 5
 
 
 def test_no_device_fails_loudly():

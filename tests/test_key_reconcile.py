@@ -550,3 +550,50 @@ def test_a_scan_that_does_not_fit_leaves_the_stream_as_it_was(ctx, tmp_path, ora
     assert k4_by_value(keys_b, c, sm, 4) == want_b
     st.close()
     plan.close()
+
+
+@pytest.mark.gpu
+def test_a_first_scan_that_does_not_fit_leaves_the_stream_empty(ctx, tmp_path, oracle):
+    """the FIRST scan of a stream is not redirected into a scratch state (there is nothing to protect), so its rows
+    land in the state before the dictionary is found too large.  EXON_HIP_ECAPACITY must still leave the stream as it was --
+    here: EMPTY, no keys, zero counts -- and usable: a file that fits, consumed next, gives exactly its own answer."""
+    a, b = str(tmp_path / "a.vcf"), str(tmp_path / "b.vcf")
+
+    def write(path, seed, filters):
+        rng = np.random.default_rng(seed)
+        rows = []
+        for i in range(4000):
+            f = filters[i] if i < len(filters) else filters[int(rng.integers(0, len(filters)))]
+            af = "." if rng.random() < 0.05 else ("%.4g" % (10 ** rng.uniform(-4, 0)))
+            q = "." if rng.random() < 0.05 else str(int(rng.integers(0, 8000)) / 8)
+            rows.append(f"1\t{i + 1}\t.\tA\tC\t{q}\t{f}\tAF={af}\n")
+        with open(path, "w") as fh:
+            fh.write(VCF_HEAD + "".join(rows))
+
+    write(a, 3, ["PASS", ".", "q10", "s50", "q10;s50"])   # 5 keys: does not fit n_groups = 4
+    write(b, 4, ["PASS", "q10", "."])
+    nb, want_b = OX.k4_expected(oracle, b, "vcf", "AF")
+    plan = ctx.plan_cmp_avg_by_group(">", 0.01, 4, columns=(4, 2, 3))
+    st = plan.open()
+    s = exon_amd.Scan(a, "vcf", info_field="AF", gpu_parse=True)
+    with pytest.raises(exon_amd.ExonHipError) as e:
+        st.consume(s)
+    s.close()
+    assert e.value.code == -6 and "n_groups" in str(e.value)
+    assert st.keys()[0] == []
+    s = exon_amd.Scan(b, "vcf", info_field="AF", gpu_parse=True)
+    assert st.consume(s) == nb
+    s.close()
+    keys_b = st.keys()[0]
+    c, sm = st.finish()
+    assert k4_by_value(keys_b, c, sm, 4) == want_b   # nothing of file a is left in the state
+    st.close()
+    st = plan.open()                                 # and finishing right after the failure gives the empty answer
+    s = exon_amd.Scan(a, "vcf", info_field="AF", gpu_parse=True)
+    with pytest.raises(exon_amd.ExonHipError):
+        st.consume(s)
+    s.close()
+    c, sm = st.finish()
+    assert not np.any(c) and not np.any(sm)
+    st.close()
+    plan.close()
