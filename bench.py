@@ -76,6 +76,7 @@ def parse_args():
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not measure roofline.traffic in this run (two rocprofv3 --pmc passes of a short child run); use profiles/traffic.json")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (stated-size configs, H2D-inclusive rate)")
+    ap.add_argument("--probe-reps", type=int, default=20, help="passes of the bare read probe before and after the timed steps")
     ap.add_argument("--calib-copy", action="store_true",
                     help="(child runs of measure_traffic) one 1 GiB device-to-device copy first: the counter pass calibrates its bytes-per-count on it")
     return ap.parse_args()
@@ -164,6 +165,19 @@ class Workload:
         self.counts = self.state[:self.n_i64]
         self.sums = self.state[self.n_i64:].view(torch.float64) if self.n_f64 else None
         torch.cuda.synchronize()
+
+    def probe_buffers(self):
+        """(device pointers, bytes of each) of up to 4 value buffers of this shard for exon_hip_read_probe: the plan's columns, all
+        cut to the shortest one's length in bytes (the probe walks its buffers in lock-step)."""
+        t = {"c4": [self.af, self.qual, self.fid] if self.kind == "c4" else None,
+             "c2": [self.chrom, self.pos] if self.kind == "c2" else None,
+             "c6": [self.ref, self.start, self.end] if self.kind == "c6" else None,
+             "c3": [self.flag, self.ref] if self.kind == "c3" else None,
+             "c5": [self.bytes] if self.kind == "c5" else None}[self.kind]
+        nbytes = min(x.numel() * x.element_size() for x in t)
+        if nbytes < (64 << 10):
+            return None, 0
+        return [x.data_ptr() for x in t], nbytes
 
     def run(self):
         """The hot path over the shard: main + finalize kernels; the state is DEFINED by the launch (overwrite mode),
@@ -550,7 +564,20 @@ def main():
         merge()
     torch.cuda.synchronize()
 
+    # What THIS box streams: a bare read (same grid, same 16 B/lane non-temporal loads, no predicate / aggregate) over the SAME
+    # resident columns, before and after the timed steps (rank 0's figure is reported; every rank runs it so that the ranks stay
+    # in step).  roofline.frac is against the spec peak; frac_of_box_ceiling is against what this box's HBM delivered just now.
+    probe_ptrs, probe_bytes = wl.probe_buffers()
+    probe = []
+
+    def run_probe():
+        if probe_ptrs:
+            torch.cuda.synchronize()
+            probe.append(ctx.read_probe(probe_ptrs, probe_bytes, reps=a.probe_reps, stream=torch.cuda.current_stream().cuda_stream))
+    run_probe()
+
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    ev_m = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)] if world > 1 else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -560,16 +587,39 @@ def main():
         wl.run()  # the hot path's kernel only (one launch; c5: offsets scan + main + fold)
         ev[i][1].record()
         merge()   # AggregateExec(Final) across GPUs: one all-gather over RCCL/xGMI + fixed-order fold
+        if ev_m is not None:
+            ev_m[i].record()
     torch.cuda.synchronize()
+    t_done = time.perf_counter()  # CLOCK_MONOTONIC: one clock for all ranks of a node
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
+    run_probe()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
     kern_ms = torch.tensor([sum(s.elapsed_time(e) for s, e in ev) / a.steps], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
         dist.all_reduce(kern_ms, op=dist.ReduceOp.MAX)
     elapsed, kern_ms = float(elapsed.item()), float(kern_ms.item())
+    # N > 1: what every rank saw, so that a scaling figure can be split into shard kernel / collective / skew (DESIGN section 7's
+    # prediction): mean kernel time, mean GPU time from the end of the kernel to the end of the merge (all-gather + fold: it
+    # INCLUDES the wait for the slowest rank's kernel, which is what the collective costs this rank), and when each rank started
+    # and finished its K steps on the node's monotonic clock
+    per_rank = None
+    if world > 1:
+        mine = torch.tensor([sum(s.elapsed_time(e) for s, e in ev) / a.steps,
+                             sum(ev[i][1].elapsed_time(ev_m[i]) for i in range(a.steps)) / a.steps * 1e3,
+                             t0, t_done], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rows_ = [x.cpu().tolist() for x in allr]
+        start0 = min(r[2] for r in rows_)
+        per_rank = {"kernel_ms": [round(r[0], 4) for r in rows_], "merge_us": [round(r[1], 1) for r in rows_],
+                    "start_skew_us": [round((r[2] - start0) * 1e6, 1) for r in rows_],
+                    "finish_skew_us": [round((r[3] - min(q[3] for q in rows_)) * 1e6, 1) for r in rows_],
+                    "note": "merge_us = GPU time from the end of this rank's kernel to the end of its merge (all-gather + fold), i.e. it "
+                            "includes waiting for the slowest rank's kernel; skews on the node's CLOCK_MONOTONIC: start = leaving the "
+                            "barrier in front of the timed steps, finish = this rank's last step done"}
 
     final = merged.cpu()
     counts = final[:wl.n_i64].numpy()
@@ -602,6 +652,20 @@ def main():
                                  "ONE kernel: the last workgroup to finish folds the per-workgroup records and writes the state "
                                  "(no finalize launch, no zeroing pass); c5: offsets scan + main + fold"},
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+        if probe:
+            gb = [p[0] for p in probe]
+            ceil = max(gb)
+            out["roofline"]["box_read_ceiling_GBps"] = round(ceil, 1)
+            out["roofline"]["frac_of_box_ceiling"] = round(achieved / ceil, 4)
+            out["roofline"]["box_read_probe"] = {
+                "before_GBps": round(gb[0], 1), "after_GBps": round(gb[-1], 1), "reps": a.probe_reps,
+                "frac_of_peak": round(ceil / HBM_PEAK_GBS, 4),
+                "note": "exon_hip_read_probe: bare streaming read (the fused kernels' persistent grid and 16 B/lane non-temporal loads, "
+                        "four integer adds per load, no predicate / aggregate) over the same resident value columns walked in "
+                        "lock-step, before and after the timed steps; ceiling = the better of the two; the kernel additionally "
+                        "reads the validity bitmaps (0.25 B/row in c4), which the probe leaves out"}
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
         live = measure_traffic(a, rows) if (world == 1 and not a.no_pmc and a.groups == 5) else None
         if live is not None:

@@ -134,6 +134,7 @@ SIGNATURES = {
     "exon_hip_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
     "exon_hip_memset": (C.c_int, [_vp, _vp, C.c_int, C.c_size_t, _vp]),
     "exon_hip_sync": (C.c_int, [_vp, _vp]),
+    "exon_hip_read_probe": (C.c_int, [_vp, _vp, C.POINTER(_vp), _i32, _i64, _i32, C.POINTER(_dbl), C.POINTER(_i64)]),
     "exon_hip_timer_start": (C.c_int, [_vp, _vp]),
     "exon_hip_timer_stop_ms": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "exon_hip_region_count": (C.c_int, [_vp, _vp, _colp, _colp, _i64, _i32, _i64, _i64, _vp]),

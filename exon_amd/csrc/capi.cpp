@@ -306,6 +306,37 @@ int exon_hip_timer_stop_ms(exon_hip_ctx* ctx, void* stream, float* ms) {
   return EXON_HIP_OK;
 }
 
+// Bare streaming read of `n_buffers` (1..4) device buffers, the first `bytes_each` bytes of each (whole 64 KiB tiles), walked
+// in lock-step with the grid and the 16 B/lane non-temporal loads of the fused kernels: `reps` passes on `stream`, timed with a
+// HIP event pair around them; *ms_per_pass = the average, *bytes_per_pass = what one pass read.
+int exon_hip_read_probe(exon_hip_ctx* ctx, void* stream, const void* const* buffers, int32_t n_buffers, int64_t bytes_each,
+                        int32_t reps, double* ms_per_pass, int64_t* bytes_per_pass) {
+  if (!ctx || !buffers || !ms_per_pass) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_read_probe: NULL argument");
+  if (n_buffers < 1 || n_buffers > 4 || reps < 1 || bytes_each < (64 << 10)) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_read_probe: 1..4 buffers of at least 64 KiB, reps >= 1");
+  for (int i = 0; i < n_buffers; ++i)
+    if (!buffers[i] || !aligned16(buffers[i])) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_read_probe: buffer %d is NULL or not 16-byte aligned", i);
+  hipStream_t s = pick_stream(ctx, stream);
+  unsigned* sink = static_cast<unsigned*>(exon_pool_alloc(ctx, (size_t)std::max(ctx->cfg.compute_units, 1) * 16 * 4));
+  if (!sink) return fail(ctx, EXON_HIP_ENOMEM, "exon_hip_read_probe: sink");
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  if (e == hipSuccess) e = exon::launch_read_probe(s, ctx->cfg, buffers, n_buffers, bytes_each, sink);  // (untimed: code object load, clocks)
+  if (e == hipSuccess) e = hipEventRecord(e0, s);
+  for (int r = 0; r < reps && e == hipSuccess; ++r) e = exon::launch_read_probe(s, ctx->cfg, buffers, n_buffers, bytes_each, sink);
+  if (e == hipSuccess) e = hipEventRecord(e1, s);
+  if (e == hipSuccess) e = hipEventSynchronize(e1);
+  float ms = 0;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  if (e0) hipEventDestroy(e0);
+  if (e1) hipEventDestroy(e1);
+  exon_pool_free(ctx, sink);
+  if (e != hipSuccess) return fail(ctx, EXON_HIP_EDEVICE, "exon_hip_read_probe: %s", hipGetErrorString(e));
+  *ms_per_pass = (double)ms / reps;
+  if (bytes_per_pass) *bytes_per_pass = (bytes_each / (64 << 10)) * (64 << 10) * (int64_t)n_buffers;
+  return EXON_HIP_OK;
+}
+
 // ---- operator launches ---------------------------------------------------------------------------
 // `flags`: EXON_HIP_LAUNCH_*.  OVERWRITE makes the launch DEFINE the state (finalize writes instead of adding), so a
 // query needs no zeroing pass; an empty input then still has to leave zeros behind.

@@ -92,6 +92,10 @@ hipError_t launch_fold_states(hipStream_t s, const void* gathered, int world, in
 hipError_t launch_permute_add_state(hipStream_t s, const void* src, void* dst, const int32_t* map, int n_map, int G, int planes_i64,
                                     int tail_i64, int planes_f64);
 
+// bare streaming read of up to 4 buffers in lock-step, the access pattern and grid of K2-K6 (bench.py's per-box ceiling)
+hipError_t launch_read_probe(hipStream_t s, const LaunchCfg& cfg, const void* const* buffers, int n_buffers, int64_t bytes_each,
+                             unsigned* sink);
+
 hipError_t launch_gen_c2(hipStream_t s, uint64_t seed, int64_t n_total, int64_t lo, int64_t hi, int32_t* chrom,
                          int64_t* pos);
 hipError_t launch_gen_c3(hipStream_t s, uint64_t seed, int64_t lo, int64_t hi, int32_t* flag, uint8_t* mapq,

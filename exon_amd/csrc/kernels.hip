@@ -410,6 +410,64 @@ static int grid_for(const LaunchCfg& cfg, int64_t n, int resident) {
 static int max_grid(const LaunchCfg& cfg) { return cfg.compute_units * std::max(cfg.blocks_per_cu, 1); }
 
 // ------------------------------------------------------------------------------------------------
+// Read probe: what THIS box streams out of HBM through the access pattern of K2-K6 -- the same persistent grid (one
+// 1024-thread workgroup per CU, J = 4 sub-tiles: ShapeBig), the same non-temporal 16 B/lane loads over `NB` buffers walked in
+// lock-step like a plan's columns, and next to no arithmetic (four integer adds per load; one word per wave written at the
+// end so that the loads are live).  bench.py runs it over the resident columns before and after the timed steps:
+// roofline.box_read_ceiling_GBps.  A filter + aggregate kernel cannot beat it; how close it gets is what tuning can still move.
+// ------------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(ShapeBig::THREADS) void k_read_probe(const uint4* __restrict__ b0, const uint4* __restrict__ b1,
+                                                                  const uint4* __restrict__ b2, const uint4* __restrict__ b3,
+                                                                  int64_t nvec, unsigned* __restrict__ sink) {
+  using S = ShapeBig;
+  constexpr int J = S::J, WAVES = ShapeOf<S>::WAVES, WT = 64 * J, TILE = WAVES * WT;  // in 16-byte vectors
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint4* const bufs[4] = {b0, b1, b2, b3};
+  uint4 acc = uint4{0, 0, 0, 0};
+  const int64_t ntiles = nvec / TILE;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t wbase = tile * TILE + (int64_t)wave * WT;
+    uint4 v[NB][J];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) v[b][j] = ld16<uint4>(bufs[b] + wbase + j * 64 + lane);
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        acc.x += v[b][j].x;
+        acc.y += v[b][j].y;
+        acc.z += v[b][j].z;
+        acc.w += v[b][j].w;
+      }
+  }
+  unsigned long long t = (unsigned long long)(acc.x ^ acc.y) + (acc.z ^ acc.w);
+  t = wave_sum(t);
+  if (lane == 0) sink[blockIdx.x * WAVES + wave] = (unsigned)t;
+}
+// one pass over the first `bytes_each` bytes (rounded down to whole 64 KiB tiles) of each of n_buffers (1..4) buffers;
+// sink: compute_units * 16 words
+hipError_t launch_read_probe(hipStream_t s, const LaunchCfg& cfg, const void* const* buffers, int n_buffers, int64_t bytes_each,
+                             unsigned* sink) {
+  const int64_t nvec = bytes_each / 16;
+  constexpr int64_t TILE = (int64_t)ShapeOf<ShapeBig>::WAVES * 64 * ShapeBig::J;
+  const int64_t tiles = nvec / TILE;
+  if (tiles < 1 || n_buffers < 1 || n_buffers > 4) return hipErrorInvalidValue;
+  const int grid = (int)std::min<int64_t>(tiles, std::max(cfg.compute_units, 1));
+  const uint4* b[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int i = 0; i < n_buffers; ++i) b[i] = reinterpret_cast<const uint4*>(buffers[i]);
+  switch (n_buffers) {
+    case 1: hipLaunchKernelGGL(k_read_probe<1>, dim3(grid), dim3(ShapeBig::THREADS), 0, s, b[0], b[1], b[2], b[3], nvec, sink); break;
+    case 2: hipLaunchKernelGGL(k_read_probe<2>, dim3(grid), dim3(ShapeBig::THREADS), 0, s, b[0], b[1], b[2], b[3], nvec, sink); break;
+    case 3: hipLaunchKernelGGL(k_read_probe<3>, dim3(grid), dim3(ShapeBig::THREADS), 0, s, b[0], b[1], b[2], b[3], nvec, sink); break;
+    default: hipLaunchKernelGGL(k_read_probe<4>, dim3(grid), dim3(ShapeBig::THREADS), 0, s, b[0], b[1], b[2], b[3], nvec, sink); break;
+  }
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2 region_count
 //   chrom = lit AND pos >= a AND pos <= b, Kleene AND, FilterExec keeps TRUE, COUNT(*)
 //   (exon-core/src/physical_plan/region_physical_expr.rs:220-240; interval test of

@@ -100,6 +100,13 @@ class Context:
     def sync(self, stream=None):
         self._check(self.lib.exon_hip_sync(self.h, stream))
 
+    def read_probe(self, ptrs, bytes_each, reps=20, stream=None):
+        """exon_hip_read_probe: (GB/s, ms per pass) of a bare streaming read over 1..4 device buffers in lock-step."""
+        arr = (C.c_void_p * len(ptrs))(*[int(p) for p in ptrs])
+        ms, nbytes = C.c_double(), C.c_int64()
+        self._check(self.lib.exon_hip_read_probe(self.h, stream, arr, len(ptrs), int(bytes_each), int(reps), C.byref(ms), C.byref(nbytes)))
+        return nbytes.value / (ms.value * 1e-3) / 1e9, ms.value
+
     def timer_start(self, stream=None):
         self._check(self.lib.exon_hip_timer_start(self.h, stream))
 

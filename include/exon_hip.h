@@ -134,6 +134,14 @@ int exon_hip_memset(exon_hip_ctx* ctx, void* dst, int value, size_t bytes, void*
 int exon_hip_sync(exon_hip_ctx* ctx, void* stream);
 /* Wall time of `reps` back-to-back launches measured with hipEvents on `stream` is available to
  * hosts through these two calls (bench.py uses torch events on the same stream instead). */
+/* (ABI 5) What this box streams out of HBM through the access pattern of the fused kernels: `reps` bare read passes over the
+ * first `bytes_each` bytes (whole 64 KiB tiles) of 1..4 device buffers walked in lock-step -- same persistent grid, same
+ * 16 B/lane non-temporal loads, no predicate and no aggregate -- timed by a HIP event pair on `stream`.  bench.py reports
+ * bytes_per_pass / ms_per_pass as roofline.box_read_ceiling_GBps next to the kernel's own figure: boxes of one pool differ by
+ * a few percent in what their HBM delivers, and a roofline fraction against the spec peak cannot tell a slow box from a slow
+ * kernel.  Measurement aid: not on the reference's path. */
+int exon_hip_read_probe(exon_hip_ctx* ctx, void* stream, const void* const* buffers, int32_t n_buffers, int64_t bytes_each,
+                        int32_t reps, double* ms_per_pass, int64_t* bytes_per_pass);
 int exon_hip_timer_start(exon_hip_ctx* ctx, void* stream);
 int exon_hip_timer_stop_ms(exon_hip_ctx* ctx, void* stream, float* ms);
 
