@@ -103,6 +103,10 @@ class ScanOptions(C.Structure):
                 ("info_field", C.c_char_p), ("region", C.c_char_p), ("use_index", C.c_int32), ("gpu_parse", C.c_int32)]
 
 
+class GzipStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("calls", "chunks", "repairs", "overflow_retries", "members", "comp_bytes", "out_bytes")]
+
+
 FORMATS = {"vcf": 1, "bam": 2, "fastq": 3, "fasta": 4, "sam": 5, "bcf": 6, "cram": 7}
 COMPRESSION = {"auto": 0, None: 0, "none": 1, "gzip": 2}
 
@@ -215,6 +219,10 @@ SIGNATURES = {
                                      C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "exon_hip_bgzf_inflate": (C.c_int, [_vp, _vp, _vp, C.POINTER(BgzfBlock), _i32, _vp, _i32, C.POINTER(_i32)]),
     "exon_hip_bgzf_forget_stream": (C.c_int, [_vp]),
+    "exon_hip_gzip_stream_create": (C.c_int, [_vp, _i64, _i64, C.POINTER(_vp)]),
+    "exon_hip_gzip_stream_decode": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _i64, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)]),
+    "exon_hip_gzip_stream_get_stats": (C.c_int, [_vp, C.POINTER(GzipStats)]),
+    "exon_hip_gzip_stream_destroy": (C.c_int, [_vp]),
     "exon_hip_bgzf_inflate_par_stats": (C.c_int, [_vp, _vp]),
 }
 

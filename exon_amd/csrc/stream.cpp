@@ -990,6 +990,7 @@ int exon_hip_stream_end_scan(exon_hip_stream* st, const std::vector<std::string>
       // for) -- under ids beyond n_groups that the kernels dropped or folded.  "Unchanged" means EMPTY here: the stream had no
       // rows and no keys before this scan (tracked && !redirected <=> rows_pushed was 0, KEYS_NONE), so it gets that back.
       const int rc2 = flush_slot(st);
+      (void)exon_hip_sync(st->ctx, st->stream);  // the kernels flagged the ids beyond n_groups in the device status word: take it (and clear it) here
       st->overwrite_next = true;  // the next launch defines the state; exon_hip_stream_state / finish zero it (settle_reset)
       st->rows_pushed = 0;
       if (rc2) return rc2;

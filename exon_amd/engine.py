@@ -107,6 +107,45 @@ class Context:
         self._check(self.lib.exon_hip_read_probe(self.h, stream, arr, len(ptrs), int(bytes_each), int(reps), C.byref(ms), C.byref(nbytes)))
         return nbytes.value / (ms.value * 1e-3) / 1e9, ms.value
 
+    def gzip_inflate(self, raw, slab_bytes=None, out_cap=None, scratch_bytes=0, return_stats=False):
+        """A whole plain-gzip file through exon_hip_gzip_stream_*, `slab_bytes` of compressed input per call (the unused tail of
+        a slab is passed again in front of the next bytes, as a file pipeline does): (bytes, stats)."""
+        raw = bytes(raw)
+        slab = int(slab_bytes or max(len(raw), 1))
+        cap = int(out_cap or max(4 << 20, 40 * slab))
+        h = C.c_void_p()
+        self._check(self.lib.exon_hip_gzip_stream_create(self.h, slab, int(scratch_bytes), C.byref(h)))
+        d_comp = DeviceBuffer(self, np.uint8, slab + 8192)
+        d_out = DeviceBuffer(self, np.uint8, cap)
+        out = []
+        try:
+            pos, ended = 0, False
+            while not ended:
+                n = min(slab, len(raw) - pos)
+                final = pos + n == len(raw)
+                buf = np.zeros(n + 4096, np.uint8)
+                buf[:n] = np.frombuffer(raw, np.uint8, n, pos)
+                d_comp.copy_from(buf)
+                consumed, produced, end = C.c_int64(), C.c_int64(), C.c_int32()
+                self._check(self.lib.exon_hip_gzip_stream_decode(h, None, d_comp.ptr, n, int(final), d_out.ptr, cap, C.byref(consumed),
+                                                                 C.byref(produced), C.byref(end)))
+                if produced.value:
+                    out.append(d_out.to_host(produced.value).tobytes())
+                ended = bool(end.value)
+                if not ended and consumed.value == 0 and produced.value == 0:
+                    raise ExonHipError(-1, "gzip_inflate: no progress")
+                pos += consumed.value
+                if final and not ended and consumed.value == 0:
+                    raise ExonHipError(-1, "gzip_inflate: input ended without the stream's end")
+            st = L.GzipStats()
+            self._check(self.lib.exon_hip_gzip_stream_get_stats(h, C.byref(st)))
+        finally:
+            self.lib.exon_hip_gzip_stream_destroy(h)
+            d_comp.free()
+            d_out.free()
+        data = b"".join(out)
+        return (data, {n: getattr(st, n) for n, _ in L.GzipStats._fields_}) if return_stats else data
+
     def timer_start(self, stream=None):
         self._check(self.lib.exon_hip_timer_start(self.h, stream))
 

@@ -474,6 +474,30 @@ int exon_hip_index_query(const char* index_path, int32_t is_bai, const char* ref
  * inflated on the GPU as well. */
 int exon_hip_scan_decoded_on_gpu(exon_hip_scan* scan, int32_t* decoded, int32_t* inflated);
 int exon_hip_scan_close(exon_hip_scan* scan);
+/* ---- (ABI 5) plain gzip on the GPU: RFC 1952 members that are NOT BGZF (no "BC" extra field, one DEFLATE stream per member) -------
+ * The `else` arm of the reference's openers (exon-core/src/datasources/fastq/file_opener.rs:79-92: a gzip file that fails
+ * is_bgzip_valid_header goes through file_compression_type.convert_stream).  The compressed bytes of a slab are cut into chunks, one
+ * wavefront per chunk finds a block start by itself and decodes with the 32 KiB in front of it unknown (16-bit symbols: a byte, or
+ * "byte k of the window"); the host proves the chain of chunks, the windows are resolved by composing the chunks' tail maps, a last
+ * pass writes bytes; CRC-32 and ISIZE of every member are checked (exon_amd/csrc/gzip_stream.hip).
+ * A stream is one file: create, decode slab after slab, destroy.  Any failure (EXON_HIP_EINVAL with a text) means: inflate this
+ * file on the host -- nothing of the failing call has been committed to the stream's state except that it cannot be continued. */
+typedef struct exon_hip_gzip_stream exon_hip_gzip_stream;
+typedef struct exon_hip_gzip_stats {
+  uint64_t calls, chunks, repairs, overflow_retries, members, comp_bytes, out_bytes;
+} exon_hip_gzip_stats;
+/* max_comp_bytes: the most compressed bytes one decode call is given; scratch_bytes: symbol scratch (2 bytes per output byte of a
+ * call; 0 = 16 x max_comp_bytes, at least 64 MiB -- a call whose chunks overflow their share is repeated on a quarter of the slab) */
+int exon_hip_gzip_stream_create(exon_hip_ctx* ctx, int64_t max_comp_bytes, int64_t scratch_bytes, exon_hip_gzip_stream** out);
+/* d_comp: 4-byte aligned device memory, n_comp bytes that start at the byte the previous call stopped in (the file's first byte for
+ * the first call) with 4096 readable bytes behind them; final_input: these are the file's last bytes.  Decodes whole DEFLATE blocks
+ * while their output fits out_cap; *consumed = compressed bytes used up (pass the rest again in front of the next bytes; the bit
+ * position inside the first byte is the stream's business), *produced = bytes written to d_out, *stream_end = 1 once the last
+ * member's trailer has been checked at the end of the input.  Synchronises `stream`. */
+int exon_hip_gzip_stream_decode(exon_hip_gzip_stream* s, void* stream, const uint8_t* d_comp, int64_t n_comp, int32_t final_input,
+                                uint8_t* d_out, int64_t out_cap, int64_t* consumed, int64_t* produced, int32_t* stream_end);
+int exon_hip_gzip_stream_get_stats(exon_hip_gzip_stream* s, exon_hip_gzip_stats* out);
+int exon_hip_gzip_stream_destroy(exon_hip_gzip_stream* s);
 /* ---- VCF record parsing on the GPU (raw text in HBM -> device-layout columns in HBM) ---------------------------
  * Same field rules as LazyVCFArrayBuilder::append (exon-vcf/src/array_builder/lazy_array_builder.rs:159-216) for the
  * device-layout columns.  A parser is bound to one header (contig dictionary) and one optional typed INFO field and
