@@ -64,7 +64,7 @@ enum : uint32_t {
   GZ_TRUNCATED = 10,
 };
 enum : uint32_t { START_SEARCH = 0, START_BLOCK = 1, START_MEMBER = 2 };
-enum : uint32_t { F_EXHAUSTED = 1, F_STREAM_END = 2 };
+enum : uint32_t { F_EXHAUSTED = 1, F_STREAM_END = 2, F_AT_MEMBER = 4 /* end_bit is a member header (the input ended inside it) */ };
 
 struct GzStart {
   uint64_t bit;
@@ -418,7 +418,7 @@ __device__ __noinline__ ChainResult decode_chain(const uint32_t* comp, uint64_t 
       return r;
     }
     if (h == 2) {
-      r.flags = F_EXHAUSTED;
+      r.flags = F_EXHAUSTED | F_AT_MEMBER;
       return r;
     }
   }
@@ -1249,7 +1249,7 @@ int exon_hip_gzip_stream_decode(exon_hip_gzip_stream* s, void* stream, const uin
     *consumed = (int64_t)(end_bit >> 3);
     *produced = (int64_t)off;
     s->start_bit = (uint32_t)(end_bit & 7);
-    s->start_kind = START_BLOCK;
+    s->start_kind = (last.flags & F_AT_MEMBER) ? START_MEMBER : START_BLOCK;
     s->stats.out_bytes += off;
     s->stats.comp_bytes += (uint64_t)*consumed;
     ++s->stats.calls;

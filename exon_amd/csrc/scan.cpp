@@ -119,6 +119,19 @@ static bool gpu_inflate_enabled() {
   const char* v = getenv("EXON_HIP_GPU_INFLATE");
   return !(v && v[0] == '0');
 }
+static bool gpu_gzip_enabled() {
+  const char* v = getenv("EXON_HIP_GPU_GZIP");
+  return !(v && v[0] == '0');
+}
+// gzip magic + deflate method, and not BGZF
+static bool is_plain_gzip(const std::string& path) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  unsigned char h[3] = {0, 0, 0};
+  const bool ok = fread(h, 1, 3, f) == 3 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8;
+  fclose(f);
+  return ok && !exon::BgzfParallelSource::is_bgzf(path);
+}
 static bool wants_gpu_inflate(const exon_hip_scan_options* o, const char* path) {
   return o->gpu_parse != 0 && gpu_inflate_enabled() && o->compression != EXON_HIP_COMPRESSION_NONE && exon::BgzfParallelSource::is_bgzf(path);
 }
@@ -715,11 +728,13 @@ void exon_hip_release_ctx_caches(exon_hip_ctx* ctx) {
 class GpuTextSource {
  public:
   // trim_last (BGZF only): inflated bytes to drop behind the last block -- an index chunk ends inside its last block
+  // gz: `src` delivers the RAW bytes of a plain-gzip (non-BGZF) file; they cross PCIe as they are and are inflated on the GPU
+  // (gzip_stream.hip) straight into the text buffer -- everything downstream is the plain-text mode
   GpuTextSource(exon_hip_ctx* ctx, hipStream_t hs, std::unique_ptr<exon::ByteSource> src, bool bgzf, uint64_t skip_first,
-                std::string carry, bool binary = false, bool text_async = false, size_t trim_last = 0)
-      : ctx_(ctx), hs_(hs), src_(std::move(src)), rd_(src_.get()), bgzf_(bgzf), binary_(binary), text_async_(text_async), skip_(skip_first),
+                std::string carry, bool binary = false, bool text_async = false, size_t trim_last = 0, bool gz = false)
+      : ctx_(ctx), hs_(hs), src_(std::move(src)), rd_(src_.get()), bgzf_(bgzf), binary_(binary), text_async_(text_async), gz_(gz), skip_(skip_first),
         trim_last_(trim_last), carry_(std::move(carry)) {
-    slab_ = slab_bytes(bgzf_ && !text_async_);
+    slab_ = gz_ ? gz_slab_bytes() : slab_bytes(bgzf_ && !text_async_);
     ring_geometry();
     local_cpus_ = gpu_local_cpus(ctx_->device);
     rd_.cpus = local_cpus_;
@@ -740,8 +755,19 @@ class GpuTextSource {
       text_cap_ = (size_t)target_blocks_ * 65536;   // inflated bytes per slab
     } else {
       text_cap_ = slab_;
+      if (gz_) comp_cap_ = text_cap_;  // (stored blocks: a compressed slab never needs to be larger than the text it may produce)
     }
-    gap_ = std::max<size_t>(text_cap_ / 4, 1u << 20);  // room for the carried tail (< 1 record + 1 line)
+    gap_ = gz_ ? std::max<size_t>(text_cap_ / 16, 16u << 20) : std::max<size_t>(text_cap_ / 4, 1u << 20);  // room for the carried tail (< 1 record + 1 line)
+  }
+  // Plain-gzip slabs are cut by OUTPUT bytes: 256 MiB of text per slab (32 KiB chunks: a slab of ~64 MiB of compressed bytes is
+  // ~2000 wavefronts' worth of chunks).  EXON_HIP_GZ_SLAB_MB overrides.
+  static size_t gz_slab_bytes() {
+    size_t slab = (size_t)256 << 20;
+    if (const char* v = getenv("EXON_HIP_GZ_SLAB_MB")) {
+      const long mb = atol(v);
+      if (mb >= 1 && mb <= 4096) slab = (size_t)mb << 20;
+    }
+    return slab;
   }
   ~GpuTextSource() {
     const double td0 = now_s();
@@ -753,6 +779,16 @@ class GpuTextSource {
     if (xs_) hipStreamSynchronize(xs_);
     if (cs_) hipStreamSynchronize(cs_);
     if (ev_carry_) hipEventDestroy(ev_carry_);
+    if (gzs_) {
+      if (getenv("EXON_HIP_PIPE_TRACE")) {
+        exon_hip_gzip_stats gs;
+        if (exon_hip_gzip_stream_get_stats(gzs_, &gs) == EXON_HIP_OK)
+          fprintf(stderr, "[exon-hip pipe] gzip on the GPU: %llu calls, %llu chunks, %llu repairs, %llu overflow retries, %llu members, %.1f MB -> %.1f MB; decode calls %.1f ms, reads + H2D %.1f ms\n",
+                  (unsigned long long)gs.calls, (unsigned long long)gs.chunks, (unsigned long long)gs.repairs, (unsigned long long)gs.overflow_retries, (unsigned long long)gs.members,
+                  gs.comp_bytes / 1e6, gs.out_bytes / 1e6, t_gz_decode_ * 1e3, t_gz_read_ * 1e3);
+      }
+      exon_hip_gzip_stream_destroy(gzs_);
+    }
     if (getenv("EXON_HIP_PIPE_TRACE"))
       fprintf(stderr, "[exon-hip pipe] teardown: reader join %.1f ms, stream sync %.1f ms; reader: busy %.1f ms = file reads %.1f ms + pieces %.1f ms (next piece's start %.1f, copy calls %.1f, header walk %.1f) + "
               "leftovers %.1f ms + the rest; thread start lag %.1f ms; consumer waited %.1f ms for inflates, %.1f ms for the reader\n",
@@ -844,7 +880,7 @@ class GpuTextSource {
         if (k == 0 && !h_ring_ && hipHostMalloc((void**)&h_ring_, (size_t)RING_N * (RING_HEAD + RING_PIECE)) != hipSuccess)
           return fail(ctx_, EXON_HIP_ENOMEM, "pinned staging ring could not be allocated");
         const double a1 = now_s();
-        if (hipMalloc((void**)&d_text_[k], gap_ + text_cap_ + 256) != hipSuccess || (bgzf_ && hipMalloc((void**)&d_comp_[k], comp_cap_ + 8192) != hipSuccess))
+        if (hipMalloc((void**)&d_text_[k], gap_ + text_cap_ + 256) != hipSuccess || ((bgzf_ || gz_) && hipMalloc((void**)&d_comp_[k], comp_cap_ + 8192) != hipSuccess))
           return fail(ctx_, EXON_HIP_ENOMEM, "slab buffers (%zu bytes of text) could not be allocated", text_cap_);
         t_host += a1 - a0;
         t_dev += now_s() - a1;
@@ -889,6 +925,11 @@ class GpuTextSource {
       return EXON_HIP_OK;
     }
     if (carry_.size() > gap_) return 1;  // the host reader had buffered more than the gap holds: host decoder
+    if (gz_) {
+      // symbol scratch: 2 bytes per byte of a slab's text, and a quarter more for the chunks the text buffer turns away
+      const int rcg = exon_hip_gzip_stream_create(ctx_, (int64_t)comp_cap_, (int64_t)(2 * text_cap_ + text_cap_ / 2), &gzs_);
+      if (rcg) return rcg;
+    }
     fill(0, &cur_);
     k_ = 0;
     return EXON_HIP_OK;
@@ -905,7 +946,10 @@ class GpuTextSource {
     }
     started_ = true;
     if (cur_.err) {
-      try { std::rethrow_exception(cur_.err); } catch (const std::exception& e) { return fail(ctx_, EXON_HIP_EINVAL, "%s", e.what()); }
+      try { std::rethrow_exception(cur_.err); } catch (const std::exception& e) {
+        fail(ctx_, EXON_HIP_EINVAL, "%s%s", e.what(), gz_ ? " (decoding on the host instead)" : "");
+        return gz_ ? 1 : EXON_HIP_EINVAL;  // gzip on the GPU: whatever does not prove goes to the host reader, which reports what the reference's decoder would
+      }
     }
     const int k = k_;
     const bool more = !cur_.eof;
@@ -919,6 +963,12 @@ class GpuTextSource {
     if (cur_.front_extra) {
       front = gap_ - cur_.front_extra;
       n_text = cur_.front_extra + cur_.n;
+    }
+    if (gz_ && skip_) {  // first slab: the host reader consumed the header
+      if (cur_.n < skip_) return 1;  // the header spans more than one slab: not worth handling here
+      front = gap_ + (size_t)skip_;
+      n_text = cur_.n - (size_t)skip_;
+      skip_ = 0;
     }
     HIP_TRY(ctx_, hipStreamWaitEvent(hs_, ev_h2d_[k], 0));
     if (started_prev_) {  // everything the consumer queued on slab i-1 (and the copy out of it) precedes the reuse of its buffer
@@ -1073,6 +1123,10 @@ class GpuTextSource {
     if (t_spawn_at_ > 0) t_spawn_ += t_fill0 - t_spawn_at_;
     struct Acc { double* a; double t0; ~Acc() { *a += now_s() - t0; } } acc{&t_fill_, t_fill0};
     try {
+      if (gz_) {
+        fill_gz(k, f);
+        return;
+      }
       if (!bgzf_) {
         // plain text: file -> pinned ring piece -> d_text_[k] behind the gap, piece by piece on the copy stream (under the parse
         // of the previous slab); what the host header reader had buffered goes in front of the first slab
@@ -1279,6 +1333,92 @@ class GpuTextSource {
       f->err = std::current_exception();
     }
   }
+  // Plain gzip: [compressed tail of the previous slab (device to device) | fresh bytes through the pinned ring] -> d_comp_, inflated by
+  // exon_hip_gzip_stream_decode on the copy stream straight into d_text_[k] behind the gap.  The decode takes whole DEFLATE blocks
+  // while their text fits; what it did not use opens the next slab.  The compressed bytes per slab follow the running ratio.
+  void fill_gz(int k, Filled* f) {
+    hipSetDevice(ctx_->device);
+    if (free_rec_[k] && hipStreamWaitEvent(xs_, ev_free_[k], 0) != hipSuccess) throw std::runtime_error("gzip slab: event wait failed");
+    f->front_extra = 0;
+    const int kc = (int)(gz_fills_++ & 1);
+    size_t off = 0;
+    if (gz_tail_len_) {
+      if (hipMemcpyAsync(d_comp_[kc], d_comp_[kc ^ 1] + gz_tail_off_, gz_tail_len_, hipMemcpyDeviceToDevice, xs_) != hipSuccess) throw std::runtime_error("gzip slab: carry copy failed");
+      off = gz_tail_len_;
+    }
+    size_t goal = std::min(comp_cap_, std::max(off + (1u << 20), gz_target_));
+    for (;;) {
+      const double tr0 = now_s();
+      struct Piece {
+        bool active = false;
+        int p = 0;
+        uint8_t* base = nullptr;
+        size_t want = 0;
+      };
+      auto start_piece = [&](size_t at_off) {
+        Piece pc;
+        if (at_off >= goal || file_eof_) return pc;
+        pc.p = ring_next_;
+        ring_next_ = (pc.p + 1) % RING_N;
+        if (piece_used_[pc.p] && hipEventSynchronize(ev_piece_[pc.p]) != hipSuccess) throw std::runtime_error("staging ring: event wait failed");
+        pc.base = h_ring_ + (size_t)pc.p * (RING_HEAD + RING_PIECE) + RING_HEAD;
+        pc.want = std::min(RING_PIECE, goal - at_off);
+        rd_.begin(pc.base, pc.want);
+        pc.active = true;
+        return pc;
+      };
+      Piece cur = start_piece(off);
+      while (cur.active) {
+        const size_t got = rd_.finish();
+        if (got < cur.want) file_eof_ = true;
+        Piece nxt;
+        if (!file_eof_) nxt = start_piece(off + got);
+        if (got == 0) break;
+        if (hipMemcpyAsync(d_comp_[kc] + off, cur.base, got, hipMemcpyHostToDevice, xs_) != hipSuccess || hipEventRecord(ev_piece_[cur.p], xs_) != hipSuccess)
+          throw std::runtime_error("H2D of a compressed piece failed");
+        piece_used_[cur.p] = true;
+        off += got;
+        cur = nxt;
+      }
+      if (hipMemsetAsync(d_comp_[kc] + off, 0, 4096, xs_) != hipSuccess) throw std::runtime_error("padding of a compressed slab failed");
+      const double tr1 = now_s();
+      t_gz_read_ += tr1 - tr0;
+      t_read_ += tr1 - tr0;
+      int64_t consumed = 0, produced = 0;
+      int32_t ended = 0;
+      const int rc = exon_hip_gzip_stream_decode(gzs_, xs_, d_comp_[kc], (int64_t)off, file_eof_ ? 1 : 0, d_text_[k] + gap_, (int64_t)text_cap_, &consumed, &produced, &ended);
+      t_gz_decode_ += now_s() - tr1;
+      if (rc) throw std::runtime_error(exon_hip_last_error(ctx_));
+      if (!ended && consumed == 0 && produced == 0) {
+        // not one whole block in these bytes: take more (a block larger than the largest slab is the host reader's)
+        if (file_eof_ || goal >= comp_cap_) throw std::runtime_error("gzip: a DEFLATE block larger than a slab");
+        goal = std::min(comp_cap_, goal * 2);
+        continue;
+      }
+      gz_tail_off_ = (size_t)consumed;
+      gz_tail_len_ = off - (size_t)consumed;
+      if (consumed > 0 && produced > 0) {
+        const double ratio = (double)produced / (double)consumed;
+        gz_target_ = (size_t)std::min<double>((double)comp_cap_, std::max<double>(4 << 20, 0.9 * (double)text_cap_ / ratio));
+      }
+      f->n = (size_t)produced;
+      f->eof = ended != 0;
+      if (f->eof && produced > 0) {
+        uint8_t lastb = 0;
+        if (hipMemcpyAsync(&lastb, d_text_[k] + gap_ + produced - 1, 1, hipMemcpyDeviceToHost, xs_) != hipSuccess || hipStreamSynchronize(xs_) != hipSuccess)
+          throw std::runtime_error("gzip slab: last byte copy failed");
+        f->last_byte = lastb;
+      }
+      if (hipEventRecord(ev_h2d_[k], xs_) != hipSuccess) throw std::runtime_error("gzip slab: event record failed");
+      return;
+    }
+  }
+  exon_hip_gzip_stream* gzs_ = nullptr;
+  uint64_t gz_fills_ = 0;
+  size_t gz_tail_off_ = 0, gz_tail_len_ = 0;
+  size_t gz_target_ = 16u << 20;  // compressed bytes of the next slab (the first one is small: the GPU starts early)
+  double t_gz_decode_ = 0, t_gz_read_ = 0;
+
   exon_hip_bgzf_block* h_blocks_tmp(int k) {
     scan_tmp_[k].resize((size_t)max_blocks_);
     return scan_tmp_[k].data();
@@ -1290,6 +1430,7 @@ class GpuTextSource {
   SlabReader rd_;
   bool bgzf_, binary_;
   bool text_async_;  // the consumer's kernels read the slab text after the parser has returned (FASTQ views)
+  bool gz_ = false;  // plain gzip inflated on the GPU (the text side is the plain mode)
   hipEvent_t ev_carry_ = nullptr;
   uint64_t skip_;
   size_t trim_last_ = 0;
@@ -1650,8 +1791,12 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
   const bool bgzf = gpu_inflate_enabled() && scan->opt.compression != EXON_HIP_COMPRESSION_NONE &&
                     exon::BgzfParallelSource::is_bgzf(scan->path) && (!is_vcf || indexed || scan->vcf->data_offset() >= 0);
   if ((is_bam || is_bcf || indexed) && !bgzf) return 1;
+  // a gzip file that is not BGZF (the `else` arm of the reference's openers, fastq/file_opener.rs:79-92): inflated on the GPU too
+  // (gzip_stream.hip) when the host reader can say where the records start in the uncompressed stream; EXON_HIP_GPU_GZIP=0: host zlib
+  const bool gz = !bgzf && !indexed && !is_bam && !is_bcf && gpu_inflate_enabled() && gpu_gzip_enabled() && scan->opt.compression != EXON_HIP_COMPRESSION_NONE &&
+                  is_plain_gzip(scan->path) && (!is_vcf || scan->vcf->data_offset() >= 0) && (!is_sam || scan->sam->data_offset() >= 0);
   if (!scan->exporter) {
-    scan->gpu_inflated = bgzf;
+    scan->gpu_inflated = bgzf || gz;
     scan->gpu_decoded = false;
   }
 
@@ -1697,6 +1842,10 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
                                        : 0;
         std::unique_ptr<exon::ByteSource> raw(new exon::ByteReader(scan->path, exon::Compression::None));
         src.reset(new GpuTextSource(ctx, hs, std::move(raw), true, skip, std::string(), is_bam || is_bcf, /*text_async=*/!is_vcf && !is_bam && !is_bcf && !is_sam));
+      } else if (gz) {
+        const uint64_t skip = is_vcf ? (uint64_t)scan->vcf->data_offset() : is_sam ? (uint64_t)scan->sam->data_offset() : 0;
+        std::unique_ptr<exon::ByteSource> raw(new exon::ByteReader(scan->path, exon::Compression::None));
+        src.reset(new GpuTextSource(ctx, hs, std::move(raw), false, skip, std::string(), false, false, 0, /*gz=*/true));
       } else {
         std::string carry;
         std::unique_ptr<exon::ByteSource> text = is_vcf   ? scan->vcf->take_stream(&carry)
@@ -1899,7 +2048,7 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
   if (rc == EXON_HIP_OK) {
     if (scan->exporter) {
       scan->exporter->decoded_on_gpu = true;
-      scan->exporter->inflated_on_gpu = bgzf;
+      scan->exporter->inflated_on_gpu = bgzf || gz;
     } else {
       scan->rows += total;
       scan->gpu_decoded = true;
