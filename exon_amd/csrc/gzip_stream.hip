@@ -49,6 +49,7 @@ constexpr uint32_t RM = RING - 1;
 constexpr uint32_t DRAIN = 512;      // symbols per drain step (64 lanes x 16 bytes)
 constexpr int WIN = 32768;
 constexpr int MAX_MEMBER_ENDS = 8;   // member trailers one chunk may cross
+constexpr int SPARE_REGIONS = 64;    // scratch regions beyond one per chunk: a repair decodes the gap in front of a chunk into one
 
 enum : uint32_t {
   GZ_OK = 0,
@@ -66,9 +67,11 @@ enum : uint32_t {
 enum : uint32_t { START_SEARCH = 0, START_BLOCK = 1, START_MEMBER = 2 };
 enum : uint32_t { F_EXHAUSTED = 1, F_STREAM_END = 2, F_AT_MEMBER = 4 /* end_bit is a member header (the input ended inside it) */ };
 
-struct GzStart {
-  uint64_t bit;
-  uint32_t kind, pad;
+struct GzTask {        // one wavefront's work
+  uint64_t bit;        // where to start (START_SEARCH: where the search starts)
+  uint64_t stop;       // decode up to the first block boundary at or behind this bit (~0: to the end of the input); the search ends here too
+  uint32_t kind;
+  uint32_t region;     // which region of the symbol scratch / which result record
 };
 struct GzChunk {         // 32 bytes
   uint64_t start_bit;    // where the accepted decode began
@@ -681,14 +684,12 @@ chain_done:
   return r;
 }
 
-// One wavefront per chunk.  todo == nullptr: every chunk; else the listed ones (repairs).
-__global__ __launch_bounds__(64) void k_gz_decode(const uint32_t* __restrict__ comp, uint64_t n_bits, uint32_t chunk_bytes, int n_chunks, const int* __restrict__ todo,
-                                                  const GzStart* __restrict__ starts, uint16_t* __restrict__ sym, uint32_t cap, GzChunk* __restrict__ res,
-                                                  GzMember* __restrict__ members, int input_final) {
-  const int c = todo ? todo[blockIdx.x] : (int)blockIdx.x;
-  const uint64_t chunk_bits = 8ull * chunk_bytes;
-  const uint64_t stop_bit = c + 1 < n_chunks ? (uint64_t)(c + 1) * chunk_bits : ~0ull;
-  const GzStart st = starts[c];
+// One wavefront per task (a chunk of the slab, or a repair).
+__global__ __launch_bounds__(64) void k_gz_decode(const uint32_t* __restrict__ comp, uint64_t n_bits, const GzTask* __restrict__ tasks, uint16_t* __restrict__ sym, uint32_t cap,
+                                                  GzChunk* __restrict__ res, GzMember* __restrict__ members, int input_final) {
+  const GzTask st = tasks[blockIdx.x];
+  const int c = (int)uniu(st.region);
+  const uint64_t stop_bit = uni64(st.stop);
   uint16_t* my_sym = sym + (size_t)c * cap;
   GzMember* my_members = members + (size_t)c * MAX_MEMBER_ENDS;
   ChainResult r;
@@ -701,7 +702,7 @@ __global__ __launch_bounds__(64) void k_gz_decode(const uint32_t* __restrict__ c
     r.n_out = 0;
     r.flags = 0;
     r.n_members = 0;
-    const uint64_t lo = (uint64_t)c * chunk_bits;
+    const uint64_t lo = uni64(st.bit);
     const uint64_t hi = min(stop_bit, n_bits);
     bool done = false;
     for (uint64_t p = lo; p < hi && !done; p += 64) {
@@ -982,10 +983,8 @@ struct exon_hip_gzip_stream {
   GzChunk* h_res = nullptr;  // pinned
   GzMember* d_members = nullptr;
   GzMember* h_members = nullptr;
-  GzStart* d_starts = nullptr;
-  GzStart* h_starts = nullptr;
-  int* d_todo = nullptr;
-  int* h_todo = nullptr;
+  GzTask* d_tasks = nullptr;
+  GzTask* h_tasks = nullptr;
   Accepted* d_acc = nullptr;
   Accepted* h_acc = nullptr;
   uint16_t* d_group_map = nullptr;
@@ -1011,9 +1010,9 @@ namespace {
 void gz_free(exon_hip_gzip_stream* s) {
   auto dfree = [](void* p) { if (p) hipFree(p); };
   auto hfree = [](void* p) { if (p) hipHostFree(p); };
-  dfree(s->d_sym), dfree(s->d_res), dfree(s->d_members), dfree(s->d_starts), dfree(s->d_todo), dfree(s->d_acc), dfree(s->d_group_map), dfree(s->d_group_win),
+  dfree(s->d_sym), dfree(s->d_res), dfree(s->d_members), dfree(s->d_tasks), dfree(s->d_acc), dfree(s->d_group_map), dfree(s->d_group_win),
       dfree(s->d_chunk_win), dfree(s->d_win[0]), dfree(s->d_win[1]), dfree(s->d_pieces);
-  hfree(s->h_res), hfree(s->h_members), hfree(s->h_starts), hfree(s->h_todo), hfree(s->h_acc), hfree(s->h_pieces);
+  hfree(s->h_res), hfree(s->h_members), hfree(s->h_tasks), hfree(s->h_acc), hfree(s->h_pieces);
 }
 }  // namespace
 
@@ -1031,22 +1030,23 @@ int exon_hip_gzip_stream_create(exon_hip_ctx* ctx, int64_t max_comp_bytes, int64
   }
   if (const char* v = getenv("EXON_HIP_GZ_VERIFY_CRC")) s->verify_crc = !(v[0] == '0');
   s->max_chunks = (int)((max_comp_bytes + s->chunk_bytes - 1) / s->chunk_bytes) + 1;
+  const size_t nr = (size_t)s->max_chunks + SPARE_REGIONS;  // regions: one per chunk + the spares that repairs decode gaps into
   // symbol scratch: 2 bytes per output byte.  Default: room for a ratio of 8 over the largest slab (at least 1 Mi symbols per
   // chunk are never needed: a chunk's region is scratch / chunks, the call shrinks its slab when a region overflows)
   if (scratch_bytes <= 0) scratch_bytes = std::max<int64_t>(max_comp_bytes * 16, 64 << 20);
   s->sym_words = (size_t)scratch_bytes / 2;
   hipSetDevice(ctx->device);
-  const size_t nc = (size_t)s->max_chunks;
+  const size_t nc = nr;
   const size_t ng = (nc + GROUP - 1) / GROUP;
   s->max_pieces = s->sym_words / 65536 + 2 * nc * (MAX_MEMBER_ENDS + 1) + 16;
   bool ok = hipMalloc((void**)&s->d_sym, s->sym_words * 2 + 64) == hipSuccess && hipMalloc((void**)&s->d_res, nc * sizeof(GzChunk)) == hipSuccess &&
-            hipMalloc((void**)&s->d_members, nc * MAX_MEMBER_ENDS * sizeof(GzMember)) == hipSuccess && hipMalloc((void**)&s->d_starts, nc * sizeof(GzStart)) == hipSuccess &&
-            hipMalloc((void**)&s->d_todo, nc * sizeof(int)) == hipSuccess && hipMalloc((void**)&s->d_acc, nc * sizeof(Accepted)) == hipSuccess &&
+            hipMalloc((void**)&s->d_members, nc * MAX_MEMBER_ENDS * sizeof(GzMember)) == hipSuccess && hipMalloc((void**)&s->d_tasks, nc * sizeof(GzTask)) == hipSuccess &&
+            hipMalloc((void**)&s->d_acc, nc * sizeof(Accepted)) == hipSuccess &&
             hipMalloc((void**)&s->d_group_map, ng * WIN * 2) == hipSuccess && hipMalloc((void**)&s->d_group_win, ng * WIN) == hipSuccess &&
             hipMalloc((void**)&s->d_chunk_win, nc * WIN) == hipSuccess && hipMalloc((void**)&s->d_win[0], WIN) == hipSuccess && hipMalloc((void**)&s->d_win[1], WIN) == hipSuccess &&
             hipMalloc((void**)&s->d_pieces, s->max_pieces * sizeof(CrcPiece)) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&s->h_res, nc * sizeof(GzChunk)) == hipSuccess && hipHostMalloc((void**)&s->h_members, nc * MAX_MEMBER_ENDS * sizeof(GzMember)) == hipSuccess &&
-       hipHostMalloc((void**)&s->h_starts, nc * sizeof(GzStart)) == hipSuccess && hipHostMalloc((void**)&s->h_todo, nc * sizeof(int)) == hipSuccess &&
+       hipHostMalloc((void**)&s->h_tasks, nc * sizeof(GzTask)) == hipSuccess &&
        hipHostMalloc((void**)&s->h_acc, nc * sizeof(Accepted)) == hipSuccess && hipHostMalloc((void**)&s->h_pieces, s->max_pieces * sizeof(CrcPiece)) == hipSuccess;
   if (ok) ok = hipMemset(s->d_win[0], 0, WIN) == hipSuccess && hipMemset(s->d_win[1], 0, WIN) == hipSuccess;
   if (!ok) {
@@ -1094,41 +1094,73 @@ int exon_hip_gzip_stream_decode(exon_hip_gzip_stream* s, void* stream, const uin
   for (int attempt = 0; attempt < 6; ++attempt) {
     const bool final_here = final_input && n_use == n_comp;
     const int n_chunks = (int)((n_use + s->chunk_bytes - 1) / s->chunk_bytes);
-    const uint32_t cap = (uint32_t)std::min<size_t>((s->sym_words / (size_t)n_chunks) & ~(size_t)(DRAIN - 1), 1u << 30);
+    const int n_spare = n_chunks > 1 ? std::min(SPARE_REGIONS, n_chunks) : 0;  // (one chunk: nothing to repair, the whole scratch is its region)
+    const uint32_t cap = (uint32_t)std::min<size_t>((s->sym_words / (size_t)(n_chunks + n_spare)) & ~(size_t)(DRAIN - 1), 1u << 30);
     if (cap < 2 * DRAIN) return fail(ctx, EXON_HIP_EINVAL, "gzip: symbol scratch too small");
     const uint64_t n_bits = 8ull * (uint64_t)n_use;
-    s->h_starts[0] = GzStart{s->start_bit, s->start_kind, 0};
-    for (int c = 1; c < n_chunks; ++c) s->h_starts[c] = GzStart{0, START_SEARCH, 0};
-    HIP_TRY(ctx, hipMemcpyAsync(s->d_starts, s->h_starts, (size_t)n_chunks * sizeof(GzStart), hipMemcpyHostToDevice, hs));
-    hipLaunchKernelGGL(k_gz_decode, dim3(n_chunks), dim3(64), 0, hs, reinterpret_cast<const uint32_t*>(d_comp), n_bits, s->chunk_bytes, n_chunks, (const int*)nullptr,
-                       s->d_starts, s->d_sym, cap, s->d_res, s->d_members, final_here ? 1 : 0);
+    const uint64_t chunk_bits = 8ull * s->chunk_bytes;
+    for (int c = 0; c < n_chunks; ++c) {
+      const uint64_t stop = c + 1 < n_chunks ? (uint64_t)(c + 1) * chunk_bits : ~0ull;
+      s->h_tasks[c] = c == 0 ? GzTask{s->start_bit, stop, s->start_kind, 0} : GzTask{(uint64_t)c * chunk_bits, stop, START_SEARCH, (uint32_t)c};
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(s->d_tasks, s->h_tasks, (size_t)n_chunks * sizeof(GzTask), hipMemcpyHostToDevice, hs));
+    hipLaunchKernelGGL(k_gz_decode, dim3(n_chunks), dim3(64), 0, hs, reinterpret_cast<const uint32_t*>(d_comp), n_bits, (const GzTask*)s->d_tasks, s->d_sym, cap, s->d_res, s->d_members,
+                       final_here ? 1 : 0);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(s->h_res, s->d_res, (size_t)n_chunks * sizeof(GzChunk), hipMemcpyDeviceToHost, hs));
     HIP_TRY(ctx, hipStreamSynchronize(hs));
     s->stats.chunks += n_chunks;
-    // the chain: chunk i + 1 must have started where chunk i stopped
+    // The chain: chunk i + 1 must have started where chunk i stopped.  `chain` lists REGIONS in stream order.
     std::vector<int> chain;
     uint64_t cur = s->start_bit;
     bool overflow = false, at_end = false;
     uint32_t bad = GZ_OK;
-    const uint64_t chunk_bits = 8ull * s->chunk_bytes;
+    int spares = 0;
+    const bool trace = getenv("EXON_HIP_GZ_TRACE") != nullptr;
+    // one more wavefront: decode from `bit` up to `stop` into `region`
+    auto redo = [&](uint64_t bit, uint64_t stop, int region) -> int {
+      s->h_tasks[region] = GzTask{bit, stop, START_BLOCK, (uint32_t)region};
+      HIP_TRY(ctx, hipMemcpyAsync(s->d_tasks + region, s->h_tasks + region, sizeof(GzTask), hipMemcpyHostToDevice, hs));
+      hipLaunchKernelGGL(k_gz_decode, dim3(1), dim3(64), 0, hs, reinterpret_cast<const uint32_t*>(d_comp), n_bits, (const GzTask*)(s->d_tasks + region), s->d_sym, cap, s->d_res,
+                         s->d_members, final_here ? 1 : 0);
+      HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipMemcpyAsync(s->h_res + region, s->d_res + region, sizeof(GzChunk), hipMemcpyDeviceToHost, hs));
+      HIP_TRY(ctx, hipStreamSynchronize(hs));
+      ++s->stats.repairs;
+      return EXON_HIP_OK;
+    };
     for (int c = 0; c < n_chunks && !at_end; ++c) {
-      if (c > 0 && cur >= (uint64_t)(c + 1) * chunk_bits) continue;  // the chunk in front decoded through this one's whole range
-      GzChunk& r = s->h_res[c];
-      const bool fits = (r.status == GZ_OK || r.status == GZ_SYM_OVERFLOW) && r.start_bit == cur;
-      if (c > 0 && !fits) {
-        // not proven (a false start, or no dynamic header in its range): decode it from the proven position
-        s->h_starts[c] = GzStart{cur, START_BLOCK, 0};
-        s->h_todo[0] = c;
-        HIP_TRY(ctx, hipMemcpyAsync(s->d_starts + c, s->h_starts + c, sizeof(GzStart), hipMemcpyHostToDevice, hs));
-        HIP_TRY(ctx, hipMemcpyAsync(s->d_todo, s->h_todo, sizeof(int), hipMemcpyHostToDevice, hs));
-        hipLaunchKernelGGL(k_gz_decode, dim3(1), dim3(64), 0, hs, reinterpret_cast<const uint32_t*>(d_comp), n_bits, s->chunk_bytes, n_chunks, (const int*)s->d_todo, s->d_starts,
-                           s->d_sym, cap, s->d_res, s->d_members, final_here ? 1 : 0);
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipMemcpyAsync(&r, s->d_res + c, sizeof(GzChunk), hipMemcpyDeviceToHost, hs));
-        HIP_TRY(ctx, hipStreamSynchronize(hs));
-        ++s->stats.repairs;
+      const uint64_t stop = c + 1 < n_chunks ? (uint64_t)(c + 1) * chunk_bits : ~0ull;
+      if (c > 0 && cur >= stop) continue;  // the chunk in front decoded through this one's whole range
+      int region = c;
+      const GzChunk found = s->h_res[c];
+      const bool usable = found.status == GZ_OK || found.status == GZ_SYM_OVERFLOW;
+      if (c > 0 && !(usable && found.start_bit == cur)) {
+        // Not proven.  Either the search skipped what stands at the chain's position (an empty stored block of a full flush, a fixed
+        // block, the stream's last block: it only looks for dynamic headers) and found the next header behind it -- then the GAP is
+        // decoded into a spare region and, when it ends exactly where this chunk began, both stand -- or the chunk began somewhere
+        // false (or nowhere): it is decoded again from the proven position.
+        if (trace)
+          fprintf(stderr, "[exon-hip gz] repair: chunk %d of %d began at %llu (status %u flags %u n_out %u end %llu), the chain is at %llu\n", c, n_chunks,
+                  (unsigned long long)found.start_bit, found.status, found.flags, found.n_out, (unsigned long long)found.end_bit, (unsigned long long)cur);
+        bool spliced = false;
+        if (usable && found.start_bit > cur && found.start_bit - cur <= chunk_bits && spares < n_spare) {
+          const int gap = n_chunks + spares;  // (the regions right behind this call's chunks)
+          const int rc = redo(cur, found.start_bit, gap);
+          if (rc) return rc;
+          const GzChunk& g = s->h_res[gap];
+          if (g.status == GZ_OK && g.flags == 0 && g.end_bit == found.start_bit) {
+            ++spares;
+            chain.push_back(gap);
+            spliced = true;
+          }
+        }
+        if (!spliced) {
+          const int rc = redo(cur, stop, c);
+          if (rc) return rc;
+        }
       }
+      const GzChunk& r = s->h_res[region];
       if (r.status == GZ_SYM_OVERFLOW) {
         overflow = true;
         break;
@@ -1137,7 +1169,7 @@ int exon_hip_gzip_stream_decode(exon_hip_gzip_stream* s, void* stream, const uin
         bad = r.status;
         break;
       }
-      chain.push_back(c);
+      chain.push_back(region);
       cur = r.end_bit;
       if (r.flags & (F_EXHAUSTED | F_STREAM_END)) at_end = true;
     }
@@ -1152,9 +1184,9 @@ int exon_hip_gzip_stream_decode(exon_hip_gzip_stream* s, void* stream, const uin
     }
     if (overflow && n_acc == 0) {
       // a chunk's symbols did not fit its region: fewer chunks share the scratch next time
-      ++s->stats.overflow_retries;
-      n_use = std::max<int64_t>((int64_t)s->chunk_bytes, (n_use / 4) & ~(int64_t)(s->chunk_bytes - 1));
       if (n_chunks == 1) return fail(ctx, EXON_HIP_EINVAL, "gzip stream: one chunk inflates to more than the symbol scratch holds");
+      ++s->stats.overflow_retries;
+      n_use = std::min<int64_t>(n_use, std::max<int64_t>((int64_t)s->chunk_bytes, (n_use / 4) & ~(int64_t)(s->chunk_bytes - 1)));
       continue;
     }
     if (n_acc == 0) {
@@ -1193,7 +1225,7 @@ int exon_hip_gzip_stream_decode(exon_hip_gzip_stream* s, void* stream, const uin
     std::vector<std::pair<uint64_t, const GzMember*>> ends;  // (absolute output offset of a member end, its trailer)
     if (s->verify_crc) {
       if (total_members) {
-        HIP_TRY(ctx, hipMemcpyAsync(s->h_members, s->d_members, (size_t)n_chunks * MAX_MEMBER_ENDS * sizeof(GzMember), hipMemcpyDeviceToHost, hs));
+        HIP_TRY(ctx, hipMemcpyAsync(s->h_members, s->d_members, ((size_t)n_chunks + SPARE_REGIONS) * MAX_MEMBER_ENDS * sizeof(GzMember), hipMemcpyDeviceToHost, hs));
         HIP_TRY(ctx, hipStreamSynchronize(hs));
         for (size_t a = 0; a < n_acc; ++a) {
           const GzChunk& r = s->h_res[chain[a]];
