@@ -1088,20 +1088,23 @@ int exon_hip_gzip_stream_decode(exon_hip_gzip_stream* s, void* stream, const uin
     return EXON_HIP_OK;
   }
   if (!d_comp || !d_out) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_gzip_stream_decode: NULL buffer");
-  if (reinterpret_cast<uintptr_t>(d_comp) & 3) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_gzip_stream_decode: d_comp must be 4-byte aligned");
+  // the bit reader takes aligned dwords: positions are counted from the aligned address at or below d_comp
+  const uint32_t lead = (uint32_t)(reinterpret_cast<uintptr_t>(d_comp) & 3);
+  d_comp -= lead;
   hipStream_t hs = pick_stream(ctx, stream);
-  int64_t n_use = std::min<int64_t>(n_comp, (int64_t)(s->max_chunks - 1) * s->chunk_bytes);
+  int64_t n_use = std::min<int64_t>(n_comp, (int64_t)(s->max_chunks - 1) * s->chunk_bytes - 4);
   for (int attempt = 0; attempt < 6; ++attempt) {
     const bool final_here = final_input && n_use == n_comp;
-    const int n_chunks = (int)((n_use + s->chunk_bytes - 1) / s->chunk_bytes);
+    const int n_chunks = (int)((lead + n_use + s->chunk_bytes - 1) / s->chunk_bytes);
     const int n_spare = n_chunks > 1 ? std::min(SPARE_REGIONS, n_chunks) : 0;  // (one chunk: nothing to repair, the whole scratch is its region)
     const uint32_t cap = (uint32_t)std::min<size_t>((s->sym_words / (size_t)(n_chunks + n_spare)) & ~(size_t)(DRAIN - 1), 1u << 30);
     if (cap < 2 * DRAIN) return fail(ctx, EXON_HIP_EINVAL, "gzip: symbol scratch too small");
-    const uint64_t n_bits = 8ull * (uint64_t)n_use;
+    const uint64_t n_bits = 8ull * (uint64_t)(lead + n_use);
     const uint64_t chunk_bits = 8ull * s->chunk_bytes;
+    const uint64_t first_bit = 8ull * lead + s->start_bit;
     for (int c = 0; c < n_chunks; ++c) {
       const uint64_t stop = c + 1 < n_chunks ? (uint64_t)(c + 1) * chunk_bits : ~0ull;
-      s->h_tasks[c] = c == 0 ? GzTask{s->start_bit, stop, s->start_kind, 0} : GzTask{(uint64_t)c * chunk_bits, stop, START_SEARCH, (uint32_t)c};
+      s->h_tasks[c] = c == 0 ? GzTask{first_bit, stop, s->start_kind, 0} : GzTask{(uint64_t)c * chunk_bits, stop, START_SEARCH, (uint32_t)c};
     }
     HIP_TRY(ctx, hipMemcpyAsync(s->d_tasks, s->h_tasks, (size_t)n_chunks * sizeof(GzTask), hipMemcpyHostToDevice, hs));
     hipLaunchKernelGGL(k_gz_decode, dim3(n_chunks), dim3(64), 0, hs, reinterpret_cast<const uint32_t*>(d_comp), n_bits, (const GzTask*)s->d_tasks, s->d_sym, cap, s->d_res, s->d_members,
@@ -1112,7 +1115,7 @@ int exon_hip_gzip_stream_decode(exon_hip_gzip_stream* s, void* stream, const uin
     s->stats.chunks += n_chunks;
     // The chain: chunk i + 1 must have started where chunk i stopped.  `chain` lists REGIONS in stream order.
     std::vector<int> chain;
-    uint64_t cur = s->start_bit;
+    uint64_t cur = first_bit;
     bool overflow = false, at_end = false;
     uint32_t bad = GZ_OK;
     int spares = 0;
@@ -1278,7 +1281,7 @@ int exon_hip_gzip_stream_decode(exon_hip_gzip_stream* s, void* stream, const uin
     }
     s->win_k ^= 1;
     const uint64_t end_bit = last.end_bit;
-    *consumed = (int64_t)(end_bit >> 3);
+    *consumed = (int64_t)(end_bit >> 3) - (int64_t)lead;
     *produced = (int64_t)off;
     s->start_bit = (uint32_t)(end_bit & 7);
     s->start_kind = (last.flags & F_AT_MEMBER) ? START_MEMBER : START_BLOCK;

@@ -759,10 +759,11 @@ class GpuTextSource {
     }
     gap_ = gz_ ? std::max<size_t>(text_cap_ / 16, 16u << 20) : std::max<size_t>(text_cap_ / 4, 1u << 20);  // room for the carried tail (< 1 record + 1 line)
   }
-  // Plain-gzip slabs are cut by OUTPUT bytes: 256 MiB of text per slab (32 KiB chunks: a slab of ~64 MiB of compressed bytes is
-  // ~2000 wavefronts' worth of chunks).  EXON_HIP_GZ_SLAB_MB overrides.
+  // Plain-gzip slabs are cut by OUTPUT bytes: 512 MiB of text per slab = ~4000 chunks of 64 KiB at FASTQ's ratio of 2, one per
+  // wavefront slot of the decode kernel (17 per CU); 20 M-read .fastq.gz: 256 MiB 517 ms, 512 MiB 380 ms, 1 GiB 343 ms
+  // (profiles/r6_plain_gzip.log).  EXON_HIP_GZ_SLAB_MB overrides.
   static size_t gz_slab_bytes() {
-    size_t slab = (size_t)256 << 20;
+    size_t slab = (size_t)512 << 20;
     if (const char* v = getenv("EXON_HIP_GZ_SLAB_MB")) {
       const long mb = atol(v);
       if (mb >= 1 && mb <= 4096) slab = (size_t)mb << 20;
@@ -772,6 +773,7 @@ class GpuTextSource {
   ~GpuTextSource() {
     const double td0 = now_s();
     if (reader_.joinable()) reader_.join();
+    if (gz_pref_.joinable()) gz_pref_.join();
     // fill() starts the next piece's read before the H2D copy and the header walk, either of which may throw: a read may still
     // be in flight into the pinned ring that is handed back to the cache (or freed) below -- wait for it first
     (void)rd_.finish();
@@ -789,6 +791,8 @@ class GpuTextSource {
       }
       exon_hip_gzip_stream_destroy(gzs_);
     }
+    if (ev_gz_tail_) hipEventDestroy(ev_gz_tail_);
+    if (ev_gz_pref_) hipEventDestroy(ev_gz_pref_);
     if (getenv("EXON_HIP_PIPE_TRACE"))
       fprintf(stderr, "[exon-hip pipe] teardown: reader join %.1f ms, stream sync %.1f ms; reader: busy %.1f ms = file reads %.1f ms + pieces %.1f ms (next piece's start %.1f, copy calls %.1f, header walk %.1f) + "
               "leftovers %.1f ms + the rest; thread start lag %.1f ms; consumer waited %.1f ms for inflates, %.1f ms for the reader\n",
@@ -880,7 +884,7 @@ class GpuTextSource {
         if (k == 0 && !h_ring_ && hipHostMalloc((void**)&h_ring_, (size_t)RING_N * (RING_HEAD + RING_PIECE)) != hipSuccess)
           return fail(ctx_, EXON_HIP_ENOMEM, "pinned staging ring could not be allocated");
         const double a1 = now_s();
-        if (hipMalloc((void**)&d_text_[k], gap_ + text_cap_ + 256) != hipSuccess || ((bgzf_ || gz_) && hipMalloc((void**)&d_comp_[k], comp_cap_ + 8192) != hipSuccess))
+        if (hipMalloc((void**)&d_text_[k], gap_ + text_cap_ + 256) != hipSuccess || ((bgzf_ || gz_) && hipMalloc((void**)&d_comp_[k], comp_cap_ + (gz_ ? GZ_RESERVE : 0) + 8192) != hipSuccess))
           return fail(ctx_, EXON_HIP_ENOMEM, "slab buffers (%zu bytes of text) could not be allocated", text_cap_);
         t_host += a1 - a0;
         t_dev += now_s() - a1;
@@ -900,7 +904,7 @@ class GpuTextSource {
     int prio_least = 0, prio_greatest = 0;
     const char* pv = getenv("EXON_HIP_STREAM_PRIORITY");
     const bool use_prio = !(pv && pv[0] == '0') && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess && prio_least != prio_greatest;
-    if ((bgzf_ && !cs_ && (use_prio ? hipStreamCreateWithPriority(&cs_, hipStreamNonBlocking, prio_least) : hipStreamCreateWithFlags(&cs_, hipStreamNonBlocking)) != hipSuccess) ||
+    if (((bgzf_ || gz_) && !cs_ && (use_prio ? hipStreamCreateWithPriority(&cs_, hipStreamNonBlocking, prio_least) : hipStreamCreateWithFlags(&cs_, hipStreamNonBlocking)) != hipSuccess) ||
         (!xs_ && hipStreamCreateWithFlags(&xs_, hipStreamNonBlocking) != hipSuccess))
       return fail(ctx_, EXON_HIP_EDEVICE, "stream creation failed");
     for (int k = 0; k < 2; ++k)
@@ -926,8 +930,10 @@ class GpuTextSource {
     }
     if (carry_.size() > gap_) return 1;  // the host reader had buffered more than the gap holds: host decoder
     if (gz_) {
+      if (hipEventCreateWithFlags(&ev_gz_tail_, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_gz_pref_, hipEventDisableTiming) != hipSuccess)
+        return fail(ctx_, EXON_HIP_EDEVICE, "event creation failed");
       // symbol scratch: 2 bytes per byte of a slab's text, and a quarter more for the chunks the text buffer turns away
-      const int rcg = exon_hip_gzip_stream_create(ctx_, (int64_t)comp_cap_, (int64_t)(2 * text_cap_ + text_cap_ / 2), &gzs_);
+      const int rcg = exon_hip_gzip_stream_create(ctx_, (int64_t)(comp_cap_ + GZ_RESERVE), (int64_t)(2 * text_cap_ + text_cap_ / 2), &gzs_);
       if (rcg) return rcg;
     }
     fill(0, &cur_);
@@ -948,6 +954,7 @@ class GpuTextSource {
     if (cur_.err) {
       try { std::rethrow_exception(cur_.err); } catch (const std::exception& e) {
         fail(ctx_, EXON_HIP_EINVAL, "%s%s", e.what(), gz_ ? " (decoding on the host instead)" : "");
+        if (gz_ && getenv("EXON_HIP_PIPE_TRACE")) fprintf(stderr, "[exon-hip pipe] gzip on the GPU gave up: %s\n", e.what());
         return gz_ ? 1 : EXON_HIP_EINVAL;  // gzip on the GPU: whatever does not prove goes to the host reader, which reports what the reference's decoder would
       }
     }
@@ -1336,67 +1343,135 @@ class GpuTextSource {
   // Plain gzip: [compressed tail of the previous slab (device to device) | fresh bytes through the pinned ring] -> d_comp_, inflated by
   // exon_hip_gzip_stream_decode on the copy stream straight into d_text_[k] behind the gap.  The decode takes whole DEFLATE blocks
   // while their text fits; what it did not use opens the next slab.  The compressed bytes per slab follow the running ratio.
+  // While a slab is being decoded a helper thread already reads the NEXT slab's fresh bytes and copies them (on a stream of their
+  // own) behind a reserve at the front of the other compressed buffer; the tail of this slab is then placed right in front of them.
+  static constexpr size_t GZ_RESERVE = 32u << 20;
+  // file -> pinned ring -> d_comp_[kc] + at, up to `want` bytes, copies on stream `cp`; returns the bytes that arrived
+  size_t gz_read(int kc, size_t at, size_t want, hipStream_t cp) {
+    struct Piece {
+      bool active = false;
+      int p = 0;
+      uint8_t* base = nullptr;
+      size_t want = 0;
+    };
+    size_t got_total = 0;
+    auto start_piece = [&](size_t done) {
+      Piece pc;
+      if (done >= want || file_eof_) return pc;
+      pc.p = ring_next_;
+      ring_next_ = (pc.p + 1) % RING_N;
+      if (piece_used_[pc.p] && hipEventSynchronize(ev_piece_[pc.p]) != hipSuccess) throw std::runtime_error("staging ring: event wait failed");
+      pc.base = h_ring_ + (size_t)pc.p * (RING_HEAD + RING_PIECE) + RING_HEAD;
+      pc.want = std::min(RING_PIECE, want - done);
+      rd_.begin(pc.base, pc.want);
+      pc.active = true;
+      return pc;
+    };
+    Piece cur = start_piece(0);
+    size_t begun = cur.active ? cur.want : 0;
+    while (cur.active) {
+      const size_t got = rd_.finish();
+      if (got < cur.want) file_eof_ = true;
+      Piece nxt;
+      if (!file_eof_) {
+        nxt = start_piece(begun);
+        if (nxt.active) begun += nxt.want;
+      }
+      if (got == 0) break;
+      if (hipMemcpyAsync(d_comp_[kc] + at + got_total, cur.base, got, hipMemcpyHostToDevice, cp) != hipSuccess || hipEventRecord(ev_piece_[cur.p], cp) != hipSuccess)
+        throw std::runtime_error("H2D of a compressed piece failed");
+      piece_used_[cur.p] = true;
+      got_total += got;
+      cur = nxt;
+    }
+    return got_total;
+  }
   void fill_gz(int k, Filled* f) {
     hipSetDevice(ctx_->device);
     if (free_rec_[k] && hipStreamWaitEvent(xs_, ev_free_[k], 0) != hipSuccess) throw std::runtime_error("gzip slab: event wait failed");
     f->front_extra = 0;
     const int kc = (int)(gz_fills_++ & 1);
-    size_t off = 0;
-    if (gz_tail_len_) {
-      if (hipMemcpyAsync(d_comp_[kc], d_comp_[kc ^ 1] + gz_tail_off_, gz_tail_len_, hipMemcpyDeviceToDevice, xs_) != hipSuccess) throw std::runtime_error("gzip slab: carry copy failed");
+    // the helper's bytes: d_comp_[kc] + GZ_RESERVE ..
+    size_t pre = 0;
+    if (gz_pref_.joinable()) {
+      gz_pref_.join();
+      if (gz_pref_err_) std::rethrow_exception(gz_pref_err_);
+      pre = gz_pref_len_;
+      gz_pref_len_ = 0;
+      if (hipStreamWaitEvent(xs_, ev_gz_pref_, 0) != hipSuccess) throw std::runtime_error("gzip slab: event wait failed");
+    }
+    size_t start = 0, off = 0;  // the slab's bytes are d_comp_[kc] + [start, off)
+    if (pre && gz_tail_len_ <= GZ_RESERVE) {
+      start = GZ_RESERVE - gz_tail_len_;
+      off = GZ_RESERVE + pre;
+      if (gz_tail_len_ && hipMemcpyAsync(d_comp_[kc] + start, d_comp_[kc ^ 1] + gz_tail_off_, gz_tail_len_, hipMemcpyDeviceToDevice, xs_) != hipSuccess)
+        throw std::runtime_error("gzip slab: carry copy failed");
+    } else {
+      if (pre) {  // the tail is larger than the reserve (a slab whose text did not fit): the helper's bytes are read again behind it
+        rd_.foff -= (int64_t)pre;
+        file_eof_ = false;
+      }
+      if (gz_tail_len_ && hipMemcpyAsync(d_comp_[kc], d_comp_[kc ^ 1] + gz_tail_off_, gz_tail_len_, hipMemcpyDeviceToDevice, xs_) != hipSuccess)
+        throw std::runtime_error("gzip slab: carry copy failed");
       off = gz_tail_len_;
     }
-    size_t goal = std::min(comp_cap_, std::max(off + (1u << 20), gz_target_));
+    if (hipEventRecord(ev_gz_tail_, xs_) != hipSuccess) throw std::runtime_error("gzip slab: event record failed");  // (the other buffer may be overwritten behind this)
+    size_t goal = std::min(gz_room(), std::max(off - start + (1u << 20), gz_target_));
+    bool helper_started = false;
     for (;;) {
       const double tr0 = now_s();
-      struct Piece {
-        bool active = false;
-        int p = 0;
-        uint8_t* base = nullptr;
-        size_t want = 0;
-      };
-      auto start_piece = [&](size_t at_off) {
-        Piece pc;
-        if (at_off >= goal || file_eof_) return pc;
-        pc.p = ring_next_;
-        ring_next_ = (pc.p + 1) % RING_N;
-        if (piece_used_[pc.p] && hipEventSynchronize(ev_piece_[pc.p]) != hipSuccess) throw std::runtime_error("staging ring: event wait failed");
-        pc.base = h_ring_ + (size_t)pc.p * (RING_HEAD + RING_PIECE) + RING_HEAD;
-        pc.want = std::min(RING_PIECE, goal - at_off);
-        rd_.begin(pc.base, pc.want);
-        pc.active = true;
-        return pc;
-      };
-      Piece cur = start_piece(off);
-      while (cur.active) {
-        const size_t got = rd_.finish();
-        if (got < cur.want) file_eof_ = true;
-        Piece nxt;
-        if (!file_eof_) nxt = start_piece(off + got);
-        if (got == 0) break;
-        if (hipMemcpyAsync(d_comp_[kc] + off, cur.base, got, hipMemcpyHostToDevice, xs_) != hipSuccess || hipEventRecord(ev_piece_[cur.p], xs_) != hipSuccess)
-          throw std::runtime_error("H2D of a compressed piece failed");
-        piece_used_[cur.p] = true;
-        off += got;
-        cur = nxt;
-      }
+      if (off - start < goal && off < gz_room()) off += gz_read(kc, off, std::min(goal - (off - start), gz_room() - off), xs_);  // (never beyond the buffer)
       if (hipMemsetAsync(d_comp_[kc] + off, 0, 4096, xs_) != hipSuccess) throw std::runtime_error("padding of a compressed slab failed");
       const double tr1 = now_s();
       t_gz_read_ += tr1 - tr0;
       t_read_ += tr1 - tr0;
+      if (!file_eof_ && !helper_started && gz_prefetch_enabled()) {
+        // the next slab's fresh bytes, under this slab's decode
+        helper_started = true;
+        const size_t want = std::min(gz_room() - GZ_RESERVE, gz_target_);
+        gz_pref_err_ = nullptr;
+        gz_pref_ = std::thread([this, kc, want] {
+          try {
+            run_on(local_cpus_);
+            hipSetDevice(ctx_->device);
+            if (hipStreamWaitEvent(cs_, ev_gz_tail_, 0) != hipSuccess) throw std::runtime_error("gzip slab: event wait failed");
+            gz_pref_len_ = gz_read(kc ^ 1, GZ_RESERVE, want, cs_);
+            if (hipEventRecord(ev_gz_pref_, cs_) != hipSuccess) throw std::runtime_error("gzip slab: event record failed");
+          } catch (...) {
+            gz_pref_err_ = std::current_exception();
+          }
+        });
+      }
       int64_t consumed = 0, produced = 0;
       int32_t ended = 0;
-      const int rc = exon_hip_gzip_stream_decode(gzs_, xs_, d_comp_[kc], (int64_t)off, file_eof_ ? 1 : 0, d_text_[k] + gap_, (int64_t)text_cap_, &consumed, &produced, &ended);
+      const bool final_in = !gz_pref_.joinable() && file_eof_;  // (while the helper runs, file_eof_ is its to write)
+      const int rc = exon_hip_gzip_stream_decode(gzs_, xs_, d_comp_[kc] + start, (int64_t)(off - start), final_in ? 1 : 0, d_text_[k] + gap_, (int64_t)text_cap_, &consumed, &produced,
+                                                 &ended);
       t_gz_decode_ += now_s() - tr1;
       if (rc) throw std::runtime_error(exon_hip_last_error(ctx_));
       if (!ended && consumed == 0 && produced == 0) {
         // not one whole block in these bytes: take more (a block larger than the largest slab is the host reader's)
-        if (file_eof_ || goal >= comp_cap_) throw std::runtime_error("gzip: a DEFLATE block larger than a slab");
-        goal = std::min(comp_cap_, goal * 2);
+        if (gz_pref_.joinable()) {  // the helper holds the file's next bytes: they go behind this slab's
+          gz_pref_.join();
+          if (gz_pref_err_) std::rethrow_exception(gz_pref_err_);
+          const size_t m = std::min(gz_pref_len_, gz_room() - off);
+          if (m < gz_pref_len_) {
+            rd_.foff -= (int64_t)(gz_pref_len_ - m);
+            file_eof_ = false;
+          }
+          if (hipStreamWaitEvent(xs_, ev_gz_pref_, 0) != hipSuccess || (m && hipMemcpyAsync(d_comp_[kc] + off, d_comp_[kc ^ 1] + GZ_RESERVE, m, hipMemcpyDeviceToDevice, xs_) != hipSuccess))
+            throw std::runtime_error("gzip slab: carry copy failed");
+          off += m;
+          gz_pref_len_ = 0;
+          goal = std::max(goal, off - start);
+          if (m) continue;
+        }
+        if (file_eof_ || off >= gz_room() || goal >= gz_room() - start) throw std::runtime_error("gzip: a DEFLATE block larger than a slab");
+        goal = std::min(gz_room() - start, goal * 2);
         continue;
       }
-      gz_tail_off_ = (size_t)consumed;
-      gz_tail_len_ = off - (size_t)consumed;
+      gz_tail_off_ = start + (size_t)consumed;
+      gz_tail_len_ = off - start - (size_t)consumed;
       if (consumed > 0 && produced > 0) {
         const double ratio = (double)produced / (double)consumed;
         gz_target_ = (size_t)std::min<double>((double)comp_cap_, std::max<double>(4 << 20, 0.9 * (double)text_cap_ / ratio));
@@ -1413,11 +1488,23 @@ class GpuTextSource {
       return;
     }
   }
+  size_t gz_room() const { return comp_cap_ + GZ_RESERVE; }  // bytes a compressed buffer holds (4096 of padding follow)
+  static bool gz_prefetch_enabled() {
+    static const bool on = [] {
+      const char* v = getenv("EXON_HIP_GZ_PREFETCH");
+      return !(v && v[0] == '0');
+    }();
+    return on;
+  }
   exon_hip_gzip_stream* gzs_ = nullptr;
   uint64_t gz_fills_ = 0;
   size_t gz_tail_off_ = 0, gz_tail_len_ = 0;
   size_t gz_target_ = 16u << 20;  // compressed bytes of the next slab (the first one is small: the GPU starts early)
   double t_gz_decode_ = 0, t_gz_read_ = 0;
+  std::thread gz_pref_;
+  size_t gz_pref_len_ = 0;
+  std::exception_ptr gz_pref_err_;
+  hipEvent_t ev_gz_tail_ = nullptr, ev_gz_pref_ = nullptr;
 
   exon_hip_bgzf_block* h_blocks_tmp(int k) {
     scan_tmp_[k].resize((size_t)max_blocks_);

@@ -489,8 +489,8 @@ typedef struct exon_hip_gzip_stats {
 /* max_comp_bytes: the most compressed bytes one decode call is given; scratch_bytes: symbol scratch (2 bytes per output byte of a
  * call; 0 = 16 x max_comp_bytes, at least 64 MiB -- a call whose chunks overflow their share is repeated on a quarter of the slab) */
 int exon_hip_gzip_stream_create(exon_hip_ctx* ctx, int64_t max_comp_bytes, int64_t scratch_bytes, exon_hip_gzip_stream** out);
-/* d_comp: 4-byte aligned device memory, n_comp bytes that start at the byte the previous call stopped in (the file's first byte for
- * the first call) with 4096 readable bytes behind them; final_input: these are the file's last bytes.  Decodes whole DEFLATE blocks
+/* d_comp: device memory (any alignment; the up to 3 bytes in front of it down to the 4-byte boundary must be readable), n_comp bytes
+ * that start at the byte the previous call stopped in (the file's first byte for the first call) with 4096 readable bytes behind them; final_input: these are the file's last bytes.  Decodes whole DEFLATE blocks
  * while their output fits out_cap; *consumed = compressed bytes used up (pass the rest again in front of the next bytes; the bit
  * position inside the first byte is the stream's business), *produced = bytes written to d_out, *stream_end = 1 once the last
  * member's trailer has been checked at the end of the input.  Synchronises `stream`. */

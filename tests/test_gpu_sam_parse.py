@@ -73,7 +73,8 @@ def test_sam_file_to_gpu_pipeline_equals_host_decode(ctx, tmp_path, monkeypatch,
 
 def test_sam_bgzf_is_inflated_and_parsed_on_the_gpu(ctx, tmp_path, monkeypatch):
     """bgzip-compressed SAM: the blocks are inflated by inflate.hip and the text never visits the host; a plain gzip
-    member (not BGZF) is inflated by the host reader and still parsed on the device."""
+    member (not BGZF) is inflated on the GPU as well since round 6 (gzip_stream.hip) -- and by the host reader, still parsed on the
+    device, with EXON_HIP_GPU_GZIP=0."""
     import gzip
     n = 100_000
     path = tmp_path / "syn.sam"
@@ -87,8 +88,11 @@ def test_sam_bgzf_is_inflated_and_parsed_on_the_gpu(ctx, tmp_path, monkeypatch):
     plain_gz = tmp_path / "member.sam.gz"
     with gzip.open(plain_gz, "wb", compresslevel=1) as f:
         f.write(open(path, "rb").read())
-    g2 = _k3(ctx, plain_gz, True, compression="gzip", inflated=False)
+    g2 = _k3(ctx, plain_gz, True, compression="gzip", inflated=True)
     assert g2[0] == n and np.array_equal(g2[1], h[1])
+    monkeypatch.setenv("EXON_HIP_GPU_GZIP", "0")
+    g3 = _k3(ctx, plain_gz, True, compression="gzip", inflated=False)
+    assert g3[0] == n and np.array_equal(g3[1], h[1])
 
 
 def test_sam_lines_the_device_cannot_decide_fall_back(ctx, tmp_path):
