@@ -124,6 +124,8 @@ REGION_OPEN_END = 2**63 - 1
 _vp, _i32, _i64, _u64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
 _colp = C.POINTER(Column)
 
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)  # exon_hip_allgather_fn
+
 # every symbol include/exon_hip.h declares: (restype, argtypes)
 SIGNATURES = {
     "exon_hip_abi_version": (C.c_int, []),
@@ -164,6 +166,8 @@ SIGNATURES = {
     "exon_hip_rccl_unique_id": (C.c_int, [_vp]),
     "exon_hip_rccl_comm_init": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_vp)]),
     "exon_hip_rccl_comm_destroy": (C.c_int, [_vp]),
+    "exon_hip_comm_wrap_rccl": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "exon_hip_comm_from_callbacks": (C.c_int, [_i32, _i32, ALLGATHER_FN, _vp, C.POINTER(_vp)]),
     "exon_hip_rccl_comm_count": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "exon_hip_stream_reset": (C.c_int, [_vp]),
     "exon_hip_stream_open": (C.c_int, [_vp, _i32, C.POINTER(_vp)]),

@@ -18,6 +18,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -122,6 +123,7 @@ struct exon_hip_stream {
   int32_t region_id_override = INT32_MIN;
 };
 enum { KEYS_NONE = 0, KEYS_LOCAL = 1, KEYS_AGREED = 2 };
+constexpr size_t COLL_SCRATCH = 8192;  // device words for the collectives' votes (up to 511 ranks x 16 bytes), allocated with the state
 constexpr int64_t HOLD_MAX_ROWS = 1 << 17;  // batches up to this many rows are held until their slot is flushed
 
 // keyed layout of a plan's packed state: [planes_i x G int64][tail int64][planes_f x G float64]
@@ -636,7 +638,8 @@ int exon_hip_stream_open(exon_hip_plan* plan, int32_t partition, exon_hip_stream
   const bool use_prio = !(pv && pv[0] == '0') && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess && prio_least != prio_greatest;
   if ((e = use_prio ? hipStreamCreateWithPriority(&st->stream, hipStreamNonBlocking, prio_greatest)
                     : hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking)) != hipSuccess ||
-      (e = hipMalloc((void**)&st->d_state, sbytes)) != hipSuccess ||
+      // (+ COLL_SCRATCH bytes behind the state: the votes of the collectives -- a rank that is out of memory can still say so)
+      (e = hipMalloc((void**)&st->d_state, ((sbytes + 63) & ~(size_t)63) + COLL_SCRATCH)) != hipSuccess ||
       (e = hipMemsetAsync(st->d_state, 0, sbytes, st->stream)) != hipSuccess) {
     if (st->stream) hipStreamDestroy(st->stream);
     if (st->d_state) hipFree(st->d_state);
@@ -1085,6 +1088,123 @@ constexpr size_t GATHER_MERGE_MAX_STATE = 1 << 20;  // larger states (K3 with mi
 
 extern "C" {
 
+// ---- communicators ----------------------------------------------------------------------------------------------------------
+// The handle the collectives take (exon_hip_rccl_comm_init, exon_hip_comm_from_callbacks) wraps one of two transports:
+//   RCCL       ncclAllGather / ncclAllReduce on the stream's hipStream_t (the product path: one process per GPU over xGMI);
+//   callbacks  an all-gather over HOST buffers supplied by the caller (torch.distributed / gloo, MPI, a Rust host's own runtime):
+//              the same vote / reconcile / merge logic runs on machines where RCCL cannot form the communicator -- e.g. several
+//              ranks on ONE GPU, which is how tests/test_collective_faults.py drives 2 and 8 ranks through every failure path.
+// Every collective entry point VOTES first: each rank contributes one word (0, or why it cannot go on), all ranks see all words,
+// and either all go on or all return the same error.  No rank-local early return sits between two collectives.
+struct ExonComm {
+  uint32_t magic = 0x45584343u;  // "EXCC"
+  int kind = 0;                  // 0 RCCL, 1 callbacks
+  void* nccl = nullptr;
+  int world = 1, rank = 0;
+  exon_hip_allgather_fn fn = nullptr;
+  void* user = nullptr;
+  bool aborted = false;
+  bool owned = true;  // the ncclComm_t was made by exon_hip_rccl_comm_init (destroyed with the handle); false: the caller's own
+};
+static ExonComm* comm_of(void* h) {
+  ExonComm* c = static_cast<ExonComm*>(h);
+  return c && c->magic == 0x45584343u ? c : nullptr;
+}
+// EXON_HIP_FAULT="site@rank[,site@rank...]": the named site fails on that rank (tests of the fail-together paths).
+// Sites: reconcile_enter, reconcile_malloc, reconcile_rekey, allreduce_enter, allreduce_malloc, stall (the rank sleeps instead of entering)
+static bool fault_at(const char* site, int rank) {
+  const char* v = getenv("EXON_HIP_FAULT");
+  if (!v || !*v) return false;
+  const std::string all(v);
+  size_t i = 0;
+  while (i < all.size()) {
+    size_t j = all.find(',', i);
+    if (j == std::string::npos) j = all.size();
+    const std::string item = all.substr(i, j - i);
+    const size_t at = item.find('@');
+    if (at != std::string::npos && item.compare(0, at, site) == 0 && atoi(item.c_str() + at + 1) == rank) return true;
+    i = j + 1;
+  }
+  return false;
+}
+static double collective_timeout_s() {
+  const char* v = getenv("EXON_HIP_COLLECTIVE_TIMEOUT_S");
+  const double t = v ? atof(v) : 120.0;
+  return t > 0 ? t : 120.0;
+}
+// hipStreamSynchronize with a bound: a peer that never enters a collective leaves this rank's kernel spinning for ever; after the
+// bound the communicator is aborted (ncclCommAbort) and the call fails.  The communicator is unusable afterwards.
+static int bounded_sync(exon_hip_ctx* ctx, ExonComm* c, hipStream_t s, const char* what) {
+  const double limit = collective_timeout_s();
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; ++spins) {
+    const hipError_t q = hipStreamQuery(s);
+    if (q == hipSuccess) return EXON_HIP_OK;
+    if (q != hipErrorNotReady) return fail(ctx, EXON_HIP_EDEVICE, "%s: %s", what, hipGetErrorString(q));
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (dt > limit) {
+      if (c && c->kind == 0 && c->nccl && !c->aborted) {
+        typedef int (*abort_fn)(void*);
+        if (abort_fn f = (abort_fn)dlsym(rccl().lib, "ncclCommAbort")) (void)f(c->nccl);
+        c->aborted = true;
+        c->nccl = nullptr;
+      }
+      return fail(ctx, EXON_HIP_EDEVICE, "%s: no answer from the other ranks within %.0f s (EXON_HIP_COLLECTIVE_TIMEOUT_S); the communicator was aborted", what, limit);
+    }
+    if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
+// all-gather of `bytes` (a multiple of 8) per rank between DEVICE buffers, enqueued on `s` (callbacks: staged through the host)
+static int comm_all_gather_dev(exon_hip_ctx* ctx, ExonComm* c, hipStream_t s, const void* d_send, void* d_recv, size_t bytes) {
+  if (c->aborted) return fail(ctx, EXON_HIP_ESTATE, "the communicator was aborted by an earlier time-out");
+  if (c->kind == 0) {
+    const int e = rccl().all_gather(d_send, d_recv, bytes / 8, NCCL_INT64, c->nccl, s);
+    return e ? fail(ctx, EXON_HIP_EDEVICE, "ncclAllGather failed with ncclResult_t %d", e) : EXON_HIP_OK;
+  }
+  std::vector<uint8_t> mine(bytes), all(bytes * (size_t)c->world);
+  HIP_TRY(ctx, hipMemcpyAsync(mine.data(), d_send, bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  if (c->fn(c->user, mine.data(), all.data(), bytes)) return fail(ctx, EXON_HIP_EDEVICE, "the caller's all-gather failed");
+  HIP_TRY(ctx, hipMemcpyAsync(d_recv, all.data(), all.size(), hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));  // (pageable staging: `all` must outlive the copy)
+  return EXON_HIP_OK;
+}
+// all-gather of `bytes` (a multiple of 8, world x bytes <= COLL_SCRATCH / 2) per rank between HOST buffers, through `d_scratch`
+static int comm_all_gather_host(exon_hip_ctx* ctx, ExonComm* c, hipStream_t s, uint8_t* d_scratch, const void* h_send, void* h_recv, size_t bytes, const char* what) {
+  if (c->aborted) return fail(ctx, EXON_HIP_ESTATE, "the communicator was aborted by an earlier time-out");
+  if (c->kind == 1) {
+    if (c->fn(c->user, h_send, h_recv, bytes)) return fail(ctx, EXON_HIP_EDEVICE, "%s: the caller's all-gather failed", what);
+    return EXON_HIP_OK;
+  }
+  uint8_t* d_all = d_scratch;
+  uint8_t* d_mine = d_scratch + COLL_SCRATCH / 2;
+  HIP_TRY(ctx, hipMemcpyAsync(d_mine, h_send, bytes, hipMemcpyHostToDevice, s));
+  const int e = rccl().all_gather(d_mine, d_all, bytes / 8, NCCL_INT64, c->nccl, s);
+  if (e) return fail(ctx, EXON_HIP_EDEVICE, "%s: ncclAllGather failed with ncclResult_t %d", what, e);
+  HIP_TRY(ctx, hipMemcpyAsync(h_recv, d_all, bytes * (size_t)c->world, hipMemcpyDeviceToHost, s));
+  return bounded_sync(ctx, c, s, what);
+}
+// The vote: my_code = 0, or an EXON_HIP_E* code with `why`.  Returns 0 when every rank said 0; otherwise every rank returns the
+// code of the LOWEST failing rank, with a text that names it.
+static int comm_vote(exon_hip_ctx* ctx, ExonComm* c, hipStream_t s, uint8_t* d_scratch, int my_code, const char* why, const char* what) {
+  if ((size_t)c->world * 16 > COLL_SCRATCH / 2) return fail(ctx, EXON_HIP_EUNSUPPORTED, "%s: more than %zu ranks", what, COLL_SCRATCH / 32);
+  if (fault_at("stall", c->rank)) {  // (test hook) this rank never enters: the others must time out, not hang
+    std::this_thread::sleep_for(std::chrono::duration<double>(collective_timeout_s() * 3));
+    return fail(ctx, EXON_HIP_EDEVICE, "%s: stalled by EXON_HIP_FAULT", what);
+  }
+  int64_t mine[2] = {my_code, 0};
+  std::vector<int64_t> all((size_t)c->world * 2, 0);
+  const int rc = comm_all_gather_host(ctx, c, s, d_scratch, mine, all.data(), 16, what);
+  if (rc) return rc;
+  for (int r = 0; r < c->world; ++r)
+    if (all[(size_t)r * 2] != 0) {
+      const int code = (int)all[(size_t)r * 2];
+      if (r == c->rank) return fail(ctx, code, "%s: %s (this rank, %d; every rank of the communicator returns this error, none has entered the data exchange)", what, why ? why : "failed", r);
+      return fail(ctx, code, "%s: rank %d could not go on (status %d: its own error text says why); no rank has entered the data exchange", what, r, code);
+    }
+  return EXON_HIP_OK;
+}
+
 // ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy for hosts without an RCCL binding of their own: rank 0 creates the id,
 // ships its 128 bytes to the other ranks by any means, every rank (one process per GPU) calls comm_init on its ctx.
 int exon_hip_rccl_unique_id(uint8_t* id128) {
@@ -1105,37 +1225,82 @@ int exon_hip_rccl_comm_init(exon_hip_ctx* ctx, const uint8_t* id128, int32_t wor
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   typedef int (*init_fn)(void**, int, UniqueId, int);
   *comm = nullptr;
-  const int e = ((init_fn)rccl().init_rank)(comm, world, id, rank);
+  void* nccl = nullptr;
+  const int e = ((init_fn)rccl().init_rank)(&nccl, world, id, rank);
   if (e) return fail(ctx, EXON_HIP_EDEVICE, "ncclCommInitRank(world %d, rank %d) failed with ncclResult_t %d", world, rank, e);
+  ExonComm* c = new ExonComm();
+  c->kind = 0;
+  c->nccl = nccl;
+  c->world = world;
+  c->rank = rank;
+  *comm = c;
+  return EXON_HIP_OK;
+}
+int exon_hip_comm_wrap_rccl(void* nccl_comm, void** comm) {
+  if (!nccl_comm || !comm) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_comm_wrap_rccl: NULL argument");
+  if (!rccl().ok()) return fail(nullptr, EXON_HIP_EUNSUPPORTED, "librccl.so could not be loaded");
+  int w = 0, r = 0;
+  int e = rccl().comm_count(nccl_comm, &w);
+  if (!e) e = rccl().comm_rank(nccl_comm, &r);
+  if (e || w < 1) return fail(nullptr, EXON_HIP_EDEVICE, "ncclCommCount / ncclCommUserRank failed with ncclResult_t %d", e);
+  ExonComm* c = new ExonComm();
+  c->kind = 0;
+  c->nccl = nccl_comm;
+  c->world = w;
+  c->rank = r;
+  c->owned = false;
+  *comm = c;
+  return EXON_HIP_OK;
+}
+int exon_hip_comm_from_callbacks(int32_t world, int32_t rank, exon_hip_allgather_fn all_gather, void* user, void** comm) {
+  if (!all_gather || !comm) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_comm_from_callbacks: NULL argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(nullptr, EXON_HIP_EINVAL, "rank %d outside a world of %d", rank, world);
+  ExonComm* c = new ExonComm();
+  c->kind = 1;
+  c->world = world;
+  c->rank = rank;
+  c->fn = all_gather;
+  c->user = user;
+  *comm = c;
   return EXON_HIP_OK;
 }
 int exon_hip_rccl_comm_destroy(void* comm) {
   if (!comm) return EXON_HIP_OK;
-  if (!rccl().ok()) return fail(nullptr, EXON_HIP_EUNSUPPORTED, "librccl.so could not be loaded");
-  const int e = rccl().comm_destroy(comm);
+  ExonComm* c = comm_of(comm);
+  if (!c) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_rccl_comm_destroy: not a communicator of this library");
+  int e = 0;
+  if (c->kind == 0 && c->nccl && c->owned) e = rccl().comm_destroy(c->nccl);
+  c->magic = 0;
+  delete c;
   return e ? fail(nullptr, EXON_HIP_EDEVICE, "ncclCommDestroy failed with ncclResult_t %d", e) : EXON_HIP_OK;
 }
 
 int exon_hip_rccl_comm_count(void* comm, int32_t* world, int32_t* rank) {
   if (!comm || !world) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_rccl_comm_count: NULL argument");
-  if (!rccl().ok()) return fail(nullptr, EXON_HIP_EUNSUPPORTED, "librccl.so could not be loaded");
-  int w = 0, r = 0;
-  int e = rccl().comm_count(comm, &w);
-  if (!e && rank) e = rccl().comm_rank(comm, &r);
-  if (e) return fail(nullptr, EXON_HIP_EDEVICE, "ncclCommCount / ncclCommUserRank failed with ncclResult_t %d", e);
+  ExonComm* c = comm_of(comm);
+  if (!c) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_rccl_comm_count: not a communicator of this library");
+  int w = c->world, r = c->rank;
+  if (c->kind == 0 && c->nccl) {  // what RCCL itself says (a launcher prints it to prove how many GPUs merged)
+    int e = rccl().comm_count(c->nccl, &w);
+    if (!e && rank) e = rccl().comm_rank(c->nccl, &r);
+    if (e) return fail(nullptr, EXON_HIP_EDEVICE, "ncclCommCount / ncclCommUserRank failed with ncclResult_t %d", e);
+  }
   *world = w;
   if (rank) *rank = r;
   return EXON_HIP_OK;
 }
 
-// Merge of packed partial states across the ranks of `rccl_comm`, enqueued on `stream`: ONE ncclAllGather of the state
+// Merge of packed partial states across the ranks of `comm`, enqueued on `stream`: ONE all-gather of the state
 // (d_state -> d_gather[world][words]) + the fixed-order fold into d_out (may be d_state itself).  The f64 sums come out
 // bit-identical on every rank and for every collective algorithm RCCL may pick.  States above 1 MiB are integer counters
 // only (K3 with millions of references) or too large to gather 8x: those are all-reduced in place (integer sums are exact).
-int exon_hip_merge_states(exon_hip_ctx* ctx, void* stream, void* rccl_comm, void* d_state, int64_t n_i64, int64_t n_f64,
+// No vote here (the caller owns the buffers: nothing in this call can fail on one rank alone but the collective itself).
+int exon_hip_merge_states(exon_hip_ctx* ctx, void* stream, void* comm, void* d_state, int64_t n_i64, int64_t n_f64,
                           void* d_gather, void* d_out) {
-  if (!ctx || !rccl_comm || !d_state || !d_out) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_merge_states: NULL argument");
-  if (!rccl().ok()) return fail(ctx, EXON_HIP_EUNSUPPORTED, "librccl.so could not be loaded");
+  if (!ctx || !comm || !d_state || !d_out) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_merge_states: NULL argument");
+  ExonComm* c = comm_of(comm);
+  if (!c) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_merge_states: not a communicator of this library (exon_hip_rccl_comm_init / exon_hip_comm_from_callbacks)");
+  if (c->kind == 0 && !rccl().ok()) return fail(ctx, EXON_HIP_EUNSUPPORTED, "librccl.so could not be loaded");
   if (n_i64 < 0 || n_f64 < 0 || n_i64 + n_f64 < 1) return fail(ctx, EXON_HIP_EINVAL, "empty state");
   hipStream_t s = pick_stream(ctx, stream);
   const size_t words = (size_t)(n_i64 + n_f64);
@@ -1144,54 +1309,89 @@ int exon_hip_merge_states(exon_hip_ctx* ctx, void* stream, void* rccl_comm, void
   if (d_gather == nullptr) {  // in-place all-reduce form (large integer states)
     if (n_f64) return fail(ctx, EXON_HIP_EINVAL, "a state with float64 sums is merged by gather + fold: pass d_gather");
     if (d_out != d_state) return fail(ctx, EXON_HIP_EINVAL, "the all-reduce form is in place");
-    const int e = rccl().all_reduce(d_state, d_state, words, NCCL_INT64, NCCL_SUM, rccl_comm, s);
-    return e ? fail(ctx, EXON_HIP_EDEVICE, "ncclAllReduce failed with ncclResult_t %d", e) : EXON_HIP_OK;
+    if (c->aborted) return fail(ctx, EXON_HIP_ESTATE, "the communicator was aborted by an earlier time-out");
+    if (c->kind == 0) {
+      const int e = rccl().all_reduce(d_state, d_state, words, NCCL_INT64, NCCL_SUM, c->nccl, s);
+      return e ? fail(ctx, EXON_HIP_EDEVICE, "ncclAllReduce failed with ncclResult_t %d", e) : EXON_HIP_OK;
+    }
+    std::vector<int64_t> mine(words), all(words * (size_t)c->world);
+    HIP_TRY(ctx, hipMemcpyAsync(mine.data(), d_state, words * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (c->fn(c->user, mine.data(), all.data(), words * 8)) return fail(ctx, EXON_HIP_EDEVICE, "the caller's all-gather failed");
+    for (size_t w = 0; w < words; ++w) {
+      int64_t t = 0;
+      for (int r = 0; r < c->world; ++r) t += all[(size_t)r * words + w];
+      mine[w] = t;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(d_state, mine.data(), words * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return EXON_HIP_OK;
   }
-  int world = 0;
-  int e = rccl().comm_count(rccl_comm, &world);
-  if (e || world < 1) return fail(ctx, EXON_HIP_EDEVICE, "ncclCommCount failed with ncclResult_t %d", e);
+  const int world = c->world;
   {  // the fold reads every rank's copy while it writes d_out: d_out inside the gather buffer would race
     const uintptr_t g0 = reinterpret_cast<uintptr_t>(d_gather), g1 = g0 + (size_t)world * words * 8, o0 = reinterpret_cast<uintptr_t>(d_out);
     if (o0 + words * 8 > g0 && o0 < g1) return fail(ctx, EXON_HIP_EINVAL, "d_out must not lie inside d_gather");
   }
-  e = rccl().all_gather(d_state, d_gather, words, NCCL_INT64, rccl_comm, s);  // 8-byte words; no arithmetic in flight
-  if (e) return fail(ctx, EXON_HIP_EDEVICE, "ncclAllGather failed with ncclResult_t %d", e);
+  const int rc = comm_all_gather_dev(ctx, c, s, d_state, d_gather, words * 8);  // 8-byte words; no arithmetic in flight
+  if (rc) return rc;
   HIP_TRY(ctx, exon::launch_fold_states(s, d_gather, world, n_i64, n_f64, d_out));
   return EXON_HIP_OK;
 }
 
 // AggregateExec(Final) across GPUs in native code, on the stream's hipStream_t: afterwards every rank's state holds the
 // sum over all ranks (the name is kept from ABI 1; since ABI 2 it is one all-gather + a fixed-order fold, see above).
-int exon_hip_stream_all_reduce(exon_hip_stream* st, void* rccl_comm) {
-  if (!st || !rccl_comm) return fail(st ? st->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_stream_all_reduce: NULL argument");
-  if (st->closed) return fail(st->ctx, EXON_HIP_ESTATE, "all_reduce after finish/close");
-  if (st->keys_state == KEYS_LOCAL)  // ids of file-derived keys are per rank: adding states by id would merge different groups
-    return fail(st->ctx, EXON_HIP_ESTATE,
-                "the state is keyed by this rank's own dictionary (%zu keys from its scans): call exon_hip_stream_reconcile_keys "
-                "(or exon_hip_stream_set_keys with the agreed dictionary) on every rank before the merge", st->keys.size());
-  if (!rccl().ok()) return fail(st->ctx, EXON_HIP_EUNSUPPORTED, "librccl.so could not be loaded");
-  int rc = flush_slot(st);
-  if (!rc) rc = settle_reset(st);
-  if (rc) return rc;
+// Collective: every rank calls it.  Whatever stops ONE rank -- the stream finished, a state keyed by its own dictionary, rows
+// that cannot be launched, no memory for the gather buffer -- is put to the vote first: all ranks return that error, none waits
+// in the all-gather for a peer that has left.  (Costs one 16-byte all-gather in front of the merge; exon_hip_merge_states is
+// the form without it.)
+int exon_hip_stream_all_reduce(exon_hip_stream* st, void* comm) {
+  if (!st || !comm) return fail(st ? st->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_stream_all_reduce: NULL argument");
+  ExonComm* c = comm_of(comm);
+  if (!c) return fail(st->ctx, EXON_HIP_EINVAL, "exon_hip_stream_all_reduce: not a communicator of this library");
+  if (c->kind == 0 && !rccl().ok()) return fail(st->ctx, EXON_HIP_EUNSUPPORTED, "librccl.so could not be loaded");  // (the same on every rank of a node)
+  hipSetDevice(st->ctx->device);
   const exon_hip_plan* p = st->plan;
   const size_t sbytes = (size_t)(p->n_i64 + p->n_f64) * 8;
-  if (sbytes > GATHER_MERGE_MAX_STATE && p->n_f64 == 0)
-    return exon_hip_merge_states(st->ctx, st->stream, rccl_comm, st->d_state, p->n_i64, 0, nullptr, st->d_state);
-  int world = 0;
-  const int e = rccl().comm_count(rccl_comm, &world);
-  if (e || world < 1) return fail(st->ctx, EXON_HIP_EDEVICE, "ncclCommCount failed with ncclResult_t %d", e);
-  if (st->gather_bytes < sbytes * (size_t)world) {
+  uint8_t* d_scratch = st->d_state + ((sbytes + 63) & ~(size_t)63);
+  int code = EXON_HIP_OK;
+  std::string why;
+  auto local = [&](int rc_, const char* text) {
+    if (code == EXON_HIP_OK) {
+      code = rc_;
+      why = text;
+    }
+  };
+  if (fault_at("allreduce_enter", c->rank)) local(EXON_HIP_ESTATE, "EXON_HIP_FAULT=allreduce_enter");
+  if (st->closed) local(EXON_HIP_ESTATE, "all_reduce after finish/close");
+  if (st->keys_state == KEYS_LOCAL)  // ids of file-derived keys are per rank: adding states by id would merge different groups
+    local(EXON_HIP_ESTATE, "the state is keyed by this rank's own dictionary: call exon_hip_stream_reconcile_keys (or exon_hip_stream_set_keys with the agreed "
+                           "dictionary) on every rank before the merge");
+  if (code == EXON_HIP_OK) {
+    int rc = flush_slot(st);
+    if (!rc) rc = settle_reset(st);
+    if (rc) local(rc, exon_hip_last_error(st->ctx));
+  }
+  const bool big = sbytes > GATHER_MERGE_MAX_STATE && p->n_f64 == 0;
+  const int world = c->world;
+  if (code == EXON_HIP_OK && !big && st->gather_bytes < sbytes * (size_t)world) {
     if (st->d_gather) {
-      HIP_TRY(st->ctx, hipStreamSynchronize(st->stream));
+      hipStreamSynchronize(st->stream);
       hipFree(st->d_gather);
       st->d_gather = nullptr;
       st->gather_bytes = 0;
     }
-    if (hipMalloc((void**)&st->d_gather, sbytes * (size_t)world) != hipSuccess)
-      return fail(st->ctx, EXON_HIP_ENOMEM, "gather buffer of %zu bytes", sbytes * (size_t)world);
-    st->gather_bytes = sbytes * (size_t)world;
+    if (fault_at("allreduce_malloc", c->rank) || hipMalloc((void**)&st->d_gather, sbytes * (size_t)world) != hipSuccess) {
+      (void)hipGetLastError();
+      st->d_gather = nullptr;
+      local(EXON_HIP_ENOMEM, "no memory for the gather buffer");
+    } else {
+      st->gather_bytes = sbytes * (size_t)world;
+    }
   }
-  return exon_hip_merge_states(st->ctx, st->stream, rccl_comm, st->d_state, p->n_i64, p->n_f64, st->d_gather, st->d_state);
+  const int v = comm_vote(st->ctx, c, st->stream, d_scratch, code, why.c_str(), "exon_hip_stream_all_reduce");
+  if (v) return v;
+  if (big) return exon_hip_merge_states(st->ctx, st->stream, comm, st->d_state, p->n_i64, 0, nullptr, st->d_state);
+  return exon_hip_merge_states(st->ctx, st->stream, comm, st->d_state, p->n_i64, p->n_f64, st->d_gather, st->d_state);
 }
 
 // ---- group keys by value: the C ABI (include/exon_hip.h "group keys") ---------------------------------------------------------
@@ -1329,64 +1529,99 @@ int exon_hip_stream_set_region_contig(exon_hip_stream* st, const char* name) {
   return EXON_HIP_OK;
 }
 
-// The ranks of `rccl_comm` agree on ONE dictionary: two small all-gathers (sizes, then the packed names padded to the longest),
-// the union in rank order on every rank, each state permuted into it.  Collective: every rank must call it.
-int exon_hip_stream_reconcile_keys(exon_hip_stream* st, void* rccl_comm) {
-  if (!st || !rccl_comm) return fail(st ? st->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_stream_reconcile_keys: NULL argument");
-  if (st->closed) return fail(st->ctx, EXON_HIP_ESTATE, "reconcile_keys after finish/close");
-  if (!exon_hip_stream_is_keyed(st)) return EXON_HIP_OK;  // plans without group keys have nothing to agree on
-  // A rank that may not take part (rows pushed under the caller's own ids, never declared) still ENTERS the collective and says so
-  // in the size exchange: every rank then fails together.  Returning here would leave the other ranks blocked in ncclAllGather.
-  const bool unkeyed = st->keys_state == KEYS_NONE && st->rows_pushed > 0;
-  if (!rccl().ok()) return fail(st->ctx, EXON_HIP_EUNSUPPORTED, "librccl.so could not be loaded");
-  int world = 0, rank = 0;
-  int e = rccl().comm_count(rccl_comm, &world);
-  if (!e) e = rccl().comm_rank(rccl_comm, &rank);
-  if (e || world < 1) return fail(st->ctx, EXON_HIP_EDEVICE, "ncclCommCount / ncclCommUserRank failed with ncclResult_t %d", e);
+// The ranks of `comm` agree on ONE dictionary: the sizes (with the vote folded in), one more vote behind the local allocations, the
+// packed names padded to the longest, the union in rank order on every rank, each state permuted into it.  Collective: every rank
+// must call it -- and every rank leaves it with the same verdict: nothing that can stop one rank alone (the stream finished, rows
+// pushed under undeclared ids, no memory for the exchange or the re-keying buffers) sits between two exchanges unannounced.
+int exon_hip_stream_reconcile_keys(exon_hip_stream* st, void* comm) {
+  if (!st || !comm) return fail(st ? st->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_stream_reconcile_keys: NULL argument");
+  ExonComm* c = comm_of(comm);
+  if (!c) return fail(st->ctx, EXON_HIP_EINVAL, "exon_hip_stream_reconcile_keys: not a communicator of this library");
+  if (!exon_hip_stream_is_keyed(st)) return EXON_HIP_OK;  // plans without group keys have nothing to agree on (the plan is the same on every rank)
+  if (c->kind == 0 && !rccl().ok()) return fail(st->ctx, EXON_HIP_EUNSUPPORTED, "librccl.so could not be loaded");
+  const int world = c->world;
+  if ((size_t)world * 32 > COLL_SCRATCH / 2) return fail(st->ctx, EXON_HIP_EUNSUPPORTED, "exon_hip_stream_reconcile_keys: more than %zu ranks", COLL_SCRATCH / 64);
   hipSetDevice(st->ctx->device);
-  // (1) sizes
-  // (per rank: number of keys, packed bytes, "I cannot take part")
-  int64_t mine[4] = {unkeyed ? 0 : (int64_t)st->keys.size(), unkeyed ? 0 : (int64_t)packed_size(st->keys), unkeyed ? 1 : 0, 0};
-  int64_t* d_sz = nullptr;
-  HIP_TRY(st->ctx, hipMalloc((void**)&d_sz, (size_t)(world + 1) * 32));
-  std::vector<int64_t> sizes4((size_t)world * 4), sizes((size_t)world * 2);
-  hipError_t he = hipMemcpyAsync(d_sz + 4 * world, mine, 32, hipMemcpyHostToDevice, st->stream);
-  if (he == hipSuccess) e = rccl().all_gather(d_sz + 4 * world, d_sz, 4, NCCL_INT64, rccl_comm, st->stream);
-  if (he == hipSuccess && !e) he = hipMemcpyAsync(sizes4.data(), d_sz, (size_t)world * 32, hipMemcpyDeviceToHost, st->stream);
-  if (he == hipSuccess && !e) he = hipStreamSynchronize(st->stream);
-  hipFree(d_sz);
-  if (e) return fail(st->ctx, EXON_HIP_EDEVICE, "ncclAllGather (key dictionary sizes) failed with ncclResult_t %d", e);
-  if (he != hipSuccess) return fail(st->ctx, EXON_HIP_EDEVICE, "key dictionary sizes: %s", hipGetErrorString(he));
-  for (int r = 0; r < world; ++r) {
-    sizes[(size_t)r * 2] = sizes4[(size_t)r * 4];
-    sizes[(size_t)r * 2 + 1] = sizes4[(size_t)r * 4 + 1];
-    if (sizes4[(size_t)r * 4 + 2])  // decided by all ranks on the same data: all of them leave here
+  const size_t sbytes = state_bytes_of(st);
+  uint8_t* d_scratch = st->d_state + ((sbytes + 63) & ~(size_t)63);
+  // (1) sizes + vote.  A rank that may not take part (finished; rows pushed under the caller's own ids, never declared) still ENTERS
+  // and says so: every rank then fails together.
+  const bool unkeyed = st->keys_state == KEYS_NONE && st->rows_pushed > 0;
+  int code = EXON_HIP_OK;
+  if (st->closed) code = EXON_HIP_ESTATE;
+  if (fault_at("reconcile_enter", c->rank)) code = EXON_HIP_ESTATE;
+  const bool mute = unkeyed || code != EXON_HIP_OK;
+  if (fault_at("stall", c->rank)) {
+    std::this_thread::sleep_for(std::chrono::duration<double>(collective_timeout_s() * 3));
+    return fail(st->ctx, EXON_HIP_EDEVICE, "exon_hip_stream_reconcile_keys: stalled by EXON_HIP_FAULT");
+  }
+  int64_t mine[4] = {mute ? 0 : (int64_t)st->keys.size(), mute ? 0 : (int64_t)packed_size(st->keys), unkeyed ? 1 : 0, code};
+  std::vector<int64_t> sizes4((size_t)world * 4, 0);
+  int rc = comm_all_gather_host(st->ctx, c, st->stream, d_scratch, mine, sizes4.data(), 32, "exon_hip_stream_reconcile_keys (sizes)");
+  if (rc) return rc;
+  for (int r = 0; r < world; ++r) {  // decided by all ranks on the same data: all of them leave here
+    if (sizes4[(size_t)r * 4 + 3])
+      return fail(st->ctx, (int)sizes4[(size_t)r * 4 + 3], "exon_hip_stream_reconcile_keys: rank %d cannot take part (%s); no rank's state was touched", r,
+                  r == c->rank && st->closed ? "its stream has finished" : "status from that rank");
+    if (sizes4[(size_t)r * 4 + 2])
       return fail(st->ctx, EXON_HIP_ESTATE,
                   "rank %d pushed rows under the caller's own dictionary ids and never declared their values (exon_hip_stream_set_keys): "
                   "no rank's state was touched", r);
   }
   size_t slot = 8;
-  for (int r = 0; r < world; ++r) slot = std::max(slot, (size_t)sizes[(size_t)r * 2 + 1]);
+  for (int r = 0; r < world; ++r) slot = std::max(slot, (size_t)sizes4[(size_t)r * 4 + 1]);
   slot = (slot + 7) / 8 * 8;
-  // (2) the packed names, one padded slot per rank
+  // (2) what this rank needs for the exchange and for the re-keying behind it, BEFORE the names travel; then the second vote
   std::vector<char> all(slot * (size_t)world), own(slot, 0);
   pack_names(st->keys, own.data());
   char* d_txt = nullptr;
-  HIP_TRY(st->ctx, hipMalloc((void**)&d_txt, slot * (size_t)(world + 1)));
-  he = hipMemcpyAsync(d_txt + slot * (size_t)world, own.data(), slot, hipMemcpyHostToDevice, st->stream);
-  if (he == hipSuccess) e = rccl().all_gather(d_txt + slot * (size_t)world, d_txt, slot / 8, NCCL_INT64, rccl_comm, st->stream);
-  if (he == hipSuccess && !e) he = hipMemcpyAsync(all.data(), d_txt, all.size(), hipMemcpyDeviceToHost, st->stream);
-  if (he == hipSuccess && !e) he = hipStreamSynchronize(st->stream);
-  hipFree(d_txt);
-  if (e) return fail(st->ctx, EXON_HIP_EDEVICE, "ncclAllGather (key dictionaries) failed with ncclResult_t %d", e);
-  if (he != hipSuccess) return fail(st->ctx, EXON_HIP_EDEVICE, "key dictionaries: %s", hipGetErrorString(he));
+  std::string why;
+  if (fault_at("reconcile_malloc", c->rank) || (c->kind == 0 && hipMalloc((void**)&d_txt, slot * (size_t)(world + 1)) != hipSuccess)) {
+    (void)hipGetLastError();
+    d_txt = nullptr;
+    code = EXON_HIP_ENOMEM;
+    why = "no memory for the key exchange";
+  }
+  if (code == EXON_HIP_OK && (fault_at("reconcile_rekey", c->rank) || ensure_rekey_buffers(st, st->keys.size()) != EXON_HIP_OK)) {
+    code = EXON_HIP_ENOMEM;
+    why = "no memory for the re-keying buffers";
+  }
+  if (code == EXON_HIP_OK) {  // rows staged by earlier pushes belong to the state that is about to be permuted
+    int rf = flush_slot(st);
+    if (!rf) rf = settle_reset(st);
+    if (rf) {
+      code = rf;
+      why = exon_hip_last_error(st->ctx);
+    }
+  }
+  rc = comm_vote(st->ctx, c, st->stream, d_scratch, code, why.c_str(), "exon_hip_stream_reconcile_keys");
+  if (rc) {
+    if (d_txt) hipFree(d_txt);
+    return rc;
+  }
+  // (3) the packed names, one padded slot per rank
+  if (c->kind == 0) {
+    hipError_t he = hipMemcpyAsync(d_txt + slot * (size_t)world, own.data(), slot, hipMemcpyHostToDevice, st->stream);
+    int e = 0;
+    if (he == hipSuccess) e = rccl().all_gather(d_txt + slot * (size_t)world, d_txt, slot / 8, NCCL_INT64, c->nccl, st->stream);
+    if (he == hipSuccess && !e) he = hipMemcpyAsync(all.data(), d_txt, all.size(), hipMemcpyDeviceToHost, st->stream);
+    int rs = EXON_HIP_OK;
+    if (he == hipSuccess && !e) rs = bounded_sync(st->ctx, c, st->stream, "exon_hip_stream_reconcile_keys (names)");
+    hipFree(d_txt);
+    if (e) return fail(st->ctx, EXON_HIP_EDEVICE, "ncclAllGather (key dictionaries) failed with ncclResult_t %d", e);
+    if (he != hipSuccess) return fail(st->ctx, EXON_HIP_EDEVICE, "key dictionaries: %s", hipGetErrorString(he));
+    if (rs) return rs;
+  } else if (c->fn(c->user, own.data(), all.data(), slot)) {
+    return fail(st->ctx, EXON_HIP_EDEVICE, "exon_hip_stream_reconcile_keys: the caller's all-gather failed");
+  }
   std::vector<std::vector<std::string>> dicts((size_t)world);
   for (int r = 0; r < world; ++r)
-    if (!unpack_names(all.data() + slot * (size_t)r, (size_t)sizes[(size_t)r * 2 + 1], (int32_t)sizes[(size_t)r * 2], &dicts[(size_t)r]))
-      return fail(st->ctx, EXON_HIP_EINVAL, "rank %d sent a malformed key dictionary", r);
+    if (!unpack_names(all.data() + slot * (size_t)r, (size_t)sizes4[(size_t)r * 4 + 1], (int32_t)sizes4[(size_t)r * 4], &dicts[(size_t)r]))
+      return fail(st->ctx, EXON_HIP_EINVAL, "rank %d sent a malformed key dictionary", r);  // (the same bytes on every rank: all of them leave here)
   std::vector<std::string> uni;
   union_in_rank_order(dicts, &uni, nullptr);
   if (st->keys_state == KEYS_NONE) st->keys_state = KEYS_LOCAL;  // a rank that scanned nothing holds an empty dictionary
+  // the union and n_groups are the same on every rank (ECAPACITY is everybody's); the buffers it needs exist since (2)
   return adopt_keys(st, uni);
 }
 

@@ -210,6 +210,43 @@ def scan_files(ctx, paths, fmt, make_plan, rank=None, world=None, group=None, co
         plan.close()
 
 
+class CallbackComm:
+    """exon_hip_comm_from_callbacks over a torch.distributed group (gloo works): the library's collectives -- votes, key
+    reconciliation, merge -- with the bytes moved by the caller's all-gather of host buffers.  For hosts that own a transport
+    already, and for rehearsals of the multi-rank logic where RCCL cannot form a communicator (several ranks on one GPU)."""
+
+    def __init__(self, ctx, group=None):
+        import torch
+        import torch.distributed as dist
+        from ._lib import ALLGATHER_FN
+        self.ctx, self.h = ctx, None
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+        def all_gather(_user, send, recv, nbytes):
+            try:
+                mine = torch.frombuffer((C.c_uint8 * nbytes).from_address(send), dtype=torch.uint8).clone()
+                out = torch.empty(nbytes * self.world, dtype=torch.uint8)
+                dist.all_gather_into_tensor(out, mine, group=group)
+                C.memmove(recv, out.data_ptr(), nbytes * self.world)
+                return 0
+            except Exception:  # noqa: BLE001 -- a time-out / a dead peer: the library reports it
+                return -1
+        self._cb = ALLGATHER_FN(all_gather)  # (kept alive with the communicator)
+        h = C.c_void_p()
+        ctx._check(ctx.lib.exon_hip_comm_from_callbacks(self.world, self.rank, self._cb, None, C.byref(h)))
+        self.h = h
+
+    def count(self):
+        w, r = C.c_int32(), C.c_int32()
+        self.ctx._check(self.ctx.lib.exon_hip_rccl_comm_count(self.h, C.byref(w), C.byref(r)))
+        return w.value, r.value
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.exon_hip_rccl_comm_destroy(self.h)
+            self.h = None
+
+
 class NativeComm:
     """An ncclComm_t created through the C ABI (exon_hip_rccl_unique_id / _comm_init): rank 0 makes the unique id, the
     128 bytes travel through the already initialised torch.distributed group, every rank joins on its own GPU."""

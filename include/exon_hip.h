@@ -324,10 +324,27 @@ int exon_hip_merge_states(exon_hip_ctx* ctx, void* stream, void* rccl_comm, void
                           void* d_gather, void* d_out);
 /* ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy for hosts without an RCCL binding: rank 0 makes the 128-byte id and
  * ships it to the other ranks by any means; every rank then calls comm_init (collective) on its own ctx / GPU. */
+/* ---- communicators (ABI 5: the handle is OPAQUE -- made by one of the two calls below, never a bare ncclComm_t) --------------------
+ * exon_hip_rccl_comm_init: ncclGetUniqueId / ncclCommInitRank for hosts without an RCCL binding of their own (rank 0 creates the id,
+ * ships its 128 bytes to the other ranks by any means; one process per GPU).  exon_hip_comm_from_callbacks: the same collectives over
+ * an all-gather of HOST buffers the caller supplies (torch.distributed / gloo, MPI ...): `all_gather(user, send, recv, bytes)` copies
+ * `bytes` from every rank's `send` into recv[rank * bytes ...] on every rank and returns 0 -- for hosts that already own a transport,
+ * and for machines where RCCL cannot form the communicator (several ranks on one GPU: tests/test_collective_faults.py).
+ * Every collective entry point of a stream VOTES before it exchanges data: a rank that cannot go on (stream finished, undeclared keys,
+ * out of memory) says so in a 16-byte all-gather and EVERY rank returns that error -- none is left waiting in a collective for a peer
+ * that has returned.  A peer that never enters at all is met by a bounded wait (EXON_HIP_COLLECTIVE_TIMEOUT_S, default 120):
+ * the RCCL communicator is aborted (ncclCommAbort), the call fails with EXON_HIP_EDEVICE, the handle is unusable afterwards.
+ * EXON_HIP_FAULT="site@rank[,...]" makes a named site fail on one rank (reconcile_enter, reconcile_malloc, reconcile_rekey,
+ * allreduce_enter, allreduce_malloc, stall): how the tests reach every one of those paths. */
+typedef int (*exon_hip_allgather_fn)(void* user, const void* send, void* recv, size_t bytes_per_rank);
+int exon_hip_comm_from_callbacks(int32_t world, int32_t rank, exon_hip_allgather_fn all_gather, void* user, void** comm);
+/* a host that made its ncclComm_t itself wraps it (not owned: exon_hip_rccl_comm_destroy frees the handle, not the ncclComm_t) */
+int exon_hip_comm_wrap_rccl(void* nccl_comm, void** comm);
 int exon_hip_rccl_unique_id(uint8_t* id128);
 int exon_hip_rccl_comm_init(exon_hip_ctx* ctx, const uint8_t* id128, int32_t world, int32_t rank, void** rccl_comm);
 int exon_hip_rccl_comm_destroy(void* rccl_comm);
-/* ncclCommCount / ncclCommUserRank of a communicator (rank may be NULL): what a launcher prints to prove how many GPUs merged */
+/* ranks of a communicator and this one's index (ncclCommCount / ncclCommUserRank for the RCCL kind; rank may be NULL): what a
+ * launcher prints to prove how many GPUs merged */
 int exon_hip_rccl_comm_count(void* rccl_comm, int32_t* world, int32_t* rank);
 
 /* One stream per partition (= per file group); single-threaded handle, owns one HIP stream, a
@@ -349,13 +366,14 @@ int exon_hip_stream_push_device(exon_hip_stream* s, const struct ArrowDeviceArra
  * host can all-reduce them over RCCL, plus the hipStream_t the kernels run on. */
 int exon_hip_stream_state(exon_hip_stream* s, int64_t** d_i64, double** d_f64, void** hip_stream);
 /* The merge across GPUs in native code on the stream's hipStream_t: afterwards the state of every rank is the sum over all
- * ranks.  One ncclAllGather + fixed-order fold (exon_hip_merge_states); `rccl_comm` is an ncclComm_t the host created (one
- * rank per GPU, e.g. exon_hip_rccl_comm_init).
- * The argument and state checks of this call are RANK-LOCAL (the step budget has no room for a second collective): a rank
- * that fails them -- EXON_HIP_ESTATE for a state keyed by its own dictionary, above all -- returns WITHOUT entering the
- * collective, and the ranks that did enter wait for it.  Treat a nonzero return on any rank as fatal for the communicator
- * (abort the job, or ncclCommAbort), and call exon_hip_stream_reconcile_keys first wherever keys come from files: that call
- * decides collectively and fails on every rank together. */
+ * ranks.  One all-gather + fixed-order fold (exon_hip_merge_states); `rccl_comm` is a communicator of this library (one rank
+ * per GPU: exon_hip_rccl_comm_init).
+ * (ABI 5) Collective, and it FAILS TOGETHER: what stops one rank -- the stream finished, a state keyed by its own dictionary
+ * (EXON_HIP_ESTATE: call exon_hip_stream_reconcile_keys first wherever keys come from files), staged rows that cannot be
+ * launched, no memory for the gather buffer -- goes into a 16-byte vote in front of the merge, and every rank returns that
+ * error without entering the data exchange.  (Until ABI 4 these checks were rank-local and the peers of a failing rank waited
+ * in ncclAllGather for ever.)  The vote synchronises the stream; the merge behind it is enqueued.  exon_hip_merge_states is
+ * the bare form for callers that own the buffers and the step budget (bench.py's timed region). */
 int exon_hip_stream_all_reduce(exon_hip_stream* s, void* rccl_comm);
 /* ---- group keys by VALUE (ABI 4) --------------------------------------------------------------------------------------------
  * K3 / K4 states are indexed by dictionary id, and ids are per FILE: FILTER lists are numbered in order of first appearance in
@@ -380,10 +398,12 @@ int exon_hip_stream_set_keys(exon_hip_stream* s, const char* packed_names, size_
  * sum of n_keys entries, rank-major) the union id of every input key. */
 int exon_hip_keys_union(const char* packed, size_t packed_bytes, const int32_t* n_keys, int32_t world, char* out, size_t cap,
                         int32_t* n_out, size_t* out_bytes, int32_t* maps);
-/* collective over `rccl_comm` (every rank calls it, between its last consume_scan and exon_hip_stream_all_reduce): two small
- * ncclAllGathers move the dictionaries, every rank forms the same union and permutes its state into it.  A rank that cannot take
- * part (rows pushed under undeclared ids) says so INSIDE the first exchange: every rank then returns EXON_HIP_ESTATE, none hangs.
- * A union larger than the plan's n_groups is EXON_HIP_ECAPACITY on every rank (all ranks compute the same union). */
+/* collective over `rccl_comm` (every rank calls it, between its last consume_scan and exon_hip_stream_all_reduce): small
+ * all-gathers move the dictionaries, every rank forms the same union and permutes its state into it.  A rank that cannot take
+ * part (its stream finished; rows pushed under undeclared ids) says so INSIDE the first exchange, one that runs out of memory for
+ * the exchange or the re-keying buffers says so in a vote in front of the second: every rank then returns that error (EXON_HIP_ESTATE
+ * / EXON_HIP_ENOMEM), none hangs, no state has been touched.  A union larger than the plan's n_groups is EXON_HIP_ECAPACITY on
+ * every rank (all ranks compute the same union). */
 int exon_hip_stream_reconcile_keys(exon_hip_stream* s, void* rccl_comm);
 /* Region plans (K2 / K6 / K7) fed by files: name the contig instead of fixing exon_hip_plan_desc.region_chrom_id -- every
  * exon_hip_stream_consume_scan then resolves the name in that file's own contig / reference dictionary (a BAM without such

@@ -155,7 +155,9 @@ def test_native_rccl_all_reduce_on_a_one_rank_communicator(ctx, oracle):
     plan = ctx.plan_cmp_avg_by_group(">", 0.01, 5, columns=(0, 1, 2))
     st = plan.open()
     st.push_device([(af, av, None), (q, qv, None), (fid, None, None)], n)
-    st.all_reduce(comm.value)
+    h = C.c_void_p()  # (ABI 5: the collectives take the library's handle; a caller's own ncclComm_t is wrapped)
+    assert ctx.lib.exon_hip_comm_wrap_rccl(comm, C.byref(h)) == 0
+    st.all_reduce(h.value)
     st.sync()
     counts, sums = st.finish()
     haf, hav, hq, hqv, hfid = oracle.gen_c4(4, 0, n)
@@ -164,6 +166,7 @@ def test_native_rccl_all_reduce_on_a_one_rank_communicator(ctx, oracle):
     assert np.allclose(np.array(sums), s_, rtol=1e-9)
     st.close()
     plan.close()
+    ctx.lib.exon_hip_rccl_comm_destroy(h)
     rccl.ncclCommDestroy(comm)
 
 

@@ -361,13 +361,13 @@ def test_merge_of_a_rank_local_dictionary_is_refused_until_reconciled(ctx, tmp_p
     s = exon_amd.Scan(p, "vcf", info_field="AF", gpu_parse=True)
     st.consume(s)
     s.close()
-    with pytest.raises(exon_amd.ExonHipError) as e:
-        st.all_reduce(1)                                                      # refused before the communicator is touched
-    assert e.value.code == -5 and "reconcile" in str(e.value)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300))
     dist.init_process_group("gloo", rank=0, world_size=1)
     try:
         comm = NativeComm(ctx)
+        with pytest.raises(exon_amd.ExonHipError) as e:
+            st.all_reduce(comm.h.value)                                       # refused in the vote (ABI 5): every rank would return this
+        assert e.value.code == -5 and "reconcile" in str(e.value)
         st.reconcile_keys(comm.h.value)
         keys, agreed = st.keys()
         assert agreed and {"PASS", "s50"} <= set(keys)
