@@ -100,7 +100,8 @@ class VCFColumns(C.Structure):
 
 class ScanOptions(C.Structure):
     _fields_ = [("format", C.c_int32), ("compression", C.c_int32), ("batch_size", C.c_int64),
-                ("info_field", C.c_char_p), ("region", C.c_char_p), ("use_index", C.c_int32), ("gpu_parse", C.c_int32)]
+                ("info_field", C.c_char_p), ("region", C.c_char_p), ("use_index", C.c_int32), ("gpu_parse", C.c_int32),
+                ("projection", C.c_uint64)]
 
 
 class GzipStats(C.Structure):

@@ -61,6 +61,7 @@ struct BamOut {
   int64_t* start;
   int64_t* end;
   uint32_t* pos_valid;
+  uint32_t* rec_of_row;  // byte offset of every row's record (the string columns are built from it: text_columns.hip)
 };
 
 __global__ __launch_bounds__(256) void k_bam_extract(const uint8_t* __restrict__ d, const SegInfo* __restrict__ seg,
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(256) void k_bam_extract(const uint8_t* __restrict__
       o.ref_id[row] = ref < 0 ? -1 : ref;
       o.start[row] = pv ? (int64_t)pos + 1 : 0;
       o.end[row] = pv ? (int64_t)pos + ref_len : 0;
+      o.rec_of_row[row] = r;
     }
     const uint32_t wave_row = row - lane;  // the row of the wave's lane 0 (rows are consecutive across a wave's lanes)
     publish(o.mapq_valid, ok && mapq != 255, wave_row);
@@ -120,7 +122,7 @@ struct exon_hip_bam_parser {
   uint32_t max_seg = 0;
   SegInfo* d_seg = nullptr;
   uint32_t *d_base = nullptr, *d_rec_off = nullptr, *d_scalars = nullptr;
-  void* bufs[8] = {nullptr};
+  void* bufs[9] = {nullptr};
   BamOut out{};
   unsigned* h_scalars = nullptr;
 };
@@ -156,6 +158,7 @@ int exon_hip_bam_parser_create(exon_hip_ctx* ctx, int32_t n_references, int64_t 
   dalloc(&p->bufs[5], r * 8);
   dalloc(&p->bufs[6], r * 8);
   dalloc(&p->bufs[7], w);
+  dalloc(&p->bufs[8], r * 4);
   if (e == hipSuccess) e = hipHostMalloc((void**)&p->h_scalars, 16);
   if (e != hipSuccess) {
     const std::string msg = hipGetErrorString(e);
@@ -163,7 +166,7 @@ int exon_hip_bam_parser_create(exon_hip_ctx* ctx, int32_t n_references, int64_t 
     return fail(ctx, EXON_HIP_ENOMEM, "bam parser allocation: %s", msg.c_str());
   }
   p->out = BamOut{(int32_t*)p->bufs[0], (uint8_t*)p->bufs[1], (uint32_t*)p->bufs[2], (int32_t*)p->bufs[3],
-                  (uint32_t*)p->bufs[4], (int64_t*)p->bufs[5], (int64_t*)p->bufs[6], (uint32_t*)p->bufs[7]};
+                  (uint32_t*)p->bufs[4], (int64_t*)p->bufs[5], (int64_t*)p->bufs[6], (uint32_t*)p->bufs[7], (uint32_t*)p->bufs[8]};
   *outp = p;
   return EXON_HIP_OK;
 }
@@ -219,3 +222,5 @@ int exon_hip_bam_parser_parse(exon_hip_bam_parser* p, void* stream, const uint8_
 }
 
 }  // extern "C"
+
+const uint32_t* exon_hip_bam_parser_row_records(exon_hip_bam_parser* p) { return p ? p->out.rec_of_row : nullptr; }

@@ -985,6 +985,10 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* p, void* stream, const uint8_
   return EXON_HIP_OK;
 }
 
+}  // extern "C"
+const unsigned* exon_hip_vcf_parser_newlines(exon_hip_vcf_parser* p) { return p ? p->d_nl : nullptr; }
+extern "C" {
+
 // FILTER dictionary discovered so far: names are written '\0'-separated into `buf` (id order); returns the count
 int exon_hip_vcf_parser_filters(exon_hip_vcf_parser* p, char* buf, size_t cap, int32_t* n_filters) {
   if (!p || !n_filters) return fail(p ? p->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_vcf_parser_filters: NULL argument");

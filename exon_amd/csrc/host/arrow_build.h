@@ -350,6 +350,28 @@ struct ListBuilder {
     return a;
   }
 };
+// List<Utf8> (VCF id / alt: exon-vcf/src/array_builder/lazy_array_builder.rs:169-205)
+struct ListUtf8Builder {
+  std::vector<int32_t> offsets{0};
+  std::vector<uint8_t> valid;
+  Utf8Builder items;
+  void append_null() {
+    offsets.push_back((int32_t)items.len());
+    valid.push_back(0);
+  }
+  void close_row() {
+    offsets.push_back((int32_t)items.len());
+    valid.push_back(1);
+  }
+  size_t len() const { return offsets.size() - 1; }
+  struct ArrowArray* finish() {
+    struct ArrowArray* a = static_cast<struct ArrowArray*>(malloc(sizeof *a));
+    make_list(a, offsets, valid, items.finish());
+    offsets.assign(1, 0);
+    valid.clear();
+    return a;
+  }
+};
 // schema field "+l" with its "item" child (item_fmt "f" / "i"; a dictionary-encoded item passes its value type in `dict`)
 inline struct ArrowSchema* new_list_field(const char* item_fmt, const char* name, struct ArrowSchema* item_dict = nullptr) {
   struct ArrowSchema* s = static_cast<struct ArrowSchema*>(malloc(sizeof *s));

@@ -98,6 +98,7 @@ struct VCFConfig {
   // until `batch_size` of them hit the region, then appends up to `batch_size` FURTHER records of the chunk UNFILTERED
   // (:143-154).  Off (default): every record is tested -- the documented semantics of vcf_region_filter.
   bool reference_tail_quirk = false;
+  uint64_t projection = 0;  // EXON_HIP_PROJECT_VCF_*: id / ref / alt behind the default columns (decoded by ONE thread)
 };
 
 inline std::string header_attr(const std::string& line, const char* key) {
@@ -189,9 +190,9 @@ inline std::vector<InfoSpec> resolve_info_specs(const std::string& fields, const
 class VCFArrayBuilder : public ExonArrayBuilder {
  public:
   // info_dicts: one dictionary per spec (used by the 's' kind only), owned by the caller like the other dictionaries
-  VCFArrayBuilder(Dictionary* chrom_dict, Dictionary* filter_dict, const std::vector<InfoSpec>& specs, std::vector<Dictionary>* info_dicts)
+  VCFArrayBuilder(Dictionary* chrom_dict, Dictionary* filter_dict, const std::vector<InfoSpec>& specs, std::vector<Dictionary>* info_dicts, uint64_t projection = 0)
       : chrom_dict_(chrom_dict), filter_dict_(filter_dict), specs_(specs), info_dicts_(info_dicts), info_f_(specs.size()),
-        info_i_(specs.size()), info_lf_(specs.size()), info_li_(specs.size()) {}
+        info_i_(specs.size()), info_lf_(specs.size()), info_li_(specs.size()), projection_(projection) {}
 
   // one data line (no terminator).  Field rules: lazy_array_builder.rs:159-216.
   void append(const std::string& line) { append(line.data(), line.size()); }
@@ -222,6 +223,26 @@ class VCFArrayBuilder : public ExonArrayBuilder {
     if (fl[6] == 1 && f[6][0] == '.') filter_.append_value(filter_dict_->lookup_or_insert("", 0));
     else filter_.append_value(filter_dict_->lookup_or_insert(f[6], fl[6]));
     if (!specs_.empty()) append_info(f[7], fl[7]);
+    if (projection_ & 1) {  // id: List<Utf8>, NULL when there is none (lazy_array_builder.rs:169-180)
+      if (fl[2] == 0 || (fl[2] == 1 && f[2][0] == '.')) {
+        id_.append_null();
+      } else {
+        size_t a = 0;
+        for (size_t i = 0; i <= fl[2]; ++i)
+          if (i == fl[2] || f[2][i] == ';') {
+            id_.items.append_value(f[2] + a, i - a);
+            a = i + 1;
+          }
+        id_.close_row();
+      }
+    }
+    if (projection_ & 2) ref_.append_value(f[3], fl[3]);  // :181-190
+    if (projection_ & 4) {
+      // alt: the reference builds a string of the alternate bases and then appends the LIST without a value (:191-205): every
+      // record with alternate bases gets an empty list, one without gets NULL
+      if (fl[4] == 0 || (fl[4] == 1 && f[4][0] == '.')) alt_.append_null();
+      else alt_.close_row();
+    }
     ++rows_;
   }
 
@@ -249,6 +270,9 @@ class VCFArrayBuilder : public ExonArrayBuilder {
         out.push_back(a);
       }
     }
+    if (projection_ & 1) out.push_back(id_.finish());
+    if (projection_ & 2) out.push_back(ref_.finish());
+    if (projection_ & 4) out.push_back(alt_.finish());
     rows_ = 0;
     return out;
   }
@@ -451,6 +475,9 @@ class VCFArrayBuilder : public ExonArrayBuilder {
   std::vector<PrimitiveBuilder<int32_t>> info_i_;
   std::vector<ListBuilder<float>> info_lf_;    // 'F'
   std::vector<ListBuilder<int32_t>> info_li_;  // 'I' values, 'S' dictionary ids
+  uint64_t projection_ = 0;
+  ListUtf8Builder id_, alt_;
+  Utf8Builder ref_;
   size_t rows_ = 0;
 };
 
@@ -549,7 +576,7 @@ class VCFBatchReader {
       // multi-threaded decode of the rest of the stream (files of at least a couple of slabs)
       const int threads = cfg_.threads > 0 ? cfg_.threads : decode_threads();
       const long fsize = file_size(path);
-      if (threads > 1 && fsize >= (8 << 20) && !cfg_.defer_decode && !string_info) {
+      if (threads > 1 && fsize >= (8 << 20) && !cfg_.defer_decode && !string_info && !cfg_.projection) {  // (id / ref / alt: the sequential builder)
         StreamSource* ss = static_cast<StreamSource*>(r_.get());
         std::string carry = has_pending_ ? pending_ + "\n" : std::string();
         has_pending_ = false;
@@ -569,7 +596,7 @@ class VCFBatchReader {
   bool read_batch(struct ArrowArray* out) {
     if (pipe_) return read_batch_parallel(out);
     if (cfg_.reference_tail_quirk && n_chunks >= 0 && cfg_.filter.active) return read_batch_reference_quirk(out);
-    VCFArrayBuilder b(&chrom_dict, &filter_dict, info_specs, &info_dicts);
+    VCFArrayBuilder b(&chrom_dict, &filter_dict, info_specs, &info_dicts, cfg_.projection);
     std::string line;
     while ((int64_t)b.len() < cfg_.batch_size) {
       if (has_pending_) {
@@ -592,7 +619,7 @@ class VCFBatchReader {
   // until batch_size of them passed `filter` or the chunk ends; the second loop then reads up to batch_size MORE records and
   // appends them WITHOUT the test (it reads nothing when the first loop stopped at the chunk's end).  Opt-in only.
   bool read_batch_reference_quirk(struct ArrowArray* out) {
-    VCFArrayBuilder b(&chrom_dict, &filter_dict, info_specs, &info_dicts);
+    VCFArrayBuilder b(&chrom_dict, &filter_dict, info_specs, &info_dicts, cfg_.projection);
     std::string line;
     for (;;) {  // skip chunks that yield nothing (the reference's stream of such a chunk ends without a batch)
       if (!r_->next_record()) return false;
@@ -682,6 +709,9 @@ class VCFBatchReader {
       else if (sp.kind == 'S') kids.push_back(new_list_field("i", name.c_str(), new_field("u", "", false)));
       else kids.push_back(new_field("i", name.c_str(), true, new_field("u", "", false)));
     }
+    if (cfg_.projection & 1) kids.push_back(new_list_field("u", "id"));
+    if (cfg_.projection & 2) kids.push_back(new_field("u", "ref", false));
+    if (cfg_.projection & 4) kids.push_back(new_list_field("u", "alt"));
     make_schema(out, "+s", "", false, kids);
   }
 
@@ -767,12 +797,49 @@ struct BAMConfig {
   int64_t batch_size = DEFAULT_BATCH_SIZE;
   int threads = 0;  // BGZF inflate threads (0 = all host cores)
   RegionFilter filter;  // bam_region_filter: SemiLazyRecord::intersects
+  uint64_t projection = 0;  // EXON_HIP_PROJECT_BAM_*: name / cigar / sequence / quality_scores behind the default columns
 };
 
 // device-layout BAM batch: flag i32, mapq u8? (255 -> NULL), reference dict? (-1 -> NULL), start i64?, end i64?
 class BAMArrayBuilder : public ExonArrayBuilder {
  public:
-  explicit BAMArrayBuilder(const std::vector<std::string>* ref_names) : ref_names_(ref_names) {}
+  explicit BAMArrayBuilder(const std::vector<std::string>* ref_names, uint64_t projection = 0) : ref_names_(ref_names), projection_(projection) {}
+  // the record's variable part (exon-bam/src/array_builder.rs:105-201); rec = the bytes behind block_size
+  void append_text(const uint8_t* rec, size_t n) {
+    if (!projection_) return;
+    const uint32_t l_name = rec[8];
+    uint16_t n_cigar;
+    int32_t l_seq;
+    memcpy(&n_cigar, rec + 12, 2);
+    memcpy(&l_seq, rec + 16, 4);
+    const uint8_t* c = rec + 32 + l_name;
+    const uint8_t* s = c + 4u * n_cigar;
+    const uint8_t* q = s + ((size_t)l_seq + 1) / 2;
+    if (l_seq < 0 || (size_t)(q - rec) + (size_t)l_seq > n) throw std::runtime_error("corrupt BAM record");
+    if (projection_ & 1) {
+      if (l_name == 2 && rec[32] == '*') name_.append_null();  // noodles: "*" is a missing name
+      else name_.append_value(reinterpret_cast<const char*>(rec + 32), l_name ? l_name - 1 : 0);
+    }
+    if (projection_ & 2) {
+      std::string t;
+      for (uint16_t k = 0; k < n_cigar; ++k) {
+        uint32_t op;
+        memcpy(&op, c + 4u * k, 4);
+        t += std::to_string(op >> 4);
+        t += (op & 0xF) < 9 ? "MIDNSHP=X"[op & 0xF] : '?';
+      }
+      cigar_.append_value(t);
+    }
+    if (projection_ & 4) {
+      std::string t((size_t)l_seq, '=');
+      for (int32_t i = 0; i < l_seq; ++i) t[(size_t)i] = "=ACMGRSVTWYHKDBN"[(s[i >> 1] >> ((i & 1) ? 0 : 4)) & 0xF];
+      seq_.append_value(t);
+    }
+    if (projection_ & 8) {
+      for (int32_t i = 0; i < l_seq; ++i) qual_.items.append_value((int64_t)(int8_t)q[i]);
+      qual_.close_row();
+    }
+  }
   void append(int32_t flag, int32_t ref_id, int64_t pos0, int mapq, int64_t ref_len) {
     flag_.append_value(flag);  // array_builder.rs:114-117: raw u16 bits as Int32
     if (mapq == 255) mapq_.append_null(255);  // :136-143 (reference: decimal string, NULL when missing)
@@ -791,7 +858,16 @@ class BAMArrayBuilder : public ExonArrayBuilder {
   size_t len() const override { return rows_; }
   std::vector<struct ArrowArray*> finish() override {
     rows_ = 0;
-    return {flag_.finish(), mapq_.finish(), ref_.finish(utf8_array(*ref_names_)), start_.finish(), end_.finish()};
+    std::vector<struct ArrowArray*> out = {flag_.finish(), mapq_.finish(), ref_.finish(utf8_array(*ref_names_)), start_.finish(), end_.finish()};
+    if (projection_ & 1) out.push_back(name_.finish());
+    if (projection_ & 2) out.push_back(cigar_.finish());
+    if (projection_ & 4) out.push_back(seq_.finish());
+    if (projection_ & 8) {
+      // (quality_scores items are never NULL: the child carries no validity bitmap)
+      qual_.items.valid.clear();
+      out.push_back(qual_.finish());
+    }
+    return out;
   }
 
  private:
@@ -799,6 +875,9 @@ class BAMArrayBuilder : public ExonArrayBuilder {
   PrimitiveBuilder<int32_t> flag_, ref_;
   PrimitiveBuilder<uint8_t> mapq_;
   PrimitiveBuilder<int64_t> start_, end_;
+  uint64_t projection_ = 0;
+  Utf8Builder name_, cigar_, seq_;
+  ListBuilder<int64_t> qual_;
   size_t rows_ = 0;
 };
 
@@ -840,7 +919,7 @@ class BAMBatchReader {
   int64_t data_offset() const { return n_chunks >= 0 ? -1 : (int64_t)static_cast<StreamSource*>(r_.get())->r.consumed(); }
 
   bool read_batch(struct ArrowArray* out) {
-    BAMArrayBuilder b(&ref_names);
+    BAMArrayBuilder b(&ref_names, cfg_.projection);
     std::vector<uint8_t> rec;
     while ((int64_t)b.len() < cfg_.batch_size) {
       uint8_t szb[4];
@@ -875,6 +954,7 @@ class BAMBatchReader {
         if (!(ref_id == region_ref_id_ && s <= rg.end && rg.start <= e)) continue;
       }
       b.append((int32_t)flag, ref_id, pos, mapq, ref_len);
+      b.append_text(rec.data(), rec.size());
     }
     if (b.is_empty()) return false;
     b.try_into_record_batch(out);
@@ -882,10 +962,14 @@ class BAMBatchReader {
   }
 
   void schema(struct ArrowSchema* out) const {
-    make_schema(out, "+s", "", false,
-                {new_field("i", "flag", false), new_field("C", "mapping_quality", true),
-                 new_field("i", "reference", true, new_field("u", "", false)), new_field("l", "start", true),
-                 new_field("l", "end", true)});
+    std::vector<struct ArrowSchema*> kids = {new_field("i", "flag", false), new_field("C", "mapping_quality", true),
+                                             new_field("i", "reference", true, new_field("u", "", false)), new_field("l", "start", true),
+                                             new_field("l", "end", true)};
+    if (cfg_.projection & 1) kids.push_back(new_field("u", "name", true));
+    if (cfg_.projection & 2) kids.push_back(new_field("u", "cigar", false));
+    if (cfg_.projection & 4) kids.push_back(new_field("u", "sequence", false));
+    if (cfg_.projection & 8) kids.push_back(new_list_field("l", "quality_score"));
+    make_schema(out, "+s", "", false, kids);
   }
 
   std::string header_text;
@@ -1141,7 +1225,7 @@ class FASTQBatchReader {
   void schema(struct ArrowSchema* out) const {
     make_schema(out, "+s", "", false,
                 {new_field("u", "name", false), new_field("u", "description", true), new_field("u", "sequence", false),
-                 new_field("u", "quality_scores", false)});
+                 new_field("u", "quality_score", false)});
   }
 
  private:

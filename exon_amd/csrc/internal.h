@@ -52,6 +52,34 @@ const void* exon_hip_gpu_local_cpus(int device);  // scan.cpp: a cpu_set_t of th
 void exon_hip_run_on(const void* cpus);            // ... the calling thread's affinity set to it (host threads that feed the DMA engine)
 void exon_hip_prewarm_ctx(exon_hip_ctx* ctx);  // scan.cpp: the file pipelines' side streams and events, made with the context
 
+// text_columns.hip: the reference's string / list columns of a slab as Arrow buffers on the device (exon_hip_scan_options.projection)
+struct ExonTextScratch;
+struct ExonVcfText {
+  const int32_t* id_list_offsets;  // [n_rows + 1] -> items
+  const uint8_t* id_valid;         // bitmap: the ID field is not '.'
+  const int32_t* id_item_offsets;  // [n_id_items + 1] -> id_values
+  const uint8_t* id_values;
+  int64_t n_id_items, n_id_bytes;
+  const int32_t* ref_offsets;      // [n_rows + 1]
+  const uint8_t* ref_values;
+  int64_t n_ref_bytes;
+  const uint8_t* alt_valid;        // bitmap: the ALT field is not '.' (the list itself has no items: see text_columns.hip)
+};
+struct ExonBamText {
+  const int32_t *name_offsets, *cigar_offsets, *seq_offsets;  // [n_rows + 1] each; seq_offsets are quality_scores' list offsets too
+  const uint8_t *name_values, *cigar_values, *seq_values, *name_valid;
+  const int64_t* qual_values;
+  int64_t n_name_bytes, n_cigar_bytes, n_seq_bytes;
+};
+int exon_text_vcf(exon_hip_ctx* ctx, void* stream, ExonTextScratch** scratch, const uint8_t* d_text, int64_t n_bytes, const unsigned* d_nl, int64_t n_rows, uint64_t projection,
+                  ExonVcfText* out);
+int exon_text_bam(exon_hip_ctx* ctx, void* stream, ExonTextScratch** scratch, const uint8_t* d_data, int64_t n_bytes, const uint32_t* d_rec_of_row, int64_t n_rows, uint64_t projection,
+                  ExonBamText* out);
+void exon_text_scratch_destroy(ExonTextScratch* s);
+// the parsers' own indexes the text columns are built from (valid until the next parse call)
+const unsigned* exon_hip_vcf_parser_newlines(exon_hip_vcf_parser* p);      // gpu_parse.hip: byte offset of every line's '\n' in the aligned slab
+const uint32_t* exon_hip_bam_parser_row_records(exon_hip_bam_parser* p);   // bam_parse.hip: byte offset of every row's record
+
 // capi.cpp: size-keyed recycling of device buffers (released by exon_hip_ctx_destroy)
 void* exon_pool_alloc(exon_hip_ctx* ctx, size_t bytes);
 void exon_pool_free(exon_hip_ctx* ctx, void* p);

@@ -59,6 +59,7 @@ struct exon_hip_scan {
   size_t region_mask_cap = 0;
   unsigned long long* d_region_pass = nullptr;  // rows kept so far in this consume
   exon_hip_ctx* region_ctx = nullptr;
+  ExonTextScratch* text_scratch = nullptr;  // device buffers of the projected string / list columns (text_columns.hip)
 };
 
 // Batches from the GPU decode pipeline (exon_hip_scan_bind_ctx + exon_hip_scan_next on a scan opened with gpu_parse): a producer
@@ -192,12 +193,16 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
       rf.use_index = o->use_index != 0;
     }
     s->region = rf;
+    if (o->projection && o->format != EXON_HIP_FORMAT_VCF && o->format != EXON_HIP_FORMAT_BAM)
+      return fail(nullptr, EXON_HIP_EUNSUPPORTED, "exon_hip_scan_options.projection: the id / ref / alt and name / cigar / sequence / quality_scores columns are built for VCF text and BAM scans");
     switch (o->format) {
       case EXON_HIP_FORMAT_VCF: {
         exon::VCFConfig cfg;
         cfg.batch_size = bs;
         cfg.info_field = o->info_field ? o->info_field : "";
         cfg.filter = rf;
+        cfg.projection = o->projection;
+        if (o->projection & ~7ull) return fail(nullptr, EXON_HIP_EINVAL, "projection 0x%llx: VCF knows EXON_HIP_PROJECT_VCF_ID / _REF / _ALT", (unsigned long long)o->projection);
         // a pushed-down region filter rides along as a row mask (k_region_mask); with use_index the host plans the
         // tabix chunks and only their BGZF blocks are shipped (indexed scans are BGZF by definition)
         s->gpu_parse = o->gpu_parse != 0 && (!rf.use_index || (rf.active && wants_gpu_inflate(o, path)));
@@ -228,6 +233,8 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         exon::BAMConfig cfg;
         cfg.batch_size = bs;
         cfg.filter = rf;
+        cfg.projection = o->projection;
+        if (o->projection & ~15ull) return fail(nullptr, EXON_HIP_EINVAL, "projection 0x%llx: BAM knows EXON_HIP_PROJECT_BAM_NAME / _CIGAR / _SEQUENCE / _QUALITY_SCORES", (unsigned long long)o->projection);
         // BAM is BGZF by definition: the GPU path inflates and splits records on the device or is not taken at all
         s->gpu_parse = wants_gpu_inflate(o, path);  // with a region: row mask on the device, BAI chunks planned on the host
         if (s->gpu_parse) cfg.threads = 1;  // only the header is read on the host
@@ -423,6 +430,7 @@ int exon_hip_scan_close(exon_hip_scan* s) {
   if (s && s->bam_parser) exon_hip_bam_parser_destroy(s->bam_parser);
   if (s && s->bcf_parser) exon_hip_bcf_parser_destroy(s->bcf_parser);
   if (s && s->sam_parser) exon_hip_sam_parser_destroy(s->sam_parser);
+  if (s && s->text_scratch) exon_text_scratch_destroy(s->text_scratch);
   if (s && s->d_region_mask) hipFree(s->d_region_mask);
   if (s && s->d_region_pass) hipFree(s->d_region_pass);
   delete s;
@@ -1732,9 +1740,122 @@ void export_block_put(void* p, size_t bytes) {
 // One slab's device columns -> one pinned host block -> batch_size-row Arrow batches on the exporter's queue.  Without a region
 // mask the batches are VIEWS into the block (children with an offset; validity bitmaps shared, null counts left to the
 // consumer); with one the kept rows are gathered.  Returns 2 when the consumer has gone away (scan closed with batches left).
-static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n_rows, const uint8_t* row_mask, hipStream_t hs) {
+// the projected string / list columns of a slab, copied back: per-batch arrays are cut out of these
+struct HostText {
+  bool vcf = false, bam = false;
+  uint64_t projection = 0;
+  std::vector<int32_t> off[3], item_off;
+  std::vector<uint8_t> val[3], valid[2];
+  std::vector<int64_t> qual;
+};
+static int fetch_text(exon_hip_ctx* ctx, hipStream_t hs, int64_t n_rows, uint64_t projection, const ExonVcfText* vt, const ExonBamText* bt, HostText* h) {
+  h->projection = projection;
+  hipError_t e = hipSuccess;
+  auto get = [&](auto& vec, const void* src, size_t count) {
+    vec.resize(count);
+    if (e == hipSuccess && count && src) e = hipMemcpyAsync(vec.data(), src, count * sizeof(vec[0]), hipMemcpyDeviceToHost, hs);
+  };
+  const size_t n = (size_t)n_rows, nb = (n + 7) / 8;
+  if (vt) {
+    h->vcf = true;
+    if (projection & EXON_HIP_PROJECT_VCF_ID) {
+      get(h->off[0], vt->id_list_offsets, n + 1);
+      get(h->valid[0], vt->id_valid, nb);
+      get(h->item_off, vt->id_item_offsets, (size_t)vt->n_id_items + 1);
+      get(h->val[0], vt->id_values, (size_t)vt->n_id_bytes);
+    }
+    if (projection & EXON_HIP_PROJECT_VCF_REF) {
+      get(h->off[2], vt->ref_offsets, n + 1);
+      get(h->val[2], vt->ref_values, (size_t)vt->n_ref_bytes);
+    }
+    if (projection & EXON_HIP_PROJECT_VCF_ALT) get(h->valid[1], vt->alt_valid, nb);
+  }
+  if (bt) {
+    h->bam = true;
+    if (projection & EXON_HIP_PROJECT_BAM_NAME) {
+      get(h->off[0], bt->name_offsets, n + 1);
+      get(h->val[0], bt->name_values, (size_t)bt->n_name_bytes);
+      get(h->valid[0], bt->name_valid, nb);
+    }
+    if (projection & EXON_HIP_PROJECT_BAM_CIGAR) {
+      get(h->off[1], bt->cigar_offsets, n + 1);
+      get(h->val[1], bt->cigar_values, (size_t)bt->n_cigar_bytes);
+    }
+    if (projection & (EXON_HIP_PROJECT_BAM_SEQUENCE | EXON_HIP_PROJECT_BAM_QUALITY_SCORES)) get(h->off[2], bt->seq_offsets, n + 1);
+    if (projection & EXON_HIP_PROJECT_BAM_SEQUENCE) get(h->val[2], bt->seq_values, (size_t)bt->n_seq_bytes);
+    if (projection & EXON_HIP_PROJECT_BAM_QUALITY_SCORES) get(h->qual, bt->qual_values, (size_t)bt->n_seq_bytes);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(hs);
+  if (e != hipSuccess) return fail(ctx, EXON_HIP_EDEVICE, "string columns of a slab back to the host: %s", hipGetErrorString(e));
+  return EXON_HIP_OK;
+}
+// the projected columns of the rows `rows[0 .. n)` of the slab (in the order of the projection bits), appended to `kids`
+static void text_batch(const HostText& h, const int64_t* rows, int64_t r0, int64_t n, std::vector<struct ArrowArray*>* kids) {
+  auto row_at = [&](int64_t i) { return rows ? rows[i] : r0 + i; };
+  auto bit = [&](const std::vector<uint8_t>& bm, int64_t r) { return (uint8_t)((bm[(size_t)(r >> 3)] >> (r & 7)) & 1); };
+  auto utf8 = [&](const std::vector<int32_t>& off, const std::vector<uint8_t>& val, const std::vector<uint8_t>* valid) {
+    exon::Utf8Builder b;
+    for (int64_t i = 0; i < n; ++i) {
+      const int64_t r = row_at(i);
+      if (valid && !bit(*valid, r)) b.append_null();
+      else b.append_value(reinterpret_cast<const char*>(val.data()) + off[(size_t)r], (size_t)(off[(size_t)r + 1] - off[(size_t)r]));
+    }
+    if (!valid) b.valid.clear();
+    return b.finish();
+  };
+  if (h.vcf) {
+    if (h.projection & EXON_HIP_PROJECT_VCF_ID) {
+      exon::ListUtf8Builder b;
+      for (int64_t i = 0; i < n; ++i) {
+        const int64_t r = row_at(i);
+        if (!bit(h.valid[0], r)) {
+          b.append_null();
+          continue;
+        }
+        for (int32_t k = h.off[0][(size_t)r]; k < h.off[0][(size_t)r + 1]; ++k)
+          b.items.append_value(reinterpret_cast<const char*>(h.val[0].data()) + h.item_off[(size_t)k], (size_t)(h.item_off[(size_t)k + 1] - h.item_off[(size_t)k]));
+        b.close_row();
+      }
+      b.items.valid.clear();
+      kids->push_back(b.finish());
+    }
+    if (h.projection & EXON_HIP_PROJECT_VCF_REF) kids->push_back(utf8(h.off[2], h.val[2], nullptr));
+    if (h.projection & EXON_HIP_PROJECT_VCF_ALT) {
+      exon::ListUtf8Builder b;
+      for (int64_t i = 0; i < n; ++i) {
+        if (bit(h.valid[1], row_at(i))) b.close_row();
+        else b.append_null();
+      }
+      b.items.valid.clear();
+      kids->push_back(b.finish());
+    }
+  }
+  if (h.bam) {
+    if (h.projection & EXON_HIP_PROJECT_BAM_NAME) kids->push_back(utf8(h.off[0], h.val[0], &h.valid[0]));
+    if (h.projection & EXON_HIP_PROJECT_BAM_CIGAR) kids->push_back(utf8(h.off[1], h.val[1], nullptr));
+    if (h.projection & EXON_HIP_PROJECT_BAM_SEQUENCE) kids->push_back(utf8(h.off[2], h.val[2], nullptr));
+    if (h.projection & EXON_HIP_PROJECT_BAM_QUALITY_SCORES) {
+      exon::ListBuilder<int64_t> b;
+      for (int64_t i = 0; i < n; ++i) {
+        const int64_t r = row_at(i);
+        const int32_t a = h.off[2][(size_t)r], z = h.off[2][(size_t)r + 1];
+        b.items.values.insert(b.items.values.end(), h.qual.begin() + a, h.qual.begin() + z);
+        b.close_row();
+      }
+      kids->push_back(b.finish());
+    }
+  }
+}
+
+static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n_rows, const uint8_t* row_mask, hipStream_t hs, const ExonVcfText* vt = nullptr,
+                       const ExonBamText* bt = nullptr) {
   GpuExporter* ex = scan->exporter;
   exon_hip_ctx* ctx = ex->ctx;
+  HostText text;
+  if ((vt || bt) && scan->opt.projection) {
+    const int rc = fetch_text(ctx, hs, n_rows, scan->opt.projection, vt, bt, &text);
+    if (rc) return rc;
+  }
   const bool vcf_like = scan->vcf || scan->bcf;
   const std::vector<exon::InfoSpec>* specs = scan->vcf ? &scan->vcf->info_specs : scan->bcf ? &scan->bcf->info_specs : nullptr;
   const int n_cols = vcf_like ? 4 + (int)specs->size() : 5;
@@ -1820,6 +1941,7 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
         a->offset = b0;
         kids.push_back(a);
       }
+      if (text.vcf || text.bam) text_batch(text, nullptr, b0, n, &kids);
       const int rc = enqueue(std::move(kids), n);
       if (rc) return rc;
     }
@@ -1860,6 +1982,7 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
         kids.push_back(a);
       }
     }
+    if (text.vcf || text.bam) text_batch(text, keep.data() + b0, 0, n, &kids);
     const int rc = enqueue(std::move(kids), n);
     if (rc) return rc;
   }
@@ -2089,6 +2212,14 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
                                                   scan->d_region_mask, scan->d_region_pass));
             row_mask = scan->d_region_mask;
           }
+          if (scan->exporter && scan->opt.projection && (is_vcf || is_bam)) {
+            // the reference's string / list columns of this slab, built on the device from the index the parser has just made
+            ExonVcfText vt;
+            ExonBamText bt;
+            rc = is_vcf ? exon_text_vcf(ctx, hs, &scan->text_scratch, d_text, (int64_t)n, exon_hip_vcf_parser_newlines(scan->parser), n_rows, scan->opt.projection, &vt)
+                        : exon_text_bam(ctx, hs, &scan->text_scratch, d_text, (int64_t)n, exon_hip_bam_parser_row_records(scan->bam_parser), n_rows, scan->opt.projection, &bt);
+            if (!rc) rc = export_slab(scan, sc, n_rows, row_mask, hs, is_vcf ? &vt : nullptr, is_bam ? &bt : nullptr);
+          } else
           rc = scan->exporter ? export_slab(scan, sc, n_rows, row_mask, hs)
                               : exon_hip_stream_launch_scan_columns(st, sc, 4 + EXON_HIP_MAX_INFO_FIELDS, n_rows, row_mask);
           // the parser's column buffers (and the row mask) are reused by the next slab; the kernel is stream-ordered before that

@@ -1,0 +1,391 @@
+// text_columns.hip -- the reference's STRING / LIST columns out of the GPU decode pipeline: Arrow Utf8 / List<Utf8> / List<Int64>
+// buffers (offsets + compact values) built on the device from the slab the parsers have just indexed.
+//
+// Reference columns rebuilt here (the ones outside the fused kernels' operands, selected by exon_hip_scan_options.projection):
+//   VCF  id         List<Utf8>, NULL when the ID field is '.'       exon-vcf/src/array_builder/lazy_array_builder.rs:169-180
+//        ref        Utf8                                             :181-190
+//        alt        List<Utf8>: NULL when ALT is '.', otherwise a list with NO items -- the reference concatenates the alternate
+//                   bases into a local string and then calls `alternates.append(true)` without ever appending a value (:191-205);
+//                   reproduced as it is (results identical to the reference's), the quirk is written down in DESIGN.md
+//   BAM  name       Utf8, NULL for '*'                                exon-bam/src/array_builder.rs:105-113
+//        cigar      Utf8, "<len><op>..." with ops MIDNSHP=X           :144-167
+//        sequence   Utf8, 4-bit codes through "=ACMGRSVTWYHKDBN"      :178-183
+//        quality_scores  List<Int64>, the raw bytes as i8 -> i64      :184-201
+// One thread per row measures, an exclusive scan turns lengths into offsets, one thread per row fills (rows are short; the bytes
+// of a slab are read twice, L2-resident the second time).  Nothing here is on the fused kernels' path: a scan that projects none of
+// these columns launches none of this.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+#include "internal.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+// ---- exclusive scan of n u32 lengths into n + 1 int32 offsets (three launches; n is known on the host) ------------------------------
+__global__ __launch_bounds__(TPB) void k_block_sums(const uint32_t* __restrict__ len, unsigned n, unsigned* __restrict__ sums) {
+  __shared__ unsigned red[TPB / 64];
+  const unsigned i = blockIdx.x * TPB + threadIdx.x;
+  unsigned c = i < n ? len[i] : 0u;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void k_scan_sums(unsigned* __restrict__ sums, int nb, unsigned* __restrict__ total) {
+  __shared__ unsigned part[256];
+  const int per = (nb + 255) / 256;
+  const int b0 = threadIdx.x * per, b1 = min(nb, b0 + per);
+  unsigned s = 0;
+  for (int b = b0; b < b1; ++b) s += sums[b];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const unsigned v = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  unsigned run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
+  for (int b = b0; b < b1; ++b) {
+    const unsigned c = sums[b];
+    sums[b] = run;
+    run += c;
+  }
+  if (threadIdx.x == 255) *total = part[255];
+}
+__global__ __launch_bounds__(TPB) void k_write_offsets(const uint32_t* __restrict__ len, unsigned n, const unsigned* __restrict__ sums, int32_t* __restrict__ offsets) {
+  __shared__ unsigned wave_tot[TPB / 64];
+  const unsigned i = blockIdx.x * TPB + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned c = i < n ? len[i] : 0u;
+  unsigned incl = c;
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  unsigned base = sums[blockIdx.x];
+  for (int w = 0; w < wave; ++w) base += wave_tot[w];
+  if (i < n) offsets[i] = (int32_t)(base + incl - c);
+  if (i == n - 1) offsets[n] = (int32_t)(base + incl);
+}
+
+// ---- VCF ---------------------------------------------------------------------------------------------------------------------------
+// line r of the slab: [begin, end) in the aligned text; fields 2, 3, 4 (ID, REF, ALT) by their tabs
+struct VcfLens {
+  uint32_t* id_items;   // items of the ID list (0 for '.')
+  uint32_t* id_bytes;   // bytes of its items (the ';' between them do not count)
+  uint32_t* ref_bytes;
+  uint32_t* field_off;  // [3 n]: where ID, REF, ALT start
+  uint32_t* field_len;  // [3 n]
+};
+__global__ __launch_bounds__(TPB) void k_vcf_measure(const uint8_t* __restrict__ text, const unsigned* __restrict__ nl, unsigned n_rows, unsigned skip, VcfLens o,
+                                                     uint32_t* __restrict__ id_valid, uint32_t* __restrict__ alt_valid) {
+  const unsigned row = blockIdx.x * TPB + threadIdx.x;
+  bool idv = false, altv = false;
+  if (row < n_rows) {
+    const unsigned begin = row ? nl[row - 1] + 1 : skip;
+    unsigned end = nl[row];
+    if (end > begin && text[end - 1] == '\r') --end;
+    unsigned fs[6];
+    int nf = 0;
+    fs[0] = begin;
+    for (unsigned i = begin; i < end && nf < 5; ++i)
+      if (text[i] == '\t') fs[++nf] = i + 1;
+    // (rows with fewer than 5 fields are not data lines: the parser has counted them undecided, the slab goes to the host reader)
+    unsigned off[3] = {0, 0, 0}, len[3] = {0, 0, 0};
+    for (int f = 0; f < 3; ++f)
+      if (nf >= f + 3) {
+        off[f] = fs[f + 2];
+        len[f] = fs[f + 3] - 1 - fs[f + 2];
+      } else if (nf == f + 2) {
+        off[f] = fs[f + 2];
+        len[f] = end - fs[f + 2];
+      }
+    unsigned items = 0, bytes = 0;
+    if (!(len[0] == 0 || (len[0] == 1 && text[off[0]] == '.'))) {
+      items = 1;
+      bytes = len[0];
+      for (unsigned i = 0; i < len[0]; ++i)
+        if (text[off[0] + i] == ';') {
+          ++items;
+          --bytes;
+        }
+      idv = true;
+    }
+    altv = !(len[2] == 0 || (len[2] == 1 && text[off[2]] == '.'));
+    o.id_items[row] = items;
+    o.id_bytes[row] = bytes;
+    o.ref_bytes[row] = len[1];
+    for (int f = 0; f < 3; ++f) {
+      o.field_off[3 * row + f] = off[f];
+      o.field_len[3 * row + f] = len[f];
+    }
+  }
+  // validity bitmaps: one word per 32 rows (a wave covers two)
+  const unsigned long long bi = __ballot(idv), ba = __ballot(altv);
+  const unsigned lane = threadIdx.x & 63u, wrow = row - lane;
+  if (lane < 2 && wrow + 32 * lane < n_rows) {
+    id_valid[(wrow >> 5) + lane] = (uint32_t)(bi >> (32 * lane));
+    alt_valid[(wrow >> 5) + lane] = (uint32_t)(ba >> (32 * lane));
+  }
+}
+__global__ __launch_bounds__(TPB) void k_vcf_fill(const uint8_t* __restrict__ text, unsigned n_rows, VcfLens o, const int32_t* __restrict__ id_list_off,
+                                                  const int32_t* __restrict__ id_byte_off, const int32_t* __restrict__ ref_off, int32_t* __restrict__ id_item_off,
+                                                  uint8_t* __restrict__ id_values, uint8_t* __restrict__ ref_values, unsigned id_items_total, unsigned id_bytes_total) {
+  const unsigned row = blockIdx.x * TPB + threadIdx.x;
+  if (row >= n_rows) return;
+  {  // REF
+    const unsigned off = o.field_off[3 * row + 1], len = o.field_len[3 * row + 1];
+    uint8_t* dst = ref_values + ref_off[row];
+    for (unsigned i = 0; i < len; ++i) dst[i] = text[off + i];
+  }
+  const unsigned items = o.id_items[row];
+  if (items) {  // ID: the items back to back, an offset per item
+    const unsigned off = o.field_off[3 * row + 0], len = o.field_len[3 * row + 0];
+    unsigned k = (unsigned)id_list_off[row], w = (unsigned)id_byte_off[row];
+    id_item_off[k++] = (int32_t)w;
+    for (unsigned i = 0; i < len; ++i) {
+      const uint8_t c = text[off + i];
+      if (c == ';') id_item_off[k++] = (int32_t)w;
+      else id_values[w++] = c;
+    }
+  }
+  if (row == n_rows - 1) id_item_off[id_items_total] = (int32_t)id_bytes_total;
+}
+
+// ---- BAM ---------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ld32u(const uint8_t* p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+__device__ __forceinline__ unsigned dec_digits(uint32_t v) {
+  unsigned d = 1;
+  while (v >= 10) {
+    v /= 10;
+    ++d;
+  }
+  return d;
+}
+struct BamLens {
+  uint32_t* name_bytes;
+  uint32_t* cigar_bytes;
+  uint32_t* seq_bytes;  // = items of quality_scores
+};
+__global__ __launch_bounds__(TPB) void k_bam_measure(const uint8_t* __restrict__ d, const uint32_t* __restrict__ rec_of_row, unsigned n_rows, BamLens o,
+                                                     uint32_t* __restrict__ name_valid) {
+  const unsigned row = blockIdx.x * TPB + threadIdx.x;
+  bool nv = false;
+  if (row < n_rows) {
+    const uint8_t* r = d + rec_of_row[row];
+    const uint32_t l_name = r[12], n_cigar = (uint32_t)r[16] | (uint32_t)r[17] << 8, l_seq = ld32u(r + 20);
+    // noodles: a read name of "*" is a missing name (Record::name -> None)
+    nv = !(l_name == 2 && r[36] == '*');
+    o.name_bytes[row] = nv ? l_name - 1 : 0u;
+    unsigned cb = 0;
+    const uint8_t* c = r + 36 + l_name;
+    for (uint32_t k = 0; k < n_cigar; ++k) cb += dec_digits(ld32u(c + 4 * k) >> 4) + 1;
+    o.cigar_bytes[row] = cb;
+    o.seq_bytes[row] = l_seq;
+  }
+  const unsigned long long b = __ballot(nv);
+  const unsigned lane = threadIdx.x & 63u, wrow = row - lane;
+  if (lane < 2 && wrow + 32 * lane < n_rows) name_valid[(wrow >> 5) + lane] = (uint32_t)(b >> (32 * lane));
+}
+__global__ __launch_bounds__(TPB) void k_bam_fill(const uint8_t* __restrict__ d, const uint32_t* __restrict__ rec_of_row, unsigned n_rows, uint64_t projection,
+                                                  const int32_t* __restrict__ name_off, const int32_t* __restrict__ cigar_off, const int32_t* __restrict__ seq_off,
+                                                  uint8_t* __restrict__ name_values, uint8_t* __restrict__ cigar_values, uint8_t* __restrict__ seq_values,
+                                                  int64_t* __restrict__ qual_values) {
+  const unsigned row = blockIdx.x * TPB + threadIdx.x;
+  if (row >= n_rows) return;
+  const uint8_t* r = d + rec_of_row[row];
+  const uint32_t l_name = r[12], n_cigar = (uint32_t)r[16] | (uint32_t)r[17] << 8, l_seq = ld32u(r + 20);
+  if (projection & EXON_HIP_PROJECT_BAM_NAME) {
+    const unsigned n = (unsigned)(name_off[row + 1] - name_off[row]);
+    uint8_t* dst = name_values + name_off[row];
+    for (unsigned i = 0; i < n; ++i) dst[i] = r[36 + i];
+  }
+  const uint8_t* c = r + 36 + l_name;
+  if (projection & EXON_HIP_PROJECT_BAM_CIGAR) {
+    uint8_t* dst = cigar_values + cigar_off[row];
+    for (uint32_t k = 0; k < n_cigar; ++k) {
+      const uint32_t op = ld32u(c + 4 * k);
+      uint32_t v = op >> 4;
+      const unsigned nd = dec_digits(v);
+      for (unsigned i = nd; i > 0; --i) {
+        dst[i - 1] = (uint8_t)('0' + v % 10);
+        v /= 10;
+      }
+      dst += nd;
+      const uint32_t code = op & 0xF;
+      *dst++ = code < 9 ? (uint8_t)"MIDNSHP=X"[code] : (uint8_t)'?';
+    }
+  }
+  const uint8_t* s = c + 4 * n_cigar;
+  if (projection & EXON_HIP_PROJECT_BAM_SEQUENCE) {
+    uint8_t* dst = seq_values + seq_off[row];
+    for (uint32_t i = 0; i < l_seq; ++i) dst[i] = (uint8_t)"=ACMGRSVTWYHKDBN"[(s[i >> 1] >> ((i & 1) ? 0 : 4)) & 0xF];
+  }
+  if (projection & EXON_HIP_PROJECT_BAM_QUALITY_SCORES) {
+    const uint8_t* q = s + (l_seq + 1) / 2;
+    int64_t* dst = qual_values + seq_off[row];
+    for (uint32_t i = 0; i < l_seq; ++i) dst[i] = (int64_t)(int8_t)q[i];
+  }
+}
+
+}  // namespace
+
+// ---- host side -----------------------------------------------------------------------------------------------------------------------
+struct ExonTextScratch {
+  exon_hip_ctx* ctx = nullptr;
+  int64_t max_rows = 0, max_bytes = 0;
+  uint32_t* len[3] = {nullptr, nullptr, nullptr};
+  int32_t* off[3] = {nullptr, nullptr, nullptr};
+  uint32_t* valid[2] = {nullptr, nullptr};
+  uint32_t *field_off = nullptr, *field_len = nullptr;
+  unsigned* sums = nullptr;
+  unsigned* totals = nullptr;    // device [4]
+  unsigned* h_totals = nullptr;  // pinned
+  int32_t* item_off = nullptr;   // VCF id items
+  uint8_t* values[3] = {nullptr, nullptr, nullptr};
+  int64_t* qual = nullptr;
+  size_t qual_cap = 0;
+};
+
+void exon_text_scratch_destroy(ExonTextScratch* s) {
+  if (!s) return;
+  auto f = [&](void* p) { if (p) exon_pool_free(s->ctx, p); };
+  for (int k = 0; k < 3; ++k) f(s->len[k]), f(s->off[k]), f(s->values[k]);
+  f(s->valid[0]), f(s->valid[1]), f(s->field_off), f(s->field_len), f(s->sums), f(s->totals), f(s->item_off), f(s->qual);
+  if (s->h_totals) hipHostFree(s->h_totals);
+  delete s;
+}
+
+static int scratch_for(exon_hip_ctx* ctx, ExonTextScratch** sp, int64_t max_rows, int64_t max_bytes, bool vcf) {
+  ExonTextScratch* s = *sp;
+  if (s && s->max_rows >= max_rows && s->max_bytes >= max_bytes) return EXON_HIP_OK;
+  if (s) exon_text_scratch_destroy(s);
+  *sp = nullptr;
+  s = new (std::nothrow) ExonTextScratch();
+  if (!s) return fail(ctx, EXON_HIP_ENOMEM, "out of host memory");
+  s->ctx = ctx;
+  s->max_rows = max_rows;
+  s->max_bytes = max_bytes;
+  hipSetDevice(ctx->device);
+  bool ok = true;
+  auto a = [&](void** p, size_t bytes) {
+    if (ok && !(*p = exon_pool_alloc(ctx, bytes))) ok = false;
+  };
+  const size_t r = (size_t)max_rows + 64;
+  for (int k = 0; k < 3; ++k) {
+    a((void**)&s->len[k], r * 4);
+    a((void**)&s->off[k], (r + 1) * 4);
+    a((void**)&s->values[k], (size_t)max_bytes + 64);
+  }
+  a((void**)&s->valid[0], r / 8 + 64);
+  a((void**)&s->valid[1], r / 8 + 64);
+  if (vcf) {
+    a((void**)&s->field_off, 3 * r * 4);
+    a((void**)&s->field_len, 3 * r * 4);
+    a((void**)&s->item_off, ((size_t)max_bytes / 2 + r + 2) * 4);
+  }
+  a((void**)&s->sums, (r / TPB + 2) * 4);
+  a((void**)&s->totals, 16);
+  if (ok && hipHostMalloc((void**)&s->h_totals, 16) != hipSuccess) ok = false;
+  if (!ok) {
+    (void)hipGetLastError();
+    exon_text_scratch_destroy(s);
+    return fail(ctx, EXON_HIP_ENOMEM, "buffers for the string columns of a slab (%lld rows, %lld bytes)", (long long)max_rows, (long long)max_bytes);
+  }
+  *sp = s;
+  return EXON_HIP_OK;
+}
+
+static void scan_lengths(hipStream_t hs, ExonTextScratch* s, const uint32_t* len, unsigned n, int32_t* offsets, int total_slot) {
+  const int nb = (int)((n + TPB - 1) / TPB);
+  hipLaunchKernelGGL(k_block_sums, dim3(nb), dim3(TPB), 0, hs, len, n, s->sums);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, hs, s->sums, nb, s->totals + total_slot);
+  hipLaunchKernelGGL(k_write_offsets, dim3(nb), dim3(TPB), 0, hs, len, n, s->sums, offsets);
+}
+
+int exon_text_vcf(exon_hip_ctx* ctx, void* stream, ExonTextScratch** sp, const uint8_t* d_text, int64_t n_bytes, const unsigned* d_nl, int64_t n_rows, uint64_t projection,
+                  ExonVcfText* out) {
+  memset(out, 0, sizeof *out);
+  if (n_rows == 0 || !(projection & (EXON_HIP_PROJECT_VCF_ID | EXON_HIP_PROJECT_VCF_REF | EXON_HIP_PROJECT_VCF_ALT))) return EXON_HIP_OK;
+  const unsigned skip = (unsigned)(reinterpret_cast<uintptr_t>(d_text) & 15);
+  d_text -= skip;
+  n_bytes += skip;
+  int rc = scratch_for(ctx, sp, std::max<int64_t>(n_rows, 1 << 16), std::max<int64_t>(n_bytes, 1 << 20), true);
+  if (rc) return rc;
+  ExonTextScratch* s = *sp;
+  hipStream_t hs = pick_stream(ctx, stream);
+  const unsigned n = (unsigned)n_rows;
+  const int nb = (int)((n + TPB - 1) / TPB);
+  VcfLens L{s->len[0], s->len[1], s->len[2], s->field_off, s->field_len};
+  hipLaunchKernelGGL(k_vcf_measure, dim3(nb), dim3(TPB), 0, hs, d_text, d_nl, n, skip, L, s->valid[0], s->valid[1]);
+  scan_lengths(hs, s, s->len[0], n, s->off[0], 0);  // ID: list offsets
+  scan_lengths(hs, s, s->len[1], n, s->off[1], 1);  // ID: byte offsets of every row's items
+  scan_lengths(hs, s, s->len[2], n, s->off[2], 2);  // REF
+  HIP_TRY(ctx, hipMemcpyAsync(s->h_totals, s->totals, 16, hipMemcpyDeviceToHost, hs));
+  HIP_TRY(ctx, hipStreamSynchronize(hs));
+  const unsigned id_items = s->h_totals[0], id_bytes = s->h_totals[1], ref_bytes = s->h_totals[2];
+  hipLaunchKernelGGL(k_vcf_fill, dim3(nb), dim3(TPB), 0, hs, d_text, n, L, s->off[0], s->off[1], s->off[2], s->item_off, s->values[0], s->values[2], id_items, id_bytes);
+  if (id_items == 0) HIP_TRY(ctx, hipMemsetAsync(s->item_off, 0, 4, hs));
+  HIP_TRY(ctx, hipGetLastError());
+  out->id_list_offsets = s->off[0];
+  out->id_valid = reinterpret_cast<const uint8_t*>(s->valid[0]);
+  out->id_item_offsets = s->item_off;
+  out->id_values = s->values[0];
+  out->n_id_items = id_items;
+  out->n_id_bytes = id_bytes;
+  out->ref_offsets = s->off[2];
+  out->ref_values = s->values[2];
+  out->n_ref_bytes = ref_bytes;
+  out->alt_valid = reinterpret_cast<const uint8_t*>(s->valid[1]);
+  return EXON_HIP_OK;
+}
+
+int exon_text_bam(exon_hip_ctx* ctx, void* stream, ExonTextScratch** sp, const uint8_t* d_data, int64_t n_bytes, const uint32_t* d_rec_of_row, int64_t n_rows, uint64_t projection,
+                  ExonBamText* out) {
+  memset(out, 0, sizeof *out);
+  const uint64_t all = EXON_HIP_PROJECT_BAM_NAME | EXON_HIP_PROJECT_BAM_CIGAR | EXON_HIP_PROJECT_BAM_SEQUENCE | EXON_HIP_PROJECT_BAM_QUALITY_SCORES;
+  if (n_rows == 0 || !(projection & all)) return EXON_HIP_OK;
+  int rc = scratch_for(ctx, sp, std::max<int64_t>(n_rows, 1 << 16), std::max<int64_t>(2 * n_bytes, 1 << 20), false);  // (a sequence doubles its 4-bit codes)
+  if (rc) return rc;
+  ExonTextScratch* s = *sp;
+  hipStream_t hs = pick_stream(ctx, stream);
+  const unsigned n = (unsigned)n_rows;
+  const int nb = (int)((n + TPB - 1) / TPB);
+  BamLens L{s->len[0], s->len[1], s->len[2]};
+  hipLaunchKernelGGL(k_bam_measure, dim3(nb), dim3(TPB), 0, hs, d_data, d_rec_of_row, n, L, s->valid[0]);
+  for (int k = 0; k < 3; ++k) scan_lengths(hs, s, s->len[k], n, s->off[k], k);
+  HIP_TRY(ctx, hipMemcpyAsync(s->h_totals, s->totals, 16, hipMemcpyDeviceToHost, hs));
+  HIP_TRY(ctx, hipStreamSynchronize(hs));
+  const unsigned name_bytes = s->h_totals[0], cigar_bytes = s->h_totals[1], seq_bytes = s->h_totals[2];
+  if ((projection & EXON_HIP_PROJECT_BAM_QUALITY_SCORES) && s->qual_cap < (size_t)seq_bytes) {
+    if (s->qual) exon_pool_free(ctx, s->qual);
+    s->qual_cap = std::max<size_t>((size_t)seq_bytes, (size_t)1 << 20);
+    s->qual = static_cast<int64_t*>(exon_pool_alloc(ctx, s->qual_cap * 8));
+    if (!s->qual) {
+      s->qual_cap = 0;
+      return fail(ctx, EXON_HIP_ENOMEM, "quality_scores of a slab (%u items)", seq_bytes);
+    }
+  }
+  hipLaunchKernelGGL(k_bam_fill, dim3(nb), dim3(TPB), 0, hs, d_data, d_rec_of_row, n, projection, s->off[0], s->off[1], s->off[2], s->values[0], s->values[1], s->values[2], s->qual);
+  HIP_TRY(ctx, hipGetLastError());
+  out->name_offsets = s->off[0];
+  out->name_values = s->values[0];
+  out->name_valid = reinterpret_cast<const uint8_t*>(s->valid[0]);
+  out->n_name_bytes = name_bytes;
+  out->cigar_offsets = s->off[1];
+  out->cigar_values = s->values[1];
+  out->n_cigar_bytes = cigar_bytes;
+  out->seq_offsets = s->off[2];
+  out->seq_values = s->values[2];
+  out->n_seq_bytes = seq_bytes;
+  out->qual_values = s->qual;
+  return EXON_HIP_OK;
+}

@@ -395,13 +395,20 @@ class Scan:
     """Native decoder + device-layout array builder over one file (FileOpener::open + read_batch analogue).
     CPU-only: usable without a GPU."""
 
+    PROJECT = {"vcf": {"id": 1, "ref": 2, "alt": 4}, "bam": {"name": 1, "cigar": 2, "sequence": 4, "quality_score": 8}}
+
     def __init__(self, path, fmt, compression=None, batch_size=0, info_field=None, region=None, use_index=False,
-                 gpu_parse=False):
+                 gpu_parse=False, project=()):
+        """project: names of the reference's columns beyond the fused kernels' operands (EXON_HIP_PROJECT_*): VCF "id", "ref", "alt";
+        BAM "name", "cigar", "sequence", "quality_score" -- appended behind the default columns in that order."""
         self.lib = L.load()
         self.fmt = fmt
+        mask = 0
+        for name in project:
+            mask |= self.PROJECT[fmt][name]
         opt = L.ScanOptions(L.FORMATS[fmt], L.COMPRESSION[compression], batch_size,
                             info_field.encode() if info_field else None, region.encode() if region else None,
-                            1 if use_index else 0, 1 if gpu_parse else 0)
+                            1 if use_index else 0, 1 if gpu_parse else 0, mask)
         h = C.c_void_p()
         rc = self.lib.exon_hip_scan_open(str(path).encode(), C.byref(opt), C.byref(h))
         if rc:

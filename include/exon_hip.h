@@ -460,7 +460,20 @@ typedef struct exon_hip_scan_options {
                              them on the GPU (exon_hip_bgzf_inflate, exon_hip_vcf_parser_* / exon_hip_fastq_parser_* /
                              exon_hip_bam_parser_* ...).  exon_hip_scan_next on such a scan needs exon_hip_scan_bind_ctx first
                              (batches then come out of the same GPU pipeline); without a bound ctx it returns ESTATE */
+  uint64_t projection;    /* (ABI 5) EXON_HIP_PROJECT_* bits: columns of the reference's schema beyond the fused kernels' operands,
+                             appended BEHIND the default ones in bit order (0 = none: the hot path ships only what a plan reads).
+                             VCF text: id List<Utf8>?, ref Utf8, alt List<Utf8>? (lazy_array_builder.rs:169-205; the alt list has no
+                             items, as in the reference -- see text_columns.hip); BAM: name Utf8?, cigar Utf8, sequence Utf8,
+                             quality_score List<Int64> (exon-bam/src/array_builder.rs:105-201).  Built by the host readers (one
+                             thread) and by the GPU pipeline (exon_hip_scan_bind_ctx); EXON_HIP_EUNSUPPORTED for other formats */
 } exon_hip_scan_options;
+#define EXON_HIP_PROJECT_VCF_ID 1ull
+#define EXON_HIP_PROJECT_VCF_REF 2ull
+#define EXON_HIP_PROJECT_VCF_ALT 4ull
+#define EXON_HIP_PROJECT_BAM_NAME 1ull
+#define EXON_HIP_PROJECT_BAM_CIGAR 2ull
+#define EXON_HIP_PROJECT_BAM_SEQUENCE 4ull
+#define EXON_HIP_PROJECT_BAM_QUALITY_SCORES 8ull
 
 int exon_hip_scan_open(const char* path, const exon_hip_scan_options* options, exon_hip_scan** out);
 int exon_hip_scan_schema(exon_hip_scan* scan, struct ArrowSchema* out);

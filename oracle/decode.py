@@ -30,10 +30,13 @@ def read_bytes(path):
 # ---- VCF ---------------------------------------------------------------------------------------------
 def decode_vcf(path):
     """-> dict(contigs, filters_header, info_header, chrom[str], pos[int|None], qual[np.float32|None],
-    filter[list[str]], info[dict|None])"""
+    filter[list[str]], info[dict|None], id[list[str]|None], ref[str], alt[list|None])
+    id / ref / alt follow LazyVCFArrayBuilder::append (exon-vcf/src/array_builder/lazy_array_builder.rs:169-205): ids NULL when the
+    field is '.', else its ';'-separated items; ref the field; alt NULL when '.', else a list WITHOUT items -- the reference
+    builds a string of the alternate bases and then calls `alternates.append(true)` without appending it (:191-205)."""
     text = read_bytes(path).decode()
     contigs, filt_hdr, info_hdr = [], [], {}
-    rows = dict(chrom=[], pos=[], qual=[], filter=[], info=[])
+    rows = dict(chrom=[], pos=[], qual=[], filter=[], info=[], id=[], ref=[], alt=[])
     for line in text.split("\n"):
         line = line[:-1] if line.endswith("\r") else line  # the line reader drops a CR in front of the LF (noodles' read_line)
         if not line:
@@ -61,6 +64,9 @@ def decode_vcf(path):
         rows["pos"].append(int(digits) or None)
         rows["qual"].append(None if c[5] == "." else np.float32(c[5]))
         rows["filter"].append([] if c[6] == "." else c[6].split(";"))
+        rows["id"].append(None if c[2] in (".", "") else c[2].split(";"))
+        rows["ref"].append(c[3])
+        rows["alt"].append(None if c[4] in (".", "") else [])
         if c[7] == ".":
             rows["info"].append(None)
         else:

@@ -446,6 +446,7 @@ impl ExecutionPlan for GpuFilterAggExec {
                                 region: region_c.as_ref().map_or(std::ptr::null(), |c| c.as_ptr()),
                                 use_index: use_index as i32,
                                 gpu_parse: 1,
+                                projection: 0, // the fused kernels read chrom / pos / qual / filter / typed INFO only
                             };
                             let cpath = CString::new(path.as_str()).unwrap();
                             let mut raw = std::ptr::null_mut();

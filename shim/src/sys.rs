@@ -67,6 +67,7 @@ pub struct exon_hip_scan_options {
     pub region: *const c_char,
     pub use_index: i32,
     pub gpu_parse: i32,
+    pub projection: u64, // EXON_HIP_PROJECT_* (ABI 5): columns beyond the fused kernels' operands; 0 on the aggregate path
 }
 
 /// mirrors `exon_hip_column` (an Arrow array already resident in HBM)
