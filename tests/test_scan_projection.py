@@ -145,11 +145,14 @@ def test_gpu_vcf_text_columns_equal_the_host_readers_on_synthetic_rows(ctx, tmp_
         assert dev[k] == host[k], k
     v = decode.decode_vcf(str(out))
     assert dev["id"] == v["id"] and dev["ref"] == v["ref"] and dev["alt"] == v["alt"]
-    # SELECT chrom, pos, id FROM t WHERE vcf_region_filter('7:5000-400000', chrom, pos)
-    s = exon_amd.Scan(gz, "vcf", gpu_parse=True, region="7:5000-400000", project=("id",)).bind_ctx(ctx)
+    # SELECT chrom, pos, id FROM t WHERE vcf_region_filter('<chrom>:<lo>-<hi>', chrom, pos)
+    c0 = v["chrom"][n // 2]
+    ps = sorted(p for c, p in zip(v["chrom"], v["pos"]) if c == c0 and p is not None)
+    lo, hi = ps[len(ps) // 4], ps[len(ps) // 4 + 5000]
+    s = exon_amd.Scan(gz, "vcf", gpu_parse=True, region=f"{c0}:{lo}-{hi}", project=("id",)).bind_ctx(ctx)
     hit = table(s)
     s.close()
-    want = [(c, p, d) for c, p, d in zip(v["chrom"], v["pos"], v["id"]) if c == "7" and p is not None and 5000 <= p <= 400000]
+    want = [(c, p, d) for c, p, d in zip(v["chrom"], v["pos"], v["id"]) if c == c0 and p is not None and lo <= p <= hi]
     assert list(zip(hit["chrom"], hit["pos"], hit["id"])) == want and len(want) > 100
 
 
