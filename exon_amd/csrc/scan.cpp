@@ -1708,53 +1708,86 @@ static int gpu_filter_names(exon_hip_scan* scan, std::vector<std::string>* names
 namespace {
 std::mutex g_export_pool_mu;
 std::vector<std::pair<void*, size_t>> g_export_pool;
-void* export_block_get(size_t bytes) {
+// Pinned blocks come in size classes (a quarter of headroom, rounded to 8 MiB): the slabs of one scan differ by a few rows, and with
+// exact sizes a slab a little larger than the last found no block to reuse while the pool filled up with blocks a little too small --
+// every slab then paid a hipHostMalloc (0.23 ms per MB) and a hipHostFree (the native timer's warm passes were SLOWER than its first:
+// profiles/r6_scan_next_native.log).
+size_t export_block_class(size_t bytes) { return (bytes + bytes / 4 + (8u << 20) - 1) & ~(size_t)((8u << 20) - 1); }
+void* export_block_get(size_t* bytes) {
   {
     std::lock_guard<std::mutex> g(g_export_pool_mu);
+    size_t best = g_export_pool.size();
     for (size_t i = 0; i < g_export_pool.size(); ++i)
-      if (g_export_pool[i].second >= bytes && g_export_pool[i].second <= 2 * bytes + (1u << 20)) {
-        void* p = g_export_pool[i].first;
-        g_export_pool.erase(g_export_pool.begin() + (long)i);
-        return p;
-      }
+      if (g_export_pool[i].second >= *bytes && (best == g_export_pool.size() || g_export_pool[i].second < g_export_pool[best].second)) best = i;
+    if (best < g_export_pool.size()) {
+      void* p = g_export_pool[best].first;
+      *bytes = g_export_pool[best].second;
+      g_export_pool.erase(g_export_pool.begin() + (long)best);
+      return p;
+    }
   }
   void* p = nullptr;
-  if (hipHostMalloc(&p, bytes) != hipSuccess) {
+  *bytes = export_block_class(*bytes);
+  if (hipHostMalloc(&p, *bytes) != hipSuccess) {
     (void)hipGetLastError();
     return nullptr;
   }
   return p;
 }
 void export_block_put(void* p, size_t bytes) {
+  void* drop = p;
   {
     std::lock_guard<std::mutex> g(g_export_pool_mu);
-    if (g_export_pool.size() < 4) {
+    if (g_export_pool.size() < 6) {
       g_export_pool.emplace_back(p, bytes);
       return;
     }
+    size_t small = 0;  // full: the smallest block goes
+    for (size_t i = 1; i < g_export_pool.size(); ++i)
+      if (g_export_pool[i].second < g_export_pool[small].second) small = i;
+    if (g_export_pool[small].second < bytes) {
+      drop = g_export_pool[small].first;
+      g_export_pool[small] = {p, bytes};
+    }
   }
-  hipHostFree(p);
+  hipHostFree(drop);
 }
 }  // namespace
 
 // One slab's device columns -> one pinned host block -> batch_size-row Arrow batches on the exporter's queue.  Without a region
 // mask the batches are VIEWS into the block (children with an offset; validity bitmaps shared, null counts left to the
 // consumer); with one the kept rows are gathered.  Returns 2 when the consumer has gone away (scan closed with batches left).
-// the projected string / list columns of a slab, copied back: per-batch arrays are cut out of these
+// the projected string / list columns of a slab, copied back into ONE pinned block of the export pool (pageable destinations are
+// staged by the runtime at a tenth of the link's rate): per-batch arrays are cut out of these
+template <class T>
+struct Span {
+  const T* p = nullptr;
+  size_t n = 0;
+  const T& operator[](size_t i) const { return p[i]; }
+  const T* data() const { return p; }
+  const T* begin() const { return p; }
+};
 struct HostText {
   bool vcf = false, bam = false;
   uint64_t projection = 0;
-  std::vector<int32_t> off[3], item_off;
-  std::vector<uint8_t> val[3], valid[2];
-  std::vector<int64_t> qual;
+  Span<int32_t> off[3], item_off;
+  Span<uint8_t> val[3], valid[2];
+  Span<int64_t> qual;
+  void* blk = nullptr;
+  size_t blk_bytes = 0;
+  ~HostText() {
+    if (blk) export_block_put(blk, blk_bytes);
+  }
 };
 static int fetch_text(exon_hip_ctx* ctx, hipStream_t hs, int64_t n_rows, uint64_t projection, const ExonVcfText* vt, const ExonBamText* bt, HostText* h) {
   h->projection = projection;
-  hipError_t e = hipSuccess;
-  auto get = [&](auto& vec, const void* src, size_t count) {
-    vec.resize(count);
-    if (e == hipSuccess && count && src) e = hipMemcpyAsync(vec.data(), src, count * sizeof(vec[0]), hipMemcpyDeviceToHost, hs);
+  struct Want {
+    void* span;
+    const void* src;
+    size_t count, elem;
   };
+  std::vector<Want> wants;
+  auto get = [&](auto& span, const void* src, size_t count) { wants.push_back(Want{&span, src, count, sizeof(*span.p)}); };
   const size_t n = (size_t)n_rows, nb = (n + 7) / 8;
   if (vt) {
     h->vcf = true;
@@ -1785,6 +1818,24 @@ static int fetch_text(exon_hip_ctx* ctx, hipStream_t hs, int64_t n_rows, uint64_
     if (projection & EXON_HIP_PROJECT_BAM_SEQUENCE) get(h->val[2], bt->seq_values, (size_t)bt->n_seq_bytes);
     if (projection & EXON_HIP_PROJECT_BAM_QUALITY_SCORES) get(h->qual, bt->qual_values, (size_t)bt->n_seq_bytes);
   }
+  size_t total = 64;
+  for (const Want& w : wants) total += (w.count * w.elem + 63) & ~(size_t)63;
+  h->blk_bytes = total;
+  h->blk = export_block_get(&h->blk_bytes);
+  if (!h->blk) return fail(ctx, EXON_HIP_ENOMEM, "no pinned block of %zu bytes for a slab's string columns", total);
+  hipError_t e = hipSuccess;
+  size_t at = 0;
+  for (const Want& w : wants) {
+    uint8_t* dst = static_cast<uint8_t*>(h->blk) + at;
+    // (every Span has the layout {pointer, count})
+    struct Raw {
+      const void* p;
+      size_t n;
+    };
+    *static_cast<Raw*>(w.span) = Raw{dst, w.count};
+    if (e == hipSuccess && w.count && w.src) e = hipMemcpyAsync(dst, w.src, w.count * w.elem, hipMemcpyDeviceToHost, hs);
+    at += (w.count * w.elem + 63) & ~(size_t)63;
+  }
   if (e == hipSuccess) e = hipStreamSynchronize(hs);
   if (e != hipSuccess) return fail(ctx, EXON_HIP_EDEVICE, "string columns of a slab back to the host: %s", hipGetErrorString(e));
   return EXON_HIP_OK;
@@ -1792,8 +1843,8 @@ static int fetch_text(exon_hip_ctx* ctx, hipStream_t hs, int64_t n_rows, uint64_
 // the projected columns of the rows `rows[0 .. n)` of the slab (in the order of the projection bits), appended to `kids`
 static void text_batch(const HostText& h, const int64_t* rows, int64_t r0, int64_t n, std::vector<struct ArrowArray*>* kids) {
   auto row_at = [&](int64_t i) { return rows ? rows[i] : r0 + i; };
-  auto bit = [&](const std::vector<uint8_t>& bm, int64_t r) { return (uint8_t)((bm[(size_t)(r >> 3)] >> (r & 7)) & 1); };
-  auto utf8 = [&](const std::vector<int32_t>& off, const std::vector<uint8_t>& val, const std::vector<uint8_t>* valid) {
+  auto bit = [&](const Span<uint8_t>& bm, int64_t r) { return (uint8_t)((bm[(size_t)(r >> 3)] >> (r & 7)) & 1); };
+  auto utf8 = [&](const Span<int32_t>& off, const Span<uint8_t>& val, const Span<uint8_t>* valid) {
     exon::Utf8Builder b;
     for (int64_t i = 0; i < n; ++i) {
       const int64_t r = row_at(i);
@@ -1879,11 +1930,12 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
   }
   const size_t moff = bytes;
   bytes += nb;
-  uint8_t* blk = static_cast<uint8_t*>(export_block_get(bytes));
+  size_t blk_bytes = bytes;
+  uint8_t* blk = static_cast<uint8_t*>(export_block_get(&blk_bytes));
   if (!blk) return fail(ctx, EXON_HIP_ENOMEM, "no pinned block of %zu bytes for a slab's columns", bytes);
   exon::SharedBlock* sb = new exon::SharedBlock();
   sb->block = blk;
-  sb->bytes = bytes;
+  sb->bytes = blk_bytes;
   sb->put = export_block_put;
   struct Unref {
     exon::SharedBlock* b;
