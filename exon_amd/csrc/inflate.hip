@@ -21,7 +21,7 @@
 //     the tables are decoded inside the walk, a match that overlaps its own output takes its sources whole periods back, a round
 //     ends in front of a symbol that starts beyond its 64 bytes.  Rounds 1-4's loops -- one symbol per step on the scalar unit
 //     (symbol_run), on the vector unit with software pipelining (symbol_run_v) -- stay selectable (EXON_HIP_INFLATE_FLAVOR=0|1|2)
-//     and serve the lane-parallel kernel's hand-backs.  Tuning logs: profiles/r1_tuning.md ... DESIGN.md section 7e.
+//     and serve the lane-parallel kernel's hand-backs.  Tuning logs: profiles/r1_tuning.md ... HISTORY.md section 7e.
 // Every block reports a status; any failure makes the caller inflate on the host instead.  The CRC-32 of every
 // inflated block is checked by a second kernel (k_crc32: 64 slices per block, combined in GF(2)[x] mod P with powers of x from a table).
 #include <hip/hip_runtime.h>
@@ -3122,7 +3122,7 @@ extern "C" int exon_hip_bgzf_forget_stream(void* stream) {
 // vector-unit loop with deferred far copies (symbol_run_v, round 4), 0 round 1's scalar loop (symbol_run), 2 loops 0 and 1 side by
 // side.  EXON_HIP_INFLATE_FLAVOR forces one; otherwise the caller's hint, otherwise 3.  One resident launch, same box
 // (profiles/r5_inflate_wide_v3_32waves.log): VCF text 113 -> 178 GB/s, BAM payloads 102 -> 127, FASTQ 81 -> 82; the file pipelines
-// .vcf.gz 59 -> 41 ms, BAM 59 -> 48-51 ms, .fastq.gz 119 -> 115-120 ms.  (Round 4's history of loops 0 / 1 / 2: DESIGN.md section 7e.)
+// .vcf.gz 59 -> 41 ms, BAM 59 -> 48-51 ms, .fastq.gz 119 -> 115-120 ms.  (Round 4's history of loops 0 / 1 / 2: HISTORY.md section 7e.)
 static int inflate_flavor(int hint) {
   static const int forced = [] {
     const char* e = getenv("EXON_HIP_INFLATE_FLAVOR");

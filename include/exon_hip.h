@@ -512,7 +512,7 @@ int exon_hip_scan_close(exon_hip_scan* scan);
  * is_bgzip_valid_header goes through file_compression_type.convert_stream).  The compressed bytes of a slab are cut into chunks, one
  * wavefront per chunk finds a block start by itself and decodes with the 32 KiB in front of it unknown (16-bit symbols: a byte, or
  * "byte k of the window"); the host proves the chain of chunks, the windows are resolved by composing the chunks' tail maps, a last
- * pass writes bytes; CRC-32 and ISIZE of every member are checked (exon_amd/csrc/gzip_stream.hip, DESIGN.md section 7k).
+ * pass writes bytes; CRC-32 and ISIZE of every member are checked (exon_amd/csrc/gzip_stream.hip, DESIGN.md section 8.4).
  * A stream is one file: create, decode slab after slab, destroy.  Any failure (EXON_HIP_EINVAL with a text) means: inflate this
  * file on the host -- nothing of the failing call has been committed to the stream's state except that it cannot be continued. */
 typedef struct exon_hip_gzip_stream exon_hip_gzip_stream;
@@ -604,7 +604,7 @@ int exon_hip_bgzf_inflate(exon_hip_ctx* ctx, void* stream, const uint8_t* d_comp
  * for a stream that inflated a 1536-member launch -- until the stream's owner lets go: streams the library owns do that
  * themselves; for a caller-owned `stream` passed to exon_hip_bgzf_inflate call this once the stream is idle. */
 int exon_hip_bgzf_forget_stream(void* stream);
-/* Diagnostics of the lane-parallel block decoder (used for launches of up to 1536 members unless
+/* Diagnostics of the lane-parallel block decoder (HISTORY.md section 7e; used for launches of up to 1536 members unless
  * EXON_HIP_INFLATE_PAR says otherwise: 0 = never, 1 = always, 2 = side by side with the serial kernel): out32[0] = DEFLATE blocks
  * it decoded on the current device since the process started, out32[1..15] = blocks it handed back to the serial symbol loop, by
  * reason.  `stream` is ignored.  Synchronises the device. */

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Pins the CRAM 3.1 reader on htslib-written files -- for a machine that HAS samtools (this build image does not, which is why
-DESIGN.md section 7j calls the rANS Nx16 decoder "unpinned against htslib").  No GPU needed: the host decoder is driven through
+HISTORY.md section 7j calls the rANS Nx16 decoder "unpinned against htslib").  No GPU needed: the host decoder is driven through
 `exon_amd.Scan`.
 
     python tools/check_cram31_against_samtools.py input.bam|input.sam|input.cram [more files ...]
