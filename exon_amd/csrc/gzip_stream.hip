@@ -343,7 +343,11 @@ __device__ __forceinline__ void copy_match(Out& o, uint32_t len, uint32_t dist) 
     uint16_t v;
     if (idx < 0) v = (uint16_t)(256 + WIN + idx);
     else if ((uint32_t)idx + 1024u >= o.pos) v = g_lds.ring[(uint32_t)idx & RM];
+#ifdef EXON_GZ_NOFAR  // (timing experiment only: what the far sources' global round trips cost -- the output is wrong)
+    else v = g_lds.ring[(uint32_t)idx & RM];
+#else
     else v = o.sym[idx];
+#endif
     g_lds.ring[(o.pos + j) & RM] = v;
   }
   o.pos += len;
@@ -975,7 +979,10 @@ const char* gz_status_name(uint32_t s) {
 // ---- host driver ------------------------------------------------------------------------------------------------------------------
 struct exon_hip_gzip_stream {
   exon_hip_ctx* ctx = nullptr;
-  uint32_t chunk_bytes = 65536;
+  uint32_t chunk_bytes = 65536;     // the largest chunk (EXON_HIP_GZ_CHUNK_KB fixes the size)
+  uint32_t min_chunk_bytes = 16384; // a call picks its chunk size in between so that the chip's wavefront slots are filled twice
+  bool fixed_chunk = false;
+  int64_t max_comp = 0;
   int max_chunks = 0;
   size_t sym_words = 0;  // symbols of scratch
   uint16_t* d_sym = nullptr;
@@ -1026,10 +1033,16 @@ int exon_hip_gzip_stream_create(exon_hip_ctx* ctx, int64_t max_comp_bytes, int64
   s->ctx = ctx;
   if (const char* v = getenv("EXON_HIP_GZ_CHUNK_KB")) {
     const long kb = atol(v);
-    if (kb >= 1 && kb <= 4096) s->chunk_bytes = (uint32_t)kb << 10;
+    if (kb >= 1 && kb <= 4096) {
+      s->chunk_bytes = s->min_chunk_bytes = (uint32_t)kb << 10;
+      s->fixed_chunk = true;
+    }
   }
   if (const char* v = getenv("EXON_HIP_GZ_VERIFY_CRC")) s->verify_crc = !(v[0] == '0');
-  s->max_chunks = (int)((max_comp_bytes + s->chunk_bytes - 1) / s->chunk_bytes) + 1;
+  s->max_comp = max_comp_bytes;
+  // adaptive chunks: a call never has more than two rounds of wavefront slots' worth of them, or max_comp / 64 KiB
+  s->max_chunks = s->fixed_chunk ? (int)((max_comp_bytes + s->chunk_bytes - 1) / s->chunk_bytes) + 1
+                                 : (int)std::max<int64_t>(2ll * 17 * std::max(ctx->cfg.compute_units, 1) + 2, (max_comp_bytes + s->chunk_bytes - 1) / s->chunk_bytes + 2);
   const size_t nr = (size_t)s->max_chunks + SPARE_REGIONS;  // regions: one per chunk + the spares that repairs decode gaps into
   // symbol scratch: 2 bytes per output byte.  Default: room for a ratio of 8 over the largest slab (at least 1 Mi symbols per
   // chunk are never needed: a chunk's region is scratch / chunks, the call shrinks its slab when a region overflows)
@@ -1092,15 +1105,26 @@ int exon_hip_gzip_stream_decode(exon_hip_gzip_stream* s, void* stream, const uin
   const uint32_t lead = (uint32_t)(reinterpret_cast<uintptr_t>(d_comp) & 3);
   d_comp -= lead;
   hipStream_t hs = pick_stream(ctx, stream);
-  int64_t n_use = std::min<int64_t>(n_comp, (int64_t)(s->max_chunks - 1) * s->chunk_bytes - 4);
+  int64_t n_use = std::min<int64_t>(n_comp, s->fixed_chunk ? (int64_t)(s->max_chunks - 1) * s->chunk_bytes - 4 : s->max_comp);
   for (int attempt = 0; attempt < 6; ++attempt) {
     const bool final_here = final_input && n_use == n_comp;
-    const int n_chunks = (int)((lead + n_use + s->chunk_bytes - 1) / s->chunk_bytes);
+    // Chunk size of this call.  The kernel's throughput is flat in the chunk size once every wavefront slot is taken (17 per CU),
+    // but a call lasts at least as long as ONE chunk takes one wavefront (~0.3 us per compressed byte): a slab of well-compressing
+    // text holds few 64 KiB chunks (VCF: 128 MiB -> 2000 chunks = half the slots, 25 ms whatever the count).  So: enough chunks
+    // for two rounds of the chip's slots, between 16 and 64 KiB (profiles/r6_gz_chunk_sweep.log).
+    uint32_t chunk_bytes = s->chunk_bytes;
+    if (!s->fixed_chunk) {
+      const int64_t slots2 = 2ll * 17 * std::max(ctx->cfg.compute_units, 1);
+      const int64_t want = ((lead + n_use) / slots2 + 4095) & ~4095ll;
+      chunk_bytes = (uint32_t)std::min<int64_t>(s->chunk_bytes, std::max<int64_t>(s->min_chunk_bytes, want));
+    }
+    while ((lead + n_use + chunk_bytes - 1) / chunk_bytes > (int64_t)s->max_chunks - 1) chunk_bytes += 4096;  // (never more chunks than the tables hold)
+    const int n_chunks = (int)((lead + n_use + chunk_bytes - 1) / chunk_bytes);
     const int n_spare = n_chunks > 1 ? std::min(SPARE_REGIONS, n_chunks) : 0;  // (one chunk: nothing to repair, the whole scratch is its region)
     const uint32_t cap = (uint32_t)std::min<size_t>((s->sym_words / (size_t)(n_chunks + n_spare)) & ~(size_t)(DRAIN - 1), 1u << 30);
     if (cap < 2 * DRAIN) return fail(ctx, EXON_HIP_EINVAL, "gzip: symbol scratch too small");
     const uint64_t n_bits = 8ull * (uint64_t)(lead + n_use);
-    const uint64_t chunk_bits = 8ull * s->chunk_bytes;
+    const uint64_t chunk_bits = 8ull * chunk_bytes;
     const uint64_t first_bit = 8ull * lead + s->start_bit;
     for (int c = 0; c < n_chunks; ++c) {
       const uint64_t stop = c + 1 < n_chunks ? (uint64_t)(c + 1) * chunk_bits : ~0ull;
@@ -1189,7 +1213,7 @@ int exon_hip_gzip_stream_decode(exon_hip_gzip_stream* s, void* stream, const uin
       // a chunk's symbols did not fit its region: fewer chunks share the scratch next time
       if (n_chunks == 1) return fail(ctx, EXON_HIP_EINVAL, "gzip stream: one chunk inflates to more than the symbol scratch holds");
       ++s->stats.overflow_retries;
-      n_use = std::min<int64_t>(n_use, std::max<int64_t>((int64_t)s->chunk_bytes, (n_use / 4) & ~(int64_t)(s->chunk_bytes - 1)));
+      n_use = std::min<int64_t>(n_use, std::max<int64_t>((int64_t)chunk_bytes, (n_use / 4) & ~(int64_t)(chunk_bytes - 1)));
       continue;
     }
     if (n_acc == 0) {

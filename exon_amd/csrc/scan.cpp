@@ -940,8 +940,9 @@ class GpuTextSource {
     if (gz_) {
       if (hipEventCreateWithFlags(&ev_gz_tail_, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_gz_pref_, hipEventDisableTiming) != hipSuccess)
         return fail(ctx_, EXON_HIP_EDEVICE, "event creation failed");
-      // symbol scratch: 2 bytes per byte of a slab's text, and a quarter more for the chunks the text buffer turns away
-      const int rcg = exon_hip_gzip_stream_create(ctx_, (int64_t)(comp_cap_ + GZ_RESERVE), (int64_t)(2 * text_cap_ + text_cap_ / 2), &gzs_);
+      // symbol scratch: 2 bytes per byte of a slab's text, three times over -- every chunk has the same share, and a chunk decodes
+      // up to the first block boundary behind its range: small chunks overshoot their share by a block
+      const int rcg = exon_hip_gzip_stream_create(ctx_, (int64_t)(comp_cap_ + GZ_RESERVE), (int64_t)(6 * text_cap_), &gzs_);
       if (rcg) return rcg;
     }
     fill(0, &cur_);
