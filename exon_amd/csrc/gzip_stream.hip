@@ -44,9 +44,15 @@ namespace {
 
 constexpr int LIT_BITS = 9, DIST_BITS = 8, CL_BITS = 7;
 constexpr uint32_t E_LIT = 1u << 8, E_EOB = 1u << 9, E_INVALID = 1u << 10;
-constexpr int RING = 2048;           // symbols of recent output kept in LDS per wavefront
+// LDS per wavefront decides how many chunks a CU decodes at once, and the kernel waits (LDS lookups, the window's reads) for about
+// half of its cycles (profiles/r6_gz_decode_pmc_*.txt): 8988 bytes = 17 waves per CU at first; a 1 Ki-symbol ring, the
+// code-length table laid over the distance table and the code lengths over the literal/length table make it 6108 = 26.
+constexpr int GZ_WAVES_PER_CU = 26;  // resident wavefronts of k_gz_decode per CU (160 KiB of LDS / 6108 bytes)
+constexpr int RING = 1024;           // symbols of recent output kept in LDS per wavefront
 constexpr uint32_t RM = RING - 1;
-constexpr uint32_t DRAIN = 512;      // symbols per drain step (64 lanes x 16 bytes)
+constexpr uint32_t DRAIN = 256;      // symbols per drain step (64 lanes x 8 bytes)
+constexpr uint32_t NEAR = DRAIN + 264;  // sources at most this far back are read from the ring; everything older has been drained
+static_assert(RING >= (int)NEAR + 258, "a match may not overwrite ring entries that count as near");
 constexpr int WIN = 32768;
 constexpr int MAX_MEMBER_ENDS = 8;   // member trailers one chunk may cross
 constexpr int SPARE_REGIONS = 64;    // scratch regions beyond one per chunk: a repair decodes the gap in front of a chunk into one
@@ -84,13 +90,18 @@ struct GzMember {        // a member trailer crossed by a chunk: `out_off` symbo
 };
 
 struct Lds {
-  uint32_t lit_lut[1 << LIT_BITS];
-  uint32_t dist_lut[1 << DIST_BITS];
-  uint32_t cl_lut[1 << CL_BITS];
+  union {  // the code lengths of a header are dead once the literal/length table -- built LAST, from lengths its builder has in registers -- is written
+    uint32_t lit_lut[1 << LIT_BITS];
+    uint8_t lens[320];
+  };
+  union {  // the code-length code is dead once the lengths are read; the distance table is built after that
+    uint32_t dist_lut[1 << DIST_BITS];
+    uint32_t cl_lut[1 << CL_BITS];
+  };
   uint16_t ring[RING];
   uint16_t lit_sym[288], dist_sym[32], cl_sym[20];
   uint16_t count[3][16], first[3][16], offs[3][16];
-  uint8_t lens[320], cl_lens[20];
+  uint8_t cl_lens[20];
 };
 enum { C_LIT = 0, C_DIST = 1, C_CL = 2 };
 __shared__ __attribute__((aligned(16))) Lds g_lds;
@@ -209,6 +220,7 @@ __device__ __noinline__ int build_code(int which, const uint8_t* lens, int n) {
     const int s = k * 64 + lane;
     myl[k] = s < n ? (int)lens[s] : 0;
   }
+  wave_fence();  // (the literal/length table lies over the lengths just read)
   for (int i = lane; i < (1 << bits); i += 64) lut[i] = 0;
   int cnt_l = 0;  // lane q: symbols of length q
 #pragma unroll
@@ -317,8 +329,8 @@ __device__ __forceinline__ bool drain_full(Out& o) {  // false: the scratch regi
   while (o.pos - o.drained >= DRAIN) {
     if (o.drained + DRAIN > o.cap) return false;
     wave_fence();
-    const uint4 v = *reinterpret_cast<const uint4*>(&g_lds.ring[(o.drained & RM) + lane_id() * 8u]);
-    *reinterpret_cast<uint4*>(&o.sym[o.drained + lane_id() * 8u]) = v;
+    const uint2 v = *reinterpret_cast<const uint2*>(&g_lds.ring[(o.drained & RM) + lane_id() * 4u]);
+    *reinterpret_cast<uint2*>(&o.sym[o.drained + lane_id() * 4u]) = v;
     o.drained += DRAIN;
   }
   return true;
@@ -332,8 +344,8 @@ __device__ __forceinline__ bool drain_rest(Out& o) {
   wave_fence();
   return true;
 }
-// `len` symbols from `dist` back.  Sources in front of the chunk become markers; sources of the last 1024 symbols are in the ring,
-// older ones in the scratch region (drain_full keeps pos - drained < DRAIN + 258, so everything older than 1024 has been stored).
+// `len` symbols from `dist` back.  Sources in front of the chunk become markers; sources of the last NEAR symbols are in the ring,
+// older ones in the scratch region (drain_full keeps pos - drained < DRAIN + 258, so everything older than NEAR has been stored).
 __device__ __forceinline__ void copy_match(Out& o, uint32_t len, uint32_t dist) {
   wave_fence();
   const int32_t src0 = (int32_t)o.pos - (int32_t)dist;
@@ -342,7 +354,7 @@ __device__ __forceinline__ void copy_match(Out& o, uint32_t len, uint32_t dist) 
     const int32_t idx = src0 + (int32_t)jj;
     uint16_t v;
     if (idx < 0) v = (uint16_t)(256 + WIN + idx);
-    else if ((uint32_t)idx + 1024u >= o.pos) v = g_lds.ring[(uint32_t)idx & RM];
+    else if ((uint32_t)idx + NEAR >= o.pos) v = g_lds.ring[(uint32_t)idx & RM];
 #ifdef EXON_GZ_NOFAR  // (timing experiment only: what the far sources' global round trips cost -- the output is wrong)
     else v = g_lds.ring[(uint32_t)idx & RM];
 #else
@@ -489,8 +501,8 @@ __device__ __noinline__ ChainResult decode_chain(const uint32_t* comp, uint64_t 
       if (btype == 1) {
         for (int i = (int)lane_id(); i < 320; i += 64) L.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5;
         wave_fence();
+        (void)build_code(C_DIST, L.lens + 288, 32);  // (the lengths lie under the literal/length table: it is built last)
         (void)build_code(C_LIT, L.lens, 288);
-        (void)build_code(C_DIST, L.lens + 288, 32);
       } else {
         br.refill();
         const int hlit = (int)br.take(5) + 257, hdist = (int)br.take(5) + 1, hclen = (int)br.take(4) + 4;
@@ -586,7 +598,7 @@ __device__ __noinline__ ChainResult decode_chain(const uint32_t* comp, uint64_t 
         wave_fence();
         if ((int)lane_id() < 32) L.lens[288 + lane_id()] = (int)lane_id() < hdist ? dl : 0;
         wave_fence();
-        if (!uni(build_code(C_LIT, L.lens, hlit)) || !uni(build_code(C_DIST, L.lens + 288, hdist))) {
+        if (!uni(build_code(C_DIST, L.lens + 288, hdist)) || !uni(build_code(C_LIT, L.lens, hlit))) {
           if (br.pos() > n_bits) {  // (bits behind the end of the input are padding, not a verdict)
             exhausted();
             goto chain_done;
@@ -1042,7 +1054,7 @@ int exon_hip_gzip_stream_create(exon_hip_ctx* ctx, int64_t max_comp_bytes, int64
   s->max_comp = max_comp_bytes;
   // adaptive chunks: a call never has more than two rounds of wavefront slots' worth of them, or max_comp / 64 KiB
   s->max_chunks = s->fixed_chunk ? (int)((max_comp_bytes + s->chunk_bytes - 1) / s->chunk_bytes) + 1
-                                 : (int)std::max<int64_t>(2ll * 17 * std::max(ctx->cfg.compute_units, 1) + 2, (max_comp_bytes + s->chunk_bytes - 1) / s->chunk_bytes + 2);
+                                 : (int)std::max<int64_t>(2ll * GZ_WAVES_PER_CU * std::max(ctx->cfg.compute_units, 1) + 2, (max_comp_bytes + s->chunk_bytes - 1) / s->chunk_bytes + 2);
   const size_t nr = (size_t)s->max_chunks + SPARE_REGIONS;  // regions: one per chunk + the spares that repairs decode gaps into
   // symbol scratch: 2 bytes per output byte.  Default: room for a ratio of 8 over the largest slab (at least 1 Mi symbols per
   // chunk are never needed: a chunk's region is scratch / chunks, the call shrinks its slab when a region overflows)
@@ -1108,13 +1120,13 @@ int exon_hip_gzip_stream_decode(exon_hip_gzip_stream* s, void* stream, const uin
   int64_t n_use = std::min<int64_t>(n_comp, s->fixed_chunk ? (int64_t)(s->max_chunks - 1) * s->chunk_bytes - 4 : s->max_comp);
   for (int attempt = 0; attempt < 6; ++attempt) {
     const bool final_here = final_input && n_use == n_comp;
-    // Chunk size of this call.  The kernel's throughput is flat in the chunk size once every wavefront slot is taken (17 per CU),
+    // Chunk size of this call.  The kernel's throughput is flat in the chunk size once every wavefront slot is taken (26 per CU),
     // but a call lasts at least as long as ONE chunk takes one wavefront (~0.3 us per compressed byte): a slab of well-compressing
     // text holds few 64 KiB chunks (VCF: 128 MiB -> 2000 chunks = half the slots, 25 ms whatever the count).  So: enough chunks
     // for two rounds of the chip's slots, between 16 and 64 KiB (profiles/r6_gz_chunk_sweep.log).
     uint32_t chunk_bytes = s->chunk_bytes;
     if (!s->fixed_chunk) {
-      const int64_t slots2 = 2ll * 17 * std::max(ctx->cfg.compute_units, 1);
+      const int64_t slots2 = 2ll * GZ_WAVES_PER_CU * std::max(ctx->cfg.compute_units, 1);
       const int64_t want = ((lead + n_use) / slots2 + 4095) & ~4095ll;
       chunk_bytes = (uint32_t)std::min<int64_t>(s->chunk_bytes, std::max<int64_t>(s->min_chunk_bytes, want));
     }
