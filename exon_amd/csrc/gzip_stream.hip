@@ -79,11 +79,12 @@ struct GzTask {        // one wavefront's work
   uint32_t kind;
   uint32_t region;     // which region of the symbol scratch / which result record
 };
-struct GzChunk {         // 32 bytes
+struct GzChunk {         // 40 bytes
   uint64_t start_bit;    // where the accepted decode began
   uint64_t end_bit;      // the block boundary it stopped at
   uint32_t n_out;        // symbols
   uint32_t status, flags, n_members;
+  uint32_t ticks, slot;  // diagnostics (EXON_HIP_GZ_TRACE): 100 MHz ticks this wavefront spent on the task, when it started
 };
 struct GzMember {        // a member trailer crossed by a chunk: `out_off` symbols of the chunk belong to the member that ends
   uint32_t out_off, crc, isize, pad;
@@ -607,36 +608,59 @@ __device__ __noinline__ ChainResult decode_chain(const uint32_t* comp, uint64_t 
           return r;
         }
       }
-      // symbols
+      // symbols.  The kernel is bound by instruction issue (profiles/r6_gz_decode_pmc_*.txt: ~15 scalar + 7 vector instructions
+      // per output byte at first), so the two common cases are kept short: a run of literals is a loop of lookup / store / shift
+      // with the drain test reduced to one compare against a precomputed position (FASTQ +7 %, VCF text unchanged).
       bool ran_out = false;
+      uint32_t drain_at = o.drained + DRAIN;  // (pos - drained < DRAIN holds here: a drain is due when pos reaches drain_at)
       for (;;) {
-        br.refill();
-        const uint32_t e = decode_symbol<C_LIT>(br);
-        if (e & E_LIT) {
-          if (lane_id() == 0) L.ring[o.pos & RM] = (uint16_t)(e >> 16);
-          ++o.pos;
-        } else if (e & E_EOB) {
-          break;
-        } else if (e & E_INVALID) {
-          r.status = GZ_BAD_CODE;
-          break;
-        } else {
-          const uint32_t len = (e >> 16) + br.take((int)((e >> 4) & 15u));
+        uint32_t e;
+        for (;;) {  // literals
           br.refill();
-          const uint32_t de = decode_symbol<C_DIST>(br);
-          if (de & E_INVALID) {
-            r.status = GZ_BAD_DISTANCE;
-            break;
-          }
-          const uint32_t dist = (de >> 16) + br.take((int)((de >> 4) & 15u));
-          copy_match(o, len, dist);
+          e = uniu(L.lit_lut[br.peek(LIT_BITS)]);
+          if (!(e & E_LIT)) break;  // (a literal entry always carries its code length: long codes and everything else leave)
+          L.ring[o.pos & RM] = (uint16_t)(e >> 16);  // all lanes store the same value to the same address
+          ++o.pos;
+          br.drop((int)(e & 15u));
+          if (o.pos == drain_at) break;
         }
-        if (o.pos - o.drained >= DRAIN) {
+        if (e & E_LIT) {
+          // a drain is due (checked below)
+        } else {
+          if ((e & 15u) == 0) {  // longer than the table, or no such code
+            const int rl = uni(decode_long(C_LIT, (uint32_t)br.buf));
+            e = rl < 0 ? (uint32_t)E_INVALID : entry_for(C_LIT, rl >> 8) | (uint32_t)(rl & 255);
+          }
+          br.drop((int)(e & 15u));
+          if (e & (E_LIT | E_EOB | E_INVALID)) {
+            if (e & E_LIT) {
+              L.ring[o.pos & RM] = (uint16_t)(e >> 16);
+              ++o.pos;
+            } else if (e & E_EOB) {
+              break;
+            } else {
+              r.status = GZ_BAD_CODE;
+              break;
+            }
+          } else {
+            const uint32_t len = (e >> 16) + br.take((int)((e >> 4) & 15u));
+            br.refill();
+            const uint32_t de = decode_symbol<C_DIST>(br);
+            if (de & E_INVALID) {
+              r.status = GZ_BAD_DISTANCE;
+              break;
+            }
+            const uint32_t dist = (de >> 16) + br.take((int)((de >> 4) & 15u));
+            copy_match(o, len, dist);  // (a special case for short matches whose sources all lie in the ring measured SLOWER on VCF text: profiles/r6_gz_loop_ab.log)
+          }
+        }
+        if (o.pos >= drain_at) {
           if (!drain_full(o)) {
             r.status = GZ_SYM_OVERFLOW;
             break;
           }
-          if (br.pos() > n_bits) {  // (checked once per 512 symbols: zero padding decodes as symbols for ever)
+          drain_at = o.drained + DRAIN;
+          if (br.pos() > n_bits) {  // (checked once per drain: zero padding decodes as symbols for ever)
             ran_out = true;
             break;
           }
@@ -703,6 +727,7 @@ chain_done:
 // One wavefront per task (a chunk of the slab, or a repair).
 __global__ __launch_bounds__(64) void k_gz_decode(const uint32_t* __restrict__ comp, uint64_t n_bits, const GzTask* __restrict__ tasks, uint16_t* __restrict__ sym, uint32_t cap,
                                                   GzChunk* __restrict__ res, GzMember* __restrict__ members, int input_final) {
+  const uint64_t t_begin = wall_clock64();
   const GzTask st = tasks[blockIdx.x];
   const int c = (int)uniu(st.region);
   const uint64_t stop_bit = uni64(st.stop);
@@ -772,6 +797,8 @@ __global__ __launch_bounds__(64) void k_gz_decode(const uint32_t* __restrict__ c
     out.status = r.status;
     out.flags = r.flags;
     out.n_members = r.n_members;
+    out.ticks = (uint32_t)(wall_clock64() - t_begin);
+    out.slot = (uint32_t)t_begin;
     res[c] = out;
   }
 }
@@ -1149,6 +1176,22 @@ int exon_hip_gzip_stream_decode(exon_hip_gzip_stream* s, void* stream, const uin
     HIP_TRY(ctx, hipMemcpyAsync(s->h_res, s->d_res, (size_t)n_chunks * sizeof(GzChunk), hipMemcpyDeviceToHost, hs));
     HIP_TRY(ctx, hipStreamSynchronize(hs));
     s->stats.chunks += n_chunks;
+    if (getenv("EXON_HIP_GZ_TRACE")) {  // how even is the work? (ticks of the constant 100 MHz counter)
+      uint64_t sum = 0;
+      uint32_t mx = 0, t_lo = ~0u, t_hi = 0;
+      std::vector<uint32_t> tk((size_t)n_chunks);
+      for (int c = 0; c < n_chunks; ++c) {
+        const GzChunk& r = s->h_res[c];
+        tk[(size_t)c] = r.ticks;
+        sum += r.ticks;
+        mx = std::max(mx, r.ticks);
+        t_lo = std::min(t_lo, r.slot);
+        t_hi = std::max(t_hi, r.slot + r.ticks);
+      }
+      std::sort(tk.begin(), tk.end());
+      fprintf(stderr, "[exon-hip gz] %d chunks of %u bytes: wavefront time sum %.1f ms, median %.0f us, p90 %.0f us, max %.0f us; first start .. last end %.2f ms\n", n_chunks, chunk_bytes,
+              sum / 1e5, tk[tk.size() / 2] / 100.0, tk[tk.size() * 9 / 10] / 100.0, mx / 100.0, (t_hi - t_lo) / 1e5);
+    }
     // The chain: chunk i + 1 must have started where chunk i stopped.  `chain` lists REGIONS in stream order.
     std::vector<int> chain;
     uint64_t cur = first_bit;

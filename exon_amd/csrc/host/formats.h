@@ -1225,7 +1225,7 @@ class FASTQBatchReader {
   void schema(struct ArrowSchema* out) const {
     make_schema(out, "+s", "", false,
                 {new_field("u", "name", false), new_field("u", "description", true), new_field("u", "sequence", false),
-                 new_field("u", "quality_score", false)});
+                 new_field("u", "quality_scores", false)});
   }
 
  private:
