@@ -95,7 +95,8 @@ class VCFColumns(C.Structure):
                 ("pos_valid", C.c_void_p), ("qual", C.c_void_p), ("qual_valid", C.c_void_p), ("filter_id", C.c_void_p),
                 ("info", C.c_void_p), ("info_valid", C.c_void_p), ("consumed_bytes", C.c_int64),
                 ("n_info", C.c_int32), ("reserved", C.c_int32), ("infos", C.c_void_p * 16), ("infos_valid", C.c_void_p * 16),
-                ("info_kinds", C.c_char * 16), ("list_offsets", C.c_void_p * 16), ("list_item_valid", C.c_void_p * 16)]
+                ("info_kinds", C.c_char * 16), ("list_offsets", C.c_void_p * 16), ("list_item_valid", C.c_void_p * 16),
+                ("info_nulls", C.c_int32 * 16)]
 
 
 class ScanOptions(C.Structure):
@@ -203,6 +204,7 @@ SIGNATURES = {
     "exon_hip_vcf_parser_create": (C.c_int, [_vp, C.POINTER(C.c_char_p), _i32, C.c_char_p, _i64, C.POINTER(_vp)]),
     "exon_hip_vcf_parser_parse": (C.c_int, [_vp, _vp, _vp, _i64, C.POINTER(VCFColumns)]),
     "exon_hip_vcf_parser_filters": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(_i32)]),
+    "exon_hip_vcf_parser_info_values": (C.c_int, [_vp, _i32, C.c_char_p, C.c_size_t, C.POINTER(_i32)]),
     "exon_hip_vcf_parser_destroy": (C.c_int, [_vp]),
     "exon_hip_qual_pos_hist_chunks": (C.c_int, [_vp, _vp, _colp, _i32, _vp, _i32, _vp]),
     "exon_hip_qual_pos_hist_views": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),

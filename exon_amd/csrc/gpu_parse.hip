@@ -571,7 +571,11 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
                 const int vl = (int)(j - vb);
                 if (!(vl == 0 || (vl == 1 && text[vb] == '.'))) {
                   uint32_t bits;
-                  if (ik.kind[q] == 'F' || ik.kind[q] == 'I') {
+                  if (ik.kind[q] == 's') {  // String / Character: the value's text; its dictionary id comes from k_info_string_ids
+                    out.lv_off[q][row] = vb;
+                    out.lv_cnt[q][row] = (uint32_t)vl;
+                    info_ok |= 1u << q;
+                  } else if (ik.kind[q] == 'F' || ik.kind[q] == 'I') {
                     unsigned items = 1;  // items are separated by ','; they are parsed by k_list_fill
                     for (int k = 0; k < vl; ++k) items += text[vb + k] == ',';
                     out.lv_off[q][row] = vb;
@@ -631,6 +635,53 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
   for (int q = 0; q < ik.n; ++q) store_valid(out.info_valid[q], wave_row0, n_rows, (info_ok >> q & 1u) != 0, lane);
   const unsigned long long nb = __ballot(bad);
   if (lane == 0 && nb) atomicAdd(out.exceptions, (unsigned)__popcll(nb));
+}
+
+// Number=1 String / Character INFO key (info_builder.rs:152-309 builds a Utf8 column; here: dictionary ids + the dictionary, like
+// FILTER): every row with a value hashes its text into the key's table -- provisional slot in ids[row], replaced by the dense id
+// by k_remap_filters once k_assign_filters has numbered the new values.  counters[3] += rows WITHOUT a value (a consumer that
+// groups by the key needs to know whether there is a NULL group).
+__global__ __launch_bounds__(TPB) void k_info_string_ids(const uint8_t* __restrict__ text, const uint32_t* __restrict__ voff, const uint32_t* __restrict__ vlen,
+                                                         const uint8_t* __restrict__ valid, const unsigned* __restrict__ n_lines_p, unsigned cap, FilterTable t,
+                                                         int32_t* __restrict__ ids) {
+  const unsigned n = min(*n_lines_p, cap);
+  const unsigned row = blockIdx.x * TPB + threadIdx.x;
+  bool has = false;
+  if (row < n) {
+    has = (valid[row >> 3] >> (row & 7)) & 1;
+    int found = 0;
+    if (has) {
+      const uint8_t* p = text + voff[row];
+      const int len = (int)vlen[row];
+      const unsigned long long h = fnv1a(p, len);
+      int slot = (int)(h & (FILTER_SLOTS - 1));
+      found = -1;
+      for (int probe = 0; probe < FILTER_SLOTS; ++probe) {
+        unsigned long long k = t.keys[slot];
+        if (k == 0) {
+          k = atomicCAS(&t.keys[slot], 0ull, h);
+          if (k == 0) {
+            t.text_off[slot] = voff[row];
+            t.text_len[slot] = (uint32_t)len;
+            found = slot;
+            break;
+          }
+        }
+        if (k == h) {
+          found = slot;
+          break;
+        }
+        slot = (slot + 1) & (FILTER_SLOTS - 1);
+      }
+      if (found < 0) {
+        atomicExch(&t.counters[2], 1);
+        found = 0;
+      }
+    }
+    ids[row] = found;
+  }
+  const unsigned long long miss = __ballot(row < n && !has);
+  if ((threadIdx.x & 63) == 0 && miss) atomicAdd(&t.counters[3], __popcll(miss));
 }
 
 // dense ids for FILTER lists inserted during the last parse, text copied into the persistent pool.  New lists are
@@ -777,6 +828,8 @@ struct exon_hip_vcf_parser {
   unsigned* d_list_blocks = nullptr;  // per-workgroup sums of the item counts (scanned in place)
   int64_t cap_items = 0;
   unsigned* h_scalars = nullptr;  // pinned mirror of d_scalars
+  FilterTable str_tables[MAX_INFO] = {};
+  int32_t h_str_stat[MAX_INFO][2] = {{0, 0}};  // per 's' key, last slab: {dictionary overflow, rows without a value}  // kind 's': the key's value dictionary, built on the device like the FILTER dictionary
 };
 
 extern "C" {
@@ -828,7 +881,7 @@ int exon_hip_vcf_parser_create(exon_hip_ctx* ctx, const char* const* contig_name
       std::string item = f.substr(i, j - i);
       char kind = 'f';
       const size_t c = item.rfind(':');
-      if (c != std::string::npos && c + 2 == item.size() && (item[c + 1] == 'f' || item[c + 1] == 'b' || item[c + 1] == 'i' || item[c + 1] == 'F' || item[c + 1] == 'I')) {
+      if (c != std::string::npos && c + 2 == item.size() && (item[c + 1] == 'f' || item[c + 1] == 'b' || item[c + 1] == 'i' || item[c + 1] == 'F' || item[c + 1] == 'I' || item[c + 1] == 's')) {
         kind = item[c + 1];
         item.resize(c);
       }
@@ -860,8 +913,22 @@ int exon_hip_vcf_parser_create(exon_hip_ctx* ctx, const char* const* contig_name
                                      // items (legal: "AF=,,,,") overflows this and is decoded by the host reader (k_list_fill / k_pack_bits clamp)
   for (int q = 0; q < p->ik.n; ++q) {
     const char kind = p->ik.kind[q];
-    if (kind == 'f' || kind == 'i') dalloc(&p->out_bufs[6 + 2 * q], r * 4);
+    if (kind == 'f' || kind == 'i' || kind == 's') dalloc(&p->out_bufs[6 + 2 * q], r * 4);
     dalloc(&p->out_bufs[7 + 2 * q], rb);
+    if (kind == 's') {  // Number=1 String / Character: where the value text is (k_parse_lines), then dictionary ids (k_info_string_ids)
+      dalloc(&p->list_bufs[5 * q + 0], r * 4);
+      dalloc(&p->list_bufs[5 * q + 1], r * 4);
+      FilterTable& t = p->str_tables[q];
+      dalloc((void**)&t.keys, FILTER_SLOTS * 8);
+      dalloc((void**)&t.ids, FILTER_SLOTS * 4);
+      dalloc((void**)&t.text_off, FILTER_SLOTS * 4);
+      dalloc((void**)&t.text_len, FILTER_SLOTS * 4);
+      dalloc((void**)&t.pool, FILTER_POOL);
+      dalloc((void**)&t.counters, 16);
+      if (e == hipSuccess) e = hipMemset(t.keys, 0, FILTER_SLOTS * 8);
+      if (e == hipSuccess) e = hipMemset(t.ids, 0xFF, FILTER_SLOTS * 4);
+      if (e == hipSuccess) e = hipMemset(t.counters, 0, 16);
+    }
     if (kind == 'F' || kind == 'I') {
       dalloc(&p->out_bufs[6 + 2 * q], (size_t)p->cap_items * 4);  // the items
       dalloc(&p->list_bufs[5 * q + 0], r * 4);
@@ -912,6 +979,14 @@ int exon_hip_vcf_parser_destroy(exon_hip_vcf_parser* p) {
   if (p->d_nl) exon_pool_free(p->ctx, p->d_nl);
   if (p->d_scalars) exon_pool_free(p->ctx, p->d_scalars);
   if (p->d_info_key) exon_pool_free(p->ctx, p->d_info_key);
+  for (FilterTable& t : p->str_tables) {
+    if (t.keys) exon_pool_free(p->ctx, t.keys);
+    if (t.ids) exon_pool_free(p->ctx, t.ids);
+    if (t.text_off) exon_pool_free(p->ctx, t.text_off);
+    if (t.text_len) exon_pool_free(p->ctx, t.text_len);
+    if (t.pool) exon_pool_free(p->ctx, t.pool);
+    if (t.counters) exon_pool_free(p->ctx, t.counters);
+  }
   for (void* b : p->list_bufs)
     if (b) exon_pool_free(p->ctx, b);
   if (p->d_list_blocks) exon_pool_free(p->ctx, p->d_list_blocks);
@@ -956,6 +1031,16 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* p, void* stream, const uint8_
     hipLaunchKernelGGL(k_pack_bits, dim3(1024), dim3(256), 0, s, (const uint8_t*)p->list_bufs[5 * q + 3], offsets, p->d_scalars, (unsigned)row_bound,
                        (unsigned)std::min<int64_t>(p->cap_items, 0xFFFFFFFFLL), (uint8_t*)p->list_bufs[5 * q + 4]);
   }
+  for (int q = 0; q < p->ik.n; ++q) {  // String / Character keys: value text -> dictionary ids
+    if (p->ik.kind[q] != 's') continue;
+    FilterTable& t = p->str_tables[q];
+    HIP_TRY(ctx, hipMemsetAsync(t.counters + 3, 0, 4, s));
+    hipLaunchKernelGGL(k_info_string_ids, dim3(pblocks), dim3(TPB), 0, s, d_text, p->out.lv_off[q], p->out.lv_cnt[q], p->out.info_valid[q], p->d_scalars, (unsigned)row_bound, t,
+                       (int32_t*)p->out.info[q]);
+    hipLaunchKernelGGL(k_assign_filters, dim3(1), dim3(256), 0, s, d_text, t);
+    hipLaunchKernelGGL(k_remap_filters, dim3(std::min(pblocks, 4096)), dim3(TPB), 0, s, (int32_t*)p->out.info[q], p->d_scalars, t.ids, (unsigned)row_bound);
+    HIP_TRY(ctx, hipMemcpyAsync(p->h_str_stat[q], t.counters + 2, 8, hipMemcpyDeviceToHost, s));  // {overflow, rows without a value}
+  }
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(p->h_scalars, p->d_scalars, 12, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -977,6 +1062,8 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* p, void* stream, const uint8_
     cols->infos[q] = p->out.info[q];  // NULL for a Flag: its column IS the presence bitmap
     cols->infos_valid[q] = p->out.info_valid[q];
     cols->info_kinds[q] = p->ik.kind[q];
+    cols->info_nulls[q] = p->ik.kind[q] == 's' ? p->h_str_stat[q][1] : -1;
+    if (p->ik.kind[q] == 's' && p->h_str_stat[q][0]) ++cols->n_undecided;  // more distinct values than the dictionary holds: the host reader's
     if (p->ik.kind[q] == 'F' || p->ik.kind[q] == 'I') {
       cols->list_offsets[q] = (int32_t*)p->list_bufs[5 * q + 2];
       cols->list_item_valid[q] = (uint8_t*)p->list_bufs[5 * q + 4];
@@ -989,31 +1076,29 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* p, void* stream, const uint8_
 const unsigned* exon_hip_vcf_parser_newlines(exon_hip_vcf_parser* p) { return p ? p->d_nl : nullptr; }
 extern "C" {
 
-// FILTER dictionary discovered so far: names are written '\0'-separated into `buf` (id order); returns the count
-int exon_hip_vcf_parser_filters(exon_hip_vcf_parser* p, char* buf, size_t cap, int32_t* n_filters) {
-  if (!p || !n_filters) return fail(p ? p->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_vcf_parser_filters: NULL argument");
-  exon_hip_ctx* ctx = p->ctx;
+// a device-built dictionary (FILTER lists, or the values of a String INFO key) in id order: names '\0'-separated into `buf`
+static int table_names(exon_hip_ctx* ctx, const FilterTable& t, const char* what, char* buf, size_t cap, int32_t* n_names) {
   int32_t counters[4];
-  HIP_TRY(ctx, hipMemcpy(counters, p->filters.counters, 16, hipMemcpyDeviceToHost));
-  if (counters[2]) return fail(ctx, EXON_HIP_EUNSUPPORTED, "more than %d distinct FILTER lists (or filter pool exhausted)", EXON_HIP_MAX_GROUPS);
+  HIP_TRY(ctx, hipMemcpy(counters, t.counters, 16, hipMemcpyDeviceToHost));
+  if (counters[2]) return fail(ctx, EXON_HIP_EUNSUPPORTED, "more than %d distinct %s (or their text pool exhausted)", EXON_HIP_MAX_GROUPS, what);
   std::vector<unsigned long long> keys(FILTER_SLOTS);
   std::vector<int32_t> ids(FILTER_SLOTS);
   std::vector<uint32_t> toff(FILTER_SLOTS), tlen(FILTER_SLOTS);
   std::vector<uint8_t> pool((size_t)std::max(counters[1], 1));
-  HIP_TRY(ctx, hipMemcpy(keys.data(), p->filters.keys, FILTER_SLOTS * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(ctx, hipMemcpy(ids.data(), p->filters.ids, FILTER_SLOTS * 4, hipMemcpyDeviceToHost));
-  HIP_TRY(ctx, hipMemcpy(toff.data(), p->filters.text_off, FILTER_SLOTS * 4, hipMemcpyDeviceToHost));
-  HIP_TRY(ctx, hipMemcpy(tlen.data(), p->filters.text_len, FILTER_SLOTS * 4, hipMemcpyDeviceToHost));
-  if (counters[1] > 0) HIP_TRY(ctx, hipMemcpy(pool.data(), p->filters.pool, (size_t)counters[1], hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(keys.data(), t.keys, FILTER_SLOTS * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(ids.data(), t.ids, FILTER_SLOTS * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(toff.data(), t.text_off, FILTER_SLOTS * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(tlen.data(), t.text_len, FILTER_SLOTS * 4, hipMemcpyDeviceToHost));
+  if (counters[1] > 0) HIP_TRY(ctx, hipMemcpy(pool.data(), t.pool, (size_t)counters[1], hipMemcpyDeviceToHost));
   std::vector<std::string> names((size_t)counters[0]);
   for (int s = 0; s < FILTER_SLOTS; ++s)
     if (keys[(size_t)s] != 0 && ids[(size_t)s] >= 0 && ids[(size_t)s] < counters[0])
       names[(size_t)ids[(size_t)s]] = std::string(reinterpret_cast<const char*>(pool.data()) + toff[(size_t)s], tlen[(size_t)s]);
   size_t need = 0;
   for (const auto& nm : names) need += nm.size() + 1;
-  *n_filters = counters[0];
+  *n_names = counters[0];
   if (buf) {
-    if (need > cap) return fail(ctx, EXON_HIP_EINVAL, "filter name buffer too small (%zu needed)", need);
+    if (need > cap) return fail(ctx, EXON_HIP_EINVAL, "name buffer too small (%zu needed)", need);
     size_t o = 0;
     for (const auto& nm : names) {
       memcpy(buf + o, nm.c_str(), nm.size() + 1);
@@ -1021,6 +1106,17 @@ int exon_hip_vcf_parser_filters(exon_hip_vcf_parser* p, char* buf, size_t cap, i
     }
   }
   return EXON_HIP_OK;
+}
+// FILTER dictionary discovered so far: names are written '\0'-separated into `buf` (id order); returns the count
+int exon_hip_vcf_parser_filters(exon_hip_vcf_parser* p, char* buf, size_t cap, int32_t* n_filters) {
+  if (!p || !n_filters) return fail(p ? p->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_vcf_parser_filters: NULL argument");
+  return table_names(p->ctx, p->filters, "FILTER lists", buf, cap, n_filters);
+}
+// the value dictionary of INFO key `key` (its index in the parser's key list; kind 's') in id order
+int exon_hip_vcf_parser_info_values(exon_hip_vcf_parser* p, int32_t key, char* buf, size_t cap, int32_t* n_values) {
+  if (!p || !n_values) return fail(p ? p->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_vcf_parser_info_values: NULL argument");
+  if (key < 0 || key >= p->ik.n || p->ik.kind[key] != 's') return fail(p->ctx, EXON_HIP_EINVAL, "exon_hip_vcf_parser_info_values: key %d is not a String / Character key of this parser", key);
+  return table_names(p->ctx, p->str_tables[key], "values of a String INFO key", buf, cap, n_values);
 }
 
 }  // extern "C"

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <map>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -84,6 +85,7 @@ struct GpuExporter {
   std::string err;
   int64_t emitted = 0;                       // rows handed to the queue so far
   std::vector<std::string> final_filters;    // the FILTER dictionary when the producer has finished
+  std::vector<std::vector<std::string>> final_info_names;  // ... and the String INFO keys' dictionaries
   bool decoded_on_gpu = false, inflated_on_gpu = false;
   // the host reader that takes over when the device hands the file back.  It lives HERE while the producer thread runs: the
   // scan's own reader (which exon_hip_scan_schema / _dictionary_* read from the consumer's thread) is never touched by the
@@ -152,6 +154,10 @@ static const char* unsupported_codec(const char* path) {
   return nullptr;
 }
 
+// INFO kinds the GPU pipeline of THIS scan decodes: Float / Integer / Flag everywhere; Number=1 String / Character (dictionary ids,
+// the dictionary built on the device) for VCF text
+static bool info_kind_decoded_on_gpu(const exon_hip_scan* s, char kind) { return exon::info_kind_on_device(kind) || (kind == 's' && s->vcf != nullptr); }
+
 static exon::Dictionary* dict_of(exon_hip_scan* s, int col) {
   if (s->format == EXON_HIP_FORMAT_BCF && col == 0) return &s->bcf->chrom_dict;
   if (s->format == EXON_HIP_FORMAT_BCF && col == 3) return s->bcf_parser ? &s->gpu_filter_dict : &s->bcf->filter_dict;
@@ -218,7 +224,7 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         s->vcf.reset(new exon::VCFBatchReader(path, c, cfg));
         if (s->gpu_parse) {
           bool string_info = false;
-          for (const auto& sp : s->vcf->info_specs) string_info |= !exon::info_kind_on_device(sp.kind);
+          for (const auto& sp : s->vcf->info_specs) string_info |= !info_kind_decoded_on_gpu(s.get(), sp.kind);
           if (string_info) {  // string / list INFO columns are built by the host reader only: batches come from there
             s->gpu_parse = false;
             s->gpu_candidate = true;
@@ -1704,6 +1710,32 @@ static int gpu_filter_names(exon_hip_scan* scan, std::vector<std::string>* names
   return rc;
 }
 
+// the value dictionaries of the String INFO keys the device decoded (VCF text): names[k] for scan column 4 + k (empty for other kinds)
+static int gpu_info_names(exon_hip_scan* scan, std::vector<std::vector<std::string>>* names) {
+  names->clear();
+  if (!scan->vcf || !scan->parser) return EXON_HIP_OK;
+  const std::vector<exon::InfoSpec>& specs = scan->vcf->info_specs;
+  names->resize(specs.size());
+  int q = 0;
+  std::vector<char> buf;
+  for (size_t k = 0; k < specs.size(); ++k) {
+    if (specs[k].kind == 'S') continue;
+    if (specs[k].kind == 's') {
+      int32_t nv = 0;
+      buf.resize(2u << 20);
+      const int rc = exon_hip_vcf_parser_info_values(scan->parser, q, buf.data(), buf.size(), &nv);
+      if (rc) return rc;
+      size_t o = 0;
+      for (int32_t i = 0; i < nv; ++i) {
+        (*names)[k].emplace_back(buf.data() + o);
+        o += (*names)[k].back().size() + 1;
+      }
+    }
+    ++q;
+  }
+  return EXON_HIP_OK;
+}
+
 // pinned host blocks that carry a slab's columns: a few are kept for reuse (pinning costs ~0.2 ms per MB); a block goes back
 // when the last batch that views it has been released -- which may be long after its scan was closed, hence process-wide
 namespace {
@@ -1783,12 +1815,16 @@ struct HostText {
 static int fetch_text(exon_hip_ctx* ctx, hipStream_t hs, int64_t n_rows, uint64_t projection, const ExonVcfText* vt, const ExonBamText* bt, HostText* h) {
   h->projection = projection;
   struct Want {
-    void* span;
+    std::function<void(const uint8_t*)> place;  // points the span at its bytes inside the block
     const void* src;
     size_t count, elem;
   };
   std::vector<Want> wants;
-  auto get = [&](auto& span, const void* src, size_t count) { wants.push_back(Want{&span, src, count, sizeof(*span.p)}); };
+  auto get = [&](auto& span, const void* src, size_t count) {
+    typedef typename std::remove_reference<decltype(*span.p)>::type T;
+    auto* sp = &span;
+    wants.push_back(Want{[sp, count](const uint8_t* at) { sp->p = reinterpret_cast<const T*>(at); sp->n = count; }, src, count, sizeof(T)});
+  };
   const size_t n = (size_t)n_rows, nb = (n + 7) / 8;
   if (vt) {
     h->vcf = true;
@@ -1828,12 +1864,7 @@ static int fetch_text(exon_hip_ctx* ctx, hipStream_t hs, int64_t n_rows, uint64_
   size_t at = 0;
   for (const Want& w : wants) {
     uint8_t* dst = static_cast<uint8_t*>(h->blk) + at;
-    // (every Span has the layout {pointer, count})
-    struct Raw {
-      const void* p;
-      size_t n;
-    };
-    *static_cast<Raw*>(w.span) = Raw{dst, w.count};
+    w.place(dst);
     if (e == hipSuccess && w.count && w.src) e = hipMemcpyAsync(dst, w.src, w.count * w.elem, hipMemcpyDeviceToHost, hs);
     at += (w.count * w.elem + 63) & ~(size_t)63;
   }
@@ -1959,10 +1990,16 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
     const int rc = gpu_filter_names(scan, &filters);
     if (rc) return rc;
   }
+  std::vector<std::vector<std::string>> info_names;
+  if (scan->vcf) {
+    const int rc = gpu_info_names(scan, &info_names);
+    if (rc) return rc;
+  }
   const int64_t bs = scan->opt.batch_size > 0 ? scan->opt.batch_size : 8192;
   auto dict_of_col = [&](int c) -> struct ArrowArray* {
     if (vcf_like && c == 0) return exon::utf8_array(scan->vcf ? scan->vcf->chrom_dict.names : scan->bcf->chrom_dict.names);
     if (vcf_like && c == 3) return exon::utf8_array(filters);
+    if (scan->vcf && c >= 4 && (size_t)(c - 4) < info_names.size() && (*specs)[(size_t)(c - 4)].kind == 's') return exon::utf8_array(info_names[(size_t)(c - 4)]);
     if (!vcf_like && c == 2) return exon::utf8_array(scan->bam_dict_view.names);
     return nullptr;
   };
@@ -2126,9 +2163,9 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
     if (is_vcf && !scan->parser) {
       std::vector<const char*> names;
       for (const auto& c : scan->vcf->header.contigs) names.push_back(c.c_str());
-      std::string keys;  // "name:kind,..." from the header-typed specs of the host reader; String / Character keys are not decoded
+      std::string keys;  // "name:kind,..." from the header-typed specs of the host reader; String LISTS are not decoded
       for (const auto& sp : scan->vcf->info_specs)
-        if (sp.kind != 's' && sp.kind != 'S') keys += (keys.empty() ? "" : ",") + sp.name + ":" + std::string(1, sp.kind);
+        if (sp.kind != 'S') keys += (keys.empty() ? "" : ",") + sp.name + ":" + std::string(1, sp.kind);
       rc = exon_hip_vcf_parser_create(ctx, names.data(), (int32_t)names.size(), keys.empty() ? nullptr : keys.c_str(),
                                       (int64_t)src->max_text_bytes(), &scan->parser);
       if (rc) break;
@@ -2208,10 +2245,13 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
             int q = 0;
             for (size_t k = 0; k < specs.size() && k < (size_t)EXON_HIP_MAX_INFO_FIELDS; ++k) {
               const char kind = specs[k].kind;
-              if (kind == 's' || kind == 'S') continue;
+              if (kind == 'S' || (kind == 's' && !is_vcf)) continue;  // (not given to the device parser)
               if (q < cols.n_info && !exon::info_kind_is_list(kind)) {
                 sc[4 + k].values = cols.infos[q] ? (const void*)cols.infos[q] : (const void*)cols.infos_valid[q];  // a Flag's values ARE its bitmap
                 sc[4 + k].validity = cols.infos_valid[q];
+                // a String key's dictionary ids: without a NULL in this slab the column goes out as NOT NULL (a fused plan that
+                // groups by it refuses nullable ids: there is no NULL group in its state)
+                if (kind == 's' && cols.info_nulls[q] == 0 && !scan->exporter) sc[4 + k].validity = nullptr;
               }
               ++q;
             }
@@ -2314,6 +2354,18 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
     if (!rc) {
       if (scan->exporter) scan->exporter->final_filters.swap(names);  // (adopted by the consumer's thread at the end of the batches)
       else scan->gpu_filter_dict.names.swap(names);
+    }
+  }
+  if (rc == EXON_HIP_OK && is_vcf && scan->parser) {  // String INFO keys: their dictionaries -> scan
+    std::vector<std::vector<std::string>> info_names;
+    rc = gpu_info_names(scan, &info_names);
+    if (!rc) {
+      if (scan->exporter) {
+        scan->exporter->final_info_names.swap(info_names);
+      } else {
+        for (size_t k = 0; k < info_names.size() && k < scan->vcf->info_dicts.size(); ++k)
+          if (scan->vcf->info_specs[k].kind == 's') scan->vcf->info_dicts[k].names.swap(info_names[k]);
+      }
     }
   }
   if (rc == EXON_HIP_OK) {
@@ -2492,9 +2544,13 @@ static int gpu_next(exon_hip_scan* s, struct ArrowArray* out) {
     }
     ex->handed_over = false;
     ex->final_filters.clear();
+    ex->final_info_names.clear();
   }
   if (ex->rc) return fail(ex->ctx, ex->rc, "%s", ex->err.c_str());
   if (!ex->final_filters.empty()) s->gpu_filter_dict.names.swap(ex->final_filters);
+  if (s->vcf)
+    for (size_t k = 0; k < ex->final_info_names.size() && k < s->vcf->info_dicts.size(); ++k)
+      if (s->vcf->info_specs[k].kind == 's') s->vcf->info_dicts[k].names.swap(ex->final_info_names[k]);
   s->gpu_decoded = ex->decoded_on_gpu;
   s->gpu_inflated = ex->inflated_on_gpu;
   return 1;
@@ -2564,7 +2620,7 @@ static int consume_scan_impl(exon_hip_stream* st, exon_hip_scan* scan, int64_t* 
     bool reads_host_only = false;
     for (int a = 0; a < 4; ++a) {
       const int col = exon_hip_stream_plan_column(st, a);
-      if (col >= 4 && (size_t)(col - 4) < specs.size() && !exon::info_kind_on_device(specs[(size_t)(col - 4)].kind)) reads_host_only = true;
+      if (col >= 4 && (size_t)(col - 4) < specs.size() && !info_kind_decoded_on_gpu(scan, specs[(size_t)(col - 4)].kind)) reads_host_only = true;
     }
     if (!reads_host_only) {
       try {  // the host reader goes back to "header only": the bytes are the device's

@@ -451,7 +451,7 @@ typedef struct exon_hip_scan_options {
   const char* info_field; /* VCF / BCF: typed INFO fields to extract (exon.vcf_parse_info), up to 16 comma-separated header
                              IDs ("AF,DP,DB"), NULL = none.  They become scan columns 4, 5, ..., typed from the header as the
                              reference does (schema_builder.rs:197-249): Number=1 Float -> f32?, Number=1 Integer -> i32?,
-                             Flag -> bool? (true when present, NULL when absent), Number=1 String / Character -> dictionary?,
+                             Flag -> bool? (true when present, NULL when absent), Number=1 String / Character -> dictionary? (VCF text: built on the device too),
                              any other Number -> List<f32 | i32 | dictionary>? (items '.' are NULL items; host decoders);
                              INFO '.' makes all of them NULL (the struct itself is NULL in the reference) */
   const char* region;     /* pushed-down vcf_region_filter / bam_region_filter ("chr1:1-100"), NULL = none */
@@ -564,6 +564,10 @@ typedef struct exon_hip_vcf_columns {
    * list_item_valid[k] = validity of the items (a '.' item is a NULL item: info_builder.rs:258-305).  NULL for scalar kinds. */
   int32_t* list_offsets[EXON_HIP_MAX_INFO_FIELDS];
   uint8_t* list_item_valid[EXON_HIP_MAX_INFO_FIELDS];
+  /* (ABI 5) info_kinds[k] = 's' (Number=1 String / Character, VCF text only): infos[k] = int32 dictionary ids, infos_valid[k] =
+   * validity; the dictionary is built on the device like the FILTER one: exon_hip_vcf_parser_info_values.  info_nulls[k] = rows
+   * of this slab without a value (-1 for other kinds): a GROUP BY over the key has a NULL group unless this is 0. */
+  int32_t info_nulls[EXON_HIP_MAX_INFO_FIELDS];
 } exon_hip_vcf_columns;
 /* info_field: NULL, or up to EXON_HIP_MAX_INFO_FIELDS comma-separated INFO keys "name[:kind]" -- kind f (default): Number=1
  * Float -> f32; kind i: Number=1 Integer -> i32; kind b: Flag -> presence bitmap; kinds F / I: list-valued Float / Integer
@@ -576,6 +580,8 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* parser, void* stream, const u
                               exon_hip_vcf_columns* cols);
 /* FILTER dictionary discovered so far, '\0'-separated in id order ("" = the empty list) */
 int exon_hip_vcf_parser_filters(exon_hip_vcf_parser* parser, char* buf, size_t cap, int32_t* n_filters);
+/* values of the String / Character INFO key `key` (index in the parser's key list) seen so far, '\0'-separated, in id order */
+int exon_hip_vcf_parser_info_values(exon_hip_vcf_parser* parser, int32_t key, char* buf, size_t cap, int32_t* n_values);
 int exon_hip_vcf_parser_destroy(exon_hip_vcf_parser* parser);
 
 /* ---- BGZF inflate on the GPU (compressed blocks in HBM -> inflated bytes in HBM) ------------------------------------

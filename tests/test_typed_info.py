@@ -415,15 +415,16 @@ def test_string_and_list_info_keys_the_plan_does_not_read_stay_on_the_gpu(ctx, t
 
 
 @pytest.mark.gpu
-def test_a_plan_that_reads_a_string_info_key_keeps_the_scan_on_the_host(ctx, tmp_path):
-    """GROUP BY info.CSQ (a String key: the host reader's dictionary ids are the group ids): the device does not build that column,
-    so this consume stays with the host decoder -- and says so."""
+def test_a_plan_that_groups_by_a_string_info_key_stays_on_the_gpu(ctx, tmp_path):
+    """GROUP BY info.CSQ (a Number=1 String key).  Until round 5 the device did not build that column and the consume went to the host
+    decoder; since round 6 the key's dictionary is built on the device like the FILTER one (k_info_string_ids): the consume stays
+    on the GPU, the dictionary ids are the group ids, the names come back with the scan."""
     p = tmp_path / "t.vcf"
     p.write_text(HEAD + "".join(f"1\t{i + 1}\t.\tA\tC\t{i}\tPASS\tAF=0.{1 + i % 9};CSQ=c{i % 3}\n" for i in range(5000)))
     scan = exon_amd.Scan(str(p), "vcf", info_field="AF,CSQ", gpu_parse=True)
     plan = ctx.plan_cmp_avg_by_group(">", 0.01, 8, columns=(4, 2, 5))
     st = plan.open()
-    assert st.consume(scan) == 5000 and not scan.decoded_on_gpu()[0]
+    assert st.consume(scan) == 5000 and scan.decoded_on_gpu()[0]
     counts, sums = st.finish()
     names = scan.dictionary(5)
     assert sorted(names) == ["c0", "c1", "c2"] and sorted(int(counts[8 + g]) for g in range(3)) == [1666, 1667, 1667]
@@ -432,4 +433,55 @@ def test_a_plan_that_reads_a_string_info_key_keeps_the_scan_on_the_host(ctx, tmp
     scan.close()
     s = exon_amd.Scan(str(p), "vcf", info_field="AF,CSQ")
     assert s.dictionary(5) == [] and len(list(s)) == 1 and s.dictionary(5) == ["c0", "c1", "c2"]
+    s.close()
+
+
+@pytest.mark.gpu
+def test_string_info_key_dictionary_on_the_device_equals_the_host_readers(ctx, tmp_path, monkeypatch):
+    """A String key with missing values, '.', a Character key, and rows whose INFO is '.': batches out of the GPU pipeline carry
+    the key as a dictionary column with the host reader's VALUES and NULLs (ids may be numbered differently); a GROUP BY over a key
+    with NULLs is refused by name (the fused state has no NULL group) instead of counting them somewhere; more distinct values than
+    the device dictionary holds hand the file to the host reader."""
+    rng = np.random.default_rng(3)
+    head = HEAD.replace("##INFO=<ID=AF", '##INFO=<ID=TYPE,Number=1,Type=Character,Description="t">\n##INFO=<ID=AF')
+    lines = []
+    for i in range(60000):
+        k = i % 11
+        info = "." if k == 0 else f"AF=0.{1 + i % 9}" + ("" if k == 1 else f";CSQ={'.' if k == 2 else ('gene' + str(int(rng.integers(0, 40))))}") + (f";TYPE={'SID'[i % 3]}" if k % 2 else "")
+        lines.append(f"1\t{i + 1}\t.\tA\tC\t{i % 97}\tPASS\t{info}\n")
+    p = tmp_path / "s.vcf"
+    p.write_text(head + "".join(lines))
+    monkeypatch.setenv("EXON_HIP_GPU_PARSE_SLAB_MB", "1")   # several slabs: the dictionary grows from slab to slab
+
+    def cols(scan):
+        out = {}
+        for b in scan:
+            for i in range(b.type.num_fields):
+                out.setdefault(b.type.field(i).name, []).extend(b.field(i).to_pylist())
+        return out
+    s = exon_amd.Scan(str(p), "vcf", info_field="AF,CSQ,TYPE", gpu_parse=True).bind_ctx(ctx)
+    dev = cols(s)
+    assert s.decoded_on_gpu()[0]
+    assert sorted(s.dictionary(5)) == sorted({v for v in dev["info.CSQ"] if v is not None}) and len(s.dictionary(5)) == 40
+    s.close()
+    host = cols(exon_amd.Scan(str(p), "vcf", info_field="AF,CSQ,TYPE"))
+    for k in ("info.AF", "info.CSQ", "info.TYPE", "pos"):
+        assert dev[k] == host[k], k
+    assert dev["info.CSQ"].count(None) > 10000 and set(dev["info.TYPE"]) == {"S", "I", "D", None}
+    # GROUP BY a key that has NULLs: refused by name
+    scan = exon_amd.Scan(str(p), "vcf", info_field="AF,CSQ", gpu_parse=True)
+    plan = ctx.plan_cmp_avg_by_group(">", 0.01, 64, columns=(4, 2, 5))
+    st = plan.open()
+    with pytest.raises(exon_amd.ExonHipError) as e:
+        st.consume(scan)
+    assert "nullable group ids" in str(e.value)
+    st.close()
+    plan.close()
+    scan.close()
+    # more distinct values than the device dictionary holds: the host reader takes the file (and builds every value)
+    q = tmp_path / "many.vcf"
+    q.write_text(HEAD + "".join(f"1\t{i + 1}\t.\tA\tC\t1\tPASS\tAF=0.5;CSQ=v{i}\n" for i in range(9000)))
+    s = exon_amd.Scan(str(q), "vcf", info_field="AF,CSQ", gpu_parse=True).bind_ctx(ctx)
+    many = cols(s)
+    assert many["info.CSQ"] == [f"v{i}" for i in range(9000)] and not s.decoded_on_gpu()[0]
     s.close()
