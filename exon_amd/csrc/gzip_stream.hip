@@ -55,6 +55,7 @@ constexpr uint32_t NEAR = DRAIN + 264;  // sources at most this far back are rea
 static_assert(RING >= (int)NEAR + 258, "a match may not overwrite ring entries that count as near");
 constexpr int WIN = 32768;
 constexpr int MAX_MEMBER_ENDS = 8;   // member trailers one chunk may cross
+constexpr uint32_t GAP_CAP = 8192;   // symbols a batched gap decode may produce (a gap is what the header search skipped: an empty stored block, a short fixed block)
 constexpr int SPARE_REGIONS = 64;    // scratch regions beyond one per chunk: a repair decodes the gap in front of a chunk into one
 
 enum : uint32_t {
@@ -807,8 +808,9 @@ __global__ __launch_bounds__(64) void k_gz_decode(const uint32_t* __restrict__ c
 // accepted chunk a: symbols sym[chunk[a] * cap ...], n_out[a] of them.  Its TAIL map T over the window W in front of it
 // (32 Ki entries, W[32767] = the byte right in front of the chunk): T[j] = the symbol that becomes byte j of the window behind it.
 struct Accepted {
-  uint32_t chunk, n_out;
+  uint64_t sym_off;  // where its symbols start in the scratch
   uint64_t out_off;  // bytes in front of it in the slab's output
+  uint32_t n_out, pad;
 };
 __device__ __forceinline__ uint16_t tail_symbol(const uint16_t* __restrict__ s, uint32_t n_out, int j) {
   if (n_out >= (uint32_t)WIN) return s[n_out - WIN + j];
@@ -826,7 +828,7 @@ __global__ __launch_bounds__(1024) void k_gz_compose(const uint16_t* __restrict_
   for (int j = threadIdx.x; j < WIN; j += 1024) cur[j] = (uint16_t)(256 + j);
   __syncthreads();
   for (int a = a0; a < a1; ++a) {
-    const uint16_t* s = sym + (size_t)acc[a].chunk * cap;
+    const uint16_t* s = sym + acc[a].sym_off;
     const uint32_t n = acc[a].n_out;
     for (int j = threadIdx.x; j < WIN; j += 1024) {
       const uint16_t t = tail_symbol(s, n, j);
@@ -871,7 +873,7 @@ __global__ __launch_bounds__(1024) void k_gz_windows(const uint16_t* __restrict_
   __syncthreads();
   for (int a = a0; a < a1; ++a) {
     uint8_t* dst = chunk_win + (size_t)a * WIN;
-    const uint16_t* s = sym + (size_t)acc[a].chunk * cap;
+    const uint16_t* s = sym + acc[a].sym_off;
     const uint32_t n = acc[a].n_out;
     const bool last = a + 1 == a1;
     for (int j = threadIdx.x; j < WIN; j += 1024) {
@@ -896,7 +898,7 @@ __global__ __launch_bounds__(256) void k_gz_emit(const uint16_t* __restrict__ sy
   const uint32_t lo = (uint32_t)piece * EMIT_PIECE;
   if (lo >= A.n_out) return;
   const uint32_t hi = min(A.n_out, lo + EMIT_PIECE);
-  const uint16_t* s = sym + (size_t)A.chunk * cap;
+  const uint16_t* s = sym + A.sym_off;
   const uint8_t* w = chunk_win + (size_t)a * WIN;
   uint8_t* o = out + A.out_off;
   for (uint32_t i = lo + threadIdx.x * 8u; i < hi; i += 256u * 8u) {
@@ -1020,7 +1022,8 @@ struct exon_hip_gzip_stream {
   bool fixed_chunk = false;
   int64_t max_comp = 0;
   int max_chunks = 0;
-  size_t sym_words = 0;  // symbols of scratch
+  size_t sym_words = 0;  // symbols of scratch (the chunks' regions)
+  size_t gap_words = 0;  // ... and behind them GAP_CAP symbols per batched gap
   uint16_t* d_sym = nullptr;
   GzChunk* d_res = nullptr;
   GzChunk* h_res = nullptr;  // pinned
@@ -1079,16 +1082,17 @@ int exon_hip_gzip_stream_create(exon_hip_ctx* ctx, int64_t max_comp_bytes, int64
   // adaptive chunks: a call never has more than two rounds of wavefront slots' worth of them, or max_comp / 64 KiB
   s->max_chunks = s->fixed_chunk ? (int)((max_comp_bytes + s->chunk_bytes - 1) / s->chunk_bytes) + 1
                                  : (int)std::max<int64_t>(2ll * GZ_WAVES_PER_CU * std::max(ctx->cfg.compute_units, 1) + 2, (max_comp_bytes + s->chunk_bytes - 1) / s->chunk_bytes + 2);
-  const size_t nr = (size_t)s->max_chunks + SPARE_REGIONS;  // regions: one per chunk + the spares that repairs decode gaps into
+  const size_t nr = 2 * (size_t)s->max_chunks + SPARE_REGIONS;  // records: one per chunk + the spares of sequential repairs + one per batched gap
   // symbol scratch: 2 bytes per output byte.  Default: room for a ratio of 8 over the largest slab (at least 1 Mi symbols per
   // chunk are never needed: a chunk's region is scratch / chunks, the call shrinks its slab when a region overflows)
   if (scratch_bytes <= 0) scratch_bytes = std::max<int64_t>(max_comp_bytes * 16, 64 << 20);
   s->sym_words = (size_t)scratch_bytes / 2;
+  s->gap_words = (size_t)s->max_chunks * GAP_CAP;  // the batched gaps' own area behind the chunks' regions
   hipSetDevice(ctx->device);
   const size_t nc = nr;
   const size_t ng = (nc + GROUP - 1) / GROUP;
   s->max_pieces = s->sym_words / 65536 + 2 * nc * (MAX_MEMBER_ENDS + 1) + 16;
-  bool ok = hipMalloc((void**)&s->d_sym, s->sym_words * 2 + 64) == hipSuccess && hipMalloc((void**)&s->d_res, nc * sizeof(GzChunk)) == hipSuccess &&
+  bool ok = hipMalloc((void**)&s->d_sym, (s->sym_words + s->gap_words) * 2 + 64) == hipSuccess && hipMalloc((void**)&s->d_res, nc * sizeof(GzChunk)) == hipSuccess &&
             hipMalloc((void**)&s->d_members, nc * MAX_MEMBER_ENDS * sizeof(GzMember)) == hipSuccess && hipMalloc((void**)&s->d_tasks, nc * sizeof(GzTask)) == hipSuccess &&
             hipMalloc((void**)&s->d_acc, nc * sizeof(Accepted)) == hipSuccess &&
             hipMalloc((void**)&s->d_group_map, ng * WIN * 2) == hipSuccess && hipMalloc((void**)&s->d_group_win, ng * WIN) == hipSuccess &&
@@ -1162,6 +1166,7 @@ int exon_hip_gzip_stream_decode(exon_hip_gzip_stream* s, void* stream, const uin
     const uint64_t n_bits = 8ull * (uint64_t)(lead + n_use);
     const uint64_t chunk_bits = 8ull * chunk_bytes;
     const uint64_t first_bit = 8ull * lead + s->start_bit;
+    int n_records = n_chunks + n_spare;  // result records / member slots in use (chunks, sequential spares, batched gaps)
     for (int c = 0; c < n_chunks; ++c) {
       const uint64_t stop = c + 1 < n_chunks ? (uint64_t)(c + 1) * chunk_bits : ~0ull;
       s->h_tasks[c] = c == 0 ? GzTask{first_bit, stop, s->start_kind, 0} : GzTask{(uint64_t)c * chunk_bits, stop, START_SEARCH, (uint32_t)c};
@@ -1189,7 +1194,47 @@ int exon_hip_gzip_stream_decode(exon_hip_gzip_stream* s, void* stream, const uin
       fprintf(stderr, "[exon-hip gz] %d chunks of %u bytes: wavefront time sum %.1f ms, median %.0f us, p90 %.0f us, max %.0f us; first start .. last end %.2f ms\n", n_chunks, chunk_bytes,
               sum / 1e5, tk[tk.size() / 2] / 100.0, tk[tk.size() * 9 / 10] / 100.0, mx / 100.0, (t_hi - t_lo) / 1e5);
     }
-    // The chain: chunk i + 1 must have started where chunk i stopped.  `chain` lists REGIONS in stream order.
+    // Gaps, all at once.  The header search only looks for DYNAMIC blocks: where a stored or fixed block stands at the chain's
+    // position (pigz ends every 128 KiB of input with an empty stored block, zlib's Z_SYNC_FLUSH the same) the chunk behind it began
+    // a few bytes late.  One walk over the records as they are -- trusting every usable chunk -- lists those gaps, ONE launch decodes
+    // them (a wavefront each, into small regions of their own), and the proving walk below takes them where they fit.  (One by one
+    // they cost a launch and a host round trip each: ~40 us x a third of the chunks of a pigz file.)
+    struct Gap {
+      uint64_t from, to;
+      int record;  // index of its result record / member slots
+    };
+    std::vector<Gap> gap_of((size_t)n_chunks, Gap{0, 0, -1});
+    {
+      uint64_t cur0 = first_bit;
+      int n_gaps = 0;
+      const int gap_base = n_chunks + n_spare;
+      for (int c = 0; c < n_chunks; ++c) {
+        const uint64_t stop = c + 1 < n_chunks ? (uint64_t)(c + 1) * chunk_bits : ~0ull;
+        if (c > 0 && cur0 >= stop) continue;
+        const GzChunk& f = s->h_res[c];
+        const bool usable = f.status == GZ_OK || f.status == GZ_SYM_OVERFLOW;
+        if (c > 0 && !(usable && f.start_bit == cur0)) {
+          if (!(usable && f.start_bit > cur0 && f.start_bit - cur0 <= chunk_bits) || n_gaps >= s->max_chunks) break;  // a real repair: the walk below
+          gap_of[(size_t)c] = Gap{cur0, f.start_bit, gap_base + n_gaps};
+          s->h_tasks[gap_base + n_gaps] = GzTask{cur0, f.start_bit, START_BLOCK, (uint32_t)n_gaps};
+          ++n_gaps;
+        }
+        if (!usable || f.status == GZ_SYM_OVERFLOW) break;
+        cur0 = f.end_bit;
+        if (f.flags & (F_EXHAUSTED | F_STREAM_END)) break;
+      }
+      if (n_gaps > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(s->d_tasks + gap_base, s->h_tasks + gap_base, (size_t)n_gaps * sizeof(GzTask), hipMemcpyHostToDevice, hs));
+        hipLaunchKernelGGL(k_gz_decode, dim3(n_gaps), dim3(64), 0, hs, reinterpret_cast<const uint32_t*>(d_comp), n_bits, (const GzTask*)(s->d_tasks + gap_base), s->d_sym + s->sym_words, GAP_CAP,
+                           s->d_res + gap_base, s->d_members + (size_t)gap_base * MAX_MEMBER_ENDS, final_here ? 1 : 0);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(s->h_res + gap_base, s->d_res + gap_base, (size_t)n_gaps * sizeof(GzChunk), hipMemcpyDeviceToHost, hs));
+        HIP_TRY(ctx, hipStreamSynchronize(hs));
+        s->stats.repairs += (uint64_t)n_gaps;
+      }
+      n_records = gap_base + n_gaps;
+    }
+    // The chain: chunk i + 1 must have started where chunk i stopped.  `chain` lists result RECORDS in stream order.
     std::vector<int> chain;
     uint64_t cur = first_bit;
     bool overflow = false, at_end = false;
@@ -1223,7 +1268,15 @@ int exon_hip_gzip_stream_decode(exon_hip_gzip_stream* s, void* stream, const uin
           fprintf(stderr, "[exon-hip gz] repair: chunk %d of %d began at %llu (status %u flags %u n_out %u end %llu), the chain is at %llu\n", c, n_chunks,
                   (unsigned long long)found.start_bit, found.status, found.flags, found.n_out, (unsigned long long)found.end_bit, (unsigned long long)cur);
         bool spliced = false;
-        if (usable && found.start_bit > cur && found.start_bit - cur <= chunk_bits && spares < n_spare) {
+        const Gap& bg = gap_of[(size_t)c];
+        if (usable && bg.record >= 0 && bg.from == cur && bg.to == found.start_bit) {
+          const GzChunk& g = s->h_res[bg.record];
+          if (g.status == GZ_OK && g.flags == 0 && g.end_bit == found.start_bit) {
+            chain.push_back(bg.record);
+            spliced = true;
+          }
+        }
+        if (!spliced && usable && found.start_bit > cur && found.start_bit - cur <= chunk_bits && spares < n_spare) {
           const int gap = n_chunks + spares;  // (the regions right behind this call's chunks)
           const int rc = redo(cur, found.start_bit, gap);
           if (rc) return rc;
@@ -1284,7 +1337,9 @@ int exon_hip_gzip_stream_decode(exon_hip_gzip_stream* s, void* stream, const uin
     int total_members = 0;
     for (size_t a = 0; a < n_acc; ++a) {
       const GzChunk& r = s->h_res[chain[a]];
-      s->h_acc[a] = Accepted{(uint32_t)chain[a], r.n_out, off};
+      const int rec = chain[a];
+      const uint64_t sym_off = rec < n_chunks + n_spare ? (uint64_t)rec * cap : (uint64_t)s->sym_words + (uint64_t)(rec - (n_chunks + n_spare)) * GAP_CAP;
+      s->h_acc[a] = Accepted{sym_off, off, r.n_out, 0};
       off += r.n_out;
       total_members += (int)r.n_members;
     }
@@ -1306,7 +1361,7 @@ int exon_hip_gzip_stream_decode(exon_hip_gzip_stream* s, void* stream, const uin
     std::vector<std::pair<uint64_t, const GzMember*>> ends;  // (absolute output offset of a member end, its trailer)
     if (s->verify_crc) {
       if (total_members) {
-        HIP_TRY(ctx, hipMemcpyAsync(s->h_members, s->d_members, ((size_t)n_chunks + SPARE_REGIONS) * MAX_MEMBER_ENDS * sizeof(GzMember), hipMemcpyDeviceToHost, hs));
+        HIP_TRY(ctx, hipMemcpyAsync(s->h_members, s->d_members, (size_t)n_records * MAX_MEMBER_ENDS * sizeof(GzMember), hipMemcpyDeviceToHost, hs));
         HIP_TRY(ctx, hipStreamSynchronize(hs));
         for (size_t a = 0; a < n_acc; ++a) {
           const GzChunk& r = s->h_res[chain[a]];

@@ -218,3 +218,18 @@ def test_fuzz_3000_streams(ctx, small_chunks):
             got = ctx.gzip_inflate(raw, out_cap=2 << 20)
         assert got == data, (it, k, n, level, strategy, mem, wbits, slab)
     assert n_multi > 300
+
+
+@pytest.mark.parametrize("flush", [zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH])
+def test_pigz_style_streams_with_empty_stored_blocks(ctx, small_chunks, flush):
+    """pigz (and anything that uses Z_SYNC_FLUSH) ends every 128 KiB of input with an EMPTY STORED block; back-references go on
+    across it.  The chunk search only looks for dynamic headers, so the chunk behind such a marker begins a few bytes late: the
+    gaps are decoded all at once (one launch) and spliced in front of their chunks -- same bytes as zlib, one call."""
+    data = vcf_like(60000, seed=17) + fastq_like(3000, seed=18)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    raw = b"".join(co.compress(data[i:i + 8192]) + co.flush(flush) for i in range(0, len(data), 8192)) + co.flush()
+    assert gzip.decompress(raw) == data
+    got, st = ctx.gzip_inflate(raw, return_stats=True)
+    assert got == data and st["calls"] == 1 and st["repairs"] > 20
+    got, st = ctx.gzip_inflate(raw, slab_bytes=64 << 10, out_cap=4 << 20, return_stats=True)
+    assert got == data and st["calls"] > 3
