@@ -82,18 +82,19 @@ static void ensure_tail_scratch(exon_hip_ctx* ctx, hipStream_t s, size_t records
   std::lock_guard<std::mutex> g(ctx->mu);
   Workspace& ws = ctx->workspaces[s];
   if (ws.tail_capacity < records) {
-    if (ws.tail_rec_a || ws.tail_rec_b) {
+    if (ws.tail_rec_a) {
       hipStreamSynchronize(s);
-      if (ws.tail_rec_a) hipFree(ws.tail_rec_a);
-      if (ws.tail_rec_b) hipFree(ws.tail_rec_b);
+      hipFree(ws.tail_rec_a);
       ws.tail_rec_a = ws.tail_rec_b = nullptr;
       ws.tail_capacity = 0;
     }
-    if (hipMalloc((void**)&ws.tail_rec_a, records * 8) != hipSuccess || hipMalloc((void**)&ws.tail_rec_b, records * 8) != hipSuccess) {
+    // ONE allocation, rec_b = its second half: the direct partition (kernels.hip, k4_one_launch) uses both halves as one
+    // pool of chunks
+    if (hipMalloc((void**)&ws.tail_rec_a, records * 16) != hipSuccess) {
       (void)hipGetLastError();
-      if (ws.tail_rec_a) hipFree(ws.tail_rec_a);
       ws.tail_rec_a = ws.tail_rec_b = nullptr;
     } else {
+      ws.tail_rec_b = ws.tail_rec_a + records;
       ws.tail_capacity = records;
     }
   }
@@ -208,7 +209,6 @@ int exon_hip_ctx_destroy(exon_hip_ctx* ctx) {
     if (kv.second.partials) hipFree(kv.second.partials);
     if (kv.second.status) hipFree(kv.second.status);
     if (kv.second.tail_rec_a) hipFree(kv.second.tail_rec_a);
-    if (kv.second.tail_rec_b) hipFree(kv.second.tail_rec_b);
     if (kv.second.tail_u32) hipFree(kv.second.tail_u32);
   }
   if (ctx->ev0) hipEventDestroy(ctx->ev0);

@@ -959,6 +959,26 @@ constexpr int K4_TAIL_RANGE = 8192;  // ids per range of the partitioned tier 3 
 __host__ __device__ static inline int k4_hist_copies_log2(int n_ranges) {
   return n_ranges <= 192 ? 4 : n_ranges <= 384 ? 3 : n_ranges <= 768 ? 2 : n_ranges <= 1536 ? 1 : 0;
 }
+// Direct partition (round 6): the main kernel writes a tier-3 record straight into a CHUNK of its id range -- no compaction,
+// no scatter pass.  A workgroup owns `cpw` chunks of K4_CHUNK records (its rows / K4_CHUNK + one per stream: what it can
+// fill + one partly filled chunk per stream); a STREAM = (id range, copy) has an LDS cursor word  chunk << 13 | position:
+// one returning LDS add per record hands out the slot, the lane that draws position K4_CHUNK opens the stream's next chunk
+// (an LDS counter: the chunks are the workgroup's own, no global atomic) and publishes the new cursor; lanes that drew a
+// position behind it wait for that.  Few ranges get 2-4 copies each (picked by lane) so that the 64 lanes of an add do not
+// queue on a dozen addresses.  Behind the tile loop the workgroup appends its chunks to the per-range chunk lists
+// (one global atomic per range and workgroup); k4_tail_aggregate_chunks walks the lists.
+constexpr int K4_CHUNK = 2048;        // records per chunk (16 KiB): two per thread of k4_tail_aggregate_chunks
+constexpr int K4_POS_BITS = 13;       // position field of a cursor: K4_CHUNK + 1024 lanes' failed draws < 8192
+constexpr unsigned K4_POS_MASK = (1u << K4_POS_BITS) - 1u;
+constexpr int K4_DIRECT_MAX_RANGES = 128;
+static inline int k4_stream_copies_log2(int n_ranges) {
+  static const int forced = [] {
+    const char* v = getenv("EXON_HIP_K4_STREAM_COPIES_LOG2");  // A/B
+    return v && v[0] >= '0' && v[0] <= '3' ? v[0] - '0' : -1;
+  }();
+  if (forced >= 0) return forced;
+  return n_ranges == 1 ? 2 : 0;  // measured (profiles/r6_groupby_direct.md): the main kernel slows down with the streams a wave store spreads over
+}
 struct K4Tail {                 // tier 3 (unused when NG == NL)
   unsigned long long* counts;   // the caller's [cnn[NG]] [crow[NG]]
   double* sums;                 // the caller's [sum[NG]]
@@ -970,6 +990,12 @@ struct K4Tail {                 // tier 3 (unused when NG == NL)
   unsigned* wg_count;           // [grid] records each workgroup wrote
   unsigned* wg_hist;            // [grid][n_ranges] records per workgroup and id range
   int no_uniform_test;          // EXON_HIP_K4_UNIFORM=0 (A/B): tier 2 never tests for a uniform key
+  // direct partition (lists != nullptr; rec = the chunk pool)
+  uint2* lists;                 // [n_ranges][list_stride] {chunk, records in it}
+  unsigned list_stride;
+  unsigned* n_list;             // [n_ranges] entries of each list   (zeroed before the launch)
+  unsigned* totals;             // [n_ranges] records of each range  (zeroed before the launch)
+  int copies_log2;              // streams per range
 };
 struct K4Entry {  // tier-2 table entry
   double sum;
@@ -1080,11 +1106,100 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
   const unsigned hcopy = (unsigned)lane & ((1u << hcl) - 1u);
   // rows a workgroup can meet in the tile loop = the size of its region (the host computes the same number)
   const unsigned cap_wg = (unsigned)(((n / TILE + gridDim.x - 1) / gridDim.x) * TILE);
-  if (OVF && tail.rec) {
+  // direct partition: LDS block behind the tier-2 table = [cursor[S]] [entries[R]] [records[R]] [base[R]] [stream of chunk: u16[cpw]]
+  // [list slot of chunk: u16[cpw]]
+  const bool direct = OVF && tail.rec && tail.lists;
+  const int ccl = tail.copies_log2, n_streams = n_ranges << ccl;
+  const unsigned ccopy = (unsigned)lane & ((1u << ccl) - 1u);
+  const unsigned cpw = cap_wg / K4_CHUNK + (unsigned)n_streams;  // chunks of this workgroup
+  unsigned* const d_cur = tail_hist;
+  unsigned* const d_ent = d_cur + n_streams + 64;  // (64 per-lane dummy cursors in between)
+  unsigned* const d_rec = d_ent + n_ranges;
+  unsigned* const d_base = d_rec + n_ranges;
+  unsigned short* const d_cstream = reinterpret_cast<unsigned short*>(d_base + n_ranges);
+  unsigned short* const d_cslot = d_cstream + cpw;
+  uint2* const d_pool = tail.rec + (size_t)blockIdx.x * cpw * K4_CHUNK;
+  if (direct) {
+    if (threadIdx.x == 0) tail_cursor = (unsigned)n_streams;  // the next chunk to open; stream s starts in chunk s
+    for (int i = threadIdx.x; i < n_streams; i += THREADS) {
+      d_cur[i] = (unsigned)i << K4_POS_BITS;
+      d_cstream[i] = (unsigned short)i;
+    }
+    for (int i = threadIdx.x; i < 2 * n_ranges; i += THREADS) d_ent[i] = 0;
+    __syncthreads();
+  } else if (OVF && tail.rec) {
     if (threadIdx.x == 0) tail_cursor = 0;
     for (int i = threadIdx.x; i < (n_ranges << hcl); i += THREADS) tail_hist[i] = 0;
     __syncthreads();
   }
+  // Called by all 64 lanes.  Fast path: the 4 draws of a lane go out back to back (a lane without a tier-3 row draws from
+  // its own dummy word: no branch around the LDS atomics), then the records are stored.  Slow path, once per K4_CHUNK
+  // records of a stream: the lane that drew position K4_CHUNK opens the stream's next chunk and publishes the new cursor;
+  // lanes that drew a position behind it draw again once they see it.  That loop is WAVE-UNIFORM (a vote) and its body
+  // straight-line predicated code: a lane never spins on its own -- the lane that opens the chunk may sit in this very
+  // wave, and a divergent spin loop would keep it from running.
+  auto rows4_tail_direct = [&](unsigned p0, unsigned p1, unsigned p2, unsigned p3, float4 y4, int4 g4, unsigned yv) {
+    const unsigned span = (unsigned)(NG - NL);
+    const unsigned pp[4] = {p0, p1, p2, p3};
+    const int32_t gg[4] = {g4.x, g4.y, g4.z, g4.w};
+    const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
+    unsigned pend = 0, so[4], v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned d = (unsigned)gg[k] - (unsigned)NL;
+      const bool t = pp[k] && d < span;
+      pend |= (unsigned)t << k;
+      so[k] = t ? ((d / K4_TAIL_RANGE) << ccl) + ccopy : (unsigned)n_streams + (unsigned)lane;
+    }
+    if (!__any(pend != 0)) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = atomicAdd(&d_cur[so[k]], 1u);
+    auto store = [&](int k, unsigned chunk, unsigned pos) {
+      const unsigned byte_off = ((chunk << 11) | pos) << 3;  // < cpw * 16 KiB: 32 bits
+      const v2u_t r = {(unsigned)gg[k] | ((yv >> k & 1u) << 31), (unsigned)__float_as_int(yy[k])};
+      *reinterpret_cast<v2u_t*>(reinterpret_cast<char*>(d_pool) + byte_off) = r;  // (the streaming hint changes nothing: 902 / 904 us)
+    };
+    auto open_next = [&](int k) {
+      const unsigned c2 = atomicAdd(&tail_cursor, 1u);
+      if (c2 < cpw) {  // cannot fail: cpw covers every row of the tile loop + a partly filled chunk per stream
+        d_cstream[c2] = (unsigned short)so[k];
+        store(k, c2, 0u);
+      }
+      __threadfence_block();
+      *reinterpret_cast<volatile unsigned*>(&d_cur[so[k]]) = (c2 << K4_POS_BITS) | 1u;
+    };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if ((pend >> k & 1u) && (v[k] & K4_POS_MASK) < (unsigned)K4_CHUNK) {
+        store(k, v[k] >> K4_POS_BITS, v[k] & K4_POS_MASK);
+        pend &= ~(1u << k);
+      }
+    }
+    if (!__any(pend != 0)) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if ((pend >> k & 1u) && (v[k] & K4_POS_MASK) == (unsigned)K4_CHUNK) {
+        open_next(k);
+        pend &= ~(1u << k);
+      }
+    }
+    while (__any(pend != 0)) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!(pend >> k & 1u)) continue;
+        if ((*reinterpret_cast<volatile unsigned*>(&d_cur[so[k]]) & K4_POS_MASK) >= (unsigned)K4_CHUNK) continue;  // not yet published
+        const unsigned w = atomicAdd(&d_cur[so[k]], 1u);
+        const unsigned pos = w & K4_POS_MASK;
+        if (pos < (unsigned)K4_CHUNK) {
+          store(k, w >> K4_POS_BITS, pos);
+          pend &= ~(1u << k);
+        } else if (pos == (unsigned)K4_CHUNK) {
+          open_next(k);
+          pend &= ~(1u << k);
+        }
+      }
+    }
+  };
   // (one reservation for the 4 rows of every lane: the returning LDS atomic and the readfirstlane behind it are a round trip
   //  the wave waits for)
   auto rows4_tail_append = [&](unsigned p0, unsigned p1, unsigned p2, unsigned p3, float4 y4, int4 g4, unsigned yv) {
@@ -1176,7 +1291,9 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
             row_lds(p3, ys[j].w, gs[j].w, ym[j] >> 3 & 1);
           }
           if (NG > NL && __any(gm >= (unsigned)NL)) {
-            if (tail.rec) {
+            if (direct) {
+              rows4_tail_direct(p0, p1, p2, p3, ys[j], gs[j], ym[j]);
+            } else if (tail.rec) {
               rows4_tail_append(p0, p1, p2, p3, ys[j], gs[j], ym[j]);
             } else {
               row_tail(p0, ys[j].x, gs[j].x, ym[j] >> 0 & 1);
@@ -1224,7 +1341,31 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
   spill();
 
   if (gmax >= (unsigned)(OVF ? NG : G)) atomicOr(status, 4);
-  if (OVF && tail.rec) {  // what this workgroup compacted: its record count, and its share of the per-range histogram
+  if (direct) {  // this workgroup's chunks -> the per-range chunk lists
+    __syncthreads();
+    const unsigned used = min(tail_cursor, cpw);
+    for (unsigned j = threadIdx.x; j < used; j += THREADS) {
+      const unsigned st = d_cstream[j], v = d_cur[st];
+      const unsigned cnt = (v >> K4_POS_BITS) == j ? min(v & K4_POS_MASK, (unsigned)K4_CHUNK) : (unsigned)K4_CHUNK;
+      if (cnt) {
+        d_cslot[j] = (unsigned short)atomicAdd(&d_ent[st >> ccl], 1u);
+        atomicAdd(&d_rec[st >> ccl], cnt);
+      }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < n_ranges; r += THREADS) {
+      if (d_ent[r]) {
+        d_base[r] = atomicAdd(&tail.n_list[r], d_ent[r]);
+        atomicAdd(&tail.totals[r], d_rec[r]);
+      }
+    }
+    __syncthreads();
+    for (unsigned j = threadIdx.x; j < used; j += THREADS) {
+      const unsigned st = d_cstream[j], v = d_cur[st], r = st >> ccl;
+      const unsigned cnt = (v >> K4_POS_BITS) == j ? min(v & K4_POS_MASK, (unsigned)K4_CHUNK) : (unsigned)K4_CHUNK;
+      if (cnt) tail.lists[(size_t)r * tail.list_stride + d_base[r] + d_cslot[j]] = uint2{blockIdx.x * cpw + j, cnt};
+    }
+  } else if (OVF && tail.rec) {  // what this workgroup compacted: its record count, and its share of the per-range histogram
     __syncthreads();
     if (threadIdx.x == 0) tail.wg_count[blockIdx.x] = min(tail_cursor, cap_wg);
     for (int i = threadIdx.x; i < n_ranges; i += THREADS) {
@@ -1289,7 +1430,13 @@ static hipError_t k4_launch(hipStream_t s, const LaunchCfg& cfg, int* grid_out, 
                             const FoldArgs& fa, const K4Tail& tail) {
   const int nl = k4_nl(n_groups);
   const size_t n_ranges = (OVF && tail.rec) ? (size_t)(n_groups - nl + K4_TAIL_RANGE - 1) / K4_TAIL_RANGE : 0;
-  const size_t lds = OVF ? (size_t)(nl - G + 64) * sizeof(K4Entry) + (n_ranges << k4_hist_copies_log2((int)n_ranges)) * sizeof(unsigned) : 0;
+  size_t lds = OVF ? (size_t)(nl - G + 64) * sizeof(K4Entry) + (n_ranges << k4_hist_copies_log2((int)n_ranges)) * sizeof(unsigned) : 0;
+  if (OVF && tail.rec && tail.lists) {  // the direct partition's block instead of the histogram (an upper bound: the grid is not known yet)
+    const int64_t tiles = n / ShapeOf<S>::TILE, g_min = std::max<int64_t>(1, std::min<int64_t>(tiles, cfg.compute_units));
+    const size_t n_streams = n_ranges << k4_stream_copies_log2((int)n_ranges);
+    const size_t cpw_ub = (size_t)((tiles + g_min - 1) / g_min) * ShapeOf<S>::TILE / K4_CHUNK + n_streams;
+    lds = (size_t)(nl - G + 64) * sizeof(K4Entry) + (n_streams + 64 + 3 * n_ranges) * sizeof(unsigned) + 4 * cpw_ub + 8;
+  }
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k4_cmp_avg_by_group_main<G, S, OVF, YI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1609,6 +1756,64 @@ __global__ __launch_bounds__(1024) void k4_tail_aggregate(const uint2* __restric
   }
 }
 
+// The direct partition's aggregate: the same table, fed from the chunk list of the workgroup's range (slices of a range
+// take the list's entries in turns, 4 chunks = 8 records per thread in flight).
+__global__ __launch_bounds__(1024) void k4_tail_aggregate_chunks(const uint2* __restrict__ pool, const uint2* __restrict__ lists, unsigned list_stride,
+                                                                 const unsigned* __restrict__ n_list, const unsigned* __restrict__ slice_start,
+                                                                 int n_ranges, int NL, int NG, int yint, unsigned long long* __restrict__ counts,
+                                                                 double* __restrict__ sums) {
+  static_assert(K4_CHUNK == 2048, "two records per thread and chunk");
+  __shared__ K4Entry tab[K4_TAIL_RANGE];
+  if (blockIdx.x >= slice_start[n_ranges]) return;
+  int rlo = 0, rhi = n_ranges - 1;
+  while (rlo < rhi) {
+    const int mid = (rlo + rhi + 1) >> 1;
+    if (slice_start[mid] <= blockIdx.x) rlo = mid;
+    else rhi = mid - 1;
+  }
+  const int range = rlo;
+  const unsigned n_slices = slice_start[range + 1] - slice_start[range], slice = blockIdx.x - slice_start[range];
+  const unsigned nl = n_list[range];
+  constexpr unsigned Q = 4;
+  if (slice * Q >= nl) return;
+  for (int i = threadIdx.x; i < K4_TAIL_RANGE; i += 1024) {
+    tab[i].sum = 0.0;
+    tab[i].cnn = 0;
+    tab[i].crow = 0;
+  }
+  __syncthreads();
+  const unsigned id0 = (unsigned)NL + (unsigned)range * (unsigned)K4_TAIL_RANGE;
+  const uint2* L = lists + (size_t)range * list_stride;
+  for (unsigned k0 = slice * Q; k0 < nl; k0 += n_slices * Q) {
+    uint2 v[2 * Q];
+#pragma unroll
+    for (unsigned q = 0; q < Q; ++q) {
+      const uint2 e = k0 + q < nl ? L[k0 + q] : uint2{0, 0};
+      const uint2* src = pool + (size_t)e.x * K4_CHUNK;
+      v[2 * q] = threadIdx.x < e.y ? ldnt8(src + threadIdx.x) : uint2{0xFFFFFFFFu, 0};
+      v[2 * q + 1] = threadIdx.x + 1024u < e.y ? ldnt8(src + threadIdx.x + 1024u) : uint2{0xFFFFFFFFu, 0};
+    }
+#pragma unroll
+    for (unsigned k = 0; k < 2 * Q; ++k) {
+      if (v[k].x == 0xFFFFFFFFu) continue;  // (an id is < 2^24)
+      K4Entry* e = &tab[(v[k].x & 0x7FFFFFFFu) - id0];
+      const unsigned yv = v[k].x >> 31;
+      atomicAdd(reinterpret_cast<unsigned long long*>(&e->cnn), (1ull << 32) | yv);
+      atomicAdd(&e->sum, yv ? (yint ? (double)(int32_t)v[k].y : (double)__uint_as_float(v[k].y)) : 0.0);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < K4_TAIL_RANGE; i += 1024) {
+    const unsigned g = id0 + (unsigned)i;
+    if (g >= (unsigned)NG || tab[i].crow == 0) continue;
+    atomicAdd(&counts[NG + g], (unsigned long long)tab[i].crow);
+    if (tab[i].cnn) {
+      atomicAdd(&counts[g], (unsigned long long)tab[i].cnn);
+      atomicAdd(&sums[g], tab[i].sum);
+    }
+  }
+}
+
 // rows per launch of the partitioned tier 3: its scratch is 2 x 8 bytes per row of a launch, so a longer table is cut
 // into launches of this many rows (a multiple of every tile size and of 8: column and bitmap pointers stay aligned)
 constexpr int64_t K4_TAIL_CHUNK_ROWS = int64_t(1) << 28;
@@ -1641,12 +1846,27 @@ static hipError_t k4_one_launch(hipStream_t s, const LaunchCfg& cfg, const Works
     const char* v = getenv("EXON_HIP_K4_UNIFORM");
     return v && v[0] == '0' ? 1 : 0;
   }();
-  K4Tail tail{reinterpret_cast<unsigned long long*>(d_counts), d_sums, nullptr, nullptr, nullptr, no_uni};
+  K4Tail tail{reinterpret_cast<unsigned long long*>(d_counts), d_sums, nullptr, nullptr, nullptr, no_uni, nullptr, 0, nullptr, nullptr, 0};
   const int n_ranges = has_tail ? (n_groups - nl + K4_TAIL_RANGE - 1) / K4_TAIL_RANGE : 0;
   // partitioned tier 3 when its scratch is there (capi.cpp sizes it with k4_tail_records) and the launch has whole tiles
   const bool partition = has_tail && !k4_tail_atomics_forced() && ws.tail_rec_a && ws.tail_rec_b && ws.tail_u32 &&
                          ws.tail_capacity >= (size_t)(n + K4_TAIL_SLACK) && n_ranges <= K4_TAIL_MAX_RANGES &&
                          max_grid(cfg) <= K4_TAIL_MAX_GRID;
+  // the direct partition (round 6) when the chunk pool + the chunk lists fit the two record buffers (one allocation)
+  static const bool scatter_forced = [] {
+    const char* v = getenv("EXON_HIP_K4_TAIL_SCATTER");  // A/B: round 3's compact -> scatter -> aggregate
+    return v && v[0] == '1';
+  }();
+  const int64_t tile_rows = big ? ShapeOf<ShapeBigJ2>::TILE : ShapeOf<ShapeSmall>::TILE;
+  const size_t n_streams = (size_t)n_ranges << k4_stream_copies_log2(n_ranges);
+  // chunks of all workgroups, at most: their rows (rounded up to tiles per workgroup) + one per stream and workgroup
+  const int64_t grid_ub = big ? cfg.compute_units : std::min<int64_t>(max_grid(cfg), n / tile_rows + 1);  // grid_for's bounds
+  const size_t pool_chunks = (size_t)(n + grid_ub * tile_rows) / K4_CHUNK + (size_t)grid_ub * n_streams;
+  const int64_t tiles_all = n / tile_rows, grid_min = std::max<int64_t>(1, std::min<int64_t>(tiles_all, cfg.compute_units));
+  const size_t cpw_max = (size_t)((tiles_all + grid_min - 1) / grid_min) * tile_rows / K4_CHUNK + n_streams;
+  const bool direct = partition && !scatter_forced && n_ranges <= K4_DIRECT_MAX_RANGES && ws.tail_rec_b == ws.tail_rec_a + ws.tail_capacity &&
+                      pool_chunks * K4_CHUNK + (size_t)n_ranges * pool_chunks <= 2 * ws.tail_capacity &&
+                      cpw_max < 65536;  // chunk numbers inside a workgroup are 16-bit
   unsigned *wg_count = nullptr, *totals = nullptr, *offsets = nullptr, *slice_start = nullptr, *wg_hist = nullptr;
   if (partition) {  // every word the kernels below read is written by the launch before it: nothing to clear
     wg_count = ws.tail_u32;                       // [K4_TAIL_MAX_GRID]
@@ -1657,6 +1877,15 @@ static hipError_t k4_one_launch(hipStream_t s, const LaunchCfg& cfg, const Works
     tail.rec = ws.tail_rec_a;
     tail.wg_count = wg_count;
     tail.wg_hist = wg_hist;
+    if (direct) {
+      tail.lists = ws.tail_rec_a + pool_chunks * K4_CHUNK;
+      tail.list_stride = (unsigned)pool_chunks;
+      tail.n_list = wg_count;
+      tail.totals = totals;
+      tail.copies_log2 = k4_stream_copies_log2(n_ranges);
+      hipError_t ez = hipMemsetAsync(wg_count, 0, (size_t)(K4_TAIL_MAX_GRID + K4_TAIL_MAX_RANGES) * 4, s);  // list lengths + range totals
+      if (ez != hipSuccess) return ez;
+    }
   }
   // (Round 4 also built the partition INSIDE the main kernel -- records grouped by id range per tile, no scatter pass -- bit-identical
   // and not faster: 5.84 -> 5.82 ms per 1e9 rows at 1e5 uniform keys, 3.84 -> 5.19 ms at zipf keys; the barrier per 8192-row tile
@@ -1687,7 +1916,17 @@ static hipError_t k4_one_launch(hipStream_t s, const LaunchCfg& cfg, const Works
   if (has_tail) {
     hipLaunchKernelGGL(k4_finalize_head, dim3((3 * nl + 31) / 32), dim3(1024), 0, s, ws.partials, grid, nl, n_groups,
                        reinterpret_cast<unsigned long long*>(d_counts), d_sums);
-    if (partition) {
+    static const int rounds_d = [] {
+      const char* v = getenv("EXON_HIP_K4_TAIL_ROUNDS");
+      const int k = v ? atoi(v) : 0;
+      return k >= 1 && k <= 16 ? k : 1;
+    }();
+    if (direct) {
+      const int target = std::max(1, rounds_d * cfg.compute_units - n_ranges);
+      hipLaunchKernelGGL(k4_tail_offsets, dim3(1), dim3(1024), 0, s, totals, n_ranges, offsets, target, slice_start);
+      hipLaunchKernelGGL(k4_tail_aggregate_chunks, dim3(target + n_ranges), dim3(1024), 0, s, ws.tail_rec_a, tail.lists, tail.list_stride, tail.n_list,
+                         slice_start, n_ranges, nl, n_groups, yint, reinterpret_cast<unsigned long long*>(d_counts), d_sums);
+    } else if (partition) {
       const int64_t tile = big ? ShapeOf<ShapeBigJ2>::TILE : ShapeOf<ShapeSmall>::TILE;
       const unsigned cap_wg = (unsigned)(((n / tile + grid - 1) / grid) * tile);  // the main kernel's formula
       hipLaunchKernelGGL(k4_tail_wg_scan, dim3(n_ranges), dim3(1024), 0, s, wg_hist, grid, n_ranges, totals);

@@ -1807,7 +1807,6 @@ int exon_hip_stream_close(exon_hip_stream* st) {
       if (it->second.partials) hipFree(it->second.partials);
       if (it->second.status) hipFree(it->second.status);
       if (it->second.tail_rec_a) hipFree(it->second.tail_rec_a);
-      if (it->second.tail_rec_b) hipFree(it->second.tail_rec_b);
       if (it->second.tail_u32) hipFree(it->second.tail_u32);
       st->ctx->workspaces.erase(it);
     }

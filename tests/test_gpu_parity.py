@@ -686,3 +686,29 @@ def test_k4_tier3_big_launches_with_many_id_ranges(ctx, G, dist):
     st = state.to_host()
     assert np.array_equal(st[:G], 2 * cn) and np.array_equal(st[G:2 * G], 2 * cr)
     assert np.allclose(st[2 * G:].view(np.float64), 2 * s, rtol=RTOL, atol=0)
+
+
+@pytest.mark.parametrize("G,n", [(4100 + 8192, 40_000_000 + 77), (30_000, 40_000_000), (100_000, 64_000_000 + 5)])
+def test_k4_direct_partition_fills_many_chunks_per_stream(ctx, G, n):
+    """Tier 3's direct partition (round 6): enough tier-3 records per workgroup and stream that every stream walks through
+    several 2048-record chunks (the 6 M-row cases above stay inside their first chunk): counts bit-exact vs numpy, sums within
+    the budget, and the same again through round 3's compact -> scatter path of the library is covered by the A/B switch
+    (EXON_HIP_K4_TAIL_SCATTER=1) in tools/groupby_ab.sh."""
+    rng = np.random.default_rng(G)
+    af = rng.random(n, dtype=np.float32)
+    q = (rng.random(n, dtype=np.float32) * 100).astype(np.float32)
+    fid = rng.integers(0, G, n).astype(np.int32)
+    qvb = rng.random(n) < 0.9
+    qv = np.packbits(qvb, bitorder="little")
+    keep = af.astype(np.float64) > 0.5
+    cr = np.bincount(fid[keep], minlength=G)
+    cn = np.bincount(fid[keep & qvb], minlength=G)
+    s_ = np.bincount(fid[keep & qvb], weights=q[keep & qvb].astype(np.float64), minlength=G)
+    d = [ctx.to_device(x) for x in (af, q, qv, fid)]
+    plan = ctx.plan_cmp_avg_by_group(">", 0.5, G)
+    state = ctx.to_device(np.zeros(3 * G, np.int64))
+    plan.launch([(d[0], None, None), (d[1], d[2], None), (d[3], None, None)], n, state, overwrite=True)
+    ctx.sync()
+    st = state.to_host()
+    assert np.array_equal(st[:G], cn) and np.array_equal(st[G:2 * G], cr)
+    assert np.allclose(st[2 * G:].view(np.float64), s_, rtol=RTOL, atol=0)
