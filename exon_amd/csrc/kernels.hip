@@ -1266,13 +1266,18 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
     for (int j = 0; j < J; ++j) {
       const unsigned p0 = passes(xs[j].x, xm[j] >> 0 & 1), p1 = passes(xs[j].y, xm[j] >> 1 & 1),
                      p2 = passes(xs[j].z, xm[j] >> 2 & 1), p3 = passes(xs[j].w, xm[j] >> 3 & 1);
-      row(p0, ys[j].x, gs[j].x, ym[j] >> 0 & 1);
-      row(p1, ys[j].y, gs[j].y, ym[j] >> 1 & 1);
-      row(p2, ys[j].z, gs[j].z, ym[j] >> 2 & 1);
-      row(p3, ys[j].w, gs[j].w, ym[j] >> 3 & 1);
+      // (high-cardinality keys: a wave whose 256 rows hold no register group skips tier 1 -- 4 conditional f64 adds per row)
+      const unsigned gn = OVF ? min(min((unsigned)gs[j].x, (unsigned)gs[j].y), min((unsigned)gs[j].z, (unsigned)gs[j].w)) : 0u;
+      if (!OVF || NG <= NL || __any(gn < (unsigned)G)) {
+        row(p0, ys[j].x, gs[j].x, ym[j] >> 0 & 1);
+        row(p1, ys[j].y, gs[j].y, ym[j] >> 1 & 1);
+        row(p2, ys[j].z, gs[j].z, ym[j] >> 2 & 1);
+        row(p3, ys[j].w, gs[j].w, ym[j] >> 3 & 1);
+      }
       if (OVF) {
         // largest id among this lane's 4 rows (unsigned: a negative id is "huge" and is reported through gmax)
         const unsigned gm = max(max((unsigned)gs[j].x, (unsigned)gs[j].y), max((unsigned)gs[j].z, (unsigned)gs[j].w));
+        gmax = max(gmax, gm);
         if (__any(gm >= (unsigned)G)) {
           bool uni = false;
           const int kw = __builtin_amdgcn_readfirstlane(gs[j].x);
@@ -1757,13 +1762,15 @@ __global__ __launch_bounds__(1024) void k4_tail_aggregate(const uint2* __restric
 }
 
 // The direct partition's aggregate: the same table, fed from the chunk list of the workgroup's range (slices of a range
-// take the list's entries in turns, 4 chunks = 8 records per thread in flight).
+// take the list's entries in turns, 8 chunks = 16 records per thread in flight).
 __global__ __launch_bounds__(1024) void k4_tail_aggregate_chunks(const uint2* __restrict__ pool, const uint2* __restrict__ lists, unsigned list_stride,
                                                                  const unsigned* __restrict__ n_list, const unsigned* __restrict__ slice_start,
                                                                  int n_ranges, int NL, int NG, int yint, unsigned long long* __restrict__ counts,
                                                                  double* __restrict__ sums) {
   static_assert(K4_CHUNK == 2048, "two records per thread and chunk");
-  __shared__ K4Entry tab[K4_TAIL_RANGE];
+  // sums and counts in separate arrays: a wave instruction's 64 adds then spread over all LDS banks (16-byte entries: over half)
+  __shared__ double tab_sum[K4_TAIL_RANGE];
+  __shared__ unsigned long long tab_cnt[K4_TAIL_RANGE];  // count(*) << 32 | count(y): a slice holds < 2^28 records
   if (blockIdx.x >= slice_start[n_ranges]) return;
   int rlo = 0, rhi = n_ranges - 1;
   while (rlo < rhi) {
@@ -1774,42 +1781,44 @@ __global__ __launch_bounds__(1024) void k4_tail_aggregate_chunks(const uint2* __
   const int range = rlo;
   const unsigned n_slices = slice_start[range + 1] - slice_start[range], slice = blockIdx.x - slice_start[range];
   const unsigned nl = n_list[range];
-  constexpr unsigned Q = 4;
+  constexpr unsigned Q = 8;  // chunks per trip: one 16-byte load (2 records) per thread and chunk, 128 B in flight per thread
   if (slice * Q >= nl) return;
   for (int i = threadIdx.x; i < K4_TAIL_RANGE; i += 1024) {
-    tab[i].sum = 0.0;
-    tab[i].cnn = 0;
-    tab[i].crow = 0;
+    tab_sum[i] = 0.0;
+    tab_cnt[i] = 0;
   }
   __syncthreads();
   const unsigned id0 = (unsigned)NL + (unsigned)range * (unsigned)K4_TAIL_RANGE;
   const uint2* L = lists + (size_t)range * list_stride;
+  auto add = [&](unsigned key, unsigned ybits) {
+    const unsigned i = (key & 0x7FFFFFFFu) - id0, yv = key >> 31;
+    atomicAdd(&tab_cnt[i], (1ull << 32) | yv);
+    atomicAdd(&tab_sum[i], yv ? (yint ? (double)(int32_t)ybits : (double)__uint_as_float(ybits)) : 0.0);
+  };
   for (unsigned k0 = slice * Q; k0 < nl; k0 += n_slices * Q) {
-    uint2 v[2 * Q];
+    uint4 v[Q];
+    unsigned cnt[Q];
 #pragma unroll
     for (unsigned q = 0; q < Q; ++q) {
       const uint2 e = k0 + q < nl ? L[k0 + q] : uint2{0, 0};
-      const uint2* src = pool + (size_t)e.x * K4_CHUNK;
-      v[2 * q] = threadIdx.x < e.y ? ldnt8(src + threadIdx.x) : uint2{0xFFFFFFFFu, 0};
-      v[2 * q + 1] = threadIdx.x + 1024u < e.y ? ldnt8(src + threadIdx.x + 1024u) : uint2{0xFFFFFFFFu, 0};
+      cnt[q] = e.y;
+      v[q] = 2u * threadIdx.x < e.y ? ld16<uint4>(pool + (size_t)e.x * K4_CHUNK + 2u * threadIdx.x) : uint4{0, 0, 0, 0};
     }
 #pragma unroll
-    for (unsigned k = 0; k < 2 * Q; ++k) {
-      if (v[k].x == 0xFFFFFFFFu) continue;  // (an id is < 2^24)
-      K4Entry* e = &tab[(v[k].x & 0x7FFFFFFFu) - id0];
-      const unsigned yv = v[k].x >> 31;
-      atomicAdd(reinterpret_cast<unsigned long long*>(&e->cnn), (1ull << 32) | yv);
-      atomicAdd(&e->sum, yv ? (yint ? (double)(int32_t)v[k].y : (double)__uint_as_float(v[k].y)) : 0.0);
+    for (unsigned q = 0; q < Q; ++q) {
+      if (2u * threadIdx.x < cnt[q]) add(v[q].x, v[q].y);
+      if (2u * threadIdx.x + 1u < cnt[q]) add(v[q].z, v[q].w);
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < K4_TAIL_RANGE; i += 1024) {
     const unsigned g = id0 + (unsigned)i;
-    if (g >= (unsigned)NG || tab[i].crow == 0) continue;
-    atomicAdd(&counts[NG + g], (unsigned long long)tab[i].crow);
-    if (tab[i].cnn) {
-      atomicAdd(&counts[g], (unsigned long long)tab[i].cnn);
-      atomicAdd(&sums[g], tab[i].sum);
+    const unsigned long long c = tab_cnt[i];
+    if (g >= (unsigned)NG || c == 0) continue;
+    atomicAdd(&counts[NG + g], c >> 32);
+    if (c & 0xFFFFFFFFull) {
+      atomicAdd(&counts[g], c & 0xFFFFFFFFull);
+      atomicAdd(&sums[g], tab_sum[i]);
     }
   }
 }

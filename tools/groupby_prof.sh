@@ -7,6 +7,6 @@ f=$(find $out/prof_${g}_${dist} -name "*kernel_stats.csv" | head -1)
 echo "## $g $dist $@"; python - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-for r in rows[:9]:
+for r in [r for r in rows if "exon::" in r["Name"] or "Memset" in r["Name"] or "fill" in r["Name"].lower()][:12]:
     print(f"{r['Name'][:70]:70s} calls {r['Calls']:>6s} avg_us {float(r['AverageNs'])/1e3:9.1f} total_ms {float(r['TotalDurationNs'])/1e6:9.2f}")
 PY
