@@ -27,6 +27,7 @@
 #include "parallel.h"
 #include "raw_batch.h"
 #include "region.h"
+#include "vcf_text.h"
 
 namespace exon {
 
@@ -84,6 +85,7 @@ struct VCFHeader {
   std::vector<std::string> contigs;                          // ##contig order = chrom dictionary order
   std::vector<std::string> filters;                          // ##FILTER ids
   std::vector<std::pair<std::string, std::string>> infos;    // (ID, "Number|Type")
+  std::vector<std::pair<std::string, std::string>> formats;  // ##FORMAT lines, same form
   std::vector<std::string> samples;
 };
 
@@ -190,9 +192,13 @@ inline std::vector<InfoSpec> resolve_info_specs(const std::string& fields, const
 class VCFArrayBuilder : public ExonArrayBuilder {
  public:
   // info_dicts: one dictionary per spec (used by the 's' kind only), owned by the caller like the other dictionaries
-  VCFArrayBuilder(Dictionary* chrom_dict, Dictionary* filter_dict, const std::vector<InfoSpec>& specs, std::vector<Dictionary>* info_dicts, uint64_t projection = 0)
+  // key_types: the header's INFO / FORMAT value types, needed by the `info` / `formats` text columns (projection bits 8 / 16)
+  VCFArrayBuilder(Dictionary* chrom_dict, Dictionary* filter_dict, const std::vector<InfoSpec>& specs, std::vector<Dictionary>* info_dicts, uint64_t projection = 0,
+                  const VcfKeyTypes* key_types = nullptr)
       : chrom_dict_(chrom_dict), filter_dict_(filter_dict), specs_(specs), info_dicts_(info_dicts), info_f_(specs.size()),
-        info_i_(specs.size()), info_lf_(specs.size()), info_li_(specs.size()), projection_(projection) {}
+        info_i_(specs.size()), info_lf_(specs.size()), info_li_(specs.size()), projection_(projection), key_types_(key_types) {
+    if ((projection_ & 24) && !key_types_) throw std::runtime_error("the info / formats text columns need the header's key types");
+  }
 
   // one data line (no terminator).  Field rules: lazy_array_builder.rs:159-216.
   void append(const std::string& line) { append(line.data(), line.size()); }
@@ -208,6 +214,7 @@ class VCFArrayBuilder : public ExonArrayBuilder {
         ++nf;
         start = i + 1;
       }
+    const size_t samples_at = start;  // behind FORMAT's TAB (> len: the record has no samples)
     if (nf < 8) throw std::runtime_error("VCF record has fewer than 8 fields");
     chrom_.append_value(chrom_dict_->lookup_or_insert(f[0], fl[0]));
     // POS: "0" (telomere) has no variant_start -> NULL; anything that is not a number is the reference's parse error
@@ -243,6 +250,18 @@ class VCFArrayBuilder : public ExonArrayBuilder {
       if (fl[4] == 0 || (fl[4] == 1 && f[4][0] == '.')) alt_.append_null();
       else alt_.close_row();
     }
+    // info / formats as text: the parsed entries printed again, not the fields' bytes (host/vcf_text.h; lazy_array_builder.rs:216-297, :310-423)
+    auto pf = [](const char* p, size_t n) { return parse_f32(p, n); };
+    if (projection_ & 8) {
+      vcf_info_string(f[7], fl[7], *key_types_, pf, &text_);
+      info_text_.append_value(text_.data(), text_.size());
+    }
+    if (projection_ & 16) {
+      const bool has = nf >= 9;
+      vcf_formats_string(has ? f[8] : nullptr, has ? fl[8] : 0, has && samples_at <= len ? line + samples_at : nullptr,
+                         has && samples_at <= len ? len - samples_at : 0, *key_types_, pf, &text_);
+      formats_text_.append_value(text_.data(), text_.size());
+    }
     ++rows_;
   }
 
@@ -273,6 +292,8 @@ class VCFArrayBuilder : public ExonArrayBuilder {
     if (projection_ & 1) out.push_back(id_.finish());
     if (projection_ & 2) out.push_back(ref_.finish());
     if (projection_ & 4) out.push_back(alt_.finish());
+    if (projection_ & 8) out.push_back(info_text_.finish());
+    if (projection_ & 16) out.push_back(formats_text_.finish());
     rows_ = 0;
     return out;
   }
@@ -476,8 +497,10 @@ class VCFArrayBuilder : public ExonArrayBuilder {
   std::vector<ListBuilder<float>> info_lf_;    // 'F'
   std::vector<ListBuilder<int32_t>> info_li_;  // 'I' values, 'S' dictionary ids
   uint64_t projection_ = 0;
+  const VcfKeyTypes* key_types_ = nullptr;
   ListUtf8Builder id_, alt_;
-  Utf8Builder ref_;
+  Utf8Builder ref_, info_text_, formats_text_;
+  std::string text_;
   size_t rows_ = 0;
 };
 
@@ -539,6 +562,8 @@ class VCFBatchReader {
         else if (line.rfind("##FILTER=", 0) == 0) header.filters.push_back(header_attr(line, "ID"));
         else if (line.rfind("##INFO=", 0) == 0)
           header.infos.emplace_back(header_attr(line, "ID"), header_attr(line, "Number") + "|" + header_attr(line, "Type"));
+        else if (line.rfind("##FORMAT=", 0) == 0)
+          header.formats.emplace_back(header_attr(line, "ID"), header_attr(line, "Number") + "|" + header_attr(line, "Type"));
         continue;
       }
       if (!line.empty() && line[0] == '#') {
@@ -556,6 +581,8 @@ class VCFBatchReader {
       break;
     }
     for (const auto& c2 : header.contigs) chrom_dict.names.push_back(c2);
+    for (const auto& kv : header.infos) key_types.info.emplace(kv.first, VcfKeyTypes::type_char(kv.second.substr(kv.second.find('|') + 1)));  // (the first line of an ID wins)
+    for (const auto& kv : header.formats) key_types.format.emplace(kv.first, VcfKeyTypes::type_char(kv.second.substr(kv.second.find('|') + 1)));
     info_specs = resolve_info_specs(cfg_.info_field, header.infos);  // INFO typing: schema_builder.rs:197-249
     info_dicts.assign(info_specs.size(), Dictionary());
     bool string_info = false;
@@ -596,7 +623,7 @@ class VCFBatchReader {
   bool read_batch(struct ArrowArray* out) {
     if (pipe_) return read_batch_parallel(out);
     if (cfg_.reference_tail_quirk && n_chunks >= 0 && cfg_.filter.active) return read_batch_reference_quirk(out);
-    VCFArrayBuilder b(&chrom_dict, &filter_dict, info_specs, &info_dicts, cfg_.projection);
+    VCFArrayBuilder b(&chrom_dict, &filter_dict, info_specs, &info_dicts, cfg_.projection, &key_types);
     std::string line;
     while ((int64_t)b.len() < cfg_.batch_size) {
       if (has_pending_) {
@@ -619,7 +646,7 @@ class VCFBatchReader {
   // until batch_size of them passed `filter` or the chunk ends; the second loop then reads up to batch_size MORE records and
   // appends them WITHOUT the test (it reads nothing when the first loop stopped at the chunk's end).  Opt-in only.
   bool read_batch_reference_quirk(struct ArrowArray* out) {
-    VCFArrayBuilder b(&chrom_dict, &filter_dict, info_specs, &info_dicts, cfg_.projection);
+    VCFArrayBuilder b(&chrom_dict, &filter_dict, info_specs, &info_dicts, cfg_.projection, &key_types);
     std::string line;
     for (;;) {  // skip chunks that yield nothing (the reference's stream of such a chunk ends without a batch)
       if (!r_->next_record()) return false;
@@ -712,10 +739,13 @@ class VCFBatchReader {
     if (cfg_.projection & 1) kids.push_back(new_list_field("u", "id"));
     if (cfg_.projection & 2) kids.push_back(new_field("u", "ref", false));
     if (cfg_.projection & 4) kids.push_back(new_list_field("u", "alt"));
+    if (cfg_.projection & 8) kids.push_back(new_field("u", "info", true));      // schema_builder.rs:119-121: both nullable Utf8
+    if (cfg_.projection & 16) kids.push_back(new_field("u", "formats", true));  // (the builder never appends a NULL)
     make_schema(out, "+s", "", false, kids);
   }
 
   VCFHeader header;
+  VcfKeyTypes key_types;  // value types of the header's INFO / FORMAT keys
   Dictionary chrom_dict, filter_dict;
   std::vector<InfoSpec> info_specs;    // the typed INFO fields of this scan (scan columns 4 ..)
   std::vector<Dictionary> info_dicts;  // dictionaries of the 's' kind (same index as info_specs)

@@ -208,10 +208,13 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         cfg.info_field = o->info_field ? o->info_field : "";
         cfg.filter = rf;
         cfg.projection = o->projection;
-        if (o->projection & ~7ull) return fail(nullptr, EXON_HIP_EINVAL, "projection 0x%llx: VCF knows EXON_HIP_PROJECT_VCF_ID / _REF / _ALT", (unsigned long long)o->projection);
+        if (o->projection & ~31ull) return fail(nullptr, EXON_HIP_EINVAL, "projection 0x%llx: VCF knows EXON_HIP_PROJECT_VCF_ID / _REF / _ALT / _INFO / _FORMATS", (unsigned long long)o->projection);
         // a pushed-down region filter rides along as a row mask (k_region_mask); with use_index the host plans the
         // tabix chunks and only their BGZF blocks are shipped (indexed scans are BGZF by definition)
         s->gpu_parse = o->gpu_parse != 0 && (!rf.use_index || (rf.active && wants_gpu_inflate(o, path)));
+        // info / formats as text are the reference's re-printed entries (host/vcf_text.h: number formatting per header type):
+        // the host reader builds them, so such a scan decodes there
+        if (o->projection & (EXON_HIP_PROJECT_VCF_INFO | EXON_HIP_PROJECT_VCF_FORMATS)) s->gpu_parse = false;
         // EXON_HIP_REFERENCE_QUIRKS=1: an indexed VCF scan reproduces the reference's unfiltered tail after a full batch of
         // hits (exon-vcf/src/indexed_async_batch_stream.rs:143-154) -- a property of its per-chunk record loop, so the host
         // reader runs it; default: every record is tested (what vcf_region_filter documents)

@@ -465,11 +465,17 @@ typedef struct exon_hip_scan_options {
                              VCF text: id List<Utf8>?, ref Utf8, alt List<Utf8>? (lazy_array_builder.rs:169-205; the alt list has no
                              items, as in the reference -- see text_columns.hip); BAM: name Utf8?, cigar Utf8, sequence Utf8,
                              quality_score List<Int64> (exon-bam/src/array_builder.rs:105-201).  Built by the host readers (one
-                             thread) and by the GPU pipeline (exon_hip_scan_bind_ctx); EXON_HIP_EUNSUPPORTED for other formats */
+                             thread) and by the GPU pipeline (exon_hip_scan_bind_ctx); EXON_HIP_EUNSUPPORTED for other formats.
+                             VCF text also: info Utf8, formats Utf8 -- the unparsed forms of the reference's default schema, which
+                             are the parsed entries PRINTED AGAIN, not the fields' bytes ("AF=0.50" -> "AF=0.5", a Flag ->
+                             "DB=true", formats = keys TAB samples; lazy_array_builder.rs:216-297, :310-423; host/vcf_text.h).
+                             These two are built by the host reader only: a gpu_parse scan that asks for them decodes on the host */
 } exon_hip_scan_options;
 #define EXON_HIP_PROJECT_VCF_ID 1ull
 #define EXON_HIP_PROJECT_VCF_REF 2ull
 #define EXON_HIP_PROJECT_VCF_ALT 4ull
+#define EXON_HIP_PROJECT_VCF_INFO 8ull
+#define EXON_HIP_PROJECT_VCF_FORMATS 16ull
 #define EXON_HIP_PROJECT_BAM_NAME 1ull
 #define EXON_HIP_PROJECT_BAM_CIGAR 2ull
 #define EXON_HIP_PROJECT_BAM_SEQUENCE 4ull

@@ -186,3 +186,109 @@ def test_gpu_bam_text_columns(ctx, tmp_path, monkeypatch):
     one = table(s)
     s.close()
     assert one["cigar"] == host["cigar"] and "name" not in one
+
+
+# ---- info / formats as the reference's unparsed Utf8 columns (parse_info / parse_formats = false, its default schema) --------
+def test_host_vcf_info_and_formats_text_golden_rows():
+    """slt/vcf-select-tests.slt:6-16: `SELECT info FROM vcf_table LIMIT 2` and `SELECT formats ... LIMIT 1` over index.vcf; every
+    row against oracle/decode.py's restatement of lazy_array_builder.rs:216-297 / :310-423."""
+    p = os.path.join(FX, "vcf", "index.vcf")
+    for path in (p, p + ".gz"):
+        s = exon_amd.Scan(path, "vcf", batch_size=64, project=("info", "formats"))
+        sch = s.schema()
+        assert [sch.field(i).name for i in range(sch.num_fields)][-2:] == ["info", "formats"]
+        c = table(s)
+        s.close()
+        assert c["info"][:2] == ["DP=1;I16=1,0,0,0,26,676,0,0,60,3600,0,0,0,0,0,0;QS=1,0;MQ0F=0",
+                                 "DP=1;I16=1,0,0,0,34,1156,0,0,60,3600,0,0,1,1,0,0;QS=1,0;MQ0F=0"]
+        if path == p:  # (the .gz fixture is another file: its first record has FORMAT "PL")
+            assert c["formats"][0] == "GT:PL:PG\t0/0:0,3,26:0"
+        v = decode.decode_vcf(path)
+        assert c["info"] == [decode.info_string(v, i) for i in range(len(v["chrom"]))]
+        assert c["formats"] == [decode.formats_string(v, i) for i in range(len(v["chrom"]))]
+        assert len(c["info"]) == 621
+
+
+TEXT_HEAD = ("##fileformat=VCFv4.2\n##contig=<ID=1>\n"
+             "##INFO=<ID=XF,Number=1,Type=Float,Description=\"f\">\n##INFO=<ID=XL,Number=.,Type=Float,Description=\"f\">\n"
+             "##INFO=<ID=XI,Number=1,Type=Integer,Description=\"i\">\n##INFO=<ID=XJ,Number=A,Type=Integer,Description=\"i\">\n"
+             "##INFO=<ID=XB,Number=0,Type=Flag,Description=\"b\">\n##INFO=<ID=XC,Number=1,Type=Character,Description=\"c\">\n"
+             "##INFO=<ID=XD,Number=.,Type=Character,Description=\"c\">\n##INFO=<ID=XS,Number=.,Type=String,Description=\"s\">\n"
+             "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"g\">\n##FORMAT=<ID=XQ,Number=1,Type=Float,Description=\"q\">\n"
+             "##FORMAT=<ID=XP,Number=G,Type=Integer,Description=\"p\">\n##FORMAT=<ID=XT,Number=1,Type=String,Description=\"t\">\n"
+             "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\tS2\n")
+
+
+def test_host_vcf_info_and_formats_text_are_printed_again_not_copied(tmp_path):
+    """What the reference's builder does to the values (Rust's Display of f32 / i32, Flag -> key=true, missing list items, the
+    reserved keys a header does not declare, genotypes through allele + phasing), spelled out and against the oracle."""
+    rows = [
+        ("XF=0.50;XL=1e-5,.,1.0,-0,123456790528,3.4028235e38;XI=007;XJ=+5,.,-3;XB;XC=q;XD=a,.,b;XS=a,b,.;AF=0.010;DB;ZZ=0.50",
+         "GT:XQ:XP:XT", ["0|1:0.250:0,03,26:x,y", "1/2:1e2:1,.,3:z"]),
+        (".", "GT", ["0/1/2", "0|1|2"]),
+        ("XF=16777217;XI=-2147483648", "GT:XQ", ["0|1/2:7", ".|1:0.1234567"]),
+        ("XF=nan;XL=inf,-inf", "XP", ["1", "2"]),
+        ("XS=only", ".", []),
+    ]
+    p = tmp_path / "text.vcf"
+    body = ""
+    for i, (info, fmt, samples) in enumerate(rows):
+        cols = ["1", str(10 + i), ".", "A", "C", ".", ".", info]
+        if fmt != ".":
+            cols += [fmt] + samples
+        body += "\t".join(cols) + "\n"
+    p.write_text(TEXT_HEAD + body)
+    c = table(exon_amd.Scan(str(p), "vcf", project=("info", "formats")))
+    assert c["info"][0] == ("XF=0.5;XL=0.00001,.,1,-0,123456790000,340282350000000000000000000000000000000;XI=7;XJ=5,.,-3;XB=true;XC=q;"
+                            "XD=a,b;XS=a,b,.;AF=0.01;DB=true;ZZ=0.50")
+    assert c["formats"][0] == "GT:XQ:XP:XT\t0|1:0.25:0,3,26:x,y\t1/2:100:1,.,3:z"
+    assert c["info"][1] == "" and c["formats"][1] == "GT\t0/1/2\t0|1|2"
+    assert c["info"][2] == "XF=16777216;XI=-2147483648" and c["formats"][2] == "GT:XQ\t0/1|2:7\t.|1:0.1234567"
+    assert c["info"][3] == "XF=NaN;XL=inf,-inf" and c["formats"][3] == "XP\t1\t2"
+    assert c["info"][4] == "XS=only" and c["formats"][4] == "\t"
+    v = decode.decode_vcf(str(p))
+    assert c["info"] == [decode.info_string(v, i) for i in range(len(rows))]
+    assert c["formats"] == [decode.formats_string(v, i) for i in range(len(rows))]
+
+
+@pytest.mark.parametrize("info,fmt,sample,project", [("XF=.", "GT", "0/1", "info"), ("XI", "GT", "0/1", "info"), ("XI=1x", "GT", "0/1", "info"),
+                                                      ("XI=1", "GT:XQ", "0/1:.", "formats"), ("XI=1", "GT", "0/x", "formats")])
+def test_host_vcf_text_columns_report_what_the_reference_cannot_print(tmp_path, info, fmt, sample, project):
+    """A missing value is `value_option.unwrap()` on None in the reference (lazy_array_builder.rs:223, :326: a panic), an
+    unparsable number its parse error: an error here, and in the oracle."""
+    p = tmp_path / "bad.vcf"
+    p.write_text(TEXT_HEAD + "\t".join(["1", "10", ".", "A", "C", ".", ".", info, fmt, sample, sample]) + "\n")
+    with pytest.raises(exon_amd.ExonHipError):
+        table(exon_amd.Scan(str(p), "vcf", project=(project,)))
+    v = decode.decode_vcf(str(p))
+    with pytest.raises(ValueError):
+        (decode.info_string if project == "info" else decode.formats_string)(v, 0)
+
+
+def test_rust_f32_display_of_the_host_reader_equals_numpy_dragon4_on_random_floats(tmp_path):
+    """Float items go text -> f32 -> Rust's `{}`: 20 000 random bit patterns (all exponents) printed by the host reader
+    (std::to_chars shortest digits, expanded) and by the oracle (numpy's Dragon4, unique digits, positional)."""
+    rng = np.random.default_rng(11)
+    bits = rng.integers(0, 2**32, 20_000, dtype=np.uint64).astype(np.uint32)
+    f = bits.view(np.float32)
+    f = f[np.isfinite(f)]
+    texts = [np.format_float_scientific(x, unique=True) for x in f]  # any spelling that parses back to x
+    p = tmp_path / "floats.vcf"
+    p.write_text(TEXT_HEAD + "".join(f"1\t{i + 1}\t.\tA\tC\t.\t.\tXF={t}\n" for i, t in enumerate(texts)))
+    c = table(exon_amd.Scan(str(p), "vcf", project=("info",)))
+    assert c["info"] == ["XF=" + decode.rust_f32_display(x) for x in f]
+
+
+@pytest.mark.gpu
+def test_gpu_scan_with_the_text_columns_decodes_on_the_host(ctx):
+    """info / formats as text are printed from the parsed entries with the header's types: the host reader builds them; a
+    gpu_parse scan that asks for them says so (decoded_on_gpu = 0) and serves the same batches."""
+    p = os.path.join(FX, "vcf", "index.vcf.gz")
+    v = decode.decode_vcf(p)
+    s = exon_amd.Scan(p, "vcf", batch_size=100, gpu_parse=True, project=("id", "info", "formats")).bind_ctx(ctx)
+    c = table(s)
+    assert not s.decoded_on_gpu()[0]
+    s.close()
+    assert c["id"] == v["id"]
+    assert c["info"] == [decode.info_string(v, i) for i in range(621)]
+    assert c["formats"] == [decode.formats_string(v, i) for i in range(621)]
