@@ -421,112 +421,11 @@ def decode_bcf(path):
         rows["filter"].append([by_idx[i] for i in filt])
         rows["info"].append(info if n_info else None)
         o += 8 + l_shared + l_indiv
-    rows.update(contigs=contigs, filters_header=filt_hdr, info_header=info_hdr, format_header=format_hdr)
+    rows.update(contigs=contigs, filters_header=filt_hdr, info_header=info_hdr)
     return rows
 
 
-# reserved keys of the VCF specification (4.3, tables 1 and 2 + the structural-variant keys): the types noodles takes for a key
-# the header does not declare (then String)
-_RESERVED_INFO = dict.fromkeys("AC AD ADF ADR AN DP END MQ0 NS SB SVLEN CIPOS CIEND HOMLEN CILEN DPADJ CN CNADJ CICN CICNADJ".split(), "Integer")
-_RESERVED_INFO.update(dict.fromkeys("AF BQ MQ".split(), "Float"))
-_RESERVED_INFO.update(dict.fromkeys("DB H2 H3 SOMATIC VALIDATED 1000G IMPRECISE NOVEL".split(), "Flag"))
-_RESERVED_FORMAT = dict.fromkeys("AD ADF ADR DP EC GQ HQ MQ PL PP PQ PS CN NQ HAP AHAP".split(), "Integer")
-_RESERVED_FORMAT.update(dict.fromkeys("GL GP CNQ CNL CNP".split(), "Float"))
 
-
-def rust_f32_display(x):
-    """Rust's `{}` of an f32 (`v.to_string()`, lazy_array_builder.rs:233): shortest digits that round-trip, never an exponent."""
-    v = np.float32(x)
-    if np.isnan(v):
-        return "NaN"
-    if np.isinf(v):
-        return "-inf" if v < 0 else "inf"
-    return np.format_float_positional(v, unique=True, trim="-")
-
-
-def _print_value(typ, text):
-    if typ in ("String", None) or (typ == "Character" and "," not in text):
-        return text
-    out = []
-    for item in text.split(","):
-        if item == ".":
-            if typ != "Character":  # a Character list drops its missing items (lazy_array_builder.rs:364-368 / :238-250 keeps them for INFO ...)
-                out.append(".")
-        elif typ == "Integer":
-            if not (item.isascii() and item.lstrip("+-").isdigit() and len(item) - len(item.lstrip("+-")) <= 1):
-                raise ValueError(f"invalid integer {item!r}")
-            if not -2**31 <= int(item) < 2**31:
-                raise ValueError(f"integer out of the int32 range {item!r}")
-            out.append(str(int(item)))
-        elif typ == "Float":
-            out.append(rust_f32_display(np.float32(item)))
-        else:
-            out.append(item)
-    return ",".join(out)
-
-
-def info_string(v, row):
-    """The `info` Utf8 column (parse_info = false) of row `row` of a `decode_vcf` result: the parsed entries printed again
-    (exon-vcf/src/array_builder/lazy_array_builder.rs:216-297): key=value joined by ';', a Flag as key=true, Integer / Float items
-    through Rust's Display, missing items '.', INFO '.' -> the empty string; a missing value is the reference's unwrap panic."""
-    raw = v["info_raw"][row]
-    if raw in (".", ""):
-        return ""
-    out = []
-    for kv in raw.split(";"):
-        if not kv:
-            continue
-        k, eq, val = kv.partition("=")
-        typ = v["info_header"].get(k, (None, _RESERVED_INFO.get(k, "String")))[1]
-        if typ == "Flag":
-            out.append(k + "=true")
-            continue
-        if not eq or val in ("", "."):
-            raise ValueError(f"INFO key {k!r} has no value (the reference panics)")
-        out.append(k + "=" + _print_value(typ, val))
-    return ";".join(out)
-
-
-def formats_string(v, row):
-    """The `formats` Utf8 column (parse_formats = false): FORMAT keys joined by ':', TAB, samples joined by TAB, each sample's
-    values printed like INFO values and joined by ':' (lazy_array_builder.rs:310-423).  A genotype prints allele 0, then for
-    every further allele the separator of the allele BEFORE it (:331-360); allele 0's own phasing is, before VCF 4.4, unphased
-    when any separator of the genotype is '/' (noodles-vcf 0.70 as published; not in /root/reference)."""
-    fmt = v["format_raw"][row]
-    keys = [] if fmt in (None, ".", "") else fmt.split(":")
-    head = ":".join(keys)
-    if not keys:
-        return head + "\t"
-    samples = []
-    for stext in v["samples_raw"][row]:
-        vals = []
-        for k, val in zip(keys, stext.split(":")):
-            if val in ("", "."):
-                raise ValueError("a sample value is missing (the reference panics)")
-            if k == "GT":
-                alleles, seps, cur = [], [], ""
-                for ch in val:
-                    if ch in "/|":
-                        alleles.append(cur)
-                        seps.append(ch)
-                        cur = ""
-                    else:
-                        cur += ch
-                alleles.append(cur)
-                phasing = ["/" if "/" in val else "|"] + seps  # phasing[i] belongs to allele i
-                txt = ""
-                for i, a in enumerate(alleles):
-                    a = a if a == "." else str(int(a))
-                    txt += a if i == 0 else phasing[i - 1] + a
-                vals.append(txt)
-            else:
-                typ = v["format_header"].get(k, (None, _RESERVED_FORMAT.get(k, "String")))[1]
-                vals.append(_print_value(typ, val))
-        samples.append(":".join(vals))
-    return head + "\t" + "\t".join(samples)
-
-
-# ---- FASTQ / FASTA -----------------------------------------------------------------------------------
 def decode_fastq(path):
     lines = read_bytes(path).decode().split("\n")
     recs = []
