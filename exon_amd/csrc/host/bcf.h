@@ -97,8 +97,22 @@ class BCFBatchReader {
     std::vector<PrimitiveBuilder<int32_t>> info_i(K);
     std::vector<ListBuilder<float>> info_lf(K);    // 'F'
     std::vector<ListBuilder<int32_t>> info_li(K);  // 'I' values, 'S' dictionary ids
+    // projected text columns: BCF records go through the reference's EAGER builder (exon-bcf/src/batch_reader.rs:72 ->
+    // exon-vcf/src/array_builder/eager_array_builder.rs:112-134): ids and alternate bases are lists WITH their items and are
+    // never NULL (an empty list when there is none) -- unlike the lazy builder VCF text takes
+    ListUtf8Builder ids, alts;
+    Utf8Builder refs;
     std::vector<uint8_t> rec;
     size_t rows = 0;
+    auto typed_string = [&](size_t* o, size_t end, const char** p, size_t* n) {
+      int type, count;
+      typed_header(rec, o, end, &type, &count);
+      if (type != 7 && !(type == 0 && count == 0)) throw std::runtime_error("corrupt BCF record: a string was expected");
+      if (*o + (size_t)count > end) throw std::runtime_error("corrupt BCF typed value");
+      *p = reinterpret_cast<const char*>(rec.data() + *o);
+      *n = type == 7 ? (size_t)count : 0;
+      *o += *n;
+    };
     while ((int64_t)rows < cfg_.batch_size) {
       uint8_t lens[8];
       if (!r_->read_exact(lens, 8)) break;
@@ -122,8 +136,33 @@ class BCFBatchReader {
       }
       size_t o = 24;
       const size_t end = l_shared;
-      skip_typed(rec, &o, end);                               // ID
-      for (int a = 0; a < n_allele; ++a) skip_typed(rec, &o, end);  // REF + ALTs
+      if (!cfg_.projection) {
+        skip_typed(rec, &o, end);                               // ID
+        for (int a = 0; a < n_allele; ++a) skip_typed(rec, &o, end);  // REF + ALTs
+      } else {
+        const char* tp;
+        size_t tn;
+        typed_string(&o, end, &tp, &tn);  // ID: ';'-separated, "." = none
+        if ((cfg_.projection & 1) && !(tn == 0 || (tn == 1 && tp[0] == '.'))) {
+          size_t a = 0;
+          for (size_t i = 0; i <= tn; ++i)
+            if (i == tn || tp[i] == ';') {
+              ids.items.append_value(tp + a, i - a);
+              a = i + 1;
+            }
+        }
+        if (cfg_.projection & 1) ids.close_row();
+        for (int a = 0; a < n_allele; ++a) {
+          typed_string(&o, end, &tp, &tn);
+          if (a == 0) {
+            if (cfg_.projection & 2) refs.append_value(tp, tn);
+          } else if (cfg_.projection & 4) {
+            alts.items.append_value(tp, tn);
+          }
+        }
+        if ((cfg_.projection & 2) && n_allele == 0) refs.append_value("", 0);
+        if (cfg_.projection & 4) alts.close_row();
+      }
       // FILTER: typed int vector of dictionary indexes; empty = '.'
       std::string fl;
       {
@@ -299,6 +338,9 @@ class BCFBatchReader {
         kids.push_back(a);
       }
     }
+    if (cfg_.projection & 1) kids.push_back(ids.finish());
+    if (cfg_.projection & 2) kids.push_back(refs.finish());
+    if (cfg_.projection & 4) kids.push_back(alts.finish());
     make_struct(out, (int64_t)rows, std::move(kids));
     return true;
   }
@@ -316,6 +358,9 @@ class BCFBatchReader {
       else if (sp.kind == 'b') kids.push_back(new_field("b", name.c_str(), true));
       else kids.push_back(new_field("i", name.c_str(), true, new_field("u", "", false)));
     }
+    if (cfg_.projection & 1) kids.push_back(new_list_field("u", "id"));
+    if (cfg_.projection & 2) kids.push_back(new_field("u", "ref", false));
+    if (cfg_.projection & 4) kids.push_back(new_list_field("u", "alt"));
     make_schema(out, "+s", "", false, kids);
   }
 

@@ -870,6 +870,48 @@ class BAMArrayBuilder : public ExonArrayBuilder {
       qual_.close_row();
     }
   }
+  // the same columns from a SAM line's fields (exon-sam/src/array_builder.rs:101-185 over noodles' RecordBuf): QNAME "*" is no
+  // name; the CIGAR is printed again op by op ("*" -> ""); SEQ "*" -> ""; QUAL "*" -> an empty list, else Phred = char - 33
+  void append_sam_text(const char* name, size_t nn, const char* cigar, size_t nc, const char* seq, size_t ns, const char* qual, size_t nq) {
+    if (projection_ & 1) {
+      if (nn == 1 && name[0] == '*') name_.append_null();
+      else name_.append_value(name, nn);
+    }
+    if (projection_ & 2) {
+      std::string t;
+      if (!(nc == 1 && cigar[0] == '*')) {
+        uint64_t num = 0;
+        bool digits = false;
+        for (size_t i = 0; i < nc; ++i) {
+          const char ch = cigar[i];
+          if (ch >= '0' && ch <= '9') {
+            num = num * 10 + (uint64_t)(ch - '0');
+            digits = true;
+          } else {
+            if (!digits || !strchr("MIDNSHP=X", ch)) throw std::runtime_error("invalid CIGAR '" + std::string(cigar, nc) + "'");
+            t += std::to_string(num);
+            t += ch;
+            num = 0;
+            digits = false;
+          }
+        }
+        if (digits) throw std::runtime_error("invalid CIGAR '" + std::string(cigar, nc) + "'");
+      }
+      cigar_.append_value(t);
+    }
+    if (projection_ & 4) {
+      if (ns == 1 && seq[0] == '*') seq_.append_value("", 0);
+      else seq_.append_value(seq, ns);
+    }
+    if (projection_ & 8) {
+      if (!(nq == 1 && qual[0] == '*'))
+        for (size_t i = 0; i < nq; ++i) {
+          if (qual[i] < 33 || qual[i] > 126) throw std::runtime_error("invalid quality score character");
+          qual_.items.append_value((int64_t)(qual[i] - 33));
+        }
+      qual_.close_row();
+    }
+  }
   void append(int32_t flag, int32_t ref_id, int64_t pos0, int mapq, int64_t ref_len) {
     flag_.append_value(flag);  // array_builder.rs:114-117: raw u16 bits as Int32
     if (mapq == 255) mapq_.append_null(255);  // :136-143 (reference: decimal string, NULL when missing)
@@ -1074,7 +1116,7 @@ class SAMBatchReader {
   }
 
   bool read_batch(struct ArrowArray* out) {
-    BAMArrayBuilder b(&ref_names);
+    BAMArrayBuilder b(&ref_names, cfg_.projection);
     std::string line;
     while ((int64_t)b.len() < cfg_.batch_size) {
       if (has_pending_) {
@@ -1084,11 +1126,12 @@ class SAMBatchReader {
         break;
       }
       if (line.empty() || line[0] == '@') continue;
-      const char* f[6];
-      size_t fl[6];
+      const char* f[11];
+      size_t fl[11];
       int nf = 0;
       size_t start = 0;
-      for (size_t i = 0; i <= line.size() && nf < 6; ++i)
+      const int want = cfg_.projection ? 11 : 6;
+      for (size_t i = 0; i <= line.size() && nf < want; ++i)
         if (i == line.size() || line[i] == '\t') {
           f[nf] = line.data() + start;
           fl[nf] = i - start;
@@ -1119,6 +1162,10 @@ class SAMBatchReader {
         const Region& rg = cfg_.filter.region;
         if (!(ref_id == region_ref_id_ && pos1 <= rg.end && rg.start <= e)) continue;
       }
+      if (cfg_.projection) {
+        if (nf < 11) throw std::runtime_error("SAM record has fewer than 11 fields");
+        b.append_sam_text(f[0], fl[0], f[5], fl[5], f[9], fl[9], f[10], fl[10]);
+      }
       b.append(flag, ref_id, pos1 - 1, mapq, ref_len);
     }
     if (b.is_empty()) return false;
@@ -1126,10 +1173,14 @@ class SAMBatchReader {
     return true;
   }
   void schema(struct ArrowSchema* out) const {
-    make_schema(out, "+s", "", false,
-                {new_field("i", "flag", false), new_field("C", "mapping_quality", true),
-                 new_field("i", "reference", true, new_field("u", "", false)), new_field("l", "start", true),
-                 new_field("l", "end", true)});
+    std::vector<struct ArrowSchema*> kids = {new_field("i", "flag", false), new_field("C", "mapping_quality", true),
+                                             new_field("i", "reference", true, new_field("u", "", false)), new_field("l", "start", true),
+                                             new_field("l", "end", true)};
+    if (cfg_.projection & 1) kids.push_back(new_field("u", "name", true));
+    if (cfg_.projection & 2) kids.push_back(new_field("u", "cigar", false));
+    if (cfg_.projection & 4) kids.push_back(new_field("u", "sequence", false));
+    if (cfg_.projection & 8) kids.push_back(new_list_field("l", "quality_score"));
+    make_schema(out, "+s", "", false, kids);
   }
   std::string header_text;
   std::vector<std::string> ref_names;

@@ -199,8 +199,8 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
       rf.use_index = o->use_index != 0;
     }
     s->region = rf;
-    if (o->projection && o->format != EXON_HIP_FORMAT_VCF && o->format != EXON_HIP_FORMAT_BAM)
-      return fail(nullptr, EXON_HIP_EUNSUPPORTED, "exon_hip_scan_options.projection: the id / ref / alt and name / cigar / sequence / quality_scores columns are built for VCF text and BAM scans");
+    if (o->projection && o->format != EXON_HIP_FORMAT_VCF && o->format != EXON_HIP_FORMAT_BAM && o->format != EXON_HIP_FORMAT_BCF && o->format != EXON_HIP_FORMAT_SAM)
+      return fail(nullptr, EXON_HIP_EUNSUPPORTED, "exon_hip_scan_options.projection: the id / ref / alt (/ info / formats) and name / cigar / sequence / quality_score columns are built for VCF, BCF, BAM and SAM scans");
     switch (o->format) {
       case EXON_HIP_FORMAT_VCF: {
         exon::VCFConfig cfg;
@@ -257,7 +257,9 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         cfg.info_field = o->info_field ? o->info_field : "";
         cfg.filter = rf;
         cfg.filter.use_index = false;
-        s->gpu_parse = wants_gpu_inflate(o, path);  // BCF is BGZF by definition; a region becomes a row mask
+        cfg.projection = o->projection;
+        if (o->projection & ~7ull) return fail(nullptr, EXON_HIP_EINVAL, "projection 0x%llx: BCF knows EXON_HIP_PROJECT_VCF_ID / _REF / _ALT", (unsigned long long)o->projection);
+        s->gpu_parse = wants_gpu_inflate(o, path) && !o->projection;  // BCF is BGZF by definition; a region becomes a row mask; the text columns: host reader
         if (s->gpu_parse) cfg.threads = 1;  // only the header is read on the host
         s->bcf.reset(new exon::BCFBatchReader(path, cfg));
         if (s->gpu_parse) {
@@ -277,7 +279,9 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         cfg.batch_size = bs;
         cfg.filter = rf;
         cfg.filter.use_index = false;
-        s->gpu_parse = o->gpu_parse != 0;
+        cfg.projection = o->projection;
+        if (o->projection & ~15ull) return fail(nullptr, EXON_HIP_EINVAL, "projection 0x%llx: SAM knows EXON_HIP_PROJECT_BAM_NAME / _CIGAR / _SEQUENCE / _QUALITY_SCORES", (unsigned long long)o->projection);
+        s->gpu_parse = o->gpu_parse != 0 && !o->projection;  // the text columns of SAM: host reader
         s->sam.reset(new exon::SAMBatchReader(path, c, cfg));
         s->bam_dict_view.names = s->sam->ref_names;
         break;

@@ -395,7 +395,8 @@ class Scan:
     """Native decoder + device-layout array builder over one file (FileOpener::open + read_batch analogue).
     CPU-only: usable without a GPU."""
 
-    PROJECT = {"vcf": {"id": 1, "ref": 2, "alt": 4, "info": 8, "formats": 16}, "bam": {"name": 1, "cigar": 2, "sequence": 4, "quality_score": 8}}
+    PROJECT = {"vcf": {"id": 1, "ref": 2, "alt": 4, "info": 8, "formats": 16}, "bam": {"name": 1, "cigar": 2, "sequence": 4, "quality_score": 8},
+               "bcf": {"id": 1, "ref": 2, "alt": 4}, "sam": {"name": 1, "cigar": 2, "sequence": 4, "quality_score": 8}}
 
     def __init__(self, path, fmt, compression=None, batch_size=0, info_field=None, region=None, use_index=False,
                  gpu_parse=False, project=()):

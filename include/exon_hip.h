@@ -469,7 +469,10 @@ typedef struct exon_hip_scan_options {
                              VCF text also: info Utf8, formats Utf8 -- the unparsed forms of the reference's default schema, which
                              are the parsed entries PRINTED AGAIN, not the fields' bytes ("AF=0.50" -> "AF=0.5", a Flag ->
                              "DB=true", formats = keys TAB samples; lazy_array_builder.rs:216-297, :310-423; host/vcf_text.h).
-                             These two are built by the host reader only: a gpu_parse scan that asks for them decodes on the host */
+                             These two are built by the host reader only: a gpu_parse scan that asks for them decodes on the host.
+                             BCF: id List<Utf8>, ref Utf8, alt List<Utf8> through the reference's EAGER builder (lists with their
+                             items, never NULL: eager_array_builder.rs:112-134); SAM: the BAM columns from the line's fields
+                             (exon-sam/src/array_builder.rs:101-185); both host reader only */
 } exon_hip_scan_options;
 #define EXON_HIP_PROJECT_VCF_ID 1ull
 #define EXON_HIP_PROJECT_VCF_REF 2ull

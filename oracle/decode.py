@@ -341,7 +341,11 @@ def decode_sam(path):
         start = pos if pos >= 1 else None
         recs.append(dict(name=c[0], flag=int(c[1]), ref_id=names.index(c[2]) if c[2] in names else None, start=start,
                          end=(start + ref_len - 1) if start is not None else None, mapq=None if mapq == 255 else mapq,
-                         cigar=c[5]))
+                         cigar="" if c[5] == "*" else c[5],
+                         # exon-sam/src/array_builder.rs:101-185 over noodles' RecordBuf: QNAME '*' -> None, SEQ '*' -> "",
+                         # QUAL '*' -> [], else Phred = char - 33
+                         name_opt=None if c[0] == "*" else c[0], sequence="" if c[9] == "*" else c[9],
+                         quality_score=[] if c[10] == "*" else [ord(ch) - 33 for ch in c[10]]))
     return refs, recs
 
 
@@ -369,7 +373,9 @@ def decode_bcf(path):
                 strings[f["ID"]] = int(f["IDX"]) if "IDX" in f else len(order)
                 order.append(f["ID"])
     by_idx = {v: k for k, v in strings.items()}
-    rows = dict(chrom=[], pos=[], qual=[], filter=[], info=[])
+    # id / ref / alt: BCF records go through the reference's EAGER builder (exon-bcf/src/batch_reader.rs:72 ->
+    # exon-vcf/src/array_builder/eager_array_builder.rs:112-134): lists with their items, never NULL
+    rows = dict(chrom=[], pos=[], qual=[], filter=[], info=[], id=[], ref=[], alt=[])
     size = {1: 1, 2: 2, 3: 4, 5: 4, 7: 1}
     fmt = {1: "b", 2: "h", 3: "i", 5: "f"}
     missing = {1: -128, 2: -32768, 3: -2147483648}
@@ -401,8 +407,14 @@ def decode_bcf(path):
         n_info, n_allele = nia & 0xFFFF, nia >> 16
         p = r + 24
         _id, p = typed(p)
+        alleles = []
         for _ in range(n_allele):
             _a, p = typed(p)
+            alleles.append(bytes(_a).decode())
+        ids = bytes(_id).decode()
+        rows["id"].append([] if ids in ("", ".") else ids.split(";"))
+        rows["ref"].append(alleles[0] if alleles else "")
+        rows["alt"].append(alleles[1:])
         filt, p = typed(p)
         info = {}
         for _ in range(n_info):

@@ -292,3 +292,41 @@ def test_gpu_scan_with_the_text_columns_decodes_on_the_host(ctx):
     assert c["id"] == v["id"]
     assert c["info"] == [decode.info_string(v, i) for i in range(621)]
     assert c["formats"] == [decode.formats_string(v, i) for i in range(621)]
+
+
+# ---- BCF (eager builder: lists with items) and SAM (the BAM columns from the line's fields), host readers -----------------------
+def test_host_bcf_id_ref_alt_on_the_fixture():
+    p = os.path.join(FX, "bcf", "index.bcf")
+    v = decode.decode_bcf(p)
+    s = exon_amd.Scan(p, "bcf", batch_size=50, project=("id", "ref", "alt"))
+    sch = s.schema()
+    assert [sch.field(i).name for i in range(sch.num_fields)][-3:] == ["id", "ref", "alt"]
+    c = table(s)
+    s.close()
+    assert c["chrom"] == v["chrom"] and c["pos"] == v["pos"]
+    assert c["id"] == v["id"] and c["ref"] == v["ref"] and c["alt"] == v["alt"]
+    assert any(a for a in c["alt"]) and all(i is not None for i in c["id"])  # items are there; an empty list, never NULL
+    # the same file as VCF text goes through the LAZY builder: ids NULL when missing, alt lists without items
+    t = table(exon_amd.Scan(os.path.join(FX, "vcf", "index.vcf"), "vcf", project=("ref",)))
+    assert t["ref"][:50] == c["ref"][:50]
+
+
+def test_host_sam_text_columns_on_the_fixture(tmp_path):
+    p = os.path.join(FX, "sam", "test.sam")
+    refs, recs = decode.decode_sam(p)
+    proj = ("name", "cigar", "sequence", "quality_score")
+    c = table(exon_amd.Scan(p, "sam", batch_size=7, project=proj))
+    assert c["name"] == [r["name_opt"] for r in recs] and c["cigar"] == [r["cigar"] for r in recs]
+    assert c["sequence"] == [r["sequence"] for r in recs] and c["quality_score"] == [r["quality_score"] for r in recs]
+    # slt/sam-select-tests.slt:6-19
+    assert (c["name"][0], c["flag"][0], c["start"][0], c["end"][0], c["mapping_quality"][0], c["cigar"][0]) == ("ref1_grp1_p001", 99, 1, 10, 0, "10M")
+    assert c["sequence"][0] == "CGAGCTCGGT" and c["quality_score"][0] == [0] * 10
+    # missing fields and a CIGAR that is printed again
+    q = tmp_path / "m.sam"
+    q.write_text("@SQ\tSN:r\tLN:100\n*\t4\t*\t0\t255\t*\t*\t0\t0\t*\t*\nx\t0\tr\t5\t9\t03M2I\t=\t9\t0\tACGTA\t!+5?~\n")
+    c = table(exon_amd.Scan(str(q), "sam", project=proj))
+    assert c["name"] == [None, "x"] and c["cigar"] == ["", "3M2I"] and c["sequence"] == ["", "ACGTA"]
+    assert c["quality_score"] == [[], [0, 10, 20, 30, 93]]
+    with pytest.raises(exon_amd.ExonHipError):
+        q.write_text("@SQ\tSN:r\tLN:100\nx\t0\tr\t5\t9\t3Q\t=\t9\t0\tACG\t!!!\n")
+        table(exon_amd.Scan(str(q), "sam", project=("cigar",)))
