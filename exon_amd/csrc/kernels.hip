@@ -1423,7 +1423,16 @@ __global__ __launch_bounds__(S::THREADS) void k4_cmp_avg_by_group_main(
 }
 
 constexpr int K4_OVF_REGS = 4;                   // register groups of the > 8-group variant
-constexpr int K4_LDS_GROUPS = K4_OVF_REGS + 4096;  // ids handled by registers + the LDS table
+// ids handled by registers + the LDS table
+static int k4_lds_groups() {
+  static const int ids = [] {
+    const char* v = getenv("EXON_HIP_K4_LDS_IDS");  // A/B: entries of the tier-2 table
+    const int k = v ? atoi(v) : 0;
+    return k >= 64 && k <= 8192 ? k : 4096;
+  }();
+  return K4_OVF_REGS + ids;
+}
+#define K4_LDS_GROUPS k4_lds_groups()
 static int k4_nl(int n_groups) { return n_groups < K4_LDS_GROUPS ? n_groups : K4_LDS_GROUPS; }
 
 size_t k4_partial_words(const LaunchCfg& cfg, int n_groups) { return (size_t)max_grid(cfg) * 3 * (size_t)k4_nl(n_groups); }

@@ -214,7 +214,10 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         s->gpu_parse = o->gpu_parse != 0 && (!rf.use_index || (rf.active && wants_gpu_inflate(o, path)));
         // info / formats as text are the reference's re-printed entries (host/vcf_text.h: number formatting per header type):
         // the host reader builds them, so such a scan decodes there
-        if (o->projection & (EXON_HIP_PROJECT_VCF_INFO | EXON_HIP_PROJECT_VCF_FORMATS)) s->gpu_parse = false;
+        if (o->projection & (EXON_HIP_PROJECT_VCF_INFO | EXON_HIP_PROJECT_VCF_FORMATS)) {
+          s->gpu_candidate = s->gpu_parse;  // (a fused plan never reads them: exon_hip_stream_consume_scan may still decode on the device)
+          s->gpu_parse = false;
+        }
         // EXON_HIP_REFERENCE_QUIRKS=1: an indexed VCF scan reproduces the reference's unfiltered tail after a full batch of
         // hits (exon-vcf/src/indexed_async_batch_stream.rs:143-154) -- a property of its per-chunk record loop, so the host
         // reader runs it; default: every record is tested (what vcf_region_filter documents)

@@ -281,17 +281,31 @@ def test_rust_f32_display_of_the_host_reader_equals_numpy_dragon4_on_random_floa
 
 @pytest.mark.gpu
 def test_gpu_scan_with_the_text_columns_decodes_on_the_host(ctx):
-    """info / formats as text are printed from the parsed entries with the header's types: the host reader builds them; a
-    gpu_parse scan that asks for them says so (decoded_on_gpu = 0) and serves the same batches."""
+    """info / formats as text are printed from the parsed entries with the header's types: the host reader builds them.  A
+    gpu_parse scan that asks for them cannot be bound to the GPU pipeline (EUNSUPPORTED, as for String INFO keys), serves the same
+    batches from the host reader and says so; a fused plan over the same scan (it never reads those columns) still decodes on
+    the device."""
     p = os.path.join(FX, "vcf", "index.vcf.gz")
     v = decode.decode_vcf(p)
-    s = exon_amd.Scan(p, "vcf", batch_size=100, gpu_parse=True, project=("id", "info", "formats")).bind_ctx(ctx)
+    s = exon_amd.Scan(p, "vcf", batch_size=100, gpu_parse=True, project=("id", "info", "formats"))
+    with pytest.raises(exon_amd.ExonHipError):
+        s.bind_ctx(ctx)
     c = table(s)
     assert not s.decoded_on_gpu()[0]
     s.close()
     assert c["id"] == v["id"]
     assert c["info"] == [decode.info_string(v, i) for i in range(621)]
     assert c["formats"] == [decode.formats_string(v, i) for i in range(621)]
+    scan = exon_amd.Scan(p, "vcf", gpu_parse=True, project=("info",))
+    plan = ctx.plan_region_count(scan.dictionary(0).index("1"), 1, None, columns=(0, 1))
+    st = plan.open()
+    rows = st.consume(scan)
+    counts, _ = st.finish()
+    assert scan.decoded_on_gpu()[0]
+    assert rows == 621 and int(counts[0]) == 191
+    st.close()
+    plan.close()
+    scan.close()
 
 
 # ---- BCF (eager builder: lists with items) and SAM (the BAM columns from the line's fields), host readers -----------------------
