@@ -205,6 +205,7 @@ SIGNATURES = {
     "exon_hip_vcf_parser_parse": (C.c_int, [_vp, _vp, _vp, _i64, C.POINTER(VCFColumns)]),
     "exon_hip_vcf_parser_filters": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(_i32)]),
     "exon_hip_vcf_parser_info_values": (C.c_int, [_vp, _i32, C.c_char_p, C.c_size_t, C.POINTER(_i32)]),
+    "exon_hip_vcf_parser_set_null_key": (C.c_int, [_vp, _i32]),
     "exon_hip_vcf_parser_destroy": (C.c_int, [_vp]),
     "exon_hip_qual_pos_hist_chunks": (C.c_int, [_vp, _vp, _colp, _i32, _vp, _i32, _vp]),
     "exon_hip_qual_pos_hist_views": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),

@@ -643,16 +643,18 @@ __global__ __launch_bounds__(TPB) void k_parse_lines(const uint8_t* __restrict__
 // groups by the key needs to know whether there is a NULL group).
 __global__ __launch_bounds__(TPB) void k_info_string_ids(const uint8_t* __restrict__ text, const uint32_t* __restrict__ voff, const uint32_t* __restrict__ vlen,
                                                          const uint8_t* __restrict__ valid, const unsigned* __restrict__ n_lines_p, unsigned cap, FilterTable t,
-                                                         int32_t* __restrict__ ids) {
+                                                         int32_t* __restrict__ ids, int null_as_value) {
   const unsigned n = min(*n_lines_p, cap);
   const unsigned row = blockIdx.x * TPB + threadIdx.x;
   bool has = false;
   if (row < n) {
     has = (valid[row >> 3] >> (row & 7)) & 1;
     int found = 0;
-    if (has) {
-      const uint8_t* p = text + voff[row];
-      const int len = (int)vlen[row];
+    // null_as_value (a fused plan groups by this key): a row without a value takes the id of the EMPTY text -- a value no row can
+    // carry ("key=" is a missing value) -- so that NULL is a group of its own, as in DataFusion's GROUP BY
+    if (has || null_as_value) {
+      const uint8_t* p = text + (has ? voff[row] : 0u);
+      const int len = has ? (int)vlen[row] : 0;
       const unsigned long long h = fnv1a(p, len);
       int slot = (int)(h & (FILTER_SLOTS - 1));
       found = -1;
@@ -661,7 +663,7 @@ __global__ __launch_bounds__(TPB) void k_info_string_ids(const uint8_t* __restri
         if (k == 0) {
           k = atomicCAS(&t.keys[slot], 0ull, h);
           if (k == 0) {
-            t.text_off[slot] = voff[row];
+            t.text_off[slot] = has ? voff[row] : 0u;
             t.text_len[slot] = (uint32_t)len;
             found = slot;
             break;
@@ -680,8 +682,9 @@ __global__ __launch_bounds__(TPB) void k_info_string_ids(const uint8_t* __restri
     }
     ids[row] = found;
   }
-  const unsigned long long miss = __ballot(row < n && !has);
+  const unsigned long long miss = __ballot(row < n && !has && !null_as_value);
   if ((threadIdx.x & 63) == 0 && miss) atomicAdd(&t.counters[3], __popcll(miss));
+  // (null_as_value: counters[3] stays 0 = "no row without an id": the consumer then takes the ids without the bitmap)
 }
 
 // dense ids for FILTER lists inserted during the last parse, text copied into the persistent pool.  New lists are
@@ -829,6 +832,7 @@ struct exon_hip_vcf_parser {
   int64_t cap_items = 0;
   unsigned* h_scalars = nullptr;  // pinned mirror of d_scalars
   FilterTable str_tables[MAX_INFO] = {};
+  int null_as_value = 0;  // exon_hip_vcf_parser_set_null_key: rows without a value of a String key take the id of the empty text
   int32_t h_str_stat[MAX_INFO][2] = {{0, 0}};  // per 's' key, last slab: {dictionary overflow, rows without a value}  // kind 's': the key's value dictionary, built on the device like the FILTER dictionary
 };
 
@@ -1036,7 +1040,7 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* p, void* stream, const uint8_
     FilterTable& t = p->str_tables[q];
     HIP_TRY(ctx, hipMemsetAsync(t.counters + 3, 0, 4, s));
     hipLaunchKernelGGL(k_info_string_ids, dim3(pblocks), dim3(TPB), 0, s, d_text, p->out.lv_off[q], p->out.lv_cnt[q], p->out.info_valid[q], p->d_scalars, (unsigned)row_bound, t,
-                       (int32_t*)p->out.info[q]);
+                       (int32_t*)p->out.info[q], p->null_as_value);
     hipLaunchKernelGGL(k_assign_filters, dim3(1), dim3(256), 0, s, d_text, t);
     hipLaunchKernelGGL(k_remap_filters, dim3(std::min(pblocks, 4096)), dim3(TPB), 0, s, (int32_t*)p->out.info[q], p->d_scalars, t.ids, (unsigned)row_bound);
     HIP_TRY(ctx, hipMemcpyAsync(p->h_str_stat[q], t.counters + 2, 8, hipMemcpyDeviceToHost, s));  // {overflow, rows without a value}
@@ -1111,6 +1115,13 @@ static int table_names(exon_hip_ctx* ctx, const FilterTable& t, const char* what
 int exon_hip_vcf_parser_filters(exon_hip_vcf_parser* p, char* buf, size_t cap, int32_t* n_filters) {
   if (!p || !n_filters) return fail(p ? p->ctx : nullptr, EXON_HIP_EINVAL, "exon_hip_vcf_parser_filters: NULL argument");
   return table_names(p->ctx, p->filters, "FILTER lists", buf, cap, n_filters);
+}
+// on != 0: a row without a value of a String / Character key gets the dictionary id of the EMPTY text (no row can carry it) and
+// counts as valid: NULL becomes a group key of its own for a plan that groups by the key.  Off (default): NULL stays NULL.
+int exon_hip_vcf_parser_set_null_key(exon_hip_vcf_parser* p, int32_t on) {
+  if (!p) return fail(nullptr, EXON_HIP_EINVAL, "exon_hip_vcf_parser_set_null_key: NULL argument");
+  p->null_as_value = on ? 1 : 0;
+  return EXON_HIP_OK;
 }
 // the value dictionary of INFO key `key` (its index in the parser's key list; kind 's') in id order
 int exon_hip_vcf_parser_info_values(exon_hip_vcf_parser* p, int32_t key, char* buf, size_t cap, int32_t* n_values) {

@@ -106,6 +106,7 @@ int exon_hip_stream_plan_first_column(exon_hip_stream* st);
 int exon_hip_stream_plan_kind(exon_hip_stream* st);
 int exon_hip_stream_plan_column(exon_hip_stream* st, int arg);
 void exon_hip_stream_set_value_types(exon_hip_stream* st, int x_type, int y_type);
+int exon_hip_stream_set_null_group(exon_hip_stream* st, std::function<int32_t()> id_of_null);
 int exon_hip_stream_launch_views(exon_hip_stream* st, const uint8_t* d_text, const exon_hip_fastq_views& v);
 void* exon_hip_stream_hip_stream(exon_hip_stream* st);
 exon_hip_ctx* exon_hip_stream_ctx(exon_hip_stream* st);
@@ -2237,6 +2238,8 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
         const int64_t *c_start = nullptr, *c_end = nullptr;
         if (is_vcf || is_bcf) {
           exon_hip_vcf_columns cols;
+          // a fused plan that groups by a String key: NULL is a group of its own (the empty text's id); batches keep NULL
+          if (is_vcf) exon_hip_vcf_parser_set_null_key(scan->parser, scan->exporter ? 0 : 1);
           rc = is_vcf ? exon_hip_vcf_parser_parse(scan->parser, hs, d_text, (int64_t)n, &cols)
                       : exon_hip_bcf_parser_parse(scan->bcf_parser, hs, d_text, (int64_t)n, &cols);
           t_parse += now_s() - t1;
@@ -2713,6 +2716,22 @@ static int consume_scan_impl(exon_hip_stream* st, exon_hip_scan* scan, int64_t* 
     }
     // fall through to the host paths below
   }
+  // K4 grouped by a String / Character INFO key (a dictionary column WITH NULLs from the host readers): the stream turns a NULL
+  // key into the id of the empty text in this scan's dictionary -- interned when the first NULL shows up -- so that NULL is a
+  // group of its own (DataFusion's GROUP BY); the device parser does the same (exon_hip_vcf_parser_set_null_key)
+  struct NullGroupGuard {
+    exon_hip_stream* st;
+    ~NullGroupGuard() { exon_hip_stream_set_null_group(st, nullptr); }
+  } null_group_guard{st};
+  if (exon_hip_stream_plan_kind(st) == EXON_HIP_PLAN_CMP_AVG_BY_GROUP && (scan->vcf || scan->bcf)) {
+    const std::vector<exon::InfoSpec>& specs = scan->vcf ? scan->vcf->info_specs : scan->bcf->info_specs;
+    const int gcol = exon_hip_stream_plan_column(st, 2);
+    if (gcol >= 4 && (size_t)(gcol - 4) < specs.size() && specs[(size_t)(gcol - 4)].kind == 's')
+      exon_hip_stream_set_null_group(st, [scan, gcol]() -> int32_t {
+        exon::Dictionary* d = dict_of(scan, gcol);
+        return d ? d->lookup_or_insert("", 0) : -1;
+      });
+  }
   // fast path: a multi-threaded VCF scan hands its slabs over as raw vectors (no Arrow batch in between)
   if (scan->vcf) {
     try {
@@ -2726,7 +2745,7 @@ static int consume_scan_impl(exon_hip_stream* st, exon_hip_scan* scan, int64_t* 
       }
       if (end) {
         if (rows) *rows = n;
-        return EXON_HIP_OK;
+        return exon_hip_stream_set_null_group(st, nullptr);  // (flushes what is staged while the scan's dictionary is at hand)
       }
     } catch (const std::exception& e) {
       return fail(nullptr, EXON_HIP_EINVAL, "%s", e.what());
@@ -2742,5 +2761,5 @@ static int consume_scan_impl(exon_hip_stream* st, exon_hip_scan* scan, int64_t* 
     if (rc < 0) return rc;
   }
   if (rows) *rows = n;
-  return EXON_HIP_OK;
+  return exon_hip_stream_set_null_group(st, nullptr);  // (flushes what is staged while the scan's dictionary is at hand)
 }

@@ -24,6 +24,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <functional>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -103,6 +104,9 @@ struct exon_hip_stream {
   double t_copy = 0, t_wait = 0, t_enqueue = 0;  // EXON_HIP_STAGE_TRACE: staging copies / waits for a free slot / H2D + launch calls
   bool overwrite_next = false;  // exon_hip_stream_reset: the next launch DEFINES the state (no zeroing kernel)
   int x_type = -1, y_type = -1; // K4 fed by a scan: the INFO fields' types from the file's header (-1: the plan's)
+  // K4 fed by a scan whose group key is nullable (a String INFO key): the id the scan's dictionary gives the NULL group, asked for
+  // when the first NULL key is staged (exon_hip_stream_set_null_group)
+  std::function<int32_t()> null_group;
   uint8_t* d_gather = nullptr;  // [world][state words] receive buffer of the all-gather merge
   size_t gather_bytes = 0;
   // ---- group keys by VALUE (ABI 4).  A plan that groups by a dictionary-encoded key (K3 reference, K4 filter) indexes its
@@ -462,12 +466,22 @@ static int flush_slot(exon_hip_stream* st) {
   for (int c = 0; c < p->n_cols; ++c) {
     ColStage& cs = s.cols[(size_t)c];
     const size_t vbytes = p->cols[c].utf8 ? (size_t)s.bytes : (size_t)s.rows * (size_t)p->cols[c].elem;
+    bool null_key_rewritten = false;
+    if (cs.any_null_bitmap && c == 2 && p->d.kind == EXON_HIP_PLAN_CMP_AVG_BY_GROUP && st->null_group) {
+      // a NULL group key becomes the scan's id of the NULL group (in the staging copy, before it goes to HBM): no bitmap
+      const int32_t id = st->null_group();
+      if (id < 0) return fail(st->ctx, EXON_HIP_ESTATE, "the scan has no dictionary for its nullable group key");
+      int32_t* ids = reinterpret_cast<int32_t*>(cs.h_values);
+      for (int64_t i = 0; i < s.rows; ++i)
+        if (!((cs.h_valid[i >> 3] >> (i & 7)) & 1)) ids[i] = id;
+      null_key_rewritten = true;
+    }
     if (vbytes) HIP_TRY(st->ctx, hipMemcpyAsync(cs.d_values, cs.h_values, vbytes, hipMemcpyHostToDevice, st->stream));
     cols[c].values = cs.d_values;
     cols[c].validity = nullptr;
     cols[c].offsets = nullptr;
     cols[c].length = s.rows;
-    if (cs.any_null_bitmap) {
+    if (cs.any_null_bitmap && !null_key_rewritten) {
       HIP_TRY(st->ctx, hipMemcpyAsync(cs.d_valid, cs.h_valid, (size_t)(s.rows + 7) / 8, hipMemcpyHostToDevice, st->stream));
       cols[c].validity = cs.d_valid;
     }
@@ -781,6 +795,13 @@ int exon_hip_stream_plan_column(exon_hip_stream* st, int arg) { return arg >= 0 
 void exon_hip_stream_set_value_types(exon_hip_stream* st, int x_type, int y_type) {
   st->x_type = x_type;
   st->y_type = y_type;
+}
+// (taking the provider away flushes what is staged first: those rows' NULL keys still need it)
+int exon_hip_stream_set_null_group(exon_hip_stream* st, std::function<int32_t()> id_of_null) {
+  int rc = EXON_HIP_OK;
+  if (!id_of_null && st->null_group && !st->closed) rc = flush_slot(st);
+  st->null_group = std::move(id_of_null);
+  return rc;
 }
 // K5 over views into text resident in HBM (FASTQ slabs): scan column 2 = sequence lines, 3 = quality lines
 int exon_hip_stream_launch_views(exon_hip_stream* st, const uint8_t* d_text, const exon_hip_fastq_views& v) {

@@ -591,6 +591,11 @@ int exon_hip_vcf_parser_parse(exon_hip_vcf_parser* parser, void* stream, const u
 int exon_hip_vcf_parser_filters(exon_hip_vcf_parser* parser, char* buf, size_t cap, int32_t* n_filters);
 /* values of the String / Character INFO key `key` (index in the parser's key list) seen so far, '\0'-separated, in id order */
 int exon_hip_vcf_parser_info_values(exon_hip_vcf_parser* parser, int32_t key, char* buf, size_t cap, int32_t* n_values);
+/* on != 0: rows WITHOUT a value of a String / Character key take the dictionary id of the EMPTY text (a value no row can carry:
+ * "key=" is a missing value) and info_nulls stays 0 -- NULL becomes a group key of its own, which is what DataFusion's GROUP BY
+ * does with a nullable key.  exon_hip_stream_consume_scan switches it on (a fused plan cannot skip rows by a key's bitmap);
+ * batches (exon_hip_scan_next) keep NULL as NULL.  In a keyed stream's dictionary the NULL group is the key "". */
+int exon_hip_vcf_parser_set_null_key(exon_hip_vcf_parser* parser, int32_t on);
 int exon_hip_vcf_parser_destroy(exon_hip_vcf_parser* parser);
 
 /* ---- BGZF inflate on the GPU (compressed blocks in HBM -> inflated bytes in HBM) ------------------------------------

@@ -440,7 +440,7 @@ def test_a_plan_that_groups_by_a_string_info_key_stays_on_the_gpu(ctx, tmp_path)
 def test_string_info_key_dictionary_on_the_device_equals_the_host_readers(ctx, tmp_path, monkeypatch):
     """A String key with missing values, '.', a Character key, and rows whose INFO is '.': batches out of the GPU pipeline carry
     the key as a dictionary column with the host reader's VALUES and NULLs (ids may be numbered differently); a GROUP BY over a key
-    with NULLs is refused by name (the fused state has no NULL group) instead of counting them somewhere; more distinct values than
+    with NULLs has a NULL group (the key ""), from the device parser and from the host path alike; more distinct values than
     the device dictionary holds hand the file to the host reader."""
     rng = np.random.default_rng(3)
     head = HEAD.replace("##INFO=<ID=AF", '##INFO=<ID=TYPE,Number=1,Type=Character,Description="t">\n##INFO=<ID=AF')
@@ -468,16 +468,35 @@ def test_string_info_key_dictionary_on_the_device_equals_the_host_readers(ctx, t
     for k in ("info.AF", "info.CSQ", "info.TYPE", "pos"):
         assert dev[k] == host[k], k
     assert dev["info.CSQ"].count(None) > 10000 and set(dev["info.TYPE"]) == {"S", "I", "D", None}
-    # GROUP BY a key that has NULLs: refused by name
-    scan = exon_amd.Scan(str(p), "vcf", info_field="AF,CSQ", gpu_parse=True)
-    plan = ctx.plan_cmp_avg_by_group(">", 0.01, 64, columns=(4, 2, 5))
-    st = plan.open()
-    with pytest.raises(exon_amd.ExonHipError) as e:
-        st.consume(scan)
-    assert "nullable group ids" in str(e.value)
-    st.close()
-    plan.close()
-    scan.close()
+    # GROUP BY a key that has NULLs: NULL is a group of its own (DataFusion's GROUP BY), carried as the key "" -- the id of the empty
+    # text, which no row can have as a value -- by the device parser and, with EXON_HIP_GPU_PARSE off, by the host path
+    want = {}
+    for i in range(60000):
+        k = i % 11
+        if k == 0:
+            continue  # INFO '.': AF is NULL, the row does not pass
+        key = "" if k in (1, 2) else None
+        if key is None:
+            key = host["info.CSQ"][i]
+        w = want.setdefault(key, [0, 0, 0.0])
+        w[0] += 1
+        w[1] += 1
+        w[2] += float(i % 97)
+    assert "" in want and want[""][0] == 2 * (60000 // 11) + (1 if 60000 % 11 > 1 else 0) + (1 if 60000 % 11 > 2 else 0)
+    for gpu in (True, False):
+        scan = exon_amd.Scan(str(p), "vcf", info_field="AF,CSQ", gpu_parse=gpu)
+        plan = ctx.plan_cmp_avg_by_group(">", 0.01, 64, columns=(4, 2, 5))
+        st = plan.open()
+        assert st.consume(scan) == 60000 and scan.decoded_on_gpu()[0] == gpu
+        counts, sums = st.finish()
+        names = scan.dictionary(5)
+        got = {names[g]: [int(counts[64 + g]), int(counts[g]), float(sums[g])] for g in range(len(names)) if counts[64 + g]}
+        assert got.keys() == want.keys(), gpu
+        for k in want:
+            assert got[k][:2] == want[k][:2] and got[k][2] == pytest.approx(want[k][2], rel=1e-12), (gpu, k)
+        st.close()
+        plan.close()
+        scan.close()
     # more distinct values than the device dictionary holds: the host reader takes the file (and builds every value)
     q = tmp_path / "many.vcf"
     q.write_text(HEAD + "".join(f"1\t{i + 1}\t.\tA\tC\t1\tPASS\tAF=0.5;CSQ=v{i}\n" for i in range(9000)))
