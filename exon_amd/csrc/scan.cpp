@@ -784,11 +784,12 @@ class GpuTextSource {
     }
     gap_ = gz_ ? std::max<size_t>(text_cap_ / 16, 16u << 20) : std::max<size_t>(text_cap_ / 4, 1u << 20);  // room for the carried tail (< 1 record + 1 line)
   }
-  // Plain-gzip slabs are cut by OUTPUT bytes: 512 MiB of text per slab = ~4000 chunks of 64 KiB at FASTQ's ratio of 2, one per
-  // wavefront slot of the decode kernel (17 per CU); 20 M-read .fastq.gz: 256 MiB 517 ms, 512 MiB 380 ms, 1 GiB 343 ms
-  // (profiles/r6_plain_gzip.log).  EXON_HIP_GZ_SLAB_MB overrides.
+  // Plain-gzip slabs are cut by OUTPUT bytes: 1 GiB of text per slab (a decode call has fixed costs -- the host's proof of the
+  // chunk chain, its round trips --, and its chunk size follows the wavefront slots anyway).  End of round 6
+  // (profiles/r6_plain_gzip.log): 20 M-read .fastq.gz 306 ms at 512 MiB, 240 ms at 1 GiB; 100 M-row .vcf.gz 267 / 220 ms; 30 M rows
+  // 104 / 97 ms.  EXON_HIP_GZ_SLAB_MB overrides.
   static size_t gz_slab_bytes() {
-    size_t slab = (size_t)512 << 20;
+    size_t slab = (size_t)1024 << 20;
     if (const char* v = getenv("EXON_HIP_GZ_SLAB_MB")) {
       const long mb = atol(v);
       if (mb >= 1 && mb <= 4096) slab = (size_t)mb << 20;
