@@ -1818,12 +1818,15 @@ struct HostText {
   Span<int32_t> off[3], item_off;
   Span<uint8_t> val[3], valid[2];
   Span<int64_t> qual;
+  Span<int32_t> zeros;  // n_rows + 1 zero offsets: the item-less `alt` lists
   void* blk = nullptr;
   size_t blk_bytes = 0;
-  ~HostText() {
-    if (blk) export_block_put(blk, blk_bytes);
-  }
+  exon::SharedBlock* sb = nullptr;  // the block, shared with the batches that are views into it
+  ~HostText() { exon::block_unref(sb); }
 };
+// EXON_HIP_PIPE_TRACE: where a slab's export spends its time (seconds, one producer thread)
+static double g_t_batches = 0, g_t_release = 0, g_t_text_batch = 0, g_t_views = 0;
+static double g_t_text_kernels = 0, g_t_fetch_text = 0, g_t_fetch_cols = 0, g_t_block_get = 0, g_t_enqueue = 0, g_t_names = 0;
 static int fetch_text(exon_hip_ctx* ctx, hipStream_t hs, int64_t n_rows, uint64_t projection, const ExonVcfText* vt, const ExonBamText* bt, HostText* h) {
   h->projection = projection;
   struct Want {
@@ -1850,7 +1853,10 @@ static int fetch_text(exon_hip_ctx* ctx, hipStream_t hs, int64_t n_rows, uint64_
       get(h->off[2], vt->ref_offsets, n + 1);
       get(h->val[2], vt->ref_values, (size_t)vt->n_ref_bytes);
     }
-    if (projection & EXON_HIP_PROJECT_VCF_ALT) get(h->valid[1], vt->alt_valid, nb);
+    if (projection & EXON_HIP_PROJECT_VCF_ALT) {
+      get(h->valid[1], vt->alt_valid, nb);
+      get(h->zeros, nullptr, n + 1);  // (no source: cleared below)
+    }
   }
   if (bt) {
     h->bam = true;
@@ -1870,13 +1876,20 @@ static int fetch_text(exon_hip_ctx* ctx, hipStream_t hs, int64_t n_rows, uint64_
   size_t total = 64;
   for (const Want& w : wants) total += (w.count * w.elem + 63) & ~(size_t)63;
   h->blk_bytes = total;
+  const double tb0 = now_s();
   h->blk = export_block_get(&h->blk_bytes);
+  g_t_block_get += now_s() - tb0;
   if (!h->blk) return fail(ctx, EXON_HIP_ENOMEM, "no pinned block of %zu bytes for a slab's string columns", total);
+  h->sb = new exon::SharedBlock();
+  h->sb->block = h->blk;
+  h->sb->bytes = h->blk_bytes;
+  h->sb->put = export_block_put;
   hipError_t e = hipSuccess;
   size_t at = 0;
   for (const Want& w : wants) {
     uint8_t* dst = static_cast<uint8_t*>(h->blk) + at;
     w.place(dst);
+    if (!w.src) memset(dst, 0, w.count * w.elem);
     if (e == hipSuccess && w.count && w.src) e = hipMemcpyAsync(dst, w.src, w.count * w.elem, hipMemcpyDeviceToHost, hs);
     at += (w.count * w.elem + 63) & ~(size_t)63;
   }
@@ -1885,7 +1898,36 @@ static int fetch_text(exon_hip_ctx* ctx, hipStream_t hs, int64_t n_rows, uint64_
   return EXON_HIP_OK;
 }
 // the projected columns of the rows `rows[0 .. n)` of the slab (in the order of the projection bits), appended to `kids`
+// Without a row list (no pushed-down region) the batch's columns are VIEWS into the slab's pinned block: the slab-wide validity /
+// offsets / data buffers with ArrowArray::offset = the batch's first row, the item arrays of the lists shared by reference -- no
+// per-row work on the host (profiles/r6_scan_next_native.log).
 static void text_batch(const HostText& h, const int64_t* rows, int64_t r0, int64_t n, std::vector<struct ArrowArray*>* kids) {
+  if (!rows) {
+    auto utf8_view = [&](const Span<int32_t>& off, const Span<uint8_t>& val, const Span<uint8_t>* valid, int64_t first, int64_t len) {
+      return exon::new_view_array_ex(h.sb, {valid ? (const void*)valid->data() : nullptr, off.data(), val.data()}, len, valid ? -1 : 0, first);
+    };
+    if (h.vcf) {
+      if (h.projection & EXON_HIP_PROJECT_VCF_ID) {
+        struct ArrowArray* items = utf8_view(h.item_off, h.val[0], nullptr, 0, (int64_t)h.item_off.n - 1);
+        kids->push_back(exon::new_view_array_ex(h.sb, {h.valid[0].data(), h.off[0].data()}, n, -1, r0, {items}));
+      }
+      if (h.projection & EXON_HIP_PROJECT_VCF_REF) kids->push_back(utf8_view(h.off[2], h.val[2], nullptr, r0, n));
+      if (h.projection & EXON_HIP_PROJECT_VCF_ALT) {
+        struct ArrowArray* items = exon::new_view_array_ex(h.sb, {nullptr, h.zeros.data(), h.zeros.data()}, 0, 0, 0);
+        kids->push_back(exon::new_view_array_ex(h.sb, {h.valid[1].data(), h.zeros.data()}, n, -1, r0, {items}));
+      }
+    }
+    if (h.bam) {
+      if (h.projection & EXON_HIP_PROJECT_BAM_NAME) kids->push_back(utf8_view(h.off[0], h.val[0], &h.valid[0], r0, n));
+      if (h.projection & EXON_HIP_PROJECT_BAM_CIGAR) kids->push_back(utf8_view(h.off[1], h.val[1], nullptr, r0, n));
+      if (h.projection & EXON_HIP_PROJECT_BAM_SEQUENCE) kids->push_back(utf8_view(h.off[2], h.val[2], nullptr, r0, n));
+      if (h.projection & EXON_HIP_PROJECT_BAM_QUALITY_SCORES) {
+        struct ArrowArray* items = exon::new_view_array_ex(h.sb, {nullptr, h.qual.data()}, (int64_t)h.qual.n, 0, 0);
+        kids->push_back(exon::new_view_array_ex(h.sb, {nullptr, h.off[2].data()}, n, 0, r0, {items}));
+      }
+    }
+    return;
+  }
   auto row_at = [&](int64_t i) { return rows ? rows[i] : r0 + i; };
   auto bit = [&](const Span<uint8_t>& bm, int64_t r) { return (uint8_t)((bm[(size_t)(r >> 3)] >> (r & 7)) & 1); };
   auto utf8 = [&](const Span<int32_t>& off, const Span<uint8_t>& val, const Span<uint8_t>* valid) {
@@ -1948,9 +1990,12 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
   exon_hip_ctx* ctx = ex->ctx;
   HostText text;
   if ((vt || bt) && scan->opt.projection) {
+    const double tf0 = now_s();
     const int rc = fetch_text(ctx, hs, n_rows, scan->opt.projection, vt, bt, &text);
+    g_t_fetch_text += now_s() - tf0;
     if (rc) return rc;
   }
+  const double tc0 = now_s();
   const bool vcf_like = scan->vcf || scan->bcf;
   const std::vector<exon::InfoSpec>* specs = scan->vcf ? &scan->vcf->info_specs : scan->bcf ? &scan->bcf->info_specs : nullptr;
   const int n_cols = vcf_like ? 4 + (int)specs->size() : 5;
@@ -1997,6 +2042,8 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
   if (e == hipSuccess && row_mask) e = hipMemcpyAsync(blk + moff, row_mask, (size_t)(n_rows + 7) / 8, hipMemcpyDeviceToHost, hs);
   if (e == hipSuccess) e = hipStreamSynchronize(hs);
   if (e != hipSuccess) return fail(ctx, EXON_HIP_EDEVICE, "columns of a slab back to the host: %s", hipGetErrorString(e));
+  g_t_fetch_cols += now_s() - tc0;
+  const double tn0 = now_s();
   std::vector<std::string> filters;
   if (vcf_like) {
     const int rc = gpu_filter_names(scan, &filters);
@@ -2007,6 +2054,7 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
     const int rc = gpu_info_names(scan, &info_names);
     if (rc) return rc;
   }
+  g_t_names += now_s() - tn0;
   const int64_t bs = scan->opt.batch_size > 0 ? scan->opt.batch_size : 8192;
   auto dict_of_col = [&](int c) -> struct ArrowArray* {
     if (vcf_like && c == 0) return exon::utf8_array(scan->vcf ? scan->vcf->chrom_dict.names : scan->bcf->chrom_dict.names);
@@ -2018,8 +2066,10 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
   auto enqueue = [&](std::vector<struct ArrowArray*> kids, int64_t n) -> int {
     struct ArrowArray* out = static_cast<struct ArrowArray*>(malloc(sizeof *out));
     exon::make_struct(out, n, std::move(kids));
+    const double te0 = now_s();
     std::unique_lock<std::mutex> lk(ex->mu);
     ex->cv_put.wait(lk, [&] { return ex->stop || ex->q.size() < ex->cap; });
+    g_t_enqueue += now_s() - te0;
     if (ex->stop) {
       lk.unlock();
       out->release(out);
@@ -2033,9 +2083,14 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
     return EXON_HIP_OK;
   };
   if (!row_mask) {
+    struct Tm {
+      double t0 = now_s();
+      ~Tm() { g_t_batches += now_s() - t0; }
+    } tm;
     for (int64_t b0 = 0; b0 < n_rows; b0 += bs) {
       const int64_t n = std::min(n_rows, b0 + bs) - b0;
       std::vector<struct ArrowArray*> kids;
+      const double tv0 = now_s();
       for (int c = 0; c < n_cols; ++c) {
         const void* bits = has_bits[(size_t)c] ? blk + boff[(size_t)c] : nullptr;
         const void* vals = elem[(size_t)c] ? (const void*)(blk + voff[(size_t)c]) : bits;  // a Flag: true where present
@@ -2043,7 +2098,10 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
         a->offset = b0;
         kids.push_back(a);
       }
+      const double tv1 = now_s();
+      g_t_views += tv1 - tv0;
       if (text.vcf || text.bam) text_batch(text, nullptr, b0, n, &kids);
+      g_t_text_batch += now_s() - tv1;
       const int rc = enqueue(std::move(kids), n);
       if (rc) return rc;
     }
@@ -2323,8 +2381,10 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
             // the reference's string / list columns of this slab, built on the device from the index the parser has just made
             ExonVcfText vt;
             ExonBamText bt;
+            const double tk0 = now_s();
             rc = is_vcf ? exon_text_vcf(ctx, hs, &scan->text_scratch, d_text, (int64_t)n, exon_hip_vcf_parser_newlines(scan->parser), n_rows, scan->opt.projection, &vt)
                         : exon_text_bam(ctx, hs, &scan->text_scratch, d_text, (int64_t)n, exon_hip_bam_parser_row_records(scan->bam_parser), n_rows, scan->opt.projection, &bt);
+            g_t_text_kernels += now_s() - tk0;
             if (!rc) rc = export_slab(scan, sc, n_rows, row_mask, hs, is_vcf ? &vt : nullptr, is_bam ? &bt : nullptr);
           } else
           rc = scan->exporter ? export_slab(scan, sc, n_rows, row_mask, hs)
@@ -2346,7 +2406,9 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
       }
       if (rc) break;
       if (!final && n > 0 && consumed == 0) { rc = 1; break; }  // a record larger than a slab
+      const double tr0 = now_s();
       rc = src->release(consumed, final);
+      g_t_release += now_s() - tr0;
       if (rc || final) break;
     }
     if (hipStreamSynchronize(hs) != hipSuccess && rc == EXON_HIP_OK) rc = fail(ctx, EXON_HIP_EDEVICE, "stream synchronize failed");
@@ -2355,6 +2417,9 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
   }
   const double t_loop = now_s();
   if (trace)
+    if (scan->exporter)
+      fprintf(stderr, "[exon-hip pipe] export (cumulative over this process): text kernels %.1f ms, text columns D2H %.1f (pinned block %.1f), path columns D2H %.1f, names %.1f, batches %.1f (path views %.1f, text views %.1f, waiting for the consumer %.1f), slab release %.1f\n",
+              g_t_text_kernels * 1e3, g_t_fetch_text * 1e3, g_t_block_get * 1e3, g_t_fetch_cols * 1e3, g_t_names * 1e3, g_t_batches * 1e3, g_t_views * 1e3, g_t_text_batch * 1e3, g_t_enqueue * 1e3, g_t_release * 1e3);
     fprintf(stderr, "[exon-hip pipe] setup %.1f ms, loop %.1f ms (%zu source(s); slabs: wait+H2D+inflate %.1f, parse %.1f, other %.1f; file reader busy %.1f)\n",
             (t_init - t_begin) * 1e3, (t_loop - t_init) * 1e3, n_sources, t_next * 1e3, t_parse * 1e3, (t_loop - t_init - t_next - t_parse) * 1e3, t_reader * 1e3);
   if (rc == EXON_HIP_OK && filtered) {  // the scan emitted the rows that hit the region
