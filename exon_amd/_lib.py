@@ -87,7 +87,7 @@ class BAMColumns(C.Structure):
 class FASTQViews(C.Structure):
     _fields_ = [("n_reads", C.c_int64), ("n_undecided", C.c_int64), ("consumed_bytes", C.c_int64),
                 ("seq_start", C.c_void_p), ("seq_end", C.c_void_p), ("qual_start", C.c_void_p), ("qual_end", C.c_void_p),
-                ("text_base", C.c_void_p)]
+                ("text_base", C.c_void_p), ("head_start", C.c_void_p), ("head_end", C.c_void_p)]
 
 
 class VCFColumns(C.Structure):

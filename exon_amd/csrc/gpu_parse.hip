@@ -1142,7 +1142,8 @@ namespace {
 __global__ __launch_bounds__(TPB) void k_fastq_views(const uint8_t* __restrict__ text, const unsigned* __restrict__ nl,
                                                      unsigned* __restrict__ scalars, unsigned cap_lines, int final_slab,
                                                      int32_t* __restrict__ seq_s, int32_t* __restrict__ seq_e,
-                                                     int32_t* __restrict__ qual_s, int32_t* __restrict__ qual_e, unsigned skip) {
+                                                     int32_t* __restrict__ qual_s, int32_t* __restrict__ qual_e, int32_t* __restrict__ head_s,
+                                                     int32_t* __restrict__ head_e, unsigned skip) {
   const unsigned n_lines = scalars[0];
   const int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x;
   if (n_lines > cap_lines) {  // the index was truncated: nothing can be trusted
@@ -1165,6 +1166,10 @@ __global__ __launch_bounds__(TPB) void k_fastq_views(const uint8_t* __restrict__
   seq_e[r] = (int32_t)se;
   qual_s[r] = (int32_t)(e2 + 1);
   qual_e[r] = (int32_t)qe;
+  unsigned he = e0;  // the header line behind its '@', CR dropped (name + description: exon-fastq/src/array_builder.rs:68-102)
+  if (he > l0 + 1 && text[he - 1] == '\r') --he;
+  head_s[r] = (int32_t)(l0 + 1);
+  head_e[r] = (int32_t)he;
   if (bad) atomicAdd(&scalars[1], 1u);
 }
 
@@ -1176,7 +1181,7 @@ struct exon_hip_fastq_parser {
   unsigned *d_block_counts = nullptr, *d_nl = nullptr, *d_scalars = nullptr;
   int64_t index_blocks = 0;
   unsigned index_gen = 0;
-  int32_t* d_views = nullptr;  // 4 arrays of max_lines / 4 + 1
+  int32_t* d_views = nullptr;  // 6 arrays of max_lines / 4 + 1
   unsigned* h_scalars = nullptr;
 };
 
@@ -1203,7 +1208,7 @@ int exon_hip_fastq_parser_create(exon_hip_ctx* ctx, int64_t max_bytes, exon_hip_
   if (e == hipSuccess && p->d_block_counts) e = hipMemset(p->d_block_counts, 0, ((size_t)nblocks + 1) * 8);
   dalloc((void**)&p->d_nl, (size_t)p->max_lines * 4);
   dalloc((void**)&p->d_scalars, 16);
-  dalloc((void**)&p->d_views, per * 4 * 4);
+  dalloc((void**)&p->d_views, per * 6 * 4);
   if (e == hipSuccess) e = hipHostMalloc((void**)&p->h_scalars, 16);
   if (e != hipSuccess) {
     const std::string msg = hipGetErrorString(e);
@@ -1244,7 +1249,7 @@ int exon_hip_fastq_parser_parse(exon_hip_fastq_parser* p, void* stream, const ui
   launch_line_index(s, d_text, n_bytes, skip, p->d_block_counts, p->index_blocks, nblocks, &p->index_gen, p->d_nl, (unsigned)p->max_lines, p->d_scalars);
   const int64_t read_bound = std::min<int64_t>((int64_t)per, n_bytes / 4 + 1);  // a record holds 4 newlines
   hipLaunchKernelGGL(k_fastq_views, dim3((unsigned)((read_bound + TPB - 1) / TPB)), dim3(TPB), 0, s, d_text, p->d_nl, p->d_scalars,
-                     (unsigned)p->max_lines, (int)final_slab, v, v + per, v + 2 * per, v + 3 * per, skip);
+                     (unsigned)p->max_lines, (int)final_slab, v, v + per, v + 2 * per, v + 3 * per, v + 4 * per, v + 5 * per, skip);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(p->h_scalars, p->d_scalars, 16, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -1256,6 +1261,8 @@ int exon_hip_fastq_parser_parse(exon_hip_fastq_parser* p, void* stream, const ui
   views->seq_end = v + per;
   views->qual_start = v + 2 * per;
   views->qual_end = v + 3 * per;
+  views->head_start = v + 4 * per;
+  views->head_end = v + 5 * per;
   return EXON_HIP_OK;
 }
 

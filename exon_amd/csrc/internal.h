@@ -75,6 +75,13 @@ int exon_text_vcf(exon_hip_ctx* ctx, void* stream, ExonTextScratch** scratch, co
                   ExonVcfText* out);
 int exon_text_bam(exon_hip_ctx* ctx, void* stream, ExonTextScratch** scratch, const uint8_t* d_data, int64_t n_bytes, const uint32_t* d_rec_of_row, int64_t n_rows, uint64_t projection,
                   ExonBamText* out);
+struct ExonFastqText {  // name, description, sequence, quality_scores (exon-fastq/src/config.rs:79-88), in that order
+  const int32_t* offsets[4];  // [n_reads + 1] each
+  const uint8_t* values[4];
+  int64_t n_bytes[4];
+  const uint8_t* desc_valid;  // bitmap: the header has something behind its first space
+};
+int exon_text_fastq(exon_hip_ctx* ctx, void* stream, ExonTextScratch** scratch, const exon_hip_fastq_views* views, int64_t n_bytes, ExonFastqText* out);
 void exon_text_scratch_destroy(ExonTextScratch* s);
 // the parsers' own indexes the text columns are built from (valid until the next parse call)
 const unsigned* exon_hip_vcf_parser_newlines(exon_hip_vcf_parser* p);      // gpu_parse.hip: byte offset of every line's '\n' in the aligned slab

@@ -94,6 +94,7 @@ struct GpuExporter {
   std::unique_ptr<exon::BAMBatchReader> fb_bam;
   std::unique_ptr<exon::SAMBatchReader> fb_sam;
   std::unique_ptr<exon::BCFBatchReader> fb_bcf;
+  std::unique_ptr<exon::FASTQBatchReader> fb_fastq;
   bool handed_over = false;
 };
 
@@ -430,8 +431,8 @@ int exon_hip_index_query(const char* index_path, int32_t is_bai, const char* ref
 int exon_hip_scan_bind_ctx(exon_hip_scan* s, exon_hip_ctx* ctx) {
   if (!s || !ctx) return fail(ctx, EXON_HIP_EINVAL, "exon_hip_scan_bind_ctx: NULL argument");
   if (s->exporter) return fail(ctx, EXON_HIP_ESTATE, "the scan is bound to a context already");
-  if (!(s->vcf || s->bcf || s->bam || s->sam))
-    return fail(ctx, EXON_HIP_EUNSUPPORTED, "batches from the GPU pipeline: VCF, BCF, BAM and SAM scans (FASTQ / FASTA / CRAM batches come from the host readers)");
+  if (!(s->vcf || s->bcf || s->bam || s->sam || s->fastq))
+    return fail(ctx, EXON_HIP_EUNSUPPORTED, "batches from the GPU pipeline: VCF, BCF, BAM, SAM and FASTQ scans (FASTA / CRAM batches come from the host readers)");
   if (!s->gpu_parse)  // not opened with gpu_parse, or String / list-valued INFO keys were named: the host reader builds those columns
     return fail(ctx, EXON_HIP_EUNSUPPORTED, "this scan's batches come from the host reader (opened without gpu_parse, or it names INFO keys only the host reader builds)");
   if (s->rows != 0) return fail(ctx, EXON_HIP_ESTATE, "the scan has been read from already");
@@ -2149,6 +2150,67 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
   return EXON_HIP_OK;
 }
 
+// FASTQ batches from the GPU pipeline: the slab's four Utf8 columns (text_columns.hip: name, description?, sequence,
+// quality_scores -- exon-fastq/src/config.rs:79-88) come back into ONE pinned block and go out as batch_size-row views into it
+// (slab-wide offsets / data buffers, ArrowArray::offset = the batch's first read).
+static int export_fastq_slab(exon_hip_scan* scan, const ExonFastqText& ft, int64_t n_reads, hipStream_t hs) {
+  GpuExporter* ex = scan->exporter;
+  exon_hip_ctx* ctx = ex->ctx;
+  if (n_reads == 0) return EXON_HIP_OK;
+  const size_t n = (size_t)n_reads;
+  auto pad = [](size_t b) { return (b + 63) & ~size_t(63); };
+  size_t at_off[4], at_val[4], total = 64;
+  for (int k = 0; k < 4; ++k) {
+    at_off[k] = total;
+    total += pad((n + 1) * 4);
+    at_val[k] = total;
+    total += pad((size_t)ft.n_bytes[k] + 8);
+  }
+  const size_t at_valid = total;
+  total += pad((n + 7) / 8 + 8);
+  size_t blk_bytes = total;
+  uint8_t* blk = static_cast<uint8_t*>(export_block_get(&blk_bytes));
+  if (!blk) return fail(ctx, EXON_HIP_ENOMEM, "no pinned block of %zu bytes for a slab of reads", total);
+  exon::SharedBlock* sb = new exon::SharedBlock();
+  sb->block = blk;
+  sb->bytes = blk_bytes;
+  sb->put = export_block_put;
+  struct Unref {
+    exon::SharedBlock* b;
+    ~Unref() { exon::block_unref(b); }
+  } unref{sb};
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < 4 && e == hipSuccess; ++k) {
+    e = hipMemcpyAsync(blk + at_off[k], ft.offsets[k], (n + 1) * 4, hipMemcpyDeviceToHost, hs);
+    if (e == hipSuccess && ft.n_bytes[k]) e = hipMemcpyAsync(blk + at_val[k], ft.values[k], (size_t)ft.n_bytes[k], hipMemcpyDeviceToHost, hs);
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(blk + at_valid, ft.desc_valid, (n + 7) / 8, hipMemcpyDeviceToHost, hs);
+  if (e == hipSuccess) e = hipStreamSynchronize(hs);
+  if (e != hipSuccess) return fail(ctx, EXON_HIP_EDEVICE, "reads of a slab back to the host: %s", hipGetErrorString(e));
+  const int64_t bs = scan->opt.batch_size > 0 ? scan->opt.batch_size : 8192;
+  for (int64_t b0 = 0; b0 < n_reads; b0 += bs) {
+    const int64_t m = std::min(n_reads, b0 + bs) - b0;
+    std::vector<struct ArrowArray*> kids;
+    for (int k = 0; k < 4; ++k)
+      kids.push_back(exon::new_view_array_ex(sb, {k == 1 ? (const void*)(blk + at_valid) : nullptr, blk + at_off[k], blk + at_val[k]}, m, k == 1 ? -1 : 0, b0));
+    struct ArrowArray* out = static_cast<struct ArrowArray*>(malloc(sizeof *out));
+    exon::make_struct(out, m, std::move(kids));
+    std::unique_lock<std::mutex> lk(ex->mu);
+    ex->cv_put.wait(lk, [&] { return ex->stop || ex->q.size() < ex->cap; });
+    if (ex->stop) {
+      lk.unlock();
+      out->release(out);
+      free(out);
+      return 2;
+    }
+    ex->q.push_back(out);
+    ex->emitted += m;
+    lk.unlock();
+    ex->cv_get.notify_one();
+  }
+  return EXON_HIP_OK;
+}
+
 static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* rows_out) {
   const bool trace = getenv("EXON_HIP_PIPE_TRACE") != nullptr;  // phase timings on stderr
   const double t_begin = now_s();
@@ -2399,7 +2461,12 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
         if (!rc && !final && v.consumed_bytes == 0) rc = 1;  // not one whole record in a slab
         if (rc) break;
         consumed = (size_t)v.consumed_bytes;
-        if (v.n_reads > 0) {
+        if (v.n_reads > 0 && scan->exporter) {  // batches: the four Utf8 columns, built on the device
+          ExonFastqText ft;
+          rc = exon_text_fastq(ctx, hs, &scan->text_scratch, &v, (int64_t)n + 16, &ft);
+          if (!rc) rc = export_fastq_slab(scan, ft, v.n_reads, hs);
+          total += v.n_reads;
+        } else if (v.n_reads > 0) {
           rc = exon_hip_stream_launch_views(st, d_text, v);  // asynchronous: overlaps with preparing the next slab
           total += v.n_reads;
         }
@@ -2500,6 +2567,11 @@ static void open_fallback_reader(exon_hip_scan* scan, GpuExporter* ex) {
     ex->fb_bcf.reset(new exon::BCFBatchReader(scan->path, cfg));
   } else if (scan->sam) {
     ex->fb_sam.reset(new exon::SAMBatchReader(scan->path, c, scan->sam->config()));
+  } else if (scan->fastq) {
+    exon::FASTQConfig cfg = scan->fastq->config();
+    cfg.defer_decode = false;
+    cfg.threads = 0;
+    ex->fb_fastq.reset(new exon::FASTQBatchReader(scan->path, c, cfg));
   }
 }
 
@@ -2532,7 +2604,7 @@ static void gpu_export_producer(exon_hip_scan* scan) {
       for (;;) {
         struct ArrowArray* out = static_cast<struct ArrowArray*>(malloc(sizeof *out));
         memset(out, 0, sizeof *out);
-        const bool got = ex->fb_vcf ? ex->fb_vcf->read_batch(out) : ex->fb_bam ? ex->fb_bam->read_batch(out) : ex->fb_bcf ? ex->fb_bcf->read_batch(out) : ex->fb_sam->read_batch(out);
+        const bool got = ex->fb_vcf ? ex->fb_vcf->read_batch(out) : ex->fb_bam ? ex->fb_bam->read_batch(out) : ex->fb_bcf ? ex->fb_bcf->read_batch(out) : ex->fb_sam ? ex->fb_sam->read_batch(out) : ex->fb_fastq->read_batch(out);
         if (!got) {
           free(out);
           break;
@@ -2620,6 +2692,8 @@ static int gpu_next(exon_hip_scan* s, struct ArrowArray* out) {
       s->bam = std::move(ex->fb_bam);
     } else if (ex->fb_sam) {
       s->sam = std::move(ex->fb_sam);
+    } else if (ex->fb_fastq) {
+      s->fastq = std::move(ex->fb_fastq);
     }
     ex->handed_over = false;
     ex->final_filters.clear();

@@ -239,18 +239,72 @@ __global__ __launch_bounds__(TPB) void k_bam_fill(const uint8_t* __restrict__ d,
 }  // namespace
 
 // ---- host side -----------------------------------------------------------------------------------------------------------------------
+// ---- FASTQ -------------------------------------------------------------------------------------------------------------------------
+// name, description, sequence, quality_scores (exon-fastq/src/array_builder.rs:68-102; schema exon-fastq/src/config.rs:79-88): the
+// header line behind '@' up to the first space is the name, what follows the space the description (NULL when there is no space
+// or nothing behind it); sequence and quality lines as they are (CR dropped by the views).
+struct FastqLens {
+  uint32_t *name, *desc, *seq, *qual;
+};
+__global__ __launch_bounds__(TPB) void k_fastq_measure(const uint8_t* __restrict__ text, unsigned n_reads, const int32_t* __restrict__ head_s,
+                                                       const int32_t* __restrict__ head_e, const int32_t* __restrict__ seq_s, const int32_t* __restrict__ seq_e,
+                                                       const int32_t* __restrict__ qual_s, const int32_t* __restrict__ qual_e, FastqLens o,
+                                                       uint32_t* __restrict__ desc_valid) {
+  const unsigned r = blockIdx.x * TPB + threadIdx.x;
+  bool has_desc = false;
+  if (r < n_reads) {
+    const unsigned b = (unsigned)head_s[r], e = (unsigned)head_e[r];
+    unsigned sp = b;
+    while (sp < e && text[sp] != ' ') ++sp;
+    o.name[r] = sp - b;
+    has_desc = sp + 1 < e;
+    o.desc[r] = has_desc ? e - sp - 1 : 0u;
+    o.seq[r] = (unsigned)(seq_e[r] - seq_s[r]);
+    o.qual[r] = (unsigned)(qual_e[r] - qual_s[r]);
+  }
+  const unsigned long long m = __ballot(has_desc);
+  if ((threadIdx.x & 63) == 0 && r < n_reads + 63) {
+    desc_valid[r >> 5] = (uint32_t)m;
+    desc_valid[(r >> 5) + 1] = (uint32_t)(m >> 32);
+  }
+}
+// bytes [src, src + n) of the text to dst: 8 at a time (unaligned on both sides: the hardware takes it), the rest one by one
+__device__ __forceinline__ void copy_run(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, unsigned n) {
+  unsigned i = 0;
+  for (; i + 8 <= n; i += 8) {
+    const uint32_t a = *reinterpret_cast<const uint32_t*>(src + i), b = *reinterpret_cast<const uint32_t*>(src + i + 4);
+    *reinterpret_cast<uint32_t*>(dst + i) = a;
+    *reinterpret_cast<uint32_t*>(dst + i + 4) = b;
+  }
+  for (; i < n; ++i) dst[i] = src[i];
+}
+__global__ __launch_bounds__(TPB) void k_fastq_fill(const uint8_t* __restrict__ text, unsigned n_reads, const int32_t* __restrict__ head_s,
+                                                    const int32_t* __restrict__ seq_s, const int32_t* __restrict__ qual_s, const int32_t* __restrict__ name_off,
+                                                    const int32_t* __restrict__ desc_off, const int32_t* __restrict__ seq_off, const int32_t* __restrict__ qual_off,
+                                                    uint8_t* __restrict__ name_v, uint8_t* __restrict__ desc_v, uint8_t* __restrict__ seq_v,
+                                                    uint8_t* __restrict__ qual_v) {
+  const unsigned r = blockIdx.x * TPB + threadIdx.x;
+  if (r >= n_reads) return;
+  const unsigned nn = (unsigned)(name_off[r + 1] - name_off[r]), nd = (unsigned)(desc_off[r + 1] - desc_off[r]);
+  copy_run(name_v + name_off[r], text + head_s[r], nn);
+  if (nd) copy_run(desc_v + desc_off[r], text + head_s[r] + nn + 1, nd);
+  copy_run(seq_v + seq_off[r], text + seq_s[r], (unsigned)(seq_off[r + 1] - seq_off[r]));
+  copy_run(qual_v + qual_off[r], text + qual_s[r], (unsigned)(qual_off[r + 1] - qual_off[r]));
+}
+
 struct ExonTextScratch {
   exon_hip_ctx* ctx = nullptr;
   int64_t max_rows = 0, max_bytes = 0;
-  uint32_t* len[3] = {nullptr, nullptr, nullptr};
-  int32_t* off[3] = {nullptr, nullptr, nullptr};
+  int n_cols = 3;
+  uint32_t* len[4] = {nullptr, nullptr, nullptr, nullptr};
+  int32_t* off[4] = {nullptr, nullptr, nullptr, nullptr};
   uint32_t* valid[2] = {nullptr, nullptr};
   uint32_t *field_off = nullptr, *field_len = nullptr;
   unsigned* sums = nullptr;
   unsigned* totals = nullptr;    // device [4]
   unsigned* h_totals = nullptr;  // pinned
   int32_t* item_off = nullptr;   // VCF id items
-  uint8_t* values[3] = {nullptr, nullptr, nullptr};
+  uint8_t* values[4] = {nullptr, nullptr, nullptr, nullptr};
   int64_t* qual = nullptr;
   size_t qual_cap = 0;
 };
@@ -258,15 +312,15 @@ struct ExonTextScratch {
 void exon_text_scratch_destroy(ExonTextScratch* s) {
   if (!s) return;
   auto f = [&](void* p) { if (p) exon_pool_free(s->ctx, p); };
-  for (int k = 0; k < 3; ++k) f(s->len[k]), f(s->off[k]), f(s->values[k]);
+  for (int k = 0; k < 4; ++k) f(s->len[k]), f(s->off[k]), f(s->values[k]);
   f(s->valid[0]), f(s->valid[1]), f(s->field_off), f(s->field_len), f(s->sums), f(s->totals), f(s->item_off), f(s->qual);
   if (s->h_totals) hipHostFree(s->h_totals);
   delete s;
 }
 
-static int scratch_for(exon_hip_ctx* ctx, ExonTextScratch** sp, int64_t max_rows, int64_t max_bytes, bool vcf) {
+static int scratch_for(exon_hip_ctx* ctx, ExonTextScratch** sp, int64_t max_rows, int64_t max_bytes, bool vcf, int n_cols = 3) {
   ExonTextScratch* s = *sp;
-  if (s && s->max_rows >= max_rows && s->max_bytes >= max_bytes) return EXON_HIP_OK;
+  if (s && s->max_rows >= max_rows && s->max_bytes >= max_bytes && s->n_cols >= n_cols) return EXON_HIP_OK;
   if (s) exon_text_scratch_destroy(s);
   *sp = nullptr;
   s = new (std::nothrow) ExonTextScratch();
@@ -274,13 +328,14 @@ static int scratch_for(exon_hip_ctx* ctx, ExonTextScratch** sp, int64_t max_rows
   s->ctx = ctx;
   s->max_rows = max_rows;
   s->max_bytes = max_bytes;
+  s->n_cols = n_cols;
   hipSetDevice(ctx->device);
   bool ok = true;
   auto a = [&](void** p, size_t bytes) {
     if (ok && !(*p = exon_pool_alloc(ctx, bytes))) ok = false;
   };
   const size_t r = (size_t)max_rows + 64;
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < n_cols; ++k) {
     a((void**)&s->len[k], r * 4);
     a((void**)&s->off[k], (r + 1) * 4);
     a((void**)&s->values[k], (size_t)max_bytes + 64);
@@ -294,7 +349,7 @@ static int scratch_for(exon_hip_ctx* ctx, ExonTextScratch** sp, int64_t max_rows
   }
   a((void**)&s->sums, (r / TPB + 2) * 4);
   a((void**)&s->totals, 16);
-  if (ok && hipHostMalloc((void**)&s->h_totals, 16) != hipSuccess) ok = false;
+  if (ok && hipHostMalloc((void**)&s->h_totals, 16) != hipSuccess) ok = false;  // (4 totals: the FASTQ columns use them all)
   if (!ok) {
     (void)hipGetLastError();
     exon_text_scratch_destroy(s);
@@ -387,5 +442,33 @@ int exon_text_bam(exon_hip_ctx* ctx, void* stream, ExonTextScratch** sp, const u
   out->seq_values = s->values[2];
   out->n_seq_bytes = seq_bytes;
   out->qual_values = s->qual;
+  return EXON_HIP_OK;
+}
+
+int exon_text_fastq(exon_hip_ctx* ctx, void* stream, ExonTextScratch** sp, const exon_hip_fastq_views* v, int64_t n_bytes, ExonFastqText* out) {
+  memset(out, 0, sizeof *out);
+  const int64_t n_reads = v->n_reads;
+  if (n_reads == 0) return EXON_HIP_OK;
+  int rc = scratch_for(ctx, sp, std::max<int64_t>(n_reads, 1 << 16), std::max<int64_t>(n_bytes, 1 << 20), false, 4);
+  if (rc) return rc;
+  ExonTextScratch* s = *sp;
+  hipStream_t hs = pick_stream(ctx, stream);
+  const unsigned n = (unsigned)n_reads;
+  const int nb = (int)((n + TPB - 1) / TPB);
+  FastqLens L{s->len[0], s->len[1], s->len[2], s->len[3]};
+  hipLaunchKernelGGL(k_fastq_measure, dim3(nb), dim3(TPB), 0, hs, v->text_base, n, v->head_start, v->head_end, v->seq_start, v->seq_end, v->qual_start, v->qual_end, L,
+                     s->valid[0]);
+  for (int k = 0; k < 4; ++k) scan_lengths(hs, s, s->len[k], n, s->off[k], k);
+  hipLaunchKernelGGL(k_fastq_fill, dim3(nb), dim3(TPB), 0, hs, v->text_base, n, v->head_start, v->seq_start, v->qual_start, s->off[0], s->off[1], s->off[2], s->off[3],
+                     s->values[0], s->values[1], s->values[2], s->values[3]);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(s->h_totals, s->totals, 16, hipMemcpyDeviceToHost, hs));
+  HIP_TRY(ctx, hipStreamSynchronize(hs));
+  for (int k = 0; k < 4; ++k) {
+    out->offsets[k] = s->off[k];
+    out->values[k] = s->values[k];
+    out->n_bytes[k] = s->h_totals[k];
+  }
+  out->desc_valid = reinterpret_cast<const uint8_t*>(s->valid[0]);
   return EXON_HIP_OK;
 }

@@ -499,8 +499,10 @@ int exon_hip_scan_rows(exon_hip_scan* scan, int64_t* rows_emitted);
  * batches in the host readers' layout and file order -- for queries that do NOT end in one of the fused kernels (the surface
  * of <Fmt>Scan::execute, exon/exon-core/src/datasources/vcf/scanner.rs:142-162, bam/scanner.rs:138-158).  A producer thread
  * fills a bounded queue; if the device cannot decide a record the host reader takes over behind the last row emitted.
- * VCF / BCF (chrom, pos, qual, filter, Float / Integer / Flag INFO keys), BAM, SAM; EXON_HIP_EUNSUPPORTED for other formats and
- * for scans whose batches the host reader must build (String / list-valued INFO keys).  Call before the first
+ * VCF / BCF (chrom, pos, qual, filter, Float / Integer / Flag INFO keys), BAM, SAM, and (round 6) FASTQ -- name, description,
+ * sequence, quality_scores as Utf8 columns built on the device (exon-fastq/src/array_builder.rs:68-102), plain, gzip or BGZF;
+ * EXON_HIP_EUNSUPPORTED for other formats and for scans whose batches the host reader must build (list-valued INFO keys, the
+ * info / formats text columns).  Call before the first
  * exon_hip_scan_next; `ctx` must outlive the scan. */
 int exon_hip_scan_bind_ctx(exon_hip_scan* scan, exon_hip_ctx* ctx);
 /* number of index chunks an indexed scan planned (-1 when the scan is not index-driven) */
@@ -646,6 +648,8 @@ typedef struct exon_hip_fastq_views {
   const int32_t* qual_start;
   const int32_t* qual_end;
   const uint8_t* text_base; /* what the views index: the 16-byte aligned address at or below d_text */
+  const int32_t* head_start; /* (appended in round 6) the header line behind its '@' ... */
+  const int32_t* head_end;   /* ... up to its end, CR dropped: name [space description] (exon-fastq/src/array_builder.rs:68-102) */
 } exon_hip_fastq_views;
 int exon_hip_fastq_parser_create(exon_hip_ctx* ctx, int64_t max_slab_bytes, exon_hip_fastq_parser** out);
 /* d_text: any alignment, < 2 GiB.  final_slab != 0: the text ends the input (it must end with '\n').

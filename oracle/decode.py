@@ -439,7 +439,8 @@ def decode_bcf(path):
 
 
 def decode_fastq(path):
-    lines = read_bytes(path).decode().split("\n")
+    # (the line reader drops a CR in front of the LF, as for VCF)
+    lines = [ln[:-1] if ln.endswith("\r") else ln for ln in read_bytes(path).decode().split("\n")]
     recs = []
     i = 0
     while i + 3 < len(lines) and lines[i].startswith("@"):

@@ -117,3 +117,68 @@ def test_scan_closed_with_batches_outstanding(ctx, tmp_path):
     g.close()                      # the producer is blocked on a full queue: close() must wake and join it
     with pytest.raises(exon_amd.ExonHipError):
         exon_amd.Scan(path, "fasta", gpu_parse=True).bind_ctx(ctx)
+
+
+# ---- FASTQ batches from the GPU pipeline (round 6): the four Utf8 columns built on the device (text_columns.hip) --------------------
+def _fastq_cols(scan):
+    out = {}
+    for b in scan:
+        for i in range(b.type.num_fields):
+            out.setdefault(b.type.field(i).name, []).extend(b.field(i).to_pylist())
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["test.fastq", "test.fastq.gz", "test_bgzip.fastq.gz"])
+def test_gpu_fastq_batches_on_the_fixtures(ctx, name):
+    """name / description / sequence / quality_scores (exon-fastq/src/array_builder.rs:68-102) of the reference's fixtures --
+    plain, gzip (one member: gzip_stream.hip) and BGZF -- out of exon_hip_scan_bind_ctx + exon_hip_scan_next = the host reader
+    = oracle/decode.py; slt/fastq-scan-test.slt:51-60 pins the row count (2)."""
+    from oracle import decode
+    p = os.path.join(FX, "fastq", name)
+    recs = decode.decode_fastq(p)
+    s = exon_amd.Scan(p, "fastq", batch_size=1, gpu_parse=True).bind_ctx(ctx)
+    sch = s.schema()
+    assert [sch.field(i).name for i in range(sch.num_fields)] == ["name", "description", "sequence", "quality_scores"]
+    dev = _fastq_cols(s)
+    assert s.decoded_on_gpu()[0]
+    s.close()
+    host = _fastq_cols(exon_amd.Scan(p, "fastq"))
+    for k in ("name", "description", "sequence", "quality_scores"):
+        assert dev[k] == host[k] == [r[k] for r in recs], k
+    assert len(recs) == 2
+
+
+@pytest.mark.gpu
+def test_gpu_fastq_batches_equal_the_host_reader_on_synthetic_reads(ctx, tmp_path, monkeypatch):
+    """300 k reads of ragged length with and without a description, CRLF line ends on a few, over several slabs (BGZF and plain
+    text): device columns = host reader = oracle, read by read; the quality histogram of the same file still decodes on the device."""
+    from oracle import decode
+    rng = np.random.default_rng(17)
+    n = 300_000
+    lens = rng.integers(1, 180, n)
+    bases = np.frombuffer(b"ACGTN", np.uint8)
+    lines = []
+    for i in range(n):
+        L = int(lens[i])
+        seq = bases[rng.integers(0, 5, L)].tobytes().decode()
+        qual = (rng.integers(33, 74, L).astype(np.uint8)).tobytes().decode()
+        head = f"@r{i}" + ("" if i % 3 == 0 else f" lane:{i % 7} x y" if i % 3 == 1 else " ")
+        eol = "\r\n" if i % 1000 == 7 else "\n"
+        lines.append(f"{head}{eol}{seq}{eol}+{eol}{qual}{eol}")
+    p = tmp_path / "syn.fastq"
+    p.write_text("".join(lines), newline="")
+    gz = str(p) + ".gz"
+    subprocess.check_call([BGZIP, str(p), gz, "6"])
+    recs = decode.decode_fastq(str(p))
+    assert len(recs) == n
+    monkeypatch.setenv("EXON_HIP_GPU_PARSE_SLAB_MB", "8")
+    for path in (gz, str(p)):
+        s = exon_amd.Scan(path, "fastq", gpu_parse=True).bind_ctx(ctx)
+        dev = _fastq_cols(s)
+        assert s.decoded_on_gpu()[0], path
+        s.close()
+        for k in ("name", "description", "sequence", "quality_scores"):
+            assert dev[k] == [r[k] for r in recs], (path, k)
+    host = _fastq_cols(exon_amd.Scan(gz, "fastq"))
+    assert host["description"] == dev["description"] and host["name"] == dev["name"]

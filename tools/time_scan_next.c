@@ -1,6 +1,6 @@
 /* time_scan_next.c -- what a native caller sees from exon_hip_scan_next on a scan bound to the GPU pipeline (exon_hip_scan_bind_ctx):
  * batches per second without a Python harness in the way (tools/time_scan_batches.py costs ~30 us per batch itself).
- * usage: time_scan_next FILE {vcf|bam} [runs] [projection-mask] [info_field]
+ * usage: time_scan_next FILE {vcf|bam|fastq} [runs] [projection-mask] [info_field]   (EXON_TIME_HOST=1: the host reader)
  * Prints rows, batches, seconds per pass (open .. last batch .. close) -- plain C against include/exon_hip.h. */
 #include <stdio.h>
 #include <stdlib.h>
@@ -17,7 +17,7 @@ static double now_s(void) {
 
 int main(int argc, char** argv) {
   if (argc < 3) {
-    fprintf(stderr, "usage: time_scan_next FILE {vcf|bam} [runs] [projection-mask] [info_field]\n");
+    fprintf(stderr, "usage: time_scan_next FILE {vcf|bam|fastq} [runs] [projection-mask] [info_field]   (EXON_TIME_HOST=1: the host reader, no GPU)\n");
     return 2;
   }
   const int runs = argc > 3 ? atoi(argv[3]) : 4;
@@ -30,13 +30,14 @@ int main(int argc, char** argv) {
   for (int rep = 0; rep < runs; ++rep) {
     exon_hip_scan_options o;
     memset(&o, 0, sizeof o);
-    o.format = !strcmp(argv[2], "bam") ? EXON_HIP_FORMAT_BAM : EXON_HIP_FORMAT_VCF;
-    o.gpu_parse = 1;
+    o.format = !strcmp(argv[2], "bam") ? EXON_HIP_FORMAT_BAM : !strcmp(argv[2], "fastq") ? EXON_HIP_FORMAT_FASTQ : EXON_HIP_FORMAT_VCF;
+    const int host = getenv("EXON_TIME_HOST") != NULL;
+    o.gpu_parse = host ? 0 : 1;
     o.projection = argc > 4 ? strtoull(argv[4], NULL, 0) : 0;
     o.info_field = argc > 5 ? argv[5] : (o.format == EXON_HIP_FORMAT_VCF ? "AF" : NULL);
     const double t0 = now_s();
     exon_hip_scan* s = NULL;
-    if (exon_hip_scan_open(argv[1], &o, &s) || exon_hip_scan_bind_ctx(s, ctx)) {
+    if (exon_hip_scan_open(argv[1], &o, &s) || (!host && exon_hip_scan_bind_ctx(s, ctx))) {
       fprintf(stderr, "%s\n", exon_hip_last_error(NULL));
       return 1;
     }
