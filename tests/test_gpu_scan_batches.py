@@ -182,3 +182,29 @@ def test_gpu_fastq_batches_equal_the_host_reader_on_synthetic_reads(ctx, tmp_pat
             assert dev[k] == [r[k] for r in recs], (path, k)
     host = _fastq_cols(exon_amd.Scan(gz, "fastq"))
     assert host["description"] == dev["description"] and host["name"] == dev["name"]
+
+
+@pytest.mark.gpu
+def test_gpu_fastq_batches_hand_over_to_the_host_reader_mid_file(ctx, tmp_path, monkeypatch):
+    """A .fastq.gz whose first member holds 60 000 reads and whose tail is 3000 one-read members: the device inflates the first
+    slabs (1 MiB of text each), refuses the run of tiny members (more member ends in a chunk than it tracks), and the host reader
+    takes over behind the last read emitted -- every read once, in file order; the scan says it was not decoded on the GPU."""
+    import gzip
+    def rec(i):
+        return f"@n{i} d{i}\nACGTACGTACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII{chr(33 + i % 40)}\n"
+    n1, n2 = 60_000, 3000
+    p = tmp_path / "members.fastq.gz"
+    with open(p, "wb") as f:
+        f.write(gzip.compress("".join(rec(i) for i in range(n1)).encode(), 6))
+        for i in range(n1, n1 + n2):
+            f.write(gzip.compress(rec(i).encode(), 6))
+    want = [dict(name=f"n{i}", description=f"d{i}", sequence="ACGTACGTACGTACGTACGTACGTACGTACGT", quality_scores="I" * 31 + chr(33 + i % 40)) for i in range(n1 + n2)]
+    monkeypatch.setenv("EXON_HIP_GZ_SLAB_MB", "1")
+    s = exon_amd.Scan(str(p), "fastq", gpu_parse=True).bind_ctx(ctx)
+    dev = _fastq_cols(s)
+    decoded = s.decoded_on_gpu()[0]
+    s.close()
+    assert len(dev["name"]) == n1 + n2
+    for k in ("name", "description", "sequence", "quality_scores"):
+        assert dev[k] == [r[k] for r in want], k
+    assert not decoded
