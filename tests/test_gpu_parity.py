@@ -712,3 +712,35 @@ def test_k4_direct_partition_fills_many_chunks_per_stream(ctx, G, n):
     st = state.to_host()
     assert np.array_equal(st[:G], cn) and np.array_equal(st[G:2 * G], cr)
     assert np.allclose(st[2 * G:].view(np.float64), s_, rtol=RTOL, atol=0)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_k4_tier3_random_shapes_against_numpy(ctx, seed):
+    """Random row counts (whole tiles + remainders, small and big launch shapes), key counts from just above the LDS table to 1.1 M
+    (1 .. 135 id ranges: the direct partition with 1 and 4 streams per range, and the scatter path beyond 128 ranges), uniform and
+    skewed keys, NULLs in x and y: counts bit-exact vs numpy, sums within the budget, twice (the second launch accumulates)."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([70_001, 2_500_000 + int(rng.integers(0, 9000)), 9_000_000 + int(rng.integers(0, 20000))]))
+    G = int(rng.choice([4101, 4100 + 8192, 4100 + 8193, 50_000, 300_000, 4100 + 130 * 8192 + 5]))
+    af = rng.random(n, dtype=np.float32)
+    q = (rng.random(n, dtype=np.float32) * 50).astype(np.float32)
+    if rng.random() < 0.5:
+        fid = rng.integers(0, G, n).astype(np.int32)
+    else:
+        fid = np.minimum(rng.exponential(G / 12.0, n).astype(np.int64), G - 1).astype(np.int32)
+    avb, qvb = rng.random(n) < 0.97, rng.random(n) < 0.9
+    av, qv = np.packbits(avb, bitorder="little"), np.packbits(qvb, bitorder="little")
+    keep = avb & (af.astype(np.float64) > 0.3)
+    cr = np.bincount(fid[keep], minlength=G)
+    cn = np.bincount(fid[keep & qvb], minlength=G)
+    s_ = np.bincount(fid[keep & qvb], weights=q[keep & qvb].astype(np.float64), minlength=G)
+    d = [ctx.to_device(x) for x in (af, av, q, qv, fid)]
+    plan = ctx.plan_cmp_avg_by_group(">", 0.3, G)
+    state = ctx.to_device(np.full(3 * G, 0x0101010101010101, np.int64))
+    cols = [(d[0], d[1], None), (d[2], d[3], None), (d[4], None, None)]
+    for k in (1, 2):
+        plan.launch(cols, n, state, overwrite=(k == 1))
+        ctx.sync()
+        st = state.to_host()
+        assert np.array_equal(st[:G], k * cn) and np.array_equal(st[G:2 * G], k * cr), (n, G, k)
+        assert np.allclose(st[2 * G:].view(np.float64), k * s_, rtol=RTOL, atol=0)
