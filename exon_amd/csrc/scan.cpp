@@ -2083,13 +2083,40 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
     ex->cv_get.notify_one();
     return EXON_HIP_OK;
   };
-  if (!row_mask) {
+  // A pushed-down region keeps ONE run of consecutive rows of a slab when the file is sorted (every indexed file is; the
+  // reference's own benchmark query is such a scan: exon-benchmarks/src/main.rs:143-157): that run goes out as views like an
+  // unfiltered slab, only rows kept here and there are gathered
+  int64_t run_lo = 0, run_hi = n_rows;
+  bool as_views = !row_mask;
+  if (row_mask) {
+    const uint8_t* mask = blk + moff;
+    int64_t first = -1, last = -1, kept = 0;
+    for (int64_t byte = 0; byte < (n_rows + 7) / 8; ++byte) {
+      uint8_t m = mask[(size_t)byte];
+      if (byte == (n_rows - 1) / 8 && (n_rows & 7)) m &= (uint8_t)((1u << (n_rows & 7)) - 1u);
+      if (!m) continue;
+      if (first < 0) first = byte * 8 + __builtin_ctz(m);
+      last = byte * 8 + (31 - __builtin_clz((unsigned)m));
+      kept += __builtin_popcount(m);
+    }
+    if (kept == 0) return EXON_HIP_OK;
+    static const bool gather_forced = [] {
+      const char* v = getenv("EXON_HIP_EXPORT_GATHER");  // A/B: 1 = every filtered slab through the row-by-row gather
+      return v && v[0] == '1';
+    }();
+    if (last - first + 1 == kept && !gather_forced) {
+      as_views = true;
+      run_lo = first;
+      run_hi = last + 1;
+    }
+  }
+  if (as_views) {
     struct Tm {
       double t0 = now_s();
       ~Tm() { g_t_batches += now_s() - t0; }
     } tm;
-    for (int64_t b0 = 0; b0 < n_rows; b0 += bs) {
-      const int64_t n = std::min(n_rows, b0 + bs) - b0;
+    for (int64_t b0 = run_lo; b0 < run_hi; b0 += bs) {
+      const int64_t n = std::min(run_hi, b0 + bs) - b0;
       std::vector<struct ArrowArray*> kids;
       const double tv0 = now_s();
       for (int c = 0; c < n_cols; ++c) {

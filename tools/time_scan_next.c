@@ -33,6 +33,7 @@ int main(int argc, char** argv) {
     o.format = !strcmp(argv[2], "bam") ? EXON_HIP_FORMAT_BAM : !strcmp(argv[2], "fastq") ? EXON_HIP_FORMAT_FASTQ : EXON_HIP_FORMAT_VCF;
     const int host = getenv("EXON_TIME_HOST") != NULL;
     o.gpu_parse = host ? 0 : 1;
+    o.region = getenv("EXON_TIME_REGION");  /* a pushed-down region filter, e.g. "1" or "7:50000000-100000000" */
     o.projection = argc > 4 ? strtoull(argv[4], NULL, 0) : 0;
     o.info_field = argc > 5 ? argv[5] : (o.format == EXON_HIP_FORMAT_VCF ? "AF" : NULL);
     const double t0 = now_s();
