@@ -1989,6 +1989,37 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
                        const ExonBamText* bt = nullptr) {
   GpuExporter* ex = scan->exporter;
   exon_hip_ctx* ctx = ex->ctx;
+  // A pushed-down region: the row mask comes back first.  A slab that keeps nothing sends nothing else; when the kept rows are
+  // ONE run of consecutive rows (sorted files: every indexed file, and the reference's own benchmark query,
+  // exon-benchmarks/src/main.rs:143-157) only that run's part of every column crosses PCIe and goes out as views like an
+  // unfiltered slab; rows kept here and there are gathered from the whole slab.
+  std::vector<uint8_t> hmask;
+  int64_t run_lo = 0, run_hi = n_rows;  // the rows that go out as views
+  bool as_views = !row_mask;
+  if (row_mask) {
+    hmask.resize((size_t)(n_rows + 7) / 8);
+    if (hipMemcpyAsync(hmask.data(), row_mask, hmask.size(), hipMemcpyDeviceToHost, hs) != hipSuccess || hipStreamSynchronize(hs) != hipSuccess)
+      return fail(ctx, EXON_HIP_EDEVICE, "row mask of a slab back to the host");
+    if (n_rows & 7) hmask.back() &= (uint8_t)((1u << (n_rows & 7)) - 1u);
+    int64_t first = -1, last = -1, kept = 0;
+    for (size_t byte = 0; byte < hmask.size(); ++byte) {
+      const uint8_t m = hmask[byte];
+      if (!m) continue;
+      if (first < 0) first = (int64_t)byte * 8 + __builtin_ctz(m);
+      last = (int64_t)byte * 8 + (31 - __builtin_clz((unsigned)m));
+      kept += __builtin_popcount(m);
+    }
+    if (kept == 0) return EXON_HIP_OK;
+    static const bool gather_forced = [] {
+      const char* v = getenv("EXON_HIP_EXPORT_GATHER");  // A/B: 1 = every filtered slab through the row-by-row gather
+      return v && v[0] == '1';
+    }();
+    if (last - first + 1 == kept && !gather_forced) {
+      as_views = true;
+      run_lo = first;
+      run_hi = last + 1;
+    }
+  }
   HostText text;
   if ((vt || bt) && scan->opt.projection) {
     const double tf0 = now_s();
@@ -2009,12 +2040,14 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
     elem[1] = 1;
     elem[3] = elem[4] = 8;
   }
-  const size_t nb = ((size_t)(n_rows + 7) / 8 + 63) & ~size_t(63);
+  // rows [c_lo, c_hi) of every column come back (c_lo a multiple of 8: bitmaps are cut at a byte)
+  const int64_t c_lo = as_views ? (run_lo & ~int64_t(7)) : 0, c_hi = as_views ? run_hi : n_rows, c_n = c_hi - c_lo;
+  const size_t nb = ((size_t)(c_n + 7) / 8 + 63) & ~size_t(63);
   std::vector<size_t> voff((size_t)n_cols, 0), boff((size_t)n_cols, 0);
   size_t bytes = 0;
   for (int c = 0; c < n_cols; ++c) {
     voff[(size_t)c] = bytes;
-    bytes += (((size_t)n_rows * (size_t)elem[(size_t)c]) + 63) & ~size_t(63);
+    bytes += (((size_t)c_n * (size_t)elem[(size_t)c]) + 63) & ~size_t(63);
     boff[(size_t)c] = bytes;
     bytes += nb;
   }
@@ -2034,13 +2067,15 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
   std::vector<bool> has_bits((size_t)n_cols, false);
   hipError_t e = hipSuccess;
   for (int c = 0; c < n_cols && e == hipSuccess; ++c) {
-    if (elem[(size_t)c] && sc[c].values) e = hipMemcpyAsync(blk + voff[(size_t)c], sc[c].values, (size_t)n_rows * (size_t)elem[(size_t)c], hipMemcpyDeviceToHost, hs);
+    if (elem[(size_t)c] && sc[c].values)
+      e = hipMemcpyAsync(blk + voff[(size_t)c], static_cast<const uint8_t*>(sc[c].values) + (size_t)c_lo * (size_t)elem[(size_t)c], (size_t)c_n * (size_t)elem[(size_t)c],
+                         hipMemcpyDeviceToHost, hs);
     if (e == hipSuccess && sc[c].validity) {
-      e = hipMemcpyAsync(blk + boff[(size_t)c], sc[c].validity, (size_t)(n_rows + 7) / 8, hipMemcpyDeviceToHost, hs);
+      e = hipMemcpyAsync(blk + boff[(size_t)c], sc[c].validity + (c_lo >> 3), (size_t)(c_n + 7) / 8, hipMemcpyDeviceToHost, hs);
       has_bits[(size_t)c] = true;
     }
   }
-  if (e == hipSuccess && row_mask) e = hipMemcpyAsync(blk + moff, row_mask, (size_t)(n_rows + 7) / 8, hipMemcpyDeviceToHost, hs);
+  if (e == hipSuccess && row_mask && !as_views) memcpy(blk + moff, hmask.data(), hmask.size());
   if (e == hipSuccess) e = hipStreamSynchronize(hs);
   if (e != hipSuccess) return fail(ctx, EXON_HIP_EDEVICE, "columns of a slab back to the host: %s", hipGetErrorString(e));
   g_t_fetch_cols += now_s() - tc0;
@@ -2083,33 +2118,6 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
     ex->cv_get.notify_one();
     return EXON_HIP_OK;
   };
-  // A pushed-down region keeps ONE run of consecutive rows of a slab when the file is sorted (every indexed file is; the
-  // reference's own benchmark query is such a scan: exon-benchmarks/src/main.rs:143-157): that run goes out as views like an
-  // unfiltered slab, only rows kept here and there are gathered
-  int64_t run_lo = 0, run_hi = n_rows;
-  bool as_views = !row_mask;
-  if (row_mask) {
-    const uint8_t* mask = blk + moff;
-    int64_t first = -1, last = -1, kept = 0;
-    for (int64_t byte = 0; byte < (n_rows + 7) / 8; ++byte) {
-      uint8_t m = mask[(size_t)byte];
-      if (byte == (n_rows - 1) / 8 && (n_rows & 7)) m &= (uint8_t)((1u << (n_rows & 7)) - 1u);
-      if (!m) continue;
-      if (first < 0) first = byte * 8 + __builtin_ctz(m);
-      last = byte * 8 + (31 - __builtin_clz((unsigned)m));
-      kept += __builtin_popcount(m);
-    }
-    if (kept == 0) return EXON_HIP_OK;
-    static const bool gather_forced = [] {
-      const char* v = getenv("EXON_HIP_EXPORT_GATHER");  // A/B: 1 = every filtered slab through the row-by-row gather
-      return v && v[0] == '1';
-    }();
-    if (last - first + 1 == kept && !gather_forced) {
-      as_views = true;
-      run_lo = first;
-      run_hi = last + 1;
-    }
-  }
   if (as_views) {
     struct Tm {
       double t0 = now_s();
@@ -2123,7 +2131,7 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
         const void* bits = has_bits[(size_t)c] ? blk + boff[(size_t)c] : nullptr;
         const void* vals = elem[(size_t)c] ? (const void*)(blk + voff[(size_t)c]) : bits;  // a Flag: true where present
         struct ArrowArray* a = exon::new_view_array(sb, bits, vals, n, bits ? -1 : 0, dict_of_col(c));
-        a->offset = b0;
+        a->offset = b0 - c_lo;
         kids.push_back(a);
       }
       const double tv1 = now_s();
