@@ -1986,7 +1986,7 @@ static void text_batch(const HostText& h, const int64_t* rows, int64_t r0, int64
 }
 
 static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n_rows, const uint8_t* row_mask, hipStream_t hs, const ExonVcfText* vt = nullptr,
-                       const ExonBamText* bt = nullptr) {
+                       const ExonBamText* bt = nullptr, const std::function<int()>* build_text = nullptr) {
   GpuExporter* ex = scan->exporter;
   exon_hip_ctx* ctx = ex->ctx;
   // A pushed-down region: the row mask comes back first.  A slab that keeps nothing sends nothing else; when the kept rows are
@@ -2022,6 +2022,10 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
   }
   HostText text;
   if ((vt || bt) && scan->opt.projection) {
+    if (build_text) {  // the device builds *vt / *bt now
+      const int rc = (*build_text)();
+      if (rc) return rc;
+    }
     const double tf0 = now_s();
     const int rc = fetch_text(ctx, hs, n_rows, scan->opt.projection, vt, bt, &text);
     g_t_fetch_text += now_s() - tf0;
@@ -2476,13 +2480,17 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
           }
           if (scan->exporter && scan->opt.projection && (is_vcf || is_bam)) {
             // the reference's string / list columns of this slab, built on the device from the index the parser has just made
+            // (by export_slab, once it knows that the slab keeps rows at all)
             ExonVcfText vt;
             ExonBamText bt;
-            const double tk0 = now_s();
-            rc = is_vcf ? exon_text_vcf(ctx, hs, &scan->text_scratch, d_text, (int64_t)n, exon_hip_vcf_parser_newlines(scan->parser), n_rows, scan->opt.projection, &vt)
-                        : exon_text_bam(ctx, hs, &scan->text_scratch, d_text, (int64_t)n, exon_hip_bam_parser_row_records(scan->bam_parser), n_rows, scan->opt.projection, &bt);
-            g_t_text_kernels += now_s() - tk0;
-            if (!rc) rc = export_slab(scan, sc, n_rows, row_mask, hs, is_vcf ? &vt : nullptr, is_bam ? &bt : nullptr);
+            const std::function<int()> build_text = [&]() -> int {
+              const double tk0 = now_s();
+              const int r = is_vcf ? exon_text_vcf(ctx, hs, &scan->text_scratch, d_text, (int64_t)n, exon_hip_vcf_parser_newlines(scan->parser), n_rows, scan->opt.projection, &vt)
+                                   : exon_text_bam(ctx, hs, &scan->text_scratch, d_text, (int64_t)n, exon_hip_bam_parser_row_records(scan->bam_parser), n_rows, scan->opt.projection, &bt);
+              g_t_text_kernels += now_s() - tk0;
+              return r;
+            };
+            rc = export_slab(scan, sc, n_rows, row_mask, hs, is_vcf ? &vt : nullptr, is_bam ? &bt : nullptr, &build_text);
           } else
           rc = scan->exporter ? export_slab(scan, sc, n_rows, row_mask, hs)
                               : exon_hip_stream_launch_scan_columns(st, sc, 4 + EXON_HIP_MAX_INFO_FIELDS, n_rows, row_mask);
