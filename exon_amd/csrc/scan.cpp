@@ -1825,9 +1825,9 @@ struct HostText {
   exon::SharedBlock* sb = nullptr;  // the block, shared with the batches that are views into it
   ~HostText() { exon::block_unref(sb); }
 };
-// EXON_HIP_PIPE_TRACE: where a slab's export spends its time (seconds, one producer thread)
-static double g_t_batches = 0, g_t_release = 0, g_t_text_batch = 0, g_t_views = 0;
-static double g_t_text_kernels = 0, g_t_fetch_text = 0, g_t_fetch_cols = 0, g_t_block_get = 0, g_t_enqueue = 0, g_t_names = 0;
+// EXON_HIP_PIPE_TRACE: where a slab's export spends its time (seconds; per producer thread: every scan's pipeline runs in its own)
+static thread_local double g_t_batches = 0, g_t_release = 0, g_t_text_batch = 0, g_t_views = 0;
+static thread_local double g_t_text_kernels = 0, g_t_fetch_text = 0, g_t_fetch_cols = 0, g_t_block_get = 0, g_t_enqueue = 0, g_t_names = 0;
 static int fetch_text(exon_hip_ctx* ctx, hipStream_t hs, int64_t n_rows, uint64_t projection, const ExonVcfText* vt, const ExonBamText* bt, HostText* h) {
   h->projection = projection;
   struct Want {
@@ -2528,7 +2528,7 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
   const double t_loop = now_s();
   if (trace)
     if (scan->exporter)
-      fprintf(stderr, "[exon-hip pipe] export (cumulative over this process): text kernels %.1f ms, text columns D2H %.1f (pinned block %.1f), path columns D2H %.1f, names %.1f, batches %.1f (path views %.1f, text views %.1f, waiting for the consumer %.1f), slab release %.1f\n",
+      fprintf(stderr, "[exon-hip pipe] export (cumulative over this thread): text kernels %.1f ms, text columns D2H %.1f (pinned block %.1f), path columns D2H %.1f, names %.1f, batches %.1f (path views %.1f, text views %.1f, waiting for the consumer %.1f), slab release %.1f\n",
               g_t_text_kernels * 1e3, g_t_fetch_text * 1e3, g_t_block_get * 1e3, g_t_fetch_cols * 1e3, g_t_names * 1e3, g_t_batches * 1e3, g_t_views * 1e3, g_t_text_batch * 1e3, g_t_enqueue * 1e3, g_t_release * 1e3);
     fprintf(stderr, "[exon-hip pipe] setup %.1f ms, loop %.1f ms (%zu source(s); slabs: wait+H2D+inflate %.1f, parse %.1f, other %.1f; file reader busy %.1f)\n",
             (t_init - t_begin) * 1e3, (t_loop - t_init) * 1e3, n_sources, t_next * 1e3, t_parse * 1e3, (t_loop - t_init - t_next - t_parse) * 1e3, t_reader * 1e3);
