@@ -1994,30 +1994,56 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
   // exon-benchmarks/src/main.rs:143-157) only that run's part of every column crosses PCIe and goes out as views like an
   // unfiltered slab; rows kept here and there are gathered from the whole slab.
   std::vector<uint8_t> hmask;
-  int64_t run_lo = 0, run_hi = n_rows;  // the rows that go out as views
+  int64_t run_lo = 0, run_hi = n_rows;  // the span of rows that go out as views ...
+  std::vector<std::pair<int64_t, int64_t>> runs;  // ... and the runs inside it (one run = the whole span without a mask)
   bool as_views = !row_mask;
   if (row_mask) {
     hmask.resize((size_t)(n_rows + 7) / 8);
     if (hipMemcpyAsync(hmask.data(), row_mask, hmask.size(), hipMemcpyDeviceToHost, hs) != hipSuccess || hipStreamSynchronize(hs) != hipSuccess)
       return fail(ctx, EXON_HIP_EDEVICE, "row mask of a slab back to the host");
     if (n_rows & 7) hmask.back() &= (uint8_t)((1u << (n_rows & 7)) - 1u);
-    int64_t first = -1, last = -1, kept = 0;
-    for (size_t byte = 0; byte < hmask.size(); ++byte) {
+    // the runs of consecutive kept rows: one for a point region over a sorted file, a handful when reads that reach into the
+    // region from the left are interleaved with reads that do not (SemiLazyRecord::intersects is an overlap test)
+    int64_t kept = 0;
+    bool too_many = false;
+    constexpr size_t MAX_RUNS = 256;
+    int64_t open_lo = -1;
+    for (size_t byte = 0; byte < hmask.size() && !too_many; ++byte) {
       const uint8_t m = hmask[byte];
-      if (!m) continue;
-      if (first < 0) first = (int64_t)byte * 8 + __builtin_ctz(m);
-      last = (int64_t)byte * 8 + (31 - __builtin_clz((unsigned)m));
-      kept += __builtin_popcount(m);
+      if (m == 0xFF) {
+        if (open_lo < 0) open_lo = (int64_t)byte * 8;
+        kept += 8;
+        continue;
+      }
+      if (m == 0 && open_lo < 0) continue;
+      for (int b = 0; b < 8; ++b) {
+        const int64_t r = (int64_t)byte * 8 + b;
+        if ((m >> b) & 1) {
+          if (open_lo < 0) open_lo = r;
+          ++kept;
+        } else if (open_lo >= 0) {
+          runs.emplace_back(open_lo, r);
+          open_lo = -1;
+          if (runs.size() > MAX_RUNS) too_many = true;
+        }
+      }
     }
-    if (kept == 0) return EXON_HIP_OK;
+    if (open_lo >= 0) runs.emplace_back(open_lo, n_rows);
+    if (too_many) {  // (kept is not complete then: the gather below counts for itself)
+      runs.clear();
+    } else if (kept == 0) {
+      return EXON_HIP_OK;
+    }
     static const bool gather_forced = [] {
       const char* v = getenv("EXON_HIP_EXPORT_GATHER");  // A/B: 1 = every filtered slab through the row-by-row gather
       return v && v[0] == '1';
     }();
-    if (last - first + 1 == kept && !gather_forced) {
+    if (!too_many && !gather_forced) {
       as_views = true;
-      run_lo = first;
-      run_hi = last + 1;
+      run_lo = runs.front().first;
+      run_hi = runs.back().second;
+    } else {
+      runs.clear();
     }
   }
   HostText text;
@@ -2127,8 +2153,10 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
       double t0 = now_s();
       ~Tm() { g_t_batches += now_s() - t0; }
     } tm;
-    for (int64_t b0 = run_lo; b0 < run_hi; b0 += bs) {
-      const int64_t n = std::min(run_hi, b0 + bs) - b0;
+    if (runs.empty()) runs.emplace_back(run_lo, run_hi);
+    for (const auto& run : runs)
+    for (int64_t b0 = run.first; b0 < run.second; b0 += bs) {
+      const int64_t n = std::min(run.second, b0 + bs) - b0;
       std::vector<struct ArrowArray*> kids;
       const double tv0 = now_s();
       for (int c = 0; c < n_cols; ++c) {
@@ -2526,12 +2554,13 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
     src.reset();
   }
   const double t_loop = now_s();
-  if (trace)
+  if (trace) {
     if (scan->exporter)
       fprintf(stderr, "[exon-hip pipe] export (cumulative over this thread): text kernels %.1f ms, text columns D2H %.1f (pinned block %.1f), path columns D2H %.1f, names %.1f, batches %.1f (path views %.1f, text views %.1f, waiting for the consumer %.1f), slab release %.1f\n",
               g_t_text_kernels * 1e3, g_t_fetch_text * 1e3, g_t_block_get * 1e3, g_t_fetch_cols * 1e3, g_t_names * 1e3, g_t_batches * 1e3, g_t_views * 1e3, g_t_text_batch * 1e3, g_t_enqueue * 1e3, g_t_release * 1e3);
     fprintf(stderr, "[exon-hip pipe] setup %.1f ms, loop %.1f ms (%zu source(s); slabs: wait+H2D+inflate %.1f, parse %.1f, other %.1f; file reader busy %.1f)\n",
             (t_init - t_begin) * 1e3, (t_loop - t_init) * 1e3, n_sources, t_next * 1e3, t_parse * 1e3, (t_loop - t_init - t_next - t_parse) * 1e3, t_reader * 1e3);
+  }
   if (rc == EXON_HIP_OK && filtered) {  // the scan emitted the rows that hit the region
     unsigned long long kept = 0;
     HIP_TRY(ctx, hipMemcpy(&kept, scan->d_region_pass, 8, hipMemcpyDeviceToHost));

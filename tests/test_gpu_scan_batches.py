@@ -208,3 +208,31 @@ def test_gpu_fastq_batches_hand_over_to_the_host_reader_mid_file(ctx, tmp_path, 
     for k in ("name", "description", "sequence", "quality_scores"):
         assert dev[k] == [r[k] for r in want], k
     assert not decoded
+
+
+def test_region_batches_with_several_kept_runs_per_slab(ctx, tmp_path, monkeypatch):
+    """A region that keeps several runs of rows inside one slab (blocks of contig 1 between blocks of contig 2; bam_region_filter's
+    overlap test produces the same in front of a region's start): every run goes out as views (the row-by-row gather takes over
+    beyond 256 runs per slab): GPU batches = host reader, with views and with the gather forced; a region nothing matches sends
+    nothing."""
+    head = "##fileformat=VCFv4.2\n##contig=<ID=1>\n##contig=<ID=2>\n##INFO=<ID=AF,Number=1,Type=Float,Description=\"a\">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n"
+    rows, pos = [], 0
+    for block, n in enumerate([5000, 3, 12000, 1, 7, 20000, 9000, 2, 15000]):
+        chrom = "1" if block % 2 == 0 else "2"
+        for _ in range(n):
+            pos += 1
+            rows.append(f"{chrom}\t{pos}\t{'.' if pos % 3 else 'rs' + str(pos)}\tA\tC\t{pos % 50}\tPASS\tAF=0.{1 + pos % 9}\n")
+    p = tmp_path / "runs.vcf"
+    p.write_text(head + "".join(rows))
+    for region in ("1", "2", "1:5001-5010", "2:1-4"):
+        want = _fastq_cols(exon_amd.Scan(str(p), "vcf", info_field="AF", region=region, project=("id",)))
+        for forced in ("0", "1"):
+            monkeypatch.setenv("EXON_HIP_EXPORT_GATHER", forced)
+            s = exon_amd.Scan(str(p), "vcf", info_field="AF", region=region, gpu_parse=True, batch_size=1000, project=("id",)).bind_ctx(ctx)
+            got = _fastq_cols(s)
+            assert s.decoded_on_gpu()[0]
+            s.close()
+            assert got.keys() == want.keys(), (region, forced)
+            for k in want:
+                assert got[k] == want[k], (region, forced, k)
+    assert len(_fastq_cols(exon_amd.Scan(str(p), "vcf", region="1")).get("pos", [])) == 5000 + 12000 + 7 + 9000 + 15000
