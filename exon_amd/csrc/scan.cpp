@@ -9,6 +9,7 @@
 #include <cstring>
 #include <map>
 #include <deque>
+#include <array>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -96,6 +97,67 @@ struct GpuExporter {
   std::unique_ptr<exon::BCFBatchReader> fb_bcf;
   std::unique_ptr<exon::FASTQBatchReader> fb_fastq;
   bool handed_over = false;
+  // A slab's columns cross PCIe while the NEXT slab is inflated and parsed: export_slab copies what it needs device to device
+  // into a staging slot (the parsers reuse their output buffers), a copy stream takes it to the pinned block, and the slab's
+  // batches are cut when the next slab arrives (or the scan ends) -- `pending` waits for the copy and emits them.
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_done[2] = {nullptr, nullptr};
+  uint8_t* d_stage[2] = {nullptr, nullptr};
+  size_t stage_cap[2] = {0, 0};
+  uint64_t n_exports = 0;
+  std::function<int()> pending;
+};
+
+// copies of one slab: device source -> staging slot (on the pipeline's stream) -> host destination (on the copy stream)
+struct SlabCopier {
+  GpuExporter* ex;
+  hipStream_t hs;
+  int slot;
+  size_t used = 0;
+  struct Item {
+    void* dst;
+    size_t off, bytes;
+  };
+  std::vector<Item> items;
+  hipError_t err = hipSuccess;
+  SlabCopier(GpuExporter* e, hipStream_t s) : ex(e), hs(s), slot((int)(e->n_exports & 1)) {}
+  // room for `bytes` more (called before the first add of a group of copies whose sizes are known)
+  bool reserve(size_t bytes) {
+    const size_t need = used + bytes + 4096;
+    if (ex->stage_cap[slot] >= need) return true;
+    if (used) return false;  // (never: every caller reserves its whole need up front)
+    if (ex->d_stage[slot]) hipFree(ex->d_stage[slot]);
+    ex->d_stage[slot] = nullptr;
+    ex->stage_cap[slot] = 0;
+    const size_t cap = need + need / 4;
+    if (hipMalloc((void**)&ex->d_stage[slot], cap) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    ex->stage_cap[slot] = cap;
+    return true;
+  }
+  void add(void* dst, const void* src, size_t bytes) {
+    if (!bytes || err != hipSuccess) return;
+    const size_t off = (used + 255) & ~size_t(255);
+    if (off + bytes > ex->stage_cap[slot]) {
+      err = hipErrorOutOfMemory;
+      return;
+    }
+    err = hipMemcpyAsync(ex->d_stage[slot] + off, src, bytes, hipMemcpyDeviceToDevice, hs);
+    items.push_back(Item{dst, off, bytes});
+    used = off + bytes;
+  }
+  // the staged bytes start for the host; ev_done[slot] fires when they have arrived
+  hipError_t launch() {
+    if (err != hipSuccess) return err;
+    hipError_t e = hipEventRecord(ex->ev_ready, hs);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ex->copy_stream, ex->ev_ready, 0);
+    for (const Item& it : items)
+      if (e == hipSuccess) e = hipMemcpyAsync(it.dst, ex->d_stage[slot] + it.off, it.bytes, hipMemcpyDeviceToHost, ex->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(ex->ev_done[slot], ex->copy_stream);
+    return e;
+  }
 };
 
 static int gpu_next(exon_hip_scan* s, struct ArrowArray* out);
@@ -1828,7 +1890,8 @@ struct HostText {
 // EXON_HIP_PIPE_TRACE: where a slab's export spends its time (seconds; per producer thread: every scan's pipeline runs in its own)
 static thread_local double g_t_batches = 0, g_t_release = 0, g_t_text_batch = 0, g_t_views = 0;
 static thread_local double g_t_text_kernels = 0, g_t_fetch_text = 0, g_t_fetch_cols = 0, g_t_block_get = 0, g_t_enqueue = 0, g_t_names = 0;
-static int fetch_text(exon_hip_ctx* ctx, hipStream_t hs, int64_t n_rows, uint64_t projection, const ExonVcfText* vt, const ExonBamText* bt, HostText* h) {
+// (the copies go through `cp`: they have arrived when the slab's copy event has fired)
+static int fetch_text(exon_hip_ctx* ctx, SlabCopier* cp, size_t also_reserve, int64_t n_rows, uint64_t projection, const ExonVcfText* vt, const ExonBamText* bt, HostText* h) {
   h->projection = projection;
   struct Want {
     std::function<void(const uint8_t*)> place;  // points the span at its bytes inside the block
@@ -1876,6 +1939,7 @@ static int fetch_text(exon_hip_ctx* ctx, hipStream_t hs, int64_t n_rows, uint64_
   }
   size_t total = 64;
   for (const Want& w : wants) total += (w.count * w.elem + 63) & ~(size_t)63;
+  if (!cp->reserve(total + 256 * wants.size() + also_reserve)) return fail(ctx, EXON_HIP_ENOMEM, "no device staging buffer of %zu bytes for a slab's string columns", total);
   h->blk_bytes = total;
   const double tb0 = now_s();
   h->blk = export_block_get(&h->blk_bytes);
@@ -1885,17 +1949,15 @@ static int fetch_text(exon_hip_ctx* ctx, hipStream_t hs, int64_t n_rows, uint64_
   h->sb->block = h->blk;
   h->sb->bytes = h->blk_bytes;
   h->sb->put = export_block_put;
-  hipError_t e = hipSuccess;
   size_t at = 0;
   for (const Want& w : wants) {
     uint8_t* dst = static_cast<uint8_t*>(h->blk) + at;
     w.place(dst);
     if (!w.src) memset(dst, 0, w.count * w.elem);
-    if (e == hipSuccess && w.count && w.src) e = hipMemcpyAsync(dst, w.src, w.count * w.elem, hipMemcpyDeviceToHost, hs);
+    if (w.count && w.src) cp->add(dst, w.src, w.count * w.elem);
     at += (w.count * w.elem + 63) & ~(size_t)63;
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(hs);
-  if (e != hipSuccess) return fail(ctx, EXON_HIP_EDEVICE, "string columns of a slab back to the host: %s", hipGetErrorString(e));
+  if (cp->err != hipSuccess) return fail(ctx, EXON_HIP_EDEVICE, "string columns of a slab towards the host: %s", hipGetErrorString(cp->err));
   return EXON_HIP_OK;
 }
 // the projected columns of the rows `rows[0 .. n)` of the slab (in the order of the projection bits), appended to `kids`
@@ -2046,17 +2108,17 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
       runs.clear();
     }
   }
-  HostText text;
-  if ((vt || bt) && scan->opt.projection) {
-    if (build_text) {  // the device builds *vt / *bt now
-      const int rc = (*build_text)();
-      if (rc) return rc;
-    }
-    const double tf0 = now_s();
-    const int rc = fetch_text(ctx, hs, n_rows, scan->opt.projection, vt, bt, &text);
-    g_t_fetch_text += now_s() - tf0;
+  // the batches of the slab before this one: its copy ran under this slab's inflate and parse
+  if (ex->pending) {
+    std::function<int()> emit;
+    emit.swap(ex->pending);
+    const int rc = emit();
     if (rc) return rc;
   }
+  SlabCopier cp(ex, hs);
+  ++ex->n_exports;
+  auto text_p = std::make_shared<HostText>();
+  HostText& text = *text_p;
   const double tc0 = now_s();
   const bool vcf_like = scan->vcf || scan->bcf;
   const std::vector<exon::InfoSpec>* specs = scan->vcf ? &scan->vcf->info_specs : scan->bcf ? &scan->bcf->info_specs : nullptr;
@@ -2083,6 +2145,19 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
   }
   const size_t moff = bytes;
   bytes += nb;
+  const size_t path_stage = bytes + 512 * (size_t)n_cols;
+  if ((vt || bt) && scan->opt.projection) {
+    if (build_text) {  // the device builds *vt / *bt now
+      const int rc = (*build_text)();
+      if (rc) return rc;
+    }
+    const double tf0 = now_s();
+    const int rc = fetch_text(ctx, &cp, path_stage, n_rows, scan->opt.projection, vt, bt, &text);
+    g_t_fetch_text += now_s() - tf0;
+    if (rc) return rc;
+  } else if (!cp.reserve(path_stage)) {
+    return fail(ctx, EXON_HIP_ENOMEM, "no device staging buffer of %zu bytes for a slab's columns", path_stage);
+  }
   size_t blk_bytes = bytes;
   uint8_t* blk = static_cast<uint8_t*>(export_block_get(&blk_bytes));
   if (!blk) return fail(ctx, EXON_HIP_ENOMEM, "no pinned block of %zu bytes for a slab's columns", bytes);
@@ -2090,25 +2165,27 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
   sb->block = blk;
   sb->bytes = blk_bytes;
   sb->put = export_block_put;
-  struct Unref {
-    exon::SharedBlock* b;
-    ~Unref() { exon::block_unref(b); }
-  } unref{sb};  // this function's own reference
+  std::shared_ptr<exon::SharedBlock> sb_ref(sb, [](exon::SharedBlock* b) { exon::block_unref(b); });  // this slab's own reference
   std::vector<bool> has_bits((size_t)n_cols, false);
-  hipError_t e = hipSuccess;
-  for (int c = 0; c < n_cols && e == hipSuccess; ++c) {
+  for (int c = 0; c < n_cols; ++c) {
     if (elem[(size_t)c] && sc[c].values)
-      e = hipMemcpyAsync(blk + voff[(size_t)c], static_cast<const uint8_t*>(sc[c].values) + (size_t)c_lo * (size_t)elem[(size_t)c], (size_t)c_n * (size_t)elem[(size_t)c],
-                         hipMemcpyDeviceToHost, hs);
-    if (e == hipSuccess && sc[c].validity) {
-      e = hipMemcpyAsync(blk + boff[(size_t)c], sc[c].validity + (c_lo >> 3), (size_t)(c_n + 7) / 8, hipMemcpyDeviceToHost, hs);
+      cp.add(blk + voff[(size_t)c], static_cast<const uint8_t*>(sc[c].values) + (size_t)c_lo * (size_t)elem[(size_t)c], (size_t)c_n * (size_t)elem[(size_t)c]);
+    if (sc[c].validity) {
+      cp.add(blk + boff[(size_t)c], sc[c].validity + (c_lo >> 3), (size_t)(c_n + 7) / 8);
       has_bits[(size_t)c] = true;
     }
   }
-  if (e == hipSuccess && row_mask && !as_views) memcpy(blk + moff, hmask.data(), hmask.size());
-  if (e == hipSuccess) e = hipStreamSynchronize(hs);
-  if (e != hipSuccess) return fail(ctx, EXON_HIP_EDEVICE, "columns of a slab back to the host: %s", hipGetErrorString(e));
+  if (row_mask && !as_views) memcpy(blk + moff, hmask.data(), hmask.size());
+  const hipError_t e = cp.launch();
+  if (e != hipSuccess) return fail(ctx, EXON_HIP_EDEVICE, "columns of a slab towards the host: %s", hipGetErrorString(e));
   g_t_fetch_cols += now_s() - tc0;
+  const int slot = cp.slot;
+  const int64_t bs = scan->opt.batch_size > 0 ? scan->opt.batch_size : 8192;
+  // ---- everything below runs when the NEXT slab arrives (or the scan ends): by then the copies have landed -----------------------
+  ex->pending = [=]() mutable -> int {
+  (void)sb_ref;  // (the slab's own reference to its block lives as long as this closure)
+  if (hipEventSynchronize(ex->ev_done[slot]) != hipSuccess) return fail(ctx, EXON_HIP_EDEVICE, "columns of a slab back to the host: the copy failed");
+  const HostText& text = *text_p;
   const double tn0 = now_s();
   std::vector<std::string> filters;
   if (vcf_like) {
@@ -2121,7 +2198,6 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
     if (rc) return rc;
   }
   g_t_names += now_s() - tn0;
-  const int64_t bs = scan->opt.batch_size > 0 ? scan->opt.batch_size : 8192;
   auto dict_of_col = [&](int c) -> struct ArrowArray* {
     if (vcf_like && c == 0) return exon::utf8_array(scan->vcf ? scan->vcf->chrom_dict.names : scan->bcf->chrom_dict.names);
     if (vcf_like && c == 3) return exon::utf8_array(filters);
@@ -2215,6 +2291,13 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
     if (rc) return rc;
   }
   return EXON_HIP_OK;
+  };
+  if (getenv("EXON_HIP_EXPORT_SYNC") && getenv("EXON_HIP_EXPORT_SYNC")[0] == '1') {  // A/B: no overlap with the next slab
+    std::function<int()> emit;
+    emit.swap(ex->pending);
+    return emit();
+  }
+  return EXON_HIP_OK;
 }
 
 // FASTQ batches from the GPU pipeline: the slab's four Utf8 columns (text_columns.hip: name, description?, sequence,
@@ -2223,18 +2306,28 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
 static int export_fastq_slab(exon_hip_scan* scan, const ExonFastqText& ft, int64_t n_reads, hipStream_t hs) {
   GpuExporter* ex = scan->exporter;
   exon_hip_ctx* ctx = ex->ctx;
+  if (ex->pending) {  // the batches of the slab before this one
+    std::function<int()> emit;
+    emit.swap(ex->pending);
+    const int rc = emit();
+    if (rc) return rc;
+  }
   if (n_reads == 0) return EXON_HIP_OK;
   const size_t n = (size_t)n_reads;
   auto pad = [](size_t b) { return (b + 63) & ~size_t(63); };
-  size_t at_off[4], at_val[4], total = 64;
+  size_t total = 64;
+  std::array<size_t, 4> at_off, at_val;
   for (int k = 0; k < 4; ++k) {
-    at_off[k] = total;
+    at_off[(size_t)k] = total;
     total += pad((n + 1) * 4);
-    at_val[k] = total;
+    at_val[(size_t)k] = total;
     total += pad((size_t)ft.n_bytes[k] + 8);
   }
   const size_t at_valid = total;
   total += pad((n + 7) / 8 + 8);
+  SlabCopier cp(ex, hs);
+  ++ex->n_exports;
+  if (!cp.reserve(total + 4096)) return fail(ctx, EXON_HIP_ENOMEM, "no device staging buffer of %zu bytes for a slab of reads", total);
   size_t blk_bytes = total;
   uint8_t* blk = static_cast<uint8_t*>(export_block_get(&blk_bytes));
   if (!blk) return fail(ctx, EXON_HIP_ENOMEM, "no pinned block of %zu bytes for a slab of reads", total);
@@ -2242,40 +2335,57 @@ static int export_fastq_slab(exon_hip_scan* scan, const ExonFastqText& ft, int64
   sb->block = blk;
   sb->bytes = blk_bytes;
   sb->put = export_block_put;
-  struct Unref {
-    exon::SharedBlock* b;
-    ~Unref() { exon::block_unref(b); }
-  } unref{sb};
-  hipError_t e = hipSuccess;
-  for (int k = 0; k < 4 && e == hipSuccess; ++k) {
-    e = hipMemcpyAsync(blk + at_off[k], ft.offsets[k], (n + 1) * 4, hipMemcpyDeviceToHost, hs);
-    if (e == hipSuccess && ft.n_bytes[k]) e = hipMemcpyAsync(blk + at_val[k], ft.values[k], (size_t)ft.n_bytes[k], hipMemcpyDeviceToHost, hs);
+  std::shared_ptr<exon::SharedBlock> sb_ref(sb, [](exon::SharedBlock* b) { exon::block_unref(b); });
+  for (int k = 0; k < 4; ++k) {
+    cp.add(blk + at_off[(size_t)k], ft.offsets[k], (n + 1) * 4);
+    cp.add(blk + at_val[(size_t)k], ft.values[k], (size_t)ft.n_bytes[k]);
   }
-  if (e == hipSuccess) e = hipMemcpyAsync(blk + at_valid, ft.desc_valid, (n + 7) / 8, hipMemcpyDeviceToHost, hs);
-  if (e == hipSuccess) e = hipStreamSynchronize(hs);
-  if (e != hipSuccess) return fail(ctx, EXON_HIP_EDEVICE, "reads of a slab back to the host: %s", hipGetErrorString(e));
+  cp.add(blk + at_valid, ft.desc_valid, (n + 7) / 8);
+  const hipError_t e = cp.launch();
+  if (e != hipSuccess) return fail(ctx, EXON_HIP_EDEVICE, "reads of a slab towards the host: %s", hipGetErrorString(e));
+  const int slot = cp.slot;
   const int64_t bs = scan->opt.batch_size > 0 ? scan->opt.batch_size : 8192;
-  for (int64_t b0 = 0; b0 < n_reads; b0 += bs) {
-    const int64_t m = std::min(n_reads, b0 + bs) - b0;
-    std::vector<struct ArrowArray*> kids;
-    for (int k = 0; k < 4; ++k)
-      kids.push_back(exon::new_view_array_ex(sb, {k == 1 ? (const void*)(blk + at_valid) : nullptr, blk + at_off[k], blk + at_val[k]}, m, k == 1 ? -1 : 0, b0));
-    struct ArrowArray* out = static_cast<struct ArrowArray*>(malloc(sizeof *out));
-    exon::make_struct(out, m, std::move(kids));
-    std::unique_lock<std::mutex> lk(ex->mu);
-    ex->cv_put.wait(lk, [&] { return ex->stop || ex->q.size() < ex->cap; });
-    if (ex->stop) {
+  ex->pending = [=]() -> int {
+    (void)sb_ref;
+    if (hipEventSynchronize(ex->ev_done[slot]) != hipSuccess) return fail(ctx, EXON_HIP_EDEVICE, "reads of a slab back to the host: the copy failed");
+    for (int64_t b0 = 0; b0 < n_reads; b0 += bs) {
+      const int64_t m = std::min(n_reads, b0 + bs) - b0;
+      std::vector<struct ArrowArray*> kids;
+      for (int k = 0; k < 4; ++k)
+        kids.push_back(exon::new_view_array_ex(sb, {k == 1 ? (const void*)(blk + at_valid) : nullptr, blk + at_off[(size_t)k], blk + at_val[(size_t)k]}, m, k == 1 ? -1 : 0, b0));
+      struct ArrowArray* out = static_cast<struct ArrowArray*>(malloc(sizeof *out));
+      exon::make_struct(out, m, std::move(kids));
+      std::unique_lock<std::mutex> lk(ex->mu);
+      ex->cv_put.wait(lk, [&] { return ex->stop || ex->q.size() < ex->cap; });
+      if (ex->stop) {
+        lk.unlock();
+        out->release(out);
+        free(out);
+        return 2;
+      }
+      ex->q.push_back(out);
+      ex->emitted += m;
       lk.unlock();
-      out->release(out);
-      free(out);
-      return 2;
+      ex->cv_get.notify_one();
     }
-    ex->q.push_back(out);
-    ex->emitted += m;
-    lk.unlock();
-    ex->cv_get.notify_one();
+    return EXON_HIP_OK;
+  };
+  if (getenv("EXON_HIP_EXPORT_SYNC") && getenv("EXON_HIP_EXPORT_SYNC")[0] == '1') {
+    std::function<int()> emit;
+    emit.swap(ex->pending);
+    return emit();
   }
   return EXON_HIP_OK;
+}
+
+// the last slab's batches (its copy has nothing left to hide behind); also in front of a hand-over to the host reader, which
+// continues behind the rows EMITTED
+static int export_flush(exon_hip_scan* scan) {
+  GpuExporter* ex = scan->exporter;
+  if (!ex || !ex->pending) return EXON_HIP_OK;
+  std::function<int()> emit;
+  emit.swap(ex->pending);
+  return emit();
 }
 
 static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* rows_out) {
@@ -2553,6 +2663,15 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
     t_reader += src->reader_seconds();
     src.reset();
   }
+  if (scan->exporter) {
+    if (rc == EXON_HIP_OK || rc == 1) {  // the last slab's batches (a hand-over continues behind the rows EMITTED)
+      const int fr = export_flush(scan);
+      if (fr) rc = fr;
+    } else if (scan->exporter->pending) {  // an error: nothing more goes out; its copy must not outlive its block
+      hipStreamSynchronize(scan->exporter->copy_stream);
+      scan->exporter->pending = nullptr;
+    }
+  }
   const double t_loop = now_s();
   if (trace) {
     if (scan->exporter)
@@ -2659,8 +2778,15 @@ static void gpu_export_producer(exon_hip_scan* scan) {
   d.columns[1] = 1;
   rc = exon_hip_plan_create(ex->ctx, &d, &ex->plan);
   if (!rc) rc = exon_hip_stream_open(ex->plan, 0, &ex->st);
+  if (!rc && (hipStreamCreateWithFlags(&ex->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ex->ev_ready, hipEventDisableTiming) != hipSuccess ||
+              hipEventCreateWithFlags(&ex->ev_done[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ex->ev_done[1], hipEventDisableTiming) != hipSuccess))
+    rc = fail(ex->ctx, EXON_HIP_EDEVICE, "copy stream / events of the batch export");
   int64_t rows = 0;
   if (!rc) rc = consume_text_gpu(ex->st, scan, &rows);
+  if (ex->pending) {  // (an early error return inside the pipeline: see consume_text_gpu's own clean-up for the other exits)
+    if (ex->copy_stream) hipStreamSynchronize(ex->copy_stream);
+    ex->pending = nullptr;
+  }
   if (rc == 1) {
     // the device could not decide something: the host reader goes over the file again and takes over behind the rows emitted
     try {
@@ -2793,6 +2919,14 @@ static void gpu_export_shutdown(exon_hip_scan* s) {
     if (a->release) a->release(a);
     free(a);
   }
+  if (ex->copy_stream) hipStreamSynchronize(ex->copy_stream);
+  ex->pending = nullptr;
+  for (int k = 0; k < 2; ++k) {
+    if (ex->d_stage[k]) hipFree(ex->d_stage[k]);
+    if (ex->ev_done[k]) hipEventDestroy(ex->ev_done[k]);
+  }
+  if (ex->ev_ready) hipEventDestroy(ex->ev_ready);
+  if (ex->copy_stream) hipStreamDestroy(ex->copy_stream);
   if (ex->st) exon_hip_stream_close(ex->st);
   if (ex->plan) exon_hip_plan_destroy(ex->plan);
   delete ex;
