@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -232,6 +233,38 @@ inline struct ArrowArray* utf8_array(const std::vector<std::string>& strs) {
   }
   struct ArrowArray* a = static_cast<struct ArrowArray*>(malloc(sizeof *a));
   make_utf8(a, off, data, {});
+  return a;
+}
+
+// A dictionary (Utf8 values) shared by many batches: the values are built once (per slab), every batch's dictionary column gets a
+// thin ArrowArray of its own that keeps the values alive (the C data interface gives every exported array its own release).
+struct SharedUtf8 {
+  std::vector<int32_t> offsets{0};
+  std::string data;
+  explicit SharedUtf8(const std::vector<std::string>& strs) {
+    for (const auto& s : strs) {
+      data += s;
+      offsets.push_back((int32_t)data.size());
+    }
+  }
+};
+struct SharedUtf8Ref {
+  std::shared_ptr<const SharedUtf8> values;
+  const void* bufs[3];
+};
+inline struct ArrowArray* shared_utf8_array(const std::shared_ptr<const SharedUtf8>& v) {
+  struct ArrowArray* a = static_cast<struct ArrowArray*>(malloc(sizeof *a));
+  SharedUtf8Ref* r = new SharedUtf8Ref{v, {nullptr, v->offsets.data(), v->data.data()}};
+  memset(a, 0, sizeof *a);
+  a->length = (int64_t)v->offsets.size() - 1;
+  a->n_buffers = 3;
+  a->buffers = r->bufs;
+  a->private_data = r;
+  a->release = [](struct ArrowArray* x) {
+    if (!x || !x->release) return;
+    delete static_cast<SharedUtf8Ref*>(x->private_data);
+    x->release = nullptr;
+  };
   return a;
 }
 

@@ -2198,13 +2198,16 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
     if (rc) return rc;
   }
   g_t_names += now_s() - tn0;
-  auto dict_of_col = [&](int c) -> struct ArrowArray* {
-    if (vcf_like && c == 0) return exon::utf8_array(scan->vcf ? scan->vcf->chrom_dict.names : scan->bcf->chrom_dict.names);
-    if (vcf_like && c == 3) return exon::utf8_array(filters);
-    if (scan->vcf && c >= 4 && (size_t)(c - 4) < info_names.size() && (*specs)[(size_t)(c - 4)].kind == 's') return exon::utf8_array(info_names[(size_t)(c - 4)]);
-    if (!vcf_like && c == 2) return exon::utf8_array(scan->bam_dict_view.names);
-    return nullptr;
-  };
+  // the dictionaries of this slab's batches: built once, shared by every batch's column (exon::shared_utf8_array)
+  std::vector<std::shared_ptr<const exon::SharedUtf8>> dicts((size_t)n_cols);
+  for (int c = 0; c < n_cols; ++c) {
+    if (vcf_like && c == 0) dicts[(size_t)c] = std::make_shared<const exon::SharedUtf8>(scan->vcf ? scan->vcf->chrom_dict.names : scan->bcf->chrom_dict.names);
+    else if (vcf_like && c == 3) dicts[(size_t)c] = std::make_shared<const exon::SharedUtf8>(filters);
+    else if (scan->vcf && c >= 4 && (size_t)(c - 4) < info_names.size() && (*specs)[(size_t)(c - 4)].kind == 's')
+      dicts[(size_t)c] = std::make_shared<const exon::SharedUtf8>(info_names[(size_t)(c - 4)]);
+    else if (!vcf_like && c == 2) dicts[(size_t)c] = std::make_shared<const exon::SharedUtf8>(scan->bam_dict_view.names);
+  }
+  auto dict_of_col = [&](int c) -> struct ArrowArray* { return dicts[(size_t)c] ? exon::shared_utf8_array(dicts[(size_t)c]) : nullptr; };
   auto enqueue = [&](std::vector<struct ArrowArray*> kids, int64_t n) -> int {
     struct ArrowArray* out = static_cast<struct ArrowArray*>(malloc(sizeof *out));
     exon::make_struct(out, n, std::move(kids));
