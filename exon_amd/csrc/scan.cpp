@@ -1964,20 +1964,20 @@ static int fetch_text(exon_hip_ctx* ctx, SlabCopier* cp, size_t also_reserve, in
 // Without a row list (no pushed-down region) the batch's columns are VIEWS into the slab's pinned block: the slab-wide validity /
 // offsets / data buffers with ArrowArray::offset = the batch's first row, the item arrays of the lists shared by reference -- no
 // per-row work on the host (profiles/r6_scan_next_native.log).
-static void text_batch(const HostText& h, const int64_t* rows, int64_t r0, int64_t n, std::vector<struct ArrowArray*>* kids) {
+static void text_batch(const HostText& h, const int64_t* rows, int64_t r0, int64_t n, std::vector<struct ArrowArray*>* kids, exon::BatchArena* arena = nullptr) {
   if (!rows) {
     auto utf8_view = [&](const Span<int32_t>& off, const Span<uint8_t>& val, const Span<uint8_t>* valid, int64_t first, int64_t len) {
-      return exon::new_view_array_ex(h.sb, {valid ? (const void*)valid->data() : nullptr, off.data(), val.data()}, len, valid ? -1 : 0, first);
+      return exon::arena_array(arena, len, first, valid ? -1 : 0, 3, valid ? (const void*)valid->data() : nullptr, off.data(), val.data());
     };
     if (h.vcf) {
       if (h.projection & EXON_HIP_PROJECT_VCF_ID) {
         struct ArrowArray* items = utf8_view(h.item_off, h.val[0], nullptr, 0, (int64_t)h.item_off.n - 1);
-        kids->push_back(exon::new_view_array_ex(h.sb, {h.valid[0].data(), h.off[0].data()}, n, -1, r0, {items}));
+        kids->push_back(exon::arena_array(arena, n, r0, -1, 2, h.valid[0].data(), h.off[0].data(), nullptr, items));
       }
       if (h.projection & EXON_HIP_PROJECT_VCF_REF) kids->push_back(utf8_view(h.off[2], h.val[2], nullptr, r0, n));
       if (h.projection & EXON_HIP_PROJECT_VCF_ALT) {
-        struct ArrowArray* items = exon::new_view_array_ex(h.sb, {nullptr, h.zeros.data(), h.zeros.data()}, 0, 0, 0);
-        kids->push_back(exon::new_view_array_ex(h.sb, {h.valid[1].data(), h.zeros.data()}, n, -1, r0, {items}));
+        struct ArrowArray* items = exon::arena_array(arena, 0, 0, 0, 3, nullptr, h.zeros.data(), h.zeros.data());
+        kids->push_back(exon::arena_array(arena, n, r0, -1, 2, h.valid[1].data(), h.zeros.data(), nullptr, items));
       }
     }
     if (h.bam) {
@@ -1985,8 +1985,8 @@ static void text_batch(const HostText& h, const int64_t* rows, int64_t r0, int64
       if (h.projection & EXON_HIP_PROJECT_BAM_CIGAR) kids->push_back(utf8_view(h.off[1], h.val[1], nullptr, r0, n));
       if (h.projection & EXON_HIP_PROJECT_BAM_SEQUENCE) kids->push_back(utf8_view(h.off[2], h.val[2], nullptr, r0, n));
       if (h.projection & EXON_HIP_PROJECT_BAM_QUALITY_SCORES) {
-        struct ArrowArray* items = exon::new_view_array_ex(h.sb, {nullptr, h.qual.data()}, (int64_t)h.qual.n, 0, 0);
-        kids->push_back(exon::new_view_array_ex(h.sb, {nullptr, h.off[2].data()}, n, 0, r0, {items}));
+        struct ArrowArray* items = exon::arena_array(arena, (int64_t)h.qual.n, 0, 0, 2, nullptr, h.qual.data(), nullptr);
+        kids->push_back(exon::arena_array(arena, n, r0, 0, 2, nullptr, h.off[2].data(), nullptr, items));
       }
     }
     return;
@@ -2198,8 +2198,9 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
     if (rc) return rc;
   }
   g_t_names += now_s() - tn0;
-  // the dictionaries of this slab's batches: built once, shared by every batch's column (exon::shared_utf8_array)
-  std::vector<std::shared_ptr<const exon::SharedUtf8>> dicts((size_t)n_cols);
+  // the dictionaries of this slab's batches: built once, shared by every batch's column
+  auto dicts_p = std::make_shared<std::vector<std::shared_ptr<const exon::SharedUtf8>>>((size_t)n_cols);
+  std::vector<std::shared_ptr<const exon::SharedUtf8>>& dicts = *dicts_p;
   for (int c = 0; c < n_cols; ++c) {
     if (vcf_like && c == 0) dicts[(size_t)c] = std::make_shared<const exon::SharedUtf8>(scan->vcf ? scan->vcf->chrom_dict.names : scan->bcf->chrom_dict.names);
     else if (vcf_like && c == 3) dicts[(size_t)c] = std::make_shared<const exon::SharedUtf8>(filters);
@@ -2208,6 +2209,28 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
     else if (!vcf_like && c == 2) dicts[(size_t)c] = std::make_shared<const exon::SharedUtf8>(scan->bam_dict_view.names);
   }
   auto dict_of_col = [&](int c) -> struct ArrowArray* { return dicts[(size_t)c] ? exon::shared_utf8_array(dicts[(size_t)c]) : nullptr; };
+  auto push_batch = [&](struct ArrowArray* out, int64_t n) -> int {
+    const double te0 = now_s();
+    std::unique_lock<std::mutex> lk(ex->mu);
+    ex->cv_put.wait(lk, [&] { return ex->stop || ex->q.size() < ex->cap; });
+    g_t_enqueue += now_s() - te0;
+    if (ex->stop) {
+      lk.unlock();
+      out->release(out);
+      free(out);
+      return 2;
+    }
+    ex->q.push_back(out);
+    ex->emitted += n;
+    lk.unlock();
+    ex->cv_get.notify_one();
+    return EXON_HIP_OK;
+  };
+  auto enqueue_arena = [&](exon::BatchArena* arena, const std::vector<struct ArrowArray*>& kids, int64_t n) -> int {
+    struct ArrowArray* out = static_cast<struct ArrowArray*>(malloc(sizeof *out));
+    exon::make_struct_of_arena(out, n, arena, kids);
+    return push_batch(out, n);
+  };
   auto enqueue = [&](std::vector<struct ArrowArray*> kids, int64_t n) -> int {
     struct ArrowArray* out = static_cast<struct ArrowArray*>(malloc(sizeof *out));
     exon::make_struct(out, n, std::move(kids));
@@ -2238,18 +2261,20 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
       const int64_t n = std::min(run.second, b0 + bs) - b0;
       std::vector<struct ArrowArray*> kids;
       const double tv0 = now_s();
+      // every array of the batch out of one allocation (exon::BatchArena): per column its array + its dictionary, the text
+      // columns' lists + items, the struct itself
+      exon::BatchArena* arena = exon::new_batch_arena(2 * n_cols + 8 + 1, n_cols + 4, sb, text.sb, dicts_p);
       for (int c = 0; c < n_cols; ++c) {
         const void* bits = has_bits[(size_t)c] ? blk + boff[(size_t)c] : nullptr;
         const void* vals = elem[(size_t)c] ? (const void*)(blk + voff[(size_t)c]) : bits;  // a Flag: true where present
-        struct ArrowArray* a = exon::new_view_array(sb, bits, vals, n, bits ? -1 : 0, dict_of_col(c));
-        a->offset = b0 - c_lo;
-        kids.push_back(a);
+        struct ArrowArray* dict = dicts[(size_t)c] ? exon::arena_dictionary(arena, *dicts[(size_t)c]) : nullptr;
+        kids.push_back(exon::arena_array(arena, n, b0 - c_lo, bits ? -1 : 0, 2, bits, vals, nullptr, nullptr, dict));
       }
       const double tv1 = now_s();
       g_t_views += tv1 - tv0;
-      if (text.vcf || text.bam) text_batch(text, nullptr, b0, n, &kids);
+      if (text.vcf || text.bam) text_batch(text, nullptr, b0, n, &kids, arena);
       g_t_text_batch += now_s() - tv1;
-      const int rc = enqueue(std::move(kids), n);
+      const int rc = enqueue_arena(arena, kids, n);
       if (rc) return rc;
     }
     return EXON_HIP_OK;
@@ -2354,10 +2379,11 @@ static int export_fastq_slab(exon_hip_scan* scan, const ExonFastqText& ft, int64
     for (int64_t b0 = 0; b0 < n_reads; b0 += bs) {
       const int64_t m = std::min(n_reads, b0 + bs) - b0;
       std::vector<struct ArrowArray*> kids;
+      exon::BatchArena* arena = exon::new_batch_arena(5, 4, sb, nullptr, nullptr);
       for (int k = 0; k < 4; ++k)
-        kids.push_back(exon::new_view_array_ex(sb, {k == 1 ? (const void*)(blk + at_valid) : nullptr, blk + at_off[(size_t)k], blk + at_val[(size_t)k]}, m, k == 1 ? -1 : 0, b0));
+        kids.push_back(exon::arena_array(arena, m, b0, k == 1 ? -1 : 0, 3, k == 1 ? (const void*)(blk + at_valid) : nullptr, blk + at_off[(size_t)k], blk + at_val[(size_t)k]));
       struct ArrowArray* out = static_cast<struct ArrowArray*>(malloc(sizeof *out));
-      exon::make_struct(out, m, std::move(kids));
+      exon::make_struct_of_arena(out, m, arena, kids);
       std::unique_lock<std::mutex> lk(ex->mu);
       ex->cv_put.wait(lk, [&] { return ex->stop || ex->q.size() < ex->cap; });
       if (ex->stop) {
