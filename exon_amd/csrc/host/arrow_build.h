@@ -80,30 +80,6 @@ inline struct ArrowArray* new_view_array(SharedBlock* block, const void* validit
   a->private_data = o;
   return a;
 }
-// the same with any number of buffers and children (Utf8: validity, offsets, data; List: validity, offsets + the item array):
-// `offset` = the first row inside the block's slab-wide buffers
-inline struct ArrowArray* new_view_array_ex(SharedBlock* block, std::vector<const void*> buffers, int64_t n, int64_t nulls, int64_t offset,
-                                            std::vector<struct ArrowArray*> children = {}) {
-  struct ArrowArray* a = static_cast<struct ArrowArray*>(malloc(sizeof *a));
-  OwnedArray* o = new OwnedArray();
-  o->buf_ptrs = std::move(buffers);
-  o->children = std::move(children);
-  if (block) {
-    block->refs.fetch_add(1, std::memory_order_relaxed);
-    o->block = block;
-  }
-  memset(a, 0, sizeof *a);
-  a->length = n;
-  a->null_count = nulls;
-  a->offset = offset;
-  a->n_buffers = (int64_t)o->buf_ptrs.size();
-  a->buffers = o->buf_ptrs.data();
-  a->n_children = (int64_t)o->children.size();
-  a->children = o->children.empty() ? nullptr : o->children.data();
-  a->release = release_array;
-  a->private_data = o;
-  return a;
-}
 struct OwnedSchema {
   std::string format, name;
   std::vector<struct ArrowSchema*> children;
