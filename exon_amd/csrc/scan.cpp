@@ -1891,7 +1891,11 @@ struct HostText {
 static thread_local double g_t_batches = 0, g_t_release = 0, g_t_text_batch = 0, g_t_views = 0;
 static thread_local double g_t_text_kernels = 0, g_t_fetch_text = 0, g_t_fetch_cols = 0, g_t_block_get = 0, g_t_enqueue = 0, g_t_names = 0;
 // (the copies go through `cp`: they have arrived when the slab's copy event has fired)
-static int fetch_text(exon_hip_ctx* ctx, SlabCopier* cp, size_t also_reserve, int64_t n_rows, uint64_t projection, const ExonVcfText* vt, const ExonBamText* bt, HostText* h) {
+// zero offsets for the item-less `alt` lists of a batch: every batch of up to K_ZERO_ROWS rows points at the same static array
+static constexpr int64_t K_ZERO_ROWS = 65000;
+static const int32_t k_zero_offsets[K_ZERO_ROWS + 64] = {0};
+static int fetch_text(exon_hip_ctx* ctx, SlabCopier* cp, size_t also_reserve, int64_t n_rows, uint64_t projection, const ExonVcfText* vt, const ExonBamText* bt, HostText* h,
+                      bool big_batches) {
   h->projection = projection;
   struct Want {
     std::function<void(const uint8_t*)> place;  // points the span at its bytes inside the block
@@ -1919,7 +1923,7 @@ static int fetch_text(exon_hip_ctx* ctx, SlabCopier* cp, size_t also_reserve, in
     }
     if (projection & EXON_HIP_PROJECT_VCF_ALT) {
       get(h->valid[1], vt->alt_valid, nb);
-      get(h->zeros, nullptr, n + 1);  // (no source: cleared below)
+      if (big_batches) get(h->zeros, nullptr, n + 1);  // (no source: cleared below; batches of up to 65 000 rows share a static array)
     }
   }
   if (bt) {
@@ -1976,8 +1980,13 @@ static void text_batch(const HostText& h, const int64_t* rows, int64_t r0, int64
       }
       if (h.projection & EXON_HIP_PROJECT_VCF_REF) kids->push_back(utf8_view(h.off[2], h.val[2], nullptr, r0, n));
       if (h.projection & EXON_HIP_PROJECT_VCF_ALT) {
-        struct ArrowArray* items = exon::arena_array(arena, 0, 0, 0, 3, nullptr, h.zeros.data(), h.zeros.data());
-        kids->push_back(exon::arena_array(arena, n, r0, -1, 2, h.valid[1].data(), h.zeros.data(), nullptr, items));
+        if (h.zeros.p) {  // (batches larger than the static zero array: slab-wide zeros)
+          struct ArrowArray* items = exon::arena_array(arena, 0, 0, 0, 3, nullptr, h.zeros.data(), h.zeros.data());
+          kids->push_back(exon::arena_array(arena, n, r0, -1, 2, h.valid[1].data(), h.zeros.data(), nullptr, items));
+        } else {  // the bitmap from the byte the batch starts in, the offsets from the shared zeros
+          struct ArrowArray* items = exon::arena_array(arena, 0, 0, 0, 3, nullptr, k_zero_offsets, k_zero_offsets);
+          kids->push_back(exon::arena_array(arena, n, r0 & 7, -1, 2, h.valid[1].data() + (r0 >> 3), k_zero_offsets, nullptr, items));
+        }
       }
     }
     if (h.bam) {
@@ -2152,7 +2161,7 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
       if (rc) return rc;
     }
     const double tf0 = now_s();
-    const int rc = fetch_text(ctx, &cp, path_stage, n_rows, scan->opt.projection, vt, bt, &text);
+    const int rc = fetch_text(ctx, &cp, path_stage, n_rows, scan->opt.projection, vt, bt, &text, scan->opt.batch_size > K_ZERO_ROWS);
     g_t_fetch_text += now_s() - tf0;
     if (rc) return rc;
   } else if (!cp.reserve(path_stage)) {
