@@ -236,3 +236,29 @@ def test_region_batches_with_several_kept_runs_per_slab(ctx, tmp_path, monkeypat
             for k in want:
                 assert got[k] == want[k], (region, forced, k)
     assert len(_fastq_cols(exon_amd.Scan(str(p), "vcf", region="1")).get("pos", [])) == 5000 + 12000 + 7 + 9000 + 15000
+
+
+def test_batches_outlive_the_scan(ctx, tmp_path):
+    """Batches are views into pinned blocks shared by reference count (exon::BatchArena): closing the scan -- and dropping single
+    columns of a batch early -- must not pull the memory from under the batches still held; their content is read afterwards."""
+    import gc
+    path = str(tmp_path / "t.vcf")
+    subprocess.check_call([GEN, "vcf", "200000", path], stdout=subprocess.DEVNULL)
+    want = _fastq_cols(exon_amd.Scan(path, "vcf", info_field="AF", project=("id", "ref", "alt")))
+    s = exon_amd.Scan(path, "vcf", info_field="AF", gpu_parse=True, batch_size=5000, project=("id", "ref", "alt")).bind_ctx(ctx)
+    held = list(s)
+    s.close()
+    del s
+    cols_first = [b.field(0) for b in held[::2]]   # single columns kept, their batches dropped
+    held = held[1::2]
+    gc.collect()
+    got = {}
+    for b in held:
+        for i in range(b.type.num_fields):
+            got.setdefault(b.type.field(i).name, []).extend(b.field(i).to_pylist())
+    n = 5000
+    for k in want:
+        expect = [v for j in range(1, 40, 2) for v in want[k][j * n:(j + 1) * n]]
+        assert got[k] == expect, k
+    chrom0 = [v for c in cols_first for v in c.to_pylist()]
+    assert chrom0 == [v for j in range(0, 40, 2) for v in want["chrom"][j * n:(j + 1) * n]]
