@@ -1389,6 +1389,7 @@ struct exon_hip_sam_parser {
   SamOut out{};
   unsigned* h_scalars = nullptr;
 };
+const unsigned* exon_hip_sam_parser_newlines(exon_hip_sam_parser* p) { return p ? p->d_nl : nullptr; }
 
 extern "C" {
 

@@ -70,6 +70,8 @@ struct ExonBamText {
   const uint8_t *name_values, *cigar_values, *seq_values, *name_valid;
   const int64_t* qual_values;
   int64_t n_name_bytes, n_cigar_bytes, n_seq_bytes;
+  const int32_t* qual_offsets;  // quality_scores' list offsets (BAM: = seq_offsets; SAM: its own, QUAL may be '*' next to a SEQ)
+  int64_t n_qual_items;
 };
 int exon_text_vcf(exon_hip_ctx* ctx, void* stream, ExonTextScratch** scratch, const uint8_t* d_text, int64_t n_bytes, const unsigned* d_nl, int64_t n_rows, uint64_t projection,
                   ExonVcfText* out);
@@ -81,10 +83,14 @@ struct ExonFastqText {  // name, description, sequence, quality_scores (exon-fas
   int64_t n_bytes[4];
   const uint8_t* desc_valid;  // bitmap: the header has something behind its first space
 };
+// SAM lines (the parser's newline index) -> the same columns; n_undecided != 0: a line the device does not print the way the reader would
+int exon_text_sam(exon_hip_ctx* ctx, void* stream, ExonTextScratch** scratch, const uint8_t* d_text, int64_t n_bytes, const unsigned* d_nl, int64_t n_rows, uint64_t projection,
+                  ExonBamText* out, int64_t* n_undecided);
 int exon_text_fastq(exon_hip_ctx* ctx, void* stream, ExonTextScratch** scratch, const exon_hip_fastq_views* views, int64_t n_bytes, ExonFastqText* out);
 void exon_text_scratch_destroy(ExonTextScratch* s);
 // the parsers' own indexes the text columns are built from (valid until the next parse call)
-const unsigned* exon_hip_vcf_parser_newlines(exon_hip_vcf_parser* p);      // gpu_parse.hip: byte offset of every line's '\n' in the aligned slab
+const unsigned* exon_hip_vcf_parser_newlines(exon_hip_vcf_parser* p);
+const unsigned* exon_hip_sam_parser_newlines(exon_hip_sam_parser* p);      // gpu_parse.hip: the same for SAM lines      // gpu_parse.hip: byte offset of every line's '\n' in the aligned slab
 const uint32_t* exon_hip_bam_parser_row_records(exon_hip_bam_parser* p);   // bam_parse.hip: byte offset of every row's record
 
 // capi.cpp: size-keyed recycling of device buffers (released by exon_hip_ctx_destroy)

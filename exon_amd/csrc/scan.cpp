@@ -348,7 +348,7 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         cfg.filter.use_index = false;
         cfg.projection = o->projection;
         if (o->projection & ~15ull) return fail(nullptr, EXON_HIP_EINVAL, "projection 0x%llx: SAM knows EXON_HIP_PROJECT_BAM_NAME / _CIGAR / _SEQUENCE / _QUALITY_SCORES", (unsigned long long)o->projection);
-        s->gpu_parse = o->gpu_parse != 0 && !o->projection;  // the text columns of SAM: host reader
+        s->gpu_parse = o->gpu_parse != 0;  // (the text columns come from the device too: text_columns.hip, k_sam_measure / k_sam_fill)
         s->sam.reset(new exon::SAMBatchReader(path, c, cfg));
         s->bam_dict_view.names = s->sam->ref_names;
         break;
@@ -1878,7 +1878,7 @@ struct Span {
 struct HostText {
   bool vcf = false, bam = false;
   uint64_t projection = 0;
-  Span<int32_t> off[3], item_off;
+  Span<int32_t> off[3], item_off, qual_off;  // qual_off: quality_scores' own list offsets (SAM), else off[2]
   Span<uint8_t> val[3], valid[2];
   Span<int64_t> qual;
   Span<int32_t> zeros;  // n_rows + 1 zero offsets: the item-less `alt` lists
@@ -1939,7 +1939,10 @@ static int fetch_text(exon_hip_ctx* ctx, SlabCopier* cp, size_t also_reserve, in
     }
     if (projection & (EXON_HIP_PROJECT_BAM_SEQUENCE | EXON_HIP_PROJECT_BAM_QUALITY_SCORES)) get(h->off[2], bt->seq_offsets, n + 1);
     if (projection & EXON_HIP_PROJECT_BAM_SEQUENCE) get(h->val[2], bt->seq_values, (size_t)bt->n_seq_bytes);
-    if (projection & EXON_HIP_PROJECT_BAM_QUALITY_SCORES) get(h->qual, bt->qual_values, (size_t)bt->n_seq_bytes);
+    if (projection & EXON_HIP_PROJECT_BAM_QUALITY_SCORES) {
+      get(h->qual, bt->qual_values, (size_t)bt->n_qual_items);
+      if (bt->qual_offsets != bt->seq_offsets) get(h->qual_off, bt->qual_offsets, n + 1);  // SAM: QUAL may be '*' next to a SEQ
+    }
   }
   size_t total = 64;
   for (const Want& w : wants) total += (w.count * w.elem + 63) & ~(size_t)63;
@@ -1995,7 +1998,7 @@ static void text_batch(const HostText& h, const int64_t* rows, int64_t r0, int64
       if (h.projection & EXON_HIP_PROJECT_BAM_SEQUENCE) kids->push_back(utf8_view(h.off[2], h.val[2], nullptr, r0, n));
       if (h.projection & EXON_HIP_PROJECT_BAM_QUALITY_SCORES) {
         struct ArrowArray* items = exon::arena_array(arena, (int64_t)h.qual.n, 0, 0, 2, nullptr, h.qual.data(), nullptr);
-        kids->push_back(exon::arena_array(arena, n, r0, 0, 2, nullptr, h.off[2].data(), nullptr, items));
+        kids->push_back(exon::arena_array(arena, n, r0, 0, 2, nullptr, (h.qual_off.p ? h.qual_off : h.off[2]).data(), nullptr, items));
       }
     }
     return;
@@ -2047,7 +2050,8 @@ static void text_batch(const HostText& h, const int64_t* rows, int64_t r0, int64
       exon::ListBuilder<int64_t> b;
       for (int64_t i = 0; i < n; ++i) {
         const int64_t r = row_at(i);
-        const int32_t a = h.off[2][(size_t)r], z = h.off[2][(size_t)r + 1];
+        const Span<int32_t>& qo = h.qual_off.p ? h.qual_off : h.off[2];
+        const int32_t a = qo[(size_t)r], z = qo[(size_t)r + 1];
         b.items.values.insert(b.items.values.end(), h.qual.begin() + a, h.qual.begin() + z);
         b.close_row();
       }
@@ -2654,19 +2658,26 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
                                                   scan->d_region_mask, scan->d_region_pass));
             row_mask = scan->d_region_mask;
           }
-          if (scan->exporter && scan->opt.projection && (is_vcf || is_bam)) {
+          if (scan->exporter && scan->opt.projection && (is_vcf || is_bam || is_sam)) {
             // the reference's string / list columns of this slab, built on the device from the index the parser has just made
             // (by export_slab, once it knows that the slab keeps rows at all)
             ExonVcfText vt;
             ExonBamText bt;
             const std::function<int()> build_text = [&]() -> int {
               const double tk0 = now_s();
-              const int r = is_vcf ? exon_text_vcf(ctx, hs, &scan->text_scratch, d_text, (int64_t)n, exon_hip_vcf_parser_newlines(scan->parser), n_rows, scan->opt.projection, &vt)
-                                   : exon_text_bam(ctx, hs, &scan->text_scratch, d_text, (int64_t)n, exon_hip_bam_parser_row_records(scan->bam_parser), n_rows, scan->opt.projection, &bt);
+              int r;
+              if (is_sam) {
+                int64_t undecided = 0;
+                r = exon_text_sam(ctx, hs, &scan->text_scratch, d_text, (int64_t)n, exon_hip_sam_parser_newlines(scan->sam_parser), n_rows, scan->opt.projection, &bt, &undecided);
+                if (!r && undecided) r = 1;  // a CIGAR / QUAL the device would not print the way the reader does: the host reader takes over
+              } else {
+                r = is_vcf ? exon_text_vcf(ctx, hs, &scan->text_scratch, d_text, (int64_t)n, exon_hip_vcf_parser_newlines(scan->parser), n_rows, scan->opt.projection, &vt)
+                           : exon_text_bam(ctx, hs, &scan->text_scratch, d_text, (int64_t)n, exon_hip_bam_parser_row_records(scan->bam_parser), n_rows, scan->opt.projection, &bt);
+              }
               g_t_text_kernels += now_s() - tk0;
               return r;
             };
-            rc = export_slab(scan, sc, n_rows, row_mask, hs, is_vcf ? &vt : nullptr, is_bam ? &bt : nullptr, &build_text);
+            rc = export_slab(scan, sc, n_rows, row_mask, hs, is_vcf ? &vt : nullptr, is_vcf ? nullptr : &bt, &build_text);
           } else
           rc = scan->exporter ? export_slab(scan, sc, n_rows, row_mask, hs)
                               : exon_hip_stream_launch_scan_columns(st, sc, 4 + EXON_HIP_MAX_INFO_FIELDS, n_rows, row_mask);

@@ -292,6 +292,97 @@ __global__ __launch_bounds__(TPB) void k_fastq_fill(const uint8_t* __restrict__ 
   copy_run(qual_v + qual_off[r], text + qual_s[r], (unsigned)(qual_off[r + 1] - qual_off[r]));
 }
 
+// ---- SAM ---------------------------------------------------------------------------------------------------------------------------
+// The BAM columns from an alignment LINE (exon-sam/src/array_builder.rs:101-185 over noodles' RecordBuf): QNAME '*' -> NULL; the
+// CIGAR printed op by op ('*' -> ""; a text the printer would change -- an op count with a leading zero -- or would refuse makes
+// the row undecided: the host reader takes the file); SEQ '*' -> ""; QUAL '*' -> an empty list, else Phred = char - 33 (a
+// character outside '!'..'~' is the reader's error: undecided).  Fields 1 (QNAME), 6 (CIGAR), 10 (SEQ), 11 (QUAL) by their tabs.
+struct SamLens {
+  uint32_t *name, *cigar, *seq, *qual;
+  uint32_t* field_off;  // [4 n]: where QNAME, CIGAR, SEQ, QUAL start
+};
+__global__ __launch_bounds__(TPB) void k_sam_measure(const uint8_t* __restrict__ text, const unsigned* __restrict__ nl, unsigned n_rows, unsigned skip, SamLens o,
+                                                     uint32_t* __restrict__ name_valid, unsigned* __restrict__ undecided) {
+  const unsigned row = blockIdx.x * TPB + threadIdx.x;
+  bool nv = false, bad = false;
+  if (row < n_rows) {
+    const unsigned begin = row ? nl[row - 1] + 1 : skip;
+    unsigned end = nl[row];
+    if (end > begin && text[end - 1] == '\r') --end;
+    unsigned fs[12];
+    int nf = 0;
+    fs[0] = begin;
+    for (unsigned i = begin; i < end && nf < 11; ++i)
+      if (text[i] == '\t') fs[++nf] = i + 1;
+    unsigned off[4] = {begin, begin, begin, begin}, len[4] = {0, 0, 0, 0};
+    if (nf < 10) {
+      bad = true;  // fewer than 11 fields
+    } else {
+      const int which[4] = {0, 5, 9, 10};
+      for (int k = 0; k < 4; ++k) {
+        const int f = which[k];
+        off[k] = fs[f];
+        len[k] = (f < nf ? fs[f + 1] - 1 : end) - fs[f];
+      }
+      auto star = [&](int k) { return len[k] == 1 && text[off[k]] == '*'; };
+      nv = !star(0);
+      if (star(0)) len[0] = 0;
+      if (star(1)) {
+        len[1] = 0;
+      } else {  // digits (no leading zero: the printed form is the text) then one of MIDNSHP=X, repeated
+        bool digits = false, lead = true;
+        for (unsigned i = 0; i < len[1]; ++i) {
+          const uint8_t c = text[off[1] + i];
+          if (c >= '0' && c <= '9') {
+            if (lead && c == '0') bad = true;
+            lead = false;
+            digits = true;
+          } else {
+            const bool op = c == 'M' || c == 'I' || c == 'D' || c == 'N' || c == 'S' || c == 'H' || c == 'P' || c == '=' || c == 'X';
+            if (!digits || !op) bad = true;
+            digits = false;
+            lead = true;
+          }
+        }
+        if (digits || len[1] == 0) bad = true;
+      }
+      if (star(2)) len[2] = 0;
+      if (star(3)) {
+        len[3] = 0;
+      } else {
+        for (unsigned i = 0; i < len[3]; ++i) {
+          const uint8_t c = text[off[3] + i];
+          if (c < 33 || c > 126) bad = true;
+        }
+      }
+    }
+    o.name[row] = len[0];
+    o.cigar[row] = len[1];
+    o.seq[row] = len[2];
+    o.qual[row] = len[3];
+    for (int k = 0; k < 4; ++k) o.field_off[4 * row + k] = off[k];
+  }
+  const unsigned long long bv = __ballot(nv), bb = __ballot(bad);
+  const unsigned lane = threadIdx.x & 63u, wrow = row - lane;
+  if (lane < 2 && wrow + 32 * lane < n_rows) name_valid[(wrow >> 5) + lane] = (uint32_t)(bv >> (32 * lane));
+  if (lane == 0 && bb) atomicAdd(undecided, (unsigned)__popcll(bb));
+}
+__global__ __launch_bounds__(TPB) void k_sam_fill(const uint8_t* __restrict__ text, unsigned n_rows, SamLens o, uint64_t projection, const int32_t* __restrict__ name_off,
+                                                  const int32_t* __restrict__ cigar_off, const int32_t* __restrict__ seq_off, const int32_t* __restrict__ qual_off,
+                                                  uint8_t* __restrict__ name_v, uint8_t* __restrict__ cigar_v, uint8_t* __restrict__ seq_v, int64_t* __restrict__ qual_v) {
+  const unsigned row = blockIdx.x * TPB + threadIdx.x;
+  if (row >= n_rows) return;
+  const uint32_t* fo = o.field_off + 4 * row;
+  if (projection & EXON_HIP_PROJECT_BAM_NAME) copy_run(name_v + name_off[row], text + fo[0], o.name[row]);
+  if (projection & EXON_HIP_PROJECT_BAM_CIGAR) copy_run(cigar_v + cigar_off[row], text + fo[1], o.cigar[row]);
+  if (projection & EXON_HIP_PROJECT_BAM_SEQUENCE) copy_run(seq_v + seq_off[row], text + fo[2], o.seq[row]);
+  if (projection & EXON_HIP_PROJECT_BAM_QUALITY_SCORES) {
+    int64_t* dst = qual_v + qual_off[row];
+    const uint8_t* q = text + fo[3];
+    for (unsigned i = 0; i < o.qual[row]; ++i) dst[i] = (int64_t)q[i] - 33;
+  }
+}
+
 struct ExonTextScratch {
   exon_hip_ctx* ctx = nullptr;
   int64_t max_rows = 0, max_bytes = 0;
@@ -300,6 +391,7 @@ struct ExonTextScratch {
   int32_t* off[4] = {nullptr, nullptr, nullptr, nullptr};
   uint32_t* valid[2] = {nullptr, nullptr};
   uint32_t *field_off = nullptr, *field_len = nullptr;
+  uint32_t* sam_field_off = nullptr;  // [4 r] (SAM)
   unsigned* sums = nullptr;
   unsigned* totals = nullptr;    // device [4]
   unsigned* h_totals = nullptr;  // pinned
@@ -313,7 +405,7 @@ void exon_text_scratch_destroy(ExonTextScratch* s) {
   if (!s) return;
   auto f = [&](void* p) { if (p) exon_pool_free(s->ctx, p); };
   for (int k = 0; k < 4; ++k) f(s->len[k]), f(s->off[k]), f(s->values[k]);
-  f(s->valid[0]), f(s->valid[1]), f(s->field_off), f(s->field_len), f(s->sums), f(s->totals), f(s->item_off), f(s->qual);
+  f(s->valid[0]), f(s->valid[1]), f(s->field_off), f(s->field_len), f(s->sam_field_off), f(s->sums), f(s->totals), f(s->item_off), f(s->qual);
   if (s->h_totals) hipHostFree(s->h_totals);
   delete s;
 }
@@ -347,7 +439,8 @@ static int scratch_for(exon_hip_ctx* ctx, ExonTextScratch** sp, int64_t max_rows
     a((void**)&s->field_len, 3 * r * 4);
     a((void**)&s->item_off, ((size_t)max_bytes / 2 + r + 2) * 4);
   }
-  a((void**)&s->sums, (r / TPB + 2) * 4);
+  if (n_cols >= 4) a((void**)&s->sam_field_off, 4 * r * 4);
+  a((void**)&s->sums, (r / TPB + 4) * 4);
   a((void**)&s->totals, 16);
   if (ok && hipHostMalloc((void**)&s->h_totals, 16) != hipSuccess) ok = false;  // (4 totals: the FASTQ columns use them all)
   if (!ok) {
@@ -442,6 +535,8 @@ int exon_text_bam(exon_hip_ctx* ctx, void* stream, ExonTextScratch** sp, const u
   out->seq_values = s->values[2];
   out->n_seq_bytes = seq_bytes;
   out->qual_values = s->qual;
+  out->qual_offsets = s->off[2];  // (a BAM record's qualities are as many as its bases)
+  out->n_qual_items = seq_bytes;
   return EXON_HIP_OK;
 }
 
@@ -470,5 +565,62 @@ int exon_text_fastq(exon_hip_ctx* ctx, void* stream, ExonTextScratch** sp, const
     out->n_bytes[k] = s->h_totals[k];
   }
   out->desc_valid = reinterpret_cast<const uint8_t*>(s->valid[0]);
+  return EXON_HIP_OK;
+}
+
+// SAM lines -> the BAM text columns (ExonBamText; quality_scores has list offsets of its own here: QUAL may be '*' next to a SEQ)
+int exon_text_sam(exon_hip_ctx* ctx, void* stream, ExonTextScratch** sp, const uint8_t* d_text, int64_t n_bytes, const unsigned* d_nl, int64_t n_rows, uint64_t projection,
+                  ExonBamText* out, int64_t* n_undecided) {
+  memset(out, 0, sizeof *out);
+  *n_undecided = 0;
+  const uint64_t all = EXON_HIP_PROJECT_BAM_NAME | EXON_HIP_PROJECT_BAM_CIGAR | EXON_HIP_PROJECT_BAM_SEQUENCE | EXON_HIP_PROJECT_BAM_QUALITY_SCORES;
+  if (n_rows == 0 || !(projection & all)) return EXON_HIP_OK;
+  const unsigned skip = (unsigned)(reinterpret_cast<uintptr_t>(d_text) & 15);
+  d_text -= skip;
+  n_bytes += skip;
+  int rc = scratch_for(ctx, sp, std::max<int64_t>(n_rows, 1 << 16), std::max<int64_t>(n_bytes, 1 << 20), false, 4);
+  if (rc) return rc;
+  ExonTextScratch* s = *sp;
+  hipStream_t hs = pick_stream(ctx, stream);
+  const unsigned n = (unsigned)n_rows;
+  const int nb = (int)((n + TPB - 1) / TPB);
+  SamLens L{s->len[0], s->len[1], s->len[2], s->len[3], s->sam_field_off};
+  HIP_TRY(ctx, hipMemsetAsync(s->totals, 0, 16, hs));
+  unsigned* d_und = s->sums + (s->max_rows + 64) / TPB + 2;  // a word of the block-sum buffer behind what scan_lengths uses (nb <= r / TPB + 1)
+  HIP_TRY(ctx, hipMemsetAsync(d_und, 0, 4, hs));
+  hipLaunchKernelGGL(k_sam_measure, dim3(nb), dim3(TPB), 0, hs, d_text, d_nl, n, skip, L, s->valid[0], d_und);
+  for (int k = 0; k < 4; ++k) scan_lengths(hs, s, s->len[k], n, s->off[k], k);
+  HIP_TRY(ctx, hipMemcpyAsync(s->h_totals, s->totals, 16, hipMemcpyDeviceToHost, hs));
+  unsigned h_und = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&h_und, d_und, 4, hipMemcpyDeviceToHost, hs));
+  HIP_TRY(ctx, hipStreamSynchronize(hs));
+  *n_undecided = h_und;
+  if (h_und) return EXON_HIP_OK;
+  const unsigned qual_items = s->h_totals[3];
+  if ((projection & EXON_HIP_PROJECT_BAM_QUALITY_SCORES) && s->qual_cap < (size_t)qual_items) {
+    if (s->qual) exon_pool_free(ctx, s->qual);
+    s->qual_cap = std::max<size_t>((size_t)qual_items, (size_t)1 << 20);
+    s->qual = static_cast<int64_t*>(exon_pool_alloc(ctx, s->qual_cap * 8));
+    if (!s->qual) {
+      s->qual_cap = 0;
+      return fail(ctx, EXON_HIP_ENOMEM, "quality_scores of a slab (%u items)", qual_items);
+    }
+  }
+  hipLaunchKernelGGL(k_sam_fill, dim3(nb), dim3(TPB), 0, hs, d_text, n, L, projection, s->off[0], s->off[1], s->off[2], s->off[3], s->values[0], s->values[1], s->values[2],
+                     s->qual);
+  HIP_TRY(ctx, hipGetLastError());
+  out->name_offsets = s->off[0];
+  out->name_values = s->values[0];
+  out->name_valid = reinterpret_cast<const uint8_t*>(s->valid[0]);
+  out->n_name_bytes = s->h_totals[0];
+  out->cigar_offsets = s->off[1];
+  out->cigar_values = s->values[1];
+  out->n_cigar_bytes = s->h_totals[1];
+  out->seq_offsets = s->off[2];
+  out->seq_values = s->values[2];
+  out->n_seq_bytes = s->h_totals[2];
+  out->qual_values = s->qual;
+  out->qual_offsets = s->off[3];
+  out->n_qual_items = qual_items;
   return EXON_HIP_OK;
 }

@@ -402,3 +402,46 @@ def test_host_vcf_text_columns_fuzz_against_the_oracle(tmp_path):
     for i in range(2000):
         assert c["info"][i] == decode.info_string(v, i), (i, rows[i])
         assert c["formats"][i] == decode.formats_string(v, i), (i, rows[i])
+
+
+@pytest.mark.gpu
+def test_gpu_sam_text_columns(ctx, tmp_path, monkeypatch):
+    """SAM name / cigar / sequence / quality_score out of the GPU pipeline (k_sam_measure / k_sam_fill: the line's fields 1, 6, 10,
+    11) = host reader = oracle: the reference's fixture (slt/sam-select-tests.slt:6-19), 200 k synthetic lines over several slabs
+    (plain and BGZF), '*' fields; a CIGAR the printer would change ("03M") hands the file to the host reader, which prints it."""
+    proj = ("name", "cigar", "sequence", "quality_score")
+    p = os.path.join(FX, "sam", "test.sam")
+    refs, recs = decode.decode_sam(p)
+    s = exon_amd.Scan(p, "sam", batch_size=7, gpu_parse=True, project=proj).bind_ctx(ctx)
+    c = table(s)
+    assert s.decoded_on_gpu()[0]
+    s.close()
+    assert c["name"] == [r["name_opt"] for r in recs] and c["cigar"] == [r["cigar"] for r in recs]
+    assert c["sequence"] == [r["sequence"] for r in recs] and c["quality_score"] == [r["quality_score"] for r in recs]
+    assert (c["name"][0], c["flag"][0], c["cigar"][0], c["sequence"][0], c["quality_score"][0]) == ("ref1_grp1_p001", 99, "10M", "CGAGCTCGGT", [0] * 10)
+    syn = tmp_path / "syn.sam"
+    subprocess.check_call([GEN, "sam", "200000", str(syn), "100"])
+    gz = str(syn) + ".gz"
+    subprocess.check_call([BGZIP, str(syn), gz, "6"])
+    monkeypatch.setenv("EXON_HIP_GPU_PARSE_SLAB_MB", "8")
+    host = table(exon_amd.Scan(str(syn), "sam", project=proj))
+    for path in (str(syn), gz):
+        s = exon_amd.Scan(path, "sam", gpu_parse=True, project=proj).bind_ctx(ctx)
+        dev = table(s)
+        assert s.decoded_on_gpu()[0], path
+        s.close()
+        for k in ("flag", "start", "end", "reference") + proj:
+            assert dev[k] == host[k], (path, k)
+    q = tmp_path / "m.sam"
+    q.write_text("@SQ\tSN:r\tLN:100\n*\t4\t*\t0\t255\t*\t*\t0\t0\t*\t*\nx\t0\tr\t5\t9\t3M2I\t=\t9\t0\tACGTA\t!+5?~\ny\t0\tr\t7\t9\t5M\t=\t9\t0\tACGTA\t*\n")
+    s = exon_amd.Scan(str(q), "sam", gpu_parse=True, project=proj).bind_ctx(ctx)
+    c = table(s)
+    assert s.decoded_on_gpu()[0]
+    s.close()
+    assert c["name"] == [None, "x", "y"] and c["cigar"] == ["", "3M2I", "5M"] and c["sequence"] == ["", "ACGTA", "ACGTA"]
+    assert c["quality_score"] == [[], [0, 10, 20, 30, 93], []]
+    q.write_text("@SQ\tSN:r\tLN:100\nx\t0\tr\t5\t9\t03M2I\t=\t9\t0\tACGTA\t!+5?~\n")
+    s = exon_amd.Scan(str(q), "sam", gpu_parse=True, project=proj).bind_ctx(ctx)
+    c = table(s)
+    assert not s.decoded_on_gpu()[0] and c["cigar"] == ["3M2I"]
+    s.close()
