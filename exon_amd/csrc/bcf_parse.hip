@@ -74,6 +74,7 @@ struct BcfOut {
   uint32_t* lv_off[EXON_HIP_MAX_INFO_FIELDS];  // list kinds ('F' / 'I'): where the row's typed vector starts (| value type << 29)
   uint32_t* lv_cnt[EXON_HIP_MAX_INFO_FIELDS];  // ... and how many items it holds (0: NULL list)
   uint32_t* pos_valid;  // POS 0 (BCF pos0 = -1, the telomere) is NULL like in the VCF path
+  uint32_t* rec_of_row;  // byte offset of every row's record (id / ref / alt are built from it: text_columns.hip)
 };
 struct BcfInfoKeys {  // header-string indexes of the INFO fields to extract; kind 'f' -> f32, 'i' -> i32, 'b' Flag -> presence,
                       // 'F' / 'I' -> List<f32> / List<i32> (typed vectors: list_kernels.h + k_bcf_list_fill)
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(256) void k_bcf_extract(const uint8_t* __restrict__
   };
   for (uint32_t k = threadIdx.x; k < cnt; k += 256) {
     const uint32_t r = offs[k], row = row0 + k;
+    out.rec_of_row[row] = r;
     const uint32_t wave_row = row - lane;  // the row of the wave's lane 0 (rows are consecutive across a wave's lanes)
     bool row_ok = false;                   // the record was decided: its validity bits count
     const uint32_t ls = ld32(d + r);
@@ -352,6 +354,7 @@ struct exon_hip_bcf_parser {
   uint32_t *d_base = nullptr, *d_rec_off = nullptr, *d_scalars = nullptr;
   void* bufs[8] = {nullptr};
   void* fbufs[5] = {nullptr};
+  uint32_t* d_rec_of_row = nullptr;
   BcfOut out{};
   FilterLists filters{};
   unsigned* h_scalars = nullptr;
@@ -393,6 +396,7 @@ int exon_hip_bcf_parser_create(exon_hip_ctx* ctx, int32_t n_contigs, int32_t n_s
   dalloc(&p->bufs[5], r * 4);
   dalloc(&p->bufs[6], w);
   dalloc(&p->bufs[7], w);
+  dalloc((void**)&p->d_rec_of_row, r * 4 + 64);
   dalloc(&p->fbufs[0], (size_t)FSLOTS * 8);
   dalloc(&p->fbufs[1], (size_t)FSLOTS * 4);
   dalloc(&p->fbufs[2], (size_t)FSLOTS * FLIST * 4);
@@ -416,6 +420,7 @@ int exon_hip_bcf_parser_create(exon_hip_ctx* ctx, int32_t n_contigs, int32_t n_s
   p->out.info[0] = (float*)p->bufs[5];
   p->out.info_valid[0] = (uint32_t*)p->bufs[6];
   p->out.pos_valid = (uint32_t*)p->bufs[7];
+  p->out.rec_of_row = p->d_rec_of_row;
   p->words = w;
   if (info_key >= 0) {
     p->ik.n = 1;
@@ -474,6 +479,7 @@ int exon_hip_bcf_parser_destroy(exon_hip_bcf_parser* p) {
   exon_pool_free(p->ctx, p->d_seg);
   exon_pool_free(p->ctx, p->d_base);
   exon_pool_free(p->ctx, p->d_rec_off);
+  if (p->d_rec_of_row) exon_pool_free(p->ctx, p->d_rec_of_row);
   exon_pool_free(p->ctx, p->d_scalars);
   if (p->h_scalars) hipHostFree(p->h_scalars);
   delete p;
@@ -568,3 +574,5 @@ int exon_hip_bcf_parser_filters(exon_hip_bcf_parser* p, int32_t* lists, int32_t*
 }
 
 }  // extern "C"
+
+const uint32_t* exon_hip_bcf_parser_row_records(exon_hip_bcf_parser* p) { return p ? p->out.rec_of_row : nullptr; }

@@ -65,6 +65,13 @@ struct ExonVcfText {
   int64_t n_ref_bytes;
   const uint8_t* alt_valid;        // bitmap: the ALT field is not '.' (the list itself has no items: see text_columns.hip)
 };
+// BCF id / ref / alt through the reference's EAGER builder (eager_array_builder.rs:112-134): both lists carry their items, neither is
+// ever NULL (an empty list when the record has no id / no alternate bases)
+struct ExonBcfText {
+  const int32_t *id_list_offsets, *id_item_offsets, *ref_offsets, *alt_list_offsets, *alt_item_offsets;
+  const uint8_t *id_values, *ref_values, *alt_values;
+  int64_t n_id_items, n_id_bytes, n_ref_bytes, n_alt_items, n_alt_bytes;
+};
 struct ExonBamText {
   const int32_t *name_offsets, *cigar_offsets, *seq_offsets;  // [n_rows + 1] each; seq_offsets are quality_scores' list offsets too
   const uint8_t *name_values, *cigar_values, *seq_values, *name_valid;
@@ -87,11 +94,14 @@ struct ExonFastqText {  // name, description, sequence, quality_scores (exon-fas
 int exon_text_sam(exon_hip_ctx* ctx, void* stream, ExonTextScratch** scratch, const uint8_t* d_text, int64_t n_bytes, const unsigned* d_nl, int64_t n_rows, uint64_t projection,
                   ExonBamText* out, int64_t* n_undecided);
 int exon_text_fastq(exon_hip_ctx* ctx, void* stream, ExonTextScratch** scratch, const exon_hip_fastq_views* views, int64_t n_bytes, ExonFastqText* out);
+int exon_text_bcf(exon_hip_ctx* ctx, void* stream, ExonTextScratch** scratch, const uint8_t* d_data, int64_t n_bytes, const uint32_t* d_rec_of_row, int64_t n_rows, uint64_t projection,
+                  ExonBcfText* out, int64_t* n_undecided);
 void exon_text_scratch_destroy(ExonTextScratch* s);
 // the parsers' own indexes the text columns are built from (valid until the next parse call)
 const unsigned* exon_hip_vcf_parser_newlines(exon_hip_vcf_parser* p);
 const unsigned* exon_hip_sam_parser_newlines(exon_hip_sam_parser* p);      // gpu_parse.hip: the same for SAM lines      // gpu_parse.hip: byte offset of every line's '\n' in the aligned slab
-const uint32_t* exon_hip_bam_parser_row_records(exon_hip_bam_parser* p);   // bam_parse.hip: byte offset of every row's record
+const uint32_t* exon_hip_bam_parser_row_records(exon_hip_bam_parser* p);
+const uint32_t* exon_hip_bcf_parser_row_records(exon_hip_bcf_parser* p);   // bcf_parse.hip: the same for BCF records   // bam_parse.hip: byte offset of every row's record
 
 // capi.cpp: size-keyed recycling of device buffers (released by exon_hip_ctx_destroy)
 void* exon_pool_alloc(exon_hip_ctx* ctx, size_t bytes);

@@ -326,7 +326,7 @@ int exon_hip_scan_open(const char* path, const exon_hip_scan_options* o, exon_hi
         cfg.filter.use_index = false;
         cfg.projection = o->projection;
         if (o->projection & ~7ull) return fail(nullptr, EXON_HIP_EINVAL, "projection 0x%llx: BCF knows EXON_HIP_PROJECT_VCF_ID / _REF / _ALT", (unsigned long long)o->projection);
-        s->gpu_parse = wants_gpu_inflate(o, path) && !o->projection;  // BCF is BGZF by definition; a region becomes a row mask; the text columns: host reader
+        s->gpu_parse = wants_gpu_inflate(o, path);  // BCF is BGZF by definition; a region becomes a row mask (id / ref / alt come from the device too)
         if (s->gpu_parse) cfg.threads = 1;  // only the header is read on the host
         s->bcf.reset(new exon::BCFBatchReader(path, cfg));
         if (s->gpu_parse) {
@@ -1876,8 +1876,9 @@ struct Span {
   const T* begin() const { return p; }
 };
 struct HostText {
-  bool vcf = false, bam = false;
+  bool vcf = false, bam = false, bcf = false;
   uint64_t projection = 0;
+  Span<int32_t> alt_item_off;  // BCF: off[1] = alt's list offsets, alt_item_off / val[1] its items
   Span<int32_t> off[3], item_off, qual_off;  // qual_off: quality_scores' own list offsets (SAM), else off[2]
   Span<uint8_t> val[3], valid[2];
   Span<int64_t> qual;
@@ -1895,7 +1896,7 @@ static thread_local double g_t_text_kernels = 0, g_t_fetch_text = 0, g_t_fetch_c
 static constexpr int64_t K_ZERO_ROWS = 65000;
 static const int32_t k_zero_offsets[K_ZERO_ROWS + 64] = {0};
 static int fetch_text(exon_hip_ctx* ctx, SlabCopier* cp, size_t also_reserve, int64_t n_rows, uint64_t projection, const ExonVcfText* vt, const ExonBamText* bt, HostText* h,
-                      bool big_batches) {
+                      bool big_batches, const ExonBcfText* ct = nullptr) {
   h->projection = projection;
   struct Want {
     std::function<void(const uint8_t*)> place;  // points the span at its bytes inside the block
@@ -1924,6 +1925,23 @@ static int fetch_text(exon_hip_ctx* ctx, SlabCopier* cp, size_t also_reserve, in
     if (projection & EXON_HIP_PROJECT_VCF_ALT) {
       get(h->valid[1], vt->alt_valid, nb);
       if (big_batches) get(h->zeros, nullptr, n + 1);  // (no source: cleared below; batches of up to 65 000 rows share a static array)
+    }
+  }
+  if (ct) {  // BCF: lists with their items, never NULL (eager_array_builder.rs:112-134)
+    h->bcf = true;
+    if (projection & EXON_HIP_PROJECT_VCF_ID) {
+      get(h->off[0], ct->id_list_offsets, n + 1);
+      get(h->item_off, ct->id_item_offsets, (size_t)ct->n_id_items + 1);
+      get(h->val[0], ct->id_values, (size_t)ct->n_id_bytes);
+    }
+    if (projection & EXON_HIP_PROJECT_VCF_REF) {
+      get(h->off[2], ct->ref_offsets, n + 1);
+      get(h->val[2], ct->ref_values, (size_t)ct->n_ref_bytes);
+    }
+    if (projection & EXON_HIP_PROJECT_VCF_ALT) {
+      get(h->off[1], ct->alt_list_offsets, n + 1);
+      get(h->alt_item_off, ct->alt_item_offsets, (size_t)ct->n_alt_items + 1);
+      get(h->val[1], ct->alt_values, (size_t)ct->n_alt_bytes);
     }
   }
   if (bt) {
@@ -1992,6 +2010,17 @@ static void text_batch(const HostText& h, const int64_t* rows, int64_t r0, int64
         }
       }
     }
+    if (h.bcf) {
+      if (h.projection & EXON_HIP_PROJECT_VCF_ID) {
+        struct ArrowArray* items = utf8_view(h.item_off, h.val[0], nullptr, 0, (int64_t)h.item_off.n - 1);
+        kids->push_back(exon::arena_array(arena, n, r0, 0, 2, nullptr, h.off[0].data(), nullptr, items));
+      }
+      if (h.projection & EXON_HIP_PROJECT_VCF_REF) kids->push_back(utf8_view(h.off[2], h.val[2], nullptr, r0, n));
+      if (h.projection & EXON_HIP_PROJECT_VCF_ALT) {
+        struct ArrowArray* items = utf8_view(h.alt_item_off, h.val[1], nullptr, 0, (int64_t)h.alt_item_off.n - 1);
+        kids->push_back(exon::arena_array(arena, n, r0, 0, 2, nullptr, h.off[1].data(), nullptr, items));
+      }
+    }
     if (h.bam) {
       if (h.projection & EXON_HIP_PROJECT_BAM_NAME) kids->push_back(utf8_view(h.off[0], h.val[0], &h.valid[0], r0, n));
       if (h.projection & EXON_HIP_PROJECT_BAM_CIGAR) kids->push_back(utf8_view(h.off[1], h.val[1], nullptr, r0, n));
@@ -2042,6 +2071,23 @@ static void text_batch(const HostText& h, const int64_t* rows, int64_t r0, int64
       kids->push_back(b.finish());
     }
   }
+  if (h.bcf) {
+    auto list_of = [&](const Span<int32_t>& list_off, const Span<int32_t>& item_off, const Span<uint8_t>& val) {
+      exon::ListUtf8Builder b;
+      for (int64_t i = 0; i < n; ++i) {
+        const int64_t r = row_at(i);
+        for (int32_t k = list_off[(size_t)r]; k < list_off[(size_t)r + 1]; ++k)
+          b.items.append_value(reinterpret_cast<const char*>(val.data()) + item_off[(size_t)k], (size_t)(item_off[(size_t)k + 1] - item_off[(size_t)k]));
+        b.close_row();
+      }
+      b.items.valid.clear();
+      b.valid.clear();
+      return b.finish();
+    };
+    if (h.projection & EXON_HIP_PROJECT_VCF_ID) kids->push_back(list_of(h.off[0], h.item_off, h.val[0]));
+    if (h.projection & EXON_HIP_PROJECT_VCF_REF) kids->push_back(utf8(h.off[2], h.val[2], nullptr));
+    if (h.projection & EXON_HIP_PROJECT_VCF_ALT) kids->push_back(list_of(h.off[1], h.alt_item_off, h.val[1]));
+  }
   if (h.bam) {
     if (h.projection & EXON_HIP_PROJECT_BAM_NAME) kids->push_back(utf8(h.off[0], h.val[0], &h.valid[0]));
     if (h.projection & EXON_HIP_PROJECT_BAM_CIGAR) kids->push_back(utf8(h.off[1], h.val[1], nullptr));
@@ -2061,7 +2107,7 @@ static void text_batch(const HostText& h, const int64_t* rows, int64_t r0, int64
 }
 
 static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n_rows, const uint8_t* row_mask, hipStream_t hs, const ExonVcfText* vt = nullptr,
-                       const ExonBamText* bt = nullptr, const std::function<int()>* build_text = nullptr) {
+                       const ExonBamText* bt = nullptr, const std::function<int()>* build_text = nullptr, const ExonBcfText* ct = nullptr) {
   GpuExporter* ex = scan->exporter;
   exon_hip_ctx* ctx = ex->ctx;
   // A pushed-down region: the row mask comes back first.  A slab that keeps nothing sends nothing else; when the kept rows are
@@ -2159,13 +2205,13 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
   const size_t moff = bytes;
   bytes += nb;
   const size_t path_stage = bytes + 512 * (size_t)n_cols;
-  if ((vt || bt) && scan->opt.projection) {
-    if (build_text) {  // the device builds *vt / *bt now
+  if ((vt || bt || ct) && scan->opt.projection) {
+    if (build_text) {  // the device builds *vt / *bt / *ct now
       const int rc = (*build_text)();
       if (rc) return rc;
     }
     const double tf0 = now_s();
-    const int rc = fetch_text(ctx, &cp, path_stage, n_rows, scan->opt.projection, vt, bt, &text, scan->opt.batch_size > K_ZERO_ROWS);
+    const int rc = fetch_text(ctx, &cp, path_stage, n_rows, scan->opt.projection, vt, bt, &text, scan->opt.batch_size > K_ZERO_ROWS, ct);
     g_t_fetch_text += now_s() - tf0;
     if (rc) return rc;
   } else if (!cp.reserve(path_stage)) {
@@ -2285,7 +2331,7 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
       }
       const double tv1 = now_s();
       g_t_views += tv1 - tv0;
-      if (text.vcf || text.bam) text_batch(text, nullptr, b0, n, &kids, arena);
+      if (text.vcf || text.bam || text.bcf) text_batch(text, nullptr, b0, n, &kids, arena);
       g_t_text_batch += now_s() - tv1;
       const int rc = enqueue_arena(arena, kids, n);
       if (rc) return rc;
@@ -2327,7 +2373,7 @@ static int export_slab(exon_hip_scan* scan, const exon_hip_column* sc, int64_t n
         kids.push_back(a);
       }
     }
-    if (text.vcf || text.bam) text_batch(text, keep.data() + b0, 0, n, &kids);
+    if (text.vcf || text.bam || text.bcf) text_batch(text, keep.data() + b0, 0, n, &kids);
     const int rc = enqueue(std::move(kids), n);
     if (rc) return rc;
   }
@@ -2658,15 +2704,20 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
                                                   scan->d_region_mask, scan->d_region_pass));
             row_mask = scan->d_region_mask;
           }
-          if (scan->exporter && scan->opt.projection && (is_vcf || is_bam || is_sam)) {
+          if (scan->exporter && scan->opt.projection && (is_vcf || is_bam || is_sam || is_bcf)) {
             // the reference's string / list columns of this slab, built on the device from the index the parser has just made
             // (by export_slab, once it knows that the slab keeps rows at all)
             ExonVcfText vt;
             ExonBamText bt;
+            ExonBcfText ct;
             const std::function<int()> build_text = [&]() -> int {
               const double tk0 = now_s();
               int r;
-              if (is_sam) {
+              if (is_bcf) {
+                int64_t undecided = 0;
+                r = exon_text_bcf(ctx, hs, &scan->text_scratch, d_text, (int64_t)n, exon_hip_bcf_parser_row_records(scan->bcf_parser), n_rows, scan->opt.projection, &ct, &undecided);
+                if (!r && undecided) r = 1;  // an ID / allele that is not a typed string: the host reader reports what it is
+              } else if (is_sam) {
                 int64_t undecided = 0;
                 r = exon_text_sam(ctx, hs, &scan->text_scratch, d_text, (int64_t)n, exon_hip_sam_parser_newlines(scan->sam_parser), n_rows, scan->opt.projection, &bt, &undecided);
                 if (!r && undecided) r = 1;  // a CIGAR / QUAL the device would not print the way the reader does: the host reader takes over
@@ -2677,7 +2728,7 @@ static int consume_text_gpu(exon_hip_stream* st, exon_hip_scan* scan, int64_t* r
               g_t_text_kernels += now_s() - tk0;
               return r;
             };
-            rc = export_slab(scan, sc, n_rows, row_mask, hs, is_vcf ? &vt : nullptr, is_vcf ? nullptr : &bt, &build_text);
+            rc = export_slab(scan, sc, n_rows, row_mask, hs, is_vcf ? &vt : nullptr, (is_bam || is_sam) ? &bt : nullptr, &build_text, is_bcf ? &ct : nullptr);
           } else
           rc = scan->exporter ? export_slab(scan, sc, n_rows, row_mask, hs)
                               : exon_hip_stream_launch_scan_columns(st, sc, 4 + EXON_HIP_MAX_INFO_FIELDS, n_rows, row_mask);

@@ -383,19 +383,131 @@ __global__ __launch_bounds__(TPB) void k_sam_fill(const uint8_t* __restrict__ te
   }
 }
 
+// ---- BCF ---------------------------------------------------------------------------------------------------------------------------
+// id / ref / alt of a BCF record (VCF specification 6.3.1): behind the 24 fixed bytes of the shared block (the record starts with
+// l_shared, l_indiv) the ID as a typed string (';'-separated, "." = none) and n_allele typed strings, the first one REF.  A typed
+// value's descriptor byte is count << 4 | type (7 = characters); count 15 = the real count follows as a typed integer.
+struct BcfLens {
+  uint32_t *id_items, *id_bytes, *ref_bytes, *alt_items, *alt_bytes;
+};
+// the typed string at p: where its characters start and how many there are; false: not a string (or past `end`)
+__device__ __forceinline__ bool bcf_typed_string(const uint8_t* d, uint32_t* p, uint32_t end, uint32_t* at, uint32_t* len) {
+  if (*p >= end) return false;
+  const uint8_t b = d[(*p)++];
+  uint32_t n = b >> 4;
+  const uint32_t t = b & 15u;
+  if (n == 15) {
+    if (*p >= end) return false;
+    const uint8_t c = d[(*p)++];
+    const uint32_t ct = c & 15u;
+    if ((c >> 4) != 1 || ct < 1 || ct > 3) return false;
+    const uint32_t w = ct == 1 ? 1u : ct == 2 ? 2u : 4u;
+    if (*p + w > end) return false;
+    n = 0;
+    for (uint32_t i = 0; i < w; ++i) n |= (uint32_t)d[*p + i] << (8 * i);
+    *p += w;
+  }
+  if (!(t == 7 || (t == 0 && n == 0))) return false;
+  if (*p + n > end) return false;
+  *at = *p;
+  *len = t == 7 ? n : 0u;
+  *p += *len;
+  return true;
+}
+__global__ __launch_bounds__(TPB) void k_bcf_measure(const uint8_t* __restrict__ d, const uint32_t* __restrict__ rec_of_row, unsigned n_rows, BcfLens o,
+                                                     unsigned* __restrict__ undecided) {
+  const unsigned row = blockIdx.x * TPB + threadIdx.x;
+  bool bad = false;
+  if (row < n_rows) {
+    const uint32_t r = rec_of_row[row];
+    const uint32_t ls = ld32u(d + r), nia = ld32u(d + r + 24);
+    const uint32_t n_allele = nia >> 16, end = r + 8 + ls;
+    uint32_t p = r + 32, at = 0, len = 0;
+    unsigned id_items = 0, id_bytes = 0, ref_bytes = 0, alt_items = 0, alt_bytes = 0;
+    if (!bcf_typed_string(d, &p, end, &at, &len)) bad = true;
+    if (!bad && !(len == 0 || (len == 1 && d[at] == '.'))) {
+      id_items = 1;
+      id_bytes = len;
+      for (uint32_t i = 0; i < len; ++i)
+        if (d[at + i] == ';') {
+          ++id_items;
+          --id_bytes;
+        }
+    }
+    for (uint32_t a = 0; a < n_allele && !bad; ++a) {
+      if (!bcf_typed_string(d, &p, end, &at, &len)) {
+        bad = true;
+        break;
+      }
+      if (a == 0) ref_bytes = len;
+      else {
+        ++alt_items;
+        alt_bytes += len;
+      }
+    }
+    o.id_items[row] = bad ? 0u : id_items;
+    o.id_bytes[row] = bad ? 0u : id_bytes;
+    o.ref_bytes[row] = bad ? 0u : ref_bytes;
+    o.alt_items[row] = bad ? 0u : alt_items;
+    o.alt_bytes[row] = bad ? 0u : alt_bytes;
+  }
+  const unsigned long long bb = __ballot(bad);
+  if ((threadIdx.x & 63) == 0 && bb) atomicAdd(undecided, (unsigned)__popcll(bb));
+}
+__global__ __launch_bounds__(TPB) void k_bcf_fill(const uint8_t* __restrict__ d, const uint32_t* __restrict__ rec_of_row, unsigned n_rows, uint64_t projection,
+                                                  const int32_t* __restrict__ id_list_off, const int32_t* __restrict__ id_byte_off, const int32_t* __restrict__ ref_off,
+                                                  const int32_t* __restrict__ alt_list_off, const int32_t* __restrict__ alt_byte_off, int32_t* __restrict__ id_item_off,
+                                                  int32_t* __restrict__ alt_item_off, uint8_t* __restrict__ id_values, uint8_t* __restrict__ ref_values,
+                                                  uint8_t* __restrict__ alt_values, unsigned id_items_total, unsigned id_bytes_total, unsigned alt_items_total,
+                                                  unsigned alt_bytes_total) {
+  const unsigned row = blockIdx.x * TPB + threadIdx.x;
+  if (row >= n_rows) return;
+  const uint32_t r = rec_of_row[row];
+  const uint32_t ls = ld32u(d + r), nia = ld32u(d + r + 24);
+  const uint32_t n_allele = nia >> 16, end = r + 8 + ls;
+  uint32_t p = r + 32, at = 0, len = 0;
+  if (bcf_typed_string(d, &p, end, &at, &len) && (projection & EXON_HIP_PROJECT_VCF_ID) && id_list_off[row + 1] > id_list_off[row]) {
+    unsigned k = (unsigned)id_list_off[row], w = (unsigned)id_byte_off[row];
+    id_item_off[k++] = (int32_t)w;
+    for (uint32_t i = 0; i < len; ++i) {
+      const uint8_t c = d[at + i];
+      if (c == ';') id_item_off[k++] = (int32_t)w;
+      else id_values[w++] = c;
+    }
+  }
+  unsigned ak = (unsigned)alt_list_off[row], aw = (unsigned)alt_byte_off[row];
+  for (uint32_t a = 0; a < n_allele; ++a) {
+    if (!bcf_typed_string(d, &p, end, &at, &len)) break;
+    if (a == 0) {
+      if (projection & EXON_HIP_PROJECT_VCF_REF) copy_run(ref_values + ref_off[row], d + at, len);
+    } else if (projection & EXON_HIP_PROJECT_VCF_ALT) {
+      alt_item_off[ak++] = (int32_t)aw;
+      copy_run(alt_values + aw, d + at, len);
+      aw += len;
+    }
+  }
+  if (row == n_rows - 1) {
+    id_item_off[id_items_total] = (int32_t)id_bytes_total;
+    alt_item_off[alt_items_total] = (int32_t)alt_bytes_total;
+  }
+}
+
 struct ExonTextScratch {
   exon_hip_ctx* ctx = nullptr;
   int64_t max_rows = 0, max_bytes = 0;
   int n_cols = 3;
-  uint32_t* len[4] = {nullptr, nullptr, nullptr, nullptr};
-  int32_t* off[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint32_t* len[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int32_t* off[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   uint32_t* valid[2] = {nullptr, nullptr};
   uint32_t *field_off = nullptr, *field_len = nullptr;
   uint32_t* sam_field_off = nullptr;  // [4 r] (SAM)
   unsigned* sums = nullptr;
   unsigned* totals = nullptr;    // device [4]
   unsigned* h_totals = nullptr;  // pinned
-  int32_t* item_off = nullptr;   // VCF id items
+  int32_t* item_off = nullptr;   // VCF / BCF id items
+  int32_t* item_off2 = nullptr;  // BCF alt items
+  unsigned* totals5 = nullptr;   // device [8]: the five totals of the BCF columns
+  unsigned* h_totals5 = nullptr; // pinned
   uint8_t* values[4] = {nullptr, nullptr, nullptr, nullptr};
   int64_t* qual = nullptr;
   size_t qual_cap = 0;
@@ -404,7 +516,10 @@ struct ExonTextScratch {
 void exon_text_scratch_destroy(ExonTextScratch* s) {
   if (!s) return;
   auto f = [&](void* p) { if (p) exon_pool_free(s->ctx, p); };
-  for (int k = 0; k < 4; ++k) f(s->len[k]), f(s->off[k]), f(s->values[k]);
+  for (int k = 0; k < 4; ++k) f(s->values[k]);
+  for (int k = 0; k < 5; ++k) f(s->len[k]), f(s->off[k]);
+  f(s->item_off2), f(s->totals5);
+  if (s->h_totals5) hipHostFree(s->h_totals5);
   f(s->valid[0]), f(s->valid[1]), f(s->field_off), f(s->field_len), f(s->sam_field_off), f(s->sums), f(s->totals), f(s->item_off), f(s->qual);
   if (s->h_totals) hipHostFree(s->h_totals);
   delete s;
@@ -430,7 +545,12 @@ static int scratch_for(exon_hip_ctx* ctx, ExonTextScratch** sp, int64_t max_rows
   for (int k = 0; k < n_cols; ++k) {
     a((void**)&s->len[k], r * 4);
     a((void**)&s->off[k], (r + 1) * 4);
-    a((void**)&s->values[k], (size_t)max_bytes + 64);
+    if (k < 4) a((void**)&s->values[k], (size_t)max_bytes + 64);
+  }
+  if (n_cols >= 5) {  // BCF: alt items
+    a((void**)&s->item_off2, ((size_t)max_bytes / 2 + r + 2) * 4);
+    a((void**)&s->totals5, 32);
+    if (ok && hipHostMalloc((void**)&s->h_totals5, 32) != hipSuccess) ok = false;
   }
   a((void**)&s->valid[0], r / 8 + 64);
   a((void**)&s->valid[1], r / 8 + 64);
@@ -622,5 +742,52 @@ int exon_text_sam(exon_hip_ctx* ctx, void* stream, ExonTextScratch** sp, const u
   out->qual_values = s->qual;
   out->qual_offsets = s->off[3];
   out->n_qual_items = qual_items;
+  return EXON_HIP_OK;
+}
+
+int exon_text_bcf(exon_hip_ctx* ctx, void* stream, ExonTextScratch** sp, const uint8_t* d_data, int64_t n_bytes, const uint32_t* d_rec_of_row, int64_t n_rows, uint64_t projection,
+                  ExonBcfText* out, int64_t* n_undecided) {
+  memset(out, 0, sizeof *out);
+  *n_undecided = 0;
+  if (n_rows == 0 || !(projection & (EXON_HIP_PROJECT_VCF_ID | EXON_HIP_PROJECT_VCF_REF | EXON_HIP_PROJECT_VCF_ALT))) return EXON_HIP_OK;
+  int rc = scratch_for(ctx, sp, std::max<int64_t>(n_rows, 1 << 16), std::max<int64_t>(n_bytes, 1 << 20), true, 5);
+  if (rc) return rc;
+  ExonTextScratch* s = *sp;
+  hipStream_t hs = pick_stream(ctx, stream);
+  const unsigned n = (unsigned)n_rows;
+  const int nb = (int)((n + TPB - 1) / TPB);
+  BcfLens L{s->len[0], s->len[1], s->len[2], s->len[3], s->len[4]};
+  unsigned* d_und = s->totals5 + 7;
+  HIP_TRY(ctx, hipMemsetAsync(s->totals5, 0, 32, hs));
+  hipLaunchKernelGGL(k_bcf_measure, dim3(nb), dim3(TPB), 0, hs, d_data, d_rec_of_row, n, L, d_und);
+  for (int k = 0; k < 5; ++k) {  // (scan_lengths' three launches with the totals in this call's own eight words)
+    const int nbk = (int)((n + TPB - 1) / TPB);
+    hipLaunchKernelGGL(k_block_sums, dim3(nbk), dim3(TPB), 0, hs, s->len[k], n, s->sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, hs, s->sums, nbk, s->totals5 + k);
+    hipLaunchKernelGGL(k_write_offsets, dim3(nbk), dim3(TPB), 0, hs, s->len[k], n, s->sums, s->off[k]);
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(s->h_totals5, s->totals5, 32, hipMemcpyDeviceToHost, hs));
+  HIP_TRY(ctx, hipStreamSynchronize(hs));
+  *n_undecided = s->h_totals5[7];
+  if (*n_undecided) return EXON_HIP_OK;
+  const unsigned id_items = s->h_totals5[0], id_bytes = s->h_totals5[1], ref_bytes = s->h_totals5[2], alt_items = s->h_totals5[3], alt_bytes = s->h_totals5[4];
+  hipLaunchKernelGGL(k_bcf_fill, dim3(nb), dim3(TPB), 0, hs, d_data, d_rec_of_row, n, projection, s->off[0], s->off[1], s->off[2], s->off[3], s->off[4], s->item_off, s->item_off2,
+                     s->values[0], s->values[1], s->values[2], id_items, id_bytes, alt_items, alt_bytes);
+  if (id_items == 0) HIP_TRY(ctx, hipMemsetAsync(s->item_off, 0, 4, hs));
+  if (alt_items == 0) HIP_TRY(ctx, hipMemsetAsync(s->item_off2, 0, 4, hs));
+  HIP_TRY(ctx, hipGetLastError());
+  out->id_list_offsets = s->off[0];
+  out->id_item_offsets = s->item_off;
+  out->id_values = s->values[0];
+  out->n_id_items = id_items;
+  out->n_id_bytes = id_bytes;
+  out->ref_offsets = s->off[2];
+  out->ref_values = s->values[1];
+  out->n_ref_bytes = ref_bytes;
+  out->alt_list_offsets = s->off[3];
+  out->alt_item_offsets = s->item_off2;
+  out->alt_values = s->values[2];
+  out->n_alt_items = alt_items;
+  out->n_alt_bytes = alt_bytes;
   return EXON_HIP_OK;
 }

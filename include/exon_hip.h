@@ -471,8 +471,8 @@ typedef struct exon_hip_scan_options {
                              "DB=true", formats = keys TAB samples; lazy_array_builder.rs:216-297, :310-423; host/vcf_text.h).
                              These two are built by the host reader only: a gpu_parse scan that asks for them decodes on the host.
                              BCF: id List<Utf8>, ref Utf8, alt List<Utf8> through the reference's EAGER builder (lists with their
-                             items, never NULL: eager_array_builder.rs:112-134), host reader only; SAM: the BAM columns from the line's
-                             fields (exon-sam/src/array_builder.rs:101-185), host reader and GPU pipeline */
+                             items, never NULL: eager_array_builder.rs:112-134); SAM: the BAM columns from the line's fields
+                             (exon-sam/src/array_builder.rs:101-185); both from the host readers and from the GPU pipeline */
 } exon_hip_scan_options;
 #define EXON_HIP_PROJECT_VCF_ID 1ull
 #define EXON_HIP_PROJECT_VCF_REF 2ull

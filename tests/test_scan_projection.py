@@ -445,3 +445,42 @@ def test_gpu_sam_text_columns(ctx, tmp_path, monkeypatch):
     c = table(s)
     assert not s.decoded_on_gpu()[0] and c["cigar"] == ["3M2I"]
     s.close()
+
+
+@pytest.mark.gpu
+def test_gpu_bcf_id_ref_alt(ctx, tmp_path, monkeypatch):
+    """BCF id / ref / alt out of the GPU pipeline (k_bcf_measure / k_bcf_fill over the typed strings of every record; the eager
+    builder's rules: lists with their items, never NULL) = host reader = oracle: the reference's fixture, also under a region
+    (the kept runs as views and the row-by-row gather), and 300 k synthetic records over several slabs."""
+    proj = ("id", "ref", "alt")
+    p = os.path.join(FX, "bcf", "index.bcf")
+    v = decode.decode_bcf(p)
+    s = exon_amd.Scan(p, "bcf", batch_size=50, gpu_parse=True, project=proj).bind_ctx(ctx)
+    c = table(s)
+    assert s.decoded_on_gpu()[0]
+    s.close()
+    assert c["chrom"] == v["chrom"] and c["pos"] == v["pos"]
+    assert c["id"] == v["id"] and c["ref"] == v["ref"] and c["alt"] == v["alt"]
+    assert any(a for a in c["alt"]) and len(c["id"]) == 621
+    for forced in ("0", "1"):
+        monkeypatch.setenv("EXON_HIP_EXPORT_GATHER", forced)
+        want = table(exon_amd.Scan(p, "bcf", region="1", project=proj))
+        s = exon_amd.Scan(p, "bcf", region="1", gpu_parse=True, project=proj).bind_ctx(ctx)
+        got = table(s)
+        s.close()
+        assert len(got["pos"]) == 191
+        for k in ("pos",) + proj:
+            assert got[k] == want[k], (forced, k)
+    monkeypatch.delenv("EXON_HIP_EXPORT_GATHER")
+    ub, bcf = tmp_path / "syn.ubcf", tmp_path / "syn.bcf"
+    subprocess.check_call([GEN, "bcf", "300000", str(ub)])
+    subprocess.check_call([BGZIP, str(ub), str(bcf), "6"])
+    monkeypatch.setenv("EXON_HIP_GPU_PARSE_SLAB_MB", "4")
+    host = table(exon_amd.Scan(str(bcf), "bcf", project=proj))
+    s = exon_amd.Scan(str(bcf), "bcf", gpu_parse=True, project=proj).bind_ctx(ctx)
+    dev = table(s)
+    assert s.decoded_on_gpu()[0]
+    s.close()
+    for k in ("chrom", "pos") + proj:
+        assert dev[k] == host[k], k
+    assert len(dev["pos"]) == 300000
